@@ -1,0 +1,36 @@
+"""Pins the CPU oracle against the reference's own golden fixtures
+(internal/engine/engine_test.go:46-210 TestCheck / TestCheckWithLenientScopeSearch)."""
+import pytest
+
+from helpers import load_json, norm_actions, store_rule_table
+from oracle.check import EvalParams, RuleTableOracle
+
+CASES = load_json("engine_cases.json")
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return RuleTableOracle(store_rule_table())
+
+
+def _modes(case):
+    return [False, True] if case["lenient"] is None else [case["lenient"]]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_engine_case(oracle, case):
+    for lenient in _modes(case):
+        params = EvalParams(globals_={"environment": "test"}, now_ns=1_700_000_000_000_000_000,
+                            lenient_scope_search=lenient)
+        for inp, want in zip(case["inputs"], case["wantOutputs"]):
+            have = oracle.check(inp, params)
+            assert norm_actions(have) == norm_actions(want), (case["name"], lenient)
+            assert sorted(have["effectiveDerivedRoles"]) == sorted(want.get("effectiveDerivedRoles") or [])
+            assert have["requestId"] == want.get("requestId", "")
+            assert have["resourceId"] == want.get("resourceId", "")
+            want_errs = want.get("evaluationErrors") or []
+            assert have["evaluationErrors"] == want_errs
+            want_outs = sorted(want.get("outputs") or [], key=lambda o: o["src"])
+            have_outs = sorted(have["outputs"], key=lambda o: o["src"])
+            if "output_now" not in case["name"]:
+                assert have_outs == want_outs
