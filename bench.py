@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the CheckResources hot path on MI355X.
+
+A "step" is one pass of the decision kernels over one resident batch of synthetic tuples
+(BASELINE.json configs[1]: 1 resource policy + 5 CEL conditions, 1M (principal, resource,
+action) tuples per GPU).  Inputs are already in HBM when the timed region starts; the
+PCIe-inclusive one-shot rate is reported separately (never as `value`).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: independent request shards per rank (weak scaling), no data-path collective; the
+only collective is the one-time RCCL broadcast of the lowered policy image from rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+ALG_BYTES_PER_DECISION = {"C2": 49.0}   # 32 + 9*A/actions + 1 with A=7, 4 actions
+HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--requests", type=int, default=250_000, help="requests per GPU (x4 actions = tuples)")
+    ap.add_argument("--cpu-sample", type=int, default=100_000, help="requests timed through the CPU oracle (~15 s)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the decision path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+
+    from cerbos_amd import capi, workloads
+    from cerbos_amd.flatten import Flattener
+    from cerbos_amd.lower.blob import lower_rule_table
+    from cerbos_amd.policy.loader import policies_from_docs
+    from cerbos_amd.ruletable.build import rule_table_from_policies
+
+    capi.init(local_rank)
+    rt = rule_table_from_policies(policies_from_docs(workloads.c2_policies()))
+    lt = lower_rule_table(rt)   # deterministic: every rank derives the same host-side dictionaries
+
+    # ---- policy image: lowered once, broadcast GPU->GPU over RCCL/xGMI
+    bcast_ms = None
+    if world > 1:
+        n = len(lt.blob)
+        img = torch.empty(n, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            img.copy_(torch.frombuffer(bytearray(lt.blob), dtype=torch.uint8))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.broadcast(img, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+        table = capi.Table.adopt(img.data_ptr(), n)   # `img` stays alive until exit
+    else:
+        table = capi.Table(lt.blob)
+
+    # ---- this rank's shard (weak scaling: fixed tuples per GPU, different seed per rank)
+    cr = workloads.c2_requests(args.requests, seed=2 + rank)
+    batch = cr.to_batch(Flattener(lt))
+    tuples = batch.n_tuples
+    now = 1_700_000_000_000_000_000
+    dbatch = table.upload(batch)
+
+    def sync_all():
+        table.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        table.launch(dbatch, now_ns=now)
+    sync_all()
+    if args.warmup:
+        table.kernel_time_ms()  # reset the kernel timer
+
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        table.launch(dbatch, now_ns=now)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    check_ms, resolve_ms = table.kernel_time_ms()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # per-step latency distribution (each step synchronised; outside the timed region)
+    lat = []
+    for _ in range(min(args.steps, 20)):
+        s0 = time.perf_counter()
+        table.launch(dbatch, now_ns=now)
+        table.synchronize()
+        lat.append(time.perf_counter() - s0)
+    p50_us_per_decision = float(np.median(lat)) / tuples * 1e6
+
+    res = table.download(dbatch)
+    eff = res.effect
+    assert (res.status != capi.ST_UNSUPPORTED).all()
+
+    # PCIe-inclusive one-shot path (upload + kernels + download), for DESIGN.md; not `value`
+    o0 = time.perf_counter()
+    table.check(batch, now_ns=now, want=())
+    oneshot_s = time.perf_counter() - o0
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the oracle = checker + reported CPU baseline ("port": a restatement, not the Go binary)
+        from oracle.check import EvalParams, RuleTableOracle
+        orc = RuleTableOracle(rt)
+        sample = cr.to_inputs(0, args.cpu_sample)
+        params = EvalParams(now_ns=now)
+        c0 = time.perf_counter()
+        outs = [orc.check(i, params) for i in sample]
+        cpu_s = time.perf_counter() - c0
+        want = np.array([1 if o["actions"][a]["effect"] == "EFFECT_ALLOW" else 2
+                         for i, o in zip(sample, outs) for a in i["actions"]], dtype=np.uint8)
+        assert np.array_equal(eff[:want.size], want), "GPU effects differ from the oracle on the sample"
+        cpu = {"value": want.size / cpu_s, "unit": "decisions/s", "cores": 1, "kind": "port",
+               "sample": "first %d requests (%d tuples) of the same batch, Python restatement of check.go, "
+                         "1 thread, %.1f s" % (len(sample), want.size, cpu_s)}
+
+    if rank == 0:
+        total = tuples * world * args.steps
+        alg = ALG_BYTES_PER_DECISION["C2"]
+        achieved = alg * tuples / (check_ms * 1e-3) / 1e9
+        out = {
+            "metric": "CheckResources decisions/sec at batch=1M; p50 per-decision us",
+            "value": total / elapsed,
+            "unit": "decisions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 ids + f64 attributes (CEL int64/uint64/double)",
+            "data": "synthetic",
+            "config": {"workload": "C2: 1 resource policy + 5 CEL conditions, %d tuples/GPU "
+                                   "(%d requests x 4 actions), seed 2+rank" % (tuples, args.requests),
+                       "parallelism": "independent request shards per GPU, policy image broadcast once"},
+            "p50_us_per_decision": p50_us_per_decision,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "cbh_check_kernel", "kernel_ms": check_ms,
+                         "alg_bytes_per_decision": alg},
+            "cpu_baseline": cpu,
+            "resolve_kernel_ms": resolve_ms,
+            "oneshot_pcie_inclusive_decisions_per_s": tuples / oneshot_s,
+            "allow_fraction": float((eff == 1).mean()),
+            "policy_bcast_ms": bcast_ms,
+        }
+        print(json.dumps(out))
+    dbatch.close()
+    table.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,161 @@
+// Layout of the lowered policy table image ("blob") shared by the lowering step
+// (cerbos_amd/lower/blob.py writes it) and the device code (cbh_engine.hip reads it).
+// Little-endian, every section 64-byte aligned.  The image is position independent: it is
+// copied to HBM verbatim (or broadcast GPU->GPU) and addressed as base + section offset.
+#pragma once
+#include <stdint.h>
+
+#define CBH_BLOB_MAGIC 0x31484243u /* "CBH1" */
+#define CBH_BLOB_VERSION 3u
+
+struct CbhBlobHeader {  // 32 bytes
+  uint32_t magic;
+  uint32_t version;
+  uint32_t n_sections;
+  uint32_t reserved0;
+  uint64_t total_len;
+  uint64_t reserved1;
+};
+
+struct CbhBlobSection {  // 32 bytes
+  uint32_t id;
+  uint32_t count;  // element count (section specific)
+  uint64_t offset; // from blob start
+  uint64_t nbytes;
+  uint64_t reserved;
+};
+
+enum CbhSectionId {
+  CBH_SEC_META = 1,        // u32[CBH_META_N]
+  CBH_SEC_STR_OFF = 2,     // u32[K+1]
+  CBH_SEC_STR_BYTES = 3,   // u8[]
+  CBH_SEC_SCOPE_PARENT = 4, // u32[NS]  parent scope index or CBH_NONE
+  CBH_SEC_SCOPE_FLAGS = 5, // u32[NS]  bit0 resource map, bit1 principal map, bits 2..3 scope permissions
+  CBH_SEC_SCOPE_SID = 6,   // u32[NS]  string id of the scope
+  CBH_SEC_HASH = 7,        // CbhHashSlot[nslots]
+  CBH_SEC_ROWS = 8,        // u32[CBH_ROW_NF][n_rows]  field-major
+  CBH_SEC_RPROWS = 9,      // u32[CBH_RP_NF][n_rprows]
+  CBH_SEC_U32POOL = 10,    // u32[] (pattern lists, parent-role lists)
+  CBH_SEC_DR = 11,         // u32[CBH_DR_NF][n_dr]
+  CBH_SEC_CODE = 12,       // u32[]
+  CBH_SEC_CONST_TAG = 13,  // u8[]
+  CBH_SEC_CONST_VAL = 14,  // u64[]
+  CBH_SEC_THEAP_TAG = 15,  // u8[]
+  CBH_SEC_THEAP_VAL = 16,  // u64[]
+  CBH_SEC_GBITS = 17,      // u64[3][K]  glob match bits of table strings per dimension
+  CBH_SEC_NFA_ACTION = 18, // see CbhNfa layout below
+  CBH_SEC_NFA_ROLE = 19,
+  CBH_SEC_NFA_KIND = 20,
+  CBH_SEC_POLICY_SID = 21, // u32[n_policies] string ids of policy keys (host decode)
+  CBH_SEC_DRNAME_SID = 22, // u32[n_drnames]  string ids of derived role names (bit order of edr_mask)
+};
+
+enum CbhMeta {
+  CBH_M_NSTRINGS = 0,
+  CBH_M_NCOLUMNS = 1,
+  CBH_M_NSCOPES = 2,
+  CBH_M_HASH_MASK = 3, // nslots - 1 (power of two)
+  CBH_M_NROWS = 4,
+  CBH_M_NRPROWS = 5,
+  CBH_M_NDR = 6,
+  CBH_M_NPOLICIES = 7,
+  CBH_M_NCONSTS = 8,
+  CBH_M_CODE_LEN = 9,
+  CBH_M_FLAGS = 10,     // bit0: some program reads runtime.effectiveDerivedRoles
+  CBH_M_MAX_STACK = 11,
+  CBH_M_NDRNAMES = 12,
+  CBH_M_NFA_WORDS_ACTION = 13, // u64 words of NFA state per dimension (0 = no globs)
+  CBH_M_NFA_WORDS_ROLE = 14,
+  CBH_M_NFA_WORDS_KIND = 15,
+  CBH_M_THEAP_LEN = 16,
+  CBH_M_MAX_LOCALS = 17,
+  CBH_META_N = 24
+};
+#define CBH_MF_USES_RUNTIME_EDR 1u
+
+// Directory: open addressing, linear probing, key.x == CBH_NONE marks an empty slot.
+struct CbhHashSlot { // 32 bytes
+  uint32_t k0, k1, k2, k3; // k0 = bucket type
+  uint32_t v0, v1, v2, v3;
+};
+enum CbhBucketType {
+  CBH_B_RESOURCE = 1,  // (ver sid, kind sid, scope idx) -> v0 row_begin, v1 row_count, v2 dr_begin, v3 dr_count
+  CBH_B_PRINCIPAL = 2, // (ver sid, scope idx, principal sid) -> v0 row_begin, v1 row_count
+  CBH_B_ROLEPOL = 3,   // (ver sid, scope idx, role sid) -> v0 rprow_begin, v1 rprow_count, v2 policy id
+  CBH_B_PPEXISTS = 4,  // (ver sid, scope idx, 0) -> exists (any principal policy row)
+  CBH_B_RPRES = 5,     // (ver sid, scope idx, 0) -> v0 off, v1 cnt into U32POOL of resource pattern refs of role-policy rows
+  CBH_B_PARENTS = 6,   // (scope idx, role sid, 0) -> v0 off, v1 cnt into U32POOL of ancestor role sids
+  CBH_B_RESEXISTS = 7, // (ver sid, kind sid, scope idx): same key as RESOURCE, present for every resource policy
+};
+
+// Pattern reference: bit31 set -> glob index within the dimension, else literal string id.
+#define CBH_PAT_GLOB 0x80000000u
+
+enum CbhRowField { // regular rows (resource + principal policies)
+  CBH_ROW_ACTION = 0,   // pattern ref (action dim)
+  CBH_ROW_ROLE = 1,     // pattern ref (role dim)
+  CBH_ROW_RESOURCE = 2, // pattern ref (kind dim) - tested for principal-policy rows only
+  CBH_ROW_FLAGS = 3,    // bits 0..1 effect (1 ALLOW, 2 DENY)
+  CBH_ROW_COND = 4,     // program entry or CBH_NONE
+  CBH_ROW_DRCOND = 5,   // program entry or CBH_NONE
+  CBH_ROW_POLICY = 6,   // policy id of the origin policy (strict-mode attribution)
+  CBH_ROW_NF = 7
+};
+enum CbhRpField { // role-policy rows
+  CBH_RP_RESOURCE = 0,  // pattern ref (kind dim)
+  CBH_RP_ALLOW_OFF = 1, // into U32POOL: pattern refs (action dim)
+  CBH_RP_ALLOW_CNT = 2,
+  CBH_RP_COND = 3,      // program of the USER condition (synthetic DENY fires when it is false)
+  CBH_RP_NF = 4
+};
+enum CbhDrField { // derived roles of one resource policy
+  CBH_DR_NAME = 0,        // bit index into edr mask
+  CBH_DR_PARENTS_OFF = 1, // into U32POOL: role string ids
+  CBH_DR_PARENTS_CNT = 2, // CBH_NONE = "*" (any role)
+  CBH_DR_COND = 3,        // program or CBH_NONE
+  CBH_DR_NF = 4
+};
+
+// Glob NFA section (bit-parallel, one bit per pattern position):
+//   u64 init[NW]; u64 star[NW]; u64 cls[256][NW]; u64 self[256][NW];
+//   u32 n_accept; u32 pad; { u32 bitpos; u32 glob_index; } accept[n_accept];
+// step(c): A = ((A & cls[c]) << 1) | (A & self[c]); then closure A |= (A & star) << 1 to fixpoint.
+
+// Bytecode: one u32 per instruction = op | (arg << 8); some ops take a second word.
+enum CbhOp {
+  OP_RET = 0,
+  OP_CONST = 1,      // push const[arg]
+  OP_COL = 2,        // push column arg (ABSENT -> error)
+  OP_HASCOL = 3,     // push presence of column arg
+  OP_REQSTR = 4,     // push request string field arg (cbh_req_field)
+  OP_ROLES = 5,      // push P.roles
+  OP_SELECT = 6,     // TOS = TOS.<string id arg>
+  OP_HASSEL = 7,     // TOS = has(TOS.<string id arg>)
+  OP_INDEX = 8,      // pop i; TOS = TOS[i]
+  OP_EQ = 9, OP_NE = 10, OP_LT = 11, OP_LE = 12, OP_GT = 13, OP_GE = 14,
+  OP_IN = 15,
+  OP_ADD = 16, OP_SUB = 17, OP_MUL = 18, OP_DIV = 19, OP_MOD = 20,
+  OP_NEG = 21, OP_NOT = 22,
+  OP_JF = 23,        // if TOS is bool false: pc = arg (TOS kept)
+  OP_JT = 24,        // if TOS is bool true : pc = arg (TOS kept)
+  OP_AND = 25, OP_OR = 26, // pop b, a; push a && b / a || b with CEL error absorption
+  OP_JTERN = 27,     // pop c; non-bool/error: push error, pc = next word; false: pc = arg; true: skip next word
+  OP_JMP = 28,
+  OP_POP = 29,
+  OP_LEAF = 30,      // TOS -> plain bool (error/non-bool -> false; strict mode + error -> abort)
+  OP_SIZE = 31, OP_STARTSWITH = 32, OP_ENDSWITH = 33, OP_CONTAINS = 34,
+  OP_TIMESTAMP = 35, OP_DURATION = 36, OP_TIMESINCE = 37, OP_NOW = 38,
+  OP_EDRHAS = 39,    // push (derived role bit arg) in runtime.effectiveDerivedRoles
+  OP_LOCAL = 40,     // push local arg
+  OP_ITER_BEGIN = 41, // pop container -> iteration slot arg ; next word = kind | (end_pc << 8)
+  OP_ITER_NEXT = 42,  // arg = slot; next word = end_pc : exhausted -> pc = end_pc, else bind locals
+  OP_ITER_ACC = 43,   // arg = slot; next word = loop_pc : pop predicate, fold, maybe finish
+  OP_ITER_END = 44,   // arg = slot: push folded result
+  OP_TOINT = 45, OP_TODOUBLE = 46, OP_TOSTRING_UNSUPPORTED = 47,
+  OP_INIPRANGE = 48, // pop cidr, ip (strings)
+  OP_UNSUPPORTED = 49, // marks the tuple CBH_ST_UNSUPPORTED and yields an error
+  OP_TS_GETTER = 50,  // arg = getter kind; pops tz string if arg bit 7 set
+  OP_HASINTERSECTION = 51, OP_ISSUBSET = 52,
+  OP_NOPS
+};
+enum CbhIterKind { IT_ALL = 0, IT_EXISTS = 1, IT_EXISTS_ONE = 2 };

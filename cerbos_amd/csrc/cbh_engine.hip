@@ -1,0 +1,273 @@
+// libcerbos_hip.so - MI355X (gfx950 / CDNA4) batched decision engine for the Cerbos
+// CheckResources hot path.  Hand-written HIP; no MFMA (branchy integer / string-id work,
+// HBM- and VALU-issue bound).
+//
+// Kernels
+//   cbh_resolve_globs_kernel : one lane per batch-local string; bit-parallel glob NFA
+//                              (LDS-staged transition tables) -> match bits per dimension.
+//                              Replaces gobwas glob.Match per query
+//                              (internal/ruletable/index/glob_dimension.go:62-95).
+//   cbh_check_kernel         : one lane per (principal, resource, action) tuple; restates
+//                              ruletable.(*RuleTable).check (internal/ruletable/check.go:97-460),
+//                              Index.Query + appendRolePolicyDenies
+//                              (internal/ruletable/index/index.go:214-530), GetAllScopes
+//                              (internal/ruletable/ruletable.go:848-882) over the flat table image.
+//
+// Host side: the C ABI of include/cerbos_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "cbh_kernels.h"
+#include "cbh_image.h"
+
+// ======================================================================== host code
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return -1; }
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(_e)); } while (0)
+
+struct cbh_table {
+  int device = 0;
+  void* image = nullptr; size_t image_len = 0; bool owns_image = true;
+  std::vector<uint32_t> meta;
+  TableDev dev{};
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  double check_ms_sum = 0, resolve_ms_sum = 0; uint64_t timed = 0; bool pending = false;
+  std::mutex mu;
+};
+
+struct cbh_device_batch {
+  cbh_table* table = nullptr;
+  BatchDev dev{};
+  OutDev out{};
+  std::vector<void*> allocs;
+};
+
+static int g_device = 0;
+static bool g_inited = false;
+
+extern "C" const char* cbh_last_error(void) { return g_err.c_str(); }
+extern "C" uint32_t cbh_abi_version(void) { return CBH_ABI_VERSION; }
+
+extern "C" int cbh_init(const cbh_config* cfg) {
+  if (cfg && cfg->abi_version != CBH_ABI_VERSION) return fail("ABI version mismatch");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) return fail("no HIP device available: the decision engine requires an MI355X (no CPU fallback)");
+  g_device = cfg ? cfg->device : 0;
+  if (g_device < 0 || g_device >= n) return fail("invalid device ordinal");
+  HIPCHK(hipSetDevice(g_device));
+  g_inited = true;
+  return 0;
+}
+extern "C" void cbh_shutdown(void) { g_inited = false; }
+
+static int parse_image(cbh_table* t, const uint8_t* host_copy, size_t len) {
+  const char* e = cbh_parse_image(t->dev, t->meta, static_cast<const uint8_t*>(t->image), host_copy, len);
+  return e ? fail(e) : 0;
+}
+
+static int table_finish(cbh_table* t) {
+  HIPCHK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+  for (auto& e : t->ev) HIPCHK(hipEventCreate(&e));
+  return 0;
+}
+
+extern "C" int cbh_table_load(const void* blob, size_t len, cbh_table** out) {
+  if (!g_inited) return fail("cbh_init has not been called");
+  if (!blob || !out) return fail("null argument");
+  HIPCHK(hipSetDevice(g_device));
+  cbh_table* t = new (std::nothrow) cbh_table();
+  if (!t) return fail("out of memory");
+  t->device = g_device; t->image_len = len;
+  if (hipMalloc(&t->image, len) != hipSuccess) { delete t; return fail("hipMalloc(table image) failed"); }
+  if (hipMemcpy(t->image, blob, len, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(t->image); delete t; return fail("hipMemcpy(table image) failed"); }
+  if (parse_image(t, static_cast<const uint8_t*>(blob), len) != 0 || table_finish(t) != 0) { (void)hipFree(t->image); delete t; return -1; }
+  *out = t;
+  return 0;
+}
+
+extern "C" int cbh_table_adopt_device_image(void* device_image, size_t len, cbh_table** out) {
+  if (!g_inited) return fail("cbh_init has not been called");
+  if (!device_image || !out) return fail("null argument");
+  HIPCHK(hipSetDevice(g_device));
+  std::vector<uint8_t> host(len);
+  HIPCHK(hipMemcpy(host.data(), device_image, len, hipMemcpyDeviceToHost));
+  cbh_table* t = new (std::nothrow) cbh_table();
+  if (!t) return fail("out of memory");
+  t->device = g_device; t->image = device_image; t->image_len = len; t->owns_image = false;
+  if (parse_image(t, host.data(), len) != 0 || table_finish(t) != 0) { delete t; return -1; }
+  *out = t;
+  return 0;
+}
+
+extern "C" void cbh_table_release(cbh_table* t) {
+  if (!t) return;
+  (void)hipSetDevice(t->device);
+  if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
+  for (auto& e : t->ev) if (e) (void)hipEventDestroy(e);
+  if (t->image && t->owns_image) (void)hipFree(t->image);
+  delete t;
+}
+extern "C" uint32_t cbh_table_num_strings(const cbh_table* t) { return t ? t->meta[CBH_M_NSTRINGS] : 0; }
+extern "C" uint32_t cbh_table_num_columns(const cbh_table* t) { return t ? t->meta[CBH_M_NCOLUMNS] : 0; }
+extern "C" uint64_t cbh_table_device_bytes(const cbh_table* t) { return t ? t->image_len : 0; }
+extern "C" void* cbh_table_device_ptr(const cbh_table* t) { return t ? t->image : nullptr; }
+
+extern "C" void cbh_batch_release(cbh_device_batch* b) {
+  if (!b) return;
+  if (b->table) { (void)hipSetDevice(b->table->device); (void)hipStreamSynchronize(b->table->stream); }
+  for (void* p : b->allocs) (void)hipFree(p);
+  delete b;
+}
+
+template <typename T>
+static int up(cbh_device_batch* b, const T*& dst, const T* src, size_t n, hipStream_t s) {
+  dst = nullptr;
+  size_t bytes = (n ? n : 1) * sizeof(T);
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, bytes));
+  b->allocs.push_back(p);
+  if (n) {
+    if (!src) return fail("cbh_batch: a required array is NULL");
+    HIPCHK(hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  dst = static_cast<const T*>(p);
+  return 0;
+}
+template <typename T>
+static int dalloc(cbh_device_batch* b, T*& dst, size_t n) {
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+  b->allocs.push_back(p);
+  dst = static_cast<T*>(p);
+  return 0;
+}
+
+extern "C" int cbh_batch_upload(cbh_table* t, const cbh_batch* in, cbh_device_batch** out) {
+  if (!t || !in || !out) return fail("null argument");
+  if (in->n_columns != t->meta[CBH_M_NCOLUMNS]) return fail("cbh_batch.n_columns does not match the table's column schema");
+  HIPCHK(hipSetDevice(t->device));
+  cbh_device_batch* b = new (std::nothrow) cbh_device_batch();
+  if (!b) return fail("out of memory");
+  b->table = t;
+  BatchDev& d = b->dev;
+  d.n_requests = in->n_requests; d.n_tuples = in->n_tuples; d.n_roles = in->n_roles;
+  d.n_columns = in->n_columns; d.n_strings = in->n_strings; d.heap_len = in->heap_len;
+  hipStream_t s = t->stream;
+  const size_t NR = in->n_requests;
+  int rc = 0;
+  rc |= up(b, d.req_u32, in->req_u32, (size_t)CBH_RQ_NFIELDS * NR, s);
+  rc |= up(b, d.roles, in->roles, in->n_roles, s);
+  rc |= up(b, d.tuple_req, in->tuple_req, in->n_tuples, s);
+  rc |= up(b, d.tuple_action, in->tuple_action, in->n_tuples, s);
+  rc |= up(b, d.col_tag, in->col_tag, (size_t)in->n_columns * NR, s);
+  rc |= up(b, d.col_val, in->col_val, (size_t)in->n_columns * NR, s);
+  rc |= up(b, d.heap_tag, in->heap_tag, in->heap_len, s);
+  rc |= up(b, d.heap_val, in->heap_val, in->heap_len, s);
+  rc |= up(b, d.str_off, in->str_off, (size_t)in->n_strings + 1, s);
+  rc |= up(b, d.str_bytes, in->str_bytes, in->str_bytes_len, s);
+  rc |= up(b, d.str_flags, in->str_flags, in->n_strings, s);
+  rc |= dalloc(b, d.gbits, (size_t)3 * in->n_strings);
+  rc |= dalloc(b, b->out.effect, in->n_tuples);
+  rc |= dalloc(b, b->out.policy, in->n_tuples);
+  rc |= dalloc(b, b->out.scope, in->n_tuples);
+  rc |= dalloc(b, b->out.status, in->n_tuples);
+  rc |= dalloc(b, b->out.edr, NR);
+  if (rc != 0) { cbh_batch_release(b); return -1; }
+  if (hipStreamSynchronize(s) != hipSuccess) { cbh_batch_release(b); return fail("upload failed"); }
+  *out = b;
+  return 0;
+}
+
+static void collect_times(cbh_table* t) {
+  if (!t->pending) return;
+  float a = 0, c = 0;
+  if (hipEventElapsedTime(&a, t->ev[0], t->ev[1]) == hipSuccess && hipEventElapsedTime(&c, t->ev[2], t->ev[3]) == hipSuccess) {
+    t->resolve_ms_sum += a; t->check_ms_sum += c; t->timed += 1;
+  }
+  t->pending = false;
+}
+
+extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_params* p) {
+  if (!t || !b || !p) return fail("null argument");
+  if (b->table != t) return fail("batch was uploaded for a different table");
+  std::lock_guard<std::mutex> lk(t->mu);
+  HIPCHK(hipSetDevice(t->device));
+  hipStream_t s = t->stream;
+  if (t->pending) { HIPCHK(hipEventSynchronize(t->ev[3])); collect_times(t); }
+  const BatchDev& d = b->dev;
+  HIPCHK(hipMemsetAsync(b->out.edr, 0, (size_t)(d.n_requests ? d.n_requests : 1) * sizeof(u64), s));
+  HIPCHK(hipEventRecord(t->ev[0], s));
+  const u32 maxw = std::max(std::max(t->dev.nfa_words[0], t->dev.nfa_words[1]), t->dev.nfa_words[2]);
+  if (d.n_strings && maxw) {
+    const u32 grid = (d.n_strings + CBH_BLOCK - 1) / CBH_BLOCK;
+    const size_t lds = (size_t)(2 + 512) * maxw * sizeof(u64);
+    hipLaunchKernelGGL(cbh_resolve_globs_kernel, dim3(grid), dim3(CBH_BLOCK), lds, s, t->dev, d);
+  } else if (d.n_strings) {
+    HIPCHK(hipMemsetAsync(d.gbits, 0, (size_t)3 * d.n_strings * sizeof(u64), s));
+  }
+  HIPCHK(hipEventRecord(t->ev[1], s));
+  HIPCHK(hipEventRecord(t->ev[2], s));
+  if (d.n_tuples) {
+    const u32 grid = (d.n_tuples + CBH_BLOCK - 1) / CBH_BLOCK;
+    hipLaunchKernelGGL(cbh_check_kernel, dim3(grid), dim3(CBH_BLOCK), 0, s, t->dev, d, b->out, (i64)p->now_ns, p->flags);
+  }
+  HIPCHK(hipEventRecord(t->ev[3], s));
+  HIPCHK(hipGetLastError());
+  t->pending = true;
+  return 0;
+}
+
+extern "C" int cbh_synchronize(cbh_table* t) {
+  if (!t) return fail("null argument");
+  std::lock_guard<std::mutex> lk(t->mu);
+  HIPCHK(hipSetDevice(t->device));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  collect_times(t);
+  return 0;
+}
+
+extern "C" int cbh_kernel_time_ms(cbh_table* t, float* check_ms, float* resolve_ms) {
+  if (!t) return fail("null argument");
+  std::lock_guard<std::mutex> lk(t->mu);
+  if (t->timed == 0) return fail("no timed launches yet");
+  if (check_ms) *check_ms = (float)(t->check_ms_sum / (double)t->timed);
+  if (resolve_ms) *resolve_ms = (float)(t->resolve_ms_sum / (double)t->timed);
+  t->check_ms_sum = t->resolve_ms_sum = 0; t->timed = 0;
+  return 0;
+}
+
+extern "C" int cbh_result_download(cbh_table* t, cbh_device_batch* b, cbh_result* out) {
+  if (!t || !b || !out || !out->effect) return fail("null argument");
+  std::lock_guard<std::mutex> lk(t->mu);
+  HIPCHK(hipSetDevice(t->device));
+  hipStream_t s = t->stream;
+  const BatchDev& d = b->dev;
+  HIPCHK(hipMemcpyAsync(out->effect, b->out.effect, d.n_tuples, hipMemcpyDeviceToHost, s));
+  if (out->policy) HIPCHK(hipMemcpyAsync(out->policy, b->out.policy, (size_t)d.n_tuples * 4, hipMemcpyDeviceToHost, s));
+  if (out->scope) HIPCHK(hipMemcpyAsync(out->scope, b->out.scope, (size_t)d.n_tuples * 4, hipMemcpyDeviceToHost, s));
+  if (out->status) HIPCHK(hipMemcpyAsync(out->status, b->out.status, d.n_tuples, hipMemcpyDeviceToHost, s));
+  if (out->edr_mask) HIPCHK(hipMemcpyAsync(out->edr_mask, b->out.edr, (size_t)d.n_requests * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  collect_times(t);
+  return 0;
+}
+
+extern "C" int cbh_check_batch(cbh_table* t, const cbh_batch* in, const cbh_params* p, cbh_result* out) {
+  cbh_device_batch* b = nullptr;
+  if (cbh_batch_upload(t, in, &b) != 0) return -1;
+  int rc = cbh_check_resident(t, b, p);
+  if (rc == 0) rc = cbh_result_download(t, b, out);
+  cbh_batch_release(b);
+  return rc;
+}

@@ -1,0 +1,56 @@
+// Table image (blob) parsing shared by the product library and the test-only host simulation.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <vector>
+#include "cbh_vm.h"
+
+#ifndef NFA_MAXW
+#define NFA_MAXW 8
+#endif
+
+// Fills `d` / `meta` from a table image.  `base` is the address the image lives at (device or host),
+// `host_copy` a readable copy of it.  Returns nullptr on success or a static error string.
+static inline const char* cbh_parse_image(TableDev& d, std::vector<uint32_t>& meta_out, const uint8_t* base, const uint8_t* host_copy, size_t len) {
+  if (len < sizeof(CbhBlobHeader)) return ("blob too small");
+  const CbhBlobHeader* h = reinterpret_cast<const CbhBlobHeader*>(host_copy);
+  if (h->magic != CBH_BLOB_MAGIC) return ("bad blob magic");
+  if (h->version != CBH_BLOB_VERSION) return ("blob version mismatch: re-lower the rule table");
+  if (h->total_len != len) return ("blob length mismatch");
+  const CbhBlobSection* secs = reinterpret_cast<const CbhBlobSection*>(host_copy + sizeof(CbhBlobHeader));
+    auto find = [&](uint32_t id) -> const CbhBlobSection* {
+    for (uint32_t i = 0; i < h->n_sections; ++i) if (secs[i].id == id) return &secs[i];
+    return nullptr;
+  };
+  auto dptr = [&](uint32_t id) -> const uint8_t* {
+    const CbhBlobSection* s = find(id);
+    return s ? base + s->offset : nullptr;
+  };
+  const CbhBlobSection* ms = find(CBH_SEC_META);
+  if (!ms || ms->nbytes < CBH_META_N * 4) return ("blob has no META section");
+  for (uint32_t i = 0; i < h->n_sections; ++i)
+    if (secs[i].offset + secs[i].nbytes > len) return ("blob section out of range");
+  meta_out.assign(reinterpret_cast<const uint32_t*>(host_copy + ms->offset),
+                 reinterpret_cast<const uint32_t*>(host_copy + ms->offset) + CBH_META_N);
+  const uint32_t* m = meta_out.data();
+  if (m[CBH_M_MAX_STACK] > CBH_STACK_DEPTH) return ("a CEL program needs a deeper operand stack than the device provides");
+  if (m[CBH_M_MAX_LOCALS] > CBH_MAX_LOCALS) return ("a CEL program needs more comprehension locals than the device provides");
+  d.str_off = (const u32*)dptr(CBH_SEC_STR_OFF); d.str_bytes = dptr(CBH_SEC_STR_BYTES);
+  d.scope_parent = (const u32*)dptr(CBH_SEC_SCOPE_PARENT); d.scope_flags = (const u32*)dptr(CBH_SEC_SCOPE_FLAGS);
+  d.hash = (const CbhHashSlot*)dptr(CBH_SEC_HASH); d.hash_mask = m[CBH_M_HASH_MASK];
+  d.rows = (const u32*)dptr(CBH_SEC_ROWS); d.n_rows = m[CBH_M_NROWS];
+  d.rprows = (const u32*)dptr(CBH_SEC_RPROWS); d.n_rprows = m[CBH_M_NRPROWS];
+  d.pool = (const u32*)dptr(CBH_SEC_U32POOL);
+  d.dr = (const u32*)dptr(CBH_SEC_DR); d.n_dr = m[CBH_M_NDR];
+  d.code = (const u32*)dptr(CBH_SEC_CODE);
+  d.const_tag = dptr(CBH_SEC_CONST_TAG); d.const_val = (const u64*)dptr(CBH_SEC_CONST_VAL);
+  d.theap_tag = dptr(CBH_SEC_THEAP_TAG); d.theap_val = (const u64*)dptr(CBH_SEC_THEAP_VAL);
+  d.gbits = (const u64*)dptr(CBH_SEC_GBITS); d.K = m[CBH_M_NSTRINGS];
+  d.nfa[0] = (const u64*)dptr(CBH_SEC_NFA_ACTION); d.nfa[1] = (const u64*)dptr(CBH_SEC_NFA_ROLE); d.nfa[2] = (const u64*)dptr(CBH_SEC_NFA_KIND);
+  d.nfa_words[0] = m[CBH_M_NFA_WORDS_ACTION]; d.nfa_words[1] = m[CBH_M_NFA_WORDS_ROLE]; d.nfa_words[2] = m[CBH_M_NFA_WORDS_KIND];
+  for (int i = 0; i < 3; ++i) if (d.nfa_words[i] > NFA_MAXW) return ("glob NFA wider than the device supports");
+  d.flags = m[CBH_M_FLAGS];
+  if (!d.hash || !d.code || !d.str_off || !d.scope_flags) return ("blob is missing required sections");
+  return nullptr;
+}
+

@@ -1,0 +1,152 @@
+"""Host-side mirror of the reference's evaluator seam for the CheckResources hot path.
+
+Reference interface (``internal/evaluator/evaluator.go:16-19``)::
+
+    type Evaluator interface {
+        Check(ctx, []*enginev1.CheckInput, ...CheckOpt) ([]*enginev1.CheckOutput, error)
+        ...
+    }
+
+implemented by ``engine.(*Engine).Check`` (``internal/engine/engine.go:216-240``).
+``HipEvaluator.check`` takes the same inputs (JSON-shaped ``CheckInput`` dicts), the same
+per-call options (``CheckOpt`` -> keyword arguments: ``evaluator.go:22-73``) and returns
+JSON-shaped ``CheckOutput`` dicts (``check.go:64-94``).  All decisions are made by the HIP
+kernels behind the C ABI (``capi``); nothing here evaluates policies on the CPU.
+"""
+from __future__ import annotations
+
+import time
+
+from . import capi, namer
+from .flatten import Flattener
+from .lower.blob import LoweredTable, lower_rule_table
+from .policy.loader import load_policy_dir, policies_from_docs
+from .ruletable.build import rule_table_from_policies
+
+_EFFECT_NAMES = {capi.EFFECT_ALLOW: "EFFECT_ALLOW", capi.EFFECT_DENY: "EFFECT_DENY"}
+
+
+class DeviceUnsupported(RuntimeError):
+    """Some inputs hit an operation outside the device subset (status CBH_ST_UNSUPPORTED).
+    The caller (in production: ``ruletable.Manager.Check``) must evaluate those inputs with
+    its own engine; this package never does so itself."""
+
+    def __init__(self, request_indices, expressions):
+        self.request_indices = request_indices
+        self.expressions = expressions
+        super().__init__(
+            "%d input(s) need CEL features outside the device subset (%s)"
+            % (len(request_indices), "; ".join(e for e, _ in expressions[:3]) or "runtime limits"))
+
+
+class Conf:
+    """evaluator.Conf (``internal/evaluator/conf.go:38-67``) - the fields the path reads."""
+
+    def __init__(self, default_policy_version="default", default_scope="", globals_=None,
+                 lenient_scope_search=False, strict_evaluation=False):
+        self.default_policy_version = default_policy_version
+        self.default_scope = default_scope
+        self.globals = dict(globals_ or {})
+        self.lenient_scope_search = lenient_scope_search
+        self.strict_evaluation = strict_evaluation
+
+
+class HipEvaluator:
+    def __init__(self, lowered: LoweredTable, conf: Conf = None, device: int = 0):
+        self.conf = conf or Conf()
+        self.lt = lowered
+        if capi._inited_device is None:
+            capi.init(device)
+        self.table = capi.Table(lowered.blob)
+        self.flattener = Flattener(lowered)
+
+    # -- constructors ---------------------------------------------------------------------
+    @classmethod
+    def from_rule_table(cls, rt: dict, conf: Conf = None, device: int = 0):
+        conf = conf or Conf()
+        return cls(lower_rule_table(rt, conf.globals), conf, device)
+
+    @classmethod
+    def from_policies(cls, docs, conf: Conf = None, device: int = 0):
+        return cls.from_rule_table(rule_table_from_policies(policies_from_docs(docs)), conf, device)
+
+    @classmethod
+    def from_policy_dir(cls, path: str, conf: Conf = None, device: int = 0):
+        return cls.from_rule_table(rule_table_from_policies(load_policy_dir(path)), conf, device)
+
+    # -- the seam -------------------------------------------------------------------------
+    def check(self, inputs, now_ns=None, lenient_scope_search=None, strict_evaluation=None,
+              default_policy_version=None, default_scope=None, allow_unsupported=False):
+        """``Evaluator.Check``: one CheckOutput per CheckInput, same order."""
+        conf = self.conf
+        lenient = conf.lenient_scope_search if lenient_scope_search is None else lenient_scope_search
+        strict = conf.strict_evaluation if strict_evaluation is None else strict_evaluation
+        dver = conf.default_policy_version if default_policy_version is None else default_policy_version
+        dscope = conf.default_scope if default_scope is None else default_scope
+        if now_ns is None:
+            now_ns = time.time_ns()  # frozen once per call (evaluator_trace_common.go:24-26)
+        batch = self.flattener.flatten(inputs, dver, dscope)
+        flags = capi.F_WANT_DERIVED_ROLES
+        if lenient:
+            flags |= capi.F_LENIENT_SCOPE_SEARCH
+        if strict:
+            flags |= capi.F_STRICT_EVALUATION
+        res = self.table.check(batch, now_ns=now_ns, flags=flags)
+        return self.assemble(inputs, batch, res, dver, allow_unsupported)
+
+    def assemble(self, inputs, batch, res, default_policy_version, allow_unsupported=False):
+        """ids -> CheckOutput (check.go:64-94)."""
+        lt = self.lt
+        outs = []
+        bad = []
+        t = 0
+        for r, inp in enumerate(inputs):
+            actions = {}
+            unsupported = False
+            for a in batch.actions_per_request[r]:
+                st = int(res.status[t]) if res.status is not None else 0
+                if st == capi.ST_UNSUPPORTED:
+                    unsupported = True
+                eff = _EFFECT_NAMES[int(res.effect[t])]
+                pol = self._policy_string(int(res.policy[t]), inp, default_policy_version)
+                sc = int(res.scope[t])
+                scope = "" if sc == capi.NONE else lt.scopes[sc]
+                prev = actions.get(a)
+                if prev is None or eff == "EFFECT_DENY" or prev["effect"] != "EFFECT_DENY":
+                    actions[a] = {"effect": eff, "policy": pol, "scope": scope}  # setEffect: DENY sticky
+                t += 1
+            if unsupported:
+                bad.append(r)
+            mask = int(res.edr[r]) if res.edr is not None else 0
+            edr = [n for i, n in enumerate(lt.dr_names) if (mask >> i) & 1]
+            outs.append({
+                "requestId": inp.get("requestId", ""),
+                "resourceId": inp["resource"].get("id", ""),
+                "actions": actions,
+                "effectiveDerivedRoles": edr,
+            })
+        if bad and not allow_unsupported:
+            raise DeviceUnsupported(bad, lt.unsupported)
+        if allow_unsupported:
+            return outs, bad
+        return outs
+
+    def _policy_string(self, word, inp, default_policy_version):
+        kind, ident = word >> 28, word & 0x0FFFFFFF
+        if kind == capi.P_EMPTY:
+            return ""
+        if kind == capi.P_NO_MATCH:
+            return "NO_MATCH"
+        if kind == capi.P_NO_MATCH_SP:
+            return "NO_MATCH_FOR_SCOPE_PERMISSIONS"
+        if kind == capi.P_TABLE:
+            return self.lt.policy_keys[ident]
+        scope = self.lt.scopes[ident]
+        if kind == capi.P_RESOURCE:
+            ver = inp["resource"].get("policyVersion", "") or default_policy_version
+            return namer.policy_key_from_fqn(namer.resource_policy_fqn(inp["resource"]["kind"], ver, scope))
+        ver = inp["principal"].get("policyVersion", "") or default_policy_version
+        return namer.policy_key_from_fqn(namer.principal_policy_fqn(inp["principal"]["id"], ver, scope))
+
+    def close(self):
+        self.table.close()

@@ -1,0 +1,405 @@
+"""Rule table -> flat, column-oriented device image ("lowering", done once per table version).
+
+Input: the rule-table dict of ``cerbos_amd.ruletable.build`` (mirror of
+``runtimev1.RuleTable``).  Output: ``LoweredTable`` = the blob bytes consumed by
+``cbh_table_load`` (layout: cerbos_amd/csrc/cbh_blob.h) + the host-side dictionaries the
+request flattener and the response assembler need (string ids, scope indices, column
+schema, policy keys, derived-role names).
+
+What the reference computes per query with bitmap ANDs (``index/index.go:214-336``) is
+precomputed here into a directory keyed by (policy kind, version, kind|principal|role,
+scope): every string is an integer id, rows of one bucket are contiguous and in binding
+order, glob keys become bit positions of a per-dimension automaton (``lower/globs.py``).
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+from .. import namer
+from ..cel import parser as celparser
+from ..ruletable.build import KIND_PRINCIPAL, KIND_RESOURCE
+from . import celc
+from .celc import LoweringError, Params, ProgramBuilder
+from .globs import GlobNFA, fix_glob, has_meta
+
+BLOB_MAGIC = 0x31484243
+BLOB_VERSION = 3
+NONE = 0xFFFFFFFF
+PAT_GLOB = 0x80000000
+
+(SEC_META, SEC_STR_OFF, SEC_STR_BYTES, SEC_SCOPE_PARENT, SEC_SCOPE_FLAGS, SEC_SCOPE_SID, SEC_HASH,
+ SEC_ROWS, SEC_RPROWS, SEC_U32POOL, SEC_DR, SEC_CODE, SEC_CONST_TAG, SEC_CONST_VAL, SEC_THEAP_TAG,
+ SEC_THEAP_VAL, SEC_GBITS, SEC_NFA_ACTION, SEC_NFA_ROLE, SEC_NFA_KIND, SEC_POLICY_SID,
+ SEC_DRNAME_SID) = range(1, 23)
+
+(M_NSTRINGS, M_NCOLUMNS, M_NSCOPES, M_HASH_MASK, M_NROWS, M_NRPROWS, M_NDR, M_NPOLICIES, M_NCONSTS,
+ M_CODE_LEN, M_FLAGS, M_MAX_STACK, M_NDRNAMES, M_NFA_WORDS_ACTION, M_NFA_WORDS_ROLE,
+ M_NFA_WORDS_KIND, M_THEAP_LEN, M_MAX_LOCALS) = range(18)
+META_N = 24
+MF_USES_RUNTIME_EDR = 1
+
+B_RESOURCE, B_PRINCIPAL, B_ROLEPOL, B_PPEXISTS, B_RPRES, B_PARENTS, B_RESEXISTS = range(1, 8)
+
+DIM_ACTION, DIM_ROLE, DIM_KIND = 0, 1, 2
+FLAG_RES, FLAG_PRIN = 1, 2
+
+
+def hash4(a, b, c, d):
+    """Must match hash4() in cbh_engine.hip."""
+    M = 0xFFFFFFFF
+    h = (a * 0x9E3779B1) & M
+    h = ((h ^ (h >> 15)) + b * 0x85EBCA77) & M
+    h = ((h ^ (h >> 13)) + c * 0xC2B2AE3D) & M
+    h = ((h ^ (h >> 16)) + d * 0x27D4EB2F) & M
+    h ^= h >> 15
+    h = (h * 0x2C1B3C6D) & M
+    h ^= h >> 12
+    return h
+
+
+class _Dim:
+    """Pattern set of one index dimension (action / role / resource kind)."""
+
+    def __init__(self):
+        self.globs = {}  # pattern text -> glob index
+
+    def glob_ref(self, pattern):
+        gi = self.globs.get(pattern)
+        if gi is None:
+            gi = len(self.globs)
+            self.globs[pattern] = gi
+        return PAT_GLOB | gi
+
+
+class LoweredTable:
+    def __init__(self):
+        self.blob = b""
+        self.strings = []       # id -> str
+        self.string_ids = {}    # str -> id
+        self.scopes = []        # scope index -> scope string
+        self.scope_index = {}
+        self.columns = []       # column index -> (root, keys)
+        self.policy_keys = []   # policy id -> policy key string
+        self.dr_names = []      # bit -> derived role name
+        self.unsupported = []   # [(expression, reason)] compiled to OP_UNSUPPORTED
+        self.nfas = [None, None, None]
+        self.stats = {}
+
+    def sid(self, s):
+        return self.string_ids.get(s)
+
+
+def _cond_uses_runtime(cond, params: Params):
+    if cond is None:
+        return False
+    if cond[0] == "expr":
+        ast = params.inline(celparser.parse(cond[1]))
+        return any(n[0] == "ident" and n[1] == "runtime" for n in celparser.walk(ast))
+    return any(_cond_uses_runtime(c, params) for c in cond[1])
+
+
+def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
+    lt = LoweredTable()
+    globals_ = dict(globals_ or {})
+
+    def sid(s):
+        i = lt.string_ids.get(s)
+        if i is None:
+            i = len(lt.strings)
+            lt.string_ids[s] = i
+            lt.strings.append(s)
+        return i
+
+    sid("")  # string 0 is always the empty string
+    pb = ProgramBuilder(sid, globals_)
+    dims = [_Dim(), _Dim(), _Dim()]
+
+    def dim_ref(dim, key):
+        """globDimension.Set: a key is a pattern only if it contains '*' (glob_dimension.go:32)."""
+        if "*" in key:
+            return dims[dim].glob_ref(key)
+        return sid(key)
+
+    def allow_action_ref(a):
+        """Role-policy allow actions are matched with ``a == action || MatchesGlob(a, action)``
+        (index.go:447-452): any glob metacharacter makes it a pattern."""
+        if has_meta(a):
+            return dims[DIM_ACTION].glob_ref(a)
+        return sid(a)
+
+    # ---- scopes: every scope of a row or role policy plus all ancestors; "" is index 0
+    scope_set = {""}
+    for r in rt["rules"]:
+        scope_set.add(r["scope"])
+    for s in rt["scope_parent_roles"]:
+        scope_set.add(s)
+    for s in list(scope_set):
+        scope_set.update(namer.scope_parents(s))
+    lt.scopes = sorted(scope_set, key=lambda s: (s.count(".") if s else -1, s))
+    lt.scope_index = {s: i for i, s in enumerate(lt.scopes)}
+    res_scopes, prin_scopes = set(rt["resource_scopes"]), set(rt["principal_scopes"])
+    scope_parent, scope_flags, scope_sid = [], [], []
+    for s in lt.scopes:
+        if s == "":
+            scope_parent.append(NONE)
+        else:
+            scope_parent.append(lt.scope_index[next(iter(namer.scope_parents(s)))])
+        fl = (FLAG_RES if s in res_scopes else 0) | (FLAG_PRIN if s in prin_scopes else 0)
+        fl |= (rt["scope_permissions"].get(s, 0) & 3) << 2
+        scope_flags.append(fl)
+        scope_sid.append(sid(s))
+
+    # ---- policies (ids used for role-policy / strict-mode attribution)
+    policy_index = {}
+
+    def policy_id(fqn):
+        key = namer.policy_key_from_fqn(fqn)
+        i = policy_index.get(key)
+        if i is None:
+            i = len(lt.policy_keys)
+            policy_index[key] = i
+            lt.policy_keys.append(key)
+        return i
+
+    # ---- bucket the rows
+    res_buckets, prin_buckets, rp_buckets = {}, {}, {}
+    res_exists, pp_exists, rp_res = set(), set(), {}
+    rp_evalkeys = {}
+    for r in rt["rules"]:
+        ver, scope = r["version"], r["scope"]
+        if r["allow_actions"] is not None:
+            rp_buckets.setdefault((ver, scope, r["role"]), []).append(r)
+            rp_res.setdefault((ver, scope), []).append(r["resource"])
+            # only conditional rules are ever evaluated (and cached) through their key (index.go:463-487)
+            prev = r["condition"] if r["condition"] is None else rp_evalkeys.setdefault(r["evaluation_key"], r["condition"])
+            if prev != r["condition"]:
+                raise LoweringError(
+                    "role policy %s has rules for different resources that share an evaluation key but not a "
+                    "condition; the reference's result then depends on evaluation history (ruletable.go:445-455)"
+                    % namer.policy_key_from_fqn(r["origin_fqn"]))
+        elif r["policy_kind"] == KIND_RESOURCE:
+            if "*" in r["resource"]:
+                raise LoweringError("resource policy with a wildcard resource name is not supported: %s" % r["resource"])
+            key = (ver, r["resource"], scope)
+            res_exists.add(key)
+            res_buckets.setdefault(key, [])
+            if r["action"] is not None:
+                res_buckets[key].append(r)
+        else:
+            pp_exists.add((ver, scope))
+            if r["action"] is not None:
+                prin_buckets.setdefault((ver, scope, r["principal"]), []).append(r)
+
+    pool = []
+    row_cols = [[] for _ in range(7)]
+    rp_cols = [[] for _ in range(4)]
+    dr_cols = [[] for _ in range(4)]
+    entries = []  # (k0,k1,k2,k3, v0,v1,v2,v3)
+
+    def add_row(r, principal_policy):
+        params = Params(r["params"]["constants"], r["params"]["ordered_variables"], globals_) if r["params"] else Params(None, None, globals_)
+        if principal_policy and _cond_uses_runtime(r["condition"], params):
+            raise LoweringError(
+                "principal policy %s reads runtime.effectiveDerivedRoles: in the reference its value depends on the "
+                "previously evaluated action (check.go:281), which a per-tuple evaluation cannot reproduce"
+                % namer.policy_key_from_fqn(r["origin_fqn"]))
+        cond = pb.condition_program(r["condition"], params) if r["condition"] is not None else NONE
+        drc = NONE
+        if r["derived_role_condition"] is not None:
+            dp = r["derived_role_params"] or {"constants": {}, "ordered_variables": []}
+            drc = pb.condition_program(r["derived_role_condition"], Params(dp["constants"], dp["ordered_variables"], globals_))
+        row_cols[0].append(dim_ref(DIM_ACTION, r["action"]))
+        row_cols[1].append(dim_ref(DIM_ROLE, r["role"]) if r["role"] else NONE)
+        row_cols[2].append(dim_ref(DIM_KIND, r["resource"]) if r["resource"] else NONE)
+        row_cols[3].append({"ALLOW": 1, "DENY": 2}.get(r["effect"], 0))
+        row_cols[4].append(cond)
+        row_cols[5].append(drc)
+        row_cols[6].append(policy_id(r["origin_fqn"]))
+
+    # resource policies (+ their derived roles)
+    for key in sorted(res_buckets):
+        ver, kind, scope = key
+        rows = sorted(res_buckets[key], key=lambda r: r["id"])
+        begin = len(row_cols[0])
+        for r in rows:
+            add_row(r, False)
+        dr_begin = len(dr_cols[0])
+        drs = rt["policy_derived_roles"].get(namer.resource_policy_fqn(kind, ver, scope)) or {}
+        for name, dr in drs.items():
+            dr_cols[0].append(pb.dr_bit(name))
+            if "*" in dr["parent_roles"]:
+                dr_cols[1].append(0)
+                dr_cols[2].append(NONE)
+            else:
+                dr_cols[1].append(len(pool))
+                dr_cols[2].append(len(dr["parent_roles"]))
+                pool.extend(sid(p) for p in dr["parent_roles"])
+            dparams = Params(dr["constants"], dr["ordered_variables"], globals_)
+            # a derived-role definition that reads runtime.effectiveDerivedRoles sees, in the reference, the
+            # roles of whichever scope/action was processed last (check.go:262,281): not reproducible per tuple
+            dr_cols[3].append(pb.condition_program(dr["condition"], dparams, allow_runtime=False)
+                              if dr["condition"] is not None else NONE)
+        entries.append((B_RESOURCE, sid(ver), sid(kind), lt.scope_index[scope],
+                        begin, len(rows), dr_begin, len(dr_cols[0]) - dr_begin))
+    for ver, kind, scope in sorted(res_exists):
+        entries.append((B_RESEXISTS, sid(ver), sid(kind), lt.scope_index[scope], 1, 0, 0, 0))
+
+    # principal policies
+    for key in sorted(prin_buckets):
+        ver, scope, principal = key
+        rows = sorted(prin_buckets[key], key=lambda r: r["id"])
+        begin = len(row_cols[0])
+        for r in rows:
+            add_row(r, True)
+        entries.append((B_PRINCIPAL, sid(ver), lt.scope_index[scope], sid(principal), begin, len(rows), 0, 0))
+    for ver, scope in sorted(pp_exists):
+        entries.append((B_PPEXISTS, sid(ver), lt.scope_index[scope], 0, 1, 0, 0, 0))
+
+    # role policies
+    for key in sorted(rp_buckets):
+        ver, scope, role = key
+        rows = sorted(rp_buckets[key], key=lambda r: r["id"])
+        begin = len(rp_cols[0])
+        for r in rows:
+            params = Params(r["params"]["constants"], r["params"]["ordered_variables"], globals_)
+            rp_cols[0].append(dim_ref(DIM_KIND, r["resource"]))
+            rp_cols[1].append(len(pool))
+            rp_cols[2].append(len(r["allow_actions"]))
+            pool.extend(allow_action_ref(a) for a in r["allow_actions"])
+            rp_cols[3].append(pb.condition_program(r["condition"], params) if r["condition"] is not None else NONE)
+        pid = policy_id(namer.role_policy_fqn(role, ver, scope))
+        entries.append((B_ROLEPOL, sid(ver), lt.scope_index[scope], sid(role), begin, len(rows), pid, 0))
+    for (ver, scope), pats in sorted(rp_res.items()):
+        uniq = list(dict.fromkeys(pats))
+        entries.append((B_RPRES, sid(ver), lt.scope_index[scope], 0, len(pool), len(uniq), 0, 0))
+        pool.extend(dim_ref(DIM_KIND, p) for p in uniq)
+
+    # parent roles (index.go:749-788), looked up with the request's own resource scope
+    for scope, roles in sorted(rt["parent_roles"].items()):
+        for role, ancestors in sorted(roles.items()):
+            if not ancestors:
+                continue
+            entries.append((B_PARENTS, lt.scope_index[scope], sid(role), 0, len(pool), len(ancestors), 0, 0))
+            pool.extend(sid(a) for a in ancestors)
+
+    # ---- glob automata + match bits of the table's own strings
+    gbits = np.zeros((3, 0), dtype=np.uint64)
+    nfa_bytes = []
+    for d in range(3):
+        pats = [p for p, _ in sorted(dims[d].globs.items(), key=lambda kv: kv[1])]
+        nfa = GlobNFA(pats)
+        lt.nfas[d] = nfa
+        nfa_bytes.append(nfa.tables())
+    K = len(lt.strings)  # final: no string may be interned after this point
+    gbits = np.zeros((3, K), dtype=np.uint64)
+    for d in range(3):
+        if lt.nfas[d].patterns:
+            for i, s in enumerate(lt.strings):
+                gbits[d, i] = lt.nfas[d].match_bits(s.encode("utf-8"))
+
+    # ---- directory hash table
+    nslots = 16
+    while nslots < 2 * len(entries):
+        nslots *= 2
+    slots = np.full((nslots, 8), NONE, dtype=np.uint32)
+    for e in entries:
+        i = hash4(e[0], e[1], e[2], e[3]) & (nslots - 1)
+        while slots[i, 0] != NONE:
+            if tuple(slots[i, :4]) == e[:4]:
+                raise LoweringError("duplicate directory key %r" % (e[:4],))
+            i = (i + 1) & (nslots - 1)
+        slots[i, :] = e
+
+    # ---- assemble
+    lt.columns = [k for k, _ in sorted(pb.columns.items(), key=lambda kv: kv[1])]
+    lt.dr_names = [n for n, _ in sorted(pb.dr_names.items(), key=lambda kv: kv[1])]
+    lt.unsupported = list(dict.fromkeys(pb.unsupported))
+    assert len(lt.strings) == K, "string interned after the pool was frozen"
+
+    enc = [s.encode("utf-8") for s in lt.strings]
+    str_off = np.zeros(K + 1, dtype=np.uint32)
+    str_off[1:] = np.cumsum([len(b) for b in enc])
+    meta = np.zeros(META_N, dtype=np.uint32)
+    meta[M_NSTRINGS] = K
+    meta[M_NCOLUMNS] = len(lt.columns)
+    meta[M_NSCOPES] = len(lt.scopes)
+    meta[M_HASH_MASK] = nslots - 1
+    meta[M_NROWS] = len(row_cols[0])
+    meta[M_NRPROWS] = len(rp_cols[0])
+    meta[M_NDR] = len(dr_cols[0])
+    meta[M_NPOLICIES] = len(lt.policy_keys)
+    meta[M_NCONSTS] = len(pb.const_tag)
+    meta[M_CODE_LEN] = len(pb.code)
+    meta[M_FLAGS] = MF_USES_RUNTIME_EDR if pb.uses_runtime else 0
+    meta[M_MAX_STACK] = pb.max_stack
+    meta[M_NDRNAMES] = len(lt.dr_names)
+    meta[M_NFA_WORDS_ACTION] = lt.nfas[0].words
+    meta[M_NFA_WORDS_ROLE] = lt.nfas[1].words
+    meta[M_NFA_WORDS_KIND] = lt.nfas[2].words
+    meta[M_THEAP_LEN] = len(pb.theap_tag)
+    meta[M_MAX_LOCALS] = pb.max_locals
+
+    def u32(a):
+        return np.asarray(a, dtype=np.uint32).tobytes()
+
+    def u64(a):
+        return np.array([int(x) & 0xFFFFFFFFFFFFFFFF for x in a], dtype=np.uint64).tobytes()
+
+    def u8(a):
+        return np.asarray(a, dtype=np.uint8).tobytes()
+
+    code = list(pb.code) or [celc.OP_RET]
+    sections = [
+        (SEC_META, META_N, meta.tobytes()),
+        (SEC_STR_OFF, K + 1, str_off.tobytes()),
+        (SEC_STR_BYTES, int(str_off[-1]), b"".join(enc)),
+        (SEC_SCOPE_PARENT, len(lt.scopes), u32(scope_parent)),
+        (SEC_SCOPE_FLAGS, len(lt.scopes), u32(scope_flags)),
+        (SEC_SCOPE_SID, len(lt.scopes), u32(scope_sid)),
+        (SEC_HASH, nslots, slots.tobytes()),
+        (SEC_ROWS, len(row_cols[0]), b"".join(u32(c) for c in row_cols)),
+        (SEC_RPROWS, len(rp_cols[0]), b"".join(u32(c) for c in rp_cols)),
+        (SEC_U32POOL, len(pool), u32(pool)),
+        (SEC_DR, len(dr_cols[0]), b"".join(u32(c) for c in dr_cols)),
+        (SEC_CODE, len(code), u32(code)),
+        (SEC_CONST_TAG, len(pb.const_tag), u8(pb.const_tag)),
+        (SEC_CONST_VAL, len(pb.const_val), u64(pb.const_val)),
+        (SEC_THEAP_TAG, len(pb.theap_tag), u8(pb.theap_tag)),
+        (SEC_THEAP_VAL, len(pb.theap_val), u64(pb.theap_val)),
+        (SEC_GBITS, 3 * K, gbits.tobytes()),
+        (SEC_NFA_ACTION, lt.nfas[0].words, nfa_bytes[0]),
+        (SEC_NFA_ROLE, lt.nfas[1].words, nfa_bytes[1]),
+        (SEC_NFA_KIND, lt.nfas[2].words, nfa_bytes[2]),
+        (SEC_POLICY_SID, len(lt.policy_keys), u32([0] * len(lt.policy_keys))),
+        (SEC_DRNAME_SID, len(lt.dr_names), u32([0] * len(lt.dr_names))),
+    ]
+    lt.blob = _pack(sections)
+    lt.stats = {
+        "strings": K, "scopes": len(lt.scopes), "rows": len(row_cols[0]), "role_policy_rows": len(rp_cols[0]),
+        "derived_roles": len(dr_cols[0]), "programs": len(pb.programs), "code_words": len(pb.code),
+        "columns": len(lt.columns), "directory_slots": nslots, "blob_bytes": len(lt.blob),
+        "unsupported_expressions": len(lt.unsupported),
+        "globs": [len(d.globs) for d in dims],
+    }
+    return lt
+
+
+def _pack(sections):
+    hdr_len = 32 + 32 * len(sections)
+    off = (hdr_len + 63) // 64 * 64
+    table, bodies = [], []
+    for sid_, count, data in sections:
+        # keep every section non-empty so device pointers are always valid
+        if not data:
+            data = b"\0" * 8
+        table.append(struct.pack("<IIQQQ", sid_, count, off, len(data), 0))
+        pad = (-len(data)) % 64
+        bodies.append(data + b"\0" * pad)
+        off += len(data) + pad
+    total = off
+    head = struct.pack("<IIIIQQ", BLOB_MAGIC, BLOB_VERSION, len(sections), 0, total, 0)
+    out = head + b"".join(table)
+    out += b"\0" * ((-len(out)) % 64)
+    return out + b"".join(bodies)

@@ -1,0 +1,603 @@
+"""CEL condition trees -> device bytecode (the "CEL bytecode tape" of the table image).
+
+Input: the condition tuple trees of rule-table rows (``cerbos_amd.policy.compile``) and
+the row's params (constants + ordered variables).  Policy variables / constants / globals
+are inlined into the expression (CEL is side-effect free, so ``V.x`` evaluated at its use
+is equivalent to the reference evaluating it once per request - check.go:651-677 - as far
+as effects go; the evaluation_errors *text* differs and is not produced by the device).
+
+Instruction encoding and operand-stack discipline: see cerbos_amd/csrc/cbh_blob.h (CbhOp)
+and cbh_vm.h (run_program).  Anything outside the device subset compiles to
+OP_UNSUPPORTED: the table still loads, and a tuple that actually executes such an
+instruction is reported with status CBH_ST_UNSUPPORTED (never a silently wrong effect).
+"""
+from __future__ import annotations
+
+import struct
+
+from ..cel import parser as celparser
+
+# keep in sync with cbh_blob.h
+(OP_RET, OP_CONST, OP_COL, OP_HASCOL, OP_REQSTR, OP_ROLES, OP_SELECT, OP_HASSEL, OP_INDEX,
+ OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE, OP_IN, OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_MOD,
+ OP_NEG, OP_NOT, OP_JF, OP_JT, OP_AND, OP_OR, OP_JTERN, OP_JMP, OP_POP, OP_LEAF, OP_SIZE,
+ OP_STARTSWITH, OP_ENDSWITH, OP_CONTAINS, OP_TIMESTAMP, OP_DURATION, OP_TIMESINCE, OP_NOW,
+ OP_EDRHAS, OP_LOCAL, OP_ITER_BEGIN, OP_ITER_NEXT, OP_ITER_ACC, OP_ITER_END, OP_TOINT,
+ OP_TODOUBLE, OP_TOSTRING_UNSUPPORTED, OP_INIPRANGE, OP_UNSUPPORTED, OP_TS_GETTER,
+ OP_HASINTERSECTION, OP_ISSUBSET) = range(53)
+
+T_NULL, T_BOOL, T_INT, T_UINT, T_DOUBLE, T_STRING, T_LIST, T_MAP, T_TIMESTAMP, T_DURATION = range(10)
+T_ABSENT, T_ERR = 0xF0, 0xFF
+
+HEAP_TABLE, HEAP_BATCH, HEAP_ROLES = 0, 1, 2
+
+# request string fields (cbh_req_field)
+RQ_PRINCIPAL_ID, RQ_S_RESOURCE_ID, RQ_S_KIND = 0, 8, 9
+RQ_S_P_SCOPE, RQ_S_R_SCOPE, RQ_S_P_VERSION, RQ_S_R_VERSION = 10, 11, 12, 13
+
+IT_ALL, IT_EXISTS, IT_EXISTS_ONE = 0, 1, 2
+
+MAX_STACK = 10
+MAX_LOCALS = 4
+MAX_ITERS = 2
+
+_BINOPS = {"==": OP_EQ, "!=": OP_NE, "<": OP_LT, "<=": OP_LE, ">": OP_GT, ">=": OP_GE, "in": OP_IN,
+           "+": OP_ADD, "-": OP_SUB, "*": OP_MUL, "/": OP_DIV, "%": OP_MOD}
+
+_P_FIELDS = {"id": RQ_PRINCIPAL_ID, "scope": RQ_S_P_SCOPE, "policyVersion": RQ_S_P_VERSION,
+             "policy_version": RQ_S_P_VERSION}
+_R_FIELDS = {"id": RQ_S_RESOURCE_ID, "kind": RQ_S_KIND, "scope": RQ_S_R_SCOPE,
+             "policyVersion": RQ_S_R_VERSION, "policy_version": RQ_S_R_VERSION}
+
+
+class LoweringError(ValueError):
+    pass
+
+
+def f64_bits(x: float) -> int:
+    return struct.unpack("<Q", struct.pack("<d", float(x)))[0]
+
+
+def cont_payload(sel: int, off: int, length: int) -> int:
+    return (sel << 62) | (off << 32) | length
+
+
+def value_to_ast(v):
+    """A constant / global value (YAML/JSON) as a CEL literal AST; numbers are doubles
+    because they travel as google.protobuf.Value (structpb)."""
+    if v is None:
+        return ("lit", "null", None)
+    if isinstance(v, bool):
+        return ("lit", "bool", v)
+    if isinstance(v, (int, float)):
+        return ("lit", "double", float(v))
+    if isinstance(v, str):
+        return ("lit", "string", v)
+    if isinstance(v, (list, tuple)):
+        return ("list", tuple(value_to_ast(x) for x in v))
+    if isinstance(v, dict):
+        return ("map", tuple((("lit", "string", str(k)), value_to_ast(x)) for k, x in v.items()))
+    raise LoweringError("unsupported constant value %r" % (v,))
+
+
+def _subst(ast, fn):
+    """Bottom-up rewrite."""
+    k = ast[0]
+    if k in ("lit", "ident"):
+        return fn(ast)
+    if k in ("select", "has"):
+        return fn((k, _subst(ast[1], fn), ast[2]))
+    if k == "index":
+        return fn((k, _subst(ast[1], fn), _subst(ast[2], fn)))
+    if k == "call":
+        tgt = None if ast[2] is None else _subst(ast[2], fn)
+        return fn((k, ast[1], tgt, tuple(_subst(a, fn) for a in ast[3])))
+    if k == "list":
+        return fn((k, tuple(_subst(a, fn) for a in ast[1])))
+    if k == "map":
+        return fn((k, tuple((_subst(a, fn), _subst(b, fn)) for a, b in ast[1])))
+    if k in ("not", "neg"):
+        return fn((k, _subst(ast[1], fn)))
+    if k == "bin":
+        return fn((k, ast[1], _subst(ast[2], fn), _subst(ast[3], fn)))
+    if k in ("and", "or"):
+        return fn((k, _subst(ast[1], fn), _subst(ast[2], fn)))
+    if k == "tern":
+        return fn((k, _subst(ast[1], fn), _subst(ast[2], fn), _subst(ast[3], fn)))
+    if k == "comp":
+        return fn((k, ast[1], _subst(ast[2], fn), ast[3], tuple(_subst(a, fn) for a in ast[4])))
+    if k == "bind":
+        return fn((k, ast[1], _subst(ast[2], fn), _subst(ast[3], fn)))
+    return ast
+
+
+class Params:
+    """Constants + variables visible to one condition (RuleRow.Params)."""
+
+    def __init__(self, constants=None, ordered_variables=None, globals_=None):
+        self.constants = dict(constants or {})
+        self.variables = {n: t for n, t in (ordered_variables or [])}
+        self.globals = dict(globals_ or {})
+        self._inlined = {}
+
+    def key(self):
+        return (tuple(sorted((k, repr(v)) for k, v in self.constants.items())),
+                tuple(sorted(self.variables.items())))
+
+    def inline(self, ast, depth=0):
+        if depth > 32:
+            raise LoweringError("variable definitions nest too deeply")
+
+        def fn(n):
+            if n[0] == "select" and n[1][0] == "ident":
+                base, name = n[1][1], n[2]
+                if base in ("V", "variables"):
+                    if name not in self.variables:
+                        return ("call", "__unsupported__", None, ())
+                    if name not in self._inlined:
+                        self._inlined[name] = self.inline(celparser.parse(self.variables[name]), depth + 1)
+                    return self._inlined[name]
+                if base in ("C", "constants"):
+                    if name not in self.constants:
+                        return ("call", "__unsupported__", None, ())
+                    return value_to_ast(self.constants[name])
+                if base in ("G", "globals"):
+                    if name not in self.globals:
+                        return ("call", "__error__", None, ())   # undefined field -> CEL error
+                    return value_to_ast(self.globals[name])
+            return n
+
+        return _subst(ast, fn)
+
+
+class ProgramBuilder:
+    """Accumulates code, constants, table heap, strings and the column schema for a table."""
+
+    def __init__(self, intern_string, globals_=None):
+        self.sid = intern_string           # str -> table string id
+        self.globals = dict(globals_ or {})
+        self.code = []
+        self.const_index = {}
+        self.const_tag = []
+        self.const_val = []
+        self.theap_tag = []
+        self.theap_val = []
+        self.columns = {}                  # (root, keys) -> column index
+        self.programs = {}                 # dedup key -> entry pc
+        self.dr_names = {}                 # derived role name -> bit
+        self.unsupported = []              # [(expr text, reason)]
+        self.uses_runtime = False
+        self.max_stack = 0
+        self.max_locals = 0
+
+    # ---- pools ---------------------------------------------------------------------
+    def const(self, tag, val):
+        k = (tag, val)
+        i = self.const_index.get(k)
+        if i is None:
+            i = len(self.const_tag)
+            self.const_index[k] = i
+            self.const_tag.append(tag)
+            self.const_val.append(val)
+        return i
+
+    def column(self, root, keys):
+        k = (root, tuple(keys))
+        i = self.columns.get(k)
+        if i is None:
+            i = len(self.columns)
+            self.columns[k] = i
+        return i
+
+    def dr_bit(self, name):
+        if name not in self.dr_names:
+            if len(self.dr_names) >= 64:
+                raise LoweringError("more than 64 distinct derived role names: not supported by the device table")
+            self.dr_names[name] = len(self.dr_names)
+        return self.dr_names[name]
+
+    def _heap_value(self, ast):
+        """Constant AST -> (tag, payload) stored in the table heap when it is a container."""
+        k = ast[0]
+        if k == "lit":
+            kind, v = ast[1], ast[2]
+            if kind == "null":
+                return T_NULL, 0
+            if kind == "bool":
+                return T_BOOL, int(v)
+            if kind == "int":
+                return T_INT, v & 0xFFFFFFFFFFFFFFFF
+            if kind == "uint":
+                return T_UINT, v
+            if kind == "double":
+                return T_DOUBLE, f64_bits(v)
+            if kind == "string":
+                return T_STRING, self.sid(v)
+            raise _Unsupported("bytes literal")
+        if k == "list":
+            vals = [self._heap_value(e) for e in ast[1]]
+            off = len(self.theap_tag)
+            for t, v in vals:
+                self.theap_tag.append(t)
+                self.theap_val.append(v)
+            return T_LIST, cont_payload(HEAP_TABLE, off, len(vals))
+        if k == "map":
+            ents = []
+            for ke, ve in ast[1]:
+                kt, kv = self._heap_value(ke)
+                if kt != T_STRING:
+                    raise _Unsupported("non-string map key literal")
+                ents.append(((kt, kv), self._heap_value(ve)))
+            off = len(self.theap_tag)
+            for (kt, kv), (vt, vv) in ents:
+                self.theap_tag.extend((kt, vt))
+                self.theap_val.extend((kv, vv))
+            return T_MAP, cont_payload(HEAP_TABLE, off, len(ents))
+        raise _Unsupported("non-constant container element")
+
+    # ---- programs ------------------------------------------------------------------
+    def condition_program(self, cond, params: Params, allow_runtime=True):
+        """Compile a condition tree; returns the entry pc (deduplicated)."""
+        key = (cond, params.key(), allow_runtime)
+        pc = self.programs.get(key)
+        if pc is not None:
+            return pc
+        fc = _FuncCompiler(self, params, allow_runtime)
+        fc.cond(cond)
+        fc.emit(OP_RET)
+        pc = len(self.code)
+        self.code.extend(fc.finish(pc))
+        self.programs[key] = pc
+        self.max_stack = max(self.max_stack, fc.max_depth)
+        self.max_locals = max(self.max_locals, fc.max_locals)
+        if fc.max_depth > MAX_STACK:
+            raise LoweringError("condition needs operand stack depth %d (device limit %d)" % (fc.max_depth, MAX_STACK))
+        return pc
+
+
+class _Unsupported(Exception):
+    pass
+
+
+def _is_const(ast):
+    k = ast[0]
+    if k == "lit":
+        return ast[1] != "bytes"
+    if k == "list":
+        return all(_is_const(e) for e in ast[1])
+    if k == "map":
+        return all(ke[0] == "lit" and ke[1] == "string" and _is_const(ve) for ke, ve in ast[1])
+    return False
+
+
+class _FuncCompiler:
+    def __init__(self, pb: ProgramBuilder, params: Params, allow_runtime: bool):
+        self.pb = pb
+        self.params = params
+        self.allow_runtime = allow_runtime
+        self.out = []          # list of ints or ('label', id) / ('ref', op, id)
+        self.depth = 0
+        self.max_depth = 0
+        self.labels = {}
+        self.nlabels = 0
+        self.locals = {}       # var name -> slot
+        self.max_locals = 0
+        self.iter_depth = 0
+        self.cur_text = ""
+
+    # -- emission helpers
+    def emit(self, op, arg=0, delta=0):
+        self.out.append(op | (arg << 8))
+        self.depth += delta
+        self.max_depth = max(self.max_depth, self.depth)
+
+    def word(self, w):
+        self.out.append(w)
+
+    def new_label(self):
+        self.nlabels += 1
+        return self.nlabels
+
+    def place(self, lab):
+        self.out.append(("label", lab))
+
+    def emit_ref(self, op, lab, delta=0):
+        self.out.append(("ref", op, lab))
+        self.depth += delta
+        self.max_depth = max(self.max_depth, self.depth)
+
+    def word_ref(self, lab):
+        """A full word holding the address of ``lab``."""
+        self.out.append(("wref", lab, None))
+
+    def word_ref_packed(self, lab, low):
+        """A word holding ``low | address(lab) << 8``."""
+        self.out.append(("wref", lab, low))
+
+    def finish(self, base):
+        pos, addr = 0, {}
+        for x in self.out:
+            if isinstance(x, tuple) and x[0] == "label":
+                addr[x[1]] = base + pos
+            else:
+                pos += 1
+        code = []
+        for x in self.out:
+            if isinstance(x, tuple):
+                if x[0] == "label":
+                    continue
+                if x[0] == "ref":
+                    code.append(x[1] | (addr[x[2]] << 8))
+                elif x[2] is None:
+                    code.append(addr[x[1]])
+                else:
+                    code.append(x[2] | (addr[x[1]] << 8))
+            else:
+                code.append(x)
+        return code
+
+    def unsupported(self, reason):
+        self.pb.unsupported.append((self.cur_text, reason))
+        self.emit(OP_UNSUPPORTED, 0, +1)
+
+    # -- condition trees (check.go:679-756)
+    def cond(self, c):
+        if c is None:
+            self.emit(OP_CONST, self.pb.const(T_BOOL, 1), +1)
+            return
+        op = c[0]
+        if op == "expr":
+            self.cur_text = c[1]
+            ast = self.params.inline(celparser.parse(c[1]))
+            d0 = self.depth
+            self.expr(ast)
+            assert self.depth == d0 + 1, (c[1], self.depth, d0)
+            self.emit(OP_LEAF)
+            return
+        kids = c[1]
+        if not kids:
+            self.emit(OP_CONST, self.pb.const(T_BOOL, 1 if op in ("all", "none") else 0), +1)
+            return
+        end = self.new_label()
+        jop = OP_JF if op == "all" else OP_JT
+        for i, kid in enumerate(kids):
+            self.cond(kid)
+            if i + 1 < len(kids):
+                self.emit_ref(jop, end)
+                self.emit(OP_POP, 0, -1)
+        self.place(end)
+        if op == "none":
+            self.emit(OP_NOT)
+
+    # -- paths
+    def _path(self, ast):
+        """Resolve a select/index chain to ('col', root, keys) | ('req', field) | ('roles',) |
+        ('edr',) | None."""
+        keys = []
+        n = ast
+        while True:
+            if n[0] == "select":
+                keys.append(n[2])
+                n = n[1]
+            elif n[0] == "index" and n[2][0] == "lit" and n[2][1] == "string":
+                keys.append(n[2][2])
+                n = n[1]
+            else:
+                break
+        if n[0] != "ident" or n[1] in self.locals:
+            return None
+        keys.reverse()
+        base = n[1]
+        if base == "request":
+            if not keys:
+                return None
+            top = keys[0]
+            if top == "principal":
+                base, keys = "P", keys[1:]
+            elif top == "resource":
+                base, keys = "R", keys[1:]
+            elif top in ("aux_data", "auxData"):
+                if len(keys) >= 2 and keys[1] == "jwt":
+                    return ("col", "J", tuple(keys[2:]))
+                return None
+            else:
+                return None
+        if base in ("P", "R"):
+            if not keys:
+                return None
+            f = keys[0]
+            if f == "attr":
+                return ("col", base, tuple(keys[1:]))
+            if len(keys) == 1:
+                if base == "P" and f == "roles":
+                    return ("roles",)
+                fields = _P_FIELDS if base == "P" else _R_FIELDS
+                if f in fields:
+                    return ("req", fields[f])
+            return None
+        if base == "runtime" and len(keys) == 1 and keys[0] in ("effectiveDerivedRoles", "effective_derived_roles"):
+            return ("edr",)
+        return None
+
+    # -- expressions
+    def expr(self, ast):  # noqa: C901
+        try:
+            self._expr(ast)
+        except _Unsupported as e:
+            raise LoweringError("internal: unsupported escaped: %s" % e)
+
+    def _expr(self, ast):  # noqa: C901
+        k = ast[0]
+        pb = self.pb
+        if k == "lit" or ((k == "list" or k == "map") and _is_const(ast)):
+            try:
+                t, v = pb._heap_value(ast)
+            except _Unsupported as e:
+                return self.unsupported(str(e))
+            return self.emit(OP_CONST, pb.const(t, v), +1)
+        if k in ("list", "map"):
+            return self.unsupported("container literal with non-constant elements")
+        if k == "ident":
+            if ast[1] in self.locals:
+                return self.emit(OP_LOCAL, self.locals[ast[1]], +1)
+            return self.unsupported("identifier %s used as a value" % ast[1])
+        if k in ("select", "index"):
+            p = self._path(ast)
+            if p is not None:
+                if p[0] == "col":
+                    return self.emit(OP_COL, pb.column(p[1], p[2]), +1)
+                if p[0] == "req":
+                    return self.emit(OP_REQSTR, p[1], +1)
+                if p[0] == "roles":
+                    return self.emit(OP_ROLES, 0, +1)
+                return self.unsupported("runtime.effectiveDerivedRoles used other than `name in ...`")
+            if k == "select":
+                self._expr(ast[1])
+                return self.emit(OP_SELECT, pb.sid(ast[2]))
+            self._expr(ast[1])
+            self._expr(ast[2])
+            return self.emit(OP_INDEX, 0, -1)
+        if k == "has":
+            p = self._path(("select", ast[1], ast[2]))
+            if p is not None and p[0] == "col" and len(p[2]) >= 1:
+                return self.emit(OP_HASCOL, pb.column(p[1], p[2]), +1)
+            if p is not None:
+                return self.unsupported("has() on a request field")
+            self._expr(ast[1])
+            return self.emit(OP_HASSEL, pb.sid(ast[2]))
+        if k == "not":
+            self._expr(ast[1])
+            return self.emit(OP_NOT)
+        if k == "neg":
+            self._expr(ast[1])
+            return self.emit(OP_NEG)
+        if k in ("and", "or"):
+            end = self.new_label()
+            self._expr(ast[1])
+            self.emit_ref(OP_JF if k == "and" else OP_JT, end)
+            self._expr(ast[2])
+            self.emit(OP_AND if k == "and" else OP_OR, 0, -1)
+            self.place(end)
+            return
+        if k == "tern":
+            els, end = self.new_label(), self.new_label()
+            self._expr(ast[1])
+            self.emit_ref(OP_JTERN, els, -1)
+            self.word_ref(end)
+            d0 = self.depth
+            self._expr(ast[2])
+            self.emit_ref(OP_JMP, end)
+            self.place(els)
+            self.depth = d0
+            self._expr(ast[3])
+            self.place(end)
+            return
+        if k == "bin":
+            op = ast[1]
+            if op == "in":
+                p = self._path(ast[3]) if ast[3][0] in ("select", "index") else None
+                if p is not None and p[0] == "edr":
+                    if ast[2][0] == "lit" and ast[2][1] == "string" and self.allow_runtime:
+                        pb.uses_runtime = True
+                        return self.emit(OP_EDRHAS, pb.dr_bit(ast[2][2]), +1)
+                    return self.unsupported("runtime.effectiveDerivedRoles membership with a non-constant name")
+            self._expr(ast[2])
+            self._expr(ast[3])
+            return self.emit(_BINOPS[op], 0, -1)
+        if k == "call":
+            return self._call(ast)
+        if k == "comp":
+            return self._comp(ast)
+        return self.unsupported("%s expression" % k)
+
+    def _call(self, ast):
+        _, name, target, args = ast
+        if name == "__unsupported__":
+            return self.unsupported("reference to an undefined variable or constant")
+        if name == "__error__":
+            # evaluates to a CEL error without marking the tuple unsupported
+            self.emit(OP_CONST, self.pb.const(T_NULL, 0), +1)
+            return self.emit(OP_NEG)
+        allargs = ([target] if target is not None else []) + list(args)
+        n = len(allargs)
+
+        def unary(op):
+            self._expr(allargs[0])
+            self.emit(op)
+
+        def binary(op):
+            self._expr(allargs[0])
+            self._expr(allargs[1])
+            self.emit(op, 0, -1)
+
+        ns = target is not None and target[0] == "ident" and target[1] in ("sets", "math", "lists", "base64", "strings", "regex") \
+            and target[1] not in self.locals
+        if not ns:
+            if name == "size" and n == 1:
+                return unary(OP_SIZE)
+            if name in ("startsWith", "endsWith", "contains") and n == 2:
+                return binary({"startsWith": OP_STARTSWITH, "endsWith": OP_ENDSWITH, "contains": OP_CONTAINS}[name])
+            if name == "timestamp" and n == 1 and target is None:
+                return unary(OP_TIMESTAMP)
+            if name == "duration" and n == 1 and target is None:
+                return unary(OP_DURATION)
+            if name == "timeSince" and n == 1:
+                return unary(OP_TIMESINCE)
+            if name == "now" and n == 0:
+                return self.emit(OP_NOW, 0, +1)
+            if name == "int" and n == 1 and target is None:
+                return unary(OP_TOINT)
+            if name == "double" and n == 1 and target is None:
+                return unary(OP_TODOUBLE)
+            if name == "dyn" and n == 1 and target is None:
+                return self._expr(allargs[0])
+            if name == "inIPAddrRange" and n == 2:
+                return binary(OP_INIPRANGE)
+            if name in ("hasIntersection", "has_intersection") and n == 2:
+                return binary(OP_HASINTERSECTION)
+            if name in ("isSubset", "is_subset") and n == 2:
+                return binary(OP_ISSUBSET)
+        elif target[1] == "sets" and n == 3:
+            a, b = args
+            if name == "intersects":
+                self._expr(a); self._expr(b)
+                return self.emit(OP_HASINTERSECTION, 0, -1)
+            if name == "contains":   # sets.contains(a, b): every element of b is in a
+                self._expr(b); self._expr(a)
+                return self.emit(OP_ISSUBSET, 0, -1)
+        return self.unsupported("function %s/%d" % (name, n))
+
+    def _comp(self, ast):
+        _, kind, target, vars_, args = ast
+        kinds = {"all": IT_ALL, "exists": IT_EXISTS, "exists_one": IT_EXISTS_ONE, "existsOne": IT_EXISTS_ONE}
+        if kind not in kinds:
+            return self.unsupported("macro %s" % kind)
+        if self.iter_depth >= MAX_ITERS or len(self.locals) + len(vars_) > MAX_LOCALS:
+            return self.unsupported("comprehension nesting beyond the device limits")
+        slot = self.iter_depth
+        self._expr(target)
+        loop, end = self.new_label(), self.new_label()
+        self.emit(OP_ITER_BEGIN, slot, -1)
+        self.word_ref_packed(end, kinds[kind])
+        saved = dict(self.locals)
+        slots = []
+        for v in vars_:
+            s = len(self.locals)
+            self.locals[v] = s
+            slots.append(s)
+        self.max_locals = max(self.max_locals, len(self.locals))
+        self.iter_depth += 1
+        self.place(loop)
+        self.emit(OP_ITER_NEXT, slot)
+        self.word_ref(end)
+        self.word(slots[0] | ((slots[1] if len(slots) > 1 else 0) << 8) | (len(slots) << 16))
+        d0 = self.depth
+        self._expr(args[0])
+        assert self.depth == d0 + 1
+        self.emit(OP_ITER_ACC, slot, -1)
+        self.word_ref(loop)
+        self.word_ref(end)
+        self.place(end)
+        self.emit(OP_ITER_END, slot, +1)
+        self.iter_depth -= 1
+        self.locals = saved

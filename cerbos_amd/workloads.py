@@ -1,0 +1,207 @@
+"""Synthetic policy sets + request batches for the BASELINE.json configurations.
+
+Seeds and shapes follow BASELINE.md "Synthetic configs" / SURVEY.md §8(d):
+  C1  RBAC-only policy family of internal/engine/testdata/policy_template.yaml.gotmpl
+      (10 rules x 12 literal actions, one role each, no CEL), 10k requests x 2 actions, seed 1
+  C2  one resource policy `doc`, 5 conditional rules (4 ALLOW + 1 DENY), 1M tuples =
+      250k requests x 4 actions, 2 % of requests miss an attribute, seed 2
+  C3  10 kinds x 20 rules, scopes root/acme/acme.hr/acme.hr.uk (30 % REQUIRE_PARENTAL_CONSENT),
+      2 derived-role sets, 1-3 of 12 roles per principal, 4M tuples, seed 3
+All data is synthetic; generators are numpy-vectorised (``numpy.random.default_rng(seed)``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .columnar import Attr, ColumnarRequests, Ragged, Vocab
+
+API = "api.cerbos.dev/v1"
+
+
+def _expr(e):
+    return {"match": {"expr": e}}
+
+
+# ------------------------------------------------------------------------------------- C1
+C1_ACTIONS = ["Create", "View", "Edit", "Delete", "Comment", "Flag", "Approve", "Reject", "Share", "Archive",
+              "Restore", "Export"]
+
+
+def c1_policies(n_sets=1):
+    """policy_template.yaml.gotmpl rendered for N = 0..n_sets-1: resource kind
+    ``resource_<N>``; rule i grants ``<Action><Suffix_i>`` actions to role ``role_<N>_<i>``."""
+    suffixes = ["Reports", "Invoices", "Orders", "Users", "Teams", "Projects", "Tasks", "Files", "Notes", "Alerts"]
+    docs = []
+    for s in range(n_sets):
+        rules = []
+        for i, suf in enumerate(suffixes):
+            rules.append({"actions": [a + suf for a in C1_ACTIONS], "effect": "EFFECT_ALLOW",
+                          "roles": ["role_%d_%d" % (s, i)]})
+        docs.append({"apiVersion": API, "resourcePolicy": {"resource": "resource_%d" % s, "version": "default",
+                                                            "rules": rules}})
+    return docs
+
+
+def c1_requests(n_requests=10_000, seed=1, n_sets=1):
+    rng = np.random.default_rng(seed)
+    roles_v = ["role_%d_%d" % (s, i) for s in range(n_sets) for i in range(10)] + ["unknown_role"]
+    ridx = rng.integers(0, n_sets * 10, n_requests)
+    ridx = np.where(rng.random(n_requests) < 0.10, len(roles_v) - 1, ridx)
+    kinds_v = ["resource_%d" % s for s in range(n_sets)]
+    kidx = rng.integers(0, n_sets, n_requests)
+    acts_v = ["ViewReports", "DeleteReports"]
+    return ColumnarRequests(
+        n_requests,
+        principal_id=Vocab(["user_%d" % i for i in range(1000)], rng.integers(0, 1000, n_requests)),
+        roles=Ragged(roles_v, np.arange(n_requests + 1), ridx),
+        resource_kind=Vocab(kinds_v, kidx),
+        resource_id=Vocab(["res_%d" % i for i in range(n_requests)], np.arange(n_requests)),
+        actions=Ragged(acts_v, np.arange(n_requests + 1) * 2, np.tile([0, 1], n_requests)),
+    )
+
+
+# ------------------------------------------------------------------------------------- C2
+C2_ACTIONS = ["view", "edit", "approve", "delete", "comment"]
+C2_STATUS = ["OPEN", "PENDING", "CLOSED", "ARCHIVED"]
+C2_DEPTS = ["eng", "ops", "sales", "legal", "hr", "finance", "support", "design"]
+
+
+def c2_policies():
+    rp = {
+        "resource": "doc", "version": "default",
+        "rules": [
+            {"name": "public-view", "actions": ["view"], "roles": ["user", "manager"], "effect": "EFFECT_ALLOW",
+             "condition": _expr("R.attr.public == true")},
+            {"name": "owner", "actions": ["view", "edit"], "roles": ["user"], "effect": "EFFECT_ALLOW",
+             "condition": _expr("R.attr.owner == P.id")},
+            {"name": "big-approve", "actions": ["approve"], "roles": ["manager"], "effect": "EFFECT_ALLOW",
+             "condition": _expr("R.attr.amount > 1000")},
+            {"name": "same-dept", "actions": ["view", "comment"], "roles": ["user", "manager"], "effect": "EFFECT_ALLOW",
+             "condition": _expr("P.attr.department == R.attr.department")},
+            {"name": "frozen", "actions": ["edit", "delete"], "roles": ["user", "manager"], "effect": "EFFECT_DENY",
+             "condition": _expr('R.attr.status in ["CLOSED", "ARCHIVED"]')},
+            ],
+    }
+    return [{"apiVersion": API, "resourcePolicy": rp}]
+
+
+def c2_requests(n_requests=250_000, seed=2, actions_per_request=4):
+    rng = np.random.default_rng(seed)
+    n = n_requests
+    n_ids = 1000
+    ids_v = ["u%04d" % i for i in range(n_ids)]
+    pid = rng.integers(0, n_ids, n)
+    owner = np.where(rng.random(n) < 0.10, pid, rng.integers(0, n_ids, n))
+    role_choice = rng.integers(0, 3, n)  # 0 user, 1 manager, 2 both
+    roles_v = ["user", "manager"]
+    cnt = np.where(role_choice == 2, 2, 1)
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    flat = np.zeros(off[-1], dtype=np.int64)
+    flat[off[:-1]] = np.where(role_choice == 1, 1, 0)
+    both = role_choice == 2
+    flat[off[:-1][both] + 1] = 1
+    # 2 % of requests drop one attribute (exercises the CEL error path)
+    drop = rng.random(n) < 0.02
+    which = rng.integers(0, 5, n)
+    pres = [~(drop & (which == k)) for k in range(5)]
+    # every request asks for `actions_per_request` distinct actions
+    perm = np.argsort(rng.random((n, len(C2_ACTIONS))), axis=1)[:, :actions_per_request]
+    return ColumnarRequests(
+        n,
+        principal_id=Vocab(ids_v, pid),
+        roles=Ragged(roles_v, off, flat),
+        resource_kind=Vocab(["doc"], np.zeros(n, dtype=np.int64)),
+        resource_id=Vocab(["d%07d" % i for i in range(n)], np.arange(n)),
+        actions=Ragged(C2_ACTIONS, np.arange(n + 1) * actions_per_request, perm.reshape(-1)),
+        p_attr={"department": Attr("str", rng.integers(0, 8, n), pres[2], C2_DEPTS)},
+        r_attr={
+            "owner": Attr("str", owner, pres[0], ids_v),
+            "amount": Attr("num", rng.random(n) * 2000.0, pres[1]),
+            "department": Attr("str", rng.integers(0, 8, n), None, C2_DEPTS),
+            "public": Attr("bool", rng.random(n) < 0.3, pres[3]),
+            "status": Attr("str", rng.integers(0, 4, n), pres[4], C2_STATUS),
+        },
+    )
+
+
+# ------------------------------------------------------------------------------------- C3
+C3_SCOPES = ["", "acme", "acme.hr", "acme.hr.uk"]
+C3_ROLES = ["role%02d" % i for i in range(12)]
+C3_ACTIONS = ["view", "edit", "delete", "share", "approve", "create", "comment", "export"]
+
+
+def c3_policies(seed=3, n_kinds=10, rules_per_kind=20):
+    """10 kinds x 20 rules spread over the scope chain root..acme.hr.uk (5 rules per scope),
+    30 % of the scoped policies REQUIRE_PARENTAL_CONSENT_FOR_ALLOWS, two derived-role sets."""
+    rng = np.random.default_rng(seed)
+    docs = [
+        {"apiVersion": API, "derivedRoles": {"name": "ownership", "definitions": [
+            {"name": "owner", "parentRoles": C3_ROLES[:6], "condition": _expr("R.attr.owner == P.id")},
+            {"name": "teammate", "parentRoles": ["*"], "condition": _expr("R.attr.team == P.attr.team")}]}},
+        {"apiVersion": API, "derivedRoles": {"name": "org", "definitions": [
+            {"name": "same_department", "parentRoles": C3_ROLES[3:],
+             "condition": _expr("P.attr.department == R.attr.department")},
+            {"name": "senior", "parentRoles": C3_ROLES, "condition": _expr("P.attr.level >= 5")}]}},
+    ]
+    conds = [None, None, "R.attr.public == true", "R.attr.amount > 500", "P.attr.level >= 3",
+             'R.attr.status in ["OPEN", "PENDING"]', "R.attr.owner == P.id"]
+    drs = ["owner", "teammate", "same_department", "senior"]
+    per_scope = rules_per_kind // len(C3_SCOPES)
+    for k in range(n_kinds):
+        for scope in C3_SCOPES:
+            rules = []
+            for i in range(per_scope):
+                rule = {"actions": [str(a) for a in rng.choice(C3_ACTIONS, size=int(rng.integers(1, 4)), replace=False)],
+                        "effect": "EFFECT_DENY" if rng.random() < 0.2 else "EFFECT_ALLOW"}
+                if rng.random() < 0.35:
+                    rule["derivedRoles"] = [str(x) for x in rng.choice(drs, size=int(rng.integers(1, 3)), replace=False)]
+                else:
+                    rule["roles"] = [str(x) for x in rng.choice(C3_ROLES, size=int(rng.integers(1, 4)), replace=False)]
+                c = conds[int(rng.integers(0, len(conds)))]
+                if c:
+                    rule["condition"] = _expr(c)
+                rules.append(rule)
+            rp = {"resource": "kind%02d" % k, "version": "default", "rules": rules,
+                  "importDerivedRoles": ["ownership", "org"]}
+            if scope:
+                rp["scope"] = scope
+                if rng.random() < 0.30:
+                    rp["scopePermissions"] = "SCOPE_PERMISSIONS_REQUIRE_PARENTAL_CONSENT_FOR_ALLOWS"
+            docs.append({"apiVersion": API, "resourcePolicy": rp})
+    return docs
+
+
+def c3_requests(n_requests=1_000_000, seed=3, actions_per_request=4, n_kinds=10):
+    rng = np.random.default_rng(seed + 1000)
+    n = n_requests
+    n_ids = 2000
+    ids_v = ["p%04d" % i for i in range(n_ids)]
+    pid = rng.integers(0, n_ids, n)
+    owner = np.where(rng.random(n) < 0.15, pid, rng.integers(0, n_ids, n))
+    cnt = rng.integers(1, 4, n)
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    # distinct roles per principal: take a random rotation of the role list
+    start = rng.integers(0, len(C3_ROLES), n)
+    flat = (np.repeat(start, cnt) + (np.arange(off[-1]) - np.repeat(off[:-1], cnt)) * 5) % len(C3_ROLES)
+    scopes_v = C3_SCOPES + ["acme.hr.uk.london", "other"]
+    perm = np.argsort(rng.random((n, len(C3_ACTIONS))), axis=1)[:, :actions_per_request]
+    teams = ["t%d" % i for i in range(16)]
+    return ColumnarRequests(
+        n,
+        principal_id=Vocab(ids_v, pid),
+        roles=Ragged(C3_ROLES, off, flat),
+        resource_kind=Vocab(["kind%02d" % k for k in range(n_kinds)] + ["unknown_kind"],
+                            np.where(rng.random(n) < 0.02, n_kinds, rng.integers(0, n_kinds, n))),
+        resource_id=Vocab(["r%07d" % i for i in range(n)], np.arange(n)),
+        actions=Ragged(C3_ACTIONS, np.arange(n + 1) * actions_per_request, perm.reshape(-1)),
+        resource_scope=Vocab(scopes_v, rng.choice(len(scopes_v), n, p=[0.2, 0.2, 0.2, 0.3, 0.05, 0.05])),
+        p_attr={"department": Attr("str", rng.integers(0, 8, n), None, C2_DEPTS),
+                "team": Attr("str", rng.integers(0, 16, n), None, teams),
+                "level": Attr("num", rng.integers(1, 9, n).astype(np.float64), rng.random(n) > 0.01)},
+        r_attr={"owner": Attr("str", owner, None, ids_v),
+                "team": Attr("str", rng.integers(0, 16, n), None, teams),
+                "department": Attr("str", rng.integers(0, 8, n), None, C2_DEPTS),
+                "amount": Attr("num", rng.random(n) * 1000.0, rng.random(n) > 0.01),
+                "public": Attr("bool", rng.random(n) < 0.3),
+                "status": Attr("str", rng.integers(0, 4, n), None, C2_STATUS)},
+    )

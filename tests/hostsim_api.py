@@ -1,0 +1,63 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes driver for tests/hostsim/libcbh_hostsim.so - the device
+source of the decision kernel compiled for the host (see tests/hostsim/hostsim.cpp).
+Lets the CPU tier check lowering + bytecode + kernel logic without a GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from cerbos_amd import capi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "hostsim", "hostsim.cpp")
+LIB = os.path.join(HERE, "hostsim", "libcbh_hostsim.so")
+_DEPS = [SRC] + [os.path.join(ROOT, "cerbos_amd", "csrc", f) for f in
+                 ("cbh_kernels.h", "cbh_vm.h", "cbh_blob.h", "cbh_image.h")] + [os.path.join(ROOT, "include", "cerbos_hip.h")]
+
+_lib = None
+
+
+def build():
+    if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in _DEPS):
+        return
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+                           SRC, "-o", LIB])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB)
+        _lib.hostsim_check.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(capi.CBatch), C.POINTER(capi.CParams),
+                                       C.POINTER(capi.CResult), C.c_void_p]
+        _lib.hostsim_check.restype = C.c_int
+        _lib.hostsim_last_error.restype = C.c_char_p
+    return _lib
+
+
+def batch_gbits(lt, batch):
+    """[3][n_strings] glob bits of batch-local strings via the host simulation of the device NFA."""
+    g = np.zeros((3, max(batch.n_strings, 1)), dtype=np.uint64)
+    off, data, flags = batch.str_off, batch.str_bytes.tobytes(), batch.str_flags
+    for i in range(batch.n_strings):
+        s = data[off[i]:off[i + 1]]
+        for d in range(3):
+            if flags[i] & (1 << d) and lt.nfas[d].patterns:
+                g[d, i] = lt.nfas[d].match_bits(s)
+    return g[:, :batch.n_strings].copy() if batch.n_strings else g
+
+
+def check(lt, batch, now_ns=0, flags=0):
+    res = capi.Result(batch.n_tuples, batch.n_requests, ("policy", "scope", "status", "edr"))
+    cb = capi.make_cbatch(batch, len(lt.columns))
+    p = capi.CParams(now_ns, flags, 0)
+    g = batch_gbits(lt, batch)
+    buf = C.create_string_buffer(lt.blob, len(lt.blob))
+    rc = lib().hostsim_check(C.cast(buf, C.c_void_p), len(lt.blob), C.byref(cb), C.byref(p), C.byref(res.c),
+                             g.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RuntimeError(lib().hostsim_last_error().decode())
+    return res

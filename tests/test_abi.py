@@ -1,0 +1,34 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/cerbos_hip.h declares;
+without a GPU the product path fails loudly instead of falling back."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from cerbos_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "cerbos_hip.h")).read()
+    return sorted(set(re.findall(r"\b(cbh_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build()
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    declared = _declared()
+    assert sorted(capi.EXPORTED_SYMBOLS) == declared
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.HipEngineError):
+        capi.init(0)

@@ -1,0 +1,33 @@
+"""GPU tier: the reference's golden engine cases through the real library on an MI355X
+(lowering -> cbh_table_load -> flatten -> cbh_check_batch -> response assembly)."""
+import pytest
+
+from cerbos_amd.engine import Conf, HipEvaluator
+from helpers import load_json, norm_actions, store_rule_table
+
+pytestmark = pytest.mark.gpu
+
+CASES = load_json("engine_cases.json")
+GLOBALS = {"environment": "test"}
+EXPECT_UNSUPPORTED = {"engine/case_21"}  # see tests/test_hostsim_golden.py
+
+
+@pytest.fixture(scope="module")
+def evaluator():
+    ev = HipEvaluator.from_rule_table(store_rule_table(), Conf(globals_=GLOBALS))
+    yield ev
+    ev.close()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_engine_case(evaluator, case):
+    modes = [False, True] if case["lenient"] is None else [case["lenient"]]
+    for lenient in modes:
+        outs, bad = evaluator.check(case["inputs"], now_ns=1_700_000_000_000_000_000,
+                                    lenient_scope_search=lenient, allow_unsupported=True)
+        for i, (have, want) in enumerate(zip(outs, case["wantOutputs"])):
+            if i in bad:
+                assert case["name"] in EXPECT_UNSUPPORTED
+                continue
+            assert norm_actions(have) == norm_actions(want), (case["name"], lenient)
+            assert sorted(have["effectiveDerivedRoles"]) == sorted(want.get("effectiveDerivedRoles") or [])

@@ -1,0 +1,106 @@
+"""GPU tier: HIP path vs oracle on the synthetic BASELINE configs (sizes the oracle finishes in
+seconds) and, at BASELINE.json's full batch size, through size-independent properties."""
+import numpy as np
+import pytest
+
+from cerbos_amd import capi, workloads
+from cerbos_amd.flatten import Flattener
+from cerbos_amd.lower.blob import lower_rule_table
+from cerbos_amd.policy.loader import policies_from_docs
+from cerbos_amd.ruletable.build import rule_table_from_policies
+from test_hostsim_synthetic import CONFIGS, NOW, oracle_effects
+
+pytestmark = pytest.mark.gpu
+
+
+def _table(pol_fn):
+    rt = rule_table_from_policies(policies_from_docs(pol_fn()))
+    lt = lower_rule_table(rt)
+    return rt, lt, capi.Table(lt.blob)
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+@pytest.mark.parametrize("mode", ["default", "lenient", "strict"])
+def test_config_matches_oracle(name, mode):
+    pol_fn, req_fn = CONFIGS[name]
+    rt, lt, table = _table(pol_fn)
+    cr = req_fn(1500)
+    inputs = cr.to_inputs()
+    want = oracle_effects(rt, inputs, lenient_scope_search=mode == "lenient", strict_evaluation=mode == "strict")
+    flags = (capi.F_LENIENT_SCOPE_SEARCH if mode == "lenient" else 0) | (capi.F_STRICT_EVALUATION if mode == "strict" else 0)
+    fl = Flattener(lt)
+    for batch in (fl.flatten(inputs), cr.to_batch(fl)):
+        res = table.check(batch, now_ns=NOW, flags=flags)
+        assert (res.status != capi.ST_UNSUPPORTED).all()
+        assert np.array_equal(res.effect, want)
+    table.close()
+
+
+def test_c2_full_batch_properties():
+    """1M tuples (BASELINE configs[1]): oracle parity on a sample + permutation / split invariance."""
+    rt, lt, table = _table(workloads.c2_policies)
+    fl = Flattener(lt)
+    cr = workloads.c2_requests(250_000)
+    batch = cr.to_batch(fl)
+    assert batch.n_tuples == 1_000_000
+    res = table.check(batch, now_ns=NOW)
+    assert (res.status != capi.ST_UNSUPPORTED).all()
+    eff = res.effect.copy()
+    assert set(np.unique(eff)) == {capi.EFFECT_ALLOW, capi.EFFECT_DENY}
+    # (a) the first 3000 requests against the oracle
+    sample = cr.to_inputs(0, 3000)
+    want = oracle_effects(rt, sample)
+    assert np.array_equal(eff[:want.size], want)
+    # (b) determinism
+    assert np.array_equal(table.check(batch, now_ns=NOW).effect, eff)
+    # (c) request order does not matter: evaluate a permuted tuple list, un-permute
+    perm = np.random.default_rng(0).permutation(batch.n_tuples)
+    import copy
+    b2 = copy.copy(batch)
+    b2.tuple_req = np.ascontiguousarray(batch.tuple_req[perm])
+    b2.tuple_action = np.ascontiguousarray(batch.tuple_action[perm])
+    e2 = table.check(b2, now_ns=NOW).effect
+    back = np.empty_like(e2)
+    back[perm] = e2
+    assert np.array_equal(back, eff)
+    # (d) a sub-batch gives the same answers as the same tuples inside the big batch
+    b3 = copy.copy(batch)
+    b3.n_tuples = 400_000
+    b3.tuple_req = np.ascontiguousarray(batch.tuple_req[:400_000])
+    b3.tuple_action = np.ascontiguousarray(batch.tuple_action[:400_000])
+    assert np.array_equal(table.check(b3, now_ns=NOW).effect, eff[:400_000])
+    table.close()
+
+
+def test_empty_and_ragged_batches():
+    rt, lt, table = _table(workloads.c2_policies)
+    fl = Flattener(lt)
+    # empty batch
+    res = table.check(fl.flatten([]), now_ns=NOW)
+    assert res.effect.size == 0
+    # a request without actions, one without roles, one with an unknown kind
+    inputs = [
+        {"principal": {"id": "a", "roles": ["user"]}, "resource": {"kind": "doc", "id": "1"}, "actions": []},
+        {"principal": {"id": "a", "roles": []}, "resource": {"kind": "doc", "id": "1"}, "actions": ["view"]},
+        {"principal": {"id": "a", "roles": ["user"]}, "resource": {"kind": "nope", "id": "1"}, "actions": ["view", "edit"]},
+    ]
+    res = table.check(fl.flatten(inputs), now_ns=NOW)
+    want = oracle_effects(rt, inputs)
+    assert np.array_equal(res.effect, want)
+    table.close()
+
+
+def test_resident_path_and_kernel_timer():
+    rt, lt, table = _table(workloads.c2_policies)
+    cr = workloads.c2_requests(5000)
+    batch = cr.to_batch(Flattener(lt))
+    db = table.upload(batch)
+    for _ in range(3):
+        table.launch(db, now_ns=NOW)
+    table.synchronize()
+    check_ms, resolve_ms = table.kernel_time_ms()
+    assert check_ms > 0
+    res = table.download(db)
+    assert np.array_equal(res.effect, table.check(batch, now_ns=NOW).effect)
+    db.close()
+    table.close()

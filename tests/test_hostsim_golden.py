@@ -1,0 +1,57 @@
+"""CPU tier: the decision kernel's device source, compiled for the host (tests/hostsim), must
+reproduce the reference's golden engine cases through the real lowering + flattening +
+response assembly.  The GPU tier (test_gpu_golden.py) re-runs them on the MI355X."""
+import pytest
+
+import hostsim_api
+from cerbos_amd import capi
+from cerbos_amd.engine import Conf, HipEvaluator
+from cerbos_amd.flatten import Flattener
+from cerbos_amd.lower.blob import lower_rule_table
+from helpers import load_json, norm_actions, store_rule_table
+
+CASES = load_json("engine_cases.json")
+GLOBALS = {"environment": "test"}
+
+# Golden cases whose decision path needs CEL outside the device subset: the kernel must
+# flag them (status UNSUPPORTED), never return a wrong effect silently.
+EXPECT_UNSUPPORTED = {
+    "engine/case_21",  # derived-role definitions compare runtime.effectiveDerivedRoles == [] (list value)
+}
+
+
+class HostSimEvaluator(HipEvaluator):
+    """HipEvaluator with the table.check call routed to the host simulation."""
+
+    def __init__(self, lt, conf):
+        self.conf = conf
+        self.lt = lt
+        self.flattener = Flattener(lt)
+
+        class _T:
+            def check(_self, batch, now_ns=0, flags=0, want=()):
+                return hostsim_api.check(lt, batch, now_ns, flags)
+        self.table = _T()
+
+
+@pytest.fixture(scope="module")
+def evaluator():
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    return HostSimEvaluator(lt, Conf(globals_=GLOBALS))
+
+
+def _modes(case):
+    return [False, True] if case["lenient"] is None else [case["lenient"]]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_engine_case(evaluator, case):
+    for lenient in _modes(case):
+        outs, bad = evaluator.check(case["inputs"], now_ns=1_700_000_000_000_000_000,
+                                    lenient_scope_search=lenient, allow_unsupported=True)
+        for i, (have, want) in enumerate(zip(outs, case["wantOutputs"])):
+            if i in bad:
+                assert case["name"] in EXPECT_UNSUPPORTED, "unexpected UNSUPPORTED in %s" % case["name"]
+                continue
+            assert norm_actions(have) == norm_actions(want), (case["name"], lenient)
+            assert sorted(have["effectiveDerivedRoles"]) == sorted(want.get("effectiveDerivedRoles") or [])
