@@ -248,16 +248,17 @@ extern "C" int cbh_kernel_time_ms(cbh_table* t, float* check_ms, float* resolve_
 }
 
 extern "C" int cbh_result_download(cbh_table* t, cbh_device_batch* b, cbh_result* out) {
-  if (!t || !b || !out || !out->effect) return fail("null argument");
+  if (!t || !b || !out) return fail("null argument");
+  if (b->dev.n_tuples && !out->effect) return fail("cbh_result.effect is required");
   std::lock_guard<std::mutex> lk(t->mu);
   HIPCHK(hipSetDevice(t->device));
   hipStream_t s = t->stream;
   const BatchDev& d = b->dev;
-  HIPCHK(hipMemcpyAsync(out->effect, b->out.effect, d.n_tuples, hipMemcpyDeviceToHost, s));
-  if (out->policy) HIPCHK(hipMemcpyAsync(out->policy, b->out.policy, (size_t)d.n_tuples * 4, hipMemcpyDeviceToHost, s));
-  if (out->scope) HIPCHK(hipMemcpyAsync(out->scope, b->out.scope, (size_t)d.n_tuples * 4, hipMemcpyDeviceToHost, s));
-  if (out->status) HIPCHK(hipMemcpyAsync(out->status, b->out.status, d.n_tuples, hipMemcpyDeviceToHost, s));
-  if (out->edr_mask) HIPCHK(hipMemcpyAsync(out->edr_mask, b->out.edr, (size_t)d.n_requests * 8, hipMemcpyDeviceToHost, s));
+  if (d.n_tuples) HIPCHK(hipMemcpyAsync(out->effect, b->out.effect, d.n_tuples, hipMemcpyDeviceToHost, s));
+  if (out->policy && d.n_tuples) HIPCHK(hipMemcpyAsync(out->policy, b->out.policy, (size_t)d.n_tuples * 4, hipMemcpyDeviceToHost, s));
+  if (out->scope && d.n_tuples) HIPCHK(hipMemcpyAsync(out->scope, b->out.scope, (size_t)d.n_tuples * 4, hipMemcpyDeviceToHost, s));
+  if (out->status && d.n_tuples) HIPCHK(hipMemcpyAsync(out->status, b->out.status, d.n_tuples, hipMemcpyDeviceToHost, s));
+  if (out->edr_mask && d.n_requests) HIPCHK(hipMemcpyAsync(out->edr_mask, b->out.edr, (size_t)d.n_requests * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   collect_times(t);
   return 0;
