@@ -72,16 +72,13 @@ def main():
     # ---- policy image: lowered once, broadcast GPU->GPU over RCCL/xGMI
     bcast_ms = None
     if world > 1:
-        n = len(lt.blob)
-        img = torch.empty(n, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            img.copy_(torch.frombuffer(bytearray(lt.blob), dtype=torch.uint8))
+        from cerbos_amd import dist as cdist
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        dist.broadcast(img, src=0)
+        img = cdist.broadcast_image(lt.blob if rank == 0 else None, src=0, device="cuda")
         torch.cuda.synchronize()
         bcast_ms = (time.perf_counter() - t0) * 1e3
-        table = capi.Table.adopt(img.data_ptr(), n)   # `img` stays alive until exit
+        table = capi.Table.adopt(img.data_ptr(), img.numel())   # `img` stays alive until exit
     else:
         table = capi.Table(lt.blob)
 
