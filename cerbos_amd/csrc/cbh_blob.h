@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define CBH_BLOB_MAGIC 0x31484243u /* "CBH1" */
-#define CBH_BLOB_VERSION 3u
+#define CBH_BLOB_VERSION 4u
 
 struct CbhBlobHeader {  // 32 bytes
   uint32_t magic;
@@ -72,6 +72,8 @@ enum CbhMeta {
   CBH_META_N = 24
 };
 #define CBH_MF_USES_RUNTIME_EDR 1u
+#define CBH_MF_HAS_PARENT_ROLES 2u
+#define CBH_MF_HAS_ROLE_POLICIES 4u
 
 // Directory: open addressing, linear probing, key.x == CBH_NONE marks an empty slot.
 struct CbhHashSlot { // 32 bytes
@@ -87,6 +89,10 @@ enum CbhBucketType {
   CBH_B_PARENTS = 6,   // (scope idx, role sid, 0) -> v0 off, v1 cnt into U32POOL of ancestor role sids
   CBH_B_RESEXISTS = 7, // (ver sid, kind sid, scope idx): same key as RESOURCE, present for every resource policy
 };
+
+// Condition reference (row / derived-role cond fields): bit31 set -> the program at (ref & ~bit31)
+// is a single OP_LEAF_BIN + OP_RET and may be evaluated inline.
+#define CBH_COND_LEAF 0x80000000u
 
 // Pattern reference: bit31 set -> glob index within the dimension, else literal string id.
 #define CBH_PAT_GLOB 0x80000000u
@@ -156,6 +162,11 @@ enum CbhOp {
   OP_UNSUPPORTED = 49, // marks the tuple CBH_ST_UNSUPPORTED and yields an error
   OP_TS_GETTER = 50,  // arg = getter kind; pops tz string if arg bit 7 set
   OP_HASINTERSECTION = 51, OP_ISSUBSET = 52,
+  OP_LEAF_BIN = 53,   // arg = binop | kindA << 8 | kindB << 12; next two words = operand args; pushes a plain bool
+  OP_TERN = 54,       // pop else, then, guard -> guard ? then : else (error if the guard is not a bool)
+  OP_TREE_BEGIN = 55, // arg = kind (0 all, 1 any, 2 none): open a condition tree level
+  OP_TREE_ACC = 56,   // arg = kind: pop a child's plain-bool result into the level's accumulator
+  OP_TREE_END = 57,   // arg = kind: close the level, push its result
   OP_NOPS
 };
 enum CbhIterKind { IT_ALL = 0, IT_EXISTS = 1, IT_EXISTS_ONE = 2 };

@@ -1,0 +1,331 @@
+// cbh_check_kernel - the decision kernel, wave-cooperative formulation.
+//
+// One lane per (principal, resource, action) tuple, restating ruletable.(*RuleTable).check
+// (internal/ruletable/check.go:97-460).  The TABLE WALK is wave-uniform: lanes are grouped
+// (waterfall over ballot/readlane) by the key that selects their policy buckets - (scope chain
+// start, policy version, resource kind | principal id) - and each group walks its scope chain,
+// directory buckets, rule rows and CEL programs ONCE on uniform (scalar) values, while per-lane
+// predicates carry the data-dependent part (action / role match, condition results, the
+// ALLOW/DENY fold).  Rows of one bucket are visited in binding order exactly like
+// Index.Query's result (index/index.go:214-336); role-policy synthetic DENYs first
+// (index.go:318-322, 352-530).
+//
+// Discipline (also what tests/hostsim emulates): no lane returns early; every cross-lane call
+// (wave_ballot / wave_readlane / run_uniform) is reached by all 64 lanes under uniform control
+// flow.  Divergent branches contain only per-lane code.
+#pragma once
+#include "cbh_interp.h"
+
+struct RoleSet {   // [role] ++ ancestors(role) for the request's resource scope (index.go:716-742)
+  u32 role; u32 par_off; u32 par_cnt; u64 gbits;   // gbits: OR of role-dimension glob bits over the set
+};
+
+__device__ __forceinline__ bool roleset_has(const TableDev& t, const RoleSet& rs, u32 pref) {
+  if (pref & CBH_PAT_GLOB) return ((rs.gbits >> (pref & 63u)) & 1ull) != 0;
+  if (pref == rs.role) return true;
+  for (u32 k = 0; k < rs.par_cnt; ++k) if (t.pool[rs.par_off + k] == pref) return true;
+  return false;
+}
+
+// directory probe with wave-uniform key -> wave-uniform result
+__device__ inline bool udir_find(const TableDev& t, u32 k0, u32 k1, u32 k2, u32 k3, uint4& v) {
+  u32 i = hash4(k0, k1, k2, k3) & t.hash_mask;
+  for (u32 probe = 0; probe <= t.hash_mask; ++probe) {
+    const u32* s = reinterpret_cast<const u32*>(&t.hash[i]);
+    const u32 kx = uload(s);
+    if (kx == CBH_NONE) return false;
+    if (kx == k0 && uload(s + 1) == k1 && uload(s + 2) == k2 && uload(s + 3) == k3) {
+      v.x = uload(s + 4); v.y = uload(s + 5); v.z = uload(s + 6); v.w = uload(s + 7);
+      return true;
+    }
+    i = (i + 1) & t.hash_mask;
+  }
+  return false;
+}
+
+__device__ __forceinline__ u32 uchain_next(const TableDev& t, u32 si, u32 flagbit) {   // uniform si
+  while (si != CBH_NONE && !(uload(&t.scope_flags[si]) & flagbit)) si = uload(&t.scope_parent[si]);
+  return si;
+}
+
+// does one of the request's roles (or an ancestor of one) appear in the derived role's parent list?
+// (internal.SetIntersects(dr.ParentRoles, includingParentRoles), check.go:244)
+__device__ inline bool lane_has_parent_role(const TableDev& t, const BatchDev& b, u32 poff, u32 pcnt, u32 role_off,
+                                            u32 role_cnt, u32 scope_key, bool has_parents) {
+  for (u32 r = 0; r < role_cnt; ++r) {
+    const u32 role = b.roles[role_off + r];
+    uint4 pv; u32 aoff = 0, acnt = 0;
+    if (has_parents && scope_key != CBH_NONE && dir_find(t, CBH_B_PARENTS, scope_key, role, 0, pv)) { aoff = pv.x; acnt = pv.y; }
+    for (u32 k = 0; k < pcnt; ++k) {
+      const u32 want = t.pool[poff + k];
+      if (want == role) return true;
+      for (u32 a = 0; a < acnt; ++a) if (t.pool[aoff + a] == want) return true;
+    }
+  }
+  return false;
+}
+
+// Evaluate a condition reference for the lanes with active=true (all lanes call together).
+// Bit 31 of the reference marks a program that is one fused leaf: it is evaluated inline -
+// no call, no operand stack - which is the shape of almost every real-world condition.
+__device__ __forceinline__ int eval_cond(const Ctx& c, Lane& L, u32 ref, bool active) {
+  if (ref & CBH_COND_LEAF) {
+    const u32 pc = ref & ~CBH_COND_LEAF;
+    const u32 w = uload(&c.t.code[pc]), a0 = uload(&c.t.code[pc + 1]), a1 = uload(&c.t.code[pc + 2]);
+    const u32 a = w >> 8;
+    int r = 0;
+    if (active) {
+      const Val x = load_operand(c, L, (a >> 8) & 0xF, a0);
+      const Val y = load_operand(c, L, (a >> 12) & 0xF, a1);
+      const int f = fast_compare(c, a & 0xFF, x, y);
+      Val v = f >= 0 ? mk_bool(f != 0) : (f == -1 ? mk_err() : compare_op_slow(c, L, a & 0xFF, x, y));
+      if (v.t == CBH_T_ERR) {
+        L.status |= CBH_ST_CEL_ERROR;
+        r = (c.flags & CBH_F_STRICT_EVALUATION) ? 2 : 0;
+      } else r = (v.t == CBH_T_BOOL && v.v) ? 1 : 0;
+    }
+    return r;
+  }
+  return run_uniform(c, L, ref, active);
+}
+
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs* __restrict__ ka) {
+  const TableDev& t = ka->t;
+  const BatchDev& b = ka->b;
+  const OutDev& o = ka->o;
+  const i64 now_ns = ka->now_ns;
+  const u32 flags = ka->flags;
+  __shared__ u64 s_val[CBH_STACK_DEPTH * CBH_BLOCK];
+  __shared__ u64 l_val[CBH_MAX_LOCALS * CBH_BLOCK];
+  __shared__ u64 it_cont[CBH_MAX_ITERS * CBH_BLOCK];
+  __shared__ u32 it_idx[CBH_MAX_ITERS * CBH_BLOCK];
+  __shared__ u32 it_state[CBH_MAX_ITERS * CBH_BLOCK];
+  __shared__ u8 s_tag[CBH_STACK_DEPTH * CBH_BLOCK];
+  __shared__ u8 l_tag[CBH_MAX_LOCALS * CBH_BLOCK];
+
+  const u32 tup = blockIdx.x * CBH_BLOCK + threadIdx.x;
+  const bool valid = tup < b.n_tuples;
+  const u32 tix = valid ? tup : 0;   // tail lanes shadow tuple 0 and never store
+  Ctx c{t, b, now_ns, flags, threadIdx.x, s_val, s_tag, l_val, l_tag, it_cont, it_idx, it_state};
+
+  const u32 req = b.tuple_req[tix];
+  const u32 act = b.tuple_action[tix];
+  const u32 NR = b.n_requests;
+#define RQ(f) b.req_u32[(size_t)(f) * NR + req]
+  const u32 pid = RQ(CBH_RQ_PRINCIPAL_ID);
+  const u32 p_scope = RQ(CBH_RQ_P_SCOPE), p_ver = RQ(CBH_RQ_P_VERSION);
+  const u32 kind = RQ(CBH_RQ_KIND);
+  const u32 r_scope = RQ(CBH_RQ_R_SCOPE), r_ver = RQ(CBH_RQ_R_VERSION);
+  const u32 role_off = RQ(CBH_RQ_ROLE_OFF), role_cnt = RQ(CBH_RQ_ROLE_CNT);
+#undef RQ
+  const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
+  const bool strict = (flags & CBH_F_STRICT_EVALUATION) != 0;
+  const bool want_edr = (flags & CBH_F_WANT_DERIVED_ROLES) != 0 || (t.flags & CBH_MF_USES_RUNTIME_EDR) != 0;
+  const bool has_parents = (t.flags & CBH_MF_HAS_PARENT_ROLES) != 0;
+  const bool has_rolepol = (t.flags & CBH_MF_HAS_ROLE_POLICIES) != 0;
+
+  Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false;
+  u64 edr_acc = 0;   // derived roles activated for this tuple's request; published once at the end
+
+  u32 eff = EFF_NO_MATCH, pol = ((u32)CBH_P_NO_MATCH << 28), scp = CBH_NONE;
+  const u64 act_bits = gbits_of(t, b, DIM_ACTION, act);
+  const u64 kind_bits = gbits_of(t, b, DIM_KIND, kind);
+  // parent roles are looked up with the request's own resource scope only (check.go:172,227)
+  const u32 pr_scope_key = (r_scope & CBH_SCOPE_EXACT) ? (r_scope & ~CBH_SCOPE_EXACT) : CBH_NONE;
+
+  // ---- per-lane preamble: scope chains and existence (check.go:116-121, 165-170)
+  const u32 p_first = chain_first(t, p_scope, FLAG_PRIN, lenient);
+  const u32 r_first = chain_first(t, r_scope, FLAG_RES, lenient);
+  bool decided = (p_first == CBH_NONE && r_first == CBH_NONE);
+  bool p_exists = false, r_exists = false;
+  if (!decided) {
+    uint4 v;
+    for (u32 si = p_first; si != CBH_NONE && !p_exists; si = chain_next(t, t.scope_parent[si], FLAG_PRIN))
+      p_exists = dir_find(t, CBH_B_PPEXISTS, p_ver, si, 0, v);                      // index.go:999-1021
+    for (u32 si = r_first; si != CBH_NONE && !r_exists; si = chain_next(t, t.scope_parent[si], FLAG_RES)) {
+      if (dir_find(t, CBH_B_RESEXISTS, r_ver, kind, si, v)) { r_exists = true; break; }   // index.go:966-997
+      if (has_rolepol && dir_find(t, CBH_B_RPRES, r_ver, si, 0, v))
+        for (u32 k = 0; k < v.y && !r_exists; ++k) r_exists = pat_match(t.pool[v.x + k], kind, kind_bits);
+    }
+    if (!p_exists && !r_exists) decided = true;
+  }
+  if (!decided) pol = ((u32)CBH_P_EMPTY << 28);   // zero EffectInfo (check.go:191)
+  bool action_done = decided || !valid;           // nothing (more) to do: the lane rides along
+
+  for (u32 pt = 0; pt < 2; ++pt) {                // 0 = principal policies, 1 = resource policies (check.go:195)
+    const bool is_res = pt == 1;
+    const u32 first = is_res ? r_first : p_first;
+    const u32 flagbit = is_res ? FLAG_RES : FLAG_PRIN;
+    const bool exists = is_res ? r_exists : p_exists;
+    const u32 gx = is_res ? kind : pid;
+    // a definitive principal-policy result ends the action (check.go:445-448); an empty principal
+    // chain leaves nothing behind that the resource pass does not overwrite
+    const bool in_pass = !action_done && !(eff == CBH_EFFECT_ALLOW || eff == CBH_EFFECT_DENY) &&
+                         (is_res || first != CBH_NONE);
+    if (in_pass) eff = EFF_NO_MATCH;                                    // check.go:206
+    const u32 n_iter = is_res ? role_cnt : (role_cnt ? 1u : 0u);      // check.go:208-213
+    bool pend = in_pass && n_iter > 0;
+    bool roles_done = false;                                           // ALLOW found: leave the role loop
+
+    for (;;) {   // ---- waterfall over groups that share (chain start, version, kind | principal)
+      const u64 rem = wave_ballot(pend);
+      if (rem == 0) break;
+      const u32 lead = first_lane(rem);
+      const u32 g_first = wave_readlane(first, lead), g_ver = wave_readlane(r_ver, lead), g_x = wave_readlane(gx, lead);
+      const bool ing = pend && first == g_first && r_ver == g_ver && gx == g_x;
+      pend = pend && !ing;
+
+      for (u32 ri = 0;; ++ri) {   // ---- roles (check.go:208)
+        const bool A = ing && !action_done && !roles_done && ri < n_iter;
+        if (wave_ballot(A) == 0) break;
+        RoleSet rs; rs.role = 0; rs.par_off = 0; rs.par_cnt = 0; rs.gbits = 0;
+        if (A) {
+          rs.role = b.roles[role_off + ri];
+          rs.gbits = gbits_of(t, b, DIM_ROLE, rs.role);
+          uint4 pv;
+          if (has_parents && pr_scope_key != CBH_NONE && dir_find(t, CBH_B_PARENTS, pr_scope_key, rs.role, 0, pv)) {
+            rs.par_off = pv.x; rs.par_cnt = pv.y;
+            for (u32 k = 0; k < rs.par_cnt; ++k) rs.gbits |= t.gbits[(size_t)DIM_ROLE * t.K + t.pool[rs.par_off + k]];
+          }
+        }
+        bool has_allow = false;
+        u32 r_eff = EFF_NO_MATCH, r_scp = CBH_NONE;
+        u32 r_pol = exists ? (((u32)(is_res ? CBH_P_RESOURCE : CBH_P_PRINCIPAL) << 28) | g_first)
+                           : ((u32)CBH_P_NO_MATCH << 28);
+        bool S = A;   // lane is still walking the scope chain
+
+        for (u32 si = g_first; si != CBH_NONE; si = uchain_next(t, uload(&t.scope_parent[si]), flagbit)) {   // check.go:231
+          if (wave_ballot(S) == 0) break;
+          uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
+          const bool have_bucket = is_res ? udir_find(t, CBH_B_RESOURCE, g_ver, g_x, si, bucket)
+                                          : udir_find(t, CBH_B_PRINCIPAL, g_ver, si, g_x, bucket);   // resource version: check.go:294
+
+          if (is_res && want_edr) {   // derived roles of this scope's resource policy (check.go:237-282)
+            u64 m = 0; bool derr = false;
+            if (have_bucket) {
+              for (u32 d = bucket.z; d < bucket.z + bucket.w; ++d) {
+                const u32 pcnt = uload(&t.dr[CBH_DR_PARENTS_CNT * t.n_dr + d]);
+                const u32 poff = uload(&t.dr[CBH_DR_PARENTS_OFF * t.n_dr + d]);
+                const u32 cond = uload(&t.dr[CBH_DR_COND * t.n_dr + d]);
+                const u32 bit = uload(&t.dr[CBH_DR_NAME * t.n_dr + d]);
+                const bool applies = S && (pcnt == CBH_NONE ||
+                                           lane_has_parent_role(t, b, poff, pcnt, role_off, role_cnt, pr_scope_key, has_parents));
+                if (wave_ballot(applies) == 0) continue;
+                int r = 1;
+                if (cond != CBH_NONE) r = eval_cond(c, L, cond, applies);
+                if (applies) { if (r == 2) derr = true; else if (r == 1) m |= 1ull << bit; }
+              }
+            }
+            if (S) {
+              L.edr = m; L.edr_err = derr;
+              edr_acc |= m;
+            }
+          }
+
+          if (is_res && has_rolepol) {
+            // synthetic DENYs from the role policies of [role] ++ ancestors (index.go:352-530)
+            for (u32 k = 0;; ++k) {
+              const bool P = S && k <= rs.par_cnt;
+              if (wave_ballot(P) == 0) break;
+              const u32 srole = P ? (k == 0 ? rs.role : t.pool[rs.par_off + k - 1]) : 0;
+              bool pend2 = P;
+              for (;;) {   // waterfall over the distinct roles in flight
+                const u64 rem2 = wave_ballot(pend2);
+                if (rem2 == 0) break;
+                const u32 g_sr = wave_readlane(srole, first_lane(rem2));
+                bool in2 = pend2 && srole == g_sr;
+                pend2 = pend2 && !in2;
+                uint4 rp;
+                if (!udir_find(t, CBH_B_ROLEPOL, g_ver, si, g_sr, rp)) continue;
+                bool any_action = false;
+                for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
+                  const u32 rres = uload(&t.rprows[CBH_RP_RESOURCE * t.n_rprows + row]);
+                  const u32 ao = uload(&t.rprows[CBH_RP_ALLOW_OFF * t.n_rprows + row]);
+                  const u32 ac = uload(&t.rprows[CBH_RP_ALLOW_CNT * t.n_rprows + row]);
+                  if (!pat_match(rres, kind, kind_bits)) continue;   // kind is uniform within a resource group
+                  for (u32 a = 0; a < ac; ++a) any_action |= pat_match(uload(&t.pool[ao + a]), act, act_bits);
+                }
+                bool deny = in2 && !any_action;   // no binding for the resource, or no allow-action matched (index.go:436-461)
+                for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
+                  const u32 cond = uload(&t.rprows[CBH_RP_COND * t.n_rprows + row]);
+                  if (cond == CBH_NONE) continue;
+                  const u32 rres = uload(&t.rprows[CBH_RP_RESOURCE * t.n_rprows + row]);
+                  const u32 ao = uload(&t.rprows[CBH_RP_ALLOW_OFF * t.n_rprows + row]);
+                  const u32 ac = uload(&t.rprows[CBH_RP_ALLOW_CNT * t.n_rprows + row]);
+                  bool mm = in2 && !deny && pat_match(rres, kind, kind_bits);
+                  bool am = false;
+                  for (u32 a = 0; a < ac; ++a) am |= pat_match(uload(&t.pool[ao + a]), act, act_bits);
+                  mm = mm && am;
+                  if (wave_ballot(mm) == 0) continue;
+                  const int r = eval_cond(c, L, cond, mm);   // synthetic row = DENY if none(cond)
+                  if (mm && r == 2) {
+                    eff = CBH_EFFECT_DENY; pol = ((u32)CBH_P_TABLE << 28) | rp.z; scp = si;
+                    action_done = true; S = false; in2 = false;
+                  } else if (mm && r == 0) deny = true;
+                }
+                if (in2 && deny) {   // check.go:395-403
+                  r_eff = CBH_EFFECT_DENY; r_scp = si; r_pol = ((u32)CBH_P_TABLE << 28) | rp.z;
+                  S = false;
+                }
+              }
+            }
+          }
+
+          if (have_bucket) {   // ---- regular rows of the bucket, in binding order (check.go:295-414)
+            for (u32 row = bucket.x; row < bucket.x + bucket.y; ++row) {
+              const u32 ra = uload(&t.rows[CBH_ROW_ACTION * t.n_rows + row]);
+              const u32 e = uload(&t.rows[CBH_ROW_FLAGS * t.n_rows + row]) & 3u;
+              bool m = S && pat_match(ra, act, act_bits);
+              if (is_res) m = m && roleset_has(t, rs, uload(&t.rows[CBH_ROW_ROLE * t.n_rows + row]));
+              else m = m && pat_match(uload(&t.rows[CBH_ROW_RESOURCE * t.n_rows + row]), kind, kind_bits);
+              // once an ALLOW fired only a DENY can change the outcome of this scope (check.go:392-403);
+              // strict mode still evaluates everything because an error there is itself a DENY
+              if (has_allow && e == CBH_EFFECT_ALLOW && !strict) m = false;
+              if (wave_ballot(m) == 0) continue;
+              const u32 drc = uload(&t.rows[CBH_ROW_DRCOND * t.n_rows + row]);
+              const u32 cnd = uload(&t.rows[CBH_ROW_COND * t.n_rows + row]);
+              int r = 1;
+              if (drc != CBH_NONE) r = eval_cond(c, L, drc, m);                    // check.go:328-366
+              const bool m2 = m && r == 1;
+              if (cnd != CBH_NONE && wave_ballot(m2) != 0) {                        // check.go:368-380
+                const int r2 = eval_cond(c, L, cnd, m2);
+                if (m2) r = r2;
+              }
+              if (m && r == 2) {   // strict evaluation error: DENY attributed to the row's policy
+                eff = CBH_EFFECT_DENY; pol = ((u32)CBH_P_TABLE << 28) | uload(&t.rows[CBH_ROW_POLICY * t.n_rows + row]); scp = si;
+                action_done = true; S = false;
+              } else if (m && r == 1) {
+                if (e == CBH_EFFECT_ALLOW) has_allow = true;
+                else if (e == CBH_EFFECT_DENY) { r_eff = CBH_EFFECT_DENY; r_scp = si; S = false; }
+              }
+            }
+          }
+
+          if (S && has_allow) {   // check.go:416-425
+            const u32 sp = (uload(&t.scope_flags[si]) >> 2) & 3u;
+            if (sp == SP_REQUIRE_CONSENT) has_allow = false;
+            else if (sp == SP_OVERRIDE_PARENT) { r_eff = CBH_EFFECT_ALLOW; r_scp = si; S = false; }
+          }
+        }
+
+        if (A && !action_done) {   // fold this role's result (check.go:428-442)
+          if (eff == EFF_NO_MATCH) { eff = r_eff; pol = r_pol; scp = r_scp; }
+          if (r_eff == CBH_EFFECT_ALLOW) { eff = r_eff; pol = r_pol; scp = r_scp; roles_done = true; }
+          else if (r_eff == CBH_EFFECT_DENY && (pol >> 28) == CBH_P_NO_MATCH_SCOPE_PERMISSIONS &&
+                   (r_pol >> 28) != CBH_P_NO_MATCH_SCOPE_PERMISSIONS) { eff = r_eff; pol = r_pol; scp = r_scp; }
+        }
+      }
+    }
+  }
+  if (eff == EFF_NO_MATCH) eff = CBH_EFFECT_DENY;                     // check.go:451-453
+
+  if (valid) {
+    // the only global writes of the kernel come last, so every table read above is a read of
+    // never-clobbered memory (lets the compiler keep uniform reads on the scalar unit)
+    if (o.edr && edr_acc) atomicOr(reinterpret_cast<unsigned long long*>(&o.edr[req]), (unsigned long long)edr_acc);
+    o.effect[tup] = (u8)eff;
+    if (o.policy) o.policy[tup] = pol;
+    if (o.scope) o.scope[tup] = scp;
+    if (o.status) o.status[tup] = (u8)((L.status & CBH_ST_UNSUPPORTED) ? CBH_ST_UNSUPPORTED : (L.status & CBH_ST_CEL_ERROR));
+  }
+}

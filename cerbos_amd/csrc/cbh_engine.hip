@@ -49,6 +49,7 @@ struct cbh_device_batch {
   cbh_table* table = nullptr;
   BatchDev dev{};
   OutDev out{};
+  KernelArgs* d_args = nullptr;   // device copy of the launch arguments
   std::vector<void*> allocs;
 };
 
@@ -183,6 +184,7 @@ extern "C" int cbh_batch_upload(cbh_table* t, const cbh_batch* in, cbh_device_ba
   rc |= dalloc(b, b->out.scope, in->n_tuples);
   rc |= dalloc(b, b->out.status, in->n_tuples);
   rc |= dalloc(b, b->out.edr, NR);
+  rc |= dalloc(b, b->d_args, 1);
   if (rc != 0) { cbh_batch_release(b); return -1; }
   if (hipStreamSynchronize(s) != hipSuccess) { cbh_batch_release(b); return fail("upload failed"); }
   *out = b;
@@ -207,6 +209,11 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   if (t->pending) { HIPCHK(hipEventSynchronize(t->ev[3])); collect_times(t); }
   const BatchDev& d = b->dev;
   HIPCHK(hipMemsetAsync(b->out.edr, 0, (size_t)(d.n_requests ? d.n_requests : 1) * sizeof(u64), s));
+  {
+    KernelArgs ka{};
+    ka.t = t->dev; ka.b = d; ka.o = b->out; ka.now_ns = p->now_ns; ka.flags = p->flags;
+    HIPCHK(hipMemcpyAsync(b->d_args, &ka, sizeof(ka), hipMemcpyHostToDevice, s));
+  }
   HIPCHK(hipEventRecord(t->ev[0], s));
   const u32 maxw = std::max(std::max(t->dev.nfa_words[0], t->dev.nfa_words[1]), t->dev.nfa_words[2]);
   if (d.n_strings && maxw) {
@@ -220,7 +227,7 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   HIPCHK(hipEventRecord(t->ev[2], s));
   if (d.n_tuples) {
     const u32 grid = (d.n_tuples + CBH_BLOCK - 1) / CBH_BLOCK;
-    hipLaunchKernelGGL(cbh_check_kernel, dim3(grid), dim3(CBH_BLOCK), 0, s, t->dev, d, b->out, (i64)p->now_ns, p->flags);
+    hipLaunchKernelGGL(cbh_check_kernel, dim3(grid), dim3(CBH_BLOCK), 0, s, (const KernelArgs*)b->d_args);
   }
   HIPCHK(hipEventRecord(t->ev[3], s));
   HIPCHK(hipGetLastError());

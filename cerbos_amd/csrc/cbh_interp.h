@@ -1,0 +1,381 @@
+// Wave-uniform CEL bytecode interpreter.
+//
+// Every lane of a wave that calls run_uniform() executes the SAME program: the program
+// counter, the operand-stack pointer and the opcode dispatch are wave-uniform (they live on
+// the scalar unit: no exec-mask juggling per instruction), only the values are per lane.
+// Lanes the program does not apply to ride along predicated off (`active` = false).
+//
+// Because control flow is uniform, nothing inside an expression short-circuits: `a && b`
+// evaluates both sides and combines them with CEL's error absorption, a ternary evaluates
+// both branches and selects, comprehensions iterate until every live lane is finished.  CEL
+// is side-effect free, so results are unchanged.  The places where the reference's laziness
+// IS observable - which leaf of an all/any/none tree gets evaluated, hence which CEL errors
+// are recorded and which errors deny in strict mode (check.go:697-749, 823-837) - are kept
+// exact with a per-lane "tree-live" predicate (TREE_* instructions).
+#pragma once
+#include "cbh_vm.h"
+
+// ---- wave primitives ---------------------------------------------------------------------
+// Discipline: every lane of the wave reaches every call (callers keep finished lanes
+// predicated off instead of returning), so the exec mask is full at each of them.
+#ifndef CBH_HOSTSIM
+__device__ __forceinline__ u64 wave_ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ u32 wave_readlane(u32 v, u32 lane) { return (u32)__builtin_amdgcn_readlane((int)v, (int)lane); }
+__device__ __forceinline__ u32 uniform(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+#else
+// hostsim.cpp provides wave_ballot / wave_readlane
+static inline u32 uniform(u32 v) { return v; }
+#endif
+__device__ __forceinline__ u32 first_lane(u64 m) { return (u32)__builtin_ctzll(m); }
+// a value every lane computed identically (uniform address) -> scalar register
+__device__ __forceinline__ u32 uload(const u32* p) { return uniform(*p); }
+__device__ __forceinline__ u64 wave_readlane64(u64 v, u32 lane) {
+  return (u64)wave_readlane((u32)v, lane) | ((u64)wave_readlane((u32)(v >> 32), lane) << 32);
+}
+
+#define ST(i) c.s_tag[(i) * CBH_BLOCK + c.tid]
+#define SV(i) c.s_val[(i) * CBH_BLOCK + c.tid]
+#define PUSHV(x) do { Val _x = (x); ST(sp) = (u8)_x.t; SV(sp) = _x.v; ++sp; } while (0)
+#define TOPV(k) mk(ST(sp - 1 - (k)), SV(sp - 1 - (k)))
+#define SETTOP(x) do { Val _x = (x); ST(sp - 1) = (u8)_x.t; SV(sp - 1) = _x.v; } while (0)
+
+// iteration-slot state word (per lane): bits 0..7 kind, bit 8 saw-error, bit 9 decided
+// (short-circuit value reached), bit 10 lane-live-at-entry, bit 11 iterating (not exhausted /
+// decided), bit 30 container is a map, bit 31 the macro itself is an error; bits 16..29 count.
+#define ITS_ERRSEEN 0x100u
+#define ITS_DECIDED 0x200u
+#define ITS_ENTRY_LIVE 0x400u
+#define ITS_RUNNING 0x800u
+#define ITS_MAP 0x40000000u
+#define ITS_FAIL 0x80000000u
+
+// Runs the program at wave-uniform `pc` for the lanes with active=true.
+// Per lane result: 0 = false, 1 = true, 2 = strict-mode evaluation error (inactive lanes: 0).
+#ifndef CBH_HOSTSIM
+__attribute__((noinline))
+#endif
+__device__ int run_uniform(const Ctx& c, Lane& L, u32 pc, bool active) {
+  int sp = 0;
+  const bool strict = (c.flags & CBH_F_STRICT_EVALUATION) != 0;
+  bool live = active;     // lane still evaluates leaves (tree-live && not aborted)
+  int result = 0;
+  u32 tree_saved = 0;     // bit d = `live` saved at tree depth d
+  u32 tree_acc = 0;       // bit d = accumulator at tree depth d
+  int tree_depth = 0;
+  pc = uniform(pc);
+  for (u32 steps = 0; steps < 1000000u; ++steps) {
+    const u32 w = uload(&c.t.code[pc]); ++pc;
+    const u32 op = w & 0xFFu, a = w >> 8;
+    const bool live_in = live;        // status bits raised by a lane that is not live are dropped
+    const u32 status_in = L.status;
+    switch (op) {
+      case OP_RET: {
+        if (active && result != 2) result = (sp > 0 && ST(sp - 1) == CBH_T_BOOL && SV(sp - 1) != 0) ? 1 : 0;
+        return result;
+      }
+      case OP_CONST: PUSHV(mk(c.t.const_tag[a], c.t.const_val[a])); break;
+      case OP_COL: PUSHV(load_operand(c, L, 1, a)); break;
+      case OP_HASCOL: {
+        u32 t = c.b.col_tag[(size_t)a * c.b.n_requests + L.req];
+        if (t == CBH_T_ERR) PUSHV(mk_err()); else PUSHV(mk_bool(t != CBH_T_ABSENT));
+        break;
+      }
+      case OP_REQSTR: PUSHV(load_operand(c, L, 2, a)); break;
+      case OP_ROLES: {
+        u64 off = c.b.req_u32[(size_t)CBH_RQ_ROLE_OFF * c.b.n_requests + L.req];
+        u64 cnt = c.b.req_u32[(size_t)CBH_RQ_ROLE_CNT * c.b.n_requests + L.req];
+        PUSHV(mk(CBH_T_LIST, ((u64)CBH_HEAP_ROLES << 62) | (off << 32) | cnt));
+        break;
+      }
+      case OP_SELECT: case OP_HASSEL: {
+        Val m = TOPV(0), out;
+        if (m.t != CBH_T_MAP) { ST(sp - 1) = CBH_T_ERR; break; }
+        bool f = map_find(c, m, mk(CBH_T_STRING, a), out);
+        if (op == OP_HASSEL) SETTOP(mk_bool(f));
+        else if (!f) ST(sp - 1) = CBH_T_ERR;
+        else SETTOP(out);
+        break;
+      }
+      case OP_INDEX: {
+        Val i = TOPV(0), m = TOPV(1), out = mk_err(); --sp;
+        if (m.t == CBH_T_ERR || i.t == CBH_T_ERR) { /* error */ }
+        else if (m.t == CBH_T_MAP) { if (!map_find(c, m, i, out)) out = mk_err(); }
+        else if (m.t == CBH_T_LIST && is_num(i.t)) {
+          i64 k = -1;
+          if (i.t == CBH_T_INT) k = (i64)i.v;
+          else if (i.t == CBH_T_UINT) k = i.v < (1ull << 62) ? (i64)i.v : -1;
+          else { double d = as_f64(i.v); if (d == trunc(d) && d >= 0 && d < 4e18) k = (i64)d; }
+          if (k >= 0 && (u64)k < cont_len(m.v)) out = heap_get(c, cont_sel(m.v), cont_off(m.v) + (u32)k);
+        }
+        SETTOP(out);
+        break;
+      }
+      case OP_EQ: case OP_NE: case OP_LT: case OP_LE: case OP_GT: case OP_GE: case OP_IN: {
+        Val y = TOPV(0), x = TOPV(1); --sp;
+        SETTOP(compare_op(c, L, op, x, y));
+        break;
+      }
+      case OP_LEAF_BIN: {   // fused leaf: operands straight from columns / constants
+        const u32 a0 = uload(&c.t.code[pc]), a1 = uload(&c.t.code[pc + 1]); pc += 2;
+        Val x = load_operand(c, L, (a >> 8) & 0xF, a0);
+        Val y = load_operand(c, L, (a >> 12) & 0xF, a1);
+        Val r = compare_op(c, L, a & 0xFF, x, y);
+        if (r.t == CBH_T_ERR && live) {
+          L.status |= CBH_ST_CEL_ERROR;
+          if (strict) { result = 2; live = false; }
+        }
+        PUSHV(mk_bool(r.t == CBH_T_BOOL && r.v));
+        break;
+      }
+      case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_MOD: {
+        Val y = TOPV(0), x = TOPV(1); --sp;
+        Val r = (x.t == CBH_T_ERR || y.t == CBH_T_ERR) ? mk_err() : arith(op, x, y);
+        if (r.t == CBH_T_ERR && x.t != CBH_T_ERR && y.t != CBH_T_ERR &&
+            (x.t == CBH_T_STRING || x.t == CBH_T_LIST) && x.t == y.t && op == OP_ADD && live)
+          L.status |= CBH_ST_UNSUPPORTED;  // concatenation allocates: not on the device
+        SETTOP(r);
+        break;
+      }
+      case OP_NEG: {
+        Val x = TOPV(0);
+        if (x.t == CBH_T_INT) { if ((i64)x.v == INT64_MIN) ST(sp - 1) = CBH_T_ERR; else SV(sp - 1) = (u64)(-(i64)x.v); }
+        else if (x.t == CBH_T_DOUBLE) SV(sp - 1) = f64_bits(-as_f64(x.v));
+        else ST(sp - 1) = CBH_T_ERR;
+        break;
+      }
+      case OP_NOT: {
+        if (ST(sp - 1) == CBH_T_BOOL) SV(sp - 1) = SV(sp - 1) ? 0 : 1; else ST(sp - 1) = CBH_T_ERR;
+        break;
+      }
+      case OP_AND: case OP_OR: {
+        Val y = TOPV(0), x = TOPV(1); --sp;
+        const u64 absorbing = (op == OP_OR) ? 1 : 0;
+        bool xb = x.t == CBH_T_BOOL, yb = y.t == CBH_T_BOOL;
+        if ((xb && x.v == absorbing) || (yb && y.v == absorbing)) SETTOP(mk_bool(absorbing != 0));
+        else if (xb && yb) SETTOP(mk_bool(absorbing == 0));
+        else ST(sp - 1) = CBH_T_ERR;
+        break;
+      }
+      case OP_TERN: {     // pop else, then, guard
+        Val e = TOPV(0), t = TOPV(1), g = TOPV(2); sp -= 2;
+        if (g.t != CBH_T_BOOL) ST(sp - 1) = CBH_T_ERR; else SETTOP(g.v ? t : e);
+        break;
+      }
+      case OP_JMP: pc = a; break;
+      case OP_POP: --sp; break;
+      case OP_LEAF: {
+        Val x = TOPV(0);
+        if (x.t == CBH_T_ERR && live) {
+          L.status |= CBH_ST_CEL_ERROR;
+          if (strict) { result = 2; live = false; }
+        }
+        SETTOP(mk_bool(x.t == CBH_T_BOOL && x.v));
+        break;
+      }
+      // ---- condition trees (check.go:697-749): children in order, later children are not
+      //      evaluated (no error recorded / no strict abort) once the outcome is known
+      case OP_TREE_BEGIN: {   // a = kind (0 all, 1 any, 2 none)
+        const u32 bit = 1u << tree_depth;
+        tree_saved = live ? (tree_saved | bit) : (tree_saved & ~bit);
+        tree_acc = (a == 0) ? (tree_acc | bit) : (tree_acc & ~bit);   // all starts true, any/none false
+        ++tree_depth;
+        break;
+      }
+      case OP_TREE_ACC: {     // pop child result (plain bool)
+        const u32 bit = 1u << (tree_depth - 1);
+        const bool v = SV(sp - 1) != 0; --sp;
+        if (live) {
+          if (a == 0) { if (!v) { tree_acc &= ~bit; live = false; } }
+          else if (v) { tree_acc |= bit; live = false; }
+        }
+        break;
+      }
+      case OP_TREE_END: {
+        --tree_depth;
+        const u32 bit = 1u << tree_depth;
+        const bool acc = (tree_acc & bit) != 0;
+        if (result != 2) live = (tree_saved & bit) != 0;
+        PUSHV(mk_bool(a == 2 ? !acc : acc));
+        break;
+      }
+      case OP_SIZE: {
+        Val x = TOPV(0);
+        if (x.t == CBH_T_STRING) SETTOP(mk(CBH_T_INT, str_codepoints(c, (u32)x.v)));
+        else if (x.t == CBH_T_LIST || x.t == CBH_T_MAP) SETTOP(mk(CBH_T_INT, cont_len(x.v)));
+        else ST(sp - 1) = CBH_T_ERR;
+        break;
+      }
+      case OP_STARTSWITH: case OP_ENDSWITH: case OP_CONTAINS: {
+        Val y = TOPV(0), x = TOPV(1); --sp;
+        if (x.t != CBH_T_STRING || y.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
+        SETTOP(mk_bool(str_find(c, (u32)x.v, (u32)y.v, op == OP_STARTSWITH ? 0 : (op == OP_ENDSWITH ? 1 : 2))));
+        break;
+      }
+      case OP_TIMESTAMP: {
+        Val x = TOPV(0);
+        if (x.t == CBH_T_TIMESTAMP) break;
+        if (x.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
+        const u8* p; u32 n; str_span(c, (u32)x.v, p, n);
+        i64 ns = 0; int rc = parse_timestamp(p, n, ns);
+        if (rc == 2 && live) L.status |= CBH_ST_UNSUPPORTED;
+        if (rc != 0) { ST(sp - 1) = CBH_T_ERR; break; }
+        SETTOP(mk(CBH_T_TIMESTAMP, (u64)ns));
+        break;
+      }
+      case OP_DURATION: {
+        Val x = TOPV(0);
+        if (x.t == CBH_T_DURATION) break;
+        if (x.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
+        const u8* p; u32 n; str_span(c, (u32)x.v, p, n);
+        i64 ns = 0;
+        if (parse_duration(p, n, ns) != 0) { ST(sp - 1) = CBH_T_ERR; break; }
+        SETTOP(mk(CBH_T_DURATION, (u64)ns));
+        break;
+      }
+      case OP_TIMESINCE: {
+        Val x = TOPV(0); i64 r;
+        if (x.t != CBH_T_TIMESTAMP || __builtin_sub_overflow(c.now_ns, (i64)x.v, &r)) { ST(sp - 1) = CBH_T_ERR; break; }
+        SETTOP(mk(CBH_T_DURATION, (u64)r));
+        break;
+      }
+      case OP_NOW: PUSHV(mk(CBH_T_TIMESTAMP, (u64)c.now_ns)); break;
+      case OP_EDRHAS: {
+        if (L.edr_err) PUSHV(mk_err()); else PUSHV(mk_bool((L.edr >> a) & 1));
+        break;
+      }
+      case OP_LOCAL: PUSHV(mk(c.l_tag[a * CBH_BLOCK + c.tid], c.l_val[a * CBH_BLOCK + c.tid])); break;
+      // ---- comprehensions: wave-uniform loop, per-lane progress
+      case OP_ITER_BEGIN: {   // a = slot; next word = kind
+        Val x = TOPV(0); --sp;
+        const u32 kind = uload(&c.t.code[pc]); ++pc;
+        u32 st = kind | (live ? ITS_ENTRY_LIVE : 0);
+        if (x.t != CBH_T_LIST && x.t != CBH_T_MAP) { st |= ITS_FAIL; x.v = 0; }
+        else { if (live) st |= ITS_RUNNING; if (x.t == CBH_T_MAP) st |= ITS_MAP; }   // lanes that are not live sit the loop out
+        c.it_cont[a * CBH_BLOCK + c.tid] = x.v;
+        c.it_idx[a * CBH_BLOCK + c.tid] = 0;
+        c.it_state[a * CBH_BLOCK + c.tid] = st;
+        break;
+      }
+      case OP_ITER_NEXT: {    // a = slot; next words: end_pc, locals (v1 | v2 << 8 | nvars << 16)
+        const u32 end_pc = uload(&c.t.code[pc]), lw = uload(&c.t.code[pc + 1]); pc += 2;
+        const u64 cont = c.it_cont[a * CBH_BLOCK + c.tid];
+        const u32 i = c.it_idx[a * CBH_BLOCK + c.tid];
+        u32 st = c.it_state[a * CBH_BLOCK + c.tid];
+        bool more = (st & ITS_RUNNING) && i < cont_len(cont);
+        if (!more) st &= ~ITS_RUNNING;
+        c.it_state[a * CBH_BLOCK + c.tid] = st;
+        live = more && (st & ITS_ENTRY_LIVE) && result != 2;
+        if (wave_ballot(more) == 0) { pc = end_pc; break; }
+        if (more) {
+          const bool is_map = (st & ITS_MAP) != 0;
+          const u32 l1 = lw & 0xFF, l2 = (lw >> 8) & 0xFF, nv = (lw >> 16) & 0xFF;
+          Val k, v;
+          if (is_map) { k = heap_get(c, cont_sel(cont), cont_off(cont) + 2 * i); v = heap_get(c, cont_sel(cont), cont_off(cont) + 2 * i + 1); }
+          else { k = mk(CBH_T_INT, i); v = heap_get(c, cont_sel(cont), cont_off(cont) + i); }
+          if (nv == 2) {
+            c.l_tag[l1 * CBH_BLOCK + c.tid] = (u8)k.t; c.l_val[l1 * CBH_BLOCK + c.tid] = k.v;
+            c.l_tag[l2 * CBH_BLOCK + c.tid] = (u8)v.t; c.l_val[l2 * CBH_BLOCK + c.tid] = v.v;
+          } else {
+            Val e = is_map ? k : v;
+            c.l_tag[l1 * CBH_BLOCK + c.tid] = (u8)e.t; c.l_val[l1 * CBH_BLOCK + c.tid] = e.v;
+          }
+          c.it_idx[a * CBH_BLOCK + c.tid] = i + 1;
+        }
+        break;
+      }
+      case OP_ITER_ACC: {     // a = slot; next word = loop_pc
+        const u32 loop_pc = uload(&c.t.code[pc]); ++pc;
+        Val x = TOPV(0); --sp;
+        u32 st = c.it_state[a * CBH_BLOCK + c.tid];
+        if (st & ITS_RUNNING) {
+          const u32 kind = st & 0xFF;
+          if (x.t != CBH_T_BOOL) {
+            if (kind == IT_EXISTS_ONE) { st |= ITS_FAIL; st &= ~ITS_RUNNING; }   // errors propagate
+            else st |= ITS_ERRSEEN;                                               // may be absorbed
+          } else if (kind == IT_ALL) { if (!x.v) { st |= ITS_DECIDED; st &= ~ITS_RUNNING; } }
+          else if (kind == IT_EXISTS) { if (x.v) { st |= ITS_DECIDED; st &= ~ITS_RUNNING; } }
+          else if (x.v) st += 0x10000u;
+          c.it_state[a * CBH_BLOCK + c.tid] = st;
+        }
+        pc = loop_pc;
+        break;
+      }
+      case OP_ITER_END: {
+        const u32 st = c.it_state[a * CBH_BLOCK + c.tid];
+        const u32 kind = st & 0xFF;
+        if (result != 2) live = (st & ITS_ENTRY_LIVE) != 0;
+        if (st & ITS_FAIL) { PUSHV(mk_err()); break; }
+        if (kind == IT_ALL) { if (st & ITS_DECIDED) PUSHV(mk_bool(false)); else if (st & ITS_ERRSEEN) PUSHV(mk_err()); else PUSHV(mk_bool(true)); }
+        else if (kind == IT_EXISTS) { if (st & ITS_DECIDED) PUSHV(mk_bool(true)); else if (st & ITS_ERRSEEN) PUSHV(mk_err()); else PUSHV(mk_bool(false)); }
+        else PUSHV(mk_bool(((st >> 16) & 0x3FFFu) == 1));
+        break;
+      }
+      case OP_TOINT: {
+        Val x = TOPV(0);
+        if (x.t == CBH_T_INT) break;
+        if (x.t == CBH_T_UINT) { if (x.v > (u64)INT64_MAX) ST(sp - 1) = CBH_T_ERR; else ST(sp - 1) = CBH_T_INT; break; }
+        if (x.t == CBH_T_DOUBLE) {
+          double d = as_f64(x.v);
+          if (d != d || d >= 9223372036854775807.0 || d <= -9223372036854775808.0) ST(sp - 1) = CBH_T_ERR;
+          else SETTOP(mk(CBH_T_INT, (u64)(i64)d));
+          break;
+        }
+        if (x.t == CBH_T_TIMESTAMP) { i64 ns = (i64)x.v; i64 s = ns / 1000000000LL; if (ns % 1000000000LL < 0) --s; SETTOP(mk(CBH_T_INT, (u64)s)); break; }
+        if (x.t == CBH_T_DURATION) { ST(sp - 1) = CBH_T_INT; break; }
+        if (x.t == CBH_T_STRING && live) L.status |= CBH_ST_UNSUPPORTED;
+        ST(sp - 1) = CBH_T_ERR;
+        break;
+      }
+      case OP_TODOUBLE: {
+        Val x = TOPV(0);
+        if (x.t == CBH_T_DOUBLE) break;
+        if (x.t == CBH_T_INT) { SETTOP(mk(CBH_T_DOUBLE, f64_bits((double)(i64)x.v))); break; }
+        if (x.t == CBH_T_UINT) { SETTOP(mk(CBH_T_DOUBLE, f64_bits((double)x.v))); break; }
+        if (x.t == CBH_T_STRING && live) L.status |= CBH_ST_UNSUPPORTED;
+        ST(sp - 1) = CBH_T_ERR;
+        break;
+      }
+      case OP_INIPRANGE: {
+        Val y = TOPV(0), x = TOPV(1); --sp;
+        if (x.t != CBH_T_STRING || y.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
+        const u8 *pi, *pc2; u32 ni, nc;
+        str_span(c, (u32)x.v, pi, ni); str_span(c, (u32)y.v, pc2, nc);
+        bool v6 = false;
+        for (u32 i = 0; i < ni; ++i) v6 |= pi[i] == ':';
+        for (u32 i = 0; i < nc; ++i) v6 |= pc2[i] == ':';
+        if (v6) { if (live) L.status |= CBH_ST_UNSUPPORTED; ST(sp - 1) = CBH_T_ERR; break; }   // IPv6: not on the device
+        u32 slash = nc;
+        for (u32 i = 0; i < nc; ++i) if (pc2[i] == '/') { slash = i; break; }
+        u32 ip = 0, net = 0, bits = 0, nd = 0;
+        bool ok = slash < nc && parse_ipv4(pi, ni, ip) && parse_ipv4(pc2, slash, net);
+        for (u32 i = slash + 1; ok && i < nc; ++i) { if (!dig(pc2[i]) || nd >= 2) ok = false; else { bits = bits * 10 + (pc2[i] - '0'); ++nd; } }
+        if (ok && (nd == 0 || bits > 32 || (nd == 2 && pc2[slash + 1] == '0'))) ok = false;
+        if (!ok) { ST(sp - 1) = CBH_T_ERR; break; }
+        u32 mask = bits == 0 ? 0u : (0xFFFFFFFFu << (32 - bits));
+        SETTOP(mk_bool((ip & mask) == (net & mask)));
+        break;
+      }
+      case OP_HASINTERSECTION: case OP_ISSUBSET: {
+        Val y = TOPV(0), x = TOPV(1); --sp;
+        if (x.t != CBH_T_LIST || y.t != CBH_T_LIST) { ST(sp - 1) = CBH_T_ERR; break; }
+        bool any = false, all = true;
+        for (u32 i = 0; i < cont_len(x.v); ++i) {
+          Val e = heap_get(c, cont_sel(x.v), cont_off(x.v) + i);
+          bool in = false;
+          for (u32 j = 0; j < cont_len(y.v) && !in; ++j) in = val_equal(c, L, e, heap_get(c, cont_sel(y.v), cont_off(y.v) + j));
+          any |= in; all &= in;
+        }
+        SETTOP(mk_bool((op == OP_HASINTERSECTION) ? any : all));
+        break;
+      }
+      case OP_UNSUPPORTED:
+      default:
+        if (live) L.status |= CBH_ST_UNSUPPORTED;
+        PUSHV(mk_err());
+        break;
+    }
+    if (!live_in) L.status = status_in;
+  }
+  L.status |= CBH_ST_UNSUPPORTED;  // step budget exhausted
+  return result;
+}

@@ -53,6 +53,10 @@ struct BatchDev {
 
 struct OutDev { u8* effect; u32* policy; u32* scope; u8* status; u64* edr; };
 
+// Launch arguments of the decision kernel.  They live in device memory (one uniform pointer
+// as the only kernel argument) so that every table / batch base address is a scalar load.
+struct KernelArgs { TableDev t; BatchDev b; OutDev o; long long now_ns; u32 flags; u32 pad; };
+
 struct Val { u32 t; u64 v; };
 
 struct Lane {           // per-lane evaluation state that programs can observe
@@ -425,314 +429,84 @@ __device__ inline Val arith(u32 op, Val a, Val b) {
   return mk_err();  // no such overload (incl. string/list concatenation: not on the device)
 }
 
-// iteration-slot state word: bit0 saw-error, bits 8.. count of true predicates
-// Runs the program at `pc`.  Returns 0 = false, 1 = true, 2 = strict-mode evaluation error.
-__device__ inline int run_program(const Ctx& c, Lane& L, u32 pc) {
-  int sp = 0;
-  const bool strict = (c.flags & CBH_F_STRICT_EVALUATION) != 0;
-  for (u32 steps = 0; steps < 200000u; ++steps) {
-    const u32 w = c.t.code[pc++];
-    const u32 op = w & 0xFFu, a = w >> 8;
-    switch (op) {
-      case OP_RET: {
-        return (sp > 0 && ST(sp - 1) == CBH_T_BOOL && SV(sp - 1) != 0) ? 1 : 0;
-      }
-      case OP_CONST: PUSHV(mk(c.t.const_tag[a], c.t.const_val[a])); break;
-      case OP_COL: {
-        size_t ix = (size_t)a * c.b.n_requests + L.req;
-        u32 t = c.b.col_tag[ix];
-        if (t == CBH_T_ABSENT) PUSHV(mk_err()); else PUSHV(mk(t, c.b.col_val[ix]));
-        break;
-      }
-      case OP_HASCOL: {
-        u32 t = c.b.col_tag[(size_t)a * c.b.n_requests + L.req];
-        if (t == CBH_T_ERR) PUSHV(mk_err()); else PUSHV(mk_bool(t != CBH_T_ABSENT));
-        break;
-      }
-      case OP_REQSTR: PUSHV(mk(CBH_T_STRING, c.b.req_u32[(size_t)a * c.b.n_requests + L.req])); break;
-      case OP_ROLES: {
-        u64 off = c.b.req_u32[(size_t)CBH_RQ_ROLE_OFF * c.b.n_requests + L.req];
-        u64 cnt = c.b.req_u32[(size_t)CBH_RQ_ROLE_CNT * c.b.n_requests + L.req];
-        PUSHV(mk(CBH_T_LIST, ((u64)CBH_HEAP_ROLES << 62) | (off << 32) | cnt));
-        break;
-      }
-      case OP_SELECT: case OP_HASSEL: {
-        Val m = TOPV(0), out;
-        if (m.t != CBH_T_MAP) { ST(sp - 1) = CBH_T_ERR; break; }
-        bool f = map_find(c, m, mk(CBH_T_STRING, a), out);
-        if (op == OP_HASSEL) { ST(sp - 1) = CBH_T_BOOL; SV(sp - 1) = f; }
-        else if (!f) ST(sp - 1) = CBH_T_ERR;
-        else { ST(sp - 1) = (u8)out.t; SV(sp - 1) = out.v; }
-        break;
-      }
-      case OP_INDEX: {
-        Val i = TOPV(0), m = TOPV(1), out = mk_err(); --sp;
-        if (m.t == CBH_T_ERR || i.t == CBH_T_ERR) { /* error */ }
-        else if (m.t == CBH_T_MAP) { if (!map_find(c, m, i, out)) out = mk_err(); }
-        else if (m.t == CBH_T_LIST && is_num(i.t)) {
-          i64 k = -1;
-          if (i.t == CBH_T_INT) k = (i64)i.v;
-          else if (i.t == CBH_T_UINT) k = i.v < (1ull << 62) ? (i64)i.v : -1;
-          else { double d = as_f64(i.v); if (d == trunc(d) && d >= 0 && d < 4e18) k = (i64)d; }
-          if (k >= 0 && (u64)k < cont_len(m.v)) out = heap_get(c, cont_sel(m.v), cont_off(m.v) + (u32)k);
-        }
-        ST(sp - 1) = (u8)out.t; SV(sp - 1) = out.v;
-        break;
-      }
-      case OP_EQ: case OP_NE: {
-        Val y = TOPV(0), x = TOPV(1); --sp;
-        if (x.t == CBH_T_ERR || y.t == CBH_T_ERR) { ST(sp - 1) = CBH_T_ERR; break; }
-        bool e = val_equal(c, L, x, y);
-        ST(sp - 1) = CBH_T_BOOL; SV(sp - 1) = (op == OP_EQ) ? e : !e;
-        break;
-      }
-      case OP_LT: case OP_LE: case OP_GT: case OP_GE: {
-        Val y = TOPV(0), x = TOPV(1); --sp;
-        if (x.t == CBH_T_ERR || y.t == CBH_T_ERR) { ST(sp - 1) = CBH_T_ERR; break; }
-        int r = val_compare(c, x, y);
-        if (r == 3) { ST(sp - 1) = CBH_T_ERR; break; }
-        bool res = false;
-        if (r != 2) res = (op == OP_LT) ? r < 0 : (op == OP_LE) ? r <= 0 : (op == OP_GT) ? r > 0 : r >= 0;
-        ST(sp - 1) = CBH_T_BOOL; SV(sp - 1) = res;
-        break;
-      }
-      case OP_IN: {
-        Val cont = TOPV(0), x = TOPV(1); --sp;
-        if (x.t == CBH_T_ERR || cont.t == CBH_T_ERR) { ST(sp - 1) = CBH_T_ERR; break; }
-        bool found = false;
-        if (cont.t == CBH_T_LIST) {
-          u32 n = cont_len(cont.v);
-          for (u32 i = 0; i < n && !found; ++i) found = val_equal(c, L, x, heap_get(c, cont_sel(cont.v), cont_off(cont.v) + i));
-        } else if (cont.t == CBH_T_MAP) {
-          Val tmp; found = map_find(c, cont, x, tmp);
-        } else { ST(sp - 1) = CBH_T_ERR; break; }
-        ST(sp - 1) = CBH_T_BOOL; SV(sp - 1) = found;
-        break;
-      }
-      case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_MOD: {
-        Val y = TOPV(0), x = TOPV(1); --sp;
-        Val r = (x.t == CBH_T_ERR || y.t == CBH_T_ERR) ? mk_err() : arith(op, x, y);
-        if (r.t == CBH_T_ERR && x.t != CBH_T_ERR && y.t != CBH_T_ERR &&
-            (x.t == CBH_T_STRING || x.t == CBH_T_LIST) && x.t == y.t && op == OP_ADD)
-          L.status |= CBH_ST_UNSUPPORTED;  // concatenation allocates: not on the device
-        ST(sp - 1) = (u8)r.t; SV(sp - 1) = r.v;
-        break;
-      }
-      case OP_NEG: {
-        Val x = TOPV(0);
-        if (x.t == CBH_T_INT) { if ((i64)x.v == INT64_MIN) ST(sp - 1) = CBH_T_ERR; else SV(sp - 1) = (u64)(-(i64)x.v); }
-        else if (x.t == CBH_T_DOUBLE) SV(sp - 1) = f64_bits(-as_f64(x.v));
-        else ST(sp - 1) = CBH_T_ERR;
-        break;
-      }
-      case OP_NOT: {
-        if (ST(sp - 1) == CBH_T_BOOL) SV(sp - 1) = SV(sp - 1) ? 0 : 1; else ST(sp - 1) = CBH_T_ERR;
-        break;
-      }
-      case OP_JF: if (ST(sp - 1) == CBH_T_BOOL && SV(sp - 1) == 0) pc = a; break;
-      case OP_JT: if (ST(sp - 1) == CBH_T_BOOL && SV(sp - 1) != 0) pc = a; break;
-      case OP_AND: case OP_OR: {
-        Val y = TOPV(0), x = TOPV(1); --sp;
-        const u64 absorbing = (op == OP_OR) ? 1 : 0;
-        bool xb = x.t == CBH_T_BOOL, yb = y.t == CBH_T_BOOL;
-        if ((xb && x.v == absorbing) || (yb && y.v == absorbing)) { ST(sp - 1) = CBH_T_BOOL; SV(sp - 1) = absorbing; }
-        else if (xb && yb) { ST(sp - 1) = CBH_T_BOOL; SV(sp - 1) = 1 - absorbing; }
-        else ST(sp - 1) = CBH_T_ERR;
-        break;
-      }
-      case OP_JTERN: {
-        Val g = TOPV(0); --sp;
-        const u32 end_pc = c.t.code[pc];
-        if (g.t != CBH_T_BOOL) { PUSHV(mk_err()); pc = end_pc; }
-        else if (g.v) pc += 1;
-        else pc = a;
-        break;
-      }
-      case OP_JMP: pc = a; break;
-      case OP_POP: --sp; break;
-      case OP_LEAF: {
-        Val x = TOPV(0);
-        if (x.t == CBH_T_ERR) {
-          L.status |= CBH_ST_CEL_ERROR;
-          if (strict) return 2;
-        }
-        ST(sp - 1) = CBH_T_BOOL; SV(sp - 1) = (x.t == CBH_T_BOOL && x.v) ? 1 : 0;
-        break;
-      }
-      case OP_SIZE: {
-        Val x = TOPV(0);
-        if (x.t == CBH_T_STRING) { ST(sp - 1) = CBH_T_INT; SV(sp - 1) = str_codepoints(c, (u32)x.v); }
-        else if (x.t == CBH_T_LIST || x.t == CBH_T_MAP) { ST(sp - 1) = CBH_T_INT; SV(sp - 1) = cont_len(x.v); }
-        else ST(sp - 1) = CBH_T_ERR;
-        break;
-      }
-      case OP_STARTSWITH: case OP_ENDSWITH: case OP_CONTAINS: {
-        Val y = TOPV(0), x = TOPV(1); --sp;
-        if (x.t != CBH_T_STRING || y.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
-        bool r = str_find(c, (u32)x.v, (u32)y.v, op == OP_STARTSWITH ? 0 : (op == OP_ENDSWITH ? 1 : 2));
-        ST(sp - 1) = CBH_T_BOOL; SV(sp - 1) = r;
-        break;
-      }
-      case OP_TIMESTAMP: {
-        Val x = TOPV(0);
-        if (x.t == CBH_T_TIMESTAMP) break;
-        if (x.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
-        const u8* p; u32 n; str_span(c, (u32)x.v, p, n);
-        i64 ns; int rc = parse_timestamp(p, n, ns);
-        if (rc == 2) L.status |= CBH_ST_UNSUPPORTED;
-        if (rc != 0) { ST(sp - 1) = CBH_T_ERR; break; }
-        ST(sp - 1) = CBH_T_TIMESTAMP; SV(sp - 1) = (u64)ns;
-        break;
-      }
-      case OP_DURATION: {
-        Val x = TOPV(0);
-        if (x.t == CBH_T_DURATION) break;
-        if (x.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
-        const u8* p; u32 n; str_span(c, (u32)x.v, p, n);
-        i64 ns;
-        if (parse_duration(p, n, ns) != 0) { ST(sp - 1) = CBH_T_ERR; break; }
-        ST(sp - 1) = CBH_T_DURATION; SV(sp - 1) = (u64)ns;
-        break;
-      }
-      case OP_TIMESINCE: {
-        Val x = TOPV(0); i64 r;
-        if (x.t != CBH_T_TIMESTAMP || __builtin_sub_overflow(c.now_ns, (i64)x.v, &r)) { ST(sp - 1) = CBH_T_ERR; break; }
-        ST(sp - 1) = CBH_T_DURATION; SV(sp - 1) = (u64)r;
-        break;
-      }
-      case OP_NOW: PUSHV(mk(CBH_T_TIMESTAMP, (u64)c.now_ns)); break;
-      case OP_EDRHAS: {
-        if (L.edr_err) PUSHV(mk_err()); else PUSHV(mk_bool((L.edr >> a) & 1));
-        break;
-      }
-      case OP_LOCAL: PUSHV(mk(c.l_tag[a * CBH_BLOCK + c.tid], c.l_val[a * CBH_BLOCK + c.tid])); break;
-      case OP_ITER_BEGIN: {
-        Val x = TOPV(0); --sp;
-        const u32 w2 = c.t.code[pc++];
-        if (x.t != CBH_T_LIST && x.t != CBH_T_MAP) {
-          // not iterable: the macro yields an error; park it as the folded result
-          c.it_state[a * CBH_BLOCK + c.tid] = 0x80000000u | (w2 & 0xFF);
-          c.it_idx[a * CBH_BLOCK + c.tid] = 0; c.it_cont[a * CBH_BLOCK + c.tid] = 0;
-          pc = w2 >> 8;
-          break;
-        }
-        c.it_cont[a * CBH_BLOCK + c.tid] = x.v;  // payload (sel/off/len)
-        c.it_idx[a * CBH_BLOCK + c.tid] = 0;
-        c.it_state[a * CBH_BLOCK + c.tid] = (w2 & 0xFF) | ((x.t == CBH_T_MAP) ? 0x40000000u : 0u);
-        break;
-      }
-      case OP_ITER_NEXT: {
-        // next word: end_pc ; following word: local slots (v1 | v2 << 8 | nvars << 16)
-        const u32 end_pc = c.t.code[pc++]; const u32 lw = c.t.code[pc++];
-        const u64 cont = c.it_cont[a * CBH_BLOCK + c.tid];
-        const u32 i = c.it_idx[a * CBH_BLOCK + c.tid];
-        const u32 st = c.it_state[a * CBH_BLOCK + c.tid];
-        if (i >= cont_len(cont)) { pc = end_pc; break; }
-        const bool is_map = (st & 0x40000000u) != 0;
-        const u32 l1 = lw & 0xFF, l2 = (lw >> 8) & 0xFF, nv = (lw >> 16) & 0xFF;
-        Val k, v;
-        if (is_map) { k = heap_get(c, cont_sel(cont), cont_off(cont) + 2 * i); v = heap_get(c, cont_sel(cont), cont_off(cont) + 2 * i + 1); }
-        else { k = mk(CBH_T_INT, i); v = heap_get(c, cont_sel(cont), cont_off(cont) + i); }
-        if (nv == 2) {
-          c.l_tag[l1 * CBH_BLOCK + c.tid] = (u8)k.t; c.l_val[l1 * CBH_BLOCK + c.tid] = k.v;
-          c.l_tag[l2 * CBH_BLOCK + c.tid] = (u8)v.t; c.l_val[l2 * CBH_BLOCK + c.tid] = v.v;
-        } else {
-          Val e = is_map ? k : v;
-          c.l_tag[l1 * CBH_BLOCK + c.tid] = (u8)e.t; c.l_val[l1 * CBH_BLOCK + c.tid] = e.v;
-        }
-        c.it_idx[a * CBH_BLOCK + c.tid] = i + 1;
-        break;
-      }
-      case OP_ITER_ACC: {
-        const u32 loop_pc = c.t.code[pc++]; const u32 end_pc = c.t.code[pc++];
-        Val x = TOPV(0); --sp;
-        u32 st = c.it_state[a * CBH_BLOCK + c.tid];
-        const u32 kind = st & 0xFF;
-        pc = loop_pc;
-        if (x.t != CBH_T_BOOL) {
-          if (kind == IT_EXISTS_ONE) { st |= 0x80000000u; pc = end_pc; }  // errors propagate
-          else st |= 0x100u;                                              // remembered, may be absorbed
-        } else if (kind == IT_ALL) { if (!x.v) { st |= 0x200u; pc = end_pc; } }
-        else if (kind == IT_EXISTS) { if (x.v) { st |= 0x200u; pc = end_pc; } }
-        else if (x.v) st += 0x10000u;
-        c.it_state[a * CBH_BLOCK + c.tid] = st;
-        break;
-      }
-      case OP_ITER_END: {
-        const u32 st = c.it_state[a * CBH_BLOCK + c.tid];
-        const u32 kind = st & 0xFF;
-        if (st & 0x80000000u) { PUSHV(mk_err()); break; }
-        if (kind == IT_ALL) { if (st & 0x200u) PUSHV(mk_bool(false)); else if (st & 0x100u) PUSHV(mk_err()); else PUSHV(mk_bool(true)); }
-        else if (kind == IT_EXISTS) { if (st & 0x200u) PUSHV(mk_bool(true)); else if (st & 0x100u) PUSHV(mk_err()); else PUSHV(mk_bool(false)); }
-        else PUSHV(mk_bool(((st >> 16) & 0x3FFFu) == 1));
-        break;
-      }
-      case OP_TOINT: {
-        Val x = TOPV(0);
-        if (x.t == CBH_T_INT) break;
-        if (x.t == CBH_T_UINT) { if (x.v > (u64)INT64_MAX) ST(sp - 1) = CBH_T_ERR; else ST(sp - 1) = CBH_T_INT; break; }
-        if (x.t == CBH_T_DOUBLE) {
-          double d = as_f64(x.v);
-          if (d != d || d >= 9223372036854775807.0 || d <= -9223372036854775808.0) ST(sp - 1) = CBH_T_ERR;
-          else { ST(sp - 1) = CBH_T_INT; SV(sp - 1) = (u64)(i64)d; }
-          break;
-        }
-        if (x.t == CBH_T_TIMESTAMP) { i64 ns = (i64)x.v; i64 s = ns / 1000000000LL; if (ns % 1000000000LL < 0) --s; ST(sp - 1) = CBH_T_INT; SV(sp - 1) = (u64)s; break; }
-        if (x.t == CBH_T_DURATION) { ST(sp - 1) = CBH_T_INT; break; }
-        if (x.t == CBH_T_STRING) L.status |= CBH_ST_UNSUPPORTED;
-        ST(sp - 1) = CBH_T_ERR;
-        break;
-      }
-      case OP_TODOUBLE: {
-        Val x = TOPV(0);
-        if (x.t == CBH_T_DOUBLE) break;
-        if (x.t == CBH_T_INT) { ST(sp - 1) = CBH_T_DOUBLE; SV(sp - 1) = f64_bits((double)(i64)x.v); break; }
-        if (x.t == CBH_T_UINT) { ST(sp - 1) = CBH_T_DOUBLE; SV(sp - 1) = f64_bits((double)x.v); break; }
-        if (x.t == CBH_T_STRING) L.status |= CBH_ST_UNSUPPORTED;
-        ST(sp - 1) = CBH_T_ERR;
-        break;
-      }
-      case OP_INIPRANGE: {
-        Val y = TOPV(0), x = TOPV(1); --sp;
-        if (x.t != CBH_T_STRING || y.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
-        const u8 *pi, *pc2; u32 ni, nc;
-        str_span(c, (u32)x.v, pi, ni); str_span(c, (u32)y.v, pc2, nc);
-        bool v6 = false;
-        for (u32 i = 0; i < ni; ++i) v6 |= pi[i] == ':';
-        for (u32 i = 0; i < nc; ++i) v6 |= pc2[i] == ':';
-        if (v6) { L.status |= CBH_ST_UNSUPPORTED; ST(sp - 1) = CBH_T_ERR; break; }   // IPv6: host only
-        u32 slash = nc;
-        for (u32 i = 0; i < nc; ++i) if (pc2[i] == '/') { slash = i; break; }
-        u32 ip, net, bits = 0, nd = 0;
-        bool ok = slash < nc && parse_ipv4(pi, ni, ip) && parse_ipv4(pc2, slash, net);
-        for (u32 i = slash + 1; ok && i < nc; ++i) { if (!dig(pc2[i]) || nd >= 2) ok = false; else { bits = bits * 10 + (pc2[i] - '0'); ++nd; } }
-        if (ok && (nd == 0 || bits > 32 || (nd == 2 && pc2[slash + 1] == '0'))) ok = false;
-        if (!ok) { ST(sp - 1) = CBH_T_ERR; break; }
-        u32 mask = bits == 0 ? 0u : (0xFFFFFFFFu << (32 - bits));
-        ST(sp - 1) = CBH_T_BOOL; SV(sp - 1) = ((ip & mask) == (net & mask));
-        break;
-      }
-      case OP_HASINTERSECTION: case OP_ISSUBSET: {
-        Val y = TOPV(0), x = TOPV(1); --sp;
-        if (x.t != CBH_T_LIST || y.t != CBH_T_LIST) { ST(sp - 1) = CBH_T_ERR; break; }
-        // hasIntersection(x, y): some element of x is in y.  x.isSubset(y): every element of x is in y.
-        bool any = false, all = true;
-        for (u32 i = 0; i < cont_len(x.v); ++i) {
-          Val e = heap_get(c, cont_sel(x.v), cont_off(x.v) + i);
-          bool in = false;
-          for (u32 j = 0; j < cont_len(y.v) && !in; ++j) in = val_equal(c, L, e, heap_get(c, cont_sel(y.v), cont_off(y.v) + j));
-          any |= in; all &= in;
-        }
-        ST(sp - 1) = CBH_T_BOOL; SV(sp - 1) = (op == OP_HASINTERSECTION) ? any : all;
-        break;
-      }
-      case OP_UNSUPPORTED:
-      default:
-        L.status |= CBH_ST_UNSUPPORTED;
-        PUSHV(mk_err());
-        break;
-    }
+
+// comparison / membership operators on two already-loaded values -> bool or error
+__device__ inline Val compare_op(const Ctx& c, Lane& L, u32 op, Val x, Val y) {
+  if (x.t == CBH_T_ERR || y.t == CBH_T_ERR) return mk_err();
+  if (op == OP_EQ || op == OP_NE) {
+    bool e = val_equal(c, L, x, y);
+    return mk_bool(op == OP_EQ ? e : !e);
   }
-  L.status |= CBH_ST_UNSUPPORTED;  // step budget exhausted
-  return 0;
+  if (op == OP_IN) {
+    bool found = false;
+    if (y.t == CBH_T_LIST) {
+      u32 n = cont_len(y.v);
+      for (u32 i = 0; i < n && !found; ++i) found = val_equal(c, L, x, heap_get(c, cont_sel(y.v), cont_off(y.v) + i));
+    } else if (y.t == CBH_T_MAP) {
+      Val tmp; found = map_find(c, y, x, tmp);
+    } else return mk_err();
+    return mk_bool(found);
+  }
+  int r = val_compare(c, x, y);
+  if (r == 3) return mk_err();
+  bool res = false;
+  if (r != 2) res = (op == OP_LT) ? r < 0 : (op == OP_LE) ? r <= 0 : (op == OP_GT) ? r > 0 : r >= 0;
+  return mk_bool(res);
 }
+
+#ifndef CBH_HOSTSIM
+__attribute__((noinline))
+#endif
+__device__ Val compare_op_slow(const Ctx& c, Lane& L, u32 op, Val x, Val y) { return compare_op(c, L, op, x, y); }
+
+// Same-type fast paths of compare_op for the inline fused-leaf evaluation.
+// Returns 1 / 0 = result, -1 = CEL error, -2 = not covered (caller takes the slow path).
+__device__ __forceinline__ int fast_equal(Val x, Val y) {
+  if (x.t == y.t) {
+    if (x.t == CBH_T_DOUBLE) return as_f64(x.v) == as_f64(y.v);
+    if (x.t < CBH_T_LIST || x.t == CBH_T_TIMESTAMP || x.t == CBH_T_DURATION) return x.v == y.v;
+    return -2;   // containers
+  }
+  if (is_num(x.t) && is_num(y.t)) return -2;   // cross-type numeric equality
+  return 0;                                     // different types are simply unequal
+}
+__device__ __forceinline__ int fast_compare(const Ctx& c, u32 op, Val x, Val y) {
+  if (x.t == CBH_T_ERR || y.t == CBH_T_ERR) return -1;
+  if (op == OP_EQ || op == OP_NE) {
+    const int e = fast_equal(x, y);
+    if (e < 0) return e;
+    return (op == OP_EQ) ? e : 1 - e;
+  }
+  if (op == OP_IN) {
+    if (y.t != CBH_T_LIST) return -2;
+    const u32 n = cont_len(y.v), sel = cont_sel(y.v), off = cont_off(y.v);
+    int found = 0;
+    for (u32 i = 0; i < n; ++i) {
+      const int e = fast_equal(x, heap_get(c, sel, off + i));
+      if (e == -2) return -2;
+      found |= e;
+    }
+    return found;
+  }
+  if (x.t == CBH_T_DOUBLE && y.t == CBH_T_DOUBLE) {
+    const double a = as_f64(x.v), b = as_f64(y.v);
+    return (op == OP_LT) ? a < b : (op == OP_LE) ? a <= b : (op == OP_GT) ? a > b : a >= b;   // NaN: all false
+  }
+  if (x.t == CBH_T_INT && y.t == CBH_T_INT) {
+    const i64 a = (i64)x.v, b = (i64)y.v;
+    return (op == OP_LT) ? a < b : (op == OP_LE) ? a <= b : (op == OP_GT) ? a > b : a >= b;
+  }
+  return -2;
+}
+
+// operand of a fused leaf instruction: 0 = constant, 1 = attribute column, 2 = request string field
+__device__ __forceinline__ Val load_operand(const Ctx& c, const Lane& L, u32 kind, u32 arg) {
+  if (kind == 0) return mk(c.t.const_tag[arg], c.t.const_val[arg]);
+  if (kind == 1) {
+    size_t ix = (size_t)arg * c.b.n_requests + L.req;
+    u32 t = c.b.col_tag[ix];
+    return t == CBH_T_ABSENT ? mk_err() : mk(t, c.b.col_val[ix]);
+  }
+  return mk(CBH_T_STRING, c.b.req_u32[(size_t)arg * c.b.n_requests + L.req]);
+}
+

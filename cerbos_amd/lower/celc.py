@@ -24,7 +24,11 @@ from ..cel import parser as celparser
  OP_STARTSWITH, OP_ENDSWITH, OP_CONTAINS, OP_TIMESTAMP, OP_DURATION, OP_TIMESINCE, OP_NOW,
  OP_EDRHAS, OP_LOCAL, OP_ITER_BEGIN, OP_ITER_NEXT, OP_ITER_ACC, OP_ITER_END, OP_TOINT,
  OP_TODOUBLE, OP_TOSTRING_UNSUPPORTED, OP_INIPRANGE, OP_UNSUPPORTED, OP_TS_GETTER,
- OP_HASINTERSECTION, OP_ISSUBSET) = range(53)
+ OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN, OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC,
+ OP_TREE_END) = range(58)
+
+TREE_KINDS = {"all": 0, "any": 1, "none": 2}
+COND_LEAF = 0x80000000
 
 T_NULL, T_BOOL, T_INT, T_UINT, T_DOUBLE, T_STRING, T_LIST, T_MAP, T_TIMESTAMP, T_DURATION = range(10)
 T_ABSENT, T_ERR = 0xF0, 0xFF
@@ -246,7 +250,10 @@ class ProgramBuilder:
         fc.cond(cond)
         fc.emit(OP_RET)
         pc = len(self.code)
-        self.code.extend(fc.finish(pc))
+        words = fc.finish(pc)
+        self.code.extend(words)
+        if len(words) == 4 and (words[0] & 0xFF) == OP_LEAF_BIN:
+            pc |= COND_LEAF   # one fused leaf: the kernel evaluates it inline (cbh_check_wave.h eval_cond)
         self.programs[key] = pc
         self.max_stack = max(self.max_stack, fc.max_depth)
         self.max_locals = max(self.max_locals, fc.max_locals)
@@ -257,6 +264,12 @@ class ProgramBuilder:
 
 class _Unsupported(Exception):
     pass
+
+
+def _int_lit_as_double(ast):
+    if ast[0] == "lit" and ast[1] in ("int", "uint") and abs(ast[2]) <= (1 << 53):
+        return ("lit", "double", float(ast[2]))
+    return ast
 
 
 def _is_const(ast):
@@ -283,6 +296,7 @@ class _FuncCompiler:
         self.locals = {}       # var name -> slot
         self.max_locals = 0
         self.iter_depth = 0
+        self.tree_depth = 0
         self.cur_text = ""
 
     # -- emission helpers
@@ -349,6 +363,8 @@ class _FuncCompiler:
         if op == "expr":
             self.cur_text = c[1]
             ast = self.params.inline(celparser.parse(c[1]))
+            if self._fused_leaf(ast):
+                return
             d0 = self.depth
             self.expr(ast)
             assert self.depth == d0 + 1, (c[1], self.depth, d0)
@@ -358,16 +374,57 @@ class _FuncCompiler:
         if not kids:
             self.emit(OP_CONST, self.pb.const(T_BOOL, 1 if op in ("all", "none") else 0), +1)
             return
-        end = self.new_label()
-        jop = OP_JF if op == "all" else OP_JT
-        for i, kid in enumerate(kids):
+        # control flow is wave-uniform: no jumps; the interpreter keeps a per-lane "tree-live"
+        # predicate so that children after the deciding one record no errors (check.go:697-749)
+        kind = TREE_KINDS[op]
+        self.tree_depth += 1
+        if self.tree_depth > 16:
+            raise LoweringError("condition tree nests deeper than 16 levels")
+        self.emit(OP_TREE_BEGIN, kind)
+        for kid in kids:
             self.cond(kid)
-            if i + 1 < len(kids):
-                self.emit_ref(jop, end)
-                self.emit(OP_POP, 0, -1)
-        self.place(end)
-        if op == "none":
-            self.emit(OP_NOT)
+            self.emit(OP_TREE_ACC, kind, -1)
+        self.emit(OP_TREE_END, kind, +1)
+        self.tree_depth -= 1
+
+    # -- fused leaves: `operand <cmp|in> operand` with operands read straight from a column, a
+    #    request string field or the constant pool (the shape of almost every real condition)
+    def _simple_operand(self, ast):
+        """-> (kind, arg) with kind 0 const / 1 column / 2 request string, or None."""
+        k = ast[0]
+        if k == "lit" or (k in ("list", "map") and _is_const(ast)):
+            try:
+                t, v = self.pb._heap_value(ast)
+            except _Unsupported:
+                return None
+            return 0, self.pb.const(t, v)
+        if k in ("select", "index"):
+            p = self._path(ast)
+            if p is not None and p[0] == "col":
+                return 1, self.pb.column(p[1], p[2])
+            if p is not None and p[0] == "req":
+                return 2, p[1]
+        return None
+
+    def _fused_leaf(self, ast) -> bool:
+        if ast[0] != "bin" or ast[1] not in ("==", "!=", "<", "<=", ">", ">=", "in"):
+            return False
+        if self.locals:
+            return False
+        lhs, rhs = ast[2], ast[3]
+        if ast[1] != "in":
+            # request attributes always arrive as doubles (structpb); an int literal that a double
+            # represents exactly compares identically as a double under CEL's cross-type numeric
+            # comparison, and lets the device take the same-type fast path
+            lhs, rhs = _int_lit_as_double(lhs), _int_lit_as_double(rhs)
+        a = self._simple_operand(lhs)
+        b = self._simple_operand(rhs)
+        if a is None or b is None:
+            return False
+        self.emit(OP_LEAF_BIN, _BINOPS[ast[1]] | (a[0] << 8) | (b[0] << 12), +1)
+        self.word(a[1])
+        self.word(b[1])
+        return True
 
     # -- paths
     def _path(self, ast):
@@ -472,26 +529,15 @@ class _FuncCompiler:
             self._expr(ast[1])
             return self.emit(OP_NEG)
         if k in ("and", "or"):
-            end = self.new_label()
+            # both sides are evaluated (uniform control flow); AND/OR absorb errors like CEL
             self._expr(ast[1])
-            self.emit_ref(OP_JF if k == "and" else OP_JT, end)
             self._expr(ast[2])
-            self.emit(OP_AND if k == "and" else OP_OR, 0, -1)
-            self.place(end)
-            return
+            return self.emit(OP_AND if k == "and" else OP_OR, 0, -1)
         if k == "tern":
-            els, end = self.new_label(), self.new_label()
             self._expr(ast[1])
-            self.emit_ref(OP_JTERN, els, -1)
-            self.word_ref(end)
-            d0 = self.depth
             self._expr(ast[2])
-            self.emit_ref(OP_JMP, end)
-            self.place(els)
-            self.depth = d0
             self._expr(ast[3])
-            self.place(end)
-            return
+            return self.emit(OP_TERN, 0, -2)
         if k == "bin":
             op = ast[1]
             if op == "in":
@@ -578,7 +624,7 @@ class _FuncCompiler:
         self._expr(target)
         loop, end = self.new_label(), self.new_label()
         self.emit(OP_ITER_BEGIN, slot, -1)
-        self.word_ref_packed(end, kinds[kind])
+        self.word(kinds[kind])
         saved = dict(self.locals)
         slots = []
         for v in vars_:
@@ -596,7 +642,6 @@ class _FuncCompiler:
         assert self.depth == d0 + 1
         self.emit(OP_ITER_ACC, slot, -1)
         self.word_ref(loop)
-        self.word_ref(end)
         self.place(end)
         self.emit(OP_ITER_END, slot, +1)
         self.iter_depth -= 1

@@ -2,13 +2,20 @@
 // libcerbos_hip.so and nothing else).
 //
 // Compiles the *device* source of the decision kernel (cerbos_amd/csrc/cbh_kernels.h) as
-// plain host C++ by shimming the HIP keywords, and runs it one "lane" at a time.  This lets
-// the CPU-only test tier (-m "not gpu") exercise the lowering + bytecode + kernel logic
-// against the oracle and the reference's golden cases without a GPU.  It proves nothing
-// about performance and is not a fallback: the GPU tier re-runs the same cases through the
-// real library on an MI355X.
+// plain host C++ by shimming the HIP keywords.  One workgroup = 256 fibers (ucontext) on one
+// OS thread; the wave-level primitives the kernel uses (ballot / readlane) and
+// __syncthreads() are rendezvous points between the fibers of a wave / block, so a
+// wave-cooperative kernel runs with exactly the cross-lane semantics it has on the GPU as
+// long as every lane of a wave reaches every cross-lane call (the kernel's own discipline).
+// This lets the CPU-only test tier (-m "not gpu") exercise lowering + bytecode + kernel logic
+// against the oracle and the reference's golden cases.  It proves nothing about performance
+// and is not a fallback: the GPU tier re-runs the same cases through the real library.
+#include <ucontext.h>
+
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -19,44 +26,142 @@
 #define __host__
 #define __forceinline__ inline
 #define __shared__ static
-#define __launch_bounds__(x)
+#define __launch_bounds__(...)
 struct uint4 { uint32_t x, y, z, w; };
 struct Dim3 { uint32_t x = 0, y = 0, z = 0; };
-static thread_local Dim3 threadIdx, blockIdx;
+
+static const int HS_BLOCK = 256, HS_WAVE = 64;
+struct Fiber {
+  ucontext_t ctx;
+  std::vector<char> stack;
+  Dim3 tid, bid;
+  bool done = false;
+  int waiting = 0;      // 0 running, 1 wave rendezvous, 2 block barrier
+  uint64_t xchg = 0;    // value contributed to / received from a rendezvous
+  uint32_t arg = 0;
+  int op = 0;
+};
+static Fiber g_fibers[HS_BLOCK];
+static int g_cur = 0;
+static ucontext_t g_sched;
+#define threadIdx (g_fibers[g_cur].tid)
+#define blockIdx (g_fibers[g_cur].bid)
+
 static inline double __longlong_as_double(long long v) { double d; std::memcpy(&d, &v, 8); return d; }
 static inline long long __double_as_longlong(double d) { long long v; std::memcpy(&v, &d, 8); return v; }
 static inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p |= v; return o; }
 using std::trunc;
 
+static void hs_yield(int why) {
+  g_fibers[g_cur].waiting = why;
+  swapcontext(&g_fibers[g_cur].ctx, &g_sched);
+}
+enum { HS_OP_BALLOT = 1, HS_OP_READLANE = 2 };
+// wave primitives used by the kernel (see cbh_wave.h for the device versions)
+static inline uint64_t wave_ballot(bool p) {
+  Fiber& f = g_fibers[g_cur];
+  f.op = HS_OP_BALLOT; f.xchg = p ? 1 : 0;
+  hs_yield(1);
+  return g_fibers[g_cur].xchg;
+}
+static inline uint32_t wave_readlane(uint32_t v, uint32_t lane) {
+  Fiber& f = g_fibers[g_cur];
+  f.op = HS_OP_READLANE; f.xchg = v; f.arg = lane;
+  hs_yield(1);
+  return (uint32_t)g_fibers[g_cur].xchg;
+}
+static inline void __syncthreads() { hs_yield(2); }
+
 #include "../../cerbos_amd/csrc/cbh_kernels.h"
 #include "../../cerbos_amd/csrc/cbh_image.h"
 
 static thread_local std::string g_err;
-
 extern "C" const char* hostsim_last_error() { return g_err.c_str(); }
 
-// gbits: [3][n_strings] glob match bits of the batch-local strings (computed by the caller with
-// the Python simulation of the same automaton; the resolve kernel itself needs real LDS barriers).
+static KernelArgs* g_args;
+
+static void fiber_main() {
+  cbh_check_kernel(g_args);
+  g_fibers[g_cur].done = true;
+  g_fibers[g_cur].waiting = 0;
+  swapcontext(&g_fibers[g_cur].ctx, &g_sched);
+}
+
+static bool resolve_wave(int w) {
+  // all unfinished lanes of wave w are waiting at a wave rendezvous -> complete it
+  int base = w * HS_WAVE, first = -1, op = 0;
+  for (int l = 0; l < HS_WAVE; ++l) {
+    Fiber& f = g_fibers[base + l];
+    if (f.done) continue;
+    if (f.waiting != 1) return false;
+    if (first < 0) { first = l; op = f.op; }
+    else if (f.op != op) { std::fprintf(stderr, "hostsim: lanes of a wave diverged across different cross-lane ops\n"); std::abort(); }
+  }
+  if (first < 0) return false;
+  if (op == HS_OP_BALLOT) {
+    uint64_t m = 0;
+    for (int l = 0; l < HS_WAVE; ++l) if (!g_fibers[base + l].done && g_fibers[base + l].xchg) m |= 1ull << l;
+    for (int l = 0; l < HS_WAVE; ++l) if (!g_fibers[base + l].done) { g_fibers[base + l].xchg = m; g_fibers[base + l].waiting = 0; }
+  } else {
+    uint32_t lane = g_fibers[base + first].arg;
+    for (int l = 0; l < HS_WAVE; ++l)
+      if (!g_fibers[base + l].done && g_fibers[base + l].arg != lane) { std::fprintf(stderr, "hostsim: readlane index is not wave-uniform\n"); std::abort(); }
+    if (g_fibers[base + lane].done) { std::fprintf(stderr, "hostsim: readlane from an exited lane\n"); std::abort(); }
+    uint64_t v = g_fibers[base + lane].xchg;
+    for (int l = 0; l < HS_WAVE; ++l) if (!g_fibers[base + l].done) { g_fibers[base + l].xchg = v; g_fibers[base + l].waiting = 0; }
+  }
+  return true;
+}
+
+static void run_block(uint32_t blk) {
+  for (int i = 0; i < HS_BLOCK; ++i) {
+    Fiber& f = g_fibers[i];
+    if (f.stack.empty()) f.stack.resize(256 * 1024);
+    f.done = false; f.waiting = 0; f.tid.x = i; f.bid.x = blk;
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack.data();
+    f.ctx.uc_stack.ss_size = f.stack.size();
+    f.ctx.uc_link = &g_sched;
+    makecontext(&f.ctx, fiber_main, 0);
+  }
+  for (;;) {
+    bool progressed = false, all_done = true;
+    for (int i = 0; i < HS_BLOCK; ++i) {
+      Fiber& f = g_fibers[i];
+      if (f.done) continue;
+      all_done = false;
+      if (f.waiting == 0) { g_cur = i; swapcontext(&g_sched, &f.ctx); progressed = true; }
+    }
+    if (all_done) return;
+    for (int w = 0; w < HS_BLOCK / HS_WAVE; ++w) progressed |= resolve_wave(w);
+    // block barrier: every unfinished fiber waits at __syncthreads
+    bool all_bar = true; int n = 0;
+    for (int i = 0; i < HS_BLOCK; ++i) if (!g_fibers[i].done) { ++n; all_bar &= g_fibers[i].waiting == 2; }
+    if (n && all_bar) { for (int i = 0; i < HS_BLOCK; ++i) g_fibers[i].waiting = 0; progressed = true; }
+    if (!progressed) { std::fprintf(stderr, "hostsim: deadlock (lanes wait at different sync points)\n"); std::abort(); }
+  }
+}
+
+// gbits: [3][n_strings] glob match bits of the batch-local strings (computed by the caller with the
+// Python simulation of the same automaton).
 extern "C" int hostsim_check(const void* blob, size_t len, const cbh_batch* in, const cbh_params* p,
                              cbh_result* out, uint64_t* gbits) {
-  TableDev t{};
+  KernelArgs a{};
   std::vector<uint32_t> meta;
   const uint8_t* base = static_cast<const uint8_t*>(blob);
-  if (const char* e = cbh_parse_image(t, meta, base, base, len)) { g_err = e; return -1; }
+  if (const char* e = cbh_parse_image(a.t, meta, base, base, len)) { g_err = e; return -1; }
   if (in->n_columns != meta[CBH_M_NCOLUMNS]) { g_err = "n_columns mismatch"; return -1; }
-  BatchDev b{};
+  BatchDev& b = a.b;
   b.n_requests = in->n_requests; b.n_tuples = in->n_tuples; b.n_roles = in->n_roles;
   b.n_columns = in->n_columns; b.n_strings = in->n_strings; b.heap_len = in->heap_len;
   b.req_u32 = in->req_u32; b.roles = in->roles; b.tuple_req = in->tuple_req; b.tuple_action = in->tuple_action;
   b.col_tag = in->col_tag; b.col_val = in->col_val; b.heap_tag = in->heap_tag; b.heap_val = in->heap_val;
   b.str_off = in->str_off; b.str_bytes = in->str_bytes; b.str_flags = in->str_flags; b.gbits = gbits;
-  OutDev o{out->effect, out->policy, out->scope, out->status, out->edr_mask};
-  if (o.edr) std::memset(o.edr, 0, sizeof(uint64_t) * in->n_requests);
+  a.o = OutDev{out->effect, out->policy, out->scope, out->status, out->edr_mask};
+  a.now_ns = p->now_ns; a.flags = p->flags;
+  if (a.o.edr) std::memset(a.o.edr, 0, sizeof(uint64_t) * in->n_requests);
+  g_args = &a;
   const uint32_t nblocks = (in->n_tuples + CBH_BLOCK - 1) / CBH_BLOCK;
-  for (uint32_t blk = 0; blk < nblocks; ++blk)
-    for (uint32_t th = 0; th < CBH_BLOCK; ++th) {
-      blockIdx.x = blk; threadIdx.x = th;
-      cbh_check_kernel(t, b, o, p->now_ns, p->flags);
-    }
+  for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
   return 0;
 }
