@@ -74,6 +74,7 @@ enum CbhMeta {
 #define CBH_MF_USES_RUNTIME_EDR 1u
 #define CBH_MF_HAS_PARENT_ROLES 2u
 #define CBH_MF_HAS_ROLE_POLICIES 4u
+#define CBH_MF_HAS_GENERIC_PROGRAMS 8u  /* some program needs the operand-stack interpreter */
 
 // Directory: open addressing, linear probing, key.x == CBH_NONE marks an empty slot.
 struct CbhHashSlot { // 32 bytes
@@ -93,6 +94,8 @@ enum CbhBucketType {
 // Condition reference (row / derived-role cond fields): bit31 set -> the program at (ref & ~bit31)
 // is a single OP_LEAF_BIN + OP_RET and may be evaluated inline.
 #define CBH_COND_LEAF 0x80000000u
+#define CBH_COND_LEAFTREE 0x40000000u  /* all/any/none tree of fused leaves: inline, no operand stack */
+#define CBH_COND_PC_MASK 0x3FFFFFFFu
 
 // Pattern reference: bit31 set -> glob index within the dimension, else literal string id.
 #define CBH_PAT_GLOB 0x80000000u

@@ -13,6 +13,10 @@
 // Discipline (also what tests/hostsim emulates): no lane returns early; every cross-lane call
 // (wave_ballot / wave_readlane / run_uniform) is reached by all 64 lanes under uniform control
 // flow.  Divergent branches contain only per-lane code.
+//
+// Two instantiations: GENERIC = true carries the operand-stack interpreter (LDS stack, a real
+// function call); GENERIC = false is selected by the host when every program of the table is a
+// fused leaf or a tree of fused leaves (the common case) and needs neither LDS nor a call.
 #pragma once
 #include "cbh_interp.h"
 
@@ -65,48 +69,90 @@ __device__ inline bool lane_has_parent_role(const TableDev& t, const BatchDev& b
   return false;
 }
 
+// One fused leaf (OP_LEAF_BIN word + two operand words at `pc`) for a lane: 0 false, 1 true, 3 CEL error.
+__device__ __forceinline__ int leaf_value(const Ctx& c, Lane& L, u32 w, u32 a0, u32 a1) {
+  const u32 a = w >> 8;
+  const Val x = load_operand(c, L, (a >> 8) & 0xF, a0);
+  const Val y = load_operand(c, L, (a >> 12) & 0xF, a1);
+  const int f = fast_compare(c, a & 0xFF, x, y);
+  if (f >= 0) return f;
+  if (f == -1) return 3;
+  const Val v = compare_op_slow(c, L, a & 0xFF, x, y);
+  if (v.t == CBH_T_ERR) return 3;
+  return (v.t == CBH_T_BOOL && v.v) ? 1 : 0;
+}
+
 // Evaluate a condition reference for the lanes with active=true (all lanes call together).
-// Bit 31 of the reference marks a program that is one fused leaf: it is evaluated inline -
-// no call, no operand stack - which is the shape of almost every real-world condition.
+// Per lane: 0 = not satisfied, 1 = satisfied, 2 = strict-mode evaluation error.
+//   CBH_COND_LEAF     one fused leaf: evaluated inline
+//   CBH_COND_LEAFTREE all/any/none tree whose leaves are all fused leaves: inline, no operand
+//                     stack (each TREE_ACC consumes the value its child just produced)
+//   otherwise         the operand-stack interpreter (GENERIC instantiation only)
+template <bool GENERIC>
 __device__ __forceinline__ int eval_cond(const Ctx& c, Lane& L, u32 ref, bool active) {
+  const bool strict = (c.flags & CBH_F_STRICT_EVALUATION) != 0;
   if (ref & CBH_COND_LEAF) {
-    const u32 pc = ref & ~CBH_COND_LEAF;
+    const u32 pc = ref & CBH_COND_PC_MASK;
     const u32 w = uload(&c.t.code[pc]), a0 = uload(&c.t.code[pc + 1]), a1 = uload(&c.t.code[pc + 2]);
-    const u32 a = w >> 8;
     int r = 0;
     if (active) {
-      const Val x = load_operand(c, L, (a >> 8) & 0xF, a0);
-      const Val y = load_operand(c, L, (a >> 12) & 0xF, a1);
-      const int f = fast_compare(c, a & 0xFF, x, y);
-      Val v = f >= 0 ? mk_bool(f != 0) : (f == -1 ? mk_err() : compare_op_slow(c, L, a & 0xFF, x, y));
-      if (v.t == CBH_T_ERR) {
-        L.status |= CBH_ST_CEL_ERROR;
-        r = (c.flags & CBH_F_STRICT_EVALUATION) ? 2 : 0;
-      } else r = (v.t == CBH_T_BOOL && v.v) ? 1 : 0;
+      r = leaf_value(c, L, w, a0, a1);
+      if (r == 3) { L.status |= CBH_ST_CEL_ERROR; r = strict ? 2 : 0; }
     }
     return r;
   }
-  return run_uniform(c, L, ref, active);
+  if (ref & CBH_COND_LEAFTREE) {
+    u32 pc = ref & CBH_COND_PC_MASK;
+    bool live = active, last = false;
+    int result = 0;
+    u32 saved = 0, acc = 0, depth = 0;
+    for (;;) {
+      const u32 w = uload(&c.t.code[pc]); ++pc;
+      const u32 op = w & 0xFFu, a = w >> 8;
+      if (op == OP_LEAF_BIN) {
+        const u32 a0 = uload(&c.t.code[pc]), a1 = uload(&c.t.code[pc + 1]); pc += 2;
+        last = false;
+        if (live) {   // leaves after the deciding one are not evaluated (check.go:697-749)
+          const int v = leaf_value(c, L, w, a0, a1);
+          if (v == 3) { L.status |= CBH_ST_CEL_ERROR; if (strict) { result = 2; live = false; } }
+          last = v == 1;
+        }
+      } else if (op == OP_TREE_BEGIN) {
+        const u32 bit = 1u << depth;
+        saved = live ? (saved | bit) : (saved & ~bit);
+        acc = (a == 0) ? (acc | bit) : (acc & ~bit);
+        ++depth;
+      } else if (op == OP_TREE_ACC) {
+        const u32 bit = 1u << (depth - 1);
+        if (live) {
+          if (a == 0) { if (!last) { acc &= ~bit; live = false; } }
+          else if (last) { acc |= bit; live = false; }
+        }
+      } else if (op == OP_TREE_END) {
+        --depth;
+        const u32 bit = 1u << depth;
+        if (result != 2) live = (saved & bit) != 0;
+        last = ((acc & bit) != 0) != (a == 2);
+      } else break;   // OP_RET
+    }
+    if (result == 2) return 2;
+    return (active && last) ? 1 : 0;
+  }
+  if (GENERIC) return run_uniform(c, L, ref, active);
+  if (active) L.status |= CBH_ST_UNSUPPORTED;   // unreachable: the host picks the GENERIC kernel for such tables
+  return 0;
 }
 
-__global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs* __restrict__ ka) {
+template <bool GENERIC>
+__device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ctx& c) {
   const TableDev& t = ka->t;
   const BatchDev& b = ka->b;
   const OutDev& o = ka->o;
-  const i64 now_ns = ka->now_ns;
   const u32 flags = ka->flags;
-  __shared__ u64 s_val[CBH_STACK_DEPTH * CBH_BLOCK];
-  __shared__ u64 l_val[CBH_MAX_LOCALS * CBH_BLOCK];
-  __shared__ u64 it_cont[CBH_MAX_ITERS * CBH_BLOCK];
-  __shared__ u32 it_idx[CBH_MAX_ITERS * CBH_BLOCK];
-  __shared__ u32 it_state[CBH_MAX_ITERS * CBH_BLOCK];
-  __shared__ u8 s_tag[CBH_STACK_DEPTH * CBH_BLOCK];
-  __shared__ u8 l_tag[CBH_MAX_LOCALS * CBH_BLOCK];
 
   const u32 tup = blockIdx.x * CBH_BLOCK + threadIdx.x;
   const bool valid = tup < b.n_tuples;
   const u32 tix = valid ? tup : 0;   // tail lanes shadow tuple 0 and never store
-  Ctx c{t, b, now_ns, flags, threadIdx.x, s_val, s_tag, l_val, l_tag, it_cont, it_idx, it_state};
 
   const u32 req = b.tuple_req[tix];
   const u32 act = b.tuple_action[tix];
@@ -212,14 +258,11 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs* 
                                            lane_has_parent_role(t, b, poff, pcnt, role_off, role_cnt, pr_scope_key, has_parents));
                 if (wave_ballot(applies) == 0) continue;
                 int r = 1;
-                if (cond != CBH_NONE) r = eval_cond(c, L, cond, applies);
+                if (cond != CBH_NONE) r = eval_cond<GENERIC>(c, L, cond, applies);
                 if (applies) { if (r == 2) derr = true; else if (r == 1) m |= 1ull << bit; }
               }
             }
-            if (S) {
-              L.edr = m; L.edr_err = derr;
-              edr_acc |= m;
-            }
+            if (S) { L.edr = m; L.edr_err = derr; edr_acc |= m; }
           }
 
           if (is_res && has_rolepol) {
@@ -257,7 +300,7 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs* 
                   for (u32 a = 0; a < ac; ++a) am |= pat_match(uload(&t.pool[ao + a]), act, act_bits);
                   mm = mm && am;
                   if (wave_ballot(mm) == 0) continue;
-                  const int r = eval_cond(c, L, cond, mm);   // synthetic row = DENY if none(cond)
+                  const int r = eval_cond<GENERIC>(c, L, cond, mm);   // synthetic row = DENY if none(cond)
                   if (mm && r == 2) {
                     eff = CBH_EFFECT_DENY; pol = ((u32)CBH_P_TABLE << 28) | rp.z; scp = si;
                     action_done = true; S = false; in2 = false;
@@ -285,10 +328,10 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs* 
               const u32 drc = uload(&t.rows[CBH_ROW_DRCOND * t.n_rows + row]);
               const u32 cnd = uload(&t.rows[CBH_ROW_COND * t.n_rows + row]);
               int r = 1;
-              if (drc != CBH_NONE) r = eval_cond(c, L, drc, m);                    // check.go:328-366
+              if (drc != CBH_NONE) r = eval_cond<GENERIC>(c, L, drc, m);           // check.go:328-366
               const bool m2 = m && r == 1;
               if (cnd != CBH_NONE && wave_ballot(m2) != 0) {                        // check.go:368-380
-                const int r2 = eval_cond(c, L, cnd, m2);
+                const int r2 = eval_cond<GENERIC>(c, L, cnd, m2);
                 if (m2) r = r2;
               }
               if (m && r == 2) {   // strict evaluation error: DENY attributed to the row's policy
@@ -321,11 +364,30 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs* 
 
   if (valid) {
     // the only global writes of the kernel come last, so every table read above is a read of
-    // never-clobbered memory (lets the compiler keep uniform reads on the scalar unit)
+    // never-clobbered memory
     if (o.edr && edr_acc) atomicOr(reinterpret_cast<unsigned long long*>(&o.edr[req]), (unsigned long long)edr_acc);
     o.effect[tup] = (u8)eff;
     if (o.policy) o.policy[tup] = pol;
     if (o.scope) o.scope[tup] = scp;
     if (o.status) o.status[tup] = (u8)((L.status & CBH_ST_UNSUPPORTED) ? CBH_ST_UNSUPPORTED : (L.status & CBH_ST_CEL_ERROR));
   }
+}
+
+// GENERIC instantiation: operand stack, locals and iteration slots in LDS, laid out [slot][lane].
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs* __restrict__ ka) {
+  __shared__ u64 s_val[CBH_STACK_DEPTH * CBH_BLOCK];
+  __shared__ u64 l_val[CBH_MAX_LOCALS * CBH_BLOCK];
+  __shared__ u64 it_cont[CBH_MAX_ITERS * CBH_BLOCK];
+  __shared__ u32 it_idx[CBH_MAX_ITERS * CBH_BLOCK];
+  __shared__ u32 it_state[CBH_MAX_ITERS * CBH_BLOCK];
+  __shared__ u8 s_tag[CBH_STACK_DEPTH * CBH_BLOCK];
+  __shared__ u8 l_tag[CBH_MAX_LOCALS * CBH_BLOCK];
+  Ctx c{ka->t, ka->b, ka->now_ns, ka->flags, threadIdx.x, s_val, s_tag, l_val, l_tag, it_cont, it_idx, it_state};
+  check_body<true>(ka, c);
+}
+
+// Leaf-only instantiation: no LDS, no calls.
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel_leaf(const KernelArgs* __restrict__ ka) {
+  Ctx c{ka->t, ka->b, ka->now_ns, ka->flags, threadIdx.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  check_body<false>(ka, c);
 }

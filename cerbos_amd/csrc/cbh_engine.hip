@@ -227,7 +227,10 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   HIPCHK(hipEventRecord(t->ev[2], s));
   if (d.n_tuples) {
     const u32 grid = (d.n_tuples + CBH_BLOCK - 1) / CBH_BLOCK;
-    hipLaunchKernelGGL(cbh_check_kernel, dim3(grid), dim3(CBH_BLOCK), 0, s, (const KernelArgs*)b->d_args);
+    if (t->dev.flags & CBH_MF_HAS_GENERIC_PROGRAMS)
+      hipLaunchKernelGGL(cbh_check_kernel, dim3(grid), dim3(CBH_BLOCK), 0, s, (const KernelArgs*)b->d_args);
+    else
+      hipLaunchKernelGGL(cbh_check_kernel_leaf, dim3(grid), dim3(CBH_BLOCK), 0, s, (const KernelArgs*)b->d_args);
   }
   HIPCHK(hipEventRecord(t->ev[3], s));
   HIPCHK(hipGetLastError());

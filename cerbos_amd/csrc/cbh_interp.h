@@ -27,8 +27,23 @@ __device__ __forceinline__ u32 uniform(u32 v) { return (u32)__builtin_amdgcn_rea
 static inline u32 uniform(u32 v) { return v; }
 #endif
 __device__ __forceinline__ u32 first_lane(u64 m) { return (u32)__builtin_ctzll(m); }
-// a value every lane computed identically (uniform address) -> scalar register
-__device__ __forceinline__ u32 uload(const u32* p) { return uniform(*p); }
+// Read of table data at a wave-uniform address.  The table image is immutable while kernels run,
+// so it is read through the constant address space: the compiler emits s_load_dword (scalar
+// cache, result in an SGPR) instead of a 64-lane vector load of one address.
+#ifndef CBH_HOSTSIM
+__device__ __forceinline__ u32 uload(const u32* p) {
+  typedef const __attribute__((address_space(4))) u32* cptr;
+  return *(cptr)(unsigned long long)(p);
+}
+#else
+static inline u32 uload(const u32* p) { return *p; }
+#endif
+// a pointer every lane holds identically, moved to scalar registers (e.g. after it travelled through
+// memory into a non-inlined function, where the compiler can no longer tell it is uniform)
+template <typename T> __device__ __forceinline__ const T* uniform_ptr(const T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  return (const T*)(((unsigned long long)uniform((u32)(v >> 32)) << 32) | uniform((u32)v));
+}
 __device__ __forceinline__ u64 wave_readlane64(u64 v, u32 lane) {
   return (u64)wave_readlane((u32)v, lane) | ((u64)wave_readlane((u32)(v >> 32), lane) << 32);
 }
@@ -63,8 +78,9 @@ __device__ int run_uniform(const Ctx& c, Lane& L, u32 pc, bool active) {
   u32 tree_acc = 0;       // bit d = accumulator at tree depth d
   int tree_depth = 0;
   pc = uniform(pc);
+  const u32* code = uniform_ptr(c.t.code);
   for (u32 steps = 0; steps < 1000000u; ++steps) {
-    const u32 w = uload(&c.t.code[pc]); ++pc;
+    const u32 w = uload(&code[pc]); ++pc;
     const u32 op = w & 0xFFu, a = w >> 8;
     const bool live_in = live;        // status bits raised by a lane that is not live are dropped
     const u32 status_in = L.status;
@@ -116,7 +132,7 @@ __device__ int run_uniform(const Ctx& c, Lane& L, u32 pc, bool active) {
         break;
       }
       case OP_LEAF_BIN: {   // fused leaf: operands straight from columns / constants
-        const u32 a0 = uload(&c.t.code[pc]), a1 = uload(&c.t.code[pc + 1]); pc += 2;
+        const u32 a0 = uload(&code[pc]), a1 = uload(&code[pc + 1]); pc += 2;
         Val x = load_operand(c, L, (a >> 8) & 0xF, a0);
         Val y = load_operand(c, L, (a >> 12) & 0xF, a1);
         Val r = compare_op(c, L, a & 0xFF, x, y);
@@ -247,7 +263,7 @@ __device__ int run_uniform(const Ctx& c, Lane& L, u32 pc, bool active) {
       // ---- comprehensions: wave-uniform loop, per-lane progress
       case OP_ITER_BEGIN: {   // a = slot; next word = kind
         Val x = TOPV(0); --sp;
-        const u32 kind = uload(&c.t.code[pc]); ++pc;
+        const u32 kind = uload(&code[pc]); ++pc;
         u32 st = kind | (live ? ITS_ENTRY_LIVE : 0);
         if (x.t != CBH_T_LIST && x.t != CBH_T_MAP) { st |= ITS_FAIL; x.v = 0; }
         else { if (live) st |= ITS_RUNNING; if (x.t == CBH_T_MAP) st |= ITS_MAP; }   // lanes that are not live sit the loop out
@@ -257,7 +273,7 @@ __device__ int run_uniform(const Ctx& c, Lane& L, u32 pc, bool active) {
         break;
       }
       case OP_ITER_NEXT: {    // a = slot; next words: end_pc, locals (v1 | v2 << 8 | nvars << 16)
-        const u32 end_pc = uload(&c.t.code[pc]), lw = uload(&c.t.code[pc + 1]); pc += 2;
+        const u32 end_pc = uload(&code[pc]), lw = uload(&code[pc + 1]); pc += 2;
         const u64 cont = c.it_cont[a * CBH_BLOCK + c.tid];
         const u32 i = c.it_idx[a * CBH_BLOCK + c.tid];
         u32 st = c.it_state[a * CBH_BLOCK + c.tid];
@@ -284,7 +300,7 @@ __device__ int run_uniform(const Ctx& c, Lane& L, u32 pc, bool active) {
         break;
       }
       case OP_ITER_ACC: {     // a = slot; next word = loop_pc
-        const u32 loop_pc = uload(&c.t.code[pc]); ++pc;
+        const u32 loop_pc = uload(&code[pc]); ++pc;
         Val x = TOPV(0); --sp;
         u32 st = c.it_state[a * CBH_BLOCK + c.tid];
         if (st & ITS_RUNNING) {

@@ -334,7 +334,8 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
     meta[M_CODE_LEN] = len(pb.code)
     meta[M_FLAGS] = ((MF_USES_RUNTIME_EDR if pb.uses_runtime else 0)
                      | (2 if any(v for r in rt["parent_roles"].values() for v in r.values()) else 0)
-                     | (4 if rp_buckets else 0))
+                     | (4 if rp_buckets else 0)
+                     | (8 if pb.has_generic else 0))
     meta[M_MAX_STACK] = pb.max_stack
     meta[M_NDRNAMES] = len(lt.dr_names)
     meta[M_NFA_WORDS_ACTION] = lt.nfas[0].words

@@ -29,6 +29,24 @@ from ..cel import parser as celparser
 
 TREE_KINDS = {"all": 0, "any": 1, "none": 2}
 COND_LEAF = 0x80000000
+COND_LEAFTREE = 0x40000000
+COND_PC_MASK = 0x3FFFFFFF
+
+
+def _is_leaf_tree(words):
+    """True if the program is only TREE_* structure around fused leaves (no operand stack needed)."""
+    i, n = 0, len(words)
+    while i < n:
+        op = words[i] & 0xFF
+        if op == OP_LEAF_BIN:
+            i += 3
+        elif op in (OP_TREE_BEGIN, OP_TREE_ACC, OP_TREE_END):
+            i += 1
+        elif op == OP_RET and i == n - 1:
+            return True
+        else:
+            return False
+    return False
 
 T_NULL, T_BOOL, T_INT, T_UINT, T_DOUBLE, T_STRING, T_LIST, T_MAP, T_TIMESTAMP, T_DURATION = range(10)
 T_ABSENT, T_ERR = 0xF0, 0xFF
@@ -171,6 +189,7 @@ class ProgramBuilder:
         self.dr_names = {}                 # derived role name -> bit
         self.unsupported = []              # [(expr text, reason)]
         self.uses_runtime = False
+        self.has_generic = False           # some program needs the operand-stack interpreter
         self.max_stack = 0
         self.max_locals = 0
 
@@ -252,8 +271,14 @@ class ProgramBuilder:
         pc = len(self.code)
         words = fc.finish(pc)
         self.code.extend(words)
+        if pc >= COND_PC_MASK:
+            raise LoweringError("bytecode tape exceeds 2^30 words")
         if len(words) == 4 and (words[0] & 0xFF) == OP_LEAF_BIN:
             pc |= COND_LEAF   # one fused leaf: the kernel evaluates it inline (cbh_check_wave.h eval_cond)
+        elif _is_leaf_tree(words):
+            pc |= COND_LEAFTREE
+        else:
+            self.has_generic = True
         self.programs[key] = pc
         self.max_stack = max(self.max_stack, fc.max_depth)
         self.max_locals = max(self.max_locals, fc.max_locals)
