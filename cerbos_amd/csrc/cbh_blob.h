@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define CBH_BLOB_MAGIC 0x31484243u /* "CBH1" */
-#define CBH_BLOB_VERSION 4u
+#define CBH_BLOB_VERSION 5u
 
 struct CbhBlobHeader {  // 32 bytes
   uint32_t magic;
@@ -33,10 +33,10 @@ enum CbhSectionId {
   CBH_SEC_SCOPE_FLAGS = 5, // u32[NS]  bit0 resource map, bit1 principal map, bits 2..3 scope permissions
   CBH_SEC_SCOPE_SID = 6,   // u32[NS]  string id of the scope
   CBH_SEC_HASH = 7,        // CbhHashSlot[nslots]
-  CBH_SEC_ROWS = 8,        // u32[CBH_ROW_NF][n_rows]  field-major
-  CBH_SEC_RPROWS = 9,      // u32[CBH_RP_NF][n_rprows]
+  CBH_SEC_ROWS = 8,        // u32[n_rows][8]   row-major records (CbhRowField order + pad): one s_load_dwordx8 each
+  CBH_SEC_RPROWS = 9,      // u32[n_rprows][4] row-major records (CbhRpField order)
   CBH_SEC_U32POOL = 10,    // u32[] (pattern lists, parent-role lists)
-  CBH_SEC_DR = 11,         // u32[CBH_DR_NF][n_dr]
+  CBH_SEC_DR = 11,         // u32[n_dr][4]     row-major records (CbhDrField order)
   CBH_SEC_CODE = 12,       // u32[]
   CBH_SEC_CONST_TAG = 13,  // u8[]
   CBH_SEC_CONST_VAL = 14,  // u64[]

@@ -31,15 +31,44 @@ __device__ __forceinline__ bool roleset_has(const TableDev& t, const RoleSet& rs
   return false;
 }
 
+// Table records are stored row-major and naturally aligned so that one wide scalar load
+// (s_load_dwordx4 / x8) fetches a whole record at a wave-uniform index.
+struct __attribute__((aligned(32))) TblRow { u32 action, role, resource, flags, cond, drcond, policy, pad; };
+struct __attribute__((aligned(16))) TblRp { u32 resource, allow_off, allow_cnt, cond; };
+struct __attribute__((aligned(16))) TblDr { u32 name, parents_off, parents_cnt, cond; };
+struct __attribute__((aligned(32))) TblSlot { u32 k0, k1, k2, k3, v0, v1, v2, v3; };
+
+template <typename R>
+__device__ __forceinline__ R uload_rec(const u32* base, u32 idx) {
+#ifndef CBH_HOSTSIM
+  static_assert(sizeof(R) == 16 || sizeof(R) == 32, "table records are 4 or 8 dwords");
+  const unsigned long long addr = (unsigned long long)(base + (size_t)idx * (sizeof(R) / 4));
+  R r;
+  if constexpr (sizeof(R) == 32) {
+    typedef u32 u32x8 __attribute__((ext_vector_type(8)));
+    const u32x8 v = *(const __attribute__((address_space(4))) u32x8*)addr;
+    __builtin_memcpy(&r, &v, 32);
+  } else {
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = *(const __attribute__((address_space(4))) u32x4*)addr;
+    __builtin_memcpy(&r, &v, 16);
+  }
+  return r;
+#else
+  R r;   // the host copy of the image carries no alignment guarantee
+  __builtin_memcpy(&r, base + (size_t)idx * (sizeof(R) / 4), sizeof(R));
+  return r;
+#endif
+}
+
 // directory probe with wave-uniform key -> wave-uniform result
 __device__ inline bool udir_find(const TableDev& t, u32 k0, u32 k1, u32 k2, u32 k3, uint4& v) {
   u32 i = hash4(k0, k1, k2, k3) & t.hash_mask;
   for (u32 probe = 0; probe <= t.hash_mask; ++probe) {
-    const u32* s = reinterpret_cast<const u32*>(&t.hash[i]);
-    const u32 kx = uload(s);
-    if (kx == CBH_NONE) return false;
-    if (kx == k0 && uload(s + 1) == k1 && uload(s + 2) == k2 && uload(s + 3) == k3) {
-      v.x = uload(s + 4); v.y = uload(s + 5); v.z = uload(s + 6); v.w = uload(s + 7);
+    const TblSlot s = uload_rec<TblSlot>(reinterpret_cast<const u32*>(t.hash), i);
+    if (s.k0 == CBH_NONE) return false;
+    if (s.k0 == k0 && s.k1 == k1 && s.k2 == k2 && s.k3 == k3) {
+      v.x = s.v0; v.y = s.v1; v.z = s.v2; v.w = s.v3;
       return true;
     }
     i = (i + 1) & t.hash_mask;
@@ -164,6 +193,21 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
   const u32 r_scope = RQ(CBH_RQ_R_SCOPE), r_ver = RQ(CBH_RQ_R_VERSION);
   const u32 role_off = RQ(CBH_RQ_ROLE_OFF), role_cnt = RQ(CBH_RQ_ROLE_CNT);
 #undef RQ
+  // column cache: issue every load of this lane's request attributes now, park them in LDS
+  {
+    u8 tg[CBH_CACHE_COLS]; u64 vl[CBH_CACHE_COLS];
+#pragma unroll
+    for (u32 k = 0; k < CBH_CACHE_COLS; ++k) {
+      if (k < c.n_cached) {
+        const size_t ix = (size_t)k * NR + req;
+        tg[k] = b.col_tag[ix]; vl[k] = b.col_val[ix];
+      }
+    }
+#pragma unroll
+    for (u32 k = 0; k < CBH_CACHE_COLS; ++k) {
+      if (k < c.n_cached) { c.cc_tag[k * CBH_BLOCK + c.tid] = tg[k]; c.cc_val[k * CBH_BLOCK + c.tid] = vl[k]; }
+    }
+  }
   const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
   const bool strict = (flags & CBH_F_STRICT_EVALUATION) != 0;
   const bool want_edr = (flags & CBH_F_WANT_DERIVED_ROLES) != 0 || (t.flags & CBH_MF_USES_RUNTIME_EDR) != 0;
@@ -250,10 +294,8 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
             u64 m = 0; bool derr = false;
             if (have_bucket) {
               for (u32 d = bucket.z; d < bucket.z + bucket.w; ++d) {
-                const u32 pcnt = uload(&t.dr[CBH_DR_PARENTS_CNT * t.n_dr + d]);
-                const u32 poff = uload(&t.dr[CBH_DR_PARENTS_OFF * t.n_dr + d]);
-                const u32 cond = uload(&t.dr[CBH_DR_COND * t.n_dr + d]);
-                const u32 bit = uload(&t.dr[CBH_DR_NAME * t.n_dr + d]);
+                const TblDr dr = uload_rec<TblDr>(t.dr, d);
+                const u32 pcnt = dr.parents_cnt, poff = dr.parents_off, cond = dr.cond, bit = dr.name;
                 const bool applies = S && (pcnt == CBH_NONE ||
                                            lane_has_parent_role(t, b, poff, pcnt, role_off, role_cnt, pr_scope_key, has_parents));
                 if (wave_ballot(applies) == 0) continue;
@@ -282,19 +324,17 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
                 if (!udir_find(t, CBH_B_ROLEPOL, g_ver, si, g_sr, rp)) continue;
                 bool any_action = false;
                 for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
-                  const u32 rres = uload(&t.rprows[CBH_RP_RESOURCE * t.n_rprows + row]);
-                  const u32 ao = uload(&t.rprows[CBH_RP_ALLOW_OFF * t.n_rprows + row]);
-                  const u32 ac = uload(&t.rprows[CBH_RP_ALLOW_CNT * t.n_rprows + row]);
+                  const TblRp rr = uload_rec<TblRp>(t.rprows, row);
+                  const u32 rres = rr.resource, ao = rr.allow_off, ac = rr.allow_cnt;
                   if (!pat_match(rres, kind, kind_bits)) continue;   // kind is uniform within a resource group
                   for (u32 a = 0; a < ac; ++a) any_action |= pat_match(uload(&t.pool[ao + a]), act, act_bits);
                 }
                 bool deny = in2 && !any_action;   // no binding for the resource, or no allow-action matched (index.go:436-461)
                 for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
-                  const u32 cond = uload(&t.rprows[CBH_RP_COND * t.n_rprows + row]);
+                  const TblRp rr = uload_rec<TblRp>(t.rprows, row);
+                  const u32 cond = rr.cond;
                   if (cond == CBH_NONE) continue;
-                  const u32 rres = uload(&t.rprows[CBH_RP_RESOURCE * t.n_rprows + row]);
-                  const u32 ao = uload(&t.rprows[CBH_RP_ALLOW_OFF * t.n_rprows + row]);
-                  const u32 ac = uload(&t.rprows[CBH_RP_ALLOW_CNT * t.n_rprows + row]);
+                  const u32 rres = rr.resource, ao = rr.allow_off, ac = rr.allow_cnt;
                   bool mm = in2 && !deny && pat_match(rres, kind, kind_bits);
                   bool am = false;
                   for (u32 a = 0; a < ac; ++a) am |= pat_match(uload(&t.pool[ao + a]), act, act_bits);
@@ -316,17 +356,18 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
 
           if (have_bucket) {   // ---- regular rows of the bucket, in binding order (check.go:295-414)
             for (u32 row = bucket.x; row < bucket.x + bucket.y; ++row) {
-              const u32 ra = uload(&t.rows[CBH_ROW_ACTION * t.n_rows + row]);
-              const u32 e = uload(&t.rows[CBH_ROW_FLAGS * t.n_rows + row]) & 3u;
+              const TblRow rw = uload_rec<TblRow>(t.rows, row);   // one s_load_dwordx8
+              const u32 ra = rw.action;
+              const u32 e = rw.flags & 3u;
               bool m = S && pat_match(ra, act, act_bits);
-              if (is_res) m = m && roleset_has(t, rs, uload(&t.rows[CBH_ROW_ROLE * t.n_rows + row]));
-              else m = m && pat_match(uload(&t.rows[CBH_ROW_RESOURCE * t.n_rows + row]), kind, kind_bits);
+              if (is_res) m = m && roleset_has(t, rs, rw.role);
+              else m = m && pat_match(rw.resource, kind, kind_bits);
               // once an ALLOW fired only a DENY can change the outcome of this scope (check.go:392-403);
               // strict mode still evaluates everything because an error there is itself a DENY
               if (has_allow && e == CBH_EFFECT_ALLOW && !strict) m = false;
               if (wave_ballot(m) == 0) continue;
-              const u32 drc = uload(&t.rows[CBH_ROW_DRCOND * t.n_rows + row]);
-              const u32 cnd = uload(&t.rows[CBH_ROW_COND * t.n_rows + row]);
+              const u32 drc = rw.drcond;
+              const u32 cnd = rw.cond;
               int r = 1;
               if (drc != CBH_NONE) r = eval_cond<GENERIC>(c, L, drc, m);           // check.go:328-366
               const bool m2 = m && r == 1;
@@ -335,7 +376,7 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
                 if (m2) r = r2;
               }
               if (m && r == 2) {   // strict evaluation error: DENY attributed to the row's policy
-                eff = CBH_EFFECT_DENY; pol = ((u32)CBH_P_TABLE << 28) | uload(&t.rows[CBH_ROW_POLICY * t.n_rows + row]); scp = si;
+                eff = CBH_EFFECT_DENY; pol = ((u32)CBH_P_TABLE << 28) | rw.policy; scp = si;
                 action_done = true; S = false;
               } else if (m && r == 1) {
                 if (e == CBH_EFFECT_ALLOW) has_allow = true;
@@ -373,6 +414,17 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
   }
 }
 
+// Dynamic LDS of both kernels = the column cache: n_cached * CBH_BLOCK * (8 + 1) bytes.
+#ifndef CBH_HOSTSIM
+extern __shared__ __attribute__((aligned(16))) unsigned char cbh_dyn_lds[];
+#else
+static unsigned char cbh_dyn_lds[CBH_CACHE_COLS * CBH_BLOCK * 9 + 16];
+#endif
+__device__ __forceinline__ u32 cached_columns(const KernelArgs* ka) {
+  const u32 n = ka->b.n_columns;
+  return n < CBH_CACHE_COLS ? n : CBH_CACHE_COLS;
+}
+
 // GENERIC instantiation: operand stack, locals and iteration slots in LDS, laid out [slot][lane].
 __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs* __restrict__ ka) {
   __shared__ u64 s_val[CBH_STACK_DEPTH * CBH_BLOCK];
@@ -382,12 +434,16 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs* 
   __shared__ u32 it_state[CBH_MAX_ITERS * CBH_BLOCK];
   __shared__ u8 s_tag[CBH_STACK_DEPTH * CBH_BLOCK];
   __shared__ u8 l_tag[CBH_MAX_LOCALS * CBH_BLOCK];
-  Ctx c{ka->t, ka->b, ka->now_ns, ka->flags, threadIdx.x, s_val, s_tag, l_val, l_tag, it_cont, it_idx, it_state};
+  const u32 ncc = cached_columns(ka);
+  Ctx c{ka->t, ka->b, ka->now_ns, ka->flags, threadIdx.x, s_val, s_tag, l_val, l_tag, it_cont, it_idx, it_state,
+        reinterpret_cast<u64*>(cbh_dyn_lds), cbh_dyn_lds + (size_t)ncc * CBH_BLOCK * 8, ncc};
   check_body<true>(ka, c);
 }
 
-// Leaf-only instantiation: no LDS, no calls.
+// Leaf-only instantiation: no operand stack, no interpreter call.
 __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel_leaf(const KernelArgs* __restrict__ ka) {
-  Ctx c{ka->t, ka->b, ka->now_ns, ka->flags, threadIdx.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const u32 ncc = cached_columns(ka);
+  Ctx c{ka->t, ka->b, ka->now_ns, ka->flags, threadIdx.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+        reinterpret_cast<u64*>(cbh_dyn_lds), cbh_dyn_lds + (size_t)ncc * CBH_BLOCK * 8, ncc};
   check_body<false>(ka, c);
 }

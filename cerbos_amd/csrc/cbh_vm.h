@@ -72,7 +72,12 @@ struct Ctx {
   u64* s_val; u8* s_tag;       // operand stack   [CBH_STACK_DEPTH][CBH_BLOCK]
   u64* l_val; u8* l_tag;       // locals          [CBH_MAX_LOCALS][CBH_BLOCK]
   u64* it_cont; u32* it_idx; u32* it_state; // iteration slots [CBH_MAX_ITERS][CBH_BLOCK]
+  // Per-lane cache of the request's first n_cached attribute columns, filled once in the kernel
+  // preamble (all loads in flight together) so condition leaves read LDS instead of paying one
+  // HBM round trip each.  [column][lane]
+  u64* cc_val; u8* cc_tag; u32 n_cached;
 };
+#define CBH_CACHE_COLS 16
 
 __device__ __forceinline__ Val mk(u32 t, u64 v) { Val x; x.t = t; x.v = v; return x; }
 __device__ __forceinline__ Val mk_err() { return mk(CBH_T_ERR, 0); }
@@ -503,6 +508,10 @@ __device__ __forceinline__ int fast_compare(const Ctx& c, u32 op, Val x, Val y) 
 __device__ __forceinline__ Val load_operand(const Ctx& c, const Lane& L, u32 kind, u32 arg) {
   if (kind == 0) return mk(c.t.const_tag[arg], c.t.const_val[arg]);
   if (kind == 1) {
+    if (arg < c.n_cached) {   // uniform: arg comes from the bytecode
+      const u32 t = c.cc_tag[arg * CBH_BLOCK + c.tid];
+      return t == CBH_T_ABSENT ? mk_err() : mk(t, c.cc_val[arg * CBH_BLOCK + c.tid]);
+    }
     size_t ix = (size_t)arg * c.b.n_requests + L.req;
     u32 t = c.b.col_tag[ix];
     return t == CBH_T_ABSENT ? mk_err() : mk(t, c.b.col_val[ix]);

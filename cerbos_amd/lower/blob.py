@@ -25,7 +25,7 @@ from .celc import LoweringError, Params, ProgramBuilder
 from .globs import GlobNFA, fix_glob, has_meta
 
 BLOB_MAGIC = 0x31484243
-BLOB_VERSION = 4
+BLOB_VERSION = 5
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
 
@@ -353,6 +353,14 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
     def u8(a):
         return np.asarray(a, dtype=np.uint8).tobytes()
 
+    def row_major(cols, width):
+        """Records of `width` u32 (fields = cols, zero padded): one wide scalar load per record."""
+        n = len(cols[0])
+        out = np.zeros((n, width), dtype=np.uint32)
+        for k, c in enumerate(cols):
+            out[:, k] = np.asarray(c, dtype=np.uint32) if n else []
+        return out.tobytes()
+
     code = list(pb.code) or [celc.OP_RET]
     sections = [
         (SEC_META, META_N, meta.tobytes()),
@@ -362,10 +370,10 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         (SEC_SCOPE_FLAGS, len(lt.scopes), u32(scope_flags)),
         (SEC_SCOPE_SID, len(lt.scopes), u32(scope_sid)),
         (SEC_HASH, nslots, slots.tobytes()),
-        (SEC_ROWS, len(row_cols[0]), b"".join(u32(c) for c in row_cols)),
-        (SEC_RPROWS, len(rp_cols[0]), b"".join(u32(c) for c in rp_cols)),
+        (SEC_ROWS, len(row_cols[0]), row_major(row_cols, 8)),
+        (SEC_RPROWS, len(rp_cols[0]), row_major(rp_cols, 4)),
         (SEC_U32POOL, len(pool), u32(pool)),
-        (SEC_DR, len(dr_cols[0]), b"".join(u32(c) for c in dr_cols)),
+        (SEC_DR, len(dr_cols[0]), row_major(dr_cols, 4)),
         (SEC_CODE, len(code), u32(code)),
         (SEC_CONST_TAG, len(pb.const_tag), u8(pb.const_tag)),
         (SEC_CONST_VAL, len(pb.const_val), u64(pb.const_val)),

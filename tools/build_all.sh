@@ -1,0 +1,14 @@
+#!/bin/bash
+# Rebuild the host simulator + the gfx950 library; print the kernels' resource usage.
+set -e
+cd "$(dirname "$0")/.."
+g++ -O1 -g -std=c++17 -shared -fPIC -Iinclude tests/hostsim/hostsim.cpp -o tests/hostsim/libcbh_hostsim.so
+cd cerbos_amd/csrc
+LOG=$(mktemp)
+if ! hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -I../../include cbh_engine.hip -o ../libcerbos_hip.so -Rpass-analysis=kernel-resource-usage > "$LOG" 2>&1; then
+  grep -E "error" -A3 "$LOG" | head -40
+  echo "HIPCC FAILED"
+  exit 1
+fi
+grep -E "Function Name|VGPRs:|Occupancy|SGPRs Spill|Scratch|LDS Size" "$LOG" | grep -A5 "check_kernel" | sed -e 's/.*remark: *//' -e 's/ \[-Rpass.*//' | paste -sd' ' | sed 's/Function Name/\nFunction Name/g'
+echo
