@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcerbos_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 F_LENIENT_SCOPE_SEARCH = 1
 F_STRICT_EVALUATION = 2
 F_WANT_DERIVED_ROLES = 4
@@ -197,14 +197,14 @@ class Table:
         cb = make_cbatch(batch, self.num_columns)
         p = CParams(now_ns, flags, 0)
         _check(load().cbh_check_batch(self.h, C.byref(cb), C.byref(p), C.byref(res.c)))
-        return res
+        return res.to_input_order(batch)
 
     # ---- resident
     def upload(self, batch):
         cb = make_cbatch(batch, self.num_columns)
         h = C.c_void_p()
         _check(load().cbh_batch_upload(self.h, C.byref(cb), C.byref(h)))
-        return DeviceBatch(self, h, batch.n_tuples, batch.n_requests)
+        return DeviceBatch(self, h, batch.n_tuples, batch.n_requests, batch)
 
     def launch(self, dbatch, now_ns=0, flags=0):
         p = CParams(now_ns, flags, 0)
@@ -221,12 +221,18 @@ class Table:
     def download(self, dbatch, want=("policy", "scope", "status", "edr")):
         res = Result(dbatch.n_tuples, dbatch.n_requests, want)
         _check(load().cbh_result_download(self.h, dbatch.h, C.byref(res.c)))
-        return res
+        return res.to_input_order(dbatch.order)
 
 
 class DeviceBatch:
-    def __init__(self, table, h, n_tuples, n_requests):
+    def __init__(self, table, h, n_tuples, n_requests, batch=None):
         self.table, self.h, self.n_tuples, self.n_requests = table, h, n_tuples, n_requests
+
+        class _Order:   # what is needed to map device order back to input order, without the big arrays
+            tuple_perm = getattr(batch, "tuple_perm", None)
+            req_perm = getattr(batch, "req_perm", None)
+            vreq_input = getattr(batch, "vreq_input", None)
+        self.order = _Order
 
     def close(self):
         if self.h:
@@ -249,3 +255,29 @@ class Result:
         self.edr = np.zeros(n_requests, dtype=np.uint64) if "edr" in want else None
         self.c = CResult(_ptr(self.effect) or 0, _ptr(self.policy), _ptr(self.scope), _ptr(self.status),
                          _ptr(self.edr))
+
+    def to_input_order(self, batch):
+        """Undo the flattener's routing sort / request splitting: per-tuple arrays back in input
+        tuple order, ``edr`` indexed by input request."""
+        tp = getattr(batch, "tuple_perm", None)
+        if tp is not None:
+            for name in ("effect", "policy", "scope", "status"):
+                a = getattr(self, name)
+                if a is not None:
+                    out = np.empty_like(a)
+                    out[tp] = a
+                    setattr(self, name, out)
+        if self.edr is not None:
+            rp = getattr(batch, "req_perm", None)
+            vi = getattr(batch, "vreq_input", None)
+            edr = self.edr
+            if rp is not None:
+                e2 = np.empty_like(edr)
+                e2[rp] = edr
+                edr = e2
+            if vi is not None and edr.size:
+                out = np.zeros(int(vi.max()) + 1 if vi.size else 0, dtype=np.uint64)
+                np.bitwise_or.at(out, vi, edr)
+                edr = out
+            self.edr = edr
+        return self

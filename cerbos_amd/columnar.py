@@ -13,7 +13,8 @@ from __future__ import annotations
 import numpy as np
 
 from . import namer
-from .flatten import (HEAP_BATCH, RQ_NFIELDS, RQ_KIND, RQ_P_SCOPE, RQ_P_VERSION, RQ_PRINCIPAL_ID,
+from .flatten import (HEAP_BATCH, MAX_ACTIONS_PER_REQUEST, RQ_ACT_CNT, RQ_ACT_OFF, RQ_NFIELDS, RQ_KIND,
+                      RQ_P_SCOPE, RQ_P_VERSION, RQ_PRINCIPAL_ID, sort_batch_by_route,
                       RQ_R_SCOPE, RQ_R_VERSION, RQ_ROLE_CNT, RQ_ROLE_OFF, RQ_S_KIND, RQ_S_P_SCOPE,
                       RQ_S_P_VERSION, RQ_S_R_SCOPE, RQ_S_R_VERSION, RQ_S_RESOURCE_ID, SF_ACTION,
                       SF_KIND, SF_ROLE, T_ABSENT, T_BOOL, T_DOUBLE, T_ERR, T_LIST, T_MAP, T_NULL,
@@ -76,6 +77,25 @@ class ColumnarRequests:
         self.principal_scope, self.resource_scope = principal_scope, resource_scope
         self.principal_version, self.resource_version = principal_version, resource_version
 
+    def head(self, n):
+        """The first ``n`` requests as a new ColumnarRequests."""
+        n = min(n, self.n)
+
+        def voc(v):
+            return None if v is None else Vocab(v.values, v.idx[:n])
+
+        def rag(r):
+            return Ragged(r.values, r.off[:n + 1], r.flat[:r.off[n]])
+
+        def att(d):
+            return {k: Attr(a.kind, a.data[:n], None if a.present is None else a.present[:n], a.values)
+                    for k, a in d.items()}
+
+        return ColumnarRequests(n, voc(self.principal_id), rag(self.roles), voc(self.resource_kind),
+                                voc(self.resource_id), rag(self.actions), att(self.p_attr), att(self.r_attr),
+                                voc(self.principal_scope), voc(self.resource_scope),
+                                voc(self.principal_version), voc(self.resource_version))
+
     # ---- dict route ---------------------------------------------------------------------
     def to_inputs(self, start=0, stop=None):
         stop = self.n if stop is None else min(stop, self.n)
@@ -103,7 +123,7 @@ class ColumnarRequests:
         return out
 
     # ---- SoA route ----------------------------------------------------------------------
-    def to_batch(self, fl: Flattener, default_policy_version="default", default_scope="") -> Batch:  # noqa: C901
+    def to_batch(self, fl: Flattener, default_policy_version="default", default_scope="", sort=True) -> Batch:  # noqa: C901
         lt, K, n = fl.lt, fl.K, self.n
         table_ids = lt.string_ids
         local, local_strings, local_flags = {}, [], []
@@ -194,6 +214,10 @@ class ColumnarRequests:
 
         act_ids = np.array([sid(s, SF_ACTION) for s in self.actions.values], dtype=np.uint32)
         counts = np.diff(self.actions.off)
+        if counts.size and counts.max() > MAX_ACTIONS_PER_REQUEST:
+            raise ValueError("the columnar route carries at most %d actions per request" % MAX_ACTIONS_PER_REQUEST)
+        req[RQ_ACT_OFF] = self.actions.off[:-1].astype(np.uint32)
+        req[RQ_ACT_CNT] = counts.astype(np.uint32)
         tuple_req = np.repeat(np.arange(n, dtype=np.uint32), counts)
         tuple_action = act_ids[self.actions.flat]
 
@@ -257,4 +281,4 @@ class ColumnarRequests:
         b.str_flags = np.asarray(local_flags, dtype=np.uint8)
         b.n_strings = len(local_strings)
         b.actions_per_request = None  # use actions.at(i) when decoding
-        return b
+        return sort_batch_by_route(b) if sort else b

@@ -1,14 +1,20 @@
-// cbh_check_kernel - the decision kernel, wave-cooperative formulation.
+// cbh_check_kernel - the decision kernel: request-major, wave-cooperative.
 //
-// One lane per (principal, resource, action) tuple, restating ruletable.(*RuleTable).check
-// (internal/ruletable/check.go:97-460).  The TABLE WALK is wave-uniform: lanes are grouped
-// (waterfall over ballot/readlane) by the key that selects their policy buckets - (scope chain
-// start, policy version, resource kind | principal id) - and each group walks its scope chain,
-// directory buckets, rule rows and CEL programs ONCE on uniform (scalar) values, while per-lane
-// predicates carry the data-dependent part (action / role match, condition results, the
-// ALLOW/DENY fold).  Rows of one bucket are visited in binding order exactly like
+// One lane per CheckInput (principal, resource, up to 64 actions) restating
+// ruletable.(*RuleTable).check (internal/ruletable/check.go:97-460).  Per-action state of the
+// effect fold lives in 64-bit masks (bit k = k-th action of the request), so everything the
+// reference does per action - rule match, ALLOW/DENY bookkeeping, scope permissions, the role
+// fold - is bit-parallel over the request's actions, and a rule's condition is evaluated once per
+// request instead of once per (action, rule).
+//
+// The TABLE WALK is wave-uniform: lanes are grouped (waterfall over ballot/readlane) by the key
+// that selects their policy buckets - (scope chain start, policy version, resource kind |
+// principal id) - and each group walks its scope chain, directory buckets, rule rows and CEL
+// programs ONCE on uniform (scalar-unit) values; per-lane data carries the role match, the action
+// masks and the condition results.  Rows of one bucket are visited in binding order exactly like
 // Index.Query's result (index/index.go:214-336); role-policy synthetic DENYs first
-// (index.go:318-322, 352-530).
+// (index.go:318-322, 352-530).  The host flattener orders requests by that key so that a wave
+// usually holds one group.
 //
 // Discipline (also what tests/hostsim emulates): no lane returns early; every cross-lane call
 // (wave_ballot / wave_readlane / run_uniform) is reached by all 64 lanes under uniform control
@@ -16,7 +22,7 @@
 //
 // Two instantiations: GENERIC = true carries the operand-stack interpreter (LDS stack, a real
 // function call); GENERIC = false is selected by the host when every program of the table is a
-// fused leaf or a tree of fused leaves (the common case) and needs neither LDS nor a call.
+// fused leaf or a tree of fused leaves (the common case).
 #pragma once
 #include "cbh_interp.h"
 
@@ -98,7 +104,7 @@ __device__ inline bool lane_has_parent_role(const TableDev& t, const BatchDev& b
   return false;
 }
 
-// One fused leaf (OP_LEAF_BIN word + two operand words at `pc`) for a lane: 0 false, 1 true, 3 CEL error.
+// One fused leaf (OP_LEAF_BIN word + two operand words) for a lane: 0 false, 1 true, 3 CEL error.
 __device__ __forceinline__ int leaf_value(const Ctx& c, Lane& L, u32 w, u32 a0, u32 a1) {
   const u32 a = w >> 8;
   const Val x = load_operand(c, L, (a >> 8) & 0xF, a0);
@@ -179,12 +185,9 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
   const OutDev& o = ka->o;
   const u32 flags = ka->flags;
 
-  const u32 tup = blockIdx.x * CBH_BLOCK + threadIdx.x;
-  const bool valid = tup < b.n_tuples;
-  const u32 tix = valid ? tup : 0;   // tail lanes shadow tuple 0 and never store
-
-  const u32 req = b.tuple_req[tix];
-  const u32 act = b.tuple_action[tix];
+  const u32 rix = blockIdx.x * CBH_BLOCK + threadIdx.x;
+  const bool valid = rix < b.n_requests;
+  const u32 req = valid ? rix : 0;   // tail lanes shadow request 0 and never store
   const u32 NR = b.n_requests;
 #define RQ(f) b.req_u32[(size_t)(f) * NR + req]
   const u32 pid = RQ(CBH_RQ_PRINCIPAL_ID);
@@ -192,6 +195,8 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
   const u32 kind = RQ(CBH_RQ_KIND);
   const u32 r_scope = RQ(CBH_RQ_R_SCOPE), r_ver = RQ(CBH_RQ_R_VERSION);
   const u32 role_off = RQ(CBH_RQ_ROLE_OFF), role_cnt = RQ(CBH_RQ_ROLE_CNT);
+  const u32 act_off = RQ(CBH_RQ_ACT_OFF);
+  const u32 act_cnt = valid ? RQ(CBH_RQ_ACT_CNT) : 0;   // <= 64 (the flattener splits larger requests)
 #undef RQ
   // column cache: issue every load of this lane's request attributes now, park them in LDS
   {
@@ -208,17 +213,47 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
       if (k < c.n_cached) { c.cc_tag[k * CBH_BLOCK + c.tid] = tg[k]; c.cc_val[k * CBH_BLOCK + c.tid] = vl[k]; }
     }
   }
+  const u64 all = act_cnt >= 64 ? ~0ull : ((1ull << act_cnt) - 1);
+  // the first four action ids stay in registers (requests rarely carry more)
+  const u32 a0 = act_cnt > 0 ? b.tuple_action[act_off] : CBH_NONE;
+  const u32 a1 = act_cnt > 1 ? b.tuple_action[act_off + 1] : CBH_NONE;
+  const u32 a2 = act_cnt > 2 ? b.tuple_action[act_off + 2] : CBH_NONE;
+  const u32 a3 = act_cnt > 3 ? b.tuple_action[act_off + 3] : CBH_NONE;
+
   const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
   const bool strict = (flags & CBH_F_STRICT_EVALUATION) != 0;
   const bool want_edr = (flags & CBH_F_WANT_DERIVED_ROLES) != 0 || (t.flags & CBH_MF_USES_RUNTIME_EDR) != 0;
   const bool has_parents = (t.flags & CBH_MF_HAS_PARENT_ROLES) != 0;
   const bool has_rolepol = (t.flags & CBH_MF_HAS_ROLE_POLICIES) != 0;
+  const bool want_ps = o.policy != nullptr || o.scope != nullptr;
 
   Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false;
-  u64 edr_acc = 0;   // derived roles activated for this tuple's request; published once at the end
+  u64 edr_acc = 0;
 
-  u32 eff = EFF_NO_MATCH, pol = ((u32)CBH_P_NO_MATCH << 28), scp = CBH_NONE;
-  const u64 act_bits = gbits_of(t, b, DIM_ACTION, act);
+  // mask of this request's actions matching an action-dimension pattern reference
+  auto match_actions = [&](u32 pat) -> u64 {
+    u64 m = 0;
+    if (!(pat & CBH_PAT_GLOB)) {
+      m = (u64)(a0 == pat) | ((u64)(a1 == pat) << 1) | ((u64)(a2 == pat) << 2) | ((u64)(a3 == pat) << 3);
+      for (u32 k = 4; k < act_cnt; ++k) m |= (u64)(b.tuple_action[act_off + k] == pat) << k;
+    } else {
+      const u32 gi = pat & 63u;
+      for (u32 k = 0; k < act_cnt; ++k)
+        m |= ((gbits_of(t, b, DIM_ACTION, b.tuple_action[act_off + k]) >> gi) & 1ull) << k;
+    }
+    return m & all;
+  };
+  // policy / scope outputs are written at the moment an action's (tentative) result changes
+  auto write_ps = [&](u64 mask, u32 polw, u32 scpw) {
+    if (!want_ps) return;
+    while (mask) {
+      const u32 k = (u32)__builtin_ctzll(mask);
+      mask &= mask - 1;
+      if (o.policy) o.policy[act_off + k] = polw;
+      if (o.scope) o.scope[act_off + k] = scpw;
+    }
+  };
+
   const u64 kind_bits = gbits_of(t, b, DIM_KIND, kind);
   // parent roles are looked up with the request's own resource scope only (check.go:172,227)
   const u32 pr_scope_key = (r_scope & CBH_SCOPE_EXACT) ? (r_scope & ~CBH_SCOPE_EXACT) : CBH_NONE;
@@ -239,8 +274,13 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
     }
     if (!p_exists && !r_exists) decided = true;
   }
-  if (!decided) pol = ((u32)CBH_P_EMPTY << 28);   // zero EffectInfo (check.go:191)
-  bool action_done = decided || !valid;           // nothing (more) to do: the lane rides along
+
+  // ---- per-action state, bit k = k-th action of the request
+  u64 todo = (valid && !decided) ? all : 0;   // actions still being resolved
+  u64 eff_allow = 0, eff_deny = 0;            // neither bit set = EFFECT_NO_MATCH so far
+  u64 st_err = 0, st_unsup = 0;
+  // "NO_MATCH" when there is nothing to evaluate (check.go:119-121, 168-170), else the zero EffectInfo (:191)
+  write_ps(all, (u32)(decided ? CBH_P_NO_MATCH : CBH_P_EMPTY) << 28, CBH_NONE);
 
   for (u32 pt = 0; pt < 2; ++pt) {                // 0 = principal policies, 1 = resource policies (check.go:195)
     const bool is_res = pt == 1;
@@ -248,14 +288,15 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
     const u32 flagbit = is_res ? FLAG_RES : FLAG_PRIN;
     const bool exists = is_res ? r_exists : p_exists;
     const u32 gx = is_res ? kind : pid;
-    // a definitive principal-policy result ends the action (check.go:445-448); an empty principal
-    // chain leaves nothing behind that the resource pass does not overwrite
-    const bool in_pass = !action_done && !(eff == CBH_EFFECT_ALLOW || eff == CBH_EFFECT_DENY) &&
-                         (is_res || first != CBH_NONE);
-    if (in_pass) eff = EFF_NO_MATCH;                                    // check.go:206
     const u32 n_iter = is_res ? role_cnt : (role_cnt ? 1u : 0u);      // check.go:208-213
-    bool pend = in_pass && n_iter > 0;
-    bool roles_done = false;                                           // ALLOW found: leave the role loop
+    // An empty principal chain leaves nothing behind that the resource pass does not overwrite.
+    const u64 Pm = (is_res || first != CBH_NONE) && n_iter > 0 ? todo : 0;   // actions taking part in this pass
+    // roleEffectInfo.Policy: the main policy key if a policy exists at all, else "NO_MATCH" (check.go:216-225)
+    const u32 pol_default = exists ? (((u32)(is_res ? CBH_P_RESOURCE : CBH_P_PRINCIPAL) << 28) | first)
+                                   : ((u32)CBH_P_NO_MATCH << 28);
+    write_ps(Pm, pol_default, CBH_NONE);   // what the first role seeds when nothing matches (check.go:429-431)
+    u64 rdone = 0;                          // actions that reached ALLOW: they leave the role loop (check.go:433-436)
+    bool pend = Pm != 0;
 
     for (;;) {   // ---- waterfall over groups that share (chain start, version, kind | principal)
       const u64 rem = wave_ballot(pend);
@@ -266,10 +307,10 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
       pend = pend && !ing;
 
       for (u32 ri = 0;; ++ri) {   // ---- roles (check.go:208)
-        const bool A = ing && !action_done && !roles_done && ri < n_iter;
-        if (wave_ballot(A) == 0) break;
+        const u64 Am = (ing && ri < n_iter) ? (Pm & todo & ~rdone) : 0;
+        if (wave_ballot(Am != 0) == 0) break;
         RoleSet rs; rs.role = 0; rs.par_off = 0; rs.par_cnt = 0; rs.gbits = 0;
-        if (A) {
+        if (Am != 0) {
           rs.role = b.roles[role_off + ri];
           rs.gbits = gbits_of(t, b, DIM_ROLE, rs.role);
           uint4 pv;
@@ -278,14 +319,34 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
             for (u32 k = 0; k < rs.par_cnt; ++k) rs.gbits |= t.gbits[(size_t)DIM_ROLE * t.K + t.pool[rs.par_off + k]];
           }
         }
-        bool has_allow = false;
-        u32 r_eff = EFF_NO_MATCH, r_scp = CBH_NONE;
-        u32 r_pol = exists ? (((u32)(is_res ? CBH_P_RESOURCE : CBH_P_PRINCIPAL) << 28) | g_first)
-                           : ((u32)CBH_P_NO_MATCH << 28);
-        bool S = A;   // lane is still walking the scope chain
+        u64 has_allow = 0;
+        u64 S = Am;   // actions still walking the scope chain for this role
+
+        // effect events of this role iteration (fold of check.go:382-442, applied as they happen)
+        auto role_deny = [&](u64 mask, u32 polw, u32 si) {
+          const u64 seed = mask & ~(eff_allow | eff_deny);   // still NO_MATCH: this role's DENY seeds the result
+          eff_deny |= seed;
+          write_ps(seed, polw, si);
+          S &= ~mask;
+        };
+        auto role_allow = [&](u64 mask, u32 si) {           // first independent ALLOW wins (check.go:433-436)
+          eff_allow |= mask; eff_deny &= ~mask; rdone |= mask;
+          write_ps(mask, pol_default, si);
+          S &= ~mask;
+        };
+        auto strict_deny = [&](u64 mask, u32 polw, u32 si) { // evaluation error in strict mode (check.go:353-356, 371-374)
+          eff_deny |= mask; eff_allow &= ~mask; todo &= ~mask;
+          write_ps(mask, polw, si);
+          S &= ~mask;
+        };
+        auto take_status = [&](u64 mask) {                    // attribute VM status bits to the actions served
+          if (L.status & CBH_ST_CEL_ERROR) st_err |= mask;
+          if (L.status & CBH_ST_UNSUPPORTED) st_unsup |= mask;
+          L.status = 0;
+        };
 
         for (u32 si = g_first; si != CBH_NONE; si = uchain_next(t, uload(&t.scope_parent[si]), flagbit)) {   // check.go:231
-          if (wave_ballot(S) == 0) break;
+          if (wave_ballot(S != 0) == 0) break;
           uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
           const bool have_bucket = is_res ? udir_find(t, CBH_B_RESOURCE, g_ver, g_x, si, bucket)
                                           : udir_find(t, CBH_B_PRINCIPAL, g_ver, si, g_x, bucket);   // resource version: check.go:294
@@ -295,22 +356,21 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
             if (have_bucket) {
               for (u32 d = bucket.z; d < bucket.z + bucket.w; ++d) {
                 const TblDr dr = uload_rec<TblDr>(t.dr, d);
-                const u32 pcnt = dr.parents_cnt, poff = dr.parents_off, cond = dr.cond, bit = dr.name;
-                const bool applies = S && (pcnt == CBH_NONE ||
-                                           lane_has_parent_role(t, b, poff, pcnt, role_off, role_cnt, pr_scope_key, has_parents));
+                const bool applies = S != 0 && (dr.parents_cnt == CBH_NONE ||
+                    lane_has_parent_role(t, b, dr.parents_off, dr.parents_cnt, role_off, role_cnt, pr_scope_key, has_parents));
                 if (wave_ballot(applies) == 0) continue;
                 int r = 1;
-                if (cond != CBH_NONE) r = eval_cond<GENERIC>(c, L, cond, applies);
-                if (applies) { if (r == 2) derr = true; else if (r == 1) m |= 1ull << bit; }
+                if (dr.cond != CBH_NONE) r = eval_cond<GENERIC>(c, L, dr.cond, applies);
+                if (applies) { if (r == 2) derr = true; else if (r == 1) m |= 1ull << dr.name; take_status(S); }
               }
             }
-            if (S) { L.edr = m; L.edr_err = derr; edr_acc |= m; }
+            if (S != 0) { L.edr = m; L.edr_err = derr; edr_acc |= m; }
           }
 
           if (is_res && has_rolepol) {
             // synthetic DENYs from the role policies of [role] ++ ancestors (index.go:352-530)
             for (u32 k = 0;; ++k) {
-              const bool P = S && k <= rs.par_cnt;
+              const bool P = S != 0 && k <= rs.par_cnt;
               if (wave_ballot(P) == 0) break;
               const u32 srole = P ? (k == 0 ? rs.role : t.pool[rs.par_off + k - 1]) : 0;
               bool pend2 = P;
@@ -318,38 +378,37 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
                 const u64 rem2 = wave_ballot(pend2);
                 if (rem2 == 0) break;
                 const u32 g_sr = wave_readlane(srole, first_lane(rem2));
-                bool in2 = pend2 && srole == g_sr;
+                const bool in2 = pend2 && srole == g_sr;
                 pend2 = pend2 && !in2;
                 uint4 rp;
                 if (!udir_find(t, CBH_B_ROLEPOL, g_ver, si, g_sr, rp)) continue;
-                bool any_action = false;
+                const u32 rp_pol = ((u32)CBH_P_TABLE << 28) | rp.z;
+                u64 any_mask = 0;   // actions allowed (subject to conditions) by some rule for this resource
                 for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
                   const TblRp rr = uload_rec<TblRp>(t.rprows, row);
-                  const u32 rres = rr.resource, ao = rr.allow_off, ac = rr.allow_cnt;
-                  if (!pat_match(rres, kind, kind_bits)) continue;   // kind is uniform within a resource group
-                  for (u32 a = 0; a < ac; ++a) any_action |= pat_match(uload(&t.pool[ao + a]), act, act_bits);
+                  if (!in2 || !pat_match(rr.resource, kind, kind_bits)) continue;
+                  for (u32 a = 0; a < rr.allow_cnt; ++a) any_mask |= match_actions(uload(&t.pool[rr.allow_off + a]));
                 }
-                bool deny = in2 && !any_action;   // no binding for the resource, or no allow-action matched (index.go:436-461)
+                // no binding for the resource, or no allow-action matched (index.go:436-461)
+                u64 deny = in2 ? (S & ~any_mask) : 0;
                 for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
                   const TblRp rr = uload_rec<TblRp>(t.rprows, row);
-                  const u32 cond = rr.cond;
-                  if (cond == CBH_NONE) continue;
-                  const u32 rres = rr.resource, ao = rr.allow_off, ac = rr.allow_cnt;
-                  bool mm = in2 && !deny && pat_match(rres, kind, kind_bits);
-                  bool am = false;
-                  for (u32 a = 0; a < ac; ++a) am |= pat_match(uload(&t.pool[ao + a]), act, act_bits);
-                  mm = mm && am;
-                  if (wave_ballot(mm) == 0) continue;
-                  const int r = eval_cond<GENERIC>(c, L, cond, mm);   // synthetic row = DENY if none(cond)
-                  if (mm && r == 2) {
-                    eff = CBH_EFFECT_DENY; pol = ((u32)CBH_P_TABLE << 28) | rp.z; scp = si;
-                    action_done = true; S = false; in2 = false;
-                  } else if (mm && r == 0) deny = true;
+                  if (rr.cond == CBH_NONE) continue;
+                  u64 mm = 0;
+                  if (in2 && pat_match(rr.resource, kind, kind_bits)) {
+                    for (u32 a = 0; a < rr.allow_cnt; ++a) mm |= match_actions(uload(&t.pool[rr.allow_off + a]));
+                    mm &= S & ~deny;
+                  }
+                  if (wave_ballot(mm != 0) == 0) continue;
+                  const int r = eval_cond<GENERIC>(c, L, rr.cond, mm != 0);   // synthetic row = DENY if none(cond)
+                  if (mm != 0) {
+                    take_status(mm);
+                    if (r == 2) strict_deny(mm, rp_pol, si);
+                    else if (r == 0) deny |= mm;
+                  }
                 }
-                if (in2 && deny) {   // check.go:395-403
-                  r_eff = CBH_EFFECT_DENY; r_scp = si; r_pol = ((u32)CBH_P_TABLE << 28) | rp.z;
-                  S = false;
-                }
+                deny &= S;
+                if (deny != 0) role_deny(deny, rp_pol, si);   // check.go:395-403
               }
             }
           }
@@ -357,60 +416,54 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
           if (have_bucket) {   // ---- regular rows of the bucket, in binding order (check.go:295-414)
             for (u32 row = bucket.x; row < bucket.x + bucket.y; ++row) {
               const TblRow rw = uload_rec<TblRow>(t.rows, row);   // one s_load_dwordx8
-              const u32 ra = rw.action;
               const u32 e = rw.flags & 3u;
-              bool m = S && pat_match(ra, act, act_bits);
-              if (is_res) m = m && roleset_has(t, rs, rw.role);
-              else m = m && pat_match(rw.resource, kind, kind_bits);
-              // once an ALLOW fired only a DENY can change the outcome of this scope (check.go:392-403);
+              u64 mrow = 0;
+              if (S != 0 && (is_res ? roleset_has(t, rs, rw.role) : pat_match(rw.resource, kind, kind_bits)))
+                mrow = match_actions(rw.action) & S;
+              // once an ALLOW fired only a DENY can change an action's outcome in this scope (check.go:392-403);
               // strict mode still evaluates everything because an error there is itself a DENY
-              if (has_allow && e == CBH_EFFECT_ALLOW && !strict) m = false;
-              if (wave_ballot(m) == 0) continue;
-              const u32 drc = rw.drcond;
-              const u32 cnd = rw.cond;
+              u64 need = mrow;
+              if (e == CBH_EFFECT_ALLOW && !strict) need &= ~has_allow;
+              if (wave_ballot(need != 0) == 0) continue;
+              const bool m = need != 0;
               int r = 1;
-              if (drc != CBH_NONE) r = eval_cond<GENERIC>(c, L, drc, m);           // check.go:328-366
+              if (rw.drcond != CBH_NONE) r = eval_cond<GENERIC>(c, L, rw.drcond, m);   // check.go:328-366
               const bool m2 = m && r == 1;
-              if (cnd != CBH_NONE && wave_ballot(m2) != 0) {                        // check.go:368-380
-                const int r2 = eval_cond<GENERIC>(c, L, cnd, m2);
+              if (rw.cond != CBH_NONE && wave_ballot(m2) != 0) {                         // check.go:368-380
+                const int r2 = eval_cond<GENERIC>(c, L, rw.cond, m2);
                 if (m2) r = r2;
               }
-              if (m && r == 2) {   // strict evaluation error: DENY attributed to the row's policy
-                eff = CBH_EFFECT_DENY; pol = ((u32)CBH_P_TABLE << 28) | rw.policy; scp = si;
-                action_done = true; S = false;
-              } else if (m && r == 1) {
-                if (e == CBH_EFFECT_ALLOW) has_allow = true;
-                else if (e == CBH_EFFECT_DENY) { r_eff = CBH_EFFECT_DENY; r_scp = si; S = false; }
+              if (m) {
+                take_status(need);
+                if (r == 2) strict_deny(need, ((u32)CBH_P_TABLE << 28) | rw.policy, si);
+                else if (r == 1) {
+                  if (e == CBH_EFFECT_ALLOW) has_allow |= mrow;
+                  else if (e == CBH_EFFECT_DENY) role_deny(mrow, pol_default, si);
+                }
               }
             }
           }
 
-          if (S && has_allow) {   // check.go:416-425
+          const u64 ha = has_allow & S;   // check.go:416-425
+          if (ha != 0) {
             const u32 sp = (uload(&t.scope_flags[si]) >> 2) & 3u;
-            if (sp == SP_REQUIRE_CONSENT) has_allow = false;
-            else if (sp == SP_OVERRIDE_PARENT) { r_eff = CBH_EFFECT_ALLOW; r_scp = si; S = false; }
+            if (sp == SP_REQUIRE_CONSENT) has_allow &= ~ha;
+            else if (sp == SP_OVERRIDE_PARENT) role_allow(ha, si);
           }
-        }
-
-        if (A && !action_done) {   // fold this role's result (check.go:428-442)
-          if (eff == EFF_NO_MATCH) { eff = r_eff; pol = r_pol; scp = r_scp; }
-          if (r_eff == CBH_EFFECT_ALLOW) { eff = r_eff; pol = r_pol; scp = r_scp; roles_done = true; }
-          else if (r_eff == CBH_EFFECT_DENY && (pol >> 28) == CBH_P_NO_MATCH_SCOPE_PERMISSIONS &&
-                   (r_pol >> 28) != CBH_P_NO_MATCH_SCOPE_PERMISSIONS) { eff = r_eff; pol = r_pol; scp = r_scp; }
         }
       }
     }
+    // a definitive principal-policy result ends the action (check.go:445-448)
+    todo &= ~(eff_allow | eff_deny);
   }
-  if (eff == EFF_NO_MATCH) eff = CBH_EFFECT_DENY;                     // check.go:451-453
 
   if (valid) {
-    // the only global writes of the kernel come last, so every table read above is a read of
-    // never-clobbered memory
-    if (o.edr && edr_acc) atomicOr(reinterpret_cast<unsigned long long*>(&o.edr[req]), (unsigned long long)edr_acc);
-    o.effect[tup] = (u8)eff;
-    if (o.policy) o.policy[tup] = pol;
-    if (o.scope) o.scope[tup] = scp;
-    if (o.status) o.status[tup] = (u8)((L.status & CBH_ST_UNSUPPORTED) ? CBH_ST_UNSUPPORTED : (L.status & CBH_ST_CEL_ERROR));
+    if (o.edr) o.edr[req] = edr_acc;
+    for (u32 k = 0; k < act_cnt; ++k) {
+      const u64 bit = 1ull << k;
+      o.effect[act_off + k] = (u8)((eff_allow & bit) ? CBH_EFFECT_ALLOW : CBH_EFFECT_DENY);   // NO_MATCH -> DENY (check.go:451-453)
+      if (o.status) o.status[act_off + k] = (u8)((st_unsup & bit) ? CBH_ST_UNSUPPORTED : ((st_err & bit) ? CBH_ST_CEL_ERROR : CBH_ST_OK));
+    }
   }
 }
 

@@ -225,8 +225,8 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   }
   HIPCHK(hipEventRecord(t->ev[1], s));
   HIPCHK(hipEventRecord(t->ev[2], s));
-  if (d.n_tuples) {
-    const u32 grid = (d.n_tuples + CBH_BLOCK - 1) / CBH_BLOCK;
+  if (d.n_requests) {
+    const u32 grid = (d.n_requests + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
     const u32 ncc = d.n_columns < CBH_CACHE_COLS ? d.n_columns : CBH_CACHE_COLS;
     const size_t dyn_lds = (size_t)ncc * CBH_BLOCK * 9;   // column cache: u64 value + u8 tag per lane
     if (t->dev.flags & CBH_MF_HAS_GENERIC_PROGRAMS)

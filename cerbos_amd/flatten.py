@@ -7,6 +7,11 @@ integer ids.  Strings are interned against the table's own string pool so that o
 device string equality is id equality; strings the table has never seen get batch-local
 ids and are shipped with the batch (their glob match bits are resolved on the device).
 
+The device evaluates one request per lane and walks the rule table once per group of lanes
+that share a routing key (resource kind, policy version, scope), so requests are ordered by
+that key here (``sort_batch_by_route``); results are mapped back to input order by
+``Batch.tuple_perm`` / ``Batch.req_perm``.
+
 This Python flattener is the reference implementation of the ``cbh_batch`` contract; the
 per-batch cost is host-side and outside the GPU timed region (see DESIGN.md - the C++
 wire-format flattener is SURVEY.md §8(f) rank 1).
@@ -20,10 +25,12 @@ import numpy as np
 from . import namer
 from .lower.blob import LoweredTable
 
-RQ_NFIELDS = 14
+RQ_NFIELDS = 16
 (RQ_PRINCIPAL_ID, RQ_P_SCOPE, RQ_P_VERSION, RQ_KIND, RQ_R_SCOPE, RQ_R_VERSION, RQ_ROLE_OFF, RQ_ROLE_CNT,
- RQ_S_RESOURCE_ID, RQ_S_KIND, RQ_S_P_SCOPE, RQ_S_R_SCOPE, RQ_S_P_VERSION, RQ_S_R_VERSION) = range(14)
+ RQ_S_RESOURCE_ID, RQ_S_KIND, RQ_S_P_SCOPE, RQ_S_R_SCOPE, RQ_S_P_VERSION, RQ_S_R_VERSION,
+ RQ_ACT_OFF, RQ_ACT_CNT) = range(16)
 SCOPE_EXACT = 0x80000000
+MAX_ACTIONS_PER_REQUEST = 64
 
 T_NULL, T_BOOL, T_INT, T_UINT, T_DOUBLE, T_STRING, T_LIST, T_MAP = range(8)
 T_ABSENT, T_ERR = 0xF0, 0xFF
@@ -39,7 +46,7 @@ class Batch:
     """Host image of a ``cbh_batch`` plus what is needed to decode results."""
 
     def __init__(self):
-        self.n_requests = 0
+        self.n_requests = 0      # device (virtual) requests
         self.n_tuples = 0
         self.req_u32 = None
         self.roles = None
@@ -53,7 +60,45 @@ class Batch:
         self.str_bytes = None
         self.str_flags = None
         self.n_strings = 0
-        self.actions_per_request = []  # [[action, ...]]
+        self.actions_per_request = []  # [[action, ...]] per INPUT, input order
+        self.tuple_perm = None   # device tuple j holds input-order tuple tuple_perm[j] (None = identity)
+        self.req_perm = None     # device request i is pre-sort request req_perm[i]
+        self.vreq_input = None   # pre-sort (virtual) request -> index of the CheckInput it came from
+
+
+def sort_batch_by_route(b: Batch) -> Batch:
+    """Order requests by (kind, resource version, resource scope) so that the lanes of a wave
+    share their policy buckets; regroups the tuple arrays accordingly (in place)."""
+    n = b.n_requests
+    if n < 2:
+        return b
+    req = b.req_u32
+    order = np.lexsort((req[RQ_R_SCOPE], req[RQ_R_VERSION], req[RQ_KIND]))   # stable
+    if np.array_equal(order, np.arange(n)):
+        return b
+    return permute_requests(b, order)
+
+
+def permute_requests(b: Batch, order) -> Batch:
+    """Device request i becomes the current request order[i]; tuple arrays are regrouped and the
+    permutations recorded so results can be returned in input order (in place)."""
+    n = b.n_requests
+    req = b.req_u32
+    order = np.asarray(order, dtype=np.int64)
+    counts = req[RQ_ACT_CNT][order].astype(np.int64)
+    starts = req[RQ_ACT_OFF][order].astype(np.int64)
+    new_off = np.cumsum(counts) - counts
+    total = int(counts.sum())
+    src = np.repeat(starts - new_off, counts) + np.arange(total, dtype=np.int64)   # device tuple j <- old tuple src[j]
+    b.req_u32 = np.ascontiguousarray(req[:, order])
+    b.req_u32[RQ_ACT_OFF] = new_off.astype(np.uint32)
+    b.col_tag = np.ascontiguousarray(b.col_tag[:, order])
+    b.col_val = np.ascontiguousarray(b.col_val[:, order])
+    b.tuple_action = np.ascontiguousarray(b.tuple_action[src])
+    b.tuple_req = np.repeat(np.arange(n, dtype=np.uint32), counts)
+    b.tuple_perm = src if b.tuple_perm is None else b.tuple_perm[src]
+    b.req_perm = order if b.req_perm is None else b.req_perm[order]
+    return b
 
 
 class Flattener:
@@ -79,7 +124,7 @@ class Flattener:
             self._scope_cache[scope] = w
         return w
 
-    def flatten(self, inputs, default_policy_version="default", default_scope="") -> Batch:
+    def flatten(self, inputs, default_policy_version="default", default_scope="", sort=True) -> Batch:
         lt, K = self.lt, self.K
         table_ids = lt.string_ids
         local = {}
@@ -127,14 +172,25 @@ class Flattener:
                 return T_MAP, (HEAP_BATCH << 62) | (off << 32) | len(ents)
             raise TypeError("unsupported attribute value %r" % (v,))
 
-        n = len(inputs)
+        # a CheckInput with more than 64 actions becomes several device requests
+        chunks = []
+        for i, inp in enumerate(inputs):
+            acts = list(inp.get("actions") or [])
+            if not acts:
+                chunks.append((i, acts))
+            for s in range(0, len(acts), MAX_ACTIONS_PER_REQUEST):
+                chunks.append((i, acts[s:s + MAX_ACTIONS_PER_REQUEST]))
+        n = len(chunks)
         ncol = len(lt.columns)
         req = np.zeros((RQ_NFIELDS, n), dtype=np.uint32)
         col_tag = np.full((ncol, n), T_ABSENT, dtype=np.uint8)
         col_val = np.zeros((ncol, n), dtype=np.uint64)
         roles, t_req, t_act = [], [], []
         b = Batch()
-        for r, inp in enumerate(inputs):
+        b.actions_per_request = [list(inp.get("actions") or []) for inp in inputs]
+        b.vreq_input = np.array([i for i, _ in chunks], dtype=np.int64)
+        for r, (i_in, acts) in enumerate(chunks):
+            inp = inputs[i_in]
             p, res = inp["principal"], inp["resource"]
             aux = inp.get("auxData") or {}
             p_scope_raw = p.get("scope", "") or ""
@@ -175,8 +231,8 @@ class Flattener:
                     tag, val = enc(cur)
                     col_val[ci, r] = val
                 col_tag[ci, r] = tag
-            acts = list(inp.get("actions") or [])
-            b.actions_per_request.append(acts)
+            req[RQ_ACT_OFF, r] = len(t_act)
+            req[RQ_ACT_CNT, r] = len(acts)
             for a in acts:
                 t_req.append(r)
                 t_act.append(sid(a, SF_ACTION))
@@ -199,4 +255,4 @@ class Flattener:
         b.str_bytes = np.frombuffer(b"".join(enc_strings), dtype=np.uint8).copy()
         b.str_flags = np.asarray(local_flags, dtype=np.uint8)
         b.n_strings = len(local_strings)
-        return b
+        return sort_batch_by_route(b) if sort else b

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CBH_ABI_VERSION 1u
+#define CBH_ABI_VERSION 2u
 #define CBH_NONE 0xFFFFFFFFu
 
 /* Effect values = effectv1.Effect (api/public/cerbos/effect/v1/effect.proto). */
@@ -58,8 +58,11 @@ enum cbh_req_field {
   CBH_RQ_S_R_SCOPE = 11,
   CBH_RQ_S_P_VERSION = 12,
   CBH_RQ_S_R_VERSION = 13,
-  CBH_RQ_NFIELDS = 14
+  CBH_RQ_ACT_OFF = 14,     /* this request's actions are tuple_action[ACT_OFF .. ACT_OFF+ACT_CNT)    */
+  CBH_RQ_ACT_CNT = 15,     /* <= CBH_MAX_ACTIONS_PER_REQUEST; split larger CheckInputs into several */
+  CBH_RQ_NFIELDS = 16
 };
+#define CBH_MAX_ACTIONS_PER_REQUEST 64u /* the default request limit of the reference is 50 (server/conf.go:34-35) */
 #define CBH_SCOPE_EXACT 0x80000000u
 
 /* Attribute value tags (col_tag / heap_tag). */
@@ -106,7 +109,8 @@ typedef struct cbh_batch {
   uint64_t str_bytes_len;
   const uint32_t* req_u32;      /* [CBH_RQ_NFIELDS][n_requests] */
   const uint32_t* roles;        /* [n_roles] string ids */
-  const uint32_t* tuple_req;    /* [n_tuples] request index */
+  const uint32_t* tuple_req;    /* [n_tuples] request index (informational; tuples MUST be grouped by  */
+                                /* request, each request owning the contiguous slice ACT_OFF/ACT_CNT) */
   const uint32_t* tuple_action; /* [n_tuples] string id of the action */
   const uint8_t* col_tag;       /* [n_columns][n_requests] */
   const uint64_t* col_val;      /* [n_columns][n_requests] */

@@ -161,7 +161,7 @@ extern "C" int hostsim_check(const void* blob, size_t len, const cbh_batch* in, 
   a.now_ns = p->now_ns; a.flags = p->flags;
   if (a.o.edr) std::memset(a.o.edr, 0, sizeof(uint64_t) * in->n_requests);
   g_args = &a;
-  const uint32_t nblocks = (in->n_tuples + CBH_BLOCK - 1) / CBH_BLOCK;
+  const uint32_t nblocks = (in->n_requests + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
   for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
   return 0;
 }

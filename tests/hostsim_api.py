@@ -60,4 +60,4 @@ def check(lt, batch, now_ns=0, flags=0):
                              g.ctypes.data_as(C.c_void_p))
     if rc != 0:
         raise RuntimeError(lib().hostsim_last_error().decode())
-    return res
+    return res.to_input_order(batch)
