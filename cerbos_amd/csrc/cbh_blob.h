@@ -48,6 +48,8 @@ enum CbhSectionId {
   CBH_SEC_NFA_KIND = 20,
   CBH_SEC_POLICY_SID = 21, // u32[n_policies] string ids of policy keys (host decode)
   CBH_SEC_DRNAME_SID = 22, // u32[n_drnames]  string ids of derived role names (bit order of edr_mask)
+  CBH_SEC_CONST_REC = 23,  // u32[n_consts][4]  {tag, 0, lo, hi}: the constant pool as scalar-loadable records
+  CBH_SEC_THEAP_REC = 24,  // u32[theap_len][4] the constant heap, same record form
 };
 
 enum CbhMeta {

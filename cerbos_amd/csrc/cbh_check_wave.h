@@ -44,8 +44,8 @@ struct __attribute__((aligned(16))) TblRp { u32 resource, allow_off, allow_cnt, 
 struct __attribute__((aligned(16))) TblDr { u32 name, parents_off, parents_cnt, cond; };
 struct __attribute__((aligned(32))) TblSlot { u32 k0, k1, k2, k3, v0, v1, v2, v3; };
 
-template <typename R>
-__device__ __forceinline__ R uload_rec(const u32* base, u32 idx) {
+template <typename R, typename P>
+__device__ __forceinline__ R uload_rec(P base, u32 idx) {   // P: pointer to u32 in any address space
 #ifndef CBH_HOSTSIM
   static_assert(sizeof(R) == 16 || sizeof(R) == 32, "table records are 4 or 8 dwords");
   const unsigned long long addr = (unsigned long long)(base + (size_t)idx * (sizeof(R) / 4));
@@ -71,7 +71,7 @@ __device__ __forceinline__ R uload_rec(const u32* base, u32 idx) {
 __device__ inline bool udir_find(const TableDev& t, u32 k0, u32 k1, u32 k2, u32 k3, uint4& v) {
   u32 i = hash4(k0, k1, k2, k3) & t.hash_mask;
   for (u32 probe = 0; probe <= t.hash_mask; ++probe) {
-    const TblSlot s = uload_rec<TblSlot>(reinterpret_cast<const u32*>(t.hash), i);
+    const TblSlot s = uload_rec<TblSlot>((const CBH_G u32*)t.hash, i);
     if (s.k0 == CBH_NONE) return false;
     if (s.k0 == k0 && s.k1 == k1 && s.k2 == k2 && s.k3 == k3) {
       v.x = s.v0; v.y = s.v1; v.z = s.v2; v.w = s.v3;
@@ -105,11 +105,30 @@ __device__ inline bool lane_has_parent_role(const TableDev& t, const BatchDev& b
 }
 
 // One fused leaf (OP_LEAF_BIN word + two operand words) for a lane: 0 false, 1 true, 3 CEL error.
+struct __attribute__((aligned(16))) TblVal { u32 tag, pad, lo, hi; };
+template <typename P>
+__device__ __forceinline__ Val uval(P recs, u32 idx) {   // constant / constant-heap entry, scalar load
+  const TblVal r = uload_rec<TblVal>(recs, idx);
+  return mk(r.tag, (u64)r.lo | ((u64)r.hi << 32));
+}
+
 __device__ __forceinline__ int leaf_value(const Ctx& c, Lane& L, u32 w, u32 a0, u32 a1) {
   const u32 a = w >> 8;
-  const Val x = load_operand(c, L, (a >> 8) & 0xF, a0);
-  const Val y = load_operand(c, L, (a >> 12) & 0xF, a1);
-  const int f = fast_compare(c, a & 0xFF, x, y);
+  const u32 ka = (a >> 8) & 0xF, kb = (a >> 12) & 0xF, op = a & 0xFF;   // all wave-uniform
+  const Val x = ka == 0 ? uval(c.t.const_rec, a0) : load_operand(c, L, ka, a0);
+  const Val y = kb == 0 ? uval(c.t.const_rec, a1) : load_operand(c, L, kb, a1);
+  if (op == OP_IN && kb == 0 && y.t == CBH_T_LIST && cont_sel(y.v) == CBH_HEAP_TABLE) {
+    // membership in a constant list: the elements are uniform, walk them on the scalar unit
+    if (x.t == CBH_T_ERR) return 3;
+    const u32 n = cont_len(y.v), off = cont_off(y.v);
+    int found = 0; bool slow = false;
+    for (u32 i = 0; i < n; ++i) {
+      const int e = fast_equal(x, uval(c.t.theap_rec, off + i));
+      if (e == -2) slow = true; else found |= e;
+    }
+    if (!slow) return found;
+  }
+  const int f = fast_compare(c, op, x, y);
   if (f >= 0) return f;
   if (f == -1) return 3;
   const Val v = compare_op_slow(c, L, a & 0xFF, x, y);
@@ -244,8 +263,16 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
     return m & all;
   };
   // policy / scope outputs are written at the moment an action's (tentative) result changes
+  // The first four actions keep theirs in registers until the end (no stores in the middle of the
+  // kernel: vmcnt is in-order, an early store would sit in front of every later load's wait).
+  u32 pol0 = 0, pol1 = 0, pol2 = 0, pol3 = 0, scp0 = CBH_NONE, scp1 = CBH_NONE, scp2 = CBH_NONE, scp3 = CBH_NONE;
   auto write_ps = [&](u64 mask, u32 polw, u32 scpw) {
     if (!want_ps) return;
+    if (mask & 1) { pol0 = polw; scp0 = scpw; }
+    if (mask & 2) { pol1 = polw; scp1 = scpw; }
+    if (mask & 4) { pol2 = polw; scp2 = scpw; }
+    if (mask & 8) { pol3 = polw; scp3 = scpw; }
+    mask &= ~0xFull;
     while (mask) {
       const u32 k = (u32)__builtin_ctzll(mask);
       mask &= mask - 1;
@@ -459,6 +486,16 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
 
   if (valid) {
     if (o.edr) o.edr[req] = edr_acc;
+    if (want_ps) {
+      const u32 pk[4] = {pol0, pol1, pol2, pol3}, sk[4] = {scp0, scp1, scp2, scp3};
+#pragma unroll
+      for (u32 k = 0; k < 4; ++k) {
+        if (k < act_cnt) {
+          if (o.policy) o.policy[act_off + k] = pk[k];
+          if (o.scope) o.scope[act_off + k] = sk[k];
+        }
+      }
+    }
     for (u32 k = 0; k < act_cnt; ++k) {
       const u64 bit = 1ull << k;
       o.effect[act_off + k] = (u8)((eff_allow & bit) ? CBH_EFFECT_ALLOW : CBH_EFFECT_DENY);   // NO_MATCH -> DENY (check.go:451-453)
@@ -488,8 +525,10 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs* 
   __shared__ u8 s_tag[CBH_STACK_DEPTH * CBH_BLOCK];
   __shared__ u8 l_tag[CBH_MAX_LOCALS * CBH_BLOCK];
   const u32 ncc = cached_columns(ka);
-  Ctx c{ka->t, ka->b, ka->now_ns, ka->flags, threadIdx.x, s_val, s_tag, l_val, l_tag, it_cont, it_idx, it_state,
-        reinterpret_cast<u64*>(cbh_dyn_lds), cbh_dyn_lds + (size_t)ncc * CBH_BLOCK * 8, ncc};
+  Ctx c{ka->t, ka->b, ka->now_ns, ka->flags, threadIdx.x,
+        (CBH_L u64*)s_val, (CBH_L u8*)s_tag, (CBH_L u64*)l_val, (CBH_L u8*)l_tag,
+        (CBH_L u64*)it_cont, (CBH_L u32*)it_idx, (CBH_L u32*)it_state,
+        (CBH_L u64*)cbh_dyn_lds, (CBH_L u8*)(cbh_dyn_lds + (size_t)ncc * CBH_BLOCK * 8), ncc};
   check_body<true>(ka, c);
 }
 
@@ -497,6 +536,6 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs* 
 __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel_leaf(const KernelArgs* __restrict__ ka) {
   const u32 ncc = cached_columns(ka);
   Ctx c{ka->t, ka->b, ka->now_ns, ka->flags, threadIdx.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-        reinterpret_cast<u64*>(cbh_dyn_lds), cbh_dyn_lds + (size_t)ncc * CBH_BLOCK * 8, ncc};
+        (CBH_L u64*)cbh_dyn_lds, (CBH_L u8*)(cbh_dyn_lds + (size_t)ncc * CBH_BLOCK * 8), ncc};
   check_body<false>(ka, c);
 }

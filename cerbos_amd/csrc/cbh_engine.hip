@@ -29,6 +29,8 @@
 #include "cbh_image.h"
 
 // ======================================================================== host code
+// (skipped in the device compilation pass, where the device structs carry address-space qualifiers)
+#if !defined(__HIP_DEVICE_COMPILE__)
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return -1; }
@@ -50,6 +52,8 @@ struct cbh_device_batch {
   BatchDev dev{};
   OutDev out{};
   KernelArgs* d_args = nullptr;   // device copy of the launch arguments
+  KernelArgs last_args;           // what d_args currently holds
+  bool have_args = false;
   std::vector<void*> allocs;
 };
 
@@ -208,11 +212,16 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   hipStream_t s = t->stream;
   if (t->pending) { HIPCHK(hipEventSynchronize(t->ev[3])); collect_times(t); }
   const BatchDev& d = b->dev;
-  HIPCHK(hipMemsetAsync(b->out.edr, 0, (size_t)(d.n_requests ? d.n_requests : 1) * sizeof(u64), s));
   {
-    KernelArgs ka{};
+    // launch arguments live in device memory; re-sent only when they change (the kernel itself
+    // writes every output word of every request, so nothing needs clearing between launches)
+    KernelArgs ka;
+    std::memset(&ka, 0, sizeof(ka));
     ka.t = t->dev; ka.b = d; ka.o = b->out; ka.now_ns = p->now_ns; ka.flags = p->flags;
-    HIPCHK(hipMemcpyAsync(b->d_args, &ka, sizeof(ka), hipMemcpyHostToDevice, s));
+    if (!b->have_args || std::memcmp(&ka, &b->last_args, sizeof(ka)) != 0) {
+      b->last_args = ka; b->have_args = true;
+      HIPCHK(hipMemcpyAsync(b->d_args, &b->last_args, sizeof(ka), hipMemcpyHostToDevice, s));
+    }
   }
   HIPCHK(hipEventRecord(t->ev[0], s));
   const u32 maxw = std::max(std::max(t->dev.nfa_words[0], t->dev.nfa_words[1]), t->dev.nfa_words[2]);
@@ -284,3 +293,4 @@ extern "C" int cbh_check_batch(cbh_table* t, const cbh_batch* in, const cbh_para
   cbh_batch_release(b);
   return rc;
 }
+#endif  // !__HIP_DEVICE_COMPILE__

@@ -11,6 +11,7 @@
 
 // Fills `d` / `meta` from a table image.  `base` is the address the image lives at (device or host),
 // `host_copy` a readable copy of it.  Returns nullptr on success or a static error string.
+#if !defined(__HIP_DEVICE_COMPILE__)   // host code: in the device pass the struct members are address-space qualified
 static inline const char* cbh_parse_image(TableDev& d, std::vector<uint32_t>& meta_out, const uint8_t* base, const uint8_t* host_copy, size_t len) {
   if (len < sizeof(CbhBlobHeader)) return ("blob too small");
   const CbhBlobHeader* h = reinterpret_cast<const CbhBlobHeader*>(host_copy);
@@ -45,6 +46,8 @@ static inline const char* cbh_parse_image(TableDev& d, std::vector<uint32_t>& me
   d.code = (const u32*)dptr(CBH_SEC_CODE);
   d.const_tag = dptr(CBH_SEC_CONST_TAG); d.const_val = (const u64*)dptr(CBH_SEC_CONST_VAL);
   d.theap_tag = dptr(CBH_SEC_THEAP_TAG); d.theap_val = (const u64*)dptr(CBH_SEC_THEAP_VAL);
+  d.const_rec = (const u32*)dptr(CBH_SEC_CONST_REC); d.theap_rec = (const u32*)dptr(CBH_SEC_THEAP_REC);
+  if (!d.const_rec || !d.theap_rec) return ("blob is missing the constant record sections");
   d.gbits = (const u64*)dptr(CBH_SEC_GBITS); d.K = m[CBH_M_NSTRINGS];
   d.nfa[0] = (const u64*)dptr(CBH_SEC_NFA_ACTION); d.nfa[1] = (const u64*)dptr(CBH_SEC_NFA_ROLE); d.nfa[2] = (const u64*)dptr(CBH_SEC_NFA_KIND);
   d.nfa_words[0] = m[CBH_M_NFA_WORDS_ACTION]; d.nfa_words[1] = m[CBH_M_NFA_WORDS_ROLE]; d.nfa_words[2] = m[CBH_M_NFA_WORDS_KIND];
@@ -53,4 +56,5 @@ static inline const char* cbh_parse_image(TableDev& d, std::vector<uint32_t>& me
   if (!d.hash || !d.code || !d.str_off || !d.scope_flags) return ("blob is missing required sections");
   return nullptr;
 }
+#endif  // !__HIP_DEVICE_COMPILE__
 

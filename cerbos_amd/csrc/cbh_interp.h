@@ -31,7 +31,7 @@ __device__ __forceinline__ u32 first_lane(u64 m) { return (u32)__builtin_ctzll(m
 // so it is read through the constant address space: the compiler emits s_load_dword (scalar
 // cache, result in an SGPR) instead of a 64-lane vector load of one address.
 #ifndef CBH_HOSTSIM
-__device__ __forceinline__ u32 uload(const u32* p) {
+template <typename P> __device__ __forceinline__ u32 uload(P p) {   // P: pointer to u32 in any address space
   typedef const __attribute__((address_space(4))) u32* cptr;
   return *(cptr)(unsigned long long)(p);
 }
@@ -40,9 +40,9 @@ static inline u32 uload(const u32* p) { return *p; }
 #endif
 // a pointer every lane holds identically, moved to scalar registers (e.g. after it travelled through
 // memory into a non-inlined function, where the compiler can no longer tell it is uniform)
-template <typename T> __device__ __forceinline__ const T* uniform_ptr(const T* p) {
+template <typename P> __device__ __forceinline__ P uniform_ptr(P p) {
   const unsigned long long v = (unsigned long long)p;
-  return (const T*)(((unsigned long long)uniform((u32)(v >> 32)) << 32) | uniform((u32)v));
+  return (P)(((unsigned long long)uniform((u32)(v >> 32)) << 32) | uniform((u32)v));
 }
 __device__ __forceinline__ u64 wave_readlane64(u64 v, u32 lane) {
   return (u64)wave_readlane((u32)v, lane) | ((u64)wave_readlane((u32)(v >> 32), lane) << 32);
@@ -78,7 +78,7 @@ __device__ int run_uniform(const Ctx& c, Lane& L, u32 pc, bool active) {
   u32 tree_acc = 0;       // bit d = accumulator at tree depth d
   int tree_depth = 0;
   pc = uniform(pc);
-  const u32* code = uniform_ptr(c.t.code);
+  const CBH_G u32* code = uniform_ptr(c.t.code);
   for (u32 steps = 0; steps < 1000000u; ++steps) {
     const u32 w = uload(&code[pc]); ++pc;
     const u32 op = w & 0xFFu, a = w >> 8;
@@ -231,7 +231,7 @@ __device__ int run_uniform(const Ctx& c, Lane& L, u32 pc, bool active) {
         Val x = TOPV(0);
         if (x.t == CBH_T_TIMESTAMP) break;
         if (x.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
-        const u8* p; u32 n; str_span(c, (u32)x.v, p, n);
+        gbytes p; u32 n; str_span(c, (u32)x.v, p, n);
         i64 ns = 0; int rc = parse_timestamp(p, n, ns);
         if (rc == 2 && live) L.status |= CBH_ST_UNSUPPORTED;
         if (rc != 0) { ST(sp - 1) = CBH_T_ERR; break; }
@@ -242,7 +242,7 @@ __device__ int run_uniform(const Ctx& c, Lane& L, u32 pc, bool active) {
         Val x = TOPV(0);
         if (x.t == CBH_T_DURATION) break;
         if (x.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
-        const u8* p; u32 n; str_span(c, (u32)x.v, p, n);
+        gbytes p; u32 n; str_span(c, (u32)x.v, p, n);
         i64 ns = 0;
         if (parse_duration(p, n, ns) != 0) { ST(sp - 1) = CBH_T_ERR; break; }
         SETTOP(mk(CBH_T_DURATION, (u64)ns));
@@ -354,7 +354,7 @@ __device__ int run_uniform(const Ctx& c, Lane& L, u32 pc, bool active) {
       case OP_INIPRANGE: {
         Val y = TOPV(0), x = TOPV(1); --sp;
         if (x.t != CBH_T_STRING || y.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
-        const u8 *pi, *pc2; u32 ni, nc;
+        gbytes pi, pc2; u32 ni, nc;
         str_span(c, (u32)x.v, pi, ni); str_span(c, (u32)y.v, pc2, nc);
         bool v6 = false;
         for (u32 i = 0; i < ni; ++i) v6 |= pi[i] == ':';

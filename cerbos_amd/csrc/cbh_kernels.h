@@ -21,7 +21,7 @@ __device__ __forceinline__ u32 hash4(u32 a, u32 b, u32 c, u32 d) {
 __device__ inline bool dir_find(const TableDev& t, u32 k0, u32 k1, u32 k2, u32 k3, uint4& v) {
   u32 i = hash4(k0, k1, k2, k3) & t.hash_mask;
   for (u32 probe = 0; probe <= t.hash_mask; ++probe) {
-    const uint4* s = reinterpret_cast<const uint4*>(&t.hash[i]);
+    const CBH_G uint4* s = (const CBH_G uint4*)(&t.hash[i]);
     uint4 k = s[0];
     if (k.x == CBH_NONE) return false;
     if (k.x == k0 && k.y == k1 && k.z == k2 && k.w == k3) { v = s[1]; return true; }
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_resolve_globs_kernel(TableDev t
       }
     }
     // accept table follows the transition arrays in global memory
-    const u32* acc = reinterpret_cast<const u32*>(t.nfa[dim] + (size_t)(2 + 512) * nw);
+    const CBH_G u32* acc = (const CBH_G u32*)(t.nfa[dim] + (size_t)(2 + 512) * nw);
     const u32 nacc = acc[0];
     u64 out = 0;
     for (u32 k = 0; k < nacc; ++k) {

@@ -21,37 +21,54 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 typedef int64_t i64;
 
-#define CBH_BLOCK 256
+// One wave per workgroup: the kernels need no cross-wave cooperation, and with one lane per
+// request a 1M-tuple batch is only ~4k waves, so single-wave groups spread evenly over 256 CUs.
+#define CBH_BLOCK 64
 #define CBH_STACK_DEPTH 10
 #define CBH_MAX_LOCALS 4
 #define CBH_MAX_ITERS 2
 
+// Address spaces.  The structs below are filled by host code with plain pointers and read by the
+// kernels out of device memory; a pointer loaded from memory is a *flat* pointer to the compiler
+// (flat_load: slower, and it ties vmcnt and lgkmcnt together).  In the device compilation pass the
+// members are therefore declared in their real address space - global (1) for table / batch /
+// output arrays, LDS (3) for the per-lane VM state - which turns every access into
+// global_load / ds_read.  Same size and layout in both passes.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CBH_HOSTSIM)
+#define CBH_G __attribute__((address_space(1)))
+#define CBH_L __attribute__((address_space(3)))
+#else
+#define CBH_G
+#define CBH_L
+#endif
+
 struct TableDev {
-  const u32* str_off; const u8* str_bytes;
-  const u32* scope_parent; const u32* scope_flags;
-  const CbhHashSlot* hash; u32 hash_mask;
-  const u32* rows; u32 n_rows;
-  const u32* rprows; u32 n_rprows;
-  const u32* pool;
-  const u32* dr; u32 n_dr;
-  const u32* code;
-  const u8* const_tag; const u64* const_val;
-  const u8* theap_tag; const u64* theap_val;
-  const u64* gbits; u32 K;
-  const u64* nfa[3]; u32 nfa_words[3];
+  const CBH_G u32* str_off; const CBH_G u8* str_bytes;
+  const CBH_G u32* scope_parent; const CBH_G u32* scope_flags;
+  const CBH_G CbhHashSlot* hash; u32 hash_mask;
+  const CBH_G u32* rows; u32 n_rows;
+  const CBH_G u32* rprows; u32 n_rprows;
+  const CBH_G u32* pool;
+  const CBH_G u32* dr; u32 n_dr;
+  const CBH_G u32* code;
+  const CBH_G u8* const_tag; const CBH_G u64* const_val;
+  const CBH_G u8* theap_tag; const CBH_G u64* theap_val;
+  const CBH_G u32* const_rec; const CBH_G u32* theap_rec;   // the same values as 16-byte scalar-loadable records
+  const CBH_G u64* gbits; u32 K;
+  const CBH_G u64* nfa[3]; u32 nfa_words[3];
   u32 flags;
 };
 
 struct BatchDev {
   u32 n_requests, n_tuples, n_roles, n_columns, n_strings, heap_len;
-  const u32* req_u32; const u32* roles; const u32* tuple_req; const u32* tuple_action;
-  const u8* col_tag; const u64* col_val;
-  const u8* heap_tag; const u64* heap_val;
-  const u32* str_off; const u8* str_bytes; const u8* str_flags;
-  u64* gbits; // [3][n_strings], written by the resolve kernel
+  const CBH_G u32* req_u32; const CBH_G u32* roles; const CBH_G u32* tuple_req; const CBH_G u32* tuple_action;
+  const CBH_G u8* col_tag; const CBH_G u64* col_val;
+  const CBH_G u8* heap_tag; const CBH_G u64* heap_val;
+  const CBH_G u32* str_off; const CBH_G u8* str_bytes; const CBH_G u8* str_flags;
+  CBH_G u64* gbits; // [3][n_strings], written by the resolve kernel
 };
 
-struct OutDev { u8* effect; u32* policy; u32* scope; u8* status; u64* edr; };
+struct OutDev { CBH_G u8* effect; CBH_G u32* policy; CBH_G u32* scope; CBH_G u8* status; CBH_G u64* edr; };
 
 // Launch arguments of the decision kernel.  They live in device memory (one uniform pointer
 // as the only kernel argument) so that every table / batch base address is a scalar load.
@@ -69,13 +86,13 @@ struct Lane {           // per-lane evaluation state that programs can observe
 struct Ctx {
   const TableDev& t; const BatchDev& b;
   i64 now_ns; u32 flags; u32 tid;
-  u64* s_val; u8* s_tag;       // operand stack   [CBH_STACK_DEPTH][CBH_BLOCK]
-  u64* l_val; u8* l_tag;       // locals          [CBH_MAX_LOCALS][CBH_BLOCK]
-  u64* it_cont; u32* it_idx; u32* it_state; // iteration slots [CBH_MAX_ITERS][CBH_BLOCK]
+  CBH_L u64* s_val; CBH_L u8* s_tag;       // operand stack   [CBH_STACK_DEPTH][CBH_BLOCK]
+  CBH_L u64* l_val; CBH_L u8* l_tag;       // locals          [CBH_MAX_LOCALS][CBH_BLOCK]
+  CBH_L u64* it_cont; CBH_L u32* it_idx; CBH_L u32* it_state; // iteration slots [CBH_MAX_ITERS][CBH_BLOCK]
   // Per-lane cache of the request's first n_cached attribute columns, filled once in the kernel
   // preamble (all loads in flight together) so condition leaves read LDS instead of paying one
   // HBM round trip each.  [column][lane]
-  u64* cc_val; u8* cc_tag; u32 n_cached;
+  CBH_L u64* cc_val; CBH_L u8* cc_tag; u32 n_cached;
 };
 #define CBH_CACHE_COLS 16
 
@@ -86,8 +103,9 @@ __device__ __forceinline__ double as_f64(u64 v) { return __longlong_as_double((l
 __device__ __forceinline__ u64 f64_bits(double d) { return (u64)__double_as_longlong(d); }
 __device__ __forceinline__ bool is_num(u32 t) { return t == CBH_T_INT || t == CBH_T_UINT || t == CBH_T_DOUBLE; }
 
+typedef const CBH_G u8* gbytes;   // string bytes live in the table image / batch pool (global memory)
 // ---- strings -------------------------------------------------------------------------
-__device__ __forceinline__ void str_span(const Ctx& c, u32 sid, const u8*& p, u32& n) {
+__device__ __forceinline__ void str_span(const Ctx& c, u32 sid, gbytes& p, u32& n) {
   if (sid < c.t.K) {
     u32 o = c.t.str_off[sid];
     n = c.t.str_off[sid + 1] - o;
@@ -102,7 +120,7 @@ __device__ __forceinline__ void str_span(const Ctx& c, u32 sid, const u8*& p, u3
 
 __device__ inline int str_cmp(const Ctx& c, u32 a, u32 b) {
   if (a == b) return 0;
-  const u8 *pa, *pb; u32 na, nb;
+  gbytes pa, pb; u32 na, nb;
   str_span(c, a, pa, na); str_span(c, b, pb, nb);
   u32 n = na < nb ? na : nb;
   for (u32 i = 0; i < n; ++i) {
@@ -113,14 +131,14 @@ __device__ inline int str_cmp(const Ctx& c, u32 a, u32 b) {
 
 // number of code points (CEL size(string))
 __device__ inline u32 str_codepoints(const Ctx& c, u32 sid) {
-  const u8* p; u32 n; str_span(c, sid, p, n);
+  gbytes p; u32 n; str_span(c, sid, p, n);
   u32 k = 0;
   for (u32 i = 0; i < n; ++i) k += ((p[i] & 0xC0) != 0x80);
   return k;
 }
 
 __device__ inline bool str_find(const Ctx& c, u32 hay, u32 needle, int mode /*0 starts,1 ends,2 contains*/) {
-  const u8 *ph, *pn; u32 nh, nn;
+  gbytes ph, pn; u32 nh, nn;
   str_span(c, hay, ph, nh); str_span(c, needle, pn, nn);
   if (nn > nh) return false;
   u32 lo = 0, hi = nh - nn;
@@ -254,7 +272,7 @@ __device__ inline i64 days_from_civil(i64 y, u32 m, u32 d) {
 __device__ __forceinline__ bool dig(u8 ch) { return ch >= '0' && ch <= '9'; }
 
 // RFC 3339 (Go time.Parse(time.RFC3339)): returns 0 ok, 1 parse error, 2 outside the i64-ns range
-__device__ inline int parse_timestamp(const u8* p, u32 n, i64& out_ns) {
+__device__ inline int parse_timestamp(gbytes p, u32 n, i64& out_ns) {
   if (n < 20) return 1;
   for (int i = 0; i < 19; ++i) {
     bool d = dig(p[i]);
@@ -295,7 +313,7 @@ __device__ inline int parse_timestamp(const u8* p, u32 n, i64& out_ns) {
 }
 
 // Go time.ParseDuration: returns 0 ok, 1 error
-__device__ inline int parse_duration(const u8* p, u32 n, i64& out_ns) {
+__device__ inline int parse_duration(gbytes p, u32 n, i64& out_ns) {
   u32 i = 0; bool neg = false;
   if (n == 0) return 1;
   if (p[0] == '-' || p[0] == '+') { neg = p[0] == '-'; i = 1; }
@@ -331,7 +349,7 @@ __device__ inline int parse_duration(const u8* p, u32 n, i64& out_ns) {
     u32 us = i;
     while (i < n && p[i] != '.' && !dig(p[i])) ++i;
     u32 ul = i - us; if (ul == 0) return 1;
-    u64 unit = 0; const u8* q = p + us;
+    u64 unit = 0; gbytes q = p + us;
     if (ul == 2 && q[0] == 'n' && q[1] == 's') unit = 1;
     else if (ul == 2 && q[0] == 'u' && q[1] == 's') unit = 1000;
     else if (ul == 3 && q[0] == 0xC2 && q[1] == 0xB5 && q[2] == 's') unit = 1000;
@@ -358,7 +376,7 @@ __device__ inline int parse_duration(const u8* p, u32 n, i64& out_ns) {
 
 // dotted IPv4 "a.b.c.d" (Go netip / net.ParseIP accept no leading zeros > 1 digit... net.ParseCIDR and
 // net.ParseIP reject leading zeros since Go 1.17): returns false on any deviation.
-__device__ inline bool parse_ipv4(const u8* p, u32 n, u32& out) {
+__device__ inline bool parse_ipv4(gbytes p, u32 n, u32& out) {
   u32 v = 0, parts = 0, i = 0;
   while (parts < 4) {
     if (i >= n || !dig(p[i])) return false;

@@ -32,7 +32,7 @@ PAT_GLOB = 0x80000000
 (SEC_META, SEC_STR_OFF, SEC_STR_BYTES, SEC_SCOPE_PARENT, SEC_SCOPE_FLAGS, SEC_SCOPE_SID, SEC_HASH,
  SEC_ROWS, SEC_RPROWS, SEC_U32POOL, SEC_DR, SEC_CODE, SEC_CONST_TAG, SEC_CONST_VAL, SEC_THEAP_TAG,
  SEC_THEAP_VAL, SEC_GBITS, SEC_NFA_ACTION, SEC_NFA_ROLE, SEC_NFA_KIND, SEC_POLICY_SID,
- SEC_DRNAME_SID) = range(1, 23)
+ SEC_DRNAME_SID, SEC_CONST_REC, SEC_THEAP_REC) = range(1, 25)
 
 (M_NSTRINGS, M_NCOLUMNS, M_NSCOPES, M_HASH_MASK, M_NROWS, M_NRPROWS, M_NDR, M_NPOLICIES, M_NCONSTS,
  M_CODE_LEN, M_FLAGS, M_MAX_STACK, M_NDRNAMES, M_NFA_WORDS_ACTION, M_NFA_WORDS_ROLE,
@@ -353,6 +353,13 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
     def u8(a):
         return np.asarray(a, dtype=np.uint8).tobytes()
 
+    def val_records(tags, vals):
+        out = np.zeros((len(tags), 4), dtype=np.uint32)
+        for i, (tg, v) in enumerate(zip(tags, vals)):
+            v = int(v) & 0xFFFFFFFFFFFFFFFF
+            out[i] = (tg, 0, v & 0xFFFFFFFF, v >> 32)
+        return out.tobytes()
+
     def row_major(cols, width):
         """Records of `width` u32 (fields = cols, zero padded): one wide scalar load per record."""
         n = len(cols[0])
@@ -385,6 +392,10 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         (SEC_NFA_KIND, lt.nfas[2].words, nfa_bytes[2]),
         (SEC_POLICY_SID, len(lt.policy_keys), u32([0] * len(lt.policy_keys))),
         (SEC_DRNAME_SID, len(lt.dr_names), u32([0] * len(lt.dr_names))),
+        # the same constants / constant-heap entries as 16-byte records {tag, 0, lo, hi}: one
+        # s_load_dwordx4 at a wave-uniform index (fused leaves read their constant operands this way)
+        (SEC_CONST_REC, len(pb.const_tag), val_records(pb.const_tag, pb.const_val)),
+        (SEC_THEAP_REC, len(pb.theap_tag), val_records(pb.theap_tag, pb.theap_val)),
     ]
     lt.blob = _pack(sections)
     lt.stats = {

@@ -30,7 +30,7 @@
 struct uint4 { uint32_t x, y, z, w; };
 struct Dim3 { uint32_t x = 0, y = 0, z = 0; };
 
-static const int HS_BLOCK = 256, HS_WAVE = 64;
+static const int HS_BLOCK = 64, HS_WAVE = 64;   // = CBH_BLOCK (checked below)
 struct Fiber {
   ucontext_t ctx;
   std::vector<char> stack;
@@ -75,6 +75,7 @@ static inline void __syncthreads() { hs_yield(2); }
 #include "../../cerbos_amd/csrc/cbh_kernels.h"
 #include "../../cerbos_amd/csrc/cbh_image.h"
 
+static_assert(HS_BLOCK == CBH_BLOCK, "hostsim block size must match the kernels'");
 static thread_local std::string g_err;
 extern "C" const char* hostsim_last_error() { return g_err.c_str(); }
 
