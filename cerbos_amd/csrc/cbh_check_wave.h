@@ -48,7 +48,7 @@ template <typename R, typename P>
 __device__ __forceinline__ R uload_rec(P base, u32 idx) {   // P: pointer to u32 in any address space
 #ifndef CBH_HOSTSIM
   static_assert(sizeof(R) == 16 || sizeof(R) == 32, "table records are 4 or 8 dwords");
-  const unsigned long long addr = (unsigned long long)(base + (size_t)idx * (sizeof(R) / 4));
+  const unsigned long long addr = uniform_addr((unsigned long long)(base + (size_t)idx * (sizeof(R) / 4)));
   R r;
   if constexpr (sizeof(R) == 32) {
     typedef u32 u32x8 __attribute__((ext_vector_type(8)));
@@ -131,32 +131,22 @@ __device__ __forceinline__ int leaf_value(const Ctx& c, Lane& L, u32 w, u32 a0, 
   const int f = fast_compare(c, op, x, y);
   if (f >= 0) return f;
   if (f == -1) return 3;
-  const Val v = compare_op_slow(c, L, a & 0xFF, x, y);
+  const SlowVal v = compare_op_slow(c.ka_mem, L.req, a & 0xFF, x, y);
+  L.status |= v.status;
   if (v.t == CBH_T_ERR) return 3;
   return (v.t == CBH_T_BOOL && v.v) ? 1 : 0;
 }
 
-// Evaluate a condition reference for the lanes with active=true (all lanes call together).
-// Per lane: 0 = not satisfied, 1 = satisfied, 2 = strict-mode evaluation error.
-//   CBH_COND_LEAF     one fused leaf: evaluated inline
-//   CBH_COND_LEAFTREE all/any/none tree whose leaves are all fused leaves: inline, no operand
-//                     stack (each TREE_ACC consumes the value its child just produced)
-//   otherwise         the operand-stack interpreter (GENERIC instantiation only)
-template <bool GENERIC>
-__device__ __forceinline__ int eval_cond(const Ctx& c, Lane& L, u32 ref, bool active) {
+// all/any/none tree of fused leaves, out of line: a real call keeps the (hot) single-leaf path and the
+// rule-row loop around it small.  Works from the launch arguments in memory like run_uniform.
+#ifndef CBH_HOSTSIM
+__attribute__((noinline))
+#endif
+__device__ u32 eval_leaf_tree(const KernelArgs* ka, const VmLds lds, u32 req, u32 pc, bool active) {
+  const Ctx c = ctx_from_memory(uniform_ptr(ka), lds);
+  Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false;   // leaves never read runtime.*
   const bool strict = (c.flags & CBH_F_STRICT_EVALUATION) != 0;
-  if (ref & CBH_COND_LEAF) {
-    const u32 pc = ref & CBH_COND_PC_MASK;
-    const u32 w = uload(&c.t.code[pc]), a0 = uload(&c.t.code[pc + 1]), a1 = uload(&c.t.code[pc + 2]);
-    int r = 0;
-    if (active) {
-      r = leaf_value(c, L, w, a0, a1);
-      if (r == 3) { L.status |= CBH_ST_CEL_ERROR; r = strict ? 2 : 0; }
-    }
-    return r;
-  }
-  if (ref & CBH_COND_LEAFTREE) {
-    u32 pc = ref & CBH_COND_PC_MASK;
+  pc = uniform(pc);
     bool live = active, last = false;
     int result = 0;
     u32 saved = 0, acc = 0, depth = 0;
@@ -189,21 +179,71 @@ __device__ __forceinline__ int eval_cond(const Ctx& c, Lane& L, u32 ref, bool ac
         last = ((acc & bit) != 0) != (a == 2);
       } else break;   // OP_RET
     }
-    if (result == 2) return 2;
-    return (active && last) ? 1 : 0;
+    const u32 r = result == 2 ? 2u : ((active && last) ? 1u : 0u);
+    return r | (L.status << 8);   // result | status bits raised while evaluating
+}
+
+// Evaluate a condition reference for the lanes with active=true (all lanes call together).
+// Per lane: 0 = not satisfied, 1 = satisfied, 2 = strict-mode evaluation error.
+//   CBH_COND_LEAF     one fused leaf: evaluated inline
+//   CBH_COND_LEAFTREE all/any/none tree whose leaves are all fused leaves: inline, no operand
+//                     stack (each TREE_ACC consumes the value its child just produced)
+//   otherwise         the operand-stack interpreter (GENERIC instantiation only)
+template <bool GENERIC>
+__device__ __forceinline__ int eval_cond(const Ctx& c, Lane& L, u32 ref, bool active) {
+  const bool strict = (c.flags & CBH_F_STRICT_EVALUATION) != 0;
+  if (ref & CBH_COND_LEAF) {
+    const u32 pc = ref & CBH_COND_PC_MASK;
+    const u32 w = uload(&c.t.code[pc]), a0 = uload(&c.t.code[pc + 1]), a1 = uload(&c.t.code[pc + 2]);
+    int r = 0;
+    if (active) {
+      r = leaf_value(c, L, w, a0, a1);
+      if (r == 3) { L.status |= CBH_ST_CEL_ERROR; r = strict ? 2 : 0; }
+    }
+    return r;
   }
-  if (GENERIC) return run_uniform(c, L, ref, active);
+  if (ref & CBH_COND_LEAFTREE) {
+    const u32 r = eval_leaf_tree(c.ka_mem, lds_of(c), L.req, ref & CBH_COND_PC_MASK, active);
+    L.status |= r >> 8;
+    return (int)(r & 0xFF);
+  }
+  if (GENERIC) {
+    const u32 r = run_uniform(c.ka_mem, lds_of(c), L.req, L.edr, L.edr_err, ref, active);
+    L.status |= r >> 8;
+    return (int)(r & 0xFF);
+  }
   if (active) L.status |= CBH_ST_UNSUPPORTED;   // unreachable: the host picks the GENERIC kernel for such tables
   return 0;
 }
 
-template <bool GENERIC>
-__device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ctx& c) {
-  const TableDev& t = ka->t;
-  const BatchDev& b = ka->b;
-  const OutDev& o = ka->o;
-  const u32 flags = ka->flags;
+// Copy the launch arguments into registers once, with scalar loads.  Read through the pointer they
+// would be re-fetched from memory (vector loads + a full wait) at every use inside the loops, because
+// the compiler cannot prove the kernel's own stores leave them untouched.
+__device__ __forceinline__ void load_args(KernelArgs& dst, const KernelArgs* src) {
+#ifndef CBH_HOSTSIM
+  typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+  static_assert(sizeof(KernelArgs) % 16 == 0, "KernelArgs is copied in 16-byte scalar loads");
+  constexpr int N = sizeof(KernelArgs) / 16;
+  const unsigned long long base = uniform_addr((unsigned long long)src);
+  u32x4 v[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = *(const __attribute__((address_space(4))) u32x4*)(base + 16ull * i);
+  __builtin_memcpy(&dst, v, sizeof(KernelArgs));
+#else
+  dst = *src;
+#endif
+}
 
+template <bool GENERIC>
+__device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
+  const TableDev& t = ka_regs.t;
+  const BatchDev& b = ka_regs.b;
+  const OutDev& o = ka_regs.o;
+  const u32 flags = ka_regs.flags;
+
+#ifndef CBH_HOSTSIM
+  const u64 cyc_start = __builtin_readcyclecounter();
+#endif
   const u32 rix = blockIdx.x * CBH_BLOCK + threadIdx.x;
   const bool valid = rix < b.n_requests;
   const u32 req = valid ? rix : 0;   // tail lanes shadow request 0 and never store
@@ -303,6 +343,17 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
   }
 
   // ---- per-action state, bit k = k-th action of the request
+#ifndef CBH_HOSTSIM
+  const u64 cyc_pre = __builtin_readcyclecounter();   // only consumed under CBH_F_DEBUG_CYCLES
+  const bool dbg = (flags & CBH_F_DEBUG_CYCLES) != 0;
+  u64 dbg_t0 = 0, dbg_eval = 0, dbg_n = 0;
+#define DBG_T0() do { if (dbg) dbg_t0 = __builtin_readcyclecounter(); } while (0)
+#define DBG_ACC(acc) do { if (dbg) { acc += __builtin_readcyclecounter() - dbg_t0; ++dbg_n; } } while (0)
+#else
+  const u64 cyc_pre = 0;
+#define DBG_T0() do {} while (0)
+#define DBG_ACC(acc) do {} while (0)
+#endif
   u64 todo = (valid && !decided) ? all : 0;   // actions still being resolved
   u64 eff_allow = 0, eff_deny = 0;            // neither bit set = EFFECT_NO_MATCH so far
   u64 st_err = 0, st_unsup = 0;
@@ -454,12 +505,14 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
               if (wave_ballot(need != 0) == 0) continue;
               const bool m = need != 0;
               int r = 1;
+              DBG_T0();
               if (rw.drcond != CBH_NONE) r = eval_cond<GENERIC>(c, L, rw.drcond, m);   // check.go:328-366
               const bool m2 = m && r == 1;
               if (rw.cond != CBH_NONE && wave_ballot(m2) != 0) {                         // check.go:368-380
                 const int r2 = eval_cond<GENERIC>(c, L, rw.cond, m2);
                 if (m2) r = r2;
               }
+              DBG_ACC(dbg_eval);
               if (m) {
                 take_status(need);
                 if (r == 2) strict_deny(need, ((u32)CBH_P_TABLE << 28) | rw.policy, si);
@@ -484,6 +537,14 @@ __device__ __forceinline__ void check_body(const KernelArgs* __restrict__ ka, Ct
     todo &= ~(eff_allow | eff_deny);
   }
 
+#ifndef CBH_HOSTSIM
+  if ((flags & CBH_F_DEBUG_CYCLES) && want_ps && act_cnt >= 3) {
+    // profiling aid: policy words of the first three actions <- cycles spent in the preamble,
+    // in the two policy passes, and the wave's start time (low 32 bits)
+    const u64 cyc_end = __builtin_readcyclecounter();
+    pol0 = (u32)(cyc_pre - cyc_start); pol1 = (u32)(cyc_end - cyc_pre); pol2 = (u32)dbg_eval; pol3 = (u32)dbg_n;
+  }
+#endif
   if (valid) {
     if (o.edr) o.edr[req] = edr_acc;
     if (want_ps) {
@@ -524,18 +585,22 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs* 
   __shared__ u32 it_state[CBH_MAX_ITERS * CBH_BLOCK];
   __shared__ u8 s_tag[CBH_STACK_DEPTH * CBH_BLOCK];
   __shared__ u8 l_tag[CBH_MAX_LOCALS * CBH_BLOCK];
-  const u32 ncc = cached_columns(ka);
-  Ctx c{ka->t, ka->b, ka->now_ns, ka->flags, threadIdx.x,
+  KernelArgs a;
+  load_args(a, ka);
+  const u32 ncc = cached_columns(&a);
+  Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x,
         (CBH_L u64*)s_val, (CBH_L u8*)s_tag, (CBH_L u64*)l_val, (CBH_L u8*)l_tag,
         (CBH_L u64*)it_cont, (CBH_L u32*)it_idx, (CBH_L u32*)it_state,
-        (CBH_L u64*)cbh_dyn_lds, (CBH_L u8*)(cbh_dyn_lds + (size_t)ncc * CBH_BLOCK * 8), ncc};
-  check_body<true>(ka, c);
+        (CBH_L u64*)cbh_dyn_lds, (CBH_L u8*)(cbh_dyn_lds + (size_t)ncc * CBH_BLOCK * 8), ncc, ka};
+  check_body<true>(a, c);
 }
 
 // Leaf-only instantiation: no operand stack, no interpreter call.
 __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel_leaf(const KernelArgs* __restrict__ ka) {
-  const u32 ncc = cached_columns(ka);
-  Ctx c{ka->t, ka->b, ka->now_ns, ka->flags, threadIdx.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-        (CBH_L u64*)cbh_dyn_lds, (CBH_L u8*)(cbh_dyn_lds + (size_t)ncc * CBH_BLOCK * 8), ncc};
-  check_body<false>(ka, c);
+  KernelArgs a;
+  load_args(a, ka);
+  const u32 ncc = cached_columns(&a);
+  Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+        (CBH_L u64*)cbh_dyn_lds, (CBH_L u8*)(cbh_dyn_lds + (size_t)ncc * CBH_BLOCK * 8), ncc, ka};
+  check_body<false>(a, c);
 }

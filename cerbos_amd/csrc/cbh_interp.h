@@ -31,9 +31,14 @@ __device__ __forceinline__ u32 first_lane(u64 m) { return (u32)__builtin_ctzll(m
 // so it is read through the constant address space: the compiler emits s_load_dword (scalar
 // cache, result in an SGPR) instead of a 64-lane vector load of one address.
 #ifndef CBH_HOSTSIM
+// The address goes through readfirstlane: it pins the value to SGPRs and keeps the optimiser from
+// tracing the pointer back to its global-memory origin and demoting the load to a vector load.
+__device__ __forceinline__ unsigned long long uniform_addr(unsigned long long v) {
+  return ((unsigned long long)uniform((u32)(v >> 32)) << 32) | uniform((u32)v);
+}
 template <typename P> __device__ __forceinline__ u32 uload(P p) {   // P: pointer to u32 in any address space
   typedef const __attribute__((address_space(4))) u32* cptr;
-  return *(cptr)(unsigned long long)(p);
+  return *(cptr)uniform_addr((unsigned long long)(p));
 }
 #else
 static inline u32 uload(const u32* p) { return *p; }
@@ -69,7 +74,9 @@ __device__ __forceinline__ u64 wave_readlane64(u64 v, u32 lane) {
 #ifndef CBH_HOSTSIM
 __attribute__((noinline))
 #endif
-__device__ int run_uniform(const Ctx& c, Lane& L, u32 pc, bool active) {
+__device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 edr, bool edr_err, u32 pc, bool active) {
+  const Ctx c = ctx_from_memory(uniform_ptr(ka), lds);   // a real call: work from the arguments in memory
+  Lane L; L.req = req; L.edr = edr; L.status = 0; L.edr_err = edr_err;   // by value: see compare_op_slow
   int sp = 0;
   const bool strict = (c.flags & CBH_F_STRICT_EVALUATION) != 0;
   bool live = active;     // lane still evaluates leaves (tree-live && not aborted)
@@ -87,7 +94,7 @@ __device__ int run_uniform(const Ctx& c, Lane& L, u32 pc, bool active) {
     switch (op) {
       case OP_RET: {
         if (active && result != 2) result = (sp > 0 && ST(sp - 1) == CBH_T_BOOL && SV(sp - 1) != 0) ? 1 : 0;
-        return result;
+        return (u32)result | (L.status << 8);
       }
       case OP_CONST: PUSHV(mk(c.t.const_tag[a], c.t.const_val[a])); break;
       case OP_COL: PUSHV(load_operand(c, L, 1, a)); break;
@@ -393,5 +400,5 @@ __device__ int run_uniform(const Ctx& c, Lane& L, u32 pc, bool active) {
     if (!live_in) L.status = status_in;
   }
   L.status |= CBH_ST_UNSUPPORTED;  // step budget exhausted
-  return result;
+  return (u32)result | (L.status << 8);
 }

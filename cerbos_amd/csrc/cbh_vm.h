@@ -72,7 +72,7 @@ struct OutDev { CBH_G u8* effect; CBH_G u32* policy; CBH_G u32* scope; CBH_G u8*
 
 // Launch arguments of the decision kernel.  They live in device memory (one uniform pointer
 // as the only kernel argument) so that every table / batch base address is a scalar load.
-struct KernelArgs { TableDev t; BatchDev b; OutDev o; long long now_ns; u32 flags; u32 pad; };
+struct __attribute__((aligned(16))) KernelArgs { TableDev t; BatchDev b; OutDev o; long long now_ns; u32 flags; u32 pad; };
 
 struct Val { u32 t; u64 v; };
 
@@ -93,7 +93,25 @@ struct Ctx {
   // preamble (all loads in flight together) so condition leaves read LDS instead of paying one
   // HBM round trip each.  [column][lane]
   CBH_L u64* cc_val; CBH_L u8* cc_tag; u32 n_cached;
+  // The launch arguments as they sit in device memory.  `t` / `b` above refer to a register copy
+  // inside the kernels; functions that are real calls (slow paths, the stack interpreter) are
+  // handed this pointer instead and build their own view, so the register copy's address never
+  // escapes (it would be forced into scratch memory).
+  const KernelArgs* ka_mem;
 };
+// the LDS part of a Ctx, passed by value across real calls
+struct VmLds {
+  CBH_L u64* s_val; CBH_L u8* s_tag; CBH_L u64* l_val; CBH_L u8* l_tag;
+  CBH_L u64* it_cont; CBH_L u32* it_idx; CBH_L u32* it_state;
+  CBH_L u64* cc_val; CBH_L u8* cc_tag; u32 n_cached; u32 tid;
+};
+__device__ __forceinline__ VmLds lds_of(const Ctx& c) {
+  return VmLds{c.s_val, c.s_tag, c.l_val, c.l_tag, c.it_cont, c.it_idx, c.it_state, c.cc_val, c.cc_tag, c.n_cached, c.tid};
+}
+__device__ __forceinline__ Ctx ctx_from_memory(const KernelArgs* ka, const VmLds& m) {
+  return Ctx{ka->t, ka->b, ka->now_ns, ka->flags, m.tid, m.s_val, m.s_tag, m.l_val, m.l_tag, m.it_cont, m.it_idx,
+             m.it_state, m.cc_val, m.cc_tag, m.n_cached, ka};
+}
 #define CBH_CACHE_COLS 16
 
 __device__ __forceinline__ Val mk(u32 t, u64 v) { Val x; x.t = t; x.v = v; return x; }
@@ -480,7 +498,16 @@ __device__ inline Val compare_op(const Ctx& c, Lane& L, u32 op, Val x, Val y) {
 #ifndef CBH_HOSTSIM
 __attribute__((noinline))
 #endif
-__device__ Val compare_op_slow(const Ctx& c, Lane& L, u32 op, Val x, Val y) { return compare_op(c, L, op, x, y); }
+// Lane state crosses real calls BY VALUE (a reference would pin the caller's copy in scratch memory
+// and turn every L.req / L.status access of the hot path into a memory round trip).
+struct SlowVal { u32 t; u32 status; u64 v; };
+__device__ SlowVal compare_op_slow(const KernelArgs* ka, u32 req, u32 op, Val x, Val y) {
+  VmLds none{};   // comparisons touch only the table / batch arrays
+  const Ctx c = ctx_from_memory(ka, none);
+  Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false;
+  const Val r = compare_op(c, L, op, x, y);
+  return SlowVal{r.t, L.status, r.v};
+}
 
 // Same-type fast paths of compare_op for the inline fused-leaf evaluation.
 // Returns 1 / 0 = result, -1 = CEL error, -2 = not covered (caller takes the slow path).

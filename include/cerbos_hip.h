@@ -40,6 +40,7 @@ extern "C" {
 #define CBH_F_LENIENT_SCOPE_SEARCH 1u /* EvalParams.LenientScopeSearch */
 #define CBH_F_STRICT_EVALUATION 2u    /* EvalParams.StrictEvaluation   */
 #define CBH_F_WANT_DERIVED_ROLES 4u   /* fill cbh_result.edr_mask (CheckOutput.effective_derived_roles) */
+#define CBH_F_DEBUG_CYCLES 0x100u     /* profiling aid: policy words carry per-wave cycle counts, not policies */
 
 /* Per-request u32 fields, field-major: req_u32[field * n_requests + r]. */
 enum cbh_req_field {

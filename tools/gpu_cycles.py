@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""GPU-box profiling aid: per-wave cycle counts of the decision kernel (CBH_F_DEBUG_CYCLES)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from cerbos_amd import capi, workloads
+from cerbos_amd.flatten import Flattener
+from cerbos_amd.lower.blob import lower_rule_table
+from cerbos_amd.policy.loader import policies_from_docs
+from cerbos_amd.ruletable.build import rule_table_from_policies
+
+capi.init(0)
+lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c2_policies())))
+table = capi.Table(lt.blob)
+cr = workloads.c2_requests(250_000)
+batch = cr.to_batch(Flattener(lt))
+db = table.upload(batch)
+for _ in range(3):
+    table.launch(db, now_ns=1, flags=0x100)
+table.synchronize()
+res = table.download(db)
+pol = res.policy.reshape(-1, 4)[::64]          # lane 0 of every wave
+pre, body, ev, nev = (pol[:, k].astype(np.int64) for k in range(4))
+print("waves", len(pre))
+for name, a in (("preamble", pre), ("passes", body), ("eval_sum", ev), ("n_evals", nev)):
+    print("%-9s min %8d  p50 %8d  p90 %8d  max %8d" % (name, a.min(), np.median(a), np.percentile(a, 90), a.max()))
