@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define CBH_BLOB_MAGIC 0x31484243u /* "CBH1" */
-#define CBH_BLOB_VERSION 5u
+#define CBH_BLOB_VERSION 6u
 
 struct CbhBlobHeader {  // 32 bytes
   uint32_t magic;
@@ -102,16 +102,22 @@ enum CbhBucketType {
 // Pattern reference: bit31 set -> glob index within the dimension, else literal string id.
 #define CBH_PAT_GLOB 0x80000000u
 
-enum CbhRowField { // regular rows (resource + principal policies)
-  CBH_ROW_ACTION = 0,   // pattern ref (action dim)
-  CBH_ROW_ROLE = 1,     // pattern ref (role dim)
+// Regular rows (resource + principal policies).  One record stands for the rule-table rows of ONE
+// rule that share effect / condition / derived-role condition: the cross product of its role list
+// and its action list (a single role or action is stored inline, a list lives in U32POOL).
+enum CbhRowField {
+  CBH_ROW_ACTION = 0,   // pattern ref (action dim), or U32POOL offset of a list of them (CBH_ROW_F_ACTION_LIST)
+  CBH_ROW_ROLE = 1,     // pattern ref (role dim), or U32POOL offset of a list of them (CBH_ROW_F_ROLE_LIST)
   CBH_ROW_RESOURCE = 2, // pattern ref (kind dim) - tested for principal-policy rows only
-  CBH_ROW_FLAGS = 3,    // bits 0..1 effect (1 ALLOW, 2 DENY)
+  CBH_ROW_FLAGS = 3,    // bits 0..1 effect (1 ALLOW, 2 DENY), CBH_ROW_F_*
   CBH_ROW_COND = 4,     // program entry or CBH_NONE
   CBH_ROW_DRCOND = 5,   // program entry or CBH_NONE
   CBH_ROW_POLICY = 6,   // policy id of the origin policy (strict-mode attribution)
-  CBH_ROW_NF = 7
+  CBH_ROW_COUNTS = 7,   // action list length | role list length << 16 (0 = inline)
+  CBH_ROW_NF = 8
 };
+#define CBH_ROW_F_ACTION_LIST 4u
+#define CBH_ROW_F_ROLE_LIST 8u
 enum CbhRpField { // role-policy rows
   CBH_RP_RESOURCE = 0,  // pattern ref (kind dim)
   CBH_RP_ALLOW_OFF = 1, // into U32POOL: pattern refs (action dim)

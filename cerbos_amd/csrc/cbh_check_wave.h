@@ -39,7 +39,7 @@ __device__ __forceinline__ bool roleset_has(const TableDev& t, const RoleSet& rs
 
 // Table records are stored row-major and naturally aligned so that one wide scalar load
 // (s_load_dwordx4 / x8) fetches a whole record at a wave-uniform index.
-struct __attribute__((aligned(32))) TblRow { u32 action, role, resource, flags, cond, drcond, policy, pad; };
+struct __attribute__((aligned(32))) TblRow { u32 action, role, resource, flags, cond, drcond, policy, counts; };
 struct __attribute__((aligned(16))) TblRp { u32 resource, allow_off, allow_cnt, cond; };
 struct __attribute__((aligned(16))) TblDr { u32 name, parents_off, parents_cnt, cond; };
 struct __attribute__((aligned(32))) TblSlot { u32 k0, k1, k2, k3, v0, v1, v2, v3; };
@@ -189,31 +189,37 @@ __device__ u32 eval_leaf_tree(const KernelArgs* ka, const VmLds lds, u32 req, u3
 //   CBH_COND_LEAFTREE all/any/none tree whose leaves are all fused leaves: inline, no operand
 //                     stack (each TREE_ACC consumes the value its child just produced)
 //   otherwise         the operand-stack interpreter (GENERIC instantiation only)
+// A real call on purpose: the table walk around it then carries none of the evaluator's code or
+// registers, and the three places that evaluate conditions (derived roles, role policies, rule rows)
+// share one copy.  Returns result | status bits << 8.
 template <bool GENERIC>
-__device__ __forceinline__ int eval_cond(const Ctx& c, Lane& L, u32 ref, bool active) {
-  const bool strict = (c.flags & CBH_F_STRICT_EVALUATION) != 0;
+#ifndef CBH_HOSTSIM
+__attribute__((noinline))
+#endif
+__device__ u32 eval_ref(const KernelArgs* ka, const VmLds lds, u32 req, u64 edr, bool edr_err, u32 ref, bool active) {
+  ref = uniform(ref);
   if (ref & CBH_COND_LEAF) {
+    const Ctx c = ctx_from_memory(uniform_ptr(ka), lds);
     const u32 pc = ref & CBH_COND_PC_MASK;
     const u32 w = uload(&c.t.code[pc]), a0 = uload(&c.t.code[pc + 1]), a1 = uload(&c.t.code[pc + 2]);
-    int r = 0;
+    Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false;   // leaves never read runtime.*
+    u32 r = 0;
     if (active) {
-      r = leaf_value(c, L, w, a0, a1);
-      if (r == 3) { L.status |= CBH_ST_CEL_ERROR; r = strict ? 2 : 0; }
+      r = (u32)leaf_value(c, L, w, a0, a1);
+      if (r == 3) { L.status |= CBH_ST_CEL_ERROR; r = (c.flags & CBH_F_STRICT_EVALUATION) ? 2u : 0u; }
     }
-    return r;
+    return r | (L.status << 8);
   }
-  if (ref & CBH_COND_LEAFTREE) {
-    const u32 r = eval_leaf_tree(c.ka_mem, lds_of(c), L.req, ref & CBH_COND_PC_MASK, active);
-    L.status |= r >> 8;
-    return (int)(r & 0xFF);
-  }
-  if (GENERIC) {
-    const u32 r = run_uniform(c.ka_mem, lds_of(c), L.req, L.edr, L.edr_err, ref, active);
-    L.status |= r >> 8;
-    return (int)(r & 0xFF);
-  }
-  if (active) L.status |= CBH_ST_UNSUPPORTED;   // unreachable: the host picks the GENERIC kernel for such tables
-  return 0;
+  if (ref & CBH_COND_LEAFTREE) return eval_leaf_tree(ka, lds, req, ref & CBH_COND_PC_MASK, active);
+  if (GENERIC) return run_uniform(ka, lds, req, edr, edr_err, ref, active);
+  return active ? ((u32)CBH_ST_UNSUPPORTED << 8) : 0u;   // unreachable: the host picks the GENERIC kernel for such tables
+}
+
+template <bool GENERIC>
+__device__ __forceinline__ int eval_cond(const Ctx& c, Lane& L, u32 ref, bool active) {
+  const u32 r = eval_ref<GENERIC>(c.ka_mem, lds_of(c), L.req, L.edr, L.edr_err, ref, active);
+  L.status |= r >> 8;
+  return (int)(r & 0xFF);
 }
 
 // Copy the launch arguments into registers once, with scalar loads.  Read through the pointer they
@@ -241,7 +247,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   const OutDev& o = ka_regs.o;
   const u32 flags = ka_regs.flags;
 
-#ifndef CBH_HOSTSIM
+#ifdef CBH_PROFILE_CYCLES   // profiling build only (tools/gpu_cycles.py): the counters cost ~20 SGPRs
   const u64 cyc_start = __builtin_readcyclecounter();
 #endif
   const u32 rix = blockIdx.x * CBH_BLOCK + threadIdx.x;
@@ -343,16 +349,19 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   }
 
   // ---- per-action state, bit k = k-th action of the request
-#ifndef CBH_HOSTSIM
+#ifdef CBH_PROFILE_CYCLES
   const u64 cyc_pre = __builtin_readcyclecounter();   // only consumed under CBH_F_DEBUG_CYCLES
   const bool dbg = (flags & CBH_F_DEBUG_CYCLES) != 0;
-  u64 dbg_t0 = 0, dbg_eval = 0, dbg_n = 0;
+  u64 dbg_t0 = 0, dbg_eval = 0, dbg_n = 0, dbg_t1 = 0, dbg_a = 0, dbg_b = 0, dbg_c = 0, dbg_d = 0;
+#define DBG2_T0() do { if (dbg) dbg_t1 = __builtin_readcyclecounter(); } while (0)
+#define DBG2_ACC(acc) do { if (dbg) { acc += __builtin_readcyclecounter() - dbg_t1; } } while (0)
 #define DBG_T0() do { if (dbg) dbg_t0 = __builtin_readcyclecounter(); } while (0)
 #define DBG_ACC(acc) do { if (dbg) { acc += __builtin_readcyclecounter() - dbg_t0; ++dbg_n; } } while (0)
 #else
-  const u64 cyc_pre = 0;
 #define DBG_T0() do {} while (0)
 #define DBG_ACC(acc) do {} while (0)
+#define DBG2_T0() do {} while (0)
+#define DBG2_ACC(acc) do {} while (0)
 #endif
   u64 todo = (valid && !decided) ? all : 0;   // actions still being resolved
   u64 eff_allow = 0, eff_deny = 0;            // neither bit set = EFFECT_NO_MATCH so far
@@ -375,6 +384,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
     write_ps(Pm, pol_default, CBH_NONE);   // what the first role seeds when nothing matches (check.go:429-431)
     u64 rdone = 0;                          // actions that reached ALLOW: they leave the role loop (check.go:433-436)
     bool pend = Pm != 0;
+    u64 memo_done = 0, memo_val = 0, memo_err = 0;   // per-lane condition outcomes of this pass, bit = record position
 
     for (;;) {   // ---- waterfall over groups that share (chain start, version, kind | principal)
       const u64 rem = wave_ballot(pend);
@@ -387,6 +397,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
       for (u32 ri = 0;; ++ri) {   // ---- roles (check.go:208)
         const u64 Am = (ing && ri < n_iter) ? (Pm & todo & ~rdone) : 0;
         if (wave_ballot(Am != 0) == 0) break;
+        DBG2_T0();
         RoleSet rs; rs.role = 0; rs.par_off = 0; rs.par_cnt = 0; rs.gbits = 0;
         if (Am != 0) {
           rs.role = b.roles[role_off + ri];
@@ -399,6 +410,8 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
         }
         u64 has_allow = 0;
         u64 S = Am;   // actions still walking the scope chain for this role
+        u32 site_ctr = 0;
+        DBG2_ACC(dbg_a);
 
         // effect events of this role iteration (fold of check.go:382-442, applied as they happen)
         auto role_deny = [&](u64 mask, u32 polw, u32 si) {
@@ -425,10 +438,12 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
 
         for (u32 si = g_first; si != CBH_NONE; si = uchain_next(t, uload(&t.scope_parent[si]), flagbit)) {   // check.go:231
           if (wave_ballot(S != 0) == 0) break;
+          DBG2_T0();
           uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
           const bool have_bucket = is_res ? udir_find(t, CBH_B_RESOURCE, g_ver, g_x, si, bucket)
                                           : udir_find(t, CBH_B_PRINCIPAL, g_ver, si, g_x, bucket);   // resource version: check.go:294
 
+          DBG2_ACC(dbg_b);
           if (is_res && want_edr) {   // derived roles of this scope's resource policy (check.go:237-282)
             u64 m = 0; bool derr = false;
             if (have_bucket) {
@@ -493,26 +508,59 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
 
           if (have_bucket) {   // ---- regular rows of the bucket, in binding order (check.go:295-414)
             for (u32 row = bucket.x; row < bucket.x + bucket.y; ++row) {
+              DBG2_T0();
               const TblRow rw = uload_rec<TblRow>(t.rows, row);   // one s_load_dwordx8
+              const u32 site = site_ctr++;   // position of the record in this group's walk: the same for every role
               const u32 e = rw.flags & 3u;
+              // a record = roles x actions of one rule (cbh_blob.h): the lists are wave-uniform
+              const u32 n_act = (rw.flags & CBH_ROW_F_ACTION_LIST) ? (rw.counts & 0xFFFFu) : 0u;
+              const u32 n_role = (rw.flags & CBH_ROW_F_ROLE_LIST) ? (rw.counts >> 16) : 0u;
+              bool rmatch = false;
+              if (S != 0) {
+                if (!is_res) rmatch = pat_match(rw.resource, kind, kind_bits);
+                else if (n_role == 0) rmatch = roleset_has(t, rs, rw.role);
+                else for (u32 i = 0; i < n_role; ++i) rmatch = rmatch || roleset_has(t, rs, uload(&t.pool[rw.role + i]));
+              }
               u64 mrow = 0;
-              if (S != 0 && (is_res ? roleset_has(t, rs, rw.role) : pat_match(rw.resource, kind, kind_bits)))
-                mrow = match_actions(rw.action) & S;
+              if (rmatch) {
+                if (n_act == 0) mrow = match_actions(rw.action);
+                else for (u32 i = 0; i < n_act; ++i) mrow |= match_actions(uload(&t.pool[rw.action + i]));
+                mrow &= S;
+              }
               // once an ALLOW fired only a DENY can change an action's outcome in this scope (check.go:392-403);
               // strict mode still evaluates everything because an error there is itself a DENY
               u64 need = mrow;
               if (e == CBH_EFFECT_ALLOW && !strict) need &= ~has_allow;
+              DBG2_ACC(dbg_c);
               if (wave_ballot(need != 0) == 0) continue;
               const bool m = need != 0;
+              // A request meets the same record once per role it holds; its conditions read only the
+              // request (and this scope's derived roles), so the first outcome is kept per lane for the
+              // first 64 records of the walk and replayed - including the error status - afterwards.
+              const u64 sbit = site < 64 ? (1ull << site) : 0;
+              const bool hit = m && (memo_done & sbit) != 0;
+              const bool mev = m && !hit;
               int r = 1;
-              DBG_T0();
-              if (rw.drcond != CBH_NONE) r = eval_cond<GENERIC>(c, L, rw.drcond, m);   // check.go:328-366
-              const bool m2 = m && r == 1;
-              if (rw.cond != CBH_NONE && wave_ballot(m2) != 0) {                         // check.go:368-380
-                const int r2 = eval_cond<GENERIC>(c, L, rw.cond, m2);
-                if (m2) r = r2;
+              if ((rw.cond != CBH_NONE || rw.drcond != CBH_NONE) && wave_ballot(mev) != 0) {
+                DBG_T0();
+                if (rw.drcond != CBH_NONE) r = eval_cond<GENERIC>(c, L, rw.drcond, mev);   // check.go:328-366
+                const bool m2 = mev && r == 1;
+                if (rw.cond != CBH_NONE && wave_ballot(m2) != 0) {                         // check.go:368-380
+                  const int r2 = eval_cond<GENERIC>(c, L, rw.cond, m2);
+                  if (m2) r = r2;
+                }
+                DBG_ACC(dbg_eval);
+                if (mev && !(L.status & CBH_ST_UNSUPPORTED)) {
+                  memo_done |= sbit;
+                  if (r == 1) memo_val |= sbit;
+                  if (L.status & CBH_ST_CEL_ERROR) memo_err |= sbit;
+                }
               }
-              DBG_ACC(dbg_eval);
+              DBG2_T0();
+              if (hit) {
+                r = (memo_val & sbit) ? 1 : 0;
+                if (memo_err & sbit) { L.status |= CBH_ST_CEL_ERROR; if (strict) r = 2; }   // an error is a DENY in strict mode
+              }
               if (m) {
                 take_status(need);
                 if (r == 2) strict_deny(need, ((u32)CBH_P_TABLE << 28) | rw.policy, si);
@@ -521,6 +569,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                   else if (e == CBH_EFFECT_DENY) role_deny(mrow, pol_default, si);
                 }
               }
+              DBG2_ACC(dbg_d);
             }
           }
 
@@ -537,12 +586,13 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
     todo &= ~(eff_allow | eff_deny);
   }
 
-#ifndef CBH_HOSTSIM
+#ifdef CBH_PROFILE_CYCLES
   if ((flags & CBH_F_DEBUG_CYCLES) && want_ps && act_cnt >= 3) {
     // profiling aid: policy words of the first three actions <- cycles spent in the preamble,
     // in the two policy passes, and the wave's start time (low 32 bits)
     const u64 cyc_end = __builtin_readcyclecounter();
     pol0 = (u32)(cyc_pre - cyc_start); pol1 = (u32)(cyc_end - cyc_pre); pol2 = (u32)dbg_eval; pol3 = (u32)dbg_n;
+    scp0 = (u32)dbg_a; scp1 = (u32)dbg_b; scp2 = (u32)dbg_c; scp3 = (u32)dbg_d;
   }
 #endif
   if (valid) {
@@ -577,7 +627,7 @@ __device__ __forceinline__ u32 cached_columns(const KernelArgs* ka) {
 }
 
 // GENERIC instantiation: operand stack, locals and iteration slots in LDS, laid out [slot][lane].
-__global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs* __restrict__ ka) {
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
   __shared__ u64 s_val[CBH_STACK_DEPTH * CBH_BLOCK];
   __shared__ u64 l_val[CBH_MAX_LOCALS * CBH_BLOCK];
   __shared__ u64 it_cont[CBH_MAX_ITERS * CBH_BLOCK];
@@ -585,8 +635,6 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs* 
   __shared__ u32 it_state[CBH_MAX_ITERS * CBH_BLOCK];
   __shared__ u8 s_tag[CBH_STACK_DEPTH * CBH_BLOCK];
   __shared__ u8 l_tag[CBH_MAX_LOCALS * CBH_BLOCK];
-  KernelArgs a;
-  load_args(a, ka);
   const u32 ncc = cached_columns(&a);
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x,
         (CBH_L u64*)s_val, (CBH_L u8*)s_tag, (CBH_L u64*)l_val, (CBH_L u8*)l_tag,
@@ -596,9 +644,7 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs* 
 }
 
 // Leaf-only instantiation: no operand stack, no interpreter call.
-__global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel_leaf(const KernelArgs* __restrict__ ka) {
-  KernelArgs a;
-  load_args(a, ka);
+__global__ __launch_bounds__(CBH_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void cbh_check_kernel_leaf(const KernelArgs a, const KernelArgs* __restrict__ ka) {
   const u32 ncc = cached_columns(&a);
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
         (CBH_L u64*)cbh_dyn_lds, (CBH_L u8*)(cbh_dyn_lds + (size_t)ncc * CBH_BLOCK * 8), ncc, ka};

@@ -239,9 +239,9 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
     const u32 ncc = d.n_columns < CBH_CACHE_COLS ? d.n_columns : CBH_CACHE_COLS;
     const size_t dyn_lds = (size_t)ncc * CBH_BLOCK * 9;   // column cache: u64 value + u8 tag per lane
     if (t->dev.flags & CBH_MF_HAS_GENERIC_PROGRAMS)
-      hipLaunchKernelGGL(cbh_check_kernel, dim3(grid), dim3(CBH_BLOCK), dyn_lds, s, (const KernelArgs*)b->d_args);
+      hipLaunchKernelGGL(cbh_check_kernel, dim3(grid), dim3(CBH_BLOCK), dyn_lds, s, b->last_args, (const KernelArgs*)b->d_args);
     else
-      hipLaunchKernelGGL(cbh_check_kernel_leaf, dim3(grid), dim3(CBH_BLOCK), dyn_lds, s, (const KernelArgs*)b->d_args);
+      hipLaunchKernelGGL(cbh_check_kernel_leaf, dim3(grid), dim3(CBH_BLOCK), dyn_lds, s, b->last_args, (const KernelArgs*)b->d_args);
   }
   HIPCHK(hipEventRecord(t->ev[3], s));
   HIPCHK(hipGetLastError());

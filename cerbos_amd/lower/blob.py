@@ -25,9 +25,10 @@ from .celc import LoweringError, Params, ProgramBuilder
 from .globs import GlobNFA, fix_glob, has_meta
 
 BLOB_MAGIC = 0x31484243
-BLOB_VERSION = 5
+BLOB_VERSION = 6
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
+ROW_F_ACTION_LIST, ROW_F_ROLE_LIST = 4, 8
 
 (SEC_META, SEC_STR_OFF, SEC_STR_BYTES, SEC_SCOPE_PARENT, SEC_SCOPE_FLAGS, SEC_SCOPE_SID, SEC_HASH,
  SEC_ROWS, SEC_RPROWS, SEC_U32POOL, SEC_DR, SEC_CODE, SEC_CONST_TAG, SEC_CONST_VAL, SEC_THEAP_TAG,
@@ -193,12 +194,12 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
                 prin_buckets.setdefault((ver, scope, r["principal"]), []).append(r)
 
     pool = []
-    row_cols = [[] for _ in range(7)]
+    row_cols = [[] for _ in range(8)]
     rp_cols = [[] for _ in range(4)]
     dr_cols = [[] for _ in range(4)]
     entries = []  # (k0,k1,k2,k3, v0,v1,v2,v3)
 
-    def add_row(r, principal_policy):
+    def row_programs(r, principal_policy):
         params = Params(r["params"]["constants"], r["params"]["ordered_variables"], globals_) if r["params"] else Params(None, None, globals_)
         if principal_policy and _cond_uses_runtime(r["condition"], params):
             raise LoweringError(
@@ -210,21 +211,66 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         if r["derived_role_condition"] is not None:
             dp = r["derived_role_params"] or {"constants": {}, "ordered_variables": []}
             drc = pb.condition_program(r["derived_role_condition"], Params(dp["constants"], dp["ordered_variables"], globals_))
-        row_cols[0].append(dim_ref(DIM_ACTION, r["action"]))
-        row_cols[1].append(dim_ref(DIM_ROLE, r["role"]) if r["role"] else NONE)
-        row_cols[2].append(dim_ref(DIM_KIND, r["resource"]) if r["resource"] else NONE)
-        row_cols[3].append({"ALLOW": 1, "DENY": 2}.get(r["effect"], 0))
-        row_cols[4].append(cond)
-        row_cols[5].append(drc)
-        row_cols[6].append(policy_id(r["origin_fqn"]))
+        return cond, drc
+
+    def dim_list(dim, keys):
+        """One key -> its reference; several -> (pool offset, count)."""
+        if len(keys) == 1:
+            return (dim_ref(dim, keys[0]) if keys[0] else NONE), 0
+        off = len(pool)
+        pool.extend(dim_ref(dim, k) for k in keys)
+        return off, len(keys)
+
+    def add_bucket_rows(rows, principal_policy):
+        """Emit the device rows of one bucket; returns how many.
+
+        The rule table holds one row per (rule, role, action) (ruletable.go addResourcePolicy /
+        addPrincipalPolicy).  Rows of ONE rule that share effect, condition and derived-role condition
+        differ only in (role, action) and form the cross product roles x actions, so the device walks
+        them as a single record carrying both lists: the condition is evaluated once per request instead
+        of once per (role, action) row.  A rule's rows are contiguous and each of its signature groups
+        keeps its first-occurrence position, so for every (role, action) the matching records are met
+        in the order Index.Query returns the rows (index/index.go:214-336)."""
+        blocks = []   # [(rule identity, {signature: [rows]})] in binding order
+        for r in rows:
+            ident = (r["origin_fqn"], r["name"])
+            if not blocks or blocks[-1][0] != ident:
+                blocks.append((ident, {}))
+            cond, drc = row_programs(r, principal_policy)
+            sig = (r["resource"], r["effect"], cond, drc)
+            blocks[-1][1].setdefault(sig, []).append(r)
+        n = 0
+        for _ident, groups in blocks:
+            for (resource, effect, cond, drc), grp in groups.items():
+                roles = list(dict.fromkeys(r["role"] for r in grp))
+                actions = list(dict.fromkeys(r["action"] for r in grp))
+                pairs = {(r["role"], r["action"]) for r in grp}
+                if len(pairs) == len(roles) * len(actions) and len(actions) < 0x10000 and len(roles) < 0x10000:
+                    merged = [(roles, actions)]
+                else:   # not a cross product: keep the reference's rows one by one
+                    merged = [([r["role"]], [r["action"]]) for r in grp]
+                for rl, al in merged:
+                    a_ref, a_cnt = dim_list(DIM_ACTION, al)
+                    r_ref, r_cnt = dim_list(DIM_ROLE, rl)
+                    fl = {"ALLOW": 1, "DENY": 2}.get(effect, 0)
+                    fl |= (ROW_F_ACTION_LIST if a_cnt else 0) | (ROW_F_ROLE_LIST if r_cnt else 0)
+                    row_cols[0].append(a_ref)
+                    row_cols[1].append(r_ref)
+                    row_cols[2].append(dim_ref(DIM_KIND, resource) if resource else NONE)
+                    row_cols[3].append(fl)
+                    row_cols[4].append(cond)
+                    row_cols[5].append(drc)
+                    row_cols[6].append(policy_id(grp[0]["origin_fqn"]))
+                    row_cols[7].append(a_cnt | (r_cnt << 16))
+                    n += 1
+        return n
 
     # resource policies (+ their derived roles)
     for key in sorted(res_buckets):
         ver, kind, scope = key
         rows = sorted(res_buckets[key], key=lambda r: r["id"])
         begin = len(row_cols[0])
-        for r in rows:
-            add_row(r, False)
+        n_rows = add_bucket_rows(rows, False)
         dr_begin = len(dr_cols[0])
         drs = rt["policy_derived_roles"].get(namer.resource_policy_fqn(kind, ver, scope)) or {}
         for name, dr in drs.items():
@@ -242,7 +288,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
             dr_cols[3].append(pb.condition_program(dr["condition"], dparams, allow_runtime=False)
                               if dr["condition"] is not None else NONE)
         entries.append((B_RESOURCE, sid(ver), sid(kind), lt.scope_index[scope],
-                        begin, len(rows), dr_begin, len(dr_cols[0]) - dr_begin))
+                        begin, n_rows, dr_begin, len(dr_cols[0]) - dr_begin))
     for ver, kind, scope in sorted(res_exists):
         entries.append((B_RESEXISTS, sid(ver), sid(kind), lt.scope_index[scope], 1, 0, 0, 0))
 
@@ -251,9 +297,8 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         ver, scope, principal = key
         rows = sorted(prin_buckets[key], key=lambda r: r["id"])
         begin = len(row_cols[0])
-        for r in rows:
-            add_row(r, True)
-        entries.append((B_PRINCIPAL, sid(ver), lt.scope_index[scope], sid(principal), begin, len(rows), 0, 0))
+        n_rows = add_bucket_rows(rows, True)
+        entries.append((B_PRINCIPAL, sid(ver), lt.scope_index[scope], sid(principal), begin, n_rows, 0, 0))
     for ver, scope in sorted(pp_exists):
         entries.append((B_PPEXISTS, sid(ver), lt.scope_index[scope], 0, 1, 0, 0, 0))
 

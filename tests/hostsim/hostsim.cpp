@@ -82,7 +82,7 @@ extern "C" const char* hostsim_last_error() { return g_err.c_str(); }
 static KernelArgs* g_args;
 
 static void fiber_main() {
-  if (g_args->t.flags & CBH_MF_HAS_GENERIC_PROGRAMS) cbh_check_kernel(g_args); else cbh_check_kernel_leaf(g_args);
+  if (g_args->t.flags & CBH_MF_HAS_GENERIC_PROGRAMS) cbh_check_kernel(*g_args, g_args); else cbh_check_kernel_leaf(*g_args, g_args);
   g_fibers[g_cur].done = true;
   g_fibers[g_cur].waiting = 0;
   swapcontext(&g_fibers[g_cur].ctx, &g_sched);

@@ -22,5 +22,8 @@ res = table.download(db)
 pol = res.policy.reshape(-1, 4)[::64]          # lane 0 of every wave
 pre, body, ev, nev = (pol[:, k].astype(np.int64) for k in range(4))
 print("waves", len(pre))
-for name, a in (("preamble", pre), ("passes", body), ("eval_sum", ev), ("n_evals", nev)):
+scp = res.scope.reshape(-1, 4)[::64]
+ra, rb, rc, rd = (scp[:, k].astype(np.int64) for k in range(4))
+for name, a in (("preamble", pre), ("passes", body), ("eval_sum", ev), ("n_evals", nev), ("role_setup", ra),
+                ("bucket_dir", rb), ("row_match", rc), ("row_post", rd)):
     print("%-9s min %8d  p50 %8d  p90 %8d  max %8d" % (name, a.min(), np.median(a), np.percentile(a, 90), a.max()))
