@@ -644,7 +644,14 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs a
 }
 
 // Leaf-only instantiation: no operand stack, no interpreter call.
-__global__ __launch_bounds__(CBH_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void cbh_check_kernel_leaf(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+// A batch of 1M tuples is ~3.9k waves for 1024 SIMDs: holding the kernel to 128 VGPRs lets all of
+// them be resident at once (4 waves per SIMD) instead of running in two rounds.
+#ifndef CBH_HOSTSIM
+#define CBH_FOUR_WAVES __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define CBH_FOUR_WAVES
+#endif
+__global__ __launch_bounds__(CBH_BLOCK) CBH_FOUR_WAVES void cbh_check_kernel_leaf(const KernelArgs a, const KernelArgs* __restrict__ ka) {
   const u32 ncc = cached_columns(&a);
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
         (CBH_L u64*)cbh_dyn_lds, (CBH_L u8*)(cbh_dyn_lds + (size_t)ncc * CBH_BLOCK * 8), ncc, ka};

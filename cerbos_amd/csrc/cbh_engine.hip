@@ -42,8 +42,13 @@ struct cbh_table {
   std::vector<uint32_t> meta;
   TableDev dev{};
   hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  double check_ms_sum = 0, resolve_ms_sum = 0; uint64_t timed = 0; bool pending = false;
+  // Kernel timing: a ring of event sets so that launches queue back to back; the host only waits
+  // when it laps the ring.  ev[0..1] bracket the glob-resolve kernel, ev[2..3] the decision kernel.
+  static constexpr int RING = 32;
+  struct Slot { hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool pending = false; bool resolved = false; };
+  Slot ring[RING];
+  uint64_t next_slot = 0;
+  double check_ms_sum = 0, resolve_ms_sum = 0; uint64_t timed = 0;
   std::mutex mu;
 };
 
@@ -83,7 +88,7 @@ static int parse_image(cbh_table* t, const uint8_t* host_copy, size_t len) {
 
 static int table_finish(cbh_table* t) {
   HIPCHK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
-  for (auto& e : t->ev) HIPCHK(hipEventCreate(&e));
+  for (auto& sl : t->ring) for (auto& e : sl.ev) HIPCHK(hipEventCreate(&e));
   return 0;
 }
 
@@ -119,7 +124,7 @@ extern "C" void cbh_table_release(cbh_table* t) {
   if (!t) return;
   (void)hipSetDevice(t->device);
   if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
-  for (auto& e : t->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& sl : t->ring) for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
   if (t->image && t->owns_image) (void)hipFree(t->image);
   delete t;
 }
@@ -190,18 +195,27 @@ extern "C" int cbh_batch_upload(cbh_table* t, const cbh_batch* in, cbh_device_ba
   rc |= dalloc(b, b->out.edr, NR);
   rc |= dalloc(b, b->d_args, 1);
   if (rc != 0) { cbh_batch_release(b); return -1; }
+  // glob bits of the batch-local strings: all zero unless the table has automata to run (then
+  // cbh_check_resident overwrites every word on each launch)
+  if (in->n_strings && hipMemsetAsync(d.gbits, 0, (size_t)3 * in->n_strings * sizeof(u64), s) != hipSuccess) {
+    cbh_batch_release(b); return fail("upload failed");
+  }
   if (hipStreamSynchronize(s) != hipSuccess) { cbh_batch_release(b); return fail("upload failed"); }
   *out = b;
   return 0;
 }
 
-static void collect_times(cbh_table* t) {
-  if (!t->pending) return;
+static void collect_slot(cbh_table* t, cbh_table::Slot& sl) {   // the slot's last event has completed
+  if (!sl.pending) return;
   float a = 0, c = 0;
-  if (hipEventElapsedTime(&a, t->ev[0], t->ev[1]) == hipSuccess && hipEventElapsedTime(&c, t->ev[2], t->ev[3]) == hipSuccess) {
+  if (sl.resolved && hipEventElapsedTime(&a, sl.ev[0], sl.ev[1]) != hipSuccess) a = 0;
+  if (hipEventElapsedTime(&c, sl.ev[2], sl.ev[3]) == hipSuccess) {
     t->resolve_ms_sum += a; t->check_ms_sum += c; t->timed += 1;
   }
-  t->pending = false;
+  sl.pending = false;
+}
+static void collect_times(cbh_table* t) {   // after the stream has been synchronised
+  for (auto& sl : t->ring) collect_slot(t, sl);
 }
 
 extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_params* p) {
@@ -210,7 +224,8 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   std::lock_guard<std::mutex> lk(t->mu);
   HIPCHK(hipSetDevice(t->device));
   hipStream_t s = t->stream;
-  if (t->pending) { HIPCHK(hipEventSynchronize(t->ev[3])); collect_times(t); }
+  cbh_table::Slot& sl = t->ring[t->next_slot++ % cbh_table::RING];
+  if (sl.pending) { HIPCHK(hipEventSynchronize(sl.ev[3])); collect_slot(t, sl); }
   const BatchDev& d = b->dev;
   {
     // launch arguments live in device memory; re-sent only when they change (the kernel itself
@@ -223,17 +238,18 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
       HIPCHK(hipMemcpyAsync(b->d_args, &b->last_args, sizeof(ka), hipMemcpyHostToDevice, s));
     }
   }
-  HIPCHK(hipEventRecord(t->ev[0], s));
+  // batch-local strings against the table's glob automata; a table without globs has nothing to
+  // resolve (the bits were zeroed once at upload)
   const u32 maxw = std::max(std::max(t->dev.nfa_words[0], t->dev.nfa_words[1]), t->dev.nfa_words[2]);
-  if (d.n_strings && maxw) {
+  sl.resolved = d.n_strings && maxw;
+  if (sl.resolved) {
+    HIPCHK(hipEventRecord(sl.ev[0], s));
     const u32 grid = (d.n_strings + CBH_BLOCK - 1) / CBH_BLOCK;
     const size_t lds = (size_t)(2 + 512) * maxw * sizeof(u64);
     hipLaunchKernelGGL(cbh_resolve_globs_kernel, dim3(grid), dim3(CBH_BLOCK), lds, s, t->dev, d);
-  } else if (d.n_strings) {
-    HIPCHK(hipMemsetAsync(d.gbits, 0, (size_t)3 * d.n_strings * sizeof(u64), s));
+    HIPCHK(hipEventRecord(sl.ev[1], s));
   }
-  HIPCHK(hipEventRecord(t->ev[1], s));
-  HIPCHK(hipEventRecord(t->ev[2], s));
+  HIPCHK(hipEventRecord(sl.ev[2], s));
   if (d.n_requests) {
     const u32 grid = (d.n_requests + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
     const u32 ncc = d.n_columns < CBH_CACHE_COLS ? d.n_columns : CBH_CACHE_COLS;
@@ -243,9 +259,9 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
     else
       hipLaunchKernelGGL(cbh_check_kernel_leaf, dim3(grid), dim3(CBH_BLOCK), dyn_lds, s, b->last_args, (const KernelArgs*)b->d_args);
   }
-  HIPCHK(hipEventRecord(t->ev[3], s));
+  HIPCHK(hipEventRecord(sl.ev[3], s));
   HIPCHK(hipGetLastError());
-  t->pending = true;
+  sl.pending = true;
   return 0;
 }
 

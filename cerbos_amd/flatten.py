@@ -67,13 +67,26 @@ class Batch:
 
 
 def sort_batch_by_route(b: Batch) -> Batch:
-    """Order requests by (kind, resource version, resource scope) so that the lanes of a wave
-    share their policy buckets; regroups the tuple arrays accordingly (in place)."""
+    """Order requests by (kind, resource version, resource scope), then by role list, so that the
+    lanes of a wave share their policy buckets AND walk them the same number of times (the kernel
+    visits a bucket once per role index any lane still needs, check.go:208); regroups the tuple
+    arrays accordingly (in place)."""
     n = b.n_requests
     if n < 2:
         return b
     req = b.req_u32
-    order = np.lexsort((req[RQ_R_SCOPE], req[RQ_R_VERSION], req[RQ_KIND]))   # stable
+    cnt = req[RQ_ROLE_CNT].astype(np.int64)
+    sig = np.zeros(n, dtype=np.uint64)
+    if b.roles is not None and len(b.roles) and cnt.any():
+        off = req[RQ_ROLE_OFF].astype(np.int64)
+        start = np.cumsum(cnt) - cnt
+        pos = np.arange(int(cnt.sum()), dtype=np.int64) - np.repeat(start, cnt)   # index of a role within its list
+        with np.errstate(over="ignore"):
+            w = (np.asarray(b.roles).astype(np.uint64)[np.repeat(off, cnt) + pos] + np.uint64(1)) \
+                * (pos.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0xC2B2AE3D27D4EB4F))
+            csum = np.concatenate([np.zeros(1, dtype=np.uint64), np.cumsum(w, dtype=np.uint64)])
+            sig = csum[start + cnt] - csum[start]                                 # order-sensitive list signature
+    order = np.lexsort((sig, cnt, req[RQ_R_SCOPE], req[RQ_R_VERSION], req[RQ_KIND]))   # stable
     if np.array_equal(order, np.arange(n)):
         return b
     return permute_requests(b, order)
