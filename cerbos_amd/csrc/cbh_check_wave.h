@@ -240,7 +240,7 @@ __device__ __forceinline__ void load_args(KernelArgs& dst, const KernelArgs* src
 #endif
 }
 
-template <bool GENERIC>
+template <bool GENERIC, typename AM>   // AM: per-request action mask, u32 when no request of the batch carries more than 32 actions
 __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   const TableDev& t = ka_regs.t;
   const BatchDev& b = ka_regs.b;
@@ -278,7 +278,8 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
       if (k < c.n_cached) { c.cc_tag[k * CBH_BLOCK + c.tid] = tg[k]; c.cc_val[k * CBH_BLOCK + c.tid] = vl[k]; }
     }
   }
-  const u64 all = act_cnt >= 64 ? ~0ull : ((1ull << act_cnt) - 1);
+  constexpr u32 AM_BITS = sizeof(AM) * 8;
+  const AM all = act_cnt >= AM_BITS ? (AM)~(AM)0 : (AM)(((AM)1 << act_cnt) - 1);
   // the first four action ids stay in registers (requests rarely carry more)
   const u32 a0 = act_cnt > 0 ? b.tuple_action[act_off] : CBH_NONE;
   const u32 a1 = act_cnt > 1 ? b.tuple_action[act_off + 1] : CBH_NONE;
@@ -296,15 +297,15 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   u64 edr_acc = 0;
 
   // mask of this request's actions matching an action-dimension pattern reference
-  auto match_actions = [&](u32 pat) -> u64 {
-    u64 m = 0;
+  auto match_actions = [&](u32 pat) -> AM {
+    AM m = 0;
     if (!(pat & CBH_PAT_GLOB)) {
-      m = (u64)(a0 == pat) | ((u64)(a1 == pat) << 1) | ((u64)(a2 == pat) << 2) | ((u64)(a3 == pat) << 3);
-      for (u32 k = 4; k < act_cnt; ++k) m |= (u64)(b.tuple_action[act_off + k] == pat) << k;
+      m = (AM)(a0 == pat) | ((AM)(a1 == pat) << 1) | ((AM)(a2 == pat) << 2) | ((AM)(a3 == pat) << 3);
+      for (u32 k = 4; k < act_cnt; ++k) m |= (AM)(b.tuple_action[act_off + k] == pat) << k;
     } else {
       const u32 gi = pat & 63u;
       for (u32 k = 0; k < act_cnt; ++k)
-        m |= ((gbits_of(t, b, DIM_ACTION, b.tuple_action[act_off + k]) >> gi) & 1ull) << k;
+        m |= (AM)((gbits_of(t, b, DIM_ACTION, b.tuple_action[act_off + k]) >> gi) & 1ull) << k;
     }
     return m & all;
   };
@@ -312,15 +313,15 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   // The first four actions keep theirs in registers until the end (no stores in the middle of the
   // kernel: vmcnt is in-order, an early store would sit in front of every later load's wait).
   u32 pol0 = 0, pol1 = 0, pol2 = 0, pol3 = 0, scp0 = CBH_NONE, scp1 = CBH_NONE, scp2 = CBH_NONE, scp3 = CBH_NONE;
-  auto write_ps = [&](u64 mask, u32 polw, u32 scpw) {
+  auto write_ps = [&](AM mask, u32 polw, u32 scpw) {
     if (!want_ps) return;
     if (mask & 1) { pol0 = polw; scp0 = scpw; }
     if (mask & 2) { pol1 = polw; scp1 = scpw; }
     if (mask & 4) { pol2 = polw; scp2 = scpw; }
     if (mask & 8) { pol3 = polw; scp3 = scpw; }
-    mask &= ~0xFull;
+    mask &= ~(AM)0xF;
     while (mask) {
-      const u32 k = (u32)__builtin_ctzll(mask);
+      const u32 k = (u32)__builtin_ctzll((u64)mask);
       mask &= mask - 1;
       if (o.policy) o.policy[act_off + k] = polw;
       if (o.scope) o.scope[act_off + k] = scpw;
@@ -363,9 +364,9 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
 #define DBG2_T0() do {} while (0)
 #define DBG2_ACC(acc) do {} while (0)
 #endif
-  u64 todo = (valid && !decided) ? all : 0;   // actions still being resolved
-  u64 eff_allow = 0, eff_deny = 0;            // neither bit set = EFFECT_NO_MATCH so far
-  u64 st_err = 0, st_unsup = 0;
+  AM todo = (valid && !decided) ? all : (AM)0;   // actions still being resolved
+  AM eff_allow = 0, eff_deny = 0;             // neither bit set = EFFECT_NO_MATCH so far
+  AM st_err = 0, st_unsup = 0;
   // "NO_MATCH" when there is nothing to evaluate (check.go:119-121, 168-170), else the zero EffectInfo (:191)
   write_ps(all, (u32)(decided ? CBH_P_NO_MATCH : CBH_P_EMPTY) << 28, CBH_NONE);
 
@@ -377,12 +378,12 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
     const u32 gx = is_res ? kind : pid;
     const u32 n_iter = is_res ? role_cnt : (role_cnt ? 1u : 0u);      // check.go:208-213
     // An empty principal chain leaves nothing behind that the resource pass does not overwrite.
-    const u64 Pm = (is_res || first != CBH_NONE) && n_iter > 0 ? todo : 0;   // actions taking part in this pass
+    const AM Pm = (is_res || first != CBH_NONE) && n_iter > 0 ? todo : (AM)0;   // actions taking part in this pass
     // roleEffectInfo.Policy: the main policy key if a policy exists at all, else "NO_MATCH" (check.go:216-225)
     const u32 pol_default = exists ? (((u32)(is_res ? CBH_P_RESOURCE : CBH_P_PRINCIPAL) << 28) | first)
                                    : ((u32)CBH_P_NO_MATCH << 28);
     write_ps(Pm, pol_default, CBH_NONE);   // what the first role seeds when nothing matches (check.go:429-431)
-    u64 rdone = 0;                          // actions that reached ALLOW: they leave the role loop (check.go:433-436)
+    AM rdone = 0;                           // actions that reached ALLOW: they leave the role loop (check.go:433-436)
     bool pend = Pm != 0;
     u64 memo_done = 0, memo_val = 0, memo_err = 0;   // per-lane condition outcomes of this pass, bit = record position
 
@@ -395,7 +396,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
       pend = pend && !ing;
 
       for (u32 ri = 0;; ++ri) {   // ---- roles (check.go:208)
-        const u64 Am = (ing && ri < n_iter) ? (Pm & todo & ~rdone) : 0;
+        const AM Am = (ing && ri < n_iter) ? (AM)(Pm & todo & ~rdone) : (AM)0;
         if (wave_ballot(Am != 0) == 0) break;
         DBG2_T0();
         RoleSet rs; rs.role = 0; rs.par_off = 0; rs.par_cnt = 0; rs.gbits = 0;
@@ -408,29 +409,29 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
             for (u32 k = 0; k < rs.par_cnt; ++k) rs.gbits |= t.gbits[(size_t)DIM_ROLE * t.K + t.pool[rs.par_off + k]];
           }
         }
-        u64 has_allow = 0;
-        u64 S = Am;   // actions still walking the scope chain for this role
+        AM has_allow = 0;
+        AM S = Am;   // actions still walking the scope chain for this role
         u32 site_ctr = 0;
         DBG2_ACC(dbg_a);
 
         // effect events of this role iteration (fold of check.go:382-442, applied as they happen)
-        auto role_deny = [&](u64 mask, u32 polw, u32 si) {
-          const u64 seed = mask & ~(eff_allow | eff_deny);   // still NO_MATCH: this role's DENY seeds the result
+        auto role_deny = [&](AM mask, u32 polw, u32 si) {
+          const AM seed = mask & ~(eff_allow | eff_deny);   // still NO_MATCH: this role's DENY seeds the result
           eff_deny |= seed;
           write_ps(seed, polw, si);
           S &= ~mask;
         };
-        auto role_allow = [&](u64 mask, u32 si) {           // first independent ALLOW wins (check.go:433-436)
+        auto role_allow = [&](AM mask, u32 si) {           // first independent ALLOW wins (check.go:433-436)
           eff_allow |= mask; eff_deny &= ~mask; rdone |= mask;
           write_ps(mask, pol_default, si);
           S &= ~mask;
         };
-        auto strict_deny = [&](u64 mask, u32 polw, u32 si) { // evaluation error in strict mode (check.go:353-356, 371-374)
+        auto strict_deny = [&](AM mask, u32 polw, u32 si) { // evaluation error in strict mode (check.go:353-356, 371-374)
           eff_deny |= mask; eff_allow &= ~mask; todo &= ~mask;
           write_ps(mask, polw, si);
           S &= ~mask;
         };
-        auto take_status = [&](u64 mask) {                    // attribute VM status bits to the actions served
+        auto take_status = [&](AM mask) {                    // attribute VM status bits to the actions served
           if (L.status & CBH_ST_CEL_ERROR) st_err |= mask;
           if (L.status & CBH_ST_UNSUPPORTED) st_unsup |= mask;
           L.status = 0;
@@ -476,18 +477,18 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                 uint4 rp;
                 if (!udir_find(t, CBH_B_ROLEPOL, g_ver, si, g_sr, rp)) continue;
                 const u32 rp_pol = ((u32)CBH_P_TABLE << 28) | rp.z;
-                u64 any_mask = 0;   // actions allowed (subject to conditions) by some rule for this resource
+                AM any_mask = 0;   // actions allowed (subject to conditions) by some rule for this resource
                 for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
                   const TblRp rr = uload_rec<TblRp>(t.rprows, row);
                   if (!in2 || !pat_match(rr.resource, kind, kind_bits)) continue;
                   for (u32 a = 0; a < rr.allow_cnt; ++a) any_mask |= match_actions(uload(&t.pool[rr.allow_off + a]));
                 }
                 // no binding for the resource, or no allow-action matched (index.go:436-461)
-                u64 deny = in2 ? (S & ~any_mask) : 0;
+                AM deny = in2 ? (AM)(S & ~any_mask) : (AM)0;
                 for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
                   const TblRp rr = uload_rec<TblRp>(t.rprows, row);
                   if (rr.cond == CBH_NONE) continue;
-                  u64 mm = 0;
+                  AM mm = 0;
                   if (in2 && pat_match(rr.resource, kind, kind_bits)) {
                     for (u32 a = 0; a < rr.allow_cnt; ++a) mm |= match_actions(uload(&t.pool[rr.allow_off + a]));
                     mm &= S & ~deny;
@@ -521,7 +522,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                 else if (n_role == 0) rmatch = roleset_has(t, rs, rw.role);
                 else for (u32 i = 0; i < n_role; ++i) rmatch = rmatch || roleset_has(t, rs, uload(&t.pool[rw.role + i]));
               }
-              u64 mrow = 0;
+              AM mrow = 0;
               if (rmatch) {
                 if (n_act == 0) mrow = match_actions(rw.action);
                 else for (u32 i = 0; i < n_act; ++i) mrow |= match_actions(uload(&t.pool[rw.action + i]));
@@ -529,7 +530,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
               }
               // once an ALLOW fired only a DENY can change an action's outcome in this scope (check.go:392-403);
               // strict mode still evaluates everything because an error there is itself a DENY
-              u64 need = mrow;
+              AM need = mrow;
               if (e == CBH_EFFECT_ALLOW && !strict) need &= ~has_allow;
               DBG2_ACC(dbg_c);
               if (wave_ballot(need != 0) == 0) continue;
@@ -573,7 +574,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
             }
           }
 
-          const u64 ha = has_allow & S;   // check.go:416-425
+          const AM ha = has_allow & S;   // check.go:416-425
           if (ha != 0) {
             const u32 sp = (uload(&t.scope_flags[si]) >> 2) & 3u;
             if (sp == SP_REQUIRE_CONSENT) has_allow &= ~ha;
@@ -608,7 +609,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
       }
     }
     for (u32 k = 0; k < act_cnt; ++k) {
-      const u64 bit = 1ull << k;
+      const AM bit = (AM)1 << k;
       o.effect[act_off + k] = (u8)((eff_allow & bit) ? CBH_EFFECT_ALLOW : CBH_EFFECT_DENY);   // NO_MATCH -> DENY (check.go:451-453)
       if (o.status) o.status[act_off + k] = (u8)((st_unsup & bit) ? CBH_ST_UNSUPPORTED : ((st_err & bit) ? CBH_ST_CEL_ERROR : CBH_ST_OK));
     }
@@ -627,7 +628,8 @@ __device__ __forceinline__ u32 cached_columns(const KernelArgs* ka) {
 }
 
 // GENERIC instantiation: operand stack, locals and iteration slots in LDS, laid out [slot][lane].
-__global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+template <typename AM>
+__device__ __forceinline__ void generic_kernel_body(const KernelArgs& a, const KernelArgs* ka) {
   __shared__ u64 s_val[CBH_STACK_DEPTH * CBH_BLOCK];
   __shared__ u64 l_val[CBH_MAX_LOCALS * CBH_BLOCK];
   __shared__ u64 it_cont[CBH_MAX_ITERS * CBH_BLOCK];
@@ -640,20 +642,36 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs a
         (CBH_L u64*)s_val, (CBH_L u8*)s_tag, (CBH_L u64*)l_val, (CBH_L u8*)l_tag,
         (CBH_L u64*)it_cont, (CBH_L u32*)it_idx, (CBH_L u32*)it_state,
         (CBH_L u64*)cbh_dyn_lds, (CBH_L u8*)(cbh_dyn_lds + (size_t)ncc * CBH_BLOCK * 8), ncc, ka};
-  check_body<true>(a, c);
+  check_body<true, AM>(a, c);
 }
 
 // Leaf-only instantiation: no operand stack, no interpreter call.
-// A batch of 1M tuples is ~3.9k waves for 1024 SIMDs: holding the kernel to 128 VGPRs lets all of
-// them be resident at once (4 waves per SIMD) instead of running in two rounds.
+template <typename AM>
+__device__ __forceinline__ void leaf_kernel_body(const KernelArgs& a, const KernelArgs* ka) {
+  const u32 ncc = cached_columns(&a);
+  Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+        (CBH_L u64*)cbh_dyn_lds, (CBH_L u8*)(cbh_dyn_lds + (size_t)ncc * CBH_BLOCK * 8), ncc, ka};
+  check_body<false, AM>(a, c);
+}
+
+// A batch of 1M tuples is ~3.9k waves for 1024 SIMDs: holding the leaf kernels to 128 VGPRs lets all
+// of them be resident at once (4 waves per SIMD) instead of running in two rounds.
 #ifndef CBH_HOSTSIM
 #define CBH_FOUR_WAVES __attribute__((amdgpu_waves_per_eu(4, 4)))
 #else
 #define CBH_FOUR_WAVES
 #endif
+// The host picks by table (every program a fused leaf / leaf tree?) and by batch (no request with
+// more than 32 actions -> 32-bit action masks).
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+  generic_kernel_body<u64>(a, ka);
+}
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel_a32(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+  generic_kernel_body<u32>(a, ka);
+}
 __global__ __launch_bounds__(CBH_BLOCK) CBH_FOUR_WAVES void cbh_check_kernel_leaf(const KernelArgs a, const KernelArgs* __restrict__ ka) {
-  const u32 ncc = cached_columns(&a);
-  Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-        (CBH_L u64*)cbh_dyn_lds, (CBH_L u8*)(cbh_dyn_lds + (size_t)ncc * CBH_BLOCK * 8), ncc, ka};
-  check_body<false>(a, c);
+  leaf_kernel_body<u64>(a, ka);
+}
+__global__ __launch_bounds__(CBH_BLOCK) CBH_FOUR_WAVES void cbh_check_kernel_leaf_a32(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+  leaf_kernel_body<u32>(a, ka);
 }

@@ -59,6 +59,7 @@ struct cbh_device_batch {
   KernelArgs* d_args = nullptr;   // device copy of the launch arguments
   KernelArgs last_args;           // what d_args currently holds
   bool have_args = false;
+  u32 max_actions = 0;            // largest CBH_RQ_ACT_CNT of the batch: selects the action-mask width
   std::vector<void*> allocs;
 };
 
@@ -194,6 +195,11 @@ extern "C" int cbh_batch_upload(cbh_table* t, const cbh_batch* in, cbh_device_ba
   rc |= dalloc(b, b->out.status, in->n_tuples);
   rc |= dalloc(b, b->out.edr, NR);
   rc |= dalloc(b, b->d_args, 1);
+  for (size_t r = 0; r < NR; ++r) {
+    const u32 n = in->req_u32[(size_t)CBH_RQ_ACT_CNT * NR + r];
+    if (n > CBH_MAX_ACTIONS_PER_REQUEST) { cbh_batch_release(b); return fail("cbh_batch: a request carries more than CBH_MAX_ACTIONS_PER_REQUEST actions"); }
+    if (n > b->max_actions) b->max_actions = n;
+  }
   if (rc != 0) { cbh_batch_release(b); return -1; }
   // glob bits of the batch-local strings: all zero unless the table has automata to run (then
   // cbh_check_resident overwrites every word on each launch)
@@ -254,10 +260,9 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
     const u32 grid = (d.n_requests + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
     const u32 ncc = d.n_columns < CBH_CACHE_COLS ? d.n_columns : CBH_CACHE_COLS;
     const size_t dyn_lds = (size_t)ncc * CBH_BLOCK * 9;   // column cache: u64 value + u8 tag per lane
-    if (t->dev.flags & CBH_MF_HAS_GENERIC_PROGRAMS)
-      hipLaunchKernelGGL(cbh_check_kernel, dim3(grid), dim3(CBH_BLOCK), dyn_lds, s, b->last_args, (const KernelArgs*)b->d_args);
-    else
-      hipLaunchKernelGGL(cbh_check_kernel_leaf, dim3(grid), dim3(CBH_BLOCK), dyn_lds, s, b->last_args, (const KernelArgs*)b->d_args);
+    const bool generic = (t->dev.flags & CBH_MF_HAS_GENERIC_PROGRAMS) != 0, a32 = b->max_actions <= 32;
+    auto kernel = generic ? (a32 ? cbh_check_kernel_a32 : cbh_check_kernel) : (a32 ? cbh_check_kernel_leaf_a32 : cbh_check_kernel_leaf);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), dyn_lds, s, b->last_args, (const KernelArgs*)b->d_args);
   }
   HIPCHK(hipEventRecord(sl.ev[3], s));
   HIPCHK(hipGetLastError());

@@ -81,8 +81,12 @@ extern "C" const char* hostsim_last_error() { return g_err.c_str(); }
 
 static KernelArgs* g_args;
 
+static bool g_a32;   // same kernel selection as cbh_check_resident (cbh_engine.hip)
+
 static void fiber_main() {
-  if (g_args->t.flags & CBH_MF_HAS_GENERIC_PROGRAMS) cbh_check_kernel(*g_args, g_args); else cbh_check_kernel_leaf(*g_args, g_args);
+  const bool generic = (g_args->t.flags & CBH_MF_HAS_GENERIC_PROGRAMS) != 0;
+  if (generic) { if (g_a32) cbh_check_kernel_a32(*g_args, g_args); else cbh_check_kernel(*g_args, g_args); }
+  else { if (g_a32) cbh_check_kernel_leaf_a32(*g_args, g_args); else cbh_check_kernel_leaf(*g_args, g_args); }
   g_fibers[g_cur].done = true;
   g_fibers[g_cur].waiting = 0;
   swapcontext(&g_fibers[g_cur].ctx, &g_sched);
@@ -162,6 +166,10 @@ extern "C" int hostsim_check(const void* blob, size_t len, const cbh_batch* in, 
   a.now_ns = p->now_ns; a.flags = p->flags;
   if (a.o.edr) std::memset(a.o.edr, 0, sizeof(uint64_t) * in->n_requests);
   g_args = &a;
+  uint32_t max_actions = 0;
+  for (uint32_t r = 0; r < in->n_requests; ++r)
+    max_actions = std::max(max_actions, in->req_u32[(size_t)CBH_RQ_ACT_CNT * in->n_requests + r]);
+  g_a32 = max_actions <= 32;
   const uint32_t nblocks = (in->n_requests + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
   for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
   return 0;
