@@ -215,11 +215,66 @@ __device__ u32 eval_ref(const KernelArgs* ka, const VmLds lds, u32 req, u64 edr,
   return active ? ((u32)CBH_ST_UNSUPPORTED << 8) : 0u;   // unreachable: the host picks the GENERIC kernel for such tables
 }
 
+// A CBH_COND_LEAF program is an 8-dword record on an 8-dword boundary of the tape (celc.py
+// condition_program): instruction, operands and the value of its constant operand in one scalar load.
+struct __attribute__((aligned(32))) LeafRec { u32 w, a0, a1, ret, ctag, clo, chi, pad; };
+
+// The common outcome of a fused leaf, inline in the table walk: both operands present, same-typed
+// scalars (or plainly unequal types), or an operand missing.  Returns 0 / 1, 3 = CEL error, or 4 when
+// this lane needs the full evaluator (mixed numeric types, containers, lists that are not table constants).
+__device__ __forceinline__ u32 leaf_fast(const Ctx& c, const Lane& L, const LeafRec& lr) {
+  const u32 a = lr.w >> 8;
+  const u32 ka = (a >> 8) & 0xF, kb = (a >> 12) & 0xF, op = a & 0xFF;   // all wave-uniform
+  if (lr.ctag == CBH_NONE && (ka == 0 || kb == 0)) return 4;
+  const Val cv = mk(lr.ctag, (u64)lr.clo | ((u64)lr.chi << 32));
+  // P.id is already in a register: do not fetch it again (operand kind 2 = request string field)
+  const Val x = ka == 0 ? cv : (ka == 2 && lr.a0 == CBH_RQ_PRINCIPAL_ID) ? mk(CBH_T_STRING, L.pid) : load_operand(c, L, ka, lr.a0);
+  const Val y = kb == 0 ? cv : (kb == 2 && lr.a1 == CBH_RQ_PRINCIPAL_ID) ? mk(CBH_T_STRING, L.pid) : load_operand(c, L, kb, lr.a1);
+  if (x.t == CBH_T_ERR || y.t == CBH_T_ERR) return 3;   // a missing attribute: every comparison of an error is that error
+  if (op == OP_EQ || op == OP_NE) {
+    const int e = fast_equal(x, y);
+    return e < 0 ? 4u : (u32)(op == OP_EQ ? e : 1 - e);
+  }
+  if (op == OP_IN) {
+    if (kb != 0 || y.t != CBH_T_LIST || cont_sel(y.v) != CBH_HEAP_TABLE) return 4;   // uniform
+    const u32 n = cont_len(y.v), off = cont_off(y.v);
+    u32 found = 0; bool slow = false;
+    for (u32 i = 0; i < n; ++i) {   // the elements are uniform: scalar loads
+      const int e = fast_equal(x, uval(c.t.theap_rec, off + i));
+      if (e == -2) slow = true; else found |= (u32)e;
+    }
+    return slow ? 4u : found;
+  }
+  if (x.t == CBH_T_DOUBLE && y.t == CBH_T_DOUBLE) {
+    const double p = as_f64(x.v), q = as_f64(y.v);
+    return (op == OP_LT) ? p < q : (op == OP_LE) ? p <= q : (op == OP_GT) ? p > q : p >= q;   // NaN: all false
+  }
+  if (x.t == CBH_T_INT && y.t == CBH_T_INT) {
+    const i64 p = (i64)x.v, q = (i64)y.v;
+    return (op == OP_LT) ? p < q : (op == OP_LE) ? p <= q : (op == OP_GT) ? p > q : p >= q;
+  }
+  return 4;
+}
+
 template <bool GENERIC>
 __device__ __forceinline__ int eval_cond(const Ctx& c, Lane& L, u32 ref, bool active) {
-  const u32 r = eval_ref<GENERIC>(c.ka_mem, lds_of(c), L.req, L.edr, L.edr_err, ref, active);
-  L.status |= r >> 8;
-  return (int)(r & 0xFF);
+  u32 fast = 0;
+  bool rest = active;
+  if (ref & CBH_COND_LEAF) {
+    const LeafRec lr = uload_rec<LeafRec>(c.t.code, (ref & CBH_COND_PC_MASK) >> 3);
+    if (active) {
+      fast = leaf_fast(c, L, lr);
+      if (fast == 3) {   // CEL error: the leaf counts as false, or as a DENY in strict mode (check.go:697-749)
+        L.status |= CBH_ST_CEL_ERROR;
+        fast = (c.flags & CBH_F_STRICT_EVALUATION) ? 2u : 0u;
+      }
+    }
+    rest = active && fast == 4;
+    if (wave_ballot(rest) == 0) return (int)fast;   // the whole wave was served inline
+  }
+  const u32 r = eval_ref<GENERIC>(c.ka_mem, lds_of(c), L.req, L.edr, L.edr_err, ref, rest);
+  if (rest) { L.status |= r >> 8; fast = r & 0xFF; }
+  return (int)fast;
 }
 
 // Copy the launch arguments into registers once, with scalar loads.  Read through the pointer they
@@ -285,6 +340,10 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   const u32 a1 = act_cnt > 1 ? b.tuple_action[act_off + 1] : CBH_NONE;
   const u32 a2 = act_cnt > 2 ? b.tuple_action[act_off + 2] : CBH_NONE;
   const u32 a3 = act_cnt > 3 ? b.tuple_action[act_off + 3] : CBH_NONE;
+  // ... and the first two roles: fetched with the rest of the request instead of one memory round
+  // trip at the head of every role iteration
+  const u32 role0 = role_cnt > 0 ? b.roles[role_off] : 0;
+  const u32 role1 = role_cnt > 1 ? b.roles[role_off + 1] : 0;
 
   const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
   const bool strict = (flags & CBH_F_STRICT_EVALUATION) != 0;
@@ -293,7 +352,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   const bool has_rolepol = (t.flags & CBH_MF_HAS_ROLE_POLICIES) != 0;
   const bool want_ps = o.policy != nullptr || o.scope != nullptr;
 
-  Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false;
+  Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false; L.pid = pid;
   u64 edr_acc = 0;
 
   // mask of this request's actions matching an action-dimension pattern reference
@@ -370,7 +429,13 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   // "NO_MATCH" when there is nothing to evaluate (check.go:119-121, 168-170), else the zero EffectInfo (:191)
   write_ps(all, (u32)(decided ? CBH_P_NO_MATCH : CBH_P_EMPTY) << 28, CBH_NONE);
 
-  for (u32 pt = 0; pt < 2; ++pt) {                // 0 = principal policies, 1 = resource policies (check.go:195)
+#ifdef CBH_ABLATION   // measurement build (tools/gpu_cycles.py): switch parts of the walk off by flag
+  const u32 n_pass = (flags & 0x200u) ? 0u : 2u;   // ablation: skip both passes
+  const bool abl_noeval = (flags & 0x400u) != 0, abl_norows = (flags & 0x800u) != 0;
+#else
+  const u32 n_pass = 2;
+#endif
+  for (u32 pt = 0; pt < n_pass; ++pt) {                // 0 = principal policies, 1 = resource policies (check.go:195)
     const bool is_res = pt == 1;
     const u32 first = is_res ? r_first : p_first;
     const u32 flagbit = is_res ? FLAG_RES : FLAG_PRIN;
@@ -401,7 +466,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
         DBG2_T0();
         RoleSet rs; rs.role = 0; rs.par_off = 0; rs.par_cnt = 0; rs.gbits = 0;
         if (Am != 0) {
-          rs.role = b.roles[role_off + ri];
+          rs.role = ri == 0 ? role0 : ri == 1 ? role1 : b.roles[role_off + ri];
           rs.gbits = gbits_of(t, b, DIM_ROLE, rs.role);
           uint4 pv;
           if (has_parents && pr_scope_key != CBH_NONE && dir_find(t, CBH_B_PARENTS, pr_scope_key, rs.role, 0, pv)) {
@@ -508,6 +573,9 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
           }
 
           if (have_bucket) {   // ---- regular rows of the bucket, in binding order (check.go:295-414)
+#ifdef CBH_ABLATION
+            if (abl_norows) bucket.y = 0;
+#endif
             for (u32 row = bucket.x; row < bucket.x + bucket.y; ++row) {
               DBG2_T0();
               const TblRow rw = uload_rec<TblRow>(t.rows, row);   // one s_load_dwordx8
@@ -542,6 +610,9 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
               const bool hit = m && (memo_done & sbit) != 0;
               const bool mev = m && !hit;
               int r = 1;
+#ifdef CBH_ABLATION
+              if (abl_noeval) {} else
+#endif
               if ((rw.cond != CBH_NONE || rw.drcond != CBH_NONE) && wave_ballot(mev) != 0) {
                 DBG_T0();
                 if (rw.drcond != CBH_NONE) r = eval_cond<GENERIC>(c, L, rw.drcond, mev);   // check.go:328-366
@@ -596,7 +667,25 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
     scp0 = (u32)dbg_a; scp1 = (u32)dbg_b; scp2 = (u32)dbg_c; scp3 = (u32)dbg_d;
   }
 #endif
-  if (valid) {
+  // A request with exactly four actions on a 4-tuple boundary (the usual batch shape) writes each
+  // output array with ONE full-width store per lane: whole cache lines per wave instead of byte
+  // stores scattered four bytes apart.
+  const bool packed = valid && act_cnt == 4 && (act_off & 3u) == 0;
+  if (packed) {
+    struct __attribute__((aligned(16))) u32x4 { u32 x, y, z, w; };
+    u32 e4 = 0, s4 = 0;
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+      const AM bit = (AM)1 << k;
+      e4 |= (u32)((eff_allow & bit) ? CBH_EFFECT_ALLOW : CBH_EFFECT_DENY) << (8 * k);
+      s4 |= (u32)((st_unsup & bit) ? CBH_ST_UNSUPPORTED : ((st_err & bit) ? CBH_ST_CEL_ERROR : CBH_ST_OK)) << (8 * k);
+    }
+    if (o.edr) o.edr[req] = edr_acc;
+    *(CBH_G u32*)(o.effect + act_off) = e4;
+    if (o.status) *(CBH_G u32*)(o.status + act_off) = s4;
+    if (o.policy) { u32x4 v; v.x = pol0; v.y = pol1; v.z = pol2; v.w = pol3; *(CBH_G u32x4*)(o.policy + act_off) = v; }
+    if (o.scope) { u32x4 v; v.x = scp0; v.y = scp1; v.z = scp2; v.w = scp3; *(CBH_G u32x4*)(o.scope + act_off) = v; }
+  } else if (valid) {
     if (o.edr) o.edr[req] = edr_acc;
     if (want_ps) {
       const u32 pk[4] = {pol0, pol1, pol2, pol3}, sk[4] = {scp0, scp1, scp2, scp3};

@@ -31,6 +31,7 @@ __device__ inline bool dir_find(const TableDev& t, u32 k0, u32 k1, u32 k2, u32 k
 }
 
 __device__ __forceinline__ u64 gbits_of(const TableDev& t, const BatchDev& b, u32 dim, u32 sid) {
+  if (t.nfa_words[dim] == 0) return 0;   // no glob patterns in this dimension: nothing to look up
   if (sid < t.K) return t.gbits[(size_t)dim * t.K + sid];
   return b.gbits[(size_t)dim * b.n_strings + (sid - t.K)];
 }

@@ -81,6 +81,7 @@ struct Lane {           // per-lane evaluation state that programs can observe
   u64 edr;              // effective derived roles of the scope being processed
   u32 status;           // CBH_ST_* accumulated
   bool edr_err;         // strict mode: derived roles of this scope failed to evaluate
+  u32 pid;              // principal id, valid in the table walk only (leaf_fast reads P.id from here)
 };
 
 struct Ctx {

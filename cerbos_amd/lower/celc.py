@@ -270,11 +270,26 @@ class ProgramBuilder:
         fc.emit(OP_RET)
         pc = len(self.code)
         words = fc.finish(pc)
+        is_leaf = len(words) == 4 and (words[0] & 0xFF) == OP_LEAF_BIN
+        if is_leaf:
+            # A single fused leaf becomes an 8-dword record {op, a0, a1, RET, ctag, clo, chi, 0} on an
+            # 8-dword boundary: one s_load_dwordx8 fetches the instruction AND the value of its
+            # constant operand (ctag = NONE when neither / both operands are constants).
+            self.code.extend([OP_RET] * (-len(self.code) % 8))
+            pc = len(self.code)
+            a = words[0] >> 8
+            ka, kb = (a >> 8) & 0xF, (a >> 12) & 0xF
+            if (ka == 0) != (kb == 0):
+                ci = words[1] if ka == 0 else words[2]
+                cv = int(self.const_val[ci]) & 0xFFFFFFFFFFFFFFFF
+                words = words + [self.const_tag[ci], cv & 0xFFFFFFFF, cv >> 32, 0]
+            else:
+                words = words + [0xFFFFFFFF, 0, 0, 0]
         self.code.extend(words)
         if pc >= COND_PC_MASK:
             raise LoweringError("bytecode tape exceeds 2^30 words")
-        if len(words) == 4 and (words[0] & 0xFF) == OP_LEAF_BIN:
-            pc |= COND_LEAF   # one fused leaf: the kernel evaluates it inline (cbh_check_wave.h eval_cond)
+        if is_leaf:
+            pc |= COND_LEAF   # evaluated inline by the table walk (cbh_check_wave.h leaf_fast / eval_cond)
         elif _is_leaf_tree(words):
             pc |= COND_LEAFTREE
         else:

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""GPU-box measurement aid: decision-kernel time with parts of the walk switched off.
+
+Needs a library built with CBH_ABLATION=1 (tools/build_all.sh); in a production build the flags
+are ignored and every line prints the same time."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cerbos_amd import capi, workloads
+from cerbos_amd.flatten import Flattener
+from cerbos_amd.lower.blob import lower_rule_table
+from cerbos_amd.policy.loader import policies_from_docs
+from cerbos_amd.ruletable.build import rule_table_from_policies
+
+capi.init(0)
+lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c2_policies())))
+table = capi.Table(lt.blob)
+batch = workloads.c2_requests(250_000).to_batch(Flattener(lt))
+db = table.upload(batch)
+for name, fl in (("full", 0), ("no_eval", 0x400), ("no_rows", 0x800), ("no_passes", 0x200)):
+    for _ in range(5):
+        table.launch(db, now_ns=1, flags=fl)
+    table.synchronize()
+    table.kernel_time_ms()
+    for _ in range(30):
+        table.launch(db, now_ns=1, flags=fl)
+    table.synchronize()
+    ck, _ = table.kernel_time_ms()
+    print("ablation %-10s kernel %.4f ms" % (name, ck))

@@ -27,3 +27,11 @@ ra, rb, rc, rd = (scp[:, k].astype(np.int64) for k in range(4))
 for name, a in (("preamble", pre), ("passes", body), ("eval_sum", ev), ("n_evals", nev), ("role_setup", ra),
                 ("bucket_dir", rb), ("row_match", rc), ("row_post", rd)):
     print("%-9s min %8d  p50 %8d  p90 %8d  max %8d" % (name, a.min(), np.median(a), np.percentile(a, 90), a.max()))
+
+# ablations (profile build only): kernel time with parts of the walk switched off
+for name, fl in (("full", 0), ("no_eval", 0x400), ("no_rows", 0x800), ("no_passes", 0x200)):
+    for _ in range(20):
+        table.launch(db, now_ns=1, flags=fl)
+    table.synchronize()
+    ck, _ = table.kernel_time_ms()
+    print("ablation %-10s kernel %.4f ms" % (name, ck))
