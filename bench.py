@@ -29,6 +29,18 @@ import numpy as np  # noqa: E402
 
 ALG_BYTES_PER_DECISION = {"C2": 49.0}   # 32 + 9*A/actions + 1 with A=7, 4 actions
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # written by tools/gpu_profile.sh
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (FETCH_SIZE and WRITE_SIZE need separate passes, so bench.py cannot collect them on itself)."""
+    try:
+        with open(PMC_TRAFFIC) as fh:
+            d = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    return d["bytes_per_launch"] if d.get("kernel") == kernel else None
 
 
 def main():
@@ -152,6 +164,9 @@ def main():
         total = tuples * world * args.steps
         alg = ALG_BYTES_PER_DECISION["C2"]
         achieved = alg * tuples / (check_ms * 1e-3) / 1e9
+        # the instantiation cbh_check_resident picks for this table / batch (cbh_engine.hip)
+        kernel = "cbh_check_kernel" + ("" if lt.stats["generic_programs"] else "_leaf") + \
+                 ("_a32" if int(batch.req_u32[15].max()) <= 32 else "")
         out = {
             "metric": "CheckResources decisions/sec at batch=1M; p50 per-decision us",
             "value": total / elapsed,
@@ -170,8 +185,8 @@ def main():
                        "parallelism": "independent request shards per GPU, policy image broadcast once"},
             "p50_us_per_decision": p50_us_per_decision,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "cbh_check_kernel", "kernel_ms": check_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel),
+                         "kernel": kernel, "kernel_ms": check_ms,
                          "alg_bytes_per_decision": alg},
             "cpu_baseline": cpu,
             "resolve_kernel_ms": resolve_ms,

@@ -87,6 +87,14 @@ __device__ __forceinline__ u32 uchain_next(const TableDev& t, u32 si, u32 flagbi
   return si;
 }
 
+// first scope of the chain for a wave-uniform request scope word (ruletable.go:848-882)
+__device__ __forceinline__ u32 uchain_first(const TableDev& t, u32 raw, u32 flagbit, bool lenient) {
+  const u32 si = raw & ~CBH_SCOPE_EXACT;
+  const bool exact = (raw & CBH_SCOPE_EXACT) != 0;
+  if (!lenient && !(exact && (uload(&t.scope_flags[si]) & flagbit))) return CBH_NONE;
+  return uchain_next(t, si, flagbit);
+}
+
 // does one of the request's roles (or an ancestor of one) appear in the derived role's parent list?
 // (internal.SetIntersects(dr.ParentRoles, includingParentRoles), check.go:244)
 __device__ inline bool lane_has_parent_role(const TableDev& t, const BatchDev& b, u32 poff, u32 pcnt, u32 role_off,
@@ -391,22 +399,35 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   // parent roles are looked up with the request's own resource scope only (check.go:172,227)
   const u32 pr_scope_key = (r_scope & CBH_SCOPE_EXACT) ? (r_scope & ~CBH_SCOPE_EXACT) : CBH_NONE;
 
-  // ---- per-lane preamble: scope chains and existence (check.go:116-121, 165-170)
-  const u32 p_first = chain_first(t, p_scope, FLAG_PRIN, lenient);
-  const u32 r_first = chain_first(t, r_scope, FLAG_RES, lenient);
-  bool decided = (p_first == CBH_NONE && r_first == CBH_NONE);
+  // ---- routing preamble: scope chains and existence (check.go:116-121, 165-170), resolved once per
+  // distinct route of the wave on the scalar unit (a sorted batch has one route per wave)
+  u32 p_first = CBH_NONE, r_first = CBH_NONE;
   bool p_exists = false, r_exists = false;
-  if (!decided) {
-    uint4 v;
-    for (u32 si = p_first; si != CBH_NONE && !p_exists; si = chain_next(t, t.scope_parent[si], FLAG_PRIN))
-      p_exists = dir_find(t, CBH_B_PPEXISTS, p_ver, si, 0, v);                      // index.go:999-1021
-    for (u32 si = r_first; si != CBH_NONE && !r_exists; si = chain_next(t, t.scope_parent[si], FLAG_RES)) {
-      if (dir_find(t, CBH_B_RESEXISTS, r_ver, kind, si, v)) { r_exists = true; break; }   // index.go:966-997
-      if (has_rolepol && dir_find(t, CBH_B_RPRES, r_ver, si, 0, v))
-        for (u32 k = 0; k < v.y && !r_exists; ++k) r_exists = pat_match(t.pool[v.x + k], kind, kind_bits);
+  {
+    bool pendq = true;
+    for (;;) {
+      const u64 remq = wave_ballot(pendq);
+      if (remq == 0) break;
+      const u32 lead = first_lane(remq);
+      const u32 g_ps = wave_readlane(p_scope, lead), g_pv = wave_readlane(p_ver, lead), g_rs = wave_readlane(r_scope, lead),
+                g_rv = wave_readlane(r_ver, lead), g_k = wave_readlane(kind, lead);
+      const u64 g_kbits = wave_readlane64(kind_bits, lead);
+      const bool inq = pendq && p_scope == g_ps && p_ver == g_pv && r_scope == g_rs && r_ver == g_rv && kind == g_k;
+      pendq = pendq && !inq;
+      const u32 pf = uchain_first(t, g_ps, FLAG_PRIN, lenient), rf = uchain_first(t, g_rs, FLAG_RES, lenient);
+      bool pe = false, re = false;
+      uint4 v;
+      for (u32 si = pf; si != CBH_NONE && !pe; si = uchain_next(t, uload(&t.scope_parent[si]), FLAG_PRIN))
+        pe = udir_find(t, CBH_B_PPEXISTS, g_pv, si, 0, v);                              // index.go:999-1021
+      for (u32 si = rf; si != CBH_NONE && !re; si = uchain_next(t, uload(&t.scope_parent[si]), FLAG_RES)) {
+        if (udir_find(t, CBH_B_RESEXISTS, g_rv, g_k, si, v)) { re = true; break; }      // index.go:966-997
+        if (has_rolepol && udir_find(t, CBH_B_RPRES, g_rv, si, 0, v))
+          for (u32 k = 0; k < v.y && !re; ++k) re = pat_match(uload(&t.pool[v.x + k]), g_k, g_kbits);
+      }
+      if (inq) { p_first = pf; r_first = rf; p_exists = pe; r_exists = re; }
     }
-    if (!p_exists && !r_exists) decided = true;
   }
+  const bool decided = (p_first == CBH_NONE && r_first == CBH_NONE) || (!p_exists && !r_exists);
 
   // ---- per-action state, bit k = k-th action of the request
 #ifdef CBH_PROFILE_CYCLES

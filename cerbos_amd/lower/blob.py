@@ -449,6 +449,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         "columns": len(lt.columns), "directory_slots": nslots, "blob_bytes": len(lt.blob),
         "unsupported_expressions": len(lt.unsupported),
         "globs": [len(d.globs) for d in dims],
+        "generic_programs": bool(pb.has_generic),   # selects the kernel with the operand-stack interpreter
     }
     return lt
 
