@@ -7,7 +7,8 @@
 //                              (LDS-staged transition tables) -> match bits per dimension.
 //                              Replaces gobwas glob.Match per query
 //                              (internal/ruletable/index/glob_dimension.go:62-95).
-//   cbh_check_kernel         : one lane per (principal, resource, action) tuple; restates
+//   cbh_check_kernel*        : one lane per CheckInput (its actions as a bit mask), wave-uniform
+//                              table walk (cbh_check_wave.h); restates
 //                              ruletable.(*RuleTable).check (internal/ruletable/check.go:97-460),
 //                              Index.Query + appendRolePolicyDenies
 //                              (internal/ruletable/index/index.go:214-530), GetAllScopes
