@@ -27,7 +27,7 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-ALG_BYTES_PER_DECISION = {"C2": 49.0}   # 32 + 9*A/actions + 1 with A=7, 4 actions
+ALG_BYTES_PER_DECISION = {"C1": 33.0, "C2": 49.0, "C3": 42.0}   # 32 + 9*A/actions + 1 (C2: A=7, 4 actions)
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # written by tools/gpu_profile.sh
 
@@ -48,7 +48,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--requests", type=int, default=250_000, help="requests per GPU (x4 actions = tuples)")
+    ap.add_argument("--workload", choices=("C1", "C2", "C3"), default="C2",
+                    help="BASELINE.json config; the metric is quoted on C2 (the default), the others are side measurements")
+    ap.add_argument("--requests", type=int, default=None, help="requests per GPU (default: the config's size: C1 10k x2, C2 250k x4, C3 1M x4 actions)")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="requests timed through the CPU oracle (~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -78,7 +80,12 @@ def main():
     from cerbos_amd.ruletable.build import rule_table_from_policies
 
     capi.init(local_rank)
-    rt = rule_table_from_policies(policies_from_docs(workloads.c2_policies()))
+    wl = {"C1": (workloads.c1_policies, workloads.c1_requests, 10_000, "RBAC-only template policy, no CEL"),
+          "C2": (workloads.c2_policies, workloads.c2_requests, 250_000, "1 resource policy + 5 CEL conditions"),
+          "C3": (workloads.c3_policies, workloads.c3_requests, 1_000_000,
+                 "10 kinds x 20 rules, 4-level scope chain, 2 derived-role sets")}[args.workload]
+    n_requests = args.requests or wl[2]
+    rt = rule_table_from_policies(policies_from_docs(wl[0]()))
     lt = lower_rule_table(rt)   # deterministic: every rank derives the same host-side dictionaries
 
     # ---- policy image: lowered once, broadcast GPU->GPU over RCCL/xGMI
@@ -95,10 +102,12 @@ def main():
         table = capi.Table(lt.blob)
 
     # ---- this rank's shard (weak scaling: fixed tuples per GPU, different seed per rank)
-    cr = workloads.c2_requests(args.requests, seed=2 + rank)
+    cr = wl[1](n_requests, seed={"C1": 1, "C2": 2, "C3": 3}[args.workload] + rank)
     batch = cr.to_batch(Flattener(lt))
     tuples = batch.n_tuples
     now = 1_700_000_000_000_000_000
+    # the reference always computes effective derived roles (part of CheckOutput): so does every step here
+    FLAGS = capi.F_WANT_DERIVED_ROLES
     dbatch = table.upload(batch)
 
     def sync_all():
@@ -108,14 +117,14 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        table.launch(dbatch, now_ns=now)
+        table.launch(dbatch, now_ns=now, flags=FLAGS)
     sync_all()
     if args.warmup:
         table.kernel_time_ms()  # reset the kernel timer
 
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        table.launch(dbatch, now_ns=now)
+        table.launch(dbatch, now_ns=now, flags=FLAGS)
     sync_all()
     elapsed = time.perf_counter() - t0
     check_ms, resolve_ms = table.kernel_time_ms()
@@ -129,7 +138,7 @@ def main():
     lat = []
     for _ in range(min(args.steps, 20)):
         s0 = time.perf_counter()
-        table.launch(dbatch, now_ns=now)
+        table.launch(dbatch, now_ns=now, flags=FLAGS)
         table.synchronize()
         lat.append(time.perf_counter() - s0)
     p50_us_per_decision = float(np.median(lat)) / tuples * 1e6
@@ -140,29 +149,47 @@ def main():
 
     # PCIe-inclusive one-shot path (upload + kernels + download), for DESIGN.md; not `value`
     o0 = time.perf_counter()
-    table.check(batch, now_ns=now, want=())
+    table.check(batch, now_ns=now, flags=FLAGS, want=())
     oneshot_s = time.perf_counter() - o0
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # the oracle = checker + reported CPU baseline ("port": a restatement, not the Go binary)
+        # the oracle = checker + reported CPU baseline ("port": restatements, not the Go binary)
+        #  * oracle/ccheck.cpp (scalar C++ restatement of check.go, -O2) over the WHOLE batch: every
+        #    output of every tuple must equal the GPU's; timed on 1 thread (repeated passes, ~10 s)
+        #    and once on all host cores;
+        #  * oracle/check.py (the restatement pinned on the reference's golden fixtures) over the first
+        #    requests as the independent check of both.
+        from oracle import ccheck
         from oracle.check import EvalParams, RuleTableOracle
-        orc = RuleTableOracle(rt)
-        sample = cr.to_inputs(0, args.cpu_sample)
-        params = EvalParams(now_ns=now)
-        c0 = time.perf_counter()
-        outs = [orc.check(i, params) for i in sample]
+        prep = ccheck.Prepared(lt, batch)
+        cres = prep.run(now_ns=now, flags=FLAGS, threads=1).to_input_order(batch)
+        for name in ("effect", "policy", "scope"):
+            assert np.array_equal(getattr(res, name), getattr(cres, name)), "GPU %s differs from the C++ oracle" % name
+        reps, c0 = 0, time.perf_counter()
+        while reps < 3 or time.perf_counter() - c0 < 10.0:
+            prep.run(now_ns=now, flags=FLAGS, threads=1, want=())
+            reps += 1
         cpu_s = time.perf_counter() - c0
+        ncpu = os.cpu_count() or 1
+        m0 = time.perf_counter()
+        prep.run(now_ns=now, flags=FLAGS, threads=ncpu, want=())
+        mt_s = time.perf_counter() - m0
+        orc = RuleTableOracle(rt)
+        sample = cr.to_inputs(0, min(args.cpu_sample, n_requests, 5000))
+        params = EvalParams(now_ns=now)
+        outs = [orc.check(i, params) for i in sample]
         want = np.array([1 if o["actions"][a]["effect"] == "EFFECT_ALLOW" else 2
                          for i, o in zip(sample, outs) for a in i["actions"]], dtype=np.uint8)
-        assert np.array_equal(eff[:want.size], want), "GPU effects differ from the oracle on the sample"
-        cpu = {"value": want.size / cpu_s, "unit": "decisions/s", "cores": 1, "kind": "port",
-               "sample": "first %d requests (%d tuples) of the same batch, Python restatement of check.go, "
-                         "1 thread, %.1f s" % (len(sample), want.size, cpu_s)}
+        assert np.array_equal(eff[:want.size], want), "GPU effects differ from the Python oracle on the sample"
+        cpu = {"value": tuples * reps / cpu_s, "unit": "decisions/s", "cores": 1, "kind": "port",
+               "sample": "%d passes over the same %d-tuple batch, scalar C++ restatement of check.go (oracle/ccheck.cpp, "
+                         "g++ -O2), 1 thread, %.1f s; all %d host threads: %.3g decisions/s"
+                         % (reps, tuples, cpu_s, ncpu, tuples / mt_s)}
 
     if rank == 0:
         total = tuples * world * args.steps
-        alg = ALG_BYTES_PER_DECISION["C2"]
+        alg = ALG_BYTES_PER_DECISION[args.workload]
         achieved = alg * tuples / (check_ms * 1e-3) / 1e9
         # the instantiation cbh_check_resident picks for this table / batch (cbh_engine.hip)
         kernel = "cbh_check_kernel" + ("" if lt.stats["generic_programs"] else "_leaf") + \
@@ -180,12 +207,12 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 ids + f64 attributes (CEL int64/uint64/double)",
             "data": "synthetic",
-            "config": {"workload": "C2: 1 resource policy + 5 CEL conditions, %d tuples/GPU "
-                                   "(%d requests x 4 actions), seed 2+rank" % (tuples, args.requests),
+            "config": {"workload": "%s: %s, %d tuples/GPU (%d requests), seeded per rank"
+                                   % (args.workload, wl[3], tuples, n_requests),
                        "parallelism": "independent request shards per GPU, policy image broadcast once"},
             "p50_us_per_decision": p50_us_per_decision,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel) if args.workload == "C2" and n_requests == wl[2] else None,
                          "kernel": kernel, "kernel_ms": check_ms,
                          "alg_bytes_per_decision": alg},
             "cpu_baseline": cpu,

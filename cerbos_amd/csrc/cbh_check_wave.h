@@ -327,19 +327,24 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   const u32 act_cnt = valid ? RQ(CBH_RQ_ACT_CNT) : 0;   // <= 64 (the flattener splits larger requests)
 #undef RQ
   // column cache: issue every load of this lane's request attributes now, park them in LDS
-  {
-    u8 tg[CBH_CACHE_COLS]; u64 vl[CBH_CACHE_COLS];
-#pragma unroll
-    for (u32 k = 0; k < CBH_CACHE_COLS; ++k) {
-      if (k < c.n_cached) {
-        const size_t ix = (size_t)k * NR + req;
-        tg[k] = b.col_tag[ix]; vl[k] = b.col_val[ix];
-      }
-    }
-#pragma unroll
-    for (u32 k = 0; k < CBH_CACHE_COLS; ++k) {
-      if (k < c.n_cached) { c.cc_tag[k * CBH_BLOCK + c.tid] = tg[k]; c.cc_val[k * CBH_BLOCK + c.tid] = vl[k]; }
-    }
+  // (async global->LDS copies, `global_load_lds_dword`: no staging registers, the loads of every
+  // column are in flight together; the destination of such a copy is wave-uniform base + lane * 4,
+  // which is exactly a [column][lane] dword plane)
+  for (u32 k = 0; k < c.n_cached; ++k) {
+    const size_t ix = (size_t)k * NR + req;
+    const CBH_G u32* vsrc = (const CBH_G u32*)(b.col_val + ix);
+    const CBH_G u8* tsrc = b.col_tag + (ix & ~(size_t)3);   // the aligned dword holding this lane's tag byte
+#ifndef CBH_HOSTSIM
+    __builtin_amdgcn_global_load_lds((const CBH_G void*)vsrc, (CBH_L void*)(c.cc + k * CBH_BLOCK), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((const CBH_G void*)(vsrc + 1), (CBH_L void*)(c.cc + (c.n_cached + k) * CBH_BLOCK), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((const CBH_G void*)tsrc, (CBH_L void*)(c.cc + (2 * c.n_cached + k) * CBH_BLOCK), 4, 0, 0);
+#else
+    (void)tsrc;   // the host arrays carry no slack after their last byte: place the one byte instead
+    const u32 tw = (u32)b.col_tag[ix] << ((ix & 3u) * 8u);
+    c.cc[k * CBH_BLOCK + c.tid] = vsrc[0];
+    c.cc[(c.n_cached + k) * CBH_BLOCK + c.tid] = vsrc[1];
+    c.cc[(2 * c.n_cached + k) * CBH_BLOCK + c.tid] = tw;
+#endif
   }
   constexpr u32 AM_BITS = sizeof(AM) * 8;
   const AM all = act_cnt >= AM_BITS ? (AM)~(AM)0 : (AM)(((AM)1 << act_cnt) - 1);
@@ -377,15 +382,18 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
     return m & all;
   };
   // policy / scope outputs are written at the moment an action's (tentative) result changes
-  // The first four actions keep theirs in registers until the end (no stores in the middle of the
-  // kernel: vmcnt is in-order, an early store would sit in front of every later load's wait).
-  u32 pol0 = 0, pol1 = 0, pol2 = 0, pol3 = 0, scp0 = CBH_NONE, scp1 = CBH_NONE, scp2 = CBH_NONE, scp3 = CBH_NONE;
+  // The first four actions park theirs in LDS until the end (no global stores in the middle of the
+  // kernel: vmcnt is in-order, an early store would sit in front of every later load's wait; and
+  // not in registers: eight rarely touched VGPRs are what pushes the kernel over its 128-VGPR budget).
+  __shared__ u32 ps_lds[8 * CBH_BLOCK];
+#define PS_POL(k) ps_lds[(k) * CBH_BLOCK + c.tid]
+#define PS_SCP(k) ps_lds[(4 + (k)) * CBH_BLOCK + c.tid]
   auto write_ps = [&](AM mask, u32 polw, u32 scpw) {
     if (!want_ps) return;
-    if (mask & 1) { pol0 = polw; scp0 = scpw; }
-    if (mask & 2) { pol1 = polw; scp1 = scpw; }
-    if (mask & 4) { pol2 = polw; scp2 = scpw; }
-    if (mask & 8) { pol3 = polw; scp3 = scpw; }
+    if (mask & 1) { PS_POL(0) = polw; PS_SCP(0) = scpw; }
+    if (mask & 2) { PS_POL(1) = polw; PS_SCP(1) = scpw; }
+    if (mask & 4) { PS_POL(2) = polw; PS_SCP(2) = scpw; }
+    if (mask & 8) { PS_POL(3) = polw; PS_SCP(3) = scpw; }
     mask &= ~(AM)0xF;
     while (mask) {
       const u32 k = (u32)__builtin_ctzll((u64)mask);
@@ -395,7 +403,9 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
     }
   };
 
-  const u64 kind_bits = gbits_of(t, b, DIM_KIND, kind);
+  // kind-dimension glob bits of the resource kind: looked up where a pattern needs them (zero loads
+  // for a table without kind globs) rather than held in two registers for the whole kernel
+#define KIND_BITS() gbits_of(t, b, DIM_KIND, kind)
   // parent roles are looked up with the request's own resource scope only (check.go:172,227)
   const u32 pr_scope_key = (r_scope & CBH_SCOPE_EXACT) ? (r_scope & ~CBH_SCOPE_EXACT) : CBH_NONE;
 
@@ -411,7 +421,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
       const u32 lead = first_lane(remq);
       const u32 g_ps = wave_readlane(p_scope, lead), g_pv = wave_readlane(p_ver, lead), g_rs = wave_readlane(r_scope, lead),
                 g_rv = wave_readlane(r_ver, lead), g_k = wave_readlane(kind, lead);
-      const u64 g_kbits = wave_readlane64(kind_bits, lead);
+      const u64 g_kbits = wave_readlane64(KIND_BITS(), lead);
       const bool inq = pendq && p_scope == g_ps && p_ver == g_pv && r_scope == g_rs && r_ver == g_rv && kind == g_k;
       pendq = pendq && !inq;
       const u32 pf = uchain_first(t, g_ps, FLAG_PRIN, lenient), rf = uchain_first(t, g_rs, FLAG_RES, lenient);
@@ -471,7 +481,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
     write_ps(Pm, pol_default, CBH_NONE);   // what the first role seeds when nothing matches (check.go:429-431)
     AM rdone = 0;                           // actions that reached ALLOW: they leave the role loop (check.go:433-436)
     bool pend = Pm != 0;
-    u64 memo_done = 0, memo_val = 0, memo_err = 0;   // per-lane condition outcomes of this pass, bit = record position
+    AM memo_done = 0, memo_val = 0, memo_err = 0;   // per-lane condition outcomes of this pass, bit = record position
 
     for (;;) {   // ---- waterfall over groups that share (chain start, version, kind | principal)
       const u64 rem = wave_ballot(pend);
@@ -566,7 +576,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                 AM any_mask = 0;   // actions allowed (subject to conditions) by some rule for this resource
                 for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
                   const TblRp rr = uload_rec<TblRp>(t.rprows, row);
-                  if (!in2 || !pat_match(rr.resource, kind, kind_bits)) continue;
+                  if (!in2 || !pat_match(rr.resource, kind, KIND_BITS())) continue;
                   for (u32 a = 0; a < rr.allow_cnt; ++a) any_mask |= match_actions(uload(&t.pool[rr.allow_off + a]));
                 }
                 // no binding for the resource, or no allow-action matched (index.go:436-461)
@@ -575,7 +585,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                   const TblRp rr = uload_rec<TblRp>(t.rprows, row);
                   if (rr.cond == CBH_NONE) continue;
                   AM mm = 0;
-                  if (in2 && pat_match(rr.resource, kind, kind_bits)) {
+                  if (in2 && pat_match(rr.resource, kind, KIND_BITS())) {
                     for (u32 a = 0; a < rr.allow_cnt; ++a) mm |= match_actions(uload(&t.pool[rr.allow_off + a]));
                     mm &= S & ~deny;
                   }
@@ -607,7 +617,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
               const u32 n_role = (rw.flags & CBH_ROW_F_ROLE_LIST) ? (rw.counts >> 16) : 0u;
               bool rmatch = false;
               if (S != 0) {
-                if (!is_res) rmatch = pat_match(rw.resource, kind, kind_bits);
+                if (!is_res) rmatch = pat_match(rw.resource, kind, KIND_BITS());
                 else if (n_role == 0) rmatch = roleset_has(t, rs, rw.role);
                 else for (u32 i = 0; i < n_role; ++i) rmatch = rmatch || roleset_has(t, rs, uload(&t.pool[rw.role + i]));
               }
@@ -617,17 +627,16 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                 else for (u32 i = 0; i < n_act; ++i) mrow |= match_actions(uload(&t.pool[rw.action + i]));
                 mrow &= S;
               }
-              // once an ALLOW fired only a DENY can change an action's outcome in this scope (check.go:392-403);
-              // strict mode still evaluates everything because an error there is itself a DENY
-              AM need = mrow;
-              if (e == CBH_EFFECT_ALLOW && !strict) need &= ~has_allow;
+              // every matched row is evaluated, also an ALLOW after an ALLOW that already fired: the
+              // reference does the same (check.go:295-414), and its errors belong in evaluation_errors
+              const AM need = mrow;
               DBG2_ACC(dbg_c);
               if (wave_ballot(need != 0) == 0) continue;
               const bool m = need != 0;
               // A request meets the same record once per role it holds; its conditions read only the
               // request (and this scope's derived roles), so the first outcome is kept per lane for the
               // first 64 records of the walk and replayed - including the error status - afterwards.
-              const u64 sbit = site < 64 ? (1ull << site) : 0;
+              const AM sbit = site < AM_BITS ? (AM)((AM)1 << site) : (AM)0;
               const bool hit = m && (memo_done & sbit) != 0;
               const bool mev = m && !hit;
               int r = 1;
@@ -684,8 +693,8 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
     // profiling aid: policy words of the first three actions <- cycles spent in the preamble,
     // in the two policy passes, and the wave's start time (low 32 bits)
     const u64 cyc_end = __builtin_readcyclecounter();
-    pol0 = (u32)(cyc_pre - cyc_start); pol1 = (u32)(cyc_end - cyc_pre); pol2 = (u32)dbg_eval; pol3 = (u32)dbg_n;
-    scp0 = (u32)dbg_a; scp1 = (u32)dbg_b; scp2 = (u32)dbg_c; scp3 = (u32)dbg_d;
+    PS_POL(0) = (u32)(cyc_pre - cyc_start); PS_POL(1) = (u32)(cyc_end - cyc_pre); PS_POL(2) = (u32)dbg_eval; PS_POL(3) = (u32)dbg_n;
+    PS_SCP(0) = (u32)dbg_a; PS_SCP(1) = (u32)dbg_b; PS_SCP(2) = (u32)dbg_c; PS_SCP(3) = (u32)dbg_d;
   }
 #endif
   // A request with exactly four actions on a 4-tuple boundary (the usual batch shape) writes each
@@ -704,17 +713,16 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
     if (o.edr) o.edr[req] = edr_acc;
     *(CBH_G u32*)(o.effect + act_off) = e4;
     if (o.status) *(CBH_G u32*)(o.status + act_off) = s4;
-    if (o.policy) { u32x4 v; v.x = pol0; v.y = pol1; v.z = pol2; v.w = pol3; *(CBH_G u32x4*)(o.policy + act_off) = v; }
-    if (o.scope) { u32x4 v; v.x = scp0; v.y = scp1; v.z = scp2; v.w = scp3; *(CBH_G u32x4*)(o.scope + act_off) = v; }
+    if (o.policy) { u32x4 v; v.x = PS_POL(0); v.y = PS_POL(1); v.z = PS_POL(2); v.w = PS_POL(3); *(CBH_G u32x4*)(o.policy + act_off) = v; }
+    if (o.scope) { u32x4 v; v.x = PS_SCP(0); v.y = PS_SCP(1); v.z = PS_SCP(2); v.w = PS_SCP(3); *(CBH_G u32x4*)(o.scope + act_off) = v; }
   } else if (valid) {
     if (o.edr) o.edr[req] = edr_acc;
     if (want_ps) {
-      const u32 pk[4] = {pol0, pol1, pol2, pol3}, sk[4] = {scp0, scp1, scp2, scp3};
 #pragma unroll
       for (u32 k = 0; k < 4; ++k) {
         if (k < act_cnt) {
-          if (o.policy) o.policy[act_off + k] = pk[k];
-          if (o.scope) o.scope[act_off + k] = sk[k];
+          if (o.policy) o.policy[act_off + k] = PS_POL(k);
+          if (o.scope) o.scope[act_off + k] = PS_SCP(k);
         }
       }
     }
@@ -724,13 +732,16 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
       if (o.status) o.status[act_off + k] = (u8)((st_unsup & bit) ? CBH_ST_UNSUPPORTED : ((st_err & bit) ? CBH_ST_CEL_ERROR : CBH_ST_OK));
     }
   }
+#undef PS_POL
+#undef KIND_BITS
+#undef PS_SCP
 }
 
-// Dynamic LDS of both kernels = the column cache: n_cached * CBH_BLOCK * (8 + 1) bytes.
+// Dynamic LDS of the kernels = the column cache: n_cached * CBH_BLOCK * 12 bytes.
 #ifndef CBH_HOSTSIM
 extern __shared__ __attribute__((aligned(16))) unsigned char cbh_dyn_lds[];
 #else
-static unsigned char cbh_dyn_lds[CBH_CACHE_COLS * CBH_BLOCK * 9 + 16];
+static unsigned char cbh_dyn_lds[CBH_CACHE_COLS * CBH_BLOCK * 12];
 #endif
 __device__ __forceinline__ u32 cached_columns(const KernelArgs* ka) {
   const u32 n = ka->b.n_columns;
@@ -751,7 +762,7 @@ __device__ __forceinline__ void generic_kernel_body(const KernelArgs& a, const K
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x,
         (CBH_L u64*)s_val, (CBH_L u8*)s_tag, (CBH_L u64*)l_val, (CBH_L u8*)l_tag,
         (CBH_L u64*)it_cont, (CBH_L u32*)it_idx, (CBH_L u32*)it_state,
-        (CBH_L u64*)cbh_dyn_lds, (CBH_L u8*)(cbh_dyn_lds + (size_t)ncc * CBH_BLOCK * 8), ncc, ka};
+        (CBH_L u32*)cbh_dyn_lds, ncc, ka};
   check_body<true, AM>(a, c);
 }
 
@@ -760,7 +771,7 @@ template <typename AM>
 __device__ __forceinline__ void leaf_kernel_body(const KernelArgs& a, const KernelArgs* ka) {
   const u32 ncc = cached_columns(&a);
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-        (CBH_L u64*)cbh_dyn_lds, (CBH_L u8*)(cbh_dyn_lds + (size_t)ncc * CBH_BLOCK * 8), ncc, ka};
+        (CBH_L u32*)cbh_dyn_lds, ncc, ka};
   check_body<false, AM>(a, c);
 }
 

@@ -92,8 +92,10 @@ struct Ctx {
   CBH_L u64* it_cont; CBH_L u32* it_idx; CBH_L u32* it_state; // iteration slots [CBH_MAX_ITERS][CBH_BLOCK]
   // Per-lane cache of the request's first n_cached attribute columns, filled once in the kernel
   // preamble (all loads in flight together) so condition leaves read LDS instead of paying one
-  // HBM round trip each.  [column][lane]
-  CBH_L u64* cc_val; CBH_L u8* cc_tag; u32 n_cached;
+  // HBM round trip each.  Three dword planes of [column][lane]: value low, value high, and the
+  // aligned dword of col_tag that holds the lane's tag byte (the fill is an async global->LDS copy,
+  // which moves dwords: cbh_check_wave.h).
+  CBH_L u32* cc; u32 n_cached;
   // The launch arguments as they sit in device memory.  `t` / `b` above refer to a register copy
   // inside the kernels; functions that are real calls (slow paths, the stack interpreter) are
   // handed this pointer instead and build their own view, so the register copy's address never
@@ -104,14 +106,14 @@ struct Ctx {
 struct VmLds {
   CBH_L u64* s_val; CBH_L u8* s_tag; CBH_L u64* l_val; CBH_L u8* l_tag;
   CBH_L u64* it_cont; CBH_L u32* it_idx; CBH_L u32* it_state;
-  CBH_L u64* cc_val; CBH_L u8* cc_tag; u32 n_cached; u32 tid;
+  CBH_L u32* cc; u32 n_cached; u32 tid;
 };
 __device__ __forceinline__ VmLds lds_of(const Ctx& c) {
-  return VmLds{c.s_val, c.s_tag, c.l_val, c.l_tag, c.it_cont, c.it_idx, c.it_state, c.cc_val, c.cc_tag, c.n_cached, c.tid};
+  return VmLds{c.s_val, c.s_tag, c.l_val, c.l_tag, c.it_cont, c.it_idx, c.it_state, c.cc, c.n_cached, c.tid};
 }
 __device__ __forceinline__ Ctx ctx_from_memory(const KernelArgs* ka, const VmLds& m) {
   return Ctx{ka->t, ka->b, ka->now_ns, ka->flags, m.tid, m.s_val, m.s_tag, m.l_val, m.l_tag, m.it_cont, m.it_idx,
-             m.it_state, m.cc_val, m.cc_tag, m.n_cached, ka};
+             m.it_state, m.cc, m.n_cached, ka};
 }
 #define CBH_CACHE_COLS 16
 
@@ -555,8 +557,10 @@ __device__ __forceinline__ Val load_operand(const Ctx& c, const Lane& L, u32 kin
   if (kind == 0) return mk(c.t.const_tag[arg], c.t.const_val[arg]);
   if (kind == 1) {
     if (arg < c.n_cached) {   // uniform: arg comes from the bytecode
-      const u32 t = c.cc_tag[arg * CBH_BLOCK + c.tid];
-      return t == CBH_T_ABSENT ? mk_err() : mk(t, c.cc_val[arg * CBH_BLOCK + c.tid]);
+      const u32 tw = c.cc[(2 * c.n_cached + arg) * CBH_BLOCK + c.tid];
+      const u32 t = (tw >> ((((size_t)arg * c.b.n_requests + L.req) & 3u) * 8u)) & 0xFFu;
+      if (t == CBH_T_ABSENT) return mk_err();
+      return mk(t, (u64)c.cc[arg * CBH_BLOCK + c.tid] | ((u64)c.cc[(c.n_cached + arg) * CBH_BLOCK + c.tid] << 32));
     }
     size_t ix = (size_t)arg * c.b.n_requests + L.req;
     u32 t = c.b.col_tag[ix];

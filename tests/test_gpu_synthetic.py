@@ -97,3 +97,32 @@ def test_resident_path_and_kernel_timer():
     assert np.array_equal(res.effect, table.check(batch, now_ns=NOW).effect)
     db.close()
     table.close()
+
+
+@pytest.mark.parametrize("name,n_requests,mode", [("C2", 250_000, "default"), ("C2", 250_000, "strict"),
+                                                  ("C3", 1_000_000, "default"), ("C3", 250_000, "lenient")])
+def test_full_size_bit_exact_against_cpp_oracle(name, n_requests, mode):
+    """Every tuple of the full-size configurations (C2: 1M, C3: 4M tuples): effect, policy, scope and
+    derived-role mask identical to oracle/ccheck.cpp, and the same requests report CEL errors.
+    (ccheck is pinned against oracle/check.py in tests/test_ccheck.py.)"""
+    import os
+    from oracle import ccheck
+    full = {"C2": workloads.c2_requests, "C3": workloads.c3_requests}[name]
+    pol_fn = CONFIGS[name][0]
+    rt, lt, table = _table(pol_fn)
+    batch = full(n_requests).to_batch(Flattener(lt))
+    flags = capi.F_WANT_DERIVED_ROLES
+    flags |= capi.F_LENIENT_SCOPE_SEARCH if mode == "lenient" else 0
+    flags |= capi.F_STRICT_EVALUATION if mode == "strict" else 0
+    got = table.check(batch, now_ns=NOW, flags=flags)
+    want = ccheck.check(lt, batch, NOW, flags, threads=min(16, os.cpu_count() or 1))
+    assert (got.status != capi.ST_UNSUPPORTED).all() and (want.status != capi.ST_UNSUPPORTED).all()
+    for f in ("effect", "policy", "scope", "edr"):
+        a, b = getattr(got, f), getattr(want, f)
+        mism = np.nonzero(a != b)[0]
+        assert mism.size == 0, "%s: %d mismatches, first at %s" % (f, mism.size, mism[:5])
+    # evaluation errors are a per-CheckOutput property: compare per request (4 actions each)
+    ge = (got.status == capi.ST_CEL_ERROR).reshape(-1, 4).any(axis=1)
+    we = (want.status == capi.ST_CEL_ERROR).reshape(-1, 4).any(axis=1)
+    assert np.array_equal(ge, we)
+    table.close()

@@ -14,9 +14,13 @@ from cerbos_amd.policy.loader import policies_from_docs
 from cerbos_amd.ruletable.build import rule_table_from_policies
 
 capi.init(0)
-lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c2_policies())))
+wl = sys.argv[1] if len(sys.argv) > 1 else "C2"
+pol, reqs, n = {"C2": (workloads.c2_policies, workloads.c2_requests, 250_000),
+                "C3": (workloads.c3_policies, workloads.c3_requests, 1_000_000)}[wl]
+lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol())))
 table = capi.Table(lt.blob)
-batch = workloads.c2_requests(250_000).to_batch(Flattener(lt))
+batch = reqs(n).to_batch(Flattener(lt))
+print("workload", wl, "requests", n)
 db = table.upload(batch)
 for name, fl in (("full", 0), ("no_eval", 0x400), ("no_rows", 0x800), ("no_passes", 0x200)):
     for _ in range(5):
