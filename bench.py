@@ -46,8 +46,9 @@ def pmc_traffic(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # a step is ~40 us: the defaults keep the GPU busy long enough (~20 ms) for its clocks to settle
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", choices=("C1", "C2", "C3"), default="C2",
                     help="BASELINE.json config; the metric is quoted on C2 (the default), the others are side measurements")
     ap.add_argument("--requests", type=int, default=None, help="requests per GPU (default: the config's size: C1 10k x2, C2 250k x4, C3 1M x4 actions)")
@@ -107,7 +108,7 @@ def main():
     tuples = batch.n_tuples
     now = 1_700_000_000_000_000_000
     # the reference always computes effective derived roles (part of CheckOutput): so does every step here
-    FLAGS = capi.F_WANT_DERIVED_ROLES
+    FLAGS = int(os.environ.get("CBH_BENCH_FLAGS", capi.F_WANT_DERIVED_ROLES))   # (override: experiments only)
     dbatch = table.upload(batch)
 
     def sync_all():

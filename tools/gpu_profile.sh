@@ -13,7 +13,7 @@ cd $R
 
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/prof $OUT/pmc_t
-BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r -- $BENCH > $OUT/prof.log 2>&1
 DB=$(find $OUT/prof -name '*.db' | head -1)
 [ -n "$DB" ] && python $R/tools/rocpd_summary.py "$DB" $OUT/kernel_stats.txt > /dev/null
