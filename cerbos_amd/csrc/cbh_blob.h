@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define CBH_BLOB_MAGIC 0x31484243u /* "CBH1" */
-#define CBH_BLOB_VERSION 7u
+#define CBH_BLOB_VERSION 8u
 
 struct CbhBlobHeader {  // 32 bytes
   uint32_t magic;
@@ -33,7 +33,7 @@ enum CbhSectionId {
   CBH_SEC_SCOPE_FLAGS = 5, // u32[NS]  bit0 resource map, bit1 principal map, bits 2..3 scope permissions
   CBH_SEC_SCOPE_SID = 6,   // u32[NS]  string id of the scope
   CBH_SEC_HASH = 7,        // CbhHashSlot[nslots]
-  CBH_SEC_ROWS = 8,        // u32[n_rows][8]   row-major records (CbhRowField order + pad): one s_load_dwordx8 each
+  CBH_SEC_ROWS = 8,        // u32[n_rows][16]  row-major records (CbhRowField order): one s_load_dwordx16 each
   CBH_SEC_RPROWS = 9,      // u32[n_rprows][4] row-major records (CbhRpField order)
   CBH_SEC_U32POOL = 10,    // u32[] (pattern lists, parent-role lists)
   CBH_SEC_DR = 11,         // u32[n_dr][4]     row-major records (CbhDrField order)
@@ -113,8 +113,10 @@ enum CbhRowField {
   CBH_ROW_COND = 4,     // program entry or CBH_NONE
   CBH_ROW_DRCOND = 5,   // program entry or CBH_NONE
   CBH_ROW_POLICY = 6,   // policy id of the origin policy (strict-mode attribution)
-  CBH_ROW_COUNTS = 7,   // action list length | role list length << 16 (0 = inline)
-  CBH_ROW_NF = 8
+  CBH_ROW_COUNTS = 7,   // action list length | role list length << 16 (0 = one inline reference)
+  CBH_ROW_A1 = 8,       // 2nd..4th action pattern ref of a list of at most four (inline, no CBH_ROW_F_ACTION_LIST)
+  CBH_ROW_R1 = 11,      // 2nd..4th role pattern ref likewise
+  CBH_ROW_NF = 16       // record = 16 dwords, 64-byte aligned
 };
 #define CBH_ROW_F_ACTION_LIST 4u
 #define CBH_ROW_F_ROLE_LIST 8u

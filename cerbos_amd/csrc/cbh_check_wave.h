@@ -39,7 +39,11 @@ __device__ __forceinline__ bool roleset_has(const TableDev& t, const RoleSet& rs
 
 // Table records are stored row-major and naturally aligned so that one wide scalar load
 // (s_load_dwordx4 / x8) fetches a whole record at a wave-uniform index.
+// A rule record is 16 dwords, read as two independent 8-dword halves: the rule itself (live through
+// the evaluation of its conditions) and its inline lists (dead as soon as the lanes are matched).
+// One 16-dword register tuple would be spilled and reloaded as a unit around every call.
 struct __attribute__((aligned(32))) TblRow { u32 action, role, resource, flags, cond, drcond, policy, counts; };
+struct __attribute__((aligned(32))) TblRowLists { u32 a1, a2, a3, r1, r2, r3, pad0, pad1; };   // 2nd..4th action / role (cbh_blob.h)
 struct __attribute__((aligned(16))) TblRp { u32 resource, allow_off, allow_cnt, cond; };
 struct __attribute__((aligned(16))) TblDr { u32 name, parents_off, parents_cnt, cond; };
 struct __attribute__((aligned(32))) TblSlot { u32 k0, k1, k2, k3, v0, v1, v2, v3; };
@@ -47,10 +51,14 @@ struct __attribute__((aligned(32))) TblSlot { u32 k0, k1, k2, k3, v0, v1, v2, v3
 template <typename R, typename P>
 __device__ __forceinline__ R uload_rec(P base, u32 idx) {   // P: pointer to u32 in any address space
 #ifndef CBH_HOSTSIM
-  static_assert(sizeof(R) == 16 || sizeof(R) == 32, "table records are 4 or 8 dwords");
+  static_assert(sizeof(R) == 16 || sizeof(R) == 32 || sizeof(R) == 64, "table records are 4, 8 or 16 dwords");
   const unsigned long long addr = uniform_addr((unsigned long long)(base + (size_t)idx * (sizeof(R) / 4)));
   R r;
-  if constexpr (sizeof(R) == 32) {
+  if constexpr (sizeof(R) == 64) {
+    typedef u32 u32x16 __attribute__((ext_vector_type(16)));
+    const u32x16 v = *(const __attribute__((address_space(4))) u32x16*)addr;
+    __builtin_memcpy(&r, &v, 64);
+  } else if constexpr (sizeof(R) == 32) {
     typedef u32 u32x8 __attribute__((ext_vector_type(8)));
     const u32x8 v = *(const __attribute__((address_space(4))) u32x8*)addr;
     __builtin_memcpy(&r, &v, 32);
@@ -609,22 +617,34 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
 #endif
             for (u32 row = bucket.x; row < bucket.x + bucket.y; ++row) {
               DBG2_T0();
-              const TblRow rw = uload_rec<TblRow>(t.rows, row);   // one s_load_dwordx8
+              const TblRow rw = uload_rec<TblRow>(t.rows, 2 * row);            // both halves are issued together:
+              const TblRowLists rl = uload_rec<TblRowLists>(t.rows, 2 * row + 1);   // no dependent load for short lists
               const u32 site = site_ctr++;   // position of the record in this group's walk: the same for every role
               const u32 e = rw.flags & 3u;
               // a record = roles x actions of one rule (cbh_blob.h): the lists are wave-uniform
-              const u32 n_act = (rw.flags & CBH_ROW_F_ACTION_LIST) ? (rw.counts & 0xFFFFu) : 0u;
-              const u32 n_role = (rw.flags & CBH_ROW_F_ROLE_LIST) ? (rw.counts >> 16) : 0u;
+              const u32 n_act = rw.counts & 0xFFFFu, n_role = rw.counts >> 16;   // 0 = a single inline reference
               bool rmatch = false;
               if (S != 0) {
                 if (!is_res) rmatch = pat_match(rw.resource, kind, KIND_BITS());
-                else if (n_role == 0) rmatch = roleset_has(t, rs, rw.role);
-                else for (u32 i = 0; i < n_role; ++i) rmatch = rmatch || roleset_has(t, rs, uload(&t.pool[rw.role + i]));
+                else if (rw.flags & CBH_ROW_F_ROLE_LIST) {   // more than four roles: the list lives in the pool
+                  for (u32 i = 0; i < n_role; ++i) rmatch = rmatch || roleset_has(t, rs, uload(&t.pool[rw.role + i]));
+                } else {
+                  rmatch = roleset_has(t, rs, rw.role);
+                  if (n_role > 1) rmatch = rmatch || roleset_has(t, rs, rl.r1);
+                  if (n_role > 2) rmatch = rmatch || roleset_has(t, rs, rl.r2);
+                  if (n_role > 3) rmatch = rmatch || roleset_has(t, rs, rl.r3);
+                }
               }
               AM mrow = 0;
               if (rmatch) {
-                if (n_act == 0) mrow = match_actions(rw.action);
-                else for (u32 i = 0; i < n_act; ++i) mrow |= match_actions(uload(&t.pool[rw.action + i]));
+                if (rw.flags & CBH_ROW_F_ACTION_LIST) {
+                  for (u32 i = 0; i < n_act; ++i) mrow |= match_actions(uload(&t.pool[rw.action + i]));
+                } else {
+                  mrow = match_actions(rw.action);
+                  if (n_act > 1) mrow |= match_actions(rl.a1);
+                  if (n_act > 2) mrow |= match_actions(rl.a2);
+                  if (n_act > 3) mrow |= match_actions(rl.a3);
+                }
                 mrow &= S;
               }
               // every matched row is evaluated, also an ALLOW after an ALLOW that already fired: the

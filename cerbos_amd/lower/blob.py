@@ -25,7 +25,7 @@ from .celc import LoweringError, Params, ProgramBuilder
 from .globs import GlobNFA, fix_glob, has_meta
 
 BLOB_MAGIC = 0x31484243
-BLOB_VERSION = 7
+BLOB_VERSION = 8
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
 ROW_F_ACTION_LIST, ROW_F_ROLE_LIST = 4, 8
@@ -194,7 +194,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
                 prin_buckets.setdefault((ver, scope, r["principal"]), []).append(r)
 
     pool = []
-    row_cols = [[] for _ in range(8)]
+    row_cols = [[] for _ in range(14)]
     rp_cols = [[] for _ in range(4)]
     dr_cols = [[] for _ in range(4)]
     entries = []  # (k0,k1,k2,k3, v0,v1,v2,v3)
@@ -214,12 +214,16 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         return cond, drc
 
     def dim_list(dim, keys):
-        """One key -> its reference; several -> (pool offset, count)."""
+        """-> (first word, count, list flag, [2nd..4th inline refs]).  One key: its reference, count 0.
+        Up to four: all inline in the record.  More: a slice of the u32 pool."""
         if len(keys) == 1:
-            return (dim_ref(dim, keys[0]) if keys[0] else NONE), 0
+            return (dim_ref(dim, keys[0]) if keys[0] else NONE), 0, False, [NONE] * 3
+        refs = [dim_ref(dim, k) for k in keys]
+        if len(refs) <= 4:
+            return refs[0], len(refs), False, (refs[1:] + [NONE] * 3)[:3]
         off = len(pool)
-        pool.extend(dim_ref(dim, k) for k in keys)
-        return off, len(keys)
+        pool.extend(refs)
+        return off, len(refs), True, [NONE] * 3
 
     def add_bucket_rows(rows, principal_policy):
         """Emit the device rows of one bucket; returns how many.
@@ -250,10 +254,10 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
                 else:   # not a cross product: keep the reference's rows one by one
                     merged = [([r["role"]], [r["action"]]) for r in grp]
                 for rl, al in merged:
-                    a_ref, a_cnt = dim_list(DIM_ACTION, al)
-                    r_ref, r_cnt = dim_list(DIM_ROLE, rl)
+                    a_ref, a_cnt, a_pool, a_more = dim_list(DIM_ACTION, al)
+                    r_ref, r_cnt, r_pool, r_more = dim_list(DIM_ROLE, rl)
                     fl = {"ALLOW": 1, "DENY": 2}.get(effect, 0)
-                    fl |= (ROW_F_ACTION_LIST if a_cnt else 0) | (ROW_F_ROLE_LIST if r_cnt else 0)
+                    fl |= (ROW_F_ACTION_LIST if a_pool else 0) | (ROW_F_ROLE_LIST if r_pool else 0)
                     row_cols[0].append(a_ref)
                     row_cols[1].append(r_ref)
                     row_cols[2].append(dim_ref(DIM_KIND, resource) if resource else NONE)
@@ -262,6 +266,9 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
                     row_cols[5].append(drc)
                     row_cols[6].append(policy_id(grp[0]["origin_fqn"]))
                     row_cols[7].append(a_cnt | (r_cnt << 16))
+                    for i in range(3):
+                        row_cols[8 + i].append(a_more[i])
+                        row_cols[11 + i].append(r_more[i])
                     n += 1
         return n
 
@@ -422,7 +429,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         (SEC_SCOPE_FLAGS, len(lt.scopes), u32(scope_flags)),
         (SEC_SCOPE_SID, len(lt.scopes), u32(scope_sid)),
         (SEC_HASH, nslots, slots.tobytes()),
-        (SEC_ROWS, len(row_cols[0]), row_major(row_cols, 8)),
+        (SEC_ROWS, len(row_cols[0]), row_major(row_cols, 16)),
         (SEC_RPROWS, len(rp_cols[0]), row_major(rp_cols, 4)),
         (SEC_U32POOL, len(pool), u32(pool)),
         (SEC_DR, len(dr_cols[0]), row_major(dr_cols, 4)),

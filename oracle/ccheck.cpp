@@ -346,17 +346,18 @@ void check_request(const Img& g, const cbh_batch& b, const cbh_params& p, u32 r,
                                          : dir_find(g, CBH_B_PRINCIPAL, r_ver, si, pid);   // resource version: check.go:294
           bool brk = false;
           for (u32 row = bk ? bk->v0 : 0; bk && row < bk->v0 + bk->v1; ++row) {  // :295-414, binding order
-            const u32* rw = g.rows + 8 * (size_t)row;
+            const u32* rw = g.rows + CBH_ROW_NF * (size_t)row;
             const u32 fl = rw[CBH_ROW_FLAGS];
-            const u32 n_act = (fl & CBH_ROW_F_ACTION_LIST) ? (rw[CBH_ROW_COUNTS] & 0xFFFFu) : 0u;
-            const u32 n_role = (fl & CBH_ROW_F_ROLE_LIST) ? (rw[CBH_ROW_COUNTS] >> 16) : 0u;
+            const u32 n_act = rw[CBH_ROW_COUNTS] & 0xFFFFu, n_role = rw[CBH_ROW_COUNTS] >> 16;   // 0 = one reference
+            // the i-th pattern of a list: in the pool, or inline in the record (first word + CBH_ROW_A1 / R1 ...)
+            auto nth = [&](u32 first, u32 more, bool in_pool, u32 i) { return in_pool ? g.pool[rw[first] + i] : (i == 0 ? rw[first] : rw[more + i - 1]); };
             bool m;
             if (!is_res) m = pat_match(rw[CBH_ROW_RESOURCE], kind, kind_bits);
             else if (n_role == 0) m = pat_match(rw[CBH_ROW_ROLE], role, role_bits);
-            else { m = false; for (u32 i = 0; i < n_role; ++i) m = m || pat_match(g.pool[rw[CBH_ROW_ROLE] + i], role, role_bits); }
+            else { m = false; for (u32 i = 0; i < n_role; ++i) m = m || pat_match(nth(CBH_ROW_ROLE, CBH_ROW_R1, fl & CBH_ROW_F_ROLE_LIST, i), role, role_bits); }
             if (!m) continue;
             if (n_act == 0) m = pat_match(rw[CBH_ROW_ACTION], action, act_bits);
-            else { m = false; for (u32 i = 0; i < n_act; ++i) m = m || pat_match(g.pool[rw[CBH_ROW_ACTION] + i], action, act_bits); }
+            else { m = false; for (u32 i = 0; i < n_act; ++i) m = m || pat_match(nth(CBH_ROW_ACTION, CBH_ROW_A1, fl & CBH_ROW_F_ACTION_LIST, i), action, act_bits); }
             if (!m) continue;
             const u32 e = fl & 3u;
             const int res = cond_pair(row, rw[CBH_ROW_DRCOND], rw[CBH_ROW_COND], err);
