@@ -56,22 +56,27 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: keep RCCL's version banner (NCCL_DEBUG=VERSION/INFO) off it
+    if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO"):
+        os.environ["NCCL_DEBUG"] = "WARN"
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # CBH_BENCH_FORCE_DIST=1: take the multi-GPU code path (RCCL init, image broadcast, adopt) even with one rank
+    use_dist = world > 1 or os.environ.get("CBH_BENCH_FORCE_DIST") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the decision path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__
     if rank == 0:
         __graft_entry__.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     from cerbos_amd import capi, workloads
@@ -91,7 +96,7 @@ def main():
 
     # ---- policy image: lowered once, broadcast GPU->GPU over RCCL/xGMI
     bcast_ms = None
-    if world > 1:
+    if use_dist:
         from cerbos_amd import dist as cdist
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -114,7 +119,7 @@ def main():
     def sync_all():
         table.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -131,7 +136,7 @@ def main():
     check_ms, resolve_ms = table.kernel_time_ms()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -225,7 +230,7 @@ def main():
         print(json.dumps(out))
     dbatch.close()
     table.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

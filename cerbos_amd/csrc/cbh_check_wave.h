@@ -394,6 +394,8 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   // kernel: vmcnt is in-order, an early store would sit in front of every later load's wait; and
   // not in registers: eight rarely touched VGPRs are what pushes the kernel over its 128-VGPR budget).
   __shared__ u32 ps_lds[8 * CBH_BLOCK];
+  __shared__ AM drm_lds[3 * CBH_BLOCK];   // derived-role outcome memo, see the walk below
+#define DRM(i) drm_lds[(i) * CBH_BLOCK + c.tid]
 #define PS_POL(k) ps_lds[(k) * CBH_BLOCK + c.tid]
 #define PS_SCP(k) ps_lds[(4 + (k)) * CBH_BLOCK + c.tid]
   auto write_ps = [&](AM mask, u32 polw, u32 scpw) {
@@ -490,6 +492,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
     AM rdone = 0;                           // actions that reached ALLOW: they leave the role loop (check.go:433-436)
     bool pend = Pm != 0;
     AM memo_done = 0, memo_val = 0, memo_err = 0;   // per-lane condition outcomes of this pass, bit = record position
+    if (want_edr) { DRM(0) = 0; DRM(1) = 0; DRM(2) = 0; }   // likewise for derived-role definitions (done / true / error)
 
     for (;;) {   // ---- waterfall over groups that share (chain start, version, kind | principal)
       const u64 rem = wave_ballot(pend);
@@ -515,7 +518,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
         }
         AM has_allow = 0;
         AM S = Am;   // actions still walking the scope chain for this role
-        u32 site_ctr = 0;
+        u32 site_ctr = 0, dr_site_ctr = 0;
         DBG2_ACC(dbg_a);
 
         // effect events of this role iteration (fold of check.go:382-442, applied as they happen)
@@ -550,16 +553,36 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
 
           DBG2_ACC(dbg_b);
           if (is_res && want_edr) {   // derived roles of this scope's resource policy (check.go:237-282)
+            // Whether a definition applies (parent roles) and what its condition yields depend on the
+            // request only, not on the role being walked: the outcome of the first DRM_SITES
+            // definitions met in this group's walk is kept per lane (LDS) and replayed for the
+            // request's other roles - the reference computes them once per scope too (check.go:237).
             u64 m = 0; bool derr = false;
             if (have_bucket) {
               for (u32 d = bucket.z; d < bucket.z + bucket.w; ++d) {
                 const TblDr dr = uload_rec<TblDr>(t.dr, d);
-                const bool applies = S != 0 && (dr.parents_cnt == CBH_NONE ||
-                    lane_has_parent_role(t, b, dr.parents_off, dr.parents_cnt, role_off, role_cnt, pr_scope_key, has_parents));
-                if (wave_ballot(applies) == 0) continue;
+                const u32 dsite = dr_site_ctr++;
+                const AM dbit = dsite < AM_BITS ? (AM)((AM)1 << dsite) : (AM)0;
+                const bool act = S != 0;
+                const bool hit = act && (DRM(0) & dbit) != 0;
+                const bool fresh = act && !hit;
+                bool applies = false;
+                if (fresh) applies = dr.parents_cnt == CBH_NONE ||
+                    lane_has_parent_role(t, b, dr.parents_off, dr.parents_cnt, role_off, role_cnt, pr_scope_key, has_parents);
                 int r = 1;
-                if (dr.cond != CBH_NONE) r = eval_cond<GENERIC>(c, L, dr.cond, applies);
-                if (applies) { if (r == 2) derr = true; else if (r == 1) m |= 1ull << dr.name; take_status(S); }
+                if (dr.cond != CBH_NONE && wave_ballot(applies) != 0) r = eval_cond<GENERIC>(c, L, dr.cond, applies);
+                if (fresh) {
+                  if (!(L.status & CBH_ST_UNSUPPORTED)) {
+                    DRM(0) |= dbit;
+                    if (applies && r == 1) DRM(1) |= dbit;
+                    if (applies && (L.status & CBH_ST_CEL_ERROR)) DRM(2) |= dbit;
+                  }
+                  if (applies) { if (r == 2) derr = true; else if (r == 1) m |= 1ull << dr.name; take_status(S); }
+                }
+                if (hit) {
+                  if (DRM(2) & dbit) { L.status |= CBH_ST_CEL_ERROR; if (strict) derr = true; take_status(S); }   // an error is a failed definition in strict mode
+                  else if (DRM(1) & dbit) m |= 1ull << dr.name;
+                }
               }
             }
             if (S != 0) { L.edr = m; L.edr_err = derr; edr_acc |= m; }
@@ -752,6 +775,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
       if (o.status) o.status[act_off + k] = (u8)((st_unsup & bit) ? CBH_ST_UNSUPPORTED : ((st_err & bit) ? CBH_ST_CEL_ERROR : CBH_ST_OK));
     }
   }
+#undef DRM
 #undef PS_POL
 #undef KIND_BITS
 #undef PS_SCP

@@ -22,7 +22,12 @@ table = capi.Table(lt.blob)
 batch = reqs(n).to_batch(Flattener(lt))
 print("workload", wl, "requests", n)
 db = table.upload(batch)
-for name, fl in (("full", 0), ("no_eval", 0x400), ("no_rows", 0x800), ("no_passes", 0x200)):
+VARIANTS = (("full", 0), ("no_eval", 0x400), ("no_rows", 0x800), ("no_passes", 0x200))
+if len(sys.argv) > 2:   # one variant only (for counter collection: tools/gpu_pmc_ablate.sh)
+    VARIANTS = tuple(v for v in VARIANTS if v[1] == int(sys.argv[2], 0))
+BASE = 4   # CBH_F_WANT_DERIVED_ROLES, as bench.py
+for name, fl in VARIANTS:
+    fl |= BASE
     for _ in range(5):
         table.launch(db, now_ns=1, flags=fl)
     table.synchronize()
