@@ -243,9 +243,12 @@ __device__ __forceinline__ u32 leaf_fast(const Ctx& c, const Lane& L, const Leaf
   const u32 ka = (a >> 8) & 0xF, kb = (a >> 12) & 0xF, op = a & 0xFF;   // all wave-uniform
   if (lr.ctag == CBH_NONE && (ka == 0 || kb == 0)) return 4;
   const Val cv = mk(lr.ctag, (u64)lr.clo | ((u64)lr.chi << 32));
-  // P.id is already in a register: do not fetch it again (operand kind 2 = request string field)
-  const Val x = ka == 0 ? cv : (ka == 2 && lr.a0 == CBH_RQ_PRINCIPAL_ID) ? mk(CBH_T_STRING, L.pid) : load_operand(c, L, ka, lr.a0);
-  const Val y = kb == 0 ? cv : (kb == 2 && lr.a1 == CBH_RQ_PRINCIPAL_ID) ? mk(CBH_T_STRING, L.pid) : load_operand(c, L, kb, lr.a1);
+  // the lowering tells the two cheap operand kinds apart (celc.py): 3 = a column parked in LDS,
+  // 4 = P.id, which is already in a register; the rest goes through the general loader
+  // (operands that need a memory access - kinds 1 and 2 - are left to the full evaluator)
+  if (ka == 1 || ka == 2 || kb == 1 || kb == 2) return 4;
+  const Val x = ka == 3 ? cached_column(c, L, lr.a0) : ka == 0 ? cv : mk(CBH_T_STRING, L.pid);
+  const Val y = kb == 0 ? cv : kb == 3 ? cached_column(c, L, lr.a1) : mk(CBH_T_STRING, L.pid);
   if (x.t == CBH_T_ERR || y.t == CBH_T_ERR) return 3;   // a missing attribute: every comparison of an error is that error
   if (op == OP_EQ || op == OP_NE) {
     const int e = fast_equal(x, y);

@@ -552,20 +552,26 @@ __device__ __forceinline__ int fast_compare(const Ctx& c, u32 op, Val x, Val y) 
   return -2;
 }
 
-// operand of a fused leaf instruction: 0 = constant, 1 = attribute column, 2 = request string field
+// a column of the kernel's LDS column cache (arg < n_cached)
+__device__ __forceinline__ Val cached_column(const Ctx& c, const Lane& L, u32 arg) {
+  const u32 tw = c.cc[(2 * c.n_cached + arg) * CBH_BLOCK + c.tid];
+  const u32 t = (tw >> ((((size_t)arg * c.b.n_requests + L.req) & 3u) * 8u)) & 0xFFu;
+  if (t == CBH_T_ABSENT) return mk_err();
+  return mk(t, (u64)c.cc[arg * CBH_BLOCK + c.tid] | ((u64)c.cc[(c.n_cached + arg) * CBH_BLOCK + c.tid] << 32));
+}
+
+// operand of a fused leaf instruction (celc.py _simple_operand): 0 = constant, 1 = attribute column,
+// 2 = request string field, 3 = attribute column known to sit in the column cache, 4 = principal id
 __device__ __forceinline__ Val load_operand(const Ctx& c, const Lane& L, u32 kind, u32 arg) {
+  if (kind == 3) return cached_column(c, L, arg);
   if (kind == 0) return mk(c.t.const_tag[arg], c.t.const_val[arg]);
   if (kind == 1) {
-    if (arg < c.n_cached) {   // uniform: arg comes from the bytecode
-      const u32 tw = c.cc[(2 * c.n_cached + arg) * CBH_BLOCK + c.tid];
-      const u32 t = (tw >> ((((size_t)arg * c.b.n_requests + L.req) & 3u) * 8u)) & 0xFFu;
-      if (t == CBH_T_ABSENT) return mk_err();
-      return mk(t, (u64)c.cc[arg * CBH_BLOCK + c.tid] | ((u64)c.cc[(c.n_cached + arg) * CBH_BLOCK + c.tid] << 32));
-    }
+    if (arg < c.n_cached) return cached_column(c, L, arg);   // uniform: arg comes from the bytecode
     size_t ix = (size_t)arg * c.b.n_requests + L.req;
     u32 t = c.b.col_tag[ix];
     return t == CBH_T_ABSENT ? mk_err() : mk(t, c.b.col_val[ix]);
   }
+  if (kind == 4) arg = CBH_RQ_PRINCIPAL_ID;
   return mk(CBH_T_STRING, c.b.req_u32[(size_t)arg * c.b.n_requests + L.req]);
 }
 

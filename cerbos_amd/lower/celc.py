@@ -60,6 +60,7 @@ RQ_S_P_SCOPE, RQ_S_R_SCOPE, RQ_S_P_VERSION, RQ_S_R_VERSION = 10, 11, 12, 13
 IT_ALL, IT_EXISTS, IT_EXISTS_ONE = 0, 1, 2
 
 MAX_STACK = 10
+CACHE_COLS = 16      # CBH_CACHE_COLS (cbh_vm.h): columns the decision kernel parks in LDS
 MAX_LOCALS = 4
 MAX_ITERS = 2
 
@@ -430,7 +431,9 @@ class _FuncCompiler:
     # -- fused leaves: `operand <cmp|in> operand` with operands read straight from a column, a
     #    request string field or the constant pool (the shape of almost every real condition)
     def _simple_operand(self, ast):
-        """-> (kind, arg) with kind 0 const / 1 column / 2 request string, or None."""
+        """-> (kind, arg) or None.  Kinds: 0 constant, 1 column, 2 request string field, and the two
+        the decision kernel serves without a memory access (cbh_check_wave.h leaf_fast): 3 = a column
+        of the kernel's LDS column cache (the first CACHE_COLS columns), 4 = the principal id."""
         k = ast[0]
         if k == "lit" or (k in ("list", "map") and _is_const(ast)):
             try:
@@ -441,9 +444,10 @@ class _FuncCompiler:
         if k in ("select", "index"):
             p = self._path(ast)
             if p is not None and p[0] == "col":
-                return 1, self.pb.column(p[1], p[2])
+                ci = self.pb.column(p[1], p[2])
+                return (3 if ci < CACHE_COLS else 1), ci
             if p is not None and p[0] == "req":
-                return 2, p[1]
+                return (4, 0) if p[1] == RQ_PRINCIPAL_ID else (2, p[1])
         return None
 
     def _fused_leaf(self, ast) -> bool:

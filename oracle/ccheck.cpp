@@ -168,7 +168,8 @@ struct Req {
   }
   V operand(u32 kind, u32 arg) const {
     if (kind == 0) { const u32* q = g.const_rec + 4 * (size_t)arg; return V{q[0], (u64)q[2] | ((u64)q[3] << 32)}; }
-    if (kind == 1) return column(arg);
+    if (kind == 1 || kind == 3) return column(arg);   // 3: a column (the GPU keeps the first ones in LDS)
+    if (kind == 4) arg = CBH_RQ_PRINCIPAL_ID;         // 4: P.id
     return V{CBH_T_STRING, b.req_u32[(size_t)arg * b.n_requests + r]};
   }
   // equality as CEL defines it: 1 / 0, or 4 = outside this restatement's subset
