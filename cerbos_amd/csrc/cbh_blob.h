@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define CBH_BLOB_MAGIC 0x31484243u /* "CBH1" */
-#define CBH_BLOB_VERSION 9u
+#define CBH_BLOB_VERSION 10u
 
 struct CbhBlobHeader {  // 32 bytes
   uint32_t magic;

@@ -241,6 +241,46 @@ struct __attribute__((aligned(32))) LeafRec { u32 w, a0, a1, ret, ctag, clo, chi
 __device__ __forceinline__ u32 leaf_fast(const Ctx& c, const Lane& L, const LeafRec& lr) {
   const u32 a = lr.w >> 8;
   const u32 ka = (a >> 8) & 0xF, kb = (a >> 12) & 0xF, op = a & 0xFF;   // all wave-uniform
+  // The shapes conditions usually have are classified by the lowering (celc.py leaf_class) and run
+  // as straight-line code behind ONE uniform branch; each arm answers only what it is sure of and
+  // sends the rest (mixed numeric types, orderings of mismatched types) to the full evaluator.
+  switch (lr.pad) {
+    case 1: {   // cached column ==/!= string or bool constant
+      const Val x = cached_column(c, L, lr.a0);
+      if (x.t == CBH_T_ERR) return 3;
+      const bool eq = x.t == lr.ctag && (u32)x.v == lr.clo;   // other types are plainly unequal
+      return (u32)(eq == (op == OP_EQ));
+    }
+    case 2: {   // cached column <op> double constant
+      const Val x = cached_column(c, L, lr.a0);
+      if (x.t == CBH_T_ERR) return 3;
+      if (x.t != CBH_T_DOUBLE) return (x.t == CBH_T_INT || x.t == CBH_T_UINT) ? 4u : op == OP_EQ ? 0u : op == OP_NE ? 1u : 4u;
+      const double p = as_f64(x.v), q = as_f64((u64)lr.clo | ((u64)lr.chi << 32));
+      return (op == OP_EQ) ? p == q : (op == OP_NE) ? p != q : (op == OP_LT) ? p < q : (op == OP_LE) ? p <= q
+           : (op == OP_GT) ? p > q : p >= q;   // NaN: every ordering false, != true
+    }
+    case 3: {   // cached column ==/!= cached column
+      const Val x = cached_column(c, L, lr.a0), y = cached_column(c, L, lr.a1);
+      if (x.t == CBH_T_ERR || y.t == CBH_T_ERR) return 3;
+      const int e = fast_equal(x, y);
+      return e < 0 ? 4u : (u32)(op == OP_EQ ? e : 1 - e);
+    }
+    case 4: {   // cached column ==/!= P.id (either order)
+      const Val x = cached_column(c, L, ka == 3 ? lr.a0 : lr.a1);
+      if (x.t == CBH_T_ERR) return 3;
+      const bool eq = x.t == CBH_T_STRING && (u32)x.v == L.pid;
+      return (u32)(eq == (op == OP_EQ));
+    }
+    case 5: {   // cached column in [string constants]
+      const Val x = cached_column(c, L, lr.a0);
+      if (x.t == CBH_T_ERR) return 3;
+      const u32 n = lr.clo, off = lr.chi & 0x3FFFFFFFu;   // list payload: sel:2 | off:30 | len:32
+      u32 found = 0;
+      for (u32 i = 0; i < n; ++i) found |= (u32)((u32)x.v == uload(&c.t.theap_rec[4 * (size_t)(off + i) + 2]));
+      return x.t == CBH_T_STRING ? found : 0u;   // a non-string equals no string
+    }
+    default: break;
+  }
   if (lr.ctag == CBH_NONE && (ka == 0 || kb == 0)) return 4;
   const Val cv = mk(lr.ctag, (u64)lr.clo | ((u64)lr.chi << 32));
   // the lowering tells the two cheap operand kinds apart (celc.py): 3 = a column parked in LDS,

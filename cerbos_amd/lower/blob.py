@@ -25,7 +25,7 @@ from .celc import LoweringError, Params, ProgramBuilder
 from .globs import GlobNFA, fix_glob, has_meta
 
 BLOB_MAGIC = 0x31484243
-BLOB_VERSION = 9
+BLOB_VERSION = 10
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
 ROW_F_ACTION_LIST, ROW_F_ROLE_LIST = 4, 8

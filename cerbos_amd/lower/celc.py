@@ -259,6 +259,27 @@ class ProgramBuilder:
             return T_MAP, cont_payload(HEAP_TABLE, off, len(ents))
         raise _Unsupported("non-constant container element")
 
+    def _leaf_class(self, op, ka, kb, ci):
+        """Shape of a fused leaf for the kernel's straight-line arms (cbh_check_wave.h leaf_fast);
+        0 = no special arm.  Operand kinds: 0 constant (index ci), 3 cached column, 4 principal id."""
+        eqne = op in (OP_EQ, OP_NE)
+        if ka == 3 and kb == 0:
+            tag, val = self.const_tag[ci], int(self.const_val[ci])
+            if eqne and tag in (T_STRING, T_BOOL):
+                return 1
+            if tag == T_DOUBLE and op in (OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE):
+                return 2
+            if op == OP_IN and tag == T_LIST and (val >> 62) == HEAP_TABLE:
+                off, n = (val >> 32) & 0x3FFFFFFF, val & 0xFFFFFFFF
+                if all(self.theap_tag[off + i] == T_STRING for i in range(n)):
+                    return 5
+            return 0
+        if eqne and ka == 3 and kb == 3:
+            return 3
+        if eqne and ((ka == 3 and kb == 4) or (ka == 4 and kb == 3)):
+            return 4
+        return 0
+
     # ---- programs ------------------------------------------------------------------
     def condition_program(self, cond, params: Params, allow_runtime=True):
         """Compile a condition tree; returns the entry pc (deduplicated)."""
@@ -283,9 +304,9 @@ class ProgramBuilder:
             if (ka == 0) != (kb == 0):
                 ci = words[1] if ka == 0 else words[2]
                 cv = int(self.const_val[ci]) & 0xFFFFFFFFFFFFFFFF
-                words = words + [self.const_tag[ci], cv & 0xFFFFFFFF, cv >> 32, 0]
+                words = words + [self.const_tag[ci], cv & 0xFFFFFFFF, cv >> 32, self._leaf_class(a & 0xFF, ka, kb, ci)]
             else:
-                words = words + [0xFFFFFFFF, 0, 0, 0]
+                words = words + [0xFFFFFFFF, 0, 0, self._leaf_class(a & 0xFF, ka, kb, None)]
         self.code.extend(words)
         if pc >= COND_PC_MASK:
             raise LoweringError("bytecode tape exceeds 2^30 words")
