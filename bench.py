@@ -149,6 +149,16 @@ def main():
         lat.append(time.perf_counter() - s0)
     p50_us_per_decision = float(np.median(lat)) / tuples * 1e6
 
+    # p50 of a small synchronous round trip (SURVEY.md §8(d) metric 2): the first ~50 tuples as their own
+    # one-shot batch (upload + kernels + download), the latency a single CheckResources call would see
+    small = cr.head(max(1, min(n_requests, 50 // max(1, tuples // n_requests)))).to_batch(Flattener(lt))
+    small_lat = []
+    for _ in range(60):
+        s0 = time.perf_counter()
+        table.check(small, now_ns=now, flags=FLAGS, want=())
+        small_lat.append(time.perf_counter() - s0)
+    p50_small_batch_us = float(np.median(small_lat[10:])) * 1e6
+
     res = table.download(dbatch)
     eff = res.effect
     assert (res.status != capi.ST_UNSUPPORTED).all()
@@ -217,6 +227,8 @@ def main():
                                    % (args.workload, wl[3], tuples, n_requests),
                        "parallelism": "independent request shards per GPU, policy image broadcast once"},
             "p50_us_per_decision": p50_us_per_decision,
+            "p50_small_batch_roundtrip_us": p50_small_batch_us,
+            "small_batch_tuples": int(small.n_tuples),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel) if args.workload == "C2" and n_requests == wl[2] else None,
                          "kernel": kernel, "kernel_ms": check_ms,

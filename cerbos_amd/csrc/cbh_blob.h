@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define CBH_BLOB_MAGIC 0x31484243u /* "CBH1" */
-#define CBH_BLOB_VERSION 10u
+#define CBH_BLOB_VERSION 11u
 
 struct CbhBlobHeader {  // 32 bytes
   uint32_t magic;
@@ -50,6 +50,7 @@ enum CbhSectionId {
   CBH_SEC_DRNAME_SID = 22, // u32[n_drnames]  string ids of derived role names (bit order of edr_mask)
   CBH_SEC_CONST_REC = 23,  // u32[n_consts][4]  {tag, 0, lo, hi}: the constant pool as scalar-loadable records
   CBH_SEC_THEAP_REC = 24,  // u32[theap_len][4] the constant heap, same record form
+  CBH_SEC_ROLE_CLASS = 25, // u8[K] class (0..61) of a string that is a literal rule role, 63 = any other string
 };
 
 enum CbhMeta {
@@ -116,6 +117,7 @@ enum CbhRowField {
   CBH_ROW_COUNTS = 7,   // action list length | role list length << 16 (0 = one inline reference)
   CBH_ROW_A1 = 8,       // 2nd..4th action pattern ref of a list of at most four (inline, no CBH_ROW_F_ACTION_LIST)
   CBH_ROW_R1 = 11,      // 2nd..4th role pattern ref likewise
+  CBH_ROW_ROLE_CLASSES = 14,   // u64 (2 dwords): role classes the record's role list can match (CBH_SEC_ROLE_CLASS)
   CBH_ROW_NF = 16       // record = 16 dwords, 64-byte aligned
 };
 #define CBH_ROW_F_ACTION_LIST 4u

@@ -43,7 +43,7 @@ __device__ __forceinline__ bool roleset_has(const TableDev& t, const RoleSet& rs
 // the evaluation of its conditions) and its inline lists (dead as soon as the lanes are matched).
 // One 16-dword register tuple would be spilled and reloaded as a unit around every call.
 struct __attribute__((aligned(32))) TblRow { u32 action, role, resource, flags, cond, drcond, policy, counts; };
-struct __attribute__((aligned(32))) TblRowLists { u32 a1, a2, a3, r1, r2, r3, pad0, pad1; };   // 2nd..4th action / role (cbh_blob.h)
+struct __attribute__((aligned(32))) TblRowLists { u32 a1, a2, a3, r1, r2, r3, pad0, pad1; };   // 2nd..4th action / role; pad0|pad1<<32 = role class mask (cbh_blob.h)
 struct __attribute__((aligned(16))) TblRp { u32 resource, allow_off, allow_cnt, cond; };
 struct __attribute__((aligned(16))) TblDr { u32 name, parents_off, parents_cnt, cond; };
 struct __attribute__((aligned(32))) TblSlot { u32 k0, k1, k2, k3, v0, v1, v2, v3; };
@@ -559,6 +559,22 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
             for (u32 k = 0; k < rs.par_cnt; ++k) rs.gbits |= t.gbits[(size_t)DIM_ROLE * t.K + t.pool[rs.par_off + k]];
           }
         }
+        // Role classes this wave is walking now (cbh_blob.h CBH_SEC_ROLE_CLASS): a rule record whose
+        // class mask misses all of them cannot match any lane and is skipped on the scalar unit.
+        // Parent roles widen a lane's role set beyond its own class: no skipping then.
+        u64 wave_classes = ~0ull;
+        if (is_res && !has_parents) {
+          wave_classes = 0;
+          const u32 cls = (Am != 0 && rs.role < t.K) ? (u32)t.role_class[rs.role] : 63u;
+          bool pendc = Am != 0;
+          for (;;) {   // OR over the (few) distinct classes in the wave
+            const u64 remc = wave_ballot(pendc);
+            if (remc == 0) break;
+            const u32 g_cls = wave_readlane(cls, first_lane(remc));
+            wave_classes |= 1ull << g_cls;
+            pendc = pendc && cls != g_cls;
+          }
+        }
         AM has_allow = 0;
         AM S = Am;   // actions still walking the scope chain for this role
         u32 site_ctr = 0, dr_site_ctr = 0;
@@ -686,6 +702,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
               const TblRow rw = uload_rec<TblRow>(t.rows, 2 * row);            // both halves are issued together:
               const TblRowLists rl = uload_rec<TblRowLists>(t.rows, 2 * row + 1);   // no dependent load for short lists
               const u32 site = site_ctr++;   // position of the record in this group's walk: the same for every role
+              if ((((u64)rl.pad0 | ((u64)rl.pad1 << 32)) & wave_classes) == 0) continue;   // no lane's role can match
               const u32 e = rw.flags & 3u;
               // a record = roles x actions of one rule (cbh_blob.h): the lists are wave-uniform
               const u32 n_act = rw.counts & 0xFFFFu, n_role = rw.counts >> 16;   // 0 = a single inline reference

@@ -25,7 +25,7 @@ from .celc import LoweringError, Params, ProgramBuilder
 from .globs import GlobNFA, fix_glob, has_meta
 
 BLOB_MAGIC = 0x31484243
-BLOB_VERSION = 10
+BLOB_VERSION = 11
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
 ROW_F_ACTION_LIST, ROW_F_ROLE_LIST = 4, 8
@@ -33,7 +33,7 @@ ROW_F_ACTION_LIST, ROW_F_ROLE_LIST = 4, 8
 (SEC_META, SEC_STR_OFF, SEC_STR_BYTES, SEC_SCOPE_PARENT, SEC_SCOPE_FLAGS, SEC_SCOPE_SID, SEC_HASH,
  SEC_ROWS, SEC_RPROWS, SEC_U32POOL, SEC_DR, SEC_CODE, SEC_CONST_TAG, SEC_CONST_VAL, SEC_THEAP_TAG,
  SEC_THEAP_VAL, SEC_GBITS, SEC_NFA_ACTION, SEC_NFA_ROLE, SEC_NFA_KIND, SEC_POLICY_SID,
- SEC_DRNAME_SID, SEC_CONST_REC, SEC_THEAP_REC) = range(1, 25)
+ SEC_DRNAME_SID, SEC_CONST_REC, SEC_THEAP_REC, SEC_ROLE_CLASS) = range(1, 26)
 
 (M_NSTRINGS, M_NCOLUMNS, M_NSCOPES, M_HASH_MASK, M_NROWS, M_NRPROWS, M_NDR, M_NPOLICIES, M_NCONSTS,
  M_CODE_LEN, M_FLAGS, M_MAX_STACK, M_NDRNAMES, M_NFA_WORDS_ACTION, M_NFA_WORDS_ROLE,
@@ -194,7 +194,8 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
                 prin_buckets.setdefault((ver, scope, r["principal"]), []).append(r)
 
     pool = []
-    row_cols = [[] for _ in range(14)]
+    row_cols = [[] for _ in range(16)]
+    row_roles = []   # per device row: its role strings (None for principal-policy rows)
     rp_cols = [[] for _ in range(4)]
     dr_cols = [[] for _ in range(4)]
     entries = []  # (k0,k1,k2,k3, v0,v1,v2,v3)
@@ -269,6 +270,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
                     for i in range(3):
                         row_cols[8 + i].append(a_more[i])
                         row_cols[11 + i].append(r_more[i])
+                    row_roles.append(None if principal_policy else rl)
                     n += 1
         return n
 
@@ -350,6 +352,28 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         if lt.nfas[d].patterns:
             for i, s in enumerate(lt.strings):
                 gbits[d, i] = lt.nfas[d].match_bits(s.encode("utf-8"))
+
+    # ---- role classes: every literal role of a rule gets a small class number, every rule record the
+    # mask of the classes its role list can match.  A wave ORs the classes of the roles it is walking
+    # and skips, on the scalar unit, the records none of them can match (cbh_check_wave.h).
+    # Class 63 = "any other string"; a glob role or a role beyond 62 classes matches everything.
+    role_class_of = {}
+    for rl in row_roles:
+        for role in rl or ():
+            if role and "*" not in role and role not in role_class_of and len(role_class_of) < 62:
+                role_class_of[role] = len(role_class_of)
+    role_class = np.full(K, 63, dtype=np.uint8)
+    for role, cls in role_class_of.items():
+        role_class[lt.string_ids[role]] = cls
+    for rl in row_roles:
+        mask = 0
+        for role in rl or [None]:
+            if not role or "*" in role:
+                mask = 0xFFFFFFFFFFFFFFFF
+            else:
+                mask |= 1 << role_class_of.get(role, 63)
+        row_cols[14].append(mask & 0xFFFFFFFF)
+        row_cols[15].append(mask >> 32)
 
     # ---- directory hash table
     nslots = 16
@@ -448,6 +472,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         # s_load_dwordx4 at a wave-uniform index (fused leaves read their constant operands this way)
         (SEC_CONST_REC, len(pb.const_tag), val_records(pb.const_tag, pb.const_val)),
         (SEC_THEAP_REC, len(pb.theap_tag), val_records(pb.theap_tag, pb.theap_val)),
+        (SEC_ROLE_CLASS, K, role_class.tobytes()),
     ]
     lt.blob = _pack(sections)
     lt.stats = {
