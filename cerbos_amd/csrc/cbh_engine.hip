@@ -51,6 +51,8 @@ struct cbh_table {
   uint64_t next_slot = 0, launches = 0;
   double check_ms_sum = 0, resolve_ms_sum = 0; uint64_t timed = 0;
   std::mutex mu;
+  std::mutex pool_mu;
+  std::vector<std::pair<void*, size_t>> pool_free;   // idle device blocks of released batches
 };
 
 struct cbh_device_batch {
@@ -61,7 +63,7 @@ struct cbh_device_batch {
   KernelArgs last_args;           // what d_args currently holds
   bool have_args = false;
   u32 max_actions = 0;            // largest CBH_RQ_ACT_CNT of the batch: selects the action-mask width
-  std::vector<void*> allocs;
+  std::vector<std::pair<void*, size_t>> allocs;   // (block, capacity) taken from the table's pool
 };
 
 static int g_device = 0;
@@ -128,6 +130,7 @@ extern "C" void cbh_table_release(cbh_table* t) {
   if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
   for (auto& sl : t->ring) for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
   if (t->image && t->owns_image) (void)hipFree(t->image);
+  for (auto& a : t->pool_free) (void)hipFree(a.first);
   delete t;
 }
 extern "C" uint32_t cbh_table_num_strings(const cbh_table* t) { return t ? t->meta[CBH_M_NSTRINGS] : 0; }
@@ -135,10 +138,38 @@ extern "C" uint32_t cbh_table_num_columns(const cbh_table* t) { return t ? t->me
 extern "C" uint64_t cbh_table_device_bytes(const cbh_table* t) { return t ? t->image_len : 0; }
 extern "C" void* cbh_table_device_ptr(const cbh_table* t) { return t ? t->image : nullptr; }
 
+// Device buffers of batches come from a per-table pool of power-of-two blocks: a small synchronous
+// CheckResources round trip must not pay ~17 hipMalloc / hipFree pairs (each hipFree also
+// synchronises the device).  Blocks go back to the pool on cbh_batch_release and to the driver on
+// cbh_table_release.
+static int pool_alloc(cbh_device_batch* b, size_t bytes, void** out) {
+  size_t cap = 256;
+  while (cap < bytes) cap <<= 1;
+  cbh_table* t = b->table;
+  {
+    std::lock_guard<std::mutex> lk(t->pool_mu);
+    for (size_t i = 0; i < t->pool_free.size(); ++i)
+      if (t->pool_free[i].second == cap) {
+        *out = t->pool_free[i].first;
+        t->pool_free[i] = t->pool_free.back(); t->pool_free.pop_back();
+        b->allocs.push_back({*out, cap});
+        return 0;
+      }
+  }
+  HIPCHK(hipMalloc(out, cap));
+  b->allocs.push_back({*out, cap});
+  return 0;
+}
+
 extern "C" void cbh_batch_release(cbh_device_batch* b) {
   if (!b) return;
-  if (b->table) { (void)hipSetDevice(b->table->device); (void)hipStreamSynchronize(b->table->stream); }
-  for (void* p : b->allocs) (void)hipFree(p);
+  if (b->table) {
+    (void)hipSetDevice(b->table->device); (void)hipStreamSynchronize(b->table->stream);
+    std::lock_guard<std::mutex> lk(b->table->pool_mu);
+    for (auto& a : b->allocs) b->table->pool_free.push_back(a);
+  } else {
+    for (auto& a : b->allocs) (void)hipFree(a.first);
+  }
   delete b;
 }
 
@@ -147,8 +178,7 @@ static int up(cbh_device_batch* b, const T*& dst, const T* src, size_t n, hipStr
   dst = nullptr;
   size_t bytes = (n ? n : 1) * sizeof(T);
   void* p = nullptr;
-  HIPCHK(hipMalloc(&p, bytes));
-  b->allocs.push_back(p);
+  if (pool_alloc(b, bytes, &p) != 0) return -1;
   if (n) {
     if (!src) return fail("cbh_batch: a required array is NULL");
     HIPCHK(hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
@@ -159,8 +189,7 @@ static int up(cbh_device_batch* b, const T*& dst, const T* src, size_t n, hipStr
 template <typename T>
 static int dalloc(cbh_device_batch* b, T*& dst, size_t n) {
   void* p = nullptr;
-  HIPCHK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
-  b->allocs.push_back(p);
+  if (pool_alloc(b, (n ? n : 1) * sizeof(T), &p) != 0) return -1;
   dst = static_cast<T*>(p);
   return 0;
 }
