@@ -16,6 +16,7 @@
 //
 // Host side: the C ABI of include/cerbos_hip.h.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -260,8 +261,12 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   std::lock_guard<std::mutex> lk(t->mu);
   HIPCHK(hipSetDevice(t->device));
   hipStream_t s = t->stream;
-  // Every fourth launch is bracketed by events (and the first few, so that a short run has a figure):
-  // event records are packets of their own between the kernels of back-to-back launches.
+  // Kernel durations come from the dispatches' own begin / end timestamps (hipExtLaunchKernelGGL
+  // with start / stop events: what rocprofv3's kernel trace reads too), not from event-record
+  // packets placed around them, which would sit between back-to-back launches and add their own
+  // latency to the figure.
+  // Every fourth launch is timed (and the first few, so that a short run has a figure): a
+  // timestamped dispatch costs the queue a little more than a plain one.
   const uint64_t launch_no = t->launches++;
   const bool timed = launch_no < 4 || (launch_no & 3) == 0;
   cbh_table::Slot scratch_slot;
@@ -284,24 +289,23 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   const u32 maxw = std::max(std::max(t->dev.nfa_words[0], t->dev.nfa_words[1]), t->dev.nfa_words[2]);
   sl.resolved = d.n_strings && maxw;
   if (sl.resolved) {
-    if (timed) HIPCHK(hipEventRecord(sl.ev[0], s));
     const u32 grid = (d.n_strings + CBH_BLOCK - 1) / CBH_BLOCK;
     const size_t lds = (size_t)(2 + 512) * maxw * sizeof(u64);
-    hipLaunchKernelGGL(cbh_resolve_globs_kernel, dim3(grid), dim3(CBH_BLOCK), lds, s, t->dev, d);
-    if (timed) HIPCHK(hipEventRecord(sl.ev[1], s));
+    if (timed) hipExtLaunchKernelGGL(cbh_resolve_globs_kernel, dim3(grid), dim3(CBH_BLOCK), lds, s, sl.ev[0], sl.ev[1], 0, t->dev, d);
+    else hipLaunchKernelGGL(cbh_resolve_globs_kernel, dim3(grid), dim3(CBH_BLOCK), lds, s, t->dev, d);
   }
-  if (timed) HIPCHK(hipEventRecord(sl.ev[2], s));
+  sl.pending = false;
   if (d.n_requests) {
     const u32 grid = (d.n_requests + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
     const u32 ncc = d.n_columns < CBH_CACHE_COLS ? d.n_columns : CBH_CACHE_COLS;
     const size_t dyn_lds = (size_t)ncc * CBH_BLOCK * 12;   // column cache: value low / high / tag dword per lane
     const bool generic = (t->dev.flags & CBH_MF_HAS_GENERIC_PROGRAMS) != 0, a32 = b->max_actions <= 32;
     auto kernel = generic ? (a32 ? cbh_check_kernel_a32 : cbh_check_kernel) : (a32 ? cbh_check_kernel_leaf_a32 : cbh_check_kernel_leaf);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), dyn_lds, s, b->last_args, (const KernelArgs*)b->d_args);
+    if (timed) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), dyn_lds, s, sl.ev[2], sl.ev[3], 0, b->last_args, (const KernelArgs*)b->d_args);
+    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), dyn_lds, s, b->last_args, (const KernelArgs*)b->d_args);
+    sl.pending = timed;
   }
-  if (timed) HIPCHK(hipEventRecord(sl.ev[3], s));
   HIPCHK(hipGetLastError());
-  sl.pending = timed;
   return 0;
 }
 
