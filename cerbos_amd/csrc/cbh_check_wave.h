@@ -862,6 +862,16 @@ __device__ __forceinline__ void generic_kernel_body(const KernelArgs& a, const K
   __shared__ u32 it_state[CBH_MAX_ITERS * CBH_BLOCK];
   __shared__ u8 s_tag[CBH_STACK_DEPTH * CBH_BLOCK];
   __shared__ u8 l_tag[CBH_MAX_LOCALS * CBH_BLOCK];
+  // The interpreter runs every lane of the wave through a program, lanes that are not evaluating it
+  // included, and those read whatever their operand slots hold.  LDS is not cleared between
+  // workgroups: start every slot of this lane as an error value / empty container, so that a stale
+  // "string id" or "list offset" left by another kernel can never be dereferenced.
+  {
+    const u32 tid = threadIdx.x;
+    for (u32 k = 0; k < CBH_STACK_DEPTH; ++k) { s_tag[k * CBH_BLOCK + tid] = CBH_T_ERR; s_val[k * CBH_BLOCK + tid] = 0; }
+    for (u32 k = 0; k < CBH_MAX_LOCALS; ++k) { l_tag[k * CBH_BLOCK + tid] = CBH_T_ERR; l_val[k * CBH_BLOCK + tid] = 0; }
+    for (u32 k = 0; k < CBH_MAX_ITERS; ++k) { it_cont[k * CBH_BLOCK + tid] = 0; it_idx[k * CBH_BLOCK + tid] = 0; it_state[k * CBH_BLOCK + tid] = 0; }
+  }
   const u32 ncc = cached_columns(&a);
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x,
         (CBH_L u64*)s_val, (CBH_L u8*)s_tag, (CBH_L u64*)l_val, (CBH_L u8*)l_tag,

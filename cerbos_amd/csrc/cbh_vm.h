@@ -134,6 +134,7 @@ __device__ __forceinline__ void str_span(const Ctx& c, u32 sid, gbytes& p, u32& 
     p = c.t.str_bytes + o;
   } else {
     u32 i = sid - c.t.K;
+    if (i >= c.b.n_strings) { n = 0; p = c.b.str_bytes; return; }   // never index past the batch's strings
     u32 o = c.b.str_off[i];
     n = c.b.str_off[i + 1] - o;
     p = c.b.str_bytes + o;

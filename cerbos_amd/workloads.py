@@ -205,3 +205,186 @@ def c3_requests(n_requests=1_000_000, seed=3, actions_per_request=4, n_kinds=10)
                 "public": Attr("bool", rng.random(n) < 0.3),
                 "status": Attr("str", rng.integers(0, 4, n), None, C2_STATUS)},
     )
+
+
+# ------------------------------------------------------------------------------------- C4
+C4_SCOPES = ["", "acme", "acme.hr"]
+C4_ROLES = ["r%02d" % i for i in range(24)]
+C4_ACTIONS = ["act%02d" % i for i in range(16)]
+C4_REGIONS = ["eu", "us", "apac", "latam"]
+
+
+def c4_condition_pool():
+    """64 condition shapes over nine attributes: single comparisons and all/any/none trees of them."""
+    leaves = (["R.attr.amount > %d" % v for v in (100, 250, 500, 750, 900)]
+              + ["R.attr.amount <= %d" % v for v in (200, 400, 600, 800)]
+              + ["P.attr.level >= %d" % v for v in range(1, 9)]
+              + ['R.attr.region == "%s"' % r for r in C4_REGIONS]
+              + ['R.attr.region != "%s"' % r for r in C4_REGIONS]
+              + ["R.attr.owner == P.id", "R.attr.owner != P.id", "R.attr.public == true", "R.attr.public != true",
+                 "P.attr.department == R.attr.department", "P.attr.department != R.attr.department",
+                 "R.attr.team == P.attr.team", 'R.attr.status in ["OPEN", "PENDING"]',
+                 'R.attr.status in ["CLOSED"]', 'R.attr.region in ["eu", "us"]'])
+    pool = [_expr(e) for e in leaves]
+    rng = np.random.default_rng(4040)
+    kinds = ["all", "any", "none"]
+    while len(pool) < 64:
+        k = kinds[len(pool) % 3]
+        picks = rng.choice(len(leaves), size=int(rng.integers(2, 4)), replace=False)
+        pool.append({"match": {k: {"of": [{"expr": leaves[int(i)]} for i in picks]}}})
+    return pool[:64]
+
+
+def c4_policies(seed=4, n_policies=1000, rules_per_policy=50):
+    """`n_policies` resource policies = kinds k0000.. x the scopes root/acme/acme.hr (three policies per
+    kind), `rules_per_policy` rules each (1000 x 50 = 50k rules), 40 % with a condition of the pool."""
+    rng = np.random.default_rng(seed)
+    pool = c4_condition_pool()
+    docs = []
+    for p in range(n_policies):
+        kind, scope = "k%04d" % (p // 3), C4_SCOPES[p % 3]
+        rules = []
+        for _ in range(rules_per_policy):
+            rule = {"actions": [str(a) for a in rng.choice(C4_ACTIONS, size=int(rng.integers(1, 4)), replace=False)],
+                    "roles": [str(r) for r in rng.choice(C4_ROLES, size=int(rng.integers(1, 4)), replace=False)],
+                    "effect": "EFFECT_DENY" if rng.random() < 0.15 else "EFFECT_ALLOW"}
+            if rng.random() < 0.40:
+                rule["condition"] = pool[int(rng.integers(0, len(pool)))]
+            rules.append(rule)
+        rp = {"resource": kind, "version": "default", "rules": rules}
+        if scope:
+            rp["scope"] = scope
+            if rng.random() < 0.25:
+                rp["scopePermissions"] = "SCOPE_PERMISSIONS_REQUIRE_PARENTAL_CONSENT_FOR_ALLOWS"
+        docs.append({"apiVersion": API, "resourcePolicy": rp})
+    return docs
+
+
+def c4_requests(n_requests=500_000, seed=4, actions_per_request=4, n_policies=1000):
+    """Zipf(1.1) over the kinds; 2M tuples per GPU at the default size (16M over 8 GPUs)."""
+    rng = np.random.default_rng(seed + 2000)
+    n = n_requests
+    n_kinds = (n_policies + 2) // 3
+    kidx = np.minimum(rng.zipf(1.1, n) - 1, n_kinds * 4) % (n_kinds + 1)      # the last index = an unknown kind
+    n_ids = 4000
+    ids_v = ["p%04d" % i for i in range(n_ids)]
+    pid = rng.integers(0, n_ids, n)
+    cnt = rng.integers(1, 4, n)
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    start = rng.integers(0, len(C4_ROLES), n)
+    flat = (np.repeat(start, cnt) + (np.arange(off[-1]) - np.repeat(off[:-1], cnt)) * 7) % len(C4_ROLES)
+    scopes_v = C4_SCOPES + ["acme.hr.uk", "other"]
+    perm = np.argsort(rng.random((n, len(C4_ACTIONS))), axis=1)[:, :actions_per_request]
+    teams = ["t%d" % i for i in range(16)]
+    return ColumnarRequests(
+        n,
+        principal_id=Vocab(ids_v, pid),
+        roles=Ragged(C4_ROLES, off, flat),
+        resource_kind=Vocab(["k%04d" % k for k in range(n_kinds)] + ["unknown_kind"], kidx),
+        resource_id=Vocab(["r%07d" % i for i in range(n)], np.arange(n)),
+        actions=Ragged(C4_ACTIONS, np.arange(n + 1) * actions_per_request, perm.reshape(-1)),
+        resource_scope=Vocab(scopes_v, rng.choice(len(scopes_v), n, p=[0.25, 0.25, 0.3, 0.15, 0.05])),
+        p_attr={"department": Attr("str", rng.integers(0, 8, n), None, C2_DEPTS),
+                "team": Attr("str", rng.integers(0, 16, n), None, teams),
+                "level": Attr("num", rng.integers(1, 9, n).astype(np.float64), rng.random(n) > 0.01)},
+        r_attr={"owner": Attr("str", np.where(rng.random(n) < 0.15, pid, rng.integers(0, n_ids, n)), None, ids_v),
+                "team": Attr("str", rng.integers(0, 16, n), None, teams),
+                "department": Attr("str", rng.integers(0, 8, n), None, C2_DEPTS),
+                "amount": Attr("num", rng.random(n) * 1000.0, rng.random(n) > 0.01),
+                "public": Attr("bool", rng.random(n) < 0.3),
+                "region": Attr("str", rng.integers(0, 4, n), rng.random(n) > 0.01, C4_REGIONS),
+                "status": Attr("str", rng.integers(0, 4, n), None, C2_STATUS)},
+    )
+
+
+# ------------------------------------------------------------------------------------- C5
+C5_ACTIONS = ["view", "view:public", "view:internal", "edit", "edit:public", "delete", "share:public", "approve"]
+
+
+def c5_policies(seed=5, n_principal_policies=100):
+    """C3 plus: principal-policy overrides for 100 principals, action globs (``view:*``, ``*:public``,
+    ``*``), role policies with allow-lists, and conditions over nested attributes (map / list values,
+    comprehension macros) that need the operand-stack interpreter."""
+    rng = np.random.default_rng(seed)
+    docs = c3_policies(seed=3)
+    for k in range(10):   # glob rules + nested conditions on every kind, root scope
+        docs.append({"apiVersion": API, "resourcePolicy": {
+            "resource": "kind%02d" % k, "version": "v5", "rules": [
+                {"actions": ["view:*"], "roles": ["role00", "role01", "role02"], "effect": "EFFECT_ALLOW",
+                 "condition": _expr("R.attr.tags.region in P.attr.tags.regions")},
+                {"actions": ["*:public"], "roles": ["*"], "effect": "EFFECT_ALLOW"},
+                {"actions": ["edit", "edit:public"], "roles": ["role03", "role04"], "effect": "EFFECT_ALLOW",
+                 "condition": _expr('P.attr.teams.exists(t, t.startsWith("comm"))')},
+                {"actions": ["*"], "roles": ["role05"], "effect": "EFFECT_ALLOW",
+                 "condition": _expr("R.attr.acl[P.id].level >= 2")},
+                {"actions": ["delete"], "roles": ["*"], "effect": "EFFECT_DENY",
+                 "condition": _expr('"legal-hold" in R.attr.labels')},
+            ]}})
+    for i in range(n_principal_policies):   # principal overrides
+        rules = [{"resource": "kind%02d" % int(rng.integers(0, 10)),
+                  "actions": [{"action": str(rng.choice(["view", "edit", "delete", "view:*", "*"])),
+                               "effect": "EFFECT_DENY" if rng.random() < 0.5 else "EFFECT_ALLOW"}
+                              for _ in range(int(rng.integers(1, 3)))]}
+                 for _ in range(int(rng.integers(1, 3)))]
+        for r in rules:   # one action entry per action string
+            seen = {}
+            for a in r["actions"]:
+                seen.setdefault(a["action"], a)
+            r["actions"] = list(seen.values())
+        merged = {}
+        for r in rules:
+            merged.setdefault(r["resource"], r)
+        docs.append({"apiVersion": API, "principalPolicy": {"principal": "p%04d" % (i * 20), "version": "v5",
+                                                             "rules": list(merged.values())}})
+    for role, parents in (("contractor", ["role00"]), ("auditor", [])):   # role policies (allow-lists)
+        rp = {"role": role, "rules": [
+            {"resource": "kind00", "allowActions": ["view", "view:*"]},
+            {"resource": "kind01", "allowActions": ["view:public", "share:public"],
+             "condition": _expr("R.attr.public == true")},
+            {"resource": "*", "allowActions": ["approve"]}]}
+        if parents:
+            rp["parentRoles"] = parents
+        docs.append({"apiVersion": API, "rolePolicy": rp})
+    return docs
+
+
+def c5_requests(n_requests=250_000, seed=5, actions_per_request=4):
+    """Mixed batch: half of the requests ask for the v5 policies (globs + nested conditions), 5 % of the
+    principals have a principal policy, 10 % hold a role-policy role; 1M tuples per GPU by default."""
+    rng = np.random.default_rng(seed + 3000)
+    n = n_requests
+    base = c3_requests(n, seed=seed, actions_per_request=actions_per_request)
+    n_ids = 2000
+    ids_v = ["p%04d" % i for i in range(n_ids)]
+    pid = rng.integers(0, n_ids, n)
+    roles_v = C3_ROLES + ["contractor", "auditor"]
+    cnt = rng.integers(1, 4, n)
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    start = rng.integers(0, len(C3_ROLES), n)
+    flat = (np.repeat(start, cnt) + (np.arange(off[-1]) - np.repeat(off[:-1], cnt)) * 5) % len(C3_ROLES)
+    special = rng.random(n) < 0.10
+    flat[off[:-1][special]] = len(C3_ROLES) + rng.integers(0, 2, int(special.sum()))
+    perm = np.argsort(rng.random((n, len(C5_ACTIONS))), axis=1)[:, :actions_per_request]
+    regions = ["eu", "us", "apac"]
+    tag_v = [{"region": r} for r in regions] + [{"zone": "z1"}]
+    ptag_v = [{"regions": ["eu"]}, {"regions": ["eu", "us"]}, {"regions": []}, {"regions": ["apac", "us", "eu"]}]
+    teams_v = [["commerce", "ops"], ["core"], [], ["community", "design", "comms"]]
+    labels_v = [[], ["legal-hold"], ["pii", "legal-hold"], ["pii"]]
+    acl_ids = ["p%04d" % i for i in range(0, n_ids, 40)]
+    acl_v = [{}] + [{a: {"level": lvl}} for a in acl_ids[:25] for lvl in (1, 3)]
+    return ColumnarRequests(
+        n,
+        principal_id=Vocab(ids_v, pid),
+        roles=Ragged(roles_v, off, flat),
+        resource_kind=base.resource_kind,
+        resource_id=base.resource_id,
+        actions=Ragged(C5_ACTIONS, np.arange(n + 1) * actions_per_request, perm.reshape(-1)),
+        resource_scope=base.resource_scope,
+        principal_version=Vocab(["default", "v5"], (rng.random(n) < 0.5).astype(np.int64)),
+        resource_version=Vocab(["default", "v5"], (rng.random(n) < 0.5).astype(np.int64)),
+        p_attr=dict(base.p_attr, tags=Attr("json", rng.integers(0, len(ptag_v), n), rng.random(n) > 0.02, ptag_v),
+                    teams=Attr("json", rng.integers(0, len(teams_v), n), None, teams_v)),
+        r_attr=dict(base.r_attr, tags=Attr("json", rng.integers(0, len(tag_v), n), None, tag_v),
+                    labels=Attr("json", rng.integers(0, len(labels_v), n), rng.random(n) > 0.02, labels_v),
+                    acl=Attr("json", rng.integers(0, len(acl_v), n), None, acl_v)),
+    )

@@ -100,15 +100,17 @@ def test_resident_path_and_kernel_timer():
 
 
 @pytest.mark.parametrize("name,n_requests,mode", [("C2", 250_000, "default"), ("C2", 250_000, "strict"),
-                                                  ("C3", 1_000_000, "default"), ("C3", 250_000, "lenient")])
+                                                  ("C3", 1_000_000, "default"), ("C3", 250_000, "lenient"),
+                                                  ("C4", 500_000, "default"), ("C4", 100_000, "strict")])
 def test_full_size_bit_exact_against_cpp_oracle(name, n_requests, mode):
-    """Every tuple of the full-size configurations (C2: 1M, C3: 4M tuples): effect, policy, scope and
-    derived-role mask identical to oracle/ccheck.cpp, and the same requests report CEL errors.
+    """Every tuple of the full-size configurations (C2: 1M, C3: 4M, C4: one GPU's 2M tuples against the
+    1000-policy / 50k-rule table): effect, policy, scope and derived-role mask identical to
+    oracle/ccheck.cpp, and the same requests report CEL errors.
     (ccheck is pinned against oracle/check.py in tests/test_ccheck.py.)"""
     import os
     from oracle import ccheck
-    full = {"C2": workloads.c2_requests, "C3": workloads.c3_requests}[name]
-    pol_fn = CONFIGS[name][0]
+    full = {"C2": workloads.c2_requests, "C3": workloads.c3_requests, "C4": workloads.c4_requests}[name]
+    pol_fn = {"C4": workloads.c4_policies}.get(name, CONFIGS[name][0])
     rt, lt, table = _table(pol_fn)
     batch = full(n_requests).to_batch(Flattener(lt))
     flags = capi.F_WANT_DERIVED_ROLES
@@ -125,4 +127,28 @@ def test_full_size_bit_exact_against_cpp_oracle(name, n_requests, mode):
     ge = (got.status == capi.ST_CEL_ERROR).reshape(-1, 4).any(axis=1)
     we = (want.status == capi.ST_CEL_ERROR).reshape(-1, 4).any(axis=1)
     assert np.array_equal(ge, we)
+    table.close()
+
+
+def test_c5_full_batch_properties():
+    """C5 (principal overrides, action globs, role policies, nested-attribute CEL on the operand-stack
+    interpreter) at one GPU's share, 1M tuples: the first 1500 requests against oracle/check.py (the
+    C++ restatement does not cover role policies), determinism, and request-order invariance."""
+    from cerbos_amd.flatten import permute_requests
+    rt, lt, table = _table(workloads.c5_policies)
+    assert lt.stats["generic_programs"] and lt.stats["role_policy_rows"] > 0 and sum(lt.stats["globs"]) > 0
+    fl = Flattener(lt)
+    cr = workloads.c5_requests(250_000)
+    batch = cr.to_batch(fl)
+    assert batch.n_tuples == 1_000_000
+    res = table.check(batch, now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES)
+    assert (res.status != capi.ST_UNSUPPORTED).all()
+    eff = res.effect.copy()
+    want = oracle_effects(rt, cr.to_inputs(0, 1500))
+    assert np.array_equal(eff[:want.size], want)
+    assert 0.05 < (eff == capi.EFFECT_ALLOW).mean() < 0.95
+    assert np.array_equal(table.check(batch, now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES).effect, eff)
+    b2 = cr.to_batch(fl)
+    permute_requests(b2, np.random.default_rng(1).permutation(b2.n_requests))
+    assert np.array_equal(table.check(b2, now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES).effect, eff)
     table.close()

@@ -19,6 +19,9 @@ CONFIGS = {
     "C1": (lambda: workloads.c1_policies(2), lambda n: workloads.c1_requests(n, n_sets=2)),
     "C2": (workloads.c2_policies, lambda n: workloads.c2_requests(n)),
     "C3": (workloads.c3_policies, lambda n: workloads.c3_requests(n)),
+    # C4 at 1/10 of its table size here (the GPU tier runs the 1000-policy table); C5 whole
+    "C4": (lambda: workloads.c4_policies(n_policies=99), lambda n: workloads.c4_requests(n, n_policies=99)),
+    "C5": (workloads.c5_policies, lambda n: workloads.c5_requests(n)),
 }
 
 
