@@ -153,12 +153,6 @@ def main():
         table.synchronize()
         lat.append(time.perf_counter() - s0)
     p50_us_per_decision = float(np.median(lat)) / tuples * 1e6
-    # the same kernel with nothing else in flight (what a serialising profiler such as rocprofv3
-    # --kernel-trace sees); in the timed region consecutive launches overlap head and tail
-    for _ in range(40):
-        table.launch(dbatch, now_ns=now, flags=FLAGS)
-        table.synchronize()
-    check_ms_isolated, _ = table.kernel_time_ms()
 
     # p50 of a small synchronous round trip (SURVEY.md §8(d) metric 2): the first ~50 tuples as their own
     # one-shot batch (upload + kernels + download), the latency a single CheckResources call would see
@@ -252,7 +246,7 @@ def main():
             "small_batch_tuples": int(small.n_tuples),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(kernel) if args.workload == "C2" and n_requests == wl[2] else None,
-                         "kernel": kernel, "kernel_ms": check_ms, "kernel_ms_isolated": check_ms_isolated,
+                         "kernel": kernel, "kernel_ms": check_ms,
                          "alg_bytes_per_decision": alg},
             "cpu_baseline": cpu,
             "resolve_kernel_ms": resolve_ms,

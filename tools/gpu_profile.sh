@@ -36,7 +36,7 @@ if vals:
     write_kb = sum(vals['WRITE_SIZE']) / len(vals['WRITE_SIZE'])
     out = {"kernel": kernel, "fetch_kb_per_launch": fetch_kb, "write_kb_per_launch": write_kb,
            "bytes_per_launch": (fetch_kb + write_kb) * 1024.0, "launches": len(vals['FETCH_SIZE']),
-           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KB), separate passes over `bench.py --steps 20 --warmup 3`; "
+           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KB), separate passes over `bench.py --steps 100 --warmup 10`; "
                    "unscaled: the kernel reads with dword / 8-byte loads, not the 16 B/lane streaming reads the "
                    "MI355X guide's x2 correction was calibrated on (see DESIGN.md, Measurement)"}
     json.dump(out, open('gpurun_out/pmc_traffic.json', 'w'), indent=1)
