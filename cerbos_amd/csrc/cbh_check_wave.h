@@ -354,6 +354,9 @@ __device__ __forceinline__ void load_args(KernelArgs& dst, const KernelArgs* src
 #endif
 }
 
+struct CbhPassPrincipal { static constexpr bool value = false; };   // tags of the two instantiations of the
+struct CbhPassResource { static constexpr bool value = true; };     // policy pass (check_body below)
+
 template <bool GENERIC, typename AM>   // AM: per-request action mask, u32 when no request of the batch carries more than 32 actions
 __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   const TableDev& t = ka_regs.t;
@@ -519,8 +522,11 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
 #else
   const u32 n_pass = 2;
 #endif
-  for (u32 pt = 0; pt < n_pass; ++pt) {                // 0 = principal policies, 1 = resource policies (check.go:195)
-    const bool is_res = pt == 1;
+  // The two passes (principal policies, then resource policies: check.go:195) are two instantiations
+  // of one body: which pass it is is a compile-time fact, so the principal pass carries no derived-role
+  // / role-policy / role-class code and the resource pass none of the principal-only branches.
+  auto policy_pass = [&](auto is_res_t) {
+    constexpr bool is_res = decltype(is_res_t)::value;
     const u32 first = is_res ? r_first : p_first;
     const u32 flagbit = is_res ? FLAG_RES : FLAG_PRIN;
     const bool exists = is_res ? r_exists : p_exists;
@@ -789,7 +795,8 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
     }
     // a definitive principal-policy result ends the action (check.go:445-448)
     todo &= ~(eff_allow | eff_deny);
-  }
+  };
+  if (n_pass) { policy_pass(CbhPassPrincipal{}); policy_pass(CbhPassResource{}); }
 
 #ifdef CBH_PROFILE_CYCLES
   if ((flags & CBH_F_DEBUG_CYCLES) && want_ps && act_cnt >= 3) {
