@@ -357,7 +357,10 @@ __device__ __forceinline__ void load_args(KernelArgs& dst, const KernelArgs* src
 struct CbhPassPrincipal { static constexpr bool value = false; };   // tags of the two instantiations of the
 struct CbhPassResource { static constexpr bool value = true; };     // policy pass (check_body below)
 
-template <bool GENERIC, typename AM>   // AM: per-request action mask, u32 when no request of the batch carries more than 32 actions
+#define CBH_FEAT_DERIVED_ROLES 1   /* FEAT bits: what the table uses, compiled in only then */
+#define CBH_FEAT_ROLE_POLICIES 2  /* role policies and / or parent roles */
+
+template <bool GENERIC, typename AM, int FEAT>   // AM: per-request action mask, u32 when no request of the batch carries more than 32 actions
 __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   const TableDev& t = ka_regs.t;
   const BatchDev& b = ka_regs.b;
@@ -414,9 +417,10 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
 
   const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
   const bool strict = (flags & CBH_F_STRICT_EVALUATION) != 0;
-  const bool want_edr = (flags & CBH_F_WANT_DERIVED_ROLES) != 0 || (t.flags & CBH_MF_USES_RUNTIME_EDR) != 0;
-  const bool has_parents = (t.flags & CBH_MF_HAS_PARENT_ROLES) != 0;
-  const bool has_rolepol = (t.flags & CBH_MF_HAS_ROLE_POLICIES) != 0;
+  constexpr bool F_DR = (FEAT & CBH_FEAT_DERIVED_ROLES) != 0, F_RP = (FEAT & CBH_FEAT_ROLE_POLICIES) != 0;
+  const bool want_edr = F_DR && ((flags & CBH_F_WANT_DERIVED_ROLES) != 0 || (t.flags & CBH_MF_USES_RUNTIME_EDR) != 0);
+  const bool has_parents = F_RP && (t.flags & CBH_MF_HAS_PARENT_ROLES) != 0;
+  const bool has_rolepol = F_RP && (t.flags & CBH_MF_HAS_ROLE_POLICIES) != 0;
   const bool want_ps = o.policy != nullptr || o.scope != nullptr;
 
   Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false; L.pid = pid;
@@ -860,7 +864,7 @@ __device__ __forceinline__ u32 cached_columns(const KernelArgs* ka) {
 }
 
 // GENERIC instantiation: operand stack, locals and iteration slots in LDS, laid out [slot][lane].
-template <typename AM>
+template <typename AM, int FEAT>
 __device__ __forceinline__ void generic_kernel_body(const KernelArgs& a, const KernelArgs* ka) {
   __shared__ u64 s_val[CBH_STACK_DEPTH * CBH_BLOCK];
   __shared__ u64 l_val[CBH_MAX_LOCALS * CBH_BLOCK];
@@ -884,16 +888,16 @@ __device__ __forceinline__ void generic_kernel_body(const KernelArgs& a, const K
         (CBH_L u64*)s_val, (CBH_L u8*)s_tag, (CBH_L u64*)l_val, (CBH_L u8*)l_tag,
         (CBH_L u64*)it_cont, (CBH_L u32*)it_idx, (CBH_L u32*)it_state,
         (CBH_L u32*)cbh_dyn_lds, ncc, ka};
-  check_body<true, AM>(a, c);
+  check_body<true, AM, FEAT>(a, c);
 }
 
 // Leaf-only instantiation: no operand stack, no interpreter call.
-template <typename AM>
+template <typename AM, int FEAT>
 __device__ __forceinline__ void leaf_kernel_body(const KernelArgs& a, const KernelArgs* ka) {
   const u32 ncc = cached_columns(&a);
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
         (CBH_L u32*)cbh_dyn_lds, ncc, ka};
-  check_body<false, AM>(a, c);
+  check_body<false, AM, FEAT>(a, c);
 }
 
 // A batch of 1M tuples is ~3.9k waves for 1024 SIMDs: holding the leaf kernels to 128 VGPRs lets all
@@ -903,17 +907,35 @@ __device__ __forceinline__ void leaf_kernel_body(const KernelArgs& a, const Kern
 #else
 #define CBH_FOUR_WAVES
 #endif
-// The host picks by table (every program a fused leaf / leaf tree?) and by batch (no request with
-// more than 32 actions -> 32-bit action masks).
-__global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
-  generic_kernel_body<u64>(a, ka);
-}
-__global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel_a32(const KernelArgs a, const KernelArgs* __restrict__ ka) {
-  generic_kernel_body<u32>(a, ka);
-}
-__global__ __launch_bounds__(CBH_BLOCK) CBH_FOUR_WAVES void cbh_check_kernel_leaf(const KernelArgs a, const KernelArgs* __restrict__ ka) {
-  leaf_kernel_body<u64>(a, ka);
-}
-__global__ __launch_bounds__(CBH_BLOCK) CBH_FOUR_WAVES void cbh_check_kernel_leaf_a32(const KernelArgs a, const KernelArgs* __restrict__ ka) {
-  leaf_kernel_body<u32>(a, ka);
+// The host picks by table - every program a fused leaf / leaf tree?  which features does it use
+// (CBH_FEAT_*: a table without derived roles / role policies / parent roles gets a kernel that does
+// not carry their code or registers) - and by batch (no request with more than 32 actions -> 32-bit
+// action masks).  Name = cbh_check_kernel[_leaf][_a32][_f0 | _f1]; no feature suffix = everything.
+#define CBH_DEFINE_CHECK_KERNELS(FEAT, SUF)                                                                                   \
+  __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel##SUF(const KernelArgs a, const KernelArgs* __restrict__ ka) { \
+    generic_kernel_body<u64, FEAT>(a, ka);                                                                                    \
+  }                                                                                                                           \
+  __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel_a32##SUF(const KernelArgs a, const KernelArgs* __restrict__ ka) { \
+    generic_kernel_body<u32, FEAT>(a, ka);                                                                                    \
+  }                                                                                                                           \
+  __global__ __launch_bounds__(CBH_BLOCK) CBH_FOUR_WAVES void cbh_check_kernel_leaf##SUF(const KernelArgs a, const KernelArgs* __restrict__ ka) { \
+    leaf_kernel_body<u64, FEAT>(a, ka);                                                                                       \
+  }                                                                                                                           \
+  __global__ __launch_bounds__(CBH_BLOCK) CBH_FOUR_WAVES void cbh_check_kernel_leaf_a32##SUF(const KernelArgs a, const KernelArgs* __restrict__ ka) { \
+    leaf_kernel_body<u32, FEAT>(a, ka);                                                                                       \
+  }
+CBH_DEFINE_CHECK_KERNELS(0, _f0)                                    // plain resource / principal policies
+CBH_DEFINE_CHECK_KERNELS(CBH_FEAT_DERIVED_ROLES, _f1)               // + derived roles
+CBH_DEFINE_CHECK_KERNELS(CBH_FEAT_DERIVED_ROLES | CBH_FEAT_ROLE_POLICIES, )   // + role policies / parent roles
+
+typedef void (*cbh_check_kernel_fn)(const KernelArgs, const KernelArgs*);
+// the instantiation for a table (its meta flags, number of derived-role records) and a batch
+static inline cbh_check_kernel_fn cbh_pick_check_kernel(u32 table_flags, u32 n_derived_roles, u32 max_actions) {
+  const bool generic = (table_flags & CBH_MF_HAS_GENERIC_PROGRAMS) != 0, a32 = max_actions <= 32;
+  const int feat = (table_flags & (CBH_MF_HAS_ROLE_POLICIES | CBH_MF_HAS_PARENT_ROLES)) ? 2 : (n_derived_roles || (table_flags & CBH_MF_USES_RUNTIME_EDR)) ? 1 : 0;
+  static const cbh_check_kernel_fn tab[3][2][2] = {
+      {{cbh_check_kernel_leaf_f0, cbh_check_kernel_leaf_a32_f0}, {cbh_check_kernel_f0, cbh_check_kernel_a32_f0}},
+      {{cbh_check_kernel_leaf_f1, cbh_check_kernel_leaf_a32_f1}, {cbh_check_kernel_f1, cbh_check_kernel_a32_f1}},
+      {{cbh_check_kernel_leaf, cbh_check_kernel_leaf_a32}, {cbh_check_kernel, cbh_check_kernel_a32}}};
+  return tab[feat][generic ? 1 : 0][a32 ? 1 : 0];
 }

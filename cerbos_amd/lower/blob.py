@@ -482,6 +482,10 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         "unsupported_expressions": len(lt.unsupported),
         "globs": [len(d.globs) for d in dims],
         "generic_programs": bool(pb.has_generic),   # selects the kernel with the operand-stack interpreter
+        # feature class of the kernel (cbh_pick_check_kernel): "" = role policies / parent roles,
+        # "_f1" = derived roles, "_f0" = neither
+        "kernel_features": ("" if int(meta[M_FLAGS]) & 6 else
+                            "_f1" if (len(dr_cols[0]) or int(meta[M_FLAGS]) & MF_USES_RUNTIME_EDR) else "_f0"),
     }
     return lt
 

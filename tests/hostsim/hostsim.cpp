@@ -84,9 +84,7 @@ static KernelArgs* g_args;
 static bool g_a32;   // same kernel selection as cbh_check_resident (cbh_engine.hip)
 
 static void fiber_main() {
-  const bool generic = (g_args->t.flags & CBH_MF_HAS_GENERIC_PROGRAMS) != 0;
-  if (generic) { if (g_a32) cbh_check_kernel_a32(*g_args, g_args); else cbh_check_kernel(*g_args, g_args); }
-  else { if (g_a32) cbh_check_kernel_leaf_a32(*g_args, g_args); else cbh_check_kernel_leaf(*g_args, g_args); }
+  cbh_pick_check_kernel(g_args->t.flags, g_args->t.n_dr, g_a32 ? 1u : 64u)(*g_args, g_args);
   g_fibers[g_cur].done = true;
   g_fibers[g_cur].waiting = 0;
   swapcontext(&g_fibers[g_cur].ctx, &g_sched);
