@@ -30,8 +30,9 @@ struct RoleSet {   // [role] ++ ancestors(role) for the request's resource scope
   u32 role; u32 par_off; u32 par_cnt; u64 gbits;   // gbits: OR of role-dimension glob bits over the set
 };
 
-__device__ __forceinline__ bool roleset_has(const TableDev& t, const RoleSet& rs, u32 pref) {
-  if (pref & CBH_PAT_GLOB) return ((rs.gbits >> (pref & 63u)) & 1ull) != 0;
+// `globbit` = CBH_PAT_GLOB, or 0 in kernels for tables without glob patterns (the branch folds away)
+__device__ __forceinline__ bool roleset_has(const TableDev& t, const RoleSet& rs, u32 pref, u32 globbit) {
+  if (pref & globbit) return ((rs.gbits >> (pref & 63u)) & 1ull) != 0;
   if (pref == rs.role) return true;
   for (u32 k = 0; k < rs.par_cnt; ++k) if (t.pool[rs.par_off + k] == pref) return true;
   return false;
@@ -359,6 +360,7 @@ struct CbhPassResource { static constexpr bool value = true; };     // policy pa
 
 #define CBH_FEAT_DERIVED_ROLES 1   /* FEAT bits: what the table uses, compiled in only then */
 #define CBH_FEAT_ROLE_POLICIES 2  /* role policies and / or parent roles */
+#define CBH_FEAT_GLOBS 4          /* glob patterns in some dimension (action / role / kind) */
 
 template <bool GENERIC, typename AM, int FEAT>   // AM: per-request action mask, u32 when no request of the batch carries more than 32 actions
 __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
@@ -418,6 +420,9 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
   const bool strict = (flags & CBH_F_STRICT_EVALUATION) != 0;
   constexpr bool F_DR = (FEAT & CBH_FEAT_DERIVED_ROLES) != 0, F_RP = (FEAT & CBH_FEAT_ROLE_POLICIES) != 0;
+  constexpr bool F_GLOB = (FEAT & CBH_FEAT_GLOBS) != 0;
+  constexpr u32 GLOBBIT = F_GLOB ? CBH_PAT_GLOB : 0u;   // no glob patterns in the table: every pattern reference is a literal
+  auto pmatch = [&](u32 pref, u32 sid, u64 bits) -> bool { return (pref & GLOBBIT) ? ((bits >> (pref & 63u)) & 1ull) != 0 : pref == sid; };
   const bool want_edr = F_DR && ((flags & CBH_F_WANT_DERIVED_ROLES) != 0 || (t.flags & CBH_MF_USES_RUNTIME_EDR) != 0);
   const bool has_parents = F_RP && (t.flags & CBH_MF_HAS_PARENT_ROLES) != 0;
   const bool has_rolepol = F_RP && (t.flags & CBH_MF_HAS_ROLE_POLICIES) != 0;
@@ -429,7 +434,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   // mask of this request's actions matching an action-dimension pattern reference
   auto match_actions = [&](u32 pat) -> AM {
     AM m = 0;
-    if (!(pat & CBH_PAT_GLOB)) {
+    if (!(pat & GLOBBIT)) {
       m = (AM)(a0 == pat) | ((AM)(a1 == pat) << 1) | ((AM)(a2 == pat) << 2) | ((AM)(a3 == pat) << 3);
       for (u32 k = 4; k < act_cnt; ++k) m |= (AM)(b.tuple_action[act_off + k] == pat) << k;
     } else {
@@ -465,7 +470,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
 
   // kind-dimension glob bits of the resource kind: looked up where a pattern needs them (zero loads
   // for a table without kind globs) rather than held in two registers for the whole kernel
-#define KIND_BITS() gbits_of(t, b, DIM_KIND, kind)
+#define KIND_BITS() (F_GLOB ? gbits_of(t, b, DIM_KIND, kind) : 0ull)
   // parent roles are looked up with the request's own resource scope only (check.go:172,227)
   const u32 pr_scope_key = (r_scope & CBH_SCOPE_EXACT) ? (r_scope & ~CBH_SCOPE_EXACT) : CBH_NONE;
 
@@ -492,7 +497,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
       for (u32 si = rf; si != CBH_NONE && !re; si = uchain_next(t, uload(&t.scope_parent[si]), FLAG_RES)) {
         if (udir_find(t, CBH_B_RESEXISTS, g_rv, g_k, si, v)) { re = true; break; }      // index.go:966-997
         if (has_rolepol && udir_find(t, CBH_B_RPRES, g_rv, si, 0, v))
-          for (u32 k = 0; k < v.y && !re; ++k) re = pat_match(uload(&t.pool[v.x + k]), g_k, g_kbits);
+          for (u32 k = 0; k < v.y && !re; ++k) re = pmatch(uload(&t.pool[v.x + k]), g_k, g_kbits);
       }
       if (inq) { p_first = pf; r_first = rf; p_exists = pe; r_exists = re; }
     }
@@ -562,11 +567,11 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
         RoleSet rs; rs.role = 0; rs.par_off = 0; rs.par_cnt = 0; rs.gbits = 0;
         if (Am != 0) {
           rs.role = ri == 0 ? role0 : ri == 1 ? role1 : b.roles[role_off + ri];
-          rs.gbits = gbits_of(t, b, DIM_ROLE, rs.role);
+          rs.gbits = F_GLOB ? gbits_of(t, b, DIM_ROLE, rs.role) : 0ull;
           uint4 pv;
           if (has_parents && pr_scope_key != CBH_NONE && dir_find(t, CBH_B_PARENTS, pr_scope_key, rs.role, 0, pv)) {
             rs.par_off = pv.x; rs.par_cnt = pv.y;
-            for (u32 k = 0; k < rs.par_cnt; ++k) rs.gbits |= t.gbits[(size_t)DIM_ROLE * t.K + t.pool[rs.par_off + k]];
+            if (F_GLOB) for (u32 k = 0; k < rs.par_cnt; ++k) rs.gbits |= t.gbits[(size_t)DIM_ROLE * t.K + t.pool[rs.par_off + k]];
           }
         }
         // Role classes this wave is walking now (cbh_blob.h CBH_SEC_ROLE_CLASS): a rule record whose
@@ -676,7 +681,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                 AM any_mask = 0;   // actions allowed (subject to conditions) by some rule for this resource
                 for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
                   const TblRp rr = uload_rec<TblRp>(t.rprows, row);
-                  if (!in2 || !pat_match(rr.resource, kind, KIND_BITS())) continue;
+                  if (!in2 || !pmatch(rr.resource, kind, KIND_BITS())) continue;
                   for (u32 a = 0; a < rr.allow_cnt; ++a) any_mask |= match_actions(uload(&t.pool[rr.allow_off + a]));
                 }
                 // no binding for the resource, or no allow-action matched (index.go:436-461)
@@ -685,7 +690,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                   const TblRp rr = uload_rec<TblRp>(t.rprows, row);
                   if (rr.cond == CBH_NONE) continue;
                   AM mm = 0;
-                  if (in2 && pat_match(rr.resource, kind, KIND_BITS())) {
+                  if (in2 && pmatch(rr.resource, kind, KIND_BITS())) {
                     for (u32 a = 0; a < rr.allow_cnt; ++a) mm |= match_actions(uload(&t.pool[rr.allow_off + a]));
                     mm &= S & ~deny;
                   }
@@ -718,14 +723,14 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
               const u32 n_act = rw.counts & 0xFFFFu, n_role = rw.counts >> 16;   // 0 = a single inline reference
               bool rmatch = false;
               if (S != 0) {
-                if (!is_res) rmatch = pat_match(rw.resource, kind, KIND_BITS());
+                if (!is_res) rmatch = pmatch(rw.resource, kind, KIND_BITS());
                 else if (rw.flags & CBH_ROW_F_ROLE_LIST) {   // more than four roles: the list lives in the pool
-                  for (u32 i = 0; i < n_role; ++i) rmatch = rmatch || roleset_has(t, rs, uload(&t.pool[rw.role + i]));
+                  for (u32 i = 0; i < n_role; ++i) rmatch = rmatch || roleset_has(t, rs, uload(&t.pool[rw.role + i]), GLOBBIT);
                 } else {
-                  rmatch = roleset_has(t, rs, rw.role);
-                  if (n_role > 1) rmatch = rmatch || roleset_has(t, rs, rl.r1);
-                  if (n_role > 2) rmatch = rmatch || roleset_has(t, rs, rl.r2);
-                  if (n_role > 3) rmatch = rmatch || roleset_has(t, rs, rl.r3);
+                  rmatch = roleset_has(t, rs, rw.role, GLOBBIT);
+                  if (n_role > 1) rmatch = rmatch || roleset_has(t, rs, rl.r1, GLOBBIT);
+                  if (n_role > 2) rmatch = rmatch || roleset_has(t, rs, rl.r2, GLOBBIT);
+                  if (n_role > 3) rmatch = rmatch || roleset_has(t, rs, rl.r3, GLOBBIT);
                 }
               }
               AM mrow = 0;
@@ -910,32 +915,30 @@ __device__ __forceinline__ void leaf_kernel_body(const KernelArgs& a, const Kern
 // The host picks by table - every program a fused leaf / leaf tree?  which features does it use
 // (CBH_FEAT_*: a table without derived roles / role policies / parent roles gets a kernel that does
 // not carry their code or registers) - and by batch (no request with more than 32 actions -> 32-bit
-// action masks).  Name = cbh_check_kernel[_leaf][_a32][_f0 | _f1]; no feature suffix = everything.
-#define CBH_DEFINE_CHECK_KERNELS(FEAT, SUF)                                                                                   \
+// action masks).  Name = cbh_check_kernel[_leaf][_a32[_f<feature bits>]]; no feature suffix = everything.
+#define CBH_DEFINE_CHECK_KERNELS(AMT, FEAT, SUF)                                                                              \
   __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel##SUF(const KernelArgs a, const KernelArgs* __restrict__ ka) { \
-    generic_kernel_body<u64, FEAT>(a, ka);                                                                                    \
-  }                                                                                                                           \
-  __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel_a32##SUF(const KernelArgs a, const KernelArgs* __restrict__ ka) { \
-    generic_kernel_body<u32, FEAT>(a, ka);                                                                                    \
+    generic_kernel_body<AMT, FEAT>(a, ka);                                                                                    \
   }                                                                                                                           \
   __global__ __launch_bounds__(CBH_BLOCK) CBH_FOUR_WAVES void cbh_check_kernel_leaf##SUF(const KernelArgs a, const KernelArgs* __restrict__ ka) { \
-    leaf_kernel_body<u64, FEAT>(a, ka);                                                                                       \
-  }                                                                                                                           \
-  __global__ __launch_bounds__(CBH_BLOCK) CBH_FOUR_WAVES void cbh_check_kernel_leaf_a32##SUF(const KernelArgs a, const KernelArgs* __restrict__ ka) { \
-    leaf_kernel_body<u32, FEAT>(a, ka);                                                                                       \
+    leaf_kernel_body<AMT, FEAT>(a, ka);                                                                                       \
   }
-CBH_DEFINE_CHECK_KERNELS(0, _f0)                                    // plain resource / principal policies
-CBH_DEFINE_CHECK_KERNELS(CBH_FEAT_DERIVED_ROLES, _f1)               // + derived roles
-CBH_DEFINE_CHECK_KERNELS(CBH_FEAT_DERIVED_ROLES | CBH_FEAT_ROLE_POLICIES, )   // + role policies / parent roles
+CBH_DEFINE_CHECK_KERNELS(u32, 0, _a32_f0)                                                   // plain policies, literal patterns
+CBH_DEFINE_CHECK_KERNELS(u32, CBH_FEAT_DERIVED_ROLES, _a32_f1)                              // + derived roles
+CBH_DEFINE_CHECK_KERNELS(u32, CBH_FEAT_GLOBS, _a32_f4)                                      // plain + glob patterns
+CBH_DEFINE_CHECK_KERNELS(u32, CBH_FEAT_DERIVED_ROLES | CBH_FEAT_GLOBS, _a32_f5)             // derived roles + globs
+CBH_DEFINE_CHECK_KERNELS(u32, CBH_FEAT_DERIVED_ROLES | CBH_FEAT_ROLE_POLICIES | CBH_FEAT_GLOBS, _a32)   // everything
+CBH_DEFINE_CHECK_KERNELS(u64, CBH_FEAT_DERIVED_ROLES | CBH_FEAT_ROLE_POLICIES | CBH_FEAT_GLOBS, )       // everything, > 32 actions
 
 typedef void (*cbh_check_kernel_fn)(const KernelArgs, const KernelArgs*);
 // the instantiation for a table (its meta flags, number of derived-role records) and a batch
-static inline cbh_check_kernel_fn cbh_pick_check_kernel(u32 table_flags, u32 n_derived_roles, u32 max_actions) {
-  const bool generic = (table_flags & CBH_MF_HAS_GENERIC_PROGRAMS) != 0, a32 = max_actions <= 32;
-  const int feat = (table_flags & (CBH_MF_HAS_ROLE_POLICIES | CBH_MF_HAS_PARENT_ROLES)) ? 2 : (n_derived_roles || (table_flags & CBH_MF_USES_RUNTIME_EDR)) ? 1 : 0;
-  static const cbh_check_kernel_fn tab[3][2][2] = {
-      {{cbh_check_kernel_leaf_f0, cbh_check_kernel_leaf_a32_f0}, {cbh_check_kernel_f0, cbh_check_kernel_a32_f0}},
-      {{cbh_check_kernel_leaf_f1, cbh_check_kernel_leaf_a32_f1}, {cbh_check_kernel_f1, cbh_check_kernel_a32_f1}},
-      {{cbh_check_kernel_leaf, cbh_check_kernel_leaf_a32}, {cbh_check_kernel, cbh_check_kernel_a32}}};
-  return tab[feat][generic ? 1 : 0][a32 ? 1 : 0];
+static inline cbh_check_kernel_fn cbh_pick_check_kernel(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 max_actions) {
+  const int g = (table_flags & CBH_MF_HAS_GENERIC_PROGRAMS) ? 1 : 0;
+  if (max_actions > 32) return g ? cbh_check_kernel : cbh_check_kernel_leaf;
+  if (table_flags & (CBH_MF_HAS_ROLE_POLICIES | CBH_MF_HAS_PARENT_ROLES)) return g ? cbh_check_kernel_a32 : cbh_check_kernel_leaf_a32;
+  const bool dr = n_derived_roles || (table_flags & CBH_MF_USES_RUNTIME_EDR);
+  static const cbh_check_kernel_fn tab[2][2][2] = {   // [globs][derived roles][generic]
+      {{cbh_check_kernel_leaf_a32_f0, cbh_check_kernel_a32_f0}, {cbh_check_kernel_leaf_a32_f1, cbh_check_kernel_a32_f1}},
+      {{cbh_check_kernel_leaf_a32_f4, cbh_check_kernel_a32_f4}, {cbh_check_kernel_leaf_a32_f5, cbh_check_kernel_a32_f5}}};
+  return tab[has_globs ? 1 : 0][dr ? 1 : 0][g];
 }

@@ -482,10 +482,11 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         "unsupported_expressions": len(lt.unsupported),
         "globs": [len(d.globs) for d in dims],
         "generic_programs": bool(pb.has_generic),   # selects the kernel with the operand-stack interpreter
-        # feature class of the kernel (cbh_pick_check_kernel): "" = role policies / parent roles,
-        # "_f1" = derived roles, "_f0" = neither
-        "kernel_features": ("" if int(meta[M_FLAGS]) & 6 else
-                            "_f1" if (len(dr_cols[0]) or int(meta[M_FLAGS]) & MF_USES_RUNTIME_EDR) else "_f0"),
+        # feature class of the 32-bit-mask kernels (cbh_pick_check_kernel): "" = everything (role policies /
+        # parent roles), else "_f<bits>" with bit 0 = derived roles, bit 2 = glob patterns
+        "kernel_features": ("" if int(meta[M_FLAGS]) & 6 else "_f%d" % (
+            (1 if (len(dr_cols[0]) or int(meta[M_FLAGS]) & MF_USES_RUNTIME_EDR) else 0)
+            | (4 if any(lt.nfas[d].patterns for d in range(3)) else 0))),
     }
     return lt
 
