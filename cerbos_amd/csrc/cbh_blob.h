@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define CBH_BLOB_MAGIC 0x31484243u /* "CBH1" */
-#define CBH_BLOB_VERSION 11u
+#define CBH_BLOB_VERSION 12u
 
 struct CbhBlobHeader {  // 32 bytes
   uint32_t magic;
@@ -78,6 +78,7 @@ enum CbhMeta {
 #define CBH_MF_HAS_PARENT_ROLES 2u
 #define CBH_MF_HAS_ROLE_POLICIES 4u
 #define CBH_MF_HAS_GENERIC_PROGRAMS 8u  /* some program needs the operand-stack interpreter */
+#define CBH_MF_HAS_ANY_PATTERN 16u      /* some pattern reference is CBH_PAT_ANY (treated as a glob table) */
 
 // Directory: open addressing, linear probing, key.x == CBH_NONE marks an empty slot.
 struct CbhHashSlot { // 32 bytes
@@ -102,6 +103,8 @@ enum CbhBucketType {
 
 // Pattern reference: bit31 set -> glob index within the dimension, else literal string id.
 #define CBH_PAT_GLOB 0x80000000u
+// The lone "*" (= "**", util/globs_common.go:74-81: matches every string) needs no automaton.
+#define CBH_PAT_ANY 0x7FFFFFFFu
 
 // Regular rows (resource + principal policies).  One record stands for the rule-table rows of ONE
 // rule that share effect / condition / derived-role condition: the cross product of its role list

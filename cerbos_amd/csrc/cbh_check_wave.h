@@ -32,6 +32,7 @@ struct RoleSet {   // [role] ++ ancestors(role) for the request's resource scope
 
 // `globbit` = CBH_PAT_GLOB, or 0 in kernels for tables without glob patterns (the branch folds away)
 __device__ __forceinline__ bool roleset_has(const TableDev& t, const RoleSet& rs, u32 pref, u32 globbit) {
+  if (globbit && pref == CBH_PAT_ANY) return true;   // ("*" counts as a glob pattern for the kernel classes)
   if (pref & globbit) return ((rs.gbits >> (pref & 63u)) & 1ull) != 0;
   if (pref == rs.role) return true;
   for (u32 k = 0; k < rs.par_cnt; ++k) if (t.pool[rs.par_off + k] == pref) return true;
@@ -422,7 +423,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   constexpr bool F_DR = (FEAT & CBH_FEAT_DERIVED_ROLES) != 0, F_RP = (FEAT & CBH_FEAT_ROLE_POLICIES) != 0;
   constexpr bool F_GLOB = (FEAT & CBH_FEAT_GLOBS) != 0;
   constexpr u32 GLOBBIT = F_GLOB ? CBH_PAT_GLOB : 0u;   // no glob patterns in the table: every pattern reference is a literal
-  auto pmatch = [&](u32 pref, u32 sid, u64 bits) -> bool { return (pref & GLOBBIT) ? ((bits >> (pref & 63u)) & 1ull) != 0 : pref == sid; };
+  auto pmatch = [&](u32 pref, u32 sid, u64 bits) -> bool { return (F_GLOB && pref == CBH_PAT_ANY) || ((pref & GLOBBIT) ? ((bits >> (pref & 63u)) & 1ull) != 0 : pref == sid); };
   const bool want_edr = F_DR && ((flags & CBH_F_WANT_DERIVED_ROLES) != 0 || (t.flags & CBH_MF_USES_RUNTIME_EDR) != 0);
   const bool has_parents = F_RP && (t.flags & CBH_MF_HAS_PARENT_ROLES) != 0;
   const bool has_rolepol = F_RP && (t.flags & CBH_MF_HAS_ROLE_POLICIES) != 0;
@@ -434,6 +435,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   // mask of this request's actions matching an action-dimension pattern reference
   auto match_actions = [&](u32 pat) -> AM {
     AM m = 0;
+    if (F_GLOB && pat == CBH_PAT_ANY) return all;
     if (!(pat & GLOBBIT)) {
       m = (AM)(a0 == pat) | ((AM)(a1 == pat) << 1) | ((AM)(a2 == pat) << 2) | ((AM)(a3 == pat) << 3);
       for (u32 k = 4; k < act_cnt; ++k) m |= (AM)(b.tuple_action[act_off + k] == pat) << k;

@@ -299,7 +299,7 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
     const u32 grid = (d.n_requests + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
     const u32 ncc = d.n_columns < CBH_CACHE_COLS ? d.n_columns : CBH_CACHE_COLS;
     const size_t dyn_lds = (size_t)ncc * CBH_BLOCK * 12;   // column cache: value low / high / tag dword per lane
-    const cbh_check_kernel_fn kernel = cbh_pick_check_kernel(t->dev.flags, t->dev.n_dr, maxw != 0, b->max_actions);
+    const cbh_check_kernel_fn kernel = cbh_pick_check_kernel(t->dev.flags, t->dev.n_dr, maxw != 0 || (t->dev.flags & CBH_MF_HAS_ANY_PATTERN), b->max_actions);
     if (timed) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), dyn_lds, s, sl.ev[2], sl.ev[3], 0, b->last_args, (const KernelArgs*)b->d_args);
     else hipLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), dyn_lds, s, b->last_args, (const KernelArgs*)b->d_args);
     sl.pending = timed;

@@ -36,6 +36,7 @@ __device__ __forceinline__ u64 gbits_of(const TableDev& t, const BatchDev& b, u3
   return b.gbits[(size_t)dim * b.n_strings + (sid - t.K)];
 }
 __device__ __forceinline__ bool pat_match(u32 pref, u32 sid, u64 bits) {
+  if (pref == CBH_PAT_ANY) return true;
   return (pref & CBH_PAT_GLOB) ? ((bits >> (pref & 63u)) & 1ull) != 0 : pref == sid;
 }
 

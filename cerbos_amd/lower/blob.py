@@ -25,9 +25,10 @@ from .celc import LoweringError, Params, ProgramBuilder
 from .globs import GlobNFA, fix_glob, has_meta
 
 BLOB_MAGIC = 0x31484243
-BLOB_VERSION = 11
+BLOB_VERSION = 12
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
+PAT_ANY = 0x7FFFFFFF     # the lone "*": matches every string, no automaton needed
 ROW_F_ACTION_LIST, ROW_F_ROLE_LIST = 4, 8
 
 (SEC_META, SEC_STR_OFF, SEC_STR_BYTES, SEC_SCOPE_PARENT, SEC_SCOPE_FLAGS, SEC_SCOPE_SID, SEC_HASH,
@@ -116,9 +117,13 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
     sid("")  # string 0 is always the empty string
     pb = ProgramBuilder(sid, globals_)
     dims = [_Dim(), _Dim(), _Dim()]
+    used_any = []   # dimensions in which a lone "*" was met
 
     def dim_ref(dim, key):
         """globDimension.Set: a key is a pattern only if it contains '*' (glob_dimension.go:32)."""
+        if key == "*":
+            used_any.append(dim)
+            return PAT_ANY          # fixGlob: "*" means "**" (util/globs_common.go:74-81)
         if "*" in key:
             return dims[dim].glob_ref(key)
         return sid(key)
@@ -411,7 +416,8 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
     meta[M_FLAGS] = ((MF_USES_RUNTIME_EDR if pb.uses_runtime else 0)
                      | (2 if any(v for r in rt["parent_roles"].values() for v in r.values()) else 0)
                      | (4 if rp_buckets else 0)
-                     | (8 if pb.has_generic else 0))
+                     | (8 if pb.has_generic else 0)
+                     | (16 if used_any else 0))
     meta[M_MAX_STACK] = pb.max_stack
     meta[M_NDRNAMES] = len(lt.dr_names)
     meta[M_NFA_WORDS_ACTION] = lt.nfas[0].words
@@ -486,7 +492,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         # parent roles), else "_f<bits>" with bit 0 = derived roles, bit 2 = glob patterns
         "kernel_features": ("" if int(meta[M_FLAGS]) & 6 else "_f%d" % (
             (1 if (len(dr_cols[0]) or int(meta[M_FLAGS]) & MF_USES_RUNTIME_EDR) else 0)
-            | (4 if any(lt.nfas[d].patterns for d in range(3)) else 0))),
+            | (4 if (used_any or any(lt.nfas[d].patterns for d in range(3))) else 0))),
     }
     return lt
 

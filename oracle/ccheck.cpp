@@ -135,7 +135,7 @@ u64 glob_bits(const Img& g, const cbh_batch& b, u32 dim, u32 sid) {
   }
   return bits;
 }
-bool pat_match(u32 pref, u32 sid, u64 bits) { return (pref & CBH_PAT_GLOB) ? ((bits >> (pref & 63u)) & 1) != 0 : pref == sid; }
+bool pat_match(u32 pref, u32 sid, u64 bits) { if (pref == CBH_PAT_ANY) return true; return (pref & CBH_PAT_GLOB) ? ((bits >> (pref & 63u)) & 1) != 0 : pref == sid; }
 
 // ---- CEL values of the fused-leaf subset ---------------------------------------------------------
 struct V { u32 t; u64 v; };

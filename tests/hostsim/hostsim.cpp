@@ -84,7 +84,7 @@ static KernelArgs* g_args;
 static bool g_a32;   // same kernel selection as cbh_check_resident (cbh_engine.hip)
 
 static void fiber_main() {
-  cbh_pick_check_kernel(g_args->t.flags, g_args->t.n_dr, (g_args->t.nfa_words[0] | g_args->t.nfa_words[1] | g_args->t.nfa_words[2]) != 0, g_a32 ? 1u : 64u)(*g_args, g_args);
+  cbh_pick_check_kernel(g_args->t.flags, g_args->t.n_dr, (g_args->t.nfa_words[0] | g_args->t.nfa_words[1] | g_args->t.nfa_words[2] | (g_args->t.flags & CBH_MF_HAS_ANY_PATTERN)) != 0, g_a32 ? 1u : 64u)(*g_args, g_args);
   g_fibers[g_cur].done = true;
   g_fibers[g_cur].waiting = 0;
   swapcontext(&g_fibers[g_cur].ctx, &g_sched);
