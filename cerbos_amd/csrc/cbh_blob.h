@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define CBH_BLOB_MAGIC 0x31484243u /* "CBH1" */
-#define CBH_BLOB_VERSION 12u
+#define CBH_BLOB_VERSION 13u
 
 struct CbhBlobHeader {  // 32 bytes
   uint32_t magic;
@@ -79,6 +79,7 @@ enum CbhMeta {
 #define CBH_MF_HAS_ROLE_POLICIES 4u
 #define CBH_MF_HAS_GENERIC_PROGRAMS 8u  /* some program needs the operand-stack interpreter */
 #define CBH_MF_HAS_ANY_PATTERN 16u      /* some pattern reference is CBH_PAT_ANY (treated as a glob table) */
+#define CBH_MF_HAS_PRINCIPAL_POLICIES 32u
 
 // Directory: open addressing, linear probing, key.x == CBH_NONE marks an empty slot.
 struct CbhHashSlot { // 32 bytes

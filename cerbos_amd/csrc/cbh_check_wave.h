@@ -362,6 +362,8 @@ struct CbhPassResource { static constexpr bool value = true; };     // policy pa
 #define CBH_FEAT_DERIVED_ROLES 1   /* FEAT bits: what the table uses, compiled in only then */
 #define CBH_FEAT_ROLE_POLICIES 2  /* role policies and / or parent roles */
 #define CBH_FEAT_GLOBS 4          /* glob patterns in some dimension (action / role / kind) */
+#define CBH_FEAT_PRINCIPAL_POLICIES 8
+#define CBH_FEAT_ALL 15
 
 template <bool GENERIC, typename AM, int FEAT>   // AM: per-request action mask, u32 when no request of the batch carries more than 32 actions
 __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
@@ -422,6 +424,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   const bool strict = (flags & CBH_F_STRICT_EVALUATION) != 0;
   constexpr bool F_DR = (FEAT & CBH_FEAT_DERIVED_ROLES) != 0, F_RP = (FEAT & CBH_FEAT_ROLE_POLICIES) != 0;
   constexpr bool F_GLOB = (FEAT & CBH_FEAT_GLOBS) != 0;
+  constexpr bool F_PP = (FEAT & CBH_FEAT_PRINCIPAL_POLICIES) != 0;
   constexpr u32 GLOBBIT = F_GLOB ? CBH_PAT_GLOB : 0u;   // no glob patterns in the table: every pattern reference is a literal
   auto pmatch = [&](u32 pref, u32 sid, u64 bits) -> bool { return (F_GLOB && pref == CBH_PAT_ANY) || ((pref & GLOBBIT) ? ((bits >> (pref & 63u)) & 1ull) != 0 : pref == sid); };
   const bool want_edr = F_DR && ((flags & CBH_F_WANT_DERIVED_ROLES) != 0 || (t.flags & CBH_MF_USES_RUNTIME_EDR) != 0);
@@ -489,13 +492,16 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
       const u32 g_ps = wave_readlane(p_scope, lead), g_pv = wave_readlane(p_ver, lead), g_rs = wave_readlane(r_scope, lead),
                 g_rv = wave_readlane(r_ver, lead), g_k = wave_readlane(kind, lead);
       const u64 g_kbits = wave_readlane64(KIND_BITS(), lead);
-      const bool inq = pendq && p_scope == g_ps && p_ver == g_pv && r_scope == g_rs && r_ver == g_rv && kind == g_k;
+      // (a table without principal policies has no scope in the principal map: its kernels leave the
+      // principal side out altogether)
+      const bool inq = pendq && (!F_PP || (p_scope == g_ps && p_ver == g_pv)) && r_scope == g_rs && r_ver == g_rv && kind == g_k;
       pendq = pendq && !inq;
-      const u32 pf = uchain_first(t, g_ps, FLAG_PRIN, lenient), rf = uchain_first(t, g_rs, FLAG_RES, lenient);
+      const u32 pf = F_PP ? uchain_first(t, g_ps, FLAG_PRIN, lenient) : CBH_NONE, rf = uchain_first(t, g_rs, FLAG_RES, lenient);
       bool pe = false, re = false;
       uint4 v;
-      for (u32 si = pf; si != CBH_NONE && !pe; si = uchain_next(t, uload(&t.scope_parent[si]), FLAG_PRIN))
-        pe = udir_find(t, CBH_B_PPEXISTS, g_pv, si, 0, v);                              // index.go:999-1021
+      if (F_PP)
+        for (u32 si = pf; si != CBH_NONE && !pe; si = uchain_next(t, uload(&t.scope_parent[si]), FLAG_PRIN))
+          pe = udir_find(t, CBH_B_PPEXISTS, g_pv, si, 0, v);                            // index.go:999-1021
       for (u32 si = rf; si != CBH_NONE && !re; si = uchain_next(t, uload(&t.scope_parent[si]), FLAG_RES)) {
         if (udir_find(t, CBH_B_RESEXISTS, g_rv, g_k, si, v)) { re = true; break; }      // index.go:966-997
         if (has_rolepol && udir_find(t, CBH_B_RPRES, g_rv, si, 0, v))
@@ -807,7 +813,10 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
     // a definitive principal-policy result ends the action (check.go:445-448)
     todo &= ~(eff_allow | eff_deny);
   };
-  if (n_pass) { policy_pass(CbhPassPrincipal{}); policy_pass(CbhPassResource{}); }
+  if (n_pass) {
+    if constexpr (F_PP) policy_pass(CbhPassPrincipal{});
+    policy_pass(CbhPassResource{});
+  }
 
 #ifdef CBH_PROFILE_CYCLES
   if ((flags & CBH_F_DEBUG_CYCLES) && want_ps && act_cnt >= 3) {
@@ -929,15 +938,16 @@ CBH_DEFINE_CHECK_KERNELS(u32, 0, _a32_f0)                                       
 CBH_DEFINE_CHECK_KERNELS(u32, CBH_FEAT_DERIVED_ROLES, _a32_f1)                              // + derived roles
 CBH_DEFINE_CHECK_KERNELS(u32, CBH_FEAT_GLOBS, _a32_f4)                                      // plain + glob patterns
 CBH_DEFINE_CHECK_KERNELS(u32, CBH_FEAT_DERIVED_ROLES | CBH_FEAT_GLOBS, _a32_f5)             // derived roles + globs
-CBH_DEFINE_CHECK_KERNELS(u32, CBH_FEAT_DERIVED_ROLES | CBH_FEAT_ROLE_POLICIES | CBH_FEAT_GLOBS, _a32)   // everything
-CBH_DEFINE_CHECK_KERNELS(u64, CBH_FEAT_DERIVED_ROLES | CBH_FEAT_ROLE_POLICIES | CBH_FEAT_GLOBS, )       // everything, > 32 actions
+CBH_DEFINE_CHECK_KERNELS(u32, CBH_FEAT_ALL, _a32)   // everything: + role policies, parent roles, principal policies
+CBH_DEFINE_CHECK_KERNELS(u64, CBH_FEAT_ALL, )       // everything, > 32 actions
 
 typedef void (*cbh_check_kernel_fn)(const KernelArgs, const KernelArgs*);
 // the instantiation for a table (its meta flags, number of derived-role records) and a batch
 static inline cbh_check_kernel_fn cbh_pick_check_kernel(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 max_actions) {
   const int g = (table_flags & CBH_MF_HAS_GENERIC_PROGRAMS) ? 1 : 0;
   if (max_actions > 32) return g ? cbh_check_kernel : cbh_check_kernel_leaf;
-  if (table_flags & (CBH_MF_HAS_ROLE_POLICIES | CBH_MF_HAS_PARENT_ROLES)) return g ? cbh_check_kernel_a32 : cbh_check_kernel_leaf_a32;
+  if (table_flags & (CBH_MF_HAS_ROLE_POLICIES | CBH_MF_HAS_PARENT_ROLES | CBH_MF_HAS_PRINCIPAL_POLICIES))
+    return g ? cbh_check_kernel_a32 : cbh_check_kernel_leaf_a32;
   const bool dr = n_derived_roles || (table_flags & CBH_MF_USES_RUNTIME_EDR);
   static const cbh_check_kernel_fn tab[2][2][2] = {   // [globs][derived roles][generic]
       {{cbh_check_kernel_leaf_a32_f0, cbh_check_kernel_a32_f0}, {cbh_check_kernel_leaf_a32_f1, cbh_check_kernel_a32_f1}},

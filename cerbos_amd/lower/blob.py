@@ -25,7 +25,7 @@ from .celc import LoweringError, Params, ProgramBuilder
 from .globs import GlobNFA, fix_glob, has_meta
 
 BLOB_MAGIC = 0x31484243
-BLOB_VERSION = 12
+BLOB_VERSION = 13
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
 PAT_ANY = 0x7FFFFFFF     # the lone "*": matches every string, no automaton needed
@@ -417,7 +417,8 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
                      | (2 if any(v for r in rt["parent_roles"].values() for v in r.values()) else 0)
                      | (4 if rp_buckets else 0)
                      | (8 if pb.has_generic else 0)
-                     | (16 if used_any else 0))
+                     | (16 if used_any else 0)
+                     | (32 if pp_exists else 0))
     meta[M_MAX_STACK] = pb.max_stack
     meta[M_NDRNAMES] = len(lt.dr_names)
     meta[M_NFA_WORDS_ACTION] = lt.nfas[0].words
@@ -490,7 +491,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         "generic_programs": bool(pb.has_generic),   # selects the kernel with the operand-stack interpreter
         # feature class of the 32-bit-mask kernels (cbh_pick_check_kernel): "" = everything (role policies /
         # parent roles), else "_f<bits>" with bit 0 = derived roles, bit 2 = glob patterns
-        "kernel_features": ("" if int(meta[M_FLAGS]) & 6 else "_f%d" % (
+        "kernel_features": ("" if int(meta[M_FLAGS]) & (2 | 4 | 32) else "_f%d" % (
             (1 if (len(dr_cols[0]) or int(meta[M_FLAGS]) & MF_USES_RUNTIME_EDR) else 0)
             | (4 if (used_any or any(lt.nfas[d].patterns for d in range(3))) else 0))),
     }
