@@ -224,7 +224,9 @@ def main():
         achieved = alg * tuples / (check_ms * 1e-3) / 1e9
         # the instantiation cbh_check_resident picks for this table / batch (cbh_engine.hip)
         kernel = "cbh_check_kernel" + ("" if lt.stats["generic_programs"] else "_leaf") + \
-                 ("_a32" + lt.stats["kernel_features"] if int(batch.req_u32[15].max()) <= 32 else "")
+                 (("_a4" if (int(batch.req_u32[15].max()) <= 4 and not lt.stats["generic_programs"]
+                             and lt.stats["kernel_features"]) else "_a32") + lt.stats["kernel_features"]
+                  if int(batch.req_u32[15].max()) <= 32 else "")
         out = {
             "metric": "CheckResources decisions/sec at batch=1M; p50 per-decision us",
             "value": total / elapsed,

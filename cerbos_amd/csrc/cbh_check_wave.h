@@ -364,6 +364,7 @@ struct CbhPassResource { static constexpr bool value = true; };     // policy pa
 #define CBH_FEAT_GLOBS 4          /* glob patterns in some dimension (action / role / kind) */
 #define CBH_FEAT_PRINCIPAL_POLICIES 8
 #define CBH_FEAT_ALL 15
+#define CBH_FEAT_MAX4 16          /* a property of the batch, not the table: at most four actions per request */
 
 template <bool GENERIC, typename AM, int FEAT>   // AM: per-request action mask, u32 when no request of the batch carries more than 32 actions
 __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
@@ -425,6 +426,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   constexpr bool F_DR = (FEAT & CBH_FEAT_DERIVED_ROLES) != 0, F_RP = (FEAT & CBH_FEAT_ROLE_POLICIES) != 0;
   constexpr bool F_GLOB = (FEAT & CBH_FEAT_GLOBS) != 0;
   constexpr bool F_PP = (FEAT & CBH_FEAT_PRINCIPAL_POLICIES) != 0;
+  constexpr bool F_MAX4 = (FEAT & CBH_FEAT_MAX4) != 0;   // no request of the batch has more than four actions
   constexpr u32 GLOBBIT = F_GLOB ? CBH_PAT_GLOB : 0u;   // no glob patterns in the table: every pattern reference is a literal
   auto pmatch = [&](u32 pref, u32 sid, u64 bits) -> bool { return (F_GLOB && pref == CBH_PAT_ANY) || ((pref & GLOBBIT) ? ((bits >> (pref & 63u)) & 1ull) != 0 : pref == sid); };
   const bool want_edr = F_DR && ((flags & CBH_F_WANT_DERIVED_ROLES) != 0 || (t.flags & CBH_MF_USES_RUNTIME_EDR) != 0);
@@ -441,7 +443,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
     if (F_GLOB && pat == CBH_PAT_ANY) return all;
     if (!(pat & GLOBBIT)) {
       m = (AM)(a0 == pat) | ((AM)(a1 == pat) << 1) | ((AM)(a2 == pat) << 2) | ((AM)(a3 == pat) << 3);
-      for (u32 k = 4; k < act_cnt; ++k) m |= (AM)(b.tuple_action[act_off + k] == pat) << k;
+      if (!F_MAX4) for (u32 k = 4; k < act_cnt; ++k) m |= (AM)(b.tuple_action[act_off + k] == pat) << k;
     } else {
       const u32 gi = pat & 63u;
       for (u32 k = 0; k < act_cnt; ++k)
@@ -464,7 +466,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
     if (mask & 2) { PS_POL(1) = polw; PS_SCP(1) = scpw; }
     if (mask & 4) { PS_POL(2) = polw; PS_SCP(2) = scpw; }
     if (mask & 8) { PS_POL(3) = polw; PS_SCP(3) = scpw; }
-    mask &= ~(AM)0xF;
+    mask &= F_MAX4 ? (AM)0 : ~(AM)0xF;
     while (mask) {
       const u32 k = (u32)__builtin_ctzll((u64)mask);
       mask &= mask - 1;
@@ -940,6 +942,15 @@ CBH_DEFINE_CHECK_KERNELS(u32, CBH_FEAT_GLOBS, _a32_f4)                          
 CBH_DEFINE_CHECK_KERNELS(u32, CBH_FEAT_DERIVED_ROLES | CBH_FEAT_GLOBS, _a32_f5)             // derived roles + globs
 CBH_DEFINE_CHECK_KERNELS(u32, CBH_FEAT_ALL, _a32)   // everything: + role policies, parent roles, principal policies
 CBH_DEFINE_CHECK_KERNELS(u64, CBH_FEAT_ALL, )       // everything, > 32 actions
+// the leaf kernels of the four common table classes once more for batches with <= 4 actions per request
+#define CBH_DEFINE_LEAF_A4(FEAT, SUF)                                                                                          \
+  __global__ __launch_bounds__(CBH_BLOCK) CBH_FOUR_WAVES void cbh_check_kernel_leaf##SUF(const KernelArgs a, const KernelArgs* __restrict__ ka) { \
+    leaf_kernel_body<u32, (FEAT) | CBH_FEAT_MAX4>(a, ka);                                                                      \
+  }
+CBH_DEFINE_LEAF_A4(0, _a4_f0)
+CBH_DEFINE_LEAF_A4(CBH_FEAT_DERIVED_ROLES, _a4_f1)
+CBH_DEFINE_LEAF_A4(CBH_FEAT_GLOBS, _a4_f4)
+CBH_DEFINE_LEAF_A4(CBH_FEAT_DERIVED_ROLES | CBH_FEAT_GLOBS, _a4_f5)
 
 typedef void (*cbh_check_kernel_fn)(const KernelArgs, const KernelArgs*);
 // the instantiation for a table (its meta flags, number of derived-role records) and a batch
@@ -952,5 +963,10 @@ static inline cbh_check_kernel_fn cbh_pick_check_kernel(u32 table_flags, u32 n_d
   static const cbh_check_kernel_fn tab[2][2][2] = {   // [globs][derived roles][generic]
       {{cbh_check_kernel_leaf_a32_f0, cbh_check_kernel_a32_f0}, {cbh_check_kernel_leaf_a32_f1, cbh_check_kernel_a32_f1}},
       {{cbh_check_kernel_leaf_a32_f4, cbh_check_kernel_a32_f4}, {cbh_check_kernel_leaf_a32_f5, cbh_check_kernel_a32_f5}}};
+  if (!g && max_actions <= 4) {
+    static const cbh_check_kernel_fn tab4[2][2] = {{cbh_check_kernel_leaf_a4_f0, cbh_check_kernel_leaf_a4_f1},
+                                                   {cbh_check_kernel_leaf_a4_f4, cbh_check_kernel_leaf_a4_f5}};
+    return tab4[has_globs ? 1 : 0][dr ? 1 : 0];
+  }
   return tab[has_globs ? 1 : 0][dr ? 1 : 0][g];
 }

@@ -81,10 +81,10 @@ extern "C" const char* hostsim_last_error() { return g_err.c_str(); }
 
 static KernelArgs* g_args;
 
-static bool g_a32;   // same kernel selection as cbh_check_resident (cbh_engine.hip)
+static uint32_t g_max_actions;   // same kernel selection as cbh_check_resident (cbh_engine.hip)
 
 static void fiber_main() {
-  cbh_pick_check_kernel(g_args->t.flags, g_args->t.n_dr, (g_args->t.nfa_words[0] | g_args->t.nfa_words[1] | g_args->t.nfa_words[2] | (g_args->t.flags & CBH_MF_HAS_ANY_PATTERN)) != 0, g_a32 ? 1u : 64u)(*g_args, g_args);
+  cbh_pick_check_kernel(g_args->t.flags, g_args->t.n_dr, (g_args->t.nfa_words[0] | g_args->t.nfa_words[1] | g_args->t.nfa_words[2] | (g_args->t.flags & CBH_MF_HAS_ANY_PATTERN)) != 0, g_max_actions)(*g_args, g_args);
   g_fibers[g_cur].done = true;
   g_fibers[g_cur].waiting = 0;
   swapcontext(&g_fibers[g_cur].ctx, &g_sched);
@@ -167,7 +167,7 @@ extern "C" int hostsim_check(const void* blob, size_t len, const cbh_batch* in, 
   uint32_t max_actions = 0;
   for (uint32_t r = 0; r < in->n_requests; ++r)
     max_actions = std::max(max_actions, in->req_u32[(size_t)CBH_RQ_ACT_CNT * in->n_requests + r]);
-  g_a32 = max_actions <= 32;
+  g_max_actions = max_actions;
   const uint32_t nblocks = (in->n_requests + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
   for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
   return 0;
