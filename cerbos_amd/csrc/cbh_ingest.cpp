@@ -1,0 +1,586 @@
+// cbh_ingest.cpp - libcerbos_ingest.so: serialized enginev1.CheckInput -> cbh_batch (include/cerbos_ingest.h).
+//
+// Host-only C++ (no HIP, no protobuf runtime): the wire format is walked in place, attribute columns are
+// looked up directly in the serialized google.protobuf.Struct maps, and only the values a column selects
+// are materialised (scalars inline, lists / maps as tapes in the batch heap).  The interning order, heap
+// order and routing sort are those of cerbos_amd/flatten.py - tests/test_ingest.py compares every array.
+//
+// Reference behaviour restated (never copied):
+//   internal/ruletable/check.go:536-554     checkInputToRequest (which fields a condition can see)
+//   internal/ruletable/check.go:101-117     effective scope / policy version of principal and resource
+//   internal/evaluator/evaluator.go:108-122 defaults (EvalParams.DefaultScope / DefaultPolicyVersion)
+//   internal/namer/namer.go:213-218         SanitizedResource; :77-87 ScopeParents; :276-278 ScopeValue
+//   api/public/cerbos/engine/v1/engine.proto:130-200 field numbers of CheckInput / Resource / Principal / AuxData
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/cerbos_ingest.h"
+#include "cbh_blob.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string& m) { g_err = m; return -1; }
+
+using u8 = uint8_t; using u32 = uint32_t; using u64 = uint64_t;
+
+// ---- protobuf wire walking -------------------------------------------------------------------------
+struct Span { const u8* p; const u8* e; bool empty() const { return p >= e; } };
+struct Field { u32 num; u32 wt; u64 v; Span s; };   // v: varint / fixed value, s: length-delimited payload
+
+bool varint(Span& s, u64& out) {
+  u64 r = 0;
+  for (int sh = 0; sh < 64 && s.p < s.e; sh += 7) {
+    u8 b = *s.p++;
+    r |= (u64)(b & 0x7F) << sh;
+    if (!(b & 0x80)) { out = r; return true; }
+  }
+  return false;
+}
+
+// Next field of a message; false at the end or on malformed input (`bad` set).
+bool next(Span& s, Field& f, bool& bad) {
+  if (s.empty()) return false;
+  u64 key;
+  if (!varint(s, key)) { bad = true; return false; }
+  f.num = (u32)(key >> 3); f.wt = (u32)(key & 7);
+  switch (f.wt) {
+    case 0: if (!varint(s, f.v)) { bad = true; return false; } return true;
+    case 1: if (s.e - s.p < 8) { bad = true; return false; } memcpy(&f.v, s.p, 8); s.p += 8; return true;
+    case 5: if (s.e - s.p < 4) { bad = true; return false; } { u32 w; memcpy(&w, s.p, 4); f.v = w; } s.p += 4; return true;
+    case 2: {
+      u64 n;
+      if (!varint(s, n) || n > (u64)(s.e - s.p)) { bad = true; return false; }
+      f.s = Span{s.p, s.p + n}; s.p += n; return true;
+    }
+    default: bad = true; return false;
+  }
+}
+
+std::string_view sv(Span s) { return std::string_view((const char*)s.p, (size_t)(s.e - s.p)); }
+
+// map<string, google.protobuf.Value> entry: key = 1, value = 2
+struct Entry { Span key{nullptr, nullptr}; Span val{nullptr, nullptr}; };
+bool entry(Span e, Entry& out, bool& bad) {
+  Field f;
+  while (next(e, f, bad)) {
+    if (f.num == 1 && f.wt == 2) out.key = f.s;
+    else if (f.num == 2 && f.wt == 2) out.val = f.s;
+  }
+  return !bad;
+}
+
+// Looks `key` up in the map field `fnum` of message `msg` (last entry wins, as protobuf maps decode).
+bool map_get(Span msg, u32 fnum, std::string_view key, Span& val, bool& bad) {
+  Field f; bool found = false;
+  while (next(msg, f, bad)) {
+    if (f.num != fnum || f.wt != 2) continue;
+    Entry en;
+    if (!entry(f.s, en, bad)) return false;
+    if (sv(en.key) == key) { val = en.val; found = true; }
+  }
+  return found;
+}
+
+// google.protobuf.Value oneof: null 1, number 2 (double), string 3, bool 4, struct 5, list 6.  The last
+// field present wins; an empty message is null.
+struct Val { u32 kind = 1; u64 v = 0; Span s{nullptr, nullptr}; };
+bool value(Span m, Val& out, bool& bad) {
+  Field f;
+  while (next(m, f, bad)) {
+    if (f.num >= 1 && f.num <= 6) { out.kind = f.num; out.v = f.v; out.s = f.s; }
+  }
+  return !bad;
+}
+
+// ---- string dictionaries ---------------------------------------------------------------------------------
+inline u64 hash_bytes(std::string_view s) {
+  const char* p = s.data(); size_t n = s.size();
+  u64 h = 0x9E3779B97F4A7C15ull ^ (n * 0xff51afd7ed558ccdull);
+  while (n >= 8) { u64 w; memcpy(&w, p, 8); h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 29; p += 8; n -= 8; }
+  if (n) { u64 w = 0; memcpy(&w, p, n); h = (h ^ w) * 0xff51afd7ed558ccdull; h ^= h >> 29; }
+  return h ^ (h >> 32);
+}
+
+// Open-addressing set of string ids; the strings themselves live wherever `at(id)` finds them.
+struct StrIndex {
+  struct Slot { u32 h; u32 id1; };   // id1 = id + 1, 0 = empty
+  std::vector<Slot> slots;
+  u32 used = 0;
+  StrIndex() : slots(64, Slot{0, 0}) {}
+  template <class At> bool find(std::string_view s, u64 h, At at, u32& id) const {
+    const u32 mask = (u32)slots.size() - 1, h32 = (u32)h;
+    for (u32 i = h32 & mask;; i = (i + 1) & mask) {
+      const Slot& sl = slots[i];
+      if (!sl.id1) return false;
+      if (sl.h == h32 && at(sl.id1 - 1) == s) { id = sl.id1 - 1; return true; }
+    }
+  }
+  void insert(u64 h, u32 id) {   // the caller knows the string is absent
+    if ((used + 1) * 2 > slots.size()) {
+      std::vector<Slot> old(slots.size() * 2, Slot{0, 0});
+      old.swap(slots);
+      for (const Slot& sl : old) if (sl.id1) place(sl);
+    }
+    place(Slot{(u32)h, id + 1});
+    ++used;
+  }
+  void reserve(size_t n) {
+    size_t want = 64;
+    while (want < 4 * n) want *= 2;
+    if (want > slots.size() && !used) slots.assign(want, Slot{0, 0});
+  }
+  void place(Slot s) {
+    const u32 mask = (u32)slots.size() - 1;
+    u32 i = s.h & mask;
+    while (slots[i].id1) i = (i + 1) & mask;
+    slots[i] = s;
+  }
+};
+
+struct Column { u32 root; std::vector<std::string> keys; };
+
+}  // namespace
+
+struct cbi_table {
+  std::vector<u8> blob;
+  u32 K = 0;
+  const u32* str_off = nullptr;      // table string pool (views into blob)
+  const char* str_bytes = nullptr;
+  StrIndex ids;                      // table string -> id
+  std::unordered_map<std::string, u32> scope_index;    // scope -> index
+  std::vector<Column> columns;
+  std::string_view at(u32 i) const { return std::string_view(str_bytes + str_off[i], str_off[i + 1] - str_off[i]); }
+};
+
+struct cbi_batch {
+  cbh_batch view{};
+  std::vector<u32> req, roles, tuple_req, tuple_action, str_off, req_input;
+  std::vector<u8> col_tag, heap_tag, str_bytes, str_flags;
+  std::vector<u64> col_val, heap_val, tuple_perm;
+};
+
+namespace {
+
+enum { T_NULL = 0, T_BOOL = 1, T_DOUBLE = 4, T_STRING = 5, T_LIST = 6, T_MAP = 7, T_ABSENT = 0xF0, T_ERR = 0xFF };
+enum { RQ_PRINCIPAL_ID, RQ_P_SCOPE, RQ_P_VERSION, RQ_KIND, RQ_R_SCOPE, RQ_R_VERSION, RQ_ROLE_OFF, RQ_ROLE_CNT,
+       RQ_S_RESOURCE_ID, RQ_S_KIND, RQ_S_P_SCOPE, RQ_S_R_SCOPE, RQ_S_P_VERSION, RQ_S_R_VERSION, RQ_ACT_OFF, RQ_ACT_CNT, RQ_N };
+constexpr u32 SCOPE_EXACT = 0x80000000u;
+constexpr u32 MAX_ACTIONS = 64;
+constexpr u32 SF_ACTION = 1, SF_ROLE = 2, SF_KIND = 4;
+
+// namer.go:276-278
+std::string_view scope_value(std::string_view s) { return (!s.empty() && s[0] == '.') ? s.substr(1) : s; }
+
+bool name_char(char c) {
+  return (c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '_' || c == '@' || c == '.' || c == '-' || c == '/';
+}
+bool alpha(char c) { return (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z'); }
+
+// namer.go:213-218: a name of the pre-0.30 form (segments "[A-Za-z][0-9A-Za-z_@.\-/]*" joined by ':') has
+// every run of characters outside [0-9A-Za-z_.] replaced by one '_'; any other name is kept as it is.
+std::string_view sanitize(std::string_view v, std::string& out) {
+  bool plain = true;
+  for (char c : v) if (!((c >= '0' && c <= '9') || alpha(c) || c == '_' || c == '.')) { plain = false; break; }
+  if (plain) return v;   // nothing to rewrite whichever form it is
+  bool old_form = !v.empty();
+  bool seg_start = true;
+  for (char c : v) {
+    if (seg_start) { if (!alpha(c)) { old_form = false; break; } seg_start = false; }
+    else if (c == ':') seg_start = true;
+    else if (!name_char(c)) { old_form = false; break; }
+  }
+  if (seg_start) old_form = false;
+  if (!old_form) return v;
+  out.clear(); bool in_run = false;
+  for (char c : v) {
+    bool ok = (c >= '0' && c <= '9') || alpha(c) || c == '_' || c == '.';
+    if (ok) { out.push_back(c); in_run = false; }
+    else if (!in_run) { out.push_back('_'); in_run = true; }
+  }
+  return out;
+}
+
+struct Interner {
+  const cbi_table* t;
+  cbi_batch* b;
+  StrIndex local;
+  u32 sid(std::string_view s, u32 flag = 0) {
+    const u64 h = hash_bytes(s);
+    u32 id;
+    if (t->ids.find(s, h, [this](u32 i) { return t->at(i); }, id)) return id;
+    auto at = [this](u32 i) {
+      return std::string_view((const char*)b->str_bytes.data() + b->str_off[i], b->str_off[i + 1] - b->str_off[i]);
+    };
+    if (local.find(s, h, at, id)) {
+      if (flag) b->str_flags[id] |= (u8)flag;
+    } else {
+      id = (u32)b->str_flags.size();
+      b->str_bytes.insert(b->str_bytes.end(), s.begin(), s.end());
+      b->str_off.push_back((u32)b->str_bytes.size());
+      b->str_flags.push_back((u8)flag);
+      local.insert(h, id);
+    }
+    return t->K + id;
+  }
+  // Same, through a one-entry memo: request fields that rarely change from one message to the next
+  // (versions, scopes, kind) skip the hash.  The views stay valid for the whole call.
+  struct Memo { std::string_view s; u32 id = 0; bool set = false; };
+  Memo memo[8];
+  u32 sid_memo(u32 slot, std::string_view s, u32 flag = 0) {
+    Memo& m = memo[slot];
+    if (m.set && m.s == s) return m.id;
+    m.s = s; m.id = sid(s, flag); m.set = true;
+    return m.id;
+  }
+};
+
+struct TV { u8 tag; u64 val; };
+
+struct Encoder {
+  Interner& in;
+  cbi_batch* b;
+  bool bad = false;
+  int depth = 0;
+
+  u64 container(u32 off, size_t n) { return ((u64)1 << 62) | ((u64)off << 32) | (u64)n; }
+
+  // entries of a map<string, Value> field `fnum` of `msg`, children first, then the (key, value) pairs
+  TV enc_map(Span msg, u32 fnum) {
+    std::vector<TV> ents;
+    Field f;
+    while (next(msg, f, bad)) {
+      if (f.num != fnum || f.wt != 2) continue;
+      Entry en;
+      if (!entry(f.s, en, bad)) break;
+      ents.push_back(TV{(u8)T_STRING, in.sid(sv(en.key))});
+      ents.push_back(enc(en.val));
+    }
+    u32 off = (u32)b->heap_tag.size();
+    for (const TV& x : ents) { b->heap_tag.push_back(x.tag); b->heap_val.push_back(x.val); }
+    return TV{(u8)T_MAP, container(off, ents.size() / 2)};
+  }
+
+  TV enc(Span m) {
+    Val v;
+    if (!value(m, v, bad)) return TV{(u8)T_NULL, 0};
+    switch (v.kind) {
+      case 1: return TV{(u8)T_NULL, 0};
+      case 2: return TV{(u8)T_DOUBLE, v.v};                 // structpb: every number is a double
+      case 3: return TV{(u8)T_STRING, in.sid(sv(v.s))};
+      case 4: return TV{(u8)T_BOOL, v.v ? 1u : 0u};
+      case 5: {
+        if (++depth > 100) { bad = true; return TV{(u8)T_NULL, 0}; }
+        TV r = enc_map(v.s, 1);
+        --depth;
+        return r;
+      }
+      default: {  // 6: ListValue.values = 1
+        if (++depth > 100) { bad = true; return TV{(u8)T_NULL, 0}; }
+        std::vector<TV> vals;
+        Span l = v.s; Field f;
+        while (next(l, f, bad)) if (f.num == 1 && f.wt == 2) vals.push_back(enc(f.s));
+        --depth;
+        u32 off = (u32)b->heap_tag.size();
+        for (const TV& x : vals) { b->heap_tag.push_back(x.tag); b->heap_val.push_back(x.val); }
+        return TV{(u8)T_LIST, container(off, vals.size())};
+      }
+    }
+  }
+};
+
+struct ScopeCache {   // scope -> scope word, per call (the table stays immutable and shareable between threads)
+  StrIndex index;
+  std::vector<std::string> keys;
+  std::vector<u32> words;
+};
+
+u32 scope_word(const cbi_table* t, ScopeCache& sc, std::string_view scope) {
+  const u64 h = hash_bytes(scope);
+  u32 slot;
+  if (sc.index.find(scope, h, [&sc](u32 i) { return std::string_view(sc.keys[i]); }, slot)) return sc.words[slot];
+  std::string key(scope);
+  u32 w = 0;
+  auto it = t->scope_index.find(key);
+  if (it != t->scope_index.end()) w = it->second | SCOPE_EXACT;
+  else {
+    // namer.go:77-87: "a.b.c" -> "a.b", "a", ""
+    for (size_t i = scope.size(); i-- > 0;) {
+      if (scope[i] == '.' || i == 0) {
+        auto p = t->scope_index.find(std::string(scope.substr(0, i)));
+        if (p != t->scope_index.end()) { w = p->second; break; }
+      }
+    }
+  }
+  sc.index.insert(h, (u32)sc.keys.size());
+  sc.keys.push_back(std::move(key));
+  sc.words.push_back(w);
+  return w;
+}
+
+struct Msg {   // the pieces of one CheckInput
+  Span principal{nullptr, nullptr}, resource{nullptr, nullptr}, aux{nullptr, nullptr};
+};
+
+struct Party { std::string_view id, version, scope, kind; };
+
+}  // namespace
+
+extern "C" {
+
+const char* cbi_last_error(void) { return g_err.c_str(); }
+
+int cbi_table_open(const void* blob, size_t len, cbi_table** out) {
+  if (!blob || !out) return fail("cbi_table_open: null argument");
+  if (len < sizeof(CbhBlobHeader)) return fail("blob too small");
+  auto* t = new cbi_table();
+  t->blob.assign((const u8*)blob, (const u8*)blob + len);
+  const u8* base = t->blob.data();
+  auto* h = (const CbhBlobHeader*)base;
+  auto bail = [&](const char* m) { delete t; return fail(m); };
+  if (h->magic != CBH_BLOB_MAGIC) return bail("bad blob magic");
+  if (h->version != CBH_BLOB_VERSION) return bail("blob version mismatch: re-lower the rule table");
+  if (h->total_len != len || sizeof(CbhBlobHeader) + (u64)h->n_sections * sizeof(CbhBlobSection) > len) return bail("blob length mismatch");
+  auto* secs = (const CbhBlobSection*)(base + sizeof(CbhBlobHeader));
+  auto find = [&](u32 id) -> const CbhBlobSection* {
+    for (u32 i = 0; i < h->n_sections; ++i)
+      if (secs[i].id == id) return (secs[i].offset + secs[i].nbytes <= len) ? &secs[i] : nullptr;
+    return nullptr;
+  };
+  const CbhBlobSection *so = find(CBH_SEC_STR_OFF), *sb = find(CBH_SEC_STR_BYTES), *ss = find(CBH_SEC_SCOPE_SID), *sc = find(CBH_SEC_COLUMN_PATHS),
+                       *sm = find(CBH_SEC_META);
+  if (!so || !sb || !ss || !sc || !sm) return bail("blob is missing a section the ingest needs");
+  const u32* meta = (const u32*)(base + sm->offset);
+  t->K = meta[CBH_M_NSTRINGS];
+  if ((u64)(t->K + 1) * 4 > so->nbytes) return bail("string offset section too short");
+  const u32* off = (const u32*)(base + so->offset);
+  const char* bytes = (const char*)(base + sb->offset);
+  if (off[t->K] > sb->nbytes) return bail("string byte section too short");
+  t->str_off = off; t->str_bytes = bytes;
+  for (u32 i = 0; i < t->K; ++i) {
+    if (off[i + 1] < off[i] || off[i + 1] > off[t->K]) { delete t; return fail("string offsets are not monotonic"); }
+    t->ids.insert(hash_bytes(t->at(i)), i);
+  }
+  u32 ns = meta[CBH_M_NSCOPES];
+  if ((u64)ns * 4 > ss->nbytes) return bail("scope section too short");
+  const u32* ssid = (const u32*)(base + ss->offset);
+  for (u32 i = 0; i < ns; ++i) {
+    if (ssid[i] >= t->K) return bail("scope string id out of range");
+    t->scope_index.emplace(std::string(bytes + off[ssid[i]], off[ssid[i] + 1] - off[ssid[i]]), i);
+  }
+  const u8* p = base + sc->offset; const u8* e = p + sc->nbytes;
+  u32 ncol = meta[CBH_M_NCOLUMNS];
+  for (u32 c = 0; c < ncol; ++c) {
+    if (e - p < 2) return bail("column path section truncated");
+    Column col; col.root = p[0]; u32 nk = p[1]; p += 2;
+    if (col.root > 2) return bail("bad column root");
+    for (u32 k = 0; k < nk; ++k) {
+      if (e - p < 2) return bail("column path section truncated");
+      u32 l = p[0] | (p[1] << 8); p += 2;
+      if ((u32)(e - p) < l) return bail("column path section truncated");
+      col.keys.emplace_back((const char*)p, l); p += l;
+    }
+    t->columns.push_back(std::move(col));
+  }
+  *out = t;
+  return 0;
+}
+
+void cbi_table_close(cbi_table* t) { delete t; }
+
+int cbi_flatten_pb(const cbi_table* t, const uint8_t* bytes, const uint64_t* offsets, uint32_t n, const char* default_version,
+                   const char* default_scope, int sort, cbi_batch** out) {
+  if (!t || !out || (n && (!bytes || !offsets))) return fail("cbi_flatten_pb: null argument");
+  std::string_view dver = default_version ? default_version : "default";
+  std::string_view dscope = default_scope ? default_scope : "";
+  auto b = new cbi_batch();
+  auto bail = [&](const std::string& m) { delete b; return fail(m); };
+  const u32 ncol = (u32)t->columns.size();
+
+  // pass 1: count device requests (a CheckInput with > 64 actions becomes several) and tuples
+  u64 nreq = 0, ntup = 0;
+  for (u32 i = 0; i < n; ++i) {
+    if (offsets[i + 1] < offsets[i]) return bail("offsets must not decrease");
+    Span m{bytes + offsets[i], bytes + offsets[i + 1]};
+    Field f; bool bad = false; size_t na = 0;
+    while (next(m, f, bad)) na += (f.num == 4 && f.wt == 2);
+    if (bad) return bail("malformed CheckInput at index " + std::to_string(i));
+    nreq += na ? (na + MAX_ACTIONS - 1) / MAX_ACTIONS : 1;
+    ntup += na;
+  }
+  if (nreq > 0xFFFFFFFFull || ntup > 0xFFFFFFFFull) return bail("batch too large");
+  const u32 R = (u32)nreq;
+  b->req.assign((size_t)RQ_N * R, 0);
+  b->col_tag.assign((size_t)ncol * R, (u8)T_ABSENT);
+  b->col_val.assign((size_t)ncol * R, 0);
+  b->req_input.reserve(R);
+  b->tuple_req.reserve(ntup); b->tuple_action.reserve(ntup);
+  b->str_off.push_back(0);
+  b->str_bytes.reserve(1 << 16);
+  Interner in{t, b, {}, {}};
+  in.local.reserve(n);
+  Encoder encd{in, b};
+  ScopeCache scopes;
+  auto RQ = [&](u32 f, u32 r) -> u32& { return b->req[(size_t)f * R + r]; };
+
+  // per message scratch, reused
+  std::vector<std::string_view> actions, roles;
+  std::vector<Entry> attrs[3];   // entries of Principal.attr / Resource.attr / AuxData.jwt, wire order
+  std::string kind_buf;
+  bool need_root[3] = {false, false, false};
+  for (const Column& c : t->columns) need_root[c.root] = true;
+
+  u32 r = 0;
+  for (u32 i = 0; i < n; ++i) {
+    Msg m;
+    actions.clear(); roles.clear();
+    for (auto& a : attrs) a.clear();
+    bool bad = false;
+    { Span s{bytes + offsets[i], bytes + offsets[i + 1]}; Field f;
+      while (next(s, f, bad)) { if (f.wt != 2) continue;
+        if (f.num == 2) m.resource = f.s; else if (f.num == 3) m.principal = f.s; else if (f.num == 4) actions.push_back(sv(f.s)); else if (f.num == 5) m.aux = f.s; } }
+    // Principal: id 1, policy_version 2, roles 3, attr 4, scope 5;  Resource: kind 1, policy_version 2, id 3, attr 4, scope 5
+    Party P, Rs;
+    { Span s = m.principal; Field f;
+      while (next(s, f, bad)) { if (f.wt != 2) continue;
+        if (f.num == 1) P.id = sv(f.s); else if (f.num == 2) P.version = sv(f.s); else if (f.num == 3) roles.push_back(sv(f.s));
+        else if (f.num == 5) P.scope = sv(f.s);
+        else if (f.num == 4 && need_root[0]) { Entry en; if (entry(f.s, en, bad)) attrs[0].push_back(en); } } }
+    { Span s = m.resource; Field f;
+      while (next(s, f, bad)) { if (f.wt != 2) continue;
+        if (f.num == 1) Rs.kind = sv(f.s); else if (f.num == 2) Rs.version = sv(f.s); else if (f.num == 3) Rs.id = sv(f.s);
+        else if (f.num == 5) Rs.scope = sv(f.s);
+        else if (f.num == 4 && need_root[1]) { Entry en; if (entry(f.s, en, bad)) attrs[1].push_back(en); } } }
+    if (need_root[2]) { Span s = m.aux; Field f;
+      while (next(s, f, bad)) if (f.num == 1 && f.wt == 2) { Entry en; if (entry(f.s, en, bad)) attrs[2].push_back(en); } }
+    if (bad) return bail("malformed CheckInput at index " + std::to_string(i));
+    const size_t na = actions.size();
+    const size_t nchunks = na ? (na + MAX_ACTIONS - 1) / MAX_ACTIONS : 1;
+    for (size_t ch = 0; ch < nchunks; ++ch, ++r) {
+      b->req_input.push_back(i);
+      std::string_view p_scope = scope_value(P.scope.empty() ? dscope : P.scope);
+      std::string_view r_scope = scope_value(Rs.scope.empty() ? dscope : Rs.scope);
+      std::string_view p_ver = P.version.empty() ? dver : P.version;
+      std::string_view r_ver = Rs.version.empty() ? dver : Rs.version;
+      RQ(RQ_PRINCIPAL_ID, r) = in.sid(P.id);
+      RQ(RQ_P_SCOPE, r) = scope_word(t, scopes, p_scope);
+      RQ(RQ_P_VERSION, r) = in.sid_memo(0, p_ver);
+      { Interner::Memo& mk = in.memo[1];   // keyed by the raw kind, holds the id of the sanitised one
+        if (!(mk.set && mk.s == Rs.kind)) { mk.s = Rs.kind; mk.id = in.sid(sanitize(Rs.kind, kind_buf), SF_KIND); mk.set = true; }
+        RQ(RQ_KIND, r) = mk.id; }
+      RQ(RQ_R_SCOPE, r) = scope_word(t, scopes, r_scope);
+      RQ(RQ_R_VERSION, r) = in.sid_memo(2, r_ver);
+      RQ(RQ_ROLE_OFF, r) = (u32)b->roles.size();
+      RQ(RQ_ROLE_CNT, r) = (u32)roles.size();
+      for (std::string_view x : roles) b->roles.push_back(in.sid(x, SF_ROLE));
+      RQ(RQ_S_RESOURCE_ID, r) = in.sid(Rs.id);
+      RQ(RQ_S_KIND, r) = in.sid_memo(3, Rs.kind);
+      RQ(RQ_S_P_SCOPE, r) = in.sid_memo(4, scope_value(P.scope));
+      RQ(RQ_S_R_SCOPE, r) = in.sid_memo(5, scope_value(Rs.scope));
+      RQ(RQ_S_P_VERSION, r) = in.sid_memo(6, P.version);
+      RQ(RQ_S_R_VERSION, r) = in.sid_memo(7, Rs.version);
+      for (u32 c = 0; c < ncol; ++c) {
+        const Column& col = t->columns[c];
+        const std::vector<Entry>& root = attrs[col.root];
+        u8 tag = 0; u64 val = 0; bool done = false;
+        if (col.keys.empty()) {
+          // the whole root map: Principal.attr (4) / Resource.attr (4) / AuxData.jwt (1)
+          TV tv = encd.enc_map(col.root == 0 ? m.principal : col.root == 1 ? m.resource : m.aux, col.root == 2 ? 1 : 4);
+          tag = tv.tag; val = tv.val; done = true;
+        } else {
+          Span cur{nullptr, nullptr};
+          const size_t nk = col.keys.size();
+          for (size_t k = 0; k < nk && !done; ++k) {
+            bool found = false;
+            if (k == 0) {
+              for (const Entry& en : root) if (sv(en.key) == col.keys[0]) { cur = en.val; found = true; }   // last entry wins
+            } else {
+              Val v;
+              if (!value(cur, v, encd.bad) || v.kind != 5) { tag = (u8)T_ERR; done = true; break; }
+              found = map_get(v.s, 1, col.keys[k], cur, encd.bad);
+            }
+            if (!found) { tag = (k == nk - 1) ? (u8)T_ABSENT : (u8)T_ERR; done = true; }
+          }
+          if (!done) { TV tv = encd.enc(cur); tag = tv.tag; val = tv.val; }
+        }
+        b->col_tag[(size_t)c * R + r] = tag;
+        b->col_val[(size_t)c * R + r] = val;
+      }
+      if (encd.bad) return bail("malformed attribute value at index " + std::to_string(i));
+      RQ(RQ_ACT_OFF, r) = (u32)b->tuple_action.size();
+      size_t a0 = ch * MAX_ACTIONS, a1 = std::min(na, a0 + MAX_ACTIONS);
+      RQ(RQ_ACT_CNT, r) = (u32)(a1 - a0);
+      for (size_t a = a0; a < a1; ++a) { b->tuple_req.push_back(r); b->tuple_action.push_back(in.sid(actions[a], SF_ACTION)); }
+    }
+  }
+
+  // routing sort (flatten.py sort_batch_by_route): kind, resource version, resource scope, role count,
+  // order-sensitive signature of the role list; stable
+  const u32 T = (u32)b->tuple_action.size();
+  b->tuple_perm.resize(T);
+  std::iota(b->tuple_perm.begin(), b->tuple_perm.end(), (u64)0);
+  if (sort && R > 1) {
+    std::vector<u64> sig(R, 0);
+    for (u32 q = 0; q < R; ++q) {
+      u32 off = RQ(RQ_ROLE_OFF, q), cnt = RQ(RQ_ROLE_CNT, q);
+      u64 s = 0;
+      for (u32 k = 0; k < cnt; ++k) s += ((u64)b->roles[off + k] + 1) * ((u64)k * 0x9E3779B97F4A7C15ull + 0xC2B2AE3D27D4EB4Full);
+      sig[q] = s;
+    }
+    std::vector<u32> order(R);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) {
+      u32 a, c;
+      if ((a = RQ(RQ_KIND, x)) != (c = RQ(RQ_KIND, y))) return a < c;
+      if ((a = RQ(RQ_R_VERSION, x)) != (c = RQ(RQ_R_VERSION, y))) return a < c;
+      if ((a = RQ(RQ_R_SCOPE, x)) != (c = RQ(RQ_R_SCOPE, y))) return a < c;
+      if ((a = RQ(RQ_ROLE_CNT, x)) != (c = RQ(RQ_ROLE_CNT, y))) return a < c;
+      return sig[x] < sig[y];
+    });
+    bool identity = true;
+    for (u32 q = 0; q < R; ++q) if (order[q] != q) { identity = false; break; }
+    if (!identity) {
+      std::vector<u32> req2((size_t)RQ_N * R), ta(T), tr(T), ri(R);
+      std::vector<u8> ct((size_t)ncol * R);
+      std::vector<u64> cv((size_t)ncol * R), tp(T);
+      u32 pos = 0;
+      for (u32 q = 0; q < R; ++q) {
+        u32 o = order[q];
+        for (u32 f = 0; f < RQ_N; ++f) req2[(size_t)f * R + q] = b->req[(size_t)f * R + o];
+        for (u32 c = 0; c < ncol; ++c) { ct[(size_t)c * R + q] = b->col_tag[(size_t)c * R + o]; cv[(size_t)c * R + q] = b->col_val[(size_t)c * R + o]; }
+        u32 s0 = RQ(RQ_ACT_OFF, o), cn = RQ(RQ_ACT_CNT, o);
+        req2[(size_t)RQ_ACT_OFF * R + q] = pos;
+        for (u32 k = 0; k < cn; ++k, ++pos) { ta[pos] = b->tuple_action[s0 + k]; tr[pos] = q; tp[pos] = s0 + k; }
+        ri[q] = b->req_input[o];
+      }
+      b->req.swap(req2); b->col_tag.swap(ct); b->col_val.swap(cv);
+      b->tuple_action.swap(ta); b->tuple_req.swap(tr); b->tuple_perm.swap(tp); b->req_input.swap(ri);
+    }
+  }
+
+  // never hand out null pointers for empty arrays
+  auto nz32 = [](std::vector<u32>& v) { if (v.empty()) v.reserve(1); return v.data(); };
+  cbh_batch& v = b->view;
+  v.n_requests = R; v.n_tuples = T; v.n_roles = (u32)b->roles.size(); v.n_columns = ncol;
+  v.n_strings = (u32)b->str_flags.size(); v.heap_len = (u32)b->heap_tag.size(); v.str_bytes_len = b->str_bytes.size();
+  b->heap_tag.reserve(1); b->heap_val.reserve(1); b->str_bytes.reserve(1); b->str_flags.reserve(1);
+  b->col_tag.reserve(1); b->col_val.reserve(1); b->tuple_perm.reserve(1); b->req_input.reserve(1);
+  v.req_u32 = nz32(b->req); v.roles = nz32(b->roles); v.tuple_req = nz32(b->tuple_req); v.tuple_action = nz32(b->tuple_action);
+  v.col_tag = b->col_tag.data(); v.col_val = b->col_val.data(); v.heap_tag = b->heap_tag.data(); v.heap_val = b->heap_val.data();
+  v.str_off = b->str_off.data(); v.str_bytes = b->str_bytes.data(); v.str_flags = b->str_flags.data();
+  *out = b;
+  return 0;
+}
+
+void cbi_batch_free(cbi_batch* b) { delete b; }
+const cbh_batch* cbi_batch_view(const cbi_batch* b) { return b ? &b->view : nullptr; }
+const uint64_t* cbi_batch_tuple_perm(const cbi_batch* b) { return b ? b->tuple_perm.data() : nullptr; }
+const uint32_t* cbi_batch_request_input(const cbi_batch* b) { return b ? b->req_input.data() : nullptr; }
+
+}  // extern "C"

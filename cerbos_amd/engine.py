@@ -52,13 +52,19 @@ class Conf:
 
 
 class HipEvaluator:
-    def __init__(self, lowered: LoweredTable, conf: Conf = None, device: int = 0):
+    def __init__(self, lowered: LoweredTable, conf: Conf = None, device: int = 0, native_ingest: bool = False):
+        """``native_ingest``: flatten through the protobuf wire format and libcerbos_ingest.so (what a Go
+        caller does, include/cerbos_ingest.h) instead of the Python flattener; same batch either way."""
         self.conf = conf or Conf()
         self.lt = lowered
         if capi._inited_device is None:
             capi.init(device)
         self.table = capi.Table(lowered.blob)
-        self.flattener = Flattener(lowered)
+        if native_ingest:
+            from .ingest import WireFlattener
+            self.flattener = WireFlattener(lowered)
+        else:
+            self.flattener = Flattener(lowered)
 
     # -- constructors ---------------------------------------------------------------------
     @classmethod

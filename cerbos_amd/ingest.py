@@ -1,0 +1,123 @@
+"""ctypes binding of ``libcerbos_ingest.so`` (include/cerbos_ingest.h): serialized ``CheckInput`` messages ->
+``flatten.Batch``, by the C++ ingest instead of the Python flattener.
+
+The C++ ingest and ``flatten.Flattener`` implement the same contract (tests/test_ingest.py compares them
+array for array); this module exists so Python callers, the tests and the bench can drive the native one.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+from .flatten import RQ_NFIELDS, Batch
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcerbos_ingest.so")
+_lib = None
+
+
+class IngestError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IngestError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        lib.cbi_last_error.restype = C.c_char_p
+        lib.cbi_table_open.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+        lib.cbi_table_close.argtypes = [vp]
+        lib.cbi_table_close.restype = None
+        lib.cbi_flatten_pb.argtypes = [vp, vp, vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
+        lib.cbi_batch_free.argtypes = [vp]
+        lib.cbi_batch_free.restype = None
+        lib.cbi_batch_view.argtypes = [vp]
+        lib.cbi_batch_view.restype = C.POINTER(capi.CBatch)
+        lib.cbi_batch_tuple_perm.argtypes = [vp]
+        lib.cbi_batch_tuple_perm.restype = C.POINTER(C.c_uint64)
+        lib.cbi_batch_request_input.argtypes = [vp]
+        lib.cbi_batch_request_input.restype = C.POINTER(C.c_uint32)
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise IngestError(load().cbi_last_error().decode("utf-8", "replace"))
+
+
+def _copy(ptr, ctype, dtype, n):
+    if not ptr or n == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)).astype(dtype, copy=True)
+
+
+class IngestTable:
+    """Host dictionaries of one lowered table image (``cbi_table``)."""
+
+    def __init__(self, blob: bytes):
+        self.h = C.c_void_p()
+        self._blob = bytes(blob)
+        _check(load().cbi_table_open(self._blob, len(self._blob), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            load().cbi_table_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def flatten_pb(self, data, offsets, default_policy_version="default", default_scope="", sort=True) -> Batch:
+        """``data``: uint8 array holding the messages back to back, ``offsets``: uint64[n + 1]."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        h = C.c_void_p()
+        _check(load().cbi_flatten_pb(self.h, data.ctypes.data if data.size else None, offsets.ctypes.data, n,
+                                     default_policy_version.encode(), default_scope.encode(), int(bool(sort)), C.byref(h)))
+        try:
+            v = load().cbi_batch_view(h).contents
+            b = Batch()
+            R, T = v.n_requests, v.n_tuples
+            b.n_requests, b.n_tuples, b.n_strings = R, T, v.n_strings
+            b.req_u32 = _copy(v.req_u32, C.c_uint32, np.uint32, RQ_NFIELDS * R).reshape(RQ_NFIELDS, R)
+            b.roles = _copy(v.roles, C.c_uint32, np.uint32, v.n_roles)
+            b.tuple_req = _copy(v.tuple_req, C.c_uint32, np.uint32, T)
+            b.tuple_action = _copy(v.tuple_action, C.c_uint32, np.uint32, T)
+            b.col_tag = _copy(v.col_tag, C.c_uint8, np.uint8, v.n_columns * R).reshape(v.n_columns, R)
+            b.col_val = _copy(v.col_val, C.c_uint64, np.uint64, v.n_columns * R).reshape(v.n_columns, R)
+            b.heap_tag = _copy(v.heap_tag, C.c_uint8, np.uint8, v.heap_len)
+            b.heap_val = _copy(v.heap_val, C.c_uint64, np.uint64, v.heap_len)
+            b.str_off = _copy(v.str_off, C.c_uint32, np.uint32, v.n_strings + 1)
+            b.str_bytes = _copy(v.str_bytes, C.c_uint8, np.uint8, v.str_bytes_len)
+            b.str_flags = _copy(v.str_flags, C.c_uint8, np.uint8, v.n_strings)
+            b.tuple_perm = _copy(load().cbi_batch_tuple_perm(h), C.c_uint64, np.int64, T)
+            b.req_perm = None
+            b.vreq_input = _copy(load().cbi_batch_request_input(h), C.c_uint32, np.int64, R)   # device request -> input
+            return b
+        finally:
+            load().cbi_batch_free(h)
+
+
+class WireFlattener:
+    """Drop-in for ``flatten.Flattener`` that goes through the wire format and the C++ ingest:
+    dict -> ``CheckInput`` bytes (wire.py) -> ``cbi_flatten_pb``."""
+
+    def __init__(self, lt):
+        self.table = IngestTable(lt.blob)
+
+    def flatten(self, inputs, default_policy_version="default", default_scope="", sort=True) -> Batch:
+        from . import wire
+        data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+        b = self.table.flatten_pb(data, off, default_policy_version, default_scope, sort)
+        b.actions_per_request = [list(inp.get("actions") or []) for inp in inputs]
+        return b

@@ -25,7 +25,7 @@ from .celc import LoweringError, Params, ProgramBuilder
 from .globs import GlobNFA, fix_glob, has_meta
 
 BLOB_MAGIC = 0x31484243
-BLOB_VERSION = 13
+BLOB_VERSION = 14
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
 PAT_ANY = 0x7FFFFFFF     # the lone "*": matches every string, no automaton needed
@@ -34,7 +34,7 @@ ROW_F_ACTION_LIST, ROW_F_ROLE_LIST = 4, 8
 (SEC_META, SEC_STR_OFF, SEC_STR_BYTES, SEC_SCOPE_PARENT, SEC_SCOPE_FLAGS, SEC_SCOPE_SID, SEC_HASH,
  SEC_ROWS, SEC_RPROWS, SEC_U32POOL, SEC_DR, SEC_CODE, SEC_CONST_TAG, SEC_CONST_VAL, SEC_THEAP_TAG,
  SEC_THEAP_VAL, SEC_GBITS, SEC_NFA_ACTION, SEC_NFA_ROLE, SEC_NFA_KIND, SEC_POLICY_SID,
- SEC_DRNAME_SID, SEC_CONST_REC, SEC_THEAP_REC, SEC_ROLE_CLASS) = range(1, 26)
+ SEC_DRNAME_SID, SEC_CONST_REC, SEC_THEAP_REC, SEC_ROLE_CLASS, SEC_COLUMN_PATHS) = range(1, 27)
 
 (M_NSTRINGS, M_NCOLUMNS, M_NSCOPES, M_HASH_MASK, M_NROWS, M_NRPROWS, M_NDR, M_NPOLICIES, M_NCONSTS,
  M_CODE_LEN, M_FLAGS, M_MAX_STACK, M_NDRNAMES, M_NFA_WORDS_ACTION, M_NFA_WORDS_ROLE,
@@ -480,6 +480,8 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         (SEC_CONST_REC, len(pb.const_tag), val_records(pb.const_tag, pb.const_val)),
         (SEC_THEAP_REC, len(pb.theap_tag), val_records(pb.theap_tag, pb.theap_val)),
         (SEC_ROLE_CLASS, K, role_class.tobytes()),
+        # host only: where each attribute column comes from (the C++ ingest walks these paths)
+        (SEC_COLUMN_PATHS, len(lt.columns), _column_paths(lt.columns)),
     ]
     lt.blob = _pack(sections)
     lt.stats = {
@@ -496,6 +498,18 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
             | (4 if (used_any or any(lt.nfas[d].patterns for d in range(3))) else 0))),
     }
     return lt
+
+
+def _column_paths(columns):
+    """Per column: u8 root (0 = P.attr, 1 = R.attr, 2 = auxData.jwt), u8 n_keys, then per key u16 length +
+    UTF-8 bytes."""
+    out = bytearray()
+    for root, keys in columns:
+        out += struct.pack("<BB", "PRJ".index(root), len(keys))
+        for k in keys:
+            kb = k.encode("utf-8")
+            out += struct.pack("<H", len(kb)) + kb
+    return bytes(out)
 
 
 def _pack(sections):

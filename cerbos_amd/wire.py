@@ -1,0 +1,78 @@
+"""Protobuf wire encoding of ``cerbos.engine.v1.CheckInput`` from its JSON-shaped dict.
+
+What a Go caller already holds (``proto.Marshal(checkInput)``) and what ``libcerbos_ingest.so`` consumes;
+here so that tests, the bench and Python callers can produce the same bytes without a protobuf runtime.
+Field numbers: api/public/cerbos/engine/v1/engine.proto:130-200 (CheckInput 1 request_id, 2 resource,
+3 principal, 4 actions, 5 aux_data; Resource 1 kind, 2 policy_version, 3 id, 4 attr, 5 scope; Principal 1 id,
+2 policy_version, 3 roles, 4 attr, 5 scope; AuxData 1 jwt) and google/protobuf/struct.proto (Value 1 null,
+2 number, 3 string, 4 bool, 5 struct, 6 list).
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+
+def _varint(n: int) -> bytes:
+    out = bytearray()
+    while True:
+        b = n & 0x7F
+        n >>= 7
+        if n:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _ld(field: int, payload: bytes) -> bytes:
+    return _varint(field << 3 | 2) + _varint(len(payload)) + payload
+
+
+def _string(field: int, s: str) -> bytes:
+    return _ld(field, s.encode("utf-8")) if s else b""      # proto3: default values are not emitted
+
+
+def encode_value(v) -> bytes:
+    if v is None:
+        return _varint(1 << 3 | 0) + b"\0"
+    if isinstance(v, bool):
+        return _varint(4 << 3 | 0) + (b"\1" if v else b"\0")
+    if isinstance(v, (int, float)):
+        return _varint(2 << 3 | 1) + struct.pack("<d", float(v))
+    if isinstance(v, str):
+        return _ld(3, v.encode("utf-8"))                    # a oneof member is emitted even when empty
+    if isinstance(v, (list, tuple)):
+        return _ld(6, b"".join(_ld(1, encode_value(x)) for x in v))
+    if isinstance(v, dict):
+        return _ld(5, encode_map(1, v))
+    raise TypeError("unsupported attribute value %r" % (v,))
+
+
+def encode_map(field: int, m: dict) -> bytes:
+    """map<string, google.protobuf.Value> as repeated entries {1: key, 2: value}, in dict order."""
+    return b"".join(_ld(field, _ld(1, str(k).encode("utf-8")) + _ld(2, encode_value(x))) for k, x in m.items())
+
+
+def encode_check_input(inp: dict) -> bytes:
+    p, r = inp.get("principal") or {}, inp.get("resource") or {}
+    aux = inp.get("auxData") or {}
+    out = _string(1, inp.get("requestId", "") or "")
+    out += _ld(2, _string(1, r.get("kind", "") or "") + _string(2, r.get("policyVersion", "") or "")
+               + _string(3, r.get("id", "") or "") + encode_map(4, r.get("attr") or {}) + _string(5, r.get("scope", "") or ""))
+    out += _ld(3, _string(1, p.get("id", "") or "") + _string(2, p.get("policyVersion", "") or "")
+               + b"".join(_ld(3, str(x).encode("utf-8")) for x in (p.get("roles") or []))
+               + encode_map(4, p.get("attr") or {}) + _string(5, p.get("scope", "") or ""))
+    out += b"".join(_ld(4, str(a).encode("utf-8")) for a in (inp.get("actions") or []))
+    if aux.get("jwt"):
+        out += _ld(5, encode_map(1, aux["jwt"]))
+    return out
+
+
+def pack_messages(msgs):
+    """[bytes] -> (one contiguous uint8 array, uint64 offsets[n + 1])."""
+    off = np.zeros(len(msgs) + 1, dtype=np.uint64)
+    if msgs:
+        off[1:] = np.cumsum([len(m) for m in msgs])
+    return np.frombuffer(b"".join(msgs), dtype=np.uint8), off

@@ -32,3 +32,15 @@ def test_no_cpu_fallback_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(capi.HipEngineError):
         capi.init(0)
+
+
+def test_ingest_library_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build()
+    from cerbos_amd import ingest
+    text = open(os.path.join(ROOT, "include", "cerbos_ingest.h")).read()
+    declared = sorted(set(re.findall(r"\b(cbi_[a-z_]+)\s*\(", text)))
+    assert len(declared) == 8
+    lib = ctypes.CDLL(ingest.LIB_PATH)
+    for sym in declared:
+        assert getattr(lib, sym) is not None

@@ -31,3 +31,21 @@ def test_engine_case(evaluator, case):
                 continue
             assert norm_actions(have) == norm_actions(want), (case["name"], lenient)
             assert sorted(have["effectiveDerivedRoles"]) == sorted(want.get("effectiveDerivedRoles") or [])
+
+
+def test_engine_cases_through_the_native_ingest():
+    """The same cases entering as serialized CheckInput bytes: wire.py -> libcerbos_ingest.so -> cbh_check_batch."""
+    from cerbos_amd.lower.blob import lower_rule_table
+    ev = HipEvaluator(lower_rule_table(store_rule_table(), GLOBALS), Conf(globals_=GLOBALS), native_ingest=True)
+    compared = 0
+    for case in CASES:
+        for lenient in ([False, True] if case["lenient"] is None else [case["lenient"]]):
+            outs, bad = ev.check(case["inputs"], now_ns=1_700_000_000_000_000_000, lenient_scope_search=lenient, allow_unsupported=True)
+            for i, (have, want) in enumerate(zip(outs, case["wantOutputs"])):
+                if i in bad:
+                    assert case["name"] in EXPECT_UNSUPPORTED
+                    continue
+                assert norm_actions(have) == norm_actions(want), (case["name"], lenient)
+                compared += 1
+    ev.close()
+    assert compared > 60

@@ -1,0 +1,119 @@
+"""CPU tier: the C++ wire-format ingest (libcerbos_ingest.so) against the Python
+flattener that defines the ``cbh_batch`` contract - every array of the batch must be identical, with and
+without the routing sort - and end to end: reference golden cases through wire bytes -> C++ ingest -> the
+decision kernel's source on the host simulator."""
+import numpy as np
+import pytest
+
+from cerbos_amd import wire, workloads
+from cerbos_amd.engine import Conf
+from cerbos_amd.flatten import Flattener
+from cerbos_amd.ingest import IngestError, IngestTable, WireFlattener
+from cerbos_amd.lower.blob import lower_rule_table
+from cerbos_amd.lower.celc import LoweringError
+from cerbos_amd.policy.loader import policies_from_docs
+from cerbos_amd.ruletable.build import rule_table_from_policies
+from helpers import load_json, norm_actions, store_rule_table
+from test_fuzz_parity import _policies, _requests
+from test_hostsim_golden import GLOBALS, HostSimEvaluator
+
+ARRAYS = ("req_u32", "roles", "tuple_req", "tuple_action", "col_tag", "col_val", "heap_tag", "heap_val",
+          "str_off", "str_bytes", "str_flags")
+
+
+def _same(lt, inputs, **kw):
+    it = IngestTable(lt.blob)
+    data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+    for sort in (False, True):
+        want = Flattener(lt).flatten(inputs, sort=sort, **kw)
+        have = it.flatten_pb(data, off, kw.get("default_policy_version", "default"), kw.get("default_scope", ""), sort)
+        assert (have.n_requests, have.n_tuples, have.n_strings) == (want.n_requests, want.n_tuples, want.n_strings)
+        for name in ARRAYS:
+            a, b = getattr(have, name), getattr(want, name)
+            assert a.dtype == b.dtype and a.shape == b.shape, (name, sort, a.shape, b.shape)
+            assert np.array_equal(a, b), (name, sort)
+        tp = want.tuple_perm if want.tuple_perm is not None else np.arange(want.n_tuples)
+        assert np.array_equal(have.tuple_perm, tp), sort
+        vi = want.vreq_input if want.req_perm is None else want.vreq_input[want.req_perm]
+        assert np.array_equal(have.vreq_input, vi), sort
+    it.close()
+
+
+def test_golden_store_inputs_flatten_identically():
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    inputs = [inp for case in load_json("engine_cases.json") for inp in case["inputs"]]
+    assert len(inputs) > 50
+    _same(lt, inputs)
+    _same(lt, inputs, default_policy_version="v9", default_scope=".acme")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_inputs_flatten_identically(seed):
+    rng = np.random.default_rng(10_000 + seed)
+    rt = rule_table_from_policies(policies_from_docs(_policies(rng)))
+    try:
+        lt = lower_rule_table(rt)
+    except LoweringError:
+        pytest.skip("store refused by the lowering")
+    _same(lt, _requests(rng, 300))     # ragged roles / actions, > 64 actions, nested and wrongly typed attributes
+
+
+@pytest.mark.parametrize("name", ["C2", "C3", "C5"])
+def test_synthetic_workloads_flatten_identically(name):
+    pol, reqs = {"C2": (workloads.c2_policies, lambda: workloads.c2_requests(n_requests=5000)),
+                 "C3": (workloads.c3_policies, lambda: workloads.c3_requests(n_requests=5000)),
+                 "C5": (workloads.c5_policies, lambda: workloads.c5_requests(n_requests=5000))}[name]
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol())))
+    _same(lt, reqs().to_inputs())
+
+
+def test_edge_cases():
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    weird = [
+        {"principal": {"id": "", "roles": []}, "resource": {"kind": "", "id": ""}, "actions": []},
+        {"principal": {"id": "x", "roles": ["", "employee", ""], "scope": ".acme.hr.uk", "policyVersion": "20210210"},
+         "resource": {"kind": "leave_request:special-kind/x", "id": "Ünïcode ✓", "scope": "acme.hr.zz.yy",
+                      "attr": {"owner": None, "n": 1e308, "neg": -0.0, "deep": {"a": {"b": {"c": [1, [2, [3, {"k": "v"}]]]}}},
+                               "empty_list": [], "empty_map": {}, "": "empty key"}},
+         "actions": ["view", "", "view", "a" * 300], "auxData": {"jwt": {"iss": "cerbos", "aud": ["a", "b"], "nested": {"x": True}}}},
+        {"principal": {"id": "y", "roles": ["r%d" % i for i in range(200)]}, "resource": {"kind": "leave_request", "id": "1"},
+         "actions": ["act%d" % i for i in range(129)]},
+    ]
+    _same(lt, weird)
+    _same(lt, [])
+
+
+def test_malformed_input_is_rejected():
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    it = IngestTable(lt.blob)
+    good = wire.encode_check_input({"principal": {"id": "p", "roles": ["a"], "attr": {"k": [1, 2, {"z": "w"}]}},
+                                    "resource": {"kind": "leave_request", "id": "r", "attr": {"owner": "p"}}, "actions": ["view"]})
+    for cut in range(1, len(good)):      # every truncation either parses as a shorter message or is refused, never crashes
+        data, off = wire.pack_messages([good[:cut]])
+        try:
+            it.flatten_pb(data, off)
+        except IngestError:
+            pass
+    with pytest.raises(IngestError):
+        it.flatten_pb(*wire.pack_messages([b"\x12\xff\xff\xff\xff\x0f"]))   # length runs past the end
+    with pytest.raises(IngestError):
+        IngestTable(lt.blob[:100])
+    with pytest.raises(IngestError):
+        IngestTable(b"\0" * 4096)
+
+
+def test_golden_cases_through_the_wire_format():
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    ev = HostSimEvaluator(lt, Conf(globals_=GLOBALS))
+    ev.flattener = WireFlattener(lt)
+    compared = 0
+    for case in load_json("engine_cases.json"):
+        for lenient in ([False, True] if case["lenient"] is None else [case["lenient"]]):
+            outs, bad = ev.check(case["inputs"], now_ns=1_700_000_000_000_000_000, lenient_scope_search=lenient, allow_unsupported=True)
+            for i, (have, want) in enumerate(zip(outs, case["wantOutputs"])):
+                if i in bad:
+                    continue
+                assert norm_actions(have) == norm_actions(want), (case["name"], lenient)
+                assert sorted(have["effectiveDerivedRoles"]) == sorted(want.get("effectiveDerivedRoles") or [])
+                compared += 1
+    assert compared > 60
