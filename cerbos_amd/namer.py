@@ -20,7 +20,7 @@ DEFAULT_VERSION = "default"
 # namer.go:18-20 (RE2 classes are ASCII-only)
 _INVALID_IDENT_CHARS = re.compile(r"[^\w.]+", re.ASCII)
 _OLD_NAME_PATTERN = re.compile(
-    r"^[A-Za-z][0-9A-Za-z_@.\-/]*(:[A-Za-z][0-9A-Za-z_@.\-/]*)*$"
+    r"^[A-Za-z][0-9A-Za-z_@.\-/]*(:[A-Za-z][0-9A-Za-z_@.\-/]*)*\Z"   # \Z: Go's `$` is end of text, never "before a final newline"
 )
 
 

@@ -79,6 +79,9 @@ def test_edge_cases():
         {"principal": {"id": "y", "roles": ["r%d" % i for i in range(200)]}, "resource": {"kind": "leave_request", "id": "1"},
          "actions": ["act%d" % i for i in range(129)]},
     ]
+    # namer.SanitizedResource: only names of the pre-0.30 form are rewritten (namer.go:213-218)
+    weird += [{"principal": {"id": "z", "roles": ["employee"]}, "resource": {"kind": k, "id": "1"}, "actions": ["view"]}
+              for k in ("a-b\n", "9abc-x", "a::b", "a:b:", "a@b/c-d:e.f", "x--y@@z", "ü-x", ":a")]
     _same(lt, weird)
     _same(lt, [])
 
