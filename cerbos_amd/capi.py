@@ -192,12 +192,12 @@ class Table:
             pass
 
     # ---- one-shot
-    def check(self, batch, now_ns=0, flags=0, want=("policy", "scope", "status", "edr")):
+    def check(self, batch, now_ns=0, flags=0, want=("policy", "scope", "status", "edr"), device_order=False):
         res = Result(batch.n_tuples, batch.n_requests, want)
         cb = make_cbatch(batch, self.num_columns)
         p = CParams(now_ns, flags, 0)
         _check(load().cbh_check_batch(self.h, C.byref(cb), C.byref(p), C.byref(res.c)))
-        return res.to_input_order(batch)
+        return res if device_order else res.to_input_order(batch)
 
     # ---- resident
     def upload(self, batch):

@@ -156,7 +156,13 @@ struct cbi_table {
   StrIndex ids;                      // table string -> id
   std::unordered_map<std::string, u32> scope_index;    // scope -> index
   std::vector<Column> columns;
+  std::vector<std::string> policy_keys, dr_names, scopes;   // response assembly
   std::string_view at(u32 i) const { return std::string_view(str_bytes + str_off[i], str_off[i + 1] - str_off[i]); }
+};
+
+struct cbi_outputs {
+  std::vector<u8> bytes, flags;
+  std::vector<u64> offsets;
 };
 
 struct cbi_batch {
@@ -374,6 +380,21 @@ int cbi_table_open(const void* blob, size_t len, cbi_table** out) {
     if (ssid[i] >= t->K) return bail("scope string id out of range");
     t->scope_index.emplace(std::string(bytes + off[ssid[i]], off[ssid[i] + 1] - off[ssid[i]]), i);
   }
+  t->scopes.resize(ns);
+  for (u32 i = 0; i < ns; ++i) t->scopes[i] = std::string(t->at(ssid[i]));
+  if (const CbhBlobSection* sn = find(CBH_SEC_HOST_NAMES)) {
+    const u8* q = base + sn->offset; const u8* qe = q + sn->nbytes;
+    for (std::vector<std::string>* dst : {&t->policy_keys, &t->dr_names}) {
+      if (qe - q < 4) return bail("host name section truncated");
+      u32 cnt; memcpy(&cnt, q, 4); q += 4;
+      for (u32 k = 0; k < cnt; ++k) {
+        if (qe - q < 2) return bail("host name section truncated");
+        u32 l = q[0] | (q[1] << 8); q += 2;
+        if ((u32)(qe - q) < l) return bail("host name section truncated");
+        dst->emplace_back((const char*)q, l); q += l;
+      }
+    }
+  } else return bail("blob is missing the host name section");
   const u8* p = base + sc->offset; const u8* e = p + sc->nbytes;
   u32 ncol = meta[CBH_M_NCOLUMNS];
   for (u32 c = 0; c < ncol; ++c) {
@@ -577,6 +598,105 @@ int cbi_flatten_pb(const cbi_table* t, const uint8_t* bytes, const uint64_t* off
   *out = b;
   return 0;
 }
+
+// ---- response assembly ---------------------------------------------------------------------------------
+static void put_varint(std::vector<u8>& o, u64 v) { while (v >= 0x80) { o.push_back((u8)(v | 0x80)); v >>= 7; } o.push_back((u8)v); }
+static void put_ld(std::vector<u8>& o, u32 field, std::string_view s) {
+  put_varint(o, (u64)field << 3 | 2); put_varint(o, s.size()); o.insert(o.end(), s.begin(), s.end());
+}
+static void put_str(std::vector<u8>& o, u32 field, std::string_view s) { if (!s.empty()) put_ld(o, field, s); }   // proto3 default: omitted
+
+int cbi_assemble_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* bytes, const uint64_t* offsets,
+                    uint32_t n, const char* default_version, cbi_outputs** out) {
+  if (!t || !b || !res || !res->effect || !out || (n && (!bytes || !offsets))) return fail("cbi_assemble_pb: null argument");
+  std::string_view dver = default_version ? default_version : "default";
+  const u32 T = b->view.n_tuples, R = b->view.n_requests;
+  // input-order tuple k lives at device tuple inv[k]; derived roles of an input = OR over its device requests
+  std::vector<u32> inv(T);
+  for (u32 j = 0; j < T; ++j) { if (b->tuple_perm[j] >= T) return fail("corrupt tuple permutation"); inv[b->tuple_perm[j]] = j; }
+  std::vector<u64> edr(n, 0);
+  if (res->edr_mask)
+    for (u32 q = 0; q < R; ++q) { if (b->req_input[q] >= n) return fail("batch does not belong to these inputs"); edr[b->req_input[q]] |= res->edr_mask[q]; }
+  auto o = new cbi_outputs();
+  auto bail = [&](const std::string& m) { delete o; return fail(m); };
+  o->offsets.reserve(n + 1); o->offsets.push_back(0); o->flags.assign(n, 0);
+  o->bytes.reserve((size_t)n * 96);
+  struct Act { std::string_view name; u32 j; };
+  std::vector<Act> acts;
+  std::vector<u8> eff, ent;
+  std::string pol, kbuf, vbuf;
+  u64 k = 0;
+  for (u32 i = 0; i < n; ++i) {
+    Span m{bytes + offsets[i], bytes + offsets[i + 1]};
+    Span principal{nullptr, nullptr}, resource{nullptr, nullptr};
+    std::string_view request_id;
+    acts.clear();
+    bool bad = false; Field f;
+    while (next(m, f, bad)) { if (f.wt != 2) continue;
+      if (f.num == 1) request_id = sv(f.s); else if (f.num == 2) resource = f.s; else if (f.num == 3) principal = f.s;
+      else if (f.num == 4) {
+        if (k >= T) return bail("batch does not belong to these inputs");
+        // setEffect (check.go:513-530): a later duplicate replaces an earlier one unless that one is a DENY and it is not
+        std::string_view name = sv(f.s); u32 j = inv[k++]; bool dup = false;
+        for (Act& a : acts) if (a.name == name) {
+          if (res->effect[j] == CBH_EFFECT_DENY || res->effect[a.j] != CBH_EFFECT_DENY) a.j = j;
+          dup = true; break;
+        }
+        if (!dup) acts.push_back(Act{name, j});
+        if (res->status) { u8 st = res->status[j]; if (st == CBH_ST_UNSUPPORTED) o->flags[i] |= CBI_OUT_UNSUPPORTED; else if (st == CBH_ST_CEL_ERROR) o->flags[i] |= CBI_OUT_CEL_ERROR; }
+      } }
+    Party P, Rs;
+    { Span s = principal; while (next(s, f, bad)) { if (f.wt != 2) continue; if (f.num == 1) P.id = sv(f.s); else if (f.num == 2) P.version = sv(f.s); } }
+    { Span s = resource; while (next(s, f, bad)) { if (f.wt != 2) continue; if (f.num == 1) Rs.kind = sv(f.s); else if (f.num == 2) Rs.version = sv(f.s); else if (f.num == 3) Rs.id = sv(f.s); } }
+    if (bad) return bail("malformed CheckInput at index " + std::to_string(i));
+    std::vector<u8>& ob = o->bytes;
+    put_str(ob, 1, request_id);
+    put_str(ob, 2, Rs.id);
+    for (const Act& a : acts) {
+      eff.clear(); ent.clear();
+      if (res->effect[a.j]) { eff.push_back(1 << 3 | 0); put_varint(eff, res->effect[a.j]); }
+      if (res->policy) {
+        const u32 w = res->policy[a.j], kind = w >> 28, ident = w & 0x0FFFFFFFu;
+        pol.clear();
+        switch (kind) {   // enum cbh_policy_kind; keys as namer.PolicyKeyFromFQN gives them (namer.go:95-134)
+          case CBH_P_EMPTY: break;
+          case CBH_P_NO_MATCH: pol = "NO_MATCH"; break;
+          case CBH_P_NO_MATCH_SCOPE_PERMISSIONS: pol = "NO_MATCH_FOR_SCOPE_PERMISSIONS"; break;
+          case CBH_P_TABLE: if (ident >= t->policy_keys.size()) return bail("policy id out of range"); pol = t->policy_keys[ident]; break;
+          case CBH_P_RESOURCE: case CBH_P_PRINCIPAL: {
+            if (ident >= t->scopes.size()) return bail("scope index out of range");
+            const bool rp = kind == CBH_P_RESOURCE;
+            std::string_view ver = rp ? Rs.version : P.version;
+            pol = rp ? "resource." : "principal.";
+            pol += sanitize(rp ? Rs.kind : P.id, kbuf); pol += ".v"; pol += sanitize(ver.empty() ? dver : ver, vbuf);
+            if (!t->scopes[ident].empty()) { pol += '/'; pol += t->scopes[ident]; }
+            break;
+          }
+          default: return bail("unknown policy word");
+        }
+        put_str(eff, 2, pol);
+      }
+      if (res->scope && res->scope[a.j] != 0xFFFFFFFFu) {
+        if (res->scope[a.j] >= t->scopes.size()) return bail("scope index out of range");
+        put_str(eff, 3, t->scopes[res->scope[a.j]]);
+      }
+      put_ld(ent, 1, a.name);
+      put_ld(ent, 2, std::string_view((const char*)eff.data(), eff.size()));
+      put_ld(ob, 3, std::string_view((const char*)ent.data(), ent.size()));
+    }
+    for (u32 d = 0; d < 64 && d < t->dr_names.size(); ++d) if ((edr[i] >> d) & 1) put_ld(ob, 4, t->dr_names[d]);
+    o->offsets.push_back(ob.size());
+  }
+  if (k != T) return bail("batch does not belong to these inputs");
+  o->bytes.reserve(1);
+  *out = o;
+  return 0;
+}
+
+void cbi_outputs_free(cbi_outputs* o) { delete o; }
+const uint8_t* cbi_outputs_bytes(const cbi_outputs* o) { return o ? o->bytes.data() : nullptr; }
+const uint64_t* cbi_outputs_offsets(const cbi_outputs* o) { return o ? o->offsets.data() : nullptr; }
+const uint8_t* cbi_outputs_flags(const cbi_outputs* o) { return o ? o->flags.data() : nullptr; }
 
 void cbi_batch_free(cbi_batch* b) { delete b; }
 const cbh_batch* cbi_batch_view(const cbi_batch* b) { return b ? &b->view : nullptr; }

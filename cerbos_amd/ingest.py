@@ -42,6 +42,15 @@ def load():
         lib.cbi_batch_tuple_perm.restype = C.POINTER(C.c_uint64)
         lib.cbi_batch_request_input.argtypes = [vp]
         lib.cbi_batch_request_input.restype = C.POINTER(C.c_uint32)
+        lib.cbi_assemble_pb.argtypes = [vp, vp, C.POINTER(capi.CResult), vp, vp, C.c_uint32, C.c_char_p, C.POINTER(vp)]
+        lib.cbi_outputs_free.argtypes = [vp]
+        lib.cbi_outputs_free.restype = None
+        lib.cbi_outputs_bytes.argtypes = [vp]
+        lib.cbi_outputs_bytes.restype = C.POINTER(C.c_uint8)
+        lib.cbi_outputs_offsets.argtypes = [vp]
+        lib.cbi_outputs_offsets.restype = C.POINTER(C.c_uint64)
+        lib.cbi_outputs_flags.argtypes = [vp]
+        lib.cbi_outputs_flags.restype = C.POINTER(C.c_uint8)
         _lib = lib
     return _lib
 
@@ -55,6 +64,21 @@ def _copy(ptr, ctype, dtype, n):
     if not ptr or n == 0:
         return np.zeros(0, dtype=dtype)
     return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)).astype(dtype, copy=True)
+
+
+class _NativeBatch:
+    """Keeps a ``cbi_batch`` alive for response assembly."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        try:
+            if self.h:
+                load().cbi_batch_free(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 class IngestTable:
@@ -103,9 +127,28 @@ class IngestTable:
             b.tuple_perm = _copy(load().cbi_batch_tuple_perm(h), C.c_uint64, np.int64, T)
             b.req_perm = None
             b.vreq_input = _copy(load().cbi_batch_request_input(h), C.c_uint32, np.int64, R)   # device request -> input
+            b.native = _NativeBatch(h)
             return b
-        finally:
+        except Exception:
             load().cbi_batch_free(h)
+            raise
+
+    def assemble_pb(self, batch, res, data, offsets, default_policy_version="default"):
+        """Device-order results (``capi.Result`` before ``to_input_order``) of a batch made by ``flatten_pb`` from
+        the same messages -> ([serialized CheckOutput], flags uint8[n])."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        h = C.c_void_p()
+        _check(load().cbi_assemble_pb(self.h, batch.native.h, C.byref(res.c), data.ctypes.data if data.size else None,
+                                      offsets.ctypes.data, n, default_policy_version.encode(), C.byref(h)))
+        try:
+            off = _copy(load().cbi_outputs_offsets(h), C.c_uint64, np.int64, n + 1)
+            raw = _copy(load().cbi_outputs_bytes(h), C.c_uint8, np.uint8, int(off[-1])).tobytes()
+            flags = _copy(load().cbi_outputs_flags(h), C.c_uint8, np.uint8, n)
+            return [raw[off[i]:off[i + 1]] for i in range(n)], flags
+        finally:
+            load().cbi_outputs_free(h)
 
 
 class WireFlattener:

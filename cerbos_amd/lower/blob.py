@@ -25,7 +25,7 @@ from .celc import LoweringError, Params, ProgramBuilder
 from .globs import GlobNFA, fix_glob, has_meta
 
 BLOB_MAGIC = 0x31484243
-BLOB_VERSION = 14
+BLOB_VERSION = 15
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
 PAT_ANY = 0x7FFFFFFF     # the lone "*": matches every string, no automaton needed
@@ -34,7 +34,7 @@ ROW_F_ACTION_LIST, ROW_F_ROLE_LIST = 4, 8
 (SEC_META, SEC_STR_OFF, SEC_STR_BYTES, SEC_SCOPE_PARENT, SEC_SCOPE_FLAGS, SEC_SCOPE_SID, SEC_HASH,
  SEC_ROWS, SEC_RPROWS, SEC_U32POOL, SEC_DR, SEC_CODE, SEC_CONST_TAG, SEC_CONST_VAL, SEC_THEAP_TAG,
  SEC_THEAP_VAL, SEC_GBITS, SEC_NFA_ACTION, SEC_NFA_ROLE, SEC_NFA_KIND, SEC_POLICY_SID,
- SEC_DRNAME_SID, SEC_CONST_REC, SEC_THEAP_REC, SEC_ROLE_CLASS, SEC_COLUMN_PATHS) = range(1, 27)
+ SEC_DRNAME_SID, SEC_CONST_REC, SEC_THEAP_REC, SEC_ROLE_CLASS, SEC_COLUMN_PATHS, SEC_HOST_NAMES) = range(1, 28)
 
 (M_NSTRINGS, M_NCOLUMNS, M_NSCOPES, M_HASH_MASK, M_NROWS, M_NRPROWS, M_NDR, M_NPOLICIES, M_NCONSTS,
  M_CODE_LEN, M_FLAGS, M_MAX_STACK, M_NDRNAMES, M_NFA_WORDS_ACTION, M_NFA_WORDS_ROLE,
@@ -482,6 +482,8 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         (SEC_ROLE_CLASS, K, role_class.tobytes()),
         # host only: where each attribute column comes from (the C++ ingest walks these paths)
         (SEC_COLUMN_PATHS, len(lt.columns), _column_paths(lt.columns)),
+        # host only: policy keys of CBH_P_TABLE policy words, then derived-role names in edr_mask bit order
+        (SEC_HOST_NAMES, len(lt.policy_keys) + len(lt.dr_names), _names(lt.policy_keys) + _names(lt.dr_names)),
     ]
     lt.blob = _pack(sections)
     lt.stats = {
@@ -509,6 +511,15 @@ def _column_paths(columns):
         for k in keys:
             kb = k.encode("utf-8")
             out += struct.pack("<H", len(kb)) + kb
+    return bytes(out)
+
+
+def _names(names):
+    """u32 count, then per name u16 length + UTF-8 bytes."""
+    out = bytearray(struct.pack("<I", len(names)))
+    for n in names:
+        nb = n.encode("utf-8")
+        out += struct.pack("<H", len(nb)) + nb
     return bytes(out)
 
 

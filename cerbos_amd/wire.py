@@ -76,3 +76,64 @@ def pack_messages(msgs):
     if msgs:
         off[1:] = np.cumsum([len(m) for m in msgs])
     return np.frombuffer(b"".join(msgs), dtype=np.uint8), off
+
+
+# ---- decoding of enginev1.CheckOutput (engine.proto:152-166), for tests and Python callers -----------------
+def _fields(buf: bytes):
+    i, n = 0, len(buf)
+    while i < n:
+        key = shift = 0
+        while True:
+            b = buf[i]; i += 1
+            key |= (b & 0x7F) << shift; shift += 7
+            if not b & 0x80:
+                break
+        num, wt = key >> 3, key & 7
+        if wt == 0:
+            v = shift = 0
+            while True:
+                b = buf[i]; i += 1
+                v |= (b & 0x7F) << shift; shift += 7
+                if not b & 0x80:
+                    break
+            yield num, v
+        elif wt == 2:
+            ln = shift = 0
+            while True:
+                b = buf[i]; i += 1
+                ln |= (b & 0x7F) << shift; shift += 7
+                if not b & 0x80:
+                    break
+            yield num, buf[i:i + ln]
+            i += ln
+        else:
+            raise ValueError("unexpected wire type %d" % wt)
+
+
+_EFFECTS = {0: "EFFECT_UNSPECIFIED", 1: "EFFECT_ALLOW", 2: "EFFECT_DENY", 3: "EFFECT_NO_MATCH"}
+
+
+def decode_check_output(buf: bytes) -> dict:
+    out = {"requestId": "", "resourceId": "", "actions": {}, "effectiveDerivedRoles": []}
+    for num, v in _fields(buf):
+        if num == 1:
+            out["requestId"] = v.decode("utf-8")
+        elif num == 2:
+            out["resourceId"] = v.decode("utf-8")
+        elif num == 3:
+            key, eff = "", {"effect": _EFFECTS[0], "policy": "", "scope": ""}
+            for n2, v2 in _fields(v):
+                if n2 == 1:
+                    key = v2.decode("utf-8")
+                elif n2 == 2:
+                    for n3, v3 in _fields(v2):
+                        if n3 == 1:
+                            eff["effect"] = _EFFECTS[v3]
+                        elif n3 == 2:
+                            eff["policy"] = v3.decode("utf-8")
+                        elif n3 == 3:
+                            eff["scope"] = v3.decode("utf-8")
+            out["actions"][key] = eff
+        elif num == 4:
+            out["effectiveDerivedRoles"].append(v.decode("utf-8"))
+    return out

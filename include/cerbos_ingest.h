@@ -58,6 +58,29 @@ const uint64_t* cbi_batch_tuple_perm(const cbi_batch* b);
 /* Index of the CheckInput each device request came from.  n_requests entries. */
 const uint32_t* cbi_batch_request_input(const cbi_batch* b);
 
+/*
+ * Response assembly: one serialized enginev1.CheckOutput (engine.proto:152-166) per
+ * CheckInput, in input order, from the device results of the batch that cbi_flatten_pb made of the same
+ * inputs - what checkWithAuditTrail builds from the per-action results (internal/ruletable/check.go:58-95):
+ * request_id, resource_id, actions{effect, policy, scope} with duplicates of an action folded "DENY sticky"
+ * (check.go:513-530), effective_derived_roles.  `res` is in DEVICE order exactly as cbh_check_batch /
+ * cbh_result_download filled it (policy / scope / status / edr_mask may be NULL: those fields are then left out).
+ * Not produced here: validation_errors, outputs, evaluation_errors text (inputs whose flags carry
+ * CBI_OUT_CEL_ERROR had a CEL error absorbed: the caller re-evaluates those if it wants the messages).
+ */
+typedef struct cbi_outputs cbi_outputs;
+#define CBI_OUT_UNSUPPORTED 1u /* device hit an operation outside its subset: output invalid, caller's engine must run this input */
+#define CBI_OUT_CEL_ERROR 2u   /* a CEL runtime error was absorbed on the decision path of at least one action */
+
+int cbi_assemble_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* bytes,
+                    const uint64_t* offsets, uint32_t n, const char* default_version, cbi_outputs** out);
+void cbi_outputs_free(cbi_outputs* o);
+/* Output i = bytes[offsets[i] .. offsets[i+1]); n + 1 offsets. */
+const uint8_t* cbi_outputs_bytes(const cbi_outputs* o);
+const uint64_t* cbi_outputs_offsets(const cbi_outputs* o);
+/* Per input: CBI_OUT_* bits. */
+const uint8_t* cbi_outputs_flags(const cbi_outputs* o);
+
 #ifdef __cplusplus
 }
 #endif

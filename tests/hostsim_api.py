@@ -50,7 +50,7 @@ def batch_gbits(lt, batch):
     return g[:, :batch.n_strings].copy() if batch.n_strings else g
 
 
-def check(lt, batch, now_ns=0, flags=0):
+def check(lt, batch, now_ns=0, flags=0, device_order=False):
     res = capi.Result(batch.n_tuples, batch.n_requests, ("policy", "scope", "status", "edr"))
     cb = capi.make_cbatch(batch, len(lt.columns))
     p = capi.CParams(now_ns, flags, 0)
@@ -60,4 +60,4 @@ def check(lt, batch, now_ns=0, flags=0):
                              g.ctypes.data_as(C.c_void_p))
     if rc != 0:
         raise RuntimeError(lib().hostsim_last_error().decode())
-    return res.to_input_order(batch)
+    return res if device_order else res.to_input_order(batch)

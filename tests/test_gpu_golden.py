@@ -49,3 +49,25 @@ def test_engine_cases_through_the_native_ingest():
                 compared += 1
     ev.close()
     assert compared > 60
+
+
+def test_engine_cases_bytes_in_bytes_out():
+    """check_pb on the GPU: serialized CheckInput -> libcerbos_ingest.so -> cbh_check_batch -> serialized CheckOutput."""
+    from cerbos_amd import wire
+    from cerbos_amd.lower.blob import lower_rule_table
+    ev = HipEvaluator(lower_rule_table(store_rule_table(), GLOBALS), Conf(globals_=GLOBALS))
+    compared = 0
+    for case in CASES:
+        data, off = wire.pack_messages([wire.encode_check_input(i) for i in case["inputs"]])
+        for lenient in ([False, True] if case["lenient"] is None else [case["lenient"]]):
+            raw, flags = ev.check_pb(data, off, now_ns=1_700_000_000_000_000_000, lenient_scope_search=lenient)
+            for have, want, f in zip(raw, case["wantOutputs"], flags):
+                if f & 1:
+                    assert case["name"] in EXPECT_UNSUPPORTED
+                    continue
+                have = wire.decode_check_output(have)
+                assert norm_actions(have) == norm_actions(want), (case["name"], lenient)
+                assert sorted(have["effectiveDerivedRoles"]) == sorted(want.get("effectiveDerivedRoles") or [])
+                compared += 1
+    ev.close()
+    assert compared > 60

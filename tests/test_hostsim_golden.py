@@ -29,8 +29,8 @@ class HostSimEvaluator(HipEvaluator):
         self.flattener = Flattener(lt)
 
         class _T:
-            def check(_self, batch, now_ns=0, flags=0, want=()):
-                return hostsim_api.check(lt, batch, now_ns, flags)
+            def check(_self, batch, now_ns=0, flags=0, want=(), device_order=False):
+                return hostsim_api.check(lt, batch, now_ns, flags, device_order)
         self.table = _T()
 
 

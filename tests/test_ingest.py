@@ -120,3 +120,81 @@ def test_golden_cases_through_the_wire_format():
                 assert sorted(have["effectiveDerivedRoles"]) == sorted(want.get("effectiveDerivedRoles") or [])
                 compared += 1
     assert compared > 60
+
+
+# ---- response assembly: device results -> serialized CheckOutput, against engine.assemble ------
+def _assemble_both(lt, inputs, conf, flags_extra=0, dver="default"):
+    import copy
+
+    import hostsim_api
+    from cerbos_amd import capi
+    it = IngestTable(lt.blob)
+    data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+    batch = it.flatten_pb(data, off, dver, "")
+    batch.actions_per_request = [list(inp.get("actions") or []) for inp in inputs]
+    res = hostsim_api.check(lt, batch, 1_700_000_000_000_000_000, capi.F_WANT_DERIVED_ROLES | flags_extra, device_order=True)
+    raw, flags = it.assemble_pb(batch, res, data, off, dver)
+    have = [wire.decode_check_output(r) for r in raw]
+    ev = HostSimEvaluator(lt, conf)
+    want, bad = ev.assemble(inputs, batch, copy.copy(res).to_input_order(batch), dver, allow_unsupported=True)
+    assert sorted(bad) == [i for i, f in enumerate(flags) if f & 1]
+    return have, want, flags
+
+
+def test_assembly_matches_python_on_golden_cases():
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    inputs = [inp for case in load_json("engine_cases.json") for inp in case["inputs"]]
+    for dver in ("default", "20210210"):
+        have, want, flags = _assemble_both(lt, inputs, Conf(globals_=GLOBALS), dver=dver)
+        assert have == want
+    assert any(f & 2 for f in flags)      # the golden store has cases with absorbed CEL errors
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_assembly_matches_python_on_fuzzed_stores(seed):
+    from cerbos_amd import capi
+    rng = np.random.default_rng(10_000 + seed)
+    rt = rule_table_from_policies(policies_from_docs(_policies(rng)))
+    try:
+        lt = lower_rule_table(rt)
+    except LoweringError:
+        pytest.skip("store refused by the lowering")
+    inputs = _requests(rng, 200)
+    inputs[3]["actions"] = ["view", "edit", "view", "view", "edit"]      # duplicates fold DENY-sticky
+    inputs[4]["actions"] = []
+    for extra in (0, capi.F_LENIENT_SCOPE_SEARCH):
+        have, want, _ = _assemble_both(lt, inputs, Conf(), extra)
+        assert have == want
+
+
+def test_assembly_rejects_a_foreign_batch():
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    inputs = [inp for case in load_json("engine_cases.json")[:3] for inp in case["inputs"]]
+    import hostsim_api
+    it = IngestTable(lt.blob)
+    data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+    batch = it.flatten_pb(data, off)
+    res = hostsim_api.check(lt, batch, 0, 0, device_order=True)
+    d2, o2 = wire.pack_messages([wire.encode_check_input(i) for i in inputs[:-1]])
+    with pytest.raises(IngestError):
+        it.assemble_pb(batch, res, d2, o2)
+
+
+def test_bytes_in_bytes_out_on_golden_cases():
+    """HipEvaluator.check_pb (wire -> ingest -> kernel -> assembly) against the reference's golden outputs."""
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    ev = HostSimEvaluator(lt, Conf(globals_=GLOBALS))
+    compared = 0
+    for case in load_json("engine_cases.json"):
+        data, off = wire.pack_messages([wire.encode_check_input(i) for i in case["inputs"]])
+        for lenient in ([False, True] if case["lenient"] is None else [case["lenient"]]):
+            raw, flags = ev.check_pb(data, off, now_ns=1_700_000_000_000_000_000, lenient_scope_search=lenient)
+            for have, want, f, inp in zip(raw, case["wantOutputs"], flags, case["inputs"]):
+                if f & 1:
+                    continue
+                have = wire.decode_check_output(have)
+                assert norm_actions(have) == norm_actions(want), (case["name"], lenient)
+                assert sorted(have["effectiveDerivedRoles"]) == sorted(want.get("effectiveDerivedRoles") or [])
+                assert have["requestId"] == inp.get("requestId", "") and have["resourceId"] == inp["resource"].get("id", "")
+                compared += 1
+    assert compared > 60
