@@ -169,9 +169,11 @@ def main():
     assert (res.status != capi.ST_UNSUPPORTED).all()
 
     # PCIe-inclusive one-shot path (upload + kernels + download), for DESIGN.md; not `value`
-    o0 = time.perf_counter()
-    table.check(batch, now_ns=now, flags=FLAGS, want=())
-    oneshot_s = time.perf_counter() - o0
+    oneshot_s = 1e9
+    for _ in range(3):      # the first call also grows the context's device block
+        o0 = time.perf_counter()
+        table.check(batch, now_ns=now, flags=FLAGS, want=())
+        oneshot_s = min(oneshot_s, time.perf_counter() - o0)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

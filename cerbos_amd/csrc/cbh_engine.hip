@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <string>
@@ -54,6 +55,14 @@ struct cbh_table {
   std::mutex mu;
   std::mutex pool_mu;
   std::vector<std::pair<void*, size_t>> pool_free;   // idle device blocks of released batches
+  // One-shot calls (cbh_check_batch) run on their own small set of contexts - stream, pinned staging
+  // block, device block - so that calls from different threads overlap on the device.
+  struct OneShot { hipStream_t stream = nullptr; uint8_t* h = nullptr; size_t h_cap = 0; uint8_t* d = nullptr; size_t d_cap = 0; };
+  static constexpr int MAX_ONESHOT = 8;
+  std::mutex ctx_mu;
+  std::condition_variable ctx_cv;
+  std::vector<OneShot*> ctx_idle;
+  int ctx_count = 0;
 };
 
 struct cbh_device_batch {
@@ -132,6 +141,12 @@ extern "C" void cbh_table_release(cbh_table* t) {
   for (auto& sl : t->ring) for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
   if (t->image && t->owns_image) (void)hipFree(t->image);
   for (auto& a : t->pool_free) (void)hipFree(a.first);
+  for (auto* c : t->ctx_idle) {
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->h) (void)hipHostFree(c->h);
+    if (c->d) (void)hipFree(c->d);
+    delete c;
+  }
   delete t;
 }
 extern "C" uint32_t cbh_table_num_strings(const cbh_table* t) { return t ? t->meta[CBH_M_NSTRINGS] : 0; }
@@ -344,12 +359,139 @@ extern "C" int cbh_result_download(cbh_table* t, cbh_device_batch* b, cbh_result
   return 0;
 }
 
+// ---- one-shot path: CheckResources round trip for a host batch ------------------------------------------
+// All arrays of the batch go into ONE device block.  A small batch (the latency case) is packed into
+// a pinned staging block and crosses PCIe in one copy each way; a large one copies array by array
+// straight from / to the caller's memory (the driver pins those pages on the fly, which beats a host
+// memcpy into staging).  Each call owns a context (stream + blocks), so concurrent callers overlap.
+static cbh_table::OneShot* ctx_acquire(cbh_table* t) {
+  std::unique_lock<std::mutex> lk(t->ctx_mu);
+  for (;;) {
+    if (!t->ctx_idle.empty()) { auto* c = t->ctx_idle.back(); t->ctx_idle.pop_back(); return c; }
+    if (t->ctx_count < cbh_table::MAX_ONESHOT) {
+      ++t->ctx_count;
+      lk.unlock();
+      auto* c = new (std::nothrow) cbh_table::OneShot();
+      if (c && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; c = nullptr; }
+      if (!c) { lk.lock(); --t->ctx_count; t->ctx_cv.notify_one(); }
+      return c;
+    }
+    t->ctx_cv.wait(lk);
+  }
+}
+struct CtxLease {
+  cbh_table* t; cbh_table::OneShot* c;
+  ~CtxLease() {
+    if (!c) return;
+    (void)hipStreamSynchronize(c->stream);   // an error return must not leave copies from caller memory in flight
+    { std::lock_guard<std::mutex> lk(t->ctx_mu); t->ctx_idle.push_back(c); }
+    t->ctx_cv.notify_one();
+  }
+};
+static int ctx_reserve(cbh_table::OneShot* c, size_t hbytes, size_t dbytes) {
+  if (hbytes > c->h_cap) {
+    if (c->h) { (void)hipHostFree(c->h); c->h = nullptr; c->h_cap = 0; }
+    size_t cap = 1 << 16; while (cap < hbytes) cap <<= 1;
+    HIPCHK(hipHostMalloc((void**)&c->h, cap, hipHostMallocDefault));
+    c->h_cap = cap;
+  }
+  if (dbytes > c->d_cap) {
+    if (c->d) { (void)hipFree(c->d); c->d = nullptr; c->d_cap = 0; }
+    size_t cap = 1 << 16; while (cap < dbytes) cap <<= 1;
+    HIPCHK(hipMalloc((void**)&c->d, cap));
+    c->d_cap = cap;
+  }
+  return 0;
+}
+
 extern "C" int cbh_check_batch(cbh_table* t, const cbh_batch* in, const cbh_params* p, cbh_result* out) {
-  cbh_device_batch* b = nullptr;
-  if (cbh_batch_upload(t, in, &b) != 0) return -1;
-  int rc = cbh_check_resident(t, b, p);
-  if (rc == 0) rc = cbh_result_download(t, b, out);
-  cbh_batch_release(b);
-  return rc;
+  if (!t || !in || !p || !out) return fail("null argument");
+  if (in->n_columns != t->meta[CBH_M_NCOLUMNS]) return fail("cbh_batch.n_columns does not match the table's column schema");
+  if (in->n_tuples && !out->effect) return fail("cbh_result.effect is required");
+  const size_t NR = in->n_requests, NT = in->n_tuples, NS = in->n_strings;
+  u32 max_actions = 0;
+  if (NR && !in->req_u32) return fail("cbh_batch: a required array is NULL");
+  for (size_t r = 0; r < NR; ++r) {
+    const u32 n = in->req_u32[(size_t)CBH_RQ_ACT_CNT * NR + r];
+    if (n > CBH_MAX_ACTIONS_PER_REQUEST) return fail("cbh_batch: a request carries more than CBH_MAX_ACTIONS_PER_REQUEST actions");
+    if (n > max_actions) max_actions = n;
+  }
+  // layout of the device block: [launch arguments | inputs ... | glob bits | outputs ...], 256-byte aligned pieces
+  struct Seg { size_t off, bytes; const void* src; };
+  size_t cur = 0;
+  auto seg = [&](const void* src, size_t bytes) { Seg g{cur, bytes, src}; cur += (bytes + 255) & ~(size_t)255; return g; };
+  const Seg s_args = seg(nullptr, sizeof(KernelArgs));
+  const Seg ins[11] = {
+    seg(in->req_u32, (size_t)CBH_RQ_NFIELDS * NR * 4), seg(in->roles, (size_t)in->n_roles * 4), seg(in->tuple_req, NT * 4),
+    seg(in->tuple_action, NT * 4), seg(in->col_tag, (size_t)in->n_columns * NR), seg(in->col_val, (size_t)in->n_columns * NR * 8),
+    seg(in->heap_tag, in->heap_len), seg(in->heap_val, (size_t)in->heap_len * 8), seg(in->str_off, (NS + 1) * 4),
+    seg(in->str_bytes, in->str_bytes_len), seg(in->str_flags, NS)};
+  for (const Seg& g : ins) if (g.bytes && !g.src) return fail("cbh_batch: a required array is NULL");
+  const size_t in_end = cur;
+  const Seg s_gbits = seg(nullptr, 3 * NS * 8);
+  const size_t out_begin = cur;
+  const Seg s_eff = seg(nullptr, NT), s_pol = seg(nullptr, NT * 4), s_scope = seg(nullptr, NT * 4), s_status = seg(nullptr, NT),
+            s_edr = seg(nullptr, NR * 8);
+  const size_t total = cur;
+  const bool staged = in_end <= ((size_t)4 << 20);
+
+  HIPCHK(hipSetDevice(t->device));
+  CtxLease lease{t, ctx_acquire(t)};
+  cbh_table::OneShot* c = lease.c;
+  if (!c) return fail("could not create a launch context");
+  if (ctx_reserve(c, staged ? total : 256, total) != 0) return -1;
+  hipStream_t s = c->stream;
+
+  KernelArgs ka;
+  std::memset(&ka, 0, sizeof(ka));
+  ka.t = t->dev; ka.now_ns = p->now_ns; ka.flags = p->flags;
+  BatchDev& d = ka.b;
+  d.n_requests = in->n_requests; d.n_tuples = in->n_tuples; d.n_roles = in->n_roles;
+  d.n_columns = in->n_columns; d.n_strings = in->n_strings; d.heap_len = in->heap_len;
+  uint8_t* base = c->d;
+  d.req_u32 = (const u32*)(base + ins[0].off); d.roles = (const u32*)(base + ins[1].off); d.tuple_req = (const u32*)(base + ins[2].off);
+  d.tuple_action = (const u32*)(base + ins[3].off); d.col_tag = base + ins[4].off; d.col_val = (const u64*)(base + ins[5].off);
+  d.heap_tag = base + ins[6].off; d.heap_val = (const u64*)(base + ins[7].off); d.str_off = (const u32*)(base + ins[8].off);
+  d.str_bytes = base + ins[9].off; d.str_flags = base + ins[10].off; d.gbits = (u64*)(base + s_gbits.off);
+  ka.o.effect = base + s_eff.off; ka.o.policy = (u32*)(base + s_pol.off); ka.o.scope = (u32*)(base + s_scope.off);
+  ka.o.status = base + s_status.off; ka.o.edr = (u64*)(base + s_edr.off);
+
+  std::memcpy(c->h + s_args.off, &ka, sizeof(ka));
+  if (staged) {
+    for (const Seg& g : ins) if (g.bytes) std::memcpy(c->h + g.off, g.src, g.bytes);
+    HIPCHK(hipMemcpyAsync(base, c->h, in_end, hipMemcpyHostToDevice, s));
+  } else {
+    HIPCHK(hipMemcpyAsync(base, c->h, sizeof(ka), hipMemcpyHostToDevice, s));
+    for (const Seg& g : ins) if (g.bytes) HIPCHK(hipMemcpyAsync(base + g.off, g.src, g.bytes, hipMemcpyHostToDevice, s));
+  }
+  const u32 maxw = std::max(std::max(t->dev.nfa_words[0], t->dev.nfa_words[1]), t->dev.nfa_words[2]);
+  if (NS) {
+    if (maxw) {
+      const u32 grid = (d.n_strings + CBH_BLOCK - 1) / CBH_BLOCK;
+      const size_t lds = (size_t)(2 + 512) * maxw * sizeof(u64);
+      hipLaunchKernelGGL(cbh_resolve_globs_kernel, dim3(grid), dim3(CBH_BLOCK), lds, s, t->dev, d);
+    } else {
+      HIPCHK(hipMemsetAsync(d.gbits, 0, s_gbits.bytes, s));   // no automata: no string matches a glob
+    }
+  }
+  if (NR) {
+    const u32 grid = (d.n_requests + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
+    const u32 ncc = d.n_columns < CBH_CACHE_COLS ? d.n_columns : CBH_CACHE_COLS;
+    const size_t dyn_lds = (size_t)ncc * CBH_BLOCK * 12;
+    const cbh_check_kernel_fn kernel = cbh_pick_check_kernel(t->dev.flags, t->dev.n_dr, maxw != 0 || (t->dev.flags & CBH_MF_HAS_ANY_PATTERN), max_actions);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), dyn_lds, s, ka, (const KernelArgs*)(base + s_args.off));
+  }
+  HIPCHK(hipGetLastError());
+  struct Dst { const Seg* g; void* dst; };
+  const Dst outs[5] = {{&s_eff, out->effect}, {&s_pol, out->policy}, {&s_scope, out->scope}, {&s_status, out->status}, {&s_edr, out->edr_mask}};
+  if (staged) {
+    if (total > out_begin) HIPCHK(hipMemcpyAsync(c->h + out_begin, base + out_begin, total - out_begin, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (const Dst& o : outs) if (o.dst && o.g->bytes) std::memcpy(o.dst, c->h + o.g->off, o.g->bytes);
+  } else {
+    for (const Dst& o : outs) if (o.dst && o.g->bytes) HIPCHK(hipMemcpyAsync(o.dst, base + o.g->off, o.g->bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  return 0;
 }
 #endif  // !__HIP_DEVICE_COMPILE__
