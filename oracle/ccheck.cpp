@@ -10,10 +10,11 @@
 // tests/test_ccheck.py against oracle/check.py (the restatement that is pinned on the reference's
 // golden fixtures) on the golden store and the synthetic configurations.
 //
-// Deliberately partial - it reports `unsupported` instead of guessing:
-//   * tables with role policies or parent roles (index.go:352-530, 716-788) -> ccheck_run returns 1;
-//   * conditions that are not a fused comparison or an all/any/none tree of them -> the request's
-//     tuples carry CBH_ST_UNSUPPORTED (oracle/check.py stays the oracle for those).
+// Covers principal and resource policies, scope chains and scope permissions, derived roles, role policies
+// (the synthetic DENY bindings of index.go:352-530) and parent roles (index.go:716-788).
+// Deliberately partial in one respect - it reports instead of guessing: conditions that are not a fused
+// comparison or an all/any/none tree of them -> the request's tuples carry CBH_ST_UNSUPPORTED
+// (oracle/check.py stays the oracle for those).
 //
 // Build: g++ -O2 -std=c++17 -shared -fPIC -pthread -Iinclude -Icerbos_amd/csrc oracle/ccheck.cpp -o oracle/libccheck.so
 #include <stdint.h>
@@ -36,7 +37,7 @@ namespace {
 struct Img {
   const u8* base = nullptr;
   u32 meta[CBH_META_N];
-  const u32 *str_off, *scope_parent, *scope_flags, *rows, *pool, *dr, *code, *const_rec, *theap_rec;
+  const u32 *str_off, *scope_parent, *scope_flags, *rows, *rprows, *pool, *dr, *code, *const_rec, *theap_rec;
   const u8* str_bytes;
   const CbhHashSlot* hash;
   const u64* gbits;
@@ -59,7 +60,7 @@ bool parse(Img& g, const u8* blob, size_t len) {
   g.str_off = (const u32*)section(blob, CBH_SEC_STR_OFF); g.str_bytes = section(blob, CBH_SEC_STR_BYTES);
   g.scope_parent = (const u32*)section(blob, CBH_SEC_SCOPE_PARENT); g.scope_flags = (const u32*)section(blob, CBH_SEC_SCOPE_FLAGS);
   g.hash = (const CbhHashSlot*)section(blob, CBH_SEC_HASH); g.hash_mask = g.meta[CBH_M_HASH_MASK];
-  g.rows = (const u32*)section(blob, CBH_SEC_ROWS); g.pool = (const u32*)section(blob, CBH_SEC_U32POOL);
+  g.rows = (const u32*)section(blob, CBH_SEC_ROWS); g.rprows = (const u32*)section(blob, CBH_SEC_RPROWS); g.pool = (const u32*)section(blob, CBH_SEC_U32POOL);
   g.dr = (const u32*)section(blob, CBH_SEC_DR); g.code = (const u32*)section(blob, CBH_SEC_CODE);
   g.const_rec = (const u32*)section(blob, CBH_SEC_CONST_REC); g.theap_rec = (const u32*)section(blob, CBH_SEC_THEAP_REC);
   g.gbits = (const u64*)section(blob, CBH_SEC_GBITS); g.K = g.meta[CBH_M_NSTRINGS];
@@ -284,10 +285,23 @@ void check_request(const Img& g, const cbh_batch& b, const cbh_params& p, u32 r,
   const std::vector<u32> r_scopes = scope_chain(g, RQ(CBH_RQ_R_SCOPE), 1u, lenient);   // check.go:165-170
   bool p_exists = false, r_exists = false;
   for (u32 si : p_scopes) if (dir_find(g, CBH_B_PPEXISTS, p_ver, si, 0)) { p_exists = true; break; }
-  for (u32 si : r_scopes) if (dir_find(g, CBH_B_RESEXISTS, r_ver, kind, si)) { r_exists = true; break; }
+  const u64 kind_bits = glob_bits(g, b, 2, kind);
+  for (u32 si : r_scopes) {                                                    // index.go:966-997: role-policy rows count too
+    if (dir_find(g, CBH_B_RESEXISTS, r_ver, kind, si)) { r_exists = true; break; }
+    if (const CbhHashSlot* rp = dir_find(g, CBH_B_RPRES, r_ver, si, 0))
+      for (u32 k = 0; k < rp->v1 && !r_exists; ++k) r_exists = pat_match(g.pool[rp->v0 + k], kind, kind_bits);
+    if (r_exists) break;
+  }
+  // AddParentRoles (index.go:716-742) for the request's effective resource scope: the ancestors of a role
+  const u32 r_scope_w = RQ(CBH_RQ_R_SCOPE);
+  const bool has_parents = (g.meta[CBH_M_FLAGS] & CBH_MF_HAS_PARENT_ROLES) && (r_scope_w & CBH_SCOPE_EXACT);
+  auto ancestors = [&](u32 role, u32& off, u32& cnt) {
+    off = cnt = 0;
+    if (!has_parents) return;
+    if (const CbhHashSlot* pv = dir_find(g, CBH_B_PARENTS, r_scope_w & ~CBH_SCOPE_EXACT, role, 0)) { off = pv->v0; cnt = pv->v1; }
+  };
   const bool nothing = (p_scopes.empty() && r_scopes.empty()) || (!p_exists && !r_exists);
 
-  const u64 kind_bits = glob_bits(g, b, 2, kind);
   std::vector<CondMemo> memo;            // conditionCache of the request (check.go:186, 316-340)
   std::vector<std::pair<u32, u64>> sdr;  // processedScopedDerivedRoles: scope -> effective derived roles (check.go:237-282)
   std::vector<std::pair<u32, bool>> sdr_err;
@@ -317,6 +331,13 @@ void check_request(const Img& g, const cbh_batch& b, const cbh_params& p, u32 r,
         if (ri > 0 && !is_res) break;
         const u32 role = b.roles[role_off + ri];
         const u64 role_bits = glob_bits(g, b, 1, role);
+        u32 anc_off = 0, anc_cnt = 0;
+        if (is_res) ancestors(role, anc_off, anc_cnt);
+        auto role_match = [&](u32 pat) {   // the pattern against [role] ++ its ancestors (check.go:293, index.go:214-336)
+          if (pat_match(pat, role, role_bits)) return true;
+          for (u32 q = 0; q < anc_cnt; ++q) if (pat_match(pat, g.pool[anc_off + q], glob_bits(g, b, 1, g.pool[anc_off + q]))) return true;
+          return false;
+        };
         bool has_allow = false;
         u32 r_eff = 0, r_pol = exists && !scopes.empty() ? main_key : ((u32)CBH_P_NO_MATCH << 28), r_scp = CBH_NONE;
         for (u32 si : scopes) {                                                  // :231
@@ -330,7 +351,12 @@ void check_request(const Img& g, const cbh_batch& b, const cbh_params& p, u32 r,
                   const u32* dr = g.dr + 4 * (size_t)d;
                   bool applies = dr[CBH_DR_PARENTS_CNT] == CBH_NONE;
                   for (u32 q = 0; !applies && q < dr[CBH_DR_PARENTS_CNT]; ++q)
-                    for (u32 x = 0; !applies && x < role_cnt; ++x) applies = g.pool[dr[CBH_DR_PARENTS_OFF] + q] == b.roles[role_off + x];
+                    for (u32 x = 0; !applies && x < role_cnt; ++x) {              // includingParentRoles (check.go:244)
+                      const u32 want = g.pool[dr[CBH_DR_PARENTS_OFF] + q], have = b.roles[role_off + x];
+                      applies = want == have;
+                      u32 ao, ac; ancestors(have, ao, ac);
+                      for (u32 z = 0; !applies && z < ac; ++z) applies = g.pool[ao + z] == want;
+                    }
                   if (!applies) continue;
                   bool e = false;
                   const int res = rq.satisfies(dr[CBH_DR_COND], strict, e);
@@ -343,9 +369,38 @@ void check_request(const Img& g, const cbh_batch& b, const cbh_params& p, u32 r,
             }
           }
           if (r_eff != 0) break;                                                 // :284
+          bool brk = false;
+          if (is_res && (g.meta[CBH_M_FLAGS] & CBH_MF_HAS_ROLE_POLICIES)) {
+            // synthetic DENY bindings from the role policies of [role] ++ ancestors come first (index.go:352-530)
+            for (u32 k = 0; k <= anc_cnt && !brk && !done; ++k) {
+              const u32 srole = k == 0 ? role : g.pool[anc_off + k - 1];
+              const CbhHashSlot* rp = dir_find(g, CBH_B_ROLEPOL, r_ver, si, srole);
+              if (!rp) continue;
+              const u32 rp_pol = ((u32)CBH_P_TABLE << 28) | rp->v2;
+              auto rule_matches = [&](const u32* rr) {   // the rule is for this resource and allows this action
+                if (!pat_match(rr[CBH_RP_RESOURCE], kind, kind_bits)) return false;
+                for (u32 a = 0; a < rr[CBH_RP_ALLOW_CNT]; ++a) if (pat_match(g.pool[rr[CBH_RP_ALLOW_OFF] + a], action, act_bits)) return true;
+                return false;
+              };
+              bool any = false;
+              for (u32 row = rp->v0; row < rp->v0 + rp->v1 && !any; ++row) any = rule_matches(g.rprows + CBH_RP_NF * (size_t)row);
+              bool deny = !any;                          // no rule for the resource / no allow-action matched (index.go:436-461)
+              for (u32 row = rp->v0; row < rp->v0 + rp->v1 && !deny; ++row) {
+                const u32* rr = g.rprows + CBH_RP_NF * (size_t)row;
+                if (rr[CBH_RP_COND] == CBH_NONE || !rule_matches(rr)) continue;
+                bool e = false;
+                const int res = rq.satisfies(rr[CBH_RP_COND], strict, e);   // the binding is DENY when none(condition)
+                if (e) err = true;
+                if (res == 2) { eff = CBH_EFFECT_DENY; pol = rp_pol; scp = si; done = true; break; }
+                if (res == 0) deny = true;
+              }
+              if (done) break;
+              if (deny) { r_eff = CBH_EFFECT_DENY; r_pol = rp_pol; r_scp = si; brk = true; }   // check.go:395-403
+            }
+          }
+          if (done || brk) break;
           const CbhHashSlot* bk = is_res ? dir_find(g, CBH_B_RESOURCE, r_ver, kind, si)
                                          : dir_find(g, CBH_B_PRINCIPAL, r_ver, si, pid);   // resource version: check.go:294
-          bool brk = false;
           for (u32 row = bk ? bk->v0 : 0; bk && row < bk->v0 + bk->v1; ++row) {  // :295-414, binding order
             const u32* rw = g.rows + CBH_ROW_NF * (size_t)row;
             const u32 fl = rw[CBH_ROW_FLAGS];
@@ -354,8 +409,8 @@ void check_request(const Img& g, const cbh_batch& b, const cbh_params& p, u32 r,
             auto nth = [&](u32 first, u32 more, bool in_pool, u32 i) { return in_pool ? g.pool[rw[first] + i] : (i == 0 ? rw[first] : rw[more + i - 1]); };
             bool m;
             if (!is_res) m = pat_match(rw[CBH_ROW_RESOURCE], kind, kind_bits);
-            else if (n_role == 0) m = pat_match(rw[CBH_ROW_ROLE], role, role_bits);
-            else { m = false; for (u32 i = 0; i < n_role; ++i) m = m || pat_match(nth(CBH_ROW_ROLE, CBH_ROW_R1, fl & CBH_ROW_F_ROLE_LIST, i), role, role_bits); }
+            else if (n_role == 0) m = role_match(rw[CBH_ROW_ROLE]);
+            else { m = false; for (u32 i = 0; i < n_role; ++i) m = m || role_match(nth(CBH_ROW_ROLE, CBH_ROW_R1, fl & CBH_ROW_F_ROLE_LIST, i)); }
             if (!m) continue;
             if (n_act == 0) m = pat_match(rw[CBH_ROW_ACTION], action, act_bits);
             else { m = false; for (u32 i = 0; i < n_act; ++i) m = m || pat_match(nth(CBH_ROW_ACTION, CBH_ROW_A1, fl & CBH_ROW_F_ACTION_LIST, i), action, act_bits); }
@@ -394,11 +449,10 @@ void check_request(const Img& g, const cbh_batch& b, const cbh_params& p, u32 r,
 
 }  // namespace
 
-// 0 = done, 1 = the table uses features outside this restatement, -1 = bad image
+// 0 = done, -1 = bad image (1 is reserved for "table outside this restatement"; no such table today)
 extern "C" int ccheck_run(const void* blob, size_t len, const cbh_batch* in, const cbh_params* p, cbh_result* out, int n_threads) {
   Img g;
   if (!parse(g, (const u8*)blob, len)) return -1;
-  if (g.meta[CBH_M_FLAGS] & (CBH_MF_HAS_PARENT_ROLES | CBH_MF_HAS_ROLE_POLICIES)) return 1;
   const u32 n = in->n_requests;
   if (n_threads <= 1) {
     for (u32 r = 0; r < n; ++r) check_request(g, *in, *p, r, *out);

@@ -20,7 +20,7 @@ _lib = None
 
 
 class Unsupported(Exception):
-    """The table uses features outside the C++ restatement (role policies, parent roles)."""
+    """The table uses features outside the C++ restatement (ccheck_run returned 1; none today)."""
 
 
 def build(force=False):
@@ -57,7 +57,7 @@ class Prepared:
         rc = lib().ccheck_run(C.cast(self.buf, C.c_void_p), len(self.lt.blob), C.byref(self.cb), C.byref(p),
                               C.byref(res.c), threads)
         if rc == 1:
-            raise Unsupported("table has role policies / parent roles")
+            raise Unsupported("table outside the C++ restatement")
         if rc != 0:
             raise RuntimeError("ccheck_run failed: bad table image")
         return res

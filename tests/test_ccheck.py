@@ -4,8 +4,8 @@ baseline) against oracle/check.py, which is itself pinned on the reference's gol
 
 * the synthetic BASELINE configurations in every evaluation mode - effect, policy key, scope,
   effective derived roles of every tuple, and whether the request produced evaluation errors;
-* the reference's own golden store with its role policies taken out (ccheck reports tables with
-  role policies / parent roles as unsupported) over the inputs of all golden engine cases.
+* the reference's own golden store (with and without its role policies) over the inputs of all golden
+  engine cases, C5, and fuzzed stores with role policies / parent roles / principal policies.
 """
 import json
 import os
@@ -39,14 +39,14 @@ class _Decoder(HipEvaluator):
         self.lt = lt
 
 
-def _compare(rt, lt, inputs, batch, mode, threads=1, check_errors=True):
+def _compare(rt, lt, inputs, batch, mode, threads=1, check_errors=True, globals_=None):
     flags = capi.F_WANT_DERIVED_ROLES
     flags |= capi.F_LENIENT_SCOPE_SEARCH if mode == "lenient" else 0
     flags |= capi.F_STRICT_EVALUATION if mode == "strict" else 0
     res = ccheck.check(lt, batch, NOW, flags, threads)
     outs, bad = _Decoder(lt).assemble(inputs, batch, res, "default", allow_unsupported=True)
     orc = RuleTableOracle(rt)
-    params = EvalParams(now_ns=NOW, lenient_scope_search=mode == "lenient", strict_evaluation=mode == "strict")
+    params = EvalParams(globals_=globals_, now_ns=NOW, lenient_scope_search=mode == "lenient", strict_evaluation=mode == "strict")
     t = 0
     n_cmp = 0
     for r, (inp, got) in enumerate(zip(inputs, outs)):
@@ -107,34 +107,49 @@ def test_ccheck_on_golden_store_without_role_policies():
     assert total > skipped, (total, skipped)
 
 
-def test_ccheck_refuses_role_policy_tables():
+def test_ccheck_on_golden_store_with_role_policies():
+    """The whole golden store (role policies, parent roles, scope permissions) over every golden input."""
     with open(os.path.join(GOLDEN, "store_policies.json")) as fh:
         docs = json.load(fh)
+    with open(os.path.join(GOLDEN, "engine_cases.json")) as fh:
+        cases = json.load(fh)
+    assert any("rolePolicy" in d for d in docs)
     rt = rule_table_from_policies(policies_from_docs(docs))
-    lt = lower_rule_table(rt)
-    batch = Flattener(lt).flatten([{"principal": {"id": "x", "roles": ["user"]}, "resource": {"kind": "leave_request", "id": "1"},
-                                    "actions": ["view"]}])
-    with pytest.raises(ccheck.Unsupported):
-        ccheck.check(lt, batch, NOW, 0)
+    lt = lower_rule_table(rt, {"environment": "test"})
+    inputs = [inp for c in cases for inp in c["inputs"]]
+    total = skipped = 0
+    for mode in ("default", "lenient", "strict"):
+        n_cmp, n_bad = _compare(rt, lt, inputs, Flattener(lt).flatten(inputs, sort=False), mode, check_errors=False,
+                                globals_={"environment": "test"})
+        total += n_cmp
+        skipped += n_bad
+    assert total > 2 * skipped, (total, skipped)
 
 
-@pytest.mark.parametrize("name", ["C2", "C3"])
 @pytest.mark.parametrize("mode", ["default", "lenient", "strict"])
-def test_device_source_bit_exact_against_ccheck(name, mode):
-    """The decision kernel's source (host-simulated waves) vs the C++ restatement on 3000 requests:
-    every output array identical, and the same requests report CEL errors."""
-    import hostsim_api
-    pol_fn = CONFIGS[name][0]
-    full = {"C2": workloads.c2_requests, "C3": workloads.c3_requests}[name]
-    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol_fn())))
-    batch = full(3000).to_batch(Flattener(lt))
-    flags = capi.F_WANT_DERIVED_ROLES
-    flags |= capi.F_LENIENT_SCOPE_SEARCH if mode == "lenient" else 0
-    flags |= capi.F_STRICT_EVALUATION if mode == "strict" else 0
-    got = hostsim_api.check(lt, batch, NOW, flags)
-    want = ccheck.check(lt, batch, NOW, flags)
-    for f in ("effect", "policy", "scope", "edr"):
-        assert np.array_equal(getattr(got, f), getattr(want, f)), f
-    ge = (got.status == capi.ST_CEL_ERROR).reshape(-1, 4).any(axis=1)
-    we = (want.status == capi.ST_CEL_ERROR).reshape(-1, 4).any(axis=1)
-    assert np.array_equal(ge, we)
+def test_ccheck_matches_python_oracle_on_c5(mode):
+    """C5: principal policies, role policies, action globs, nested CEL.  Requests whose path needs the
+    general CEL interpreter are reported unsupported by ccheck (it evaluates leaf trees only)."""
+    rt = rule_table_from_policies(policies_from_docs(workloads.c5_policies()))
+    lt = lower_rule_table(rt)
+    inputs = workloads.c5_requests(300).to_inputs()
+    n_cmp, n_bad = _compare(rt, lt, inputs, Flattener(lt).flatten(inputs), mode)
+    assert n_cmp > 50, (n_cmp, n_bad)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_ccheck_matches_python_oracle_on_fuzzed_stores(seed):
+    from cerbos_amd.lower.celc import LoweringError
+    from test_fuzz_parity import _policies, _requests
+    rng = np.random.default_rng(10_000 + seed)
+    rt = rule_table_from_policies(policies_from_docs(_policies(rng)))
+    try:
+        lt = lower_rule_table(rt)
+    except LoweringError:
+        pytest.skip("store refused by the lowering")
+    inputs = _requests(rng, 120)
+    total = 0
+    for mode in ("default", "lenient", "strict"):
+        n_cmp, _ = _compare(rt, lt, inputs, Flattener(lt).flatten(inputs), mode, check_errors=False)
+        total += n_cmp
+    assert total > 100

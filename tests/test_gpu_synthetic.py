@@ -130,10 +130,38 @@ def test_full_size_bit_exact_against_cpp_oracle(name, n_requests, mode):
     table.close()
 
 
+@pytest.mark.parametrize("mode", ["default", "strict", "lenient"])
+def test_c5_full_size_against_cpp_oracle(mode):
+    """C5 at one GPU's share (1M tuples; principal policies, role policies, action globs, nested CEL): every
+    tuple whose decision path the C++ restatement covers (it flags the ones that need general CEL programs,
+    ~15 %) must agree in effect, policy, scope, derived-role mask and error status."""
+    import os
+    from oracle import ccheck
+    rt, lt, table = _table(workloads.c5_policies)
+    batch = workloads.c5_requests(250_000).to_batch(Flattener(lt))
+    flags = capi.F_WANT_DERIVED_ROLES
+    flags |= capi.F_LENIENT_SCOPE_SEARCH if mode == "lenient" else 0
+    flags |= capi.F_STRICT_EVALUATION if mode == "strict" else 0
+    got = table.check(batch, now_ns=NOW, flags=flags)
+    want = ccheck.check(lt, batch, NOW, flags, threads=min(16, os.cpu_count() or 1))
+    assert (got.status != capi.ST_UNSUPPORTED).all()
+    ok = want.status != capi.ST_UNSUPPORTED
+    assert ok.mean() > 0.7
+    for f in ("effect", "policy", "scope"):
+        mism = np.nonzero(getattr(got, f)[ok] != getattr(want, f)[ok])[0]
+        assert mism.size == 0, "%s: %d mismatches, first at %s" % (f, mism.size, mism[:5])
+    okr = ok.reshape(-1, 4).all(axis=1)
+    assert np.array_equal(got.edr[okr], want.edr[okr])
+    ge = (got.status == capi.ST_CEL_ERROR).reshape(-1, 4).any(axis=1)
+    we = (want.status == capi.ST_CEL_ERROR).reshape(-1, 4).any(axis=1)
+    assert np.array_equal(ge[okr], we[okr])
+    table.close()
+
+
 def test_c5_full_batch_properties():
     """C5 (principal overrides, action globs, role policies, nested-attribute CEL on the operand-stack
-    interpreter) at one GPU's share, 1M tuples: the first 1500 requests against oracle/check.py (the
-    C++ restatement does not cover role policies), determinism, and request-order invariance."""
+    interpreter) at one GPU's share, 1M tuples: the first 1500 requests against oracle/check.py (all of
+    them, including the ones the C++ restatement flags), determinism, and request-order invariance."""
     from cerbos_amd.flatten import permute_requests
     rt, lt, table = _table(workloads.c5_policies)
     assert lt.stats["generic_programs"] and lt.stats["role_policy_rows"] > 0 and sum(lt.stats["globs"]) > 0

@@ -56,3 +56,26 @@ def test_config_matches_oracle(name, mode):
         assert mism.size == 0, "first mismatching tuple %s of %s/%s" % (mism[:5], name, mode)
     # the workload must exercise both outcomes
     assert 0 < (want == capi.EFFECT_ALLOW).sum() < want.size
+
+
+@pytest.mark.parametrize("name,n", [("C3", 8000), ("C5", 8000)])
+def test_kernel_source_matches_cpp_oracle_on_larger_batches(name, n):
+    """The host-simulated kernels against oracle/ccheck.cpp (pinned on oracle/check.py in test_ccheck.py) on
+    batches too large for the Python oracle: every output of every tuple ccheck covers (it flags requests
+    that need general CEL programs)."""
+    from oracle import ccheck
+    pol_fn, req_fn = CONFIGS[name]
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol_fn())))
+    batch = req_fn(n).to_batch(Flattener(lt))
+    for flags in (capi.F_WANT_DERIVED_ROLES, capi.F_WANT_DERIVED_ROLES | capi.F_STRICT_EVALUATION,
+                  capi.F_WANT_DERIVED_ROLES | capi.F_LENIENT_SCOPE_SEARCH):
+        want = ccheck.check(lt, batch, NOW, flags, 4)
+        got = hostsim_api.check(lt, batch, NOW, flags)
+        ok = want.status != capi.ST_UNSUPPORTED
+        assert ok.mean() > 0.7
+        for f in ("effect", "policy", "scope"):
+            assert np.array_equal(getattr(got, f)[ok], getattr(want, f)[ok]), (f, flags)
+        okr = ok.reshape(-1, 4).all(axis=1)
+        assert np.array_equal(got.edr[okr], want.edr[okr])
+        assert np.array_equal((got.status == capi.ST_CEL_ERROR).reshape(-1, 4).any(axis=1)[okr],
+                              (want.status == capi.ST_CEL_ERROR).reshape(-1, 4).any(axis=1)[okr])
