@@ -17,6 +17,7 @@
 #include <numeric>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -415,13 +416,13 @@ int cbi_table_open(const void* blob, size_t len, cbi_table** out) {
 
 void cbi_table_close(cbi_table* t) { delete t; }
 
-int cbi_flatten_pb(const cbi_table* t, const uint8_t* bytes, const uint64_t* offsets, uint32_t n, const char* default_version,
-                   const char* default_scope, int sort, cbi_batch** out) {
-  if (!t || !out || (n && (!bytes || !offsets))) return fail("cbi_flatten_pb: null argument");
-  std::string_view dver = default_version ? default_version : "default";
-  std::string_view dscope = default_scope ? default_scope : "";
-  auto b = new cbi_batch();
-  auto bail = [&](const std::string& m) { delete b; return fail(m); };
+// (the three helpers below are file-local)
+}  // extern "C"
+
+// Flattens messages [0, n) into `b` in input order: no routing sort, no view; req_input holds slice-local indices.
+static int flatten_slice(const cbi_table* t, const uint8_t* bytes, const uint64_t* offsets, uint32_t n, std::string_view dver,
+                         std::string_view dscope, cbi_batch* b, std::string& err) {
+  auto bail = [&](const std::string& m) { err = m; return -1; };
   const u32 ncol = (u32)t->columns.size();
 
   // pass 1: count device requests (a CheckInput with > 64 actions becomes several) and tuples
@@ -540,63 +541,187 @@ int cbi_flatten_pb(const cbi_table* t, const uint8_t* bytes, const uint64_t* off
       for (size_t a = a0; a < a1; ++a) { b->tuple_req.push_back(r); b->tuple_action.push_back(in.sid(actions[a], SF_ACTION)); }
     }
   }
+  return 0;
+}
 
-  // routing sort (flatten.py sort_batch_by_route): kind, resource version, resource scope, role count,
-  // order-sensitive signature of the role list; stable
+// Routing sort (flatten.py sort_batch_by_route): kind, resource version, resource scope, role count,
+// order-sensitive signature of the role list; stable.  Fills tuple_perm.
+static void sort_batch(cbi_batch* b, u32 ncol, bool sort) {
+  const u32 R = (u32)b->req_input.size();
+  auto RQ = [&](u32 f, u32 r) -> u32& { return b->req[(size_t)f * R + r]; };
   const u32 T = (u32)b->tuple_action.size();
   b->tuple_perm.resize(T);
   std::iota(b->tuple_perm.begin(), b->tuple_perm.end(), (u64)0);
-  if (sort && R > 1) {
-    std::vector<u64> sig(R, 0);
-    for (u32 q = 0; q < R; ++q) {
-      u32 off = RQ(RQ_ROLE_OFF, q), cnt = RQ(RQ_ROLE_CNT, q);
-      u64 s = 0;
-      for (u32 k = 0; k < cnt; ++k) s += ((u64)b->roles[off + k] + 1) * ((u64)k * 0x9E3779B97F4A7C15ull + 0xC2B2AE3D27D4EB4Full);
-      sig[q] = s;
-    }
-    std::vector<u32> order(R);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) {
-      u32 a, c;
-      if ((a = RQ(RQ_KIND, x)) != (c = RQ(RQ_KIND, y))) return a < c;
-      if ((a = RQ(RQ_R_VERSION, x)) != (c = RQ(RQ_R_VERSION, y))) return a < c;
-      if ((a = RQ(RQ_R_SCOPE, x)) != (c = RQ(RQ_R_SCOPE, y))) return a < c;
-      if ((a = RQ(RQ_ROLE_CNT, x)) != (c = RQ(RQ_ROLE_CNT, y))) return a < c;
-      return sig[x] < sig[y];
-    });
-    bool identity = true;
-    for (u32 q = 0; q < R; ++q) if (order[q] != q) { identity = false; break; }
-    if (!identity) {
-      std::vector<u32> req2((size_t)RQ_N * R), ta(T), tr(T), ri(R);
-      std::vector<u8> ct((size_t)ncol * R);
-      std::vector<u64> cv((size_t)ncol * R), tp(T);
-      u32 pos = 0;
-      for (u32 q = 0; q < R; ++q) {
-        u32 o = order[q];
-        for (u32 f = 0; f < RQ_N; ++f) req2[(size_t)f * R + q] = b->req[(size_t)f * R + o];
-        for (u32 c = 0; c < ncol; ++c) { ct[(size_t)c * R + q] = b->col_tag[(size_t)c * R + o]; cv[(size_t)c * R + q] = b->col_val[(size_t)c * R + o]; }
-        u32 s0 = RQ(RQ_ACT_OFF, o), cn = RQ(RQ_ACT_CNT, o);
-        req2[(size_t)RQ_ACT_OFF * R + q] = pos;
-        for (u32 k = 0; k < cn; ++k, ++pos) { ta[pos] = b->tuple_action[s0 + k]; tr[pos] = q; tp[pos] = s0 + k; }
-        ri[q] = b->req_input[o];
-      }
-      b->req.swap(req2); b->col_tag.swap(ct); b->col_val.swap(cv);
-      b->tuple_action.swap(ta); b->tuple_req.swap(tr); b->tuple_perm.swap(tp); b->req_input.swap(ri);
-    }
+  if (!sort || R < 2) return;
+  // compact sort keys: the comparator then touches one 32-byte record per side instead of five strided arrays
+  struct Key { u32 kind, ver, scope, cnt; u64 sig; u32 idx; };
+  std::vector<Key> keys(R);
+  for (u32 q = 0; q < R; ++q) {
+    const u32 off = RQ(RQ_ROLE_OFF, q), cnt = RQ(RQ_ROLE_CNT, q);
+    u64 sg = 0;
+    for (u32 k = 0; k < cnt; ++k) sg += ((u64)b->roles[off + k] + 1) * ((u64)k * 0x9E3779B97F4A7C15ull + 0xC2B2AE3D27D4EB4Full);
+    keys[q] = Key{RQ(RQ_KIND, q), RQ(RQ_R_VERSION, q), RQ(RQ_R_SCOPE, q), cnt, sg, q};
   }
+  auto less = [](const Key& x, const Key& y) {
+    if (x.kind != y.kind) return x.kind < y.kind;
+    if (x.ver != y.ver) return x.ver < y.ver;
+    if (x.scope != y.scope) return x.scope < y.scope;
+    if (x.cnt != y.cnt) return x.cnt < y.cnt;
+    if (x.sig != y.sig) return x.sig < y.sig;
+    return x.idx < y.idx;   // = stable
+  };
+  if (std::is_sorted(keys.begin(), keys.end(), less)) return;
+  std::sort(keys.begin(), keys.end(), less);
+  std::vector<u32> req2((size_t)RQ_N * R), ta(T), tr(T), ri(R);
+  std::vector<u8> ct((size_t)ncol * R);
+  std::vector<u64> cv((size_t)ncol * R), tp(T);
+  u32 pos = 0;
+  for (u32 q = 0; q < R; ++q) {
+    const u32 o = keys[q].idx;
+    for (u32 f = 0; f < RQ_N; ++f) req2[(size_t)f * R + q] = b->req[(size_t)f * R + o];
+    for (u32 c = 0; c < ncol; ++c) { ct[(size_t)c * R + q] = b->col_tag[(size_t)c * R + o]; cv[(size_t)c * R + q] = b->col_val[(size_t)c * R + o]; }
+    const u32 s0 = RQ(RQ_ACT_OFF, o), cn = RQ(RQ_ACT_CNT, o);
+    req2[(size_t)RQ_ACT_OFF * R + q] = pos;
+    for (u32 k = 0; k < cn; ++k, ++pos) { ta[pos] = b->tuple_action[s0 + k]; tr[pos] = q; tp[pos] = s0 + k; }
+    ri[q] = b->req_input[o];
+  }
+  b->req.swap(req2); b->col_tag.swap(ct); b->col_val.swap(cv);
+  b->tuple_action.swap(ta); b->tuple_req.swap(tr); b->tuple_perm.swap(tp); b->req_input.swap(ri);
+}
 
+static void finish_view(cbi_batch* b, u32 ncol) {
   // never hand out null pointers for empty arrays
   auto nz32 = [](std::vector<u32>& v) { if (v.empty()) v.reserve(1); return v.data(); };
   cbh_batch& v = b->view;
-  v.n_requests = R; v.n_tuples = T; v.n_roles = (u32)b->roles.size(); v.n_columns = ncol;
+  v.n_requests = (u32)b->req_input.size(); v.n_tuples = (u32)b->tuple_action.size(); v.n_roles = (u32)b->roles.size(); v.n_columns = ncol;
   v.n_strings = (u32)b->str_flags.size(); v.heap_len = (u32)b->heap_tag.size(); v.str_bytes_len = b->str_bytes.size();
   b->heap_tag.reserve(1); b->heap_val.reserve(1); b->str_bytes.reserve(1); b->str_flags.reserve(1);
   b->col_tag.reserve(1); b->col_val.reserve(1); b->tuple_perm.reserve(1); b->req_input.reserve(1);
   v.req_u32 = nz32(b->req); v.roles = nz32(b->roles); v.tuple_req = nz32(b->tuple_req); v.tuple_action = nz32(b->tuple_action);
   v.col_tag = b->col_tag.data(); v.col_val = b->col_val.data(); v.heap_tag = b->heap_tag.data(); v.heap_val = b->heap_val.data();
   v.str_off = b->str_off.data(); v.str_bytes = b->str_bytes.data(); v.str_flags = b->str_flags.data();
+}
+
+// Concatenates slice batches (slice k = inputs [base[k], base[k+1])) into one.  A batch-local string keeps
+// the id it would have had in a single pass: the merged dictionary takes slice 0's strings, then the
+// strings slice 1 saw first, ... - which is first-appearance order over the whole input.  Heap tapes
+// and role lists concatenate; only offsets and batch-local ids are rebased.
+static void merge_slices(const cbi_table* t, std::vector<cbi_batch*>& parts, const std::vector<u32>& base, cbi_batch* out, int n_threads) {
+  const u32 ncol = (u32)t->columns.size(), K = t->K, P = (u32)parts.size();
+  std::vector<u32> rb(P + 1, 0), tb(P + 1, 0), hb(P + 1, 0), lb(P + 1, 0);   // request / tuple / heap / role bases
+  for (u32 k = 0; k < P; ++k) {
+    rb[k + 1] = rb[k] + (u32)parts[k]->req_input.size(); tb[k + 1] = tb[k] + (u32)parts[k]->tuple_action.size();
+    hb[k + 1] = hb[k] + (u32)parts[k]->heap_tag.size(); lb[k + 1] = lb[k] + (u32)parts[k]->roles.size();
+  }
+  const u32 R = rb[P], T = tb[P];
+  // merged dictionary (serial: it defines the ids)
+  std::vector<std::vector<u32>> remap(P);
+  out->str_off.assign(1, 0);
+  StrIndex index;
+  { size_t tot = 0; for (cbi_batch* p : parts) tot += p->str_flags.size(); index.reserve(tot); }
+  auto at = [&](u32 i) { return std::string_view((const char*)out->str_bytes.data() + out->str_off[i], out->str_off[i + 1] - out->str_off[i]); };
+  for (u32 k = 0; k < P; ++k) {
+    const cbi_batch* p = parts[k];
+    const u32 ns = (u32)p->str_flags.size();
+    remap[k].resize(ns);
+    for (u32 j = 0; j < ns; ++j) {
+      std::string_view sj((const char*)p->str_bytes.data() + p->str_off[j], p->str_off[j + 1] - p->str_off[j]);
+      const u64 h = hash_bytes(sj);
+      u32 id;
+      if (k > 0 && index.find(sj, h, at, id)) out->str_flags[id] |= p->str_flags[j];
+      else {
+        id = (u32)out->str_flags.size();
+        out->str_bytes.insert(out->str_bytes.end(), sj.begin(), sj.end());
+        out->str_off.push_back((u32)out->str_bytes.size());
+        out->str_flags.push_back(p->str_flags[j]);
+        index.insert(h, id);
+      }
+      remap[k][j] = id;
+    }
+  }
+  out->req.assign((size_t)RQ_N * R, 0);
+  out->col_tag.assign((size_t)ncol * R, 0); out->col_val.assign((size_t)ncol * R, 0);
+  out->roles.resize(lb[P]); out->tuple_req.resize(T); out->tuple_action.resize(T);
+  out->heap_tag.resize(hb[P]); out->heap_val.resize(hb[P]); out->req_input.resize(R);
+  static const u32 STRING_FIELDS[] = {RQ_PRINCIPAL_ID, RQ_P_VERSION, RQ_KIND, RQ_R_VERSION, RQ_S_RESOURCE_ID, RQ_S_KIND,
+                                      RQ_S_P_SCOPE, RQ_S_R_SCOPE, RQ_S_P_VERSION, RQ_S_R_VERSION};
+  auto place = [&](u32 k) {   // slices write disjoint ranges: one thread each
+    const cbi_batch* p = parts[k];
+    const std::vector<u32>& mp = remap[k];
+    const u32 r0 = rb[k], nr = rb[k + 1] - rb[k], h0 = hb[k];
+    auto sid = [&](u32 id) { return id >= K ? K + mp[id - K] : id; };
+    auto val = [&](u8 tag, u64 v) -> u64 {
+      if (tag == T_STRING) return sid((u32)v);
+      if (tag == T_LIST || tag == T_MAP) return v + ((u64)h0 << 32);   // (HEAP_BATCH << 62) | off << 32 | len
+      return v;
+    };
+    for (u32 f = 0; f < RQ_N; ++f) std::memcpy(&out->req[(size_t)f * R + r0], &p->req[(size_t)f * nr], (size_t)nr * 4);
+    for (u32 f : STRING_FIELDS) for (u32 r = 0; r < nr; ++r) { u32& x = out->req[(size_t)f * R + r0 + r]; x = sid(x); }
+    for (u32 r = 0; r < nr; ++r) {
+      out->req[(size_t)RQ_ROLE_OFF * R + r0 + r] += lb[k]; out->req[(size_t)RQ_ACT_OFF * R + r0 + r] += tb[k];
+      out->req_input[r0 + r] = p->req_input[r] + base[k];
+    }
+    for (size_t i = 0; i < p->roles.size(); ++i) out->roles[lb[k] + i] = sid(p->roles[i]);
+    for (size_t i = 0; i < p->tuple_action.size(); ++i) { out->tuple_action[tb[k] + i] = sid(p->tuple_action[i]); out->tuple_req[tb[k] + i] = p->tuple_req[i] + r0; }
+    for (u32 c = 0; c < ncol; ++c)
+      for (u32 r = 0; r < nr; ++r) {
+        const u8 tag = p->col_tag[(size_t)c * nr + r];
+        out->col_tag[(size_t)c * R + r0 + r] = tag;
+        out->col_val[(size_t)c * R + r0 + r] = val(tag, p->col_val[(size_t)c * nr + r]);
+      }
+    for (size_t i = 0; i < p->heap_tag.size(); ++i) { out->heap_tag[h0 + i] = p->heap_tag[i]; out->heap_val[h0 + i] = val(p->heap_tag[i], p->heap_val[i]); }
+  };
+  if (n_threads <= 1) { for (u32 k = 0; k < P; ++k) place(k); }
+  else {
+    std::vector<std::thread> th;
+    for (u32 k = 0; k < P; ++k) th.emplace_back(place, k);
+    for (auto& x : th) x.join();
+  }
+}
+
+extern "C" {
+
+int cbi_flatten_pb_mt(const cbi_table* t, const uint8_t* bytes, const uint64_t* offsets, uint32_t n, const char* default_version,
+                      const char* default_scope, int sort, int n_threads, cbi_batch** out) {
+  if (!t || !out || (n && (!bytes || !offsets))) return fail("cbi_flatten_pb: null argument");
+  const std::string_view dver = default_version ? default_version : "default";
+  const std::string_view dscope = default_scope ? default_scope : "";
+  const u32 ncol = (u32)t->columns.size();
+  u32 P = n_threads > 1 ? (u32)n_threads : 1u;
+  if (P > 64) P = 64;
+  if (n < 1024u * P) P = n / 1024u ? n / 1024u : 1u;   // not worth a thread below ~1k messages
+  auto b = new cbi_batch();
+  std::string err;
+  if (P == 1) {
+    if (flatten_slice(t, bytes, offsets, n, dver, dscope, b, err) != 0) { delete b; return fail(err); }
+  } else {
+    std::vector<u32> base(P + 1);
+    for (u32 k = 0; k <= P; ++k) base[k] = (u32)((u64)n * k / P);
+    std::vector<cbi_batch*> parts(P);
+    std::vector<std::string> errs(P);
+    std::vector<int> rcs(P, 0);
+    for (u32 k = 0; k < P; ++k) parts[k] = new cbi_batch();
+    {
+      std::vector<std::thread> th;
+      for (u32 k = 0; k < P; ++k)
+        th.emplace_back([&, k]() { rcs[k] = flatten_slice(t, bytes, offsets + base[k], base[k + 1] - base[k], dver, dscope, parts[k], errs[k]); });
+      for (auto& x : th) x.join();
+    }
+    int bad = -1;
+    for (u32 k = 0; k < P && bad < 0; ++k) if (rcs[k] != 0) bad = (int)k;
+    if (bad < 0) merge_slices(t, parts, base, b, (int)P);
+    for (cbi_batch* p : parts) delete p;
+    if (bad >= 0) { delete b; return fail(errs[bad] + " (slice starting at message " + std::to_string(base[bad]) + ")"); }
+  }
+  sort_batch(b, ncol, sort != 0);
+  finish_view(b, ncol);
   *out = b;
   return 0;
+}
+
+int cbi_flatten_pb(const cbi_table* t, const uint8_t* bytes, const uint64_t* offsets, uint32_t n, const char* default_version,
+                   const char* default_scope, int sort, cbi_batch** out) {
+  return cbi_flatten_pb_mt(t, bytes, offsets, n, default_version, default_scope, sort, 1, out);
 }
 
 // ---- response assembly ---------------------------------------------------------------------------------

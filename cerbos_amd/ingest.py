@@ -34,6 +34,7 @@ def load():
         lib.cbi_table_close.argtypes = [vp]
         lib.cbi_table_close.restype = None
         lib.cbi_flatten_pb.argtypes = [vp, vp, vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
+        lib.cbi_flatten_pb_mt.argtypes = [vp, vp, vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
         lib.cbi_batch_free.argtypes = [vp]
         lib.cbi_batch_free.restype = None
         lib.cbi_batch_view.argtypes = [vp]
@@ -100,14 +101,16 @@ class IngestTable:
         except Exception:
             pass
 
-    def flatten_pb(self, data, offsets, default_policy_version="default", default_scope="", sort=True) -> Batch:
-        """``data``: uint8 array holding the messages back to back, ``offsets``: uint64[n + 1]."""
+    def flatten_pb(self, data, offsets, default_policy_version="default", default_scope="", sort=True, threads=1) -> Batch:
+        """``data``: uint8 array holding the messages back to back, ``offsets``: uint64[n + 1]; ``threads`` > 1
+        flattens slices concurrently inside the call (same batch, bit for bit)."""
         data = np.ascontiguousarray(data, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offsets) - 1
         h = C.c_void_p()
-        _check(load().cbi_flatten_pb(self.h, data.ctypes.data if data.size else None, offsets.ctypes.data, n,
-                                     default_policy_version.encode(), default_scope.encode(), int(bool(sort)), C.byref(h)))
+        _check(load().cbi_flatten_pb_mt(self.h, data.ctypes.data if data.size else None, offsets.ctypes.data, n,
+                                        default_policy_version.encode(), default_scope.encode(), int(bool(sort)), int(threads),
+                                        C.byref(h)))
         try:
             v = load().cbi_batch_view(h).contents
             b = Batch()

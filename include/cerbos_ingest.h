@@ -48,6 +48,11 @@ void cbi_table_close(cbi_table* t);
  */
 int cbi_flatten_pb(const cbi_table* t, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
                    const char* default_version, const char* default_scope, int sort, cbi_batch** out);
+/* Same result, bit for bit, computed on up to n_threads threads inside the call: slices of the input are
+ * flattened concurrently and merged (batch-local string ids, heap offsets and role / tuple offsets rebased so
+ * that the batch equals the single-pass one).  n_threads <= 1, or fewer than ~1k messages per thread: single pass. */
+int cbi_flatten_pb_mt(const cbi_table* t, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
+                      const char* default_version, const char* default_scope, int sort, int n_threads, cbi_batch** out);
 void cbi_batch_free(cbi_batch* b);
 
 /* The flattened batch; valid until cbi_batch_free. */

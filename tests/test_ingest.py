@@ -34,6 +34,11 @@ def _same(lt, inputs, **kw):
             assert np.array_equal(a, b), (name, sort)
         tp = want.tuple_perm if want.tuple_perm is not None else np.arange(want.n_tuples)
         assert np.array_equal(have.tuple_perm, tp), sort
+        if len(inputs) >= 2048:     # the in-call parallel flatten must give the very same batch
+            for threads in (2, 5):
+                par = it.flatten_pb(data, off, kw.get("default_policy_version", "default"), kw.get("default_scope", ""), sort, threads)
+                for name in ARRAYS + ("tuple_perm", "vreq_input"):
+                    assert np.array_equal(getattr(par, name), getattr(have, name)), (name, sort, threads)
         vi = want.vreq_input if want.req_perm is None else want.vreq_input[want.req_perm]
         assert np.array_equal(have.vreq_input, vi), sort
     it.close()
@@ -56,6 +61,8 @@ def test_fuzz_inputs_flatten_identically(seed):
     except LoweringError:
         pytest.skip("store refused by the lowering")
     _same(lt, _requests(rng, 300))     # ragged roles / actions, > 64 actions, nested and wrongly typed attributes
+    if seed < 3:
+        _same(lt, _requests(rng, 5200))    # large enough for the in-call parallel flatten (slices of >= 1024)
 
 
 @pytest.mark.parametrize("name", ["C2", "C3", "C5"])

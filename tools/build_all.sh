@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/.."
 g++ -O1 -g -std=c++17 -shared -fPIC -Iinclude tests/hostsim/hostsim.cpp -o tests/hostsim/libcbh_hostsim.so
-g++ -O2 -std=c++17 -Wall -Wextra -shared -fPIC -Iinclude cerbos_amd/csrc/cbh_ingest.cpp -o cerbos_amd/libcerbos_ingest.so
+g++ -O2 -std=c++17 -Wall -Wextra -shared -fPIC -pthread -Iinclude cerbos_amd/csrc/cbh_ingest.cpp -o cerbos_amd/libcerbos_ingest.so
 cd cerbos_amd/csrc
 LOG=$(mktemp)
 # CBH_PROFILE=1 builds the per-wave cycle counters in (tools/gpu_cycles.py); never ship that build.

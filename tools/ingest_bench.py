@@ -52,3 +52,14 @@ for threads in (2, 4, 8, 16, 32):
             list(ex.map(lambda p: it.flatten_pb(p[0], p[1]), parts))
             best = min(best, time.perf_counter() - t0)
     print("%2d threads: %.1f ms = %.2f M requests/s" % (threads, best * 1e3, n / best / 1e6))
+
+# the same, inside ONE call (cbi_flatten_pb_mt): slices flattened concurrently and merged into one batch
+for threads in (1, 2, 4, 8, 16, 32):
+    if threads > (os.cpu_count() or 1):
+        break
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        it.flatten_pb(data, off, threads=threads)
+        best = min(best, time.perf_counter() - t0)
+    print("in-call %2d threads: %.1f ms = %.2f M requests/s" % (threads, best * 1e3, n / best / 1e6))
