@@ -731,91 +731,139 @@ static void put_ld(std::vector<u8>& o, u32 field, std::string_view s) {
 }
 static void put_str(std::vector<u8>& o, u32 field, std::string_view s) { if (!s.empty()) put_ld(o, field, s); }   // proto3 default: omitted
 
-int cbi_assemble_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* bytes, const uint64_t* offsets,
-                    uint32_t n, const char* default_version, cbi_outputs** out) {
+int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* bytes, const uint64_t* offsets,
+                       uint32_t n, const char* default_version, int n_threads, cbi_outputs** out) {
   if (!t || !b || !res || !res->effect || !out || (n && (!bytes || !offsets))) return fail("cbi_assemble_pb: null argument");
   std::string_view dver = default_version ? default_version : "default";
   const u32 T = b->view.n_tuples, R = b->view.n_requests;
   // input-order tuple k lives at device tuple inv[k]; derived roles of an input = OR over its device requests
   std::vector<u32> inv(T);
   for (u32 j = 0; j < T; ++j) { if (b->tuple_perm[j] >= T) return fail("corrupt tuple permutation"); inv[b->tuple_perm[j]] = j; }
-  std::vector<u64> edr(n, 0);
-  if (res->edr_mask)
-    for (u32 q = 0; q < R; ++q) { if (b->req_input[q] >= n) return fail("batch does not belong to these inputs"); edr[b->req_input[q]] |= res->edr_mask[q]; }
-  auto o = new cbi_outputs();
-  auto bail = [&](const std::string& m) { delete o; return fail(m); };
-  o->offsets.reserve(n + 1); o->offsets.push_back(0); o->flags.assign(n, 0);
-  o->bytes.reserve((size_t)n * 96);
-  struct Act { std::string_view name; u32 j; };
-  std::vector<Act> acts;
-  std::vector<u8> eff, ent;
-  std::string pol, kbuf, vbuf;
-  u64 k = 0;
-  for (u32 i = 0; i < n; ++i) {
-    Span m{bytes + offsets[i], bytes + offsets[i + 1]};
-    Span principal{nullptr, nullptr}, resource{nullptr, nullptr};
-    std::string_view request_id;
-    acts.clear();
-    bool bad = false; Field f;
-    while (next(m, f, bad)) { if (f.wt != 2) continue;
-      if (f.num == 1) request_id = sv(f.s); else if (f.num == 2) resource = f.s; else if (f.num == 3) principal = f.s;
-      else if (f.num == 4) {
-        if (k >= T) return bail("batch does not belong to these inputs");
-        // setEffect (check.go:513-530): a later duplicate replaces an earlier one unless that one is a DENY and it is not
-        std::string_view name = sv(f.s); u32 j = inv[k++]; bool dup = false;
-        for (Act& a : acts) if (a.name == name) {
-          if (res->effect[j] == CBH_EFFECT_DENY || res->effect[a.j] != CBH_EFFECT_DENY) a.j = j;
-          dup = true; break;
-        }
-        if (!dup) acts.push_back(Act{name, j});
-        if (res->status) { u8 st = res->status[j]; if (st == CBH_ST_UNSUPPORTED) o->flags[i] |= CBI_OUT_UNSUPPORTED; else if (st == CBH_ST_CEL_ERROR) o->flags[i] |= CBI_OUT_CEL_ERROR; }
-      } }
-    Party P, Rs;
-    { Span s = principal; while (next(s, f, bad)) { if (f.wt != 2) continue; if (f.num == 1) P.id = sv(f.s); else if (f.num == 2) P.version = sv(f.s); } }
-    { Span s = resource; while (next(s, f, bad)) { if (f.wt != 2) continue; if (f.num == 1) Rs.kind = sv(f.s); else if (f.num == 2) Rs.version = sv(f.s); else if (f.num == 3) Rs.id = sv(f.s); } }
-    if (bad) return bail("malformed CheckInput at index " + std::to_string(i));
-    std::vector<u8>& ob = o->bytes;
-    put_str(ob, 1, request_id);
-    put_str(ob, 2, Rs.id);
-    for (const Act& a : acts) {
-      eff.clear(); ent.clear();
-      if (res->effect[a.j]) { eff.push_back(1 << 3 | 0); put_varint(eff, res->effect[a.j]); }
-      if (res->policy) {
-        const u32 w = res->policy[a.j], kind = w >> 28, ident = w & 0x0FFFFFFFu;
-        pol.clear();
-        switch (kind) {   // enum cbh_policy_kind; keys as namer.PolicyKeyFromFQN gives them (namer.go:95-134)
-          case CBH_P_EMPTY: break;
-          case CBH_P_NO_MATCH: pol = "NO_MATCH"; break;
-          case CBH_P_NO_MATCH_SCOPE_PERMISSIONS: pol = "NO_MATCH_FOR_SCOPE_PERMISSIONS"; break;
-          case CBH_P_TABLE: if (ident >= t->policy_keys.size()) return bail("policy id out of range"); pol = t->policy_keys[ident]; break;
-          case CBH_P_RESOURCE: case CBH_P_PRINCIPAL: {
-            if (ident >= t->scopes.size()) return bail("scope index out of range");
-            const bool rp = kind == CBH_P_RESOURCE;
-            std::string_view ver = rp ? Rs.version : P.version;
-            pol = rp ? "resource." : "principal.";
-            pol += sanitize(rp ? Rs.kind : P.id, kbuf); pol += ".v"; pol += sanitize(ver.empty() ? dver : ver, vbuf);
-            if (!t->scopes[ident].empty()) { pol += '/'; pol += t->scopes[ident]; }
-            break;
-          }
-          default: return bail("unknown policy word");
-        }
-        put_str(eff, 2, pol);
-      }
-      if (res->scope && res->scope[a.j] != 0xFFFFFFFFu) {
-        if (res->scope[a.j] >= t->scopes.size()) return bail("scope index out of range");
-        put_str(eff, 3, t->scopes[res->scope[a.j]]);
-      }
-      put_ld(ent, 1, a.name);
-      put_ld(ent, 2, std::string_view((const char*)eff.data(), eff.size()));
-      put_ld(ob, 3, std::string_view((const char*)ent.data(), ent.size()));
-    }
-    for (u32 d = 0; d < 64 && d < t->dr_names.size(); ++d) if ((edr[i] >> d) & 1) put_ld(ob, 4, t->dr_names[d]);
-    o->offsets.push_back(ob.size());
+  std::vector<u64> edr(n, 0), first(n + 1, 0);   // first[i] = input-order index of input i's first tuple
+  for (u32 q = 0; q < R; ++q) {
+    const u32 i = b->req_input[q];
+    if (i >= n) return fail("batch does not belong to these inputs");
+    if (res->edr_mask) edr[i] |= res->edr_mask[q];
+    first[i + 1] += b->req[(size_t)RQ_ACT_CNT * R + q];
   }
-  if (k != T) return bail("batch does not belong to these inputs");
+  for (u32 i = 0; i < n; ++i) first[i + 1] += first[i];
+  if (first[n] != T) return fail("batch does not belong to these inputs");
+
+  // inputs [lo, hi) -> o (offsets relative to the part)
+  auto assemble_range = [&](u32 lo, u32 hi, cbi_outputs* o, std::string& err) -> int {
+    auto bail = [&](const std::string& m) { err = m; return -1; };
+    o->offsets.reserve(hi - lo + 1); o->offsets.push_back(0); o->flags.assign(hi - lo, 0);
+    o->bytes.reserve((size_t)(hi - lo) * 96);
+    struct Act { std::string_view name; u32 j; };
+    std::vector<Act> acts;
+    std::vector<u8> eff, ent;
+    std::string pol, kbuf, vbuf;
+    u64 k = first[lo];
+    const u64 k_hi = first[hi];
+    for (u32 i = lo; i < hi; ++i) {
+      Span m{bytes + offsets[i], bytes + offsets[i + 1]};
+      Span principal{nullptr, nullptr}, resource{nullptr, nullptr};
+      std::string_view request_id;
+      acts.clear();
+      bool bad = false; Field f;
+      while (next(m, f, bad)) { if (f.wt != 2) continue;
+        if (f.num == 1) request_id = sv(f.s); else if (f.num == 2) resource = f.s; else if (f.num == 3) principal = f.s;
+        else if (f.num == 4) {
+          if (k >= k_hi) return bail("batch does not belong to these inputs");
+          // setEffect (check.go:513-530): a later duplicate replaces an earlier one unless that one is a DENY and it is not
+          std::string_view name = sv(f.s); u32 j = inv[k++]; bool dup = false;
+          for (Act& a : acts) if (a.name == name) {
+            if (res->effect[j] == CBH_EFFECT_DENY || res->effect[a.j] != CBH_EFFECT_DENY) a.j = j;
+            dup = true; break;
+          }
+          if (!dup) acts.push_back(Act{name, j});
+          if (res->status) { u8 st = res->status[j]; if (st == CBH_ST_UNSUPPORTED) o->flags[i - lo] |= CBI_OUT_UNSUPPORTED; else if (st == CBH_ST_CEL_ERROR) o->flags[i - lo] |= CBI_OUT_CEL_ERROR; }
+        } }
+      Party P, Rs;
+      { Span s = principal; while (next(s, f, bad)) { if (f.wt != 2) continue; if (f.num == 1) P.id = sv(f.s); else if (f.num == 2) P.version = sv(f.s); } }
+      { Span s = resource; while (next(s, f, bad)) { if (f.wt != 2) continue; if (f.num == 1) Rs.kind = sv(f.s); else if (f.num == 2) Rs.version = sv(f.s); else if (f.num == 3) Rs.id = sv(f.s); } }
+      if (bad) return bail("malformed CheckInput at index " + std::to_string(i));
+      std::vector<u8>& ob = o->bytes;
+      put_str(ob, 1, request_id);
+      put_str(ob, 2, Rs.id);
+      for (const Act& a : acts) {
+        eff.clear(); ent.clear();
+        if (res->effect[a.j]) { eff.push_back(1 << 3 | 0); put_varint(eff, res->effect[a.j]); }
+        if (res->policy) {
+          const u32 w = res->policy[a.j], kind = w >> 28, ident = w & 0x0FFFFFFFu;
+          pol.clear();
+          switch (kind) {   // enum cbh_policy_kind; keys as namer.PolicyKeyFromFQN gives them (namer.go:95-134)
+            case CBH_P_EMPTY: break;
+            case CBH_P_NO_MATCH: pol = "NO_MATCH"; break;
+            case CBH_P_NO_MATCH_SCOPE_PERMISSIONS: pol = "NO_MATCH_FOR_SCOPE_PERMISSIONS"; break;
+            case CBH_P_TABLE: if (ident >= t->policy_keys.size()) return bail("policy id out of range"); pol = t->policy_keys[ident]; break;
+            case CBH_P_RESOURCE: case CBH_P_PRINCIPAL: {
+              if (ident >= t->scopes.size()) return bail("scope index out of range");
+              const bool rp = kind == CBH_P_RESOURCE;
+              std::string_view ver = rp ? Rs.version : P.version;
+              pol = rp ? "resource." : "principal.";
+              pol += sanitize(rp ? Rs.kind : P.id, kbuf); pol += ".v"; pol += sanitize(ver.empty() ? dver : ver, vbuf);
+              if (!t->scopes[ident].empty()) { pol += '/'; pol += t->scopes[ident]; }
+              break;
+            }
+            default: return bail("unknown policy word");
+          }
+          put_str(eff, 2, pol);
+        }
+        if (res->scope && res->scope[a.j] != 0xFFFFFFFFu) {
+          if (res->scope[a.j] >= t->scopes.size()) return bail("scope index out of range");
+          put_str(eff, 3, t->scopes[res->scope[a.j]]);
+        }
+        put_ld(ent, 1, a.name);
+        put_ld(ent, 2, std::string_view((const char*)eff.data(), eff.size()));
+        put_ld(ob, 3, std::string_view((const char*)ent.data(), ent.size()));
+      }
+      for (u32 d = 0; d < 64 && d < t->dr_names.size(); ++d) if ((edr[i] >> d) & 1) put_ld(ob, 4, t->dr_names[d]);
+      o->offsets.push_back(ob.size());
+    }
+    if (k != k_hi) return bail("batch does not belong to these inputs");
+    return 0;
+  };
+
+  u32 P = n_threads > 1 ? (u32)n_threads : 1u;
+  if (P > 64) P = 64;
+  if (n < 1024u * P) P = n / 1024u ? n / 1024u : 1u;
+  auto o = new cbi_outputs();
+  std::string err;
+  if (P == 1) {
+    if (assemble_range(0, n, o, err) != 0) { delete o; return fail(err); }
+  } else {
+    std::vector<cbi_outputs> parts(P);
+    std::vector<std::string> errs(P);
+    std::vector<int> rcs(P, 0);
+    std::vector<u32> base(P + 1);
+    for (u32 k = 0; k <= P; ++k) base[k] = (u32)((u64)n * k / P);
+    {
+      std::vector<std::thread> th;
+      for (u32 k = 0; k < P; ++k) th.emplace_back([&, k]() { rcs[k] = assemble_range(base[k], base[k + 1], &parts[k], errs[k]); });
+      for (auto& x : th) x.join();
+    }
+    for (u32 k = 0; k < P; ++k) if (rcs[k] != 0) { delete o; return fail(errs[k]); }
+    size_t total = 0;
+    for (const cbi_outputs& p : parts) total += p.bytes.size();
+    o->bytes.resize(total); o->flags.resize(n); o->offsets.resize((size_t)n + 1);
+    size_t at = 0;
+    for (u32 k = 0; k < P; ++k) {
+      const cbi_outputs& p = parts[k];
+      if (!p.bytes.empty()) std::memcpy(o->bytes.data() + at, p.bytes.data(), p.bytes.size());
+      if (!p.flags.empty()) std::memcpy(o->flags.data() + base[k], p.flags.data(), p.flags.size());
+      for (u32 i = base[k]; i <= base[k + 1]; ++i) o->offsets[i] = at + p.offsets[i - base[k]];
+      at += p.bytes.size();
+    }
+  }
   o->bytes.reserve(1);
   *out = o;
   return 0;
+}
+
+int cbi_assemble_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* bytes, const uint64_t* offsets,
+                    uint32_t n, const char* default_version, cbi_outputs** out) {
+  return cbi_assemble_pb_mt(t, b, res, bytes, offsets, n, default_version, 1, out);
 }
 
 void cbi_outputs_free(cbi_outputs* o) { delete o; }

@@ -44,6 +44,7 @@ def load():
         lib.cbi_batch_request_input.argtypes = [vp]
         lib.cbi_batch_request_input.restype = C.POINTER(C.c_uint32)
         lib.cbi_assemble_pb.argtypes = [vp, vp, C.POINTER(capi.CResult), vp, vp, C.c_uint32, C.c_char_p, C.POINTER(vp)]
+        lib.cbi_assemble_pb_mt.argtypes = [vp, vp, C.POINTER(capi.CResult), vp, vp, C.c_uint32, C.c_char_p, C.c_int, C.POINTER(vp)]
         lib.cbi_outputs_free.argtypes = [vp]
         lib.cbi_outputs_free.restype = None
         lib.cbi_outputs_bytes.argtypes = [vp]
@@ -136,15 +137,15 @@ class IngestTable:
             load().cbi_batch_free(h)
             raise
 
-    def assemble_pb(self, batch, res, data, offsets, default_policy_version="default"):
+    def assemble_pb(self, batch, res, data, offsets, default_policy_version="default", threads=1):
         """Device-order results (``capi.Result`` before ``to_input_order``) of a batch made by ``flatten_pb`` from
         the same messages -> ([serialized CheckOutput], flags uint8[n])."""
         data = np.ascontiguousarray(data, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offsets) - 1
         h = C.c_void_p()
-        _check(load().cbi_assemble_pb(self.h, batch.native.h, C.byref(res.c), data.ctypes.data if data.size else None,
-                                      offsets.ctypes.data, n, default_policy_version.encode(), C.byref(h)))
+        _check(load().cbi_assemble_pb_mt(self.h, batch.native.h, C.byref(res.c), data.ctypes.data if data.size else None,
+                                         offsets.ctypes.data, n, default_policy_version.encode(), int(threads), C.byref(h)))
         try:
             off = _copy(load().cbi_outputs_offsets(h), C.c_uint64, np.int64, n + 1)
             raw = _copy(load().cbi_outputs_bytes(h), C.c_uint8, np.uint8, int(off[-1])).tobytes()

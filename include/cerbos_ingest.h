@@ -79,6 +79,9 @@ typedef struct cbi_outputs cbi_outputs;
 
 int cbi_assemble_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* bytes,
                     const uint64_t* offsets, uint32_t n, const char* default_version, cbi_outputs** out);
+/* Same bytes, assembled on up to n_threads threads inside the call (contiguous ranges of inputs). */
+int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* bytes,
+                       const uint64_t* offsets, uint32_t n, const char* default_version, int n_threads, cbi_outputs** out);
 void cbi_outputs_free(cbi_outputs* o);
 /* Output i = bytes[offsets[i] .. offsets[i+1]); n + 1 offsets. */
 const uint8_t* cbi_outputs_bytes(const cbi_outputs* o);

@@ -141,6 +141,9 @@ def _assemble_both(lt, inputs, conf, flags_extra=0, dver="default"):
     batch.actions_per_request = [list(inp.get("actions") or []) for inp in inputs]
     res = hostsim_api.check(lt, batch, 1_700_000_000_000_000_000, capi.F_WANT_DERIVED_ROLES | flags_extra, device_order=True)
     raw, flags = it.assemble_pb(batch, res, data, off, dver)
+    if len(inputs) >= 2048:     # assembled on several threads: the very same bytes
+        raw4, flags4 = it.assemble_pb(batch, res, data, off, dver, threads=4)
+        assert raw4 == raw and np.array_equal(flags4, flags)
     have = [wire.decode_check_output(r) for r in raw]
     ev = HostSimEvaluator(lt, conf)
     want, bad = ev.assemble(inputs, batch, copy.copy(res).to_input_order(batch), dver, allow_unsupported=True)
@@ -166,7 +169,7 @@ def test_assembly_matches_python_on_fuzzed_stores(seed):
         lt = lower_rule_table(rt)
     except LoweringError:
         pytest.skip("store refused by the lowering")
-    inputs = _requests(rng, 200)
+    inputs = _requests(rng, 200 if seed else 4500)
     inputs[3]["actions"] = ["view", "edit", "view", "view", "edit"]      # duplicates fold DENY-sticky
     inputs[4]["actions"] = []
     for extra in (0, capi.F_LENIENT_SCOPE_SEARCH):

@@ -3,7 +3,10 @@ cbh_check_batch (H2D, kernels, D2H over PCIe) -> cbi_assemble_pb (serialized Che
 that each work through slices of the request stream - the shape of a Go server with one goroutine per slice.
 Not the bench.py metric (that one is the HBM-resident rate); this is the number DESIGN.md quotes next to it.
 
-    python tools/e2e_bench.py [C2|C3] [n_requests] [slice_requests] [seconds] [threads,threads,...]
+    python tools/e2e_bench.py [C2|C3] [n_requests] [slice_requests] [seconds] [threads,threads,...] [inner]
+
+`inner` > 1 uses cbi_flatten_pb_mt / cbi_assemble_pb_mt with that many threads inside each call (fewer, larger
+slices per Python thread).
 """
 import ctypes as C
 import json
@@ -24,6 +27,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 131072
 slice_req = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
 seconds = float(sys.argv[4]) if len(sys.argv) > 4 else 3.0
 thread_counts = [int(x) for x in sys.argv[5].split(",")] if len(sys.argv) > 5 else [1, 8, 32, 64, 128]
+inner = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 
 pol, reqs = {"C2": (workloads.c2_policies, workloads.c2_requests), "C3": (workloads.c3_policies, workloads.c3_requests)}[name]
 lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol())))
@@ -54,14 +58,14 @@ def worker(k, stop, counts, phase):
         i += 1
         hb, ho = C.c_void_p(), C.c_void_p()
         t0 = time.perf_counter()
-        if ing.cbi_flatten_pb(itab.h, d.ctypes.data, o.ctypes.data, cnt, b"default", b"", 1, C.byref(hb)) != 0:
+        if ing.cbi_flatten_pb_mt(itab.h, d.ctypes.data, o.ctypes.data, cnt, b"default", b"", 1, inner, C.byref(hb)) != 0:
             raise RuntimeError(ing.cbi_last_error())
         t1 = time.perf_counter()
         view = ing.cbi_batch_view(hb)
         if hip.cbh_check_batch(table.h, view, C.byref(params), C.byref(res.c)) != 0:
             raise RuntimeError(hip.cbh_last_error())
         t2 = time.perf_counter()
-        if ing.cbi_assemble_pb(itab.h, hb, C.byref(res.c), d.ctypes.data, o.ctypes.data, cnt, b"default", C.byref(ho)) != 0:
+        if ing.cbi_assemble_pb_mt(itab.h, hb, C.byref(res.c), d.ctypes.data, o.ctypes.data, cnt, b"default", inner, C.byref(ho)) != 0:
             raise RuntimeError(ing.cbi_last_error())
         t3 = time.perf_counter()
         done += view.contents.n_tuples
@@ -87,7 +91,7 @@ for T in thread_counts:
     dt = time.perf_counter() - t0
     tot = [sum(p[j] for p in phase) for j in range(3)]
     s = sum(tot) or 1.0
-    run = {"threads": T, "decisions_per_s": sum(counts) / dt,
+    run = {"threads": T, "inner_threads": inner, "decisions_per_s": sum(counts) / dt,
            "share_flatten": tot[0] / s, "share_gpu_roundtrip": tot[1] / s, "share_assemble": tot[2] / s}
     out["runs"].append(run)
     print(json.dumps(run), flush=True)
