@@ -713,6 +713,7 @@ int cbi_flatten_pb_mt(const cbi_table* t, const uint8_t* bytes, const uint64_t* 
     for (cbi_batch* p : parts) delete p;
     if (bad >= 0) { delete b; return fail(errs[bad] + " (slice starting at message " + std::to_string(base[bad]) + ")"); }
   }
+  if (b->heap_tag.size() >= ((size_t)1 << 30)) { delete b; return fail("batch too large: nested attribute values exceed the heap's 30-bit offsets"); }
   sort_batch(b, ncol, sort != 0);
   finish_view(b, ncol);
   *out = b;

@@ -208,3 +208,39 @@ def test_bytes_in_bytes_out_on_golden_cases():
                 assert have["requestId"] == inp.get("requestId", "") and have["resourceId"] == inp["resource"].get("id", "")
                 compared += 1
     assert compared > 60
+
+
+def test_mutated_messages_never_crash():
+    """The ingest takes bytes from the network side: random corruptions of valid messages (bit flips, cuts,
+    splices, inserted bytes) must end in an error or in some batch - never in a crash or a hang.  (Run under
+    ASan/UBSan when changing the parser: see the build line in DESIGN.md.)"""
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    it = IngestTable(lt.blob)
+    inputs = [inp for case in load_json("engine_cases.json") for inp in case["inputs"]][:40]
+    msgs = [wire.encode_check_input(i) for i in inputs]
+    rng = np.random.default_rng(7)
+    ok = bad = 0
+    for trial in range(1500):
+        m = bytearray(msgs[int(rng.integers(0, len(msgs)))])
+        for _ in range(int(rng.integers(1, 4))):
+            kind = int(rng.integers(0, 4))
+            pos = int(rng.integers(0, len(m))) if m else 0
+            if kind == 0 and m:
+                m[pos] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:
+                del m[pos:pos + int(rng.integers(1, 9))]
+            elif kind == 2:
+                m[pos:pos] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 6)), dtype=np.uint8))
+            else:
+                other = msgs[int(rng.integers(0, len(msgs)))]
+                cut = int(rng.integers(0, len(other)))
+                m[pos:] = other[cut:]
+        batch = [bytes(m), msgs[trial % len(msgs)]]
+        data, off = wire.pack_messages(batch)
+        try:
+            b = it.flatten_pb(data, off)
+            assert b.n_requests >= 2 and b.tuple_action.size == b.n_tuples
+            ok += 1
+        except IngestError:
+            bad += 1
+    assert ok > 100 and bad > 100, (ok, bad)
