@@ -1,0 +1,137 @@
+//go:build hipengine
+
+// cgo binding of the MI355X decision engine behind engine.Check (INTEGRATION.md §1-2a).  Bytes in, bytes out:
+// the CheckInputs are marshalled once, libcerbos_ingest.so flattens them, libcerbos_hip.so decides, and
+// libcerbos_ingest.so assembles the serialized CheckOutputs.  Inputs the device cannot evaluate
+// (CBI_OUT_UNSUPPORTED) are handed back to the caller's CPU path, which also serves the whole batch on any error.
+package engine
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../third_party/cerbos_hip/include
+#cgo LDFLAGS: -L${SRCDIR}/../../third_party/cerbos_hip/lib -lcerbos_ingest -lcerbos_hip
+#include <stdlib.h>
+#include "cerbos_ingest.h"
+*/
+import "C"
+
+import (
+	"context"
+	"errors"
+	"fmt"
+	"runtime"
+	"unsafe"
+
+	"google.golang.org/protobuf/proto"
+
+	enginev1 "github.com/cerbos/cerbos/api/genpb/cerbos/engine/v1"
+	"github.com/cerbos/cerbos/internal/evaluator"
+)
+
+type gpuEngine struct {
+	table  *C.cbh_table // device image of the lowered rule table
+	ingest *C.cbi_table // host dictionaries of the same image (immutable: shared by all goroutines)
+}
+
+func newGPUEngine(blob []byte, device int) (*gpuEngine, error) {
+	cfg := C.cbh_config{abi_version: C.CBH_ABI_VERSION, device: C.int32_t(device)}
+	if C.cbh_init(&cfg) != 0 {
+		return nil, errors.New(C.GoString(C.cbh_last_error()))
+	}
+	g := &gpuEngine{}
+	// both libraries copy the image: a Go pointer may be passed for the duration of the call
+	if C.cbh_table_load(unsafe.Pointer(&blob[0]), C.size_t(len(blob)), &g.table) != 0 {
+		return nil, errors.New(C.GoString(C.cbh_last_error()))
+	}
+	if C.cbi_table_open(unsafe.Pointer(&blob[0]), C.size_t(len(blob)), &g.ingest) != 0 {
+		C.cbh_table_release(g.table)
+		return nil, errors.New(C.GoString(C.cbi_last_error()))
+	}
+	return g, nil
+}
+
+func (g *gpuEngine) close() {
+	C.cbi_table_close(g.ingest)
+	C.cbh_table_release(g.table)
+}
+
+// checkBatchGPU returns one output per input; fallback[i] is true where the caller must run input i itself.
+func (g *gpuEngine) checkBatchGPU(_ context.Context, inputs []*enginev1.CheckInput, p evaluator.EvalParams) (outs []*enginev1.CheckOutput, fallback []bool, err error) {
+	n := len(inputs)
+	buf := make([]byte, 0, 256*n)
+	offs := make([]C.uint64_t, 1, n+1)
+	for _, in := range inputs {
+		if buf, err = (proto.MarshalOptions{}).MarshalAppend(buf, in); err != nil {
+			return nil, nil, err
+		}
+		offs = append(offs, C.uint64_t(len(buf)))
+	}
+	var pin runtime.Pinner // the C side only reads these during the calls below
+	pin.Pin(&buf[0])
+	pin.Pin(&offs[0])
+	defer pin.Unpin()
+	bytesPtr := (*C.uint8_t)(unsafe.Pointer(&buf[0]))
+
+	dv, ds := C.CString(p.DefaultPolicyVersion), C.CString(p.DefaultScope)
+	defer C.free(unsafe.Pointer(dv))
+	defer C.free(unsafe.Pointer(ds))
+
+	var batch *C.cbi_batch
+	if C.cbi_flatten_pb(g.ingest, bytesPtr, &offs[0], C.uint32_t(n), dv, ds, 1, &batch) != 0 {
+		return nil, nil, errors.New(C.GoString(C.cbi_last_error()))
+	}
+	defer C.cbi_batch_free(batch)
+	view := C.cbi_batch_view(batch)
+
+	// result arrays in C memory (cgo: no Go pointers to Go pointers inside cbh_result)
+	nt, nr := C.size_t(view.n_tuples), C.size_t(view.n_requests)
+	res := C.cbh_result{
+		effect:   (*C.uint8_t)(C.calloc(nt+1, 1)),
+		policy:   (*C.uint32_t)(C.calloc(nt+1, 4)),
+		scope:    (*C.uint32_t)(C.calloc(nt+1, 4)),
+		status:   (*C.uint8_t)(C.calloc(nt+1, 1)),
+		edr_mask: (*C.uint64_t)(C.calloc(nr+1, 8)),
+	}
+	defer func() {
+		C.free(unsafe.Pointer(res.effect))
+		C.free(unsafe.Pointer(res.policy))
+		C.free(unsafe.Pointer(res.scope))
+		C.free(unsafe.Pointer(res.status))
+		C.free(unsafe.Pointer(res.edr_mask))
+	}()
+
+	flags := C.uint32_t(C.CBH_F_WANT_DERIVED_ROLES)
+	if p.LenientScopeSearch {
+		flags |= C.CBH_F_LENIENT_SCOPE_SEARCH
+	}
+	if p.StrictEvaluation {
+		flags |= C.CBH_F_STRICT_EVALUATION
+	}
+	params := C.cbh_params{now_ns: C.int64_t(p.NowFunc().UnixNano()), flags: flags}
+	if C.cbh_check_batch(g.table, view, &params, &res) != 0 {
+		return nil, nil, errors.New(C.GoString(C.cbh_last_error()))
+	}
+
+	var assembled *C.cbi_outputs
+	if C.cbi_assemble_pb(g.ingest, batch, &res, bytesPtr, &offs[0], C.uint32_t(n), dv, &assembled) != 0 {
+		return nil, nil, errors.New(C.GoString(C.cbi_last_error()))
+	}
+	defer C.cbi_outputs_free(assembled)
+	ooffs := unsafe.Slice((*uint64)(unsafe.Pointer(C.cbi_outputs_offsets(assembled))), n+1)
+	oflags := unsafe.Slice((*byte)(unsafe.Pointer(C.cbi_outputs_flags(assembled))), n)
+	obytes := unsafe.Slice((*byte)(unsafe.Pointer(C.cbi_outputs_bytes(assembled))), int(ooffs[n]))
+
+	outs = make([]*enginev1.CheckOutput, n)
+	fallback = make([]bool, n)
+	for i := range inputs {
+		if oflags[i]&C.CBI_OUT_UNSUPPORTED != 0 {
+			fallback[i] = true
+			continue
+		}
+		out := &enginev1.CheckOutput{}
+		if err := proto.Unmarshal(obytes[ooffs[i]:ooffs[i+1]], out); err != nil {
+			return nil, nil, fmt.Errorf("output %d: %w", i, err)
+		}
+		outs[i] = out
+	}
+	return outs, fallback, nil
+}
