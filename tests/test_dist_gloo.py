@@ -75,3 +75,68 @@ def test_shard_range_covers_everything():
             spans = [shard_range(n, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _worker_bytes(rank, world, port, out):
+    """The widened path under sharding: each rank ingests its contiguous shard of serialized CheckInputs with
+    the image it RECEIVED, decides, assembles serialized CheckOutputs; rank 0 collects them in input order."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pickle
+
+    import torch.distributed as dist
+
+    import hostsim_api
+    from cerbos_amd import capi, wire, workloads
+    from cerbos_amd import dist as cdist
+    from cerbos_amd.ingest import IngestTable
+    from cerbos_amd.lower.blob import lower_rule_table
+    from cerbos_amd.policy.loader import policies_from_docs
+    from cerbos_amd.ruletable.build import rule_table_from_policies
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c3_policies())))
+    img = cdist.broadcast_image(lt.blob if rank == 0 else None, src=0)
+    lt.blob = bytes(img.numpy().tobytes())
+    cr = workloads.c3_requests(900, seed=3)
+    lo, hi = cdist.shard_range(cr.n, rank, world)
+    data, off = wire.pack_messages([wire.encode_check_input(i) for i in cr.to_inputs(lo, hi)])
+    it = IngestTable(lt.blob)
+    batch = it.flatten_pb(data, off)
+    res = hostsim_api.check(lt, batch, 1_700_000_000_000_000_000, capi.F_WANT_DERIVED_ROLES, device_order=True)
+    raw, flags = it.assemble_pb(batch, res, data, off)
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object((lo, raw, flags.tolist()), gathered, dst=0)   # test-only collection
+    if rank == 0:
+        with open(out, "wb") as fh:
+            pickle.dump(sorted(gathered), fh)
+    dist.destroy_process_group()
+
+
+def test_sharded_bytes_path_equals_single_process(tmp_path):
+    import pickle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hostsim_api
+    from cerbos_amd import capi, wire, workloads
+    from cerbos_amd.ingest import IngestTable
+    from cerbos_amd.lower.blob import lower_rule_table
+    from cerbos_amd.policy.loader import policies_from_docs
+    from cerbos_amd.ruletable.build import rule_table_from_policies
+
+    hostsim_api.build()
+    out = str(tmp_path / "outs.pkl")
+    mp.spawn(_worker_bytes, args=(2, _free_port(), out), nprocs=2, join=True)
+    with open(out, "rb") as fh:
+        parts = pickle.load(fh)
+    got = [r for _, raw, _ in parts for r in raw]
+    got_flags = [f for _, _, fl in parts for f in fl]
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c3_policies())))
+    inputs = workloads.c3_requests(900, seed=3).to_inputs()
+    data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+    it = IngestTable(lt.blob)
+    batch = it.flatten_pb(data, off)
+    res = hostsim_api.check(lt, batch, 1_700_000_000_000_000_000, capi.F_WANT_DERIVED_ROLES, device_order=True)
+    want, want_flags = it.assemble_pb(batch, res, data, off)
+    assert [wire.decode_check_output(r) for r in got] == [wire.decode_check_output(r) for r in want]
+    assert got_flags == want_flags.tolist()
+    assert any(o["effectiveDerivedRoles"] for o in map(wire.decode_check_output, want))
