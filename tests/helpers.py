@@ -25,3 +25,21 @@ def norm_actions(out):
     for a, e in (out.get("actions") or {}).items():
         res[a] = (e.get("effect", "EFFECT_UNSPECIFIED"), e.get("policy", ""), e.get("scope", ""))
     return res
+
+
+def assert_server_case(case, outs, skip=()):
+    """A CheckOutput per input against a service-level CheckResources case (tests/golden/server_check_cases.json):
+    results[i].actions = the effects; meta.actions[a].matchedPolicy / matchedScope = ActionEffect.policy / scope;
+    meta.effectiveDerivedRoles (cerbos_svc.go:297-343).  Returns the number of outputs compared."""
+    n = 0
+    for i, (have, want) in enumerate(zip(outs, case["want"])):
+        if i in skip:
+            continue
+        assert {a: e["effect"] for a, e in have["actions"].items()} == want["actions"], (case["name"], i)
+        for a, m in want["meta"].items():
+            assert have["actions"][a]["policy"] == m["matchedPolicy"], (case["name"], i, a)
+            assert have["actions"][a].get("scope", "") == m["matchedScope"], (case["name"], i, a)
+        if want["hasMeta"]:
+            assert sorted(have["effectiveDerivedRoles"]) == sorted(want["effectiveDerivedRoles"] or []), (case["name"], i)
+        n += 1
+    return n

@@ -71,3 +71,15 @@ def test_engine_cases_bytes_in_bytes_out():
                 compared += 1
     ev.close()
     assert compared > 60
+
+
+SERVER_CASES = load_json("server_check_cases.json")
+
+
+@pytest.mark.parametrize("case", SERVER_CASES, ids=[c["name"] for c in SERVER_CASES])
+def test_service_level_check_resources_case(evaluator, case):
+    """The reference's service-level CheckResources cases (server/checks/check_resources) on the GPU."""
+    from helpers import assert_server_case
+    outs, bad = evaluator.check(case["inputs"], now_ns=1_700_000_000_000_000_000, allow_unsupported=True)
+    assert assert_server_case(case, outs, skip=bad) + len(bad) == len(case["inputs"])
+    assert len(bad) < len(case["inputs"])

@@ -55,3 +55,14 @@ def test_engine_case(evaluator, case):
                 continue
             assert norm_actions(have) == norm_actions(want), (case["name"], lenient)
             assert sorted(have["effectiveDerivedRoles"]) == sorted(want.get("effectiveDerivedRoles") or [])
+
+
+SERVER_CASES = load_json("server_check_cases.json")
+
+
+@pytest.mark.parametrize("case", SERVER_CASES, ids=[c["name"] for c in SERVER_CASES])
+def test_service_level_check_resources_case(evaluator, case):
+    from helpers import assert_server_case
+    outs, bad = evaluator.check(case["inputs"], now_ns=1_700_000_000_000_000_000, allow_unsupported=True)
+    assert assert_server_case(case, outs, skip=bad) + len(bad) == len(case["inputs"])
+    assert len(bad) < len(case["inputs"])

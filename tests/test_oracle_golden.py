@@ -34,3 +34,14 @@ def test_engine_case(oracle, case):
             have_outs = sorted(have["outputs"], key=lambda o: o["src"])
             if "output_now" not in case["name"]:
                 assert have_outs == want_outs
+
+
+SERVER_CASES = load_json("server_check_cases.json")
+
+
+@pytest.mark.parametrize("case", SERVER_CASES, ids=[c["name"] for c in SERVER_CASES])
+def test_service_level_check_resources_case(oracle, case):
+    """internal/test/testdata/server/checks/check_resources: the same store seen through CheckResources."""
+    from helpers import assert_server_case
+    params = EvalParams(globals_={"environment": "test"}, now_ns=1_700_000_000_000_000_000)
+    assert assert_server_case(case, [oracle.check(i, params) for i in case["inputs"]]) == len(case["inputs"])

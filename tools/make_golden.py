@@ -11,6 +11,9 @@ Sources (data fixtures, not code):
   internal/test/testdata/engine_strict_scope_search/*   (engine_test.go:63)
   internal/test/testdata/engine_lenient_scope_search/*  (engine_test.go:153-210)
   internal/test/testdata/cel_eval/*.yaml                TestSatisfiesCondition KATs (evaluator_test.go:22-48)
+  internal/test/testdata/server/checks/check_resources/cr_case_*.yaml   service-level CheckResources cases
+                                                        (server_test.go; svc/cerbos_svc.go:274-343), the ones
+                                                        that need neither JWT verification nor schema rejection
   internal/engine/testdata/policy_template.yaml.gotmpl  BenchmarkEvaluator policy family (rendered for N=0..1)
 
 The YAML is parsed and re-emitted as compact JSON (decision logs dropped: audit is out of
@@ -84,6 +87,36 @@ def engine_cases(subdir, lenient):
     return out
 
 
+def server_check_cases():
+    """CheckResourcesRequest cases -> one CheckInput per resource entry (cerbos_svc.go:274-287) with the wanted
+    per-action effects and, where the case asks for meta, matched policy / scope and effective derived roles
+    (cerbos_svc.go:297-343).  Skipped: cases whose auxData carries JWT tokens (verification is outside the path)
+    and cases where the test server's schema enforcement rejects an input (validationErrors)."""
+    out = []
+    for p in sorted(glob.glob(os.path.join(TD, "server/checks/check_resources", "cr_case_*.yaml"))):
+        with open(p, encoding="utf-8") as f:
+            raw = f.read()
+        doc = load_yaml(raw)
+        cr = doc.get("checkResources") or {}
+        req, want = cr.get("input") or {}, cr.get("wantResponse") or {}
+        if "token" in raw or "validationErrors" in raw or not want.get("results"):
+            continue
+        inputs, wants = [], []
+        for entry, res in zip(req["resources"], want["results"]):
+            inp = {"requestId": req.get("requestId", ""), "principal": req["principal"], "resource": entry["resource"],
+                   "actions": entry["actions"]}
+            inputs.append(_norm_input(inp))
+            meta = res.get("meta") or {}
+            wants.append({"actions": res["actions"],
+                          "meta": {a: {"matchedPolicy": m.get("matchedPolicy", ""), "matchedScope": m.get("matchedScope", "")}
+                                   for a, m in (meta.get("actions") or {}).items()},
+                          "effectiveDerivedRoles": meta.get("effectiveDerivedRoles"),
+                          "hasMeta": bool(meta)})
+        out.append({"name": "check_resources/%s" % os.path.basename(p)[:-5], "description": doc.get("description", ""),
+                    "inputs": inputs, "want": wants})
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     pols = load_policy_dir(os.path.join(TD, "store"))
@@ -102,6 +135,7 @@ def main():
                     "request": doc["request"], "want": bool(doc.get("want", False)),
                     "wantError": bool(doc.get("wantError", False))})
     dump("cel_eval_cases.json", cel)
+    dump("server_check_cases.json", server_check_cases())
 
 
 if __name__ == "__main__":
