@@ -52,7 +52,7 @@ enum CbhSectionId {
   CBH_SEC_THEAP_REC = 24,  // u32[theap_len][4] the constant heap, same record form
   CBH_SEC_ROLE_CLASS = 25, // u8[K] class (0..61) of a string that is a literal rule role, 63 = any other string
   CBH_SEC_HOST_NAMES = 27,   // host only: {u32 n, {u16 len, bytes}*} policy keys (CBH_P_TABLE ids), then the same for derived-role names
-  CBH_SEC_COLUMN_PATHS = 26, // host only (cbh_ingest.cpp): per column {u8 root 0=P.attr 1=R.attr 2=jwt, u8 n_keys, {u16 len, bytes}*}
+  CBH_SEC_COLUMN_PATHS = 26, // host only (cbh_ingest.cpp): per column {u8 root 0=P.attr 1=R.attr 2=auxData.jwt 3=auxData.jwts, u8 n_keys, {u16 len, bytes}*}
 };
 
 enum CbhMeta {

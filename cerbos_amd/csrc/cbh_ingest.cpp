@@ -401,7 +401,7 @@ int cbi_table_open(const void* blob, size_t len, cbi_table** out) {
   for (u32 c = 0; c < ncol; ++c) {
     if (e - p < 2) return bail("column path section truncated");
     Column col; col.root = p[0]; u32 nk = p[1]; p += 2;
-    if (col.root > 2) return bail("bad column root");
+    if (col.root > 3) return bail("bad column root");
     for (u32 k = 0; k < nk; ++k) {
       if (e - p < 2) return bail("column path section truncated");
       u32 l = p[0] | (p[1] << 8); p += 2;
@@ -455,7 +455,7 @@ static int flatten_slice(const cbi_table* t, const uint8_t* bytes, const uint64_
   std::vector<std::string_view> actions, roles;
   std::vector<Entry> attrs[3];   // entries of Principal.attr / Resource.attr / AuxData.jwt, wire order
   std::string kind_buf;
-  bool need_root[3] = {false, false, false};
+  bool need_root[4] = {false, false, false, false};
   for (const Column& c : t->columns) need_root[c.root] = true;
 
   u32 r = 0;
@@ -509,28 +509,57 @@ static int flatten_slice(const cbi_table* t, const uint8_t* bytes, const uint64_
       RQ(RQ_S_R_VERSION, r) = in.sid_memo(7, Rs.version);
       for (u32 c = 0; c < ncol; ++c) {
         const Column& col = t->columns[c];
-        const std::vector<Entry>& root = attrs[col.root];
         u8 tag = 0; u64 val = 0; bool done = false;
-        if (col.keys.empty()) {
+        const size_t nk = col.keys.size();
+        Span cur{nullptr, nullptr};
+        size_t k = 0;   // keys consumed so far; `cur` is a google.protobuf.Value once k > 0
+        if (col.root == 3) {
+          // AuxData.jwts (field 2): map<string, JWT>, JWT.claims (field 1): map<string, Value>.  The request view
+          // is name -> {"claims": {...}} (check.go:536-554), so the 2nd key of a path must be "claims".
+          auto jwt_as_map = [&](Span jwt) {   // {"claims": {...}}: the key is interned before the claims, children first
+            const u64 key = in.sid("claims");
+            const TV inner = encd.enc_map(jwt, 1);
+            const u32 off = (u32)b->heap_tag.size();
+            b->heap_tag.push_back((u8)T_STRING); b->heap_val.push_back(key);
+            b->heap_tag.push_back(inner.tag); b->heap_val.push_back(inner.val);
+            return TV{(u8)T_MAP, encd.container(off, 1)};
+          };
+          Span jwt{nullptr, nullptr};
+          if (nk == 0) {
+            std::vector<TV> ents;
+            Span s = m.aux; Field f;
+            while (next(s, f, encd.bad)) {
+              if (f.num != 2 || f.wt != 2) continue;
+              Entry en;
+              if (!entry(f.s, en, encd.bad)) break;
+              ents.push_back(TV{(u8)T_STRING, in.sid(sv(en.key))});
+              ents.push_back(jwt_as_map(en.val));
+            }
+            const u32 off = (u32)b->heap_tag.size();
+            for (const TV& x : ents) { b->heap_tag.push_back(x.tag); b->heap_val.push_back(x.val); }
+            tag = (u8)T_MAP; val = encd.container(off, ents.size() / 2); done = true;
+          } else if (!map_get(m.aux, 2, col.keys[0], jwt, encd.bad)) { tag = nk == 1 ? (u8)T_ABSENT : (u8)T_ERR; done = true; }
+          else if (nk == 1) { TV tv = jwt_as_map(jwt); tag = tv.tag; val = tv.val; done = true; }
+          else if (col.keys[1] != "claims") { tag = nk == 2 ? (u8)T_ABSENT : (u8)T_ERR; done = true; }
+          else if (nk == 2) { TV tv = encd.enc_map(jwt, 1); tag = tv.tag; val = tv.val; done = true; }
+          else if (!map_get(jwt, 1, col.keys[2], cur, encd.bad)) { tag = nk == 3 ? (u8)T_ABSENT : (u8)T_ERR; done = true; }
+          else k = 3;
+        } else if (nk == 0) {
           // the whole root map: Principal.attr (4) / Resource.attr (4) / AuxData.jwt (1)
           TV tv = encd.enc_map(col.root == 0 ? m.principal : col.root == 1 ? m.resource : m.aux, col.root == 2 ? 1 : 4);
           tag = tv.tag; val = tv.val; done = true;
         } else {
-          Span cur{nullptr, nullptr};
-          const size_t nk = col.keys.size();
-          for (size_t k = 0; k < nk && !done; ++k) {
-            bool found = false;
-            if (k == 0) {
-              for (const Entry& en : root) if (sv(en.key) == col.keys[0]) { cur = en.val; found = true; }   // last entry wins
-            } else {
-              Val v;
-              if (!value(cur, v, encd.bad) || v.kind != 5) { tag = (u8)T_ERR; done = true; break; }
-              found = map_get(v.s, 1, col.keys[k], cur, encd.bad);
-            }
-            if (!found) { tag = (k == nk - 1) ? (u8)T_ABSENT : (u8)T_ERR; done = true; }
-          }
-          if (!done) { TV tv = encd.enc(cur); tag = tv.tag; val = tv.val; }
+          bool found = false;
+          for (const Entry& en : attrs[col.root]) if (sv(en.key) == col.keys[0]) { cur = en.val; found = true; }   // last entry wins
+          if (!found) { tag = nk == 1 ? (u8)T_ABSENT : (u8)T_ERR; done = true; }
+          k = 1;
         }
+        for (; k < nk && !done; ++k) {
+          Val v;
+          if (!value(cur, v, encd.bad) || v.kind != 5) { tag = (u8)T_ERR; done = true; break; }
+          if (!map_get(v.s, 1, col.keys[k], cur, encd.bad)) { tag = (k == nk - 1) ? (u8)T_ABSENT : (u8)T_ERR; done = true; }
+        }
+        if (!done) { TV tv = encd.enc(cur); tag = tv.tag; val = tv.val; }
         b->col_tag[(size_t)c * R + r] = tag;
         b->col_val[(size_t)c * R + r] = val;
       }

@@ -228,7 +228,9 @@ class Flattener:
             req[RQ_S_R_SCOPE, r] = sid(namer.scope_value(r_scope_raw))
             req[RQ_S_P_VERSION, r] = sid(p.get("policyVersion", "") or "")
             req[RQ_S_R_VERSION, r] = sid(res.get("policyVersion", "") or "")
-            roots = {"P": p.get("attr") or {}, "R": res.get("attr") or {}, "J": aux.get("jwt") or {}}
+            roots = {"P": p.get("attr") or {}, "R": res.get("attr") or {}, "J": aux.get("jwt") or {},
+                     # name -> {"claims": {...}}; a JWT without claims has an empty map (as the protobuf message does)
+                     "S": {k: {"claims": (j or {}).get("claims") or {}} for k, j in (aux.get("jwts") or {}).items()}}
             for ci, (root, keys) in enumerate(lt.columns):
                 cur = roots[root]
                 tag = None

@@ -503,11 +503,11 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
 
 
 def _column_paths(columns):
-    """Per column: u8 root (0 = P.attr, 1 = R.attr, 2 = auxData.jwt), u8 n_keys, then per key u16 length +
-    UTF-8 bytes."""
+    """Per column: u8 root (0 = P.attr, 1 = R.attr, 2 = auxData.jwt, 3 = auxData.jwts), u8 n_keys, then per key
+    u16 length + UTF-8 bytes."""
     out = bytearray()
     for root, keys in columns:
-        out += struct.pack("<BB", "PRJ".index(root), len(keys))
+        out += struct.pack("<BB", "PRJS".index(root), len(keys))
         for k in keys:
             kb = k.encode("utf-8")
             out += struct.pack("<H", len(kb)) + kb

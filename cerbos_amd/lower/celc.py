@@ -521,6 +521,8 @@ class _FuncCompiler:
             elif top in ("aux_data", "auxData"):
                 if len(keys) >= 2 and keys[1] == "jwt":
                     return ("col", "J", tuple(keys[2:]))
+                if len(keys) >= 2 and keys[1] == "jwts":     # AuxData.jwts: name -> {claims: map} (engine.proto:314-321)
+                    return ("col", "S", tuple(keys[2:]))
                 return None
             else:
                 return None

@@ -65,8 +65,11 @@ def encode_check_input(inp: dict) -> bytes:
                + b"".join(_ld(3, str(x).encode("utf-8")) for x in (p.get("roles") or []))
                + encode_map(4, p.get("attr") or {}) + _string(5, p.get("scope", "") or ""))
     out += b"".join(_ld(4, str(a).encode("utf-8")) for a in (inp.get("actions") or []))
-    if aux.get("jwt"):
-        out += _ld(5, encode_map(1, aux["jwt"]))
+    if aux.get("jwt") or aux.get("jwts"):     # AuxData: 1 jwt map<string, Value>, 2 jwts map<string, JWT{1 claims}>
+        body = encode_map(1, aux.get("jwt") or {})
+        for name, jwt in (aux.get("jwts") or {}).items():
+            body += _ld(2, _ld(1, str(name).encode("utf-8")) + _ld(2, encode_map(1, (jwt or {}).get("claims") or {})))
+        out += _ld(5, body)
     return out
 
 

@@ -43,3 +43,10 @@ def assert_server_case(case, outs, skip=()):
             assert sorted(have["effectiveDerivedRoles"]) == sorted(want["effectiveDerivedRoles"] or []), (case["name"], i)
         n += 1
     return n
+
+
+def rfc3339_ns(text):
+    """'2022-08-02T15:00:00Z' -> ns since the epoch (test-suite `options.now`)."""
+    import datetime
+    dt = datetime.datetime.fromisoformat(text.replace("Z", "+00:00"))
+    return int(dt.timestamp()) * 1_000_000_000 + dt.microsecond * 1000

@@ -66,3 +66,36 @@ def test_service_level_check_resources_case(evaluator, case):
     outs, bad = evaluator.check(case["inputs"], now_ns=1_700_000_000_000_000_000, allow_unsupported=True)
     assert assert_server_case(case, outs, skip=bad) + len(bad) == len(case["inputs"])
     assert len(bad) < len(case["inputs"])
+
+
+def _run_verify_vectors(make_evaluator):
+    """tests/golden/verify_vectors.json (effects the reference engine returned for the policy-test-framework
+    fixtures) through the product path; shared with the GPU tier."""
+    import json
+
+    from helpers import rfc3339_ns
+    vectors = load_json("verify_vectors.json")
+    groups = {}
+    for v in vectors:
+        groups.setdefault(json.dumps(v["globals"], sort_keys=True), []).append(v)
+    compared = flagged = 0
+    for gkey, vs in groups.items():
+        ev = make_evaluator(json.loads(gkey))
+        for v in vs:
+            outs, bad = ev.check([v["input"]], now_ns=rfc3339_ns(v["now"]) if v["now"] else 1_700_000_000_000_000_000,
+                                 lenient_scope_search=v["lenient"], strict_evaluation=v["strict"],
+                                 default_policy_version=v["defaultPolicyVersion"], default_scope=v["defaultScope"],
+                                 allow_unsupported=True)
+            if bad:
+                flagged += 1
+                continue
+            assert {a: e["effect"] for a, e in outs[0]["actions"].items()} == v["want"], (v["suite"], v["test"])
+            compared += 1
+    return compared, flagged
+
+
+def test_policy_test_framework_vectors():
+    def make(globals_):
+        return HostSimEvaluator(lower_rule_table(store_rule_table(), globals_), Conf(globals_=globals_))
+    compared, flagged = _run_verify_vectors(make)
+    assert compared >= 40 and compared > 4 * flagged, (compared, flagged)

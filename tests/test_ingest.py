@@ -74,6 +74,17 @@ def test_synthetic_workloads_flatten_identically(name):
     _same(lt, reqs().to_inputs())
 
 
+def test_policy_test_framework_inputs_flatten_identically():
+    """Inputs of tests/golden/verify_vectors.json: JWT claims (auxData.jwt) and named JWTs (auxData.jwts)."""
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    assert any(root == "S" for root, _ in lt.columns) and any(root == "J" for root, _ in lt.columns)
+    inputs = [v["input"] for v in load_json("verify_vectors.json")]
+    assert sum("jwts" in (i.get("auxData") or {}) for i in inputs) >= 2
+    inputs.append({"principal": {"id": "p", "roles": ["employee"]}, "resource": {"kind": "leave_request", "id": "r"}, "actions": ["frobnicate"],
+                   "auxData": {"jwts": {"token_a": {"claims": {"aud": "x"}}, "token_b": {}, "other": {"claims": {"customArray": ["A"]}}}}})
+    _same(lt, inputs)
+
+
 def test_edge_cases():
     lt = lower_rule_table(store_rule_table(), GLOBALS)
     weird = [

@@ -45,3 +45,22 @@ def test_service_level_check_resources_case(oracle, case):
     from helpers import assert_server_case
     params = EvalParams(globals_={"environment": "test"}, now_ns=1_700_000_000_000_000_000)
     assert assert_server_case(case, [oracle.check(i, params) for i in case["inputs"]]) == len(case["inputs"])
+
+
+VERIFY_VECTORS = load_json("verify_vectors.json")
+
+
+def test_policy_test_framework_vectors(oracle):
+    """Effects the reference engine itself returned while running the policy-test-framework fixtures
+    (testdata/verify/cases/*.golden, mined by tools/make_golden_verify.py): test-level `now`, JWT claims,
+    globals, default policy version and lenient scope search on the golden store."""
+    from helpers import rfc3339_ns
+    n = 0
+    for v in VERIFY_VECTORS:
+        params = EvalParams(globals_=v["globals"], now_ns=rfc3339_ns(v["now"]) if v["now"] else 1_700_000_000_000_000_000,
+                            default_policy_version=v["defaultPolicyVersion"], default_scope=v["defaultScope"],
+                            lenient_scope_search=v["lenient"], strict_evaluation=v["strict"])
+        have = oracle.check(v["input"], params)
+        assert {a: e["effect"] for a, e in have["actions"].items()} == v["want"], (v["suite"], v["test"])
+        n += len(v["want"])
+    assert n > 100
