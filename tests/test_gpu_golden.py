@@ -83,3 +83,18 @@ def test_service_level_check_resources_case(evaluator, case):
     outs, bad = evaluator.check(case["inputs"], now_ns=1_700_000_000_000_000_000, allow_unsupported=True)
     assert assert_server_case(case, outs, skip=bad) + len(bad) == len(case["inputs"])
     assert len(bad) < len(case["inputs"])
+
+
+def test_policy_test_framework_vectors():
+    """tests/golden/verify_vectors.json - effects the reference engine returned for its policy-test-framework
+    fixtures (test-level now, JWT claims, named JWTs, globals, strict / lenient modes) - on the GPU."""
+    from cerbos_amd.lower.blob import lower_rule_table
+    from test_hostsim_golden import _run_verify_vectors
+    evs = []
+
+    def make(globals_):
+        evs.append(HipEvaluator(lower_rule_table(store_rule_table(), globals_), Conf(globals_=globals_)))
+        return evs[-1]
+    assert _run_verify_vectors(make) == (64, 0)
+    for ev in evs:
+        ev.close()
