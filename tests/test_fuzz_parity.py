@@ -55,6 +55,35 @@ CONDITIONS = [
     '"admin" in P.roles',
     'R.kind == "doc" || R.id.startsWith("r1")',
 ]
+# wider CEL surface (SURVEY.md §8a "device-subset CEL"): whatever the device cannot run must be flagged, never guessed
+CONDITIONS_WIDE = CONDITIONS + [
+    "R.attr.amount + 10.0 > 110.0",
+    "R.attr.amount * 2.0 <= 900.0 || R.attr.amount / 4.0 > 150.0",
+    "P.attr.level % 2.0 == 0.0" ,
+    "!(R.attr.public == true) && P.attr.level > 1",
+    'R.attr.public == true ? P.attr.level > 2 : R.attr.owner == P.id',
+    'size(R.attr.status) == 4',
+    'R.attr.status.endsWith("ING") || R.attr.status.contains("PE")',
+    'P.id in R.attr.acl',
+    'P.attr.teams.all(t, size(t) > 2)',
+    'P.attr.teams.exists_one(t, t == "ops")',
+    'P.attr.regions.exists(r, r == R.attr.tags.region)',
+    'has(R.attr.acl) && size(R.attr.acl) > 0',
+    'timestamp(R.attr.created) < now()',
+    'now() - timestamp(R.attr.created) > duration("24h")',
+    'timestamp(R.attr.created).timeSince() > duration("1h")',
+    'R.attr.ip.inIPAddrRange("10.0.0.0/8")',
+    'request.auxData.jwt.iss == "cerbos" && "admin" in request.auxData.jwt.groups',
+    'request.aux_data.jwt.level > 2',
+    '"eu" in P.attr.regions && !("us" in P.attr.regions)',
+    'R.attr.amount > 100 == (P.attr.level > 3)',
+    'P.attr.department != R.attr.department && R.attr.status != "CLOSED"',
+    'R.attr.tags.region == "eu" || R.attr.tags.zone == "z"',
+    'size(P.roles) > 1 && P.roles.exists(r, r.startsWith("man"))',
+    'R.attr.owner.startsWith("p") && R.attr.owner.size() == 2',
+    'R.scope == "acme" || P.scope == "acme.hr"',
+    'R.policyVersion == "v2"',
+]
 
 
 def _cond(rng, pool):
@@ -65,10 +94,14 @@ def _cond(rng, pool):
     return {"match": {kind: {"of": [{"expr": str(e)} for e in rng.choice(pool, size=int(rng.integers(2, 4)), replace=False)]}}}
 
 
-def _policies(rng):
+def _policies(rng, wide=True):
     # half of the stores use single comparisons only (the leaf kernels), and principal / role policies
     # are left out often enough that every kernel feature class gets its share of seeds
-    pool = CONDITIONS[:10] if rng.random() < 0.5 else CONDITIONS
+    r = rng.random()
+    if wide:
+        pool = CONDITIONS[:10] if r < 0.4 else (CONDITIONS if r < 0.7 else CONDITIONS_WIDE)
+    else:     # the generator as the GPU tier was validated with (tests/test_gpu_fuzz.py)
+        pool = CONDITIONS[:10] if r < 0.5 else CONDITIONS
     with_principal, with_roles = rng.random() < 0.4, rng.random() < 0.4
     action_patterns = ACTION_PATTERNS if rng.random() < 0.6 else ACTIONS
     role_patterns = ROLE_PATTERNS if rng.random() < 0.6 else ROLES
@@ -149,7 +182,7 @@ def _value(rng, kind):
     raise AssertionError(kind)
 
 
-def _requests(rng, n):
+def _requests(rng, n, wide=True):
     out = []
     for i in range(n):
         pid = "p%d" % int(rng.integers(0, 6))
@@ -176,6 +209,15 @@ def _requests(rng, n):
             r_attr["tags"] = {"region": str(rng.choice(["eu", "us"]))} if rng.random() < 0.8 else {"zone": "z"}
         if rng.random() < 0.6:
             r_attr["acl"] = {("p%d" % int(rng.integers(0, 6))): float(rng.integers(1, 4)) for _ in range(int(rng.integers(0, 3)))}
+        if wide and rng.random() < 0.8:
+            r_attr["created"] = str(rng.choice(["2023-11-14T00:00:00Z", "2023-11-14T22:00:00Z", "2024-01-01T00:00:00Z", "yesterday"]))
+        if wide and rng.random() < 0.8:
+            r_attr["ip"] = str(rng.choice(["10.1.2.3", "192.168.0.1", "10.255.0.9", "not-an-ip"]))
+        aux = None
+        if wide and rng.random() < 0.6:
+            aux = {"jwt": {"iss": str(rng.choice(["cerbos", "other"])), "groups": [str(x) for x in rng.choice(["admin", "dev", "ops"], size=int(rng.integers(0, 3)), replace=False)]}}
+            if rng.random() < 0.7:
+                aux["jwt"]["level"] = float(rng.integers(0, 6))
         n_act = int(rng.choice([1, 2, 3, 4, 5, 7, 40, 70], p=[0.2, 0.2, 0.2, 0.2, 0.1, 0.06, 0.02, 0.02]))
         if n_act <= len(ACTIONS):
             actions = [str(a) for a in rng.choice(ACTIONS, size=n_act, replace=False)]
@@ -186,6 +228,8 @@ def _requests(rng, n):
                              "attr": p_attr},
                "resource": {"kind": str(rng.choice(KINDS + ["unknown"])), "id": "r%d" % int(rng.integers(0, 30)), "attr": r_attr},
                "actions": actions}
+        if aux is not None:
+            inp["auxData"] = aux
         if rng.random() < 0.5:
             inp["resource"]["scope"] = str(rng.choice(SCOPES + ["acme.hr.uk", "zzz"]))
         if rng.random() < 0.3:
