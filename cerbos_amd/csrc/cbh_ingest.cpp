@@ -582,33 +582,70 @@ static void sort_batch(cbi_batch* b, u32 ncol, bool sort) {
   b->tuple_perm.resize(T);
   std::iota(b->tuple_perm.begin(), b->tuple_perm.end(), (u64)0);
   if (!sort || R < 2) return;
-  // compact sort keys: the comparator then touches one 32-byte record per side instead of five strided arrays
-  struct Key { u32 kind, ver, scope, cnt; u64 sig; u32 idx; };
-  std::vector<Key> keys(R);
-  for (u32 q = 0; q < R; ++q) {
-    const u32 off = RQ(RQ_ROLE_OFF, q), cnt = RQ(RQ_ROLE_CNT, q);
-    u64 sg = 0;
-    for (u32 k = 0; k < cnt; ++k) sg += ((u64)b->roles[off + k] + 1) * ((u64)k * 0x9E3779B97F4A7C15ull + 0xC2B2AE3D27D4EB4Full);
-    keys[q] = Key{RQ(RQ_KIND, q), RQ(RQ_R_VERSION, q), RQ(RQ_R_SCOPE, q), cnt, sg, q};
-  }
-  auto less = [](const Key& x, const Key& y) {
+  // Requests fall into few routing groups (distinct kind / version / scope / role list): find the groups with a
+  // hash table, order the groups, then place the requests with one stable counting pass - O(R + G log G)
+  // instead of a comparison sort of all requests.
+  struct Key { u32 kind, ver, scope, cnt; u64 sig; };
+  auto key_eq = [](const Key& x, const Key& y) { return x.kind == y.kind && x.ver == y.ver && x.scope == y.scope && x.cnt == y.cnt && x.sig == y.sig; };
+  auto key_less = [](const Key& x, const Key& y) {
     if (x.kind != y.kind) return x.kind < y.kind;
     if (x.ver != y.ver) return x.ver < y.ver;
     if (x.scope != y.scope) return x.scope < y.scope;
     if (x.cnt != y.cnt) return x.cnt < y.cnt;
-    if (x.sig != y.sig) return x.sig < y.sig;
-    return x.idx < y.idx;   // = stable
+    return x.sig < y.sig;
   };
-  if (std::is_sorted(keys.begin(), keys.end(), less)) return;
-  std::sort(keys.begin(), keys.end(), less);
+  std::vector<Key> groups;
+  std::vector<u32> group_of(R);
+  {
+    size_t cap = 256;
+    std::vector<u32> slots(cap, 0);   // group index + 1
+    auto hash = [](const Key& k) {
+      u64 h = (u64)k.kind * 0x9E3779B97F4A7C15ull ^ (u64)k.ver * 0xC2B2AE3D27D4EB4Full ^ (u64)k.scope * 0x165667B19E3779F9ull ^ k.sig ^ ((u64)k.cnt << 40);
+      h ^= h >> 29; h *= 0xff51afd7ed558ccdull; h ^= h >> 32;
+      return (size_t)h;
+    };
+    for (u32 q = 0; q < R; ++q) {
+      const u32 off = RQ(RQ_ROLE_OFF, q), cnt = RQ(RQ_ROLE_CNT, q);
+      u64 sg = 0;
+      for (u32 k = 0; k < cnt; ++k) sg += ((u64)b->roles[off + k] + 1) * ((u64)k * 0x9E3779B97F4A7C15ull + 0xC2B2AE3D27D4EB4Full);
+      const Key key{RQ(RQ_KIND, q), RQ(RQ_R_VERSION, q), RQ(RQ_R_SCOPE, q), cnt, sg};
+      if ((groups.size() + 1) * 2 > cap) {   // grow and re-place
+        cap *= 4;
+        slots.assign(cap, 0);
+        for (u32 g = 0; g < groups.size(); ++g) { size_t i = hash(groups[g]) & (cap - 1); while (slots[i]) i = (i + 1) & (cap - 1); slots[i] = g + 1; }
+      }
+      size_t i = hash(key) & (cap - 1);
+      while (slots[i] && !key_eq(groups[slots[i] - 1], key)) i = (i + 1) & (cap - 1);
+      if (!slots[i]) { groups.push_back(key); slots[i] = (u32)groups.size(); }
+      group_of[q] = slots[i] - 1;
+    }
+  }
+  const u32 G = (u32)groups.size();
+  std::vector<u32> by_rank(G);
+  std::iota(by_rank.begin(), by_rank.end(), 0u);
+  std::sort(by_rank.begin(), by_rank.end(), [&](u32 x, u32 y) { return key_less(groups[x], groups[y]); });
+  std::vector<u32> rank(G), start(G + 1, 0);
+  for (u32 r = 0; r < G; ++r) rank[by_rank[r]] = r;
+  for (u32 q = 0; q < R; ++q) ++start[rank[group_of[q]] + 1];
+  for (u32 r = 0; r < G; ++r) start[r + 1] += start[r];
+  std::vector<u32> order(R);
+  bool identity = true;
+  for (u32 q = 0; q < R; ++q) { const u32 pos = start[rank[group_of[q]]]++; order[pos] = q; identity = identity && pos == q; }
+  if (identity) return;
+  // gather array by array: sequential writes, reads confined to one array at a time
   std::vector<u32> req2((size_t)RQ_N * R), ta(T), tr(T), ri(R);
   std::vector<u8> ct((size_t)ncol * R);
   std::vector<u64> cv((size_t)ncol * R), tp(T);
+  const u32* ord = order.data();
+  for (u32 f = 0; f < RQ_N; ++f) { const u32* src = &b->req[(size_t)f * R]; u32* dst = &req2[(size_t)f * R]; for (u32 q = 0; q < R; ++q) dst[q] = src[ord[q]]; }
+  for (u32 c = 0; c < ncol; ++c) {
+    const u8* st = &b->col_tag[(size_t)c * R]; u8* dt = &ct[(size_t)c * R];
+    const u64* sv_ = &b->col_val[(size_t)c * R]; u64* dv = &cv[(size_t)c * R];
+    for (u32 q = 0; q < R; ++q) { dt[q] = st[ord[q]]; dv[q] = sv_[ord[q]]; }
+  }
   u32 pos = 0;
   for (u32 q = 0; q < R; ++q) {
-    const u32 o = keys[q].idx;
-    for (u32 f = 0; f < RQ_N; ++f) req2[(size_t)f * R + q] = b->req[(size_t)f * R + o];
-    for (u32 c = 0; c < ncol; ++c) { ct[(size_t)c * R + q] = b->col_tag[(size_t)c * R + o]; cv[(size_t)c * R + q] = b->col_val[(size_t)c * R + o]; }
+    const u32 o = ord[q];
     const u32 s0 = RQ(RQ_ACT_OFF, o), cn = RQ(RQ_ACT_CNT, o);
     req2[(size_t)RQ_ACT_OFF * R + q] = pos;
     for (u32 k = 0; k < cn; ++k, ++pos) { ta[pos] = b->tuple_action[s0 + k]; tr[pos] = q; tp[pos] = s0 + k; }
