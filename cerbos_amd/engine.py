@@ -176,4 +176,7 @@ class HipEvaluator:
         return namer.policy_key_from_fqn(namer.principal_policy_fqn(inp["principal"]["id"], ver, scope))
 
     def close(self):
+        if getattr(self, "_ingest", None) is not None:
+            self._ingest.close()
+            self._ingest = None
         self.table.close()

@@ -83,6 +83,26 @@ def test_empty_and_ragged_batches():
     table.close()
 
 
+def test_concurrent_one_shot_calls():
+    """cbh_check_batch from many threads at once (each call owns one of the table's one-shot contexts: stream,
+    staging block, device block): every call must return exactly what it returns when called alone - small
+    batches (staged, one copy each way) and a large one (array-by-array copies) mixed."""
+    from concurrent.futures import ThreadPoolExecutor
+    rt, lt, table = _table(workloads.c3_policies)
+    fl = Flattener(lt)
+    sizes = [1, 7, 64, 300, 2_000, 150_000, 5, 900]
+    batches = [workloads.c3_requests(n, seed=100 + i).to_batch(fl) for i, n in enumerate(sizes)]
+    flags = capi.F_WANT_DERIVED_ROLES
+    alone = [table.check(b, now_ns=NOW, flags=flags) for b in batches]
+    jobs = [i % len(batches) for i in range(64)]
+    with ThreadPoolExecutor(16) as ex:
+        got = list(ex.map(lambda i: table.check(batches[i], now_ns=NOW, flags=flags), jobs))
+    for i, res in zip(jobs, got):
+        for f in ("effect", "policy", "scope", "status", "edr"):
+            assert np.array_equal(getattr(res, f), getattr(alone[i], f)), (sizes[i], f)
+    table.close()
+
+
 def test_resident_path_and_kernel_timer():
     rt, lt, table = _table(workloads.c2_policies)
     cr = workloads.c2_requests(5000)
