@@ -171,6 +171,7 @@ struct cbi_batch {
   std::vector<u32> req, roles, tuple_req, tuple_action, str_off, req_input;
   std::vector<u8> col_tag, heap_tag, str_bytes, str_flags;
   std::vector<u64> col_val, heap_val, tuple_perm;
+  std::vector<u64> str_hash;   // hash_bytes of each batch-local string (merge of slices)
 };
 
 namespace {
@@ -232,6 +233,7 @@ struct Interner {
       b->str_bytes.insert(b->str_bytes.end(), s.begin(), s.end());
       b->str_off.push_back((u32)b->str_bytes.size());
       b->str_flags.push_back((u8)flag);
+      b->str_hash.push_back(h);
       local.insert(h, id);
     }
     return t->K + id;
@@ -575,7 +577,7 @@ static int flatten_slice(const cbi_table* t, const uint8_t* bytes, const uint64_
 
 // Routing sort (flatten.py sort_batch_by_route): kind, resource version, resource scope, role count,
 // order-sensitive signature of the role list; stable.  Fills tuple_perm.
-static void sort_batch(cbi_batch* b, u32 ncol, bool sort) {
+static void sort_batch(cbi_batch* b, u32 ncol, bool sort, int n_threads) {
   const u32 R = (u32)b->req_input.size();
   auto RQ = [&](u32 f, u32 r) -> u32& { return b->req[(size_t)f * R + r]; };
   const u32 T = (u32)b->tuple_action.size();
@@ -632,24 +634,39 @@ static void sort_batch(cbi_batch* b, u32 ncol, bool sort) {
   bool identity = true;
   for (u32 q = 0; q < R; ++q) { const u32 pos = start[rank[group_of[q]]]++; order[pos] = q; identity = identity && pos == q; }
   if (identity) return;
-  // gather array by array: sequential writes, reads confined to one array at a time
-  std::vector<u32> req2((size_t)RQ_N * R), ta(T), tr(T), ri(R);
+  // gather array by array (sequential writes, reads confined to one array at a time); the arrays are independent
+  // jobs and go round-robin to the threads of a parallel call
+  std::vector<u32> req2((size_t)RQ_N * R), ta(T), tr(T), ri(R), new_off(R + 1, 0);
   std::vector<u8> ct((size_t)ncol * R);
   std::vector<u64> cv((size_t)ncol * R), tp(T);
   const u32* ord = order.data();
-  for (u32 f = 0; f < RQ_N; ++f) { const u32* src = &b->req[(size_t)f * R]; u32* dst = &req2[(size_t)f * R]; for (u32 q = 0; q < R; ++q) dst[q] = src[ord[q]]; }
-  for (u32 c = 0; c < ncol; ++c) {
-    const u8* st = &b->col_tag[(size_t)c * R]; u8* dt = &ct[(size_t)c * R];
-    const u64* sv_ = &b->col_val[(size_t)c * R]; u64* dv = &cv[(size_t)c * R];
-    for (u32 q = 0; q < R; ++q) { dt[q] = st[ord[q]]; dv[q] = sv_[ord[q]]; }
-  }
-  u32 pos = 0;
-  for (u32 q = 0; q < R; ++q) {
-    const u32 o = ord[q];
-    const u32 s0 = RQ(RQ_ACT_OFF, o), cn = RQ(RQ_ACT_CNT, o);
-    req2[(size_t)RQ_ACT_OFF * R + q] = pos;
-    for (u32 k = 0; k < cn; ++k, ++pos) { ta[pos] = b->tuple_action[s0 + k]; tr[pos] = q; tp[pos] = s0 + k; }
-    ri[q] = b->req_input[o];
+  for (u32 q = 0; q < R; ++q) new_off[q + 1] = new_off[q] + RQ(RQ_ACT_CNT, ord[q]);
+  const u32 n_jobs = RQ_N + ncol + 1;
+  auto job = [&](u32 j) {
+    if (j < RQ_N) {
+      const u32* src = &b->req[(size_t)j * R]; u32* dst = &req2[(size_t)j * R];
+      if (j == RQ_ACT_OFF) { for (u32 q = 0; q < R; ++q) dst[q] = new_off[q]; }
+      else for (u32 q = 0; q < R; ++q) dst[q] = src[ord[q]];
+    } else if (j < RQ_N + ncol) {
+      const u32 c = j - RQ_N;
+      const u8* st = &b->col_tag[(size_t)c * R]; u8* dt = &ct[(size_t)c * R];
+      const u64* sv_ = &b->col_val[(size_t)c * R]; u64* dv = &cv[(size_t)c * R];
+      for (u32 q = 0; q < R; ++q) { dt[q] = st[ord[q]]; dv[q] = sv_[ord[q]]; }
+    } else {
+      for (u32 q = 0; q < R; ++q) {
+        const u32 o = ord[q], s0 = RQ(RQ_ACT_OFF, o), cn = RQ(RQ_ACT_CNT, o);
+        u32 pos = new_off[q];
+        for (u32 k = 0; k < cn; ++k, ++pos) { ta[pos] = b->tuple_action[s0 + k]; tr[pos] = q; tp[pos] = s0 + k; }
+        ri[q] = b->req_input[o];
+      }
+    }
+  };
+  const u32 W = n_threads > 1 ? std::min<u32>((u32)n_threads, n_jobs) : 1u;
+  if (W == 1) { for (u32 j = 0; j < n_jobs; ++j) job(j); }
+  else {
+    std::vector<std::thread> th;
+    for (u32 w = 0; w < W; ++w) th.emplace_back([&, w]() { for (u32 j = w; j < n_jobs; j += W) job(j); });
+    for (auto& x : th) x.join();
   }
   b->req.swap(req2); b->col_tag.swap(ct); b->col_val.swap(cv);
   b->tuple_action.swap(ta); b->tuple_req.swap(tr); b->tuple_perm.swap(tp); b->req_input.swap(ri);
@@ -680,29 +697,66 @@ static void merge_slices(const cbi_table* t, std::vector<cbi_batch*>& parts, con
     hb[k + 1] = hb[k] + (u32)parts[k]->heap_tag.size(); lb[k + 1] = lb[k] + (u32)parts[k]->roles.size();
   }
   const u32 R = rb[P], T = tb[P];
-  // merged dictionary (serial: it defines the ids)
+  // Merged dictionary.  The id of a string is its rank in first-appearance order over (slice, position).
+  // Finding each string's first appearance is the expensive part (hashing, comparing) and splits by hash:
+  // partition p looks only at strings with hash % B == p, so partitions never share a string.  What is left
+  // for the serial pass is handing out ids in order and copying the bytes.
   std::vector<std::vector<u32>> remap(P);
+  std::vector<std::vector<u64>> owner(P);           // (slice << 32 | position) of the first appearance
+  std::vector<std::vector<u8>> oflags(P);           // flags OR-ed over all appearances, kept at the owner
+  for (u32 k = 0; k < P; ++k) { const size_t ns = parts[k]->str_flags.size(); remap[k].resize(ns); owner[k].resize(ns); oflags[k] = parts[k]->str_flags; }
+  auto str_of = [&](u64 ref) {
+    const cbi_batch* p = parts[ref >> 32]; const u32 j = (u32)ref;
+    return std::string_view((const char*)p->str_bytes.data() + p->str_off[j], p->str_off[j + 1] - p->str_off[j]);
+  };
+  const u32 B = n_threads > 1 ? (u32)n_threads : 1u;
+  auto dedupe = [&](u32 part) {
+    size_t mine = 0;
+    for (u32 k = 0; k < P; ++k) for (u64 h : parts[k]->str_hash) mine += ((h >> 32) % B) == part;
+    size_t cap = 64; while (cap < 2 * mine) cap <<= 1;
+    struct Slot { u32 h; u32 used; u64 ref; };
+    std::vector<Slot> slots(cap, Slot{0, 0, 0});
+    for (u32 k = 0; k < P; ++k) {
+      const std::vector<u64>& hs = parts[k]->str_hash;
+      for (u32 j = 0; j < hs.size(); ++j) {
+        const u64 h = hs[j];
+        if (((h >> 32) % B) != part) continue;
+        const u64 ref = ((u64)k << 32) | j;
+        size_t i = (size_t)h & (cap - 1);
+        for (;; i = (i + 1) & (cap - 1)) {
+          Slot& sl = slots[i];
+          if (!sl.used) { sl = Slot{(u32)h, 1, ref}; owner[k][j] = ref; break; }
+          if (sl.h == (u32)h && str_of(sl.ref) == str_of(ref)) {
+            owner[k][j] = sl.ref;
+            oflags[sl.ref >> 32][(u32)sl.ref] |= parts[k]->str_flags[j];
+            break;
+          }
+        }
+      }
+    }
+  };
+  if (B == 1) dedupe(0);
+  else {
+    std::vector<std::thread> th;
+    for (u32 part = 0; part < B; ++part) th.emplace_back(dedupe, part);
+    for (auto& x : th) x.join();
+  }
   out->str_off.assign(1, 0);
-  StrIndex index;
-  { size_t tot = 0; for (cbi_batch* p : parts) tot += p->str_flags.size(); index.reserve(tot); }
-  auto at = [&](u32 i) { return std::string_view((const char*)out->str_bytes.data() + out->str_off[i], out->str_off[i + 1] - out->str_off[i]); };
+  { size_t bytes = 0, cnt = 0; for (cbi_batch* p : parts) { bytes += p->str_bytes.size(); cnt += p->str_flags.size(); }
+    out->str_bytes.reserve(bytes); out->str_off.reserve(cnt + 1); out->str_flags.reserve(cnt); out->str_hash.reserve(cnt); }
   for (u32 k = 0; k < P; ++k) {
     const cbi_batch* p = parts[k];
-    const u32 ns = (u32)p->str_flags.size();
-    remap[k].resize(ns);
-    for (u32 j = 0; j < ns; ++j) {
-      std::string_view sj((const char*)p->str_bytes.data() + p->str_off[j], p->str_off[j + 1] - p->str_off[j]);
-      const u64 h = hash_bytes(sj);
-      u32 id;
-      if (k > 0 && index.find(sj, h, at, id)) out->str_flags[id] |= p->str_flags[j];
-      else {
-        id = (u32)out->str_flags.size();
-        out->str_bytes.insert(out->str_bytes.end(), sj.begin(), sj.end());
+    for (u32 j = 0; j < p->str_flags.size(); ++j) {
+      const u64 ow = owner[k][j];
+      if (ow == (((u64)k << 32) | j)) {
+        remap[k][j] = (u32)out->str_flags.size();
+        out->str_bytes.insert(out->str_bytes.end(), p->str_bytes.begin() + p->str_off[j], p->str_bytes.begin() + p->str_off[j + 1]);
         out->str_off.push_back((u32)out->str_bytes.size());
-        out->str_flags.push_back(p->str_flags[j]);
-        index.insert(h, id);
+        out->str_flags.push_back(oflags[k][j]);
+        out->str_hash.push_back(p->str_hash[j]);
+      } else {
+        remap[k][j] = remap[ow >> 32][(u32)ow];   // the owner comes earlier in (slice, position) order
       }
-      remap[k][j] = id;
     }
   }
   out->req.assign((size_t)RQ_N * R, 0);
@@ -780,7 +834,7 @@ int cbi_flatten_pb_mt(const cbi_table* t, const uint8_t* bytes, const uint64_t* 
     if (bad >= 0) { delete b; return fail(errs[bad] + " (slice starting at message " + std::to_string(base[bad]) + ")"); }
   }
   if (b->heap_tag.size() >= ((size_t)1 << 30)) { delete b; return fail("batch too large: nested attribute values exceed the heap's 30-bit offsets"); }
-  sort_batch(b, ncol, sort != 0);
+  sort_batch(b, ncol, sort != 0, (int)P);
   finish_view(b, ncol);
   *out = b;
   return 0;
