@@ -847,6 +847,7 @@ int cbi_flatten_pb(const cbi_table* t, const uint8_t* bytes, const uint64_t* off
 
 // ---- response assembly ---------------------------------------------------------------------------------
 static void put_varint(std::vector<u8>& o, u64 v) { while (v >= 0x80) { o.push_back((u8)(v | 0x80)); v >>= 7; } o.push_back((u8)v); }
+static size_t varint_size(u64 v) { size_t n = 1; while (v >= 0x80) { v >>= 7; ++n; } return n; }
 static void put_ld(std::vector<u8>& o, u32 field, std::string_view s) {
   put_varint(o, (u64)field << 3 | 2); put_varint(o, s.size()); o.insert(o.end(), s.begin(), s.end());
 }
@@ -877,7 +878,6 @@ int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result*
     o->bytes.reserve((size_t)(hi - lo) * 96);
     struct Act { std::string_view name; u32 j; };
     std::vector<Act> acts;
-    std::vector<u8> eff, ent;
     std::string pol, kbuf, vbuf;
     u64 k = first[lo];
     const u64 k_hi = first[hi];
@@ -907,11 +907,11 @@ int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result*
       std::vector<u8>& ob = o->bytes;
       put_str(ob, 1, request_id);
       put_str(ob, 2, Rs.id);
+      u32 pol_word = 0xFFFFFFFFu;   // `pol` holds the key of this word (the actions of one input mostly share it)
       for (const Act& a : acts) {
-        eff.clear(); ent.clear();
-        if (res->effect[a.j]) { eff.push_back(1 << 3 | 0); put_varint(eff, res->effect[a.j]); }
-        if (res->policy) {
-          const u32 w = res->policy[a.j], kind = w >> 28, ident = w & 0x0FFFFFFFu;
+        if (res->policy && res->policy[a.j] != pol_word) {
+          pol_word = res->policy[a.j];
+          const u32 kind = pol_word >> 28, ident = pol_word & 0x0FFFFFFFu;
           pol.clear();
           switch (kind) {   // enum cbh_policy_kind; keys as namer.PolicyKeyFromFQN gives them (namer.go:95-134)
             case CBH_P_EMPTY: break;
@@ -929,15 +929,25 @@ int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result*
             }
             default: return bail("unknown policy word");
           }
-          put_str(eff, 2, pol);
         }
+        std::string_view scope_s;
         if (res->scope && res->scope[a.j] != 0xFFFFFFFFu) {
           if (res->scope[a.j] >= t->scopes.size()) return bail("scope index out of range");
-          put_str(eff, 3, t->scopes[res->scope[a.j]]);
+          scope_s = t->scopes[res->scope[a.j]];
         }
-        put_ld(ent, 1, a.name);
-        put_ld(ent, 2, std::string_view((const char*)eff.data(), eff.size()));
-        put_ld(ob, 3, std::string_view((const char*)ent.data(), ent.size()));
+        // sizes first, then one pass of writes: entry {1: action, 2: ActionEffect {1: effect, 2: policy, 3: scope}}
+        const std::string_view pol_s = res->policy ? std::string_view(pol) : std::string_view();
+        const u8 effect = res->effect[a.j];
+        auto ld_size = [](size_t n) { return 1 + varint_size(n) + n; };
+        const size_t eff_len = (effect ? 1 + varint_size(effect) : 0) + (pol_s.empty() ? 0 : ld_size(pol_s.size())) +
+                               (scope_s.empty() ? 0 : ld_size(scope_s.size()));
+        const size_t ent_len = ld_size(a.name.size()) + ld_size(eff_len);
+        put_varint(ob, 3u << 3 | 2); put_varint(ob, ent_len);
+        put_ld(ob, 1, a.name);
+        put_varint(ob, 2u << 3 | 2); put_varint(ob, eff_len);
+        if (effect) { ob.push_back(1 << 3 | 0); put_varint(ob, effect); }
+        put_str(ob, 2, pol_s);
+        put_str(ob, 3, scope_s);
       }
       for (u32 d = 0; d < 64 && d < t->dr_names.size(); ++d) if ((edr[i] >> d) & 1) put_ld(ob, 4, t->dr_names[d]);
       o->offsets.push_back(ob.size());
