@@ -2,6 +2,8 @@
 kernel feature class (plain / derived roles / globs / everything; leaf and interpreter; 4, 32 and 64
 action masks) on hardware, against oracle/check.py.  (The wider CEL surface of CONDITIONS_WIDE runs on the
 kernel source in the CPU tier; it joins this tier once it has been run on hardware.)"""
+import os
+
 import numpy as np
 import pytest
 
@@ -16,18 +18,21 @@ from test_fuzz_parity import NOW, _policies, _requests
 
 pytestmark = pytest.mark.gpu
 
+# CBH_GPU_FUZZ_WIDE=1 switches to the wider CEL pool (CONDITIONS_WIDE) that has so far run on the kernel source only
+WIDE = os.environ.get("CBH_GPU_FUZZ_WIDE", "0") == "1"
+
 
 @pytest.mark.parametrize("seed", range(24))
 def test_fuzz_store_on_gpu(seed):
     rng = np.random.default_rng(10_000 + seed)
-    rt = rule_table_from_policies(policies_from_docs(_policies(rng, wide=False)))
+    rt = rule_table_from_policies(policies_from_docs(_policies(rng, wide=WIDE)))
     try:
         lt = lower_rule_table(rt)
     except LoweringError:
         pytest.skip("store refused by the lowering")
     ev = HipEvaluator(lt, Conf())
     orc = RuleTableOracle(rt)
-    inputs = _requests(rng, 150, wide=False)
+    inputs = _requests(rng, 150, wide=WIDE)
     compared = 0
     for lenient, strict in ((False, False), (True, False), (False, True)):
         outs, bad = ev.check(inputs, now_ns=NOW, lenient_scope_search=lenient, strict_evaluation=strict, allow_unsupported=True)
