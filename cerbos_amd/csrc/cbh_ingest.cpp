@@ -455,6 +455,7 @@ static int flatten_slice(const cbi_table* t, const uint8_t* bytes, const uint64_
 
   // per message scratch, reused
   std::vector<std::string_view> actions, roles;
+  std::vector<std::pair<std::string_view, u32>> prev_roles, prev_actions;
   std::vector<Entry> attrs[3];   // entries of Principal.attr / Resource.attr / AuxData.jwt, wire order
   std::string kind_buf;
   bool need_root[4] = {false, false, false, false};
@@ -502,7 +503,14 @@ static int flatten_slice(const cbi_table* t, const uint8_t* bytes, const uint64_
       RQ(RQ_R_VERSION, r) = in.sid_memo(2, r_ver);
       RQ(RQ_ROLE_OFF, r) = (u32)b->roles.size();
       RQ(RQ_ROLE_CNT, r) = (u32)roles.size();
-      for (std::string_view x : roles) b->roles.push_back(in.sid(x, SF_ROLE));
+      // role and action lists repeat from one message to the next: try the previous message's string at the same
+      // position before hashing (the id already carries the role / action flag from when it was interned that way)
+      for (size_t x = 0; x < roles.size(); ++x) {
+        if (x >= prev_roles.size()) prev_roles.emplace_back(std::string_view(), 0u);
+        auto& pr = prev_roles[x];
+        if (!(pr.first.data() && pr.first == roles[x])) { pr.first = roles[x]; pr.second = in.sid(roles[x], SF_ROLE); }
+        b->roles.push_back(pr.second);
+      }
       RQ(RQ_S_RESOURCE_ID, r) = in.sid(Rs.id);
       RQ(RQ_S_KIND, r) = in.sid_memo(3, Rs.kind);
       RQ(RQ_S_P_SCOPE, r) = in.sid_memo(4, scope_value(P.scope));
@@ -569,7 +577,12 @@ static int flatten_slice(const cbi_table* t, const uint8_t* bytes, const uint64_
       RQ(RQ_ACT_OFF, r) = (u32)b->tuple_action.size();
       size_t a0 = ch * MAX_ACTIONS, a1 = std::min(na, a0 + MAX_ACTIONS);
       RQ(RQ_ACT_CNT, r) = (u32)(a1 - a0);
-      for (size_t a = a0; a < a1; ++a) { b->tuple_req.push_back(r); b->tuple_action.push_back(in.sid(actions[a], SF_ACTION)); }
+      for (size_t a = a0; a < a1; ++a) {
+        if (a >= prev_actions.size()) prev_actions.emplace_back(std::string_view(), 0u);
+        auto& pa = prev_actions[a];
+        if (!(pa.first.data() && pa.first == actions[a])) { pa.first = actions[a]; pa.second = in.sid(actions[a], SF_ACTION); }
+        b->tuple_req.push_back(r); b->tuple_action.push_back(pa.second);
+      }
     }
   }
   return 0;
