@@ -98,4 +98,4 @@ def test_policy_test_framework_vectors():
     def make(globals_):
         return HostSimEvaluator(lower_rule_table(store_rule_table(), globals_), Conf(globals_=globals_))
     compared, flagged = _run_verify_vectors(make)
-    assert (compared, flagged) == (64, 0)
+    assert (compared, flagged) == (len(load_json("verify_vectors.json")), 0)

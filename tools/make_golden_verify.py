@@ -120,6 +120,27 @@ def main():
                                         "globals": opt.get("globals") or {}, "lenient": bool(opt.get("lenientScopeSearch")), "strict": bool(opt.get("strictEvaluation")),
                                         "defaultPolicyVersion": opt.get("defaultPolicyVersion") or "default",
                                         "defaultScope": opt.get("defaultScope") or "", "input": inp, "want": want})
+    # testdata/store/tests/*_test.yaml: the store's own policy tests (inline fixtures, `expected` effects; an action
+    # an expectation does not name must be denied - verify/run_test_suite.go)
+    for spath in sorted(glob.glob(os.path.join(REF, "internal/test/testdata/store/tests", "*_test.yaml"))):
+        with open(spath, encoding="utf-8") as fh:
+            suite = load(fh.read()) or {}
+        sopt = suite.get("options") or {}
+        for t in suite.get("tests") or []:
+            opt = dict(sopt)
+            opt.update(t.get("options") or {})
+            tin = t.get("input") or {}
+            for exp in t.get("expected") or []:
+                p, r = (suite.get("principals") or {}).get(exp["principal"]), (suite.get("resources") or {}).get(exp["resource"])
+                if p is None or r is None:
+                    continue
+                want = {a: (exp.get("actions") or {}).get(a, "EFFECT_DENY") for a in tin.get("actions") or []}
+                inp = {"requestId": "store/tests/%s" % t["name"], "principal": p, "resource": r, "actions": list(want)}
+                vectors.append({"suite": "store/tests/%s" % os.path.basename(spath), "test": t["name"], "now": opt.get("now"),
+                                "globals": opt.get("globals") or {}, "lenient": bool(opt.get("lenientScopeSearch")),
+                                "strict": bool(opt.get("strictEvaluation")),
+                                "defaultPolicyVersion": opt.get("defaultPolicyVersion") or "default",
+                                "defaultScope": opt.get("defaultScope") or "", "input": inp, "want": want})
     # the framework's own test cases repeat the same suites: keep one of each (input, options, result)
     seen, uniq = set(), []
     for v in vectors:
