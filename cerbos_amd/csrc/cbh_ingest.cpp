@@ -421,19 +421,32 @@ void cbi_table_close(cbi_table* t) { delete t; }
 // (the three helpers below are file-local)
 }  // extern "C"
 
-// Flattens messages [0, n) into `b` in input order: no routing sort, no view; req_input holds slice-local indices.
-static int flatten_slice(const cbi_table* t, const uint8_t* bytes, const uint64_t* offsets, uint32_t n, std::string_view dver,
+// Where the inputs come from: serialized CheckInputs (bytes + offsets), or the resource entries of ONE serialized
+// CheckResourcesRequest, which share its principal and the caller's (verified) auxiliary data - the CheckInputs
+// svc.CheckResources would build from it (cerbos_svc.go:274-287), without building them.
+struct Source {
+  const uint8_t* bytes = nullptr; const uint64_t* offsets = nullptr;
+  bool request = false; Span principal{nullptr, nullptr}, aux{nullptr, nullptr};
+  const Span* entries = nullptr;   // CheckResourcesRequest.ResourceEntry messages: actions = 1, resource = 2
+};
+
+// Flattens inputs [first, first + n) of `src` into `b` in input order: no routing sort, no view; req_input holds
+// slice-local indices.
+static int flatten_slice(const cbi_table* t, const Source& src, uint32_t first, uint32_t n, std::string_view dver,
                          std::string_view dscope, cbi_batch* b, std::string& err) {
+  const uint8_t* bytes = src.bytes;
+  const uint64_t* offsets = src.request ? nullptr : src.offsets + first;
   auto bail = [&](const std::string& m) { err = m; return -1; };
   const u32 ncol = (u32)t->columns.size();
 
   // pass 1: count device requests (a CheckInput with > 64 actions becomes several) and tuples
   u64 nreq = 0, ntup = 0;
+  const u32 action_field = src.request ? 1u : 4u;
   for (u32 i = 0; i < n; ++i) {
-    if (offsets[i + 1] < offsets[i]) return bail("offsets must not decrease");
-    Span m{bytes + offsets[i], bytes + offsets[i + 1]};
+    if (!src.request && offsets[i + 1] < offsets[i]) return bail("offsets must not decrease");
+    Span m = src.request ? src.entries[first + i] : Span{bytes + offsets[i], bytes + offsets[i + 1]};
     Field f; bool bad = false; size_t na = 0;
-    while (next(m, f, bad)) na += (f.num == 4 && f.wt == 2);
+    while (next(m, f, bad)) na += (f.num == action_field && f.wt == 2);
     if (bad) return bail("malformed CheckInput at index " + std::to_string(i));
     nreq += na ? (na + MAX_ACTIONS - 1) / MAX_ACTIONS : 1;
     ntup += na;
@@ -467,9 +480,15 @@ static int flatten_slice(const cbi_table* t, const uint8_t* bytes, const uint64_
     actions.clear(); roles.clear();
     for (auto& a : attrs) a.clear();
     bool bad = false;
-    { Span s{bytes + offsets[i], bytes + offsets[i + 1]}; Field f;
+    if (src.request) {
+      m.principal = src.principal; m.aux = src.aux;
+      Span s = src.entries[first + i]; Field f;
+      while (next(s, f, bad)) { if (f.wt != 2) continue; if (f.num == 1) actions.push_back(sv(f.s)); else if (f.num == 2) m.resource = f.s; }
+    } else {
+      Span s{bytes + offsets[i], bytes + offsets[i + 1]}; Field f;
       while (next(s, f, bad)) { if (f.wt != 2) continue;
-        if (f.num == 2) m.resource = f.s; else if (f.num == 3) m.principal = f.s; else if (f.num == 4) actions.push_back(sv(f.s)); else if (f.num == 5) m.aux = f.s; } }
+        if (f.num == 2) m.resource = f.s; else if (f.num == 3) m.principal = f.s; else if (f.num == 4) actions.push_back(sv(f.s)); else if (f.num == 5) m.aux = f.s; }
+    }
     // Principal: id 1, policy_version 2, roles 3, attr 4, scope 5;  Resource: kind 1, policy_version 2, id 3, attr 4, scope 5
     Party P, Rs;
     { Span s = m.principal; Field f;
@@ -814,9 +833,10 @@ static void merge_slices(const cbi_table* t, std::vector<cbi_batch*>& parts, con
 
 extern "C" {
 
-int cbi_flatten_pb_mt(const cbi_table* t, const uint8_t* bytes, const uint64_t* offsets, uint32_t n, const char* default_version,
-                      const char* default_scope, int sort, int n_threads, cbi_batch** out) {
-  if (!t || !out || (n && (!bytes || !offsets))) return fail("cbi_flatten_pb: null argument");
+}  // extern "C"
+
+static int flatten_source(const cbi_table* t, const Source& src, uint32_t n, const char* default_version, const char* default_scope,
+                          int sort, int n_threads, cbi_batch** out) {
   const std::string_view dver = default_version ? default_version : "default";
   const std::string_view dscope = default_scope ? default_scope : "";
   const u32 ncol = (u32)t->columns.size();
@@ -826,7 +846,7 @@ int cbi_flatten_pb_mt(const cbi_table* t, const uint8_t* bytes, const uint64_t* 
   auto b = new cbi_batch();
   std::string err;
   if (P == 1) {
-    if (flatten_slice(t, bytes, offsets, n, dver, dscope, b, err) != 0) { delete b; return fail(err); }
+    if (flatten_slice(t, src, 0, n, dver, dscope, b, err) != 0) { delete b; return fail(err); }
   } else {
     std::vector<u32> base(P + 1);
     for (u32 k = 0; k <= P; ++k) base[k] = (u32)((u64)n * k / P);
@@ -837,7 +857,7 @@ int cbi_flatten_pb_mt(const cbi_table* t, const uint8_t* bytes, const uint64_t* 
     {
       std::vector<std::thread> th;
       for (u32 k = 0; k < P; ++k)
-        th.emplace_back([&, k]() { rcs[k] = flatten_slice(t, bytes, offsets + base[k], base[k + 1] - base[k], dver, dscope, parts[k], errs[k]); });
+        th.emplace_back([&, k]() { rcs[k] = flatten_slice(t, src, base[k], base[k + 1] - base[k], dver, dscope, parts[k], errs[k]); });
       for (auto& x : th) x.join();
     }
     int bad = -1;
@@ -853,12 +873,75 @@ int cbi_flatten_pb_mt(const cbi_table* t, const uint8_t* bytes, const uint64_t* 
   return 0;
 }
 
+// The resource entries (field 4) of a CheckResourcesRequest, its principal (3), request id (1), include_meta (2).
+struct RequestParts { std::vector<Span> entries; Span principal{nullptr, nullptr}; std::string_view request_id; bool include_meta = false; };
+static bool split_request(const uint8_t* request, uint64_t len, RequestParts& rp) {
+  Span s{request, request + len}; Field f; bool bad = false;
+  while (next(s, f, bad)) {
+    if (f.num == 2 && f.wt == 0) rp.include_meta = f.v != 0;
+    if (f.wt != 2) continue;
+    if (f.num == 1) rp.request_id = sv(f.s); else if (f.num == 3) rp.principal = f.s; else if (f.num == 4) rp.entries.push_back(f.s);
+  }
+  return !bad;
+}
+
+extern "C" {
+
+int cbi_flatten_pb_mt(const cbi_table* t, const uint8_t* bytes, const uint64_t* offsets, uint32_t n, const char* default_version,
+                      const char* default_scope, int sort, int n_threads, cbi_batch** out) {
+  if (!t || !out || (n && (!bytes || !offsets))) return fail("cbi_flatten_pb: null argument");
+  Source src; src.bytes = bytes; src.offsets = offsets;
+  return flatten_source(t, src, n, default_version, default_scope, sort, n_threads, out);
+}
+
+int cbi_flatten_request_pb(const cbi_table* t, const uint8_t* request, uint64_t request_len, const uint8_t* aux_data, uint64_t aux_len,
+                           const char* default_version, const char* default_scope, int sort, int n_threads, cbi_batch** out) {
+  if (!t || !out || !request) return fail("cbi_flatten_request_pb: null argument");
+  RequestParts rp;
+  if (!split_request(request, request_len, rp)) return fail("malformed CheckResourcesRequest");
+  if (rp.entries.size() > 0xFFFFFFFFull) return fail("batch too large");
+  Source src; src.request = true; src.principal = rp.principal; src.entries = rp.entries.data();
+  if (aux_data) src.aux = Span{aux_data, aux_data + aux_len};
+  return flatten_source(t, src, (u32)rp.entries.size(), default_version, default_scope, sort, n_threads, out);
+}
+
 int cbi_flatten_pb(const cbi_table* t, const uint8_t* bytes, const uint64_t* offsets, uint32_t n, const char* default_version,
                    const char* default_scope, int sort, cbi_batch** out) {
   return cbi_flatten_pb_mt(t, bytes, offsets, n, default_version, default_scope, sort, 1, out);
 }
 
 // ---- response assembly ---------------------------------------------------------------------------------
+}  // extern "C"
+
+// Policy key of a device policy word (enum cbh_policy_kind), as namer.PolicyKeyFromFQN gives it (namer.go:95-134).
+// Returns an error text, or nullptr.
+static const char* policy_key(const cbi_table* t, u32 word, const Party& P, const Party& Rs, std::string_view dver,
+                              std::string& pol, std::string& kbuf, std::string& vbuf) {
+  const u32 kind = word >> 28, ident = word & 0x0FFFFFFFu;
+  pol.clear();
+  switch (kind) {
+    case CBH_P_EMPTY: return nullptr;
+    case CBH_P_NO_MATCH: pol = "NO_MATCH"; return nullptr;
+    case CBH_P_NO_MATCH_SCOPE_PERMISSIONS: pol = "NO_MATCH_FOR_SCOPE_PERMISSIONS"; return nullptr;
+    case CBH_P_TABLE:
+      if (ident >= t->policy_keys.size()) return "policy id out of range";
+      pol = t->policy_keys[ident];
+      return nullptr;
+    case CBH_P_RESOURCE: case CBH_P_PRINCIPAL: {
+      if (ident >= t->scopes.size()) return "scope index out of range";
+      const bool rp = kind == CBH_P_RESOURCE;
+      std::string_view ver = rp ? Rs.version : P.version;
+      pol = rp ? "resource." : "principal.";
+      pol += sanitize(rp ? Rs.kind : P.id, kbuf); pol += ".v"; pol += sanitize(ver.empty() ? dver : ver, vbuf);
+      if (!t->scopes[ident].empty()) { pol += '/'; pol += t->scopes[ident]; }
+      return nullptr;
+    }
+    default: return "unknown policy word";
+  }
+}
+
+extern "C" {
+
 static void put_varint(std::vector<u8>& o, u64 v) { while (v >= 0x80) { o.push_back((u8)(v | 0x80)); v >>= 7; } o.push_back((u8)v); }
 static size_t varint_size(u64 v) { size_t n = 1; while (v >= 0x80) { v >>= 7; ++n; } return n; }
 static void put_ld(std::vector<u8>& o, u32 field, std::string_view s) {
@@ -924,24 +1007,7 @@ int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result*
       for (const Act& a : acts) {
         if (res->policy && res->policy[a.j] != pol_word) {
           pol_word = res->policy[a.j];
-          const u32 kind = pol_word >> 28, ident = pol_word & 0x0FFFFFFFu;
-          pol.clear();
-          switch (kind) {   // enum cbh_policy_kind; keys as namer.PolicyKeyFromFQN gives them (namer.go:95-134)
-            case CBH_P_EMPTY: break;
-            case CBH_P_NO_MATCH: pol = "NO_MATCH"; break;
-            case CBH_P_NO_MATCH_SCOPE_PERMISSIONS: pol = "NO_MATCH_FOR_SCOPE_PERMISSIONS"; break;
-            case CBH_P_TABLE: if (ident >= t->policy_keys.size()) return bail("policy id out of range"); pol = t->policy_keys[ident]; break;
-            case CBH_P_RESOURCE: case CBH_P_PRINCIPAL: {
-              if (ident >= t->scopes.size()) return bail("scope index out of range");
-              const bool rp = kind == CBH_P_RESOURCE;
-              std::string_view ver = rp ? Rs.version : P.version;
-              pol = rp ? "resource." : "principal.";
-              pol += sanitize(rp ? Rs.kind : P.id, kbuf); pol += ".v"; pol += sanitize(ver.empty() ? dver : ver, vbuf);
-              if (!t->scopes[ident].empty()) { pol += '/'; pol += t->scopes[ident]; }
-              break;
-            }
-            default: return bail("unknown policy word");
-          }
+          if (const char* e = policy_key(t, pol_word, P, Rs, dver, pol, kbuf, vbuf)) return bail(e);
         }
         std::string_view scope_s;
         if (res->scope && res->scope[a.j] != 0xFFFFFFFFu) {
@@ -1008,6 +1074,98 @@ int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result*
 int cbi_assemble_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* bytes, const uint64_t* offsets,
                     uint32_t n, const char* default_version, cbi_outputs** out) {
   return cbi_assemble_pb_mt(t, b, res, bytes, offsets, n, default_version, 1, out);
+}
+
+int cbi_assemble_response_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* request, uint64_t request_len,
+                             const char* default_version, cbi_outputs** out) {
+  if (!t || !b || !res || !res->effect || !out || !request) return fail("cbi_assemble_response_pb: null argument");
+  const std::string_view dver = default_version ? default_version : "default";
+  RequestParts rp;
+  if (!split_request(request, request_len, rp)) return fail("malformed CheckResourcesRequest");
+  const u32 n = (u32)rp.entries.size(), T = b->view.n_tuples, R = b->view.n_requests;
+  std::vector<u32> inv(T);
+  for (u32 j = 0; j < T; ++j) { if (b->tuple_perm[j] >= T) return fail("corrupt tuple permutation"); inv[b->tuple_perm[j]] = j; }
+  std::vector<u64> edr(n, 0);
+  for (u32 q = 0; q < R; ++q) {
+    if (b->req_input[q] >= n) return fail("batch does not belong to this request");
+    if (res->edr_mask) edr[b->req_input[q]] |= res->edr_mask[q];
+  }
+  auto o = new cbi_outputs();
+  auto bail = [&](const std::string& m) { delete o; return fail(m); };
+  o->flags.assign(n, 0);
+  std::vector<u8>& ob = o->bytes;
+  ob.reserve((size_t)n * 96 + 64);
+  // CheckResourcesResponse (response.proto:187-300): request_id = 1, results = 2 {resource = 1 {id, kind, policy_version,
+  // scope}, actions = 2 map<string, Effect>, meta = 4 {actions = 1 map<string, {matched_policy = 1, matched_scope = 2}>,
+  // effective_derived_roles = 2}} - what CheckResources assembles from the outputs (cerbos_svc.go:297-343)
+  put_str(ob, 1, rp.request_id);
+  Party P;
+  { Span s = rp.principal; Field f; bool bad = false;
+    while (next(s, f, bad)) { if (f.wt != 2) continue; if (f.num == 1) P.id = sv(f.s); else if (f.num == 2) P.version = sv(f.s); }
+    if (bad) return bail("malformed principal"); }
+  struct Act { std::string_view name; u32 j; };
+  std::vector<Act> acts;
+  std::vector<u8> entry_buf, meta_buf, tmp;
+  std::string pol, kbuf, vbuf;
+  u64 k = 0;
+  auto ld_size = [](size_t len) { return 1 + varint_size(len) + len; };
+  for (u32 i = 0; i < n; ++i) {
+    Span e = rp.entries[i]; Field f; bool bad = false;
+    Span resource{nullptr, nullptr};
+    acts.clear();
+    while (next(e, f, bad)) { if (f.wt != 2) continue;
+      if (f.num == 2) resource = f.s;
+      else if (f.num == 1) {
+        if (k >= T) return bail("batch does not belong to this request");
+        std::string_view name = sv(f.s); const u32 j = inv[k++]; bool dup = false;
+        for (Act& a : acts) if (a.name == name) { if (res->effect[j] == CBH_EFFECT_DENY || res->effect[a.j] != CBH_EFFECT_DENY) a.j = j; dup = true; break; }
+        if (!dup) acts.push_back(Act{name, j});
+        if (res->status) { const u8 st = res->status[j]; if (st == CBH_ST_UNSUPPORTED) o->flags[i] |= CBI_OUT_UNSUPPORTED; else if (st == CBH_ST_CEL_ERROR) o->flags[i] |= CBI_OUT_CEL_ERROR; }
+      } }
+    Party Rs;
+    { Span s = resource; while (next(s, f, bad)) { if (f.wt != 2) continue;
+        if (f.num == 1) Rs.kind = sv(f.s); else if (f.num == 2) Rs.version = sv(f.s); else if (f.num == 3) Rs.id = sv(f.s); else if (f.num == 5) Rs.scope = sv(f.s); } }
+    if (bad) return bail("malformed resource entry " + std::to_string(i));
+    entry_buf.clear(); meta_buf.clear();
+    tmp.clear();
+    put_str(tmp, 1, Rs.id); put_str(tmp, 2, Rs.kind); put_str(tmp, 3, Rs.version); put_str(tmp, 4, Rs.scope);
+    put_ld(entry_buf, 1, std::string_view((const char*)tmp.data(), tmp.size()));
+    u32 pol_word = 0xFFFFFFFFu;
+    for (const Act& a : acts) {
+      const u8 effect = res->effect[a.j];
+      // actions map entry {1: name, 2: effect (enum varint, left out when 0)}
+      put_varint(entry_buf, 2u << 3 | 2); put_varint(entry_buf, ld_size(a.name.size()) + (effect ? 1 + varint_size(effect) : 0));
+      put_ld(entry_buf, 1, a.name);
+      if (effect) { entry_buf.push_back(2 << 3 | 0); put_varint(entry_buf, effect); }
+      if (rp.include_meta) {
+        if (res->policy && res->policy[a.j] != pol_word) {
+          pol_word = res->policy[a.j];
+          if (const char* err = policy_key(t, pol_word, P, Rs, dver, pol, kbuf, vbuf)) return bail(err);
+        }
+        std::string_view scope_s;
+        if (res->scope && res->scope[a.j] != 0xFFFFFFFFu) {
+          if (res->scope[a.j] >= t->scopes.size()) return bail("scope index out of range");
+          scope_s = t->scopes[res->scope[a.j]];
+        }
+        const std::string_view pol_s = res->policy ? std::string_view(pol) : std::string_view();
+        const size_t em_len = (pol_s.empty() ? 0 : ld_size(pol_s.size())) + (scope_s.empty() ? 0 : ld_size(scope_s.size()));
+        put_varint(meta_buf, 1u << 3 | 2); put_varint(meta_buf, ld_size(a.name.size()) + ld_size(em_len));
+        put_ld(meta_buf, 1, a.name);
+        put_varint(meta_buf, 2u << 3 | 2); put_varint(meta_buf, em_len);
+        put_str(meta_buf, 1, pol_s); put_str(meta_buf, 2, scope_s);
+      }
+    }
+    if (rp.include_meta) {
+      for (u32 d = 0; d < 64 && d < t->dr_names.size(); ++d) if ((edr[i] >> d) & 1) put_ld(meta_buf, 2, t->dr_names[d]);
+      put_ld(entry_buf, 4, std::string_view((const char*)meta_buf.data(), meta_buf.size()));   // present (possibly empty) when asked for
+    }
+    put_ld(ob, 2, std::string_view((const char*)entry_buf.data(), entry_buf.size()));
+  }
+  if (k != T) return bail("batch does not belong to this request");
+  o->offsets.assign({0, (u64)ob.size()});
+  ob.reserve(1);
+  *out = o;
+  return 0;
 }
 
 void cbi_outputs_free(cbi_outputs* o) { delete o; }

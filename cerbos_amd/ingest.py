@@ -35,6 +35,8 @@ def load():
         lib.cbi_table_close.restype = None
         lib.cbi_flatten_pb.argtypes = [vp, vp, vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
         lib.cbi_flatten_pb_mt.argtypes = [vp, vp, vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
+        lib.cbi_flatten_request_pb.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
+        lib.cbi_assemble_response_pb.argtypes = [vp, vp, C.POINTER(capi.CResult), vp, C.c_uint64, C.c_char_p, C.POINTER(vp)]
         lib.cbi_batch_free.argtypes = [vp]
         lib.cbi_batch_free.restype = None
         lib.cbi_batch_view.argtypes = [vp]
@@ -112,6 +114,33 @@ class IngestTable:
         _check(load().cbi_flatten_pb_mt(self.h, data.ctypes.data if data.size else None, offsets.ctypes.data, n,
                                         default_policy_version.encode(), default_scope.encode(), int(bool(sort)), int(threads),
                                         C.byref(h)))
+        return self._batch(h)
+
+    def flatten_request_pb(self, request: bytes, aux_data: bytes = None, default_policy_version="default", default_scope="",
+                           sort=True, threads=1) -> Batch:
+        """One serialized ``CheckResourcesRequest`` (+ the serialized engine ``AuxData`` the server derived from its
+        JWT, if any): one device request per resource entry."""
+        h = C.c_void_p()
+        _check(load().cbi_flatten_request_pb(self.h, request, len(request), aux_data, len(aux_data) if aux_data else 0,
+                                             default_policy_version.encode(), default_scope.encode(), int(bool(sort)),
+                                             int(threads), C.byref(h)))
+        return self._batch(h)
+
+    def assemble_response_pb(self, batch, res, request: bytes, default_policy_version="default"):
+        """-> (serialized ``CheckResourcesResponse``, flags uint8[n resource entries])."""
+        h = C.c_void_p()
+        _check(load().cbi_assemble_response_pb(self.h, batch.native.h, C.byref(res.c), request, len(request),
+                                               default_policy_version.encode(), C.byref(h)))
+        try:
+            off = _copy(load().cbi_outputs_offsets(h), C.c_uint64, np.int64, 2)
+            raw = _copy(load().cbi_outputs_bytes(h), C.c_uint8, np.uint8, int(off[-1])).tobytes()
+            n_entries = int(np.unique(batch.vreq_input).size) if batch.vreq_input.size else 0
+            flags = _copy(load().cbi_outputs_flags(h), C.c_uint8, np.uint8, n_entries)
+            return raw, flags
+        finally:
+            load().cbi_outputs_free(h)
+
+    def _batch(self, h) -> Batch:
         try:
             v = load().cbi_batch_view(h).contents
             b = Batch()

@@ -55,21 +55,45 @@ def encode_map(field: int, m: dict) -> bytes:
     return b"".join(_ld(field, _ld(1, str(k).encode("utf-8")) + _ld(2, encode_value(x))) for k, x in m.items())
 
 
+def encode_resource(r: dict) -> bytes:
+    return (_string(1, r.get("kind", "") or "") + _string(2, r.get("policyVersion", "") or "")
+            + _string(3, r.get("id", "") or "") + encode_map(4, r.get("attr") or {}) + _string(5, r.get("scope", "") or ""))
+
+
+def encode_principal(p: dict) -> bytes:
+    return (_string(1, p.get("id", "") or "") + _string(2, p.get("policyVersion", "") or "")
+            + b"".join(_ld(3, str(x).encode("utf-8")) for x in (p.get("roles") or []))
+            + encode_map(4, p.get("attr") or {}) + _string(5, p.get("scope", "") or ""))
+
+
+def encode_aux_data(aux: dict) -> bytes:
+    """cerbos.engine.v1.AuxData: 1 jwt map<string, Value>, 2 jwts map<string, JWT{1 claims}>."""
+    body = encode_map(1, aux.get("jwt") or {})
+    for name, jwt in (aux.get("jwts") or {}).items():
+        body += _ld(2, _ld(1, str(name).encode("utf-8")) + _ld(2, encode_map(1, (jwt or {}).get("claims") or {})))
+    return body
+
+
 def encode_check_input(inp: dict) -> bytes:
-    p, r = inp.get("principal") or {}, inp.get("resource") or {}
     aux = inp.get("auxData") or {}
     out = _string(1, inp.get("requestId", "") or "")
-    out += _ld(2, _string(1, r.get("kind", "") or "") + _string(2, r.get("policyVersion", "") or "")
-               + _string(3, r.get("id", "") or "") + encode_map(4, r.get("attr") or {}) + _string(5, r.get("scope", "") or ""))
-    out += _ld(3, _string(1, p.get("id", "") or "") + _string(2, p.get("policyVersion", "") or "")
-               + b"".join(_ld(3, str(x).encode("utf-8")) for x in (p.get("roles") or []))
-               + encode_map(4, p.get("attr") or {}) + _string(5, p.get("scope", "") or ""))
+    out += _ld(2, encode_resource(inp.get("resource") or {}))
+    out += _ld(3, encode_principal(inp.get("principal") or {}))
     out += b"".join(_ld(4, str(a).encode("utf-8")) for a in (inp.get("actions") or []))
-    if aux.get("jwt") or aux.get("jwts"):     # AuxData: 1 jwt map<string, Value>, 2 jwts map<string, JWT{1 claims}>
-        body = encode_map(1, aux.get("jwt") or {})
-        for name, jwt in (aux.get("jwts") or {}).items():
-            body += _ld(2, _ld(1, str(name).encode("utf-8")) + _ld(2, encode_map(1, (jwt or {}).get("claims") or {})))
-        out += _ld(5, body)
+    if aux.get("jwt") or aux.get("jwts"):
+        out += _ld(5, encode_aux_data(aux))
+    return out
+
+
+def encode_check_resources_request(req: dict) -> bytes:
+    """cerbos.request.v1.CheckResourcesRequest (request.proto:222-273): 1 request_id, 2 include_meta, 3 principal,
+    4 resources {1 actions, 2 resource}.  (5 aux_data carries a JWT *token*; the claims travel as engine AuxData.)"""
+    out = _string(1, req.get("requestId", "") or "")
+    if req.get("includeMeta"):
+        out += _varint(2 << 3 | 0) + b"\1"
+    out += _ld(3, encode_principal(req.get("principal") or {}))
+    for e in req.get("resources") or []:
+        out += _ld(4, b"".join(_ld(1, str(a).encode("utf-8")) for a in (e.get("actions") or [])) + _ld(2, encode_resource(e.get("resource") or {})))
     return out
 
 
@@ -139,4 +163,43 @@ def decode_check_output(buf: bytes) -> dict:
             out["actions"][key] = eff
         elif num == 4:
             out["effectiveDerivedRoles"].append(v.decode("utf-8"))
+    return out
+
+
+def decode_check_resources_response(buf: bytes) -> dict:
+    """cerbos.response.v1.CheckResourcesResponse (response.proto:187-300)."""
+    out = {"requestId": "", "results": []}
+    for num, v in _fields(buf):
+        if num == 1:
+            out["requestId"] = v.decode("utf-8")
+        elif num == 2:
+            entry = {"resource": {"id": "", "kind": "", "policyVersion": "", "scope": ""}, "actions": {}, "meta": None}
+            for n2, v2 in _fields(v):
+                if n2 == 1:
+                    for n3, v3 in _fields(v2):
+                        entry["resource"][{1: "id", 2: "kind", 3: "policyVersion", 4: "scope"}[n3]] = v3.decode("utf-8")
+                elif n2 == 2:
+                    key, eff = "", _EFFECTS[0]
+                    for n3, v3 in _fields(v2):
+                        if n3 == 1:
+                            key = v3.decode("utf-8")
+                        elif n3 == 2:
+                            eff = _EFFECTS[v3]
+                    entry["actions"][key] = eff
+                elif n2 == 4:
+                    meta = {"actions": {}, "effectiveDerivedRoles": []}
+                    for n3, v3 in _fields(v2):
+                        if n3 == 1:
+                            key, em = "", {"matchedPolicy": "", "matchedScope": ""}
+                            for n4, v4 in _fields(v3):
+                                if n4 == 1:
+                                    key = v4.decode("utf-8")
+                                elif n4 == 2:
+                                    for n5, v5 in _fields(v4):
+                                        em[{1: "matchedPolicy", 2: "matchedScope"}[n5]] = v5.decode("utf-8")
+                            meta["actions"][key] = em
+                        elif n3 == 2:
+                            meta["effectiveDerivedRoles"].append(v3.decode("utf-8"))
+                    entry["meta"] = meta
+            out["results"].append(entry)
     return out

@@ -53,6 +53,16 @@ int cbi_flatten_pb(const cbi_table* t, const uint8_t* bytes, const uint64_t* off
  * that the batch equals the single-pass one).  n_threads <= 1, or fewer than ~1k messages per thread: single pass. */
 int cbi_flatten_pb_mt(const cbi_table* t, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
                       const char* default_version, const char* default_scope, int sort, int n_threads, cbi_batch** out);
+/*
+ * The same for ONE serialized cerbos.request.v1.CheckResourcesRequest (request.proto:222-273): every resource entry
+ * becomes the CheckInput that svc.CheckResources builds from it (cerbos_svc.go:274-287: the request's principal and
+ * request id, the entry's resource and actions) without those messages ever being built.  `aux_data` / `aux_len`:
+ * the serialized cerbos.engine.v1.AuxData the server derived from the request's JWT (verification is the caller's
+ * business), or NULL.  Input index (cbi_batch_request_input) = index of the resource entry.
+ */
+int cbi_flatten_request_pb(const cbi_table* t, const uint8_t* request, uint64_t request_len, const uint8_t* aux_data,
+                           uint64_t aux_len, const char* default_version, const char* default_scope, int sort,
+                           int n_threads, cbi_batch** out);
 void cbi_batch_free(cbi_batch* b);
 
 /* The flattened batch; valid until cbi_batch_free. */
@@ -82,6 +92,12 @@ int cbi_assemble_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* re
 /* Same bytes, assembled on up to n_threads threads inside the call (contiguous ranges of inputs). */
 int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* bytes,
                        const uint64_t* offsets, uint32_t n, const char* default_version, int n_threads, cbi_outputs** out);
+/* One serialized cerbos.response.v1.CheckResourcesResponse (response.proto:187-300) for the request that
+ * cbi_flatten_request_pb flattened: request_id, and per resource entry the resource, actions -> effect and - when
+ * the request has include_meta - meta {actions -> matched policy / scope, effective_derived_roles}
+ * (cerbos_svc.go:297-343).  cbi_outputs_offsets = {0, length}; cbi_outputs_flags: one byte per resource entry. */
+int cbi_assemble_response_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* request,
+                             uint64_t request_len, const char* default_version, cbi_outputs** out);
 void cbi_outputs_free(cbi_outputs* o);
 /* Output i = bytes[offsets[i] .. offsets[i+1]); n + 1 offsets. */
 const uint8_t* cbi_outputs_bytes(const cbi_outputs* o);

@@ -255,3 +255,95 @@ def test_mutated_messages_never_crash():
         except IngestError:
             bad += 1
     assert ok > 100 and bad > 100, (ok, bad)
+
+
+# ---- one serialized CheckResourcesRequest in, one serialized CheckResourcesResponse out --------------------------
+def _request_of(inputs, include_meta=True):
+    return {"requestId": inputs[0].get("requestId", ""), "includeMeta": include_meta, "principal": inputs[0]["principal"],
+            "resources": [{"actions": i["actions"], "resource": i["resource"]} for i in inputs]}
+
+
+def _same_as_check_inputs(lt, inputs, aux=None, threads=1):
+    """cbi_flatten_request_pb must give the very batch that the equivalent CheckInputs give."""
+    it = IngestTable(lt.blob)
+    ins = [dict(i, principal=inputs[0]["principal"], requestId=inputs[0].get("requestId", ""), **({"auxData": aux} if aux else {}))
+           for i in inputs]
+    for i in ins:
+        if not aux:
+            i.pop("auxData", None)
+    want = it.flatten_pb(*wire.pack_messages([wire.encode_check_input(i) for i in ins]))
+    have = it.flatten_request_pb(wire.encode_check_resources_request(_request_of(ins)), wire.encode_aux_data(aux) if aux else None,
+                                 threads=threads)
+    for name in ARRAYS + ("tuple_perm", "vreq_input"):
+        assert np.array_equal(getattr(have, name), getattr(want, name)), name
+    return it, ins, have
+
+
+def test_request_form_flattens_like_its_check_inputs():
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    for case in load_json("server_check_cases.json"):
+        _same_as_check_inputs(lt, case["inputs"])
+    jwt_inputs = [v["input"] for v in load_json("verify_vectors.json") if "auxData" in v["input"]]
+    _same_as_check_inputs(lt, jwt_inputs[:1], aux=jwt_inputs[0]["auxData"])
+    rng = np.random.default_rng(3)
+    rt = rule_table_from_policies(policies_from_docs(_policies(rng)))
+    lt2 = lower_rule_table(rt)
+    _same_as_check_inputs(lt2, _requests(rng, 4300), threads=4)      # many resource entries: the in-call parallel path
+
+
+@pytest.mark.parametrize("case", load_json("server_check_cases.json"), ids=lambda c: c["name"])
+def test_service_level_cases_request_in_response_out(case):
+    """The reference's CheckResources cases as the service sees them: CheckResourcesRequest bytes in,
+    CheckResourcesResponse bytes out (libcerbos_ingest.so around the kernel source)."""
+    import hostsim_api
+    from cerbos_amd import capi
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    it = IngestTable(lt.blob)
+    for include_meta in (True, False):
+        req = wire.encode_check_resources_request(_request_of(case["inputs"], include_meta))
+        batch = it.flatten_request_pb(req)
+        res = hostsim_api.check(lt, batch, 1_700_000_000_000_000_000, capi.F_WANT_DERIVED_ROLES, device_order=True)
+        raw, flags = it.assemble_response_pb(batch, res, req)
+        resp = wire.decode_check_resources_response(raw)
+        assert resp["requestId"] == case["inputs"][0].get("requestId", "") and len(resp["results"]) == len(case["inputs"])
+        for inp, have, want, f in zip(case["inputs"], resp["results"], case["want"], flags):
+            assert not f & 1
+            r = inp["resource"]
+            assert have["resource"] == {"id": r.get("id", ""), "kind": r.get("kind", ""), "policyVersion": r.get("policyVersion", ""),
+                                        "scope": r.get("scope", "")}
+            assert have["actions"] == want["actions"], case["name"]
+            if not include_meta:
+                assert have["meta"] is None
+                continue
+            for a, m in want["meta"].items():
+                assert have["meta"]["actions"][a] == m, (case["name"], a)
+            if want["hasMeta"]:
+                assert sorted(have["meta"]["effectiveDerivedRoles"]) == sorted(want["effectiveDerivedRoles"] or [])
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_response_assembly_matches_python_on_fuzzed_requests(seed):
+    import copy
+
+    import hostsim_api
+    from cerbos_amd import capi
+    rng = np.random.default_rng(20_000 + seed)
+    rt = rule_table_from_policies(policies_from_docs(_policies(rng)))
+    try:
+        lt = lower_rule_table(rt)
+    except LoweringError:
+        pytest.skip("store refused by the lowering")
+    inputs = _requests(rng, 300)
+    inputs[5]["actions"] = ["view", "edit", "view", "edit", "view"]
+    it, ins, batch = _same_as_check_inputs(lt, inputs)
+    batch.actions_per_request = [list(i["actions"]) for i in ins]
+    req = wire.encode_check_resources_request(_request_of(ins))
+    res = hostsim_api.check(lt, batch, 1_700_000_000_000_000_000, capi.F_WANT_DERIVED_ROLES, device_order=True)
+    raw, flags = it.assemble_response_pb(batch, res, req)
+    resp = wire.decode_check_resources_response(raw)
+    want, bad = HostSimEvaluator(lt, Conf()).assemble(ins, batch, copy.copy(res).to_input_order(batch), "default", allow_unsupported=True)
+    assert sorted(bad) == [i for i, f in enumerate(flags) if f & 1]
+    for have, w in zip(resp["results"], want):
+        assert have["actions"] == {a: e["effect"] for a, e in w["actions"].items()}
+        assert have["meta"]["actions"] == {a: {"matchedPolicy": e["policy"], "matchedScope": e["scope"]} for a, e in w["actions"].items()}
+        assert have["meta"]["effectiveDerivedRoles"] == w["effectiveDerivedRoles"]
