@@ -135,3 +135,77 @@ func (g *gpuEngine) checkBatchGPU(_ context.Context, inputs []*enginev1.CheckInp
 	}
 	return outs, fallback, nil
 }
+
+// checkResourcesGPU serves one CheckResourcesRequest without building CheckInputs (svc/cerbos_svc.go:255-344 would
+// call this instead of cs.eng.Check when the engine is a GPU engine): the request's own bytes go in, the serialized
+// CheckResourcesResponse comes back.  auxData is what cs.auxData.Extract returned for the request's JWT (may be nil).
+// fallback[i] is true where resource entry i must be evaluated on the CPU path and patched into the response.
+func (g *gpuEngine) checkResourcesGPU(reqBytes []byte, auxData *enginev1.AuxData, p evaluator.EvalParams) (respBytes []byte, fallback []bool, err error) {
+	var auxBytes []byte
+	if auxData != nil {
+		if auxBytes, err = proto.Marshal(auxData); err != nil {
+			return nil, nil, err
+		}
+	}
+	var pin runtime.Pinner
+	pin.Pin(&reqBytes[0])
+	defer pin.Unpin()
+	reqPtr := (*C.uint8_t)(unsafe.Pointer(&reqBytes[0]))
+	var auxPtr *C.uint8_t
+	if len(auxBytes) > 0 {
+		pin.Pin(&auxBytes[0])
+		auxPtr = (*C.uint8_t)(unsafe.Pointer(&auxBytes[0]))
+	}
+	dv, ds := C.CString(p.DefaultPolicyVersion), C.CString(p.DefaultScope)
+	defer C.free(unsafe.Pointer(dv))
+	defer C.free(unsafe.Pointer(ds))
+
+	var batch *C.cbi_batch
+	if C.cbi_flatten_request_pb(g.ingest, reqPtr, C.uint64_t(len(reqBytes)), auxPtr, C.uint64_t(len(auxBytes)), dv, ds, 1, 1, &batch) != 0 {
+		return nil, nil, errors.New(C.GoString(C.cbi_last_error()))
+	}
+	defer C.cbi_batch_free(batch)
+	view := C.cbi_batch_view(batch)
+	nt, nr := C.size_t(view.n_tuples), C.size_t(view.n_requests)
+	res := C.cbh_result{
+		effect: (*C.uint8_t)(C.calloc(nt+1, 1)), policy: (*C.uint32_t)(C.calloc(nt+1, 4)), scope: (*C.uint32_t)(C.calloc(nt+1, 4)),
+		status: (*C.uint8_t)(C.calloc(nt+1, 1)), edr_mask: (*C.uint64_t)(C.calloc(nr+1, 8)),
+	}
+	defer func() {
+		for _, ptr := range []unsafe.Pointer{unsafe.Pointer(res.effect), unsafe.Pointer(res.policy), unsafe.Pointer(res.scope), unsafe.Pointer(res.status), unsafe.Pointer(res.edr_mask)} {
+			C.free(ptr)
+		}
+	}()
+	flags := C.uint32_t(C.CBH_F_WANT_DERIVED_ROLES)
+	if p.LenientScopeSearch {
+		flags |= C.CBH_F_LENIENT_SCOPE_SEARCH
+	}
+	if p.StrictEvaluation {
+		flags |= C.CBH_F_STRICT_EVALUATION
+	}
+	params := C.cbh_params{now_ns: C.int64_t(p.NowFunc().UnixNano()), flags: flags}
+	if C.cbh_check_batch(g.table, view, &params, &res) != 0 {
+		return nil, nil, errors.New(C.GoString(C.cbh_last_error()))
+	}
+	var assembled *C.cbi_outputs
+	if C.cbi_assemble_response_pb(g.ingest, batch, &res, reqPtr, C.uint64_t(len(reqBytes)), dv, &assembled) != 0 {
+		return nil, nil, errors.New(C.GoString(C.cbi_last_error()))
+	}
+	defer C.cbi_outputs_free(assembled)
+	ooffs := unsafe.Slice((*uint64)(unsafe.Pointer(C.cbi_outputs_offsets(assembled))), 2)
+	respBytes = C.GoBytes(unsafe.Pointer(C.cbi_outputs_bytes(assembled)), C.int(ooffs[1]))
+	// one flag byte per resource entry; the entry count is the largest input index of the batch + 1
+	nEntries := 0
+	inputOf := unsafe.Slice((*uint32)(unsafe.Pointer(C.cbi_batch_request_input(batch))), int(view.n_requests))
+	for _, i := range inputOf {
+		if int(i)+1 > nEntries {
+			nEntries = int(i) + 1
+		}
+	}
+	oflags := unsafe.Slice((*byte)(unsafe.Pointer(C.cbi_outputs_flags(assembled))), nEntries)
+	fallback = make([]bool, nEntries)
+	for i, f := range oflags {
+		fallback[i] = f&C.CBI_OUT_UNSUPPORTED != 0
+	}
+	return respBytes, fallback, nil
+}
