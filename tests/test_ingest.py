@@ -347,3 +347,34 @@ def test_response_assembly_matches_python_on_fuzzed_requests(seed):
         assert have["actions"] == {a: e["effect"] for a, e in w["actions"].items()}
         assert have["meta"]["actions"] == {a: {"matchedPolicy": e["policy"], "matchedScope": e["scope"]} for a, e in w["actions"].items()}
         assert have["meta"]["effectiveDerivedRoles"] == w["effectiveDerivedRoles"]
+
+
+def test_mutated_requests_never_crash():
+    """The same for corrupted CheckResourcesRequest bytes (and corrupted AuxData)."""
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    it = IngestTable(lt.blob)
+    cases = load_json("server_check_cases.json")
+    reqs = [wire.encode_check_resources_request(_request_of(c["inputs"])) for c in cases]
+    aux = wire.encode_aux_data({"jwt": {"iss": "x", "aud": ["a", "b"], "n": {"k": [1, 2]}}, "jwts": {"t": {"claims": {"aud": ["a"]}}}})
+    rng = np.random.default_rng(11)
+    ok = bad = 0
+    for trial in range(1200):
+        m = bytearray(reqs[int(rng.integers(0, len(reqs)))])
+        a = bytearray(aux)
+        for buf in (m, a) if trial % 3 == 0 else (m,):
+            for _ in range(int(rng.integers(1, 4))):
+                pos = int(rng.integers(0, len(buf)))
+                kind = int(rng.integers(0, 3))
+                if kind == 0:
+                    buf[pos] ^= 1 << int(rng.integers(0, 8))
+                elif kind == 1:
+                    del buf[pos:pos + int(rng.integers(1, 9))]
+                else:
+                    buf[pos:pos] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 6)), dtype=np.uint8))
+        try:
+            b = it.flatten_request_pb(bytes(m), bytes(a))
+            assert b.tuple_action.size == b.n_tuples
+            ok += 1
+        except IngestError:
+            bad += 1
+    assert ok > 100 and bad > 100, (ok, bad)
