@@ -418,7 +418,6 @@ int cbi_table_open(const void* blob, size_t len, cbi_table** out) {
 
 void cbi_table_close(cbi_table* t) { delete t; }
 
-// (the three helpers below are file-local)
 }  // extern "C"
 
 // Where the inputs come from: serialized CheckInputs (bytes + offsets), or the resource entries of ONE serialized
@@ -831,10 +830,6 @@ static void merge_slices(const cbi_table* t, std::vector<cbi_batch*>& parts, con
   }
 }
 
-extern "C" {
-
-}  // extern "C"
-
 static int flatten_source(const cbi_table* t, const Source& src, uint32_t n, const char* default_version, const char* default_scope,
                           int sort, int n_threads, cbi_batch** out) {
   const std::string_view dver = default_version ? default_version : "default";
@@ -910,9 +905,9 @@ int cbi_flatten_pb(const cbi_table* t, const uint8_t* bytes, const uint64_t* off
   return cbi_flatten_pb_mt(t, bytes, offsets, n, default_version, default_scope, sort, 1, out);
 }
 
-// ---- response assembly ---------------------------------------------------------------------------------
 }  // extern "C"
 
+// ---- response assembly ---------------------------------------------------------------------------------
 // Policy key of a device policy word (enum cbh_policy_kind), as namer.PolicyKeyFromFQN gives it (namer.go:95-134).
 // Returns an error text, or nullptr.
 static const char* policy_key(const cbi_table* t, u32 word, const Party& P, const Party& Rs, std::string_view dver,
@@ -940,14 +935,14 @@ static const char* policy_key(const cbi_table* t, u32 word, const Party& P, cons
   }
 }
 
-extern "C" {
-
 static void put_varint(std::vector<u8>& o, u64 v) { while (v >= 0x80) { o.push_back((u8)(v | 0x80)); v >>= 7; } o.push_back((u8)v); }
 static size_t varint_size(u64 v) { size_t n = 1; while (v >= 0x80) { v >>= 7; ++n; } return n; }
 static void put_ld(std::vector<u8>& o, u32 field, std::string_view s) {
   put_varint(o, (u64)field << 3 | 2); put_varint(o, s.size()); o.insert(o.end(), s.begin(), s.end());
 }
 static void put_str(std::vector<u8>& o, u32 field, std::string_view s) { if (!s.empty()) put_ld(o, field, s); }   // proto3 default: omitted
+
+extern "C" {
 
 int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* bytes, const uint64_t* offsets,
                        uint32_t n, const char* default_version, int n_threads, cbi_outputs** out) {
