@@ -15,3 +15,6 @@ for w in C1 C3 C4 C5; do timeout 120 python bench.py --workload $w --steps 100 -
 timeout 60 python tools/e2e_bench.py C2 131072 8192 2 1,8,32,64 > "$OUT/e2e_outer.log" 2>&1; grep '^{"threads"' "$OUT/e2e_outer.log"
 timeout 60 python tools/e2e_bench.py C2 131072 32768 2 2,4,8 16 > "$OUT/e2e_inner16.log" 2>&1; grep '^{"threads"' "$OUT/e2e_inner16.log"
 timeout 90 python tools/ingest_bench.py C2 200000 > "$OUT/ingest_bench.log" 2>&1; tail -12 "$OUT/ingest_bench.log"
+# the same end-to-end loop without Python in it (no GIL between the C calls)
+python tools/export_wire.py C2 131072 /tmp/c2wire > /dev/null && g++ -O2 -std=c++17 -pthread -Iinclude tools/e2e_bench.cpp -Lcerbos_amd -lcerbos_ingest -lcerbos_hip -Wl,-rpath,$PWD/cerbos_amd -o /tmp/e2e_bench \
+  && timeout 90 /tmp/e2e_bench /tmp/c2wire 8192 2 1,8,32,64,128,224 > "$OUT/e2e_cpp.log" 2>&1; cat "$OUT/e2e_cpp.log"
