@@ -1,0 +1,118 @@
+"""Batching across concurrent ``Check`` calls - the GPU analogue of ``engine.checkParallel``.
+
+The reference fans one call's inputs OUT to a worker pool (``internal/engine/engine.go:309-338``); a device wants
+the opposite: the inputs of many small concurrent calls gathered IN to one batch.
+``BatchingEvaluator.check`` blocks like ``Evaluator.Check`` and is safe to call from any number of threads; a
+dispatcher thread collects what arrives within ``max_wait_s`` of the first waiting call (or until ``max_inputs``),
+evaluates it as ONE device batch and hands every caller its own outputs, in its own input order.
+
+Calls are only batched together when their evaluation parameters are equal.  ``now`` is frozen per device batch
+(the reference freezes it per call, ``evaluator_trace_common.go:24-26``): every call of a batch sees the same
+instant, taken while all of them were waiting.
+"""
+from __future__ import annotations
+
+import threading
+import time
+
+from .engine import DeviceUnsupported
+
+
+class _Call:
+    __slots__ = ("inputs", "key", "done", "outputs", "bad", "error")
+
+    def __init__(self, inputs, key):
+        self.inputs, self.key = inputs, key
+        self.done = threading.Event()
+        self.outputs = self.bad = self.error = None
+
+
+class BatchingEvaluator:
+    def __init__(self, evaluator, max_inputs: int = 4096, max_wait_s: float = 200e-6):
+        self.ev = evaluator
+        self.max_inputs = max_inputs
+        self.max_wait_s = max_wait_s
+        self._cv = threading.Condition()
+        self._queue = []
+        self._closed = False
+        self.batches = 0          # device batches evaluated
+        self.calls = 0            # calls served
+        self._thread = threading.Thread(target=self._run, name="cbh-batcher", daemon=True)
+        self._thread.start()
+
+    # -- Evaluator.Check --------------------------------------------------------------------------
+    def check(self, inputs, now_ns=None, lenient_scope_search=None, strict_evaluation=None,
+              default_policy_version=None, default_scope=None, allow_unsupported=False):
+        inputs = list(inputs)
+        if not inputs:
+            return ([], []) if allow_unsupported else []
+        call = _Call(inputs, (now_ns, lenient_scope_search, strict_evaluation, default_policy_version, default_scope))
+        with self._cv:
+            if self._closed:
+                raise RuntimeError("BatchingEvaluator is closed")
+            self._queue.append(call)
+            self._cv.notify_all()
+        call.done.wait()
+        if call.error is not None:
+            raise call.error
+        if allow_unsupported:
+            return call.outputs, call.bad
+        if call.bad:
+            raise DeviceUnsupported(call.bad, getattr(self.ev.lt, "unsupported", []))
+        return call.outputs
+
+    def close(self):
+        with self._cv:
+            self._closed = True
+            self._cv.notify_all()
+        self._thread.join()
+
+    # -- dispatcher -------------------------------------------------------------------------------
+    def _take(self):
+        """Blocks for the first call, lingers for more, returns the calls of one batch (equal parameters)."""
+        with self._cv:
+            while not self._queue and not self._closed:
+                self._cv.wait()
+            if not self._queue:
+                return None
+            deadline = time.monotonic() + self.max_wait_s
+            while not self._closed and sum(len(c.inputs) for c in self._queue) < self.max_inputs:
+                left = deadline - time.monotonic()
+                if left <= 0:
+                    break
+                self._cv.wait(left)
+            key = self._queue[0].key
+            batch, rest, n = [], [], 0
+            for c in self._queue:
+                if c.key == key and (not batch or n + len(c.inputs) <= self.max_inputs):
+                    batch.append(c)
+                    n += len(c.inputs)
+                else:
+                    rest.append(c)
+            self._queue = rest
+            return batch
+
+    def _run(self):
+        while True:
+            batch = self._take()
+            if batch is None:
+                return
+            now_ns, lenient, strict, dver, dscope = batch[0].key
+            flat = [i for c in batch for i in c.inputs]
+            try:
+                outs, bad = self.ev.check(flat, now_ns=now_ns, lenient_scope_search=lenient, strict_evaluation=strict,
+                                          default_policy_version=dver, default_scope=dscope, allow_unsupported=True)
+                bad = set(bad)
+                at = 0
+                for c in batch:
+                    n = len(c.inputs)
+                    c.outputs = outs[at:at + n]
+                    c.bad = [i - at for i in range(at, at + n) if i in bad]
+                    at += n
+            except Exception as e:  # noqa: BLE001 - every waiting caller gets the failure, none is left hanging
+                for c in batch:
+                    c.error = e
+            self.batches += 1
+            self.calls += len(batch)
+            for c in batch:
+                c.done.set()
