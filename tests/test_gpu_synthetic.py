@@ -90,11 +90,14 @@ def test_concurrent_one_shot_calls():
     from concurrent.futures import ThreadPoolExecutor
     rt, lt, table = _table(workloads.c3_policies)
     fl = Flattener(lt)
-    sizes = [1, 7, 64, 300, 2_000, 150_000, 5, 900]
+    sizes = [1, 7, 64, 300, 2_000, 5, 900, 150_000, 120_000]      # the last two take the array-by-array path
     batches = [workloads.c3_requests(n, seed=100 + i).to_batch(fl) for i, n in enumerate(sizes)]
     flags = capi.F_WANT_DERIVED_ROLES
     alone = [table.check(b, now_ns=NOW, flags=flags) for b in batches]
-    jobs = [i % len(batches) for i in range(64)]
+    # small batches many times over, each large one once (its host arrays are then read by one call at a time)
+    jobs = [i % 7 for i in range(56)]
+    jobs.insert(10, 7)
+    jobs.insert(30, 8)
     with ThreadPoolExecutor(16) as ex:
         got = list(ex.map(lambda i: table.check(batches[i], now_ns=NOW, flags=flags), jobs))
     for i, res in zip(jobs, got):
