@@ -203,3 +203,32 @@ def test_c5_full_batch_properties():
     permute_requests(b2, np.random.default_rng(1).permutation(b2.n_requests))
     assert np.array_equal(table.check(b2, now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES).effect, eff)
     table.close()
+
+
+def test_cross_product_batch_on_gpu():
+    """A cross-product batch (cerbos_amd/cross.py: 400 principals x 300 resources x 4 actions = 480k decisions from
+    700 flattened messages) against oracle/ccheck.cpp on the very same batch, and its cube against explicit
+    CheckInputs for a corner of it."""
+    import os
+    from cerbos_amd.cross import cross_product_batch, result_cubes
+    from oracle import ccheck
+    rt, lt, table = _table(workloads.c3_policies)
+    ins = workloads.c3_requests(700, seed=9).to_inputs()
+    principals, resources = [i["principal"] for i in ins[:400]], [i["resource"] for i in ins[400:]]
+    actions = ins[0]["actions"]
+    cb = cross_product_batch(Flattener(lt), lt.columns, principals, resources, actions)
+    flags = capi.F_WANT_DERIVED_ROLES
+    got = table.check(cb, now_ns=NOW, flags=flags)
+    want = ccheck.check(lt, cb, NOW, flags, threads=min(16, os.cpu_count() or 1))
+    assert (want.status != capi.ST_UNSUPPORTED).all()
+    for f in ("effect", "policy", "scope", "edr"):
+        assert np.array_equal(getattr(got, f), getattr(want, f)), f
+    # evaluation errors are a per-CheckOutput property: compare per request
+    a = len(actions)
+    assert np.array_equal((got.status == capi.ST_CEL_ERROR).reshape(-1, a).any(axis=1), (want.status == capi.ST_CEL_ERROR).reshape(-1, a).any(axis=1))
+    cubes, _ = result_cubes(cb, got)
+    explicit = [{"principal": p, "resource": r, "actions": actions} for p in principals[:20] for r in resources[:15]]
+    eff = table.check(Flattener(lt).flatten(explicit), now_ns=NOW, flags=flags).effect
+    assert np.array_equal(cubes["effect"][:20, :15].reshape(-1), eff)
+    assert 0.02 < (cubes["effect"] == capi.EFFECT_ALLOW).mean() < 0.98
+    table.close()
