@@ -18,3 +18,4 @@ timeout 90 python tools/ingest_bench.py C2 200000 > "$OUT/ingest_bench.log" 2>&1
 # the same end-to-end loop without Python in it (no GIL between the C calls)
 python tools/export_wire.py C2 131072 /tmp/c2wire > /dev/null && g++ -O2 -std=c++17 -pthread -Iinclude tools/e2e_bench.cpp -Lcerbos_amd -lcerbos_ingest -lcerbos_hip -Wl,-rpath,$PWD/cerbos_amd -o /tmp/e2e_bench \
   && timeout 90 /tmp/e2e_bench /tmp/c2wire 8192 2 1,8,32,64,128,224 > "$OUT/e2e_cpp.log" 2>&1; cat "$OUT/e2e_cpp.log"
+timeout 120 python tools/cross_bench.py C2 2000 1000 50 > "$OUT/cross_bench.log" 2>&1; tail -1 "$OUT/cross_bench.log"
