@@ -16,8 +16,10 @@
  * Conventions: plain C types only; every pointer in cbh_batch / cbh_result is HOST memory
  * owned by the caller (never retained after the call returns - cgo-safe).  Return value
  * 0 = OK, < 0 = hard error (text via cbh_last_error(), thread-local).  No function
- * aborts or throws across the boundary.  All entry points are thread-safe; calls on one
- * table from many threads are serialised per device stream.
+ * aborts or throws across the boundary.  All entry points are thread-safe: one-shot calls
+ * (cbh_check_batch) from different threads run on separate launch contexts and overlap on the
+ * device (up to 8 per table, further callers wait); the resident calls of one table share one
+ * stream and queue in call order.
  */
 #ifndef CERBOS_HIP_H
 #define CERBOS_HIP_H
@@ -172,7 +174,8 @@ void* cbh_table_device_ptr(const cbh_table* t);
 /* Adopt an image that already sits in device memory (received by broadcast). */
 int cbh_table_adopt_device_image(void* device_image, size_t len, cbh_table** out);
 
-/* One-shot: upload `in`, evaluate, download into `out` (all host pointers). */
+/* One-shot: upload `in`, evaluate, download into `out` (all host pointers).  A batch under 4 MB is packed into a
+ * pinned staging block and crosses PCIe in one copy each way. */
 int cbh_check_batch(cbh_table* t, const cbh_batch* in, const cbh_params* p, cbh_result* out);
 
 /* Resident path (what bench.py times): inputs already in HBM when the clock starts. */
