@@ -359,7 +359,8 @@ int cbi_table_open(const void* blob, size_t len, cbi_table** out) {
   auto* secs = (const CbhBlobSection*)(base + sizeof(CbhBlobHeader));
   auto find = [&](u32 id) -> const CbhBlobSection* {
     for (u32 i = 0; i < h->n_sections; ++i)
-      if (secs[i].id == id) return (secs[i].offset + secs[i].nbytes <= len) ? &secs[i] : nullptr;
+      if (secs[i].id == id)   // sections are 64-byte aligned and lie inside the image (no wrap-around)
+        return (secs[i].offset % 8 == 0 && secs[i].offset <= len && secs[i].nbytes <= len - secs[i].offset) ? &secs[i] : nullptr;
     return nullptr;
   };
   const CbhBlobSection *so = find(CBH_SEC_STR_OFF), *sb = find(CBH_SEC_STR_BYTES), *ss = find(CBH_SEC_SCOPE_SID), *sc = find(CBH_SEC_COLUMN_PATHS),

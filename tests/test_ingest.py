@@ -378,3 +378,30 @@ def test_mutated_requests_never_crash():
         except IngestError:
             bad += 1
     assert ok > 100 and bad > 100, (ok, bad)
+
+
+def test_corrupted_table_images_are_refused_or_harmless():
+    """Bit flips in the image's header / section table / anywhere: cbi_table_open refuses it or opens something
+    that still flattens without touching memory outside the image (run under ASan/UBSan when changing the parser)."""
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    inputs = [i for c in load_json("engine_cases.json")[:5] for i in c["inputs"]]
+    data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+    rng = np.random.default_rng(1)
+    opened = refused = 0
+    for trial in range(800):
+        b = bytearray(lt.blob)
+        region = 32 + 32 * 27 if trial % 2 else len(b)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(0, region))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            it = IngestTable(bytes(b))
+        except IngestError:
+            refused += 1
+            continue
+        opened += 1
+        try:
+            it.flatten_pb(data, off)
+        except IngestError:
+            pass
+        it.close()
+    assert opened > 100 and refused > 50, (opened, refused)
