@@ -121,6 +121,26 @@ class HipEvaluator:
         res = self.table.check(batch, now_ns=now_ns, flags=flags, device_order=True)
         return self._ingest.assemble_pb(batch, res, data, offsets, dver)
 
+    def check_request_pb(self, request: bytes, aux_data: bytes = None, now_ns=None, lenient_scope_search=None,
+                         strict_evaluation=None, default_policy_version=None, default_scope=None):
+        """``svc.CheckResources`` on bytes (cerbos_svc.go:255-344): one serialized ``CheckResourcesRequest`` (and the
+        serialized engine ``AuxData`` derived from its JWT) -> (serialized ``CheckResourcesResponse``, flags per
+        resource entry: bit 0 = the caller's own engine must evaluate that entry)."""
+        from .ingest import IngestTable
+        conf = self.conf
+        lenient = conf.lenient_scope_search if lenient_scope_search is None else lenient_scope_search
+        strict = conf.strict_evaluation if strict_evaluation is None else strict_evaluation
+        dver = conf.default_policy_version if default_policy_version is None else default_policy_version
+        dscope = conf.default_scope if default_scope is None else default_scope
+        if now_ns is None:
+            now_ns = time.time_ns()
+        if getattr(self, "_ingest", None) is None:
+            self._ingest = IngestTable(self.lt.blob)
+        batch = self._ingest.flatten_request_pb(request, aux_data, dver, dscope)
+        flags = capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0) | (capi.F_STRICT_EVALUATION if strict else 0)
+        res = self.table.check(batch, now_ns=now_ns, flags=flags, device_order=True)
+        return self._ingest.assemble_response_pb(batch, res, request, dver)
+
     def assemble(self, inputs, batch, res, default_policy_version, allow_unsupported=False):
         """ids -> CheckOutput (check.go:64-94)."""
         lt = self.lt

@@ -405,3 +405,23 @@ def test_corrupted_table_images_are_refused_or_harmless():
             pass
         it.close()
     assert opened > 100 and refused > 50, (opened, refused)
+
+
+def test_check_request_pb_with_jwt_claims():
+    """HipEvaluator.check_request_pb incl. the AuxData side channel: the verify vectors that carry JWT claims."""
+    lt = lower_rule_table(store_rule_table(), {})
+    ev = HostSimEvaluator(lt, Conf())
+    n = 0
+    for v in load_json("verify_vectors.json"):
+        if "auxData" not in v["input"] or v["globals"]:
+            continue
+        from helpers import rfc3339_ns
+        req = wire.encode_check_resources_request(_request_of([v["input"]], include_meta=False))
+        raw, flags = ev.check_request_pb(req, wire.encode_aux_data(v["input"]["auxData"]),
+                                         now_ns=rfc3339_ns(v["now"]) if v["now"] else 1_700_000_000_000_000_000,
+                                         lenient_scope_search=v["lenient"], strict_evaluation=v["strict"],
+                                         default_policy_version=v["defaultPolicyVersion"], default_scope=v["defaultScope"])
+        assert not flags[0] & 1
+        assert wire.decode_check_resources_response(raw)["results"][0]["actions"] == v["want"], (v["suite"], v["test"])
+        n += 1
+    assert n >= 20
