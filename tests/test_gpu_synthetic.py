@@ -83,6 +83,7 @@ def test_empty_and_ragged_batches():
     table.close()
 
 
+@pytest.mark.timeout(180)
 def test_concurrent_one_shot_calls():
     """cbh_check_batch from many threads at once (each call owns one of the table's one-shot contexts: stream,
     staging block, device block): every call must return exactly what it returns when called alone - small
@@ -205,6 +206,7 @@ def test_c5_full_batch_properties():
     table.close()
 
 
+@pytest.mark.timeout(180)
 def test_cross_product_batch_on_gpu():
     """A cross-product batch (cerbos_amd/cross.py: 400 principals x 300 resources x 4 actions = 480k decisions from
     700 flattened messages) against oracle/ccheck.cpp on the very same batch, and its cube against explicit
