@@ -481,6 +481,21 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   // parent roles are looked up with the request's own resource scope only (check.go:172,227)
   const u32 pr_scope_key = (r_scope & CBH_SCOPE_EXACT) ? (r_scope & ~CBH_SCOPE_EXACT) : CBH_NONE;
 
+  // does a rule record's role list (wave-uniform) match this lane's [role] ++ ancestors?
+  auto rec_role_match = [&](const TblRow& rw, const TblRowLists& rl, const RoleSet& rs) -> bool {
+    const u32 n_role = rw.counts >> 16;   // 0 = a single inline reference
+    bool m = false;
+    if (rw.flags & CBH_ROW_F_ROLE_LIST) {   // more than four roles: the list lives in the pool
+      for (u32 i = 0; i < n_role; ++i) m = m || roleset_has(t, rs, uload(&t.pool[rw.role + i]), GLOBBIT);
+    } else {
+      m = roleset_has(t, rs, rw.role, GLOBBIT);
+      if (n_role > 1) m = m || roleset_has(t, rs, rl.r1, GLOBBIT);
+      if (n_role > 2) m = m || roleset_has(t, rs, rl.r2, GLOBBIT);
+      if (n_role > 3) m = m || roleset_has(t, rs, rl.r3, GLOBBIT);
+    }
+    return m;
+  };
+
   // ---- routing preamble: scope chains and existence (check.go:116-121, 165-170), resolved once per
   // distinct route of the wave on the scalar unit (a sorted batch has one route per wave)
   u32 p_first = CBH_NONE, r_first = CBH_NONE;
@@ -673,9 +688,38 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
           }
 
           if (is_res && has_rolepol) {
+            // baseBM of Index.Query (index.go:250-305): the scope yields synthetic DENYs only if SOME binding at
+            // (version, scope) - a rule of the resource policy or a role-policy rule - matches the resource and
+            // one of [role] ++ ancestors; an empty base returns before appendRolePolicyDenies.
+            bool base = false;
+            if (have_bucket)
+              for (u32 row = bucket.x; row < bucket.x + bucket.y; ++row) {
+                const TblRow rw = uload_rec<TblRow>(t.rows, 2 * row);
+                const TblRowLists rl = uload_rec<TblRowLists>(t.rows, 2 * row + 1);
+                if (S != 0 && !base) base = rec_role_match(rw, rl, rs);
+              }
+            for (u32 k = 0;; ++k) {
+              const bool P = S != 0 && !base && k <= rs.par_cnt;
+              if (wave_ballot(P) == 0) break;
+              const u32 srole = P ? (k == 0 ? rs.role : t.pool[rs.par_off + k - 1]) : 0;
+              bool pend2 = P;
+              for (;;) {
+                const u64 rem2 = wave_ballot(pend2);
+                if (rem2 == 0) break;
+                const u32 g_sr = wave_readlane(srole, first_lane(rem2));
+                const bool in2 = pend2 && srole == g_sr;
+                pend2 = pend2 && !in2;
+                uint4 rp;
+                if (!udir_find(t, CBH_B_ROLEPOL, g_ver, si, g_sr, rp)) continue;
+                for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
+                  const TblRp rr = uload_rec<TblRp>(t.rprows, row);
+                  if (in2 && pmatch(rr.resource, kind, KIND_BITS())) base = true;
+                }
+              }
+            }
             // synthetic DENYs from the role policies of [role] ++ ancestors (index.go:352-530)
             for (u32 k = 0;; ++k) {
-              const bool P = S != 0 && k <= rs.par_cnt;
+              const bool P = S != 0 && base && k <= rs.par_cnt;
               if (wave_ballot(P) == 0) break;
               const u32 srole = P ? (k == 0 ? rs.role : t.pool[rs.par_off + k - 1]) : 0;
               bool pend2 = P;
@@ -730,19 +774,9 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
               if ((((u64)rl.pad0 | ((u64)rl.pad1 << 32)) & wave_classes) == 0) continue;   // no lane's role can match
               const u32 e = rw.flags & 3u;
               // a record = roles x actions of one rule (cbh_blob.h): the lists are wave-uniform
-              const u32 n_act = rw.counts & 0xFFFFu, n_role = rw.counts >> 16;   // 0 = a single inline reference
+              const u32 n_act = rw.counts & 0xFFFFu;   // 0 = a single inline reference
               bool rmatch = false;
-              if (S != 0) {
-                if (!is_res) rmatch = pmatch(rw.resource, kind, KIND_BITS());
-                else if (rw.flags & CBH_ROW_F_ROLE_LIST) {   // more than four roles: the list lives in the pool
-                  for (u32 i = 0; i < n_role; ++i) rmatch = rmatch || roleset_has(t, rs, uload(&t.pool[rw.role + i]), GLOBBIT);
-                } else {
-                  rmatch = roleset_has(t, rs, rw.role, GLOBBIT);
-                  if (n_role > 1) rmatch = rmatch || roleset_has(t, rs, rl.r1, GLOBBIT);
-                  if (n_role > 2) rmatch = rmatch || roleset_has(t, rs, rl.r2, GLOBBIT);
-                  if (n_role > 3) rmatch = rmatch || roleset_has(t, rs, rl.r3, GLOBBIT);
-                }
-              }
+              if (S != 0) rmatch = is_res ? rec_role_match(rw, rl, rs) : pmatch(rw.resource, kind, KIND_BITS());
               AM mrow = 0;
               if (rmatch) {
                 if (rw.flags & CBH_ROW_F_ACTION_LIST) {

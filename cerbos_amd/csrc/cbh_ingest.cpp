@@ -32,8 +32,8 @@ int fail(const std::string& m) { g_err = m; return -1; }
 using u8 = uint8_t; using u32 = uint32_t; using u64 = uint64_t;
 
 // ---- protobuf wire walking -------------------------------------------------------------------------
-struct Span { const u8* p; const u8* e; bool empty() const { return p >= e; } };
-struct Field { u32 num; u32 wt; u64 v; Span s; };   // v: varint / fixed value, s: length-delimited payload
+struct Span { const u8* p = nullptr; const u8* e = nullptr; bool empty() const { return p >= e; } };
+struct Field { u32 num = 0; u32 wt = 0; u64 v = 0; Span s{}; };   // v: varint / fixed value, s: length-delimited payload
 
 bool varint(Span& s, u64& out) {
   u64 r = 0;
@@ -93,9 +93,14 @@ bool map_get(Span msg, u32 fnum, std::string_view key, Span& val, bool& bad) {
 // field present wins; an empty message is null.
 struct Val { u32 kind = 1; u64 v = 0; Span s{nullptr, nullptr}; };
 bool value(Span m, Val& out, bool& bad) {
+  // a field counts only with the wire type its declaration has (null / bool: varint, number: fixed64,
+  // string / struct / list: length-delimited); anything else is an unknown field, skipped as protobuf does
+  static const u8 want_wt[7] = {0xFF, 0, 1, 2, 0, 2, 2};
   Field f;
   while (next(m, f, bad)) {
-    if (f.num >= 1 && f.num <= 6) { out.kind = f.num; out.v = f.v; out.s = f.s; }
+    if (f.num >= 1 && f.num <= 6 && f.wt == want_wt[f.num]) {
+      out.kind = f.num; out.v = f.wt == 2 ? 0 : f.v; out.s = f.wt == 2 ? f.s : Span{};
+    }
   }
   return !bad;
 }
@@ -366,9 +371,10 @@ int cbi_table_open(const void* blob, size_t len, cbi_table** out) {
   const CbhBlobSection *so = find(CBH_SEC_STR_OFF), *sb = find(CBH_SEC_STR_BYTES), *ss = find(CBH_SEC_SCOPE_SID), *sc = find(CBH_SEC_COLUMN_PATHS),
                        *sm = find(CBH_SEC_META);
   if (!so || !sb || !ss || !sc || !sm) return bail("blob is missing a section the ingest needs");
+  if (sm->nbytes < (u64)CBH_META_N * 4) return bail("META section too short");
   const u32* meta = (const u32*)(base + sm->offset);
   t->K = meta[CBH_M_NSTRINGS];
-  if ((u64)(t->K + 1) * 4 > so->nbytes) return bail("string offset section too short");
+  if (((u64)t->K + 1) * 4 > so->nbytes) return bail("string offset section too short");
   const u32* off = (const u32*)(base + so->offset);
   const char* bytes = (const char*)(base + sb->offset);
   if (off[t->K] > sb->nbytes) return bail("string byte section too short");

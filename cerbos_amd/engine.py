@@ -15,6 +15,7 @@ kernels behind the C ABI (``capi``); nothing here evaluates policies on the CPU.
 """
 from __future__ import annotations
 
+import threading
 import time
 
 from . import capi, namer
@@ -52,6 +53,9 @@ class Conf:
 
 
 class HipEvaluator:
+    _ingest = None
+    _ingest_lock = threading.Lock()   # check_pb / check_request_pb are called from many threads
+
     def __init__(self, lowered: LoweredTable, conf: Conf = None, device: int = 0, native_ingest: bool = False):
         """``native_ingest``: flatten through the protobuf wire format and libcerbos_ingest.so (what a Go
         caller does, include/cerbos_ingest.h) instead of the Python flattener; same batch either way."""
@@ -106,7 +110,6 @@ class HipEvaluator:
         messages (``data`` uint8, ``offsets`` uint64[n + 1]) -> C++ ingest -> ``cbh_check_batch`` -> C++ response
         assembly.  Returns ([serialized CheckOutput], flags uint8[n]); flags bit 0 = the device could not
         evaluate that input (the caller's own engine must), bit 1 = a CEL error was absorbed."""
-        from .ingest import IngestTable
         conf = self.conf
         lenient = conf.lenient_scope_search if lenient_scope_search is None else lenient_scope_search
         strict = conf.strict_evaluation if strict_evaluation is None else strict_evaluation
@@ -114,8 +117,7 @@ class HipEvaluator:
         dscope = conf.default_scope if default_scope is None else default_scope
         if now_ns is None:
             now_ns = time.time_ns()
-        if getattr(self, "_ingest", None) is None:
-            self._ingest = IngestTable(self.lt.blob)
+        self._ingest_table()
         batch = self._ingest.flatten_pb(data, offsets, dver, dscope)
         flags = capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0) | (capi.F_STRICT_EVALUATION if strict else 0)
         res = self.table.check(batch, now_ns=now_ns, flags=flags, device_order=True)
@@ -126,7 +128,6 @@ class HipEvaluator:
         """``svc.CheckResources`` on bytes (cerbos_svc.go:255-344): one serialized ``CheckResourcesRequest`` (and the
         serialized engine ``AuxData`` derived from its JWT) -> (serialized ``CheckResourcesResponse``, flags per
         resource entry: bit 0 = the caller's own engine must evaluate that entry)."""
-        from .ingest import IngestTable
         conf = self.conf
         lenient = conf.lenient_scope_search if lenient_scope_search is None else lenient_scope_search
         strict = conf.strict_evaluation if strict_evaluation is None else strict_evaluation
@@ -134,12 +135,19 @@ class HipEvaluator:
         dscope = conf.default_scope if default_scope is None else default_scope
         if now_ns is None:
             now_ns = time.time_ns()
-        if getattr(self, "_ingest", None) is None:
-            self._ingest = IngestTable(self.lt.blob)
+        self._ingest_table()
         batch = self._ingest.flatten_request_pb(request, aux_data, dver, dscope)
         flags = capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0) | (capi.F_STRICT_EVALUATION if strict else 0)
         res = self.table.check(batch, now_ns=now_ns, flags=flags, device_order=True)
         return self._ingest.assemble_response_pb(batch, res, request, dver)
+
+    def _ingest_table(self):
+        if self._ingest is None:
+            with self._ingest_lock:
+                if self._ingest is None:
+                    from .ingest import IngestTable
+                    self._ingest = IngestTable(self.lt.blob)
+        return self._ingest
 
     def assemble(self, inputs, batch, res, default_policy_version, allow_unsupported=False):
         """ids -> CheckOutput (check.go:64-94)."""

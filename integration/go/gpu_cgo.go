@@ -57,6 +57,9 @@ func (g *gpuEngine) close() {
 // checkBatchGPU returns one output per input; fallback[i] is true where the caller must run input i itself.
 func (g *gpuEngine) checkBatchGPU(_ context.Context, inputs []*enginev1.CheckInput, p evaluator.EvalParams) (outs []*enginev1.CheckOutput, fallback []bool, err error) {
 	n := len(inputs)
+	if n == 0 { // nothing to pin: &buf[0] of an empty slice panics
+		return nil, nil, nil
+	}
 	buf := make([]byte, 0, 256*n)
 	offs := make([]C.uint64_t, 1, n+1)
 	for _, in := range inputs {
@@ -64,6 +67,9 @@ func (g *gpuEngine) checkBatchGPU(_ context.Context, inputs []*enginev1.CheckInp
 			return nil, nil, err
 		}
 		offs = append(offs, C.uint64_t(len(buf)))
+	}
+	if len(buf) == 0 { // n all-empty messages serialise to nothing: keep &buf[0] valid
+		buf = append(buf, 0)[:1]
 	}
 	var pin runtime.Pinner // the C side only reads these during the calls below
 	pin.Pin(&buf[0])
@@ -146,6 +152,9 @@ func (g *gpuEngine) checkResourcesGPU(reqBytes []byte, auxData *enginev1.AuxData
 		if auxBytes, err = proto.Marshal(auxData); err != nil {
 			return nil, nil, err
 		}
+	}
+	if len(reqBytes) == 0 { // an empty request has no resource entries (protovalidate rejects it upstream)
+		return nil, nil, errors.New("empty CheckResourcesRequest")
 	}
 	var pin runtime.Pinner
 	pin.Pin(&reqBytes[0])

@@ -370,7 +370,26 @@ void check_request(const Img& g, const cbh_batch& b, const cbh_params& p, u32 r,
           }
           if (r_eff != 0) break;                                                 // :284
           bool brk = false;
+          // baseBM (index.go:250-305): some binding at (version, scope) - a resource-policy row or a role-policy
+          // row - matches the resource and one of [role] ++ ancestors; otherwise Query returns before
+          // appendRolePolicyDenies and the scope contributes nothing.
+          bool base = false;
           if (is_res && (g.meta[CBH_M_FLAGS] & CBH_MF_HAS_ROLE_POLICIES)) {
+            if (const CbhHashSlot* bk0 = dir_find(g, CBH_B_RESOURCE, r_ver, kind, si))
+              for (u32 row = bk0->v0; row < bk0->v0 + bk0->v1 && !base; ++row) {
+                const u32* rw = g.rows + CBH_ROW_NF * (size_t)row;
+                const u32 n_role = rw[CBH_ROW_COUNTS] >> 16;
+                if (n_role == 0) base = role_match(rw[CBH_ROW_ROLE]);
+                else for (u32 i = 0; i < n_role && !base; ++i)
+                  base = role_match((rw[CBH_ROW_FLAGS] & CBH_ROW_F_ROLE_LIST) ? g.pool[rw[CBH_ROW_ROLE] + i] : (i == 0 ? rw[CBH_ROW_ROLE] : rw[CBH_ROW_R1 + i - 1]));
+              }
+            for (u32 k = 0; k <= anc_cnt && !base; ++k) {
+              const CbhHashSlot* rp = dir_find(g, CBH_B_ROLEPOL, r_ver, si, k == 0 ? role : g.pool[anc_off + k - 1]);
+              for (u32 row = rp ? rp->v0 : 0; rp && row < rp->v0 + rp->v1 && !base; ++row)
+                base = pat_match(g.rprows[CBH_RP_NF * (size_t)row + CBH_RP_RESOURCE], kind, kind_bits);
+            }
+          }
+          if (base) {
             // synthetic DENY bindings from the role policies of [role] ++ ancestors come first (index.go:352-530)
             for (u32 k = 0; k <= anc_cnt && !brk && !done; ++k) {
               const u32 srole = k == 0 ? role : g.pool[anc_off + k - 1];
