@@ -178,13 +178,18 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         if r["allow_actions"] is not None:
             rp_buckets.setdefault((ver, scope, r["role"]), []).append(r)
             rp_res.setdefault((ver, scope), []).append(r["resource"])
-            # only conditional rules are ever evaluated (and cached) through their key (index.go:463-487)
-            prev = r["condition"] if r["condition"] is None else rp_evalkeys.setdefault(r["evaluation_key"], r["condition"])
-            if prev != r["condition"]:
-                raise LoweringError(
-                    "role policy %s has rules for different resources that share an evaluation key but not a "
-                    "condition; the reference's result then depends on evaluation history (ruletable.go:445-455)"
-                    % namer.policy_key_from_fqn(r["origin_fqn"]))
+            # Only conditional rules are ever evaluated (and cached) through their key (index.go:463-487).  The key
+            # leaves the resource out (ruletable.go:445-455), so rules of one role policy for different resources
+            # share it; the per-request conditionCache (check.go:186, 324) can only confuse them when both rules
+            # match the SAME resource kind, i.e. when one of the two resource names is a glob.
+            if r["condition"] is not None:
+                for o_res, o_cond in rp_evalkeys.setdefault(r["evaluation_key"], []):
+                    if o_cond != r["condition"] and ("*" in o_res or "*" in r["resource"]):
+                        raise LoweringError(
+                            "role policy %s has rules for overlapping resource globs that share an evaluation key but "
+                            "not a condition; the reference's result then depends on evaluation history "
+                            "(ruletable.go:445-455)" % namer.policy_key_from_fqn(r["origin_fqn"]))
+                rp_evalkeys[r["evaluation_key"]].append((r["resource"], r["condition"]))
         elif r["policy_kind"] == KIND_RESOURCE:
             if "*" in r["resource"]:
                 raise LoweringError("resource policy with a wildcard resource name is not supported: %s" % r["resource"])

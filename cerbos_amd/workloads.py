@@ -388,3 +388,58 @@ def c5_requests(n_requests=250_000, seed=5, actions_per_request=4):
                     labels=Attr("json", rng.integers(0, len(labels_v), n), rng.random(n) > 0.02, labels_v),
                     acl=Attr("json", rng.integers(0, len(acl_v), n), None, acl_v)),
     )
+
+
+# ------------------------------------------------------------------------------------- hack/loadtest
+# BASELINE.json configs[0] names the reference's own load-test sets.  tests/golden/loadtest_templates.json holds
+# the template text of hack/loadtest/templates/{classic,multitenant} (tools/make_golden_loadtest.py); rendering
+# follows hack/loadtest/generate.go:49-51,84-100: every template once per N in 0..count-1 with
+# NameMod(x) = "%s_%05d" % (x, N) and RequestID = "REQ_%05d" % N, static files copied once.
+_LOADTEST_FIXTURE = None
+
+
+def _loadtest_fixture():
+    global _LOADTEST_FIXTURE
+    if _LOADTEST_FIXTURE is None:
+        import json
+        import os
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                            "loadtest_templates.json")
+        with open(path, encoding="utf-8") as f:
+            _LOADTEST_FIXTURE = json.load(f)
+    return _LOADTEST_FIXTURE
+
+
+def loadtest_policies(set_name="classic", count=10):
+    """Policy documents of `./loadtest.sh -g` with NUM_POLICIES=count (schemas dropped: validation is out of scope)."""
+    from .policy.loader import load_yaml_documents
+    fx = _loadtest_fixture()[set_name]
+    docs = []
+    for t in fx["static_policies"]:
+        docs.extend(load_yaml_documents(t["text"]))
+    for n in range(count):
+        for t in fx["policies"]:
+            docs.extend(load_yaml_documents(t["text"].replace("@N@", "%05d" % n)))
+    for d in docs:
+        for k in ("resourcePolicy", "principalPolicy"):
+            if k in d:
+                d[k].pop("schemas", None)
+    return docs
+
+
+def loadtest_inputs(set_name="classic", count=10):
+    """The sets' CheckResourcesRequest templates as CheckInputs, one per resource entry
+    (svc/cerbos_svc.go:274-287), in template order for N = 0..count-1."""
+    import json
+    fx = _loadtest_fixture()[set_name]
+    out = []
+    for n in range(count):
+        for t in fx["requests"]:
+            req = json.loads(t["text"].replace("@N@", "%05d" % n))
+            for k, entry in enumerate(req["resources"]):
+                inp = {"requestId": "%s/%s/%d" % (req.get("requestId", ""), t["file"], k),
+                       "principal": req["principal"], "resource": entry["resource"], "actions": entry["actions"]}
+                if req.get("auxData"):
+                    inp["auxData"] = req["auxData"]
+                out.append(inp)
+    return out

@@ -1,7 +1,8 @@
 """GPU tier: the differential fuzz of tests/test_fuzz_parity.py through the real library - every
 kernel feature class (plain / derived roles / globs / everything; leaf and interpreter; 4, 32 and 64
-action masks) on hardware, against oracle/check.py.  (The wider CEL surface of CONDITIONS_WIDE runs on the
-kernel source in the CPU tier; it joins this tier once it has been run on hardware.)"""
+action masks) on hardware, against oracle/check.py: 24 seeds with the generator the tier started with and 24 with
+the wider CEL surface of CONDITIONS_WIDE (arithmetic, ternaries, string functions, comprehensions, timestamps,
+IP ranges, JWT claims)."""
 import os
 
 import numpy as np
@@ -18,13 +19,14 @@ from test_fuzz_parity import NOW, _policies, _requests
 
 pytestmark = pytest.mark.gpu
 
-# CBH_GPU_FUZZ_WIDE=1 switches to the wider CEL pool (CONDITIONS_WIDE) that has so far run on the kernel source only
-WIDE = os.environ.get("CBH_GPU_FUZZ_WIDE", "0") == "1"
+N_SEEDS = int(os.environ.get("CBH_GPU_FUZZ_SEEDS", "24"))
 
 
-@pytest.mark.parametrize("seed", range(24))
-def test_fuzz_store_on_gpu(seed):
-    rng = np.random.default_rng(10_000 + seed)
+@pytest.mark.parametrize("seed", range(N_SEEDS))
+@pytest.mark.parametrize("pool", ["base", "wide"])
+def test_fuzz_store_on_gpu(seed, pool):
+    WIDE = pool == "wide"
+    rng = np.random.default_rng((10_000 if not WIDE else 20_000) + seed)
     rt = rule_table_from_policies(policies_from_docs(_policies(rng, wide=WIDE)))
     try:
         lt = lower_rule_table(rt)

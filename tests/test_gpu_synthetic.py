@@ -234,3 +234,115 @@ def test_cross_product_batch_on_gpu():
     assert np.array_equal(cubes["effect"][:20, :15].reshape(-1), eff)
     assert 0.02 < (cubes["effect"] == capi.EFFECT_ALLOW).mean() < 0.98
     table.close()
+
+
+# ---- C5: the tuples the C++ restatement does not cover (general CEL programs), against oracle/check.py ----------
+_POOL_ORACLE = None
+
+
+def _pool_init():
+    global _POOL_ORACLE
+    from oracle.check import RuleTableOracle
+    _POOL_ORACLE = RuleTableOracle(rule_table_from_policies(policies_from_docs(workloads.c5_policies())))
+
+
+def _pool_check(args):
+    from oracle.check import EvalParams
+    inputs, lenient, strict = args
+    p = EvalParams(now_ns=NOW, lenient_scope_search=lenient, strict_evaluation=strict)
+    out = []
+    for inp in inputs:
+        o = _POOL_ORACLE.check(inp, p)
+        out.append(([(o["actions"][a]["effect"], o["actions"][a]["policy"], o["actions"][a].get("scope", "")) for a in inp["actions"]],
+                    sorted(o.get("effectiveDerivedRoles") or []), bool(o.get("evaluationErrors"))))
+    return out
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("mode", ["default", "strict"])
+def test_c5_general_cel_tuples_against_python_oracle(mode):
+    """The ~15 % of C5's requests whose conditions need general CEL programs are outside oracle/ccheck.cpp
+    (test_c5_full_size_against_cpp_oracle skips them).  A stratified sample of 50 000 of exactly those requests
+    (200k tuples of the 1M-tuple batch) goes through oracle/check.py - the restatement pinned on the reference's
+    goldens - on the host cores in parallel: effect, policy key, scope, derived roles and error presence must equal
+    the GPU's.  Together the two tests leave no C5 decision path unchecked at full size."""
+    import multiprocessing as mp
+    import os
+    from cerbos_amd.engine import HipEvaluator
+    from oracle import ccheck
+
+    class _Decoder(HipEvaluator):
+        def __init__(self, lt):   # noqa: D401 - ids -> strings only, no device table of its own
+            self.lt = lt
+
+    rt, lt, table = _table(workloads.c5_policies)
+    cr = workloads.c5_requests(250_000)
+    batch = cr.to_batch(Flattener(lt))
+    lenient, strict = False, mode == "strict"
+    flags = capi.F_WANT_DERIVED_ROLES | (capi.F_STRICT_EVALUATION if strict else 0)
+    got = table.check(batch, now_ns=NOW, flags=flags)
+    cres = ccheck.check(lt, batch, NOW, flags, threads=min(16, os.cpu_count() or 1))
+    skipped = np.nonzero((cres.status == capi.ST_UNSUPPORTED).reshape(-1, 4).any(axis=1))[0]
+    assert skipped.size > 20_000, skipped.size
+    pick = skipped[np.unique(np.linspace(0, skipped.size - 1, 50_000).astype(np.int64))]
+    inputs = [cr.to_inputs(int(r), int(r) + 1)[0] for r in pick]
+    nproc = max(1, min(48, (os.cpu_count() or 2) - 2))
+    chunks = [(inputs[i:i + 250], lenient, strict) for i in range(0, len(inputs), 250)]
+    with mp.get_context("fork").Pool(nproc, initializer=_pool_init) as pool:
+        want = [w for part in pool.map(_pool_check, chunks) for w in part]
+    dec = _Decoder(lt)
+    eff_name = {capi.EFFECT_ALLOW: "EFFECT_ALLOW", capi.EFFECT_DENY: "EFFECT_DENY"}
+    for r, inp, (acts, edr, err) in zip(pick, inputs, want):
+        for k, (we, wp, ws) in enumerate(acts):
+            t = 4 * int(r) + k
+            sc = int(got.scope[t])
+            have = (eff_name[int(got.effect[t])], dec._policy_string(int(got.policy[t]), inp, "default"), "" if sc == capi.NONE else lt.scopes[sc])
+            assert have == (we, wp, ws), (int(r), k, inp)
+        mask = int(got.edr[int(r)])
+        assert sorted(n for i, n in enumerate(lt.dr_names) if (mask >> i) & 1) == edr, (int(r), inp)
+        assert bool((got.status[4 * int(r):4 * int(r) + 4] == capi.ST_CEL_ERROR).any()) == err, (int(r), inp)
+    table.close()
+
+
+def _wide_requests(n_requests, n_actions, seed=33):
+    """C3 requests whose action lists are widened to `n_actions` distinct actions: the policies' own eight
+    actions at random positions among names no rule mentions."""
+    from cerbos_amd.columnar import Ragged
+    cr = workloads.c3_requests(n_requests, seed=seed)
+    vocab = list(workloads.C3_ACTIONS) + ["pad%02d" % i for i in range(80)]
+    rng = np.random.default_rng(seed)
+    perm = np.argsort(rng.random((n_requests, len(vocab))), axis=1)[:, :n_actions]
+    cr.actions = Ragged(vocab, np.arange(n_requests + 1) * n_actions, perm.reshape(-1))
+    return cr
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("n_actions,n_requests", [(40, 50_000), (64, 30_000), (70, 4_000)])
+def test_wide_action_lists_at_size(n_actions, n_requests):
+    """The 64-bit action-mask kernels (33..64 actions per request) at size - C3 requests (scopes, derived roles)
+    carrying 40 / 64 actions each, ~2M tuples - and the flattener's split of CheckInputs with more than 64
+    actions: bit for bit against oracle/ccheck.cpp, and the first requests against oracle/check.py."""
+    import os
+    from oracle import ccheck
+    rt, lt, table = _table(workloads.c3_policies)
+    cr = _wide_requests(n_requests, n_actions)
+    fl = Flattener(lt)
+    batch = cr.to_batch(fl) if n_actions <= 64 else fl.flatten(cr.to_inputs())   # only the dict route splits > 64
+    assert batch.n_tuples == n_requests * n_actions
+    assert int(batch.req_u32[15].max()) == min(n_actions, 64)
+    flags = capi.F_WANT_DERIVED_ROLES
+    got = table.check(batch, now_ns=NOW, flags=flags)
+    want = ccheck.check(lt, batch, NOW, flags, threads=min(16, os.cpu_count() or 1))
+    assert (got.status != capi.ST_UNSUPPORTED).all() and (want.status != capi.ST_UNSUPPORTED).all()
+    for f in ("effect", "policy", "scope"):
+        mism = np.nonzero(getattr(got, f) != getattr(want, f))[0]
+        assert mism.size == 0, "%s: %d mismatches, first at %s" % (f, mism.size, mism[:5])
+    # evaluation errors are a per-CheckOutput property: compare per CheckInput
+    assert np.array_equal((got.status == capi.ST_CEL_ERROR).reshape(-1, n_actions).any(axis=1),
+                          (want.status == capi.ST_CEL_ERROR).reshape(-1, n_actions).any(axis=1))
+    if n_actions <= 64:   # (a split CheckInput has one derived-role mask per part)
+        assert np.array_equal(got.edr, want.edr)
+    w = oracle_effects(rt, cr.to_inputs(0, 200))
+    assert np.array_equal(got.effect[:w.size], w)
+    assert 0.005 < (got.effect == capi.EFFECT_ALLOW).mean() < 0.98
+    table.close()

@@ -17,7 +17,7 @@ CASES = load_json("cel_eval_cases.json")
 API = "api.cerbos.dev/v1"
 
 
-def _decide(case, rules):
+def _decide(case, rules, make_evaluator=None):
     req = dict(case["request"])
     principal = dict(req.get("principal") or {})
     principal.setdefault("id", "kat")
@@ -38,7 +38,12 @@ def _decide(case, rules):
     aux = req.get("auxData") or req.get("aux_data")
     if aux:
         inp["auxData"] = aux
-    outs, bad = HostSimEvaluator(lt, Conf()).check([inp], now_ns=CEL_EVAL_NOW_NS, allow_unsupported=True)
+    ev = (make_evaluator or HostSimEvaluator)(lt, Conf())
+    try:
+        outs, bad = ev.check([inp], now_ns=CEL_EVAL_NOW_NS, allow_unsupported=True)
+    finally:
+        if make_evaluator is not None:
+            ev.close()
     return None if bad else {a: e["effect"] == "EFFECT_ALLOW" for a, e in outs[0]["actions"].items()}
 
 
@@ -53,7 +58,7 @@ def test_condition_on_device_path(case):
     assert got["kat"] == bool(case["want"]), case["name"]
 
 
-def test_true_leaves_on_device_path():
+def test_true_leaves_on_device_path(make_evaluator=None):
     """Every leaf of an `all` condition whose golden result is true must itself decide ALLOW."""
     checked = flagged = 0
     for case in CASES:
@@ -62,7 +67,7 @@ def test_true_leaves_on_device_path():
         leaves = [m["expr"] for m in case["condition"]["all"]["of"] if "expr" in m]
         for i, expr in enumerate(leaves):   # one store per leaf: an unsupported leaf flags only itself
             try:
-                got = _decide(case, [{"actions": ["leaf"], "condition": {"match": {"expr": expr}}}])
+                got = _decide(case, [{"actions": ["leaf"], "condition": {"match": {"expr": expr}}}], make_evaluator)
             except LoweringError:
                 flagged += 1
                 continue
