@@ -14,7 +14,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcerbos_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
+MAX_DEVICES = 16
 F_LENIENT_SCOPE_SEARCH = 1
 F_STRICT_EVALUATION = 2
 F_WANT_DERIVED_ROLES = 4
@@ -25,10 +26,11 @@ P_EMPTY, P_NO_MATCH, P_RESOURCE, P_PRINCIPAL, P_TABLE, P_NO_MATCH_SP = range(6)
 NONE = 0xFFFFFFFF
 
 EXPORTED_SYMBOLS = [
-    "cbh_init", "cbh_shutdown", "cbh_last_error", "cbh_abi_version",
-    "cbh_table_load", "cbh_table_release", "cbh_table_num_strings", "cbh_table_num_columns",
+    "cbh_init", "cbh_shutdown", "cbh_last_error", "cbh_abi_version", "cbh_num_devices", "cbh_device_ordinal",
+    "cbh_alloc_pinned", "cbh_free_pinned", "cbh_batch_slab_bytes", "cbh_batch_bind_slab", "cbh_result_slab_bytes", "cbh_result_bind_slab",
+    "cbh_table_load", "cbh_table_retain", "cbh_table_release", "cbh_table_broadcast_kind", "cbh_table_num_strings", "cbh_table_num_columns",
     "cbh_table_device_bytes", "cbh_table_device_ptr", "cbh_table_adopt_device_image",
-    "cbh_check_batch", "cbh_batch_upload", "cbh_batch_release", "cbh_check_resident",
+    "cbh_check_batch", "cbh_batch_upload", "cbh_batch_upload_on", "cbh_batch_release", "cbh_check_resident",
     "cbh_synchronize", "cbh_result_download", "cbh_kernel_time_ms",
 ]
 
@@ -38,7 +40,7 @@ class HipEngineError(RuntimeError):
 
 
 class Config(C.Structure):
-    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32)]
+    _fields_ = [("abi_version", C.c_uint32), ("n_devices", C.c_uint32), ("devices", C.c_int32 * MAX_DEVICES)]
 
 
 class CBatch(C.Structure):
@@ -85,6 +87,27 @@ def load():
     lib.cbh_table_load.restype = i32
     lib.cbh_table_release.argtypes = [vp]
     lib.cbh_table_release.restype = None
+    lib.cbh_table_retain.argtypes = [vp]
+    lib.cbh_table_retain.restype = None
+    lib.cbh_table_broadcast_kind.argtypes = [vp]
+    lib.cbh_table_broadcast_kind.restype = C.c_char_p
+    lib.cbh_num_devices.restype = u32
+    lib.cbh_device_ordinal.argtypes = [u32]
+    lib.cbh_device_ordinal.restype = i32
+    lib.cbh_alloc_pinned.argtypes = [C.c_size_t]
+    lib.cbh_alloc_pinned.restype = vp
+    lib.cbh_free_pinned.argtypes = [vp]
+    lib.cbh_free_pinned.restype = None
+    lib.cbh_batch_slab_bytes.argtypes = [C.POINTER(CBatch)]
+    lib.cbh_batch_slab_bytes.restype = C.c_size_t
+    lib.cbh_batch_bind_slab.argtypes = [C.POINTER(CBatch), vp]
+    lib.cbh_batch_bind_slab.restype = None
+    lib.cbh_result_slab_bytes.argtypes = [u32, u32]
+    lib.cbh_result_slab_bytes.restype = C.c_size_t
+    lib.cbh_result_bind_slab.argtypes = [C.POINTER(CResult), vp, u32, u32]
+    lib.cbh_result_bind_slab.restype = None
+    lib.cbh_batch_upload_on.argtypes = [vp, u32, C.POINTER(CBatch), C.POINTER(vp)]
+    lib.cbh_batch_upload_on.restype = i32
     lib.cbh_table_num_strings.argtypes = [vp]
     lib.cbh_table_num_strings.restype = u32
     lib.cbh_table_num_columns.argtypes = [vp]
@@ -121,14 +144,49 @@ def _check(rc):
 _inited_device = None
 
 
-def init(device: int = 0):
+def init(device=0):
+    """``device``: one HIP ordinal, or the list of ordinals the engine may use (cbh_config.devices; a batch is then
+    sharded over them and the table image broadcast once).  ``"all"`` = every visible device."""
     global _inited_device
     lib = load()
     if lib.cbh_abi_version() != ABI_VERSION:
         raise HipEngineError("libcerbos_hip.so ABI mismatch")
-    cfg = Config(ABI_VERSION, device)
+    devs = [] if device == "all" else ([int(device)] if isinstance(device, int) else [int(d) for d in device])
+    cfg = Config(ABI_VERSION, len(devs), (C.c_int32 * MAX_DEVICES)(*devs))
     _check(lib.cbh_init(C.byref(cfg)))
-    _inited_device = device
+    _inited_device = devs[0] if devs else 0
+
+
+def num_devices() -> int:
+    return load().cbh_num_devices()
+
+
+class _PinnedBlock:
+    """Owner of one cbh_alloc_pinned block; numpy views keep it alive through their ``base`` chain."""
+
+    def __init__(self, nbytes):
+        self.ptr = load().cbh_alloc_pinned(max(1, nbytes))
+        if not self.ptr:
+            raise HipEngineError("cbh_alloc_pinned failed")
+        self.nbytes = nbytes
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                load().cbh_free_pinned(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """numpy array in page-locked host memory (cbh_alloc_pinned): cbh_check_batch moves such arrays by DMA."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) if not isinstance(shape, int) else int(shape)
+    blk = _PinnedBlock(n * dtype.itemsize)
+    buf = (C.c_uint8 * max(1, n * dtype.itemsize)).from_address(blk.ptr)
+    buf._owner = blk   # the ctypes buffer is the numpy array's base: keeps the block alive
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
 
 
 def _ptr(a):
@@ -149,6 +207,31 @@ def make_cbatch(batch, n_columns):
               "heap_val", "str_off", "str_bytes", "str_flags"):
         setattr(cb, f, _ptr(getattr(batch, f)))
     return cb
+
+
+def _slab_view(slab, addr, shape, dtype):
+    """numpy view of `shape` x `dtype` at absolute address `addr` inside the pinned uint8 array `slab`."""
+    off = addr - slab.ctypes.data
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    return slab[off:off + n].view(dtype).reshape(shape)
+
+
+def pin_batch(batch):
+    """Move a flatten.Batch's arrays into ONE page-locked slab in the library's canonical order
+    (cbh_batch_bind_slab): cbh_check_batch then uploads the batch with a single DMA.  In place; returns the batch."""
+    lib = load()
+    n_columns = int(batch.col_tag.shape[0]) if batch.col_tag.ndim == 2 else 0
+    cb = make_cbatch(batch, n_columns)
+    slab = pinned_empty(max(1, lib.cbh_batch_slab_bytes(C.byref(cb))), np.uint8)
+    lib.cbh_batch_bind_slab(C.byref(cb), slab.ctypes.data_as(C.c_void_p))
+    for f in ("req_u32", "roles", "tuple_action", "col_tag", "col_val", "heap_tag", "heap_val", "str_off", "str_bytes", "str_flags"):
+        a = getattr(batch, f)
+        if a is not None and a.size:
+            v = _slab_view(slab, getattr(cb, f), a.shape, a.dtype)
+            v[...] = a
+            setattr(batch, f, v)
+    batch.slab = slab
+    return batch
 
 
 class Table:
@@ -174,6 +257,16 @@ class Table:
         self.num_columns = lib.cbh_table_num_columns(h)
         return self
 
+    @classmethod
+    def borrow(cls, other: "Table"):
+        """A second handle object on ``other``'s table holding its own reference (cbh_table_retain): stays valid
+        after ``other.close()``; its own ``close()`` drops that reference."""
+        load().cbh_table_retain(other.h)
+        self = cls.__new__(cls)
+        self.h = C.c_void_p(other.h.value)
+        self.num_strings, self.num_columns = other.num_strings, other.num_columns
+        return self
+
     def device_ptr(self) -> int:
         return load().cbh_table_device_ptr(self.h)
 
@@ -192,18 +285,27 @@ class Table:
             pass
 
     # ---- one-shot
-    def check(self, batch, now_ns=0, flags=0, want=("policy", "scope", "status", "edr"), device_order=False):
-        res = Result(batch.n_tuples, batch.n_requests, want)
+    def check(self, batch, now_ns=0, flags=0, want=("policy", "scope", "status", "edr"), device_order=False, pinned=False,
+              into=None):
+        """``pinned``: results in page-locked memory (with a pin_batch'ed batch the call is pure DMA);
+        ``into``: reuse a Result of the right shape instead of allocating one."""
+        res = into if into is not None else Result(batch.n_tuples, batch.n_requests, want, pinned)
         cb = make_cbatch(batch, self.num_columns)
         p = CParams(now_ns, flags, 0)
         _check(load().cbh_check_batch(self.h, C.byref(cb), C.byref(p), C.byref(res.c)))
         return res if device_order else res.to_input_order(batch)
 
     # ---- resident
-    def upload(self, batch):
+    def broadcast_kind(self) -> str:
+        return load().cbh_table_broadcast_kind(self.h).decode()
+
+    def retain(self):
+        load().cbh_table_retain(self.h)
+
+    def upload(self, batch, device_index=0):
         cb = make_cbatch(batch, self.num_columns)
         h = C.c_void_p()
-        _check(load().cbh_batch_upload(self.h, C.byref(cb), C.byref(h)))
+        _check(load().cbh_batch_upload_on(self.h, device_index, C.byref(cb), C.byref(h)))
         return DeviceBatch(self, h, batch.n_tuples, batch.n_requests, batch)
 
     def launch(self, dbatch, now_ns=0, flags=0):
@@ -247,12 +349,29 @@ class DeviceBatch:
 
 
 class Result:
-    def __init__(self, n_tuples, n_requests, want):
-        self.effect = np.zeros(n_tuples, dtype=np.uint8)
-        self.policy = np.zeros(n_tuples, dtype=np.uint32) if "policy" in want else None
-        self.scope = np.zeros(n_tuples, dtype=np.uint32) if "scope" in want else None
-        self.status = np.zeros(n_tuples, dtype=np.uint8) if "status" in want else None
-        self.edr = np.zeros(n_requests, dtype=np.uint64) if "edr" in want else None
+    def __init__(self, n_tuples, n_requests, want, pinned=False):
+        """``pinned``: all five arrays in one page-locked result slab (cbh_result_bind_slab) - the wanted ones come
+        back in one DMA each run of neighbours; otherwise ordinary numpy arrays."""
+        self.effect = self.policy = self.scope = self.status = self.edr = None
+        if pinned:
+            lib = load()
+            slab = pinned_empty(max(1, lib.cbh_result_slab_bytes(n_tuples, n_requests)), np.uint8)
+            c = CResult()
+            lib.cbh_result_bind_slab(C.byref(c), slab.ctypes.data_as(C.c_void_p), n_tuples, n_requests)
+            self.slab = slab
+            mk = lambda n, dt, addr: _slab_view(slab, addr, (n,), dt)   # noqa: E731
+        else:
+            c = CResult(0, 0, 0, 0, 0)
+            mk = lambda n, dt, addr: np.zeros(n, dtype=dt)   # noqa: E731
+        self.effect = mk(n_tuples, np.uint8, c.effect)
+        if "policy" in want:
+            self.policy = mk(n_tuples, np.uint32, c.policy)
+        if "scope" in want:
+            self.scope = mk(n_tuples, np.uint32, c.scope)
+        if "status" in want:
+            self.status = mk(n_tuples, np.uint8, c.status)
+        if "edr" in want:
+            self.edr = mk(n_requests, np.uint64, c.edr_mask)
         self.c = CResult(_ptr(self.effect) or 0, _ptr(self.policy), _ptr(self.scope), _ptr(self.status),
                          _ptr(self.edr))
 

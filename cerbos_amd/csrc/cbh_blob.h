@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define CBH_BLOB_MAGIC 0x31484243u /* "CBH1" */
-#define CBH_BLOB_VERSION 15u
+#define CBH_BLOB_VERSION 16u
 
 struct CbhBlobHeader {  // 32 bytes
   uint32_t magic;
@@ -82,6 +82,8 @@ enum CbhMeta {
 #define CBH_MF_HAS_GENERIC_PROGRAMS 8u  /* some program needs the operand-stack interpreter */
 #define CBH_MF_HAS_ANY_PATTERN 16u      /* some pattern reference is CBH_PAT_ANY (treated as a glob table) */
 #define CBH_MF_HAS_PRINCIPAL_POLICIES 32u
+#define CBH_MF_NEEDS_STRING_BYTES 128u   /* glob automata, or a program that looks inside a string: upload str_off / str_bytes / str_flags */
+#define CBH_MF_READS_REQUEST_STRINGS 64u /* some program reads a raw request string (CBH_RQ_S_*): upload those fields */
 
 // Directory: open addressing, linear probing, key.x == CBH_NONE marks an empty slot.
 struct CbhHashSlot { // 32 bytes

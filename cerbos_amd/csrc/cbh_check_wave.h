@@ -376,9 +376,9 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
 #ifdef CBH_PROFILE_CYCLES   // profiling build only (tools/gpu_cycles.py): the counters cost ~20 SGPRs
   const u64 cyc_start = __builtin_readcyclecounter();
 #endif
-  const u32 rix = blockIdx.x * CBH_BLOCK + threadIdx.x;
-  const bool valid = rix < b.n_requests;
-  const u32 req = valid ? rix : 0;   // tail lanes shadow request 0 and never store
+  const u32 rix = b.req_lo + blockIdx.x * CBH_BLOCK + threadIdx.x;
+  const bool valid = rix < b.req_hi;
+  const u32 req = valid ? rix : b.req_lo;   // tail lanes shadow the chunk's first request and never store
   const u32 NR = b.n_requests;
 #define RQ(f) b.req_u32[(size_t)(f) * NR + req]
   const u32 pid = RQ(CBH_RQ_PRINCIPAL_ID);

@@ -15,17 +15,25 @@
 //                              (internal/ruletable/ruletable.go:848-882) over the flat table image.
 //
 // Host side: the C ABI of include/cerbos_hip.h.
+//   * a table = one replica of the image per device of the engine (broadcast once: RCCL, or peer copies);
+//   * cbh_check_batch = the reference's fan-out (engine.go:309-338) as contiguous request ranges over the
+//     devices, each range pipelined in chunks over three streams (upload / kernels / download overlap);
+//   * tables are reference counted, so a released table drains its in-flight batches (manager.go:86-124).
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <condition_variable>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cbh_kernels.h"
@@ -39,12 +47,102 @@ static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return -1; }
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(_e)); } while (0)
 
-struct cbh_table {
+// ---- engine-wide state -------------------------------------------------------------------------------------
+struct Rccl {   // the few RCCL entry points the image broadcast needs, bound at first use (no link-time dependency:
+                // a single-GPU deployment never loads the collective library)
+  void* lib = nullptr;
+  int (*CommInitAll)(void**, int, const int*) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  std::vector<void*> comms;
+  bool tried = false, ok = false;
+};
+static struct Engine {
+  std::mutex mu;
+  bool inited = false;
+  std::vector<int> devices;
+  Rccl rccl;
+} g_eng;
+
+// CBH_TRACE=1: one line per one-shot call on stderr (path taken, phase times) - measurement aid
+static bool trace_on() { static const bool on = getenv("CBH_TRACE") != nullptr; return on; }
+static double now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+// CBH_SPIN=1: wait for a stream by polling hipStreamQuery instead of hipStreamSynchronize
+static hipError_t stream_wait(hipStream_t s) {
+  static const bool spin = [] { const char* e = getenv("CBH_SPIN"); return e && *e == '1'; }();
+  if (!spin) return hipStreamSynchronize(s);
+  for (;;) { const hipError_t e = hipStreamQuery(s); if (e != hipErrorNotReady) return e; }
+}
+static const size_t SMALL_BATCH_BYTES = (size_t)1 << 20;   // inputs under this: one staged copy each way
+static const u32 SHARD_MIN_REQUESTS = 8192;                 // a device is given at least this many requests
+static const int N_STREAMS = 3;
+
+extern "C" const char* cbh_last_error(void) { return g_err.c_str(); }
+extern "C" uint32_t cbh_abi_version(void) { return CBH_ABI_VERSION; }
+
+extern "C" int cbh_init(const cbh_config* cfg) {
+  if (cfg && cfg->abi_version != CBH_ABI_VERSION) return fail("ABI version mismatch");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) return fail("no HIP device available: the decision engine requires an MI355X (no CPU fallback)");
+  std::vector<int> devs;
+  if (cfg && cfg->n_devices) {
+    if (cfg->n_devices > CBH_MAX_DEVICES) return fail("too many devices");
+    for (u32 i = 0; i < cfg->n_devices; ++i) {
+      if (cfg->devices[i] < 0 || cfg->devices[i] >= n) return fail("invalid device ordinal");
+      devs.push_back(cfg->devices[i]);
+    }
+  } else {
+    for (int i = 0; i < n && i < (int)CBH_MAX_DEVICES; ++i) devs.push_back(i);
+    if (!cfg) devs.resize(1);   // no configuration: the first device only
+  }
+  for (int d : devs) { HIPCHK(hipSetDevice(d)); HIPCHK(hipFree(nullptr)); }   // create the contexts now, not under a request
+  // peer access between the engine's devices (image broadcast by peer copy, should RCCL be unavailable)
+  for (int a : devs) for (int b : devs) if (a != b) {
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) { (void)hipSetDevice(a); (void)hipDeviceEnablePeerAccess(b, 0); (void)hipGetLastError(); }
+  }
+  HIPCHK(hipSetDevice(devs[0]));
+  std::lock_guard<std::mutex> lk(g_eng.mu);
+  g_eng.devices = devs;
+  g_eng.inited = true;
+  return 0;
+}
+
+extern "C" void cbh_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_eng.mu);
+  Rccl& r = g_eng.rccl;
+  if (r.ok) for (void* c : r.comms) if (c) (void)r.CommDestroy(c);
+  r.comms.clear(); r.ok = false; r.tried = false;
+  if (r.lib) { dlclose(r.lib); r.lib = nullptr; }
+  g_eng.inited = false;
+  g_eng.devices.clear();
+}
+extern "C" uint32_t cbh_num_devices(void) { std::lock_guard<std::mutex> lk(g_eng.mu); return (uint32_t)g_eng.devices.size(); }
+extern "C" int32_t cbh_device_ordinal(uint32_t i) { std::lock_guard<std::mutex> lk(g_eng.mu); return i < g_eng.devices.size() ? g_eng.devices[i] : -1; }
+
+extern "C" void* cbh_alloc_pinned(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); g_err = "hipHostMalloc failed"; return nullptr; }
+  return p;
+}
+extern "C" void cbh_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+
+// ---- tables -----------------------------------------------------------------------------------------------
+struct OneShot {   // what one cbh_check_batch call owns on one device while it runs
+  hipStream_t s[N_STREAMS] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_setup = nullptr;
+  uint8_t* h = nullptr; size_t h_cap = 0;   // pinned staging block (small batches)
+  uint8_t* d = nullptr; size_t d_cap = 0;   // device block
+};
+
+struct Replica {   // the table on one device
   int device = 0;
-  void* image = nullptr; size_t image_len = 0; bool owns_image = true;
-  std::vector<uint32_t> meta;
+  void* image = nullptr; bool owns_image = true;
   TableDev dev{};
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // resident path
   // Kernel timing: a ring of event sets so that launches queue back to back; the host only waits
   // when it laps the ring.  ev[0..1] bracket the glob-resolve kernel, ev[2..3] the decision kernel.
   static constexpr int RING = 32;
@@ -55,9 +153,7 @@ struct cbh_table {
   std::mutex mu;
   std::mutex pool_mu;
   std::vector<std::pair<void*, size_t>> pool_free;   // idle device blocks of released batches
-  // One-shot calls (cbh_check_batch) run on their own small set of contexts - stream, pinned staging
-  // block, device block - so that calls from different threads overlap on the device.
-  struct OneShot { hipStream_t stream = nullptr; uint8_t* h = nullptr; size_t h_cap = 0; uint8_t* d = nullptr; size_t d_cap = 0; };
+  // One-shot calls run on their own small set of contexts so that calls from different threads overlap.
   static constexpr int MAX_ONESHOT = 8;
   std::mutex ctx_mu;
   std::condition_variable ctx_cv;
@@ -65,109 +161,211 @@ struct cbh_table {
   int ctx_count = 0;
 };
 
+struct cbh_table {
+  std::vector<Replica*> reps;
+  size_t image_len = 0;
+  std::vector<uint32_t> meta;
+  std::atomic<int> refs{1};
+  const char* bcast = "none";
+};
+
 struct cbh_device_batch {
   cbh_table* table = nullptr;
+  Replica* rep = nullptr;
   BatchDev dev{};
   OutDev out{};
   KernelArgs* d_args = nullptr;   // device copy of the launch arguments
   KernelArgs last_args;           // what d_args currently holds
   bool have_args = false;
   u32 max_actions = 0;            // largest CBH_RQ_ACT_CNT of the batch: selects the action-mask width
-  std::vector<std::pair<void*, size_t>> allocs;   // (block, capacity) taken from the table's pool
+  std::vector<std::pair<void*, size_t>> allocs;   // (block, capacity) taken from the replica's pool
 };
 
-static int g_device = 0;
-static bool g_inited = false;
+static void replica_destroy(Replica* r) {
+  if (!r) return;
+  (void)hipSetDevice(r->device);
+  if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
+  for (auto& sl : r->ring) for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
+  if (r->image && r->owns_image) (void)hipFree(r->image);
+  for (auto& a : r->pool_free) (void)hipFree(a.first);
+  for (auto* c : r->ctx_idle) {
+    for (auto& s : c->s) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    if (c->ev_setup) (void)hipEventDestroy(c->ev_setup);
+    if (c->h) (void)hipHostFree(c->h);
+    if (c->d) (void)hipFree(c->d);
+    delete c;
+  }
+  delete r;
+}
+static void table_destroy(cbh_table* t) {
+  for (Replica* r : t->reps) replica_destroy(r);
+  delete t;
+}
+// every entry point that works on a table holds a reference while it runs: the table outlives a
+// concurrent cbh_table_release (the last reference frees it)
+struct TableRef {
+  cbh_table* t;
+  explicit TableRef(cbh_table* t_) : t(t_) { t->refs.fetch_add(1, std::memory_order_relaxed); }
+  ~TableRef() { if (t->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) table_destroy(t); }
+};
+extern "C" void cbh_table_retain(cbh_table* t) { if (t) t->refs.fetch_add(1, std::memory_order_relaxed); }
+extern "C" void cbh_table_release(cbh_table* t) {
+  if (t && t->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) table_destroy(t);
+}
 
-extern "C" const char* cbh_last_error(void) { return g_err.c_str(); }
-extern "C" uint32_t cbh_abi_version(void) { return CBH_ABI_VERSION; }
-
-extern "C" int cbh_init(const cbh_config* cfg) {
-  if (cfg && cfg->abi_version != CBH_ABI_VERSION) return fail("ABI version mismatch");
-  int n = 0;
-  hipError_t e = hipGetDeviceCount(&n);
-  if (e != hipSuccess || n == 0) return fail("no HIP device available: the decision engine requires an MI355X (no CPU fallback)");
-  g_device = cfg ? cfg->device : 0;
-  if (g_device < 0 || g_device >= n) return fail("invalid device ordinal");
-  HIPCHK(hipSetDevice(g_device));
-  g_inited = true;
+static int replica_finish(Replica* r) {
+  HIPCHK(hipSetDevice(r->device));
+  HIPCHK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+  for (auto& sl : r->ring) for (auto& e : sl.ev) HIPCHK(hipEventCreate(&e));
   return 0;
 }
-extern "C" void cbh_shutdown(void) { g_inited = false; }
 
-static int parse_image(cbh_table* t, const uint8_t* host_copy, size_t len) {
-  const char* e = cbh_parse_image(t->dev, t->meta, static_cast<const uint8_t*>(t->image), host_copy, len);
-  return e ? fail(e) : 0;
+static bool rccl_bind(Rccl& r, const std::vector<int>& devs) {   // under g_eng.mu
+  if (r.tried) return r.ok;
+  r.tried = true;
+  const char* off = getenv("CBH_BCAST");
+  if (off && !strcmp(off, "peer")) return false;
+  for (size_t i = 0; i < devs.size(); ++i) for (size_t j = i + 1; j < devs.size(); ++j) if (devs[i] == devs[j]) return false;   // one rank per GPU
+  r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!r.lib) r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!r.lib) return false;
+  r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
+  r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+  r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+  r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
+  r.Broadcast = (decltype(r.Broadcast))dlsym(r.lib, "ncclBroadcast");
+  if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Broadcast) return false;
+  r.comms.assign(devs.size(), nullptr);
+  if (r.CommInitAll(r.comms.data(), (int)devs.size(), devs.data()) != 0) { r.comms.clear(); return false; }
+  r.ok = true;
+  return true;
 }
 
-static int table_finish(cbh_table* t) {
-  HIPCHK(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
-  for (auto& sl : t->ring) for (auto& e : sl.ev) HIPCHK(hipEventCreate(&e));
+// the image sits on reps[0]; put a copy on every other replica
+static int broadcast_image(cbh_table* t) {
+  const size_t len = t->image_len;
+  for (size_t i = 1; i < t->reps.size(); ++i) {
+    HIPCHK(hipSetDevice(t->reps[i]->device));
+    HIPCHK(hipMalloc(&t->reps[i]->image, len));
+  }
+  bool done = false;
+  {
+    std::lock_guard<std::mutex> lk(g_eng.mu);
+    Rccl& r = g_eng.rccl;
+    if (rccl_bind(r, g_eng.devices) && r.comms.size() == t->reps.size()) {
+      // one-time RCCL broadcast over xGMI from the first device (ncclUint8 = 1)
+      bool ok = r.GroupStart() == 0;
+      for (size_t i = 0; ok && i < t->reps.size(); ++i) {
+        ok = hipSetDevice(t->reps[i]->device) == hipSuccess &&
+             r.Broadcast(t->reps[0]->image, t->reps[i]->image, len, 1, 0, r.comms[i], t->reps[i]->stream) == 0;
+      }
+      ok = (r.GroupEnd() == 0) && ok;
+      for (size_t i = 0; i < t->reps.size(); ++i) { (void)hipSetDevice(t->reps[i]->device); ok = (hipStreamSynchronize(t->reps[i]->stream) == hipSuccess) && ok; }
+      if (ok) { done = true; t->bcast = "rccl"; } else (void)hipGetLastError();
+    }
+  }
+  if (!done) {
+    for (size_t i = 1; i < t->reps.size(); ++i)
+      HIPCHK(hipMemcpyPeer(t->reps[i]->image, t->reps[i]->device, t->reps[0]->image, t->reps[0]->device, len));
+    t->bcast = "peer-copy";
+  }
   return 0;
 }
 
 extern "C" int cbh_table_load(const void* blob, size_t len, cbh_table** out) {
-  if (!g_inited) return fail("cbh_init has not been called");
+  std::vector<int> devs;
+  { std::lock_guard<std::mutex> lk(g_eng.mu); if (!g_eng.inited) return fail("cbh_init has not been called"); devs = g_eng.devices; }
   if (!blob || !out) return fail("null argument");
-  HIPCHK(hipSetDevice(g_device));
   cbh_table* t = new (std::nothrow) cbh_table();
   if (!t) return fail("out of memory");
-  t->device = g_device; t->image_len = len;
-  if (hipMalloc(&t->image, len) != hipSuccess) { delete t; return fail("hipMalloc(table image) failed"); }
-  if (hipMemcpy(t->image, blob, len, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(t->image); delete t; return fail("hipMemcpy(table image) failed"); }
-  if (parse_image(t, static_cast<const uint8_t*>(blob), len) != 0 || table_finish(t) != 0) { (void)hipFree(t->image); delete t; return -1; }
+  t->image_len = len;
+  auto bail = [&]() { table_destroy(t); return -1; };
+  for (int d : devs) { Replica* r = new (std::nothrow) Replica(); if (!r) { fail("out of memory"); return bail(); } r->device = d; t->reps.push_back(r); }
+  for (Replica* r : t->reps) if (replica_finish(r) != 0) return bail();
+  Replica* r0 = t->reps[0];
+  if (hipSetDevice(r0->device) != hipSuccess || hipMalloc(&r0->image, len) != hipSuccess) { fail("hipMalloc(table image) failed"); return bail(); }
+  if (hipMemcpy(r0->image, blob, len, hipMemcpyHostToDevice) != hipSuccess) { fail("hipMemcpy(table image) failed"); return bail(); }
+  if (t->reps.size() > 1 && broadcast_image(t) != 0) return bail();
+  for (Replica* r : t->reps) {
+    const char* e = cbh_parse_image(r->dev, t->meta, static_cast<const uint8_t*>(r->image), static_cast<const uint8_t*>(blob), len);
+    if (e) { fail(e); return bail(); }
+  }
   *out = t;
   return 0;
 }
 
 extern "C" int cbh_table_adopt_device_image(void* device_image, size_t len, cbh_table** out) {
-  if (!g_inited) return fail("cbh_init has not been called");
+  int dev0;
+  { std::lock_guard<std::mutex> lk(g_eng.mu); if (!g_eng.inited) return fail("cbh_init has not been called"); dev0 = g_eng.devices[0]; }
   if (!device_image || !out) return fail("null argument");
-  HIPCHK(hipSetDevice(g_device));
+  HIPCHK(hipSetDevice(dev0));
   std::vector<uint8_t> host(len);
   HIPCHK(hipMemcpy(host.data(), device_image, len, hipMemcpyDeviceToHost));
   cbh_table* t = new (std::nothrow) cbh_table();
   if (!t) return fail("out of memory");
-  t->device = g_device; t->image = device_image; t->image_len = len; t->owns_image = false;
-  if (parse_image(t, host.data(), len) != 0 || table_finish(t) != 0) { delete t; return -1; }
+  Replica* r = new (std::nothrow) Replica();
+  if (!r) { delete t; return fail("out of memory"); }
+  r->device = dev0; r->image = device_image; r->owns_image = false;
+  t->reps.push_back(r); t->image_len = len;
+  const char* e = cbh_parse_image(r->dev, t->meta, static_cast<const uint8_t*>(r->image), host.data(), len);
+  if (e) { table_destroy(t); return fail(e); }
+  if (replica_finish(r) != 0) { table_destroy(t); return -1; }
   *out = t;
   return 0;
 }
 
-extern "C" void cbh_table_release(cbh_table* t) {
-  if (!t) return;
-  (void)hipSetDevice(t->device);
-  if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
-  for (auto& sl : t->ring) for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
-  if (t->image && t->owns_image) (void)hipFree(t->image);
-  for (auto& a : t->pool_free) (void)hipFree(a.first);
-  for (auto* c : t->ctx_idle) {
-    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-    if (c->h) (void)hipHostFree(c->h);
-    if (c->d) (void)hipFree(c->d);
-    delete c;
-  }
-  delete t;
-}
+extern "C" const char* cbh_table_broadcast_kind(const cbh_table* t) { return t ? t->bcast : "none"; }
 extern "C" uint32_t cbh_table_num_strings(const cbh_table* t) { return t ? t->meta[CBH_M_NSTRINGS] : 0; }
 extern "C" uint32_t cbh_table_num_columns(const cbh_table* t) { return t ? t->meta[CBH_M_NCOLUMNS] : 0; }
 extern "C" uint64_t cbh_table_device_bytes(const cbh_table* t) { return t ? t->image_len : 0; }
-extern "C" void* cbh_table_device_ptr(const cbh_table* t) { return t ? t->image : nullptr; }
+extern "C" void* cbh_table_device_ptr(const cbh_table* t) { return t ? t->reps[0]->image : nullptr; }
 
-// Device buffers of batches come from a per-table pool of power-of-two blocks: a small synchronous
+// ---- batch validation (O(n_requests), both entry points) ---------------------------------------------------
+// Offsets and counts the kernels index device memory with must lie inside the arrays they index.  String ids
+// need no host pass: the kernels only compare them, or bound them before using one as an index.
+struct BatchShape { u32 max_actions = 0; bool ascending = true; };
+static int validate_batch(const cbh_table* t, const cbh_batch* in, BatchShape& sh) {
+  if (in->n_columns != t->meta[CBH_M_NCOLUMNS]) return fail("cbh_batch.n_columns does not match the table's column schema");
+  const size_t NR = in->n_requests;
+  if (NR && !in->req_u32) return fail("cbh_batch: a required array is NULL");
+  if (in->n_tuples && !in->tuple_action) return fail("cbh_batch: a required array is NULL");
+  if (in->n_roles && !in->roles) return fail("cbh_batch: a required array is NULL");
+  if (NR && in->n_columns && (!in->col_tag || !in->col_val)) return fail("cbh_batch: a required array is NULL");
+  if (in->heap_len && (!in->heap_tag || !in->heap_val)) return fail("cbh_batch: a required array is NULL");
+  if (in->n_strings && (!in->str_off || !in->str_flags)) return fail("cbh_batch: a required array is NULL");
+  if (in->str_bytes_len && !in->str_bytes) return fail("cbh_batch: a required array is NULL");
+  const u32* role_off = in->req_u32 + (size_t)CBH_RQ_ROLE_OFF * NR; const u32* role_cnt = in->req_u32 + (size_t)CBH_RQ_ROLE_CNT * NR;
+  const u32* act_off = in->req_u32 + (size_t)CBH_RQ_ACT_OFF * NR; const u32* act_cnt = in->req_u32 + (size_t)CBH_RQ_ACT_CNT * NR;
+  u32 maxa = 0; u64 bad = 0, prev_end = 0; bool asc = true;
+  for (size_t r = 0; r < NR; ++r) {
+    const u32 n = act_cnt[r];
+    maxa = n > maxa ? n : maxa;
+    bad |= (u64)((u64)role_off[r] + role_cnt[r] > in->n_roles) | (u64)((u64)act_off[r] + n > in->n_tuples);
+    asc = asc && act_off[r] >= prev_end;
+    prev_end = (u64)act_off[r] + n;
+  }
+  if (maxa > CBH_MAX_ACTIONS_PER_REQUEST) return fail("cbh_batch: a request carries more than CBH_MAX_ACTIONS_PER_REQUEST actions");
+  if (bad) return fail("cbh_batch: a request's role or action slice lies outside the batch");
+  if (in->n_strings && in->str_off[in->n_strings] > in->str_bytes_len) return fail("cbh_batch: string offsets exceed str_bytes_len");
+  sh.max_actions = maxa; sh.ascending = asc;
+  return 0;
+}
+
+// ---- resident path ----------------------------------------------------------------------------------------
+// Device buffers of batches come from a per-replica pool of power-of-two blocks: a small synchronous
 // CheckResources round trip must not pay ~17 hipMalloc / hipFree pairs (each hipFree also
-// synchronises the device).  Blocks go back to the pool on cbh_batch_release and to the driver on
-// cbh_table_release.
+// synchronises the device).  Blocks go back to the pool on cbh_batch_release and to the driver when the
+// table goes.
 static int pool_alloc(cbh_device_batch* b, size_t bytes, void** out) {
   size_t cap = 256;
   while (cap < bytes) cap <<= 1;
-  cbh_table* t = b->table;
+  Replica* r = b->rep;
   {
-    std::lock_guard<std::mutex> lk(t->pool_mu);
-    for (size_t i = 0; i < t->pool_free.size(); ++i)
-      if (t->pool_free[i].second == cap) {
-        *out = t->pool_free[i].first;
-        t->pool_free[i] = t->pool_free.back(); t->pool_free.pop_back();
+    std::lock_guard<std::mutex> lk(r->pool_mu);
+    for (size_t i = 0; i < r->pool_free.size(); ++i)
+      if (r->pool_free[i].second == cap) {
+        *out = r->pool_free[i].first;
+        r->pool_free[i] = r->pool_free.back(); r->pool_free.pop_back();
         b->allocs.push_back({*out, cap});
         return 0;
       }
@@ -179,14 +377,14 @@ static int pool_alloc(cbh_device_batch* b, size_t bytes, void** out) {
 
 extern "C" void cbh_batch_release(cbh_device_batch* b) {
   if (!b) return;
-  if (b->table) {
-    (void)hipSetDevice(b->table->device); (void)hipStreamSynchronize(b->table->stream);
-    std::lock_guard<std::mutex> lk(b->table->pool_mu);
-    for (auto& a : b->allocs) b->table->pool_free.push_back(a);
-  } else {
-    for (auto& a : b->allocs) (void)hipFree(a.first);
+  cbh_table* t = b->table;
+  (void)hipSetDevice(b->rep->device); (void)hipStreamSynchronize(b->rep->stream);
+  {
+    std::lock_guard<std::mutex> lk(b->rep->pool_mu);
+    for (auto& a : b->allocs) b->rep->pool_free.push_back(a);
   }
   delete b;
+  cbh_table_release(t);   // the reference the batch held
 }
 
 template <typename T>
@@ -195,10 +393,7 @@ static int up(cbh_device_batch* b, const T*& dst, const T* src, size_t n, hipStr
   size_t bytes = (n ? n : 1) * sizeof(T);
   void* p = nullptr;
   if (pool_alloc(b, bytes, &p) != 0) return -1;
-  if (n) {
-    if (!src) return fail("cbh_batch: a required array is NULL");
-    HIPCHK(hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
-  }
+  if (n) HIPCHK(hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, s));
   dst = static_cast<const T*>(p);
   return 0;
 }
@@ -210,28 +405,33 @@ static int dalloc(cbh_device_batch* b, T*& dst, size_t n) {
   return 0;
 }
 
-extern "C" int cbh_batch_upload(cbh_table* t, const cbh_batch* in, cbh_device_batch** out) {
+extern "C" int cbh_batch_upload_on(cbh_table* t, uint32_t device_index, const cbh_batch* in, cbh_device_batch** out) {
   if (!t || !in || !out) return fail("null argument");
-  if (in->n_columns != t->meta[CBH_M_NCOLUMNS]) return fail("cbh_batch.n_columns does not match the table's column schema");
-  HIPCHK(hipSetDevice(t->device));
+  if (device_index >= t->reps.size()) return fail("device index out of range");
+  BatchShape sh;
+  if (validate_batch(t, in, sh) != 0) return -1;
+  Replica* rep = t->reps[device_index];
+  HIPCHK(hipSetDevice(rep->device));
   cbh_device_batch* b = new (std::nothrow) cbh_device_batch();
   if (!b) return fail("out of memory");
-  b->table = t;
+  cbh_table_retain(t);
+  b->table = t; b->rep = rep; b->max_actions = sh.max_actions;
   BatchDev& d = b->dev;
   d.n_requests = in->n_requests; d.n_tuples = in->n_tuples; d.n_roles = in->n_roles;
   d.n_columns = in->n_columns; d.n_strings = in->n_strings; d.heap_len = in->heap_len;
-  hipStream_t s = t->stream;
+  d.req_lo = 0; d.req_hi = in->n_requests;
+  hipStream_t s = rep->stream;
   const size_t NR = in->n_requests;
   int rc = 0;
   rc |= up(b, d.req_u32, in->req_u32, (size_t)CBH_RQ_NFIELDS * NR, s);
   rc |= up(b, d.roles, in->roles, in->n_roles, s);
-  rc |= up(b, d.tuple_req, in->tuple_req, in->n_tuples, s);
+  d.tuple_req = nullptr;   // informational on the host side; no kernel reads it
   rc |= up(b, d.tuple_action, in->tuple_action, in->n_tuples, s);
   rc |= up(b, d.col_tag, in->col_tag, (size_t)in->n_columns * NR, s);
   rc |= up(b, d.col_val, in->col_val, (size_t)in->n_columns * NR, s);
   rc |= up(b, d.heap_tag, in->heap_tag, in->heap_len, s);
   rc |= up(b, d.heap_val, in->heap_val, in->heap_len, s);
-  rc |= up(b, d.str_off, in->str_off, (size_t)in->n_strings + 1, s);
+  rc |= up(b, d.str_off, in->str_off, in->n_strings ? (size_t)in->n_strings + 1 : 0, s);
   rc |= up(b, d.str_bytes, in->str_bytes, in->str_bytes_len, s);
   rc |= up(b, d.str_flags, in->str_flags, in->n_strings, s);
   rc |= dalloc(b, d.gbits, (size_t)3 * in->n_strings);
@@ -241,11 +441,6 @@ extern "C" int cbh_batch_upload(cbh_table* t, const cbh_batch* in, cbh_device_ba
   rc |= dalloc(b, b->out.status, in->n_tuples);
   rc |= dalloc(b, b->out.edr, NR);
   rc |= dalloc(b, b->d_args, 1);
-  for (size_t r = 0; r < NR; ++r) {
-    const u32 n = in->req_u32[(size_t)CBH_RQ_ACT_CNT * NR + r];
-    if (n > CBH_MAX_ACTIONS_PER_REQUEST) { cbh_batch_release(b); return fail("cbh_batch: a request carries more than CBH_MAX_ACTIONS_PER_REQUEST actions"); }
-    if (n > b->max_actions) b->max_actions = n;
-  }
   if (rc != 0) { cbh_batch_release(b); return -1; }
   // glob bits of the batch-local strings: all zero unless the table has automata to run (then
   // cbh_check_resident overwrites every word on each launch)
@@ -256,44 +451,52 @@ extern "C" int cbh_batch_upload(cbh_table* t, const cbh_batch* in, cbh_device_ba
   *out = b;
   return 0;
 }
+extern "C" int cbh_batch_upload(cbh_table* t, const cbh_batch* in, cbh_device_batch** out) { return cbh_batch_upload_on(t, 0, in, out); }
 
-static void collect_slot(cbh_table* t, cbh_table::Slot& sl) {   // the slot's last event has completed
+static void collect_slot(Replica* r, Replica::Slot& sl) {   // the slot's last event has completed
   if (!sl.pending) return;
   float a = 0, c = 0;
   if (sl.resolved && hipEventElapsedTime(&a, sl.ev[0], sl.ev[1]) != hipSuccess) a = 0;
   if (hipEventElapsedTime(&c, sl.ev[2], sl.ev[3]) == hipSuccess) {
-    t->resolve_ms_sum += a; t->check_ms_sum += c; t->timed += 1;
+    r->resolve_ms_sum += a; r->check_ms_sum += c; r->timed += 1;
   }
   sl.pending = false;
 }
-static void collect_times(cbh_table* t) {   // after the stream has been synchronised
-  for (auto& sl : t->ring) collect_slot(t, sl);
+static void collect_times(Replica* r) {   // after the stream has been synchronised
+  for (auto& sl : r->ring) collect_slot(r, sl);
+}
+
+static u32 nfa_maxw(const TableDev& d) { return std::max(std::max(d.nfa_words[0], d.nfa_words[1]), d.nfa_words[2]); }
+static size_t check_lds_bytes(const BatchDev& d) {   // column cache: value low / high / tag dword per lane
+  const u32 ncc = d.n_columns < CBH_CACHE_COLS ? d.n_columns : CBH_CACHE_COLS;
+  return (size_t)ncc * CBH_BLOCK * 12;
 }
 
 extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_params* p) {
   if (!t || !b || !p) return fail("null argument");
   if (b->table != t) return fail("batch was uploaded for a different table");
-  std::lock_guard<std::mutex> lk(t->mu);
-  HIPCHK(hipSetDevice(t->device));
-  hipStream_t s = t->stream;
+  Replica* rep = b->rep;
+  std::lock_guard<std::mutex> lk(rep->mu);
+  HIPCHK(hipSetDevice(rep->device));
+  hipStream_t s = rep->stream;
   // Kernel durations come from the dispatches' own begin / end timestamps (hipExtLaunchKernelGGL
   // with start / stop events: what rocprofv3's kernel trace reads too), not from event-record
   // packets placed around them, which would sit between back-to-back launches and add their own
   // latency to the figure.
   // Every fourth launch is timed (and the first few, so that a short run has a figure): a
   // timestamped dispatch costs the queue a little more than a plain one.
-  const uint64_t launch_no = t->launches++;
+  const uint64_t launch_no = rep->launches++;
   const bool timed = launch_no < 4 || (launch_no & 3) == 0;
-  cbh_table::Slot scratch_slot;
-  cbh_table::Slot& sl = timed ? t->ring[t->next_slot++ % cbh_table::RING] : scratch_slot;
-  if (timed && sl.pending) { HIPCHK(hipEventSynchronize(sl.ev[3])); collect_slot(t, sl); }
+  Replica::Slot scratch_slot;
+  Replica::Slot& sl = timed ? rep->ring[rep->next_slot++ % Replica::RING] : scratch_slot;
+  if (timed && sl.pending) { HIPCHK(hipEventSynchronize(sl.ev[3])); collect_slot(rep, sl); }
   const BatchDev& d = b->dev;
   {
     // launch arguments live in device memory; re-sent only when they change (the kernel itself
     // writes every output word of every request, so nothing needs clearing between launches)
     KernelArgs ka;
     std::memset(&ka, 0, sizeof(ka));
-    ka.t = t->dev; ka.b = d; ka.o = b->out; ka.now_ns = p->now_ns; ka.flags = p->flags;
+    ka.t = rep->dev; ka.b = d; ka.o = b->out; ka.now_ns = p->now_ns; ka.flags = p->flags;
     if (!b->have_args || std::memcmp(&ka, &b->last_args, sizeof(ka)) != 0) {
       b->last_args = ka; b->have_args = true;
       HIPCHK(hipMemcpyAsync(b->d_args, &b->last_args, sizeof(ka), hipMemcpyHostToDevice, s));
@@ -301,22 +504,20 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   }
   // batch-local strings against the table's glob automata; a table without globs has nothing to
   // resolve (the bits were zeroed once at upload)
-  const u32 maxw = std::max(std::max(t->dev.nfa_words[0], t->dev.nfa_words[1]), t->dev.nfa_words[2]);
+  const u32 maxw = nfa_maxw(rep->dev);
   sl.resolved = d.n_strings && maxw;
   if (sl.resolved) {
     const u32 grid = (d.n_strings + CBH_BLOCK - 1) / CBH_BLOCK;
     const size_t lds = (size_t)(2 + 512) * maxw * sizeof(u64);
-    if (timed) hipExtLaunchKernelGGL(cbh_resolve_globs_kernel, dim3(grid), dim3(CBH_BLOCK), lds, s, sl.ev[0], sl.ev[1], 0, t->dev, d);
-    else hipLaunchKernelGGL(cbh_resolve_globs_kernel, dim3(grid), dim3(CBH_BLOCK), lds, s, t->dev, d);
+    if (timed) hipExtLaunchKernelGGL(cbh_resolve_globs_kernel, dim3(grid), dim3(CBH_BLOCK), lds, s, sl.ev[0], sl.ev[1], 0, rep->dev, d);
+    else hipLaunchKernelGGL(cbh_resolve_globs_kernel, dim3(grid), dim3(CBH_BLOCK), lds, s, rep->dev, d);
   }
   sl.pending = false;
   if (d.n_requests) {
     const u32 grid = (d.n_requests + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
-    const u32 ncc = d.n_columns < CBH_CACHE_COLS ? d.n_columns : CBH_CACHE_COLS;
-    const size_t dyn_lds = (size_t)ncc * CBH_BLOCK * 12;   // column cache: value low / high / tag dword per lane
-    const cbh_check_kernel_fn kernel = cbh_pick_check_kernel(t->dev.flags, t->dev.n_dr, maxw != 0 || (t->dev.flags & CBH_MF_HAS_ANY_PATTERN), b->max_actions);
-    if (timed) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), dyn_lds, s, sl.ev[2], sl.ev[3], 0, b->last_args, (const KernelArgs*)b->d_args);
-    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), dyn_lds, s, b->last_args, (const KernelArgs*)b->d_args);
+    const cbh_check_kernel_fn kernel = cbh_pick_check_kernel(rep->dev.flags, rep->dev.n_dr, maxw != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), b->max_actions);
+    if (timed) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), check_lds_bytes(d), s, sl.ev[2], sl.ev[3], 0, b->last_args, (const KernelArgs*)b->d_args);
+    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), check_lds_bytes(d), s, b->last_args, (const KernelArgs*)b->d_args);
     sl.pending = timed;
   }
   HIPCHK(hipGetLastError());
@@ -325,29 +526,36 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
 
 extern "C" int cbh_synchronize(cbh_table* t) {
   if (!t) return fail("null argument");
-  std::lock_guard<std::mutex> lk(t->mu);
-  HIPCHK(hipSetDevice(t->device));
-  HIPCHK(hipStreamSynchronize(t->stream));
-  collect_times(t);
+  for (Replica* rep : t->reps) {
+    std::lock_guard<std::mutex> lk(rep->mu);
+    HIPCHK(hipSetDevice(rep->device));
+    HIPCHK(hipStreamSynchronize(rep->stream));
+    collect_times(rep);
+  }
   return 0;
 }
 
 extern "C" int cbh_kernel_time_ms(cbh_table* t, float* check_ms, float* resolve_ms) {
   if (!t) return fail("null argument");
-  std::lock_guard<std::mutex> lk(t->mu);
-  if (t->timed == 0) return fail("no timed launches yet");
-  if (check_ms) *check_ms = (float)(t->check_ms_sum / (double)t->timed);
-  if (resolve_ms) *resolve_ms = (float)(t->resolve_ms_sum / (double)t->timed);
-  t->check_ms_sum = t->resolve_ms_sum = 0; t->timed = 0;
+  double c = 0, r = 0; uint64_t n = 0;
+  for (Replica* rep : t->reps) {
+    std::lock_guard<std::mutex> lk(rep->mu);
+    c += rep->check_ms_sum; r += rep->resolve_ms_sum; n += rep->timed;
+    rep->check_ms_sum = rep->resolve_ms_sum = 0; rep->timed = 0;
+  }
+  if (n == 0) return fail("no timed launches yet");
+  if (check_ms) *check_ms = (float)(c / (double)n);
+  if (resolve_ms) *resolve_ms = (float)(r / (double)n);
   return 0;
 }
 
 extern "C" int cbh_result_download(cbh_table* t, cbh_device_batch* b, cbh_result* out) {
   if (!t || !b || !out) return fail("null argument");
   if (b->dev.n_tuples && !out->effect) return fail("cbh_result.effect is required");
-  std::lock_guard<std::mutex> lk(t->mu);
-  HIPCHK(hipSetDevice(t->device));
-  hipStream_t s = t->stream;
+  Replica* rep = b->rep;
+  std::lock_guard<std::mutex> lk(rep->mu);
+  HIPCHK(hipSetDevice(rep->device));
+  hipStream_t s = rep->stream;
   const BatchDev& d = b->dev;
   if (d.n_tuples) HIPCHK(hipMemcpyAsync(out->effect, b->out.effect, d.n_tuples, hipMemcpyDeviceToHost, s));
   if (out->policy && d.n_tuples) HIPCHK(hipMemcpyAsync(out->policy, b->out.policy, (size_t)d.n_tuples * 4, hipMemcpyDeviceToHost, s));
@@ -355,47 +563,53 @@ extern "C" int cbh_result_download(cbh_table* t, cbh_device_batch* b, cbh_result
   if (out->status && d.n_tuples) HIPCHK(hipMemcpyAsync(out->status, b->out.status, d.n_tuples, hipMemcpyDeviceToHost, s));
   if (out->edr_mask && d.n_requests) HIPCHK(hipMemcpyAsync(out->edr_mask, b->out.edr, (size_t)d.n_requests * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  collect_times(t);
+  collect_times(rep);
   return 0;
 }
 
 // ---- one-shot path: CheckResources round trip for a host batch ------------------------------------------
-// All arrays of the batch go into ONE device block.  A small batch (the latency case) is packed into
-// a pinned staging block and crosses PCIe in one copy each way; a large one copies array by array
-// straight from / to the caller's memory (the driver pins those pages on the fly, which beats a host
-// memcpy into staging).  Each call owns a context (stream + blocks), so concurrent callers overlap.
-static cbh_table::OneShot* ctx_acquire(cbh_table* t) {
-  std::unique_lock<std::mutex> lk(t->ctx_mu);
+// All arrays of the batch go into ONE device block per device used, laid out for the whole batch; a device
+// that decides the request range [lo, hi) receives only the slices of that range (the kernels address the
+// whole-batch layout through BatchDev.req_lo / req_hi).
+static OneShot* ctx_acquire(Replica* r) {
+  std::unique_lock<std::mutex> lk(r->ctx_mu);
   for (;;) {
-    if (!t->ctx_idle.empty()) { auto* c = t->ctx_idle.back(); t->ctx_idle.pop_back(); return c; }
-    if (t->ctx_count < cbh_table::MAX_ONESHOT) {
-      ++t->ctx_count;
+    if (!r->ctx_idle.empty()) { auto* c = r->ctx_idle.back(); r->ctx_idle.pop_back(); return c; }
+    if (r->ctx_count < Replica::MAX_ONESHOT) {
+      ++r->ctx_count;
       lk.unlock();
-      auto* c = new (std::nothrow) cbh_table::OneShot();
-      if (c && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; c = nullptr; }
-      if (!c) { lk.lock(); --t->ctx_count; t->ctx_cv.notify_one(); }
+      auto* c = new (std::nothrow) OneShot();
+      bool ok = c != nullptr;
+      for (int i = 0; ok && i < N_STREAMS; ++i) ok = hipStreamCreateWithFlags(&c->s[i], hipStreamNonBlocking) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&c->ev_setup, hipEventDisableTiming) == hipSuccess;
+      if (!ok) {
+        if (c) { for (auto& s : c->s) if (s) (void)hipStreamDestroy(s); if (c->ev_setup) (void)hipEventDestroy(c->ev_setup); delete c; c = nullptr; }
+        lk.lock(); --r->ctx_count; r->ctx_cv.notify_one();
+      }
       return c;
     }
-    t->ctx_cv.wait(lk);
+    r->ctx_cv.wait(lk);
   }
 }
 struct CtxLease {
-  cbh_table* t; cbh_table::OneShot* c;
+  Replica* r; OneShot* c;
+  int used = N_STREAMS;   // streams the call has touched
   ~CtxLease() {
     if (!c) return;
-    (void)hipStreamSynchronize(c->stream);   // an error return must not leave copies from caller memory in flight
-    { std::lock_guard<std::mutex> lk(t->ctx_mu); t->ctx_idle.push_back(c); }
-    t->ctx_cv.notify_one();
+    (void)hipSetDevice(r->device);
+    for (int i = 0; i < used; ++i) (void)hipStreamSynchronize(c->s[i]);   // an error return must not leave copies from caller memory in flight
+    { std::lock_guard<std::mutex> lk(r->ctx_mu); r->ctx_idle.push_back(c); }
+    r->ctx_cv.notify_one();
   }
 };
-static int ctx_reserve(cbh_table::OneShot* c, size_t hbytes, size_t dbytes) {
+static int ctx_reserve(OneShot* c, size_t hbytes, size_t dbytes) {
   if (hbytes > c->h_cap) {
     if (c->h) { (void)hipHostFree(c->h); c->h = nullptr; c->h_cap = 0; }
     size_t cap = 1 << 16; while (cap < hbytes) cap <<= 1;
     HIPCHK(hipHostMalloc((void**)&c->h, cap, hipHostMallocDefault));
     c->h_cap = cap;
   }
-  if (dbytes > c->d_cap) {
+  if (dbytes && dbytes > c->d_cap) {
     if (c->d) { (void)hipFree(c->d); c->d = nullptr; c->d_cap = 0; }
     size_t cap = 1 << 16; while (cap < dbytes) cap <<= 1;
     HIPCHK(hipMalloc((void**)&c->d, cap));
@@ -404,94 +618,347 @@ static int ctx_reserve(cbh_table::OneShot* c, size_t hbytes, size_t dbytes) {
   return 0;
 }
 
-extern "C" int cbh_check_batch(cbh_table* t, const cbh_batch* in, const cbh_params* p, cbh_result* out) {
-  if (!t || !in || !p || !out) return fail("null argument");
-  if (in->n_columns != t->meta[CBH_M_NCOLUMNS]) return fail("cbh_batch.n_columns does not match the table's column schema");
-  if (in->n_tuples && !out->effect) return fail("cbh_result.effect is required");
+static bool is_pinned(const void* p) {
+  if (!p) return true;   // an absent array does not decide
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+
+struct Seg { size_t off, bytes; const void* src; };
+// The canonical order of a batch's arrays.  It is the order of the device block AND of a caller's "slab" (one
+// page-locked block holding all arrays, cbh_batch_bind_slab): a slab crosses PCIe in ONE copy because the device
+// block mirrors it byte for byte.  What a table may not need comes last - the raw request strings (req_u32 rows
+// CBH_RQ_NCORE..), then the batch-local string pool - so that the one copy simply stops earlier.
+struct InOffsets { size_t roles, act, ctag, cval, htag, hval, req, soff, sbytes, sflags, end; };
+static InOffsets in_offsets(const cbh_batch* in) {
+  InOffsets o; size_t cur = 0;
   const size_t NR = in->n_requests, NT = in->n_tuples, NS = in->n_strings;
-  u32 max_actions = 0;
-  if (NR && !in->req_u32) return fail("cbh_batch: a required array is NULL");
-  for (size_t r = 0; r < NR; ++r) {
-    const u32 n = in->req_u32[(size_t)CBH_RQ_ACT_CNT * NR + r];
-    if (n > CBH_MAX_ACTIONS_PER_REQUEST) return fail("cbh_batch: a request carries more than CBH_MAX_ACTIONS_PER_REQUEST actions");
-    if (n > max_actions) max_actions = n;
+  auto seg = [&](size_t bytes) { const size_t at = cur; cur += (bytes + 255) & ~(size_t)255; return at; };
+  o.roles = seg((size_t)in->n_roles * 4); o.act = seg(NT * 4);
+  o.ctag = seg((size_t)in->n_columns * NR + 4);   // + 4: a lane reads the aligned dword around its tag byte
+  o.cval = seg((size_t)in->n_columns * NR * 8);
+  o.htag = seg(in->heap_len); o.hval = seg((size_t)in->heap_len * 8);
+  o.req = seg((size_t)CBH_RQ_NFIELDS * NR * 4);
+  o.soff = seg(NS ? (NS + 1) * 4 : 0); o.sbytes = seg(in->str_bytes_len); o.sflags = seg(NS);
+  o.end = cur;
+  return o;
+}
+struct OutOffsets { size_t eff, status, pol, scope, edr, end; };
+static OutOffsets out_offsets(size_t NT, size_t NR) {
+  OutOffsets o; size_t cur = 0;
+  auto seg = [&](size_t bytes) { const size_t at = cur; cur += (bytes + 255) & ~(size_t)255; return at; };
+  o.eff = seg(NT); o.status = seg(NT); o.pol = seg(NT * 4); o.scope = seg(NT * 4); o.edr = seg(NR * 8);
+  o.end = cur;
+  return o;
+}
+extern "C" size_t cbh_batch_slab_bytes(const cbh_batch* counts) { return counts ? in_offsets(counts).end : 0; }
+extern "C" void cbh_batch_bind_slab(cbh_batch* b, void* slab) {
+  if (!b || !slab) return;
+  const InOffsets o = in_offsets(b);
+  uint8_t* p = static_cast<uint8_t*>(slab);
+  b->roles = (const uint32_t*)(p + o.roles); b->tuple_req = nullptr; b->tuple_action = (const uint32_t*)(p + o.act);
+  b->col_tag = p + o.ctag; b->col_val = (const uint64_t*)(p + o.cval); b->heap_tag = p + o.htag; b->heap_val = (const uint64_t*)(p + o.hval);
+  b->req_u32 = (const uint32_t*)(p + o.req); b->str_off = (const uint32_t*)(p + o.soff); b->str_bytes = p + o.sbytes; b->str_flags = p + o.sflags;
+}
+extern "C" size_t cbh_result_slab_bytes(uint32_t n_tuples, uint32_t n_requests) { return out_offsets(n_tuples, n_requests).end; }
+extern "C" void cbh_result_bind_slab(cbh_result* r, void* slab, uint32_t n_tuples, uint32_t n_requests) {
+  if (!r || !slab) return;
+  const OutOffsets o = out_offsets(n_tuples, n_requests);
+  uint8_t* p = static_cast<uint8_t*>(slab);
+  r->effect = p + o.eff; r->status = p + o.status; r->policy = (uint32_t*)(p + o.pol); r->scope = (uint32_t*)(p + o.scope); r->edr_mask = (uint64_t*)(p + o.edr);
+}
+
+struct Layout {
+  Seg args, req, roles, act, ctag, cval, htag, hval, soff, sbytes, sflags, gbits, eff, pol, scope, status, edr;
+  size_t in_begin, in_end, out_begin, total;
+};
+static Layout make_layout(const cbh_batch* in) {
+  Layout L;
+  const size_t NR = in->n_requests, NT = in->n_tuples, NS = in->n_strings;
+  const InOffsets io = in_offsets(in);
+  const size_t A = (sizeof(KernelArgs) + 255) & ~(size_t)255;
+  L.args = Seg{0, sizeof(KernelArgs), nullptr};
+  L.in_begin = A;
+  L.roles = Seg{A + io.roles, (size_t)in->n_roles * 4, in->roles}; L.act = Seg{A + io.act, NT * 4, in->tuple_action};
+  L.ctag = Seg{A + io.ctag, (size_t)in->n_columns * NR, in->col_tag}; L.cval = Seg{A + io.cval, (size_t)in->n_columns * NR * 8, in->col_val};
+  L.htag = Seg{A + io.htag, in->heap_len, in->heap_tag}; L.hval = Seg{A + io.hval, (size_t)in->heap_len * 8, in->heap_val};
+  L.req = Seg{A + io.req, (size_t)CBH_RQ_NFIELDS * NR * 4, in->req_u32};
+  L.soff = Seg{A + io.soff, NS ? (NS + 1) * 4 : 0, in->str_off}; L.sbytes = Seg{A + io.sbytes, in->str_bytes_len, in->str_bytes};
+  L.sflags = Seg{A + io.sflags, NS, in->str_flags};
+  L.in_end = A + io.end;
+  size_t cur = L.in_end;
+  L.gbits = Seg{cur, 3 * NS * 8, nullptr}; cur += (L.gbits.bytes + 255) & ~(size_t)255;
+  L.out_begin = cur;
+  const OutOffsets oo = out_offsets(NT, NR);
+  L.eff = Seg{cur + oo.eff, NT, nullptr}; L.status = Seg{cur + oo.status, NT, nullptr}; L.pol = Seg{cur + oo.pol, NT * 4, nullptr};
+  L.scope = Seg{cur + oo.scope, NT * 4, nullptr}; L.edr = Seg{cur + oo.edr, NR * 8, nullptr};
+  L.total = cur + oo.end;
+  return L;
+}
+// are the batch's arrays one slab in canonical order?  -> its base address, else nullptr
+static const uint8_t* slab_base(const Layout& L) {
+  const uint8_t* base = nullptr;
+  for (const Seg* g : {&L.roles, &L.act, &L.ctag, &L.cval, &L.htag, &L.hval, &L.req, &L.soff, &L.sbytes, &L.sflags}) {
+    if (!g->bytes) continue;
+    const uint8_t* b = static_cast<const uint8_t*>(g->src) - (g->off - L.in_begin);
+    if (!base) base = b; else if (b != base) return nullptr;
   }
-  // layout of the device block: [launch arguments | inputs ... | glob bits | outputs ...], 256-byte aligned pieces
-  struct Seg { size_t off, bytes; const void* src; };
-  size_t cur = 0;
-  auto seg = [&](const void* src, size_t bytes) { Seg g{cur, bytes, src}; cur += (bytes + 255) & ~(size_t)255; return g; };
-  const Seg s_args = seg(nullptr, sizeof(KernelArgs));
-  const Seg ins[11] = {
-    seg(in->req_u32, (size_t)CBH_RQ_NFIELDS * NR * 4), seg(in->roles, (size_t)in->n_roles * 4), seg(in->tuple_req, NT * 4),
-    seg(in->tuple_action, NT * 4), seg(in->col_tag, (size_t)in->n_columns * NR), seg(in->col_val, (size_t)in->n_columns * NR * 8),
-    seg(in->heap_tag, in->heap_len), seg(in->heap_val, (size_t)in->heap_len * 8), seg(in->str_off, (NS + 1) * 4),
-    seg(in->str_bytes, in->str_bytes_len), seg(in->str_flags, NS)};
-  for (const Seg& g : ins) if (g.bytes && !g.src) return fail("cbh_batch: a required array is NULL");
-  const size_t in_end = cur;
-  const Seg s_gbits = seg(nullptr, 3 * NS * 8);
-  const size_t out_begin = cur;
-  const Seg s_eff = seg(nullptr, NT), s_pol = seg(nullptr, NT * 4), s_scope = seg(nullptr, NT * 4), s_status = seg(nullptr, NT),
-            s_edr = seg(nullptr, NR * 8);
-  const size_t total = cur;
-  const bool staged = in_end <= ((size_t)4 << 20);
-
-  HIPCHK(hipSetDevice(t->device));
-  CtxLease lease{t, ctx_acquire(t)};
-  cbh_table::OneShot* c = lease.c;
-  if (!c) return fail("could not create a launch context");
-  if (ctx_reserve(c, staged ? total : 256, total) != 0) return -1;
-  hipStream_t s = c->stream;
-
-  KernelArgs ka;
+  return base;
+}
+static void bind_args(KernelArgs& ka, const TableDev& tdev, const cbh_batch* in, const cbh_params* p, const Layout& L, uint8_t* base) {
   std::memset(&ka, 0, sizeof(ka));
-  ka.t = t->dev; ka.now_ns = p->now_ns; ka.flags = p->flags;
+  ka.t = tdev; ka.now_ns = p->now_ns; ka.flags = p->flags;
   BatchDev& d = ka.b;
   d.n_requests = in->n_requests; d.n_tuples = in->n_tuples; d.n_roles = in->n_roles;
   d.n_columns = in->n_columns; d.n_strings = in->n_strings; d.heap_len = in->heap_len;
-  uint8_t* base = c->d;
-  d.req_u32 = (const u32*)(base + ins[0].off); d.roles = (const u32*)(base + ins[1].off); d.tuple_req = (const u32*)(base + ins[2].off);
-  d.tuple_action = (const u32*)(base + ins[3].off); d.col_tag = base + ins[4].off; d.col_val = (const u64*)(base + ins[5].off);
-  d.heap_tag = base + ins[6].off; d.heap_val = (const u64*)(base + ins[7].off); d.str_off = (const u32*)(base + ins[8].off);
-  d.str_bytes = base + ins[9].off; d.str_flags = base + ins[10].off; d.gbits = (u64*)(base + s_gbits.off);
-  ka.o.effect = base + s_eff.off; ka.o.policy = (u32*)(base + s_pol.off); ka.o.scope = (u32*)(base + s_scope.off);
-  ka.o.status = base + s_status.off; ka.o.edr = (u64*)(base + s_edr.off);
+  d.req_lo = 0; d.req_hi = in->n_requests;
+  d.req_u32 = (const u32*)(base + L.req.off); d.roles = (const u32*)(base + L.roles.off); d.tuple_req = nullptr;
+  d.tuple_action = (const u32*)(base + L.act.off); d.col_tag = base + L.ctag.off; d.col_val = (const u64*)(base + L.cval.off);
+  d.heap_tag = base + L.htag.off; d.heap_val = (const u64*)(base + L.hval.off); d.str_off = (const u32*)(base + L.soff.off);
+  d.str_bytes = base + L.sbytes.off; d.str_flags = base + L.sflags.off; d.gbits = (u64*)(base + L.gbits.off);
+  ka.o.effect = base + L.eff.off; ka.o.policy = (u32*)(base + L.pol.off); ka.o.scope = (u32*)(base + L.scope.off);
+  ka.o.status = base + L.status.off; ka.o.edr = (u64*)(base + L.edr.off);
+}
+static void launch_resolve(const Replica* rep, const KernelArgs& ka, const Layout& L, hipStream_t s, int& rc) {
+  const u32 maxw = nfa_maxw(rep->dev);
+  if (!ka.b.n_strings) return;
+  if (maxw) {
+    const u32 grid = (ka.b.n_strings + CBH_BLOCK - 1) / CBH_BLOCK;
+    hipLaunchKernelGGL(cbh_resolve_globs_kernel, dim3(grid), dim3(CBH_BLOCK), (size_t)(2 + 512) * maxw * sizeof(u64), s, rep->dev, ka.b);
+  } else if (hipMemsetAsync(ka.b.gbits, 0, L.gbits.bytes, s) != hipSuccess) rc = -1;   // no automata: no string matches a glob
+}
+static void launch_check(const Replica* rep, KernelArgs ka, const KernelArgs* d_args, u32 lo, u32 hi, u32 max_actions, hipStream_t s) {
+  if (hi <= lo) return;
+  ka.b.req_lo = lo; ka.b.req_hi = hi;
+  const u32 grid = (hi - lo + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
+  const cbh_check_kernel_fn kernel = cbh_pick_check_kernel(rep->dev.flags, rep->dev.n_dr, nfa_maxw(rep->dev) != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), max_actions);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), check_lds_bytes(ka.b), s, ka, d_args);
+}
 
-  std::memcpy(c->h + s_args.off, &ka, sizeof(ka));
-  if (staged) {
-    for (const Seg& g : ins) if (g.bytes) std::memcpy(c->h + g.off, g.src, g.bytes);
-    HIPCHK(hipMemcpyAsync(base, c->h, in_end, hipMemcpyHostToDevice, s));
+// a small batch on one device: everything packed into the pinned staging block.  Two ways across PCIe:
+//   copy      one H2D of the inputs, kernels on device memory, one D2H of the results (three queue operations);
+//   zero-copy the kernels read the inputs from, and write the results to, the page-locked block itself (it is
+//             mapped into the device's address space): a few KB per request wave over PCIe, ONE queue operation.
+// Zero-copy wins while a batch is a handful of waves (the latency case); the choice is by input size.
+static int run_small(cbh_table* t, Replica* rep, const cbh_batch* in, const cbh_params* p, cbh_result* out, const BatchShape& sh, const Layout& L) {
+  HIPCHK(hipSetDevice(rep->device));
+  CtxLease lease{rep, ctx_acquire(rep)};
+  OneShot* c = lease.c;
+  if (!c) return fail("could not create a launch context");
+  static const size_t zc_limit = [] { const char* e = getenv("CBH_ZEROCOPY_BYTES"); return e ? (size_t)atol(e) : (size_t)(64 << 10); }();
+  const bool zero_copy = L.in_end <= zc_limit;
+  if (ctx_reserve(c, L.total, zero_copy ? 0 : L.total) != 0) return -1;
+  hipStream_t s = c->s[0];
+  lease.used = 1;
+  const double t_0 = trace_on() ? now_us() : 0;
+  uint8_t* base = c->d;
+  if (zero_copy) HIPCHK(hipHostGetDevicePointer((void**)&base, c->h, 0));
+  KernelArgs ka;
+  bind_args(ka, rep->dev, in, p, L, base);
+  std::memcpy(c->h + L.args.off, &ka, sizeof(ka));
+  for (const Seg* g : {&L.req, &L.roles, &L.act, &L.ctag, &L.cval, &L.htag, &L.hval, &L.soff, &L.sbytes, &L.sflags})
+    if (g->bytes) std::memcpy(c->h + g->off, g->src, g->bytes);
+  int rc = 0;
+  if (zero_copy) {
+    if (in->n_strings && !nfa_maxw(rep->dev)) std::memset(c->h + L.gbits.off, 0, L.gbits.bytes);   // no automata: no string matches a glob
+    else launch_resolve(rep, ka, L, s, rc);
   } else {
-    HIPCHK(hipMemcpyAsync(base, c->h, sizeof(ka), hipMemcpyHostToDevice, s));
-    for (const Seg& g : ins) if (g.bytes) HIPCHK(hipMemcpyAsync(base + g.off, g.src, g.bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d, c->h, L.in_end, hipMemcpyHostToDevice, s));
+    launch_resolve(rep, ka, L, s, rc);
   }
-  const u32 maxw = std::max(std::max(t->dev.nfa_words[0], t->dev.nfa_words[1]), t->dev.nfa_words[2]);
-  if (NS) {
-    if (maxw) {
-      const u32 grid = (d.n_strings + CBH_BLOCK - 1) / CBH_BLOCK;
-      const size_t lds = (size_t)(2 + 512) * maxw * sizeof(u64);
-      hipLaunchKernelGGL(cbh_resolve_globs_kernel, dim3(grid), dim3(CBH_BLOCK), lds, s, t->dev, d);
-    } else {
-      HIPCHK(hipMemsetAsync(d.gbits, 0, s_gbits.bytes, s));   // no automata: no string matches a glob
+  launch_check(rep, ka, (const KernelArgs*)(base + L.args.off), 0, in->n_requests, sh.max_actions, s);
+  HIPCHK(hipGetLastError());
+  if (rc != 0) return fail("hipMemsetAsync failed");
+  if (!zero_copy && L.total > L.out_begin) HIPCHK(hipMemcpyAsync(c->h + L.out_begin, c->d + L.out_begin, L.total - L.out_begin, hipMemcpyDeviceToHost, s));
+  const double t_1 = trace_on() ? now_us() : 0;
+  HIPCHK(stream_wait(s));
+  if (trace_on()) std::fprintf(stderr, "[cbh] small zero_copy=%d in=%zu B enqueue=%.1f us wait=%.1f us\n", (int)zero_copy, L.in_end, t_1 - t_0, now_us() - t_1);
+  struct Dst { const Seg* g; void* dst; };
+  const Dst outs[5] = {{&L.eff, out->effect}, {&L.pol, out->policy}, {&L.scope, out->scope}, {&L.status, out->status}, {&L.edr, out->edr_mask}};
+  for (const Dst& o : outs) if (o.dst && o.g->bytes) std::memcpy(o.dst, c->h + o.g->off, o.g->bytes);
+  (void)t;
+  return 0;
+}
+
+// the request range [lo, hi) of a large batch on one device
+static int run_range(cbh_table* t, Replica* rep, const cbh_batch* in, const cbh_params* p, cbh_result* out, const BatchShape& sh,
+                     const Layout& L, u32 lo, u32 hi, bool pinned, u32 chunk_requests) {
+  HIPCHK(hipSetDevice(rep->device));
+  CtxLease lease{rep, ctx_acquire(rep)};
+  OneShot* c = lease.c;
+  if (!c) return fail("could not create a launch context");
+  const double t_0 = trace_on() ? now_us() : 0;
+  if (ctx_reserve(c, 4096, L.total) != 0) return -1;
+  const size_t NR = in->n_requests;
+  const bool whole = lo == 0 && hi == NR;
+  KernelArgs ka;
+  uint8_t* base = c->d;
+  bind_args(ka, rep->dev, in, p, L, base);
+  std::memcpy(c->h, &ka, sizeof(ka));
+  const KernelArgs* d_args = (const KernelArgs*)(base + L.args.off);
+  const u32* act_off = in->req_u32 + (size_t)CBH_RQ_ACT_OFF * NR; const u32* act_cnt = in->req_u32 + (size_t)CBH_RQ_ACT_CNT * NR;
+  // tuples of the requests [a, b), a < b (ACT_OFF ascends whenever a batch is split; a batch in any other
+  // order is only ever handled whole)
+  auto tuples_of = [&](u32 a, u32 b, size_t& tb, size_t& te) {
+    if (!sh.ascending) { tb = 0; te = in->n_tuples; return; }
+    tb = act_off[a]; te = (size_t)act_off[b - 1] + act_cnt[b - 1];
+  };
+  const bool reads_strings = (rep->dev.flags & CBH_MF_READS_REQUEST_STRINGS) != 0;
+
+  const bool need_bytes = (rep->dev.flags & CBH_MF_NEEDS_STRING_BYTES) != 0;
+  hipStream_t s0 = c->s[0];
+  int rc = 0;
+
+  // ---- a slab (cbh_batch_bind_slab) in page-locked memory, decided whole on this device: ONE copy up - it stops
+  // before the raw request strings / the string pool when the table reads neither -, the kernels, and the
+  // results down in as few copies as the caller's result arrays are contiguous (one for a result slab)
+  const uint8_t* slab = (whole && pinned) ? slab_base(L) : nullptr;
+  if (slab) {
+    lease.used = 1;
+    const size_t end = need_bytes ? L.in_end : L.req.off + (size_t)(reads_strings ? CBH_RQ_NFIELDS : CBH_RQ_NCORE) * NR * 4;
+    HIPCHK(hipMemcpyAsync(base, c->h, sizeof(ka), hipMemcpyHostToDevice, s0));
+    HIPCHK(hipMemcpyAsync(base + L.in_begin, slab, end - L.in_begin, hipMemcpyHostToDevice, s0));
+    launch_resolve(rep, ka, L, s0, rc);
+    if (rc != 0) return fail("hipMemsetAsync failed");
+    launch_check(rep, ka, d_args, 0, (u32)NR, sh.max_actions, s0);
+    HIPCHK(hipGetLastError());
+    struct Run { size_t off, bytes; uint8_t* dst; };
+    Run run{0, 0, nullptr};
+    const Seg* segs[5] = {&L.eff, &L.status, &L.pol, &L.scope, &L.edr};
+    void* dsts[5] = {out->effect, out->status, out->policy, out->scope, out->edr_mask};
+    for (int i = 0; i < 5; ++i) {
+      if (!dsts[i] || !segs[i]->bytes) continue;
+      uint8_t* d = static_cast<uint8_t*>(dsts[i]);
+      if (run.dst && d == run.dst + (segs[i]->off - run.off)) { run.bytes = segs[i]->off + segs[i]->bytes - run.off; continue; }   // contiguous with the run: extend it
+      if (run.dst) HIPCHK(hipMemcpyAsync(run.dst, base + run.off, run.bytes, hipMemcpyDeviceToHost, s0));
+      run = Run{segs[i]->off, segs[i]->bytes, d};
     }
+    if (run.dst) HIPCHK(hipMemcpyAsync(run.dst, base + run.off, run.bytes, hipMemcpyDeviceToHost, s0));
+    const double t_1 = trace_on() ? now_us() : 0;
+    HIPCHK(stream_wait(s0));
+    if (trace_on()) std::fprintf(stderr, "[cbh] slab dev=%d up=%zu B enqueue=%.1f us wait=%.1f us\n", rep->device, end - L.in_begin, t_1 - t_0, now_us() - t_1);
+    return 0;
   }
-  if (NR) {
-    const u32 grid = (d.n_requests + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
-    const u32 ncc = d.n_columns < CBH_CACHE_COLS ? d.n_columns : CBH_CACHE_COLS;
-    const size_t dyn_lds = (size_t)ncc * CBH_BLOCK * 12;
-    const cbh_check_kernel_fn kernel = cbh_pick_check_kernel(t->dev.flags, t->dev.n_dr, maxw != 0 || (t->dev.flags & CBH_MF_HAS_ANY_PATTERN), max_actions);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), dyn_lds, s, ka, (const KernelArgs*)(base + s_args.off));
+
+  // ---- setup on stream 0: launch arguments + the arrays that are not per request (roles, heap, strings)
+  HIPCHK(hipMemcpyAsync(base, c->h, sizeof(ka), hipMemcpyHostToDevice, s0));
+  for (const Seg* g : {&L.roles, &L.htag, &L.hval, &L.soff, &L.sbytes, &L.sflags}) {
+    if (!need_bytes && (g == &L.soff || g == &L.sbytes || g == &L.sflags)) continue;   // no program looks inside a string
+    if (g->bytes) HIPCHK(hipMemcpyAsync(base + g->off, g->src, g->bytes, hipMemcpyHostToDevice, s0));
+  }
+  launch_resolve(rep, ka, L, s0, rc);
+  if (rc != 0) return fail("hipMemsetAsync failed");
+  HIPCHK(hipEventRecord(c->ev_setup, s0));
+
+  // rows [r0, r1) of a field-major [rows][NR] array of `esz`-byte elements, requests [a, b): one 2-D copy
+  static const int copy_mode = [] { const char* e = getenv("CBH_COPY_MODE"); return e ? atoi(e) : 0; }();   // 1: a row at a time instead of 2-D copies
+  auto up2d = [&](const Seg& g, size_t esz, u32 r0, u32 r1, u32 a, u32 b, hipStream_t s) -> hipError_t {
+    if (r1 <= r0 || b <= a) return hipSuccess;
+    const size_t pitch = NR * esz, o = (size_t)r0 * pitch + (size_t)a * esz;
+    if (a == 0 && b == NR) return hipMemcpyAsync(base + g.off + o, (const uint8_t*)g.src + o, (size_t)(r1 - r0) * pitch, hipMemcpyHostToDevice, s);
+    if (copy_mode == 1) {
+      for (u32 r = r0; r < r1; ++r) {
+        const size_t oo = (size_t)r * pitch + (size_t)a * esz;
+        const hipError_t e = hipMemcpyAsync(base + g.off + oo, (const uint8_t*)g.src + oo, (size_t)(b - a) * esz, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return e;
+      }
+      return hipSuccess;
+    }
+    return hipMemcpy2DAsync(base + g.off + o, pitch, (const uint8_t*)g.src + o, pitch, (size_t)(b - a) * esz, r1 - r0, hipMemcpyHostToDevice, s);
+  };
+  if (!pinned) {
+    // pageable arrays: the driver stages every copy itself and the calling thread waits for it - chunking buys
+    // nothing, so the range goes up array by array, is decided by one launch and comes down array by array
+    hipStream_t s = s0;
+    HIPCHK(up2d(L.req, 4, 0, reads_strings ? CBH_RQ_NFIELDS : CBH_RQ_NCORE, lo, hi, s));
+    HIPCHK(up2d(L.ctag, 1, 0, in->n_columns, lo, hi, s));
+    HIPCHK(up2d(L.cval, 8, 0, in->n_columns, lo, hi, s));
+    size_t tb = 0, te = 0;
+    if (hi > lo) tuples_of(lo, hi, tb, te);
+    if (te > tb) HIPCHK(hipMemcpyAsync(base + L.act.off + tb * 4, in->tuple_action + tb, (te - tb) * 4, hipMemcpyHostToDevice, s));
+    launch_check(rep, ka, d_args, lo, hi, sh.max_actions, s);
+    HIPCHK(hipGetLastError());
+    if (te > tb) {
+      HIPCHK(hipMemcpyAsync(out->effect + tb, base + L.eff.off + tb, te - tb, hipMemcpyDeviceToHost, s));
+      if (out->policy) HIPCHK(hipMemcpyAsync(out->policy + tb, base + L.pol.off + tb * 4, (te - tb) * 4, hipMemcpyDeviceToHost, s));
+      if (out->scope) HIPCHK(hipMemcpyAsync(out->scope + tb, base + L.scope.off + tb * 4, (te - tb) * 4, hipMemcpyDeviceToHost, s));
+      if (out->status) HIPCHK(hipMemcpyAsync(out->status + tb, base + L.status.off + tb, te - tb, hipMemcpyDeviceToHost, s));
+    }
+    if (out->edr_mask && hi > lo) HIPCHK(hipMemcpyAsync(out->edr_mask + lo, base + L.edr.off + (size_t)lo * 8, (size_t)(hi - lo) * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (trace_on()) std::fprintf(stderr, "[cbh] range [%u,%u) dev=%d pageable total=%.1f us\n", lo, hi, rep->device, now_us() - t_0);
+    (void)t;
+    return 0;
+  }
+  // ---- page-locked arrays: chunks of the range round-robin over the streams; on each stream a chunk is
+  // uploaded, decided and downloaded in order, and the three streams overlap each other's phases
+  u32 k = 0;
+  for (u32 a = lo; a < hi; a += chunk_requests, ++k) {
+    const u32 b = std::min<u64>((u64)a + chunk_requests, hi);
+    hipStream_t s = c->s[k % N_STREAMS];
+    if (k < (u32)N_STREAMS && s != s0) HIPCHK(hipStreamWaitEvent(s, c->ev_setup, 0));
+    if (reads_strings) HIPCHK(up2d(L.req, 4, 0, CBH_RQ_NFIELDS, a, b, s));
+    else HIPCHK(up2d(L.req, 4, 0, CBH_RQ_NCORE, a, b, s));
+    HIPCHK(up2d(L.ctag, 1, 0, in->n_columns, a, b, s));
+    HIPCHK(up2d(L.cval, 8, 0, in->n_columns, a, b, s));
+    size_t tb = 0, te = 0;
+    tuples_of(a, b, tb, te);
+    if (te > tb) HIPCHK(hipMemcpyAsync(base + L.act.off + tb * 4, in->tuple_action + tb, (te - tb) * 4, hipMemcpyHostToDevice, s));
+    launch_check(rep, ka, d_args, a, b, sh.max_actions, s);
+    if (te > tb) {
+      HIPCHK(hipMemcpyAsync(out->effect + tb, base + L.eff.off + tb, te - tb, hipMemcpyDeviceToHost, s));
+      if (out->policy) HIPCHK(hipMemcpyAsync(out->policy + tb, base + L.pol.off + tb * 4, (te - tb) * 4, hipMemcpyDeviceToHost, s));
+      if (out->scope) HIPCHK(hipMemcpyAsync(out->scope + tb, base + L.scope.off + tb * 4, (te - tb) * 4, hipMemcpyDeviceToHost, s));
+      if (out->status) HIPCHK(hipMemcpyAsync(out->status + tb, base + L.status.off + tb, te - tb, hipMemcpyDeviceToHost, s));
+    }
+    if (out->edr_mask) HIPCHK(hipMemcpyAsync(out->edr_mask + a, base + L.edr.off + (size_t)a * 8, (size_t)(b - a) * 8, hipMemcpyDeviceToHost, s));
   }
   HIPCHK(hipGetLastError());
-  struct Dst { const Seg* g; void* dst; };
-  const Dst outs[5] = {{&s_eff, out->effect}, {&s_pol, out->policy}, {&s_scope, out->scope}, {&s_status, out->status}, {&s_edr, out->edr_mask}};
-  if (staged) {
-    if (total > out_begin) HIPCHK(hipMemcpyAsync(c->h + out_begin, base + out_begin, total - out_begin, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    for (const Dst& o : outs) if (o.dst && o.g->bytes) std::memcpy(o.dst, c->h + o.g->off, o.g->bytes);
-  } else {
-    for (const Dst& o : outs) if (o.dst && o.g->bytes) HIPCHK(hipMemcpyAsync(o.dst, base + o.g->off, o.g->bytes, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-  }
+  const double t_1 = trace_on() ? now_us() : 0;
+  for (auto& s : c->s) HIPCHK(stream_wait(s));
+  if (trace_on()) std::fprintf(stderr, "[cbh] range [%u,%u) dev=%d pinned chunks=%u enqueue=%.1f us wait=%.1f us\n", lo, hi, rep->device, k, t_1 - t_0, now_us() - t_1);
+  return 0;
+}
+
+extern "C" int cbh_check_batch(cbh_table* t, const cbh_batch* in, const cbh_params* p, cbh_result* out) {
+  if (!t || !in || !p || !out) return fail("null argument");
+  if (in->n_tuples && !out->effect) return fail("cbh_result.effect is required");
+  TableRef ref(t);
+  BatchShape sh;
+  if (validate_batch(t, in, sh) != 0) return -1;
+  const Layout L = make_layout(in);
+  const u32 NR = in->n_requests;
+  if (L.in_end <= SMALL_BATCH_BYTES || NR == 0) return run_small(t, t->reps[0], in, p, out, sh, L);
+
+  // chunks of the three-stream pipeline carry at least ~32 MB of input each: a copy costs a fixed ~20 us on top of
+  // its bytes, so smaller chunks lose more to that than the overlap wins (measured, profiles/r02_oneshot_probe.txt)
+  const u32 chunk_env = [&] {
+    const char* e = getenv("CBH_CHUNK_REQUESTS"); long v = e ? atol(e) : 0;
+    if (v > 0) return (u32)((v + 63) & ~63l);
+    const size_t per_request = NR ? std::max<size_t>(1, (L.in_end - L.in_begin) / NR) : 1;
+    return (u32)std::min<size_t>(0xFFFFFFC0u, ((((size_t)32 << 20) / per_request) + 63) & ~(size_t)63);
+  }();
+  bool pinned = true;
+  for (const void* q : {(const void*)in->req_u32, (const void*)in->tuple_action, (const void*)in->col_tag, (const void*)in->col_val,
+                        (const void*)out->effect, (const void*)out->policy, (const void*)out->scope, (const void*)out->status, (const void*)out->edr_mask})
+    pinned = pinned && is_pinned(q);
+  // contiguous request ranges over the devices (engine.go:309-338 deals inputs to workers; here a worker is a GPU)
+  u32 n_dev = 1;
+  if (t->reps.size() > 1 && sh.ascending) n_dev = (u32)std::min<size_t>(t->reps.size(), std::max<u32>(1, NR / SHARD_MIN_REQUESTS));
+  if (n_dev == 1) return run_range(t, t->reps[0], in, p, out, sh, L, 0, NR, pinned, sh.ascending ? chunk_env : NR);
+  std::vector<int> rcs(n_dev, 0);
+  std::vector<std::string> errs(n_dev);
+  auto work = [&](u32 i) {
+    const u32 lo = (u32)(((u64)NR * i / n_dev) & ~63ull), hi = i + 1 == n_dev ? NR : (u32)(((u64)NR * (i + 1) / n_dev) & ~63ull);
+    rcs[i] = run_range(t, t->reps[i], in, p, out, sh, L, lo, hi, pinned, chunk_env);
+    if (rcs[i] != 0) errs[i] = g_err;
+  };
+  std::vector<std::thread> th;
+  for (u32 i = 1; i < n_dev; ++i) th.emplace_back(work, i);
+  work(0);
+  for (auto& x : th) x.join();
+  for (u32 i = 0; i < n_dev; ++i) if (rcs[i] != 0) return fail("device " + std::to_string(t->reps[i]->device) + ": " + errs[i]);
   return 0;
 }
 #endif  // !__HIP_DEVICE_COMPILE__

@@ -182,8 +182,9 @@ struct cbi_batch {
 namespace {
 
 enum { T_NULL = 0, T_BOOL = 1, T_DOUBLE = 4, T_STRING = 5, T_LIST = 6, T_MAP = 7, T_ABSENT = 0xF0, T_ERR = 0xFF };
-enum { RQ_PRINCIPAL_ID, RQ_P_SCOPE, RQ_P_VERSION, RQ_KIND, RQ_R_SCOPE, RQ_R_VERSION, RQ_ROLE_OFF, RQ_ROLE_CNT,
-       RQ_S_RESOURCE_ID, RQ_S_KIND, RQ_S_P_SCOPE, RQ_S_R_SCOPE, RQ_S_P_VERSION, RQ_S_R_VERSION, RQ_ACT_OFF, RQ_ACT_CNT, RQ_N };
+enum { RQ_PRINCIPAL_ID, RQ_P_SCOPE, RQ_P_VERSION, RQ_KIND, RQ_R_SCOPE, RQ_R_VERSION, RQ_ROLE_OFF, RQ_ROLE_CNT, RQ_ACT_OFF, RQ_ACT_CNT,
+       RQ_S_RESOURCE_ID, RQ_S_KIND, RQ_S_P_SCOPE, RQ_S_R_SCOPE, RQ_S_P_VERSION, RQ_S_R_VERSION, RQ_N };
+static_assert(RQ_ACT_OFF == CBH_RQ_ACT_OFF && RQ_S_R_VERSION == CBH_RQ_S_R_VERSION && RQ_N == CBH_RQ_NFIELDS, "field order of include/cerbos_hip.h");
 constexpr u32 SCOPE_EXACT = 0x80000000u;
 constexpr u32 MAX_ACTIONS = 64;
 constexpr u32 SF_ACTION = 1, SF_ROLE = 2, SF_KIND = 4;

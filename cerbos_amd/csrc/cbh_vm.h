@@ -62,6 +62,9 @@ struct TableDev {
 
 struct BatchDev {
   u32 n_requests, n_tuples, n_roles, n_columns, n_strings, heap_len;
+  // the requests this launch decides: a chunk [req_lo, req_hi) of the batch (the arrays keep their
+  // whole-batch layout, so a chunk's slices can be uploaded while another chunk is being decided)
+  u32 req_lo, req_hi;
   const CBH_G u32* req_u32; const CBH_G u32* roles; const CBH_G u32* tuple_req; const CBH_G u32* tuple_action;
   const CBH_G u8* col_tag; const CBH_G u64* col_val;
   const CBH_G u8* heap_tag; const CBH_G u64* heap_val;

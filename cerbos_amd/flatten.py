@@ -27,8 +27,8 @@ from .lower.blob import LoweredTable
 
 RQ_NFIELDS = 16
 (RQ_PRINCIPAL_ID, RQ_P_SCOPE, RQ_P_VERSION, RQ_KIND, RQ_R_SCOPE, RQ_R_VERSION, RQ_ROLE_OFF, RQ_ROLE_CNT,
- RQ_S_RESOURCE_ID, RQ_S_KIND, RQ_S_P_SCOPE, RQ_S_R_SCOPE, RQ_S_P_VERSION, RQ_S_R_VERSION,
- RQ_ACT_OFF, RQ_ACT_CNT) = range(16)
+ RQ_ACT_OFF, RQ_ACT_CNT,
+ RQ_S_RESOURCE_ID, RQ_S_KIND, RQ_S_P_SCOPE, RQ_S_R_SCOPE, RQ_S_P_VERSION, RQ_S_R_VERSION) = range(16)
 SCOPE_EXACT = 0x80000000
 MAX_ACTIONS_PER_REQUEST = 64
 

@@ -25,7 +25,7 @@ from .celc import LoweringError, Params, ProgramBuilder
 from .globs import GlobNFA, fix_glob, has_meta
 
 BLOB_MAGIC = 0x31484243
-BLOB_VERSION = 15
+BLOB_VERSION = 16
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
 PAT_ANY = 0x7FFFFFFF     # the lone "*": matches every string, no automaton needed
@@ -423,7 +423,9 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
                      | (4 if rp_buckets else 0)
                      | (8 if pb.has_generic else 0)
                      | (16 if used_any else 0)
-                     | (32 if pp_exists else 0))
+                     | (32 if pp_exists else 0)
+                     | (64 if any(f >= 10 for f in pb.req_fields) else 0)
+                     | (128 if (pb.reads_string_bytes or any(lt.nfas[d].patterns for d in range(3))) else 0))
     meta[M_MAX_STACK] = pb.max_stack
     meta[M_NDRNAMES] = len(lt.dr_names)
     meta[M_NFA_WORDS_ACTION] = lt.nfas[0].words
@@ -497,6 +499,8 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         "columns": len(lt.columns), "directory_slots": nslots, "blob_bytes": len(lt.blob),
         "unsupported_expressions": len(lt.unsupported),
         "globs": [len(d.globs) for d in dims],
+        "reads_request_strings": bool(int(meta[M_FLAGS]) & 64),
+        "needs_string_bytes": bool(int(meta[M_FLAGS]) & 128),   # glob automata or programs that look inside strings   # raw request strings (R.id, R.kind, scopes, versions) read by some program
         "generic_programs": bool(pb.has_generic),   # selects the kernel with the operand-stack interpreter
         # feature class of the 32-bit-mask kernels (cbh_pick_check_kernel): "" = everything (role policies /
         # parent roles), else "_f<bits>" with bit 0 = derived roles, bit 2 = glob patterns

@@ -54,8 +54,8 @@ T_ABSENT, T_ERR = 0xF0, 0xFF
 HEAP_TABLE, HEAP_BATCH, HEAP_ROLES = 0, 1, 2
 
 # request string fields (cbh_req_field)
-RQ_PRINCIPAL_ID, RQ_S_RESOURCE_ID, RQ_S_KIND = 0, 8, 9
-RQ_S_P_SCOPE, RQ_S_R_SCOPE, RQ_S_P_VERSION, RQ_S_R_VERSION = 10, 11, 12, 13
+RQ_PRINCIPAL_ID, RQ_S_RESOURCE_ID, RQ_S_KIND = 0, 10, 11
+RQ_S_P_SCOPE, RQ_S_R_SCOPE, RQ_S_P_VERSION, RQ_S_R_VERSION = 12, 13, 14, 15
 
 IT_ALL, IT_EXISTS, IT_EXISTS_ONE = 0, 1, 2
 
@@ -71,6 +71,15 @@ _P_FIELDS = {"id": RQ_PRINCIPAL_ID, "scope": RQ_S_P_SCOPE, "policyVersion": RQ_S
              "policy_version": RQ_S_P_VERSION}
 _R_FIELDS = {"id": RQ_S_RESOURCE_ID, "kind": RQ_S_KIND, "scope": RQ_S_R_SCOPE,
              "policyVersion": RQ_S_R_VERSION, "policy_version": RQ_S_R_VERSION}
+
+
+# opcodes that never look inside a string: they move values, compare interned ids / numbers, or steer control flow.
+# A table whose programs use only these needs no batch-local string bytes on the device (cbh_engine.hip skips
+# their upload); orderings are decided per use (OP_LEAF_BIN in _fused_leaf, OP_LT.. here count as content reads).
+_ID_ONLY_OPS = frozenset([OP_RET, OP_CONST, OP_COL, OP_HASCOL, OP_REQSTR, OP_ROLES, OP_SELECT, OP_HASSEL, OP_INDEX, OP_EQ, OP_NE,
+                          OP_IN, OP_NOT, OP_JF, OP_JT, OP_AND, OP_OR, OP_JTERN, OP_JMP, OP_POP, OP_LEAF, OP_EDRHAS, OP_LOCAL,
+                          OP_ITER_BEGIN, OP_ITER_NEXT, OP_ITER_ACC, OP_ITER_END, OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN,
+                          OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC, OP_TREE_END, OP_UNSUPPORTED])
 
 
 class LoweringError(ValueError):
@@ -190,6 +199,8 @@ class ProgramBuilder:
         self.dr_names = {}                 # derived role name -> bit
         self.unsupported = []              # [(expr text, reason)]
         self.uses_runtime = False
+        self.reads_string_bytes = False   # some program may look INSIDE a string (ordering, prefix, size, parsing ...)
+        self.req_fields = set()   # cbh_req_field indices some program reads (the host uploads the raw-string fields only then)
         self.has_generic = False           # some program needs the operand-stack interpreter
         self.max_stack = 0
         self.max_locals = 0
@@ -363,6 +374,8 @@ class _FuncCompiler:
 
     # -- emission helpers
     def emit(self, op, arg=0, delta=0):
+        if op not in _ID_ONLY_OPS:   # conservatively: everything that is not known to work on ids / numbers alone
+            self.pb.reads_string_bytes = True
         self.out.append(op | (arg << 8))
         self.depth += delta
         self.max_depth = max(self.max_depth, self.depth)
@@ -486,6 +499,11 @@ class _FuncCompiler:
         b = self._simple_operand(rhs)
         if a is None or b is None:
             return False
+        if ast[1] in ("<", "<=", ">", ">="):
+            # an ordering compares string CONTENTS unless one side is a constant that is not a string
+            tags = [self.pb.const_tag[x[1]] for x in (a, b) if x[0] == 0]
+            if not tags or any(t == T_STRING for t in tags):
+                self.pb.reads_string_bytes = True
         self.emit(OP_LEAF_BIN, _BINOPS[ast[1]] | (a[0] << 8) | (b[0] << 12), +1)
         self.word(a[1])
         self.word(b[1])
@@ -537,6 +555,7 @@ class _FuncCompiler:
                     return ("roles",)
                 fields = _P_FIELDS if base == "P" else _R_FIELDS
                 if f in fields:
+                    self.pb.req_fields.add(fields[f])
                     return ("req", fields[f])
             return None
         if base == "runtime" and len(keys) == 1 and keys[0] in ("effectiveDerivedRoles", "effective_derived_roles"):

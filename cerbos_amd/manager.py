@@ -1,0 +1,104 @@
+"""Versioned rule-table manager: the host-side mirror of ``ruletable.Manager``
+(``internal/ruletable/manager.go:50-124``).
+
+The reference keeps the current ``*RuleTable`` behind an RWMutex: ``Check`` takes the read lock for the whole
+evaluation (manager.go:50-55), a storage event rebuilds the table and swaps it under the write lock
+(manager.go:86-124).  Here the swap never waits for readers: a request *retains* the table it was handed
+(``cbh_table_retain``), the swap publishes the new table and drops the owner's reference of the old one, and the
+old image leaves HBM when its last in-flight batch has drained (tables are reference counted inside the library).
+A batch is flattened against one table's string pool, so a request must use the ingest table and the device table
+of the SAME version - ``acquire()`` hands out both.
+"""
+from __future__ import annotations
+
+import threading
+
+from . import capi
+from .flatten import Flattener
+from .lower.blob import LoweredTable
+
+
+class _Version:
+    __slots__ = ("number", "lowered", "table", "flattener", "ingest")
+
+    def __init__(self, number, lowered, table, flattener, ingest):
+        self.number, self.lowered, self.table, self.flattener, self.ingest = number, lowered, table, flattener, ingest
+
+
+class TableLease:
+    """One request's hold on a table version (the reference's RLock scope)."""
+
+    def __init__(self, version: _Version):
+        self.v = version
+        self.table = capi.Table.borrow(version.table)   # this request's own reference (cbh_table_retain)
+
+    number = property(lambda self: self.v.number)
+    lowered = property(lambda self: self.v.lowered)
+    flattener = property(lambda self: self.v.flattener)
+    ingest = property(lambda self: self.v.ingest)
+
+    def release(self):
+        self.table.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.release()
+
+
+class TableManager:
+    def __init__(self, lowered: LoweredTable = None, native_ingest: bool = False):
+        self._lock = threading.Lock()
+        self._cur = None
+        self._n = 0
+        self._native_ingest = native_ingest
+        if lowered is not None:
+            self.swap(lowered)
+
+    def _build(self, lowered):
+        table = capi.Table(lowered.blob)
+        ingest = None
+        if self._native_ingest:
+            from .ingest import IngestTable
+            ingest = IngestTable(lowered.blob)
+        return table, Flattener(lowered), ingest
+
+    def swap(self, lowered: LoweredTable) -> int:
+        """Load ``lowered`` on every device, publish it, retire the previous version (manager.go:86-124).  The
+        upload and broadcast happen before the lock is taken: requests keep flowing on the old table meanwhile."""
+        table, flattener, ingest = self._build(lowered)
+        with self._lock:
+            self._n += 1
+            old, self._cur = self._cur, _Version(self._n, lowered, table, flattener, ingest)
+            n = self._n
+        if old is not None:
+            old.table.close()   # the owner's reference: the image is freed once in-flight batches have drained
+        return n
+
+    def acquire(self) -> TableLease:
+        with self._lock:
+            if self._cur is None:
+                raise RuntimeError("no rule table loaded")
+            return TableLease(self._cur)
+
+    @property
+    def version(self) -> int:
+        with self._lock:
+            return self._n
+
+    def check_batch(self, inputs, now_ns=0, flags=capi.F_WANT_DERIVED_ROLES, default_policy_version="default", default_scope=""):
+        """Flatten + decide ``inputs`` on whichever version is current when the call starts.
+        Returns (version number, lowered table, batch, result)."""
+        with self.acquire() as lease:
+            batch = lease.flattener.flatten(inputs, default_policy_version, default_scope)
+            res = lease.table.check(batch, now_ns=now_ns, flags=flags)
+            return lease.number, lease.lowered, batch, res
+
+    def close(self):
+        with self._lock:
+            old, self._cur = self._cur, None
+        if old is not None:
+            old.table.close()
+            if old.ingest is not None:
+                old.ingest.close()

@@ -18,8 +18,14 @@
  * 0 = OK, < 0 = hard error (text via cbh_last_error(), thread-local).  No function
  * aborts or throws across the boundary.  All entry points are thread-safe: one-shot calls
  * (cbh_check_batch) from different threads run on separate launch contexts and overlap on the
- * device (up to 8 per table, further callers wait); the resident calls of one table share one
- * stream and queue in call order.
+ * device (up to 8 per table and device, further callers wait); the resident calls of one table
+ * and device share one stream and queue in call order.
+ *
+ * Devices: cbh_init names the GPUs of the node the engine may use (the reference's fan-out over
+ * NumCPU+4 goroutines, engine.go:309-338, becomes a fan-out over devices).  cbh_table_load puts
+ * the image on the first device and broadcasts it to the others (RCCL over xGMI, peer copies if
+ * RCCL is unavailable); cbh_check_batch shards a large batch into contiguous request ranges, one
+ * per device, and writes every result at the caller's offsets (engine.go:332).
  */
 #ifndef CERBOS_HIP_H
 #define CERBOS_HIP_H
@@ -31,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CBH_ABI_VERSION 2u
+#define CBH_ABI_VERSION 3u
 #define CBH_NONE 0xFFFFFFFFu
 
 /* Effect values = effectv1.Effect (api/public/cerbos/effect/v1/effect.proto). */
@@ -55,14 +61,16 @@ enum cbh_req_field {
   CBH_RQ_R_VERSION = 5,    /* string id of the effective resource policy version          */
   CBH_RQ_ROLE_OFF = 6,     /* first entry of this principal's roles in `roles`            */
   CBH_RQ_ROLE_CNT = 7,
-  CBH_RQ_S_RESOURCE_ID = 8,  /* the rest are raw strings only CEL programs read           */
-  CBH_RQ_S_KIND = 9,
-  CBH_RQ_S_P_SCOPE = 10,
-  CBH_RQ_S_R_SCOPE = 11,
-  CBH_RQ_S_P_VERSION = 12,
-  CBH_RQ_S_R_VERSION = 13,
-  CBH_RQ_ACT_OFF = 14,     /* this request's actions are tuple_action[ACT_OFF .. ACT_OFF+ACT_CNT)    */
-  CBH_RQ_ACT_CNT = 15,     /* <= CBH_MAX_ACTIONS_PER_REQUEST; split larger CheckInputs into several */
+  CBH_RQ_ACT_OFF = 8,      /* this request's actions are tuple_action[ACT_OFF .. ACT_OFF+ACT_CNT)    */
+  CBH_RQ_ACT_CNT = 9,      /* <= CBH_MAX_ACTIONS_PER_REQUEST; split larger CheckInputs into several */
+  CBH_RQ_NCORE = 10,       /* fields 0..9 are read for every request; the rest are raw strings only CEL  */
+                           /* programs read (uploaded only for a table that has such a program)       */
+  CBH_RQ_S_RESOURCE_ID = 10,
+  CBH_RQ_S_KIND = 11,
+  CBH_RQ_S_P_SCOPE = 12,
+  CBH_RQ_S_R_SCOPE = 13,
+  CBH_RQ_S_P_VERSION = 14,
+  CBH_RQ_S_R_VERSION = 15,
   CBH_RQ_NFIELDS = 16
 };
 #define CBH_MAX_ACTIONS_PER_REQUEST 64u /* the default request limit of the reference is 50 (server/conf.go:34-35) */
@@ -92,9 +100,11 @@ enum cbh_tag {
 #define CBH_SF_ROLE 2u
 #define CBH_SF_KIND 4u
 
+#define CBH_MAX_DEVICES 16
 typedef struct cbh_config {
   uint32_t abi_version; /* CBH_ABI_VERSION */
-  int32_t device;       /* HIP device ordinal */
+  uint32_t n_devices;   /* entries of `devices` in use; 0 = every visible device */
+  int32_t devices[CBH_MAX_DEVICES]; /* HIP device ordinals (a repeated ordinal = two replicas on one GPU: tests) */
 } cbh_config;
 
 /*
@@ -162,10 +172,38 @@ void cbh_shutdown(void);
 const char* cbh_last_error(void);
 uint32_t cbh_abi_version(void);
 
-/* Table lifetime.  The blob is the output of the lowering step (cerbos_amd.lower); it is
- * copied to the device, the caller's buffer is not retained. */
+uint32_t cbh_num_devices(void);          /* devices the engine was initialised with */
+int32_t cbh_device_ordinal(uint32_t i);  /* HIP ordinal of the i-th of them, -1 if out of range */
+
+/* Page-locked host memory for batch / result arrays: cbh_check_batch moves arrays that live in such
+ * memory by DMA straight from / to the caller's pages, chunked over several streams so that upload,
+ * kernels and download overlap; ordinary (pageable) memory works too but goes through the driver's
+ * staging copies.  C memory only, as cgo requires. */
+void* cbh_alloc_pinned(size_t bytes);
+void cbh_free_pinned(void* p);
+
+/* Slabs.  A batch whose arrays lie in ONE page-locked block in the library's canonical order crosses PCIe in a
+ * single copy (and a result slab comes back in one): cbh_batch_slab_bytes sizes the block from the counts in
+ * `counts` (n_requests ... str_bytes_len), cbh_batch_bind_slab points the array members of `b` into it
+ * (tuple_req = NULL: the device never reads it).  The producer then fills the arrays in place - this is how
+ * libcerbos_ingest.so and the Go shim hand batches over.  Any other placement of the arrays is accepted too. */
+size_t cbh_batch_slab_bytes(const cbh_batch* counts);
+void cbh_batch_bind_slab(cbh_batch* b, void* slab);
+size_t cbh_result_slab_bytes(uint32_t n_tuples, uint32_t n_requests);
+void cbh_result_bind_slab(cbh_result* r, void* slab, uint32_t n_tuples, uint32_t n_requests);
+
+/* Table lifetime.  The blob is the output of the lowering step (cerbos_amd.lower); it is copied to
+ * the first device and broadcast to the others, the caller's buffer is not retained.
+ * Tables are reference counted: cbh_table_load returns the owner's reference, every call that takes
+ * a table holds one for its duration, cbh_table_retain adds one (a manager handing the current
+ * table to a request, ruletable/manager.go:50-55), cbh_table_release drops one.  The table is freed
+ * when the last reference goes - i.e. a released table drains its in-flight batches first
+ * (manager.go:86-124: the swap does not wait for readers of the old table). */
 int cbh_table_load(const void* blob, size_t len, cbh_table** out);
+void cbh_table_retain(cbh_table* t);
 void cbh_table_release(cbh_table* t);
+/* How the image reached the other devices: "none" (one device), "rccl", "peer-copy". */
+const char* cbh_table_broadcast_kind(const cbh_table* t);
 uint32_t cbh_table_num_strings(const cbh_table* t);
 uint32_t cbh_table_num_columns(const cbh_table* t);
 uint64_t cbh_table_device_bytes(const cbh_table* t);
@@ -174,16 +212,25 @@ void* cbh_table_device_ptr(const cbh_table* t);
 /* Adopt an image that already sits in device memory (received by broadcast). */
 int cbh_table_adopt_device_image(void* device_image, size_t len, cbh_table** out);
 
-/* One-shot: upload `in`, evaluate, download into `out` (all host pointers).  A batch under 4 MB is packed into a
- * pinned staging block and crosses PCIe in one copy each way. */
+/* One-shot: upload `in`, evaluate, download into `out` (all host pointers).
+ *  - a small batch (under 1 MB of inputs) is packed into a pinned staging block and crosses PCIe in one
+ *    copy each way;
+ *  - a large batch is split into contiguous request ranges, one per device (when the engine has several
+ *    and the batch at least 16k requests), and each range is pipelined in chunks over three streams -
+ *    upload of chunk c+1, kernels of chunk c and download of chunk c-1 overlap - provided the arrays are
+ *    page-locked (cbh_alloc_pinned); pageable arrays are copied whole, array by array.
+ * Requests must own contiguous, ascending tuple slices (ACT_OFF non-decreasing in request order) for
+ * the split; any other order is accepted and evaluated in one piece on one device. */
 int cbh_check_batch(cbh_table* t, const cbh_batch* in, const cbh_params* p, cbh_result* out);
 
-/* Resident path (what bench.py times): inputs already in HBM when the clock starts. */
+/* Resident path (what bench.py times): inputs already in HBM when the clock starts.
+ * cbh_batch_upload places the batch on the table's first device, cbh_batch_upload_on on the i-th. */
 int cbh_batch_upload(cbh_table* t, const cbh_batch* in, cbh_device_batch** out);
+int cbh_batch_upload_on(cbh_table* t, uint32_t device_index, const cbh_batch* in, cbh_device_batch** out);
 void cbh_batch_release(cbh_device_batch* b);
 /* Launches the kernels on the library's stream and returns without synchronising. */
 int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_params* p);
-int cbh_synchronize(cbh_table* t);
+int cbh_synchronize(cbh_table* t); /* every device of the table */
 /* Copies the results of the last cbh_check_resident on `b` to host memory. */
 int cbh_result_download(cbh_table* t, cbh_device_batch* b, cbh_result* out);
 /* Average duration in ms of the decision kernel over the last `n` cbh_check_resident

@@ -157,6 +157,7 @@ extern "C" int hostsim_check(const void* blob, size_t len, const cbh_batch* in, 
   BatchDev& b = a.b;
   b.n_requests = in->n_requests; b.n_tuples = in->n_tuples; b.n_roles = in->n_roles;
   b.n_columns = in->n_columns; b.n_strings = in->n_strings; b.heap_len = in->heap_len;
+  b.req_lo = 0; b.req_hi = in->n_requests;
   b.req_u32 = in->req_u32; b.roles = in->roles; b.tuple_req = in->tuple_req; b.tuple_action = in->tuple_action;
   b.col_tag = in->col_tag; b.col_val = in->col_val; b.heap_tag = in->heap_tag; b.heap_val = in->heap_val;
   b.str_off = in->str_off; b.str_bytes = in->str_bytes; b.str_flags = in->str_flags; b.gbits = gbits;
@@ -168,7 +169,14 @@ extern "C" int hostsim_check(const void* blob, size_t len, const cbh_batch* in, 
   for (uint32_t r = 0; r < in->n_requests; ++r)
     max_actions = std::max(max_actions, in->req_u32[(size_t)CBH_RQ_ACT_CNT * in->n_requests + r]);
   g_max_actions = max_actions;
-  const uint32_t nblocks = (in->n_requests + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
-  for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
+  // two launches over an arbitrary (unaligned) split of the batch: the chunk window [req_lo, req_hi) that the
+  // one-shot path pipelines with (cbh_engine.hip) is exercised by every test of the CPU tier
+  const uint32_t n = in->n_requests, mid = n > 3 ? (n / 2) - (n / 2) % 3 + 1 : n;
+  const uint32_t cuts[3] = {0, mid, n};
+  for (int c = 0; c < 2; ++c) {
+    b.req_lo = cuts[c]; b.req_hi = cuts[c + 1];
+    const uint32_t nblocks = (b.req_hi - b.req_lo + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
+    for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
+  }
   return 0;
 }

@@ -329,7 +329,7 @@ def test_wide_action_lists_at_size(n_actions, n_requests):
     fl = Flattener(lt)
     batch = cr.to_batch(fl) if n_actions <= 64 else fl.flatten(cr.to_inputs())   # only the dict route splits > 64
     assert batch.n_tuples == n_requests * n_actions
-    assert int(batch.req_u32[15].max()) == min(n_actions, 64)
+    assert int(batch.req_u32[9].max()) == min(n_actions, 64)
     flags = capi.F_WANT_DERIVED_ROLES
     got = table.check(batch, now_ns=NOW, flags=flags)
     want = ccheck.check(lt, batch, NOW, flags, threads=min(16, os.cpu_count() or 1))

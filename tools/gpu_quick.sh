@@ -1,11 +1,10 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): GPU parity tests, then a short bench line.
-mkdir -p gpurun_out
-(timeout 400 python -m pytest tests -m gpu -x -q 2>&1 | tail -4) > gpurun_out/pytest_gpu.log
-(timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | grep '^{' | tail -1) > gpurun_out/bench_quick.json
-cat gpurun_out/pytest_gpu.log
-python - <<'PY'
-import json
-d = json.load(open('gpurun_out/bench_quick.json'))
-print("value %.3e dec/s  ms/step %.4f  kernel_ms %.4f  frac %.4f  oneshot %.3e" % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['frac'], d['oneshot_pcie_inclusive_decisions_per_s']))
-PY
+# quick GPU check: build, the engine tests, smoke, one short default bench
+set -u
+OUT=gpurun_out/${1:-quick}
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+python __graft_entry__.py > "$OUT/build.log" 2>&1 || { tail -20 "$OUT/build.log"; exit 1; }
+timeout 600 python -m pytest tests/test_gpu_engine.py tests/test_gpu_synthetic.py -x -q -m gpu --durations=8 > "$OUT/pytest_engine.log" 2>&1; tail -30 "$OUT/pytest_engine.log"
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+timeout 300 python bench.py --steps 20 --warmup 3 --batches 12 > "$OUT/bench.log" 2>&1; tail -1 "$OUT/bench.log" | tee "$OUT/bench.json" | cut -c1-1800
