@@ -33,7 +33,7 @@ enum CbhSectionId {
   CBH_SEC_SCOPE_FLAGS = 5, // u32[NS]  bit0 resource map, bit1 principal map, bits 2..3 scope permissions
   CBH_SEC_SCOPE_SID = 6,   // u32[NS]  string id of the scope
   CBH_SEC_HASH = 7,        // CbhHashSlot[nslots]
-  CBH_SEC_ROWS = 8,        // u32[n_rows][16]  row-major records (CbhRowField order): one s_load_dwordx16 each
+  CBH_SEC_ROWS = 8,        // u32[n_rows][16]  row-major records (CbhRowField order): two s_load_dwordx8 halves
   CBH_SEC_RPROWS = 9,      // u32[n_rprows][4] row-major records (CbhRpField order)
   CBH_SEC_U32POOL = 10,    // u32[] (pattern lists, parent-role lists)
   CBH_SEC_DR = 11,         // u32[n_dr][4]     row-major records (CbhDrField order)
@@ -51,6 +51,7 @@ enum CbhSectionId {
   CBH_SEC_CONST_REC = 23,  // u32[n_consts][4]  {tag, 0, lo, hi}: the constant pool as scalar-loadable records
   CBH_SEC_THEAP_REC = 24,  // u32[theap_len][4] the constant heap, same record form
   CBH_SEC_ROLE_CLASS = 25, // u8[K] class (0..61) of a string that is a literal rule role, 63 = any other string
+  CBH_SEC_ACTION_CLASS = 28, // u8[K] class (0..61) of a string that is a literal rule action of a resource policy, 63 = any other string
   CBH_SEC_HOST_NAMES = 27,   // host only: {u32 n, {u16 len, bytes}*} policy keys (CBH_P_TABLE ids), then the same for derived-role names
   CBH_SEC_COLUMN_PATHS = 26, // host only (cbh_ingest.cpp): per column {u8 root 0=P.attr 1=R.attr 2=auxData.jwt 3=auxData.jwts, u8 n_keys, {u16 len, bytes}*}
 };
@@ -113,23 +114,34 @@ enum CbhBucketType {
 
 // Regular rows (resource + principal policies).  One record stands for the rule-table rows of ONE
 // rule that share effect / condition / derived-role condition: the cross product of its role list
-// and its action list (a single role or action is stored inline, a list lives in U32POOL).
+// and its action list.  A record is two 8-dword halves:
+//   hot half   what every visit needs: effect, condition references, and the role / action lists as
+//              64-bit CLASS masks (CBH_SEC_ROLE_CLASS / CBH_SEC_ACTION_CLASS give every literal role /
+//              action of the table a class number < 62; 63 = any other string).  When a list is all
+//              literals with a class (or "*": every bit set) the mask decides the match exactly
+//              (CBH_ROW_F_ROLE_BY_CLASS / _ACTION_BY_CLASS) and the second half is never read;
+//   pattern half  the pattern references themselves (up to three inline, longer lists in U32POOL) for
+//              records with glob patterns or more classes than fit, and for principal-policy rows.
 enum CbhRowField {
-  CBH_ROW_ACTION = 0,   // pattern ref (action dim), or U32POOL offset of a list of them (CBH_ROW_F_ACTION_LIST)
-  CBH_ROW_ROLE = 1,     // pattern ref (role dim), or U32POOL offset of a list of them (CBH_ROW_F_ROLE_LIST)
-  CBH_ROW_RESOURCE = 2, // pattern ref (kind dim) - tested for principal-policy rows only
-  CBH_ROW_FLAGS = 3,    // bits 0..1 effect (1 ALLOW, 2 DENY), CBH_ROW_F_*
-  CBH_ROW_COND = 4,     // program entry or CBH_NONE
-  CBH_ROW_DRCOND = 5,   // program entry or CBH_NONE
-  CBH_ROW_POLICY = 6,   // policy id of the origin policy (strict-mode attribution)
-  CBH_ROW_COUNTS = 7,   // action list length | role list length << 16 (0 = one inline reference)
-  CBH_ROW_A1 = 8,       // 2nd..4th action pattern ref of a list of at most four (inline, no CBH_ROW_F_ACTION_LIST)
-  CBH_ROW_R1 = 11,      // 2nd..4th role pattern ref likewise
-  CBH_ROW_ROLE_CLASSES = 14,   // u64 (2 dwords): role classes the record's role list can match (CBH_SEC_ROLE_CLASS)
+  CBH_ROW_FLAGS = 0,    // bits 0..1 effect (1 ALLOW, 2 DENY), CBH_ROW_F_*
+  CBH_ROW_COND = 1,     // program entry or CBH_NONE
+  CBH_ROW_DRCOND = 2,   // program entry or CBH_NONE
+  CBH_ROW_POLICY = 3,   // policy id of the origin policy (strict-mode attribution)
+  CBH_ROW_ROLE_CLASSES = 4,    // u64 (2 dwords): role classes the record's role list can match
+  CBH_ROW_ACTION_CLASSES = 6,  // u64 (2 dwords): action classes its action list can match
+  CBH_ROW_ACTION = 8,   // pattern ref (action dim), or U32POOL offset of a list of them (CBH_ROW_F_ACTION_LIST)
+  CBH_ROW_ROLE = 9,     // pattern ref (role dim), or U32POOL offset of a list of them (CBH_ROW_F_ROLE_LIST)
+  CBH_ROW_RESOURCE = 10, // pattern ref (kind dim) - tested for principal-policy rows only
+  CBH_ROW_COUNTS = 11,  // action list length | role list length << 16 (0 = one inline reference)
+  CBH_ROW_A1 = 12,      // 2nd, 3rd action pattern ref of a list of at most three (inline, no CBH_ROW_F_ACTION_LIST)
+  CBH_ROW_R1 = 14,      // 2nd, 3rd role pattern ref likewise
   CBH_ROW_NF = 16       // record = 16 dwords, 64-byte aligned
 };
+#define CBH_ROW_INLINE_MAX 3u           /* longer lists live in U32POOL */
 #define CBH_ROW_F_ACTION_LIST 4u
 #define CBH_ROW_F_ROLE_LIST 8u
+#define CBH_ROW_F_ROLE_BY_CLASS 16u     /* the role class mask decides the role match exactly */
+#define CBH_ROW_F_ACTION_BY_CLASS 32u   /* the action class mask decides the action match exactly */
 enum CbhRpField { // role-policy rows
   CBH_RP_RESOURCE = 0,  // pattern ref (kind dim)
   CBH_RP_ALLOW_OFF = 1, // into U32POOL: pattern refs (action dim)

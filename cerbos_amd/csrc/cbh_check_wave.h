@@ -28,6 +28,7 @@
 
 struct RoleSet {   // [role] ++ ancestors(role) for the request's resource scope (index.go:716-742)
   u32 role; u32 par_off; u32 par_cnt; u64 gbits;   // gbits: OR of role-dimension glob bits over the set
+  u64 classes;                                      // OR of 1 << role class over the set (CBH_SEC_ROLE_CLASS)
 };
 
 // `globbit` = CBH_PAT_GLOB, or 0 in kernels for tables without glob patterns (the branch folds away)
@@ -41,11 +42,12 @@ __device__ __forceinline__ bool roleset_has(const TableDev& t, const RoleSet& rs
 
 // Table records are stored row-major and naturally aligned so that one wide scalar load
 // (s_load_dwordx4 / x8) fetches a whole record at a wave-uniform index.
-// A rule record is 16 dwords, read as two independent 8-dword halves: the rule itself (live through
-// the evaluation of its conditions) and its inline lists (dead as soon as the lanes are matched).
-// One 16-dword register tuple would be spilled and reloaded as a unit around every call.
-struct __attribute__((aligned(32))) TblRow { u32 action, role, resource, flags, cond, drcond, policy, counts; };
-struct __attribute__((aligned(32))) TblRowLists { u32 a1, a2, a3, r1, r2, r3, pad0, pad1; };   // 2nd..4th action / role; pad0|pad1<<32 = role class mask (cbh_blob.h)
+// A rule record is 16 dwords in two 8-dword halves (cbh_blob.h CbhRowField): the hot half - effect, condition
+// references, role / action CLASS masks - is what every visit reads; the pattern half holds the pattern
+// references and is read only for records whose masks do not decide the match (globs, class overflow) and for
+// principal-policy rows.
+struct __attribute__((aligned(32))) TblRow { u32 flags, cond, drcond, policy, rm_lo, rm_hi, am_lo, am_hi; };
+struct __attribute__((aligned(32))) TblRowPat { u32 action, role, resource, counts, a1, a2, r1, r2; };
 struct __attribute__((aligned(16))) TblRp { u32 resource, allow_off, allow_cnt, cond; };
 struct __attribute__((aligned(16))) TblDr { u32 name, parents_off, parents_cnt, cond; };
 struct __attribute__((aligned(32))) TblSlot { u32 k0, k1, k2, k3, v0, v1, v2, v3; };
@@ -416,6 +418,15 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   const u32 a1 = act_cnt > 1 ? b.tuple_action[act_off + 1] : CBH_NONE;
   const u32 a2 = act_cnt > 2 ? b.tuple_action[act_off + 2] : CBH_NONE;
   const u32 a3 = act_cnt > 3 ? b.tuple_action[act_off + 3] : CBH_NONE;
+  // their action classes (CBH_SEC_ACTION_CLASS; 63 = not a literal rule action), for the records whose class
+  // masks decide the match
+  u32 ac0 = 63u, ac1 = 63u, ac2 = 63u, ac3 = 63u;
+  if ((FEAT & CBH_FEAT_MAX4) != 0) {
+    if (a0 < t.K) ac0 = t.action_class[a0];
+    if (a1 < t.K) ac1 = t.action_class[a1];
+    if (a2 < t.K) ac2 = t.action_class[a2];
+    if (a3 < t.K) ac3 = t.action_class[a3];
+  }
   // ... and the first two roles: fetched with the rest of the request instead of one memory round
   // trip at the head of every role iteration
   const u32 role0 = role_cnt > 0 ? b.roles[role_off] : 0;
@@ -481,19 +492,25 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   // parent roles are looked up with the request's own resource scope only (check.go:172,227)
   const u32 pr_scope_key = (r_scope & CBH_SCOPE_EXACT) ? (r_scope & ~CBH_SCOPE_EXACT) : CBH_NONE;
 
-  // does a rule record's role list (wave-uniform) match this lane's [role] ++ ancestors?
-  auto rec_role_match = [&](const TblRow& rw, const TblRowLists& rl, const RoleSet& rs) -> bool {
-    const u32 n_role = rw.counts >> 16;   // 0 = a single inline reference
+  // does a rule record's role list (wave-uniform) match this lane's [role] ++ ancestors?  Decided by the class
+  // mask where the lowering says it is exact, else by the pattern references of the record's second half.
+  auto pat_role_match = [&](const TblRow& rw, const TblRowPat& pt, const RoleSet& rs, bool active) -> bool {
+    if (rw.flags & CBH_ROW_F_ROLE_BY_CLASS) return active && ((((u64)rw.rm_lo | ((u64)rw.rm_hi << 32)) & rs.classes) != 0);
+    const u32 n_role = pt.counts >> 16;   // 0 = a single inline reference
     bool m = false;
-    if (rw.flags & CBH_ROW_F_ROLE_LIST) {   // more than four roles: the list lives in the pool
-      for (u32 i = 0; i < n_role; ++i) m = m || roleset_has(t, rs, uload(&t.pool[rw.role + i]), GLOBBIT);
-    } else {
-      m = roleset_has(t, rs, rw.role, GLOBBIT);
-      if (n_role > 1) m = m || roleset_has(t, rs, rl.r1, GLOBBIT);
-      if (n_role > 2) m = m || roleset_has(t, rs, rl.r2, GLOBBIT);
-      if (n_role > 3) m = m || roleset_has(t, rs, rl.r3, GLOBBIT);
+    if (rw.flags & CBH_ROW_F_ROLE_LIST) {   // more than three roles: the list lives in the pool
+      for (u32 i = 0; i < n_role; ++i) { const u32 pref = uload(&t.pool[pt.role + i]); m = m || (active && roleset_has(t, rs, pref, GLOBBIT)); }
+    } else if (active) {
+      m = roleset_has(t, rs, pt.role, GLOBBIT);
+      if (n_role > 1) m = m || roleset_has(t, rs, pt.r1, GLOBBIT);
+      if (n_role > 2) m = m || roleset_has(t, rs, pt.r2, GLOBBIT);
     }
     return m;
+  };
+  auto rec_role_match = [&](const TblRow& rw, u32 row, const RoleSet& rs, bool active) -> bool {
+    if (rw.flags & CBH_ROW_F_ROLE_BY_CLASS) return active && ((((u64)rw.rm_lo | ((u64)rw.rm_hi << 32)) & rs.classes) != 0);
+    const TblRowPat pt = uload_rec<TblRowPat>(t.rows, 2 * row + 1);
+    return pat_role_match(rw, pt, rs, active);
   };
 
   // ---- routing preamble: scope chains and existence (check.go:116-121, 165-170), resolved once per
@@ -589,14 +606,20 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
         const AM Am = (ing && ri < n_iter) ? (AM)(Pm & todo & ~rdone) : (AM)0;
         if (wave_ballot(Am != 0) == 0) break;
         DBG2_T0();
-        RoleSet rs; rs.role = 0; rs.par_off = 0; rs.par_cnt = 0; rs.gbits = 0;
+        RoleSet rs; rs.role = 0; rs.par_off = 0; rs.par_cnt = 0; rs.gbits = 0; rs.classes = 0;
+        u32 cls = 63u;
         if (Am != 0) {
           rs.role = ri == 0 ? role0 : ri == 1 ? role1 : b.roles[role_off + ri];
           rs.gbits = F_GLOB ? gbits_of(t, b, DIM_ROLE, rs.role) : 0ull;
+          if (is_res) { cls = rs.role < t.K ? (u32)t.role_class[rs.role] : 63u; rs.classes = 1ull << cls; }
           uint4 pv;
           if (has_parents && pr_scope_key != CBH_NONE && dir_find(t, CBH_B_PARENTS, pr_scope_key, rs.role, 0, pv)) {
             rs.par_off = pv.x; rs.par_cnt = pv.y;
-            if (F_GLOB) for (u32 k = 0; k < rs.par_cnt; ++k) rs.gbits |= t.gbits[(size_t)DIM_ROLE * t.K + t.pool[rs.par_off + k]];
+            for (u32 k = 0; k < rs.par_cnt; ++k) {   // ancestors are table strings
+              const u32 anc = t.pool[rs.par_off + k];
+              if (F_GLOB) rs.gbits |= t.gbits[(size_t)DIM_ROLE * t.K + anc];
+              rs.classes |= 1ull << (u32)t.role_class[anc];
+            }
           }
         }
         // Role classes this wave is walking now (cbh_blob.h CBH_SEC_ROLE_CLASS): a rule record whose
@@ -605,7 +628,6 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
         u64 wave_classes = ~0ull;
         if (is_res && !has_parents) {
           wave_classes = 0;
-          const u32 cls = (Am != 0 && rs.role < t.K) ? (u32)t.role_class[rs.role] : 63u;
           bool pendc = Am != 0;
           for (;;) {   // OR over the (few) distinct classes in the wave
             const u64 remc = wave_ballot(pendc);
@@ -695,8 +717,8 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
             if (have_bucket)
               for (u32 row = bucket.x; row < bucket.x + bucket.y; ++row) {
                 const TblRow rw = uload_rec<TblRow>(t.rows, 2 * row);
-                const TblRowLists rl = uload_rec<TblRowLists>(t.rows, 2 * row + 1);
-                if (S != 0 && !base) base = rec_role_match(rw, rl, rs);
+                const bool m = rec_role_match(rw, row, rs, S != 0 && !base);
+                base = base || m;
               }
             for (u32 k = 0;; ++k) {
               const bool P = S != 0 && !base && k <= rs.par_cnt;
@@ -768,26 +790,33 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
 #endif
             for (u32 row = bucket.x; row < bucket.x + bucket.y; ++row) {
               DBG2_T0();
-              const TblRow rw = uload_rec<TblRow>(t.rows, 2 * row);            // both halves are issued together:
-              const TblRowLists rl = uload_rec<TblRowLists>(t.rows, 2 * row + 1);   // no dependent load for short lists
+              const TblRow rw = uload_rec<TblRow>(t.rows, 2 * row);
               const u32 site = site_ctr++;   // position of the record in this group's walk: the same for every role
-              if ((((u64)rl.pad0 | ((u64)rl.pad1 << 32)) & wave_classes) == 0) continue;   // no lane's role can match
+              if ((((u64)rw.rm_lo | ((u64)rw.rm_hi << 32)) & wave_classes) == 0) continue;   // no lane's role can match
               const u32 e = rw.flags & 3u;
               // a record = roles x actions of one rule (cbh_blob.h): the lists are wave-uniform
-              const u32 n_act = rw.counts & 0xFFFFu;   // 0 = a single inline reference
-              bool rmatch = false;
-              if (S != 0) rmatch = is_res ? rec_role_match(rw, rl, rs) : pmatch(rw.resource, kind, KIND_BITS());
               AM mrow = 0;
-              if (rmatch) {
-                if (rw.flags & CBH_ROW_F_ACTION_LIST) {
-                  for (u32 i = 0; i < n_act; ++i) mrow |= match_actions(uload(&t.pool[rw.action + i]));
-                } else {
-                  mrow = match_actions(rw.action);
-                  if (n_act > 1) mrow |= match_actions(rl.a1);
-                  if (n_act > 2) mrow |= match_actions(rl.a2);
-                  if (n_act > 3) mrow |= match_actions(rl.a3);
+              constexpr u32 BY_CLASS = CBH_ROW_F_ROLE_BY_CLASS | CBH_ROW_F_ACTION_BY_CLASS;
+              if (is_res && F_MAX4 && (rw.flags & BY_CLASS) == BY_CLASS) {
+                // both lists are literals with a class: two mask tests, no pattern reference is read
+                const u64 am = (u64)rw.am_lo | ((u64)rw.am_hi << 32);
+                const bool rmatch = S != 0 && ((((u64)rw.rm_lo | ((u64)rw.rm_hi << 32)) & rs.classes) != 0);
+                const AM mact = (AM)(((am >> ac0) & 1ull) | (((am >> ac1) & 1ull) << 1) | (((am >> ac2) & 1ull) << 2) | (((am >> ac3) & 1ull) << 3));
+                mrow = rmatch ? (AM)(mact & S) : (AM)0;
+              } else {
+                const TblRowPat pt = uload_rec<TblRowPat>(t.rows, 2 * row + 1);
+                const u32 n_act = pt.counts & 0xFFFFu;   // 0 = a single inline reference
+                const bool rmatch = is_res ? pat_role_match(rw, pt, rs, S != 0) : (S != 0 && pmatch(pt.resource, kind, KIND_BITS()));
+                if (rmatch) {
+                  if (rw.flags & CBH_ROW_F_ACTION_LIST) {
+                    for (u32 i = 0; i < n_act; ++i) mrow |= match_actions(uload(&t.pool[pt.action + i]));
+                  } else {
+                    mrow = match_actions(pt.action);
+                    if (n_act > 1) mrow |= match_actions(pt.a1);
+                    if (n_act > 2) mrow |= match_actions(pt.a2);
+                  }
+                  mrow &= S;
                 }
-                mrow &= S;
               }
               // every matched row is evaluated, also an ALLOW after an ALLOW that already fired: the
               // reference does the same (check.go:295-414), and its errors belong in evaluation_errors

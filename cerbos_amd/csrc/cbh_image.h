@@ -50,6 +50,8 @@ static inline const char* cbh_parse_image(TableDev& d, std::vector<uint32_t>& me
   if (!d.const_rec || !d.theap_rec) return ("blob is missing the constant record sections");
   d.role_class = dptr(CBH_SEC_ROLE_CLASS);
   if (!d.role_class) return ("blob is missing the role class section");
+  d.action_class = dptr(CBH_SEC_ACTION_CLASS);
+  if (!d.action_class) return ("blob is missing the action class section");
   d.gbits = (const u64*)dptr(CBH_SEC_GBITS); d.K = m[CBH_M_NSTRINGS];
   d.nfa[0] = (const u64*)dptr(CBH_SEC_NFA_ACTION); d.nfa[1] = (const u64*)dptr(CBH_SEC_NFA_ROLE); d.nfa[2] = (const u64*)dptr(CBH_SEC_NFA_KIND);
   d.nfa_words[0] = m[CBH_M_NFA_WORDS_ACTION]; d.nfa_words[1] = m[CBH_M_NFA_WORDS_ROLE]; d.nfa_words[2] = m[CBH_M_NFA_WORDS_KIND];

@@ -55,6 +55,7 @@ struct TableDev {
   const CBH_G u8* theap_tag; const CBH_G u64* theap_val;
   const CBH_G u32* const_rec; const CBH_G u32* theap_rec;   // the same values as 16-byte scalar-loadable records
   const CBH_G u8* role_class;                               // [K] role class of a string (cbh_blob.h CBH_SEC_ROLE_CLASS)
+  const CBH_G u8* action_class;                             // [K] action class of a string (CBH_SEC_ACTION_CLASS)
   const CBH_G u64* gbits; u32 K;
   const CBH_G u64* nfa[3]; u32 nfa_words[3];
   u32 flags;

@@ -29,7 +29,11 @@ BLOB_VERSION = 16
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
 PAT_ANY = 0x7FFFFFFF     # the lone "*": matches every string, no automaton needed
-ROW_F_ACTION_LIST, ROW_F_ROLE_LIST = 4, 8
+ROW_F_ACTION_LIST, ROW_F_ROLE_LIST, ROW_F_ROLE_BY_CLASS, ROW_F_ACTION_BY_CLASS = 4, 8, 16, 32
+# CbhRowField (cbh_blob.h): the hot half, then the pattern half of a rule record
+(ROW_FLAGS, ROW_COND, ROW_DRCOND, ROW_POLICY, ROW_ROLE_CLASSES, _, ROW_ACTION_CLASSES, _, ROW_ACTION, ROW_ROLE, ROW_RESOURCE,
+ ROW_COUNTS, ROW_A1, _, ROW_R1, _) = range(16)
+SEC_ACTION_CLASS = 28
 
 (SEC_META, SEC_STR_OFF, SEC_STR_BYTES, SEC_SCOPE_PARENT, SEC_SCOPE_FLAGS, SEC_SCOPE_SID, SEC_HASH,
  SEC_ROWS, SEC_RPROWS, SEC_U32POOL, SEC_DR, SEC_CODE, SEC_CONST_TAG, SEC_CONST_VAL, SEC_THEAP_TAG,
@@ -206,6 +210,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
     pool = []
     row_cols = [[] for _ in range(16)]
     row_roles = []   # per device row: its role strings (None for principal-policy rows)
+    row_actions = []  # likewise its action strings
     rp_cols = [[] for _ in range(4)]
     dr_cols = [[] for _ in range(4)]
     entries = []  # (k0,k1,k2,k3, v0,v1,v2,v3)
@@ -225,16 +230,16 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         return cond, drc
 
     def dim_list(dim, keys):
-        """-> (first word, count, list flag, [2nd..4th inline refs]).  One key: its reference, count 0.
-        Up to four: all inline in the record.  More: a slice of the u32 pool."""
+        """-> (first word, count, list flag, [2nd, 3rd inline refs]).  One key: its reference, count 0.
+        Up to three: all inline in the record.  More: a slice of the u32 pool."""
         if len(keys) == 1:
-            return (dim_ref(dim, keys[0]) if keys[0] else NONE), 0, False, [NONE] * 3
+            return (dim_ref(dim, keys[0]) if keys[0] else NONE), 0, False, [NONE] * 2
         refs = [dim_ref(dim, k) for k in keys]
-        if len(refs) <= 4:
-            return refs[0], len(refs), False, (refs[1:] + [NONE] * 3)[:3]
+        if len(refs) <= 3:
+            return refs[0], len(refs), False, (refs[1:] + [NONE] * 2)[:2]
         off = len(pool)
         pool.extend(refs)
-        return off, len(refs), True, [NONE] * 3
+        return off, len(refs), True, [NONE] * 2
 
     def add_bucket_rows(rows, principal_policy):
         """Emit the device rows of one bucket; returns how many.
@@ -269,18 +274,19 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
                     r_ref, r_cnt, r_pool, r_more = dim_list(DIM_ROLE, rl)
                     fl = {"ALLOW": 1, "DENY": 2}.get(effect, 0)
                     fl |= (ROW_F_ACTION_LIST if a_pool else 0) | (ROW_F_ROLE_LIST if r_pool else 0)
-                    row_cols[0].append(a_ref)
-                    row_cols[1].append(r_ref)
-                    row_cols[2].append(dim_ref(DIM_KIND, resource) if resource else NONE)
-                    row_cols[3].append(fl)
-                    row_cols[4].append(cond)
-                    row_cols[5].append(drc)
-                    row_cols[6].append(policy_id(grp[0]["origin_fqn"]))
-                    row_cols[7].append(a_cnt | (r_cnt << 16))
-                    for i in range(3):
-                        row_cols[8 + i].append(a_more[i])
-                        row_cols[11 + i].append(r_more[i])
+                    row_cols[ROW_FLAGS].append(fl)
+                    row_cols[ROW_COND].append(cond)
+                    row_cols[ROW_DRCOND].append(drc)
+                    row_cols[ROW_POLICY].append(policy_id(grp[0]["origin_fqn"]))
+                    row_cols[ROW_ACTION].append(a_ref)
+                    row_cols[ROW_ROLE].append(r_ref)
+                    row_cols[ROW_RESOURCE].append(dim_ref(DIM_KIND, resource) if resource else NONE)
+                    row_cols[ROW_COUNTS].append(a_cnt | (r_cnt << 16))
+                    for i in range(2):
+                        row_cols[ROW_A1 + i].append(a_more[i])
+                        row_cols[ROW_R1 + i].append(r_more[i])
                     row_roles.append(None if principal_policy else rl)
+                    row_actions.append(None if principal_policy else al)
                     n += 1
         return n
 
@@ -367,23 +373,39 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
     # mask of the classes its role list can match.  A wave ORs the classes of the roles it is walking
     # and skips, on the scalar unit, the records none of them can match (cbh_check_wave.h).
     # Class 63 = "any other string"; a glob role or a role beyond 62 classes matches everything.
-    role_class_of = {}
-    for rl in row_roles:
-        for role in rl or ():
-            if role and "*" not in role and role not in role_class_of and len(role_class_of) < 62:
-                role_class_of[role] = len(role_class_of)
-    role_class = np.full(K, 63, dtype=np.uint8)
-    for role, cls in role_class_of.items():
-        role_class[lt.string_ids[role]] = cls
-    for rl in row_roles:
-        mask = 0
-        for role in rl or [None]:
-            if not role or "*" in role:
-                mask = 0xFFFFFFFFFFFFFFFF
-            else:
-                mask |= 1 << role_class_of.get(role, 63)
-        row_cols[14].append(mask & 0xFFFFFFFF)
-        row_cols[15].append(mask >> 32)
+    def classes(lists):
+        """class numbers for the literal strings of `lists` (first come, first numbered; at most 62), the u8[K]
+        lookup table, and per row (mask of classes the list can match, does the mask decide the match exactly)."""
+        class_of = {}
+        for lst in lists:
+            for key in lst or ():
+                if key and "*" not in key and key not in class_of and len(class_of) < 62:
+                    class_of[key] = len(class_of)
+        table = np.full(K, 63, dtype=np.uint8)
+        for key, cls in class_of.items():
+            table[lt.string_ids[key]] = cls
+        per_row = []
+        for lst in lists:
+            mask, exact = 0, lst is not None
+            for key in lst or [None]:
+                if key == "*":                      # matches every string: every bit, still exact
+                    mask = 0xFFFFFFFFFFFFFFFF
+                elif not key or "*" in key:         # a glob (or no list: principal-policy row): cannot be told by class
+                    mask, exact = 0xFFFFFFFFFFFFFFFF, False
+                else:
+                    mask |= 1 << class_of.get(key, 63)
+                    exact = exact and key in class_of
+            per_row.append((mask, exact))
+        return table, per_row
+
+    role_class, role_rows = classes(row_roles)
+    action_class, action_rows = classes(row_actions)
+    for i, ((rmask, rexact), (amask, aexact)) in enumerate(zip(role_rows, action_rows)):
+        row_cols[ROW_ROLE_CLASSES].append(rmask & 0xFFFFFFFF)
+        row_cols[ROW_ROLE_CLASSES + 1].append(rmask >> 32)
+        row_cols[ROW_ACTION_CLASSES].append(amask & 0xFFFFFFFF)
+        row_cols[ROW_ACTION_CLASSES + 1].append(amask >> 32)
+        row_cols[ROW_FLAGS][i] |= (ROW_F_ROLE_BY_CLASS if rexact else 0) | (ROW_F_ACTION_BY_CLASS if aexact else 0)
 
     # ---- directory hash table
     nslots = 16
@@ -487,6 +509,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         (SEC_CONST_REC, len(pb.const_tag), val_records(pb.const_tag, pb.const_val)),
         (SEC_THEAP_REC, len(pb.theap_tag), val_records(pb.theap_tag, pb.theap_val)),
         (SEC_ROLE_CLASS, K, role_class.tobytes()),
+        (SEC_ACTION_CLASS, K, action_class.tobytes()),
         # host only: where each attribute column comes from (the C++ ingest walks these paths)
         (SEC_COLUMN_PATHS, len(lt.columns), _column_paths(lt.columns)),
         # host only: policy keys of CBH_P_TABLE policy words, then derived-role names in edr_mask bit order
