@@ -84,6 +84,7 @@ enum CbhMeta {
 #define CBH_MF_HAS_ANY_PATTERN 16u      /* some pattern reference is CBH_PAT_ANY (treated as a glob table) */
 #define CBH_MF_HAS_PRINCIPAL_POLICIES 32u
 #define CBH_MF_NEEDS_STRING_BYTES 128u   /* glob automata, or a program that looks inside a string: upload str_off / str_bytes / str_flags */
+#define CBH_MF_FLAT 256u                  /* resource policies only, leaf conditions, every record decided by class masks: cbh_check_flat.h */
 #define CBH_MF_READS_REQUEST_STRINGS 64u /* some program reads a raw request string (CBH_RQ_S_*): upload those fields */
 
 // Directory: open addressing, linear probing, key.x == CBH_NONE marks an empty slot.

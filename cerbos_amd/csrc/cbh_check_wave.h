@@ -358,6 +358,29 @@ __device__ __forceinline__ void load_args(KernelArgs& dst, const KernelArgs* src
 #endif
 }
 
+// Column cache: issue every load of this lane's request attributes now, park them in LDS
+// (async global->LDS copies, `global_load_lds_dword`: no staging registers, the loads of every
+// column are in flight together; the destination of such a copy is wave-uniform base + lane * 4,
+// which is exactly a [column][lane] dword plane)
+__device__ __forceinline__ void fill_column_cache(const Ctx& c, const BatchDev& b, u32 NR, u32 req) {
+  for (u32 k = 0; k < c.n_cached; ++k) {
+    const size_t ix = (size_t)k * NR + req;
+    const CBH_G u32* vsrc = (const CBH_G u32*)(b.col_val + ix);
+    const CBH_G u8* tsrc = b.col_tag + (ix & ~(size_t)3);   // the aligned dword holding this lane's tag byte
+#ifndef CBH_HOSTSIM
+    __builtin_amdgcn_global_load_lds((const CBH_G void*)vsrc, (CBH_L void*)(c.cc + k * CBH_BLOCK), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((const CBH_G void*)(vsrc + 1), (CBH_L void*)(c.cc + (c.n_cached + k) * CBH_BLOCK), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((const CBH_G void*)tsrc, (CBH_L void*)(c.cc + (2 * c.n_cached + k) * CBH_BLOCK), 4, 0, 0);
+#else
+    (void)tsrc;   // the host arrays carry no slack after their last byte: place the one byte instead
+    const u32 tw = (u32)b.col_tag[ix] << ((ix & 3u) * 8u);
+    c.cc[k * CBH_BLOCK + c.tid] = vsrc[0];
+    c.cc[(c.n_cached + k) * CBH_BLOCK + c.tid] = vsrc[1];
+    c.cc[(2 * c.n_cached + k) * CBH_BLOCK + c.tid] = tw;
+#endif
+  }
+}
+
 struct CbhPassPrincipal { static constexpr bool value = false; };   // tags of the two instantiations of the
 struct CbhPassResource { static constexpr bool value = true; };     // policy pass (check_body below)
 
@@ -391,26 +414,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   const u32 act_off = RQ(CBH_RQ_ACT_OFF);
   const u32 act_cnt = valid ? RQ(CBH_RQ_ACT_CNT) : 0;   // <= 64 (the flattener splits larger requests)
 #undef RQ
-  // column cache: issue every load of this lane's request attributes now, park them in LDS
-  // (async global->LDS copies, `global_load_lds_dword`: no staging registers, the loads of every
-  // column are in flight together; the destination of such a copy is wave-uniform base + lane * 4,
-  // which is exactly a [column][lane] dword plane)
-  for (u32 k = 0; k < c.n_cached; ++k) {
-    const size_t ix = (size_t)k * NR + req;
-    const CBH_G u32* vsrc = (const CBH_G u32*)(b.col_val + ix);
-    const CBH_G u8* tsrc = b.col_tag + (ix & ~(size_t)3);   // the aligned dword holding this lane's tag byte
-#ifndef CBH_HOSTSIM
-    __builtin_amdgcn_global_load_lds((const CBH_G void*)vsrc, (CBH_L void*)(c.cc + k * CBH_BLOCK), 4, 0, 0);
-    __builtin_amdgcn_global_load_lds((const CBH_G void*)(vsrc + 1), (CBH_L void*)(c.cc + (c.n_cached + k) * CBH_BLOCK), 4, 0, 0);
-    __builtin_amdgcn_global_load_lds((const CBH_G void*)tsrc, (CBH_L void*)(c.cc + (2 * c.n_cached + k) * CBH_BLOCK), 4, 0, 0);
-#else
-    (void)tsrc;   // the host arrays carry no slack after their last byte: place the one byte instead
-    const u32 tw = (u32)b.col_tag[ix] << ((ix & 3u) * 8u);
-    c.cc[k * CBH_BLOCK + c.tid] = vsrc[0];
-    c.cc[(c.n_cached + k) * CBH_BLOCK + c.tid] = vsrc[1];
-    c.cc[(2 * c.n_cached + k) * CBH_BLOCK + c.tid] = tw;
-#endif
-  }
+  fill_column_cache(c, b, NR, req);
   constexpr u32 AM_BITS = sizeof(AM) * 8;
   const AM all = act_cnt >= AM_BITS ? (AM)~(AM)0 : (AM)(((AM)1 << act_cnt) - 1);
   // the first four action ids stay in registers (requests rarely carry more)

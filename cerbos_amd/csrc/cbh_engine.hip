@@ -177,7 +177,7 @@ struct cbh_device_batch {
   KernelArgs* d_args = nullptr;   // device copy of the launch arguments
   KernelArgs last_args;           // what d_args currently holds
   bool have_args = false;
-  u32 max_actions = 0;            // largest CBH_RQ_ACT_CNT of the batch: selects the action-mask width
+  u32 max_actions = 0, max_roles = 0;   // largest CBH_RQ_ACT_CNT / ROLE_CNT of the batch: select the kernel
   std::vector<std::pair<void*, size_t>> allocs;   // (block, capacity) taken from the replica's pool
 };
 
@@ -323,7 +323,7 @@ extern "C" void* cbh_table_device_ptr(const cbh_table* t) { return t ? t->reps[0
 // ---- batch validation (O(n_requests), both entry points) ---------------------------------------------------
 // Offsets and counts the kernels index device memory with must lie inside the arrays they index.  String ids
 // need no host pass: the kernels only compare them, or bound them before using one as an index.
-struct BatchShape { u32 max_actions = 0; bool ascending = true; };
+struct BatchShape { u32 max_actions = 0, max_roles = 0; bool ascending = true; };
 static int validate_batch(const cbh_table* t, const cbh_batch* in, BatchShape& sh) {
   if (in->n_columns != t->meta[CBH_M_NCOLUMNS]) return fail("cbh_batch.n_columns does not match the table's column schema");
   const size_t NR = in->n_requests;
@@ -336,10 +336,11 @@ static int validate_batch(const cbh_table* t, const cbh_batch* in, BatchShape& s
   if (in->str_bytes_len && !in->str_bytes) return fail("cbh_batch: a required array is NULL");
   const u32* role_off = in->req_u32 + (size_t)CBH_RQ_ROLE_OFF * NR; const u32* role_cnt = in->req_u32 + (size_t)CBH_RQ_ROLE_CNT * NR;
   const u32* act_off = in->req_u32 + (size_t)CBH_RQ_ACT_OFF * NR; const u32* act_cnt = in->req_u32 + (size_t)CBH_RQ_ACT_CNT * NR;
-  u32 maxa = 0; u64 bad = 0, prev_end = 0; bool asc = true;
+  u32 maxa = 0, maxr = 0; u64 bad = 0, prev_end = 0; bool asc = true;
   for (size_t r = 0; r < NR; ++r) {
     const u32 n = act_cnt[r];
     maxa = n > maxa ? n : maxa;
+    maxr = role_cnt[r] > maxr ? role_cnt[r] : maxr;
     bad |= (u64)((u64)role_off[r] + role_cnt[r] > in->n_roles) | (u64)((u64)act_off[r] + n > in->n_tuples);
     asc = asc && act_off[r] >= prev_end;
     prev_end = (u64)act_off[r] + n;
@@ -347,7 +348,7 @@ static int validate_batch(const cbh_table* t, const cbh_batch* in, BatchShape& s
   if (maxa > CBH_MAX_ACTIONS_PER_REQUEST) return fail("cbh_batch: a request carries more than CBH_MAX_ACTIONS_PER_REQUEST actions");
   if (bad) return fail("cbh_batch: a request's role or action slice lies outside the batch");
   if (in->n_strings && in->str_off[in->n_strings] > in->str_bytes_len) return fail("cbh_batch: string offsets exceed str_bytes_len");
-  sh.max_actions = maxa; sh.ascending = asc;
+  sh.max_actions = maxa; sh.max_roles = maxr; sh.ascending = asc;
   return 0;
 }
 
@@ -415,7 +416,7 @@ extern "C" int cbh_batch_upload_on(cbh_table* t, uint32_t device_index, const cb
   cbh_device_batch* b = new (std::nothrow) cbh_device_batch();
   if (!b) return fail("out of memory");
   cbh_table_retain(t);
-  b->table = t; b->rep = rep; b->max_actions = sh.max_actions;
+  b->table = t; b->rep = rep; b->max_actions = sh.max_actions; b->max_roles = sh.max_roles;
   BatchDev& d = b->dev;
   d.n_requests = in->n_requests; d.n_tuples = in->n_tuples; d.n_roles = in->n_roles;
   d.n_columns = in->n_columns; d.n_strings = in->n_strings; d.heap_len = in->heap_len;
@@ -515,7 +516,7 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   sl.pending = false;
   if (d.n_requests) {
     const u32 grid = (d.n_requests + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
-    const cbh_check_kernel_fn kernel = cbh_pick_check_kernel(rep->dev.flags, rep->dev.n_dr, maxw != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), b->max_actions);
+    const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, maxw != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), b->max_actions, b->max_roles, p->flags);
     if (timed) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), check_lds_bytes(d), s, sl.ev[2], sl.ev[3], 0, b->last_args, (const KernelArgs*)b->d_args);
     else hipLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), check_lds_bytes(d), s, b->last_args, (const KernelArgs*)b->d_args);
     sl.pending = timed;
@@ -728,11 +729,11 @@ static void launch_resolve(const Replica* rep, const KernelArgs& ka, const Layou
     hipLaunchKernelGGL(cbh_resolve_globs_kernel, dim3(grid), dim3(CBH_BLOCK), (size_t)(2 + 512) * maxw * sizeof(u64), s, rep->dev, ka.b);
   } else if (hipMemsetAsync(ka.b.gbits, 0, L.gbits.bytes, s) != hipSuccess) rc = -1;   // no automata: no string matches a glob
 }
-static void launch_check(const Replica* rep, KernelArgs ka, const KernelArgs* d_args, u32 lo, u32 hi, u32 max_actions, hipStream_t s) {
+static void launch_check(const Replica* rep, KernelArgs ka, const KernelArgs* d_args, u32 lo, u32 hi, const BatchShape& sh, hipStream_t s) {
   if (hi <= lo) return;
   ka.b.req_lo = lo; ka.b.req_hi = hi;
   const u32 grid = (hi - lo + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
-  const cbh_check_kernel_fn kernel = cbh_pick_check_kernel(rep->dev.flags, rep->dev.n_dr, nfa_maxw(rep->dev) != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), max_actions);
+  const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, nfa_maxw(rep->dev) != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), sh.max_actions, sh.max_roles, ka.flags);
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), check_lds_bytes(ka.b), s, ka, d_args);
 }
 
@@ -767,7 +768,7 @@ static int run_small(cbh_table* t, Replica* rep, const cbh_batch* in, const cbh_
     HIPCHK(hipMemcpyAsync(c->d, c->h, L.in_end, hipMemcpyHostToDevice, s));
     launch_resolve(rep, ka, L, s, rc);
   }
-  launch_check(rep, ka, (const KernelArgs*)(base + L.args.off), 0, in->n_requests, sh.max_actions, s);
+  launch_check(rep, ka, (const KernelArgs*)(base + L.args.off), 0, in->n_requests, sh, s);
   HIPCHK(hipGetLastError());
   if (rc != 0) return fail("hipMemsetAsync failed");
   if (!zero_copy && L.total > L.out_begin) HIPCHK(hipMemcpyAsync(c->h + L.out_begin, c->d + L.out_begin, L.total - L.out_begin, hipMemcpyDeviceToHost, s));
@@ -821,7 +822,7 @@ static int run_range(cbh_table* t, Replica* rep, const cbh_batch* in, const cbh_
     HIPCHK(hipMemcpyAsync(base + L.in_begin, slab, end - L.in_begin, hipMemcpyHostToDevice, s0));
     launch_resolve(rep, ka, L, s0, rc);
     if (rc != 0) return fail("hipMemsetAsync failed");
-    launch_check(rep, ka, d_args, 0, (u32)NR, sh.max_actions, s0);
+    launch_check(rep, ka, d_args, 0, (u32)NR, sh, s0);
     HIPCHK(hipGetLastError());
     struct Run { size_t off, bytes; uint8_t* dst; };
     Run run{0, 0, nullptr};
@@ -877,7 +878,7 @@ static int run_range(cbh_table* t, Replica* rep, const cbh_batch* in, const cbh_
     size_t tb = 0, te = 0;
     if (hi > lo) tuples_of(lo, hi, tb, te);
     if (te > tb) HIPCHK(hipMemcpyAsync(base + L.act.off + tb * 4, in->tuple_action + tb, (te - tb) * 4, hipMemcpyHostToDevice, s));
-    launch_check(rep, ka, d_args, lo, hi, sh.max_actions, s);
+    launch_check(rep, ka, d_args, lo, hi, sh, s);
     HIPCHK(hipGetLastError());
     if (te > tb) {
       HIPCHK(hipMemcpyAsync(out->effect + tb, base + L.eff.off + tb, te - tb, hipMemcpyDeviceToHost, s));
@@ -905,7 +906,7 @@ static int run_range(cbh_table* t, Replica* rep, const cbh_batch* in, const cbh_
     size_t tb = 0, te = 0;
     tuples_of(a, b, tb, te);
     if (te > tb) HIPCHK(hipMemcpyAsync(base + L.act.off + tb * 4, in->tuple_action + tb, (te - tb) * 4, hipMemcpyHostToDevice, s));
-    launch_check(rep, ka, d_args, a, b, sh.max_actions, s);
+    launch_check(rep, ka, d_args, a, b, sh, s);
     if (te > tb) {
       HIPCHK(hipMemcpyAsync(out->effect + tb, base + L.eff.off + tb, te - tb, hipMemcpyDeviceToHost, s));
       if (out->policy) HIPCHK(hipMemcpyAsync(out->policy + tb, base + L.pol.off + tb * 4, (te - tb) * 4, hipMemcpyDeviceToHost, s));

@@ -131,3 +131,4 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_resolve_globs_kernel(TableDev t
 #endif  // CBH_HOSTSIM
 
 #include "cbh_check_wave.h"
+#include "cbh_check_flat.h"

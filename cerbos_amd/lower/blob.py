@@ -448,6 +448,13 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
                      | (32 if pp_exists else 0)
                      | (64 if any(f >= 10 for f in pb.req_fields) else 0)
                      | (128 if (pb.reads_string_bytes or any(lt.nfas[d].patterns for d in range(3))) else 0))
+    # FLAT (cbh_check_flat.h): nothing but resource policies with leaf conditions whose records the class masks decide
+    max_depth = max(len(list(namer.scope_parents(sc))) + 1 if sc else 1 for sc in lt.scopes)
+    by_class = ROW_F_ROLE_BY_CLASS | ROW_F_ACTION_BY_CLASS
+    flat = (not pb.has_generic and not pb.uses_runtime and not dr_cols[0] and not rp_buckets and not pp_exists
+            and not (int(meta[M_FLAGS]) & 2) and not any(lt.nfas[d].patterns for d in range(3)) and max_depth <= 16
+            and all((f & by_class) == by_class for f in row_cols[ROW_FLAGS]) and all(d == NONE for d in row_cols[ROW_DRCOND]))
+    meta[M_FLAGS] |= 256 if flat else 0
     meta[M_MAX_STACK] = pb.max_stack
     meta[M_NDRNAMES] = len(lt.dr_names)
     meta[M_NFA_WORDS_ACTION] = lt.nfas[0].words
@@ -523,7 +530,8 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         "unsupported_expressions": len(lt.unsupported),
         "globs": [len(d.globs) for d in dims],
         "reads_request_strings": bool(int(meta[M_FLAGS]) & 64),
-        "needs_string_bytes": bool(int(meta[M_FLAGS]) & 128),   # glob automata or programs that look inside strings   # raw request strings (R.id, R.kind, scopes, versions) read by some program
+        "needs_string_bytes": bool(int(meta[M_FLAGS]) & 128),
+        "flat": bool(int(meta[M_FLAGS]) & 256),   # eligible for cbh_check_flat_kernel (batch shape and mode permitting)   # glob automata or programs that look inside strings   # raw request strings (R.id, R.kind, scopes, versions) read by some program
         "generic_programs": bool(pb.has_generic),   # selects the kernel with the operand-stack interpreter
         # feature class of the 32-bit-mask kernels (cbh_pick_check_kernel): "" = everything (role policies /
         # parent roles), else "_f<bits>" with bit 0 = derived roles, bit 2 = glob patterns

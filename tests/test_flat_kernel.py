@@ -1,0 +1,133 @@
+"""cbh_check_flat_kernel (cbh_check_flat.h): the scopes -> records -> roles-side-by-side walk for flat tables, fuzzed
+against oracle/check.py.
+
+Stores here are built to BE flat (resource policies only, literal or `*` roles and actions, leaf conditions) and to
+stress what the inside-out loop order must keep exact: several roles per principal where a later role allows at a
+shallower scope than an earlier one, DENY rules between ALLOW rules, REQUIRE_PARENTAL_CONSENT / OVERRIDE_PARENT
+chains, conditions that raise CEL errors (missing attributes) on rules only a LATER role matches - the reference
+never evaluates a role after the one that allowed (check.go:433-436), so those errors must not be reported.
+Compared per action: effect, policy key, scope; per request: whether evaluation errors were recorded.
+CPU tier: the kernel source on the host simulator.  GPU tier: the kernel.
+"""
+import numpy as np
+import pytest
+
+from cerbos_amd import capi
+from cerbos_amd.engine import Conf, HipEvaluator
+from cerbos_amd.flatten import Flattener
+from cerbos_amd.lower.blob import lower_rule_table
+from cerbos_amd.policy.loader import policies_from_docs
+from cerbos_amd.ruletable.build import rule_table_from_policies
+from helpers import norm_actions
+from oracle.check import EvalParams, RuleTableOracle
+
+API = "api.cerbos.dev/v1"
+NOW = 1_700_000_000_000_000_000
+SCOPES = ["", "acme", "acme.hr", "acme.hr.uk"]
+KINDS = ["doc", "report"]
+ROLES = ["user", "manager", "admin", "guest", "auditor", "intern"]
+ACTIONS = ["view", "edit", "delete", "approve", "share", "export"]
+CONDS = ["R.attr.public == true", "R.attr.owner == P.id", "R.attr.amount > 100", "P.attr.department == R.attr.department",
+         'R.attr.status in ["OPEN", "PENDING"]', "R.attr.missing == 1", "P.attr.level >= 3", "R.attr.owner != P.id"]
+
+
+def _cond(rng):
+    r = rng.random()
+    if r < 0.35:
+        return None
+    if r < 0.8:
+        return {"match": {"expr": str(rng.choice(CONDS))}}
+    kind = str(rng.choice(["all", "any", "none"]))
+    return {"match": {kind: {"of": [{"expr": str(e)} for e in rng.choice(CONDS, size=int(rng.integers(2, 4)), replace=False)]}}}
+
+
+def _store(rng):
+    docs = []
+    for kind in KINDS:
+        for si, scope in enumerate(SCOPES):
+            if scope and rng.random() < 0.2:
+                continue
+            rules = []
+            for _ in range(int(rng.integers(1, 7))):
+                rule = {"actions": [str(a) for a in rng.choice(ACTIONS + ["*"], size=int(rng.integers(1, 6)), replace=False)],
+                        "roles": [str(r) for r in rng.choice(ROLES + ["*"], size=int(rng.integers(1, 5)), replace=False)],
+                        "effect": "EFFECT_ALLOW" if rng.random() < 0.7 else "EFFECT_DENY"}
+                c = _cond(rng)
+                if c:
+                    rule["condition"] = c
+                rules.append(rule)
+            pol = {"resource": kind, "version": "default", "rules": rules}
+            if scope:
+                pol["scope"] = scope
+                if rng.random() < 0.5:
+                    pol["scopePermissions"] = "SCOPE_PERMISSIONS_REQUIRE_PARENTAL_CONSENT_FOR_ALLOWS"
+            docs.append({"apiVersion": API, "resourcePolicy": pol})
+    return docs
+
+
+def _requests(rng, n):
+    out = []
+    for i in range(n):
+        roles = [str(r) for r in rng.choice(ROLES + ["stranger"], size=int(rng.integers(0, 5)), replace=False)]
+        acts = [str(a) for a in rng.choice(ACTIONS + ["nothing"], size=int(rng.integers(0, 5)), replace=False)]
+        pid = "p%d" % rng.integers(0, 4)
+        rattr = {"public": bool(rng.random() < 0.4), "owner": "p%d" % rng.integers(0, 4), "amount": float(rng.integers(0, 200)),
+                 "department": str(rng.choice(["eng", "ops"])), "status": str(rng.choice(["OPEN", "CLOSED"]))}
+        pattr = {"department": str(rng.choice(["eng", "ops"])), "level": float(rng.integers(1, 6))}
+        for d in (rattr, pattr):
+            for k in list(d):
+                if rng.random() < 0.08:
+                    del d[k]
+        out.append({"requestId": "q%d" % i, "actions": acts, "principal": {"id": pid, "roles": roles, "attr": pattr},
+                    "resource": {"kind": str(rng.choice(KINDS + ["other"])), "id": "r%d" % i, "attr": rattr,
+                                 "scope": str(rng.choice(SCOPES + ["acme.hr.uk.london", "zzz"]))}})
+    return out
+
+
+def _run_seed(seed, make_evaluator, close):
+    rng = np.random.default_rng(40_000 + seed)
+    rt = rule_table_from_policies(policies_from_docs(_store(rng)))
+    lt = lower_rule_table(rt)
+    assert lt.stats["flat"], "the generator must produce flat tables"
+    inputs = _requests(rng, 200)
+    batch = Flattener(lt).flatten(inputs)
+    assert int(batch.req_u32[9].max()) <= 4 and int(batch.req_u32[7].max()) <= 4   # the flat kernel's batch shape
+    ev = make_evaluator(lt)
+    orc = RuleTableOracle(rt)
+    n_err = 0
+    try:
+        for lenient in (False, True):
+            flags = capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0)
+            res = ev.table.check(batch, now_ns=NOW, flags=flags)
+            outs, bad = ev.assemble(inputs, batch, res, "default", allow_unsupported=True)
+            assert not bad
+            t = 0
+            for inp, have in zip(inputs, outs):
+                want = orc.check(inp, EvalParams(now_ns=NOW, lenient_scope_search=lenient))
+                assert norm_actions(have) == norm_actions(want), (seed, lenient, inp)
+                na = len(inp["actions"])
+                got_err = bool((res.status[t:t + na] == capi.ST_CEL_ERROR).any())
+                assert got_err == bool(want.get("evaluationErrors")), (seed, lenient, inp, want.get("evaluationErrors"))
+                n_err += got_err
+                t += na
+    finally:
+        if close:
+            ev.close()
+    return n_err
+
+
+@pytest.mark.parametrize("seed", range(25))
+def test_flat_kernel_source_vs_oracle(seed):
+    from test_hostsim_golden import HostSimEvaluator
+    _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False)
+
+
+def test_error_cases_do_occur():
+    from test_hostsim_golden import HostSimEvaluator
+    assert sum(_run_seed(s, lambda lt: HostSimEvaluator(lt, Conf()), False) for s in range(3)) > 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(25))
+def test_flat_kernel_on_gpu(seed):
+    _run_seed(seed, lambda lt: HipEvaluator(lt, Conf()), True)
