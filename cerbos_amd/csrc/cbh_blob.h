@@ -51,6 +51,7 @@ enum CbhSectionId {
   CBH_SEC_CONST_REC = 23,  // u32[n_consts][4]  {tag, 0, lo, hi}: the constant pool as scalar-loadable records
   CBH_SEC_THEAP_REC = 24,  // u32[theap_len][4] the constant heap, same record form
   CBH_SEC_ROLE_CLASS = 25, // u8[K] class (0..61) of a string that is a literal rule role, 63 = any other string
+  CBH_SEC_ROWPAT = 29,       // u32[n_rows][8]  pattern halves of the rule records (CbhRowPatField order)
   CBH_SEC_ACTION_CLASS = 28, // u8[K] class (0..61) of a string that is a literal rule action of a resource policy, 63 = any other string
   CBH_SEC_HOST_NAMES = 27,   // host only: {u32 n, {u16 len, bytes}*} policy keys (CBH_P_TABLE ids), then the same for derived-role names
   CBH_SEC_COLUMN_PATHS = 26, // host only (cbh_ingest.cpp): per column {u8 root 0=P.attr 1=R.attr 2=auxData.jwt 3=auxData.jwts, u8 n_keys, {u16 len, bytes}*}
@@ -121,8 +122,10 @@ enum CbhBucketType {
 //              action of the table a class number < 62; 63 = any other string).  When a list is all
 //              literals with a class (or "*": every bit set) the mask decides the match exactly
 //              (CBH_ROW_F_ROLE_BY_CLASS / _ACTION_BY_CLASS) and the second half is never read;
-//   pattern half  the pattern references themselves (up to three inline, longer lists in U32POOL) for
-//              records with glob patterns or more classes than fit, and for principal-policy rows.
+//   leaf half  a copy of the 8-dword fused-leaf record of the rule's condition when that is a single leaf.
+// The pattern references themselves (up to three inline, longer lists in U32POOL) live in a parallel section,
+// CBH_SEC_ROWPAT: they are read only for records with glob patterns or more classes than fit, and for
+// principal-policy rows.
 enum CbhRowField {
   CBH_ROW_FLAGS = 0,    // bits 0..1 effect (1 ALLOW, 2 DENY), CBH_ROW_F_*
   CBH_ROW_COND = 1,     // program entry or CBH_NONE
@@ -130,19 +133,25 @@ enum CbhRowField {
   CBH_ROW_POLICY = 3,   // policy id of the origin policy (strict-mode attribution)
   CBH_ROW_ROLE_CLASSES = 4,    // u64 (2 dwords): role classes the record's role list can match
   CBH_ROW_ACTION_CLASSES = 6,  // u64 (2 dwords): action classes its action list can match
-  CBH_ROW_ACTION = 8,   // pattern ref (action dim), or U32POOL offset of a list of them (CBH_ROW_F_ACTION_LIST)
-  CBH_ROW_ROLE = 9,     // pattern ref (role dim), or U32POOL offset of a list of them (CBH_ROW_F_ROLE_LIST)
-  CBH_ROW_RESOURCE = 10, // pattern ref (kind dim) - tested for principal-policy rows only
-  CBH_ROW_COUNTS = 11,  // action list length | role list length << 16 (0 = one inline reference)
-  CBH_ROW_A1 = 12,      // 2nd, 3rd action pattern ref of a list of at most three (inline, no CBH_ROW_F_ACTION_LIST)
-  CBH_ROW_R1 = 14,      // 2nd, 3rd role pattern ref likewise
+  CBH_ROW_LEAF = 8,     // 8 dwords: a copy of the condition's fused-leaf record (CBH_ROW_F_LEAF_EMBEDDED) - the
+                        // visit that needs the condition has it without a second, dependent load
   CBH_ROW_NF = 16       // record = 16 dwords, 64-byte aligned
+};
+enum CbhRowPatField {   // CBH_SEC_ROWPAT: the pattern half of record i, 8 dwords
+  CBH_PAT_ACTION = 0,   // pattern ref (action dim), or U32POOL offset of a list of them (CBH_ROW_F_ACTION_LIST)
+  CBH_PAT_ROLE = 1,     // pattern ref (role dim), or U32POOL offset of a list of them (CBH_ROW_F_ROLE_LIST)
+  CBH_PAT_RESOURCE = 2, // pattern ref (kind dim) - tested for principal-policy rows only
+  CBH_PAT_COUNTS = 3,   // action list length | role list length << 16 (0 = one inline reference)
+  CBH_PAT_A1 = 4,       // 2nd, 3rd action pattern ref of a list of at most three (inline, no CBH_ROW_F_ACTION_LIST)
+  CBH_PAT_R1 = 6,       // 2nd, 3rd role pattern ref likewise
+  CBH_PAT_NF = 8
 };
 #define CBH_ROW_INLINE_MAX 3u           /* longer lists live in U32POOL */
 #define CBH_ROW_F_ACTION_LIST 4u
 #define CBH_ROW_F_ROLE_LIST 8u
 #define CBH_ROW_F_ROLE_BY_CLASS 16u     /* the role class mask decides the role match exactly */
 #define CBH_ROW_F_ACTION_BY_CLASS 32u   /* the action class mask decides the action match exactly */
+#define CBH_ROW_F_LEAF_EMBEDDED 64u     /* dwords 8..15 hold the condition's fused-leaf record (no derived-role condition) */
 enum CbhRpField { // role-policy rows
   CBH_RP_RESOURCE = 0,  // pattern ref (kind dim)
   CBH_RP_ALLOW_OFF = 1, // into U32POOL: pattern refs (action dim)

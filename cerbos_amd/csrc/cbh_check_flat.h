@@ -51,24 +51,29 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 #undef RQ
   fill_column_cache(c, b, NR, req);
   const u32 all = (1u << act_cnt) - 1u;
-  // actions and roles -> classes (CBH_SEC_ACTION_CLASS / CBH_SEC_ROLE_CLASS; 63 = a string no rule names)
+  // actions and roles -> classes (CBH_SEC_ACTION_CLASS / CBH_SEC_ROLE_CLASS; 63 = a string no rule names).
+  // A flat table has fewer than 32 classes per dimension and its masks mirror "any other string" (bit 63)
+  // in bit 31 of the low dword: the match is a 1-bit field extract from ONE dword at a per-lane position.
   u32 ac[4], rc[4];
 #pragma unroll
   for (u32 k = 0; k < 4; ++k) {
     const u32 a = k < act_cnt ? b.tuple_action[act_off + k] : CBH_NONE;
-    ac[k] = a < t.K ? (u32)t.action_class[a] : 63u;
+    const u32 ca = a < t.K ? (u32)t.action_class[a] : 63u;
+    ac[k] = ca < 31u ? ca : 31u;
     const u32 r = k < role_cnt ? b.roles[role_off + k] : CBH_NONE;
-    rc[k] = r < t.K ? (u32)t.role_class[r] : 63u;
+    const u32 cr = r < t.K ? (u32)t.role_class[r] : 63u;
+    rc[k] = cr < 31u ? cr : 31u;
   }
-  u64 lane_ac = 0, lane_rc = 0;
+  u32 lane_ac = 0, lane_rc = 0;
   u32 walks = 0;   // bit 4r + k: role r exists and action k exists
 #pragma unroll
   for (u32 k = 0; k < 4; ++k) {
-    if (k < act_cnt) lane_ac |= 1ull << ac[k];
-    if (k < role_cnt) { lane_rc |= 1ull << rc[k]; walks |= all << (4 * k); }
+    if (k < act_cnt) lane_ac |= 1u << ac[k];
+    if (k < role_cnt) { lane_rc |= 1u << rc[k]; walks |= all << (4 * k); }
   }
   // classes present in the wave: a record none of them can match is skipped on the scalar unit
-  const u64 wave_ac = wave_or64(lane_ac), wave_rc = wave_or64(lane_rc);
+  const u64 wave_cls = wave_or64((u64)lane_ac | ((u64)lane_rc << 32));
+  const u32 wave_ac = (u32)wave_cls, wave_rc = (u32)(wave_cls >> 32);
 
   const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
   Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false; L.pid = pid;
@@ -102,15 +107,18 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
       if (have_bucket) {
         for (u32 row = bucket.x; row < bucket.x + bucket.y; ++row) {   // bindings in order (check.go:295-414)
           const TblRow rw = uload_rec<TblRow>(t.rows, 2 * row);
-          const u64 rm = (u64)rw.rm_lo | ((u64)rw.rm_hi << 32), am = (u64)rw.am_lo | ((u64)rw.am_hi << 32);
-          if ((rm & wave_rc) == 0 || (am & wave_ac) == 0) continue;
-          const u32 mact = (u32)((am >> ac[0]) & 1ull) | ((u32)((am >> ac[1]) & 1ull) << 1) | ((u32)((am >> ac[2]) & 1ull) << 2) | ((u32)((am >> ac[3]) & 1ull) << 3);
-          const u32 mrole = ((u32)((rm >> rc[0]) & 1ull) * 0xFu) | ((u32)((rm >> rc[1]) & 1ull) * 0xF0u) | ((u32)((rm >> rc[2]) & 1ull) * 0xF00u) | ((u32)((rm >> rc[3]) & 1ull) * 0xF000u);
+          const LeafRec lf = uload_rec<LeafRec>(t.rows, 2 * row + 1);
+          if ((rw.rm_lo & wave_rc) == 0 || (rw.am_lo & wave_ac) == 0) continue;
+          const u32 mact = ((rw.am_lo >> ac[0]) & 1u) | (((rw.am_lo >> ac[1]) & 1u) << 1) | (((rw.am_lo >> ac[2]) & 1u) << 2) | (((rw.am_lo >> ac[3]) & 1u) << 3);
+          // one nibble per role (sign-extended 1-bit extracts), one bit per nibble for the actions; walks of other groups sit out
+          const u32 mrole = ((0u - ((rw.rm_lo >> rc[0]) & 1u)) & 0xFu) | ((0u - ((rw.rm_lo >> rc[1]) & 1u)) & 0xF0u) |
+                            ((0u - ((rw.rm_lo >> rc[2]) & 1u)) & 0xF00u) | ((0u - ((rw.rm_lo >> rc[3]) & 1u)) & 0xF000u);
           const u32 m = ing ? (mrole & (mact * 0x1111u) & S) : 0u;
           if (wave_ballot(m != 0) == 0) continue;
           int r = 1;
           if (rw.cond != CBH_NONE) {
-            r = eval_cond<false>(c, L, rw.cond, m != 0);   // once per record and request, whatever the roles (check.go:316-340)
+            // once per record and request, whatever the roles (check.go:316-340)
+            r = (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) ? eval_cond_rec<false>(c, L, rw.cond, lf, m != 0) : eval_cond<false>(c, L, rw.cond, m != 0);
             if (L.status & CBH_ST_CEL_ERROR) err |= m;
             if (L.status & CBH_ST_UNSUPPORTED) unsup |= m;
             L.status = 0;

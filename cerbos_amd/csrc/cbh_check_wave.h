@@ -283,6 +283,12 @@ __device__ __forceinline__ u32 leaf_fast(const Ctx& c, const Lane& L, const Leaf
       for (u32 i = 0; i < n; ++i) found |= (u32)((u32)x.v == uload(&c.t.theap_rec[4 * (size_t)(off + i) + 2]));
       return x.t == CBH_T_STRING ? found : 0u;   // a non-string equals no string
     }
+    case 6: {   // cached column in [at most three string constants]: their ids are in the record (CBH_NONE pads)
+      const Val x = cached_column(c, L, lr.a0);
+      if (x.t == CBH_T_ERR) return 3;
+      const u32 v = (u32)x.v;
+      return x.t == CBH_T_STRING ? (u32)((v == lr.ctag) | (v == lr.clo) | (v == lr.chi)) : 0u;   // a non-string equals no string
+    }
     default: break;
   }
   if (lr.ctag == CBH_NONE && (ka == 0 || kb == 0)) return 4;
@@ -319,24 +325,33 @@ __device__ __forceinline__ u32 leaf_fast(const Ctx& c, const Lane& L, const Leaf
   return 4;
 }
 
+// `lr` = the fused-leaf record of `ref` when the caller already holds it (the copy embedded in a rule record)
 template <bool GENERIC>
-__device__ __forceinline__ int eval_cond(const Ctx& c, Lane& L, u32 ref, bool active) {
+__device__ __forceinline__ int eval_cond_rec(const Ctx& c, Lane& L, u32 ref, const LeafRec& lr, bool active) {
   u32 fast = 0;
-  bool rest = active;
-  if (ref & CBH_COND_LEAF) {
-    const LeafRec lr = uload_rec<LeafRec>(c.t.code, (ref & CBH_COND_PC_MASK) >> 3);
-    if (active) {
-      fast = leaf_fast(c, L, lr);
-      if (fast == 3) {   // CEL error: the leaf counts as false, or as a DENY in strict mode (check.go:697-749)
-        L.status |= CBH_ST_CEL_ERROR;
-        fast = (c.flags & CBH_F_STRICT_EVALUATION) ? 2u : 0u;
-      }
+  if (active) {
+    fast = leaf_fast(c, L, lr);
+    if (fast == 3) {   // CEL error: the leaf counts as false, or as a DENY in strict mode (check.go:697-749)
+      L.status |= CBH_ST_CEL_ERROR;
+      fast = (c.flags & CBH_F_STRICT_EVALUATION) ? 2u : 0u;
     }
-    rest = active && fast == 4;
-    if (wave_ballot(rest) == 0) return (int)fast;   // the whole wave was served inline
   }
+  const bool rest = active && fast == 4;
+  if (wave_ballot(rest) == 0) return (int)fast;   // the whole wave was served inline
   const u32 r = eval_ref<GENERIC>(c.ka_mem, lds_of(c), L.req, L.edr, L.edr_err, ref, rest);
   if (rest) { L.status |= r >> 8; fast = r & 0xFF; }
+  return (int)fast;
+}
+
+template <bool GENERIC>
+__device__ __forceinline__ int eval_cond(const Ctx& c, Lane& L, u32 ref, bool active) {
+  if (ref & CBH_COND_LEAF) {
+    const LeafRec lr = uload_rec<LeafRec>(c.t.code, (ref & CBH_COND_PC_MASK) >> 3);
+    return eval_cond_rec<GENERIC>(c, L, ref, lr, active);
+  }
+  const u32 r = eval_ref<GENERIC>(c.ka_mem, lds_of(c), L.req, L.edr, L.edr_err, ref, active);
+  u32 fast = 0;
+  if (active) { L.status |= r >> 8; fast = r & 0xFF; }
   return (int)fast;
 }
 
@@ -513,7 +528,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   };
   auto rec_role_match = [&](const TblRow& rw, u32 row, const RoleSet& rs, bool active) -> bool {
     if (rw.flags & CBH_ROW_F_ROLE_BY_CLASS) return active && ((((u64)rw.rm_lo | ((u64)rw.rm_hi << 32)) & rs.classes) != 0);
-    const TblRowPat pt = uload_rec<TblRowPat>(t.rows, 2 * row + 1);
+    const TblRowPat pt = uload_rec<TblRowPat>(t.rowpat, row);
     return pat_role_match(rw, pt, rs, active);
   };
 
@@ -795,6 +810,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
             for (u32 row = bucket.x; row < bucket.x + bucket.y; ++row) {
               DBG2_T0();
               const TblRow rw = uload_rec<TblRow>(t.rows, 2 * row);
+              const LeafRec lf = uload_rec<LeafRec>(t.rows, 2 * row + 1);   // issued with the first half: no dependent load for a leaf condition
               const u32 site = site_ctr++;   // position of the record in this group's walk: the same for every role
               if ((((u64)rw.rm_lo | ((u64)rw.rm_hi << 32)) & wave_classes) == 0) continue;   // no lane's role can match
               const u32 e = rw.flags & 3u;
@@ -808,7 +824,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                 const AM mact = (AM)(((am >> ac0) & 1ull) | (((am >> ac1) & 1ull) << 1) | (((am >> ac2) & 1ull) << 2) | (((am >> ac3) & 1ull) << 3));
                 mrow = rmatch ? (AM)(mact & S) : (AM)0;
               } else {
-                const TblRowPat pt = uload_rec<TblRowPat>(t.rows, 2 * row + 1);
+                const TblRowPat pt = uload_rec<TblRowPat>(t.rowpat, row);
                 const u32 n_act = pt.counts & 0xFFFFu;   // 0 = a single inline reference
                 const bool rmatch = is_res ? pat_role_match(rw, pt, rs, S != 0) : (S != 0 && pmatch(pt.resource, kind, KIND_BITS()));
                 if (rmatch) {
@@ -843,7 +859,8 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                 if (rw.drcond != CBH_NONE) r = eval_cond<GENERIC>(c, L, rw.drcond, mev);   // check.go:328-366
                 const bool m2 = mev && r == 1;
                 if (rw.cond != CBH_NONE && wave_ballot(m2) != 0) {                         // check.go:368-380
-                  const int r2 = eval_cond<GENERIC>(c, L, rw.cond, m2);
+                  const int r2 = (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) ? eval_cond_rec<GENERIC>(c, L, rw.cond, lf, m2)
+                                                                      : eval_cond<GENERIC>(c, L, rw.cond, m2);
                   if (m2) r = r2;
                 }
                 DBG_ACC(dbg_eval);

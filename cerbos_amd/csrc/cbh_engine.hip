@@ -467,6 +467,8 @@ static void collect_times(Replica* r) {   // after the stream has been synchroni
   for (auto& sl : r->ring) collect_slot(r, sl);
 }
 
+// CBH_NO_FLAT=1 (measurement aid): decide with the general walk even where the flat kernel applies
+static u32 pick_flags(u32 eval_flags) { static const bool no_flat = getenv("CBH_NO_FLAT") != nullptr; return no_flat ? (eval_flags | CBH_F_STRICT_EVALUATION) : eval_flags; }
 static u32 nfa_maxw(const TableDev& d) { return std::max(std::max(d.nfa_words[0], d.nfa_words[1]), d.nfa_words[2]); }
 static size_t check_lds_bytes(const BatchDev& d) {   // column cache: value low / high / tag dword per lane
   const u32 ncc = d.n_columns < CBH_CACHE_COLS ? d.n_columns : CBH_CACHE_COLS;
@@ -516,7 +518,7 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   sl.pending = false;
   if (d.n_requests) {
     const u32 grid = (d.n_requests + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
-    const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, maxw != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), b->max_actions, b->max_roles, p->flags);
+    const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, maxw != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), b->max_actions, b->max_roles, pick_flags(p->flags));
     if (timed) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), check_lds_bytes(d), s, sl.ev[2], sl.ev[3], 0, b->last_args, (const KernelArgs*)b->d_args);
     else hipLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), check_lds_bytes(d), s, b->last_args, (const KernelArgs*)b->d_args);
     sl.pending = timed;
@@ -733,7 +735,7 @@ static void launch_check(const Replica* rep, KernelArgs ka, const KernelArgs* d_
   if (hi <= lo) return;
   ka.b.req_lo = lo; ka.b.req_hi = hi;
   const u32 grid = (hi - lo + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
-  const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, nfa_maxw(rep->dev) != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), sh.max_actions, sh.max_roles, ka.flags);
+  const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, nfa_maxw(rep->dev) != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), sh.max_actions, sh.max_roles, pick_flags(ka.flags));
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), check_lds_bytes(ka.b), s, ka, d_args);
 }
 

@@ -47,6 +47,7 @@ struct TableDev {
   const CBH_G u32* scope_parent; const CBH_G u32* scope_flags;
   const CBH_G CbhHashSlot* hash; u32 hash_mask;
   const CBH_G u32* rows; u32 n_rows;
+  const CBH_G u32* rowpat;                                  // [n_rows][8] pattern halves (cbh_blob.h CbhRowPatField)
   const CBH_G u32* rprows; u32 n_rprows;
   const CBH_G u32* pool;
   const CBH_G u32* dr; u32 n_dr;

@@ -21,7 +21,7 @@ from .. import namer
 from ..cel import parser as celparser
 from ..ruletable.build import KIND_PRINCIPAL, KIND_RESOURCE
 from . import celc
-from .celc import LoweringError, Params, ProgramBuilder
+from .celc import COND_LEAF, COND_PC_MASK, LoweringError, Params, ProgramBuilder
 from .globs import GlobNFA, fix_glob, has_meta
 
 BLOB_MAGIC = 0x31484243
@@ -31,9 +31,11 @@ PAT_GLOB = 0x80000000
 PAT_ANY = 0x7FFFFFFF     # the lone "*": matches every string, no automaton needed
 ROW_F_ACTION_LIST, ROW_F_ROLE_LIST, ROW_F_ROLE_BY_CLASS, ROW_F_ACTION_BY_CLASS = 4, 8, 16, 32
 # CbhRowField (cbh_blob.h): the hot half, then the pattern half of a rule record
-(ROW_FLAGS, ROW_COND, ROW_DRCOND, ROW_POLICY, ROW_ROLE_CLASSES, _, ROW_ACTION_CLASSES, _, ROW_ACTION, ROW_ROLE, ROW_RESOURCE,
- ROW_COUNTS, ROW_A1, _, ROW_R1, _) = range(16)
-SEC_ACTION_CLASS = 28
+(ROW_FLAGS, ROW_COND, ROW_DRCOND, ROW_POLICY, ROW_ROLE_CLASSES, _, ROW_ACTION_CLASSES, _) = range(8)
+ROW_LEAF = 8           # dwords 8..15: the embedded fused-leaf record
+(PAT_ACTION, PAT_ROLE, PAT_RESOURCE, PAT_COUNTS, PAT_A1, _, PAT_R1, _) = range(8)   # CbhRowPatField
+ROW_F_LEAF_EMBEDDED = 64
+SEC_ACTION_CLASS, SEC_ROWPAT = 28, 29
 
 (SEC_META, SEC_STR_OFF, SEC_STR_BYTES, SEC_SCOPE_PARENT, SEC_SCOPE_FLAGS, SEC_SCOPE_SID, SEC_HASH,
  SEC_ROWS, SEC_RPROWS, SEC_U32POOL, SEC_DR, SEC_CODE, SEC_CONST_TAG, SEC_CONST_VAL, SEC_THEAP_TAG,
@@ -209,6 +211,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
 
     pool = []
     row_cols = [[] for _ in range(16)]
+    pat_cols = [[] for _ in range(8)]
     row_roles = []   # per device row: its role strings (None for principal-policy rows)
     row_actions = []  # likewise its action strings
     rp_cols = [[] for _ in range(4)]
@@ -278,13 +281,13 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
                     row_cols[ROW_COND].append(cond)
                     row_cols[ROW_DRCOND].append(drc)
                     row_cols[ROW_POLICY].append(policy_id(grp[0]["origin_fqn"]))
-                    row_cols[ROW_ACTION].append(a_ref)
-                    row_cols[ROW_ROLE].append(r_ref)
-                    row_cols[ROW_RESOURCE].append(dim_ref(DIM_KIND, resource) if resource else NONE)
-                    row_cols[ROW_COUNTS].append(a_cnt | (r_cnt << 16))
+                    pat_cols[PAT_ACTION].append(a_ref)
+                    pat_cols[PAT_ROLE].append(r_ref)
+                    pat_cols[PAT_RESOURCE].append(dim_ref(DIM_KIND, resource) if resource else NONE)
+                    pat_cols[PAT_COUNTS].append(a_cnt | (r_cnt << 16))
                     for i in range(2):
-                        row_cols[ROW_A1 + i].append(a_more[i])
-                        row_cols[ROW_R1 + i].append(r_more[i])
+                        pat_cols[PAT_A1 + i].append(a_more[i])
+                        pat_cols[PAT_R1 + i].append(r_more[i])
                     row_roles.append(None if principal_policy else rl)
                     row_actions.append(None if principal_policy else al)
                     n += 1
@@ -396,16 +399,32 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
                     mask |= 1 << class_of.get(key, 63)
                     exact = exact and key in class_of
             per_row.append((mask, exact))
-        return table, per_row
+        return table, per_row, len(class_of)
 
-    role_class, role_rows = classes(row_roles)
-    action_class, action_rows = classes(row_actions)
+    role_class, role_rows, n_role_classes = classes(row_roles)
+    action_class, action_rows, n_action_classes = classes(row_actions)
+    # fewer than 32 classes in both dimensions: "any other string" (bit 63) is mirrored in bit 31 of the low dwords,
+    # so that a kernel may match on the low dword alone (cbh_check_flat.h); no lane ever holds class 31 itself
+    small_classes = n_role_classes < 31 and n_action_classes < 31
+    if small_classes:
+        role_rows = [(m | ((m >> 63) << 31), e) for m, e in role_rows]
+        action_rows = [(m | ((m >> 63) << 31), e) for m, e in action_rows]
     for i, ((rmask, rexact), (amask, aexact)) in enumerate(zip(role_rows, action_rows)):
         row_cols[ROW_ROLE_CLASSES].append(rmask & 0xFFFFFFFF)
         row_cols[ROW_ROLE_CLASSES + 1].append(rmask >> 32)
         row_cols[ROW_ACTION_CLASSES].append(amask & 0xFFFFFFFF)
         row_cols[ROW_ACTION_CLASSES + 1].append(amask >> 32)
         row_cols[ROW_FLAGS][i] |= (ROW_F_ROLE_BY_CLASS if rexact else 0) | (ROW_F_ACTION_BY_CLASS if aexact else 0)
+    # the leaf half: a copy of the condition's 8-dword fused-leaf record (celc.py condition_program), so that the
+    # visit which needs the condition already has it
+    for i, (cond, drc) in enumerate(zip(row_cols[ROW_COND], row_cols[ROW_DRCOND])):
+        rec = [0] * 8
+        if cond != NONE and (cond & COND_LEAF) and drc == NONE:
+            pc = cond & COND_PC_MASK
+            rec = [int(w) & 0xFFFFFFFF for w in pb.code[pc:pc + 8]]
+            row_cols[ROW_FLAGS][i] |= ROW_F_LEAF_EMBEDDED
+        for k in range(8):
+            row_cols[ROW_LEAF + k].append(rec[k])
 
     # ---- directory hash table
     nslots = 16
@@ -451,7 +470,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
     # FLAT (cbh_check_flat.h): nothing but resource policies with leaf conditions whose records the class masks decide
     max_depth = max(len(list(namer.scope_parents(sc))) + 1 if sc else 1 for sc in lt.scopes)
     by_class = ROW_F_ROLE_BY_CLASS | ROW_F_ACTION_BY_CLASS
-    flat = (not pb.has_generic and not pb.uses_runtime and not dr_cols[0] and not rp_buckets and not pp_exists
+    flat = (small_classes and not pb.has_generic and not pb.uses_runtime and not dr_cols[0] and not rp_buckets and not pp_exists
             and not (int(meta[M_FLAGS]) & 2) and not any(lt.nfas[d].patterns for d in range(3)) and max_depth <= 16
             and all((f & by_class) == by_class for f in row_cols[ROW_FLAGS]) and all(d == NONE for d in row_cols[ROW_DRCOND]))
     meta[M_FLAGS] |= 256 if flat else 0
@@ -497,6 +516,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         (SEC_SCOPE_SID, len(lt.scopes), u32(scope_sid)),
         (SEC_HASH, nslots, slots.tobytes()),
         (SEC_ROWS, len(row_cols[0]), row_major(row_cols, 16)),
+        (SEC_ROWPAT, len(pat_cols[0]), row_major(pat_cols, 8)),
         (SEC_RPROWS, len(rp_cols[0]), row_major(rp_cols, 4)),
         (SEC_U32POOL, len(pool), u32(pool)),
         (SEC_DR, len(dr_cols[0]), row_major(dr_cols, 4)),

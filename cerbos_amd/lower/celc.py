@@ -283,7 +283,7 @@ class ProgramBuilder:
             if op == OP_IN and tag == T_LIST and (val >> 62) == HEAP_TABLE:
                 off, n = (val >> 32) & 0x3FFFFFFF, val & 0xFFFFFFFF
                 if all(self.theap_tag[off + i] == T_STRING for i in range(n)):
-                    return 5
+                    return 6 if n <= 3 else 5   # 6: the (at most three) element ids travel in the record itself
             return 0
         if eqne and ka == 3 and kb == 3:
             return 3
@@ -315,7 +315,13 @@ class ProgramBuilder:
             if (ka == 0) != (kb == 0):
                 ci = words[1] if ka == 0 else words[2]
                 cv = int(self.const_val[ci]) & 0xFFFFFFFFFFFFFFFF
-                words = words + [self.const_tag[ci], cv & 0xFFFFFFFF, cv >> 32, self._leaf_class(a & 0xFF, ka, kb, ci)]
+                cls = self._leaf_class(a & 0xFF, ka, kb, ci)
+                if cls == 6:   # column in [<= 3 strings]: the ids instead of the list's heap reference
+                    off, n = (cv >> 32) & 0x3FFFFFFF, cv & 0xFFFFFFFF
+                    ids = [int(self.theap_val[off + i]) & 0xFFFFFFFF for i in range(n)] + [0xFFFFFFFF] * (3 - n)
+                    words = words + ids + [6]
+                else:
+                    words = words + [self.const_tag[ci], cv & 0xFFFFFFFF, cv >> 32, cls]
             else:
                 words = words + [0xFFFFFFFF, 0, 0, self._leaf_class(a & 0xFF, ka, kb, None)]
         self.code.extend(words)

@@ -37,7 +37,7 @@ namespace {
 struct Img {
   const u8* base = nullptr;
   u32 meta[CBH_META_N];
-  const u32 *str_off, *scope_parent, *scope_flags, *rows, *rprows, *pool, *dr, *code, *const_rec, *theap_rec;
+  const u32 *str_off, *scope_parent, *scope_flags, *rows, *rowpat, *rprows, *pool, *dr, *code, *const_rec, *theap_rec;
   const u8* str_bytes;
   const CbhHashSlot* hash;
   const u64* gbits;
@@ -60,7 +60,7 @@ bool parse(Img& g, const u8* blob, size_t len) {
   g.str_off = (const u32*)section(blob, CBH_SEC_STR_OFF); g.str_bytes = section(blob, CBH_SEC_STR_BYTES);
   g.scope_parent = (const u32*)section(blob, CBH_SEC_SCOPE_PARENT); g.scope_flags = (const u32*)section(blob, CBH_SEC_SCOPE_FLAGS);
   g.hash = (const CbhHashSlot*)section(blob, CBH_SEC_HASH); g.hash_mask = g.meta[CBH_M_HASH_MASK];
-  g.rows = (const u32*)section(blob, CBH_SEC_ROWS); g.rprows = (const u32*)section(blob, CBH_SEC_RPROWS); g.pool = (const u32*)section(blob, CBH_SEC_U32POOL);
+  g.rows = (const u32*)section(blob, CBH_SEC_ROWS); g.rowpat = (const u32*)section(blob, CBH_SEC_ROWPAT); g.rprows = (const u32*)section(blob, CBH_SEC_RPROWS); g.pool = (const u32*)section(blob, CBH_SEC_U32POOL);
   g.dr = (const u32*)section(blob, CBH_SEC_DR); g.code = (const u32*)section(blob, CBH_SEC_CODE);
   g.const_rec = (const u32*)section(blob, CBH_SEC_CONST_REC); g.theap_rec = (const u32*)section(blob, CBH_SEC_THEAP_REC);
   g.gbits = (const u64*)section(blob, CBH_SEC_GBITS); g.K = g.meta[CBH_M_NSTRINGS];
@@ -378,10 +378,11 @@ void check_request(const Img& g, const cbh_batch& b, const cbh_params& p, u32 r,
             if (const CbhHashSlot* bk0 = dir_find(g, CBH_B_RESOURCE, r_ver, kind, si))
               for (u32 row = bk0->v0; row < bk0->v0 + bk0->v1 && !base; ++row) {
                 const u32* rw = g.rows + CBH_ROW_NF * (size_t)row;
-                const u32 n_role = rw[CBH_ROW_COUNTS] >> 16;
-                if (n_role == 0) base = role_match(rw[CBH_ROW_ROLE]);
+                const u32* pt = g.rowpat + CBH_PAT_NF * (size_t)row;
+                const u32 n_role = pt[CBH_PAT_COUNTS] >> 16;
+                if (n_role == 0) base = role_match(pt[CBH_PAT_ROLE]);
                 else for (u32 i = 0; i < n_role && !base; ++i)
-                  base = role_match((rw[CBH_ROW_FLAGS] & CBH_ROW_F_ROLE_LIST) ? g.pool[rw[CBH_ROW_ROLE] + i] : (i == 0 ? rw[CBH_ROW_ROLE] : rw[CBH_ROW_R1 + i - 1]));
+                  base = role_match((rw[CBH_ROW_FLAGS] & CBH_ROW_F_ROLE_LIST) ? g.pool[pt[CBH_PAT_ROLE] + i] : (i == 0 ? pt[CBH_PAT_ROLE] : pt[CBH_PAT_R1 + i - 1]));
               }
             for (u32 k = 0; k <= anc_cnt && !base; ++k) {
               const CbhHashSlot* rp = dir_find(g, CBH_B_ROLEPOL, r_ver, si, k == 0 ? role : g.pool[anc_off + k - 1]);
@@ -422,17 +423,18 @@ void check_request(const Img& g, const cbh_batch& b, const cbh_params& p, u32 r,
                                          : dir_find(g, CBH_B_PRINCIPAL, r_ver, si, pid);   // resource version: check.go:294
           for (u32 row = bk ? bk->v0 : 0; bk && row < bk->v0 + bk->v1; ++row) {  // :295-414, binding order
             const u32* rw = g.rows + CBH_ROW_NF * (size_t)row;
+            const u32* pt = g.rowpat + CBH_PAT_NF * (size_t)row;   // the pattern references: this restatement never uses the class masks
             const u32 fl = rw[CBH_ROW_FLAGS];
-            const u32 n_act = rw[CBH_ROW_COUNTS] & 0xFFFFu, n_role = rw[CBH_ROW_COUNTS] >> 16;   // 0 = one reference
+            const u32 n_act = pt[CBH_PAT_COUNTS] & 0xFFFFu, n_role = pt[CBH_PAT_COUNTS] >> 16;   // 0 = one reference
             // the i-th pattern of a list: in the pool, or inline in the record (first word + CBH_ROW_A1 / R1 ...)
-            auto nth = [&](u32 first, u32 more, bool in_pool, u32 i) { return in_pool ? g.pool[rw[first] + i] : (i == 0 ? rw[first] : rw[more + i - 1]); };
+            auto nth = [&](u32 first, u32 more, bool in_pool, u32 i) { return in_pool ? g.pool[pt[first] + i] : (i == 0 ? pt[first] : pt[more + i - 1]); };
             bool m;
-            if (!is_res) m = pat_match(rw[CBH_ROW_RESOURCE], kind, kind_bits);
-            else if (n_role == 0) m = role_match(rw[CBH_ROW_ROLE]);
-            else { m = false; for (u32 i = 0; i < n_role; ++i) m = m || role_match(nth(CBH_ROW_ROLE, CBH_ROW_R1, fl & CBH_ROW_F_ROLE_LIST, i)); }
+            if (!is_res) m = pat_match(pt[CBH_PAT_RESOURCE], kind, kind_bits);
+            else if (n_role == 0) m = role_match(pt[CBH_PAT_ROLE]);
+            else { m = false; for (u32 i = 0; i < n_role; ++i) m = m || role_match(nth(CBH_PAT_ROLE, CBH_PAT_R1, fl & CBH_ROW_F_ROLE_LIST, i)); }
             if (!m) continue;
-            if (n_act == 0) m = pat_match(rw[CBH_ROW_ACTION], action, act_bits);
-            else { m = false; for (u32 i = 0; i < n_act; ++i) m = m || pat_match(nth(CBH_ROW_ACTION, CBH_ROW_A1, fl & CBH_ROW_F_ACTION_LIST, i), action, act_bits); }
+            if (n_act == 0) m = pat_match(pt[CBH_PAT_ACTION], action, act_bits);
+            else { m = false; for (u32 i = 0; i < n_act; ++i) m = m || pat_match(nth(CBH_PAT_ACTION, CBH_PAT_A1, fl & CBH_ROW_F_ACTION_LIST, i), action, act_bits); }
             if (!m) continue;
             const u32 e = fl & 3u;
             const int res = cond_pair(row, rw[CBH_ROW_DRCOND], rw[CBH_ROW_COND], err);
