@@ -35,6 +35,72 @@ __device__ __forceinline__ u64 wave_or64(u64 v) {
   return r;
 }
 
+// A cached attribute column for this lane: tag and the two value dwords (cbh_check_wave.h fill_column_cache).
+struct FlatCol { u32 t, lo, hi; };
+__device__ __forceinline__ FlatCol flat_col(const Ctx& c, u32 col, u32 req) {   // `col` wave-uniform
+  FlatCol v;
+  const u32 tw = c.cc[(2 * c.n_cached + col) * CBH_BLOCK + c.tid];
+  v.t = (tw >> (((col * c.b.n_requests + req) & 3u) * 8u)) & 0xFFu;   // the lane's byte of the aligned tag dword
+  v.lo = c.cc[col * CBH_BLOCK + c.tid];
+  v.hi = c.cc[(c.n_cached + col) * CBH_BLOCK + c.tid];
+  return v;
+}
+// The classified fused leaves (celc.py _leaf_class 1, 2, 3, 4, 6) without a single divergent branch: every lane
+// computes the answer, the error flag and the "needs the full evaluator" flag with compares and selects; which
+// class it is is a wave-uniform switch.  Same answers as leaf_fast (cbh_check_wave.h), which stays the reference
+// for the shapes not listed here.  Returns bit 0 = satisfied, bit 1 = CEL error (counts as not satisfied),
+// bit 2 = undecided here (mixed numeric types, containers): the caller hands that lane to eval_cond_rec.
+__device__ __forceinline__ u32 flat_leaf(const Ctx& c, const LeafRec& lr, u32 req, u32 pid) {
+  const u32 a = lr.w >> 8;
+  const u32 ka = (a >> 8) & 0xFu, op = a & 0xFFu;   // wave-uniform
+  const bool want_eq = op == OP_EQ;
+  switch (lr.pad) {
+    case 1: {   // column ==/!= string or bool constant
+      const FlatCol x = flat_col(c, lr.a0, req);
+      const bool err = x.t >= CBH_T_ABSENT;   // ABSENT (0xF0) or ERR (0xFF)
+      const bool eq = x.t == lr.ctag && x.lo == lr.clo;   // other types are plainly unequal
+      return err ? 2u : (u32)(eq == want_eq);
+    }
+    case 2: {   // column <op> double constant
+      const FlatCol x = flat_col(c, lr.a0, req);
+      const bool err = x.t >= CBH_T_ABSENT;
+      const bool dbl = x.t == CBH_T_DOUBLE, othernum = x.t == CBH_T_INT || x.t == CBH_T_UINT;
+      const double p = as_f64((u64)x.lo | ((u64)x.hi << 32)), q = as_f64((u64)lr.clo | ((u64)lr.chi << 32));
+      const bool ordering = op != OP_EQ && op != OP_NE;
+      const bool cmp = (op == OP_EQ) ? p == q : (op == OP_NE) ? p != q : (op == OP_LT) ? p < q : (op == OP_LE) ? p <= q
+                     : (op == OP_GT) ? p > q : p >= q;   // NaN: every ordering false, != true
+      const bool slow = !err && !dbl && (othernum || ordering);   // cross-type numerics / ordering of mismatched types
+      const u32 r = dbl ? (u32)cmp : (u32)(op == OP_NE);           // a non-number is plainly unequal to a number
+      return err ? 2u : slow ? 4u : r;
+    }
+    case 3: {   // column ==/!= column
+      const FlatCol x = flat_col(c, lr.a0, req), y = flat_col(c, lr.a1, req);
+      const bool err = x.t >= CBH_T_ABSENT || y.t >= CBH_T_ABSENT;
+      const bool same = x.t == y.t;
+      const bool scalar = x.t < CBH_T_LIST || x.t == CBH_T_TIMESTAMP || x.t == CBH_T_DURATION;
+      const bool xnum = x.t == CBH_T_INT || x.t == CBH_T_UINT || x.t == CBH_T_DOUBLE, ynum = y.t == CBH_T_INT || y.t == CBH_T_UINT || y.t == CBH_T_DOUBLE;
+      const bool bits_eq = x.lo == y.lo && x.hi == y.hi;
+      const bool dbl_eq = as_f64((u64)x.lo | ((u64)x.hi << 32)) == as_f64((u64)y.lo | ((u64)y.hi << 32));
+      const bool eq = same && (x.t == CBH_T_DOUBLE ? dbl_eq : bits_eq);
+      const bool slow = !err && ((same && !scalar) || (!same && xnum && ynum));   // containers / cross-type numeric equality
+      return err ? 2u : slow ? 4u : (u32)(eq == want_eq);
+    }
+    case 4: {   // column ==/!= P.id (either order)
+      const FlatCol x = flat_col(c, ka == 3 ? lr.a0 : lr.a1, req);
+      const bool err = x.t >= CBH_T_ABSENT;
+      const bool eq = x.t == CBH_T_STRING && x.lo == pid;
+      return err ? 2u : (u32)(eq == want_eq);
+    }
+    case 6: {   // column in [at most three string constants]
+      const FlatCol x = flat_col(c, lr.a0, req);
+      const bool err = x.t >= CBH_T_ABSENT;
+      const bool found = x.t == CBH_T_STRING && (x.lo == lr.ctag || x.lo == lr.clo || x.lo == lr.chi);
+      return err ? 2u : (u32)found;
+    }
+    default: return 4u;
+  }
+}
+
 __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   const TableDev& t = ka_regs.t;
   const BatchDev& b = ka_regs.b;
@@ -106,8 +172,8 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
       const u32 S_before = S;
       if (have_bucket) {
         for (u32 row = bucket.x; row < bucket.x + bucket.y; ++row) {   // bindings in order (check.go:295-414)
-          const TblRow rw = uload_rec<TblRow>(t.rows, 2 * row);
-          const LeafRec lf = uload_rec<LeafRec>(t.rows, 2 * row + 1);
+          const TblRowFull rf = uload_rec<TblRowFull>(t.rows, row);   // hot half + embedded leaf: one scalar load
+          const TblRow& rw = rf.hot;
           if ((rw.rm_lo & wave_rc) == 0 || (rw.am_lo & wave_ac) == 0) continue;
           const u32 mact = ((rw.am_lo >> ac[0]) & 1u) | (((rw.am_lo >> ac[1]) & 1u) << 1) | (((rw.am_lo >> ac[2]) & 1u) << 2) | (((rw.am_lo >> ac[3]) & 1u) << 3);
           // one nibble per role (sign-extended 1-bit extracts), one bit per nibble for the actions; walks of other groups sit out
@@ -115,18 +181,23 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
                             ((0u - ((rw.rm_lo >> rc[2]) & 1u)) & 0xF00u) | ((0u - ((rw.rm_lo >> rc[3]) & 1u)) & 0xF000u);
           const u32 m = ing ? (mrole & (mact * 0x1111u) & S) : 0u;
           if (wave_ballot(m != 0) == 0) continue;
-          int r = 1;
+          u32 hit = m;   // the walks this record's effect applies to: all matched ones unless a condition says no
           if (rw.cond != CBH_NONE) {
             // once per record and request, whatever the roles (check.go:316-340)
-            r = (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) ? eval_cond_rec<false>(c, L, rw.cond, lf, m != 0) : eval_cond<false>(c, L, rw.cond, m != 0);
-            if (L.status & CBH_ST_CEL_ERROR) err |= m;
-            if (L.status & CBH_ST_UNSUPPORTED) unsup |= m;
-            L.status = 0;
+            u32 lv = 4u;
+            if (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) lv = flat_leaf(c, rf.leaf, req, pid);
+            const bool slow = m != 0 && lv == 4u;
+            if (wave_ballot(slow) != 0) {   // shapes flat_leaf leaves open, leaf trees: the shared evaluator
+              const int r = (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) ? eval_cond_rec<false>(c, L, rw.cond, rf.leaf, slow) : eval_cond<false>(c, L, rw.cond, slow);
+              if (slow) lv = (r == 1 ? 1u : 0u) | ((L.status & CBH_ST_CEL_ERROR) ? 2u : 0u) | ((L.status & CBH_ST_UNSUPPORTED) ? 8u : 0u);
+              L.status = 0;
+            }
+            err |= (lv & 2u) ? m : 0u;
+            unsup |= (lv & 8u) ? m : 0u;
+            hit = (lv & 1u) ? m : 0u;
           }
-          if (m != 0 && r == 1) {
-            if ((rw.flags & 3u) == CBH_EFFECT_ALLOW) has_allow |= m;
-            else if ((rw.flags & 3u) == CBH_EFFECT_DENY) { deny |= m; S &= ~m; }   // ends these walks (check.go:392-403)
-          }
+          if ((rw.flags & 3u) == CBH_EFFECT_ALLOW) has_allow |= hit;
+          else if ((rw.flags & 3u) == CBH_EFFECT_DENY) { deny |= hit; S &= ~hit; }   // ends these walks (check.go:392-403)
         }
       }
       const u32 ha = ing ? (has_allow & S) : 0u;   // check.go:416-425

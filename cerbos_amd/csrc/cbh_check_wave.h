@@ -47,6 +47,7 @@ __device__ __forceinline__ bool roleset_has(const TableDev& t, const RoleSet& rs
 // references and is read only for records whose masks do not decide the match (globs, class overflow) and for
 // principal-policy rows.
 struct __attribute__((aligned(32))) TblRow { u32 flags, cond, drcond, policy, rm_lo, rm_hi, am_lo, am_hi; };
+struct LeafRec;
 struct __attribute__((aligned(32))) TblRowPat { u32 action, role, resource, counts, a1, a2, r1, r2; };
 struct __attribute__((aligned(16))) TblRp { u32 resource, allow_off, allow_cnt, cond; };
 struct __attribute__((aligned(16))) TblDr { u32 name, parents_off, parents_cnt, cond; };
@@ -238,6 +239,7 @@ __device__ u32 eval_ref(const KernelArgs* ka, const VmLds lds, u32 req, u64 edr,
 // A CBH_COND_LEAF program is an 8-dword record on an 8-dword boundary of the tape (celc.py
 // condition_program): instruction, operands and the value of its constant operand in one scalar load.
 struct __attribute__((aligned(32))) LeafRec { u32 w, a0, a1, ret, ctag, clo, chi, pad; };
+struct __attribute__((aligned(64))) TblRowFull { TblRow hot; LeafRec leaf; };   // a whole 16-dword rule record
 
 // The common outcome of a fused leaf, inline in the table walk: both operands present, same-typed
 // scalars (or plainly unequal types), or an operand missing.  Returns 0 / 1, 3 = CEL error, or 4 when
