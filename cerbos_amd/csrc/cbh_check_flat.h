@@ -120,15 +120,20 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   // actions and roles -> classes (CBH_SEC_ACTION_CLASS / CBH_SEC_ROLE_CLASS; 63 = a string no rule names).
   // A flat table has fewer than 32 classes per dimension and its masks mirror "any other string" (bit 63)
   // in bit 31 of the low dword: the match is a 1-bit field extract from ONE dword at a per-lane position.
-  u32 ac[4], rc[4];
+  // Every load below is unconditional (an index that does not exist reads element 0 instead and is masked
+  // afterwards): the eight id loads go out together, then the eight class loads - two round trips, not sixteen.
+  u32 ac[4], rc[4], aid[4], rid[4];
 #pragma unroll
   for (u32 k = 0; k < 4; ++k) {
-    const u32 a = k < act_cnt ? b.tuple_action[act_off + k] : CBH_NONE;
-    const u32 ca = a < t.K ? (u32)t.action_class[a] : 63u;
-    ac[k] = ca < 31u ? ca : 31u;
-    const u32 r = k < role_cnt ? b.roles[role_off + k] : CBH_NONE;
-    const u32 cr = r < t.K ? (u32)t.role_class[r] : 63u;
-    rc[k] = cr < 31u ? cr : 31u;
+    aid[k] = b.tuple_action[k < act_cnt ? act_off + k : 0u];
+    rid[k] = b.roles[k < role_cnt ? role_off + k : 0u];
+  }
+  const u32 kmax = t.K ? t.K - 1u : 0u;
+#pragma unroll
+  for (u32 k = 0; k < 4; ++k) {
+    const u32 ca = t.action_class[aid[k] < t.K ? aid[k] : kmax], cr = t.role_class[rid[k] < t.K ? rid[k] : kmax];
+    ac[k] = (k < act_cnt && aid[k] < t.K && ca < 31u) ? ca : 31u;    // 31 = a string no rule names (cbh_blob.h)
+    rc[k] = (k < role_cnt && rid[k] < t.K && cr < 31u) ? cr : 31u;
   }
   u32 lane_ac = 0, lane_rc = 0;
   u32 walks = 0;   // bit 4r + k: role r exists and action k exists

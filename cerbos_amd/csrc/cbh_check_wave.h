@@ -435,23 +435,24 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   constexpr u32 AM_BITS = sizeof(AM) * 8;
   const AM all = act_cnt >= AM_BITS ? (AM)~(AM)0 : (AM)(((AM)1 << act_cnt) - 1);
   // the first four action ids stay in registers (requests rarely carry more)
-  const u32 a0 = act_cnt > 0 ? b.tuple_action[act_off] : CBH_NONE;
-  const u32 a1 = act_cnt > 1 ? b.tuple_action[act_off + 1] : CBH_NONE;
-  const u32 a2 = act_cnt > 2 ? b.tuple_action[act_off + 2] : CBH_NONE;
-  const u32 a3 = act_cnt > 3 ? b.tuple_action[act_off + 3] : CBH_NONE;
+  // (unconditional loads - an action that does not exist reads element 0 and is masked - so that they all go
+  // out together instead of one guarded round trip after another)
+  const u32 l0 = b.tuple_action[act_cnt > 0 ? act_off : 0u], l1 = b.tuple_action[act_cnt > 1 ? act_off + 1 : 0u];
+  const u32 l2 = b.tuple_action[act_cnt > 2 ? act_off + 2 : 0u], l3 = b.tuple_action[act_cnt > 3 ? act_off + 3 : 0u];
+  const u32 a0 = act_cnt > 0 ? l0 : CBH_NONE, a1 = act_cnt > 1 ? l1 : CBH_NONE, a2 = act_cnt > 2 ? l2 : CBH_NONE, a3 = act_cnt > 3 ? l3 : CBH_NONE;
   // their action classes (CBH_SEC_ACTION_CLASS; 63 = not a literal rule action), for the records whose class
   // masks decide the match
   u32 ac0 = 63u, ac1 = 63u, ac2 = 63u, ac3 = 63u;
   if ((FEAT & CBH_FEAT_MAX4) != 0) {
-    if (a0 < t.K) ac0 = t.action_class[a0];
-    if (a1 < t.K) ac1 = t.action_class[a1];
-    if (a2 < t.K) ac2 = t.action_class[a2];
-    if (a3 < t.K) ac3 = t.action_class[a3];
+    const u32 kmax = t.K ? t.K - 1u : 0u;
+    const u32 c0 = t.action_class[a0 < t.K ? a0 : kmax], c1 = t.action_class[a1 < t.K ? a1 : kmax];
+    const u32 c2 = t.action_class[a2 < t.K ? a2 : kmax], c3 = t.action_class[a3 < t.K ? a3 : kmax];
+    ac0 = a0 < t.K ? c0 : 63u; ac1 = a1 < t.K ? c1 : 63u; ac2 = a2 < t.K ? c2 : 63u; ac3 = a3 < t.K ? c3 : 63u;
   }
   // ... and the first two roles: fetched with the rest of the request instead of one memory round
   // trip at the head of every role iteration
-  const u32 role0 = role_cnt > 0 ? b.roles[role_off] : 0;
-  const u32 role1 = role_cnt > 1 ? b.roles[role_off + 1] : 0;
+  const u32 lr0 = b.roles[role_cnt > 0 ? role_off : 0u], lr1 = b.roles[role_cnt > 1 ? role_off + 1 : 0u];
+  const u32 role0 = role_cnt > 0 ? lr0 : 0, role1 = role_cnt > 1 ? lr1 : 0;
 
   const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
   const bool strict = (flags & CBH_F_STRICT_EVALUATION) != 0;

@@ -158,9 +158,12 @@ extern "C" int hostsim_check(const void* blob, size_t len, const cbh_batch* in, 
   b.n_requests = in->n_requests; b.n_tuples = in->n_tuples; b.n_roles = in->n_roles;
   b.n_columns = in->n_columns; b.n_strings = in->n_strings; b.heap_len = in->heap_len;
   b.req_lo = 0; b.req_hi = in->n_requests;
+  static const uint32_t none[4] = {0, 0, 0, 0};   // the kernels read element 0 of these unconditionally (masked afterwards)
   b.req_u32 = in->req_u32; b.roles = in->roles; b.tuple_req = in->tuple_req; b.tuple_action = in->tuple_action;
   b.col_tag = in->col_tag; b.col_val = in->col_val; b.heap_tag = in->heap_tag; b.heap_val = in->heap_val;
   b.str_off = in->str_off; b.str_bytes = in->str_bytes; b.str_flags = in->str_flags; b.gbits = gbits;
+  if (!b.roles) b.roles = none;
+  if (!b.tuple_action) b.tuple_action = none;
   a.o = OutDev{out->effect, out->policy, out->scope, out->status, out->edr_mask};
   a.now_ns = p->now_ns; a.flags = p->flags;
   if (a.o.edr) std::memset(a.o.edr, 0, sizeof(uint64_t) * in->n_requests);
