@@ -22,16 +22,27 @@
 #include "cbh_check_wave.h"
 
 #define CBH_FLAT_MAX_DEPTH 16   /* scope chain entries a request can have here (the lowering checks the table) */
+// Workgroups of four waves: the waves never talk to each other (each owns a quarter of the group's LDS), the
+// size only quarters the number of workgroups the dispatcher has to start - ~1.7 us of a ~20 us launch at 1M tuples
+// (tools/skeleton_bench.hip).  The host simulation runs one wave per block.
+#ifndef CBH_HOSTSIM
+#define CBH_FLAT_WAVES 4u
+#else
+#define CBH_FLAT_WAVES 1u
+#endif
+#define CBH_FLAT_THREADS (CBH_FLAT_WAVES * CBH_BLOCK)
 
-// OR of a 64-bit value over the wave (single-wave workgroups: LDS atomics + barriers that cost nothing)
-__device__ __forceinline__ u64 wave_or64(u64 v) {
-  __shared__ unsigned long long acc;
-  if (threadIdx.x == 0) acc = 0;
-  __syncthreads();
-  if (v) atomicOr(&acc, (unsigned long long)v);
-  __syncthreads();
-  const u64 r = acc;
-  __syncthreads();
+// OR of a 64-bit value over the wave, through LDS: a wave's LDS operations execute in program order, so the zeroing
+// store, the 64 atomic ORs and the read-back need no barrier on the device; the ballots are the rendezvous the host
+// simulation's lane fibers need (and cost the device one scalar move each).
+__device__ __forceinline__ u64 wave_or64(u64 v, u32 wave, u32 lane) {
+  __shared__ unsigned long long acc[CBH_FLAT_WAVES];
+  if (lane == 0) acc[wave] = 0;
+  (void)wave_ballot(true);
+  if (v) atomicOr(&acc[wave], (unsigned long long)v);
+  (void)wave_ballot(true);
+  const u64 r = acc[wave];
+  (void)wave_ballot(true);
   return r;
 }
 
@@ -106,7 +117,8 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   const BatchDev& b = ka_regs.b;
   const OutDev& o = ka_regs.o;
   const u32 flags = ka_regs.flags;
-  const u32 rix = b.req_lo + blockIdx.x * CBH_BLOCK + threadIdx.x;
+  const u32 wave = threadIdx.x / CBH_BLOCK;   // which of the group's waves (c.tid is the lane within it)
+  const u32 rix = b.req_lo + blockIdx.x * CBH_FLAT_THREADS + threadIdx.x;
   const bool valid = rix < b.req_hi;
   const u32 req = valid ? rix : b.req_lo;
   const u32 NR = b.n_requests;
@@ -143,13 +155,14 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
     if (k < role_cnt) { lane_rc |= 1u << rc[k]; walks |= all << (4 * k); }
   }
   // classes present in the wave: a record none of them can match is skipped on the scalar unit
-  const u64 wave_cls = wave_or64((u64)lane_ac | ((u64)lane_rc << 32));
+  const u64 wave_cls = wave_or64((u64)lane_ac | ((u64)lane_rc << 32), wave, c.tid);
   const u32 wave_ac = (u32)wave_cls, wave_rc = (u32)(wave_cls >> 32);
 
   const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
   Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false; L.pid = pid;
 
-  __shared__ u32 chain_si[CBH_FLAT_MAX_DEPTH * CBH_BLOCK];   // [depth][lane]: scope index at that depth of the lane's chain
+  __shared__ u32 chain_all[CBH_FLAT_WAVES * CBH_FLAT_MAX_DEPTH * CBH_BLOCK];
+  u32* chain_si = chain_all + wave * (CBH_FLAT_MAX_DEPTH * CBH_BLOCK);   // [depth][lane]: scope index at that depth of the lane's chain
   u32 S = walks;                 // walks still going
   u32 has_allow = 0, allow = 0, deny = 0, err = 0, unsup = 0;
   u32 dp0 = 0, dp1 = 0, dp2 = 0, dp3 = 0;   // bit planes of the depth a walk was decided at
@@ -259,20 +272,27 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 }
 
 #ifndef CBH_HOSTSIM
-#define CBH_FLAT_ATTRS __launch_bounds__(CBH_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
+#define CBH_FLAT_ATTRS __launch_bounds__(CBH_FLAT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
 #else
 #define CBH_FLAT_ATTRS
 #endif
 __global__ CBH_FLAT_ATTRS void cbh_check_flat_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
   const u32 ncc = cached_columns(&a);
-  Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-        (CBH_L u32*)cbh_dyn_lds, ncc, ka};
+  // each wave of the group owns its slice of the column cache: [3 planes][ncc][64 lanes] dwords
+  Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+        (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * (3u * ncc * CBH_BLOCK), ncc, ka};
   flat_body(a, c);
 }
 
 // Which kernel decides this batch: the flat one when table (CBH_MF_FLAT), batch shape (<= 4 actions and <= 4 roles per
 // request) and evaluation mode (not strict) allow it, else the general walk's instantiation for the table class.
-static inline cbh_check_kernel_fn cbh_pick_kernel(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 max_actions, u32 max_roles, u32 eval_flags) {
-  if ((table_flags & CBH_MF_FLAT) && max_actions <= 4 && max_roles <= 4 && !(eval_flags & CBH_F_STRICT_EVALUATION)) return cbh_check_flat_kernel;
+// `threads` = the workgroup size to launch it with (dynamic LDS = column cache bytes of one wave x threads / 64).
+static inline cbh_check_kernel_fn cbh_pick_kernel(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 max_actions, u32 max_roles, u32 eval_flags,
+                                                  u32* threads) {
+  if ((table_flags & CBH_MF_FLAT) && max_actions <= 4 && max_roles <= 4 && !(eval_flags & CBH_F_STRICT_EVALUATION)) {
+    *threads = CBH_FLAT_THREADS;
+    return cbh_check_flat_kernel;
+  }
+  *threads = CBH_BLOCK;
   return cbh_pick_check_kernel(table_flags, n_derived_roles, has_globs, max_actions);
 }

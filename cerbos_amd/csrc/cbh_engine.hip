@@ -517,10 +517,12 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   }
   sl.pending = false;
   if (d.n_requests) {
-    const u32 grid = (d.n_requests + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
-    const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, maxw != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), b->max_actions, b->max_roles, pick_flags(p->flags));
-    if (timed) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), check_lds_bytes(d), s, sl.ev[2], sl.ev[3], 0, b->last_args, (const KernelArgs*)b->d_args);
-    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), check_lds_bytes(d), s, b->last_args, (const KernelArgs*)b->d_args);
+    u32 threads = CBH_BLOCK;
+    const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, maxw != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), b->max_actions, b->max_roles, pick_flags(p->flags), &threads);
+    const u32 grid = (d.n_requests + threads - 1) / threads;   // one lane per request
+    const size_t lds = check_lds_bytes(d) * (threads / CBH_BLOCK);
+    if (timed) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, sl.ev[2], sl.ev[3], 0, b->last_args, (const KernelArgs*)b->d_args);
+    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, b->last_args, (const KernelArgs*)b->d_args);
     sl.pending = timed;
   }
   HIPCHK(hipGetLastError());
@@ -734,9 +736,10 @@ static void launch_resolve(const Replica* rep, const KernelArgs& ka, const Layou
 static void launch_check(const Replica* rep, KernelArgs ka, const KernelArgs* d_args, u32 lo, u32 hi, const BatchShape& sh, hipStream_t s) {
   if (hi <= lo) return;
   ka.b.req_lo = lo; ka.b.req_hi = hi;
-  const u32 grid = (hi - lo + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
-  const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, nfa_maxw(rep->dev) != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), sh.max_actions, sh.max_roles, pick_flags(ka.flags));
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(CBH_BLOCK), check_lds_bytes(ka.b), s, ka, d_args);
+  u32 threads = CBH_BLOCK;
+  const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, nfa_maxw(rep->dev) != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), sh.max_actions, sh.max_roles, pick_flags(ka.flags), &threads);
+  const u32 grid = (hi - lo + threads - 1) / threads;   // one lane per request
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), check_lds_bytes(ka.b) * (threads / CBH_BLOCK), s, ka, d_args);
 }
 
 // a small batch on one device: everything packed into the pinned staging block.  Two ways across PCIe:
