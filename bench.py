@@ -325,12 +325,15 @@ def main():
         total = tuples * n_batches * world * args.steps
         alg = ALG_BYTES_PER_DECISION[args.workload]
         achieved = alg * tuples / (check_ms * 1e-3) / 1e9
-        # the instantiation cbh_check_resident picks for this table / batch (cbh_engine.hip)
-        max_act = int(batch0.req_u32[9].max())
-        kernel = "cbh_check_kernel" + ("" if lt.stats["generic_programs"] else "_leaf") + \
-                 (("_a4" if (max_act <= 4 and not lt.stats["generic_programs"]
-                             and lt.stats["kernel_features"]) else "_a32") + lt.stats["kernel_features"]
-                  if max_act <= 32 else "")
+        # the kernel cbh_check_resident picks for this table / batch / mode (cbh_check_flat.h cbh_pick_kernel)
+        max_act, max_roles = int(batch0.req_u32[9].max()), int(batch0.req_u32[7].max())
+        if lt.stats["flat"] and max_act <= 4 and max_roles <= 4 and not (FLAGS & capi.F_STRICT_EVALUATION) and not os.environ.get("CBH_NO_FLAT"):
+            kernel = "cbh_check_flat_kernel"
+        else:
+            kernel = "cbh_check_kernel" + ("" if lt.stats["generic_programs"] else "_leaf") + \
+                     (("_a4" if (max_act <= 4 and not lt.stats["generic_programs"]
+                                 and lt.stats["kernel_features"]) else "_a32") + lt.stats["kernel_features"]
+                      if max_act <= 32 else "")
         traffic, traffic_source = pmc_traffic(kernel, args.workload) if n_requests == wl[2] else (None, None)
         out = {
             "metric": "CheckResources decisions/sec at batch=1M; p50 per-decision us",

@@ -25,7 +25,9 @@
 // Workgroups of four waves: the waves never talk to each other (each owns a quarter of the group's LDS), the
 // size only quarters the number of workgroups the dispatcher has to start - ~1.7 us of a ~20 us launch at 1M tuples
 // (tools/skeleton_bench.hip).  The host simulation runs one wave per block.
-#ifndef CBH_HOSTSIM
+#if defined(CBH_FLAT_WAVES_OVERRIDE)
+#define CBH_FLAT_WAVES CBH_FLAT_WAVES_OVERRIDE
+#elif !defined(CBH_HOSTSIM)
 #define CBH_FLAT_WAVES 4u
 #else
 #define CBH_FLAT_WAVES 1u

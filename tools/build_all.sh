@@ -7,7 +7,7 @@ g++ -O2 -std=c++17 -Wall -Wextra -shared -fPIC -pthread -Iinclude cerbos_amd/csr
 cd cerbos_amd/csrc
 LOG=$(mktemp)
 # CBH_PROFILE=1 builds the per-wave cycle counters in (tools/gpu_cycles.py); never ship that build.
-if ! hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC ${CBH_PROFILE:+-DCBH_PROFILE_CYCLES} ${CBH_ABLATION:+-DCBH_ABLATION} -I../../include cbh_engine.hip -o ../libcerbos_hip.so -Rpass-analysis=kernel-resource-usage > "$LOG" 2>&1; then
+if ! hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC ${CBH_PROFILE:+-DCBH_PROFILE_CYCLES} ${CBH_ABLATION:+-DCBH_ABLATION} ${CBH_EXTRA_FLAGS:-} -I../../include cbh_engine.hip -o ../libcerbos_hip.so -Rpass-analysis=kernel-resource-usage > "$LOG" 2>&1; then
   grep -E "error" -A3 "$LOG" | head -40
   echo "HIPCC FAILED"
   exit 1
