@@ -44,7 +44,7 @@ traffic = {"calibration": {"read_b32": f_read, "read_lds_b32": f_lds, "write_b32
                            "source": "tools/pmc_calib.hip, 512 MiB per launch, same box and profiler"}, "workloads": {}}
 for d in sorted(glob.glob(os.path.join(out_dir, "pmc_C*"))):
     w = os.path.basename(d)[4:]
-    vals = counters(os.path.join(d, "**", "*counter_collection.csv"), lambda n: n.startswith("cbh_check_kernel"))
+    vals = counters(os.path.join(d, "**", "*counter_collection.csv"), lambda n: n.startswith("cbh_check_"))
     kernels = sorted({k for k, _ in vals})
     if not kernels:
         continue
