@@ -32,8 +32,16 @@ type gpuEngine struct {
 	ingest *C.cbi_table // host dictionaries of the same image (immutable: shared by all goroutines)
 }
 
-func newGPUEngine(blob []byte, device int) (*gpuEngine, error) {
-	cfg := C.cbh_config{abi_version: C.CBH_ABI_VERSION, device: C.int32_t(device)}
+// devices: the HIP ordinals the engine may use. A large batch is cut into one contiguous request range per device
+// (the fan-out of engine.go:309-338 with GPUs for workers); the image is broadcast once at load.
+func newGPUEngine(blob []byte, devices []int) (*gpuEngine, error) {
+	if len(blob) == 0 || len(devices) > C.CBH_MAX_DEVICES {
+		return nil, errors.New("gpu engine: empty table image or too many devices")
+	}
+	cfg := C.cbh_config{abi_version: C.CBH_ABI_VERSION, n_devices: C.uint32_t(len(devices))}
+	for i, d := range devices {
+		cfg.devices[i] = C.int32_t(d)
+	}
 	if C.cbh_init(&cfg) != 0 {
 		return nil, errors.New(C.GoString(C.cbh_last_error()))
 	}
@@ -49,6 +57,8 @@ func newGPUEngine(blob []byte, device int) (*gpuEngine, error) {
 	return g, nil
 }
 
+// close drops the owner's reference: the image leaves HBM when the last in-flight batch has drained
+// (ruletable/manager.go:86-124 swaps tables without waiting for readers; so does this).
 func (g *gpuEngine) close() {
 	C.cbi_table_close(g.ingest)
 	C.cbh_table_release(g.table)
