@@ -77,6 +77,13 @@ class HipEvaluator:
         return cls(lower_rule_table(rt, conf.globals), conf, device)
 
     @classmethod
+    def from_rule_table_pb(cls, wire: bytes, conf: Conf = None, device: int = 0):
+        """From the reference's own artefact: serialized ``runtimev1.RuleTable`` (what ``ruletable.Manager`` holds,
+        ``private/ruletable/ruletable.go:27-44``) - no policy YAML, no compile step on this side."""
+        from .ruletable.proto import decode_rule_table
+        return cls.from_rule_table(decode_rule_table(wire), conf, device)
+
+    @classmethod
     def from_policies(cls, docs, conf: Conf = None, device: int = 0):
         return cls.from_rule_table(rule_table_from_policies(policies_from_docs(docs)), conf, device)
 

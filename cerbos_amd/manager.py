@@ -76,6 +76,13 @@ class TableManager:
             old.table.close()   # the owner's reference: the image is freed once in-flight batches have drained
         return n
 
+    def swap_pb(self, wire: bytes, globals_=None) -> int:
+        """``swap`` from serialized ``runtimev1.RuleTable`` bytes - the storage-event path of the reference
+        (manager.go:86-124: rebuild the table, then swap)."""
+        from .lower.blob import lower_rule_table
+        from .ruletable.proto import decode_rule_table
+        return self.swap(lower_rule_table(decode_rule_table(wire), globals_))
+
     def acquire(self) -> TableLease:
         with self._lock:
             if self._cur is None:

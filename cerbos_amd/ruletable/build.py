@@ -167,7 +167,12 @@ def build_rule_table(runnable_sets) -> dict:
         rt["rules"].extend(rows)
     for i, row in enumerate(rt["rules"]):
         row["id"] = i
-    # indexRules (ruletable.go:798-834)
+    return finish_rule_table(rt)
+
+
+def finish_rule_table(rt: dict) -> dict:
+    """The side tables ``indexRules`` derives from the rows at load time (ruletable.go:798-834) - a table decoded
+    from ``runtimev1.RuleTable`` bytes (``cerbos_amd.ruletable.proto``) gets them the same way."""
     rt["principal_scopes"] = sorted({r["scope"] for r in rt["rules"] if r["policy_kind"] == KIND_PRINCIPAL})
     rt["resource_scopes"] = sorted({r["scope"] for r in rt["rules"] if r["policy_kind"] == KIND_RESOURCE})
     sp = {}

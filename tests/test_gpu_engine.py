@@ -176,8 +176,13 @@ def test_versioned_swap_under_load():
     th = [threading.Thread(target=worker) for _ in range(4)]
     for x in th:
         x.start()
+    from cerbos_amd.ruletable.proto import encode_rule_table
+    wires = [encode_rule_table(rt) for rt in rts]   # the reference's artefact: serialized runtimev1.RuleTable
     for k in range(1, 9):
-        mgr.swap(lts[k % 2])
+        if k % 3 == 0:
+            mgr.swap(lts[k % 2])
+        else:
+            mgr.swap_pb(wires[k % 2])
     stop.set()
     for x in th:
         x.join()

@@ -1,0 +1,108 @@
+"""the table arrives as the reference's own artefact - serialized ``runtimev1.RuleTable``
+(runtime.proto:41-105) - and lowers to the same device image as the table built from policy YAML.
+
+No Go toolchain exists here to marshal a table, so the bytes come from ``encode_rule_table`` (the message, field
+for field); the tests pin (a) the wire format against hand-assembled golden bytes of a small row - independent of
+the encoder - and xxhash64 against its published test vectors, (b) dict -> bytes -> dict identity and (c) byte-identical
+device images for the reference's golden store, every synthetic configuration and fuzzed stores.
+"""
+import numpy as np
+import pytest
+
+from cerbos_amd import workloads
+from cerbos_amd.lower.blob import lower_rule_table
+from cerbos_amd.policy.loader import policies_from_docs
+from cerbos_amd.ruletable.build import rule_table_from_policies
+from cerbos_amd.ruletable.proto import decode_rule_table, encode_rule_table, module_id, xxhash64
+from helpers import store_rule_table
+
+
+def test_xxhash64_known_answers():
+    # reference vectors of the xxHash specification (XXH64, seed 0)
+    assert xxhash64(b"") == 0xEF46DB3751D8E999
+    assert xxhash64(b"a") == 0xD24EC4F1A98C6E5B
+    assert xxhash64(b"abc") == 0x44BC2CF5AD770999
+    assert xxhash64(b"Nobody inspects the spammish repetition") == 0xFBCEA83C8A378BF1
+    assert module_id("cerbos.resource.leave_request.vdefault") == xxhash64(b"cerbos.resource.leave_request.vdefault")
+    try:
+        import xxhash   # the C implementation, where the image has it
+    except ImportError:
+        return
+    rng = np.random.default_rng(5)
+    for n in list(range(0, 70)) + [127, 128, 129, 1000]:
+        data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert xxhash64(data) == xxhash.xxh64(data).intdigest(), n
+
+
+def test_wire_format_against_hand_assembled_bytes():
+    """A RuleTable with one RuleRow, written out by hand from runtime.proto's field numbers."""
+    def ld(f, b):
+        return bytes([(f << 3) | 2, len(b)]) + b
+    expr = ld(1, b"R.attr.public == true")                       # Expr.original = 1
+    cond = ld(4, expr)                                           # Condition.expr = 4
+    row = (ld(1, b"cerbos.resource.doc.vdefault") + ld(2, b"doc") + ld(3, b"user") + ld(4, b"view")
+           + ld(5, cond) + bytes([7 << 3, 1])                    # effect = ALLOW
+           + bytes([9 << 3, 1]) + ld(10, b"default") + ld(13, b"rule-001")
+           + bytes([(19 << 3) & 0x7F | 0x80, 1, 4]))             # policy_kind = 19 (two-byte tag), KIND_RESOURCE = 4
+    rt = decode_rule_table(ld(1, row))
+    r = rt["rules"][0]
+    assert (r["origin_fqn"], r["resource"], r["role"], r["action"], r["effect"]) == ("cerbos.resource.doc.vdefault", "doc", "user", "view", "ALLOW")
+    assert r["condition"] == ("expr", "R.attr.public == true") and r["scope_permissions"] == 1 and r["version"] == "default"
+    assert r["policy_kind"] == "RESOURCE" and r["name"] == "rule-001" and r["scope"] == ""
+    assert rt["resource_scopes"] == [""] and rt["scope_permissions"] == {"": 1}
+
+
+def _same_rows(a, b):
+    assert len(a["rules"]) == len(b["rules"])
+    for x, y in zip(a["rules"], b["rules"]):
+        assert x == y, (x, y)
+    for k in ("meta", "scope_parent_roles", "policy_derived_roles", "principal_scopes", "resource_scopes", "scope_permissions", "parent_roles"):
+        assert a[k] == b[k], k
+
+
+STORES = {
+    "golden": lambda: store_rule_table(),
+    "C1": lambda: rule_table_from_policies(policies_from_docs(workloads.c1_policies(2))),
+    "C2": lambda: rule_table_from_policies(policies_from_docs(workloads.c2_policies())),
+    "C3": lambda: rule_table_from_policies(policies_from_docs(workloads.c3_policies())),
+    "C4": lambda: rule_table_from_policies(policies_from_docs(workloads.c4_policies(n_policies=60))),
+    "C5": lambda: rule_table_from_policies(policies_from_docs(workloads.c5_policies())),
+    "loadtest_classic": lambda: rule_table_from_policies(policies_from_docs(workloads.loadtest_policies("classic", 3))),
+    "loadtest_multitenant": lambda: rule_table_from_policies(policies_from_docs(workloads.loadtest_policies("multitenant", 3))),
+}
+
+
+@pytest.mark.parametrize("name", sorted(STORES))
+def test_table_from_proto_bytes_lowers_to_the_same_image(name):
+    rt = STORES[name]()
+    globals_ = {"environment": "test"} if name == "golden" else None
+    wire = encode_rule_table(rt)
+    back = decode_rule_table(wire)
+    _same_rows(rt, back)
+    assert encode_rule_table(back) == wire
+    assert lower_rule_table(back, globals_).blob == lower_rule_table(rt, globals_).blob
+
+
+def test_fuzzed_stores_round_trip():
+    from test_fuzz_parity import _policies
+    from cerbos_amd.lower.celc import LoweringError
+    n = 0
+    for seed in range(12):
+        rt = rule_table_from_policies(policies_from_docs(_policies(np.random.default_rng(777 + seed), wide=True)))
+        back = decode_rule_table(encode_rule_table(rt))
+        _same_rows(rt, back)
+        try:
+            assert lower_rule_table(back).blob == lower_rule_table(rt).blob
+            n += 1
+        except LoweringError:
+            pass
+    assert n >= 6
+
+
+def test_truncated_and_foreign_bytes_are_rejected_not_crashing():
+    wire = encode_rule_table(STORES["C2"]())
+    for cut in (1, 7, len(wire) // 2, len(wire) - 1):
+        try:
+            decode_rule_table(wire[:cut])
+        except (ValueError, IndexError, KeyError, UnicodeDecodeError):
+            pass
