@@ -51,6 +51,8 @@ enum CbhSectionId {
   CBH_SEC_CONST_REC = 23,  // u32[n_consts][4]  {tag, 0, lo, hi}: the constant pool as scalar-loadable records
   CBH_SEC_THEAP_REC = 24,  // u32[theap_len][4] the constant heap, same record form
   CBH_SEC_ROLE_CLASS = 25, // u8[K] class (0..61) of a string that is a literal rule role, 63 = any other string
+  CBH_SEC_ROWLEAF2 = 30,     // u32[n_rows][8]  copy of the fused-leaf record of a rule's DERIVED-ROLE condition (CBH_ROW_F_DRLEAF_EMBEDDED)
+  CBH_SEC_DRX = 31,          // u32[n_dr][16]   derived-role definitions for the flat kernel (CbhDrxField order)
   CBH_SEC_ROWPAT = 29,       // u32[n_rows][8]  pattern halves of the rule records (CbhRowPatField order)
   CBH_SEC_ACTION_CLASS = 28, // u8[K] class (0..61) of a string that is a literal rule action of a resource policy, 63 = any other string
   CBH_SEC_HOST_NAMES = 27,   // host only: {u32 n, {u16 len, bytes}*} policy keys (CBH_P_TABLE ids), then the same for derived-role names
@@ -151,7 +153,8 @@ enum CbhRowPatField {   // CBH_SEC_ROWPAT: the pattern half of record i, 8 dword
 #define CBH_ROW_F_ROLE_LIST 8u
 #define CBH_ROW_F_ROLE_BY_CLASS 16u     /* the role class mask decides the role match exactly */
 #define CBH_ROW_F_ACTION_BY_CLASS 32u   /* the action class mask decides the action match exactly */
-#define CBH_ROW_F_LEAF_EMBEDDED 64u     /* dwords 8..15 hold the condition's fused-leaf record (no derived-role condition) */
+#define CBH_ROW_F_LEAF_EMBEDDED 64u     /* dwords 8..15 hold the condition's fused-leaf record */
+#define CBH_ROW_F_DRLEAF_EMBEDDED 128u  /* CBH_SEC_ROWLEAF2[row] holds the derived-role condition's fused-leaf record */
 enum CbhRpField { // role-policy rows
   CBH_RP_RESOURCE = 0,  // pattern ref (kind dim)
   CBH_RP_ALLOW_OFF = 1, // into U32POOL: pattern refs (action dim)
@@ -165,6 +168,15 @@ enum CbhDrField { // derived roles of one resource policy
   CBH_DR_PARENTS_CNT = 2, // CBH_NONE = "*" (any role)
   CBH_DR_COND = 3,        // program or CBH_NONE
   CBH_DR_NF = 4
+};
+
+enum CbhDrxField { // CBH_SEC_DRX: one 16-dword record per CBH_SEC_DR record, same index
+  CBH_DRX_ROLES = 0,   // u64 (2 dwords): role classes of the parent roles (every bit for "*"), exact for a flat table
+  CBH_DRX_FLAGS = 2,   // bit 0: dwords 8..15 hold the condition's fused-leaf record
+  CBH_DRX_COND = 3,    // program or CBH_NONE
+  CBH_DRX_NAME = 4,    // bit index into the edr mask
+  CBH_DRX_LEAF = 8,
+  CBH_DRX_NF = 16
 };
 
 // Glob NFA section (bit-parallel, one bit per pattern position):

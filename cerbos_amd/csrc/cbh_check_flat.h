@@ -48,6 +48,9 @@ __device__ __forceinline__ u64 wave_or64(u64 v, u32 wave, u32 lane) {
   return r;
 }
 
+// one record of CBH_SEC_DRX (cbh_blob.h CbhDrxField): a derived-role definition as the flat kernel reads it
+struct __attribute__((aligned(64))) TblDrx { u32 rm_lo, rm_hi, flags, cond, name, p0, p1, p2; LeafRec leaf; };
+
 // A cached attribute column for this lane: tag and the two value dwords (cbh_check_wave.h fill_column_cache).
 struct FlatCol { u32 t, lo, hi; };
 __device__ __forceinline__ FlatCol flat_col(const Ctx& c, u32 col, u32 req) {   // `col` wave-uniform
@@ -170,6 +173,20 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   u32 dp0 = 0, dp1 = 0, dp2 = 0, dp3 = 0;   // bit planes of the depth a walk was decided at
   u32 first = CBH_NONE; bool exists = false;
 
+  // a condition reference for the lanes with `active`: bit 0 satisfied, bit 1 CEL error, bit 3 outside the device subset.
+  // Classified leaves inline (flat_leaf); what they leave open - and leaf trees - through the shared evaluator.
+  auto leafish = [&](u32 ref, bool embedded, const LeafRec& lr, bool active) -> u32 {
+    u32 lv = 4u;
+    if (embedded) lv = flat_leaf(c, lr, req, pid);
+    const bool slow = active && lv == 4u;
+    if (wave_ballot(slow) != 0) {
+      const int r = embedded ? eval_cond_rec<false>(c, L, ref, lr, slow) : eval_cond<false>(c, L, ref, slow);
+      if (slow) lv = (r == 1 ? 1u : 0u) | ((L.status & CBH_ST_CEL_ERROR) ? 2u : 0u) | ((L.status & CBH_ST_UNSUPPORTED) ? 8u : 0u);
+      L.status = 0;
+    }
+    return active ? lv : 0u;
+  };
+
   bool pend = true;   // every lane takes part in routing: "no policy at all" is an answer too (check.go:119-121, 168-170)
   for (;;) {   // ---- waterfall over groups that share (scope, version, kind); a sorted batch has one per wave
     const u64 rem = wave_ballot(pend);
@@ -201,20 +218,21 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
                             ((0u - ((rw.rm_lo >> rc[2]) & 1u)) & 0xF00u) | ((0u - ((rw.rm_lo >> rc[3]) & 1u)) & 0xF000u);
           const u32 m = ing ? (mrole & (mact * 0x1111u) & S) : 0u;
           if (wave_ballot(m != 0) == 0) continue;
-          u32 hit = m;   // the walks this record's effect applies to: all matched ones unless a condition says no
-          if (rw.cond != CBH_NONE) {
-            // once per record and request, whatever the roles (check.go:316-340)
-            u32 lv = 4u;
-            if (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) lv = flat_leaf(c, rf.leaf, req, pid);
-            const bool slow = m != 0 && lv == 4u;
-            if (wave_ballot(slow) != 0) {   // shapes flat_leaf leaves open, leaf trees: the shared evaluator
-              const int r = (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) ? eval_cond_rec<false>(c, L, rw.cond, rf.leaf, slow) : eval_cond<false>(c, L, rw.cond, slow);
-              if (slow) lv = (r == 1 ? 1u : 0u) | ((L.status & CBH_ST_CEL_ERROR) ? 2u : 0u) | ((L.status & CBH_ST_UNSUPPORTED) ? 8u : 0u);
-              L.status = 0;
-            }
-            err |= (lv & 2u) ? m : 0u;
-            unsup |= (lv & 8u) ? m : 0u;
-            hit = (lv & 1u) ? m : 0u;
+          // the walks this record's effect applies to: all matched ones unless a condition says no.  The derived-role
+          // condition comes first and the rule's own condition is evaluated only where that held (check.go:328-380);
+          // each once per record and request, whatever the roles (check.go:316-340)
+          u32 hit = m;
+          if (rw.drcond != CBH_NONE) {
+            const bool emb = (rw.flags & CBH_ROW_F_DRLEAF_EMBEDDED) != 0;
+            const LeafRec l2 = uload_rec<LeafRec>(t.rowleaf2, row);
+            const u32 lv = leafish(rw.drcond, emb, l2, hit != 0);
+            err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
+            hit = (lv & 1u) ? hit : 0u;
+          }
+          if (rw.cond != CBH_NONE && wave_ballot(hit != 0) != 0) {
+            const u32 lv = leafish(rw.cond, (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) != 0, rf.leaf, hit != 0);
+            err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
+            hit = (lv & 1u) ? hit : 0u;
           }
           if ((rw.flags & 3u) == CBH_EFFECT_ALLOW) has_allow |= hit;
           else if ((rw.flags & 3u) == CBH_EFFECT_DENY) { deny |= hit; S &= ~hit; }   // ends these walks (check.go:392-403)
@@ -251,16 +269,69 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
     st4 |= (u32)(uk ? CBH_ST_UNSUPPORTED : (ek ? CBH_ST_CEL_ERROR : CBH_ST_OK)) << (8 * k);
   }
 
+  // ---- effective derived roles (check.go:237-282): the definitions of a scope's policy are evaluated when a role
+  // walk REACHES that scope - a walk the reference really makes, i.e. not one of a role after the role that
+  // allowed its action.  Known now: a decided walk reached the scopes up to the one that decided it, an undecided
+  // one the whole chain.  The chain is walked a second time for the definitions alone.
+  u64 edr = 0;
+  if ((flags & CBH_F_WANT_DERIVED_ROLES) && t.n_dr) {
+    u32 legit = 0;
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+      const u32 ak = (allow >> k) & 0x1111u;
+      const u32 seen = ak ? (((ak & (0u - ak)) << 1) - 1u) : 0xFFFFu;
+      legit |= ((walks >> k) & 0x1111u & seen) << k;
+    }
+    const u32 done = allow | deny;
+    u32 reach = 0;   // deepest chain position a legitimate walk reached, + 1 (0 = none)
+    if (legit & ~done) reach = CBH_FLAT_MAX_DEPTH;
+    else if (legit) {   // maximum over the decided walks, from the bit planes (most significant plane first)
+      u32 cand = legit, d = 0;
+      u32 tp = cand & dp3; if (tp) { cand = tp; d |= 8u; }
+      tp = cand & dp2; if (tp) { cand = tp; d |= 4u; }
+      tp = cand & dp1; if (tp) { cand = tp; d |= 2u; }
+      tp = cand & dp0; if (tp) { cand = tp; d |= 1u; }
+      reach = d + 1u;
+    }
+    bool derr = false, dr_unsup = false;
+    bool pend2 = true;
+    for (;;) {
+      const u64 rem = wave_ballot(pend2);
+      if (rem == 0) break;
+      const u32 lead = first_lane(rem);
+      const u32 g_rs = wave_readlane(r_scope, lead), g_ver = wave_readlane(r_ver, lead), g_k = wave_readlane(kind, lead);
+      const bool ing = pend2 && r_scope == g_rs && r_ver == g_ver && kind == g_k;
+      pend2 = pend2 && !ing;
+      u32 depth = 0;
+      for (u32 si = uchain_first(t, g_rs, FLAG_RES, lenient); si != CBH_NONE && depth < CBH_FLAT_MAX_DEPTH;
+           si = uchain_next(t, uload(&t.scope_parent[si]), FLAG_RES), ++depth) {
+        if (wave_ballot(ing && depth < reach) == 0) break;
+        uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
+        if (!udir_find(t, CBH_B_RESOURCE, g_ver, g_k, si, bucket)) continue;
+        for (u32 d = bucket.z; d < bucket.z + bucket.w; ++d) {
+          const TblDrx dx = uload_rec<TblDrx>(t.drx, d);
+          const bool applies = ing && depth < reach && (dx.rm_lo & lane_rc) != 0;   // parent roles x the request's roles (check.go:244)
+          if (wave_ballot(applies) == 0) continue;
+          u32 lv = 1u;
+          if (dx.cond != CBH_NONE) lv = leafish(dx.cond, (dx.flags & 1u) != 0, dx.leaf, applies);
+          if (applies) { if (lv & 1u) edr |= 1ull << dx.name; derr = derr || (lv & 2u) != 0; dr_unsup = dr_unsup || (lv & 8u) != 0; }
+        }
+      }
+    }
+    if (derr) st4 |= 0x01010101u & ~((st4 >> 1) & 0x01010101u);   // evaluation errors are a per-request fact: every action that is not UNSUPPORTED
+    if (dr_unsup) st4 = 0x02020202u;
+  }
+
   const bool packed = valid && act_cnt == 4 && (act_off & 3u) == 0;
   if (packed) {
     struct __attribute__((aligned(16))) u32x4 { u32 x, y, z, w; };
-    if (o.edr) o.edr[req] = 0;
+    if (o.edr) o.edr[req] = edr;
     *(CBH_G u32*)(o.effect + act_off) = eff4;
     if (o.status) *(CBH_G u32*)(o.status + act_off) = st4;
     if (o.policy) { u32x4 v; v.x = pol[0]; v.y = pol[1]; v.z = pol[2]; v.w = pol[3]; *(CBH_G u32x4*)(o.policy + act_off) = v; }
     if (o.scope) { u32x4 v; v.x = scp[0]; v.y = scp[1]; v.z = scp[2]; v.w = scp[3]; *(CBH_G u32x4*)(o.scope + act_off) = v; }
   } else if (valid) {
-    if (o.edr) o.edr[req] = 0;
+    if (o.edr) o.edr[req] = edr;
 #pragma unroll
     for (u32 k = 0; k < 4; ++k) {
       if (k < act_cnt) {

@@ -35,7 +35,8 @@ ROW_F_ACTION_LIST, ROW_F_ROLE_LIST, ROW_F_ROLE_BY_CLASS, ROW_F_ACTION_BY_CLASS =
 ROW_LEAF = 8           # dwords 8..15: the embedded fused-leaf record
 (PAT_ACTION, PAT_ROLE, PAT_RESOURCE, PAT_COUNTS, PAT_A1, _, PAT_R1, _) = range(8)   # CbhRowPatField
 ROW_F_LEAF_EMBEDDED = 64
-SEC_ACTION_CLASS, SEC_ROWPAT = 28, 29
+SEC_ACTION_CLASS, SEC_ROWPAT, SEC_ROWLEAF2, SEC_DRX = 28, 29, 30, 31
+ROW_F_DRLEAF_EMBEDDED = 128
 
 (SEC_META, SEC_STR_OFF, SEC_STR_BYTES, SEC_SCOPE_PARENT, SEC_SCOPE_FLAGS, SEC_SCOPE_SID, SEC_HASH,
  SEC_ROWS, SEC_RPROWS, SEC_U32POOL, SEC_DR, SEC_CODE, SEC_CONST_TAG, SEC_CONST_VAL, SEC_THEAP_TAG,
@@ -216,6 +217,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
     row_actions = []  # likewise its action strings
     rp_cols = [[] for _ in range(4)]
     dr_cols = [[] for _ in range(4)]
+    dr_parents = []   # per derived-role record: its parent role strings
     entries = []  # (k0,k1,k2,k3, v0,v1,v2,v3)
 
     def row_programs(r, principal_policy):
@@ -303,6 +305,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         drs = rt["policy_derived_roles"].get(namer.resource_policy_fqn(kind, ver, scope)) or {}
         for name, dr in drs.items():
             dr_cols[0].append(pb.dr_bit(name))
+            dr_parents.append(list(dr["parent_roles"]))
             if "*" in dr["parent_roles"]:
                 dr_cols[1].append(0)
                 dr_cols[2].append(NONE)
@@ -376,11 +379,11 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
     # mask of the classes its role list can match.  A wave ORs the classes of the roles it is walking
     # and skips, on the scalar unit, the records none of them can match (cbh_check_wave.h).
     # Class 63 = "any other string"; a glob role or a role beyond 62 classes matches everything.
-    def classes(lists):
-        """class numbers for the literal strings of `lists` (first come, first numbered; at most 62), the u8[K]
-        lookup table, and per row (mask of classes the list can match, does the mask decide the match exactly)."""
+    def classes(lists, also=()):
+        """class numbers for the literal strings of `lists` and `also` (first come, first numbered; at most 62), the
+        u8[K] lookup table, and per row (mask of classes the list can match, does the mask decide the match exactly)."""
         class_of = {}
-        for lst in lists:
+        for lst in list(lists) + list(also):
             for key in lst or ():
                 if key and "*" not in key and key not in class_of and len(class_of) < 62:
                     class_of[key] = len(class_of)
@@ -401,7 +404,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
             per_row.append((mask, exact))
         return table, per_row, len(class_of)
 
-    role_class, role_rows, n_role_classes = classes(row_roles)
+    role_class, role_rows, n_role_classes = classes(row_roles, dr_parents)   # parent roles of derived roles get classes too
     action_class, action_rows, n_action_classes = classes(row_actions)
     # fewer than 32 classes in both dimensions: "any other string" (bit 63) is mirrored in bit 31 of the low dwords,
     # so that a kernel may match on the low dword alone (cbh_check_flat.h); no lane ever holds class 31 itself
@@ -416,15 +419,40 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         row_cols[ROW_ACTION_CLASSES + 1].append(amask >> 32)
         row_cols[ROW_FLAGS][i] |= (ROW_F_ROLE_BY_CLASS if rexact else 0) | (ROW_F_ACTION_BY_CLASS if aexact else 0)
     # the leaf half: a copy of the condition's 8-dword fused-leaf record (celc.py condition_program), so that the
-    # visit which needs the condition already has it
+    # visit which needs the condition already has it; the derived-role condition's leaf likewise, in its own section
+    leaf2_cols = [[] for _ in range(8)]
     for i, (cond, drc) in enumerate(zip(row_cols[ROW_COND], row_cols[ROW_DRCOND])):
+        for ref, flag, cols, base in ((cond, ROW_F_LEAF_EMBEDDED, row_cols, ROW_LEAF), (drc, ROW_F_DRLEAF_EMBEDDED, leaf2_cols, 0)):
+            rec = [0] * 8
+            if ref != NONE and (ref & COND_LEAF):
+                pc = ref & COND_PC_MASK
+                rec = [int(w) & 0xFFFFFFFF for w in pb.code[pc:pc + 8]]
+                row_cols[ROW_FLAGS][i] |= flag
+            for k in range(8):
+                cols[base + k].append(rec[k])
+    # derived-role definitions once more for the flat kernel: parent roles as a class mask, the condition's leaf inline
+    drx_cols = [[] for _ in range(16)]
+    drx_exact = True
+    for i, parents in enumerate(dr_parents):
+        mask = 0
+        for role in parents:
+            if role == "*":
+                mask = 0xFFFFFFFFFFFFFFFF
+            elif "*" in role or role not in lt.string_ids or int(role_class[lt.string_ids[role]]) >= 62:
+                mask, drx_exact = 0xFFFFFFFFFFFFFFFF, False     # a glob / a role outside the classes: not decidable by class
+            else:
+                mask |= 1 << int(role_class[lt.string_ids[role]])
+        if small_classes:
+            mask |= (mask >> 63) << 31
+        cond = dr_cols[3][i]
         rec = [0] * 8
-        if cond != NONE and (cond & COND_LEAF) and drc == NONE:
+        emb = cond != NONE and bool(cond & COND_LEAF)
+        if emb:
             pc = cond & COND_PC_MASK
             rec = [int(w) & 0xFFFFFFFF for w in pb.code[pc:pc + 8]]
-            row_cols[ROW_FLAGS][i] |= ROW_F_LEAF_EMBEDDED
-        for k in range(8):
-            row_cols[ROW_LEAF + k].append(rec[k])
+        vals = [mask & 0xFFFFFFFF, mask >> 32, 1 if emb else 0, cond, dr_cols[0][i], 0, 0, 0] + rec
+        for k in range(16):
+            drx_cols[k].append(vals[k])
 
     # ---- directory hash table
     nslots = 16
@@ -470,9 +498,9 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
     # FLAT (cbh_check_flat.h): nothing but resource policies with leaf conditions whose records the class masks decide
     max_depth = max(len(list(namer.scope_parents(sc))) + 1 if sc else 1 for sc in lt.scopes)
     by_class = ROW_F_ROLE_BY_CLASS | ROW_F_ACTION_BY_CLASS
-    flat = (small_classes and not pb.has_generic and not pb.uses_runtime and not dr_cols[0] and not rp_buckets and not pp_exists
+    flat = (small_classes and not pb.has_generic and not pb.uses_runtime and drx_exact and len(lt.dr_names) <= 64 and not rp_buckets and not pp_exists
             and not (int(meta[M_FLAGS]) & 2) and not any(lt.nfas[d].patterns for d in range(3)) and max_depth <= 16
-            and all((f & by_class) == by_class for f in row_cols[ROW_FLAGS]) and all(d == NONE for d in row_cols[ROW_DRCOND]))
+            and all((f & by_class) == by_class for f in row_cols[ROW_FLAGS]))
     meta[M_FLAGS] |= 256 if flat else 0
     meta[M_MAX_STACK] = pb.max_stack
     meta[M_NDRNAMES] = len(lt.dr_names)
@@ -517,6 +545,8 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         (SEC_HASH, nslots, slots.tobytes()),
         (SEC_ROWS, len(row_cols[0]), row_major(row_cols, 16)),
         (SEC_ROWPAT, len(pat_cols[0]), row_major(pat_cols, 8)),
+        (SEC_ROWLEAF2, len(leaf2_cols[0]), row_major(leaf2_cols, 8)),
+        (SEC_DRX, len(drx_cols[0]), row_major(drx_cols, 16)),
         (SEC_RPROWS, len(rp_cols[0]), row_major(rp_cols, 4)),
         (SEC_U32POOL, len(pool), u32(pool)),
         (SEC_DR, len(dr_cols[0]), row_major(dr_cols, 4)),

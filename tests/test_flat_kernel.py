@@ -41,8 +41,20 @@ def _cond(rng):
     return {"match": {kind: {"of": [{"expr": str(e)} for e in rng.choice(CONDS, size=int(rng.integers(2, 4)), replace=False)]}}}
 
 
+DRS = ["owner", "peer", "senior", "anyone"]
+
+
 def _store(rng):
     docs = []
+    with_dr = rng.random() < 0.6
+    if with_dr:   # derived roles: definitions with and without conditions, `*` parents, conditions that can raise errors
+        docs.append({"apiVersion": API, "derivedRoles": {"name": "flat_roles", "definitions": [
+            {"name": "owner", "parentRoles": [str(r) for r in rng.choice(ROLES, size=2, replace=False)],
+             "condition": {"match": {"expr": "R.attr.owner == P.id"}}},
+            {"name": "peer", "parentRoles": ["*"], "condition": {"match": {"expr": "P.attr.department == R.attr.department"}}},
+            {"name": "senior", "parentRoles": [str(r) for r in rng.choice(ROLES, size=3, replace=False)],
+             "condition": {"match": {"expr": str(rng.choice(["P.attr.level >= 3", "R.attr.missing == 1"]))}}},
+            {"name": "anyone", "parentRoles": [str(rng.choice(ROLES))]}]}})
     for kind in KINDS:
         for si, scope in enumerate(SCOPES):
             if scope and rng.random() < 0.2:
@@ -50,13 +62,20 @@ def _store(rng):
             rules = []
             for _ in range(int(rng.integers(1, 7))):
                 rule = {"actions": [str(a) for a in rng.choice(ACTIONS + ["*"], size=int(rng.integers(1, 6)), replace=False)],
-                        "roles": [str(r) for r in rng.choice(ROLES + ["*"], size=int(rng.integers(1, 5)), replace=False)],
                         "effect": "EFFECT_ALLOW" if rng.random() < 0.7 else "EFFECT_DENY"}
+                if with_dr and rng.random() < 0.4:
+                    rule["derivedRoles"] = [str(d) for d in rng.choice(DRS, size=int(rng.integers(1, 3)), replace=False)]
+                    if rng.random() < 0.3:
+                        rule["roles"] = [str(rng.choice(ROLES))]
+                else:
+                    rule["roles"] = [str(r) for r in rng.choice(ROLES + ["*"], size=int(rng.integers(1, 5)), replace=False)]
                 c = _cond(rng)
                 if c:
                     rule["condition"] = c
                 rules.append(rule)
             pol = {"resource": kind, "version": "default", "rules": rules}
+            if with_dr:
+                pol["importDerivedRoles"] = ["flat_roles"]
             if scope:
                 pol["scope"] = scope
                 if rng.random() < 0.5:
@@ -105,6 +124,7 @@ def _run_seed(seed, make_evaluator, close):
             for inp, have in zip(inputs, outs):
                 want = orc.check(inp, EvalParams(now_ns=NOW, lenient_scope_search=lenient))
                 assert norm_actions(have) == norm_actions(want), (seed, lenient, inp)
+                assert sorted(have["effectiveDerivedRoles"]) == sorted(want.get("effectiveDerivedRoles") or []), (seed, lenient, inp)
                 na = len(inp["actions"])
                 got_err = bool((res.status[t:t + na] == capi.ST_CEL_ERROR).any())
                 assert got_err == bool(want.get("evaluationErrors")), (seed, lenient, inp, want.get("evaluationErrors"))
@@ -116,7 +136,7 @@ def _run_seed(seed, make_evaluator, close):
     return n_err
 
 
-@pytest.mark.parametrize("seed", range(25))
+@pytest.mark.parametrize("seed", range(40))
 def test_flat_kernel_source_vs_oracle(seed):
     from test_hostsim_golden import HostSimEvaluator
     _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False)
@@ -124,10 +144,10 @@ def test_flat_kernel_source_vs_oracle(seed):
 
 def test_error_cases_do_occur():
     from test_hostsim_golden import HostSimEvaluator
-    assert sum(_run_seed(s, lambda lt: HostSimEvaluator(lt, Conf()), False) for s in range(3)) > 20
+    assert sum(_run_seed(s, lambda lt: HostSimEvaluator(lt, Conf()), False) for s in range(4)) > 20
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(25))
+@pytest.mark.parametrize("seed", range(40))
 def test_flat_kernel_on_gpu(seed):
     _run_seed(seed, lambda lt: HipEvaluator(lt, Conf()), True)
