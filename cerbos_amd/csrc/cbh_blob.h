@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define CBH_BLOB_MAGIC 0x31484243u /* "CBH1" */
-#define CBH_BLOB_VERSION 16u
+#define CBH_BLOB_VERSION 17u
 
 struct CbhBlobHeader {  // 32 bytes
   uint32_t magic;
@@ -87,6 +87,7 @@ enum CbhMeta {
 #define CBH_MF_HAS_ANY_PATTERN 16u      /* some pattern reference is CBH_PAT_ANY (treated as a glob table) */
 #define CBH_MF_HAS_PRINCIPAL_POLICIES 32u
 #define CBH_MF_NEEDS_STRING_BYTES 128u   /* glob automata, or a program that looks inside a string: upload str_off / str_bytes / str_flags */
+#define CBH_MF_FLAT_CLOSED 512u           /* FLAT and every condition is evaluated inline by the flat kernel: no evaluator call needed for plain batches */
 #define CBH_MF_FLAT 256u                  /* resource policies only, leaf conditions, every record decided by class masks: cbh_check_flat.h */
 #define CBH_MF_READS_REQUEST_STRINGS 64u /* some program reads a raw request string (CBH_RQ_S_*): upload those fields */
 
@@ -155,6 +156,14 @@ enum CbhRowPatField {   // CBH_SEC_ROWPAT: the pattern half of record i, 8 dword
 #define CBH_ROW_F_ACTION_BY_CLASS 32u   /* the action class mask decides the action match exactly */
 #define CBH_ROW_F_LEAF_EMBEDDED 64u     /* dwords 8..15 hold the condition's fused-leaf record */
 #define CBH_ROW_F_DRLEAF_EMBEDDED 128u  /* CBH_SEC_ROWLEAF2[row] holds the derived-role condition's fused-leaf record */
+/* The condition is an all/any/none tree of classified fused leaves (celc.py _tree_strip): the slot holds a descriptor laid
+ * over the fused-leaf record's fields - {ops 0-7, ops 8-15, index of the first leaf record in the tape in 8-dword units,
+ * ops 16-23, ops 24-31, n leaves, 0, 7} - and the n leaf records follow each other there.  ops = 4 bits each: 1 = the next
+ * leaf, 2 + k / 5 + k / 8 + k = OP_TREE_BEGIN / _ACC / _END of kind k (0 all, 1 any, 2 none), 0 = end
+ * (cbh_check_flat.h flat_tree; the tape program is unchanged). */
+#define CBH_ROW_F_TREE_EMBEDDED 256u
+#define CBH_ROW_F_DRTREE_EMBEDDED 512u
+#define CBH_TREE_STRIP_MAX 8u
 enum CbhRpField { // role-policy rows
   CBH_RP_RESOURCE = 0,  // pattern ref (kind dim)
   CBH_RP_ALLOW_OFF = 1, // into U32POOL: pattern refs (action dim)
@@ -172,7 +181,7 @@ enum CbhDrField { // derived roles of one resource policy
 
 enum CbhDrxField { // CBH_SEC_DRX: one 16-dword record per CBH_SEC_DR record, same index
   CBH_DRX_ROLES = 0,   // u64 (2 dwords): role classes of the parent roles (every bit for "*"), exact for a flat table
-  CBH_DRX_FLAGS = 2,   // bit 0: dwords 8..15 hold the condition's fused-leaf record
+  CBH_DRX_FLAGS = 2,   // bit 0: dwords 8..15 hold the condition's fused-leaf record; bit 1: a tree descriptor (CBH_ROW_F_TREE_EMBEDDED)
   CBH_DRX_COND = 3,    // program or CBH_NONE
   CBH_DRX_NAME = 4,    // bit index into the edr mask
   CBH_DRX_LEAF = 8,

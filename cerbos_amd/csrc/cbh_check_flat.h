@@ -85,9 +85,10 @@ __device__ __forceinline__ u32 flat_leaf(const Ctx& c, const LeafRec& lr, u32 re
       const bool ordering = op != OP_EQ && op != OP_NE;
       const bool cmp = (op == OP_EQ) ? p == q : (op == OP_NE) ? p != q : (op == OP_LT) ? p < q : (op == OP_LE) ? p <= q
                      : (op == OP_GT) ? p > q : p >= q;   // NaN: every ordering false, != true
-      const bool slow = !err && !dbl && (othernum || ordering);   // cross-type numerics / ordering of mismatched types
+      const bool slow = !err && othernum;                          // int / uint against a double constant: cross-type numerics
+      const bool overload = !dbl && !othernum && ordering;         // ordering a non-number against a number: no such overload (cbh_vm.h val_compare)
       const u32 r = dbl ? (u32)cmp : (u32)(op == OP_NE);           // a non-number is plainly unequal to a number
-      return err ? 2u : slow ? 4u : r;
+      return (err || overload) ? 2u : slow ? 4u : r;
     }
     case 3: {   // column ==/!= column
       const FlatCol x = flat_col(c, lr.a0, req), y = flat_col(c, lr.a1, req);
@@ -117,6 +118,54 @@ __device__ __forceinline__ u32 flat_leaf(const Ctx& c, const LeafRec& lr, u32 re
   }
 }
 
+// A condition tree of classified leaves (cbh_blob.h CBH_ROW_F_TREE_EMBEDDED; `desc` = the descriptor in the record's leaf
+// slot): the 4-bit ops in order, leaves from the strip, no tape reads and no divergent branch.  Same bookkeeping as
+// eval_leaf_tree (cbh_check_wave.h): a leaf behind the deciding one of its level is not evaluated by the reference
+// (check.go:697-749), so its error / "needs the full evaluator" flags do not count.  Returns flat_leaf's bits for the tree.
+__device__ __forceinline__ u32 flat_tree(const Ctx& c, const LeafRec& desc, u32 req, u32 pid) {
+  const u32 opw[4] = {desc.w, desc.a0, desc.ret, desc.ctag};   // wave-uniform
+  bool live = true, last = false;
+  u32 saved = 0, acc = 0, depth = 0, leaf = desc.a1, err = 0, slow = 0;
+  for (u32 k = 0; k < 32; ++k) {
+    const u32 op = (opw[k >> 3] >> (4u * (k & 7u))) & 15u;
+    if (op == 0) break;
+    if (op == 1) {
+      const LeafRec lr = uload_rec<LeafRec>(c.t.code, leaf++);
+      const u32 lv = flat_leaf(c, lr, req, pid);
+      last = live && (lv & 1u) != 0;
+      err |= live ? (lv & 2u) : 0u;
+      slow |= live ? (lv & 4u) : 0u;
+    } else if (op < 5) {          // TREE_BEGIN kind op - 2
+      const u32 bit = 1u << depth;
+      saved = live ? (saved | bit) : (saved & ~bit);
+      acc = (op == 2) ? (acc | bit) : (acc & ~bit);
+      ++depth;
+    } else if (op < 8) {          // TREE_ACC kind op - 5: all - the first false decides; any / none - the first true
+      const u32 bit = 1u << (depth - 1u);
+      const bool decides = live && ((op == 5) ? !last : last);
+      acc = decides ? ((op == 5) ? (acc & ~bit) : (acc | bit)) : acc;
+      live = live && !decides;
+    } else {                      // TREE_END kind op - 8
+      --depth;
+      const u32 bit = 1u << depth;
+      live = (saved & bit) != 0;
+      last = ((acc & bit) != 0) != (op == 10);
+    }
+  }
+  return slow ? 4u : ((u32)last | err);
+}
+
+// The largest value of `v` (< 2^nbits) over the lanes with `in`, bit by bit from the top: one ballot per bit.
+__device__ __forceinline__ u32 wave_max_bits(u32 v, bool in, u32 nbits) {
+  u32 best = 0;
+  for (u32 k = nbits; k-- > 0;) {   // wave-uniform trip count
+    const bool bit = ((v >> k) & 1u) != 0;
+    if (wave_ballot(in && bit) != 0) { in = in && bit; best |= 1u << k; }
+  }
+  return best;
+}
+
+template <bool WITH_CALL>
 __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   const TableDev& t = ka_regs.t;
   const BatchDev& b = ka_regs.b;
@@ -166,50 +215,72 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
   Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false; L.pid = pid;
 
-  __shared__ u32 chain_all[CBH_FLAT_WAVES * CBH_FLAT_MAX_DEPTH * CBH_BLOCK];
-  u32* chain_si = chain_all + wave * (CBH_FLAT_MAX_DEPTH * CBH_BLOCK);   // [depth][lane]: scope index at that depth of the lane's chain
+  // [depth][lane]: scope index at that depth of the lane's chain - in the dynamic LDS behind the column caches,
+  // sized by the table's longest chain (a one-scope table pays 256 B per wave, not 4 KB: LDS sets the occupancy here)
+  const u32 max_depth = t.max_depth < CBH_FLAT_MAX_DEPTH ? t.max_depth : CBH_FLAT_MAX_DEPTH;
+  CBH_L u32* chain_si = (CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * (3u * c.n_cached * CBH_BLOCK) + wave * (max_depth * CBH_BLOCK);
   u32 S = walks;                 // walks still going
   u32 has_allow = 0, allow = 0, deny = 0, err = 0, unsup = 0;
   u32 dp0 = 0, dp1 = 0, dp2 = 0, dp3 = 0;   // bit planes of the depth a walk was decided at
-  u32 first = CBH_NONE; bool exists = false;
+  // scope indices are < 2^scope_bits; the walk below merges lanes by scope, deepest (= largest index) first
+  const u32 scope_bits = t.n_scopes > 1 ? 32u - (u32)__builtin_clz(t.n_scopes - 1u) : 0u;
 
   // a condition reference for the lanes with `active`: bit 0 satisfied, bit 1 CEL error, bit 3 outside the device subset.
-  // Classified leaves inline (flat_leaf); what they leave open - and leaf trees - through the shared evaluator.
-  auto leafish = [&](u32 ref, bool embedded, const LeafRec& lr, bool active) -> u32 {
+  // `how`: 1 = `lr` is the fused leaf, 2 = `lr` describes a one-level tree of classified leaves (both inline: flat_leaf /
+  // flat_tree), 0 = neither; what the inline code leaves open goes through the shared evaluator.
+  auto leafish = [&](u32 ref, u32 how, const LeafRec& lr, bool active) -> u32 {
     u32 lv = 4u;
-    if (embedded) lv = flat_leaf(c, lr, req, pid);
+    if (how == 1u) lv = flat_leaf(c, lr, req, pid);
+    else if (how == 2u) lv = flat_tree(c, lr, req, pid);
     const bool slow = active && lv == 4u;
-    if (wave_ballot(slow) != 0) {
-      const int r = embedded ? eval_cond_rec<false>(c, L, ref, lr, slow) : eval_cond<false>(c, L, ref, slow);
-      if (slow) lv = (r == 1 ? 1u : 0u) | ((L.status & CBH_ST_CEL_ERROR) ? 2u : 0u) | ((L.status & CBH_ST_UNSUPPORTED) ? 8u : 0u);
-      L.status = 0;
-    }
+    if (WITH_CALL) {
+      // The classified leaves leave open only what needs memory (container equality) or cross-type numerics.  The
+      // kernel variant for batches that can hold such values makes ONE real call into the shared evaluator here; the
+      // call's register convention costs the whole kernel its occupancy, so batches whose attribute columns are all
+      // null / bool / double / string / timestamp / duration (the host checks, cbh_engine.hip validate_batch) run
+      // the variant compiled without it - there `slow` cannot be true.
+      if (wave_ballot(slow) != 0) {
+        const u32 r = eval_ref<false>(c.ka_mem, lds_of(c), req, 0, false, ref, slow);
+        if (slow) lv = ((r & 0xFFu) == 1u ? 1u : 0u) | (((r >> 8) & CBH_ST_CEL_ERROR) ? 2u : 0u) | (((r >> 8) & CBH_ST_UNSUPPORTED) ? 8u : 0u);
+      }
+    } else if (slow) lv = 8u;   // unreachable by the host's check; loud (UNSUPPORTED), never a guessed effect
     return active ? lv : 0u;
   };
 
-  bool pend = true;   // every lane takes part in routing: "no policy at all" is an answer too (check.go:119-121, 168-170)
-  for (;;) {   // ---- waterfall over groups that share (scope, version, kind); a sorted batch has one per wave
-    const u64 rem = wave_ballot(pend);
-    if (rem == 0) break;
-    const u32 lead = first_lane(rem);
-    const u32 g_rs = wave_readlane(r_scope, lead), g_ver = wave_readlane(r_ver, lead), g_k = wave_readlane(kind, lead);
-    const bool ing = pend && r_scope == g_rs && r_ver == g_ver && kind == g_k;
-    pend = pend && !ing;
-    const u32 g_first = uchain_first(t, g_rs, FLAG_RES, lenient);
-    bool g_exists = false;
-    u32 depth = 0;
-    for (u32 si = g_first; si != CBH_NONE && depth < CBH_FLAT_MAX_DEPTH; si = uchain_next(t, uload(&t.scope_parent[si]), FLAG_RES), ++depth) {   // check.go:231
-      const bool go = wave_ballot(ing && S != 0) != 0;
-      if (!go && g_exists) break;   // every walk of the group is decided and a policy is known to exist
-      uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
-      const bool have_bucket = udir_find(t, CBH_B_RESOURCE, g_ver, g_k, si, bucket);   // present for every resource policy (index.go:966-997)
-      g_exists = g_exists || have_bucket;
-      if (!go) continue;
-      if (ing) chain_si[depth * CBH_BLOCK + c.tid] = si;
+  // ---- the walk.  check.go:208-442 walks, per request, its scope chain from the request's scope up to the root and,
+  // per scope, the bindings of (version, kind, scope).  Here every lane keeps the scope it stands at (`cur`, its own
+  // depth in `mydepth`); each round takes the DEEPEST scope any lane stands at (scopes are numbered parents first, so
+  // that is the largest index), and the lanes standing there with the leader's (version, kind) walk that one bucket
+  // together, then step to their parent scope.  Lanes whose chains start at different scopes of one branch therefore
+  // fall in with each other as soon as the deeper ones have climbed to the shallower ones' start: a wave holding the
+  // five request scopes of one kind walks its three buckets once, not once per request scope.  Each lane still meets
+  // its own scopes in chain order and a bucket's records in binding order.
+  const u32 first = chain_first(t, r_scope, FLAG_RES, lenient);   // per lane (ruletable.go:848-882)
+  u32 cur = first, mydepth = 0;
+  bool exists = false;
+  for (;;) {
+    // a lane goes on while it has walks to decide, and after that until it knows that some policy exists
+    // (check.go:119-121, 168-170: "no policy at all" is an answer too)
+    const bool active = cur != CBH_NONE && (S != 0 || !exists);
+    if (wave_ballot(active) == 0) break;
+    const u32 g_si = wave_max_bits(cur, active, scope_bits);
+    const u64 here = wave_ballot(active && cur == g_si);
+    const u32 lead = first_lane(here);
+    const u32 g_ver = wave_readlane(r_ver, lead), g_k = wave_readlane(kind, lead);
+    const bool ing = active && cur == g_si && r_ver == g_ver && kind == g_k;
+    const bool go = wave_ballot(ing && S != 0) != 0;
+    uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
+    const bool have_bucket = udir_find(t, CBH_B_RESOURCE, g_ver, g_k, g_si, bucket);   // present for every resource policy (index.go:966-997)
+    exists = exists || (ing && have_bucket);
+    if (go) {
+      if (ing && mydepth < max_depth) chain_si[mydepth * CBH_BLOCK + c.tid] = g_si;
       const u32 S_before = S;
-      if (have_bucket) {
-        for (u32 row = bucket.x; row < bucket.x + bucket.y; ++row) {   // bindings in order (check.go:295-414)
-          const TblRowFull rf = uload_rec<TblRowFull>(t.rows, row);   // hot half + embedded leaf: one scalar load
+      if (have_bucket && bucket.y) {
+        const u32 last = bucket.x + bucket.y - 1u;
+        TblRowFull nxt = uload_rec<TblRowFull>(t.rows, bucket.x);
+        for (u32 row = bucket.x; row <= last; ++row) {   // bindings in order (check.go:295-414)
+          const TblRowFull rf = nxt;   // hot half + leaf slot: one scalar load, issued one record ahead
+          nxt = uload_rec<TblRowFull>(t.rows, row < last ? row + 1u : last);
           const TblRow& rw = rf.hot;
           if ((rw.rm_lo & wave_rc) == 0 || (rw.am_lo & wave_ac) == 0) continue;
           const u32 mact = ((rw.am_lo >> ac[0]) & 1u) | (((rw.am_lo >> ac[1]) & 1u) << 1) | (((rw.am_lo >> ac[2]) & 1u) << 2) | (((rw.am_lo >> ac[3]) & 1u) << 3);
@@ -223,14 +294,15 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
           // each once per record and request, whatever the roles (check.go:316-340)
           u32 hit = m;
           if (rw.drcond != CBH_NONE) {
-            const bool emb = (rw.flags & CBH_ROW_F_DRLEAF_EMBEDDED) != 0;
+            const u32 how = (rw.flags & CBH_ROW_F_DRLEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_DRTREE_EMBEDDED) ? 2u : 0u;
             const LeafRec l2 = uload_rec<LeafRec>(t.rowleaf2, row);
-            const u32 lv = leafish(rw.drcond, emb, l2, hit != 0);
+            const u32 lv = leafish(rw.drcond, how, l2, hit != 0);
             err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
             hit = (lv & 1u) ? hit : 0u;
           }
           if (rw.cond != CBH_NONE && wave_ballot(hit != 0) != 0) {
-            const u32 lv = leafish(rw.cond, (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) != 0, rf.leaf, hit != 0);
+            const u32 how = (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_TREE_EMBEDDED) ? 2u : 0u;
+            const u32 lv = leafish(rw.cond, how, rf.leaf, hit != 0);
             err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
             hit = (lv & 1u) ? hit : 0u;
           }
@@ -239,13 +311,14 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
         }
       }
       const u32 ha = ing ? (has_allow & S) : 0u;   // check.go:416-425
-      const u32 sp = (uload(&t.scope_flags[si]) >> 2) & 3u;
+      const u32 sp = (uload(&t.scope_flags[g_si]) >> 2) & 3u;
       if (sp == SP_REQUIRE_CONSENT) has_allow &= ~ha;
       else if (sp == SP_OVERRIDE_PARENT) { allow |= ha; S &= ~ha; }
       const u32 newly = S_before & ~S;
-      dp0 |= (depth & 1u) ? newly : 0u; dp1 |= (depth & 2u) ? newly : 0u; dp2 |= (depth & 4u) ? newly : 0u; dp3 |= (depth & 8u) ? newly : 0u;
+      dp0 |= (mydepth & 1u) ? newly : 0u; dp1 |= (mydepth & 2u) ? newly : 0u; dp2 |= (mydepth & 4u) ? newly : 0u; dp3 |= (mydepth & 8u) ? newly : 0u;
     }
-    if (ing) { first = g_first; exists = g_exists; S = 0; }
+    const u32 up = uchain_next(t, uload(&t.scope_parent[g_si]), FLAG_RES);   // check.go:231
+    if (ing) { cur = (mydepth + 1u < max_depth) ? up : CBH_NONE; ++mydepth; }
   }
 
   // ---- the fold (check.go:429-442), per action: the first role that allowed, else the first role that denied
@@ -294,29 +367,27 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
       reach = d + 1u;
     }
     bool derr = false, dr_unsup = false;
-    bool pend2 = true;
+    u32 cur2 = first, d2 = 0;   // the same merged climb as the walk above, for the scopes a legitimate walk reached
     for (;;) {
-      const u64 rem = wave_ballot(pend2);
-      if (rem == 0) break;
-      const u32 lead = first_lane(rem);
-      const u32 g_rs = wave_readlane(r_scope, lead), g_ver = wave_readlane(r_ver, lead), g_k = wave_readlane(kind, lead);
-      const bool ing = pend2 && r_scope == g_rs && r_ver == g_ver && kind == g_k;
-      pend2 = pend2 && !ing;
-      u32 depth = 0;
-      for (u32 si = uchain_first(t, g_rs, FLAG_RES, lenient); si != CBH_NONE && depth < CBH_FLAT_MAX_DEPTH;
-           si = uchain_next(t, uload(&t.scope_parent[si]), FLAG_RES), ++depth) {
-        if (wave_ballot(ing && depth < reach) == 0) break;
-        uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
-        if (!udir_find(t, CBH_B_RESOURCE, g_ver, g_k, si, bucket)) continue;
+      const bool active = cur2 != CBH_NONE && d2 < reach;
+      if (wave_ballot(active) == 0) break;
+      const u32 g_si = wave_max_bits(cur2, active, scope_bits);
+      const u32 lead = first_lane(wave_ballot(active && cur2 == g_si));
+      const u32 g_ver = wave_readlane(r_ver, lead), g_k = wave_readlane(kind, lead);
+      const bool ing = active && cur2 == g_si && r_ver == g_ver && kind == g_k;
+      uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
+      if (udir_find(t, CBH_B_RESOURCE, g_ver, g_k, g_si, bucket)) {
         for (u32 d = bucket.z; d < bucket.z + bucket.w; ++d) {
           const TblDrx dx = uload_rec<TblDrx>(t.drx, d);
-          const bool applies = ing && depth < reach && (dx.rm_lo & lane_rc) != 0;   // parent roles x the request's roles (check.go:244)
+          const bool applies = ing && (dx.rm_lo & lane_rc) != 0;   // parent roles x the request's roles (check.go:244)
           if (wave_ballot(applies) == 0) continue;
           u32 lv = 1u;
-          if (dx.cond != CBH_NONE) lv = leafish(dx.cond, (dx.flags & 1u) != 0, dx.leaf, applies);
+          if (dx.cond != CBH_NONE) lv = leafish(dx.cond, dx.flags & 3u, dx.leaf, applies);
           if (applies) { if (lv & 1u) edr |= 1ull << dx.name; derr = derr || (lv & 2u) != 0; dr_unsup = dr_unsup || (lv & 8u) != 0; }
         }
       }
+      const u32 up = uchain_next(t, uload(&t.scope_parent[g_si]), FLAG_RES);
+      if (ing) { cur2 = up; ++d2; }
     }
     if (derr) st4 |= 0x01010101u & ~((st4 >> 1) & 0x01010101u);   // evaluation errors are a per-request fact: every action that is not UNSUPPORTED
     if (dr_unsup) st4 = 0x02020202u;
@@ -345,26 +416,41 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 }
 
 #ifndef CBH_HOSTSIM
-#define CBH_FLAT_ATTRS __launch_bounds__(CBH_FLAT_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8)))
+#define CBH_FLAT_ATTRS(MINW) __launch_bounds__(CBH_FLAT_THREADS) __attribute__((amdgpu_waves_per_eu(MINW, 8)))
 #else
-#define CBH_FLAT_ATTRS
+#define CBH_FLAT_ATTRS(MINW)
 #endif
-__global__ CBH_FLAT_ATTRS void cbh_check_flat_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
-  const u32 ncc = cached_columns(&a);
-  // each wave of the group owns its slice of the column cache: [3 planes][ncc][64 lanes] dwords
-  Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-        (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * (3u * ncc * CBH_BLOCK), ncc, ka};
-  flat_body(a, c);
+// each wave of the group owns its slice of the column cache: [3 planes][ncc][64 lanes] dwords
+#define CBH_FLAT_CTX(a, ka)                                                                                                       \
+  const u32 ncc = cached_columns(&a);                                                                                             \
+  Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,  \
+        (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * (3u * ncc * CBH_BLOCK), ncc, ka}
+// batches of plain scalars (no int / uint / list / map attribute values): no call, ~64 VGPRs, 7-8 waves per SIMD
+__global__ CBH_FLAT_ATTRS(7) void cbh_check_flat_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+  CBH_FLAT_CTX(a, ka);
+  flat_body<false>(a, c);
+}
+// any batch: the same walk with the call into the shared evaluator compiled in (4 waves per SIMD)
+__global__ CBH_FLAT_ATTRS(4) void cbh_check_flat_kernel_any(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+  CBH_FLAT_CTX(a, ka);
+  flat_body<true>(a, c);
 }
 
-// Which kernel decides this batch: the flat one when table (CBH_MF_FLAT), batch shape (<= 4 actions and <= 4 roles per
-// request) and evaluation mode (not strict) allow it, else the general walk's instantiation for the table class.
-// `threads` = the workgroup size to launch it with (dynamic LDS = column cache bytes of one wave x threads / 64).
-static inline cbh_check_kernel_fn cbh_pick_kernel(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 max_actions, u32 max_roles, u32 eval_flags,
-                                                  u32* threads) {
-  if ((table_flags & CBH_MF_FLAT) && max_actions <= 4 && max_roles <= 4 && !(eval_flags & CBH_F_STRICT_EVALUATION)) {
+// Which kernel decides this batch: a flat one when table (CBH_MF_FLAT), batch shape (<= 4 actions and <= 4 roles per
+// request; `plain_tags`: no attribute value is an int / uint / list / map - selects the variant without the evaluator call)
+// and evaluation mode (not strict) allow it, else the general walk's instantiation for the table class.
+// `threads` = the workgroup size to launch it with; dynamic LDS per wave = the column cache, plus - `flat` - the
+// scope-chain scratch (cbh_flat_lds_bytes).
+// dynamic LDS of one wave of the flat kernel: column cache + [max_depth][64] scope indices
+static inline size_t cbh_flat_chain_bytes(u32 table_max_depth) {
+  return (size_t)(table_max_depth < CBH_FLAT_MAX_DEPTH ? table_max_depth : CBH_FLAT_MAX_DEPTH) * CBH_BLOCK * 4;
+}
+static inline cbh_check_kernel_fn cbh_pick_kernel(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 max_actions, u32 max_roles, bool plain_tags,
+                                                  u32 eval_flags, u32* threads, bool* flat) {
+  *flat = (table_flags & CBH_MF_FLAT) && max_actions <= 4 && max_roles <= 4 && !(eval_flags & CBH_F_STRICT_EVALUATION);
+  if (*flat) {
     *threads = CBH_FLAT_THREADS;
-    return cbh_check_flat_kernel;
+    return (plain_tags && (table_flags & CBH_MF_FLAT_CLOSED)) ? cbh_check_flat_kernel : cbh_check_flat_kernel_any;
   }
   *threads = CBH_BLOCK;
   return cbh_pick_check_kernel(table_flags, n_derived_roles, has_globs, max_actions);

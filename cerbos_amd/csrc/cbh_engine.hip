@@ -178,6 +178,7 @@ struct cbh_device_batch {
   KernelArgs last_args;           // what d_args currently holds
   bool have_args = false;
   u32 max_actions = 0, max_roles = 0;   // largest CBH_RQ_ACT_CNT / ROLE_CNT of the batch: select the kernel
+  bool plain_tags = false;              // BatchShape::plain_tags
   std::vector<std::pair<void*, size_t>> allocs;   // (block, capacity) taken from the replica's pool
 };
 
@@ -323,7 +324,7 @@ extern "C" void* cbh_table_device_ptr(const cbh_table* t) { return t ? t->reps[0
 // ---- batch validation (O(n_requests), both entry points) ---------------------------------------------------
 // Offsets and counts the kernels index device memory with must lie inside the arrays they index.  String ids
 // need no host pass: the kernels only compare them, or bound them before using one as an index.
-struct BatchShape { u32 max_actions = 0, max_roles = 0; bool ascending = true; };
+struct BatchShape { u32 max_actions = 0, max_roles = 0; bool ascending = true; bool plain_tags = false; };
 static int validate_batch(const cbh_table* t, const cbh_batch* in, BatchShape& sh) {
   if (in->n_columns != t->meta[CBH_M_NCOLUMNS]) return fail("cbh_batch.n_columns does not match the table's column schema");
   const size_t NR = in->n_requests;
@@ -349,6 +350,17 @@ static int validate_batch(const cbh_table* t, const cbh_batch* in, BatchShape& s
   if (bad) return fail("cbh_batch: a request's role or action slice lies outside the batch");
   if (in->n_strings && in->str_off[in->n_strings] > in->str_bytes_len) return fail("cbh_batch: string offsets exceed str_bytes_len");
   sh.max_actions = maxa; sh.max_roles = maxr; sh.ascending = asc;
+  // Do the attribute columns hold plain scalars only - no int / uint (cross-type numerics) and no list / map (deep
+  // equality)?  Then no classified leaf can need the shared evaluator and the flat kernel without that call decides
+  // the batch (cbh_check_flat.h).  One pass over the tag bytes, and only where the answer selects a kernel.
+  sh.plain_tags = false;
+  if ((t->meta[CBH_M_FLAGS] & CBH_MF_FLAT) && maxa <= 4 && maxr <= 4) {
+    const uint8_t* tg = in->col_tag; const size_t n = (size_t)in->n_columns * NR;
+    u32 seen = 0;
+    for (size_t i = 0; i < n; ++i) { const u32 x = tg[i]; seen |= (u32)((x - CBH_T_INT) < 2u) | (u32)((x - CBH_T_LIST) < 2u); }
+    static const bool force_any = getenv("CBH_FLAT_ANY") != nullptr;   // measurement / test aid: always the variant with the call
+    sh.plain_tags = seen == 0 && !force_any;
+  }
   return 0;
 }
 
@@ -416,7 +428,7 @@ extern "C" int cbh_batch_upload_on(cbh_table* t, uint32_t device_index, const cb
   cbh_device_batch* b = new (std::nothrow) cbh_device_batch();
   if (!b) return fail("out of memory");
   cbh_table_retain(t);
-  b->table = t; b->rep = rep; b->max_actions = sh.max_actions; b->max_roles = sh.max_roles;
+  b->table = t; b->rep = rep; b->max_actions = sh.max_actions; b->max_roles = sh.max_roles; b->plain_tags = sh.plain_tags;
   BatchDev& d = b->dev;
   d.n_requests = in->n_requests; d.n_tuples = in->n_tuples; d.n_roles = in->n_roles;
   d.n_columns = in->n_columns; d.n_strings = in->n_strings; d.heap_len = in->heap_len;
@@ -517,10 +529,10 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   }
   sl.pending = false;
   if (d.n_requests) {
-    u32 threads = CBH_BLOCK;
-    const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, maxw != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), b->max_actions, b->max_roles, pick_flags(p->flags), &threads);
+    u32 threads = CBH_BLOCK; bool flat = false;
+    const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, maxw != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), b->max_actions, b->max_roles, b->plain_tags, pick_flags(p->flags), &threads, &flat);
     const u32 grid = (d.n_requests + threads - 1) / threads;   // one lane per request
-    const size_t lds = check_lds_bytes(d) * (threads / CBH_BLOCK);
+    const size_t lds = (check_lds_bytes(d) + (flat ? cbh_flat_chain_bytes(rep->dev.max_depth) : 0)) * (threads / CBH_BLOCK);
     if (timed) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, sl.ev[2], sl.ev[3], 0, b->last_args, (const KernelArgs*)b->d_args);
     else hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, b->last_args, (const KernelArgs*)b->d_args);
     sl.pending = timed;
@@ -736,10 +748,10 @@ static void launch_resolve(const Replica* rep, const KernelArgs& ka, const Layou
 static void launch_check(const Replica* rep, KernelArgs ka, const KernelArgs* d_args, u32 lo, u32 hi, const BatchShape& sh, hipStream_t s) {
   if (hi <= lo) return;
   ka.b.req_lo = lo; ka.b.req_hi = hi;
-  u32 threads = CBH_BLOCK;
-  const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, nfa_maxw(rep->dev) != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), sh.max_actions, sh.max_roles, pick_flags(ka.flags), &threads);
+  u32 threads = CBH_BLOCK; bool flat = false;
+  const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, nfa_maxw(rep->dev) != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), sh.max_actions, sh.max_roles, sh.plain_tags, pick_flags(ka.flags), &threads, &flat);
   const u32 grid = (hi - lo + threads - 1) / threads;   // one lane per request
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), check_lds_bytes(ka.b) * (threads / CBH_BLOCK), s, ka, d_args);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), (check_lds_bytes(ka.b) + (flat ? cbh_flat_chain_bytes(rep->dev.max_depth) : 0)) * (threads / CBH_BLOCK), s, ka, d_args);
 }
 
 // a small batch on one device: everything packed into the pinned staging block.  Two ways across PCIe:

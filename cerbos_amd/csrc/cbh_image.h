@@ -61,6 +61,23 @@ static inline const char* cbh_parse_image(TableDev& d, std::vector<uint32_t>& me
   d.nfa_words[0] = m[CBH_M_NFA_WORDS_ACTION]; d.nfa_words[1] = m[CBH_M_NFA_WORDS_ROLE]; d.nfa_words[2] = m[CBH_M_NFA_WORDS_KIND];
   for (int i = 0; i < 3; ++i) if (d.nfa_words[i] > NFA_MAXW) return ("glob NFA wider than the device supports");
   d.flags = m[CBH_M_FLAGS];
+  {   // longest scope chain: sizes the flat kernel's per-wave chain scratch (cbh_check_flat.h)
+    const CbhBlobSection* ps = find(CBH_SEC_SCOPE_PARENT);
+    const uint32_t ns = m[CBH_M_NSCOPES];
+    if (!ps || ps->nbytes < (uint64_t)ns * 4) return ("blob scope section too small");
+    const uint32_t* par = reinterpret_cast<const uint32_t*>(host_copy + ps->offset);
+    uint32_t deepest = 1;
+    for (uint32_t s = 0; s < ns; ++s) {
+      uint32_t n = 1, at = par[s];
+      while (at != CBH_NONE && at < ns && n <= ns) { ++n; at = par[at]; }
+      if (n > ns) return ("scope parents form a cycle");
+      if (n > deepest) deepest = n;
+    }
+    d.max_depth = deepest;
+    d.n_scopes = ns;
+    for (uint32_t s = 0; s < ns; ++s)   // the flat kernel's merge order relies on it (cbh_check_flat.h)
+      if (par[s] != CBH_NONE && par[s] >= s) return ("scopes are not numbered parents first");
+  }
   if (!d.hash || !d.code || !d.str_off || !d.scope_flags) return ("blob is missing required sections");
   return nullptr;
 }

@@ -62,6 +62,8 @@ struct TableDev {
   const CBH_G u64* gbits; u32 K;
   const CBH_G u64* nfa[3]; u32 nfa_words[3];
   u32 flags;
+  u32 max_depth;                                            // longest scope chain of the table (entries), computed at load
+  u32 n_scopes;                                             // scopes are numbered parents first (root = 0): a deeper scope has the larger index
 };
 
 struct BatchDev {

@@ -21,11 +21,11 @@ from .. import namer
 from ..cel import parser as celparser
 from ..ruletable.build import KIND_PRINCIPAL, KIND_RESOURCE
 from . import celc
-from .celc import COND_LEAF, COND_PC_MASK, LoweringError, Params, ProgramBuilder
+from .celc import COND_LEAF, COND_LEAFTREE, COND_PC_MASK, LoweringError, Params, ProgramBuilder
 from .globs import GlobNFA, fix_glob, has_meta
 
 BLOB_MAGIC = 0x31484243
-BLOB_VERSION = 16
+BLOB_VERSION = 17
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
 PAT_ANY = 0x7FFFFFFF     # the lone "*": matches every string, no automaton needed
@@ -37,6 +37,8 @@ ROW_LEAF = 8           # dwords 8..15: the embedded fused-leaf record
 ROW_F_LEAF_EMBEDDED = 64
 SEC_ACTION_CLASS, SEC_ROWPAT, SEC_ROWLEAF2, SEC_DRX = 28, 29, 30, 31
 ROW_F_DRLEAF_EMBEDDED = 128
+ROW_F_TREE_EMBEDDED, ROW_F_DRTREE_EMBEDDED = 256, 512   # the slot holds a tree descriptor (_tree_descriptor)
+MF_FLAT_CLOSED = 512
 
 (SEC_META, SEC_STR_OFF, SEC_STR_BYTES, SEC_SCOPE_PARENT, SEC_SCOPE_FLAGS, SEC_SCOPE_SID, SEC_HASH,
  SEC_ROWS, SEC_RPROWS, SEC_U32POOL, SEC_DR, SEC_CODE, SEC_CONST_TAG, SEC_CONST_VAL, SEC_THEAP_TAG,
@@ -422,12 +424,16 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
     # visit which needs the condition already has it; the derived-role condition's leaf likewise, in its own section
     leaf2_cols = [[] for _ in range(8)]
     for i, (cond, drc) in enumerate(zip(row_cols[ROW_COND], row_cols[ROW_DRCOND])):
-        for ref, flag, cols, base in ((cond, ROW_F_LEAF_EMBEDDED, row_cols, ROW_LEAF), (drc, ROW_F_DRLEAF_EMBEDDED, leaf2_cols, 0)):
+        for ref, flag, tflag, cols, base in ((cond, ROW_F_LEAF_EMBEDDED, ROW_F_TREE_EMBEDDED, row_cols, ROW_LEAF),
+                                             (drc, ROW_F_DRLEAF_EMBEDDED, ROW_F_DRTREE_EMBEDDED, leaf2_cols, 0)):
             rec = [0] * 8
             if ref != NONE and (ref & COND_LEAF):
                 pc = ref & COND_PC_MASK
                 rec = [int(w) & 0xFFFFFFFF for w in pb.code[pc:pc + 8]]
                 row_cols[ROW_FLAGS][i] |= flag
+            elif ref != NONE and (ref & COND_LEAFTREE) and (ref & COND_PC_MASK) in pb.tree_strips:
+                rec = _tree_descriptor(pb.tree_strips[ref & COND_PC_MASK])
+                row_cols[ROW_FLAGS][i] |= tflag
             for k in range(8):
                 cols[base + k].append(rec[k])
     # derived-role definitions once more for the flat kernel: parent roles as a class mask, the condition's leaf inline
@@ -450,7 +456,10 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         if emb:
             pc = cond & COND_PC_MASK
             rec = [int(w) & 0xFFFFFFFF for w in pb.code[pc:pc + 8]]
-        vals = [mask & 0xFFFFFFFF, mask >> 32, 1 if emb else 0, cond, dr_cols[0][i], 0, 0, 0] + rec
+        tree = cond != NONE and bool(cond & COND_LEAFTREE) and (cond & COND_PC_MASK) in pb.tree_strips
+        if tree:
+            rec = _tree_descriptor(pb.tree_strips[cond & COND_PC_MASK])
+        vals = [mask & 0xFFFFFFFF, mask >> 32, (1 if emb else 0) | (2 if tree else 0), cond, dr_cols[0][i], 0, 0, 0] + rec
         for k in range(16):
             drx_cols[k].append(vals[k])
 
@@ -502,6 +511,16 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
             and not (int(meta[M_FLAGS]) & 2) and not any(lt.nfas[d].patterns for d in range(3)) and max_depth <= 16
             and all((f & by_class) == by_class for f in row_cols[ROW_FLAGS]))
     meta[M_FLAGS] |= 256 if flat else 0
+    # FLAT_CLOSED: besides, every condition is a classified leaf or a tree of them the flat kernel evaluates inline -
+    # with a batch of plain scalars no evaluation can need the shared evaluator (the kernel variant without the call)
+    def inline_ok(ref, leaf_slot_class, embedded, tree):
+        return ref == NONE or tree or (embedded and leaf_slot_class in (1, 2, 3, 4, 6))
+    closed = flat and all(
+        inline_ok(row_cols[ROW_COND][i], row_cols[ROW_LEAF + 7][i], f & ROW_F_LEAF_EMBEDDED, f & ROW_F_TREE_EMBEDDED)
+        and inline_ok(row_cols[ROW_DRCOND][i], leaf2_cols[7][i], f & ROW_F_DRLEAF_EMBEDDED, f & ROW_F_DRTREE_EMBEDDED)
+        for i, f in enumerate(row_cols[ROW_FLAGS])) and all(
+        inline_ok(drx_cols[3][i], drx_cols[15][i], drx_cols[2][i] & 1, drx_cols[2][i] & 2) for i in range(len(drx_cols[0])))
+    meta[M_FLAGS] |= MF_FLAT_CLOSED if closed else 0
     meta[M_MAX_STACK] = pb.max_stack
     meta[M_NDRNAMES] = len(lt.dr_names)
     meta[M_NFA_WORDS_ACTION] = lt.nfas[0].words
@@ -581,6 +600,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         "globs": [len(d.globs) for d in dims],
         "reads_request_strings": bool(int(meta[M_FLAGS]) & 64),
         "needs_string_bytes": bool(int(meta[M_FLAGS]) & 128),
+        "flat_closed": bool(int(meta[M_FLAGS]) & MF_FLAT_CLOSED),   # ... and every condition inline: the variant without the evaluator call serves plain batches
         "flat": bool(int(meta[M_FLAGS]) & 256),   # eligible for cbh_check_flat_kernel (batch shape and mode permitting)   # glob automata or programs that look inside strings   # raw request strings (R.id, R.kind, scopes, versions) read by some program
         "generic_programs": bool(pb.has_generic),   # selects the kernel with the operand-stack interpreter
         # feature class of the 32-bit-mask kernels (cbh_pick_check_kernel): "" = everything (role policies /
@@ -590,6 +610,14 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
             | (4 if (used_any or any(lt.nfas[d].patterns for d in range(3))) else 0))),
     }
     return lt
+
+
+def _tree_descriptor(strip):
+    """The leaf slot of a record whose condition is a tree of classified leaves (celc.py _tree_strip), laid over the
+    fused-leaf record's fields: {ops 0-7, ops 8-15, index of the first leaf record in 8-dword units of the tape,
+    ops 16-23, ops 24-31, number of leaves, 0, 7}."""
+    packed, n, first = strip
+    return [packed[0], packed[1], first, packed[2], packed[3], n, 0, 7]
 
 
 def _column_paths(columns):

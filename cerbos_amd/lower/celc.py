@@ -60,6 +60,7 @@ RQ_S_P_SCOPE, RQ_S_R_SCOPE, RQ_S_P_VERSION, RQ_S_R_VERSION = 12, 13, 14, 15
 IT_ALL, IT_EXISTS, IT_EXISTS_ONE = 0, 1, 2
 
 MAX_STACK = 10
+TREE_STRIP_MAX = 8   # leaves of a condition tree the flat kernel evaluates inline (cbh_blob.h CBH_TREE_STRIP_MAX)
 CACHE_COLS = 16      # CBH_CACHE_COLS (cbh_vm.h): columns the decision kernel parks in LDS
 MAX_LOCALS = 4
 MAX_ITERS = 2
@@ -196,6 +197,8 @@ class ProgramBuilder:
         self.theap_val = []
         self.columns = {}                  # (root, keys) -> column index
         self.programs = {}                 # dedup key -> entry pc
+        self.tree_strips = {}              # entry pc of a leaf tree -> (packed ops, n leaves, strip index / 8): _tree_strip
+        self._pending_strip = None
         self.dr_names = {}                 # derived role name -> bit
         self.unsupported = []              # [(expr text, reason)]
         self.uses_runtime = False
@@ -291,6 +294,52 @@ class ProgramBuilder:
             return 4
         return 0
 
+    def _leaf_record(self, w3):
+        """[OP_LEAF_BIN word, a0, a1] -> the 8-dword fused-leaf record {w, a0, a1, RET, ctag, clo, chi, class}."""
+        words = list(w3) + [OP_RET]
+        a = words[0] >> 8
+        ka, kb = (a >> 8) & 0xF, (a >> 12) & 0xF
+        if (ka == 0) != (kb == 0):
+            ci = words[1] if ka == 0 else words[2]
+            cv = int(self.const_val[ci]) & 0xFFFFFFFFFFFFFFFF
+            cls = self._leaf_class(a & 0xFF, ka, kb, ci)
+            if cls == 6:   # column in [<= 3 strings]: the ids instead of the list's heap reference
+                off, n = (cv >> 32) & 0x3FFFFFFF, cv & 0xFFFFFFFF
+                ids = [int(self.theap_val[off + i]) & 0xFFFFFFFF for i in range(n)] + [0xFFFFFFFF] * (3 - n)
+                return words + ids + [6]
+            return words + [self.const_tag[ci], cv & 0xFFFFFFFF, cv >> 32, cls]
+        return words + [0xFFFFFFFF, 0, 0, self._leaf_class(a & 0xFF, ka, kb, None)]
+
+    def _tree_strip(self, pc, words):
+        """A condition tree of at most TREE_STRIP_MAX classified leaves (any nesting the op budget holds) also gets, for
+        the flat kernel (cbh_check_flat.h flat_tree): its leaves as a strip of consecutive 8-dword fused-leaf records
+        behind the program, and its structure as 4-bit ops - 1 = the next leaf of the strip, 2 + k / 5 + k / 8 + k =
+        TREE_BEGIN / TREE_ACC / TREE_END of kind k (0 all, 1 any, 2 none), 0 = end - so that a wave evaluates it
+        inline and branch-free with no tape reads.  Recorded in tree_strips[pc] = (ops as four u32, n leaves, first
+        record's index in 8-dword units); the tape program stays what the general walk runs."""
+        ops, leaves, i, depth = [], [], 0, 0
+        body = words[:-1]   # without the closing OP_RET
+        while i < len(body):
+            op, arg = body[i] & 0xFF, body[i] >> 8
+            if op == OP_LEAF_BIN:
+                leaves.append(self._leaf_record(body[i:i + 3]))
+                ops.append(1)
+                i += 3
+                continue
+            if op not in (OP_TREE_BEGIN, OP_TREE_ACC, OP_TREE_END) or arg > 2:
+                return
+            ops.append({OP_TREE_BEGIN: 2, OP_TREE_ACC: 5, OP_TREE_END: 8}[op] + arg)
+            depth += (op == OP_TREE_BEGIN) - (op == OP_TREE_END)
+            if depth > 8:
+                return
+            i += 1
+        if not 1 <= len(leaves) <= TREE_STRIP_MAX or len(ops) > 32 or any(rec[7] not in (1, 2, 3, 4, 6) for rec in leaves):
+            return
+        packed = [0, 0, 0, 0]
+        for k, o in enumerate(ops):
+            packed[k // 8] |= o << (4 * (k % 8))
+        self._pending_strip = (pc, packed, leaves)
+
     # ---- programs ------------------------------------------------------------------
     def condition_program(self, cond, params: Params, allow_runtime=True):
         """Compile a condition tree; returns the entry pc (deduplicated)."""
@@ -305,26 +354,23 @@ class ProgramBuilder:
         words = fc.finish(pc)
         is_leaf = len(words) == 4 and (words[0] & 0xFF) == OP_LEAF_BIN
         if is_leaf:
-            # A single fused leaf becomes an 8-dword record {op, a0, a1, RET, ctag, clo, chi, 0} on an
+            # A single fused leaf becomes an 8-dword record {op, a0, a1, RET, ctag, clo, chi, class} on an
             # 8-dword boundary: one s_load_dwordx8 fetches the instruction AND the value of its
             # constant operand (ctag = NONE when neither / both operands are constants).
             self.code.extend([OP_RET] * (-len(self.code) % 8))
             pc = len(self.code)
-            a = words[0] >> 8
-            ka, kb = (a >> 8) & 0xF, (a >> 12) & 0xF
-            if (ka == 0) != (kb == 0):
-                ci = words[1] if ka == 0 else words[2]
-                cv = int(self.const_val[ci]) & 0xFFFFFFFFFFFFFFFF
-                cls = self._leaf_class(a & 0xFF, ka, kb, ci)
-                if cls == 6:   # column in [<= 3 strings]: the ids instead of the list's heap reference
-                    off, n = (cv >> 32) & 0x3FFFFFFF, cv & 0xFFFFFFFF
-                    ids = [int(self.theap_val[off + i]) & 0xFFFFFFFF for i in range(n)] + [0xFFFFFFFF] * (3 - n)
-                    words = words + ids + [6]
-                else:
-                    words = words + [self.const_tag[ci], cv & 0xFFFFFFFF, cv >> 32, cls]
-            else:
-                words = words + [0xFFFFFFFF, 0, 0, self._leaf_class(a & 0xFF, ka, kb, None)]
+            words = self._leaf_record(words[:3])
+        self._pending_strip = None
+        if not is_leaf and _is_leaf_tree(words):
+            self._tree_strip(pc, words)
         self.code.extend(words)
+        if self._pending_strip is not None:
+            _, packed, leaves = self._pending_strip
+            self.code.extend([OP_RET] * (-len(self.code) % 8))
+            self.tree_strips[pc] = (packed, len(leaves), len(self.code) // 8)
+            for rec in leaves:
+                self.code.extend(rec)
+        self._pending_strip = None
         if pc >= COND_PC_MASK:
             raise LoweringError("bytecode tape exceeds 2^30 words")
         if is_leaf:

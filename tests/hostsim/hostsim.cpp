@@ -81,10 +81,10 @@ extern "C" const char* hostsim_last_error() { return g_err.c_str(); }
 
 static KernelArgs* g_args;
 
-static uint32_t g_max_actions, g_max_roles, g_threads;   // same kernel selection as cbh_check_resident (cbh_engine.hip)
+static uint32_t g_max_actions, g_max_roles, g_threads; static bool g_flat, g_plain;   // same kernel selection as cbh_check_resident (cbh_engine.hip)
 
 static void fiber_main() {
-  cbh_pick_kernel(g_args->t.flags, g_args->t.n_dr, (g_args->t.nfa_words[0] | g_args->t.nfa_words[1] | g_args->t.nfa_words[2] | (g_args->t.flags & CBH_MF_HAS_ANY_PATTERN)) != 0, g_max_actions, g_max_roles, g_args->flags, &g_threads)(*g_args, g_args);
+  cbh_pick_kernel(g_args->t.flags, g_args->t.n_dr, (g_args->t.nfa_words[0] | g_args->t.nfa_words[1] | g_args->t.nfa_words[2] | (g_args->t.flags & CBH_MF_HAS_ANY_PATTERN)) != 0, g_max_actions, g_max_roles, g_plain, g_args->flags, &g_threads, &g_flat)(*g_args, g_args);
   g_fibers[g_cur].done = true;
   g_fibers[g_cur].waiting = 0;
   swapcontext(&g_fibers[g_cur].ctx, &g_sched);
@@ -176,6 +176,11 @@ extern "C" int hostsim_check(const void* blob, size_t len, const cbh_batch* in, 
   for (uint32_t r = 0; r < in->n_requests; ++r)
     max_roles = std::max(max_roles, in->req_u32[(size_t)CBH_RQ_ROLE_CNT * in->n_requests + r]);
   g_max_roles = max_roles;
+  g_plain = getenv("CBH_FLAT_ANY") == nullptr;   // cbh_engine.hip validate_batch
+  for (size_t i = 0; i < (size_t)in->n_columns * in->n_requests; ++i) {
+    const uint32_t x = in->col_tag[i];
+    if ((x - CBH_T_INT) < 2u || (x - CBH_T_LIST) < 2u) g_plain = false;
+  }
   // two launches over an arbitrary (unaligned) split of the batch: the chunk window [req_lo, req_hi) that the
   // one-shot path pipelines with (cbh_engine.hip) is exercised by every test of the CPU tier
   const uint32_t n = in->n_requests, mid = n > 3 ? (n / 2) - (n / 2) % 3 + 1 : n;

@@ -27,24 +27,32 @@ SCOPES = ["", "acme", "acme.hr", "acme.hr.uk"]
 KINDS = ["doc", "report"]
 ROLES = ["user", "manager", "admin", "guest", "auditor", "intern"]
 ACTIONS = ["view", "edit", "delete", "approve", "share", "export"]
+# conditions that leave the classified leaves' inline code: container equality (class 3 on lists), a list where a
+# number is expected - these batches carry list tags and run the kernel variant with the evaluator call
+CONDS_ANY = ["R.attr.tags == P.attr.tags", "R.attr.tags != P.attr.tags", "R.attr.amount >= 50"]
 CONDS = ["R.attr.public == true", "R.attr.owner == P.id", "R.attr.amount > 100", "P.attr.department == R.attr.department",
          'R.attr.status in ["OPEN", "PENDING"]', "R.attr.missing == 1", "P.attr.level >= 3", "R.attr.owner != P.id"]
 
 
-def _cond(rng):
+def _cond(rng, pool=None):
+    pool = pool or CONDS
     r = rng.random()
     if r < 0.35:
         return None
     if r < 0.8:
-        return {"match": {"expr": str(rng.choice(CONDS))}}
+        return {"match": {"expr": str(rng.choice(pool))}}
     kind = str(rng.choice(["all", "any", "none"]))
-    return {"match": {kind: {"of": [{"expr": str(e)} for e in rng.choice(CONDS, size=int(rng.integers(2, 4)), replace=False)]}}}
+    of = [{"expr": str(e)} for e in rng.choice(pool, size=int(rng.integers(2, 4)), replace=False)]
+    if rng.random() < 0.3:   # a nested level
+        inner = str(rng.choice(["all", "any", "none"]))
+        of.append({inner: {"of": [{"expr": str(e)} for e in rng.choice(pool, size=2, replace=False)]}})
+    return {"match": {kind: {"of": of}}}
 
 
 DRS = ["owner", "peer", "senior", "anyone"]
 
 
-def _store(rng):
+def _store(rng, pool=None):
     docs = []
     with_dr = rng.random() < 0.6
     if with_dr:   # derived roles: definitions with and without conditions, `*` parents, conditions that can raise errors
@@ -69,7 +77,7 @@ def _store(rng):
                         rule["roles"] = [str(rng.choice(ROLES))]
                 else:
                     rule["roles"] = [str(r) for r in rng.choice(ROLES + ["*"], size=int(rng.integers(1, 5)), replace=False)]
-                c = _cond(rng)
+                c = _cond(rng, pool)
                 if c:
                     rule["condition"] = c
                 rules.append(rule)
@@ -84,7 +92,7 @@ def _store(rng):
     return docs
 
 
-def _requests(rng, n):
+def _requests(rng, n, with_lists=False):
     out = []
     for i in range(n):
         roles = [str(r) for r in rng.choice(ROLES + ["stranger"], size=int(rng.integers(0, 5)), replace=False)]
@@ -93,6 +101,12 @@ def _requests(rng, n):
         rattr = {"public": bool(rng.random() < 0.4), "owner": "p%d" % rng.integers(0, 4), "amount": float(rng.integers(0, 200)),
                  "department": str(rng.choice(["eng", "ops"])), "status": str(rng.choice(["OPEN", "CLOSED"]))}
         pattr = {"department": str(rng.choice(["eng", "ops"])), "level": float(rng.integers(1, 6))}
+        if with_lists:
+            tagsets = [["a"], ["a", "b"], ["b", "a"], [], "a", 3.0]
+            rattr["tags"] = tagsets[int(rng.integers(0, len(tagsets)))]
+            pattr["tags"] = tagsets[int(rng.integers(0, len(tagsets)))]
+            if rng.random() < 0.2:
+                rattr["amount"] = [1.0, 2.0]   # a list where the policies compare a number
         for d in (rattr, pattr):
             for k in list(d):
                 if rng.random() < 0.08:
@@ -103,13 +117,15 @@ def _requests(rng, n):
     return out
 
 
-def _run_seed(seed, make_evaluator, close):
+def _run_seed(seed, make_evaluator, close, with_lists=False):
     rng = np.random.default_rng(40_000 + seed)
-    rt = rule_table_from_policies(policies_from_docs(_store(rng)))
+    rt = rule_table_from_policies(policies_from_docs(_store(rng, CONDS + CONDS_ANY if with_lists else None)))
     lt = lower_rule_table(rt)
-    assert lt.stats["flat"], "the generator must produce flat tables"
-    inputs = _requests(rng, 200)
+    assert lt.stats["flat"] and lt.stats["flat_closed"], "the generator must produce flat tables whose conditions are all inline"
+    inputs = _requests(rng, 200, with_lists)
     batch = Flattener(lt).flatten(inputs)
+    plain = not np.isin(batch.col_tag, (2, 3, 6, 7)).any()   # cbh_engine.hip validate_batch: selects the kernel variant
+    assert plain != with_lists
     assert int(batch.req_u32[9].max()) <= 4 and int(batch.req_u32[7].max()) <= 4   # the flat kernel's batch shape
     ev = make_evaluator(lt)
     orc = RuleTableOracle(rt)
@@ -142,6 +158,22 @@ def test_flat_kernel_source_vs_oracle(seed):
     _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False)
 
 
+@pytest.mark.parametrize("seed", range(100, 116))
+def test_flat_kernel_with_evaluator_call_vs_oracle(seed):
+    """Batches with list-valued attributes: container equality and a list met where a number is compared go through
+    the shared evaluator (cbh_check_flat_kernel_any)."""
+    from test_hostsim_golden import HostSimEvaluator
+    _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False, with_lists=True)
+
+
+def test_plain_batches_through_the_variant_with_the_call(monkeypatch):
+    """CBH_FLAT_ANY=1 sends plain batches through the variant with the call too: both variants decide them alike."""
+    from test_hostsim_golden import HostSimEvaluator
+    monkeypatch.setenv("CBH_FLAT_ANY", "1")
+    for seed in range(6):
+        _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False)
+
+
 def test_error_cases_do_occur():
     from test_hostsim_golden import HostSimEvaluator
     assert sum(_run_seed(s, lambda lt: HostSimEvaluator(lt, Conf()), False) for s in range(4)) > 20
@@ -151,3 +183,9 @@ def test_error_cases_do_occur():
 @pytest.mark.parametrize("seed", range(40))
 def test_flat_kernel_on_gpu(seed):
     _run_seed(seed, lambda lt: HipEvaluator(lt, Conf()), True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(100, 116))
+def test_flat_kernel_with_evaluator_call_on_gpu(seed):
+    _run_seed(seed, lambda lt: HipEvaluator(lt, Conf()), True, with_lists=True)
