@@ -48,6 +48,28 @@ __device__ __forceinline__ u64 wave_or64(u64 v, u32 wave, u32 lane) {
   return r;
 }
 
+#define CBH_FLAT_LDS_STRINGS 4096u   /* class tables of at most this many table strings are staged in LDS (2 bytes each) */
+struct u32x4u { u32 x, y, z, w; };
+__device__ __forceinline__ u32x4u load_u32x4(const CBH_G u32* p) {   // one 16-byte load; `p` is dword aligned
+#ifndef CBH_HOSTSIM
+  typedef u32 v4 __attribute__((ext_vector_type(4), aligned(4)));
+  const v4 v = *(const CBH_G v4*)p;
+  return u32x4u{v.x, v.y, v.z, v.w};
+#else
+  return u32x4u{p[0], p[1], p[2], p[3]};
+#endif
+}
+// stores of results nobody in this kernel reads again: written through, so that the end of the kernel does not have to
+// flush them out of the L2 (the dirty lines of a 1M-tuple batch are 12 MB)
+template <typename T>
+__device__ __forceinline__ void store_nt(CBH_G T* p, T v) {
+#ifndef CBH_HOSTSIM
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 // one record of CBH_SEC_DRX (cbh_blob.h CbhDrxField): a derived-role definition as the flat kernel reads it
 struct __attribute__((aligned(64))) TblDrx { u32 rm_lo, rm_hi, flags, cond, name, p0, p1, p2; LeafRec leaf; };
 
@@ -172,6 +194,14 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   const OutDev& o = ka_regs.o;
   const u32 flags = ka_regs.flags;
   const u32 wave = threadIdx.x / CBH_BLOCK;   // which of the group's waves (c.tid is the lane within it)
+#ifdef CBH_PROFILE_CYCLES   // profiling build only (tools/gpu_cycles_flat.py)
+  const u64 cyc0 = __builtin_readcyclecounter();
+  const u64 rt0 = __builtin_amdgcn_s_memrealtime();
+  u32 dbg_rows = 0, dbg_rounds = 0;
+#define FLAT_DBG(x) x
+#else
+#define FLAT_DBG(x)
+#endif
   const u32 rix = b.req_lo + blockIdx.x * CBH_FLAT_THREADS + threadIdx.x;
   const bool valid = rix < b.req_hi;
   const u32 req = valid ? rix : b.req_lo;
@@ -183,23 +213,55 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 #undef RQ
   fill_column_cache(c, b, NR, req);
   const u32 all = (1u << act_cnt) - 1u;
+  // [depth][lane]: scope index at that depth of the lane's chain - in the dynamic LDS behind the column caches,
+  // sized by the table's longest chain (a one-scope table pays 256 B per wave, not 4 KB: LDS sets the occupancy here)
+  const u32 max_depth = t.max_depth < CBH_FLAT_MAX_DEPTH ? t.max_depth : CBH_FLAT_MAX_DEPTH;
+  CBH_L u32* chain_si = (CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * (3u * c.n_cached * CBH_BLOCK) + wave * (max_depth * CBH_BLOCK);
   // actions and roles -> classes (CBH_SEC_ACTION_CLASS / CBH_SEC_ROLE_CLASS; 63 = a string no rule names).
   // A flat table has fewer than 32 classes per dimension and its masks mirror "any other string" (bit 63)
   // in bit 31 of the low dword: the match is a 1-bit field extract from ONE dword at a per-lane position.
   // Every load below is unconditional (an index that does not exist reads element 0 instead and is masked
   // afterwards): the eight id loads go out together, then the eight class loads - two round trips, not sixteen.
   u32 ac[4], rc[4], aid[4], rid[4];
+  // The class tables (one byte per table string) are copied into LDS by the workgroup while the request loads are in
+  // flight - a table of up to CBH_FLAT_LDS_STRINGS strings - so that the lookups below are LDS reads, not a third
+  // dependent trip to memory.
+  const bool cls_in_lds = t.K <= CBH_FLAT_LDS_STRINGS;
+  CBH_L u8* cls_lds = (CBH_L u8*)((CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * ((3u * c.n_cached + max_depth) * CBH_BLOCK));   // [action classes K][role classes K]
+  if (cls_in_lds) {
+    for (u32 i = threadIdx.x; i < t.K; i += CBH_FLAT_THREADS) { cls_lds[i] = t.action_class[i]; cls_lds[t.K + i] = t.role_class[i]; }
+  }
+  // Actions: a batch of four-action requests laid out back to back has ACT_OFF = 4 * request - read the four ids from
+  // there with ONE 16-byte load that does not wait for ACT_OFF to arrive, and fall back to the dependent loads for the
+  // lanes where the guess was wrong.
+  const bool spec = b.n_tuples >= 4u;   // wave-uniform
+  const u32 spec_ix = (4u * req + 4u <= b.n_tuples) ? 4u * req : 0u;
+  u32x4u sp; sp.x = sp.y = sp.z = sp.w = 0;
+  if (spec) sp = load_u32x4(b.tuple_action + spec_ix);
 #pragma unroll
-  for (u32 k = 0; k < 4; ++k) {
-    aid[k] = b.tuple_action[k < act_cnt ? act_off + k : 0u];
-    rid[k] = b.roles[k < role_cnt ? role_off + k : 0u];
+  for (u32 k = 0; k < 4; ++k) rid[k] = b.roles[k < role_cnt ? role_off + k : 0u];
+  const bool spec_hit = spec && act_cnt == 4u && act_off == spec_ix;
+  aid[0] = sp.x; aid[1] = sp.y; aid[2] = sp.z; aid[3] = sp.w;
+  if (!spec_hit) {
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) aid[k] = b.tuple_action[k < act_cnt ? act_off + k : 0u];
   }
   const u32 kmax = t.K ? t.K - 1u : 0u;
+  if (cls_in_lds) {
+    __syncthreads();
 #pragma unroll
-  for (u32 k = 0; k < 4; ++k) {
-    const u32 ca = t.action_class[aid[k] < t.K ? aid[k] : kmax], cr = t.role_class[rid[k] < t.K ? rid[k] : kmax];
-    ac[k] = (k < act_cnt && aid[k] < t.K && ca < 31u) ? ca : 31u;    // 31 = a string no rule names (cbh_blob.h)
-    rc[k] = (k < role_cnt && rid[k] < t.K && cr < 31u) ? cr : 31u;
+    for (u32 k = 0; k < 4; ++k) {
+      const u32 ca = cls_lds[aid[k] < t.K ? aid[k] : kmax], cr = cls_lds[t.K + (rid[k] < t.K ? rid[k] : kmax)];
+      ac[k] = (k < act_cnt && aid[k] < t.K && ca < 31u) ? ca : 31u;    // 31 = a string no rule names (cbh_blob.h)
+      rc[k] = (k < role_cnt && rid[k] < t.K && cr < 31u) ? cr : 31u;
+    }
+  } else {
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+      const u32 ca = t.action_class[aid[k] < t.K ? aid[k] : kmax], cr = t.role_class[rid[k] < t.K ? rid[k] : kmax];
+      ac[k] = (k < act_cnt && aid[k] < t.K && ca < 31u) ? ca : 31u;
+      rc[k] = (k < role_cnt && rid[k] < t.K && cr < 31u) ? cr : 31u;
+    }
   }
   u32 lane_ac = 0, lane_rc = 0;
   u32 walks = 0;   // bit 4r + k: role r exists and action k exists
@@ -211,14 +273,11 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   // classes present in the wave: a record none of them can match is skipped on the scalar unit
   const u64 wave_cls = wave_or64((u64)lane_ac | ((u64)lane_rc << 32), wave, c.tid);
   const u32 wave_ac = (u32)wave_cls, wave_rc = (u32)(wave_cls >> 32);
+  FLAT_DBG(const u64 cyc1 = __builtin_readcyclecounter();)   // request fields, ids and classes have arrived
 
   const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
   Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false; L.pid = pid;
 
-  // [depth][lane]: scope index at that depth of the lane's chain - in the dynamic LDS behind the column caches,
-  // sized by the table's longest chain (a one-scope table pays 256 B per wave, not 4 KB: LDS sets the occupancy here)
-  const u32 max_depth = t.max_depth < CBH_FLAT_MAX_DEPTH ? t.max_depth : CBH_FLAT_MAX_DEPTH;
-  CBH_L u32* chain_si = (CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * (3u * c.n_cached * CBH_BLOCK) + wave * (max_depth * CBH_BLOCK);
   u32 S = walks;                 // walks still going
   u32 has_allow = 0, allow = 0, deny = 0, err = 0, unsup = 0;
   u32 dp0 = 0, dp1 = 0, dp2 = 0, dp3 = 0;   // bit planes of the depth a walk was decided at
@@ -258,6 +317,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   const u32 first = chain_first(t, r_scope, FLAG_RES, lenient);   // per lane (ruletable.go:848-882)
   u32 cur = first, mydepth = 0;
   bool exists = false;
+  FLAT_DBG(const u64 cyc2 = cyc1 + (__builtin_readcyclecounter() - cyc1) * (u64)(wave_ballot(first != 0xFFFFFFFEu) != 0);)   // chain starts known
   for (;;) {
     // a lane goes on while it has walks to decide, and after that until it knows that some policy exists
     // (check.go:119-121, 168-170: "no policy at all" is an answer too)
@@ -269,6 +329,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
     const u32 g_ver = wave_readlane(r_ver, lead), g_k = wave_readlane(kind, lead);
     const bool ing = active && cur == g_si && r_ver == g_ver && kind == g_k;
     const bool go = wave_ballot(ing && S != 0) != 0;
+    FLAT_DBG(++dbg_rounds;)
     uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
     const bool have_bucket = udir_find(t, CBH_B_RESOURCE, g_ver, g_k, g_si, bucket);   // present for every resource policy (index.go:966-997)
     exists = exists || (ing && have_bucket);
@@ -282,6 +343,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
           const TblRowFull rf = nxt;   // hot half + leaf slot: one scalar load, issued one record ahead
           nxt = uload_rec<TblRowFull>(t.rows, row < last ? row + 1u : last);
           const TblRow& rw = rf.hot;
+          FLAT_DBG(++dbg_rows;)
           if ((rw.rm_lo & wave_rc) == 0 || (rw.am_lo & wave_ac) == 0) continue;
           const u32 mact = ((rw.am_lo >> ac[0]) & 1u) | (((rw.am_lo >> ac[1]) & 1u) << 1) | (((rw.am_lo >> ac[2]) & 1u) << 2) | (((rw.am_lo >> ac[3]) & 1u) << 3);
           // one nibble per role (sign-extended 1-bit extracts), one bit per nibble for the actions; walks of other groups sit out
@@ -321,6 +383,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
     if (ing) { cur = (mydepth + 1u < max_depth) ? up : CBH_NONE; ++mydepth; }
   }
 
+  FLAT_DBG(const u64 cyc3 = __builtin_readcyclecounter();)   // the walk is over
   // ---- the fold (check.go:429-442), per action: the first role that allowed, else the first role that denied
   const bool decided = first == CBH_NONE || !exists;   // nothing to evaluate: "NO_MATCH" (check.go:119-121, 168-170)
   const u32 pol_none = (u32)(decided ? CBH_P_NO_MATCH : (role_cnt ? CBH_P_RESOURCE : CBH_P_EMPTY)) << 28 | ((!decided && role_cnt) ? first : 0u);
@@ -393,14 +456,25 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
     if (dr_unsup) st4 = 0x02020202u;
   }
 
+#ifdef CBH_PROFILE_CYCLES
+  if (flags & CBH_F_DEBUG_CYCLES) {   // policy / scope words <- phase cycles, wall-clock (100 MHz) start / end, visit counts
+    const u64 cyc4 = __builtin_readcyclecounter();
+    pol[0] = (u32)(cyc1 - cyc0); pol[1] = (u32)(cyc2 - cyc1); pol[2] = (u32)(cyc3 - cyc2); pol[3] = (u32)(cyc4 - cyc3);
+    scp[0] = (u32)rt0; scp[1] = (u32)__builtin_amdgcn_s_memrealtime(); scp[2] = dbg_rows; scp[3] = dbg_rounds;
+  }
+#endif
   const bool packed = valid && act_cnt == 4 && (act_off & 3u) == 0;
   if (packed) {
-    struct __attribute__((aligned(16))) u32x4 { u32 x, y, z, w; };
-    if (o.edr) o.edr[req] = edr;
-    *(CBH_G u32*)(o.effect + act_off) = eff4;
-    if (o.status) *(CBH_G u32*)(o.status + act_off) = st4;
-    if (o.policy) { u32x4 v; v.x = pol[0]; v.y = pol[1]; v.z = pol[2]; v.w = pol[3]; *(CBH_G u32x4*)(o.policy + act_off) = v; }
-    if (o.scope) { u32x4 v; v.x = scp[0]; v.y = scp[1]; v.z = scp[2]; v.w = scp[3]; *(CBH_G u32x4*)(o.scope + act_off) = v; }
+#ifndef CBH_HOSTSIM
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+#else
+    struct u32x4 { u32 x, y, z, w; };
+#endif
+    if (o.edr) store_nt(o.edr + req, edr);
+    store_nt((CBH_G u32*)(o.effect + act_off), eff4);
+    if (o.status) store_nt((CBH_G u32*)(o.status + act_off), st4);
+    if (o.policy) { u32x4 v; v.x = pol[0]; v.y = pol[1]; v.z = pol[2]; v.w = pol[3]; store_nt((CBH_G u32x4*)(o.policy + act_off), v); }
+    if (o.scope) { u32x4 v; v.x = scp[0]; v.y = scp[1]; v.z = scp[2]; v.w = scp[3]; store_nt((CBH_G u32x4*)(o.scope + act_off), v); }
   } else if (valid) {
     if (o.edr) o.edr[req] = edr;
 #pragma unroll
@@ -444,6 +518,10 @@ __global__ CBH_FLAT_ATTRS(4) void cbh_check_flat_kernel_any(const KernelArgs a, 
 // dynamic LDS of one wave of the flat kernel: column cache + [max_depth][64] scope indices
 static inline size_t cbh_flat_chain_bytes(u32 table_max_depth) {
   return (size_t)(table_max_depth < CBH_FLAT_MAX_DEPTH ? table_max_depth : CBH_FLAT_MAX_DEPTH) * CBH_BLOCK * 4;
+}
+// ... and, once per workgroup, the two class tables (one byte per table string each) when they are staged in LDS
+static inline size_t cbh_flat_class_bytes(u32 table_strings) {
+  return table_strings <= CBH_FLAT_LDS_STRINGS ? (((size_t)2 * table_strings + 15) & ~(size_t)15) : 0;
 }
 static inline cbh_check_kernel_fn cbh_pick_kernel(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 max_actions, u32 max_roles, bool plain_tags,
                                                   u32 eval_flags, u32* threads, bool* flat) {
