@@ -48,6 +48,7 @@ __device__ __forceinline__ u64 wave_or64(u64 v, u32 wave, u32 lane) {
   return r;
 }
 
+#define CBH_FLAT_SIFT_MIN 12u         /* buckets with more records than this are sifted by class masks before any record is read */
 #define CBH_FLAT_LDS_STRINGS 4096u   /* class tables of at most this many table strings are staged in LDS (2 bytes each) */
 struct u32x4u { u32 x, y, z, w; };
 __device__ __forceinline__ u32x4u load_u32x4(const CBH_G u32* p) {   // one 16-byte load; `p` is dword aligned
@@ -73,12 +74,50 @@ __device__ __forceinline__ void store_nt(CBH_G T* p, T v) {
 // one record of CBH_SEC_DRX (cbh_blob.h CbhDrxField): a derived-role definition as the flat kernel reads it
 struct __attribute__((aligned(64))) TblDrx { u32 rm_lo, rm_hi, flags, cond, name, p0, p1, p2; LeafRec leaf; };
 
-// A cached attribute column for this lane: tag and the two value dwords (cbh_check_wave.h fill_column_cache).
+// The attribute columns of this lane's request.  Values: two dword planes [column][lane] in LDS, filled by asynchronous
+// global->LDS copies (cbh_check_wave.h fill_column_cache).  Tags: one byte each, packed four to a register - sixteen
+// columns in four VGPRs instead of a third LDS plane (LDS is what bounds this kernel's occupancy).
+struct FlatTags { u32 w0, w1, w2, w3; };   // (four members, not an array: an array indexed in a loop ends up in scratch memory)
+template <u32 N>
+__device__ __forceinline__ void flat_load_tags(FlatTags& tg, const BatchDev& b, u32 NR, u32 req) {   // columns 0 .. N-1, all loads in flight together
+  u32 t[N];
+#pragma unroll
+  for (u32 k = 0; k < N; ++k) t[k] = b.col_tag[(size_t)k * NR + req];
+  tg.w0 = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
+  if constexpr (N > 4) tg.w1 = t[4] | (t[5] << 8) | (t[6] << 16) | (t[7] << 24);
+  if constexpr (N > 8) tg.w2 = t[8] | (t[9] << 8) | (t[10] << 16) | (t[11] << 24);
+  if constexpr (N > 12) tg.w3 = t[12] | (t[13] << 8) | (t[14] << 16) | (t[15] << 24);
+}
+template <bool WITH_CALL>
+__device__ __forceinline__ void flat_fill_columns(const Ctx& c, FlatTags& tg, const BatchDev& b, u32 NR, u32 req) {
+  tg.w0 = tg.w1 = tg.w2 = tg.w3 = 0;
+  if (WITH_CALL) fill_column_cache(c, b, NR, req);   // the shared evaluator reads tags from the third LDS plane
+  else {
+    for (u32 k = 0; k < c.n_cached; ++k) {
+      const CBH_G u32* vsrc = (const CBH_G u32*)(b.col_val + ((size_t)k * NR + req));
+#ifndef CBH_HOSTSIM
+      __builtin_amdgcn_global_load_lds((const CBH_G void*)vsrc, (CBH_L void*)(c.cc + k * CBH_BLOCK), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((const CBH_G void*)(vsrc + 1), (CBH_L void*)(c.cc + (c.n_cached + k) * CBH_BLOCK), 4, 0, 0);
+#else
+      c.cc[k * CBH_BLOCK + c.tid] = vsrc[0];
+      c.cc[(c.n_cached + k) * CBH_BLOCK + c.tid] = vsrc[1];
+#endif
+    }
+  }
+  const u32 n = c.n_cached;   // wave-uniform: the arm that covers it, every load of it unconditional
+  if (n > 12) flat_load_tags<16>(tg, b, NR, req);
+  else if (n > 8) flat_load_tags<12>(tg, b, NR, req);
+  else if (n > 4) flat_load_tags<8>(tg, b, NR, req);
+  else if (n > 0) flat_load_tags<4>(tg, b, NR, req);
+}
 struct FlatCol { u32 t, lo, hi; };
-__device__ __forceinline__ FlatCol flat_col(const Ctx& c, u32 col, u32 req) {   // `col` wave-uniform
+__device__ __forceinline__ FlatCol flat_col(const Ctx& c, const FlatTags& tg, u32 col) {   // `col` wave-uniform, < n_cached
   FlatCol v;
-  const u32 tw = c.cc[(2 * c.n_cached + col) * CBH_BLOCK + c.tid];
-  v.t = (tw >> (((col * c.b.n_requests + req) & 3u) * 8u)) & 0xFFu;   // the lane's byte of the aligned tag dword
+  // (mask blends, not selects: the compiler turns a select between members into an indexed load of the struct, which
+  // then lives in scratch memory)
+  const u32 g = col >> 2;
+  const u32 w = (tg.w0 & (0u - (u32)(g == 0u))) | (tg.w1 & (0u - (u32)(g == 1u))) | (tg.w2 & (0u - (u32)(g == 2u))) | (tg.w3 & (0u - (u32)(g == 3u)));
+  v.t = (w >> ((col & 3u) * 8u)) & 0xFFu;
   v.lo = c.cc[col * CBH_BLOCK + c.tid];
   v.hi = c.cc[(c.n_cached + col) * CBH_BLOCK + c.tid];
   return v;
@@ -87,23 +126,23 @@ __device__ __forceinline__ FlatCol flat_col(const Ctx& c, u32 col, u32 req) {   
 // computes the answer, the error flag and the "needs the full evaluator" flag with compares and selects; which
 // class it is is a wave-uniform switch.  Same answers as leaf_fast (cbh_check_wave.h), which stays the reference
 // for the shapes not listed here.  Returns bit 0 = satisfied, bit 1 = CEL error (counts as not satisfied),
-// bit 2 = undecided here (mixed numeric types, containers): the caller hands that lane to eval_cond_rec.
-__device__ __forceinline__ u32 flat_leaf(const Ctx& c, const LeafRec& lr, u32 req, u32 pid) {
-  const u32 a = lr.w >> 8;
-  const u32 ka = (a >> 8) & 0xFu, op = a & 0xFFu;   // wave-uniform
+// bit 2 = undecided here (cross-type numerics, containers): needs the shared evaluator.
+// `cls` = the leaf class, `op` = OP_EQ .. OP_IN, `ca` / `cb` = the column(s), `k0 k1 k2` = the constant: (tag, value) of a
+// string / bool, the two halves of a double, or up to three string ids.  All wave-uniform.
+__device__ __forceinline__ u32 flat_leaf_core(const Ctx& c, const FlatTags& tg, u32 cls, u32 op, u32 ca, u32 cb, u32 k0, u32 k1, u32 k2, u32 pid) {
   const bool want_eq = op == OP_EQ;
-  switch (lr.pad) {
-    case 1: {   // column ==/!= string or bool constant
-      const FlatCol x = flat_col(c, lr.a0, req);
+  switch (cls) {
+    case 1: {   // column ==/!= string or bool constant (k0 = its tag, k1 = its value)
+      const FlatCol x = flat_col(c, tg, ca);
       const bool err = x.t >= CBH_T_ABSENT;   // ABSENT (0xF0) or ERR (0xFF)
-      const bool eq = x.t == lr.ctag && x.lo == lr.clo;   // other types are plainly unequal
+      const bool eq = x.t == k0 && x.lo == k1;   // other types are plainly unequal
       return err ? 2u : (u32)(eq == want_eq);
     }
-    case 2: {   // column <op> double constant
-      const FlatCol x = flat_col(c, lr.a0, req);
+    case 2: {   // column <op> double constant (k1, k2 = its halves)
+      const FlatCol x = flat_col(c, tg, ca);
       const bool err = x.t >= CBH_T_ABSENT;
       const bool dbl = x.t == CBH_T_DOUBLE, othernum = x.t == CBH_T_INT || x.t == CBH_T_UINT;
-      const double p = as_f64((u64)x.lo | ((u64)x.hi << 32)), q = as_f64((u64)lr.clo | ((u64)lr.chi << 32));
+      const double p = as_f64((u64)x.lo | ((u64)x.hi << 32)), q = as_f64((u64)k1 | ((u64)k2 << 32));
       const bool ordering = op != OP_EQ && op != OP_NE;
       const bool cmp = (op == OP_EQ) ? p == q : (op == OP_NE) ? p != q : (op == OP_LT) ? p < q : (op == OP_LE) ? p <= q
                      : (op == OP_GT) ? p > q : p >= q;   // NaN: every ordering false, != true
@@ -113,7 +152,7 @@ __device__ __forceinline__ u32 flat_leaf(const Ctx& c, const LeafRec& lr, u32 re
       return (err || overload) ? 2u : slow ? 4u : r;
     }
     case 3: {   // column ==/!= column
-      const FlatCol x = flat_col(c, lr.a0, req), y = flat_col(c, lr.a1, req);
+      const FlatCol x = flat_col(c, tg, ca), y = flat_col(c, tg, cb);
       const bool err = x.t >= CBH_T_ABSENT || y.t >= CBH_T_ABSENT;
       const bool same = x.t == y.t;
       const bool scalar = x.t < CBH_T_LIST || x.t == CBH_T_TIMESTAMP || x.t == CBH_T_DURATION;
@@ -124,36 +163,68 @@ __device__ __forceinline__ u32 flat_leaf(const Ctx& c, const LeafRec& lr, u32 re
       const bool slow = !err && ((same && !scalar) || (!same && xnum && ynum));   // containers / cross-type numeric equality
       return err ? 2u : slow ? 4u : (u32)(eq == want_eq);
     }
-    case 4: {   // column ==/!= P.id (either order)
-      const FlatCol x = flat_col(c, ka == 3 ? lr.a0 : lr.a1, req);
+    case 4: {   // column ==/!= P.id
+      const FlatCol x = flat_col(c, tg, ca);
       const bool err = x.t >= CBH_T_ABSENT;
       const bool eq = x.t == CBH_T_STRING && x.lo == pid;
       return err ? 2u : (u32)(eq == want_eq);
     }
-    case 6: {   // column in [at most three string constants]
-      const FlatCol x = flat_col(c, lr.a0, req);
+    case 6: {   // column in [at most three string constants] (k0 k1 k2 = their ids, CBH_NONE pads)
+      const FlatCol x = flat_col(c, tg, ca);
       const bool err = x.t >= CBH_T_ABSENT;
-      const bool found = x.t == CBH_T_STRING && (x.lo == lr.ctag || x.lo == lr.clo || x.lo == lr.chi);
+      const bool found = x.t == CBH_T_STRING && (x.lo == k0 || x.lo == k1 || x.lo == k2);
       return err ? 2u : (u32)found;
     }
     default: return 4u;
   }
 }
+// ... from the 8-dword fused-leaf record embedded in a rule record (celc.py _leaf_record)
+__device__ __forceinline__ u32 flat_leaf(const Ctx& c, const FlatTags& tg, const LeafRec& lr, u32 pid) {
+  const u32 a = lr.w >> 8;
+  const u32 ka = (a >> 8) & 0xFu, op = a & 0xFFu;
+  const u32 cls = lr.pad;
+  return flat_leaf_core(c, tg, cls, op, (cls == 4u && ka != 3u) ? lr.a1 : lr.a0, lr.a1, lr.ctag, lr.clo, lr.chi, pid);
+}
 
 // A condition tree of classified leaves (cbh_blob.h CBH_ROW_F_TREE_EMBEDDED; `desc` = the descriptor in the record's leaf
-// slot): the 4-bit ops in order, leaves from the strip, no tape reads and no divergent branch.  Same bookkeeping as
-// eval_leaf_tree (cbh_check_wave.h): a leaf behind the deciding one of its level is not evaluated by the reference
-// (check.go:697-749), so its error / "needs the full evaluator" flags do not count.  Returns flat_leaf's bits for the tree.
-__device__ __forceinline__ u32 flat_tree(const Ctx& c, const LeafRec& desc, u32 req, u32 pid) {
-  const u32 opw[4] = {desc.w, desc.a0, desc.ret, desc.ctag};   // wave-uniform
+// slot): the 4-bit ops in order, leaves from the strip - four dwords each {class | op << 4 | column a << 12 | column b << 20 |
+// constant tag << 28, k0, k1, k2}, fetched four leaves at a time with one 16-dword scalar load - no tape reads and no
+// divergent branch.  Same bookkeeping as eval_leaf_tree (cbh_check_wave.h): a leaf behind the deciding one of its level
+// is not evaluated by the reference (check.go:697-749), so its error / "needs the full evaluator" flags do not count.
+// Returns flat_leaf's bits for the tree.
+#ifndef CBH_HOSTSIM
+typedef u32 LeafQuad __attribute__((ext_vector_type(16)));   // (a vector, not a struct of an array: that one the compiler parks in scratch)
+__device__ __forceinline__ LeafQuad load_quad(const CBH_G u32* code, u32 idx) {
+  return *(const __attribute__((address_space(4))) LeafQuad*)uniform_addr((unsigned long long)(code + (size_t)idx * 16u));
+}
+#define QD(q, i) ((q)[i])
+#else
+struct LeafQuad { u32 d[16]; };
+static inline LeafQuad load_quad(const u32* code, u32 idx) { LeafQuad q; __builtin_memcpy(&q, code + (size_t)idx * 16u, 64); return q; }
+#define QD(q, i) ((q).d[i])
+#endif
+__device__ __forceinline__ u32 flat_tree(const Ctx& c, const FlatTags& tg, const LeafRec& desc, u32 pid) {
   bool live = true, last = false;
-  u32 saved = 0, acc = 0, depth = 0, leaf = desc.a1, err = 0, slow = 0;
+  u32 saved = 0, acc = 0, depth = 0, li = 0, err = 0, slow = 0;
+  LeafQuad q = load_quad(c.t.code, desc.a1);   // strips start on a 16-dword boundary; a1 = that boundary's index
   for (u32 k = 0; k < 32; ++k) {
-    const u32 op = (opw[k >> 3] >> (4u * (k & 7u))) & 15u;
+    const u32 g = k >> 3;   // wave-uniform; mask blends, see flat_col
+    const u32 opw = (desc.w & (0u - (u32)(g == 0u))) | (desc.a0 & (0u - (u32)(g == 1u))) | (desc.ret & (0u - (u32)(g == 2u))) | (desc.ctag & (0u - (u32)(g == 3u)));
+    const u32 op = (opw >> (4u * (k & 7u))) & 15u;
     if (op == 0) break;
     if (op == 1) {
-      const LeafRec lr = uload_rec<LeafRec>(c.t.code, leaf++);
-      const u32 lv = flat_leaf(c, lr, req, pid);
+      const u32 j = li & 3u;
+      if (j == 0 && li != 0) q = load_quad(c.t.code, desc.a1 + (li >> 2));
+      const u32 m0 = 0u - (u32)(j == 0u), m1 = 0u - (u32)(j == 1u), m2 = 0u - (u32)(j == 2u), m3 = 0u - (u32)(j == 3u);
+      const u32 h = (QD(q, 0) & m0) | (QD(q, 4) & m1) | (QD(q, 8) & m2) | (QD(q, 12) & m3);
+      const u32 k0 = (QD(q, 1) & m0) | (QD(q, 5) & m1) | (QD(q, 9) & m2) | (QD(q, 13) & m3);
+      const u32 k1 = (QD(q, 2) & m0) | (QD(q, 6) & m1) | (QD(q, 10) & m2) | (QD(q, 14) & m3);
+      const u32 k2 = (QD(q, 3) & m0) | (QD(q, 7) & m1) | (QD(q, 11) & m2) | (QD(q, 15) & m3);
+      ++li;
+      const u32 cls = h & 15u;
+      // classes 1 / 2 carry (value lo, value hi) in k0 k1 and the tag in the header; class 6 three ids
+      const u32 lv = cls == 6u ? flat_leaf_core(c, tg, cls, (h >> 4) & 0xFFu, (h >> 12) & 0xFFu, (h >> 20) & 0xFFu, k0, k1, k2, pid)
+                               : flat_leaf_core(c, tg, cls, (h >> 4) & 0xFFu, (h >> 12) & 0xFFu, (h >> 20) & 0xFFu, h >> 28, k0, k1, pid);
       last = live && (lv & 1u) != 0;
       err |= live ? (lv & 2u) : 0u;
       slow |= live ? (lv & 4u) : 0u;
@@ -211,12 +282,14 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   const u32 role_off = RQ(CBH_RQ_ROLE_OFF), act_off = RQ(CBH_RQ_ACT_OFF);
   const u32 role_cnt = valid ? RQ(CBH_RQ_ROLE_CNT) : 0, act_cnt = valid ? RQ(CBH_RQ_ACT_CNT) : 0;   // both <= 4 (host-checked)
 #undef RQ
-  fill_column_cache(c, b, NR, req);
+  FlatTags tg;
+  flat_fill_columns<WITH_CALL>(c, tg, b, NR, req);
   const u32 all = (1u << act_cnt) - 1u;
   // [depth][lane]: scope index at that depth of the lane's chain - in the dynamic LDS behind the column caches,
   // sized by the table's longest chain (a one-scope table pays 256 B per wave, not 4 KB: LDS sets the occupancy here)
   const u32 max_depth = t.max_depth < CBH_FLAT_MAX_DEPTH ? t.max_depth : CBH_FLAT_MAX_DEPTH;
-  CBH_L u32* chain_si = (CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * (3u * c.n_cached * CBH_BLOCK) + wave * (max_depth * CBH_BLOCK);
+  constexpr u32 PLANES = WITH_CALL ? 3u : 2u;   // column planes per wave: value low, value high (+ tag words for the shared evaluator)
+  CBH_L u32* chain_si = (CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * (PLANES * c.n_cached * CBH_BLOCK) + wave * (max_depth * CBH_BLOCK);
   // actions and roles -> classes (CBH_SEC_ACTION_CLASS / CBH_SEC_ROLE_CLASS; 63 = a string no rule names).
   // A flat table has fewer than 32 classes per dimension and its masks mirror "any other string" (bit 63)
   // in bit 31 of the low dword: the match is a 1-bit field extract from ONE dword at a per-lane position.
@@ -227,7 +300,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   // flight - a table of up to CBH_FLAT_LDS_STRINGS strings - so that the lookups below are LDS reads, not a third
   // dependent trip to memory.
   const bool cls_in_lds = t.K <= CBH_FLAT_LDS_STRINGS;
-  CBH_L u8* cls_lds = (CBH_L u8*)((CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * ((3u * c.n_cached + max_depth) * CBH_BLOCK));   // [action classes K][role classes K]
+  CBH_L u8* cls_lds = (CBH_L u8*)((CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * ((PLANES * c.n_cached + max_depth) * CBH_BLOCK));   // [action classes K][role classes K]
   if (cls_in_lds) {
     for (u32 i = threadIdx.x; i < t.K; i += CBH_FLAT_THREADS) { cls_lds[i] = t.action_class[i]; cls_lds[t.K + i] = t.role_class[i]; }
   }
@@ -289,8 +362,8 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   // flat_tree), 0 = neither; what the inline code leaves open goes through the shared evaluator.
   auto leafish = [&](u32 ref, u32 how, const LeafRec& lr, bool active) -> u32 {
     u32 lv = 4u;
-    if (how == 1u) lv = flat_leaf(c, lr, req, pid);
-    else if (how == 2u) lv = flat_tree(c, lr, req, pid);
+    if (how == 1u) lv = flat_leaf(c, tg, lr, pid);
+    else if (how == 2u) lv = flat_tree(c, tg, lr, pid);
     const bool slow = active && lv == 4u;
     if (WITH_CALL) {
       // The classified leaves leave open only what needs memory (container equality) or cross-type numerics.  The
@@ -336,40 +409,63 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
     if (go) {
       if (ing && mydepth < max_depth) chain_si[mydepth * CBH_BLOCK + c.tid] = g_si;
       const u32 S_before = S;
+      // one binding (check.go:295-414) for the lanes of this round
+      auto visit = [&](u32 row, const TblRowFull& rf) {
+        const TblRow& rw = rf.hot;
+        FLAT_DBG(++dbg_rows;)
+        if ((rw.rm_lo & wave_rc) == 0 || (rw.am_lo & wave_ac) == 0) return;   // no lane of the wave holds a class it names
+        const u32 mact = ((rw.am_lo >> ac[0]) & 1u) | (((rw.am_lo >> ac[1]) & 1u) << 1) | (((rw.am_lo >> ac[2]) & 1u) << 2) | (((rw.am_lo >> ac[3]) & 1u) << 3);
+        // one nibble per role (sign-extended 1-bit extracts), one bit per nibble for the actions; walks of other groups sit out
+        const u32 mrole = ((0u - ((rw.rm_lo >> rc[0]) & 1u)) & 0xFu) | ((0u - ((rw.rm_lo >> rc[1]) & 1u)) & 0xF0u) |
+                          ((0u - ((rw.rm_lo >> rc[2]) & 1u)) & 0xF00u) | ((0u - ((rw.rm_lo >> rc[3]) & 1u)) & 0xF000u);
+        const u32 m = ing ? (mrole & (mact * 0x1111u) & S) : 0u;
+        if (wave_ballot(m != 0) == 0) return;
+        // the walks this record's effect applies to: all matched ones unless a condition says no.  The derived-role
+        // condition comes first and the rule's own condition is evaluated only where that held (check.go:328-380);
+        // each once per record and request, whatever the roles (check.go:316-340)
+        u32 hit = m;
+        if (rw.drcond != CBH_NONE) {
+          const u32 how = (rw.flags & CBH_ROW_F_DRLEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_DRTREE_EMBEDDED) ? 2u : 0u;
+          const LeafRec l2 = uload_rec<LeafRec>(t.rowleaf2, row);
+          const u32 lv = leafish(rw.drcond, how, l2, hit != 0);
+          err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
+          hit = (lv & 1u) ? hit : 0u;
+        }
+        if (rw.cond != CBH_NONE && wave_ballot(hit != 0) != 0) {
+          const u32 how = (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_TREE_EMBEDDED) ? 2u : 0u;
+          const u32 lv = leafish(rw.cond, how, rf.leaf, hit != 0);
+          err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
+          hit = (lv & 1u) ? hit : 0u;
+        }
+        if ((rw.flags & 3u) == CBH_EFFECT_ALLOW) has_allow |= hit;
+        else if ((rw.flags & 3u) == CBH_EFFECT_DENY) { deny |= hit; S &= ~hit; }   // ends these walks (check.go:392-403)
+      };
       if (have_bucket && bucket.y) {
-        const u32 last = bucket.x + bucket.y - 1u;
-        TblRowFull nxt = uload_rec<TblRowFull>(t.rows, bucket.x);
-        for (u32 row = bucket.x; row <= last; ++row) {   // bindings in order (check.go:295-414)
-          const TblRowFull rf = nxt;   // hot half + leaf slot: one scalar load, issued one record ahead
-          nxt = uload_rec<TblRowFull>(t.rows, row < last ? row + 1u : last);
-          const TblRow& rw = rf.hot;
-          FLAT_DBG(++dbg_rows;)
-          if ((rw.rm_lo & wave_rc) == 0 || (rw.am_lo & wave_ac) == 0) continue;
-          const u32 mact = ((rw.am_lo >> ac[0]) & 1u) | (((rw.am_lo >> ac[1]) & 1u) << 1) | (((rw.am_lo >> ac[2]) & 1u) << 2) | (((rw.am_lo >> ac[3]) & 1u) << 3);
-          // one nibble per role (sign-extended 1-bit extracts), one bit per nibble for the actions; walks of other groups sit out
-          const u32 mrole = ((0u - ((rw.rm_lo >> rc[0]) & 1u)) & 0xFu) | ((0u - ((rw.rm_lo >> rc[1]) & 1u)) & 0xF0u) |
-                            ((0u - ((rw.rm_lo >> rc[2]) & 1u)) & 0xF00u) | ((0u - ((rw.rm_lo >> rc[3]) & 1u)) & 0xF000u);
-          const u32 m = ing ? (mrole & (mact * 0x1111u) & S) : 0u;
-          if (wave_ballot(m != 0) == 0) continue;
-          // the walks this record's effect applies to: all matched ones unless a condition says no.  The derived-role
-          // condition comes first and the rule's own condition is evaluated only where that held (check.go:328-380);
-          // each once per record and request, whatever the roles (check.go:316-340)
-          u32 hit = m;
-          if (rw.drcond != CBH_NONE) {
-            const u32 how = (rw.flags & CBH_ROW_F_DRLEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_DRTREE_EMBEDDED) ? 2u : 0u;
-            const LeafRec l2 = uload_rec<LeafRec>(t.rowleaf2, row);
-            const u32 lv = leafish(rw.drcond, how, l2, hit != 0);
-            err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
-            hit = (lv & 1u) ? hit : 0u;
+        // Bindings in order, 64 at a time.  A large bucket is first sifted by the (role classes, action classes) pairs of
+        // its records (CBH_SEC_ROWMASK: lane j tests record j against the classes present in the wave, one 8-byte load
+        // per lane) so that only records some lane can match are fetched at all; a small one is read record by record.
+        // Either way the next record to be visited is loaded while the current one is processed.
+        const u32 end = bucket.x + bucket.y;
+        const bool sift = bucket.y > CBH_FLAT_SIFT_MIN;
+        for (u32 base = bucket.x; base < end; base += 64u) {
+          const u32 n_here = end - base < 64u ? end - base : 64u;
+          u64 vis = n_here == 64u ? ~0ull : ((1ull << n_here) - 1ull);
+          if (sift) {
+            const u32 mine = base + (c.tid < n_here ? c.tid : 0u);
+            const u32 rm = t.rowmask[2u * (size_t)mine], am = t.rowmask[2u * (size_t)mine + 1u];
+            vis = wave_ballot(c.tid < n_here && (rm & wave_rc) != 0 && (am & wave_ac) != 0);
           }
-          if (rw.cond != CBH_NONE && wave_ballot(hit != 0) != 0) {
-            const u32 how = (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_TREE_EMBEDDED) ? 2u : 0u;
-            const u32 lv = leafish(rw.cond, how, rf.leaf, hit != 0);
-            err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
-            hit = (lv & 1u) ? hit : 0u;
+          if (vis == 0) continue;
+          u32 j = (u32)__builtin_ctzll(vis); vis &= vis - 1ull;
+          TblRowFull nxt = uload_rec<TblRowFull>(t.rows, base + j);   // hot half + leaf slot: one scalar load
+          for (;;) {
+            const TblRowFull rf = nxt;
+            const u32 row = base + j;
+            const bool more = vis != 0;
+            if (more) { j = (u32)__builtin_ctzll(vis); vis &= vis - 1ull; nxt = uload_rec<TblRowFull>(t.rows, base + j); }
+            visit(row, rf);
+            if (!more) break;
           }
-          if ((rw.flags & 3u) == CBH_EFFECT_ALLOW) has_allow |= hit;
-          else if ((rw.flags & 3u) == CBH_EFFECT_DENY) { deny |= hit; S &= ~hit; }   // ends these walks (check.go:392-403)
         }
       }
       const u32 ha = ing ? (has_allow & S) : 0u;   // check.go:416-425
@@ -494,19 +590,19 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 #else
 #define CBH_FLAT_ATTRS(MINW)
 #endif
-// each wave of the group owns its slice of the column cache: [3 planes][ncc][64 lanes] dwords
-#define CBH_FLAT_CTX(a, ka)                                                                                                       \
+// each wave of the group owns its slice of the column cache: [planes][ncc][64 lanes] dwords
+#define CBH_FLAT_CTX(a, ka, PLANES)                                                                                               \
   const u32 ncc = cached_columns(&a);                                                                                             \
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,  \
-        (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * (3u * ncc * CBH_BLOCK), ncc, ka}
+        (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * ((PLANES) * ncc * CBH_BLOCK), ncc, ka}
 // batches of plain scalars (no int / uint / list / map attribute values): no call, ~64 VGPRs, 7-8 waves per SIMD
 __global__ CBH_FLAT_ATTRS(7) void cbh_check_flat_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
-  CBH_FLAT_CTX(a, ka);
+  CBH_FLAT_CTX(a, ka, 2u);
   flat_body<false>(a, c);
 }
 // any batch: the same walk with the call into the shared evaluator compiled in (4 waves per SIMD)
 __global__ CBH_FLAT_ATTRS(4) void cbh_check_flat_kernel_any(const KernelArgs a, const KernelArgs* __restrict__ ka) {
-  CBH_FLAT_CTX(a, ka);
+  CBH_FLAT_CTX(a, ka, 3u);
   flat_body<true>(a, c);
 }
 
@@ -524,11 +620,14 @@ static inline size_t cbh_flat_class_bytes(u32 table_strings) {
   return table_strings <= CBH_FLAT_LDS_STRINGS ? (((size_t)2 * table_strings + 15) & ~(size_t)15) : 0;
 }
 static inline cbh_check_kernel_fn cbh_pick_kernel(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 max_actions, u32 max_roles, bool plain_tags,
-                                                  u32 eval_flags, u32* threads, bool* flat) {
+                                                  u32 eval_flags, u32* threads, bool* flat, u32* col_planes) {
+  *col_planes = 3;
   *flat = (table_flags & CBH_MF_FLAT) && max_actions <= 4 && max_roles <= 4 && !(eval_flags & CBH_F_STRICT_EVALUATION);
   if (*flat) {
     *threads = CBH_FLAT_THREADS;
-    return (plain_tags && (table_flags & CBH_MF_FLAT_CLOSED)) ? cbh_check_flat_kernel : cbh_check_flat_kernel_any;
+    const bool nocall = plain_tags && (table_flags & CBH_MF_FLAT_CLOSED);
+    *col_planes = nocall ? 2 : 3;
+    return nocall ? cbh_check_flat_kernel : cbh_check_flat_kernel_any;
   }
   *threads = CBH_BLOCK;
   return cbh_pick_check_kernel(table_flags, n_derived_roles, has_globs, max_actions);

@@ -52,7 +52,7 @@ def _cond(rng, pool=None):
 DRS = ["owner", "peer", "senior", "anyone"]
 
 
-def _store(rng, pool=None):
+def _store(rng, pool=None, many_rules=False):
     docs = []
     with_dr = rng.random() < 0.6
     if with_dr:   # derived roles: definitions with and without conditions, `*` parents, conditions that can raise errors
@@ -68,7 +68,7 @@ def _store(rng, pool=None):
             if scope and rng.random() < 0.2:
                 continue
             rules = []
-            for _ in range(int(rng.integers(1, 7))):
+            for _ in range(int(rng.integers(14, 80)) if many_rules else int(rng.integers(1, 7))):
                 rule = {"actions": [str(a) for a in rng.choice(ACTIONS + ["*"], size=int(rng.integers(1, 6)), replace=False)],
                         "effect": "EFFECT_ALLOW" if rng.random() < 0.7 else "EFFECT_DENY"}
                 if with_dr and rng.random() < 0.4:
@@ -117,9 +117,9 @@ def _requests(rng, n, with_lists=False):
     return out
 
 
-def _run_seed(seed, make_evaluator, close, with_lists=False):
+def _run_seed(seed, make_evaluator, close, with_lists=False, many_rules=False):
     rng = np.random.default_rng(40_000 + seed)
-    rt = rule_table_from_policies(policies_from_docs(_store(rng, CONDS + CONDS_ANY if with_lists else None)))
+    rt = rule_table_from_policies(policies_from_docs(_store(rng, CONDS + CONDS_ANY if with_lists else None, many_rules)))
     lt = lower_rule_table(rt)
     assert lt.stats["flat"] and lt.stats["flat_closed"], "the generator must produce flat tables whose conditions are all inline"
     inputs = _requests(rng, 200, with_lists)
@@ -166,6 +166,13 @@ def test_flat_kernel_with_evaluator_call_vs_oracle(seed):
     _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False, with_lists=True)
 
 
+@pytest.mark.parametrize("seed", range(200, 212))
+def test_flat_kernel_large_buckets_vs_oracle(seed):
+    """Policies of 14-80 rules: buckets above CBH_FLAT_SIFT_MIN are sifted by class masks, 64 records at a time."""
+    from test_hostsim_golden import HostSimEvaluator
+    _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False, many_rules=True)
+
+
 def test_plain_batches_through_the_variant_with_the_call(monkeypatch):
     """CBH_FLAT_ANY=1 sends plain batches through the variant with the call too: both variants decide them alike."""
     from test_hostsim_golden import HostSimEvaluator
@@ -183,6 +190,12 @@ def test_error_cases_do_occur():
 @pytest.mark.parametrize("seed", range(40))
 def test_flat_kernel_on_gpu(seed):
     _run_seed(seed, lambda lt: HipEvaluator(lt, Conf()), True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(200, 212))
+def test_flat_kernel_large_buckets_on_gpu(seed):
+    _run_seed(seed, lambda lt: HipEvaluator(lt, Conf()), True, many_rules=True)
 
 
 @pytest.mark.gpu
