@@ -48,7 +48,14 @@ __device__ __forceinline__ u64 wave_or64(u64 v, u32 wave, u32 lane) {
   return r;
 }
 
+#ifdef CBH_FLAT_NO_NT
+#define CBH_FLAT_DMA_AUX 0
+#else
+#define CBH_FLAT_DMA_AUX 2   /* nt */
+#endif
+#ifndef CBH_FLAT_SIFT_MIN
 #define CBH_FLAT_SIFT_MIN 12u         /* buckets with more records than this are sifted by class masks before any record is read */
+#endif
 #define CBH_FLAT_LDS_STRINGS 4096u   /* class tables of at most this many table strings are staged in LDS (2 bytes each) */
 struct u32x4u { u32 x, y, z, w; };
 __device__ __forceinline__ u32x4u load_u32x4(const CBH_G u32* p) {   // one 16-byte load; `p` is dword aligned
@@ -60,6 +67,38 @@ __device__ __forceinline__ u32x4u load_u32x4(const CBH_G u32* p) {   // one 16-b
   return u32x4u{p[0], p[1], p[2], p[3]};
 #endif
 }
+// A rule record fetched by vector loads at a wave-uniform address, and its move into scalar registers.
+#if !defined(CBH_HOSTSIM) && defined(CBH_FLAT_SCALAR_RECS)
+struct VRec { TblRowFull r; };
+__device__ __forceinline__ VRec vload_rec(const CBH_G u32* rows, u32 idx) { VRec v; v.r = uload_rec<TblRowFull>(rows, idx); return v; }
+__device__ __forceinline__ TblRowFull rec_uniform(const VRec& v) { return v.r; }
+__device__ __forceinline__ void flat_keep(u32 v) { asm volatile("" ::"v"(v)); }
+#elif !defined(CBH_HOSTSIM)
+typedef u32 u32v4 __attribute__((ext_vector_type(4)));
+struct VRec { u32v4 a, b, c, d; };
+__device__ __forceinline__ VRec vload_rec(const CBH_G u32* rows, u32 idx) {
+  const CBH_G u32v4* p = (const CBH_G u32v4*)(rows + (size_t)idx * 16u);
+  VRec r; r.a = p[0]; r.b = p[1]; r.c = p[2]; r.d = p[3];
+  return r;
+}
+#define RFL(x) ((u32)__builtin_amdgcn_readfirstlane((int)(x)))
+__device__ __forceinline__ TblRowFull rec_uniform(const VRec& v) {
+  TblRowFull r;
+  r.hot.flags = RFL(v.a.x); r.hot.cond = RFL(v.a.y); r.hot.drcond = RFL(v.a.z); r.hot.policy = RFL(v.a.w);
+  r.hot.rm_lo = RFL(v.b.x); r.hot.rm_hi = RFL(v.b.y); r.hot.am_lo = RFL(v.b.z); r.hot.am_hi = RFL(v.b.w);
+  r.leaf.w = RFL(v.c.x); r.leaf.a0 = RFL(v.c.y); r.leaf.a1 = RFL(v.c.z); r.leaf.ret = RFL(v.c.w);
+  r.leaf.ctag = RFL(v.d.x); r.leaf.clo = RFL(v.d.y); r.leaf.chi = RFL(v.d.z); r.leaf.pad = RFL(v.d.w);
+  return r;
+}
+#undef RFL
+// a value loaded only for the load's side effect (a cache line on its way): keep the load, wait for it here
+__device__ __forceinline__ void flat_keep(u32 v) { asm volatile("" ::"v"(v)); }
+#else
+struct VRec { TblRowFull r; };
+static inline VRec vload_rec(const u32* rows, u32 idx) { VRec v; __builtin_memcpy(&v.r, rows + (size_t)idx * 16u, 64); return v; }
+static inline TblRowFull rec_uniform(const VRec& v) { return v.r; }
+static inline void flat_keep(u32) {}
+#endif
 // stores of results nobody in this kernel reads again: written through, so that the end of the kernel does not have to
 // flush them out of the L2 (the dirty lines of a 1M-tuple batch are 12 MB)
 template <typename T>
@@ -74,50 +113,88 @@ __device__ __forceinline__ void store_nt(CBH_G T* p, T v) {
 // one record of CBH_SEC_DRX (cbh_blob.h CbhDrxField): a derived-role definition as the flat kernel reads it
 struct __attribute__((aligned(64))) TblDrx { u32 rm_lo, rm_hi, flags, cond, name, p0, p1, p2; LeafRec leaf; };
 
-// The attribute columns of this lane's request.  Values: two dword planes [column][lane] in LDS, filled by asynchronous
-// global->LDS copies (cbh_check_wave.h fill_column_cache).  Tags: one byte each, packed four to a register - sixteen
-// columns in four VGPRs instead of a third LDS plane (LDS is what bounds this kernel's occupancy).
-struct FlatTags { u32 w0, w1, w2, w3; };   // (four members, not an array: an array indexed in a loop ends up in scratch memory)
+// Dynamic LDS of the flat kernels, in dwords.  Per wave: the value planes [2][ncc][64] (low / high dword of every
+// cached column; filled by asynchronous global->LDS copies), for the variant with the evaluator call the tag-word plane
+// [ncc][64] the shared evaluator reads (cbh_check_wave.h fill_column_cache), the packed tags [ceil(ncc / 4)][64] (one byte
+// per column, four columns to a dword: a tag is one ds_read_u8), the scope-chain scratch [max_depth][64].  Behind the
+// waves' regions, once per workgroup: the two class tables.  Host and kernel size it with this one function.
+struct FlatLds { u32 tagw_off, tags_off, chain_off, wave_dwords, class_bytes; };
+static __host__ __device__ __forceinline__ FlatLds cbh_flat_lds(u32 ncc, u32 table_max_depth, u32 table_strings, bool with_call) {
+  FlatLds l;
+  const u32 depth = table_max_depth < CBH_FLAT_MAX_DEPTH ? table_max_depth : CBH_FLAT_MAX_DEPTH;
+  l.tagw_off = 2u * ncc * CBH_BLOCK;
+#ifdef CBH_FLAT_TAGW   /* lab variant: tags read from the tag-word plane in both kernels */
+  with_call = true;
+#endif
+  l.tags_off = l.tagw_off + (with_call ? ncc * CBH_BLOCK : 0u);
+  l.chain_off = l.tags_off + ((ncc + 3u) / 4u) * CBH_BLOCK;
+  l.wave_dwords = l.chain_off + depth * CBH_BLOCK;
+  l.class_bytes = table_strings <= CBH_FLAT_LDS_STRINGS ? ((2u * table_strings + 15u) & ~15u) : 0u;
+  return l;
+}
+static inline size_t cbh_flat_lds_bytes(u32 ncc, u32 table_max_depth, u32 table_strings, bool with_call, u32 waves) {
+  const FlatLds l = cbh_flat_lds(ncc, table_max_depth, table_strings, with_call);
+  return (size_t)l.wave_dwords * 4u * waves + l.class_bytes;
+}
+
+// Request data is read once: loaded past the caches' retention (nt) so that it does not push the table out of the L2.
+template <typename T>
+__device__ __forceinline__ T load_nt(const CBH_G T* p) {
+#if !defined(CBH_HOSTSIM) && !defined(CBH_FLAT_NO_NT)
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+
+// The attribute columns of this lane's request: values by asynchronous global->LDS copies, tags as bytes packed four
+// columns to a dword (`tags` = this wave's packed-tag planes).
 template <u32 N>
-__device__ __forceinline__ void flat_load_tags(FlatTags& tg, const BatchDev& b, u32 NR, u32 req) {   // columns 0 .. N-1, all loads in flight together
+__device__ __forceinline__ void flat_load_tags(CBH_L u32* tags, u32 tid, u32 n, const BatchDev& b, u32 NR, u32 req) {   // columns 0 .. N-1, all loads in flight together
   u32 t[N];
 #pragma unroll
-  for (u32 k = 0; k < N; ++k) t[k] = b.col_tag[(size_t)k * NR + req];
-  tg.w0 = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
-  if constexpr (N > 4) tg.w1 = t[4] | (t[5] << 8) | (t[6] << 16) | (t[7] << 24);
-  if constexpr (N > 8) tg.w2 = t[8] | (t[9] << 8) | (t[10] << 16) | (t[11] << 24);
-  if constexpr (N > 12) tg.w3 = t[12] | (t[13] << 8) | (t[14] << 16) | (t[15] << 24);
+  for (u32 k = 0; k < N; ++k) t[k] = load_nt(b.col_tag + ((size_t)(k < n ? k : 0u) * NR + req));   // (N rounds n up to a multiple of four: the spare slots re-read column 0)
+#pragma unroll
+  for (u32 g = 0; g < N / 4; ++g) tags[g * CBH_BLOCK + tid] = t[4 * g] | (t[4 * g + 1] << 8) | (t[4 * g + 2] << 16) | (t[4 * g + 3] << 24);
 }
 template <bool WITH_CALL>
-__device__ __forceinline__ void flat_fill_columns(const Ctx& c, FlatTags& tg, const BatchDev& b, u32 NR, u32 req) {
-  tg.w0 = tg.w1 = tg.w2 = tg.w3 = 0;
-  if (WITH_CALL) fill_column_cache(c, b, NR, req);   // the shared evaluator reads tags from the third LDS plane
-  else {
-    for (u32 k = 0; k < c.n_cached; ++k) {
-      const CBH_G u32* vsrc = (const CBH_G u32*)(b.col_val + ((size_t)k * NR + req));
+__device__ __forceinline__ void flat_fill_columns(const Ctx& c, CBH_L u32* tags, const BatchDev& b, u32 NR, u32 req) {
+  for (u32 k = 0; k < c.n_cached; ++k) {
+    const size_t ix = (size_t)k * NR + req;
+    const CBH_G u32* vsrc = (const CBH_G u32*)(b.col_val + ix);
 #ifndef CBH_HOSTSIM
-      __builtin_amdgcn_global_load_lds((const CBH_G void*)vsrc, (CBH_L void*)(c.cc + k * CBH_BLOCK), 4, 0, 0);
-      __builtin_amdgcn_global_load_lds((const CBH_G void*)(vsrc + 1), (CBH_L void*)(c.cc + (c.n_cached + k) * CBH_BLOCK), 4, 0, 0);
+    __builtin_amdgcn_global_load_lds((const CBH_G void*)vsrc, (CBH_L void*)(c.cc + k * CBH_BLOCK), 4, 0, CBH_FLAT_DMA_AUX);
+    __builtin_amdgcn_global_load_lds((const CBH_G void*)(vsrc + 1), (CBH_L void*)(c.cc + (c.n_cached + k) * CBH_BLOCK), 4, 0, CBH_FLAT_DMA_AUX);
+#ifdef CBH_FLAT_TAGW
+    if (true)
 #else
-      c.cc[k * CBH_BLOCK + c.tid] = vsrc[0];
-      c.cc[(c.n_cached + k) * CBH_BLOCK + c.tid] = vsrc[1];
+    if (WITH_CALL)   // the shared evaluator's tag-word plane: the aligned dword holding this lane's tag byte
 #endif
-    }
+      __builtin_amdgcn_global_load_lds((const CBH_G void*)(b.col_tag + (ix & ~(size_t)3)), (CBH_L void*)(c.cc + (2 * c.n_cached + k) * CBH_BLOCK), 4, 0, CBH_FLAT_DMA_AUX);
+#else
+    c.cc[k * CBH_BLOCK + c.tid] = vsrc[0];
+    c.cc[(c.n_cached + k) * CBH_BLOCK + c.tid] = vsrc[1];
+    if (WITH_CALL) c.cc[(2 * c.n_cached + k) * CBH_BLOCK + c.tid] = (u32)b.col_tag[ix] << ((ix & 3u) * 8u);
+#endif
   }
+#ifdef CBH_FLAT_TAGW
+  return;
+#endif
   const u32 n = c.n_cached;   // wave-uniform: the arm that covers it, every load of it unconditional
-  if (n > 12) flat_load_tags<16>(tg, b, NR, req);
-  else if (n > 8) flat_load_tags<12>(tg, b, NR, req);
-  else if (n > 4) flat_load_tags<8>(tg, b, NR, req);
-  else if (n > 0) flat_load_tags<4>(tg, b, NR, req);
+  if (n > 12) flat_load_tags<16>(tags, c.tid, n, b, NR, req);
+  else if (n > 8) flat_load_tags<12>(tags, c.tid, n, b, NR, req);
+  else if (n > 4) flat_load_tags<8>(tags, c.tid, n, b, NR, req);
+  else if (n > 0) flat_load_tags<4>(tags, c.tid, n, b, NR, req);
 }
 struct FlatCol { u32 t, lo, hi; };
+struct FlatTags { const CBH_L u8* bytes; const CBH_L u32* tagw; u32 NR, req; };   // this lane's packed tag bytes: column k at bytes[(k / 4) * 256 + k % 4]
 __device__ __forceinline__ FlatCol flat_col(const Ctx& c, const FlatTags& tg, u32 col) {   // `col` wave-uniform, < n_cached
   FlatCol v;
-  // (mask blends, not selects: the compiler turns a select between members into an indexed load of the struct, which
-  // then lives in scratch memory)
-  const u32 g = col >> 2;
-  const u32 w = (tg.w0 & (0u - (u32)(g == 0u))) | (tg.w1 & (0u - (u32)(g == 1u))) | (tg.w2 & (0u - (u32)(g == 2u))) | (tg.w3 & (0u - (u32)(g == 3u)));
-  v.t = (w >> ((col & 3u) * 8u)) & 0xFFu;
+#ifdef CBH_FLAT_TAGW
+  v.t = (tg.tagw[col * CBH_BLOCK] >> (((col * tg.NR + tg.req) & 3u) * 8u)) & 0xFFu;
+#else
+  v.t = tg.bytes[(col >> 2) * (CBH_BLOCK * 4u) + (col & 3u)];
+#endif
   v.lo = c.cc[col * CBH_BLOCK + c.tid];
   v.hi = c.cc[(c.n_cached + col) * CBH_BLOCK + c.tid];
   return v;
@@ -268,28 +345,34 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 #ifdef CBH_PROFILE_CYCLES   // profiling build only (tools/gpu_cycles_flat.py)
   const u64 cyc0 = __builtin_readcyclecounter();
   const u64 rt0 = __builtin_amdgcn_s_memrealtime();
-  u32 dbg_rows = 0, dbg_rounds = 0;
+  u32 dbg_rows = 0, dbg_rounds = 0, dbg_match = 0;
+  u64 dbg_dir = 0, dbg_sift = 0, dbg_visit = 0, dbg_cond = 0, dbg_t = 0;
+#define FLAT_T0() dbg_t = __builtin_readcyclecounter()
+#define FLAT_ACC(acc) acc += __builtin_readcyclecounter() - dbg_t
 #define FLAT_DBG(x) x
 #else
 #define FLAT_DBG(x)
+#define FLAT_T0()
+#define FLAT_ACC(acc)
 #endif
   const u32 rix = b.req_lo + blockIdx.x * CBH_FLAT_THREADS + threadIdx.x;
   const bool valid = rix < b.req_hi;
   const u32 req = valid ? rix : b.req_lo;
   const u32 NR = b.n_requests;
-#define RQ(f) b.req_u32[(size_t)(f) * NR + req]
+#define RQ(f) load_nt(b.req_u32 + ((size_t)(f) * NR + req))
   const u32 pid = RQ(CBH_RQ_PRINCIPAL_ID), kind = RQ(CBH_RQ_KIND), r_scope = RQ(CBH_RQ_R_SCOPE), r_ver = RQ(CBH_RQ_R_VERSION);
   const u32 role_off = RQ(CBH_RQ_ROLE_OFF), act_off = RQ(CBH_RQ_ACT_OFF);
   const u32 role_cnt = valid ? RQ(CBH_RQ_ROLE_CNT) : 0, act_cnt = valid ? RQ(CBH_RQ_ACT_CNT) : 0;   // both <= 4 (host-checked)
 #undef RQ
-  FlatTags tg;
-  flat_fill_columns<WITH_CALL>(c, tg, b, NR, req);
+  const FlatLds lds = cbh_flat_lds(c.n_cached, t.max_depth, t.K, WITH_CALL);
+  CBH_L u32* tag_planes = c.cc + lds.tags_off;   // (c.cc = this wave's region)
+  flat_fill_columns<WITH_CALL>(c, tag_planes, b, NR, req);
+  FlatTags tg; tg.bytes = (const CBH_L u8*)(tag_planes + c.tid); tg.tagw = c.cc + lds.tagw_off + c.tid; tg.NR = NR; tg.req = req;
   const u32 all = (1u << act_cnt) - 1u;
   // [depth][lane]: scope index at that depth of the lane's chain - in the dynamic LDS behind the column caches,
   // sized by the table's longest chain (a one-scope table pays 256 B per wave, not 4 KB: LDS sets the occupancy here)
   const u32 max_depth = t.max_depth < CBH_FLAT_MAX_DEPTH ? t.max_depth : CBH_FLAT_MAX_DEPTH;
-  constexpr u32 PLANES = WITH_CALL ? 3u : 2u;   // column planes per wave: value low, value high (+ tag words for the shared evaluator)
-  CBH_L u32* chain_si = (CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * (PLANES * c.n_cached * CBH_BLOCK) + wave * (max_depth * CBH_BLOCK);
+  CBH_L u32* chain_si = c.cc + lds.chain_off;
   // actions and roles -> classes (CBH_SEC_ACTION_CLASS / CBH_SEC_ROLE_CLASS; 63 = a string no rule names).
   // A flat table has fewer than 32 classes per dimension and its masks mirror "any other string" (bit 63)
   // in bit 31 of the low dword: the match is a 1-bit field extract from ONE dword at a per-lane position.
@@ -300,7 +383,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   // flight - a table of up to CBH_FLAT_LDS_STRINGS strings - so that the lookups below are LDS reads, not a third
   // dependent trip to memory.
   const bool cls_in_lds = t.K <= CBH_FLAT_LDS_STRINGS;
-  CBH_L u8* cls_lds = (CBH_L u8*)((CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * ((PLANES * c.n_cached + max_depth) * CBH_BLOCK));   // [action classes K][role classes K]
+  CBH_L u8* cls_lds = (CBH_L u8*)((CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * lds.wave_dwords);   // [action classes K][role classes K]
   if (cls_in_lds) {
     for (u32 i = threadIdx.x; i < t.K; i += CBH_FLAT_THREADS) { cls_lds[i] = t.action_class[i]; cls_lds[t.K + i] = t.role_class[i]; }
   }
@@ -312,7 +395,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   u32x4u sp; sp.x = sp.y = sp.z = sp.w = 0;
   if (spec) sp = load_u32x4(b.tuple_action + spec_ix);
 #pragma unroll
-  for (u32 k = 0; k < 4; ++k) rid[k] = b.roles[k < role_cnt ? role_off + k : 0u];
+  for (u32 k = 0; k < 4; ++k) rid[k] = load_nt(b.roles + (k < role_cnt ? role_off + k : 0u));
   const bool spec_hit = spec && act_cnt == 4u && act_off == spec_ix;
   aid[0] = sp.x; aid[1] = sp.y; aid[2] = sp.z; aid[3] = sp.w;
   if (!spec_hit) {
@@ -404,7 +487,9 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
     const bool go = wave_ballot(ing && S != 0) != 0;
     FLAT_DBG(++dbg_rounds;)
     uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
+    FLAT_T0();
     const bool have_bucket = udir_find(t, CBH_B_RESOURCE, g_ver, g_k, g_si, bucket);   // present for every resource policy (index.go:966-997)
+    FLAT_DBG(if (have_bucket) { dbg_dir += (__builtin_readcyclecounter() - dbg_t) * (u64)(bucket.y != 0xFFFFFFFFu); })
     exists = exists || (ing && have_bucket);
     if (go) {
       if (ing && mydepth < max_depth) chain_si[mydepth * CBH_BLOCK + c.tid] = g_si;
@@ -420,6 +505,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
                           ((0u - ((rw.rm_lo >> rc[2]) & 1u)) & 0xF00u) | ((0u - ((rw.rm_lo >> rc[3]) & 1u)) & 0xF000u);
         const u32 m = ing ? (mrole & (mact * 0x1111u) & S) : 0u;
         if (wave_ballot(m != 0) == 0) return;
+        FLAT_DBG(++dbg_match; const u64 c0 = __builtin_readcyclecounter();)
         // the walks this record's effect applies to: all matched ones unless a condition says no.  The derived-role
         // condition comes first and the rule's own condition is evaluated only where that held (check.go:328-380);
         // each once per record and request, whatever the roles (check.go:316-340)
@@ -437,34 +523,61 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
           err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
           hit = (lv & 1u) ? hit : 0u;
         }
+        FLAT_DBG(dbg_cond += (__builtin_readcyclecounter() - c0) * (u64)(hit != 0xFFFFFFFFu || true);)
         if ((rw.flags & 3u) == CBH_EFFECT_ALLOW) has_allow |= hit;
         else if ((rw.flags & 3u) == CBH_EFFECT_DENY) { deny |= hit; S &= ~hit; }   // ends these walks (check.go:392-403)
       };
       if (have_bucket && bucket.y) {
-        // Bindings in order, 64 at a time.  A large bucket is first sifted by the (role classes, action classes) pairs of
-        // its records (CBH_SEC_ROWMASK: lane j tests record j against the classes present in the wave, one 8-byte load
-        // per lane) so that only records some lane can match are fetched at all; a small one is read record by record.
-        // Either way the next record to be visited is loaded while the current one is processed.
+        // Bindings in order.  A large bucket is taken 64 records at a time and first sifted by the (role classes, action
+        // classes) pairs of its records (CBH_SEC_ROWMASK: lane j tests record j against the classes present in the
+        // wave, one 8-byte load per lane) so that only records some lane can match are fetched at all; a small one is
+        // read record by record.  Either way the next record to be visited is loaded while the current one is processed.
+        // Records travel through VECTOR loads at a wave-uniform address (every lane gets the same 64 bytes) and are moved to
+        // scalar registers when their turn comes: vector loads return in order, so two records stay in flight while a
+        // third is processed and nothing else waits for them.  (Scalar loads share their counter with the LDS, and return
+        // out of order: a record prefetched that way is waited for in full by the first LDS read of a condition.)
         const u32 end = bucket.x + bucket.y;
-        const bool sift = bucket.y > CBH_FLAT_SIFT_MIN;
-        for (u32 base = bucket.x; base < end; base += 64u) {
-          const u32 n_here = end - base < 64u ? end - base : 64u;
-          u64 vis = n_here == 64u ? ~0ull : ((1ull << n_here) - 1ull);
-          if (sift) {
+        if (bucket.y <= CBH_FLAT_SIFT_MIN) {   // a small bucket: record by record
+          VRec q0 = vload_rec(t.rows, bucket.x), q1 = vload_rec(t.rows, bucket.x + 1u < end ? bucket.x + 1u : bucket.x);
+          for (u32 row = bucket.x; row < end; ++row) {
+            const VRec cur = q0;
+            q0 = q1;
+            q1 = vload_rec(t.rows, row + 2u < end ? row + 2u : end - 1u);
+            const TblRowFull rf = rec_uniform(cur);
+            FLAT_DBG(const u64 v0 = __builtin_readcyclecounter() * (u64)(rf.hot.flags != 0xFFFFFFFFu);)
+            visit(row, rf);
+            FLAT_DBG(dbg_visit += __builtin_readcyclecounter() - v0;)
+          }
+        } else {
+          for (u32 base = bucket.x; base < end; base += 64u) {
+            FLAT_T0();
+            const u32 n_here = end - base < 64u ? end - base : 64u;
             const u32 mine = base + (c.tid < n_here ? c.tid : 0u);
             const u32 rm = t.rowmask[2u * (size_t)mine], am = t.rowmask[2u * (size_t)mine + 1u];
-            vis = wave_ballot(c.tid < n_here && (rm & wave_rc) != 0 && (am & wave_ac) != 0);
-          }
-          if (vis == 0) continue;
-          u32 j = (u32)__builtin_ctzll(vis); vis &= vis - 1ull;
-          TblRowFull nxt = uload_rec<TblRowFull>(t.rows, base + j);   // hot half + leaf slot: one scalar load
-          for (;;) {
-            const TblRowFull rf = nxt;
-            const u32 row = base + j;
-            const bool more = vis != 0;
-            if (more) { j = (u32)__builtin_ctzll(vis); vis &= vis - 1ull; nxt = uload_rec<TblRowFull>(t.rows, base + j); }
-            visit(row, rf);
-            if (!more) break;
+            const bool pass = c.tid < n_here && (rm & wave_rc) != 0 && (am & wave_ac) != 0;
+            u64 vis = wave_ballot(pass);
+            FLAT_DBG(dbg_sift += (__builtin_readcyclecounter() - dbg_t) * (u64)(vis != 0xFFFFFFFFFFFFFFFEull);)
+            if (vis == 0) continue;
+            // the records that passed: their lines are pulled towards the L2 together now (one touch per lane), the
+            // loads below then find them there instead of each paying a trip to memory in turn
+            const u32 touched = pass ? t.rows[(size_t)mine * 16u] : 0u;
+            u32 n_left = (u32)__builtin_popcountll(vis);
+            u32 ja = (u32)__builtin_ctzll(vis); vis &= vis - 1ull;
+            VRec qa = vload_rec(t.rows, base + ja);
+            u32 jb = ja; VRec qb = qa;
+            if (vis) { jb = (u32)__builtin_ctzll(vis); vis &= vis - 1ull; qb = vload_rec(t.rows, base + jb); }
+            while (n_left) {
+              const VRec cur = qa;
+              const u32 row = base + ja;
+              qa = qb; ja = jb;
+              if (vis) { jb = (u32)__builtin_ctzll(vis); vis &= vis - 1ull; qb = vload_rec(t.rows, base + jb); }
+              const TblRowFull rf = rec_uniform(cur);
+              FLAT_DBG(const u64 v0 = __builtin_readcyclecounter() * (u64)(rf.hot.flags != 0xFFFFFFFFu);)
+              visit(row, rf);
+              FLAT_DBG(dbg_visit += __builtin_readcyclecounter() - v0;)
+              --n_left;
+            }
+            flat_keep(touched);
           }
         }
       }
@@ -555,8 +668,13 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 #ifdef CBH_PROFILE_CYCLES
   if (flags & CBH_F_DEBUG_CYCLES) {   // policy / scope words <- phase cycles, wall-clock (100 MHz) start / end, visit counts
     const u64 cyc4 = __builtin_readcyclecounter();
-    pol[0] = (u32)(cyc1 - cyc0); pol[1] = (u32)(cyc2 - cyc1); pol[2] = (u32)(cyc3 - cyc2); pol[3] = (u32)(cyc4 - cyc3);
-    scp[0] = (u32)rt0; scp[1] = (u32)__builtin_amdgcn_s_memrealtime(); scp[2] = dbg_rows; scp[3] = dbg_rounds;
+    if (flags & 0x200u) {   // second view: where the walk's cycles went
+      pol[0] = (u32)(cyc3 - cyc2); pol[1] = (u32)dbg_dir; pol[2] = (u32)dbg_sift; pol[3] = (u32)dbg_visit;
+      scp[0] = (u32)dbg_cond; scp[1] = dbg_match; scp[2] = dbg_rows; scp[3] = dbg_rounds;
+    } else {
+      pol[0] = (u32)(cyc1 - cyc0); pol[1] = (u32)(cyc2 - cyc1); pol[2] = (u32)(cyc3 - cyc2); pol[3] = (u32)(cyc4 - cyc3);
+      scp[0] = (u32)rt0; scp[1] = (u32)__builtin_amdgcn_s_memrealtime(); scp[2] = dbg_rows; scp[3] = dbg_rounds;
+    }
   }
 #endif
   const bool packed = valid && act_cnt == 4 && (act_off & 3u) == 0;
@@ -590,43 +708,35 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 #else
 #define CBH_FLAT_ATTRS(MINW)
 #endif
-// each wave of the group owns its slice of the column cache: [planes][ncc][64 lanes] dwords
-#define CBH_FLAT_CTX(a, ka, PLANES)                                                                                               \
+// each wave of the group owns its region of the dynamic LDS (cbh_flat_lds); Ctx::cc = the start of that region
+#define CBH_FLAT_CTX(a, ka, WITH_CALL)                                                                                            \
   const u32 ncc = cached_columns(&a);                                                                                             \
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,  \
-        (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * ((PLANES) * ncc * CBH_BLOCK), ncc, ka}
-// batches of plain scalars (no int / uint / list / map attribute values): no call, ~64 VGPRs, 7-8 waves per SIMD
-__global__ CBH_FLAT_ATTRS(7) void cbh_check_flat_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
-  CBH_FLAT_CTX(a, ka, 2u);
+        (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * cbh_flat_lds(ncc, a.t.max_depth, a.t.K, WITH_CALL).wave_dwords, ncc, ka}
+// batches of plain scalars (no int / uint / list / map attribute values): no call, under 96 VGPRs (two records in flight), 5 waves per SIMD
+__global__ CBH_FLAT_ATTRS(5) void cbh_check_flat_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+  CBH_FLAT_CTX(a, ka, false);
   flat_body<false>(a, c);
 }
 // any batch: the same walk with the call into the shared evaluator compiled in (4 waves per SIMD)
 __global__ CBH_FLAT_ATTRS(4) void cbh_check_flat_kernel_any(const KernelArgs a, const KernelArgs* __restrict__ ka) {
-  CBH_FLAT_CTX(a, ka, 3u);
+  CBH_FLAT_CTX(a, ka, true);
   flat_body<true>(a, c);
 }
 
 // Which kernel decides this batch: a flat one when table (CBH_MF_FLAT), batch shape (<= 4 actions and <= 4 roles per
 // request; `plain_tags`: no attribute value is an int / uint / list / map - selects the variant without the evaluator call)
 // and evaluation mode (not strict) allow it, else the general walk's instantiation for the table class.
-// `threads` = the workgroup size to launch it with; dynamic LDS per wave = the column cache, plus - `flat` - the
-// scope-chain scratch (cbh_flat_lds_bytes).
-// dynamic LDS of one wave of the flat kernel: column cache + [max_depth][64] scope indices
-static inline size_t cbh_flat_chain_bytes(u32 table_max_depth) {
-  return (size_t)(table_max_depth < CBH_FLAT_MAX_DEPTH ? table_max_depth : CBH_FLAT_MAX_DEPTH) * CBH_BLOCK * 4;
-}
-// ... and, once per workgroup, the two class tables (one byte per table string each) when they are staged in LDS
-static inline size_t cbh_flat_class_bytes(u32 table_strings) {
-  return table_strings <= CBH_FLAT_LDS_STRINGS ? (((size_t)2 * table_strings + 15) & ~(size_t)15) : 0;
-}
+// `threads` = the workgroup size to launch it with; dynamic LDS: the column cache of cbh_check_wave.h, or - `flat` - what
+// cbh_flat_lds_bytes says for the variant (`flat_with_call`).
 static inline cbh_check_kernel_fn cbh_pick_kernel(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 max_actions, u32 max_roles, bool plain_tags,
-                                                  u32 eval_flags, u32* threads, bool* flat, u32* col_planes) {
-  *col_planes = 3;
+                                                  u32 eval_flags, u32* threads, bool* flat, bool* flat_with_call) {
+  *flat_with_call = true;
   *flat = (table_flags & CBH_MF_FLAT) && max_actions <= 4 && max_roles <= 4 && !(eval_flags & CBH_F_STRICT_EVALUATION);
   if (*flat) {
     *threads = CBH_FLAT_THREADS;
     const bool nocall = plain_tags && (table_flags & CBH_MF_FLAT_CLOSED);
-    *col_planes = nocall ? 2 : 3;
+    *flat_with_call = !nocall;
     return nocall ? cbh_check_flat_kernel : cbh_check_flat_kernel_any;
   }
   *threads = CBH_BLOCK;

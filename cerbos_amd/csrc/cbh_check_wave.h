@@ -961,7 +961,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
 #ifndef CBH_HOSTSIM
 extern __shared__ __attribute__((aligned(16))) unsigned char cbh_dyn_lds[];
 #else
-static unsigned char cbh_dyn_lds[CBH_CACHE_COLS * CBH_BLOCK * 12 + 16 * CBH_BLOCK * 4 + 2 * 4096 + 16];   // + the flat kernel's chain scratch and class tables
+static unsigned char cbh_dyn_lds[CBH_CACHE_COLS * CBH_BLOCK * 16 + 16 * CBH_BLOCK * 4 + 2 * 4096 + 16];   // the largest cbh_flat_lds layout (cbh_check_flat.h)
 #endif
 __device__ __forceinline__ u32 cached_columns(const KernelArgs* ka) {
   const u32 n = ka->b.n_columns;
