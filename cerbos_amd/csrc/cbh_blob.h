@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define CBH_BLOB_MAGIC 0x31484243u /* "CBH1" */
-#define CBH_BLOB_VERSION 18u
+#define CBH_BLOB_VERSION 17u
 
 struct CbhBlobHeader {  // 32 bytes
   uint32_t magic;
@@ -53,7 +53,6 @@ enum CbhSectionId {
   CBH_SEC_ROLE_CLASS = 25, // u8[K] class (0..61) of a string that is a literal rule role, 63 = any other string
   CBH_SEC_ROWLEAF2 = 30,     // u32[n_rows][8]  copy of the fused-leaf record of a rule's DERIVED-ROLE condition (CBH_ROW_F_DRLEAF_EMBEDDED)
   CBH_SEC_DRX = 31,          // u32[n_dr][16]   derived-role definitions for the flat kernel (CbhDrxField order)
-  CBH_SEC_ROWMASK = 32,      // u32[n_rows][2]  low dwords of a record's role / action class masks: the flat kernel sifts large buckets by them
   CBH_SEC_ROWPAT = 29,       // u32[n_rows][8]  pattern halves of the rule records (CbhRowPatField order)
   CBH_SEC_ACTION_CLASS = 28, // u8[K] class (0..61) of a string that is a literal rule action of a resource policy, 63 = any other string
   CBH_SEC_HOST_NAMES = 27,   // host only: {u32 n, {u16 len, bytes}*} policy keys (CBH_P_TABLE ids), then the same for derived-role names
@@ -158,9 +157,8 @@ enum CbhRowPatField {   // CBH_SEC_ROWPAT: the pattern half of record i, 8 dword
 #define CBH_ROW_F_LEAF_EMBEDDED 64u     /* dwords 8..15 hold the condition's fused-leaf record */
 #define CBH_ROW_F_DRLEAF_EMBEDDED 128u  /* CBH_SEC_ROWLEAF2[row] holds the derived-role condition's fused-leaf record */
 /* The condition is an all/any/none tree of classified fused leaves (celc.py _tree_strip): the slot holds a descriptor laid
- * over the fused-leaf record's fields - {ops 0-7, ops 8-15, index of the leaf strip in the tape in 16-dword units,
- * ops 16-23, ops 24-31, n leaves, 0, 7}.  The strip holds the n leaves, four dwords each: {class | op << 4 | column a << 12 |
- * column b << 20 | constant tag << 28, k0, k1, k2} ((k0, k1) = the constant's value, class 6: three string ids).  ops = 4 bits each: 1 = the next
+ * over the fused-leaf record's fields - {ops 0-7, ops 8-15, index of the first leaf record in the tape in 8-dword units,
+ * ops 16-23, ops 24-31, n leaves, 0, 7} - and the n leaf records follow each other there.  ops = 4 bits each: 1 = the next
  * leaf, 2 + k / 5 + k / 8 + k = OP_TREE_BEGIN / _ACC / _END of kind k (0 all, 1 any, 2 none), 0 = end
  * (cbh_check_flat.h flat_tree; the tape program is unchanged). */
 #define CBH_ROW_F_TREE_EMBEDDED 256u

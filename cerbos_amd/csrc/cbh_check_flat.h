@@ -48,14 +48,6 @@ __device__ __forceinline__ u64 wave_or64(u64 v, u32 wave, u32 lane) {
   return r;
 }
 
-#ifdef CBH_FLAT_NO_NT
-#define CBH_FLAT_DMA_AUX 0
-#else
-#define CBH_FLAT_DMA_AUX 2   /* nt */
-#endif
-#ifndef CBH_FLAT_SIFT_MIN
-#define CBH_FLAT_SIFT_MIN 12u         /* buckets with more records than this are sifted by class masks before any record is read */
-#endif
 #define CBH_FLAT_LDS_STRINGS 4096u   /* class tables of at most this many table strings are staged in LDS (2 bytes each) */
 struct u32x4u { u32 x, y, z, w; };
 __device__ __forceinline__ u32x4u load_u32x4(const CBH_G u32* p) {   // one 16-byte load; `p` is dword aligned
@@ -67,38 +59,6 @@ __device__ __forceinline__ u32x4u load_u32x4(const CBH_G u32* p) {   // one 16-b
   return u32x4u{p[0], p[1], p[2], p[3]};
 #endif
 }
-// A rule record fetched by vector loads at a wave-uniform address, and its move into scalar registers.
-#if !defined(CBH_HOSTSIM) && defined(CBH_FLAT_SCALAR_RECS)
-struct VRec { TblRowFull r; };
-__device__ __forceinline__ VRec vload_rec(const CBH_G u32* rows, u32 idx) { VRec v; v.r = uload_rec<TblRowFull>(rows, idx); return v; }
-__device__ __forceinline__ TblRowFull rec_uniform(const VRec& v) { return v.r; }
-__device__ __forceinline__ void flat_keep(u32 v) { asm volatile("" ::"v"(v)); }
-#elif !defined(CBH_HOSTSIM)
-typedef u32 u32v4 __attribute__((ext_vector_type(4)));
-struct VRec { u32v4 a, b, c, d; };
-__device__ __forceinline__ VRec vload_rec(const CBH_G u32* rows, u32 idx) {
-  const CBH_G u32v4* p = (const CBH_G u32v4*)(rows + (size_t)idx * 16u);
-  VRec r; r.a = p[0]; r.b = p[1]; r.c = p[2]; r.d = p[3];
-  return r;
-}
-#define RFL(x) ((u32)__builtin_amdgcn_readfirstlane((int)(x)))
-__device__ __forceinline__ TblRowFull rec_uniform(const VRec& v) {
-  TblRowFull r;
-  r.hot.flags = RFL(v.a.x); r.hot.cond = RFL(v.a.y); r.hot.drcond = RFL(v.a.z); r.hot.policy = RFL(v.a.w);
-  r.hot.rm_lo = RFL(v.b.x); r.hot.rm_hi = RFL(v.b.y); r.hot.am_lo = RFL(v.b.z); r.hot.am_hi = RFL(v.b.w);
-  r.leaf.w = RFL(v.c.x); r.leaf.a0 = RFL(v.c.y); r.leaf.a1 = RFL(v.c.z); r.leaf.ret = RFL(v.c.w);
-  r.leaf.ctag = RFL(v.d.x); r.leaf.clo = RFL(v.d.y); r.leaf.chi = RFL(v.d.z); r.leaf.pad = RFL(v.d.w);
-  return r;
-}
-#undef RFL
-// a value loaded only for the load's side effect (a cache line on its way): keep the load, wait for it here
-__device__ __forceinline__ void flat_keep(u32 v) { asm volatile("" ::"v"(v)); }
-#else
-struct VRec { TblRowFull r; };
-static inline VRec vload_rec(const u32* rows, u32 idx) { VRec v; __builtin_memcpy(&v.r, rows + (size_t)idx * 16u, 64); return v; }
-static inline TblRowFull rec_uniform(const VRec& v) { return v.r; }
-static inline void flat_keep(u32) {}
-#endif
 // stores of results nobody in this kernel reads again: written through, so that the end of the kernel does not have to
 // flush them out of the L2 (the dirty lines of a 1M-tuple batch are 12 MB)
 template <typename T>
@@ -113,88 +73,12 @@ __device__ __forceinline__ void store_nt(CBH_G T* p, T v) {
 // one record of CBH_SEC_DRX (cbh_blob.h CbhDrxField): a derived-role definition as the flat kernel reads it
 struct __attribute__((aligned(64))) TblDrx { u32 rm_lo, rm_hi, flags, cond, name, p0, p1, p2; LeafRec leaf; };
 
-// Dynamic LDS of the flat kernels, in dwords.  Per wave: the value planes [2][ncc][64] (low / high dword of every
-// cached column; filled by asynchronous global->LDS copies), for the variant with the evaluator call the tag-word plane
-// [ncc][64] the shared evaluator reads (cbh_check_wave.h fill_column_cache), the packed tags [ceil(ncc / 4)][64] (one byte
-// per column, four columns to a dword: a tag is one ds_read_u8), the scope-chain scratch [max_depth][64].  Behind the
-// waves' regions, once per workgroup: the two class tables.  Host and kernel size it with this one function.
-struct FlatLds { u32 tagw_off, tags_off, chain_off, wave_dwords, class_bytes; };
-static __host__ __device__ __forceinline__ FlatLds cbh_flat_lds(u32 ncc, u32 table_max_depth, u32 table_strings, bool with_call) {
-  FlatLds l;
-  const u32 depth = table_max_depth < CBH_FLAT_MAX_DEPTH ? table_max_depth : CBH_FLAT_MAX_DEPTH;
-  l.tagw_off = 2u * ncc * CBH_BLOCK;
-#ifdef CBH_FLAT_TAGW   /* lab variant: tags read from the tag-word plane in both kernels */
-  with_call = true;
-#endif
-  l.tags_off = l.tagw_off + (with_call ? ncc * CBH_BLOCK : 0u);
-  l.chain_off = l.tags_off + ((ncc + 3u) / 4u) * CBH_BLOCK;
-  l.wave_dwords = l.chain_off + depth * CBH_BLOCK;
-  l.class_bytes = table_strings <= CBH_FLAT_LDS_STRINGS ? ((2u * table_strings + 15u) & ~15u) : 0u;
-  return l;
-}
-static inline size_t cbh_flat_lds_bytes(u32 ncc, u32 table_max_depth, u32 table_strings, bool with_call, u32 waves) {
-  const FlatLds l = cbh_flat_lds(ncc, table_max_depth, table_strings, with_call);
-  return (size_t)l.wave_dwords * 4u * waves + l.class_bytes;
-}
-
-// Request data is read once: loaded past the caches' retention (nt) so that it does not push the table out of the L2.
-template <typename T>
-__device__ __forceinline__ T load_nt(const CBH_G T* p) {
-#if !defined(CBH_HOSTSIM) && !defined(CBH_FLAT_NO_NT)
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
-}
-
-// The attribute columns of this lane's request: values by asynchronous global->LDS copies, tags as bytes packed four
-// columns to a dword (`tags` = this wave's packed-tag planes).
-template <u32 N>
-__device__ __forceinline__ void flat_load_tags(CBH_L u32* tags, u32 tid, u32 n, const BatchDev& b, u32 NR, u32 req) {   // columns 0 .. N-1, all loads in flight together
-  u32 t[N];
-#pragma unroll
-  for (u32 k = 0; k < N; ++k) t[k] = load_nt(b.col_tag + ((size_t)(k < n ? k : 0u) * NR + req));   // (N rounds n up to a multiple of four: the spare slots re-read column 0)
-#pragma unroll
-  for (u32 g = 0; g < N / 4; ++g) tags[g * CBH_BLOCK + tid] = t[4 * g] | (t[4 * g + 1] << 8) | (t[4 * g + 2] << 16) | (t[4 * g + 3] << 24);
-}
-template <bool WITH_CALL>
-__device__ __forceinline__ void flat_fill_columns(const Ctx& c, CBH_L u32* tags, const BatchDev& b, u32 NR, u32 req) {
-  for (u32 k = 0; k < c.n_cached; ++k) {
-    const size_t ix = (size_t)k * NR + req;
-    const CBH_G u32* vsrc = (const CBH_G u32*)(b.col_val + ix);
-#ifndef CBH_HOSTSIM
-    __builtin_amdgcn_global_load_lds((const CBH_G void*)vsrc, (CBH_L void*)(c.cc + k * CBH_BLOCK), 4, 0, CBH_FLAT_DMA_AUX);
-    __builtin_amdgcn_global_load_lds((const CBH_G void*)(vsrc + 1), (CBH_L void*)(c.cc + (c.n_cached + k) * CBH_BLOCK), 4, 0, CBH_FLAT_DMA_AUX);
-#ifdef CBH_FLAT_TAGW
-    if (true)
-#else
-    if (WITH_CALL)   // the shared evaluator's tag-word plane: the aligned dword holding this lane's tag byte
-#endif
-      __builtin_amdgcn_global_load_lds((const CBH_G void*)(b.col_tag + (ix & ~(size_t)3)), (CBH_L void*)(c.cc + (2 * c.n_cached + k) * CBH_BLOCK), 4, 0, CBH_FLAT_DMA_AUX);
-#else
-    c.cc[k * CBH_BLOCK + c.tid] = vsrc[0];
-    c.cc[(c.n_cached + k) * CBH_BLOCK + c.tid] = vsrc[1];
-    if (WITH_CALL) c.cc[(2 * c.n_cached + k) * CBH_BLOCK + c.tid] = (u32)b.col_tag[ix] << ((ix & 3u) * 8u);
-#endif
-  }
-#ifdef CBH_FLAT_TAGW
-  return;
-#endif
-  const u32 n = c.n_cached;   // wave-uniform: the arm that covers it, every load of it unconditional
-  if (n > 12) flat_load_tags<16>(tags, c.tid, n, b, NR, req);
-  else if (n > 8) flat_load_tags<12>(tags, c.tid, n, b, NR, req);
-  else if (n > 4) flat_load_tags<8>(tags, c.tid, n, b, NR, req);
-  else if (n > 0) flat_load_tags<4>(tags, c.tid, n, b, NR, req);
-}
+// A cached attribute column for this lane: tag and the two value dwords (cbh_check_wave.h fill_column_cache).
 struct FlatCol { u32 t, lo, hi; };
-struct FlatTags { const CBH_L u8* bytes; const CBH_L u32* tagw; u32 NR, req; };   // this lane's packed tag bytes: column k at bytes[(k / 4) * 256 + k % 4]
-__device__ __forceinline__ FlatCol flat_col(const Ctx& c, const FlatTags& tg, u32 col) {   // `col` wave-uniform, < n_cached
+__device__ __forceinline__ FlatCol flat_col(const Ctx& c, u32 col, u32 req) {   // `col` wave-uniform
   FlatCol v;
-#ifdef CBH_FLAT_TAGW
-  v.t = (tg.tagw[col * CBH_BLOCK] >> (((col * tg.NR + tg.req) & 3u) * 8u)) & 0xFFu;
-#else
-  v.t = tg.bytes[(col >> 2) * (CBH_BLOCK * 4u) + (col & 3u)];
-#endif
+  const u32 tw = c.cc[(2 * c.n_cached + col) * CBH_BLOCK + c.tid];
+  v.t = (tw >> (((col * c.b.n_requests + req) & 3u) * 8u)) & 0xFFu;   // the lane's byte of the aligned tag dword
   v.lo = c.cc[col * CBH_BLOCK + c.tid];
   v.hi = c.cc[(c.n_cached + col) * CBH_BLOCK + c.tid];
   return v;
@@ -203,23 +87,23 @@ __device__ __forceinline__ FlatCol flat_col(const Ctx& c, const FlatTags& tg, u3
 // computes the answer, the error flag and the "needs the full evaluator" flag with compares and selects; which
 // class it is is a wave-uniform switch.  Same answers as leaf_fast (cbh_check_wave.h), which stays the reference
 // for the shapes not listed here.  Returns bit 0 = satisfied, bit 1 = CEL error (counts as not satisfied),
-// bit 2 = undecided here (cross-type numerics, containers): needs the shared evaluator.
-// `cls` = the leaf class, `op` = OP_EQ .. OP_IN, `ca` / `cb` = the column(s), `k0 k1 k2` = the constant: (tag, value) of a
-// string / bool, the two halves of a double, or up to three string ids.  All wave-uniform.
-__device__ __forceinline__ u32 flat_leaf_core(const Ctx& c, const FlatTags& tg, u32 cls, u32 op, u32 ca, u32 cb, u32 k0, u32 k1, u32 k2, u32 pid) {
+// bit 2 = undecided here (mixed numeric types, containers): the caller hands that lane to eval_cond_rec.
+__device__ __forceinline__ u32 flat_leaf(const Ctx& c, const LeafRec& lr, u32 req, u32 pid) {
+  const u32 a = lr.w >> 8;
+  const u32 ka = (a >> 8) & 0xFu, op = a & 0xFFu;   // wave-uniform
   const bool want_eq = op == OP_EQ;
-  switch (cls) {
-    case 1: {   // column ==/!= string or bool constant (k0 = its tag, k1 = its value)
-      const FlatCol x = flat_col(c, tg, ca);
+  switch (lr.pad) {
+    case 1: {   // column ==/!= string or bool constant
+      const FlatCol x = flat_col(c, lr.a0, req);
       const bool err = x.t >= CBH_T_ABSENT;   // ABSENT (0xF0) or ERR (0xFF)
-      const bool eq = x.t == k0 && x.lo == k1;   // other types are plainly unequal
+      const bool eq = x.t == lr.ctag && x.lo == lr.clo;   // other types are plainly unequal
       return err ? 2u : (u32)(eq == want_eq);
     }
-    case 2: {   // column <op> double constant (k1, k2 = its halves)
-      const FlatCol x = flat_col(c, tg, ca);
+    case 2: {   // column <op> double constant
+      const FlatCol x = flat_col(c, lr.a0, req);
       const bool err = x.t >= CBH_T_ABSENT;
       const bool dbl = x.t == CBH_T_DOUBLE, othernum = x.t == CBH_T_INT || x.t == CBH_T_UINT;
-      const double p = as_f64((u64)x.lo | ((u64)x.hi << 32)), q = as_f64((u64)k1 | ((u64)k2 << 32));
+      const double p = as_f64((u64)x.lo | ((u64)x.hi << 32)), q = as_f64((u64)lr.clo | ((u64)lr.chi << 32));
       const bool ordering = op != OP_EQ && op != OP_NE;
       const bool cmp = (op == OP_EQ) ? p == q : (op == OP_NE) ? p != q : (op == OP_LT) ? p < q : (op == OP_LE) ? p <= q
                      : (op == OP_GT) ? p > q : p >= q;   // NaN: every ordering false, != true
@@ -229,7 +113,7 @@ __device__ __forceinline__ u32 flat_leaf_core(const Ctx& c, const FlatTags& tg, 
       return (err || overload) ? 2u : slow ? 4u : r;
     }
     case 3: {   // column ==/!= column
-      const FlatCol x = flat_col(c, tg, ca), y = flat_col(c, tg, cb);
+      const FlatCol x = flat_col(c, lr.a0, req), y = flat_col(c, lr.a1, req);
       const bool err = x.t >= CBH_T_ABSENT || y.t >= CBH_T_ABSENT;
       const bool same = x.t == y.t;
       const bool scalar = x.t < CBH_T_LIST || x.t == CBH_T_TIMESTAMP || x.t == CBH_T_DURATION;
@@ -240,68 +124,36 @@ __device__ __forceinline__ u32 flat_leaf_core(const Ctx& c, const FlatTags& tg, 
       const bool slow = !err && ((same && !scalar) || (!same && xnum && ynum));   // containers / cross-type numeric equality
       return err ? 2u : slow ? 4u : (u32)(eq == want_eq);
     }
-    case 4: {   // column ==/!= P.id
-      const FlatCol x = flat_col(c, tg, ca);
+    case 4: {   // column ==/!= P.id (either order)
+      const FlatCol x = flat_col(c, ka == 3 ? lr.a0 : lr.a1, req);
       const bool err = x.t >= CBH_T_ABSENT;
       const bool eq = x.t == CBH_T_STRING && x.lo == pid;
       return err ? 2u : (u32)(eq == want_eq);
     }
-    case 6: {   // column in [at most three string constants] (k0 k1 k2 = their ids, CBH_NONE pads)
-      const FlatCol x = flat_col(c, tg, ca);
+    case 6: {   // column in [at most three string constants]
+      const FlatCol x = flat_col(c, lr.a0, req);
       const bool err = x.t >= CBH_T_ABSENT;
-      const bool found = x.t == CBH_T_STRING && (x.lo == k0 || x.lo == k1 || x.lo == k2);
+      const bool found = x.t == CBH_T_STRING && (x.lo == lr.ctag || x.lo == lr.clo || x.lo == lr.chi);
       return err ? 2u : (u32)found;
     }
     default: return 4u;
   }
 }
-// ... from the 8-dword fused-leaf record embedded in a rule record (celc.py _leaf_record)
-__device__ __forceinline__ u32 flat_leaf(const Ctx& c, const FlatTags& tg, const LeafRec& lr, u32 pid) {
-  const u32 a = lr.w >> 8;
-  const u32 ka = (a >> 8) & 0xFu, op = a & 0xFFu;
-  const u32 cls = lr.pad;
-  return flat_leaf_core(c, tg, cls, op, (cls == 4u && ka != 3u) ? lr.a1 : lr.a0, lr.a1, lr.ctag, lr.clo, lr.chi, pid);
-}
 
 // A condition tree of classified leaves (cbh_blob.h CBH_ROW_F_TREE_EMBEDDED; `desc` = the descriptor in the record's leaf
-// slot): the 4-bit ops in order, leaves from the strip - four dwords each {class | op << 4 | column a << 12 | column b << 20 |
-// constant tag << 28, k0, k1, k2}, fetched four leaves at a time with one 16-dword scalar load - no tape reads and no
-// divergent branch.  Same bookkeeping as eval_leaf_tree (cbh_check_wave.h): a leaf behind the deciding one of its level
-// is not evaluated by the reference (check.go:697-749), so its error / "needs the full evaluator" flags do not count.
-// Returns flat_leaf's bits for the tree.
-#ifndef CBH_HOSTSIM
-typedef u32 LeafQuad __attribute__((ext_vector_type(16)));   // (a vector, not a struct of an array: that one the compiler parks in scratch)
-__device__ __forceinline__ LeafQuad load_quad(const CBH_G u32* code, u32 idx) {
-  return *(const __attribute__((address_space(4))) LeafQuad*)uniform_addr((unsigned long long)(code + (size_t)idx * 16u));
-}
-#define QD(q, i) ((q)[i])
-#else
-struct LeafQuad { u32 d[16]; };
-static inline LeafQuad load_quad(const u32* code, u32 idx) { LeafQuad q; __builtin_memcpy(&q, code + (size_t)idx * 16u, 64); return q; }
-#define QD(q, i) ((q).d[i])
-#endif
-__device__ __forceinline__ u32 flat_tree(const Ctx& c, const FlatTags& tg, const LeafRec& desc, u32 pid) {
+// slot): the 4-bit ops in order, leaves from the strip, no tape reads and no divergent branch.  Same bookkeeping as
+// eval_leaf_tree (cbh_check_wave.h): a leaf behind the deciding one of its level is not evaluated by the reference
+// (check.go:697-749), so its error / "needs the full evaluator" flags do not count.  Returns flat_leaf's bits for the tree.
+__device__ __forceinline__ u32 flat_tree(const Ctx& c, const LeafRec& desc, u32 req, u32 pid) {
+  const u32 opw[4] = {desc.w, desc.a0, desc.ret, desc.ctag};   // wave-uniform
   bool live = true, last = false;
-  u32 saved = 0, acc = 0, depth = 0, li = 0, err = 0, slow = 0;
-  LeafQuad q = load_quad(c.t.code, desc.a1);   // strips start on a 16-dword boundary; a1 = that boundary's index
+  u32 saved = 0, acc = 0, depth = 0, leaf = desc.a1, err = 0, slow = 0;
   for (u32 k = 0; k < 32; ++k) {
-    const u32 g = k >> 3;   // wave-uniform; mask blends, see flat_col
-    const u32 opw = (desc.w & (0u - (u32)(g == 0u))) | (desc.a0 & (0u - (u32)(g == 1u))) | (desc.ret & (0u - (u32)(g == 2u))) | (desc.ctag & (0u - (u32)(g == 3u)));
-    const u32 op = (opw >> (4u * (k & 7u))) & 15u;
+    const u32 op = (opw[k >> 3] >> (4u * (k & 7u))) & 15u;
     if (op == 0) break;
     if (op == 1) {
-      const u32 j = li & 3u;
-      if (j == 0 && li != 0) q = load_quad(c.t.code, desc.a1 + (li >> 2));
-      const u32 m0 = 0u - (u32)(j == 0u), m1 = 0u - (u32)(j == 1u), m2 = 0u - (u32)(j == 2u), m3 = 0u - (u32)(j == 3u);
-      const u32 h = (QD(q, 0) & m0) | (QD(q, 4) & m1) | (QD(q, 8) & m2) | (QD(q, 12) & m3);
-      const u32 k0 = (QD(q, 1) & m0) | (QD(q, 5) & m1) | (QD(q, 9) & m2) | (QD(q, 13) & m3);
-      const u32 k1 = (QD(q, 2) & m0) | (QD(q, 6) & m1) | (QD(q, 10) & m2) | (QD(q, 14) & m3);
-      const u32 k2 = (QD(q, 3) & m0) | (QD(q, 7) & m1) | (QD(q, 11) & m2) | (QD(q, 15) & m3);
-      ++li;
-      const u32 cls = h & 15u;
-      // classes 1 / 2 carry (value lo, value hi) in k0 k1 and the tag in the header; class 6 three ids
-      const u32 lv = cls == 6u ? flat_leaf_core(c, tg, cls, (h >> 4) & 0xFFu, (h >> 12) & 0xFFu, (h >> 20) & 0xFFu, k0, k1, k2, pid)
-                               : flat_leaf_core(c, tg, cls, (h >> 4) & 0xFFu, (h >> 12) & 0xFFu, (h >> 20) & 0xFFu, h >> 28, k0, k1, pid);
+      const LeafRec lr = uload_rec<LeafRec>(c.t.code, leaf++);
+      const u32 lv = flat_leaf(c, lr, req, pid);
       last = live && (lv & 1u) != 0;
       err |= live ? (lv & 2u) : 0u;
       slow |= live ? (lv & 4u) : 0u;
@@ -345,34 +197,26 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 #ifdef CBH_PROFILE_CYCLES   // profiling build only (tools/gpu_cycles_flat.py)
   const u64 cyc0 = __builtin_readcyclecounter();
   const u64 rt0 = __builtin_amdgcn_s_memrealtime();
-  u32 dbg_rows = 0, dbg_rounds = 0, dbg_match = 0;
-  u64 dbg_dir = 0, dbg_sift = 0, dbg_visit = 0, dbg_cond = 0, dbg_t = 0;
-#define FLAT_T0() dbg_t = __builtin_readcyclecounter()
-#define FLAT_ACC(acc) acc += __builtin_readcyclecounter() - dbg_t
+  u32 dbg_rows = 0, dbg_rounds = 0;
 #define FLAT_DBG(x) x
 #else
 #define FLAT_DBG(x)
-#define FLAT_T0()
-#define FLAT_ACC(acc)
 #endif
   const u32 rix = b.req_lo + blockIdx.x * CBH_FLAT_THREADS + threadIdx.x;
   const bool valid = rix < b.req_hi;
   const u32 req = valid ? rix : b.req_lo;
   const u32 NR = b.n_requests;
-#define RQ(f) load_nt(b.req_u32 + ((size_t)(f) * NR + req))
+#define RQ(f) b.req_u32[(size_t)(f) * NR + req]
   const u32 pid = RQ(CBH_RQ_PRINCIPAL_ID), kind = RQ(CBH_RQ_KIND), r_scope = RQ(CBH_RQ_R_SCOPE), r_ver = RQ(CBH_RQ_R_VERSION);
   const u32 role_off = RQ(CBH_RQ_ROLE_OFF), act_off = RQ(CBH_RQ_ACT_OFF);
   const u32 role_cnt = valid ? RQ(CBH_RQ_ROLE_CNT) : 0, act_cnt = valid ? RQ(CBH_RQ_ACT_CNT) : 0;   // both <= 4 (host-checked)
 #undef RQ
-  const FlatLds lds = cbh_flat_lds(c.n_cached, t.max_depth, t.K, WITH_CALL);
-  CBH_L u32* tag_planes = c.cc + lds.tags_off;   // (c.cc = this wave's region)
-  flat_fill_columns<WITH_CALL>(c, tag_planes, b, NR, req);
-  FlatTags tg; tg.bytes = (const CBH_L u8*)(tag_planes + c.tid); tg.tagw = c.cc + lds.tagw_off + c.tid; tg.NR = NR; tg.req = req;
+  fill_column_cache(c, b, NR, req);
   const u32 all = (1u << act_cnt) - 1u;
   // [depth][lane]: scope index at that depth of the lane's chain - in the dynamic LDS behind the column caches,
   // sized by the table's longest chain (a one-scope table pays 256 B per wave, not 4 KB: LDS sets the occupancy here)
   const u32 max_depth = t.max_depth < CBH_FLAT_MAX_DEPTH ? t.max_depth : CBH_FLAT_MAX_DEPTH;
-  CBH_L u32* chain_si = c.cc + lds.chain_off;
+  CBH_L u32* chain_si = (CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * (3u * c.n_cached * CBH_BLOCK) + wave * (max_depth * CBH_BLOCK);
   // actions and roles -> classes (CBH_SEC_ACTION_CLASS / CBH_SEC_ROLE_CLASS; 63 = a string no rule names).
   // A flat table has fewer than 32 classes per dimension and its masks mirror "any other string" (bit 63)
   // in bit 31 of the low dword: the match is a 1-bit field extract from ONE dword at a per-lane position.
@@ -383,7 +227,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   // flight - a table of up to CBH_FLAT_LDS_STRINGS strings - so that the lookups below are LDS reads, not a third
   // dependent trip to memory.
   const bool cls_in_lds = t.K <= CBH_FLAT_LDS_STRINGS;
-  CBH_L u8* cls_lds = (CBH_L u8*)((CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * lds.wave_dwords);   // [action classes K][role classes K]
+  CBH_L u8* cls_lds = (CBH_L u8*)((CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * ((3u * c.n_cached + max_depth) * CBH_BLOCK));   // [action classes K][role classes K]
   if (cls_in_lds) {
     for (u32 i = threadIdx.x; i < t.K; i += CBH_FLAT_THREADS) { cls_lds[i] = t.action_class[i]; cls_lds[t.K + i] = t.role_class[i]; }
   }
@@ -395,7 +239,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   u32x4u sp; sp.x = sp.y = sp.z = sp.w = 0;
   if (spec) sp = load_u32x4(b.tuple_action + spec_ix);
 #pragma unroll
-  for (u32 k = 0; k < 4; ++k) rid[k] = load_nt(b.roles + (k < role_cnt ? role_off + k : 0u));
+  for (u32 k = 0; k < 4; ++k) rid[k] = b.roles[k < role_cnt ? role_off + k : 0u];
   const bool spec_hit = spec && act_cnt == 4u && act_off == spec_ix;
   aid[0] = sp.x; aid[1] = sp.y; aid[2] = sp.z; aid[3] = sp.w;
   if (!spec_hit) {
@@ -445,8 +289,8 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   // flat_tree), 0 = neither; what the inline code leaves open goes through the shared evaluator.
   auto leafish = [&](u32 ref, u32 how, const LeafRec& lr, bool active) -> u32 {
     u32 lv = 4u;
-    if (how == 1u) lv = flat_leaf(c, tg, lr, pid);
-    else if (how == 2u) lv = flat_tree(c, tg, lr, pid);
+    if (how == 1u) lv = flat_leaf(c, lr, req, pid);
+    else if (how == 2u) lv = flat_tree(c, lr, req, pid);
     const bool slow = active && lv == 4u;
     if (WITH_CALL) {
       // The classified leaves leave open only what needs memory (container equality) or cross-type numerics.  The
@@ -487,98 +331,45 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
     const bool go = wave_ballot(ing && S != 0) != 0;
     FLAT_DBG(++dbg_rounds;)
     uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
-    FLAT_T0();
     const bool have_bucket = udir_find(t, CBH_B_RESOURCE, g_ver, g_k, g_si, bucket);   // present for every resource policy (index.go:966-997)
-    FLAT_DBG(if (have_bucket) { dbg_dir += (__builtin_readcyclecounter() - dbg_t) * (u64)(bucket.y != 0xFFFFFFFFu); })
     exists = exists || (ing && have_bucket);
     if (go) {
       if (ing && mydepth < max_depth) chain_si[mydepth * CBH_BLOCK + c.tid] = g_si;
       const u32 S_before = S;
-      // one binding (check.go:295-414) for the lanes of this round
-      auto visit = [&](u32 row, const TblRowFull& rf) {
-        const TblRow& rw = rf.hot;
-        FLAT_DBG(++dbg_rows;)
-        if ((rw.rm_lo & wave_rc) == 0 || (rw.am_lo & wave_ac) == 0) return;   // no lane of the wave holds a class it names
-        const u32 mact = ((rw.am_lo >> ac[0]) & 1u) | (((rw.am_lo >> ac[1]) & 1u) << 1) | (((rw.am_lo >> ac[2]) & 1u) << 2) | (((rw.am_lo >> ac[3]) & 1u) << 3);
-        // one nibble per role (sign-extended 1-bit extracts), one bit per nibble for the actions; walks of other groups sit out
-        const u32 mrole = ((0u - ((rw.rm_lo >> rc[0]) & 1u)) & 0xFu) | ((0u - ((rw.rm_lo >> rc[1]) & 1u)) & 0xF0u) |
-                          ((0u - ((rw.rm_lo >> rc[2]) & 1u)) & 0xF00u) | ((0u - ((rw.rm_lo >> rc[3]) & 1u)) & 0xF000u);
-        const u32 m = ing ? (mrole & (mact * 0x1111u) & S) : 0u;
-        if (wave_ballot(m != 0) == 0) return;
-        FLAT_DBG(++dbg_match; const u64 c0 = __builtin_readcyclecounter();)
-        // the walks this record's effect applies to: all matched ones unless a condition says no.  The derived-role
-        // condition comes first and the rule's own condition is evaluated only where that held (check.go:328-380);
-        // each once per record and request, whatever the roles (check.go:316-340)
-        u32 hit = m;
-        if (rw.drcond != CBH_NONE) {
-          const u32 how = (rw.flags & CBH_ROW_F_DRLEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_DRTREE_EMBEDDED) ? 2u : 0u;
-          const LeafRec l2 = uload_rec<LeafRec>(t.rowleaf2, row);
-          const u32 lv = leafish(rw.drcond, how, l2, hit != 0);
-          err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
-          hit = (lv & 1u) ? hit : 0u;
-        }
-        if (rw.cond != CBH_NONE && wave_ballot(hit != 0) != 0) {
-          const u32 how = (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_TREE_EMBEDDED) ? 2u : 0u;
-          const u32 lv = leafish(rw.cond, how, rf.leaf, hit != 0);
-          err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
-          hit = (lv & 1u) ? hit : 0u;
-        }
-        FLAT_DBG(dbg_cond += (__builtin_readcyclecounter() - c0) * (u64)(hit != 0xFFFFFFFFu || true);)
-        if ((rw.flags & 3u) == CBH_EFFECT_ALLOW) has_allow |= hit;
-        else if ((rw.flags & 3u) == CBH_EFFECT_DENY) { deny |= hit; S &= ~hit; }   // ends these walks (check.go:392-403)
-      };
       if (have_bucket && bucket.y) {
-        // Bindings in order.  A large bucket is taken 64 records at a time and first sifted by the (role classes, action
-        // classes) pairs of its records (CBH_SEC_ROWMASK: lane j tests record j against the classes present in the
-        // wave, one 8-byte load per lane) so that only records some lane can match are fetched at all; a small one is
-        // read record by record.  Either way the next record to be visited is loaded while the current one is processed.
-        // Records travel through VECTOR loads at a wave-uniform address (every lane gets the same 64 bytes) and are moved to
-        // scalar registers when their turn comes: vector loads return in order, so two records stay in flight while a
-        // third is processed and nothing else waits for them.  (Scalar loads share their counter with the LDS, and return
-        // out of order: a record prefetched that way is waited for in full by the first LDS read of a condition.)
-        const u32 end = bucket.x + bucket.y;
-        if (bucket.y <= CBH_FLAT_SIFT_MIN) {   // a small bucket: record by record
-          VRec q0 = vload_rec(t.rows, bucket.x), q1 = vload_rec(t.rows, bucket.x + 1u < end ? bucket.x + 1u : bucket.x);
-          for (u32 row = bucket.x; row < end; ++row) {
-            const VRec cur = q0;
-            q0 = q1;
-            q1 = vload_rec(t.rows, row + 2u < end ? row + 2u : end - 1u);
-            const TblRowFull rf = rec_uniform(cur);
-            FLAT_DBG(const u64 v0 = __builtin_readcyclecounter() * (u64)(rf.hot.flags != 0xFFFFFFFFu);)
-            visit(row, rf);
-            FLAT_DBG(dbg_visit += __builtin_readcyclecounter() - v0;)
+        const u32 last = bucket.x + bucket.y - 1u;
+        TblRowFull nxt = uload_rec<TblRowFull>(t.rows, bucket.x);
+        for (u32 row = bucket.x; row <= last; ++row) {   // bindings in order (check.go:295-414)
+          const TblRowFull rf = nxt;   // hot half + leaf slot: one scalar load, issued one record ahead
+          nxt = uload_rec<TblRowFull>(t.rows, row < last ? row + 1u : last);
+          const TblRow& rw = rf.hot;
+          FLAT_DBG(++dbg_rows;)
+          if ((rw.rm_lo & wave_rc) == 0 || (rw.am_lo & wave_ac) == 0) continue;
+          const u32 mact = ((rw.am_lo >> ac[0]) & 1u) | (((rw.am_lo >> ac[1]) & 1u) << 1) | (((rw.am_lo >> ac[2]) & 1u) << 2) | (((rw.am_lo >> ac[3]) & 1u) << 3);
+          // one nibble per role (sign-extended 1-bit extracts), one bit per nibble for the actions; walks of other groups sit out
+          const u32 mrole = ((0u - ((rw.rm_lo >> rc[0]) & 1u)) & 0xFu) | ((0u - ((rw.rm_lo >> rc[1]) & 1u)) & 0xF0u) |
+                            ((0u - ((rw.rm_lo >> rc[2]) & 1u)) & 0xF00u) | ((0u - ((rw.rm_lo >> rc[3]) & 1u)) & 0xF000u);
+          const u32 m = ing ? (mrole & (mact * 0x1111u) & S) : 0u;
+          if (wave_ballot(m != 0) == 0) continue;
+          // the walks this record's effect applies to: all matched ones unless a condition says no.  The derived-role
+          // condition comes first and the rule's own condition is evaluated only where that held (check.go:328-380);
+          // each once per record and request, whatever the roles (check.go:316-340)
+          u32 hit = m;
+          if (rw.drcond != CBH_NONE) {
+            const u32 how = (rw.flags & CBH_ROW_F_DRLEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_DRTREE_EMBEDDED) ? 2u : 0u;
+            const LeafRec l2 = uload_rec<LeafRec>(t.rowleaf2, row);
+            const u32 lv = leafish(rw.drcond, how, l2, hit != 0);
+            err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
+            hit = (lv & 1u) ? hit : 0u;
           }
-        } else {
-          for (u32 base = bucket.x; base < end; base += 64u) {
-            FLAT_T0();
-            const u32 n_here = end - base < 64u ? end - base : 64u;
-            const u32 mine = base + (c.tid < n_here ? c.tid : 0u);
-            const u32 rm = t.rowmask[2u * (size_t)mine], am = t.rowmask[2u * (size_t)mine + 1u];
-            const bool pass = c.tid < n_here && (rm & wave_rc) != 0 && (am & wave_ac) != 0;
-            u64 vis = wave_ballot(pass);
-            FLAT_DBG(dbg_sift += (__builtin_readcyclecounter() - dbg_t) * (u64)(vis != 0xFFFFFFFFFFFFFFFEull);)
-            if (vis == 0) continue;
-            // the records that passed: their lines are pulled towards the L2 together now (one touch per lane), the
-            // loads below then find them there instead of each paying a trip to memory in turn
-            const u32 touched = pass ? t.rows[(size_t)mine * 16u] : 0u;
-            u32 n_left = (u32)__builtin_popcountll(vis);
-            u32 ja = (u32)__builtin_ctzll(vis); vis &= vis - 1ull;
-            VRec qa = vload_rec(t.rows, base + ja);
-            u32 jb = ja; VRec qb = qa;
-            if (vis) { jb = (u32)__builtin_ctzll(vis); vis &= vis - 1ull; qb = vload_rec(t.rows, base + jb); }
-            while (n_left) {
-              const VRec cur = qa;
-              const u32 row = base + ja;
-              qa = qb; ja = jb;
-              if (vis) { jb = (u32)__builtin_ctzll(vis); vis &= vis - 1ull; qb = vload_rec(t.rows, base + jb); }
-              const TblRowFull rf = rec_uniform(cur);
-              FLAT_DBG(const u64 v0 = __builtin_readcyclecounter() * (u64)(rf.hot.flags != 0xFFFFFFFFu);)
-              visit(row, rf);
-              FLAT_DBG(dbg_visit += __builtin_readcyclecounter() - v0;)
-              --n_left;
-            }
-            flat_keep(touched);
+          if (rw.cond != CBH_NONE && wave_ballot(hit != 0) != 0) {
+            const u32 how = (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_TREE_EMBEDDED) ? 2u : 0u;
+            const u32 lv = leafish(rw.cond, how, rf.leaf, hit != 0);
+            err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
+            hit = (lv & 1u) ? hit : 0u;
           }
+          if ((rw.flags & 3u) == CBH_EFFECT_ALLOW) has_allow |= hit;
+          else if ((rw.flags & 3u) == CBH_EFFECT_DENY) { deny |= hit; S &= ~hit; }   // ends these walks (check.go:392-403)
         }
       }
       const u32 ha = ing ? (has_allow & S) : 0u;   // check.go:416-425
@@ -668,13 +459,8 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 #ifdef CBH_PROFILE_CYCLES
   if (flags & CBH_F_DEBUG_CYCLES) {   // policy / scope words <- phase cycles, wall-clock (100 MHz) start / end, visit counts
     const u64 cyc4 = __builtin_readcyclecounter();
-    if (flags & 0x200u) {   // second view: where the walk's cycles went
-      pol[0] = (u32)(cyc3 - cyc2); pol[1] = (u32)dbg_dir; pol[2] = (u32)dbg_sift; pol[3] = (u32)dbg_visit;
-      scp[0] = (u32)dbg_cond; scp[1] = dbg_match; scp[2] = dbg_rows; scp[3] = dbg_rounds;
-    } else {
-      pol[0] = (u32)(cyc1 - cyc0); pol[1] = (u32)(cyc2 - cyc1); pol[2] = (u32)(cyc3 - cyc2); pol[3] = (u32)(cyc4 - cyc3);
-      scp[0] = (u32)rt0; scp[1] = (u32)__builtin_amdgcn_s_memrealtime(); scp[2] = dbg_rows; scp[3] = dbg_rounds;
-    }
+    pol[0] = (u32)(cyc1 - cyc0); pol[1] = (u32)(cyc2 - cyc1); pol[2] = (u32)(cyc3 - cyc2); pol[3] = (u32)(cyc4 - cyc3);
+    scp[0] = (u32)rt0; scp[1] = (u32)__builtin_amdgcn_s_memrealtime(); scp[2] = dbg_rows; scp[3] = dbg_rounds;
   }
 #endif
   const bool packed = valid && act_cnt == 4 && (act_off & 3u) == 0;
@@ -708,36 +494,41 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 #else
 #define CBH_FLAT_ATTRS(MINW)
 #endif
-// each wave of the group owns its region of the dynamic LDS (cbh_flat_lds); Ctx::cc = the start of that region
-#define CBH_FLAT_CTX(a, ka, WITH_CALL)                                                                                            \
+// each wave of the group owns its slice of the column cache: [3 planes][ncc][64 lanes] dwords
+#define CBH_FLAT_CTX(a, ka)                                                                                                       \
   const u32 ncc = cached_columns(&a);                                                                                             \
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,  \
-        (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * cbh_flat_lds(ncc, a.t.max_depth, a.t.K, WITH_CALL).wave_dwords, ncc, ka}
-// batches of plain scalars (no int / uint / list / map attribute values): no call, under 96 VGPRs (two records in flight), 5 waves per SIMD
-__global__ CBH_FLAT_ATTRS(5) void cbh_check_flat_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
-  CBH_FLAT_CTX(a, ka, false);
+        (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * (3u * ncc * CBH_BLOCK), ncc, ka}
+// batches of plain scalars (no int / uint / list / map attribute values): no call, ~64 VGPRs, 7-8 waves per SIMD
+__global__ CBH_FLAT_ATTRS(7) void cbh_check_flat_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+  CBH_FLAT_CTX(a, ka);
   flat_body<false>(a, c);
 }
 // any batch: the same walk with the call into the shared evaluator compiled in (4 waves per SIMD)
 __global__ CBH_FLAT_ATTRS(4) void cbh_check_flat_kernel_any(const KernelArgs a, const KernelArgs* __restrict__ ka) {
-  CBH_FLAT_CTX(a, ka, true);
+  CBH_FLAT_CTX(a, ka);
   flat_body<true>(a, c);
 }
 
 // Which kernel decides this batch: a flat one when table (CBH_MF_FLAT), batch shape (<= 4 actions and <= 4 roles per
 // request; `plain_tags`: no attribute value is an int / uint / list / map - selects the variant without the evaluator call)
 // and evaluation mode (not strict) allow it, else the general walk's instantiation for the table class.
-// `threads` = the workgroup size to launch it with; dynamic LDS: the column cache of cbh_check_wave.h, or - `flat` - what
-// cbh_flat_lds_bytes says for the variant (`flat_with_call`).
+// `threads` = the workgroup size to launch it with; dynamic LDS per wave = the column cache, plus - `flat` - the
+// scope-chain scratch (cbh_flat_lds_bytes).
+// dynamic LDS of one wave of the flat kernel: column cache + [max_depth][64] scope indices
+static inline size_t cbh_flat_chain_bytes(u32 table_max_depth) {
+  return (size_t)(table_max_depth < CBH_FLAT_MAX_DEPTH ? table_max_depth : CBH_FLAT_MAX_DEPTH) * CBH_BLOCK * 4;
+}
+// ... and, once per workgroup, the two class tables (one byte per table string each) when they are staged in LDS
+static inline size_t cbh_flat_class_bytes(u32 table_strings) {
+  return table_strings <= CBH_FLAT_LDS_STRINGS ? (((size_t)2 * table_strings + 15) & ~(size_t)15) : 0;
+}
 static inline cbh_check_kernel_fn cbh_pick_kernel(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 max_actions, u32 max_roles, bool plain_tags,
-                                                  u32 eval_flags, u32* threads, bool* flat, bool* flat_with_call) {
-  *flat_with_call = true;
+                                                  u32 eval_flags, u32* threads, bool* flat) {
   *flat = (table_flags & CBH_MF_FLAT) && max_actions <= 4 && max_roles <= 4 && !(eval_flags & CBH_F_STRICT_EVALUATION);
   if (*flat) {
     *threads = CBH_FLAT_THREADS;
-    const bool nocall = plain_tags && (table_flags & CBH_MF_FLAT_CLOSED);
-    *flat_with_call = !nocall;
-    return nocall ? cbh_check_flat_kernel : cbh_check_flat_kernel_any;
+    return (plain_tags && (table_flags & CBH_MF_FLAT_CLOSED)) ? cbh_check_flat_kernel : cbh_check_flat_kernel_any;
   }
   *threads = CBH_BLOCK;
   return cbh_pick_check_kernel(table_flags, n_derived_roles, has_globs, max_actions);

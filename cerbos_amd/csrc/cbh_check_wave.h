@@ -961,7 +961,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
 #ifndef CBH_HOSTSIM
 extern __shared__ __attribute__((aligned(16))) unsigned char cbh_dyn_lds[];
 #else
-static unsigned char cbh_dyn_lds[CBH_CACHE_COLS * CBH_BLOCK * 16 + 16 * CBH_BLOCK * 4 + 2 * 4096 + 16];   // the largest cbh_flat_lds layout (cbh_check_flat.h)
+static unsigned char cbh_dyn_lds[CBH_CACHE_COLS * CBH_BLOCK * 12 + 16 * CBH_BLOCK * 4 + 2 * 4096 + 16];   // + the flat kernel's chain scratch and class tables
 #endif
 __device__ __forceinline__ u32 cached_columns(const KernelArgs* ka) {
   const u32 n = ka->b.n_columns;
@@ -1009,15 +1009,21 @@ __device__ __forceinline__ void leaf_kernel_body(const KernelArgs& a, const Kern
 // of them be resident at once (4 waves per SIMD) instead of running in two rounds.
 #ifndef CBH_HOSTSIM
 #define CBH_FOUR_WAVES __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifdef CBH_GENERIC_WPE   /* lab: occupancy target of the kernels that carry the operand-stack interpreter */
+#define CBH_GENERIC_WAVES __attribute__((amdgpu_waves_per_eu(CBH_GENERIC_WPE, CBH_GENERIC_WPE)))
+#else
+#define CBH_GENERIC_WAVES
+#endif
 #else
 #define CBH_FOUR_WAVES
+#define CBH_GENERIC_WAVES
 #endif
 // The host picks by table - every program a fused leaf / leaf tree?  which features does it use
 // (CBH_FEAT_*: a table without derived roles / role policies / parent roles gets a kernel that does
 // not carry their code or registers) - and by batch (no request with more than 32 actions -> 32-bit
 // action masks).  Name = cbh_check_kernel[_leaf][_a32[_f<feature bits>]]; no feature suffix = everything.
 #define CBH_DEFINE_CHECK_KERNELS(AMT, FEAT, SUF)                                                                              \
-  __global__ __launch_bounds__(CBH_BLOCK) void cbh_check_kernel##SUF(const KernelArgs a, const KernelArgs* __restrict__ ka) { \
+  __global__ __launch_bounds__(CBH_BLOCK) CBH_GENERIC_WAVES void cbh_check_kernel##SUF(const KernelArgs a, const KernelArgs* __restrict__ ka) { \
     generic_kernel_body<AMT, FEAT>(a, ka);                                                                                    \
   }                                                                                                                           \
   __global__ __launch_bounds__(CBH_BLOCK) CBH_FOUR_WAVES void cbh_check_kernel_leaf##SUF(const KernelArgs a, const KernelArgs* __restrict__ ka) { \

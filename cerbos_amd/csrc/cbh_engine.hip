@@ -482,12 +482,9 @@ static void collect_times(Replica* r) {   // after the stream has been synchroni
 // CBH_NO_FLAT=1 (measurement aid): decide with the general walk even where the flat kernel applies
 static u32 pick_flags(u32 eval_flags) { static const bool no_flat = getenv("CBH_NO_FLAT") != nullptr; return no_flat ? (eval_flags | CBH_F_STRICT_EVALUATION) : eval_flags; }
 static u32 nfa_maxw(const TableDev& d) { return std::max(std::max(d.nfa_words[0], d.nfa_words[1]), d.nfa_words[2]); }
-static u32 cached_cols(const BatchDev& d) { return d.n_columns < CBH_CACHE_COLS ? d.n_columns : CBH_CACHE_COLS; }
-// dynamic LDS of a decision-kernel launch: the general walk's column cache (value low / high / tag dword per lane), or the
-// flat kernels' layout (cbh_check_flat.h cbh_flat_lds)
-static size_t launch_lds_bytes(const TableDev& t, const BatchDev& d, bool flat, bool flat_with_call, u32 threads) {
-  if (flat) return cbh_flat_lds_bytes(cached_cols(d), t.max_depth, t.K, flat_with_call, threads / CBH_BLOCK);
-  return (size_t)cached_cols(d) * CBH_BLOCK * 12 * (threads / CBH_BLOCK);
+static size_t check_lds_bytes(const BatchDev& d) {   // column cache: value low / high / tag dword per lane
+  const u32 ncc = d.n_columns < CBH_CACHE_COLS ? d.n_columns : CBH_CACHE_COLS;
+  return (size_t)ncc * CBH_BLOCK * 12;
 }
 
 extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_params* p) {
@@ -532,10 +529,10 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   }
   sl.pending = false;
   if (d.n_requests) {
-    u32 threads = CBH_BLOCK; bool flat = false, with_call = true;
-    const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, maxw != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), b->max_actions, b->max_roles, b->plain_tags, pick_flags(p->flags), &threads, &flat, &with_call);
+    u32 threads = CBH_BLOCK; bool flat = false;
+    const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, maxw != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), b->max_actions, b->max_roles, b->plain_tags, pick_flags(p->flags), &threads, &flat);
     const u32 grid = (d.n_requests + threads - 1) / threads;   // one lane per request
-    const size_t lds = launch_lds_bytes(rep->dev, d, flat, with_call, threads);
+    const size_t lds = (check_lds_bytes(d) + (flat ? cbh_flat_chain_bytes(rep->dev.max_depth) : 0)) * (threads / CBH_BLOCK) + (flat ? cbh_flat_class_bytes(rep->dev.K) : 0);
     if (timed) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, sl.ev[2], sl.ev[3], 0, b->last_args, (const KernelArgs*)b->d_args);
     else hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, b->last_args, (const KernelArgs*)b->d_args);
     sl.pending = timed;
@@ -751,10 +748,10 @@ static void launch_resolve(const Replica* rep, const KernelArgs& ka, const Layou
 static void launch_check(const Replica* rep, KernelArgs ka, const KernelArgs* d_args, u32 lo, u32 hi, const BatchShape& sh, hipStream_t s) {
   if (hi <= lo) return;
   ka.b.req_lo = lo; ka.b.req_hi = hi;
-  u32 threads = CBH_BLOCK; bool flat = false, with_call = true;
-  const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, nfa_maxw(rep->dev) != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), sh.max_actions, sh.max_roles, sh.plain_tags, pick_flags(ka.flags), &threads, &flat, &with_call);
+  u32 threads = CBH_BLOCK; bool flat = false;
+  const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, nfa_maxw(rep->dev) != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), sh.max_actions, sh.max_roles, sh.plain_tags, pick_flags(ka.flags), &threads, &flat);
   const u32 grid = (hi - lo + threads - 1) / threads;   // one lane per request
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), launch_lds_bytes(rep->dev, ka.b, flat, with_call, threads), s, ka, d_args);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), (check_lds_bytes(ka.b) + (flat ? cbh_flat_chain_bytes(rep->dev.max_depth) : 0)) * (threads / CBH_BLOCK) + (flat ? cbh_flat_class_bytes(rep->dev.K) : 0), s, ka, d_args);
 }
 
 // a small batch on one device: everything packed into the pinned staging block.  Two ways across PCIe:

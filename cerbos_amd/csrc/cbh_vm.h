@@ -49,7 +49,6 @@ struct TableDev {
   const CBH_G u32* rows; u32 n_rows;
   const CBH_G u32* rowleaf2;                                // [n_rows][8] fused-leaf records of the rows' derived-role conditions
   const CBH_G u32* drx;                                     // [n_dr][16] derived-role definitions for the flat kernel (CbhDrxField)
-  const CBH_G u32* rowmask;                                 // [n_rows][2] (role classes, action classes) low dwords: the flat kernel's sieve
   const CBH_G u32* rowpat;                                  // [n_rows][8] pattern halves (cbh_blob.h CbhRowPatField)
   const CBH_G u32* rprows; u32 n_rprows;
   const CBH_G u32* pool;

@@ -25,7 +25,7 @@ from .celc import COND_LEAF, COND_LEAFTREE, COND_PC_MASK, LoweringError, Params,
 from .globs import GlobNFA, fix_glob, has_meta
 
 BLOB_MAGIC = 0x31484243
-BLOB_VERSION = 18
+BLOB_VERSION = 17
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
 PAT_ANY = 0x7FFFFFFF     # the lone "*": matches every string, no automaton needed
@@ -35,7 +35,7 @@ ROW_F_ACTION_LIST, ROW_F_ROLE_LIST, ROW_F_ROLE_BY_CLASS, ROW_F_ACTION_BY_CLASS =
 ROW_LEAF = 8           # dwords 8..15: the embedded fused-leaf record
 (PAT_ACTION, PAT_ROLE, PAT_RESOURCE, PAT_COUNTS, PAT_A1, _, PAT_R1, _) = range(8)   # CbhRowPatField
 ROW_F_LEAF_EMBEDDED = 64
-SEC_ACTION_CLASS, SEC_ROWPAT, SEC_ROWLEAF2, SEC_DRX, SEC_ROWMASK = 28, 29, 30, 31, 32
+SEC_ACTION_CLASS, SEC_ROWPAT, SEC_ROWLEAF2, SEC_DRX = 28, 29, 30, 31
 ROW_F_DRLEAF_EMBEDDED = 128
 ROW_F_TREE_EMBEDDED, ROW_F_DRTREE_EMBEDDED = 256, 512   # the slot holds a tree descriptor (_tree_descriptor)
 MF_FLAT_CLOSED = 512
@@ -566,7 +566,6 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         (SEC_ROWPAT, len(pat_cols[0]), row_major(pat_cols, 8)),
         (SEC_ROWLEAF2, len(leaf2_cols[0]), row_major(leaf2_cols, 8)),
         (SEC_DRX, len(drx_cols[0]), row_major(drx_cols, 16)),
-        (SEC_ROWMASK, len(row_cols[0]), row_major([row_cols[ROW_ROLE_CLASSES], row_cols[ROW_ACTION_CLASSES]], 2)),
         (SEC_RPROWS, len(rp_cols[0]), row_major(rp_cols, 4)),
         (SEC_U32POOL, len(pool), u32(pool)),
         (SEC_DR, len(dr_cols[0]), row_major(dr_cols, 4)),
@@ -615,7 +614,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
 
 def _tree_descriptor(strip):
     """The leaf slot of a record whose condition is a tree of classified leaves (celc.py _tree_strip), laid over the
-    fused-leaf record's fields: {ops 0-7, ops 8-15, index of the strip's first leaf in 16-dword units of the tape,
+    fused-leaf record's fields: {ops 0-7, ops 8-15, index of the first leaf record in 8-dword units of the tape,
     ops 16-23, ops 24-31, number of leaves, 0, 7}."""
     packed, n, first = strip
     return [packed[0], packed[1], first, packed[2], packed[3], n, 0, 7]

@@ -366,11 +366,10 @@ class ProgramBuilder:
         self.code.extend(words)
         if self._pending_strip is not None:
             _, packed, leaves = self._pending_strip
-            self.code.extend([OP_RET] * (-len(self.code) % 16))
-            self.tree_strips[pc] = (packed, len(leaves), len(self.code) // 16)
+            self.code.extend([OP_RET] * (-len(self.code) % 8))
+            self.tree_strips[pc] = (packed, len(leaves), len(self.code) // 8)
             for rec in leaves:
-                self.code.extend(_compact_leaf(rec))
-            self.code.extend([OP_RET] * (-len(self.code) % 16))   # the kernel fetches the strip four leaves at a time
+                self.code.extend(rec)
         self._pending_strip = None
         if pc >= COND_PC_MASK:
             raise LoweringError("bytecode tape exceeds 2^30 words")
@@ -386,21 +385,6 @@ class ProgramBuilder:
         if fc.max_depth > MAX_STACK:
             raise LoweringError("condition needs operand stack depth %d (device limit %d)" % (fc.max_depth, MAX_STACK))
         return pc
-
-
-def _compact_leaf(rec):
-    """A classified fused-leaf record {w, a0, a1, RET, ctag, clo, chi, class} as the four dwords of a tree strip
-    (cbh_check_flat.h flat_tree): {class | op << 4 | column a << 12 | column b << 20 | constant tag << 28, k0, k1, k2} with
-    (k0, k1) = the constant's value halves, or for class 6 (k0, k1, k2) = the three string ids."""
-    w, a0, a1, _, ctag, clo, chi, cls = rec
-    a = w >> 8
-    op, ka = a & 0xFF, (a >> 8) & 0xF
-    ca = a1 if (cls == 4 and ka != 3) else a0
-    if cls == 6:
-        return [cls | (op << 4) | (ca << 12) | (a1 << 20), ctag, clo, chi]
-    tag = ctag if cls == 1 else 0
-    assert ca < 256 and a1 < 256 and tag < 16
-    return [cls | (op << 4) | (ca << 12) | ((a1 if cls == 3 else 0) << 20) | (tag << 28), clo, chi, 0]
 
 
 class _Unsupported(Exception):

@@ -81,10 +81,10 @@ extern "C" const char* hostsim_last_error() { return g_err.c_str(); }
 
 static KernelArgs* g_args;
 
-static uint32_t g_max_actions, g_max_roles, g_threads; static bool g_flat, g_plain, g_with_call;   // same kernel selection as cbh_check_resident (cbh_engine.hip)
+static uint32_t g_max_actions, g_max_roles, g_threads; static bool g_flat, g_plain;   // same kernel selection as cbh_check_resident (cbh_engine.hip)
 
 static void fiber_main() {
-  cbh_pick_kernel(g_args->t.flags, g_args->t.n_dr, (g_args->t.nfa_words[0] | g_args->t.nfa_words[1] | g_args->t.nfa_words[2] | (g_args->t.flags & CBH_MF_HAS_ANY_PATTERN)) != 0, g_max_actions, g_max_roles, g_plain, g_args->flags, &g_threads, &g_flat, &g_with_call)(*g_args, g_args);
+  cbh_pick_kernel(g_args->t.flags, g_args->t.n_dr, (g_args->t.nfa_words[0] | g_args->t.nfa_words[1] | g_args->t.nfa_words[2] | (g_args->t.flags & CBH_MF_HAS_ANY_PATTERN)) != 0, g_max_actions, g_max_roles, g_plain, g_args->flags, &g_threads, &g_flat)(*g_args, g_args);
   g_fibers[g_cur].done = true;
   g_fibers[g_cur].waiting = 0;
   swapcontext(&g_fibers[g_cur].ctx, &g_sched);

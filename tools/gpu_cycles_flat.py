@@ -42,19 +42,6 @@ nb = 10
 for k in range(nb):   # by position in the grid: when did these waves start / end
     sl = slice(k * len(pol) // nb, (k + 1) * len(pol) // nb)
     print("  grid decile %d: start %.2f  end %.2f  life %.2f  records %.0f  rounds %.1f" % (k, t0[sl].mean() / 100.0, t1[sl].mean() / 100.0, life[sl].mean(), scp[sl, 2].mean(), scp[sl, 3].mean()))
-for _ in range(2):
-    table.launch(db, now_ns=1, flags=0x300)
-table.synchronize()
-res = table.download(db)
-pol = res.policy.reshape(-1, 4)[::64].astype(np.int64)
-scp = res.scope.reshape(-1, 4)[::64].astype(np.int64)
-print("walk breakdown (cycles per wave)")
-for name, a in (("walk", pol[:, 0]), ("directory", pol[:, 1]), ("sift", pol[:, 2]), ("visit", pol[:, 3]), ("matched+cond", scp[:, 0]),
-                ("n matched", scp[:, 1]), ("n visited", scp[:, 2]), ("rounds", scp[:, 3])):
-    print("%-14s min %8d  p10 %8d  p50 %8d  p90 %8d  max %8d  mean %10.1f" % (name, a.min(), np.percentile(a, 10), np.median(a), np.percentile(a, 90), a.max(), a.mean()))
-long = pol[:, 0] >= np.percentile(pol[:, 0], 99)
-print("the 1%% longest walks: walk %.0f  directory %.0f  sift %.0f  visit %.0f  matched+cond %.0f  n matched %.1f  n visited %.1f  rounds %.1f" % (
-    pol[long, 0].mean(), pol[long, 1].mean(), pol[long, 2].mean(), pol[long, 3].mean(), scp[long, 0].mean(), scp[long, 1].mean(), scp[long, 2].mean(), scp[long, 3].mean()))
 for _ in range(20):
     table.launch(db, now_ns=1, flags=0)
 table.synchronize()
