@@ -3,9 +3,10 @@
 
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on): 1 resource policy + 5 CEL
 conditions, batches of 1M synthetic (principal, resource, action) tuples.  Every rank keeps a ROTATING SET of
-such batches resident in HBM - different seeds, > 1 GB in total, so neither the 32 MiB of L2 nor the 256 MiB
-Infinity Cache can hold what the next launch reads - and a "step" is one sweep of the decision kernels over the
-whole set (one launch per 1M-tuple batch).
+such batches resident in HBM - 32 seeds, each resident four times in its own device buffers: 128 batches, 6.4 GB,
+so neither the 32 MiB of L2 nor the 256 MiB Infinity Cache can hold what the next launch reads - and a "step" is
+one sweep of the decision kernels over the whole set (one launch per 1M-tuple batch; 128 launches, ~2.2 ms: the
+driver's 20 steps keep the GPU busy for ~50 ms).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -65,6 +66,9 @@ def main():
                     help="BASELINE.json config; the metric is quoted on C2 (the default), the others are side measurements")
     ap.add_argument("--requests", type=int, default=None, help="requests per batch (default: the config's size: C1 10k x2, C2 250k x4, C3 1M x4 actions)")
     ap.add_argument("--batches", type=int, default=None, help="resident batches per GPU in the rotating set (default: enough for > 1 GB)")
+    ap.add_argument("--replicas", type=int, default=None,
+                    help="device copies of every seeded batch, each at its own HBM address and launched separately (default: 4 for C2, "
+                         "so that a sweep is 128 launches over 6.4 GB and a 20-step run keeps the GPU busy for ~50 ms; 1 otherwise)")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="requests timed through the CPU oracle (~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the PCIe-inclusive / latency legs (profiling runs)")
@@ -110,7 +114,9 @@ def main():
           "C5": (workloads.c5_policies, workloads.c5_requests, 250_000, 16,
                  "C3 + principal overrides, action globs, role policies, nested map/list CEL (one GPU's 1M of 8M)")}[args.workload]
     n_requests = args.requests or wl[2]
-    n_batches = max(1, args.batches or wl[3])
+    n_seeded = max(1, args.batches or wl[3])
+    replicas = max(1, args.replicas if args.replicas is not None else (4 if args.workload == "C2" and not args.batches else 1))
+    n_batches = n_seeded * replicas   # launches per sweep
     rt = rule_table_from_policies(policies_from_docs(wl[0]()))
     lt = lower_rule_table(rt)   # deterministic: every rank derives the same host-side dictionaries
 
@@ -132,16 +138,20 @@ def main():
     fl = Flattener(lt)
     cr0 = batch0 = None
     dbatches, tuples_per_batch, resident_bytes = [], None, 0
-    for k in range(n_batches):
+    by_replica = [[] for _ in range(replicas)]
+    for k in range(n_seeded):
         cr = wl[1](n_requests, seed=base_seed + 1000 * k + rank)
         batch = cr.to_batch(fl)
         if k == 0:
             cr0, batch0 = cr, batch
             tuples_per_batch = batch.n_tuples
         assert batch.n_tuples == tuples_per_batch
-        resident_bytes += sum(getattr(batch, f).nbytes for f in ("req_u32", "roles", "tuple_action", "col_tag", "col_val", "heap_tag",
-                                                                  "heap_val", "str_off", "str_bytes", "str_flags")) + 10 * batch.n_tuples + 8 * batch.n_requests
-        dbatches.append(table.upload(batch))
+        nbytes = sum(getattr(batch, f).nbytes for f in ("req_u32", "roles", "tuple_action", "col_tag", "col_val", "heap_tag",
+                                                         "heap_val", "str_off", "str_bytes", "str_flags")) + 10 * batch.n_tuples + 8 * batch.n_requests
+        for rep in range(replicas):   # every copy is its own set of device buffers: nothing of one launch serves another
+            resident_bytes += nbytes
+            by_replica[rep].append(table.upload(batch))
+    dbatches = [db for rep in by_replica for db in rep]   # sweep order: all seeds of copy 0, then of copy 1, ...
     tuples = tuples_per_batch
     now = 1_700_000_000_000_000_000
     # the reference always computes effective derived roles (part of CheckOutput): so does every step here
@@ -348,11 +358,12 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 ids + f64 attributes (CEL int64/uint64/double)",
             "data": "synthetic",
-            "config": {"workload": "%s: %s; per GPU a rotating set of %d resident batches x %d tuples (%d requests), one launch "
-                                   "per batch, one step = one sweep of the set (%.2f GB resident: beyond L2 and the 256 MiB "
-                                   "Infinity Cache); seeded per batch and rank"
-                                   % (args.workload, wl[4], n_batches, tuples, n_requests, resident_bytes / 1e9),
-                       "batch_tuples": tuples, "batches_per_step": n_batches,
+            "config": {"workload": "%s: %s; per GPU a rotating set of %d resident batches x %d tuples (%d requests) - %d seeded "
+                                   "batches (seed per batch and rank), each resident %d time(s) in its own device buffers - one "
+                                   "launch per batch, one step = one sweep of the set (%.2f GB resident: beyond L2 and the 256 MiB "
+                                   "Infinity Cache)"
+                                   % (args.workload, wl[4], n_batches, tuples, n_requests, n_seeded, replicas, resident_bytes / 1e9),
+                       "batch_tuples": tuples, "batches_per_step": n_batches, "seeded_batches": n_seeded, "replicas": replicas,
                        "parallelism": "independent request shards per GPU, policy image broadcast once"},
             "resident_decisions_per_s": total / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
