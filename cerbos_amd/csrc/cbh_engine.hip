@@ -324,7 +324,35 @@ extern "C" void* cbh_table_device_ptr(const cbh_table* t) { return t ? t->reps[0
 // ---- batch validation (O(n_requests), both entry points) ---------------------------------------------------
 // Offsets and counts the kernels index device memory with must lie inside the arrays they index.  String ids
 // need no host pass: the kernels only compare them, or bound them before using one as an index.
-struct BatchShape { u32 max_actions = 0, max_roles = 0; bool ascending = true; bool plain_tags = false; };
+struct BatchShape {
+  u32 max_actions = 0, max_roles = 0; bool ascending = true;
+  // Do the attribute columns hold plain scalars only - no int / uint (cross-type numerics) and no list / map (deep
+  // equality)?  Then no classified leaf can need the shared evaluator and the flat kernel without that call decides
+  // the batch (cbh_check_flat.h).  One pass over the tag bytes, made only where the answer selects a kernel and only
+  // when the first launch is being prepared - by then the uploads are enqueued and the pass runs beside them.
+  const uint8_t* tags = nullptr; size_t n_tags = 0;   // nullptr: the answer cannot matter (no flat kernel for this table / shape)
+  mutable std::atomic<int> plain{-1};                 // -1 not looked at yet (racing threads compute the same answer)
+  bool plain_tags() const {
+    int v = plain.load(std::memory_order_relaxed);
+    if (v < 0) {
+      static const bool force_any = getenv("CBH_FLAT_ANY") != nullptr;   // measurement / test aid: always the variant with the call
+      v = (tags && !force_any && !has_int_or_container_tag(tags, n_tags)) ? 1 : 0;
+      plain.store(v, std::memory_order_relaxed);
+    }
+    return v == 1;
+  }
+  // tags 2, 3 (int, uint) and 6, 7 (list, map) are exactly the bytes x with (x & 0xFA) == 0x02: eight at a time
+  static bool has_int_or_container_tag(const uint8_t* p, size_t n) {
+    size_t i = 0; uint64_t hit = 0;
+    for (; i + 8 <= n; i += 8) {
+      uint64_t w; std::memcpy(&w, p + i, 8);
+      const uint64_t z = (w & 0xFAFAFAFAFAFAFAFAull) ^ 0x0202020202020202ull;              // a zero byte where a tag matched
+      hit |= (z - 0x0101010101010101ull) & ~z & 0x8080808080808080ull;
+    }
+    for (; i < n; ++i) hit |= (uint64_t)((p[i] & 0xFAu) == 0x02u);
+    return hit != 0;
+  }
+};
 static int validate_batch(const cbh_table* t, const cbh_batch* in, BatchShape& sh) {
   if (in->n_columns != t->meta[CBH_M_NCOLUMNS]) return fail("cbh_batch.n_columns does not match the table's column schema");
   const size_t NR = in->n_requests;
@@ -350,17 +378,8 @@ static int validate_batch(const cbh_table* t, const cbh_batch* in, BatchShape& s
   if (bad) return fail("cbh_batch: a request's role or action slice lies outside the batch");
   if (in->n_strings && in->str_off[in->n_strings] > in->str_bytes_len) return fail("cbh_batch: string offsets exceed str_bytes_len");
   sh.max_actions = maxa; sh.max_roles = maxr; sh.ascending = asc;
-  // Do the attribute columns hold plain scalars only - no int / uint (cross-type numerics) and no list / map (deep
-  // equality)?  Then no classified leaf can need the shared evaluator and the flat kernel without that call decides
-  // the batch (cbh_check_flat.h).  One pass over the tag bytes, and only where the answer selects a kernel.
-  sh.plain_tags = false;
-  if ((t->meta[CBH_M_FLAGS] & CBH_MF_FLAT) && maxa <= 4 && maxr <= 4) {
-    const uint8_t* tg = in->col_tag; const size_t n = (size_t)in->n_columns * NR;
-    u32 seen = 0;
-    for (size_t i = 0; i < n; ++i) { const u32 x = tg[i]; seen |= (u32)((x - CBH_T_INT) < 2u) | (u32)((x - CBH_T_LIST) < 2u); }
-    static const bool force_any = getenv("CBH_FLAT_ANY") != nullptr;   // measurement / test aid: always the variant with the call
-    sh.plain_tags = seen == 0 && !force_any;
-  }
+  sh.tags = nullptr; sh.n_tags = 0; sh.plain.store(-1, std::memory_order_relaxed);
+  if ((t->meta[CBH_M_FLAGS] & CBH_MF_FLAT) && maxa <= 4 && maxr <= 4) { sh.tags = in->col_tag; sh.n_tags = (size_t)in->n_columns * NR; }
   return 0;
 }
 
@@ -428,7 +447,7 @@ extern "C" int cbh_batch_upload_on(cbh_table* t, uint32_t device_index, const cb
   cbh_device_batch* b = new (std::nothrow) cbh_device_batch();
   if (!b) return fail("out of memory");
   cbh_table_retain(t);
-  b->table = t; b->rep = rep; b->max_actions = sh.max_actions; b->max_roles = sh.max_roles; b->plain_tags = sh.plain_tags;
+  b->table = t; b->rep = rep; b->max_actions = sh.max_actions; b->max_roles = sh.max_roles; b->plain_tags = sh.plain_tags();
   BatchDev& d = b->dev;
   d.n_requests = in->n_requests; d.n_tuples = in->n_tuples; d.n_roles = in->n_roles;
   d.n_columns = in->n_columns; d.n_strings = in->n_strings; d.heap_len = in->heap_len;
@@ -749,7 +768,7 @@ static void launch_check(const Replica* rep, KernelArgs ka, const KernelArgs* d_
   if (hi <= lo) return;
   ka.b.req_lo = lo; ka.b.req_hi = hi;
   u32 threads = CBH_BLOCK; bool flat = false;
-  const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, nfa_maxw(rep->dev) != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), sh.max_actions, sh.max_roles, sh.plain_tags, pick_flags(ka.flags), &threads, &flat);
+  const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, nfa_maxw(rep->dev) != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), sh.max_actions, sh.max_roles, sh.plain_tags(), pick_flags(ka.flags), &threads, &flat);
   const u32 grid = (hi - lo + threads - 1) / threads;   // one lane per request
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), (check_lds_bytes(ka.b) + (flat ? cbh_flat_chain_bytes(rep->dev.max_depth) : 0)) * (threads / CBH_BLOCK) + (flat ? cbh_flat_class_bytes(rep->dev.K) : 0), s, ka, d_args);
 }
