@@ -52,8 +52,9 @@ def _cond(rng, pool=None):
 DRS = ["owner", "peer", "senior", "anyone"]
 
 
-def _store(rng, pool=None, many_rules=False):
+def _store(rng, pool=None, many_rules=False, deep=False):
     docs = []
+    scopes = SCOPES + (["acme.hr.uk.london", "acme.hr.uk.london.e1"] if deep else [])
     with_dr = rng.random() < 0.6
     if with_dr:   # derived roles: definitions with and without conditions, `*` parents, conditions that can raise errors
         docs.append({"apiVersion": API, "derivedRoles": {"name": "flat_roles", "definitions": [
@@ -64,7 +65,7 @@ def _store(rng, pool=None, many_rules=False):
              "condition": {"match": {"expr": str(rng.choice(["P.attr.level >= 3", "R.attr.missing == 1"]))}}},
             {"name": "anyone", "parentRoles": [str(rng.choice(ROLES))]}]}})
     for kind in KINDS:
-        for si, scope in enumerate(SCOPES):
+        for si, scope in enumerate(scopes):
             if scope and rng.random() < 0.2:
                 continue
             rules = []
@@ -92,8 +93,9 @@ def _store(rng, pool=None, many_rules=False):
     return docs
 
 
-def _requests(rng, n, with_lists=False):
+def _requests(rng, n, with_lists=False, deep=False):
     out = []
+    req_scopes = SCOPES + ["acme.hr.uk.london", "zzz"] + (["acme.hr.uk.london.e1", "acme.hr.uk.london.e1.desk4"] if deep else [])
     for i in range(n):
         roles = [str(r) for r in rng.choice(ROLES + ["stranger"], size=int(rng.integers(0, 5)), replace=False)]
         acts = [str(a) for a in rng.choice(ACTIONS + ["nothing"], size=int(rng.integers(0, 5)), replace=False)]
@@ -113,16 +115,16 @@ def _requests(rng, n, with_lists=False):
                     del d[k]
         out.append({"requestId": "q%d" % i, "actions": acts, "principal": {"id": pid, "roles": roles, "attr": pattr},
                     "resource": {"kind": str(rng.choice(KINDS + ["other"])), "id": "r%d" % i, "attr": rattr,
-                                 "scope": str(rng.choice(SCOPES + ["acme.hr.uk.london", "zzz"]))}})
+                                 "scope": str(rng.choice(req_scopes))}})
     return out
 
 
-def _run_seed(seed, make_evaluator, close, with_lists=False, many_rules=False):
+def _run_seed(seed, make_evaluator, close, with_lists=False, many_rules=False, deep=False):
     rng = np.random.default_rng(40_000 + seed)
-    rt = rule_table_from_policies(policies_from_docs(_store(rng, CONDS + CONDS_ANY if with_lists else None, many_rules)))
+    rt = rule_table_from_policies(policies_from_docs(_store(rng, CONDS + CONDS_ANY if with_lists else None, many_rules, deep)))
     lt = lower_rule_table(rt)
     assert lt.stats["flat"] and lt.stats["flat_closed"], "the generator must produce flat tables whose conditions are all inline"
-    inputs = _requests(rng, 200, with_lists)
+    inputs = _requests(rng, 200, with_lists, deep)
     batch = Flattener(lt).flatten(inputs)
     plain = not np.isin(batch.col_tag, (2, 3, 6, 7)).any()   # cbh_engine.hip validate_batch: selects the kernel variant
     assert plain != with_lists
@@ -173,6 +175,14 @@ def test_flat_kernel_large_buckets_vs_oracle(seed):
     _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False, many_rules=True)
 
 
+@pytest.mark.parametrize("seed", range(300, 310))
+def test_flat_kernel_deep_chains_vs_oracle(seed):
+    """Scope chains of up to six entries: derived-role definitions are evaluated in the second climb (tables whose
+    chains have at most four entries evaluate them in the walk itself)."""
+    from test_hostsim_golden import HostSimEvaluator
+    _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False, deep=True)
+
+
 def test_plain_batches_through_the_variant_with_the_call(monkeypatch):
     """CBH_FLAT_ANY=1 sends plain batches through the variant with the call too: both variants decide them alike."""
     from test_hostsim_golden import HostSimEvaluator
@@ -190,6 +200,12 @@ def test_error_cases_do_occur():
 @pytest.mark.parametrize("seed", range(40))
 def test_flat_kernel_on_gpu(seed):
     _run_seed(seed, lambda lt: HipEvaluator(lt, Conf()), True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(300, 310))
+def test_flat_kernel_deep_chains_on_gpu(seed):
+    _run_seed(seed, lambda lt: HipEvaluator(lt, Conf()), True, deep=True)
 
 
 @pytest.mark.gpu
