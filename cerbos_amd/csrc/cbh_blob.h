@@ -233,6 +233,8 @@ enum CbhOp {
   OP_TREE_BEGIN = 55, // arg = kind (0 all, 1 any, 2 none): open a condition tree level
   OP_TREE_ACC = 56,   // arg = kind: pop a child's plain-bool result into the level's accumulator
   OP_TREE_END = 57,   // arg = kind: close the level, push its result
+  OP_HIER = 58,       // arg = predicate (0 ancestorOf, 1 descendentOf, 2 immediateParentOf, 3 immediateChildOf, 4 siblingOf,
+                      // 5 overlaps): pop b, a (dot-delimited strings) -> hierarchy(a).<predicate>(hierarchy(b))
   OP_NOPS
 };
 enum CbhIterKind { IT_ALL = 0, IT_EXISTS = 1, IT_EXISTS_ONE = 2 };

@@ -234,6 +234,14 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
         SETTOP(mk_bool(str_find(c, (u32)x.v, (u32)y.v, op == OP_STARTSWITH ? 0 : (op == OP_ENDSWITH ? 1 : 2))));
         break;
       }
+      case OP_HIER: {   // a = predicate
+        Val y = TOPV(0), x = TOPV(1); --sp;
+        if (x.t == CBH_T_STRING && y.t == CBH_T_STRING) { SETTOP(mk_bool(hier_pred(c, a, (u32)x.v, (u32)y.v))); break; }
+        // hierarchy(list of strings) is valid CEL the device does not evaluate; anything else is "no such overload"
+        if ((x.t == CBH_T_LIST || y.t == CBH_T_LIST) && x.t != CBH_T_ERR && y.t != CBH_T_ERR && live) L.status |= CBH_ST_UNSUPPORTED;
+        ST(sp - 1) = CBH_T_ERR;
+        break;
+      }
       case OP_TIMESTAMP: {
         Val x = TOPV(0);
         if (x.t == CBH_T_TIMESTAMP) break;
@@ -262,6 +270,14 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
         break;
       }
       case OP_NOW: PUSHV(mk(CBH_T_TIMESTAMP, (u64)c.now_ns)); break;
+      case OP_TS_GETTER: {    // a = getter kind; next word = the zone's offset in seconds (resolved at lowering)
+        const i64 off_s = (i64)(int)uload(&code[pc]); ++pc;
+        Val x = TOPV(0);
+        i64 r = 0;
+        if (!ts_getter(x, a, off_s, r)) { ST(sp - 1) = CBH_T_ERR; break; }
+        SETTOP(mk(CBH_T_INT, (u64)r));
+        break;
+      }
       case OP_EDRHAS: {
         if (L.edr_err) PUSHV(mk_err()); else PUSHV(mk_bool((L.edr >> a) & 1));
         break;

@@ -184,6 +184,34 @@ __device__ inline bool str_find(const Ctx& c, u32 hay, u32 needle, int mode /*0 
   return false;
 }
 
+// cerbos.lib.hierarchy predicates (internal/conditions/types/hierarchy.go:259-385) on the two dot-delimited strings
+// themselves: strings.Split(s, ".") never yields a segment with a dot in it, so "the segments of P are the first
+// segments of Q" is "Q starts with P's bytes and continues with '.' or ends there", and segment counts are dot counts.
+__device__ inline bool hier_pred(const Ctx& c, u32 kind, u32 a, u32 b) {
+  gbytes pa, pb; u32 na, nb;
+  str_span(c, a, pa, na); str_span(c, b, pb, nb);
+  if (kind == 1 || kind == 3) { gbytes tp = pa; pa = pb; pb = tp; const u32 tn = na; na = nb; nb = tn; kind -= 1; }   // descendentOf / immediateChildOf: the mirrored question
+  auto dots = [](gbytes p, u32 from, u32 n) { u32 k = 0; for (u32 i = from; i < n; ++i) k += p[i] == '.'; return k; };
+  auto seg_prefix = [](gbytes p, u32 np, gbytes q, u32 nq) {   // P's segments lead Q's
+    if (nq < np) return false;
+    for (u32 i = 0; i < np; ++i) if (p[i] != q[i]) return false;
+    return nq == np || q[np] == '.';
+  };
+  if (kind == 0) return nb > na && seg_prefix(pa, na, pb, nb);                                   // ancestorOf: strictly more segments
+  if (kind == 2) return nb > na && seg_prefix(pa, na, pb, nb) && dots(pb, na + 1, nb) == 0;      // immediateParentOf: exactly one more
+  const u32 da = dots(pa, 0, na), db = dots(pb, 0, nb);
+  if (kind == 4) {   // siblingOf: as many segments, all but the last equal
+    if (da != db) return false;
+    u32 la = na, lb = nb;   // one past the last dot, 0 without one
+    while (la > 0 && pa[la - 1] != '.') --la;
+    while (lb > 0 && pb[lb - 1] != '.') --lb;
+    if (la != lb) return false;
+    for (u32 i = 0; i < la; ++i) if (pa[i] != pb[i]) return false;
+    return true;
+  }
+  return da <= db ? seg_prefix(pa, na, pb, nb) : seg_prefix(pb, nb, pa, na);   // overlaps: the shorter leads the longer
+}
+
 // ---- heap ----------------------------------------------------------------------------
 __device__ __forceinline__ u32 cont_sel(u64 v) { return (u32)(v >> 62); }
 __device__ __forceinline__ u32 cont_off(u64 v) { return (u32)((v >> 32) & 0x3FFFFFFFu); }
@@ -300,6 +328,52 @@ __device__ inline i64 days_from_civil(i64 y, u32 m, u32 d) {
   const u32 doy = (153 * (m > 2 ? m - 3 : m + 9) + 2) / 5 + d - 1;
   const u32 doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
   return era * 146097 + (i64)doe - 719468;
+}
+// Getters of cel-go's timestamp.go / duration.go.  kind: 0 getFullYear, 1 getMonth (0-based), 2 getDayOfYear (0-based),
+// 3 getDayOfMonth (0-based), 4 getDate, 5 getDayOfWeek (Sunday = 0), 6 getHours, 7 getMinutes, 8 getSeconds,
+// 9 getMilliseconds.  A timestamp is read in the fixed zone `off_s` seconds east of UTC; a duration has the last four
+// only: the whole duration in that unit, truncated towards zero (Go's float conversion of d.Hours() etc.).
+__device__ inline bool ts_getter(Val x, u32 kind, i64 off_s, i64& out) {
+  if (x.t == CBH_T_DURATION) {
+    const i64 d = (i64)x.v;
+    switch (kind) {
+      case 6: out = d / 3600000000000ll; return true;
+      case 7: out = d / 60000000000ll; return true;
+      case 8: out = d / 1000000000ll; return true;
+      case 9: out = d / 1000000ll; return true;
+      default: return false;   // no such overload
+    }
+  }
+  if (x.t != CBH_T_TIMESTAMP || kind > 9) return false;
+  i64 t;
+  if (__builtin_add_overflow((i64)x.v, off_s * 1000000000ll, &t)) return false;
+  i64 secs = t / 1000000000ll, nsec = t % 1000000000ll;
+  if (nsec < 0) { nsec += 1000000000ll; --secs; }
+  i64 days = secs / 86400, sod = secs % 86400;
+  if (sod < 0) { sod += 86400; --days; }
+  if (kind >= 6) {
+    out = kind == 6 ? sod / 3600 : kind == 7 ? (sod / 60) % 60 : kind == 8 ? sod % 60 : nsec / 1000000ll;
+    return true;
+  }
+  if (kind == 5) { i64 w = (days + 4) % 7; out = w < 0 ? w + 7 : w; return true; }   // 1970-01-01 was a Thursday
+  // civil date from days since the epoch (the inverse of days_from_civil)
+  const i64 z = days + 719468;
+  const i64 era = (z >= 0 ? z : z - 146096) / 146097;
+  const u32 doe = (u32)(z - era * 146097);
+  const u32 yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+  const u32 doy = doe - (365 * yoe + yoe / 4 - yoe / 100);   // from March 1st
+  const u32 mp = (5 * doy + 2) / 153;
+  const u32 d = doy - (153 * mp + 2) / 5 + 1;
+  const u32 m = mp < 10 ? mp + 3 : mp - 9;
+  const i64 y = (i64)yoe + era * 400 + (m <= 2);
+  switch (kind) {
+    case 0: out = y; break;
+    case 1: out = (i64)m - 1; break;
+    case 2: out = days - days_from_civil(y, 1, 1); break;
+    case 3: out = (i64)d - 1; break;
+    default: out = d; break;   // 4 getDate
+  }
+  return true;
 }
 __device__ __forceinline__ bool dig(u8 ch) { return ch >= '0' && ch <= '9'; }
 

@@ -25,7 +25,7 @@ from ..cel import parser as celparser
  OP_EDRHAS, OP_LOCAL, OP_ITER_BEGIN, OP_ITER_NEXT, OP_ITER_ACC, OP_ITER_END, OP_TOINT,
  OP_TODOUBLE, OP_TOSTRING_UNSUPPORTED, OP_INIPRANGE, OP_UNSUPPORTED, OP_TS_GETTER,
  OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN, OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC,
- OP_TREE_END) = range(58)
+ OP_TREE_END, OP_HIER) = range(59)
 
 TREE_KINDS = {"all": 0, "any": 1, "none": 2}
 COND_LEAF = 0x80000000
@@ -80,7 +80,7 @@ _R_FIELDS = {"id": RQ_S_RESOURCE_ID, "kind": RQ_S_KIND, "scope": RQ_S_R_SCOPE,
 _ID_ONLY_OPS = frozenset([OP_RET, OP_CONST, OP_COL, OP_HASCOL, OP_REQSTR, OP_ROLES, OP_SELECT, OP_HASSEL, OP_INDEX, OP_EQ, OP_NE,
                           OP_IN, OP_NOT, OP_JF, OP_JT, OP_AND, OP_OR, OP_JTERN, OP_JMP, OP_POP, OP_LEAF, OP_EDRHAS, OP_LOCAL,
                           OP_ITER_BEGIN, OP_ITER_NEXT, OP_ITER_ACC, OP_ITER_END, OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN,
-                          OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC, OP_TREE_END, OP_UNSUPPORTED])
+                          OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC, OP_TREE_END, OP_UNSUPPORTED, OP_TS_GETTER])
 
 
 class LoweringError(ValueError):
@@ -389,6 +389,35 @@ class ProgramBuilder:
 
 class _Unsupported(Exception):
     pass
+
+
+# OP_HIER kinds (cbh_vm.h hier_pred)
+_HIER_PREDICATES = {"ancestorOf": 0, "descendentOf": 1, "immediateParentOf": 2, "immediateChildOf": 3, "siblingOf": 4, "overlaps": 5}
+
+# OP_TS_GETTER kinds (cbh_interp.h): what cel-go's getters return for a timestamp (and, for the last four, a duration)
+_TS_GETTERS = {"getFullYear": 0, "getMonth": 1, "getDayOfYear": 2, "getDayOfMonth": 3, "getDate": 4, "getDayOfWeek": 5,
+               "getHours": 6, "getMinutes": 7, "getSeconds": 8, "getMilliseconds": 9}
+
+
+def _fixed_zone_seconds(ast):
+    """Seconds east of UTC of a constant time-zone argument cel-go reads without its zone database (timestamp.go
+    timeZone(): a string with a ':' is "[+-]hh:mm"), or None.  "UTC" and "" load as UTC."""
+    if ast[0] != "lit" or ast[1] != "string":
+        return None
+    tz = ast[2]
+    if tz in ("UTC", ""):
+        return 0
+    if ":" not in tz:
+        return None
+    hh, _, mm = tz.partition(":")
+    try:
+        h, m = int(hh), int(mm)
+    except ValueError:
+        return None
+    if not (-23 <= h <= 23 and 0 <= m <= 59):
+        return None
+    neg = hh.strip().startswith("-")
+    return (-1 if neg else 1) * (abs(h) * 3600 + m * 60)
 
 
 def _int_lit_as_double(ast):
@@ -729,6 +758,27 @@ class _FuncCompiler:
                 return unary(OP_TIMESINCE)
             if name == "now" and n == 0:
                 return self.emit(OP_NOW, 0, +1)
+            if name in _HIER_PREDICATES and n == 2 and all(
+                    x[0] == "call" and x[1] == "hierarchy" and x[2] is None and len(x[3]) == 1 for x in (target, args[0])):
+                # hierarchy(a).ancestorOf(hierarchy(b)) and its siblings (internal/conditions/types/hierarchy.go:259-385)
+                # over the two dot-delimited STRINGS: the predicates only compare segment prefixes, no list is built.
+                # hierarchy(list), a custom delimiter, indexing, size and commonAncestors stay outside the subset.
+                self._expr(target[3][0])
+                self._expr(args[0][3][0])
+                return self.emit(OP_HIER, _HIER_PREDICATES[name], -1)
+            if name in _TS_GETTERS and target is not None and n in (1, 2):
+                # timestamp / duration getters (cel-go timestamp.go / duration.go).  The time zone argument is resolved
+                # here: absent or "UTC" = no offset, "+hh:mm" / "-hh:mm" = a fixed offset; an IANA name needs the
+                # zone database and a computed one cannot be resolved at lowering time - both outside the subset.
+                off = 0
+                if n == 2:
+                    off = _fixed_zone_seconds(args[0])
+                    if off is None:
+                        return self.unsupported("function %s/%d with a named or computed time zone" % (name, n))
+                self._expr(target)
+                self.emit(OP_TS_GETTER, _TS_GETTERS[name])
+                self.word(off & 0xFFFFFFFF)
+                return None
             if name == "int" and n == 1 and target is None:
                 return unary(OP_TOINT)
             if name == "double" and n == 1 and target is None:

@@ -140,6 +140,8 @@ def type_name(v):
         return "google.protobuf.Timestamp"
     if isinstance(v, Duration):
         return "google.protobuf.Duration"
+    if isinstance(v, Hierarchy):
+        return "cerbos.lib.hierarchy"
     return type(v).__name__
 
 
@@ -173,6 +175,8 @@ def cel_equal(a, b):
         return _num_cmp(a, b) == 0
     if a is None or b is None:
         return a is None and b is None
+    if isinstance(a, Hierarchy) or isinstance(b, Hierarchy):   # Hierarchy.Equal (hierarchy.go:222-238)
+        return isinstance(a, Hierarchy) and isinstance(b, Hierarchy) and tuple(a) == tuple(b)
     if isinstance(a, bool) or isinstance(b, bool):
         return isinstance(a, bool) and isinstance(b, bool) and a == b
     if isinstance(a, str):
@@ -483,6 +487,12 @@ def _has(v, field):
 
 
 def _index(v, i):
+    if isinstance(v, Hierarchy):   # Hierarchy.Get (hierarchy.go:240-251)
+        if isinstance(i, bool) or not isinstance(i, int) or is_uint(i):
+            raise CelError("unsupported index type '%s'" % type_name(i))
+        if i < 0 or i >= len(v):
+            raise CelError("index out of range")
+        return v[i]
     if isinstance(v, list):
         if isinstance(i, bool) or not is_num(i):
             raise no_such_overload()
@@ -849,9 +859,64 @@ def _call(n, env, loc):
 
 
 def _f_size(env, v):
-    if isinstance(v, (str, list, dict, bytes)):
+    if isinstance(v, (str, list, dict, bytes, Hierarchy)):
         return len(v)
     raise no_such_overload()
+
+
+# ---- cerbos.lib.hierarchy (internal/conditions/types/hierarchy.go) --------------------------------------------
+class Hierarchy(tuple):
+    """hierarchy.go:160: the segments of a delimited path."""
+
+
+def _f_hierarchy(env, v, delim=None):
+    # unaryHierarchyFnImpl / binaryHierarchyFnImpl (hierarchy.go:130-158)
+    if delim is not None:
+        return Hierarchy(_need(v, str).split(_need(delim, str)))
+    if isinstance(v, Hierarchy):
+        return v
+    if isinstance(v, str):
+        return Hierarchy(v.split("."))
+    if isinstance(v, list):
+        if not all(isinstance(x, str) for x in v):
+            raise CelError("failed to convert list to string slice")
+        return Hierarchy(v)
+    raise no_such_overload()
+
+
+def _hier(v):   # toHierarchy (hierarchy.go:400-407)
+    if not isinstance(v, Hierarchy):
+        raise no_such_overload()
+    return v
+
+
+def _h_ancestor_of(h, child):          # hierarchy.go:259-276
+    return len(child) > len(h) and child[:len(h)] == h
+
+
+def _h_immediate_parent_of(h, child):  # hierarchy.go:326-343
+    return len(child) == len(h) + 1 and child[:len(h)] == h
+
+
+def _h_sibling_of(h, other):           # hierarchy.go:345-362
+    return len(other) == len(h) and h[:len(h) - 1] == other[:len(h) - 1]
+
+
+def _h_overlaps(h, other):             # hierarchy.go:364-385
+    short, long_ = (other, h) if len(other) < len(h) else (h, other)
+    return long_[:len(short)] == short
+
+
+def _h_common_ancestors(h, other):     # hierarchy.go:278-306
+    short, long_ = (other, h) if len(other) < len(h) else (h, other)
+    if len(long_) == len(short):
+        long_, short = long_[:-1], short[:-1]
+    out = []
+    for a, b in zip(short, long_):
+        if a != b:
+            break
+        out.append(a)
+    return Hierarchy(out)
 
 
 def _f_int(env, v):
@@ -1169,9 +1234,17 @@ _GLOBAL_FUNCS = {
     "contains": lambda env, s, p: _need(p, str) in _need(s, str),
     "matches": _m_matches,
     "inIPAddrRange": _m_in_ip_range,
+    "hierarchy": _f_hierarchy,
 }
 
 _METHODS = {
+    "ancestorOf": lambda env, h, o: _h_ancestor_of(_hier(h), _hier(o)),
+    "descendentOf": lambda env, h, o: _h_ancestor_of(_hier(o), _hier(h)),
+    "immediateParentOf": lambda env, h, o: _h_immediate_parent_of(_hier(h), _hier(o)),
+    "immediateChildOf": lambda env, h, o: _h_immediate_parent_of(_hier(o), _hier(h)),
+    "siblingOf": lambda env, h, o: _h_sibling_of(_hier(h), _hier(o)),
+    "overlaps": lambda env, h, o: _h_overlaps(_hier(h), _hier(o)),
+    "commonAncestors": lambda env, h, o: _h_common_ancestors(_hier(h), _hier(o)),
     "size": _f_size,
     "startsWith": lambda env, s, p: _need(s, str).startswith(_need(p, str)),
     "endsWith": lambda env, s, p: _need(s, str).endswith(_need(p, str)),
