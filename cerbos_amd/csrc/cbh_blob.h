@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define CBH_BLOB_MAGIC 0x31484243u /* "CBH1" */
-#define CBH_BLOB_VERSION 17u
+#define CBH_BLOB_VERSION 18u
 
 struct CbhBlobHeader {  // 32 bytes
   uint32_t magic;
@@ -53,6 +53,8 @@ enum CbhSectionId {
   CBH_SEC_ROLE_CLASS = 25, // u8[K] class (0..61) of a string that is a literal rule role, 63 = any other string
   CBH_SEC_ROWLEAF2 = 30,     // u32[n_rows][8]  copy of the fused-leaf record of a rule's DERIVED-ROLE condition (CBH_ROW_F_DRLEAF_EMBEDDED)
   CBH_SEC_DRX = 31,          // u32[n_dr][16]   derived-role definitions for the flat kernel (CbhDrxField order)
+  CBH_SEC_REGEX = 33,        // u32[]           DFA tables of constant `matches` patterns, back to back: {n_states, n_classes,
+                             //                 classmap (256 bytes in 64 words), flags[n_states], trans[n_states][n_classes]}
   CBH_SEC_ROWPAT = 29,       // u32[n_rows][8]  pattern halves of the rule records (CbhRowPatField order)
   CBH_SEC_ACTION_CLASS = 28, // u8[K] class (0..61) of a string that is a literal rule action of a resource policy, 63 = any other string
   CBH_SEC_HOST_NAMES = 27,   // host only: {u32 n, {u16 len, bytes}*} policy keys (CBH_P_TABLE ids), then the same for derived-role names
@@ -233,6 +235,7 @@ enum CbhOp {
   OP_TREE_BEGIN = 55, // arg = kind (0 all, 1 any, 2 none): open a condition tree level
   OP_TREE_ACC = 56,   // arg = kind: pop a child's plain-bool result into the level's accumulator
   OP_TREE_END = 57,   // arg = kind: close the level, push its result
+  OP_MATCHES = 59,    // next word = offset of the pattern's tables in CBH_SEC_REGEX: TOS (string) -> RE2 MatchString
   OP_HIER = 58,       // arg = predicate (0 ancestorOf, 1 descendentOf, 2 immediateParentOf, 3 immediateChildOf, 4 siblingOf,
                       // 5 overlaps): pop b, a (dot-delimited strings) -> hierarchy(a).<predicate>(hierarchy(b))
   OP_NOPS

@@ -42,6 +42,8 @@ static inline const char* cbh_parse_image(TableDev& d, std::vector<uint32_t>& me
   d.rows = (const u32*)dptr(CBH_SEC_ROWS); d.n_rows = m[CBH_M_NROWS];
   d.rowleaf2 = (const u32*)dptr(CBH_SEC_ROWLEAF2); d.drx = (const u32*)dptr(CBH_SEC_DRX);
   if ((m[CBH_M_NROWS] && !d.rowleaf2) || (m[CBH_M_NDR] && !d.drx)) return ("blob is missing the flat-kernel sections");
+  d.regex = (const u32*)dptr(CBH_SEC_REGEX);
+  if (!d.regex) return ("blob is missing the regex section");
   d.rowpat = (const u32*)dptr(CBH_SEC_ROWPAT);
   if (m[CBH_M_NROWS] && !d.rowpat) return ("blob is missing the row pattern section");
   d.rprows = (const u32*)dptr(CBH_SEC_RPROWS); d.n_rprows = m[CBH_M_NRPROWS];

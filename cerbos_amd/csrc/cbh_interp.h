@@ -234,6 +234,13 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
         SETTOP(mk_bool(str_find(c, (u32)x.v, (u32)y.v, op == OP_STARTSWITH ? 0 : (op == OP_ENDSWITH ? 1 : 2))));
         break;
       }
+      case OP_MATCHES: {   // next word = the pattern's tables
+        const u32 off = uload(&code[pc]); ++pc;
+        Val x = TOPV(0);
+        if (x.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
+        SETTOP(mk_bool(regex_match(c, off, (u32)x.v)));
+        break;
+      }
       case OP_HIER: {   // a = predicate
         Val y = TOPV(0), x = TOPV(1); --sp;
         if (x.t == CBH_T_STRING && y.t == CBH_T_STRING) { SETTOP(mk_bool(hier_pred(c, a, (u32)x.v, (u32)y.v))); break; }

@@ -49,6 +49,7 @@ struct TableDev {
   const CBH_G u32* rows; u32 n_rows;
   const CBH_G u32* rowleaf2;                                // [n_rows][8] fused-leaf records of the rows' derived-role conditions
   const CBH_G u32* drx;                                     // [n_dr][16] derived-role definitions for the flat kernel (CbhDrxField)
+  const CBH_G u32* regex;                                   // CBH_SEC_REGEX: DFA tables of constant `matches` patterns
   const CBH_G u32* rowpat;                                  // [n_rows][8] pattern halves (cbh_blob.h CbhRowPatField)
   const CBH_G u32* rprows; u32 n_rprows;
   const CBH_G u32* pool;
@@ -182,6 +183,27 @@ __device__ inline bool str_find(const Ctx& c, u32 hay, u32 needle, int mode /*0 
     if (j == nn) return true;
   }
   return false;
+}
+
+// RE2 MatchString with the pattern's DFA (cerbos_amd/lower/regex.py, layout in cbh_blob.h CBH_SEC_REGEX): one table
+// lookup per byte; flags bit 0 = a match is already certain, bit 1 = a match if the text ends in this state.
+__device__ inline bool regex_match(const Ctx& c, u32 off, u32 sid) {
+  const CBH_G u32* r = c.t.regex + off;
+  const u32 n_states = r[0], n_cls = r[1];
+  const CBH_G u32* classmap = r + 2;
+  const CBH_G u32* flags = r + 66;
+  const CBH_G u32* trans = flags + n_states;
+  gbytes p; u32 n;
+  str_span(c, sid, p, n);
+  u32 s = 0;
+  if (flags[0] & 1u) return true;
+  for (u32 i = 0; i < n; ++i) {
+    const u32 b = p[i];
+    const u32 cls = (classmap[b >> 2] >> ((b & 3u) * 8u)) & 0xFFu;
+    s = trans[s * n_cls + cls];
+    if (flags[s] & 1u) return true;
+  }
+  return (flags[s] & 2u) != 0;
 }
 
 // cerbos.lib.hierarchy predicates (internal/conditions/types/hierarchy.go:259-385) on the two dot-delimited strings

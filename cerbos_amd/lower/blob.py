@@ -25,7 +25,7 @@ from .celc import COND_LEAF, COND_LEAFTREE, COND_PC_MASK, LoweringError, Params,
 from .globs import GlobNFA, fix_glob, has_meta
 
 BLOB_MAGIC = 0x31484243
-BLOB_VERSION = 17
+BLOB_VERSION = 18
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
 PAT_ANY = 0x7FFFFFFF     # the lone "*": matches every string, no automaton needed
@@ -35,7 +35,7 @@ ROW_F_ACTION_LIST, ROW_F_ROLE_LIST, ROW_F_ROLE_BY_CLASS, ROW_F_ACTION_BY_CLASS =
 ROW_LEAF = 8           # dwords 8..15: the embedded fused-leaf record
 (PAT_ACTION, PAT_ROLE, PAT_RESOURCE, PAT_COUNTS, PAT_A1, _, PAT_R1, _) = range(8)   # CbhRowPatField
 ROW_F_LEAF_EMBEDDED = 64
-SEC_ACTION_CLASS, SEC_ROWPAT, SEC_ROWLEAF2, SEC_DRX = 28, 29, 30, 31
+SEC_ACTION_CLASS, SEC_ROWPAT, SEC_ROWLEAF2, SEC_DRX, SEC_REGEX = 28, 29, 30, 31, 33
 ROW_F_DRLEAF_EMBEDDED = 128
 ROW_F_TREE_EMBEDDED, ROW_F_DRTREE_EMBEDDED = 256, 512   # the slot holds a tree descriptor (_tree_descriptor)
 MF_FLAT_CLOSED = 512
@@ -566,6 +566,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         (SEC_ROWPAT, len(pat_cols[0]), row_major(pat_cols, 8)),
         (SEC_ROWLEAF2, len(leaf2_cols[0]), row_major(leaf2_cols, 8)),
         (SEC_DRX, len(drx_cols[0]), row_major(drx_cols, 16)),
+        (SEC_REGEX, len(pb.regex_words), u32(pb.regex_words)),   # DFA tables of constant `matches` patterns (lower/regex.py)
         (SEC_RPROWS, len(rp_cols[0]), row_major(rp_cols, 4)),
         (SEC_U32POOL, len(pool), u32(pool)),
         (SEC_DR, len(dr_cols[0]), row_major(dr_cols, 4)),

@@ -16,6 +16,7 @@ from __future__ import annotations
 import struct
 
 from ..cel import parser as celparser
+from . import regex
 
 # keep in sync with cbh_blob.h
 (OP_RET, OP_CONST, OP_COL, OP_HASCOL, OP_REQSTR, OP_ROLES, OP_SELECT, OP_HASSEL, OP_INDEX,
@@ -25,7 +26,7 @@ from ..cel import parser as celparser
  OP_EDRHAS, OP_LOCAL, OP_ITER_BEGIN, OP_ITER_NEXT, OP_ITER_ACC, OP_ITER_END, OP_TOINT,
  OP_TODOUBLE, OP_TOSTRING_UNSUPPORTED, OP_INIPRANGE, OP_UNSUPPORTED, OP_TS_GETTER,
  OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN, OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC,
- OP_TREE_END, OP_HIER) = range(59)
+ OP_TREE_END, OP_HIER, OP_MATCHES) = range(60)
 
 TREE_KINDS = {"all": 0, "any": 1, "none": 2}
 COND_LEAF = 0x80000000
@@ -197,6 +198,8 @@ class ProgramBuilder:
         self.theap_val = []
         self.columns = {}                  # (root, keys) -> column index
         self.programs = {}                 # dedup key -> entry pc
+        self.regex_words = []              # CBH_SEC_REGEX: the DFA tables of constant `matches` patterns, back to back
+        self.regex_index = {}              # pattern -> offset of its tables in regex_words
         self.tree_strips = {}              # entry pc of a leaf tree -> (packed ops, n leaves, strip index / 8): _tree_strip
         self._pending_strip = None
         self.dr_names = {}                 # derived role name -> bit
@@ -293,6 +296,15 @@ class ProgramBuilder:
         if eqne and ((ka == 3 and kb == 4) or (ka == 4 and kb == 3)):
             return 4
         return 0
+
+    def regex(self, pattern):
+        """Offset (in u32) of the DFA tables of `pattern` in CBH_SEC_REGEX; compiled once per distinct pattern."""
+        off = self.regex_index.get(pattern)
+        if off is None:
+            words = regex.compile_regex(pattern).words()
+            off = self.regex_index[pattern] = len(self.regex_words)
+            self.regex_words.extend(words)
+        return off
 
     def _leaf_record(self, w3):
         """[OP_LEAF_BIN word, a0, a1] -> the 8-dword fused-leaf record {w, a0, a1, RET, ctag, clo, chi, class}."""
@@ -758,6 +770,20 @@ class _FuncCompiler:
                 return unary(OP_TIMESINCE)
             if name == "now" and n == 0:
                 return self.emit(OP_NOW, 0, +1)
+            if name == "matches" and n == 2:
+                # cel-go `matches` = RE2 MatchString (an unanchored search).  A pattern that is a constant of the policy
+                # is compiled to a byte-level DFA here (regex.py); the device walks one table lookup per byte.
+                pat = allargs[1]
+                if pat[0] != "lit" or pat[1] != "string":
+                    return self.unsupported("function matches/2 with a computed pattern")
+                try:
+                    off = self.pb.regex(pat[2])
+                except (regex.Unsupported, regex.Invalid) as e:
+                    return self.unsupported("function matches/2: %s" % e)
+                self._expr(allargs[0])
+                self.emit(OP_MATCHES)
+                self.word(off)
+                return None
             if name in _HIER_PREDICATES and n == 2 and all(
                     x[0] == "call" and x[1] == "hierarchy" and x[2] is None and len(x[3]) == 1 for x in (target, args[0])):
                 # hierarchy(a).ancestorOf(hierarchy(b)) and its siblings (internal/conditions/types/hierarchy.go:259-385)

@@ -804,9 +804,50 @@ def _format(fmt, args):
     return "".join(out)
 
 
+def _re2_to_python(p):
+    """The RE2 dialect (Go regexp, what cel-go's `matches` compiles) written for Python's `re` where the two read the
+    same text differently: `$` is the end of the text only (Python also stops before a trailing newline), `\\z` is
+    Python's `\\Z`, `\\s` is [\\t\\n\\f\\r ] (Python adds \\v), a `{` that does not open `{n}`, `{n,}` or `{n,m}` is a
+    literal.  With re.ASCII for \\d \\w (RE2's are ASCII-only)."""
+    out, i, in_class = [], 0, False
+    while i < len(p):
+        c = p[i]
+        if c == "\\" and i + 1 < len(p):
+            nx = p[i + 1]
+            if nx == "z" and not in_class:
+                out.append("\\Z")
+            elif nx == "s":
+                out.append("\\t\\n\\f\\r " if in_class else "[\\t\\n\\f\\r ]")
+            elif nx == "S" and not in_class:
+                out.append("[^\\t\\n\\f\\r ]")
+            else:
+                out.append(c + nx)
+            i += 2
+            continue
+        if c == "[" and not in_class:
+            in_class = True
+            out.append(c)
+            i += 1
+            if i < len(p) and p[i] == "^":
+                out.append("^"); i += 1
+            if i < len(p) and p[i] == "]":
+                out.append("\\]"); i += 1
+            continue
+        if c == "]" and in_class:
+            in_class = False
+        if c == "$" and not in_class:
+            out.append("\\Z")
+        elif c == "{" and not in_class and not re.match(r"\{\d+(,\d*)?\}", p[i:]):
+            out.append("\\{")
+        else:
+            out.append(c)
+        i += 1
+    return "".join(out)
+
+
 def _re(pattern):
     try:
-        return re.compile(pattern)
+        return re.compile(_re2_to_python(pattern), re.ASCII)
     except re.error as e:
         raise CelError("invalid regex: %s" % e)
 
