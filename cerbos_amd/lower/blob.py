@@ -182,6 +182,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
     res_buckets, prin_buckets, rp_buckets = {}, {}, {}
     res_exists, pp_exists, rp_res = set(), set(), {}
     rp_evalkeys = {}
+    rp_history_dependent = set()   # ids of role-policy rules whose cached condition outcome depends on evaluation history
     for r in rt["rules"]:
         ver, scope = r["version"], r["scope"]
         if r["allow_actions"] is not None:
@@ -191,14 +192,13 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
             # leaves the resource out (ruletable.go:445-455), so rules of one role policy for different resources
             # share it; the per-request conditionCache (check.go:186, 324) can only confuse them when both rules
             # match the SAME resource kind, i.e. when one of the two resource names is a glob.
+            # Such rules are not refused wholesale: their conditions become UNSUPPORTED programs (the requests that
+            # reach them are flagged for the caller's own engine), the rest of the table serves as usual.
             if r["condition"] is not None:
-                for o_res, o_cond in rp_evalkeys.setdefault(r["evaluation_key"], []):
-                    if o_cond != r["condition"] and ("*" in o_res or "*" in r["resource"]):
-                        raise LoweringError(
-                            "role policy %s has rules for overlapping resource globs that share an evaluation key but "
-                            "not a condition; the reference's result then depends on evaluation history "
-                            "(ruletable.go:445-455)" % namer.policy_key_from_fqn(r["origin_fqn"]))
-                rp_evalkeys[r["evaluation_key"]].append((r["resource"], r["condition"]))
+                for o in rp_evalkeys.setdefault(r["evaluation_key"], []):
+                    if o["condition"] != r["condition"] and ("*" in o["resource"] or "*" in r["resource"]):
+                        rp_history_dependent.add(o["id"]); rp_history_dependent.add(r["id"])
+                rp_evalkeys[r["evaluation_key"]].append(r)
         elif r["policy_kind"] == KIND_RESOURCE:
             if "*" in r["resource"]:
                 raise LoweringError("resource policy with a wildcard resource name is not supported: %s" % r["resource"])
@@ -225,11 +225,12 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
     def row_programs(r, principal_policy):
         params = Params(r["params"]["constants"], r["params"]["ordered_variables"], globals_) if r["params"] else Params(None, None, globals_)
         if principal_policy and _cond_uses_runtime(r["condition"], params):
-            raise LoweringError(
-                "principal policy %s reads runtime.effectiveDerivedRoles: in the reference its value depends on the "
-                "previously evaluated action (check.go:281), which a per-tuple evaluation cannot reproduce"
-                % namer.policy_key_from_fqn(r["origin_fqn"]))
-        cond = pb.condition_program(r["condition"], params) if r["condition"] is not None else NONE
+            # in the reference the value then depends on the previously evaluated action (check.go:281), which a
+            # per-tuple evaluation cannot reproduce: whoever reaches this rule is flagged, not answered
+            cond = pb.unsupported_program(namer.policy_key_from_fqn(r["origin_fqn"]),
+                                          "principal policy condition reads runtime.effectiveDerivedRoles (history dependent, check.go:281)")
+        else:
+            cond = pb.condition_program(r["condition"], params) if r["condition"] is not None else NONE
         drc = NONE
         if r["derived_role_condition"] is not None:
             dp = r["derived_role_params"] or {"constants": {}, "ordered_variables": []}
@@ -346,7 +347,12 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
             rp_cols[1].append(len(pool))
             rp_cols[2].append(len(r["allow_actions"]))
             pool.extend(allow_action_ref(a) for a in r["allow_actions"])
-            rp_cols[3].append(pb.condition_program(r["condition"], params) if r["condition"] is not None else NONE)
+            if r["id"] in rp_history_dependent:
+                rp_cols[3].append(pb.unsupported_program(namer.policy_key_from_fqn(r["origin_fqn"]),
+                                                         "role-policy rules for overlapping resource globs share an evaluation key but "
+                                                         "not a condition (history dependent, ruletable.go:445-455)"))
+            else:
+                rp_cols[3].append(pb.condition_program(r["condition"], params) if r["condition"] is not None else NONE)
         pid = policy_id(namer.role_policy_fqn(role, ver, scope))
         entries.append((B_ROLEPOL, sid(ver), lt.scope_index[scope], sid(role), begin, len(rows), pid, 0))
     for (ver, scope), pats in sorted(rp_res.items()):

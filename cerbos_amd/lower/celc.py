@@ -297,6 +297,20 @@ class ProgramBuilder:
             return 4
         return 0
 
+    def unsupported_program(self, text, reason):
+        """A condition program that marks whoever evaluates it CBH_ST_UNSUPPORTED (the caller's own engine must decide
+        that input): for rules the device cannot evaluate faithfully, so that the rest of the table still serves."""
+        key = ("__unsupported__", text, reason)
+        pc = self.programs.get(key)
+        if pc is None:
+            self.unsupported.append((text, reason))
+            pc = len(self.code)
+            self.code.extend([OP_UNSUPPORTED, OP_LEAF, OP_RET])
+            self.programs[key] = pc
+            self.has_generic = True
+            self.max_stack = max(self.max_stack, 1)
+        return pc
+
     def regex(self, pattern):
         """Offset (in u32) of the DFA tables of `pattern` in CBH_SEC_REGEX; compiled once per distinct pattern."""
         off = self.regex_index.get(pattern)
@@ -825,6 +839,12 @@ class _FuncCompiler:
             if name == "contains":   # sets.contains(a, b): every element of b is in a
                 self._expr(b); self._expr(a)
                 return self.emit(OP_ISSUBSET, 0, -1)
+            if name == "equivalent":   # sets.equivalent(a, b) = contains(a, b) && contains(b, a) (cel-go ext/sets.go)
+                self._expr(b); self._expr(a)
+                self.emit(OP_ISSUBSET, 0, -1)
+                self._expr(a); self._expr(b)
+                self.emit(OP_ISSUBSET, 0, -1)
+                return self.emit(OP_AND, 0, -1)
         return self.unsupported("function %s/%d" % (name, n))
 
     def _comp(self, ast):
