@@ -401,6 +401,7 @@ __device__ __forceinline__ void fill_column_cache(const Ctx& c, const BatchDev& 
 struct CbhPassPrincipal { static constexpr bool value = false; };   // tags of the two instantiations of the
 struct CbhPassResource { static constexpr bool value = true; };     // policy pass (check_body below)
 
+#define CBH_BUCKET_MEMO 8u          /* chain positions whose directory answer is kept across a group's role iterations */
 #define CBH_FEAT_DERIVED_ROLES 1   /* FEAT bits: what the table uses, compiled in only then */
 #define CBH_FEAT_ROLE_POLICIES 2  /* role policies and / or parent roles */
 #define CBH_FEAT_GLOBS 4          /* glob patterns in some dimension (action / role / kind) */
@@ -490,6 +491,8 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   // not in registers: eight rarely touched VGPRs are what pushes the kernel over its 128-VGPR budget).
   __shared__ u32 ps_lds[8 * CBH_BLOCK];
   __shared__ AM drm_lds[3 * CBH_BLOCK];   // derived-role outcome memo, see the walk below
+  __shared__ u32 bucket_memo_lds[CBH_BUCKET_MEMO * 5];   // directory answers per chain position, see the role loop
+  CBH_L u32* bucket_memo = (CBH_L u32*)bucket_memo_lds;
 #define DRM(i) drm_lds[(i) * CBH_BLOCK + c.tid]
 #define PS_POL(k) ps_lds[(k) * CBH_BLOCK + c.tid]
 #define PS_SCP(k) ps_lds[(4 + (k)) * CBH_BLOCK + c.tid]
@@ -624,6 +627,10 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
       const bool ing = pend && first == g_first && r_ver == g_ver && gx == g_x;
       pend = pend && !ing;
 
+      // The directory answers for this group's scopes, kept across the role iterations: every role walks the same
+      // chain, so the probe of chain position d is made once (by the first role that gets there) and read back from
+      // LDS afterwards - a broadcast read instead of a hash probe with its dependent scalar loads.
+      u32 bmemo_n = 0;   // chain positions 0 .. bmemo_n - 1 are in bucket_memo
       for (u32 ri = 0;; ++ri) {   // ---- roles (check.go:208)
         const AM Am = (ing && ri < n_iter) ? (AM)(Pm & todo & ~rdone) : (AM)0;
         if (wave_ballot(Am != 0) == 0) break;
@@ -687,12 +694,25 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
           L.status = 0;
         };
 
-        for (u32 si = g_first; si != CBH_NONE; si = uchain_next(t, uload(&t.scope_parent[si]), flagbit)) {   // check.go:231
+        u32 chain_pos = 0;
+        for (u32 si = g_first; si != CBH_NONE; si = uchain_next(t, uload(&t.scope_parent[si]), flagbit), ++chain_pos) {   // check.go:231
           if (wave_ballot(S != 0) == 0) break;
           DBG2_T0();
           uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
-          const bool have_bucket = is_res ? udir_find(t, CBH_B_RESOURCE, g_ver, g_x, si, bucket)
-                                          : udir_find(t, CBH_B_PRINCIPAL, g_ver, si, g_x, bucket);   // resource version: check.go:294
+          bool have_bucket;
+          if (chain_pos < bmemo_n) {
+            CBH_L const u32* e = bucket_memo + chain_pos * 5u;
+            bucket.x = uniform(e[0]); bucket.y = uniform(e[1]); bucket.z = uniform(e[2]); bucket.w = uniform(e[3]);
+            have_bucket = uniform(e[4]) != 0;
+          } else {
+            have_bucket = is_res ? udir_find(t, CBH_B_RESOURCE, g_ver, g_x, si, bucket)
+                                 : udir_find(t, CBH_B_PRINCIPAL, g_ver, si, g_x, bucket);   // resource version: check.go:294
+            if (chain_pos == bmemo_n && chain_pos < CBH_BUCKET_MEMO) {
+              CBH_L u32* e = bucket_memo + chain_pos * 5u;
+              if (c.tid == 0) { e[0] = bucket.x; e[1] = bucket.y; e[2] = bucket.z; e[3] = bucket.w; e[4] = have_bucket ? 1u : 0u; }
+              ++bmemo_n;
+            }
+          }
 
           DBG2_ACC(dbg_b);
           if (is_res && want_edr) {   // derived roles of this scope's resource policy (check.go:237-282)
@@ -731,7 +751,12 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
             if (S != 0) { L.edr = m; L.edr_err = derr; edr_acc |= m; }
           }
 
-          if (is_res && has_rolepol) {
+          // role policies exist at (version, scope) at all?  CBH_B_RPRES is keyed by exactly that: without an entry no role
+          // has a role-policy bucket here, the whole block below would find nothing - one probe instead of a scan of
+          // the bucket's records plus a probe per distinct role
+          uint4 rpres_here;
+          const bool rolepol_here = is_res && has_rolepol && udir_find(t, CBH_B_RPRES, g_ver, si, 0, rpres_here);
+          if (rolepol_here) {
             // baseBM of Index.Query (index.go:250-305): the scope yields synthetic DENYs only if SOME binding at
             // (version, scope) - a rule of the resource policy or a role-policy rule - matches the resource and
             // one of [role] ++ ancestors; an empty base returns before appendRolePolicyDenies.

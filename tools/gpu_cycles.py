@@ -9,10 +9,14 @@ from cerbos_amd.lower.blob import lower_rule_table
 from cerbos_amd.policy.loader import policies_from_docs
 from cerbos_amd.ruletable.build import rule_table_from_policies
 
+W = sys.argv[1] if len(sys.argv) > 1 else "C2"
+pol_fn, req_fn, nreq = {"C2": (workloads.c2_policies, workloads.c2_requests, 250_000),
+                        "C3": (workloads.c3_policies, workloads.c3_requests, 1_000_000),
+                        "C5": (workloads.c5_policies, workloads.c5_requests, 250_000)}[W]
 capi.init(0)
-lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c2_policies())))
+lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol_fn())))
 table = capi.Table(lt.blob)
-cr = workloads.c2_requests(250_000)
+cr = req_fn(nreq)
 batch = cr.to_batch(Flattener(lt))
 db = table.upload(batch)
 for _ in range(3):
