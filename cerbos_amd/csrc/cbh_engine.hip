@@ -500,6 +500,8 @@ static void collect_times(Replica* r) {   // after the stream has been synchroni
 
 // CBH_NO_FLAT=1 (measurement aid): decide with the general walk even where the flat kernel applies
 static u32 pick_flags(u32 eval_flags) { static const bool no_flat = getenv("CBH_NO_FLAT") != nullptr; return no_flat ? (eval_flags | CBH_F_STRICT_EVALUATION) : eval_flags; }
+// CBH_LDS_PAD=<bytes> (measurement aid): extra dynamic LDS per workgroup of the resident launches, to hold the occupancy down
+static size_t lds_pad() { static const size_t pad = [] { const char* e = getenv("CBH_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }(); return pad; }
 static u32 nfa_maxw(const TableDev& d) { return std::max(std::max(d.nfa_words[0], d.nfa_words[1]), d.nfa_words[2]); }
 static size_t check_lds_bytes(const BatchDev& d) {   // column cache: value low / high / tag dword per lane
   const u32 ncc = d.n_columns < CBH_CACHE_COLS ? d.n_columns : CBH_CACHE_COLS;
@@ -551,7 +553,7 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
     u32 threads = CBH_BLOCK; bool flat = false;
     const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, maxw != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), b->max_actions, b->max_roles, b->plain_tags, pick_flags(p->flags), &threads, &flat);
     const u32 grid = (d.n_requests + threads - 1) / threads;   // one lane per request
-    const size_t lds = (check_lds_bytes(d) + (flat ? cbh_flat_chain_bytes(rep->dev.max_depth) : 0)) * (threads / CBH_BLOCK) + (flat ? cbh_flat_class_bytes(rep->dev.K) : 0);
+    const size_t lds = (check_lds_bytes(d) + (flat ? cbh_flat_chain_bytes(rep->dev.max_depth) : 0)) * (threads / CBH_BLOCK) + (flat ? cbh_flat_class_bytes(rep->dev.K) : 0) + lds_pad();
     if (timed) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, sl.ev[2], sl.ev[3], 0, b->last_args, (const KernelArgs*)b->d_args);
     else hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, b->last_args, (const KernelArgs*)b->d_args);
     sl.pending = timed;
