@@ -216,7 +216,11 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   // [depth][lane]: scope index at that depth of the lane's chain - in the dynamic LDS behind the column caches,
   // sized by the table's longest chain (a one-scope table pays 256 B per wave, not 4 KB: LDS sets the occupancy here)
   const u32 max_depth = t.max_depth < CBH_FLAT_MAX_DEPTH ? t.max_depth : CBH_FLAT_MAX_DEPTH;
-  CBH_L u32* chain_si = (CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * (3u * c.n_cached * CBH_BLOCK) + wave * (max_depth * CBH_BLOCK);
+  // A table of at most 256 scopes keeps them as bytes: a quarter of the footprint.
+  const bool chain8 = t.n_scopes <= 256u;
+  const u32 chain_dwords = chain8 ? max_depth * (CBH_BLOCK / 4u) : max_depth * CBH_BLOCK;
+  CBH_L u32* chain_si = (CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * (3u * c.n_cached * CBH_BLOCK) + wave * chain_dwords;
+  CBH_L u8* chain_si8 = (CBH_L u8*)chain_si;
   // actions and roles -> classes (CBH_SEC_ACTION_CLASS / CBH_SEC_ROLE_CLASS; 63 = a string no rule names).
   // A flat table has fewer than 32 classes per dimension and its masks mirror "any other string" (bit 63)
   // in bit 31 of the low dword: the match is a 1-bit field extract from ONE dword at a per-lane position.
@@ -227,7 +231,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   // flight - a table of up to CBH_FLAT_LDS_STRINGS strings - so that the lookups below are LDS reads, not a third
   // dependent trip to memory.
   const bool cls_in_lds = t.K <= CBH_FLAT_LDS_STRINGS;
-  CBH_L u8* cls_lds = (CBH_L u8*)((CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * ((3u * c.n_cached + max_depth) * CBH_BLOCK));   // [action classes K][role classes K]
+  CBH_L u8* cls_lds = (CBH_L u8*)((CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * (3u * c.n_cached * CBH_BLOCK + chain_dwords));   // [action classes K][role classes K]
   if (cls_in_lds) {
     for (u32 i = threadIdx.x; i < t.K; i += CBH_FLAT_THREADS) { cls_lds[i] = t.action_class[i]; cls_lds[t.K + i] = t.role_class[i]; }
   }
@@ -334,7 +338,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
     const bool have_bucket = udir_find(t, CBH_B_RESOURCE, g_ver, g_k, g_si, bucket);   // present for every resource policy (index.go:966-997)
     exists = exists || (ing && have_bucket);
     if (go) {
-      if (ing && mydepth < max_depth) chain_si[mydepth * CBH_BLOCK + c.tid] = g_si;
+      if (ing && mydepth < max_depth) { if (chain8) chain_si8[mydepth * CBH_BLOCK + c.tid] = (u8)g_si; else chain_si[mydepth * CBH_BLOCK + c.tid] = g_si; }
       const u32 S_before = S;
       if (have_bucket && bucket.y) {
         const u32 last = bucket.x + bucket.y - 1u;
@@ -397,7 +401,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
     const u32 d = ((dp0 & wb) ? 1u : 0u) | ((dp1 & wb) ? 2u : 0u) | ((dp2 & wb) ? 4u : 0u) | ((dp3 & wb) ? 8u : 0u);
     pol[k] = win ? pol_hit : pol_none;
     scp[k] = CBH_NONE;
-    if (win && k < act_cnt) scp[k] = chain_si[d * CBH_BLOCK + c.tid];
+    if (win && k < act_cnt) scp[k] = chain8 ? (u32)chain_si8[d * CBH_BLOCK + c.tid] : chain_si[d * CBH_BLOCK + c.tid];
     eff4 |= (u32)(ak ? CBH_EFFECT_ALLOW : CBH_EFFECT_DENY) << (8 * k);   // NO_MATCH -> DENY (check.go:451-453)
     // an evaluation the reference would not have made - a role after the one that allowed - does not count
     const u32 seen = ak ? (((ak & (0u - ak)) << 1) - 1u) : 0xFFFFu;
@@ -515,9 +519,9 @@ __global__ CBH_FLAT_ATTRS(4) void cbh_check_flat_kernel_any(const KernelArgs a, 
 // and evaluation mode (not strict) allow it, else the general walk's instantiation for the table class.
 // `threads` = the workgroup size to launch it with; dynamic LDS per wave = the column cache, plus - `flat` - the
 // scope-chain scratch (cbh_flat_lds_bytes).
-// dynamic LDS of one wave of the flat kernel: column cache + [max_depth][64] scope indices
-static inline size_t cbh_flat_chain_bytes(u32 table_max_depth) {
-  return (size_t)(table_max_depth < CBH_FLAT_MAX_DEPTH ? table_max_depth : CBH_FLAT_MAX_DEPTH) * CBH_BLOCK * 4;
+// dynamic LDS of one wave of the flat kernel: column cache + [max_depth][64] scope indices (bytes for a table of <= 256 scopes)
+static inline size_t cbh_flat_chain_bytes(u32 table_max_depth, u32 table_scopes) {
+  return (size_t)(table_max_depth < CBH_FLAT_MAX_DEPTH ? table_max_depth : CBH_FLAT_MAX_DEPTH) * CBH_BLOCK * (table_scopes <= 256u ? 1 : 4);
 }
 // ... and, once per workgroup, the two class tables (one byte per table string each) when they are staged in LDS
 static inline size_t cbh_flat_class_bytes(u32 table_strings) {

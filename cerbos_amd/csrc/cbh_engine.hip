@@ -553,7 +553,7 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
     u32 threads = CBH_BLOCK; bool flat = false;
     const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, maxw != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), b->max_actions, b->max_roles, b->plain_tags, pick_flags(p->flags), &threads, &flat);
     const u32 grid = (d.n_requests + threads - 1) / threads;   // one lane per request
-    const size_t lds = (check_lds_bytes(d) + (flat ? cbh_flat_chain_bytes(rep->dev.max_depth) : 0)) * (threads / CBH_BLOCK) + (flat ? cbh_flat_class_bytes(rep->dev.K) : 0) + lds_pad();
+    const size_t lds = (check_lds_bytes(d) + (flat ? cbh_flat_chain_bytes(rep->dev.max_depth, rep->dev.n_scopes) : 0)) * (threads / CBH_BLOCK) + (flat ? cbh_flat_class_bytes(rep->dev.K) : 0) + lds_pad();
     if (timed) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, sl.ev[2], sl.ev[3], 0, b->last_args, (const KernelArgs*)b->d_args);
     else hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, b->last_args, (const KernelArgs*)b->d_args);
     sl.pending = timed;
@@ -772,7 +772,7 @@ static void launch_check(const Replica* rep, KernelArgs ka, const KernelArgs* d_
   u32 threads = CBH_BLOCK; bool flat = false;
   const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, nfa_maxw(rep->dev) != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), sh.max_actions, sh.max_roles, sh.plain_tags(), pick_flags(ka.flags), &threads, &flat);
   const u32 grid = (hi - lo + threads - 1) / threads;   // one lane per request
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), (check_lds_bytes(ka.b) + (flat ? cbh_flat_chain_bytes(rep->dev.max_depth) : 0)) * (threads / CBH_BLOCK) + (flat ? cbh_flat_class_bytes(rep->dev.K) : 0), s, ka, d_args);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), (check_lds_bytes(ka.b) + (flat ? cbh_flat_chain_bytes(rep->dev.max_depth, rep->dev.n_scopes) : 0)) * (threads / CBH_BLOCK) + (flat ? cbh_flat_class_bytes(rep->dev.K) : 0), s, ka, d_args);
 }
 
 // a small batch on one device: everything packed into the pinned staging block.  Two ways across PCIe:
