@@ -35,7 +35,8 @@ using u8 = uint8_t; using u32 = uint32_t; using u64 = uint64_t;
 struct Span { const u8* p = nullptr; const u8* e = nullptr; bool empty() const { return p >= e; } };
 struct Field { u32 num = 0; u32 wt = 0; u64 v = 0; Span s{}; };   // v: varint / fixed value, s: length-delimited payload
 
-bool varint(Span& s, u64& out) {
+inline bool varint(Span& s, u64& out) {
+  if (s.p < s.e && !(*s.p & 0x80)) { out = *s.p++; return true; }   // one byte: every tag and almost every length
   u64 r = 0;
   for (int sh = 0; sh < 64 && s.p < s.e; sh += 7) {
     u8 b = *s.p++;
@@ -46,11 +47,16 @@ bool varint(Span& s, u64& out) {
 }
 
 // Next field of a message; false at the end or on malformed input (`bad` set).
-bool next(Span& s, Field& f, bool& bad) {
+inline bool next(Span& s, Field& f, bool& bad) {
   if (s.empty()) return false;
   u64 key;
   if (!varint(s, key)) { bad = true; return false; }
   f.num = (u32)(key >> 3); f.wt = (u32)(key & 7);
+  if (f.wt == 2) {   // length-delimited first: strings and sub-messages are most of a CheckInput
+    u64 n;
+    if (!varint(s, n) || n > (u64)(s.e - s.p)) { bad = true; return false; }
+    f.s = Span{s.p, s.p + n}; s.p += n; return true;
+  }
   switch (f.wt) {
     case 0: if (!varint(s, f.v)) { bad = true; return false; } return true;
     case 1: if (s.e - s.p < 8) { bad = true; return false; } memcpy(&f.v, s.p, 8); s.p += 8; return true;
@@ -68,7 +74,7 @@ std::string_view sv(Span s) { return std::string_view((const char*)s.p, (size_t)
 
 // map<string, google.protobuf.Value> entry: key = 1, value = 2
 struct Entry { Span key{nullptr, nullptr}; Span val{nullptr, nullptr}; };
-bool entry(Span e, Entry& out, bool& bad) {
+inline bool entry(Span e, Entry& out, bool& bad) {
   Field f;
   while (next(e, f, bad)) {
     if (f.num == 1 && f.wt == 2) out.key = f.s;
@@ -92,7 +98,7 @@ bool map_get(Span msg, u32 fnum, std::string_view key, Span& val, bool& bad) {
 // google.protobuf.Value oneof: null 1, number 2 (double), string 3, bool 4, struct 5, list 6.  The last
 // field present wins; an empty message is null.
 struct Val { u32 kind = 1; u64 v = 0; Span s{nullptr, nullptr}; };
-bool value(Span m, Val& out, bool& bad) {
+inline bool value(Span m, Val& out, bool& bad) {
   // a field counts only with the wire type its declaration has (null / bool: varint, number: fixed64,
   // string / struct / list: length-delimited); anything else is an unknown field, skipped as protobuf does
   static const u8 want_wt[7] = {0xFF, 0, 1, 2, 0, 2, 2};
@@ -125,7 +131,10 @@ struct StrIndex {
     for (u32 i = h32 & mask;; i = (i + 1) & mask) {
       const Slot& sl = slots[i];
       if (!sl.id1) return false;
-      if (sl.h == h32 && at(sl.id1 - 1) == s) { id = sl.id1 - 1; return true; }
+      if (sl.h == h32) {
+        const std::string_view c = at(sl.id1 - 1);
+        if (c.size() == s.size() && (s.empty() || std::memcmp(c.data(), s.data(), s.size()) == 0)) { id = sl.id1 - 1; return true; }
+      }
     }
   }
   void insert(u64 h, u32 id) {   // the caller knows the string is absent
@@ -465,8 +474,10 @@ static int flatten_slice(const cbi_table* t, const Source& src, uint32_t first, 
   b->col_val.assign((size_t)ncol * R, 0);
   b->req_input.reserve(R);
   b->tuple_req.reserve(ntup); b->tuple_action.reserve(ntup);
+  b->str_off.reserve((size_t)n * 2 + 64); b->str_flags.reserve((size_t)n * 2 + 64); b->str_hash.reserve((size_t)n * 2 + 64);
+  b->roles.reserve((size_t)n * 3);
   b->str_off.push_back(0);
-  b->str_bytes.reserve(1 << 16);
+  b->str_bytes.reserve((size_t)n * 24 + (1 << 12));
   Interner in{t, b, {}, {}};
   in.local.reserve(n);
   Encoder encd{in, b};
