@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""One-off wider sweep of the GPU differential fuzz (beyond the seeds of the test tier): flat-kernel stores incl. the
+variant with the evaluator call, large buckets and deep chains (tests/test_flat_kernel.py) and general stores with the
+wide CEL pool (tests/test_gpu_fuzz.py).   python tools/gpu_fuzz_sweep.py [first_seed] [n_seeds]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_flat_kernel as F   # noqa: E402
+import test_gpu_fuzz as G      # noqa: E402
+from cerbos_amd.engine import Conf, HipEvaluator   # noqa: E402
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+mk = lambda lt: HipEvaluator(lt, Conf())   # noqa: E731
+t0 = time.time()
+done = {"flat": 0, "lists": 0, "large": 0, "deep": 0, "general": 0, "skipped": 0}
+for s in range(first, first + n):
+    F._run_seed(s, mk, True); done["flat"] += 1
+    if s % 3 == 0:
+        F._run_seed(s, mk, True, with_lists=True); done["lists"] += 1
+    if s % 5 == 0:
+        F._run_seed(s, mk, True, many_rules=True); done["large"] += 1
+    if s % 4 == 0:
+        F._run_seed(s, mk, True, deep=True); done["deep"] += 1
+    for pool in ("base", "wide"):
+        try:
+            G.test_fuzz_store_on_gpu(s, pool); done["general"] += 1
+        except BaseException as e:   # pytest.skip raises a BaseException subclass
+            if type(e).__name__ == "Skipped":
+                done["skipped"] += 1
+            else:
+                raise
+print("sweep clean:", done, "seeds %d..%d" % (first, first + n - 1), "%.0f s" % (time.time() - t0))
