@@ -235,6 +235,8 @@ enum CbhOp {
   OP_TREE_BEGIN = 55, // arg = kind (0 all, 1 any, 2 none): open a condition tree level
   OP_TREE_ACC = 56,   // arg = kind: pop a child's plain-bool result into the level's accumulator
   OP_TREE_END = 57,   // arg = kind: close the level, push its result
+  OP_INDEXOF = 60,    // arg 0 first / 1 last: pop sub, s (strings) -> code-point index of the occurrence, -1 without one
+  OP_STREQ_CASE = 61, // arg = mode a | mode b << 2 | ne << 4 (mode 1 lowerAscii, 2 upperAscii): pop b, a -> a' == b' without building a' / b'
   OP_MATCHES = 59,    // next word = offset of the pattern's tables in CBH_SEC_REGEX: TOS (string) -> RE2 MatchString
   OP_HIER = 58,       // arg = predicate (0 ancestorOf, 1 descendentOf, 2 immediateParentOf, 3 immediateChildOf, 4 siblingOf,
                       // 5 overlaps): pop b, a (dot-delimited strings) -> hierarchy(a).<predicate>(hierarchy(b))

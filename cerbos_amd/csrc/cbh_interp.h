@@ -234,6 +234,21 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
         SETTOP(mk_bool(str_find(c, (u32)x.v, (u32)y.v, op == OP_STARTSWITH ? 0 : (op == OP_ENDSWITH ? 1 : 2))));
         break;
       }
+      case OP_INDEXOF: {   // a = 0 first / 1 last
+        Val y = TOPV(0), x = TOPV(1); --sp;
+        if (x.t != CBH_T_STRING || y.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
+        SETTOP(mk(CBH_T_INT, (u64)str_index_of(c, (u32)x.v, (u32)y.v, a != 0)));
+        break;
+      }
+      case OP_STREQ_CASE: {   // a = mode a | mode b << 2 | ne << 4
+        Val y = TOPV(0), x = TOPV(1); --sp;
+        const u32 ma = a & 3u, mb = (a >> 2) & 3u;
+        // a mapped side must be a string (no such overload otherwise); an unmapped side of another type is simply unequal
+        if (x.t == CBH_T_ERR || y.t == CBH_T_ERR || (ma && x.t != CBH_T_STRING) || (mb && y.t != CBH_T_STRING)) { ST(sp - 1) = CBH_T_ERR; break; }
+        const bool eq = x.t == CBH_T_STRING && y.t == CBH_T_STRING && str_eq_case(c, (u32)x.v, ma, (u32)y.v, mb);
+        SETTOP(mk_bool(eq != ((a >> 4) & 1u)));
+        break;
+      }
       case OP_MATCHES: {   // next word = the pattern's tables
         const u32 off = uload(&code[pc]); ++pc;
         Val x = TOPV(0);

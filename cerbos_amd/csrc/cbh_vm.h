@@ -185,6 +185,37 @@ __device__ inline bool str_find(const Ctx& c, u32 hay, u32 needle, int mode /*0 
   return false;
 }
 
+// cel-go ext/strings.go indexOf / lastIndexOf (two-argument forms): index in CODE POINTS of the first / last occurrence of
+// `sub` in `s`, -1 without one; the empty string is found at 0 / at the end.
+__device__ inline i64 str_index_of(const Ctx& c, u32 s, u32 sub, bool last) {
+  gbytes ph, pn; u32 nh, nn;
+  str_span(c, s, ph, nh); str_span(c, sub, pn, nn);
+  if (nn > nh) return -1;
+  i64 at = -1;
+  for (u32 o = 0; o + nn <= nh; ++o) {
+    u32 j = 0;
+    while (j < nn && ph[o + j] == pn[j]) ++j;
+    if (j == nn) { at = o; if (!last) break; }
+  }
+  if (at < 0) return -1;
+  i64 cp = 0;
+  for (u32 i = 0; i < (u32)at; ++i) cp += (ph[i] & 0xC0u) != 0x80u;   // bytes that start a code point
+  return cp;
+}
+// a == b through ASCII case mappings (mode 0 as is, 1 lowerAscii, 2 upperAscii), byte by byte: no string is built
+__device__ inline bool str_eq_case(const Ctx& c, u32 a, u32 ma, u32 b, u32 mb) {
+  gbytes pa, pb; u32 na, nb;
+  str_span(c, a, pa, na); str_span(c, b, pb, nb);
+  if (na != nb) return false;
+  auto map = [](u8 ch, u32 m) -> u8 {
+    if (m == 1 && ch >= 'A' && ch <= 'Z') return (u8)(ch + 32);
+    if (m == 2 && ch >= 'a' && ch <= 'z') return (u8)(ch - 32);
+    return ch;
+  };
+  for (u32 i = 0; i < na; ++i) if (map(pa[i], ma) != map(pb[i], mb)) return false;
+  return true;
+}
+
 // RE2 MatchString with the pattern's DFA (cerbos_amd/lower/regex.py, layout in cbh_blob.h CBH_SEC_REGEX): one table
 // lookup per byte; flags bit 0 = a match is already certain, bit 1 = a match if the text ends in this state.
 __device__ inline bool regex_match(const Ctx& c, u32 off, u32 sid) {

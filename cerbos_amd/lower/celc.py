@@ -26,7 +26,7 @@ from . import regex
  OP_EDRHAS, OP_LOCAL, OP_ITER_BEGIN, OP_ITER_NEXT, OP_ITER_ACC, OP_ITER_END, OP_TOINT,
  OP_TODOUBLE, OP_TOSTRING_UNSUPPORTED, OP_INIPRANGE, OP_UNSUPPORTED, OP_TS_GETTER,
  OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN, OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC,
- OP_TREE_END, OP_HIER, OP_MATCHES) = range(60)
+ OP_TREE_END, OP_HIER, OP_MATCHES, OP_INDEXOF, OP_STREQ_CASE) = range(62)
 
 TREE_KINDS = {"all": 0, "any": 1, "none": 2}
 COND_LEAF = 0x80000000
@@ -740,6 +740,20 @@ class _FuncCompiler:
                         pb.uses_runtime = True
                         return self.emit(OP_EDRHAS, pb.dr_bit(ast[2][2]), +1)
                     return self.unsupported("runtime.effectiveDerivedRoles membership with a non-constant name")
+            if op in ("==", "!="):
+                # `a.lowerAscii() == b`, `a == b.upperAscii()` ...: the device builds no strings, it compares the bytes
+                # through the case mapping (cel-go ext/strings.go lowerAscii / upperAscii: ASCII letters only)
+                modes, sides = [], []
+                for side in (ast[2], ast[3]):
+                    m = 0
+                    if side[0] == "call" and side[1] in ("lowerAscii", "upperAscii") and side[2] is not None and not side[3] \
+                            and not (side[2][0] == "ident" and side[2][1] in ("strings",) and side[2][1] not in self.locals):
+                        m, side = (1 if side[1] == "lowerAscii" else 2), side[2]
+                    modes.append(m); sides.append(side)
+                if modes[0] or modes[1]:
+                    self._expr(sides[0])
+                    self._expr(sides[1])
+                    return self.emit(OP_STREQ_CASE, modes[0] | (modes[1] << 2) | ((1 if op == "!=" else 0) << 4), -1)
             self._expr(ast[2])
             self._expr(ast[3])
             return self.emit(_BINOPS[op], 0, -1)
@@ -784,6 +798,11 @@ class _FuncCompiler:
                 return unary(OP_TIMESINCE)
             if name == "now" and n == 0:
                 return self.emit(OP_NOW, 0, +1)
+            if name in ("indexOf", "lastIndexOf") and n == 2 and target is not None:
+                # cel-go ext/strings.go: the code-point index of the first / last occurrence, -1 without one
+                self._expr(allargs[0])
+                self._expr(allargs[1])
+                return self.emit(OP_INDEXOF, 0 if name == "indexOf" else 1, -1)
             if name == "matches" and n == 2:
                 # cel-go `matches` = RE2 MatchString (an unanchored search).  A pattern that is a constant of the policy
                 # is compiled to a byte-level DFA here (regex.py); the device walks one table lookup per byte.
