@@ -401,19 +401,10 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
         if (x.t != CBH_T_STRING || y.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
         gbytes pi, pc2; u32 ni, nc;
         str_span(c, (u32)x.v, pi, ni); str_span(c, (u32)y.v, pc2, nc);
-        bool v6 = false;
-        for (u32 i = 0; i < ni; ++i) v6 |= pi[i] == ':';
-        for (u32 i = 0; i < nc; ++i) v6 |= pc2[i] == ':';
-        if (v6) { if (live) L.status |= CBH_ST_UNSUPPORTED; ST(sp - 1) = CBH_T_ERR; break; }   // IPv6: not on the device
-        u32 slash = nc;
-        for (u32 i = 0; i < nc; ++i) if (pc2[i] == '/') { slash = i; break; }
-        u32 ip = 0, net = 0, bits = 0, nd = 0;
-        bool ok = slash < nc && parse_ipv4(pi, ni, ip) && parse_ipv4(pc2, slash, net);
-        for (u32 i = slash + 1; ok && i < nc; ++i) { if (!dig(pc2[i]) || nd >= 2) ok = false; else { bits = bits * 10 + (pc2[i] - '0'); ++nd; } }
-        if (ok && (nd == 0 || bits > 32 || (nd == 2 && pc2[slash + 1] == '0'))) ok = false;
-        if (!ok) { ST(sp - 1) = CBH_T_ERR; break; }
-        u32 mask = bits == 0 ? 0u : (0xFFFFFFFFu << (32 - bits));
-        SETTOP(mk_bool((ip & mask) == (net & mask)));
+        const int r = ip_in_range(pi, ni, pc2, nc);
+        if (r == -2 && live) L.status |= CBH_ST_UNSUPPORTED;
+        if (r < 0) { ST(sp - 1) = CBH_T_ERR; break; }
+        SETTOP(mk_bool(r == 1));
         break;
       }
       case OP_HASINTERSECTION: case OP_ISSUBSET: {

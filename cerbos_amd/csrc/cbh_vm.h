@@ -549,6 +549,84 @@ __device__ inline bool parse_ipv4(gbytes p, u32 n, u32& out) {
   out = v; return true;
 }
 
+// IPv6 text as Go's net.ParseIP (netip.ParseAddr) reads it: up to eight groups of at most four hex digits, one "::" that
+// stands for at least one zero group, optionally a dotted IPv4 in the last 32 bits; no zone.  -> 128 bits (hi, lo).
+__device__ inline bool parse_ipv6(gbytes p, u32 n, u64& hi, u64& lo) {
+  u32 g[8]; int ng = 0, ellipsis = -1; u32 i = 0;
+  for (int k = 0; k < 8; ++k) g[k] = 0;
+  if (n >= 2 && p[0] == ':' && p[1] == ':') { ellipsis = 0; i = 2; }
+  else if (n == 0 || p[0] == ':') return false;
+  while (i < n) {
+    if (ng >= 8) return false;
+    u32 v = 0, nd = 0; const u32 st = i;
+    for (; i < n; ++i) {
+      const u8 ch = p[i];
+      u32 d;
+      if (ch >= '0' && ch <= '9') d = ch - '0'; else if (ch >= 'a' && ch <= 'f') d = ch - 'a' + 10; else if (ch >= 'A' && ch <= 'F') d = ch - 'A' + 10; else break;
+      if (++nd > 4) return false;
+      v = (v << 4) | d;
+    }
+    if (nd == 0) return false;
+    if (i < n && p[i] == '.') {   // the rest is a dotted IPv4: the last two groups
+      if (ng > 6) return false;
+      u32 v4;
+      if (!parse_ipv4(p + st, n - st, v4)) return false;
+      g[ng++] = v4 >> 16; g[ng++] = v4 & 0xFFFFu;
+      i = n;
+      break;
+    }
+    g[ng++] = v;
+    if (i == n) break;
+    if (p[i] != ':') return false;
+    if (++i == n) return false;                 // a single trailing colon
+    if (p[i] == ':') {
+      if (ellipsis >= 0) return false;          // a second "::"
+      ellipsis = ng;
+      if (++i == n) break;
+    }
+  }
+  if (ng < 8) {
+    if (ellipsis < 0) return false;
+    const int tail = ng - ellipsis;             // groups behind the "::" move to the end
+    for (int k = tail - 1; k >= 0; --k) g[8 - tail + k] = g[ellipsis + k];
+    for (int k = ellipsis; k < 8 - tail; ++k) g[k] = 0;
+  } else if (ellipsis >= 0) return false;       // "::" must stand for at least one group
+  hi = ((u64)g[0] << 48) | ((u64)g[1] << 32) | ((u64)g[2] << 16) | (u64)g[3];
+  lo = ((u64)g[4] << 48) | ((u64)g[5] << 32) | ((u64)g[6] << 16) | (u64)g[7];
+  return true;
+}
+
+// inIPAddrRange (internal/conditions/cerbos_lib.go:513-526: net.ParseIP + net.ParseCIDR + IPNet.Contains).
+// 1 / 0 = contained / not, -1 = one of them does not parse (an error in the reference), -2 = a form the device leaves to the
+// caller's engine (an IPv4-mapped IPv6 network, whose mask Go re-reads as an IPv4 mask).
+__device__ inline int ip_in_range(gbytes pi, u32 ni, gbytes pc, u32 nc) {
+  u32 slash = nc;
+  for (u32 i = 0; i < nc; ++i) if (pc[i] == '/') { slash = i; break; }
+  if (slash >= nc) return -1;
+  u32 bits = 0, nd = 0;
+  for (u32 i = slash + 1; i < nc; ++i) { if (!dig(pc[i]) || ++nd > 6) return -1; bits = bits * 10 + (pc[i] - '0'); }   // Go's dtoi: plain digits
+  if (nd == 0) return -1;
+  bool ip6 = false, net6 = false;
+  for (u32 i = 0; i < ni; ++i) ip6 |= pi[i] == ':';
+  for (u32 i = 0; i < slash; ++i) net6 |= pc[i] == ':';
+  u64 ih = 0, il = 0, nh = 0, nl = 0; u32 v4;
+  if (ip6) { if (!parse_ipv6(pi, ni, ih, il)) return -1; }
+  else { if (!parse_ipv4(pi, ni, v4)) return -1; il = v4; }
+  if (net6) { if (!parse_ipv6(pc, slash, nh, nl)) return -1; }
+  else { if (!parse_ipv4(pc, slash, v4)) return -1; nl = v4; }
+  if (bits > (net6 ? 128u : 32u)) return -1;
+  if (net6 && nh == 0 && (nl >> 32) == 0xFFFFull) return -2;
+  if (ip6 && ih == 0 && (il >> 32) == 0xFFFFull) { ip6 = false; il &= 0xFFFFFFFFull; }   // IP.To4(): an IPv4-mapped address is an IPv4 address
+  if (ip6 != net6) return 0;                                                                 // different lengths: not contained
+  if (!net6) {
+    const u32 mask = bits == 0 ? 0u : (0xFFFFFFFFu << (32 - bits));
+    return (((u32)il ^ (u32)nl) & mask) == 0;
+  }
+  const u64 mh = bits == 0 ? 0ull : (bits >= 64 ? ~0ull : (~0ull << (64 - bits)));
+  const u64 ml = bits <= 64 ? 0ull : (bits >= 128 ? ~0ull : (~0ull << (128 - bits)));
+  return ((ih ^ nh) & mh) == 0 && ((il ^ nl) & ml) == 0;
+}
+
 // ---- interpreter -----------------------------------------------------------------------
 #define ST(i) c.s_tag[(i) * CBH_BLOCK + c.tid]
 #define SV(i) c.s_val[(i) * CBH_BLOCK + c.tid]

@@ -863,12 +863,30 @@ def _contains_all(a, b):
 
 
 def _ip_in_range(ip, cidr):
+    """cerbos_lib.go:513-526: net.ParseIP, net.ParseCIDR, IPNet.Contains.  Where Python's ipaddress reads more than Go
+    does it is narrowed to Go: a CIDR is "<address>/<decimal digits>" (no netmask form, no bare address), an address
+    carries no zone, and an IPv4-mapped IPv6 address is the IPv4 address (IP.To4 in Contains)."""
+    addr_s, sep, bits_s = cidr.partition("/")
+    if not sep or not bits_s.isascii() or not bits_s.isdigit() or "%" in cidr or "%" in ip:
+        raise CelError("invalid CIDR address: %s" % cidr)
     try:
-        net = ipaddress.ip_network(cidr, strict=False)
+        net_addr = ipaddress.ip_address(addr_s)
         addr = ipaddress.ip_address(ip)
     except ValueError as e:
         raise CelError(str(e))
-    return addr.version == net.version and addr in net
+    bits = int(bits_s)
+    if bits > net_addr.max_prefixlen:
+        raise CelError("invalid CIDR address: %s" % cidr)
+    if addr.version == 6 and addr.ipv4_mapped is not None:
+        addr = addr.ipv4_mapped
+    width = net_addr.max_prefixlen
+    net_int = (int(net_addr) >> (width - bits)) << (width - bits)        # ParseCIDR keeps ip.Mask(m)
+    if width == 128 and (net_int >> 32) == 0xFFFF:
+        # networkNumberAndMask (net/ip.go): an IPv4-mapped network number is its IPv4 form, the mask its last four bytes
+        net_int, width, bits = net_int & 0xFFFFFFFF, 32, max(bits - 96, 0)
+    if addr.max_prefixlen != width:
+        return False
+    return (int(addr) >> (width - bits)) == (net_int >> (width - bits))
 
 
 def _codepoints(s):
