@@ -336,7 +336,7 @@ struct BatchShape {
     int v = plain.load(std::memory_order_relaxed);
     if (v < 0) {
       static const bool force_any = getenv("CBH_FLAT_ANY") != nullptr;   // measurement / test aid: always the variant with the call
-      v = (tags && !force_any && !has_int_or_container_tag(tags, n_tags)) ? 1 : 0;
+      v = (!force_any && (n_tags == 0 || (tags && !has_int_or_container_tag(tags, n_tags)))) ? 1 : 0;   // (a table without attribute columns: nothing to look at)
       plain.store(v, std::memory_order_relaxed);
     }
     return v == 1;
