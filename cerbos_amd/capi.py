@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "cbh_alloc_pinned", "cbh_free_pinned", "cbh_batch_slab_bytes", "cbh_batch_bind_slab", "cbh_result_slab_bytes", "cbh_result_bind_slab",
     "cbh_table_load", "cbh_table_retain", "cbh_table_release", "cbh_table_broadcast_kind", "cbh_table_num_strings", "cbh_table_num_columns",
     "cbh_table_device_bytes", "cbh_table_device_ptr", "cbh_table_adopt_device_image",
-    "cbh_check_batch", "cbh_batch_upload", "cbh_batch_upload_on", "cbh_batch_release", "cbh_check_resident",
+    "cbh_check_batch", "cbh_trace_batch", "cbh_batch_upload", "cbh_batch_upload_on", "cbh_batch_release", "cbh_check_resident",
     "cbh_synchronize", "cbh_result_download", "cbh_kernel_time_ms",
 ]
 
@@ -63,6 +63,12 @@ class CResult(C.Structure):
     _fields_ = [("effect", C.c_void_p), ("policy", C.c_void_p), ("scope", C.c_void_p),
                 ("status", C.c_void_p), ("edr_mask", C.c_void_p)]
 
+
+class CTrace(C.Structure):
+    _fields_ = [("records", C.c_void_p), ("capacity", C.c_uint32), ("count", C.c_uint32)]
+
+
+TRACE_RECORD_WORDS = 8
 
 _lib = None
 
@@ -120,6 +126,8 @@ def load():
     lib.cbh_table_adopt_device_image.restype = i32
     lib.cbh_check_batch.argtypes = [vp, C.POINTER(CBatch), C.POINTER(CParams), C.POINTER(CResult)]
     lib.cbh_check_batch.restype = i32
+    lib.cbh_trace_batch.argtypes = [vp, C.POINTER(CBatch), C.POINTER(CParams), C.POINTER(CResult), C.POINTER(CTrace)]
+    lib.cbh_trace_batch.restype = i32
     lib.cbh_batch_upload.argtypes = [vp, C.POINTER(CBatch), C.POINTER(vp)]
     lib.cbh_batch_upload.restype = i32
     lib.cbh_batch_release.argtypes = [vp]
@@ -294,6 +302,21 @@ class Table:
         p = CParams(now_ns, flags, 0)
         _check(load().cbh_check_batch(self.h, C.byref(cb), C.byref(p), C.byref(res.c)))
         return res if device_order else res.to_input_order(batch)
+
+    def trace(self, batch, now_ns=0, flags=0, capacity=None):
+        """``cbh_trace_batch``: decide ``batch`` with the tracing kernel -> (Result in DEVICE order, records uint32[n][8]).
+        The log is sized from the batch and grown until it holds every record."""
+        cap = capacity or max(256, 4 * batch.n_tuples)
+        cb = make_cbatch(batch, self.num_columns)
+        p = CParams(now_ns, flags, 0)
+        while True:
+            res = Result(batch.n_tuples, batch.n_requests, ("policy", "scope", "status", "edr"))
+            rec = np.zeros((cap, TRACE_RECORD_WORDS), dtype=np.uint32)
+            tr = CTrace(rec.ctypes.data, cap, 0)
+            _check(load().cbh_trace_batch(self.h, C.byref(cb), C.byref(p), C.byref(res.c), C.byref(tr)))
+            if tr.count <= cap:
+                return res, rec[:tr.count]
+            cap = int(tr.count) + 64
 
     # ---- resident
     def broadcast_kind(self) -> str:

@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define CBH_BLOB_MAGIC 0x31484243u /* "CBH1" */
-#define CBH_BLOB_VERSION 18u
+#define CBH_BLOB_VERSION 19u
 
 struct CbhBlobHeader {  // 32 bytes
   uint32_t magic;
@@ -55,6 +55,15 @@ enum CbhSectionId {
   CBH_SEC_DRX = 31,          // u32[n_dr][16]   derived-role definitions for the flat kernel (CbhDrxField order)
   CBH_SEC_REGEX = 33,        // u32[]           DFA tables of constant `matches` patterns, back to back: {n_states, n_classes,
                              //                 classmap (256 bytes in 64 words), flags[n_states], trans[n_states][n_classes]}
+  // Trace pass (cbh_trace_batch: which CEL errors were absorbed, which rule outputs fired).  Its programs live on the same
+  // tape but keep what the decision programs fuse away: every leaf carries the id of its expression text (OP_LEAF arg =
+  // trace string id + 1), an inlined variable is closed by OP_VARSCOPE, an output expression by OP_OUT.
+  CBH_SEC_TRACE_ROWS = 34,   // u32[n_rows][8]   {cond, drcond, vars_off, vars_cnt, drvars_off, drvars_cnt, out_activated, out_not_met}:
+                             //                  program entries (CBH_NONE = none) and slices of CBH_SEC_TRACE_POOL
+  CBH_SEC_TRACE_DR = 35,     // u32[n_dr][4]     {cond, vars_off, vars_cnt, 0}
+  CBH_SEC_TRACE_RP = 36,     // u32[n_rprows][4] {cond, vars_off, vars_cnt, 0}
+  CBH_SEC_TRACE_POOL = 37,   // u32[]            entries of the variable programs of a params set, in definition order
+  CBH_SEC_TRACE_STRINGS = 38, // host only: {u32 n, {u32 len, bytes}*} expression texts, variable names and rule FQNs the trace records refer to
   CBH_SEC_ROWPAT = 29,       // u32[n_rows][8]  pattern halves of the rule records (CbhRowPatField order)
   CBH_SEC_ACTION_CLASS = 28, // u8[K] class (0..61) of a string that is a literal rule action of a resource policy, 63 = any other string
   CBH_SEC_HOST_NAMES = 27,   // host only: {u32 n, {u16 len, bytes}*} policy keys (CBH_P_TABLE ids), then the same for derived-role names
@@ -240,6 +249,11 @@ enum CbhOp {
   OP_MATCHES = 59,    // next word = offset of the pattern's tables in CBH_SEC_REGEX: TOS (string) -> RE2 MatchString
   OP_HIER = 58,       // arg = predicate (0 ancestorOf, 1 descendentOf, 2 immediateParentOf, 3 immediateChildOf, 4 siblingOf,
                       // 5 overlaps): pop b, a (dot-delimited strings) -> hierarchy(a).<predicate>(hierarchy(b))
+  OP_VARSCOPE = 62,   // TOS is the inlined definition of the variable named by trace string <arg & 0x7FFFFF>.  Mode (arg >> 23) 0,
+                      // trace programs only: an error there left the variable unset (check.go:651-677), the reference reads
+                      // "undefined field '<name>'".  Mode 1, variables of a derived-role definition (check.go:612-633): the
+                      // error is recorded and the variable is null (unset in strict mode)
+  OP_OUT = 63,        // trace programs: TOS is the value of an output expression (check.go:776-807): logged, not returned
   OP_NOPS
 };
 enum CbhIterKind { IT_ALL = 0, IT_EXISTS = 1, IT_EXISTS_ONE = 2 };

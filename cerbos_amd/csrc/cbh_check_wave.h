@@ -408,6 +408,11 @@ struct CbhPassResource { static constexpr bool value = true; };     // policy pa
 #define CBH_FEAT_PRINCIPAL_POLICIES 8
 #define CBH_FEAT_ALL 15
 #define CBH_FEAT_MAX4 16          /* a property of the batch, not the table: at most four actions per request */
+#define CBH_FEAT_TRACE 32         /* the trace pass (cbh_trace_batch): conditions run as trace programs, errors and outputs are logged */
+struct __attribute__((aligned(32))) TblTraceRow { u32 cond, drcond, vars_off, vars_cnt, drvars_off, drvars_cnt, out_activated, out_not_met; };
+struct __attribute__((aligned(16))) TblTraceCond { u32 cond, vars_off, vars_cnt, pad; };
+#define CBH_TR_DRFAIL 32u         /* w1 bit 5 of an output record: the rule's derived-role condition was not satisfied (the host */
+                                  /* drops the first such visit per evaluation key, as check.go:343-347 emits nothing there)    */
 
 template <bool GENERIC, typename AM, int FEAT>   // AM: per-request action mask, u32 when no request of the batch carries more than 32 actions
 __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
@@ -461,6 +466,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   constexpr bool F_GLOB = (FEAT & CBH_FEAT_GLOBS) != 0;
   constexpr bool F_PP = (FEAT & CBH_FEAT_PRINCIPAL_POLICIES) != 0;
   constexpr bool F_MAX4 = (FEAT & CBH_FEAT_MAX4) != 0;   // no request of the batch has more than four actions
+  constexpr bool TRACE = (FEAT & CBH_FEAT_TRACE) != 0;
   constexpr u32 GLOBBIT = F_GLOB ? CBH_PAT_GLOB : 0u;   // no glob patterns in the table: every pattern reference is a literal
   auto pmatch = [&](u32 pref, u32 sid, u64 bits) -> bool { return (F_GLOB && pref == CBH_PAT_ANY) || ((pref & GLOBBIT) ? ((bits >> (pref & 63u)) & 1ull) != 0 : pref == sid); };
   const bool want_edr = F_DR && ((flags & CBH_F_WANT_DERIVED_ROLES) != 0 || (t.flags & CBH_MF_USES_RUNTIME_EDR) != 0);
@@ -468,7 +474,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   const bool has_rolepol = F_RP && (t.flags & CBH_MF_HAS_ROLE_POLICIES) != 0;
   const bool want_ps = o.policy != nullptr || o.scope != nullptr;
 
-  Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false; L.pid = pid;
+  Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false; L.pid = pid; L.edr_errmask = 0;
   u64 edr_acc = 0;
 
   // mask of this request's actions matching an action-dimension pattern reference
@@ -693,6 +699,21 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
           if (L.status & CBH_ST_UNSUPPORTED) st_unsup |= mask;
           L.status = 0;
         };
+        // ---- trace pass: the programs that keep expression identities (cbh_blob.h CBH_SEC_TRACE_*)
+        auto trace_run = [&](u32 tpc, bool on, u32 tctx, u64 tmask) -> int {   // tmask: the actions an output belongs to
+          const u32 r = run_uniform_trace(c.ka_mem, lds_of(c), L.req, L.edr, L.edr_err, tpc, on, tctx, tmask, L.edr_errmask);
+          if (on) { L.status |= r >> 8; return (int)(r & 0xFF); }
+          return 0;
+        };
+        // every variable of the params set is evaluated, referenced or not (check.go:651-677); what they yield is not
+        // needed here - the condition programs carry the definitions inline - only the errors they raise
+        auto trace_vars = [&](u32 off, u32 cnt, bool on, u32 tctx) {
+          for (u32 i = 0; i < cnt; ++i) (void)trace_run(uload(&t.trace_pool[off + i]), on, tctx, 0);
+        };
+        auto trace_ctx = [&](u32 site) -> u32 {
+          if (ri > 0xFFu || site > 0xFFFu) L.status |= CBH_ST_UNSUPPORTED;   // beyond the record's fields
+          return ((is_res ? 1u : 0u) << 4) | ((ri & 0xFFu) << 12) | ((site & 0xFFFu) << 20);
+        };
 
         u32 chain_pos = 0;
         for (u32 si = g_first; si != CBH_NONE; si = uchain_next(t, uload(&t.scope_parent[si]), flagbit), ++chain_pos) {   // check.go:231
@@ -720,7 +741,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
             // request only, not on the role being walked: the outcome of the first DRM_SITES
             // definitions met in this group's walk is kept per lane (LDS) and replayed for the
             // request's other roles - the reference computes them once per scope too (check.go:237).
-            u64 m = 0; bool derr = false;
+            u64 m = 0, derr_names = 0; bool derr = false;
             if (have_bucket) {
               for (u32 d = bucket.z; d < bucket.z + bucket.w; ++d) {
                 const TblDr dr = uload_rec<TblDr>(t.dr, d);
@@ -733,6 +754,14 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                 if (fresh) applies = dr.parents_cnt == CBH_NONE ||
                     lane_has_parent_role(t, b, dr.parents_off, dr.parents_cnt, role_off, role_cnt, pr_scope_key, has_parents);
                 int r = 1;
+                if (TRACE) {
+                  if (wave_ballot(applies) != 0) {   // check.go:251-270: the definition's variables, then its condition
+                    const TblTraceCond td = uload_rec<TblTraceCond>(t.trace_dr, d);
+                    const u32 tctx = trace_ctx(0);
+                    trace_vars(td.vars_off, td.vars_cnt, applies, tctx);
+                    if (td.cond != CBH_NONE) r = trace_run(td.cond, applies, tctx, 0);
+                  }
+                } else
                 if (dr.cond != CBH_NONE && wave_ballot(applies) != 0) r = eval_cond<GENERIC>(c, L, dr.cond, applies);
                 if (fresh) {
                   if (!(L.status & CBH_ST_UNSUPPORTED)) {
@@ -740,15 +769,15 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                     if (applies && r == 1) DRM(1) |= dbit;
                     if (applies && (L.status & CBH_ST_CEL_ERROR)) DRM(2) |= dbit;
                   }
-                  if (applies) { if (r == 2) derr = true; else if (r == 1) m |= 1ull << dr.name; take_status(S); }
+                  if (applies) { if (r == 2) { derr = true; derr_names |= 1ull << dr.name; } else if (r == 1) m |= 1ull << dr.name; take_status(S); }
                 }
                 if (hit) {
-                  if (DRM(2) & dbit) { L.status |= CBH_ST_CEL_ERROR; if (strict) derr = true; take_status(S); }   // an error is a failed definition in strict mode
+                  if (DRM(2) & dbit) { L.status |= CBH_ST_CEL_ERROR; if (strict) { derr = true; derr_names |= 1ull << dr.name; } take_status(S); }   // an error is a failed definition in strict mode
                   else if (DRM(1) & dbit) m |= 1ull << dr.name;
                 }
               }
             }
-            if (S != 0) { L.edr = m; L.edr_err = derr; edr_acc |= m; }
+            if (S != 0) { L.edr = m; L.edr_err = derr; edr_acc |= m; if (TRACE) L.edr_errmask = derr_names; }
           }
 
           // role policies exist at (version, scope) at all?  CBH_B_RPRES is keyed by exactly that: without an entry no role
@@ -818,7 +847,14 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                     mm &= S & ~deny;
                   }
                   if (wave_ballot(mm != 0) == 0) continue;
-                  const int r = eval_cond<GENERIC>(c, L, rr.cond, mm != 0);   // synthetic row = DENY if none(cond)
+                  int r;
+                  if (TRACE) {
+                    const TblTraceCond tp = uload_rec<TblTraceCond>(t.trace_rp, row);
+                    const u32 tctx = trace_ctx(0);
+                    trace_vars(tp.vars_off, tp.vars_cnt, mm != 0, tctx);
+                    r = trace_run(tp.cond, mm != 0, tctx, 0);
+                  } else
+                  r = eval_cond<GENERIC>(c, L, rr.cond, mm != 0);   // synthetic row = DENY if none(cond)
                   if (mm != 0) {
                     take_status(mm);
                     if (r == 2) strict_deny(mm, rp_pol, si);
@@ -876,9 +912,35 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
               // request (and this scope's derived roles), so the first outcome is kept per lane for the
               // first 64 records of the walk and replayed - including the error status - afterwards.
               const AM sbit = site < AM_BITS ? (AM)((AM)1 << site) : (AM)0;
-              const bool hit = m && (memo_done & sbit) != 0;
+              const bool hit = !TRACE && m && (memo_done & sbit) != 0;   // the trace pass logs every visit
               const bool mev = m && !hit;
               int r = 1;
+              if (TRACE) {
+                const TblTraceRow tr = uload_rec<TblTraceRow>(t.trace_rows, row);
+                const u32 tctx = trace_ctx(site);
+                trace_vars(tr.vars_off, tr.vars_cnt, m, tctx);                             // check.go:306-321
+                bool drfail = false;
+                if (rw.drcond != CBH_NONE) {                                               // check.go:328-366
+                  trace_vars(tr.drvars_off, tr.drvars_cnt, m, tctx);
+                  r = trace_run(tr.drcond, m, tctx, 0);
+                  drfail = m && r == 0;
+                }
+                const bool m2 = m && r == 1;
+                if (rw.cond != CBH_NONE && wave_ballot(m2) != 0) {                         // check.go:368-380
+                  const int r2 = trace_run(tr.cond, m2, tctx, 0);
+                  if (m2) r = r2;
+                }
+                // outputs (check.go:383-411): one record per visit, the actions it stands for in the mask.  (A rule with
+                // outputs keeps one record per rule-table row - blob.py add_bucket_rows - so a visit here is a visit there.)
+                // An output expression outside the device subset costs the request its outputs, not its decision or errors.
+                const bool act = m && r == 1, notmet = m && r == 0;
+                const u32 st0 = L.status;
+                if (tr.out_activated != CBH_NONE && wave_ballot(act) != 0) (void)trace_run(tr.out_activated, act, tctx, (u64)mrow);
+                if (tr.out_not_met != CBH_NONE && wave_ballot(notmet) != 0)
+                  (void)trace_run(tr.out_not_met, notmet, tctx | (drfail ? CBH_TR_DRFAIL : 0u), (u64)mrow);
+                if ((L.status & ~st0 & CBH_ST_UNSUPPORTED) != 0) trace_log(o, L.req, CBH_TR_INCOMPLETE | tctx, 0, 1, 0, (u64)mrow);
+                L.status = st0;
+              } else
 #ifdef CBH_ABLATION
               if (abl_noeval) {} else
 #endif
@@ -1000,7 +1062,7 @@ __device__ __forceinline__ void generic_kernel_body(const KernelArgs& a, const K
   __shared__ u64 l_val[CBH_MAX_LOCALS * CBH_BLOCK];
   __shared__ u64 it_cont[CBH_MAX_ITERS * CBH_BLOCK];
   __shared__ u32 it_idx[CBH_MAX_ITERS * CBH_BLOCK];
-  __shared__ u32 it_state[CBH_MAX_ITERS * CBH_BLOCK];
+  __shared__ u32 it_state[CBH_MAX_ITERS * ((FEAT & CBH_FEAT_TRACE) ? 3 : 1) * CBH_BLOCK];   // trace pass: + the absorbed error per slot (cbh_interp.h IT_ERR_*)
   __shared__ u8 s_tag[CBH_STACK_DEPTH * CBH_BLOCK];
   __shared__ u8 l_tag[CBH_MAX_LOCALS * CBH_BLOCK];
   // The interpreter runs every lane of the wave through a program, lanes that are not evaluating it
@@ -1060,6 +1122,10 @@ CBH_DEFINE_CHECK_KERNELS(u32, CBH_FEAT_GLOBS, _a32_f4)                          
 CBH_DEFINE_CHECK_KERNELS(u32, CBH_FEAT_DERIVED_ROLES | CBH_FEAT_GLOBS, _a32_f5)             // derived roles + globs
 CBH_DEFINE_CHECK_KERNELS(u32, CBH_FEAT_ALL, _a32)   // everything: + role policies, parent roles, principal policies
 CBH_DEFINE_CHECK_KERNELS(u64, CBH_FEAT_ALL, )       // everything, > 32 actions
+// the trace pass (cbh_trace_batch): everything, every condition through its trace program
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_trace_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+  generic_kernel_body<u64, CBH_FEAT_ALL | CBH_FEAT_TRACE>(a, ka);
+}
 // the leaf kernels of the four common table classes once more for batches with <= 4 actions per request
 #define CBH_DEFINE_LEAF_A4(FEAT, SUF)                                                                                          \
   __global__ __launch_bounds__(CBH_BLOCK) CBH_FOUR_WAVES void cbh_check_kernel_leaf##SUF(const KernelArgs a, const KernelArgs* __restrict__ ka) { \

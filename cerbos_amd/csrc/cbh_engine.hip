@@ -1000,4 +1000,53 @@ extern "C" int cbh_check_batch(cbh_table* t, const cbh_batch* in, const cbh_para
   for (u32 i = 0; i < n_dev; ++i) if (rcs[i] != 0) return fail("device " + std::to_string(t->reps[i]->device) + ": " + errs[i]);
   return 0;
 }
+// The trace pass (cerbos_hip.h): the batch packed into the staging block, one copy up, the tracing kernel, the
+// results and the log down.  Not a fast path - it serves the (few) inputs whose evaluation errors / outputs are wanted.
+extern "C" int cbh_trace_batch(cbh_table* t, const cbh_batch* in, const cbh_params* p, cbh_result* out, cbh_trace* trace) {
+  if (!t || !in || !p || !out || !trace) return fail("null argument");
+  if (in->n_tuples && !out->effect) return fail("cbh_result.effect is required");
+  if (trace->capacity && !trace->records) return fail("cbh_trace.records is required");
+  TableRef ref(t);
+  Replica* rep = t->reps[0];
+  if (!rep->dev.trace_pool) return fail("the table was lowered without the trace sections");
+  BatchShape sh;
+  if (validate_batch(t, in, sh) != 0) return -1;
+  trace->count = 0;
+  if (in->n_requests == 0) return 0;
+  const Layout L = make_layout(in);
+  const size_t log_off = (L.total + 255) & ~(size_t)255;                       // {count, pad ...} then the records
+  const size_t rec_off = log_off + 256, rec_bytes = (size_t)trace->capacity * CBH_TRACE_RECORD_WORDS * 4;
+  const size_t total = rec_off + rec_bytes;
+  HIPCHK(hipSetDevice(rep->device));
+  CtxLease lease{rep, ctx_acquire(rep)};
+  OneShot* c = lease.c;
+  if (!c) return fail("could not create a launch context");
+  if (ctx_reserve(c, total, total) != 0) return -1;
+  hipStream_t s = c->s[0];
+  lease.used = 1;
+  uint8_t* base = c->d;
+  KernelArgs ka;
+  bind_args(ka, rep->dev, in, p, L, base);
+  ka.o.trace_rec = (u32*)(base + rec_off); ka.o.trace_cnt = (u32*)(base + log_off); ka.o.trace_cap = trace->capacity;
+  std::memcpy(c->h + L.args.off, &ka, sizeof(ka));
+  for (const Seg* g : {&L.req, &L.roles, &L.act, &L.ctag, &L.cval, &L.htag, &L.hval, &L.soff, &L.sbytes, &L.sflags})
+    if (g->bytes) std::memcpy(c->h + g->off, g->src, g->bytes);
+  int rc = 0;
+  HIPCHK(hipMemcpyAsync(c->d, c->h, L.in_end, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(base + log_off, 0, 256, s));
+  launch_resolve(rep, ka, L, s, rc);
+  if (rc != 0) return fail("hipMemsetAsync failed");
+  const u32 grid = (in->n_requests + CBH_BLOCK - 1) / CBH_BLOCK;
+  hipLaunchKernelGGL(cbh_trace_kernel, dim3(grid), dim3(CBH_BLOCK), check_lds_bytes(ka.b), s, ka, (const KernelArgs*)(base + L.args.off));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h + L.out_begin, c->d + L.out_begin, log_off + 256 - L.out_begin, hipMemcpyDeviceToHost, s));
+  HIPCHK(stream_wait(s));
+  struct Dst { const Seg* g; void* dst; };
+  const Dst outs[5] = {{&L.eff, out->effect}, {&L.pol, out->policy}, {&L.scope, out->scope}, {&L.status, out->status}, {&L.edr, out->edr_mask}};
+  for (const Dst& o : outs) if (o.dst && o.g->bytes) std::memcpy(o.dst, c->h + o.g->off, o.g->bytes);
+  std::memcpy(&trace->count, c->h + log_off, 4);
+  const size_t kept = std::min<size_t>(trace->count, trace->capacity);
+  if (kept) HIPCHK(hipMemcpy(trace->records, base + rec_off, kept * CBH_TRACE_RECORD_WORDS * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
 #endif  // !__HIP_DEVICE_COMPILE__

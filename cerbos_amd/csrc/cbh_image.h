@@ -44,6 +44,15 @@ static inline const char* cbh_parse_image(TableDev& d, std::vector<uint32_t>& me
   if ((m[CBH_M_NROWS] && !d.rowleaf2) || (m[CBH_M_NDR] && !d.drx)) return ("blob is missing the flat-kernel sections");
   d.regex = (const u32*)dptr(CBH_SEC_REGEX);
   if (!d.regex) return ("blob is missing the regex section");
+  // the trace pass's sections travel together or not at all (a table lowered without them serves decisions only)
+  d.trace_rows = (const u32*)dptr(CBH_SEC_TRACE_ROWS); d.trace_dr = (const u32*)dptr(CBH_SEC_TRACE_DR);
+  d.trace_rp = (const u32*)dptr(CBH_SEC_TRACE_RP); d.trace_pool = (const u32*)dptr(CBH_SEC_TRACE_POOL);
+  if (d.trace_pool) {
+    const CbhBlobSection *tr = find(CBH_SEC_TRACE_ROWS), *td = find(CBH_SEC_TRACE_DR), *tp = find(CBH_SEC_TRACE_RP);
+    if (!tr || !td || !tp || tr->nbytes < (uint64_t)m[CBH_M_NROWS] * 32 || td->nbytes < (uint64_t)m[CBH_M_NDR] * 16 ||
+        tp->nbytes < (uint64_t)m[CBH_M_NRPROWS] * 16)
+      return ("blob trace sections are incomplete");
+  }
   d.rowpat = (const u32*)dptr(CBH_SEC_ROWPAT);
   if (m[CBH_M_NROWS] && !d.rowpat) return ("blob is missing the row pattern section");
   d.rprows = (const u32*)dptr(CBH_SEC_RPROWS); d.n_rprows = m[CBH_M_NRPROWS];

@@ -69,12 +69,36 @@ __device__ __forceinline__ u64 wave_readlane64(u64 v, u32 lane) {
 #define ITS_MAP 0x40000000u
 #define ITS_FAIL 0x80000000u
 
+// One record of the trace pass's log (cerbos_hip.h cbh_trace); records beyond the capacity are counted, not stored.
+__device__ inline void trace_log(const OutDev& o, u32 w0, u32 w1, u32 w2, u32 w3, u64 v, u64 mask) {
+  if (o.trace_cnt == nullptr) return;
+#ifndef CBH_HOSTSIM
+  const u32 i = __hip_atomic_fetch_add(o.trace_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  const u32 i = (*o.trace_cnt)++;
+#endif
+  if (i >= o.trace_cap) return;
+  CBH_G u32* r = o.trace_rec + (size_t)i * CBH_TRACE_RECORD_WORDS;
+  r[0] = w0; r[1] = w1; r[2] = w2; r[3] = w3; r[4] = (u32)v; r[5] = (u32)(v >> 32); r[6] = (u32)mask; r[7] = (u32)(mask >> 32);
+}
+
+// An operation fails: the slot becomes an error whose payload (cbh_vm.h mk_errc) is that of the operand that already was
+// one - the left before the right, as cel-go reports them - else `code`.  Only the trace instantiation keeps payloads.
+#define FAILTOP1(xv, code) do { if (TRACE) SV(sp - 1) = (xv).t == CBH_T_ERR ? (xv).v : (u64)(code); ST(sp - 1) = CBH_T_ERR; } while (0)
+#define FAILTOP2(xv, yv, code) do { if (TRACE) SV(sp - 1) = (xv).t == CBH_T_ERR ? (xv).v : (yv).t == CBH_T_ERR ? (yv).v : (u64)(code); \
+                                    ST(sp - 1) = CBH_T_ERR; } while (0)
+// trace instantiation: the first error a comprehension absorbed, two dwords per slot behind the iteration state words
+#define IT_ERR_LO(slot) c.it_state[(CBH_MAX_ITERS + 2 * (slot)) * CBH_BLOCK + c.tid]
+#define IT_ERR_HI(slot) c.it_state[(CBH_MAX_ITERS + 2 * (slot) + 1) * CBH_BLOCK + c.tid]
+
 // Runs the program at wave-uniform `pc` for the lanes with active=true.
 // Per lane result: 0 = false, 1 = true, 2 = strict-mode evaluation error (inactive lanes: 0).
-#ifndef CBH_HOSTSIM
-__attribute__((noinline))
-#endif
-__device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 edr, bool edr_err, u32 pc, bool active) {
+// TRACE (cbh_trace_batch): error values carry which error they are, a failing leaf / variable / output expression is
+// logged with `tctx` (word 1 of the record) and `tmask` (the actions an output belongs to); `tfailed` = the derived roles
+// that failed in strict mode (check.go:593-610 names them in the error).
+template <bool TRACE>
+__device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLds lds, u32 req, u64 edr, bool edr_err, u32 pc, bool active,
+                                                u32 tctx, u64 tmask, u64 tfailed) {
   const Ctx c = ctx_from_memory(uniform_ptr(ka), lds);   // a real call: work from the arguments in memory
   Lane L; L.req = req; L.edr = edr; L.status = 0; L.edr_err = edr_err;   // by value: see compare_op_slow
   int sp = 0;
@@ -97,10 +121,15 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
         return (u32)result | (L.status << 8);
       }
       case OP_CONST: PUSHV(mk(c.t.const_tag[a], c.t.const_val[a])); break;
-      case OP_COL: PUSHV(load_operand(c, L, 1, a)); break;
+      case OP_COL: {
+        Val v = load_operand(c, L, 1, a);
+        if (TRACE && v.t == CBH_T_ERR) v = mk_errc(CBH_ERR_ATTR_MISSING, a);
+        PUSHV(v);
+        break;
+      }
       case OP_HASCOL: {
         u32 t = c.b.col_tag[(size_t)a * c.b.n_requests + L.req];
-        if (t == CBH_T_ERR) PUSHV(mk_err()); else PUSHV(mk_bool(t != CBH_T_ABSENT));
+        if (t == CBH_T_ERR) PUSHV(mk_errc(CBH_ERR_ATTR_MISSING, a)); else PUSHV(mk_bool(t != CBH_T_ABSENT));
         break;
       }
       case OP_REQSTR: PUSHV(load_operand(c, L, 2, a)); break;
@@ -112,18 +141,20 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
       }
       case OP_SELECT: case OP_HASSEL: {
         Val m = TOPV(0), out;
-        if (m.t != CBH_T_MAP) { ST(sp - 1) = CBH_T_ERR; break; }
+        if (m.t != CBH_T_MAP) { FAILTOP1(m, CBH_ERR_NO_SUCH_OVERLOAD); break; }
         bool f = map_find(c, m, mk(CBH_T_STRING, a), out);
         if (op == OP_HASSEL) SETTOP(mk_bool(f));
-        else if (!f) ST(sp - 1) = CBH_T_ERR;
+        else if (!f) SETTOP(mk_errc(CBH_ERR_NO_SUCH_KEY, a));
         else SETTOP(out);
         break;
       }
       case OP_INDEX: {
         Val i = TOPV(0), m = TOPV(1), out = mk_err(); --sp;
-        if (m.t == CBH_T_ERR || i.t == CBH_T_ERR) { /* error */ }
-        else if (m.t == CBH_T_MAP) { if (!map_find(c, m, i, out)) out = mk_err(); }
-        else if (m.t == CBH_T_LIST && is_num(i.t)) {
+        if (m.t == CBH_T_ERR) out = m;
+        else if (i.t == CBH_T_ERR) out = i;
+        else if (m.t == CBH_T_MAP) { if (!map_find(c, m, i, out)) out = i.t == CBH_T_STRING ? mk_errc(CBH_ERR_NO_SUCH_KEY, (u32)i.v) : mk_err(); }
+        else if (m.t != CBH_T_LIST) out = mk_errc(CBH_ERR_NO_SUCH_OVERLOAD);
+        else if (is_num(i.t)) {
           i64 k = -1;
           if (i.t == CBH_T_INT) k = (i64)i.v;
           else if (i.t == CBH_T_UINT) k = i.v < (1ull << 62) ? (i64)i.v : -1;
@@ -152,7 +183,7 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
       }
       case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_MOD: {
         Val y = TOPV(0), x = TOPV(1); --sp;
-        Val r = (x.t == CBH_T_ERR || y.t == CBH_T_ERR) ? mk_err() : arith(op, x, y);
+        Val r = x.t == CBH_T_ERR ? x : y.t == CBH_T_ERR ? y : arith(op, x, y);
         if (r.t == CBH_T_ERR && x.t != CBH_T_ERR && y.t != CBH_T_ERR &&
             (x.t == CBH_T_STRING || x.t == CBH_T_LIST) && x.t == y.t && op == OP_ADD && live)
           L.status |= CBH_ST_UNSUPPORTED;  // concatenation allocates: not on the device
@@ -161,13 +192,13 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
       }
       case OP_NEG: {
         Val x = TOPV(0);
-        if (x.t == CBH_T_INT) { if ((i64)x.v == INT64_MIN) ST(sp - 1) = CBH_T_ERR; else SV(sp - 1) = (u64)(-(i64)x.v); }
+        if (x.t == CBH_T_INT) { if ((i64)x.v == INT64_MIN) SETTOP(mk_errc(CBH_ERR_INT_OVERFLOW)); else SV(sp - 1) = (u64)(-(i64)x.v); }
         else if (x.t == CBH_T_DOUBLE) SV(sp - 1) = f64_bits(-as_f64(x.v));
-        else ST(sp - 1) = CBH_T_ERR;
+        else FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD);
         break;
       }
       case OP_NOT: {
-        if (ST(sp - 1) == CBH_T_BOOL) SV(sp - 1) = SV(sp - 1) ? 0 : 1; else ST(sp - 1) = CBH_T_ERR;
+        if (ST(sp - 1) == CBH_T_BOOL) SV(sp - 1) = SV(sp - 1) ? 0 : 1; else { const Val x = TOPV(0); FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD); }
         break;
       }
       case OP_AND: case OP_OR: {
@@ -176,20 +207,22 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
         bool xb = x.t == CBH_T_BOOL, yb = y.t == CBH_T_BOOL;
         if ((xb && x.v == absorbing) || (yb && y.v == absorbing)) SETTOP(mk_bool(absorbing != 0));
         else if (xb && yb) SETTOP(mk_bool(absorbing == 0));
-        else ST(sp - 1) = CBH_T_ERR;
+        else if (TRACE && (x.t == CBH_T_ERR || !xb)) FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD);   // the first error in evaluation order
+        else FAILTOP1(y, CBH_ERR_NO_SUCH_OVERLOAD);
         break;
       }
       case OP_TERN: {     // pop else, then, guard
         Val e = TOPV(0), t = TOPV(1), g = TOPV(2); sp -= 2;
-        if (g.t != CBH_T_BOOL) ST(sp - 1) = CBH_T_ERR; else SETTOP(g.v ? t : e);
+        if (g.t != CBH_T_BOOL) FAILTOP1(g, CBH_ERR_NO_SUCH_OVERLOAD); else SETTOP(g.v ? t : e);
         break;
       }
       case OP_JMP: pc = a; break;
       case OP_POP: --sp; break;
-      case OP_LEAF: {
+      case OP_LEAF: {   // trace programs: a = trace string id of the expression + 1
         Val x = TOPV(0);
         if (x.t == CBH_T_ERR && live) {
           L.status |= CBH_ST_CEL_ERROR;
+          if (TRACE && a != 0) trace_log(ka->o, L.req, CBH_TR_ERROR | tctx, a - 1, (u32)x.v, x.v, 0);
           if (strict) { result = 2; live = false; }
         }
         SETTOP(mk_bool(x.t == CBH_T_BOOL && x.v));
@@ -225,18 +258,18 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
         Val x = TOPV(0);
         if (x.t == CBH_T_STRING) SETTOP(mk(CBH_T_INT, str_codepoints(c, (u32)x.v)));
         else if (x.t == CBH_T_LIST || x.t == CBH_T_MAP) SETTOP(mk(CBH_T_INT, cont_len(x.v)));
-        else ST(sp - 1) = CBH_T_ERR;
+        else FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD);
         break;
       }
       case OP_STARTSWITH: case OP_ENDSWITH: case OP_CONTAINS: {
         Val y = TOPV(0), x = TOPV(1); --sp;
-        if (x.t != CBH_T_STRING || y.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
+        if (x.t != CBH_T_STRING || y.t != CBH_T_STRING) { FAILTOP2(x, y, CBH_ERR_NO_SUCH_OVERLOAD); break; }
         SETTOP(mk_bool(str_find(c, (u32)x.v, (u32)y.v, op == OP_STARTSWITH ? 0 : (op == OP_ENDSWITH ? 1 : 2))));
         break;
       }
       case OP_INDEXOF: {   // a = 0 first / 1 last
         Val y = TOPV(0), x = TOPV(1); --sp;
-        if (x.t != CBH_T_STRING || y.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
+        if (x.t != CBH_T_STRING || y.t != CBH_T_STRING) { FAILTOP2(x, y, CBH_ERR_NO_SUCH_OVERLOAD); break; }
         SETTOP(mk(CBH_T_INT, (u64)str_index_of(c, (u32)x.v, (u32)y.v, a != 0)));
         break;
       }
@@ -244,7 +277,7 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
         Val y = TOPV(0), x = TOPV(1); --sp;
         const u32 ma = a & 3u, mb = (a >> 2) & 3u;
         // a mapped side must be a string (no such overload otherwise); an unmapped side of another type is simply unequal
-        if (x.t == CBH_T_ERR || y.t == CBH_T_ERR || (ma && x.t != CBH_T_STRING) || (mb && y.t != CBH_T_STRING)) { ST(sp - 1) = CBH_T_ERR; break; }
+        if (x.t == CBH_T_ERR || y.t == CBH_T_ERR || (ma && x.t != CBH_T_STRING) || (mb && y.t != CBH_T_STRING)) { FAILTOP2(x, y, CBH_ERR_NO_SUCH_OVERLOAD); break; }
         const bool eq = x.t == CBH_T_STRING && y.t == CBH_T_STRING && str_eq_case(c, (u32)x.v, ma, (u32)y.v, mb);
         SETTOP(mk_bool(eq != ((a >> 4) & 1u)));
         break;
@@ -252,7 +285,7 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
       case OP_MATCHES: {   // next word = the pattern's tables
         const u32 off = uload(&code[pc]); ++pc;
         Val x = TOPV(0);
-        if (x.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
+        if (x.t != CBH_T_STRING) { FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD); break; }
         SETTOP(mk_bool(regex_match(c, off, (u32)x.v)));
         break;
       }
@@ -261,33 +294,34 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
         if (x.t == CBH_T_STRING && y.t == CBH_T_STRING) { SETTOP(mk_bool(hier_pred(c, a, (u32)x.v, (u32)y.v))); break; }
         // hierarchy(list of strings) is valid CEL the device does not evaluate; anything else is "no such overload"
         if ((x.t == CBH_T_LIST || y.t == CBH_T_LIST) && x.t != CBH_T_ERR && y.t != CBH_T_ERR && live) L.status |= CBH_ST_UNSUPPORTED;
-        ST(sp - 1) = CBH_T_ERR;
+        FAILTOP2(x, y, CBH_ERR_NO_SUCH_OVERLOAD);
         break;
       }
       case OP_TIMESTAMP: {
         Val x = TOPV(0);
         if (x.t == CBH_T_TIMESTAMP) break;
-        if (x.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
+        if (x.t != CBH_T_STRING) { FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD); break; }
         gbytes p; u32 n; str_span(c, (u32)x.v, p, n);
         i64 ns = 0; int rc = parse_timestamp(p, n, ns);
         if (rc == 2 && live) L.status |= CBH_ST_UNSUPPORTED;
-        if (rc != 0) { ST(sp - 1) = CBH_T_ERR; break; }
+        if (rc != 0) { SETTOP(mk_err()); break; }
         SETTOP(mk(CBH_T_TIMESTAMP, (u64)ns));
         break;
       }
       case OP_DURATION: {
         Val x = TOPV(0);
         if (x.t == CBH_T_DURATION) break;
-        if (x.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
+        if (x.t != CBH_T_STRING) { FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD); break; }
         gbytes p; u32 n; str_span(c, (u32)x.v, p, n);
         i64 ns = 0;
-        if (parse_duration(p, n, ns) != 0) { ST(sp - 1) = CBH_T_ERR; break; }
+        if (parse_duration(p, n, ns) != 0) { SETTOP(mk_err()); break; }
         SETTOP(mk(CBH_T_DURATION, (u64)ns));
         break;
       }
       case OP_TIMESINCE: {
         Val x = TOPV(0); i64 r;
-        if (x.t != CBH_T_TIMESTAMP || __builtin_sub_overflow(c.now_ns, (i64)x.v, &r)) { ST(sp - 1) = CBH_T_ERR; break; }
+        if (x.t != CBH_T_TIMESTAMP) { FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD); break; }
+        if (__builtin_sub_overflow(c.now_ns, (i64)x.v, &r)) { SETTOP(mk_err()); break; }
         SETTOP(mk(CBH_T_DURATION, (u64)r));
         break;
       }
@@ -296,12 +330,13 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
         const i64 off_s = (i64)(int)uload(&code[pc]); ++pc;
         Val x = TOPV(0);
         i64 r = 0;
-        if (!ts_getter(x, a, off_s, r)) { ST(sp - 1) = CBH_T_ERR; break; }
+        if (!ts_getter(x, a, off_s, r)) { FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD); break; }
         SETTOP(mk(CBH_T_INT, (u64)r));
         break;
       }
       case OP_EDRHAS: {
-        if (L.edr_err) PUSHV(mk_err()); else PUSHV(mk_bool((L.edr >> a) & 1));
+        if (L.edr_err) PUSHV((TRACE && (tfailed >> 56) == 0) ? mk(CBH_T_ERR, (u64)CBH_ERR_EDR_FAILED | (tfailed << 8)) : mk_err());
+        else PUSHV(mk_bool((L.edr >> a) & 1));
         break;
       }
       case OP_LOCAL: PUSHV(mk(c.l_tag[a * CBH_BLOCK + c.tid], c.l_val[a * CBH_BLOCK + c.tid])); break;
@@ -310,7 +345,11 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
         Val x = TOPV(0); --sp;
         const u32 kind = uload(&code[pc]); ++pc;
         u32 st = kind | (live ? ITS_ENTRY_LIVE : 0);
-        if (x.t != CBH_T_LIST && x.t != CBH_T_MAP) { st |= ITS_FAIL; x.v = 0; }
+        if (x.t != CBH_T_LIST && x.t != CBH_T_MAP) {
+          st |= ITS_FAIL;
+          if (TRACE) { const u64 e = x.t == CBH_T_ERR ? x.v : (u64)CBH_ERR_NO_SUCH_OVERLOAD; IT_ERR_LO(a) = (u32)e; IT_ERR_HI(a) = (u32)(e >> 32); }
+          x.v = 0;
+        }
         else { if (live) st |= ITS_RUNNING; if (x.t == CBH_T_MAP) st |= ITS_MAP; }   // lanes that are not live sit the loop out
         c.it_cont[a * CBH_BLOCK + c.tid] = x.v;
         c.it_idx[a * CBH_BLOCK + c.tid] = 0;
@@ -351,6 +390,9 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
         if (st & ITS_RUNNING) {
           const u32 kind = st & 0xFF;
           if (x.t != CBH_T_BOOL) {
+            if (TRACE && !(st & ITS_ERRSEEN)) {   // the first one is the one `acc && pred` keeps
+              const u64 e = x.t == CBH_T_ERR ? x.v : (u64)CBH_ERR_NO_SUCH_OVERLOAD; IT_ERR_LO(a) = (u32)e; IT_ERR_HI(a) = (u32)(e >> 32);
+            }
             if (kind == IT_EXISTS_ONE) { st |= ITS_FAIL; st &= ~ITS_RUNNING; }   // errors propagate
             else st |= ITS_ERRSEEN;                                               // may be absorbed
           } else if (kind == IT_ALL) { if (!x.v) { st |= ITS_DECIDED; st &= ~ITS_RUNNING; } }
@@ -365,26 +407,27 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
         const u32 st = c.it_state[a * CBH_BLOCK + c.tid];
         const u32 kind = st & 0xFF;
         if (result != 2) live = (st & ITS_ENTRY_LIVE) != 0;
-        if (st & ITS_FAIL) { PUSHV(mk_err()); break; }
-        if (kind == IT_ALL) { if (st & ITS_DECIDED) PUSHV(mk_bool(false)); else if (st & ITS_ERRSEEN) PUSHV(mk_err()); else PUSHV(mk_bool(true)); }
-        else if (kind == IT_EXISTS) { if (st & ITS_DECIDED) PUSHV(mk_bool(true)); else if (st & ITS_ERRSEEN) PUSHV(mk_err()); else PUSHV(mk_bool(false)); }
+        const Val ierr = mk(CBH_T_ERR, TRACE ? ((u64)IT_ERR_LO(a) | ((u64)IT_ERR_HI(a) << 32)) : 0ull);
+        if (st & ITS_FAIL) { PUSHV(ierr); break; }
+        if (kind == IT_ALL) { if (st & ITS_DECIDED) PUSHV(mk_bool(false)); else if (st & ITS_ERRSEEN) PUSHV(ierr); else PUSHV(mk_bool(true)); }
+        else if (kind == IT_EXISTS) { if (st & ITS_DECIDED) PUSHV(mk_bool(true)); else if (st & ITS_ERRSEEN) PUSHV(ierr); else PUSHV(mk_bool(false)); }
         else PUSHV(mk_bool(((st >> 16) & 0x3FFFu) == 1));
         break;
       }
       case OP_TOINT: {
         Val x = TOPV(0);
         if (x.t == CBH_T_INT) break;
-        if (x.t == CBH_T_UINT) { if (x.v > (u64)INT64_MAX) ST(sp - 1) = CBH_T_ERR; else ST(sp - 1) = CBH_T_INT; break; }
+        if (x.t == CBH_T_UINT) { if (x.v > (u64)INT64_MAX) SETTOP(mk_errc(CBH_ERR_INT_OVERFLOW)); else ST(sp - 1) = CBH_T_INT; break; }
         if (x.t == CBH_T_DOUBLE) {
           double d = as_f64(x.v);
-          if (d != d || d >= 9223372036854775807.0 || d <= -9223372036854775808.0) ST(sp - 1) = CBH_T_ERR;
+          if (d != d || d >= 9223372036854775807.0 || d <= -9223372036854775808.0) SETTOP(mk_errc(CBH_ERR_INT_OVERFLOW));
           else SETTOP(mk(CBH_T_INT, (u64)(i64)d));
           break;
         }
         if (x.t == CBH_T_TIMESTAMP) { i64 ns = (i64)x.v; i64 s = ns / 1000000000LL; if (ns % 1000000000LL < 0) --s; SETTOP(mk(CBH_T_INT, (u64)s)); break; }
         if (x.t == CBH_T_DURATION) { ST(sp - 1) = CBH_T_INT; break; }
         if (x.t == CBH_T_STRING && live) L.status |= CBH_ST_UNSUPPORTED;
-        ST(sp - 1) = CBH_T_ERR;
+        FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD);
         break;
       }
       case OP_TODOUBLE: {
@@ -393,23 +436,23 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
         if (x.t == CBH_T_INT) { SETTOP(mk(CBH_T_DOUBLE, f64_bits((double)(i64)x.v))); break; }
         if (x.t == CBH_T_UINT) { SETTOP(mk(CBH_T_DOUBLE, f64_bits((double)x.v))); break; }
         if (x.t == CBH_T_STRING && live) L.status |= CBH_ST_UNSUPPORTED;
-        ST(sp - 1) = CBH_T_ERR;
+        FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD);
         break;
       }
       case OP_INIPRANGE: {
         Val y = TOPV(0), x = TOPV(1); --sp;
-        if (x.t != CBH_T_STRING || y.t != CBH_T_STRING) { ST(sp - 1) = CBH_T_ERR; break; }
+        if (x.t != CBH_T_STRING || y.t != CBH_T_STRING) { FAILTOP2(x, y, CBH_ERR_NO_SUCH_OVERLOAD); break; }
         gbytes pi, pc2; u32 ni, nc;
         str_span(c, (u32)x.v, pi, ni); str_span(c, (u32)y.v, pc2, nc);
         const int r = ip_in_range(pi, ni, pc2, nc);
         if (r == -2 && live) L.status |= CBH_ST_UNSUPPORTED;
-        if (r < 0) { ST(sp - 1) = CBH_T_ERR; break; }
+        if (r < 0) { SETTOP(mk_err()); break; }
         SETTOP(mk_bool(r == 1));
         break;
       }
       case OP_HASINTERSECTION: case OP_ISSUBSET: {
         Val y = TOPV(0), x = TOPV(1); --sp;
-        if (x.t != CBH_T_LIST || y.t != CBH_T_LIST) { ST(sp - 1) = CBH_T_ERR; break; }
+        if (x.t != CBH_T_LIST || y.t != CBH_T_LIST) { FAILTOP2(x, y, CBH_ERR_NO_SUCH_OVERLOAD); break; }
         bool any = false, all = true;
         for (u32 i = 0; i < cont_len(x.v); ++i) {
           Val e = heap_get(c, cont_sel(x.v), cont_off(x.v) + i);
@@ -418,6 +461,26 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
           any |= in; all &= in;
         }
         SETTOP(mk_bool((op == OP_HASINTERSECTION) ? any : all));
+        break;
+      }
+      case OP_VARSCOPE: {   // a = trace string id of the variable's name | mode << 23: TOS is the variable's inlined definition
+        if (ST(sp - 1) == CBH_T_ERR) {
+          if ((a >> 23) != 0 && !strict) {
+            // a derived-role DEFINITION's variables go through evaluateVariables (check.go:612-633): the error is recorded and
+            // the variable is null; every other params set through evaluatePrograms (:651-677), which leaves it unset
+            if (live) L.status |= CBH_ST_CEL_ERROR;
+            SETTOP(mk(CBH_T_NULL, 0));
+          } else if (TRACE) SV(sp - 1) = (u64)CBH_ERR_UNDEFINED_FIELD | ((u64)(a & 0x7FFFFFu) << 8);   // unset: "undefined field '<name>'"
+        }
+        break;
+      }
+      case OP_OUT: {        // trace programs: a = trace string id of the rule's FQN; next word = id of the rule's evaluation key
+        const u32 ek = uload(&code[pc]); ++pc;
+        const Val x = TOPV(0);
+        if (TRACE && live) {
+          if (x.t == CBH_T_ERR) trace_log(ka->o, L.req, CBH_TR_OUTPUT_ERROR | tctx, a, (u32)x.v, (u64)ek | ((x.v >> 32) << 32), tmask);
+          else trace_log(ka->o, L.req, CBH_TR_OUTPUT | tctx, a, x.t | (ek << 8), x.v, tmask);
+        }
         break;
       }
       case OP_UNSUPPORTED:
@@ -430,4 +493,22 @@ __device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 e
   }
   L.status |= CBH_ST_UNSUPPORTED;  // step budget exhausted
   return (u32)result | (L.status << 8);
+}
+#undef FAILTOP1
+#undef FAILTOP2
+#undef IT_ERR_LO
+#undef IT_ERR_HI
+
+#ifndef CBH_HOSTSIM
+__attribute__((noinline))
+#endif
+__device__ u32 run_uniform(const KernelArgs* ka, const VmLds lds, u32 req, u64 edr, bool edr_err, u32 pc, bool active) {
+  return run_uniform_impl<false>(ka, lds, req, edr, edr_err, pc, active, 0u, 0ull, 0ull);
+}
+#ifndef CBH_HOSTSIM
+__attribute__((noinline))
+#endif
+__device__ u32 run_uniform_trace(const KernelArgs* ka, const VmLds lds, u32 req, u64 edr, bool edr_err, u32 pc, bool active, u32 tctx,
+                                 u64 tmask, u64 tfailed) {
+  return run_uniform_impl<true>(ka, lds, req, edr, edr_err, pc, active, tctx, tmask, tfailed);
 }

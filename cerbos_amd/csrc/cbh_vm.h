@@ -50,6 +50,8 @@ struct TableDev {
   const CBH_G u32* rowleaf2;                                // [n_rows][8] fused-leaf records of the rows' derived-role conditions
   const CBH_G u32* drx;                                     // [n_dr][16] derived-role definitions for the flat kernel (CbhDrxField)
   const CBH_G u32* regex;                                   // CBH_SEC_REGEX: DFA tables of constant `matches` patterns
+  const CBH_G u32* trace_rows; const CBH_G u32* trace_dr;   // CBH_SEC_TRACE_*: the trace pass's programs per rule / derived-role /
+  const CBH_G u32* trace_rp; const CBH_G u32* trace_pool;   // role-policy record (cbh_trace_batch only)
   const CBH_G u32* rowpat;                                  // [n_rows][8] pattern halves (cbh_blob.h CbhRowPatField)
   const CBH_G u32* rprows; u32 n_rprows;
   const CBH_G u32* pool;
@@ -79,7 +81,10 @@ struct BatchDev {
   CBH_G u64* gbits; // [3][n_strings], written by the resolve kernel
 };
 
-struct OutDev { CBH_G u8* effect; CBH_G u32* policy; CBH_G u32* scope; CBH_G u8* status; CBH_G u64* edr; };
+struct OutDev {
+  CBH_G u8* effect; CBH_G u32* policy; CBH_G u32* scope; CBH_G u8* status; CBH_G u64* edr;
+  CBH_G u32* trace_rec; CBH_G u32* trace_cnt; u32 trace_cap; u32 pad;   // the trace pass's log (cerbos_hip.h cbh_trace), else null
+};
 
 // Launch arguments of the decision kernel.  They live in device memory (one uniform pointer
 // as the only kernel argument) so that every table / batch base address is a scalar load.
@@ -93,6 +98,7 @@ struct Lane {           // per-lane evaluation state that programs can observe
   u32 status;           // CBH_ST_* accumulated
   bool edr_err;         // strict mode: derived roles of this scope failed to evaluate
   u32 pid;              // principal id, valid in the table walk only (leaf_fast reads P.id from here)
+  u64 edr_errmask;      // trace pass only: WHICH derived roles failed (bit = name index), for the error's text
 };
 
 struct Ctx {
@@ -130,6 +136,9 @@ __device__ __forceinline__ Ctx ctx_from_memory(const KernelArgs* ka, const VmLds
 
 __device__ __forceinline__ Val mk(u32 t, u64 v) { Val x; x.t = t; x.v = v; return x; }
 __device__ __forceinline__ Val mk_err() { return mk(CBH_T_ERR, 0); }
+// An error value's payload says which error it is (cerbos_hip.h CBH_ERR_*: code | detail << 8).  Only the trace pass reads
+// it; an error that meets another keeps the payload of the one CEL would report (the left operand's).
+__device__ __forceinline__ Val mk_errc(u32 code, u32 detail = 0) { return mk(CBH_T_ERR, (u64)code | ((u64)detail << 8)); }
 __device__ __forceinline__ Val mk_bool(bool b) { return mk(CBH_T_BOOL, b ? 1u : 0u); }
 __device__ __forceinline__ double as_f64(u64 v) { return __longlong_as_double((long long)v); }
 __device__ __forceinline__ u64 f64_bits(double d) { return (u64)__double_as_longlong(d); }
@@ -641,31 +650,31 @@ __device__ inline Val arith(u32 op, Val a, Val b) {
       case OP_SUB: r = x - y; break;
       case OP_MUL: r = x * y; break;
       case OP_DIV: r = x / y; break;
-      default: return mk_err();
+      default: return mk_errc(CBH_ERR_NO_SUCH_OVERLOAD);
     }
     return mk(CBH_T_DOUBLE, f64_bits(r));
   }
   if (a.t == CBH_T_INT && b.t == CBH_T_INT) {
     i64 x = (i64)a.v, y = (i64)b.v, r;
     switch (op) {
-      case OP_ADD: if (__builtin_add_overflow(x, y, &r)) return mk_err(); break;
-      case OP_SUB: if (__builtin_sub_overflow(x, y, &r)) return mk_err(); break;
-      case OP_MUL: if (__builtin_mul_overflow(x, y, &r)) return mk_err(); break;
-      case OP_DIV: if (y == 0 || (x == INT64_MIN && y == -1)) return mk_err(); r = x / y; break;
-      case OP_MOD: if (y == 0 || (x == INT64_MIN && y == -1)) return mk_err(); r = x % y; break;
-      default: return mk_err();
+      case OP_ADD: if (__builtin_add_overflow(x, y, &r)) return mk_errc(CBH_ERR_INT_OVERFLOW); break;
+      case OP_SUB: if (__builtin_sub_overflow(x, y, &r)) return mk_errc(CBH_ERR_INT_OVERFLOW); break;
+      case OP_MUL: if (__builtin_mul_overflow(x, y, &r)) return mk_errc(CBH_ERR_INT_OVERFLOW); break;
+      case OP_DIV: if (y == 0) return mk_errc(CBH_ERR_DIV_BY_ZERO); if (x == INT64_MIN && y == -1) return mk_errc(CBH_ERR_INT_OVERFLOW); r = x / y; break;
+      case OP_MOD: if (y == 0) return mk_errc(CBH_ERR_MOD_BY_ZERO); if (x == INT64_MIN && y == -1) return mk_errc(CBH_ERR_INT_OVERFLOW); r = x % y; break;
+      default: return mk_errc(CBH_ERR_NO_SUCH_OVERLOAD);
     }
     return mk(CBH_T_INT, (u64)r);
   }
   if (a.t == CBH_T_UINT && b.t == CBH_T_UINT) {
     u64 x = a.v, y = b.v, r;
     switch (op) {
-      case OP_ADD: if (__builtin_add_overflow(x, y, &r)) return mk_err(); break;
-      case OP_SUB: if (y > x) return mk_err(); r = x - y; break;
-      case OP_MUL: if (__builtin_mul_overflow(x, y, &r)) return mk_err(); break;
-      case OP_DIV: if (y == 0) return mk_err(); r = x / y; break;
-      case OP_MOD: if (y == 0) return mk_err(); r = x % y; break;
-      default: return mk_err();
+      case OP_ADD: if (__builtin_add_overflow(x, y, &r)) return mk_errc(CBH_ERR_UINT_OVERFLOW); break;
+      case OP_SUB: if (y > x) return mk_errc(CBH_ERR_UINT_OVERFLOW); r = x - y; break;
+      case OP_MUL: if (__builtin_mul_overflow(x, y, &r)) return mk_errc(CBH_ERR_UINT_OVERFLOW); break;
+      case OP_DIV: if (y == 0) return mk_errc(CBH_ERR_DIV_BY_ZERO); r = x / y; break;
+      case OP_MOD: if (y == 0) return mk_errc(CBH_ERR_MOD_BY_ZERO); r = x % y; break;
+      default: return mk_errc(CBH_ERR_NO_SUCH_OVERLOAD);
     }
     return mk(CBH_T_UINT, r);
   }
@@ -686,13 +695,14 @@ __device__ inline Val arith(u32 op, Val a, Val b) {
     if (a.t == CBH_T_TIMESTAMP && b.t == CBH_T_DURATION) { if (__builtin_sub_overflow(x, y, &r)) return mk_err(); return mk(CBH_T_TIMESTAMP, (u64)r); }
     if (a.t == CBH_T_DURATION && b.t == CBH_T_DURATION) { if (__builtin_sub_overflow(x, y, &r)) return mk_err(); return mk(CBH_T_DURATION, (u64)r); }
   }
-  return mk_err();  // no such overload (incl. string/list concatenation: not on the device)
+  return mk_errc(CBH_ERR_NO_SUCH_OVERLOAD);  // (incl. string/list concatenation: not on the device)
 }
 
 
 // comparison / membership operators on two already-loaded values -> bool or error
 __device__ inline Val compare_op(const Ctx& c, Lane& L, u32 op, Val x, Val y) {
-  if (x.t == CBH_T_ERR || y.t == CBH_T_ERR) return mk_err();
+  if (x.t == CBH_T_ERR) return x;
+  if (y.t == CBH_T_ERR) return y;
   if (op == OP_EQ || op == OP_NE) {
     bool e = val_equal(c, L, x, y);
     return mk_bool(op == OP_EQ ? e : !e);
@@ -704,11 +714,11 @@ __device__ inline Val compare_op(const Ctx& c, Lane& L, u32 op, Val x, Val y) {
       for (u32 i = 0; i < n && !found; ++i) found = val_equal(c, L, x, heap_get(c, cont_sel(y.v), cont_off(y.v) + i));
     } else if (y.t == CBH_T_MAP) {
       Val tmp; found = map_find(c, y, x, tmp);
-    } else return mk_err();
+    } else return mk_errc(CBH_ERR_NO_SUCH_OVERLOAD);
     return mk_bool(found);
   }
   int r = val_compare(c, x, y);
-  if (r == 3) return mk_err();
+  if (r == 3) return mk_errc(CBH_ERR_NO_SUCH_OVERLOAD);
   bool res = false;
   if (r != 2) res = (op == OP_LT) ? r < 0 : (op == OP_LE) ? r <= 0 : (op == OP_GT) ? r > 0 : r >= 0;
   return mk_bool(res);

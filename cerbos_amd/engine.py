@@ -54,6 +54,7 @@ class Conf:
 
 class HipEvaluator:
     _ingest = None
+    _py_flattener = None
     _ingest_lock = threading.Lock()   # check_pb / check_request_pb are called from many threads
 
     def __init__(self, lowered: LoweredTable, conf: Conf = None, device: int = 0, native_ingest: bool = False):
@@ -93,8 +94,14 @@ class HipEvaluator:
 
     # -- the seam -------------------------------------------------------------------------
     def check(self, inputs, now_ns=None, lenient_scope_search=None, strict_evaluation=None,
-              default_policy_version=None, default_scope=None, allow_unsupported=False):
-        """``Evaluator.Check``: one CheckOutput per CheckInput, same order."""
+              default_policy_version=None, default_scope=None, allow_unsupported=False, trace=False):
+        """``Evaluator.Check``: one CheckOutput per CheckInput, same order.
+
+        ``trace``: also fill ``evaluationErrors`` and ``outputs`` as check.go:90-92 does.  They come from a second launch
+        (``cbh_trace_batch``) over the inputs that can have any: the ones a decision kernel marked CBH_ST_CEL_ERROR, or all
+        of them when the table has variables (evaluated whether a condition reads them or not) or output expressions.
+        With ``allow_unsupported`` the result is then (outputs, unsupported inputs, {input: {"errors", "outputs"}} = what the
+        device could not name all of for that input); without it such inputs raise."""
         conf = self.conf
         lenient = conf.lenient_scope_search if lenient_scope_search is None else lenient_scope_search
         strict = conf.strict_evaluation if strict_evaluation is None else strict_evaluation
@@ -109,7 +116,59 @@ class HipEvaluator:
         if strict:
             flags |= capi.F_STRICT_EVALUATION
         res = self.table.check(batch, now_ns=now_ns, flags=flags)
-        return self.assemble(inputs, batch, res, dver, allow_unsupported)
+        if not trace:
+            return self.assemble(inputs, batch, res, dver, allow_unsupported)
+        outs, bad = self.assemble(inputs, batch, res, dver, True)
+        incomplete = self._trace(inputs, batch, res, outs, bad, now_ns, flags, dver, dscope)
+        if (bad or incomplete) and not allow_unsupported:
+            raise DeviceUnsupported(sorted(set(bad) | set(incomplete)), self.lt.unsupported + self.lt.trace_unsupported)
+        return (outs, bad, incomplete) if allow_unsupported else outs
+
+    def _trace(self, inputs, batch, res, outs, bad, now_ns, flags, dver, dscope):
+        """The trace pass for the inputs that need it; fills outs[i]["evaluationErrors"] / ["outputs"] in place and returns
+        the inputs left incomplete."""
+        from .trace import TraceDecoder
+        lt = self.lt
+        for o in outs:
+            o["evaluationErrors"] = []
+            o["outputs"] = []
+        if lt.trace_has_variables or lt.trace_has_outputs:
+            sel = [i for i in range(len(inputs)) if i not in set(bad)]
+        else:
+            sel, t = [], 0
+            skip = set(bad)
+            for i in range(len(inputs)):
+                n = len(batch.actions_per_request[i])
+                if i not in skip and (res.status[t:t + n] == capi.ST_CEL_ERROR).any():
+                    sel.append(i)
+                t += n
+        if not sel:
+            return {}
+        sub = [inputs[i] for i in sel]
+        if self._py_flattener is None:
+            self._py_flattener = Flattener(lt)
+        sbatch = self._py_flattener.flatten(sub, dver, dscope)
+        tres, records = self.table.trace(sbatch, now_ns=now_ns, flags=flags)
+        decoded = TraceDecoder(lt, sbatch, sub).decode(records, len(records), tres.status)
+        # the tracing kernel decides the inputs again: anything but the same effects is a defect, never to be papered over
+        tin = tres.to_input_order(sbatch)
+        t = 0
+        for j, i in enumerate(sel):
+            for a in sbatch.actions_per_request[j]:
+                if _EFFECT_NAMES[int(tin.effect[t])] != outs[i]["actions"][a]["effect"] and int(tin.status[t]) != capi.ST_UNSUPPORTED:
+                    raise RuntimeError("trace pass and decision pass disagree on input %d action %r" % (i, a))
+                t += 1
+        incomplete = {}
+        for j, i in enumerate(sel):
+            d = decoded[j]
+            outs[i]["evaluationErrors"] = d["evaluationErrors"]
+            outs[i]["outputs"] = d["outputs"]
+            what = set(d["incomplete"])
+            if lt.trace_outputs_partial:
+                what.add("outputs")
+            if what:
+                incomplete[i] = what
+        return incomplete
 
     def check_pb(self, data, offsets, now_ns=None, lenient_scope_search=None, strict_evaluation=None,
                  default_policy_version=None, default_scope=None):

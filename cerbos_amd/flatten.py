@@ -202,6 +202,7 @@ class Flattener:
         b = Batch()
         b.actions_per_request = [list(inp.get("actions") or []) for inp in inputs]
         b.vreq_input = np.array([i for i, _ in chunks], dtype=np.int64)
+        b.vreq_actions = [acts for _, acts in chunks]   # per device request (before any routing sort): its action names
         for r, (i_in, acts) in enumerate(chunks):
             inp = inputs[i_in]
             p, res = inp["principal"], inp["resource"]

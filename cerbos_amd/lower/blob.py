@@ -25,7 +25,7 @@ from .celc import COND_LEAF, COND_LEAFTREE, COND_PC_MASK, LoweringError, Params,
 from .globs import GlobNFA, fix_glob, has_meta
 
 BLOB_MAGIC = 0x31484243
-BLOB_VERSION = 18
+BLOB_VERSION = 19
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
 PAT_ANY = 0x7FFFFFFF     # the lone "*": matches every string, no automaton needed
@@ -36,6 +36,7 @@ ROW_LEAF = 8           # dwords 8..15: the embedded fused-leaf record
 (PAT_ACTION, PAT_ROLE, PAT_RESOURCE, PAT_COUNTS, PAT_A1, _, PAT_R1, _) = range(8)   # CbhRowPatField
 ROW_F_LEAF_EMBEDDED = 64
 SEC_ACTION_CLASS, SEC_ROWPAT, SEC_ROWLEAF2, SEC_DRX, SEC_REGEX = 28, 29, 30, 31, 33
+SEC_TRACE_ROWS, SEC_TRACE_DR, SEC_TRACE_RP, SEC_TRACE_POOL, SEC_TRACE_STRINGS = 34, 35, 36, 37, 38
 ROW_F_DRLEAF_EMBEDDED = 128
 ROW_F_TREE_EMBEDDED, ROW_F_DRTREE_EMBEDDED = 256, 512   # the slot holds a tree descriptor (_tree_descriptor)
 MF_FLAT_CLOSED = 512
@@ -111,7 +112,7 @@ def _cond_uses_runtime(cond, params: Params):
     return any(_cond_uses_runtime(c, params) for c in cond[1])
 
 
-def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
+def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # noqa: C901
     lt = LoweredTable()
     globals_ = dict(globals_ or {})
 
@@ -221,6 +222,9 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
     dr_cols = [[] for _ in range(4)]
     dr_parents = []   # per derived-role record: its parent role strings
     entries = []  # (k0,k1,k2,k3, v0,v1,v2,v3)
+    trace_row_rules = []   # per device row: (a rule-table row of its rule, principal policy?) - the trace pass's programs are compiled last
+    trace_dr_defs = []     # per derived-role record: its definition
+    trace_rp_rules = []    # per role-policy record: its rule
 
     def row_programs(r, principal_policy):
         params = Params(r["params"]["constants"], r["params"]["ordered_variables"], globals_) if r["params"] else Params(None, None, globals_)
@@ -265,11 +269,13 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
             if not blocks or blocks[-1][0] != ident:
                 blocks.append((ident, {}))
             cond, drc = row_programs(r, principal_policy)
-            sig = (r["resource"], r["effect"], cond, drc)
+            # a rule with an output expression keeps the reference's rows one by one: every visit of a row emits an
+            # OutputEntry (check.go:383-411), so their number and order are observable
+            sig = (r["resource"], r["effect"], cond, drc) + ((r["id"],) if trace and r["emit_output"] else ())
             blocks[-1][1].setdefault(sig, []).append(r)
         n = 0
         for _ident, groups in blocks:
-            for (resource, effect, cond, drc), grp in groups.items():
+            for (resource, effect, cond, drc, *_row), grp in groups.items():
                 roles = list(dict.fromkeys(r["role"] for r in grp))
                 actions = list(dict.fromkeys(r["action"] for r in grp))
                 pairs = {(r["role"], r["action"]) for r in grp}
@@ -295,6 +301,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
                         pat_cols[PAT_R1 + i].append(r_more[i])
                     row_roles.append(None if principal_policy else rl)
                     row_actions.append(None if principal_policy else al)
+                    trace_row_rules.append((grp[0], principal_policy))
                     n += 1
         return n
 
@@ -316,7 +323,8 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
                 dr_cols[1].append(len(pool))
                 dr_cols[2].append(len(dr["parent_roles"]))
                 pool.extend(sid(p) for p in dr["parent_roles"])
-            dparams = Params(dr["constants"], dr["ordered_variables"], globals_)
+            trace_dr_defs.append(dr)
+            dparams = Params(dr["constants"], dr["ordered_variables"], globals_, null_on_error=True)
             # a derived-role definition that reads runtime.effectiveDerivedRoles sees, in the reference, the
             # roles of whichever scope/action was processed last (check.go:262,281): not reproducible per tuple
             dr_cols[3].append(pb.condition_program(dr["condition"], dparams, allow_runtime=False)
@@ -347,6 +355,7 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
             rp_cols[1].append(len(pool))
             rp_cols[2].append(len(r["allow_actions"]))
             pool.extend(allow_action_ref(a) for a in r["allow_actions"])
+            trace_rp_rules.append(r)
             if r["id"] in rp_history_dependent:
                 rp_cols[3].append(pb.unsupported_program(namer.policy_key_from_fqn(r["origin_fqn"]),
                                                          "role-policy rules for overlapping resource globs share an evaluation key but "
@@ -367,6 +376,75 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
                 continue
             entries.append((B_PARENTS, lt.scope_index[scope], sid(role), 0, len(pool), len(ancestors), 0, 0))
             pool.extend(sid(a) for a in ancestors)
+
+    # ---- the trace pass's programs (cbh_trace_batch; cbh_blob.h CBH_SEC_TRACE_*), compiled after every decision program so
+    # that the columns only they read (variables nothing references, output expressions) come last
+    trace_pool, trace_rows, trace_dr, trace_rp = [], [], [], []
+    if trace:
+        var_slices = {}
+        rule_ids = {}   # evaluation key -> the small id output records carry
+
+        def tparams(p):
+            return Params(p["constants"], p["ordered_variables"], globals_, trace=True) if p else Params(None, None, globals_, trace=True)
+
+        def var_slice(tp):
+            k = tp.key()
+            if k not in var_slices:
+                pcs = pb.trace_variable_programs(tp)
+                var_slices[k] = (len(trace_pool), len(pcs))
+                trace_pool.extend(pcs)
+            return var_slices[k]
+
+        for r, principal_policy in trace_row_rules:
+            tp = tparams(r["params"])
+            if principal_policy and _cond_uses_runtime(r["condition"], Params(tp.constants, tp.ordered_variables, globals_)):
+                cond = pb.trace_unsupported_program(namer.policy_key_from_fqn(r["origin_fqn"]), "history dependent (check.go:281)")
+            else:
+                cond = pb.trace_condition_program(r["condition"], tp) if r["condition"] is not None else NONE
+            voff, vcnt = var_slice(tp) if r["params"] else (0, 0)
+            drc, doff, dcnt = NONE, 0, 0
+            if r["derived_role_condition"] is not None:
+                dtp = tparams(r["derived_role_params"])
+                drc = pb.trace_condition_program(r["derived_role_condition"], dtp)
+                doff, dcnt = var_slice(dtp) if r["derived_role_params"] else (0, 0)
+            out_act = out_not = NONE
+            emit = r["emit_output"] or {}
+            if emit:
+                m = rt["meta"].get(r["origin_fqn"])
+                src = namer.rule_fqn(m["kind"], m["name"], m["version"], r["scope"], r["name"]) if m else ""
+                rule_id = rule_ids.setdefault(r["evaluation_key"], len(rule_ids))
+                if rule_id >= 1 << 24:
+                    raise LoweringError("more than 2^24 rules with outputs")
+                if emit.get("rule_activated"):
+                    out_act = pb.trace_output_program(emit["rule_activated"], tp, src, rule_id)
+                if emit.get("condition_not_met"):
+                    out_not = pb.trace_output_program(emit["condition_not_met"], tp, src, rule_id)
+            trace_rows.append([cond, drc, voff, vcnt, doff, dcnt, out_act, out_not])
+        for dr in trace_dr_defs:
+            dtp = Params(dr["constants"], dr["ordered_variables"], globals_, trace=True, null_on_error=True)
+            voff, vcnt = var_slice(dtp)
+            trace_dr.append([pb.trace_condition_program(dr["condition"], dtp, allow_runtime=False) if dr["condition"] is not None else NONE,
+                             voff, vcnt, 0])
+        for r in trace_rp_rules:
+            tp = tparams(r["params"])
+            voff, vcnt = var_slice(tp) if r["params"] else (0, 0)
+            if r["id"] in rp_history_dependent:
+                cond = pb.trace_unsupported_program(namer.policy_key_from_fqn(r["origin_fqn"]), "history dependent (ruletable.go:445-455)")
+            elif r.get("emit_output"):
+                # the synthetic rows swap the two outputs and emit them without a condition too (index.go:436-530)
+                cond = pb.trace_unsupported_program(namer.policy_key_from_fqn(r["origin_fqn"]), "outputs of role-policy rules")
+            else:
+                cond = pb.trace_condition_program(r["condition"], tp) if r["condition"] is not None else NONE
+            trace_rp.append([cond, voff, vcnt, 0])
+    lt.theap = (list(pb.theap_tag), [int(v) & 0xFFFFFFFFFFFFFFFF for v in pb.theap_val])   # constant lists / maps an output may yield
+    lt.trace_strings = list(pb.trace_strings)
+    lt.trace_unsupported = list(dict.fromkeys(pb.trace_unsupported))
+    # does the table ask for the trace pass beyond the tuples the decision kernels mark CBH_ST_CEL_ERROR?  Variables are
+    # evaluated whether or not a condition reads them (check.go:651-677), outputs on every visit of their rule
+    lt.trace_has_outputs = any(tr[6] != NONE or tr[7] != NONE for tr in trace_rows) or any(r.get("emit_output") for r in trace_rp_rules)
+    lt.trace_has_variables = bool(trace_pool)
+    # outputs of role-policy rules (index.go:436-530 emits them from synthetic rows, some without a condition): not traced
+    lt.trace_outputs_partial = any(r.get("emit_output") for r in trace_rp_rules)
 
     # ---- glob automata + match bits of the table's own strings
     gbits = np.zeros((3, 0), dtype=np.uint64)
@@ -598,6 +676,18 @@ def lower_rule_table(rt: dict, globals_=None) -> LoweredTable:  # noqa: C901
         # host only: policy keys of CBH_P_TABLE policy words, then derived-role names in edr_mask bit order
         (SEC_HOST_NAMES, len(lt.policy_keys) + len(lt.dr_names), _names(lt.policy_keys) + _names(lt.dr_names)),
     ]
+    if trace:
+        def records(rows, width):
+            return np.asarray(rows, dtype=np.uint32).reshape(len(rows), width).tobytes()
+        tstr = struct.pack("<I", len(lt.trace_strings)) + b"".join(
+            struct.pack("<I", len(b)) + b for b in (x.encode("utf-8") for x in lt.trace_strings))
+        sections += [
+            (SEC_TRACE_ROWS, len(trace_rows), records(trace_rows, 8)),
+            (SEC_TRACE_DR, len(trace_dr), records(trace_dr, 4)),
+            (SEC_TRACE_RP, len(trace_rp), records(trace_rp, 4)),
+            (SEC_TRACE_POOL, len(trace_pool), u32(trace_pool or [0])),
+            (SEC_TRACE_STRINGS, len(lt.trace_strings), tstr),   # host only
+        ]
     lt.blob = _pack(sections)
     lt.stats = {
         "strings": K, "scopes": len(lt.scopes), "rows": len(row_cols[0]), "role_policy_rows": len(rp_cols[0]),

@@ -26,7 +26,7 @@ from . import regex
  OP_EDRHAS, OP_LOCAL, OP_ITER_BEGIN, OP_ITER_NEXT, OP_ITER_ACC, OP_ITER_END, OP_TOINT,
  OP_TODOUBLE, OP_TOSTRING_UNSUPPORTED, OP_INIPRANGE, OP_UNSUPPORTED, OP_TS_GETTER,
  OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN, OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC,
- OP_TREE_END, OP_HIER, OP_MATCHES, OP_INDEXOF, OP_STREQ_CASE) = range(62)
+ OP_TREE_END, OP_HIER, OP_MATCHES, OP_INDEXOF, OP_STREQ_CASE, OP_VARSCOPE, OP_OUT) = range(64)
 
 TREE_KINDS = {"all": 0, "any": 1, "none": 2}
 COND_LEAF = 0x80000000
@@ -81,7 +81,7 @@ _R_FIELDS = {"id": RQ_S_RESOURCE_ID, "kind": RQ_S_KIND, "scope": RQ_S_R_SCOPE,
 _ID_ONLY_OPS = frozenset([OP_RET, OP_CONST, OP_COL, OP_HASCOL, OP_REQSTR, OP_ROLES, OP_SELECT, OP_HASSEL, OP_INDEX, OP_EQ, OP_NE,
                           OP_IN, OP_NOT, OP_JF, OP_JT, OP_AND, OP_OR, OP_JTERN, OP_JMP, OP_POP, OP_LEAF, OP_EDRHAS, OP_LOCAL,
                           OP_ITER_BEGIN, OP_ITER_NEXT, OP_ITER_ACC, OP_ITER_END, OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN,
-                          OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC, OP_TREE_END, OP_UNSUPPORTED, OP_TS_GETTER])
+                          OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC, OP_TREE_END, OP_UNSUPPORTED, OP_TS_GETTER, OP_VARSCOPE, OP_OUT])
 
 
 class LoweringError(ValueError):
@@ -148,15 +148,21 @@ def _subst(ast, fn):
 class Params:
     """Constants + variables visible to one condition (RuleRow.Params)."""
 
-    def __init__(self, constants=None, ordered_variables=None, globals_=None):
+    def __init__(self, constants=None, ordered_variables=None, globals_=None, trace=False, null_on_error=False):
         self.constants = dict(constants or {})
-        self.variables = {n: t for n, t in (ordered_variables or [])}
+        self.ordered_variables = list(ordered_variables or [])
+        self.variables = {n: t for n, t in self.ordered_variables}
         self.globals = dict(globals_ or {})
+        # trace programs (ProgramBuilder.trace_*): an inlined variable stays recognisable - ("varscope", name, body) - because
+        # the reference evaluates it on its own and a failure there reads differently at the place of use (check.go:651-677)
+        self.trace = trace
+        # the variables of a derived-role definition (evaluateVariables, check.go:612-633): a failing one is null, not unset
+        self.null_on_error = null_on_error
         self._inlined = {}
 
     def key(self):
         return (tuple(sorted((k, repr(v)) for k, v in self.constants.items())),
-                tuple(sorted(self.variables.items())))
+                tuple(self.ordered_variables), self.trace, self.null_on_error)
 
     def inline(self, ast, depth=0):
         if depth > 32:
@@ -170,6 +176,8 @@ class Params:
                         return ("call", "__unsupported__", None, ())
                     if name not in self._inlined:
                         self._inlined[name] = self.inline(celparser.parse(self.variables[name]), depth + 1)
+                    if self.trace or self.null_on_error:
+                        return ("varscope", name, self._inlined[name], 1 if self.null_on_error else 0)
                     return self._inlined[name]
                 if base in ("C", "constants"):
                     if name not in self.constants:
@@ -177,6 +185,8 @@ class Params:
                     return value_to_ast(self.constants[name])
                 if base in ("G", "globals"):
                     if name not in self.globals:
+                        if self.trace:
+                            return ("call", "__undef__", None, (("lit", "string", name),))
                         return ("call", "__error__", None, ())   # undefined field -> CEL error
                     return value_to_ast(self.globals[name])
             return n
@@ -210,6 +220,17 @@ class ProgramBuilder:
         self.has_generic = False           # some program needs the operand-stack interpreter
         self.max_stack = 0
         self.max_locals = 0
+        # the trace pass (cbh_trace_batch): strings its records refer to - expression texts, variable names, rule FQNs
+        self.trace_strings = []
+        self.trace_index = {}
+        self.trace_unsupported = []        # [(expr text, reason)] of trace programs only
+
+    def tid(self, text):
+        i = self.trace_index.get(text)
+        if i is None:
+            i = self.trace_index[text] = len(self.trace_strings)
+            self.trace_strings.append(text)
+        return i
 
     # ---- pools ---------------------------------------------------------------------
     def const(self, tag, val):
@@ -413,6 +434,80 @@ class ProgramBuilder:
         return pc
 
 
+    # ---- trace programs (cbh_blob.h CBH_SEC_TRACE_*): what the trace pass runs instead of the decision programs.  Same
+    # expressions, nothing fused: every leaf ends in OP_LEAF <text id + 1>, which logs a failure under the expression's
+    # text; variables keep their OP_VARSCOPE.  They never change what the decision kernels are chosen by or upload
+    # (has_generic, uses_runtime, the string / request-field flags): cbh_trace_batch uploads everything.
+    def _trace_compile(self, key, build):
+        pc = self.programs.get(key)
+        if pc is not None:
+            return pc
+        saved = (self.uses_runtime, self.reads_string_bytes, set(self.req_fields), self.has_generic, self.unsupported)
+        self.unsupported = self.trace_unsupported
+        try:
+            fc = build()
+            fc.emit(OP_RET)
+            pc = len(self.code)
+            self.code.extend(fc.finish(pc))
+        finally:
+            self.uses_runtime, self.reads_string_bytes, self.req_fields, self.has_generic, self.unsupported = saved
+        if pc >= COND_PC_MASK:
+            raise LoweringError("bytecode tape exceeds 2^30 words")
+        if fc.max_depth > MAX_STACK:
+            raise LoweringError("trace program needs operand stack depth %d (device limit %d)" % (fc.max_depth, MAX_STACK))
+        self.max_stack = max(self.max_stack, fc.max_depth)
+        self.max_locals = max(self.max_locals, fc.max_locals)
+        self.programs[key] = pc
+        return pc
+
+    def trace_condition_program(self, cond, params: Params, allow_runtime=True):
+        assert params.trace
+
+        def build():
+            fc = _FuncCompiler(self, params, allow_runtime, trace=True)
+            fc.cond(cond)
+            return fc
+        return self._trace_compile(("trace-cond", cond, params.key(), allow_runtime), build)
+
+    def trace_unsupported_program(self, text, reason):
+        def build():
+            fc = _FuncCompiler(self, Params(trace=True), True, trace=True)
+            fc.cur_text = text
+            fc.unsupported(reason)
+            fc.emit(OP_LEAF)
+            return fc
+        return self._trace_compile(("trace-unsupported", text, reason), build)
+
+    def trace_variable_programs(self, params: Params):
+        """Entries of one program per variable of the params set, in definition order (evaluatePrograms,
+        check.go:651-677): each evaluates the definition and logs a failure under its text."""
+        assert params.trace
+        out = []
+        for name, text in params.ordered_variables:
+            def build(text=text):
+                fc = _FuncCompiler(self, params, True, trace=True)
+                fc.cur_text = text
+                fc.expr(params.inline(celparser.parse(text)))
+                fc.emit(OP_LEAF, self.tid(text) + 1)
+                return fc
+            out.append(self._trace_compile(("trace-var", text, params.key()), build))
+        return out
+
+    def trace_output_program(self, text, params: Params, src, rule_id):
+        """evaluateOutput (check.go:776-807): the expression's value (or its error) logged under the rule's FQN and the id
+        of its evaluation key."""
+        assert params.trace
+
+        def build():
+            fc = _FuncCompiler(self, params, True, trace=True)
+            fc.cur_text = text
+            fc.expr(params.inline(celparser.parse(text)))
+            fc.emit(OP_OUT, self.tid(src))
+            fc.word(rule_id)
+            return fc
+        return self._trace_compile(("trace-out", text, params.key(), src, rule_id), build)
+
+
 class _Unsupported(Exception):
     pass
 
@@ -464,10 +559,11 @@ def _is_const(ast):
 
 
 class _FuncCompiler:
-    def __init__(self, pb: ProgramBuilder, params: Params, allow_runtime: bool):
+    def __init__(self, pb: ProgramBuilder, params: Params, allow_runtime: bool, trace=False):
         self.pb = pb
         self.params = params
         self.allow_runtime = allow_runtime
+        self.trace = trace
         self.out = []          # list of ints or ('label', id) / ('ref', op, id)
         self.depth = 0
         self.max_depth = 0
@@ -545,12 +641,12 @@ class _FuncCompiler:
         if op == "expr":
             self.cur_text = c[1]
             ast = self.params.inline(celparser.parse(c[1]))
-            if self._fused_leaf(ast):
+            if not self.trace and self._fused_leaf(ast):
                 return
             d0 = self.depth
             self.expr(ast)
             assert self.depth == d0 + 1, (c[1], self.depth, d0)
-            self.emit(OP_LEAF)
+            self.emit(OP_LEAF, (self.pb.tid(c[1]) + 1) if self.trace else 0)
             return
         kids = c[1]
         if not kids:
@@ -761,12 +857,19 @@ class _FuncCompiler:
             return self._call(ast)
         if k == "comp":
             return self._comp(ast)
+        if k == "varscope":   # trace programs: the inlined definition of variable ast[1]
+            self._expr(ast[2])
+            return self.emit(OP_VARSCOPE, pb.tid(ast[1]) | (ast[3] << 23))
         return self.unsupported("%s expression" % k)
 
     def _call(self, ast):
         _, name, target, args = ast
         if name == "__unsupported__":
             return self.unsupported("reference to an undefined variable or constant")
+        if name == "__undef__":   # trace programs: an undefined global reads "undefined field '<name>'"
+            self.emit(OP_CONST, self.pb.const(T_NULL, 0), +1)
+            self.emit(OP_NEG)
+            return self.emit(OP_VARSCOPE, self.pb.tid(args[0][2]))
         if name == "__error__":
             # evaluates to a CEL error without marking the tuple unsupported
             self.emit(OP_CONST, self.pb.const(T_NULL, 0), +1)

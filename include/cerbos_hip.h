@@ -237,6 +237,56 @@ int cbh_result_download(cbh_table* t, cbh_device_batch* b, cbh_result* out);
  * launches, measured with HIP events on the library's own stream. */
 int cbh_kernel_time_ms(cbh_table* t, float* check_kernel_ms, float* resolve_kernel_ms);
 
+/* ---- Trace pass: evaluation_errors and outputs (evaluator/cel_errors.go:48-118, check.go:383-411, 776-807) ----
+ * The decision kernels only mark the tuples whose evaluation absorbed a CEL error (CBH_ST_CEL_ERROR).  What the
+ * reference reports beyond the effect - the (expression, message) pairs and the values of the rules' output
+ * expressions - comes from a second launch over the inputs that need it (the ones with that mark, or every input of
+ * a table with outputs): the same walk, with programs that keep the expression identities, writing fixed-size
+ * records to a log.  cbh_trace_batch decides `in` again (its result must equal cbh_check_batch's) and fills the log.
+ *
+ * A record is eight 32-bit words:
+ *   w0  request index (into `in`)
+ *   w1  kind (bits 0-3) | pass << 4 (0 principal policies, 1 resource policies) | (bit 5, see w4) |
+ *       role iteration << 12 | site << 20
+ *       (site = position of the rule record in this request's walk of that pass; outputs are ordered by action, pass,
+ *        role iteration, site as check.go's loops nest)
+ *   w2  trace string id: the expression text (errors), or the rule's FQN (outputs)   [CBH_SEC_TRACE_STRINGS]
+ *   w3  CBH_TR_ERROR / CBH_TR_OUTPUT_ERROR: error code | detail << 8;  CBH_TR_OUTPUT: value tag (cbh_value_tag) | rule << 8
+ *   w4, w5  CBH_TR_ERROR: the whole error payload (code | detail << 8, 64 bits); CBH_TR_OUTPUT: the value (64 bits; strings are string ids, lists / maps refer to the batch heap);
+ *           CBH_TR_OUTPUT_ERROR: w4 = rule.   (rule = a small id per evaluation key, ruletable.go's EvaluationKey: w1 bit 5
+ *           marks a visit whose derived-role condition failed - check.go:343-347 emits nothing on the FIRST such visit
+ *           of a key and conditionNotMet on later ones, which the consumer replays)
+ *   w6, w7  CBH_TR_OUTPUT*: mask of the request's actions the rule was visited for (bit k = k-th action)
+ * count may exceed capacity: the log overflowed, call again with a larger one. */
+#define CBH_TR_ERROR 1u         /* a condition / variable expression failed */
+#define CBH_TR_OUTPUT 2u        /* an output expression produced a value */
+#define CBH_TR_OUTPUT_ERROR 3u  /* an output expression failed: OutputEntry.error */
+#define CBH_TR_INCOMPLETE 4u    /* an output expression of this request is outside the device subset: its outputs are not all */
+                                /* here.  (A condition / variable outside the subset marks the tuples CBH_ST_UNSUPPORTED.)     */
+/* error codes (w3 bits 0-7); detail = w3 >> 8 */
+#define CBH_ERR_OTHER 0u            /* an error the device does not classify: the message is not available */
+#define CBH_ERR_NO_SUCH_KEY 1u      /* "no such key: <string detail>"            (detail = string id) */
+#define CBH_ERR_ATTR_MISSING 2u     /* an attribute path did not resolve; detail = column index: "no such key: <first missing */
+                                    /* key of the path>" or, below a non-map value, "no such overload"                        */
+#define CBH_ERR_NO_SUCH_OVERLOAD 3u /* "no such overload" */
+#define CBH_ERR_UNDEFINED_FIELD 4u  /* "undefined field '<name>'"                (detail = trace string id of the variable) */
+#define CBH_ERR_DIV_BY_ZERO 5u      /* "division by zero" */
+#define CBH_ERR_MOD_BY_ZERO 6u      /* "modulus by zero" */
+#define CBH_ERR_INT_OVERFLOW 7u     /* "integer overflow" */
+#define CBH_ERR_UINT_OVERFLOW 8u    /* "unsigned integer overflow" */
+#define CBH_ERR_EDR_FAILED 9u       /* strict mode: "failed to compute effective derived roles [a, b]"; the 56-bit detail (w4, w5 = */
+                                    /* the whole payload, code in the low byte) = mask of the failed roles, bit = edr_mask bit       */
+#define CBH_TRACE_RECORD_WORDS 8u
+
+typedef struct cbh_trace {
+  uint32_t* records;  /* [capacity][CBH_TRACE_RECORD_WORDS] */
+  uint32_t capacity;  /* records that fit */
+  uint32_t count;     /* out: records the pass produced */
+} cbh_trace;
+
+/* Decide `in` with the tracing kernel on the table's first device: `out` as cbh_check_batch, `trace` as above. */
+int cbh_trace_batch(cbh_table* t, const cbh_batch* in, const cbh_params* p, cbh_result* out, cbh_trace* trace);
+
 #ifdef __cplusplus
 }
 #endif

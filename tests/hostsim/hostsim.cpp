@@ -83,7 +83,11 @@ static KernelArgs* g_args;
 
 static uint32_t g_max_actions, g_max_roles, g_threads; static bool g_flat, g_plain;   // same kernel selection as cbh_check_resident (cbh_engine.hip)
 
+static bool g_trace;   // hostsim_trace: the trace pass's kernel (cbh_trace_batch)
+
 static void fiber_main() {
+  if (g_trace) cbh_trace_kernel(*g_args, g_args);
+  else
   cbh_pick_kernel(g_args->t.flags, g_args->t.n_dr, (g_args->t.nfa_words[0] | g_args->t.nfa_words[1] | g_args->t.nfa_words[2] | (g_args->t.flags & CBH_MF_HAS_ANY_PATTERN)) != 0, g_max_actions, g_max_roles, g_plain, g_args->flags, &g_threads, &g_flat)(*g_args, g_args);
   g_fibers[g_cur].done = true;
   g_fibers[g_cur].waiting = 0;
@@ -147,8 +151,7 @@ static void run_block(uint32_t blk) {
 
 // gbits: [3][n_strings] glob match bits of the batch-local strings (computed by the caller with the
 // Python simulation of the same automaton).
-extern "C" int hostsim_check(const void* blob, size_t len, const cbh_batch* in, const cbh_params* p,
-                             cbh_result* out, uint64_t* gbits) {
+static int run_sim(const void* blob, size_t len, const cbh_batch* in, const cbh_params* p, cbh_result* out, uint64_t* gbits, cbh_trace* trace) {
   KernelArgs a{};
   std::vector<uint32_t> meta;
   const uint8_t* base = static_cast<const uint8_t*>(blob);
@@ -164,7 +167,13 @@ extern "C" int hostsim_check(const void* blob, size_t len, const cbh_batch* in, 
   b.str_off = in->str_off; b.str_bytes = in->str_bytes; b.str_flags = in->str_flags; b.gbits = gbits;
   if (!b.roles) b.roles = none;
   if (!b.tuple_action) b.tuple_action = none;
-  a.o = OutDev{out->effect, out->policy, out->scope, out->status, out->edr_mask};
+  a.o = OutDev{out->effect, out->policy, out->scope, out->status, out->edr_mask, nullptr, nullptr, 0, 0};
+  g_trace = trace != nullptr;
+  if (trace) {
+    if (!a.t.trace_pool) { g_err = "the table was lowered without the trace sections"; return -1; }
+    trace->count = 0;
+    a.o.trace_rec = trace->records; a.o.trace_cnt = &trace->count; a.o.trace_cap = trace->capacity;
+  }
   a.now_ns = p->now_ns; a.flags = p->flags;
   if (a.o.edr) std::memset(a.o.edr, 0, sizeof(uint64_t) * in->n_requests);
   g_args = &a;
@@ -191,4 +200,12 @@ extern "C" int hostsim_check(const void* blob, size_t len, const cbh_batch* in, 
     for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
   }
   return 0;
+}
+extern "C" int hostsim_check(const void* blob, size_t len, const cbh_batch* in, const cbh_params* p,
+                             cbh_result* out, uint64_t* gbits) {
+  return run_sim(blob, len, in, p, out, gbits, nullptr);
+}
+extern "C" int hostsim_trace(const void* blob, size_t len, const cbh_batch* in, const cbh_params* p,
+                             cbh_result* out, uint64_t* gbits, cbh_trace* trace) {
+  return run_sim(blob, len, in, p, out, gbits, trace);
 }

@@ -34,6 +34,9 @@ def lib():
         _lib.hostsim_check.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(capi.CBatch), C.POINTER(capi.CParams),
                                        C.POINTER(capi.CResult), C.c_void_p]
         _lib.hostsim_check.restype = C.c_int
+        _lib.hostsim_trace.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(capi.CBatch), C.POINTER(capi.CParams),
+                                       C.POINTER(capi.CResult), C.c_void_p, C.POINTER(capi.CTrace)]
+        _lib.hostsim_trace.restype = C.c_int
         _lib.hostsim_last_error.restype = C.c_char_p
     return _lib
 
@@ -61,3 +64,23 @@ def check(lt, batch, now_ns=0, flags=0, device_order=False):
     if rc != 0:
         raise RuntimeError(lib().hostsim_last_error().decode())
     return res if device_order else res.to_input_order(batch)
+
+
+def trace(lt, batch, now_ns=0, flags=0):
+    """The trace pass (cbh_trace_batch) on the simulator -> (Result in device order, records uint32[n][8])."""
+    cap = max(256, 4 * batch.n_tuples)
+    cb = capi.make_cbatch(batch, len(lt.columns))
+    p = capi.CParams(now_ns, flags, 0)
+    g = batch_gbits(lt, batch)
+    buf = C.create_string_buffer(lt.blob, len(lt.blob))
+    while True:
+        res = capi.Result(batch.n_tuples, batch.n_requests, ("policy", "scope", "status", "edr"))
+        rec = np.zeros((cap, capi.TRACE_RECORD_WORDS), dtype=np.uint32)
+        tr = capi.CTrace(rec.ctypes.data, cap, 0)
+        rc = lib().hostsim_trace(C.cast(buf, C.c_void_p), len(lt.blob), C.byref(cb), C.byref(p), C.byref(res.c),
+                                 g.ctypes.data_as(C.c_void_p), C.byref(tr))
+        if rc != 0:
+            raise RuntimeError(lib().hostsim_last_error().decode())
+        if tr.count <= cap:
+            return res, rec[:tr.count]
+        cap = int(tr.count) + 64

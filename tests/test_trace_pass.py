@@ -1,0 +1,211 @@
+"""The trace pass (cbh_trace_batch; cbh_check_wave.h CBH_FEAT_TRACE): ``evaluation_errors`` and ``outputs`` of a CheckOutput
+(evaluator/cel_errors.go:48-118, check.go:383-411, 776-807), which the decision kernels leave at one "an error was
+absorbed" bit per tuple.
+
+* the reference's own engine cases (tests/golden/engine_cases.json, engine_test.go:46-210): evaluationErrors and outputs
+  exactly as the reference returned them, for every input the device says it can name them for;
+* the Go-coded KATs of TestCELErrorsCheck / TestStrictEvaluationCheck: the ordered failing expressions;
+* differential fuzz against oracle/check.py on stores with variables (referenced, unreferenced, failing, chained), outputs
+  on rules (values of every scalar kind, attribute lists / maps, failing expressions) and derived-role definitions with
+  variables: same (expression, message) pairs, same OutputEntry list in the same order.
+
+CPU tier: the kernel source on the host simulator.  GPU tier: the same through libcerbos_hip.so."""
+import os
+
+import numpy as np
+import pytest
+
+import test_fuzz_parity as fz
+import test_hostsim_golden as hg
+import test_ruletable_kats as kats
+from cerbos_amd.engine import Conf, HipEvaluator
+from cerbos_amd.lower.blob import lower_rule_table
+from cerbos_amd.lower.celc import LoweringError
+from cerbos_amd.policy.loader import policies_from_docs
+from cerbos_amd.ruletable.build import rule_table_from_policies
+from helpers import load_json, norm_actions, store_rule_table
+from oracle.check import EvalParams, RuleTableOracle
+
+NOW = 1_700_000_000_000_000_000
+CASES = load_json("engine_cases.json")
+GLOBALS = {"environment": "test"}
+
+
+def _engine_cases(ev):
+    named = verified_outputs = total = 0
+    for case in CASES:
+        for lenient in hg._modes(case):
+            outs, bad, incomplete = ev.check(case["inputs"], now_ns=NOW, lenient_scope_search=lenient, allow_unsupported=True,
+                                             trace=True, strict_evaluation=case.get("strict"))
+            for i, (have, want) in enumerate(zip(outs, case["wantOutputs"])):
+                if i in bad:
+                    continue
+                total += 1
+                what = incomplete.get(i, ())
+                if "errors" not in what:
+                    assert have["evaluationErrors"] == (want.get("evaluationErrors") or []), (case["name"], lenient, i)
+                    named += 1
+                if "outputs" not in what:
+                    assert have["outputs"] == (want.get("outputs") or []), (case["name"], lenient, i)
+                    verified_outputs += bool(want.get("outputs"))
+    return total, named, verified_outputs
+
+
+def _store_table():
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    # the store's role policies carry outputs (engine/case_27, case_28), which the pass does not trace: every input would
+    # be "outputs incomplete".  Judge the rest: an input that reaches such a rule is still flagged by its trace program.
+    lt.trace_outputs_partial = False
+    return lt
+
+
+def test_engine_cases_errors_and_outputs_as_the_reference_returned_them():
+    total, named, verified_outputs = _engine_cases(hg.HostSimEvaluator(_store_table(), Conf(globals_=GLOBALS)))
+    assert named >= total - 4, (total, named)     # all but the inputs that reach a role-policy rule with an output
+    assert verified_outputs >= 8, verified_outputs  # case_22 (rule activated / condition not met), case_38 (a failing output)
+
+
+@pytest.mark.gpu
+def test_gpu_engine_cases_errors_and_outputs():
+    ev = HipEvaluator(_store_table(), Conf(globals_=GLOBALS))
+    try:
+        total, named, verified_outputs = _engine_cases(ev)
+    finally:
+        ev.close()
+    assert named >= total - 4 and verified_outputs >= 8
+
+
+def _kat_expressions(make, close):
+    rt = rule_table_from_policies(policies_from_docs(kats.FIX["policies"]))
+    lt = lower_rule_table(rt)
+    ev = make(lt)
+    try:
+        for strict in (False, True):
+            cases = [c for c in kats.FIX["cases"] if c["strict"] == strict]
+            outs, bad, incomplete = ev.check([kats._input(c) for c in cases], now_ns=NOW, strict_evaluation=strict,
+                                             allow_unsupported=True, trace=True)
+            assert not bad and not incomplete, (bad, incomplete)
+            for c, out in zip(cases, outs):
+                assert [e["celError"]["expression"] for e in out["evaluationErrors"]] == c["wantErrorExpressions"], (c["name"], strict)
+                assert all(e["celError"]["message"] for e in out["evaluationErrors"])
+    finally:
+        if close:
+            ev.close()
+
+
+def test_go_kats_failing_expressions_in_order():
+    _kat_expressions(lambda lt: hg.HostSimEvaluator(lt, Conf()), False)
+
+
+@pytest.mark.gpu
+def test_gpu_go_kats_failing_expressions_in_order():
+    _kat_expressions(lambda lt: HipEvaluator(lt, Conf()), True)
+
+
+# ---- differential fuzz ------------------------------------------------------------------------------------------------
+VARIABLES = {
+    "is_owner": "R.attr.owner == P.id",
+    "dept": "R.attr.department",                       # fails when the attribute is missing
+    "same_dept": "V.dept == P.attr.department",       # chained: undefined field 'dept' when that one failed
+    "big": "R.attr.amount > 100",                     # "no such overload" for the wrongly typed amounts
+    "ratio": "10 / (P.attr.level - P.attr.level)",    # division by zero (or a missing key)
+    "region": "R.attr.tags.region",                   # nested path: the key that is missing differs per request
+    "unused": "P.attr.nickname",                      # nothing reads it: still evaluated, still reported
+}
+VAR_CONDITIONS = ["V.is_owner", "V.same_dept", "V.big && R.attr.public == true", 'V.region == "eu"', "V.ratio > 1",
+                  'V.dept in ["eng", "ops"]', "variables.big || V.is_owner"]
+OUTPUTS = ['"fixed"', "P.id", "R.attr.status", "R.attr.amount > 100", "R.attr.amount", "P.attr.teams", "R.attr.tags", "R.attr.nothing",
+           "V.dept", "P.roles", "size(P.attr.teams)", "null", "R.attr.acl[P.id]", '["a", "b"]']
+
+
+def _trace_policies(rng):
+    docs = fz._policies(rng)
+    for d in docs:
+        rp = d.get("resourcePolicy")
+        if rp is None:
+            if "derivedRoles" in d and rng.random() < 0.7:
+                d["derivedRoles"]["variables"] = {"local": {"lvl": "P.attr.level", "dept": "R.attr.department"}}
+                d["derivedRoles"]["definitions"][2]["condition"] = {"match": {"expr": "V.lvl >= 4"}}
+                if rng.random() < 0.5:
+                    d["derivedRoles"]["definitions"][0]["condition"] = {"match": {"expr": 'V.dept != "legal" && R.attr.owner == P.id'}}
+            continue
+        if rng.random() < 0.7:
+            names = [str(x) for x in rng.choice(sorted(VARIABLES), size=int(rng.integers(2, len(VARIABLES) + 1)), replace=False)]
+            if "same_dept" in names and "dept" not in names:
+                names.append("dept")
+            rp["variables"] = {"local": {n: VARIABLES[n] for n in names}}
+            usable = [c for c in VAR_CONDITIONS if all(("V.%s" % v not in c and "variables.%s" % v not in c) or v in names for v in VARIABLES)]
+            for rule in rp["rules"]:
+                if usable and rng.random() < 0.5:
+                    rule["condition"] = {"match": {"expr": str(rng.choice(usable))}}
+        for k, rule in enumerate(rp["rules"]):
+            if rng.random() < 0.45:
+                outs = [o for o in OUTPUTS if "V.dept" not in o or "dept" in (rp.get("variables") or {}).get("local", {})]
+                when = {}
+                if rng.random() < 0.8:
+                    when["ruleActivated"] = str(rng.choice(outs))
+                if rng.random() < 0.6 or not when:
+                    when["conditionNotMet"] = str(rng.choice(outs))
+                rule["name"] = "rule-%d" % k
+                rule["output"] = {"when": when}
+    return docs
+
+
+def _fuzz_seed(seed, make, close):
+    rng = np.random.default_rng(77_000 + seed)
+    docs = _trace_policies(rng)
+    rt = rule_table_from_policies(policies_from_docs(docs))
+    try:
+        lt = lower_rule_table(rt)
+    except LoweringError:
+        return None
+    ev = make(lt)
+    orc = RuleTableOracle(rt)
+    inputs = fz._requests(rng, 120)
+    errors = outputs = with_errors = with_outputs = 0
+    try:
+        for lenient, strict in ((False, False), (True, False), (False, True)):
+            outs, bad, incomplete = ev.check(inputs, now_ns=NOW, lenient_scope_search=lenient, strict_evaluation=strict,
+                                             allow_unsupported=True, trace=True)
+            params = EvalParams(now_ns=NOW, lenient_scope_search=lenient, strict_evaluation=strict)
+            for i, (inp, have) in enumerate(zip(inputs, outs)):
+                if i in bad:
+                    continue
+                want = orc.check(inp, params)
+                assert norm_actions(have) == norm_actions(want), (seed, lenient, strict, inp)
+                what = incomplete.get(i, ())
+                if "errors" not in what:
+                    assert have["evaluationErrors"] == (want.get("evaluationErrors") or []), (seed, lenient, strict, inp)
+                    errors += 1
+                    with_errors += bool(want.get("evaluationErrors"))
+                if "outputs" not in what:
+                    assert have["outputs"] == (want.get("outputs") or []), (seed, lenient, strict, inp)
+                    outputs += 1
+                    with_outputs += bool(want.get("outputs"))
+    finally:
+        if close:
+            ev.close()
+    return errors, outputs, with_errors, with_outputs
+
+
+SEEDS = list(range(int(os.environ.get("CBH_TRACE_FUZZ_SEEDS", "12"))))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_fuzz_errors_and_outputs_against_the_oracle(seed):
+    r = _fuzz_seed(seed, lambda lt: hg.HostSimEvaluator(lt, Conf()), False)
+    if r is None:
+        pytest.skip("store refused by the lowering")
+    errors, outputs, with_errors, with_outputs = r
+    assert errors > 200 and outputs > 200, r
+    assert with_errors > 5, r
+
+
+@pytest.mark.gpu
+def test_gpu_fuzz_errors_and_outputs_against_the_oracle():
+    tot = np.zeros(4, dtype=np.int64)
+    for seed in range(8):
+        r = _fuzz_seed(seed, lambda lt: HipEvaluator(lt, Conf()), True)
+        if r is not None:
+            tot += np.array(r)
+    assert tot[0] > 1500 and tot[1] > 1500 and tot[2] > 150 and tot[3] > 100, tot
