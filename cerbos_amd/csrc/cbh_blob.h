@@ -61,7 +61,7 @@ enum CbhSectionId {
   CBH_SEC_TRACE_ROWS = 34,   // u32[n_rows][8]   {cond, drcond, vars_off, vars_cnt, drvars_off, drvars_cnt, out_activated, out_not_met}:
                              //                  program entries (CBH_NONE = none) and slices of CBH_SEC_TRACE_POOL
   CBH_SEC_TRACE_DR = 35,     // u32[n_dr][4]     {cond, vars_off, vars_cnt, 0}
-  CBH_SEC_TRACE_RP = 36,     // u32[n_rprows][4] {cond, vars_off, vars_cnt, 0}
+  CBH_SEC_TRACE_RP = 36,     // u32[n_rprows][8] {cond, vars_off, vars_cnt, out_activated, out_not_met, 0, 0, 0}
   CBH_SEC_TRACE_POOL = 37,   // u32[]            entries of the variable programs of a params set, in definition order
   CBH_SEC_TRACE_STRINGS = 38, // host only: {u32 n, {u32 len, bytes}*} expression texts, variable names and rule FQNs the trace records refer to
   CBH_SEC_ROWPAT = 29,       // u32[n_rows][8]  pattern halves of the rule records (CbhRowPatField order)
@@ -178,10 +178,23 @@ enum CbhRowPatField {   // CBH_SEC_ROWPAT: the pattern half of record i, 8 dword
 enum CbhRpField { // role-policy rows
   CBH_RP_RESOURCE = 0,  // pattern ref (kind dim)
   CBH_RP_ALLOW_OFF = 1, // into U32POOL: pattern refs (action dim)
-  CBH_RP_ALLOW_CNT = 2,
+  CBH_RP_ALLOW_CNT = 2, // count (CBH_RP_CNT_MASK) | CBH_RP_F_*
   CBH_RP_COND = 3,      // program of the USER condition (synthetic DENY fires when it is false)
   CBH_RP_NF = 4
 };
+// The evaluation key of a role-policy rule leaves the resource out (ruletable.go:445-455), so rules of one role policy
+// for different resources share it, and with it their entry of the per-request conditionCache (check.go:186, 324).  When a
+// glob makes two of them match the same resource kind, the first one a request's actions reach decides what the other sees:
+//   OUTPUT_ONLY  a rule without a condition but with an output expression: the reference visits it as a binding without
+//                effect (index.go:463-484), which caches "satisfied";
+//   SHARES_KEY   the rule shares its key with a rule of the other sort (conditional <-> output only).  A conditional rule
+//                reached after an output-only one would deny whatever its condition says: the kernels mark those actions
+//                CBH_ST_UNSUPPORTED (the order of the request's actions decides, not the policy).  The trace pass gives
+//                an output-only rule reached after a conditional one that rule's cached outcome.
+// (Two CONDITIONAL rules in that position are history dependent outright: blob.py makes their conditions UNSUPPORTED programs.)
+#define CBH_RP_CNT_MASK 0x3FFFFFFFu
+#define CBH_RP_F_OUTPUT_ONLY 0x80000000u
+#define CBH_RP_F_SHARES_KEY 0x40000000u
 enum CbhDrField { // derived roles of one resource policy
   CBH_DR_NAME = 0,        // bit index into edr mask
   CBH_DR_PARENTS_OFF = 1, // into U32POOL: role string ids

@@ -411,6 +411,7 @@ struct CbhPassResource { static constexpr bool value = true; };     // policy pa
 #define CBH_FEAT_TRACE 32         /* the trace pass (cbh_trace_batch): conditions run as trace programs, errors and outputs are logged */
 struct __attribute__((aligned(32))) TblTraceRow { u32 cond, drcond, vars_off, vars_cnt, drvars_off, drvars_cnt, out_activated, out_not_met; };
 struct __attribute__((aligned(16))) TblTraceCond { u32 cond, vars_off, vars_cnt, pad; };
+struct __attribute__((aligned(32))) TblTraceRp { u32 cond, vars_off, vars_cnt, out_activated, out_not_met, pad0, pad1, pad2; };
 #define CBH_TR_DRFAIL 32u         /* w1 bit 5 of an output record: the rule's derived-role condition was not satisfied (the host */
                                   /* drops the first such visit per evaluation key, as check.go:343-347 emits nothing there)    */
 
@@ -831,36 +832,77 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                 if (!udir_find(t, CBH_B_ROLEPOL, g_ver, si, g_sr, rp)) continue;
                 const u32 rp_pol = ((u32)CBH_P_TABLE << 28) | rp.z;
                 AM any_mask = 0;   // actions allowed (subject to conditions) by some rule for this resource
+                AM out_only = 0;   // ... by an output-only rule that shares its cache key with a conditional one (cbh_blob.h CBH_RP_F_*)
                 for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
                   const TblRp rr = uload_rec<TblRp>(t.rprows, row);
                   if (!in2 || !pmatch(rr.resource, kind, KIND_BITS())) continue;
-                  for (u32 a = 0; a < rr.allow_cnt; ++a) any_mask |= match_actions(uload(&t.pool[rr.allow_off + a]));
+                  AM ma = 0;
+                  for (u32 a = 0; a < (rr.allow_cnt & CBH_RP_CNT_MASK); ++a) ma |= match_actions(uload(&t.pool[rr.allow_off + a]));
+                  any_mask |= ma;
+                  if ((rr.allow_cnt & (CBH_RP_F_OUTPUT_ONLY | CBH_RP_F_SHARES_KEY)) == (CBH_RP_F_OUTPUT_ONLY | CBH_RP_F_SHARES_KEY)) out_only |= ma;
                 }
                 // no binding for the resource, or no allow-action matched (index.go:436-461)
                 AM deny = in2 ? (AM)(S & ~any_mask) : (AM)0;
+                const u32 site_base = site_ctr;   // trace pass: a visit's place in the walk = its row's place in the bucket
+                AM cond_seen = 0; int cond_r = 0;   // trace pass: actions a key-sharing conditional rule was evaluated for, and what it gave
+                // (trace pass: the output-only rules that share a key come last, when every conditional rule has been seen;
+                //  they have no effect, and a visit's place in the log is its row's place, so nothing else moves)
+                for (u32 late = 0; late < (TRACE ? 2u : 1u); ++late)
                 for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
                   const TblRp rr = uload_rec<TblRp>(t.rprows, row);
-                  if (rr.cond == CBH_NONE) continue;
+                  if (TRACE && (((rr.allow_cnt & (CBH_RP_F_OUTPUT_ONLY | CBH_RP_F_SHARES_KEY)) == (CBH_RP_F_OUTPUT_ONLY | CBH_RP_F_SHARES_KEY)) ? 1u : 0u) != late) continue;
+                  // the reference visits a matched role-policy rule only if it has a condition (as the synthetic DENY row
+                  // none(cond)) or an output expression (index.go:436-530)
+                  TblTraceRp tp{};
+                  if (TRACE) tp = uload_rec<TblTraceRp>(t.trace_rp, row);
+                  const bool has_out = TRACE && (tp.out_activated != CBH_NONE || tp.out_not_met != CBH_NONE);
+                  if (rr.cond == CBH_NONE && !has_out) continue;
                   AM mm = 0;
                   if (in2 && pmatch(rr.resource, kind, KIND_BITS())) {
-                    for (u32 a = 0; a < rr.allow_cnt; ++a) mm |= match_actions(uload(&t.pool[rr.allow_off + a]));
+                    for (u32 a = 0; a < (rr.allow_cnt & CBH_RP_CNT_MASK); ++a) mm |= match_actions(uload(&t.pool[rr.allow_off + a]));
                     mm &= S & ~deny;
                   }
                   if (wave_ballot(mm != 0) == 0) continue;
-                  int r;
+                  const bool shares = (rr.allow_cnt & CBH_RP_F_SHARES_KEY) != 0;
+                  // an action at or behind the first one an output-only rule of the same key is visited for finds
+                  // "satisfied" cached (check.go:324): the synthetic DENY would fire whatever the condition says
+                  if (shares && rr.cond != CBH_NONE && out_only != 0) st_unsup |= (AM)(mm & ~(AM)((out_only & (AM)(0 - out_only)) - 1));
+                  int r = 1;
                   if (TRACE) {
-                    const TblTraceCond tp = uload_rec<TblTraceCond>(t.trace_rp, row);
-                    const u32 tctx = trace_ctx(0);
+                    const u32 tctx = trace_ctx(site_base + (row - rp.x));
                     trace_vars(tp.vars_off, tp.vars_cnt, mm != 0, tctx);
-                    r = trace_run(tp.cond, mm != 0, tctx, 0);
+                    if (rr.cond != CBH_NONE) {
+                      r = trace_run(tp.cond, mm != 0, tctx, 0);
+                      if (shares && mm != 0) { if (cond_seen == 0) cond_r = r; cond_seen |= mm; }
+                    }
+                    // The rule's outputs as its author wrote them (the synthetic row swaps them together with the condition).
+                    // An output-only rule reached after a conditional one of its key sees that rule's cached outcome
+                    // none(condition): per action, since which of the two came first is a matter of the action order.
+                    AM act = (mm != 0 && r == 1) ? mm : (AM)0, notmet = (mm != 0 && r == 0) ? mm : (AM)0;
+                    bool lost = false;
+                    if (rr.cond == CBH_NONE && shares && cond_seen != 0) {
+                      const AM first = (AM)(cond_seen & (AM)(0 - cond_seen));
+                      const AM behind = (AM)(mm & ~(AM)((first << 1) - 1));       // actions after the conditional rule's first visit
+                      lost = (mm & first) != 0 || (behind != 0 && cond_r == 2);    // the same action: rule order and role order decide
+                      if (cond_r == 1) { act = (AM)(mm & ~behind & ~first); notmet = behind; }   // condition held: none(..) is false
+                      else act = (AM)(mm & ~first);
+                    }
+                    const u32 st0 = L.status;
+                    if (tp.out_activated != CBH_NONE && wave_ballot(act != 0) != 0) (void)trace_run(tp.out_activated, act != 0, tctx, (u64)act);
+                    if (tp.out_not_met != CBH_NONE && wave_ballot(notmet != 0) != 0) (void)trace_run(tp.out_not_met, notmet != 0, tctx, (u64)notmet);
+                    if (lost || (L.status & ~st0 & CBH_ST_UNSUPPORTED) != 0) trace_log(o, L.req, CBH_TR_INCOMPLETE | tctx, 0, 1, 0, (u64)mm);
+                    L.status = st0;
                   } else
                   r = eval_cond<GENERIC>(c, L, rr.cond, mm != 0);   // synthetic row = DENY if none(cond)
                   if (mm != 0) {
                     take_status(mm);
-                    if (r == 2) strict_deny(mm, rp_pol, si);
-                    else if (r == 0) deny |= mm;
+                    if (rr.cond != CBH_NONE) {
+                      if (r == 2) strict_deny(mm, rp_pol, si);
+                      else if (r == 0) deny |= mm;
+                    }
                   }
                 }
+                if (TRACE) site_ctr += rp.y;
                 deny &= S;
                 if (deny != 0) role_deny(deny, rp_pol, si);   // check.go:395-403
               }

@@ -50,7 +50,7 @@ static inline const char* cbh_parse_image(TableDev& d, std::vector<uint32_t>& me
   if (d.trace_pool) {
     const CbhBlobSection *tr = find(CBH_SEC_TRACE_ROWS), *td = find(CBH_SEC_TRACE_DR), *tp = find(CBH_SEC_TRACE_RP);
     if (!tr || !td || !tp || tr->nbytes < (uint64_t)m[CBH_M_NROWS] * 32 || td->nbytes < (uint64_t)m[CBH_M_NDR] * 16 ||
-        tp->nbytes < (uint64_t)m[CBH_M_NRPROWS] * 16)
+        tp->nbytes < (uint64_t)m[CBH_M_NRPROWS] * 32)
       return ("blob trace sections are incomplete");
   }
   d.rowpat = (const u32*)dptr(CBH_SEC_ROWPAT);

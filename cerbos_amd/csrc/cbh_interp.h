@@ -474,12 +474,14 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
         }
         break;
       }
-      case OP_OUT: {        // trace programs: a = trace string id of the rule's FQN; next word = id of the rule's evaluation key
-        const u32 ek = uload(&code[pc]); ++pc;
+      case OP_OUT: {        // trace programs: a = trace string id of the rule's FQN; next words = rule word (id of the rule's
+                            // evaluation key | not-met << 23), number of the part ("hole") of the output expression TOS is
+        const u32 ek = uload(&code[pc]), part = uload(&code[pc + 1]); pc += 2;
         const Val x = TOPV(0);
         if (TRACE && live) {
-          if (x.t == CBH_T_ERR) trace_log(ka->o, L.req, CBH_TR_OUTPUT_ERROR | tctx, a, (u32)x.v, (u64)ek | ((x.v >> 32) << 32), tmask);
-          else trace_log(ka->o, L.req, CBH_TR_OUTPUT | tctx, a, x.t | (ek << 8), x.v, tmask);
+          const u32 w1 = tctx | ((part & 63u) << 6);
+          if (x.t == CBH_T_ERR) trace_log(ka->o, L.req, CBH_TR_OUTPUT_ERROR | w1, a, (u32)x.v, (u64)ek | ((x.v >> 32) << 32), tmask);
+          else trace_log(ka->o, L.req, CBH_TR_OUTPUT | w1, a, x.t | (ek << 8), x.v, tmask);
         }
         break;
       }

@@ -164,8 +164,6 @@ class HipEvaluator:
             outs[i]["evaluationErrors"] = d["evaluationErrors"]
             outs[i]["outputs"] = d["outputs"]
             what = set(d["incomplete"])
-            if lt.trace_outputs_partial:
-                what.add("outputs")
             if what:
                 incomplete[i] = what
         return incomplete

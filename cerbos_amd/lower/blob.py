@@ -37,6 +37,7 @@ ROW_LEAF = 8           # dwords 8..15: the embedded fused-leaf record
 ROW_F_LEAF_EMBEDDED = 64
 SEC_ACTION_CLASS, SEC_ROWPAT, SEC_ROWLEAF2, SEC_DRX, SEC_REGEX = 28, 29, 30, 31, 33
 SEC_TRACE_ROWS, SEC_TRACE_DR, SEC_TRACE_RP, SEC_TRACE_POOL, SEC_TRACE_STRINGS = 34, 35, 36, 37, 38
+RP_F_OUTPUT_ONLY, RP_F_SHARES_KEY = 0x80000000, 0x40000000   # cbh_blob.h CBH_RP_F_*: flags in CBH_RP_ALLOW_CNT
 ROW_F_DRLEAF_EMBEDDED = 128
 ROW_F_TREE_EMBEDDED, ROW_F_DRTREE_EMBEDDED = 256, 512   # the slot holds a tree descriptor (_tree_descriptor)
 MF_FLAT_CLOSED = 512
@@ -184,6 +185,7 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
     res_exists, pp_exists, rp_res = set(), set(), {}
     rp_evalkeys = {}
     rp_history_dependent = set()   # ids of role-policy rules whose cached condition outcome depends on evaluation history
+    rp_shares_key = set()          # ids of role-policy rules sharing their key across "conditional" / "output only"
     for r in rt["rules"]:
         ver, scope = r["version"], r["scope"]
         if r["allow_actions"] is not None:
@@ -195,10 +197,17 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
             # match the SAME resource kind, i.e. when one of the two resource names is a glob.
             # Such rules are not refused wholesale: their conditions become UNSUPPORTED programs (the requests that
             # reach them are flagged for the caller's own engine), the rest of the table serves as usual.
-            if r["condition"] is not None:
+            # (A rule without a condition but with an output expression is visited as well - as a binding without effect,
+            # index.go:463-484 - and caches "satisfied" under the shared key: it takes part like a condition that is None.)
+            # Against a conditional rule that is one more way to confuse the cache, and one the device can follow: whichever
+            # of the two the request's actions reach first decides what both see (cbh_check_wave.h CBH_RP_F_*).
+            if r["condition"] is not None or r["emit_output"]:
                 for o in rp_evalkeys.setdefault(r["evaluation_key"], []):
                     if o["condition"] != r["condition"] and ("*" in o["resource"] or "*" in r["resource"]):
-                        rp_history_dependent.add(o["id"]); rp_history_dependent.add(r["id"])
+                        if o["condition"] is not None and r["condition"] is not None:
+                            rp_history_dependent.add(o["id"]); rp_history_dependent.add(r["id"])
+                        else:
+                            rp_shares_key.add(o["id"]); rp_shares_key.add(r["id"])
                 rp_evalkeys[r["evaluation_key"]].append(r)
         elif r["policy_kind"] == KIND_RESOURCE:
             if "*" in r["resource"]:
@@ -353,7 +362,9 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
             params = Params(r["params"]["constants"], r["params"]["ordered_variables"], globals_)
             rp_cols[0].append(dim_ref(DIM_KIND, r["resource"]))
             rp_cols[1].append(len(pool))
-            rp_cols[2].append(len(r["allow_actions"]))
+            rp_cols[2].append(len(r["allow_actions"])
+                              | (RP_F_OUTPUT_ONLY if (r["condition"] is None and r["emit_output"]) else 0)
+                              | (RP_F_SHARES_KEY if r["id"] in rp_shares_key else 0))
             pool.extend(allow_action_ref(a) for a in r["allow_actions"])
             trace_rp_rules.append(r)
             if r["id"] in rp_history_dependent:
@@ -382,7 +393,7 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
     trace_pool, trace_rows, trace_dr, trace_rp = [], [], [], []
     if trace:
         var_slices = {}
-        rule_ids = {}   # evaluation key -> the small id output records carry
+        rule_ids = {}   # (evaluation key, rule FQN) -> the small id output records carry (role-policy rules can share a key)
 
         def tparams(p):
             return Params(p["constants"], p["ordered_variables"], globals_, trace=True) if p else Params(None, None, globals_, trace=True)
@@ -412,13 +423,13 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
             if emit:
                 m = rt["meta"].get(r["origin_fqn"])
                 src = namer.rule_fqn(m["kind"], m["name"], m["version"], r["scope"], r["name"]) if m else ""
-                rule_id = rule_ids.setdefault(r["evaluation_key"], len(rule_ids))
-                if rule_id >= 1 << 24:
+                rule_id = rule_ids.setdefault((r["evaluation_key"], src), len(rule_ids))
+                if rule_id >= 1 << 23:
                     raise LoweringError("more than 2^24 rules with outputs")
                 if emit.get("rule_activated"):
-                    out_act = pb.trace_output_program(emit["rule_activated"], tp, src, rule_id)
+                    out_act = pb.trace_output_program(emit["rule_activated"], tp, src, rule_id, False)
                 if emit.get("condition_not_met"):
-                    out_not = pb.trace_output_program(emit["condition_not_met"], tp, src, rule_id)
+                    out_not = pb.trace_output_program(emit["condition_not_met"], tp, src, rule_id, True)
             trace_rows.append([cond, drc, voff, vcnt, doff, dcnt, out_act, out_not])
         for dr in trace_dr_defs:
             dtp = Params(dr["constants"], dr["ordered_variables"], globals_, trace=True, null_on_error=True)
@@ -430,21 +441,33 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
             voff, vcnt = var_slice(tp) if r["params"] else (0, 0)
             if r["id"] in rp_history_dependent:
                 cond = pb.trace_unsupported_program(namer.policy_key_from_fqn(r["origin_fqn"]), "history dependent (ruletable.go:445-455)")
-            elif r.get("emit_output"):
-                # the synthetic rows swap the two outputs and emit them without a condition too (index.go:436-530)
-                cond = pb.trace_unsupported_program(namer.policy_key_from_fqn(r["origin_fqn"]), "outputs of role-policy rules")
             else:
                 cond = pb.trace_condition_program(r["condition"], tp) if r["condition"] is not None else NONE
-            trace_rp.append([cond, voff, vcnt, 0])
+            out_act = out_not = NONE
+            emit = r.get("emit_output") or {}
+            if emit:
+                # the synthetic row the reference evaluates is none(condition) with the two outputs swapped (index.go:436-530):
+                # taken together, the rule's own ruleActivated fires when its condition holds (or it has none),
+                # conditionNotMet when it does not - which is how the device walks it
+                m = rt["meta"].get(r["origin_fqn"])
+                src = namer.rule_fqn(m["kind"], m["name"], m["version"], r["scope"], r["name"]) if m else ""
+                rule_id = rule_ids.setdefault((r["evaluation_key"], src), len(rule_ids))
+                if rule_id >= 1 << 23:
+                    raise LoweringError("more than 2^23 rules with outputs")
+                if emit.get("rule_activated"):
+                    out_act = pb.trace_output_program(emit["rule_activated"], tp, src, rule_id, False)
+                if emit.get("condition_not_met"):
+                    out_not = pb.trace_output_program(emit["condition_not_met"], tp, src, rule_id, True)
+            trace_rp.append([cond, voff, vcnt, out_act, out_not, 0, 0, 0])
     lt.theap = (list(pb.theap_tag), [int(v) & 0xFFFFFFFFFFFFFFFF for v in pb.theap_val])   # constant lists / maps an output may yield
     lt.trace_strings = list(pb.trace_strings)
+    lt.trace_templates = dict(pb.trace_templates)   # what the outputs' constructors look like (host side of trace.py)
     lt.trace_unsupported = list(dict.fromkeys(pb.trace_unsupported))
     # does the table ask for the trace pass beyond the tuples the decision kernels mark CBH_ST_CEL_ERROR?  Variables are
     # evaluated whether or not a condition reads them (check.go:651-677), outputs on every visit of their rule
-    lt.trace_has_outputs = any(tr[6] != NONE or tr[7] != NONE for tr in trace_rows) or any(r.get("emit_output") for r in trace_rp_rules)
+    lt.trace_has_outputs = any(tr[6] != NONE or tr[7] != NONE for tr in trace_rows) or any(tr[3] != NONE or tr[4] != NONE for tr in trace_rp)
     lt.trace_has_variables = bool(trace_pool)
-    # outputs of role-policy rules (index.go:436-530 emits them from synthetic rows, some without a condition): not traced
-    lt.trace_outputs_partial = any(r.get("emit_output") for r in trace_rp_rules)
+
 
     # ---- glob automata + match bits of the table's own strings
     gbits = np.zeros((3, 0), dtype=np.uint64)
@@ -684,7 +707,7 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
         sections += [
             (SEC_TRACE_ROWS, len(trace_rows), records(trace_rows, 8)),
             (SEC_TRACE_DR, len(trace_dr), records(trace_dr, 4)),
-            (SEC_TRACE_RP, len(trace_rp), records(trace_rp, 4)),
+            (SEC_TRACE_RP, len(trace_rp), records(trace_rp, 8)),
             (SEC_TRACE_POOL, len(trace_pool), u32(trace_pool or [0])),
             (SEC_TRACE_STRINGS, len(lt.trace_strings), tstr),   # host only
         ]

@@ -224,6 +224,7 @@ class ProgramBuilder:
         self.trace_strings = []
         self.trace_index = {}
         self.trace_unsupported = []        # [(expr text, reason)] of trace programs only
+        self.trace_templates = {}          # output word (rule id | not-met << 23) -> (template, number of holes): trace_output_program
 
     def tid(self, text):
         i = self.trace_index.get(text)
@@ -493,19 +494,52 @@ class ProgramBuilder:
             out.append(self._trace_compile(("trace-var", text, params.key()), build))
         return out
 
-    def trace_output_program(self, text, params: Params, src, rule_id):
-        """evaluateOutput (check.go:776-807): the expression's value (or its error) logged under the rule's FQN and the id
-        of its evaluation key."""
+    def trace_output_program(self, text, params: Params, src, rule_id, not_met):
+        """evaluateOutput (check.go:776-807).  What an output expression BUILDS - a list or map literal with computed
+        elements, a `"...".format([...])` - is not built on the device: the expression is cut into a template of those
+        constructors (kept for the host, trace_templates) and the maximal sub-expressions below them ("holes"), and the
+        program evaluates the holes one after the other, logging each value (or error) under the rule's FQN, the id of its
+        evaluation key and the hole's number.  An expression without such constructors is one hole."""
         assert params.trace
+        ast = params.inline(celparser.parse(text))
+        holes = []
+        tmpl = _output_template(ast, holes)
+        if len(holes) > 64:
+            return self.trace_unsupported_program(text, "output expression with more than 64 computed parts")
+        if not holes:   # a constant: still one record per visit
+            holes, tmpl = [ast], ("hole", 0)
+        word = rule_id | ((1 << 23) if not_met else 0)
+        self.trace_templates[word] = (tmpl, len(holes))
 
         def build():
             fc = _FuncCompiler(self, params, True, trace=True)
             fc.cur_text = text
-            fc.expr(params.inline(celparser.parse(text)))
-            fc.emit(OP_OUT, self.tid(src))
-            fc.word(rule_id)
+            for j, h in enumerate(holes):
+                fc.expr(h)
+                fc.emit(OP_OUT, self.tid(src))
+                fc.word(word)
+                fc.word(j)
+                if j + 1 < len(holes):
+                    fc.emit(OP_POP, 0, -1)
             return fc
-        return self._trace_compile(("trace-out", text, params.key(), src, rule_id), build)
+        return self._trace_compile(("trace-out", text, params.key(), src, word), build)
+
+
+def _output_template(ast, holes):
+    """-> ("hole", j) | ("const", value) | ("list", [t]) | ("map", [(kt, vt)]) | ("format", fmt, [t]); appends the holes'
+    expressions to `holes` in evaluation order."""
+    k = ast[0]
+    if k == "lit" and ast[1] in ("int", "uint", "double", "string", "bool", "null"):
+        return ("const", ast[2] if ast[1] != "null" else None)
+    if k == "list" and not _is_const(ast):
+        return ("list", [_output_template(e, holes) for e in ast[1]])
+    if k == "map" and not _is_const(ast):
+        return ("map", [(_output_template(ke, holes), _output_template(ve, holes)) for ke, ve in ast[1]])
+    if k == "call" and ast[1] == "format" and ast[2] is not None and ast[2][0] == "lit" and ast[2][1] == "string" \
+            and len(ast[3]) == 1 and ast[3][0][0] == "list":
+        return ("format", ast[2][2], [_output_template(e, holes) for e in ast[3][0][1]])
+    holes.append(ast)
+    return ("hole", len(holes) - 1)
 
 
 class _Unsupported(Exception):

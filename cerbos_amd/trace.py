@@ -78,15 +78,16 @@ class TraceDecoder:
         raise _Incomplete()
 
     def value(self, tag, v):
-        """structpb JSON of an output value (check.go:789-807)."""
+        """A device value as a Python value that keeps its CEL type: None, bool, int (int / uint), float (double), str,
+        list, dict."""
         if tag == T_NULL:
             return None
         if tag == T_BOOL:
             return bool(v)
         if tag == T_INT:
-            return float(v - (1 << 64) if v >> 63 else v)
+            return v - (1 << 64) if v >> 63 else v
         if tag == T_UINT:
-            return float(v)
+            return v
         if tag == T_DOUBLE:
             return struct.unpack("<d", struct.pack("<Q", v))[0]
         if tag == T_STRING:
@@ -105,8 +106,7 @@ class TraceDecoder:
                 return [self.value(int(tags[off + i]), int(vals[off + i])) for i in range(n)]
             out = {}
             for i in range(n):
-                k = self.value(int(tags[off + 2 * i]), int(vals[off + 2 * i]))
-                out[k if isinstance(k, str) else _key_text(k)] = self.value(int(tags[off + 2 * i + 1]), int(vals[off + 2 * i + 1]))
+                out[self.value(int(tags[off + 2 * i]), int(vals[off + 2 * i]))] = self.value(int(tags[off + 2 * i + 1]), int(vals[off + 2 * i + 1]))
             return out
         raise _Incomplete()   # timestamps / durations as output values: formatting left to the caller's engine
 
@@ -118,6 +118,7 @@ class TraceDecoder:
         n_in = len(self.inputs)
         errs = [set() for _ in range(n_in)]
         visits = [[] for _ in range(n_in)]
+        parts = [{} for _ in range(n_in)]   # per input: visit -> the parts of its output expression logged so far
         incomplete = [set() for _ in range(n_in)]
         if count > len(records):
             raise RuntimeError("trace log overflow: %d records, room for %d" % (count, len(records)))
@@ -140,23 +141,38 @@ class TraceDecoder:
                 elif kind == TR_ERROR:
                     errs[i_in].add((lt.trace_strings[w2], self.message(int(rec[4]) | (int(rec[5]) << 32), inp)))
                 elif kind in (TR_OUTPUT, TR_OUTPUT_ERROR):
-                    mask = int(rec[6]) | (int(rec[7]) << 32)
-                    entry = {"src": lt.trace_strings[w2]}
-                    if kind == TR_OUTPUT:
-                        rule = w3 >> 8
-                        entry["val"] = self.value(w3 & 0xFF, int(rec[4]) | (int(rec[5]) << 32))
-                    else:
-                        rule = int(rec[4])
-                        entry["error"] = self.message(w3 | (int(rec[5]) << 32), inp)
+                    # one record per computed part of the output expression: collected per visit, assembled below
+                    rule = (w3 >> 8) if kind == TR_OUTPUT else int(rec[4])
                     pre = r if rp is None else int(rp[r])   # the request's index before the routing sort
-                    acts = b.vreq_actions[pre]
-                    for k in range(len(acts)):
-                        if (mask >> k) & 1:
-                            # order of check.go's loops: action, policy kind (principal first), role, scope / rule
-                            visits[i_in].append(((pre, k, (w1 >> 4) & 1, (w1 >> 12) & 0xFF, w1 >> 20), bool(w1 & TR_DRFAIL),
-                                                 dict(entry, action=acts[k]), rule))
+                    visit = (pre, (w1 >> 4) & 1, (w1 >> 12) & 0xFF, w1 >> 20, rule)
+                    part = (w1 >> 6) & 63
+                    g = parts[i_in].setdefault(visit, {"src": w2, "mask": int(rec[6]) | (int(rec[7]) << 32), "drfail": bool(w1 & TR_DRFAIL), "parts": {}})
+                    if kind == TR_OUTPUT:
+                        g["parts"][part] = (True, self.value(w3 & 0xFF, int(rec[4]) | (int(rec[5]) << 32)))
+                    else:
+                        g["parts"][part] = (False, self.message(w3 | (int(rec[5]) << 32), inp))
             except _Incomplete:
                 incomplete[i_in].add("errors" if kind == TR_ERROR else "outputs")
+        for i_in in range(n_in):
+            for (pre, pas, ri, site, rule), g in parts[i_in].items():
+                tmpl, n_holes = lt.trace_templates[rule]
+                entry = {"src": lt.trace_strings[g["src"]]}
+                try:
+                    if len(g["parts"]) != n_holes:
+                        raise _Incomplete()
+                    failed = [j for j in sorted(g["parts"]) if not g["parts"][j][0]]
+                    if failed:   # the first part to fail in evaluation order is the expression's error
+                        entry["error"] = g["parts"][failed[0]][1]
+                    else:
+                        entry["val"] = _json(_assemble(tmpl, [g["parts"][j][1] for j in range(n_holes)]))
+                except _Incomplete:
+                    incomplete[i_in].add("outputs")
+                    continue
+                acts = b.vreq_actions[pre]
+                for k in range(len(acts)):
+                    if (g["mask"] >> k) & 1:
+                        # order of check.go's loops: action, policy kind (principal first), role, scope / rule
+                        visits[i_in].append(((pre, k, pas, ri, site), g["drfail"], dict(entry, action=acts[k]), rule & 0x7FFFFF))
         out = []
         for i in range(n_in):
             outs, seen_drfail = [], set()
@@ -176,6 +192,91 @@ class TraceDecoder:
         b = self.batch
         pre = r if b.req_perm is None else int(b.req_perm[r])
         return int(b.vreq_input[pre])
+
+
+def _assemble(t, holes):
+    """The value of an output expression from its template (celc.py _output_template) and the values of its holes."""
+    k = t[0]
+    if k == "hole":
+        return holes[t[1]]
+    if k == "const":
+        return t[1]
+    if k == "list":
+        return [_assemble(e, holes) for e in t[1]]
+    if k == "map":
+        out = {}
+        for kt, vt in t[1]:
+            key = _assemble(kt, holes)
+            if isinstance(key, (list, dict)) or key is None or key in out:
+                raise _Incomplete()   # "unsupported key type" / a repeated key: errors of the literal, left to the caller's engine
+            out[key] = _assemble(vt, holes)
+        return out
+    return _format(t[1], [_assemble(e, holes) for e in t[2]])
+
+
+def _format(fmt, args):
+    """cel-go ext.Strings `format` (strings.go): the clauses that need no decision about precision or radix - %s, %d, %% -
+    anything else is left to the caller's engine."""
+    out, i, ai = [], 0, 0
+    while i < len(fmt):
+        c = fmt[i]
+        i += 1
+        if c != "%":
+            out.append(c)
+            continue
+        if i >= len(fmt):
+            raise _Incomplete()
+        spec = fmt[i]
+        i += 1
+        if spec == "%":
+            out.append("%")
+            continue
+        if ai >= len(args) or spec not in "sd":
+            raise _Incomplete()
+        a = args[ai]
+        ai += 1
+        if spec == "d":
+            if isinstance(a, bool) or not isinstance(a, (int, float)) or (isinstance(a, float) and a != int(a)):
+                raise _Incomplete()   # "decimal clause can only be used on integers"
+            out.append(str(int(a)))
+        else:
+            out.append(_format_value(a))
+    return "".join(out)
+
+
+def _format_value(v, nested=False):
+    """%s of a value (cel-go strings.go formatString and the per-type formatters)."""
+    if v is None:
+        return "null"
+    if isinstance(v, bool):
+        return "true" if v else "false"
+    if isinstance(v, str):
+        return '"%s"' % v if nested else v
+    if isinstance(v, int):
+        return str(v)
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            raise _Incomplete()
+        return str(int(v)) if v == int(v) and abs(v) < 1e21 else repr(v)
+    if isinstance(v, list):
+        return "[" + ", ".join(_format_value(x, True) for x in v) + "]"
+    if isinstance(v, dict):
+        return "{" + ", ".join("%s: %s" % (_format_value(k, True), _format_value(x, True))
+                               for k, x in sorted(v.items(), key=lambda kv: str(kv[0]))) + "}"
+    raise _Incomplete()
+
+
+def _json(v):
+    """structpb JSON of a value (check.go:789-807): every number a double, map keys their text."""
+    if isinstance(v, bool) or v is None or isinstance(v, str):
+        return v
+    if isinstance(v, (int, float)):
+        return float(v)
+    if isinstance(v, list):
+        return [_json(x) for x in v]
+    if isinstance(v, dict):
+        return {str(k): _json(x) for k, x in v.items()}
+    raise _Incomplete()
 
 
 def _key_text(k):

@@ -246,14 +246,18 @@ int cbh_kernel_time_ms(cbh_table* t, float* check_kernel_ms, float* resolve_kern
  *
  * A record is eight 32-bit words:
  *   w0  request index (into `in`)
- *   w1  kind (bits 0-3) | pass << 4 (0 principal policies, 1 resource policies) | (bit 5, see w4) |
+ *   w1  kind (bits 0-3) | pass << 4 (0 principal policies, 1 resource policies) | (bit 5, see w4) | part << 6 |
  *       role iteration << 12 | site << 20
  *       (site = position of the rule record in this request's walk of that pass; outputs are ordered by action, pass,
  *        role iteration, site as check.go's loops nest)
  *   w2  trace string id: the expression text (errors), or the rule's FQN (outputs)   [CBH_SEC_TRACE_STRINGS]
  *   w3  CBH_TR_ERROR / CBH_TR_OUTPUT_ERROR: error code | detail << 8;  CBH_TR_OUTPUT: value tag (cbh_value_tag) | rule << 8
  *   w4, w5  CBH_TR_ERROR: the whole error payload (code | detail << 8, 64 bits); CBH_TR_OUTPUT: the value (64 bits; strings are string ids, lists / maps refer to the batch heap);
- *           CBH_TR_OUTPUT_ERROR: w4 = rule.   (rule = a small id per evaluation key, ruletable.go's EvaluationKey: w1 bit 5
+ *           CBH_TR_OUTPUT_ERROR: w4 = rule.   (part: what an output expression builds - list / map literals, format() -
+ *           is assembled by the consumer from a template the lowering keeps; the device evaluates the computed parts below
+ *           those constructors and logs one record per part, numbered in evaluation order; an expression without such
+ *           constructors is part 0.  rule = a small id per evaluation key, ruletable.go's EvaluationKey, bit 23 set for
+ *           the conditionNotMet expression: w1 bit 5
  *           marks a visit whose derived-role condition failed - check.go:343-347 emits nothing on the FIRST such visit
  *           of a key and conditionNotMet on later ones, which the consumer replays)
  *   w6, w7  CBH_TR_OUTPUT*: mask of the request's actions the rule was visited for (bit k = k-th action)
