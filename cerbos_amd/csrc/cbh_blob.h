@@ -63,7 +63,10 @@ enum CbhSectionId {
   CBH_SEC_TRACE_DR = 35,     // u32[n_dr][4]     {cond, vars_off, vars_cnt, 0}
   CBH_SEC_TRACE_RP = 36,     // u32[n_rprows][8] {cond, vars_off, vars_cnt, out_activated, out_not_met, 0, 0, 0}
   CBH_SEC_TRACE_POOL = 37,   // u32[]            entries of the variable programs of a params set, in definition order
-  CBH_SEC_TRACE_STRINGS = 38, // host only: {u32 n, {u32 len, bytes}*} expression texts, variable names and rule FQNs the trace records refer to
+  CBH_SEC_TRACE_STRINGS = 38, // host only, JSON {"strings": [...], "templates": {"<rule word>": [template, parts]}}: the expression texts,
+                              // variable names and rule FQNs the trace records refer to, and how the consumer assembles an output
+                              // value from its parts (template = ["hole", j] | ["const", v] | ["list", [t..]] | ["map", [[kt, vt]..]] |
+                              // ["format", "<fmt>", [t..]])
   CBH_SEC_ROWPAT = 29,       // u32[n_rows][8]  pattern halves of the rule records (CbhRowPatField order)
   CBH_SEC_ACTION_CLASS = 28, // u8[K] class (0..61) of a string that is a literal rule action of a resource policy, 63 = any other string
   CBH_SEC_HOST_NAMES = 27,   // host only: {u32 n, {u16 len, bytes}*} policy keys (CBH_P_TABLE ids), then the same for derived-role names

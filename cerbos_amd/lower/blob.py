@@ -702,8 +702,13 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
     if trace:
         def records(rows, width):
             return np.asarray(rows, dtype=np.uint32).reshape(len(rows), width).tobytes()
-        tstr = struct.pack("<I", len(lt.trace_strings)) + b"".join(
-            struct.pack("<I", len(b)) + b for b in (x.encode("utf-8") for x in lt.trace_strings))
+        # host only, JSON: what a consumer of the trace records needs besides the batch it sent - the strings the records
+        # refer to (expression texts, variable names, rule FQNs) and the templates of the output expressions
+        # (celc.py _output_template, keyed by the records' rule word)
+        import json
+        tstr = json.dumps({"strings": lt.trace_strings,
+                           "templates": {str(k): [t, n] for k, (t, n) in sorted(lt.trace_templates.items())}},
+                          separators=(",", ":")).encode("utf-8")
         sections += [
             (SEC_TRACE_ROWS, len(trace_rows), records(trace_rows, 8)),
             (SEC_TRACE_DR, len(trace_dr), records(trace_dr, 4)),

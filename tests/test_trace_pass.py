@@ -228,3 +228,20 @@ def test_gpu_fuzz_errors_and_outputs_against_the_oracle():
         if r is not None:
             tot += np.array(r)
     assert tot[0] > 1500 and tot[1] > 1500 and tot[2] > 150 and tot[3] > 100, tot
+
+
+def test_the_image_carries_what_a_consumer_of_the_records_needs():
+    """CBH_SEC_TRACE_STRINGS (host only): strings and output templates as JSON - a Go / C caller has no LoweredTable."""
+    import json
+    import struct
+    lt = _store_table()
+    n_sec = struct.unpack_from("<I", lt.blob, 8)[0]
+    found = None
+    for i in range(n_sec):
+        sid, _count, off, nbytes, _ = struct.unpack_from("<IIQQQ", lt.blob, 32 + 32 * i)
+        if sid == 38:
+            found = json.loads(lt.blob[off:off + nbytes].decode("utf-8"))
+    assert found is not None
+    assert found["strings"] == lt.trace_strings
+    as_json = json.loads(json.dumps({str(k): [t, n] for k, (t, n) in lt.trace_templates.items()}))
+    assert found["templates"] == as_json and len(as_json) > 10
