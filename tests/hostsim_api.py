@@ -66,9 +66,9 @@ def check(lt, batch, now_ns=0, flags=0, device_order=False):
     return res if device_order else res.to_input_order(batch)
 
 
-def trace(lt, batch, now_ns=0, flags=0):
+def trace(lt, batch, now_ns=0, flags=0, capacity=None):
     """The trace pass (cbh_trace_batch) on the simulator -> (Result in device order, records uint32[n][8])."""
-    cap = max(256, 4 * batch.n_tuples)
+    cap = capacity or max(256, 4 * batch.n_tuples)
     cb = capi.make_cbatch(batch, len(lt.columns))
     p = capi.CParams(now_ns, flags, 0)
     g = batch_gbits(lt, batch)

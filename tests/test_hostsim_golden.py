@@ -32,8 +32,8 @@ class HostSimEvaluator(HipEvaluator):
             def check(_self, batch, now_ns=0, flags=0, want=(), device_order=False):
                 return hostsim_api.check(lt, batch, now_ns, flags, device_order)
 
-            def trace(_self, batch, now_ns=0, flags=0):
-                return hostsim_api.trace(lt, batch, now_ns, flags)
+            def trace(_self, batch, now_ns=0, flags=0, capacity=None):
+                return hostsim_api.trace(lt, batch, now_ns, flags, capacity)
         self.table = _T()
 
 

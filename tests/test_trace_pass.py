@@ -245,3 +245,71 @@ def test_the_image_carries_what_a_consumer_of_the_records_needs():
     assert found["strings"] == lt.trace_strings
     as_json = json.loads(json.dumps({str(k): [t, n] for k, (t, n) in lt.trace_templates.items()}))
     assert found["templates"] == as_json and len(as_json) > 10
+
+
+def _overflow(make, close):
+    """A log too small for the pass reports how many records there were (cbh_trace.count > capacity): the caller grows it."""
+    from cerbos_amd import capi
+    from cerbos_amd.flatten import Flattener
+    rt = rule_table_from_policies(policies_from_docs(kats.FIX["policies"]))
+    lt = lower_rule_table(rt)
+    ev = make(lt)
+    try:
+        inputs = [kats._input(c) for c in kats.FIX["cases"] if not c["strict"]]
+        batch = Flattener(lt).flatten(inputs)
+        _, full = ev.table.trace(batch, now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES)
+        _, grown = ev.table.trace(batch, now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES, capacity=3)
+        assert len(full) > 3 and len(grown) == len(full)
+        assert sorted(map(tuple, full.tolist())) == sorted(map(tuple, grown.tolist()))
+    finally:
+        if close:
+            ev.close()
+
+
+def test_trace_log_overflow_is_reported_and_recovered():
+    _overflow(lambda lt: hg.HostSimEvaluator(lt, Conf()), False)
+
+
+@pytest.mark.gpu
+def test_gpu_trace_log_overflow_is_reported_and_recovered():
+    _overflow(lambda lt: HipEvaluator(lt, Conf()), True)
+
+
+def _workload_errors(make, close, n, sample):
+    """C5 (scoped policies, derived roles, role policies, general CEL): the inputs a decision kernel marked are traced; the
+    trace pass must decide them as the decision pass did (HipEvaluator raises otherwise) and name the errors the oracle names."""
+    from cerbos_amd import workloads
+    rt = rule_table_from_policies(policies_from_docs(workloads.c5_policies()))
+    lt = lower_rule_table(rt)
+    inputs = workloads.c5_requests(n_requests=n).to_inputs()
+    ev = make(lt)
+    try:
+        outs, bad, incomplete = ev.check(inputs, now_ns=NOW, allow_unsupported=True, trace=True)
+    finally:
+        if close:
+            ev.close()
+    orc = RuleTableOracle(rt)
+    rng = np.random.default_rng(5)
+    with_errors = [i for i, o in enumerate(outs) if o["evaluationErrors"]]
+    picks = list(rng.choice(with_errors, size=min(sample, len(with_errors)), replace=False)) + \
+        list(rng.choice(len(inputs), size=sample, replace=False))
+    compared = 0
+    for i in picks:
+        i = int(i)
+        if i in bad or "errors" in incomplete.get(i, ()):
+            continue
+        want = orc.check(inputs[i], EvalParams(now_ns=NOW))
+        assert outs[i]["evaluationErrors"] == (want.get("evaluationErrors") or []), inputs[i]
+        compared += 1
+    return len(with_errors), compared
+
+
+def test_workload_errors_named_as_the_oracle_names_them():
+    n_err, compared = _workload_errors(lambda lt: hg.HostSimEvaluator(lt, Conf()), False, 1500, 60)
+    assert n_err > 20 and compared > 60, (n_err, compared)
+
+
+@pytest.mark.gpu
+def test_gpu_workload_errors_at_size():
+    n_err, compared = _workload_errors(lambda lt: HipEvaluator(lt, Conf()), True, 200_000, 300)
+    assert n_err > 2000 and compared > 300, (n_err, compared)
