@@ -67,6 +67,10 @@ enum CbhSectionId {
                               // variable names and rule FQNs the trace records refer to, and how the consumer assembles an output
                               // value from its parts (template = ["hole", j] | ["const", v] | ["list", [t..]] | ["map", [[kt, vt]..]] |
                               // ["format", "<fmt>", [t..]])
+  CBH_SEC_TRACE_HOST = 39,    // host only (cbh_ingest.cpp cbi_trace_pb): the same strings and templates in binary - u32 n, {u32 len, bytes}*;
+                              // u32 n_templates, {u32 rule word, u32 parts, node}*; node = u8 kind: 0 hole + u32 j | 1 const + u8 type (0 null,
+                              // 1 bool + u8, 2 int + i64, 3 double + f64, 4 string + u32 len + bytes) | 2 list + u32 n + nodes | 3 map + u32 n +
+                              // (key node, value node)* | 4 format + u32 len + bytes + u32 n + nodes
   CBH_SEC_ROWPAT = 29,       // u32[n_rows][8]  pattern halves of the rule records (CbhRowPatField order)
   CBH_SEC_ACTION_CLASS = 28, // u8[K] class (0..61) of a string that is a literal rule action of a resource policy, 63 = any other string
   CBH_SEC_HOST_NAMES = 27,   // host only: {u32 n, {u16 len, bytes}*} policy keys (CBH_P_TABLE ids), then the same for derived-role names

@@ -12,6 +12,11 @@
 //   internal/namer/namer.go:213-218         SanitizedResource; :77-87 ScopeParents; :276-278 ScopeValue
 //   api/public/cerbos/engine/v1/engine.proto:130-200 field numbers of CheckInput / Resource / Principal / AuxData
 #include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <functional>
+#include <map>
+#include <set>
 #include <cstdint>
 #include <cstring>
 #include <numeric>
@@ -161,6 +166,15 @@ struct StrIndex {
 
 struct Column { u32 root; std::vector<std::string> keys; };
 
+// A CEL value as the trace pass's consumer handles it (cbi_trace_pb): it keeps its CEL type for format().
+struct TVal {
+  enum Kind { Null, Bool, Int, Double, String, List, Map } k = Null;
+  bool b = false; long long i = 0; double d = 0; std::string s;
+  std::vector<TVal> items;   // List: the elements; Map: key, value, key, value ...
+};
+// Template of an output expression (celc.py _output_template; cbh_blob.h CBH_SEC_TRACE_HOST)
+struct TNode { u8 kind = 0; u32 hole = 0; TVal cst; std::string fmt; std::vector<TNode> kids; };
+
 }  // namespace
 
 struct cbi_table {
@@ -172,6 +186,11 @@ struct cbi_table {
   std::unordered_map<std::string, u32> scope_index;    // scope -> index
   std::vector<Column> columns;
   std::vector<std::string> policy_keys, dr_names, scopes;   // response assembly
+  // the trace pass (cbi_trace_pb): strings its records refer to, output templates by rule word, the table's constant heap
+  std::vector<std::string> trace_strings;
+  std::unordered_map<u32, std::pair<TNode, u32>> trace_templates;
+  const u8* theap_tag = nullptr; const u64* theap_val = nullptr; u32 theap_len = 0;
+  bool has_trace = false;
   std::string_view at(u32 i) const { return std::string_view(str_bytes + str_off[i], str_off[i + 1] - str_off[i]); }
 };
 
@@ -415,6 +434,46 @@ int cbi_table_open(const void* blob, size_t len, cbi_table** out) {
       }
     }
   } else return bail("blob is missing the host name section");
+  if (const CbhBlobSection* st = find(CBH_SEC_TRACE_HOST)) {
+    const u8* q = base + st->offset; const u8* qe = q + st->nbytes;
+    bool ok = true;
+    auto rd32 = [&](u32& v) { if (qe - q < 4) { ok = false; v = 0; return; } memcpy(&v, q, 4); q += 4; };
+    auto rdstr = [&](std::string& out) { u32 l; rd32(l); if (!ok || (u32)(qe - q) < l) { ok = false; return; } out.assign((const char*)q, l); q += l; };
+    u32 ns2; rd32(ns2);
+    for (u32 k = 0; ok && k < ns2; ++k) { std::string x; rdstr(x); t->trace_strings.push_back(std::move(x)); }
+    std::function<void(TNode&, int)> rdnode = [&](TNode& nd, int depth) {
+      if (!ok || depth > 64 || qe - q < 1) { ok = false; return; }
+      nd.kind = *q++;
+      if (nd.kind == 0) rd32(nd.hole);
+      else if (nd.kind == 1) {
+        if (qe - q < 1) { ok = false; return; }
+        const u8 ct = *q++;
+        if (ct == 0) nd.cst.k = TVal::Null;
+        else if (ct == 1) { if (qe - q < 1) { ok = false; return; } nd.cst.k = TVal::Bool; nd.cst.b = *q++ != 0; }
+        else if (ct == 2) { if (qe - q < 8) { ok = false; return; } nd.cst.k = TVal::Int; memcpy(&nd.cst.i, q, 8); q += 8; }
+        else if (ct == 3) { if (qe - q < 8) { ok = false; return; } nd.cst.k = TVal::Double; memcpy(&nd.cst.d, q, 8); q += 8; }
+        else if (ct == 4) { nd.cst.k = TVal::String; rdstr(nd.cst.s); }
+        else ok = false;
+      } else if (nd.kind == 2 || nd.kind == 3 || nd.kind == 4) {
+        if (nd.kind == 4) rdstr(nd.fmt);
+        u32 cnt; rd32(cnt);
+        if (nd.kind == 3) cnt *= 2;
+        if (!ok || cnt > (u32)(qe - q)) { ok = false; return; }
+        nd.kids.resize(cnt);
+        for (u32 k = 0; ok && k < cnt; ++k) rdnode(nd.kids[k], depth + 1);
+      } else ok = false;
+    };
+    u32 nt; rd32(nt);
+    for (u32 k = 0; ok && k < nt; ++k) {
+      u32 word, holes; rd32(word); rd32(holes);
+      TNode nd; rdnode(nd, 0);
+      if (ok) t->trace_templates.emplace(word, std::make_pair(std::move(nd), holes));
+    }
+    if (!ok) return bail("trace host section truncated");
+    const CbhBlobSection *ht = find(CBH_SEC_THEAP_TAG), *hv = find(CBH_SEC_THEAP_VAL);
+    if (ht && hv && hv->nbytes / 8 >= ht->nbytes) { t->theap_tag = base + ht->offset; t->theap_val = (const u64*)(base + hv->offset); t->theap_len = (u32)ht->nbytes; }
+    t->has_trace = true;
+  }
   const u8* p = base + sc->offset; const u8* e = p + sc->nbytes;
   u32 ncol = meta[CBH_M_NCOLUMNS];
   for (u32 c = 0; c < ncol; ++c) {
@@ -1182,6 +1241,299 @@ int cbi_assemble_response_pb(const cbi_table* t, const cbi_batch* b, const cbh_r
   return 0;
 }
 
+}  // extern "C"
+
+// ---- the trace pass's consumer: cbh_trace records -> the evaluation_errors / outputs fields of a CheckOutput ------------
+// (cerbos_amd/trace.py is the same consumer in Python; nothing here evaluates CEL)
+namespace {
+struct TraceIncomplete {};
+
+// %s of a value (cel-go strings.go formatString and the per-type formatters)
+void format_value(const TVal& v, bool nested, std::string& out) {
+  switch (v.k) {
+    case TVal::Null: out += "null"; return;
+    case TVal::Bool: out += v.b ? "true" : "false"; return;
+    case TVal::String: if (nested) { out += '"'; out += v.s; out += '"'; } else out += v.s; return;
+    case TVal::Int: out += std::to_string(v.i); return;
+    case TVal::Double: {
+      if (std::isnan(v.d) || std::isinf(v.d)) throw TraceIncomplete{};
+      if (v.d == std::floor(v.d) && std::fabs(v.d) < 1e21) {
+        if (std::fabs(v.d) < 9e18) { out += std::to_string((long long)v.d); return; }
+        char buf[64]; std::snprintf(buf, sizeof buf, "%.0f", v.d); out += buf; return;
+      }
+      char buf[64]; auto r = std::to_chars(buf, buf + sizeof buf, v.d); out.append(buf, r.ptr); return;   // shortest round-trip, as Python's repr
+    }
+    case TVal::List: {
+      out += '[';
+      for (size_t i = 0; i < v.items.size(); ++i) { if (i) out += ", "; format_value(v.items[i], true, out); }
+      out += ']'; return;
+    }
+    case TVal::Map: {
+      std::vector<std::pair<std::string, size_t>> order;   // by the keys' text
+      for (size_t i = 0; i + 1 < v.items.size(); i += 2) { std::string k; format_value(v.items[i], false, k); order.emplace_back(std::move(k), i); }
+      std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+      out += '{';
+      for (size_t n = 0; n < order.size(); ++n) {
+        if (n) out += ", ";
+        format_value(v.items[order[n].second], true, out); out += ": "; format_value(v.items[order[n].second + 1], true, out);
+      }
+      out += '}'; return;
+    }
+  }
+}
+// cel-go ext.Strings format: %s, %d, %% (anything else is left to the caller's engine)
+TVal format_call(const std::string& fmt, const std::vector<TVal>& args) {
+  TVal r; r.k = TVal::String;
+  size_t ai = 0;
+  for (size_t i = 0; i < fmt.size();) {
+    const char c = fmt[i++];
+    if (c != '%') { r.s += c; continue; }
+    if (i >= fmt.size()) throw TraceIncomplete{};
+    const char spec = fmt[i++];
+    if (spec == '%') { r.s += '%'; continue; }
+    if (ai >= args.size() || (spec != 's' && spec != 'd')) throw TraceIncomplete{};
+    const TVal& a = args[ai++];
+    if (spec == 'd') {
+      if (a.k == TVal::Int) r.s += std::to_string(a.i);
+      else if (a.k == TVal::Double && a.d == std::floor(a.d) && std::fabs(a.d) < 9e18) r.s += std::to_string((long long)a.d);
+      else throw TraceIncomplete{};
+    } else format_value(a, false, r.s);
+  }
+  return r;
+}
+bool tval_key_equal(const TVal& a, const TVal& b) {
+  if (a.k != b.k) return false;
+  switch (a.k) { case TVal::Bool: return a.b == b.b; case TVal::Int: return a.i == b.i; case TVal::Double: return a.d == b.d; case TVal::String: return a.s == b.s; default: return false; }
+}
+TVal assemble_template(const TNode& t, const std::vector<TVal>& holes) {
+  switch (t.kind) {
+    case 0: if (t.hole >= holes.size()) throw TraceIncomplete{}; return holes[t.hole];
+    case 1: return t.cst;
+    case 2: { TVal r; r.k = TVal::List; for (const TNode& k : t.kids) r.items.push_back(assemble_template(k, holes)); return r; }
+    case 3: {
+      TVal r; r.k = TVal::Map;
+      for (size_t i = 0; i + 1 < t.kids.size(); i += 2) {
+        TVal key = assemble_template(t.kids[i], holes);
+        if (key.k == TVal::Null || key.k == TVal::List || key.k == TVal::Map) throw TraceIncomplete{};   // "unsupported key type"
+        for (size_t j = 0; j < r.items.size(); j += 2) if (tval_key_equal(r.items[j], key)) throw TraceIncomplete{};   // a repeated key
+        r.items.push_back(std::move(key)); r.items.push_back(assemble_template(t.kids[i + 1], holes));
+      }
+      return r;
+    }
+    default: { std::vector<TVal> args; for (const TNode& k : t.kids) args.push_back(assemble_template(k, holes)); return format_call(t.fmt, args); }
+  }
+}
+// google.protobuf.Value (struct.proto): null 1, number 2, string 3, bool 4, struct 5 {fields 1: map<string, Value>}, list 6 {values 1}
+void put_value(std::vector<u8>& o, const TVal& v) {
+  auto ld = [&](u32 field, const std::vector<u8>& b) { put_varint(o, field << 3 | 2); put_varint(o, b.size()); o.insert(o.end(), b.begin(), b.end()); };
+  switch (v.k) {
+    case TVal::Null: o.push_back(1 << 3 | 0); o.push_back(0); return;
+    case TVal::Bool: o.push_back(4 << 3 | 0); o.push_back(v.b ? 1 : 0); return;
+    case TVal::Int: case TVal::Double: { const double d = v.k == TVal::Int ? (double)v.i : v.d; o.push_back(2 << 3 | 1); u8 b[8]; memcpy(b, &d, 8); o.insert(o.end(), b, b + 8); return; }
+    case TVal::String: put_ld(o, 3, v.s); return;
+    case TVal::List: {
+      std::vector<u8> lst;
+      for (const TVal& e : v.items) { std::vector<u8> eb; put_value(eb, e); put_varint(lst, 1 << 3 | 2); put_varint(lst, eb.size()); lst.insert(lst.end(), eb.begin(), eb.end()); }
+      ld(6, lst); return;
+    }
+    case TVal::Map: {
+      std::vector<u8> st;
+      for (size_t i = 0; i + 1 < v.items.size(); i += 2) {
+        std::string key; format_value(v.items[i], false, key);
+        std::vector<u8> vb, ent; put_value(vb, v.items[i + 1]);
+        put_ld(ent, 1, key); put_varint(ent, 2 << 3 | 2); put_varint(ent, vb.size()); ent.insert(ent.end(), vb.begin(), vb.end());
+        put_varint(st, 1 << 3 | 2); put_varint(st, ent.size()); st.insert(st.end(), ent.begin(), ent.end());
+      }
+      ld(5, st); return;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int cbi_trace_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint32_t* records, uint32_t count,
+                            const uint8_t* bytes, const uint64_t* offsets, uint32_t n, cbi_outputs** out) {
+  if (!t || !b || !res || !out || (count && !records) || (n && (!bytes || !offsets))) return fail("cbi_trace_pb: null argument");
+  if (!t->has_trace) return fail("the table was lowered without the trace sections");
+  const u32 T = b->view.n_tuples, R = b->view.n_requests;
+  auto RQ = [&](u32 f, u32 q) { return b->req[(size_t)f * R + q]; };
+  std::vector<u64> first(n + 1, 0);
+  for (u32 q = 0; q < R; ++q) { const u32 i = b->req_input[q]; if (i >= n) return fail("batch does not belong to these inputs"); first[i + 1] += RQ(RQ_ACT_CNT, q); }
+  for (u32 i = 0; i < n; ++i) first[i + 1] += first[i];
+  if (first[n] != T) return fail("batch does not belong to these inputs");
+  const u32 K = t->K;
+  auto str = [&](u64 id) -> std::string_view {
+    if (id < K) return t->at((u32)id);
+    const u64 l = id - K;
+    if (l >= b->str_flags.size()) throw TraceIncomplete{};
+    return std::string_view((const char*)b->str_bytes.data() + b->str_off[l], b->str_off[l + 1] - b->str_off[l]);
+  };
+  std::function<TVal(u32, u64, int)> to_tval = [&](u32 tag, u64 v, int depth) -> TVal {
+    TVal r;
+    if (depth > 64) throw TraceIncomplete{};
+    switch (tag) {
+      case 0: return r;
+      case 1: r.k = TVal::Bool; r.b = v != 0; return r;
+      case 2: r.k = TVal::Int; r.i = (long long)v; return r;
+      case 3: if (v >> 63) { r.k = TVal::Double; r.d = (double)v; } else { r.k = TVal::Int; r.i = (long long)v; } return r;
+      case 4: r.k = TVal::Double; memcpy(&r.d, &v, 8); return r;
+      case 5: r.k = TVal::String; r.s = std::string(str(v & 0xFFFFFFFFu)); return r;
+      case 6: case 7: {
+        const u32 sel = (u32)(v >> 62), off = (u32)((v >> 32) & 0x3FFFFFFFu), len = (u32)v;
+        r.k = tag == 6 ? TVal::List : TVal::Map;
+        if (sel == CBH_HEAP_ROLES) { if ((u64)off + len > b->roles.size()) throw TraceIncomplete{}; for (u32 i = 0; i < len; ++i) { TVal e; e.k = TVal::String; e.s = std::string(str(b->roles[off + i])); r.items.push_back(std::move(e)); } return r; }
+        const u8* tags; const u64* vals; u64 cap;
+        if (sel == CBH_HEAP_BATCH) { tags = b->heap_tag.data(); vals = b->heap_val.data(); cap = b->heap_tag.size(); }
+        else if (sel == CBH_HEAP_TABLE) { tags = t->theap_tag; vals = t->theap_val; cap = t->theap_len; }
+        else throw TraceIncomplete{};
+        const u64 cnt = tag == 6 ? (u64)len : 2ull * len;
+        if ((u64)off + cnt > cap) throw TraceIncomplete{};
+        for (u64 i = 0; i < cnt; ++i) r.items.push_back(to_tval(tags[off + i], vals[off + i], depth + 1));
+        return r;
+      }
+      default: throw TraceIncomplete{};   // timestamps / durations as output values
+    }
+  };
+  // the text of an error (include/cerbos_hip.h CBH_ERR_*); `msg` = the input's CheckInput bytes
+  auto message = [&](u64 payload, Span msg) -> std::string {
+    const u32 code = (u32)(payload & 0xFF); const u64 detail = payload >> 8;
+    switch (code) {
+      case CBH_ERR_NO_SUCH_OVERLOAD: return "no such overload";
+      case CBH_ERR_DIV_BY_ZERO: return "division by zero";
+      case CBH_ERR_MOD_BY_ZERO: return "modulus by zero";
+      case CBH_ERR_INT_OVERFLOW: return "integer overflow";
+      case CBH_ERR_UINT_OVERFLOW: return "unsigned integer overflow";
+      case CBH_ERR_NO_SUCH_KEY: return "no such key: " + std::string(str(detail & 0xFFFFFFFFu));
+      case CBH_ERR_UNDEFINED_FIELD: if (detail >= t->trace_strings.size()) throw TraceIncomplete{}; return "undefined field '" + t->trace_strings[detail] + "'";
+      case CBH_ERR_EDR_FAILED: {
+        std::vector<std::string> names;
+        for (u32 d = 0; d < 56 && d < t->dr_names.size(); ++d) if ((detail >> d) & 1) names.push_back(t->dr_names[d]);
+        std::sort(names.begin(), names.end());
+        std::string m = "failed to compute effective derived roles [";
+        for (size_t i = 0; i < names.size(); ++i) { if (i) m += ", "; m += names[i]; }
+        return m + "]";
+      }
+      case CBH_ERR_ATTR_MISSING: {
+        // the column's path did not resolve in this input: the step that failed decides the text
+        if (detail >= t->columns.size()) throw TraceIncomplete{};
+        const Column& col = t->columns[detail];
+        Span principal{nullptr, nullptr}, resource{nullptr, nullptr}, aux{nullptr, nullptr};
+        { Span s = msg; Field f; bool bad = false; while (next(s, f, bad)) { if (f.wt != 2) continue; if (f.num == 2) resource = f.s; else if (f.num == 3) principal = f.s; else if (f.num == 5) aux = f.s; } }
+        bool bad = false;
+        Span holder = col.root == 0 ? principal : col.root == 1 ? resource : aux;   // the message whose map field is the root
+        u32 fnum = col.root == 2 ? 1u : col.root == 3 ? 2u : 4u;
+        size_t k = 0;
+        Span cur{nullptr, nullptr};
+        if (col.keys.empty()) throw TraceIncomplete{};
+        if (!map_get(holder, fnum, col.keys[0], cur, bad)) return "no such key: " + col.keys[0];
+        k = 1;
+        if (col.root == 3) {   // name -> {"claims": {...}}
+          if (k >= col.keys.size()) throw TraceIncomplete{};
+          if (col.keys[k] != "claims") return "no such key: " + col.keys[k];
+          ++k;
+          if (k >= col.keys.size()) throw TraceIncomplete{};
+          Span inner{nullptr, nullptr};
+          if (!map_get(cur, 1, col.keys[k], inner, bad)) return "no such key: " + col.keys[k];
+          cur = inner; ++k;
+        }
+        for (; k < col.keys.size(); ++k) {
+          Val v;
+          if (!value(cur, v, bad) || v.kind != 5) return "no such overload";
+          Span nxt{nullptr, nullptr};
+          if (!map_get(v.s, 1, col.keys[k], nxt, bad)) return "no such key: " + col.keys[k];
+          cur = nxt;
+        }
+        throw TraceIncomplete{};
+      }
+      default: throw TraceIncomplete{};
+    }
+  };
+
+  struct Visit { u32 src; u64 mask; bool drfail; std::map<u32, std::pair<bool, TVal>> ok_parts; std::map<u32, std::string> err_parts; };
+  struct Key { u32 q, pass, ri, site, rule; bool operator<(const Key& o) const { return std::tie(q, pass, ri, site, rule) < std::tie(o.q, o.pass, o.ri, o.site, o.rule); } };
+  std::vector<std::set<std::pair<std::string, std::string>>> errs(n);
+  std::vector<std::map<Key, Visit>> visits(n);
+  std::vector<u8> flags(n, 0);
+  if (res->status) for (u32 q = 0; q < R; ++q) { const u32 o0 = RQ(RQ_ACT_OFF, q), c = RQ(RQ_ACT_CNT, q); for (u32 k = 0; k < c; ++k) if (res->status[o0 + k] == CBH_ST_UNSUPPORTED) flags[b->req_input[q]] |= CBI_TRACE_ERRORS_INCOMPLETE | CBI_TRACE_OUTPUTS_INCOMPLETE; }
+  for (u32 x = 0; x < count; ++x) {
+    const uint32_t* rec = records + (size_t)x * CBH_TRACE_RECORD_WORDS;
+    const u32 q = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3], kind = w1 & 0xF;
+    if (q >= R) return fail("trace record refers to a request outside the batch");
+    const u32 i = b->req_input[q];
+    const Span msg{bytes + offsets[i], bytes + offsets[i + 1]};
+    try {
+      if (kind == CBH_TR_INCOMPLETE) flags[i] |= CBI_TRACE_OUTPUTS_INCOMPLETE;
+      else if (kind == CBH_TR_ERROR) {
+        if (w2 >= t->trace_strings.size()) return fail("trace record refers to an unknown string");
+        errs[i].emplace(t->trace_strings[w2], message((u64)rec[4] | ((u64)rec[5] << 32), msg));
+      } else if (kind == CBH_TR_OUTPUT || kind == CBH_TR_OUTPUT_ERROR) {
+        const u32 rule = kind == CBH_TR_OUTPUT ? (w3 >> 8) : rec[4];
+        Visit& v = visits[i][Key{q, (w1 >> 4) & 1, (w1 >> 12) & 0xFF, w1 >> 20, rule}];
+        v.src = w2; v.mask = (u64)rec[6] | ((u64)rec[7] << 32); v.drfail = (w1 & 32u) != 0;
+        const u32 part = (w1 >> 6) & 63;
+        if (kind == CBH_TR_OUTPUT) v.ok_parts[part] = {true, to_tval(w3 & 0xFF, (u64)rec[4] | ((u64)rec[5] << 32), 0)};
+        else v.err_parts[part] = message((u64)w3 | ((u64)rec[5] << 32), msg);
+      }
+    } catch (const TraceIncomplete&) { flags[i] |= kind == CBH_TR_ERROR ? CBI_TRACE_ERRORS_INCOMPLETE : CBI_TRACE_OUTPUTS_INCOMPLETE; }
+  }
+
+  auto o = new cbi_outputs();
+  o->offsets.reserve((size_t)n + 1); o->offsets.push_back(0); o->flags = flags;
+  std::vector<u8>& ob = o->bytes;
+  std::vector<std::string_view> actions;
+  struct Entry { u64 a; u32 pass, ri, site; bool drfail; u32 rule; std::vector<u8> body; std::string_view action; };
+  for (u32 i = 0; i < n; ++i) {
+    // outputs (field 6), in the order check.go's loops reach them: action, policy kind, role, rule
+    actions.clear();
+    { Span s{bytes + offsets[i], bytes + offsets[i + 1]}; Field f; bool bad = false; while (next(s, f, bad)) if (f.num == 4 && f.wt == 2) actions.push_back(sv(f.s)); }
+    std::vector<Entry> entries;
+    for (auto& kv : visits[i]) {
+      const Key& key = kv.first; Visit& v = kv.second;
+      auto tm = t->trace_templates.find(key.rule);
+      if (tm == t->trace_templates.end() || v.src >= t->trace_strings.size()) { delete o; return fail("trace record refers to an unknown output"); }
+      std::vector<u8> body;
+      put_ld(body, 1, t->trace_strings[v.src]);
+      bool lost = false;
+      try {
+        if (v.ok_parts.size() + v.err_parts.size() != tm->second.second) throw TraceIncomplete{};
+        if (!v.err_parts.empty()) put_ld(body, 4, v.err_parts.begin()->second);   // the first part to fail in evaluation order
+        else {
+          std::vector<TVal> holes;
+          for (auto& pk : v.ok_parts) { if (pk.first != holes.size()) throw TraceIncomplete{}; holes.push_back(pk.second.second); }
+          std::vector<u8> vb; put_value(vb, assemble_template(tm->second.first, holes));
+          put_varint(body, 2 << 3 | 2); put_varint(body, vb.size()); body.insert(body.end(), vb.begin(), vb.end());
+        }
+      } catch (const TraceIncomplete&) { lost = true; }
+      if (lost) { o->flags[i] |= CBI_TRACE_OUTPUTS_INCOMPLETE; continue; }
+      const u32 o0 = RQ(RQ_ACT_OFF, key.q), cnt = RQ(RQ_ACT_CNT, key.q);
+      for (u32 k = 0; k < cnt && k < 64; ++k) if ((v.mask >> k) & 1) {
+        const u64 tp = b->tuple_perm[o0 + k];
+        if (tp < first[i] || tp >= first[i + 1] || tp - first[i] >= actions.size()) { delete o; return fail("batch does not belong to these inputs"); }
+        entries.push_back(Entry{tp - first[i], key.pass, key.ri, key.site, v.drfail, key.rule & 0x7FFFFFu, body, actions[tp - first[i]]});
+      }
+    }
+    std::stable_sort(entries.begin(), entries.end(), [](const Entry& x, const Entry& y) { return std::tie(x.a, x.pass, x.ri, x.site) < std::tie(y.a, y.pass, y.ri, y.site); });
+    std::set<u32> seen_drfail;
+    for (Entry& e : entries) {
+      // the first visit of a rule whose derived-role condition fails emits nothing (check.go:343-347 caches "false" under the
+      // evaluation key and moves on); later visits find the cached outcome and emit conditionNotMet
+      if (e.drfail && seen_drfail.insert(e.rule).second) continue;
+      put_ld(e.body, 3, e.action);
+      put_varint(ob, 6 << 3 | 2); put_varint(ob, e.body.size()); ob.insert(ob.end(), e.body.begin(), e.body.end());
+    }
+    // evaluation_errors (field 7), sorted and deduplicated as CELErrors.All() (cel_errors.go:98-118)
+    for (const auto& em : errs[i]) {
+      std::vector<u8> ce; put_str(ce, 1, em.first); put_str(ce, 2, em.second);
+      std::vector<u8> ee; put_varint(ee, 1 << 3 | 2); put_varint(ee, ce.size()); ee.insert(ee.end(), ce.begin(), ce.end());
+      put_varint(ob, 7 << 3 | 2); put_varint(ob, ee.size()); ob.insert(ob.end(), ee.begin(), ee.end());
+    }
+    o->offsets.push_back(ob.size());
+  }
+  ob.reserve(1);
+  *out = o;
+  return 0;
+}
+
+extern "C" {
 void cbi_outputs_free(cbi_outputs* o) { delete o; }
 const uint8_t* cbi_outputs_bytes(const cbi_outputs* o) { return o ? o->bytes.data() : nullptr; }
 const uint64_t* cbi_outputs_offsets(const cbi_outputs* o) { return o ? o->offsets.data() : nullptr; }

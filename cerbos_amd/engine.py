@@ -169,7 +169,7 @@ class HipEvaluator:
         return incomplete
 
     def check_pb(self, data, offsets, now_ns=None, lenient_scope_search=None, strict_evaluation=None,
-                 default_policy_version=None, default_scope=None):
+                 default_policy_version=None, default_scope=None, trace=False):
         """Bytes in, bytes out - the path a Go caller takes: serialized ``CheckInput``
         messages (``data`` uint8, ``offsets`` uint64[n + 1]) -> C++ ingest -> ``cbh_check_batch`` -> C++ response
         assembly.  Returns ([serialized CheckOutput], flags uint8[n]); flags bit 0 = the device could not
@@ -185,7 +185,36 @@ class HipEvaluator:
         batch = self._ingest.flatten_pb(data, offsets, dver, dscope)
         flags = capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0) | (capi.F_STRICT_EVALUATION if strict else 0)
         res = self.table.check(batch, now_ns=now_ns, flags=flags, device_order=True)
-        return self._ingest.assemble_pb(batch, res, data, offsets, dver)
+        outs, oflags = self._ingest.assemble_pb(batch, res, data, offsets, dver)
+        if not trace:
+            return outs, oflags
+        # evaluation_errors / outputs (check.go:90-92): the inputs that can have any go through the tracing kernel and
+        # cbi_trace_pb; its bytes - just those two fields - are appended to the CheckOutput (protobuf concatenation merges).
+        # flags bits 2 / 3 (CBI_TRACE_*): the device could not name all errors / outputs of that input.
+        import numpy as np
+
+        from .ingest import trace_pb
+        oflags = np.array(oflags, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        lt = self.lt
+        if lt.trace_has_variables or lt.trace_has_outputs:
+            sel = [i for i in range(len(outs)) if not oflags[i] & 1]
+        else:
+            sel = [i for i in range(len(outs)) if (oflags[i] & 3) == 2]
+        if not sel:
+            return outs, oflags
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        parts = [data[int(offsets[i]):int(offsets[i + 1])] for i in sel]
+        sdata = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
+        soff = np.zeros(len(sel) + 1, dtype=np.uint64)
+        soff[1:] = np.cumsum([p.size for p in parts])
+        sbatch = self._ingest.flatten_pb(sdata, soff, dver, dscope)
+        tres, records = self.table.trace(sbatch, now_ns=now_ns, flags=flags)
+        extra, tflags = trace_pb(self._ingest, sbatch, tres, records, sdata, soff)
+        for j, i in enumerate(sel):
+            outs[i] = outs[i] + extra[j]
+            oflags[i] |= tflags[j] & 12
+        return outs, oflags
 
     def check_request_pb(self, request: bytes, aux_data: bytes = None, now_ns=None, lenient_scope_search=None,
                          strict_evaluation=None, default_policy_version=None, default_scope=None):

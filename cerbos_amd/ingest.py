@@ -47,6 +47,7 @@ def load():
         lib.cbi_batch_request_input.restype = C.POINTER(C.c_uint32)
         lib.cbi_assemble_pb.argtypes = [vp, vp, C.POINTER(capi.CResult), vp, vp, C.c_uint32, C.c_char_p, C.POINTER(vp)]
         lib.cbi_assemble_pb_mt.argtypes = [vp, vp, C.POINTER(capi.CResult), vp, vp, C.c_uint32, C.c_char_p, C.c_int, C.POINTER(vp)]
+        lib.cbi_trace_pb.argtypes = [vp, vp, C.POINTER(capi.CResult), vp, C.c_uint32, vp, vp, C.c_uint32, C.POINTER(vp)]
         lib.cbi_outputs_free.argtypes = [vp]
         lib.cbi_outputs_free.restype = None
         lib.cbi_outputs_bytes.argtypes = [vp]
@@ -182,6 +183,32 @@ class IngestTable:
             return [raw[off[i]:off[i + 1]] for i in range(n)], flags
         finally:
             load().cbi_outputs_free(h)
+
+
+    def _outputs(self, h, n):
+        try:
+            off = _copy(load().cbi_outputs_offsets(h), C.c_uint64, np.int64, n + 1)
+            raw = _copy(load().cbi_outputs_bytes(h), C.c_uint8, np.uint8, int(off[-1])).tobytes()
+            flags = _copy(load().cbi_outputs_flags(h), C.c_uint8, np.uint8, n)
+            return [raw[off[i]:off[i + 1]] for i in range(n)], flags
+        finally:
+            load().cbi_outputs_free(h)
+
+
+TRACE_ERRORS_INCOMPLETE, TRACE_OUTPUTS_INCOMPLETE = 4, 8
+
+
+def trace_pb(table: IngestTable, batch, res, records, data, offsets):
+    """``cbi_trace_pb``: the log of a traced batch (``capi.Table.trace``: device-order ``res``, ``records``) ->
+    ([the evaluation_errors + outputs fields of each input's CheckOutput, serialized], flags uint8[n])."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    records = np.ascontiguousarray(records, dtype=np.uint32)
+    n = len(offsets) - 1
+    h = C.c_void_p()
+    _check(load().cbi_trace_pb(table.h, batch.native.h, C.byref(res.c), records.ctypes.data if records.size else None,
+                               len(records), data.ctypes.data if data.size else None, offsets.ctypes.data, n, C.byref(h)))
+    return table._outputs(h, n)
 
 
 class WireFlattener:

@@ -36,7 +36,7 @@ ROW_LEAF = 8           # dwords 8..15: the embedded fused-leaf record
 (PAT_ACTION, PAT_ROLE, PAT_RESOURCE, PAT_COUNTS, PAT_A1, _, PAT_R1, _) = range(8)   # CbhRowPatField
 ROW_F_LEAF_EMBEDDED = 64
 SEC_ACTION_CLASS, SEC_ROWPAT, SEC_ROWLEAF2, SEC_DRX, SEC_REGEX = 28, 29, 30, 31, 33
-SEC_TRACE_ROWS, SEC_TRACE_DR, SEC_TRACE_RP, SEC_TRACE_POOL, SEC_TRACE_STRINGS = 34, 35, 36, 37, 38
+SEC_TRACE_ROWS, SEC_TRACE_DR, SEC_TRACE_RP, SEC_TRACE_POOL, SEC_TRACE_STRINGS, SEC_TRACE_HOST = 34, 35, 36, 37, 38, 39
 RP_F_OUTPUT_ONLY, RP_F_SHARES_KEY = 0x80000000, 0x40000000   # cbh_blob.h CBH_RP_F_*: flags in CBH_RP_ALLOW_CNT
 ROW_F_DRLEAF_EMBEDDED = 128
 ROW_F_TREE_EMBEDDED, ROW_F_DRTREE_EMBEDDED = 256, 512   # the slot holds a tree descriptor (_tree_descriptor)
@@ -715,6 +715,7 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
             (SEC_TRACE_RP, len(trace_rp), records(trace_rp, 8)),
             (SEC_TRACE_POOL, len(trace_pool), u32(trace_pool or [0])),
             (SEC_TRACE_STRINGS, len(lt.trace_strings), tstr),   # host only
+            (SEC_TRACE_HOST, len(lt.trace_strings), _trace_host(lt.trace_strings, lt.trace_templates)),   # host only: the same for cbh_ingest.cpp
         ]
     lt.blob = _pack(sections)
     lt.stats = {
@@ -735,6 +736,42 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
             | (4 if (used_any or any(lt.nfas[d].patterns for d in range(3))) else 0))),
     }
     return lt
+
+
+def _trace_host(strings, templates):
+    """CBH_SEC_TRACE_HOST (cbh_blob.h): the trace strings and output templates in a form C++ reads without a JSON parser."""
+    out = bytearray(struct.pack("<I", len(strings)))
+    for x in strings:
+        b = x.encode("utf-8")
+        out += struct.pack("<I", len(b)) + b
+
+    def node(t):
+        k = t[0]
+        if k == "hole":
+            return struct.pack("<BI", 0, t[1])
+        if k == "const":
+            v = t[1]
+            if v is None:
+                return struct.pack("<BB", 1, 0)
+            if isinstance(v, bool):
+                return struct.pack("<BBB", 1, 1, int(v))
+            if isinstance(v, int):
+                return struct.pack("<BBq", 1, 2, v if v < (1 << 63) else v - (1 << 64))
+            if isinstance(v, float):
+                return struct.pack("<BBd", 1, 3, v)
+            b = v.encode("utf-8")
+            return struct.pack("<BBI", 1, 4, len(b)) + b
+        if k == "list":
+            return struct.pack("<BI", 2, len(t[1])) + b"".join(node(e) for e in t[1])
+        if k == "map":
+            return struct.pack("<BI", 3, len(t[1])) + b"".join(node(kt) + node(vt) for kt, vt in t[1])
+        fb = t[1].encode("utf-8")
+        return struct.pack("<BI", 4, len(fb)) + fb + struct.pack("<I", len(t[2])) + b"".join(node(e) for e in t[2])
+
+    out += struct.pack("<I", len(templates))
+    for word, (tmpl, n_holes) in sorted(templates.items()):
+        out += struct.pack("<II", word, n_holes) + node(tmpl)
+    return bytes(out)
 
 
 def _tree_descriptor(strip):

@@ -140,9 +140,77 @@ def _fields(buf: bytes):
 _EFFECTS = {0: "EFFECT_UNSPECIFIED", 1: "EFFECT_ALLOW", 2: "EFFECT_DENY", 3: "EFFECT_NO_MATCH"}
 
 
+def decode_value(buf: bytes):
+    """google.protobuf.Value -> JSON (the last field wins; an empty message is null)."""
+    import struct
+    out = None
+    i, n = 0, len(buf)
+    while i < n:
+        key = buf[i]; i += 1
+        num, wt = key >> 3, key & 7
+        if wt == 1:
+            out = struct.unpack_from("<d", buf, i)[0]; i += 8
+        elif wt == 0:
+            v = shift = 0
+            while True:
+                b = buf[i]; i += 1
+                v |= (b & 0x7F) << shift; shift += 7
+                if not b & 0x80:
+                    break
+            out = None if num == 1 else bool(v)
+        else:
+            ln = shift = 0
+            while True:
+                b = buf[i]; i += 1
+                ln |= (b & 0x7F) << shift; shift += 7
+                if not b & 0x80:
+                    break
+            body = buf[i:i + ln]; i += ln
+            if num == 3:
+                out = body.decode("utf-8")
+            elif num == 6:
+                out = [decode_value(v2) for n2, v2 in _fields(body) if n2 == 1]
+            elif num == 5:
+                out = {}
+                for n2, ent in _fields(body):
+                    if n2 == 1:
+                        k, val = "", None
+                        for n3, v3 in _fields(ent):
+                            if n3 == 1:
+                                k = v3.decode("utf-8")
+                            elif n3 == 2:
+                                val = decode_value(v3)
+                        out[k] = val
+    return out
+
+
 def decode_check_output(buf: bytes) -> dict:
     out = {"requestId": "", "resourceId": "", "actions": {}, "effectiveDerivedRoles": []}
     for num, v in _fields(buf):
+        if num == 6:     # OutputEntry {src 1, val 2, action 3, error 4}
+            e = {}
+            has_val = False
+            for n2, v2 in _fields(v):
+                if n2 == 1:
+                    e["src"] = v2.decode("utf-8")
+                elif n2 == 2:
+                    e["val"] = decode_value(v2); has_val = True
+                elif n2 == 3:
+                    e["action"] = v2.decode("utf-8")
+                elif n2 == 4:
+                    e["error"] = v2.decode("utf-8")
+            if not has_val and "error" not in e:
+                e["val"] = None
+            out.setdefault("outputs", []).append(e)
+            continue
+        if num == 7:     # EvaluationError {cel_error 1 {expression 1, message 2}}
+            ce = {"expression": "", "message": ""}
+            for n2, v2 in _fields(v):
+                if n2 == 1:
+                    for n3, v3 in _fields(v2):
+                        ce["expression" if n3 == 1 else "message"] = v3.decode("utf-8")
+            out.setdefault("evaluationErrors", []).append({"celError": ce})
+            continue
         if num == 1:
             out["requestId"] = v.decode("utf-8")
         elif num == 2:

@@ -98,6 +98,17 @@ int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result*
  * (cerbos_svc.go:297-343).  cbi_outputs_offsets = {0, length}; cbi_outputs_flags: one byte per resource entry. */
 int cbi_assemble_response_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* request,
                              uint64_t request_len, const char* default_version, cbi_outputs** out);
+/* The trace pass's consumer (cbh_trace_batch, include/cerbos_hip.h): the evaluation_errors (field 7) and outputs (field 6)
+ * of the CheckOutputs, from the log of a traced batch.  `b` = the batch cbi_flatten_pb made of the n traced inputs
+ * (`bytes`, `offsets`), `res` = what cbh_trace_batch returned for it, `records` / `count` = its log.  Output i holds ONLY
+ * those two fields, serialized: appended to the bytes cbi_assemble_pb produced for the same input they form one CheckOutput
+ * (protobuf concatenation is a merge).  Errors come sorted and deduplicated (cel_errors.go:98-118), outputs in the order
+ * check.go's loops reach them.  cbi_outputs_flags: CBI_TRACE_* where the device could not name everything - the decision
+ * stands, errors / outputs of that input are the caller's engine's to supply. */
+#define CBI_TRACE_ERRORS_INCOMPLETE 4u
+#define CBI_TRACE_OUTPUTS_INCOMPLETE 8u
+int cbi_trace_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint32_t* records, uint32_t count,
+                 const uint8_t* bytes, const uint64_t* offsets, uint32_t n, cbi_outputs** out);
 void cbi_outputs_free(cbi_outputs* o);
 /* Output i = bytes[offsets[i] .. offsets[i+1]); n + 1 offsets. */
 const uint8_t* cbi_outputs_bytes(const cbi_outputs* o);

@@ -313,3 +313,90 @@ def test_workload_errors_named_as_the_oracle_names_them():
 def test_gpu_workload_errors_at_size():
     n_err, compared = _workload_errors(lambda lt: HipEvaluator(lt, Conf()), True, 200_000, 300)
     assert n_err > 2000 and compared > 300, (n_err, compared)
+
+
+# ---- the bytes path: serialized CheckInputs -> C++ ingest -> trace kernel -> cbi_trace_pb -> serialized CheckOutputs --------
+def _bytes_path(ev, inputs, **kw):
+    """check_pb(trace=True) decoded, next to check(trace=True) of the same evaluator: ([CheckOutput dicts], flags)."""
+    from cerbos_amd import wire
+    data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+    raw, flags = ev.check_pb(data, off, now_ns=NOW, trace=True, **kw)
+    return [wire.decode_check_output(r) for r in raw], flags
+
+
+def _bytes_engine_cases(ev):
+    verified = outputs = 0
+    for case in CASES:
+        for lenient in hg._modes(case):
+            outs, flags = _bytes_path(ev, case["inputs"], lenient_scope_search=lenient, strict_evaluation=case.get("strict"))
+            for i, (have, want) in enumerate(zip(outs, case["wantOutputs"])):
+                if flags[i] & 1:
+                    continue
+                assert norm_actions(have) == norm_actions(want), (case["name"], lenient, i)
+                if not flags[i] & 4:
+                    assert (have.get("evaluationErrors") or []) == (want.get("evaluationErrors") or []), (case["name"], lenient, i)
+                    verified += 1
+                if not flags[i] & 8:
+                    by_src = lambda o: o["src"]   # noqa: E731
+                    assert sorted(have.get("outputs") or [], key=by_src) == sorted(want.get("outputs") or [], key=by_src), (case["name"], lenient, i)
+                    outputs += bool(want.get("outputs"))
+    return verified, outputs
+
+
+class _HostSimBytes(hg.HostSimEvaluator):
+    """The bytes path with the kernels on the host simulator: C++ ingest and C++ trace consumer are the product's."""
+    _ingest = None
+
+
+def test_bytes_path_engine_cases_through_the_cpp_consumer():
+    verified, outputs = _bytes_engine_cases(_HostSimBytes(_store_table(), Conf(globals_=GLOBALS)))
+    assert verified >= 150 and outputs >= 12, (verified, outputs)
+
+
+@pytest.mark.gpu
+def test_gpu_bytes_path_engine_cases_through_the_cpp_consumer():
+    ev = HipEvaluator(_store_table(), Conf(globals_=GLOBALS))
+    try:
+        verified, outputs = _bytes_engine_cases(ev)
+    finally:
+        ev.close()
+    assert verified >= 150 and outputs >= 12, (verified, outputs)
+
+
+def _bytes_fuzz(seed, make, close):
+    """cbi_trace_pb against cerbos_amd/trace.py (which the oracle checks above): same errors, same outputs, same order."""
+    rng = np.random.default_rng(77_000 + seed)
+    rt = rule_table_from_policies(policies_from_docs(_trace_policies(rng)))
+    try:
+        lt = lower_rule_table(rt)
+    except LoweringError:
+        return 0
+    ev = make(lt)
+    inputs = fz._requests(rng, 80)
+    n = 0
+    try:
+        for strict in (False, True):
+            pouts, pbad, pinc = ev.check(inputs, now_ns=NOW, strict_evaluation=strict, allow_unsupported=True, trace=True)
+            bouts, flags = _bytes_path(ev, inputs, strict_evaluation=strict)
+            for i, (p, b) in enumerate(zip(pouts, bouts)):
+                assert bool(flags[i] & 1) == (i in pbad), (seed, i)
+                if i in pbad:
+                    continue
+                what = pinc.get(i, ())
+                assert bool(flags[i] & 4) == ("errors" in what) and bool(flags[i] & 8) == ("outputs" in what), (seed, i, flags[i], what)
+                if "errors" not in what:
+                    assert (b.get("evaluationErrors") or []) == p["evaluationErrors"], (seed, strict, inputs[i])
+                if "outputs" not in what:
+                    # a CheckInput that repeats an action: the Python path keys its outputs by name, both keep the order
+                    assert (b.get("outputs") or []) == p["outputs"], (seed, strict, inputs[i])
+                n += 1
+    finally:
+        if close:
+            ev.close()
+    return n
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("CBH_TRACE_FUZZ_SEEDS", "12")))))
+def test_bytes_path_fuzz_against_the_python_consumer(seed):
+    n = _bytes_fuzz(seed, lambda lt: _HostSimBytes(lt, Conf()), False)
+    assert n == 0 or n > 100
