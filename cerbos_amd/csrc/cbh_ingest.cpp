@@ -190,7 +190,7 @@ struct cbi_table {
   std::vector<std::string> trace_strings;
   std::unordered_map<u32, std::pair<TNode, u32>> trace_templates;
   const u8* theap_tag = nullptr; const u64* theap_val = nullptr; u32 theap_len = 0;
-  bool has_trace = false;
+  bool has_trace = false, trace_all = false;
   std::string_view at(u32 i) const { return std::string_view(str_bytes + str_off[i], str_off[i + 1] - str_off[i]); }
 };
 
@@ -473,6 +473,10 @@ int cbi_table_open(const void* blob, size_t len, cbi_table** out) {
     const CbhBlobSection *ht = find(CBH_SEC_THEAP_TAG), *hv = find(CBH_SEC_THEAP_VAL);
     if (ht && hv && hv->nbytes / 8 >= ht->nbytes) { t->theap_tag = base + ht->offset; t->theap_val = (const u64*)(base + hv->offset); t->theap_len = (u32)ht->nbytes; }
     t->has_trace = true;
+    // variables are evaluated whether a condition reads them or not, outputs on every visit of their rule: such a table's
+    // inputs are all traced, any other table's only where a decision kernel marked CBH_ST_CEL_ERROR
+    const CbhBlobSection* tp = find(CBH_SEC_TRACE_POOL);
+    t->trace_all = (tp && tp->count > 0) || !t->trace_templates.empty();
   }
   const u8* p = base + sc->offset; const u8* e = p + sc->nbytes;
   u32 ncol = meta[CBH_M_NCOLUMNS];
@@ -493,6 +497,7 @@ int cbi_table_open(const void* blob, size_t len, cbi_table** out) {
 }
 
 void cbi_table_close(cbi_table* t) { delete t; }
+uint32_t cbi_table_trace_scope(const cbi_table* t) { return !t || !t->has_trace ? 0u : t->trace_all ? 2u : 1u; }
 
 }  // extern "C"
 

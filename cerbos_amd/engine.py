@@ -196,8 +196,7 @@ class HipEvaluator:
         from .ingest import trace_pb
         oflags = np.array(oflags, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
-        lt = self.lt
-        if lt.trace_has_variables or lt.trace_has_outputs:
+        if self._ingest.trace_scope() == 2:
             sel = [i for i in range(len(outs)) if not oflags[i] & 1]
         else:
             sel = [i for i in range(len(outs)) if (oflags[i] & 3) == 2]

@@ -47,6 +47,8 @@ def load():
         lib.cbi_batch_request_input.restype = C.POINTER(C.c_uint32)
         lib.cbi_assemble_pb.argtypes = [vp, vp, C.POINTER(capi.CResult), vp, vp, C.c_uint32, C.c_char_p, C.POINTER(vp)]
         lib.cbi_assemble_pb_mt.argtypes = [vp, vp, C.POINTER(capi.CResult), vp, vp, C.c_uint32, C.c_char_p, C.c_int, C.POINTER(vp)]
+        lib.cbi_table_trace_scope.argtypes = [vp]
+        lib.cbi_table_trace_scope.restype = C.c_uint32
         lib.cbi_trace_pb.argtypes = [vp, vp, C.POINTER(capi.CResult), vp, C.c_uint32, vp, vp, C.c_uint32, C.POINTER(vp)]
         lib.cbi_outputs_free.argtypes = [vp]
         lib.cbi_outputs_free.restype = None
@@ -104,6 +106,10 @@ class IngestTable:
             self.close()
         except Exception:
             pass
+
+    def trace_scope(self) -> int:
+        """0 = no trace sections, 1 = trace the inputs marked CEL_ERROR, 2 = trace every input (``cbi_table_trace_scope``)."""
+        return int(load().cbi_table_trace_scope(self.h))
 
     def flatten_pb(self, data, offsets, default_policy_version="default", default_scope="", sort=True, threads=1) -> Batch:
         """``data``: uint8 array holding the messages back to back, ``offsets``: uint64[n + 1]; ``threads`` > 1

@@ -80,8 +80,8 @@ const uint32_t* cbi_batch_request_input(const cbi_batch* b);
  * request_id, resource_id, actions{effect, policy, scope} with duplicates of an action folded "DENY sticky"
  * (check.go:513-530), effective_derived_roles.  `res` is in DEVICE order exactly as cbh_check_batch /
  * cbh_result_download filled it (policy / scope / status / edr_mask may be NULL: those fields are then left out).
- * Not produced here: validation_errors, outputs, evaluation_errors text (inputs whose flags carry
- * CBI_OUT_CEL_ERROR had a CEL error absorbed: the caller re-evaluates those if it wants the messages).
+ * Not produced here: validation_errors; outputs and evaluation_errors come from the trace pass (cbi_trace_pb below) for
+ * the inputs that can have any (cbi_table_trace_scope).
  */
 typedef struct cbi_outputs cbi_outputs;
 #define CBI_OUT_UNSUPPORTED 1u /* device hit an operation outside its subset: output invalid, caller's engine must run this input */
@@ -105,6 +105,10 @@ int cbi_assemble_response_pb(const cbi_table* t, const cbi_batch* b, const cbh_r
  * (protobuf concatenation is a merge).  Errors come sorted and deduplicated (cel_errors.go:98-118), outputs in the order
  * check.go's loops reach them.  cbi_outputs_flags: CBI_TRACE_* where the device could not name everything - the decision
  * stands, errors / outputs of that input are the caller's engine's to supply. */
+/* Which inputs of a table want the trace pass: 0 = the image has no trace sections, 1 = the inputs with CBI_OUT_CEL_ERROR,
+ * 2 = every input (the table has variables - evaluated whether or not a condition reads them, check.go:651-677 - or rules
+ * with output expressions). */
+uint32_t cbi_table_trace_scope(const cbi_table* t);
 #define CBI_TRACE_ERRORS_INCOMPLETE 4u
 #define CBI_TRACE_OUTPUTS_INCOMPLETE 8u
 int cbi_trace_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint32_t* records, uint32_t count,

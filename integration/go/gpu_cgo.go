@@ -136,6 +136,13 @@ func (g *gpuEngine) checkBatchGPU(_ context.Context, inputs []*enginev1.CheckInp
 	oflags := unsafe.Slice((*byte)(unsafe.Pointer(C.cbi_outputs_flags(assembled))), n)
 	obytes := unsafe.Slice((*byte)(unsafe.Pointer(C.cbi_outputs_bytes(assembled))), int(ooffs[n]))
 
+	// evaluation_errors / outputs (check.go:90-92): the inputs that can have any go through the tracing kernel once more
+	// (INTEGRATION.md §2c); what comes back per input is just those two fields, serialized - merged into the output below.
+	extra, err := g.traceGPU(buf, offs, oflags, n, dv, ds, &params)
+	if err != nil {
+		return nil, nil, err
+	}
+
 	outs = make([]*enginev1.CheckOutput, n)
 	fallback = make([]bool, n)
 	for i := range inputs {
@@ -147,9 +154,107 @@ func (g *gpuEngine) checkBatchGPU(_ context.Context, inputs []*enginev1.CheckInp
 		if err := proto.Unmarshal(obytes[ooffs[i]:ooffs[i+1]], out); err != nil {
 			return nil, nil, fmt.Errorf("output %d: %w", i, err)
 		}
+		if x, ok := extra[i]; ok {
+			if x.incomplete { // the device could not name every error / output of this input: the CPU path does
+				fallback[i] = true
+				continue
+			}
+			if err := (proto.UnmarshalOptions{Merge: true}).Unmarshal(x.bytes, out); err != nil {
+				return nil, nil, fmt.Errorf("trace of output %d: %w", i, err)
+			}
+		}
 		outs[i] = out
 	}
 	return outs, fallback, nil
+}
+
+type traced struct {
+	bytes      []byte // serialized CheckOutput holding only outputs (6) and evaluation_errors (7)
+	incomplete bool
+}
+
+// traceGPU runs cbh_trace_batch over the inputs cbi_table_trace_scope selects and decodes its log with cbi_trace_pb.
+func (g *gpuEngine) traceGPU(buf []byte, offs []C.uint64_t, oflags []byte, n int, dv, ds *C.char, params *C.cbh_params) (map[int]traced, error) {
+	scope := C.cbi_table_trace_scope(g.ingest)
+	if scope == 0 {
+		return nil, nil
+	}
+	var sel []int
+	for i := 0; i < n; i++ {
+		if oflags[i]&C.CBI_OUT_UNSUPPORTED != 0 {
+			continue
+		}
+		if scope == 2 || oflags[i]&C.CBI_OUT_CEL_ERROR != 0 {
+			sel = append(sel, i)
+		}
+	}
+	if len(sel) == 0 {
+		return nil, nil
+	}
+	sbuf := make([]byte, 0, len(buf))
+	soffs := make([]C.uint64_t, 1, len(sel)+1)
+	for _, i := range sel {
+		sbuf = append(sbuf, buf[offs[i]:offs[i+1]]...)
+		soffs = append(soffs, C.uint64_t(len(sbuf)))
+	}
+	if len(sbuf) == 0 {
+		sbuf = append(sbuf, 0)[:1]
+	}
+	var pin runtime.Pinner
+	pin.Pin(&sbuf[0])
+	pin.Pin(&soffs[0])
+	defer pin.Unpin()
+	sptr := (*C.uint8_t)(unsafe.Pointer(&sbuf[0]))
+
+	var batch *C.cbi_batch
+	if C.cbi_flatten_pb(g.ingest, sptr, &soffs[0], C.uint32_t(len(sel)), dv, ds, 1, &batch) != 0 {
+		return nil, errors.New(C.GoString(C.cbi_last_error()))
+	}
+	defer C.cbi_batch_free(batch)
+	view := C.cbi_batch_view(batch)
+	nt, nr := C.size_t(view.n_tuples), C.size_t(view.n_requests)
+	res := C.cbh_result{
+		effect:   (*C.uint8_t)(C.calloc(nt+1, 1)),
+		status:   (*C.uint8_t)(C.calloc(nt+1, 1)),
+		edr_mask: (*C.uint64_t)(C.calloc(nr+1, 8)),
+	}
+	defer func() {
+		C.free(unsafe.Pointer(res.effect))
+		C.free(unsafe.Pointer(res.status))
+		C.free(unsafe.Pointer(res.edr_mask))
+	}()
+	tr := C.cbh_trace{capacity: C.uint32_t(4*nt + 256)}
+	for {
+		tr.records = (*C.uint32_t)(C.calloc(C.size_t(tr.capacity), 4*C.CBH_TRACE_RECORD_WORDS))
+		rc := C.cbh_trace_batch(g.table, view, params, &res, &tr)
+		if rc != 0 {
+			C.free(unsafe.Pointer(tr.records))
+			return nil, errors.New(C.GoString(C.cbh_last_error()))
+		}
+		if tr.count <= tr.capacity {
+			break
+		}
+		C.free(unsafe.Pointer(tr.records)) // the log overflowed: count says how much room it needs
+		tr.capacity = tr.count + 64
+	}
+	defer C.free(unsafe.Pointer(tr.records))
+
+	var decoded *C.cbi_outputs
+	if C.cbi_trace_pb(g.ingest, batch, &res, tr.records, tr.count, sptr, &soffs[0], C.uint32_t(len(sel)), &decoded) != 0 {
+		return nil, errors.New(C.GoString(C.cbi_last_error()))
+	}
+	defer C.cbi_outputs_free(decoded)
+	doffs := unsafe.Slice((*uint64)(unsafe.Pointer(C.cbi_outputs_offsets(decoded))), len(sel)+1)
+	dflags := unsafe.Slice((*byte)(unsafe.Pointer(C.cbi_outputs_flags(decoded))), len(sel))
+	dbytes := unsafe.Slice((*byte)(unsafe.Pointer(C.cbi_outputs_bytes(decoded))), int(doffs[len(sel)]))
+	out := make(map[int]traced, len(sel))
+	for j, i := range sel {
+		out[i] = traced{
+			bytes:      append([]byte(nil), dbytes[doffs[j]:doffs[j+1]]...),
+			incomplete: dflags[j]&(C.CBI_TRACE_ERRORS_INCOMPLETE|C.CBI_TRACE_OUTPUTS_INCOMPLETE) != 0,
+		}
+	}
+	return out, nil
 }
 
 // checkResourcesGPU serves one CheckResourcesRequest without building CheckInputs (svc/cerbos_svc.go:255-344 would
