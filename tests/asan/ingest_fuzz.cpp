@@ -70,6 +70,22 @@ int main(int argc, char** argv) {
       cbh_result res{eff.data(), pol.data(), sc.data(), st.data(), edr.data()};
       cbi_outputs* o = nullptr;
       if (cbi_assemble_pb(t, b, &res, exact, offs.data(), cnt, "default", &o) == 0) cbi_outputs_free(o);
+      // the trace log's consumer on records made up at random (kinds, string ids, value tags, heap references, rule words):
+      // every record is either decoded, reported incomplete or refused - never a read outside the batch / the table
+      if (cbi_table_trace_scope(t) != 0) {
+        const uint32_t nrec = rnd() % 24;
+        std::vector<uint32_t> rec((size_t)nrec * CBH_TRACE_RECORD_WORDS + 1);
+        for (uint32_t r = 0; r < nrec; ++r) {
+          uint32_t* w = &rec[(size_t)r * CBH_TRACE_RECORD_WORDS];
+          w[0] = rnd() % 8 ? rnd() % (v->n_requests + 1) : rnd();
+          w[1] = (1 + rnd() % 4) | ((rnd() & 0xFFFFFFu) << 4);
+          w[2] = rnd() % 4 ? rnd() % 64 : rnd();
+          w[3] = rnd() % 3 ? (rnd() % 12) | ((rnd() % 40) << 8) : rnd();
+          w[4] = rnd() % 2 ? rnd() % 64 : rnd(); w[5] = rnd() % 2 ? 0 : rnd(); w[6] = rnd(); w[7] = rnd() % 2 ? 0 : rnd();
+        }
+        cbi_outputs* to = nullptr;
+        if (cbi_trace_pb(t, b, &res, rec.data(), nrec, exact, offs.data(), cnt, &to) == 0) cbi_outputs_free(to);
+      }
       cbi_batch_free(b);
       ++ok;
     } else ++refused;

@@ -30,11 +30,16 @@ def fuzz_binary(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("name", ["C2", "C5"])
+@pytest.mark.parametrize("name", ["C2", "C5", "store"])
 def test_mutated_wire_input_never_reads_out_of_bounds(fuzz_binary, tmp_path, name):
-    pol, reqs = {"C2": (workloads.c2_policies, workloads.c2_requests), "C5": (workloads.c5_policies, workloads.c5_requests)}[name]
-    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol())))
-    inputs = reqs(n_requests=64).to_inputs()
+    if name == "store":   # the golden store: variables, output expressions with templates, role policies (the trace consumer's paths)
+        from helpers import load_json, store_rule_table
+        lt = lower_rule_table(store_rule_table(), {"environment": "test"})
+        inputs = [i for c in load_json("engine_cases.json") for i in c["inputs"]][:64]
+    else:
+        pol, reqs = {"C2": (workloads.c2_policies, workloads.c2_requests), "C5": (workloads.c5_policies, workloads.c5_requests)}[name]
+        lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol())))
+        inputs = reqs(n_requests=64).to_inputs()
     data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
     (tmp_path / "table.blob").write_bytes(lt.blob)
     data.tofile(str(tmp_path / "messages.bin"))
