@@ -105,6 +105,8 @@ enum CbhMeta {
 #define CBH_MF_HAS_ANY_PATTERN 16u      /* some pattern reference is CBH_PAT_ANY (treated as a glob table) */
 #define CBH_MF_HAS_PRINCIPAL_POLICIES 32u
 #define CBH_MF_NEEDS_STRING_BYTES 128u   /* glob automata, or a program that looks inside a string: upload str_off / str_bytes / str_flags */
+#define CBH_MF_NEEDS_ARENA 1024u          /* some program builds a list (filter, map, intersect, except, list +): the kernels that run the
+                                          * operand-stack interpreter get CBH_ARENA_ENTRIES values of LDS per lane for them (cbh_vm.h) */
 #define CBH_MF_FLAT_CLOSED 512u           /* FLAT and every condition is evaluated inline by the flat kernel: no evaluator call needed for plain batches */
 #define CBH_MF_FLAT 256u                  /* resource policies only, leaf conditions, every record decided by class masks: cbh_check_flat.h */
 #define CBH_MF_READS_REQUEST_STRINGS 64u /* some program reads a raw request string (CBH_RQ_S_*): upload those fields */
@@ -274,6 +276,8 @@ enum CbhOp {
                       // "undefined field '<name>'".  Mode 1, variables of a derived-role definition (check.go:612-633): the
                       // error is recorded and the variable is null (unset in strict mode)
   OP_OUT = 63,        // trace programs: TOS is the value of an output expression (check.go:776-807): logged, not returned
+  OP_LISTOP = 64,     // arg 0 intersect / 1 except / 2 concatenation: pop b, a (lists) -> a new list in the lane's arena
   OP_NOPS
 };
-enum CbhIterKind { IT_ALL = 0, IT_EXISTS = 1, IT_EXISTS_ONE = 2 };
+enum CbhIterKind { IT_ALL = 0, IT_EXISTS = 1, IT_EXISTS_ONE = 2, IT_FILTER = 3, IT_MAP = 4 };   // filter / map build a list in the lane's arena
+#define CBH_ARENA_ENTRIES 48u   /* values per lane a program may build lists from; more marks the tuple CBH_ST_UNSUPPORTED */

@@ -1090,7 +1090,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
 #ifndef CBH_HOSTSIM
 extern __shared__ __attribute__((aligned(16))) unsigned char cbh_dyn_lds[];
 #else
-static unsigned char cbh_dyn_lds[CBH_CACHE_COLS * CBH_BLOCK * 12 + 16 * CBH_BLOCK * 4 + 2 * 4096 + 16];   // + the flat kernel's chain scratch and class tables
+static unsigned char cbh_dyn_lds[CBH_CACHE_COLS * CBH_BLOCK * 12 + CBH_ARENA_ENTRIES * CBH_BLOCK * 9 + 16 * CBH_BLOCK * 4 + 2 * 4096 + 16];   // + the flat kernel's chain scratch and class tables
 #endif
 __device__ __forceinline__ u32 cached_columns(const KernelArgs* ka) {
   const u32 n = ka->b.n_columns;

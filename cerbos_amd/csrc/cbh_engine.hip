@@ -503,9 +503,10 @@ static u32 pick_flags(u32 eval_flags) { static const bool no_flat = getenv("CBH_
 // CBH_LDS_PAD=<bytes> (measurement aid): extra dynamic LDS per workgroup of the resident launches, to hold the occupancy down
 static size_t lds_pad() { static const size_t pad = [] { const char* e = getenv("CBH_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }(); return pad; }
 static u32 nfa_maxw(const TableDev& d) { return std::max(std::max(d.nfa_words[0], d.nfa_words[1]), d.nfa_words[2]); }
-static size_t check_lds_bytes(const BatchDev& d) {   // column cache: value low / high / tag dword per lane
+static size_t check_lds_bytes(const BatchDev& d, u32 table_flags) {   // column cache: value low / high / tag dword per lane
   const u32 ncc = d.n_columns < CBH_CACHE_COLS ? d.n_columns : CBH_CACHE_COLS;
-  return (size_t)ncc * CBH_BLOCK * 12;
+  // ... and, for a table whose programs build lists, the lanes' arenas behind it (cbh_vm.h arena_vals)
+  return (size_t)ncc * CBH_BLOCK * 12 + ((table_flags & CBH_MF_NEEDS_ARENA) ? (size_t)CBH_ARENA_ENTRIES * CBH_BLOCK * 9 : 0);
 }
 
 extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_params* p) {
@@ -553,7 +554,7 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
     u32 threads = CBH_BLOCK; bool flat = false;
     const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, maxw != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), b->max_actions, b->max_roles, b->plain_tags, pick_flags(p->flags), &threads, &flat);
     const u32 grid = (d.n_requests + threads - 1) / threads;   // one lane per request
-    const size_t lds = (check_lds_bytes(d) + (flat ? cbh_flat_chain_bytes(rep->dev.max_depth, rep->dev.n_scopes) : 0)) * (threads / CBH_BLOCK) + (flat ? cbh_flat_class_bytes(rep->dev.K) : 0) + lds_pad();
+    const size_t lds = (check_lds_bytes(d, rep->dev.flags) + (flat ? cbh_flat_chain_bytes(rep->dev.max_depth, rep->dev.n_scopes) : 0)) * (threads / CBH_BLOCK) + (flat ? cbh_flat_class_bytes(rep->dev.K) : 0) + lds_pad();
     if (timed) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, sl.ev[2], sl.ev[3], 0, b->last_args, (const KernelArgs*)b->d_args);
     else hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, b->last_args, (const KernelArgs*)b->d_args);
     sl.pending = timed;
@@ -772,7 +773,7 @@ static void launch_check(const Replica* rep, KernelArgs ka, const KernelArgs* d_
   u32 threads = CBH_BLOCK; bool flat = false;
   const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, nfa_maxw(rep->dev) != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), sh.max_actions, sh.max_roles, sh.plain_tags(), pick_flags(ka.flags), &threads, &flat);
   const u32 grid = (hi - lo + threads - 1) / threads;   // one lane per request
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), (check_lds_bytes(ka.b) + (flat ? cbh_flat_chain_bytes(rep->dev.max_depth, rep->dev.n_scopes) : 0)) * (threads / CBH_BLOCK) + (flat ? cbh_flat_class_bytes(rep->dev.K) : 0), s, ka, d_args);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), (check_lds_bytes(ka.b, rep->dev.flags) + (flat ? cbh_flat_chain_bytes(rep->dev.max_depth, rep->dev.n_scopes) : 0)) * (threads / CBH_BLOCK) + (flat ? cbh_flat_class_bytes(rep->dev.K) : 0), s, ka, d_args);
 }
 
 // a small batch on one device: everything packed into the pinned staging block.  Two ways across PCIe:
@@ -1037,7 +1038,7 @@ extern "C" int cbh_trace_batch(cbh_table* t, const cbh_batch* in, const cbh_para
   launch_resolve(rep, ka, L, s, rc);
   if (rc != 0) return fail("hipMemsetAsync failed");
   const u32 grid = (in->n_requests + CBH_BLOCK - 1) / CBH_BLOCK;
-  hipLaunchKernelGGL(cbh_trace_kernel, dim3(grid), dim3(CBH_BLOCK), check_lds_bytes(ka.b), s, ka, (const KernelArgs*)(base + L.args.off));
+  hipLaunchKernelGGL(cbh_trace_kernel, dim3(grid), dim3(CBH_BLOCK), check_lds_bytes(ka.b, rep->dev.flags), s, ka, (const KernelArgs*)(base + L.args.off));
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(c->h + L.out_begin, c->d + L.out_begin, log_off + 256 - L.out_begin, hipMemcpyDeviceToHost, s));
   HIPCHK(stream_wait(s));

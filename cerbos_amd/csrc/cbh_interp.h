@@ -108,6 +108,7 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
   u32 tree_saved = 0;     // bit d = `live` saved at tree depth d
   u32 tree_acc = 0;       // bit d = accumulator at tree depth d
   int tree_depth = 0;
+  u32 ap = 0;             // this lane's arena: entries [0, ap) hold the lists the program has built so far (cbh_vm.h)
   pc = uniform(pc);
   const CBH_G u32* code = uniform_ptr(c.t.code);
   for (u32 steps = 0; steps < 1000000u; ++steps) {
@@ -345,23 +346,37 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
         Val x = TOPV(0); --sp;
         const u32 kind = uload(&code[pc]); ++pc;
         u32 st = kind | (live ? ITS_ENTRY_LIVE : 0);
+        u32 start = 0;   // filter / map: where the result list begins in the lane's arena
         if (x.t != CBH_T_LIST && x.t != CBH_T_MAP) {
           st |= ITS_FAIL;
           if (TRACE) { const u64 e = x.t == CBH_T_ERR ? x.v : (u64)CBH_ERR_NO_SUCH_OVERLOAD; IT_ERR_LO(a) = (u32)e; IT_ERR_HI(a) = (u32)(e >> 32); }
           x.v = 0;
         }
-        else { if (live) st |= ITS_RUNNING; if (x.t == CBH_T_MAP) st |= ITS_MAP; }   // lanes that are not live sit the loop out
+        else {
+          if (live) st |= ITS_RUNNING;
+          if (x.t == CBH_T_MAP) st |= ITS_MAP;   // lanes that are not live sit the loop out
+          if (kind == IT_FILTER || kind == IT_MAP) {
+            // the result has at most as many elements as the range: reserved up front, so that whatever the loop body builds
+            // lands behind it and the result stays contiguous
+            const u32 n = cont_len(x.v);
+            if (n > CBH_ARENA_ENTRIES - ap) { if (live) L.status |= CBH_ST_UNSUPPORTED; st |= ITS_FAIL; st &= ~ITS_RUNNING; if (TRACE) { IT_ERR_LO(a) = 0; IT_ERR_HI(a) = 0; } }
+            else { start = ap; ap += n; }
+          }
+        }
         c.it_cont[a * CBH_BLOCK + c.tid] = x.v;
-        c.it_idx[a * CBH_BLOCK + c.tid] = 0;
+        // index word: [31:26] the result's place in the arena, [25:20] the arena's fill when the loop starts, [19:0] the index
+        c.it_idx[a * CBH_BLOCK + c.tid] = (start << 26) | (ap << 20);
         c.it_state[a * CBH_BLOCK + c.tid] = st;
         break;
       }
       case OP_ITER_NEXT: {    // a = slot; next words: end_pc, locals (v1 | v2 << 8 | nvars << 16)
         const u32 end_pc = uload(&code[pc]), lw = uload(&code[pc + 1]); pc += 2;
         const u64 cont = c.it_cont[a * CBH_BLOCK + c.tid];
-        const u32 i = c.it_idx[a * CBH_BLOCK + c.tid];
+        const u32 iw = c.it_idx[a * CBH_BLOCK + c.tid], i = iw & 0xFFFFFu;
         u32 st = c.it_state[a * CBH_BLOCK + c.tid];
-        bool more = (st & ITS_RUNNING) && i < cont_len(cont);
+        bool more = (st & ITS_RUNNING) && i < cont_len(cont) && i < 0xFFFFFu;
+        // what the previous turn of the body built is dead now - unless the body's value IS what it built (map)
+        if ((st & ITS_RUNNING) && (st & 0xFF) != IT_MAP) ap = (iw >> 20) & 63u;
         if (!more) st &= ~ITS_RUNNING;
         c.it_state[a * CBH_BLOCK + c.tid] = st;
         live = more && (st & ITS_ENTRY_LIVE) && result != 2;
@@ -379,14 +394,28 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
             Val e = is_map ? k : v;
             c.l_tag[l1 * CBH_BLOCK + c.tid] = (u8)e.t; c.l_val[l1 * CBH_BLOCK + c.tid] = e.v;
           }
-          c.it_idx[a * CBH_BLOCK + c.tid] = i + 1;
+          c.it_idx[a * CBH_BLOCK + c.tid] = (iw & 0xFFF00000u) | (i + 1);
         }
         break;
       }
-      case OP_ITER_ACC: {     // a = slot; next word = loop_pc
-        const u32 loop_pc = uload(&code[pc]); ++pc;
+      case OP_ITER_ACC: {     // a = slot; next word = loop_pc | local of the loop variable << 30 (filter keeps its value)
+        const u32 lw2 = uload(&code[pc]); ++pc;
+        const u32 loop_pc = lw2 & 0x3FFFFFFFu;
         Val x = TOPV(0); --sp;
         u32 st = c.it_state[a * CBH_BLOCK + c.tid];
+        if ((st & ITS_RUNNING) && ((st & 0xFF) == IT_FILTER || (st & 0xFF) == IT_MAP)) {
+          // filter: a predicate that is not a bool fails the macro (`pred ? acc + [x] : acc`); map: so does a failing element
+          const bool is_map = (st & 0xFF) == IT_MAP;
+          if (x.t == CBH_T_ERR || (!is_map && x.t != CBH_T_BOOL)) {
+            if (TRACE) { const u64 e = x.t == CBH_T_ERR ? x.v : (u64)CBH_ERR_NO_SUCH_OVERLOAD; IT_ERR_LO(a) = (u32)e; IT_ERR_HI(a) = (u32)(e >> 32); }
+            st |= ITS_FAIL; st &= ~ITS_RUNNING;
+          } else if (is_map || x.v) {
+            const u32 l1 = lw2 >> 30, at = (c.it_idx[a * CBH_BLOCK + c.tid] >> 26) + ((st >> 16) & 0x3FFFu);
+            arena_put(c, at, is_map ? x : mk(c.l_tag[l1 * CBH_BLOCK + c.tid], c.l_val[l1 * CBH_BLOCK + c.tid]));
+            st += 0x10000u;
+          }
+          c.it_state[a * CBH_BLOCK + c.tid] = st;
+        } else
         if (st & ITS_RUNNING) {
           const u32 kind = st & 0xFF;
           if (x.t != CBH_T_BOOL) {
@@ -409,6 +438,10 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
         if (result != 2) live = (st & ITS_ENTRY_LIVE) != 0;
         const Val ierr = mk(CBH_T_ERR, TRACE ? ((u64)IT_ERR_LO(a) | ((u64)IT_ERR_HI(a) << 32)) : 0ull);
         if (st & ITS_FAIL) { PUSHV(ierr); break; }
+        if (kind == IT_FILTER || kind == IT_MAP) {
+          PUSHV(mk(CBH_T_LIST, ((u64)CBH_HEAP_LOCAL << 62) | ((u64)(c.it_idx[a * CBH_BLOCK + c.tid] >> 26) << 32) | ((st >> 16) & 0x3FFFu)));
+          break;
+        }
         if (kind == IT_ALL) { if (st & ITS_DECIDED) PUSHV(mk_bool(false)); else if (st & ITS_ERRSEEN) PUSHV(ierr); else PUSHV(mk_bool(true)); }
         else if (kind == IT_EXISTS) { if (st & ITS_DECIDED) PUSHV(mk_bool(true)); else if (st & ITS_ERRSEEN) PUSHV(ierr); else PUSHV(mk_bool(false)); }
         else PUSHV(mk_bool(((st >> 16) & 0x3FFFu) == 1));
@@ -461,6 +494,32 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
           any |= in; all &= in;
         }
         SETTOP(mk_bool((op == OP_HASINTERSECTION) ? any : all));
+        break;
+      }
+      case OP_LISTOP: {     // a = 0 intersect / 1 except / 2 concatenation: a new list in the lane's arena
+        Val y = TOPV(0), x = TOPV(1); --sp;
+        if (x.t != CBH_T_LIST || y.t != CBH_T_LIST) { FAILTOP2(x, y, CBH_ERR_NO_SUCH_OVERLOAD); break; }
+        const u32 nx = cont_len(x.v), ny = cont_len(y.v), need = a == 2 ? nx + ny : nx;
+        if (need > CBH_ARENA_ENTRIES - ap || nx > CBH_ARENA_ENTRIES || ny > CBH_ARENA_ENTRIES) {
+          if (live) L.status |= CBH_ST_UNSUPPORTED;
+          SETTOP(mk_err());
+          break;
+        }
+        const u32 start = ap;
+        u32 n = 0;
+        for (u32 i = 0; i < nx; ++i) {
+          const Val e = heap_get(c, cont_sel(x.v), cont_off(x.v) + i);
+          bool keep = true;
+          if (a != 2) {
+            bool in = false;
+            for (u32 j = 0; j < ny && !in; ++j) in = val_equal(c, L, e, heap_get(c, cont_sel(y.v), cont_off(y.v) + j));
+            keep = in == (a == 0);
+          }
+          if (keep) arena_put(c, start + n++, e);
+        }
+        if (a == 2) for (u32 j = 0; j < ny; ++j) arena_put(c, start + n++, heap_get(c, cont_sel(y.v), cont_off(y.v) + j));
+        ap += need;
+        SETTOP(mk(CBH_T_LIST, ((u64)CBH_HEAP_LOCAL << 62) | ((u64)start << 32) | n));
         break;
       }
       case OP_VARSCOPE: {   // a = trace string id of the variable's name | mode << 23: TOS is the variable's inlined definition

@@ -279,9 +279,18 @@ __device__ __forceinline__ u32 cont_sel(u64 v) { return (u32)(v >> 62); }
 __device__ __forceinline__ u32 cont_off(u64 v) { return (u32)((v >> 32) & 0x3FFFFFFFu); }
 __device__ __forceinline__ u32 cont_len(u64 v) { return (u32)v; }
 
+// The arena of a lane: CBH_ARENA_ENTRIES values [slot][lane] in dynamic LDS behind the column cache (the launch sizes it when the
+// table has CBH_MF_NEEDS_ARENA).  Lists a program builds live there for the program's duration (cbh_interp.h bumps a pointer).
+__device__ __forceinline__ CBH_L u64* arena_vals(const Ctx& c) { return (CBH_L u64*)(c.cc + 3u * c.n_cached * CBH_BLOCK); }
+__device__ __forceinline__ CBH_L u8* arena_tags(const Ctx& c) { return (CBH_L u8*)(arena_vals(c) + CBH_ARENA_ENTRIES * CBH_BLOCK); }
+__device__ __forceinline__ void arena_put(const Ctx& c, u32 idx, Val v) {
+  arena_vals(c)[idx * CBH_BLOCK + c.tid] = v.v; arena_tags(c)[idx * CBH_BLOCK + c.tid] = (u8)v.t;
+}
+
 __device__ __forceinline__ Val heap_get(const Ctx& c, u32 sel, u32 idx) {
   if (sel == CBH_HEAP_TABLE) return mk(c.t.theap_tag[idx], c.t.theap_val[idx]);
   if (sel == CBH_HEAP_BATCH) return mk(c.b.heap_tag[idx], c.b.heap_val[idx]);
+  if (sel == CBH_HEAP_LOCAL) return idx < CBH_ARENA_ENTRIES ? mk(arena_tags(c)[idx * CBH_BLOCK + c.tid], arena_vals(c)[idx * CBH_BLOCK + c.tid]) : mk_err();
   return mk(CBH_T_STRING, c.b.roles[idx]);
 }
 

@@ -628,6 +628,7 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
         for i, f in enumerate(row_cols[ROW_FLAGS])) and all(
         inline_ok(drx_cols[3][i], drx_cols[15][i], drx_cols[2][i] & 1, drx_cols[2][i] & 2) for i in range(len(drx_cols[0])))
     meta[M_FLAGS] |= MF_FLAT_CLOSED if closed else 0
+    meta[M_FLAGS] |= 1024 if pb.needs_arena else 0   # CBH_MF_NEEDS_ARENA: the interpreter kernels get the lanes' list arenas
     meta[M_MAX_STACK] = pb.max_stack
     meta[M_NDRNAMES] = len(lt.dr_names)
     meta[M_NFA_WORDS_ACTION] = lt.nfas[0].words

@@ -26,7 +26,7 @@ from . import regex
  OP_EDRHAS, OP_LOCAL, OP_ITER_BEGIN, OP_ITER_NEXT, OP_ITER_ACC, OP_ITER_END, OP_TOINT,
  OP_TODOUBLE, OP_TOSTRING_UNSUPPORTED, OP_INIPRANGE, OP_UNSUPPORTED, OP_TS_GETTER,
  OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN, OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC,
- OP_TREE_END, OP_HIER, OP_MATCHES, OP_INDEXOF, OP_STREQ_CASE, OP_VARSCOPE, OP_OUT) = range(64)
+ OP_TREE_END, OP_HIER, OP_MATCHES, OP_INDEXOF, OP_STREQ_CASE, OP_VARSCOPE, OP_OUT, OP_LISTOP) = range(65)
 
 TREE_KINDS = {"all": 0, "any": 1, "none": 2}
 COND_LEAF = 0x80000000
@@ -58,7 +58,7 @@ HEAP_TABLE, HEAP_BATCH, HEAP_ROLES = 0, 1, 2
 RQ_PRINCIPAL_ID, RQ_S_RESOURCE_ID, RQ_S_KIND = 0, 10, 11
 RQ_S_P_SCOPE, RQ_S_R_SCOPE, RQ_S_P_VERSION, RQ_S_R_VERSION = 12, 13, 14, 15
 
-IT_ALL, IT_EXISTS, IT_EXISTS_ONE = 0, 1, 2
+IT_ALL, IT_EXISTS, IT_EXISTS_ONE, IT_FILTER, IT_MAP = 0, 1, 2, 3, 4
 
 MAX_STACK = 10
 TREE_STRIP_MAX = 8   # leaves of a condition tree the flat kernel evaluates inline (cbh_blob.h CBH_TREE_STRIP_MAX)
@@ -81,7 +81,7 @@ _R_FIELDS = {"id": RQ_S_RESOURCE_ID, "kind": RQ_S_KIND, "scope": RQ_S_R_SCOPE,
 _ID_ONLY_OPS = frozenset([OP_RET, OP_CONST, OP_COL, OP_HASCOL, OP_REQSTR, OP_ROLES, OP_SELECT, OP_HASSEL, OP_INDEX, OP_EQ, OP_NE,
                           OP_IN, OP_NOT, OP_JF, OP_JT, OP_AND, OP_OR, OP_JTERN, OP_JMP, OP_POP, OP_LEAF, OP_EDRHAS, OP_LOCAL,
                           OP_ITER_BEGIN, OP_ITER_NEXT, OP_ITER_ACC, OP_ITER_END, OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN,
-                          OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC, OP_TREE_END, OP_UNSUPPORTED, OP_TS_GETTER, OP_VARSCOPE, OP_OUT])
+                          OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC, OP_TREE_END, OP_UNSUPPORTED, OP_TS_GETTER, OP_VARSCOPE, OP_OUT, OP_LISTOP])
 
 
 class LoweringError(ValueError):
@@ -218,6 +218,7 @@ class ProgramBuilder:
         self.reads_string_bytes = False   # some program may look INSIDE a string (ordering, prefix, size, parsing ...)
         self.req_fields = set()   # cbh_req_field indices some program reads (the host uploads the raw-string fields only then)
         self.has_generic = False           # some program needs the operand-stack interpreter
+        self.needs_arena = False           # some program builds a list (filter / map / intersect / except / list +): cbh_blob.h CBH_MF_NEEDS_ARENA
         self.max_stack = 0
         self.max_locals = 0
         # the trace pass (cbh_trace_batch): strings its records refer to - expression texts, variable names, rule FQNs
@@ -581,6 +582,20 @@ def _int_lit_as_double(ast):
     return ast
 
 
+def _builds_list(ast):
+    """Is the expression visibly a list: a literal, filter / map, intersect / except, or a concatenation of such."""
+    k = ast[0]
+    if k == "list":
+        return True
+    if k == "comp":
+        return ast[1] in ("filter", "map")
+    if k == "call":
+        return ast[1] in ("intersect", "except")
+    if k == "bin" and ast[1] == "+":
+        return _builds_list(ast[2]) or _builds_list(ast[3])
+    return False
+
+
 def _is_const(ast):
     k = ast[0]
     if k == "lit":
@@ -654,6 +669,8 @@ class _FuncCompiler:
                     continue
                 if x[0] == "ref":
                     code.append(x[1] | (addr[x[2]] << 8))
+                elif x[0] == "wrefhi":
+                    code.append(addr[x[1]] | (x[2] << 30))
                 elif x[2] is None:
                     code.append(addr[x[1]])
                 else:
@@ -884,6 +901,13 @@ class _FuncCompiler:
                     self._expr(sides[0])
                     self._expr(sides[1])
                     return self.emit(OP_STREQ_CASE, modes[0] | (modes[1] << 2) | ((1 if op == "!=" else 0) << 4), -1)
+            if op == "+" and (_builds_list(ast[2]) or _builds_list(ast[3])):
+                # list concatenation where one side is visibly a list: built in the lane's arena (any other `+` stays arithmetic,
+                # which flags lists it meets at run time)
+                self.pb.needs_arena = True
+                self._expr(ast[2])
+                self._expr(ast[3])
+                return self.emit(OP_LISTOP, 2, -1)
             self._expr(ast[2])
             self._expr(ast[3])
             return self.emit(_BINOPS[op], 0, -1)
@@ -985,6 +1009,11 @@ class _FuncCompiler:
                 return binary(OP_INIPRANGE)
             if name in ("hasIntersection", "has_intersection") and n == 2:
                 return binary(OP_HASINTERSECTION)
+            if name in ("intersect", "except") and n == 2:   # cerbos_lib.go: elements of the first list (not) in the second, in order
+                self.pb.needs_arena = True
+                self._expr(allargs[0])
+                self._expr(allargs[1])
+                return self.emit(OP_LISTOP, 0 if name == "intersect" else 1, -1)
             if name in ("isSubset", "is_subset") and n == 2:
                 return binary(OP_ISSUBSET)
         elif target[1] == "sets" and n == 3:
@@ -1005,9 +1034,12 @@ class _FuncCompiler:
 
     def _comp(self, ast):
         _, kind, target, vars_, args = ast
-        kinds = {"all": IT_ALL, "exists": IT_EXISTS, "exists_one": IT_EXISTS_ONE, "existsOne": IT_EXISTS_ONE}
-        if kind not in kinds:
-            return self.unsupported("macro %s" % kind)
+        kinds = {"all": IT_ALL, "exists": IT_EXISTS, "exists_one": IT_EXISTS_ONE, "existsOne": IT_EXISTS_ONE,
+                 "filter": IT_FILTER, "map": IT_MAP}
+        if kind not in kinds or (kind in ("filter", "map") and (len(args) != 1 or len(vars_) != 1)):
+            return self.unsupported("macro %s" % kind)   # (map with a filter argument, two-variable forms: not on the device)
+        if kind in ("filter", "map"):
+            self.pb.needs_arena = True   # the result list is built in the lane's arena (cbh_vm.h)
         if self.iter_depth >= MAX_ITERS or len(self.locals) + len(vars_) > MAX_LOCALS:
             return self.unsupported("comprehension nesting beyond the device limits")
         slot = self.iter_depth
@@ -1031,7 +1063,7 @@ class _FuncCompiler:
         self._expr(args[0])
         assert self.depth == d0 + 1
         self.emit(OP_ITER_ACC, slot, -1)
-        self.word_ref(loop)
+        self.out.append(("wrefhi", loop, slots[0]))   # loop address | the loop variable's local << 30 (filter keeps its value)
         self.place(end)
         self.emit(OP_ITER_END, slot, +1)
         self.iter_depth -= 1

@@ -94,6 +94,7 @@ enum cbh_tag {
 #define CBH_HEAP_TABLE 0u /* sel values */
 #define CBH_HEAP_BATCH 1u
 #define CBH_HEAP_ROLES 2u /* off/len index `roles`; elements are strings */
+#define CBH_HEAP_LOCAL 3u /* device only: a list a program built (filter / map / intersect / except / +); never in a batch */
 
 /* String usage flags (batch-local strings): which glob dimensions must be resolved. */
 #define CBH_SF_ACTION 1u

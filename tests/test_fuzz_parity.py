@@ -83,6 +83,17 @@ CONDITIONS_WIDE = CONDITIONS + [
     'R.attr.owner.startsWith("p") && R.attr.owner.size() == 2',
     'R.scope == "acme" || P.scope == "acme.hr"',
     'R.policyVersion == "v2"',
+    # lists built in the lane's arena (cbh_vm.h): filter / map / intersect / except / concatenation
+    'size(P.attr.teams.filter(t, t.startsWith("co"))) > 0',
+    '"ops" in P.attr.teams.filter(t, size(t) < 5)',
+    'P.attr.regions.map(r, r == "eu").exists(b, b)',
+    'P.attr.teams.map(t, size(t)).all(n, n > 3)',
+    'intersect(P.attr.regions, ["eu", "apac"]) == ["eu"]',
+    'P.attr.regions.except(["us"]).size() >= 1',
+    'size(P.attr.regions + ["zz"]) > 2 || "zz" in (P.attr.teams + ["zz"])',
+    'P.attr.teams.exists(t, P.attr.regions.filter(r, size(r) == size(t)).size() > 0)',
+    'intersect(request.auxData.jwt.groups, P.attr.teams.map(t, t)).size() == 0',
+    'P.attr.regions.filter(r, r != R.attr.tags.region) == P.attr.regions',
 ]
 
 

@@ -78,4 +78,5 @@ def test_true_leaves_on_device_path(make_evaluator=None):
             checked += 1
     # the rest (string-building / list-building / network extension functions, named time zones, hierarchy indexing)
     # is outside the device subset and flagged - DESIGN.md §8
-    assert checked >= 75 and flagged <= 62, (checked, flagged)
+    print("leaves decided on the device path:", checked, "flagged:", flagged)
+    assert checked >= 80 and flagged <= 56, (checked, flagged)
