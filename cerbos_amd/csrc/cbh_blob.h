@@ -277,7 +277,10 @@ enum CbhOp {
                       // error is recorded and the variable is null (unset in strict mode)
   OP_OUT = 63,        // trace programs: TOS is the value of an output expression (check.go:776-807): logged, not returned
   OP_LISTOP = 64,     // arg 0 intersect / 1 except / 2 concatenation: pop b, a (lists) -> a new list in the lane's arena
+  OP_LISTFN = 65,     // arg 0 reverse: TOS list -> reversed copy in the arena; 1 slice: pop end, start; TOS list -> the view
+                      // [start, end) of it; 2 lists.range: TOS int n -> [0 .. n) in the arena
   OP_NOPS
 };
-enum CbhIterKind { IT_ALL = 0, IT_EXISTS = 1, IT_EXISTS_ONE = 2, IT_FILTER = 3, IT_MAP = 4 };   // filter / map build a list in the lane's arena
+enum CbhIterKind { IT_ALL = 0, IT_EXISTS = 1, IT_EXISTS_ONE = 2, IT_FILTER = 3, IT_MAP = 4,   // filter / map build a list in the lane's arena
+                   IT_MAP_FILTER = 5 };   // map(x, pred, expr) / transformList(i, v, pred, expr): the body leaves pred and expr
 #define CBH_ARENA_ENTRIES 48u   /* values per lane a program may build lists from; more marks the tuple CBH_ST_UNSUPPORTED */

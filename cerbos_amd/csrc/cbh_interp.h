@@ -355,7 +355,7 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
         else {
           if (live) st |= ITS_RUNNING;
           if (x.t == CBH_T_MAP) st |= ITS_MAP;   // lanes that are not live sit the loop out
-          if (kind == IT_FILTER || kind == IT_MAP) {
+          if (kind == IT_FILTER || kind == IT_MAP || kind == IT_MAP_FILTER) {
             // the result has at most as many elements as the range: reserved up front, so that whatever the loop body builds
             // lands behind it and the result stays contiguous
             const u32 n = cont_len(x.v);
@@ -376,7 +376,7 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
         u32 st = c.it_state[a * CBH_BLOCK + c.tid];
         bool more = (st & ITS_RUNNING) && i < cont_len(cont) && i < 0xFFFFFu;
         // what the previous turn of the body built is dead now - unless the body's value IS what it built (map)
-        if ((st & ITS_RUNNING) && (st & 0xFF) != IT_MAP) ap = (iw >> 20) & 63u;
+        if ((st & ITS_RUNNING) && (st & 0xFF) != IT_MAP && (st & 0xFF) != IT_MAP_FILTER) ap = (iw >> 20) & 63u;
         if (!more) st &= ~ITS_RUNNING;
         c.it_state[a * CBH_BLOCK + c.tid] = st;
         live = more && (st & ITS_ENTRY_LIVE) && result != 2;
@@ -403,13 +403,18 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
         const u32 loop_pc = lw2 & 0x3FFFFFFFu;
         Val x = TOPV(0); --sp;
         u32 st = c.it_state[a * CBH_BLOCK + c.tid];
-        if ((st & ITS_RUNNING) && ((st & 0xFF) == IT_FILTER || (st & 0xFF) == IT_MAP)) {
-          // filter: a predicate that is not a bool fails the macro (`pred ? acc + [x] : acc`); map: so does a failing element
-          const bool is_map = (st & 0xFF) == IT_MAP;
-          if (x.t == CBH_T_ERR || (!is_map && x.t != CBH_T_BOOL)) {
-            if (TRACE) { const u64 e = x.t == CBH_T_ERR ? x.v : (u64)CBH_ERR_NO_SUCH_OVERLOAD; IT_ERR_LO(a) = (u32)e; IT_ERR_HI(a) = (u32)(e >> 32); }
+        Val guard = mk_bool(true);   // map with a filter: the body left the predicate under the element
+        if ((st & 0xFF) == IT_MAP_FILTER) { guard = TOPV(0); --sp; }   // (wave-uniform: the kind is the program's)
+        if ((st & ITS_RUNNING) && ((st & 0xFF) == IT_FILTER || (st & 0xFF) == IT_MAP || (st & 0xFF) == IT_MAP_FILTER)) {
+          // filter: a predicate that is not a bool fails the macro (`pred ? acc + [x] : acc`); map: so does a failing element -
+          // of a turn the predicate lets through
+          const bool is_map = (st & 0xFF) != IT_FILTER;
+          const bool bad_guard = guard.t != CBH_T_BOOL, skipped = !bad_guard && !guard.v;
+          if (bad_guard || (!skipped && (x.t == CBH_T_ERR || (!is_map && x.t != CBH_T_BOOL)))) {
+            const Val& bad = bad_guard ? guard : x;
+            if (TRACE) { const u64 e = bad.t == CBH_T_ERR ? bad.v : (u64)CBH_ERR_NO_SUCH_OVERLOAD; IT_ERR_LO(a) = (u32)e; IT_ERR_HI(a) = (u32)(e >> 32); }
             st |= ITS_FAIL; st &= ~ITS_RUNNING;
-          } else if (is_map || x.v) {
+          } else if (!skipped && (is_map || x.v)) {
             const u32 l1 = lw2 >> 30, at = (c.it_idx[a * CBH_BLOCK + c.tid] >> 26) + ((st >> 16) & 0x3FFFu);
             arena_put(c, at, is_map ? x : mk(c.l_tag[l1 * CBH_BLOCK + c.tid], c.l_val[l1 * CBH_BLOCK + c.tid]));
             st += 0x10000u;
@@ -438,7 +443,7 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
         if (result != 2) live = (st & ITS_ENTRY_LIVE) != 0;
         const Val ierr = mk(CBH_T_ERR, TRACE ? ((u64)IT_ERR_LO(a) | ((u64)IT_ERR_HI(a) << 32)) : 0ull);
         if (st & ITS_FAIL) { PUSHV(ierr); break; }
-        if (kind == IT_FILTER || kind == IT_MAP) {
+        if (kind == IT_FILTER || kind == IT_MAP || kind == IT_MAP_FILTER) {
           PUSHV(mk(CBH_T_LIST, ((u64)CBH_HEAP_LOCAL << 62) | ((u64)(c.it_idx[a * CBH_BLOCK + c.tid] >> 26) << 32) | ((st >> 16) & 0x3FFFu)));
           break;
         }
@@ -519,6 +524,26 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
         }
         if (a == 2) for (u32 j = 0; j < ny; ++j) arena_put(c, start + n++, heap_get(c, cont_sel(y.v), cont_off(y.v) + j));
         ap += need;
+        SETTOP(mk(CBH_T_LIST, ((u64)CBH_HEAP_LOCAL << 62) | ((u64)start << 32) | n));
+        break;
+      }
+      case OP_LISTFN: {
+        if (a == 1) {   // slice(start, end): a view of the same elements
+          Val e = TOPV(0), b0 = TOPV(1), x = TOPV(2); sp -= 2;
+          if (x.t != CBH_T_LIST || b0.t != CBH_T_INT || e.t != CBH_T_INT) { if (x.t == CBH_T_ERR) break; FAILTOP2(b0, e, CBH_ERR_NO_SUCH_OVERLOAD); break; }
+          const i64 lo = (i64)b0.v, hi = (i64)e.v;
+          if (lo < 0 || hi < 0 || lo > hi || hi > (i64)cont_len(x.v)) { SETTOP(mk_err()); break; }
+          SETTOP(mk(CBH_T_LIST, ((u64)cont_sel(x.v) << 62) | ((u64)(cont_off(x.v) + (u32)lo) << 32) | (u64)(hi - lo)));
+          break;
+        }
+        Val x = TOPV(0);
+        if (a == 0 ? x.t != CBH_T_LIST : x.t != CBH_T_INT) { FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD); break; }
+        const i64 n64 = a == 0 ? (i64)cont_len(x.v) : ((i64)x.v < 0 ? 0 : (i64)x.v);
+        if (n64 > (i64)(CBH_ARENA_ENTRIES - ap)) { if (live) L.status |= CBH_ST_UNSUPPORTED; SETTOP(mk_err()); break; }
+        const u32 n = (u32)n64, start = ap;
+        for (u32 i = 0; i < n; ++i)
+          arena_put(c, start + i, a == 0 ? heap_get(c, cont_sel(x.v), cont_off(x.v) + (n - 1 - i)) : mk(CBH_T_INT, i));
+        ap += n;
         SETTOP(mk(CBH_T_LIST, ((u64)CBH_HEAP_LOCAL << 62) | ((u64)start << 32) | n));
         break;
       }

@@ -26,7 +26,7 @@ from . import regex
  OP_EDRHAS, OP_LOCAL, OP_ITER_BEGIN, OP_ITER_NEXT, OP_ITER_ACC, OP_ITER_END, OP_TOINT,
  OP_TODOUBLE, OP_TOSTRING_UNSUPPORTED, OP_INIPRANGE, OP_UNSUPPORTED, OP_TS_GETTER,
  OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN, OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC,
- OP_TREE_END, OP_HIER, OP_MATCHES, OP_INDEXOF, OP_STREQ_CASE, OP_VARSCOPE, OP_OUT, OP_LISTOP) = range(65)
+ OP_TREE_END, OP_HIER, OP_MATCHES, OP_INDEXOF, OP_STREQ_CASE, OP_VARSCOPE, OP_OUT, OP_LISTOP, OP_LISTFN) = range(66)
 
 TREE_KINDS = {"all": 0, "any": 1, "none": 2}
 COND_LEAF = 0x80000000
@@ -58,7 +58,7 @@ HEAP_TABLE, HEAP_BATCH, HEAP_ROLES = 0, 1, 2
 RQ_PRINCIPAL_ID, RQ_S_RESOURCE_ID, RQ_S_KIND = 0, 10, 11
 RQ_S_P_SCOPE, RQ_S_R_SCOPE, RQ_S_P_VERSION, RQ_S_R_VERSION = 12, 13, 14, 15
 
-IT_ALL, IT_EXISTS, IT_EXISTS_ONE, IT_FILTER, IT_MAP = 0, 1, 2, 3, 4
+IT_ALL, IT_EXISTS, IT_EXISTS_ONE, IT_FILTER, IT_MAP, IT_MAP_FILTER = 0, 1, 2, 3, 4, 5
 
 MAX_STACK = 10
 TREE_STRIP_MAX = 8   # leaves of a condition tree the flat kernel evaluates inline (cbh_blob.h CBH_TREE_STRIP_MAX)
@@ -81,7 +81,7 @@ _R_FIELDS = {"id": RQ_S_RESOURCE_ID, "kind": RQ_S_KIND, "scope": RQ_S_R_SCOPE,
 _ID_ONLY_OPS = frozenset([OP_RET, OP_CONST, OP_COL, OP_HASCOL, OP_REQSTR, OP_ROLES, OP_SELECT, OP_HASSEL, OP_INDEX, OP_EQ, OP_NE,
                           OP_IN, OP_NOT, OP_JF, OP_JT, OP_AND, OP_OR, OP_JTERN, OP_JMP, OP_POP, OP_LEAF, OP_EDRHAS, OP_LOCAL,
                           OP_ITER_BEGIN, OP_ITER_NEXT, OP_ITER_ACC, OP_ITER_END, OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN,
-                          OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC, OP_TREE_END, OP_UNSUPPORTED, OP_TS_GETTER, OP_VARSCOPE, OP_OUT, OP_LISTOP])
+                          OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC, OP_TREE_END, OP_UNSUPPORTED, OP_TS_GETTER, OP_VARSCOPE, OP_OUT, OP_LISTOP, OP_LISTFN])
 
 
 class LoweringError(ValueError):
@@ -588,9 +588,10 @@ def _builds_list(ast):
     if k == "list":
         return True
     if k == "comp":
-        return ast[1] in ("filter", "map")
+        return ast[1] in ("filter", "map", "transformList")
     if k == "call":
-        return ast[1] in ("intersect", "except")
+        return ast[1] in ("intersect", "except", "slice") or (ast[1] == "reverse" and ast[2] is not None and _builds_list(ast[2])) \
+            or (ast[1] == "range" and ast[2] is not None and ast[2][0] == "ident" and ast[2][1] == "lists")
     if k == "bin" and ast[1] == "+":
         return _builds_list(ast[2]) or _builds_list(ast[3])
     return False
@@ -1009,6 +1010,14 @@ class _FuncCompiler:
                 return binary(OP_INIPRANGE)
             if name in ("hasIntersection", "has_intersection") and n == 2:
                 return binary(OP_HASINTERSECTION)
+            if name == "reverse" and n == 1 and _builds_list(allargs[0]):   # (strings reverse too: only where the operand is visibly a list)
+                self.pb.needs_arena = True
+                self._expr(allargs[0])
+                return self.emit(OP_LISTFN, 0)
+            if name == "slice" and n == 3:
+                for x in allargs:
+                    self._expr(x)
+                return self.emit(OP_LISTFN, 1, -2)
             if name in ("intersect", "except") and n == 2:   # cerbos_lib.go: elements of the first list (not) in the second, in order
                 self.pb.needs_arena = True
                 self._expr(allargs[0])
@@ -1016,6 +1025,10 @@ class _FuncCompiler:
                 return self.emit(OP_LISTOP, 0 if name == "intersect" else 1, -1)
             if name in ("isSubset", "is_subset") and n == 2:
                 return binary(OP_ISSUBSET)
+        elif target[1] == "lists" and name == "range" and n == 2:   # lists.range(n) = [0 .. n)
+            self.pb.needs_arena = True
+            self._expr(args[0])
+            return self.emit(OP_LISTFN, 2)
         elif target[1] == "sets" and n == 3:
             a, b = args
             if name == "intersects":
@@ -1035,18 +1048,23 @@ class _FuncCompiler:
     def _comp(self, ast):
         _, kind, target, vars_, args = ast
         kinds = {"all": IT_ALL, "exists": IT_EXISTS, "exists_one": IT_EXISTS_ONE, "existsOne": IT_EXISTS_ONE,
-                 "filter": IT_FILTER, "map": IT_MAP}
-        if kind not in kinds or (kind in ("filter", "map") and (len(args) != 1 or len(vars_) != 1)):
-            return self.unsupported("macro %s" % kind)   # (map with a filter argument, two-variable forms: not on the device)
-        if kind in ("filter", "map"):
+                 "filter": IT_FILTER, "map": IT_MAP, "transformList": IT_MAP}
+        if kind not in kinds or (kind == "filter" and len(args) != 1) or len(args) not in (1, 2):
+            return self.unsupported("macro %s" % kind)   # (transformMap / transformMapEntry / sortBy build maps or order: not on the device)
+        kind_id = kinds[kind]
+        if kind in ("filter", "map", "transformList"):
             self.pb.needs_arena = True   # the result list is built in the lane's arena (cbh_vm.h)
+            if len(args) == 2:           # map(x, pred, expr) / transformList(i, v, pred, expr)
+                kind_id = IT_MAP_FILTER
+        elif len(args) != 1:
+            return self.unsupported("macro %s" % kind)
         if self.iter_depth >= MAX_ITERS or len(self.locals) + len(vars_) > MAX_LOCALS:
             return self.unsupported("comprehension nesting beyond the device limits")
         slot = self.iter_depth
         self._expr(target)
         loop, end = self.new_label(), self.new_label()
         self.emit(OP_ITER_BEGIN, slot, -1)
-        self.word(kinds[kind])
+        self.word(kind_id)
         saved = dict(self.locals)
         slots = []
         for v in vars_:
@@ -1060,9 +1078,10 @@ class _FuncCompiler:
         self.word_ref(end)
         self.word(slots[0] | ((slots[1] if len(slots) > 1 else 0) << 8) | (len(slots) << 16))
         d0 = self.depth
-        self._expr(args[0])
-        assert self.depth == d0 + 1
-        self.emit(OP_ITER_ACC, slot, -1)
+        for body in args:   # the predicate (all / exists / filter), the element (map), or predicate then element
+            self._expr(body)
+        assert self.depth == d0 + len(args)
+        self.emit(OP_ITER_ACC, slot, -len(args))
         self.out.append(("wrefhi", loop, slots[0]))   # loop address | the loop variable's local << 30 (filter keeps its value)
         self.place(end)
         self.emit(OP_ITER_END, slot, +1)

@@ -94,6 +94,12 @@ CONDITIONS_WIDE = CONDITIONS + [
     'P.attr.teams.exists(t, P.attr.regions.filter(r, size(r) == size(t)).size() > 0)',
     'intersect(request.auxData.jwt.groups, P.attr.teams.map(t, t)).size() == 0',
     'P.attr.regions.filter(r, r != R.attr.tags.region) == P.attr.regions',
+    'P.attr.teams.map(t, size(t) > 3, t).size() == 1',
+    'P.attr.teams.transformList(i, t, i + size(t)).exists(n, n > 8)',
+    'P.attr.regions.transformList(i, r, i > 0, r) == P.attr.regions.slice(1, size(P.attr.regions))',
+    'lists.range(3).exists(i, i == size(P.attr.teams))',
+    '(P.attr.teams + ["zz"]).reverse()[0] == "zz"',
+    'P.attr.regions.slice(0, 2).size() == 2',
 ]
 
 
