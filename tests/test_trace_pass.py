@@ -223,10 +223,14 @@ def test_fuzz_errors_and_outputs_against_the_oracle(seed):
 @pytest.mark.gpu
 def test_gpu_fuzz_errors_and_outputs_against_the_oracle():
     tot = np.zeros(4, dtype=np.int64)
-    for seed in range(8):
+    n_seeds = int(os.environ.get("CBH_TRACE_GPU_SEEDS", "8"))   # a one-off wider sweep: CBH_TRACE_GPU_SEEDS=100
+    for seed in range(n_seeds):
         r = _fuzz_seed(seed, lambda lt: HipEvaluator(lt, Conf()), True)
         if r is not None:
             tot += np.array(r)
+        if seed < 12:   # ... and the bytes path (C++ ingest, C++ consumer) against the Python consumer on the same hardware
+            _bytes_fuzz(seed, lambda lt: HipEvaluator(lt, Conf()), True)
+    print("trace fuzz on the GPU: %d stores, inputs with errors / outputs compared: %s" % (n_seeds, tot.tolist()))
     assert tot[0] > 1500 and tot[1] > 1500 and tot[2] > 150 and tot[3] > 100, tot
 
 
