@@ -404,3 +404,53 @@ def _bytes_fuzz(seed, make, close):
 def test_bytes_path_fuzz_against_the_python_consumer(seed):
     n = _bytes_fuzz(seed, lambda lt: _HostSimBytes(lt, Conf()), False)
     assert n == 0 or n > 100
+
+
+# ---- service-level cases with outputs (server/checks/check_resources/cr_case_06.yaml: "With outputs") -----------------------
+SERVER_CASES = [c for c in load_json("server_check_cases.json") if any(w.get("outputs") for w in c["want"])]
+
+
+def _server_outputs(check):
+    """ResultEntry.outputs = CheckOutput.Outputs (cerbos_svc.go:325-327): a map literal with computed values AND computed keys
+    ("formatted_%s".format([...])), nested maps, format() - assembled from the parts the device evaluated."""
+    n = 0
+    by_src = lambda o: (o["src"], o["action"])   # noqa: E731
+    for case in SERVER_CASES:
+        outs = check(case["inputs"])
+        for have, want in zip(outs, case["want"]):
+            assert sorted(have.get("outputs") or [], key=by_src) == sorted(want["outputs"], key=by_src), case["name"]
+            n += len(want["outputs"])
+    return n
+
+
+def test_oracle_returns_the_service_level_outputs():
+    orc = RuleTableOracle(store_rule_table())
+    assert _server_outputs(lambda inputs: [orc.check(i, EvalParams(globals_=GLOBALS, now_ns=NOW)) for i in inputs]) >= 4
+
+
+def test_service_level_outputs_python_and_bytes_paths():
+    ev = _HostSimBytes(_store_table(), Conf(globals_=GLOBALS))
+
+    def py(inputs):
+        outs, bad, incomplete = ev.check(inputs, now_ns=NOW, allow_unsupported=True, trace=True)
+        assert not bad and not incomplete
+        return outs
+
+    def by(inputs):
+        outs, flags = _bytes_path(ev, inputs)
+        assert not flags.any()
+        return outs
+    assert _server_outputs(py) >= 4 and _server_outputs(by) >= 4
+
+
+@pytest.mark.gpu
+def test_gpu_service_level_outputs_python_and_bytes_paths():
+    ev = HipEvaluator(_store_table(), Conf(globals_=GLOBALS))
+    try:
+        def py(inputs):
+            outs, bad, incomplete = ev.check(inputs, now_ns=NOW, allow_unsupported=True, trace=True)
+            assert not bad and not incomplete
+            return outs
+        assert _server_outputs(py) >= 4 and _server_outputs(lambda inputs: _bytes_path(ev, inputs)[0]) >= 4
+    finally:
+        ev.close()

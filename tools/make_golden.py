@@ -111,7 +111,9 @@ def server_check_cases():
                           "meta": {a: {"matchedPolicy": m.get("matchedPolicy", ""), "matchedScope": m.get("matchedScope", "")}
                                    for a, m in (meta.get("actions") or {}).items()},
                           "effectiveDerivedRoles": meta.get("effectiveDerivedRoles"),
-                          "hasMeta": bool(meta)})
+                          "hasMeta": bool(meta),
+                          # ResultEntry.outputs = CheckOutput.Outputs (cerbos_svc.go:325-327)
+                          "outputs": res.get("outputs") or []})
         out.append({"name": "check_resources/%s" % os.path.basename(p)[:-5], "description": doc.get("description", ""),
                     "inputs": inputs, "want": wants})
     return out
