@@ -1156,6 +1156,11 @@ int cbi_assemble_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* re
 
 int cbi_assemble_response_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* request, uint64_t request_len,
                              const char* default_version, cbi_outputs** out) {
+  return cbi_assemble_response_traced_pb(t, b, res, request, request_len, default_version, nullptr, out);
+}
+
+int cbi_assemble_response_traced_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* request, uint64_t request_len,
+                                    const char* default_version, const cbi_outputs* traced, cbi_outputs** out) {
   if (!t || !b || !res || !res->effect || !out || !request) return fail("cbi_assemble_response_pb: null argument");
   const std::string_view dver = default_version ? default_version : "default";
   RequestParts rp;
@@ -1236,6 +1241,12 @@ int cbi_assemble_response_pb(const cbi_table* t, const cbi_batch* b, const cbh_r
     if (rp.include_meta) {
       for (u32 d = 0; d < 64 && d < t->dr_names.size(); ++d) if ((edr[i] >> d) & 1) put_ld(meta_buf, 2, t->dr_names[d]);
       put_ld(entry_buf, 4, std::string_view((const char*)meta_buf.data(), meta_buf.size()));   // present (possibly empty) when asked for
+    }
+    if (traced) {   // ResultEntry.outputs = 5 <- CheckOutput.outputs = 6 of the trace consumer's bytes for this entry (cerbos_svc.go:325-327)
+      if (traced->offsets.size() != (size_t)n + 1) return bail("traced outputs do not belong to this request");
+      Span ts{traced->bytes.data() + traced->offsets[i], traced->bytes.data() + traced->offsets[i + 1]}; Field tf; bool tbad = false;
+      while (next(ts, tf, tbad)) if (tf.num == 6 && tf.wt == 2) put_ld(entry_buf, 5, sv(tf.s));
+      o->flags[i] |= traced->flags[i] & (CBI_TRACE_ERRORS_INCOMPLETE | CBI_TRACE_OUTPUTS_INCOMPLETE);
     }
     put_ld(ob, 2, std::string_view((const char*)entry_buf.data(), entry_buf.size()));
   }
@@ -1355,9 +1366,13 @@ void put_value(std::vector<u8>& o, const TVal& v) {
 }
 }  // namespace
 
-extern "C" int cbi_trace_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint32_t* records, uint32_t count,
-                            const uint8_t* bytes, const uint64_t* offsets, uint32_t n, cbi_outputs** out) {
-  if (!t || !b || !res || !out || (count && !records) || (n && (!bytes || !offsets))) return fail("cbi_trace_pb: null argument");
+namespace {
+// what the consumer reads of input i: the messages its attribute paths resolve in, and its action names in order
+struct InputView { Span principal{nullptr, nullptr}, resource{nullptr, nullptr}, aux{nullptr, nullptr}; std::vector<std::string_view> actions; };
+}  // namespace
+
+static int trace_decode(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint32_t* records, uint32_t count, uint32_t n,
+                        const std::function<void(u32, InputView&)>& view_of, cbi_outputs** out) {
   if (!t->has_trace) return fail("the table was lowered without the trace sections");
   const u32 T = b->view.n_tuples, R = b->view.n_requests;
   auto RQ = [&](u32 f, u32 q) { return b->req[(size_t)f * R + q]; };
@@ -1398,8 +1413,8 @@ extern "C" int cbi_trace_pb(const cbi_table* t, const cbi_batch* b, const cbh_re
       default: throw TraceIncomplete{};   // timestamps / durations as output values
     }
   };
-  // the text of an error (include/cerbos_hip.h CBH_ERR_*); `msg` = the input's CheckInput bytes
-  auto message = [&](u64 payload, Span msg) -> std::string {
+  // the text of an error (include/cerbos_hip.h CBH_ERR_*) for input `iv`
+  auto message = [&](u64 payload, const InputView& iv) -> std::string {
     const u32 code = (u32)(payload & 0xFF); const u64 detail = payload >> 8;
     switch (code) {
       case CBH_ERR_NO_SUCH_OVERLOAD: return "no such overload";
@@ -1421,10 +1436,8 @@ extern "C" int cbi_trace_pb(const cbi_table* t, const cbi_batch* b, const cbh_re
         // the column's path did not resolve in this input: the step that failed decides the text
         if (detail >= t->columns.size()) throw TraceIncomplete{};
         const Column& col = t->columns[detail];
-        Span principal{nullptr, nullptr}, resource{nullptr, nullptr}, aux{nullptr, nullptr};
-        { Span s = msg; Field f; bool bad = false; while (next(s, f, bad)) { if (f.wt != 2) continue; if (f.num == 2) resource = f.s; else if (f.num == 3) principal = f.s; else if (f.num == 5) aux = f.s; } }
         bool bad = false;
-        Span holder = col.root == 0 ? principal : col.root == 1 ? resource : aux;   // the message whose map field is the root
+        Span holder = col.root == 0 ? iv.principal : col.root == 1 ? iv.resource : iv.aux;   // the message whose map field is the root
         u32 fnum = col.root == 2 ? 1u : col.root == 3 ? 2u : 4u;
         size_t k = 0;
         Span cur{nullptr, nullptr};
@@ -1457,14 +1470,16 @@ extern "C" int cbi_trace_pb(const cbi_table* t, const cbi_batch* b, const cbh_re
   struct Key { u32 q, pass, ri, site, rule; bool operator<(const Key& o) const { return std::tie(q, pass, ri, site, rule) < std::tie(o.q, o.pass, o.ri, o.site, o.rule); } };
   std::vector<std::set<std::pair<std::string, std::string>>> errs(n);
   std::vector<std::map<Key, Visit>> visits(n);
-  std::vector<u8> flags(n, 0);
+  std::vector<u8> flags(n, 0), have_view(n, 0);
+  std::vector<InputView> views(n);
   if (res->status) for (u32 q = 0; q < R; ++q) { const u32 o0 = RQ(RQ_ACT_OFF, q), c = RQ(RQ_ACT_CNT, q); for (u32 k = 0; k < c; ++k) if (res->status[o0 + k] == CBH_ST_UNSUPPORTED) flags[b->req_input[q]] |= CBI_TRACE_ERRORS_INCOMPLETE | CBI_TRACE_OUTPUTS_INCOMPLETE; }
   for (u32 x = 0; x < count; ++x) {
     const uint32_t* rec = records + (size_t)x * CBH_TRACE_RECORD_WORDS;
     const u32 q = rec[0], w1 = rec[1], w2 = rec[2], w3 = rec[3], kind = w1 & 0xF;
     if (q >= R) return fail("trace record refers to a request outside the batch");
     const u32 i = b->req_input[q];
-    const Span msg{bytes + offsets[i], bytes + offsets[i + 1]};
+    if (!have_view[i]) { view_of(i, views[i]); have_view[i] = 1; }
+    const InputView& msg = views[i];
     try {
       if (kind == CBH_TR_INCOMPLETE) flags[i] |= CBI_TRACE_OUTPUTS_INCOMPLETE;
       else if (kind == CBH_TR_ERROR) {
@@ -1484,12 +1499,11 @@ extern "C" int cbi_trace_pb(const cbi_table* t, const cbi_batch* b, const cbh_re
   auto o = new cbi_outputs();
   o->offsets.reserve((size_t)n + 1); o->offsets.push_back(0); o->flags = flags;
   std::vector<u8>& ob = o->bytes;
-  std::vector<std::string_view> actions;
   struct Entry { u64 a; u32 pass, ri, site; bool drfail; u32 rule; std::vector<u8> body; std::string_view action; };
   for (u32 i = 0; i < n; ++i) {
     // outputs (field 6), in the order check.go's loops reach them: action, policy kind, role, rule
-    actions.clear();
-    { Span s{bytes + offsets[i], bytes + offsets[i + 1]}; Field f; bool bad = false; while (next(s, f, bad)) if (f.num == 4 && f.wt == 2) actions.push_back(sv(f.s)); }
+    if (!visits[i].empty() && !have_view[i]) { view_of(i, views[i]); have_view[i] = 1; }
+    const std::vector<std::string_view>& actions = views[i].actions;
     std::vector<Entry> entries;
     for (auto& kv : visits[i]) {
       const Key& key = kv.first; Visit& v = kv.second;
@@ -1536,6 +1550,31 @@ extern "C" int cbi_trace_pb(const cbi_table* t, const cbi_batch* b, const cbh_re
   ob.reserve(1);
   *out = o;
   return 0;
+}
+
+extern "C" int cbi_trace_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint32_t* records, uint32_t count,
+                            const uint8_t* bytes, const uint64_t* offsets, uint32_t n, cbi_outputs** out) {
+  if (!t || !b || !res || !out || (count && !records) || (n && (!bytes || !offsets))) return fail("cbi_trace_pb: null argument");
+  return trace_decode(t, b, res, records, count, n, [&](u32 i, InputView& v) {   // CheckInput: resource 2, principal 3, actions 4, aux_data 5
+    Span s{bytes + offsets[i], bytes + offsets[i + 1]}; Field f; bool bad = false;
+    while (next(s, f, bad)) { if (f.wt != 2) continue;
+      if (f.num == 2) v.resource = f.s; else if (f.num == 3) v.principal = f.s; else if (f.num == 5) v.aux = f.s; else if (f.num == 4) v.actions.push_back(sv(f.s)); }
+  }, out);
+}
+
+// The same for the batch cbi_flatten_request_pb made of ONE CheckResourcesRequest: input i = its i-th resource entry, the principal
+// is the request's, the auxiliary data what the caller passed to the flattener.
+extern "C" int cbi_trace_request_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint32_t* records, uint32_t count,
+                                    const uint8_t* request, uint64_t request_len, const uint8_t* aux_data, uint64_t aux_len, cbi_outputs** out) {
+  if (!t || !b || !res || !out || (count && !records) || !request) return fail("cbi_trace_request_pb: null argument");
+  RequestParts rp;
+  if (!split_request(request, request_len, rp)) return fail("malformed CheckResourcesRequest");
+  const Span aux = aux_data ? Span{aux_data, aux_data + aux_len} : Span{nullptr, nullptr};
+  return trace_decode(t, b, res, records, count, (u32)rp.entries.size(), [&](u32 i, InputView& v) {   // entry: actions 1, resource 2
+    v.principal = rp.principal; v.aux = aux;
+    Span s = rp.entries[i]; Field f; bool bad = false;
+    while (next(s, f, bad)) { if (f.wt != 2) continue; if (f.num == 1) v.actions.push_back(sv(f.s)); else if (f.num == 2) v.resource = f.s; }
+  }, out);
 }
 
 extern "C" {

@@ -216,7 +216,7 @@ class HipEvaluator:
         return outs, oflags
 
     def check_request_pb(self, request: bytes, aux_data: bytes = None, now_ns=None, lenient_scope_search=None,
-                         strict_evaluation=None, default_policy_version=None, default_scope=None):
+                         strict_evaluation=None, default_policy_version=None, default_scope=None, trace=False):
         """``svc.CheckResources`` on bytes (cerbos_svc.go:255-344): one serialized ``CheckResourcesRequest`` (and the
         serialized engine ``AuxData`` derived from its JWT) -> (serialized ``CheckResourcesResponse``, flags per
         resource entry: bit 0 = the caller's own engine must evaluate that entry)."""
@@ -231,7 +231,12 @@ class HipEvaluator:
         batch = self._ingest.flatten_request_pb(request, aux_data, dver, dscope)
         flags = capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0) | (capi.F_STRICT_EVALUATION if strict else 0)
         res = self.table.check(batch, now_ns=now_ns, flags=flags, device_order=True)
-        return self._ingest.assemble_response_pb(batch, res, request, dver)
+        traced = None
+        if trace and self._ingest.trace_scope() == 2:
+            # a table with output expressions: the entries go through the tracing kernel too (the same batch) and their
+            # outputs into ResultEntry.outputs (cerbos_svc.go:325-327).  (The response carries no evaluation errors.)
+            traced = self.table.trace(batch, now_ns=now_ns, flags=flags)
+        return self._ingest.assemble_response_pb(batch, res, request, dver, traced=traced, aux_data=aux_data)
 
     def _ingest_table(self):
         if self._ingest is None:

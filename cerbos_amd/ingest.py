@@ -50,6 +50,8 @@ def load():
         lib.cbi_table_trace_scope.argtypes = [vp]
         lib.cbi_table_trace_scope.restype = C.c_uint32
         lib.cbi_trace_pb.argtypes = [vp, vp, C.POINTER(capi.CResult), vp, C.c_uint32, vp, vp, C.c_uint32, C.POINTER(vp)]
+        lib.cbi_trace_request_pb.argtypes = [vp, vp, C.POINTER(capi.CResult), vp, C.c_uint32, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(vp)]
+        lib.cbi_assemble_response_traced_pb.argtypes = [vp, vp, C.POINTER(capi.CResult), vp, C.c_uint64, C.c_char_p, vp, C.POINTER(vp)]
         lib.cbi_outputs_free.argtypes = [vp]
         lib.cbi_outputs_free.restype = None
         lib.cbi_outputs_bytes.argtypes = [vp]
@@ -133,11 +135,23 @@ class IngestTable:
                                              int(threads), C.byref(h)))
         return self._batch(h)
 
-    def assemble_response_pb(self, batch, res, request: bytes, default_policy_version="default"):
-        """-> (serialized ``CheckResourcesResponse``, flags uint8[n resource entries])."""
+    def assemble_response_pb(self, batch, res, request: bytes, default_policy_version="default", traced=None, aux_data: bytes = None):
+        """-> (serialized ``CheckResourcesResponse``, flags uint8[n resource entries]).  ``traced`` = (device-order Result,
+        records) of ``capi.Table.trace`` on the SAME batch: its outputs go into ``ResultEntry.outputs`` (cbi_trace_request_pb,
+        cbi_assemble_response_traced_pb)."""
         h = C.c_void_p()
-        _check(load().cbi_assemble_response_pb(self.h, batch.native.h, C.byref(res.c), request, len(request),
-                                               default_policy_version.encode(), C.byref(h)))
+        th = C.c_void_p()
+        if traced is not None:
+            tres, records = traced
+            records = np.ascontiguousarray(records, dtype=np.uint32)
+            _check(load().cbi_trace_request_pb(self.h, batch.native.h, C.byref(tres.c), records.ctypes.data if records.size else None,
+                                               len(records), request, len(request), aux_data, len(aux_data) if aux_data else 0, C.byref(th)))
+        try:
+            _check(load().cbi_assemble_response_traced_pb(self.h, batch.native.h, C.byref(res.c), request, len(request),
+                                                          default_policy_version.encode(), th if traced is not None else None, C.byref(h)))
+        finally:
+            if th:
+                load().cbi_outputs_free(th)
         try:
             off = _copy(load().cbi_outputs_offsets(h), C.c_uint64, np.int64, 2)
             raw = _copy(load().cbi_outputs_bytes(h), C.c_uint8, np.uint8, int(off[-1])).tobytes()

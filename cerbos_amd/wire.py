@@ -254,6 +254,20 @@ def decode_check_resources_response(buf: bytes) -> dict:
                         elif n3 == 2:
                             eff = _EFFECTS[v3]
                     entry["actions"][key] = eff
+                elif n2 == 5:    # OutputEntry {src 1, val 2, action 3, error 4}
+                    e2 = {}
+                    for n3, v3 in _fields(v2):
+                        if n3 == 1:
+                            e2["src"] = v3.decode("utf-8")
+                        elif n3 == 2:
+                            e2["val"] = decode_value(v3)
+                        elif n3 == 3:
+                            e2["action"] = v3.decode("utf-8")
+                        elif n3 == 4:
+                            e2["error"] = v3.decode("utf-8")
+                    if "val" not in e2 and "error" not in e2:
+                        e2["val"] = None
+                    entry.setdefault("outputs", []).append(e2)
                 elif n2 == 4:
                     meta = {"actions": {}, "effectiveDerivedRoles": []}
                     for n3, v3 in _fields(v2):

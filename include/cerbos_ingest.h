@@ -113,6 +113,13 @@ uint32_t cbi_table_trace_scope(const cbi_table* t);
 #define CBI_TRACE_OUTPUTS_INCOMPLETE 8u
 int cbi_trace_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint32_t* records, uint32_t count,
                  const uint8_t* bytes, const uint64_t* offsets, uint32_t n, cbi_outputs** out);
+/* The same for the batch cbi_flatten_request_pb made of one CheckResourcesRequest (input i = its i-th resource entry), and the
+ * response assembly that folds the traced outputs in: ResultEntry.outputs = CheckOutput.Outputs (cerbos_svc.go:325-327).
+ * `traced` = what cbi_trace_request_pb returned, or NULL (= cbi_assemble_response_pb). */
+int cbi_trace_request_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint32_t* records, uint32_t count,
+                         const uint8_t* request, uint64_t request_len, const uint8_t* aux_data, uint64_t aux_len, cbi_outputs** out);
+int cbi_assemble_response_traced_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* request,
+                                    uint64_t request_len, const char* default_version, const cbi_outputs* traced, cbi_outputs** out);
 void cbi_outputs_free(cbi_outputs* o);
 /* Output i = bytes[offsets[i] .. offsets[i+1]); n + 1 offsets. */
 const uint8_t* cbi_outputs_bytes(const cbi_outputs* o);

@@ -311,8 +311,34 @@ func (g *gpuEngine) checkResourcesGPU(reqBytes []byte, auxData *enginev1.AuxData
 	if C.cbh_check_batch(g.table, view, &params, &res) != 0 {
 		return nil, nil, errors.New(C.GoString(C.cbh_last_error()))
 	}
+	// a table with output expressions: the same batch once more through the tracing kernel, its outputs into
+	// ResultEntry.outputs (cerbos_svc.go:325-327; the response carries no evaluation errors)
+	var traced *C.cbi_outputs
+	if C.cbi_table_trace_scope(g.ingest) == 2 {
+		tres := C.cbh_result{effect: (*C.uint8_t)(C.calloc(nt+1, 1)), status: (*C.uint8_t)(C.calloc(nt+1, 1))}
+		defer C.free(unsafe.Pointer(tres.effect))
+		defer C.free(unsafe.Pointer(tres.status))
+		tr := C.cbh_trace{capacity: C.uint32_t(4*nt + 256)}
+		for {
+			tr.records = (*C.uint32_t)(C.calloc(C.size_t(tr.capacity), 4*C.CBH_TRACE_RECORD_WORDS))
+			if C.cbh_trace_batch(g.table, view, &params, &tres, &tr) != 0 {
+				C.free(unsafe.Pointer(tr.records))
+				return nil, nil, errors.New(C.GoString(C.cbh_last_error()))
+			}
+			if tr.count <= tr.capacity {
+				break
+			}
+			C.free(unsafe.Pointer(tr.records))
+			tr.capacity = tr.count + 64
+		}
+		defer C.free(unsafe.Pointer(tr.records))
+		if C.cbi_trace_request_pb(g.ingest, batch, &tres, tr.records, tr.count, reqPtr, C.uint64_t(len(reqBytes)), auxPtr, C.uint64_t(len(auxBytes)), &traced) != 0 {
+			return nil, nil, errors.New(C.GoString(C.cbi_last_error()))
+		}
+		defer C.cbi_outputs_free(traced)
+	}
 	var assembled *C.cbi_outputs
-	if C.cbi_assemble_response_pb(g.ingest, batch, &res, reqPtr, C.uint64_t(len(reqBytes)), dv, &assembled) != 0 {
+	if C.cbi_assemble_response_traced_pb(g.ingest, batch, &res, reqPtr, C.uint64_t(len(reqBytes)), dv, traced, &assembled) != 0 {
 		return nil, nil, errors.New(C.GoString(C.cbi_last_error()))
 	}
 	defer C.cbi_outputs_free(assembled)
@@ -329,7 +355,8 @@ func (g *gpuEngine) checkResourcesGPU(reqBytes []byte, auxData *enginev1.AuxData
 	oflags := unsafe.Slice((*byte)(unsafe.Pointer(C.cbi_outputs_flags(assembled))), nEntries)
 	fallback = make([]bool, nEntries)
 	for i, f := range oflags {
-		fallback[i] = f&C.CBI_OUT_UNSUPPORTED != 0
+		// also where the device could not build an entry's outputs (CBI_TRACE_OUTPUTS_INCOMPLETE): the CPU path supplies them
+		fallback[i] = f&(C.CBI_OUT_UNSUPPORTED|C.CBI_TRACE_OUTPUTS_INCOMPLETE) != 0
 	}
 	return respBytes, fallback, nil
 }

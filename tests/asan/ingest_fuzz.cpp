@@ -104,6 +104,21 @@ int main(int argc, char** argv) {
       cbh_result res{eff.data(), pol.data(), sc.data(), st.data(), edr.data()};
       cbi_outputs* o = nullptr;
       if (cbi_assemble_response_pb(t, rb, &res, rexact, rq.size(), "default", &o) == 0) cbi_outputs_free(o);
+      if (cbi_table_trace_scope(t) != 0) {   // the request-level trace consumer and the assembly that folds its outputs in
+        const uint32_t nrec = rnd() % 16;
+        std::vector<uint32_t> rec((size_t)nrec * CBH_TRACE_RECORD_WORDS + 1);
+        for (uint32_t r = 0; r < nrec; ++r) {
+          uint32_t* w = &rec[(size_t)r * CBH_TRACE_RECORD_WORDS];
+          w[0] = rnd() % (v->n_requests + 1); w[1] = (1 + rnd() % 4) | ((rnd() & 0xFFFFFFu) << 4); w[2] = rnd() % 64;
+          w[3] = (rnd() % 12) | ((rnd() % 40) << 8); w[4] = rnd() % 64; w[5] = 0; w[6] = rnd(); w[7] = 0;
+        }
+        cbi_outputs* to = nullptr;
+        if (cbi_trace_request_pb(t, rb, &res, rec.data(), nrec, rexact, rq.size(), nullptr, 0, &to) == 0) {
+          cbi_outputs* o2 = nullptr;
+          if (cbi_assemble_response_traced_pb(t, rb, &res, rexact, rq.size(), "default", to, &o2) == 0) cbi_outputs_free(o2);
+          cbi_outputs_free(to);
+        }
+      }
       cbi_batch_free(rb);
       ++ok;
     } else ++refused;

@@ -454,3 +454,35 @@ def test_gpu_service_level_outputs_python_and_bytes_paths():
         assert _server_outputs(py) >= 4 and _server_outputs(lambda inputs: _bytes_path(ev, inputs)[0]) >= 4
     finally:
         ev.close()
+
+
+def _response_outputs(ev):
+    """One CheckResourcesRequest in, one CheckResourcesResponse out (check_request_pb): results[i].outputs as the reference's
+    service test wants them."""
+    from cerbos_amd import wire
+    n = 0
+    by_src = lambda o: (o["src"], o["action"])   # noqa: E731
+    for case in SERVER_CASES:
+        req = {"requestId": "test", "includeMeta": True, "principal": case["inputs"][0]["principal"],
+               "resources": [{"actions": i["actions"], "resource": i["resource"]} for i in case["inputs"]]}
+        raw, flags = ev.check_request_pb(wire.encode_check_resources_request(req), now_ns=NOW, trace=True)
+        assert not flags.any()
+        resp = wire.decode_check_resources_response(raw)
+        for have, want in zip(resp["results"], case["want"]):
+            assert have["actions"] == want["actions"]
+            assert sorted(have.get("outputs") or [], key=by_src) == sorted(want["outputs"], key=by_src), case["name"]
+            n += len(want["outputs"])
+    return n
+
+
+def test_check_resources_response_carries_the_outputs():
+    assert _response_outputs(_HostSimBytes(_store_table(), Conf(globals_=GLOBALS))) >= 4
+
+
+@pytest.mark.gpu
+def test_gpu_check_resources_response_carries_the_outputs():
+    ev = HipEvaluator(_store_table(), Conf(globals_=GLOBALS))
+    try:
+        assert _response_outputs(ev) >= 4
+    finally:
+        ev.close()
