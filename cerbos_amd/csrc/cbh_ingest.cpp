@@ -171,6 +171,7 @@ struct TVal {
   enum Kind { Null, Bool, Int, Double, String, List, Map } k = Null;
   bool b = false; long long i = 0; double d = 0; std::string s;
   std::vector<TVal> items;   // List: the elements; Map: key, value, key, value ...
+  bool local = false;        // a list the program built in its lane's arena: i elements, logged as CBH_TR_OUTPUT_ELEMENT records
 };
 // Template of an output expression (celc.py _output_template; cbh_blob.h CBH_SEC_TRACE_HOST)
 struct TNode { u8 kind = 0; u32 hole = 0; TVal cst; std::string fmt; std::vector<TNode> kids; };
@@ -1401,6 +1402,7 @@ static int trace_decode(const cbi_table* t, const cbi_batch* b, const cbh_result
         const u32 sel = (u32)(v >> 62), off = (u32)((v >> 32) & 0x3FFFFFFFu), len = (u32)v;
         r.k = tag == 6 ? TVal::List : TVal::Map;
         if (sel == CBH_HEAP_ROLES) { if ((u64)off + len > b->roles.size()) throw TraceIncomplete{}; for (u32 i = 0; i < len; ++i) { TVal e; e.k = TVal::String; e.s = std::string(str(b->roles[off + i])); r.items.push_back(std::move(e)); } return r; }
+        if (sel == CBH_HEAP_LOCAL && tag == 6 && depth == 0) { r.local = true; r.i = len; return r; }
         const u8* tags; const u64* vals; u64 cap;
         if (sel == CBH_HEAP_BATCH) { tags = b->heap_tag.data(); vals = b->heap_val.data(); cap = b->heap_tag.size(); }
         else if (sel == CBH_HEAP_TABLE) { tags = t->theap_tag; vals = t->theap_val; cap = t->theap_len; }
@@ -1466,7 +1468,8 @@ static int trace_decode(const cbi_table* t, const cbi_batch* b, const cbh_result
     }
   };
 
-  struct Visit { u32 src; u64 mask; bool drfail; std::map<u32, std::pair<bool, TVal>> ok_parts; std::map<u32, std::string> err_parts; };
+  struct Visit { u32 src = 0; u64 mask = 0; bool drfail = false; std::map<u32, std::pair<bool, TVal>> ok_parts; std::map<u32, std::string> err_parts;
+                 std::map<u32, std::map<u32, TVal>> elems; };
   struct Key { u32 q, pass, ri, site, rule; bool operator<(const Key& o) const { return std::tie(q, pass, ri, site, rule) < std::tie(o.q, o.pass, o.ri, o.site, o.rule); } };
   std::vector<std::set<std::pair<std::string, std::string>>> errs(n);
   std::vector<std::map<Key, Visit>> visits(n);
@@ -1485,11 +1488,13 @@ static int trace_decode(const cbi_table* t, const cbi_batch* b, const cbh_result
       else if (kind == CBH_TR_ERROR) {
         if (w2 >= t->trace_strings.size()) return fail("trace record refers to an unknown string");
         errs[i].emplace(t->trace_strings[w2], message((u64)rec[4] | ((u64)rec[5] << 32), msg));
-      } else if (kind == CBH_TR_OUTPUT || kind == CBH_TR_OUTPUT_ERROR) {
-        const u32 rule = kind == CBH_TR_OUTPUT ? (w3 >> 8) : rec[4];
+      } else if (kind == CBH_TR_OUTPUT || kind == CBH_TR_OUTPUT_ERROR || kind == CBH_TR_OUTPUT_ELEMENT) {
+        const u32 rule = kind != CBH_TR_OUTPUT_ERROR ? (w3 >> 8) : rec[4];
         Visit& v = visits[i][Key{q, (w1 >> 4) & 1, (w1 >> 12) & 0xFF, w1 >> 20, rule}];
-        v.src = w2; v.mask = (u64)rec[6] | ((u64)rec[7] << 32); v.drfail = (w1 & 32u) != 0;
         const u32 part = (w1 >> 6) & 63;
+        v.src = w2; v.drfail = (w1 & 32u) != 0;
+        if (kind == CBH_TR_OUTPUT_ELEMENT) { v.elems[part][rec[6]] = to_tval(w3 & 0xFF, (u64)rec[4] | ((u64)rec[5] << 32), 1); continue; }
+        v.mask = (u64)rec[6] | ((u64)rec[7] << 32);
         if (kind == CBH_TR_OUTPUT) v.ok_parts[part] = {true, to_tval(w3 & 0xFF, (u64)rec[4] | ((u64)rec[5] << 32), 0)};
         else v.err_parts[part] = message((u64)w3 | ((u64)rec[5] << 32), msg);
       }
@@ -1517,7 +1522,18 @@ static int trace_decode(const cbi_table* t, const cbi_batch* b, const cbh_result
         if (!v.err_parts.empty()) put_ld(body, 4, v.err_parts.begin()->second);   // the first part to fail in evaluation order
         else {
           std::vector<TVal> holes;
-          for (auto& pk : v.ok_parts) { if (pk.first != holes.size()) throw TraceIncomplete{}; holes.push_back(pk.second.second); }
+          for (auto& pk : v.ok_parts) {
+            if (pk.first != holes.size()) throw TraceIncomplete{};
+            TVal hv = pk.second.second;
+            if (hv.local) {   // its elements were logged one by one
+              const auto& el = v.elems[pk.first];
+              if (el.size() != (size_t)hv.i) throw TraceIncomplete{};
+              hv.local = false;
+              u32 want = 0;
+              for (const auto& ek : el) { if (ek.first != want++ || ek.second.local) throw TraceIncomplete{}; hv.items.push_back(ek.second); }
+            }
+            holes.push_back(std::move(hv));
+          }
           std::vector<u8> vb; put_value(vb, assemble_template(tm->second.first, holes));
           put_varint(body, 2 << 3 | 2); put_varint(body, vb.size()); body.insert(body.end(), vb.begin(), vb.end());
         }

@@ -565,7 +565,15 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
         if (TRACE && live) {
           const u32 w1 = tctx | ((part & 63u) << 6);
           if (x.t == CBH_T_ERR) trace_log(ka->o, L.req, CBH_TR_OUTPUT_ERROR | w1, a, (u32)x.v, (u64)ek | ((x.v >> 32) << 32), tmask);
-          else trace_log(ka->o, L.req, CBH_TR_OUTPUT | w1, a, x.t | (ek << 8), x.v, tmask);
+          else {
+            trace_log(ka->o, L.req, CBH_TR_OUTPUT | w1, a, x.t | (ek << 8), x.v, tmask);
+            // a list the program built lives in this lane's arena, which is gone when the log is read: its elements follow
+            if (x.t == CBH_T_LIST && cont_sel(x.v) == CBH_HEAP_LOCAL)
+              for (u32 i = 0; i < cont_len(x.v) && i < CBH_ARENA_ENTRIES; ++i) {
+                const Val e = heap_get(c, CBH_HEAP_LOCAL, cont_off(x.v) + i);
+                trace_log(ka->o, L.req, CBH_TR_OUTPUT_ELEMENT | w1, a, e.t | (ek << 8), e.v, (u64)i);
+              }
+          }
         }
         break;
       }

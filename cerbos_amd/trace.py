@@ -13,7 +13,15 @@ import numpy as np
 
 from .flatten import HEAP_BATCH, RQ_ACT_CNT, RQ_ACT_OFF
 
-TR_ERROR, TR_OUTPUT, TR_OUTPUT_ERROR, TR_INCOMPLETE = 1, 2, 3, 4
+TR_ERROR, TR_OUTPUT, TR_OUTPUT_ERROR, TR_INCOMPLETE, TR_OUTPUT_ELEMENT = 1, 2, 3, 4, 5
+HEAP_LOCAL = 3
+
+
+class _LocalList:
+    """A list the program built in its lane's arena: the elements come in CBH_TR_OUTPUT_ELEMENT records."""
+
+    def __init__(self, n):
+        self.n = n
 TR_DRFAIL = 32   # cbh_check_wave.h CBH_TR_DRFAIL
 (ERR_OTHER, ERR_NO_SUCH_KEY, ERR_ATTR_MISSING, ERR_NO_SUCH_OVERLOAD, ERR_UNDEFINED_FIELD, ERR_DIV_BY_ZERO, ERR_MOD_BY_ZERO,
  ERR_INT_OVERFLOW, ERR_UINT_OVERFLOW, ERR_EDR_FAILED) = range(10)
@@ -77,7 +85,7 @@ class TraceDecoder:
                 cur = cur[key]
         raise _Incomplete()
 
-    def value(self, tag, v):
+    def value(self, tag, v, top=False):
         """A device value as a Python value that keeps its CEL type: None, bool, int (int / uint), float (double), str,
         list, dict."""
         if tag == T_NULL:
@@ -100,6 +108,8 @@ class TraceDecoder:
                 tags, vals = self.batch.heap_tag, self.batch.heap_val
             elif sel == HEAP_TABLE:
                 tags, vals = self.lt.theap
+            elif sel == HEAP_LOCAL and tag == T_LIST and top:
+                return _LocalList(n)
             else:
                 raise _Incomplete()
             if tag == T_LIST:
@@ -140,15 +150,19 @@ class TraceDecoder:
                     incomplete[i_in].add("outputs")
                 elif kind == TR_ERROR:
                     errs[i_in].add((lt.trace_strings[w2], self.message(int(rec[4]) | (int(rec[5]) << 32), inp)))
-                elif kind in (TR_OUTPUT, TR_OUTPUT_ERROR):
+                elif kind in (TR_OUTPUT, TR_OUTPUT_ERROR, TR_OUTPUT_ELEMENT):
                     # one record per computed part of the output expression: collected per visit, assembled below
-                    rule = (w3 >> 8) if kind == TR_OUTPUT else int(rec[4])
+                    rule = (w3 >> 8) if kind != TR_OUTPUT_ERROR else int(rec[4])
                     pre = r if rp is None else int(rp[r])   # the request's index before the routing sort
                     visit = (pre, (w1 >> 4) & 1, (w1 >> 12) & 0xFF, w1 >> 20, rule)
                     part = (w1 >> 6) & 63
-                    g = parts[i_in].setdefault(visit, {"src": w2, "mask": int(rec[6]) | (int(rec[7]) << 32), "drfail": bool(w1 & TR_DRFAIL), "parts": {}})
+                    g = parts[i_in].setdefault(visit, {"src": w2, "mask": 0, "drfail": bool(w1 & TR_DRFAIL), "parts": {}, "elems": {}})
+                    if kind == TR_OUTPUT_ELEMENT:
+                        g["elems"].setdefault(part, {})[int(rec[6])] = self.value(w3 & 0xFF, int(rec[4]) | (int(rec[5]) << 32))
+                        continue
+                    g["mask"] = int(rec[6]) | (int(rec[7]) << 32)
                     if kind == TR_OUTPUT:
-                        g["parts"][part] = (True, self.value(w3 & 0xFF, int(rec[4]) | (int(rec[5]) << 32)))
+                        g["parts"][part] = (True, self.value(w3 & 0xFF, int(rec[4]) | (int(rec[5]) << 32), top=True))
                     else:
                         g["parts"][part] = (False, self.message(w3 | (int(rec[5]) << 32), inp))
             except _Incomplete:
@@ -164,7 +178,16 @@ class TraceDecoder:
                     if failed:   # the first part to fail in evaluation order is the expression's error
                         entry["error"] = g["parts"][failed[0]][1]
                     else:
-                        entry["val"] = _json(_assemble(tmpl, [g["parts"][j][1] for j in range(n_holes)]))
+                        holes = []
+                        for j in range(n_holes):
+                            v = g["parts"][j][1]
+                            if isinstance(v, _LocalList):   # its elements were logged one by one
+                                el = g["elems"].get(j, {})
+                                if sorted(el) != list(range(v.n)):
+                                    raise _Incomplete()
+                                v = [el[k] for k in range(v.n)]
+                            holes.append(v)
+                        entry["val"] = _json(_assemble(tmpl, holes))
                 except _Incomplete:
                     incomplete[i_in].add("outputs")
                     continue

@@ -266,6 +266,8 @@ int cbh_kernel_time_ms(cbh_table* t, float* check_kernel_ms, float* resolve_kern
 #define CBH_TR_ERROR 1u         /* a condition / variable expression failed */
 #define CBH_TR_OUTPUT 2u        /* an output expression produced a value */
 #define CBH_TR_OUTPUT_ERROR 3u  /* an output expression failed: OutputEntry.error */
+#define CBH_TR_OUTPUT_ELEMENT 5u /* element w6 of the list the preceding CBH_TR_OUTPUT record of this visit / part refers to with   */
+                                /* CBH_HEAP_LOCAL (a list the program built: it lives in the lane's LDS, so its elements are logged) */
 #define CBH_TR_INCOMPLETE 4u    /* an output expression of this request is outside the device subset: its outputs are not all */
                                 /* here.  (A condition / variable outside the subset marks the tuples CBH_ST_UNSUPPORTED.)     */
 /* error codes (w3 bits 0-7); detail = w3 >> 8 */

@@ -119,7 +119,10 @@ OUTPUTS = ['"fixed"', "P.id", "R.attr.status", "R.attr.amount > 100", "R.attr.am
            # what an expression builds is assembled on the host from the parts the device evaluates (celc.py _output_template)
            '"owner:%s:%s".format([P.id, R.attr.owner])', '"n=%d lvl=%s".format([size(P.roles), P.attr.level])',
            '{"who": P.id, "amount": R.attr.amount, "tags": [R.attr.status, "x"], "fmt": "%s/%s".format([R.kind, R.id])}',
-           "[P.id, R.attr.department, R.attr.amount > 100]", '"%s".format([R.attr.tags])', '"%s %s".format([P.attr.teams, R.attr.public])']
+           "[P.id, R.attr.department, R.attr.amount > 100]", '"%s".format([R.attr.tags])', '"%s %s".format([P.attr.teams, R.attr.public])',
+           # lists the expression builds on the device (the lane's arena): logged element by element
+           'P.attr.teams.filter(t, t.startsWith("co"))', 'P.attr.regions.map(r, r + "")' if False else 'P.attr.teams.map(t, size(t))',
+           '{"kept": intersect(P.attr.regions, ["eu", "us"]), "n": size(P.attr.regions)}', '"%s".format([P.attr.teams + ["x"]])']
 
 
 def _trace_policies(rng):
