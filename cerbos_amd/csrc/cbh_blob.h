@@ -277,6 +277,8 @@ enum CbhOp {
                       // error is recorded and the variable is null (unset in strict mode)
   OP_OUT = 63,        // trace programs: TOS is the value of an output expression (check.go:776-807): logged, not returned
   OP_LISTOP = 64,     // arg 0 intersect / 1 except / 2 concatenation: pop b, a (lists) -> a new list in the lane's arena
+  OP_STRCAT = 66,     // pop b, a (strings or ropes) -> the rope a ++ b: its parts side by side in the lane's arena, no byte is copied
+  OP_STRCASE = 67,    // arg 1 lowerAscii / 2 upperAscii: TOS string -> the rope that reads it through the case mapping
   OP_LISTFN = 65,     // arg 0 reverse: TOS list -> reversed copy in the arena; 1 slice: pop end, start; TOS list -> the view
                       // [start, end) of it; 2 lists.range: TOS int n -> [0 .. n) in the arena
   OP_NOPS

@@ -88,6 +88,8 @@ __device__ inline void trace_log(const OutDev& o, u32 w0, u32 w1, u32 w2, u32 w3
 #define FAILTOP2(xv, yv, code) do { if (TRACE) SV(sp - 1) = (xv).t == CBH_T_ERR ? (xv).v : (yv).t == CBH_T_ERR ? (yv).v : (u64)(code); \
                                     ST(sp - 1) = CBH_T_ERR; } while (0)
 // trace instantiation: the first error a comprehension absorbed, two dwords per slot behind the iteration state words
+// a rope (cbh_vm.h) met by an operation that does not read ropes: the tuple is the caller's engine's, never a wrong answer
+#define ROPE_UNSUPPORTED2(xv, yv) if ((xv).t == CBH_T_ROPE || (yv).t == CBH_T_ROPE) { if (live) L.status |= CBH_ST_UNSUPPORTED; SETTOP(mk_err()); break; }
 #define IT_ERR_LO(slot) c.it_state[(CBH_MAX_ITERS + 2 * (slot)) * CBH_BLOCK + c.tid]
 #define IT_ERR_HI(slot) c.it_state[(CBH_MAX_ITERS + 2 * (slot) + 1) * CBH_BLOCK + c.tid]
 
@@ -151,6 +153,7 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
       }
       case OP_INDEX: {
         Val i = TOPV(0), m = TOPV(1), out = mk_err(); --sp;
+        if (i.t == CBH_T_ROPE || m.t == CBH_T_ROPE) { if (live) L.status |= CBH_ST_UNSUPPORTED; SETTOP(mk_err()); break; }   // a rope as a key: not read here
         if (m.t == CBH_T_ERR) out = m;
         else if (i.t == CBH_T_ERR) out = i;
         else if (m.t == CBH_T_MAP) { if (!map_find(c, m, i, out)) out = i.t == CBH_T_STRING ? mk_errc(CBH_ERR_NO_SUCH_KEY, (u32)i.v) : mk_err(); }
@@ -167,6 +170,17 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
       }
       case OP_EQ: case OP_NE: case OP_LT: case OP_LE: case OP_GT: case OP_GE: case OP_IN: {
         Val y = TOPV(0), x = TOPV(1); --sp;
+        if (x.t == CBH_T_ROPE || y.t == CBH_T_ROPE) {   // ropes are compared by content, out of line (cbh_vm.h rope_op)
+          if (x.t == CBH_T_ERR || y.t == CBH_T_ERR) { FAILTOP2(x, y, 0); break; }
+          if (op == OP_EQ || op == OP_NE || (op == OP_IN && x.t == CBH_T_ROPE)) {
+            const SlowVal r = rope_op(ka, lds, op == OP_EQ ? ROPE_EQ : op == OP_NE ? ROPE_NE : ROPE_IN, x, y);
+            SETTOP(mk(r.t, r.v));
+          } else {   // an ordering of ropes, or membership IN a rope: left to the caller's engine / no such overload
+            if (op != OP_IN && is_strlike(x.t) && is_strlike(y.t) && live) L.status |= CBH_ST_UNSUPPORTED;
+            SETTOP(mk_errc(CBH_ERR_NO_SUCH_OVERLOAD));
+          }
+          break;
+        }
         SETTOP(compare_op(c, L, op, x, y));
         break;
       }
@@ -258,18 +272,25 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
       case OP_SIZE: {
         Val x = TOPV(0);
         if (x.t == CBH_T_STRING) SETTOP(mk(CBH_T_INT, str_codepoints(c, (u32)x.v)));
+        else if (x.t == CBH_T_ROPE) { const SlowVal r = rope_op(ka, lds, ROPE_SIZE, x, x); SETTOP(mk(r.t, r.v)); }
         else if (x.t == CBH_T_LIST || x.t == CBH_T_MAP) SETTOP(mk(CBH_T_INT, cont_len(x.v)));
         else FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD);
         break;
       }
       case OP_STARTSWITH: case OP_ENDSWITH: case OP_CONTAINS: {
         Val y = TOPV(0), x = TOPV(1); --sp;
-        if (x.t != CBH_T_STRING || y.t != CBH_T_STRING) { FAILTOP2(x, y, CBH_ERR_NO_SUCH_OVERLOAD); break; }
+        if (!is_strlike(x.t) || !is_strlike(y.t)) { FAILTOP2(x, y, CBH_ERR_NO_SUCH_OVERLOAD); break; }
+        if (x.t == CBH_T_ROPE || y.t == CBH_T_ROPE) {
+          const SlowVal r = rope_op(ka, lds, op == OP_STARTSWITH ? ROPE_STARTS : (op == OP_ENDSWITH ? ROPE_ENDS : ROPE_CONTAINS), x, y);
+          SETTOP(mk(r.t, r.v));
+          break;
+        }
         SETTOP(mk_bool(str_find(c, (u32)x.v, (u32)y.v, op == OP_STARTSWITH ? 0 : (op == OP_ENDSWITH ? 1 : 2))));
         break;
       }
       case OP_INDEXOF: {   // a = 0 first / 1 last
         Val y = TOPV(0), x = TOPV(1); --sp;
+        ROPE_UNSUPPORTED2(x, y);
         if (x.t != CBH_T_STRING || y.t != CBH_T_STRING) { FAILTOP2(x, y, CBH_ERR_NO_SUCH_OVERLOAD); break; }
         SETTOP(mk(CBH_T_INT, (u64)str_index_of(c, (u32)x.v, (u32)y.v, a != 0)));
         break;
@@ -277,6 +298,7 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
       case OP_STREQ_CASE: {   // a = mode a | mode b << 2 | ne << 4
         Val y = TOPV(0), x = TOPV(1); --sp;
         const u32 ma = a & 3u, mb = (a >> 2) & 3u;
+        ROPE_UNSUPPORTED2(x, y);
         // a mapped side must be a string (no such overload otherwise); an unmapped side of another type is simply unequal
         if (x.t == CBH_T_ERR || y.t == CBH_T_ERR || (ma && x.t != CBH_T_STRING) || (mb && y.t != CBH_T_STRING)) { FAILTOP2(x, y, CBH_ERR_NO_SUCH_OVERLOAD); break; }
         const bool eq = x.t == CBH_T_STRING && y.t == CBH_T_STRING && str_eq_case(c, (u32)x.v, ma, (u32)y.v, mb);
@@ -286,12 +308,14 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
       case OP_MATCHES: {   // next word = the pattern's tables
         const u32 off = uload(&code[pc]); ++pc;
         Val x = TOPV(0);
+        ROPE_UNSUPPORTED2(x, x);
         if (x.t != CBH_T_STRING) { FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD); break; }
         SETTOP(mk_bool(regex_match(c, off, (u32)x.v)));
         break;
       }
       case OP_HIER: {   // a = predicate
         Val y = TOPV(0), x = TOPV(1); --sp;
+        ROPE_UNSUPPORTED2(x, y);
         if (x.t == CBH_T_STRING && y.t == CBH_T_STRING) { SETTOP(mk_bool(hier_pred(c, a, (u32)x.v, (u32)y.v))); break; }
         // hierarchy(list of strings) is valid CEL the device does not evaluate; anything else is "no such overload"
         if ((x.t == CBH_T_LIST || y.t == CBH_T_LIST) && x.t != CBH_T_ERR && y.t != CBH_T_ERR && live) L.status |= CBH_ST_UNSUPPORTED;
@@ -300,6 +324,7 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
       }
       case OP_TIMESTAMP: {
         Val x = TOPV(0);
+        ROPE_UNSUPPORTED2(x, x);
         if (x.t == CBH_T_TIMESTAMP) break;
         if (x.t != CBH_T_STRING) { FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD); break; }
         gbytes p; u32 n; str_span(c, (u32)x.v, p, n);
@@ -311,6 +336,7 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
       }
       case OP_DURATION: {
         Val x = TOPV(0);
+        ROPE_UNSUPPORTED2(x, x);
         if (x.t == CBH_T_DURATION) break;
         if (x.t != CBH_T_STRING) { FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD); break; }
         gbytes p; u32 n; str_span(c, (u32)x.v, p, n);
@@ -410,6 +436,11 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
           // of a turn the predicate lets through
           const bool is_map = (st & 0xFF) != IT_FILTER;
           const bool bad_guard = guard.t != CBH_T_BOOL, skipped = !bad_guard && !guard.v;
+          if (!bad_guard && !skipped && is_map && x.t == CBH_T_ROPE) {   // a rope never becomes a list element (cbh_vm.h)
+            if (live) L.status |= CBH_ST_UNSUPPORTED;
+            if (TRACE) { IT_ERR_LO(a) = 0; IT_ERR_HI(a) = 0; }
+            st |= ITS_FAIL; st &= ~ITS_RUNNING;
+          } else
           if (bad_guard || (!skipped && (x.t == CBH_T_ERR || (!is_map && x.t != CBH_T_BOOL)))) {
             const Val& bad = bad_guard ? guard : x;
             if (TRACE) { const u64 e = bad.t == CBH_T_ERR ? bad.v : (u64)CBH_ERR_NO_SUCH_OVERLOAD; IT_ERR_LO(a) = (u32)e; IT_ERR_HI(a) = (u32)(e >> 32); }
@@ -454,6 +485,7 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
       }
       case OP_TOINT: {
         Val x = TOPV(0);
+        ROPE_UNSUPPORTED2(x, x);
         if (x.t == CBH_T_INT) break;
         if (x.t == CBH_T_UINT) { if (x.v > (u64)INT64_MAX) SETTOP(mk_errc(CBH_ERR_INT_OVERFLOW)); else ST(sp - 1) = CBH_T_INT; break; }
         if (x.t == CBH_T_DOUBLE) {
@@ -470,6 +502,7 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
       }
       case OP_TODOUBLE: {
         Val x = TOPV(0);
+        ROPE_UNSUPPORTED2(x, x);
         if (x.t == CBH_T_DOUBLE) break;
         if (x.t == CBH_T_INT) { SETTOP(mk(CBH_T_DOUBLE, f64_bits((double)(i64)x.v))); break; }
         if (x.t == CBH_T_UINT) { SETTOP(mk(CBH_T_DOUBLE, f64_bits((double)x.v))); break; }
@@ -479,6 +512,7 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
       }
       case OP_INIPRANGE: {
         Val y = TOPV(0), x = TOPV(1); --sp;
+        ROPE_UNSUPPORTED2(x, y);
         if (x.t != CBH_T_STRING || y.t != CBH_T_STRING) { FAILTOP2(x, y, CBH_ERR_NO_SUCH_OVERLOAD); break; }
         gbytes pi, pc2; u32 ni, nc;
         str_span(c, (u32)x.v, pi, ni); str_span(c, (u32)y.v, pc2, nc);
@@ -525,6 +559,30 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
         if (a == 2) for (u32 j = 0; j < ny; ++j) arena_put(c, start + n++, heap_get(c, cont_sel(y.v), cont_off(y.v) + j));
         ap += need;
         SETTOP(mk(CBH_T_LIST, ((u64)CBH_HEAP_LOCAL << 62) | ((u64)start << 32) | n));
+        break;
+      }
+      case OP_STRCAT: {     // the rope a ++ b
+        Val y = TOPV(0), x = TOPV(1); --sp;
+        if (!is_strlike(x.t) || !is_strlike(y.t)) { FAILTOP2(x, y, CBH_ERR_NO_SUCH_OVERLOAD); break; }
+        const u32 nx = x.t == CBH_T_ROPE ? rope_parts(x.v) : 1u, ny = y.t == CBH_T_ROPE ? rope_parts(y.v) : 1u;
+        if (nx + ny > CBH_ARENA_ENTRIES - ap) { if (live) L.status |= CBH_ST_UNSUPPORTED; SETTOP(mk_err()); break; }   // the arena is full
+        const u32 start = ap;
+        for (u32 k = 0; k < nx; ++k) arena_put(c, ap++, x.t == CBH_T_ROPE ? heap_get(c, CBH_HEAP_LOCAL, cont_off(x.v) + k) : x);
+        for (u32 k = 0; k < ny; ++k) arena_put(c, ap++, y.t == CBH_T_ROPE ? heap_get(c, CBH_HEAP_LOCAL, cont_off(y.v) + k) : y);
+        SETTOP(mk_rope(start, nx + ny));
+        break;
+      }
+      case OP_STRCASE: {    // a = 1 lowerAscii / 2 upperAscii: the same parts, read through the mapping (the later mapping wins)
+        Val x = TOPV(0);
+        if (!is_strlike(x.t)) { FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD); break; }
+        const u32 nx = x.t == CBH_T_ROPE ? rope_parts(x.v) : 1u;
+        if (nx > CBH_ARENA_ENTRIES - ap) { if (live) L.status |= CBH_ST_UNSUPPORTED; SETTOP(mk_err()); break; }
+        const u32 start = ap;
+        for (u32 k = 0; k < nx; ++k) {
+          const Val part = x.t == CBH_T_ROPE ? heap_get(c, CBH_HEAP_LOCAL, cont_off(x.v) + k) : x;
+          arena_put(c, ap++, mk(CBH_T_STRING, (part.v & 0xFFFFFFFFull) | ((u64)a << 32)));
+        }
+        SETTOP(mk_rope(start, nx));
         break;
       }
       case OP_LISTFN: {
@@ -590,6 +648,7 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
 }
 #undef FAILTOP1
 #undef FAILTOP2
+#undef ROPE_UNSUPPORTED2
 #undef IT_ERR_LO
 #undef IT_ERR_HI
 

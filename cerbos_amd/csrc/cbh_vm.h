@@ -294,6 +294,44 @@ __device__ __forceinline__ Val heap_get(const Ctx& c, u32 sel, u32 idx) {
   return mk(CBH_T_STRING, c.b.roles[idx]);
 }
 
+// ---- ropes: strings a program puts together are never built -----------------------------------
+// A rope is the list of its parts in the lane's arena - string id | case mode << 32 (1 lowerAscii, 2 upperAscii: the part is read
+// through the mapping) -; whoever needs its bytes walks the parts.  Only the operand-stack interpreter makes and reads ropes
+// (cbh_interp.h: equality, `in`, prefix / suffix / substring search, size(); anything else flags the tuple UNSUPPORTED), through
+// ONE out-of-line function (rope_op below), so that the shared comparison code and the kernels without an interpreter stay as they are.
+// A rope never becomes a list element.
+__device__ __forceinline__ u32 rope_parts(u64 v) { return (u32)v & 0xFFFFu; }
+__device__ __forceinline__ Val mk_rope(u32 off, u32 parts) { return mk(CBH_T_ROPE, ((u64)CBH_HEAP_LOCAL << 62) | ((u64)off << 32) | parts); }
+__device__ __forceinline__ bool is_strlike(u32 t) { return t == CBH_T_STRING || t == CBH_T_ROPE; }
+__device__ inline u32 sl_len(const Ctx& c, Val x) {   // bytes of a string or rope
+  gbytes p; u32 n;
+  if (x.t == CBH_T_STRING) { str_span(c, (u32)x.v, p, n); return n; }
+  u32 tot = 0;
+  for (u32 k = 0; k < rope_parts(x.v); ++k) { str_span(c, (u32)heap_get(c, CBH_HEAP_LOCAL, cont_off(x.v) + k).v, p, n); tot += n; }
+  return tot;
+}
+__device__ inline u32 sl_byte(const Ctx& c, Val x, u32 i) {   // its i-th byte, through the part's case mode (i < sl_len)
+  gbytes p; u32 n; u32 b = 0;
+  if (x.t == CBH_T_STRING) { str_span(c, (u32)x.v, p, n); return i < n ? p[i] : 0u; }
+  u32 mode = 0;
+  for (u32 k = 0; k < rope_parts(x.v); ++k) {
+    const u64 part = heap_get(c, CBH_HEAP_LOCAL, cont_off(x.v) + k).v;
+    str_span(c, (u32)part, p, n);
+    if (i < n) { b = p[i]; mode = (u32)(part >> 32) & 3u; break; }
+    i -= n;
+  }
+  if (mode == 1 && b >= 'A' && b <= 'Z') b += 32;
+  if (mode == 2 && b >= 'a' && b <= 'z') b -= 32;
+  return b;
+}
+__device__ inline bool sl_equal(const Ctx& c, Val a, Val b) {
+  if (!is_strlike(a.t) || !is_strlike(b.t)) return false;   // a rope equals nothing that is not a string
+  const u32 n = sl_len(c, a);
+  if (n != sl_len(c, b)) return false;
+  for (u32 i = 0; i < n; ++i) if (sl_byte(c, a, i) != sl_byte(c, b, i)) return false;
+  return true;
+}
+
 // ---- numeric comparison (exact across int64 / uint64 / double) -------------------------
 // returns -1, 0, 1 or 2 (unordered: NaN)
 __device__ inline int cmp_i64_f64(i64 i, double d) {
@@ -745,6 +783,47 @@ __device__ SlowVal compare_op_slow(const KernelArgs* ka, u32 req, u32 op, Val x,
   Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false;
   const Val r = compare_op(c, L, op, x, y);
   return SlowVal{r.t, L.status, r.v};
+}
+
+// Everything the interpreter does WITH a rope (cbh_interp.h), out of line and by value like compare_op_slow.
+//   kind 0 / 1  x == y / x != y          kind 2  x in y (list or map keys)      kind 3 / 4 / 5  startsWith / endsWith / contains
+//   kind 6      size(x) in code points
+enum { ROPE_EQ = 0, ROPE_NE = 1, ROPE_IN = 2, ROPE_STARTS = 3, ROPE_ENDS = 4, ROPE_CONTAINS = 5, ROPE_SIZE = 6 };
+#ifndef CBH_HOSTSIM
+__attribute__((noinline))
+#endif
+__device__ SlowVal rope_op(const KernelArgs* ka, const VmLds lds, u32 kind, Val x, Val y) {
+  const Ctx c = ctx_from_memory(ka, lds);
+  if (kind == ROPE_EQ || kind == ROPE_NE) {
+    const bool e = sl_equal(c, x, y);
+    return SlowVal{CBH_T_BOOL, 0, (u64)(e == (kind == ROPE_EQ))};
+  }
+  if (kind == ROPE_IN) {
+    if (y.t != CBH_T_LIST && y.t != CBH_T_MAP) return SlowVal{CBH_T_ERR, 0, (u64)CBH_ERR_NO_SUCH_OVERLOAD};
+    const u32 n = cont_len(y.v), step = y.t == CBH_T_MAP ? 2u : 1u;
+    bool found = false;
+    for (u32 i = 0; i < n && !found; ++i) found = sl_equal(c, x, heap_get(c, cont_sel(y.v), cont_off(y.v) + step * i));
+    return SlowVal{CBH_T_BOOL, 0, (u64)found};
+  }
+  if (kind == ROPE_SIZE) {
+    const u32 n = sl_len(c, x);
+    u32 cp = 0;
+    for (u32 i = 0; i < n; ++i) cp += (sl_byte(c, x, i) & 0xC0u) != 0x80u;
+    return SlowVal{CBH_T_INT, 0, (u64)cp};
+  }
+  const u32 nh = sl_len(c, x), nn = sl_len(c, y);
+  bool hit = false;
+  if (nn <= nh) {
+    u32 lo = 0, hi = nh - nn;
+    if (kind == ROPE_STARTS) hi = 0;
+    if (kind == ROPE_ENDS) lo = hi;
+    for (u32 s = lo; s <= hi && !hit; ++s) {
+      u32 j = 0;
+      while (j < nn && sl_byte(c, x, s + j) == sl_byte(c, y, j)) ++j;
+      hit = j == nn;
+    }
+  }
+  return SlowVal{CBH_T_BOOL, 0, (u64)hit};
 }
 
 // Same-type fast paths of compare_op for the inline fused-leaf evaluation.

@@ -26,7 +26,8 @@ from . import regex
  OP_EDRHAS, OP_LOCAL, OP_ITER_BEGIN, OP_ITER_NEXT, OP_ITER_ACC, OP_ITER_END, OP_TOINT,
  OP_TODOUBLE, OP_TOSTRING_UNSUPPORTED, OP_INIPRANGE, OP_UNSUPPORTED, OP_TS_GETTER,
  OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN, OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC,
- OP_TREE_END, OP_HIER, OP_MATCHES, OP_INDEXOF, OP_STREQ_CASE, OP_VARSCOPE, OP_OUT, OP_LISTOP, OP_LISTFN) = range(66)
+ OP_TREE_END, OP_HIER, OP_MATCHES, OP_INDEXOF, OP_STREQ_CASE, OP_VARSCOPE, OP_OUT, OP_LISTOP, OP_LISTFN, OP_STRCAT,
+ OP_STRCASE) = range(68)
 
 TREE_KINDS = {"all": 0, "any": 1, "none": 2}
 COND_LEAF = 0x80000000
@@ -582,6 +583,18 @@ def _int_lit_as_double(ast):
     return ast
 
 
+def _builds_string(ast):
+    """Is the expression visibly a string: a literal, lowerAscii / upperAscii of something, or a concatenation with one."""
+    k = ast[0]
+    if k == "lit":
+        return ast[1] == "string"
+    if k == "call":
+        return ast[1] in ("lowerAscii", "upperAscii") and ast[2] is not None and not ast[3]
+    if k == "bin" and ast[1] == "+":
+        return _builds_string(ast[2]) or _builds_string(ast[3])
+    return False
+
+
 def _builds_list(ast):
     """Is the expression visibly a list: a literal, filter / map, intersect / except, or a concatenation of such."""
     k = ast[0]
@@ -817,6 +830,18 @@ class _FuncCompiler:
             return ("edr",)
         return None
 
+    def _stringy(self, ast):
+        """Visibly a string: a literal / case mapping / concatenation with one (_builds_string), or one of the request's string
+        fields (P.id, R.id, R.kind, scopes, policy versions)."""
+        if _builds_string(ast):
+            return True
+        if ast[0] == "bin" and ast[1] == "+":
+            return self._stringy(ast[2]) or self._stringy(ast[3])
+        if ast[0] in ("select", "index"):
+            p = self._path(ast)
+            return p is not None and p[0] == "req"
+        return False
+
     # -- expressions
     def expr(self, ast):  # noqa: C901
         try:
@@ -895,6 +920,7 @@ class _FuncCompiler:
                 for side in (ast[2], ast[3]):
                     m = 0
                     if side[0] == "call" and side[1] in ("lowerAscii", "upperAscii") and side[2] is not None and not side[3] \
+                            and not _builds_string(side[2]) \
                             and not (side[2][0] == "ident" and side[2][1] in ("strings",) and side[2][1] not in self.locals):
                         m, side = (1 if side[1] == "lowerAscii" else 2), side[2]
                     modes.append(m); sides.append(side)
@@ -902,6 +928,14 @@ class _FuncCompiler:
                     self._expr(sides[0])
                     self._expr(sides[1])
                     return self.emit(OP_STREQ_CASE, modes[0] | (modes[1] << 2) | ((1 if op == "!=" else 0) << 4), -1)
+            if op == "+" and (self._stringy(ast[2]) or self._stringy(ast[3])):
+                # string concatenation where one side is visibly a string: a rope (cbh_vm.h) - the parts side by side in the
+                # lane's arena, no byte copied; equality, `in`, startsWith / endsWith / contains and size() read ropes
+                self.pb.needs_arena = True
+                self.pb.reads_string_bytes = True
+                self._expr(ast[2])
+                self._expr(ast[3])
+                return self.emit(OP_STRCAT, 0, -1)
             if op == "+" and (_builds_list(ast[2]) or _builds_list(ast[3])):
                 # list concatenation where one side is visibly a list: built in the lane's arena (any other `+` stays arithmetic,
                 # which flags lists it meets at run time)
@@ -1010,6 +1044,13 @@ class _FuncCompiler:
                 return binary(OP_INIPRANGE)
             if name in ("hasIntersection", "has_intersection") and n == 2:
                 return binary(OP_HASINTERSECTION)
+            if name in ("lowerAscii", "upperAscii") and n == 1 and target is not None:
+                # as a value (not under == / !=, which compares through the mapping directly): a rope that reads the string
+                # through the mapping (cel-go ext/strings.go: ASCII letters only)
+                self.pb.needs_arena = True
+                self.pb.reads_string_bytes = True
+                self._expr(target)
+                return self.emit(OP_STRCASE, 1 if name == "lowerAscii" else 2)
             if name == "reverse" and n == 1 and _builds_list(allargs[0]):   # (strings reverse too: only where the operand is visibly a list)
                 self.pb.needs_arena = True
                 self._expr(allargs[0])

@@ -88,6 +88,8 @@ enum cbh_tag {
   CBH_T_MAP = 7,    /* payload as LIST; len pairs (key, value) at heap[off .. off+2*len)    */
   CBH_T_TIMESTAMP = 8, /* int64 ns since the Unix epoch */
   CBH_T_DURATION = 9,  /* int64 ns */
+  CBH_T_ROPE = 10,     /* device only: a string a program put together (concatenation, lowerAscii / upperAscii as a value) - never  */
+                       /* built, kept as the list of its parts: sel:2 (LOCAL) | off:30 | parts:32                                  */
   CBH_T_ABSENT = 0xF0, /* last key of a column path missing (has() -> false, read -> error) */
   CBH_T_ERR = 0xFF     /* reading the path is a CEL error (missing / non-map intermediate)  */
 };

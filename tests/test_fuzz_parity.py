@@ -100,6 +100,12 @@ CONDITIONS_WIDE = CONDITIONS + [
     'lists.range(3).exists(i, i == size(P.attr.teams))',
     '(P.attr.teams + ["zz"]).reverse()[0] == "zz"',
     'P.attr.regions.slice(0, 2).size() == 2',
+    # strings put together on the device are ropes (cbh_vm.h): never built, read part by part
+    '(R.attr.department + ":" + R.attr.status) in ["eng:OPEN", "ops:PENDING", "legal:CLOSED"]',
+    '(P.id + "@" + R.attr.department).endsWith("@eng") || (R.kind + "/" + R.id).startsWith("doc/r1")',
+    'R.attr.status.lowerAscii() in ["open", "closed"] && R.attr.department.upperAscii() != "OPS"',
+    'P.attr.teams.exists(t, (t + "-" + R.attr.department) == "ops-ops") || size("id:" + P.id) == 5',
+    '("x" + R.attr.status).lowerAscii().contains("xo") && P.attr.teams.map(t, t + "!").exists(x, x == "core!")',
 ]
 
 
