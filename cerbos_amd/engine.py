@@ -146,7 +146,9 @@ class HipEvaluator:
             return {}
         sub = [inputs[i] for i in sel]
         if self._py_flattener is None:
-            self._py_flattener = Flattener(lt)
+            with self._ingest_lock:   # check() is called from many threads
+                if self._py_flattener is None:
+                    self._py_flattener = Flattener(lt)
         sbatch = self._py_flattener.flatten(sub, dver, dscope)
         tres, records = self.table.trace(sbatch, now_ns=now_ns, flags=flags)
         decoded = TraceDecoder(lt, sbatch, sub).decode(records, len(records), tres.status)
