@@ -80,6 +80,19 @@ std::string_view sv(Span s) { return std::string_view((const char*)s.p, (size_t)
 // map<string, google.protobuf.Value> entry: key = 1, value = 2
 struct Entry { Span key{nullptr, nullptr}; Span val{nullptr, nullptr}; };
 inline bool entry(Span e, Entry& out, bool& bad) {
+  // the shape every encoder writes - key (field 1) then value (field 2), both with one-byte lengths, nothing else - is read
+  // without the field loop; anything else takes the general walk below
+  {
+    const u8* p = e.p; const size_t n = (size_t)(e.e - e.p);
+    if (n >= 4 && p[0] == 0x0A && !(p[1] & 0x80)) {
+      const size_t kl = p[1];
+      if (2 + kl + 2 <= n && p[2 + kl] == 0x12 && !(p[3 + kl] & 0x80) && 4 + kl + (size_t)p[3 + kl] == n) {
+        out.key = Span{p + 2, p + 2 + kl};
+        out.val = Span{p + 4 + kl, e.e};
+        return true;
+      }
+    }
+  }
   Field f;
   while (next(e, f, bad)) {
     if (f.num == 1 && f.wt == 2) out.key = f.s;
@@ -107,6 +120,13 @@ inline bool value(Span m, Val& out, bool& bad) {
   // a field counts only with the wire type its declaration has (null / bool: varint, number: fixed64,
   // string / struct / list: length-delimited); anything else is an unknown field, skipped as protobuf does
   static const u8 want_wt[7] = {0xFF, 0, 1, 2, 0, 2, 2};
+  // one field filling the whole message - what an encoder writes for a scalar - without the field loop
+  {
+    const u8* p = m.p; const size_t n = (size_t)(m.e - m.p);
+    if (n == 9 && p[0] == 0x11) { out.kind = 2; memcpy(&out.v, p + 1, 8); out.s = Span{}; return true; }                      // number_value
+    if (n >= 2 && p[0] == 0x1A && !(p[1] & 0x80) && 2 + (size_t)p[1] == n) { out.kind = 3; out.v = 0; out.s = Span{p + 2, m.e}; return true; }   // string_value
+    if (n == 2 && p[0] == 0x20 && !(p[1] & 0x80)) { out.kind = 4; out.v = p[1]; out.s = Span{}; return true; }              // bool_value
+  }
   Field f;
   while (next(m, f, bad)) {
     if (f.num >= 1 && f.num <= 6 && f.wt == want_wt[f.num]) {
@@ -165,6 +185,7 @@ struct StrIndex {
 };
 
 struct Column { u32 root; std::vector<std::string> keys; };
+enum { SPAN_REQUEST_ID, SPAN_P_ID, SPAN_P_VERSION, SPAN_R_KIND, SPAN_R_VERSION, SPAN_R_ID, IN_SPAN_N };
 
 // A CEL value as the trace pass's consumer handles it (cbi_trace_pb): it keeps its CEL type for format().
 struct TVal {
@@ -206,6 +227,10 @@ struct cbi_batch {
   std::vector<u8> col_tag, heap_tag, str_bytes, str_flags;
   std::vector<u64> col_val, heap_val, tuple_perm;
   std::vector<u64> str_hash;   // hash_bytes of each batch-local string (merge of slices)
+  // Where the strings the response needs sit in each CheckInput (offset, length relative to the message; CheckInput source only):
+  // per input IN_SPAN_N pairs - request id, principal id / version, resource kind / version / id - and per input-order tuple
+  // its action.  cbi_assemble_pb then reads them instead of walking every message a second time.
+  std::vector<u32> in_span, act_span;
 };
 
 namespace {
@@ -254,7 +279,22 @@ struct Interner {
   const cbi_table* t;
   cbi_batch* b;
   StrIndex local;
+  // A small direct-mapped cache in front of the two dictionaries: the vocabularies that repeat from message to message - actions,
+  // roles, enum-like attribute values - are answered by one probe and one short compare.  Entries point into the caller's message
+  // bytes (valid for the whole call); `flags` = the CBH_SF_* bits already recorded for the string.
+  struct CacheEnt { const char* p = nullptr; u32 len = 0, id = 0, flags = 0; u64 key = 0; };
+  CacheEnt cache[256];
   u32 sid(std::string_view s, u32 flag = 0) {
+    u64 w = 0;
+    if (!s.empty()) memcpy(&w, s.data(), s.size() < 8 ? s.size() : 8);
+    const u64 key = (w ^ ((u64)s.size() << 56)) * 0x9E3779B97F4A7C15ull;
+    CacheEnt& e = cache[key >> 56];
+    if (e.key == key && e.len == s.size() && e.p && (e.flags & flag) == flag && (s.size() <= 8 || memcmp(e.p, s.data(), s.size()) == 0)) return e.id;
+    const u32 id = sid_slow(s, flag);
+    if (e.key == key && e.len == s.size() && e.id == id) e.flags |= flag; else e = CacheEnt{s.data(), (u32)s.size(), id, flag, key};
+    return id;
+  }
+  u32 sid_slow(std::string_view s, u32 flag) {
     const u64 h = hash_bytes(s);
     u32 id;
     if (t->ids.find(s, h, [this](u32 i) { return t->at(i); }, id)) return id;
@@ -541,6 +581,8 @@ static int flatten_slice(const cbi_table* t, const Source& src, uint32_t first, 
   b->tuple_req.reserve(ntup); b->tuple_action.reserve(ntup);
   b->str_off.reserve((size_t)n * 2 + 64); b->str_flags.reserve((size_t)n * 2 + 64); b->str_hash.reserve((size_t)n * 2 + 64);
   b->roles.reserve((size_t)n * 3);
+  if (!src.request) { b->in_span.resize((size_t)n * 2 * IN_SPAN_N); b->act_span.resize((size_t)ntup * 2); }
+  size_t act_at = 0;   // next slot of act_span
   b->str_off.push_back(0);
   b->str_bytes.reserve((size_t)n * 24 + (1 << 12));
   Interner in{t, b, {}, {}};
@@ -560,6 +602,7 @@ static int flatten_slice(const cbi_table* t, const Source& src, uint32_t first, 
   u32 r = 0;
   for (u32 i = 0; i < n; ++i) {
     Msg m;
+    std::string_view request_id;
     actions.clear(); roles.clear();
     for (auto& a : attrs) a.clear();
     bool bad = false;
@@ -570,7 +613,8 @@ static int flatten_slice(const cbi_table* t, const Source& src, uint32_t first, 
     } else {
       Span s{bytes + offsets[i], bytes + offsets[i + 1]}; Field f;
       while (next(s, f, bad)) { if (f.wt != 2) continue;
-        if (f.num == 2) m.resource = f.s; else if (f.num == 3) m.principal = f.s; else if (f.num == 4) actions.push_back(sv(f.s)); else if (f.num == 5) m.aux = f.s; }
+        if (f.num == 2) m.resource = f.s; else if (f.num == 3) m.principal = f.s; else if (f.num == 4) actions.push_back(sv(f.s)); else if (f.num == 5) m.aux = f.s;
+        else if (f.num == 1) request_id = sv(f.s); }
     }
     // Principal: id 1, policy_version 2, roles 3, attr 4, scope 5;  Resource: kind 1, policy_version 2, id 3, attr 4, scope 5
     Party P, Rs;
@@ -587,6 +631,16 @@ static int flatten_slice(const cbi_table* t, const Source& src, uint32_t first, 
     if (need_root[2]) { Span s = m.aux; Field f;
       while (next(s, f, bad)) if (f.num == 1 && f.wt == 2) { Entry en; if (entry(f.s, en, bad)) attrs[2].push_back(en); } }
     if (bad) return bail("malformed CheckInput at index " + std::to_string(i));
+    if (!src.request) {
+      const char* base0 = (const char*)(bytes + offsets[i]);
+      u32* sp = b->in_span.data() + (size_t)i * 2 * IN_SPAN_N;
+      auto span = [&](u32 which, std::string_view v) { sp[2 * which] = v.empty() ? 0u : (u32)(v.data() - base0); sp[2 * which + 1] = (u32)v.size(); };
+      span(SPAN_REQUEST_ID, request_id); span(SPAN_P_ID, P.id); span(SPAN_P_VERSION, P.version); span(SPAN_R_KIND, Rs.kind);
+      span(SPAN_R_VERSION, Rs.version); span(SPAN_R_ID, Rs.id);
+      u32* ap = b->act_span.data() + act_at;
+      for (std::string_view a : actions) { *ap++ = a.empty() ? 0u : (u32)(a.data() - base0); *ap++ = (u32)a.size(); }
+      act_at += 2 * actions.size();
+    }
     const size_t na = actions.size();
     const size_t nchunks = na ? (na + MAX_ACTIONS - 1) / MAX_ACTIONS : 1;
     for (size_t ch = 0; ch < nchunks; ++ch, ++r) {
@@ -874,6 +928,10 @@ static void merge_slices(const cbi_table* t, std::vector<cbi_batch*>& parts, con
       }
     }
   }
+  for (u32 k = 0; k < P; ++k) {   // slices hold consecutive inputs: their spans follow each other
+    out->in_span.insert(out->in_span.end(), parts[k]->in_span.begin(), parts[k]->in_span.end());
+    out->act_span.insert(out->act_span.end(), parts[k]->act_span.begin(), parts[k]->act_span.end());
+  }
   out->req.assign((size_t)RQ_N * R, 0);
   out->col_tag.assign((size_t)ncol * R, 0); out->col_val.assign((size_t)ncol * R, 0);
   out->roles.resize(lb[P]); out->tuple_req.resize(T); out->tuple_action.resize(T);
@@ -1054,14 +1112,38 @@ int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result*
     struct Act { std::string_view name; u32 j; };
     std::vector<Act> acts;
     std::string pol, kbuf, vbuf;
+    auto o_flags = [&](u32 x) -> u8& { return o->flags[x]; };
     u64 k = first[lo];
     const u64 k_hi = first[hi];
+    const bool spans = b->in_span.size() == (size_t)n * 2 * IN_SPAN_N && b->act_span.size() == (size_t)T * 2;
     for (u32 i = lo; i < hi; ++i) {
       Span m{bytes + offsets[i], bytes + offsets[i + 1]};
       Span principal{nullptr, nullptr}, resource{nullptr, nullptr};
       std::string_view request_id;
       acts.clear();
       bool bad = false; Field f;
+      Party P, Rs;
+      if (spans) {
+        // the flattener noted where these strings sit in the message (cbi_batch::in_span): no second walk
+        const size_t mlen = (size_t)(m.e - m.p);
+        const u32* sp = &b->in_span[(size_t)i * 2 * IN_SPAN_N];
+        bool ok = true;
+        auto at = [&](u32 which) { const u32 o = sp[2 * which], l = sp[2 * which + 1]; if ((size_t)o + l > mlen) { ok = false; return std::string_view(); } return std::string_view((const char*)m.p + o, l); };
+        request_id = at(SPAN_REQUEST_ID); P.id = at(SPAN_P_ID); P.version = at(SPAN_P_VERSION); Rs.kind = at(SPAN_R_KIND); Rs.version = at(SPAN_R_VERSION); Rs.id = at(SPAN_R_ID);
+        const u64 k_end = first[i + 1];
+        for (; k < k_end; ++k) {
+          const u32 o = b->act_span[2 * k], l = b->act_span[2 * k + 1];
+          if ((size_t)o + l > mlen) { ok = false; break; }
+          std::string_view name((const char*)m.p + o, l); const u32 j = inv[k]; bool dup = false;
+          for (Act& a : acts) if (a.name == name) {
+            if (res->effect[j] == CBH_EFFECT_DENY || res->effect[a.j] != CBH_EFFECT_DENY) a.j = j;
+            dup = true; break;
+          }
+          if (!dup) acts.push_back(Act{name, j});
+          if (res->status) { u8 st = res->status[j]; if (st == CBH_ST_UNSUPPORTED) o_flags(i - lo) |= CBI_OUT_UNSUPPORTED; else if (st == CBH_ST_CEL_ERROR) o_flags(i - lo) |= CBI_OUT_CEL_ERROR; }
+        }
+        if (!ok) return bail("batch does not belong to these inputs");
+      } else {
       while (next(m, f, bad)) { if (f.wt != 2) continue;
         if (f.num == 1) request_id = sv(f.s); else if (f.num == 2) resource = f.s; else if (f.num == 3) principal = f.s;
         else if (f.num == 4) {
@@ -1075,13 +1157,25 @@ int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result*
           if (!dup) acts.push_back(Act{name, j});
           if (res->status) { u8 st = res->status[j]; if (st == CBH_ST_UNSUPPORTED) o->flags[i - lo] |= CBI_OUT_UNSUPPORTED; else if (st == CBH_ST_CEL_ERROR) o->flags[i - lo] |= CBI_OUT_CEL_ERROR; }
         } }
-      Party P, Rs;
       { Span s = principal; while (next(s, f, bad)) { if (f.wt != 2) continue; if (f.num == 1) P.id = sv(f.s); else if (f.num == 2) P.version = sv(f.s); } }
       { Span s = resource; while (next(s, f, bad)) { if (f.wt != 2) continue; if (f.num == 1) Rs.kind = sv(f.s); else if (f.num == 2) Rs.version = sv(f.s); else if (f.num == 3) Rs.id = sv(f.s); } }
       if (bad) return bail("malformed CheckInput at index " + std::to_string(i));
+      }
       std::vector<u8>& ob = o->bytes;
-      put_str(ob, 1, request_id);
-      put_str(ob, 2, Rs.id);
+      // One reservation for everything but the derived-role names, then plain pointer writes: the bound is the sum of the
+      // strings plus a fixed allowance per field (two bytes of tag + at most five of a length); policy keys come from
+      // policy_key (checked against its allowance below).
+      size_t bound = 32 + request_id.size() + Rs.id.size();
+      for (const Act& a : acts) bound += a.name.size() + 64;
+      const size_t at0 = ob.size();
+      size_t cap = at0 + bound + acts.size() * 256;   // + room for a policy key and a scope per action
+      if (ob.size() < cap) ob.resize(cap);
+      u8* w = ob.data() + at0;
+      auto wv = [&](u64 v) { while (v >= 0x80) { *w++ = (u8)(v | 0x80); v >>= 7; } *w++ = (u8)v; };
+      auto wld = [&](u32 field, std::string_view v) { wv((u64)field << 3 | 2); wv(v.size()); if (!v.empty()) { memcpy(w, v.data(), v.size()); w += v.size(); } };
+      auto wstr = [&](u32 field, std::string_view v) { if (!v.empty()) wld(field, v); };
+      wstr(1, request_id);
+      wstr(2, Rs.id);
       u32 pol_word = 0xFFFFFFFFu;   // `pol` holds the key of this word (the actions of one input mostly share it)
       for (const Act& a : acts) {
         if (res->policy && res->policy[a.j] != pol_word) {
@@ -1095,18 +1189,24 @@ int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result*
         }
         // sizes first, then one pass of writes: entry {1: action, 2: ActionEffect {1: effect, 2: policy, 3: scope}}
         const std::string_view pol_s = res->policy ? std::string_view(pol) : std::string_view();
+        if (pol_s.size() + scope_s.size() > 224) {   // longer than the allowance: grow (keys this long are unusual)
+          const size_t used = (size_t)(w - ob.data());
+          ob.resize(ob.size() + pol_s.size() + scope_s.size());
+          w = ob.data() + used;
+        }
         const u8 effect = res->effect[a.j];
         auto ld_size = [](size_t n) { return 1 + varint_size(n) + n; };
         const size_t eff_len = (effect ? 1 + varint_size(effect) : 0) + (pol_s.empty() ? 0 : ld_size(pol_s.size())) +
                                (scope_s.empty() ? 0 : ld_size(scope_s.size()));
         const size_t ent_len = ld_size(a.name.size()) + ld_size(eff_len);
-        put_varint(ob, 3u << 3 | 2); put_varint(ob, ent_len);
-        put_ld(ob, 1, a.name);
-        put_varint(ob, 2u << 3 | 2); put_varint(ob, eff_len);
-        if (effect) { ob.push_back(1 << 3 | 0); put_varint(ob, effect); }
-        put_str(ob, 2, pol_s);
-        put_str(ob, 3, scope_s);
+        wv(3u << 3 | 2); wv(ent_len);
+        wld(1, a.name);
+        wv(2u << 3 | 2); wv(eff_len);
+        if (effect) { *w++ = 1 << 3 | 0; wv(effect); }
+        wstr(2, pol_s);
+        wstr(3, scope_s);
       }
+      ob.resize((size_t)(w - ob.data()));
       for (u32 d = 0; d < 64 && d < t->dr_names.size(); ++d) if ((edr[i] >> d) & 1) put_ld(ob, 4, t->dr_names[d]);
       o->offsets.push_back(ob.size());
     }
