@@ -589,6 +589,7 @@ static int flatten_slice(const cbi_table* t, const Source& src, uint32_t first, 
   in.local.reserve(n);
   Encoder encd{in, b};
   ScopeCache scopes;
+  Interner::Memo scope_memos[2];
   auto RQ = [&](u32 f, u32 r) -> u32& { return b->req[(size_t)f * R + r]; };
 
   // per message scratch, reused
@@ -650,12 +651,17 @@ static int flatten_slice(const cbi_table* t, const Source& src, uint32_t first, 
       std::string_view p_ver = P.version.empty() ? dver : P.version;
       std::string_view r_ver = Rs.version.empty() ? dver : Rs.version;
       RQ(RQ_PRINCIPAL_ID, r) = in.sid(P.id);
-      RQ(RQ_P_SCOPE, r) = scope_word(t, scopes, p_scope);
+      auto scope_memo = [&](u32 slot, std::string_view sc) {   // scopes rarely change from one message to the next
+        Interner::Memo& mk = scope_memos[slot];
+        if (!(mk.set && mk.s == sc)) { mk.s = sc; mk.id = scope_word(t, scopes, sc); mk.set = true; }
+        return mk.id;
+      };
+      RQ(RQ_P_SCOPE, r) = scope_memo(0, p_scope);
       RQ(RQ_P_VERSION, r) = in.sid_memo(0, p_ver);
       { Interner::Memo& mk = in.memo[1];   // keyed by the raw kind, holds the id of the sanitised one
         if (!(mk.set && mk.s == Rs.kind)) { mk.s = Rs.kind; mk.id = in.sid(sanitize(Rs.kind, kind_buf), SF_KIND); mk.set = true; }
         RQ(RQ_KIND, r) = mk.id; }
-      RQ(RQ_R_SCOPE, r) = scope_word(t, scopes, r_scope);
+      RQ(RQ_R_SCOPE, r) = scope_memo(1, r_scope);
       RQ(RQ_R_VERSION, r) = in.sid_memo(2, r_ver);
       RQ(RQ_ROLE_OFF, r) = (u32)b->roles.size();
       RQ(RQ_ROLE_CNT, r) = (u32)roles.size();
