@@ -659,7 +659,10 @@ static int flatten_slice(const cbi_table* t, const Source& src, uint32_t first, 
       RQ(RQ_P_SCOPE, r) = scope_memo(0, p_scope);
       RQ(RQ_P_VERSION, r) = in.sid_memo(0, p_ver);
       { Interner::Memo& mk = in.memo[1];   // keyed by the raw kind, holds the id of the sanitised one
-        if (!(mk.set && mk.s == Rs.kind)) { mk.s = Rs.kind; mk.id = in.sid(sanitize(Rs.kind, kind_buf), SF_KIND); mk.set = true; }
+        if (!(mk.set && mk.s == Rs.kind)) { mk.s = Rs.kind; const std::string_view sk = sanitize(Rs.kind, kind_buf);
+          // a rewritten kind lives in the reused scratch string, not in the message bytes: it must never enter the cache
+          // in front of the dictionaries (whose entries point at what they were made from)
+          mk.id = sk.data() == Rs.kind.data() ? in.sid(sk, SF_KIND) : in.sid_slow(sk, SF_KIND); mk.set = true; }
         RQ(RQ_KIND, r) = mk.id; }
       RQ(RQ_R_SCOPE, r) = scope_memo(1, r_scope);
       RQ(RQ_R_VERSION, r) = in.sid_memo(2, r_ver);

@@ -101,6 +101,11 @@ def test_edge_cases():
     weird += [{"principal": {"id": "z", "roles": ["employee"]}, "resource": {"kind": k, "id": "1"}, "actions": ["view"]}
               for k in ("a-b\n", "9abc-x", "a::b", "a:b:", "a@b/c-d:e.f", "x--y@@z", "ü-x", ":a")]
     _same(lt, weird)
+    # old-form kinds that share length and the first eight bytes of their rewritten form: the rewritten text lives in a
+    # scratch string the ingest reuses - it must not be answered from the cache in front of the string dictionaries
+    alike = [{"principal": {"id": "z", "roles": ["employee"]}, "resource": {"kind": k, "id": "1"}, "actions": ["view"]}
+             for k in ("doc:public_aa", "doc:public_ab", "doc:public_aa", "doc-public@ac", "doc/public-ad", "doc:public_ab")]
+    _same(lt, alike)
     _same(lt, [])
 
 
