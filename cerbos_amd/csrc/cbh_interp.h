@@ -538,6 +538,8 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
       case OP_LISTOP: {     // a = 0 intersect / 1 except / 2 concatenation: a new list in the lane's arena
         Val y = TOPV(0), x = TOPV(1); --sp;
         if (x.t != CBH_T_LIST || y.t != CBH_T_LIST) { FAILTOP2(x, y, CBH_ERR_NO_SUCH_OVERLOAD); break; }
+        // intersect iterates the SHORTER list (cerbos_lib.go:434-437 swaps its operands): order and duplicates follow it
+        if (a == 0 && cont_len(x.v) > cont_len(y.v)) { const Val sw = x; x = y; y = sw; }
         const u32 nx = cont_len(x.v), ny = cont_len(y.v), need = a == 2 ? nx + ny : nx;
         if (need > CBH_ARENA_ENTRIES - ap || nx > CBH_ARENA_ENTRIES || ny > CBH_ARENA_ENTRIES) {
           if (live) L.status |= CBH_ST_UNSUPPORTED;

@@ -13,6 +13,8 @@ instruction is reported with status CBH_ST_UNSUPPORTED (never a silently wrong e
 """
 from __future__ import annotations
 
+import re
+
 import struct
 
 from ..cel import parser as celparser
@@ -556,6 +558,9 @@ _TS_GETTERS = {"getFullYear": 0, "getMonth": 1, "getDayOfYear": 2, "getDayOfMont
                "getHours": 6, "getMinutes": 7, "getSeconds": 8, "getMilliseconds": 9}
 
 
+_ATOI = re.compile(r"[+-]?[0-9]+", re.ASCII)
+
+
 def _fixed_zone_seconds(ast):
     """Seconds east of UTC of a constant time-zone argument cel-go reads without its zone database (timestamp.go
     timeZone(): a string with a ':' is "[+-]hh:mm"), or None.  "UTC" and "" load as UTC."""
@@ -567,13 +572,14 @@ def _fixed_zone_seconds(ast):
     if ":" not in tz:
         return None
     hh, _, mm = tz.partition(":")
-    try:
-        h, m = int(hh), int(mm)
-    except ValueError:
+    # strconv.Atoi's syntax, not Python's int(): ASCII digits behind an optional sign - no blanks, no '_', no other
+    # scripts' digits (cel-go answers those with an error, i.e. a condition that is false); anything else stays UNSUPPORTED
+    if not (_ATOI.fullmatch(hh) and _ATOI.fullmatch(mm)):
         return None
+    h, m = int(hh), int(mm)
     if not (-23 <= h <= 23 and 0 <= m <= 59):
         return None
-    neg = hh.strip().startswith("-")
+    neg = tz[0] == "-"     # cel-go tests val[0]
     return (-1 if neg else 1) * (abs(h) * 3600 + m * 60)
 
 

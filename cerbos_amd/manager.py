@@ -19,10 +19,40 @@ from .lower.blob import LoweredTable
 
 
 class _Version:
-    __slots__ = ("number", "lowered", "table", "flattener", "ingest")
+    """One published table: the device table (reference counted inside the library) and the host-side pieces that belong to
+    it.  The ingest table is host memory only the Python side owns: it lives until the version is retired AND its last
+    lease is back (a request may still be flattening / assembling against it when the swap happens)."""
+    __slots__ = ("number", "lowered", "table", "flattener", "ingest", "_lock", "_leases", "_retired")
 
     def __init__(self, number, lowered, table, flattener, ingest):
         self.number, self.lowered, self.table, self.flattener, self.ingest = number, lowered, table, flattener, ingest
+        self._lock, self._leases, self._retired = threading.Lock(), 0, False
+
+    def _lease(self):
+        with self._lock:
+            self._leases += 1
+
+    def _unlease(self):
+        with self._lock:
+            self._leases -= 1
+            last = self._retired and self._leases == 0
+        if last:
+            self._close_ingest()
+
+    def retire(self):
+        """The owner's references go: the device table now (it drains in-flight batches by itself), the ingest table with
+        the last lease."""
+        self.table.close()
+        with self._lock:
+            self._retired = True
+            idle = self._leases == 0
+        if idle:
+            self._close_ingest()
+
+    def _close_ingest(self):
+        ing, self.ingest = self.ingest, None
+        if ing is not None:
+            ing.close()
 
 
 class TableLease:
@@ -30,7 +60,9 @@ class TableLease:
 
     def __init__(self, version: _Version):
         self.v = version
+        version._lease()
         self.table = capi.Table.borrow(version.table)   # this request's own reference (cbh_table_retain)
+        self._released = False
 
     number = property(lambda self: self.v.number)
     lowered = property(lambda self: self.v.lowered)
@@ -38,7 +70,11 @@ class TableLease:
     ingest = property(lambda self: self.v.ingest)
 
     def release(self):
+        if self._released:
+            return
+        self._released = True
         self.table.close()
+        self.v._unlease()
 
     def __enter__(self):
         return self
@@ -73,7 +109,7 @@ class TableManager:
             old, self._cur = self._cur, _Version(self._n, lowered, table, flattener, ingest)
             n = self._n
         if old is not None:
-            old.table.close()   # the owner's reference: the image is freed once in-flight batches have drained
+            old.retire()   # the owner's references: the image is freed once in-flight batches have drained
         return n
 
     def swap_pb(self, wire: bytes, globals_=None) -> int:
@@ -106,6 +142,4 @@ class TableManager:
         with self._lock:
             old, self._cur = self._cur, None
         if old is not None:
-            old.table.close()
-            if old.ingest is not None:
-                old.ingest.close()
+            old.retire()

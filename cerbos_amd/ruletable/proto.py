@@ -318,6 +318,7 @@ def _dec_row(buf):
          "derived_role_condition": None, "effect": None, "scope": "", "scope_permissions": 0, "version": "",
          "origin_derived_role": "", "emit_output": None, "name": "", "principal": "", "params": None,
          "derived_role_params": None, "evaluation_key": None, "policy_kind": KIND_RESOURCE, "from_role_policy": False}
+    legacy_key = None
     for num, wt, v in _fields(buf):
         if wt == 2:
             if num == 1:
@@ -351,6 +352,8 @@ def _dec_row(buf):
                 r["params"] = _dec_params(v)
             elif num == 17:
                 r["derived_role_params"] = _dec_params(v)
+            elif num == 18:
+                legacy_key = v.decode("utf-8")
             elif num == 21:
                 r["evaluation_key"] = _dec_eval_key(v)
         elif wt == 0:
@@ -362,6 +365,10 @@ def _dec_row(buf):
                 r["policy_kind"] = _KIND_NAME.get(v, KIND_RESOURCE)
             elif num == 20:
                 r["from_role_policy"] = bool(v)
+    if r["evaluation_key"] is None and legacy_key is not None:
+        # tables serialized before the tuple existed: the string key alone, as the rule name of an otherwise empty tuple
+        # (index/core.go:134-137 makeEvaluationKeyTuple's fallback)
+        r["evaluation_key"] = ("",) * 7 + (legacy_key, 0)
     return r
 
 

@@ -1240,6 +1240,8 @@ def _m_slice(env, lst, a, b):
 
 def _intersect(env, a, b):
     a, b = _to_set_list(a), _to_set_list(b)
+    if len(a) > len(b):     # cerbos_lib.go:434-437: the shorter list is the one iterated
+        a, b = b, a
     return [x for x in a if any(cel_equal(x, y) for y in b)]
 
 

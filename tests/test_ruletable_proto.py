@@ -50,6 +50,12 @@ def test_wire_format_against_hand_assembled_bytes():
     assert r["condition"] == ("expr", "R.attr.public == true") and r["scope_permissions"] == 1 and r["version"] == "default"
     assert r["policy_kind"] == "RESOURCE" and r["name"] == "rule-001" and r["scope"] == ""
     assert rt["resource_scopes"] == [""] and rt["scope_permissions"] == {"": 1}
+    # a table serialized before EvaluationKeyTuple existed carries the string key only (field 18, two-byte tag): it becomes
+    # the rule name of an otherwise empty tuple (index/core.go:134-137); the tuple (field 21) wins when both are there
+    legacy = row + bytes([(18 << 3 | 2) & 0x7F | 0x80, 1, 5]) + b"k#001"
+    assert decode_rule_table(ld(1, legacy))["rules"][0]["evaluation_key"] == ("",) * 7 + ("k#001", 0)
+    both = legacy + bytes([(21 << 3 | 2) & 0x7F | 0x80, 1, 4]) + ld(8, b"rn")
+    assert decode_rule_table(ld(1, both))["rules"][0]["evaluation_key"] == ("",) * 7 + ("rn", 0)
 
 
 def _same_rows(a, b):
