@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define CBH_BLOB_MAGIC 0x31484243u /* "CBH1" */
-#define CBH_BLOB_VERSION 19u
+#define CBH_BLOB_VERSION 20u
 
 struct CbhBlobHeader {  // 32 bytes
   uint32_t magic;
@@ -71,6 +71,8 @@ enum CbhSectionId {
                               // u32 n_templates, {u32 rule word, u32 parts, node}*; node = u8 kind: 0 hole + u32 j | 1 const + u8 type (0 null,
                               // 1 bool + u8, 2 int + i64, 3 double + f64, 4 string + u32 len + bytes) | 2 list + u32 n + nodes | 3 map + u32 n +
                               // (key node, value node)* | 4 format + u32 len + bytes + u32 n + nodes
+  CBH_SEC_ROWX = 40,         // u32[n_rows][8]  what cbh_check_walk2.h reads besides the record (CbhRowXField); rows with CBH_ROW_F_X
+  CBH_SEC_RPX = 41,          // u32[n_rprows][16] role-policy rules for that kernel (CbhRpxField)
   CBH_SEC_ROWPAT = 29,       // u32[n_rows][8]  pattern halves of the rule records (CbhRowPatField order)
   CBH_SEC_ACTION_CLASS = 28, // u8[K] class (0..61) of a string that is a literal rule action of a resource policy, 63 = any other string
   CBH_SEC_HOST_NAMES = 27,   // host only: {u32 n, {u16 len, bytes}*} policy keys (CBH_P_TABLE ids), then the same for derived-role names
@@ -96,6 +98,8 @@ enum CbhMeta {
   CBH_M_NFA_WORDS_KIND = 15,
   CBH_M_THEAP_LEN = 16,
   CBH_M_MAX_LOCALS = 17,
+  CBH_M_GSLOTS_GENERIC = 18, // evaluation-site slots (cbh_check_walk2.h) of sites the walk cannot decide inline for ANY batch: slots 0 .. n - 1
+  CBH_M_GSLOTS_ALL = 19,     // ... plus the sites it can decide inline for plain scalars only: slots 0 .. n - 1
   CBH_META_N = 24
 };
 #define CBH_MF_USES_RUNTIME_EDR 1u
@@ -108,6 +112,7 @@ enum CbhMeta {
 #define CBH_MF_NEEDS_ARENA 1024u          /* some program builds a list (filter, map, intersect, except, list +): the kernels that run the
                                           * operand-stack interpreter get CBH_ARENA_ENTRIES values of LDS per lane for them (cbh_vm.h) */
 #define CBH_MF_FLAT_CLOSED 512u           /* FLAT and every condition is evaluated inline by the flat kernel: no evaluator call needed for plain batches */
+#define CBH_MF_WALK2 2048u                /* cbh_check_walk2.h decides this table (batch shape and mode permitting) */
 #define CBH_MF_FLAT 256u                  /* resource policies only, leaf conditions, every record decided by class masks: cbh_check_flat.h */
 #define CBH_MF_READS_REQUEST_STRINGS 64u /* some program reads a raw request string (CBH_RQ_S_*): upload those fields */
 
@@ -123,7 +128,10 @@ enum CbhBucketType {
   CBH_B_PPEXISTS = 4,  // (ver sid, scope idx, 0) -> exists (any principal policy row)
   CBH_B_RPRES = 5,     // (ver sid, scope idx, 0) -> v0 off, v1 cnt into U32POOL of resource pattern refs of role-policy rows
   CBH_B_PARENTS = 6,   // (scope idx, role sid, 0) -> v0 off, v1 cnt into U32POOL of ancestor role sids
-  CBH_B_RESEXISTS = 7, // (ver sid, kind sid, scope idx): same key as RESOURCE, present for every resource policy
+  CBH_B_RESEXISTS = 7, // (ver sid, kind sid, scope idx): same key as RESOURCE, present for every resource policy; v1, v2 = union of the
+                       // literal role class masks of its rules, v3 = union of their role glob masks (Index.Query's base test)
+  CBH_B_RPROLES = 8,   // (ver sid, scope idx, 0) -> v0 off, v1 cnt into U32POOL: the roles with a role policy at that scope, sorted by
+                       // name (the order of a role's ancestor list, ruletable/build.py)
 };
 
 // Condition reference (row / derived-role cond fields): bit31 set -> the program at (ref & ~bit31)
@@ -184,6 +192,33 @@ enum CbhRowPatField {   // CBH_SEC_ROWPAT: the pattern half of record i, 8 dword
 #define CBH_ROW_F_TREE_EMBEDDED 256u
 #define CBH_ROW_F_DRTREE_EMBEDDED 512u
 #define CBH_TREE_STRIP_MAX 8u
+/* cbh_check_walk2.h.  CBH_ROW_F_XEXACT: the record's match is decided exactly by class masks + glob masks (every resource-policy
+ * record of a CBH_MF_WALK2 table).  CBH_ROW_F_X: CBH_SEC_ROWX[row] holds something - glob masks (then also the class masks of
+ * the LITERAL list entries only; the record's own masks say "every class" for a list with a glob) or evaluation-site slots. */
+#define CBH_ROW_F_X 1024u
+#define CBH_ROW_F_XEXACT 2048u
+enum CbhRowXField {
+  CBH_ROWX_GSLOTS = 0,   // slot of the condition | slot of the derived-role condition << 16 (CBH_GSLOT_NONE = none)
+  CBH_ROWX_GLOBS = 1,    // action glob mask | role glob mask << 16 (bit = glob index in the dimension, < CBH_W2_MAX_GLOBS)
+  CBH_ROWX_ROLES = 2,    // u64: classes of the literal roles
+  CBH_ROWX_ACTIONS = 4,  // u64: classes of the literal actions
+  CBH_ROWX_NF = 8
+};
+#define CBH_GSLOT_NONE 0xFFFFu
+#define CBH_W2_MAX_GLOBS 16u
+#define CBH_W2_MAX_GSLOTS 256u
+#define CBH_W2_SLOTS_PER_WORD 16u   /* four result bits per site: 1 satisfied, 2 CEL error, 8 outside the device subset */
+enum CbhRpxField {       // one role-policy rule (same index as CBH_SEC_RPROWS)
+  CBH_RPX_RESOURCE = 0,  // pattern ref (kind dim)
+  CBH_RPX_CNT = 1,       // CBH_RP_ALLOW_CNT word (count | CBH_RP_F_*)
+  CBH_RPX_COND = 2,      // program of the user condition or CBH_NONE
+  CBH_RPX_GSLOT = 3,
+  CBH_RPX_ACTIONS = 4,   // u64: classes of the literal allow actions
+  CBH_RPX_AGLOBS = 6,    // glob mask of the allow list (action dim)
+  CBH_RPX_HOW = 7,       // 1: dwords 8..15 = the condition's fused-leaf record, 2: a tree descriptor (CBH_ROW_F_TREE_EMBEDDED)
+  CBH_RPX_LEAF = 8,
+  CBH_RPX_NF = 16
+};
 enum CbhRpField { // role-policy rows
   CBH_RP_RESOURCE = 0,  // pattern ref (kind dim)
   CBH_RP_ALLOW_OFF = 1, // into U32POOL: pattern refs (action dim)
@@ -217,6 +252,7 @@ enum CbhDrxField { // CBH_SEC_DRX: one 16-dword record per CBH_SEC_DR record, sa
   CBH_DRX_FLAGS = 2,   // bit 0: dwords 8..15 hold the condition's fused-leaf record; bit 1: a tree descriptor (CBH_ROW_F_TREE_EMBEDDED)
   CBH_DRX_COND = 3,    // program or CBH_NONE
   CBH_DRX_NAME = 4,    // bit index into the edr mask
+  CBH_DRX_GSLOT = 5,   // evaluation-site slot of the condition (cbh_check_walk2.h), CBH_GSLOT_NONE = none
   CBH_DRX_LEAF = 8,
   CBH_DRX_NF = 16
 };

@@ -1,0 +1,725 @@
+// cbh_walk2_kernel - the decision kernel for everything a table can hold: principal policies, role policies and parent
+// roles, glob patterns, derived roles, conditions of any shape - in the flat kernel's form (cbh_check_flat.h): a wave
+// walks scopes -> records ONCE, every lane carries all its role walks side by side as a bit vector (bit 8 r + k = role
+// r's walk for action k; at most eight actions and four roles per request, outside strict mode - anything else stays
+// on cbh_check_wave.h), lanes merge by scope node deepest first, records are decided by class masks and glob bits.
+//
+// What differs from the flat kernel, which it generalises:
+//   * Glob patterns.  A lane keeps, per action and per role, the match bits of its string for the first CBH_W2_MAX_GLOBS
+//     patterns of the dimension (from the table's precomputed bits or cbh_resolve_globs_kernel's); a record with a glob in
+//     a list carries the list's glob mask beside the class mask of its literals (CBH_SEC_ROWX).
+//   * Parent roles.  A role slot is the class SET of [role] ++ ancestors (index.go:716-742), a 64-bit mask.
+//   * Principal policies (check.go:195, the first pass): lanes differ in their principal, so the few lanes that have a
+//     policy at all (a per-lane directory probe tells) are walked group by group before the resource walk; an action a
+//     principal policy decides never enters the resource walk (check.go:445-448).
+//   * Role policies (index.go:352-530): the reference walks a request role's [role] ++ ancestors list (ancestors sorted by
+//     name).  At a scope with role policies every slot first meets the policy of its OWN role, then the roles that have a
+//     policy there are visited in name order and a slot whose set holds one takes that rule's synthetic DENYs.  Index.Query's base test (index.go:250-305) comes from the union of the
+//     bucket's role masks, kept in the directory.
+//   * Conditions the walk cannot decide inline - generic programs, classified leaves that meet an int / uint / container
+//     value - are EVALUATION SITES: cbh_walk2_pre_kernel, launched first when the table and batch have any, runs the same
+//     walk without effects, evaluates every site a lane's roles and actions can reach with the shared evaluator
+//     (cbh_check_wave.h eval_ref: the operand-stack interpreter and its ~230 registers live in THAT kernel) and leaves
+//     four result bits per site and request; the walk reads them.  A site's slot is unique among what one request can
+//     reach (lower/blob.py).  A site the reference would not have evaluated is evaluated in vain, never consulted.
+//   * runtime.effectiveDerivedRoles reads the derived roles of the scope being walked (check.go:237-282): the pre-pass
+//     evaluates a scope's definitions before that scope's sites.
+// Same contract, same outputs, bit for bit, as cbh_check_wave.h.
+#pragma once
+#include "cbh_check_flat.h"
+
+#define CBH_W2_WAVES CBH_FLAT_WAVES
+#define CBH_W2_THREADS (CBH_W2_WAVES * CBH_BLOCK)
+#define CBH_W2_MAX_RP_ROLES 32u   /* roles with a role policy at one (version, scope) */
+
+struct __attribute__((aligned(32))) TblRowX { u32 gslots, globs, rm_lo, rm_hi, am_lo, am_hi, p0, p1; };
+struct __attribute__((aligned(64))) TblRpx { u32 resource, cnt, cond, gslot, am_lo, am_hi, ag, how; LeafRec leaf; };
+
+// Dynamic LDS of one workgroup, per wave: [column cache][list arena (pre-pass of a table that builds lists)][scope chain]
+// [per-action notes][site results (pre-pass)], then once per group the two class tables.
+struct W2Layout { u32 cc_dw, arena_dw, chain_dw, aux_dw, gacc_dw, wave_dw, cls_bytes; };
+#ifndef CBH_HOSTSIM
+__host__ __device__
+#endif
+static inline W2Layout w2_layout(u32 ncc, bool arena, u32 table_max_depth, u32 table_scopes, bool pre, u32 n_gwords, u32 table_strings) {
+  W2Layout l;
+  const u32 depth = table_max_depth < CBH_FLAT_MAX_DEPTH ? table_max_depth : CBH_FLAT_MAX_DEPTH;
+  l.cc_dw = 3u * ncc * CBH_BLOCK;
+  l.arena_dw = (pre && arena) ? CBH_ARENA_ENTRIES * CBH_BLOCK * 9u / 4u : 0u;
+  l.chain_dw = pre ? 0u : (table_scopes <= 256u ? depth * (CBH_BLOCK / 4u) : depth * CBH_BLOCK);
+  l.aux_dw = pre ? 0u : CBH_W2_NA * CBH_BLOCK;
+  l.gacc_dw = pre ? n_gwords * CBH_BLOCK * 2u : 0u;
+  l.wave_dw = l.cc_dw + l.arena_dw + l.chain_dw + l.aux_dw + l.gacc_dw;
+  l.cls_bytes = table_strings <= CBH_FLAT_LDS_STRINGS ? ((2u * table_strings + 15u) & ~15u) : 0u;
+  return l;
+}
+static inline size_t w2_lds_bytes(const W2Layout& l, u32 waves) { return (size_t)l.wave_dw * 4u * waves + l.cls_bytes; }
+// words of site results a launch needs: none for a table without sites, the generic sites only for a batch of plain scalars
+static inline u32 w2_gwords(u32 gslots_generic, u32 gslots_all, bool plain_tags) {
+  const u32 n = plain_tags ? gslots_generic : gslots_all;
+  return (n + CBH_W2_SLOTS_PER_WORD - 1u) / CBH_W2_SLOTS_PER_WORD;
+}
+
+__device__ __forceinline__ u32 w2_rep_role(u32 rbits) {   // bit r -> byte r
+  const u32 x = rbits & 0xFu;
+  return ((x | (x << 7) | (x << 14) | (x << 21)) & 0x01010101u) * 0xFFu;
+}
+
+template <bool PRE>
+__device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const W2Layout& ly) {
+  const TableDev& t = ka_regs.t;
+  const BatchDev& b = ka_regs.b;
+  const OutDev& o = ka_regs.o;
+  const u32 flags = ka_regs.flags;
+  const u32 wave = threadIdx.x / CBH_BLOCK;
+  constexpr u32 NA = CBH_W2_NA, NR = CBH_W2_NR;
+  const u32 rix = b.req_lo + blockIdx.x * (PRE ? CBH_BLOCK : CBH_W2_THREADS) + threadIdx.x;
+  const u32 NRQ = b.n_requests;
+  bool valid = rix < b.req_hi;
+  if ((flags & CBH_FI_SKIP_WIDE) && valid)   // wave-uniform test first: the two loads only for a batch that has wider requests
+    valid = !cbh_is_wide(b.req_u32[(size_t)CBH_RQ_ACT_CNT * NRQ + rix], b.req_u32[(size_t)CBH_RQ_ROLE_CNT * NRQ + rix]);
+  const u32 req = valid ? rix : b.req_lo;
+  const bool has_pp = (t.flags & CBH_MF_HAS_PRINCIPAL_POLICIES) != 0;
+  const bool has_parents = (t.flags & CBH_MF_HAS_PARENT_ROLES) != 0;
+  const bool has_rolepol = (t.flags & CBH_MF_HAS_ROLE_POLICIES) != 0;
+  const bool aglobs = t.nfa_words[DIM_ACTION] != 0, rglobs = t.nfa_words[DIM_ROLE] != 0;
+#define RQ(f) b.req_u32[(size_t)(f) * NRQ + req]
+  const u32 pid = RQ(CBH_RQ_PRINCIPAL_ID), kind = RQ(CBH_RQ_KIND), r_scope = RQ(CBH_RQ_R_SCOPE), r_ver = RQ(CBH_RQ_R_VERSION);
+  const u32 role_off = RQ(CBH_RQ_ROLE_OFF), act_off = RQ(CBH_RQ_ACT_OFF);
+  const u32 role_cnt = valid ? RQ(CBH_RQ_ROLE_CNT) : 0, act_cnt = valid ? RQ(CBH_RQ_ACT_CNT) : 0;   // <= 4 / <= 8 (host-checked)
+  u32 p_scope = 0, p_ver = 0;
+  if (has_pp) { p_scope = RQ(CBH_RQ_P_SCOPE); p_ver = RQ(CBH_RQ_P_VERSION); }
+#undef RQ
+  fill_column_cache(c, b, NRQ, req);
+  const u32 all = (1u << act_cnt) - 1u;
+  const u32 max_depth = t.max_depth < CBH_FLAT_MAX_DEPTH ? t.max_depth : CBH_FLAT_MAX_DEPTH;
+  const bool chain8 = t.n_scopes <= 256u;
+  CBH_L u32* wave_lds = (CBH_L u32*)cbh_dyn_lds + wave * ly.wave_dw;
+  CBH_L u32* chain_si = wave_lds + ly.cc_dw + ly.arena_dw;
+  CBH_L u8* chain_si8 = (CBH_L u8*)chain_si;
+  CBH_L u32* aux = chain_si + ly.chain_dw;                                   // [action][lane]: see the fold
+  CBH_L u64* gacc = (CBH_L u64*)(wave_lds + ly.cc_dw + ly.arena_dw + ly.chain_dw + ly.aux_dw);   // [word][lane] (pre-pass)
+  CBH_L u8* cls_lds = (CBH_L u8*)((CBH_L u32*)cbh_dyn_lds + (PRE ? 1u : CBH_W2_WAVES) * ly.wave_dw);
+  const bool cls_in_lds = ly.cls_bytes != 0;
+  if (cls_in_lds) {
+    for (u32 i = threadIdx.x; i < t.K; i += (PRE ? CBH_BLOCK : CBH_W2_THREADS)) { cls_lds[i] = t.action_class[i]; cls_lds[t.K + i] = t.role_class[i]; }
+  }
+  if (PRE) { for (u32 w = 0; w < b.n_gwords; ++w) gacc[w * CBH_BLOCK + c.tid] = 0; }
+  else {
+#pragma unroll
+    for (u32 k = 0; k < NA; ++k) aux[k * CBH_BLOCK + c.tid] = CBH_NONE;
+  }
+
+  // ---- actions and roles: ids -> classes (63 = a string no rule names) and glob match bits
+  u32 aid[NA], rid[NR], ac[NA];
+  const bool spec = b.n_tuples >= 4u;
+  const u32 spec_ix = (4u * req + 4u <= b.n_tuples) ? 4u * req : 0u;
+  u32x4u sp; sp.x = sp.y = sp.z = sp.w = 0;
+  if (spec) sp = load_u32x4(b.tuple_action + spec_ix);
+#pragma unroll
+  for (u32 k = 0; k < NR; ++k) rid[k] = b.roles[k < role_cnt ? role_off + k : 0u];
+  const bool spec_hit = spec && act_cnt == 4u && act_off == spec_ix;
+  aid[0] = sp.x; aid[1] = sp.y; aid[2] = sp.z; aid[3] = sp.w;
+  if (!spec_hit) {
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) aid[k] = b.tuple_action[k < act_cnt ? act_off + k : 0u];
+  }
+#pragma unroll
+  for (u32 k = 4; k < NA; ++k) aid[k] = 0;
+  if (wave_ballot(act_cnt > 4u) != 0) {
+#pragma unroll
+    for (u32 k = 4; k < NA; ++k) aid[k] = b.tuple_action[k < act_cnt ? act_off + k : 0u];
+  }
+  const u32 kmax = t.K ? t.K - 1u : 0u;
+  u32 rcls[NR];
+  if (cls_in_lds) __syncthreads();
+#pragma unroll
+  for (u32 k = 0; k < NA; ++k) {
+    const u32 ix = aid[k] < t.K ? aid[k] : kmax;
+    const u32 ca = cls_in_lds ? (u32)cls_lds[ix] : (u32)t.action_class[ix];
+    ac[k] = (k < act_cnt && aid[k] < t.K && ca < 62u) ? ca : 63u;
+  }
+#pragma unroll
+  for (u32 k = 0; k < NR; ++k) {
+    const u32 ix = rid[k] < t.K ? rid[k] : kmax;
+    const u32 cr = cls_in_lds ? (u32)cls_lds[t.K + ix] : (u32)t.role_class[ix];
+    rcls[k] = (k < role_cnt && rid[k] < t.K && cr < 62u) ? cr : 63u;
+  }
+  u32 gap[NA / 2], rgp[NR / 2];   // glob match bits, two 16-bit fields to a dword
+#pragma unroll
+  for (u32 j = 0; j < NA / 2; ++j) gap[j] = 0;
+#pragma unroll
+  for (u32 j = 0; j < NR / 2; ++j) rgp[j] = 0;
+  if (aglobs) {
+#pragma unroll
+    for (u32 k = 0; k < NA; ++k) {
+      const u32 g = k < act_cnt ? ((u32)gbits_of(t, b, DIM_ACTION, aid[k]) & 0xFFFFu) : 0u;
+      gap[k >> 1] |= g << (16u * (k & 1u));
+    }
+  }
+  if (rglobs) {
+#pragma unroll
+    for (u32 k = 0; k < NR; ++k) {
+      const u32 g = k < role_cnt ? ((u32)gbits_of(t, b, DIM_ROLE, rid[k]) & 0xFFFFu) : 0u;
+      rgp[k >> 1] |= g << (16u * (k & 1u));
+    }
+  }
+  // role slots as class sets: [role] ++ ancestors for the request's own resource scope (check.go:172, 227)
+  u32 rs_lo[NR], rs_hi[NR];
+#pragma unroll
+  for (u32 k = 0; k < NR; ++k) {
+    const u64 m = k < role_cnt ? (1ull << rcls[k]) : 0ull;
+    rs_lo[k] = (u32)m; rs_hi[k] = (u32)(m >> 32);
+  }
+  if (has_parents) {
+    const u32 pr_scope_key = (r_scope & CBH_SCOPE_EXACT) ? (r_scope & ~CBH_SCOPE_EXACT) : CBH_NONE;
+#pragma unroll
+    for (u32 k = 0; k < NR; ++k) {
+      uint4 pv;
+      if (k < role_cnt && pr_scope_key != CBH_NONE && dir_find(t, CBH_B_PARENTS, pr_scope_key, rid[k], 0, pv)) {
+        for (u32 j = 0; j < pv.y; ++j) {   // ancestors are table strings
+          const u32 anc = t.pool[pv.x + j];
+          const u32 cr = t.role_class[anc];
+          const u64 m = 1ull << (cr < 62u ? cr : 63u);
+          rs_lo[k] |= (u32)m; rs_hi[k] |= (u32)(m >> 32);
+          if (rglobs) rgp[k >> 1] |= ((u32)t.gbits[(size_t)DIM_ROLE * t.K + anc] & 0xFFFFu) << (16u * (k & 1u));
+        }
+      }
+    }
+  }
+  u32 lane_rs_lo = 0, lane_rs_hi = 0, lane_ac_lo = 0, lane_ac_hi = 0, lane_ag = 0, lane_rg = 0;
+  u32 walks = 0;   // bit 8 r + k: role r exists and action k exists
+#pragma unroll
+  for (u32 k = 0; k < NA; ++k) {
+    if (k < act_cnt) { const u64 m = 1ull << ac[k]; lane_ac_lo |= (u32)m; lane_ac_hi |= (u32)(m >> 32); lane_ag |= (gap[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu; }
+  }
+#pragma unroll
+  for (u32 k = 0; k < NR; ++k) {
+    if (k < role_cnt) { lane_rs_lo |= rs_lo[k]; lane_rs_hi |= rs_hi[k]; lane_rg |= (rgp[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu; walks |= all << (8 * k); }
+  }
+  // classes / glob bits present in the wave: a record none of them can match is skipped on the scalar unit
+  const u64 wave_a = wave_or64((u64)lane_ac_lo | ((u64)lane_ac_hi << 32), wave, c.tid);
+  const u64 wave_r = wave_or64((u64)lane_rs_lo | ((u64)lane_rs_hi << 32), wave, c.tid);
+  const u64 wave_g = (aglobs || rglobs) ? wave_or64((u64)lane_ag | ((u64)lane_rg << 16), wave, c.tid) : 0ull;
+  const u32 wave_ac_lo = (u32)wave_a, wave_ac_hi = (u32)(wave_a >> 32), wave_rc_lo = (u32)wave_r, wave_rc_hi = (u32)(wave_r >> 32);
+  const u32 wave_ag = (u32)wave_g & 0xFFFFu, wave_rg = (u32)(wave_g >> 16) & 0xFFFFu;
+
+  const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
+  u64 edr_scope = 0;   // pre-pass: the derived roles of the scope being walked (what runtime.effectiveDerivedRoles reads)
+
+  // A condition reference for the lanes with `active`: bit 0 satisfied, bit 1 CEL error, bit 3 outside the device subset.
+  // `how`: 1 = `lr` is the fused leaf, 2 = `lr` describes a tree of classified leaves (both inline, cbh_check_flat.h), 0 =
+  // neither.  What the inline code leaves open is an evaluation site, slot `gslot`: the pre-pass evaluates it with the
+  // shared evaluator and files the result, the walk reads it.
+  auto leafish = [&](u32 ref, u32 how, const LeafRec& lr, u32 gslot, bool active) -> u32 {
+    u32 lv = 4u;
+    if (how == 1u) lv = flat_leaf(c, lr, req, pid);
+    else if (how == 2u) lv = flat_tree(c, lr, req, pid);
+    const bool slow = active && lv == 4u;
+    if (wave_ballot(slow) != 0) {
+      const bool filed = gslot != CBH_GSLOT_NONE && (gslot / CBH_W2_SLOTS_PER_WORD) < b.n_gwords;   // uniform
+      if (PRE) {
+        const u32 r = eval_ref<true>(c.ka_mem, lds_of(c), req, edr_scope, false, ref, slow);
+        const u32 st = r >> 8;
+        const u32 code = ((r & 0xFFu) == 1u ? 1u : 0u) | ((st & CBH_ST_CEL_ERROR) ? 2u : 0u) | ((st & CBH_ST_UNSUPPORTED) ? 8u : 0u);
+        if (slow) {
+          lv = code;
+          if (filed) gacc[(gslot / CBH_W2_SLOTS_PER_WORD) * CBH_BLOCK + c.tid] |= (u64)code << (4u * (gslot % CBH_W2_SLOTS_PER_WORD));
+        }
+      } else if (slow) {
+        // (a site without a filed result - the host launches the pre-pass whenever one can be needed - is loud, never guessed)
+        lv = filed ? (u32)(b.gres[(size_t)(gslot / CBH_W2_SLOTS_PER_WORD) * NRQ + req] >> (4u * (gslot % CBH_W2_SLOTS_PER_WORD))) & 0xBu : 8u;
+      }
+    }
+    return active ? lv : 0u;
+  };
+  auto act_bits16 = [&](u32 k) -> u32 { return (gap[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu; };
+  // the request's actions (bit k) a class mask + glob mask admits
+  auto match_actions = [&](u32 am_lo, u32 am_hi, u32 ag) -> u32 {
+    const u64 am = (u64)am_lo | ((u64)am_hi << 32);
+    u32 m = 0;
+#pragma unroll
+    for (u32 k = 0; k < NA; ++k) m |= (u32)((am >> ac[k]) & 1ull) << k;
+    if (ag) {
+#pragma unroll
+      for (u32 k = 0; k < NA; ++k) m |= ((act_bits16(k) & ag) != 0u ? 1u : 0u) << k;
+    }
+    return m & all;
+  };
+  auto match_roles = [&](u32 rm_lo, u32 rm_hi, u32 rg) -> u32 {   // bit r
+    u32 m = 0;
+#pragma unroll
+    for (u32 k = 0; k < NR; ++k) m |= (((rm_lo & rs_lo[k]) | (rm_hi & rs_hi[k])) != 0u ? 1u : 0u) << k;
+    if (rg) {
+#pragma unroll
+      for (u32 k = 0; k < NR; ++k) m |= ((((rgp[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu) & rg) != 0u ? 1u : 0u) << k;
+    }
+    return m;
+  };
+  auto kind_bits = [&]() -> u64 { return gbits_of(t, b, DIM_KIND, kind); };
+
+  u32 err = 0, unsup = 0;   // walk bits whose evaluation met a CEL error / left the device subset
+
+  // ---- principal policies (check.go:195: the first pass; one role iteration, check.go:208-213).  Lanes with a policy of
+  // their principal somewhere on the chain are walked group by group; what it decides is kept per action.
+  u32 p_allow = 0, p_deny = 0, p_err = 0, p_unsup = 0, p_pol = 0;
+  u32 p_first = CBH_NONE;
+  if (has_pp) {
+    p_first = chain_first(t, p_scope, FLAG_PRIN, lenient);
+    const bool cand = valid && p_first != CBH_NONE && role_cnt > 0 && act_cnt > 0;
+    bool pend = false;
+    if (cand) {
+      for (u32 si = p_first; si != CBH_NONE && !pend; si = chain_next(t, t.scope_parent[si], FLAG_PRIN)) {
+        uint4 v;
+        pend = dir_find(t, CBH_B_PRINCIPAL, r_ver, si, pid, v);   // the resource's version: check.go:294
+      }
+    }
+    for (;;) {
+      const u64 rem = wave_ballot(pend);
+      if (rem == 0) break;
+      const u32 lead = first_lane(rem);
+      const u32 g_first = wave_readlane(p_first, lead), g_ver = wave_readlane(r_ver, lead), g_pid = wave_readlane(pid, lead), g_pver = wave_readlane(p_ver, lead);
+      const bool ing = pend && p_first == g_first && r_ver == g_ver && pid == g_pid && p_ver == g_pver;
+      pend = pend && !ing;
+      bool pe = false;   // roleEffectInfo.Policy: the main policy key if a principal policy exists at all (check.go:216-225)
+      for (u32 si = g_first; si != CBH_NONE && !pe; si = uchain_next(t, uload(&t.scope_parent[si]), FLAG_PRIN)) {
+        uint4 v;
+        pe = udir_find(t, CBH_B_PPEXISTS, g_pver, si, 0, v);
+      }
+      if (ing) p_pol = pe ? (((u32)CBH_P_PRINCIPAL << 28) | g_first) : ((u32)CBH_P_NO_MATCH << 28);
+      u32 S = ing ? all : 0u, has_allow = 0;
+      for (u32 si = g_first; si != CBH_NONE; si = uchain_next(t, uload(&t.scope_parent[si]), FLAG_PRIN)) {
+        if (wave_ballot(S != 0) == 0) break;
+        uint4 bucket; bucket.x = bucket.y = 0;
+        if (udir_find(t, CBH_B_PRINCIPAL, g_ver, si, g_pid, bucket)) {
+          for (u32 row = bucket.x; row < bucket.x + bucket.y; ++row) {
+            const TblRowFull rf = uload_rec<TblRowFull>(t.rows, row);
+            const TblRow& rw = rf.hot;
+            const TblRowPat pt = uload_rec<TblRowPat>(t.rowpat, row);
+            const u64 kb = t.nfa_words[DIM_KIND] ? kind_bits() : 0ull;
+            u32 mrow = 0;
+            if (S != 0 && pat_match(pt.resource, kind, kb)) {
+              const u32 n_act = pt.counts & 0xFFFFu;   // 0 = a single inline reference
+              auto one = [&](u32 pat) -> u32 {
+                if (pat == CBH_PAT_ANY) return all;
+                u32 m = 0;
+                if (pat & CBH_PAT_GLOB) {
+                  const u32 gi = pat & 15u;
+#pragma unroll
+                  for (u32 k = 0; k < NA; ++k) m |= ((act_bits16(k) >> gi) & 1u) << k;
+                } else {
+#pragma unroll
+                  for (u32 k = 0; k < NA; ++k) m |= (u32)(aid[k] == pat) << k;
+                }
+                return m & all;
+              };
+              if (rw.flags & CBH_ROW_F_ACTION_LIST) { for (u32 i = 0; i < n_act; ++i) mrow |= one(uload(&t.pool[pt.action + i])); }
+              else { mrow = one(pt.action); if (n_act > 1) mrow |= one(pt.a1); if (n_act > 2) mrow |= one(pt.a2); }
+              mrow &= PRE ? all : S;
+            }
+            if (wave_ballot(mrow != 0) == 0) continue;
+            u32 hit = mrow;
+            if (rw.cond != CBH_NONE) {
+              const u32 how = (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_TREE_EMBEDDED) ? 2u : 0u;
+              u32 gslot = CBH_GSLOT_NONE;
+              if (rw.flags & CBH_ROW_F_X) gslot = uload_rec<TblRowX>(t.rowx, row).gslots & 0xFFFFu;
+              const u32 lv = leafish(rw.cond, how, rf.leaf, gslot, hit != 0);
+              p_err |= (lv & 2u) ? hit : 0u; p_unsup |= (lv & 8u) ? hit : 0u;
+              hit = (lv & 1u) ? hit : 0u;
+            }
+            if (PRE) continue;
+            if ((rw.flags & 3u) == CBH_EFFECT_ALLOW) has_allow |= hit;
+            else if ((rw.flags & 3u) == CBH_EFFECT_DENY && hit) {
+              p_deny |= hit; S &= ~hit;
+#pragma unroll
+              for (u32 k = 0; k < NA; ++k) if ((hit >> k) & 1u) aux[k * CBH_BLOCK + c.tid] = si;
+            }
+          }
+        }
+        if (PRE) continue;
+        const u32 ha = has_allow & S;   // check.go:416-425
+        const u32 spm = (uload(&t.scope_flags[si]) >> 2) & 3u;
+        if (spm == SP_REQUIRE_CONSENT) has_allow &= ~ha;
+        else if (spm == SP_OVERRIDE_PARENT && ha) {
+          p_allow |= ha; S &= ~ha;
+#pragma unroll
+          for (u32 k = 0; k < NA; ++k) if ((ha >> k) & 1u) aux[k * CBH_BLOCK + c.tid] = si;
+        }
+      }
+    }
+  }
+  const u32 p_done = p_allow | p_deny;   // a definitive principal-policy result ends the action (check.go:445-448)
+  walks &= ~(p_done * 0x01010101u);
+
+  // ---- the resource walk (cbh_check_flat.h: merged climb, deepest scope first)
+  u32 S = walks;
+  u32 has_allow = 0, allow = 0, deny = 0;
+  u32 dp0 = 0, dp1 = 0, dp2 = 0, dp3 = 0;
+  const u32 scope_bits = t.n_scopes > 1 ? 32u - (u32)__builtin_clz(t.n_scopes - 1u) : 0u;
+  const u32 first = chain_first(t, r_scope, FLAG_RES, lenient);
+  u32 cur = first, mydepth = 0;
+  bool exists = false;
+  const bool pre_edr = PRE && (t.flags & CBH_MF_USES_RUNTIME_EDR) != 0;
+  for (;;) {
+    const bool active = cur != CBH_NONE && (PRE ? walks != 0 : (S != 0 || !exists));
+    if (wave_ballot(active) == 0) break;
+    const u32 g_si = wave_max_bits(cur, active, scope_bits);
+    const u64 here = wave_ballot(active && cur == g_si);
+    const u32 lead = first_lane(here);
+    const u32 g_ver = wave_readlane(r_ver, lead), g_k = wave_readlane(kind, lead);
+    const bool ing = active && cur == g_si && r_ver == g_ver && kind == g_k;
+    const bool go = wave_ballot(ing && (PRE ? walks : S) != 0) != 0;
+    uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
+    const bool have_bucket = udir_find(t, CBH_B_RESOURCE, g_ver, g_k, g_si, bucket);
+    exists = exists || (ing && have_bucket);
+    // role policies at (version, scope)?  Their resource patterns also make the resource "exist" (index.go:966-997)
+    uint4 rpres; rpres.x = rpres.y = 0;
+    bool rolepol_here = false;
+    u64 g_kb = 0;
+    if (has_rolepol && udir_find(t, CBH_B_RPRES, g_ver, g_si, 0, rpres)) {
+      rolepol_here = true;
+      if (t.nfa_words[DIM_KIND]) g_kb = wave_readlane64(kind_bits(), lead);
+      bool m = false;
+      for (u32 k = 0; k < rpres.y && !m; ++k) m = pat_match(uload(&t.pool[rpres.x + k]), g_k, g_kb);
+      exists = exists || (ing && m);
+    }
+    if (go) {
+      if (!PRE && ing && mydepth < max_depth) { if (chain8) chain_si8[mydepth * CBH_BLOCK + c.tid] = (u8)g_si; else chain_si[mydepth * CBH_BLOCK + c.tid] = g_si; }
+      const u32 S_before = S;
+      if (PRE && have_bucket && t.n_dr) {
+        // the scope's derived roles (check.go:237-282): their sites, and - for programs that read runtime.* - their value
+        u64 m = 0;
+        for (u32 d = bucket.z; d < bucket.z + bucket.w; ++d) {
+          const TblDrx dx = uload_rec<TblDrx>(t.drx, d);
+          const bool applies = ing && (((dx.rm_lo & lane_rs_lo) | (dx.rm_hi & lane_rs_hi)) != 0);
+          if (wave_ballot(applies) == 0) continue;
+          u32 lv = 1u;
+          if (dx.cond != CBH_NONE) lv = leafish(dx.cond, dx.flags & 3u, dx.leaf, dx.p0 & 0xFFFFu, applies);
+          if (applies && (lv & 1u)) m |= 1ull << dx.name;
+        }
+        if (pre_edr && ing) edr_scope = m;
+      }
+      if (rolepol_here) {
+        // ---- synthetic DENYs of the role policies at this scope (index.go:352-530)
+        uint4 ux; ux.y = ux.z = ux.w = 0;
+        (void)udir_find(t, CBH_B_RESEXISTS, g_ver, g_k, g_si, ux);   // union of the bucket's role masks: Index.Query's base test
+        u32 base = ing ? match_roles(ux.y, ux.z, ux.w & 0xFFFFu) : 0u;
+        uint4 rl; rl.x = rl.y = 0;
+        (void)udir_find(t, CBH_B_RPROLES, g_ver, g_si, 0, rl);
+        const u32 n_rp = rl.y < CBH_W2_MAX_RP_ROLES ? rl.y : CBH_W2_MAX_RP_ROLES;
+        // ... or a rule of the role policy of a role in the slot's set names the resource
+        for (u32 j = 0; j < n_rp; ++j) {
+          const u32 g_sr = uload(&t.pool[rl.x + j]);
+          const u32 gc = (uload((const CBH_G u32*)(t.role_class + (g_sr & ~3u))) >> (8u * (g_sr & 3u))) & 0xFFu;   // its class (the lowering checks it has one)
+          const u64 gm = 1ull << (gc < 62u ? gc : 63u);
+          const u32 slot = ing ? match_roles((u32)gm, (u32)(gm >> 32), 0u) : 0u;
+          if (wave_ballot(slot != 0) == 0) continue;
+          uint4 rp;
+          if (!udir_find(t, CBH_B_ROLEPOL, g_ver, g_si, g_sr, rp)) continue;
+          bool any_res = false;
+          for (u32 row = rp.x; row < rp.x + rp.y && !any_res; ++row) any_res = pat_match(uload(&t.rpx[(size_t)row * CBH_RPX_NF + CBH_RPX_RESOURCE]), g_k, g_kb);
+          if (any_res) base |= slot;
+        }
+        // a slot's own role first (phase 0), then its ancestors in name order (phase 1): index.go:352-530 walks [role] ++ ancestors
+        for (u32 jj = 0; jj < 2u * n_rp; ++jj) {
+          const u32 j = jj < n_rp ? jj : jj - n_rp;
+          const u32 g_sr = uload(&t.pool[rl.x + j]);
+          const u32 gc = (uload((const CBH_G u32*)(t.role_class + (g_sr & ~3u))) >> (8u * (g_sr & 3u))) & 0xFFu;
+          const u64 gm = 1ull << (gc < 62u ? gc : 63u);
+          u32 own = 0;
+#pragma unroll
+          for (u32 k = 0; k < NR; ++k) own |= (u32)(k < role_cnt && rcls[k] == gc) << k;
+          const u32 slot = ing ? (match_roles((u32)gm, (u32)(gm >> 32), 0u) & base & (jj < n_rp ? own : ~own)) : 0u;
+          const u32 Wg = w2_rep_role(slot) & (PRE ? walks : S);
+          if (wave_ballot(Wg != 0) == 0) continue;
+          uint4 rp;
+          if (!udir_find(t, CBH_B_ROLEPOL, g_ver, g_si, g_sr, rp)) continue;
+          u32 any_mask = 0, out_only = 0;   // actions some rule for this resource allows (subject to conditions); ... an output-only rule that shares its key
+          for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
+            const TblRpx rr = uload_rec<TblRpx>(t.rpx, row);
+            if (!pat_match(rr.resource, g_k, g_kb)) continue;
+            const u32 ma = match_actions(rr.am_lo, rr.am_hi, rr.ag);
+            any_mask |= ma;
+            if ((rr.cnt & (CBH_RP_F_OUTPUT_ONLY | CBH_RP_F_SHARES_KEY)) == (CBH_RP_F_OUTPUT_ONLY | CBH_RP_F_SHARES_KEY)) out_only |= ma;
+          }
+          u32 dn = Wg & ~(any_mask * 0x01010101u);   // no rule for the resource, or no allow action matched (index.go:436-461)
+          for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
+            const TblRpx rr = uload_rec<TblRpx>(t.rpx, row);
+            if (rr.cond == CBH_NONE || !pat_match(rr.resource, g_k, g_kb)) continue;
+            const u32 ma = match_actions(rr.am_lo, rr.am_hi, rr.ag);
+            const u32 mm = (ma * 0x01010101u) & Wg & ~dn;
+            if (wave_ballot(mm != 0) == 0) continue;
+            // an action at or behind the first one an output-only rule of the same key is visited for finds "satisfied"
+            // cached (check.go:324): the synthetic DENY would fire whatever the condition says (cbh_blob.h CBH_RP_F_*)
+            if ((rr.cnt & CBH_RP_F_SHARES_KEY) && out_only != 0) unsup |= mm & ~((((out_only & (0u - out_only)) - 1u) & 0xFFu) * 0x01010101u);
+            const u32 lv = leafish(rr.cond, rr.how, rr.leaf, rr.gslot & 0xFFFFu, mm != 0);
+            err |= (lv & 2u) ? mm : 0u; unsup |= (lv & 8u) ? mm : 0u;
+            if (!(lv & 1u)) dn |= mm;   // the synthetic row = DENY if none(condition)
+          }
+          if (!PRE) {
+            dn &= S;
+            if (dn) {   // check.go:395-403; the policy named is the role policy's
+              deny |= dn; S &= ~dn;
+              const u32 note = rp.z & 0x0FFFFFFFu;
+#pragma unroll
+              for (u32 k = 0; k < NA; ++k) {
+                const u32 dk = (dn >> k) & 0x01010101u;
+                if (dk) {
+                  const u32 r = (u32)__builtin_ctz(dk) >> 3;
+                  const u32 old = aux[k * CBH_BLOCK + c.tid];
+                  if (old == CBH_NONE || r < (old >> 28)) aux[k * CBH_BLOCK + c.tid] = (r << 28) | note;
+                }
+              }
+            }
+          }
+        }
+      }
+      if (have_bucket && bucket.y) {
+        const u32 last = bucket.x + bucket.y - 1u;
+        TblRowFull nxt = uload_rec<TblRowFull>(t.rows, bucket.x);
+        for (u32 row = bucket.x; row <= last; ++row) {   // bindings in order (check.go:295-414)
+          const TblRowFull rf = nxt;
+          nxt = uload_rec<TblRowFull>(t.rows, row < last ? row + 1u : last);
+          const TblRow& rw = rf.hot;
+          u32 rm_lo = rw.rm_lo, rm_hi = rw.rm_hi, am_lo = rw.am_lo, am_hi = rw.am_hi, ag = 0, rg = 0, gslots = 0xFFFFFFFFu;
+          if (rw.flags & CBH_ROW_F_X) {
+            const TblRowX rx = uload_rec<TblRowX>(t.rowx, row);
+            gslots = rx.gslots;
+            if (rx.globs) { ag = rx.globs & 0xFFFFu; rg = rx.globs >> 16; rm_lo = rx.rm_lo; rm_hi = rx.rm_hi; am_lo = rx.am_lo; am_hi = rx.am_hi; }
+          }
+          if ((((rm_lo & wave_rc_lo) | (rm_hi & wave_rc_hi)) == 0 && (rg & wave_rg) == 0) ||
+              (((am_lo & wave_ac_lo) | (am_hi & wave_ac_hi)) == 0 && (ag & wave_ag) == 0)) continue;
+          const u32 mact = match_actions(am_lo, am_hi, ag);
+          const u32 mrole = match_roles(rm_lo, rm_hi, rg);
+          // (the walks a visit is for: those still going - the pre-pass evaluates for every walk the request has)
+          const u32 m = ing ? (w2_rep_role(mrole) & (mact * 0x01010101u) & (PRE ? walks : S)) : 0u;
+          if (wave_ballot(m != 0) == 0) continue;
+          u32 hit = m;
+          if (rw.drcond != CBH_NONE) {   // the derived-role condition first, the rule's own where that held (check.go:328-380)
+            const u32 how = (rw.flags & CBH_ROW_F_DRLEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_DRTREE_EMBEDDED) ? 2u : 0u;
+            const LeafRec l2 = uload_rec<LeafRec>(t.rowleaf2, row);
+            const u32 lv = leafish(rw.drcond, how, l2, gslots >> 16, hit != 0);
+            err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
+            hit = (lv & 1u) ? hit : 0u;
+          }
+          if (rw.cond != CBH_NONE && wave_ballot(hit != 0) != 0) {
+            const u32 how = (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_TREE_EMBEDDED) ? 2u : 0u;
+            const u32 lv = leafish(rw.cond, how, rf.leaf, gslots & 0xFFFFu, hit != 0);
+            err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
+            hit = (lv & 1u) ? hit : 0u;
+          }
+          if (PRE) continue;
+          if ((rw.flags & 3u) == CBH_EFFECT_ALLOW) has_allow |= hit;
+          else if ((rw.flags & 3u) == CBH_EFFECT_DENY) { deny |= hit; S &= ~hit; }
+        }
+      }
+      if (!PRE) {
+        const u32 ha = ing ? (has_allow & S) : 0u;   // check.go:416-425
+        const u32 spm = (uload(&t.scope_flags[g_si]) >> 2) & 3u;
+        if (spm == SP_REQUIRE_CONSENT) has_allow &= ~ha;
+        else if (spm == SP_OVERRIDE_PARENT) { allow |= ha; S &= ~ha; }
+        const u32 newly = S_before & ~S;
+        dp0 |= (mydepth & 1u) ? newly : 0u; dp1 |= (mydepth & 2u) ? newly : 0u; dp2 |= (mydepth & 4u) ? newly : 0u; dp3 |= (mydepth & 8u) ? newly : 0u;
+      }
+    }
+    const u32 up = uchain_next(t, uload(&t.scope_parent[g_si]), FLAG_RES);
+    if (ing) { cur = (mydepth + 1u < max_depth) ? up : CBH_NONE; ++mydepth; }
+  }
+
+  if (PRE) {   // file the results of this lane's sites
+    if (valid) for (u32 w = 0; w < b.n_gwords; ++w) b.gres[(size_t)w * NRQ + req] = gacc[w * CBH_BLOCK + c.tid];
+    return;
+  }
+
+  // ---- nothing to evaluate at all?  (check.go:116-121, 165-170)
+  bool p_exists = false;
+  if (has_pp && valid && !exists && p_first != CBH_NONE) {
+    for (u32 si = p_first; si != CBH_NONE && !p_exists; si = chain_next(t, t.scope_parent[si], FLAG_PRIN)) {
+      uint4 v;
+      p_exists = dir_find(t, CBH_B_PPEXISTS, p_ver, si, 0, v);
+    }
+  }
+  const bool decided = (p_first == CBH_NONE && first == CBH_NONE) || (!p_exists && !exists);
+  // what an action no rule decided reports (check.go:191, 216-225, 429-431)
+  const u32 pol_none = decided ? ((u32)CBH_P_NO_MATCH << 28)
+                     : role_cnt == 0 ? ((u32)CBH_P_EMPTY << 28)
+                     : exists ? (((u32)CBH_P_RESOURCE << 28) | first) : ((u32)CBH_P_NO_MATCH << 28);
+  const u32 pol_hit = ((u32)CBH_P_RESOURCE << 28) | first;
+  if (decided) { p_allow = p_deny = p_err = p_unsup = 0; }
+
+  // ---- the fold (check.go:429-442), per action: a principal policy's word, else the first role that allowed, else the
+  // first role that denied
+  u32 eff[2] = {0, 0}, st[2] = {0, 0}, pol[NA], scp[NA];
+#pragma unroll
+  for (u32 k = 0; k < NA; ++k) {
+    const u32 ak = (allow >> k) & 0x01010101u, dk = (deny >> k) & 0x01010101u;
+    const u32 win = ak ? (ak & (0u - ak)) : (dk & (0u - dk));
+    const u32 wb = win << k;
+    const u32 d = ((dp0 & wb) ? 1u : 0u) | ((dp1 & wb) ? 2u : 0u) | ((dp2 & wb) ? 4u : 0u) | ((dp3 & wb) ? 8u : 0u);
+    const bool pk = ((p_allow | p_deny) >> k) & 1u;
+    const u32 note = aux[k * CBH_BLOCK + c.tid];
+    u32 pw = win ? pol_hit : pol_none, sw = CBH_NONE;
+    if (win && k < act_cnt) sw = chain8 ? (u32)chain_si8[d * CBH_BLOCK + c.tid] : chain_si[d * CBH_BLOCK + c.tid];
+    if (win && !ak && note != CBH_NONE && (note >> 28) == ((u32)__builtin_ctz(win) >> 3)) pw = ((u32)CBH_P_TABLE << 28) | (note & 0x0FFFFFFFu);   // a role policy denied
+    bool al = ak != 0;
+    if (pk) { pw = p_pol; sw = note; al = ((p_allow >> k) & 1u) != 0; }
+    pol[k] = pw; scp[k] = sw;
+    eff[k >> 2] |= (u32)(al ? CBH_EFFECT_ALLOW : CBH_EFFECT_DENY) << (8 * (k & 3u));   // NO_MATCH -> DENY (check.go:451-453)
+    // an evaluation the reference would not have made - a role after the one that allowed - does not count
+    const u32 seen = ak ? (((ak & (0u - ak)) << 1) - 1u) : 0x01010101u * 0xFFu;
+    const u32 ek = (err >> k) & 0x01010101u & seen, uk = (unsup >> k) & 0x01010101u & seen;
+    const bool e1 = ek != 0 || ((p_err >> k) & 1u), u1 = uk != 0 || ((p_unsup >> k) & 1u);
+    st[k >> 2] |= (u32)(u1 ? CBH_ST_UNSUPPORTED : (e1 ? CBH_ST_CEL_ERROR : CBH_ST_OK)) << (8 * (k & 3u));
+  }
+
+  // ---- effective derived roles (check.go:237-282): a second merged climb over the scopes a legitimate walk reached
+  u64 edr = 0;
+  if ((flags & CBH_F_WANT_DERIVED_ROLES) && t.n_dr) {
+    u32 legit = 0;
+#pragma unroll
+    for (u32 k = 0; k < NA; ++k) {
+      const u32 ak = (allow >> k) & 0x01010101u;
+      const u32 seen = ak ? (((ak & (0u - ak)) << 1) - 1u) : 0x01010101u * 0xFFu;
+      legit |= ((walks >> k) & 0x01010101u & seen) << k;
+    }
+    const u32 done = allow | deny;
+    u32 reach = 0;
+    if (legit & ~done) reach = CBH_FLAT_MAX_DEPTH;
+    else if (legit) {
+      u32 cand = legit, d = 0;
+      u32 tp = cand & dp3; if (tp) { cand = tp; d |= 8u; }
+      tp = cand & dp2; if (tp) { cand = tp; d |= 4u; }
+      tp = cand & dp1; if (tp) { cand = tp; d |= 2u; }
+      tp = cand & dp0; if (tp) { cand = tp; d |= 1u; }
+      reach = d + 1u;
+    }
+    bool derr = false, dr_unsup = false;
+    u32 cur2 = first, d2 = 0;
+    for (;;) {
+      const bool active = cur2 != CBH_NONE && d2 < reach;
+      if (wave_ballot(active) == 0) break;
+      const u32 g_si = wave_max_bits(cur2, active, scope_bits);
+      const u32 lead = first_lane(wave_ballot(active && cur2 == g_si));
+      const u32 g_ver = wave_readlane(r_ver, lead), g_k = wave_readlane(kind, lead);
+      const bool ing = active && cur2 == g_si && r_ver == g_ver && kind == g_k;
+      uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
+      if (udir_find(t, CBH_B_RESOURCE, g_ver, g_k, g_si, bucket)) {
+        for (u32 d = bucket.z; d < bucket.z + bucket.w; ++d) {
+          const TblDrx dx = uload_rec<TblDrx>(t.drx, d);
+          const bool applies = ing && (((dx.rm_lo & lane_rs_lo) | (dx.rm_hi & lane_rs_hi)) != 0);   // parent roles x the request's roles (check.go:244)
+          if (wave_ballot(applies) == 0) continue;
+          u32 lv = 1u;
+          if (dx.cond != CBH_NONE) lv = leafish(dx.cond, dx.flags & 3u, dx.leaf, dx.p0 & 0xFFFFu, applies);
+          if (applies) { if (lv & 1u) edr |= 1ull << dx.name; derr = derr || (lv & 2u) != 0; dr_unsup = dr_unsup || (lv & 8u) != 0; }
+        }
+      }
+      const u32 up = uchain_next(t, uload(&t.scope_parent[g_si]), FLAG_RES);
+      if (ing) { cur2 = up; ++d2; }
+    }
+    if (derr) { st[0] |= 0x01010101u & ~((st[0] >> 1) & 0x01010101u); st[1] |= 0x01010101u & ~((st[1] >> 1) & 0x01010101u); }
+    if (dr_unsup) { st[0] = 0x02020202u; st[1] = 0x02020202u; }
+  }
+
+  const bool packed = valid && act_cnt == 4 && (act_off & 3u) == 0;
+  if (packed) {
+#ifndef CBH_HOSTSIM
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+#else
+    struct u32x4 { u32 x, y, z, w; };
+#endif
+    if (o.edr) store_nt(o.edr + req, edr);
+    store_nt((CBH_G u32*)(o.effect + act_off), eff[0]);
+    if (o.status) store_nt((CBH_G u32*)(o.status + act_off), st[0]);
+    if (o.policy) { u32x4 v; v.x = pol[0]; v.y = pol[1]; v.z = pol[2]; v.w = pol[3]; store_nt((CBH_G u32x4*)(o.policy + act_off), v); }
+    if (o.scope) { u32x4 v; v.x = scp[0]; v.y = scp[1]; v.z = scp[2]; v.w = scp[3]; store_nt((CBH_G u32x4*)(o.scope + act_off), v); }
+  } else if (valid) {
+    if (o.edr) o.edr[req] = edr;
+#pragma unroll
+    for (u32 k = 0; k < NA; ++k) {
+      if (k < act_cnt) {
+        o.effect[act_off + k] = (u8)((eff[k >> 2] >> (8 * (k & 3u))) & 0xFFu);
+        if (o.status) o.status[act_off + k] = (u8)((st[k >> 2] >> (8 * (k & 3u))) & 0xFFu);
+        if (o.policy) o.policy[act_off + k] = pol[k];
+        if (o.scope) o.scope[act_off + k] = scp[k];
+      }
+    }
+  }
+}
+
+#ifndef CBH_HOSTSIM
+#define CBH_W2_ATTRS __launch_bounds__(CBH_W2_THREADS)
+#else
+#define CBH_W2_ATTRS
+#endif
+// the walk: four independent waves to a workgroup, no evaluator call
+__global__ CBH_W2_ATTRS void cbh_walk2_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+  const u32 ncc = cached_columns(&a);
+  const W2Layout ly = w2_layout(ncc, false, a.t.max_depth, a.t.n_scopes, false, 0, a.t.K);
+  Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+        (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * ly.wave_dw, ncc, ka};
+  w2_body<false>(a, c, ly);
+}
+// the pre-pass: one wave to a workgroup, the shared evaluator with its operand stack (cbh_check_wave.h generic_kernel_body)
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_walk2_pre_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+  __shared__ u64 s_val[CBH_STACK_DEPTH * CBH_BLOCK];
+  __shared__ u64 l_val[CBH_MAX_LOCALS * CBH_BLOCK];
+  __shared__ u64 it_cont[CBH_MAX_ITERS * CBH_BLOCK];
+  __shared__ u32 it_idx[CBH_MAX_ITERS * CBH_BLOCK];
+  __shared__ u32 it_state[CBH_MAX_ITERS * CBH_BLOCK];
+  __shared__ u8 s_tag[CBH_STACK_DEPTH * CBH_BLOCK];
+  __shared__ u8 l_tag[CBH_MAX_LOCALS * CBH_BLOCK];
+  {
+    const u32 tid = threadIdx.x;
+    for (u32 k = 0; k < CBH_STACK_DEPTH; ++k) { s_tag[k * CBH_BLOCK + tid] = CBH_T_ERR; s_val[k * CBH_BLOCK + tid] = 0; }
+    for (u32 k = 0; k < CBH_MAX_LOCALS; ++k) { l_tag[k * CBH_BLOCK + tid] = CBH_T_ERR; l_val[k * CBH_BLOCK + tid] = 0; }
+    for (u32 k = 0; k < CBH_MAX_ITERS; ++k) { it_cont[k * CBH_BLOCK + tid] = 0; it_idx[k * CBH_BLOCK + tid] = 0; it_state[k * CBH_BLOCK + tid] = 0; }
+  }
+  const u32 ncc = cached_columns(&a);
+  const W2Layout ly = w2_layout(ncc, (a.t.flags & CBH_MF_NEEDS_ARENA) != 0, a.t.max_depth, a.t.n_scopes, true, a.b.n_gwords, a.t.K);
+  Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x,
+        (CBH_L u64*)s_val, (CBH_L u8*)s_tag, (CBH_L u64*)l_val, (CBH_L u8*)l_tag,
+        (CBH_L u64*)it_cont, (CBH_L u32*)it_idx, (CBH_L u32*)it_state,
+        (CBH_L u32*)cbh_dyn_lds, ncc, ka};
+  w2_body<true>(a, c, ly);
+}
+
+// Does cbh_walk2_kernel decide this table's batches?  (CBH_MF_WALK2; not strict mode, whose immediate DENYs are order
+// dependent.)  Requests with more than eight actions or four roles are left to the general walk, lane by lane (CBH_FI_*).
+static inline bool cbh_walk2_applies(u32 table_flags, u32 eval_flags) {
+  return (table_flags & CBH_MF_WALK2) && !(eval_flags & CBH_F_STRICT_EVALUATION);
+}
+
+// ---- which kernels decide a batch, and with how much dynamic LDS (shared by cbh_engine.hip and the host simulation)
+struct CbhPlan {
+  int kind;                      // 0 the general walk (cbh_check_wave.h), 1 a flat kernel, 2 cbh_walk2_kernel (+ its pre-pass when n_gwords)
+  cbh_check_kernel_fn kernel;
+  u32 threads;                   // workgroup size of `kernel`
+  u32 n_gwords;                  // kind 2: 64-bit words of evaluation-site results per request (0 = no pre-pass)
+  cbh_check_kernel_fn wide_kernel;   // kind 2, batch with requests wider than the walk's shape: the general walk's kernel for those (else null)
+};
+static inline CbhPlan cbh_plan(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 gslots_generic, u32 gslots_all, u32 max_actions,
+                               u32 max_roles, bool plain_tags, u32 eval_flags, bool no_flat, bool no_walk2) {
+  CbhPlan p; p.n_gwords = 0; p.wide_kernel = nullptr;
+  bool flat = false;
+  p.kernel = cbh_pick_kernel(no_flat ? (table_flags & ~(u32)CBH_MF_FLAT) : table_flags, n_derived_roles, has_globs, max_actions, max_roles, plain_tags, eval_flags, &p.threads, &flat);
+  p.kind = flat ? 1 : 0;
+  if (!flat && !no_walk2 && cbh_walk2_applies(table_flags, eval_flags)) {
+    if (max_actions > CBH_W2_NA || max_roles > CBH_W2_NR) p.wide_kernel = p.kernel;
+    p.kind = 2; p.kernel = cbh_walk2_kernel; p.threads = CBH_W2_THREADS;
+    p.n_gwords = w2_gwords(gslots_generic, gslots_all, plain_tags);
+  }
+  return p;
+}
+// dynamic LDS of a one-wave workgroup of the general walk: the column cache and, for a table whose programs build lists, the arena
+static inline size_t cbh_general_lds(u32 table_flags, u32 n_columns) {
+  const u32 ncc = n_columns < CBH_CACHE_COLS ? n_columns : CBH_CACHE_COLS;
+  return (size_t)ncc * CBH_BLOCK * 12 + ((table_flags & CBH_MF_NEEDS_ARENA) ? (size_t)CBH_ARENA_ENTRIES * CBH_BLOCK * 9 : 0);
+}
+// dynamic LDS of a launch of `kernel` (pre = the pre-pass of kind 2)
+static inline size_t cbh_plan_lds(const CbhPlan& p, u32 table_flags, u32 table_max_depth, u32 table_scopes, u32 table_strings, u32 n_columns, bool pre) {
+  const u32 ncc = n_columns < CBH_CACHE_COLS ? n_columns : CBH_CACHE_COLS;
+  if (p.kind == 2) return w2_lds_bytes(w2_layout(ncc, (table_flags & CBH_MF_NEEDS_ARENA) != 0, table_max_depth, table_scopes, pre, p.n_gwords, table_strings), pre ? 1u : CBH_W2_WAVES);
+  const size_t wave = cbh_general_lds(table_flags, n_columns);
+  if (p.kind == 1) return (wave + cbh_flat_chain_bytes(table_max_depth, table_scopes)) * (p.threads / CBH_BLOCK) + cbh_flat_class_bytes(table_strings);
+  return wave;
+}

@@ -426,9 +426,11 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   const u64 cyc_start = __builtin_readcyclecounter();
 #endif
   const u32 rix = b.req_lo + blockIdx.x * CBH_BLOCK + threadIdx.x;
-  const bool valid = rix < b.req_hi;
-  const u32 req = valid ? rix : b.req_lo;   // tail lanes shadow the chunk's first request and never store
   const u32 NR = b.n_requests;
+  bool valid = rix < b.req_hi;
+  if ((flags & CBH_FI_ONLY_WIDE) && valid)   // the requests cbh_walk2_kernel decides are not this launch's (cbh_vm.h CBH_FI_*)
+    valid = cbh_is_wide(b.req_u32[(size_t)CBH_RQ_ACT_CNT * NR + rix], b.req_u32[(size_t)CBH_RQ_ROLE_CNT * NR + rix]);
+  const u32 req = valid ? rix : b.req_lo;   // tail lanes shadow the chunk's first request and never store
 #define RQ(f) b.req_u32[(size_t)(f) * NR + req]
   const u32 pid = RQ(CBH_RQ_PRINCIPAL_ID);
   const u32 p_scope = RQ(CBH_RQ_P_SCOPE), p_ver = RQ(CBH_RQ_P_VERSION);
@@ -1090,7 +1092,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
 #ifndef CBH_HOSTSIM
 extern __shared__ __attribute__((aligned(16))) unsigned char cbh_dyn_lds[];
 #else
-static unsigned char cbh_dyn_lds[CBH_CACHE_COLS * CBH_BLOCK * 12 + CBH_ARENA_ENTRIES * CBH_BLOCK * 9 + 16 * CBH_BLOCK * 4 + 2 * 4096 + 16];   // + the flat kernel's chain scratch and class tables
+static unsigned char cbh_dyn_lds[CBH_CACHE_COLS * CBH_BLOCK * 12 + CBH_ARENA_ENTRIES * CBH_BLOCK * 9 + 16 * CBH_BLOCK * 4 + 8 * CBH_BLOCK * 4 + 16 * CBH_BLOCK * 8 + 2 * 4096 + 16];   // + the flat / walk2 kernels' chain scratch, per-action notes, site results and class tables
 #endif
 __device__ __forceinline__ u32 cached_columns(const KernelArgs* ka) {
   const u32 n = ka->b.n_columns;

@@ -178,6 +178,7 @@ struct cbh_device_batch {
   KernelArgs last_args;           // what d_args currently holds
   bool have_args = false;
   u32 max_actions = 0, max_roles = 0;   // largest CBH_RQ_ACT_CNT / ROLE_CNT of the batch: select the kernel
+  u32 wide_lo = 0, wide_hi = 0;         // BatchShape::wide_lo / wide_hi
   bool plain_tags = false;              // BatchShape::plain_tags
   std::vector<std::pair<void*, size_t>> allocs;   // (block, capacity) taken from the replica's pool
 };
@@ -326,6 +327,7 @@ extern "C" void* cbh_table_device_ptr(const cbh_table* t) { return t ? t->reps[0
 // need no host pass: the kernels only compare them, or bound them before using one as an index.
 struct BatchShape {
   u32 max_actions = 0, max_roles = 0; bool ascending = true;
+  u32 wide_lo = 0, wide_hi = 0;   // the requests with more than CBH_W2_NA actions or CBH_W2_NR roles lie in [wide_lo, wide_hi)
   // Do the attribute columns hold plain scalars only - no int / uint (cross-type numerics) and no list / map (deep
   // equality)?  Then no classified leaf can need the shared evaluator and the flat kernel without that call decides
   // the batch (cbh_check_flat.h).  One pass over the tag bytes, made only where the answer selects a kernel and only
@@ -366,8 +368,10 @@ static int validate_batch(const cbh_table* t, const cbh_batch* in, BatchShape& s
   const u32* role_off = in->req_u32 + (size_t)CBH_RQ_ROLE_OFF * NR; const u32* role_cnt = in->req_u32 + (size_t)CBH_RQ_ROLE_CNT * NR;
   const u32* act_off = in->req_u32 + (size_t)CBH_RQ_ACT_OFF * NR; const u32* act_cnt = in->req_u32 + (size_t)CBH_RQ_ACT_CNT * NR;
   u32 maxa = 0, maxr = 0; u64 bad = 0, prev_end = 0; bool asc = true;
+  u32 wlo = 0xFFFFFFFFu, whi = 0;
   for (size_t r = 0; r < NR; ++r) {
     const u32 n = act_cnt[r];
+    if (n > CBH_W2_NA || role_cnt[r] > CBH_W2_NR) { if (wlo == 0xFFFFFFFFu) wlo = (u32)r; whi = (u32)r + 1; }
     maxa = n > maxa ? n : maxa;
     maxr = role_cnt[r] > maxr ? role_cnt[r] : maxr;
     bad |= (u64)((u64)role_off[r] + role_cnt[r] > in->n_roles) | (u64)((u64)act_off[r] + n > in->n_tuples);
@@ -378,8 +382,10 @@ static int validate_batch(const cbh_table* t, const cbh_batch* in, BatchShape& s
   if (bad) return fail("cbh_batch: a request's role or action slice lies outside the batch");
   if (in->n_strings && in->str_off[in->n_strings] > in->str_bytes_len) return fail("cbh_batch: string offsets exceed str_bytes_len");
   sh.max_actions = maxa; sh.max_roles = maxr; sh.ascending = asc;
+  sh.wide_lo = whi ? wlo : 0; sh.wide_hi = whi;
   sh.tags = nullptr; sh.n_tags = 0; sh.plain.store(-1, std::memory_order_relaxed);
-  if ((t->meta[CBH_M_FLAGS] & CBH_MF_FLAT) && maxa <= 4 && maxr <= 4) { sh.tags = in->col_tag; sh.n_tags = (size_t)in->n_columns * NR; }
+  if (((t->meta[CBH_M_FLAGS] & CBH_MF_FLAT) && maxa <= 4 && maxr <= 4) ||
+      ((t->meta[CBH_M_FLAGS] & CBH_MF_WALK2) && t->meta[CBH_M_GSLOTS_ALL] > t->meta[CBH_M_GSLOTS_GENERIC])) { sh.tags = in->col_tag; sh.n_tags = (size_t)in->n_columns * NR; }
   return 0;
 }
 
@@ -448,6 +454,7 @@ extern "C" int cbh_batch_upload_on(cbh_table* t, uint32_t device_index, const cb
   if (!b) return fail("out of memory");
   cbh_table_retain(t);
   b->table = t; b->rep = rep; b->max_actions = sh.max_actions; b->max_roles = sh.max_roles; b->plain_tags = sh.plain_tags();
+  b->wide_lo = sh.wide_lo; b->wide_hi = sh.wide_hi;
   BatchDev& d = b->dev;
   d.n_requests = in->n_requests; d.n_tuples = in->n_tuples; d.n_roles = in->n_roles;
   d.n_columns = in->n_columns; d.n_strings = in->n_strings; d.heap_len = in->heap_len;
@@ -467,6 +474,8 @@ extern "C" int cbh_batch_upload_on(cbh_table* t, uint32_t device_index, const cb
   rc |= up(b, d.str_bytes, in->str_bytes, in->str_bytes_len, s);
   rc |= up(b, d.str_flags, in->str_flags, in->n_strings, s);
   rc |= dalloc(b, d.gbits, (size_t)3 * in->n_strings);
+  d.n_gwords = (rep->dev.flags & CBH_MF_WALK2) ? w2_gwords(rep->dev.gslots_generic, rep->dev.gslots_all, b->plain_tags) : 0;
+  if (d.n_gwords) rc |= dalloc(b, d.gres, (size_t)d.n_gwords * NR); else d.gres = nullptr;
   rc |= dalloc(b, b->out.effect, in->n_tuples);
   rc |= dalloc(b, b->out.policy, in->n_tuples);
   rc |= dalloc(b, b->out.scope, in->n_tuples);
@@ -498,8 +507,40 @@ static void collect_times(Replica* r) {   // after the stream has been synchroni
   for (auto& sl : r->ring) collect_slot(r, sl);
 }
 
-// CBH_NO_FLAT=1 (measurement aid): decide with the general walk even where the flat kernel applies
-static u32 pick_flags(u32 eval_flags) { static const bool no_flat = getenv("CBH_NO_FLAT") != nullptr; return no_flat ? (eval_flags | CBH_F_STRICT_EVALUATION) : eval_flags; }
+// CBH_NO_FLAT=1 / CBH_NO_WALK2=1 (measurement aids): leave the flat kernels / cbh_walk2_kernel out of the choice
+static CbhPlan plan_for(const TableDev& dev, u32 max_actions, u32 max_roles, bool plain_tags, u32 eval_flags) {
+  static const bool no_flat = getenv("CBH_NO_FLAT") != nullptr, no_walk2 = getenv("CBH_NO_WALK2") != nullptr;
+  const bool has_globs = (dev.nfa_words[0] | dev.nfa_words[1] | dev.nfa_words[2]) != 0 || (dev.flags & CBH_MF_HAS_ANY_PATTERN);
+  return cbh_plan(dev.flags, dev.n_dr, has_globs, dev.gslots_generic, dev.gslots_all, max_actions, max_roles, plain_tags, eval_flags, no_flat, no_walk2);
+}
+// the launches that decide the requests [lo, hi) of `ka.b`; [wide_lo, wide_hi) = where the batch's requests wider than
+// cbh_walk2_kernel's shape lie (empty: none)
+static void launch_plan(const CbhPlan& pl, const TableDev& dev, KernelArgs ka, const KernelArgs* d_args, u32 lo, u32 hi, u32 wide_lo, u32 wide_hi,
+                        size_t pad, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+  if (hi <= lo) return;
+  ka.b.req_lo = lo; ka.b.req_hi = hi;
+  ka.flags &= ~(u32)CBH_FI_MASK;
+  const u32 n = hi - lo;
+  // (timed launches: the start event rides on the first kernel of the plan, the stop event on the last - the figure is the
+  // whole plan's, gaps between its kernels included)
+  auto go = [&](cbh_check_kernel_fn fn, u32 grid, u32 threads, size_t lds, const KernelArgs& a, bool last) {
+    if (ev0 || (ev1 && last)) { hipExtLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, s, ev0, last ? ev1 : nullptr, 0, a, d_args); ev0 = nullptr; }
+    else hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, s, a, d_args);
+  };
+  if (pl.kind == 2) {
+    if (pl.wide_kernel) {   // the few wider requests: the general walk, on the lanes the walk below leaves alone
+      KernelArgs kw = ka;
+      kw.b.req_lo = std::max(lo, wide_lo); kw.b.req_hi = std::min(hi, wide_hi);
+      kw.flags |= CBH_FI_ONLY_WIDE;
+      if (kw.b.req_hi > kw.b.req_lo) go(pl.wide_kernel, (kw.b.req_hi - kw.b.req_lo + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, cbh_general_lds(dev.flags, ka.b.n_columns), kw, false);
+      ka.flags |= CBH_FI_SKIP_WIDE;
+    }
+    ka.b.n_gwords = ka.b.gres ? pl.n_gwords : 0;
+    if (ka.b.n_gwords)   // the evaluation sites first: their results are what the walk reads
+      go(cbh_walk2_pre_kernel, (n + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, true), ka, false);
+  }
+  go(pl.kernel, (n + pl.threads - 1) / pl.threads, pl.threads, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, false) + pad, ka, true);
+}
 // CBH_LDS_PAD=<bytes> (measurement aid): extra dynamic LDS per workgroup of the resident launches, to hold the occupancy down
 static size_t lds_pad() { static const size_t pad = [] { const char* e = getenv("CBH_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }(); return pad; }
 static u32 nfa_maxw(const TableDev& d) { return std::max(std::max(d.nfa_words[0], d.nfa_words[1]), d.nfa_words[2]); }
@@ -533,7 +574,7 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
     // writes every output word of every request, so nothing needs clearing between launches)
     KernelArgs ka;
     std::memset(&ka, 0, sizeof(ka));
-    ka.t = rep->dev; ka.b = d; ka.o = b->out; ka.now_ns = p->now_ns; ka.flags = p->flags;
+    ka.t = rep->dev; ka.b = d; ka.o = b->out; ka.now_ns = p->now_ns; ka.flags = p->flags & ~(u32)CBH_FI_MASK;
     if (!b->have_args || std::memcmp(&ka, &b->last_args, sizeof(ka)) != 0) {
       b->last_args = ka; b->have_args = true;
       HIPCHK(hipMemcpyAsync(b->d_args, &b->last_args, sizeof(ka), hipMemcpyHostToDevice, s));
@@ -551,12 +592,8 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   }
   sl.pending = false;
   if (d.n_requests) {
-    u32 threads = CBH_BLOCK; bool flat = false;
-    const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, maxw != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), b->max_actions, b->max_roles, b->plain_tags, pick_flags(p->flags), &threads, &flat);
-    const u32 grid = (d.n_requests + threads - 1) / threads;   // one lane per request
-    const size_t lds = (check_lds_bytes(d, rep->dev.flags) + (flat ? cbh_flat_chain_bytes(rep->dev.max_depth, rep->dev.n_scopes) : 0)) * (threads / CBH_BLOCK) + (flat ? cbh_flat_class_bytes(rep->dev.K) : 0) + lds_pad();
-    if (timed) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, sl.ev[2], sl.ev[3], 0, b->last_args, (const KernelArgs*)b->d_args);
-    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, s, b->last_args, (const KernelArgs*)b->d_args);
+    const CbhPlan pl = plan_for(rep->dev, b->max_actions, b->max_roles, b->plain_tags, p->flags);
+    launch_plan(pl, rep->dev, b->last_args, (const KernelArgs*)b->d_args, 0, d.n_requests, b->wide_lo, b->wide_hi, lds_pad(), s, timed ? sl.ev[2] : nullptr, timed ? sl.ev[3] : nullptr);
     sl.pending = timed;
   }
   HIPCHK(hipGetLastError());
@@ -709,10 +746,10 @@ extern "C" void cbh_result_bind_slab(cbh_result* r, void* slab, uint32_t n_tuple
 }
 
 struct Layout {
-  Seg args, req, roles, act, ctag, cval, htag, hval, soff, sbytes, sflags, gbits, eff, pol, scope, status, edr;
+  Seg args, req, roles, act, ctag, cval, htag, hval, soff, sbytes, sflags, gbits, gres, eff, pol, scope, status, edr;
   size_t in_begin, in_end, out_begin, total;
 };
-static Layout make_layout(const cbh_batch* in) {
+static Layout make_layout(const cbh_batch* in, const cbh_table* t) {
   Layout L;
   const size_t NR = in->n_requests, NT = in->n_tuples, NS = in->n_strings;
   const InOffsets io = in_offsets(in);
@@ -728,6 +765,9 @@ static Layout make_layout(const cbh_batch* in) {
   L.in_end = A + io.end;
   size_t cur = L.in_end;
   L.gbits = Seg{cur, 3 * NS * 8, nullptr}; cur += (L.gbits.bytes + 255) & ~(size_t)255;
+  // results of the evaluation sites (cbh_walk2_pre_kernel -> cbh_walk2_kernel), sized for a batch that needs all of them
+  const size_t gw = (t->meta[CBH_M_FLAGS] & CBH_MF_WALK2) ? w2_gwords(t->meta[CBH_M_GSLOTS_GENERIC], t->meta[CBH_M_GSLOTS_ALL], false) : 0;
+  L.gres = Seg{cur, gw * NR * 8, nullptr}; cur += (L.gres.bytes + 255) & ~(size_t)255;
   L.out_begin = cur;
   const OutOffsets oo = out_offsets(NT, NR);
   L.eff = Seg{cur + oo.eff, NT, nullptr}; L.status = Seg{cur + oo.status, NT, nullptr}; L.pol = Seg{cur + oo.pol, NT * 4, nullptr};
@@ -747,7 +787,7 @@ static const uint8_t* slab_base(const Layout& L) {
 }
 static void bind_args(KernelArgs& ka, const TableDev& tdev, const cbh_batch* in, const cbh_params* p, const Layout& L, uint8_t* base) {
   std::memset(&ka, 0, sizeof(ka));
-  ka.t = tdev; ka.now_ns = p->now_ns; ka.flags = p->flags;
+  ka.t = tdev; ka.now_ns = p->now_ns; ka.flags = p->flags & ~(u32)CBH_FI_MASK;
   BatchDev& d = ka.b;
   d.n_requests = in->n_requests; d.n_tuples = in->n_tuples; d.n_roles = in->n_roles;
   d.n_columns = in->n_columns; d.n_strings = in->n_strings; d.heap_len = in->heap_len;
@@ -756,6 +796,7 @@ static void bind_args(KernelArgs& ka, const TableDev& tdev, const cbh_batch* in,
   d.tuple_action = (const u32*)(base + L.act.off); d.col_tag = base + L.ctag.off; d.col_val = (const u64*)(base + L.cval.off);
   d.heap_tag = base + L.htag.off; d.heap_val = (const u64*)(base + L.hval.off); d.str_off = (const u32*)(base + L.soff.off);
   d.str_bytes = base + L.sbytes.off; d.str_flags = base + L.sflags.off; d.gbits = (u64*)(base + L.gbits.off);
+  d.gres = L.gres.bytes ? (u64*)(base + L.gres.off) : nullptr; d.n_gwords = 0;   // n_gwords: per launch (launch_plan)
   ka.o.effect = base + L.eff.off; ka.o.policy = (u32*)(base + L.pol.off); ka.o.scope = (u32*)(base + L.scope.off);
   ka.o.status = base + L.status.off; ka.o.edr = (u64*)(base + L.edr.off);
 }
@@ -769,11 +810,7 @@ static void launch_resolve(const Replica* rep, const KernelArgs& ka, const Layou
 }
 static void launch_check(const Replica* rep, KernelArgs ka, const KernelArgs* d_args, u32 lo, u32 hi, const BatchShape& sh, hipStream_t s) {
   if (hi <= lo) return;
-  ka.b.req_lo = lo; ka.b.req_hi = hi;
-  u32 threads = CBH_BLOCK; bool flat = false;
-  const cbh_check_kernel_fn kernel = cbh_pick_kernel(rep->dev.flags, rep->dev.n_dr, nfa_maxw(rep->dev) != 0 || (rep->dev.flags & CBH_MF_HAS_ANY_PATTERN), sh.max_actions, sh.max_roles, sh.plain_tags(), pick_flags(ka.flags), &threads, &flat);
-  const u32 grid = (hi - lo + threads - 1) / threads;   // one lane per request
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), (check_lds_bytes(ka.b, rep->dev.flags) + (flat ? cbh_flat_chain_bytes(rep->dev.max_depth, rep->dev.n_scopes) : 0)) * (threads / CBH_BLOCK) + (flat ? cbh_flat_class_bytes(rep->dev.K) : 0), s, ka, d_args);
+  launch_plan(plan_for(rep->dev, sh.max_actions, sh.max_roles, sh.plain_tags(), ka.flags), rep->dev, ka, d_args, lo, hi, sh.wide_lo, sh.wide_hi, 0, s);
 }
 
 // a small batch on one device: everything packed into the pinned staging block.  Two ways across PCIe:
@@ -967,7 +1004,7 @@ extern "C" int cbh_check_batch(cbh_table* t, const cbh_batch* in, const cbh_para
   TableRef ref(t);
   BatchShape sh;
   if (validate_batch(t, in, sh) != 0) return -1;
-  const Layout L = make_layout(in);
+  const Layout L = make_layout(in, t);
   const u32 NR = in->n_requests;
   if (L.in_end <= SMALL_BATCH_BYTES || NR == 0) return run_small(t, t->reps[0], in, p, out, sh, L);
 
@@ -1014,7 +1051,7 @@ extern "C" int cbh_trace_batch(cbh_table* t, const cbh_batch* in, const cbh_para
   if (validate_batch(t, in, sh) != 0) return -1;
   trace->count = 0;
   if (in->n_requests == 0) return 0;
-  const Layout L = make_layout(in);
+  const Layout L = make_layout(in, t);
   const size_t log_off = (L.total + 255) & ~(size_t)255;                       // {count, pad ...} then the records
   const size_t rec_off = log_off + 256, rec_bytes = (size_t)trace->capacity * CBH_TRACE_RECORD_WORDS * 4;
   const size_t total = rec_off + rec_bytes;

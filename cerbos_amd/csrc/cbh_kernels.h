@@ -132,3 +132,4 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_resolve_globs_kernel(TableDev t
 
 #include "cbh_check_wave.h"
 #include "cbh_check_flat.h"
+#include "cbh_check_walk2.h"

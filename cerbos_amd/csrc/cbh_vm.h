@@ -53,6 +53,8 @@ struct TableDev {
   const CBH_G u32* trace_rows; const CBH_G u32* trace_dr;   // CBH_SEC_TRACE_*: the trace pass's programs per rule / derived-role /
   const CBH_G u32* trace_rp; const CBH_G u32* trace_pool;   // role-policy record (cbh_trace_batch only)
   const CBH_G u32* rowpat;                                  // [n_rows][8] pattern halves (cbh_blob.h CbhRowPatField)
+  const CBH_G u32* rowx; const CBH_G u32* rpx;              // CBH_SEC_ROWX / CBH_SEC_RPX (cbh_check_walk2.h)
+  u32 gslots_generic, gslots_all;                           // evaluation-site slots of the table (CBH_M_GSLOTS_*)
   const CBH_G u32* rprows; u32 n_rprows;
   const CBH_G u32* pool;
   const CBH_G u32* dr; u32 n_dr;
@@ -79,6 +81,8 @@ struct BatchDev {
   const CBH_G u8* heap_tag; const CBH_G u64* heap_val;
   const CBH_G u32* str_off; const CBH_G u8* str_bytes; const CBH_G u8* str_flags;
   CBH_G u64* gbits; // [3][n_strings], written by the resolve kernel
+  CBH_G u64* gres;  // [n_gwords][n_requests] results of the evaluation sites (cbh_walk2_pre_kernel writes, cbh_walk2_kernel reads)
+  u32 n_gwords; u32 pad_gw;
 };
 
 struct OutDev {
@@ -89,6 +93,16 @@ struct OutDev {
 // Launch arguments of the decision kernel.  They live in device memory (one uniform pointer
 // as the only kernel argument) so that every table / batch base address is a scalar load.
 struct __attribute__((aligned(16))) KernelArgs { TableDev t; BatchDev b; OutDev o; long long now_ns; u32 flags; u32 pad; };
+
+// Internal launch flags (KernelArgs.flags; never part of cbh_params.flags - the entry points mask them off): a batch whose
+// requests mostly fit cbh_walk2_kernel's shape (<= 8 actions, <= 4 roles) is decided by it, and the few wider requests
+// by the general walk in a launch of its own over the same arrays - each kernel leaves the other's lanes alone.
+#define CBH_FI_SKIP_WIDE 0x10000u   /* cbh_walk2_kernel / its pre-pass: a wider request is not this launch's */
+#define CBH_FI_ONLY_WIDE 0x20000u   /* cbh_check_kernel*: only the wider requests are this launch's */
+#define CBH_FI_MASK 0x30000u
+#define CBH_W2_NA 8u
+#define CBH_W2_NR 4u
+__device__ __forceinline__ bool cbh_is_wide(u32 act_cnt, u32 role_cnt) { return act_cnt > CBH_W2_NA || role_cnt > CBH_W2_NR; }
 
 struct Val { u32 t; u64 v; };
 

@@ -25,7 +25,7 @@ from .celc import COND_LEAF, COND_LEAFTREE, COND_PC_MASK, LoweringError, Params,
 from .globs import GlobNFA, fix_glob, has_meta
 
 BLOB_MAGIC = 0x31484243
-BLOB_VERSION = 19
+BLOB_VERSION = 20
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
 PAT_ANY = 0x7FFFFFFF     # the lone "*": matches every string, no automaton needed
@@ -41,6 +41,16 @@ RP_F_OUTPUT_ONLY, RP_F_SHARES_KEY = 0x80000000, 0x40000000   # cbh_blob.h CBH_RP
 ROW_F_DRLEAF_EMBEDDED = 128
 ROW_F_TREE_EMBEDDED, ROW_F_DRTREE_EMBEDDED = 256, 512   # the slot holds a tree descriptor (_tree_descriptor)
 MF_FLAT_CLOSED = 512
+# cbh_check_walk2.h: the decision kernel for everything else a table can hold (principal policies, role policies, parent
+# roles, glob patterns, generic programs).  Per record: CBH_SEC_ROWX; per role-policy rule: CBH_SEC_RPX.
+MF_WALK2 = 2048
+ROW_F_X, ROW_F_XEXACT = 1024, 2048
+SEC_ROWX, SEC_RPX = 40, 41
+B_RPROLES = 8
+M_GSLOTS_GENERIC, M_GSLOTS_ALL = 18, 19
+GSLOT_NONE = 0xFFFF
+WALK2_MAX_GLOBS = 16      # glob patterns per dimension (action, role) a lane keeps match bits for
+WALK2_MAX_GSLOTS = 256    # evaluation-site slots of one request (4 result bits each, 16 to a 64-bit word: cbh_walk2_pre_kernel)
 
 (SEC_META, SEC_STR_OFF, SEC_STR_BYTES, SEC_SCOPE_PARENT, SEC_SCOPE_FLAGS, SEC_SCOPE_SID, SEC_HASH,
  SEC_ROWS, SEC_RPROWS, SEC_U32POOL, SEC_DR, SEC_CODE, SEC_CONST_TAG, SEC_CONST_VAL, SEC_THEAP_TAG,
@@ -234,6 +244,12 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
     trace_row_rules = []   # per device row: (a rule-table row of its rule, principal policy?) - the trace pass's programs are compiled last
     trace_dr_defs = []     # per derived-role record: its definition
     trace_rp_rules = []    # per role-policy record: its rule
+    row_family = []        # per device row: ("R", version, kind) | ("P", version, principal) - whose evaluation sites share slot numbers
+    row_scope = []         # per device row: the scope of its policy
+    rp_scope = []          # per role-policy record likewise
+    rp_family = []         # per role-policy record: its version
+    rp_allow = []          # per role-policy record: its allow-action strings
+    dr_family = []         # per derived-role record: ("R", version, kind)
 
     def row_programs(r, principal_policy):
         params = Params(r["params"]["constants"], r["params"]["ordered_variables"], globals_) if r["params"] else Params(None, None, globals_)
@@ -262,7 +278,7 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
         pool.extend(refs)
         return off, len(refs), True, [NONE] * 2
 
-    def add_bucket_rows(rows, principal_policy):
+    def add_bucket_rows(rows, principal_policy, family=None, scope=None):
         """Emit the device rows of one bucket; returns how many.
 
         The rule table holds one row per (rule, role, action) (ruletable.go addResourcePolicy /
@@ -311,6 +327,8 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
                     row_roles.append(None if principal_policy else rl)
                     row_actions.append(None if principal_policy else al)
                     trace_row_rules.append((grp[0], principal_policy))
+                    row_family.append(family)
+                    row_scope.append(scope)
                     n += 1
         return n
 
@@ -319,7 +337,7 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
         ver, kind, scope = key
         rows = sorted(res_buckets[key], key=lambda r: r["id"])
         begin = len(row_cols[0])
-        n_rows = add_bucket_rows(rows, False)
+        n_rows = add_bucket_rows(rows, False, ("R", ver, kind), scope)
         dr_begin = len(dr_cols[0])
         drs = rt["policy_derived_roles"].get(namer.resource_policy_fqn(kind, ver, scope)) or {}
         for name, dr in drs.items():
@@ -333,6 +351,7 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
                 dr_cols[2].append(len(dr["parent_roles"]))
                 pool.extend(sid(p) for p in dr["parent_roles"])
             trace_dr_defs.append(dr)
+            dr_family.append(("R", ver, kind))
             dparams = Params(dr["constants"], dr["ordered_variables"], globals_, null_on_error=True)
             # a derived-role definition that reads runtime.effectiveDerivedRoles sees, in the reference, the
             # roles of whichever scope/action was processed last (check.go:262,281): not reproducible per tuple
@@ -348,7 +367,7 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
         ver, scope, principal = key
         rows = sorted(prin_buckets[key], key=lambda r: r["id"])
         begin = len(row_cols[0])
-        n_rows = add_bucket_rows(rows, True)
+        n_rows = add_bucket_rows(rows, True, ("P", ver, principal), scope)
         entries.append((B_PRINCIPAL, sid(ver), lt.scope_index[scope], sid(principal), begin, n_rows, 0, 0))
     for ver, scope in sorted(pp_exists):
         entries.append((B_PPEXISTS, sid(ver), lt.scope_index[scope], 0, 1, 0, 0, 0))
@@ -367,6 +386,9 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
                               | (RP_F_SHARES_KEY if r["id"] in rp_shares_key else 0))
             pool.extend(allow_action_ref(a) for a in r["allow_actions"])
             trace_rp_rules.append(r)
+            rp_family.append(ver)
+            rp_scope.append(scope)
+            rp_allow.append(list(r["allow_actions"]))
             if r["id"] in rp_history_dependent:
                 rp_cols[3].append(pb.unsupported_program(namer.policy_key_from_fqn(r["origin_fqn"]),
                                                          "role-policy rules for overlapping resource globs share an evaluation key but "
@@ -513,8 +535,10 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
             per_row.append((mask, exact))
         return table, per_row, len(class_of)
 
-    role_class, role_rows, n_role_classes = classes(row_roles, dr_parents)   # parent roles of derived roles get classes too
-    action_class, action_rows, n_action_classes = classes(row_actions)
+    rp_role_names = list(dict.fromkeys(role for (_v, _s, role) in sorted(rp_buckets)))
+    # parent roles of derived roles, the roles that have role policies and the literal actions of their allow lists get classes too
+    role_class, role_rows, n_role_classes = classes(row_roles, dr_parents + [rp_role_names])
+    action_class, action_rows, n_action_classes = classes(row_actions, [[a for a in al if not has_meta(a)] for al in rp_allow])
     # fewer than 32 classes in both dimensions: "any other string" (bit 63) is mirrored in bit 31 of the low dwords,
     # so that a kernel may match on the low dword alone (cbh_check_flat.h); no lane ever holds class 31 itself
     small_classes = n_role_classes < 31 and n_action_classes < 31
@@ -569,6 +593,169 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
         vals = [mask & 0xFFFFFFFF, mask >> 32, (1 if emb else 0) | (2 if tree else 0), cond, dr_cols[0][i], 0, 0, 0] + rec
         for k in range(16):
             drx_cols[k].append(vals[k])
+
+    # ---- cbh_check_walk2.h: what the general decision kernel reads besides the records themselves
+    ALL64 = 0xFFFFFFFFFFFFFFFF
+    walk2_why = []     # reasons the table stays on the older kernels (stats["walk2_refused"])
+
+    def class_bit(table, key):
+        i = lt.string_ids.get(key)
+        c = int(table[i]) if i is not None else 63
+        return (1 << c) if c < 62 else None
+
+    def x_masks(keys, table, dim, meta_is_glob=False):
+        """(literal class mask, glob mask, exact?) of a role / action list for the kernel that matches by class AND by glob
+        bit: '*' = every class; a glob = its bit (the lane holds the match bits of its strings for the first
+        WALK2_MAX_GLOBS patterns of the dimension); a literal = its class."""
+        lit, glob, exact = 0, 0, keys is not None
+        for key in keys or ():
+            if key == "*" and not meta_is_glob:
+                lit = ALL64
+            elif ("*" in key) or (meta_is_glob and has_meta(key)):
+                gi = dims[dim].globs.get(key)
+                if gi is None or gi >= WALK2_MAX_GLOBS:
+                    exact = False
+                else:
+                    glob |= 1 << gi
+            else:
+                b = class_bit(table, key) if key else None
+                if b is None:
+                    exact = False
+                else:
+                    lit |= b
+        return lit, glob, exact
+
+    n_rows_total = len(row_cols[0])
+    rowx = np.zeros((n_rows_total, 8), dtype=np.uint32)
+    rowx[:, 0] = GSLOT_NONE | (GSLOT_NONE << 16)
+    row_rmask = []   # per row (literal role class mask, role glob mask) for the buckets' union masks
+    for i in range(n_rows_total):
+        rl, rg, rex = x_masks(row_roles[i], role_class, DIM_ROLE)
+        al, ag, aex = x_masks(row_actions[i], action_class, DIM_ACTION)
+        row_rmask.append((rl, rg))
+        rowx[i, 1] = ag | (rg << 16)
+        rowx[i, 2], rowx[i, 3], rowx[i, 4], rowx[i, 5] = rl & 0xFFFFFFFF, rl >> 32, al & 0xFFFFFFFF, al >> 32
+        if row_roles[i] is not None:
+            if rex and aex:
+                row_cols[ROW_FLAGS][i] |= ROW_F_XEXACT
+            else:
+                walk2_why.append("a rule's role / action list is not decidable by class and glob bits")
+        if ag or rg:
+            row_cols[ROW_FLAGS][i] |= ROW_F_X
+    # role-policy rules once more in the form that kernel reads (CbhRpxField): allow list as class + glob masks, the
+    # condition's leaf / tree descriptor inline
+    n_rp_total = len(rp_cols[0])
+    rpx = np.zeros((n_rp_total, 16), dtype=np.uint32)
+    for i in range(n_rp_total):
+        al, ag, aex = x_masks(rp_allow[i], action_class, DIM_ACTION, meta_is_glob=True)
+        if not aex:
+            walk2_why.append("a role policy's allow list is not decidable by class and glob bits")
+        cond = rp_cols[3][i]
+        rec, fl = [0] * 8, 0
+        if cond != NONE and (cond & COND_LEAF):
+            pc = cond & COND_PC_MASK
+            rec, fl = [int(w) & 0xFFFFFFFF for w in pb.code[pc:pc + 8]], 1
+        elif cond != NONE and (cond & COND_LEAFTREE) and (cond & COND_PC_MASK) in pb.tree_strips:
+            rec, fl = _tree_descriptor(pb.tree_strips[cond & COND_PC_MASK]), 2
+        rpx[i, :8] = [rp_cols[0][i], rp_cols[2][i], cond, GSLOT_NONE, al & 0xFFFFFFFF, al >> 32, ag, fl]
+        rpx[i, 8:] = rec
+    drx_gslot = [GSLOT_NONE] * len(drx_cols[0])
+
+    # Evaluation sites and their slots.  What the walk cannot decide inline - a generic program, or a classified leaf that
+    # meets an int / uint / container value - is evaluated by a launch of its own before the walk (cbh_walk2_pre_kernel: the
+    # interpreter's registers stay out of the walk) which leaves two result bits per site and request.  A site's slot is
+    # unique among everything ONE request can reach: the rules and derived roles of its (version, kind), the rules of its
+    # principal's policies, the role-policy rules of its version.  Generic sites take the low slots: a batch of plain
+    # scalars needs only those.
+    def site_kind(ref, leaf_class, how):
+        if ref == NONE:
+            return None
+        if how == 2 or (how == 1 and leaf_class in (1, 2, 3, 4, 6)):
+            return "open"
+        return "generic"
+
+    # (A program that reads runtime.effectiveDerivedRoles sees the derived roles of the scope being walked, check.go:237-282:
+    # with such programs in the table a slot belongs to one scope's site, not to the program.)
+    per_scope = bool(pb.uses_runtime)
+    sites = []   # (range, family, program [, scope], kind, setter)
+    for i, f in enumerate(row_cols[ROW_FLAGS]):
+        fam = row_family[i]
+        how = 1 if f & ROW_F_LEAF_EMBEDDED else 2 if f & ROW_F_TREE_EMBEDDED else 0
+        k = site_kind(row_cols[ROW_COND][i], row_cols[ROW_LEAF + 7][i], how)
+        if k:
+            sites.append((fam[0], fam, (row_cols[ROW_COND][i], row_scope[i] if per_scope else None), k, ("row", i, 0)))
+        how = 1 if f & ROW_F_DRLEAF_EMBEDDED else 2 if f & ROW_F_DRTREE_EMBEDDED else 0
+        k = site_kind(row_cols[ROW_DRCOND][i], leaf2_cols[7][i], how)
+        if k:
+            sites.append((fam[0], fam, (row_cols[ROW_DRCOND][i], row_scope[i] if per_scope else None), k, ("row", i, 16)))
+    for i in range(len(drx_cols[0])):
+        k = site_kind(drx_cols[3][i], drx_cols[15][i], drx_cols[2][i] & 3)
+        if k:
+            sites.append(("R", dr_family[i], (drx_cols[3][i], "dr"), k, ("dr", i, 0)))
+    for i in range(n_rp_total):
+        k = site_kind(int(rpx[i, 2]), int(rpx[i, 15]), int(rpx[i, 7]))
+        if k:
+            sites.append(("Q", ("Q", rp_family[i]), (int(rpx[i, 2]), rp_scope[i] if per_scope else None), k, ("rp", i, 0)))
+    slot_of, next_free, spans = {}, {}, {}
+    for kind in ("generic", "open"):
+        base = sum(spans.values())
+        for rng in ("R", "P", "Q"):
+            span = 0
+            for (r, fam, prog, k, setter) in sites:
+                if r != rng or k != kind:
+                    continue
+                key = (fam, prog)
+                if key not in slot_of:
+                    n = next_free.get((kind, fam), 0)
+                    next_free[(kind, fam)] = n + 1
+                    slot_of[key] = base + n
+                    span = max(span, n + 1)
+            spans[(kind, rng)] = span
+            base += span
+        if kind == "generic":
+            n_gslots_generic = sum(spans.values())
+    n_gslots_all = sum(spans.values())
+    if n_gslots_all > WALK2_MAX_GSLOTS:
+        walk2_why.append("more than %d evaluation sites on one request's path" % WALK2_MAX_GSLOTS)
+    else:
+        for (r, fam, prog, k, (what, i, shift)) in sites:
+            g = slot_of[(fam, prog)]
+            if what == "row":
+                rowx[i, 0] = (int(rowx[i, 0]) & ~(0xFFFF << shift)) | (g << shift)
+                row_cols[ROW_FLAGS][i] |= ROW_F_X
+            elif what == "dr":
+                drx_gslot[i] = g
+            else:
+                rpx[i, 3] = g
+    for i, g in enumerate(drx_gslot):
+        drx_cols[5][i] = g
+
+    # the roles with role policies at (version, scope), sorted by name: index.go:352-530 walks a request role's
+    # [role] ++ ancestors list, and the ancestors come sorted (ruletable/build.py; the reference's own order is Go's map
+    # iteration) - the kernel visits a slot's OWN role first, then this list
+    rp_by_vs = {}
+    for (ver, scope, role) in sorted(rp_buckets):
+        rp_by_vs.setdefault((ver, scope), []).append(role)
+    for (ver, scope), roles_here in sorted(rp_by_vs.items()):
+        order = sorted(roles_here)
+        if len(order) > 32:
+            walk2_why.append("more than 32 role policies in one scope")
+        for r in order:
+            if class_bit(role_class, r) is None:
+                walk2_why.append("a role with a role policy has no role class")
+        entries.append((B_RPROLES, lt.string_ids[ver], lt.scope_index[scope], 0, len(pool), len(order), 0, 0))
+        pool.extend(lt.string_ids[r] for r in order)
+    # union of the role lists of a resource policy's rules (the base bitmap of Index.Query, index.go:250-305: a scope
+    # yields role-policy DENYs only if some binding there ties the resource to one of the roles)
+    bucket_union = {}
+    for e in entries:
+        if e[0] == B_RESOURCE:
+            lit = glob = 0
+            for i in range(e[4], e[4] + e[5]):
+                lit |= row_rmask[i][0]; glob |= row_rmask[i][1]
+            bucket_union[e[1:4]] = (lit, glob)
+    entries[:] = [((e[0], e[1], e[2], e[3], 1) + (lambda u: (u[0] & 0xFFFFFFFF, u[0] >> 32, u[1]))(bucket_union.get(e[1:4], (0, 0)))) if e[0] == B_RESEXISTS else e
+                  for e in entries]
 
     # ---- directory hash table
     nslots = 16
@@ -629,6 +816,19 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
         inline_ok(drx_cols[3][i], drx_cols[15][i], drx_cols[2][i] & 1, drx_cols[2][i] & 2) for i in range(len(drx_cols[0])))
     meta[M_FLAGS] |= MF_FLAT_CLOSED if closed else 0
     meta[M_FLAGS] |= 1024 if pb.needs_arena else 0   # CBH_MF_NEEDS_ARENA: the interpreter kernels get the lanes' list arenas
+    # WALK2 (cbh_check_walk2.h): every record decided by class masks + glob bits, derived roles by class, no program that
+    # reads runtime.effectiveDerivedRoles (its value is the scope's being walked: the older kernel keeps those tables)
+    if not drx_exact or len(lt.dr_names) > 64:
+        walk2_why.append("a derived role's parent roles are not decidable by class")
+    if max_depth > 16:
+        walk2_why.append("scope chains longer than 16")
+    for d in (DIM_ACTION, DIM_ROLE):
+        if len(dims[d].globs) > WALK2_MAX_GLOBS:
+            walk2_why.append("more than %d glob patterns in a dimension" % WALK2_MAX_GLOBS)
+    lt.walk2_refused = list(dict.fromkeys(walk2_why))
+    meta[M_FLAGS] |= MF_WALK2 if not lt.walk2_refused else 0
+    meta[M_GSLOTS_GENERIC] = n_gslots_generic
+    meta[M_GSLOTS_ALL] = n_gslots_all
     meta[M_MAX_STACK] = pb.max_stack
     meta[M_NDRNAMES] = len(lt.dr_names)
     meta[M_NFA_WORDS_ACTION] = lt.nfas[0].words
@@ -674,6 +874,8 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
         (SEC_ROWPAT, len(pat_cols[0]), row_major(pat_cols, 8)),
         (SEC_ROWLEAF2, len(leaf2_cols[0]), row_major(leaf2_cols, 8)),
         (SEC_DRX, len(drx_cols[0]), row_major(drx_cols, 16)),
+        (SEC_ROWX, n_rows_total, rowx.tobytes()),
+        (SEC_RPX, n_rp_total, rpx.tobytes()),
         (SEC_REGEX, len(pb.regex_words), u32(pb.regex_words)),   # DFA tables of constant `matches` patterns (lower/regex.py)
         (SEC_RPROWS, len(rp_cols[0]), row_major(rp_cols, 4)),
         (SEC_U32POOL, len(pool), u32(pool)),
@@ -727,6 +929,8 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
         "globs": [len(d.globs) for d in dims],
         "reads_request_strings": bool(int(meta[M_FLAGS]) & 64),
         "needs_string_bytes": bool(int(meta[M_FLAGS]) & 128),
+        "walk2": bool(int(meta[M_FLAGS]) & MF_WALK2), "walk2_refused": lt.walk2_refused,
+        "gslots": (int(n_gslots_generic), int(n_gslots_all)),
         "flat_closed": bool(int(meta[M_FLAGS]) & MF_FLAT_CLOSED),   # ... and every condition inline: the variant without the evaluator call serves plain batches
         "flat": bool(int(meta[M_FLAGS]) & 256),   # eligible for cbh_check_flat_kernel (batch shape and mode permitting)   # glob automata or programs that look inside strings   # raw request strings (R.id, R.kind, scopes, versions) read by some program
         "generic_programs": bool(pb.has_generic),   # selects the kernel with the operand-stack interpreter

@@ -81,14 +81,15 @@ extern "C" const char* hostsim_last_error() { return g_err.c_str(); }
 
 static KernelArgs* g_args;
 
-static uint32_t g_max_actions, g_max_roles, g_threads; static bool g_flat, g_plain;   // same kernel selection as cbh_check_resident (cbh_engine.hip)
+static uint32_t g_max_actions, g_max_roles; static bool g_plain;   // same kernel selection as cbh_check_resident (cbh_engine.hip)
+static cbh_check_kernel_fn g_kernel;   // the kernel the fibers run
 
+static int g_last_kind = -1;   // which kernel family decided the last batch (hostsim_last_kind: tests assert the one they mean to exercise)
 static bool g_trace;   // hostsim_trace: the trace pass's kernel (cbh_trace_batch)
 
 static void fiber_main() {
   if (g_trace) cbh_trace_kernel(*g_args, g_args);
-  else
-  cbh_pick_kernel(g_args->t.flags, g_args->t.n_dr, (g_args->t.nfa_words[0] | g_args->t.nfa_words[1] | g_args->t.nfa_words[2] | (g_args->t.flags & CBH_MF_HAS_ANY_PATTERN)) != 0, g_max_actions, g_max_roles, g_plain, g_args->flags, &g_threads, &g_flat)(*g_args, g_args);
+  else g_kernel(*g_args, g_args);
   g_fibers[g_cur].done = true;
   g_fibers[g_cur].waiting = 0;
   swapcontext(&g_fibers[g_cur].ctx, &g_sched);
@@ -190,21 +191,38 @@ static int run_sim(const void* blob, size_t len, const cbh_batch* in, const cbh_
     const uint32_t x = in->col_tag[i];
     if ((x - CBH_T_INT) < 2u || (x - CBH_T_LIST) < 2u) g_plain = false;
   }
+  // the same choice of kernels as the library makes (cbh_engine.hip plan_for); CBH_NO_FLAT / CBH_NO_WALK2 as there
+  const bool has_globs = (a.t.nfa_words[0] | a.t.nfa_words[1] | a.t.nfa_words[2] | (a.t.flags & CBH_MF_HAS_ANY_PATTERN)) != 0;
+  const CbhPlan pl = cbh_plan(a.t.flags, a.t.n_dr, has_globs, a.t.gslots_generic, a.t.gslots_all, g_max_actions, g_max_roles, g_plain, a.flags,
+                              getenv("CBH_NO_FLAT") != nullptr, getenv("CBH_NO_WALK2") != nullptr);
+  std::vector<uint64_t> gres((size_t)pl.n_gwords * in->n_requests + 1, 0xDDDDDDDDDDDDDDDDull);
+  b.gres = pl.n_gwords ? gres.data() : nullptr; b.n_gwords = pl.n_gwords;
+  if (const char* e = getenv("CBH_HOSTSIM_REPORT")) { if (*e == '1') std::fprintf(stderr, "hostsim: kernel kind %d, %u result words\n", pl.kind, pl.n_gwords); }
+  g_last_kind = trace ? -1 : pl.kind;
   // two launches over an arbitrary (unaligned) split of the batch: the chunk window [req_lo, req_hi) that the
   // one-shot path pipelines with (cbh_engine.hip) is exercised by every test of the CPU tier
   const uint32_t n = in->n_requests, mid = n > 3 ? (n / 2) - (n / 2) % 3 + 1 : n;
   const uint32_t cuts[3] = {0, mid, n};
+  const uint32_t user_flags = a.flags & ~(uint32_t)CBH_FI_MASK;
   for (int c = 0; c < 2; ++c) {
     b.req_lo = cuts[c]; b.req_hi = cuts[c + 1];
     const uint32_t nblocks = (b.req_hi - b.req_lo + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
+    a.flags = user_flags;
+    if (!trace && pl.kind == 2) {   // as cbh_engine.hip launch_plan
+      if (pl.wide_kernel) { a.flags = user_flags | CBH_FI_ONLY_WIDE; g_kernel = pl.wide_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk); a.flags = user_flags | CBH_FI_SKIP_WIDE; }
+      if (pl.n_gwords) { g_kernel = cbh_walk2_pre_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk); }
+    }
+    g_kernel = pl.kernel;
     for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
   }
+  a.flags = user_flags;
   return 0;
 }
 extern "C" int hostsim_check(const void* blob, size_t len, const cbh_batch* in, const cbh_params* p,
                              cbh_result* out, uint64_t* gbits) {
   return run_sim(blob, len, in, p, out, gbits, nullptr);
 }
+extern "C" int hostsim_last_kind() { return g_last_kind; }
 extern "C" int hostsim_trace(const void* blob, size_t len, const cbh_batch* in, const cbh_params* p,
                              cbh_result* out, uint64_t* gbits, cbh_trace* trace) {
   return run_sim(blob, len, in, p, out, gbits, trace);

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "hostsim", "hostsim.cpp")
 LIB = os.path.join(HERE, "hostsim", "libcbh_hostsim.so")
 _DEPS = [SRC] + [os.path.join(ROOT, "cerbos_amd", "csrc", f) for f in
-                 ("cbh_kernels.h", "cbh_check_wave.h", "cbh_check_flat.h", "cbh_interp.h", "cbh_vm.h", "cbh_blob.h", "cbh_image.h")] + [os.path.join(ROOT, "include", "cerbos_hip.h")]
+                 ("cbh_kernels.h", "cbh_check_wave.h", "cbh_check_flat.h", "cbh_check_walk2.h", "cbh_interp.h", "cbh_vm.h", "cbh_blob.h", "cbh_image.h")] + [os.path.join(ROOT, "include", "cerbos_hip.h")]
 
 _lib = None
 
@@ -38,6 +38,7 @@ def lib():
                                        C.POINTER(capi.CResult), C.c_void_p, C.POINTER(capi.CTrace)]
         _lib.hostsim_trace.restype = C.c_int
         _lib.hostsim_last_error.restype = C.c_char_p
+        _lib.hostsim_last_kind.restype = C.c_int
     return _lib
 
 
@@ -64,6 +65,11 @@ def check(lt, batch, now_ns=0, flags=0, device_order=False):
     if rc != 0:
         raise RuntimeError(lib().hostsim_last_error().decode())
     return res if device_order else res.to_input_order(batch)
+
+
+def last_kind():
+    """Which kernel family decided the last batch: 0 the general walk, 1 a flat kernel, 2 cbh_walk2_kernel."""
+    return lib().hostsim_last_kind()
 
 
 def trace(lt, batch, now_ns=0, flags=0, capacity=None):

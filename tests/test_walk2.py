@@ -1,0 +1,308 @@
+"""cbh_walk2_kernel (cbh_check_walk2.h): the scopes -> records -> roles-side-by-side walk for tables with principal
+policies, role policies, parent roles, glob patterns and generic conditions - with its pre-pass for the evaluation
+sites - against the general walk (cbh_check_wave.h, the same batch with CBH_NO_WALK2=1) tuple by tuple, and against
+oracle/check.py per action (effect, policy, scope), per request (derived roles, whether evaluation errors were
+recorded).  CPU tier: the kernel sources on the host simulator.  GPU tier: the kernels through the C ABI (oracle only:
+the library reads its environment once)."""
+import os
+
+import numpy as np
+import pytest
+
+import hostsim_api
+from cerbos_amd import capi, workloads
+from cerbos_amd.engine import Conf, HipEvaluator
+from cerbos_amd.flatten import Flattener
+from cerbos_amd.lower.blob import lower_rule_table
+from cerbos_amd.lower.celc import LoweringError
+from cerbos_amd.policy.loader import policies_from_docs
+from cerbos_amd.ruletable.build import rule_table_from_policies
+from helpers import norm_actions, store_rule_table
+from oracle.check import EvalParams, RuleTableOracle
+from test_fuzz_parity import _policies, _requests
+from test_hostsim_golden import GLOBALS, HostSimEvaluator
+
+API = "api.cerbos.dev/v1"
+NOW = 1_700_000_000_000_000_000
+
+
+def _expr(e):
+    return {"match": {"expr": e}}
+
+
+class _NoWalk2:
+    def __enter__(self):
+        os.environ["CBH_NO_WALK2"] = "1"
+
+    def __exit__(self, *exc):
+        os.environ.pop("CBH_NO_WALK2", None)
+
+
+def _both_kernels(lt, batch, flags):
+    """The batch through cbh_walk2_kernel and through the general walk (device order): every output word must agree,
+    the error status per request."""
+    new = hostsim_api.check(lt, batch, NOW, flags, device_order=True)
+    assert hostsim_api.last_kind() == 2, "the table / batch must run on cbh_walk2_kernel (refused: %s)" % lt.stats["walk2_refused"]
+    with _NoWalk2():
+        old = hostsim_api.check(lt, batch, NOW, flags, device_order=True)
+        assert hostsim_api.last_kind() != 2
+    for f in ("effect", "policy", "scope", "edr"):
+        a, b = getattr(new, f), getattr(old, f)
+        assert np.array_equal(a, b), (f, np.nonzero(a != b)[0][:8])
+    assert np.array_equal(new.status == capi.ST_UNSUPPORTED, old.status == capi.ST_UNSUPPORTED)
+    n = batch.n_requests
+    off, cnt = batch.req_u32[8].astype(np.int64), batch.req_u32[9].astype(np.int64)
+    for r in range(n):
+        sl = slice(off[r], off[r] + cnt[r])
+        assert (new.status[sl] == capi.ST_CEL_ERROR).any() == (old.status[sl] == capi.ST_CEL_ERROR).any(), r
+    return new
+
+
+def _against_oracle(rt, lt, make_evaluator, inputs, lenient=False, globals_=None):
+    ev = make_evaluator(lt)
+    try:
+        batch = ev.flattener.flatten(inputs, "default", "")
+        flags = capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0)
+        res = ev.table.check(batch, now_ns=NOW, flags=flags)
+        outs, bad = ev.assemble(inputs, batch, res, "default", allow_unsupported=True)
+    finally:
+        if not isinstance(ev, HostSimEvaluator):
+            ev.close()
+    orc = RuleTableOracle(rt)
+    t = n_err = 0
+    for i, (inp, have) in enumerate(zip(inputs, outs)):
+        na = len(inp["actions"])
+        if i not in bad:
+            want = orc.check(inp, EvalParams(now_ns=NOW, lenient_scope_search=lenient, globals_=globals_))
+            assert norm_actions(have) == norm_actions(want), (lenient, inp, have["actions"], want["actions"])
+            assert sorted(have["effectiveDerivedRoles"]) == sorted(want.get("effectiveDerivedRoles") or []), (lenient, inp)
+            got_err = bool((res.status[t:t + na] == capi.ST_CEL_ERROR).any())
+            assert got_err == bool(want.get("evaluationErrors")), (lenient, inp, want.get("evaluationErrors"))
+            n_err += got_err
+        t += na
+    return len(inputs) - len(bad), n_err
+
+
+def _hostsim(lt):
+    return HostSimEvaluator(lt, Conf())
+
+
+# ---------------------------------------------------------------------------------------------------------- lowering
+def test_sites_and_slots():
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c5_policies())))
+    assert lt.stats["walk2"] and not lt.stats["flat"]
+    generic, total = lt.stats["gslots"]
+    assert 0 < generic <= total <= 256
+    lt2 = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c1_policies())))
+    assert not lt2.stats["walk2"] and lt2.stats["walk2_refused"]      # 120 literal actions: more than the class masks tell apart
+    lt3 = lower_rule_table(store_rule_table(), GLOBALS)
+    assert lt3.stats["walk2"], lt3.stats["walk2_refused"]             # the reference's own test store
+
+
+# ---------------------------------------------------------------------------------------------------------- fuzz
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_stores_walk2_vs_general_walk_vs_oracle(seed):
+    rng = np.random.default_rng(77_000 + seed)
+    rt = rule_table_from_policies(policies_from_docs(_policies(rng)))
+    try:
+        lt = lower_rule_table(rt)
+    except LoweringError:
+        pytest.skip("store refused by the lowering (history-dependent reference behaviour)")
+    if not lt.stats["walk2"]:
+        pytest.skip("table stays on the general walk: %s" % lt.stats["walk2_refused"])
+    inputs = _requests(rng, 220)
+    batch = Flattener(lt).flatten(inputs)
+    for lenient in (False, True):
+        _both_kernels(lt, batch, capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0))
+        compared, _ = _against_oracle(rt, lt, _hostsim, inputs, lenient)
+        assert compared > 120
+
+
+# ---------------------------------------------------------------------------------------------------------- targeted
+def _role_policy_store(rng):
+    """Role policies whose roles inherit from each other (a slot's set holds several roles with policies at one scope),
+    at two scopes, with conditions, globs in the allow lists and a wildcard resource."""
+    docs = [{"apiVersion": API, "derivedRoles": {"name": "dr", "definitions": [
+        {"name": "owner", "parentRoles": ["staff", "lead"], "condition": _expr("R.attr.owner == P.id")},
+        {"name": "any", "parentRoles": ["*"]}]}}]
+    acts = ["view", "view:public", "edit", "edit:draft", "delete", "approve", "share", "export"]
+    for kind in ("doc", "sheet"):
+        for scope in ("", "acme", "acme.hr"):
+            rules = []
+            for _ in range(int(rng.integers(2, 6))):
+                rule = {"actions": [str(a) for a in rng.choice(acts + ["view:*", "*"], size=int(rng.integers(1, 4)), replace=False)],
+                        "effect": "EFFECT_ALLOW" if rng.random() < 0.75 else "EFFECT_DENY"}
+                if rng.random() < 0.3:
+                    rule["derivedRoles"] = [str(rng.choice(["owner", "any"]))]
+                else:
+                    rule["roles"] = [str(r) for r in rng.choice(["staff", "lead", "temp", "vendor", "intern", "*"], size=int(rng.integers(1, 3)), replace=False)]
+                if rng.random() < 0.5:
+                    rule["condition"] = _expr(str(rng.choice(["R.attr.public == true", "R.attr.amount > 50", "R.attr.missing == 1",
+                                                              "P.attr.teams.exists(t, t == \"core\")", "R.attr.tags.region == \"eu\""])))
+                rules.append(rule)
+            pol = {"resource": kind, "version": "default", "rules": rules, "importDerivedRoles": ["dr"]}
+            if scope:
+                pol["scope"] = scope
+                if rng.random() < 0.4:
+                    pol["scopePermissions"] = "SCOPE_PERMISSIONS_REQUIRE_PARENTAL_CONSENT_FOR_ALLOWS"
+            docs.append({"apiVersion": API, "resourcePolicy": pol})
+    chain = [("temp", ["staff"]), ("vendor", ["temp"]), ("intern", ["vendor", "staff"]), ("staff", [])]
+    for role, parents in chain:
+        for scope in ("", "acme"):
+            if rng.random() < 0.25:
+                continue
+            rules = []
+            for res in rng.choice(["doc", "sheet", "*"], size=int(rng.integers(1, 3)), replace=False):
+                rule = {"resource": str(res), "allowActions": [str(a) for a in rng.choice(acts + ["view:*", "edit:*"], size=int(rng.integers(1, 4)), replace=False)]}
+                if rng.random() < 0.4:
+                    rule["condition"] = _expr(str(rng.choice(["R.attr.public == true", "R.attr.amount > 50", "R.attr.missing == 1"])))
+                rules.append(rule)
+            rp = {"role": role, "rules": rules}
+            if parents:
+                rp["parentRoles"] = parents
+            if scope:
+                rp["scope"] = scope
+            docs.append({"apiVersion": API, "rolePolicy": rp})
+    return docs, acts
+
+
+def _role_policy_requests(rng, acts, n):
+    out = []
+    for i in range(n):
+        na = int(rng.choice([1, 2, 4, 5, 8, 9, 12], p=[0.15, 0.15, 0.3, 0.15, 0.15, 0.05, 0.05]))
+        actions = [str(a) for a in rng.choice(acts + ["view:x", "edit:y", "other"], size=min(na, 11), replace=False)]
+        actions += ["extra%d" % k for k in range(na - len(actions))]
+        nr = int(rng.choice([0, 1, 2, 3, 4, 5], p=[0.05, 0.35, 0.3, 0.15, 0.1, 0.05]))
+        r_attr = {"owner": "p%d" % rng.integers(0, 3), "public": bool(rng.random() < 0.5), "amount": float(rng.integers(0, 100)),
+                  "tags": {"region": str(rng.choice(["eu", "us"]))}}
+        if rng.random() < 0.1:
+            del r_attr["public"]
+        inp = {"requestId": "q%d" % i, "actions": actions,
+               "principal": {"id": "p%d" % rng.integers(0, 3), "roles": [str(r) for r in rng.choice(["staff", "lead", "temp", "vendor", "intern", "nobody"], size=nr, replace=False)],
+                             "attr": {"teams": [["core"], ["ops"], []][int(rng.integers(0, 3))]}},
+               "resource": {"kind": str(rng.choice(["doc", "sheet", "other"])), "id": "r%d" % i, "attr": r_attr}}
+        if rng.random() < 0.6:
+            inp["resource"]["scope"] = str(rng.choice(["acme", "acme.hr", "acme.hr.uk", "zzz"]))
+        out.append(inp)
+    return out
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_role_policy_chains(seed):
+    rng = np.random.default_rng(88_000 + seed)
+    docs, acts = _role_policy_store(rng)
+    rt = rule_table_from_policies(policies_from_docs(docs))
+    try:
+        lt = lower_rule_table(rt)
+    except LoweringError:
+        pytest.skip("store refused by the lowering")
+    assert lt.stats["walk2"], lt.stats["walk2_refused"]
+    inputs = _role_policy_requests(rng, acts, 260)
+    batch = Flattener(lt).flatten(inputs)
+    assert int(batch.req_u32[9].max()) > 8     # wider requests ride along on the general walk's lanes
+    for lenient in (False, True):
+        _both_kernels(lt, batch, capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0))
+        _against_oracle(rt, lt, _hostsim, inputs, lenient)
+
+
+def _principal_store(rng):
+    docs = []
+    acts = ["view", "edit", "delete", "view:public", "approve"]
+    for kind in ("doc", "sheet"):
+        for scope in ("", "acme"):
+            rules = [{"actions": [str(a) for a in rng.choice(acts + ["*"], size=int(rng.integers(1, 3)), replace=False)],
+                      "roles": [str(r) for r in rng.choice(["user", "admin", "*"], size=1)],
+                      "effect": "EFFECT_ALLOW" if rng.random() < 0.7 else "EFFECT_DENY"} for _ in range(int(rng.integers(1, 4)))]
+            if rng.random() < 0.5:
+                rules[0]["condition"] = _expr("R.attr.public == true")
+            pol = {"resource": kind, "version": str(rng.choice(["default", "v2"])), "rules": rules}
+            if scope:
+                pol["scope"] = scope
+            docs.append({"apiVersion": API, "resourcePolicy": pol})
+    for i in range(4):
+        for scope in ("", "acme", "acme.hr"):
+            if rng.random() < 0.5:
+                continue
+            rules = {}
+            for _ in range(int(rng.integers(1, 3))):
+                res = str(rng.choice(["doc", "sheet", "*", "do*"]))
+                entries = {}
+                for _ in range(int(rng.integers(1, 4))):
+                    a = str(rng.choice(acts + ["view:*", "*"]))
+                    e = {"action": a, "effect": "EFFECT_ALLOW" if rng.random() < 0.5 else "EFFECT_DENY"}
+                    if rng.random() < 0.4:
+                        e["condition"] = _expr(str(rng.choice(["R.attr.public == true", "R.attr.missing == 1", "R.attr.amount > 50",
+                                                                "R.attr.tags.region == \"eu\""])))
+                    entries[a] = e
+                rules[res] = {"resource": res, "actions": list(entries.values())}
+            pp = {"principal": "p%d" % i, "version": str(rng.choice(["default", "v2"])), "rules": list(rules.values())}
+            if scope:
+                pp["scope"] = scope
+                if rng.random() < 0.4:
+                    pp["scopePermissions"] = "SCOPE_PERMISSIONS_REQUIRE_PARENTAL_CONSENT_FOR_ALLOWS"
+            docs.append({"apiVersion": API, "principalPolicy": pp})
+    return docs, acts
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_principal_policies(seed):
+    rng = np.random.default_rng(99_000 + seed)
+    docs, acts = _principal_store(rng)
+    rt = rule_table_from_policies(policies_from_docs(docs))
+    lt = lower_rule_table(rt)
+    assert lt.stats["walk2"], lt.stats["walk2_refused"]
+    inputs = []
+    for i in range(240):
+        inp = {"requestId": "q%d" % i, "actions": [str(a) for a in rng.choice(acts + ["view:x", "other"], size=int(rng.integers(0, 7)), replace=False)],
+               "principal": {"id": "p%d" % rng.integers(0, 6), "roles": [str(r) for r in rng.choice(["user", "admin", "x"], size=int(rng.integers(0, 3)), replace=False)]},
+               "resource": {"kind": str(rng.choice(["doc", "sheet", "dox", "other"])), "id": "r%d" % i,
+                            "attr": {"public": bool(rng.random() < 0.5), "amount": float(rng.integers(0, 100)), "tags": {"region": "eu"}}}}
+        if rng.random() < 0.5:
+            inp["principal"]["scope"] = str(rng.choice(["acme", "acme.hr", "acme.hr.uk", "zz"]))
+        if rng.random() < 0.5:
+            inp["resource"]["scope"] = str(rng.choice(["acme", "acme.hr", "zz"]))
+        if rng.random() < 0.4:
+            inp["resource"]["policyVersion"] = "v2"
+        if rng.random() < 0.4:
+            inp["principal"]["policyVersion"] = "v2"
+        inputs.append(inp)
+    batch = Flattener(lt).flatten(inputs)
+    for lenient in (False, True):
+        _both_kernels(lt, batch, capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0))
+        _against_oracle(rt, lt, _hostsim, inputs, lenient)
+
+
+def test_c5_sample_walk2_vs_general_walk():
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c5_policies())))
+    batch = workloads.c5_requests(6000).to_batch(Flattener(lt))
+    _both_kernels(lt, batch, capi.F_WANT_DERIVED_ROLES)
+
+
+# ---------------------------------------------------------------------------------------------------------- GPU tier
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_gpu_role_policy_chains(seed):
+    rng = np.random.default_rng(88_000 + seed)
+    docs, acts = _role_policy_store(rng)
+    rt = rule_table_from_policies(policies_from_docs(docs))
+    try:
+        lt = lower_rule_table(rt)
+    except LoweringError:
+        pytest.skip("store refused by the lowering")
+    inputs = _role_policy_requests(rng, acts, 260)
+    for lenient in (False, True):
+        _against_oracle(rt, lt, lambda l: HipEvaluator(l, Conf()), inputs, lenient)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_gpu_fuzz_stores(seed):
+    rng = np.random.default_rng(77_000 + seed)
+    rt = rule_table_from_policies(policies_from_docs(_policies(rng)))
+    try:
+        lt = lower_rule_table(rt)
+    except LoweringError:
+        pytest.skip("store refused by the lowering")
+    inputs = _requests(rng, 220)
+    for lenient in (False, True):
+        _against_oracle(rt, lt, lambda l: HipEvaluator(l, Conf()), inputs, lenient)
