@@ -100,6 +100,10 @@ enum CbhMeta {
   CBH_M_MAX_LOCALS = 17,
   CBH_M_GSLOTS_GENERIC = 18, // evaluation-site slots (cbh_check_walk2.h) of sites the walk cannot decide inline for ANY batch: slots 0 .. n - 1
   CBH_M_GSLOTS_ALL = 19,     // ... plus the sites it can decide inline for plain scalars only: slots 0 .. n - 1
+  CBH_M_INLINE_COLS = 20,    // the inline leaf code of the flat / walk2 kernels reads attribute columns 0 .. n - 1 only (the lowering
+                             // numbers those first): what a walk without generic programs parks in LDS
+  CBH_M_SENS_COLS = 21,      // bit c: an int / uint / list / map value in column c sends a classified leaf to the shared evaluator -
+                             // the columns the host looks at to call a batch "plain" (cbh_engine.hip validate_batch)
   CBH_META_N = 24
 };
 #define CBH_MF_USES_RUNTIME_EDR 1u
@@ -129,7 +133,8 @@ enum CbhBucketType {
   CBH_B_RPRES = 5,     // (ver sid, scope idx, 0) -> v0 off, v1 cnt into U32POOL of resource pattern refs of role-policy rows
   CBH_B_PARENTS = 6,   // (scope idx, role sid, 0) -> v0 off, v1 cnt into U32POOL of ancestor role sids
   CBH_B_RESEXISTS = 7, // (ver sid, kind sid, scope idx): same key as RESOURCE, present for every resource policy; v1, v2 = union of the
-                       // literal role class masks of its rules, v3 = union of their role glob masks (Index.Query's base test)
+                       // literal role class masks of its rules, v3 = union of their role glob masks (Index.Query's base test);
+                       // v0 = 1 | CBH_BS_*: the evaluation sites the bucket holds (cbh_check_walk2.h: the pre-pass skips the rest)
   CBH_B_RPROLES = 8,   // (ver sid, scope idx, 0) -> v0 off, v1 cnt into U32POOL: the roles with a role policy at that scope, sorted by
                        // name (the order of a role's ancestor list, ruletable/build.py)
 };
@@ -204,6 +209,10 @@ enum CbhRowXField {
   CBH_ROWX_ACTIONS = 4,  // u64: classes of the literal actions
   CBH_ROWX_NF = 8
 };
+#define CBH_BS_ROW_GENERIC 2u
+#define CBH_BS_ROW_OPEN 4u
+#define CBH_BS_DR_GENERIC 8u
+#define CBH_BS_DR_OPEN 16u
 #define CBH_GSLOT_NONE 0xFFFFu
 #define CBH_W2_MAX_GLOBS 16u
 #define CBH_W2_MAX_GSLOTS 256u

@@ -383,10 +383,16 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
       for (u32 k = 0; k < rpres.y && !m; ++k) m = pat_match(uload(&t.pool[rpres.x + k]), g_k, g_kb);
       exists = exists || (ing && m);
     }
+    u32 site_flags = 0;   // pre-pass: which kinds of sites the bucket holds (cbh_blob.h CBH_BS_*)
+    if (PRE && have_bucket) {
+      uint4 ex; ex.x = 0;
+      if (udir_find(t, CBH_B_RESEXISTS, g_ver, g_k, g_si, ex)) site_flags = ex.x;
+      if (b.n_gwords * CBH_W2_SLOTS_PER_WORD <= t.gslots_generic) site_flags &= ~(u32)(CBH_BS_ROW_OPEN | CBH_BS_DR_OPEN);   // their slots are not filed for this batch
+    }
     if (go) {
       if (!PRE && ing && mydepth < max_depth) { if (chain8) chain_si8[mydepth * CBH_BLOCK + c.tid] = (u8)g_si; else chain_si[mydepth * CBH_BLOCK + c.tid] = g_si; }
       const u32 S_before = S;
-      if (PRE && have_bucket && t.n_dr) {
+      if (PRE && have_bucket && t.n_dr && (pre_edr || (site_flags & (CBH_BS_DR_GENERIC | CBH_BS_DR_OPEN)))) {
         // the scope's derived roles (check.go:237-282): their sites, and - for programs that read runtime.* - their value
         u64 m = 0;
         for (u32 d = bucket.z; d < bucket.z + bucket.w; ++d) {
@@ -474,7 +480,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
           }
         }
       }
-      if (have_bucket && bucket.y) {
+      if (have_bucket && bucket.y && (!PRE || (site_flags & (CBH_BS_ROW_GENERIC | CBH_BS_ROW_OPEN)))) {
         const u32 last = bucket.x + bucket.y - 1u;
         TblRowFull nxt = uload_rec<TblRowFull>(t.rows, bucket.x);
         for (u32 row = bucket.x; row <= last; ++row) {   // bindings in order (check.go:295-414)
@@ -482,9 +488,11 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
           nxt = uload_rec<TblRowFull>(t.rows, row < last ? row + 1u : last);
           const TblRow& rw = rf.hot;
           u32 rm_lo = rw.rm_lo, rm_hi = rw.rm_hi, am_lo = rw.am_lo, am_hi = rw.am_hi, ag = 0, rg = 0, gslots = 0xFFFFFFFFu;
+          if (PRE && !(rw.flags & CBH_ROW_F_X)) continue;   // no site on this record
           if (rw.flags & CBH_ROW_F_X) {
             const TblRowX rx = uload_rec<TblRowX>(t.rowx, row);
             gslots = rx.gslots;
+            if (PRE && (gslots & 0xFFFFu) / CBH_W2_SLOTS_PER_WORD >= b.n_gwords && (gslots >> 16) / CBH_W2_SLOTS_PER_WORD >= b.n_gwords) continue;   // none filed for this batch
             if (rx.globs) { ag = rx.globs & 0xFFFFu; rg = rx.globs >> 16; rm_lo = rx.rm_lo; rm_hi = rx.rm_hi; am_lo = rx.am_lo; am_hi = rx.am_hi; }
           }
           if ((((rm_lo & wave_rc_lo) | (rm_hi & wave_rc_hi)) == 0 && (rg & wave_rg) == 0) ||
@@ -653,7 +661,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
 #endif
 // the walk: four independent waves to a workgroup, no evaluator call
 __global__ CBH_W2_ATTRS void cbh_walk2_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
-  const u32 ncc = cached_columns(&a);
+  const u32 ncc = a.t.inline_cols;   // no generic program runs here: only the columns the inline leaf code reads are parked in LDS
   const W2Layout ly = w2_layout(ncc, false, a.t.max_depth, a.t.n_scopes, false, 0, a.t.K);
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
         (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * ly.wave_dw, ncc, ka};
@@ -716,9 +724,9 @@ static inline size_t cbh_general_lds(u32 table_flags, u32 n_columns) {
   return (size_t)ncc * CBH_BLOCK * 12 + ((table_flags & CBH_MF_NEEDS_ARENA) ? (size_t)CBH_ARENA_ENTRIES * CBH_BLOCK * 9 : 0);
 }
 // dynamic LDS of a launch of `kernel` (pre = the pre-pass of kind 2)
-static inline size_t cbh_plan_lds(const CbhPlan& p, u32 table_flags, u32 table_max_depth, u32 table_scopes, u32 table_strings, u32 n_columns, bool pre) {
+static inline size_t cbh_plan_lds(const CbhPlan& p, u32 table_flags, u32 table_max_depth, u32 table_scopes, u32 table_strings, u32 n_columns, u32 inline_cols, bool pre) {
   const u32 ncc = n_columns < CBH_CACHE_COLS ? n_columns : CBH_CACHE_COLS;
-  if (p.kind == 2) return w2_lds_bytes(w2_layout(ncc, (table_flags & CBH_MF_NEEDS_ARENA) != 0, table_max_depth, table_scopes, pre, p.n_gwords, table_strings), pre ? 1u : CBH_W2_WAVES);
+  if (p.kind == 2) return w2_lds_bytes(w2_layout(pre ? ncc : inline_cols, (table_flags & CBH_MF_NEEDS_ARENA) != 0, table_max_depth, table_scopes, pre, p.n_gwords, table_strings), pre ? 1u : CBH_W2_WAVES);
   const size_t wave = cbh_general_lds(table_flags, n_columns);
   if (p.kind == 1) return (wave + cbh_flat_chain_bytes(table_max_depth, table_scopes)) * (p.threads / CBH_BLOCK) + cbh_flat_class_bytes(table_strings);
   return wave;

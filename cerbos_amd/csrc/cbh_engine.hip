@@ -333,12 +333,15 @@ struct BatchShape {
   // the batch (cbh_check_flat.h).  One pass over the tag bytes, made only where the answer selects a kernel and only
   // when the first launch is being prepared - by then the uploads are enqueued and the pass runs beside them.
   const uint8_t* tags = nullptr; size_t n_tags = 0;   // nullptr: the answer cannot matter (no flat kernel for this table / shape)
+  uint32_t sens_cols = 0; size_t n_req = 0;           // only these columns [bit c: tags + c * n_req] can send a classified leaf to the evaluator (CBH_M_SENS_COLS)
   mutable std::atomic<int> plain{-1};                 // -1 not looked at yet (racing threads compute the same answer)
   bool plain_tags() const {
     int v = plain.load(std::memory_order_relaxed);
     if (v < 0) {
       static const bool force_any = getenv("CBH_FLAT_ANY") != nullptr;   // measurement / test aid: always the variant with the call
-      v = (!force_any && (n_tags == 0 || (tags && !has_int_or_container_tag(tags, n_tags)))) ? 1 : 0;   // (a table without attribute columns: nothing to look at)
+      bool hit = false;
+      if (tags) for (uint32_t c = 0; c < 32 && !hit; ++c) if ((sens_cols >> c) & 1u) hit = has_int_or_container_tag(tags + (size_t)c * n_req, n_req);
+      v = (!force_any && !hit) ? 1 : 0;
       plain.store(v, std::memory_order_relaxed);
     }
     return v == 1;
@@ -386,6 +389,8 @@ static int validate_batch(const cbh_table* t, const cbh_batch* in, BatchShape& s
   sh.tags = nullptr; sh.n_tags = 0; sh.plain.store(-1, std::memory_order_relaxed);
   if (((t->meta[CBH_M_FLAGS] & CBH_MF_FLAT) && maxa <= 4 && maxr <= 4) ||
       ((t->meta[CBH_M_FLAGS] & CBH_MF_WALK2) && t->meta[CBH_M_GSLOTS_ALL] > t->meta[CBH_M_GSLOTS_GENERIC])) { sh.tags = in->col_tag; sh.n_tags = (size_t)in->n_columns * NR; }
+  sh.sens_cols = t->meta[CBH_M_SENS_COLS]; sh.n_req = NR;
+  if (in->n_columns < 32) sh.sens_cols &= (1u << in->n_columns) - 1u;
   return 0;
 }
 
@@ -537,9 +542,9 @@ static void launch_plan(const CbhPlan& pl, const TableDev& dev, KernelArgs ka, c
     }
     ka.b.n_gwords = ka.b.gres ? pl.n_gwords : 0;
     if (ka.b.n_gwords)   // the evaluation sites first: their results are what the walk reads
-      go(cbh_walk2_pre_kernel, (n + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, true), ka, false);
+      go(cbh_walk2_pre_kernel, (n + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, true), ka, false);
   }
-  go(pl.kernel, (n + pl.threads - 1) / pl.threads, pl.threads, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, false) + pad, ka, true);
+  go(pl.kernel, (n + pl.threads - 1) / pl.threads, pl.threads, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, false) + pad, ka, true);
 }
 // CBH_LDS_PAD=<bytes> (measurement aid): extra dynamic LDS per workgroup of the resident launches, to hold the occupancy down
 static size_t lds_pad() { static const size_t pad = [] { const char* e = getenv("CBH_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }(); return pad; }

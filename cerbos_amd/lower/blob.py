@@ -47,7 +47,7 @@ MF_WALK2 = 2048
 ROW_F_X, ROW_F_XEXACT = 1024, 2048
 SEC_ROWX, SEC_RPX = 40, 41
 B_RPROLES = 8
-M_GSLOTS_GENERIC, M_GSLOTS_ALL = 18, 19
+M_GSLOTS_GENERIC, M_GSLOTS_ALL, M_INLINE_COLS, M_SENS_COLS = 18, 19, 20, 21
 GSLOT_NONE = 0xFFFF
 WALK2_MAX_GLOBS = 16      # glob patterns per dimension (action, role) a lane keeps match bits for
 WALK2_MAX_GSLOTS = 256    # evaluation-site slots of one request (4 result bits each, 16 to a 64-bit word: cbh_walk2_pre_kernel)
@@ -123,7 +123,21 @@ def _cond_uses_runtime(cond, params: Params):
     return any(_cond_uses_runtime(c, params) for c in cond[1])
 
 
-def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # noqa: C901
+def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:
+    """The columns the kernels' inline leaf code reads get the lowest indices: the walk that runs no generic program
+    (cbh_walk2_kernel) parks only those in LDS, and LDS is what bounds its occupancy.  Which columns those are is known once
+    the programs are compiled - hence up to three passes, the later ones with the column order of the one before."""
+    first = ()
+    for _ in range(3):
+        lt = _lower_rule_table(rt, globals_, trace, first)
+        want = tuple(lt.columns[i] for i in sorted(lt.inline_cols))
+        if want == tuple(lt.columns[:len(want)]):
+            break
+        first = want
+    return lt
+
+
+def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:  # noqa: C901
     lt = LoweredTable()
     globals_ = dict(globals_ or {})
 
@@ -137,6 +151,8 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
 
     sid("")  # string 0 is always the empty string
     pb = ProgramBuilder(sid, globals_)
+    for root, keys in first_columns:
+        pb.column(root, keys)
     dims = [_Dim(), _Dim(), _Dim()]
     used_any = []   # dimensions in which a lone "*" was met
 
@@ -754,7 +770,22 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
             for i in range(e[4], e[4] + e[5]):
                 lit |= row_rmask[i][0]; glob |= row_rmask[i][1]
             bucket_union[e[1:4]] = (lit, glob)
-    entries[:] = [((e[0], e[1], e[2], e[3], 1) + (lambda u: (u[0] & 0xFFFFFFFF, u[0] >> 32, u[1]))(bucket_union.get(e[1:4], (0, 0)))) if e[0] == B_RESEXISTS else e
+    # ... and which kinds of evaluation sites the bucket holds (the pre-pass skips what has none): v0 = 1 | 2 rules with
+    # generic sites | 4 rules with sites that are inline for plain values | 8, 16 the same for its derived-role definitions
+    bucket_sites = {}
+    site_bit = {("row", "generic"): 2, ("row", "open"): 4, ("dr", "generic"): 8, ("dr", "open"): 16}
+    row_key, dr_key = {}, {}
+    for e in entries:
+        if e[0] == B_RESOURCE:
+            for i in range(e[4], e[4] + e[5]):
+                row_key[i] = e[1:4]
+            for i in range(e[6], e[6] + e[7]):
+                dr_key[i] = e[1:4]
+    for (_r, _fam, _prog, k, (what, i, _shift)) in sites:
+        key = row_key.get(i) if what == "row" else dr_key.get(i) if what == "dr" else None
+        if key is not None:
+            bucket_sites[key] = bucket_sites.get(key, 0) | site_bit[(what, k)]
+    entries[:] = [((e[0], e[1], e[2], e[3], 1 | bucket_sites.get(e[1:4], 0)) + (lambda u: (u[0] & 0xFFFFFFFF, u[0] >> 32, u[1]))(bucket_union.get(e[1:4], (0, 0)))) if e[0] == B_RESEXISTS else e
                   for e in entries]
 
     # ---- directory hash table
@@ -827,6 +858,9 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:  # no
             walk2_why.append("more than %d glob patterns in a dimension" % WALK2_MAX_GLOBS)
     lt.walk2_refused = list(dict.fromkeys(walk2_why))
     meta[M_FLAGS] |= MF_WALK2 if not lt.walk2_refused else 0
+    lt.inline_cols = sorted(pb.inline_cols)
+    meta[M_INLINE_COLS] = (max(pb.inline_cols) + 1) if pb.inline_cols else 0
+    meta[M_SENS_COLS] = sum(1 << c for c in pb.sensitive_cols if c < 32)
     meta[M_GSLOTS_GENERIC] = n_gslots_generic
     meta[M_GSLOTS_ALL] = n_gslots_all
     meta[M_MAX_STACK] = pb.max_stack

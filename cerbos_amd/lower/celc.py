@@ -210,6 +210,10 @@ class ProgramBuilder:
         self.theap_tag = []
         self.theap_val = []
         self.columns = {}                  # (root, keys) -> column index
+        # what the inline leaf code of the flat / walk2 kernels reads (cbh_check_flat.h flat_leaf): the columns it touches
+        # at all, and the ones where an int / uint or a container value sends a lane to the shared evaluator
+        self.inline_cols = set()
+        self.sensitive_cols = set()
         self.programs = {}                 # dedup key -> entry pc
         self.regex_words = []              # CBH_SEC_REGEX: the DFA tables of constant `matches` patterns, back to back
         self.regex_index = {}              # pattern -> offset of its tables in regex_words
@@ -355,12 +359,22 @@ class ProgramBuilder:
             ci = words[1] if ka == 0 else words[2]
             cv = int(self.const_val[ci]) & 0xFFFFFFFFFFFFFFFF
             cls = self._leaf_class(a & 0xFF, ka, kb, ci)
+            if cls in (1, 2, 6):
+                self.inline_cols.add(words[1])
+                if cls == 2:
+                    self.sensitive_cols.add(words[1])
             if cls == 6:   # column in [<= 3 strings]: the ids instead of the list's heap reference
                 off, n = (cv >> 32) & 0x3FFFFFFF, cv & 0xFFFFFFFF
                 ids = [int(self.theap_val[off + i]) & 0xFFFFFFFF for i in range(n)] + [0xFFFFFFFF] * (3 - n)
                 return words + ids + [6]
             return words + [self.const_tag[ci], cv & 0xFFFFFFFF, cv >> 32, cls]
-        return words + [0xFFFFFFFF, 0, 0, self._leaf_class(a & 0xFF, ka, kb, None)]
+        cls = self._leaf_class(a & 0xFF, ka, kb, None)
+        if cls == 3:
+            self.inline_cols.update((words[1], words[2]))
+            self.sensitive_cols.update((words[1], words[2]))
+        elif cls == 4:
+            self.inline_cols.add(words[1] if ka == 3 else words[2])
+        return words + [0xFFFFFFFF, 0, 0, cls]
 
     def _tree_strip(self, pc, words):
         """A condition tree of at most TREE_STRIP_MAX classified leaves (any nesting the op budget holds) also gets, for

@@ -186,10 +186,13 @@ static int run_sim(const void* blob, size_t len, const cbh_batch* in, const cbh_
   for (uint32_t r = 0; r < in->n_requests; ++r)
     max_roles = std::max(max_roles, in->req_u32[(size_t)CBH_RQ_ROLE_CNT * in->n_requests + r]);
   g_max_roles = max_roles;
-  g_plain = getenv("CBH_FLAT_ANY") == nullptr;   // cbh_engine.hip validate_batch
-  for (size_t i = 0; i < (size_t)in->n_columns * in->n_requests; ++i) {
-    const uint32_t x = in->col_tag[i];
-    if ((x - CBH_T_INT) < 2u || (x - CBH_T_LIST) < 2u) g_plain = false;
+  g_plain = getenv("CBH_FLAT_ANY") == nullptr;   // cbh_engine.hip validate_batch: the columns a classified leaf can leave the inline code on
+  for (uint32_t col = 0; col < in->n_columns && col < 32; ++col) {
+    if (!((meta[CBH_M_SENS_COLS] >> col) & 1u)) continue;
+    for (size_t i = (size_t)col * in->n_requests; i < (size_t)(col + 1) * in->n_requests; ++i) {
+      const uint32_t x = in->col_tag[i];
+      if ((x - CBH_T_INT) < 2u || (x - CBH_T_LIST) < 2u) g_plain = false;
+    }
   }
   // the same choice of kernels as the library makes (cbh_engine.hip plan_for); CBH_NO_FLAT / CBH_NO_WALK2 as there
   const bool has_globs = (a.t.nfa_words[0] | a.t.nfa_words[1] | a.t.nfa_words[2] | (a.t.flags & CBH_MF_HAS_ANY_PATTERN)) != 0;
