@@ -73,6 +73,14 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   const u32 flags = ka_regs.flags;
   const u32 wave = threadIdx.x / CBH_BLOCK;
   constexpr u32 NA = CBH_W2_NA, NR = CBH_W2_NR;
+#ifdef CBH_PROFILE_CYCLES   // profiling build only (tools/gpu_cycles_walk2.py): per-wave phase cycles into the policy / scope words
+  const u64 cyc0 = __builtin_readcyclecounter();
+  const u64 rt0 = __builtin_amdgcn_s_memrealtime();
+  u64 cyc_eval = 0; u32 dbg_rows = 0, dbg_rounds = 0, dbg_evals = 0;
+#define W2_DBG(x) x
+#else
+#define W2_DBG(x)
+#endif
   const u32 rix = b.req_lo + blockIdx.x * (PRE ? CBH_BLOCK : CBH_W2_THREADS) + threadIdx.x;
   const u32 NRQ = b.n_requests;
   bool valid = rix < b.req_hi;
@@ -219,7 +227,9 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     if (wave_ballot(slow) != 0) {
       const bool filed = gslot != CBH_GSLOT_NONE && (gslot / CBH_W2_SLOTS_PER_WORD) < b.n_gwords;   // uniform
       if (PRE) {
+        W2_DBG(const u64 e0 = __builtin_readcyclecounter(); ++dbg_evals;)
         const u32 r = eval_ref<true>(c.ka_mem, lds_of(c), req, edr_scope, false, ref, slow);
+        W2_DBG(cyc_eval += __builtin_readcyclecounter() - e0;)
         const u32 st = r >> 8;
         const u32 code = ((r & 0xFFu) == 1u ? 1u : 0u) | ((st & CBH_ST_CEL_ERROR) ? 2u : 0u) | ((st & CBH_ST_UNSUPPORTED) ? 8u : 0u);
         if (slow) {
@@ -259,6 +269,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   auto kind_bits = [&]() -> u64 { return gbits_of(t, b, DIM_KIND, kind); };
 
   u32 err = 0, unsup = 0;   // walk bits whose evaluation met a CEL error / left the device subset
+  W2_DBG(const u64 cyc1 = __builtin_readcyclecounter();)   // request fields, ids, classes, role sets are there
 
   // ---- principal policies (check.go:195: the first pass; one role iteration, check.go:208-213).  Lanes with a policy of
   // their principal somewhere on the chain are walked group by group; what it decides is kept per action.
@@ -349,6 +360,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     }
   }
   const u32 p_done = p_allow | p_deny;   // a definitive principal-policy result ends the action (check.go:445-448)
+  W2_DBG(const u64 cyc2 = __builtin_readcyclecounter();)   // the principal pass is over
   walks &= ~(p_done * 0x01010101u);
 
   // ---- the resource walk (cbh_check_flat.h: merged climb, deepest scope first)
@@ -368,6 +380,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     const u32 lead = first_lane(here);
     const u32 g_ver = wave_readlane(r_ver, lead), g_k = wave_readlane(kind, lead);
     const bool ing = active && cur == g_si && r_ver == g_ver && kind == g_k;
+    W2_DBG(++dbg_rounds;)
     const bool go = wave_ballot(ing && (PRE ? walks : S) != 0) != 0;
     uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
     const bool have_bucket = udir_find(t, CBH_B_RESOURCE, g_ver, g_k, g_si, bucket);
@@ -487,6 +500,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
           const TblRowFull rf = nxt;
           nxt = uload_rec<TblRowFull>(t.rows, row < last ? row + 1u : last);
           const TblRow& rw = rf.hot;
+          W2_DBG(++dbg_rows;)
           u32 rm_lo = rw.rm_lo, rm_hi = rw.rm_hi, am_lo = rw.am_lo, am_hi = rw.am_hi, ag = 0, rg = 0, gslots = 0xFFFFFFFFu;
           if (PRE && !(rw.flags & CBH_ROW_F_X)) continue;   // no site on this record
           if (rw.flags & CBH_ROW_F_X) {
@@ -534,8 +548,15 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     if (ing) { cur = (mydepth + 1u < max_depth) ? up : CBH_NONE; ++mydepth; }
   }
 
+  W2_DBG(const u64 cyc3 = __builtin_readcyclecounter();)   // the walk is over
   if (PRE) {   // file the results of this lane's sites
     if (valid) for (u32 w = 0; w < b.n_gwords; ++w) b.gres[(size_t)w * NRQ + req] = gacc[w * CBH_BLOCK + c.tid];
+#ifdef CBH_PROFILE_CYCLES
+    if ((flags & CBH_F_DEBUG_CYCLES) && valid && act_cnt == 4 && o.policy && o.scope) {
+      o.policy[act_off] = (u32)(cyc1 - cyc0); o.policy[act_off + 1] = (u32)(cyc2 - cyc1); o.policy[act_off + 2] = (u32)(cyc3 - cyc2); o.policy[act_off + 3] = (u32)cyc_eval;
+      o.scope[act_off] = (u32)rt0; o.scope[act_off + 1] = (u32)__builtin_amdgcn_s_memrealtime(); o.scope[act_off + 2] = dbg_rows | (dbg_evals << 16); o.scope[act_off + 3] = dbg_rounds;
+    }
+#endif
     return;
   }
 
@@ -628,6 +649,13 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     if (dr_unsup) { st[0] = 0x02020202u; st[1] = 0x02020202u; }
   }
 
+#ifdef CBH_PROFILE_CYCLES
+  if (flags & CBH_F_DEBUG_CYCLES) {
+    const u64 cyc4 = __builtin_readcyclecounter();
+    pol[0] = (u32)(cyc1 - cyc0); pol[1] = (u32)(cyc2 - cyc1); pol[2] = (u32)(cyc3 - cyc2); pol[3] = (u32)(cyc4 - cyc3);
+    scp[0] = (u32)rt0; scp[1] = (u32)__builtin_amdgcn_s_memrealtime(); scp[2] = dbg_rows; scp[3] = dbg_rounds;
+  }
+#endif
   const bool packed = valid && act_cnt == 4 && (act_off & 3u) == 0;
   if (packed) {
 #ifndef CBH_HOSTSIM
