@@ -73,6 +73,7 @@ enum CbhSectionId {
                               // (key node, value node)* | 4 format + u32 len + bytes + u32 n + nodes
   CBH_SEC_ROWX = 40,         // u32[n_rows][8]  what cbh_check_walk2.h reads besides the record (CbhRowXField); rows with CBH_ROW_F_X
   CBH_SEC_RPX = 41,          // u32[n_rprows][16] role-policy rules for that kernel (CbhRpxField)
+  CBH_SEC_STR_WFLAGS = 42,   // u8[K] CBH_SWF_*: what the walk would otherwise probe the directory for, lane by lane
   CBH_SEC_ROWPAT = 29,       // u32[n_rows][8]  pattern halves of the rule records (CbhRowPatField order)
   CBH_SEC_ACTION_CLASS = 28, // u8[K] class (0..61) of a string that is a literal rule action of a resource policy, 63 = any other string
   CBH_SEC_HOST_NAMES = 27,   // host only: {u32 n, {u16 len, bytes}*} policy keys (CBH_P_TABLE ids), then the same for derived-role names
@@ -102,6 +103,7 @@ enum CbhMeta {
   CBH_M_GSLOTS_ALL = 19,     // ... plus the sites it can decide inline for plain scalars only: slots 0 .. n - 1
   CBH_M_INLINE_COLS = 20,    // the inline leaf code of the flat / walk2 kernels reads attribute columns 0 .. n - 1 only (the lowering
                              // numbers those first): what a walk without generic programs parks in LDS
+  CBH_M_Q_SITES = 22,        // CBH_BS_ROW_GENERIC / _OPEN: the role-policy rules hold evaluation sites of that kind
   CBH_M_SENS_COLS = 21,      // bit c: an int / uint / list / map value in column c sends a classified leaf to the shared evaluator -
                              // the columns the host looks at to call a batch "plain" (cbh_engine.hip validate_batch)
   CBH_META_N = 24
@@ -135,6 +137,8 @@ enum CbhBucketType {
   CBH_B_RESEXISTS = 7, // (ver sid, kind sid, scope idx): same key as RESOURCE, present for every resource policy; v1, v2 = union of the
                        // literal role class masks of its rules, v3 = union of their role glob masks (Index.Query's base test);
                        // v0 = 1 | CBH_BS_*: the evaluation sites the bucket holds (cbh_check_walk2.h: the pre-pass skips the rest)
+  CBH_B_FAMILY = 9,    // (ver sid, kind sid, 0) -> v0 = OR of CBH_BS_* over the buckets of the family's scopes: a request whose
+                       // family holds no site the batch files needs no pre-pass walk
   CBH_B_RPROLES = 8,   // (ver sid, scope idx, 0) -> v0 off, v1 cnt into U32POOL: the roles with a role policy at that scope, sorted by
                        // name (the order of a role's ancestor list, ruletable/build.py)
 };
@@ -209,6 +213,9 @@ enum CbhRowXField {
   CBH_ROWX_ACTIONS = 4,  // u64: classes of the literal actions
   CBH_ROWX_NF = 8
 };
+#define CBH_SWF_PRINCIPAL 1u    /* the string is a principal with a principal policy (some version / scope) */
+#define CBH_SWF_PARENTS 2u      /* the string is a role with ancestors in some scope */
+#define CBH_SCOPE_F_ROLEPOL 16u /* CBH_SEC_SCOPE_FLAGS bit 4: some role policy lives at this scope */
 #define CBH_BS_ROW_GENERIC 2u
 #define CBH_BS_ROW_OPEN 4u
 #define CBH_BS_DR_GENERIC 8u

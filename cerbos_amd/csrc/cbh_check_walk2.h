@@ -37,11 +37,11 @@ struct __attribute__((aligned(64))) TblRpx { u32 resource, cnt, cond, gslot, am_
 
 // Dynamic LDS of one workgroup, per wave: [column cache][list arena (pre-pass of a table that builds lists)][scope chain]
 // [per-action notes][site results (pre-pass)], then once per group the two class tables.
-struct W2Layout { u32 cc_dw, arena_dw, chain_dw, aux_dw, gacc_dw, wave_dw, cls_bytes; };
+struct W2Layout { u32 cc_dw, arena_dw, chain_dw, aux_dw, gacc_dw, edr_dw, wave_dw, cls_bytes; };
 #ifndef CBH_HOSTSIM
 __host__ __device__
 #endif
-static inline W2Layout w2_layout(u32 ncc, bool arena, u32 table_max_depth, u32 table_scopes, bool pre, u32 n_gwords, u32 table_strings) {
+static inline W2Layout w2_layout(u32 ncc, bool arena, u32 table_max_depth, u32 table_scopes, bool pre, u32 n_gwords, u32 table_strings, u32 table_n_dr) {
   W2Layout l;
   const u32 depth = table_max_depth < CBH_FLAT_MAX_DEPTH ? table_max_depth : CBH_FLAT_MAX_DEPTH;
   l.cc_dw = 3u * ncc * CBH_BLOCK;
@@ -49,8 +49,9 @@ static inline W2Layout w2_layout(u32 ncc, bool arena, u32 table_max_depth, u32 t
   l.chain_dw = pre ? 0u : (table_scopes <= 256u ? depth * (CBH_BLOCK / 4u) : depth * CBH_BLOCK);
   l.aux_dw = pre ? 0u : CBH_W2_NA * CBH_BLOCK;
   l.gacc_dw = pre ? n_gwords * CBH_BLOCK * 2u : 0u;
-  l.wave_dw = l.cc_dw + l.arena_dw + l.chain_dw + l.aux_dw + l.gacc_dw;
-  l.cls_bytes = table_strings <= CBH_FLAT_LDS_STRINGS ? ((2u * table_strings + 15u) & ~15u) : 0u;
+  l.edr_dw = (!pre && table_n_dr) ? depth * CBH_BLOCK * 2u : 0u;   // [depth][lane] u64: the derived roles activated at that chain position
+  l.wave_dw = l.cc_dw + l.arena_dw + l.chain_dw + l.aux_dw + l.gacc_dw + l.edr_dw;
+  l.cls_bytes = table_strings <= CBH_FLAT_LDS_STRINGS ? ((3u * table_strings + 15u) & ~15u) : 0u;   // action class, role class, CBH_SWF_* per string
   return l;
 }
 static inline size_t w2_lds_bytes(const W2Layout& l, u32 waves) { return (size_t)l.wave_dw * 4u * waves + l.cls_bytes; }
@@ -107,10 +108,11 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   CBH_L u8* chain_si8 = (CBH_L u8*)chain_si;
   CBH_L u32* aux = chain_si + ly.chain_dw;                                   // [action][lane]: see the fold
   CBH_L u64* gacc = (CBH_L u64*)(wave_lds + ly.cc_dw + ly.arena_dw + ly.chain_dw + ly.aux_dw);   // [word][lane] (pre-pass)
+  CBH_L u64* edr_at = (CBH_L u64*)(wave_lds + ly.cc_dw + ly.arena_dw + ly.chain_dw + ly.aux_dw + ly.gacc_dw);   // [depth][lane] (walk)
   CBH_L u8* cls_lds = (CBH_L u8*)((CBH_L u32*)cbh_dyn_lds + (PRE ? 1u : CBH_W2_WAVES) * ly.wave_dw);
   const bool cls_in_lds = ly.cls_bytes != 0;
   if (cls_in_lds) {
-    for (u32 i = threadIdx.x; i < t.K; i += (PRE ? CBH_BLOCK : CBH_W2_THREADS)) { cls_lds[i] = t.action_class[i]; cls_lds[t.K + i] = t.role_class[i]; }
+    for (u32 i = threadIdx.x; i < t.K; i += (PRE ? CBH_BLOCK : CBH_W2_THREADS)) { cls_lds[i] = t.action_class[i]; cls_lds[t.K + i] = t.role_class[i]; cls_lds[2u * t.K + i] = t.str_wflags[i]; }
   }
   if (PRE) { for (u32 w = 0; w < b.n_gwords; ++w) gacc[w * CBH_BLOCK + c.tid] = 0; }
   else {
@@ -140,6 +142,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   }
   const u32 kmax = t.K ? t.K - 1u : 0u;
   u32 rcls[NR];
+  u32 rpar = 0;   // bit r: the role has ancestors in some scope (CBH_SWF_PARENTS): the only ones the directory is asked about
   if (cls_in_lds) __syncthreads();
 #pragma unroll
   for (u32 k = 0; k < NA; ++k) {
@@ -152,7 +155,10 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     const u32 ix = rid[k] < t.K ? rid[k] : kmax;
     const u32 cr = cls_in_lds ? (u32)cls_lds[t.K + ix] : (u32)t.role_class[ix];
     rcls[k] = (k < role_cnt && rid[k] < t.K && cr < 62u) ? cr : 63u;
+    if (has_parents && k < role_cnt && rid[k] < t.K) rpar |= (((cls_in_lds ? (u32)cls_lds[2u * t.K + ix] : (u32)t.str_wflags[ix]) & CBH_SWF_PARENTS) ? 1u : 0u) << k;
   }
+  // does the principal have a principal policy at all (some version, some scope)?  Else the first pass has nothing to walk
+  const bool pid_has_pp = has_pp && pid < t.K && (((cls_in_lds ? (u32)cls_lds[2u * t.K + pid] : (u32)t.str_wflags[pid]) & CBH_SWF_PRINCIPAL) != 0);
   u32 gap[NA / 2], rgp[NR / 2];   // glob match bits, two 16-bit fields to a dword
 #pragma unroll
   for (u32 j = 0; j < NA / 2; ++j) gap[j] = 0;
@@ -184,7 +190,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
 #pragma unroll
     for (u32 k = 0; k < NR; ++k) {
       uint4 pv;
-      if (k < role_cnt && pr_scope_key != CBH_NONE && dir_find(t, CBH_B_PARENTS, pr_scope_key, rid[k], 0, pv)) {
+      if (((rpar >> k) & 1u) && pr_scope_key != CBH_NONE && dir_find(t, CBH_B_PARENTS, pr_scope_key, rid[k], 0, pv)) {
         for (u32 j = 0; j < pv.y; ++j) {   // ancestors are table strings
           const u32 anc = t.pool[pv.x + j];
           const u32 cr = t.role_class[anc];
@@ -195,22 +201,20 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
       }
     }
   }
-  u32 lane_rs_lo = 0, lane_rs_hi = 0, lane_ac_lo = 0, lane_ac_hi = 0, lane_ag = 0, lane_rg = 0;
+  u32 lane_rs_lo = 0, lane_rs_hi = 0, lane_ac_lo = 0, lane_ac_hi = 0;
   u32 walks = 0;   // bit 8 r + k: role r exists and action k exists
 #pragma unroll
   for (u32 k = 0; k < NA; ++k) {
-    if (k < act_cnt) { const u64 m = 1ull << ac[k]; lane_ac_lo |= (u32)m; lane_ac_hi |= (u32)(m >> 32); lane_ag |= (gap[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu; }
+    if (k < act_cnt) { const u64 m = 1ull << ac[k]; lane_ac_lo |= (u32)m; lane_ac_hi |= (u32)(m >> 32); }
   }
 #pragma unroll
   for (u32 k = 0; k < NR; ++k) {
-    if (k < role_cnt) { lane_rs_lo |= rs_lo[k]; lane_rs_hi |= rs_hi[k]; lane_rg |= (rgp[k >> 1] >> (16u * (k & 1u))) & 0xFFFFu; walks |= all << (8 * k); }
+    if (k < role_cnt) { lane_rs_lo |= rs_lo[k]; lane_rs_hi |= rs_hi[k]; walks |= all << (8 * k); }
   }
   // classes / glob bits present in the wave: a record none of them can match is skipped on the scalar unit
   const u64 wave_a = wave_or64((u64)lane_ac_lo | ((u64)lane_ac_hi << 32), wave, c.tid);
   const u64 wave_r = wave_or64((u64)lane_rs_lo | ((u64)lane_rs_hi << 32), wave, c.tid);
-  const u64 wave_g = (aglobs || rglobs) ? wave_or64((u64)lane_ag | ((u64)lane_rg << 16), wave, c.tid) : 0ull;
   const u32 wave_ac_lo = (u32)wave_a, wave_ac_hi = (u32)(wave_a >> 32), wave_rc_lo = (u32)wave_r, wave_rc_hi = (u32)(wave_r >> 32);
-  const u32 wave_ag = (u32)wave_g & 0xFFFFu, wave_rg = (u32)(wave_g >> 16) & 0xFFFFu;
 
   const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
   u64 edr_scope = 0;   // pre-pass: the derived roles of the scope being walked (what runtime.effectiveDerivedRoles reads)
@@ -277,7 +281,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   u32 p_first = CBH_NONE;
   if (has_pp) {
     p_first = chain_first(t, p_scope, FLAG_PRIN, lenient);
-    const bool cand = valid && p_first != CBH_NONE && role_cnt > 0 && act_cnt > 0;
+    const bool cand = valid && pid_has_pp && p_first != CBH_NONE && role_cnt > 0 && act_cnt > 0;
     bool pend = false;
     if (cand) {
       for (u32 si = p_first; si != CBH_NONE && !pend; si = chain_next(t, t.scope_parent[si], FLAG_PRIN)) {
@@ -372,8 +376,18 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   u32 cur = first, mydepth = 0;
   bool exists = false;
   const bool pre_edr = PRE && (t.flags & CBH_MF_USES_RUNTIME_EDR) != 0;
+  bool pre_climbs = false;   // pre-pass: does anything on this request's path hold a site the batch files?
+  if (PRE) {
+    const u32 filed = (b.n_gwords ? (CBH_BS_ROW_GENERIC | CBH_BS_DR_GENERIC) : 0u) |
+                      (b.n_gwords * CBH_W2_SLOTS_PER_WORD > t.gslots_generic ? (CBH_BS_ROW_OPEN | CBH_BS_DR_OPEN) : 0u);
+    uint4 fv; fv.x = 0;
+    if (valid && walks != 0 && first != CBH_NONE && dir_find(t, CBH_B_FAMILY, r_ver, kind, 0, fv)) pre_climbs = (fv.x & filed) != 0;
+    pre_climbs = pre_climbs || (valid && walks != 0 && (t.q_sites & filed) != 0);   // role-policy rules: any request of the version may reach them
+  }
+  const bool want_edr = !PRE && (flags & CBH_F_WANT_DERIVED_ROLES) != 0 && t.n_dr != 0;
+  u32 derr_d = 0, dunsup_d = 0;   // bit d: a derived-role definition at chain position d raised / left the device subset
   for (;;) {
-    const bool active = cur != CBH_NONE && (PRE ? walks != 0 : (S != 0 || !exists));
+    const bool active = cur != CBH_NONE && (PRE ? pre_climbs : (S != 0 || !exists));
     if (wave_ballot(active) == 0) break;
     const u32 g_si = wave_max_bits(cur, active, scope_bits);
     const u64 here = wave_ballot(active && cur == g_si);
@@ -389,7 +403,8 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     uint4 rpres; rpres.x = rpres.y = 0;
     bool rolepol_here = false;
     u64 g_kb = 0;
-    if (has_rolepol && udir_find(t, CBH_B_RPRES, g_ver, g_si, 0, rpres)) {
+    const u32 g_sf = uload(&t.scope_flags[g_si]);
+    if (has_rolepol && (g_sf & CBH_SCOPE_F_ROLEPOL) && udir_find(t, CBH_B_RPRES, g_ver, g_si, 0, rpres)) {
       rolepol_here = true;
       if (t.nfa_words[DIM_KIND]) g_kb = wave_readlane64(kind_bits(), lead);
       bool m = false;
@@ -417,6 +432,25 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
           if (applies && (lv & 1u)) m |= 1ull << dx.name;
         }
         if (pre_edr && ing) edr_scope = m;
+      }
+      if (want_edr) {
+        // effective derived roles (check.go:237-282): the definitions of this scope's policy, for the requests a walk is
+        // still going for; which of the chain positions count - the ones a LEGITIMATE walk reached - is known at the fold
+        u64 m = 0; bool de = false, du = false;
+        if (have_bucket) {
+          for (u32 d = bucket.z; d < bucket.z + bucket.w; ++d) {
+            const TblDrx dx = uload_rec<TblDrx>(t.drx, d);
+            const bool applies = ing && S != 0 && (((dx.rm_lo & lane_rs_lo) | (dx.rm_hi & lane_rs_hi)) != 0);   // parent roles x the request's roles (check.go:244)
+            if (wave_ballot(applies) == 0) continue;
+            u32 lv = 1u;
+            if (dx.cond != CBH_NONE) lv = leafish(dx.cond, dx.flags & 3u, dx.leaf, dx.p0 & 0xFFFFu, applies);
+            if (applies) { if (lv & 1u) m |= 1ull << dx.name; de = de || (lv & 2u) != 0; du = du || (lv & 8u) != 0; }
+          }
+        }
+        if (ing && mydepth < max_depth) {
+          edr_at[mydepth * CBH_BLOCK + c.tid] = m;
+          derr_d |= (u32)de << mydepth; dunsup_d |= (u32)du << mydepth;
+        }
       }
       if (rolepol_here) {
         // ---- synthetic DENYs of the role policies at this scope (index.go:352-530)
@@ -509,8 +543,8 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
             if (PRE && (gslots & 0xFFFFu) / CBH_W2_SLOTS_PER_WORD >= b.n_gwords && (gslots >> 16) / CBH_W2_SLOTS_PER_WORD >= b.n_gwords) continue;   // none filed for this batch
             if (rx.globs) { ag = rx.globs & 0xFFFFu; rg = rx.globs >> 16; rm_lo = rx.rm_lo; rm_hi = rx.rm_hi; am_lo = rx.am_lo; am_hi = rx.am_hi; }
           }
-          if ((((rm_lo & wave_rc_lo) | (rm_hi & wave_rc_hi)) == 0 && (rg & wave_rg) == 0) ||
-              (((am_lo & wave_ac_lo) | (am_hi & wave_ac_hi)) == 0 && (ag & wave_ag) == 0)) continue;
+          // (a list with a glob is never skipped by class: the lanes' glob bits are still on their way from memory)
+          if ((((rm_lo & wave_rc_lo) | (rm_hi & wave_rc_hi)) == 0 && rg == 0) || (((am_lo & wave_ac_lo) | (am_hi & wave_ac_hi)) == 0 && ag == 0)) continue;
           const u32 mact = match_actions(am_lo, am_hi, ag);
           const u32 mrole = match_roles(rm_lo, rm_hi, rg);
           // (the walks a visit is for: those still going - the pre-pass evaluates for every walk the request has)
@@ -537,7 +571,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
       }
       if (!PRE) {
         const u32 ha = ing ? (has_allow & S) : 0u;   // check.go:416-425
-        const u32 spm = (uload(&t.scope_flags[g_si]) >> 2) & 3u;
+        const u32 spm = (g_sf >> 2) & 3u;
         if (spm == SP_REQUIRE_CONSENT) has_allow &= ~ha;
         else if (spm == SP_OVERRIDE_PARENT) { allow |= ha; S &= ~ha; }
         const u32 newly = S_before & ~S;
@@ -601,9 +635,12 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     st[k >> 2] |= (u32)(u1 ? CBH_ST_UNSUPPORTED : (e1 ? CBH_ST_CEL_ERROR : CBH_ST_OK)) << (8 * (k & 3u));
   }
 
-  // ---- effective derived roles (check.go:237-282): a second merged climb over the scopes a legitimate walk reached
+  // ---- effective derived roles (check.go:237-282): the definitions of a scope's policy are evaluated when a role walk
+  // REACHES that scope - a walk the reference really makes, i.e. not one of a role after the role that allowed its
+  // action.  A decided walk reached the chain positions up to the one that decided it, an undecided one the whole chain;
+  // the climb above left every position's roles in LDS.
   u64 edr = 0;
-  if ((flags & CBH_F_WANT_DERIVED_ROLES) && t.n_dr) {
+  if (want_edr) {
     u32 legit = 0;
 #pragma unroll
     for (u32 k = 0; k < NA; ++k) {
@@ -612,7 +649,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
       legit |= ((walks >> k) & 0x01010101u & seen) << k;
     }
     const u32 done = allow | deny;
-    u32 reach = 0;
+    u32 reach = 0;   // deepest chain position a legitimate walk reached, + 1 (0 = none)
     if (legit & ~done) reach = CBH_FLAT_MAX_DEPTH;
     else if (legit) {
       u32 cand = legit, d = 0;
@@ -622,31 +659,12 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
       tp = cand & dp0; if (tp) { cand = tp; d |= 1u; }
       reach = d + 1u;
     }
-    bool derr = false, dr_unsup = false;
-    u32 cur2 = first, d2 = 0;
-    for (;;) {
-      const bool active = cur2 != CBH_NONE && d2 < reach;
-      if (wave_ballot(active) == 0) break;
-      const u32 g_si = wave_max_bits(cur2, active, scope_bits);
-      const u32 lead = first_lane(wave_ballot(active && cur2 == g_si));
-      const u32 g_ver = wave_readlane(r_ver, lead), g_k = wave_readlane(kind, lead);
-      const bool ing = active && cur2 == g_si && r_ver == g_ver && kind == g_k;
-      uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
-      if (udir_find(t, CBH_B_RESOURCE, g_ver, g_k, g_si, bucket)) {
-        for (u32 d = bucket.z; d < bucket.z + bucket.w; ++d) {
-          const TblDrx dx = uload_rec<TblDrx>(t.drx, d);
-          const bool applies = ing && (((dx.rm_lo & lane_rs_lo) | (dx.rm_hi & lane_rs_hi)) != 0);   // parent roles x the request's roles (check.go:244)
-          if (wave_ballot(applies) == 0) continue;
-          u32 lv = 1u;
-          if (dx.cond != CBH_NONE) lv = leafish(dx.cond, dx.flags & 3u, dx.leaf, dx.p0 & 0xFFFFu, applies);
-          if (applies) { if (lv & 1u) edr |= 1ull << dx.name; derr = derr || (lv & 2u) != 0; dr_unsup = dr_unsup || (lv & 8u) != 0; }
-        }
-      }
-      const u32 up = uchain_next(t, uload(&t.scope_parent[g_si]), FLAG_RES);
-      if (ing) { cur2 = up; ++d2; }
-    }
-    if (derr) { st[0] |= 0x01010101u & ~((st[0] >> 1) & 0x01010101u); st[1] |= 0x01010101u & ~((st[1] >> 1) & 0x01010101u); }
-    if (dr_unsup) { st[0] = 0x02020202u; st[1] = 0x02020202u; }
+    if (reach > mydepth) reach = mydepth;   // (the positions this request's climb visited)
+    if (reach > max_depth) reach = max_depth;
+    for (u32 d = 0; d < reach; ++d) edr |= edr_at[d * CBH_BLOCK + c.tid];
+    const u32 upto = reach >= 32u ? 0xFFFFFFFFu : ((1u << reach) - 1u);
+    if (derr_d & upto) { st[0] |= 0x01010101u & ~((st[0] >> 1) & 0x01010101u); st[1] |= 0x01010101u & ~((st[1] >> 1) & 0x01010101u); }   // evaluation errors are a per-request fact
+    if (dunsup_d & upto) { st[0] = 0x02020202u; st[1] = 0x02020202u; }
   }
 
 #ifdef CBH_PROFILE_CYCLES
@@ -690,7 +708,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
 // the walk: four independent waves to a workgroup, no evaluator call
 __global__ CBH_W2_ATTRS void cbh_walk2_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
   const u32 ncc = a.t.inline_cols;   // no generic program runs here: only the columns the inline leaf code reads are parked in LDS
-  const W2Layout ly = w2_layout(ncc, false, a.t.max_depth, a.t.n_scopes, false, 0, a.t.K);
+  const W2Layout ly = w2_layout(ncc, false, a.t.max_depth, a.t.n_scopes, false, 0, a.t.K, a.t.n_dr);
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
         (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * ly.wave_dw, ncc, ka};
   w2_body<false>(a, c, ly);
@@ -711,7 +729,7 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_walk2_pre_kernel(const KernelAr
     for (u32 k = 0; k < CBH_MAX_ITERS; ++k) { it_cont[k * CBH_BLOCK + tid] = 0; it_idx[k * CBH_BLOCK + tid] = 0; it_state[k * CBH_BLOCK + tid] = 0; }
   }
   const u32 ncc = cached_columns(&a);
-  const W2Layout ly = w2_layout(ncc, (a.t.flags & CBH_MF_NEEDS_ARENA) != 0, a.t.max_depth, a.t.n_scopes, true, a.b.n_gwords, a.t.K);
+  const W2Layout ly = w2_layout(ncc, (a.t.flags & CBH_MF_NEEDS_ARENA) != 0, a.t.max_depth, a.t.n_scopes, true, a.b.n_gwords, a.t.K, a.t.n_dr);
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x,
         (CBH_L u64*)s_val, (CBH_L u8*)s_tag, (CBH_L u64*)l_val, (CBH_L u8*)l_tag,
         (CBH_L u64*)it_cont, (CBH_L u32*)it_idx, (CBH_L u32*)it_state,
@@ -752,9 +770,9 @@ static inline size_t cbh_general_lds(u32 table_flags, u32 n_columns) {
   return (size_t)ncc * CBH_BLOCK * 12 + ((table_flags & CBH_MF_NEEDS_ARENA) ? (size_t)CBH_ARENA_ENTRIES * CBH_BLOCK * 9 : 0);
 }
 // dynamic LDS of a launch of `kernel` (pre = the pre-pass of kind 2)
-static inline size_t cbh_plan_lds(const CbhPlan& p, u32 table_flags, u32 table_max_depth, u32 table_scopes, u32 table_strings, u32 n_columns, u32 inline_cols, bool pre) {
+static inline size_t cbh_plan_lds(const CbhPlan& p, u32 table_flags, u32 table_max_depth, u32 table_scopes, u32 table_strings, u32 n_columns, u32 inline_cols, u32 table_n_dr, bool pre) {
   const u32 ncc = n_columns < CBH_CACHE_COLS ? n_columns : CBH_CACHE_COLS;
-  if (p.kind == 2) return w2_lds_bytes(w2_layout(pre ? ncc : inline_cols, (table_flags & CBH_MF_NEEDS_ARENA) != 0, table_max_depth, table_scopes, pre, p.n_gwords, table_strings), pre ? 1u : CBH_W2_WAVES);
+  if (p.kind == 2) return w2_lds_bytes(w2_layout(pre ? ncc : inline_cols, (table_flags & CBH_MF_NEEDS_ARENA) != 0, table_max_depth, table_scopes, pre, p.n_gwords, table_strings, table_n_dr), pre ? 1u : CBH_W2_WAVES);
   const size_t wave = cbh_general_lds(table_flags, n_columns);
   if (p.kind == 1) return (wave + cbh_flat_chain_bytes(table_max_depth, table_scopes)) * (p.threads / CBH_BLOCK) + cbh_flat_class_bytes(table_strings);
   return wave;

@@ -542,11 +542,11 @@ static void launch_plan(const CbhPlan& pl, const TableDev& dev, KernelArgs ka, c
     }
     ka.b.n_gwords = ka.b.gres ? pl.n_gwords : 0;
     if (ka.b.n_gwords)   // the evaluation sites first: their results are what the walk reads
-      go(cbh_walk2_pre_kernel, (n + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, true), ka, false);
+      go(cbh_walk2_pre_kernel, (n + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, dev.n_dr, true), ka, false);
   }
   static const bool pre_only = getenv("CBH_PRE_ONLY") != nullptr;   // measurement aid (profiling build): the pre-pass alone
   if (pre_only && pl.kind == 2) return;
-  go(pl.kernel, (n + pl.threads - 1) / pl.threads, pl.threads, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, false) + pad, ka, true);
+  go(pl.kernel, (n + pl.threads - 1) / pl.threads, pl.threads, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, dev.n_dr, false) + pad, ka, true);
 }
 // CBH_LDS_PAD=<bytes> (measurement aid): extra dynamic LDS per workgroup of the resident launches, to hold the occupancy down
 static size_t lds_pad() { static const size_t pad = [] { const char* e = getenv("CBH_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }(); return pad; }

@@ -60,7 +60,9 @@ static inline const char* cbh_parse_image(TableDev& d, std::vector<uint32_t>& me
     if (!rx || !px || rx->nbytes < (uint64_t)m[CBH_M_NROWS] * 32 || px->nbytes < (uint64_t)m[CBH_M_NRPROWS] * 64) return ("blob is missing the walk sections");
   }
   d.gslots_generic = m[CBH_M_GSLOTS_GENERIC]; d.gslots_all = m[CBH_M_GSLOTS_ALL];
-  d.inline_cols = m[CBH_M_INLINE_COLS]; d.sens_cols = m[CBH_M_SENS_COLS];
+  d.inline_cols = m[CBH_M_INLINE_COLS]; d.sens_cols = m[CBH_M_SENS_COLS]; d.q_sites = m[CBH_M_Q_SITES];
+  d.str_wflags = dptr(CBH_SEC_STR_WFLAGS);
+  if (!d.str_wflags) return ("blob is missing the string flag section");
   if (d.inline_cols > CBH_CACHE_COLS || d.inline_cols > m[CBH_M_NCOLUMNS]) return ("blob inline column count out of range");
   if (d.gslots_generic > d.gslots_all || d.gslots_all > CBH_W2_MAX_GSLOTS) return ("blob evaluation-site slots out of range");
   if (m[CBH_M_NROWS] && !d.rowpat) return ("blob is missing the row pattern section");

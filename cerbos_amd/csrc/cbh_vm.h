@@ -56,6 +56,8 @@ struct TableDev {
   const CBH_G u32* rowx; const CBH_G u32* rpx;              // CBH_SEC_ROWX / CBH_SEC_RPX (cbh_check_walk2.h)
   u32 gslots_generic, gslots_all;                           // evaluation-site slots of the table (CBH_M_GSLOTS_*)
   u32 inline_cols, sens_cols;                               // CBH_M_INLINE_COLS, CBH_M_SENS_COLS
+  u32 q_sites;                                              // CBH_M_Q_SITES
+  const CBH_G u8* str_wflags;                               // [K] CBH_SWF_* (CBH_SEC_STR_WFLAGS)
   const CBH_G u32* rprows; u32 n_rprows;
   const CBH_G u32* pool;
   const CBH_G u32* dr; u32 n_dr;

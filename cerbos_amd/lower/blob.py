@@ -45,9 +45,11 @@ MF_FLAT_CLOSED = 512
 # roles, glob patterns, generic programs).  Per record: CBH_SEC_ROWX; per role-policy rule: CBH_SEC_RPX.
 MF_WALK2 = 2048
 ROW_F_X, ROW_F_XEXACT = 1024, 2048
-SEC_ROWX, SEC_RPX = 40, 41
-B_RPROLES = 8
-M_GSLOTS_GENERIC, M_GSLOTS_ALL, M_INLINE_COLS, M_SENS_COLS = 18, 19, 20, 21
+SEC_ROWX, SEC_RPX, SEC_STR_WFLAGS = 40, 41, 42
+B_RPROLES, B_FAMILY = 8, 9
+SWF_PRINCIPAL, SWF_PARENTS = 1, 2     # CBH_SEC_STR_WFLAGS bits
+SCOPE_F_ROLEPOL = 16                  # CBH_SEC_SCOPE_FLAGS bit 4: some role policy lives at this scope
+M_GSLOTS_GENERIC, M_GSLOTS_ALL, M_INLINE_COLS, M_SENS_COLS, M_Q_SITES = 18, 19, 20, 21, 22
 GSLOT_NONE = 0xFFFF
 WALK2_MAX_GLOBS = 16      # glob patterns per dimension (action, role) a lane keeps match bits for
 WALK2_MAX_GSLOTS = 256    # evaluation-site slots of one request (4 result bits each, 16 to a 64-bit word: cbh_walk2_pre_kernel)
@@ -785,6 +787,26 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
         key = row_key.get(i) if what == "row" else dr_key.get(i) if what == "dr" else None
         if key is not None:
             bucket_sites[key] = bucket_sites.get(key, 0) | site_bit[(what, k)]
+    family_sites = {}
+    for (_v, _k, _s), bits in bucket_sites.items():
+        family_sites[(_v, _k)] = family_sites.get((_v, _k), 0) | bits
+    for (fv, fk) in sorted({(e[1], e[2]) for e in entries if e[0] == B_RESOURCE}):
+        entries.append((B_FAMILY, fv, fk, 0, family_sites.get((fv, fk), 0), 0, 0, 0))
+    # per table string: is it a principal with a principal policy, a role with ancestors in some scope (what the walk would
+    # otherwise probe the directory for, lane by lane)
+    str_wflags = np.zeros(K, dtype=np.uint8)
+    for (_v, _s, principal) in prin_buckets:
+        str_wflags[lt.string_ids[principal]] |= SWF_PRINCIPAL
+    for _scope, roles in rt["parent_roles"].items():
+        for role, ancestors in roles.items():
+            if ancestors:
+                str_wflags[lt.string_ids[role]] |= SWF_PARENTS
+    for (_v, scope, _r) in rp_buckets:
+        scope_flags[lt.scope_index[scope]] |= SCOPE_F_ROLEPOL
+    q_sites = 0   # the role-policy rules' sites (any request of the version can reach them): 2 generic, 4 open
+    for (r, _fam, _prog, k, _setter) in sites:
+        if r == "Q":
+            q_sites |= 2 if k == "generic" else 4
     entries[:] = [((e[0], e[1], e[2], e[3], 1 | bucket_sites.get(e[1:4], 0)) + (lambda u: (u[0] & 0xFFFFFFFF, u[0] >> 32, u[1]))(bucket_union.get(e[1:4], (0, 0)))) if e[0] == B_RESEXISTS else e
                   for e in entries]
 
@@ -863,6 +885,7 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
     meta[M_SENS_COLS] = sum(1 << c for c in pb.sensitive_cols if c < 32)
     meta[M_GSLOTS_GENERIC] = n_gslots_generic
     meta[M_GSLOTS_ALL] = n_gslots_all
+    meta[M_Q_SITES] = q_sites
     meta[M_MAX_STACK] = pb.max_stack
     meta[M_NDRNAMES] = len(lt.dr_names)
     meta[M_NFA_WORDS_ACTION] = lt.nfas[0].words
@@ -910,6 +933,7 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
         (SEC_DRX, len(drx_cols[0]), row_major(drx_cols, 16)),
         (SEC_ROWX, n_rows_total, rowx.tobytes()),
         (SEC_RPX, n_rp_total, rpx.tobytes()),
+        (SEC_STR_WFLAGS, K, str_wflags.tobytes()),
         (SEC_REGEX, len(pb.regex_words), u32(pb.regex_words)),   # DFA tables of constant `matches` patterns (lower/regex.py)
         (SEC_RPROWS, len(rp_cols[0]), row_major(rp_cols, 4)),
         (SEC_U32POOL, len(pool), u32(pool)),
