@@ -49,7 +49,7 @@ static inline W2Layout w2_layout(u32 ncc, bool arena, u32 table_max_depth, u32 t
   l.chain_dw = pre ? 0u : (table_scopes <= 256u ? depth * (CBH_BLOCK / 4u) : depth * CBH_BLOCK);
   l.aux_dw = pre ? 0u : CBH_W2_NA * CBH_BLOCK;
   l.gacc_dw = pre ? n_gwords * CBH_BLOCK * 2u : 0u;
-  l.edr_dw = (!pre && table_n_dr) ? depth * CBH_BLOCK * 2u : 0u;   // [depth][lane] u64: the derived roles activated at that chain position
+  l.edr_dw = 0u; (void)table_n_dr;
   l.wave_dw = l.cc_dw + l.arena_dw + l.chain_dw + l.aux_dw + l.gacc_dw + l.edr_dw;
   l.cls_bytes = table_strings <= CBH_FLAT_LDS_STRINGS ? ((3u * table_strings + 15u) & ~15u) : 0u;   // action class, role class, CBH_SWF_* per string
   return l;
@@ -108,7 +108,6 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   CBH_L u8* chain_si8 = (CBH_L u8*)chain_si;
   CBH_L u32* aux = chain_si + ly.chain_dw;                                   // [action][lane]: see the fold
   CBH_L u64* gacc = (CBH_L u64*)(wave_lds + ly.cc_dw + ly.arena_dw + ly.chain_dw + ly.aux_dw);   // [word][lane] (pre-pass)
-  CBH_L u64* edr_at = (CBH_L u64*)(wave_lds + ly.cc_dw + ly.arena_dw + ly.chain_dw + ly.aux_dw + ly.gacc_dw);   // [depth][lane] (walk)
   CBH_L u8* cls_lds = (CBH_L u8*)((CBH_L u32*)cbh_dyn_lds + (PRE ? 1u : CBH_W2_WAVES) * ly.wave_dw);
   const bool cls_in_lds = ly.cls_bytes != 0;
   if (cls_in_lds) {
@@ -229,7 +228,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     else if (how == 2u) lv = flat_tree(c, lr, req, pid);
     const bool slow = active && lv == 4u;
     if (wave_ballot(slow) != 0) {
-      const bool filed = gslot != CBH_GSLOT_NONE && (gslot / CBH_W2_SLOTS_PER_WORD) < b.n_gwords;   // uniform
+      const bool filed = gslot < b.n_gslots;   // uniform (CBH_GSLOT_NONE is beyond any count)
       if (PRE) {
         W2_DBG(const u64 e0 = __builtin_readcyclecounter(); ++dbg_evals;)
         const u32 r = eval_ref<true>(c.ka_mem, lds_of(c), req, edr_scope, false, ref, slow);
@@ -378,14 +377,14 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   const bool pre_edr = PRE && (t.flags & CBH_MF_USES_RUNTIME_EDR) != 0;
   bool pre_climbs = false;   // pre-pass: does anything on this request's path hold a site the batch files?
   if (PRE) {
-    const u32 filed = (b.n_gwords ? (CBH_BS_ROW_GENERIC | CBH_BS_DR_GENERIC) : 0u) |
-                      (b.n_gwords * CBH_W2_SLOTS_PER_WORD > t.gslots_generic ? (CBH_BS_ROW_OPEN | CBH_BS_DR_OPEN) : 0u);
+    const u32 filed = (b.n_gslots ? (CBH_BS_ROW_GENERIC | CBH_BS_DR_GENERIC) : 0u) | (b.n_gslots > t.gslots_generic ? (CBH_BS_ROW_OPEN | CBH_BS_DR_OPEN) : 0u);
     uint4 fv; fv.x = 0;
     if (valid && walks != 0 && first != CBH_NONE && dir_find(t, CBH_B_FAMILY, r_ver, kind, 0, fv)) pre_climbs = (fv.x & filed) != 0;
     pre_climbs = pre_climbs || (valid && walks != 0 && (t.q_sites & filed) != 0);   // role-policy rules: any request of the version may reach them
   }
   const bool want_edr = !PRE && (flags & CBH_F_WANT_DERIVED_ROLES) != 0 && t.n_dr != 0;
-  u32 derr_d = 0, dunsup_d = 0;   // bit d: a derived-role definition at chain position d raised / left the device subset
+  u64 edr_all = 0; bool derr_all = false, dunsup_all = false;   // derived roles over the chain positions visited with a walk still going
+  u32 edr_vis = 0;                                              // ... how many those were
   for (;;) {
     const bool active = cur != CBH_NONE && (PRE ? pre_climbs : (S != 0 || !exists));
     if (wave_ballot(active) == 0) break;
@@ -415,7 +414,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     if (PRE && have_bucket) {
       uint4 ex; ex.x = 0;
       if (udir_find(t, CBH_B_RESEXISTS, g_ver, g_k, g_si, ex)) site_flags = ex.x;
-      if (b.n_gwords * CBH_W2_SLOTS_PER_WORD <= t.gslots_generic) site_flags &= ~(u32)(CBH_BS_ROW_OPEN | CBH_BS_DR_OPEN);   // their slots are not filed for this batch
+      if (b.n_gslots <= t.gslots_generic) site_flags &= ~(u32)(CBH_BS_ROW_OPEN | CBH_BS_DR_OPEN);   // their slots are not filed for this batch
     }
     if (go) {
       if (!PRE && ing && mydepth < max_depth) { if (chain8) chain_si8[mydepth * CBH_BLOCK + c.tid] = (u8)g_si; else chain_si[mydepth * CBH_BLOCK + c.tid] = g_si; }
@@ -447,10 +446,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
             if (applies) { if (lv & 1u) m |= 1ull << dx.name; de = de || (lv & 2u) != 0; du = du || (lv & 8u) != 0; }
           }
         }
-        if (ing && mydepth < max_depth) {
-          edr_at[mydepth * CBH_BLOCK + c.tid] = m;
-          derr_d |= (u32)de << mydepth; dunsup_d |= (u32)du << mydepth;
-        }
+        if (ing && S != 0) { edr_all |= m; derr_all = derr_all || de; dunsup_all = dunsup_all || du; edr_vis = mydepth + 1u; }
       }
       if (rolepol_here) {
         // ---- synthetic DENYs of the role policies at this scope (index.go:352-530)
@@ -540,7 +536,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
           if (rw.flags & CBH_ROW_F_X) {
             const TblRowX rx = uload_rec<TblRowX>(t.rowx, row);
             gslots = rx.gslots;
-            if (PRE && (gslots & 0xFFFFu) / CBH_W2_SLOTS_PER_WORD >= b.n_gwords && (gslots >> 16) / CBH_W2_SLOTS_PER_WORD >= b.n_gwords) continue;   // none filed for this batch
+            if (PRE && (gslots & 0xFFFFu) >= b.n_gslots && (gslots >> 16) >= b.n_gslots) continue;   // none filed for this batch
             if (rx.globs) { ag = rx.globs & 0xFFFFu; rg = rx.globs >> 16; rm_lo = rx.rm_lo; rm_hi = rx.rm_hi; am_lo = rx.am_lo; am_hi = rx.am_hi; }
           }
           // (a list with a glob is never skipped by class: the lanes' glob bits are still on their way from memory)
@@ -659,12 +655,39 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
       tp = cand & dp0; if (tp) { cand = tp; d |= 1u; }
       reach = d + 1u;
     }
-    if (reach > mydepth) reach = mydepth;   // (the positions this request's climb visited)
-    if (reach > max_depth) reach = max_depth;
-    for (u32 d = 0; d < reach; ++d) edr |= edr_at[d * CBH_BLOCK + c.tid];
-    const u32 upto = reach >= 32u ? 0xFFFFFFFFu : ((1u << reach) - 1u);
-    if (derr_d & upto) { st[0] |= 0x01010101u & ~((st[0] >> 1) & 0x01010101u); st[1] |= 0x01010101u & ~((st[1] >> 1) & 0x01010101u); }   // evaluation errors are a per-request fact
-    if (dunsup_d & upto) { st[0] = 0x02020202u; st[1] = 0x02020202u; }
+    // The climb evaluated the definitions at every position some walk of the request was still going for.  That is
+    // exactly the legitimate reach unless the last walks going were all of roles behind an allowing one - rare; those
+    // requests (only) climb once more, for the definitions alone.
+    edr = edr_all;
+    bool derr = derr_all, dr_unsup = dunsup_all;
+    const bool again = reach < edr_vis;
+    if (wave_ballot(again) != 0) {
+      if (again) { edr = 0; derr = false; dr_unsup = false; }
+      u32 cur2 = first, d2 = 0;
+      for (;;) {
+        const bool active = again && cur2 != CBH_NONE && d2 < reach;
+        if (wave_ballot(active) == 0) break;
+        const u32 g_si = wave_max_bits(cur2, active, scope_bits);
+        const u32 lead = first_lane(wave_ballot(active && cur2 == g_si));
+        const u32 g_ver = wave_readlane(r_ver, lead), g_k = wave_readlane(kind, lead);
+        const bool ing = active && cur2 == g_si && r_ver == g_ver && kind == g_k;
+        uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
+        if (udir_find(t, CBH_B_RESOURCE, g_ver, g_k, g_si, bucket)) {
+          for (u32 d = bucket.z; d < bucket.z + bucket.w; ++d) {
+            const TblDrx dx = uload_rec<TblDrx>(t.drx, d);
+            const bool applies = ing && (((dx.rm_lo & lane_rs_lo) | (dx.rm_hi & lane_rs_hi)) != 0);
+            if (wave_ballot(applies) == 0) continue;
+            u32 lv = 1u;
+            if (dx.cond != CBH_NONE) lv = leafish(dx.cond, dx.flags & 3u, dx.leaf, dx.p0 & 0xFFFFu, applies);
+            if (applies) { if (lv & 1u) edr |= 1ull << dx.name; derr = derr || (lv & 2u) != 0; dr_unsup = dr_unsup || (lv & 8u) != 0; }
+          }
+        }
+        const u32 up = uchain_next(t, uload(&t.scope_parent[g_si]), FLAG_RES);
+        if (ing) { cur2 = up; ++d2; }
+      }
+    }
+    if (derr) { st[0] |= 0x01010101u & ~((st[0] >> 1) & 0x01010101u); st[1] |= 0x01010101u & ~((st[1] >> 1) & 0x01010101u); }   // evaluation errors are a per-request fact
+    if (dr_unsup) { st[0] = 0x02020202u; st[1] = 0x02020202u; }
   }
 
 #ifdef CBH_PROFILE_CYCLES
@@ -749,11 +772,12 @@ struct CbhPlan {
   cbh_check_kernel_fn kernel;
   u32 threads;                   // workgroup size of `kernel`
   u32 n_gwords;                  // kind 2: 64-bit words of evaluation-site results per request (0 = no pre-pass)
+  u32 n_gslots;                  // ... the sites filed: slots 0 .. n - 1 (the generic ones only for a batch of plain values)
   cbh_check_kernel_fn wide_kernel;   // kind 2, batch with requests wider than the walk's shape: the general walk's kernel for those (else null)
 };
 static inline CbhPlan cbh_plan(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 gslots_generic, u32 gslots_all, u32 max_actions,
                                u32 max_roles, bool plain_tags, u32 eval_flags, bool no_flat, bool no_walk2) {
-  CbhPlan p; p.n_gwords = 0; p.wide_kernel = nullptr;
+  CbhPlan p; p.n_gwords = 0; p.n_gslots = 0; p.wide_kernel = nullptr;
   bool flat = false;
   p.kernel = cbh_pick_kernel(no_flat ? (table_flags & ~(u32)CBH_MF_FLAT) : table_flags, n_derived_roles, has_globs, max_actions, max_roles, plain_tags, eval_flags, &p.threads, &flat);
   p.kind = flat ? 1 : 0;
@@ -761,6 +785,7 @@ static inline CbhPlan cbh_plan(u32 table_flags, u32 n_derived_roles, bool has_gl
     if (max_actions > CBH_W2_NA || max_roles > CBH_W2_NR) p.wide_kernel = p.kernel;
     p.kind = 2; p.kernel = cbh_walk2_kernel; p.threads = CBH_W2_THREADS;
     p.n_gwords = w2_gwords(gslots_generic, gslots_all, plain_tags);
+    p.n_gslots = plain_tags ? gslots_generic : gslots_all;
   }
   return p;
 }

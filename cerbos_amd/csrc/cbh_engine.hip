@@ -480,6 +480,7 @@ extern "C" int cbh_batch_upload_on(cbh_table* t, uint32_t device_index, const cb
   rc |= up(b, d.str_flags, in->str_flags, in->n_strings, s);
   rc |= dalloc(b, d.gbits, (size_t)3 * in->n_strings);
   d.n_gwords = (rep->dev.flags & CBH_MF_WALK2) ? w2_gwords(rep->dev.gslots_generic, rep->dev.gslots_all, b->plain_tags) : 0;
+  d.n_gslots = 0;   // per launch (launch_plan)
   if (d.n_gwords) rc |= dalloc(b, d.gres, (size_t)d.n_gwords * NR); else d.gres = nullptr;
   rc |= dalloc(b, b->out.effect, in->n_tuples);
   rc |= dalloc(b, b->out.policy, in->n_tuples);
@@ -540,7 +541,7 @@ static void launch_plan(const CbhPlan& pl, const TableDev& dev, KernelArgs ka, c
       if (kw.b.req_hi > kw.b.req_lo) go(pl.wide_kernel, (kw.b.req_hi - kw.b.req_lo + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, cbh_general_lds(dev.flags, ka.b.n_columns), kw, false);
       ka.flags |= CBH_FI_SKIP_WIDE;
     }
-    ka.b.n_gwords = ka.b.gres ? pl.n_gwords : 0;
+    ka.b.n_gwords = ka.b.gres ? pl.n_gwords : 0; ka.b.n_gslots = ka.b.gres ? pl.n_gslots : 0;
     if (ka.b.n_gwords)   // the evaluation sites first: their results are what the walk reads
       go(cbh_walk2_pre_kernel, (n + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, dev.n_dr, true), ka, false);
   }
@@ -803,7 +804,7 @@ static void bind_args(KernelArgs& ka, const TableDev& tdev, const cbh_batch* in,
   d.tuple_action = (const u32*)(base + L.act.off); d.col_tag = base + L.ctag.off; d.col_val = (const u64*)(base + L.cval.off);
   d.heap_tag = base + L.htag.off; d.heap_val = (const u64*)(base + L.hval.off); d.str_off = (const u32*)(base + L.soff.off);
   d.str_bytes = base + L.sbytes.off; d.str_flags = base + L.sflags.off; d.gbits = (u64*)(base + L.gbits.off);
-  d.gres = L.gres.bytes ? (u64*)(base + L.gres.off) : nullptr; d.n_gwords = 0;   // n_gwords: per launch (launch_plan)
+  d.gres = L.gres.bytes ? (u64*)(base + L.gres.off) : nullptr; d.n_gwords = 0; d.n_gslots = 0;   // n_gwords: per launch (launch_plan)
   ka.o.effect = base + L.eff.off; ka.o.policy = (u32*)(base + L.pol.off); ka.o.scope = (u32*)(base + L.scope.off);
   ka.o.status = base + L.status.off; ka.o.edr = (u64*)(base + L.edr.off);
 }

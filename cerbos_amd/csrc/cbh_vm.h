@@ -85,7 +85,7 @@ struct BatchDev {
   const CBH_G u32* str_off; const CBH_G u8* str_bytes; const CBH_G u8* str_flags;
   CBH_G u64* gbits; // [3][n_strings], written by the resolve kernel
   CBH_G u64* gres;  // [n_gwords][n_requests] results of the evaluation sites (cbh_walk2_pre_kernel writes, cbh_walk2_kernel reads)
-  u32 n_gwords; u32 pad_gw;
+  u32 n_gwords; u32 n_gslots;   // words per request; sites filed = slots 0 .. n_gslots - 1
 };
 
 struct OutDev {

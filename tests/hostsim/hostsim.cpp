@@ -199,7 +199,7 @@ static int run_sim(const void* blob, size_t len, const cbh_batch* in, const cbh_
   const CbhPlan pl = cbh_plan(a.t.flags, a.t.n_dr, has_globs, a.t.gslots_generic, a.t.gslots_all, g_max_actions, g_max_roles, g_plain, a.flags,
                               getenv("CBH_NO_FLAT") != nullptr, getenv("CBH_NO_WALK2") != nullptr);
   std::vector<uint64_t> gres((size_t)pl.n_gwords * in->n_requests + 1, 0xDDDDDDDDDDDDDDDDull);
-  b.gres = pl.n_gwords ? gres.data() : nullptr; b.n_gwords = pl.n_gwords;
+  b.gres = pl.n_gwords ? gres.data() : nullptr; b.n_gwords = pl.n_gwords; b.n_gslots = pl.n_gslots;
   if (const char* e = getenv("CBH_HOSTSIM_REPORT")) { if (*e == '1') std::fprintf(stderr, "hostsim: kernel kind %d, %u result words\n", pl.kind, pl.n_gwords); }
   g_last_kind = trace ? -1 : pl.kind;
   // two launches over an arbitrary (unaligned) split of the batch: the chunk window [req_lo, req_hi) that the
