@@ -103,7 +103,8 @@ enum CbhMeta {
   CBH_M_GSLOTS_ALL = 19,     // ... plus the sites it can decide inline for plain scalars only: slots 0 .. n - 1
   CBH_M_INLINE_COLS = 20,    // the inline leaf code of the flat / walk2 kernels reads attribute columns 0 .. n - 1 only (the lowering
                              // numbers those first): what a walk without generic programs parks in LDS
-  CBH_M_Q_SITES = 22,        // CBH_BS_ROW_GENERIC / _OPEN: the role-policy rules hold evaluation sites of that kind
+  CBH_M_Q_SITES = 22,        // CBH_BS_ROW_GENERIC / _OPEN: the role-policy rules hold evaluation sites of that kind; CBH_BS_DR_GENERIC /
+                             // _OPEN (bits 3, 4): the principal policies' rules do
   CBH_M_SENS_COLS = 21,      // bit c: an int / uint / list / map value in column c sends a classified leaf to the shared evaluator -
                              // the columns the host looks at to call a batch "plain" (cbh_engine.hip validate_batch)
   CBH_META_N = 24
@@ -133,7 +134,7 @@ enum CbhBucketType {
   CBH_B_ROLEPOL = 3,   // (ver sid, scope idx, role sid) -> v0 rprow_begin, v1 rprow_count, v2 policy id
   CBH_B_PPEXISTS = 4,  // (ver sid, scope idx, 0) -> exists (any principal policy row)
   CBH_B_RPRES = 5,     // (ver sid, scope idx, 0) -> v0 off, v1 cnt into U32POOL of resource pattern refs of role-policy rows
-  CBH_B_PARENTS = 6,   // (scope idx, role sid, 0) -> v0 off, v1 cnt into U32POOL of ancestor role sids
+  CBH_B_PARENTS = 6,   // (scope idx, role sid, 0) -> v0 off, v1 cnt into U32POOL of ancestor role sids; v2, v3 = OR of their role classes
   CBH_B_RESEXISTS = 7, // (ver sid, kind sid, scope idx): same key as RESOURCE, present for every resource policy; v1, v2 = union of the
                        // literal role class masks of its rules, v3 = union of their role glob masks (Index.Query's base test);
                        // v0 = 1 | CBH_BS_*: the evaluation sites the bucket holds (cbh_check_walk2.h: the pre-pass skips the rest)

@@ -99,6 +99,18 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   u32 p_scope = 0, p_ver = 0;
   if (has_pp) { p_scope = RQ(CBH_RQ_P_SCOPE); p_ver = RQ(CBH_RQ_P_VERSION); }
 #undef RQ
+  const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
+  const u32 first = chain_first(t, r_scope, FLAG_RES, lenient);
+  bool pre_climbs = false;   // pre-pass: does anything on this request's path hold a site the batch files?
+  if (PRE) {
+    const u32 filed = (b.n_gslots ? (CBH_BS_ROW_GENERIC | CBH_BS_DR_GENERIC) : 0u) | (b.n_gslots > t.gslots_generic ? (CBH_BS_ROW_OPEN | CBH_BS_DR_OPEN) : 0u);
+    uint4 fv; fv.x = 0;
+    const bool has_walks = valid && role_cnt != 0 && act_cnt != 0;
+    if (has_walks && first != CBH_NONE && dir_find(t, CBH_B_FAMILY, r_ver, kind, 0, fv)) pre_climbs = (fv.x & filed) != 0;
+    pre_climbs = pre_climbs || (has_walks && (t.q_sites & filed & (CBH_BS_ROW_GENERIC | CBH_BS_ROW_OPEN)) != 0);   // role-policy rules: any request of the version may reach them
+    const bool pre_principal = has_pp && (t.q_sites & filed & (CBH_BS_DR_GENERIC | CBH_BS_DR_OPEN)) != 0;   // principal policies with sites
+    if (wave_ballot(pre_climbs || (pre_principal && has_walks)) == 0) return;   // nothing to evaluate for this wave
+  }
   fill_column_cache(c, b, NRQ, req);
   const u32 all = (1u << act_cnt) - 1u;
   const u32 max_depth = t.max_depth < CBH_FLAT_MAX_DEPTH ? t.max_depth : CBH_FLAT_MAX_DEPTH;
@@ -190,13 +202,9 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     for (u32 k = 0; k < NR; ++k) {
       uint4 pv;
       if (((rpar >> k) & 1u) && pr_scope_key != CBH_NONE && dir_find(t, CBH_B_PARENTS, pr_scope_key, rid[k], 0, pv)) {
-        for (u32 j = 0; j < pv.y; ++j) {   // ancestors are table strings
-          const u32 anc = t.pool[pv.x + j];
-          const u32 cr = t.role_class[anc];
-          const u64 m = 1ull << (cr < 62u ? cr : 63u);
-          rs_lo[k] |= (u32)m; rs_hi[k] |= (u32)(m >> 32);
-          if (rglobs) rgp[k >> 1] |= ((u32)t.gbits[(size_t)DIM_ROLE * t.K + anc] & 0xFFFFu) << (16u * (k & 1u));
-        }
+        rs_lo[k] |= pv.z; rs_hi[k] |= pv.w;   // the OR of the ancestors' classes travels in the entry
+        if (rglobs) for (u32 j = 0; j < pv.y; ++j)   // (their role-glob bits: ancestors are table strings)
+          rgp[k >> 1] |= ((u32)t.gbits[(size_t)DIM_ROLE * t.K + t.pool[pv.x + j]] & 0xFFFFu) << (16u * (k & 1u));
       }
     }
   }
@@ -215,7 +223,6 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   const u64 wave_r = wave_or64((u64)lane_rs_lo | ((u64)lane_rs_hi << 32), wave, c.tid);
   const u32 wave_ac_lo = (u32)wave_a, wave_ac_hi = (u32)(wave_a >> 32), wave_rc_lo = (u32)wave_r, wave_rc_hi = (u32)(wave_r >> 32);
 
-  const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
   u64 edr_scope = 0;   // pre-pass: the derived roles of the scope being walked (what runtime.effectiveDerivedRoles reads)
 
   // A condition reference for the lanes with `active`: bit 0 satisfied, bit 1 CEL error, bit 3 outside the device subset.
@@ -278,7 +285,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   // their principal somewhere on the chain are walked group by group; what it decides is kept per action.
   u32 p_allow = 0, p_deny = 0, p_err = 0, p_unsup = 0, p_pol = 0;
   u32 p_first = CBH_NONE;
-  if (has_pp) {
+  if (has_pp && (!PRE || (t.q_sites & (CBH_BS_DR_GENERIC | CBH_BS_DR_OPEN)) != 0)) {   // (pre-pass: only when principal policies hold sites at all)
     p_first = chain_first(t, p_scope, FLAG_PRIN, lenient);
     const bool cand = valid && pid_has_pp && p_first != CBH_NONE && role_cnt > 0 && act_cnt > 0;
     bool pend = false;
@@ -371,17 +378,9 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   u32 has_allow = 0, allow = 0, deny = 0;
   u32 dp0 = 0, dp1 = 0, dp2 = 0, dp3 = 0;
   const u32 scope_bits = t.n_scopes > 1 ? 32u - (u32)__builtin_clz(t.n_scopes - 1u) : 0u;
-  const u32 first = chain_first(t, r_scope, FLAG_RES, lenient);
   u32 cur = first, mydepth = 0;
   bool exists = false;
   const bool pre_edr = PRE && (t.flags & CBH_MF_USES_RUNTIME_EDR) != 0;
-  bool pre_climbs = false;   // pre-pass: does anything on this request's path hold a site the batch files?
-  if (PRE) {
-    const u32 filed = (b.n_gslots ? (CBH_BS_ROW_GENERIC | CBH_BS_DR_GENERIC) : 0u) | (b.n_gslots > t.gslots_generic ? (CBH_BS_ROW_OPEN | CBH_BS_DR_OPEN) : 0u);
-    uint4 fv; fv.x = 0;
-    if (valid && walks != 0 && first != CBH_NONE && dir_find(t, CBH_B_FAMILY, r_ver, kind, 0, fv)) pre_climbs = (fv.x & filed) != 0;
-    pre_climbs = pre_climbs || (valid && walks != 0 && (t.q_sites & filed) != 0);   // role-policy rules: any request of the version may reach them
-  }
   const bool want_edr = !PRE && (flags & CBH_F_WANT_DERIVED_ROLES) != 0 && t.n_dr != 0;
   u64 edr_all = 0; bool derr_all = false, dunsup_all = false;   // derived roles over the chain positions visited with a walk still going
   u32 edr_vis = 0;                                              // ... how many those were

@@ -787,6 +787,15 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
         key = row_key.get(i) if what == "row" else dr_key.get(i) if what == "dr" else None
         if key is not None:
             bucket_sites[key] = bucket_sites.get(key, 0) | site_bit[(what, k)]
+    # a role's ancestors once more as what the walk needs of them: the OR of their classes (v2, v3) - one directory probe
+    # instead of a walk over the list (which only a table with role globs still makes, for their match bits)
+    def _parents_entry(e):
+        lit = 0
+        for anc_sid in pool[e[4]:e[4] + e[5]]:
+            c = int(role_class[anc_sid])
+            lit |= 1 << (c if c < 62 else 63)
+        return (e[0], e[1], e[2], e[3], e[4], e[5], lit & 0xFFFFFFFF, lit >> 32)
+    entries[:] = [_parents_entry(e) if e[0] == B_PARENTS else e for e in entries]
     family_sites = {}
     for (_v, _k, _s), bits in bucket_sites.items():
         family_sites[(_v, _k)] = family_sites.get((_v, _k), 0) | bits
@@ -885,7 +894,8 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
     meta[M_SENS_COLS] = sum(1 << c for c in pb.sensitive_cols if c < 32)
     meta[M_GSLOTS_GENERIC] = n_gslots_generic
     meta[M_GSLOTS_ALL] = n_gslots_all
-    meta[M_Q_SITES] = q_sites
+    meta[M_Q_SITES] = q_sites | (8 if any(r == "P" and k == "generic" for (r, _f, _p, k, _s) in sites) else 0) \
+        | (16 if any(r == "P" and k == "open" for (r, _f, _p, k, _s) in sites) else 0)
     meta[M_MAX_STACK] = pb.max_stack
     meta[M_NDRNAMES] = len(lt.dr_names)
     meta[M_NFA_WORDS_ACTION] = lt.nfas[0].words
