@@ -30,6 +30,7 @@
 
 #define CBH_W2_WAVES CBH_FLAT_WAVES
 #define CBH_W2_THREADS (CBH_W2_WAVES * CBH_BLOCK)
+#define CBH_W2_LDS_GLOB_STRINGS 1024u   /* tables of at most this many strings keep their strings' glob match bits in LDS too */
 #define CBH_W2_MAX_RP_ROLES 32u   /* roles with a role policy at one (version, scope) */
 
 struct __attribute__((aligned(32))) TblRowX { u32 gslots, globs, rm_lo, rm_hi, am_lo, am_hi, p0, p1; };
@@ -51,7 +52,8 @@ static inline W2Layout w2_layout(u32 ncc, bool arena, u32 table_max_depth, u32 t
   l.gacc_dw = pre ? n_gwords * CBH_BLOCK * 2u : 0u;
   l.edr_dw = 0u; (void)table_n_dr;
   l.wave_dw = l.cc_dw + l.arena_dw + l.chain_dw + l.aux_dw + l.gacc_dw + l.edr_dw;
-  l.cls_bytes = table_strings <= CBH_FLAT_LDS_STRINGS ? ((3u * table_strings + 15u) & ~15u) : 0u;   // action class, role class, CBH_SWF_* per string
+  // action class, role class, CBH_SWF_* per string; for a small table also the low 16 glob match bits of its strings (action, role)
+  l.cls_bytes = table_strings <= CBH_FLAT_LDS_STRINGS ? (((3u * table_strings + 15u) & ~15u) + (table_strings <= CBH_W2_LDS_GLOB_STRINGS ? 4u * table_strings : 0u)) : 0u;
   return l;
 }
 static inline size_t w2_lds_bytes(const W2Layout& l, u32 waves) { return (size_t)l.wave_dw * 4u * waves + l.cls_bytes; }
@@ -122,8 +124,16 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   CBH_L u64* gacc = (CBH_L u64*)(wave_lds + ly.cc_dw + ly.arena_dw + ly.chain_dw + ly.aux_dw);   // [word][lane] (pre-pass)
   CBH_L u8* cls_lds = (CBH_L u8*)((CBH_L u32*)cbh_dyn_lds + (PRE ? 1u : CBH_W2_WAVES) * ly.wave_dw);
   const bool cls_in_lds = ly.cls_bytes != 0;
+  const bool gb_in_lds = cls_in_lds && t.K <= CBH_W2_LDS_GLOB_STRINGS && (aglobs || rglobs);
+  CBH_L unsigned short* gb_lds = (CBH_L unsigned short*)(cls_lds + ((3u * t.K + 15u) & ~15u));   // [action bits K][role bits K]
   if (cls_in_lds) {
-    for (u32 i = threadIdx.x; i < t.K; i += (PRE ? CBH_BLOCK : CBH_W2_THREADS)) { cls_lds[i] = t.action_class[i]; cls_lds[t.K + i] = t.role_class[i]; cls_lds[2u * t.K + i] = t.str_wflags[i]; }
+    for (u32 i = threadIdx.x; i < t.K; i += (PRE ? CBH_BLOCK : CBH_W2_THREADS)) {
+      cls_lds[i] = t.action_class[i]; cls_lds[t.K + i] = t.role_class[i]; cls_lds[2u * t.K + i] = t.str_wflags[i];
+      if (gb_in_lds) {
+        gb_lds[i] = aglobs ? (unsigned short)t.gbits[(size_t)DIM_ACTION * t.K + i] : (unsigned short)0;
+        gb_lds[t.K + i] = rglobs ? (unsigned short)t.gbits[(size_t)DIM_ROLE * t.K + i] : (unsigned short)0;
+      }
+    }
   }
   if (PRE) { for (u32 w = 0; w < b.n_gwords; ++w) gacc[w * CBH_BLOCK + c.tid] = 0; }
   else {
@@ -178,14 +188,14 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   if (aglobs) {
 #pragma unroll
     for (u32 k = 0; k < NA; ++k) {
-      const u32 g = k < act_cnt ? ((u32)gbits_of(t, b, DIM_ACTION, aid[k]) & 0xFFFFu) : 0u;
+      const u32 g = k >= act_cnt ? 0u : (gb_in_lds && aid[k] < t.K) ? (u32)gb_lds[aid[k]] : ((u32)gbits_of(t, b, DIM_ACTION, aid[k]) & 0xFFFFu);
       gap[k >> 1] |= g << (16u * (k & 1u));
     }
   }
   if (rglobs) {
 #pragma unroll
     for (u32 k = 0; k < NR; ++k) {
-      const u32 g = k < role_cnt ? ((u32)gbits_of(t, b, DIM_ROLE, rid[k]) & 0xFFFFu) : 0u;
+      const u32 g = k >= role_cnt ? 0u : (gb_in_lds && rid[k] < t.K) ? (u32)gb_lds[t.K + rid[k]] : ((u32)gbits_of(t, b, DIM_ROLE, rid[k]) & 0xFFFFu);
       rgp[k >> 1] |= g << (16u * (k & 1u));
     }
   }
@@ -289,25 +299,22 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     p_first = chain_first(t, p_scope, FLAG_PRIN, lenient);
     const bool cand = valid && pid_has_pp && p_first != CBH_NONE && role_cnt > 0 && act_cnt > 0;
     bool pend = false;
-    if (cand) {
-      for (u32 si = p_first; si != CBH_NONE && !pend; si = chain_next(t, t.scope_parent[si], FLAG_PRIN)) {
+    if (cand) {   // per lane, all lanes at once: is there a policy of this principal on the chain, and does a principal policy "exist" (check.go:216-225)
+      bool pe = false;
+      for (u32 si = p_first; si != CBH_NONE && !(pend && pe); si = chain_next(t, t.scope_parent[si], FLAG_PRIN)) {
         uint4 v;
-        pend = dir_find(t, CBH_B_PRINCIPAL, r_ver, si, pid, v);   // the resource's version: check.go:294
+        pend = pend || dir_find(t, CBH_B_PRINCIPAL, r_ver, si, pid, v);   // the resource's version: check.go:294
+        pe = pe || dir_find(t, CBH_B_PPEXISTS, p_ver, si, 0, v);
       }
+      p_pol = pe ? (((u32)CBH_P_PRINCIPAL << 28) | p_first) : ((u32)CBH_P_NO_MATCH << 28);
     }
     for (;;) {
       const u64 rem = wave_ballot(pend);
       if (rem == 0) break;
       const u32 lead = first_lane(rem);
-      const u32 g_first = wave_readlane(p_first, lead), g_ver = wave_readlane(r_ver, lead), g_pid = wave_readlane(pid, lead), g_pver = wave_readlane(p_ver, lead);
-      const bool ing = pend && p_first == g_first && r_ver == g_ver && pid == g_pid && p_ver == g_pver;
+      const u32 g_first = wave_readlane(p_first, lead), g_ver = wave_readlane(r_ver, lead), g_pid = wave_readlane(pid, lead);
+      const bool ing = pend && p_first == g_first && r_ver == g_ver && pid == g_pid;
       pend = pend && !ing;
-      bool pe = false;   // roleEffectInfo.Policy: the main policy key if a principal policy exists at all (check.go:216-225)
-      for (u32 si = g_first; si != CBH_NONE && !pe; si = uchain_next(t, uload(&t.scope_parent[si]), FLAG_PRIN)) {
-        uint4 v;
-        pe = udir_find(t, CBH_B_PPEXISTS, g_pver, si, 0, v);
-      }
-      if (ing) p_pol = pe ? (((u32)CBH_P_PRINCIPAL << 28) | g_first) : ((u32)CBH_P_NO_MATCH << 28);
       u32 S = ing ? all : 0u, has_allow = 0;
       for (u32 si = g_first; si != CBH_NONE; si = uchain_next(t, uload(&t.scope_parent[si]), FLAG_PRIN)) {
         if (wave_ballot(S != 0) == 0) break;
@@ -736,7 +743,12 @@ __global__ CBH_W2_ATTRS void cbh_walk2_kernel(const KernelArgs a, const KernelAr
   w2_body<false>(a, c, ly);
 }
 // the pre-pass: one wave to a workgroup, the shared evaluator with its operand stack (cbh_check_wave.h generic_kernel_body)
-__global__ __launch_bounds__(CBH_BLOCK) void cbh_walk2_pre_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+#if defined(CBH_PRE_WPE) && !defined(CBH_HOSTSIM)   /* lab: occupancy target of the pre-pass */
+#define CBH_PRE_WAVES __attribute__((amdgpu_waves_per_eu(CBH_PRE_WPE, CBH_PRE_WPE)))
+#else
+#define CBH_PRE_WAVES
+#endif
+__global__ __launch_bounds__(CBH_BLOCK) CBH_PRE_WAVES void cbh_walk2_pre_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
   __shared__ u64 s_val[CBH_STACK_DEPTH * CBH_BLOCK];
   __shared__ u64 l_val[CBH_MAX_LOCALS * CBH_BLOCK];
   __shared__ u64 it_cont[CBH_MAX_ITERS * CBH_BLOCK];
