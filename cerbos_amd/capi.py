@@ -21,7 +21,7 @@ F_STRICT_EVALUATION = 2
 F_WANT_DERIVED_ROLES = 4
 
 EFFECT_ALLOW, EFFECT_DENY = 1, 2
-ST_OK, ST_CEL_ERROR, ST_UNSUPPORTED = 0, 1, 2
+ST_OK, ST_CEL_ERROR, ST_UNSUPPORTED, ST_WANTS_TRACE = 0, 1, 2, 3
 P_EMPTY, P_NO_MATCH, P_RESOURCE, P_PRINCIPAL, P_TABLE, P_NO_MATCH_SP = range(6)
 NONE = 0xFFFFFFFF
 

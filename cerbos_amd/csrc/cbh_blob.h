@@ -119,6 +119,8 @@ enum CbhMeta {
 #define CBH_MF_NEEDS_ARENA 1024u          /* some program builds a list (filter, map, intersect, except, list +): the kernels that run the
                                           * operand-stack interpreter get CBH_ARENA_ENTRIES values of LDS per lane for them (cbh_vm.h) */
 #define CBH_MF_FLAT_CLOSED 512u           /* FLAT and every condition is evaluated inline by the flat kernel: no evaluator call needed for plain batches */
+#define CBH_MF_TRACE_ALL 4096u            /* the table has variables or output expressions: a kernel that cannot tell which inputs need the trace
+                                          * pass marks every tuple CBH_ST_WANTS_TRACE (cbh_walk2_kernel can tell) */
 #define CBH_MF_WALK2 2048u                /* cbh_check_walk2.h decides this table (batch shape and mode permitting) */
 #define CBH_MF_FLAT 256u                  /* resource policies only, leaf conditions, every record decided by class masks: cbh_check_flat.h */
 #define CBH_MF_READS_REQUEST_STRINGS 64u /* some program reads a raw request string (CBH_RQ_S_*): upload those fields */
@@ -131,7 +133,8 @@ struct CbhHashSlot { // 32 bytes
 enum CbhBucketType {
   CBH_B_RESOURCE = 1,  // (ver sid, kind sid, scope idx) -> v0 row_begin, v1 row_count, v2 dr_begin, v3 dr_count
   CBH_B_PRINCIPAL = 2, // (ver sid, scope idx, principal sid) -> v0 row_begin, v1 row_count
-  CBH_B_ROLEPOL = 3,   // (ver sid, scope idx, role sid) -> v0 rprow_begin, v1 rprow_count, v2 policy id
+  CBH_B_ROLEPOL = 3,   // (ver sid, scope idx, role sid) -> v0 rprow_begin, v1 rprow_count, v2 policy id, v3 U32POOL offset of {probe program
+                       // of the policy's variables, its site slot} or CBH_NONE
   CBH_B_PPEXISTS = 4,  // (ver sid, scope idx, 0) -> exists (any principal policy row)
   CBH_B_RPRES = 5,     // (ver sid, scope idx, 0) -> v0 off, v1 cnt into U32POOL of resource pattern refs of role-policy rows
   CBH_B_PARENTS = 6,   // (scope idx, role sid, 0) -> v0 off, v1 cnt into U32POOL of ancestor role sids; v2, v3 = OR of their role classes
@@ -207,11 +210,15 @@ enum CbhRowPatField {   // CBH_SEC_ROWPAT: the pattern half of record i, 8 dword
  * the LITERAL list entries only; the record's own masks say "every class" for a list with a glob) or evaluation-site slots. */
 #define CBH_ROW_F_X 1024u
 #define CBH_ROW_F_XEXACT 2048u
+#define CBH_ROW_F_OUTPUT 4096u   /* the rule has output expressions: a visit may emit an OutputEntry (check.go:383-411) */
 enum CbhRowXField {
   CBH_ROWX_GSLOTS = 0,   // slot of the condition | slot of the derived-role condition << 16 (CBH_GSLOT_NONE = none)
   CBH_ROWX_GLOBS = 1,    // action glob mask | role glob mask << 16 (bit = glob index in the dimension, < CBH_W2_MAX_GLOBS)
   CBH_ROWX_ROLES = 2,    // u64: classes of the literal roles
   CBH_ROWX_ACTIONS = 4,  // u64: classes of the literal actions
+  CBH_ROWX_PROBES = 6,   // site slot of the probe of the rule's variables | of its derived-role params' variables << 16 (celc.py
+                         // vars_probe_program: did any variable of the params set fail? - evaluated on a visit, check.go:651-677)
+  CBH_ROWX_PROBE_PCS = 7, // U32POOL offset of the two probe programs (CBH_NONE each where there is none), or CBH_NONE
   CBH_ROWX_NF = 8
 };
 #define CBH_SWF_PRINCIPAL 1u    /* the string is a principal with a principal policy (some version / scope) */
@@ -232,7 +239,8 @@ enum CbhRpxField {       // one role-policy rule (same index as CBH_SEC_RPROWS)
   CBH_RPX_GSLOT = 3,
   CBH_RPX_ACTIONS = 4,   // u64: classes of the literal allow actions
   CBH_RPX_AGLOBS = 6,    // glob mask of the allow list (action dim)
-  CBH_RPX_HOW = 7,       // 1: dwords 8..15 = the condition's fused-leaf record, 2: a tree descriptor (CBH_ROW_F_TREE_EMBEDDED)
+  CBH_RPX_HOW = 7,       // bits 0-1: 1 = dwords 8..15 hold the condition's fused-leaf record, 2 = a tree descriptor (CBH_ROW_F_TREE_EMBEDDED);
+                         // bit 2: the rule has output expressions
   CBH_RPX_LEAF = 8,
   CBH_RPX_NF = 16
 };
@@ -269,7 +277,9 @@ enum CbhDrxField { // CBH_SEC_DRX: one 16-dword record per CBH_SEC_DR record, sa
   CBH_DRX_FLAGS = 2,   // bit 0: dwords 8..15 hold the condition's fused-leaf record; bit 1: a tree descriptor (CBH_ROW_F_TREE_EMBEDDED)
   CBH_DRX_COND = 3,    // program or CBH_NONE
   CBH_DRX_NAME = 4,    // bit index into the edr mask
-  CBH_DRX_GSLOT = 5,   // evaluation-site slot of the condition (cbh_check_walk2.h), CBH_GSLOT_NONE = none
+  CBH_DRX_GSLOT = 5,   // evaluation-site slot of the condition (cbh_check_walk2.h), CBH_GSLOT_NONE = none; << 16: slot of the probe of
+                       // the definition's variables
+  CBH_DRX_PROBE = 6,   // that probe's program, or CBH_NONE
   CBH_DRX_LEAF = 8,
   CBH_DRX_NF = 16
 };

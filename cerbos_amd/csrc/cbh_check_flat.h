@@ -393,6 +393,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   const u32 pol_none = (u32)(decided ? CBH_P_NO_MATCH : (role_cnt ? CBH_P_RESOURCE : CBH_P_EMPTY)) << 28 | ((!decided && role_cnt) ? first : 0u);
   const u32 pol_hit = ((u32)CBH_P_RESOURCE << 28) | first;
   u32 eff4 = 0, st4 = 0, pol[4], scp[4];
+  const u32 st_ok = (t.flags & CBH_MF_TRACE_ALL) ? CBH_ST_WANTS_TRACE : CBH_ST_OK;   // outputs: this kernel cannot tell which inputs have any (cerbos_hip.h)
 #pragma unroll
   for (u32 k = 0; k < 4; ++k) {
     const u32 ak = (allow >> k) & 0x1111u, dk = (deny >> k) & 0x1111u;
@@ -406,7 +407,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
     // an evaluation the reference would not have made - a role after the one that allowed - does not count
     const u32 seen = ak ? (((ak & (0u - ak)) << 1) - 1u) : 0xFFFFu;
     const u32 ek = (err >> k) & 0x1111u & seen, uk = (unsup >> k) & 0x1111u & seen;
-    st4 |= (u32)(uk ? CBH_ST_UNSUPPORTED : (ek ? CBH_ST_CEL_ERROR : CBH_ST_OK)) << (8 * k);
+    st4 |= (u32)(uk ? CBH_ST_UNSUPPORTED : (ek ? CBH_ST_CEL_ERROR : st_ok)) << (8 * k);
   }
 
   // ---- effective derived roles (check.go:237-282): the definitions of a scope's policy are evaluated when a role
@@ -456,7 +457,10 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
       const u32 up = uchain_next(t, uload(&t.scope_parent[g_si]), FLAG_RES);
       if (ing) { cur2 = up; ++d2; }
     }
-    if (derr) st4 |= 0x01010101u & ~((st4 >> 1) & 0x01010101u);   // evaluation errors are a per-request fact: every action that is not UNSUPPORTED
+    if (derr) {   // evaluation errors are a per-request fact: every action that is not UNSUPPORTED
+      const u32 un = (st4 >> 1) & ~st4 & 0x01010101u;   // bytes that read 2
+      st4 = (un << 1) | (~un & 0x01010101u);
+    }
     if (dr_unsup) st4 = 0x02020202u;
   }
 

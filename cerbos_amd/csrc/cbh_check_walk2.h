@@ -289,11 +289,21 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   auto kind_bits = [&]() -> u64 { return gbits_of(t, b, DIM_KIND, kind); };
 
   u32 err = 0, unsup = 0;   // walk bits whose evaluation met a CEL error / left the device subset
+  u32 wtr = 0;              // walk bits that visited a rule with output expressions, or whose variables the device could not evaluate:
+                            // the trace pass has (or may have) something to say about the input (CBH_ST_WANTS_TRACE)
+  const LeafRec no_leaf{};
+  // the probe of a params set's variables (celc.py vars_probe_program; slot CBH_GSLOT_NONE = the set has none): bit 1 = one of
+  // them failed - an evaluation error whether or not anything reads it (check.go:651-677) -, bit 3 = the device cannot tell
+  auto probe = [&](u32 slot, u32 pc_off, u32 which, bool active) -> u32 {
+    if (slot == CBH_GSLOT_NONE) return 0u;   // uniform
+    const u32 pc = (PRE && pc_off != CBH_NONE) ? uload(&t.pool[pc_off + which]) : 0u;
+    return leafish(pc, 0u, no_leaf, slot, active);
+  };
   W2_DBG(const u64 cyc1 = __builtin_readcyclecounter();)   // request fields, ids, classes, role sets are there
 
   // ---- principal policies (check.go:195: the first pass; one role iteration, check.go:208-213).  Lanes with a policy of
   // their principal somewhere on the chain are walked group by group; what it decides is kept per action.
-  u32 p_allow = 0, p_deny = 0, p_err = 0, p_unsup = 0, p_pol = 0;
+  u32 p_allow = 0, p_deny = 0, p_err = 0, p_unsup = 0, p_wtr = 0, p_pol = 0;
   u32 p_first = CBH_NONE;
   if (has_pp && (!PRE || (t.q_sites & (CBH_BS_DR_GENERIC | CBH_BS_DR_OPEN)) != 0)) {   // (pre-pass: only when principal policies hold sites at all)
     p_first = chain_first(t, p_scope, FLAG_PRIN, lenient);
@@ -347,10 +357,16 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
             }
             if (wave_ballot(mrow != 0) == 0) continue;
             u32 hit = mrow;
+            u32 gslot = CBH_GSLOT_NONE;
+            if (rw.flags & CBH_ROW_F_OUTPUT) p_wtr |= mrow;
+            if (rw.flags & CBH_ROW_F_X) {
+              const TblRowX rx = uload_rec<TblRowX>(t.rowx, row);
+              gslot = rx.gslots & 0xFFFFu;
+              const u32 pv = probe(rx.p0 & 0xFFFFu, rx.p1, 0u, mrow != 0);
+              p_err |= (pv & 2u) ? mrow : 0u; p_wtr |= (pv & 8u) ? mrow : 0u;
+            }
             if (rw.cond != CBH_NONE) {
               const u32 how = (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_TREE_EMBEDDED) ? 2u : 0u;
-              u32 gslot = CBH_GSLOT_NONE;
-              if (rw.flags & CBH_ROW_F_X) gslot = uload_rec<TblRowX>(t.rowx, row).gslots & 0xFFFFu;
               const u32 lv = leafish(rw.cond, how, rf.leaf, gslot, hit != 0);
               p_err |= (lv & 2u) ? hit : 0u; p_unsup |= (lv & 8u) ? hit : 0u;
               hit = (lv & 1u) ? hit : 0u;
@@ -389,7 +405,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   bool exists = false;
   const bool pre_edr = PRE && (t.flags & CBH_MF_USES_RUNTIME_EDR) != 0;
   const bool want_edr = !PRE && (flags & CBH_F_WANT_DERIVED_ROLES) != 0 && t.n_dr != 0;
-  u64 edr_all = 0; bool derr_all = false, dunsup_all = false;   // derived roles over the chain positions visited with a walk still going
+  u64 edr_all = 0; bool derr_all = false, dunsup_all = false, dwtr_all = false;   // derived roles over the chain positions visited with a walk still going
   u32 edr_vis = 0;                                              // ... how many those were
   for (;;) {
     const bool active = cur != CBH_NONE && (PRE ? pre_climbs : (S != 0 || !exists));
@@ -432,6 +448,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
           const TblDrx dx = uload_rec<TblDrx>(t.drx, d);
           const bool applies = ing && (((dx.rm_lo & lane_rs_lo) | (dx.rm_hi & lane_rs_hi)) != 0);
           if (wave_ballot(applies) == 0) continue;
+          if ((dx.p0 >> 16) != CBH_GSLOT_NONE) (void)leafish(dx.p1, 0u, no_leaf, dx.p0 >> 16, applies);   // the definition's variables
           u32 lv = 1u;
           if (dx.cond != CBH_NONE) lv = leafish(dx.cond, dx.flags & 3u, dx.leaf, dx.p0 & 0xFFFFu, applies);
           if (applies && (lv & 1u)) m |= 1ull << dx.name;
@@ -441,18 +458,22 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
       if (want_edr) {
         // effective derived roles (check.go:237-282): the definitions of this scope's policy, for the requests a walk is
         // still going for; which of the chain positions count - the ones a LEGITIMATE walk reached - is known at the fold
-        u64 m = 0; bool de = false, du = false;
+        u64 m = 0; bool de = false, du = false, dw = false;
         if (have_bucket) {
           for (u32 d = bucket.z; d < bucket.z + bucket.w; ++d) {
             const TblDrx dx = uload_rec<TblDrx>(t.drx, d);
             const bool applies = ing && S != 0 && (((dx.rm_lo & lane_rs_lo) | (dx.rm_hi & lane_rs_hi)) != 0);   // parent roles x the request's roles (check.go:244)
             if (wave_ballot(applies) == 0) continue;
             u32 lv = 1u;
+            if ((dx.p0 >> 16) != CBH_GSLOT_NONE) {   // the definition's variables (evaluateVariables, check.go:612-633)
+              const u32 pv = leafish(dx.p1, 0u, no_leaf, dx.p0 >> 16, applies);
+              if (applies) { de = de || (pv & 2u) != 0; dw = dw || (pv & 8u) != 0; }
+            }
             if (dx.cond != CBH_NONE) lv = leafish(dx.cond, dx.flags & 3u, dx.leaf, dx.p0 & 0xFFFFu, applies);
             if (applies) { if (lv & 1u) m |= 1ull << dx.name; de = de || (lv & 2u) != 0; du = du || (lv & 8u) != 0; }
           }
         }
-        if (ing && S != 0) { edr_all |= m; derr_all = derr_all || de; dunsup_all = dunsup_all || du; edr_vis = mydepth + 1u; }
+        if (ing && S != 0) { edr_all |= m; derr_all = derr_all || de; dunsup_all = dunsup_all || du; dwtr_all = dwtr_all || dw; edr_vis = mydepth + 1u; }
       }
       if (rolepol_here) {
         // ---- synthetic DENYs of the role policies at this scope (index.go:352-530)
@@ -500,14 +521,21 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
           u32 dn = Wg & ~(any_mask * 0x01010101u);   // no rule for the resource, or no allow action matched (index.go:436-461)
           for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
             const TblRpx rr = uload_rec<TblRpx>(t.rpx, row);
-            if (rr.cond == CBH_NONE || !pat_match(rr.resource, g_k, g_kb)) continue;
+            // (the reference visits a matched rule only if it has a condition - as the synthetic DENY row - or outputs)
+            if ((rr.cond == CBH_NONE && !(rr.how & 4u)) || !pat_match(rr.resource, g_k, g_kb)) continue;
             const u32 ma = match_actions(rr.am_lo, rr.am_hi, rr.ag);
             const u32 mm = (ma * 0x01010101u) & Wg & ~dn;
             if (wave_ballot(mm != 0) == 0) continue;
+            if (rr.how & 4u) wtr |= mm;
+            if (rp.w != CBH_NONE) {   // the policy's variables
+              const u32 pv = leafish(PRE ? uload(&t.pool[rp.w]) : 0u, 0u, no_leaf, uload(&t.pool[rp.w + 1u]) & 0xFFFFu, mm != 0);
+              err |= (pv & 2u) ? mm : 0u; wtr |= (pv & 8u) ? mm : 0u;
+            }
+            if (rr.cond == CBH_NONE) continue;
             // an action at or behind the first one an output-only rule of the same key is visited for finds "satisfied"
             // cached (check.go:324): the synthetic DENY would fire whatever the condition says (cbh_blob.h CBH_RP_F_*)
             if ((rr.cnt & CBH_RP_F_SHARES_KEY) && out_only != 0) unsup |= mm & ~((((out_only & (0u - out_only)) - 1u) & 0xFFu) * 0x01010101u);
-            const u32 lv = leafish(rr.cond, rr.how, rr.leaf, rr.gslot & 0xFFFFu, mm != 0);
+            const u32 lv = leafish(rr.cond, rr.how & 3u, rr.leaf, rr.gslot & 0xFFFFu, mm != 0);
             err |= (lv & 2u) ? mm : 0u; unsup |= (lv & 8u) ? mm : 0u;
             if (!(lv & 1u)) dn |= mm;   // the synthetic row = DENY if none(condition)
           }
@@ -537,12 +565,12 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
           nxt = uload_rec<TblRowFull>(t.rows, row < last ? row + 1u : last);
           const TblRow& rw = rf.hot;
           W2_DBG(++dbg_rows;)
-          u32 rm_lo = rw.rm_lo, rm_hi = rw.rm_hi, am_lo = rw.am_lo, am_hi = rw.am_hi, ag = 0, rg = 0, gslots = 0xFFFFFFFFu;
+          u32 rm_lo = rw.rm_lo, rm_hi = rw.rm_hi, am_lo = rw.am_lo, am_hi = rw.am_hi, ag = 0, rg = 0, gslots = 0xFFFFFFFFu, probes = 0xFFFFFFFFu, probe_pcs = CBH_NONE;
           if (PRE && !(rw.flags & CBH_ROW_F_X)) continue;   // no site on this record
           if (rw.flags & CBH_ROW_F_X) {
             const TblRowX rx = uload_rec<TblRowX>(t.rowx, row);
-            gslots = rx.gslots;
-            if (PRE && (gslots & 0xFFFFu) >= b.n_gslots && (gslots >> 16) >= b.n_gslots) continue;   // none filed for this batch
+            gslots = rx.gslots; probes = rx.p0; probe_pcs = rx.p1;
+            if (PRE && (gslots & 0xFFFFu) >= b.n_gslots && (gslots >> 16) >= b.n_gslots && (probes & 0xFFFFu) >= b.n_gslots && (probes >> 16) >= b.n_gslots) continue;   // none filed for this batch
             if (rx.globs) { ag = rx.globs & 0xFFFFu; rg = rx.globs >> 16; rm_lo = rx.rm_lo; rm_hi = rx.rm_hi; am_lo = rx.am_lo; am_hi = rx.am_hi; }
           }
           // (a list with a glob is never skipped by class: the lanes' glob bits are still on their way from memory)
@@ -553,6 +581,15 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
           const u32 m = ing ? (w2_rep_role(mrole) & (mact * 0x01010101u) & (PRE ? walks : S)) : 0u;
           if (wave_ballot(m != 0) == 0) continue;
           u32 hit = m;
+          if (rw.flags & CBH_ROW_F_OUTPUT) wtr |= m;
+          if (probes != 0xFFFFFFFFu) {   // the variables of the rule's policy are evaluated on every visit (check.go:306-321)
+            const u32 pv = probe(probes & 0xFFFFu, probe_pcs, 0u, m != 0);
+            err |= (pv & 2u) ? m : 0u; wtr |= (pv & 8u) ? m : 0u;
+            if (rw.drcond != CBH_NONE) {   // ... the derived role's with its condition (check.go:328-334)
+              const u32 pd = probe(probes >> 16, probe_pcs, 1u, m != 0);
+              err |= (pd & 2u) ? m : 0u; wtr |= (pd & 8u) ? m : 0u;
+            }
+          }
           if (rw.drcond != CBH_NONE) {   // the derived-role condition first, the rule's own where that held (check.go:328-380)
             const u32 how = (rw.flags & CBH_ROW_F_DRLEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_DRTREE_EMBEDDED) ? 2u : 0u;
             const LeafRec l2 = uload_rec<LeafRec>(t.rowleaf2, row);
@@ -610,11 +647,12 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
                      : role_cnt == 0 ? ((u32)CBH_P_EMPTY << 28)
                      : exists ? (((u32)CBH_P_RESOURCE << 28) | first) : ((u32)CBH_P_NO_MATCH << 28);
   const u32 pol_hit = ((u32)CBH_P_RESOURCE << 28) | first;
-  if (decided) { p_allow = p_deny = p_err = p_unsup = 0; }
+  if (decided) { p_allow = p_deny = p_err = p_unsup = p_wtr = 0; }
 
   // ---- the fold (check.go:429-442), per action: a principal policy's word, else the first role that allowed, else the
   // first role that denied
   u32 eff[2] = {0, 0}, st[2] = {0, 0}, pol[NA], scp[NA];
+  u32 a_un = 0, a_er = 0, a_wt = 0;   // per action: outside the device subset / an evaluation error / something for the trace pass
 #pragma unroll
   for (u32 k = 0; k < NA; ++k) {
     const u32 ak = (allow >> k) & 0x01010101u, dk = (deny >> k) & 0x01010101u;
@@ -632,9 +670,10 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     eff[k >> 2] |= (u32)(al ? CBH_EFFECT_ALLOW : CBH_EFFECT_DENY) << (8 * (k & 3u));   // NO_MATCH -> DENY (check.go:451-453)
     // an evaluation the reference would not have made - a role after the one that allowed - does not count
     const u32 seen = ak ? (((ak & (0u - ak)) << 1) - 1u) : 0x01010101u * 0xFFu;
-    const u32 ek = (err >> k) & 0x01010101u & seen, uk = (unsup >> k) & 0x01010101u & seen;
-    const bool e1 = ek != 0 || ((p_err >> k) & 1u), u1 = uk != 0 || ((p_unsup >> k) & 1u);
-    st[k >> 2] |= (u32)(u1 ? CBH_ST_UNSUPPORTED : (e1 ? CBH_ST_CEL_ERROR : CBH_ST_OK)) << (8 * (k & 3u));
+    const u32 ek = (err >> k) & 0x01010101u & seen, uk = (unsup >> k) & 0x01010101u & seen, wk = (wtr >> k) & 0x01010101u & seen;
+    a_er |= (u32)(ek != 0 || ((p_err >> k) & 1u)) << k;
+    a_un |= (u32)(uk != 0 || ((p_unsup >> k) & 1u)) << k;
+    a_wt |= (u32)(wk != 0 || ((p_wtr >> k) & 1u)) << k;
   }
 
   // ---- effective derived roles (check.go:237-282): the definitions of a scope's policy are evaluated when a role walk
@@ -665,10 +704,10 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     // exactly the legitimate reach unless the last walks going were all of roles behind an allowing one - rare; those
     // requests (only) climb once more, for the definitions alone.
     edr = edr_all;
-    bool derr = derr_all, dr_unsup = dunsup_all;
+    bool derr = derr_all, dr_unsup = dunsup_all, dwtr = dwtr_all;
     const bool again = reach < edr_vis;
     if (wave_ballot(again) != 0) {
-      if (again) { edr = 0; derr = false; dr_unsup = false; }
+      if (again) { edr = 0; derr = false; dr_unsup = false; dwtr = false; }
       u32 cur2 = first, d2 = 0;
       for (;;) {
         const bool active = again && cur2 != CBH_NONE && d2 < reach;
@@ -684,6 +723,10 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
             const bool applies = ing && (((dx.rm_lo & lane_rs_lo) | (dx.rm_hi & lane_rs_hi)) != 0);
             if (wave_ballot(applies) == 0) continue;
             u32 lv = 1u;
+            if ((dx.p0 >> 16) != CBH_GSLOT_NONE) {
+              const u32 pv = leafish(dx.p1, 0u, no_leaf, dx.p0 >> 16, applies);
+              if (applies) { derr = derr || (pv & 2u) != 0; dwtr = dwtr || (pv & 8u) != 0; }
+            }
             if (dx.cond != CBH_NONE) lv = leafish(dx.cond, dx.flags & 3u, dx.leaf, dx.p0 & 0xFFFFu, applies);
             if (applies) { if (lv & 1u) edr |= 1ull << dx.name; derr = derr || (lv & 2u) != 0; dr_unsup = dr_unsup || (lv & 8u) != 0; }
           }
@@ -692,9 +735,14 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
         if (ing) { cur2 = up; ++d2; }
       }
     }
-    if (derr) { st[0] |= 0x01010101u & ~((st[0] >> 1) & 0x01010101u); st[1] |= 0x01010101u & ~((st[1] >> 1) & 0x01010101u); }   // evaluation errors are a per-request fact
-    if (dr_unsup) { st[0] = 0x02020202u; st[1] = 0x02020202u; }
+    // evaluation errors are a per-request fact: every action of the request
+    if (derr) a_er = 0xFFu;
+    if (dr_unsup) a_un = 0xFFu;
+    if (dwtr) a_wt = 0xFFu;
   }
+#pragma unroll
+  for (u32 k = 0; k < NA; ++k)
+    st[k >> 2] |= (u32)(((a_un >> k) & 1u) ? CBH_ST_UNSUPPORTED : ((a_er >> k) & 1u) ? CBH_ST_CEL_ERROR : ((a_wt >> k) & 1u) ? CBH_ST_WANTS_TRACE : CBH_ST_OK) << (8 * (k & 3u));
 
 #ifdef CBH_PROFILE_CYCLES
   if (flags & CBH_F_DEBUG_CYCLES) {

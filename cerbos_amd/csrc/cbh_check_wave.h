@@ -1050,6 +1050,8 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   // A request with exactly four actions on a 4-tuple boundary (the usual batch shape) writes each
   // output array with ONE full-width store per lane: whole cache lines per wave instead of byte
   // stores scattered four bytes apart.
+  // a table with variables or outputs: this walk cannot tell which inputs the trace pass has something for (cerbos_hip.h)
+  const u32 st_ok = (!TRACE && (t.flags & CBH_MF_TRACE_ALL)) ? CBH_ST_WANTS_TRACE : CBH_ST_OK;
   const bool packed = valid && act_cnt == 4 && (act_off & 3u) == 0;
   if (packed) {
     struct __attribute__((aligned(16))) u32x4 { u32 x, y, z, w; };
@@ -1058,7 +1060,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
     for (u32 k = 0; k < 4; ++k) {
       const AM bit = (AM)1 << k;
       e4 |= (u32)((eff_allow & bit) ? CBH_EFFECT_ALLOW : CBH_EFFECT_DENY) << (8 * k);
-      s4 |= (u32)((st_unsup & bit) ? CBH_ST_UNSUPPORTED : ((st_err & bit) ? CBH_ST_CEL_ERROR : CBH_ST_OK)) << (8 * k);
+      s4 |= (u32)((st_unsup & bit) ? CBH_ST_UNSUPPORTED : ((st_err & bit) ? CBH_ST_CEL_ERROR : st_ok)) << (8 * k);
     }
     if (o.edr) o.edr[req] = edr_acc;
     *(CBH_G u32*)(o.effect + act_off) = e4;
@@ -1079,7 +1081,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
     for (u32 k = 0; k < act_cnt; ++k) {
       const AM bit = (AM)1 << k;
       o.effect[act_off + k] = (u8)((eff_allow & bit) ? CBH_EFFECT_ALLOW : CBH_EFFECT_DENY);   // NO_MATCH -> DENY (check.go:451-453)
-      if (o.status) o.status[act_off + k] = (u8)((st_unsup & bit) ? CBH_ST_UNSUPPORTED : ((st_err & bit) ? CBH_ST_CEL_ERROR : CBH_ST_OK));
+      if (o.status) o.status[act_off + k] = (u8)((st_unsup & bit) ? CBH_ST_UNSUPPORTED : ((st_err & bit) ? CBH_ST_CEL_ERROR : st_ok));
     }
   }
 #undef DRM

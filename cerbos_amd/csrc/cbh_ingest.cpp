@@ -1149,7 +1149,7 @@ int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result*
             dup = true; break;
           }
           if (!dup) acts.push_back(Act{name, j});
-          if (res->status) { u8 st = res->status[j]; if (st == CBH_ST_UNSUPPORTED) o_flags(i - lo) |= CBI_OUT_UNSUPPORTED; else if (st == CBH_ST_CEL_ERROR) o_flags(i - lo) |= CBI_OUT_CEL_ERROR; }
+          if (res->status) { u8 st = res->status[j]; if (st == CBH_ST_UNSUPPORTED) o_flags(i - lo) |= CBI_OUT_UNSUPPORTED; else if (st == CBH_ST_CEL_ERROR) o_flags(i - lo) |= CBI_OUT_CEL_ERROR; else if (st == CBH_ST_WANTS_TRACE) o_flags(i - lo) |= CBI_OUT_WANTS_TRACE; }
         }
         if (!ok) return bail("batch does not belong to these inputs");
       } else {
@@ -1164,7 +1164,7 @@ int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result*
             dup = true; break;
           }
           if (!dup) acts.push_back(Act{name, j});
-          if (res->status) { u8 st = res->status[j]; if (st == CBH_ST_UNSUPPORTED) o->flags[i - lo] |= CBI_OUT_UNSUPPORTED; else if (st == CBH_ST_CEL_ERROR) o->flags[i - lo] |= CBI_OUT_CEL_ERROR; }
+          if (res->status) { u8 st = res->status[j]; if (st == CBH_ST_UNSUPPORTED) o->flags[i - lo] |= CBI_OUT_UNSUPPORTED; else if (st == CBH_ST_CEL_ERROR) o->flags[i - lo] |= CBI_OUT_CEL_ERROR; else if (st == CBH_ST_WANTS_TRACE) o->flags[i - lo] |= CBI_OUT_WANTS_TRACE; }
         } }
       { Span s = principal; while (next(s, f, bad)) { if (f.wt != 2) continue; if (f.num == 1) P.id = sv(f.s); else if (f.num == 2) P.version = sv(f.s); } }
       { Span s = resource; while (next(s, f, bad)) { if (f.wt != 2) continue; if (f.num == 1) Rs.kind = sv(f.s); else if (f.num == 2) Rs.version = sv(f.s); else if (f.num == 3) Rs.id = sv(f.s); } }
@@ -1313,7 +1313,7 @@ int cbi_assemble_response_traced_pb(const cbi_table* t, const cbi_batch* b, cons
         std::string_view name = sv(f.s); const u32 j = inv[k++]; bool dup = false;
         for (Act& a : acts) if (a.name == name) { if (res->effect[j] == CBH_EFFECT_DENY || res->effect[a.j] != CBH_EFFECT_DENY) a.j = j; dup = true; break; }
         if (!dup) acts.push_back(Act{name, j});
-        if (res->status) { const u8 st = res->status[j]; if (st == CBH_ST_UNSUPPORTED) o->flags[i] |= CBI_OUT_UNSUPPORTED; else if (st == CBH_ST_CEL_ERROR) o->flags[i] |= CBI_OUT_CEL_ERROR; }
+        if (res->status) { const u8 st = res->status[j]; if (st == CBH_ST_UNSUPPORTED) o->flags[i] |= CBI_OUT_UNSUPPORTED; else if (st == CBH_ST_CEL_ERROR) o->flags[i] |= CBI_OUT_CEL_ERROR; else if (st == CBH_ST_WANTS_TRACE) o->flags[i] |= CBI_OUT_WANTS_TRACE; }
       } }
     Party Rs;
     { Span s = resource; while (next(s, f, bad)) { if (f.wt != 2) continue;

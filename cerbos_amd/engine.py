@@ -18,6 +18,8 @@ from __future__ import annotations
 import threading
 import time
 
+import numpy as np
+
 from . import capi, namer
 from .flatten import Flattener
 from .lower.blob import LoweredTable, lower_rule_table
@@ -132,16 +134,17 @@ class HipEvaluator:
         for o in outs:
             o["evaluationErrors"] = []
             o["outputs"] = []
-        if lt.trace_has_variables or lt.trace_has_outputs:
-            sel = [i for i in range(len(inputs)) if i not in set(bad)]
-        else:
-            sel, t = [], 0
-            skip = set(bad)
-            for i in range(len(inputs)):
-                n = len(batch.actions_per_request[i])
-                if i not in skip and (res.status[t:t + n] == capi.ST_CEL_ERROR).any():
-                    sel.append(i)
-                t += n
+        # the inputs with a tuple marked CBH_ST_CEL_ERROR or CBH_ST_WANTS_TRACE (cerbos_hip.h): the walk marks what the trace
+        # pass has something for - an absorbed error, a visited rule with outputs, a variable it could not evaluate; a kernel
+        # that cannot tell marks every tuple of a table with variables or outputs
+        sel, t = [], 0
+        skip = set(bad)
+        for i in range(len(inputs)):
+            n = len(batch.actions_per_request[i])
+            if i not in skip and np.isin(res.status[t:t + n], (capi.ST_CEL_ERROR, capi.ST_WANTS_TRACE)).any():
+                sel.append(i)
+            t += n
+        self.last_traced = len(sel)
         if not sel:
             return {}
         sub = [inputs[i] for i in sel]
@@ -198,10 +201,7 @@ class HipEvaluator:
         from .ingest import trace_pb
         oflags = np.array(oflags, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
-        if self._ingest.trace_scope() == 2:
-            sel = [i for i in range(len(outs)) if not oflags[i] & 1]
-        else:
-            sel = [i for i in range(len(outs)) if (oflags[i] & 3) == 2]
+        sel = [i for i in range(len(outs)) if not (oflags[i] & 1) and (oflags[i] & (2 | 16))]   # CBI_OUT_CEL_ERROR | CBI_OUT_WANTS_TRACE
         if not sel:
             return outs, oflags
         data = np.ascontiguousarray(data, dtype=np.uint8)
@@ -214,7 +214,7 @@ class HipEvaluator:
         extra, tflags = trace_pb(self._ingest, sbatch, tres, records, sdata, soff)
         for j, i in enumerate(sel):
             outs[i] = outs[i] + extra[j]
-            oflags[i] |= tflags[j] & 12
+            oflags[i] = (int(oflags[i]) & 0xEF) | (int(tflags[j]) & 12)   # traced: CBI_OUT_WANTS_TRACE is answered
         return outs, oflags
 
     def check_request_pb(self, request: bytes, aux_data: bytes = None, now_ns=None, lenient_scope_search=None,
@@ -238,7 +238,10 @@ class HipEvaluator:
             # a table with output expressions: the entries go through the tracing kernel too (the same batch) and their
             # outputs into ResultEntry.outputs (cerbos_svc.go:325-327).  (The response carries no evaluation errors.)
             traced = self.table.trace(batch, now_ns=now_ns, flags=flags)
-        return self._ingest.assemble_response_pb(batch, res, request, dver, traced=traced, aux_data=aux_data)
+        raw, oflags = self._ingest.assemble_response_pb(batch, res, request, dver, traced=traced, aux_data=aux_data)
+        if traced is not None:
+            oflags = oflags & 0xEF   # traced: CBI_OUT_WANTS_TRACE is answered
+        return raw, oflags
 
     def _ingest_table(self):
         if self._ingest is None:

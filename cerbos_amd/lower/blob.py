@@ -44,7 +44,8 @@ MF_FLAT_CLOSED = 512
 # cbh_check_walk2.h: the decision kernel for everything else a table can hold (principal policies, role policies, parent
 # roles, glob patterns, generic programs).  Per record: CBH_SEC_ROWX; per role-policy rule: CBH_SEC_RPX.
 MF_WALK2 = 2048
-ROW_F_X, ROW_F_XEXACT = 1024, 2048
+ROW_F_X, ROW_F_XEXACT, ROW_F_OUTPUT = 1024, 2048, 4096
+MF_TRACE_ALL = 4096    # the older kernels cannot tell which inputs of this table need the trace pass: they mark every one
 SEC_ROWX, SEC_RPX, SEC_STR_WFLAGS = 40, 41, 42
 B_RPROLES, B_FAMILY = 8, 9
 SWF_PRINCIPAL, SWF_PARENTS = 1, 2     # CBH_SEC_STR_WFLAGS bits
@@ -268,6 +269,9 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
     rp_family = []         # per role-policy record: its version
     rp_allow = []          # per role-policy record: its allow-action strings
     dr_family = []         # per derived-role record: ("R", version, kind)
+    row_probe = []         # per device row: (probe of its params' variables, of its derived-role params' variables) - program or None
+    dr_probe = []          # per derived-role record: probe of the definition's variables
+    rp_bucket_probe = {}   # directory entry index of a role-policy bucket -> probe of the policy's variables
 
     def row_programs(r, principal_policy):
         params = Params(r["params"]["constants"], r["params"]["ordered_variables"], globals_) if r["params"] else Params(None, None, globals_)
@@ -347,6 +351,15 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
                     trace_row_rules.append((grp[0], principal_policy))
                     row_family.append(family)
                     row_scope.append(scope)
+                    r0 = grp[0]
+                    pa = pb.vars_probe_program(Params(r0["params"]["constants"], r0["params"]["ordered_variables"], globals_)) if r0["params"] else None
+                    pd = None
+                    if r0["derived_role_condition"] is not None and r0["derived_role_params"]:
+                        dp0 = r0["derived_role_params"]
+                        pd = pb.vars_probe_program(Params(dp0["constants"], dp0["ordered_variables"], globals_))
+                    row_probe.append((pa, pd))
+                    if r0["emit_output"]:
+                        row_cols[ROW_FLAGS][-1] |= ROW_F_OUTPUT
                     n += 1
         return n
 
@@ -370,6 +383,7 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
                 pool.extend(sid(p) for p in dr["parent_roles"])
             trace_dr_defs.append(dr)
             dr_family.append(("R", ver, kind))
+            dr_probe.append(pb.vars_probe_program(Params(dr["constants"], dr["ordered_variables"], globals_, null_on_error=True)))
             dparams = Params(dr["constants"], dr["ordered_variables"], globals_, null_on_error=True)
             # a derived-role definition that reads runtime.effectiveDerivedRoles sees, in the reference, the
             # roles of whichever scope/action was processed last (check.go:262,281): not reproducible per tuple
@@ -414,7 +428,11 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
             else:
                 rp_cols[3].append(pb.condition_program(r["condition"], params) if r["condition"] is not None else NONE)
         pid = policy_id(namer.role_policy_fqn(role, ver, scope))
-        entries.append((B_ROLEPOL, sid(ver), lt.scope_index[scope], sid(role), begin, len(rows), pid, 0))
+        r0 = rows[0]
+        rpp = pb.vars_probe_program(Params(r0["params"]["constants"], r0["params"]["ordered_variables"], globals_)) if r0["params"] else None
+        if rpp is not None:
+            rp_bucket_probe[len(entries)] = (rpp, ver, scope)
+        entries.append((B_ROLEPOL, sid(ver), lt.scope_index[scope], sid(role), begin, len(rows), pid, NONE))
     for (ver, scope), pats in sorted(rp_res.items()):
         uniq = list(dict.fromkeys(pats))
         entries.append((B_RPRES, sid(ver), lt.scope_index[scope], 0, len(pool), len(uniq), 0, 0))
@@ -675,6 +693,8 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
             rec, fl = [int(w) & 0xFFFFFFFF for w in pb.code[pc:pc + 8]], 1
         elif cond != NONE and (cond & COND_LEAFTREE) and (cond & COND_PC_MASK) in pb.tree_strips:
             rec, fl = _tree_descriptor(pb.tree_strips[cond & COND_PC_MASK]), 2
+        if trace_rp_rules[i].get("emit_output"):
+            fl |= 4     # CBH_RPX_HOW bit 2: the rule has output expressions
         rpx[i, :8] = [rp_cols[0][i], rp_cols[2][i], cond, GSLOT_NONE, al & 0xFFFFFFFF, al >> 32, ag, fl]
         rpx[i, 8:] = rec
     drx_gslot = [GSLOT_NONE] * len(drx_cols[0])
@@ -711,9 +731,29 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
         if k:
             sites.append(("R", dr_family[i], (drx_cols[3][i], "dr"), k, ("dr", i, 0)))
     for i in range(n_rp_total):
-        k = site_kind(int(rpx[i, 2]), int(rpx[i, 15]), int(rpx[i, 7]))
+        k = site_kind(int(rpx[i, 2]), int(rpx[i, 15]), int(rpx[i, 7]) & 3)
         if k:
             sites.append(("Q", ("Q", rp_family[i]), (int(rpx[i, 2]), rp_scope[i] if per_scope else None), k, ("rp", i, 0)))
+    # the probes of the params sets' variables (celc.py vars_probe_program): generic sites of their own
+    rowx[:, 6] = GSLOT_NONE | (GSLOT_NONE << 16)
+    rowx[:, 7] = NONE
+    for i, (pa, pd) in enumerate(row_probe):
+        fam = row_family[i]
+        if pa is not None:
+            sites.append((fam[0], fam, (pa, row_scope[i] if per_scope else None), "generic", ("rowp", i, 0)))
+        if pd is not None:
+            sites.append((fam[0], fam, (pd, row_scope[i] if per_scope else None), "generic", ("rowp", i, 16)))
+        if pa is not None or pd is not None:
+            rowx[i, 7] = len(pool)
+            pool.extend([pa if pa is not None else NONE, pd if pd is not None else NONE])
+            row_cols[ROW_FLAGS][i] |= ROW_F_X
+    for i, pr in enumerate(dr_probe):
+        drx_cols[6][i] = pr if pr is not None else NONE
+        if pr is not None:
+            sites.append(("R", dr_family[i], (pr, "dr"), "generic", ("drp", i, 0)))
+    for ei, (pr, ver, scope) in rp_bucket_probe.items():
+        sites.append(("Q", ("Q", ver), (pr, scope if per_scope else None), "generic", ("rpp", ei, 0)))
+    drx_pslot = [GSLOT_NONE] * len(drx_cols[0])
     slot_of, next_free, spans = {}, {}, {}
     for kind in ("generic", "open"):
         base = sum(spans.values())
@@ -741,12 +781,20 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
             if what == "row":
                 rowx[i, 0] = (int(rowx[i, 0]) & ~(0xFFFF << shift)) | (g << shift)
                 row_cols[ROW_FLAGS][i] |= ROW_F_X
+            elif what == "rowp":
+                rowx[i, 6] = (int(rowx[i, 6]) & ~(0xFFFF << shift)) | (g << shift)
             elif what == "dr":
                 drx_gslot[i] = g
+            elif what == "drp":
+                drx_pslot[i] = g
+            elif what == "rpp":
+                e = entries[i]
+                entries[i] = e[:7] + (len(pool),)
+                pool.extend([rp_bucket_probe[i][0], g])
             else:
                 rpx[i, 3] = g
     for i, g in enumerate(drx_gslot):
-        drx_cols[5][i] = g
+        drx_cols[5][i] = g | (drx_pslot[i] << 16)
 
     # the roles with role policies at (version, scope), sorted by name: index.go:352-530 walks a request role's
     # [role] ++ ancestors list, and the ancestors come sorted (ruletable/build.py; the reference's own order is Go's map
@@ -784,6 +832,7 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
             for i in range(e[6], e[6] + e[7]):
                 dr_key[i] = e[1:4]
     for (_r, _fam, _prog, k, (what, i, _shift)) in sites:
+        what = {"rowp": "row", "drp": "dr"}.get(what, what)
         key = row_key.get(i) if what == "row" else dr_key.get(i) if what == "dr" else None
         if key is not None:
             bucket_sites[key] = bucket_sites.get(key, 0) | site_bit[(what, k)]
@@ -887,6 +936,8 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
     for d in (DIM_ACTION, DIM_ROLE):
         if len(dims[d].globs) > WALK2_MAX_GLOBS:
             walk2_why.append("more than %d glob patterns in a dimension" % WALK2_MAX_GLOBS)
+    if lt.trace_has_variables or lt.trace_has_outputs:
+        meta[M_FLAGS] |= MF_TRACE_ALL
     lt.walk2_refused = list(dict.fromkeys(walk2_why))
     meta[M_FLAGS] |= MF_WALK2 if not lt.walk2_refused else 0
     lt.inline_cols = sorted(pb.inline_cols)

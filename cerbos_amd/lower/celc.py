@@ -453,6 +453,39 @@ class ProgramBuilder:
         return pc
 
 
+    def vars_probe_program(self, params: Params):
+        """Did any variable of the params set fail?  The reference evaluates EVERY variable of a rule's policy when the rule
+        is visited, read or not (evaluatePrograms, check.go:651-677), and a failure lands in evaluation_errors: the walk asks
+        this program (an evaluation site of its own, cbh_check_walk2.h) so that only the inputs it marks need the trace
+        pass.  Each definition is evaluated and dropped; OP_LEAF leaves the error status behind.  None = no variables."""
+        if not params.ordered_variables:
+            return None
+        key = ("vars-probe", params.key())
+        pc = self.programs.get(key)
+        if pc is not None:
+            return pc
+        fc = _FuncCompiler(self, params, True)
+        for _name, text in params.ordered_variables:
+            fc.cur_text = text
+            d0 = fc.depth
+            fc.expr(params.inline(celparser.parse(text)))
+            assert fc.depth == d0 + 1
+            fc.emit(OP_LEAF)
+            fc.emit(OP_POP, 0, -1)
+        fc.emit(OP_CONST, self.const(T_BOOL, 1), +1)
+        fc.emit(OP_RET)
+        pc = len(self.code)
+        self.code.extend(fc.finish(pc))
+        if pc >= COND_PC_MASK:
+            raise LoweringError("bytecode tape exceeds 2^30 words")
+        self.has_generic = True
+        self.programs[key] = pc
+        self.max_stack = max(self.max_stack, fc.max_depth)
+        self.max_locals = max(self.max_locals, fc.max_locals)
+        if fc.max_depth > MAX_STACK:
+            raise LoweringError("variable needs operand stack depth %d (device limit %d)" % (fc.max_depth, MAX_STACK))
+        return pc
+
     # ---- trace programs (cbh_blob.h CBH_SEC_TRACE_*): what the trace pass runs instead of the decision programs.  Same
     # expressions, nothing fused: every leaf ends in OP_LEAF <text id + 1>, which logs a failure under the expression's
     # text; variables keep their OP_VARSCOPE.  They never change what the decision kernels are chosen by or upload

@@ -158,6 +158,11 @@ enum cbh_policy_kind {
 #define CBH_ST_CEL_ERROR 1u   /* a CEL runtime error was absorbed (evaluation_errors non-empty) */
 #define CBH_ST_UNSUPPORTED 2u /* hit an operation outside the device subset: result invalid;  */
                               /* the caller must evaluate this input with its own engine     */
+#define CBH_ST_WANTS_TRACE 3u /* the decision stands and no CEL error was seen on the decision path, but what else the    */
+                              /* reference reports for this input - outputs of a visited rule, the error of a variable    */
+                              /* nothing reads - only cbh_trace_batch can tell.  Rule for callers: trace the inputs with a */
+                              /* tuple marked CBH_ST_CEL_ERROR or CBH_ST_WANTS_TRACE.  (Kernels that cannot tell mark every */
+                              /* tuple of a table with variables or outputs.)                                              */
 
 typedef struct cbh_result {
   uint8_t* effect;    /* [n_tuples] CBH_EFFECT_*            (required) */

@@ -86,6 +86,7 @@ const uint32_t* cbi_batch_request_input(const cbi_batch* b);
 typedef struct cbi_outputs cbi_outputs;
 #define CBI_OUT_UNSUPPORTED 1u /* device hit an operation outside its subset: output invalid, caller's engine must run this input */
 #define CBI_OUT_CEL_ERROR 2u   /* a CEL runtime error was absorbed on the decision path of at least one action */
+#define CBI_OUT_WANTS_TRACE 16u /* an action is marked CBH_ST_WANTS_TRACE: the trace pass has (or may have) outputs / errors for this input */
 
 int cbi_assemble_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* bytes,
                     const uint64_t* offsets, uint32_t n, const char* default_version, cbi_outputs** out);
@@ -105,9 +106,11 @@ int cbi_assemble_response_pb(const cbi_table* t, const cbi_batch* b, const cbh_r
  * (protobuf concatenation is a merge).  Errors come sorted and deduplicated (cel_errors.go:98-118), outputs in the order
  * check.go's loops reach them.  cbi_outputs_flags: CBI_TRACE_* where the device could not name everything - the decision
  * stands, errors / outputs of that input are the caller's engine's to supply. */
-/* Which inputs of a table want the trace pass: 0 = the image has no trace sections, 1 = the inputs with CBI_OUT_CEL_ERROR,
- * 2 = every input (the table has variables - evaluated whether or not a condition reads them, check.go:651-677 - or rules
- * with output expressions). */
+/* Which inputs want the trace pass: the ones whose output flags carry CBI_OUT_CEL_ERROR or CBI_OUT_WANTS_TRACE (the decision
+ * kernels mark them, cerbos_hip.h CBH_ST_*).  cbi_table_trace_scope says what to expect of a table: 0 = the image has no trace
+ * sections, 1 = only inputs with an absorbed error are ever marked, 2 = the table has variables (evaluated whether or not a
+ * condition reads them, check.go:651-677) or rules with output expressions: the walk marks the inputs that visit such a rule
+ * or whose variables fail, the older kernels (strict mode, requests wider than eight actions / four roles) every input. */
 uint32_t cbi_table_trace_scope(const cbi_table* t);
 #define CBI_TRACE_ERRORS_INCOMPLETE 4u
 #define CBI_TRACE_OUTPUTS_INCOMPLETE 8u

@@ -306,3 +306,47 @@ def test_gpu_fuzz_stores(seed):
     inputs = _requests(rng, 220)
     for lenient in (False, True):
         _against_oracle(rt, lt, lambda l: HipEvaluator(l, Conf()), inputs, lenient)
+
+
+# ---------------------------------------------------------------------------------------------------------- trace marks
+def _traced_fraction(make_evaluator):
+    """The reference's own test store has policy variables and rules with outputs: a kernel that cannot tell which inputs the
+    trace pass has something for marks them all (CBH_ST_WANTS_TRACE).  The walk marks the inputs that absorbed an error,
+    visited a rule with outputs or have a failing variable - and what engine.check(trace=True) then returns must still be
+    what the reference returned, input by input."""
+    from helpers import load_json
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    assert lt.trace_has_variables and lt.trace_has_outputs and lt.stats["walk2"]
+    ev = make_evaluator(lt)
+    cases = [c for c in load_json("engine_cases.json") if not c.get("strict")]
+    total = traced = needed = 0
+    try:
+        for case in cases:
+            lenient = bool(case["lenient"])
+            outs, bad, incomplete = ev.check(case["inputs"], now_ns=NOW, lenient_scope_search=lenient, allow_unsupported=True, trace=True)
+            traced += ev.last_traced
+            for i, (have, want) in enumerate(zip(outs, case["wantOutputs"])):
+                if i in bad:
+                    continue
+                total += 1
+                needed += bool(want.get("evaluationErrors") or want.get("outputs"))
+                what = incomplete.get(i, ())
+                if "errors" not in what:
+                    assert have["evaluationErrors"] == (want.get("evaluationErrors") or []), (case["name"], i)
+                if "outputs" not in what:
+                    assert sorted(have["outputs"], key=lambda o: o["src"]) == sorted(want.get("outputs") or [], key=lambda o: o["src"]), (case["name"], i)
+    finally:
+        if not isinstance(ev, HostSimEvaluator):
+            ev.close()
+    return total, traced, needed
+
+
+def test_only_marked_inputs_are_traced():
+    total, traced, needed = _traced_fraction(lambda lt: HostSimEvaluator(lt, Conf(globals_=GLOBALS)))
+    assert needed <= traced < 0.6 * total, (total, traced, needed)
+
+
+@pytest.mark.gpu
+def test_gpu_only_marked_inputs_are_traced():
+    total, traced, needed = _traced_fraction(lambda lt: HipEvaluator(lt, Conf(globals_=GLOBALS)))
+    assert needed <= traced < 0.6 * total, (total, traced, needed)
