@@ -12,11 +12,12 @@ driver's 20 steps keep the GPU busy for ~50 ms).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-`value` is the whole-job decision rate with the inputs already resident in HBM when the timed region starts (the
-benchmark contract of this repository: the PCIe-inclusive rate is never `value`).  SURVEY.md §8(d) defines the
-service-level metric as the wall time of cbh_check_batch INCLUDING the upload of the inputs and the download of
-the results: that figure is in the same line as `pcie_inclusive_decisions_per_s` (page-locked caller arrays,
-chunked three-stream pipeline) next to the pageable-memory rate and the p50 of a 48-tuple round trip.
+Two rates, side by side in the line: `value` = `resident_decisions_per_s`, the whole-job decision rate with the inputs
+already resident in HBM when the timed region starts (what the kernel roofline is computed from), and
+`pcie_inclusive_decisions_per_s`, SURVEY.md §8(d)'s service-level metric (1): the wall time of cbh_check_batch INCLUDING
+the upload of the inputs and the download of the results (page-locked caller arrays, chunked three-stream pipeline), next
+to the pageable-memory rate and the p50 of a 48-tuple round trip.  `--workload T` is north_star's named target set (100
+policies / 10k rules with CEL conditions).
 
 Multi-GPU: independent request shards per rank (weak scaling), no data-path collective; the only collective is the
 one-time RCCL broadcast of the lowered policy image from rank 0.  `--inproc-gpus M` adds a single-process leg: one
@@ -37,9 +38,9 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 # 32 + 9*A/actions + 1 (C2: A=7, 4 actions)
-ALG_BYTES_PER_DECISION = {"C1": 33.0, "C2": 49.0, "C3": 42.0, "C4": 47.0, "C5": 83.0}
+ALG_BYTES_PER_DECISION = {"C1": 33.0, "C2": 49.0, "C3": 42.0, "C4": 47.0, "C5": 83.0, "T": 47.0}
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # written by tools/gpu_profile.sh
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")   # written by tools/gpu_final_r03.sh
 
 
 def pmc_traffic(kernel, workload):
@@ -52,9 +53,9 @@ def pmc_traffic(kernel, workload):
     except (OSError, ValueError):
         return None, None
     e = (d.get("workloads") or {}).get(workload)
-    if not e or e.get("kernel") != kernel:
+    if not e or not all(k in kernel for k in (e.get("kernels") or [e.get("kernel", "?")])):
         return None, None
-    return e["bytes_per_launch"], "profiles/r02_pmc_traffic.json: separate rocprofv3 --pmc passes of this command (%s)" % e.get("note", "")
+    return e["bytes_per_launch"], "profiles/r03_pmc_traffic.json: separate rocprofv3 --pmc passes of this command (%s)" % e.get("note", "")
 
 
 def main():
@@ -62,8 +63,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("C1", "C2", "C3", "C4", "C5"), default="C2",
-                    help="BASELINE.json config; the metric is quoted on C2 (the default), the others are side measurements")
+    ap.add_argument("--workload", choices=("C1", "C2", "C3", "C4", "C5", "T"), default="C2",
+                    help="BASELINE.json config; the metric is quoted on C2 (the default), the others are side measurements; T = north_star's "
+                         "target set: 100 policies / 10k rules with CEL conditions")
     ap.add_argument("--requests", type=int, default=None, help="requests per batch (default: the config's size: C1 10k x2, C2 250k x4, C3 1M x4 actions)")
     ap.add_argument("--batches", type=int, default=None, help="resident batches per GPU in the rotating set (default: enough for > 1 GB)")
     ap.add_argument("--replicas", type=int, default=None,
@@ -112,7 +114,10 @@ def main():
           "C4": (workloads.c4_policies, workloads.c4_requests, 500_000, 12,
                  "1000 resource policies / 50k rules, 64-condition pool, Zipf kinds (one GPU's 2M of the 16M tuples)"),
           "C5": (workloads.c5_policies, workloads.c5_requests, 250_000, 16,
-                 "C3 + principal overrides, action globs, role policies, nested map/list CEL (one GPU's 1M of 8M)")}[args.workload]
+                 "C3 + principal overrides, action globs, role policies, nested map/list CEL (one GPU's 1M of 8M)"),
+          "T": (lambda: workloads.c4_policies(seed=7, n_policies=100, rules_per_policy=100),
+                lambda n, seed=7: workloads.c4_requests(n, seed=seed, n_policies=100), 250_000, 16,
+                "north_star's target: 100 resource policies / 10k rules, 40 % with CEL conditions (64-condition pool), 1M tuples")}[args.workload]
     n_requests = args.requests or wl[2]
     n_seeded = max(1, args.batches or wl[3])
     replicas = max(1, args.replicas if args.replicas is not None else (4 if args.workload == "C2" and not args.batches else 1))
@@ -134,7 +139,7 @@ def main():
         table = capi.Table(lt.blob)
 
     # ---- this rank's rotating set (weak scaling: fixed tuples per GPU; every batch of every rank has its own seed)
-    base_seed = {"C1": 1, "C2": 2, "C3": 3, "C4": 4, "C5": 5}[args.workload]
+    base_seed = {"C1": 1, "C2": 2, "C3": 3, "C4": 4, "C5": 5, "T": 7}[args.workload]
     fl = Flattener(lt)
     cr0 = batch0 = None
     dbatches, tuples_per_batch, resident_bytes = [], None, 0
@@ -335,11 +340,11 @@ def main():
         total = tuples * n_batches * world * args.steps
         alg = ALG_BYTES_PER_DECISION[args.workload]
         achieved = alg * tuples / (check_ms * 1e-3) / 1e9
-        # the kernel cbh_check_resident picks for this table / batch / mode (cbh_check_flat.h cbh_pick_kernel)
+        # the kernels cbh_check_resident launches for this table / batch / mode (cbh_plan_describe); kernel_ms spans the whole
+        # plan - from the start of its first kernel to the end of its last
         max_act, max_roles = int(batch0.req_u32[9].max()), int(batch0.req_u32[7].max())
-        if lt.stats["flat"] and max_act <= 4 and max_roles <= 4 and not (FLAGS & capi.F_STRICT_EVALUATION) and not os.environ.get("CBH_NO_FLAT"):
-            kernel = "cbh_check_flat_kernel"
-        else:
+        kernel = table.plan(dbatches[0], FLAGS)
+        if kernel == "cbh_check_kernel*":
             kernel = "cbh_check_kernel" + ("" if lt.stats["generic_programs"] else "_leaf") + \
                      (("_a4" if (max_act <= 4 and not lt.stats["generic_programs"]
                                  and lt.stats["kernel_features"]) else "_a32") + lt.stats["kernel_features"]

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "cbh_table_load", "cbh_table_retain", "cbh_table_release", "cbh_table_broadcast_kind", "cbh_table_num_strings", "cbh_table_num_columns",
     "cbh_table_device_bytes", "cbh_table_device_ptr", "cbh_table_adopt_device_image",
     "cbh_check_batch", "cbh_trace_batch", "cbh_batch_upload", "cbh_batch_upload_on", "cbh_batch_release", "cbh_check_resident",
-    "cbh_synchronize", "cbh_result_download", "cbh_kernel_time_ms",
+    "cbh_synchronize", "cbh_result_download", "cbh_kernel_time_ms", "cbh_plan_describe",
 ]
 
 
@@ -337,6 +337,13 @@ class Table:
 
     def synchronize(self):
         _check(load().cbh_synchronize(self.h))
+
+    def plan(self, dbatch, flags=0):
+        """The kernels cbh_check_resident launches for this batch under `flags` (cbh_plan_describe)."""
+        lib = load()
+        lib.cbh_plan_describe.restype = C.c_char_p
+        p = CParams(0, flags, 0)
+        return lib.cbh_plan_describe(self.h, dbatch.h, C.byref(p)).decode()
 
     def kernel_time_ms(self):
         a, b = C.c_float(), C.c_float()

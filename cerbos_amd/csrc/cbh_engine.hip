@@ -608,6 +608,17 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   return 0;
 }
 
+// Which kernels cbh_check_resident launches for this batch (measurement aid: bench.py names them in its line).
+extern "C" const char* cbh_plan_describe(cbh_table* t, cbh_device_batch* b, const cbh_params* p) {
+  static thread_local std::string s;
+  if (!t || !b || !p) return "";
+  const CbhPlan pl = plan_for(b->rep->dev, b->max_actions, b->max_roles, b->plain_tags, p->flags & ~(u32)CBH_FI_MASK);
+  if (pl.kind == 2) s = std::string(pl.wide_kernel ? "cbh_check_kernel*(wide requests)+" : "") + (pl.n_gwords && b->dev.gres ? "cbh_walk2_pre_kernel+" : "") + "cbh_walk2_kernel";
+  else if (pl.kind == 1) s = pl.kernel == cbh_check_flat_kernel ? "cbh_check_flat_kernel" : "cbh_check_flat_kernel_any";
+  else s = "cbh_check_kernel*";
+  return s.c_str();
+}
+
 extern "C" int cbh_synchronize(cbh_table* t) {
   if (!t) return fail("null argument");
   for (Replica* rep : t->reps) {

@@ -239,6 +239,9 @@ void cbh_batch_release(cbh_device_batch* b);
 /* Launches the kernels on the library's stream and returns without synchronising. */
 int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_params* p);
 int cbh_synchronize(cbh_table* t); /* every device of the table */
+/* The kernels cbh_check_resident launches for this batch and these parameters, e.g. "cbh_walk2_pre_kernel+cbh_walk2_kernel"
+ * (thread-local string; a measurement aid). */
+const char* cbh_plan_describe(cbh_table* t, cbh_device_batch* b, const cbh_params* p);
 /* Copies the results of the last cbh_check_resident on `b` to host memory. */
 int cbh_result_download(cbh_table* t, cbh_device_batch* b, cbh_result* out);
 /* Average duration in ms of the decision kernel over the last `n` cbh_check_resident

@@ -42,19 +42,26 @@ f_lds = (calib.get("calib_read_lds_b32") or {}).get("factor") or f_read
 f_write = (calib.get("calib_write_b32") or {}).get("factor") or 1.0
 traffic = {"calibration": {"read_b32": f_read, "read_lds_b32": f_lds, "write_b32": f_write,
                            "source": "tools/pmc_calib.hip, 512 MiB per launch, same box and profiler"}, "workloads": {}}
-for d in sorted(glob.glob(os.path.join(out_dir, "pmc_C*"))):
+for d in sorted(glob.glob(os.path.join(out_dir, "pmc_*"))):
     w = os.path.basename(d)[4:]
-    vals = counters(os.path.join(d, "**", "*counter_collection.csv"), lambda n: n.startswith("cbh_check_"))
+    if w == "calib" or not os.path.isdir(d):
+        continue
+    # a batch is decided by one launch of each kernel of its plan (cbh_walk2_pre_kernel + cbh_walk2_kernel, or one flat /
+    # general kernel): the per-batch traffic is the sum of their per-launch averages
+    vals = counters(os.path.join(d, "**", "*counter_collection.csv"), lambda n: n.startswith("cbh_check_") or n.startswith("cbh_walk2"))
     kernels = sorted({k for k, _ in vals})
     if not kernels:
         continue
-    k = kernels[0]
-    fk = vals.get((k, "FETCH_SIZE")) or [0.0]
-    wk = vals.get((k, "WRITE_SIZE")) or [0.0]
-    fetch_kb, write_kb = sum(fk) / len(fk), sum(wk) / len(wk)
+    fetch_kb = write_kb = 0.0
+    launches = 0
+    for k in kernels:
+        fk = vals.get((k, "FETCH_SIZE")) or [0.0]
+        wk = vals.get((k, "WRITE_SIZE")) or [0.0]
+        fetch_kb += sum(fk) / len(fk); write_kb += sum(wk) / len(wk)
+        launches = max(launches, len(fk))
     traffic["workloads"][w] = {
-        "kernel": k, "fetch_kb_per_launch_raw": fetch_kb, "write_kb_per_launch_raw": write_kb,
-        "bytes_per_launch": fetch_kb * 1024.0 * f_read + write_kb * 1024.0 * f_write, "launches": len(fk),
+        "kernel": "+".join(kernels), "kernels": kernels, "fetch_kb_per_launch_raw": fetch_kb, "write_kb_per_launch_raw": write_kb,
+        "bytes_per_launch": fetch_kb * 1024.0 * f_read + write_kb * 1024.0 * f_write, "launches": launches,
         "note": "FETCH_SIZE x %.3f + WRITE_SIZE x %.3f (factors calibrated on 4 B/lane accesses of known size); rotating set, "
                 "bench.py --steps 6 --warmup 2" % (f_read, f_write)}
 json.dump(traffic, open(os.path.join(out_dir, "pmc_traffic.json"), "w"), indent=1)
