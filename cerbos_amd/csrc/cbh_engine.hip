@@ -142,7 +142,14 @@ struct Replica {   // the table on one device
   int device = 0;
   void* image = nullptr; bool owns_image = true;
   TableDev dev{};
-  hipStream_t stream = nullptr;   // resident path
+  hipStream_t stream = nullptr;   // resident path (and the image broadcast)
+  // Resident batches are dealt round-robin to a few streams - a batch keeps the one it was uploaded on, so everything that
+  // touches it stays ordered - and launches of consecutive batches overlap: the dispatch ramp of one fills the CUs the
+  // drain of the one before leaves idle (~40 % of a 15 us launch is ramp + drain, profiles/r02_cycles_flat_C2.txt).
+  static constexpr int MAX_RESIDENT_STREAMS = 4;
+  hipStream_t rstreams[MAX_RESIDENT_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  int n_rstreams = 1;
+  std::atomic<uint32_t> next_rstream{0};
   // Kernel timing: a ring of event sets so that launches queue back to back; the host only waits
   // when it laps the ring.  ev[0..1] bracket the glob-resolve kernel, ev[2..3] the decision kernel.
   static constexpr int RING = 32;
@@ -174,6 +181,7 @@ struct cbh_device_batch {
   Replica* rep = nullptr;
   BatchDev dev{};
   OutDev out{};
+  hipStream_t stream = nullptr;   // the replica's resident stream this batch lives on
   KernelArgs* d_args = nullptr;   // device copy of the launch arguments
   KernelArgs last_args;           // what d_args currently holds
   bool have_args = false;
@@ -186,6 +194,7 @@ struct cbh_device_batch {
 static void replica_destroy(Replica* r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
+  for (int i = 1; i < r->n_rstreams; ++i) if (r->rstreams[i]) { (void)hipStreamSynchronize(r->rstreams[i]); (void)hipStreamDestroy(r->rstreams[i]); }
   if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
   for (auto& sl : r->ring) for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
   if (r->image && r->owns_image) (void)hipFree(r->image);
@@ -218,6 +227,10 @@ extern "C" void cbh_table_release(cbh_table* t) {
 static int replica_finish(Replica* r) {
   HIPCHK(hipSetDevice(r->device));
   HIPCHK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+  static const int n_streams = [] { const char* e = getenv("CBH_RESIDENT_STREAMS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > Replica::MAX_RESIDENT_STREAMS ? Replica::MAX_RESIDENT_STREAMS : v); }();
+  r->n_rstreams = n_streams;
+  r->rstreams[0] = r->stream;
+  for (int i = 1; i < r->n_rstreams; ++i) HIPCHK(hipStreamCreateWithFlags(&r->rstreams[i], hipStreamNonBlocking));
   for (auto& sl : r->ring) for (auto& e : sl.ev) HIPCHK(hipEventCreate(&e));
   return 0;
 }
@@ -421,7 +434,7 @@ static int pool_alloc(cbh_device_batch* b, size_t bytes, void** out) {
 extern "C" void cbh_batch_release(cbh_device_batch* b) {
   if (!b) return;
   cbh_table* t = b->table;
-  (void)hipSetDevice(b->rep->device); (void)hipStreamSynchronize(b->rep->stream);
+  (void)hipSetDevice(b->rep->device); (void)hipStreamSynchronize(b->stream ? b->stream : b->rep->stream);
   {
     std::lock_guard<std::mutex> lk(b->rep->pool_mu);
     for (auto& a : b->allocs) b->rep->pool_free.push_back(a);
@@ -464,7 +477,8 @@ extern "C" int cbh_batch_upload_on(cbh_table* t, uint32_t device_index, const cb
   d.n_requests = in->n_requests; d.n_tuples = in->n_tuples; d.n_roles = in->n_roles;
   d.n_columns = in->n_columns; d.n_strings = in->n_strings; d.heap_len = in->heap_len;
   d.req_lo = 0; d.req_hi = in->n_requests;
-  hipStream_t s = rep->stream;
+  b->stream = rep->rstreams[rep->next_rstream.fetch_add(1, std::memory_order_relaxed) % (uint32_t)rep->n_rstreams];
+  hipStream_t s = b->stream;
   const size_t NR = in->n_requests;
   int rc = 0;
   rc |= up(b, d.req_u32, in->req_u32, (size_t)CBH_RQ_NFIELDS * NR, s);
@@ -564,7 +578,7 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   Replica* rep = b->rep;
   std::lock_guard<std::mutex> lk(rep->mu);
   HIPCHK(hipSetDevice(rep->device));
-  hipStream_t s = rep->stream;
+  hipStream_t s = b->stream;
   // Kernel durations come from the dispatches' own begin / end timestamps (hipExtLaunchKernelGGL
   // with start / stop events: what rocprofv3's kernel trace reads too), not from event-record
   // packets placed around them, which would sit between back-to-back launches and add their own
@@ -624,7 +638,7 @@ extern "C" int cbh_synchronize(cbh_table* t) {
   for (Replica* rep : t->reps) {
     std::lock_guard<std::mutex> lk(rep->mu);
     HIPCHK(hipSetDevice(rep->device));
-    HIPCHK(hipStreamSynchronize(rep->stream));
+    for (int i = 0; i < rep->n_rstreams; ++i) HIPCHK(hipStreamSynchronize(rep->rstreams[i]));
     collect_times(rep);
   }
   return 0;
@@ -650,7 +664,7 @@ extern "C" int cbh_result_download(cbh_table* t, cbh_device_batch* b, cbh_result
   Replica* rep = b->rep;
   std::lock_guard<std::mutex> lk(rep->mu);
   HIPCHK(hipSetDevice(rep->device));
-  hipStream_t s = rep->stream;
+  hipStream_t s = b->stream;
   const BatchDev& d = b->dev;
   if (d.n_tuples) HIPCHK(hipMemcpyAsync(out->effect, b->out.effect, d.n_tuples, hipMemcpyDeviceToHost, s));
   if (out->policy && d.n_tuples) HIPCHK(hipMemcpyAsync(out->policy, b->out.policy, (size_t)d.n_tuples * 4, hipMemcpyDeviceToHost, s));
