@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = [
     "cbh_table_device_bytes", "cbh_table_device_ptr", "cbh_table_adopt_device_image",
     "cbh_check_batch", "cbh_trace_batch", "cbh_batch_upload", "cbh_batch_upload_on", "cbh_batch_release", "cbh_check_resident",
     "cbh_synchronize", "cbh_result_download", "cbh_kernel_time_ms", "cbh_plan_describe",
+    "cbh_check_resident_many", "cbh_table_set_resident_streams", "cbh_table_resident_streams",
 ]
 
 
@@ -140,6 +141,12 @@ def load():
     lib.cbh_result_download.restype = i32
     lib.cbh_kernel_time_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.cbh_kernel_time_ms.restype = i32
+    lib.cbh_check_resident_many.argtypes = [vp, C.POINTER(vp), u32, C.POINTER(CParams)]
+    lib.cbh_check_resident_many.restype = i32
+    lib.cbh_table_set_resident_streams.argtypes = [vp, u32]
+    lib.cbh_table_set_resident_streams.restype = i32
+    lib.cbh_table_resident_streams.argtypes = [vp]
+    lib.cbh_table_resident_streams.restype = u32
     _lib = lib
     return lib
 
@@ -334,6 +341,23 @@ class Table:
     def launch(self, dbatch, now_ns=0, flags=0):
         p = CParams(now_ns, flags, 0)
         _check(load().cbh_check_resident(self.h, dbatch.h, C.byref(p)))
+
+    def launch_many(self, dbatches, now_ns=0, flags=0):
+        """``cbh_check_resident_many``: one sweep over resident batches (a prepared handle array is cached per list)."""
+        key = id(dbatches)
+        arr = getattr(self, "_sweep", (None, None))
+        if arr[0] != key or len(arr[1]) != len(dbatches):
+            arr = (key, (C.c_void_p * len(dbatches))(*[db.h for db in dbatches]))
+            self._sweep = arr
+        p = CParams(now_ns, flags, 0)
+        _check(load().cbh_check_resident_many(self.h, arr[1], len(dbatches), C.byref(p)))
+
+    def set_resident_streams(self, n):
+        _check(load().cbh_table_set_resident_streams(self.h, int(n)))
+
+    @property
+    def resident_streams(self):
+        return int(load().cbh_table_resident_streams(self.h))
 
     def synchronize(self):
         _check(load().cbh_synchronize(self.h))

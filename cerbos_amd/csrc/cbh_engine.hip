@@ -148,7 +148,7 @@ struct Replica {   // the table on one device
   // drain of the one before leaves idle (~40 % of a 15 us launch is ramp + drain, profiles/r02_cycles_flat_C2.txt).
   static constexpr int MAX_RESIDENT_STREAMS = 4;
   hipStream_t rstreams[MAX_RESIDENT_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
-  int n_rstreams = 1;
+  std::atomic<int> n_rstreams{1};
   std::atomic<uint32_t> next_rstream{0};
   // Kernel timing: a ring of event sets so that launches queue back to back; the host only waits
   // when it laps the ring.  ev[0..1] bracket the glob-resolve kernel, ev[2..3] the decision kernel.
@@ -194,7 +194,7 @@ struct cbh_device_batch {
 static void replica_destroy(Replica* r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
-  for (int i = 1; i < r->n_rstreams; ++i) if (r->rstreams[i]) { (void)hipStreamSynchronize(r->rstreams[i]); (void)hipStreamDestroy(r->rstreams[i]); }
+  for (int i = 1; i < Replica::MAX_RESIDENT_STREAMS; ++i) if (r->rstreams[i]) { (void)hipStreamSynchronize(r->rstreams[i]); (void)hipStreamDestroy(r->rstreams[i]); }
   if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
   for (auto& sl : r->ring) for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
   if (r->image && r->owns_image) (void)hipFree(r->image);
@@ -228,9 +228,9 @@ static int replica_finish(Replica* r) {
   HIPCHK(hipSetDevice(r->device));
   HIPCHK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
   static const int n_streams = [] { const char* e = getenv("CBH_RESIDENT_STREAMS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > Replica::MAX_RESIDENT_STREAMS ? Replica::MAX_RESIDENT_STREAMS : v); }();
-  r->n_rstreams = n_streams;
+  r->n_rstreams = n_streams;   // (default; cbh_table_set_resident_streams changes it for the batches uploaded afterwards)
   r->rstreams[0] = r->stream;
-  for (int i = 1; i < r->n_rstreams; ++i) HIPCHK(hipStreamCreateWithFlags(&r->rstreams[i], hipStreamNonBlocking));
+  for (int i = 1; i < Replica::MAX_RESIDENT_STREAMS; ++i) HIPCHK(hipStreamCreateWithFlags(&r->rstreams[i], hipStreamNonBlocking));
   for (auto& sl : r->ring) for (auto& e : sl.ev) HIPCHK(hipEventCreate(&e));
   return 0;
 }
@@ -477,7 +477,7 @@ extern "C" int cbh_batch_upload_on(cbh_table* t, uint32_t device_index, const cb
   d.n_requests = in->n_requests; d.n_tuples = in->n_tuples; d.n_roles = in->n_roles;
   d.n_columns = in->n_columns; d.n_strings = in->n_strings; d.heap_len = in->heap_len;
   d.req_lo = 0; d.req_hi = in->n_requests;
-  b->stream = rep->rstreams[rep->next_rstream.fetch_add(1, std::memory_order_relaxed) % (uint32_t)rep->n_rstreams];
+  b->stream = rep->rstreams[rep->next_rstream.fetch_add(1, std::memory_order_relaxed) % (uint32_t)rep->n_rstreams.load(std::memory_order_relaxed)];
   hipStream_t s = b->stream;
   const size_t NR = in->n_requests;
   int rc = 0;
@@ -622,6 +622,24 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   return 0;
 }
 
+// A sweep: cbh_check_resident for each of `n` resident batches of the table, in order, in one call (what a server's dispatch loop
+// does between two polls of its queue; saves the caller n - 1 crossings of the boundary).
+extern "C" int cbh_check_resident_many(cbh_table* t, cbh_device_batch* const* bs, uint32_t n, const cbh_params* p) {
+  if (!t || (!bs && n) || !p) return fail("null argument");
+  for (uint32_t i = 0; i < n; ++i) if (cbh_check_resident(t, bs[i], p) != 0) return -1;
+  return 0;
+}
+
+// How many of the replica's resident streams batches uploaded FROM NOW ON are dealt to (1 .. 4; a batch keeps its stream).
+// 1 = every launch queues behind the one before it: the setting for timing one kernel by itself.
+extern "C" int cbh_table_set_resident_streams(cbh_table* t, uint32_t n) {
+  if (!t) return fail("null argument");
+  if (n < 1 || n > (uint32_t)Replica::MAX_RESIDENT_STREAMS) return fail("resident streams: 1 .. 4");
+  for (Replica* rep : t->reps) { rep->n_rstreams.store((int)n); rep->next_rstream.store(0); }
+  return 0;
+}
+extern "C" uint32_t cbh_table_resident_streams(const cbh_table* t) { return t && !t->reps.empty() ? (uint32_t)t->reps[0]->n_rstreams.load() : 0u; }
+
 // Which kernels cbh_check_resident launches for this batch (measurement aid: bench.py names them in its line).
 extern "C" const char* cbh_plan_describe(cbh_table* t, cbh_device_batch* b, const cbh_params* p) {
   static thread_local std::string s;
@@ -638,7 +656,7 @@ extern "C" int cbh_synchronize(cbh_table* t) {
   for (Replica* rep : t->reps) {
     std::lock_guard<std::mutex> lk(rep->mu);
     HIPCHK(hipSetDevice(rep->device));
-    for (int i = 0; i < rep->n_rstreams; ++i) HIPCHK(hipStreamSynchronize(rep->rstreams[i]));
+    for (int i = 0; i < Replica::MAX_RESIDENT_STREAMS; ++i) if (rep->rstreams[i]) HIPCHK(hipStreamSynchronize(rep->rstreams[i]));
     collect_times(rep);
   }
   return 0;

@@ -18,8 +18,8 @@
  * 0 = OK, < 0 = hard error (text via cbh_last_error(), thread-local).  No function
  * aborts or throws across the boundary.  All entry points are thread-safe: one-shot calls
  * (cbh_check_batch) from different threads run on separate launch contexts and overlap on the
- * device (up to 8 per table and device, further callers wait); the resident calls of one table
- * and device share one stream and queue in call order.
+ * device (up to 8 per table and device, further callers wait); the resident calls on one batch
+ * queue in call order (batches are dealt to a few streams per device, see cbh_table_set_resident_streams).
  *
  * Devices: cbh_init names the GPUs of the node the engine may use (the reference's fan-out over
  * NumCPU+4 goroutines, engine.go:309-338, becomes a fan-out over devices).  cbh_table_load puts
@@ -238,6 +238,14 @@ int cbh_batch_upload_on(cbh_table* t, uint32_t device_index, const cbh_batch* in
 void cbh_batch_release(cbh_device_batch* b);
 /* Launches the kernels on the library's stream and returns without synchronising. */
 int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_params* p);
+/* cbh_check_resident for bs[0 .. n) in order, in one call. */
+int cbh_check_resident_many(cbh_table* t, cbh_device_batch* const* bs, uint32_t n, const cbh_params* p);
+/* Resident batches are dealt round-robin to a few streams of their device at upload (a batch keeps its stream, so everything
+ * that touches it stays ordered) and launches of batches on different streams overlap on the device: the dispatch ramp of one
+ * fills the CUs the drain of another leaves idle.  n = 1 .. 4 for the batches uploaded from now on (default 3; 1 = strictly one
+ * launch after the other - the setting for timing a kernel by itself). */
+int cbh_table_set_resident_streams(cbh_table* t, uint32_t n);
+uint32_t cbh_table_resident_streams(const cbh_table* t);
 int cbh_synchronize(cbh_table* t); /* every device of the table */
 /* The kernels cbh_check_resident launches for this batch and these parameters, e.g. "cbh_walk2_pre_kernel+cbh_walk2_kernel"
  * (thread-local string; a measurement aid). */
