@@ -59,6 +59,37 @@ __device__ __forceinline__ u32x4u load_u32x4(const CBH_G u32* p) {   // one 16-b
   return u32x4u{p[0], p[1], p[2], p[3]};
 #endif
 }
+// ---- staged records.  A bucket's records used to arrive one scalar load at a time, each visit waiting for its own trip
+// to memory (~1 900 cycles a visit on a 100-rule policy, profiles/r03_*).  Now the wave fetches up to 64 records with ONE
+// round of vector loads - lane i takes record base + i into its own registers - decides from the class masks, all lanes
+// at once, which of them can match anything in the wave (a ballot), and visits only those: a visit takes its record out
+// of the owning lane's registers with v_readlane into scalar registers - no memory access - so the code behind it reads
+// wave-uniform fields exactly as it did after the scalar load.
+template <int NDW> struct StagedRec { u32 w[NDW]; };
+template <int NDW>
+__device__ __forceinline__ StagedRec<NDW> stage_rec(const CBH_G u32* base, u32 idx, bool wanted) {   // `idx` per lane; NDW % 4 == 0
+  StagedRec<NDW> r;
+#pragma unroll
+  for (int k = 0; k < NDW; ++k) r.w[k] = 0;
+  if (wanted) {
+    const CBH_G u32* p = base + (size_t)idx * NDW;
+#pragma unroll
+    for (int k = 0; k < NDW; k += 4) { const u32x4u v = load_u32x4(p + k); r.w[k] = v.x; r.w[k + 1] = v.y; r.w[k + 2] = v.z; r.w[k + 3] = v.w; }
+  }
+  return r;
+}
+template <typename R, int NDW>
+__device__ __forceinline__ R staged_take(const StagedRec<NDW>& s, u32 lane) {   // `lane` wave-uniform
+  static_assert(sizeof(R) == NDW * 4, "record size");
+  u32 w[NDW];
+#pragma unroll
+  for (int k = 0; k < NDW; ++k) w[k] = wave_readlane(s.w[k], lane);
+  R r;
+  __builtin_memcpy(&r, w, sizeof(R));
+  return r;
+}
+__device__ __forceinline__ u32 ctz64(u64 v) { return (u32)__builtin_ctzll(v); }
+
 // stores of results nobody in this kernel reads again: written through, so that the end of the kernel does not have to
 // flush them out of the L2 (the dirty lines of a 1M-tuple batch are 12 MB)
 template <typename T>
@@ -187,7 +218,7 @@ __device__ __forceinline__ u32 wave_max_bits(u32 v, bool in, u32 nbits) {
   return best;
 }
 
-template <bool WITH_CALL>
+template <bool WITH_CALL, bool STAGED>
 __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   const TableDev& t = ka_regs.t;
   const BatchDev& b = ka_regs.b;
@@ -197,7 +228,8 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 #ifdef CBH_PROFILE_CYCLES   // profiling build only (tools/gpu_cycles_flat.py)
   const u64 cyc0 = __builtin_readcyclecounter();
   const u64 rt0 = __builtin_amdgcn_s_memrealtime();
-  u32 dbg_rows = 0, dbg_rounds = 0;
+  u32 dbg_rows = 0, dbg_rounds = 0, dbg_evals = 0, dbg_visits = 0;
+  u64 cyc_eval = 0, cyc_stage = 0;
 #define FLAT_DBG(x) x
 #else
 #define FLAT_DBG(x)
@@ -293,8 +325,10 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   // flat_tree), 0 = neither; what the inline code leaves open goes through the shared evaluator.
   auto leafish = [&](u32 ref, u32 how, const LeafRec& lr, bool active) -> u32 {
     u32 lv = 4u;
+    FLAT_DBG(const u64 e0 = __builtin_readcyclecounter(); ++dbg_evals;)
     if (how == 1u) lv = flat_leaf(c, lr, req, pid);
     else if (how == 2u) lv = flat_tree(c, lr, req, pid);
+    FLAT_DBG(cyc_eval += (__builtin_readcyclecounter() - e0) * (u64)(wave_ballot(lv != 77u) != 0);)
     const bool slow = active && lv == 4u;
     if (WITH_CALL) {
       // The classified leaves leave open only what needs memory (container equality) or cross-type numerics.  The
@@ -340,40 +374,90 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
     if (go) {
       if (ing && mydepth < max_depth) { if (chain8) chain_si8[mydepth * CBH_BLOCK + c.tid] = (u8)g_si; else chain_si[mydepth * CBH_BLOCK + c.tid] = g_si; }
       const u32 S_before = S;
-      if (have_bucket && bucket.y) {
-        const u32 last = bucket.x + bucket.y - 1u;
-        TblRowFull nxt = uload_rec<TblRowFull>(t.rows, bucket.x);
-        for (u32 row = bucket.x; row <= last; ++row) {   // bindings in order (check.go:295-414)
-          const TblRowFull rf = nxt;   // hot half + leaf slot: one scalar load, issued one record ahead
-          nxt = uload_rec<TblRowFull>(t.rows, row < last ? row + 1u : last);
-          const TblRow& rw = rf.hot;
-          FLAT_DBG(++dbg_rows;)
-          if ((rw.rm_lo & wave_rc) == 0 || (rw.am_lo & wave_ac) == 0) continue;
-          const u32 mact = ((rw.am_lo >> ac[0]) & 1u) | (((rw.am_lo >> ac[1]) & 1u) << 1) | (((rw.am_lo >> ac[2]) & 1u) << 2) | (((rw.am_lo >> ac[3]) & 1u) << 3);
-          // one nibble per role (sign-extended 1-bit extracts), one bit per nibble for the actions; walks of other groups sit out
-          const u32 mrole = ((0u - ((rw.rm_lo >> rc[0]) & 1u)) & 0xFu) | ((0u - ((rw.rm_lo >> rc[1]) & 1u)) & 0xF0u) |
-                            ((0u - ((rw.rm_lo >> rc[2]) & 1u)) & 0xF00u) | ((0u - ((rw.rm_lo >> rc[3]) & 1u)) & 0xF000u);
-          const u32 m = ing ? (mrole & (mact * 0x1111u) & S) : 0u;
-          if (wave_ballot(m != 0) == 0) continue;
-          // the walks this record's effect applies to: all matched ones unless a condition says no.  The derived-role
-          // condition comes first and the rule's own condition is evaluated only where that held (check.go:328-380);
-          // each once per record and request, whatever the roles (check.go:316-340)
-          u32 hit = m;
-          if (rw.drcond != CBH_NONE) {
-            const u32 how = (rw.flags & CBH_ROW_F_DRLEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_DRTREE_EMBEDDED) ? 2u : 0u;
-            const LeafRec l2 = uload_rec<LeafRec>(t.rowleaf2, row);
-            const u32 lv = leafish(rw.drcond, how, l2, hit != 0);
-            err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
-            hit = (lv & 1u) ? hit : 0u;
+      if constexpr (STAGED) {
+        if (have_bucket && bucket.y) {
+          const u32 end = bucket.x + bucket.y;
+          for (u32 base = bucket.x; base < end && wave_ballot(ing && S != 0) != 0; base += CBH_BLOCK) {   // bindings in order (check.go:295-414)
+            const u32 n = end - base < CBH_BLOCK ? end - base : CBH_BLOCK;
+            const bool mine = c.tid < n;
+            FLAT_DBG(const u64 g0 = __builtin_readcyclecounter();)
+            const StagedRec<16> sr = stage_rec<16>(t.rows, base + c.tid, mine);   // hot half + leaf slot (TblRowFull)
+            const StagedRec<8> s2 = stage_rec<8>(t.rowleaf2, base + c.tid, mine && sr.w[2] != CBH_NONE);   // the derived-role condition's leaf
+            // records some class present in the wave can match (TblRow: rm_lo = word 4, am_lo = word 6)
+            u64 cand = wave_ballot(mine && (sr.w[4] & wave_rc) != 0 && (sr.w[6] & wave_ac) != 0);
+            FLAT_DBG(dbg_rows += n; cyc_stage += (__builtin_readcyclecounter() - g0) * (u64)(cand != 0xdeadbeefull);)
+            while (cand != 0) {
+              const u32 i = ctz64(cand);
+              cand &= cand - 1ull;
+              const u32 row = base + i;
+              const TblRowFull rf = staged_take<TblRowFull>(sr, i);
+              const TblRow& rw = rf.hot;
+              const u32 mact = ((rw.am_lo >> ac[0]) & 1u) | (((rw.am_lo >> ac[1]) & 1u) << 1) | (((rw.am_lo >> ac[2]) & 1u) << 2) | (((rw.am_lo >> ac[3]) & 1u) << 3);
+              // one nibble per role (sign-extended 1-bit extracts), one bit per nibble for the actions; walks of other groups sit out
+              const u32 mrole = ((0u - ((rw.rm_lo >> rc[0]) & 1u)) & 0xFu) | ((0u - ((rw.rm_lo >> rc[1]) & 1u)) & 0xF0u) |
+                                ((0u - ((rw.rm_lo >> rc[2]) & 1u)) & 0xF00u) | ((0u - ((rw.rm_lo >> rc[3]) & 1u)) & 0xF000u);
+              const u32 m = ing ? (mrole & (mact * 0x1111u) & S) : 0u;
+              if (wave_ballot(m != 0) == 0) continue;
+              FLAT_DBG(++dbg_visits;)
+              // the walks this record's effect applies to: all matched ones unless a condition says no.  The derived-role
+              // condition comes first and the rule's own condition is evaluated only where that held (check.go:328-380);
+              // each once per record and request, whatever the roles (check.go:316-340)
+              u32 hit = m;
+              if (rw.drcond != CBH_NONE) {
+                const u32 how = (rw.flags & CBH_ROW_F_DRLEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_DRTREE_EMBEDDED) ? 2u : 0u;
+                const LeafRec l2 = staged_take<LeafRec>(s2, i);
+                const u32 lv = leafish(rw.drcond, how, l2, hit != 0);
+                err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
+                hit = (lv & 1u) ? hit : 0u;
+              }
+              if (rw.cond != CBH_NONE && wave_ballot(hit != 0) != 0) {
+                const u32 how = (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_TREE_EMBEDDED) ? 2u : 0u;
+                const u32 lv = leafish(rw.cond, how, rf.leaf, hit != 0);
+                err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
+                hit = (lv & 1u) ? hit : 0u;
+              }
+              if ((rw.flags & 3u) == CBH_EFFECT_ALLOW) has_allow |= hit;
+              else if ((rw.flags & 3u) == CBH_EFFECT_DENY) { deny |= hit; S &= ~hit; }   // ends these walks (check.go:392-403)
+              (void)row;
+            }
           }
-          if (rw.cond != CBH_NONE && wave_ballot(hit != 0) != 0) {
-            const u32 how = (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_TREE_EMBEDDED) ? 2u : 0u;
-            const u32 lv = leafish(rw.cond, how, rf.leaf, hit != 0);
-            err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
-            hit = (lv & 1u) ? hit : 0u;
+        }
+      } else {
+        if (have_bucket && bucket.y) {
+          const u32 last = bucket.x + bucket.y - 1u;
+          TblRowFull nxt = uload_rec<TblRowFull>(t.rows, bucket.x);
+          for (u32 row = bucket.x; row <= last; ++row) {   // bindings in order (check.go:295-414)
+            const TblRowFull rf = nxt;   // hot half + leaf slot: one scalar load, issued one record ahead
+            nxt = uload_rec<TblRowFull>(t.rows, row < last ? row + 1u : last);
+            const TblRow& rw = rf.hot;
+            FLAT_DBG(++dbg_rows;)
+            if ((rw.rm_lo & wave_rc) == 0 || (rw.am_lo & wave_ac) == 0) continue;
+            const u32 mact = ((rw.am_lo >> ac[0]) & 1u) | (((rw.am_lo >> ac[1]) & 1u) << 1) | (((rw.am_lo >> ac[2]) & 1u) << 2) | (((rw.am_lo >> ac[3]) & 1u) << 3);
+            // one nibble per role (sign-extended 1-bit extracts), one bit per nibble for the actions; walks of other groups sit out
+            const u32 mrole = ((0u - ((rw.rm_lo >> rc[0]) & 1u)) & 0xFu) | ((0u - ((rw.rm_lo >> rc[1]) & 1u)) & 0xF0u) |
+                              ((0u - ((rw.rm_lo >> rc[2]) & 1u)) & 0xF00u) | ((0u - ((rw.rm_lo >> rc[3]) & 1u)) & 0xF000u);
+            const u32 m = ing ? (mrole & (mact * 0x1111u) & S) : 0u;
+            if (wave_ballot(m != 0) == 0) continue;
+            // the walks this record's effect applies to: all matched ones unless a condition says no.  The derived-role
+            // condition comes first and the rule's own condition is evaluated only where that held (check.go:328-380);
+            // each once per record and request, whatever the roles (check.go:316-340)
+            u32 hit = m;
+            if (rw.drcond != CBH_NONE) {
+              const u32 how = (rw.flags & CBH_ROW_F_DRLEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_DRTREE_EMBEDDED) ? 2u : 0u;
+              const LeafRec l2 = uload_rec<LeafRec>(t.rowleaf2, row);
+              const u32 lv = leafish(rw.drcond, how, l2, hit != 0);
+              err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
+              hit = (lv & 1u) ? hit : 0u;
+            }
+            if (rw.cond != CBH_NONE && wave_ballot(hit != 0) != 0) {
+              const u32 how = (rw.flags & CBH_ROW_F_LEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_TREE_EMBEDDED) ? 2u : 0u;
+              const u32 lv = leafish(rw.cond, how, rf.leaf, hit != 0);
+              err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
+              hit = (lv & 1u) ? hit : 0u;
+            }
+            if ((rw.flags & 3u) == CBH_EFFECT_ALLOW) has_allow |= hit;
+            else if ((rw.flags & 3u) == CBH_EFFECT_DENY) { deny |= hit; S &= ~hit; }   // ends these walks (check.go:392-403)
           }
-          if ((rw.flags & 3u) == CBH_EFFECT_ALLOW) has_allow |= hit;
-          else if ((rw.flags & 3u) == CBH_EFFECT_DENY) { deny |= hit; S &= ~hit; }   // ends these walks (check.go:392-403)
         }
       }
       const u32 ha = ing ? (has_allow & S) : 0u;   // check.go:416-425
@@ -467,8 +551,8 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 #ifdef CBH_PROFILE_CYCLES
   if (flags & CBH_F_DEBUG_CYCLES) {   // policy / scope words <- phase cycles, wall-clock (100 MHz) start / end, visit counts
     const u64 cyc4 = __builtin_readcyclecounter();
-    pol[0] = (u32)(cyc1 - cyc0); pol[1] = (u32)(cyc2 - cyc1); pol[2] = (u32)(cyc3 - cyc2); pol[3] = (u32)(cyc4 - cyc3);
-    scp[0] = (u32)rt0; scp[1] = (u32)__builtin_amdgcn_s_memrealtime(); scp[2] = dbg_rows; scp[3] = dbg_rounds;
+    pol[0] = (u32)(cyc1 - cyc0); pol[1] = (u32)cyc_eval; pol[2] = (u32)(cyc3 - cyc2); pol[3] = (u32)cyc_stage; (void)cyc4;
+    scp[0] = (u32)rt0; scp[1] = (u32)__builtin_amdgcn_s_memrealtime(); scp[2] = dbg_rows | (dbg_evals << 16); scp[3] = dbg_rounds | (dbg_visits << 16);
   }
 #endif
   const bool packed = valid && act_cnt == 4 && (act_off & 3u) == 0;
@@ -510,13 +594,24 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 // batches of plain scalars (no int / uint / list / map attribute values): no call, ~64 VGPRs, 7-8 waves per SIMD
 __global__ CBH_FLAT_ATTRS(7) void cbh_check_flat_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
   CBH_FLAT_CTX(a, ka);
-  flat_body<false>(a, c);
+  flat_body<false, false>(a, c);
 }
 // any batch: the same walk with the call into the shared evaluator compiled in (4 waves per SIMD)
 __global__ CBH_FLAT_ATTRS(4) void cbh_check_flat_kernel_any(const KernelArgs a, const KernelArgs* __restrict__ ka) {
   CBH_FLAT_CTX(a, ka);
-  flat_body<true>(a, c);
+  flat_body<true, false>(a, c);
 }
+// tables with long buckets (more than CBH_FLAT_STAGE_MIN rule records in one policy): the records arrive 64 at a time in
+// the lanes' registers (stage_rec) instead of one scalar load per visit - 16 more VGPRs, 5 waves per SIMD
+__global__ CBH_FLAT_ATTRS(5) void cbh_check_flat_kernel_staged(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+  CBH_FLAT_CTX(a, ka);
+  flat_body<false, true>(a, c);
+}
+__global__ CBH_FLAT_ATTRS(4) void cbh_check_flat_kernel_any_staged(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+  CBH_FLAT_CTX(a, ka);
+  flat_body<true, true>(a, c);
+}
+#define CBH_FLAT_STAGE_MIN 32u
 
 // Which kernel decides this batch: a flat one when table (CBH_MF_FLAT), batch shape (<= 4 actions and <= 4 roles per
 // request; `plain_tags`: no attribute value is an int / uint / list / map - selects the variant without the evaluator call)
@@ -532,11 +627,13 @@ static inline size_t cbh_flat_class_bytes(u32 table_strings) {
   return table_strings <= CBH_FLAT_LDS_STRINGS ? (((size_t)2 * table_strings + 15) & ~(size_t)15) : 0;
 }
 static inline cbh_check_kernel_fn cbh_pick_kernel(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 max_actions, u32 max_roles, bool plain_tags,
-                                                  u32 eval_flags, u32* threads, bool* flat) {
+                                                  u32 eval_flags, u32 max_bucket, u32* threads, bool* flat) {
   *flat = (table_flags & CBH_MF_FLAT) && max_actions <= 4 && max_roles <= 4 && !(eval_flags & CBH_F_STRICT_EVALUATION);
   if (*flat) {
     *threads = CBH_FLAT_THREADS;
-    return (plain_tags && (table_flags & CBH_MF_FLAT_CLOSED)) ? cbh_check_flat_kernel : cbh_check_flat_kernel_any;
+    const bool staged = max_bucket > CBH_FLAT_STAGE_MIN;
+    if (plain_tags && (table_flags & CBH_MF_FLAT_CLOSED)) return staged ? cbh_check_flat_kernel_staged : cbh_check_flat_kernel;
+    return staged ? cbh_check_flat_kernel_any_staged : cbh_check_flat_kernel_any;
   }
   *threads = CBH_BLOCK;
   return cbh_pick_check_kernel(table_flags, n_derived_roles, has_globs, max_actions);

@@ -835,10 +835,10 @@ struct CbhPlan {
   cbh_check_kernel_fn wide_kernel;   // kind 2, batch with requests wider than the walk's shape: the general walk's kernel for those (else null)
 };
 static inline CbhPlan cbh_plan(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 gslots_generic, u32 gslots_all, u32 max_actions,
-                               u32 max_roles, bool plain_tags, u32 eval_flags, bool no_flat, bool no_walk2) {
+                               u32 max_roles, bool plain_tags, u32 eval_flags, bool no_flat, bool no_walk2, u32 max_bucket) {
   CbhPlan p; p.n_gwords = 0; p.n_gslots = 0; p.wide_kernel = nullptr;
   bool flat = false;
-  p.kernel = cbh_pick_kernel(no_flat ? (table_flags & ~(u32)CBH_MF_FLAT) : table_flags, n_derived_roles, has_globs, max_actions, max_roles, plain_tags, eval_flags, &p.threads, &flat);
+  p.kernel = cbh_pick_kernel(no_flat ? (table_flags & ~(u32)CBH_MF_FLAT) : table_flags, n_derived_roles, has_globs, max_actions, max_roles, plain_tags, eval_flags, max_bucket, &p.threads, &flat);
   p.kind = flat ? 1 : 0;
   if (!flat && !no_walk2 && cbh_walk2_applies(table_flags, eval_flags)) {
     if (max_actions > CBH_W2_NA || max_roles > CBH_W2_NR) p.wide_kernel = p.kernel;

@@ -146,8 +146,8 @@ struct Replica {   // the table on one device
   // Resident batches are dealt round-robin to a few streams - a batch keeps the one it was uploaded on, so everything that
   // touches it stays ordered - and launches of consecutive batches overlap: the dispatch ramp of one fills the CUs the
   // drain of the one before leaves idle (~40 % of a 15 us launch is ramp + drain, profiles/r02_cycles_flat_C2.txt).
-  static constexpr int MAX_RESIDENT_STREAMS = 4;
-  hipStream_t rstreams[MAX_RESIDENT_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  static constexpr int MAX_RESIDENT_STREAMS = 8;
+  hipStream_t rstreams[MAX_RESIDENT_STREAMS] = {};
   std::atomic<int> n_rstreams{1};
   std::atomic<uint32_t> next_rstream{0};
   // Kernel timing: a ring of event sets so that launches queue back to back; the host only waits
@@ -531,7 +531,9 @@ static void collect_times(Replica* r) {   // after the stream has been synchroni
 static CbhPlan plan_for(const TableDev& dev, u32 max_actions, u32 max_roles, bool plain_tags, u32 eval_flags) {
   static const bool no_flat = getenv("CBH_NO_FLAT") != nullptr, no_walk2 = getenv("CBH_NO_WALK2") != nullptr;
   const bool has_globs = (dev.nfa_words[0] | dev.nfa_words[1] | dev.nfa_words[2]) != 0 || (dev.flags & CBH_MF_HAS_ANY_PATTERN);
-  return cbh_plan(dev.flags, dev.n_dr, has_globs, dev.gslots_generic, dev.gslots_all, max_actions, max_roles, plain_tags, eval_flags, no_flat, no_walk2);
+  static const bool force_staged = getenv("CBH_FORCE_STAGED") != nullptr;   // (tests: the staged record walk on tables of any size)
+  return cbh_plan(dev.flags, dev.n_dr, has_globs, dev.gslots_generic, dev.gslots_all, max_actions, max_roles, plain_tags, eval_flags, no_flat, no_walk2,
+                  force_staged ? 0xFFFFFFFFu : dev.max_bucket);
 }
 // the launches that decide the requests [lo, hi) of `ka.b`; [wide_lo, wide_hi) = where the batch's requests wider than
 // cbh_walk2_kernel's shape lie (empty: none)
@@ -634,7 +636,7 @@ extern "C" int cbh_check_resident_many(cbh_table* t, cbh_device_batch* const* bs
 // 1 = every launch queues behind the one before it: the setting for timing one kernel by itself.
 extern "C" int cbh_table_set_resident_streams(cbh_table* t, uint32_t n) {
   if (!t) return fail("null argument");
-  if (n < 1 || n > (uint32_t)Replica::MAX_RESIDENT_STREAMS) return fail("resident streams: 1 .. 4");
+  if (n < 1 || n > (uint32_t)Replica::MAX_RESIDENT_STREAMS) return fail("resident streams: 1 .. 8");
   for (Replica* rep : t->reps) { rep->n_rstreams.store((int)n); rep->next_rstream.store(0); }
   return 0;
 }
@@ -646,7 +648,8 @@ extern "C" const char* cbh_plan_describe(cbh_table* t, cbh_device_batch* b, cons
   if (!t || !b || !p) return "";
   const CbhPlan pl = plan_for(b->rep->dev, b->max_actions, b->max_roles, b->plain_tags, p->flags & ~(u32)CBH_FI_MASK);
   if (pl.kind == 2) s = std::string(pl.wide_kernel ? "cbh_check_kernel*(wide requests)+" : "") + (pl.n_gwords && b->dev.gres ? "cbh_walk2_pre_kernel+" : "") + "cbh_walk2_kernel";
-  else if (pl.kind == 1) s = pl.kernel == cbh_check_flat_kernel ? "cbh_check_flat_kernel" : "cbh_check_flat_kernel_any";
+  else if (pl.kind == 1) s = pl.kernel == cbh_check_flat_kernel ? "cbh_check_flat_kernel" : pl.kernel == cbh_check_flat_kernel_any ? "cbh_check_flat_kernel_any"
+                           : pl.kernel == cbh_check_flat_kernel_staged ? "cbh_check_flat_kernel_staged" : "cbh_check_flat_kernel_any_staged";
   else s = "cbh_check_kernel*";
   return s.c_str();
 }

@@ -101,6 +101,14 @@ static inline const char* cbh_parse_image(TableDev& d, std::vector<uint32_t>& me
       if (par[s] != CBH_NONE && par[s] >= s) return ("scopes are not numbered parents first");
   }
   if (!d.hash || !d.code || !d.str_off || !d.scope_flags) return ("blob is missing required sections");
+  {   // the longest resource-policy bucket: tables with long ones walk them 64 records at a time (cbh_check_flat.h stage_rec)
+    const CbhBlobSection* hs = find(CBH_SEC_HASH);
+    if (!hs || hs->nbytes < ((uint64_t)d.hash_mask + 1) * sizeof(CbhHashSlot)) return ("blob directory too small");
+    const CbhHashSlot* slots = reinterpret_cast<const CbhHashSlot*>(host_copy + hs->offset);
+    d.max_bucket = 0;
+    for (uint64_t i = 0; i <= d.hash_mask; ++i)
+      if (slots[i].k0 == CBH_B_RESOURCE && slots[i].v1 > d.max_bucket) d.max_bucket = slots[i].v1;
+  }
   return nullptr;
 }
 #endif  // !__HIP_DEVICE_COMPILE__

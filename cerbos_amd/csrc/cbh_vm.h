@@ -72,6 +72,7 @@ struct TableDev {
   u32 flags;
   u32 max_depth;                                            // longest scope chain of the table (entries), computed at load
   u32 n_scopes;                                             // scopes are numbered parents first (root = 0): a deeper scope has the larger index
+  u32 max_bucket;                                           // most rule records in one resource-policy bucket, computed at load (selects cbh_check_flat_kernel_staged)
 };
 
 struct BatchDev {

@@ -197,7 +197,7 @@ static int run_sim(const void* blob, size_t len, const cbh_batch* in, const cbh_
   // the same choice of kernels as the library makes (cbh_engine.hip plan_for); CBH_NO_FLAT / CBH_NO_WALK2 as there
   const bool has_globs = (a.t.nfa_words[0] | a.t.nfa_words[1] | a.t.nfa_words[2] | (a.t.flags & CBH_MF_HAS_ANY_PATTERN)) != 0;
   const CbhPlan pl = cbh_plan(a.t.flags, a.t.n_dr, has_globs, a.t.gslots_generic, a.t.gslots_all, g_max_actions, g_max_roles, g_plain, a.flags,
-                              getenv("CBH_NO_FLAT") != nullptr, getenv("CBH_NO_WALK2") != nullptr);
+                              getenv("CBH_NO_FLAT") != nullptr, getenv("CBH_NO_WALK2") != nullptr, getenv("CBH_FORCE_STAGED") ? 0xFFFFFFFFu : a.t.max_bucket);
   std::vector<uint64_t> gres((size_t)pl.n_gwords * in->n_requests + 1, 0xDDDDDDDDDDDDDDDDull);
   b.gres = pl.n_gwords ? gres.data() : nullptr; b.n_gwords = pl.n_gwords; b.n_gslots = pl.n_gslots;
   if (const char* e = getenv("CBH_HOSTSIM_REPORT")) { if (*e == '1') std::fprintf(stderr, "hostsim: kernel kind %d, %u result words\n", pl.kind, pl.n_gwords); }

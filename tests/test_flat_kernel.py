@@ -170,7 +170,7 @@ def test_flat_kernel_with_evaluator_call_vs_oracle(seed):
 
 @pytest.mark.parametrize("seed", range(200, 212))
 def test_flat_kernel_large_buckets_vs_oracle(seed):
-    """Policies of 14-80 rules: buckets above CBH_FLAT_SIFT_MIN are sifted by class masks, 64 records at a time."""
+    """Policies of 14-80 rules: tables with a bucket above CBH_FLAT_STAGE_MIN walk their records staged, 64 at a time."""
     from test_hostsim_golden import HostSimEvaluator
     _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False, many_rules=True)
 
@@ -189,6 +189,21 @@ def test_plain_batches_through_the_variant_with_the_call(monkeypatch):
     monkeypatch.setenv("CBH_FLAT_ANY", "1")
     for seed in range(6):
         _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False)
+
+
+def test_staged_record_walk_on_any_table(monkeypatch):
+    """CBH_FORCE_STAGED=1: the staged record walk (cbh_check_flat_kernel_staged / _any_staged: a bucket's records fetched
+    64 at a time into the lanes' registers, candidates picked by a ballot over the class masks) on stores of every size,
+    both variants, deep chains included - alike the scalar walk, which the other tests of this file pin."""
+    from test_hostsim_golden import HostSimEvaluator
+    monkeypatch.setenv("CBH_FORCE_STAGED", "1")
+    for seed in range(8):
+        _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False)
+    for seed in range(100, 104):
+        _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False, with_lists=True)
+    for seed in range(200, 204):
+        _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False, many_rules=True)
+    _run_seed(300, lambda lt: HostSimEvaluator(lt, Conf()), False, deep=True)
 
 
 def test_error_cases_do_occur():
@@ -218,3 +233,16 @@ def test_flat_kernel_large_buckets_on_gpu(seed):
 @pytest.mark.parametrize("seed", range(100, 116))
 def test_flat_kernel_with_evaluator_call_on_gpu(seed):
     _run_seed(seed, lambda lt: HipEvaluator(lt, Conf()), True, with_lists=True)
+
+
+@pytest.mark.parametrize("seed", range(400, 404))
+def test_flat_kernel_large_buckets_with_evaluator_call_vs_oracle(seed):
+    """Long buckets AND list-valued attributes: cbh_check_flat_kernel_any_staged."""
+    from test_hostsim_golden import HostSimEvaluator
+    _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False, with_lists=True, many_rules=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(400, 406))
+def test_flat_kernel_large_buckets_with_evaluator_call_on_gpu(seed):
+    _run_seed(seed, lambda lt: HipEvaluator(lt, Conf()), True, with_lists=True, many_rules=True)

@@ -14,7 +14,9 @@ from cerbos_amd.ruletable.build import rule_table_from_policies
 W = sys.argv[1] if len(sys.argv) > 1 else "C2"
 pol_fn, req_fn, n = {"C2": (workloads.c2_policies, workloads.c2_requests, 250_000),
                      "C3": (workloads.c3_policies, workloads.c3_requests, 1_000_000),
-                     "C4": (workloads.c4_policies, workloads.c4_requests, 500_000)}[W]
+                     "C4": (workloads.c4_policies, workloads.c4_requests, 500_000),
+                     "T": (lambda: workloads.c4_policies(seed=7, n_policies=100, rules_per_policy=100),
+                           lambda n: workloads.c4_requests(n, seed=7, n_policies=100), 250_000)}[W]
 capi.init(0)
 lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol_fn())))
 table = capi.Table(lt.blob)
@@ -28,8 +30,8 @@ assert (batch.req_u32[9] == 4).all(), "the tool reads lane 0's four policy / sco
 pol = res.policy.reshape(-1, 4)[::64].astype(np.int64)
 scp = res.scope.reshape(-1, 4)[::64].astype(np.int64)
 print(W, "waves", len(pol))
-for name, a in (("loads+classes", pol[:, 0]), ("chain_first", pol[:, 1]), ("walk", pol[:, 2]), ("fold", pol[:, 3]),
-                ("records", scp[:, 2]), ("rounds", scp[:, 3])):
+for name, a in (("loads+classes", pol[:, 0]), ("eval (in walk)", pol[:, 1]), ("walk", pol[:, 2]), ("staging (in walk)", pol[:, 3]),
+                ("records staged", scp[:, 2] & 0xFFFF), ("evals", scp[:, 2] >> 16), ("visits", scp[:, 3] >> 16), ("rounds", scp[:, 3] & 0xFFFF)):
     print("%-14s min %8d  p10 %8d  p50 %8d  p90 %8d  max %8d  mean %10.1f" % (name, a.min(), np.percentile(a, 10), np.median(a), np.percentile(a, 90), a.max(), a.mean()))
 t0 = (scp[:, 0] - scp[:, 0].min()) & 0xFFFFFFFF
 t1 = (scp[:, 1] - scp[:, 0].min()) & 0xFFFFFFFF
@@ -41,7 +43,7 @@ order = np.argsort(t0)
 nb = 10
 for k in range(nb):   # by position in the grid: when did these waves start / end
     sl = slice(k * len(pol) // nb, (k + 1) * len(pol) // nb)
-    print("  grid decile %d: start %.2f  end %.2f  life %.2f  records %.0f  rounds %.1f" % (k, t0[sl].mean() / 100.0, t1[sl].mean() / 100.0, life[sl].mean(), scp[sl, 2].mean(), scp[sl, 3].mean()))
+    print("  grid decile %d: start %.2f  end %.2f  life %.2f  records %.0f  rounds %.1f" % (k, t0[sl].mean() / 100.0, t1[sl].mean() / 100.0, life[sl].mean(), (scp[sl, 2] & 0xFFFF).mean(), (scp[sl, 3] & 0xFFFF).mean()))
 for _ in range(20):
     table.launch(db, now_ns=1, flags=0)
 table.synchronize()
