@@ -13,7 +13,7 @@ driver's 20 steps keep the GPU busy for ~50 ms).
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Launches of different batches overlap on the device: resident batches are dealt to a few streams at upload
-(cbh_table_set_resident_streams, default 3), so one launch's dispatch ramp fills what another's drain leaves idle.
+(cbh_table_set_resident_streams, default 4), so one launch's dispatch ramp fills what another's drain leaves idle.
 `roofline.achieved` is therefore the rate the device sustains over the timed region; `roofline.kernel_ms` the average
 begin-to-end time of one launch inside it; `roofline.serial` the same launches strictly one after the other on one stream.
 

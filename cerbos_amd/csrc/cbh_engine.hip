@@ -227,7 +227,7 @@ extern "C" void cbh_table_release(cbh_table* t) {
 static int replica_finish(Replica* r) {
   HIPCHK(hipSetDevice(r->device));
   HIPCHK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
-  static const int n_streams = [] { const char* e = getenv("CBH_RESIDENT_STREAMS"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > Replica::MAX_RESIDENT_STREAMS ? Replica::MAX_RESIDENT_STREAMS : v); }();
+  static const int n_streams = [] { const char* e = getenv("CBH_RESIDENT_STREAMS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > Replica::MAX_RESIDENT_STREAMS ? Replica::MAX_RESIDENT_STREAMS : v); }();
   r->n_rstreams = n_streams;   // (default; cbh_table_set_resident_streams changes it for the batches uploaded afterwards)
   r->rstreams[0] = r->stream;
   for (int i = 1; i < Replica::MAX_RESIDENT_STREAMS; ++i) HIPCHK(hipStreamCreateWithFlags(&r->rstreams[i], hipStreamNonBlocking));

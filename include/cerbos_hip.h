@@ -242,7 +242,7 @@ int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_params* p);
 int cbh_check_resident_many(cbh_table* t, cbh_device_batch* const* bs, uint32_t n, const cbh_params* p);
 /* Resident batches are dealt round-robin to a few streams of their device at upload (a batch keeps its stream, so everything
  * that touches it stays ordered) and launches of batches on different streams overlap on the device: the dispatch ramp of one
- * fills the CUs the drain of another leaves idle.  n = 1 .. 8 for the batches uploaded from now on (default 3; 1 = strictly one
+ * fills the CUs the drain of another leaves idle.  n = 1 .. 8 for the batches uploaded from now on (default 4; 1 = strictly one
  * launch after the other - the setting for timing a kernel by itself). */
 int cbh_table_set_resident_streams(cbh_table* t, uint32_t n);
 uint32_t cbh_table_resident_streams(const cbh_table* t);
