@@ -17,6 +17,7 @@ import re
 
 import struct
 
+from ..cel import fold as celfold
 from ..cel import parser as celparser
 from . import regex
 
@@ -194,7 +195,9 @@ class Params:
                     return value_to_ast(self.globals[name])
             return n
 
-        return _subst(ast, fn)
+        out = _subst(ast, fn)
+        # constant sub-expressions are computed here, once, instead of on every request (cel/fold.py)
+        return celfold.fold(out) if depth == 0 else out
 
 
 class ProgramBuilder:
