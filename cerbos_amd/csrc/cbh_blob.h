@@ -344,6 +344,13 @@ enum CbhOp {
   OP_STRCASE = 67,    // arg 1 lowerAscii / 2 upperAscii: TOS string -> the rope that reads it through the case mapping
   OP_LISTFN = 65,     // arg 0 reverse: TOS list -> reversed copy in the arena; 1 slice: pop end, start; TOS list -> the view
                       // [start, end) of it; 2 lists.range: TOS int n -> [0 .. n) in the arena
+  OP_IPFN = 68,       // cel-go ext.Network on a string the request supplies.  arg 0 isIP(s), 8 / 9 isIP(s, 4 / 6), 7 ip.isCanonical(s); 1 ip(s).family(),
+                      // 2 isUnspecified, 3 isLoopback, 4 isLinkLocalUnicast, 5 isLinkLocalMulticast, 6 isGlobalUnicast (an error where
+                      // ip(s) fails); 10: pop ip, cidr (strings) -> cidr(c).containsIP(ip)
+  OP_STRVIEW = 69,    // arg 0 substring(a): pop a; 1 substring(a, b): pop b, a; 2 charAt(i): pop i; 3 trim().  TOS string -> the rope that
+                      // is that window of it (code-point indices, cel-go ext/strings.go)
+  OP_STRREPLACE = 70, // pop new, old; TOS string s -> the rope s.replace(old, new): the pieces of s between the occurrences, `new` between them
+  OP_HIERCOMMON = 71, // pop c, b; TOS a (dot-delimited strings) -> hierarchy(a).commonAncestors(hierarchy(b)) == hierarchy(c)
   OP_NOPS
 };
 enum CbhIterKind { IT_ALL = 0, IT_EXISTS = 1, IT_EXISTS_ONE = 2, IT_FILTER = 3, IT_MAP = 4,   // filter / map build a list in the lane's arena

@@ -322,6 +322,137 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
         FAILTOP2(x, y, CBH_ERR_NO_SUCH_OVERLOAD);
         break;
       }
+      case OP_HIERCOMMON: {   // hierarchy(a).commonAncestors(hierarchy(b)) == hierarchy(c)
+        Val z = TOPV(0), y = TOPV(1), x = TOPV(2); sp -= 2;
+        if (x.t == CBH_T_ROPE || y.t == CBH_T_ROPE || z.t == CBH_T_ROPE) { if (live) L.status |= CBH_ST_UNSUPPORTED; SETTOP(mk_err()); break; }
+        if (x.t == CBH_T_STRING && y.t == CBH_T_STRING && z.t == CBH_T_STRING) { SETTOP(mk_bool(hier_common_eq(c, (u32)x.v, (u32)y.v, (u32)z.v))); break; }
+        if ((x.t == CBH_T_LIST || y.t == CBH_T_LIST || z.t == CBH_T_LIST) && x.t != CBH_T_ERR && y.t != CBH_T_ERR && z.t != CBH_T_ERR && live) L.status |= CBH_ST_UNSUPPORTED;
+        if (x.t == CBH_T_ERR || y.t == CBH_T_ERR) { SETTOP(x.t == CBH_T_ERR ? x : y); break; }
+        FAILTOP1(z, CBH_ERR_NO_SUCH_OVERLOAD);
+        break;
+      }
+      case OP_IPFN: {   // cel-go ext.Network on request strings (a: cbh_blob.h)
+        if (a == 10) {   // cidr(c).containsIP(ip): netip.ParsePrefix + netip.ParseAddr + Prefix.Contains
+          Val y = TOPV(0), x = TOPV(1); --sp;
+          ROPE_UNSUPPORTED2(x, y);
+          if (x.t != CBH_T_STRING || y.t != CBH_T_STRING) { FAILTOP2(x, y, CBH_ERR_NO_SUCH_OVERLOAD); break; }
+          gbytes pc2, pi; u32 nc, ni; u64 hi, lo;
+          str_span(c, (u32)x.v, pc2, nc); str_span(c, (u32)y.v, pi, ni);
+          if (parse_addr(pi, ni, hi, lo) == 0) { SETTOP(mk_err()); break; }
+          const int r = ip_in_range(pi, ni, pc2, nc);
+          if (r == -2 && live) L.status |= CBH_ST_UNSUPPORTED;
+          if (r < 0) { SETTOP(mk_err()); break; }
+          SETTOP(mk_bool(r == 1));
+          break;
+        }
+        Val x = TOPV(0);
+        ROPE_UNSUPPORTED2(x, x);
+        if (x.t != CBH_T_STRING) { FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD); break; }
+        gbytes p; u32 n; u64 hi, lo;
+        str_span(c, (u32)x.v, p, n);
+        const u32 fam = parse_addr(p, n, hi, lo);
+        if (a == 0 || a == 8 || a == 9) { SETTOP(mk_bool(fam != 0 && (a == 0 || fam == (a == 8 ? 4u : 6u)))); break; }
+        if (fam == 0) { SETTOP(mk_err()); break; }   // ip(s) / ip.isCanonical(s): "IP Address ... parse error"
+        if (a == 1) { SETTOP(mk(CBH_T_INT, (u64)fam)); break; }
+        if (a == 7) { SETTOP(mk_bool(addr_is_canonical(p, n, fam, hi, lo))); break; }
+        SETTOP(mk_bool(addr_is(a, fam, hi, lo)));
+        break;
+      }
+      case OP_STRVIEW: {   // a: 0 substring(from), 1 substring(from, to), 2 charAt(i), 3 trim()
+        const u32 nargs = a == 1 ? 2u : (a == 3 ? 0u : 1u);
+        Val to = mk(CBH_T_INT, 0), from = mk(CBH_T_INT, 0);
+        if (nargs == 2) { to = TOPV(0); from = TOPV(1); } else if (nargs == 1) from = TOPV(0);
+        sp -= (int)nargs;
+        Val x = TOPV(0);
+        if (x.t == CBH_T_ROPE) { if (live) L.status |= CBH_ST_UNSUPPORTED; SETTOP(mk_err()); break; }
+        if (x.t != CBH_T_STRING || from.t != CBH_T_INT || to.t != CBH_T_INT) {
+          if (x.t == CBH_T_ERR) break;
+          if (from.t == CBH_T_ERR) { SETTOP(from); break; }
+          if (to.t == CBH_T_ERR) { SETTOP(to); break; }
+          FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD); break;
+        }
+        gbytes p; u32 n; str_span(c, (u32)x.v, p, n);
+        u32 b0 = 0, b1 = n;   // the window in bytes
+        bool bad = false;
+        if (a == 3) {   // strings.TrimSpace: unicode.IsSpace
+          auto space_at = [&](u32 i, u32& len) -> bool {   // is there a space starting at byte i?
+            const u8 ch = p[i];
+            len = 1;
+            if (ch == ' ' || (ch >= 9 && ch <= 13)) return true;
+            if (ch == 0xC2 && i + 1 < n && (p[i + 1] == 0x85 || p[i + 1] == 0xA0)) { len = 2; return true; }
+            if (i + 2 < n) {
+              const u8 c1 = p[i + 1], c2 = p[i + 2];
+              len = 3;
+              if (ch == 0xE1 && c1 == 0x9A && c2 == 0x80) return true;
+              if (ch == 0xE2 && c1 == 0x80 && ((c2 >= 0x80 && c2 <= 0x8A) || c2 == 0xA8 || c2 == 0xA9 || c2 == 0xAF)) return true;
+              if (ch == 0xE2 && c1 == 0x81 && c2 == 0x9F) return true;
+              if (ch == 0xE3 && c1 == 0x80 && c2 == 0x80) return true;
+            }
+            return false;
+          };
+          u32 len;
+          while (b0 < b1 && space_at(b0, len)) b0 += len;
+          for (;;) {   // from the end: step back over one code point and test it
+            if (b1 <= b0) break;
+            u32 s0 = b1 - 1;
+            while (s0 > b0 && (p[s0] & 0xC0u) == 0x80u) --s0;
+            if (!space_at(s0, len) || s0 + len != b1) break;
+            b1 = s0;
+          }
+        } else {
+          u32 cps = 0;
+          for (u32 i = 0; i < n; ++i) cps += (p[i] & 0xC0u) != 0x80u;
+          const i64 f = (i64)from.v, t = a == 1 ? (i64)to.v : (a == 2 ? (i64)from.v + 1 : (i64)cps);
+          if (a == 2) bad = f < 0 || f > (i64)cps;          // charAt(size) is ""
+          else bad = f < 0 || f > (i64)cps || t < 0 || t > (i64)cps || f > t;
+          if (!bad) {
+            const u32 tt = (a == 2 && f == (i64)cps) ? (u32)cps : (u32)t;
+            u32 cp = 0; b0 = n; b1 = n;
+            for (u32 i = 0; i <= n; ++i) {   // byte offsets of code points f and tt
+              if (i == n || (p[i] & 0xC0u) != 0x80u) {
+                if (cp == (u32)f && b0 == n) b0 = i;
+                if (cp == tt) { b1 = i; break; }
+                ++cp;
+              }
+            }
+          }
+        }
+        if (bad) { SETTOP(mk_err()); break; }
+        if (b0 > CBH_ROPE_WINDOW_MAX || b1 - b0 > CBH_ROPE_WINDOW_MAX || ap >= CBH_ARENA_ENTRIES) { if (live) L.status |= CBH_ST_UNSUPPORTED; SETTOP(mk_err()); break; }
+        arena_put(c, ap, mk(CBH_T_STRING, rope_window((u32)x.v, b0, b1 - b0)));
+        SETTOP(mk_rope(ap, 1));
+        ++ap;
+        break;
+      }
+      case OP_STRREPLACE: {   // s.replace(old, new): every occurrence, left to right, not overlapping (strings.ReplaceAll)
+        Val nw = TOPV(0), old = TOPV(1), x = TOPV(2); sp -= 2;
+        if (x.t == CBH_T_ROPE || old.t == CBH_T_ROPE || nw.t == CBH_T_ROPE) { if (live) L.status |= CBH_ST_UNSUPPORTED; SETTOP(mk_err()); break; }
+        if (x.t != CBH_T_STRING || old.t != CBH_T_STRING || nw.t != CBH_T_STRING) {
+          if (x.t == CBH_T_ERR) break;
+          if (old.t == CBH_T_ERR) { SETTOP(old); break; }
+          if (nw.t == CBH_T_ERR) { SETTOP(nw); break; }
+          FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD); break;
+        }
+        gbytes p, q; u32 n, m; str_span(c, (u32)x.v, p, n); str_span(c, (u32)old.v, q, m);
+        if (m == 0 || n > CBH_ROPE_WINDOW_MAX) { if (live) L.status |= CBH_ST_UNSUPPORTED; SETTOP(mk_err()); break; }   // (an empty `old` matches between all code points)
+        const u32 start = ap;
+        u32 from = 0, i = 0;
+        bool full = false;
+        while (i + m <= n) {
+          u32 j = 0;
+          while (j < m && p[i + j] == q[j]) ++j;
+          if (j < m) { ++i; continue; }
+          if (ap + 2 > CBH_ARENA_ENTRIES) { full = true; break; }
+          if (i > from) arena_put(c, ap++, mk(CBH_T_STRING, rope_window((u32)x.v, from, i - from)));
+          arena_put(c, ap++, nw);
+          i += m; from = i;
+        }
+        if (!full && ap + 1 > CBH_ARENA_ENTRIES) full = true;
+        if (full) { ap = start; if (live) L.status |= CBH_ST_UNSUPPORTED; SETTOP(mk_err()); break; }
+        if (from < n || ap == start) arena_put(c, ap++, mk(CBH_T_STRING, rope_window((u32)x.v, from, n - from)));
+        SETTOP(mk_rope(start, ap - start));
+        break;
+      }
       case OP_TIMESTAMP: {
         Val x = TOPV(0);
         ROPE_UNSUPPORTED2(x, x);
@@ -354,9 +485,22 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
       }
       case OP_NOW: PUSHV(mk(CBH_T_TIMESTAMP, (u64)c.now_ns)); break;
       case OP_TS_GETTER: {    // a = getter kind; next word = the zone's offset in seconds (resolved at lowering)
-        const i64 off_s = (i64)(int)uload(&code[pc]); ++pc;
+        const u32 zw = uload(&code[pc]); ++pc;
         Val x = TOPV(0);
         i64 r = 0;
+        i64 off_s = (i64)(int)((zw & 0x80000000u) ? zw : (zw & 0x3FFFFFFFu));
+        if ((zw & 0xC0000000u) == 0x40000000u && x.t == CBH_T_TIMESTAMP) {
+          // an IANA zone: [n, from_0, offset_0, ...] in the table heap, seconds, ascending, covering 1900 .. 2100 (celc.py
+          // _named_zone_table); the offset in force at the timestamp = the last entry not after it
+          const u32 at = zw & 0x3FFFFFFFu;
+          const u32 nz = (u32)c.t.theap_val[at];
+          const i64 ns = (i64)x.v;
+          const i64 sec = ns >= 0 ? ns / 1000000000ll : -((-ns + 999999999ll) / 1000000000ll);
+          if (nz == 0 || sec < (i64)c.t.theap_val[at + 1] || sec >= 4102444800ll) { if (live) L.status |= CBH_ST_UNSUPPORTED; SETTOP(mk_err()); break; }
+          u32 lo = 0, hi = nz;   // entries [lo, hi): from_lo <= sec
+          while (hi - lo > 1) { const u32 mid = (lo + hi) / 2; if ((i64)c.t.theap_val[at + 1 + 2 * mid] <= sec) lo = mid; else hi = mid; }
+          off_s = (i64)c.t.theap_val[at + 2 + 2 * lo];
+        }
         if (!ts_getter(x, a, off_s, r)) { FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD); break; }
         SETTOP(mk(CBH_T_INT, (u64)r));
         break;

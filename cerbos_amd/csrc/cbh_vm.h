@@ -292,6 +292,31 @@ __device__ inline bool hier_pred(const Ctx& c, u32 kind, u32 a, u32 b) {
   return da <= db ? seg_prefix(pa, na, pb, nb) : seg_prefix(pb, nb, pa, na);   // overlaps: the shorter leads the longer
 }
 
+// hierarchy(a).commonAncestors(hierarchy(b)) == hierarchy(c) over the three dot-delimited strings (types/hierarchy.go:296-322:
+// hierarchies of equal length are both cut by their last segment first; the ancestors are the leading segments they share).
+// An empty ancestor list equals no hierarchy a string spells (strings.Split never returns an empty slice).
+__device__ inline bool hier_common_eq(const Ctx& c, u32 a, u32 b, u32 cc) {
+  gbytes pa, pb, pc; u32 na, nb, nc;
+  str_span(c, a, pa, na); str_span(c, b, pb, nb); str_span(c, cc, pc, nc);
+  u32 sa = 1, sb = 1;
+  for (u32 i = 0; i < na; ++i) sa += pa[i] == '.';
+  for (u32 i = 0; i < nb; ++i) sb += pb[i] == '.';
+  const u32 limit = sa == sb ? sa - 1u : (sa < sb ? sa : sb);
+  u32 ia = 0, ib = 0, m = 0, end_a = 0;   // end_a: one past the m-th shared segment of a
+  while (m < limit) {
+    u32 ea = ia, eb = ib;
+    while (ea < na && pa[ea] != '.') ++ea;
+    while (eb < nb && pb[eb] != '.') ++eb;
+    bool same = (ea - ia) == (eb - ib);
+    for (u32 k = 0; same && k < ea - ia; ++k) same = pa[ia + k] == pb[ib + k];
+    if (!same) break;
+    ++m; end_a = ea; ia = ea + 1; ib = eb + 1;
+  }
+  if (m == 0 || end_a != nc) return false;
+  for (u32 i = 0; i < nc; ++i) if (pa[i] != pc[i]) return false;
+  return true;
+}
+
 // ---- heap ----------------------------------------------------------------------------
 __device__ __forceinline__ u32 cont_sel(u64 v) { return (u32)(v >> 62); }
 __device__ __forceinline__ u32 cont_off(u64 v) { return (u32)((v >> 32) & 0x3FFFFFFFu); }
@@ -321,11 +346,20 @@ __device__ __forceinline__ Val heap_get(const Ctx& c, u32 sel, u32 idx) {
 __device__ __forceinline__ u32 rope_parts(u64 v) { return (u32)v & 0xFFFFu; }
 __device__ __forceinline__ Val mk_rope(u32 off, u32 parts) { return mk(CBH_T_ROPE, ((u64)CBH_HEAP_LOCAL << 62) | ((u64)off << 32) | parts); }
 __device__ __forceinline__ bool is_strlike(u32 t) { return t == CBH_T_STRING || t == CBH_T_ROPE; }
+// A part may be a WINDOW of its string (substring / charAt / trim / the pieces replace() keeps): bits 34-48 = first byte,
+// bits 49-63 = bytes + 1 (0 = the whole string).
+#define CBH_ROPE_WINDOW_MAX 0x7FFEu
+__device__ __forceinline__ u64 rope_window(u32 sid, u32 first, u32 bytes) { return (u64)sid | ((u64)first << 34) | ((u64)(bytes + 1u) << 49); }
+__device__ __forceinline__ void part_span(const Ctx& c, u64 part, gbytes& p, u32& n) {
+  str_span(c, (u32)part, p, n);
+  const u32 ln = (u32)(part >> 49) & 0x7FFFu;
+  if (ln) { p += (u32)(part >> 34) & 0x7FFFu; n = ln - 1u; }
+}
 __device__ inline u32 sl_len(const Ctx& c, Val x) {   // bytes of a string or rope
   gbytes p; u32 n;
   if (x.t == CBH_T_STRING) { str_span(c, (u32)x.v, p, n); return n; }
   u32 tot = 0;
-  for (u32 k = 0; k < rope_parts(x.v); ++k) { str_span(c, (u32)heap_get(c, CBH_HEAP_LOCAL, cont_off(x.v) + k).v, p, n); tot += n; }
+  for (u32 k = 0; k < rope_parts(x.v); ++k) { part_span(c, heap_get(c, CBH_HEAP_LOCAL, cont_off(x.v) + k).v, p, n); tot += n; }
   return tot;
 }
 __device__ inline u32 sl_byte(const Ctx& c, Val x, u32 i) {   // its i-th byte, through the part's case mode (i < sl_len)
@@ -334,7 +368,7 @@ __device__ inline u32 sl_byte(const Ctx& c, Val x, u32 i) {   // its i-th byte, 
   u32 mode = 0;
   for (u32 k = 0; k < rope_parts(x.v); ++k) {
     const u64 part = heap_get(c, CBH_HEAP_LOCAL, cont_off(x.v) + k).v;
-    str_span(c, (u32)part, p, n);
+    part_span(c, part, p, n);
     if (i < n) { b = p[i]; mode = (u32)(part >> 32) & 3u; break; }
     i -= n;
   }
@@ -699,6 +733,69 @@ __device__ inline int ip_in_range(gbytes pi, u32 ni, gbytes pc, u32 nc) {
   const u64 mh = bits == 0 ? 0ull : (bits >= 64 ? ~0ull : (~0ull << (64 - bits)));
   const u64 ml = bits <= 64 ? 0ull : (bits >= 128 ? ~0ull : (~0ull << (128 - bits)));
   return ((ih ^ nh) & mh) == 0 && ((il ^ nl) & ml) == 0;
+}
+
+// netip.ParseAddr as cel-go's ext.Network reads an address (isIP / ip() / cidr().containsIP): no zone, and an IPv4-mapped
+// IPv6 address is refused.  -> 0 not an address, else the family (4 / 6) and the 128 bits.
+__device__ inline u32 parse_addr(gbytes p, u32 n, u64& hi, u64& lo) {
+  bool v6 = false;
+  for (u32 i = 0; i < n; ++i) v6 |= p[i] == ':';
+  hi = lo = 0;
+  if (!v6) { u32 v4; if (!parse_ipv4(p, n, v4)) return 0; lo = v4; return 4; }
+  if (!parse_ipv6(p, n, hi, lo)) return 0;
+  if (hi == 0 && (lo >> 32) == 0xFFFFull) return 0;
+  return 6;
+}
+// the predicates of netip.Addr (family 4: the address in the low 32 bits of `lo`)
+__device__ inline bool addr_is(u32 what, u32 fam, u64 hi, u64 lo) {
+  const bool v4 = fam == 4;
+  const u32 a4 = (u32)lo;
+  const bool unspec = v4 ? a4 == 0 : (hi == 0 && lo == 0);
+  const bool loop = v4 ? (a4 >> 24) == 127u : (hi == 0 && lo == 1);
+  const bool multicast = v4 ? (a4 >> 28) == 0xEu : (hi >> 56) == 0xFFull;
+  const bool ll_uni = v4 ? (a4 >> 16) == 0xA9FEu : (hi >> 54) == (0xFE80ull >> 6);
+  const bool ll_multi = v4 ? (a4 >> 8) == 0xE00000u : ((hi >> 48) & 0xFF0Full) == 0xFF02ull;
+  switch (what) {
+    case 2: return unspec;
+    case 3: return loop;
+    case 4: return ll_uni;
+    case 5: return ll_multi;
+    default: return !unspec && !(v4 && a4 == 0xFFFFFFFFu) && !loop && !multicast && !ll_uni;   // 6: isGlobalUnicast
+  }
+}
+// Is the text netip.Addr.String() of the address it spells?  (IPv4: the parser admits nothing else; IPv6: RFC 5952 -
+// lower-case hex without leading zeros, the longest run of two or more zero groups, leftmost on a tie, as "::")
+__device__ inline bool addr_is_canonical(gbytes p, u32 n, u32 fam, u64 hi, u64 lo) {
+  if (fam == 4) return true;
+  u32 g[8];
+  for (int k = 0; k < 4; ++k) { g[k] = (u32)(hi >> (48 - 16 * k)) & 0xFFFFu; g[4 + k] = (u32)(lo >> (48 - 16 * k)) & 0xFFFFu; }
+  int best = -1, best_len = 0;
+  for (int k = 0; k < 8;) {
+    if (g[k] != 0) { ++k; continue; }
+    int e = k;
+    while (e < 8 && g[e] == 0) ++e;
+    if (e - k >= 2 && e - k > best_len) { best = k; best_len = e - k; }
+    k = e;
+  }
+  u32 i = 0;
+  for (int k = 0; k < 8; ++k) {
+    if (k == best) {
+      if (i + 2 > n || p[i] != ':' || p[i + 1] != ':') return false;
+      i += 2; k += best_len - 1;
+      continue;
+    }
+    if (k > 0 && k != best + best_len) { if (i >= n || p[i] != ':') return false; ++i; }
+    bool started = false;
+    for (int sh = 12; sh >= 0; sh -= 4) {
+      const u32 d = (g[k] >> sh) & 0xFu;
+      if (d == 0 && !started && sh != 0) continue;
+      started = true;
+      const u8 ch = (u8)(d < 10 ? '0' + d : 'a' + d - 10);
+      if (i >= n || p[i] != ch) return false;
+      ++i;
+    }
+  }
+  return i == n;
 }
 
 // ---- interpreter -----------------------------------------------------------------------

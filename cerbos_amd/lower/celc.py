@@ -30,7 +30,7 @@ from . import regex
  OP_TODOUBLE, OP_TOSTRING_UNSUPPORTED, OP_INIPRANGE, OP_UNSUPPORTED, OP_TS_GETTER,
  OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN, OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC,
  OP_TREE_END, OP_HIER, OP_MATCHES, OP_INDEXOF, OP_STREQ_CASE, OP_VARSCOPE, OP_OUT, OP_LISTOP, OP_LISTFN, OP_STRCAT,
- OP_STRCASE) = range(68)
+ OP_STRCASE, OP_IPFN, OP_STRVIEW, OP_STRREPLACE, OP_HIERCOMMON) = range(72)
 
 TREE_KINDS = {"all": 0, "any": 1, "none": 2}
 COND_LEAF = 0x80000000
@@ -254,6 +254,21 @@ class ProgramBuilder:
             self.const_tag.append(tag)
             self.const_val.append(val)
         return i
+
+    def zone_table(self, name, table):
+        """Offset in the table heap of a zone's [n, from, offset, ...] integers (one copy per zone)."""
+        if not hasattr(self, "_zones"):
+            self._zones = {}
+        at = self._zones.get(name)
+        if at is None:
+            at = self._zones[name] = len(self.theap_tag)
+            vals = [len(table)] + [x for pair in table for x in pair]
+            for v in vals:
+                self.theap_tag.append(T_INT)
+                self.theap_val.append(v & 0xFFFFFFFFFFFFFFFF)
+            if at >= 0x40000000:
+                raise LoweringError("table heap too large for a zone table")
+        return at
 
     def column(self, root, keys):
         k = (root, tuple(keys))
@@ -601,6 +616,7 @@ class _Unsupported(Exception):
 
 
 # OP_HIER kinds (cbh_vm.h hier_pred)
+_IP_METHODS = {"family": 1, "isUnspecified": 2, "isLoopback": 3, "isLinkLocalUnicast": 4, "isLinkLocalMulticast": 5, "isGlobalUnicast": 6}
 _HIER_PREDICATES = {"ancestorOf": 0, "descendentOf": 1, "immediateParentOf": 2, "immediateChildOf": 3, "siblingOf": 4, "overlaps": 5}
 
 # OP_TS_GETTER kinds (cbh_interp.h): what cel-go's getters return for a timestamp (and, for the last four, a duration)
@@ -633,6 +649,49 @@ def _fixed_zone_seconds(ast):
     return (-1 if neg else 1) * (abs(h) * 3600 + m * 60)
 
 
+_ZONE_FROM, _ZONE_TO = -2208988800, 4102444800   # 1900-01-01 .. 2100-01-01 UTC: what a lowered zone table covers
+_zone_tables = {}
+
+
+def _named_zone_table(name):
+    """The UTC offsets of an IANA zone as [(from unix second, seconds east of UTC), ...] over 1900 .. 2100 - what Go's
+    time.LoadLocation + Time.In amount to for the getters - read off the zone database through zoneinfo: the offset is
+    sampled day by day and every change bisected to the second.  None when the name is not in the database."""
+    if name in _zone_tables:
+        return _zone_tables[name]
+    import datetime
+    import zoneinfo
+    table = None
+    try:
+        if name and "/" != name[:1] and ".." not in name and name != "Local":
+            zi = zoneinfo.ZoneInfo(name)
+            utc = datetime.timezone.utc
+
+            def off(t):
+                return int(datetime.datetime.fromtimestamp(t, utc).astimezone(zi).utcoffset().total_seconds())
+            table = [(_ZONE_FROM, off(_ZONE_FROM))]
+            t, cur = _ZONE_FROM, table[0][1]
+            while t < _ZONE_TO:
+                nt = min(t + 86400, _ZONE_TO)
+                o = off(nt)
+                while o != cur:   # a change in (t, nt]: bisect to its second (twice when two changes share the day)
+                    lo, hi = t, nt
+                    while hi - lo > 1:
+                        mid = (lo + hi) // 2
+                        if off(mid) == cur:
+                            lo = mid
+                        else:
+                            hi = mid
+                    cur = off(hi)
+                    table.append((hi, cur))
+                    t = hi
+                t = nt
+    except Exception:   # unknown zone, no zone database
+        table = None
+    _zone_tables[name] = table
+    return table
+
+
 def _int_lit_as_double(ast):
     if ast[0] == "lit" and ast[1] in ("int", "uint") and abs(ast[2]) <= (1 << 53):
         return ("lit", "double", float(ast[2]))
@@ -645,7 +704,10 @@ def _builds_string(ast):
     if k == "lit":
         return ast[1] == "string"
     if k == "call":
-        return ast[1] in ("lowerAscii", "upperAscii") and ast[2] is not None and not ast[3]
+        if ast[1] in ("lowerAscii", "upperAscii", "trim") and ast[2] is not None and not ast[3]:
+            return True
+        return ast[2] is not None and ((ast[1] in ("charAt",) and len(ast[3]) == 1) or (ast[1] == "substring" and len(ast[3]) in (1, 2))
+                                       or (ast[1] == "replace" and len(ast[3]) == 2))
     if k == "bin" and ast[1] == "+":
         return _builds_string(ast[2]) or _builds_string(ast[3])
     return False
@@ -984,6 +1046,21 @@ class _FuncCompiler:
                     self._expr(sides[0])
                     self._expr(sides[1])
                     return self.emit(OP_STREQ_CASE, modes[0] | (modes[1] << 2) | ((1 if op == "!=" else 0) << 4), -1)
+            if op in ("==", "!="):
+                # hierarchy(a).commonAncestors(hierarchy(b)) == hierarchy(c) (either order): the ancestors are never built - the
+                # device walks the segments the two strings share and compares them with c's (cbh_vm.h hier_common_eq)
+                def hier_of(x):
+                    return x[3][0] if x[0] == "call" and x[1] == "hierarchy" and x[2] is None and len(x[3]) == 1 else None
+                for lhs, rhs in ((ast[2], ast[3]), (ast[3], ast[2])):
+                    if lhs[0] == "call" and lhs[1] == "commonAncestors" and lhs[2] is not None and len(lhs[3]) == 1:
+                        a, b, c3 = hier_of(lhs[2]), hier_of(lhs[3][0]), hier_of(rhs)
+                        if a is not None and b is not None and c3 is not None:
+                            self.pb.reads_string_bytes = True
+                            self._expr(a)
+                            self._expr(b)
+                            self._expr(c3)
+                            self.emit(OP_HIERCOMMON, 0, -2)
+                            return self.emit(OP_NOT) if op == "!=" else None
             if op == "+" and (self._stringy(ast[2]) or self._stringy(ast[3])):
                 # string concatenation where one side is visibly a string: a rope (cbh_vm.h) - the parts side by side in the
                 # lane's arena, no byte copied; equality, `in`, startsWith / endsWith / contains and size() read ropes
@@ -1035,9 +1112,48 @@ class _FuncCompiler:
             self._expr(allargs[1])
             self.emit(op, 0, -1)
 
+        # cel-go ext.Network on strings the request supplies (constant operands were folded by the lowering, cel/fold.py)
+        def ip_of(x):
+            return x[3][0] if x[0] == "call" and x[1] == "ip" and x[2] is None and len(x[3]) == 1 else None
+        if name == "isIP" and target is None and n in (1, 2):
+            fam = 0
+            if n == 2:
+                if args[1][0] != "lit" or args[1][1] != "int" or args[1][2] not in (4, 6):
+                    return self.unsupported("function isIP/2 with a computed version")
+                fam = 8 if args[1][2] == 4 else 9
+            self.pb.reads_string_bytes = True
+            self._expr(args[0])
+            return self.emit(OP_IPFN, fam)
+        if name == "isCanonical" and target == ("ident", "ip") and "ip" not in self.locals and n == 2:
+            self.pb.reads_string_bytes = True
+            self._expr(args[0])
+            return self.emit(OP_IPFN, 7)
+        if name in _IP_METHODS and target is not None and ip_of(target) is not None and n == 1:
+            self.pb.reads_string_bytes = True
+            self._expr(ip_of(target))
+            return self.emit(OP_IPFN, _IP_METHODS[name])
+        if name == "containsIP" and target is not None and n == 2 and target[0] == "call" and target[1] == "cidr" and target[2] is None \
+                and len(target[3]) == 1:
+            self.pb.reads_string_bytes = True
+            self._expr(target[3][0])
+            self._expr(ip_of(args[0]) if ip_of(args[0]) is not None else args[0])
+            return self.emit(OP_IPFN, 10, -1)
         ns = target is not None and target[0] == "ident" and target[1] in ("sets", "math", "lists", "base64", "strings", "regex") \
             and target[1] not in self.locals
         if not ns:
+            if target is not None and ((name == "substring" and n in (2, 3)) or (name == "charAt" and n == 2) or (name == "trim" and n == 1)):
+                # a window of the string, as a rope (cbh_vm.h): indices count code points (cel-go ext/strings.go)
+                self.pb.needs_arena = True
+                self.pb.reads_string_bytes = True
+                for x in allargs:
+                    self._expr(x)
+                return self.emit(OP_STRVIEW, {"substring": n - 2, "charAt": 2, "trim": 3}[name], -(n - 1))
+            if target is not None and name == "replace" and n == 3:
+                self.pb.needs_arena = True
+                self.pb.reads_string_bytes = True
+                for x in allargs:
+                    self._expr(x)
+                return self.emit(OP_STRREPLACE, 0, -2)
             if name == "size" and n == 1:
                 return unary(OP_SIZE)
             if name in ("startsWith", "endsWith", "contains") and n == 2:
@@ -1084,11 +1200,21 @@ class _FuncCompiler:
                 off = 0
                 if n == 2:
                     off = _fixed_zone_seconds(args[0])
+                    if off is None and args[0][0] == "lit" and args[0][1] == "string" and ":" not in args[0][2]:
+                        # an IANA name: its offsets over 1900 .. 2100 travel in the table's constant heap
+                        # ([n, from_0, offset_0, from_1, offset_1, ...]); the device looks the timestamp up (cbh_interp.h)
+                        table = _named_zone_table(args[0][2])
+                        if table is None:
+                            return self.unsupported("function %s/%d: time zone %r is not in the zone database" % (name, n, args[0][2]))
+                        self._expr(target)
+                        self.emit(OP_TS_GETTER, _TS_GETTERS[name])
+                        self.word(0x40000000 | self.pb.zone_table(args[0][2], table))
+                        return None
                     if off is None:
-                        return self.unsupported("function %s/%d with a named or computed time zone" % (name, n))
+                        return self.unsupported("function %s/%d with a computed time zone" % (name, n))
                 self._expr(target)
                 self.emit(OP_TS_GETTER, _TS_GETTERS[name])
-                self.word(off & 0xFFFFFFFF)
+                self.word(off & 0x3FFFFFFF if off >= 0 else off & 0xFFFFFFFF)
                 return None
             if name == "int" and n == 1 and target is None:
                 return unary(OP_TOINT)

@@ -197,6 +197,8 @@ def cel_equal(a, b):
         return True
     if isinstance(a, (Timestamp, Duration)):
         return a == b
+    if isinstance(a, (Optional, NetIP, NetCIDR)):
+        return a == b
     return a is b
 
 
@@ -1282,6 +1284,202 @@ def _math_extreme(pick):
     return f
 
 
+# ---- cel-go ext.Network (v0.30.0 ext/network.go, not vendored: restated from its documentation - the k8s IP / CIDR library
+# it ports): addresses are netip.Addr values parsed with netip.ParseAddr, zones and IPv4-mapped IPv6 forms refused;
+# networks are netip.Prefix values parsed with netip.ParsePrefix.  Pinned by cel_eval/network.yaml.
+class NetIP:
+    def __init__(self, addr):
+        self.addr = addr
+
+    def __eq__(self, o):
+        return isinstance(o, NetIP) and self.addr == o.addr
+
+    def __hash__(self):
+        return hash(self.addr)
+
+
+class NetCIDR:
+    def __init__(self, addr, bits):
+        self.addr, self.bits = addr, bits
+
+    def __eq__(self, o):
+        return isinstance(o, NetCIDR) and (self.addr, self.bits) == (o.addr, o.bits)
+
+    def __hash__(self):
+        return hash((self.addr, self.bits))
+
+    def network(self):
+        return ipaddress.ip_network("%s/%d" % (self.addr, self.bits), strict=False)
+
+
+def _netip_parse(text):
+    """netip.ParseAddr, then the two refusals of the library."""
+    if not isinstance(text, str):
+        raise no_such_overload()
+    if "%" in text:
+        raise CelError("IP address with zone value is not allowed")
+    if ":" not in text:
+        parts = text.split(".")
+        if len(parts) != 4 or not all(p.isascii() and p.isdigit() and (p == "0" or p[0] != "0") and int(p) < 256 and len(p) <= 3 for p in parts):
+            raise CelError("IP Address %r parse error during conversion from string" % text)
+        return ipaddress.IPv4Address(text)
+    try:
+        a = ipaddress.IPv6Address(text)
+    except ValueError:
+        raise CelError("IP Address %r parse error during conversion from string" % text)
+    if a.ipv4_mapped is not None:
+        raise CelError("IPv4-mapped IPv6 address is not allowed")
+    return a
+
+
+def _netip_prefix(text):
+    if not isinstance(text, str):
+        raise no_such_overload()
+    addr, sep, bits = text.rpartition("/")
+    if not sep or not bits.isascii() or not bits.isdigit() or (len(bits) > 1 and bits[0] == "0"):
+        raise CelError("network address parse error during conversion from string")
+    try:
+        a = _netip_parse(addr)
+    except CelError:
+        raise CelError("network address parse error during conversion from string")
+    if int(bits) > a.max_prefixlen:
+        raise CelError("network address parse error during conversion from string")
+    return NetCIDR(a, int(bits))
+
+
+def _try(fn, *a):
+    try:
+        fn(*a)
+        return True
+    except CelError as e:
+        if "no such overload" in str(e):
+            raise
+        return False
+
+
+def _n_is_ip(env, s, version=None):
+    _need(s, str)
+    if version is not None and not is_int(version):
+        raise no_such_overload()
+    try:
+        a = _netip_parse(s)
+    except CelError:
+        return False
+    return version is None or a.version == version
+
+
+def _n_ip(env, v):
+    if isinstance(v, NetCIDR):
+        return NetIP(v.addr)
+    return NetIP(_netip_parse(v))
+
+
+def _n_global_unicast(a):
+    # netip.Addr.IsGlobalUnicast: not the zero / unspecified / IPv4 broadcast / loopback / multicast / link-local unicast address
+    if a.version == 4 and a == ipaddress.IPv4Address("255.255.255.255"):
+        return False
+    return not (a.is_unspecified or a.is_loopback or a.is_multicast or a.is_link_local)
+
+
+def _n_ll_multicast(a):
+    if a.version == 4:
+        return a in ipaddress.ip_network("224.0.0.0/24")
+    return a.packed[0] == 0xFF and (a.packed[1] & 0x0F) == 0x02
+
+
+def _nip(v):
+    if not isinstance(v, NetIP):
+        raise no_such_overload()
+    return v.addr
+
+
+def _ncidr(v):
+    if not isinstance(v, NetCIDR):
+        raise no_such_overload()
+    return v
+
+
+def _n_contains_ip(env, c, ip):
+    a = ip.addr if isinstance(ip, NetIP) else _netip_parse(ip)
+    return a.version == _ncidr(c).addr.version and a in c.network()
+
+
+def _n_contains_cidr(env, c, other):
+    o = other if isinstance(other, NetCIDR) else _netip_prefix(other)
+    c = _ncidr(c)
+    return o.addr.version == c.addr.version and c.bits <= o.bits and o.addr in c.network()
+
+
+# ---- cel-go ext.Regex / optional values (what the reference's string_funcs.yaml exercises)
+class Optional:
+    def __init__(self, *value):
+        self.has = bool(value)
+        self.value = value[0] if value else None
+
+    def __eq__(self, o):
+        return isinstance(o, Optional) and self.has == o.has and (not self.has or cel_equal(self.value, o.value))
+
+    def __hash__(self):
+        return hash(self.has)
+
+
+def _rx_replace(env, s, pattern, repl, limit=-1):
+    _need(s, str); _need(repl, str)
+    if not is_int(limit):
+        raise no_such_overload()
+    rx = _re(_need(pattern, str))
+    # the replacement names groups \0 .. \9; any other backslash sequence is an error (ext/regex.go)
+    out, i = [], 0
+    while i < len(repl):
+        if repl[i] == "\\":
+            if i + 1 >= len(repl) or not repl[i + 1].isdigit():
+                raise CelError("invalid replacement string")
+            if int(repl[i + 1]) > rx.groups:
+                raise CelError("replacement string references a group that does not exist")
+            out.append("\\g<%s>" % repl[i + 1]); i += 2
+        else:
+            out.append(repl[i].replace("\\", "\\\\")); i += 1
+    if limit == 0:
+        return s
+    return rx.sub("".join(out), s, count=0 if limit < 0 else limit)
+
+
+def _rx_extract(env, s, pattern):
+    rx = _re(_need(pattern, str))
+    if rx.groups > 1:
+        raise CelError("regular expression has more than one capturing group")
+    m = rx.search(_need(s, str))
+    if m is None:
+        return Optional()
+    got = m.group(rx.groups)
+    return Optional(got) if got is not None else Optional()
+
+
+def _rx_extract_all(env, s, pattern):
+    rx = _re(_need(pattern, str))
+    if rx.groups > 1:
+        raise CelError("regular expression has more than one capturing group")
+    out = []
+    for m in rx.finditer(_need(s, str)):
+        if rx.groups == 0:
+            out.append(m.group(0))
+        elif m.group(1):
+            out.append(m.group(1))
+    return out
+
+
+def _opt(v):
+    if not isinstance(v, Optional):
+        raise no_such_overload()
+    return v
+
+
+def _o_value(env, o):
+    if not _opt(o).has:
+        raise CelError("optional.none() dereference")
+    return o.value
+
+
 _GLOBAL_FUNCS = {
     "size": _f_size, "int": _f_int, "uint": _f_uint, "double": _f_double, "string": _f_string,
     "bool": _f_bool, "bytes": _f_bytes, "timestamp": _f_timestamp, "duration": _f_duration,
@@ -1296,6 +1494,8 @@ _GLOBAL_FUNCS = {
     "matches": _m_matches,
     "inIPAddrRange": _m_in_ip_range,
     "hierarchy": _f_hierarchy,
+    "isIP": _n_is_ip, "ip": _n_ip,
+    "isCIDR": lambda env, s: _try(_netip_prefix, _need(s, str)), "cidr": lambda env, s: _netip_prefix(s),
 }
 
 _METHODS = {
@@ -1337,9 +1537,22 @@ _METHODS = {
     "getMinutes": _dur_or_ts(lambda ns: _trunc_div(ns, 60_000_000_000), lambda st, ns: st.minute),
     "getSeconds": _dur_or_ts(lambda ns: _trunc_div(ns, 1_000_000_000), lambda st, ns: st.second),
     "getMilliseconds": _dur_or_ts(lambda ns: _trunc_div(ns, 1_000_000), lambda st, ns: ns // 1_000_000),
+    "family": lambda env, a: _nip(a).version,
+    "isUnspecified": lambda env, a: _nip(a).is_unspecified,
+    "isLoopback": lambda env, a: _nip(a).is_loopback,
+    "isLinkLocalUnicast": lambda env, a: _nip(a).is_link_local,
+    "isLinkLocalMulticast": lambda env, a: _n_ll_multicast(_nip(a)),
+    "isGlobalUnicast": lambda env, a: _n_global_unicast(_nip(a)),
+    "containsIP": _n_contains_ip, "containsCIDR": _n_contains_cidr,
+    "prefixLength": lambda env, c: _ncidr(c).bits,
+    "isMask": lambda env, c: _ncidr(c).network().network_address == c.addr,
+    "masked": lambda env, c: NetCIDR(_ncidr(c).network().network_address, c.bits),
+    "ip": lambda env, c: NetIP(_ncidr(c).addr),
+    "hasValue": lambda env, o: _opt(o).has, "value": _o_value,
+    "orValue": lambda env, o, d: o.value if _opt(o).has else d,
 }
 
-_NAMESPACES = {"sets", "lists", "math", "base64", "strings"}
+_NAMESPACES = {"sets", "lists", "math", "base64", "strings", "regex", "optional", "ip"}
 
 
 def _lists_range(env, n):
@@ -1364,5 +1577,8 @@ _NS_FUNCS = {
     ("math", "isInf"): lambda env, v: math.isinf(_need(v, float)),
     ("base64", "encode"): lambda env, b: base64.b64encode(_need(b, bytes)).decode("ascii"),
     ("base64", "decode"): lambda env, s: base64.b64decode(_need(s, str) + "=" * (-len(s) % 4)),
+    ("regex", "replace"): _rx_replace, ("regex", "extract"): _rx_extract, ("regex", "extractAll"): _rx_extract_all,
+    ("optional", "of"): lambda env, v: Optional(v), ("optional", "none"): lambda env: Optional(),
+    ("ip", "isCanonical"): lambda env, s: str(_netip_parse(s)) == s,
     ("strings", "quote"): lambda env, s: '"%s"' % _need(s, str).replace("\\", "\\\\").replace('"', '\\"'),
 }
