@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "cbh_check_batch", "cbh_trace_batch", "cbh_batch_upload", "cbh_batch_upload_on", "cbh_batch_release", "cbh_check_resident",
     "cbh_synchronize", "cbh_result_download", "cbh_kernel_time_ms", "cbh_plan_describe",
     "cbh_check_resident_many", "cbh_table_set_resident_streams", "cbh_table_resident_streams",
+    "cbh_wire_flatten", "cbh_wire_spans_download",
 ]
 
 
@@ -67,6 +68,14 @@ class CResult(C.Structure):
 
 class CTrace(C.Structure):
     _fields_ = [("records", C.c_void_p), ("capacity", C.c_uint32), ("count", C.c_uint32)]
+
+
+class CWireInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("n_requests", "n_tuples", "n_host", "first_bad", "dict_slots", "heap_len", "fill_runs", "reserved")]
+
+
+class HostFlattenerNeeded(RuntimeError):
+    """cbh_wire_flatten returned 1: these messages are the host flattener's (libcerbos_ingest.so) - same results, other road."""
 
 
 TRACE_RECORD_WORDS = 8
@@ -147,6 +156,10 @@ def load():
     lib.cbh_table_set_resident_streams.restype = i32
     lib.cbh_table_resident_streams.argtypes = [vp]
     lib.cbh_table_resident_streams.restype = u32
+    lib.cbh_wire_flatten.argtypes = [vp, u32, vp, vp, u32, C.c_char_p, C.c_char_p, C.POINTER(vp), C.POINTER(CWireInfo)]
+    lib.cbh_wire_flatten.restype = i32
+    lib.cbh_wire_spans_download.argtypes = [vp, vp, vp, vp, vp]
+    lib.cbh_wire_spans_download.restype = i32
     _lib = lib
     return lib
 
@@ -337,6 +350,33 @@ class Table:
         h = C.c_void_p()
         _check(load().cbh_batch_upload_on(self.h, device_index, C.byref(cb), C.byref(h)))
         return DeviceBatch(self, h, batch.n_tuples, batch.n_requests, batch)
+
+    def wire_flatten(self, data, offsets, default_policy_version="default", default_scope="", device_index=0):
+        """``cbh_wire_flatten``: serialized CheckInputs (uint8 array + uint64[n + 1] offsets) -> a resident batch the GPU
+        flattened.  Results of ``launch`` + ``download`` on it are in input order.  Raises ``HostFlattenerNeeded`` when the
+        messages are the host flattener's."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        h = C.c_void_p()
+        info = CWireInfo()
+        rc = load().cbh_wire_flatten(self.h, device_index, data.ctypes.data if data.size else None, offsets.ctypes.data, n,
+                                     default_policy_version.encode(), default_scope.encode(), C.byref(h), C.byref(info))
+        if rc == 1:
+            raise HostFlattenerNeeded(load().cbh_last_error().decode("utf-8", "replace"))
+        _check(rc)
+        db = DeviceBatch(self, h, info.n_tuples, n)
+        db.wire_info = {f[0]: getattr(info, f[0]) for f in CWireInfo._fields_}
+        return db
+
+    def wire_spans(self, dbatch):
+        """``cbh_wire_spans_download`` -> (in_span uint32[n][12], act_span uint32[n_tuples][2], act_off uint32[n + 1])"""
+        n, T = dbatch.n_requests, dbatch.n_tuples
+        in_span = np.zeros((max(n, 1), 12), dtype=np.uint32)
+        act_span = np.zeros((max(T, 1), 2), dtype=np.uint32)
+        act_off = np.zeros(n + 1, dtype=np.uint32)
+        _check(load().cbh_wire_spans_download(self.h, dbatch.h, in_span.ctypes.data, act_span.ctypes.data, act_off.ctypes.data))
+        return in_span[:n], act_span[:T], act_off
 
     def launch(self, dbatch, now_ns=0, flags=0):
         p = CParams(now_ns, flags, 0)

@@ -38,6 +38,7 @@
 
 #include "cbh_kernels.h"
 #include "cbh_image.h"
+#include "cbh_wire_host.h"
 
 // ======================================================================== host code
 // (skipped in the device compilation pass, where the device structs carry address-space qualifiers)
@@ -166,6 +167,8 @@ struct Replica {   // the table on one device
   std::condition_variable ctx_cv;
   std::vector<OneShot*> ctx_idle;
   int ctx_count = 0;
+  // the device flattener's per-table data (cbh_wire_host.h WireIndexHost), uploaded at load
+  u64* w_tix = nullptr; u32* w_scope_of_sid = nullptr; WireCol* w_cols = nullptr; u8* w_col_keys = nullptr;
 };
 
 struct cbh_table {
@@ -174,6 +177,7 @@ struct cbh_table {
   std::vector<uint32_t> meta;
   std::atomic<int> refs{1};
   const char* bcast = "none";
+  WireIndexHost wire;   // cbh_wire_flatten
 };
 
 struct cbh_device_batch {
@@ -189,6 +193,8 @@ struct cbh_device_batch {
   u32 wide_lo = 0, wide_hi = 0;         // BatchShape::wide_lo / wide_hi
   bool plain_tags = false;              // BatchShape::plain_tags
   std::vector<std::pair<void*, size_t>> allocs;   // (block, capacity) taken from the replica's pool
+  // a batch the device flattened (cbh_wire_flatten): where the response's strings sit in the messages
+  bool wire = false; u32* w_in_span = nullptr; u32* w_act_span = nullptr;
 };
 
 static void replica_destroy(Replica* r) {
@@ -198,6 +204,7 @@ static void replica_destroy(Replica* r) {
   if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
   for (auto& sl : r->ring) for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
   if (r->image && r->owns_image) (void)hipFree(r->image);
+  for (void* p : {(void*)r->w_tix, (void*)r->w_scope_of_sid, (void*)r->w_cols, (void*)r->w_col_keys}) if (p) (void)hipFree(p);
   for (auto& a : r->pool_free) (void)hipFree(a.first);
   for (auto* c : r->ctx_idle) {
     for (auto& s : c->s) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
@@ -232,6 +239,20 @@ static int replica_finish(Replica* r) {
   r->rstreams[0] = r->stream;
   for (int i = 1; i < Replica::MAX_RESIDENT_STREAMS; ++i) HIPCHK(hipStreamCreateWithFlags(&r->rstreams[i], hipStreamNonBlocking));
   for (auto& sl : r->ring) for (auto& e : sl.ev) HIPCHK(hipEventCreate(&e));
+  return 0;
+}
+
+// the device flattener's view of the table (cbh_wire.h): built once from the image, a copy on every replica
+static int wire_index_install(cbh_table* t, const uint8_t* host_image, size_t len) {
+  if (const char* e = cbh_wire_index_build(t->wire, host_image, len, t->meta)) return fail(e);
+  const WireIndexHost& w = t->wire;
+  for (Replica* r : t->reps) {
+    HIPCHK(hipSetDevice(r->device));
+    HIPCHK(hipMalloc((void**)&r->w_tix, w.tix.size() * 8)); HIPCHK(hipMemcpy(r->w_tix, w.tix.data(), w.tix.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&r->w_scope_of_sid, w.scope_of_sid.size() * 4)); HIPCHK(hipMemcpy(r->w_scope_of_sid, w.scope_of_sid.data(), w.scope_of_sid.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&r->w_cols, w.cols.size() * sizeof(WireCol))); HIPCHK(hipMemcpy(r->w_cols, w.cols.data(), w.cols.size() * sizeof(WireCol), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&r->w_col_keys, w.col_keys.size())); HIPCHK(hipMemcpy(r->w_col_keys, w.col_keys.data(), w.col_keys.size(), hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -305,6 +326,7 @@ extern "C" int cbh_table_load(const void* blob, size_t len, cbh_table** out) {
     const char* e = cbh_parse_image(r->dev, t->meta, static_cast<const uint8_t*>(r->image), static_cast<const uint8_t*>(blob), len);
     if (e) { fail(e); return bail(); }
   }
+  if (wire_index_install(t, static_cast<const uint8_t*>(blob), len) != 0) return bail();
   *out = t;
   return 0;
 }
@@ -325,6 +347,7 @@ extern "C" int cbh_table_adopt_device_image(void* device_image, size_t len, cbh_
   const char* e = cbh_parse_image(r->dev, t->meta, static_cast<const uint8_t*>(r->image), host.data(), len);
   if (e) { table_destroy(t); return fail(e); }
   if (replica_finish(r) != 0) { table_destroy(t); return -1; }
+  if (wire_index_install(t, host.data(), len) != 0) { table_destroy(t); return -1; }
   *out = t;
   return 0;
 }
@@ -694,6 +717,153 @@ extern "C" int cbh_result_download(cbh_table* t, cbh_device_batch* b, cbh_result
   if (out->edr_mask && d.n_requests) HIPCHK(hipMemcpyAsync(out->edr_mask, b->out.edr, (size_t)d.n_requests * 8, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   collect_times(rep);
+  return 0;
+}
+
+
+// ---- device-side ingest: serialized CheckInputs -> a resident batch, flattened by the GPU (cbh_wire.h) ------------------
+// H2D of the raw bytes + offsets, count + scan launches, one small D2H (totals, shape), the fill launch, one small D2H
+// (what it needed, what it could not take).  The batch is then an ordinary resident batch: cbh_check_resident,
+// cbh_result_download - results in INPUT order (no routing sort on this path: nothing to undo).
+static int wire_stats_read(cbh_device_batch* b, const WireStats* d_stats, WireStats& st) {
+  HIPCHK(hipMemcpyAsync(&st, d_stats, sizeof(st), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
+                                const char* default_version, const char* default_scope, cbh_device_batch** out, cbh_wire_info* info) {
+  if (!t || !out || !info || (n && (!bytes || !offsets))) return fail("null argument");
+  std::memset(info, 0, sizeof(*info));
+  info->first_bad = CBH_NONE; info->n_requests = n;
+  if (device_index >= t->reps.size()) return fail("device index out of range");
+  if (t->wire.why_not) { info->n_host = n; g_err = t->wire.why_not; return 1; }
+  const u64 total = n ? offsets[n] : 0;
+  std::string dv = default_version ? default_version : "default", ds = default_scope ? default_scope : "";
+  if (!ds.empty() && ds[0] == '.') ds.erase(0, 1);   // scope_value (namer.go:276-278)
+  if (total + dv.size() + ds.size() + 64 > 0xFFFFFFFFull) return fail("cbh_wire_flatten: more than 4 GB of messages in one call");
+  Replica* rep = t->reps[device_index];
+  HIPCHK(hipSetDevice(rep->device));
+  cbh_device_batch* b = new (std::nothrow) cbh_device_batch();
+  if (!b) return fail("out of memory");
+  cbh_table_retain(t);
+  b->table = t; b->rep = rep; b->wire = true;
+  b->stream = rep->rstreams[rep->next_rstream.fetch_add(1, std::memory_order_relaxed) % (uint32_t)rep->n_rstreams.load(std::memory_order_relaxed)];
+  hipStream_t s = b->stream;
+  auto bail = [&](int rc) { cbh_batch_release(b); return rc; };
+  const u32 nw = (n + 63u) / 64u, ncol = t->meta[CBH_M_NCOLUMNS];
+  WireArgs a; std::memset(&a, 0, sizeof(a));
+  const TableDev& td = rep->dev;
+  a.t_str_off = td.str_off; a.t_str_bytes = td.str_bytes; a.K = td.K; a.t_flags = td.flags;
+  a.tix = rep->w_tix; a.tix_mask = t->wire.tix_mask; a.scope_of_sid = rep->w_scope_of_sid;
+  a.cols = rep->w_cols; a.col_keys = rep->w_col_keys; a.n_cols = ncol; a.sens_cols = t->meta[CBH_M_SENS_COLS];
+  a.n = n;
+  a.dver_off = (u32)total; a.dver_len = (u32)dv.size(); a.dscope_off = (u32)(total + dv.size()); a.dscope_len = (u32)ds.size();
+  u8* d_msg = nullptr; u64* d_moff = nullptr; WireStats* d_stats = nullptr;
+  int rc = 0;
+  rc |= dalloc(b, d_msg, (size_t)total + dv.size() + ds.size() + 64);
+  rc |= dalloc(b, d_moff, (size_t)n + 1);
+  rc |= dalloc(b, a.cnt, (size_t)n + 1); rc |= dalloc(b, a.status, (size_t)n + 1);
+  rc |= dalloc(b, a.wavesum, 2 * (size_t)nw + 2); rc |= dalloc(b, a.waveoff, 2 * (size_t)nw + 2);
+  rc |= dalloc(b, d_stats, 1);
+  if (rc != 0) return bail(-1);
+  a.msg = d_msg; a.moff = d_moff; a.stats = d_stats;
+  WireStats st; cbh_wire_stats_init(st);
+  const std::string tail = dv + ds;
+  static const u64 zero_off = 0;
+  if (total && hipMemcpyAsync(d_msg, bytes, total, hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
+  if (!tail.empty() && hipMemcpyAsync(d_msg + total, tail.data(), tail.size(), hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
+  if (hipMemcpyAsync(d_moff, n ? offsets : &zero_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(d_stats, &st, sizeof(st), hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
+  if (nw) hipLaunchKernelGGL(cbh_wire_count_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, a);
+  u32 slots = cbh_wire_dict_slots(n), heap_cap = cbh_wire_heap_guess(total);
+  u32 n_host_count = 0; bool have_outputs = false; u32 runs = 0;
+  for (;;) {
+    // (re)start from the scan: the dictionary is empty, the scan interns the call's default strings first
+    rc = 0;
+    rc |= dalloc(b, a.lix, (size_t)slots); rc |= dalloc(b, a.lflags, (size_t)slots / 4 + 1);
+    if (rc != 0) return bail(-1);
+    a.lix_mask = slots - 1;
+    if (hipMemsetAsync(a.lix, 0, (size_t)slots * 8, s) != hipSuccess || hipMemsetAsync(a.lflags, 0, ((size_t)slots / 4 + 1) * 4, s) != hipSuccess) { fail("cbh_wire_flatten: memset failed"); return bail(-1); }
+    hipLaunchKernelGGL(cbh_wire_scan_kernel, dim3(1), dim3(CBH_BLOCK), 0, s, a);
+    if (wire_stats_read(b, d_stats, st) != 0) return bail(-1);
+    if (!have_outputs) {
+      n_host_count = st.n_host;
+      if (st.first_bad != CBH_NONE) { info->first_bad = st.first_bad; fail("malformed CheckInput at index " + std::to_string(st.first_bad)); return bail(-1); }
+      rc = 0;
+      rc |= dalloc(b, a.req_u32, (size_t)CBH_RQ_NFIELDS * n); rc |= dalloc(b, a.roles, (size_t)st.n_roles); rc |= dalloc(b, a.tuple_action, (size_t)st.n_tuples);
+      rc |= dalloc(b, a.col_tag, (size_t)ncol * n); rc |= dalloc(b, a.col_val, (size_t)ncol * n);
+      rc |= dalloc(b, a.in_span, (size_t)n * 2 * CBH_WSPAN_N); rc |= dalloc(b, a.act_span, (size_t)st.n_tuples * 2);
+      if (rc != 0) return bail(-1);
+      have_outputs = true;
+    }
+    bool again = false;
+    for (;;) {   // the fill, once more with the heap it asked for if the guess was short
+      rc = 0;
+      rc |= dalloc(b, a.heap_tag, (size_t)heap_cap); rc |= dalloc(b, a.heap_val, (size_t)heap_cap);
+      if (rc != 0) return bail(-1);
+      a.heap_cap = heap_cap;
+      if (nw) hipLaunchKernelGGL(cbh_wire_fill_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, a);
+      ++runs;
+      if (wire_stats_read(b, d_stats, st) != 0) return bail(-1);
+      if (st.flags & CBH_WF_DICT_FULL) { again = true; break; }
+      if (st.heap_used <= heap_cap) break;
+      heap_cap = st.heap_used;
+      WireStats reset = st; reset.heap_used = 0; reset.n_host = n_host_count; reset.flags = 0;
+      HIPCHK(hipMemcpyAsync(d_stats, &reset, sizeof(reset), hipMemcpyHostToDevice, s));
+      HIPCHK(hipStreamSynchronize(s));   // (`reset` leaves scope)
+    }
+    if (!again) break;
+    if (slots >= (1u << 30)) { fail("cbh_wire_flatten: the batch-local dictionary cannot grow further"); return bail(-1); }
+    slots *= 4;
+    WireStats reset = st; reset.heap_used = 0; reset.n_host = n_host_count; reset.flags = 0;
+    HIPCHK(hipMemcpyAsync(d_stats, &reset, sizeof(reset), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  HIPCHK(hipGetLastError());
+  info->n_tuples = st.n_tuples; info->n_host = st.n_host; info->dict_slots = slots; info->heap_len = st.heap_used; info->fill_runs = runs;
+  if (st.first_bad != CBH_NONE) { info->first_bad = st.first_bad; fail("malformed CheckInput at index " + std::to_string(st.first_bad)); return bail(-1); }
+  if (st.n_host) { g_err = "cbh_wire_flatten: " + std::to_string(st.n_host) + " message(s) are the host flattener's (more than 64 actions, a resource kind to rewrite that no policy names, containers nested too deep)"; return bail(1); }
+  BatchDev& d = b->dev;
+  d.n_requests = n; d.n_tuples = st.n_tuples; d.n_roles = st.n_roles; d.n_columns = ncol; d.n_strings = slots; d.heap_len = st.heap_used;
+  d.req_lo = 0; d.req_hi = n;
+  d.req_u32 = a.req_u32; d.roles = a.roles; d.tuple_req = nullptr; d.tuple_action = a.tuple_action; d.col_tag = a.col_tag; d.col_val = a.col_val;
+  d.heap_tag = a.heap_tag; d.heap_val = a.heap_val; d.str_off = nullptr; d.str_bytes = d_msg; d.str_flags = (const u8*)a.lflags; d.str_keys = a.lix;
+  b->w_in_span = a.in_span; b->w_act_span = a.act_span;
+  static const bool force_any = getenv("CBH_FLAT_ANY") != nullptr;
+  b->max_actions = st.max_actions; b->max_roles = st.max_roles; b->plain_tags = !force_any && !(st.flags & CBH_WF_CONTAINER_IN_SENS);
+  b->wide_lo = st.wide_hi ? st.wide_lo : 0; b->wide_hi = st.wide_hi;
+  rc = 0;
+  const bool globs = nfa_maxw(rep->dev) != 0;
+  rc |= dalloc(b, d.gbits, globs ? (size_t)3 * slots : (size_t)1);
+  d.n_gwords = (rep->dev.flags & CBH_MF_WALK2) ? w2_gwords(rep->dev.gslots_generic, rep->dev.gslots_all, b->plain_tags) : 0;
+  d.n_gslots = 0;
+  if (d.n_gwords) rc |= dalloc(b, d.gres, (size_t)d.n_gwords * n); else d.gres = nullptr;
+  rc |= dalloc(b, b->out.effect, (size_t)st.n_tuples); rc |= dalloc(b, b->out.policy, (size_t)st.n_tuples);
+  rc |= dalloc(b, b->out.scope, (size_t)st.n_tuples); rc |= dalloc(b, b->out.status, (size_t)st.n_tuples);
+  rc |= dalloc(b, b->out.edr, (size_t)n); rc |= dalloc(b, b->d_args, 1);
+  if (rc != 0) return bail(-1);
+  if (globs && hipMemsetAsync(d.gbits, 0, (size_t)3 * slots * sizeof(u64), s) != hipSuccess) { fail("cbh_wire_flatten: memset failed"); return bail(-1); }
+  if (hipStreamSynchronize(s) != hipSuccess) { fail("cbh_wire_flatten failed"); return bail(-1); }
+  *out = b;
+  return 0;
+}
+
+// Where the strings a CheckOutput repeats sit in each message (what cbi_assemble_wire_pb reads instead of walking the messages
+// again): in_span [n][6] (offset, length) pairs relative to the message - request id, principal id / version, resource kind /
+// version / id; act_span [n_tuples] (offset, length) of each action; act_off [n + 1] first tuple of each input.
+extern "C" int cbh_wire_spans_download(cbh_table* t, cbh_device_batch* b, uint32_t* in_span, uint32_t* act_span, uint32_t* act_off) {
+  if (!t || !b || !in_span || !act_span || !act_off) return fail("null argument");
+  if (!b->wire) return fail("cbh_wire_spans_download: not a batch of cbh_wire_flatten");
+  Replica* rep = b->rep;
+  HIPCHK(hipSetDevice(rep->device));
+  const BatchDev& d = b->dev;
+  const size_t n = d.n_requests;
+  if (n) HIPCHK(hipMemcpyAsync(in_span, b->w_in_span, n * 2 * CBH_WSPAN_N * 4, hipMemcpyDeviceToHost, b->stream));
+  if (d.n_tuples) HIPCHK(hipMemcpyAsync(act_span, b->w_act_span, (size_t)d.n_tuples * 2 * 4, hipMemcpyDeviceToHost, b->stream));
+  if (n) HIPCHK(hipMemcpyAsync(act_off, d.req_u32 + (size_t)CBH_RQ_ACT_OFF * n, n * 4, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  act_off[n] = d.n_tuples;
   return 0;
 }
 

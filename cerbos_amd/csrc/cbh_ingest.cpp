@@ -1093,26 +1093,12 @@ static void put_ld(std::vector<u8>& o, u32 field, std::string_view s) {
 }
 static void put_str(std::vector<u8>& o, u32 field, std::string_view s) { if (!s.empty()) put_ld(o, field, s); }   // proto3 default: omitted
 
-extern "C" {
-
-int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* bytes, const uint64_t* offsets,
-                       uint32_t n, const char* default_version, int n_threads, cbi_outputs** out) {
-  if (!t || !b || !res || !res->effect || !out || (n && (!bytes || !offsets))) return fail("cbi_assemble_pb: null argument");
-  std::string_view dver = default_version ? default_version : "default";
-  const u32 T = b->view.n_tuples, R = b->view.n_requests;
-  // input-order tuple k lives at device tuple inv[k]; derived roles of an input = OR over its device requests
-  std::vector<u32> inv(T);
-  for (u32 j = 0; j < T; ++j) { if (b->tuple_perm[j] >= T) return fail("corrupt tuple permutation"); inv[b->tuple_perm[j]] = j; }
-  std::vector<u64> edr(n, 0), first(n + 1, 0);   // first[i] = input-order index of input i's first tuple
-  for (u32 q = 0; q < R; ++q) {
-    const u32 i = b->req_input[q];
-    if (i >= n) return fail("batch does not belong to these inputs");
-    if (res->edr_mask) edr[i] |= res->edr_mask[q];
-    first[i + 1] += b->req[(size_t)RQ_ACT_CNT * R + q];
-  }
-  for (u32 i = 0; i < n; ++i) first[i + 1] += first[i];
-  if (first[n] != T) return fail("batch does not belong to these inputs");
-
+// The CheckOutputs of inputs 0 .. n - 1.  inv: input-order tuple k -> the tuple of `res` that answers it (null: k itself);
+// edr: effective derived roles per input; first[i]: input-order index of input i's first tuple; in_span / act_span: where the
+// strings sit in the messages (null: every message is walked again).
+static int assemble_outputs(const cbi_table* t, const cbh_result* res, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
+                            std::string_view dver, int n_threads, const u32* inv, const u64* edr, const u64* first,
+                            const u32* in_span, const u32* act_span, cbi_outputs** out) {
   // inputs [lo, hi) -> o (offsets relative to the part)
   auto assemble_range = [&](u32 lo, u32 hi, cbi_outputs* o, std::string& err) -> int {
     auto bail = [&](const std::string& m) { err = m; return -1; };
@@ -1124,7 +1110,7 @@ int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result*
     auto o_flags = [&](u32 x) -> u8& { return o->flags[x]; };
     u64 k = first[lo];
     const u64 k_hi = first[hi];
-    const bool spans = b->in_span.size() == (size_t)n * 2 * IN_SPAN_N && b->act_span.size() == (size_t)T * 2;
+    const bool spans = in_span != nullptr && act_span != nullptr;
     for (u32 i = lo; i < hi; ++i) {
       Span m{bytes + offsets[i], bytes + offsets[i + 1]};
       Span principal{nullptr, nullptr}, resource{nullptr, nullptr};
@@ -1135,15 +1121,15 @@ int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result*
       if (spans) {
         // the flattener noted where these strings sit in the message (cbi_batch::in_span): no second walk
         const size_t mlen = (size_t)(m.e - m.p);
-        const u32* sp = &b->in_span[(size_t)i * 2 * IN_SPAN_N];
+        const u32* sp = in_span + (size_t)i * 2 * IN_SPAN_N;
         bool ok = true;
         auto at = [&](u32 which) { const u32 o = sp[2 * which], l = sp[2 * which + 1]; if ((size_t)o + l > mlen) { ok = false; return std::string_view(); } return std::string_view((const char*)m.p + o, l); };
         request_id = at(SPAN_REQUEST_ID); P.id = at(SPAN_P_ID); P.version = at(SPAN_P_VERSION); Rs.kind = at(SPAN_R_KIND); Rs.version = at(SPAN_R_VERSION); Rs.id = at(SPAN_R_ID);
         const u64 k_end = first[i + 1];
         for (; k < k_end; ++k) {
-          const u32 o = b->act_span[2 * k], l = b->act_span[2 * k + 1];
+          const u32 o = act_span[2 * k], l = act_span[2 * k + 1];
           if ((size_t)o + l > mlen) { ok = false; break; }
-          std::string_view name((const char*)m.p + o, l); const u32 j = inv[k]; bool dup = false;
+          std::string_view name((const char*)m.p + o, l); const u32 j = inv ? inv[k] : (u32)k; bool dup = false;
           for (Act& a : acts) if (a.name == name) {
             if (res->effect[j] == CBH_EFFECT_DENY || res->effect[a.j] != CBH_EFFECT_DENY) a.j = j;
             dup = true; break;
@@ -1158,7 +1144,7 @@ int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result*
         else if (f.num == 4) {
           if (k >= k_hi) return bail("batch does not belong to these inputs");
           // setEffect (check.go:513-530): a later duplicate replaces an earlier one unless that one is a DENY and it is not
-          std::string_view name = sv(f.s); u32 j = inv[k++]; bool dup = false;
+          std::string_view name = sv(f.s); u32 j = inv ? inv[k] : (u32)k; ++k; bool dup = false;
           for (Act& a : acts) if (a.name == name) {
             if (res->effect[j] == CBH_EFFECT_DENY || res->effect[a.j] != CBH_EFFECT_DENY) a.j = j;
             dup = true; break;
@@ -1257,6 +1243,47 @@ int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result*
   o->bytes.reserve(1);
   *out = o;
   return 0;
+}
+
+extern "C" {
+
+int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* bytes, const uint64_t* offsets,
+                       uint32_t n, const char* default_version, int n_threads, cbi_outputs** out) {
+  if (!t || !b || !res || !res->effect || !out || (n && (!bytes || !offsets))) return fail("cbi_assemble_pb: null argument");
+  std::string_view dver = default_version ? default_version : "default";
+  const u32 T = b->view.n_tuples, R = b->view.n_requests;
+  // input-order tuple k lives at device tuple inv[k]; derived roles of an input = OR over its device requests
+  std::vector<u32> inv(T);
+  for (u32 j = 0; j < T; ++j) { if (b->tuple_perm[j] >= T) return fail("corrupt tuple permutation"); inv[b->tuple_perm[j]] = j; }
+  std::vector<u64> edr(n, 0), first(n + 1, 0);   // first[i] = input-order index of input i's first tuple
+  for (u32 q = 0; q < R; ++q) {
+    const u32 i = b->req_input[q];
+    if (i >= n) return fail("batch does not belong to these inputs");
+    if (res->edr_mask) edr[i] |= res->edr_mask[q];
+    first[i + 1] += b->req[(size_t)RQ_ACT_CNT * R + q];
+  }
+  for (u32 i = 0; i < n; ++i) first[i + 1] += first[i];
+  if (first[n] != T) return fail("batch does not belong to these inputs");
+
+  return assemble_outputs(t, res, bytes, offsets, n, dver, n_threads, inv.data(), edr.data(), first.data(),
+                          b->in_span.size() == (size_t)n * 2 * IN_SPAN_N && b->act_span.size() == (size_t)T * 2 ? b->in_span.data() : nullptr,
+                          b->act_span.data(), out);
+}
+
+// Results of a batch the DEVICE flattened (cerbos_hip.h cbh_wire_flatten: tuples in input order, one request per input) ->
+// serialized CheckOutputs; in_span / act_span / act_off as cbh_wire_spans_download returns them.
+int cbi_assemble_wire_pb(const cbi_table* t, const cbh_result* res, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
+                         uint32_t n_tuples, const uint32_t* in_span, const uint32_t* act_span, const uint32_t* act_off,
+                         const char* default_version, int n_threads, cbi_outputs** out) {
+  if (!t || !res || !res->effect || !out || (n && (!bytes || !offsets || !in_span || !act_off)) || (n_tuples && !act_span)) return fail("cbi_assemble_wire_pb: null argument");
+  std::string_view dver = default_version ? default_version : "default";
+  std::vector<u64> first((size_t)n + 1, 0), edr(res->edr_mask ? 0 : n, 0);
+  for (u32 i = 0; i <= n; ++i) {
+    first[i] = n ? act_off[i] : 0;
+    if (first[i] > n_tuples || (i && first[i] < first[i - 1])) return fail("cbi_assemble_wire_pb: action offsets are not a partition of the tuples");
+  }
+  if (first[n] != n_tuples) return fail("cbi_assemble_wire_pb: action offsets are not a partition of the tuples");
+  return assemble_outputs(t, res, bytes, offsets, n, dver, n_threads, nullptr, res->edr_mask ? res->edr_mask : edr.data(), first.data(), in_span, act_span, out);
 }
 
 int cbi_assemble_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* bytes, const uint64_t* offsets,

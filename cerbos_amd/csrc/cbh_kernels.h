@@ -84,7 +84,9 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_resolve_globs_kernel(TableDev t
     u64 A[NFA_MAXW];
 #pragma unroll
     for (int w = 0; w < NFA_MAXW; ++w) A[w] = (u32)w < nw ? init[w] : 0;
-    const u32 o = b.str_off[i], n = b.str_off[i + 1] - o;
+    u32 o, n;
+    if (b.str_keys) { const u64 key = b.str_keys[i]; o = (u32)key; n = (u32)(key >> 32) & 0xFFFFu; }   // a batch the device flattened (cbh_wire.h)
+    else { o = b.str_off[i]; n = b.str_off[i + 1] - o; }
     for (u32 k = 0; k < n; ++k) {
       const u32 ch = b.str_bytes[o + k];
       u64 carry = 0;
@@ -133,3 +135,4 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_resolve_globs_kernel(TableDev t
 #include "cbh_check_wave.h"
 #include "cbh_check_flat.h"
 #include "cbh_check_walk2.h"
+#include "cbh_wire.h"

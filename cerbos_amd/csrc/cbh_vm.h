@@ -84,6 +84,9 @@ struct BatchDev {
   const CBH_G u8* col_tag; const CBH_G u64* col_val;
   const CBH_G u8* heap_tag; const CBH_G u64* heap_val;
   const CBH_G u32* str_off; const CBH_G u8* str_bytes; const CBH_G u8* str_flags;
+  // A batch the device flattened (cbh_wire.h): string i is the dictionary word str_keys[i] = {hash:16 | length:16 | offset:32},
+  // its bytes str_bytes[offset ..) (the message buffer; an empty slot has length 0); str_off is null.  Else null.
+  const CBH_G u64* str_keys;
   CBH_G u64* gbits; // [3][n_strings], written by the resolve kernel
   CBH_G u64* gres;  // [n_gwords][n_requests] results of the evaluation sites (cbh_walk2_pre_kernel writes, cbh_walk2_kernel reads)
   u32 n_gwords; u32 n_gslots;   // words per request; sites filed = slots 0 .. n_gslots - 1
@@ -172,6 +175,7 @@ __device__ __forceinline__ void str_span(const Ctx& c, u32 sid, gbytes& p, u32& 
   } else {
     u32 i = sid - c.t.K;
     if (i >= c.b.n_strings) { n = 0; p = c.b.str_bytes; return; }   // never index past the batch's strings
+    if (c.b.str_keys) { const u64 k = c.b.str_keys[i]; n = (u32)(k >> 32) & 0xFFFFu; p = c.b.str_bytes + (u32)k; return; }
     u32 o = c.b.str_off[i];
     n = c.b.str_off[i + 1] - o;
     p = c.b.str_bytes + o;

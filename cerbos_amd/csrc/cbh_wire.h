@@ -1,0 +1,635 @@
+// cbh_wire.h - device-side ingest (SURVEY §8 f1 on the GPU): serialized enginev1.CheckInput messages -> the batch arrays the
+// decision kernels read, without the host touching a byte of the messages.
+//
+// What it replaces: the reference builds its request view per input on the CPU (check.go:536-554 checkInputToRequest, the
+// protobuf decode in front of it); round 2 did the same walk in C++ (cbh_ingest.cpp flatten_slice: 63 % of the wire-inclusive
+// wall time, the GPU idle meanwhile).  Here the raw bytes + offsets cross PCIe once and three launches build the batch in HBM:
+//
+//   cbh_wire_count_kernel   one lane per message: actions, roles, well-formedness of the top level; per-wave sums
+//   cbh_wire_scan_kernel    one wave: exclusive offsets of the waves' action / role slices, totals, the call's default strings
+//   cbh_wire_fill_kernel    one lane per message: every field of include/cerbos_hip.h's cbh_batch - request words, role and
+//                           action ids, attribute columns, nested values in the tagged heap - plus where the strings the
+//                           response needs sit in the message (the host assembler reads them instead of re-walking)
+//
+// Strings.  Equality on the device is id equality, so every string is interned: against the table's pool through a hash
+// index built at table load (cbh_engine.hip wire_index_build), and - for strings the table does not know - into a
+// batch-local open-addressing dictionary in HBM.  A dictionary slot is ONE 64-bit word {hash:16 | length:16 | byte offset
+// of the first occurrence in the message buffer:32} claimed with one device-scope compare-and-swap: the word refers to
+// message bytes that were uploaded before the launch and never change, so the claim publishes everything a later finder
+// needs and no lane ever waits for another.  (A probe may read a stale EMPTY from its L1 / its XCD's L2 - the CAS that
+// follows is performed at memory and returns the truth; a non-empty word never changes.)  The id of a batch-local string is
+// K + its slot: the decision kernels find its bytes through BatchDev.str_keys (cbh_vm.h str_view, cbh_resolve_globs_kernel).
+//
+// Scope of the device path: messages the host flattener would split (> 64 actions), rewrite (resource kinds of the pre-0.30
+// form, namer.go:213-218) or that nest containers deeper than CBH_WIRE_MAX_DEPTH are counted in WireStats.n_host and the
+// caller takes the whole batch through libcerbos_ingest.so instead (product code, same result) - never a guess.
+// Same message grammar, same last-field-wins rules, same tags and values as cbh_ingest.cpp; tests/test_wire_device.py holds
+// the two against each other array by array.
+#pragma once
+#include "cbh_vm.h"
+
+#define CBH_WIRE_MAX_KEYS 4u       /* keys of a column path */
+#define CBH_WIRE_MAX_DEPTH 8u      /* containers nested deeper: host flattener */
+#define CBH_WIRE_MAX_ROLES 255u
+#define CBH_WIRE_MAX_STRLEN 0xFFFFu
+#define CBH_WIRE_MAX_VALUE_ENTRIES 0xFFFFFu   /* heap entries of one attribute value */
+#define CBH_WIRE_MAX_PROBES 256u
+
+#define CBH_WS_OK 0u
+#define CBH_WS_BAD 1u    /* malformed message */
+#define CBH_WS_HOST 2u   /* well formed, left to the host flattener */
+
+#define CBH_WF_CONTAINER_IN_SENS 1u   /* a list / map sits in a column a classified leaf is sensitive to (BatchShape::plain_tags) */
+#define CBH_WF_DICT_FULL 2u           /* the batch-local dictionary ran out of probes: the caller retries with a larger one */
+
+#define CBH_WSPAN_N 6u   /* request id, principal id / version, resource kind / version / id: (offset, length) pairs per message */
+
+struct WireCol { u32 root, nk; u32 key_off[CBH_WIRE_MAX_KEYS], key_len[CBH_WIRE_MAX_KEYS]; };
+
+struct WireStats {
+  u32 n_tuples, n_roles;        // scan kernel
+  u32 max_actions, max_roles;   // count kernel
+  u32 wide_lo, wide_hi;         // requests wider than cbh_walk2_kernel's shape lie in [wide_lo, wide_hi)
+  u32 first_bad;                // smallest index of a malformed message (CBH_NONE: none)
+  u32 n_host;                   // messages left to the host flattener
+  u32 heap_used;                // heap entries the fill asked for (may exceed the capacity: then it is re-run)
+  u32 flags;                    // CBH_WF_*
+  u32 sid_empty, sid_dver, dscope_word, sid_claims;
+  u32 pad[2];
+};
+
+struct WireArgs {
+  // the table
+  const CBH_G u32* t_str_off; const CBH_G u8* t_str_bytes; u32 K; u32 t_flags;
+  const CBH_G u64* tix; u32 tix_mask;          // hash << 32 | id + 1; 0 = empty
+  const CBH_G u32* scope_of_sid;               // [K] scope index of a table string that is a scope, else CBH_NONE
+  const CBH_G WireCol* cols; const CBH_G u8* col_keys; u32 n_cols; u32 sens_cols;
+  // the messages: message i = msg[moff[i] .. moff[i + 1]); the call's default version / scope and "claims" follow the last one
+  const CBH_G u8* msg; const CBH_G u64* moff; u32 n; u32 heap_cap;
+  u32 dver_off, dver_len, dscope_off, dscope_len;
+  // scratch
+  CBH_G u32* cnt;         // [n] actions | roles << 8
+  CBH_G u8* status;       // [n] CBH_WS_*
+  CBH_G u32* wavesum;     // [waves][2] actions, roles
+  CBH_G u32* waveoff;     // [waves][2] exclusive
+  CBH_G WireStats* stats;
+  // the batch-local dictionary
+  CBH_G u64* lix; u32 lix_mask; u32 pad0; CBH_G u32* lflags;   // flags: one byte per slot, OR-ed through the aligned dword
+  // the batch
+  CBH_G u32* req_u32; CBH_G u32* roles; CBH_G u32* tuple_action; CBH_G u8* col_tag; CBH_G u64* col_val;
+  CBH_G u8* heap_tag; CBH_G u64* heap_val;
+  CBH_G u32* in_span; CBH_G u32* act_span;
+};
+
+// ---- the string hash both sides use (the table index is built on the host) --------------------------------------
+template <class P>
+#ifndef CBH_HOSTSIM
+__host__ __device__
+#endif
+static inline u32 cbh_wire_hash(P p, u32 n) {
+  u32 h = 0x811C9DC5u ^ n;
+  for (u32 i = 0; i < n; ++i) { h ^= (u32)p[i]; h *= 0x01000193u; }
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return h;
+}
+
+// ---- atomics (device scope); the host simulation runs its fibers on one thread -----------------------------------
+#ifdef CBH_HOSTSIM
+static inline u64 w_cas64(u64* p, u64 expect, u64 v) { const u64 o = *p; if (o == expect) *p = v; return o; }
+static inline u64 w_load64(const u64* p) { return *p; }
+static inline u32 w_add32(u32* p, u32 v) { const u32 o = *p; *p += v; return o; }
+static inline void w_or32(u32* p, u32 v) { *p |= v; }
+static inline void w_max32(u32* p, u32 v) { if (v > *p) *p = v; }
+static inline void w_min32(u32* p, u32 v) { if (v < *p) *p = v; }
+#else
+__device__ __forceinline__ u64 w_cas64(CBH_G u64* p, u64 expect, u64 v) {
+  return (u64)atomicCAS((unsigned long long*)p, (unsigned long long)expect, (unsigned long long)v);
+}
+__device__ __forceinline__ u64 w_load64(const CBH_G u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u32 w_add32(CBH_G u32* p, u32 v) { return atomicAdd((unsigned int*)p, v); }
+__device__ __forceinline__ void w_or32(CBH_G u32* p, u32 v) { atomicOr((unsigned int*)p, v); }
+__device__ __forceinline__ void w_max32(CBH_G u32* p, u32 v) { atomicMax((unsigned int*)p, v); }
+__device__ __forceinline__ void w_min32(CBH_G u32* p, u32 v) { atomicMin((unsigned int*)p, v); }
+#endif
+
+// ---- protobuf wire walking (the grammar of cbh_ingest.cpp next / entry / value / map_get) -------------------------
+struct WSpan { u32 p, e; };   // byte offsets into WireArgs.msg
+struct WField { u32 num, wt; u64 v; WSpan s; };
+struct WVal { u32 kind; u64 v; WSpan s; };
+
+__device__ __forceinline__ bool w_varint(const CBH_G u8* m, WSpan& s, u64& out) {
+  u64 r = 0;
+  for (u32 sh = 0; sh < 64 && s.p < s.e; sh += 7) {
+    const u32 b = m[s.p++];
+    r |= (u64)(b & 0x7Fu) << sh;
+    if (!(b & 0x80u)) { out = r; return true; }
+  }
+  return false;
+}
+
+// Next field of a message; false at the end or on malformed input (`bad` set).
+__device__ __forceinline__ bool w_next(const CBH_G u8* m, WSpan& s, WField& f, bool& bad) {
+  if (s.p >= s.e) return false;
+  u64 key;
+  if (!w_varint(m, s, key)) { bad = true; return false; }
+  f.num = (u32)(key >> 3); f.wt = (u32)(key & 7u);
+  if (f.wt == 2u) {
+    u64 n;
+    if (!w_varint(m, s, n) || n > (u64)(s.e - s.p)) { bad = true; return false; }
+    f.s.p = s.p; f.s.e = s.p + (u32)n; s.p += (u32)n;
+    return true;
+  }
+  if (f.wt == 0u) { if (!w_varint(m, s, f.v)) { bad = true; return false; } return true; }
+  if (f.wt == 1u) {
+    if (s.e - s.p < 8u) { bad = true; return false; }
+    u64 v = 0;
+    for (u32 k = 0; k < 8u; ++k) v |= (u64)m[s.p + k] << (8u * k);
+    f.v = v; s.p += 8u; return true;
+  }
+  if (f.wt == 5u) {
+    if (s.e - s.p < 4u) { bad = true; return false; }
+    u32 v = 0;
+    for (u32 k = 0; k < 4u; ++k) v |= (u32)m[s.p + k] << (8u * k);
+    f.v = v; s.p += 4u; return true;
+  }
+  bad = true; return false;
+}
+
+// map<string, google.protobuf.Value> entry: key = 1, value = 2 (last of each wins)
+__device__ __forceinline__ bool w_entry(const CBH_G u8* m, WSpan e, WSpan& key, WSpan& val, bool& bad) {
+  key.p = key.e = 0; val.p = val.e = 0;
+  WField f;
+  while (w_next(m, e, f, bad)) {
+    if (f.num == 1u && f.wt == 2u) key = f.s;
+    else if (f.num == 2u && f.wt == 2u) val = f.s;
+  }
+  return !bad;
+}
+
+// google.protobuf.Value oneof: null 1, number 2 (double), string 3, bool 4, struct 5, list 6; a field counts only with the
+// wire type its declaration has; the last one present wins; an empty message is null.
+__device__ __forceinline__ bool w_value(const CBH_G u8* m, WSpan s, WVal& out, bool& bad) {
+  out.kind = 1u; out.v = 0; out.s.p = out.s.e = 0;
+  WField f;
+  while (w_next(m, s, f, bad)) {
+    if (f.num >= 1u && f.num <= 6u) {
+      const u32 want = (f.num == 2u) ? 1u : (f.num == 1u || f.num == 4u) ? 0u : 2u;
+      if (f.wt == want) {
+        out.kind = f.num;
+        if (f.wt == 2u) { out.v = 0; out.s = f.s; } else { out.v = f.v; out.s.p = out.s.e = 0; }
+      }
+    }
+  }
+  return !bad;
+}
+
+__device__ __forceinline__ bool w_bytes_eq(const CBH_G u8* a, const CBH_G u8* b, u32 n) {
+  for (u32 i = 0; i < n; ++i) if (a[i] != b[i]) return false;
+  return true;
+}
+
+// Looks `key` up in the map field `fnum` of `msg` (last entry wins, as protobuf maps decode).
+__device__ __forceinline__ bool w_map_get(const CBH_G u8* m, WSpan msg, u32 fnum, const CBH_G u8* key, u32 klen, WSpan& val, bool& bad) {
+  WField f; bool found = false;
+  while (w_next(m, msg, f, bad)) {
+    if (f.num != fnum || f.wt != 2u) continue;
+    WSpan k, v;
+    if (!w_entry(m, f.s, k, v, bad)) return false;
+    if (k.e - k.p == klen && w_bytes_eq(m + k.p, key, klen)) { val = v; found = true; }
+  }
+  return found;
+}
+
+// ---- interning -------------------------------------------------------------------------------------------------
+// id of a table string, CBH_NONE if the table does not hold it
+__device__ __forceinline__ u32 w_table_sid(const WireArgs& a, const CBH_G u8* s, u32 len, u32 h) {
+  for (u32 i = h & a.tix_mask, n = 0; n <= a.tix_mask; i = (i + 1u) & a.tix_mask, ++n) {
+    const u64 e = a.tix[i];
+    if (!e) return CBH_NONE;
+    if ((u32)(e >> 32) == h) {
+      const u32 id = (u32)e - 1u, o = a.t_str_off[id];
+      if (a.t_str_off[id + 1u] - o == len && w_bytes_eq(a.t_str_bytes + o, s, len)) return id;
+    }
+  }
+  return CBH_NONE;
+}
+
+struct WLane { bool bad, host, dict_full; };
+
+// string id of msg[off .. off + len): the table's id, or K + its slot in the batch-local dictionary (claimed if absent)
+__device__ __attribute__((noinline)) u32 w_intern(const WireArgs& a, u32 off, u32 len, u32 flag, WLane& L) {
+  const CBH_G u8* s = a.msg + off;
+  const u32 h = cbh_wire_hash(s, len);
+  const u32 id = w_table_sid(a, s, len, h);
+  if (id != CBH_NONE) return id;
+  if (len > CBH_WIRE_MAX_STRLEN) { L.host = true; return a.K; }
+  const u64 key = ((u64)((h >> 16) | 0x8000u) << 48) | ((u64)len << 32) | (u64)off;
+  u32 i = h & a.lix_mask;
+  for (u32 n = 0; n < CBH_WIRE_MAX_PROBES; ++n, i = (i + 1u) & a.lix_mask) {
+    u64 cur = w_load64(a.lix + i);
+    if (cur == 0) { const u64 prev = w_cas64(a.lix + i, 0, key); cur = prev == 0 ? key : prev; }
+    if (cur == key || ((cur >> 32) == (key >> 32) && w_bytes_eq(a.msg + (u32)cur, s, len))) {
+      if (flag) {
+        const u32 sh = (i & 3u) * 8u;
+        if (((a.lflags[i >> 2] >> sh) & flag) != flag) w_or32(a.lflags + (i >> 2), flag << sh);
+      }
+      return a.K + i;
+    }
+  }
+  L.dict_full = true;
+  return a.K;
+}
+
+// scope word of a scope string (cbh_ingest.cpp scope_word, namer.go:77-87): the scope itself if the table knows it (bit 31
+// set), else its nearest ancestor "a.b.c" -> "a.b", "a", "" the table knows, else 0
+__device__ __attribute__((noinline)) u32 w_scope_word(const WireArgs& a, u32 off, u32 len) {
+  const CBH_G u8* s = a.msg + off;
+  u32 id = w_table_sid(a, s, len, cbh_wire_hash(s, len));
+  if (id != CBH_NONE && a.scope_of_sid[id] != CBH_NONE) return a.scope_of_sid[id] | CBH_SCOPE_EXACT;
+  for (u32 i = len; i-- > 0u;) {
+    if (s[i] == '.' || i == 0u) {
+      id = w_table_sid(a, s, i, cbh_wire_hash(s, i));
+      if (id != CBH_NONE && a.scope_of_sid[id] != CBH_NONE) return a.scope_of_sid[id];
+    }
+  }
+  return 0u;
+}
+
+// namer.go:213-218 (cbh_ingest.cpp sanitize): does this resource kind have to be rewritten?  A name of the pre-0.30 form
+// (segments "[A-Za-z][0-9A-Za-z_@.\-/]*" joined by ':') has every run of characters outside [0-9A-Za-z_.] replaced by one '_'.
+__device__ __forceinline__ bool w_kind_ok_char(u32 c) { return (c - '0' < 10u) || ((c | 0x20u) - 'a' < 26u) || c == '_' || c == '.'; }
+__device__ __forceinline__ bool w_kind_needs_rewrite(const CBH_G u8* s, u32 len) {
+  bool plain = true;
+  for (u32 i = 0; i < len && plain; ++i) plain = w_kind_ok_char(s[i]);
+  if (plain || len == 0u) return false;
+  bool seg_start = true;
+  for (u32 i = 0; i < len; ++i) {
+    const u32 c = s[i];
+    const bool alpha = ((c | 0x20u) - 'a' < 26u);
+    if (seg_start) { if (!alpha) return false; seg_start = false; }
+    else if (c == ':') seg_start = true;
+    else if (!((c - '0' < 10u) || alpha || c == '_' || c == '@' || c == '.' || c == '-' || c == '/')) return false;
+  }
+  return !seg_start;
+}
+// The rewritten kind exists nowhere in the message, so only the table can name it: its id if the table holds the rewritten
+// string (a kind some policy is written for), else CBH_NONE - that message is the host flattener's.
+__device__ __attribute__((noinline)) u32 w_rewritten_kind_sid(const WireArgs& a, const CBH_G u8* s, u32 len) {
+  u32 n = 0; bool in_run = false;
+  for (u32 i = 0; i < len; ++i) { const bool ok = w_kind_ok_char(s[i]); n += (ok || !in_run); in_run = !ok; }
+  u32 h = 0x811C9DC5u ^ n; in_run = false;   // cbh_wire_hash over the rewritten bytes
+  for (u32 i = 0; i < len; ++i) {
+    const u32 c = s[i]; const bool ok = w_kind_ok_char(c);
+    if (ok || !in_run) { h ^= ok ? c : (u32)'_'; h *= 0x01000193u; }
+    in_run = !ok;
+  }
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  for (u32 i = h & a.tix_mask, probes = 0; probes <= a.tix_mask; i = (i + 1u) & a.tix_mask, ++probes) {
+    const u64 e = a.tix[i];
+    if (!e) return CBH_NONE;
+    if ((u32)(e >> 32) != h) continue;
+    const u32 id = (u32)e - 1u, o = a.t_str_off[id];
+    if (a.t_str_off[id + 1u] - o != n) continue;
+    bool same = true; u32 k = 0; in_run = false;
+    for (u32 j = 0; j < len && same; ++j) {
+      const u32 c = s[j]; const bool ok = w_kind_ok_char(c);
+      if (ok || !in_run) { same = a.t_str_bytes[o + k] == (ok ? c : (u32)'_'); ++k; }
+      in_run = !ok;
+    }
+    if (same) return id;
+  }
+  return CBH_NONE;
+}
+
+// ---- wave helpers ------------------------------------------------------------------------------------------------
+// exclusive prefix and total of a small per-lane count, by bit planes (reached by all 64 lanes)
+__device__ __forceinline__ u32 w_wave_prefix(u32 x, u32 bits, u32 lane, u32& total) {
+  u32 pre = 0; total = 0;
+  const u64 lt = (1ull << lane) - 1ull;
+  for (u32 b = 0; b < bits; ++b) {
+    const u64 mk = wave_ballot(((x >> b) & 1u) != 0u);
+    pre += (u32)__builtin_popcountll(mk & lt) << b;
+    total += (u32)__builtin_popcountll(mk) << b;
+  }
+  return pre;
+}
+__device__ __forceinline__ u32 w_wave_max(u32 x, u32 bits) {   // largest x of the wave
+  u32 best = 0; bool in = true;
+  for (u32 b = bits; b-- > 0u;) {
+    const u64 mk = wave_ballot(in && ((x >> b) & 1u));
+    if (mk) { best |= 1u << b; in = in && ((x >> b) & 1u); }
+  }
+  return best;
+}
+
+// ---- kernel 1: counts ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ void w_top_level(const CBH_G u8* m, WSpan s, WSpan& resource, WSpan& principal, WSpan& aux, WSpan& request_id,
+                                            u32& n_actions, bool& bad) {
+  resource.p = resource.e = principal.p = principal.e = aux.p = aux.e = request_id.p = request_id.e = 0; n_actions = 0;
+  WField f;
+  while (w_next(m, s, f, bad)) {
+    if (f.wt != 2u) continue;
+    if (f.num == 2u) resource = f.s; else if (f.num == 3u) principal = f.s; else if (f.num == 4u) ++n_actions;
+    else if (f.num == 5u) aux = f.s; else if (f.num == 1u) request_id = f.s;
+  }
+}
+
+#ifdef CBH_HOSTSIM
+static void cbh_wire_count_kernel(WireArgs a)
+#else
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_count_kernel(WireArgs a)
+#endif
+{
+  const u32 lane = threadIdx.x & 63u;
+  const u32 i = blockIdx.x * CBH_BLOCK + threadIdx.x;
+  const bool live = i < a.n;
+  u32 na = 0, nr = 0, st = CBH_WS_OK;
+  if (live) {
+    const u64 o0 = a.moff[i], o1 = a.moff[i + 1u];
+    bool bad = o1 < o0;
+    if (!bad) {
+      WSpan s; s.p = (u32)o0; s.e = (u32)o1;
+      WSpan resource, principal, aux, rid;
+      w_top_level(a.msg, s, resource, principal, aux, rid, na, bad);
+      WField f; WSpan p = principal;
+      while (w_next(a.msg, p, f, bad)) nr += (f.num == 3u && f.wt == 2u);
+    }
+    if (bad) st = CBH_WS_BAD;
+    else if (na > CBH_MAX_ACTIONS_PER_REQUEST || nr > CBH_WIRE_MAX_ROLES) st = CBH_WS_HOST;
+    if (st != CBH_WS_OK) { na = 0; nr = 0; }
+    a.cnt[i] = na | (nr << 8);
+    a.status[i] = (u8)st;
+  }
+  u32 ta, tr;
+  (void)w_wave_prefix(na, 7u, lane, ta);
+  (void)w_wave_prefix(nr, 8u, lane, tr);
+  const u32 wmax_a = w_wave_max(na, 7u), wmax_r = w_wave_max(nr, 8u);
+  const u64 wide = wave_ballot(live && cbh_is_wide(na, nr));
+  const u64 badm = wave_ballot(st == CBH_WS_BAD), hostm = wave_ballot(st == CBH_WS_HOST);
+  if (lane == 0u) {
+    const u32 w = blockIdx.x * (CBH_BLOCK / 64u) + threadIdx.x / 64u;
+    a.wavesum[2u * w] = ta; a.wavesum[2u * w + 1u] = tr;
+    const u32 base = blockIdx.x * CBH_BLOCK + (threadIdx.x & ~63u);
+    if (wmax_a > a.stats->max_actions) w_max32(&a.stats->max_actions, wmax_a);
+    if (wmax_r > a.stats->max_roles) w_max32(&a.stats->max_roles, wmax_r);
+    if (wide) {
+      w_min32(&a.stats->wide_lo, base + (u32)__builtin_ctzll(wide));
+      w_max32(&a.stats->wide_hi, base + 64u - (u32)__builtin_clzll(wide));
+    }
+    if (badm) w_min32(&a.stats->first_bad, base + (u32)__builtin_ctzll(badm));
+    if (hostm) (void)w_add32(&a.stats->n_host, (u32)__builtin_popcountll(hostm));
+  }
+}
+
+// ---- kernel 2: offsets of the waves' slices, totals, the call's default strings (one wave) ----------------------------
+#ifdef CBH_HOSTSIM
+static void cbh_wire_scan_kernel(WireArgs a)
+#else
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_scan_kernel(WireArgs a)
+#endif
+{
+  const u32 lane = threadIdx.x & 63u;
+  const u32 nw = (a.n + 63u) / 64u;
+  const u32 per = (nw + 63u) / 64u;
+  const u32 lo = lane * per, hi = (lo + per < nw) ? lo + per : nw;
+  u32 sa = 0, sr = 0;
+  for (u32 w = lo; w < hi; ++w) { sa += a.wavesum[2u * w]; sr += a.wavesum[2u * w + 1u]; }
+  u32 ta, tr;
+  u32 pa = w_wave_prefix(sa, 32u, lane, ta), pr = w_wave_prefix(sr, 32u, lane, tr);
+  for (u32 w = lo; w < hi; ++w) {
+    a.waveoff[2u * w] = pa; a.waveoff[2u * w + 1u] = pr;
+    pa += a.wavesum[2u * w]; pr += a.wavesum[2u * w + 1u];
+  }
+  if (lane == 0u) {
+    a.stats->n_tuples = ta; a.stats->n_roles = tr;
+    WLane L; L.bad = false; L.host = false; L.dict_full = false;
+    a.stats->sid_empty = w_intern(a, a.dver_off, 0u, 0u, L);
+    a.stats->sid_dver = w_intern(a, a.dver_off, a.dver_len, 0u, L);
+    a.stats->dscope_word = w_scope_word(a, a.dscope_off, a.dscope_len);
+    if (L.dict_full) w_or32(&a.stats->flags, CBH_WF_DICT_FULL);
+  }
+}
+
+// ---- kernel 3: the batch ---------------------------------------------------------------------------------------------
+struct WFrame { WSpan rest; u32 slot; u32 is_map; };
+
+__device__ __forceinline__ u32 w_count_fields(const CBH_G u8* m, WSpan s, u32 fnum, bool& bad) {
+  u32 n = 0; WField f;
+  while (w_next(m, s, f, bad)) n += (f.num == fnum && f.wt == 2u);
+  return n;
+}
+__device__ __forceinline__ u64 w_container(u32 off, u32 n) { return ((u64)CBH_HEAP_BATCH << 62) | ((u64)off << 32) | (u64)n; }
+
+// One container value - the entries of map field `fnum` of `body`, or the values (field 1) of a ListValue - and everything
+// nested in it, depth first.  WRITE = false: returns the heap entries it needs.  WRITE = true: writes them at [base, ..)
+// (the container's own entries first, each nested container's behind what was allocated before it) and returns the same.
+template <bool WRITE>
+__device__ __attribute__((noinline)) u32 w_container_walk(const WireArgs& a, WSpan body, u32 fnum, bool is_map, u32 base, WLane& L) {
+  const CBH_G u8* m = a.msg;
+  WFrame st[CBH_WIRE_MAX_DEPTH];
+  u32 depth = 0;
+  const u32 n0 = w_count_fields(m, body, fnum, L.bad);
+  u32 used = is_map ? 2u * n0 : n0;
+  st[0].rest = body; st[0].slot = base; st[0].is_map = is_map ? (0x80000000u | fnum) : fnum; depth = 1;
+  while (depth && !L.bad) {
+    WFrame& fr = st[depth - 1u];
+    const u32 want = fr.is_map & 0x7FFFFFFFu; const bool mp = (fr.is_map >> 31) != 0u;
+    WField f; bool got = false;
+    while (w_next(m, fr.rest, f, L.bad)) if (f.num == want && f.wt == 2u) { got = true; break; }
+    if (!got) { --depth; continue; }
+    WSpan elem = f.s;
+    if (mp) {
+      WSpan k, v;
+      if (!w_entry(m, f.s, k, v, L.bad)) break;
+      const u32 kid = WRITE ? w_intern(a, k.p, k.e - k.p, 0u, L) : 0u;   // (the counting pass leaves the dictionary alone)
+      if (WRITE && fr.slot < a.heap_cap) { a.heap_tag[fr.slot] = (u8)CBH_T_STRING; a.heap_val[fr.slot] = kid; }
+      ++fr.slot;
+      elem = v;
+    }
+    WVal v;
+    u32 tag = CBH_T_NULL; u64 val = 0;
+    if (w_value(m, elem, v, L.bad)) {
+      if (v.kind == 2u) { tag = CBH_T_DOUBLE; val = v.v; }
+      else if (v.kind == 3u) { tag = CBH_T_STRING; val = WRITE ? w_intern(a, v.s.p, v.s.e - v.s.p, 0u, L) : 0u; }
+      else if (v.kind == 4u) { tag = CBH_T_BOOL; val = v.v ? 1u : 0u; }
+      else if (v.kind >= 5u) {
+        const bool cm = v.kind == 5u;
+        const u32 n2 = w_count_fields(m, v.s, 1u, L.bad);
+        const u32 off2 = base + used;
+        used += cm ? 2u * n2 : n2;
+        tag = cm ? CBH_T_MAP : CBH_T_LIST; val = w_container(off2, n2);
+        if (depth == CBH_WIRE_MAX_DEPTH) { L.host = true; tag = CBH_T_NULL; val = 0; }
+        else if (n2) {
+          const u32 slot = fr.slot;
+          if (WRITE && slot < a.heap_cap) { a.heap_tag[slot] = (u8)tag; a.heap_val[slot] = val; }
+          ++st[depth - 1u].slot;
+          st[depth].rest = v.s; st[depth].slot = off2; st[depth].is_map = cm ? (0x80000000u | 1u) : 1u;
+          ++depth;
+          if (used > CBH_WIRE_MAX_VALUE_ENTRIES) { L.host = true; break; }
+          continue;
+        }
+      }
+    }
+    if (WRITE && fr.slot < a.heap_cap) { a.heap_tag[fr.slot] = (u8)tag; a.heap_val[fr.slot] = val; }
+    ++fr.slot;
+  }
+  return used;
+}
+
+#ifdef CBH_HOSTSIM
+static void cbh_wire_fill_kernel(WireArgs a)
+#else
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
+#endif
+{
+  const CBH_G u8* m = a.msg;
+  const u32 lane = threadIdx.x & 63u;
+  const u32 i = blockIdx.x * CBH_BLOCK + threadIdx.x;
+  const u32 N = a.n;
+  const bool in_range = i < N;
+  const bool live = in_range && a.status[i] == CBH_WS_OK;
+  const u32 c0 = in_range ? a.cnt[i] : 0u;
+  const u32 na = live ? (c0 & 0xFFu) : 0u, nr = live ? (c0 >> 8) : 0u;
+  u32 ta, tr;
+  const u32 wv = blockIdx.x * (CBH_BLOCK / 64u) + threadIdx.x / 64u;
+  const u32 act_off = a.waveoff[2u * wv] + w_wave_prefix(na, 7u, lane, ta);
+  const u32 role_off = a.waveoff[2u * wv + 1u] + w_wave_prefix(nr, 8u, lane, tr);
+  WLane L; L.bad = false; L.host = false; L.dict_full = false;
+  WSpan resource, principal, aux, rid;
+  resource.p = resource.e = principal.p = principal.e = aux.p = aux.e = rid.p = rid.e = 0;
+  const u32 sid_empty = a.stats->sid_empty;
+#define W_RQ(f) a.req_u32[(size_t)(f) * N + i]
+#define W_SID(sp, fl) (((sp).e == (sp).p) ? sid_empty : w_intern(a, (sp).p, (sp).e - (sp).p, (fl), L))
+  if (live) {
+    const u32 base0 = (u32)a.moff[i];
+    WSpan s; s.p = base0; s.e = (u32)a.moff[i + 1u];
+    WSpan pid, pver, pscope, kind, rver, rrid, rscope;
+    pid.p = pid.e = pver.p = pver.e = pscope.p = pscope.e = kind.p = kind.e = rver.p = rver.e = rrid.p = rrid.e = rscope.p = rscope.e = 0;
+    {   // top level: resource 2, principal 3, actions 4, aux_data 5, request_id 1
+      WField f; u32 k = 0;
+      while (w_next(m, s, f, L.bad)) {
+        if (f.wt != 2u) continue;
+        if (f.num == 2u) resource = f.s; else if (f.num == 3u) principal = f.s; else if (f.num == 5u) aux = f.s; else if (f.num == 1u) rid = f.s;
+        else if (f.num == 4u) {
+          if (k < na) {
+            const u32 len = f.s.e - f.s.p;
+            a.tuple_action[act_off + k] = w_intern(a, f.s.p, len, CBH_SF_ACTION, L);   // (an empty action is a string like any other)
+            a.act_span[2u * (act_off + k)] = len ? f.s.p - base0 : 0u; a.act_span[2u * (act_off + k) + 1u] = len;
+          }
+          ++k;
+        }
+      }
+    }
+    {   // Principal: id 1, policy_version 2, roles 3, attr 4, scope 5
+      WSpan p = principal; WField f; u32 k = 0;
+      while (w_next(m, p, f, L.bad)) {
+        if (f.wt != 2u) continue;
+        if (f.num == 1u) pid = f.s; else if (f.num == 2u) pver = f.s; else if (f.num == 5u) pscope = f.s;
+        else if (f.num == 3u) { if (k < nr) a.roles[role_off + k] = w_intern(a, f.s.p, f.s.e - f.s.p, CBH_SF_ROLE, L); ++k; }
+      }
+    }
+    {   // Resource: kind 1, policy_version 2, id 3, attr 4, scope 5
+      WSpan p = resource; WField f;
+      while (w_next(m, p, f, L.bad)) {
+        if (f.wt != 2u) continue;
+        if (f.num == 1u) kind = f.s; else if (f.num == 2u) rver = f.s; else if (f.num == 3u) rrid = f.s; else if (f.num == 5u) rscope = f.s;
+      }
+    }
+    {
+      CBH_G u32* sp = a.in_span + (size_t)i * 2u * CBH_WSPAN_N;
+#define W_SPAN(which, v) sp[2u * (which)] = ((v).e > (v).p) ? (v).p - base0 : 0u; sp[2u * (which) + 1u] = (v).e - (v).p
+      W_SPAN(0, rid); W_SPAN(1, pid); W_SPAN(2, pver); W_SPAN(3, kind); W_SPAN(4, rver); W_SPAN(5, rrid);
+#undef W_SPAN
+    }
+    // scope_value (namer.go:276-278): one leading '.' does not count
+    WSpan psv = pscope, rsv = rscope;
+    if (psv.e > psv.p && m[psv.p] == '.') ++psv.p;
+    if (rsv.e > rsv.p && m[rsv.p] == '.') ++rsv.p;
+    W_RQ(CBH_RQ_PRINCIPAL_ID) = W_SID(pid, 0u);
+    W_RQ(CBH_RQ_P_SCOPE) = (pscope.e == pscope.p) ? a.stats->dscope_word : w_scope_word(a, psv.p, psv.e - psv.p);
+    W_RQ(CBH_RQ_P_VERSION) = (pver.e == pver.p) ? a.stats->sid_dver : w_intern(a, pver.p, pver.e - pver.p, 0u, L);
+    if (w_kind_needs_rewrite(m + kind.p, kind.e - kind.p)) {
+      const u32 ks = w_rewritten_kind_sid(a, m + kind.p, kind.e - kind.p);
+      if (ks == CBH_NONE) L.host = true;
+      W_RQ(CBH_RQ_KIND) = ks;
+    } else W_RQ(CBH_RQ_KIND) = w_intern(a, kind.p, kind.e - kind.p, CBH_SF_KIND, L);
+    W_RQ(CBH_RQ_R_SCOPE) = (rscope.e == rscope.p) ? a.stats->dscope_word : w_scope_word(a, rsv.p, rsv.e - rsv.p);
+    W_RQ(CBH_RQ_R_VERSION) = (rver.e == rver.p) ? a.stats->sid_dver : w_intern(a, rver.p, rver.e - rver.p, 0u, L);
+    W_RQ(CBH_RQ_ROLE_OFF) = role_off; W_RQ(CBH_RQ_ROLE_CNT) = nr;
+    W_RQ(CBH_RQ_ACT_OFF) = act_off; W_RQ(CBH_RQ_ACT_CNT) = na;
+    if (a.t_flags & CBH_MF_READS_REQUEST_STRINGS) {   // raw request strings only CEL programs read
+      W_RQ(CBH_RQ_S_RESOURCE_ID) = W_SID(rrid, 0u);
+      W_RQ(CBH_RQ_S_KIND) = W_SID(kind, 0u);
+      W_RQ(CBH_RQ_S_P_SCOPE) = W_SID(psv, 0u);
+      W_RQ(CBH_RQ_S_R_SCOPE) = W_SID(rsv, 0u);
+      W_RQ(CBH_RQ_S_P_VERSION) = W_SID(pver, 0u);
+      W_RQ(CBH_RQ_S_R_VERSION) = W_SID(rver, 0u);
+    } else {
+      for (u32 f = CBH_RQ_NCORE; f < CBH_RQ_NFIELDS; ++f) W_RQ(f) = 0u;
+    }
+  } else if (in_range) {
+    for (u32 f = 0; f < CBH_RQ_NFIELDS; ++f) W_RQ(f) = 0u;
+    W_RQ(CBH_RQ_ACT_OFF) = act_off; W_RQ(CBH_RQ_ROLE_OFF) = role_off;
+    for (u32 k = 0; k < 2u * CBH_WSPAN_N; ++k) a.in_span[(size_t)i * 2u * CBH_WSPAN_N + k] = 0u;
+  }
+  // attribute columns: one per attribute path the table's programs read (wave-uniform loop: the heap is allocated per wave)
+  bool sens_container = false;
+  for (u32 c = 0; c < a.n_cols; ++c) {
+    const WireCol col = a.cols[c];
+    u32 tag = CBH_T_ABSENT; u64 val = 0;
+    bool is_container = false, is_map = false; WSpan body; body.p = body.e = 0; u32 fnum = 1u, need = 0u;
+    if (live) {
+      const WSpan root = col.root == 0u ? principal : col.root == 1u ? resource : aux;
+      const u32 root_fnum = col.root == 2u ? 1u : 4u;
+      bool done = false; WSpan cur; cur.p = cur.e = 0;
+      if (col.nk == 0u) { is_container = true; is_map = true; body = root; fnum = root_fnum; done = true; }
+      else {
+        if (!w_map_get(m, root, root_fnum, a.col_keys + col.key_off[0], col.key_len[0], cur, L.bad)) { tag = col.nk == 1u ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
+        for (u32 k = 1; k < col.nk && !done; ++k) {
+          WVal v;
+          if (!w_value(m, cur, v, L.bad) || v.kind != 5u) { tag = CBH_T_ERR; done = true; break; }
+          if (!w_map_get(m, v.s, 1u, a.col_keys + col.key_off[k], col.key_len[k], cur, L.bad)) { tag = (k == col.nk - 1u) ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
+        }
+      }
+      if (!done) {
+        WVal v;
+        if (!w_value(m, cur, v, L.bad)) { tag = CBH_T_NULL; }
+        else if (v.kind == 1u) tag = CBH_T_NULL;
+        else if (v.kind == 2u) { tag = CBH_T_DOUBLE; val = v.v; }             // structpb: every number is a double
+        else if (v.kind == 3u) { tag = CBH_T_STRING; val = w_intern(a, v.s.p, v.s.e - v.s.p, 0u, L); }
+        else if (v.kind == 4u) { tag = CBH_T_BOOL; val = v.v ? 1u : 0u; }
+        else { is_container = true; is_map = v.kind == 5u; body = v.s; fnum = 1u; }
+      }
+      if (is_container) {
+        need = w_container_walk<false>(a, body, fnum, is_map, 0u, L);
+        if (need > CBH_WIRE_MAX_VALUE_ENTRIES) { L.host = true; need = 0u; is_container = false; tag = CBH_T_NULL; }
+      }
+    }
+    if (wave_ballot(is_container) != 0) {   // one heap reservation for the wave's containers of this column
+      u32 total;
+      const u32 pre = w_wave_prefix(need, 20u, lane, total);
+      u32 base = 0;
+      if (lane == 0u && total) base = w_add32(&a.stats->heap_used, total);
+      base = wave_readlane(base, 0u);
+      if (is_container) {
+        const u32 off = base + pre;
+        (void)w_container_walk<true>(a, body, fnum, is_map, off, L);
+        u32 n_top = w_count_fields(m, body, fnum, L.bad);
+        tag = is_map ? CBH_T_MAP : CBH_T_LIST; val = w_container(off, n_top);
+        if (c < 32u && ((a.sens_cols >> c) & 1u)) sens_container = true;
+      }
+    }
+    if (in_range) { a.col_tag[(size_t)c * N + i] = (u8)tag; a.col_val[(size_t)c * N + i] = val; }
+  }
+#undef W_RQ
+#undef W_SID
+  const u64 badm = wave_ballot(L.bad), hostm = wave_ballot(L.host), fullm = wave_ballot(L.dict_full), sensm = wave_ballot(sens_container);
+  if (lane == 0u) {
+    const u32 base = blockIdx.x * CBH_BLOCK + (threadIdx.x & ~63u);
+    if (badm) w_min32(&a.stats->first_bad, base + (u32)__builtin_ctzll(badm));
+    if (hostm) (void)w_add32(&a.stats->n_host, (u32)__builtin_popcountll(hostm));
+    const u32 fl = (fullm ? CBH_WF_DICT_FULL : 0u) | (sensm ? CBH_WF_CONTAINER_IN_SENS : 0u);
+    if (fl) w_or32(&a.stats->flags, fl);
+  }
+}
+

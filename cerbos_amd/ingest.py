@@ -47,6 +47,7 @@ def load():
         lib.cbi_batch_request_input.restype = C.POINTER(C.c_uint32)
         lib.cbi_assemble_pb.argtypes = [vp, vp, C.POINTER(capi.CResult), vp, vp, C.c_uint32, C.c_char_p, C.POINTER(vp)]
         lib.cbi_assemble_pb_mt.argtypes = [vp, vp, C.POINTER(capi.CResult), vp, vp, C.c_uint32, C.c_char_p, C.c_int, C.POINTER(vp)]
+        lib.cbi_assemble_wire_pb.argtypes = [vp, C.POINTER(capi.CResult), vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_char_p, C.c_int, C.POINTER(vp)]
         lib.cbi_table_trace_scope.argtypes = [vp]
         lib.cbi_table_trace_scope.restype = C.c_uint32
         lib.cbi_trace_pb.argtypes = [vp, vp, C.POINTER(capi.CResult), vp, C.c_uint32, vp, vp, C.c_uint32, C.POINTER(vp)]
@@ -204,6 +205,19 @@ class IngestTable:
         finally:
             load().cbi_outputs_free(h)
 
+
+    def assemble_wire_pb(self, res, data, offsets, spans, default_policy_version="default", threads=1):
+        """Results of a batch the device flattened (``capi.Table.wire_flatten``; ``spans`` = its ``spans()``) ->
+        ([serialized CheckOutput], flags uint8[n])."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        in_span, act_span, act_off = spans
+        n = len(offsets) - 1
+        h = C.c_void_p()
+        _check(load().cbi_assemble_wire_pb(self.h, C.byref(res.c), data.ctypes.data if data.size else None, offsets.ctypes.data, n,
+                                           int(act_off[-1]) if n else 0, in_span.ctypes.data, act_span.ctypes.data, act_off.ctypes.data,
+                                           default_policy_version.encode(), int(threads), C.byref(h)))
+        return self._outputs(h, n)
 
     def _outputs(self, h, n):
         try:

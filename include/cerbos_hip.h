@@ -256,6 +256,35 @@ int cbh_result_download(cbh_table* t, cbh_device_batch* b, cbh_result* out);
  * launches, measured with HIP events on the library's own stream. */
 int cbh_kernel_time_ms(cbh_table* t, float* check_kernel_ms, float* resolve_kernel_ms);
 
+/* ---- Device-side ingest: serialized CheckInputs in, a resident batch out (the GPU flattens) ----------------------
+ * The reference decodes each CheckInput and builds its request view on the CPU (internal/ruletable/check.go:536-554); so did
+ * libcerbos_ingest.so (cbi_flatten_pb).  cbh_wire_flatten uploads the raw messages - `bytes`, message i =
+ * bytes[offsets[i] .. offsets[i + 1]) - and three kernels (cerbos_amd/csrc/cbh_wire.h) build the batch in HBM: request words,
+ * role / action ids, attribute columns, nested values, strings interned against the table and a batch-local dictionary.
+ * The batch is then an ordinary resident batch: cbh_check_resident, cbh_result_download (results in INPUT order: tuple k of
+ * input i at act_off[i] + k), cbh_batch_release.  Page-locked `bytes` (cbh_alloc_pinned) cross PCIe by DMA.
+ * Returns 0; 1 = nothing was built because some messages (info->n_host of them; all, for a table with a column the device
+ * flattener does not follow) are the host flattener's - more than 64 actions, a pre-0.30 resource kind no policy names,
+ * containers nested deeper than 8: take the batch through cbi_flatten_pb + cbh_check_batch instead, same results;
+ * < 0 = error (a malformed message: info->first_bad). */
+typedef struct cbh_wire_info {
+  uint32_t n_requests; /* = n */
+  uint32_t n_tuples;
+  uint32_t n_host;     /* messages left to the host flattener (return value 1) */
+  uint32_t first_bad;  /* index of the first malformed message, CBH_NONE */
+  uint32_t dict_slots; /* slots of the batch-local string dictionary */
+  uint32_t heap_len;   /* entries of the nested-value heap */
+  uint32_t fill_runs;  /* 1, or more when the dictionary / heap had to grow */
+  uint32_t reserved;
+} cbh_wire_info;
+int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
+                     const char* default_version, const char* default_scope, cbh_device_batch** out, cbh_wire_info* info);
+/* Where the strings a CheckOutput repeats sit in each message (cerbos_ingest.h cbi_assemble_wire_pb reads them instead of
+ * walking the messages again): in_span [n][6] (offset, length) pairs relative to the message start - request id, principal id,
+ * principal version, resource kind, resource version, resource id; act_span [n_tuples] (offset, length) of every action;
+ * act_off [n + 1] first tuple of every input. */
+int cbh_wire_spans_download(cbh_table* t, cbh_device_batch* b, uint32_t* in_span, uint32_t* act_span, uint32_t* act_off);
+
 /* ---- Trace pass: evaluation_errors and outputs (evaluator/cel_errors.go:48-118, check.go:383-411, 776-807) ----
  * The decision kernels only mark the tuples whose evaluation absorbed a CEL error (CBH_ST_CEL_ERROR).  What the
  * reference reports beyond the effect - the (expression, message) pairs and the values of the rules' output

@@ -93,6 +93,12 @@ int cbi_assemble_pb(const cbi_table* t, const cbi_batch* b, const cbh_result* re
 /* Same bytes, assembled on up to n_threads threads inside the call (contiguous ranges of inputs). */
 int cbi_assemble_pb_mt(const cbi_table* t, const cbi_batch* b, const cbh_result* res, const uint8_t* bytes,
                        const uint64_t* offsets, uint32_t n, const char* default_version, int n_threads, cbi_outputs** out);
+/* The same CheckOutputs for a batch the DEVICE flattened (cerbos_hip.h cbh_wire_flatten: the messages never went through
+ * cbi_flatten_pb).  `res` as cbh_result_download filled it for that batch (tuples in input order); in_span / act_span / act_off
+ * as cbh_wire_spans_download returned them: the strings an output repeats are read where the device found them. */
+int cbi_assemble_wire_pb(const cbi_table* t, const cbh_result* res, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
+                         uint32_t n_tuples, const uint32_t* in_span, const uint32_t* act_span, const uint32_t* act_off,
+                         const char* default_version, int n_threads, cbi_outputs** out);
 /* One serialized cerbos.response.v1.CheckResourcesResponse (response.proto:187-300) for the request that
  * cbi_flatten_request_pb flattened: request_id, and per resource entry the resource, actions -> effect and - when
  * the request has include_meta - meta {actions -> matched policy / scope, effective_derived_roles}

@@ -74,6 +74,7 @@ static inline void __syncthreads() { hs_yield(2); }
 
 #include "../../cerbos_amd/csrc/cbh_kernels.h"
 #include "../../cerbos_amd/csrc/cbh_image.h"
+#include "../../cerbos_amd/csrc/cbh_wire_host.h"
 
 static_assert(HS_BLOCK == CBH_BLOCK, "hostsim block size must match the kernels'");
 static thread_local std::string g_err;
@@ -87,8 +88,14 @@ static cbh_check_kernel_fn g_kernel;   // the kernel the fibers run
 static int g_last_kind = -1;   // which kernel family decided the last batch (hostsim_last_kind: tests assert the one they mean to exercise)
 static bool g_trace;   // hostsim_trace: the trace pass's kernel (cbh_trace_batch)
 
+static WireArgs* g_wargs;   // the device flattener's kernels (cbh_wire.h): 1 count, 2 scan, 3 fill
+static int g_wire_kind = 0;
+
 static void fiber_main() {
-  if (g_trace) cbh_trace_kernel(*g_args, g_args);
+  if (g_wire_kind == 1) cbh_wire_count_kernel(*g_wargs);
+  else if (g_wire_kind == 2) cbh_wire_scan_kernel(*g_wargs);
+  else if (g_wire_kind == 3) cbh_wire_fill_kernel(*g_wargs);
+  else if (g_trace) cbh_trace_kernel(*g_args, g_args);
   else g_kernel(*g_args, g_args);
   g_fibers[g_cur].done = true;
   g_fibers[g_cur].waiting = 0;
@@ -229,4 +236,80 @@ extern "C" int hostsim_last_kind() { return g_last_kind; }
 extern "C" int hostsim_trace(const void* blob, size_t len, const cbh_batch* in, const cbh_params* p,
                              cbh_result* out, uint64_t* gbits, cbh_trace* trace) {
   return run_sim(blob, len, in, p, out, gbits, trace);
+}
+
+// ---- the device flattener (cbh_wire.h) on the simulator: the same three launches, retries and sizing as cbh_wire_flatten ----
+struct HsWire {   // valid until the next call
+  uint32_t n, n_tuples, n_roles, n_columns, dict_slots, heap_len, K, fill_runs;
+  const uint32_t* req_u32; const uint32_t* roles; const uint32_t* tuple_action; const uint8_t* col_tag; const uint64_t* col_val;
+  const uint8_t* heap_tag; const uint64_t* heap_val; const uint64_t* dict; const uint32_t* dict_flags;
+  const uint32_t* in_span; const uint32_t* act_span; const uint8_t* msg; const uint8_t* status;
+  WireStats stats;
+};
+static struct {
+  std::vector<uint8_t> msg, status, col_tag, heap_tag; std::vector<uint64_t> moff, col_val, heap_val, dict;
+  std::vector<uint32_t> cnt, wavesum, waveoff, dict_flags, req, roles, tuple_action, in_span, act_span;
+} g_w;
+static void wire_launch(int kind, uint32_t nblocks) {
+  g_wire_kind = kind;
+  for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
+  g_wire_kind = 0;
+}
+extern "C" int hostsim_wire_flatten(const void* blob, size_t len, const uint8_t* bytes, const uint64_t* offsets, uint32_t n, const char* dver,
+                                    const char* dscope, uint32_t dict_slots_hint, uint32_t heap_hint, HsWire* out) {
+  TableDev t{}; std::vector<uint32_t> meta;
+  const uint8_t* base = static_cast<const uint8_t*>(blob);
+  if (const char* e = cbh_parse_image(t, meta, base, base, len)) { g_err = e; return -1; }
+  WireIndexHost wi;
+  if (const char* e = cbh_wire_index_build(wi, base, len, meta)) { g_err = e; return -1; }
+  if (wi.why_not) { g_err = wi.why_not; return 1; }
+  const uint64_t total = n ? offsets[n] : 0;
+  std::string dv = dver ? dver : "default", ds = dscope ? dscope : "";
+  if (!ds.empty() && ds[0] == '.') ds.erase(0, 1);   // scope_value
+  g_w.msg.assign(bytes, bytes + total);
+  g_w.msg.insert(g_w.msg.end(), dv.begin(), dv.end()); g_w.msg.insert(g_w.msg.end(), ds.begin(), ds.end()); g_w.msg.resize(g_w.msg.size() + 16, 0);
+  g_w.moff.assign(offsets, offsets + n + 1);
+  if (n == 0) g_w.moff.assign(1, 0);
+  const uint32_t nw = (n + 63) / 64;
+  WireArgs a{};
+  a.t_str_off = t.str_off; a.t_str_bytes = t.str_bytes; a.K = t.K; a.t_flags = t.flags;
+  a.tix = wi.tix.data(); a.tix_mask = wi.tix_mask; a.scope_of_sid = wi.scope_of_sid.data();
+  a.cols = wi.cols.data(); a.col_keys = wi.col_keys.data(); a.n_cols = meta[CBH_M_NCOLUMNS]; a.sens_cols = meta[CBH_M_SENS_COLS];
+  a.msg = g_w.msg.data(); a.moff = g_w.moff.data(); a.n = n;
+  a.dver_off = (uint32_t)total; a.dver_len = (uint32_t)dv.size(); a.dscope_off = (uint32_t)(total + dv.size()); a.dscope_len = (uint32_t)ds.size();
+  g_w.cnt.assign(n + 1, 0); g_w.status.assign(n + 1, 0); g_w.wavesum.assign(2 * (size_t)nw + 2, 0); g_w.waveoff.assign(2 * (size_t)nw + 2, 0);
+  a.cnt = g_w.cnt.data(); a.status = g_w.status.data(); a.wavesum = g_w.wavesum.data(); a.waveoff = g_w.waveoff.data();
+  WireStats st; cbh_wire_stats_init(st);
+  a.stats = &st;
+  g_wargs = &a;
+  wire_launch(1, nw);
+  uint32_t slots = dict_slots_hint ? dict_slots_hint : cbh_wire_dict_slots(n);
+  uint32_t heap_cap = heap_hint ? heap_hint : cbh_wire_heap_guess(total);
+  uint32_t runs = 0;
+  for (;;) {
+    g_w.dict.assign(slots, 0); g_w.dict_flags.assign(slots / 4 + 1, 0);
+    a.lix = g_w.dict.data(); a.lix_mask = slots - 1; a.lflags = g_w.dict_flags.data();
+    st.flags = 0; st.heap_used = 0;
+    const uint32_t n_host0 = st.n_host;
+    wire_launch(2, 1);
+    g_w.req.assign((size_t)CBH_RQ_NFIELDS * n + 1, 0xDDDDDDDDu); g_w.roles.assign((size_t)st.n_roles + 1, 0xDDDDDDDDu);
+    g_w.tuple_action.assign((size_t)st.n_tuples + 1, 0xDDDDDDDDu);
+    g_w.col_tag.assign((size_t)a.n_cols * n + 1, 0xDD); g_w.col_val.assign((size_t)a.n_cols * n + 1, 0xDDDDDDDDDDDDDDDDull);
+    g_w.heap_tag.assign((size_t)heap_cap + 1, 0xDD); g_w.heap_val.assign((size_t)heap_cap + 1, 0);
+    g_w.in_span.assign((size_t)n * 2 * CBH_WSPAN_N + 1, 0); g_w.act_span.assign((size_t)st.n_tuples * 2 + 1, 0);
+    a.req_u32 = g_w.req.data(); a.roles = g_w.roles.data(); a.tuple_action = g_w.tuple_action.data(); a.col_tag = g_w.col_tag.data(); a.col_val = g_w.col_val.data();
+    a.heap_tag = g_w.heap_tag.data(); a.heap_val = g_w.heap_val.data(); a.heap_cap = heap_cap; a.in_span = g_w.in_span.data(); a.act_span = g_w.act_span.data();
+    wire_launch(3, nw);
+    ++runs;
+    if (st.flags & CBH_WF_DICT_FULL) { if (slots >= (1u << 30)) { g_err = "dictionary cannot grow"; return -1; } slots *= 4; st.n_host = n_host0; continue; }
+    if (st.heap_used > heap_cap) { heap_cap = st.heap_used; st.n_host = n_host0; continue; }
+    break;
+  }
+  out->n = n; out->n_tuples = st.n_tuples; out->n_roles = st.n_roles; out->n_columns = a.n_cols; out->dict_slots = slots; out->heap_len = st.heap_used;
+  out->K = t.K; out->fill_runs = runs;
+  out->req_u32 = g_w.req.data(); out->roles = g_w.roles.data(); out->tuple_action = g_w.tuple_action.data(); out->col_tag = g_w.col_tag.data();
+  out->col_val = g_w.col_val.data(); out->heap_tag = g_w.heap_tag.data(); out->heap_val = g_w.heap_val.data(); out->dict = g_w.dict.data();
+  out->dict_flags = g_w.dict_flags.data(); out->in_span = g_w.in_span.data(); out->act_span = g_w.act_span.data(); out->msg = g_w.msg.data();
+  out->status = g_w.status.data(); out->stats = st;
+  return 0;
 }

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "hostsim", "hostsim.cpp")
 LIB = os.path.join(HERE, "hostsim", "libcbh_hostsim.so")
 _DEPS = [SRC] + [os.path.join(ROOT, "cerbos_amd", "csrc", f) for f in
-                 ("cbh_kernels.h", "cbh_check_wave.h", "cbh_check_flat.h", "cbh_check_walk2.h", "cbh_interp.h", "cbh_vm.h", "cbh_blob.h", "cbh_image.h")] + [os.path.join(ROOT, "include", "cerbos_hip.h")]
+                 ("cbh_kernels.h", "cbh_check_wave.h", "cbh_check_flat.h", "cbh_check_walk2.h", "cbh_interp.h", "cbh_vm.h", "cbh_blob.h", "cbh_image.h", "cbh_wire.h", "cbh_wire_host.h")] + [os.path.join(ROOT, "include", "cerbos_hip.h")]
 
 _lib = None
 

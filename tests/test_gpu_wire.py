@@ -1,0 +1,91 @@
+"""GPU tier: the device flattener through the C ABI - cbh_wire_flatten -> cbh_check_resident -> cbh_result_download ->
+cbh_wire_spans_download -> cbi_assemble_wire_pb - against the host road (cbi_flatten_pb -> cbh_check_batch -> cbi_assemble_pb)
+on the same serialized CheckInputs: decisions tuple by tuple, then the serialized CheckOutputs byte by byte."""
+import numpy as np
+import pytest
+
+from cerbos_amd import capi, wire, workloads
+from cerbos_amd.ingest import IngestTable
+from cerbos_amd.lower.blob import lower_rule_table
+from cerbos_amd.lower.celc import LoweringError
+from cerbos_amd.policy.loader import policies_from_docs
+from cerbos_amd.ruletable.build import rule_table_from_policies
+from test_fuzz_parity import _policies, _requests
+
+pytestmark = pytest.mark.gpu
+NOW = 1_700_000_000_000_000_000
+FIELDS = ("effect", "policy", "scope", "status", "edr")
+
+
+def _both_roads(lt, inputs, flags=0):
+    data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+    table, it = capi.Table(lt.blob), IngestTable(lt.blob)
+    try:
+        hb = it.flatten_pb(data, off)
+        want_dev = table.check(hb, now_ns=NOW, flags=flags | capi.F_WANT_DERIVED_ROLES, device_order=True)
+        want_out, want_flags = it.assemble_pb(hb, want_dev, data, off)
+        want = want_dev.to_input_order(hb)
+        db = table.wire_flatten(data, off)
+        table.launch(db, now_ns=NOW, flags=flags | capi.F_WANT_DERIVED_ROLES)
+        have = table.download(db)
+        for f in FIELDS:
+            a, b = getattr(want, f), getattr(have, f)
+            assert np.array_equal(a, b), (f, int(np.flatnonzero(a != b)[0]) if a.shape == b.shape else (a.shape, b.shape))
+        have_out, have_flags = it.assemble_wire_pb(have, data, off, table.wire_spans(db))
+        assert have_out == want_out and np.array_equal(have_flags, want_flags)
+        info = db.wire_info
+        db.close()
+        return info
+    finally:
+        table.close()
+        it.close()
+
+
+@pytest.mark.parametrize("name,n", [("C2", 20_000), ("C3", 20_000), ("C4", 6_000), ("C5", 20_000)])
+def test_workloads_by_both_roads(name, n):
+    pol = getattr(workloads, name.lower() + "_policies")
+    reqs = getattr(workloads, name.lower() + "_requests")
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol())))
+    info = _both_roads(lt, reqs(n_requests=n).to_inputs())
+    assert info["n_requests"] == n and info["n_host"] == 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_stores_by_both_roads(seed):
+    rng = np.random.default_rng(10_000 + seed)
+    rt = rule_table_from_policies(policies_from_docs(_policies(rng)))
+    try:
+        lt = lower_rule_table(rt)
+    except LoweringError:
+        pytest.skip("store refused by the lowering")
+    inputs = [i for i in _requests(rng, 1500) if len(i.get("actions") or []) <= 64]
+    for flags in (0, capi.F_LENIENT_SCOPE_SEARCH):
+        _both_roads(lt, inputs, flags)
+
+
+def test_a_quarter_million_requests():
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c2_policies())))
+    info = _both_roads(lt, workloads.c2_requests(n_requests=250_000).to_inputs())
+    assert info["n_tuples"] == 1_000_000
+
+
+def test_messages_for_the_host_flattener_and_malformed_ones():
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c2_policies())))
+    inputs = workloads.c2_requests(n_requests=500).to_inputs()
+    table = capi.Table(lt.blob)
+    try:
+        wide = list(inputs)
+        wide[77] = dict(wide[77], actions=["a%d" % k for k in range(65)])
+        data, off = wire.pack_messages([wire.encode_check_input(i) for i in wide])
+        with pytest.raises(capi.HostFlattenerNeeded):
+            table.wire_flatten(data, off)
+        msgs = [wire.encode_check_input(i) for i in inputs]
+        msgs[300] = msgs[300][:-2]
+        data, off = wire.pack_messages(msgs)
+        with pytest.raises(capi.HipEngineError, match="index 300"):
+            table.wire_flatten(data, off)
+        db = table.wire_flatten(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+        assert db.n_tuples == 0
+        db.close()
+    finally:
+        table.close()

@@ -1,0 +1,163 @@
+"""The device flattener (cerbos_amd/csrc/cbh_wire.h: serialized CheckInputs -> the batch in HBM, built by three kernels)
+against the host flattener (libcerbos_ingest.so), request by request and value by value; then decisions from a
+device-flattened batch against decisions from a host-flattened one.
+
+CPU tier: the kernels' source on the host simulator (tests/hostsim).  GPU tier: the same through the C ABI
+(cbh_wire_flatten, cbh_check_resident, cbh_wire_spans_download) - tests/test_gpu_wire.py."""
+import numpy as np
+import pytest
+
+import hostsim_api
+import wire_device_util as wu
+from cerbos_amd import wire, workloads
+from cerbos_amd.ingest import IngestTable
+from cerbos_amd.lower.blob import lower_rule_table
+from cerbos_amd.lower.celc import LoweringError
+from cerbos_amd.policy.loader import policies_from_docs
+from cerbos_amd.ruletable.build import rule_table_from_policies
+from helpers import load_json, store_rule_table
+from test_fuzz_parity import _policies, _requests
+from test_hostsim_golden import GLOBALS
+
+
+def _meta_flags(lt):
+    """cbh_blob.h: the META section's flag word"""
+    import struct
+    blob = lt.blob
+    nsec = struct.unpack_from("<I", blob, 8)[0]
+    for i in range(nsec):
+        sid, _cnt, off, _nb, _ = struct.unpack_from("<IIQQQ", blob, 32 + 32 * i)
+        if sid == 1:
+            meta = struct.unpack_from("<24I", blob, off)
+            return meta[META_FLAGS_INDEX]
+    raise AssertionError("no META section")
+
+
+def _meta_index(name):
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "cerbos_amd", "csrc", "cbh_blob.h")).read()
+    return int(re.search(name + r"\s*=\s*(\d+)", src).group(1))
+
+
+META_FLAGS_INDEX = _meta_index("CBH_M_FLAGS")
+
+
+def _compare(lt, inputs, default_version="default", default_scope="", **kw):
+    """host flattener vs device flattener on the same messages; returns (host batch, device batch)"""
+    data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+    it = IngestTable(lt.blob)
+    try:
+        hb = it.flatten_pb(data, off, default_version, default_scope, sort=False)
+    finally:
+        it.close()
+    rc, wb = wu.sim_flatten(lt, data, off, default_version, default_scope, **kw)
+    assert rc == 0
+    assert wb.stats["first_bad"] == 0xFFFFFFFF and wb.stats["n_host"] == 0, wb.stats
+    wu.assert_same_requests(lt, hb, wb, bool(_meta_flags(lt) & wu.MF_READS_REQUEST_STRINGS))
+    return hb, wb
+
+
+@pytest.mark.parametrize("name", ["C2", "C3", "C5"])
+def test_synthetic_workloads(name):
+    pol, reqs = {"C2": (workloads.c2_policies, lambda: workloads.c2_requests(n_requests=700)),
+                 "C3": (workloads.c3_policies, lambda: workloads.c3_requests(n_requests=700)),
+                 "C5": (workloads.c5_policies, lambda: workloads.c5_requests(n_requests=700))}[name]
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol())))
+    hb, wb = _compare(lt, reqs().to_inputs())
+    assert wb.stats["max_actions"] == int(hb.req_u32[9].max()) and wb.stats["max_roles"] == int(hb.req_u32[7].max())
+
+
+def test_golden_store_inputs():
+    """the reference's engine cases: principal / resource scopes, versions, nested attributes, JWT claims in auxData"""
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    inputs = [inp for case in load_json("engine_cases.json") for inp in case["inputs"]]
+    data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+    rc, wb = wu.sim_flatten(lt, data, off)
+    if rc == 1:
+        pytest.skip("the golden store reads auxData.jwts: its inputs are the host flattener's")
+    _compare(lt, inputs)
+    _compare(lt, inputs, default_version="v9", default_scope=".acme")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_inputs(seed):
+    """ragged roles / actions, nested and wrongly typed attributes, strings the table does not know"""
+    rng = np.random.default_rng(10_000 + seed)
+    rt = rule_table_from_policies(policies_from_docs(_policies(rng)))
+    try:
+        lt = lower_rule_table(rt)
+    except LoweringError:
+        pytest.skip("store refused by the lowering")
+    inputs = [i for i in _requests(rng, 300) if len(i.get("actions") or []) <= 64]
+    hb, wb = _compare(lt, inputs)
+    # a dictionary and a heap that start far too small: the call grows them and runs the fill again - same batch
+    hb2, wb2 = _compare(lt, inputs, dict_slots=16, heap=1)
+    assert wb2.fill_runs > 1 or (wb2.heap_len <= 1 and wb2.dict_slots >= 16)
+
+
+def test_messages_left_to_the_host_are_counted_not_guessed():
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c2_policies())))
+    inputs = workloads.c2_requests(n_requests=70).to_inputs()
+    inputs[3] = dict(inputs[3], actions=["a%d" % k for k in range(65)])                  # the host flattener splits it
+    inputs[9] = dict(inputs[9], resource=dict(inputs[9]["resource"], kind="doc:old-form"))   # namer.go:213-218 rewrites it
+    data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+    rc, wb = wu.sim_flatten(lt, data, off)
+    assert rc == 0 and wb.stats["n_host"] == 2 and wb.stats["first_bad"] == 0xFFFFFFFF
+    assert wb.status[3] == 2
+
+
+def test_malformed_message_is_named():
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c2_policies())))
+    msgs = [wire.encode_check_input(i) for i in workloads.c2_requests(n_requests=130).to_inputs()]
+    msgs[70] = msgs[70][:-3]          # a length that runs past the end
+    msgs[101] = b"\x0f" + msgs[101]   # wire type 7
+    data, off = wire.pack_messages(msgs)
+    rc, wb = wu.sim_flatten(lt, data, off)
+    assert rc == 0 and wb.stats["first_bad"] == 70
+
+
+def test_empty_batch_and_empty_messages():
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c2_policies())))
+    rc, wb = wu.sim_flatten(lt, np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert rc == 0 and wb.n == 0 and wb.n_tuples == 0
+    _compare(lt, [{}, {"actions": ["view"]}, {"principal": {"id": "x", "roles": []}, "resource": {"kind": ""}, "actions": ["", "view", ""]}])
+
+
+@pytest.mark.parametrize("name", ["C2", "C5"])
+def test_decisions_from_a_device_flattened_batch(name):
+    """the decision kernels (simulator) on the device-flattened batch == on the host-flattened batch, tuple by tuple"""
+    pol, reqs = {"C2": (workloads.c2_policies, lambda: workloads.c2_requests(n_requests=400)),
+                 "C5": (workloads.c5_policies, lambda: workloads.c5_requests(n_requests=400))}[name]
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol())))
+    hb, wb = _compare(lt, reqs().to_inputs())
+    now = 1_700_000_000_000_000_000
+    want = hostsim_api.check(lt, hb, now_ns=now, device_order=True)
+    have = hostsim_api.check(lt, wu.to_batch(lt, wb), now_ns=now, device_order=True)
+    for f in ("effect", "policy", "scope", "status"):
+        assert np.array_equal(getattr(want, f), getattr(have, f)), f
+
+
+def test_outputs_assembled_from_the_device_spans():
+    """cbi_assemble_wire_pb (spans the fill kernel noted) == cbi_assemble_pb (spans the host flattener noted), byte for byte"""
+    from cerbos_amd import capi
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c5_policies())))
+    inputs = workloads.c5_requests(n_requests=300).to_inputs()
+    inputs[5] = dict(inputs[5], actions=["view", "view", "edit"], requestId="")     # duplicate actions, no request id
+    data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+    it = IngestTable(lt.blob)
+    hb = it.flatten_pb(data, off, sort=False)
+    rc, wb = wu.sim_flatten(lt, data, off)
+    assert rc == 0
+    rng = np.random.default_rng(5)
+    res = capi.Result(hb.n_tuples, hb.n_requests, ("policy", "scope", "status", "edr"))
+    res.effect[:] = rng.integers(1, 3, hb.n_tuples)
+    res.policy[:] = (2 << 28)   # resource policy at the root scope
+    res.scope[:] = 0xFFFFFFFF
+    res.status[:] = rng.integers(0, 2, hb.n_tuples)
+    res.edr[:] = rng.integers(0, 4, hb.n_requests)
+    want, wflags = it.assemble_pb(hb, res, data, off)
+    act_off = np.concatenate([wb.req_u32[8], [wb.n_tuples]]).astype(np.uint32)
+    have, hflags = it.assemble_wire_pb(res, data, off, (np.ascontiguousarray(wb.in_span), np.ascontiguousarray(wb.act_span), act_off))
+    assert have == want and np.array_equal(wflags, hflags)
+    it.close()
