@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "cbh_check_batch", "cbh_trace_batch", "cbh_batch_upload", "cbh_batch_upload_on", "cbh_batch_release", "cbh_check_resident",
     "cbh_synchronize", "cbh_result_download", "cbh_kernel_time_ms", "cbh_plan_describe",
     "cbh_check_resident_many", "cbh_table_set_resident_streams", "cbh_table_resident_streams",
-    "cbh_wire_flatten", "cbh_wire_spans_download",
+    "cbh_wire_flatten", "cbh_wire_spans_download", "cbh_wire_outputs",
 ]
 
 
@@ -160,6 +160,8 @@ def load():
     lib.cbh_wire_flatten.restype = i32
     lib.cbh_wire_spans_download.argtypes = [vp, vp, vp, vp, vp]
     lib.cbh_wire_spans_download.restype = i32
+    lib.cbh_wire_outputs.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.POINTER(C.c_size_t)]
+    lib.cbh_wire_outputs.restype = i32
     _lib = lib
     return lib
 
@@ -377,6 +379,24 @@ class Table:
         act_off = np.zeros(n + 1, dtype=np.uint32)
         _check(load().cbh_wire_spans_download(self.h, dbatch.h, in_span.ctypes.data, act_span.ctypes.data, act_off.ctypes.data))
         return in_span[:n], act_span[:T], act_off
+
+    def wire_outputs(self, dbatch, cap=None):
+        """``cbh_wire_outputs``: the serialized CheckOutputs of a device-flattened batch, written by the GPU (after ``launch``)
+        -> ([bytes], flags uint8[n])"""
+        n = dbatch.n_requests
+        cap = int(cap if cap is not None else 96 * max(n, 1))
+        off = np.zeros(n + 1, dtype=np.uint64)
+        flags = np.zeros(max(n, 1), dtype=np.uint8)
+        while True:
+            buf = np.zeros(max(cap, 1), dtype=np.uint8)
+            need = C.c_size_t()
+            rc = load().cbh_wire_outputs(self.h, dbatch.h, buf.ctypes.data, cap, off.ctypes.data, flags.ctypes.data, C.byref(need))
+            if rc == 2:
+                cap = int(need.value)
+                continue
+            _check(rc)
+            raw = buf.tobytes()
+            return [raw[int(off[i]):int(off[i + 1])] for i in range(n)], flags[:n]
 
     def launch(self, dbatch, now_ns=0, flags=0):
         p = CParams(now_ns, flags, 0)

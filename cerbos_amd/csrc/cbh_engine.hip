@@ -169,6 +169,7 @@ struct Replica {   // the table on one device
   int ctx_count = 0;
   // the device flattener's per-table data (cbh_wire_host.h WireIndexHost), uploaded at load
   u64* w_tix = nullptr; u32* w_scope_of_sid = nullptr; WireCol* w_cols = nullptr; u8* w_col_keys = nullptr;
+  u32* w_name_off = nullptr; u8* w_name_bytes = nullptr;
 };
 
 struct cbh_table {
@@ -195,6 +196,8 @@ struct cbh_device_batch {
   std::vector<std::pair<void*, size_t>> allocs;   // (block, capacity) taken from the replica's pool
   // a batch the device flattened (cbh_wire_flatten): where the response's strings sit in the messages
   bool wire = false; u32* w_in_span = nullptr; u32* w_act_span = nullptr;
+  const u64* w_moff = nullptr; u32 w_dver_off = 0, w_dver_len = 0;   // (the device assembler reads the messages again)
+  u32* w_sizes = nullptr; u64* w_wavesum = nullptr; u64* w_waveoff = nullptr; WireOutStats* w_ostats = nullptr; u64* w_out_off = nullptr; u8* w_out_flags = nullptr;
 };
 
 static void replica_destroy(Replica* r) {
@@ -204,7 +207,7 @@ static void replica_destroy(Replica* r) {
   if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
   for (auto& sl : r->ring) for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
   if (r->image && r->owns_image) (void)hipFree(r->image);
-  for (void* p : {(void*)r->w_tix, (void*)r->w_scope_of_sid, (void*)r->w_cols, (void*)r->w_col_keys}) if (p) (void)hipFree(p);
+  for (void* p : {(void*)r->w_tix, (void*)r->w_scope_of_sid, (void*)r->w_cols, (void*)r->w_col_keys, (void*)r->w_name_off, (void*)r->w_name_bytes}) if (p) (void)hipFree(p);
   for (auto& a : r->pool_free) (void)hipFree(a.first);
   for (auto* c : r->ctx_idle) {
     for (auto& s : c->s) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
@@ -252,6 +255,8 @@ static int wire_index_install(cbh_table* t, const uint8_t* host_image, size_t le
     HIPCHK(hipMalloc((void**)&r->w_scope_of_sid, w.scope_of_sid.size() * 4)); HIPCHK(hipMemcpy(r->w_scope_of_sid, w.scope_of_sid.data(), w.scope_of_sid.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&r->w_cols, w.cols.size() * sizeof(WireCol))); HIPCHK(hipMemcpy(r->w_cols, w.cols.data(), w.cols.size() * sizeof(WireCol), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&r->w_col_keys, w.col_keys.size())); HIPCHK(hipMemcpy(r->w_col_keys, w.col_keys.data(), w.col_keys.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&r->w_name_off, w.name_off.size() * 4)); HIPCHK(hipMemcpy(r->w_name_off, w.name_off.data(), w.name_off.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&r->w_name_bytes, w.name_bytes.size())); HIPCHK(hipMemcpy(r->w_name_bytes, w.name_bytes.data(), w.name_bytes.size(), hipMemcpyHostToDevice));
   }
   return 0;
 }
@@ -829,7 +834,7 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
   d.req_lo = 0; d.req_hi = n;
   d.req_u32 = a.req_u32; d.roles = a.roles; d.tuple_req = nullptr; d.tuple_action = a.tuple_action; d.col_tag = a.col_tag; d.col_val = a.col_val;
   d.heap_tag = a.heap_tag; d.heap_val = a.heap_val; d.str_off = nullptr; d.str_bytes = d_msg; d.str_flags = (const u8*)a.lflags; d.str_keys = a.lix;
-  b->w_in_span = a.in_span; b->w_act_span = a.act_span;
+  b->w_in_span = a.in_span; b->w_act_span = a.act_span; b->w_moff = d_moff; b->w_dver_off = a.dver_off; b->w_dver_len = a.dver_len;
   static const bool force_any = getenv("CBH_FLAT_ANY") != nullptr;
   b->max_actions = st.max_actions; b->max_roles = st.max_roles; b->plain_tags = !force_any && !(st.flags & CBH_WF_CONTAINER_IN_SENS);
   b->wide_lo = st.wide_hi ? st.wide_lo : 0; b->wide_hi = st.wide_hi;
@@ -864,6 +869,59 @@ extern "C" int cbh_wire_spans_download(cbh_table* t, cbh_device_batch* b, uint32
   if (n) HIPCHK(hipMemcpyAsync(act_off, d.req_u32 + (size_t)CBH_RQ_ACT_OFF * n, n * 4, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   act_off[n] = d.n_tuples;
+  return 0;
+}
+
+
+// The serialized CheckOutputs of a batch the device flattened, written by the device (cbh_wire.h cbh_wire_out_*): after
+// cbh_check_resident on `b`, three launches on its stream - sizes, scan, bytes - and one copy back.
+extern "C" int cbh_wire_outputs(cbh_table* t, cbh_device_batch* b, uint8_t* bytes, size_t cap, uint64_t* offsets, uint8_t* flags, size_t* need) {
+  if (!t || !b || !offsets || !need || (cap && !bytes)) return fail("null argument");
+  if (!b->wire) return fail("cbh_wire_outputs: not a batch of cbh_wire_flatten");
+  Replica* rep = b->rep;
+  HIPCHK(hipSetDevice(rep->device));
+  hipStream_t s = b->stream;
+  const BatchDev& d = b->dev;
+  const u32 n = d.n_requests, nw = (n + 63u) / 64u;
+  *need = 0;
+  if (!b->w_sizes) {
+    int rc = 0;
+    rc |= dalloc(b, b->w_sizes, (size_t)n + 1); rc |= dalloc(b, b->w_wavesum, (size_t)nw + 1); rc |= dalloc(b, b->w_waveoff, (size_t)nw + 1);
+    rc |= dalloc(b, b->w_ostats, 1); rc |= dalloc(b, b->w_out_off, (size_t)n + 1); rc |= dalloc(b, b->w_out_flags, (size_t)n + 1);
+    if (rc != 0) return -1;
+  }
+  WireOutArgs a; std::memset(&a, 0, sizeof(a));
+  const TableDev& td = rep->dev;
+  a.t_str_off = td.str_off; a.t_str_bytes = td.str_bytes;
+  a.scope_sid = reinterpret_cast<const u32*>(static_cast<const uint8_t*>(rep->image) + t->wire.scope_sid_offset); a.n_scopes = t->wire.n_scopes;
+  a.n_policies = t->wire.n_policies; a.name_off = rep->w_name_off; a.name_bytes = rep->w_name_bytes; a.n_dr = t->wire.n_dr; a.n = n;
+  a.msg = d.str_bytes; a.moff = b->w_moff; a.dver_off = b->w_dver_off; a.dver_len = b->w_dver_len;
+  a.req_u32 = d.req_u32; a.tuple_action = d.tuple_action; a.in_span = b->w_in_span; a.act_span = b->w_act_span;
+  a.effect = b->out.effect; a.policy = b->out.policy; a.scope = b->out.scope; a.status = b->out.status; a.edr = b->out.edr;
+  a.sizes = b->w_sizes; a.wavesum = b->w_wavesum; a.waveoff = b->w_waveoff; a.stats = b->w_ostats; a.out_off = b->w_out_off; a.out_flags = b->w_out_flags;
+  WireOutStats st; std::memset(&st, 0, sizeof(st));
+  HIPCHK(hipMemcpyAsync(b->w_ostats, &st, sizeof(st), hipMemcpyHostToDevice, s));
+  if (nw) hipLaunchKernelGGL(cbh_wire_out_size_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, a);
+  hipLaunchKernelGGL(cbh_wire_out_scan_kernel, dim3(1), dim3(CBH_BLOCK), 0, s, a);
+  HIPCHK(hipMemcpyAsync(&st, b->w_ostats, sizeof(st), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (st.errors & 1u) return fail("cbh_wire_outputs: a policy or scope id of the results is out of the table's range");
+  if (st.errors & 2u) return fail("cbh_wire_outputs: a CheckOutput exceeds 16 MB");
+  *need = (size_t)st.total;
+  if (st.total > cap) { g_err = "cbh_wire_outputs: the output buffer is too small"; return 2; }
+  u8* d_out = nullptr;
+  if (dalloc(b, d_out, (size_t)st.total + 1) != 0) return -1;
+  a.out = d_out;
+  if (nw) hipLaunchKernelGGL(cbh_wire_out_write_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, a);
+  if (st.total) HIPCHK(hipMemcpyAsync(bytes, d_out, (size_t)st.total, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(offsets, b->w_out_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, s));
+  if (flags && n) HIPCHK(hipMemcpyAsync(flags, b->w_out_flags, (size_t)n, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipGetLastError());
+  {   // the output block goes back to the pool now: a batch that is asked again allocates again
+    std::lock_guard<std::mutex> lk(rep->pool_mu);
+    for (size_t i = b->allocs.size(); i-- > 0;) if (b->allocs[i].first == d_out) { rep->pool_free.push_back(b->allocs[i]); b->allocs.erase(b->allocs.begin() + (long)i); break; }
+  }
   return 0;
 }
 

@@ -633,3 +633,193 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
   }
 }
 
+
+// ============================================================================================================================
+// The way back (SURVEY §8 f2 on the GPU): serialized enginev1.CheckOutput messages written by the device, for a batch the
+// device flattened.  The reference builds them in checkWithAuditTrail / setEffect (check.go:64-94, 513-530); cbh_ingest.cpp
+// assemble_outputs does it per input on a host thread (90 % of the device road's wall time once the flattening had moved to
+// the GPU, profiles/r03_e2e_wire_inclusive.json).  Three launches - sizes, one-wave scan, bytes - and one copy back:
+//   CheckOutput { 1 request_id, 2 resource_id, 3 actions map<string, ActionEffect{1 effect, 2 policy, 3 scope}>, 4 effective_derived_roles* }
+// byte for byte what cbi_assemble_wire_pb writes (tests hold the two against each other): an action named twice keeps its
+// first place and takes the later result unless the earlier one is a DENY and the later is not (check.go:513-530); policy keys
+// as namer.PolicyKeyFromFQN gives them (namer.go:95-134), resource kinds / versions of the pre-0.30 form rewritten on the fly.
+#define CBH_WO_UNSUPPORTED 1u    /* = CBI_OUT_UNSUPPORTED (include/cerbos_ingest.h) */
+#define CBH_WO_CEL_ERROR 2u      /* = CBI_OUT_CEL_ERROR */
+#define CBH_WO_WANTS_TRACE 16u   /* = CBI_OUT_WANTS_TRACE */
+#define CBH_WO_MAX_OUTPUT 0xFFFFFFu   /* bytes of one CheckOutput (larger: the call fails) */
+
+struct WireOutStats { u64 total; u32 errors; u32 pad; };   // errors: bit 0 a policy / scope id out of range, bit 1 an output too large
+struct WireOutArgs {
+  const CBH_G u32* t_str_off; const CBH_G u8* t_str_bytes;
+  const CBH_G u32* scope_sid; u32 n_scopes; u32 n_policies;
+  const CBH_G u32* name_off; const CBH_G u8* name_bytes; u32 n_dr; u32 n;   // names: policy keys (CBH_P_TABLE ids), then derived roles
+  const CBH_G u8* msg; const CBH_G u64* moff; u32 dver_off, dver_len;
+  const CBH_G u32* req_u32; const CBH_G u32* tuple_action; const CBH_G u32* in_span; const CBH_G u32* act_span;
+  const CBH_G u8* effect; const CBH_G u32* policy; const CBH_G u32* scope; const CBH_G u8* status; const CBH_G u64* edr;
+  CBH_G u32* sizes; CBH_G u64* wavesum; CBH_G u64* waveoff; CBH_G WireOutStats* stats;
+  CBH_G u8* out; CBH_G u64* out_off; CBH_G u8* out_flags;
+};
+
+template <bool WRITE> struct WSink {
+  CBH_G u8* w; u32 n;
+  __device__ __forceinline__ void byte(u32 b) { if (WRITE) w[n] = (u8)b; ++n; }
+  __device__ __forceinline__ void varint(u64 v) { while (v >= 0x80u) { byte(((u32)v & 0x7Fu) | 0x80u); v >>= 7; } byte((u32)v); }
+  __device__ __forceinline__ void bytes(const CBH_G u8* p, u32 len) { if (WRITE) for (u32 i = 0; i < len; ++i) w[n + i] = p[i]; n += len; }
+  // namer.go:213-218: a name of the pre-0.30 form has every run of characters outside [0-9A-Za-z_.] replaced by one '_'
+  __device__ __forceinline__ void sanitized(const CBH_G u8* p, u32 len) {
+    if (!w_kind_needs_rewrite(p, len)) { bytes(p, len); return; }
+    bool in_run = false;
+    for (u32 i = 0; i < len; ++i) { const u32 c = p[i]; const bool ok = w_kind_ok_char(c); if (ok || !in_run) byte(ok ? c : (u32)'_'); in_run = !ok; }
+  }
+  __device__ __forceinline__ void lit(const char* s, u32 len) { for (u32 i = 0; i < len; ++i) byte((u32)(u8)s[i]); }
+};
+__device__ __forceinline__ u32 w_varint_size(u64 v) { u32 n = 1; while (v >= 0x80u) { v >>= 7; ++n; } return n; }
+
+// the policy key of a device policy word (cbh_ingest.cpp policy_key)
+template <bool WRITE>
+__device__ __forceinline__ void w_policy_key(const WireOutArgs& a, WSink<WRITE>& o, u32 word, const CBH_G u8* kind, u32 kind_len, const CBH_G u8* pid, u32 pid_len,
+                                             const CBH_G u8* rver, u32 rver_len, const CBH_G u8* pver, u32 pver_len, u32& errors) {
+  const u32 k = word >> 28, ident = word & 0x0FFFFFFFu;
+  if (k == CBH_P_EMPTY) return;
+  if (k == CBH_P_NO_MATCH) { o.lit("NO_MATCH", 8); return; }
+  if (k == CBH_P_NO_MATCH_SCOPE_PERMISSIONS) { o.lit("NO_MATCH_FOR_SCOPE_PERMISSIONS", 30); return; }
+  if (k == CBH_P_TABLE) {
+    if (ident >= a.n_policies) { errors |= 1u; return; }
+    o.bytes(a.name_bytes + a.name_off[ident], a.name_off[ident + 1u] - a.name_off[ident]);
+    return;
+  }
+  if (k == CBH_P_RESOURCE || k == CBH_P_PRINCIPAL) {
+    if (ident >= a.n_scopes) { errors |= 1u; return; }
+    const bool rp = k == CBH_P_RESOURCE;
+    if (rp) o.lit("resource.", 9); else o.lit("principal.", 10);
+    if (rp) o.sanitized(kind, kind_len); else o.sanitized(pid, pid_len);
+    o.lit(".v", 2);
+    const CBH_G u8* v = rp ? rver : pver; u32 vl = rp ? rver_len : pver_len;
+    if (vl == 0u) { v = a.msg + a.dver_off; vl = a.dver_len; }
+    o.sanitized(v, vl);
+    const u32 sid = a.scope_sid[ident], so = a.t_str_off[sid], sl = a.t_str_off[sid + 1u] - so;
+    if (sl) { o.byte('/'); o.bytes(a.t_str_bytes + so, sl); }
+    return;
+  }
+  errors |= 1u;
+}
+
+// the CheckOutput of input i into `o`; returns its CBH_WO_* flags
+template <bool WRITE>
+__device__ __attribute__((noinline)) u32 w_output(const WireOutArgs& a, u32 i, WSink<WRITE>& o, u32& errors) {
+  const u32 N = a.n;
+  const CBH_G u8* m = a.msg + (u32)a.moff[i];
+  const CBH_G u32* sp = a.in_span + (size_t)i * 2u * CBH_WSPAN_N;
+  const u32 act_off = a.req_u32[(size_t)CBH_RQ_ACT_OFF * N + i], na = a.req_u32[(size_t)CBH_RQ_ACT_CNT * N + i];
+  if (sp[1]) { o.byte(0x0Au); o.varint(sp[1]); o.bytes(m + sp[0], sp[1]); }        // 1 request_id
+  if (sp[11]) { o.byte(0x12u); o.varint(sp[11]); o.bytes(m + sp[10], sp[11]); }    // 2 resource_id
+  u32 flags = 0;
+  for (u32 k = 0; k < na; ++k) {
+    const u32 st = a.status[act_off + k];
+    flags |= st == CBH_ST_UNSUPPORTED ? CBH_WO_UNSUPPORTED : st == CBH_ST_CEL_ERROR ? CBH_WO_CEL_ERROR : st == CBH_ST_WANTS_TRACE ? CBH_WO_WANTS_TRACE : 0u;
+  }
+  for (u32 k = 0; k < na; ++k) {
+    const u32 id = a.tuple_action[act_off + k];
+    bool first = true;
+    for (u32 q = 0; q < k && first; ++q) first = a.tuple_action[act_off + q] != id;
+    if (!first) continue;   // named before: that entry carries the result
+    u32 j = k;
+    for (u32 q = k + 1u; q < na; ++q)
+      if (a.tuple_action[act_off + q] == id && (a.effect[act_off + q] == CBH_EFFECT_DENY || a.effect[act_off + j] != CBH_EFFECT_DENY)) j = q;
+    const u32 name_o = a.act_span[2u * (act_off + k)], name_l = a.act_span[2u * (act_off + k) + 1u];
+    const u32 effect = a.effect[act_off + j], word = a.policy[act_off + j], sc = a.scope[act_off + j];
+    WSink<false> cnt; cnt.w = nullptr; cnt.n = 0;
+    w_policy_key<false>(a, cnt, word, m + sp[6], sp[7], m + sp[2], sp[3], m + sp[8], sp[9], m + sp[4], sp[5], errors);
+    const u32 pol_l = cnt.n;
+    u32 scope_o = 0, scope_l = 0;
+    if (sc != CBH_NONE) {
+      if (sc >= a.n_scopes) errors |= 1u;
+      else { const u32 sid = a.scope_sid[sc]; scope_o = a.t_str_off[sid]; scope_l = a.t_str_off[sid + 1u] - scope_o; }
+    }
+    const u32 eff_len = (effect ? 1u + w_varint_size(effect) : 0u) + (pol_l ? 1u + w_varint_size(pol_l) + pol_l : 0u) + (scope_l ? 1u + w_varint_size(scope_l) + scope_l : 0u);
+    const u32 ent_len = 1u + w_varint_size(name_l) + name_l + 1u + w_varint_size(eff_len) + eff_len;
+    o.byte(0x1Au); o.varint(ent_len);                       // 3 actions: map entry
+    o.byte(0x0Au); o.varint(name_l); o.bytes(m + name_o, name_l);
+    o.byte(0x12u); o.varint(eff_len);
+    if (effect) { o.byte(0x08u); o.varint(effect); }
+    if (pol_l) { o.byte(0x12u); o.varint(pol_l); w_policy_key<WRITE>(a, o, word, m + sp[6], sp[7], m + sp[2], sp[3], m + sp[8], sp[9], m + sp[4], sp[5], errors); }
+    if (scope_l) { o.byte(0x1Au); o.varint(scope_l); o.bytes(a.t_str_bytes + scope_o, scope_l); }
+  }
+  const u64 edr = a.edr[i];
+  for (u32 d = 0; d < 64u && d < a.n_dr; ++d)
+    if ((edr >> d) & 1ull) {                                // 4 effective_derived_roles
+      const u32 no = a.name_off[a.n_policies + d], nl = a.name_off[a.n_policies + d + 1u] - no;
+      o.byte(0x22u); o.varint(nl); o.bytes(a.name_bytes + no, nl);
+    }
+  return flags;
+}
+
+__device__ __forceinline__ u64 w_wave_prefix64(u64 x, u32 bits, u32 lane, u64& total) {
+  u64 pre = 0; total = 0;
+  const u64 lt = (1ull << lane) - 1ull;
+  for (u32 b = 0; b < bits; ++b) {
+    const u64 mk = wave_ballot(((x >> b) & 1ull) != 0ull);
+    pre += (u64)__builtin_popcountll(mk & lt) << b;
+    total += (u64)__builtin_popcountll(mk) << b;
+  }
+  return pre;
+}
+
+#ifdef CBH_HOSTSIM
+static void cbh_wire_out_size_kernel(WireOutArgs a)
+#else
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_out_size_kernel(WireOutArgs a)
+#endif
+{
+  const u32 lane = threadIdx.x & 63u;
+  const u32 i = blockIdx.x * CBH_BLOCK + threadIdx.x;
+  u32 sz = 0, errors = 0;
+  if (i < a.n) {
+    WSink<false> o; o.w = nullptr; o.n = 0;
+    const u32 fl = w_output<false>(a, i, o, errors);
+    sz = o.n;
+    if (sz > CBH_WO_MAX_OUTPUT) { errors |= 2u; sz = 0; }
+    a.sizes[i] = sz; a.out_flags[i] = (u8)fl;
+  }
+  u32 total;
+  (void)w_wave_prefix(sz, 24u, lane, total);
+  const u64 errm = wave_ballot(errors != 0u);
+  if (lane == 0u) a.wavesum[blockIdx.x * (CBH_BLOCK / 64u) + threadIdx.x / 64u] = total;
+  if (errm && errors) w_or32(&a.stats->errors, errors);
+}
+
+#ifdef CBH_HOSTSIM
+static void cbh_wire_out_scan_kernel(WireOutArgs a)
+#else
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_out_scan_kernel(WireOutArgs a)
+#endif
+{
+  const u32 lane = threadIdx.x & 63u;
+  const u32 nw = (a.n + 63u) / 64u, per = (nw + 63u) / 64u;
+  const u32 lo = lane * per, hi = (lo + per < nw) ? lo + per : nw;
+  u64 s = 0;
+  for (u32 w = lo; w < hi; ++w) s += a.wavesum[w];
+  u64 total;
+  u64 p = w_wave_prefix64(s, 40u, lane, total);
+  for (u32 w = lo; w < hi; ++w) { a.waveoff[w] = p; p += a.wavesum[w]; }
+  if (lane == 0u) { a.stats->total = total; a.out_off[a.n] = total; }
+}
+
+#ifdef CBH_HOSTSIM
+static void cbh_wire_out_write_kernel(WireOutArgs a)
+#else
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_out_write_kernel(WireOutArgs a)
+#endif
+{
+  const u32 lane = threadIdx.x & 63u;
+  const u32 i = blockIdx.x * CBH_BLOCK + threadIdx.x;
+  const u32 sz = i < a.n ? a.sizes[i] : 0u;
+  u32 total;
+  const u64 off = a.waveoff[blockIdx.x * (CBH_BLOCK / 64u) + threadIdx.x / 64u] + w_wave_prefix(sz, 24u, lane, total);
+  if (i < a.n) {
+    a.out_off[i] = off;
+    u32 errors = 0;
+    WSink<true> o; o.w = a.out + off; o.n = 0;
+    if (sz) (void)w_output<true>(a, i, o, errors);
+  }
+}

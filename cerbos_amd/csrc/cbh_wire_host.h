@@ -11,6 +11,8 @@ struct WireIndexHost {
   std::vector<u64> tix; u32 tix_mask = 0;
   std::vector<u32> scope_of_sid;
   std::vector<WireCol> cols; std::vector<u8> col_keys;
+  // the device assembler (cbh_wire_out_*): policy keys (CBH_P_TABLE ids) then derived-role names, and where the scopes' string ids sit in the image
+  std::vector<u32> name_off; std::vector<u8> name_bytes; u32 n_policies = 0, n_dr = 0; u64 scope_sid_offset = 0; u32 n_scopes = 0;
   const char* why_not = nullptr;   // the table's inputs cannot be flattened on the device (every batch goes through libcerbos_ingest.so)
 };
 
@@ -62,6 +64,24 @@ static inline const char* cbh_wire_index_build(WireIndexHost& w, const uint8_t* 
     }
     w.cols.push_back(col);
   }
+  w.scope_sid_offset = ss->offset; w.n_scopes = ns;
+  w.name_off.assign(1, 0); w.name_bytes.clear(); w.n_policies = w.n_dr = 0;
+  if (const CbhBlobSection* sn = find(CBH_SEC_HOST_NAMES)) {
+    const u8* q = image + sn->offset; const u8* qe = q + sn->nbytes;
+    for (u32* cnt_out : {&w.n_policies, &w.n_dr}) {
+      if (qe - q < 4) return "image host name section truncated";
+      u32 cnt; memcpy(&cnt, q, 4); q += 4;
+      for (u32 k = 0; k < cnt; ++k) {
+        if (qe - q < 2) return "image host name section truncated";
+        const u32 l = q[0] | (q[1] << 8); q += 2;
+        if ((u32)(qe - q) < l) return "image host name section truncated";
+        w.name_bytes.insert(w.name_bytes.end(), q, q + l); q += l;
+        w.name_off.push_back((u32)w.name_bytes.size());
+      }
+      *cnt_out = cnt;
+    }
+  } else return "image is missing the host name section";
+  if (w.name_bytes.empty()) w.name_bytes.push_back(0);
   if (w.col_keys.empty()) w.col_keys.push_back(0);
   if (w.cols.empty()) { WireCol z; memset(&z, 0, sizeof(z)); w.cols.push_back(z); }
   return nullptr;

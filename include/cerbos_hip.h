@@ -284,6 +284,13 @@ int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8_t* bytes, 
  * principal version, resource kind, resource version, resource id; act_span [n_tuples] (offset, length) of every action;
  * act_off [n + 1] first tuple of every input. */
 int cbh_wire_spans_download(cbh_table* t, cbh_device_batch* b, uint32_t* in_span, uint32_t* act_span, uint32_t* act_off);
+/* ... or let the device write the answers too: after cbh_check_resident on a batch of cbh_wire_flatten, the serialized
+ * enginev1.CheckOutput of every input - request_id, resource_id, actions -> {effect, policy, scope}, effective_derived_roles
+ * (check.go:64-94, 513-530; byte for byte what cbi_assemble_wire_pb builds from the downloaded results) - back to back in
+ * `bytes`, output i = bytes[offsets[i] .. offsets[i + 1]) (offsets: n + 1 entries), flags[i] = CBI_OUT_* of cerbos_ingest.h
+ * (may be NULL).  Returns 0; 2 = `cap` is too small, *need holds the size (nothing was copied; call again); < 0 error.
+ * evaluation_errors / outputs of the inputs whose flags ask for them come from the trace pass, as on the host road. */
+int cbh_wire_outputs(cbh_table* t, cbh_device_batch* b, uint8_t* bytes, size_t cap, uint64_t* offsets, uint8_t* flags, size_t* need);
 
 /* ---- Trace pass: evaluation_errors and outputs (evaluator/cel_errors.go:48-118, check.go:383-411, 776-807) ----
  * The decision kernels only mark the tuples whose evaluation absorbed a CEL error (CBH_ST_CEL_ERROR).  What the

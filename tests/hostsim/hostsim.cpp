@@ -89,10 +89,12 @@ static int g_last_kind = -1;   // which kernel family decided the last batch (ho
 static bool g_trace;   // hostsim_trace: the trace pass's kernel (cbh_trace_batch)
 
 static WireArgs* g_wargs;   // the device flattener's kernels (cbh_wire.h): 1 count, 2 scan, 3 fill
+static WireOutArgs* g_woargs;   // ... and the device assembler's: 4 sizes, 5 scan, 6 bytes
 static int g_wire_kind = 0;
 
 static void fiber_main() {
-  if (g_wire_kind == 1) cbh_wire_count_kernel(*g_wargs);
+  if (g_wire_kind >= 4) { if (g_wire_kind == 4) cbh_wire_out_size_kernel(*g_woargs); else if (g_wire_kind == 5) cbh_wire_out_scan_kernel(*g_woargs); else cbh_wire_out_write_kernel(*g_woargs); }
+  else if (g_wire_kind == 1) cbh_wire_count_kernel(*g_wargs);
   else if (g_wire_kind == 2) cbh_wire_scan_kernel(*g_wargs);
   else if (g_wire_kind == 3) cbh_wire_fill_kernel(*g_wargs);
   else if (g_trace) cbh_trace_kernel(*g_args, g_args);
@@ -249,6 +251,7 @@ struct HsWire {   // valid until the next call
 static struct {
   std::vector<uint8_t> msg, status, col_tag, heap_tag; std::vector<uint64_t> moff, col_val, heap_val, dict;
   std::vector<uint32_t> cnt, wavesum, waveoff, dict_flags, req, roles, tuple_action, in_span, act_span;
+  uint32_t dver_off = 0, dver_len = 0, n = 0;
 } g_w;
 static void wire_launch(int kind, uint32_t nblocks) {
   g_wire_kind = kind;
@@ -311,5 +314,33 @@ extern "C" int hostsim_wire_flatten(const void* blob, size_t len, const uint8_t*
   out->col_val = g_w.col_val.data(); out->heap_tag = g_w.heap_tag.data(); out->heap_val = g_w.heap_val.data(); out->dict = g_w.dict.data();
   out->dict_flags = g_w.dict_flags.data(); out->in_span = g_w.in_span.data(); out->act_span = g_w.act_span.data(); out->msg = g_w.msg.data();
   out->status = g_w.status.data(); out->stats = st;
+  g_w.dver_off = a.dver_off; g_w.dver_len = a.dver_len; g_w.n = n;
   return 0;
+}
+
+// The device assembler on the batch the last hostsim_wire_flatten call built: results (input order) -> serialized CheckOutputs.
+// out_bytes / out_off / out_flags are the caller's; returns the bytes needed (nothing is written beyond `cap`), < 0 on error.
+extern "C" long long hostsim_wire_outputs(const void* blob, size_t len, const uint8_t* effect, const uint32_t* policy, const uint32_t* scope, const uint8_t* status,
+                                          const uint64_t* edr, uint8_t* out_bytes, size_t cap, uint64_t* out_off, uint8_t* out_flags) {
+  TableDev t{}; std::vector<uint32_t> meta;
+  const uint8_t* base = static_cast<const uint8_t*>(blob);
+  if (const char* e = cbh_parse_image(t, meta, base, base, len)) { g_err = e; return -1; }
+  WireIndexHost wi;
+  if (const char* e = cbh_wire_index_build(wi, base, len, meta)) { g_err = e; return -1; }
+  const uint32_t n = g_w.n, nw = (n + 63) / 64;
+  WireOutArgs a{};
+  a.t_str_off = t.str_off; a.t_str_bytes = t.str_bytes; a.scope_sid = reinterpret_cast<const uint32_t*>(base + wi.scope_sid_offset); a.n_scopes = wi.n_scopes;
+  a.n_policies = wi.n_policies; a.name_off = wi.name_off.data(); a.name_bytes = wi.name_bytes.data(); a.n_dr = wi.n_dr; a.n = n;
+  a.msg = g_w.msg.data(); a.moff = g_w.moff.data(); a.dver_off = g_w.dver_off; a.dver_len = g_w.dver_len;
+  a.req_u32 = g_w.req.data(); a.tuple_action = g_w.tuple_action.data(); a.in_span = g_w.in_span.data(); a.act_span = g_w.act_span.data();
+  a.effect = effect; a.policy = policy; a.scope = scope; a.status = status; a.edr = edr;
+  std::vector<uint32_t> sizes(n + 1, 0); std::vector<uint64_t> wavesum(nw + 1, 0), waveoff(nw + 1, 0);
+  WireOutStats st{}; 
+  a.sizes = sizes.data(); a.wavesum = wavesum.data(); a.waveoff = waveoff.data(); a.stats = &st; a.out = out_bytes; a.out_off = out_off; a.out_flags = out_flags;
+  g_woargs = &a;
+  wire_launch(4, nw);
+  wire_launch(5, 1);
+  if (st.errors) { g_err = "device assembler: a policy / scope id out of range, or an output too large"; return -1; }
+  if (st.total <= cap) wire_launch(6, nw);
+  return (long long)st.total;
 }

@@ -33,6 +33,8 @@ def _both_roads(lt, inputs, flags=0):
             assert np.array_equal(a, b), (f, int(np.flatnonzero(a != b)[0]) if a.shape == b.shape else (a.shape, b.shape))
         have_out, have_flags = it.assemble_wire_pb(have, data, off, table.wire_spans(db))
         assert have_out == want_out and np.array_equal(have_flags, want_flags)
+        dev_out, dev_flags = table.wire_outputs(db, cap=64)     # the GPU writes the answers (a first buffer that is too small)
+        assert dev_out == want_out and np.array_equal(dev_flags, want_flags)
         info = db.wire_info
         db.close()
         return info

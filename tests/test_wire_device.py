@@ -161,3 +161,51 @@ def test_outputs_assembled_from_the_device_spans():
     have, hflags = it.assemble_wire_pb(res, data, off, (np.ascontiguousarray(wb.in_span), np.ascontiguousarray(wb.act_span), act_off))
     assert have == want and np.array_equal(wflags, hflags)
     it.close()
+
+
+def _random_results(rng, lt, n_tuples, n_requests):
+    from cerbos_amd import capi
+    res = capi.Result(n_tuples, n_requests, ("policy", "scope", "status", "edr"))
+    res.effect[:] = rng.integers(0, 3, n_tuples)
+    kinds = rng.integers(0, 6, n_tuples)   # enum cbh_policy_kind
+    ident = np.where(kinds == 4, rng.integers(0, max(1, len(lt.policy_keys)), n_tuples), rng.integers(0, max(1, len(lt.scopes)), n_tuples))
+    if not lt.policy_keys:
+        kinds[kinds == 4] = 1
+    res.policy[:] = (kinds.astype(np.uint32) << 28) | ident.astype(np.uint32)
+    res.scope[:] = np.where(rng.random(n_tuples) < 0.5, 0xFFFFFFFF, rng.integers(0, max(1, len(lt.scopes)), n_tuples)).astype(np.uint32)
+    res.status[:] = rng.integers(0, 4, n_tuples)
+    res.edr[:] = rng.integers(0, 1 << min(63, max(1, len(lt.dr_names))), n_requests).astype(np.uint64)
+    return res
+
+
+@pytest.mark.parametrize("name", ["C3", "C5", "fuzz0", "fuzz3"])
+def test_outputs_written_by_the_device(name):
+    """cbh_wire_out_* (the GPU writes the CheckOutputs) == cbi_assemble_wire_pb (a host thread does), byte for byte, on results
+    that take every branch: all policy word kinds, scopes or none, every status, duplicate actions, old-form kinds and versions"""
+    rng = np.random.default_rng(77)
+    if name.startswith("fuzz"):
+        frng = np.random.default_rng(10_000 + int(name[4:]))
+        try:
+            lt = lower_rule_table(rule_table_from_policies(policies_from_docs(_policies(frng))))
+        except LoweringError:
+            pytest.skip("store refused by the lowering")
+        inputs = [i for i in _requests(frng, 300) if len(i.get("actions") or []) <= 64]
+    else:
+        pol, reqs = {"C3": (workloads.c3_policies, workloads.c3_requests), "C5": (workloads.c5_policies, workloads.c5_requests)}[name]
+        lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol())))
+        inputs = reqs(n_requests=300).to_inputs()
+    inputs[5] = dict(inputs[5], actions=["view", "view", "edit", "view"], requestId="")
+    inputs[6] = dict(inputs[6], resource=dict(inputs[6]["resource"], policyVersion="2024-01:beta"), principal=dict(inputs[6]["principal"], policyVersion="x y"))
+    inputs[7] = dict(inputs[7], actions=[])
+    data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+    rc, wb = wu.sim_flatten(lt, data, off, default_version="v:old-form")
+    assert rc == 0
+    it = IngestTable(lt.blob)
+    res = _random_results(rng, lt, wb.n_tuples, wb.n)
+    act_off = np.concatenate([wb.req_u32[8], [wb.n_tuples]]).astype(np.uint32)
+    want, wflags = it.assemble_wire_pb(res, data, off, (np.ascontiguousarray(wb.in_span), np.ascontiguousarray(wb.act_span), act_off), "v:old-form")
+    have, hflags = wu.sim_outputs(lt, res, wb.n)
+    for i, (a, b) in enumerate(zip(want, have)):
+        assert a == b, (i, wire.decode_check_output(a), wire.decode_check_output(b))
+    assert np.array_equal(wflags, hflags)
+    it.close()

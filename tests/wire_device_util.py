@@ -193,3 +193,26 @@ def to_batch(lt, wb):
     b.tuple_perm = np.arange(wb.n_tuples, dtype=np.int64)
     b.req_perm = None
     return b
+
+
+def sim_outputs(lt, res, n, cap=None):
+    """The device assembler (cbh_wire_out_* kernels, simulator) on the batch the LAST sim_flatten call built; ``res`` = a
+    capi.Result in input order.  -> ([serialized CheckOutput], flags uint8[n])"""
+    lib = hostsim_api.lib()
+    lib.hostsim_wire_outputs.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.hostsim_wire_outputs.restype = C.c_longlong
+    buf = C.create_string_buffer(lt.blob, len(lt.blob))
+    cap = 256 if cap is None else cap
+    while True:
+        out = np.zeros(cap + 8, np.uint8)
+        off = np.zeros(n + 1, np.uint64)
+        flags = np.zeros(n + 1, np.uint8)
+        need = lib.hostsim_wire_outputs(C.cast(buf, C.c_void_p), len(lt.blob), res.effect.ctypes.data, res.policy.ctypes.data, res.scope.ctypes.data,
+                                        res.status.ctypes.data, res.edr.ctypes.data, out.ctypes.data, cap, off.ctypes.data, flags.ctypes.data)
+        if need < 0:
+            raise RuntimeError(lib.hostsim_last_error().decode())
+        if need <= cap:
+            raw = out.tobytes()
+            assert int(off[n]) == need
+            return [raw[int(off[i]):int(off[i + 1])] for i in range(n)], flags[:n]
+        cap = int(need)

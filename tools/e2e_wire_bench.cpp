@@ -2,11 +2,13 @@
 // serialized CheckInputs and producing serialized CheckOutputs.
 //   host road    cbi_flatten_pb  -> cbh_check_batch                                        -> cbi_assemble_pb
 //   device road  cbh_wire_flatten -> cbh_check_resident -> cbh_result_download + cbh_wire_spans_download -> cbi_assemble_wire_pb
-// (the device road: the GPU parses the messages, cbh_wire.h; the host only assembles the answers)
+//                (the GPU parses the messages, cbh_wire.h; the host only assembles the answers)
+//   device_out   cbh_wire_flatten -> cbh_check_resident -> cbh_wire_outputs
+//                (the GPU writes the answers too: the host thread moves bytes and nothing else)
 //
 //   python tools/export_wire.py C2 262144 /tmp/c2w
 //   g++ -O2 -std=c++17 -pthread -Iinclude tools/e2e_wire_bench.cpp -Lcerbos_amd -lcerbos_ingest -lcerbos_hip -Wl,-rpath,$PWD/cerbos_amd -o /tmp/e2e_wire_bench
-//   /tmp/e2e_wire_bench /tmp/c2w <slice_requests> <seconds> <threads,threads,...> [device|host|both] [verify]
+//   /tmp/e2e_wire_bench /tmp/c2w <slice_requests> <seconds> <threads,threads,...> [device|device_out|host|both] [verify]
 // `verify`: before timing, every slice goes down both roads and the serialized outputs must be identical.
 #include <atomic>
 #include <chrono>
@@ -32,7 +34,10 @@ struct Slice { uint8_t* bytes; std::vector<uint64_t> rel; uint32_t n; };   // by
 
 struct Scratch {   // per thread, page-locked: results and spans come back by DMA
   uint8_t *eff = nullptr, *st = nullptr; uint32_t *pol = nullptr, *sc = nullptr, *in_span = nullptr, *act_span = nullptr, *act_off = nullptr; uint64_t* edr = nullptr;
+  uint8_t* out = nullptr; size_t out_cap = 0; uint64_t* out_off = nullptr; uint8_t* out_flags = nullptr;
   void alloc(uint32_t max_req, uint32_t max_tup) {
+    out_cap = (size_t)max_req * 256 + 4096; out = (uint8_t*)cbh_alloc_pinned(out_cap);
+    out_off = (uint64_t*)cbh_alloc_pinned(8 * ((size_t)max_req + 2)); out_flags = (uint8_t*)cbh_alloc_pinned((size_t)max_req + 1);
     eff = (uint8_t*)cbh_alloc_pinned(max_tup + 1); st = (uint8_t*)cbh_alloc_pinned(max_tup + 1);
     pol = (uint32_t*)cbh_alloc_pinned(4 * ((size_t)max_tup + 1)); sc = (uint32_t*)cbh_alloc_pinned(4 * ((size_t)max_tup + 1));
     edr = (uint64_t*)cbh_alloc_pinned(8 * ((size_t)max_req + 1));
@@ -63,6 +68,23 @@ static uint32_t device_road(cbh_table* gt, const cbi_table* it, const Slice& s, 
   return info.n_tuples;
 }
 
+// one slice, the answers written by the device into x.out / x.out_off / x.out_flags
+static uint32_t device_out_road(cbh_table* gt, const Slice& s, Scratch& x, double* phase) {
+  const auto t0 = Clock::now();
+  cbh_device_batch* db = nullptr; cbh_wire_info info;
+  if (cbh_wire_flatten(gt, 0, s.bytes, s.rel.data(), s.n, "default", "", &db, &info) != 0) { std::fprintf(stderr, "cbh_wire_flatten: %s\n", cbh_last_error()); return 0; }
+  const auto t1 = Clock::now();
+  if (cbh_check_resident(gt, db, &PARAMS) != 0) { std::fprintf(stderr, "cbh_check_resident: %s\n", cbh_last_error()); cbh_batch_release(db); return 0; }
+  size_t need = 0;
+  int rc = cbh_wire_outputs(gt, db, x.out, x.out_cap, x.out_off, x.out_flags, &need);
+  if (rc == 2) { cbh_free_pinned(x.out); x.out_cap = need + need / 4; x.out = (uint8_t*)cbh_alloc_pinned(x.out_cap); rc = cbh_wire_outputs(gt, db, x.out, x.out_cap, x.out_off, x.out_flags, &need); }
+  if (rc != 0) { std::fprintf(stderr, "cbh_wire_outputs: %s\n", cbh_last_error()); cbh_batch_release(db); return 0; }
+  const auto t2 = Clock::now();
+  cbh_batch_release(db);
+  if (phase) { phase[0] += secs(t0, t1); phase[1] += secs(t1, t2); }
+  return info.n_tuples;
+}
+
 static uint32_t host_road(cbh_table* gt, const cbi_table* it, const Slice& s, Scratch& x, cbi_outputs** out, double* phase) {
   const auto t0 = Clock::now();
   cbi_batch* b = nullptr;
@@ -81,7 +103,7 @@ static uint32_t host_road(cbh_table* gt, const cbi_table* it, const Slice& s, Sc
 }
 
 int main(int argc, char** argv) {
-  if (argc < 5) { std::fprintf(stderr, "usage: %s <dir> <slice_requests> <seconds> <threads,...> [device|host|both] [verify]\n", argv[0]); return 2; }
+  if (argc < 5) { std::fprintf(stderr, "usage: %s <dir> <slice_requests> <seconds> <threads,...> [device|device_out|host|both] [verify]\n", argv[0]); return 2; }
   const std::string dir = argv[1];
   const uint32_t slice = (uint32_t)std::atoi(argv[2]);
   const double seconds = std::atof(argv[3]);
@@ -112,7 +134,12 @@ int main(int argc, char** argv) {
     size_t same = 0;
     for (const Slice& s : slices) {
       cbi_outputs *a = nullptr, *b = nullptr;
-      if (!device_road(gt, it, s, x, &a, nullptr) || !host_road(gt, it, s, x, &b, nullptr)) return 1;
+      if (!device_road(gt, it, s, x, &a, nullptr) || !host_road(gt, it, s, x, &b, nullptr) || !device_out_road(gt, s, x, nullptr)) return 1;
+      {   // ... and the answers the device wrote
+        const uint64_t* ob2 = cbi_outputs_offsets(b);
+        if (x.out_off[s.n] != ob2[s.n] || std::memcmp(x.out_off, ob2, ((size_t)s.n + 1) * 8) || std::memcmp(x.out, cbi_outputs_bytes(b), ob2[s.n]) ||
+            std::memcmp(x.out_flags, cbi_outputs_flags(b), s.n)) { std::fprintf(stderr, "VERIFY FAILED: the device-written outputs differ\n"); return 1; }
+      }
       const uint64_t *oa = cbi_outputs_offsets(a), *ob = cbi_outputs_offsets(b);
       if (oa[s.n] != ob[s.n] || std::memcmp(oa, ob, ((size_t)s.n + 1) * 8) || std::memcmp(cbi_outputs_bytes(a), cbi_outputs_bytes(b), oa[s.n]) ||
           std::memcmp(cbi_outputs_flags(a), cbi_outputs_flags(b), s.n)) { std::fprintf(stderr, "VERIFY FAILED: the two roads disagree\n"); return 1; }
@@ -121,9 +148,9 @@ int main(int argc, char** argv) {
     }
     std::printf("{\"verified_identical_outputs\": %zu}\n", same);
   }
-  for (const char* road : {"device", "host"}) {
+  for (const char* road : {"device_out", "device", "host"}) {
     if (roads != "both" && roads != road) continue;
-    const bool dev = !std::strcmp(road, "device");
+    const bool dev = !std::strcmp(road, "device"), dev_out = !std::strcmp(road, "device_out");
     std::string tl = argv[4];
     for (char* tok = std::strtok(tl.data(), ","); tok; tok = std::strtok(nullptr, ",")) {
       const int T = std::atoi(tok);
@@ -139,9 +166,9 @@ int main(int argc, char** argv) {
         for (size_t i = (size_t)k; !stop.load(std::memory_order_relaxed); ++i) {
           const Slice& s = slices[i % slices.size()];
           cbi_outputs* o = nullptr;
-          const uint32_t d = dev ? device_road(gt, it, s, x, &o, phases[k].data()) : host_road(gt, it, s, x, &o, phases[k].data());
+          const uint32_t d = dev_out ? device_out_road(gt, s, x, phases[k].data()) : dev ? device_road(gt, it, s, x, &o, phases[k].data()) : host_road(gt, it, s, x, &o, phases[k].data());
           if (!d) { failed = 1; break; }
-          cbi_outputs_free(o);
+          if (o) cbi_outputs_free(o);
           mine += d;
         }
         decisions += mine;
