@@ -174,10 +174,14 @@ class HipEvaluator:
         return incomplete
 
     def check_pb(self, data, offsets, now_ns=None, lenient_scope_search=None, strict_evaluation=None,
-                 default_policy_version=None, default_scope=None, trace=False):
+                 default_policy_version=None, default_scope=None, trace=False, device_ingest=True):
         """Bytes in, bytes out - the path a Go caller takes: serialized ``CheckInput``
-        messages (``data`` uint8, ``offsets`` uint64[n + 1]) -> C++ ingest -> ``cbh_check_batch`` -> C++ response
-        assembly.  Returns ([serialized CheckOutput], flags uint8[n]); flags bit 0 = the device could not
+        messages (``data`` uint8, ``offsets`` uint64[n + 1]) -> serialized ``CheckOutput`` messages.
+        ``device_ingest`` (the default): the device road - the raw bytes cross PCIe, the GPU flattens them
+        (``cbh_wire_flatten``), decides and writes the answers (``cbh_wire_outputs``); messages the device flattener
+        leaves to the host (``capi.HostFlattenerNeeded``) and ``device_ingest=False`` take the host road: C++ ingest ->
+        ``cbh_check_batch`` -> C++ response assembly.  Same bytes either way (tests/test_gpu_wire.py).
+        Returns ([serialized CheckOutput], flags uint8[n]); flags bit 0 = the device could not
         evaluate that input (the caller's own engine must), bit 1 = a CEL error was absorbed."""
         conf = self.conf
         lenient = conf.lenient_scope_search if lenient_scope_search is None else lenient_scope_search
@@ -187,10 +191,25 @@ class HipEvaluator:
         if now_ns is None:
             now_ns = time.time_ns()
         self._ingest_table()
-        batch = self._ingest.flatten_pb(data, offsets, dver, dscope)
         flags = capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0) | (capi.F_STRICT_EVALUATION if strict else 0)
-        res = self.table.check(batch, now_ns=now_ns, flags=flags, device_order=True)
-        outs, oflags = self._ingest.assemble_pb(batch, res, data, offsets, dver)
+        outs = None
+        self.last_road = "host"
+        if device_ingest:
+            try:
+                db = self.table.wire_flatten(data, offsets, dver, dscope)
+            except capi.HostFlattenerNeeded:
+                db = None
+            if db is not None:
+                try:
+                    self.table.launch(db, now_ns=now_ns, flags=flags)
+                    outs, oflags = self.table.wire_outputs(db)
+                    self.last_road = "device"
+                finally:
+                    db.close()
+        if outs is None:
+            batch = self._ingest.flatten_pb(data, offsets, dver, dscope)
+            res = self.table.check(batch, now_ns=now_ns, flags=flags, device_order=True)
+            outs, oflags = self._ingest.assemble_pb(batch, res, data, offsets, dver)
         if not trace:
             return outs, oflags
         # evaluation_errors / outputs (check.go:90-92): the inputs that can have any go through the tracing kernel and

@@ -91,3 +91,19 @@ def test_messages_for_the_host_flattener_and_malformed_ones():
         db.close()
     finally:
         table.close()
+
+
+def test_evaluator_bytes_path_takes_the_device_road():
+    """HipEvaluator.check_pb: device road (default) == host road, with the trace pass's evaluation_errors / outputs appended"""
+    from cerbos_amd.engine import HipEvaluator
+    ev = HipEvaluator.from_policies(workloads.c5_policies())
+    try:
+        inputs = workloads.c5_requests(n_requests=3000).to_inputs()
+        data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+        want, wflags = ev.check_pb(data, off, now_ns=NOW, trace=True, device_ingest=False)
+        assert ev.last_road == "host"
+        have, hflags = ev.check_pb(data, off, now_ns=NOW, trace=True)
+        assert ev.last_road == "device"
+        assert have == want and np.array_equal(np.asarray(wflags), np.asarray(hflags))
+    finally:
+        ev.close()
