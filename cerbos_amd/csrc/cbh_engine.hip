@@ -170,6 +170,10 @@ struct Replica {   // the table on one device
   // the device flattener's per-table data (cbh_wire_host.h WireIndexHost), uploaded at load
   u64* w_tix = nullptr; u32* w_scope_of_sid = nullptr; WireCol* w_cols = nullptr; u8* w_col_keys = nullptr;
   u32* w_name_off = nullptr; u8* w_name_bytes = nullptr;
+  // A batch of cbh_wire_flatten has a stream to itself while it lives (the call synchronises it several times: on a shared
+  // stream every caller would wait for every other caller's work); idle ones are kept, at most MAX_WIRE_STREAMS are made.
+  static constexpr int MAX_WIRE_STREAMS = 64;
+  std::mutex wstream_mu; std::vector<hipStream_t> wstreams_idle, wstreams_all; int wstreams_made = 0;
 };
 
 struct cbh_table {
@@ -195,7 +199,7 @@ struct cbh_device_batch {
   bool plain_tags = false;              // BatchShape::plain_tags
   std::vector<std::pair<void*, size_t>> allocs;   // (block, capacity) taken from the replica's pool
   // a batch the device flattened (cbh_wire_flatten): where the response's strings sit in the messages
-  bool wire = false; u32* w_in_span = nullptr; u32* w_act_span = nullptr;
+  bool wire = false; bool own_wire_stream = false; u32* w_in_span = nullptr; u32* w_act_span = nullptr;
   const u64* w_moff = nullptr; u32 w_dver_off = 0, w_dver_len = 0;   // (the device assembler reads the messages again)
   u32* w_sizes = nullptr; u64* w_wavesum = nullptr; u64* w_waveoff = nullptr; WireOutStats* w_ostats = nullptr; u64* w_out_off = nullptr; u8* w_out_flags = nullptr;
 };
@@ -206,6 +210,7 @@ static void replica_destroy(Replica* r) {
   for (int i = 1; i < Replica::MAX_RESIDENT_STREAMS; ++i) if (r->rstreams[i]) { (void)hipStreamSynchronize(r->rstreams[i]); (void)hipStreamDestroy(r->rstreams[i]); }
   if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
   for (auto& sl : r->ring) for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
+  for (hipStream_t ws : r->wstreams_all) { (void)hipStreamSynchronize(ws); (void)hipStreamDestroy(ws); }
   if (r->image && r->owns_image) (void)hipFree(r->image);
   for (void* p : {(void*)r->w_tix, (void*)r->w_scope_of_sid, (void*)r->w_cols, (void*)r->w_col_keys, (void*)r->w_name_off, (void*)r->w_name_bytes}) if (p) (void)hipFree(p);
   for (auto& a : r->pool_free) (void)hipFree(a.first);
@@ -467,6 +472,7 @@ extern "C" void cbh_batch_release(cbh_device_batch* b) {
     std::lock_guard<std::mutex> lk(b->rep->pool_mu);
     for (auto& a : b->allocs) b->rep->pool_free.push_back(a);
   }
+  if (b->own_wire_stream) { std::lock_guard<std::mutex> lk(b->rep->wstream_mu); b->rep->wstreams_idle.push_back(b->stream); }
   delete b;
   cbh_table_release(t);   // the reference the batch held
 }
@@ -688,6 +694,7 @@ extern "C" int cbh_synchronize(cbh_table* t) {
     std::lock_guard<std::mutex> lk(rep->mu);
     HIPCHK(hipSetDevice(rep->device));
     for (int i = 0; i < Replica::MAX_RESIDENT_STREAMS; ++i) if (rep->rstreams[i]) HIPCHK(hipStreamSynchronize(rep->rstreams[i]));
+    { std::vector<hipStream_t> ws; { std::lock_guard<std::mutex> lw(rep->wstream_mu); ws = rep->wstreams_all; } for (hipStream_t x : ws) HIPCHK(hipStreamSynchronize(x)); }
     collect_times(rep);
   }
   return 0;
@@ -753,7 +760,12 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
   if (!b) return fail("out of memory");
   cbh_table_retain(t);
   b->table = t; b->rep = rep; b->wire = true;
-  b->stream = rep->rstreams[rep->next_rstream.fetch_add(1, std::memory_order_relaxed) % (uint32_t)rep->n_rstreams.load(std::memory_order_relaxed)];
+  {
+    std::lock_guard<std::mutex> lk(rep->wstream_mu);
+    if (!rep->wstreams_idle.empty()) { b->stream = rep->wstreams_idle.back(); rep->wstreams_idle.pop_back(); b->own_wire_stream = true; }
+    else if (rep->wstreams_made < Replica::MAX_WIRE_STREAMS && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess) { ++rep->wstreams_made; rep->wstreams_all.push_back(b->stream); b->own_wire_stream = true; }
+  }
+  if (!b->own_wire_stream) b->stream = rep->rstreams[rep->next_rstream.fetch_add(1, std::memory_order_relaxed) % (uint32_t)rep->n_rstreams.load(std::memory_order_relaxed)];
   hipStream_t s = b->stream;
   auto bail = [&](int rc) { cbh_batch_release(b); return rc; };
   const u32 nw = (n + 63u) / 64u, ncol = t->meta[CBH_M_NCOLUMNS];
@@ -764,6 +776,7 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
   a.cols = rep->w_cols; a.col_keys = rep->w_col_keys; a.n_cols = ncol; a.sens_cols = t->meta[CBH_M_SENS_COLS];
   a.n = n;
   a.dver_off = (u32)total; a.dver_len = (u32)dv.size(); a.dscope_off = (u32)(total + dv.size()); a.dscope_len = (u32)ds.size();
+  a.claims_off = (u32)(total + dv.size() + ds.size());
   u8* d_msg = nullptr; u64* d_moff = nullptr; WireStats* d_stats = nullptr;
   int rc = 0;
   rc |= dalloc(b, d_msg, (size_t)total + dv.size() + ds.size() + 64);
@@ -774,7 +787,7 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
   if (rc != 0) return bail(-1);
   a.msg = d_msg; a.moff = d_moff; a.stats = d_stats;
   WireStats st; cbh_wire_stats_init(st);
-  const std::string tail = dv + ds;
+  const std::string tail = dv + ds + "claims";
   static const u64 zero_off = 0;
   if (total && hipMemcpyAsync(d_msg, bytes, total, hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
   if (!tail.empty() && hipMemcpyAsync(d_msg + total, tail.data(), tail.size(), hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }

@@ -66,7 +66,7 @@ struct WireArgs {
   const CBH_G WireCol* cols; const CBH_G u8* col_keys; u32 n_cols; u32 sens_cols;
   // the messages: message i = msg[moff[i] .. moff[i + 1]); the call's default version / scope and "claims" follow the last one
   const CBH_G u8* msg; const CBH_G u64* moff; u32 n; u32 heap_cap;
-  u32 dver_off, dver_len, dscope_off, dscope_len;
+  u32 dver_off, dver_len, dscope_off, dscope_len, claims_off, pad1;   // ("claims": the key of the request view of a named JWT)
   // scratch
   CBH_G u32* cnt;         // [n] actions | roles << 8
   CBH_G u8* status;       // [n] CBH_WS_*
@@ -406,6 +406,7 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_scan_kernel(WireArgs a)
     a.stats->sid_empty = w_intern(a, a.dver_off, 0u, 0u, L);
     a.stats->sid_dver = w_intern(a, a.dver_off, a.dver_len, 0u, L);
     a.stats->dscope_word = w_scope_word(a, a.dscope_off, a.dscope_len);
+    a.stats->sid_claims = w_intern(a, a.claims_off, 6u, 0u, L);
     if (L.dict_full) w_or32(&a.stats->flags, CBH_WF_DICT_FULL);
   }
 }
@@ -578,18 +579,31 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
     const WireCol col = a.cols[c];
     u32 tag = CBH_T_ABSENT; u64 val = 0;
     bool is_container = false, is_map = false; WSpan body; body.p = body.e = 0; u32 fnum = 1u, need = 0u;
+    u32 shape = 0u;   // 0 a plain container; auxData.jwts (root 3): 1 one named JWT as {"claims": {...}}, 2 all of them name -> {"claims": {...}}
     if (live) {
       const WSpan root = col.root == 0u ? principal : col.root == 1u ? resource : aux;
       const u32 root_fnum = col.root == 2u ? 1u : 4u;
       bool done = false; WSpan cur; cur.p = cur.e = 0;
-      if (col.nk == 0u) { is_container = true; is_map = true; body = root; fnum = root_fnum; done = true; }
-      else {
-        if (!w_map_get(m, root, root_fnum, a.col_keys + col.key_off[0], col.key_len[0], cur, L.bad)) { tag = col.nk == 1u ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
-        for (u32 k = 1; k < col.nk && !done; ++k) {
-          WVal v;
-          if (!w_value(m, cur, v, L.bad) || v.kind != 5u) { tag = CBH_T_ERR; done = true; break; }
-          if (!w_map_get(m, v.s, 1u, a.col_keys + col.key_off[k], col.key_len[k], cur, L.bad)) { tag = (k == col.nk - 1u) ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
-        }
+      u32 k0 = 1u;
+      if (col.root == 3u) {
+        // AuxData.jwts (field 2): map<string, JWT>, JWT.claims (field 1): map<string, Value>.  The request view is
+        // name -> {"claims": {...}} (check.go:536-554), so the second key of a path must be "claims".
+        WSpan jwt; jwt.p = jwt.e = 0;
+        const CBH_G u8* k1 = a.col_keys + col.key_off[1];
+        if (col.nk == 0u) { is_container = true; is_map = true; shape = 2u; body = aux; fnum = 2u; done = true; }
+        else if (!w_map_get(m, aux, 2u, a.col_keys + col.key_off[0], col.key_len[0], jwt, L.bad)) { tag = col.nk == 1u ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
+        else if (col.nk == 1u) { is_container = true; is_map = true; shape = 1u; body = jwt; fnum = 1u; done = true; }
+        else if (!(col.key_len[1] == 6u && k1[0] == 'c' && k1[1] == 'l' && k1[2] == 'a' && k1[3] == 'i' && k1[4] == 'm' && k1[5] == 's')) { tag = col.nk == 2u ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
+        else if (col.nk == 2u) { is_container = true; is_map = true; body = jwt; fnum = 1u; done = true; }
+        else if (!w_map_get(m, jwt, 1u, a.col_keys + col.key_off[2], col.key_len[2], cur, L.bad)) { tag = col.nk == 3u ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
+        else k0 = 3u;
+      }
+      else if (col.nk == 0u) { is_container = true; is_map = true; body = root; fnum = root_fnum; done = true; }
+      else if (!w_map_get(m, root, root_fnum, a.col_keys + col.key_off[0], col.key_len[0], cur, L.bad)) { tag = col.nk == 1u ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
+      for (u32 k = k0; k < col.nk && !done; ++k) {
+        WVal v;
+        if (!w_value(m, cur, v, L.bad) || v.kind != 5u) { tag = CBH_T_ERR; done = true; break; }
+        if (!w_map_get(m, v.s, 1u, a.col_keys + col.key_off[k], col.key_len[k], cur, L.bad)) { tag = (k == col.nk - 1u) ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
       }
       if (!done) {
         WVal v;
@@ -601,7 +615,17 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
         else { is_container = true; is_map = v.kind == 5u; body = v.s; fnum = 1u; }
       }
       if (is_container) {
-        need = w_container_walk<false>(a, body, fnum, is_map, 0u, L);
+        if (shape == 0u) need = w_container_walk<false>(a, body, fnum, is_map, 0u, L);
+        else if (shape == 1u) need = 2u + w_container_walk<false>(a, body, 1u, true, 0u, L);
+        else {   // every named JWT: (name, {"claims": ..}) pairs, then per JWT its two-entry wrapper and its claims
+          WSpan s2 = body; WField f; need = 0u;
+          while (w_next(m, s2, f, L.bad)) {
+            if (f.num != 2u || f.wt != 2u) continue;
+            WSpan k, v;
+            if (!w_entry(m, f.s, k, v, L.bad)) break;
+            need += 4u + w_container_walk<false>(a, v, 1u, true, 0u, L);
+          }
+        }
         if (need > CBH_WIRE_MAX_VALUE_ENTRIES) { L.host = true; need = 0u; is_container = false; tag = CBH_T_NULL; }
       }
     }
@@ -613,9 +637,33 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
       base = wave_readlane(base, 0u);
       if (is_container) {
         const u32 off = base + pre;
-        (void)w_container_walk<true>(a, body, fnum, is_map, off, L);
-        u32 n_top = w_count_fields(m, body, fnum, L.bad);
-        tag = is_map ? CBH_T_MAP : CBH_T_LIST; val = w_container(off, n_top);
+        const u32 sid_claims = a.stats->sid_claims;
+        auto put = [&](u32 slot, u32 t, u64 v) { if (slot < a.heap_cap) { a.heap_tag[slot] = (u8)t; a.heap_val[slot] = v; } };
+        if (shape == 0u) {
+          (void)w_container_walk<true>(a, body, fnum, is_map, off, L);
+          tag = is_map ? CBH_T_MAP : CBH_T_LIST; val = w_container(off, w_count_fields(m, body, fnum, L.bad));
+        } else if (shape == 1u) {
+          put(off, CBH_T_STRING, sid_claims);
+          put(off + 1u, CBH_T_MAP, w_container(off + 2u, w_count_fields(m, body, 1u, L.bad)));
+          (void)w_container_walk<true>(a, body, 1u, true, off + 2u, L);
+          tag = CBH_T_MAP; val = w_container(off, 1u);
+        } else {
+          const u32 n_top = w_count_fields(m, body, 2u, L.bad);
+          u32 slot = off, next = off + 2u * n_top;
+          WSpan s2 = body; WField f;
+          while (w_next(m, s2, f, L.bad)) {
+            if (f.num != 2u || f.wt != 2u) continue;
+            WSpan k, v;
+            if (!w_entry(m, f.s, k, v, L.bad)) break;
+            put(slot, CBH_T_STRING, w_intern(a, k.p, k.e - k.p, 0u, L));
+            put(slot + 1u, CBH_T_MAP, w_container(next, 1u));
+            slot += 2u;
+            put(next, CBH_T_STRING, sid_claims);
+            put(next + 1u, CBH_T_MAP, w_container(next + 2u, w_count_fields(m, v, 1u, L.bad)));
+            next += 2u + w_container_walk<true>(a, v, 1u, true, next + 2u, L);
+          }
+          tag = CBH_T_MAP; val = w_container(off, n_top);
+        }
         if (c < 32u && ((a.sens_cols >> c) & 1u)) sens_container = true;
       }
     }

@@ -52,7 +52,6 @@ static inline const char* cbh_wire_index_build(WireIndexHost& w, const uint8_t* 
     WireCol col; memset(&col, 0, sizeof(col));
     col.root = p[0]; const u32 nk = p[1]; p += 2;
     if (col.root > 3) return "image column root out of range";
-    if (col.root == 3) w.why_not = "a column reads auxData.jwts (verified tokens): flattened on the host";
     if (nk > CBH_WIRE_MAX_KEYS) w.why_not = "a column path is deeper than the device flattener follows";
     col.nk = nk > CBH_WIRE_MAX_KEYS ? CBH_WIRE_MAX_KEYS : nk;
     for (u32 k = 0; k < nk; ++k) {

@@ -270,7 +270,9 @@ extern "C" int hostsim_wire_flatten(const void* blob, size_t len, const uint8_t*
   std::string dv = dver ? dver : "default", ds = dscope ? dscope : "";
   if (!ds.empty() && ds[0] == '.') ds.erase(0, 1);   // scope_value
   g_w.msg.assign(bytes, bytes + total);
-  g_w.msg.insert(g_w.msg.end(), dv.begin(), dv.end()); g_w.msg.insert(g_w.msg.end(), ds.begin(), ds.end()); g_w.msg.resize(g_w.msg.size() + 16, 0);
+  g_w.msg.insert(g_w.msg.end(), dv.begin(), dv.end()); g_w.msg.insert(g_w.msg.end(), ds.begin(), ds.end());
+  { const char* cl = "claims"; g_w.msg.insert(g_w.msg.end(), cl, cl + 6); }
+  g_w.msg.resize(g_w.msg.size() + 16, 0);
   g_w.moff.assign(offsets, offsets + n + 1);
   if (n == 0) g_w.moff.assign(1, 0);
   const uint32_t nw = (n + 63) / 64;
@@ -280,6 +282,7 @@ extern "C" int hostsim_wire_flatten(const void* blob, size_t len, const uint8_t*
   a.cols = wi.cols.data(); a.col_keys = wi.col_keys.data(); a.n_cols = meta[CBH_M_NCOLUMNS]; a.sens_cols = meta[CBH_M_SENS_COLS];
   a.msg = g_w.msg.data(); a.moff = g_w.moff.data(); a.n = n;
   a.dver_off = (uint32_t)total; a.dver_len = (uint32_t)dv.size(); a.dscope_off = (uint32_t)(total + dv.size()); a.dscope_len = (uint32_t)ds.size();
+  a.claims_off = (uint32_t)(total + dv.size() + ds.size());
   g_w.cnt.assign(n + 1, 0); g_w.status.assign(n + 1, 0); g_w.wavesum.assign(2 * (size_t)nw + 2, 0); g_w.waveoff.assign(2 * (size_t)nw + 2, 0);
   a.cnt = g_w.cnt.data(); a.status = g_w.status.data(); a.wavesum = g_w.wavesum.data(); a.waveoff = g_w.waveoff.data();
   WireStats st; cbh_wire_stats_init(st);

@@ -34,6 +34,30 @@ class HostSimEvaluator(HipEvaluator):
 
             def trace(_self, batch, now_ns=0, flags=0, capacity=None):
                 return hostsim_api.trace(lt, batch, now_ns, flags, capacity)
+
+            # the device road of check_pb (cbh_wire.h) on the simulator: the GPU's flattener, decision and assembler kernels
+            def wire_flatten(_self, data, offsets, default_policy_version="default", default_scope="", device_index=0):
+                import wire_device_util as wu
+                rc, wb = wu.sim_flatten(lt, data, offsets, default_policy_version, default_scope)
+                if rc == 1 or wb.stats["n_host"]:
+                    raise capi.HostFlattenerNeeded("host flattener")
+                if wb.stats["first_bad"] != 0xFFFFFFFF:
+                    raise capi.HipEngineError("malformed CheckInput at index %d" % wb.stats["first_bad"])
+
+                class _DB:
+                    def close(_s):
+                        pass
+                db = _DB()
+                db.wb, db.batch = wb, wu.to_batch(lt, wb)
+                return db
+
+            def launch(_self, db, now_ns=0, flags=0):
+                db.res = hostsim_api.check(lt, db.batch, now_ns, flags, device_order=True)
+
+            def wire_outputs(_self, db, cap=None):
+                import wire_device_util as wu
+                _self.device_road_calls = getattr(_self, "device_road_calls", 0) + 1
+                return wu.sim_outputs(lt, db.res, db.wb.n)
         self.table = _T()
 
 

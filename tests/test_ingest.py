@@ -223,7 +223,14 @@ def test_bytes_in_bytes_out_on_golden_cases():
                 assert sorted(have["effectiveDerivedRoles"]) == sorted(want.get("effectiveDerivedRoles") or [])
                 assert have["requestId"] == inp.get("requestId", "") and have["resourceId"] == inp["resource"].get("id", "")
                 compared += 1
+            assert ev.last_road == "device"   # the GPU's flattener / assembler kernels (simulated) produced these bytes
     assert compared > 60
+    # ... and the host road gives the same bytes
+    for case in load_json("engine_cases.json")[:12]:
+        data, off = wire.pack_messages([wire.encode_check_input(i) for i in case["inputs"]])
+        a = ev.check_pb(data, off, now_ns=1_700_000_000_000_000_000, trace=True)
+        b = ev.check_pb(data, off, now_ns=1_700_000_000_000_000_000, trace=True, device_ingest=False)
+        assert ev.last_road == "host" and a[0] == b[0] and list(a[1]) == list(b[1]), case["name"]
 
 
 def test_mutated_messages_never_crash():

@@ -72,12 +72,32 @@ def test_golden_store_inputs():
     """the reference's engine cases: principal / resource scopes, versions, nested attributes, JWT claims in auxData"""
     lt = lower_rule_table(store_rule_table(), GLOBALS)
     inputs = [inp for case in load_json("engine_cases.json") for inp in case["inputs"]]
-    data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
-    rc, wb = wu.sim_flatten(lt, data, off)
-    if rc == 1:
-        pytest.skip("the golden store reads auxData.jwts: its inputs are the host flattener's")
-    _compare(lt, inputs)
+    assert any(root == "J" for root, _ in lt.columns)   # auxData.jwts: named tokens, viewed as name -> {"claims": {...}}
+    hb, wb = _compare(lt, inputs)
     _compare(lt, inputs, default_version="v9", default_scope=".acme")
+    # ... and the decision kernels (simulator) give the same answers on the two batches, derived roles included
+    now = 1_700_000_000_000_000_000
+    for flags in (4, 4 | 1):   # CBH_F_WANT_DERIVED_ROLES, + lenient scope search
+        want = hostsim_api.check(lt, hb, now_ns=now, flags=flags, device_order=True)
+        have = hostsim_api.check(lt, wu.to_batch(lt, wb), now_ns=now, flags=flags, device_order=True)
+        for f in ("effect", "policy", "scope", "status", "edr"):
+            assert np.array_equal(getattr(want, f), getattr(have, f)), f
+
+
+def test_policy_test_framework_inputs():
+    """inputs of tests/golden/verify_vectors.json: JWT claims (auxData.jwt) and named JWTs (auxData.jwts) in every path shape"""
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    inputs = [v["input"] for v in load_json("verify_vectors.json")]
+    assert sum("jwts" in (i.get("auxData") or {}) for i in inputs) >= 2
+    inputs.append({"principal": {"id": "p", "roles": ["employee"]}, "resource": {"kind": "leave_request", "id": "r"}, "actions": ["frobnicate"],
+                   "auxData": {"jwts": {"token_a": {"claims": {"aud": "x"}}, "token_b": {}, "other": {"claims": {"customArray": ["A"]}}}}})
+    inputs.append({"principal": {"id": "x", "roles": ["", "employee", ""], "scope": ".acme.hr.uk", "policyVersion": "20210210"},
+                   "resource": {"kind": "leave_request", "id": "Ünïcode ✓", "scope": "acme.hr.zz.yy",
+                                "attr": {"owner": None, "n": 1e308, "neg": -0.0, "deep": {"a": {"b": {"c": [1, [2, [3, {"k": "v"}]]]}}},
+                                         "empty_list": [], "empty_map": {}, "": "empty key"}},
+                   "actions": ["view", "", "view", "a" * 300], "auxData": {"jwt": {"iss": "cerbos", "aud": ["a", "b"], "nested": {"x": True}}}})
+    inputs = [i for i in inputs if len(i.get("actions") or []) <= 64]
+    _compare(lt, inputs)
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -209,3 +229,48 @@ def test_outputs_written_by_the_device(name):
         assert a == b, (i, wire.decode_check_output(a), wire.decode_check_output(b))
     assert np.array_equal(wflags, hflags)
     it.close()
+
+
+def test_mutated_messages_both_flatteners_agree():
+    """Random corruptions of valid messages (bit flips, cuts, splices, inserted bytes): the device flattener and the host
+    flattener must agree on WHICH are malformed, and on the batch when they are not - and neither may crash."""
+    from cerbos_amd.ingest import IngestError
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    it = IngestTable(lt.blob)
+    inputs = [inp for case in load_json("engine_cases.json") for inp in case["inputs"] if len(inp.get("actions") or []) <= 64][:40]
+    msgs = [wire.encode_check_input(i) for i in inputs]
+    rng = np.random.default_rng(11)
+    ok = bad = 0
+    for trial in range(700):
+        m = bytearray(msgs[int(rng.integers(0, len(msgs)))])
+        for _ in range(int(rng.integers(1, 4))):
+            kind = int(rng.integers(0, 4))
+            pos = int(rng.integers(0, len(m))) if m else 0
+            if kind == 0 and m:
+                m[pos] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:
+                del m[pos:pos + int(rng.integers(1, 9))]
+            elif kind == 2:
+                m[pos:pos] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 6)), dtype=np.uint8))
+            else:
+                other = msgs[int(rng.integers(0, len(msgs)))]
+                m[pos:pos + 8] = other[:8]
+        neighbours = [msgs[0], bytes(m), msgs[1]]
+        data, off = wire.pack_messages(neighbours)
+        try:
+            hb = it.flatten_pb(data, off, sort=False)
+            host_bad = False
+        except IngestError:
+            host_bad = True
+        rc, wb = wu.sim_flatten(lt, data, off)
+        assert rc == 0
+        dev_bad = wb.stats["first_bad"] != 0xFFFFFFFF
+        assert dev_bad == host_bad, (trial, bytes(m))
+        if host_bad:
+            assert wb.stats["first_bad"] == 1
+            bad += 1
+        elif wb.stats["n_host"] == 0 and hb.n_requests == 3:
+            wu.assert_same_requests(lt, hb, wb, bool(_meta_flags(lt) & wu.MF_READS_REQUEST_STRINGS))
+            ok += 1
+    it.close()
+    assert ok > 60 and bad > 300, (ok, bad)

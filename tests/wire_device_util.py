@@ -72,7 +72,7 @@ def sim_flatten(lt, data, offsets, default_version="default", default_scope="", 
     w.in_span = _arr(out.in_span, C.c_uint32, np.uint32, n * 12).reshape(n, 12)
     w.act_span = _arr(out.act_span, C.c_uint32, np.uint32, w.n_tuples * 2).reshape(w.n_tuples, 2)
     total = int(offsets[-1]) if n else 0
-    w.msg = _arr(out.msg, C.c_uint8, np.uint8, total + len(default_version.encode()) + len(default_scope.encode()) + 8).tobytes()
+    w.msg = _arr(out.msg, C.c_uint8, np.uint8, total + len(default_version.encode()) + len(default_scope.encode()) + 6 + 8).tobytes()
     w.status = _arr(out.status, C.c_uint8, np.uint8, n)
     return 0, w
 
