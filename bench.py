@@ -17,7 +17,8 @@ Launches of different batches overlap on the device: resident batches are dealt 
 `roofline.achieved` is therefore the rate the device sustains over the timed region; `roofline.kernel_ms` the average
 begin-to-end time of one launch inside it; `roofline.serial` the same launches strictly one after the other on one stream.
 
-Two rates, side by side in the line: `value` = `resident_decisions_per_s`, the whole-job decision rate with the inputs
+Three rates, side by side in the line (the third: `wire_inclusive_decisions_per_s`, serialized CheckInputs in, serialized
+CheckOutputs out by the device road, one host thread - what a server delivers): `value` = `resident_decisions_per_s`, the whole-job decision rate with the inputs
 already resident in HBM when the timed region starts (what the kernel roofline is computed from), and
 `pcie_inclusive_decisions_per_s`, SURVEY.md §8(d)'s service-level metric (1): the wall time of cbh_check_batch INCLUDING
 the upload of the inputs and the download of the results (page-locked caller arrays, chunked three-stream pipeline), next
@@ -296,6 +297,46 @@ def main():
         side["pcie_inclusive_note"] = ("cbh_check_batch wall time, one %d-tuple batch, page-locked arrays, effect-only results "
                                        "(all_outputs: + policy, scope, status, derived-role mask); pageable: ordinary numpy arrays; "
                                        "upload_bytes / host_link_h2d_gbs = the floor the link sets" % tuples)
+
+        # Wire-inclusive (what a server delivers): serialized CheckInputs in, serialized CheckOutputs out, by the device road -
+        # the raw bytes cross PCIe, the GPU flattens them (cbh_wire_flatten), decides (cbh_check_resident) and writes the
+        # answers (cbh_wire_outputs); ONE host thread, page-locked buffers, slices of up to 128k requests of the first batch.
+        try:
+            from cerbos_amd import wire
+            nw = min(n_requests, 131072)
+            w_inputs = cr0.to_inputs(0, nw)
+            data, woff = wire.pack_messages([wire.encode_check_input(i) for i in w_inputs])
+            pdata = capi.pinned_empty(data.size + 64, np.uint8)
+            pdata[:data.size] = data
+            out_cap = 320 * nw + 4096
+            pout, poff, pfl = capi.pinned_empty(out_cap, np.uint8), capi.pinned_empty(nw + 1, np.uint64), capi.pinned_empty(nw + 1, np.uint8)
+            wbest, wt = 1e9, 0
+            for _ in range(8):
+                w0 = time.perf_counter()
+                h, info, need = C.c_void_p(), capi.CWireInfo(), C.c_size_t()
+                rc = lib.cbh_wire_flatten(table.h, 0, pdata.ctypes.data, woff.ctypes.data, nw, b"default", b"", C.byref(h), C.byref(info))
+                if rc != 0:
+                    raise RuntimeError("cbh_wire_flatten: rc %d: %s" % (rc, lib.cbh_last_error().decode()))
+                rc = lib.cbh_check_resident(table.h, h, C.byref(prm))
+                rc = rc or lib.cbh_wire_outputs(table.h, h, pout.ctypes.data, out_cap, poff.ctypes.data, pfl.ctypes.data, C.byref(need))
+                lib.cbh_batch_release(h)
+                if rc != 0:
+                    raise RuntimeError("device road: rc %d: %s" % (rc, lib.cbh_last_error().decode()))
+                wbest, wt = min(wbest, time.perf_counter() - w0), info.n_tuples
+            # the answers the device wrote are the decisions of the resident run (first requests of the same batch)
+            raw = pout[:int(poff[nw])].tobytes()
+            k = 0
+            for r in range(min(nw, 2000)):
+                o = wire.decode_check_output(raw[int(poff[r]):int(poff[r + 1])])
+                for a in w_inputs[r]["actions"]:
+                    assert (o["actions"][a]["effect"] == "EFFECT_ALLOW") == (eff[k] == 1), "device-written CheckOutput differs from the resident decision"
+                    k += 1
+            side["wire_inclusive_decisions_per_s"] = wt / wbest
+            side["wire_inclusive_note"] = ("serialized CheckInputs (%.0f B each) -> cbh_wire_flatten + cbh_check_resident + cbh_wire_outputs -> serialized "
+                                           "CheckOutputs (%.0f B each), %d requests per call, one host thread, best of 8; the host touches no message byte"
+                                           % (data.size / nw, int(poff[nw]) / nw, nw))
+        except Exception as e:   # a side leg never takes the line down
+            side["wire_inclusive_error"] = str(e)[:300]
 
     if rank == 0 and args.inproc_gpus > 1:
         # one engine over several devices in this process: cbh_check_batch cuts the batch into request ranges

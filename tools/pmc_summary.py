@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 counter CSVs of tools/gpu_profile_r02.sh into pmc_calibration.json and pmc_traffic.json.
+"""Turns the rocprofv3 counter CSVs of tools/gpu_final_r03.sh into pmc_calibration.json and pmc_traffic.json.
 
 Calibration (tools/pmc_calib.hip moves exactly 512 MiB per launch with one access shape): factor = known bytes /
 reported bytes per shape.  Traffic of the decision kernels = FETCH_SIZE x factor(dword reads) + WRITE_SIZE x
