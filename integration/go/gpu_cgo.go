@@ -19,6 +19,7 @@ import (
 	"errors"
 	"fmt"
 	"runtime"
+	"sync"
 	"unsafe"
 
 	"google.golang.org/protobuf/proto"
@@ -30,6 +31,7 @@ import (
 type gpuEngine struct {
 	table  *C.cbh_table // device image of the lowered rule table
 	ingest *C.cbi_table // host dictionaries of the same image (immutable: shared by all goroutines)
+	outPool pinnedPool  // page-locked blocks the device road's answers land in
 }
 
 // devices: the HIP ordinals the engine may use. A large batch is cut into one contiguous request range per device
@@ -91,30 +93,6 @@ func (g *gpuEngine) checkBatchGPU(_ context.Context, inputs []*enginev1.CheckInp
 	defer C.free(unsafe.Pointer(dv))
 	defer C.free(unsafe.Pointer(ds))
 
-	var batch *C.cbi_batch
-	if C.cbi_flatten_pb(g.ingest, bytesPtr, &offs[0], C.uint32_t(n), dv, ds, 1, &batch) != 0 {
-		return nil, nil, errors.New(C.GoString(C.cbi_last_error()))
-	}
-	defer C.cbi_batch_free(batch)
-	view := C.cbi_batch_view(batch)
-
-	// result arrays in C memory (cgo: no Go pointers to Go pointers inside cbh_result)
-	nt, nr := C.size_t(view.n_tuples), C.size_t(view.n_requests)
-	res := C.cbh_result{
-		effect:   (*C.uint8_t)(C.calloc(nt+1, 1)),
-		policy:   (*C.uint32_t)(C.calloc(nt+1, 4)),
-		scope:    (*C.uint32_t)(C.calloc(nt+1, 4)),
-		status:   (*C.uint8_t)(C.calloc(nt+1, 1)),
-		edr_mask: (*C.uint64_t)(C.calloc(nr+1, 8)),
-	}
-	defer func() {
-		C.free(unsafe.Pointer(res.effect))
-		C.free(unsafe.Pointer(res.policy))
-		C.free(unsafe.Pointer(res.scope))
-		C.free(unsafe.Pointer(res.status))
-		C.free(unsafe.Pointer(res.edr_mask))
-	}()
-
 	flags := C.uint32_t(C.CBH_F_WANT_DERIVED_ROLES)
 	if p.LenientScopeSearch {
 		flags |= C.CBH_F_LENIENT_SCOPE_SEARCH
@@ -123,18 +101,20 @@ func (g *gpuEngine) checkBatchGPU(_ context.Context, inputs []*enginev1.CheckInp
 		flags |= C.CBH_F_STRICT_EVALUATION
 	}
 	params := C.cbh_params{now_ns: C.int64_t(p.NowFunc().UnixNano()), flags: flags}
-	if C.cbh_check_batch(g.table, view, &params, &res) != 0 {
-		return nil, nil, errors.New(C.GoString(C.cbh_last_error()))
-	}
 
-	var assembled *C.cbi_outputs
-	if C.cbi_assemble_pb(g.ingest, batch, &res, bytesPtr, &offs[0], C.uint32_t(n), dv, &assembled) != 0 {
-		return nil, nil, errors.New(C.GoString(C.cbi_last_error()))
+	// The device road first (INTEGRATION.md §2d): the raw bytes cross PCIe once, the GPU flattens them, decides and writes
+	// the serialized CheckOutputs.  What the device flattener leaves (a CheckInput with more than 64 actions, ...) takes
+	// the host road below - same bytes either way.
+	obytes, ooffs, oflags, release, ok, err := g.deviceRoad(bytesPtr, offs, n, dv, ds, &params)
+	if err != nil {
+		return nil, nil, err
 	}
-	defer C.cbi_outputs_free(assembled)
-	ooffs := unsafe.Slice((*uint64)(unsafe.Pointer(C.cbi_outputs_offsets(assembled))), n+1)
-	oflags := unsafe.Slice((*byte)(unsafe.Pointer(C.cbi_outputs_flags(assembled))), n)
-	obytes := unsafe.Slice((*byte)(unsafe.Pointer(C.cbi_outputs_bytes(assembled))), int(ooffs[n]))
+	if !ok {
+		if obytes, ooffs, oflags, release, err = g.hostRoad(bytesPtr, offs, n, dv, ds, &params); err != nil {
+			return nil, nil, err
+		}
+	}
+	defer release()
 
 	// evaluation_errors / outputs (check.go:90-92): the inputs that can have any go through the tracing kernel once more
 	// (INTEGRATION.md §2c); what comes back per input is just those two fields, serialized - merged into the output below.
@@ -167,6 +147,120 @@ func (g *gpuEngine) checkBatchGPU(_ context.Context, inputs []*enginev1.CheckInp
 	}
 	return outs, fallback, nil
 }
+
+// hostRoad: cbi_flatten_pb -> cbh_check_batch -> cbi_assemble_pb (a host thread parses and assembles).  The returned slices
+// alias C memory until release() is called.
+func (g *gpuEngine) hostRoad(bytesPtr *C.uint8_t, offs []C.uint64_t, n int, dv, ds *C.char, params *C.cbh_params) (obytes []byte, ooffs []uint64, oflags []byte, release func(), err error) {
+	var batch *C.cbi_batch
+	if C.cbi_flatten_pb(g.ingest, bytesPtr, &offs[0], C.uint32_t(n), dv, ds, 1, &batch) != 0 {
+		return nil, nil, nil, nil, errors.New(C.GoString(C.cbi_last_error()))
+	}
+	defer C.cbi_batch_free(batch)
+	view := C.cbi_batch_view(batch)
+
+	// result arrays in C memory (cgo: no Go pointers to Go pointers inside cbh_result)
+	nt, nr := C.size_t(view.n_tuples), C.size_t(view.n_requests)
+	res := C.cbh_result{
+		effect:   (*C.uint8_t)(C.calloc(nt+1, 1)),
+		policy:   (*C.uint32_t)(C.calloc(nt+1, 4)),
+		scope:    (*C.uint32_t)(C.calloc(nt+1, 4)),
+		status:   (*C.uint8_t)(C.calloc(nt+1, 1)),
+		edr_mask: (*C.uint64_t)(C.calloc(nr+1, 8)),
+	}
+	defer func() {
+		C.free(unsafe.Pointer(res.effect))
+		C.free(unsafe.Pointer(res.policy))
+		C.free(unsafe.Pointer(res.scope))
+		C.free(unsafe.Pointer(res.status))
+		C.free(unsafe.Pointer(res.edr_mask))
+	}()
+
+	if C.cbh_check_batch(g.table, view, params, &res) != 0 {
+		return nil, nil, nil, nil, errors.New(C.GoString(C.cbh_last_error()))
+	}
+
+	var assembled *C.cbi_outputs
+	if C.cbi_assemble_pb(g.ingest, batch, &res, bytesPtr, &offs[0], C.uint32_t(n), dv, &assembled) != 0 {
+		return nil, nil, nil, nil, errors.New(C.GoString(C.cbi_last_error()))
+	}
+	ooffs = unsafe.Slice((*uint64)(unsafe.Pointer(C.cbi_outputs_offsets(assembled))), n+1)
+	oflags = unsafe.Slice((*byte)(unsafe.Pointer(C.cbi_outputs_flags(assembled))), n)
+	obytes = unsafe.Slice((*byte)(unsafe.Pointer(C.cbi_outputs_bytes(assembled))), int(ooffs[n]))
+
+	return obytes, ooffs, oflags, func() { C.cbi_outputs_free(assembled) }, nil
+}
+
+// deviceRoad: cbh_wire_flatten -> cbh_check_resident -> cbh_wire_outputs.  ok == false: these messages are the host
+// flattener's (cbh_wire_flatten returned 1).  The answers land in a page-locked block from g.outPool (DMA, no staging copy).
+func (g *gpuEngine) deviceRoad(bytesPtr *C.uint8_t, offs []C.uint64_t, n int, dv, ds *C.char, params *C.cbh_params) (obytes []byte, ooffs []uint64, oflags []byte, release func(), ok bool, err error) {
+	var db *C.cbh_device_batch
+	var info C.cbh_wire_info
+	switch rc := C.cbh_wire_flatten(g.table, 0, bytesPtr, &offs[0], C.uint32_t(n), dv, ds, &db, &info); {
+	case rc == 1:
+		return nil, nil, nil, nil, false, nil
+	case rc != 0:
+		return nil, nil, nil, nil, false, errors.New(C.GoString(C.cbh_last_error()))
+	}
+	defer C.cbh_batch_release(db)
+	if C.cbh_check_resident(g.table, db, params) != 0 {
+		return nil, nil, nil, nil, false, errors.New(C.GoString(C.cbh_last_error()))
+	}
+	blk := g.outPool.get(192*n+4096, n) // bytes | offsets (n + 1) | flags (n), one page-locked block
+	var need C.size_t
+	rc := C.cbh_wire_outputs(g.table, db, blk.bytes, C.size_t(blk.cap), blk.offs, blk.flags, &need)
+	if rc == 2 { // the guess was short: `need` is exact
+		g.outPool.put(blk)
+		blk = g.outPool.get(int(need), n)
+		rc = C.cbh_wire_outputs(g.table, db, blk.bytes, C.size_t(blk.cap), blk.offs, blk.flags, &need)
+	}
+	if rc != 0 {
+		g.outPool.put(blk)
+		return nil, nil, nil, nil, false, errors.New(C.GoString(C.cbh_last_error()))
+	}
+	ooffs = unsafe.Slice((*uint64)(unsafe.Pointer(blk.offs)), n+1)
+	oflags = unsafe.Slice((*byte)(unsafe.Pointer(blk.flags)), n)
+	obytes = unsafe.Slice((*byte)(unsafe.Pointer(blk.bytes)), int(ooffs[n]))
+	return obytes, ooffs, oflags, func() { g.outPool.put(blk) }, true, nil
+}
+
+// pinnedBlock / pinnedPool: page-locked output blocks (cbh_alloc_pinned) kept between calls.
+type pinnedBlock struct {
+	base  unsafe.Pointer
+	size  int
+	cap   int
+	bytes *C.uint8_t
+	offs  *C.uint64_t
+	flags *C.uint8_t
+}
+type pinnedPool struct {
+	mu   sync.Mutex
+	free []*pinnedBlock
+}
+
+func (p *pinnedPool) get(capBytes, n int) *pinnedBlock {
+	want := (capBytes+7)/8*8 + 8*(n+1) + n + 8
+	p.mu.Lock()
+	for i, b := range p.free {
+		if b.size >= want {
+			p.free = append(p.free[:i], p.free[i+1:]...)
+			p.mu.Unlock()
+			b.layout(want-8*(n+1)-n-8, n)
+			return b
+		}
+	}
+	p.mu.Unlock()
+	b := &pinnedBlock{base: C.cbh_alloc_pinned(C.size_t(want)), size: want}
+	b.layout(want-8*(n+1)-n-8, n)
+	return b
+}
+func (b *pinnedBlock) layout(capBytes, n int) {
+	capBytes = capBytes / 8 * 8
+	b.cap = capBytes
+	b.bytes = (*C.uint8_t)(b.base)
+	b.offs = (*C.uint64_t)(unsafe.Add(b.base, capBytes))
+	b.flags = (*C.uint8_t)(unsafe.Add(b.base, capBytes+8*(n+1)))
+}
+func (p *pinnedPool) put(b *pinnedBlock) { p.mu.Lock(); p.free = append(p.free, b); p.mu.Unlock() }
 
 type traced struct {
 	bytes      []byte // serialized CheckOutput holding only outputs (6) and evaluation_errors (7)
