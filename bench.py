@@ -314,7 +314,7 @@ def main():
             for _ in range(8):
                 w0 = time.perf_counter()
                 h, info, need = C.c_void_p(), capi.CWireInfo(), C.c_size_t()
-                rc = lib.cbh_wire_flatten(table.h, 0, pdata.ctypes.data, woff.ctypes.data, nw, b"default", b"", C.byref(h), C.byref(info))
+                rc = lib.cbh_wire_flatten(table.h, 0, pdata.ctypes.data, woff.ctypes.data, nw, b"default", b"", None, 0, C.byref(h), C.byref(info))
                 if rc != 0:
                     raise RuntimeError("cbh_wire_flatten: rc %d: %s" % (rc, lib.cbh_last_error().decode()))
                 rc = lib.cbh_check_resident(table.h, h, C.byref(prm))

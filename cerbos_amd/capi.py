@@ -156,7 +156,7 @@ def load():
     lib.cbh_table_set_resident_streams.restype = i32
     lib.cbh_table_resident_streams.argtypes = [vp]
     lib.cbh_table_resident_streams.restype = u32
-    lib.cbh_wire_flatten.argtypes = [vp, u32, vp, vp, u32, C.c_char_p, C.c_char_p, C.POINTER(vp), C.POINTER(CWireInfo)]
+    lib.cbh_wire_flatten.argtypes = [vp, u32, vp, vp, u32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(vp), C.POINTER(CWireInfo)]
     lib.cbh_wire_flatten.restype = i32
     lib.cbh_wire_spans_download.argtypes = [vp, vp, vp, vp, vp]
     lib.cbh_wire_spans_download.restype = i32
@@ -353,17 +353,19 @@ class Table:
         _check(load().cbh_batch_upload_on(self.h, device_index, C.byref(cb), C.byref(h)))
         return DeviceBatch(self, h, batch.n_tuples, batch.n_requests, batch)
 
-    def wire_flatten(self, data, offsets, default_policy_version="default", default_scope="", device_index=0):
+    def wire_flatten(self, data, offsets, default_policy_version="default", default_scope="", device_index=0, globals_pb=b""):
         """``cbh_wire_flatten``: serialized CheckInputs (uint8 array + uint64[n + 1] offsets) -> a resident batch the GPU
         flattened.  Results of ``launch`` + ``download`` on it are in input order.  Raises ``HostFlattenerNeeded`` when the
-        messages are the host flattener's."""
+        messages are the host flattener's.  ``globals_pb``: the call's globals as a serialized google.protobuf.Struct (a table
+        lowered with per-call globals reads them)."""
         data = np.ascontiguousarray(data, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offsets) - 1
         h = C.c_void_p()
         info = CWireInfo()
         rc = load().cbh_wire_flatten(self.h, device_index, data.ctypes.data if data.size else None, offsets.ctypes.data, n,
-                                     default_policy_version.encode(), default_scope.encode(), C.byref(h), C.byref(info))
+                                     default_policy_version.encode(), default_scope.encode(), globals_pb or None, len(globals_pb or b""),
+                                     C.byref(h), C.byref(info))
         if rc == 1:
             raise HostFlattenerNeeded(load().cbh_last_error().decode("utf-8", "replace"))
         _check(rc)

@@ -744,8 +744,9 @@ static int wire_stats_read(cbh_device_batch* b, const WireStats* d_stats, WireSt
 }
 
 extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
-                                const char* default_version, const char* default_scope, cbh_device_batch** out, cbh_wire_info* info) {
-  if (!t || !out || !info || (n && (!bytes || !offsets))) return fail("null argument");
+                                const char* default_version, const char* default_scope, const uint8_t* globals_pb, size_t globals_len,
+                                cbh_device_batch** out, cbh_wire_info* info) {
+  if (!t || !out || !info || (n && (!bytes || !offsets)) || (globals_len && !globals_pb)) return fail("null argument");
   std::memset(info, 0, sizeof(*info));
   info->first_bad = CBH_NONE; info->n_requests = n;
   if (device_index >= t->reps.size()) return fail("device index out of range");
@@ -753,7 +754,7 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
   const u64 total = n ? offsets[n] : 0;
   std::string dv = default_version ? default_version : "default", ds = default_scope ? default_scope : "";
   if (!ds.empty() && ds[0] == '.') ds.erase(0, 1);   // scope_value (namer.go:276-278)
-  if (total + dv.size() + ds.size() + 64 > 0xFFFFFFFFull) return fail("cbh_wire_flatten: more than 4 GB of messages in one call");
+  if (total + dv.size() + ds.size() + globals_len + 64 > 0xFFFFFFFFull) return fail("cbh_wire_flatten: more than 4 GB of messages in one call");
   Replica* rep = t->reps[device_index];
   HIPCHK(hipSetDevice(rep->device));
   cbh_device_batch* b = new (std::nothrow) cbh_device_batch();
@@ -777,9 +778,10 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
   a.n = n;
   a.dver_off = (u32)total; a.dver_len = (u32)dv.size(); a.dscope_off = (u32)(total + dv.size()); a.dscope_len = (u32)ds.size();
   a.claims_off = (u32)(total + dv.size() + ds.size());
+  a.globals_off = a.claims_off + 6u; a.globals_len = (u32)globals_len;
   u8* d_msg = nullptr; u64* d_moff = nullptr; WireStats* d_stats = nullptr;
   int rc = 0;
-  rc |= dalloc(b, d_msg, (size_t)total + dv.size() + ds.size() + 64);
+  rc |= dalloc(b, d_msg, (size_t)total + dv.size() + ds.size() + globals_len + 64);
   rc |= dalloc(b, d_moff, (size_t)n + 1);
   rc |= dalloc(b, a.cnt, (size_t)n + 1); rc |= dalloc(b, a.status, (size_t)n + 1);
   rc |= dalloc(b, a.wavesum, 2 * (size_t)nw + 2); rc |= dalloc(b, a.waveoff, 2 * (size_t)nw + 2);
@@ -787,7 +789,8 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
   if (rc != 0) return bail(-1);
   a.msg = d_msg; a.moff = d_moff; a.stats = d_stats;
   WireStats st; cbh_wire_stats_init(st);
-  const std::string tail = dv + ds + "claims";
+  std::string tail = dv + ds + "claims";
+  if (globals_len) tail.append(reinterpret_cast<const char*>(globals_pb), globals_len);
   static const u64 zero_off = 0;
   if (total && hipMemcpyAsync(d_msg, bytes, total, hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
   if (!tail.empty() && hipMemcpyAsync(d_msg + total, tail.data(), tail.size(), hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }

@@ -524,7 +524,7 @@ int cbi_table_open(const void* blob, size_t len, cbi_table** out) {
   for (u32 c = 0; c < ncol; ++c) {
     if (e - p < 2) return bail("column path section truncated");
     Column col; col.root = p[0]; u32 nk = p[1]; p += 2;
-    if (col.root > 3) return bail("bad column root");
+    if (col.root > 4) return bail("bad column root");
     for (u32 k = 0; k < nk; ++k) {
       if (e - p < 2) return bail("column path section truncated");
       u32 l = p[0] | (p[1] << 8); p += 2;
@@ -548,6 +548,7 @@ uint32_t cbi_table_trace_scope(const cbi_table* t) { return !t || !t->has_trace 
 struct Source {
   const uint8_t* bytes = nullptr; const uint64_t* offsets = nullptr;
   bool request = false; Span principal{nullptr, nullptr}, aux{nullptr, nullptr};
+  Span globals{nullptr, nullptr};   // the call's globals as a serialized google.protobuf.Struct (columns of root 4), or empty
   const Span* entries = nullptr;   // CheckResourcesRequest.ResourceEntry messages: actions = 1, resource = 2
 };
 
@@ -595,17 +596,22 @@ static int flatten_slice(const cbi_table* t, const Source& src, uint32_t first, 
   // per message scratch, reused
   std::vector<std::string_view> actions, roles;
   std::vector<std::pair<std::string_view, u32>> prev_roles, prev_actions;
-  std::vector<Entry> attrs[3];   // entries of Principal.attr / Resource.attr / AuxData.jwt, wire order
+  std::vector<Entry> attrs[5];   // entries of Principal.attr / Resource.attr / AuxData.jwt, wire order; [4]: the call's globals (once)
   std::string kind_buf;
-  bool need_root[4] = {false, false, false, false};
+  bool need_root[5] = {false, false, false, false, false};
   for (const Column& c : t->columns) need_root[c.root] = true;
+  if (need_root[4]) {   // EvalParams.Globals (evaluator.go:52-57): Struct.fields = 1
+    Span s = src.globals; Field f; bool bad = false;
+    while (next(s, f, bad)) if (f.num == 1 && f.wt == 2) { Entry en; if (entry(f.s, en, bad)) attrs[4].push_back(en); }
+    if (bad) return bail("malformed globals");
+  }
 
   u32 r = 0;
   for (u32 i = 0; i < n; ++i) {
     Msg m;
     std::string_view request_id;
     actions.clear(); roles.clear();
-    for (auto& a : attrs) a.clear();
+    for (int a = 0; a < 3; ++a) attrs[a].clear();
     bool bad = false;
     if (src.request) {
       m.principal = src.principal; m.aux = src.aux;
@@ -721,7 +727,7 @@ static int flatten_slice(const cbi_table* t, const Source& src, uint32_t first, 
           else k = 3;
         } else if (nk == 0) {
           // the whole root map: Principal.attr (4) / Resource.attr (4) / AuxData.jwt (1)
-          TV tv = encd.enc_map(col.root == 0 ? m.principal : col.root == 1 ? m.resource : m.aux, col.root == 2 ? 1 : 4);
+          TV tv = encd.enc_map(col.root == 0 ? m.principal : col.root == 1 ? m.resource : col.root == 4 ? src.globals : m.aux, (col.root == 2 || col.root == 4) ? 1 : 4);
           tag = tv.tag; val = tv.val; done = true;
         } else {
           bool found = false;
@@ -1033,11 +1039,17 @@ static bool split_request(const uint8_t* request, uint64_t len, RequestParts& rp
 
 extern "C" {
 
+int cbi_flatten_pb_g(const cbi_table* t, const uint8_t* bytes, const uint64_t* offsets, uint32_t n, const char* default_version,
+                     const char* default_scope, const uint8_t* globals_pb, uint64_t globals_len, int sort, int n_threads, cbi_batch** out) {
+  if (!t || !out || (n && (!bytes || !offsets)) || (globals_len && !globals_pb)) return fail("cbi_flatten_pb: null argument");
+  Source src; src.bytes = bytes; src.offsets = offsets;
+  if (globals_len) src.globals = Span{globals_pb, globals_pb + globals_len};
+  return flatten_source(t, src, n, default_version, default_scope, sort, n_threads, out);
+}
+
 int cbi_flatten_pb_mt(const cbi_table* t, const uint8_t* bytes, const uint64_t* offsets, uint32_t n, const char* default_version,
                       const char* default_scope, int sort, int n_threads, cbi_batch** out) {
-  if (!t || !out || (n && (!bytes || !offsets))) return fail("cbi_flatten_pb: null argument");
-  Source src; src.bytes = bytes; src.offsets = offsets;
-  return flatten_source(t, src, n, default_version, default_scope, sort, n_threads, out);
+  return cbi_flatten_pb_g(t, bytes, offsets, n, default_version, default_scope, nullptr, 0, sort, n_threads, out);
 }
 
 int cbi_flatten_request_pb(const cbi_table* t, const uint8_t* request, uint64_t request_len, const uint8_t* aux_data, uint64_t aux_len,

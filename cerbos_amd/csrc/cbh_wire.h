@@ -66,7 +66,8 @@ struct WireArgs {
   const CBH_G WireCol* cols; const CBH_G u8* col_keys; u32 n_cols; u32 sens_cols;
   // the messages: message i = msg[moff[i] .. moff[i + 1]); the call's default version / scope and "claims" follow the last one
   const CBH_G u8* msg; const CBH_G u64* moff; u32 n; u32 heap_cap;
-  u32 dver_off, dver_len, dscope_off, dscope_len, claims_off, pad1;   // ("claims": the key of the request view of a named JWT)
+  u32 dver_off, dver_len, dscope_off, dscope_len, claims_off, pad1;
+  u32 globals_off, globals_len;   // the call's globals, a serialized google.protobuf.Struct behind the messages (columns of root 4)   // ("claims": the key of the request view of a named JWT)
   // scratch
   CBH_G u32* cnt;         // [n] actions | roles << 8
   CBH_G u8* status;       // [n] CBH_WS_*
@@ -581,8 +582,9 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
     bool is_container = false, is_map = false; WSpan body; body.p = body.e = 0; u32 fnum = 1u, need = 0u;
     u32 shape = 0u;   // 0 a plain container; auxData.jwts (root 3): 1 one named JWT as {"claims": {...}}, 2 all of them name -> {"claims": {...}}
     if (live) {
-      const WSpan root = col.root == 0u ? principal : col.root == 1u ? resource : aux;
-      const u32 root_fnum = col.root == 2u ? 1u : 4u;
+      WSpan gl; gl.p = a.globals_off; gl.e = a.globals_off + a.globals_len;
+      const WSpan root = col.root == 0u ? principal : col.root == 1u ? resource : col.root == 4u ? gl : aux;
+      const u32 root_fnum = (col.root == 2u || col.root == 4u) ? 1u : 4u;
       bool done = false; WSpan cur; cur.p = cur.e = 0;
       u32 k0 = 1u;
       if (col.root == 3u) {

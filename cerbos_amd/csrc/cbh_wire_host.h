@@ -51,7 +51,7 @@ static inline const char* cbh_wire_index_build(WireIndexHost& w, const uint8_t* 
     if (e - p < 2) return "image column path section truncated";
     WireCol col; memset(&col, 0, sizeof(col));
     col.root = p[0]; const u32 nk = p[1]; p += 2;
-    if (col.root > 3) return "image column root out of range";
+    if (col.root > 4) return "image column root out of range";
     if (nk > CBH_WIRE_MAX_KEYS) w.why_not = "a column path is deeper than the device flattener follows";
     col.nk = nk > CBH_WIRE_MAX_KEYS ? CBH_WIRE_MAX_KEYS : nk;
     for (u32 k = 0; k < nk; ++k) {

@@ -75,9 +75,11 @@ class HipEvaluator:
 
     # -- constructors ---------------------------------------------------------------------
     @classmethod
-    def from_rule_table(cls, rt: dict, conf: Conf = None, device: int = 0):
+    def from_rule_table(cls, rt: dict, conf: Conf = None, device: int = 0, per_call_globals: bool = False):
+        """``per_call_globals``: the image does not fold ``conf.globals`` in; every ``check`` brings its globals
+        (``EvalParams.Globals``, evaluator.go:52-57; default: ``conf.globals``) and one image answers any of them."""
         conf = conf or Conf()
-        return cls(lower_rule_table(rt, conf.globals), conf, device)
+        return cls(lower_rule_table(rt, conf.globals, per_call_globals=per_call_globals), conf, device)
 
     @classmethod
     def from_rule_table_pb(cls, wire: bytes, conf: Conf = None, device: int = 0):
@@ -95,8 +97,16 @@ class HipEvaluator:
         return cls.from_rule_table(rule_table_from_policies(load_policy_dir(path)), conf, device)
 
     # -- the seam -------------------------------------------------------------------------
+    def _call_globals(self, globals_):
+        """The globals of one call: the override, else the configured ones; None for a table that carries them in its image."""
+        if not getattr(self.lt, "per_call_globals", False):
+            if globals_ is not None and dict(globals_) != self.conf.globals:
+                raise ValueError("this table was lowered with its globals folded in: lower it with per_call_globals=True to override them per call")
+            return None
+        return dict(self.conf.globals if globals_ is None else globals_)
+
     def check(self, inputs, now_ns=None, lenient_scope_search=None, strict_evaluation=None,
-              default_policy_version=None, default_scope=None, allow_unsupported=False, trace=False):
+              default_policy_version=None, default_scope=None, allow_unsupported=False, trace=False, globals_=None):
         """``Evaluator.Check``: one CheckOutput per CheckInput, same order.
 
         ``trace``: also fill ``evaluationErrors`` and ``outputs`` as check.go:90-92 does.  They come from a second launch
@@ -111,7 +121,8 @@ class HipEvaluator:
         dscope = conf.default_scope if default_scope is None else default_scope
         if now_ns is None:
             now_ns = time.time_ns()  # frozen once per call (evaluator_trace_common.go:24-26)
-        batch = self.flattener.flatten(inputs, dver, dscope)
+        g = self._call_globals(globals_)
+        batch = self.flattener.flatten(inputs, dver, dscope) if g is None else self.flattener.flatten(inputs, dver, dscope, globals_=g)
         flags = capi.F_WANT_DERIVED_ROLES
         if lenient:
             flags |= capi.F_LENIENT_SCOPE_SEARCH
@@ -121,12 +132,12 @@ class HipEvaluator:
         if not trace:
             return self.assemble(inputs, batch, res, dver, allow_unsupported)
         outs, bad = self.assemble(inputs, batch, res, dver, True)
-        incomplete = self._trace(inputs, batch, res, outs, bad, now_ns, flags, dver, dscope)
+        incomplete = self._trace(inputs, batch, res, outs, bad, now_ns, flags, dver, dscope, g)
         if (bad or incomplete) and not allow_unsupported:
             raise DeviceUnsupported(sorted(set(bad) | set(incomplete)), self.lt.unsupported + self.lt.trace_unsupported)
         return (outs, bad, incomplete) if allow_unsupported else outs
 
-    def _trace(self, inputs, batch, res, outs, bad, now_ns, flags, dver, dscope):
+    def _trace(self, inputs, batch, res, outs, bad, now_ns, flags, dver, dscope, g=None):
         """The trace pass for the inputs that need it; fills outs[i]["evaluationErrors"] / ["outputs"] in place and returns
         the inputs left incomplete."""
         from .trace import TraceDecoder
@@ -152,9 +163,9 @@ class HipEvaluator:
             with self._ingest_lock:   # check() is called from many threads
                 if self._py_flattener is None:
                     self._py_flattener = Flattener(lt)
-        sbatch = self._py_flattener.flatten(sub, dver, dscope)
+        sbatch = self._py_flattener.flatten(sub, dver, dscope, globals_=g)
         tres, records = self.table.trace(sbatch, now_ns=now_ns, flags=flags)
-        decoded = TraceDecoder(lt, sbatch, sub).decode(records, len(records), tres.status)
+        decoded = TraceDecoder(lt, sbatch, sub, g).decode(records, len(records), tres.status)
         # the tracing kernel decides the inputs again: anything but the same effects is a defect, never to be papered over
         tin = tres.to_input_order(sbatch)
         t = 0
@@ -174,7 +185,7 @@ class HipEvaluator:
         return incomplete
 
     def check_pb(self, data, offsets, now_ns=None, lenient_scope_search=None, strict_evaluation=None,
-                 default_policy_version=None, default_scope=None, trace=False, device_ingest=True):
+                 default_policy_version=None, default_scope=None, trace=False, device_ingest=True, globals_=None):
         """Bytes in, bytes out - the path a Go caller takes: serialized ``CheckInput``
         messages (``data`` uint8, ``offsets`` uint64[n + 1]) -> serialized ``CheckOutput`` messages.
         ``device_ingest`` (the default): the device road - the raw bytes cross PCIe, the GPU flattens them
@@ -191,12 +202,17 @@ class HipEvaluator:
         if now_ns is None:
             now_ns = time.time_ns()
         self._ingest_table()
+        g = self._call_globals(globals_)
+        gpb = b""
+        if g is not None:
+            from . import wire as _wire
+            gpb = _wire.encode_map(1, g)   # google.protobuf.Struct: fields = 1
         flags = capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0) | (capi.F_STRICT_EVALUATION if strict else 0)
         outs = None
         self.last_road = "host"
         if device_ingest:
             try:
-                db = self.table.wire_flatten(data, offsets, dver, dscope)
+                db = self.table.wire_flatten(data, offsets, dver, dscope, globals_pb=gpb)
             except capi.HostFlattenerNeeded:
                 db = None
             if db is not None:
@@ -207,7 +223,7 @@ class HipEvaluator:
                 finally:
                     db.close()
         if outs is None:
-            batch = self._ingest.flatten_pb(data, offsets, dver, dscope)
+            batch = self._ingest.flatten_pb(data, offsets, dver, dscope, globals_pb=gpb)
             res = self.table.check(batch, now_ns=now_ns, flags=flags, device_order=True)
             outs, oflags = self._ingest.assemble_pb(batch, res, data, offsets, dver)
         if not trace:
@@ -228,7 +244,7 @@ class HipEvaluator:
         sdata = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
         soff = np.zeros(len(sel) + 1, dtype=np.uint64)
         soff[1:] = np.cumsum([p.size for p in parts])
-        sbatch = self._ingest.flatten_pb(sdata, soff, dver, dscope)
+        sbatch = self._ingest.flatten_pb(sdata, soff, dver, dscope, globals_pb=gpb)
         tres, records = self.table.trace(sbatch, now_ns=now_ns, flags=flags)
         extra, tflags = trace_pb(self._ingest, sbatch, tres, records, sdata, soff)
         for j, i in enumerate(sel):

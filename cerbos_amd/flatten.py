@@ -137,7 +137,7 @@ class Flattener:
             self._scope_cache[scope] = w
         return w
 
-    def flatten(self, inputs, default_policy_version="default", default_scope="", sort=True) -> Batch:
+    def flatten(self, inputs, default_policy_version="default", default_scope="", sort=True, globals_=None) -> Batch:
         lt, K = self.lt, self.K
         table_ids = lt.string_ids
         local = {}
@@ -231,7 +231,8 @@ class Flattener:
             req[RQ_S_R_VERSION, r] = sid(res.get("policyVersion", "") or "")
             roots = {"P": p.get("attr") or {}, "R": res.get("attr") or {}, "J": aux.get("jwt") or {},
                      # name -> {"claims": {...}}; a JWT without claims has an empty map (as the protobuf message does)
-                     "S": {k: {"claims": (j or {}).get("claims") or {}} for k, j in (aux.get("jwts") or {}).items()}}
+                     "S": {k: {"claims": (j or {}).get("claims") or {}} for k, j in (aux.get("jwts") or {}).items()},
+                     "G": globals_ or {}}   # the CALL's globals (a table lowered with per_call_globals reads them as columns)
             for ci, (root, keys) in enumerate(lt.columns):
                 cur = roots[root]
                 tag = None

@@ -35,6 +35,7 @@ def load():
         lib.cbi_table_close.restype = None
         lib.cbi_flatten_pb.argtypes = [vp, vp, vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
         lib.cbi_flatten_pb_mt.argtypes = [vp, vp, vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
+        lib.cbi_flatten_pb_g.argtypes = [vp, vp, vp, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_int, C.c_int, C.POINTER(vp)]
         lib.cbi_flatten_request_pb.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
         lib.cbi_assemble_response_pb.argtypes = [vp, vp, C.POINTER(capi.CResult), vp, C.c_uint64, C.c_char_p, C.POINTER(vp)]
         lib.cbi_batch_free.argtypes = [vp]
@@ -114,16 +115,16 @@ class IngestTable:
         """0 = no trace sections, 1 = trace the inputs marked CEL_ERROR, 2 = trace every input (``cbi_table_trace_scope``)."""
         return int(load().cbi_table_trace_scope(self.h))
 
-    def flatten_pb(self, data, offsets, default_policy_version="default", default_scope="", sort=True, threads=1) -> Batch:
+    def flatten_pb(self, data, offsets, default_policy_version="default", default_scope="", sort=True, threads=1, globals_pb=b"") -> Batch:
         """``data``: uint8 array holding the messages back to back, ``offsets``: uint64[n + 1]; ``threads`` > 1
         flattens slices concurrently inside the call (same batch, bit for bit)."""
         data = np.ascontiguousarray(data, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = len(offsets) - 1
         h = C.c_void_p()
-        _check(load().cbi_flatten_pb_mt(self.h, data.ctypes.data if data.size else None, offsets.ctypes.data, n,
-                                        default_policy_version.encode(), default_scope.encode(), int(bool(sort)), int(threads),
-                                        C.byref(h)))
+        _check(load().cbi_flatten_pb_g(self.h, data.ctypes.data if data.size else None, offsets.ctypes.data, n,
+                                       default_policy_version.encode(), default_scope.encode(), globals_pb or None, len(globals_pb or b""),
+                                       int(bool(sort)), int(threads), C.byref(h)))
         return self._batch(h)
 
     def flatten_request_pb(self, request: bytes, aux_data: bytes = None, default_policy_version="default", default_scope="",
@@ -252,9 +253,10 @@ class WireFlattener:
     def __init__(self, lt):
         self.table = IngestTable(lt.blob)
 
-    def flatten(self, inputs, default_policy_version="default", default_scope="", sort=True) -> Batch:
+    def flatten(self, inputs, default_policy_version="default", default_scope="", sort=True, globals_=None) -> Batch:
         from . import wire
         data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
-        b = self.table.flatten_pb(data, off, default_policy_version, default_scope, sort)
+        b = self.table.flatten_pb(data, off, default_policy_version, default_scope, sort,
+                                  globals_pb=wire.encode_map(1, globals_) if globals_ else b"")
         b.actions_per_request = [list(inp.get("actions") or []) for inp in inputs]
         return b

@@ -111,6 +111,7 @@ class LoweredTable:
         self.dr_names = []      # bit -> derived role name
         self.unsupported = []   # [(expression, reason)] compiled to OP_UNSUPPORTED
         self.nfas = [None, None, None]
+        self.per_call_globals = False   # `G.x` read from the call's globals (a column of root "G"), not folded into the image
         self.stats = {}
 
     def sid(self, s):
@@ -126,11 +127,17 @@ def _cond_uses_runtime(cond, params: Params):
     return any(_cond_uses_runtime(c, params) for c in cond[1])
 
 
-def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:
-    """The columns the kernels' inline leaf code reads get the lowest indices: the walk that runs no generic program
+def lower_rule_table(rt: dict, globals_=None, trace=True, per_call_globals=False) -> LoweredTable:
+    """``per_call_globals``: `G.x` is not folded into the image but read from the globals every CALL brings
+    (``Flattener.flatten(globals_=...)``, ``cbi_flatten_pb_g``, ``cbh_wire_flatten``'s ``globals_pb``): one image, any globals.
+
+    The columns the kernels' inline leaf code reads get the lowest indices: the walk that runs no generic program
     (cbh_walk2_kernel) parks only those in LDS, and LDS is what bounds its occupancy.  Which columns those are is known once
     the programs are compiled - hence up to three passes, the later ones with the column order of the one before."""
     first = ()
+    if per_call_globals:
+        from .celc import PER_CALL_GLOBALS
+        globals_ = PER_CALL_GLOBALS
     for _ in range(3):
         lt = _lower_rule_table(rt, globals_, trace, first)
         want = tuple(lt.columns[i] for i in sorted(lt.inline_cols))
@@ -142,7 +149,8 @@ def lower_rule_table(rt: dict, globals_=None, trace=True) -> LoweredTable:
 
 def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:  # noqa: C901
     lt = LoweredTable()
-    globals_ = dict(globals_ or {})
+    from .celc import _PerCallGlobals
+    globals_ = globals_ if isinstance(globals_, _PerCallGlobals) else dict(globals_ or {})
 
     def sid(s):
         i = lt.string_ids.get(s)
@@ -883,6 +891,7 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
 
     # ---- assemble
     lt.columns = [k for k, _ in sorted(pb.columns.items(), key=lambda kv: kv[1])]
+    lt.per_call_globals = pb.per_call_globals
     lt.dr_names = [n for n, _ in sorted(pb.dr_names.items(), key=lambda kv: kv[1])]
     lt.unsupported = list(dict.fromkeys(pb.unsupported))
     assert len(lt.strings) == K, "string interned after the pool was frozen"
@@ -1107,11 +1116,11 @@ def _tree_descriptor(strip):
 
 
 def _column_paths(columns):
-    """Per column: u8 root (0 = P.attr, 1 = R.attr, 2 = auxData.jwt, 3 = auxData.jwts), u8 n_keys, then per key
+    """Per column: u8 root (0 = P.attr, 1 = R.attr, 2 = auxData.jwt, 3 = auxData.jwts, 4 = the call's globals), u8 n_keys, then per key
     u16 length + UTF-8 bytes."""
     out = bytearray()
     for root, keys in columns:
-        out += struct.pack("<BB", "PRJS".index(root), len(keys))
+        out += struct.pack("<BB", "PRJSG".index(root), len(keys))
         for k in keys:
             kb = k.encode("utf-8")
             out += struct.pack("<H", len(kb)) + kb

@@ -149,6 +149,15 @@ def _subst(ast, fn):
     return ast
 
 
+class _PerCallGlobals(dict):
+    """Marker: `G.x` / `globals.x` is NOT folded into the image; it compiles to a column of root "G" that every flattener fills
+    from the globals of the CALL (evaluator.EvalParams.Globals, internal/evaluator/evaluator.go:52-57, 98-106) - one image
+    answers any globals."""
+
+
+PER_CALL_GLOBALS = _PerCallGlobals()
+
+
 class Params:
     """Constants + variables visible to one condition (RuleRow.Params)."""
 
@@ -156,7 +165,7 @@ class Params:
         self.constants = dict(constants or {})
         self.ordered_variables = list(ordered_variables or [])
         self.variables = {n: t for n, t in self.ordered_variables}
-        self.globals = dict(globals_ or {})
+        self.globals = globals_ if isinstance(globals_, _PerCallGlobals) else dict(globals_ or {})
         # trace programs (ProgramBuilder.trace_*): an inlined variable stays recognisable - ("varscope", name, body) - because
         # the reference evaluates it on its own and a failure there reads differently at the place of use (check.go:651-677)
         self.trace = trace
@@ -188,6 +197,8 @@ class Params:
                         return ("call", "__unsupported__", None, ())
                     return value_to_ast(self.constants[name])
                 if base in ("G", "globals"):
+                    if isinstance(self.globals, _PerCallGlobals):
+                        return n   # a column read (CelCompiler._path): the call's globals, not the lowering's
                     if name not in self.globals:
                         if self.trace:
                             return ("call", "__undef__", None, (("lit", "string", name),))
@@ -205,6 +216,7 @@ class ProgramBuilder:
 
     def __init__(self, intern_string, globals_=None):
         self.sid = intern_string           # str -> table string id
+        self.per_call_globals = isinstance(globals_, _PerCallGlobals)
         self.globals = dict(globals_ or {})
         self.code = []
         self.const_index = {}
@@ -946,6 +958,8 @@ class _FuncCompiler:
             return None
         if base == "runtime" and len(keys) == 1 and keys[0] in ("effectiveDerivedRoles", "effective_derived_roles"):
             return ("edr",)
+        if base in ("G", "globals") and self.pb.per_call_globals:
+            return ("col", "G", tuple(keys))
         return None
 
     def _stringy(self, ast):

@@ -37,17 +37,17 @@ class _Incomplete(Exception):
     pass
 
 
-def request_roots(inp):
+def request_roots(inp, globals_=None):
     """The maps the attribute columns are paths into (flatten.py)."""
     p, res = inp["principal"], inp["resource"]
     aux = inp.get("auxData") or {}
     return {"P": p.get("attr") or {}, "R": res.get("attr") or {}, "J": aux.get("jwt") or {},
-            "S": {k: {"claims": (j or {}).get("claims") or {}} for k, j in (aux.get("jwts") or {}).items()}}
+            "S": {k: {"claims": (j or {}).get("claims") or {}} for k, j in (aux.get("jwts") or {}).items()}, "G": globals_ or {}}
 
 
 class TraceDecoder:
-    def __init__(self, lt, batch, inputs):
-        self.lt, self.batch, self.inputs = lt, batch, inputs
+    def __init__(self, lt, batch, inputs, globals_=None):
+        self.lt, self.batch, self.inputs, self.globals = lt, batch, inputs, globals_
         self.K = len(lt.strings)
         self._local = None
 
@@ -76,7 +76,7 @@ class TraceDecoder:
             # the column's path did not resolve in this input: which step failed decides the text (a missing key, or a
             # select below something that is not a map)
             root, keys = self.lt.columns[detail]
-            cur = request_roots(inp)[root]
+            cur = request_roots(inp, self.globals)[root]
             for key in keys:
                 if not isinstance(cur, dict):
                     return "no such overload"

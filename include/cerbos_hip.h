@@ -266,7 +266,10 @@ int cbh_kernel_time_ms(cbh_table* t, float* check_kernel_ms, float* resolve_kern
  * Returns 0; 1 = nothing was built because some messages (info->n_host of them; all, for a table with a column the device
  * flattener does not follow) are the host flattener's - more than 64 actions, a pre-0.30 resource kind no policy names,
  * containers nested deeper than 8: take the batch through cbi_flatten_pb + cbh_check_batch instead, same results;
- * < 0 = error (a malformed message: info->first_bad). */
+ * < 0 = error (a malformed message: info->first_bad).
+ * globals_pb / globals_len: the CALL's globals (evaluator.EvalParams.Globals, internal/evaluator/evaluator.go:52-57, 98-106) as
+ * a serialized google.protobuf.Struct, or NULL / 0: a table lowered with per-call globals reads `G.x` from them (attribute columns
+ * of root 4, like any request attribute); any other table carries its globals as constants of the image and ignores them. */
 typedef struct cbh_wire_info {
   uint32_t n_requests; /* = n */
   uint32_t n_tuples;
@@ -278,7 +281,8 @@ typedef struct cbh_wire_info {
   uint32_t reserved;
 } cbh_wire_info;
 int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
-                     const char* default_version, const char* default_scope, cbh_device_batch** out, cbh_wire_info* info);
+                     const char* default_version, const char* default_scope, const uint8_t* globals_pb, size_t globals_len,
+                     cbh_device_batch** out, cbh_wire_info* info);
 /* Where the strings a CheckOutput repeats sit in each message (cerbos_ingest.h cbi_assemble_wire_pb reads them instead of
  * walking the messages again): in_span [n][6] (offset, length) pairs relative to the message start - request id, principal id,
  * principal version, resource kind, resource version, resource id; act_span [n_tuples] (offset, length) of every action;

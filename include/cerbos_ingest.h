@@ -53,6 +53,11 @@ int cbi_flatten_pb(const cbi_table* t, const uint8_t* bytes, const uint64_t* off
  * that the batch equals the single-pass one).  n_threads <= 1, or fewer than ~1k messages per thread: single pass. */
 int cbi_flatten_pb_mt(const cbi_table* t, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
                       const char* default_version, const char* default_scope, int sort, int n_threads, cbi_batch** out);
+/* The same with the CALL's globals (evaluator.EvalParams.Globals, internal/evaluator/evaluator.go:52-57, 98-106) as a serialized
+ * google.protobuf.Struct: a table lowered with per-call globals reads `G.x` from them (columns of root 4); any other table ignores
+ * them (its globals are constants of the image). */
+int cbi_flatten_pb_g(const cbi_table* t, const uint8_t* bytes, const uint64_t* offsets, uint32_t n, const char* default_version,
+                     const char* default_scope, const uint8_t* globals_pb, uint64_t globals_len, int sort, int n_threads, cbi_batch** out);
 /*
  * The same for ONE serialized cerbos.request.v1.CheckResourcesRequest (request.proto:222-273): every resource entry
  * becomes the CheckInput that svc.CheckResources builds from it (cerbos_svc.go:274-287: the request's principal and

@@ -195,7 +195,7 @@ func (g *gpuEngine) hostRoad(bytesPtr *C.uint8_t, offs []C.uint64_t, n int, dv, 
 func (g *gpuEngine) deviceRoad(bytesPtr *C.uint8_t, offs []C.uint64_t, n int, dv, ds *C.char, params *C.cbh_params) (obytes []byte, ooffs []uint64, oflags []byte, release func(), ok bool, err error) {
 	var db *C.cbh_device_batch
 	var info C.cbh_wire_info
-	switch rc := C.cbh_wire_flatten(g.table, 0, bytesPtr, &offs[0], C.uint32_t(n), dv, ds, &db, &info); {
+	switch rc := C.cbh_wire_flatten(g.table, 0, bytesPtr, &offs[0], C.uint32_t(n), dv, ds, nil, 0 /* per-call globals: a serialized Struct */, &db, &info); {
 	case rc == 1:
 		return nil, nil, nil, nil, false, nil
 	case rc != 0:

@@ -259,7 +259,7 @@ static void wire_launch(int kind, uint32_t nblocks) {
   g_wire_kind = 0;
 }
 extern "C" int hostsim_wire_flatten(const void* blob, size_t len, const uint8_t* bytes, const uint64_t* offsets, uint32_t n, const char* dver,
-                                    const char* dscope, uint32_t dict_slots_hint, uint32_t heap_hint, HsWire* out) {
+                                    const char* dscope, const uint8_t* globals_pb, size_t globals_len, uint32_t dict_slots_hint, uint32_t heap_hint, HsWire* out) {
   TableDev t{}; std::vector<uint32_t> meta;
   const uint8_t* base = static_cast<const uint8_t*>(blob);
   if (const char* e = cbh_parse_image(t, meta, base, base, len)) { g_err = e; return -1; }
@@ -272,6 +272,7 @@ extern "C" int hostsim_wire_flatten(const void* blob, size_t len, const uint8_t*
   g_w.msg.assign(bytes, bytes + total);
   g_w.msg.insert(g_w.msg.end(), dv.begin(), dv.end()); g_w.msg.insert(g_w.msg.end(), ds.begin(), ds.end());
   { const char* cl = "claims"; g_w.msg.insert(g_w.msg.end(), cl, cl + 6); }
+  if (globals_len) g_w.msg.insert(g_w.msg.end(), globals_pb, globals_pb + globals_len);
   g_w.msg.resize(g_w.msg.size() + 16, 0);
   g_w.moff.assign(offsets, offsets + n + 1);
   if (n == 0) g_w.moff.assign(1, 0);
@@ -283,6 +284,7 @@ extern "C" int hostsim_wire_flatten(const void* blob, size_t len, const uint8_t*
   a.msg = g_w.msg.data(); a.moff = g_w.moff.data(); a.n = n;
   a.dver_off = (uint32_t)total; a.dver_len = (uint32_t)dv.size(); a.dscope_off = (uint32_t)(total + dv.size()); a.dscope_len = (uint32_t)ds.size();
   a.claims_off = (uint32_t)(total + dv.size() + ds.size());
+  a.globals_off = a.claims_off + 6; a.globals_len = (uint32_t)globals_len;
   g_w.cnt.assign(n + 1, 0); g_w.status.assign(n + 1, 0); g_w.wavesum.assign(2 * (size_t)nw + 2, 0); g_w.waveoff.assign(2 * (size_t)nw + 2, 0);
   a.cnt = g_w.cnt.data(); a.status = g_w.status.data(); a.wavesum = g_w.wavesum.data(); a.waveoff = g_w.waveoff.data();
   WireStats st; cbh_wire_stats_init(st);

@@ -36,9 +36,9 @@ class HostSimEvaluator(HipEvaluator):
                 return hostsim_api.trace(lt, batch, now_ns, flags, capacity)
 
             # the device road of check_pb (cbh_wire.h) on the simulator: the GPU's flattener, decision and assembler kernels
-            def wire_flatten(_self, data, offsets, default_policy_version="default", default_scope="", device_index=0):
+            def wire_flatten(_self, data, offsets, default_policy_version="default", default_scope="", device_index=0, globals_pb=b""):
                 import wire_device_util as wu
-                rc, wb = wu.sim_flatten(lt, data, offsets, default_policy_version, default_scope)
+                rc, wb = wu.sim_flatten(lt, data, offsets, default_policy_version, default_scope, globals_pb=globals_pb)
                 if rc == 1 or wb.stats["n_host"]:
                     raise capi.HostFlattenerNeeded("host flattener")
                 if wb.stats["first_bad"] != 0xFFFFFFFF:

@@ -38,11 +38,11 @@ def _arr(ptr, ctype, dtype, n):
     return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)).astype(dtype, copy=True)
 
 
-def sim_flatten(lt, data, offsets, default_version="default", default_scope="", dict_slots=0, heap=0):
+def sim_flatten(lt, data, offsets, default_version="default", default_scope="", dict_slots=0, heap=0, globals_pb=b""):
     """The device flattener on the host simulator.  Returns (rc, WireBatch): rc 1 = the table's inputs are the host's."""
     lib = hostsim_api.lib()
-    lib.hostsim_wire_flatten.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_uint32,
-                                         C.c_uint32, C.POINTER(HsWire)]
+    lib.hostsim_wire_flatten.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t,
+                                         C.c_uint32, C.c_uint32, C.POINTER(HsWire)]
     lib.hostsim_wire_flatten.restype = C.c_int
     data = np.ascontiguousarray(data, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -51,7 +51,7 @@ def sim_flatten(lt, data, offsets, default_version="default", default_scope="", 
     buf = C.create_string_buffer(lt.blob, len(lt.blob))
     pad = np.concatenate([data, np.zeros(8, np.uint8)])
     rc = lib.hostsim_wire_flatten(C.cast(buf, C.c_void_p), len(lt.blob), pad.ctypes.data, offsets.ctypes.data, n, default_version.encode(),
-                                  default_scope.encode(), dict_slots, heap, C.byref(out))
+                                  default_scope.encode(), globals_pb or None, len(globals_pb), dict_slots, heap, C.byref(out))
     if rc < 0:
         raise RuntimeError(lib.hostsim_last_error().decode())
     if rc == 1:
@@ -72,7 +72,7 @@ def sim_flatten(lt, data, offsets, default_version="default", default_scope="", 
     w.in_span = _arr(out.in_span, C.c_uint32, np.uint32, n * 12).reshape(n, 12)
     w.act_span = _arr(out.act_span, C.c_uint32, np.uint32, w.n_tuples * 2).reshape(w.n_tuples, 2)
     total = int(offsets[-1]) if n else 0
-    w.msg = _arr(out.msg, C.c_uint8, np.uint8, total + len(default_version.encode()) + len(default_scope.encode()) + 6 + 8).tobytes()
+    w.msg = _arr(out.msg, C.c_uint8, np.uint8, total + len(default_version.encode()) + len(default_scope.encode()) + 6 + len(globals_pb) + 8).tobytes()
     w.status = _arr(out.status, C.c_uint8, np.uint8, n)
     return 0, w
 

@@ -52,7 +52,7 @@ static const cbh_params PARAMS{1700000000000000000ll, CBH_F_WANT_DERIVED_ROLES, 
 static uint32_t device_road(cbh_table* gt, const cbi_table* it, const Slice& s, Scratch& x, cbi_outputs** out, double* phase) {
   const auto t0 = Clock::now();
   cbh_device_batch* db = nullptr; cbh_wire_info info;
-  if (cbh_wire_flatten(gt, 0, s.bytes, s.rel.data(), s.n, "default", "", &db, &info) != 0) { std::fprintf(stderr, "cbh_wire_flatten: %s\n", cbh_last_error()); return 0; }
+  if (cbh_wire_flatten(gt, 0, s.bytes, s.rel.data(), s.n, "default", "", nullptr, 0, &db, &info) != 0) { std::fprintf(stderr, "cbh_wire_flatten: %s\n", cbh_last_error()); return 0; }
   const auto t1 = Clock::now();
   cbh_result res{x.eff, x.pol, x.sc, x.st, x.edr};
   if (cbh_check_resident(gt, db, &PARAMS) != 0 || cbh_result_download(gt, db, &res) != 0 || cbh_wire_spans_download(gt, db, x.in_span, x.act_span, x.act_off) != 0) {
@@ -72,7 +72,7 @@ static uint32_t device_road(cbh_table* gt, const cbi_table* it, const Slice& s, 
 static uint32_t device_out_road(cbh_table* gt, const Slice& s, Scratch& x, double* phase) {
   const auto t0 = Clock::now();
   cbh_device_batch* db = nullptr; cbh_wire_info info;
-  if (cbh_wire_flatten(gt, 0, s.bytes, s.rel.data(), s.n, "default", "", &db, &info) != 0) { std::fprintf(stderr, "cbh_wire_flatten: %s\n", cbh_last_error()); return 0; }
+  if (cbh_wire_flatten(gt, 0, s.bytes, s.rel.data(), s.n, "default", "", nullptr, 0, &db, &info) != 0) { std::fprintf(stderr, "cbh_wire_flatten: %s\n", cbh_last_error()); return 0; }
   const auto t1 = Clock::now();
   if (cbh_check_resident(gt, db, &PARAMS) != 0) { std::fprintf(stderr, "cbh_check_resident: %s\n", cbh_last_error()); cbh_batch_release(db); return 0; }
   size_t need = 0;
