@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define CBH_BLOB_MAGIC 0x31484243u /* "CBH1" */
-#define CBH_BLOB_VERSION 20u
+#define CBH_BLOB_VERSION 21u
 
 struct CbhBlobHeader {  // 32 bytes
   uint32_t magic;
@@ -350,6 +350,8 @@ enum CbhOp {
   OP_STRVIEW = 69,    // arg 0 substring(a): pop a; 1 substring(a, b): pop b, a; 2 charAt(i): pop i; 3 trim().  TOS string -> the rope that
                       // is that window of it (code-point indices, cel-go ext/strings.go)
   OP_STRREPLACE = 70, // pop new, old; TOS string s -> the rope s.replace(old, new): the pieces of s between the occurrences, `new` between them
+  OP_EDREQ = 72,      // arg = constant index of a 64-bit mask | never << 31: push runtime.effectiveDerivedRoles == <the constant list whose names
+                      // the mask holds> (the runtime list is sorted and duplicate free: a constant list that is not can never equal it)
   OP_HIERCOMMON = 71, // pop c, b; TOS a (dot-delimited strings) -> hierarchy(a).commonAncestors(hierarchy(b)) == hierarchy(c)
   OP_NOPS
 };

@@ -510,6 +510,11 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
         else PUSHV(mk_bool((L.edr >> a) & 1));
         break;
       }
+      case OP_EDREQ: {   // runtime.effectiveDerivedRoles == [constant names]
+        if (L.edr_err) PUSHV((TRACE && (tfailed >> 56) == 0) ? mk(CBH_T_ERR, (u64)CBH_ERR_EDR_FAILED | (tfailed << 8)) : mk_err());
+        else PUSHV(mk_bool(!(a >> 31) && L.edr == c.t.const_val[a & 0x7FFFFFFFu]));
+        break;
+      }
       case OP_LOCAL: PUSHV(mk(c.l_tag[a * CBH_BLOCK + c.tid], c.l_val[a * CBH_BLOCK + c.tid])); break;
       // ---- comprehensions: wave-uniform loop, per-lane progress
       case OP_ITER_BEGIN: {   // a = slot; next word = kind

@@ -25,7 +25,7 @@ from .celc import COND_LEAF, COND_LEAFTREE, COND_PC_MASK, LoweringError, Params,
 from .globs import GlobNFA, fix_glob, has_meta
 
 BLOB_MAGIC = 0x31484243
-BLOB_VERSION = 20
+BLOB_VERSION = 21
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
 PAT_ANY = 0x7FFFFFFF     # the lone "*": matches every string, no automaton needed
@@ -393,9 +393,12 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
             dr_family.append(("R", ver, kind))
             dr_probe.append(pb.vars_probe_program(Params(dr["constants"], dr["ordered_variables"], globals_, null_on_error=True)))
             dparams = Params(dr["constants"], dr["ordered_variables"], globals_, null_on_error=True)
-            # a derived-role definition that reads runtime.effectiveDerivedRoles sees, in the reference, the
-            # roles of whichever scope/action was processed last (check.go:262,281): not reproducible per tuple
-            dr_cols[3].append(pb.condition_program(dr["condition"], dparams, allow_runtime=False)
+            # a derived-role definition that reads runtime.effectiveDerivedRoles sees, in the reference, the roles of the scope
+            # visited just before (check.go:237-282: evalCtx is replaced AFTER a scope's definitions were evaluated, a scope is
+            # evaluated once per request, and every walk visits the chain in order) - the deepest scope sees none.  That is
+            # what Lane.edr holds while the general walk evaluates a scope's definitions (cbh_check_wave.h), and tables whose
+            # programs read runtime.* stay on that kernel.
+            dr_cols[3].append(pb.condition_program(dr["condition"], dparams, allow_runtime=True)
                               if dr["condition"] is not None else NONE)
         entries.append((B_RESOURCE, sid(ver), sid(kind), lt.scope_index[scope],
                         begin, n_rows, dr_begin, len(dr_cols[0]) - dr_begin))
@@ -500,7 +503,7 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
         for dr in trace_dr_defs:
             dtp = Params(dr["constants"], dr["ordered_variables"], globals_, trace=True, null_on_error=True)
             voff, vcnt = var_slice(dtp)
-            trace_dr.append([pb.trace_condition_program(dr["condition"], dtp, allow_runtime=False) if dr["condition"] is not None else NONE,
+            trace_dr.append([pb.trace_condition_program(dr["condition"], dtp, allow_runtime=True) if dr["condition"] is not None else NONE,
                              voff, vcnt, 0])
         for r in trace_rp_rules:
             tp = tparams(r["params"])

@@ -30,7 +30,7 @@ from . import regex
  OP_TODOUBLE, OP_TOSTRING_UNSUPPORTED, OP_INIPRANGE, OP_UNSUPPORTED, OP_TS_GETTER,
  OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN, OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC,
  OP_TREE_END, OP_HIER, OP_MATCHES, OP_INDEXOF, OP_STREQ_CASE, OP_VARSCOPE, OP_OUT, OP_LISTOP, OP_LISTFN, OP_STRCAT,
- OP_STRCASE, OP_IPFN, OP_STRVIEW, OP_STRREPLACE, OP_HIERCOMMON) = range(72)
+ OP_STRCASE, OP_IPFN, OP_STRVIEW, OP_STRREPLACE, OP_HIERCOMMON, OP_EDREQ) = range(73)
 
 TREE_KINDS = {"all": 0, "any": 1, "none": 2}
 COND_LEAF = 0x80000000
@@ -85,7 +85,7 @@ _R_FIELDS = {"id": RQ_S_RESOURCE_ID, "kind": RQ_S_KIND, "scope": RQ_S_R_SCOPE,
 _ID_ONLY_OPS = frozenset([OP_RET, OP_CONST, OP_COL, OP_HASCOL, OP_REQSTR, OP_ROLES, OP_SELECT, OP_HASSEL, OP_INDEX, OP_EQ, OP_NE,
                           OP_IN, OP_NOT, OP_JF, OP_JT, OP_AND, OP_OR, OP_JTERN, OP_JMP, OP_POP, OP_LEAF, OP_EDRHAS, OP_LOCAL,
                           OP_ITER_BEGIN, OP_ITER_NEXT, OP_ITER_ACC, OP_ITER_END, OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN,
-                          OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC, OP_TREE_END, OP_UNSUPPORTED, OP_TS_GETTER, OP_VARSCOPE, OP_OUT, OP_LISTOP, OP_LISTFN])
+                          OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC, OP_TREE_END, OP_UNSUPPORTED, OP_TS_GETTER, OP_VARSCOPE, OP_OUT, OP_LISTOP, OP_LISTFN, OP_EDREQ])
 
 
 class LoweringError(ValueError):
@@ -1045,6 +1045,20 @@ class _FuncCompiler:
                         pb.uses_runtime = True
                         return self.emit(OP_EDRHAS, pb.dr_bit(ast[2][2]), +1)
                     return self.unsupported("runtime.effectiveDerivedRoles membership with a non-constant name")
+            if op in ("==", "!=") and self.allow_runtime:
+                # runtime.effectiveDerivedRoles == [constant names] (either order): the runtime list is the SORTED names of the
+                # scope's effective derived roles (check.go:601-607), so the comparison is one mask compare
+                for lhs, rhs in ((ast[2], ast[3]), (ast[3], ast[2])):
+                    p = self._path(lhs) if lhs[0] in ("select", "index") else None
+                    if p is not None and p[0] == "edr" and rhs[0] == "list" and all(e[0] == "lit" and e[1] == "string" for e in rhs[1]):
+                        names = [e[2] for e in rhs[1]]
+                        never = any(a >= b for a, b in zip(names, names[1:]))   # not strictly ascending: never equal
+                        mask = 0
+                        for nm in names:
+                            mask |= 1 << pb.dr_bit(nm)
+                        pb.uses_runtime = True
+                        self.emit(OP_EDREQ, pb.const(T_UINT, mask) | (0x80000000 if never else 0), +1)
+                        return self.emit(OP_NOT) if op == "!=" else None
             if op in ("==", "!="):
                 # `a.lowerAscii() == b`, `a == b.upperAscii()` ...: the device builds no strings, it compares the bytes
                 # through the case mapping (cel-go ext/strings.go lowerAscii / upperAscii: ASCII letters only)

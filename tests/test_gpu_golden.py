@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 CASES = load_json("engine_cases.json")
 GLOBALS = {"environment": "test"}
-EXPECT_UNSUPPORTED = {"engine/case_21"}  # see tests/test_hostsim_golden.py
+EXPECT_UNSUPPORTED = set()  # see tests/test_hostsim_golden.py
 
 
 @pytest.fixture(scope="module")

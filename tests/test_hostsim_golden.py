@@ -15,9 +15,7 @@ GLOBALS = {"environment": "test"}
 
 # Golden cases whose decision path needs CEL outside the device subset: the kernel must
 # flag them (status UNSUPPORTED), never return a wrong effect silently.
-EXPECT_UNSUPPORTED = {
-    "engine/case_21",  # derived-role definitions compare runtime.effectiveDerivedRoles == [] (list value)
-}
+EXPECT_UNSUPPORTED = set()   # (round 3: engine/case_21 - derived-role definitions comparing runtime.effectiveDerivedRoles == [] - decides on the device)
 
 
 class HostSimEvaluator(HipEvaluator):

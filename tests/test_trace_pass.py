@@ -31,8 +31,15 @@ CASES = load_json("engine_cases.json")
 GLOBALS = {"environment": "test"}
 
 
+# Inputs whose errors / outputs the trace pass reports INCOMPLETE (loud, never guessed): case_21's policy variables and output
+# expressions are `runtime.effectiveDerivedRoles` AS A VALUE (a list of names); the device decides the case (round 3) but only
+# membership / equality tests of that list are in its subset.
+EXPECT_INCOMPLETE = {"engine/case_21"}
+
+
 def _engine_cases(ev):
     named = verified_outputs = total = 0
+    seen_incomplete = set()
     for case in CASES:
         for lenient in hg._modes(case):
             outs, bad, incomplete = ev.check(case["inputs"], now_ns=NOW, lenient_scope_search=lenient, allow_unsupported=True,
@@ -40,8 +47,13 @@ def _engine_cases(ev):
             for i, (have, want) in enumerate(zip(outs, case["wantOutputs"])):
                 if i in bad:
                     continue
-                total += 1
                 what = incomplete.get(i, ())
+                if what:
+                    seen_incomplete.add(case["name"])
+                    assert case["name"] in EXPECT_INCOMPLETE, (case["name"], what)
+                    assert norm_actions(have) == norm_actions(want)   # the decision stands
+                    continue
+                total += 1
                 if "errors" not in what:
                     assert have["evaluationErrors"] == (want.get("evaluationErrors") or []), (case["name"], lenient, i)
                     named += 1
@@ -51,6 +63,7 @@ def _engine_cases(ev):
                     by_src = lambda o: o["src"]   # noqa: E731
                     assert sorted(have["outputs"], key=by_src) == sorted(want.get("outputs") or [], key=by_src), (case["name"], lenient, i)
                     verified_outputs += bool(want.get("outputs"))
+    assert seen_incomplete == EXPECT_INCOMPLETE
     return total, named, verified_outputs
 
 
