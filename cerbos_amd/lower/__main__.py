@@ -4,7 +4,7 @@ A Go host holds its compiled policies as ``runtimev1.RuleTable`` (``internal/rul
 rebuilds it on every storage event, ``manager.go:86-124``).  It marshals that message (``proto.Marshal``), hands the bytes
 to this command and loads what comes back with ``cbh_table_load`` / ``cbi_table_open``:
 
-    python -m cerbos_amd.lower ruletable.pb image.cbh [--globals '{"environment": "prod"}'] [--no-trace] [--stats]
+    python -m cerbos_amd.lower ruletable.pb image.cbh [--globals '{"environment": "prod"}' | --per-call-globals] [--no-trace] [--stats]
     some-producer | python -m cerbos_amd.lower - - > image.cbh         # stdin -> stdout
     python -m cerbos_amd.lower --policies ./policies image.cbh         # from a policy directory (YAML), for tools and tests
 
@@ -26,6 +26,9 @@ def main(argv=None) -> int:
     ap.add_argument("image", help="where to write the image ('-' = stdout)")
     ap.add_argument("--policies", action="store_true", help="SOURCE is a policy directory, compiled with the bundled front-end")
     ap.add_argument("--globals", default=None, help="JSON object: the engine's configured globals (evaluator/conf.go:40), constants of the image")
+    ap.add_argument("--per-call-globals", action="store_true",
+                    help="do not fold globals into the image: `G.x` is read from the globals every call brings (cbh_wire_flatten / cbi_flatten_pb_g "
+                         "globals_pb: evaluator.EvalParams.Globals) - one image for any globals")
     ap.add_argument("--no-trace", action="store_true", help="leave the trace pass's sections out (decisions only: no evaluation_errors / outputs)")
     ap.add_argument("--stats", action="store_true", help="print the lowering's statistics as one JSON line on stderr")
     args = ap.parse_args(argv)
@@ -45,7 +48,7 @@ def main(argv=None) -> int:
             from ..ruletable.proto import decode_rule_table
             wire = sys.stdin.buffer.read() if args.source == "-" else open(args.source, "rb").read()
             rt = decode_rule_table(wire)
-        lt = lower_rule_table(rt, globals_, trace=not args.no_trace)
+        lt = lower_rule_table(rt, globals_, trace=not args.no_trace, per_call_globals=args.per_call_globals)
     except LoweringError as e:
         print("cannot lower this rule table: %s" % e, file=sys.stderr)
         return 2

@@ -219,3 +219,34 @@ def test_invalid_batches_are_refused_not_dereferenced():
         assert call(bad, lambda cb, b: None) == (-1, -1), field
     assert b"outside the batch" in lib.cbh_last_error() or b"CBH_MAX_ACTIONS" in lib.cbh_last_error()
     table.close()
+
+
+def _visible_gpus():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+@pytest.mark.skipif(_visible_gpus() < 2, reason="needs two distinct GPUs: the in-library ncclBroadcast runs one rank per device")
+def test_image_broadcast_over_rccl_and_the_wire_road_on_the_second_device():
+    """With >= 2 distinct devices the table image reaches the others by ONE RCCL broadcast from C++ (cbh_engine.hip
+    broadcast_image: ncclCommInitAll + ncclBroadcast over xGMI), and a replica that got its image that way decides - and
+    flattens serialized CheckInputs - exactly as the first."""
+    from cerbos_amd import wire
+    capi.init([0, 1])
+    try:
+        lt = _lowered(workloads.c3_policies)
+        table = capi.Table(lt.blob)
+        assert table.broadcast_kind() == "rccl"
+        inputs = workloads.c3_requests(20_000).to_inputs()
+        data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+        res = []
+        for dev in (0, 1):
+            db = table.wire_flatten(data, off, device_index=dev)
+            table.launch(db, now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES)
+            res.append((table.download(db), table.wire_outputs(db)))
+            db.close()
+        _same(res[0][0], res[1][0], "wire road on device 1")
+        assert res[0][1][0] == res[1][1][0]
+        table.close()
+    finally:
+        capi.init(0)
