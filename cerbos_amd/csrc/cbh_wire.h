@@ -34,6 +34,7 @@
 #define CBH_WIRE_MAX_STRLEN 0xFFFFu
 #define CBH_WIRE_MAX_VALUE_ENTRIES 0xFFFFFu   /* heap entries of one attribute value */
 #define CBH_WIRE_MAX_PROBES 256u
+#define CBH_WIRE_CUR_COLS 16u      /* columns whose first key is found by the one pass per attribute map (LDS: 8 B per column and lane) */
 
 #define CBH_WS_OK 0u
 #define CBH_WS_BAD 1u    /* malformed message */
@@ -574,6 +575,36 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
     W_RQ(CBH_RQ_ACT_OFF) = act_off; W_RQ(CBH_RQ_ROLE_OFF) = role_off;
     for (u32 k = 0; k < 2u * CBH_WSPAN_N; ++k) a.in_span[(size_t)i * 2u * CBH_WSPAN_N + k] = 0u;
   }
+  // The first keys of the columns, found in ONE pass per root over its attribute map (Principal.attr, Resource.attr, AuxData.jwt,
+  // the call's globals) instead of one pass per column: where column c's first key has its value in this lane's message
+  // (last entry wins), or CBH_NONE.  The first CBH_WIRE_CUR_COLS columns; the rest (and auxData.jwts paths) walk on their own.
+  __shared__ u32 w_cur_p[CBH_WIRE_CUR_COLS][CBH_BLOCK], w_cur_e[CBH_WIRE_CUR_COLS][CBH_BLOCK];
+  const u32 ncc = a.n_cols < CBH_WIRE_CUR_COLS ? a.n_cols : CBH_WIRE_CUR_COLS;
+  for (u32 c = 0; c < ncc; ++c) w_cur_p[c][threadIdx.x] = CBH_NONE;
+  if (live) {
+    for (u32 root = 0; root < 5u; ++root) {
+      if (root == 3u) continue;
+      bool any = false;
+      for (u32 c = 0; c < ncc; ++c) any = any || (a.cols[c].root == root && a.cols[c].nk != 0u);   // (uniform)
+      if (!any) continue;
+      WSpan s2; s2.p = a.globals_off; s2.e = a.globals_off + a.globals_len;
+      if (root == 0u) s2 = principal; else if (root == 1u) s2 = resource; else if (root == 2u) s2 = aux;
+      const u32 want = (root == 2u || root == 4u) ? 1u : 4u;
+      WField f;
+      while (w_next(m, s2, f, L.bad)) {
+        if (f.num != want || f.wt != 2u) continue;
+        WSpan k, v;
+        if (!w_entry(m, f.s, k, v, L.bad)) break;
+        const u32 kl = k.e - k.p;
+        for (u32 c = 0; c < ncc; ++c) {
+          const CBH_G WireCol& col = a.cols[c];
+          if (col.root == root && col.nk != 0u && col.key_len[0] == kl && w_bytes_eq(m + k.p, a.col_keys + col.key_off[0], kl)) {
+            w_cur_p[c][threadIdx.x] = v.p; w_cur_e[c][threadIdx.x] = v.e;
+          }
+        }
+      }
+    }
+  }
   // attribute columns: one per attribute path the table's programs read (wave-uniform loop: the heap is allocated per wave)
   bool sens_container = false;
   for (u32 c = 0; c < a.n_cols; ++c) {
@@ -601,6 +632,10 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
         else k0 = 3u;
       }
       else if (col.nk == 0u) { is_container = true; is_map = true; body = root; fnum = root_fnum; done = true; }
+      else if (c < ncc) {   // found (or not) by the pass above
+        cur.p = w_cur_p[c][threadIdx.x]; cur.e = w_cur_e[c][threadIdx.x];
+        if (cur.p == CBH_NONE) { cur.p = cur.e = 0; tag = col.nk == 1u ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
+      }
       else if (!w_map_get(m, root, root_fnum, a.col_keys + col.key_off[0], col.key_len[0], cur, L.bad)) { tag = col.nk == 1u ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
       for (u32 k = k0; k < col.nk && !done; ++k) {
         WVal v;
