@@ -733,10 +733,21 @@ extern "C" int cbh_result_download(cbh_table* t, cbh_device_batch* b, cbh_result
 }
 
 
+#ifndef CBH_WIRE_LDS_DEFAULT
+#define CBH_WIRE_LDS_DEFAULT 0
+#endif
 // ---- device-side ingest: serialized CheckInputs -> a resident batch, flattened by the GPU (cbh_wire.h) ------------------
 // H2D of the raw bytes + offsets, count + scan launches, one small D2H (totals, shape), the fill launch, one small D2H
 // (what it needed, what it could not take).  The batch is then an ordinary resident batch: cbh_check_resident,
 // cbh_result_download - results in INPUT order (no routing sort on this path: nothing to undo).
+// bytes of dynamic LDS for a wave that wants `want` bytes: a power of two between 4 and 48 KB, 0 = the kernel works in place.
+// CBH_WIRE_LDS (measurement aid): 0 nothing staged, 1 the assembler's outputs only, 2 the flattener's messages too.
+static int wire_lds_mode() { static const int m = [] { const char* e = getenv("CBH_WIRE_LDS"); return e ? atoi(e) : CBH_WIRE_LDS_DEFAULT; }(); return m; }
+static u32 wire_lds_cap(size_t want, int needs_mode) {
+  if (wire_lds_mode() < needs_mode) return 0;
+  u32 c = 4096; while (c < want && c < 49152u) c <<= 1;
+  return c > 49152u ? 49152u : c;
+}
 static int wire_stats_read(cbh_device_batch* b, const WireStats* d_stats, WireStats& st) {
   HIPCHK(hipMemcpyAsync(&st, d_stats, sizeof(st), hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
@@ -824,7 +835,9 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
       rc |= dalloc(b, a.heap_tag, (size_t)heap_cap); rc |= dalloc(b, a.heap_val, (size_t)heap_cap);
       if (rc != 0) return bail(-1);
       a.heap_cap = heap_cap;
-      if (nw) hipLaunchKernelGGL(cbh_wire_fill_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, a);
+      // dynamic LDS: room for a wave's 64 messages (a quarter above the call's average; a wave whose block is larger parses in place)
+      a.lds_cap = wire_lds_cap(n ? (size_t)(total / n) * 80u + 256u : 0u, 2);
+      if (nw) hipLaunchKernelGGL(cbh_wire_fill_kernel, dim3(nw), dim3(CBH_BLOCK), a.lds_cap, s, a);
       ++runs;
       if (wire_stats_read(b, d_stats, st) != 0) return bail(-1);
       if (st.flags & CBH_WF_DICT_FULL) { again = true; break; }
@@ -928,7 +941,8 @@ extern "C" int cbh_wire_outputs(cbh_table* t, cbh_device_batch* b, uint8_t* byte
   u8* d_out = nullptr;
   if (dalloc(b, d_out, (size_t)st.total + 1) != 0) return -1;
   a.out = d_out;
-  if (nw) hipLaunchKernelGGL(cbh_wire_out_write_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, a);
+  a.lds_cap = wire_lds_cap(n ? (size_t)(st.total / n) * 80u + 256u : 0u, 1);
+  if (nw) hipLaunchKernelGGL(cbh_wire_out_write_kernel, dim3(nw), dim3(CBH_BLOCK), a.lds_cap, s, a);
   if (st.total) HIPCHK(hipMemcpyAsync(bytes, d_out, (size_t)st.total, hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(offsets, b->w_out_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, s));
   if (flags && n) HIPCHK(hipMemcpyAsync(flags, b->w_out_flags, (size_t)n, hipMemcpyDeviceToHost, s));

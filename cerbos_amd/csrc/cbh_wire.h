@@ -67,6 +67,7 @@ struct WireArgs {
   const CBH_G WireCol* cols; const CBH_G u8* col_keys; u32 n_cols; u32 sens_cols;
   // the messages: message i = msg[moff[i] .. moff[i + 1]); the call's default version / scope and "claims" follow the last one
   const CBH_G u8* msg; const CBH_G u64* moff; u32 n; u32 heap_cap;
+  u32 lds_cap, pad2;   // bytes of dynamic LDS a wave of the fill kernel may stage its messages in (0: parse in place)
   u32 dver_off, dver_len, dscope_off, dscope_len, claims_off, pad1;
   u32 globals_off, globals_len;   // the call's globals, a serialized google.protobuf.Struct behind the messages (columns of root 4)   // ("claims": the key of the request view of a named JWT)
   // scratch
@@ -114,12 +115,18 @@ __device__ __forceinline__ void w_max32(CBH_G u32* p, u32 v) { atomicMax((unsign
 __device__ __forceinline__ void w_min32(CBH_G u32* p, u32 v) { atomicMin((unsigned int*)p, v); }
 #endif
 
+// The bytes a lane parses are reached through a GENERIC pointer: the fill kernel stages its wave's messages in LDS (one
+// coalesced copy) when they fit and parses there - the walk is a chain of dependent one-byte loads, and an LDS round trip is
+// several times shorter than one to L2 - else it reads global memory through the same code.  `m[off]`: off = byte offset in
+// WireArgs.msg either way (the LDS view is biased by the block's start).
+typedef const u8* WMsg;
+
 // ---- protobuf wire walking (the grammar of cbh_ingest.cpp next / entry / value / map_get) -------------------------
 struct WSpan { u32 p, e; };   // byte offsets into WireArgs.msg
 struct WField { u32 num, wt; u64 v; WSpan s; };
 struct WVal { u32 kind; u64 v; WSpan s; };
 
-__device__ __forceinline__ bool w_varint(const CBH_G u8* m, WSpan& s, u64& out) {
+__device__ __forceinline__ bool w_varint(WMsg m, WSpan& s, u64& out) {
   u64 r = 0;
   for (u32 sh = 0; sh < 64 && s.p < s.e; sh += 7) {
     const u32 b = m[s.p++];
@@ -130,7 +137,7 @@ __device__ __forceinline__ bool w_varint(const CBH_G u8* m, WSpan& s, u64& out) 
 }
 
 // Next field of a message; false at the end or on malformed input (`bad` set).
-__device__ __forceinline__ bool w_next(const CBH_G u8* m, WSpan& s, WField& f, bool& bad) {
+__device__ __forceinline__ bool w_next(WMsg m, WSpan& s, WField& f, bool& bad) {
   if (s.p >= s.e) return false;
   u64 key;
   if (!w_varint(m, s, key)) { bad = true; return false; }
@@ -158,7 +165,7 @@ __device__ __forceinline__ bool w_next(const CBH_G u8* m, WSpan& s, WField& f, b
 }
 
 // map<string, google.protobuf.Value> entry: key = 1, value = 2 (last of each wins)
-__device__ __forceinline__ bool w_entry(const CBH_G u8* m, WSpan e, WSpan& key, WSpan& val, bool& bad) {
+__device__ __forceinline__ bool w_entry(WMsg m, WSpan e, WSpan& key, WSpan& val, bool& bad) {
   key.p = key.e = 0; val.p = val.e = 0;
   WField f;
   while (w_next(m, e, f, bad)) {
@@ -170,7 +177,7 @@ __device__ __forceinline__ bool w_entry(const CBH_G u8* m, WSpan e, WSpan& key, 
 
 // google.protobuf.Value oneof: null 1, number 2 (double), string 3, bool 4, struct 5, list 6; a field counts only with the
 // wire type its declaration has; the last one present wins; an empty message is null.
-__device__ __forceinline__ bool w_value(const CBH_G u8* m, WSpan s, WVal& out, bool& bad) {
+__device__ __forceinline__ bool w_value(WMsg m, WSpan s, WVal& out, bool& bad) {
   out.kind = 1u; out.v = 0; out.s.p = out.s.e = 0;
   WField f;
   while (w_next(m, s, f, bad)) {
@@ -185,13 +192,14 @@ __device__ __forceinline__ bool w_value(const CBH_G u8* m, WSpan s, WVal& out, b
   return !bad;
 }
 
-__device__ __forceinline__ bool w_bytes_eq(const CBH_G u8* a, const CBH_G u8* b, u32 n) {
+template <class PA, class PB>
+__device__ __forceinline__ bool w_bytes_eq(PA a, PB b, u32 n) {
   for (u32 i = 0; i < n; ++i) if (a[i] != b[i]) return false;
   return true;
 }
 
 // Looks `key` up in the map field `fnum` of `msg` (last entry wins, as protobuf maps decode).
-__device__ __forceinline__ bool w_map_get(const CBH_G u8* m, WSpan msg, u32 fnum, const CBH_G u8* key, u32 klen, WSpan& val, bool& bad) {
+__device__ __forceinline__ bool w_map_get(WMsg m, WSpan msg, u32 fnum, const CBH_G u8* key, u32 klen, WSpan& val, bool& bad) {
   WField f; bool found = false;
   while (w_next(m, msg, f, bad)) {
     if (f.num != fnum || f.wt != 2u) continue;
@@ -204,7 +212,7 @@ __device__ __forceinline__ bool w_map_get(const CBH_G u8* m, WSpan msg, u32 fnum
 
 // ---- interning -------------------------------------------------------------------------------------------------
 // id of a table string, CBH_NONE if the table does not hold it
-__device__ __forceinline__ u32 w_table_sid(const WireArgs& a, const CBH_G u8* s, u32 len, u32 h) {
+__device__ __forceinline__ u32 w_table_sid(const WireArgs& a, WMsg s, u32 len, u32 h) {
   for (u32 i = h & a.tix_mask, n = 0; n <= a.tix_mask; i = (i + 1u) & a.tix_mask, ++n) {
     const u64 e = a.tix[i];
     if (!e) return CBH_NONE;
@@ -219,13 +227,15 @@ __device__ __forceinline__ u32 w_table_sid(const WireArgs& a, const CBH_G u8* s,
 struct WLane { bool bad, host, dict_full; };
 
 // string id of msg[off .. off + len): the table's id, or K + its slot in the batch-local dictionary (claimed if absent)
-__device__ __attribute__((noinline)) u32 w_intern(const WireArgs& a, u32 off, u32 len, u32 flag, WLane& L) {
-  const CBH_G u8* s = a.msg + off;
+// `m[off]`: the string; `bias`: what to add to `off` for its offset in WireArgs.msg (the staged view of the fill kernel starts at
+// the wave's block, not at the buffer)
+__device__ __attribute__((noinline)) u32 w_intern(const WireArgs& a, WMsg m, u32 bias, u32 off, u32 len, u32 flag, WLane& L) {
+  WMsg s = m + off;
   const u32 h = cbh_wire_hash(s, len);
   const u32 id = w_table_sid(a, s, len, h);
   if (id != CBH_NONE) return id;
   if (len > CBH_WIRE_MAX_STRLEN) { L.host = true; return a.K; }
-  const u64 key = ((u64)((h >> 16) | 0x8000u) << 48) | ((u64)len << 32) | (u64)off;
+  const u64 key = ((u64)((h >> 16) | 0x8000u) << 48) | ((u64)len << 32) | (u64)(off + bias);
   u32 i = h & a.lix_mask;
   for (u32 n = 0; n < CBH_WIRE_MAX_PROBES; ++n, i = (i + 1u) & a.lix_mask) {
     u64 cur = w_load64(a.lix + i);
@@ -244,8 +254,8 @@ __device__ __attribute__((noinline)) u32 w_intern(const WireArgs& a, u32 off, u3
 
 // scope word of a scope string (cbh_ingest.cpp scope_word, namer.go:77-87): the scope itself if the table knows it (bit 31
 // set), else its nearest ancestor "a.b.c" -> "a.b", "a", "" the table knows, else 0
-__device__ __attribute__((noinline)) u32 w_scope_word(const WireArgs& a, u32 off, u32 len) {
-  const CBH_G u8* s = a.msg + off;
+__device__ __attribute__((noinline)) u32 w_scope_word(const WireArgs& a, WMsg m, u32 off, u32 len) {
+  WMsg s = m + off;
   u32 id = w_table_sid(a, s, len, cbh_wire_hash(s, len));
   if (id != CBH_NONE && a.scope_of_sid[id] != CBH_NONE) return a.scope_of_sid[id] | CBH_SCOPE_EXACT;
   for (u32 i = len; i-- > 0u;) {
@@ -260,7 +270,8 @@ __device__ __attribute__((noinline)) u32 w_scope_word(const WireArgs& a, u32 off
 // namer.go:213-218 (cbh_ingest.cpp sanitize): does this resource kind have to be rewritten?  A name of the pre-0.30 form
 // (segments "[A-Za-z][0-9A-Za-z_@.\-/]*" joined by ':') has every run of characters outside [0-9A-Za-z_.] replaced by one '_'.
 __device__ __forceinline__ bool w_kind_ok_char(u32 c) { return (c - '0' < 10u) || ((c | 0x20u) - 'a' < 26u) || c == '_' || c == '.'; }
-__device__ __forceinline__ bool w_kind_needs_rewrite(const CBH_G u8* s, u32 len) {
+template <class P>
+__device__ __forceinline__ bool w_kind_needs_rewrite(P s, u32 len) {
   bool plain = true;
   for (u32 i = 0; i < len && plain; ++i) plain = w_kind_ok_char(s[i]);
   if (plain || len == 0u) return false;
@@ -276,7 +287,7 @@ __device__ __forceinline__ bool w_kind_needs_rewrite(const CBH_G u8* s, u32 len)
 }
 // The rewritten kind exists nowhere in the message, so only the table can name it: its id if the table holds the rewritten
 // string (a kind some policy is written for), else CBH_NONE - that message is the host flattener's.
-__device__ __attribute__((noinline)) u32 w_rewritten_kind_sid(const WireArgs& a, const CBH_G u8* s, u32 len) {
+__device__ __attribute__((noinline)) u32 w_rewritten_kind_sid(const WireArgs& a, WMsg s, u32 len) {
   u32 n = 0; bool in_run = false;
   for (u32 i = 0; i < len; ++i) { const bool ok = w_kind_ok_char(s[i]); n += (ok || !in_run); in_run = !ok; }
   u32 h = 0x811C9DC5u ^ n; in_run = false;   // cbh_wire_hash over the rewritten bytes
@@ -325,7 +336,7 @@ __device__ __forceinline__ u32 w_wave_max(u32 x, u32 bits) {   // largest x of t
 }
 
 // ---- kernel 1: counts ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ void w_top_level(const CBH_G u8* m, WSpan s, WSpan& resource, WSpan& principal, WSpan& aux, WSpan& request_id,
+__device__ __forceinline__ void w_top_level(WMsg m, WSpan s, WSpan& resource, WSpan& principal, WSpan& aux, WSpan& request_id,
                                             u32& n_actions, bool& bad) {
   resource.p = resource.e = principal.p = principal.e = aux.p = aux.e = request_id.p = request_id.e = 0; n_actions = 0;
   WField f;
@@ -348,13 +359,14 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_count_kernel(WireArgs a)
   u32 na = 0, nr = 0, st = CBH_WS_OK;
   if (live) {
     const u64 o0 = a.moff[i], o1 = a.moff[i + 1u];
-    bool bad = o1 < o0;
+    bool bad = o1 < o0 || o1 > (u64)a.dver_off;   // (dver_off = the end of the messages: nothing may point past it)
     if (!bad) {
+      WMsg m = (WMsg)a.msg;
       WSpan s; s.p = (u32)o0; s.e = (u32)o1;
       WSpan resource, principal, aux, rid;
-      w_top_level(a.msg, s, resource, principal, aux, rid, na, bad);
+      w_top_level(m, s, resource, principal, aux, rid, na, bad);
       WField f; WSpan p = principal;
-      while (w_next(a.msg, p, f, bad)) nr += (f.num == 3u && f.wt == 2u);
+      while (w_next(m, p, f, bad)) nr += (f.num == 3u && f.wt == 2u);
     }
     if (bad) st = CBH_WS_BAD;
     else if (na > CBH_MAX_ACTIONS_PER_REQUEST || nr > CBH_WIRE_MAX_ROLES) st = CBH_WS_HOST;
@@ -405,10 +417,11 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_scan_kernel(WireArgs a)
   if (lane == 0u) {
     a.stats->n_tuples = ta; a.stats->n_roles = tr;
     WLane L; L.bad = false; L.host = false; L.dict_full = false;
-    a.stats->sid_empty = w_intern(a, a.dver_off, 0u, 0u, L);
-    a.stats->sid_dver = w_intern(a, a.dver_off, a.dver_len, 0u, L);
-    a.stats->dscope_word = w_scope_word(a, a.dscope_off, a.dscope_len);
-    a.stats->sid_claims = w_intern(a, a.claims_off, 6u, 0u, L);
+    WMsg m = (WMsg)a.msg; const u32 bias = 0u;
+    a.stats->sid_empty = w_intern(a, m, bias, a.dver_off, 0u, 0u, L);
+    a.stats->sid_dver = w_intern(a, m, bias, a.dver_off, a.dver_len, 0u, L);
+    a.stats->dscope_word = w_scope_word(a, m, a.dscope_off, a.dscope_len);
+    a.stats->sid_claims = w_intern(a, m, bias, a.claims_off, 6u, 0u, L);
     if (L.dict_full) w_or32(&a.stats->flags, CBH_WF_DICT_FULL);
   }
 }
@@ -416,7 +429,7 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_scan_kernel(WireArgs a)
 // ---- kernel 3: the batch ---------------------------------------------------------------------------------------------
 struct WFrame { WSpan rest; u32 slot; u32 is_map; };
 
-__device__ __forceinline__ u32 w_count_fields(const CBH_G u8* m, WSpan s, u32 fnum, bool& bad) {
+__device__ __forceinline__ u32 w_count_fields(WMsg m, WSpan s, u32 fnum, bool& bad) {
   u32 n = 0; WField f;
   while (w_next(m, s, f, bad)) n += (f.num == fnum && f.wt == 2u);
   return n;
@@ -427,8 +440,7 @@ __device__ __forceinline__ u64 w_container(u32 off, u32 n) { return ((u64)CBH_HE
 // nested in it, depth first.  WRITE = false: returns the heap entries it needs.  WRITE = true: writes them at [base, ..)
 // (the container's own entries first, each nested container's behind what was allocated before it) and returns the same.
 template <bool WRITE>
-__device__ __attribute__((noinline)) u32 w_container_walk(const WireArgs& a, WSpan body, u32 fnum, bool is_map, u32 base, WLane& L) {
-  const CBH_G u8* m = a.msg;
+__device__ __attribute__((noinline)) u32 w_container_walk(const WireArgs& a, WMsg m, u32 bias, WSpan body, u32 fnum, bool is_map, u32 base, WLane& L) {
   WFrame st[CBH_WIRE_MAX_DEPTH];
   u32 depth = 0;
   const u32 n0 = w_count_fields(m, body, fnum, L.bad);
@@ -444,7 +456,7 @@ __device__ __attribute__((noinline)) u32 w_container_walk(const WireArgs& a, WSp
     if (mp) {
       WSpan k, v;
       if (!w_entry(m, f.s, k, v, L.bad)) break;
-      const u32 kid = WRITE ? w_intern(a, k.p, k.e - k.p, 0u, L) : 0u;   // (the counting pass leaves the dictionary alone)
+      const u32 kid = WRITE ? w_intern(a, m, bias, k.p, k.e - k.p, 0u, L) : 0u;   // (the counting pass leaves the dictionary alone)
       if (WRITE && fr.slot < a.heap_cap) { a.heap_tag[fr.slot] = (u8)CBH_T_STRING; a.heap_val[fr.slot] = kid; }
       ++fr.slot;
       elem = v;
@@ -453,7 +465,7 @@ __device__ __attribute__((noinline)) u32 w_container_walk(const WireArgs& a, WSp
     u32 tag = CBH_T_NULL; u64 val = 0;
     if (w_value(m, elem, v, L.bad)) {
       if (v.kind == 2u) { tag = CBH_T_DOUBLE; val = v.v; }
-      else if (v.kind == 3u) { tag = CBH_T_STRING; val = WRITE ? w_intern(a, v.s.p, v.s.e - v.s.p, 0u, L) : 0u; }
+      else if (v.kind == 3u) { tag = CBH_T_STRING; val = WRITE ? w_intern(a, m, bias, v.s.p, v.s.e - v.s.p, 0u, L) : 0u; }
       else if (v.kind == 4u) { tag = CBH_T_BOOL; val = v.v ? 1u : 0u; }
       else if (v.kind >= 5u) {
         const bool cm = v.kind == 5u;
@@ -485,12 +497,36 @@ static void cbh_wire_fill_kernel(WireArgs a)
 __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
 #endif
 {
-  const CBH_G u8* m = a.msg;
   const u32 lane = threadIdx.x & 63u;
   const u32 i = blockIdx.x * CBH_BLOCK + threadIdx.x;
   const u32 N = a.n;
   const bool in_range = i < N;
-  const bool live = in_range && a.status[i] == CBH_WS_OK;
+  bool live = in_range && a.status[i] == CBH_WS_OK;
+  // The wave's messages lie back to back: one coalesced copy into LDS when they fit (16-byte chunks from the 16-byte
+  // boundary below the first message), and every lane parses there.  A block that does not fit is parsed in place.
+  const WMsg mg = (WMsg)a.msg;
+  WMsg m = mg;
+  u32 bias = 0u;   // offset in WireArgs.msg of m[0]
+  {
+    const u32 w0 = blockIdx.x * CBH_BLOCK, w1 = (w0 + CBH_BLOCK < N) ? w0 + CBH_BLOCK : N;
+    const u64 lo64 = a.moff[w0 < N ? w0 : N], hi64 = a.moff[w1];
+    const u32 lo16 = (u32)lo64 & ~15u;
+    const bool staged = hi64 >= lo64 && hi64 <= (u64)a.dver_off && (u32)hi64 - lo16 <= a.lds_cap && hi64 > lo64;   // (uniform)
+    if (staged) {
+      const u32 need = (u32)hi64 - lo16;
+#ifndef CBH_HOSTSIM
+      typedef u32 v4 __attribute__((ext_vector_type(4)));
+      for (u32 o = lane * 16u; o < need; o += 64u * 16u) *(CBH_L v4*)((CBH_L u8*)cbh_dyn_lds + o) = *(const CBH_G v4*)(a.msg + lo16 + o);
+#else
+      for (u32 o = lane * 16u; o < need; o += 64u * 16u) for (u32 k = 0; k < 16u; ++k) cbh_dyn_lds[o + k] = a.msg[lo16 + o + k];
+#endif
+      __syncthreads();   // (one wave per workgroup; `staged` is uniform: the copy has landed before any lane parses)
+      m = (WMsg)((const u8*)cbh_dyn_lds);   // the block's first byte: every offset below is relative to `bias`
+      bias = lo16;
+      // a lane whose message does not lie inside the block (offsets that are not monotonic: the call fails anyway) sits out
+      if (in_range) { const u64 o0 = a.moff[i], o1 = a.moff[i + 1u]; live = live && o0 >= lo64 && o1 <= hi64; }
+    }
+  }
   const u32 c0 = in_range ? a.cnt[i] : 0u;
   const u32 na = live ? (c0 & 0xFFu) : 0u, nr = live ? (c0 >> 8) : 0u;
   u32 ta, tr;
@@ -502,10 +538,10 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
   resource.p = resource.e = principal.p = principal.e = aux.p = aux.e = rid.p = rid.e = 0;
   const u32 sid_empty = a.stats->sid_empty;
 #define W_RQ(f) a.req_u32[(size_t)(f) * N + i]
-#define W_SID(sp, fl) (((sp).e == (sp).p) ? sid_empty : w_intern(a, (sp).p, (sp).e - (sp).p, (fl), L))
+#define W_SID(sp, fl) (((sp).e == (sp).p) ? sid_empty : w_intern(a, m, bias, (sp).p, (sp).e - (sp).p, (fl), L))
   if (live) {
-    const u32 base0 = (u32)a.moff[i];
-    WSpan s; s.p = base0; s.e = (u32)a.moff[i + 1u];
+    const u32 base0 = (u32)a.moff[i] - bias;
+    WSpan s; s.p = base0; s.e = (u32)a.moff[i + 1u] - bias;
     WSpan pid, pver, pscope, kind, rver, rrid, rscope;
     pid.p = pid.e = pver.p = pver.e = pscope.p = pscope.e = kind.p = kind.e = rver.p = rver.e = rrid.p = rrid.e = rscope.p = rscope.e = 0;
     {   // top level: resource 2, principal 3, actions 4, aux_data 5, request_id 1
@@ -516,7 +552,7 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
         else if (f.num == 4u) {
           if (k < na) {
             const u32 len = f.s.e - f.s.p;
-            a.tuple_action[act_off + k] = w_intern(a, f.s.p, len, CBH_SF_ACTION, L);   // (an empty action is a string like any other)
+            a.tuple_action[act_off + k] = w_intern(a, m, bias, f.s.p, len, CBH_SF_ACTION, L);   // (an empty action is a string like any other)
             a.act_span[2u * (act_off + k)] = len ? f.s.p - base0 : 0u; a.act_span[2u * (act_off + k) + 1u] = len;
           }
           ++k;
@@ -528,7 +564,7 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
       while (w_next(m, p, f, L.bad)) {
         if (f.wt != 2u) continue;
         if (f.num == 1u) pid = f.s; else if (f.num == 2u) pver = f.s; else if (f.num == 5u) pscope = f.s;
-        else if (f.num == 3u) { if (k < nr) a.roles[role_off + k] = w_intern(a, f.s.p, f.s.e - f.s.p, CBH_SF_ROLE, L); ++k; }
+        else if (f.num == 3u) { if (k < nr) a.roles[role_off + k] = w_intern(a, m, bias, f.s.p, f.s.e - f.s.p, CBH_SF_ROLE, L); ++k; }
       }
     }
     {   // Resource: kind 1, policy_version 2, id 3, attr 4, scope 5
@@ -549,15 +585,15 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
     if (psv.e > psv.p && m[psv.p] == '.') ++psv.p;
     if (rsv.e > rsv.p && m[rsv.p] == '.') ++rsv.p;
     W_RQ(CBH_RQ_PRINCIPAL_ID) = W_SID(pid, 0u);
-    W_RQ(CBH_RQ_P_SCOPE) = (pscope.e == pscope.p) ? a.stats->dscope_word : w_scope_word(a, psv.p, psv.e - psv.p);
-    W_RQ(CBH_RQ_P_VERSION) = (pver.e == pver.p) ? a.stats->sid_dver : w_intern(a, pver.p, pver.e - pver.p, 0u, L);
+    W_RQ(CBH_RQ_P_SCOPE) = (pscope.e == pscope.p) ? a.stats->dscope_word : w_scope_word(a, m, psv.p, psv.e - psv.p);
+    W_RQ(CBH_RQ_P_VERSION) = (pver.e == pver.p) ? a.stats->sid_dver : w_intern(a, m, bias, pver.p, pver.e - pver.p, 0u, L);
     if (w_kind_needs_rewrite(m + kind.p, kind.e - kind.p)) {
       const u32 ks = w_rewritten_kind_sid(a, m + kind.p, kind.e - kind.p);
       if (ks == CBH_NONE) L.host = true;
       W_RQ(CBH_RQ_KIND) = ks;
-    } else W_RQ(CBH_RQ_KIND) = w_intern(a, kind.p, kind.e - kind.p, CBH_SF_KIND, L);
-    W_RQ(CBH_RQ_R_SCOPE) = (rscope.e == rscope.p) ? a.stats->dscope_word : w_scope_word(a, rsv.p, rsv.e - rsv.p);
-    W_RQ(CBH_RQ_R_VERSION) = (rver.e == rver.p) ? a.stats->sid_dver : w_intern(a, rver.p, rver.e - rver.p, 0u, L);
+    } else W_RQ(CBH_RQ_KIND) = w_intern(a, m, bias, kind.p, kind.e - kind.p, CBH_SF_KIND, L);
+    W_RQ(CBH_RQ_R_SCOPE) = (rscope.e == rscope.p) ? a.stats->dscope_word : w_scope_word(a, m, rsv.p, rsv.e - rsv.p);
+    W_RQ(CBH_RQ_R_VERSION) = (rver.e == rver.p) ? a.stats->sid_dver : w_intern(a, m, bias, rver.p, rver.e - rver.p, 0u, L);
     W_RQ(CBH_RQ_ROLE_OFF) = role_off; W_RQ(CBH_RQ_ROLE_CNT) = nr;
     W_RQ(CBH_RQ_ACT_OFF) = act_off; W_RQ(CBH_RQ_ACT_CNT) = na;
     if (a.t_flags & CBH_MF_READS_REQUEST_STRINGS) {   // raw request strings only CEL programs read
@@ -590,15 +626,16 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
       WSpan s2; s2.p = a.globals_off; s2.e = a.globals_off + a.globals_len;
       if (root == 0u) s2 = principal; else if (root == 1u) s2 = resource; else if (root == 2u) s2 = aux;
       const u32 want = (root == 2u || root == 4u) ? 1u : 4u;
+      WMsg mr = root == 4u ? mg : m;   // the call's globals lie behind the messages: never in the staged block
       WField f;
-      while (w_next(m, s2, f, L.bad)) {
+      while (w_next(mr, s2, f, L.bad)) {
         if (f.num != want || f.wt != 2u) continue;
         WSpan k, v;
-        if (!w_entry(m, f.s, k, v, L.bad)) break;
+        if (!w_entry(mr, f.s, k, v, L.bad)) break;
         const u32 kl = k.e - k.p;
         for (u32 c = 0; c < ncc; ++c) {
           const CBH_G WireCol& col = a.cols[c];
-          if (col.root == root && col.nk != 0u && col.key_len[0] == kl && w_bytes_eq(m + k.p, a.col_keys + col.key_off[0], kl)) {
+          if (col.root == root && col.nk != 0u && col.key_len[0] == kl && w_bytes_eq(mr + k.p, a.col_keys + col.key_off[0], kl)) {
             w_cur_p[c][threadIdx.x] = v.p; w_cur_e[c][threadIdx.x] = v.e;
           }
         }
@@ -611,6 +648,8 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
     const WireCol col = a.cols[c];
     u32 tag = CBH_T_ABSENT; u64 val = 0;
     bool is_container = false, is_map = false; WSpan body; body.p = body.e = 0; u32 fnum = 1u, need = 0u;
+    WMsg mc = col.root == 4u ? mg : m;
+    const u32 bc = col.root == 4u ? 0u : bias;
     u32 shape = 0u;   // 0 a plain container; auxData.jwts (root 3): 1 one named JWT as {"claims": {...}}, 2 all of them name -> {"claims": {...}}
     if (live) {
       WSpan gl; gl.p = a.globals_off; gl.e = a.globals_off + a.globals_len;
@@ -624,11 +663,11 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
         WSpan jwt; jwt.p = jwt.e = 0;
         const CBH_G u8* k1 = a.col_keys + col.key_off[1];
         if (col.nk == 0u) { is_container = true; is_map = true; shape = 2u; body = aux; fnum = 2u; done = true; }
-        else if (!w_map_get(m, aux, 2u, a.col_keys + col.key_off[0], col.key_len[0], jwt, L.bad)) { tag = col.nk == 1u ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
+        else if (!w_map_get(mc, aux, 2u, a.col_keys + col.key_off[0], col.key_len[0], jwt, L.bad)) { tag = col.nk == 1u ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
         else if (col.nk == 1u) { is_container = true; is_map = true; shape = 1u; body = jwt; fnum = 1u; done = true; }
         else if (!(col.key_len[1] == 6u && k1[0] == 'c' && k1[1] == 'l' && k1[2] == 'a' && k1[3] == 'i' && k1[4] == 'm' && k1[5] == 's')) { tag = col.nk == 2u ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
         else if (col.nk == 2u) { is_container = true; is_map = true; body = jwt; fnum = 1u; done = true; }
-        else if (!w_map_get(m, jwt, 1u, a.col_keys + col.key_off[2], col.key_len[2], cur, L.bad)) { tag = col.nk == 3u ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
+        else if (!w_map_get(mc, jwt, 1u, a.col_keys + col.key_off[2], col.key_len[2], cur, L.bad)) { tag = col.nk == 3u ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
         else k0 = 3u;
       }
       else if (col.nk == 0u) { is_container = true; is_map = true; body = root; fnum = root_fnum; done = true; }
@@ -636,31 +675,31 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
         cur.p = w_cur_p[c][threadIdx.x]; cur.e = w_cur_e[c][threadIdx.x];
         if (cur.p == CBH_NONE) { cur.p = cur.e = 0; tag = col.nk == 1u ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
       }
-      else if (!w_map_get(m, root, root_fnum, a.col_keys + col.key_off[0], col.key_len[0], cur, L.bad)) { tag = col.nk == 1u ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
+      else if (!w_map_get(mc, root, root_fnum, a.col_keys + col.key_off[0], col.key_len[0], cur, L.bad)) { tag = col.nk == 1u ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
       for (u32 k = k0; k < col.nk && !done; ++k) {
         WVal v;
-        if (!w_value(m, cur, v, L.bad) || v.kind != 5u) { tag = CBH_T_ERR; done = true; break; }
-        if (!w_map_get(m, v.s, 1u, a.col_keys + col.key_off[k], col.key_len[k], cur, L.bad)) { tag = (k == col.nk - 1u) ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
+        if (!w_value(mc, cur, v, L.bad) || v.kind != 5u) { tag = CBH_T_ERR; done = true; break; }
+        if (!w_map_get(mc, v.s, 1u, a.col_keys + col.key_off[k], col.key_len[k], cur, L.bad)) { tag = (k == col.nk - 1u) ? CBH_T_ABSENT : CBH_T_ERR; done = true; }
       }
       if (!done) {
         WVal v;
-        if (!w_value(m, cur, v, L.bad)) { tag = CBH_T_NULL; }
+        if (!w_value(mc, cur, v, L.bad)) { tag = CBH_T_NULL; }
         else if (v.kind == 1u) tag = CBH_T_NULL;
         else if (v.kind == 2u) { tag = CBH_T_DOUBLE; val = v.v; }             // structpb: every number is a double
-        else if (v.kind == 3u) { tag = CBH_T_STRING; val = w_intern(a, v.s.p, v.s.e - v.s.p, 0u, L); }
+        else if (v.kind == 3u) { tag = CBH_T_STRING; val = w_intern(a, mc, bc, v.s.p, v.s.e - v.s.p, 0u, L); }
         else if (v.kind == 4u) { tag = CBH_T_BOOL; val = v.v ? 1u : 0u; }
         else { is_container = true; is_map = v.kind == 5u; body = v.s; fnum = 1u; }
       }
       if (is_container) {
-        if (shape == 0u) need = w_container_walk<false>(a, body, fnum, is_map, 0u, L);
-        else if (shape == 1u) need = 2u + w_container_walk<false>(a, body, 1u, true, 0u, L);
+        if (shape == 0u) need = w_container_walk<false>(a, mc, bc, body, fnum, is_map, 0u, L);
+        else if (shape == 1u) need = 2u + w_container_walk<false>(a, mc, bc, body, 1u, true, 0u, L);
         else {   // every named JWT: (name, {"claims": ..}) pairs, then per JWT its two-entry wrapper and its claims
           WSpan s2 = body; WField f; need = 0u;
-          while (w_next(m, s2, f, L.bad)) {
+          while (w_next(mc, s2, f, L.bad)) {
             if (f.num != 2u || f.wt != 2u) continue;
             WSpan k, v;
-            if (!w_entry(m, f.s, k, v, L.bad)) break;
-            need += 4u + w_container_walk<false>(a, v, 1u, true, 0u, L);
+            if (!w_entry(mc, f.s, k, v, L.bad)) break;
+            need += 4u + w_container_walk<false>(a, mc, bc, v, 1u, true, 0u, L);
           }
         }
         if (need > CBH_WIRE_MAX_VALUE_ENTRIES) { L.host = true; need = 0u; is_container = false; tag = CBH_T_NULL; }
@@ -677,27 +716,27 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_fill_kernel(WireArgs a)
         const u32 sid_claims = a.stats->sid_claims;
         auto put = [&](u32 slot, u32 t, u64 v) { if (slot < a.heap_cap) { a.heap_tag[slot] = (u8)t; a.heap_val[slot] = v; } };
         if (shape == 0u) {
-          (void)w_container_walk<true>(a, body, fnum, is_map, off, L);
-          tag = is_map ? CBH_T_MAP : CBH_T_LIST; val = w_container(off, w_count_fields(m, body, fnum, L.bad));
+          (void)w_container_walk<true>(a, mc, bc, body, fnum, is_map, off, L);
+          tag = is_map ? CBH_T_MAP : CBH_T_LIST; val = w_container(off, w_count_fields(mc, body, fnum, L.bad));
         } else if (shape == 1u) {
           put(off, CBH_T_STRING, sid_claims);
-          put(off + 1u, CBH_T_MAP, w_container(off + 2u, w_count_fields(m, body, 1u, L.bad)));
-          (void)w_container_walk<true>(a, body, 1u, true, off + 2u, L);
+          put(off + 1u, CBH_T_MAP, w_container(off + 2u, w_count_fields(mc, body, 1u, L.bad)));
+          (void)w_container_walk<true>(a, mc, bc, body, 1u, true, off + 2u, L);
           tag = CBH_T_MAP; val = w_container(off, 1u);
         } else {
-          const u32 n_top = w_count_fields(m, body, 2u, L.bad);
+          const u32 n_top = w_count_fields(mc, body, 2u, L.bad);
           u32 slot = off, next = off + 2u * n_top;
           WSpan s2 = body; WField f;
-          while (w_next(m, s2, f, L.bad)) {
+          while (w_next(mc, s2, f, L.bad)) {
             if (f.num != 2u || f.wt != 2u) continue;
             WSpan k, v;
-            if (!w_entry(m, f.s, k, v, L.bad)) break;
-            put(slot, CBH_T_STRING, w_intern(a, k.p, k.e - k.p, 0u, L));
+            if (!w_entry(mc, f.s, k, v, L.bad)) break;
+            put(slot, CBH_T_STRING, w_intern(a, mc, bc, k.p, k.e - k.p, 0u, L));
             put(slot + 1u, CBH_T_MAP, w_container(next, 1u));
             slot += 2u;
             put(next, CBH_T_STRING, sid_claims);
-            put(next + 1u, CBH_T_MAP, w_container(next + 2u, w_count_fields(m, v, 1u, L.bad)));
-            next += 2u + w_container_walk<true>(a, v, 1u, true, next + 2u, L);
+            put(next + 1u, CBH_T_MAP, w_container(next + 2u, w_count_fields(mc, v, 1u, L.bad)));
+            next += 2u + w_container_walk<true>(a, mc, bc, v, 1u, true, next + 2u, L);
           }
           tag = CBH_T_MAP; val = w_container(off, n_top);
         }
@@ -743,10 +782,12 @@ struct WireOutArgs {
   const CBH_G u8* effect; const CBH_G u32* policy; const CBH_G u32* scope; const CBH_G u8* status; const CBH_G u64* edr;
   CBH_G u32* sizes; CBH_G u64* wavesum; CBH_G u64* waveoff; CBH_G WireOutStats* stats;
   CBH_G u8* out; CBH_G u64* out_off; CBH_G u8* out_flags;
+  u32 lds_cap, pad3;   // bytes of dynamic LDS a wave of the write kernel may stage its outputs in
 };
 
-template <bool WRITE> struct WSink {
-  CBH_G u8* w; u32 n;
+template <bool WRITE, class P = CBH_G u8*> struct WSink {
+  static constexpr bool writes = WRITE;
+  P w; u32 n;
   __device__ __forceinline__ void byte(u32 b) { if (WRITE) w[n] = (u8)b; ++n; }
   __device__ __forceinline__ void varint(u64 v) { while (v >= 0x80u) { byte(((u32)v & 0x7Fu) | 0x80u); v >>= 7; } byte((u32)v); }
   __device__ __forceinline__ void bytes(const CBH_G u8* p, u32 len) { if (WRITE) for (u32 i = 0; i < len; ++i) w[n + i] = p[i]; n += len; }
@@ -761,8 +802,8 @@ template <bool WRITE> struct WSink {
 __device__ __forceinline__ u32 w_varint_size(u64 v) { u32 n = 1; while (v >= 0x80u) { v >>= 7; ++n; } return n; }
 
 // the policy key of a device policy word (cbh_ingest.cpp policy_key)
-template <bool WRITE>
-__device__ __forceinline__ void w_policy_key(const WireOutArgs& a, WSink<WRITE>& o, u32 word, const CBH_G u8* kind, u32 kind_len, const CBH_G u8* pid, u32 pid_len,
+template <class SINK>
+__device__ __forceinline__ void w_policy_key(const WireOutArgs& a, SINK& o, u32 word, const CBH_G u8* kind, u32 kind_len, const CBH_G u8* pid, u32 pid_len,
                                              const CBH_G u8* rver, u32 rver_len, const CBH_G u8* pver, u32 pver_len, u32& errors) {
   const u32 k = word >> 28, ident = word & 0x0FFFFFFFu;
   if (k == CBH_P_EMPTY) return;
@@ -790,8 +831,8 @@ __device__ __forceinline__ void w_policy_key(const WireOutArgs& a, WSink<WRITE>&
 }
 
 // the CheckOutput of input i into `o`; returns its CBH_WO_* flags
-template <bool WRITE>
-__device__ __attribute__((noinline)) u32 w_output(const WireOutArgs& a, u32 i, WSink<WRITE>& o, u32& errors) {
+template <class SINK>
+__device__ __attribute__((noinline)) u32 w_output(const WireOutArgs& a, u32 i, SINK& o, u32& errors) {
   const u32 N = a.n;
   const CBH_G u8* m = a.msg + (u32)a.moff[i];
   const CBH_G u32* sp = a.in_span + (size_t)i * 2u * CBH_WSPAN_N;
@@ -814,7 +855,7 @@ __device__ __attribute__((noinline)) u32 w_output(const WireOutArgs& a, u32 i, W
     const u32 name_o = a.act_span[2u * (act_off + k)], name_l = a.act_span[2u * (act_off + k) + 1u];
     const u32 effect = a.effect[act_off + j], word = a.policy[act_off + j], sc = a.scope[act_off + j];
     WSink<false> cnt; cnt.w = nullptr; cnt.n = 0;
-    w_policy_key<false>(a, cnt, word, m + sp[6], sp[7], m + sp[2], sp[3], m + sp[8], sp[9], m + sp[4], sp[5], errors);
+    w_policy_key(a, cnt, word, m + sp[6], sp[7], m + sp[2], sp[3], m + sp[8], sp[9], m + sp[4], sp[5], errors);
     const u32 pol_l = cnt.n;
     u32 scope_o = 0, scope_l = 0;
     if (sc != CBH_NONE) {
@@ -827,7 +868,7 @@ __device__ __attribute__((noinline)) u32 w_output(const WireOutArgs& a, u32 i, W
     o.byte(0x0Au); o.varint(name_l); o.bytes(m + name_o, name_l);
     o.byte(0x12u); o.varint(eff_len);
     if (effect) { o.byte(0x08u); o.varint(effect); }
-    if (pol_l) { o.byte(0x12u); o.varint(pol_l); w_policy_key<WRITE>(a, o, word, m + sp[6], sp[7], m + sp[2], sp[3], m + sp[8], sp[9], m + sp[4], sp[5], errors); }
+    if (pol_l) { o.byte(0x12u); o.varint(pol_l); w_policy_key(a, o, word, m + sp[6], sp[7], m + sp[2], sp[3], m + sp[8], sp[9], m + sp[4], sp[5], errors); }
     if (scope_l) { o.byte(0x1Au); o.varint(scope_l); o.bytes(a.t_str_bytes + scope_o, scope_l); }
   }
   const u64 edr = a.edr[i];
@@ -861,7 +902,7 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_out_size_kernel(WireOutArg
   u32 sz = 0, errors = 0;
   if (i < a.n) {
     WSink<false> o; o.w = nullptr; o.n = 0;
-    const u32 fl = w_output<false>(a, i, o, errors);
+    const u32 fl = w_output(a, i, o, errors);
     sz = o.n;
     if (sz > CBH_WO_MAX_OUTPUT) { errors |= 2u; sz = 0; }
     a.sizes[i] = sz; a.out_flags[i] = (u8)fl;
@@ -900,11 +941,38 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_out_write_kernel(WireOutAr
   const u32 i = blockIdx.x * CBH_BLOCK + threadIdx.x;
   const u32 sz = i < a.n ? a.sizes[i] : 0u;
   u32 total;
-  const u64 off = a.waveoff[blockIdx.x * (CBH_BLOCK / 64u) + threadIdx.x / 64u] + w_wave_prefix(sz, 24u, lane, total);
-  if (i < a.n) {
-    a.out_off[i] = off;
-    u32 errors = 0;
+  const u32 pre = w_wave_prefix(sz, 24u, lane, total);
+  const u64 woff = a.waveoff[blockIdx.x * (CBH_BLOCK / 64u) + threadIdx.x / 64u];
+  const u64 off = woff + pre;
+  if (i < a.n) a.out_off[i] = off;
+  u32 errors = 0;
+  const u32 skew = (u32)woff & 15u;
+  if (total + skew + 16u <= a.lds_cap) {
+    // The wave's outputs lie back to back: every lane writes its bytes into LDS (at the block's own 16-byte skew) and the
+    // wave copies the block out in 16-byte stores - one byte per store instruction and lane otherwise.
+#ifndef CBH_HOSTSIM
+    typedef CBH_L u8* LP;
+#else
+    typedef u8* LP;
+#endif
+    if (i < a.n && sz) { WSink<true, LP> o; o.w = (LP)cbh_dyn_lds + skew + pre; o.n = 0; (void)w_output(a, i, o, errors); }
+    __syncthreads();   // (one wave per workgroup, uniform branch)
+    const u32 end = skew + total;   // the block occupies LDS bytes [skew, end); global byte g = woff - skew + (LDS byte)
+    CBH_G u8* gbase = a.out + (woff - skew);
+    for (u32 o16 = lane * 16u; o16 < end; o16 += 64u * 16u) {
+      if (o16 >= skew && o16 + 16u <= end) {
+#ifndef CBH_HOSTSIM
+        typedef u32 v4 __attribute__((ext_vector_type(4)));
+        *(CBH_G v4*)(gbase + o16) = *(const CBH_L v4*)((const CBH_L u8*)cbh_dyn_lds + o16);
+#else
+        for (u32 k = 0; k < 16u; ++k) gbase[o16 + k] = cbh_dyn_lds[o16 + k];
+#endif
+      } else {   // the first / last chunk: only the block's own bytes (the neighbours' belong to other waves)
+        for (u32 k = 0; k < 16u; ++k) if (o16 + k >= skew && o16 + k < end) gbase[o16 + k] = ((LP)cbh_dyn_lds)[o16 + k];
+      }
+    }
+  } else if (i < a.n && sz) {
     WSink<true> o; o.w = a.out + off; o.n = 0;
-    if (sz) (void)w_output<true>(a, i, o, errors);
+    (void)w_output(a, i, o, errors);
   }
 }

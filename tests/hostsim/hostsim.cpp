@@ -282,6 +282,7 @@ extern "C" int hostsim_wire_flatten(const void* blob, size_t len, const uint8_t*
   a.tix = wi.tix.data(); a.tix_mask = wi.tix_mask; a.scope_of_sid = wi.scope_of_sid.data();
   a.cols = wi.cols.data(); a.col_keys = wi.col_keys.data(); a.n_cols = meta[CBH_M_NCOLUMNS]; a.sens_cols = meta[CBH_M_SENS_COLS];
   a.msg = g_w.msg.data(); a.moff = g_w.moff.data(); a.n = n;
+  { const char* e = getenv("CBH_WIRE_LDS_CAP"); a.lds_cap = e ? (uint32_t)atoi(e) : 16384u; if (a.lds_cap > sizeof(cbh_dyn_lds)) a.lds_cap = sizeof(cbh_dyn_lds); }
   a.dver_off = (uint32_t)total; a.dver_len = (uint32_t)dv.size(); a.dscope_off = (uint32_t)(total + dv.size()); a.dscope_len = (uint32_t)ds.size();
   a.claims_off = (uint32_t)(total + dv.size() + ds.size());
   a.globals_off = a.claims_off + 6; a.globals_len = (uint32_t)globals_len;
@@ -339,6 +340,7 @@ extern "C" long long hostsim_wire_outputs(const void* blob, size_t len, const ui
   a.msg = g_w.msg.data(); a.moff = g_w.moff.data(); a.dver_off = g_w.dver_off; a.dver_len = g_w.dver_len;
   a.req_u32 = g_w.req.data(); a.tuple_action = g_w.tuple_action.data(); a.in_span = g_w.in_span.data(); a.act_span = g_w.act_span.data();
   a.effect = effect; a.policy = policy; a.scope = scope; a.status = status; a.edr = edr;
+  { const char* e = getenv("CBH_WIRE_LDS_CAP"); a.lds_cap = e ? (uint32_t)atoi(e) : 16384u; if (a.lds_cap > sizeof(cbh_dyn_lds)) a.lds_cap = sizeof(cbh_dyn_lds); }
   std::vector<uint32_t> sizes(n + 1, 0); std::vector<uint64_t> wavesum(nw + 1, 0), waveoff(nw + 1, 0);
   WireOutStats st{}; 
   a.sizes = sizes.data(); a.wavesum = wavesum.data(); a.waveoff = waveoff.data(); a.stats = &st; a.out = out_bytes; a.out_off = out_off; a.out_flags = out_flags;
