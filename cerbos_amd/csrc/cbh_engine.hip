@@ -734,7 +734,7 @@ extern "C" int cbh_result_download(cbh_table* t, cbh_device_batch* b, cbh_result
 
 
 #ifndef CBH_WIRE_LDS_DEFAULT
-#define CBH_WIRE_LDS_DEFAULT 0
+#define CBH_WIRE_LDS_DEFAULT 1
 #endif
 // ---- device-side ingest: serialized CheckInputs -> a resident batch, flattened by the GPU (cbh_wire.h) ------------------
 // H2D of the raw bytes + offsets, count + scan launches, one small D2H (totals, shape), the fill launch, one small D2H
