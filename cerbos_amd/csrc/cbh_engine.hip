@@ -174,6 +174,9 @@ struct Replica {   // the table on one device
   // stream every caller would wait for every other caller's work); idle ones are kept, at most MAX_WIRE_STREAMS are made.
   static constexpr int MAX_WIRE_STREAMS = 64;
   std::mutex wstream_mu; std::vector<hipStream_t> wstreams_idle, wstreams_all; int wstreams_made = 0;
+  // ... and a page-locked staging block (the call's offsets, defaults and statistics cross PCIe from / to it: a pageable source makes
+  // hipMemcpyAsync a blocking, staged copy)
+  std::vector<std::pair<void*, size_t>> wpinned_idle;
 };
 
 struct cbh_table {
@@ -200,6 +203,7 @@ struct cbh_device_batch {
   std::vector<std::pair<void*, size_t>> allocs;   // (block, capacity) taken from the replica's pool
   // a batch the device flattened (cbh_wire_flatten): where the response's strings sit in the messages
   bool wire = false; bool own_wire_stream = false; u32* w_in_span = nullptr; u32* w_act_span = nullptr;
+  void* w_pinned = nullptr; size_t w_pinned_cap = 0;
   const u64* w_moff = nullptr; u32 w_dver_off = 0, w_dver_len = 0;   // (the device assembler reads the messages again)
   u32* w_sizes = nullptr; u64* w_wavesum = nullptr; u64* w_waveoff = nullptr; WireOutStats* w_ostats = nullptr; u64* w_out_off = nullptr; u8* w_out_flags = nullptr;
 };
@@ -211,6 +215,7 @@ static void replica_destroy(Replica* r) {
   if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
   for (auto& sl : r->ring) for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
   for (hipStream_t ws : r->wstreams_all) { (void)hipStreamSynchronize(ws); (void)hipStreamDestroy(ws); }
+  for (auto& pb : r->wpinned_idle) (void)hipHostFree(pb.first);
   if (r->image && r->owns_image) (void)hipFree(r->image);
   for (void* p : {(void*)r->w_tix, (void*)r->w_scope_of_sid, (void*)r->w_cols, (void*)r->w_col_keys, (void*)r->w_name_off, (void*)r->w_name_bytes}) if (p) (void)hipFree(p);
   for (auto& a : r->pool_free) (void)hipFree(a.first);
@@ -472,7 +477,11 @@ extern "C" void cbh_batch_release(cbh_device_batch* b) {
     std::lock_guard<std::mutex> lk(b->rep->pool_mu);
     for (auto& a : b->allocs) b->rep->pool_free.push_back(a);
   }
-  if (b->own_wire_stream) { std::lock_guard<std::mutex> lk(b->rep->wstream_mu); b->rep->wstreams_idle.push_back(b->stream); }
+  if (b->own_wire_stream || b->w_pinned) {
+    std::lock_guard<std::mutex> lk(b->rep->wstream_mu);
+    if (b->own_wire_stream) b->rep->wstreams_idle.push_back(b->stream);
+    if (b->w_pinned) b->rep->wpinned_idle.push_back({b->w_pinned, b->w_pinned_cap});
+  }
   delete b;
   cbh_table_release(t);   // the reference the batch held
 }
@@ -749,7 +758,16 @@ static u32 wire_lds_cap(size_t want, int needs_mode) {
   return c > 49152u ? 49152u : c;
 }
 static int wire_stats_read(cbh_device_batch* b, const WireStats* d_stats, WireStats& st) {
-  HIPCHK(hipMemcpyAsync(&st, d_stats, sizeof(st), hipMemcpyDeviceToHost, b->stream));
+  WireStats* land = static_cast<WireStats*>(b->w_pinned) + 1;   // (slot 1 of the batch's page-locked block)
+  HIPCHK(hipMemcpyAsync(land, d_stats, sizeof(st), hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  st = *land;
+  return 0;
+}
+static int wire_stats_write(cbh_device_batch* b, WireStats* d_stats, const WireStats& st) {
+  WireStats* from = static_cast<WireStats*>(b->w_pinned);       // (slot 0)
+  *from = st;
+  HIPCHK(hipMemcpyAsync(d_stats, from, sizeof(st), hipMemcpyHostToDevice, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   return 0;
 }
@@ -777,6 +795,18 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
     if (!rep->wstreams_idle.empty()) { b->stream = rep->wstreams_idle.back(); rep->wstreams_idle.pop_back(); b->own_wire_stream = true; }
     else if (rep->wstreams_made < Replica::MAX_WIRE_STREAMS && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess) { ++rep->wstreams_made; rep->wstreams_all.push_back(b->stream); b->own_wire_stream = true; }
   }
+  {
+    const size_t want = 2 * sizeof(WireStats) + dv.size() + ds.size() + 6 + globals_len + 64 + ((size_t)n + 1) * 8;
+    std::lock_guard<std::mutex> lk(rep->wstream_mu);
+    for (size_t k = 0; k < rep->wpinned_idle.size(); ++k)
+      if (rep->wpinned_idle[k].second >= want) { b->w_pinned = rep->wpinned_idle[k].first; b->w_pinned_cap = rep->wpinned_idle[k].second; rep->wpinned_idle[k] = rep->wpinned_idle.back(); rep->wpinned_idle.pop_back(); break; }
+    if (!b->w_pinned) {
+      size_t cap = 1 << 16; while (cap < want) cap <<= 1;
+      if (hipHostMalloc(&b->w_pinned, cap, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); b->w_pinned = nullptr; }
+      b->w_pinned_cap = cap;
+    }
+  }
+  if (!b->w_pinned) { cbh_batch_release(b); return fail("cbh_wire_flatten: hipHostMalloc failed"); }
   if (!b->own_wire_stream) b->stream = rep->rstreams[rep->next_rstream.fetch_add(1, std::memory_order_relaxed) % (uint32_t)rep->n_rstreams.load(std::memory_order_relaxed)];
   hipStream_t s = b->stream;
   auto bail = [&](int rc) { cbh_batch_release(b); return rc; };
@@ -802,11 +832,18 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
   WireStats st; cbh_wire_stats_init(st);
   std::string tail = dv + ds + "claims";
   if (globals_len) tail.append(reinterpret_cast<const char*>(globals_pb), globals_len);
-  static const u64 zero_off = 0;
+  // everything small goes through the batch's page-locked block: statistics (slots 0 / 1), the tail, the offsets
+  u8* pin = static_cast<u8*>(b->w_pinned);
+  WireStats* pin_st = reinterpret_cast<WireStats*>(pin);
+  u8* pin_tail = pin + 2 * sizeof(WireStats);
+  u64* pin_off = reinterpret_cast<u64*>(pin + ((2 * sizeof(WireStats) + tail.size() + 63) & ~(size_t)63));
+  *pin_st = st;
+  std::memcpy(pin_tail, tail.data(), tail.size());
+  if (n) std::memcpy(pin_off, offsets, ((size_t)n + 1) * 8); else pin_off[0] = 0;
   if (total && hipMemcpyAsync(d_msg, bytes, total, hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
-  if (!tail.empty() && hipMemcpyAsync(d_msg + total, tail.data(), tail.size(), hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
-  if (hipMemcpyAsync(d_moff, n ? offsets : &zero_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
-      hipMemcpyAsync(d_stats, &st, sizeof(st), hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
+  if (hipMemcpyAsync(d_msg + total, pin_tail, tail.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(d_moff, pin_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(d_stats, pin_st, sizeof(st), hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
   if (nw) hipLaunchKernelGGL(cbh_wire_count_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, a);
   u32 slots = cbh_wire_dict_slots(n), heap_cap = cbh_wire_heap_guess(total);
   u32 n_host_count = 0; bool have_outputs = false; u32 runs = 0;
@@ -844,15 +881,13 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
       if (st.heap_used <= heap_cap) break;
       heap_cap = st.heap_used;
       WireStats reset = st; reset.heap_used = 0; reset.n_host = n_host_count; reset.flags = 0;
-      HIPCHK(hipMemcpyAsync(d_stats, &reset, sizeof(reset), hipMemcpyHostToDevice, s));
-      HIPCHK(hipStreamSynchronize(s));   // (`reset` leaves scope)
+      if (wire_stats_write(b, d_stats, reset) != 0) return bail(-1);
     }
     if (!again) break;
     if (slots >= (1u << 30)) { fail("cbh_wire_flatten: the batch-local dictionary cannot grow further"); return bail(-1); }
     slots *= 4;
     WireStats reset = st; reset.heap_used = 0; reset.n_host = n_host_count; reset.flags = 0;
-    HIPCHK(hipMemcpyAsync(d_stats, &reset, sizeof(reset), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
+    if (wire_stats_write(b, d_stats, reset) != 0) return bail(-1);
   }
   HIPCHK(hipGetLastError());
   info->n_tuples = st.n_tuples; info->n_host = st.n_host; info->dict_slots = slots; info->heap_len = st.heap_used; info->fill_runs = runs;
@@ -929,11 +964,15 @@ extern "C" int cbh_wire_outputs(cbh_table* t, cbh_device_batch* b, uint8_t* byte
   a.effect = b->out.effect; a.policy = b->out.policy; a.scope = b->out.scope; a.status = b->out.status; a.edr = b->out.edr;
   a.sizes = b->w_sizes; a.wavesum = b->w_wavesum; a.waveoff = b->w_waveoff; a.stats = b->w_ostats; a.out_off = b->w_out_off; a.out_flags = b->w_out_flags;
   WireOutStats st; std::memset(&st, 0, sizeof(st));
-  HIPCHK(hipMemcpyAsync(b->w_ostats, &st, sizeof(st), hipMemcpyHostToDevice, s));
+  static_assert(sizeof(WireOutStats) <= sizeof(WireStats), "the batch's page-locked block has two WireStats slots");
+  WireOutStats* pin_st = static_cast<WireOutStats*>(b->w_pinned);   // (page-locked: the copies below never block on staging)
+  *pin_st = st;
+  HIPCHK(hipMemcpyAsync(b->w_ostats, pin_st, sizeof(st), hipMemcpyHostToDevice, s));
   if (nw) hipLaunchKernelGGL(cbh_wire_out_size_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, a);
   hipLaunchKernelGGL(cbh_wire_out_scan_kernel, dim3(1), dim3(CBH_BLOCK), 0, s, a);
-  HIPCHK(hipMemcpyAsync(&st, b->w_ostats, sizeof(st), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(pin_st, b->w_ostats, sizeof(st), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  st = *pin_st;
   if (st.errors & 1u) return fail("cbh_wire_outputs: a policy or scope id of the results is out of the table's range");
   if (st.errors & 2u) return fail("cbh_wire_outputs: a CheckOutput exceeds 16 MB");
   *need = (size_t)st.total;

@@ -77,3 +77,24 @@ def test_one_image_answers_every_globals_set_on_the_gpu():
     finally:
         if ev is not None:
             ev.close()
+
+
+def test_the_three_flatteners_fill_the_globals_columns_alike():
+    """Flattener(globals_=) == cbi_flatten_pb_g(globals_pb) array for array, == the device flattener value by value"""
+    import wire_device_util as wu
+    from cerbos_amd.flatten import Flattener
+    from cerbos_amd.ingest import IngestTable
+    lt = lower_rule_table(store_rule_table(), per_call_globals=True)
+    inputs = [v["input"] for v in VECTORS if len(v["input"].get("actions") or []) <= 64]
+    g = {"environment": "test", "nested": {"list": [1, "two", {"three": 3.5}], "flag": True}, "n": 42}
+    data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+    gpb = wire.encode_map(1, g)
+    want = Flattener(lt).flatten(inputs, sort=False, globals_=g)
+    it = IngestTable(lt.blob)
+    have = it.flatten_pb(data, off, sort=False, globals_pb=gpb)
+    it.close()
+    for name in ("req_u32", "roles", "tuple_action", "col_tag", "col_val", "heap_tag", "heap_val", "str_off", "str_bytes", "str_flags"):
+        assert np.array_equal(getattr(want, name), getattr(have, name)), name
+    rc, wb = wu.sim_flatten(lt, data, off, globals_pb=gpb)
+    assert rc == 0 and wb.stats["n_host"] == 0
+    wu.assert_same_requests(lt, have, wb, True)
