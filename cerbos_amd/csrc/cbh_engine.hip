@@ -859,6 +859,11 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
     if (!have_outputs) {
       n_host_count = st.n_host;
       if (st.first_bad != CBH_NONE) { info->first_bad = st.first_bad; fail("malformed CheckInput at index " + std::to_string(st.first_bad)); return bail(-1); }
+      if (st.n_host) {   // the count already found messages for the host flattener (more than 64 actions / 255 roles): no point in filling
+        info->n_tuples = st.n_tuples; info->n_host = st.n_host;
+        g_err = "cbh_wire_flatten: " + std::to_string(st.n_host) + " message(s) are the host flattener's (more than 64 actions or 255 roles)";
+        return bail(1);
+      }
       rc = 0;
       rc |= dalloc(b, a.req_u32, (size_t)CBH_RQ_NFIELDS * n); rc |= dalloc(b, a.roles, (size_t)st.n_roles); rc |= dalloc(b, a.tuple_action, (size_t)st.n_tuples);
       rc |= dalloc(b, a.col_tag, (size_t)ncol * n); rc |= dalloc(b, a.col_val, (size_t)ncol * n);
@@ -889,7 +894,7 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
     WireStats reset = st; reset.heap_used = 0; reset.n_host = n_host_count; reset.flags = 0;
     if (wire_stats_write(b, d_stats, reset) != 0) return bail(-1);
   }
-  HIPCHK(hipGetLastError());
+  { const hipError_t le = hipGetLastError(); if (le != hipSuccess) { fail(std::string("cbh_wire_flatten: ") + hipGetErrorString(le)); return bail(-1); } }
   info->n_tuples = st.n_tuples; info->n_host = st.n_host; info->dict_slots = slots; info->heap_len = st.heap_used; info->fill_runs = runs;
   if (st.first_bad != CBH_NONE) { info->first_bad = st.first_bad; fail("malformed CheckInput at index " + std::to_string(st.first_bad)); return bail(-1); }
   if (st.n_host) { g_err = "cbh_wire_flatten: " + std::to_string(st.n_host) + " message(s) are the host flattener's (more than 64 actions, a resource kind to rewrite that no policy names, containers nested too deep)"; return bail(1); }
