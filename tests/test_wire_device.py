@@ -274,3 +274,30 @@ def test_mutated_messages_both_flatteners_agree():
             ok += 1
     it.close()
     assert ok > 60 and bad > 300, (ok, bad)
+
+
+def test_nesting_and_width_boundaries():
+    """containers nested 8 deep flatten on the device, 9 deep are the host's; wide lists / maps; empty containers; a key twice"""
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c5_policies())))
+    root_cols = [keys for root, keys in lt.columns if root == "R"]
+    assert root_cols, "C5 reads resource attributes"
+    name = root_cols[0][0]
+
+    def nest(d):
+        v = "leaf"
+        for k in range(d):   # one level per step: list and map in turn, with siblings
+            v = [k, v, None] if k % 2 else {"a": v, "b": True}
+        return v
+    base = workloads.c5_requests(n_requests=4).to_inputs()
+    ok = []
+    for d in (1, 3, 8):
+        i = dict(base[0], resource=dict(base[0]["resource"], attr=dict(base[0]["resource"].get("attr") or {}, **{name: nest(d)})))
+        ok.append(i)
+    ok.append(dict(base[1], resource=dict(base[1]["resource"], attr={name: list(range(300)), "other": {"k%d" % k: [k] for k in range(120)}})))
+    ok.append(dict(base[2], resource=dict(base[2]["resource"], attr={name: [], "m": {}, "": {"": [[]]}})))
+    hb, wb = _compare(lt, ok)
+    assert wb.heap_len > 300
+    deep = dict(base[3], resource=dict(base[3]["resource"], attr={name: nest(9)}))
+    data, off = wire.pack_messages([wire.encode_check_input(i) for i in ok + [deep]])
+    rc, wb2 = wu.sim_flatten(lt, data, off)
+    assert rc == 0 and wb2.stats["n_host"] == 1 and wb2.stats["first_bad"] == 0xFFFFFFFF
