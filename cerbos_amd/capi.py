@@ -71,7 +71,7 @@ class CTrace(C.Structure):
 
 
 class CWireInfo(C.Structure):
-    _fields_ = [(n, C.c_uint32) for n in ("n_requests", "n_tuples", "n_host", "first_bad", "dict_slots", "heap_len", "fill_runs", "reserved")]
+    _fields_ = [(n, C.c_uint32) for n in ("n_requests", "n_tuples", "n_host", "first_bad", "dict_slots", "heap_len", "fill_runs", "n_routes")]
 
 
 class HostFlattenerNeeded(RuntimeError):

@@ -204,6 +204,9 @@ struct cbh_device_batch {
   // a batch the device flattened (cbh_wire_flatten): where the response's strings sit in the messages
   bool wire = false; bool own_wire_stream = false; u32* w_in_span = nullptr; u32* w_act_span = nullptr;
   void* w_pinned = nullptr; size_t w_pinned_cap = 0;
+  const u32* w_req_input = nullptr;   // the request words in INPUT order (dev.req_u32 may be the grouped copy)
+  const u32* w_inv = nullptr;         // grouped by route: input -> position of its per-request results; else null
+  u64* w_edr_input = nullptr;         // scratch of cbh_result_download: the derived-role masks back in input order
   const u64* w_moff = nullptr; u32 w_dver_off = 0, w_dver_len = 0;   // (the device assembler reads the messages again)
   u32* w_sizes = nullptr; u64* w_wavesum = nullptr; u64* w_waveoff = nullptr; WireOutStats* w_ostats = nullptr; u64* w_out_off = nullptr; u8* w_out_flags = nullptr;
 };
@@ -735,7 +738,15 @@ extern "C" int cbh_result_download(cbh_table* t, cbh_device_batch* b, cbh_result
   if (out->policy && d.n_tuples) HIPCHK(hipMemcpyAsync(out->policy, b->out.policy, (size_t)d.n_tuples * 4, hipMemcpyDeviceToHost, s));
   if (out->scope && d.n_tuples) HIPCHK(hipMemcpyAsync(out->scope, b->out.scope, (size_t)d.n_tuples * 4, hipMemcpyDeviceToHost, s));
   if (out->status && d.n_tuples) HIPCHK(hipMemcpyAsync(out->status, b->out.status, d.n_tuples, hipMemcpyDeviceToHost, s));
-  if (out->edr_mask && d.n_requests) HIPCHK(hipMemcpyAsync(out->edr_mask, b->out.edr, (size_t)d.n_requests * 8, hipMemcpyDeviceToHost, s));
+  if (out->edr_mask && d.n_requests) {
+    const u64* src = b->out.edr;
+    if (b->w_inv) {   // a batch grouped by route: the masks follow their requests back to input order
+      if (!b->w_edr_input && dalloc(b, b->w_edr_input, (size_t)d.n_requests) != 0) return -1;
+      hipLaunchKernelGGL(cbh_wire_unsort_edr_kernel, dim3((d.n_requests + 255u) / 256u), dim3(256), 0, s, b->out.edr, b->w_inv, b->w_edr_input, d.n_requests);
+      src = b->w_edr_input;
+    }
+    HIPCHK(hipMemcpyAsync(out->edr_mask, src, (size_t)d.n_requests * 8, hipMemcpyDeviceToHost, s));
+  }
   HIPCHK(hipStreamSynchronize(s));
   collect_times(rep);
   return 0;
@@ -898,10 +909,30 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
   info->n_tuples = st.n_tuples; info->n_host = st.n_host; info->dict_slots = slots; info->heap_len = st.heap_used; info->fill_runs = runs;
   if (st.first_bad != CBH_NONE) { info->first_bad = st.first_bad; fail("malformed CheckInput at index " + std::to_string(st.first_bad)); return bail(-1); }
   if (st.n_host) { g_err = "cbh_wire_flatten: " + std::to_string(st.n_host) + " message(s) are the host flattener's (more than 64 actions, a resource kind to rewrite that no policy names, containers nested too deep)"; return bail(1); }
+  // Group the requests by route (cbh_wire.h cbh_wire_route_kernel ...): what the host flattener's routing sort does for the
+  // decision kernels' merged walk.  CBH_WIRE_GROUP=0: leave the batch in input order (measurement aid).
+  static const bool group_on = [] { const char* e = getenv("CBH_WIRE_GROUP"); return !(e && *e == '0'); }();
+  WireRouteArgs ra; std::memset(&ra, 0, sizeof(ra));
+  u32* pin_routes = reinterpret_cast<u32*>(static_cast<WireStats*>(b->w_pinned) + 1);   // (slot 1 of the page-locked block: two words)
+  const bool try_group = group_on && n >= 2u * CBH_BLOCK;
+  if (try_group) {
+    ra.n = n; ra.n_cols = ncol; ra.req_u32 = a.req_u32; ra.roles = a.roles; ra.col_tag = a.col_tag; ra.col_val = a.col_val;
+    rc = 0;
+    rc |= dalloc(b, ra.rt_key, (size_t)CBH_WIRE_ROUTE_SLOTS); rc |= dalloc(b, ra.rt_cnt, (size_t)CBH_WIRE_ROUTE_SLOTS + 2);
+    rc |= dalloc(b, ra.slot, (size_t)n); rc |= dalloc(b, ra.rank, (size_t)n); rc |= dalloc(b, ra.inv, (size_t)n);
+    rc |= dalloc(b, ra.req_out, (size_t)CBH_RQ_NFIELDS * n); rc |= dalloc(b, ra.col_tag_out, (size_t)ncol * n); rc |= dalloc(b, ra.col_val_out, (size_t)ncol * n);
+    if (rc != 0) return bail(-1);
+    if (hipMemsetAsync(ra.rt_key, 0, (size_t)CBH_WIRE_ROUTE_SLOTS * 8, s) != hipSuccess || hipMemsetAsync(ra.rt_cnt, 0, ((size_t)CBH_WIRE_ROUTE_SLOTS + 2) * 4, s) != hipSuccess) { fail("cbh_wire_flatten: memset failed"); return bail(-1); }
+    hipLaunchKernelGGL(cbh_wire_route_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, ra);
+    hipLaunchKernelGGL(cbh_wire_route_scan_kernel, dim3(1), dim3(CBH_BLOCK), 0, s, ra);
+    hipLaunchKernelGGL(cbh_wire_gather_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, ra);
+    if (hipMemcpyAsync(pin_routes, ra.rt_cnt + CBH_WIRE_ROUTE_SLOTS, 8, hipMemcpyDeviceToHost, s) != hipSuccess) { fail("cbh_wire_flatten: download failed"); return bail(-1); }
+  }
   BatchDev& d = b->dev;
   d.n_requests = n; d.n_tuples = st.n_tuples; d.n_roles = st.n_roles; d.n_columns = ncol; d.n_strings = slots; d.heap_len = st.heap_used;
   d.req_lo = 0; d.req_hi = n;
   d.req_u32 = a.req_u32; d.roles = a.roles; d.tuple_req = nullptr; d.tuple_action = a.tuple_action; d.col_tag = a.col_tag; d.col_val = a.col_val;
+  b->w_req_input = a.req_u32;
   d.heap_tag = a.heap_tag; d.heap_val = a.heap_val; d.str_off = nullptr; d.str_bytes = d_msg; d.str_flags = (const u8*)a.lflags; d.str_keys = a.lix;
   b->w_in_span = a.in_span; b->w_act_span = a.act_span; b->w_moff = d_moff; b->w_dver_off = a.dver_off; b->w_dver_len = a.dver_len;
   static const bool force_any = getenv("CBH_FLAT_ANY") != nullptr;
@@ -919,6 +950,12 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
   if (rc != 0) return bail(-1);
   if (globs && hipMemsetAsync(d.gbits, 0, (size_t)3 * slots * sizeof(u64), s) != hipSuccess) { fail("cbh_wire_flatten: memset failed"); return bail(-1); }
   if (hipStreamSynchronize(s) != hipSuccess) { fail("cbh_wire_flatten failed"); return bail(-1); }
+  if (try_group && pin_routes[1] == 0u && pin_routes[0] > 1u) {   // grouped (not: a full route table, or one route - nothing to group)
+    d.req_u32 = ra.req_out; d.col_tag = ra.col_tag_out; d.col_val = ra.col_val_out;
+    b->w_inv = ra.inv;
+    if (b->wide_hi) { b->wide_lo = 0; b->wide_hi = n; }   // the wider requests lie anywhere now: their launch skips the others lane by lane
+    info->n_routes = pin_routes[0];
+  }
   *out = b;
   return 0;
 }
@@ -935,7 +972,7 @@ extern "C" int cbh_wire_spans_download(cbh_table* t, cbh_device_batch* b, uint32
   const size_t n = d.n_requests;
   if (n) HIPCHK(hipMemcpyAsync(in_span, b->w_in_span, n * 2 * CBH_WSPAN_N * 4, hipMemcpyDeviceToHost, b->stream));
   if (d.n_tuples) HIPCHK(hipMemcpyAsync(act_span, b->w_act_span, (size_t)d.n_tuples * 2 * 4, hipMemcpyDeviceToHost, b->stream));
-  if (n) HIPCHK(hipMemcpyAsync(act_off, d.req_u32 + (size_t)CBH_RQ_ACT_OFF * n, n * 4, hipMemcpyDeviceToHost, b->stream));
+  if (n) HIPCHK(hipMemcpyAsync(act_off, b->w_req_input + (size_t)CBH_RQ_ACT_OFF * n, n * 4, hipMemcpyDeviceToHost, b->stream));
   HIPCHK(hipStreamSynchronize(b->stream));
   act_off[n] = d.n_tuples;
   return 0;
@@ -965,7 +1002,7 @@ extern "C" int cbh_wire_outputs(cbh_table* t, cbh_device_batch* b, uint8_t* byte
   a.scope_sid = reinterpret_cast<const u32*>(static_cast<const uint8_t*>(rep->image) + t->wire.scope_sid_offset); a.n_scopes = t->wire.n_scopes;
   a.n_policies = t->wire.n_policies; a.name_off = rep->w_name_off; a.name_bytes = rep->w_name_bytes; a.n_dr = t->wire.n_dr; a.n = n;
   a.msg = d.str_bytes; a.moff = b->w_moff; a.dver_off = b->w_dver_off; a.dver_len = b->w_dver_len;
-  a.req_u32 = d.req_u32; a.tuple_action = d.tuple_action; a.in_span = b->w_in_span; a.act_span = b->w_act_span;
+  a.req_u32 = b->w_req_input; a.tuple_action = d.tuple_action; a.in_span = b->w_in_span; a.act_span = b->w_act_span; a.inv = b->w_inv;
   a.effect = b->out.effect; a.policy = b->out.policy; a.scope = b->out.scope; a.status = b->out.status; a.edr = b->out.edr;
   a.sizes = b->w_sizes; a.wavesum = b->w_wavesum; a.waveoff = b->w_waveoff; a.stats = b->w_ostats; a.out_off = b->w_out_off; a.out_flags = b->w_out_flags;
   WireOutStats st; std::memset(&st, 0, sizeof(st));

@@ -783,6 +783,7 @@ struct WireOutArgs {
   CBH_G u32* sizes; CBH_G u64* wavesum; CBH_G u64* waveoff; CBH_G WireOutStats* stats;
   CBH_G u8* out; CBH_G u64* out_off; CBH_G u8* out_flags;
   u32 lds_cap, pad3;   // bytes of dynamic LDS a wave of the write kernel may stage its outputs in
+  const CBH_G u32* inv;   // a batch grouped by route (cbh_wire_route_kernel): input -> position of its per-request results; else null
 };
 
 template <bool WRITE, class P = CBH_G u8*> struct WSink {
@@ -871,7 +872,7 @@ __device__ __attribute__((noinline)) u32 w_output(const WireOutArgs& a, u32 i, S
     if (pol_l) { o.byte(0x12u); o.varint(pol_l); w_policy_key(a, o, word, m + sp[6], sp[7], m + sp[2], sp[3], m + sp[8], sp[9], m + sp[4], sp[5], errors); }
     if (scope_l) { o.byte(0x1Au); o.varint(scope_l); o.bytes(a.t_str_bytes + scope_o, scope_l); }
   }
-  const u64 edr = a.edr[i];
+  const u64 edr = a.edr[a.inv ? a.inv[i] : i];
   for (u32 d = 0; d < 64u && d < a.n_dr; ++d)
     if ((edr >> d) & 1ull) {                                // 4 effective_derived_roles
       const u32 no = a.name_off[a.n_policies + d], nl = a.name_off[a.n_policies + d + 1u] - no;
@@ -976,3 +977,112 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_out_write_kernel(WireOutAr
     (void)w_output(a, i, o, errors);
   }
 }
+
+// ============================================================================================================================
+// Routing on the device.  The decision kernels walk the table wave by wave and merge the lanes that stand at the same scope
+// of the same (version, kind): a wave whose 64 requests are of 40 different routes walks 40 buckets.  The host flattener
+// therefore orders requests by route (cbh_ingest.cpp sort_batch: kind, version, scope, role count, role signature); a batch the
+// device flattened arrives in INPUT order.  Three launches group it: cbh_wire_route_kernel gives every request its route - a
+// 64-bit fingerprint of those five facts, found or claimed in a small open-addressing table by one compare-and-swap (two
+// routes that collide merely share a group: grouping is for speed, never for meaning) - and its rank inside the route, drawn
+// with ONE returning atomic per distinct route and wave; cbh_wire_route_scan_kernel turns the routes' counts into their
+// starts; cbh_wire_gather_kernel writes the per-request arrays (request words, attribute columns) in grouped order.  Tuples
+// stay where they are (a request carries its ACT_OFF along), so results come back in input tuple order as before; only the
+// per-request derived-role mask is indexed by grouped position (WireRouteArgs.inv maps an input to it).
+#define CBH_WIRE_ROUTE_SLOTS 4096u   /* routes a call can tell apart (a fuller table: the batch stays in input order) */
+
+struct WireRouteArgs {
+  u32 n, n_cols; u32 pad[2];
+  const CBH_G u32* req_u32; const CBH_G u32* roles; const CBH_G u8* col_tag; const CBH_G u64* col_val;   // as the fill kernel left them
+  CBH_G u64* rt_key;     // [CBH_WIRE_ROUTE_SLOTS] fingerprints (0 = empty)
+  CBH_G u32* rt_cnt;     // [CBH_WIRE_ROUTE_SLOTS + 2] requests per route; after the scan: the routes' starts; [SLOTS] = routes in use, [SLOTS + 1] = overflow flag
+  CBH_G u32* slot;       // [n] route of a request
+  CBH_G u32* rank;       // [n] its rank inside the route
+  CBH_G u32* inv;        // [n] input -> grouped position
+  CBH_G u32* req_out; CBH_G u8* col_tag_out; CBH_G u64* col_val_out;
+};
+
+__device__ __forceinline__ u64 w_mix64(u64 h, u64 v) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); h *= 0xFF51AFD7ED558CCDull; return h ^ (h >> 29); }
+
+#ifdef CBH_HOSTSIM
+static void cbh_wire_route_kernel(WireRouteArgs a)
+#else
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_route_kernel(WireRouteArgs a)
+#endif
+{
+  const u32 lane = threadIdx.x & 63u;
+  const u32 i = blockIdx.x * CBH_BLOCK + threadIdx.x;
+  const u32 N = a.n;
+  const bool live = i < N;
+  u32 my_slot = CBH_NONE;
+  if (live) {
+    const u32 kind = a.req_u32[(size_t)CBH_RQ_KIND * N + i], ver = a.req_u32[(size_t)CBH_RQ_R_VERSION * N + i], scope = a.req_u32[(size_t)CBH_RQ_R_SCOPE * N + i];
+    const u32 ro = a.req_u32[(size_t)CBH_RQ_ROLE_OFF * N + i], rc = a.req_u32[(size_t)CBH_RQ_ROLE_CNT * N + i];
+    u64 h = w_mix64(0x243F6A8885A308D3ull, ((u64)kind << 32) | ver);
+    h = w_mix64(h, ((u64)scope << 32) | rc);
+    for (u32 k = 0; k < rc && k < 8u; ++k) h = w_mix64(h, a.roles[ro + k]);   // order-sensitive, like the host's signature
+    if (h == 0) h = 1;
+    u32 s = (u32)(h >> 20) & (CBH_WIRE_ROUTE_SLOTS - 1u);
+    for (u32 p = 0; p < 64u; ++p, s = (s + 1u) & (CBH_WIRE_ROUTE_SLOTS - 1u)) {
+      u64 cur = w_load64(a.rt_key + s);
+      if (cur == 0) { const u64 prev = w_cas64(a.rt_key + s, 0, h); cur = prev == 0 ? h : prev; }
+      if (cur == h) { my_slot = s; break; }
+    }
+  }
+  // rank inside the route: the lanes of a wave that share a route draw their ranks with one returning add
+  u32 my_rank = 0;
+  u64 todo = wave_ballot(live && my_slot != CBH_NONE);
+  const u64 lost = wave_ballot(live && my_slot == CBH_NONE);
+  while (todo) {
+    const u32 lead = (u32)__builtin_ctzll(todo);
+    const u32 ls = wave_readlane(my_slot, lead);
+    const u64 same = wave_ballot(live && my_slot == ls);
+    u32 base = 0;
+    if (lane == lead) base = w_add32(a.rt_cnt + ls, (u32)__builtin_popcountll(same));
+    base = wave_readlane(base, lead);
+    if (live && my_slot == ls) my_rank = base + (u32)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  if (live) { a.slot[i] = my_slot; a.rank[i] = my_rank; }
+  if (lost && lane == 0u) w_or32(a.rt_cnt + CBH_WIRE_ROUTE_SLOTS + 1u, 1u);   // the table is too full to place a route: no grouping this time
+}
+
+#ifdef CBH_HOSTSIM
+static void cbh_wire_route_scan_kernel(WireRouteArgs a)
+#else
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_route_scan_kernel(WireRouteArgs a)
+#endif
+{
+  const u32 lane = threadIdx.x & 63u;
+  const u32 per = CBH_WIRE_ROUTE_SLOTS / 64u;
+  u32 s = 0, used = 0;
+  for (u32 k = 0; k < per; ++k) { const u32 c = a.rt_cnt[lane * per + k]; s += c; used += c != 0u; }
+  u32 total, total_used;
+  u32 p = w_wave_prefix(s, 32u, lane, total);
+  (void)w_wave_prefix(used, 13u, lane, total_used);
+  for (u32 k = 0; k < per; ++k) { const u32 c = a.rt_cnt[lane * per + k]; a.rt_cnt[lane * per + k] = p; p += c; }
+  if (lane == 0u) a.rt_cnt[CBH_WIRE_ROUTE_SLOTS] = total_used;
+}
+
+#ifdef CBH_HOSTSIM
+static void cbh_wire_gather_kernel(WireRouteArgs a)
+#else
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_gather_kernel(WireRouteArgs a)
+#endif
+{
+  const u32 i = blockIdx.x * CBH_BLOCK + threadIdx.x;
+  const u32 N = a.n;
+  if (i >= N) return;
+  const u32 pos = a.rt_cnt[a.slot[i]] + a.rank[i];
+  a.inv[i] = pos;
+  for (u32 f = 0; f < CBH_RQ_NFIELDS; ++f) a.req_out[(size_t)f * N + pos] = a.req_u32[(size_t)f * N + i];
+  for (u32 c = 0; c < a.n_cols; ++c) { a.col_tag_out[(size_t)c * N + pos] = a.col_tag[(size_t)c * N + i]; a.col_val_out[(size_t)c * N + pos] = a.col_val[(size_t)c * N + i]; }
+}
+
+#ifndef CBH_HOSTSIM
+// derived-role masks back in input order (cbh_result_download of a grouped batch)
+__global__ __launch_bounds__(256) void cbh_wire_unsort_edr_kernel(const CBH_G u64* edr_grouped, const CBH_G u32* inv, CBH_G u64* edr_input, u32 n) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) edr_input[i] = edr_grouped[inv[i]];
+}
+#endif

@@ -278,7 +278,7 @@ typedef struct cbh_wire_info {
   uint32_t dict_slots; /* slots of the batch-local string dictionary */
   uint32_t heap_len;   /* entries of the nested-value heap */
   uint32_t fill_runs;  /* 1, or more when the dictionary / heap had to grow */
-  uint32_t reserved;
+  uint32_t n_routes;   /* > 0: the requests were grouped by route on the device (so many routes); 0: the batch is in input order */
 } cbh_wire_info;
 int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
                      const char* default_version, const char* default_scope, const uint8_t* globals_pb, size_t globals_len,

@@ -89,11 +89,13 @@ static int g_last_kind = -1;   // which kernel family decided the last batch (ho
 static bool g_trace;   // hostsim_trace: the trace pass's kernel (cbh_trace_batch)
 
 static WireArgs* g_wargs;   // the device flattener's kernels (cbh_wire.h): 1 count, 2 scan, 3 fill
+static WireRouteArgs* g_wrargs;   // ... and the routing kernels': 7 routes, 8 scan, 9 gather
 static WireOutArgs* g_woargs;   // ... and the device assembler's: 4 sizes, 5 scan, 6 bytes
 static int g_wire_kind = 0;
 
 static void fiber_main() {
-  if (g_wire_kind >= 4) { if (g_wire_kind == 4) cbh_wire_out_size_kernel(*g_woargs); else if (g_wire_kind == 5) cbh_wire_out_scan_kernel(*g_woargs); else cbh_wire_out_write_kernel(*g_woargs); }
+  if (g_wire_kind >= 7) { if (g_wire_kind == 7) cbh_wire_route_kernel(*g_wrargs); else if (g_wire_kind == 8) cbh_wire_route_scan_kernel(*g_wrargs); else cbh_wire_gather_kernel(*g_wrargs); }
+  else if (g_wire_kind >= 4) { if (g_wire_kind == 4) cbh_wire_out_size_kernel(*g_woargs); else if (g_wire_kind == 5) cbh_wire_out_scan_kernel(*g_woargs); else cbh_wire_out_write_kernel(*g_woargs); }
   else if (g_wire_kind == 1) cbh_wire_count_kernel(*g_wargs);
   else if (g_wire_kind == 2) cbh_wire_scan_kernel(*g_wargs);
   else if (g_wire_kind == 3) cbh_wire_fill_kernel(*g_wargs);
@@ -247,11 +249,14 @@ struct HsWire {   // valid until the next call
   const uint8_t* heap_tag; const uint64_t* heap_val; const uint64_t* dict; const uint32_t* dict_flags;
   const uint32_t* in_span; const uint32_t* act_span; const uint8_t* msg; const uint8_t* status;
   WireStats stats;
+  // grouped by route (cbh_wire_route_kernel ...): the per-request arrays in grouped order and input -> position; null when not grouped
+  const uint32_t* req_grouped; const uint8_t* col_tag_grouped; const uint64_t* col_val_grouped; const uint32_t* inv; uint32_t n_routes, pad;
 };
 static struct {
   std::vector<uint8_t> msg, status, col_tag, heap_tag; std::vector<uint64_t> moff, col_val, heap_val, dict;
   std::vector<uint32_t> cnt, wavesum, waveoff, dict_flags, req, roles, tuple_action, in_span, act_span;
   uint32_t dver_off = 0, dver_len = 0, n = 0;
+  std::vector<uint64_t> rt_key, col_val_g; std::vector<uint32_t> rt_cnt, slot, rank, inv, req_g; std::vector<uint8_t> col_tag_g; bool grouped = false;
 } g_w;
 static void wire_launch(int kind, uint32_t nblocks) {
   g_wire_kind = kind;
@@ -321,13 +326,31 @@ extern "C" int hostsim_wire_flatten(const void* blob, size_t len, const uint8_t*
   out->dict_flags = g_w.dict_flags.data(); out->in_span = g_w.in_span.data(); out->act_span = g_w.act_span.data(); out->msg = g_w.msg.data();
   out->status = g_w.status.data(); out->stats = st;
   g_w.dver_off = a.dver_off; g_w.dver_len = a.dver_len; g_w.n = n;
+  // grouping by route, as cbh_wire_flatten does after a fill that left nothing to the host
+  out->req_grouped = nullptr; out->col_tag_grouped = nullptr; out->col_val_grouped = nullptr; out->inv = nullptr; out->n_routes = 0; g_w.grouped = false;
+  if (n && st.n_host == 0 && st.first_bad == CBH_NONE && getenv("CBH_WIRE_GROUP") && *getenv("CBH_WIRE_GROUP") != '0') {
+    WireRouteArgs r{};
+    r.n = n; r.n_cols = a.n_cols; r.req_u32 = g_w.req.data(); r.roles = g_w.roles.data(); r.col_tag = g_w.col_tag.data(); r.col_val = g_w.col_val.data();
+    g_w.rt_key.assign(CBH_WIRE_ROUTE_SLOTS, 0); g_w.rt_cnt.assign(CBH_WIRE_ROUTE_SLOTS + 2, 0); g_w.slot.assign(n, 0); g_w.rank.assign(n, 0); g_w.inv.assign(n, 0xDDDDDDDDu);
+    g_w.req_g.assign((size_t)CBH_RQ_NFIELDS * n, 0xDDDDDDDDu); g_w.col_tag_g.assign((size_t)a.n_cols * n + 1, 0xDD); g_w.col_val_g.assign((size_t)a.n_cols * n + 1, 0);
+    r.rt_key = g_w.rt_key.data(); r.rt_cnt = g_w.rt_cnt.data(); r.slot = g_w.slot.data(); r.rank = g_w.rank.data(); r.inv = g_w.inv.data();
+    r.req_out = g_w.req_g.data(); r.col_tag_out = g_w.col_tag_g.data(); r.col_val_out = g_w.col_val_g.data();
+    g_wrargs = &r;
+    wire_launch(7, nw);
+    if (!g_w.rt_cnt[CBH_WIRE_ROUTE_SLOTS + 1]) {
+      wire_launch(8, 1);
+      wire_launch(9, nw);
+      out->req_grouped = g_w.req_g.data(); out->col_tag_grouped = g_w.col_tag_g.data(); out->col_val_grouped = g_w.col_val_g.data(); out->inv = g_w.inv.data();
+      out->n_routes = g_w.rt_cnt[CBH_WIRE_ROUTE_SLOTS]; g_w.grouped = true;
+    }
+  }
   return 0;
 }
 
 // The device assembler on the batch the last hostsim_wire_flatten call built: results (input order) -> serialized CheckOutputs.
 // out_bytes / out_off / out_flags are the caller's; returns the bytes needed (nothing is written beyond `cap`), < 0 on error.
 extern "C" long long hostsim_wire_outputs(const void* blob, size_t len, const uint8_t* effect, const uint32_t* policy, const uint32_t* scope, const uint8_t* status,
-                                          const uint64_t* edr, uint8_t* out_bytes, size_t cap, uint64_t* out_off, uint8_t* out_flags) {
+                                          const uint64_t* edr, uint8_t* out_bytes, size_t cap, uint64_t* out_off, uint8_t* out_flags, int edr_is_grouped) {
   TableDev t{}; std::vector<uint32_t> meta;
   const uint8_t* base = static_cast<const uint8_t*>(blob);
   if (const char* e = cbh_parse_image(t, meta, base, base, len)) { g_err = e; return -1; }
@@ -340,6 +363,7 @@ extern "C" long long hostsim_wire_outputs(const void* blob, size_t len, const ui
   a.msg = g_w.msg.data(); a.moff = g_w.moff.data(); a.dver_off = g_w.dver_off; a.dver_len = g_w.dver_len;
   a.req_u32 = g_w.req.data(); a.tuple_action = g_w.tuple_action.data(); a.in_span = g_w.in_span.data(); a.act_span = g_w.act_span.data();
   a.effect = effect; a.policy = policy; a.scope = scope; a.status = status; a.edr = edr;
+  a.inv = (edr_is_grouped && g_w.grouped) ? g_w.inv.data() : nullptr;
   { const char* e = getenv("CBH_WIRE_LDS_CAP"); a.lds_cap = e ? (uint32_t)atoi(e) : 16384u; if (a.lds_cap > sizeof(cbh_dyn_lds)) a.lds_cap = sizeof(cbh_dyn_lds); }
   std::vector<uint32_t> sizes(n + 1, 0); std::vector<uint64_t> wavesum(nw + 1, 0), waveoff(nw + 1, 0);
   WireOutStats st{}; 

@@ -48,8 +48,12 @@ def test_workloads_by_both_roads(name, n):
     pol = getattr(workloads, name.lower() + "_policies")
     reqs = getattr(workloads, name.lower() + "_requests")
     lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol())))
-    info = _both_roads(lt, reqs(n_requests=n).to_inputs())
+    inputs = reqs(n_requests=n).to_inputs()
+    rng = np.random.default_rng(1)
+    inputs = [inputs[k] for k in rng.permutation(n)]   # arrival order: the routes thoroughly mixed
+    info = _both_roads(lt, inputs)
     assert info["n_requests"] == n and info["n_host"] == 0
+    assert (info["n_routes"] > 1) == (name != "C2")   # grouped by route on the device (C2 has one route: nothing to group)
 
 
 @pytest.mark.parametrize("seed", range(6))

@@ -301,3 +301,47 @@ def test_nesting_and_width_boundaries():
     data, off = wire.pack_messages([wire.encode_check_input(i) for i in ok + [deep]])
     rc, wb2 = wu.sim_flatten(lt, data, off)
     assert rc == 0 and wb2.stats["n_host"] == 1 and wb2.stats["first_bad"] == 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("name", ["C3", "C5", "fuzz1"])
+def test_grouping_by_route_on_the_device(name, monkeypatch):
+    """cbh_wire_route / route_scan / gather kernels: a permutation that puts equal routes side by side; the decision kernels give
+    the same answers on the grouped batch (tuples never move; derived-role masks follow their request), the assembler the same bytes"""
+    monkeypatch.setenv("CBH_WIRE_GROUP", "1")
+    if name.startswith("fuzz"):
+        frng = np.random.default_rng(10_000 + int(name[4:]))
+        try:
+            lt = lower_rule_table(rule_table_from_policies(policies_from_docs(_policies(frng))))
+        except LoweringError:
+            pytest.skip("store refused by the lowering")
+        inputs = [i for i in _requests(frng, 500) if len(i.get("actions") or []) <= 64]
+    else:
+        pol, reqs = {"C3": (workloads.c3_policies, workloads.c3_requests), "C5": (workloads.c5_policies, workloads.c5_requests)}[name]
+        lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol())))
+        inputs = reqs(n_requests=900).to_inputs()
+    rng = np.random.default_rng(3)
+    inputs = [inputs[k] for k in rng.permutation(len(inputs))]   # arrival order: routes thoroughly mixed
+    data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+    rc, wb = wu.sim_flatten(lt, data, off)
+    assert rc == 0 and wb.grouped is not None
+    req_g, tag_g, val_g, inv, n_routes = wb.grouped
+    n = wb.n
+    assert sorted(inv.tolist()) == list(range(n))
+    assert np.array_equal(req_g[:, inv], wb.req_u32) and np.array_equal(tag_g[:, inv], wb.col_tag) and np.array_equal(val_g[:, inv], wb.col_val)
+    def route(r, req):
+        ro, rc_ = int(req[6, r]), int(req[7, r])
+        return (int(req[3, r]), int(req[5, r]), int(req[4, r]), rc_, tuple(wb.roles[ro:ro + min(rc_, 8)].tolist()))
+    routes_in_order = [route(r, req_g) for r in range(n)]
+    distinct = len(set(routes_in_order))
+    changes = 1 + sum(routes_in_order[r] != routes_in_order[r - 1] for r in range(1, n))
+    assert n_routes == distinct == changes, (n_routes, distinct, changes)   # every route one contiguous run
+    assert distinct > 3
+    now = 1_700_000_000_000_000_000
+    plain = hostsim_api.check(lt, wu.to_batch(lt, wb), now_ns=now, flags=4, device_order=True)
+    grouped = hostsim_api.check(lt, wu.to_batch(lt, wb, grouped=True), now_ns=now, flags=4, device_order=True)
+    for f in ("effect", "policy", "scope", "status"):
+        assert np.array_equal(getattr(plain, f), getattr(grouped, f)), f
+    assert np.array_equal(grouped.edr[inv], plain.edr)
+    a, af = wu.sim_outputs(lt, plain, n)
+    b, bf = wu.sim_outputs(lt, grouped, n, edr_is_grouped=True)
+    assert a == b and np.array_equal(af, bf)

@@ -21,7 +21,8 @@ class HsWire(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("n", "n_tuples", "n_roles", "n_columns", "dict_slots", "heap_len", "K", "fill_runs")] + \
                [(n, C.c_void_p) for n in ("req_u32", "roles", "tuple_action", "col_tag", "col_val", "heap_tag", "heap_val", "dict",
                                           "dict_flags", "in_span", "act_span", "msg", "status")] + \
-               [("stats", C.c_uint32 * 16)]
+               [("stats", C.c_uint32 * 16)] + \
+               [(n, C.c_void_p) for n in ("req_grouped", "col_tag_grouped", "col_val_grouped", "inv")] + [("n_routes", C.c_uint32), ("pad", C.c_uint32)]
 
 
 STAT_NAMES = ("n_tuples", "n_roles", "max_actions", "max_roles", "wide_lo", "wide_hi", "first_bad", "n_host", "heap_used", "flags",
@@ -74,6 +75,12 @@ def sim_flatten(lt, data, offsets, default_version="default", default_scope="", 
     total = int(offsets[-1]) if n else 0
     w.msg = _arr(out.msg, C.c_uint8, np.uint8, total + len(default_version.encode()) + len(default_scope.encode()) + 6 + len(globals_pb) + 8).tobytes()
     w.status = _arr(out.status, C.c_uint8, np.uint8, n)
+    w.grouped = None   # CBH_WIRE_GROUP=1: (request words, column tags, column values) in grouped order, input -> position, routes
+    if out.inv:
+        w.grouped = (_arr(out.req_grouped, C.c_uint32, np.uint32, 16 * n).reshape(16, n),
+                     _arr(out.col_tag_grouped, C.c_uint8, np.uint8, w.n_columns * n).reshape(w.n_columns, n),
+                     _arr(out.col_val_grouped, C.c_uint64, np.uint64, w.n_columns * n).reshape(w.n_columns, n),
+                     _arr(out.inv, C.c_uint32, np.uint32, n), int(out.n_routes))
     return 0, w
 
 
@@ -158,8 +165,9 @@ def assert_same_requests(lt, hb, wb, reads_request_strings):
             assert seen.setdefault(s, int(x)) == int(x), "two ids for %r" % s
 
 
-def to_batch(lt, wb):
-    """A flatten.Batch the simulator's decision kernels accept: the dictionary made dense (test side only - the library hands the
+def to_batch(lt, wb, grouped=False):
+    """``grouped``: the per-request arrays in the order the routing kernels left them (wb.grouped).
+    A flatten.Batch the simulator's decision kernels accept: the dictionary made dense (test side only - the library hands the
     dictionary itself to the kernels, BatchDev.str_keys)."""
     b = Batch()
     b.n_requests, b.n_tuples = wb.n, wb.n_tuples
@@ -174,14 +182,14 @@ def to_batch(lt, wb):
     b.str_bytes = np.frombuffer(b"".join(parts), dtype=np.uint8).copy() if parts else np.zeros(0, np.uint8)
     b.str_flags = wb.dict_flags[used].astype(np.uint8)
     rm = np.vectorize(lambda x: remap.get(int(x), int(x)), otypes=[np.uint32])
-    b.req_u32 = wb.req_u32.copy()
+    b.req_u32 = (wb.grouped[0] if grouped else wb.req_u32).copy()
     for f in RQ_STRING_FIELDS + RQ_RAW_STRING_FIELDS:
         b.req_u32[f] = rm(b.req_u32[f]) if wb.n else b.req_u32[f]
     b.roles = rm(wb.roles) if wb.n_roles else wb.roles.copy()
     b.tuple_action = rm(wb.tuple_action) if wb.n_tuples else wb.tuple_action.copy()
-    b.tuple_req = np.repeat(np.arange(wb.n, dtype=np.uint32), wb.req_u32[9].astype(np.int64))
-    b.col_tag = wb.col_tag.copy()
-    b.col_val = wb.col_val.copy()
+    b.tuple_req = np.repeat(np.arange(wb.n, dtype=np.uint32), wb.req_u32[9].astype(np.int64)) if not grouped else np.zeros(wb.n_tuples, np.uint32)
+    b.col_tag = (wb.grouped[1] if grouped else wb.col_tag).copy()
+    b.col_val = (wb.grouped[2] if grouped else wb.col_val).copy()
     m = b.col_tag == T_STRING
     if m.any():
         b.col_val[m] = rm(b.col_val[m]).astype(np.uint64)
@@ -195,11 +203,11 @@ def to_batch(lt, wb):
     return b
 
 
-def sim_outputs(lt, res, n, cap=None):
+def sim_outputs(lt, res, n, cap=None, edr_is_grouped=False):
     """The device assembler (cbh_wire_out_* kernels, simulator) on the batch the LAST sim_flatten call built; ``res`` = a
     capi.Result in input order.  -> ([serialized CheckOutput], flags uint8[n])"""
     lib = hostsim_api.lib()
-    lib.hostsim_wire_outputs.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.hostsim_wire_outputs.argtypes = [C.c_void_p, C.c_size_t] + [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
     lib.hostsim_wire_outputs.restype = C.c_longlong
     buf = C.create_string_buffer(lt.blob, len(lt.blob))
     cap = 256 if cap is None else cap
@@ -208,7 +216,7 @@ def sim_outputs(lt, res, n, cap=None):
         off = np.zeros(n + 1, np.uint64)
         flags = np.zeros(n + 1, np.uint8)
         need = lib.hostsim_wire_outputs(C.cast(buf, C.c_void_p), len(lt.blob), res.effect.ctypes.data, res.policy.ctypes.data, res.scope.ctypes.data,
-                                        res.status.ctypes.data, res.edr.ctypes.data, out.ctypes.data, cap, off.ctypes.data, flags.ctypes.data)
+                                        res.status.ctypes.data, res.edr.ctypes.data, out.ctypes.data, cap, off.ctypes.data, flags.ctypes.data, int(edr_is_grouped))
         if need < 0:
             raise RuntimeError(lib.hostsim_last_error().decode())
         if need <= cap:
