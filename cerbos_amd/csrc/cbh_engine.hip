@@ -742,7 +742,8 @@ extern "C" int cbh_result_download(cbh_table* t, cbh_device_batch* b, cbh_result
     const u64* src = b->out.edr;
     if (b->w_inv) {   // a batch grouped by route: the masks follow their requests back to input order
       if (!b->w_edr_input && dalloc(b, b->w_edr_input, (size_t)d.n_requests) != 0) return -1;
-      hipLaunchKernelGGL(cbh_wire_unsort_edr_kernel, dim3((d.n_requests + 255u) / 256u), dim3(256), 0, s, b->out.edr, b->w_inv, b->w_edr_input, d.n_requests);
+      WireUnsortArgs ua; ua.edr_grouped = b->out.edr; ua.inv = b->w_inv; ua.edr_input = b->w_edr_input; ua.n = d.n_requests; ua.pad = 0;
+      hipLaunchKernelGGL(cbh_wire_unsort_edr_kernel, dim3((d.n_requests + 255u) / 256u), dim3(256), 0, s, ua);
       src = b->w_edr_input;
     }
     HIPCHK(hipMemcpyAsync(out->edr_mask, src, (size_t)d.n_requests * 8, hipMemcpyDeviceToHost, s));

@@ -989,7 +989,7 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_out_write_kernel(WireOutAr
 // starts; cbh_wire_gather_kernel writes the per-request arrays (request words, attribute columns) in grouped order.  Tuples
 // stay where they are (a request carries its ACT_OFF along), so results come back in input tuple order as before; only the
 // per-request derived-role mask is indexed by grouped position (WireRouteArgs.inv maps an input to it).
-#define CBH_WIRE_ROUTE_SLOTS 4096u   /* routes a call can tell apart (a fuller table: the batch stays in input order) */
+#define CBH_WIRE_ROUTE_SLOTS 16384u   /* routes a call can tell apart (a fuller table: the batch stays in input order) */
 
 struct WireRouteArgs {
   u32 n, n_cols; u32 pad[2];
@@ -1017,10 +1017,10 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_route_kernel(WireRouteArgs
   u32 my_slot = CBH_NONE;
   if (live) {
     const u32 kind = a.req_u32[(size_t)CBH_RQ_KIND * N + i], ver = a.req_u32[(size_t)CBH_RQ_R_VERSION * N + i], scope = a.req_u32[(size_t)CBH_RQ_R_SCOPE * N + i];
-    const u32 ro = a.req_u32[(size_t)CBH_RQ_ROLE_OFF * N + i], rc = a.req_u32[(size_t)CBH_RQ_ROLE_CNT * N + i];
+    // (kind, version, scope): what lanes must share to walk a bucket together; the role lists - the host sort's secondary key - are
+    // left out: they differ from request to request, are decided per lane by class masks, and would only scatter a kind's requests
     u64 h = w_mix64(0x243F6A8885A308D3ull, ((u64)kind << 32) | ver);
-    h = w_mix64(h, ((u64)scope << 32) | rc);
-    for (u32 k = 0; k < rc && k < 8u; ++k) h = w_mix64(h, a.roles[ro + k]);   // order-sensitive, like the host's signature
+    h = w_mix64(h, (u64)scope);
     if (h == 0) h = 1;
     u32 s = (u32)(h >> 20) & (CBH_WIRE_ROUTE_SLOTS - 1u);
     for (u32 p = 0; p < 64u; ++p, s = (s + 1u) & (CBH_WIRE_ROUTE_SLOTS - 1u)) {
@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_route_scan_kernel(WireRout
   for (u32 k = 0; k < per; ++k) { const u32 c = a.rt_cnt[lane * per + k]; s += c; used += c != 0u; }
   u32 total, total_used;
   u32 p = w_wave_prefix(s, 32u, lane, total);
-  (void)w_wave_prefix(used, 13u, lane, total_used);
+  (void)w_wave_prefix(used, 15u, lane, total_used);
   for (u32 k = 0; k < per; ++k) { const u32 c = a.rt_cnt[lane * per + k]; a.rt_cnt[lane * per + k] = p; p += c; }
   if (lane == 0u) a.rt_cnt[CBH_WIRE_ROUTE_SLOTS] = total_used;
 }
@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_gather_kernel(WireRouteArg
 {
   const u32 i = blockIdx.x * CBH_BLOCK + threadIdx.x;
   const u32 N = a.n;
-  if (i >= N) return;
+  if (i >= N || a.rt_cnt[CBH_WIRE_ROUTE_SLOTS + 1u] != 0u) return;   // (a route found no slot: nothing is grouped, the host reads the flag)
   const u32 pos = a.rt_cnt[a.slot[i]] + a.rank[i];
   a.inv[i] = pos;
   for (u32 f = 0; f < CBH_RQ_NFIELDS; ++f) a.req_out[(size_t)f * N + pos] = a.req_u32[(size_t)f * N + i];
@@ -1080,9 +1080,11 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_gather_kernel(WireRouteArg
 }
 
 #ifndef CBH_HOSTSIM
-// derived-role masks back in input order (cbh_result_download of a grouped batch)
-__global__ __launch_bounds__(256) void cbh_wire_unsort_edr_kernel(const CBH_G u64* edr_grouped, const CBH_G u32* inv, CBH_G u64* edr_input, u32 n) {
+// derived-role masks back in input order (cbh_result_download of a grouped batch).  (Arguments in a struct, as everywhere here: a
+// kernel whose SIGNATURE carries address-space qualified pointers has one mangled name in the device pass and another on the host.)
+struct WireUnsortArgs { const CBH_G u64* edr_grouped; const CBH_G u32* inv; CBH_G u64* edr_input; u32 n; u32 pad; };
+__global__ __launch_bounds__(256) void cbh_wire_unsort_edr_kernel(WireUnsortArgs a) {
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) edr_input[i] = edr_grouped[inv[i]];
+  if (i < a.n) a.edr_input[i] = a.edr_grouped[a.inv[i]];
 }
 #endif
