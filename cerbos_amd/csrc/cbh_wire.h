@@ -1014,35 +1014,38 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_route_kernel(WireRouteArgs
   const u32 i = blockIdx.x * CBH_BLOCK + threadIdx.x;
   const u32 N = a.n;
   const bool live = i < N;
-  u32 my_slot = CBH_NONE;
+  u64 h = 0;
   if (live) {
     const u32 kind = a.req_u32[(size_t)CBH_RQ_KIND * N + i], ver = a.req_u32[(size_t)CBH_RQ_R_VERSION * N + i], scope = a.req_u32[(size_t)CBH_RQ_R_SCOPE * N + i];
     // (kind, version, scope): what lanes must share to walk a bucket together; the role lists - the host sort's secondary key - are
     // left out: they differ from request to request, are decided per lane by class masks, and would only scatter a kind's requests
-    u64 h = w_mix64(0x243F6A8885A308D3ull, ((u64)kind << 32) | ver);
+    h = w_mix64(0x243F6A8885A308D3ull, ((u64)kind << 32) | ver);
     h = w_mix64(h, (u64)scope);
     if (h == 0) h = 1;
-    u32 s = (u32)(h >> 20) & (CBH_WIRE_ROUTE_SLOTS - 1u);
-    for (u32 p = 0; p < 64u; ++p, s = (s + 1u) & (CBH_WIRE_ROUTE_SLOTS - 1u)) {
-      u64 cur = w_load64(a.rt_key + s);
-      if (cur == 0) { const u64 prev = w_cas64(a.rt_key + s, 0, h); cur = prev == 0 ? h : prev; }
-      if (cur == h) { my_slot = s; break; }
-    }
   }
-  // rank inside the route: the lanes of a wave that share a route draw their ranks with one returning add
-  u32 my_rank = 0;
-  u64 todo = wave_ballot(live && my_slot != CBH_NONE);
-  const u64 lost = wave_ballot(live && my_slot == CBH_NONE);
+  // One lane per distinct route of the wave goes to the table (a stream of one kind would otherwise send every lane's
+  // compare-and-swap to the same word) and draws the ranks of all the wave's requests of that route with one returning add.
+  u32 my_slot = CBH_NONE, my_rank = 0;
+  u64 todo = wave_ballot(live);
   while (todo) {
     const u32 lead = (u32)__builtin_ctzll(todo);
-    const u32 ls = wave_readlane(my_slot, lead);
-    const u64 same = wave_ballot(live && my_slot == ls);
-    u32 base = 0;
-    if (lane == lead) base = w_add32(a.rt_cnt + ls, (u32)__builtin_popcountll(same));
-    base = wave_readlane(base, lead);
-    if (live && my_slot == ls) my_rank = base + (u32)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+    const u64 lh = wave_readlane64(h, lead);
+    const u64 same = wave_ballot(live && h == lh);
+    u32 ls = CBH_NONE, base = 0;
+    if (lane == lead) {
+      u32 s = (u32)(lh >> 20) & (CBH_WIRE_ROUTE_SLOTS - 1u);
+      for (u32 p = 0; p < 64u; ++p, s = (s + 1u) & (CBH_WIRE_ROUTE_SLOTS - 1u)) {
+        u64 cur = w_load64(a.rt_key + s);
+        if (cur == 0) { const u64 prev = w_cas64(a.rt_key + s, 0, lh); cur = prev == 0 ? lh : prev; }
+        if (cur == lh) { ls = s; break; }
+      }
+      if (ls != CBH_NONE) base = w_add32(a.rt_cnt + ls, (u32)__builtin_popcountll(same));
+    }
+    ls = wave_readlane(ls, lead); base = wave_readlane(base, lead);
+    if (live && h == lh) { my_slot = ls; my_rank = base + (u32)__builtin_popcountll(same & ((1ull << lane) - 1ull)); }
     todo &= ~same;
   }
+  const u64 lost = wave_ballot(live && my_slot == CBH_NONE);
   if (live) { a.slot[i] = my_slot; a.rank[i] = my_rank; }
   if (lost && lane == 0u) w_or32(a.rt_cnt + CBH_WIRE_ROUTE_SLOTS + 1u, 1u);   // the table is too full to place a route: no grouping this time
 }
@@ -1072,7 +1075,8 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_gather_kernel(WireRouteArg
 {
   const u32 i = blockIdx.x * CBH_BLOCK + threadIdx.x;
   const u32 N = a.n;
-  if (i >= N || a.rt_cnt[CBH_WIRE_ROUTE_SLOTS + 1u] != 0u) return;   // (a route found no slot: nothing is grouped, the host reads the flag)
+  // (a route found no slot, or the stream is of one route: nothing to group - the host reads the same two words)
+  if (i >= N || a.rt_cnt[CBH_WIRE_ROUTE_SLOTS + 1u] != 0u || a.rt_cnt[CBH_WIRE_ROUTE_SLOTS] <= 1u) return;
   const u32 pos = a.rt_cnt[a.slot[i]] + a.rank[i];
   a.inv[i] = pos;
   for (u32 f = 0; f < CBH_RQ_NFIELDS; ++f) a.req_out[(size_t)f * N + pos] = a.req_u32[(size_t)f * N + i];
