@@ -907,6 +907,7 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
     if (wire_stats_write(b, d_stats, reset) != 0) return bail(-1);
   }
   { const hipError_t le = hipGetLastError(); if (le != hipSuccess) { fail(std::string("cbh_wire_flatten: ") + hipGetErrorString(le)); return bail(-1); } }
+  if (st.heap_used >= (1u << 30)) { fail("cbh_wire_flatten: batch too large: nested attribute values exceed the heap's 30-bit offsets"); return bail(-1); }   // (as cbi_flatten_pb)
   info->n_tuples = st.n_tuples; info->n_host = st.n_host; info->dict_slots = slots; info->heap_len = st.heap_used; info->fill_runs = runs;
   if (st.first_bad != CBH_NONE) { info->first_bad = st.first_bad; fail("malformed CheckInput at index " + std::to_string(st.first_bad)); return bail(-1); }
   if (st.n_host) { g_err = "cbh_wire_flatten: " + std::to_string(st.n_host) + " message(s) are the host flattener's (more than 64 actions, a resource kind to rewrite that no policy names, containers nested too deep)"; return bail(1); }
