@@ -47,3 +47,14 @@ def test_bad_input_is_an_error_not_an_image(tmp_path):
     assert p.returncode == 2 and not dst.exists() and p.stderr
     p = _run(["-", str(dst), "--globals", "[1]"], stdin=b"")
     assert p.returncode == 2
+
+
+def test_per_call_globals_flag(tmp_path):
+    """--per-call-globals: the image reads `G.x` from the call (a column of root "G"), byte for byte the in-process lowering"""
+    rt = store_rule_table()
+    src, dst = tmp_path / "ruletable.pb", tmp_path / "image.cbh"
+    src.write_bytes(encode_rule_table(rt))
+    p = _run([str(src), str(dst), "--per-call-globals"])
+    assert p.returncode == 0, p.stderr.decode()
+    lt = lower_rule_table(rt, per_call_globals=True)
+    assert dst.read_bytes() == lt.blob and any(root == "G" for root, _ in lt.columns)
