@@ -60,6 +60,31 @@ class CIDR:
         self.addr, self.bits = addr, bits   # the address AS WRITTEN (not masked) and the prefix length
 
 
+class SpiffeId:
+    """cerbos.lib.spiffeID (types/spiffe.go over go-spiffe v2 spiffeid.ID): the id's text and where its path begins."""
+
+    def __init__(self, text, pathidx):
+        self.text, self.pathidx = text, pathidx
+
+    @property
+    def domain(self):
+        return self.text[9:self.pathidx]
+
+
+class SpiffeDomain:
+    """cerbos.lib.spiffeTrustDomain"""
+
+    def __init__(self, name):
+        self.name = name
+
+
+class SpiffeMatch:
+    """cerbos.lib.spiffeMatcher: any | one id | one of several | every id of a trust domain"""
+
+    def __init__(self, kind, arg=None):
+        self.kind, self.arg = kind, arg
+
+
 def _is_int(v):
     return isinstance(v, int) and not isinstance(v, (bool, UInt))
 
@@ -112,6 +137,23 @@ def equal(a, b):
         return isinstance(b, IPAddr) and a.a == b.a
     if isinstance(a, CIDR):
         return isinstance(b, CIDR) and a.addr == b.addr and a.bits == b.bits
+    if isinstance(a, SpiffeDomain):   # spiffe.go SPIFFETrustDomain.Equal (cel-go asks the left operand): a trust domain, or a string that parses to one
+        if isinstance(b, SpiffeDomain):
+            return a.name == b.name
+        if isinstance(b, str):
+            try:
+                return _spiffe_domain(b).name == a.name
+            except FoldError:
+                return False
+        raise FoldError("no such overload")
+    if isinstance(a, SpiffeId):       # SPIFFEID.Equal: an id, or its string form
+        if isinstance(b, SpiffeId):
+            return a.text == b.text
+        if isinstance(b, str):
+            return a.text == b
+        raise FoldError("no such overload")
+    if isinstance(a, SpiffeMatch):
+        return False
     raise NotConst("equality of %s" % type(a).__name__)
 
 
@@ -284,6 +326,43 @@ def _regex_replace(s, p, repl, limit=-1):
     if re.search(r"\\([0-9])", repl) and any(int(d) > rx.groups for d in re.findall(r"\\([0-9])", repl)):
         raise FoldError("invalid replacement")
     return rx.sub(re.sub(r"\\([0-9])", r"\\g<\1>", repl), s, count=0 if limit < 0 else limit)
+
+
+# ---- SPIFFE ids (types/spiffe.go; the grammar of github.com/spiffe/go-spiffe/v2 v2.8.1 spiffeid - go.mod:81, not vendored:
+# FromString, TrustDomainFromString, ValidatePath as published)
+_SPIFFE_TD = frozenset("abcdefghijklmnopqrstuvwxyz0123456789-._")
+_SPIFFE_SEG = _SPIFFE_TD | frozenset("ABCDEFGHIJKLMNOPQRSTUVWXYZ")
+
+
+def _spiffe_id(text):
+    if not text.startswith("spiffe://"):
+        raise FoldError("failed to parse SPIFFE ID")
+    i = 9
+    while i < len(text) and text[i] != "/":
+        if text[i] not in _SPIFFE_TD:
+            raise FoldError("failed to parse SPIFFE ID")
+        i += 1
+    if i == 9:
+        raise FoldError("failed to parse SPIFFE ID")
+    path = text[i:]
+    if path:
+        segs = path.split("/")[1:]   # path starts with '/': the first piece is empty
+        if any(seg in ("", ".", "..") or any(c not in _SPIFFE_SEG for c in seg) for seg in segs):
+            raise FoldError("failed to parse SPIFFE ID")
+    return SpiffeId(text, i)
+
+
+def _spiffe_domain(text):
+    if text == "":
+        raise FoldError("failed to parse SPIFFE trust domain")
+    if ":/" in text:
+        try:
+            return SpiffeDomain(_spiffe_id(text).domain)
+        except FoldError:
+            raise FoldError("failed to parse SPIFFE trust domain")
+    if any(c not in _SPIFFE_TD for c in text):
+        raise FoldError("failed to parse SPIFFE trust domain")
+    return SpiffeDomain(text)
 
 
 class _Eval:
@@ -755,6 +834,53 @@ class _Eval:
             if name in ("hasIntersection", "has_intersection"):
                 return any(equal(e, f) for e in a for f in b)
             return all(any(equal(e, f) for f in b) for e in a)
+
+        # SPIFFE (types/spiffe.go)
+        if not method and ns is None and name.startswith("spiffe"):
+            if name == "spiffeID" and nv == 1:
+                return vals[0] if isinstance(vals[0], SpiffeId) else _spiffe_id(_need(vals[0], str))
+            if name == "spiffeTrustDomain" and nv == 1:
+                v0 = vals[0]
+                return v0 if isinstance(v0, SpiffeDomain) else SpiffeDomain(v0.domain) if isinstance(v0, SpiffeId) else _spiffe_domain(_need(v0, str))
+            if name == "spiffeMatchAny" and nv == 0:
+                return SpiffeMatch("any")
+            if name == "spiffeMatchExact" and nv == 1:
+                return SpiffeMatch("exact", (vals[0] if isinstance(vals[0], SpiffeId) else _spiffe_id(_need(vals[0], str))).text)
+            if name == "spiffeMatchOneOf" and nv == 1:
+                lst = _need(vals[0], list)
+                if all(isinstance(x, SpiffeId) for x in lst):
+                    return SpiffeMatch("oneof", frozenset(x.text for x in lst))
+                if all(isinstance(x, str) for x in lst):
+                    try:
+                        return SpiffeMatch("oneof", frozenset(_spiffe_id(x).text for x in lst))
+                    except FoldError:
+                        raise FoldError("no such overload")
+                raise FoldError("no such overload")
+            if name == "spiffeMatchTrustDomain" and nv == 1:
+                return SpiffeMatch("td", (vals[0] if isinstance(vals[0], SpiffeDomain) else _spiffe_domain(_need(vals[0], str))).name)
+        if method and isinstance(vals[0], SpiffeId):
+            if name == "isMemberOf" and nv == 2:
+                if not isinstance(vals[1], SpiffeDomain):
+                    raise FoldError("no such overload")
+                return vals[0].domain == vals[1].name
+            if name == "path" and nv == 1:
+                return vals[0].text[vals[0].pathidx:]
+            if name == "trustDomain" and nv == 1:
+                return SpiffeDomain(vals[0].domain)
+            raise FoldError("no such overload")
+        if method and isinstance(vals[0], SpiffeDomain):
+            if name == "name" and nv == 1:
+                return vals[0].name
+            if name == "id" and nv == 1:
+                return "spiffe://" + vals[0].name
+            raise FoldError("no such overload")
+        if method and isinstance(vals[0], SpiffeMatch):
+            if name != "matchesID" or nv != 2:
+                raise FoldError("no such overload")
+            sid = vals[1] if isinstance(vals[1], SpiffeId) else _spiffe_id(_need(vals[1], str))
+            mt = vals[0]
+            return mt.kind == "any" or (mt.kind == "exact" and sid.text == mt.arg) or (mt.kind == "oneof" and sid.text in mt.arg) or \
+                (mt.kind == "td" and sid.domain == mt.arg)
 
         # hierarchy (types/hierarchy.go)
         if name == "hierarchy" and not method and nv in (1, 2):

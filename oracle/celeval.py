@@ -199,6 +199,24 @@ def cel_equal(a, b):
         return a == b
     if isinstance(a, (Optional, NetIP, NetCIDR)):
         return a == b
+    for x, y in ((a, b),):   # (cel-go asks the LEFT operand: lhs.Equal(rhs))
+        if isinstance(x, SpiffeTrustDomain):   # spiffe.go SPIFFETrustDomain.Equal: another trust domain, or a string that parses to one
+            if isinstance(y, SpiffeTrustDomain):
+                return x.name == y.name
+            if isinstance(y, str):
+                try:
+                    return _spiffe_td_from_string(y).name == x.name
+                except CelError:
+                    return False
+            raise no_such_overload()
+        if isinstance(x, SpiffeID):            # SPIFFEID.Equal: another id, or its string form
+            if isinstance(y, SpiffeID):
+                return x.text == y.text
+            if isinstance(y, str):
+                return x.text == y
+            raise no_such_overload()
+    if isinstance(a, SpiffeMatcher) or isinstance(b, SpiffeMatcher):
+        return False
     return a is b
 
 
@@ -1480,6 +1498,170 @@ def _o_value(env, o):
     return o.value
 
 
+# ---- SPIFFE (internal/conditions/types/spiffe.go over github.com/spiffe/go-spiffe/v2 v2.8.1 spiffeid, go.mod:81 - third party,
+# not vendored: the published grammar of spiffeid.FromString / TrustDomainFromString / ValidatePath is restated; pinned by the 18
+# TestCerbosLib KATs that use it) ----------------------------------------------------------------------------------------------
+_TD_CHARS = set("abcdefghijklmnopqrstuvwxyz0123456789-._")
+_SEG_CHARS = _TD_CHARS | set("ABCDEFGHIJKLMNOPQRSTUVWXYZ")
+
+
+class SpiffeID:
+    def __init__(self, text, pathidx):
+        self.text, self.pathidx = text, pathidx
+
+    def __eq__(self, o):
+        return isinstance(o, SpiffeID) and o.text == self.text
+
+    def __hash__(self):
+        return hash(self.text)
+
+
+class SpiffeTrustDomain:
+    def __init__(self, name):
+        self.name = name
+
+    def __eq__(self, o):
+        return isinstance(o, SpiffeTrustDomain) and o.name == self.name
+
+    def __hash__(self):
+        return hash(self.name)
+
+
+class SpiffeMatcher:
+    def __init__(self, kind, arg=None):
+        self.kind, self.arg = kind, arg   # "any" | "exact" (id text) | "oneof" (set of id texts) | "td" (name)
+
+    def matches(self, sid):
+        if self.kind == "any":
+            return True
+        if self.kind == "exact":
+            return sid.text == self.arg
+        if self.kind == "oneof":
+            return sid.text in self.arg
+        return sid.text[9:sid.pathidx] == self.arg
+
+
+def _spiffe_validate_path(path):
+    if path == "":
+        return
+    if path[0] != "/":
+        raise CelError("path must have a leading slash")
+    start = 0
+    for end, c in enumerate(path):
+        if c == "/":
+            seg = path[start:end]
+            if seg == "/":
+                raise CelError("path cannot contain empty segments")
+            if seg in ("/.", "/.."):
+                raise CelError("path cannot contain dot segments")
+            start = end
+            continue
+        if c not in _SEG_CHARS:
+            raise CelError("path segment characters are limited to letters, numbers, dots, dashes, and underscores")
+    seg = path[start:]
+    if seg == "/":
+        raise CelError("path cannot have a trailing slash")
+    if seg in ("/.", "/.."):
+        raise CelError("path cannot contain dot segments")
+
+
+def _spiffe_id_from_string(text, what="failed to parse SPIFFE ID"):
+    def bad(m):
+        return CelError("%s: %s" % (what, m))
+    if text == "":
+        raise bad("cannot be empty")
+    if not text.startswith("spiffe://"):
+        raise bad("scheme is missing or invalid")
+    i = 9
+    while i < len(text) and text[i] != "/":
+        if text[i] not in _TD_CHARS:
+            raise bad("trust domain characters are limited to lowercase letters, numbers, dots, dashes, and underscores")
+        i += 1
+    if i == 9:
+        raise bad("trust domain is missing")
+    try:
+        _spiffe_validate_path(text[i:])
+    except CelError as e:
+        raise bad(str(e))
+    return SpiffeID(text, i)
+
+
+def _spiffe_td_from_string(text, what="failed to parse SPIFFE trust domain"):
+    if text == "":
+        raise CelError("%s: trust domain is missing" % what)
+    if ":/" in text:
+        sid = _spiffe_id_from_string(text, what)
+        return SpiffeTrustDomain(sid.text[9:sid.pathidx])
+    if any(c not in _TD_CHARS for c in text):
+        raise CelError("%s: trust domain characters are limited to lowercase letters, numbers, dots, dashes, and underscores" % what)
+    return SpiffeTrustDomain(text)
+
+
+def _f_spiffe_id(env, v):                       # spiffe.go unarySPIFFEIDFnImpl
+    if isinstance(v, SpiffeID):
+        return v
+    return _spiffe_id_from_string(_need(v, str))
+
+
+def _f_spiffe_td(env, v):                       # unarySPIFFETrustDomainFnImpl
+    if isinstance(v, SpiffeTrustDomain):
+        return v
+    if isinstance(v, SpiffeID):
+        return SpiffeTrustDomain(v.text[9:v.pathidx])
+    return _spiffe_td_from_string(_need(v, str))
+
+
+def _f_spiffe_match_exact(env, v):
+    sid = v if isinstance(v, SpiffeID) else _spiffe_id_from_string(_need(v, str))
+    return SpiffeMatcher("exact", sid.text)
+
+
+def _f_spiffe_match_one_of(env, lst):           # unarySPIFFEMatchOneOfFnImpl: a list of ids, else a list of strings
+    lst = _need(lst, list)
+    if all(isinstance(x, SpiffeID) for x in lst):
+        return SpiffeMatcher("oneof", {x.text for x in lst})
+    if all(isinstance(x, str) for x in lst):
+        try:
+            return SpiffeMatcher("oneof", {_spiffe_id_from_string(x).text for x in lst})
+        except CelError:
+            raise no_such_overload()
+    raise no_such_overload()
+
+
+def _f_spiffe_match_td(env, v):
+    td = v if isinstance(v, SpiffeTrustDomain) else _spiffe_td_from_string(_need(v, str))
+    return SpiffeMatcher("td", td.name)
+
+
+def _m_spiffe_is_member_of(env, sid, td):
+    if not isinstance(sid, SpiffeID) or not isinstance(td, SpiffeTrustDomain):
+        raise no_such_overload()
+    return sid.text[9:sid.pathidx] == td.name
+
+
+def _m_spiffe_matches_id(env, m, v):
+    if not isinstance(m, SpiffeMatcher):
+        raise no_such_overload()
+    sid = v if isinstance(v, SpiffeID) else _spiffe_id_from_string(_need(v, str), "invalid SPIFFE ID")
+    return m.matches(sid)
+
+
+def _m_spiffe_td_or_id(field):
+    def g(env, v):
+        if isinstance(v, SpiffeID):
+            if field == "path":
+                return v.text[v.pathidx:]
+            if field == "trustDomain":
+                return SpiffeTrustDomain(v.text[9:v.pathidx])
+        if isinstance(v, SpiffeTrustDomain):
+            if field == "name":
+                return v.name
+            if field == "id":
+                return "spiffe://" + v.name
+        raise no_such_overload()
+    return g
+
+
 _GLOBAL_FUNCS = {
     "size": _f_size, "int": _f_int, "uint": _f_uint, "double": _f_double, "string": _f_string,
     "bool": _f_bool, "bytes": _f_bytes, "timestamp": _f_timestamp, "duration": _f_duration,
@@ -1496,6 +1678,8 @@ _GLOBAL_FUNCS = {
     "hierarchy": _f_hierarchy,
     "isIP": _n_is_ip, "ip": _n_ip,
     "isCIDR": lambda env, s: _try(_netip_prefix, _need(s, str)), "cidr": lambda env, s: _netip_prefix(s),
+    "spiffeID": _f_spiffe_id, "spiffeTrustDomain": _f_spiffe_td, "spiffeMatchAny": lambda env: SpiffeMatcher("any"),
+    "spiffeMatchExact": _f_spiffe_match_exact, "spiffeMatchOneOf": _f_spiffe_match_one_of, "spiffeMatchTrustDomain": _f_spiffe_match_td,
 }
 
 _METHODS = {
@@ -1548,6 +1732,8 @@ _METHODS = {
     "isMask": lambda env, c: _ncidr(c).network().network_address == c.addr,
     "masked": lambda env, c: NetCIDR(_ncidr(c).network().network_address, c.bits),
     "ip": lambda env, c: NetIP(_ncidr(c).addr),
+    "isMemberOf": _m_spiffe_is_member_of, "matchesID": _m_spiffe_matches_id,
+    "path": _m_spiffe_td_or_id("path"), "trustDomain": _m_spiffe_td_or_id("trustDomain"), "name": _m_spiffe_td_or_id("name"), "id": _m_spiffe_td_or_id("id"),
     "hasValue": lambda env, o: _opt(o).has, "value": _o_value,
     "orValue": lambda env, o, d: o.value if _opt(o).has else d,
 }
