@@ -328,7 +328,8 @@ extern "C" int hostsim_wire_flatten(const void* blob, size_t len, const uint8_t*
   g_w.dver_off = a.dver_off; g_w.dver_len = a.dver_len; g_w.n = n;
   // grouping by route, as cbh_wire_flatten does after a fill that left nothing to the host
   out->req_grouped = nullptr; out->col_tag_grouped = nullptr; out->col_val_grouped = nullptr; out->inv = nullptr; out->n_routes = 0; g_w.grouped = false;
-  if (n && st.n_host == 0 && st.first_bad == CBH_NONE && getenv("CBH_WIRE_GROUP") && *getenv("CBH_WIRE_GROUP") != '0') {
+  const char* ge = getenv("CBH_WIRE_GROUP");   // (as the library: on unless CBH_WIRE_GROUP=0; CBH_WIRE_GROUP=1 also groups batches smaller than two waves)
+  if (n && st.n_host == 0 && st.first_bad == CBH_NONE && !(ge && *ge == '0') && (n >= 2u * CBH_BLOCK || (ge && *ge == '1'))) {
     WireRouteArgs r{};
     r.n = n; r.n_cols = a.n_cols; r.req_u32 = g_w.req.data(); r.roles = g_w.roles.data(); r.col_tag = g_w.col_tag.data(); r.col_val = g_w.col_val.data();
     g_w.rt_key.assign(CBH_WIRE_ROUTE_SLOTS, 0); g_w.rt_cnt.assign(CBH_WIRE_ROUTE_SLOTS + 2, 0); g_w.slot.assign(n, 0); g_w.rank.assign(n, 0); g_w.inv.assign(n, 0xDDDDDDDDu);

@@ -46,7 +46,7 @@ class HostSimEvaluator(HipEvaluator):
                     def close(_s):
                         pass
                 db = _DB()
-                db.wb, db.batch = wb, wu.to_batch(lt, wb)
+                db.wb, db.batch = wb, wu.to_batch(lt, wb, grouped=wb.grouped is not None)
                 return db
 
             def launch(_self, db, now_ns=0, flags=0):
@@ -55,7 +55,7 @@ class HostSimEvaluator(HipEvaluator):
             def wire_outputs(_self, db, cap=None):
                 import wire_device_util as wu
                 _self.device_road_calls = getattr(_self, "device_road_calls", 0) + 1
-                return wu.sim_outputs(lt, db.res, db.wb.n)
+                return wu.sim_outputs(lt, db.res, db.wb.n, edr_is_grouped=db.wb.grouped is not None)
         self.table = _T()
 
 

@@ -344,3 +344,20 @@ def test_grouping_by_route_on_the_device(name, monkeypatch):
     a, af = wu.sim_outputs(lt, plain, n)
     b, bf = wu.sim_outputs(lt, grouped, n, edr_is_grouped=True)
     assert a == b and np.array_equal(af, bf)
+
+
+def test_bytes_road_on_the_simulator_with_grouping(monkeypatch):
+    """HipEvaluator.check_pb on the simulator: device road (flattener, routing, decision, assembler kernels) == host road on a
+    stream of mixed routes large enough to be grouped"""
+    from cerbos_amd.engine import Conf
+    from test_hostsim_golden import HostSimEvaluator
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c5_policies())))
+    inputs = workloads.c5_requests(n_requests=400).to_inputs()
+    rng = np.random.default_rng(9)
+    inputs = [inputs[k] for k in rng.permutation(len(inputs))]
+    data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+    ev = HostSimEvaluator(lt, Conf())
+    a = ev.check_pb(data, off, now_ns=1_700_000_000_000_000_000)
+    assert ev.last_road == "device"
+    b = ev.check_pb(data, off, now_ns=1_700_000_000_000_000_000, device_ingest=False)
+    assert ev.last_road == "host" and a[0] == b[0] and list(a[1]) == list(b[1])
