@@ -26,6 +26,13 @@ import ipaddress
 import math
 import re
 
+from . import crosspath
+
+_PATH_FUNCS = {"basePath": (crosspath.base, "s"), "dirPath": (crosspath.dir_, "s"), "extPath": (crosspath.ext, "s"),
+               "joinPath": (crosspath.join, "l"), "relPath": (crosspath.rel, "ss"), "volumeName": (crosspath.volume_name, "s"),
+               "pathHasPrefix": (crosspath.has_prefix, "ss"), "pathMatch": (crosspath.match, "ss"), "pathMatchAnyOf": (crosspath.match_any_of, "sl")}
+_PATH_MEMBERS = ("pathHasPrefix", "pathMatch", "pathMatchAnyOf")
+
 INT_MIN, INT_MAX, UINT_MAX = -(1 << 63), (1 << 63) - 1, (1 << 64) - 1
 
 
@@ -834,6 +841,24 @@ class _Eval:
             if name in ("hasIntersection", "has_intersection"):
                 return any(equal(e, f) for e in a for f in b)
             return all(any(equal(e, f) for f in b) for e in a)
+
+        # file paths (cerbos_lib.go:138-236 over crosspath): the three with member overloads take their first argument as the target
+        if ns is None and name in _PATH_FUNCS and (not method or name in _PATH_MEMBERS):
+            fn, kinds = _PATH_FUNCS[name]
+            if nv != len(kinds):
+                raise FoldError("no such overload")
+            args = []
+            for v, kind in zip(vals, kinds):
+                if kind == "s":
+                    args.append(_need(v, str))
+                elif isinstance(v, list) and all(isinstance(x, str) for x in v):
+                    args.append(v)
+                else:
+                    raise FoldError("not a list of strings")
+            try:
+                return fn(*args)
+            except crosspath.PathError as err:
+                raise FoldError(str(err))
 
         # SPIFFE (types/spiffe.go)
         if not method and ns is None and name.startswith("spiffe"):

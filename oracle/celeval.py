@@ -26,6 +26,8 @@ import re
 
 from cerbos_amd.cel.parser import parse
 
+from . import crosspath
+
 INT_MIN, INT_MAX = -(1 << 63), (1 << 63) - 1
 UINT_MAX = (1 << 64) - 1
 
@@ -1662,6 +1664,39 @@ def _m_spiffe_td_or_id(field):
     return g
 
 
+# ---- file-path helpers (cerbos_lib.go:138-236 over internal/conditions/crosspath; restated in oracle/crosspath.py) ----------
+def _path_fn(fn, *kinds):
+    """callInString...Err (cerbos_lib.go:555-700): string / list-of-strings arguments, a Go error becomes a CEL error."""
+    def g(env, *args):
+        if len(args) != len(kinds):
+            raise no_such_overload()
+        vals = []
+        for a, k in zip(args, kinds):
+            if k == "s":
+                vals.append(_need(a, str))
+            else:
+                lst = _need(a, list)
+                if not all(isinstance(x, str) for x in lst):
+                    raise CelError("failed to convert list to string slice")
+                vals.append(list(lst))
+        try:
+            return fn(*vals)
+        except crosspath.PathError as x:
+            raise CelError(str(x))
+    return g
+
+
+_PATH_FUNCS = {
+    "basePath": _path_fn(crosspath.base, "s"), "dirPath": _path_fn(crosspath.dir_, "s"), "extPath": _path_fn(crosspath.ext, "s"),
+    "joinPath": _path_fn(crosspath.join, "l"), "relPath": _path_fn(crosspath.rel, "s", "s"),
+    "volumeName": _path_fn(crosspath.volume_name, "s"),
+}
+# these three also have member overloads (cerbos_lib.go:174-218)
+_PATH_MEMBER_FUNCS = {
+    "pathHasPrefix": _path_fn(crosspath.has_prefix, "s", "s"), "pathMatch": _path_fn(crosspath.match, "s", "s"),
+    "pathMatchAnyOf": _path_fn(crosspath.match_any_of, "s", "l"),
+}
+
 _GLOBAL_FUNCS = {
     "size": _f_size, "int": _f_int, "uint": _f_uint, "double": _f_double, "string": _f_string,
     "bool": _f_bool, "bytes": _f_bytes, "timestamp": _f_timestamp, "duration": _f_duration,
@@ -1680,9 +1715,11 @@ _GLOBAL_FUNCS = {
     "isCIDR": lambda env, s: _try(_netip_prefix, _need(s, str)), "cidr": lambda env, s: _netip_prefix(s),
     "spiffeID": _f_spiffe_id, "spiffeTrustDomain": _f_spiffe_td, "spiffeMatchAny": lambda env: SpiffeMatcher("any"),
     "spiffeMatchExact": _f_spiffe_match_exact, "spiffeMatchOneOf": _f_spiffe_match_one_of, "spiffeMatchTrustDomain": _f_spiffe_match_td,
+    **_PATH_FUNCS, **_PATH_MEMBER_FUNCS,
 }
 
 _METHODS = {
+    **_PATH_MEMBER_FUNCS,
     "ancestorOf": lambda env, h, o: _h_ancestor_of(_hier(h), _hier(o)),
     "descendentOf": lambda env, h, o: _h_ancestor_of(_hier(o), _hier(h)),
     "immediateParentOf": lambda env, h, o: _h_immediate_parent_of(_hier(h), _hier(o)),

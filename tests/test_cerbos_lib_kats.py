@@ -2,11 +2,10 @@
 library - 143 closed expressions that must be true, one that must fail - mined into tests/golden/cerbos_lib_kats.json
 (tools/make_golden_cerbos_lib.py).
 
-* the oracle (oracle/celeval.py): the answer for every expression it implements; the families it does not implement
-  (SPIFFE, file-path helpers) are listed, not skipped silently - they are parity-unpinned and unsupported;
+* the oracle (oracle/celeval.py, oracle/crosspath.py): the answer for every expression;
 * the device path (kernel source on the host simulator; GPU tier: the kernel): each expression as the condition of an ALLOW
-  rule - ALLOW where the KAT says true, a CEL error where it says error, or the input flagged UNSUPPORTED; never a wrong
-  answer."""
+  rule - ALLOW where the KAT says true, a CEL error where it says error; every one of them decided (none flagged
+  UNSUPPORTED), never a wrong answer."""
 import pytest
 
 from cerbos_amd import capi
@@ -21,8 +20,8 @@ from oracle import celeval
 CASES = load_json("cerbos_lib_kats.json")["cases"]
 NOW = 1_700_000_000_000_000_000
 API = "api.cerbos.dev/v1"
-# function families oracle/celeval.py does not restate (cerbos_lib.go:96-244: the file-path helpers over the un-vendored crosspath package)
-ORACLE_GAPS = ("basePath", "dirPath", "extPath", "joinPath", "pathHasPrefix", "pathMatch", "relPath", "volumeName")
+# function families oracle/celeval.py does not restate: none (the file-path helpers: oracle/crosspath.py, SPIFFE: celeval.py)
+ORACLE_GAPS = ()
 
 
 def _oracle_implements(expr):
@@ -41,7 +40,7 @@ def test_oracle_answers_as_the_reference_asserts(case):
 
 def test_oracle_coverage_of_the_library_kats():
     done = sum(_oracle_implements(c["expr"]) for c in CASES)
-    assert done >= 108, done   # the rest: the file-path helpers, parity-unpinned
+    assert done == len(CASES) == 143, done
 
 
 def _device(make, close):
@@ -81,10 +80,10 @@ def test_kernel_source_never_answers_a_library_kat_wrongly():
     from test_hostsim_golden import HostSimEvaluator
     decided, wrong = _device(lambda lt: HostSimEvaluator(lt, Conf()), False)
     assert wrong == 0
-    assert decided >= 105, decided
+    assert decided == len(CASES), decided
 
 
 @pytest.mark.gpu
 def test_gpu_never_answers_a_library_kat_wrongly():
     decided, wrong = _device(lambda lt: HipEvaluator(lt, Conf()), True)
-    assert wrong == 0 and decided >= 105, (decided, wrong)
+    assert wrong == 0 and decided == len(CASES), (decided, wrong)
