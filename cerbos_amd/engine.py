@@ -23,7 +23,7 @@ import numpy as np
 from . import capi, namer
 from .flatten import Flattener
 from .lower.blob import LoweredTable, lower_rule_table
-from .policy.loader import load_policy_dir, policies_from_docs
+from .policy.loader import load_policy_dir_with_sources, policies_from_docs
 from .ruletable.build import rule_table_from_policies
 
 _EFFECT_NAMES = {capi.EFFECT_ALLOW: "EFFECT_ALLOW", capi.EFFECT_DENY: "EFFECT_DENY"}
@@ -94,7 +94,8 @@ class HipEvaluator:
 
     @classmethod
     def from_policy_dir(cls, path: str, conf: Conf = None, device: int = 0):
-        return cls.from_rule_table(rule_table_from_policies(load_policy_dir(path)), conf, device)
+        policies, sources = load_policy_dir_with_sources(path)   # compile errors carry file:line:column; scope ancestors must exist
+        return cls.from_rule_table(rule_table_from_policies(policies, sources, require_ancestors=True), conf, device)
 
     # -- the seam -------------------------------------------------------------------------
     def _call_globals(self, globals_):

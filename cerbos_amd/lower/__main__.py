@@ -41,9 +41,9 @@ def main(argv=None) -> int:
         return 2
     try:
         if args.policies:
-            from ..policy.loader import load_policy_dir
+            from ..policy.loader import load_policy_dir_with_sources
             from ..ruletable.build import rule_table_from_policies
-            rt = rule_table_from_policies(load_policy_dir(args.source))
+            rt = rule_table_from_policies(*load_policy_dir_with_sources(args.source), require_ancestors=True)
         else:
             from ..ruletable.proto import decode_rule_table
             wire = sys.stdin.buffer.read() if args.source == "-" else open(args.source, "rb").read()

@@ -69,7 +69,14 @@ def _is_hidden(name: str) -> bool:
 
 def load_policy_dir(root: str) -> dict:
     """Walk ``root`` and return {fqn: policy dict} in deterministic (path-sorted) order."""
-    out = {}
+    return load_policy_dir_with_sources(root)[0]
+
+
+def load_policy_dir_with_sources(root: str):
+    """({fqn: policy dict}, {fqn: policy.source.Source}): the policies of a directory and where their values sit in the files
+    (paths relative to ``root``), for the compiler's error reports."""
+    from .source import load_yaml_with_source
+    out, sources = {}, {}
     for dirpath, dirnames, filenames in os.walk(root):
         dirnames[:] = sorted(
             d for d in dirnames if not _is_hidden(d) and d != "testdata" and d != "_schemas"
@@ -81,13 +88,14 @@ def load_policy_dir(root: str) -> dict:
             if stem.endswith("_test"):
                 continue
             with open(os.path.join(dirpath, fn), "r", encoding="utf-8") as f:
-                doc = load_yaml(f.read())
+                doc, source = load_yaml_with_source(f.read(), os.path.relpath(os.path.join(dirpath, fn), root))
             if not isinstance(doc, dict) or "apiVersion" not in doc:
                 continue
             if doc.get("disabled"):
                 continue
             out[policy_fqn(doc)] = doc
-    return out
+            sources[policy_fqn(doc)] = source
+    return out, sources
 
 
 def policies_from_docs(docs) -> dict:

@@ -184,5 +184,6 @@ def finish_rule_table(rt: dict) -> dict:
     return rt
 
 
-def rule_table_from_policies(policies: dict) -> dict:
-    return build_rule_table(compile_all(policies))
+def rule_table_from_policies(policies: dict, sources: dict | None = None, require_ancestors: bool = False) -> dict:
+    """`require_ancestors`: see policy.compile.compile_all - the entry points that read a policy directory pass True."""
+    return build_rule_table(compile_all(policies, sources, require_ancestors))
