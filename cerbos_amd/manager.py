@@ -119,6 +119,15 @@ class TableManager:
         from .ruletable.proto import decode_rule_table
         return self.swap(lower_rule_table(decode_rule_table(wire), globals_))
 
+    def swap_policies(self, policies: dict, sources: dict | None = None, globals_=None) -> int:
+        """``swap`` from policy documents ({fqn: policy}, ``policy.loader``) - a storage event as the reference handles it
+        (manager.go:86-124): compile, build the rows, lower, then swap.  A set that does not compile raises
+        ``policy.compile.CompileError`` with every error and the published version stays
+        (ruletable_test.go:109-140 maintain_valid_state_on_missing_derived_role)."""
+        from .lower.blob import lower_rule_table
+        from .ruletable.build import rule_table_from_policies
+        return self.swap(lower_rule_table(rule_table_from_policies(policies, sources, require_ancestors=True), globals_))
+
     def acquire(self) -> TableLease:
         with self._lock:
             if self._cur is None:
