@@ -19,10 +19,10 @@ import numpy as np
 
 from .. import namer
 from ..cel import parser as celparser
-from ..ruletable.build import KIND_PRINCIPAL, KIND_RESOURCE
+from ..ruletable.build import KIND_RESOURCE
 from . import celc
 from .celc import COND_LEAF, COND_LEAFTREE, COND_PC_MASK, LoweringError, Params, ProgramBuilder
-from .globs import GlobNFA, fix_glob, has_meta
+from .globs import GlobNFA, has_meta
 
 BLOB_MAGIC = 0x31484243
 BLOB_VERSION = 21

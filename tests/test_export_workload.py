@@ -7,7 +7,6 @@ import sys
 
 import pytest
 
-from cerbos_amd import workloads
 from cerbos_amd.policy.loader import load_policy_dir, policies_from_docs
 from cerbos_amd.ruletable.build import rule_table_from_policies
 

@@ -10,7 +10,6 @@ CPU tier: the lowering's host simulation of the automaton.  GPU tier: cbh_resolv
 batch-local strings on the device and the decision kernel consumes the bits - compared per action with the
 oracle's decision.
 """
-import itertools
 
 import numpy as np
 import pytest

@@ -6,7 +6,6 @@ import os
 import subprocess
 import sys
 
-import numpy as np
 
 from cerbos_amd.lower.blob import lower_rule_table
 from cerbos_amd.ruletable.proto import encode_rule_table

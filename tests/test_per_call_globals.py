@@ -7,7 +7,7 @@ import json
 import numpy as np
 import pytest
 
-from cerbos_amd import capi, wire
+from cerbos_amd import wire
 from cerbos_amd.engine import Conf, HipEvaluator
 from cerbos_amd.lower.blob import lower_rule_table
 from helpers import load_json, rfc3339_ns, store_rule_table
