@@ -61,10 +61,14 @@ def main(argv=None) -> int:
         with open(args.image, "wb") as fh:
             fh.write(lt.blob)
     if args.stats:
-        st = dict(lt.stats)
-        st["unsupported"] = [list(x) for x in lt.unsupported]
-        print(json.dumps(st, sort_keys=True), file=sys.stderr)
+        print(json.dumps(stats_of(lt), sort_keys=True), file=sys.stderr)
     return 0
+
+
+def stats_of(lt) -> dict:
+    st = dict(lt.stats)
+    st["unsupported"] = [list(x) for x in lt.unsupported]
+    return st
 
 
 if __name__ == "__main__":

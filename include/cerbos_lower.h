@@ -1,0 +1,55 @@
+/* cerbos_lower.h - the lowering behind a C ABI: serialized runtimev1.RuleTable in, device table image out.
+ *
+ * Replaces, for a Go host, what `ruletable.NewRuleTable` does with a freshly compiled table before it serves checks
+ * (internal/ruletable/ruletable.go:637-691; rebuilt on every storage event by ruletable.Manager, manager.go:86-124): the host
+ * marshals its runtimev1.RuleTable (api/private/cerbos/runtime/v1/runtime.proto:41-105; private/ruletable/ruletable.go:27-44),
+ * calls cbl_lower_ruletable_pb and hands the image to cbh_table_load (cerbos_hip.h) / cbi_table_open (cerbos_ingest.h).
+ *
+ * libcerbos_lower.so carries no lowering of its own: it embeds the CPython interpreter (libpython3.10) and runs the package's
+ * lowering (cerbos_amd/lower: CEL parser and compiler, regex automata, glob tables, constant folder, time-zone tables) in the
+ * calling process - the same code as `python -m cerbos_amd.lower`, without a child process.  It runs once per published table,
+ * never on the path of a check.  The package is found next to the library (<dir>/../cerbos_amd) or under $CERBOS_AMD_ROOT.
+ * Calls are serialised on the interpreter's lock; any thread may call.
+ */
+#ifndef CERBOS_LOWER_H
+#define CERBOS_LOWER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CBL_ABI_VERSION 1
+
+/* flags of cbl_lower_ruletable_pb */
+#define CBL_PER_CALL_GLOBALS 1u /* `G.x` is read from the globals every call brings (cbh_wire_flatten / cbi_flatten_pb_g): one image for any globals */
+#define CBL_NO_TRACE 2u         /* leave the trace pass's sections out: decisions only, no evaluation_errors / outputs */
+
+/* status */
+#define CBL_OK 0
+#define CBL_CANNOT_LOWER 2 /* the table holds constructs the device path refuses (the caller keeps it on its CPU engine); *error says which */
+#define CBL_BAD_INPUT 3    /* not a runtimev1.RuleTable, bad globals JSON */
+#define CBL_RUNTIME 4      /* the interpreter or the package could not be started; *error says why */
+
+int cbl_abi_version(void);
+
+/* ruletable_pb / len : proto.Marshal of the runtimev1.RuleTable
+ * globals_json       : NULL, or a JSON object - the engine's configured globals (evaluator/conf.go:40), folded into the image
+ *                      unless CBL_PER_CALL_GLOBALS
+ * image / image_len  : on CBL_OK the image, allocated by the library: release it with cbl_free
+ * error              : on any other status a NUL-terminated message, release with cbl_free (may be NULL: no message wanted)   */
+int cbl_lower_ruletable_pb(const uint8_t* ruletable_pb, size_t len, const char* globals_json, uint32_t flags,
+                           uint8_t** image, size_t* image_len, char** error);
+
+/* the lowering's statistics of the LAST successful call on this thread's behalf, one JSON object (sizes, kernels the table is
+ * eligible for, what is outside the device subset); NUL-terminated, release with cbl_free; NULL before the first call */
+char* cbl_last_stats_json(void);
+
+void cbl_free(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -44,3 +44,14 @@ def test_ingest_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(ingest.LIB_PATH)
     for sym in declared:
         assert getattr(lib, sym) is not None
+
+
+def test_lower_library_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build_lower()
+    text = open(os.path.join(ROOT, "include", "cerbos_lower.h")).read()
+    declared = sorted(set(re.findall(r"\b(cbl_[a-z_]+)\s*\(", text)))
+    assert declared == ["cbl_abi_version", "cbl_free", "cbl_last_stats_json", "cbl_lower_ruletable_pb"]
+    lib = ctypes.CDLL(os.path.join(ROOT, "cerbos_amd", "libcerbos_lower.so"))
+    for sym in declared:
+        assert getattr(lib, sym) is not None
