@@ -681,7 +681,8 @@ class _Eval:
             if isinstance(v, UInt):
                 return _int(int(v))
             if isinstance(v, float):
-                if math.isnan(v) or math.isinf(v) or not (-9.3e18 < v < 9.3e18):
+                # cel-go doubleToInt64Checked: both ends excluded (-2^63 itself, exact as a double, is an overflow)
+                if math.isnan(v) or math.isinf(v) or v <= -9223372036854775808.0 or v >= 9223372036854775808.0:
                     raise FoldError("integer overflow")
                 return _int(int(v))
             if isinstance(v, str):

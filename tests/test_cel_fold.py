@@ -81,8 +81,13 @@ def test_values_without_a_constant_form_give_way_to_the_expression():
 
 def test_errors_are_left_to_the_device():
     for expr in ("1 / 0", "[1, 2][5]", '"a" + 1', "9223372036854775807 + 1", '{"a": 1}.b', '"abc".substring(2, 1)', "[1, 'a'].sort()",
-                 "1u - 2u", "5 % 0", 'int("x")', 'ip("999.1.1.1")'):
-        assert F.fold(parser.parse(expr)) == parser.parse(expr), expr
+                 "1u - 2u", "5 % 0", 'int("x")', 'ip("999.1.1.1")', "int(double(-9223372036854775807 - 1))", "int(9223372036854775808.0)",
+                 'basePath("C:x")', 'pathMatch("a", "[")'):
+        assert _folded(expr) is None, expr                    # not turned into a value ...
+        with pytest.raises(F.FoldError):                      # ... because evaluating it is a CEL error
+            F._Eval().ev(parser.parse(expr), {})
+        with pytest.raises(celeval.CelError):
+            celeval.evaluate(expr, celeval.Env({}, NOW))
 
 
 STRS = ["", "a", "abc", "a.b.c", "a,b,,c", "  pad  ", "Ünï", "x.y", "ABC", "a.b", "/a/b", "/a/b/c.txt", "/a/*.txt", "../x", "C:\\\\d\\\\e.f",

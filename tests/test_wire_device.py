@@ -9,7 +9,7 @@ import pytest
 
 import hostsim_api
 import wire_device_util as wu
-from cerbos_amd import wire, workloads
+from cerbos_amd import namer, wire, workloads
 from cerbos_amd.ingest import IngestTable
 from cerbos_amd.lower.blob import lower_rule_table
 from cerbos_amd.lower.celc import LoweringError
@@ -110,6 +110,15 @@ def test_fuzz_inputs(seed):
     except LoweringError:
         pytest.skip("store refused by the lowering")
     inputs = [i for i in _requests(rng, 300) if len(i.get("actions") or []) <= 64]
+    # a kind in the pre-0.30 form (`album:photo`) is looked up rewritten (namer.go:213-218): when the table does not hold the
+    # rewritten text the device has no bytes to give it (they are not in the message) and leaves the message to the host
+    for_host = [i for i in inputs if namer.sanitize(i["resource"]["kind"]) != i["resource"]["kind"]
+                and namer.sanitize(i["resource"]["kind"]) not in lt.string_ids]
+    if for_host:
+        data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+        rc, wb = wu.sim_flatten(lt, data, off)
+        assert rc == 0 and wb.stats["n_host"] == len(for_host) and wb.stats["first_bad"] == 0xFFFFFFFF
+        inputs = [i for i in inputs if not any(i is h for h in for_host)]
     hb, wb = _compare(lt, inputs)
     # a dictionary and a heap that start far too small: the call grows them and runs the fill again - same batch
     hb2, wb2 = _compare(lt, inputs, dict_slots=16, heap=1)
