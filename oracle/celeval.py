@@ -1181,6 +1181,8 @@ def _m_char_at(env, s, i):
 def _m_index_of(env, s, sub, start=0):
     _need(s, str)
     _need(sub, str)
+    if not is_int(start):
+        raise no_such_overload()
     if start < 0 or start > len(s):
         raise CelError("index out of range: %d" % start)
     return s.find(sub, start)
@@ -1191,18 +1193,24 @@ def _m_last_index_of(env, s, sub, start=None):
     _need(sub, str)
     if start is None:
         return s.rfind(sub)
+    if not is_int(start):
+        raise no_such_overload()
     if start < 0 or start > len(s):
         raise CelError("index out of range: %d" % start)
     return s.rfind(sub, 0, start + len(sub))
 
 
 def _m_replace(env, s, old, new, limit=-1):
-    _need(s, str)
+    _need(s, str), _need(old, str), _need(new, str)
+    if not is_int(limit):
+        raise no_such_overload()
     return s.replace(old, new) if limit < 0 else s.replace(old, new, limit)
 
 
 def _m_split(env, s, sep, limit=-1):
-    _need(s, str)
+    _need(s, str), _need(sep, str)
+    if not is_int(limit):
+        raise no_such_overload()
     if limit == 0:
         return []
     if limit == 1:
@@ -1216,7 +1224,7 @@ def _m_split(env, s, sep, limit=-1):
 
 
 def _m_join(env, lst, sep=""):
-    _need(lst, list)
+    _need(lst, list), _need(sep, str)
     if not all(isinstance(x, str) for x in lst):
         raise no_such_overload()
     return sep.join(lst)
