@@ -63,19 +63,43 @@ static inline u32 w2_gwords(u32 gslots_generic, u32 gslots_all, bool plain_tags)
   return (n + CBH_W2_SLOTS_PER_WORD - 1u) / CBH_W2_SLOTS_PER_WORD;
 }
 
-__device__ __forceinline__ u32 w2_rep_role(u32 rbits) {   // bit r -> byte r
-  const u32 x = rbits & 0xFu;
-  return ((x | (x << 7) | (x << 14) | (x << 21)) & 0x01010101u) * 0xFFu;
+// The shape of a walk: NA actions x NR roles, one bit per (role, action) pair in a walk vector W - 32 bits for the base
+// shape (8 x 4), 64 for the wider one (8 x 8: the requests with five to eight roles).  Bit NA r + k = role r's walk for
+// action k.
+template <bool WIDE> struct W2Word { typedef u32 type; };
+template <> struct W2Word<true> { typedef u64 type; };
+template <u32 NA, u32 NR> struct W2Shape {
+  static_assert(NA * NR == 32u || NA * NR == 64u, "a walk vector is one or two dwords");
+  static_assert(NA <= 8u && NR <= 8u, "per-action words (effect, status) and the role index of a note are sized for eight");
+  typedef typename W2Word<(NA * NR > 32u)>::type W;
+  static constexpr W rep() { W m = 0; for (u32 r = 0; r < NR; ++r) m |= (W)1 << (NA * r); return m; }   // bit 0 of every role's field
+};
+__device__ __forceinline__ u32 w2_ctz(u32 x) { return (u32)__builtin_ctz(x); }
+__device__ __forceinline__ u32 w2_ctz(u64 x) { return (u32)__builtin_ctzll(x); }
+template <u32 NA, u32 NR>
+__device__ __forceinline__ typename W2Shape<NA, NR>::W w2_rep_role(u32 rbits) {   // bit r -> all NA bits of field r
+  typedef typename W2Shape<NA, NR>::W W;
+  if (NA == 8u && NR == 4u) {
+    const u32 x = rbits & 0xFu;
+    return (W)(((x | (x << 7) | (x << 14) | (x << 21)) & 0x01010101u) * 0xFFu);
+  }
+  W m = 0;
+#pragma unroll
+  for (u32 r = 0; r < NR; ++r) m |= (W)((rbits >> r) & 1u) << (NA * r);
+  return m * (W)((1u << NA) - 1u);
 }
 
-template <bool PRE>
+template <bool PRE, u32 NA_, u32 NR_>
 __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const W2Layout& ly) {
   const TableDev& t = ka_regs.t;
   const BatchDev& b = ka_regs.b;
   const OutDev& o = ka_regs.o;
   const u32 flags = ka_regs.flags;
   const u32 wave = threadIdx.x / CBH_BLOCK;
-  constexpr u32 NA = CBH_W2_NA, NR = CBH_W2_NR;
+  constexpr u32 NA = NA_, NR = NR_;
+  typedef typename W2Shape<NA, NR>::W W;
+  constexpr W REP = W2Shape<NA, NR>::rep();       // x * REP: an action mask in every role's field
+  constexpr u32 AMASK = (1u << NA) - 1u;
 #ifdef CBH_PROFILE_CYCLES   // profiling build only (tools/gpu_cycles_walk2.py): per-wave phase cycles into the policy / scope words
   const u64 cyc0 = __builtin_readcyclecounter();
   const u64 rt0 = __builtin_amdgcn_s_memrealtime();
@@ -87,8 +111,10 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   const u32 rix = b.req_lo + blockIdx.x * (PRE ? CBH_BLOCK : CBH_W2_THREADS) + threadIdx.x;
   const u32 NRQ = b.n_requests;
   bool valid = rix < b.req_hi;
-  if ((flags & CBH_FI_SKIP_WIDE) && valid)   // wave-uniform test first: the two loads only for a batch that has wider requests
-    valid = !cbh_is_wide(b.req_u32[(size_t)CBH_RQ_ACT_CNT * NRQ + rix], b.req_u32[(size_t)CBH_RQ_ROLE_CNT * NRQ + rix]);
+  if ((flags & CBH_FI_SKIP_WIDE) && valid) {   // wave-uniform test first: the two loads only for a batch that has wider requests
+    const u32 na = b.req_u32[(size_t)CBH_RQ_ACT_CNT * NRQ + rix], nr = b.req_u32[(size_t)CBH_RQ_ROLE_CNT * NRQ + rix];
+    valid = NR == CBH_W2_NR ? !cbh_is_wide(na, nr) : (cbh_is_wide(na, nr) && !cbh_is_wider(na, nr));   // base shape : the wider one
+  }
   const u32 req = valid ? rix : b.req_lo;
   const bool has_pp = (t.flags & CBH_MF_HAS_PRINCIPAL_POLICIES) != 0;
   const bool has_parents = (t.flags & CBH_MF_HAS_PARENT_ROLES) != 0;
@@ -97,7 +123,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
 #define RQ(f) b.req_u32[(size_t)(f) * NRQ + req]
   const u32 pid = RQ(CBH_RQ_PRINCIPAL_ID), kind = RQ(CBH_RQ_KIND), r_scope = RQ(CBH_RQ_R_SCOPE), r_ver = RQ(CBH_RQ_R_VERSION);
   const u32 role_off = RQ(CBH_RQ_ROLE_OFF), act_off = RQ(CBH_RQ_ACT_OFF);
-  const u32 role_cnt = valid ? RQ(CBH_RQ_ROLE_CNT) : 0, act_cnt = valid ? RQ(CBH_RQ_ACT_CNT) : 0;   // <= 4 / <= 8 (host-checked)
+  const u32 role_cnt = valid ? RQ(CBH_RQ_ROLE_CNT) : 0, act_cnt = valid ? RQ(CBH_RQ_ACT_CNT) : 0;   // <= NR / <= NA (host-checked, or filtered above)
   u32 p_scope = 0, p_ver = 0;
   if (has_pp) { p_scope = RQ(CBH_RQ_P_SCOPE); p_ver = RQ(CBH_RQ_P_VERSION); }
 #undef RQ
@@ -219,14 +245,14 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     }
   }
   u32 lane_rs_lo = 0, lane_rs_hi = 0, lane_ac_lo = 0, lane_ac_hi = 0;
-  u32 walks = 0;   // bit 8 r + k: role r exists and action k exists
+  W walks = 0;   // bit NA r + k: role r exists and action k exists
 #pragma unroll
   for (u32 k = 0; k < NA; ++k) {
     if (k < act_cnt) { const u64 m = 1ull << ac[k]; lane_ac_lo |= (u32)m; lane_ac_hi |= (u32)(m >> 32); }
   }
 #pragma unroll
   for (u32 k = 0; k < NR; ++k) {
-    if (k < role_cnt) { lane_rs_lo |= rs_lo[k]; lane_rs_hi |= rs_hi[k]; walks |= all << (8 * k); }
+    if (k < role_cnt) { lane_rs_lo |= rs_lo[k]; lane_rs_hi |= rs_hi[k]; walks |= (W)all << (NA * k); }
   }
   // classes / glob bits present in the wave: a record none of them can match is skipped on the scalar unit
   const u64 wave_a = wave_or64((u64)lane_ac_lo | ((u64)lane_ac_hi << 32), wave, c.tid);
@@ -288,8 +314,8 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   };
   auto kind_bits = [&]() -> u64 { return gbits_of(t, b, DIM_KIND, kind); };
 
-  u32 err = 0, unsup = 0;   // walk bits whose evaluation met a CEL error / left the device subset
-  u32 wtr = 0;              // walk bits that visited a rule with output expressions, or whose variables the device could not evaluate:
+  W err = 0, unsup = 0;   // walk bits whose evaluation met a CEL error / left the device subset
+  W wtr = 0;                // walk bits that visited a rule with output expressions, or whose variables the device could not evaluate:
                             // the trace pass has (or may have) something to say about the input (CBH_ST_WANTS_TRACE)
   const LeafRec no_leaf{};
   // the probe of a params set's variables (celc.py vars_probe_program; slot CBH_GSLOT_NONE = the set has none): bit 1 = one of
@@ -394,12 +420,12 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   }
   const u32 p_done = p_allow | p_deny;   // a definitive principal-policy result ends the action (check.go:445-448)
   W2_DBG(const u64 cyc2 = __builtin_readcyclecounter();)   // the principal pass is over
-  walks &= ~(p_done * 0x01010101u);
+  walks &= ~((W)p_done * REP);
 
   // ---- the resource walk (cbh_check_flat.h: merged climb, deepest scope first)
-  u32 S = walks;
-  u32 has_allow = 0, allow = 0, deny = 0;
-  u32 dp0 = 0, dp1 = 0, dp2 = 0, dp3 = 0;
+  W S = walks;
+  W has_allow = 0, allow = 0, deny = 0;
+  W dp0 = 0, dp1 = 0, dp2 = 0, dp3 = 0;
   const u32 scope_bits = t.n_scopes > 1 ? 32u - (u32)__builtin_clz(t.n_scopes - 1u) : 0u;
   u32 cur = first, mydepth = 0;
   bool exists = false;
@@ -440,7 +466,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     }
     if (go) {
       if (!PRE && ing && mydepth < max_depth) { if (chain8) chain_si8[mydepth * CBH_BLOCK + c.tid] = (u8)g_si; else chain_si[mydepth * CBH_BLOCK + c.tid] = g_si; }
-      const u32 S_before = S;
+      const W S_before = S;
       if (PRE && have_bucket && t.n_dr && (pre_edr || (site_flags & (CBH_BS_DR_GENERIC | CBH_BS_DR_OPEN)))) {
         // the scope's derived roles (check.go:237-282): their sites, and - for programs that read runtime.* - their value
         u64 m = 0;
@@ -506,7 +532,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
 #pragma unroll
           for (u32 k = 0; k < NR; ++k) own |= (u32)(k < role_cnt && rcls[k] == gc) << k;
           const u32 slot = ing ? (match_roles((u32)gm, (u32)(gm >> 32), 0u) & base & (jj < n_rp ? own : ~own)) : 0u;
-          const u32 Wg = w2_rep_role(slot) & (PRE ? walks : S);
+          const W Wg = w2_rep_role<NA, NR>(slot) & (PRE ? walks : S);
           if (wave_ballot(Wg != 0) == 0) continue;
           uint4 rp;
           if (!udir_find(t, CBH_B_ROLEPOL, g_ver, g_si, g_sr, rp)) continue;
@@ -518,13 +544,13 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
             any_mask |= ma;
             if ((rr.cnt & (CBH_RP_F_OUTPUT_ONLY | CBH_RP_F_SHARES_KEY)) == (CBH_RP_F_OUTPUT_ONLY | CBH_RP_F_SHARES_KEY)) out_only |= ma;
           }
-          u32 dn = Wg & ~(any_mask * 0x01010101u);   // no rule for the resource, or no allow action matched (index.go:436-461)
+          W dn = Wg & ~((W)any_mask * REP);   // no rule for the resource, or no allow action matched (index.go:436-461)
           for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
             const TblRpx rr = uload_rec<TblRpx>(t.rpx, row);
             // (the reference visits a matched rule only if it has a condition - as the synthetic DENY row - or outputs)
             if ((rr.cond == CBH_NONE && !(rr.how & 4u)) || !pat_match(rr.resource, g_k, g_kb)) continue;
             const u32 ma = match_actions(rr.am_lo, rr.am_hi, rr.ag);
-            const u32 mm = (ma * 0x01010101u) & Wg & ~dn;
+            const W mm = ((W)ma * REP) & Wg & ~dn;
             if (wave_ballot(mm != 0) == 0) continue;
             if (rr.how & 4u) wtr |= mm;
             if (rp.w != CBH_NONE) {   // the policy's variables
@@ -534,7 +560,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
             if (rr.cond == CBH_NONE) continue;
             // an action at or behind the first one an output-only rule of the same key is visited for finds "satisfied"
             // cached (check.go:324): the synthetic DENY would fire whatever the condition says (cbh_blob.h CBH_RP_F_*)
-            if ((rr.cnt & CBH_RP_F_SHARES_KEY) && out_only != 0) unsup |= mm & ~((((out_only & (0u - out_only)) - 1u) & 0xFFu) * 0x01010101u);
+            if ((rr.cnt & CBH_RP_F_SHARES_KEY) && out_only != 0) unsup |= mm & ~((W)(((out_only & (0u - out_only)) - 1u) & AMASK) * REP);
             const u32 lv = leafish(rr.cond, rr.how & 3u, rr.leaf, rr.gslot & 0xFFFFu, mm != 0);
             err |= (lv & 2u) ? mm : 0u; unsup |= (lv & 8u) ? mm : 0u;
             if (!(lv & 1u)) dn |= mm;   // the synthetic row = DENY if none(condition)
@@ -546,9 +572,9 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
               const u32 note = rp.z & 0x0FFFFFFFu;
 #pragma unroll
               for (u32 k = 0; k < NA; ++k) {
-                const u32 dk = (dn >> k) & 0x01010101u;
+                const W dk = (dn >> k) & REP;
                 if (dk) {
-                  const u32 r = (u32)__builtin_ctz(dk) >> 3;
+                  const u32 r = w2_ctz(dk) / NA;
                   const u32 old = aux[k * CBH_BLOCK + c.tid];
                   if (old == CBH_NONE || r < (old >> 28)) aux[k * CBH_BLOCK + c.tid] = (r << 28) | note;
                 }
@@ -578,9 +604,9 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
           const u32 mact = match_actions(am_lo, am_hi, ag);
           const u32 mrole = match_roles(rm_lo, rm_hi, rg);
           // (the walks a visit is for: those still going - the pre-pass evaluates for every walk the request has)
-          const u32 m = ing ? (w2_rep_role(mrole) & (mact * 0x01010101u) & (PRE ? walks : S)) : 0u;
+          const W m = ing ? (w2_rep_role<NA, NR>(mrole) & ((W)mact * REP) & (PRE ? walks : S)) : (W)0;
           if (wave_ballot(m != 0) == 0) continue;
-          u32 hit = m;
+          W hit = m;
           if (rw.flags & CBH_ROW_F_OUTPUT) wtr |= m;
           if (probes != 0xFFFFFFFFu) {   // the variables of the rule's policy are evaluated on every visit (check.go:306-321)
             const u32 pv = probe(probes & 0xFFFFu, probe_pcs, 0u, m != 0);
@@ -609,12 +635,12 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
         }
       }
       if (!PRE) {
-        const u32 ha = ing ? (has_allow & S) : 0u;   // check.go:416-425
+        const W ha = ing ? (has_allow & S) : (W)0;   // check.go:416-425
         const u32 spm = (g_sf >> 2) & 3u;
         if (spm == SP_REQUIRE_CONSENT) has_allow &= ~ha;
         else if (spm == SP_OVERRIDE_PARENT) { allow |= ha; S &= ~ha; }
-        const u32 newly = S_before & ~S;
-        dp0 |= (mydepth & 1u) ? newly : 0u; dp1 |= (mydepth & 2u) ? newly : 0u; dp2 |= (mydepth & 4u) ? newly : 0u; dp3 |= (mydepth & 8u) ? newly : 0u;
+        const W newly = S_before & ~S;
+        dp0 |= (mydepth & 1u) ? newly : (W)0; dp1 |= (mydepth & 2u) ? newly : (W)0; dp2 |= (mydepth & 4u) ? newly : (W)0; dp3 |= (mydepth & 8u) ? newly : (W)0;
       }
     }
     const u32 up = uchain_next(t, uload(&t.scope_parent[g_si]), FLAG_RES);
@@ -651,26 +677,26 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
 
   // ---- the fold (check.go:429-442), per action: a principal policy's word, else the first role that allowed, else the
   // first role that denied
-  u32 eff[2] = {0, 0}, st[2] = {0, 0}, pol[NA], scp[NA];
+  u32 eff[(NA + 3u) / 4u] = {}, st[(NA + 3u) / 4u] = {}, pol[NA], scp[NA];
   u32 a_un = 0, a_er = 0, a_wt = 0;   // per action: outside the device subset / an evaluation error / something for the trace pass
 #pragma unroll
   for (u32 k = 0; k < NA; ++k) {
-    const u32 ak = (allow >> k) & 0x01010101u, dk = (deny >> k) & 0x01010101u;
-    const u32 win = ak ? (ak & (0u - ak)) : (dk & (0u - dk));
-    const u32 wb = win << k;
+    const W ak = (allow >> k) & REP, dk = (deny >> k) & REP;
+    const W win = ak ? (ak & ((W)0 - ak)) : (dk & ((W)0 - dk));
+    const W wb = win << k;
     const u32 d = ((dp0 & wb) ? 1u : 0u) | ((dp1 & wb) ? 2u : 0u) | ((dp2 & wb) ? 4u : 0u) | ((dp3 & wb) ? 8u : 0u);
     const bool pk = ((p_allow | p_deny) >> k) & 1u;
     const u32 note = aux[k * CBH_BLOCK + c.tid];
     u32 pw = win ? pol_hit : pol_none, sw = CBH_NONE;
     if (win && k < act_cnt) sw = chain8 ? (u32)chain_si8[d * CBH_BLOCK + c.tid] : chain_si[d * CBH_BLOCK + c.tid];
-    if (win && !ak && note != CBH_NONE && (note >> 28) == ((u32)__builtin_ctz(win) >> 3)) pw = ((u32)CBH_P_TABLE << 28) | (note & 0x0FFFFFFFu);   // a role policy denied
+    if (win && !ak && note != CBH_NONE && (note >> 28) == w2_ctz(win) / NA) pw = ((u32)CBH_P_TABLE << 28) | (note & 0x0FFFFFFFu);   // a role policy denied
     bool al = ak != 0;
     if (pk) { pw = p_pol; sw = note; al = ((p_allow >> k) & 1u) != 0; }
     pol[k] = pw; scp[k] = sw;
     eff[k >> 2] |= (u32)(al ? CBH_EFFECT_ALLOW : CBH_EFFECT_DENY) << (8 * (k & 3u));   // NO_MATCH -> DENY (check.go:451-453)
     // an evaluation the reference would not have made - a role after the one that allowed - does not count
-    const u32 seen = ak ? (((ak & (0u - ak)) << 1) - 1u) : 0x01010101u * 0xFFu;
-    const u32 ek = (err >> k) & 0x01010101u & seen, uk = (unsup >> k) & 0x01010101u & seen, wk = (wtr >> k) & 0x01010101u & seen;
+    const W seen = ak ? (((ak & ((W)0 - ak)) << 1) - 1u) : ~(W)0;
+    const W ek = (err >> k) & REP & seen, uk = (unsup >> k) & REP & seen, wk = (wtr >> k) & REP & seen;
     a_er |= (u32)(ek != 0 || ((p_err >> k) & 1u)) << k;
     a_un |= (u32)(uk != 0 || ((p_unsup >> k) & 1u)) << k;
     a_wt |= (u32)(wk != 0 || ((p_wtr >> k) & 1u)) << k;
@@ -682,19 +708,19 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   // the climb above left every position's roles in LDS.
   u64 edr = 0;
   if (want_edr) {
-    u32 legit = 0;
+    W legit = 0;
 #pragma unroll
     for (u32 k = 0; k < NA; ++k) {
-      const u32 ak = (allow >> k) & 0x01010101u;
-      const u32 seen = ak ? (((ak & (0u - ak)) << 1) - 1u) : 0x01010101u * 0xFFu;
-      legit |= ((walks >> k) & 0x01010101u & seen) << k;
+      const W ak = (allow >> k) & REP;
+      const W seen = ak ? (((ak & ((W)0 - ak)) << 1) - 1u) : ~(W)0;
+      legit |= ((walks >> k) & REP & seen) << k;
     }
-    const u32 done = allow | deny;
+    const W done = allow | deny;
     u32 reach = 0;   // deepest chain position a legitimate walk reached, + 1 (0 = none)
     if (legit & ~done) reach = CBH_FLAT_MAX_DEPTH;
     else if (legit) {
-      u32 cand = legit, d = 0;
-      u32 tp = cand & dp3; if (tp) { cand = tp; d |= 8u; }
+      W cand = legit; u32 d = 0;
+      W tp = cand & dp3; if (tp) { cand = tp; d |= 8u; }
       tp = cand & dp2; if (tp) { cand = tp; d |= 4u; }
       tp = cand & dp1; if (tp) { cand = tp; d |= 2u; }
       tp = cand & dp0; if (tp) { cand = tp; d |= 1u; }
@@ -736,9 +762,9 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
       }
     }
     // evaluation errors are a per-request fact: every action of the request
-    if (derr) a_er = 0xFFu;
-    if (dr_unsup) a_un = 0xFFu;
-    if (dwtr) a_wt = 0xFFu;
+    if (derr) a_er = AMASK;
+    if (dr_unsup) a_un = AMASK;
+    if (dwtr) a_wt = AMASK;
   }
 #pragma unroll
   for (u32 k = 0; k < NA; ++k)
@@ -783,20 +809,25 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
 #define CBH_W2_ATTRS
 #endif
 // the walk: four independent waves to a workgroup, no evaluator call
-__global__ CBH_W2_ATTRS void cbh_walk2_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+template <u32 NR>
+__device__ __forceinline__ void w2_walk_kernel_body(const KernelArgs& a, const KernelArgs* __restrict__ ka) {
   const u32 ncc = a.t.inline_cols;   // no generic program runs here: only the columns the inline leaf code reads are parked in LDS
   const W2Layout ly = w2_layout(ncc, false, a.t.max_depth, a.t.n_scopes, false, 0, a.t.K, a.t.n_dr);
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
         (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * ly.wave_dw, ncc, ka};
-  w2_body<false>(a, c, ly);
+  w2_body<false, CBH_W2_NA, NR>(a, c, ly);
 }
+__global__ CBH_W2_ATTRS void cbh_walk2_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_walk_kernel_body<CBH_W2_NR>(a, ka); }
+// the same walk for the requests with five to eight roles: 64-bit walk vectors (launched over the part of a batch that has any, CBH_FI_SKIP_WIDE)
+__global__ CBH_W2_ATTRS void cbh_walk2_wide_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_walk_kernel_body<CBH_W2_WIDE_NR>(a, ka); }
 // the pre-pass: one wave to a workgroup, the shared evaluator with its operand stack (cbh_check_wave.h generic_kernel_body)
 #if defined(CBH_PRE_WPE) && !defined(CBH_HOSTSIM)   /* lab: occupancy target of the pre-pass */
 #define CBH_PRE_WAVES __attribute__((amdgpu_waves_per_eu(CBH_PRE_WPE, CBH_PRE_WPE)))
 #else
 #define CBH_PRE_WAVES
 #endif
-__global__ __launch_bounds__(CBH_BLOCK) CBH_PRE_WAVES void cbh_walk2_pre_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+template <u32 NR>
+__device__ __forceinline__ void w2_pre_kernel_body(const KernelArgs& a, const KernelArgs* __restrict__ ka) {
   __shared__ u64 s_val[CBH_STACK_DEPTH * CBH_BLOCK];
   __shared__ u64 l_val[CBH_MAX_LOCALS * CBH_BLOCK];
   __shared__ u64 it_cont[CBH_MAX_ITERS * CBH_BLOCK];
@@ -816,11 +847,14 @@ __global__ __launch_bounds__(CBH_BLOCK) CBH_PRE_WAVES void cbh_walk2_pre_kernel(
         (CBH_L u64*)s_val, (CBH_L u8*)s_tag, (CBH_L u64*)l_val, (CBH_L u8*)l_tag,
         (CBH_L u64*)it_cont, (CBH_L u32*)it_idx, (CBH_L u32*)it_state,
         (CBH_L u32*)cbh_dyn_lds, ncc, ka};
-  w2_body<true>(a, c, ly);
+  w2_body<true, CBH_W2_NA, NR>(a, c, ly);
 }
+__global__ __launch_bounds__(CBH_BLOCK) CBH_PRE_WAVES void cbh_walk2_pre_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_pre_kernel_body<CBH_W2_NR>(a, ka); }
+__global__ __launch_bounds__(CBH_BLOCK) CBH_PRE_WAVES void cbh_walk2_pre_wide_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_pre_kernel_body<CBH_W2_WIDE_NR>(a, ka); }
 
 // Does cbh_walk2_kernel decide this table's batches?  (CBH_MF_WALK2; not strict mode, whose immediate DENYs are order
-// dependent.)  Requests with more than eight actions or four roles are left to the general walk, lane by lane (CBH_FI_*).
+// dependent.)  Requests with five to eight roles take the walk's wider form, requests with more than eight actions or
+// roles are left to the general walk, lane by lane (CBH_FI_*).
 static inline bool cbh_walk2_applies(u32 table_flags, u32 eval_flags) {
   return (table_flags & CBH_MF_WALK2) && !(eval_flags & CBH_F_STRICT_EVALUATION);
 }
@@ -832,16 +866,19 @@ struct CbhPlan {
   u32 threads;                   // workgroup size of `kernel`
   u32 n_gwords;                  // kind 2: 64-bit words of evaluation-site results per request (0 = no pre-pass)
   u32 n_gslots;                  // ... the sites filed: slots 0 .. n - 1 (the generic ones only for a batch of plain values)
-  cbh_check_kernel_fn wide_kernel;   // kind 2, batch with requests wider than the walk's shape: the general walk's kernel for those (else null)
+  cbh_check_kernel_fn wide_kernel;   // kind 2, batch with requests wider than the walk's shapes: the general walk's kernel for those (else null)
+  bool walk_wide;                    // kind 2, batch with requests of five to eight roles: cbh_walk2_wide_kernel (+ its pre-pass) for those
 };
 static inline CbhPlan cbh_plan(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 gslots_generic, u32 gslots_all, u32 max_actions,
-                               u32 max_roles, bool plain_tags, u32 eval_flags, bool no_flat, bool no_walk2, u32 max_bucket) {
-  CbhPlan p; p.n_gwords = 0; p.n_gslots = 0; p.wide_kernel = nullptr;
+                               u32 max_roles, bool plain_tags, u32 eval_flags, bool no_flat, bool no_walk2, u32 max_bucket, bool no_walk2_wide = false) {
+  CbhPlan p; p.n_gwords = 0; p.n_gslots = 0; p.wide_kernel = nullptr; p.walk_wide = false;
   bool flat = false;
   p.kernel = cbh_pick_kernel(no_flat ? (table_flags & ~(u32)CBH_MF_FLAT) : table_flags, n_derived_roles, has_globs, max_actions, max_roles, plain_tags, eval_flags, max_bucket, &p.threads, &flat);
   p.kind = flat ? 1 : 0;
   if (!flat && !no_walk2 && cbh_walk2_applies(table_flags, eval_flags)) {
-    if (max_actions > CBH_W2_NA || max_roles > CBH_W2_NR) p.wide_kernel = p.kernel;
+    const bool beyond_base = max_actions > CBH_W2_NA || max_roles > CBH_W2_NR, beyond_wide = max_actions > CBH_W2_NA || max_roles > CBH_W2_WIDE_NR;
+    p.walk_wide = beyond_base && max_roles > CBH_W2_NR && !no_walk2_wide;
+    if (beyond_wide || (beyond_base && !p.walk_wide)) p.wide_kernel = p.kernel;
     p.kind = 2; p.kernel = cbh_walk2_kernel; p.threads = CBH_W2_THREADS;
     p.n_gwords = w2_gwords(gslots_generic, gslots_all, plain_tags);
     p.n_gslots = plain_tags ? gslots_generic : gslots_all;

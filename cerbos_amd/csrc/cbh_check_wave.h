@@ -428,8 +428,10 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   const u32 rix = b.req_lo + blockIdx.x * CBH_BLOCK + threadIdx.x;
   const u32 NR = b.n_requests;
   bool valid = rix < b.req_hi;
-  if ((flags & CBH_FI_ONLY_WIDE) && valid)   // the requests cbh_walk2_kernel decides are not this launch's (cbh_vm.h CBH_FI_*)
-    valid = cbh_is_wide(b.req_u32[(size_t)CBH_RQ_ACT_CNT * NR + rix], b.req_u32[(size_t)CBH_RQ_ROLE_CNT * NR + rix]);
+  if ((flags & (CBH_FI_ONLY_WIDE | CBH_FI_ONLY_WIDER)) && valid) {   // the requests the cbh_walk2 kernels decide are not this launch's (cbh_vm.h CBH_FI_*)
+    const u32 na = b.req_u32[(size_t)CBH_RQ_ACT_CNT * NR + rix], nr = b.req_u32[(size_t)CBH_RQ_ROLE_CNT * NR + rix];
+    valid = (flags & CBH_FI_ONLY_WIDER) ? cbh_is_wider(na, nr) : cbh_is_wide(na, nr);
+  }
   const u32 req = valid ? rix : b.req_lo;   // tail lanes shadow the chunk's first request and never store
 #define RQ(f) b.req_u32[(size_t)(f) * NR + req]
   const u32 pid = RQ(CBH_RQ_PRINCIPAL_ID);

@@ -573,13 +573,14 @@ static void collect_times(Replica* r) {   // after the stream has been synchroni
   for (auto& sl : r->ring) collect_slot(r, sl);
 }
 
-// CBH_NO_FLAT=1 / CBH_NO_WALK2=1 (measurement aids): leave the flat kernels / cbh_walk2_kernel out of the choice
+// CBH_NO_FLAT=1 / CBH_NO_WALK2=1 / CBH_NO_WALK2_WIDE=1 (measurement aids): leave the flat kernels / cbh_walk2_kernel out of the choice
 static CbhPlan plan_for(const TableDev& dev, u32 max_actions, u32 max_roles, bool plain_tags, u32 eval_flags) {
   static const bool no_flat = getenv("CBH_NO_FLAT") != nullptr, no_walk2 = getenv("CBH_NO_WALK2") != nullptr;
+  static const bool no_walk2_wide = getenv("CBH_NO_WALK2_WIDE") != nullptr;   // (measurement aid: requests with five to eight roles on the general walk, as before the wider shape)
   const bool has_globs = (dev.nfa_words[0] | dev.nfa_words[1] | dev.nfa_words[2]) != 0 || (dev.flags & CBH_MF_HAS_ANY_PATTERN);
   static const bool force_staged = getenv("CBH_FORCE_STAGED") != nullptr;   // (tests: the staged record walk on tables of any size)
   return cbh_plan(dev.flags, dev.n_dr, has_globs, dev.gslots_generic, dev.gslots_all, max_actions, max_roles, plain_tags, eval_flags, no_flat, no_walk2,
-                  force_staged ? 0xFFFFFFFFu : dev.max_bucket);
+                  force_staged ? 0xFFFFFFFFu : dev.max_bucket, no_walk2_wide);
 }
 // the launches that decide the requests [lo, hi) of `ka.b`; [wide_lo, wide_hi) = where the batch's requests wider than
 // cbh_walk2_kernel's shape lie (empty: none)
@@ -596,14 +597,22 @@ static void launch_plan(const CbhPlan& pl, const TableDev& dev, KernelArgs ka, c
     else hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, s, a, d_args);
   };
   if (pl.kind == 2) {
-    if (pl.wide_kernel) {   // the few wider requests: the general walk, on the lanes the walk below leaves alone
+    const u32 wlo = std::max(lo, wide_lo), whi = std::min(hi, wide_hi);   // where the requests wider than the base shape lie
+    if (pl.wide_kernel) {   // the few requests wider than the walk's shapes: the general walk, on the lanes the walks below leave alone
       KernelArgs kw = ka;
-      kw.b.req_lo = std::max(lo, wide_lo); kw.b.req_hi = std::min(hi, wide_hi);
-      kw.flags |= CBH_FI_ONLY_WIDE;
-      if (kw.b.req_hi > kw.b.req_lo) go(pl.wide_kernel, (kw.b.req_hi - kw.b.req_lo + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, cbh_general_lds(dev.flags, ka.b.n_columns), kw, false);
-      ka.flags |= CBH_FI_SKIP_WIDE;
+      kw.b.req_lo = wlo; kw.b.req_hi = whi;
+      kw.flags |= pl.walk_wide ? CBH_FI_ONLY_WIDER : CBH_FI_ONLY_WIDE;
+      if (whi > wlo) go(pl.wide_kernel, (whi - wlo + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, cbh_general_lds(dev.flags, ka.b.n_columns), kw, false);
     }
+    if (pl.wide_kernel || pl.walk_wide) ka.flags |= CBH_FI_SKIP_WIDE;
     ka.b.n_gwords = ka.b.gres ? pl.n_gwords : 0; ka.b.n_gslots = ka.b.gres ? pl.n_gslots : 0;
+    if (pl.walk_wide && whi > wlo) {   // the requests with five to eight roles: the walk's wider form (and its pre-pass), over their part of the batch
+      KernelArgs kv = ka;
+      kv.b.req_lo = wlo; kv.b.req_hi = whi;
+      if (kv.b.n_gwords)
+        go(cbh_walk2_pre_wide_kernel, (whi - wlo + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, dev.n_dr, true), kv, false);
+      go(cbh_walk2_wide_kernel, (whi - wlo + pl.threads - 1) / pl.threads, pl.threads, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, dev.n_dr, false), kv, false);
+    }
     if (ka.b.n_gwords)   // the evaluation sites first: their results are what the walk reads
       go(cbh_walk2_pre_kernel, (n + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, dev.n_dr, true), ka, false);
   }
@@ -693,7 +702,7 @@ extern "C" const char* cbh_plan_describe(cbh_table* t, cbh_device_batch* b, cons
   static thread_local std::string s;
   if (!t || !b || !p) return "";
   const CbhPlan pl = plan_for(b->rep->dev, b->max_actions, b->max_roles, b->plain_tags, p->flags & ~(u32)CBH_FI_MASK);
-  if (pl.kind == 2) s = std::string(pl.wide_kernel ? "cbh_check_kernel*(wide requests)+" : "") + (pl.n_gwords && b->dev.gres ? "cbh_walk2_pre_kernel+" : "") + "cbh_walk2_kernel";
+  if (pl.kind == 2) s = std::string(pl.wide_kernel ? "cbh_check_kernel*(wide requests)+" : "") + (pl.walk_wide ? "cbh_walk2_wide_kernel(5-8 roles)+" : "") + (pl.n_gwords && b->dev.gres ? "cbh_walk2_pre_kernel+" : "") + "cbh_walk2_kernel";
   else if (pl.kind == 1) s = pl.kernel == cbh_check_flat_kernel ? "cbh_check_flat_kernel" : pl.kernel == cbh_check_flat_kernel_any ? "cbh_check_flat_kernel_any"
                            : pl.kernel == cbh_check_flat_kernel_staged ? "cbh_check_flat_kernel_staged" : "cbh_check_flat_kernel_any_staged";
   else s = "cbh_check_kernel*";

@@ -102,14 +102,19 @@ struct OutDev {
 struct __attribute__((aligned(16))) KernelArgs { TableDev t; BatchDev b; OutDev o; long long now_ns; u32 flags; u32 pad; };
 
 // Internal launch flags (KernelArgs.flags; never part of cbh_params.flags - the entry points mask them off): a batch whose
-// requests mostly fit cbh_walk2_kernel's shape (<= 8 actions, <= 4 roles) is decided by it, and the few wider requests
-// by the general walk in a launch of its own over the same arrays - each kernel leaves the other's lanes alone.
-#define CBH_FI_SKIP_WIDE 0x10000u   /* cbh_walk2_kernel / its pre-pass: a wider request is not this launch's */
-#define CBH_FI_ONLY_WIDE 0x20000u   /* cbh_check_kernel*: only the wider requests are this launch's */
-#define CBH_FI_MASK 0x30000u
+// requests mostly fit cbh_walk2_kernel's shape (<= 8 actions, <= 4 roles) is decided by it; the requests with more roles
+// (<= 8) by the same walk in its wider form (cbh_walk2_wide_kernel: 64-bit walk vectors), and the few still wider ones by
+// the general walk - each in a launch of its own over the same arrays, each kernel leaving the others' lanes alone.
+#define CBH_FI_SKIP_WIDE 0x10000u   /* cbh_walk2_kernel / its pre-pass: a request wider than the base shape is not this launch's; */
+                                    /* cbh_walk2_wide_kernel / its pre-pass: only those that fit the wider shape are               */
+#define CBH_FI_ONLY_WIDE 0x20000u   /* cbh_check_kernel*: only the requests wider than the base shape are this launch's */
+#define CBH_FI_ONLY_WIDER 0x40000u  /* cbh_check_kernel*: only the requests wider than the WIDER shape are this launch's */
+#define CBH_FI_MASK 0x70000u
 #define CBH_W2_NA 8u
 #define CBH_W2_NR 4u
+#define CBH_W2_WIDE_NR 8u           /* roles of the wider shape (actions: CBH_W2_NA) */
 __device__ __forceinline__ bool cbh_is_wide(u32 act_cnt, u32 role_cnt) { return act_cnt > CBH_W2_NA || role_cnt > CBH_W2_NR; }
+__device__ __forceinline__ bool cbh_is_wider(u32 act_cnt, u32 role_cnt) { return act_cnt > CBH_W2_NA || role_cnt > CBH_W2_WIDE_NR; }
 
 struct Val { u32 t; u64 v; };
 

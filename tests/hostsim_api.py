@@ -39,6 +39,7 @@ def lib():
         _lib.hostsim_trace.restype = C.c_int
         _lib.hostsim_last_error.restype = C.c_char_p
         _lib.hostsim_last_kind.restype = C.c_int
+        _lib.hostsim_last_walk_wide.restype = C.c_int
     return _lib
 
 
@@ -70,6 +71,11 @@ def check(lt, batch, now_ns=0, flags=0, device_order=False):
 def last_kind():
     """Which kernel family decided the last batch: 0 the general walk, 1 a flat kernel, 2 cbh_walk2_kernel."""
     return lib().hostsim_last_kind()
+
+
+def last_walk_wide():
+    """Did the last batch launch cbh_walk2_wide_kernel (requests with five to eight roles)?"""
+    return bool(lib().hostsim_last_walk_wide())
 
 
 def trace(lt, batch, now_ns=0, flags=0, capacity=None):

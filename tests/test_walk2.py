@@ -43,6 +43,7 @@ def _both_kernels(lt, batch, flags):
     the error status per request."""
     new = hostsim_api.check(lt, batch, NOW, flags, device_order=True)
     assert hostsim_api.last_kind() == 2, "the table / batch must run on cbh_walk2_kernel (refused: %s)" % lt.stats["walk2_refused"]
+    _both_kernels.walk_wide = hostsim_api.last_walk_wide()   # did cbh_walk2_wide_kernel take part?
     with _NoWalk2():
         old = hostsim_api.check(lt, batch, NOW, flags, device_order=True)
         assert hostsim_api.last_kind() != 2
@@ -116,6 +117,93 @@ def test_fuzz_stores_walk2_vs_general_walk_vs_oracle(seed):
         _both_kernels(lt, batch, capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0))
         compared, _ = _against_oracle(rt, lt, _hostsim, inputs, lenient)
         assert compared > 120
+
+
+# ---------------------------------------------------------------------------------------------------------- the wider shape
+def _more_roles(rng, inputs, pool, share=0.5):
+    """Give a share of the requests five to ten roles (the request's own first, then names of the pool and names no
+    policy knows, shuffled): five to eight take cbh_walk2_wide_kernel, more than eight stay on the general walk."""
+    out = []
+    for inp in inputs:
+        inp = dict(inp, principal=dict(inp["principal"]))
+        if rng.random() < share:
+            have = list(inp["principal"]["roles"])
+            extra = [r for r in pool + ["nobody%d" % k for k in range(6)] if r not in have]
+            rng.shuffle(extra)
+            n = int(rng.choice([5, 6, 7, 8, 9, 10], p=[0.25, 0.2, 0.2, 0.2, 0.1, 0.05]))
+            roles = have + extra[:max(0, n - len(have))]
+            rng.shuffle(roles)
+            inp["principal"]["roles"] = [str(r) for r in roles]
+        out.append(inp)
+    return out
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_stores_requests_with_five_to_eight_roles(seed):
+    """The fuzz stores with requests of up to ten roles: cbh_walk2_wide_kernel (64-bit walk vectors) against the general
+    walk tuple by tuple and against the oracle."""
+    rng = np.random.default_rng(79_000 + seed)
+    rt = rule_table_from_policies(policies_from_docs(_policies(rng)))
+    try:
+        lt = lower_rule_table(rt)
+    except LoweringError:
+        pytest.skip("store refused by the lowering (history-dependent reference behaviour)")
+    if not lt.stats["walk2"]:
+        pytest.skip("table stays on the general walk: %s" % lt.stats["walk2_refused"])
+    from test_fuzz_parity import ROLES
+    inputs = _more_roles(rng, _requests(rng, 200), ROLES + ["other"])
+    batch = Flattener(lt).flatten(inputs)
+    assert 4 < int(batch.req_u32[7].max())
+    for lenient in (False, True):
+        _both_kernels(lt, batch, capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0))
+        assert _both_kernels.walk_wide
+        compared, _ = _against_oracle(rt, lt, _hostsim, inputs, lenient)
+        assert compared > 100
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_role_policy_chains_with_five_to_eight_roles(seed):
+    rng = np.random.default_rng(89_000 + seed)
+    docs, acts = _role_policy_store(rng)
+    rt = rule_table_from_policies(policies_from_docs(docs))
+    try:
+        lt = lower_rule_table(rt)
+    except LoweringError:
+        pytest.skip("store refused by the lowering")
+    inputs = _more_roles(rng, _role_policy_requests(rng, acts, 220), ["staff", "lead", "temp", "vendor", "intern"], share=0.6)
+    batch = Flattener(lt).flatten(inputs)
+    for lenient in (False, True):
+        _both_kernels(lt, batch, capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0))
+        assert _both_kernels.walk_wide
+        _against_oracle(rt, lt, _hostsim, inputs, lenient)
+
+
+def test_only_wide_requests_and_base_only_batches_take_one_walk_each():
+    """A batch whose requests all have five to eight roles launches the wider walk alone beside an idle base walk; a batch
+    without such requests never launches it; CBH_NO_WALK2_WIDE=1 sends them to the general walk as before - same words."""
+    rng = np.random.default_rng(5)
+    rt = rule_table_from_policies(policies_from_docs(workloads.c5_policies()))
+    lt = lower_rule_table(rt)
+    base = workloads.c5_requests(300, seed=3).to_inputs()
+    batch = Flattener(lt).flatten(base)
+    hostsim_api.check(lt, batch, NOW, capi.F_WANT_DERIVED_ROLES, device_order=True)
+    assert hostsim_api.last_kind() == 2 and not hostsim_api.last_walk_wide()
+    pool = sorted({r for i in base for r in i["principal"]["roles"]})
+    wide = _more_roles(rng, base, pool, share=1.0)
+    wide = [i for i in wide if len(i["principal"]["roles"]) <= 8]
+    batch = Flattener(lt).flatten(wide)
+    assert int(batch.req_u32[7].min()) >= 5 and int(batch.req_u32[7].max()) == 8
+    new = _both_kernels(lt, batch, capi.F_WANT_DERIVED_ROLES)
+    assert _both_kernels.walk_wide
+    os.environ["CBH_NO_WALK2_WIDE"] = "1"
+    try:
+        old = hostsim_api.check(lt, batch, NOW, capi.F_WANT_DERIVED_ROLES, device_order=True)
+        assert hostsim_api.last_kind() == 2 and not hostsim_api.last_walk_wide()
+    finally:
+        os.environ.pop("CBH_NO_WALK2_WIDE", None)
+    for f in ("effect", "policy", "scope", "edr", "status"):
+        assert np.array_equal(getattr(new, f), getattr(old, f)), f
+    _against_oracle(rt, lt, _hostsim, wide)
 
 
 # ---------------------------------------------------------------------------------------------------------- targeted
@@ -306,6 +394,47 @@ def test_gpu_fuzz_stores(seed):
     inputs = _requests(rng, 220)
     for lenient in (False, True):
         _against_oracle(rt, lt, lambda l: HipEvaluator(l, Conf()), inputs, lenient)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_gpu_requests_with_five_to_eight_roles(seed):
+    """cbh_walk2_wide_kernel on the device: the fuzz stores and the role-policy chains with requests of up to ten roles,
+    one-shot (cbh_check_batch) against the oracle and resident (cbh_check_resident: the plan must name the wider walk)."""
+    from test_fuzz_parity import ROLES
+    rng = np.random.default_rng(79_000 + seed)
+    if seed % 2:
+        docs, acts = _role_policy_store(rng)
+        make = lambda: _more_roles(rng, _role_policy_requests(rng, acts, 220), ["staff", "lead", "temp", "vendor", "intern"], share=0.6)   # noqa: E731
+    else:
+        docs = _policies(rng)
+        make = lambda: _more_roles(rng, _requests(rng, 200), ROLES + ["other"])   # noqa: E731
+    rt = rule_table_from_policies(policies_from_docs(docs))
+    try:
+        lt = lower_rule_table(rt)
+    except LoweringError:
+        pytest.skip("store refused by the lowering")
+    if not lt.stats["walk2"]:
+        pytest.skip("table stays on the general walk: %s" % lt.stats["walk2_refused"])
+    inputs = make()
+    for lenient in (False, True):
+        _against_oracle(rt, lt, lambda l: HipEvaluator(l, Conf()), inputs, lenient)
+    # resident: the same batch by cbh_check_resident, word for word what the one-shot call returned
+    table = capi.Table(lt.blob)
+    try:
+        batch = Flattener(lt).flatten(inputs)
+        flags = capi.F_WANT_DERIVED_ROLES
+        one = table.check(batch, now_ns=NOW, flags=flags)
+        db = table.upload(batch)
+        assert "cbh_walk2_wide_kernel" in table.plan(db, flags)
+        table.launch(db, now_ns=NOW, flags=flags)
+        table.synchronize()
+        res = table.download(db)
+        for f in ("effect", "policy", "scope", "status", "edr"):
+            assert np.array_equal(getattr(res, f), getattr(one, f)), f
+        db.close()
+    finally:
+        table.close()
 
 
 # ---------------------------------------------------------------------------------------------------------- trace marks
