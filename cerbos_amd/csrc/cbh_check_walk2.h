@@ -42,13 +42,13 @@ struct W2Layout { u32 cc_dw, arena_dw, chain_dw, aux_dw, gacc_dw, edr_dw, wave_d
 #ifndef CBH_HOSTSIM
 __host__ __device__
 #endif
-static inline W2Layout w2_layout(u32 ncc, bool arena, u32 table_max_depth, u32 table_scopes, bool pre, u32 n_gwords, u32 table_strings, u32 table_n_dr) {
+static inline W2Layout w2_layout(u32 ncc, bool arena, u32 table_max_depth, u32 table_scopes, bool pre, u32 n_gwords, u32 table_strings, u32 table_n_dr, u32 na = CBH_W2_NA) {
   W2Layout l;
   const u32 depth = table_max_depth < CBH_FLAT_MAX_DEPTH ? table_max_depth : CBH_FLAT_MAX_DEPTH;
   l.cc_dw = 3u * ncc * CBH_BLOCK;
   l.arena_dw = (pre && arena) ? CBH_ARENA_ENTRIES * CBH_BLOCK * 9u / 4u : 0u;
   l.chain_dw = pre ? 0u : (table_scopes <= 256u ? depth * (CBH_BLOCK / 4u) : depth * CBH_BLOCK);
-  l.aux_dw = pre ? 0u : CBH_W2_NA * CBH_BLOCK;
+  l.aux_dw = pre ? 0u : na * CBH_BLOCK;
   l.gacc_dw = pre ? n_gwords * CBH_BLOCK * 2u : 0u;
   l.edr_dw = 0u; (void)table_n_dr;
   l.wave_dw = l.cc_dw + l.arena_dw + l.chain_dw + l.aux_dw + l.gacc_dw + l.edr_dw;
@@ -64,13 +64,13 @@ static inline u32 w2_gwords(u32 gslots_generic, u32 gslots_all, bool plain_tags)
 }
 
 // The shape of a walk: NA actions x NR roles, one bit per (role, action) pair in a walk vector W - 32 bits for the base
-// shape (8 x 4), 64 for the wider one (8 x 8: the requests with five to eight roles).  Bit NA r + k = role r's walk for
-// action k.
+// shape (8 x 4), 64 for the wider ones (8 x 8: the requests with five to eight roles; 16 x 4: those with nine to sixteen
+// actions).  Bit NA r + k = role r's walk for action k.
 template <bool WIDE> struct W2Word { typedef u32 type; };
 template <> struct W2Word<true> { typedef u64 type; };
 template <u32 NA, u32 NR> struct W2Shape {
   static_assert(NA * NR == 32u || NA * NR == 64u, "a walk vector is one or two dwords");
-  static_assert(NA <= 8u && NR <= 8u, "per-action words (effect, status) and the role index of a note are sized for eight");
+  static_assert(NA <= 16u && NR <= 8u, "glob bits of two actions to a dword; the role index of a note has three bits to spare");
   typedef typename W2Word<(NA * NR > 32u)>::type W;
   static constexpr W rep() { W m = 0; for (u32 r = 0; r < NR; ++r) m |= (W)1 << (NA * r); return m; }   // bit 0 of every role's field
 };
@@ -113,7 +113,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   bool valid = rix < b.req_hi;
   if ((flags & CBH_FI_SKIP_WIDE) && valid) {   // wave-uniform test first: the two loads only for a batch that has wider requests
     const u32 na = b.req_u32[(size_t)CBH_RQ_ACT_CNT * NRQ + rix], nr = b.req_u32[(size_t)CBH_RQ_ROLE_CNT * NRQ + rix];
-    valid = NR == CBH_W2_NR ? !cbh_is_wide(na, nr) : (cbh_is_wide(na, nr) && !cbh_is_wider(na, nr));   // base shape : the wider one
+    valid = cbh_w2_class(na, nr) == (NA > CBH_W2_NA ? 2u : NR > CBH_W2_NR ? 1u : 0u);   // the requests of this shape's class
   }
   const u32 req = valid ? rix : b.req_lo;
   const bool has_pp = (t.flags & CBH_MF_HAS_PRINCIPAL_POLICIES) != 0;
@@ -809,24 +809,26 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
 #define CBH_W2_ATTRS
 #endif
 // the walk: four independent waves to a workgroup, no evaluator call
-template <u32 NR>
+template <u32 NA, u32 NR>
 __device__ __forceinline__ void w2_walk_kernel_body(const KernelArgs& a, const KernelArgs* __restrict__ ka) {
   const u32 ncc = a.t.inline_cols;   // no generic program runs here: only the columns the inline leaf code reads are parked in LDS
-  const W2Layout ly = w2_layout(ncc, false, a.t.max_depth, a.t.n_scopes, false, 0, a.t.K, a.t.n_dr);
+  const W2Layout ly = w2_layout(ncc, false, a.t.max_depth, a.t.n_scopes, false, 0, a.t.K, a.t.n_dr, NA);
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
         (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * ly.wave_dw, ncc, ka};
-  w2_body<false, CBH_W2_NA, NR>(a, c, ly);
+  w2_body<false, NA, NR>(a, c, ly);
 }
-__global__ CBH_W2_ATTRS void cbh_walk2_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_walk_kernel_body<CBH_W2_NR>(a, ka); }
-// the same walk for the requests with five to eight roles: 64-bit walk vectors (launched over the part of a batch that has any, CBH_FI_SKIP_WIDE)
-__global__ CBH_W2_ATTRS void cbh_walk2_wide_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_walk_kernel_body<CBH_W2_WIDE_NR>(a, ka); }
+__global__ CBH_W2_ATTRS void cbh_walk2_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_walk_kernel_body<CBH_W2_NA, CBH_W2_NR>(a, ka); }
+// the same walk for the requests with five to eight roles, and for those with nine to sixteen actions: 64-bit walk vectors
+// (launched over the part of a batch that has any, CBH_FI_SKIP_WIDE)
+__global__ CBH_W2_ATTRS void cbh_walk2_wide_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_walk_kernel_body<CBH_W2_NA, CBH_W2_WIDE_NR>(a, ka); }
+__global__ CBH_W2_ATTRS void cbh_walk2_awide_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_walk_kernel_body<CBH_W2_AWIDE_NA, CBH_W2_NR>(a, ka); }
 // the pre-pass: one wave to a workgroup, the shared evaluator with its operand stack (cbh_check_wave.h generic_kernel_body)
 #if defined(CBH_PRE_WPE) && !defined(CBH_HOSTSIM)   /* lab: occupancy target of the pre-pass */
 #define CBH_PRE_WAVES __attribute__((amdgpu_waves_per_eu(CBH_PRE_WPE, CBH_PRE_WPE)))
 #else
 #define CBH_PRE_WAVES
 #endif
-template <u32 NR>
+template <u32 NA, u32 NR>
 __device__ __forceinline__ void w2_pre_kernel_body(const KernelArgs& a, const KernelArgs* __restrict__ ka) {
   __shared__ u64 s_val[CBH_STACK_DEPTH * CBH_BLOCK];
   __shared__ u64 l_val[CBH_MAX_LOCALS * CBH_BLOCK];
@@ -847,14 +849,15 @@ __device__ __forceinline__ void w2_pre_kernel_body(const KernelArgs& a, const Ke
         (CBH_L u64*)s_val, (CBH_L u8*)s_tag, (CBH_L u64*)l_val, (CBH_L u8*)l_tag,
         (CBH_L u64*)it_cont, (CBH_L u32*)it_idx, (CBH_L u32*)it_state,
         (CBH_L u32*)cbh_dyn_lds, ncc, ka};
-  w2_body<true, CBH_W2_NA, NR>(a, c, ly);
+  w2_body<true, NA, NR>(a, c, ly);
 }
-__global__ __launch_bounds__(CBH_BLOCK) CBH_PRE_WAVES void cbh_walk2_pre_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_pre_kernel_body<CBH_W2_NR>(a, ka); }
-__global__ __launch_bounds__(CBH_BLOCK) CBH_PRE_WAVES void cbh_walk2_pre_wide_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_pre_kernel_body<CBH_W2_WIDE_NR>(a, ka); }
+__global__ __launch_bounds__(CBH_BLOCK) CBH_PRE_WAVES void cbh_walk2_pre_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_pre_kernel_body<CBH_W2_NA, CBH_W2_NR>(a, ka); }
+__global__ __launch_bounds__(CBH_BLOCK) CBH_PRE_WAVES void cbh_walk2_pre_wide_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_pre_kernel_body<CBH_W2_NA, CBH_W2_WIDE_NR>(a, ka); }
+__global__ __launch_bounds__(CBH_BLOCK) CBH_PRE_WAVES void cbh_walk2_pre_awide_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_pre_kernel_body<CBH_W2_AWIDE_NA, CBH_W2_NR>(a, ka); }
 
 // Does cbh_walk2_kernel decide this table's batches?  (CBH_MF_WALK2; not strict mode, whose immediate DENYs are order
-// dependent.)  Requests with five to eight roles take the walk's wider form, requests with more than eight actions or
-// roles are left to the general walk, lane by lane (CBH_FI_*).
+// dependent.)  Requests with five to eight roles or nine to sixteen actions take the walk's wider forms, what is wider
+// still is left to the general walk, lane by lane (CBH_FI_*, cbh_w2_class).
 static inline bool cbh_walk2_applies(u32 table_flags, u32 eval_flags) {
   return (table_flags & CBH_MF_WALK2) && !(eval_flags & CBH_F_STRICT_EVALUATION);
 }
@@ -868,17 +871,21 @@ struct CbhPlan {
   u32 n_gslots;                  // ... the sites filed: slots 0 .. n - 1 (the generic ones only for a batch of plain values)
   cbh_check_kernel_fn wide_kernel;   // kind 2, batch with requests wider than the walk's shapes: the general walk's kernel for those (else null)
   bool walk_wide;                    // kind 2, batch with requests of five to eight roles: cbh_walk2_wide_kernel (+ its pre-pass) for those
+  bool walk_awide;                   // kind 2, batch with requests of nine to sixteen actions: cbh_walk2_awide_kernel (+ its pre-pass) for those
 };
 static inline CbhPlan cbh_plan(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 gslots_generic, u32 gslots_all, u32 max_actions,
                                u32 max_roles, bool plain_tags, u32 eval_flags, bool no_flat, bool no_walk2, u32 max_bucket, bool no_walk2_wide = false) {
-  CbhPlan p; p.n_gwords = 0; p.n_gslots = 0; p.wide_kernel = nullptr; p.walk_wide = false;
+  CbhPlan p; p.n_gwords = 0; p.n_gslots = 0; p.wide_kernel = nullptr; p.walk_wide = false; p.walk_awide = false;
   bool flat = false;
   p.kernel = cbh_pick_kernel(no_flat ? (table_flags & ~(u32)CBH_MF_FLAT) : table_flags, n_derived_roles, has_globs, max_actions, max_roles, plain_tags, eval_flags, max_bucket, &p.threads, &flat);
   p.kind = flat ? 1 : 0;
   if (!flat && !no_walk2 && cbh_walk2_applies(table_flags, eval_flags)) {
-    const bool beyond_base = max_actions > CBH_W2_NA || max_roles > CBH_W2_NR, beyond_wide = max_actions > CBH_W2_NA || max_roles > CBH_W2_WIDE_NR;
-    p.walk_wide = beyond_base && max_roles > CBH_W2_NR && !no_walk2_wide;
-    if (beyond_wide || (beyond_base && !p.walk_wide)) p.wide_kernel = p.kernel;
+    // (the batch's maxima only: a launch that finds no request of its class costs a few idle waves)
+    p.walk_wide = max_roles > CBH_W2_NR && !no_walk2_wide;
+    p.walk_awide = max_actions > CBH_W2_NA && !no_walk2_wide;
+    const bool beyond_base = max_actions > CBH_W2_NA || max_roles > CBH_W2_NR;
+    const bool beyond_all = max_actions > CBH_W2_AWIDE_NA || max_roles > CBH_W2_WIDE_NR || (max_actions > CBH_W2_NA && max_roles > CBH_W2_NR);
+    if (no_walk2_wide ? beyond_base : beyond_all) p.wide_kernel = p.kernel;
     p.kind = 2; p.kernel = cbh_walk2_kernel; p.threads = CBH_W2_THREADS;
     p.n_gwords = w2_gwords(gslots_generic, gslots_all, plain_tags);
     p.n_gslots = plain_tags ? gslots_generic : gslots_all;
@@ -891,9 +898,9 @@ static inline size_t cbh_general_lds(u32 table_flags, u32 n_columns) {
   return (size_t)ncc * CBH_BLOCK * 12 + ((table_flags & CBH_MF_NEEDS_ARENA) ? (size_t)CBH_ARENA_ENTRIES * CBH_BLOCK * 9 : 0);
 }
 // dynamic LDS of a launch of `kernel` (pre = the pre-pass of kind 2)
-static inline size_t cbh_plan_lds(const CbhPlan& p, u32 table_flags, u32 table_max_depth, u32 table_scopes, u32 table_strings, u32 n_columns, u32 inline_cols, u32 table_n_dr, bool pre) {
+static inline size_t cbh_plan_lds(const CbhPlan& p, u32 table_flags, u32 table_max_depth, u32 table_scopes, u32 table_strings, u32 n_columns, u32 inline_cols, u32 table_n_dr, bool pre, u32 na = CBH_W2_NA) {
   const u32 ncc = n_columns < CBH_CACHE_COLS ? n_columns : CBH_CACHE_COLS;
-  if (p.kind == 2) return w2_lds_bytes(w2_layout(pre ? ncc : inline_cols, (table_flags & CBH_MF_NEEDS_ARENA) != 0, table_max_depth, table_scopes, pre, p.n_gwords, table_strings, table_n_dr), pre ? 1u : CBH_W2_WAVES);
+  if (p.kind == 2) return w2_lds_bytes(w2_layout(pre ? ncc : inline_cols, (table_flags & CBH_MF_NEEDS_ARENA) != 0, table_max_depth, table_scopes, pre, p.n_gwords, table_strings, table_n_dr, na), pre ? 1u : CBH_W2_WAVES);
   const size_t wave = cbh_general_lds(table_flags, n_columns);
   if (p.kind == 1) return (wave + cbh_flat_chain_bytes(table_max_depth, table_scopes)) * (p.threads / CBH_BLOCK) + cbh_flat_class_bytes(table_strings);
   return wave;

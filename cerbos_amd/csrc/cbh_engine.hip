@@ -601,17 +601,22 @@ static void launch_plan(const CbhPlan& pl, const TableDev& dev, KernelArgs ka, c
     if (pl.wide_kernel) {   // the few requests wider than the walk's shapes: the general walk, on the lanes the walks below leave alone
       KernelArgs kw = ka;
       kw.b.req_lo = wlo; kw.b.req_hi = whi;
-      kw.flags |= pl.walk_wide ? CBH_FI_ONLY_WIDER : CBH_FI_ONLY_WIDE;
+      kw.flags |= (pl.walk_wide || pl.walk_awide) ? CBH_FI_ONLY_WIDER : CBH_FI_ONLY_WIDE;
       if (whi > wlo) go(pl.wide_kernel, (whi - wlo + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, cbh_general_lds(dev.flags, ka.b.n_columns), kw, false);
     }
-    if (pl.wide_kernel || pl.walk_wide) ka.flags |= CBH_FI_SKIP_WIDE;
+    if (pl.wide_kernel || pl.walk_wide || pl.walk_awide) ka.flags |= CBH_FI_SKIP_WIDE;
     ka.b.n_gwords = ka.b.gres ? pl.n_gwords : 0; ka.b.n_gslots = ka.b.gres ? pl.n_gslots : 0;
-    if (pl.walk_wide && whi > wlo) {   // the requests with five to eight roles: the walk's wider form (and its pre-pass), over their part of the batch
+    // the requests with five to eight roles / nine to sixteen actions: the walk's wider forms (and their pre-passes), over their part of the batch
+    for (int shape = 1; shape <= 2 && whi > wlo; ++shape) {
+      if (!(shape == 1 ? pl.walk_wide : pl.walk_awide)) continue;
       KernelArgs kv = ka;
       kv.b.req_lo = wlo; kv.b.req_hi = whi;
+      const u32 na = shape == 1 ? CBH_W2_NA : CBH_W2_AWIDE_NA;
       if (kv.b.n_gwords)
-        go(cbh_walk2_pre_wide_kernel, (whi - wlo + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, dev.n_dr, true), kv, false);
-      go(cbh_walk2_wide_kernel, (whi - wlo + pl.threads - 1) / pl.threads, pl.threads, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, dev.n_dr, false), kv, false);
+        go(shape == 1 ? cbh_walk2_pre_wide_kernel : cbh_walk2_pre_awide_kernel, (whi - wlo + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK,
+           cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, dev.n_dr, true, na), kv, false);
+      go(shape == 1 ? cbh_walk2_wide_kernel : cbh_walk2_awide_kernel, (whi - wlo + pl.threads - 1) / pl.threads, pl.threads,
+         cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, dev.n_dr, false, na), kv, false);
     }
     if (ka.b.n_gwords)   // the evaluation sites first: their results are what the walk reads
       go(cbh_walk2_pre_kernel, (n + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, dev.n_dr, true), ka, false);
@@ -702,7 +707,7 @@ extern "C" const char* cbh_plan_describe(cbh_table* t, cbh_device_batch* b, cons
   static thread_local std::string s;
   if (!t || !b || !p) return "";
   const CbhPlan pl = plan_for(b->rep->dev, b->max_actions, b->max_roles, b->plain_tags, p->flags & ~(u32)CBH_FI_MASK);
-  if (pl.kind == 2) s = std::string(pl.wide_kernel ? "cbh_check_kernel*(wide requests)+" : "") + (pl.walk_wide ? "cbh_walk2_wide_kernel(5-8 roles)+" : "") + (pl.n_gwords && b->dev.gres ? "cbh_walk2_pre_kernel+" : "") + "cbh_walk2_kernel";
+  if (pl.kind == 2) s = std::string(pl.wide_kernel ? "cbh_check_kernel*(wide requests)+" : "") + (pl.walk_wide ? "cbh_walk2_wide_kernel(5-8 roles)+" : "") + (pl.walk_awide ? "cbh_walk2_awide_kernel(9-16 actions)+" : "") + (pl.n_gwords && b->dev.gres ? "cbh_walk2_pre_kernel+" : "") + "cbh_walk2_kernel";
   else if (pl.kind == 1) s = pl.kernel == cbh_check_flat_kernel ? "cbh_check_flat_kernel" : pl.kernel == cbh_check_flat_kernel_any ? "cbh_check_flat_kernel_any"
                            : pl.kernel == cbh_check_flat_kernel_staged ? "cbh_check_flat_kernel_staged" : "cbh_check_flat_kernel_any_staged";
   else s = "cbh_check_kernel*";

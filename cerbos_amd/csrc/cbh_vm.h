@@ -103,18 +103,24 @@ struct __attribute__((aligned(16))) KernelArgs { TableDev t; BatchDev b; OutDev 
 
 // Internal launch flags (KernelArgs.flags; never part of cbh_params.flags - the entry points mask them off): a batch whose
 // requests mostly fit cbh_walk2_kernel's shape (<= 8 actions, <= 4 roles) is decided by it; the requests with more roles
-// (<= 8) by the same walk in its wider form (cbh_walk2_wide_kernel: 64-bit walk vectors), and the few still wider ones by
-// the general walk - each in a launch of its own over the same arrays, each kernel leaving the others' lanes alone.
+// (<= 8) or more actions (<= 16) by the same walk in its wider forms (cbh_walk2_wide_kernel, cbh_walk2_awide_kernel: 64-bit
+// walk vectors), and the few still wider ones by the general walk - each in a launch of its own over the same arrays, each kernel leaving the others' lanes alone.
 #define CBH_FI_SKIP_WIDE 0x10000u   /* cbh_walk2_kernel / its pre-pass: a request wider than the base shape is not this launch's; */
-                                    /* cbh_walk2_wide_kernel / its pre-pass: only those that fit the wider shape are               */
+                                    /* the wider walks / their pre-passes: only the requests of their class are (cbh_w2_class)   */
 #define CBH_FI_ONLY_WIDE 0x20000u   /* cbh_check_kernel*: only the requests wider than the base shape are this launch's */
-#define CBH_FI_ONLY_WIDER 0x40000u  /* cbh_check_kernel*: only the requests wider than the WIDER shape are this launch's */
+#define CBH_FI_ONLY_WIDER 0x40000u  /* cbh_check_kernel*: only the requests no shape of the walk holds are this launch's */
 #define CBH_FI_MASK 0x70000u
 #define CBH_W2_NA 8u
 #define CBH_W2_NR 4u
-#define CBH_W2_WIDE_NR 8u           /* roles of the wider shape (actions: CBH_W2_NA) */
+#define CBH_W2_WIDE_NR 8u           /* the wider shapes: 8 actions x 8 roles (cbh_walk2_wide_kernel) ... */
+#define CBH_W2_AWIDE_NA 16u         /* ... and 16 actions x 4 roles (cbh_walk2_awide_kernel); both carry 64-bit walk vectors */
 __device__ __forceinline__ bool cbh_is_wide(u32 act_cnt, u32 role_cnt) { return act_cnt > CBH_W2_NA || role_cnt > CBH_W2_NR; }
-__device__ __forceinline__ bool cbh_is_wider(u32 act_cnt, u32 role_cnt) { return act_cnt > CBH_W2_NA || role_cnt > CBH_W2_WIDE_NR; }
+// which walk decides a request: 0 the base shape, 1 the shape with more roles, 2 the shape with more actions, 3 none of them (the general walk)
+__device__ __forceinline__ u32 cbh_w2_class(u32 act_cnt, u32 role_cnt) {
+  if (act_cnt <= CBH_W2_NA) return role_cnt <= CBH_W2_NR ? 0u : role_cnt <= CBH_W2_WIDE_NR ? 1u : 3u;
+  return (act_cnt <= CBH_W2_AWIDE_NA && role_cnt <= CBH_W2_NR) ? 2u : 3u;
+}
+__device__ __forceinline__ bool cbh_is_wider(u32 act_cnt, u32 role_cnt) { return cbh_w2_class(act_cnt, role_cnt) == 3u; }
 
 struct Val { u32 t; u64 v; };
 

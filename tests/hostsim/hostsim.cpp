@@ -85,6 +85,7 @@ static KernelArgs* g_args;
 static uint32_t g_max_actions, g_max_roles; static bool g_plain;   // same kernel selection as cbh_check_resident (cbh_engine.hip)
 static cbh_check_kernel_fn g_kernel;   // the kernel the fibers run
 
+static bool g_used_walk_awide = false;
 static bool g_used_walk_wide = false;   // did the last batch launch cbh_walk2_wide_kernel? (hostsim_last_walk_wide)
 static int g_last_kind = -1;   // which kernel family decided the last batch (hostsim_last_kind: tests assert the one they mean to exercise)
 static bool g_trace;   // hostsim_trace: the trace pass's kernel (cbh_trace_batch)
@@ -214,7 +215,7 @@ static int run_sim(const void* blob, size_t len, const cbh_batch* in, const cbh_
   b.gres = pl.n_gwords ? gres.data() : nullptr; b.n_gwords = pl.n_gwords; b.n_gslots = pl.n_gslots;
   if (const char* e = getenv("CBH_HOSTSIM_REPORT")) { if (*e == '1') std::fprintf(stderr, "hostsim: kernel kind %d, %u result words\n", pl.kind, pl.n_gwords); }
   g_last_kind = trace ? -1 : pl.kind;
-  g_used_walk_wide = false;
+  g_used_walk_wide = false; g_used_walk_awide = false;
   // two launches over an arbitrary (unaligned) split of the batch: the chunk window [req_lo, req_hi) that the
   // one-shot path pipelines with (cbh_engine.hip) is exercised by every test of the CPU tier
   const uint32_t n = in->n_requests, mid = n > 3 ? (n / 2) - (n / 2) % 3 + 1 : n;
@@ -225,12 +226,17 @@ static int run_sim(const void* blob, size_t len, const cbh_batch* in, const cbh_
     const uint32_t nblocks = (b.req_hi - b.req_lo + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
     a.flags = user_flags;
     if (!trace && pl.kind == 2) {   // as cbh_engine.hip launch_plan
-      if (pl.wide_kernel) { a.flags = user_flags | (pl.walk_wide ? CBH_FI_ONLY_WIDER : CBH_FI_ONLY_WIDE); g_kernel = pl.wide_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk); }
-      if (pl.wide_kernel || pl.walk_wide) a.flags = user_flags | CBH_FI_SKIP_WIDE;
+      if (pl.wide_kernel) { a.flags = user_flags | ((pl.walk_wide || pl.walk_awide) ? CBH_FI_ONLY_WIDER : CBH_FI_ONLY_WIDE); g_kernel = pl.wide_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk); }
+      if (pl.wide_kernel || pl.walk_wide || pl.walk_awide) a.flags = user_flags | CBH_FI_SKIP_WIDE;
       if (pl.walk_wide) {
         if (pl.n_gwords) { g_kernel = cbh_walk2_pre_wide_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk); }
         g_kernel = cbh_walk2_wide_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
         g_used_walk_wide = true;
+      }
+      if (pl.walk_awide) {
+        if (pl.n_gwords) { g_kernel = cbh_walk2_pre_awide_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk); }
+        g_kernel = cbh_walk2_awide_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
+        g_used_walk_awide = true;
       }
       if (pl.n_gwords) { g_kernel = cbh_walk2_pre_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk); }
     }
@@ -245,7 +251,7 @@ extern "C" int hostsim_check(const void* blob, size_t len, const cbh_batch* in, 
   return run_sim(blob, len, in, p, out, gbits, nullptr);
 }
 extern "C" int hostsim_last_kind() { return g_last_kind; }
-extern "C" int hostsim_last_walk_wide() { return g_used_walk_wide ? 1 : 0; }
+extern "C" int hostsim_last_walk_wide() { return (g_used_walk_wide ? 1 : 0) | (g_used_walk_awide ? 2 : 0); }
 extern "C" int hostsim_trace(const void* blob, size_t len, const cbh_batch* in, const cbh_params* p,
                              cbh_result* out, uint64_t* gbits, cbh_trace* trace) {
   return run_sim(blob, len, in, p, out, gbits, trace);

@@ -74,8 +74,9 @@ def last_kind():
 
 
 def last_walk_wide():
-    """Did the last batch launch cbh_walk2_wide_kernel (requests with five to eight roles)?"""
-    return bool(lib().hostsim_last_walk_wide())
+    """Which wider walks the last batch launched: bit 0 cbh_walk2_wide_kernel (requests with five to eight roles), bit 1
+    cbh_walk2_awide_kernel (nine to sixteen actions)."""
+    return int(lib().hostsim_last_walk_wide())
 
 
 def trace(lt, batch, now_ns=0, flags=0, capacity=None):

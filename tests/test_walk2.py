@@ -156,9 +156,65 @@ def test_fuzz_stores_requests_with_five_to_eight_roles(seed):
     assert 4 < int(batch.req_u32[7].max())
     for lenient in (False, True):
         _both_kernels(lt, batch, capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0))
-        assert _both_kernels.walk_wide
+        assert _both_kernels.walk_wide & 1
         compared, _ = _against_oracle(rt, lt, _hostsim, inputs, lenient)
         assert compared > 100
+
+
+def _more_actions(rng, inputs, pool, share=0.4):
+    """Give a share of the requests nine to eighteen actions (their own first, then names of the pool and names no rule
+    knows): nine to sixteen with at most four roles take cbh_walk2_awide_kernel, the rest of them the general walk."""
+    out = []
+    for inp in inputs:
+        if rng.random() < share:
+            have = list(inp["actions"])[:8]
+            extra = [a for a in pool + ["nothing:%d" % k for k in range(12)] if a not in have]
+            rng.shuffle(extra)
+            n = int(rng.choice([9, 10, 12, 15, 16, 17, 18], p=[0.2, 0.15, 0.2, 0.15, 0.2, 0.05, 0.05]))
+            acts = have + extra[:n - len(have)]
+            rng.shuffle(acts)
+            inp = dict(inp, actions=[str(a) for a in acts])
+        out.append(inp)
+    return out
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_stores_requests_with_nine_to_sixteen_actions(seed):
+    """cbh_walk2_awide_kernel (16 actions x 4 roles) - and, in the same batches, the shape with more roles and the general walk
+    for what neither holds - against the general walk tuple by tuple and against the oracle."""
+    from test_fuzz_parity import ACTIONS, ROLES
+    rng = np.random.default_rng(81_000 + seed)
+    rt = rule_table_from_policies(policies_from_docs(_policies(rng)))
+    try:
+        lt = lower_rule_table(rt)
+    except LoweringError:
+        pytest.skip("store refused by the lowering (history-dependent reference behaviour)")
+    if not lt.stats["walk2"]:
+        pytest.skip("table stays on the general walk: %s" % lt.stats["walk2_refused"])
+    inputs = _more_actions(rng, _more_roles(rng, _requests(rng, 220), ROLES + ["other"], share=0.25), list(ACTIONS))
+    batch = Flattener(lt).flatten(inputs)
+    for lenient in (False, True):
+        _both_kernels(lt, batch, capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0))
+        assert _both_kernels.walk_wide == 3
+        compared, _ = _against_oracle(rt, lt, _hostsim, inputs, lenient)
+        assert compared > 100
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_role_policy_chains_with_nine_to_sixteen_actions(seed):
+    rng = np.random.default_rng(91_000 + seed)
+    docs, acts = _role_policy_store(rng)
+    rt = rule_table_from_policies(policies_from_docs(docs))
+    try:
+        lt = lower_rule_table(rt)
+    except LoweringError:
+        pytest.skip("store refused by the lowering")
+    inputs = _more_actions(rng, _role_policy_requests(rng, acts, 220), acts + ["view:x", "edit:y", "other"], share=0.5)
+    batch = Flattener(lt).flatten(inputs)
+    for lenient in (False, True):
+        _both_kernels(lt, batch, capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0))
+        assert _both_kernels.walk_wide & 2
+        _against_oracle(rt, lt, _hostsim, inputs, lenient)
 
 
 @pytest.mark.parametrize("seed", range(16))
@@ -174,7 +230,7 @@ def test_role_policy_chains_with_five_to_eight_roles(seed):
     batch = Flattener(lt).flatten(inputs)
     for lenient in (False, True):
         _both_kernels(lt, batch, capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0))
-        assert _both_kernels.walk_wide
+        assert _both_kernels.walk_wide & 1
         _against_oracle(rt, lt, _hostsim, inputs, lenient)
 
 
@@ -194,7 +250,7 @@ def test_only_wide_requests_and_base_only_batches_take_one_walk_each():
     batch = Flattener(lt).flatten(wide)
     assert int(batch.req_u32[7].min()) >= 5 and int(batch.req_u32[7].max()) == 8
     new = _both_kernels(lt, batch, capi.F_WANT_DERIVED_ROLES)
-    assert _both_kernels.walk_wide
+    assert _both_kernels.walk_wide == 1
     os.environ["CBH_NO_WALK2_WIDE"] = "1"
     try:
         old = hostsim_api.check(lt, batch, NOW, capi.F_WANT_DERIVED_ROLES, device_order=True)
@@ -398,17 +454,19 @@ def test_gpu_fuzz_stores(seed):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(8))
-def test_gpu_requests_with_five_to_eight_roles(seed):
-    """cbh_walk2_wide_kernel on the device: the fuzz stores and the role-policy chains with requests of up to ten roles,
-    one-shot (cbh_check_batch) against the oracle and resident (cbh_check_resident: the plan must name the wider walk)."""
-    from test_fuzz_parity import ROLES
-    rng = np.random.default_rng(79_000 + seed)
+def test_gpu_wider_requests(seed):
+    """cbh_walk2_wide_kernel / cbh_walk2_awide_kernel on the device: the fuzz stores and the role-policy chains with requests of
+    up to ten roles and eighteen actions, one-shot (cbh_check_batch) against the oracle and resident (cbh_check_resident: the
+    plan must name the wider walks) word for word what the one-shot call returned."""
+    from test_fuzz_parity import ACTIONS, ROLES
+    rng = np.random.default_rng(83_000 + seed)
     if seed % 2:
         docs, acts = _role_policy_store(rng)
-        make = lambda: _more_roles(rng, _role_policy_requests(rng, acts, 220), ["staff", "lead", "temp", "vendor", "intern"], share=0.6)   # noqa: E731
+        inputs = _more_roles(rng, _role_policy_requests(rng, acts, 220), ["staff", "lead", "temp", "vendor", "intern"], share=0.4)
+        inputs = _more_actions(rng, inputs, acts + ["view:x", "edit:y", "other"], share=0.4)
     else:
         docs = _policies(rng)
-        make = lambda: _more_roles(rng, _requests(rng, 200), ROLES + ["other"])   # noqa: E731
+        inputs = _more_actions(rng, _more_roles(rng, _requests(rng, 200), ROLES + ["other"], share=0.35), list(ACTIONS))
     rt = rule_table_from_policies(policies_from_docs(docs))
     try:
         lt = lower_rule_table(rt)
@@ -416,17 +474,16 @@ def test_gpu_requests_with_five_to_eight_roles(seed):
         pytest.skip("store refused by the lowering")
     if not lt.stats["walk2"]:
         pytest.skip("table stays on the general walk: %s" % lt.stats["walk2_refused"])
-    inputs = make()
     for lenient in (False, True):
         _against_oracle(rt, lt, lambda l: HipEvaluator(l, Conf()), inputs, lenient)
-    # resident: the same batch by cbh_check_resident, word for word what the one-shot call returned
     table = capi.Table(lt.blob)
     try:
         batch = Flattener(lt).flatten(inputs)
         flags = capi.F_WANT_DERIVED_ROLES
         one = table.check(batch, now_ns=NOW, flags=flags)
         db = table.upload(batch)
-        assert "cbh_walk2_wide_kernel" in table.plan(db, flags)
+        plan = table.plan(db, flags)
+        assert "cbh_walk2_wide_kernel" in plan and "cbh_walk2_awide_kernel" in plan, plan
         table.launch(db, now_ns=NOW, flags=flags)
         table.synchronize()
         res = table.download(db)
