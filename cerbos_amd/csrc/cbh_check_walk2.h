@@ -1,8 +1,9 @@
 // cbh_walk2_kernel - the decision kernel for everything a table can hold: principal policies, role policies and parent
 // roles, glob patterns, derived roles, conditions of any shape - in the flat kernel's form (cbh_check_flat.h): a wave
-// walks scopes -> records ONCE, every lane carries all its role walks side by side as a bit vector (bit 8 r + k = role
-// r's walk for action k; at most eight actions and four roles per request, outside strict mode - anything else stays
-// on cbh_check_wave.h), lanes merge by scope node deepest first, records are decided by class masks and glob bits.
+// walks scopes -> records ONCE, every lane carries all its role walks side by side as a bit vector (bit NA r + k = role
+// r's walk for action k; three shapes NA x NR: eight actions and four roles in 32 bits, eight and eight or sixteen and four
+// in 64; outside strict mode - anything else stays on cbh_check_wave.h), lanes merge by scope node deepest first,
+// records are decided by class masks and glob bits.
 //
 // What differs from the flat kernel, which it generalises:
 //   * Glob patterns.  A lane keeps, per action and per role, the match bits of its string for the first CBH_W2_MAX_GLOBS
