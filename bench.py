@@ -44,7 +44,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 # 32 + 9*A/actions + 1 (C2: A=7, 4 actions)
-ALG_BYTES_PER_DECISION = {"C1": 33.0, "C2": 49.0, "C3": 42.0, "C4": 47.0, "C5": 83.0, "T": 47.0}
+ALG_BYTES_PER_DECISION = {"C1": 33.0, "C2": 49.0, "C3": 42.0, "C4": 47.0, "C5": 83.0, "T": 47.0, "C5W": 83.0}
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 SERIAL_BATCHES = 16                     # resident batches of the one-stream leg (0.8 GB at C2: beyond the Infinity Cache)
 PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")   # written by tools/gpu_final_r03.sh
@@ -70,9 +70,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("C1", "C2", "C3", "C4", "C5", "T"), default="C2",
+    ap.add_argument("--workload", choices=("C1", "C2", "C3", "C4", "C5", "T", "C5W"), default="C2",
                     help="BASELINE.json config; the metric is quoted on C2 (the default), the others are side measurements; T = north_star's "
-                         "target set: 100 policies / 10k rules with CEL conditions")
+                         "target set: 100 policies / 10k rules with CEL conditions; C5W = C5 with principals of five to eight roles")
     ap.add_argument("--requests", type=int, default=None, help="requests per batch (default: the config's size: C1 10k x2, C2 250k x4, C3 1M x4 actions)")
     ap.add_argument("--batches", type=int, default=None, help="resident batches per GPU in the rotating set (default: enough for > 1 GB)")
     ap.add_argument("--replicas", type=int, default=None,
@@ -122,6 +122,8 @@ def main():
                  "1000 resource policies / 50k rules, 64-condition pool, Zipf kinds (one GPU's 2M of the 16M tuples)"),
           "C5": (workloads.c5_policies, workloads.c5_requests, 250_000, 16,
                  "C3 + principal overrides, action globs, role policies, nested map/list CEL (one GPU's 1M of 8M)"),
+          "C5W": (workloads.c5_policies, lambda n, seed=5: workloads.c5_requests(n, seed=seed, roles_per_request=(5, 8)), 250_000, 16,
+                  "C5's table, principals with five to eight roles (cbh_walk2_wide_kernel; CBH_NO_WALK2_WIDE=1: the general walk) - a side line"),
           "T": (lambda: workloads.c4_policies(seed=7, n_policies=100, rules_per_policy=100),
                 lambda n, seed=7: workloads.c4_requests(n, seed=seed, n_policies=100), 250_000, 16,
                 "north_star's target: 100 resource policies / 10k rules, 40 % with CEL conditions (64-condition pool), 1M tuples")}[args.workload]
@@ -146,7 +148,7 @@ def main():
         table = capi.Table(lt.blob)
 
     # ---- this rank's rotating set (weak scaling: fixed tuples per GPU; every batch of every rank has its own seed)
-    base_seed = {"C1": 1, "C2": 2, "C3": 3, "C4": 4, "C5": 5, "T": 7}[args.workload]
+    base_seed = {"C1": 1, "C2": 2, "C3": 3, "C4": 4, "C5": 5, "T": 7, "C5W": 5}[args.workload]
     fl = Flattener(lt)
     cr0 = batch0 = None
     dbatches, tuples_per_batch, resident_bytes = [], None, 0

@@ -348,9 +348,10 @@ def c5_policies(seed=5, n_principal_policies=100):
     return docs
 
 
-def c5_requests(n_requests=250_000, seed=5, actions_per_request=4):
+def c5_requests(n_requests=250_000, seed=5, actions_per_request=4, roles_per_request=(1, 3)):
     """Mixed batch: half of the requests ask for the v5 policies (globs + nested conditions), 5 % of the
-    principals have a principal policy, 10 % hold a role-policy role; 1M tuples per GPU by default."""
+    principals have a principal policy, 10 % hold a role-policy role; 1M tuples per GPU by default.
+    ``roles_per_request`` = (lowest, highest) number of roles of a principal (at most 8: distinct names of C3_ROLES)."""
     rng = np.random.default_rng(seed + 3000)
     n = n_requests
     base = c3_requests(n, seed=seed, actions_per_request=actions_per_request)
@@ -358,7 +359,8 @@ def c5_requests(n_requests=250_000, seed=5, actions_per_request=4):
     ids_v = ["p%04d" % i for i in range(n_ids)]
     pid = rng.integers(0, n_ids, n)
     roles_v = C3_ROLES + ["contractor", "auditor"]
-    cnt = rng.integers(1, 4, n)
+    assert 1 <= roles_per_request[0] <= roles_per_request[1] <= 8
+    cnt = rng.integers(roles_per_request[0], roles_per_request[1] + 1, n)
     off = np.concatenate([[0], np.cumsum(cnt)])
     start = rng.integers(0, len(C3_ROLES), n)
     flat = (np.repeat(start, cnt) + (np.arange(off[-1]) - np.repeat(off[:-1], cnt)) * 5) % len(C3_ROLES)

@@ -422,6 +422,18 @@ def test_c5_sample_walk2_vs_general_walk():
     _both_kernels(lt, batch, capi.F_WANT_DERIVED_ROLES)
 
 
+def test_c5w_sample_wide_walk_vs_general_walk_vs_oracle():
+    """bench.py --workload C5W: C5's table, principals with five to eight roles - every request on cbh_walk2_wide_kernel."""
+    rt = rule_table_from_policies(policies_from_docs(workloads.c5_policies()))
+    lt = lower_rule_table(rt)
+    cr = workloads.c5_requests(4000, roles_per_request=(5, 8))
+    batch = cr.to_batch(Flattener(lt))
+    assert int(batch.req_u32[7].min()) == 5 and int(batch.req_u32[7].max()) == 8
+    _both_kernels(lt, batch, capi.F_WANT_DERIVED_ROLES)
+    assert _both_kernels.walk_wide == 1
+    _against_oracle(rt, lt, _hostsim, cr.head(400).to_inputs())
+
+
 # ---------------------------------------------------------------------------------------------------------- GPU tier
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(12))
