@@ -6,7 +6,12 @@ internal/test/testdata/compile: bad_variables.yaml, variables_index_lookup.yaml)
 * `V["x"]`, `C["x"]`, `G["x"]`: cerbos.Variables is an object type, it has fields and no index operator -
   `found no matching overload for '_[_]' applied to '(cerbos.Variables, string)'`.
 
-Everything else cel-go's checker would reject (unknown fields of request / P / R, unknown functions, argument types) is NOT
+* a field the message types of the environment do not have - `undefined field 'wat'` for `request.wat`, `runtime.wat`,
+  `P.wat`, `request.aux_data.wat` ... (internal/conditions/types/registry_test.go TestJSONFields / TestRuntime pin the text;
+  the messages are engine.proto:304-322, 397-422 Request / Request.Principal / Request.Resource / AuxData / AuxData.JWT / Runtime, every field
+  under its proto name and its JSON name, registry.go:58-125).
+
+Everything else cel-go's checker would reject (unknown functions, argument types, a field selected from a scalar) is NOT
 checked: the lowering refuses what it cannot compile, but a policy the reference rejects for those reasons is accepted here."""
 from . import parser
 
@@ -14,6 +19,15 @@ DECLARED = frozenset(("request", "P", "R", "runtime", "constants", "C", "variabl
 VARIABLES_TYPED = frozenset(("constants", "C", "variables", "V", "globals", "G"))
 # type names are identifiers of the standard environment; google.* / cerbos.* start qualified message and enum names
 _TYPES = frozenset(("bool", "bytes", "double", "int", "uint", "string", "list", "map", "null_type", "type", "optional_type", "google", "cerbos"))
+# message types: field (proto or JSON name) -> the message type behind it, ("map", type) for a map of messages, None where the
+# value is a scalar / list / map of values
+_PRINCIPAL = {"id": None, "roles": None, "attr": None, "policy_version": None, "policyVersion": None, "scope": None}
+_RESOURCE = {"kind": None, "id": None, "attr": None, "policy_version": None, "policyVersion": None, "scope": None}
+_JWT = {"claims": None}
+_AUX = {"jwt": None, "jwts": ("map", _JWT)}
+_REQUEST = {"principal": _PRINCIPAL, "resource": _RESOURCE, "aux_data": _AUX, "auxData": _AUX}
+_RUNTIME = {"effective_derived_roles": None, "effectiveDerivedRoles": None}
+_MESSAGES = {"request": _REQUEST, "P": _PRINCIPAL, "R": _RESOURCE, "runtime": _RUNTIME}
 _LIT_TYPE = {"null": "null", "bool": "bool", "int": "int", "uint": "uint", "double": "double", "string": "string", "bytes": "bytes"}
 
 
@@ -22,6 +36,18 @@ def issues(ast):
     out = []
     _visit(ast, frozenset(), out)
     return out
+
+
+def _message_type(n, bound):
+    """The message type of the value of `n`, when it is one of the environment's (else None)."""
+    if n[0] == "ident":
+        return _MESSAGES.get(n[1]) if n[1] not in bound else None
+    if n[0] in ("select", "index"):
+        parent = _message_type(n[1], bound)
+        if isinstance(parent, tuple):      # a map of messages: any key
+            return parent[1]
+        return parent.get(n[2]) if isinstance(parent, dict) and n[0] == "select" else None
+    return None
 
 
 def _visit(n, bound, out):   # noqa: C901
@@ -34,6 +60,9 @@ def _visit(n, bound, out):   # noqa: C901
         return
     if k in ("select", "has"):
         _visit(n[1], bound, out)
+        msg = _message_type(n[1], bound)
+        if isinstance(msg, dict) and n[2] not in msg:
+            out.append("undefined field '%s'" % n[2])
     elif k == "index":
         _visit(n[1], bound, out)
         _visit(n[2], bound, out)
