@@ -112,3 +112,31 @@ def test_truncated_and_foreign_bytes_are_rejected_not_crashing():
             decode_rule_table(wire[:cut])
         except (ValueError, IndexError, KeyError, UnicodeDecodeError):
             pass
+
+
+def test_engine_cases_on_a_table_that_went_through_the_wire():
+    """internal/ruletable/marshal_test.go TestMarshaledIndexCheck: the reference runs its whole engine suite (engine + strict
+    scope search cases) against an evaluator whose table was round-tripped through Marshal / Unmarshal.  The same here: the golden
+    store's table -> ``runtimev1.RuleTable`` bytes -> decoded table, and every engine case answered from the DECODED table by the
+    policy-level oracle (effects, policies, scopes, derived roles, evaluation errors, outputs) and by the device path on the
+    simulator (what the oracle decides, the image lowered from the decoded table decides)."""
+    import test_hostsim_golden as hg
+    import test_oracle_golden as og
+    from cerbos_amd.engine import Conf
+    from helpers import norm_actions
+    from oracle.check import RuleTableOracle
+    back = decode_rule_table(encode_rule_table(store_rule_table()))
+    oracle = RuleTableOracle(back)
+    ev = hg.HostSimEvaluator(lower_rule_table(back, hg.GLOBALS), Conf(globals_=hg.GLOBALS))
+    n = 0
+    for case in og.CASES:
+        og.test_engine_case.__wrapped__(oracle, case) if hasattr(og.test_engine_case, "__wrapped__") else og.test_engine_case(oracle, case)
+        for lenient in hg._modes(case):
+            outs, bad = ev.check(case["inputs"], now_ns=1_700_000_000_000_000_000, lenient_scope_search=lenient, allow_unsupported=True)
+            for i, (have, want) in enumerate(zip(outs, case["wantOutputs"])):
+                if i in bad:
+                    continue
+                assert norm_actions(have) == norm_actions(want), (case["name"], lenient)
+                assert sorted(have["effectiveDerivedRoles"]) == sorted(want.get("effectiveDerivedRoles") or [])
+                n += 1
+    assert n >= 100
