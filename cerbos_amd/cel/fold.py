@@ -202,6 +202,82 @@ def _uint(v):
     return UInt(v)
 
 
+_M64 = (1 << 64) - 1
+
+
+def _as_int64(bits):
+    bits &= _M64
+    return bits - (1 << 64) if bits >> 63 else bits
+
+
+def _math(name, vals):
+    """cel-go ext.Math() (cerbos enables it unversioned = latest, conditions/cel.go:78) on constants - greatest / least are
+    handled by the caller.  Rounding is half away from zero; bit operations want two ints or two uints; a shift takes an int
+    offset (negative: an error; 64 and more: zero) and moves the 64-bit pattern, so a right shift of a negative int fills
+    with zeros; sign keeps the operand's type."""
+    n = len(vals)
+    if n == 1:
+        v = vals[0]
+        if name in ("ceil", "floor", "round", "trunc", "isNaN", "isInf", "isFinite"):
+            d = _need(v, float)
+            if name == "isNaN":
+                return math.isnan(d)
+            if name == "isInf":
+                return math.isinf(d)
+            if name == "isFinite":
+                return not (math.isnan(d) or math.isinf(d))
+            if math.isnan(d) or math.isinf(d):
+                return d
+            if name == "ceil":
+                return float(math.ceil(d))
+            if name == "floor":
+                return float(math.floor(d))
+            if name == "trunc":
+                return float(math.trunc(d))
+            return math.copysign(float(math.floor(abs(d) + 0.5)), d)
+        if name == "abs":
+            if isinstance(v, UInt):
+                return v
+            if _is_int(v):
+                return _int(-v if v < 0 else v)
+            return abs(_need(v, float))
+        if name == "sign":
+            if isinstance(v, UInt):
+                return UInt(1 if v else 0)
+            if _is_int(v):
+                return 1 if v > 0 else -1 if v < 0 else 0
+            d = _need(v, float)
+            return d if math.isnan(d) else 1.0 if d > 0 else -1.0 if d < 0 else 0.0
+        if name == "sqrt":
+            if not _is_num(v):
+                raise FoldError("no such overload")
+            d = float(v)
+            return math.nan if math.isnan(d) or d < 0 else math.sqrt(d)
+        if name == "bitNot":
+            if isinstance(v, UInt):
+                return UInt(~int(v) & _M64)
+            return ~_need(v, int)
+    if n == 2:
+        a, b = vals
+        if name in ("bitAnd", "bitOr", "bitXor"):
+            both_u = isinstance(a, UInt) and isinstance(b, UInt)
+            if not both_u and not (_is_int(a) and _is_int(b)):
+                raise FoldError("no such overload")
+            r = (int(a) & int(b)) if name == "bitAnd" else (int(a) | int(b)) if name == "bitOr" else (int(a) ^ int(b))
+            return UInt(r & _M64) if both_u else _as_int64(r)
+        if name in ("bitShiftLeft", "bitShiftRight"):
+            if not (isinstance(a, UInt) or _is_int(a)) or not _is_int(b):
+                raise FoldError("no such overload")
+            if b < 0:
+                raise FoldError("negative offset")
+            if b >= 64:
+                return UInt(0) if isinstance(a, UInt) else 0
+            bits = int(a) & _M64
+            r = (bits << b) & _M64 if name == "bitShiftLeft" else bits >> b
+            return UInt(r) if isinstance(a, UInt) else _as_int64(r)
+    raise NotConst("math.%s" % name)
+
+
 def _cps(s):
     return list(s)   # Python strings index by code point, as cel-go's string extensions do
 
@@ -629,6 +705,8 @@ class _Eval:
                 if (r > 0) == (name == "greatest") and r != 0:
                     best = x
             return best
+        if ns == "math":
+            return _math(name, vals)
         if ns == "regex":
             if name == "replace" and nv in (3, 4):
                 return _regex_replace(_need(vals[0], str), vals[1], _need(vals[2], str), _need(vals[3], int) if nv == 4 else -1)

@@ -1297,6 +1297,70 @@ def _m_in_ip_range(env, ip, cidr):
     return _ip_in_range(ip, cidr)
 
 
+# cel-go ext.Math() beyond greatest / least (ext/math.go; cerbos enables the library at its latest version, conditions/cel.go:78;
+# the functions and one example each: docs/modules/policies/pages/conditions.adoc:456-472).  Bit operations take two ints or two
+# uints; shifts take the value and an int offset: a negative offset is an error, an offset of 64 or more gives 0, a right shift
+# of an int fills with zeros (the value is shifted as its 64-bit pattern).
+def _wrap_int(x):
+    x &= 0xFFFFFFFFFFFFFFFF
+    return x - (1 << 64) if x >> 63 else x
+
+
+def _math_bit(op):
+    def fn(env, a, b):
+        if is_uint(a) and is_uint(b):
+            return UInt(op(int(a), int(b)) & 0xFFFFFFFFFFFFFFFF)
+        if is_int(a) and is_int(b):
+            return _wrap_int(op(int(a), int(b)))
+        raise no_such_overload()
+    return fn
+
+
+def _math_bit_not(env, a):
+    if is_uint(a):
+        return UInt(~int(a) & 0xFFFFFFFFFFFFFFFF)
+    if is_int(a):
+        return ~int(a)
+    raise no_such_overload()
+
+
+def _math_shift(left):
+    def fn(env, a, n):
+        if not (is_int(a) or is_uint(a)) or not is_int(n):
+            raise no_such_overload()
+        if n < 0:
+            raise CelError("math.bitShift%s() negative offset: %d" % ("Left" if left else "Right", n))
+        if n >= 64:
+            return UInt(0) if is_uint(a) else 0
+        bits = int(a) & 0xFFFFFFFFFFFFFFFF
+        out = (bits << n) & 0xFFFFFFFFFFFFFFFF if left else bits >> n
+        return UInt(out) if is_uint(a) else _wrap_int(out)
+    return fn
+
+
+def _math_sign(env, v):
+    if is_uint(v):
+        return UInt(1 if v > 0 else 0)
+    if is_int(v):
+        return (v > 0) - (v < 0)
+    if is_double(v):
+        return v if math.isnan(v) else float((v > 0) - (v < 0))
+    raise no_such_overload()
+
+
+def _math_sqrt(env, v):
+    if not is_num(v):
+        raise no_such_overload()
+    f = float(v)
+    return math.nan if math.isnan(f) or f < 0 else math.sqrt(f)
+
+
+def _dbl_round(fn, v):
+    """Go's math.Ceil / Floor / Trunc / Round: NaN and the infinities come back unchanged."""
+    _need(v, float)
+    return v if math.isnan(v) or math.isinf(v) else float(fn(v))
+
+
 def _math_extreme(pick):
     def f(env, *args):
         if len(args) == 1 and isinstance(args[0], list):
@@ -1799,13 +1863,18 @@ _NS_FUNCS = {
     ("lists", "range"): _lists_range,
     ("math", "greatest"): _math_extreme(+1),
     ("math", "least"): _math_extreme(-1),
-    ("math", "abs"): lambda env, v: (_chk_int(abs(v)) if is_int(v) else abs(v)) if is_num(v) else (_ for _ in ()).throw(no_such_overload()),
-    ("math", "ceil"): lambda env, v: float(math.ceil(_need(v, float))),
-    ("math", "floor"): lambda env, v: float(math.floor(_need(v, float))),
-    ("math", "round"): lambda env, v: float(math.floor(abs(_need(v, float)) + 0.5) * (1 if v >= 0 else -1)),
-    ("math", "trunc"): lambda env, v: float(math.trunc(_need(v, float))),
+    ("math", "abs"): lambda env, v: (v if is_uint(v) else _chk_int(abs(v)) if is_int(v) else abs(v)) if is_num(v) else (_ for _ in ()).throw(no_such_overload()),
+    ("math", "ceil"): lambda env, v: _dbl_round(math.ceil, v),
+    ("math", "floor"): lambda env, v: _dbl_round(math.floor, v),
+    ("math", "round"): lambda env, v: _dbl_round(lambda d: math.floor(abs(d) + 0.5) * (1 if d >= 0 else -1), v),
+    ("math", "trunc"): lambda env, v: _dbl_round(math.trunc, v),
     ("math", "isNaN"): lambda env, v: math.isnan(_need(v, float)),
     ("math", "isInf"): lambda env, v: math.isinf(_need(v, float)),
+    ("math", "isFinite"): lambda env, v: math.isfinite(_need(v, float)),
+    ("math", "sign"): _math_sign, ("math", "sqrt"): _math_sqrt,
+    ("math", "bitAnd"): _math_bit(lambda a, b: a & b), ("math", "bitOr"): _math_bit(lambda a, b: a | b),
+    ("math", "bitXor"): _math_bit(lambda a, b: a ^ b), ("math", "bitNot"): _math_bit_not,
+    ("math", "bitShiftLeft"): _math_shift(True), ("math", "bitShiftRight"): _math_shift(False),
     ("base64", "encode"): lambda env, b: base64.b64encode(_need(b, bytes)).decode("ascii"),
     ("base64", "decode"): lambda env, s: base64.b64decode(_need(s, str) + "=" * (-len(s) % 4)),
     ("regex", "replace"): _rx_replace, ("regex", "extract"): _rx_extract, ("regex", "extractAll"): _rx_extract_all,

@@ -202,3 +202,37 @@ def test_generated_constant_expressions_against_the_oracle(seed):
             assert _same(_lit_value(lit), want), (expr, lit, want)
             folded += 1
     assert folded > 300 and errors > 20, (folded, errors)
+
+
+def _math_arg(rng, kind):
+    if kind == "int":
+        return str(rng.choice([0, 1, -1, 2, -2, 3, 5, -7, 63, 64, 1024, -1024, (1 << 62), -(1 << 62), (1 << 63) - 1, -(1 << 63) + 1]))
+    if kind == "uint":
+        return "%du" % rng.choice([0, 1, 2, 3, 5, 200, 1024, (1 << 63), (1 << 64) - 1])
+    return rng.choice(["0.0", "1.2", "-1.2", "1.5", "-1.5", "2.5", "-0.5", "1e300", "-1e300", "(0.0/0.0)", "(1.0/0.0)", "(-1.0/0.0)", "81.0", "-4.0"])
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_math_library_on_constants_against_the_oracle(seed):
+    """cel-go ext.Math() (conditions.adoc:456-472 lists the functions): the product's folder (cel/fold.py _math) and the oracle
+    (celeval._NAMESPACE_FUNCS) are two restatements - the same value, the same type, an error in one is an error in the other."""
+    rng = random.Random(31_000 + seed)
+    one = ["abs", "ceil", "floor", "round", "trunc", "isNaN", "isInf", "isFinite", "sign", "sqrt", "bitNot"]
+    two = ["bitAnd", "bitOr", "bitXor", "bitShiftLeft", "bitShiftRight"]
+    folded = errors = 0
+    for _ in range(1500):
+        if rng.random() < 0.5:
+            expr = "math.%s(%s)" % (rng.choice(one), _math_arg(rng, rng.choice(["int", "uint", "dbl"])))
+        else:
+            expr = "math.%s(%s, %s)" % (rng.choice(two), _math_arg(rng, rng.choice(["int", "uint", "dbl"])), _math_arg(rng, rng.choice(["int", "int", "uint"])))
+        lit = _folded(expr)
+        try:
+            want = celeval.evaluate(expr, celeval.Env({}, NOW))
+        except celeval.CelError:
+            assert lit is None, (expr, lit)
+            errors += 1
+            continue
+        assert lit is not None, expr
+        assert _same(_lit_value(lit), want), (expr, lit, want)
+        folded += 1
+    assert folded > 600 and errors > 100, (folded, errors)
