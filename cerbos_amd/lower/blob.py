@@ -405,6 +405,15 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
     for ver, kind, scope in sorted(res_exists):
         entries.append((B_RESEXISTS, sid(ver), sid(kind), lt.scope_index[scope], 1, 0, 0, 0))
 
+    # A request whose principal id is EMPTY (protovalidate rejects it on the gRPC path; an in-process caller of engine.Check can
+    # still bring one): Index.Query leaves the principal dimension out of the AND when the id is "" (index/index.go:228-234),
+    # so the rows of EVERY principal policy of (version, scope) answer it, in binding order.  The directory is keyed by the
+    # exact principal string, so that union is one more bucket under the empty string (no policy can be written for it:
+    # the compiler requires a principal name).
+    for (ver, scope) in sorted({(v, s) for (v, s, _p) in prin_buckets}):
+        if (ver, scope, "") not in prin_buckets:
+            prin_buckets[(ver, scope, "")] = [r for (v, s, _p), rows in prin_buckets.items() if (v, s) == (ver, scope) for r in rows]
+
     # principal policies
     for key in sorted(prin_buckets):
         ver, scope, principal = key
