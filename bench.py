@@ -122,10 +122,9 @@ def main():
                  "1000 resource policies / 50k rules, 64-condition pool, Zipf kinds (one GPU's 2M of the 16M tuples)"),
           "C5": (workloads.c5_policies, workloads.c5_requests, 250_000, 16,
                  "C3 + principal overrides, action globs, role policies, nested map/list CEL (one GPU's 1M of 8M)"),
-          "C5W": (workloads.c5_policies, lambda n, seed=5: workloads.c5_requests(n, seed=seed, roles_per_request=(5, 8)), 250_000, 16,
+          "C5W": (workloads.c5_policies, workloads.c5w_requests, 250_000, 16,
                   "C5's table, principals with five to eight roles (cbh_walk2_wide_kernel; CBH_NO_WALK2_WIDE=1: the general walk) - a side line"),
-          "T": (lambda: workloads.c4_policies(seed=7, n_policies=100, rules_per_policy=100),
-                lambda n, seed=7: workloads.c4_requests(n, seed=seed, n_policies=100), 250_000, 16,
+          "T": (workloads.t_policies, workloads.t_requests, 250_000, 16,
                 "north_star's target: 100 resource policies / 10k rules, 40 % with CEL conditions (64-condition pool), 1M tuples")}[args.workload]
     n_requests = args.requests or wl[2]
     n_seeded = max(1, args.batches or wl[3])

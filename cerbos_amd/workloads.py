@@ -297,6 +297,17 @@ def c4_requests(n_requests=500_000, seed=4, actions_per_request=4, n_policies=10
     )
 
 
+# ------------------------------------------------------------------------------------- T
+def t_policies(seed=7):
+    """north_star's target set: 100 resource policies x 100 rules = 10k rules, 40 % with a CEL condition of C4's pool
+    (34 kinds x the scopes root / acme / acme.hr: 100 rules per (kind, scope) bucket)."""
+    return c4_policies(seed=seed, n_policies=100, rules_per_policy=100)
+
+
+def t_requests(n_requests=250_000, seed=7):
+    return c4_requests(n_requests, seed=seed, n_policies=100)
+
+
 # ------------------------------------------------------------------------------------- C5
 C5_ACTIONS = ["view", "view:public", "view:internal", "edit", "edit:public", "delete", "share:public", "approve"]
 
@@ -445,3 +456,8 @@ def loadtest_inputs(set_name="classic", count=10):
                     inp["auxData"] = req["auxData"]
                 out.append(inp)
     return out
+
+
+def c5w_requests(n_requests=250_000, seed=5):
+    """C5's table, principals with five to eight roles (cbh_walk2_wide_kernel's shape)."""
+    return c5_requests(n_requests, seed=seed, roles_per_request=(5, 8))

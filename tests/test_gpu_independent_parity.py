@@ -95,13 +95,16 @@ def _independent(docs, cr, n_sample, lenient=False, block=50, expect=None, make_
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("name,n_requests", [("C2", 250_000), ("C3", 1_000_000), ("C4", 500_000)])
+@pytest.mark.parametrize("name,n_requests", [("C2", 250_000), ("C3", 1_000_000), ("C4", 500_000), ("T", 250_000), ("C5W", 250_000)])
 def test_full_size_against_the_policy_level_oracle(name, n_requests):
+    """T = north_star's target set (100 policies / 10k rules with CEL conditions, 1M tuples); C5W = C5's table with principals
+    of five to eight roles (the walk's 8 x 8 shape)."""
     pol_fn, req_fn = {"C2": (workloads.c2_policies, workloads.c2_requests), "C3": (workloads.c3_policies, workloads.c3_requests),
-                      "C4": (workloads.c4_policies, workloads.c4_requests)}[name]
-    checked, plan, _ = _independent(pol_fn(), req_fn(n_requests), 100_000)
-    assert checked >= 100_000
-    assert plan.startswith("cbh_check_flat_kernel")
+                      "C4": (workloads.c4_policies, workloads.c4_requests), "T": (workloads.t_policies, workloads.t_requests),
+                      "C5W": (workloads.c5_policies, workloads.c5w_requests)}[name]
+    checked, plan, _ = _independent(pol_fn(), req_fn(n_requests), 100_000 if name != "C5W" else 50_000)
+    assert checked >= (100_000 if name != "C5W" else 50_000)
+    assert ("walk2_wide" in plan) if name == "C5W" else plan.startswith("cbh_check_flat_kernel")
 
 
 @pytest.mark.timeout(900)

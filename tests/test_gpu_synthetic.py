@@ -125,16 +125,18 @@ def test_resident_path_and_kernel_timer():
 
 @pytest.mark.parametrize("name,n_requests,mode", [("C2", 250_000, "default"), ("C2", 250_000, "strict"),
                                                   ("C3", 1_000_000, "default"), ("C3", 250_000, "lenient"),
-                                                  ("C4", 500_000, "default"), ("C4", 100_000, "strict")])
+                                                  ("C4", 500_000, "default"), ("C4", 100_000, "strict"),
+                                                  ("T", 250_000, "default"), ("T", 250_000, "lenient"), ("T", 100_000, "strict")])
 def test_full_size_bit_exact_against_cpp_oracle(name, n_requests, mode):
     """Every tuple of the full-size configurations (C2: 1M, C3: 4M, C4: one GPU's 2M tuples against the
-    1000-policy / 50k-rule table): effect, policy, scope and derived-role mask identical to
+    1000-policy / 50k-rule table; T: north_star's target set, 100 policies / 10k rules with CEL conditions, the 1M tuples its
+    >= 10 M decisions/s are quoted on): effect, policy, scope and derived-role mask identical to
     oracle/ccheck.cpp, and the same requests report CEL errors.
     (ccheck is pinned against oracle/check.py in tests/test_ccheck.py.)"""
     import os
     from oracle import ccheck
-    full = {"C2": workloads.c2_requests, "C3": workloads.c3_requests, "C4": workloads.c4_requests}[name]
-    pol_fn = {"C4": workloads.c4_policies}.get(name, CONFIGS[name][0])
+    full = {"C2": workloads.c2_requests, "C3": workloads.c3_requests, "C4": workloads.c4_requests, "T": workloads.t_requests}[name]
+    pol_fn = {"C4": workloads.c4_policies, "T": workloads.t_policies}.get(name) or CONFIGS[name][0]
     rt, lt, table = _table(pol_fn)
     batch = full(n_requests).to_batch(Flattener(lt))
     flags = capi.F_WANT_DERIVED_ROLES
@@ -154,23 +156,29 @@ def test_full_size_bit_exact_against_cpp_oracle(name, n_requests, mode):
     table.close()
 
 
-@pytest.mark.parametrize("mode", ["default", "strict", "lenient"])
-def test_c5_full_size_against_cpp_oracle(mode):
+@pytest.mark.parametrize("mode,req_fn", [("default", workloads.c5_requests), ("strict", workloads.c5_requests), ("lenient", workloads.c5_requests),
+                                         ("default", workloads.c5w_requests), ("lenient", workloads.c5w_requests)],
+                         ids=["default", "strict", "lenient", "C5W-default", "C5W-lenient"])
+def test_c5_full_size_against_cpp_oracle(mode, req_fn):
     """C5 at one GPU's share (1M tuples; principal policies, role policies, action globs, nested CEL): every
     tuple whose decision path the C++ restatement covers (it flags the ones that need general CEL programs,
     ~15 %) must agree in effect, policy, scope, derived-role mask and error status."""
     import os
     from oracle import ccheck
     rt, lt, table = _table(workloads.c5_policies)
-    batch = workloads.c5_requests(250_000).to_batch(Flattener(lt))
+    batch = req_fn(250_000).to_batch(Flattener(lt))
     flags = capi.F_WANT_DERIVED_ROLES
     flags |= capi.F_LENIENT_SCOPE_SEARCH if mode == "lenient" else 0
     flags |= capi.F_STRICT_EVALUATION if mode == "strict" else 0
     got = table.check(batch, now_ns=NOW, flags=flags)
+    if req_fn is workloads.c5w_requests:     # principals with five to eight roles: the walk's 8 x 8 shape decides them
+        db = table.upload(batch)
+        assert "walk2_wide" in table.plan(db, flags)
+        db.close()
     want = ccheck.check(lt, batch, NOW, flags, threads=min(16, os.cpu_count() or 1))
     assert (got.status != capi.ST_UNSUPPORTED).all()
     ok = want.status != capi.ST_UNSUPPORTED
-    assert ok.mean() > 0.7
+    assert ok.mean() > 0.6
     for f in ("effect", "policy", "scope"):
         mism = np.nonzero(getattr(got, f)[ok] != getattr(want, f)[ok])[0]
         assert mism.size == 0, "%s: %d mismatches, first at %s" % (f, mism.size, mism[:5])

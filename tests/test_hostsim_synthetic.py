@@ -22,6 +22,9 @@ CONFIGS = {
     # C4 at 1/10 of its table size here (the GPU tier runs the 1000-policy table); C5 whole
     "C4": (lambda: workloads.c4_policies(n_policies=99), lambda n: workloads.c4_requests(n, n_policies=99)),
     "C5": (workloads.c5_policies, lambda n: workloads.c5_requests(n)),
+    # north_star's target set (100 policies / 10k rules, 100 rules per (kind, scope) bucket) and C5 with 5-8 roles per principal
+    "T": (workloads.t_policies, lambda n: workloads.t_requests(n)),
+    "C5W": (workloads.c5_policies, lambda n: workloads.c5w_requests(n)),
 }
 
 
