@@ -84,7 +84,12 @@ def main():
     ap.add_argument("--inproc-gpus", type=int, default=0, help="also time one engine over this many devices in THIS process")
     args = ap.parse_args()
 
-    # stdout carries exactly one JSON line: keep RCCL's version banner (NCCL_DEBUG=VERSION/INFO) off it
+    # stdout carries exactly one JSON line.  RCCL writes its banner and its warnings to file descriptor 1 from its own threads
+    # (seen: a warning landing in the middle of the line), so everything else that writes there is sent to stderr and the
+    # line goes out through a private copy of the original descriptor.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", "INFO"):
         os.environ["NCCL_DEBUG"] = "WARN"
     import torch
@@ -93,13 +98,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # CBH_BENCH_FORCE_DIST=1: take the multi-GPU code path (RCCL init, image broadcast, adopt) even with one rank
-    use_dist = world > 1 or os.environ.get("CBH_BENCH_FORCE_DIST") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the decision path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    # The multi-GPU code path (RCCL init, image broadcast, adopt) is taken with ONE rank too, so that every run executes it and
+    # `policy_bcast_ms` is a measured number (CBH_BENCH_NO_DIST=1: skip it at world 1).  A lone process brings its own rendezvous.
+    use_dist = world > 1 or os.environ.get("CBH_BENCH_NO_DIST") != "1"
+    dist_note = None
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1 and "MASTER_ADDR" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": str(local_rank)})
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        except Exception as e:   # a lone rank may go on without the collective; several ranks may not
+            if world > 1:
+                raise
+            use_dist, dist_note = False, "RCCL init failed at world 1: %s" % str(e)[:200]
 
     import __graft_entry__
     if rank == 0:
@@ -466,9 +484,10 @@ def main():
             "resolve_kernel_ms": resolve_ms,
             "allow_fraction": float((eff == 1).mean()),
             "policy_bcast_ms": bcast_ms,
+            "policy_bcast_note": dist_note or ("RCCL broadcast of the %d-byte image from rank 0 (world %d) + cbh_table_adopt_device_image" % (len(lt.blob), world) if use_dist else "skipped (CBH_BENCH_NO_DIST=1)"),
         }
         out.update(side)
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out, flush=True)
     for db in dbatches:
         db.close()
     table.close()

@@ -6,7 +6,7 @@
 #include <stdint.h>
 
 #define CBH_BLOB_MAGIC 0x31484243u /* "CBH1" */
-#define CBH_BLOB_VERSION 21u
+#define CBH_BLOB_VERSION 22u
 
 struct CbhBlobHeader {  // 32 bytes
   uint32_t magic;
@@ -74,6 +74,15 @@ enum CbhSectionId {
   CBH_SEC_ROWX = 40,         // u32[n_rows][8]  what cbh_check_walk2.h reads besides the record (CbhRowXField); rows with CBH_ROW_F_X
   CBH_SEC_RPX = 41,          // u32[n_rprows][16] role-policy rules for that kernel (CbhRpxField)
   CBH_SEC_STR_WFLAGS = 42,   // u8[K] CBH_SWF_*: what the walk would otherwise probe the directory for, lane by lane
+  // A FLAT table's buckets once more as SEGMENTS of up to 64 consecutive records each, held the way the reference's own index
+  // holds its rows - one bitmap per dimension value (index/index.go:270-305) - for the flat kernel's mask walk
+  // (cbh_check_flat.h).  Bit i of every mask = record i of the segment, in binding order.  A segment is one block, a multiple
+  // of 16 dwords: {CbhSegHdr}{u64 action_mask[32]}{u64 role_mask[32]}{u8 item of record i's condition [64]}{u8 ... of its
+  // derived-role condition [64]} (0xFF = none, or an item the lanes do not decide by themselves) {CbhSegDesc[n_items]}
+  // {u32 ref[n_items]: the items' condition references} {CbhSegItem[n_complex], on a 16-dword boundary}{CbhLeaf4[n_leaves],
+  // padded to a multiple of four}; the segments of a bucket follow each other (CBH_B_RESSEG: first block, count).
+  CBH_SEC_SEGS = 43,
+  CBH_SEC_LEAFPOOL = 44,     // CbhLeaf4[n] the distinct fused leaves of a POOLED table's conditions (CBH_M_SEGS), n <= 64, padded to a multiple of four
   CBH_SEC_ROWPAT = 29,       // u32[n_rows][8]  pattern halves of the rule records (CbhRowPatField order)
   CBH_SEC_ACTION_CLASS = 28, // u8[K] class (0..61) of a string that is a literal rule action of a resource policy, 63 = any other string
   CBH_SEC_HOST_NAMES = 27,   // host only: {u32 n, {u16 len, bytes}*} policy keys (CBH_P_TABLE ids), then the same for derived-role names
@@ -107,7 +116,48 @@ enum CbhMeta {
                              // _OPEN (bits 3, 4): the principal policies' rules do
   CBH_M_SENS_COLS = 21,      // bit c: an int / uint / list / map value in column c sends a classified leaf to the shared evaluator -
                              // the columns the host looks at to call a batch "plain" (cbh_engine.hip validate_batch)
+  CBH_M_SEGS = 23,          // CBH_MSEG_PRESENT: the table has CBH_SEC_SEGS; CBH_MSEG_POOLED: its conditions are built from at most 64
+                            // distinct fused leaves - numbered table-wide, in CBH_SEC_LEAFPOOL (bits 0..7: how many), the segments
+                            // carry none
   CBH_META_N = 24
+};
+#define CBH_MSEG_PRESENT 0x80000000u
+#define CBH_MSEG_POOLED 0x40000000u
+#define CBH_SEG_RECORDS 64u
+#define CBH_SEG_COMPLEX 16u     /* CbhSegItem entries of one segment at most */
+#define CBH_SEG_FIXED_DWORDS 176u   /* header + class masks + the two record -> item tables; the item descriptors follow */
+struct CbhSegHdr {   // 16 dwords
+  uint32_t allow_lo, allow_hi;       // the segment's ALLOW records
+  uint32_t deny_lo, deny_hi;         // ... its DENY records
+  uint32_t simple_c_lo, simple_c_hi; // the records whose condition is an item a lane decides by itself (CbhSegDesc)
+  uint32_t simple_d_lo, simple_d_hi; // ... whose derived-role condition is
+  uint32_t n_items, n_leaves;        // distinct conditions / fused leaves of the segment (n_leaves = 0 in a pooled table)
+  uint32_t size16;                   // the block's size in 16-dword units: the next segment of the bucket starts there
+  uint32_t n_records, row_begin;     // the records CBH_SEC_ROWS[row_begin .. row_begin + n_records)
+  uint32_t n_complex;                // CbhSegItem entries: the conditions the wave evaluates as one (deeper trees, more than four leaves, programs)
+  uint32_t off_refs_complex;         // dword offsets from the block's start: ref[] | CbhSegItem[] << 16
+  uint32_t off_leaves;               // ... of the segment's own fused-leaf records
+};
+struct CbhLeaf4 {    // 4 dwords: a classified fused leaf as the mask walk evaluates it (blob.py _compact_leaves)
+  uint32_t w;        // bits 0..3 class (celc.py _leaf_class 1, 2, 3, 4, 6; 0 = none of them), 4..11 the comparison (OP_EQ ..), 16..23 column, 24..31 second column
+  uint32_t c[3];     // class 1: constant's tag, low dword; class 2: the double's dwords; class 6: up to three string ids (CBH_NONE beyond)
+};
+struct CbhSegDesc {  // 2 dwords: ONE level of at most four classified leaves, in order (cbh_check_flat.h lane_items)
+  uint8_t leaf[4];   // numbers in the pool, or indices into the segment's leaves
+  uint8_t flags;     // bits 0..2 number of leaves (0 = not such an item: a CbhSegItem holds it), bit 3 any instead of all, bit 4 negated
+  uint8_t pad[3];
+};
+struct CbhSegItem {  // 16 dwords: one condition of a segment that the wave evaluates as one
+  uint32_t cc_lo, cc_hi;         // the records it is the rule condition of
+  uint32_t cd_lo, cd_hi;         // ... the derived-role condition of
+  uint32_t how;                  // bits 0..1: 1 = ONE level of classified leaves in leaf_idx order (bit 8: any instead of all, bit 9: the result
+                                 // negated - none(..) = not any(..); one fused leaf = all(leaf)), 2 = a deeper tree (ops + leaf_idx), 0 = neither
+  uint32_t ref;                  // the condition reference (what the shared evaluator runs where the inline code cannot decide)
+  uint32_t id;                   // its index among the segment's items
+  uint32_t n_leaves;
+  uint32_t leaf_idx[2];          // 8 x u8: the tree's leaves in order - numbers in the pool, or indices into the segment's leaves
+  uint32_t pad[2];
+  uint32_t ops[4];               // the tree's 4-bit ops (CBH_ROW_F_TREE_EMBEDDED)
 };
 #define CBH_MF_USES_RUNTIME_EDR 1u
 #define CBH_MF_HAS_PARENT_ROLES 2u
@@ -145,6 +195,8 @@ enum CbhBucketType {
                        // family holds no site the batch files needs no pre-pass walk
   CBH_B_RPROLES = 8,   // (ver sid, scope idx, 0) -> v0 off, v1 cnt into U32POOL: the roles with a role policy at that scope, sorted by
                        // name (the order of a role's ancestor list, ruletable/build.py)
+  CBH_B_RESSEG = 10,   // (ver sid, kind sid, scope idx), a table with CBH_SEC_SEGS: same key as RESOURCE -> v0 the bucket's first segment
+                       // block (16-dword units of CBH_SEC_SEGS), v1 segments, v2 dr_begin, v3 dr_count
 };
 
 // Condition reference (row / derived-role cond fields): bit31 set -> the program at (ref & ~bit31)

@@ -218,8 +218,163 @@ __device__ __forceinline__ u32 wave_max_bits(u32 v, bool in, u32 nbits) {
   return best;
 }
 
-template <bool WITH_CALL, bool STAGED>
+// ---- the mask walk's leaf results.  A fused leaf's outcome is one of four: false, true, CEL error, "needs the full evaluator"
+// (flat_leaf's 0 / 1 / 2 / 4) - two bits.  A wave keeps the outcomes of its (at most 64) numbered leaves in LDS, four leaves to
+// a byte, [leaf / 4][lane]: written leaf by leaf (wave-uniform number), read by each lane for the leaves ITS candidates'
+// conditions name (lane_items) - a byte read at a per-lane row.
+#define CBH_LV_ROWS 16u
+__device__ __forceinline__ u32 lv_code(const CBH_L u8* lvtab, u32 tid, u32 leaf) {   // 0 false, 1 true, 2 error, 3 needs the evaluator
+  return ((u32)lvtab[(leaf >> 2) * CBH_BLOCK + tid] >> ((leaf & 3u) * 2u)) & 3u;
+}
+__device__ __forceinline__ u32 lv_of_code(u32 code) { return code == 3u ? 4u : code; }   // back to flat_leaf's bits
+// ---- evaluating a pool of classified leaves (cbh_blob.h CbhLeaf4) for every lane of the wave.  Four leaves - one 16-dword
+// scalar load - at a time, and the four of a block are of ONE class (blob.py _layout_leaves pads a class's run), so a block's
+// code is straight-line: no dispatch per leaf, the comparison of a numeric leaf picked by masks instead of branches.  The
+// lane's last column stays in registers (a class's leaves are laid out by column).  The answers are flat_leaf's, as 2-bit
+// outcomes: 0 false, 1 true, 2 CEL error, 3 needs the full evaluator.
+struct __attribute__((aligned(64))) Leaf4x4 { u32 w[16]; };
+__device__ __forceinline__ void leaf_col(const Ctx& c, u32 w, u32 req, u32& curcol, FlatCol& x) {   // `w`, `curcol` wave-uniform
+  const u32 col = (w >> 16) & 0xFFu;
+  if (col != curcol) { x = flat_col(c, col, req); curcol = col; }
+}
+__device__ __forceinline__ u32 leaf_block_codes(const Ctx& c, const Leaf4x4& b, u32 req, u32 pid, u32& curcol, FlatCol& x) {
+  const u32 cls = b.w[0] & 15u;   // the block's class
+  u32 acc = 0;
+  if (cls == 1u) {          // column ==/!= string or bool constant
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+      const u32 w = b.w[4 * q];
+      leaf_col(c, w, req, curcol, x);
+      const bool ne = ((w >> 4) & 0xFFu) != OP_EQ;
+      const bool eq = x.t == b.w[4 * q + 1] && x.lo == b.w[4 * q + 2];
+      acc |= (x.t >= CBH_T_ABSENT ? 2u : (u32)(eq != ne)) << (2u * q);
+    }
+  } else if (cls == 2u) {   // column <op> double constant: what the comparison accepts is three wave-uniform masks
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+      const u32 w = b.w[4 * q], op = (w >> 4) & 0xFFu;
+      leaf_col(c, w, req, curcol, x);
+      const bool a_lt = op == OP_LT || op == OP_LE || op == OP_NE, a_eq = op == OP_EQ || op == OP_LE || op == OP_GE,
+                 a_gt = op == OP_GT || op == OP_GE || op == OP_NE, a_un = op == OP_NE;   // (NaN: every ordering false, != true)
+      const double p = as_f64((u64)x.lo | ((u64)x.hi << 32)), k = as_f64((u64)b.w[4 * q + 1] | ((u64)b.w[4 * q + 2] << 32));
+      const bool lt = p < k, eq = p == k, gt = p > k;
+      const bool cmp = (a_lt && lt) || (a_eq && eq) || (a_gt && gt) || (a_un && !(lt || eq || gt));
+      const bool dbl = x.t == CBH_T_DOUBLE, othernum = x.t == CBH_T_INT || x.t == CBH_T_UINT;
+      const bool ordering = op != OP_EQ && op != OP_NE;
+      const u32 r = dbl ? (u32)cmp : (u32)(op == OP_NE);   // a non-number is plainly unequal to a number
+      acc |= ((x.t >= CBH_T_ABSENT || (!dbl && !othernum && ordering)) ? 2u : othernum ? 3u : r) << (2u * q);
+    }
+  } else if (cls == 6u) {   // column in [at most three string constants]
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+      const u32 w = b.w[4 * q];
+      leaf_col(c, w, req, curcol, x);
+      const bool found = x.t == CBH_T_STRING && (x.lo == b.w[4 * q + 1] || x.lo == b.w[4 * q + 2] || x.lo == b.w[4 * q + 3]);
+      acc |= (x.t >= CBH_T_ABSENT ? 2u : (u32)found) << (2u * q);
+    }
+  } else if (cls == 4u) {   // column ==/!= P.id
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+      const u32 w = b.w[4 * q];
+      leaf_col(c, w, req, curcol, x);
+      const bool ne = ((w >> 4) & 0xFFu) != OP_EQ;
+      acc |= (x.t >= CBH_T_ABSENT ? 2u : (u32)((x.t == CBH_T_STRING && x.lo == pid) != ne)) << (2u * q);
+    }
+  } else if (cls == 3u) {   // column ==/!= column
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {
+      const u32 w = b.w[4 * q];
+      leaf_col(c, w, req, curcol, x);
+      const FlatCol y = flat_col(c, (w >> 24) & 0xFFu, req);
+      const bool ne = ((w >> 4) & 0xFFu) != OP_EQ;
+      const bool same = x.t == y.t;
+      const bool scalar = x.t < CBH_T_LIST || x.t == CBH_T_TIMESTAMP || x.t == CBH_T_DURATION;
+      const bool xnum = x.t == CBH_T_INT || x.t == CBH_T_UINT || x.t == CBH_T_DOUBLE, ynum = y.t == CBH_T_INT || y.t == CBH_T_UINT || y.t == CBH_T_DOUBLE;
+      const bool bits_eq = x.lo == y.lo && x.hi == y.hi;
+      const bool dbl_eq = as_f64((u64)x.lo | ((u64)x.hi << 32)) == as_f64((u64)y.lo | ((u64)y.hi << 32));
+      const bool eq = same && (x.t == CBH_T_DOUBLE ? dbl_eq : bits_eq);
+      const bool slow = (same && !scalar) || (!same && xnum && ynum);   // containers / cross-type numeric equality
+      acc |= ((x.t >= CBH_T_ABSENT || y.t >= CBH_T_ABSENT) ? 2u : slow ? 3u : (u32)(eq != ne)) << (2u * q);
+    }
+  } else acc = 0xFFu;       // none of the classified shapes: the shared evaluator's
+  return acc;
+}
+// `n` = slots of the pool (a multiple of four); `recs` wave-uniform.  The next block is in flight while this one is evaluated.
+__device__ __forceinline__ void eval_leaf_pool(const Ctx& c, const CBH_G u32* recs, u32 n, u32 req, u32 pid, CBH_L u8* lvtab) {
+  if (n == 0) return;
+  u32 curcol = CBH_NONE;
+  FlatCol cx; cx.t = 0; cx.lo = 0; cx.hi = 0;
+  const u32 nblk = (n + 3u) >> 2;
+  Leaf4x4 nxt = uload_rec<Leaf4x4>(recs, 0);
+  for (u32 g = 0; g < nblk; ++g) {
+    const Leaf4x4 b = nxt;
+    nxt = uload_rec<Leaf4x4>(recs, g + 1u < nblk ? g + 1u : g);
+    lvtab[g * CBH_BLOCK + c.tid] = (u8)leaf_block_codes(c, b, req, pid, curcol, cx);
+  }
+}
+// A deeper tree of classified leaves from the leaves' outcomes in `lvtab` (flat_tree's bookkeeping): `ops` / `idx` wave-uniform.
+__device__ __forceinline__ u32 tree_from_codes(const u32 (&opw)[4], u64 idx, const CBH_L u8* lvtab, u32 tid) {
+  bool live = true, last = false;
+  u32 saved = 0, acc = 0, depth = 0, err = 0, slow = 0;
+  for (u32 k = 0; k < 32; ++k) {
+    const u32 op = (opw[k >> 3] >> (4u * (k & 7u))) & 15u;
+    if (op == 0) break;
+    if (op == 1) {
+      const u32 code = lv_code(lvtab, tid, (u32)idx & 0xFFu); idx >>= 8;
+      last = live && code == 1u;
+      err |= (live && code == 2u) ? 2u : 0u;
+      slow |= (live && code == 3u) ? 4u : 0u;
+    } else if (op < 5) {
+      const u32 bit = 1u << depth;
+      saved = live ? (saved | bit) : (saved & ~bit);
+      acc = (op == 2) ? (acc | bit) : (acc & ~bit);
+      ++depth;
+    } else if (op < 8) {
+      const u32 bit = 1u << (depth - 1u);
+      const bool decides = live && ((op == 5) ? !last : last);
+      acc = decides ? ((op == 5) ? (acc & ~bit) : (acc | bit)) : acc;
+      live = live && !decides;
+    } else {
+      --depth;
+      const u32 bit = 1u << depth;
+      live = (saved & bit) != 0;
+      last = ((acc & bit) != 0) != (op == 10);
+    }
+  }
+  return slow ? 4u : ((u32)last | err);
+}
+// ONE level of leaves from their 2-bit outcomes packed in `w` (leaf j of the level = bits 2j, 2j + 1; `n` leaves):
+// all - the first leaf that is not satisfied decides (an error counts as not satisfied and is reported, check.go:697-749);
+// any - the first satisfied leaf decides; the leaves behind the deciding one are never evaluated by the reference, so their
+// errors / "needs the evaluator" outcomes do not count.  Everything may differ from lane to lane.  Returns flat_leaf's bits.
+__device__ __forceinline__ u32 level_from_codes(u32 w, u32 n, bool any, bool neg) {
+  const u32 F = 0x5555u & ((1u << (2u * n)) - 1u);   // bit 2j for the leaves that exist
+  const u32 lo = w & F, hi = (w >> 1) & F;
+  const u32 s = lo & ~hi, e = hi & ~lo, sl = lo & hi;   // satisfied / error / needs the evaluator, at bit 2j
+  const u32 dec = any ? s : (~s & F);                   // the leaves that would decide; the first of them does
+  const u32 first = dec & (0u - dec);
+  const u32 evald = dec ? (first | (first - 1u)) : F;   // the leaves the reference evaluates
+  const bool res = any ? dec != 0 : dec == 0;
+  return (evald & sl) ? 4u : ((u32)(res != neg) | ((evald & e) ? 2u : 0u));
+}
+struct __attribute__((aligned(64))) SegHdr { u32 allow_lo, allow_hi, deny_lo, deny_hi, sc_lo, sc_hi, sd_lo, sd_hi, n_items, n_leaves, size16, n_records, row_begin, n_complex, off_rc, off_leaves; };
+struct __attribute__((aligned(64))) SegItem { u32 cc_lo, cc_hi, cd_lo, cd_hi, how, ref, id, n_leaves, idx_lo, idx_hi, pad0, pad1, ops[4]; };
+// per wave, in LDS: the segment's class masks u64[64], record -> item u8[2][64], item descriptors u64[64], the leaves' outcomes u8[16][64]
+#define CBH_SEG_LDS_BYTES (512u + 128u + 512u + CBH_LV_ROWS * CBH_BLOCK)
+__device__ __forceinline__ u64 load_u64g(const CBH_G u32* p) {   // 8-byte aligned
+#ifndef CBH_HOSTSIM
+  return *(const CBH_G u64*)p;
+#else
+  u64 v; __builtin_memcpy(&v, p, 8); return v;
+#endif
+}
+
+// MODE 0: records one scalar load at a time; 1: staged 64 at a time in the lanes' registers; 2: no record is visited - the
+// bucket's SEGMENTS decide by masks (cbh_blob.h CBH_SEC_SEGS).
+template <bool WITH_CALL, int MODE>
 __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
+  constexpr bool STAGED = MODE == 1;
+  constexpr u32 BTYPE = MODE == 2 ? (u32)CBH_B_RESSEG : (u32)CBH_B_RESOURCE;
   const TableDev& t = ka_regs.t;
   const BatchDev& b = ka_regs.b;
   const OutDev& o = ka_regs.o;
@@ -267,6 +422,11 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   if (cls_in_lds) {
     for (u32 i = threadIdx.x; i < t.K; i += CBH_FLAT_THREADS) { cls_lds[i] = t.action_class[i]; cls_lds[t.K + i] = t.role_class[i]; }
   }
+  // MODE 2: the class masks of the segment being decided, per wave (behind the class tables: cbh_flat_class_bytes is a multiple of 16)
+  CBH_L u64* segm = (CBH_L u64*)(cls_lds + (cls_in_lds ? ((2u * t.K + 15u) & ~15u) : 0u)) + wave * (CBH_SEG_LDS_BYTES / 8u);
+  CBH_L u8* seg_rec = (CBH_L u8*)(segm + 64);      // [2][64]: record -> item of its condition / of its derived-role condition
+  CBH_L u64* seg_desc = segm + 64 + 16;            // [64] CbhSegDesc
+  CBH_L u8* lvtab = (CBH_L u8*)(segm + 64 + 16 + 64);   // [CBH_LV_ROWS][64]
   // Actions: a batch of four-action requests laid out back to back has ACT_OFF = 4 * request - read the four ids from
   // there with ONE 16-byte load that does not wait for ACT_OFF to arrive, and fall back to the dependent loads for the
   // lanes where the guess was wrong.
@@ -355,6 +515,10 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   const u32 first = chain_first(t, r_scope, FLAG_RES, lenient);   // per lane (ruletable.go:848-882)
   u32 cur = first, mydepth = 0;
   bool exists = false;
+  // MODE 2.  Pooled table: the leaves are numbered table-wide and evaluated ONCE per wave, when the first lane meets a
+  // candidate with a condition; else every segment brings its own.
+  const bool pooled = MODE == 2 && (t.seg_info & CBH_MSEG_POOLED) != 0;
+  bool leaves_done = false;   // wave-uniform
   FLAT_DBG(const u64 cyc2 = cyc1 + (__builtin_readcyclecounter() - cyc1) * (u64)(wave_ballot(first != 0xFFFFFFFEu) != 0);)   // chain starts known
   for (;;) {
     // a lane goes on while it has walks to decide, and after that until it knows that some policy exists
@@ -369,12 +533,149 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
     const bool go = wave_ballot(ing && S != 0) != 0;
     FLAT_DBG(++dbg_rounds;)
     uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
-    const bool have_bucket = udir_find(t, CBH_B_RESOURCE, g_ver, g_k, g_si, bucket);   // present for every resource policy (index.go:966-997)
+    const bool have_bucket = udir_find(t, BTYPE, g_ver, g_k, g_si, bucket);   // present for every resource policy (index.go:966-997)
     exists = exists || (ing && have_bucket);
     if (go) {
       if (ing && mydepth < max_depth) { if (chain8) chain_si8[mydepth * CBH_BLOCK + c.tid] = (u8)g_si; else chain_si[mydepth * CBH_BLOCK + c.tid] = g_si; }
       const u32 S_before = S;
-      if constexpr (STAGED) {
+      if constexpr (MODE == 2) {
+        // ---- the mask walk.  Index.Query answers a request with an AND of per-dimension bitmaps (index/index.go:270-305);
+        // so does this: per segment of <= 64 records, a lane's candidates = (OR of the masks of its action classes) &
+        // (OR of its role classes'); the fused leaves of the table's conditions are evaluated once per wave, for every lane
+        // (eval_leaf_pool); each lane then decides the conditions of ITS candidates from the leaves' outcomes (lane_items);
+        // and a walk's outcome in the segment is mask algebra: hits = candidates of (role, action) & satisfied records, the
+        // first DENY among them ends the walk (check.go:392-403), an ALLOW before it counts, an evaluation error before it counts.
+        u32 blk16 = bucket.x;
+        for (u32 sgi = 0; have_bucket && sgi < bucket.y && wave_ballot(ing && S != 0) != 0; ++sgi) {
+          const CBH_G u32* blk = t.segs + (size_t)blk16 * 16u;
+          const SegHdr hd = uload_rec<SegHdr>(t.segs, blk16);
+          blk16 += hd.size16;
+          // the segment's tables -> LDS, one element per lane: 64 class masks, 2 x 64 record -> item bytes (32 dwords), the items' descriptors
+          segm[c.tid] = load_u64g(blk + 16u + 2u * c.tid);
+          if (c.tid < 32u) ((CBH_L u32*)seg_rec)[c.tid] = blk[144u + c.tid];
+          if (c.tid < hd.n_items) seg_desc[c.tid] = load_u64g(blk + CBH_SEG_FIXED_DWORDS + 2u * c.tid);
+          (void)wave_ballot(true);
+          u64 A = 0, R = 0;
+#pragma unroll
+          for (u32 k = 0; k < 4; ++k) { if (k < act_cnt) A |= segm[ac[k]]; if (k < role_cnt) R |= segm[32u + rc[k]]; }
+          const u64 cand_any = (ing && S != 0) ? (A & R) : 0ull;
+          FLAT_DBG(dbg_rows += hd.n_records;)
+          if (wave_ballot(cand_any != 0) != 0) {
+            u64 csat = ~0ull, dsat = ~0ull, cerr = 0, derr = 0, cuns = 0, duns = 0;
+            const u64 simple_c = (u64)hd.sc_lo | ((u64)hd.sc_hi << 32), simple_d = (u64)hd.sd_lo | ((u64)hd.sd_hi << 32);
+            FLAT_DBG(const u64 i0 = __builtin_readcyclecounter();)
+            const bool any_cond = hd.n_complex != 0 || wave_ballot((cand_any & (simple_c | simple_d)) != 0) != 0;   // some candidate has a condition
+            if (any_cond && (!pooled || !leaves_done)) {   // the leaves' outcomes, for every lane of the wave
+              FLAT_DBG(const u64 l0 = __builtin_readcyclecounter();)
+              if (pooled) { eval_leaf_pool(c, t.leafpool, t.seg_info & 0xFFu, req, pid, lvtab); leaves_done = true; }
+              else eval_leaf_pool(c, blk + hd.off_leaves, hd.n_leaves, req, pid, lvtab);
+              (void)wave_ballot(true);
+              FLAT_DBG(cyc_stage += (__builtin_readcyclecounter() - l0) * (u64)(wave_ballot(req != 0xdeadbeefu) != 0); ++dbg_visits;)
+            }
+            // the conditions the wave evaluates as one (deeper trees, more than four leaves, programs): rare
+            for (u32 ci = 0; ci < hd.n_complex; ++ci) {
+              const SegItem it = uload_rec<SegItem>(blk + (hd.off_rc >> 16), ci);
+              const u64 cc = (u64)it.cc_lo | ((u64)it.cc_hi << 32), cd = (u64)it.cd_lo | ((u64)it.cd_hi << 32);
+              const bool need = ((cc | cd) & cand_any) != 0;
+              if (wave_ballot(need) == 0) continue;
+              FLAT_DBG(++dbg_evals;)
+              const u64 idx = (u64)it.idx_lo | ((u64)it.idx_hi << 32);
+              u32 lv = 4u;
+              if ((it.how & 3u) == 1u) {
+                u32 w = 0;
+                for (u32 j = 0; j < it.n_leaves; ++j) w |= lv_code(lvtab, c.tid, (u32)(idx >> (8u * j)) & 0xFFu) << (2u * j);
+                lv = level_from_codes(w, it.n_leaves, (it.how & 256u) != 0, (it.how & 512u) != 0);
+              } else if ((it.how & 3u) == 2u) lv = tree_from_codes(it.ops, idx, lvtab, c.tid);
+              const bool slow = need && lv == 4u;
+              if (WITH_CALL) {
+                if (wave_ballot(slow) != 0) {
+                  const u32 r = eval_ref<false>(c.ka_mem, lds_of(c), req, 0, false, it.ref, slow);
+                  if (slow) lv = ((r & 0xFFu) == 1u ? 1u : 0u) | (((r >> 8) & CBH_ST_CEL_ERROR) ? 2u : 0u) | (((r >> 8) & CBH_ST_UNSUPPORTED) ? 8u : 0u);
+                }
+              } else if (slow) lv = 8u;   // unreachable by the host's check; loud (UNSUPPORTED), never a guessed effect
+              csat &= (lv & 1u) ? ~0ull : ~cc; dsat &= (lv & 1u) ? ~0ull : ~cd;
+              cerr |= (lv & 2u) ? cc : 0ull; derr |= (lv & 2u) ? cd : 0ull; cuns |= (lv & 8u) ? cc : 0ull; duns |= (lv & 8u) ? cd : 0ull;
+            }
+            // every lane by itself: its candidates' conditions that are ONE level of at most four leaves (nearly all are), from
+            // the leaves' outcomes - straight-line code, as many rounds as the lane with the most such candidates has
+            u64 cslow = 0, dslow = 0;
+            auto lane_items = [&](u64 m, const CBH_L u8* rec, u64& sat, u64& errm, u64& slowm) {
+              while (wave_ballot(m != 0) != 0) {
+                const bool act = m != 0;
+                const u32 i = act ? ctz64(m) : 0u;
+                m &= m - 1ull;
+                const u32 itx = rec[i];
+                const u64 d = seg_desc[itx < CBH_SEG_RECORDS ? itx : 0u];
+                const u32 lw = (u32)d, fl = (u32)(d >> 32);
+                u32 w = 0;
+#pragma unroll
+                for (u32 j = 0; j < 4; ++j) w |= lv_code(lvtab, c.tid, (lw >> (8u * j)) & 0xFFu) << (2u * j);
+                const u32 lv = level_from_codes(w, fl & 7u, (fl & 8u) != 0, (fl & 16u) != 0);
+                const u64 bit = act ? (1ull << i) : 0ull;
+                sat &= (lv & 1u) ? ~0ull : ~bit;
+                errm |= (lv & 2u) ? bit : 0ull;
+                slowm |= (lv & 4u) ? bit : 0ull;
+                FLAT_DBG(++dbg_evals;)
+              }
+            };
+            if (simple_c) lane_items(cand_any & simple_c, seg_rec, csat, cerr, cslow);
+            if (simple_d) lane_items(cand_any & simple_d, seg_rec + CBH_SEG_RECORDS, dsat, derr, dslow);
+            // a leaf that needs the full evaluator (int / uint / container values): the variant with the call runs the item's
+            // program for the lanes whose candidate it is, one record at a time; the other variant cannot meet one (the host checks)
+            if (wave_ballot((cslow | dslow) != 0) != 0) {
+              if (WITH_CALL) {
+                for (;;) {
+                  const u64 who = wave_ballot((cslow | dslow) != 0);
+                  if (who == 0) break;
+                  const u32 ld = first_lane(who);
+                  const u64 lc = wave_readlane64(cslow, ld), ldd = wave_readlane64(dslow, ld);
+                  const bool is_d = lc == 0;
+                  const u32 i = ctz64(is_d ? ldd : lc);
+                  const u64 bit = 1ull << i;
+                  const u32 itx = uniform((u32)seg_rec[(is_d ? CBH_SEG_RECORDS : 0u) + i]);
+                  const u32 ref = uload(blk + (hd.off_rc & 0xFFFFu) + itx);
+                  const bool mine = ((is_d ? dslow : cslow) & bit) != 0;
+                  const u32 r = eval_ref<false>(c.ka_mem, lds_of(c), req, 0, false, ref, mine);
+                  if (mine) {
+                    const bool ok = (r & 0xFFu) == 1u, e = ((r >> 8) & CBH_ST_CEL_ERROR) != 0, u = ((r >> 8) & CBH_ST_UNSUPPORTED) != 0;
+                    if (is_d) { dslow &= ~bit; dsat = ok ? (dsat | bit) : dsat; derr |= e ? bit : 0ull; duns |= u ? bit : 0ull; }
+                    else { cslow &= ~bit; csat = ok ? (csat | bit) : csat; cerr |= e ? bit : 0ull; cuns |= u ? bit : 0ull; }
+                  }
+                }
+              } else { cuns |= cslow; duns |= dslow; }   // loud (UNSUPPORTED), never a guessed effect
+            }
+            FLAT_DBG(cyc_eval += (__builtin_readcyclecounter() - i0) * (u64)(wave_ballot(csat != 77u) != 0);)
+            // the derived-role condition comes first; the rule's own condition counts only where that held (check.go:328-380)
+            const u64 satrec = dsat & csat, errrec = derr | (dsat & cerr), unsrec = duns | (dsat & cuns);
+            const u64 allow_m = (u64)hd.allow_lo | ((u64)hd.allow_hi << 32), deny_m = (u64)hd.deny_lo | ((u64)hd.deny_hi << 32);
+            const bool anybad = wave_ballot(((errrec | unsrec) & cand_any) != 0) != 0;
+            u64 amk[4];
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) amk[k] = segm[ac[k]] & satrec;
+#pragma unroll
+            for (u32 r = 0; r < 4; ++r) {
+              if (wave_ballot(ing && ((S >> (4u * r)) & 0xFu) != 0) == 0) continue;   // no lane has a live walk of its r-th role
+              const u64 rmk = segm[32u + rc[r]];
+#pragma unroll
+              for (u32 k = 0; k < 4; ++k) {
+                const u32 bit = 1u << (4u * r + k);
+                const bool live = ing && (S & bit) != 0;
+                const u64 hits = live ? (rmk & amk[k]) : 0ull;   // the walk's candidates whose conditions hold
+                const u64 dh = hits & deny_m;
+                has_allow |= (hits & allow_m) ? bit : 0u;   // (a walk a DENY ends leaves S: its has_allow bit is never read again)
+                if (anybad) {
+                  const u64 cand = live ? (rmk & segm[ac[k]]) : 0ull;
+                  const u64 below = dh ? (((dh & (0ull - dh)) << 1) - 1ull) : ~0ull;   // the records met up to and including the first satisfied DENY (a tree can be satisfied AND have absorbed an error)
+                  err |= (cand & errrec & below) ? bit : 0u;
+                  unsup |= (cand & unsrec & below) ? bit : 0u;
+                }
+                if (dh) { deny |= bit; S &= ~bit; }   // ends this walk (check.go:392-403)
+              }
+            }
+          }
+          (void)wave_ballot(true);   // (the next segment's tables overwrite these)
+        }
+      } else if constexpr (STAGED) {
         if (have_bucket && bucket.y) {
           const u32 end = bucket.x + bucket.y;
           for (u32 base = bucket.x; base < end && wave_ballot(ing && S != 0) != 0; base += CBH_BLOCK) {   // bindings in order (check.go:295-414)
@@ -528,7 +829,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
       const u32 g_ver = wave_readlane(r_ver, lead), g_k = wave_readlane(kind, lead);
       const bool ing = active && cur2 == g_si && r_ver == g_ver && kind == g_k;
       uint4 bucket; bucket.x = bucket.y = bucket.z = bucket.w = 0;
-      if (udir_find(t, CBH_B_RESOURCE, g_ver, g_k, g_si, bucket)) {
+      if (udir_find(t, BTYPE, g_ver, g_k, g_si, bucket)) {
         for (u32 d = bucket.z; d < bucket.z + bucket.w; ++d) {
           const TblDrx dx = uload_rec<TblDrx>(t.drx, d);
           const bool applies = ing && (dx.rm_lo & lane_rc) != 0;   // parent roles x the request's roles (check.go:244)
@@ -594,24 +895,40 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 // batches of plain scalars (no int / uint / list / map attribute values): no call, ~64 VGPRs, 7-8 waves per SIMD
 __global__ CBH_FLAT_ATTRS(7) void cbh_check_flat_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
   CBH_FLAT_CTX(a, ka);
-  flat_body<false, false>(a, c);
+  flat_body<false, 0>(a, c);
 }
 // any batch: the same walk with the call into the shared evaluator compiled in (4 waves per SIMD)
 __global__ CBH_FLAT_ATTRS(4) void cbh_check_flat_kernel_any(const KernelArgs a, const KernelArgs* __restrict__ ka) {
   CBH_FLAT_CTX(a, ka);
-  flat_body<true, false>(a, c);
+  flat_body<true, 0>(a, c);
 }
 // tables with long buckets (more than CBH_FLAT_STAGE_MIN rule records in one policy): the records arrive 64 at a time in
 // the lanes' registers (stage_rec) instead of one scalar load per visit - 16 more VGPRs, 5 waves per SIMD
 __global__ CBH_FLAT_ATTRS(5) void cbh_check_flat_kernel_staged(const KernelArgs a, const KernelArgs* __restrict__ ka) {
   CBH_FLAT_CTX(a, ka);
-  flat_body<false, true>(a, c);
+  flat_body<false, 1>(a, c);
 }
 __global__ CBH_FLAT_ATTRS(4) void cbh_check_flat_kernel_any_staged(const KernelArgs a, const KernelArgs* __restrict__ ka) {
   CBH_FLAT_CTX(a, ka);
-  flat_body<true, true>(a, c);
+  flat_body<true, 1>(a, c);
+}
+// tables with segments (cbh_blob.h CBH_SEC_SEGS) and long buckets: the mask walk - no record is visited
+__global__ CBH_FLAT_ATTRS(4) void cbh_check_flat_kernel_masks(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+  CBH_FLAT_CTX(a, ka);
+  flat_body<false, 2>(a, c);
+}
+__global__ CBH_FLAT_ATTRS(3) void cbh_check_flat_kernel_any_masks(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+  CBH_FLAT_CTX(a, ka);
+  flat_body<true, 2>(a, c);
 }
 #define CBH_FLAT_STAGE_MIN 32u
+// the mask walk decides a table that has segments and long buckets (CBH_FLAT_MASKS=0: never, =1: whatever the buckets' length - tests, A/B)
+static inline bool cbh_flat_use_masks(const void* segs, u32 max_bucket) {
+  static const char* e = getenv("CBH_FLAT_MASKS");
+  static const bool force_staged = getenv("CBH_FORCE_STAGED") != nullptr;
+  if ((e && *e == '0') || force_staged) return false;
+  return segs != nullptr && ((e && *e == '1') || max_bucket > CBH_FLAT_STAGE_MIN);
+}
 
 // Which kernel decides this batch: a flat one when table (CBH_MF_FLAT), batch shape (<= 4 actions and <= 4 roles per
 // request; `plain_tags`: no attribute value is an int / uint / list / map - selects the variant without the evaluator call)
@@ -626,12 +943,16 @@ static inline size_t cbh_flat_chain_bytes(u32 table_max_depth, u32 table_scopes)
 static inline size_t cbh_flat_class_bytes(u32 table_strings) {
   return table_strings <= CBH_FLAT_LDS_STRINGS ? (((size_t)2 * table_strings + 15) & ~(size_t)15) : 0;
 }
+// ... and, for the mask walk, a segment's class masks per wave
+static inline size_t cbh_flat_mask_bytes(u32 threads) { return (size_t)(threads / CBH_BLOCK) * CBH_SEG_LDS_BYTES; }
+static inline bool cbh_is_mask_kernel(cbh_check_kernel_fn fn) { return fn == cbh_check_flat_kernel_masks || fn == cbh_check_flat_kernel_any_masks; }
 static inline cbh_check_kernel_fn cbh_pick_kernel(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 max_actions, u32 max_roles, bool plain_tags,
-                                                  u32 eval_flags, u32 max_bucket, u32* threads, bool* flat) {
+                                                  u32 eval_flags, u32 max_bucket, u32* threads, bool* flat, bool masks = false) {
   *flat = (table_flags & CBH_MF_FLAT) && max_actions <= 4 && max_roles <= 4 && !(eval_flags & CBH_F_STRICT_EVALUATION);
   if (*flat) {
     *threads = CBH_FLAT_THREADS;
     const bool staged = max_bucket > CBH_FLAT_STAGE_MIN;
+    if (masks) return (plain_tags && (table_flags & CBH_MF_FLAT_CLOSED)) ? cbh_check_flat_kernel_masks : cbh_check_flat_kernel_any_masks;
     if (plain_tags && (table_flags & CBH_MF_FLAT_CLOSED)) return staged ? cbh_check_flat_kernel_staged : cbh_check_flat_kernel;
     return staged ? cbh_check_flat_kernel_any_staged : cbh_check_flat_kernel_any;
   }

@@ -875,10 +875,10 @@ struct CbhPlan {
   bool walk_awide;                   // kind 2, batch with requests of nine to sixteen actions: cbh_walk2_awide_kernel (+ its pre-pass) for those
 };
 static inline CbhPlan cbh_plan(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 gslots_generic, u32 gslots_all, u32 max_actions,
-                               u32 max_roles, bool plain_tags, u32 eval_flags, bool no_flat, bool no_walk2, u32 max_bucket, bool no_walk2_wide = false) {
+                               u32 max_roles, bool plain_tags, u32 eval_flags, bool no_flat, bool no_walk2, u32 max_bucket, bool no_walk2_wide = false, bool masks = false) {
   CbhPlan p; p.n_gwords = 0; p.n_gslots = 0; p.wide_kernel = nullptr; p.walk_wide = false; p.walk_awide = false;
   bool flat = false;
-  p.kernel = cbh_pick_kernel(no_flat ? (table_flags & ~(u32)CBH_MF_FLAT) : table_flags, n_derived_roles, has_globs, max_actions, max_roles, plain_tags, eval_flags, max_bucket, &p.threads, &flat);
+  p.kernel = cbh_pick_kernel(no_flat ? (table_flags & ~(u32)CBH_MF_FLAT) : table_flags, n_derived_roles, has_globs, max_actions, max_roles, plain_tags, eval_flags, max_bucket, &p.threads, &flat, masks);
   p.kind = flat ? 1 : 0;
   if (!flat && !no_walk2 && cbh_walk2_applies(table_flags, eval_flags)) {
     // (the batch's maxima only: a launch that finds no request of its class costs a few idle waves)
@@ -903,6 +903,7 @@ static inline size_t cbh_plan_lds(const CbhPlan& p, u32 table_flags, u32 table_m
   const u32 ncc = n_columns < CBH_CACHE_COLS ? n_columns : CBH_CACHE_COLS;
   if (p.kind == 2) return w2_lds_bytes(w2_layout(pre ? ncc : inline_cols, (table_flags & CBH_MF_NEEDS_ARENA) != 0, table_max_depth, table_scopes, pre, p.n_gwords, table_strings, table_n_dr, na), pre ? 1u : CBH_W2_WAVES);
   const size_t wave = cbh_general_lds(table_flags, n_columns);
-  if (p.kind == 1) return (wave + cbh_flat_chain_bytes(table_max_depth, table_scopes)) * (p.threads / CBH_BLOCK) + cbh_flat_class_bytes(table_strings);
+  if (p.kind == 1) return (wave + cbh_flat_chain_bytes(table_max_depth, table_scopes)) * (p.threads / CBH_BLOCK) + cbh_flat_class_bytes(table_strings)
+                          + (cbh_is_mask_kernel(p.kernel) ? cbh_flat_mask_bytes(p.threads) : 0);
   return wave;
 }

@@ -580,7 +580,7 @@ static CbhPlan plan_for(const TableDev& dev, u32 max_actions, u32 max_roles, boo
   const bool has_globs = (dev.nfa_words[0] | dev.nfa_words[1] | dev.nfa_words[2]) != 0 || (dev.flags & CBH_MF_HAS_ANY_PATTERN);
   static const bool force_staged = getenv("CBH_FORCE_STAGED") != nullptr;   // (tests: the staged record walk on tables of any size)
   return cbh_plan(dev.flags, dev.n_dr, has_globs, dev.gslots_generic, dev.gslots_all, max_actions, max_roles, plain_tags, eval_flags, no_flat, no_walk2,
-                  force_staged ? 0xFFFFFFFFu : dev.max_bucket, no_walk2_wide);
+                  force_staged ? 0xFFFFFFFFu : dev.max_bucket, no_walk2_wide, cbh_flat_use_masks(dev.segs, dev.max_bucket));
 }
 // the launches that decide the requests [lo, hi) of `ka.b`; [wide_lo, wide_hi) = where the batch's requests wider than
 // cbh_walk2_kernel's shape lie (empty: none)
@@ -709,7 +709,8 @@ extern "C" const char* cbh_plan_describe(cbh_table* t, cbh_device_batch* b, cons
   const CbhPlan pl = plan_for(b->rep->dev, b->max_actions, b->max_roles, b->plain_tags, p->flags & ~(u32)CBH_FI_MASK);
   if (pl.kind == 2) s = std::string(pl.wide_kernel ? "cbh_check_kernel*(wide requests)+" : "") + (pl.walk_wide ? "cbh_walk2_wide_kernel(5-8 roles)+" : "") + (pl.walk_awide ? "cbh_walk2_awide_kernel(9-16 actions)+" : "") + (pl.n_gwords && b->dev.gres ? "cbh_walk2_pre_kernel+" : "") + "cbh_walk2_kernel";
   else if (pl.kind == 1) s = pl.kernel == cbh_check_flat_kernel ? "cbh_check_flat_kernel" : pl.kernel == cbh_check_flat_kernel_any ? "cbh_check_flat_kernel_any"
-                           : pl.kernel == cbh_check_flat_kernel_staged ? "cbh_check_flat_kernel_staged" : "cbh_check_flat_kernel_any_staged";
+                           : pl.kernel == cbh_check_flat_kernel_staged ? "cbh_check_flat_kernel_staged" : pl.kernel == cbh_check_flat_kernel_masks ? "cbh_check_flat_kernel_masks"
+                           : pl.kernel == cbh_check_flat_kernel_any_masks ? "cbh_check_flat_kernel_any_masks" : "cbh_check_flat_kernel_any_staged";
   else s = "cbh_check_kernel*";
   return s.c_str();
 }

@@ -61,6 +61,10 @@ static inline const char* cbh_parse_image(TableDev& d, std::vector<uint32_t>& me
   }
   d.gslots_generic = m[CBH_M_GSLOTS_GENERIC]; d.gslots_all = m[CBH_M_GSLOTS_ALL];
   d.inline_cols = m[CBH_M_INLINE_COLS]; d.sens_cols = m[CBH_M_SENS_COLS]; d.q_sites = m[CBH_M_Q_SITES];
+  d.seg_info = m[CBH_M_SEGS]; d.segs = (const u32*)dptr(CBH_SEC_SEGS); d.leafpool = (const u32*)dptr(CBH_SEC_LEAFPOOL);
+  if ((d.seg_info & CBH_MSEG_PRESENT) && (!d.segs || !d.leafpool || !(m[CBH_M_FLAGS] & CBH_MF_FLAT))) return ("blob segment sections are inconsistent");
+  if ((d.seg_info & 0xFFu) > CBH_SEG_RECORDS) return ("blob leaf pool too large");
+  if (!(d.seg_info & CBH_MSEG_PRESENT)) { d.segs = nullptr; d.leafpool = nullptr; }
   d.str_wflags = dptr(CBH_SEC_STR_WFLAGS);
   if (!d.str_wflags) return ("blob is missing the string flag section");
   if (d.inline_cols > CBH_CACHE_COLS || d.inline_cols > m[CBH_M_NCOLUMNS]) return ("blob inline column count out of range");
@@ -108,6 +112,50 @@ static inline const char* cbh_parse_image(TableDev& d, std::vector<uint32_t>& me
     d.max_bucket = 0;
     for (uint64_t i = 0; i <= d.hash_mask; ++i)
       if (slots[i].k0 == CBH_B_RESOURCE && slots[i].v1 > d.max_bucket) d.max_bucket = slots[i].v1;
+    // the segments the mask walk follows (cbh_check_flat.h): every bucket's chain of blocks stays inside the section, item and
+    // leaf numbers inside what the kernel keeps one bit each for
+    if (d.seg_info & CBH_MSEG_PRESENT) {
+      const CbhBlobSection* ss = find(CBH_SEC_SEGS);
+      const CbhBlobSection* ls = find(CBH_SEC_LEAFPOOL);
+      const uint64_t seg16 = ss->nbytes / 64, pool_n = d.seg_info & 0xFFu;
+      if (ls->nbytes < ((pool_n + 3) / 4) * 64) return ("blob leaf pool too small");
+      const bool pooled = (d.seg_info & CBH_MSEG_POOLED) != 0;
+      const uint32_t* sw = reinterpret_cast<const uint32_t*>(host_copy + ss->offset);
+      for (uint64_t i = 0; i <= d.hash_mask; ++i) {
+        if (slots[i].k0 != CBH_B_RESSEG) continue;
+        uint64_t at = slots[i].v0;
+        for (uint32_t sgi = 0; sgi < slots[i].v1; ++sgi) {
+          if (at + CBH_SEG_FIXED_DWORDS / 16 > seg16) return ("blob segment out of range");
+          const CbhSegHdr* hd = reinterpret_cast<const CbhSegHdr*>(sw + at * 16);
+          const uint64_t size = (uint64_t)hd->size16 * 16, off_refs = hd->off_refs_complex & 0xFFFFu, off_cx = hd->off_refs_complex >> 16;
+          if (hd->n_items > CBH_SEG_RECORDS || hd->n_leaves > CBH_SEG_RECORDS || hd->n_records > CBH_SEG_RECORDS || hd->n_complex > CBH_SEG_COMPLEX ||
+              at + hd->size16 > seg16 || (pooled && hd->n_leaves) || CBH_SEG_FIXED_DWORDS + 2ull * hd->n_items > size ||
+              off_refs + hd->n_items > size || (off_cx & 15u) || off_cx + 16ull * hd->n_complex > size || (hd->off_leaves & 15u) ||
+              hd->off_leaves + 16ull * ((hd->n_leaves + 3) / 4) > size)
+            return ("blob segment header out of range");
+          const uint32_t n_leaf = pooled ? (uint32_t)pool_n : hd->n_leaves;
+          const uint8_t* rec = reinterpret_cast<const uint8_t*>(sw + at * 16 + 144);
+          const uint64_t simple_c = hd->simple_c_lo | ((uint64_t)hd->simple_c_hi << 32), simple_d = hd->simple_d_lo | ((uint64_t)hd->simple_d_hi << 32);
+          const CbhSegDesc* ds = reinterpret_cast<const CbhSegDesc*>(sw + at * 16 + CBH_SEG_FIXED_DWORDS);
+          for (uint32_t k = 0; k < CBH_SEG_RECORDS; ++k)
+            for (int which = 0; which < 2; ++which) {
+              if (!(((which ? simple_d : simple_c) >> k) & 1)) continue;
+              const uint32_t itx = rec[which * 64 + k];
+              if (itx >= hd->n_items) return ("blob segment record names no item");
+              const uint32_t n = ds[itx].flags & 7u;
+              if (n == 0 || n > 4 || (ds[itx].flags & ~0x1Fu)) return ("blob segment item descriptor out of range");
+              for (uint32_t j = 0; j < n; ++j) if (ds[itx].leaf[j] >= n_leaf) return ("blob segment leaf number out of range");
+            }
+          const CbhSegItem* it = reinterpret_cast<const CbhSegItem*>(sw + at * 16 + off_cx);
+          for (uint32_t k = 0; k < hd->n_complex; ++k) {
+            if ((it[k].how & 3u) > 2 || (it[k].how & ~0x303u) || it[k].n_leaves > 8 || it[k].id >= hd->n_items) return ("blob segment item out of range");
+            for (uint32_t j = 0; j < ((it[k].how & 3u) ? it[k].n_leaves : 0u); ++j)
+              if (((j < 4 ? it[k].leaf_idx[0] >> (8 * j) : it[k].leaf_idx[1] >> (8 * (j - 4))) & 0xFFu) >= n_leaf) return ("blob segment leaf number out of range");
+          }
+          at += hd->size16;
+        }
+      }
+    }
   }
   return nullptr;
 }

@@ -73,6 +73,8 @@ struct TableDev {
   u32 max_depth;                                            // longest scope chain of the table (entries), computed at load
   u32 n_scopes;                                             // scopes are numbered parents first (root = 0): a deeper scope has the larger index
   u32 max_bucket;                                           // most rule records in one resource-policy bucket, computed at load (selects cbh_check_flat_kernel_staged)
+  const CBH_G u32* segs; const CBH_G u32* leafpool;         // CBH_SEC_SEGS / CBH_SEC_LEAFPOOL (the flat kernel's mask walk), null without
+  u32 seg_info;                                             // CBH_M_SEGS
 };
 
 struct BatchDev {

@@ -25,7 +25,7 @@ from .celc import COND_LEAF, COND_LEAFTREE, COND_PC_MASK, LoweringError, Params,
 from .globs import GlobNFA, has_meta
 
 BLOB_MAGIC = 0x31484243
-BLOB_VERSION = 21
+BLOB_VERSION = 22
 NONE = 0xFFFFFFFF
 PAT_GLOB = 0x80000000
 PAT_ANY = 0x7FFFFFFF     # the lone "*": matches every string, no automaton needed
@@ -48,6 +48,14 @@ ROW_F_X, ROW_F_XEXACT, ROW_F_OUTPUT = 1024, 2048, 4096
 MF_TRACE_ALL = 4096    # the older kernels cannot tell which inputs of this table need the trace pass: they mark every one
 SEC_ROWX, SEC_RPX, SEC_STR_WFLAGS = 40, 41, 42
 B_RPROLES, B_FAMILY = 8, 9
+B_RESSEG = 10                         # (ver sid, kind sid, scope idx) -> v0 first segment block (16-dword units of CBH_SEC_SEGS), v1 segments, v2 dr_begin, v3 dr_count
+SEC_SEGS, SEC_LEAFPOOL = 43, 44
+M_SEGS = 23                           # CBH_M_SEGS: M_SEGS_PRESENT | M_SEGS_POOLED | leaves in CBH_SEC_LEAFPOOL
+M_SEGS_PRESENT, M_SEGS_POOLED, M_SEGS_ITEMS_POOLED = 1 << 31, 1 << 30, 1 << 29
+SEG_RECORDS = 64                      # records (and distinct conditions, and distinct leaves) per segment: one bit each of a 64-bit mask
+SEG_TAIL_PAD = 0
+SEG_COMPLEX = 16                      # items of a segment the lanes cannot decide by themselves (deeper trees, more than four leaves, programs)
+SEG_FIXED_DWORDS = 176                # header 16 + class masks 128 + the two record -> item tables 32
 SWF_PRINCIPAL, SWF_PARENTS = 1, 2     # CBH_SEC_STR_WFLAGS bits
 SCOPE_F_ROLEPOL = 16                  # CBH_SEC_SCOPE_FLAGS bit 4: some role policy lives at this scope
 M_GSLOTS_GENERIC, M_GSLOTS_ALL, M_INLINE_COLS, M_SENS_COLS, M_Q_SITES = 18, 19, 20, 21, 22
@@ -888,19 +896,6 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
     entries[:] = [((e[0], e[1], e[2], e[3], 1 | bucket_sites.get(e[1:4], 0)) + (lambda u: (u[0] & 0xFFFFFFFF, u[0] >> 32, u[1]))(bucket_union.get(e[1:4], (0, 0)))) if e[0] == B_RESEXISTS else e
                   for e in entries]
 
-    # ---- directory hash table
-    nslots = 16
-    while nslots < 2 * len(entries):
-        nslots *= 2
-    slots = np.full((nslots, 8), NONE, dtype=np.uint32)
-    for e in entries:
-        i = hash4(e[0], e[1], e[2], e[3]) & (nslots - 1)
-        while slots[i, 0] != NONE:
-            if tuple(slots[i, :4]) == e[:4]:
-                raise LoweringError("duplicate directory key %r" % (e[:4],))
-            i = (i + 1) & (nslots - 1)
-        slots[i, :] = e
-
     # ---- assemble
     lt.columns = [k for k, _ in sorted(pb.columns.items(), key=lambda kv: kv[1])]
     lt.per_call_globals = pb.per_call_globals
@@ -915,7 +910,6 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
     meta[M_NSTRINGS] = K
     meta[M_NCOLUMNS] = len(lt.columns)
     meta[M_NSCOPES] = len(lt.scopes)
-    meta[M_HASH_MASK] = nslots - 1
     meta[M_NROWS] = len(row_cols[0])
     meta[M_NRPROWS] = len(rp_cols[0])
     meta[M_NDR] = len(dr_cols[0])
@@ -947,6 +941,30 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
         for i, f in enumerate(row_cols[ROW_FLAGS])) and all(
         inline_ok(drx_cols[3][i], drx_cols[15][i], drx_cols[2][i] & 1, drx_cols[2][i] & 2) for i in range(len(drx_cols[0])))
     meta[M_FLAGS] |= MF_FLAT_CLOSED if closed else 0
+    # ---- segments (cbh_check_flat.h, the mask walk): a flat table's buckets once more, 64 records at a time, as the
+    # reference's own index holds them - one bitmap per dimension value (index/index.go:270-305, bitmap.go:109-158)
+    seg_words, leaf_pool, n_pool_leaves = [], [], 0
+    if flat:
+        seg_words, leaf_pool, seg_entries, seg_stats = _segments(
+            [e for e in entries if e[0] == B_RESOURCE], row_cols, leaf2_cols, pb)
+        entries.extend(seg_entries)
+        n_pool_leaves = seg_stats["pool_slots"]
+        meta[M_SEGS] = M_SEGS_PRESENT | (M_SEGS_POOLED if seg_stats["pooled"] else 0) | n_pool_leaves
+        lt.seg_stats = seg_stats
+
+    # ---- directory hash table
+    nslots = 16
+    while nslots < 2 * len(entries):
+        nslots *= 2
+    slots = np.full((nslots, 8), NONE, dtype=np.uint32)
+    for e in entries:
+        i = hash4(e[0], e[1], e[2], e[3]) & (nslots - 1)
+        while slots[i, 0] != NONE:
+            if tuple(slots[i, :4]) == e[:4]:
+                raise LoweringError("duplicate directory key %r" % (e[:4],))
+            i = (i + 1) & (nslots - 1)
+        slots[i, :] = e
+    meta[M_HASH_MASK] = nslots - 1
     meta[M_FLAGS] |= 1024 if pb.needs_arena else 0   # CBH_MF_NEEDS_ARENA: the interpreter kernels get the lanes' list arenas
     # WALK2 (cbh_check_walk2.h): every record decided by class masks + glob bits, derived roles by class, no program that
     # reads runtime.effectiveDerivedRoles (its value is the scope's being walked: the older kernel keeps those tables)
@@ -1016,6 +1034,8 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
         (SEC_ROWX, n_rows_total, rowx.tobytes()),
         (SEC_RPX, n_rp_total, rpx.tobytes()),
         (SEC_STR_WFLAGS, K, str_wflags.tobytes()),
+        (SEC_SEGS, len(seg_words) // 16, u32(seg_words + [0] * (16 * SEG_TAIL_PAD))),   # (+ a tail the speculative staging loads may read)
+        (SEC_LEAFPOOL, n_pool_leaves, u32(leaf_pool + [0] * 16)),
         (SEC_REGEX, len(pb.regex_words), u32(pb.regex_words)),   # DFA tables of constant `matches` patterns (lower/regex.py)
         (SEC_RPROWS, len(rp_cols[0]), row_major(rp_cols, 4)),
         (SEC_U32POOL, len(pool), u32(pool)),
@@ -1125,6 +1145,260 @@ def _tree_descriptor(strip):
     ops 16-23, ops 24-31, number of leaves, 0, 7}."""
     packed, n, first = strip
     return [packed[0], packed[1], first, packed[2], packed[3], n, 0, 7]
+
+
+def _layout_leaves(leaves):
+    """Fused-leaf records (8 dwords, celc.py _leaf_record) -> (slot of each leaf, the words of their 4-dword forms, slots).
+
+    The mask walk evaluates a pool front to back, FOUR leaves (one 16-dword scalar load) at a time, and the four of a block
+    are of one class - the block's code is straight-line, no per-leaf dispatch (cbh_check_flat.h eval_leaf_pool): the leaves
+    are laid out by (class, column) and every class's run is padded to a multiple of four with copies of its last leaf.
+    CbhLeaf4 (cbh_blob.h): {class | op << 4 | column << 16 | second column << 24, c0, c1, c2} - class 1: c0 = the constant's
+    tag, c1 = its low dword; class 2: c0, c1 = the double's dwords; class 6: c0..c2 = the (at most three) string ids; class 3:
+    both columns; class 4: the column compared with P.id; class 0 = none of these (the lane goes to the shared evaluator)."""
+    def compact(lf):
+        w, a0, a1, _ret, ctag, clo, chi, cls = lf
+        a = w >> 8
+        op, ka = a & 0xFF, (a >> 8) & 0xF
+        if cls in (1, 6):
+            rec = (cls | (op << 4) | (a0 << 16), ctag, clo, chi)
+        elif cls == 2:
+            rec = (cls | (op << 4) | (a0 << 16), clo, chi, 0)
+        elif cls == 3:
+            rec = (cls | (op << 4) | (a0 << 16) | (a1 << 24), 0, 0, 0)
+        elif cls == 4:
+            rec = (cls | (op << 4) | ((a0 if ka == 3 else a1) << 16), 0, 0, 0)
+        else:
+            return (0, 0, 0, 0)
+        if max(a0 if cls != 4 or ka == 3 else a1, a1 if cls == 3 else 0) > 0xFF:
+            raise LoweringError("attribute column beyond 255 in a fused leaf")
+        return rec
+    recs = sorted(((compact(lf), lf) for lf in leaves), key=lambda t: (t[0][0] & 15, (t[0][0] >> 16) & 0xFFFF, t[0]))
+    slot_of, words = {}, []
+    k = 0
+    while k < len(recs):
+        cls = recs[k][0][0] & 15
+        run = [r for r in recs[k:] if (r[0][0] & 15) == cls]
+        k += len(run)
+        for rec, lf in run:
+            slot_of[lf] = len(words) // 4
+            words += list(rec)
+        for _ in range(-len(run) % 4):
+            words += list(run[-1][0])
+    return slot_of, words, len(words) // 4
+
+
+def _segments(res_entries, row_cols, leaf2_cols, pb):
+    """The buckets of a FLAT table as SEGMENTS for the flat kernel's mask walk (cbh_check_flat.h, cbh_blob.h CBH_SEC_SEGS).
+
+    A segment holds up to 64 consecutive records of one bucket as bit masks - bit i = record i of the segment, in binding
+    order: per action class and per role class the records whose list holds it (what `Index.Query` ANDs per request,
+    index/index.go:270-305), the ALLOW and the DENY records, and per DISTINCT condition of the segment (an item) the records
+    it is the condition / the derived-role condition of.  A request's candidates are then (OR of its actions' masks) AND (OR
+    of its roles' masks), a condition is evaluated once per wave and request whatever the number of records that carry it,
+    and the first DENY of a walk is a count-trailing-zeros - no record is visited.
+
+    A table whose conditions are built from at most 64 distinct fused leaves is POOLED: the leaves are numbered table-wide and
+    live once in CBH_SEC_LEAFPOOL, and what a wave evaluated for one bucket serves the next; with at most 64 distinct
+    conditions the items are numbered table-wide too (ITEMS_POOLED).
+    Returns (words of the section, leaf pool, directory entries, stats)."""
+    NONE_ = 0xFFFFFFFF
+
+    def one_level(packed):
+        """A tree's 4-bit ops (celc.py _tree_strip) -> (any?, negated?) when it is, after dropping levels that hold a single
+        subtree, ONE level over leaves only; None otherwise.  all(x) = any(x) = x and none(x) = not x with x's errors kept
+        (a level's only child is always evaluated: check.go:697-749) - which is what ruletable.go wraps a condition in for
+        a REQUIRE_PARENTAL_CONSENT scope (none(cond))."""
+        ops = []
+        for k in range(32):
+            o = (packed[k // 8] >> (4 * (k % 8))) & 15
+            if o == 0:
+                break
+            ops.append(o)
+        pos = [0]
+
+        def node():
+            kind = ops[pos[0]] - 2
+            pos[0] += 1
+            children = []
+            while ops[pos[0]] < 8:
+                if ops[pos[0]] == 1:
+                    children.append("leaf")
+                    pos[0] += 1
+                elif 2 <= ops[pos[0]] < 5:
+                    children.append(node())
+                if 5 <= ops[pos[0]] < 8:
+                    pos[0] += 1      # the child's TREE_ACC
+            pos[0] += 1              # TREE_END
+            return (kind, children)
+        try:
+            top = node()
+            if pos[0] != len(ops):
+                return None
+        except IndexError:
+            return None
+        neg = False
+        while len(top[1]) == 1 and top[1][0] != "leaf":
+            neg ^= top[0] == 2
+            top = top[1][0]
+        if not top[1] or any(c != "leaf" for c in top[1]):
+            return None
+        kind = top[0]
+        if len(top[1]) == 1:       # one leaf: all(l) = any(l) = l
+            return (False, neg ^ (kind == 2))
+        return (kind != 0, neg ^ (kind == 2))
+
+    def item_of(ref, flags, leaf_rec, leaf_flag, tree_flag):
+        """(how, leaves, ops): how & 3 = 1 - ONE level of classified leaves, any order (bit 8: any instead of all, bit 9:
+        negated; a single fused leaf is all(leaf)), 2 = a deeper tree of classified leaves (its 4-bit ops), 0 = neither (the
+        kernel hands those lanes to the shared evaluator, or flags them)."""
+        if flags & leaf_flag:
+            return 1, [tuple(leaf_rec)], [0, 0, 0, 0]
+        if flags & tree_flag:
+            d = leaf_rec
+            first, n = d[2], d[5]
+            leaves = [tuple(int(w) & 0xFFFFFFFF for w in pb.code[(first + j) * 8:(first + j) * 8 + 8]) for j in range(n)]
+            ops = [d[0], d[1], d[3], d[4]]
+            lvl = one_level(ops)
+            if lvl is not None:
+                return 1 | (256 if lvl[0] else 0) | (512 if lvl[1] else 0), leaves, [0, 0, 0, 0]
+            return 2, leaves, ops
+        return 0, [], [0, 0, 0, 0]
+
+    n_rows = len(row_cols[0])
+    row_items = []   # per row: [(is_drcond, ref, how, leaves, ops)]
+    item_ref = {}
+    all_items, all_leaves = {}, {}
+    for i in range(n_rows):
+        f = row_cols[ROW_FLAGS][i]
+        its = []
+        for is_dr, ref, rec, lf, tf in ((False, row_cols[ROW_COND][i], [row_cols[ROW_LEAF + k][i] for k in range(8)], ROW_F_LEAF_EMBEDDED, ROW_F_TREE_EMBEDDED),
+                                        (True, row_cols[ROW_DRCOND][i], [leaf2_cols[k][i] for k in range(8)], ROW_F_DRLEAF_EMBEDDED, ROW_F_DRTREE_EMBEDDED)):
+            if ref == NONE_:
+                continue
+            how, leaves, ops = item_of(ref, f, rec, lf, tf)
+            # one item per distinct FUNCTION: programs of different policies that read the same (their params sets differ, their
+            # fused leaves do not) share an item; `ref` stays a program that computes it (the shared evaluator's entry)
+            key = (how, tuple(leaves), tuple(ops)) if how else ref
+            its.append((is_dr, item_ref.setdefault(key, ref), how, leaves, ops))
+        row_items.append(its)
+    in_buckets = set()
+    for e in res_entries:
+        in_buckets.update(range(e[4], e[4] + e[5]))
+    for i in sorted(in_buckets):
+        for (_d, ref, _h, leaves, _o) in row_items[i]:
+            all_items.setdefault(ref, len(all_items))
+            for lf in leaves:
+                all_leaves.setdefault(lf, len(all_leaves))
+    pool_slot, pool_words, pool_slots = _layout_leaves(list(all_leaves))
+    pooled = pool_slots <= SEG_RECORDS                              # the leaves are numbered table-wide
+    words, entries = [], []
+    n_segments = max_items = max_leaves = n_complex_total = 0
+
+    def is_simple(how, ls):
+        return (how & 3) == 1 and 1 <= len(ls) <= 4
+
+    for e in res_entries:
+        _t, ver, kind, scope_ix, begin, count, dr_begin, dr_count = e
+        first_block = len(words) // 16
+        n_seg = 0
+        i = begin
+        while i < begin + count:
+            items, leaves, n_cx = {}, {}, 0       # ref -> local index; leaf record -> local index; complex items so far
+            j = i
+            while j < begin + count and j - i < SEG_RECORDS:
+                new_items = {ref: (how, ls) for (_d, ref, how, ls, _o) in row_items[j] if ref not in items}
+                new_leaves = {lf for (_d, _r, _h, ls, _o) in row_items[j] for lf in ls} - set(leaves)
+                new_cx = sum(1 for (how, ls) in new_items.values() if not is_simple(how, ls))
+                if (len(items) + len(new_items) > SEG_RECORDS or n_cx + new_cx > SEG_COMPLEX
+                        or (not pooled and new_leaves and _layout_leaves(list(leaves) + list(new_leaves))[2] > SEG_RECORDS)):
+                    break
+                n_cx += new_cx
+                for (_d, ref, _h, ls, _o) in row_items[j]:
+                    items.setdefault(ref, len(items))
+                    for lf in ls:
+                        leaves.setdefault(lf, len(leaves))
+                j += 1
+            if j == i:
+                raise LoweringError("a rule's conditions hold more than %d distinct leaves" % SEG_RECORDS)
+            seg_slot, seg_leaf_words, seg_slots = ({}, [], 0) if pooled else _layout_leaves(list(leaves))
+            allow = deny = simple_c = simple_d = 0
+            am, rm = [0] * 32, [0] * 32
+            item_recs = {}   # ref -> [crec_c, crec_d, how, leaves, ops]
+            rec_c, rec_d = [0xFF] * 64, [0xFF] * 64
+            for k, row in enumerate(range(i, j)):
+                bit = 1 << k
+                eff = row_cols[ROW_FLAGS][row] & 3
+                allow |= bit if eff == 1 else 0
+                deny |= bit if eff == 2 else 0
+                a_lo, r_lo = row_cols[ROW_ACTION_CLASSES][row], row_cols[ROW_ROLE_CLASSES][row]
+                for c in range(32):
+                    if (a_lo >> c) & 1:
+                        am[c] |= bit
+                    if (r_lo >> c) & 1:
+                        rm[c] |= bit
+                for (is_dr, ref, how, ls, ops) in row_items[row]:
+                    it = item_recs.setdefault(ref, [0, 0, how, ls, ops])
+                    it[1 if is_dr else 0] |= bit
+                    if is_simple(how, ls):
+                        if is_dr:
+                            rec_d[k], simple_d = items[ref], simple_d | bit
+                        else:
+                            rec_c[k], simple_c = items[ref], simple_c | bit
+            lid = pool_slot if pooled else seg_slot
+            ordered = sorted(items.items(), key=lambda kv: kv[1])
+            descs, refs, complex_words = [], [], []
+            for ref, _local in ordered:
+                cc, cd, how, ls, ops = item_recs[ref]
+                ids = [lid[lf] for lf in ls]
+                refs.append(ref)
+                if is_simple(how, ls):
+                    b4 = ids + [0] * (4 - len(ids))
+                    descs += [sum(b4[q] << (8 * q) for q in range(4)), len(ids) | (8 if how & 256 else 0) | (16 if how & 512 else 0)]
+                else:
+                    descs += [0, 0]
+                    ids8 = ids + [0] * (8 - len(ids))
+                    complex_words += [cc & 0xFFFFFFFF, cc >> 32, cd & 0xFFFFFFFF, cd >> 32, how, ref, items[ref], len(ls),
+                                      sum(ids8[q] << (8 * q) for q in range(4)), sum(ids8[4 + q] << (8 * q) for q in range(4)), 0, 0] + list(ops)
+            n_leaves = seg_slots
+            block = [allow & 0xFFFFFFFF, allow >> 32, deny & 0xFFFFFFFF, deny >> 32, simple_c & 0xFFFFFFFF, simple_c >> 32,
+                     simple_d & 0xFFFFFFFF, simple_d >> 32, len(items), n_leaves, 0, j - i, i, len(complex_words) // 16, 0, 0]
+            for m in am + rm:
+                block += [m & 0xFFFFFFFF, m >> 32]
+            for tab in (rec_c, rec_d):
+                block += [sum(tab[4 * q + z] << (8 * z) for z in range(4)) for q in range(16)]
+            assert len(block) == SEG_FIXED_DWORDS
+            block += descs
+            off_refs = len(block)
+            block += refs
+            block += [0] * (-len(block) % 16)
+            off_complex = len(block)
+            block += complex_words
+            off_leaves = len(block)
+            block += seg_leaf_words
+            block += [0] * (-len(block) % 16)
+            block[10] = len(block) // 16
+            block[14] = off_refs | (off_complex << 16)
+            block[15] = off_leaves
+            if len(block) >= 1 << 16:
+                raise LoweringError("a segment block exceeds 2^16 dwords")
+            words += block
+            n_seg += 1
+            n_segments += 1
+            n_complex_total += len(complex_words) // 16
+            max_items, max_leaves = max(max_items, len(items)), max(max_leaves, len(leaves))
+            i = j
+        entries.append((B_RESSEG, ver, kind, scope_ix, first_block, n_seg, dr_begin, dr_count))
+    pool = pool_words if pooled else []
+    hows = {}
+    for its in row_items:
+        for (_d, ref, how, _l, _o) in its:
+            hows[ref] = how & 3
+    stats = {"segments": n_segments, "pooled": pooled, "pool_slots": pool_slots if pooled else 0, "items": len(all_items),
+             "items_one_level": sum(1 for r in all_items if hows[r] == 1), "items_deeper": sum(1 for r in all_items if hows[r] == 2),
+             "complex_entries": n_complex_total, "leaves": len(all_leaves),
+             "max_items": max_items, "max_leaves": max_leaves, "bytes": len(words) * 4}
+    return words, pool, entries, stats
 
 
 def _column_paths(columns):

@@ -81,12 +81,19 @@ static thread_local std::string g_err;
 extern "C" const char* hostsim_last_error() { return g_err.c_str(); }
 
 static KernelArgs* g_args;
+// (the simulator reads the switch on every call: tests flip it between runs)
+static bool cbh_flat_use_masks_now(const void* segs, uint32_t max_bucket) {
+  const char* e = getenv("CBH_FLAT_MASKS");
+  if ((e && *e == '0') || getenv("CBH_FORCE_STAGED")) return false;
+  return segs != nullptr && ((e && *e == '1') || max_bucket > CBH_FLAT_STAGE_MIN);
+}
 
 static uint32_t g_max_actions, g_max_roles; static bool g_plain;   // same kernel selection as cbh_check_resident (cbh_engine.hip)
 static cbh_check_kernel_fn g_kernel;   // the kernel the fibers run
 
 static bool g_used_walk_awide = false;
 static bool g_used_walk_wide = false;   // did the last batch launch cbh_walk2_wide_kernel? (hostsim_last_walk_wide)
+static bool g_last_masks = false;
 static int g_last_kind = -1;   // which kernel family decided the last batch (hostsim_last_kind: tests assert the one they mean to exercise)
 static bool g_trace;   // hostsim_trace: the trace pass's kernel (cbh_trace_batch)
 
@@ -210,11 +217,13 @@ static int run_sim(const void* blob, size_t len, const cbh_batch* in, const cbh_
   // the same choice of kernels as the library makes (cbh_engine.hip plan_for); CBH_NO_FLAT / CBH_NO_WALK2 as there
   const bool has_globs = (a.t.nfa_words[0] | a.t.nfa_words[1] | a.t.nfa_words[2] | (a.t.flags & CBH_MF_HAS_ANY_PATTERN)) != 0;
   const CbhPlan pl = cbh_plan(a.t.flags, a.t.n_dr, has_globs, a.t.gslots_generic, a.t.gslots_all, g_max_actions, g_max_roles, g_plain, a.flags,
-                              getenv("CBH_NO_FLAT") != nullptr, getenv("CBH_NO_WALK2") != nullptr, getenv("CBH_FORCE_STAGED") ? 0xFFFFFFFFu : a.t.max_bucket, getenv("CBH_NO_WALK2_WIDE") != nullptr);
+                              getenv("CBH_NO_FLAT") != nullptr, getenv("CBH_NO_WALK2") != nullptr, getenv("CBH_FORCE_STAGED") ? 0xFFFFFFFFu : a.t.max_bucket, getenv("CBH_NO_WALK2_WIDE") != nullptr,
+                              cbh_flat_use_masks_now(a.t.segs, a.t.max_bucket));
   std::vector<uint64_t> gres((size_t)pl.n_gwords * in->n_requests + 1, 0xDDDDDDDDDDDDDDDDull);
   b.gres = pl.n_gwords ? gres.data() : nullptr; b.n_gwords = pl.n_gwords; b.n_gslots = pl.n_gslots;
   if (const char* e = getenv("CBH_HOSTSIM_REPORT")) { if (*e == '1') std::fprintf(stderr, "hostsim: kernel kind %d, %u result words\n", pl.kind, pl.n_gwords); }
   g_last_kind = trace ? -1 : pl.kind;
+  g_last_masks = !trace && pl.kind == 1 && cbh_is_mask_kernel(pl.kernel);
   g_used_walk_wide = false; g_used_walk_awide = false;
   // two launches over an arbitrary (unaligned) split of the batch: the chunk window [req_lo, req_hi) that the
   // one-shot path pipelines with (cbh_engine.hip) is exercised by every test of the CPU tier
@@ -251,6 +260,7 @@ extern "C" int hostsim_check(const void* blob, size_t len, const cbh_batch* in, 
   return run_sim(blob, len, in, p, out, gbits, nullptr);
 }
 extern "C" int hostsim_last_kind() { return g_last_kind; }
+extern "C" int hostsim_last_masks() { return g_last_masks ? 1 : 0; }   // did the last batch take the flat kernel's mask walk?
 extern "C" int hostsim_last_walk_wide() { return (g_used_walk_wide ? 1 : 0) | (g_used_walk_awide ? 2 : 0); }
 extern "C" int hostsim_trace(const void* blob, size_t len, const cbh_batch* in, const cbh_params* p,
                              cbh_result* out, uint64_t* gbits, cbh_trace* trace) {

@@ -206,6 +206,64 @@ def test_staged_record_walk_on_any_table(monkeypatch):
     _run_seed(300, lambda lt: HostSimEvaluator(lt, Conf()), False, deep=True)
 
 
+def test_mask_walk_on_any_table(monkeypatch):
+    """CBH_FLAT_MASKS=1: the mask walk (cbh_check_flat_kernel_masks / _any_masks: a bucket's segments decide by bitmaps per
+    action class, role class and distinct condition - no record is visited) on stores of every size, both variants, deep
+    chains and derived-role conditions included; tables with long buckets take it by themselves (the large-bucket tests)."""
+    import hostsim_api
+    from test_hostsim_golden import HostSimEvaluator
+    monkeypatch.setenv("CBH_FLAT_MASKS", "1")
+    for seed in range(12):
+        _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False)
+    for seed in range(100, 106):
+        _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False, with_lists=True)
+    for seed in range(300, 303):
+        _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False, deep=True)
+    assert hostsim_api.lib().hostsim_last_masks() == 1
+
+
+def test_long_buckets_take_the_mask_walk_and_the_staged_walk_agrees(monkeypatch):
+    import hostsim_api
+    from test_hostsim_golden import HostSimEvaluator
+    _run_seed(200, lambda lt: HostSimEvaluator(lt, Conf()), False, many_rules=True)
+    assert hostsim_api.lib().hostsim_last_masks() == 1
+    monkeypatch.setenv("CBH_FLAT_MASKS", "0")
+    for seed in range(200, 204):
+        _run_seed(seed, lambda lt: HostSimEvaluator(lt, Conf()), False, many_rules=True)
+    assert hostsim_api.lib().hostsim_last_masks() == 0
+
+
+def test_segments_of_a_table_that_is_not_pooled():
+    """More than 64 distinct fused leaves: every segment carries its own leaves and numbers (CBH_MSEG_POOLED off); a
+    bucket of 150 rules is three segments."""
+    import hostsim_api
+    rng = np.random.default_rng(77)
+    rules = []
+    for i in range(150):
+        rules.append({"actions": [str(a) for a in rng.choice(ACTIONS, size=2, replace=False)], "roles": [str(r) for r in rng.choice(ROLES, size=2, replace=False)],
+                      "effect": "EFFECT_ALLOW" if rng.random() < 0.8 else "EFFECT_DENY",
+                      "condition": {"match": {"expr": "R.attr.amount > %d" % i} if i % 3 else {"any": {"of": [{"expr": "R.attr.amount > %d" % (i + 200)}, {"expr": "R.attr.owner == P.id"}]}}}})
+    docs = [{"apiVersion": API, "resourcePolicy": {"resource": "doc", "version": "default", "rules": rules}}]
+    rt = rule_table_from_policies(policies_from_docs(docs))
+    lt = lower_rule_table(rt)
+    assert lt.stats["flat"] and not lt.seg_stats["pooled"] and lt.seg_stats["segments"] == 3, lt.seg_stats
+    inputs = [i for i in _requests(rng, 300, False, False) if i["resource"]["kind"] in ("doc", "other")]
+    for i in inputs:
+        i["resource"]["scope"] = ""
+    batch = Flattener(lt).flatten(inputs)
+    res = hostsim_api.check(lt, batch, NOW, capi.F_WANT_DERIVED_ROLES)
+    assert hostsim_api.lib().hostsim_last_masks() == 1
+    orc = RuleTableOracle(rt)
+    t = 0
+    for inp in inputs:
+        want = orc.check(inp, EvalParams(now_ns=NOW))
+        for a in inp["actions"]:
+            assert (res.effect[t] == capi.EFFECT_ALLOW) == (want["actions"][a]["effect"] == "EFFECT_ALLOW"), (inp, a)
+            t += 1
+        na = len(inp["actions"])
+        assert bool((res.status[t - na:t] == capi.ST_CEL_ERROR).any()) == bool(want.get("evaluationErrors"))
+
+
 def test_error_cases_do_occur():
     from test_hostsim_golden import HostSimEvaluator
     assert sum(_run_seed(s, lambda lt: HostSimEvaluator(lt, Conf()), False) for s in range(4)) > 20
