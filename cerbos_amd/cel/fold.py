@@ -234,7 +234,8 @@ def _math(name, vals):
                 return float(math.floor(d))
             if name == "trunc":
                 return float(math.trunc(d))
-            return math.copysign(float(math.floor(abs(d) + 0.5)), d)
+            t = float(math.trunc(d))       # Go's math.Round: half away from zero, exact where floor(|d| + 0.5) is not
+            return math.copysign(t + math.copysign(1.0, d) if abs(d - t) >= 0.5 else t, d)
         if name == "abs":
             if isinstance(v, UInt):
                 return v
@@ -392,12 +393,25 @@ _SAFE_PATTERN = re.compile(r"^(?:[A-Za-z0-9 _\-,:;@#%&=<>!~'\"/]|\\[dDwWsS.\\]|[
 
 
 def _regex(p):
+    """RE2 (Go regexp) reads \\d \\w \\s as ASCII classes and \\s without \\v; Python's `re` needs re.ASCII and its own
+    spelling of \\s for the same reading (the whitelist admits those escapes outside brackets only)."""
     if not isinstance(p, str) or not _SAFE_PATTERN.match(p) or "(?" in p:
         raise NotConst("regular expression outside the folder's subset")
+    py = re.sub(r"\\([sS\\])", lambda m: {"s": "[\t\n\f\r ]", "S": "[^\t\n\f\r ]", "\\": "\\\\"}[m.group(1)], p)
     try:
-        return re.compile(p)
+        return re.compile(py, re.ASCII)
     except re.error:
         raise NotConst("regular expression")
+
+
+def _go_matches(rx, s):
+    """Go's regexp drops an EMPTY match that begins where the previous match ended (regexp.go allMatches); Python keeps it."""
+    prev_end = -1
+    for m in rx.finditer(s):
+        if m.start() == m.end() == prev_end:
+            continue
+        prev_end = m.end()
+        yield m
 
 
 def _regex_replace(s, p, repl, limit=-1):
@@ -408,7 +422,16 @@ def _regex_replace(s, p, repl, limit=-1):
         return s
     if re.search(r"\\([0-9])", repl) and any(int(d) > rx.groups for d in re.findall(r"\\([0-9])", repl)):
         raise FoldError("invalid replacement")
-    return rx.sub(re.sub(r"\\([0-9])", r"\\g<\1>", repl), s, count=0 if limit < 0 else limit)
+    template = re.sub(r"\\([0-9])", r"\\g<\1>", repl)
+    out, at, n = [], 0, 0
+    for m in _go_matches(rx, s):
+        if 0 <= limit <= n:
+            break
+        out += [s[at:m.start()], m.expand(template)]
+        at = m.end()
+        n += 1
+    out.append(s[at:])
+    return "".join(out)
 
 
 # ---- SPIFFE ids (types/spiffe.go; the grammar of github.com/spiffe/go-spiffe/v2 v2.8.1 spiffeid - go.mod:81, not vendored:
@@ -726,7 +749,7 @@ class _Eval:
                 if rx.groups > 1:
                     raise FoldError("regular expression has more than one capturing group")
                 out = []
-                for m in rx.finditer(_need(vals[0], str)):
+                for m in _go_matches(rx, _need(vals[0], str)):
                     got = m.group(1) if rx.groups == 1 else m.group(0)
                     if got is not None and (rx.groups == 0 or got != ""):
                         out.append(got)

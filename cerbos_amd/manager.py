@@ -61,7 +61,11 @@ class TableLease:
     def __init__(self, version: _Version):
         self.v = version
         version._lease()
-        self.table = capi.Table.borrow(version.table)   # this request's own reference (cbh_table_retain)
+        try:
+            self.table = capi.Table.borrow(version.table)   # this request's own reference (cbh_table_retain)
+        except BaseException:
+            version._unlease()   # a lease that never came to be must not keep a retired version's ingest table alive
+            raise
         self._released = False
 
     number = property(lambda self: self.v.number)

@@ -206,11 +206,16 @@ func (g *gpuEngine) deviceRoad(bytesPtr *C.uint8_t, offs []C.uint64_t, n int, dv
 		return nil, nil, nil, nil, false, errors.New(C.GoString(C.cbh_last_error()))
 	}
 	blk := g.outPool.get(192*n+4096, n) // bytes | offsets (n + 1) | flags (n), one page-locked block
+	if blk == nil {                     // no page-locked memory to be had: the host road answers this call
+		return nil, nil, nil, nil, false, nil
+	}
 	var need C.size_t
 	rc := C.cbh_wire_outputs(g.table, db, blk.bytes, C.size_t(blk.cap), blk.offs, blk.flags, &need)
 	if rc == 2 { // the guess was short: `need` is exact
 		g.outPool.put(blk)
-		blk = g.outPool.get(int(need), n)
+		if blk = g.outPool.get(int(need), n); blk == nil {
+			return nil, nil, nil, nil, false, nil
+		}
 		rc = C.cbh_wire_outputs(g.table, db, blk.bytes, C.size_t(blk.cap), blk.offs, blk.flags, &need)
 	}
 	if rc != 0 {
@@ -249,7 +254,11 @@ func (p *pinnedPool) get(capBytes, n int) *pinnedBlock {
 		}
 	}
 	p.mu.Unlock()
-	b := &pinnedBlock{base: C.cbh_alloc_pinned(C.size_t(want)), size: want}
+	base := C.cbh_alloc_pinned(C.size_t(want))
+	if base == nil { // hipHostMalloc failed: never lay out - or pool - a block without memory behind it
+		return nil
+	}
+	b := &pinnedBlock{base: base, size: want}
 	b.layout(want-8*(n+1)-n-8, n)
 	return b
 }
@@ -260,7 +269,25 @@ func (b *pinnedBlock) layout(capBytes, n int) {
 	b.offs = (*C.uint64_t)(unsafe.Add(b.base, capBytes))
 	b.flags = (*C.uint8_t)(unsafe.Add(b.base, capBytes+8*(n+1)))
 }
-func (p *pinnedPool) put(b *pinnedBlock) { p.mu.Lock(); p.free = append(p.free, b); p.mu.Unlock() }
+
+// put returns a block to the pool; the pool keeps at most pinnedPoolMax blocks and frees the rest (page-locked memory is
+// not the process's to hoard).
+const pinnedPoolMax = 16
+
+func (p *pinnedPool) put(b *pinnedBlock) {
+	if b == nil || b.base == nil {
+		return
+	}
+	p.mu.Lock()
+	if len(p.free) < pinnedPoolMax {
+		p.free = append(p.free, b)
+		b = nil
+	}
+	p.mu.Unlock()
+	if b != nil {
+		C.cbh_free_pinned(b.base)
+	}
+}
 
 type traced struct {
 	bytes      []byte // serialized CheckOutput holding only outputs (6) and evaluation_errors (7)

@@ -1355,6 +1355,15 @@ def _math_sqrt(env, v):
     return math.nan if math.isnan(f) or f < 0 else math.sqrt(f)
 
 
+def _go_round(d):
+    """Go's math.Round: half away from zero, exact (floor(|d| + 0.5) is not: 0.49999999999999994 + 0.5 rounds up to 1.0,
+    and above 2^52 adding 0.5 moves to the next even integer); the sign of zero is kept."""
+    t = float(math.trunc(d))
+    if abs(d - t) >= 0.5:
+        t += math.copysign(1.0, d)
+    return math.copysign(t, d)
+
+
 def _dbl_round(fn, v):
     """Go's math.Ceil / Floor / Trunc / Round: NaN and the infinities come back unchanged."""
     _need(v, float)
@@ -1515,6 +1524,32 @@ class Optional:
         return hash(self.has)
 
 
+def go_matches(rx, s):
+    """The matches Go's regexp yields for its *All functions over `s` (regexp.go allMatches): Python's, minus an EMPTY match
+    that begins where the previous match ended ("if 'All' is present ... empty matches abutting a preceding match are ignored")
+    - `x*` over "abxd" matches at 0, 1, 2..3 and 4, not at 3."""
+    prev_end = -1
+    for m in rx.finditer(s):
+        if m.start() == m.end() == prev_end:
+            continue
+        prev_end = m.end()
+        yield m
+
+
+def go_replace_all(rx, s, template, limit):
+    """regexp.ReplaceAllString with Go's match list; `template` in Python's expand syntax; limit < 0 = all."""
+    out, at, n = [], 0, 0
+    for m in go_matches(rx, s):
+        if 0 <= limit <= n:
+            break
+        out.append(s[at:m.start()])
+        out.append(m.expand(template))
+        at = m.end()
+        n += 1
+    out.append(s[at:])
+    return "".join(out)
+
+
 def _rx_replace(env, s, pattern, repl, limit=-1):
     _need(s, str); _need(repl, str)
     if not is_int(limit):
@@ -1533,7 +1568,7 @@ def _rx_replace(env, s, pattern, repl, limit=-1):
             out.append(repl[i].replace("\\", "\\\\")); i += 1
     if limit == 0:
         return s
-    return rx.sub("".join(out), s, count=0 if limit < 0 else limit)
+    return go_replace_all(rx, s, "".join(out), limit)
 
 
 def _rx_extract(env, s, pattern):
@@ -1552,7 +1587,7 @@ def _rx_extract_all(env, s, pattern):
     if rx.groups > 1:
         raise CelError("regular expression has more than one capturing group")
     out = []
-    for m in rx.finditer(_need(s, str)):
+    for m in go_matches(rx, _need(s, str)):
         if rx.groups == 0:
             out.append(m.group(0))
         elif m.group(1):
@@ -1866,7 +1901,7 @@ _NS_FUNCS = {
     ("math", "abs"): lambda env, v: (v if is_uint(v) else _chk_int(abs(v)) if is_int(v) else abs(v)) if is_num(v) else (_ for _ in ()).throw(no_such_overload()),
     ("math", "ceil"): lambda env, v: _dbl_round(math.ceil, v),
     ("math", "floor"): lambda env, v: _dbl_round(math.floor, v),
-    ("math", "round"): lambda env, v: _dbl_round(lambda d: math.floor(abs(d) + 0.5) * (1 if d >= 0 else -1), v),
+    ("math", "round"): lambda env, v: _dbl_round(_go_round, v),
     ("math", "trunc"): lambda env, v: _dbl_round(math.trunc, v),
     ("math", "isNaN"): lambda env, v: math.isnan(_need(v, float)),
     ("math", "isInf"): lambda env, v: math.isinf(_need(v, float)),

@@ -236,3 +236,25 @@ def test_math_library_on_constants_against_the_oracle(seed):
         assert _same(_lit_value(lit), want), (expr, lit, want)
         folded += 1
     assert folded > 600 and errors > 100, (folded, errors)
+
+
+def test_go_regexp_and_round_vectors():
+    """Hand-computed against Go's regexp / math (the folder and the oracle used to share Python's reading of these):
+    an empty match abutting the previous match is dropped by ReplaceAllString / FindAll (regexp.go allMatches); RE2's
+    \\d \\w \\s are ASCII classes and \\s has no \\v; math.Round is exact (floor(|d| + 0.5) is not)."""
+    kats = [
+        ('regex.replace("abxd", "x*", "-")', "-a-b-d-"),
+        ('regex.extractAll("abxd", "x*")', ["", "", "x", ""]),
+        ('regex.replace("٣x", "\\\\d", "N")', "٣x"),
+        ('regex.replace("a\\u000bb", "\\\\s", "_")', "a\x0bb"),
+        ('regex.replace("a b\\tc", "\\\\s", "_")', "a_b_c"),
+        ('regex.replace("banana", "a", "o", 2)', "bonona"),
+        ("math.round(0.49999999999999994)", 0.0),
+        ("math.round(4503599627370497.0)", 4503599627370497.0),
+        ("math.round(-2.5)", -3.0),
+        ("math.round(2.5)", 3.0),
+    ]
+    for expr, want in kats:
+        assert celeval.evaluate(expr, celeval.Env({}, NOW)) == want, expr
+        lit = _folded(expr)
+        assert lit is not None and _lit_value(lit) == want, (expr, lit)
