@@ -299,17 +299,21 @@ __device__ __forceinline__ u32 leaf_block_codes(const Ctx& c, const Leaf4x4& b, 
   } else acc = 0xFFu;       // none of the classified shapes: the shared evaluator's
   return acc;
 }
-// `n` = slots of the pool (a multiple of four); `recs` wave-uniform.  The next block is in flight while this one is evaluated.
-__device__ __forceinline__ void eval_leaf_pool(const Ctx& c, const CBH_G u32* recs, u32 n, u32 req, u32 pid, CBH_L u8* lvtab) {
-  if (n == 0) return;
+// The blocks of `todo` (bit g = leaves 4g .. 4g + 3 of the pool at `recs`; wave-uniform) into `lvtab`, front to back; the next
+// block's record is in flight while this one is evaluated.
+__device__ __forceinline__ void eval_leaf_blocks(const Ctx& c, const CBH_G u32* recs, u32 todo, u32 req, u32 pid, CBH_L u8* lvtab) {
+  if (todo == 0) return;
   u32 curcol = CBH_NONE;
   FlatCol cx; cx.t = 0; cx.lo = 0; cx.hi = 0;
-  const u32 nblk = (n + 3u) >> 2;
-  Leaf4x4 nxt = uload_rec<Leaf4x4>(recs, 0);
-  for (u32 g = 0; g < nblk; ++g) {
+  u32 g = (u32)__builtin_ctz(todo);
+  Leaf4x4 nxt = uload_rec<Leaf4x4>(recs, g);
+  while (todo != 0) {
+    todo &= todo - 1u;
     const Leaf4x4 b = nxt;
-    nxt = uload_rec<Leaf4x4>(recs, g + 1u < nblk ? g + 1u : g);
+    const u32 gn = todo ? (u32)__builtin_ctz(todo) : g;
+    nxt = uload_rec<Leaf4x4>(recs, gn);
     lvtab[g * CBH_BLOCK + c.tid] = (u8)leaf_block_codes(c, b, req, pid, curcol, cx);
+    g = gn;
   }
 }
 // A deeper tree of classified leaves from the leaves' outcomes in `lvtab` (flat_tree's bookkeeping): `ops` / `idx` wave-uniform.
@@ -518,7 +522,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   // MODE 2.  Pooled table: the leaves are numbered table-wide and evaluated ONCE per wave, when the first lane meets a
   // candidate with a condition; else every segment brings its own.
   const bool pooled = MODE == 2 && (t.seg_info & CBH_MSEG_POOLED) != 0;
-  bool leaves_done = false;   // wave-uniform
+  u32 blocks_done = 0;   // wave-uniform: the blocks of four leaves whose outcomes lvtab holds
   FLAT_DBG(const u64 cyc2 = cyc1 + (__builtin_readcyclecounter() - cyc1) * (u64)(wave_ballot(first != 0xFFFFFFFEu) != 0);)   // chain starts known
   for (;;) {
     // a lane goes on while it has walks to decide, and after that until it knows that some policy exists
@@ -551,6 +555,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
           const SegHdr hd = uload_rec<SegHdr>(t.segs, blk16);
           blk16 += hd.size16;
           // the segment's tables -> LDS, one element per lane: 64 class masks, 2 x 64 record -> item bytes (32 dwords), the items' descriptors
+          if (!pooled) blocks_done = 0;   // the segment's own leaves
           segm[c.tid] = load_u64g(blk + 16u + 2u * c.tid);
           if (c.tid < 32u) ((CBH_L u32*)seg_rec)[c.tid] = blk[144u + c.tid];
           if (c.tid < hd.n_items) seg_desc[c.tid] = load_u64g(blk + CBH_SEG_FIXED_DWORDS + 2u * c.tid);
@@ -565,12 +570,19 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
             const u64 simple_c = (u64)hd.sc_lo | ((u64)hd.sc_hi << 32), simple_d = (u64)hd.sd_lo | ((u64)hd.sd_hi << 32);
             FLAT_DBG(const u64 i0 = __builtin_readcyclecounter();)
             const bool any_cond = hd.n_complex != 0 || wave_ballot((cand_any & (simple_c | simple_d)) != 0) != 0;   // some candidate has a condition
-            if (any_cond && (!pooled || !leaves_done)) {   // the leaves' outcomes, for every lane of the wave
-              FLAT_DBG(const u64 l0 = __builtin_readcyclecounter();)
-              if (pooled) { eval_leaf_pool(c, t.leafpool, t.seg_info & 0xFFu, req, pid, lvtab); leaves_done = true; }
-              else eval_leaf_pool(c, blk + hd.off_leaves, hd.n_leaves, req, pid, lvtab);
-              (void)wave_ballot(true);
-              FLAT_DBG(cyc_stage += (__builtin_readcyclecounter() - l0) * (u64)(wave_ballot(req != 0xdeadbeefu) != 0); ++dbg_visits;)
+            if (any_cond) {
+              // the leaves' outcomes, for every lane of the wave: every block lvtab does not hold yet, in one go.  (Evaluating
+              // only the blocks the wave's role classes can reach - about half of them on T - was measured SLOWER, 25.5 against
+              // 29.7 G decisions/s sustained: the short batches of blocks expose the scalar loads the long run hides.)
+              const u32 nblk = ((pooled ? (t.seg_info & 0xFFu) : hd.n_leaves) + 3u) >> 2;
+              const u32 todo = ~blocks_done & ((1u << nblk) - 1u);
+              if (todo) {
+                FLAT_DBG(const u64 l0 = __builtin_readcyclecounter();)
+                eval_leaf_blocks(c, pooled ? t.leafpool : blk + hd.off_leaves, todo, req, pid, lvtab);
+                blocks_done |= todo;
+                (void)wave_ballot(true);
+                FLAT_DBG(cyc_stage += (__builtin_readcyclecounter() - l0) * (u64)(wave_ballot(req != 0xdeadbeefu) != 0); dbg_visits += (u32)__builtin_popcount(todo);)
+              }
             }
             // the conditions the wave evaluates as one (deeper trees, more than four leaves, programs): rare
             for (u32 ci = 0; ci < hd.n_complex; ++ci) {
@@ -599,6 +611,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
             // every lane by itself: its candidates' conditions that are ONE level of at most four leaves (nearly all are), from
             // the leaves' outcomes - straight-line code, as many rounds as the lane with the most such candidates has
             u64 cslow = 0, dslow = 0;
+            u32 lane_slow = 0;   // the variant without the call: some candidate's condition needs the evaluator (cannot be: the host checks)
             auto lane_items = [&](u64 m, const CBH_L u8* rec, u64& sat, u64& errm, u64& slowm) {
               while (wave_ballot(m != 0) != 0) {
                 const bool act = m != 0;
@@ -609,12 +622,15 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
                 const u32 lw = (u32)d, fl = (u32)(d >> 32);
                 u32 w = 0;
 #pragma unroll
-                for (u32 j = 0; j < 4; ++j) w |= lv_code(lvtab, c.tid, (lw >> (8u * j)) & 0xFFu) << (2u * j);
+                for (u32 j = 0; j < 4; ++j) {   // leaf number l: its outcome is bits 2 (l & 3) .. of lvtab[l >> 2][lane]
+                  const u32 row = (lw >> (8u * j + 2u)) & 0x3Fu, sh = ((lw >> (8u * j)) & 3u) * 2u;
+                  w |= (((u32)lvtab[row * CBH_BLOCK + c.tid] >> sh) & 3u) << (2u * j);
+                }
                 const u32 lv = level_from_codes(w, fl & 7u, (fl & 8u) != 0, (fl & 16u) != 0);
                 const u64 bit = act ? (1ull << i) : 0ull;
                 sat &= (lv & 1u) ? ~0ull : ~bit;
                 errm |= (lv & 2u) ? bit : 0ull;
-                slowm |= (lv & 4u) ? bit : 0ull;
+                if (WITH_CALL) slowm |= (lv & 4u) ? bit : 0ull; else lane_slow |= act ? (lv & 4u) : 0u;
                 FLAT_DBG(++dbg_evals;)
               }
             };
@@ -642,8 +658,9 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
                     else { cslow &= ~bit; csat = ok ? (csat | bit) : csat; cerr |= e ? bit : 0ull; cuns |= u ? bit : 0ull; }
                   }
                 }
-              } else { cuns |= cslow; duns |= dslow; }   // loud (UNSUPPORTED), never a guessed effect
+              }
             }
+            if (!WITH_CALL && lane_slow) { cuns |= cand_any; duns |= cand_any; }   // loud (UNSUPPORTED on every candidate), never a guessed effect
             FLAT_DBG(cyc_eval += (__builtin_readcyclecounter() - i0) * (u64)(wave_ballot(csat != 77u) != 0);)
             // the derived-role condition comes first; the rule's own condition counts only where that held (check.go:328-380)
             const u64 satrec = dsat & csat, errrec = derr | (dsat & cerr), unsrec = duns | (dsat & cuns);

@@ -1322,6 +1322,7 @@ def _segments(res_entries, row_cols, leaf2_cols, pb):
             if j == i:
                 raise LoweringError("a rule's conditions hold more than %d distinct leaves" % SEG_RECORDS)
             seg_slot, seg_leaf_words, seg_slots = ({}, [], 0) if pooled else _layout_leaves(list(leaves))
+            lid = pool_slot if pooled else seg_slot
             allow = deny = simple_c = simple_d = 0
             am, rm = [0] * 32, [0] * 32
             item_recs = {}   # ref -> [crec_c, crec_d, how, leaves, ops]
@@ -1345,7 +1346,6 @@ def _segments(res_entries, row_cols, leaf2_cols, pb):
                             rec_d[k], simple_d = items[ref], simple_d | bit
                         else:
                             rec_c[k], simple_c = items[ref], simple_c | bit
-            lid = pool_slot if pooled else seg_slot
             ordered = sorted(items.items(), key=lambda kv: kv[1])
             descs, refs, complex_words = [], [], []
             for ref, _local in ordered:
