@@ -135,6 +135,7 @@ extern "C" void cbh_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
 struct OneShot {   // what one cbh_check_batch call owns on one device while it runs
   hipStream_t s[N_STREAMS] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_setup = nullptr;
+  hipEvent_t ev_piece[N_STREAMS] = {nullptr, nullptr, nullptr};   // the pieces of a slab upload (run_range)
   uint8_t* h = nullptr; size_t h_cap = 0;   // pinned staging block (small batches)
   uint8_t* d = nullptr; size_t d_cap = 0;   // device block
 };
@@ -225,6 +226,7 @@ static void replica_destroy(Replica* r) {
   for (auto* c : r->ctx_idle) {
     for (auto& s : c->s) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     if (c->ev_setup) (void)hipEventDestroy(c->ev_setup);
+    for (auto& e : c->ev_piece) if (e) (void)hipEventDestroy(e);
     if (c->h) (void)hipHostFree(c->h);
     if (c->d) (void)hipFree(c->d);
     delete c;
@@ -412,7 +414,8 @@ struct BatchShape {
     return hit != 0;
   }
 };
-static int validate_batch(const cbh_table* t, const cbh_batch* in, BatchShape& sh) {
+// the O(1) part of validate_batch: the arrays a batch of these counts needs are there
+static int validate_header(const cbh_table* t, const cbh_batch* in) {
   if (in->n_columns != t->meta[CBH_M_NCOLUMNS]) return fail("cbh_batch.n_columns does not match the table's column schema");
   const size_t NR = in->n_requests;
   if (NR && !in->req_u32) return fail("cbh_batch: a required array is NULL");
@@ -422,23 +425,32 @@ static int validate_batch(const cbh_table* t, const cbh_batch* in, BatchShape& s
   if (in->heap_len && (!in->heap_tag || !in->heap_val)) return fail("cbh_batch: a required array is NULL");
   if (in->n_strings && (!in->str_off || !in->str_flags)) return fail("cbh_batch: a required array is NULL");
   if (in->str_bytes_len && !in->str_bytes) return fail("cbh_batch: a required array is NULL");
+  return 0;
+}
+static int validate_batch(const cbh_table* t, const cbh_batch* in, BatchShape& sh) {
+  if (validate_header(t, in) != 0) return -1;
+  const size_t NR = in->n_requests;
   const u32* role_off = in->req_u32 + (size_t)CBH_RQ_ROLE_OFF * NR; const u32* role_cnt = in->req_u32 + (size_t)CBH_RQ_ROLE_CNT * NR;
   const u32* act_off = in->req_u32 + (size_t)CBH_RQ_ACT_OFF * NR; const u32* act_cnt = in->req_u32 + (size_t)CBH_RQ_ACT_CNT * NR;
-  u32 maxa = 0, maxr = 0; u64 bad = 0, prev_end = 0; bool asc = true;
-  u32 wlo = 0xFFFFFFFFu, whi = 0;
+  // (three passes without loop-carried dependences other than max / or reductions: the compiler vectorises them - this scan
+  // sits on the path of every one-shot call, 250 000 requests at the headline size)
+  u32 maxa = 0, maxr = 0; u32 bad = 0;
+  const u64 n_roles = in->n_roles, n_tuples = in->n_tuples;
   for (size_t r = 0; r < NR; ++r) {
-    const u32 n = act_cnt[r];
-    if (n > CBH_W2_NA || role_cnt[r] > CBH_W2_NR) { if (wlo == 0xFFFFFFFFu) wlo = (u32)r; whi = (u32)r + 1; }
-    maxa = n > maxa ? n : maxa;
+    maxa = act_cnt[r] > maxa ? act_cnt[r] : maxa;
     maxr = role_cnt[r] > maxr ? role_cnt[r] : maxr;
-    bad |= (u64)((u64)role_off[r] + role_cnt[r] > in->n_roles) | (u64)((u64)act_off[r] + n > in->n_tuples);
-    asc = asc && act_off[r] >= prev_end;
-    prev_end = (u64)act_off[r] + n;
+    bad |= (u32)((u64)role_off[r] + role_cnt[r] > n_roles) | (u32)((u64)act_off[r] + act_cnt[r] > n_tuples);
   }
+  u32 unordered = 0;
+  for (size_t r = 1; r < NR; ++r) unordered |= (u32)((u64)act_off[r] < (u64)act_off[r - 1] + act_cnt[r - 1]);
+  u32 wlo = 0xFFFFFFFFu, whi = 0;
+  if (maxa > CBH_W2_NA || maxr > CBH_W2_NR)   // where the requests wider than the walk's base shape lie (rare: found in a pass of its own)
+    for (size_t r = 0; r < NR; ++r)
+      if (act_cnt[r] > CBH_W2_NA || role_cnt[r] > CBH_W2_NR) { if (wlo == 0xFFFFFFFFu) wlo = (u32)r; whi = (u32)r + 1; }
   if (maxa > CBH_MAX_ACTIONS_PER_REQUEST) return fail("cbh_batch: a request carries more than CBH_MAX_ACTIONS_PER_REQUEST actions");
   if (bad) return fail("cbh_batch: a request's role or action slice lies outside the batch");
   if (in->n_strings && in->str_off[in->n_strings] > in->str_bytes_len) return fail("cbh_batch: string offsets exceed str_bytes_len");
-  sh.max_actions = maxa; sh.max_roles = maxr; sh.ascending = asc;
+  sh.max_actions = maxa; sh.max_roles = maxr; sh.ascending = !unordered;
   sh.wide_lo = whi ? wlo : 0; sh.wide_hi = whi;
   sh.tags = nullptr; sh.n_tags = 0; sh.plain.store(-1, std::memory_order_relaxed);
   if (((t->meta[CBH_M_FLAGS] & CBH_MF_FLAT) && maxa <= 4 && maxr <= 4) ||
@@ -1068,8 +1080,9 @@ static OneShot* ctx_acquire(Replica* r) {
       bool ok = c != nullptr;
       for (int i = 0; ok && i < N_STREAMS; ++i) ok = hipStreamCreateWithFlags(&c->s[i], hipStreamNonBlocking) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&c->ev_setup, hipEventDisableTiming) == hipSuccess;
+      if (c) for (auto& e : c->ev_piece) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
       if (!ok) {
-        if (c) { for (auto& s : c->s) if (s) (void)hipStreamDestroy(s); if (c->ev_setup) (void)hipEventDestroy(c->ev_setup); delete c; c = nullptr; }
+        if (c) { for (auto& s : c->s) if (s) (void)hipStreamDestroy(s); if (c->ev_setup) (void)hipEventDestroy(c->ev_setup); for (auto& e : c->ev_piece) if (e) (void)hipEventDestroy(e); delete c; c = nullptr; }
         lk.lock(); --r->ctx_count; r->ctx_cv.notify_one();
       }
       return c;
@@ -1269,14 +1282,37 @@ static int run_small(cbh_table* t, Replica* rep, const cbh_batch* in, const cbh_
 }
 
 // the request range [lo, hi) of a large batch on one device
+// the bytes of a slab that go up: it stops before the raw request strings / the string pool when the table reads neither
+static size_t slab_upload_end(const Replica* rep, const Layout& L, size_t NR) {
+  const bool reads_strings = (rep->dev.flags & CBH_MF_READS_REQUEST_STRINGS) != 0, need_bytes = (rep->dev.flags & CBH_MF_NEEDS_STRING_BYTES) != 0;
+  return need_bytes ? L.in_end : L.req.off + (size_t)(reads_strings ? CBH_RQ_NFIELDS : CBH_RQ_NCORE) * NR * 4;
+}
+// One DMA engine does not fill the host link (a 29 MB slab went up at ~39 GB/s where the link gives 56): a large slab goes up
+// in pieces on the context's streams - each stream's copies run on an engine of their own - and stream 0 waits for all.
+static int slab_upload(OneShot* c, const Replica* rep, const Layout& L, const uint8_t* slab, size_t NR) {
+  static const u32 slab_split = [] { const char* e = getenv("CBH_SLAB_SPLIT"); const long v = e ? atol(e) : 2; return (u32)std::min<long>(std::max<long>(v, 1), N_STREAMS); }();
+  uint8_t* base = c->d;
+  const size_t up = slab_upload_end(rep, L, NR) - L.in_begin;
+  const u32 pieces = up >= ((size_t)8 << 20) ? slab_split : 1u;
+  if (pieces <= 1) { HIPCHK(hipMemcpyAsync(base + L.in_begin, slab, up, hipMemcpyHostToDevice, c->s[0])); return 0; }
+  const size_t step = ((up / pieces) + 4095) & ~(size_t)4095;
+  for (u32 i = 0; i < pieces; ++i) {
+    const size_t o = (size_t)i * step, n = o >= up ? 0 : std::min(step, up - o);
+    if (!n) break;
+    HIPCHK(hipMemcpyAsync(base + L.in_begin + o, slab + o, n, hipMemcpyHostToDevice, c->s[i]));
+    if (i) { HIPCHK(hipEventRecord(c->ev_piece[i], c->s[i])); HIPCHK(hipStreamWaitEvent(c->s[0], c->ev_piece[i], 0)); }
+  }
+  return 0;
+}
+// `pre`: a context the caller holds whose slab upload is already in flight (cbh_check_batch starts it before it validates)
 static int run_range(cbh_table* t, Replica* rep, const cbh_batch* in, const cbh_params* p, cbh_result* out, const BatchShape& sh,
-                     const Layout& L, u32 lo, u32 hi, bool pinned, u32 chunk_requests) {
+                     const Layout& L, u32 lo, u32 hi, bool pinned, u32 chunk_requests, OneShot* pre = nullptr) {
   HIPCHK(hipSetDevice(rep->device));
-  CtxLease lease{rep, ctx_acquire(rep)};
-  OneShot* c = lease.c;
+  CtxLease lease{rep, pre ? nullptr : ctx_acquire(rep)};
+  OneShot* c = pre ? pre : lease.c;
   if (!c) return fail("could not create a launch context");
   const double t_0 = trace_on() ? now_us() : 0;
-  if (ctx_reserve(c, 4096, L.total) != 0) return -1;
+  if (!pre && ctx_reserve(c, 4096, L.total) != 0) return -1;
   const size_t NR = in->n_requests;
   const bool whole = lo == 0 && hi == NR;
   KernelArgs ka;
@@ -1302,10 +1338,9 @@ static int run_range(cbh_table* t, Replica* rep, const cbh_batch* in, const cbh_
   // results down in as few copies as the caller's result arrays are contiguous (one for a result slab)
   const uint8_t* slab = (whole && pinned) ? slab_base(L) : nullptr;
   if (slab) {
-    lease.used = 1;
-    const size_t end = need_bytes ? L.in_end : L.req.off + (size_t)(reads_strings ? CBH_RQ_NFIELDS : CBH_RQ_NCORE) * NR * 4;
+    const size_t end = slab_upload_end(rep, L, NR);
     HIPCHK(hipMemcpyAsync(base, c->h, sizeof(ka), hipMemcpyHostToDevice, s0));
-    HIPCHK(hipMemcpyAsync(base + L.in_begin, slab, end - L.in_begin, hipMemcpyHostToDevice, s0));
+    if (!pre && slab_upload(c, rep, L, slab, NR) != 0) return -1;
     launch_resolve(rep, ka, L, s0, rc);
     if (rc != 0) return fail("hipMemsetAsync failed");
     launch_check(rep, ka, d_args, 0, (u32)NR, sh, s0);
@@ -1413,10 +1448,13 @@ extern "C" int cbh_check_batch(cbh_table* t, const cbh_batch* in, const cbh_para
   if (in->n_tuples && !out->effect) return fail("cbh_result.effect is required");
   TableRef ref(t);
   BatchShape sh;
-  if (validate_batch(t, in, sh) != 0) return -1;
+  if (validate_header(t, in) != 0) return -1;
   const Layout L = make_layout(in, t);
   const u32 NR = in->n_requests;
-  if (L.in_end <= SMALL_BATCH_BYTES || NR == 0) return run_small(t, t->reps[0], in, p, out, sh, L);
+  if (L.in_end <= SMALL_BATCH_BYTES || NR == 0) {
+    if (validate_batch(t, in, sh) != 0) return -1;
+    return run_small(t, t->reps[0], in, p, out, sh, L);
+  }
 
   // chunks of the three-stream pipeline carry at least ~32 MB of input each: a copy costs a fixed ~20 us on top of
   // its bytes, so smaller chunks lose more to that than the overlap wins (measured, profiles/r02_oneshot_probe.txt)
@@ -1430,10 +1468,22 @@ extern "C" int cbh_check_batch(cbh_table* t, const cbh_batch* in, const cbh_para
   for (const void* q : {(const void*)in->req_u32, (const void*)in->tuple_action, (const void*)in->col_tag, (const void*)in->col_val,
                         (const void*)out->effect, (const void*)out->policy, (const void*)out->scope, (const void*)out->status, (const void*)out->edr_mask})
     pinned = pinned && is_pinned(q);
+  // One device and a page-locked slab: the upload starts NOW and the O(n_requests) validation below runs while the DMA does
+  // (a batch that fails it never reaches a kernel: the lease waits for the copies and hands the context back).
+  CtxLease early{t->reps[0], nullptr};
+  if (pinned && t->reps.size() == 1) {
+    if (const uint8_t* slab = slab_base(L)) {
+      HIPCHK(hipSetDevice(t->reps[0]->device));
+      early.c = ctx_acquire(t->reps[0]);
+      if (!early.c) return fail("could not create a launch context");
+      if (ctx_reserve(early.c, 4096, L.total) != 0 || slab_upload(early.c, t->reps[0], L, slab, NR) != 0) return -1;
+    }
+  }
+  if (validate_batch(t, in, sh) != 0) return -1;
   // contiguous request ranges over the devices (engine.go:309-338 deals inputs to workers; here a worker is a GPU)
   u32 n_dev = 1;
   if (t->reps.size() > 1 && sh.ascending) n_dev = (u32)std::min<size_t>(t->reps.size(), std::max<u32>(1, NR / SHARD_MIN_REQUESTS));
-  if (n_dev == 1) return run_range(t, t->reps[0], in, p, out, sh, L, 0, NR, pinned, sh.ascending ? chunk_env : NR);
+  if (n_dev == 1) return run_range(t, t->reps[0], in, p, out, sh, L, 0, NR, pinned, sh.ascending ? chunk_env : NR, early.c);
   std::vector<int> rcs(n_dev, 0);
   std::vector<std::string> errs(n_dev);
   auto work = [&](u32 i) {
