@@ -124,6 +124,7 @@ enum CbhMeta {
 #define CBH_MSEG_PRESENT 0x80000000u
 #define CBH_MSEG_POOLED 0x40000000u
 #define CBH_SEG_RECORDS 64u
+#define CBH_SEG_TAIL_PAD16 20u  /* 16-dword units of zeros behind the last block of CBH_SEC_SEGS: a lane loads its descriptor slot whatever n_items */
 #define CBH_SEG_COMPLEX 16u     /* CbhSegItem entries of one segment at most */
 #define CBH_SEG_FIXED_DWORDS 176u   /* header + class masks + the two record -> item tables; the item descriptors follow */
 struct CbhSegHdr {   // 16 dwords

@@ -117,7 +117,8 @@ static inline const char* cbh_parse_image(TableDev& d, std::vector<uint32_t>& me
     if (d.seg_info & CBH_MSEG_PRESENT) {
       const CbhBlobSection* ss = find(CBH_SEC_SEGS);
       const CbhBlobSection* ls = find(CBH_SEC_LEAFPOOL);
-      const uint64_t seg16 = ss->nbytes / 64, pool_n = d.seg_info & 0xFFu;
+      if (ss->nbytes < 64ull * CBH_SEG_TAIL_PAD16) return ("blob segment section too small");
+      const uint64_t seg16 = ss->nbytes / 64 - CBH_SEG_TAIL_PAD16, pool_n = d.seg_info & 0xFFu;   // (the tail: what the unconditional descriptor loads of the last block may touch)
       if (ls->nbytes < ((pool_n + 3) / 4) * 64) return ("blob leaf pool too small");
       const bool pooled = (d.seg_info & CBH_MSEG_POOLED) != 0;
       const uint32_t* sw = reinterpret_cast<const uint32_t*>(host_copy + ss->offset);

@@ -53,7 +53,7 @@ SEC_SEGS, SEC_LEAFPOOL = 43, 44
 M_SEGS = 23                           # CBH_M_SEGS: M_SEGS_PRESENT | M_SEGS_POOLED | leaves in CBH_SEC_LEAFPOOL
 M_SEGS_PRESENT, M_SEGS_POOLED, M_SEGS_ITEMS_POOLED = 1 << 31, 1 << 30, 1 << 29
 SEG_RECORDS = 64                      # records (and distinct conditions, and distinct leaves) per segment: one bit each of a 64-bit mask
-SEG_TAIL_PAD = 0
+SEG_TAIL_PAD = 20                     # 16-dword units behind the last block: every lane loads an item descriptor slot, whatever n_items
 SEG_COMPLEX = 16                      # items of a segment the lanes cannot decide by themselves (deeper trees, more than four leaves, programs)
 SEG_FIXED_DWORDS = 176                # header 16 + class masks 128 + the two record -> item tables 32
 SWF_PRINCIPAL, SWF_PARENTS = 1, 2     # CBH_SEC_STR_WFLAGS bits
