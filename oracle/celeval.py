@@ -24,7 +24,7 @@ import ipaddress
 import math
 import re
 
-from cerbos_amd.cel.parser import parse
+from .celparse import parse   # the oracle reads CEL text with its own parser (tests/test_oracle_parser.py holds it against the product's)
 
 from . import crosspath
 
