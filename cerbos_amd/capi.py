@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "cbh_check_batch", "cbh_trace_batch", "cbh_batch_upload", "cbh_batch_upload_on", "cbh_batch_release", "cbh_check_resident",
     "cbh_synchronize", "cbh_result_download", "cbh_kernel_time_ms", "cbh_plan_describe",
     "cbh_check_resident_many", "cbh_table_set_resident_streams", "cbh_table_resident_streams",
-    "cbh_wire_flatten", "cbh_wire_spans_download", "cbh_wire_outputs",
+    "cbh_wire_flatten", "cbh_wire_spans_download", "cbh_wire_outputs", "cbh_wire_check_pb",
 ]
 
 
@@ -162,6 +162,9 @@ def load():
     lib.cbh_wire_spans_download.restype = i32
     lib.cbh_wire_outputs.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.POINTER(C.c_size_t)]
     lib.cbh_wire_outputs.restype = i32
+    lib.cbh_wire_check_pb.argtypes = [vp, u32, vp, vp, u32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(CParams), vp, C.c_size_t, vp, vp,
+                                      C.POINTER(C.c_size_t), C.POINTER(CWireInfo)]
+    lib.cbh_wire_check_pb.restype = i32
     _lib = lib
     return lib
 
@@ -372,6 +375,29 @@ class Table:
         db = DeviceBatch(self, h, info.n_tuples, n)
         db.wire_info = {f[0]: getattr(info, f[0]) for f in CWireInfo._fields_}
         return db
+
+    def wire_check_pb(self, data, offsets, now_ns=0, flags=0, default_policy_version="default", default_scope="", device_index=0,
+                      globals_pb=b"", out=None):
+        """``cbh_wire_check_pb``: the device road in one call.  -> ([serialized CheckOutput], flags uint8[n]).  ``out`` =
+        (bytes uint8[cap], offsets uint64[n + 1], flags uint8[n]) to reuse (page-locked) buffers; they are grown when short."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        ob, oo, of = out if out is not None else (np.empty(256 * n + 4096, dtype=np.uint8), np.empty(n + 1, dtype=np.uint64), np.empty(max(n, 1), dtype=np.uint8))
+        p = CParams(now_ns, flags, 0)
+        info, need = CWireInfo(), C.c_size_t()
+        for _ in range(2):
+            rc = load().cbh_wire_check_pb(self.h, device_index, data.ctypes.data if data.size else None, offsets.ctypes.data, n,
+                                          default_policy_version.encode(), default_scope.encode(), globals_pb or None, len(globals_pb or b""),
+                                          C.byref(p), ob.ctypes.data, ob.size, oo.ctypes.data, of.ctypes.data, C.byref(need), C.byref(info))
+            if rc != 2:
+                break
+            ob = np.empty(int(need.value) + 64, dtype=np.uint8)
+        if rc == 1:
+            raise HostFlattenerNeeded(load().cbh_last_error().decode("utf-8", "replace"))
+        _check(rc)
+        raw = ob[:int(oo[n])].tobytes()
+        return [raw[int(oo[i]):int(oo[i + 1])] for i in range(n)], of[:n].copy()
 
     def wire_spans(self, dbatch):
         """``cbh_wire_spans_download`` -> (in_span uint32[n][12], act_span uint32[n_tuples][2], act_off uint32[n + 1])"""

@@ -209,6 +209,7 @@ struct cbh_device_batch {
   const u32* w_inv = nullptr;         // grouped by route: input -> position of its per-request results; else null
   u64* w_edr_input = nullptr;         // scratch of cbh_result_download: the derived-role masks back in input order
   const u64* w_moff = nullptr; u32 w_dver_off = 0, w_dver_len = 0;   // (the device assembler reads the messages again)
+  bool w_total_known = false; uint64_t w_total = 0; uint32_t w_out_errors = 0;   // cbh_wire_outputs ran its size / scan launches for this batch's current results
   u32* w_sizes = nullptr; u64* w_wavesum = nullptr; u64* w_waveoff = nullptr; WireOutStats* w_ostats = nullptr; u64* w_out_off = nullptr; u8* w_out_flags = nullptr;
 };
 
@@ -653,6 +654,7 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   std::lock_guard<std::mutex> lk(rep->mu);
   HIPCHK(hipSetDevice(rep->device));
   hipStream_t s = b->stream;
+  b->w_total_known = false;   // (the sizes cbh_wire_outputs computed belong to the results this launch replaces)
   // Kernel durations come from the dispatches' own begin / end timestamps (hipExtLaunchKernelGGL
   // with start / stop events: what rocprofv3's kernel trace reads too), not from event-record
   // packets placed around them, which would sit between back-to-back launches and add their own
@@ -811,9 +813,25 @@ static int wire_stats_write(cbh_device_batch* b, WireStats* d_stats, const WireS
   return 0;
 }
 
+// (cbh_wire_check_pb) the uploads of a call's slices go over the link ONE AFTER THE OTHER, in slice order, so that slice k is being
+// decided while slice k + 1 is still on its way: a slice's upload waits for the event its predecessor recorded behind its own
+struct WireChain {
+  hipEvent_t wait = nullptr, record = nullptr;
+  std::atomic<int>* prev_recorded = nullptr; std::atomic<int>* recorded = nullptr;
+  void done() { if (recorded) recorded->store(1, std::memory_order_release); }   // (also on every early return: the successor must not wait for ever)
+};
+static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
+                             const char* default_version, const char* default_scope, const uint8_t* globals_pb, size_t globals_len,
+                             cbh_device_batch** out, cbh_wire_info* info, WireChain* chain);
 extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
                                 const char* default_version, const char* default_scope, const uint8_t* globals_pb, size_t globals_len,
                                 cbh_device_batch** out, cbh_wire_info* info) {
+  return wire_flatten_impl(t, device_index, bytes, offsets, n, default_version, default_scope, globals_pb, globals_len, out, info, nullptr);
+}
+static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
+                             const char* default_version, const char* default_scope, const uint8_t* globals_pb, size_t globals_len,
+                             cbh_device_batch** out, cbh_wire_info* info, WireChain* chain) {
+  struct ChainGuard { WireChain* c; ~ChainGuard() { if (c) c->done(); } } chain_guard{chain};
   if (!t || !out || !info || (n && (!bytes || !offsets)) || (globals_len && !globals_pb)) return fail("null argument");
   std::memset(info, 0, sizeof(*info));
   info->first_bad = CBH_NONE; info->n_requests = n;
@@ -879,7 +897,12 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
   *pin_st = st;
   std::memcpy(pin_tail, tail.data(), tail.size());
   if (n) std::memcpy(pin_off, offsets, ((size_t)n + 1) * 8); else pin_off[0] = 0;
+  if (chain && chain->prev_recorded) {   // behind the predecessor's upload (its thread has enqueued the record by now, or is about to)
+    while (!chain->prev_recorded->load(std::memory_order_acquire)) std::this_thread::yield();
+    if (chain->wait && hipStreamWaitEvent(s, chain->wait, 0) != hipSuccess) { fail("cbh_wire_flatten: hipStreamWaitEvent failed"); return bail(-1); }
+  }
   if (total && hipMemcpyAsync(d_msg, bytes, total, hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
+  if (chain && chain->record) { (void)hipEventRecord(chain->record, s); chain->done(); }
   if (hipMemcpyAsync(d_msg + total, pin_tail, tail.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
       hipMemcpyAsync(d_moff, pin_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
       hipMemcpyAsync(d_stats, pin_st, sizeof(st), hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
@@ -1036,14 +1059,18 @@ extern "C" int cbh_wire_outputs(cbh_table* t, cbh_device_batch* b, uint8_t* byte
   a.sizes = b->w_sizes; a.wavesum = b->w_wavesum; a.waveoff = b->w_waveoff; a.stats = b->w_ostats; a.out_off = b->w_out_off; a.out_flags = b->w_out_flags;
   WireOutStats st; std::memset(&st, 0, sizeof(st));
   static_assert(sizeof(WireOutStats) <= sizeof(WireStats), "the batch's page-locked block has two WireStats slots");
-  WireOutStats* pin_st = static_cast<WireOutStats*>(b->w_pinned);   // (page-locked: the copies below never block on staging)
-  *pin_st = st;
-  HIPCHK(hipMemcpyAsync(b->w_ostats, pin_st, sizeof(st), hipMemcpyHostToDevice, s));
-  if (nw) hipLaunchKernelGGL(cbh_wire_out_size_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, a);
-  hipLaunchKernelGGL(cbh_wire_out_scan_kernel, dim3(1), dim3(CBH_BLOCK), 0, s, a);
-  HIPCHK(hipMemcpyAsync(pin_st, b->w_ostats, sizeof(st), hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-  st = *pin_st;
+  if (b->w_total_known) { st.total = b->w_total; st.errors = b->w_out_errors; }   // sizes and offsets of these results are on the device already
+  else {
+    WireOutStats* pin_st = static_cast<WireOutStats*>(b->w_pinned);   // (page-locked: the copies below never block on staging)
+    *pin_st = st;
+    HIPCHK(hipMemcpyAsync(b->w_ostats, pin_st, sizeof(st), hipMemcpyHostToDevice, s));
+    if (nw) hipLaunchKernelGGL(cbh_wire_out_size_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(cbh_wire_out_scan_kernel, dim3(1), dim3(CBH_BLOCK), 0, s, a);
+    HIPCHK(hipMemcpyAsync(pin_st, b->w_ostats, sizeof(st), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    st = *pin_st;
+    b->w_total_known = true; b->w_total = st.total; b->w_out_errors = st.errors;
+  }
   if (st.errors & 1u) return fail("cbh_wire_outputs: a policy or scope id of the results is out of the table's range");
   if (st.errors & 2u) return fail("cbh_wire_outputs: a CheckOutput exceeds 16 MB");
   *need = (size_t)st.total;
@@ -1062,6 +1089,116 @@ extern "C" int cbh_wire_outputs(cbh_table* t, cbh_device_batch* b, uint8_t* byte
     std::lock_guard<std::mutex> lk(rep->pool_mu);
     for (size_t i = b->allocs.size(); i-- > 0;) if (b->allocs[i].first == d_out) { rep->pool_free.push_back(b->allocs[i]); b->allocs.erase(b->allocs.begin() + (long)i); break; }
   }
+  return 0;
+}
+
+// Bytes in, bytes out in ONE call: serialized CheckInputs -> serialized CheckOutputs by the device road (cbh_wire_flatten,
+// cbh_check_resident, cbh_wire_outputs), the call cut into up to four slices of contiguous messages that go down the road side
+// by side, each on a thread and a stream of its own - one slice's copies run under another's kernels, which a single caller
+// thread making the three calls in a row never gets (its H2D, kernels and D2H queue behind each other).  The slices' outputs
+// land back to back in `out_bytes`: every slice first learns its size (the size / scan launches), the bases follow, then each
+// writes and copies into its own range.  Returns 0; 1 = some message is the host flattener's (info->n_host; nothing was
+// written); 2 = `out_cap` is too small, *need holds the size; < 0 error.
+extern "C" int cbh_wire_check_pb(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
+                                 const char* default_version, const char* default_scope, const uint8_t* globals_pb, size_t globals_len,
+                                 const cbh_params* p, uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags,
+                                 size_t* need, cbh_wire_info* info) {
+  if (!t || !p || !out_offsets || !need || !info || (n && (!bytes || !offsets)) || (out_cap && !out_bytes)) return fail("null argument");
+  TableRef ref(t);
+  std::memset(info, 0, sizeof(*info));
+  info->first_bad = CBH_NONE; info->n_requests = n;
+  *need = 0;
+  static const u32 max_slices = [] { const char* e = getenv("CBH_WIRE_SLICES"); const long v = e ? atol(e) : 4; return (u32)std::min<long>(std::max<long>(v, 1), 8); }();
+  const u32 S = std::max<u32>(1u, std::min<u32>(max_slices, n / 16384u));
+  struct Slice {
+    u32 lo = 0, hi = 0; cbh_device_batch* b = nullptr; cbh_wire_info wi{}; size_t total = 0, base = 0; int rc = 0; std::string err;
+    std::vector<uint64_t> off, ooff;
+  };
+  std::vector<Slice> sl(S);
+  for (u32 k = 0; k < S; ++k) { sl[k].lo = (u32)((u64)n * k / S); sl[k].hi = (u32)((u64)n * (k + 1) / S); }
+  // the slices' uploads in slice order (WireChain)
+  if (device_index >= t->reps.size()) return fail("device index out of range");
+  HIPCHK(hipSetDevice(t->reps[device_index]->device));
+  std::vector<hipEvent_t> evs(S, nullptr);
+  std::vector<std::atomic<int>> recorded(S);
+  std::vector<WireChain> chains(S);
+  struct EvGuard { std::vector<hipEvent_t>& e; ~EvGuard() { for (auto x : e) if (x) (void)hipEventDestroy(x); } } ev_guard{evs};
+  for (u32 k = 0; k < S; ++k) {
+    recorded[k].store(0);
+    if (S > 1 && hipEventCreateWithFlags(&evs[k], hipEventDisableTiming) != hipSuccess) return fail("cbh_wire_check_pb: hipEventCreate failed");
+    chains[k].record = evs[k]; chains[k].recorded = &recorded[k];
+    if (k) { chains[k].wait = evs[k - 1]; chains[k].prev_recorded = &recorded[k - 1]; }
+  }
+  // stage 1 (per slice): flatten, decide, sizes of the outputs
+  auto stage1 = [&](u32 k) {
+    Slice& x = sl[k];
+    const u32 cnt = x.hi - x.lo;
+    x.off.resize((size_t)cnt + 1);
+    const uint64_t o0 = n ? offsets[x.lo] : 0;
+    for (u32 i = 0; i <= cnt; ++i) x.off[i] = (n ? offsets[x.lo + i] : 0) - o0;
+    x.rc = wire_flatten_impl(t, device_index, bytes ? bytes + o0 : nullptr, x.off.data(), cnt, default_version, default_scope, globals_pb, globals_len, &x.b, &x.wi,
+                             S > 1 ? &chains[k] : nullptr);
+    if (x.rc != 0) { x.err = g_err; x.b = nullptr; return; }
+    x.rc = cbh_check_resident(t, x.b, p);
+    if (x.rc != 0) { x.err = g_err; return; }
+    x.ooff.resize((size_t)cnt + 1);
+    size_t nd = 0;
+    const int r = cbh_wire_outputs(t, x.b, nullptr, 0, x.ooff.data(), nullptr, &nd);   // cap 0: sizes only (2 = "too small" unless the slice has no output bytes)
+    if (r != 0 && r != 2) { x.rc = r; x.err = g_err; return; }
+    x.total = nd;
+  };
+  auto stage2 = [&](u32 k) {
+    Slice& x = sl[k];
+    const u32 cnt = x.hi - x.lo;
+    size_t nd = 0;
+    x.rc = cbh_wire_outputs(t, x.b, out_bytes + x.base, x.total, x.ooff.data(), out_flags ? out_flags + x.lo : nullptr, &nd);
+    if (x.rc != 0) { x.err = g_err; return; }
+    for (u32 i = 0; i <= cnt; ++i) out_offsets[x.lo + i] = x.ooff[i] + x.base;
+  };
+  // A slice writes as soon as the slices before it know their sizes (its base is their sum): no barrier between the stages, so
+  // the first slice's answers are on their way back while the last slice's messages are still going up.  A slice that failed,
+  // or met a message for the host flattener, publishes "no size": nobody writes after that.
+  std::vector<std::atomic<int>> sized(S);   // 0 not yet, 1 size known, 2 failed
+  for (auto& q : sized) q.store(0);
+  std::atomic<int> overflow{0};
+  auto work = [&](u32 k) {
+    stage1(k);
+    Slice& x = sl[k];
+    sized[k].store(x.rc == 0 ? 1 : 2, std::memory_order_release);
+    if (x.rc != 0) return;
+    size_t base = 0;
+    for (u32 j = 0; j < k; ++j) {
+      int st;
+      while ((st = sized[j].load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+      if (st == 2) return;
+      base += sl[j].total;
+    }
+    x.base = base;
+    if (base + x.total > out_cap) { overflow.store(1); return; }
+    stage2(k);
+  };
+  {
+    std::vector<std::thread> th;
+    for (u32 k = 1; k < S; ++k) th.emplace_back(work, k);
+    work(0);
+    for (auto& q : th) q.join();
+  }
+  auto release = [&] { for (auto& x : sl) if (x.b) { cbh_batch_release(x.b); x.b = nullptr; } };
+  int rc = 0; std::string err;
+  size_t total = 0;
+  for (auto& x : sl) {
+    info->n_tuples += x.wi.n_tuples; info->n_host += x.wi.n_host; info->heap_len += x.wi.heap_len; info->dict_slots += x.wi.dict_slots;
+    info->fill_runs = std::max(info->fill_runs, x.wi.fill_runs); info->n_routes = std::max(info->n_routes, x.wi.n_routes);
+    if (x.wi.first_bad != CBH_NONE && info->first_bad == CBH_NONE) info->first_bad = x.lo + x.wi.first_bad;
+    if (x.rc < 0 && rc >= 0) { rc = x.rc; err = x.err; }
+    else if (x.rc == 1 && rc == 0) { rc = 1; err = x.err; }
+    total += x.total;
+  }
+  release();
+  if (rc != 0) { g_err = err; return rc; }
+  *need = total;
+  if (overflow.load() || total > out_cap) { g_err = "cbh_wire_check_pb: the output buffer is too small"; return 2; }
+  if (n == 0) out_offsets[0] = 0;
   return 0;
 }
 

@@ -295,6 +295,19 @@ int cbh_wire_spans_download(cbh_table* t, cbh_device_batch* b, uint32_t* in_span
  * (may be NULL).  Returns 0; 2 = `cap` is too small, *need holds the size (nothing was copied; call again); < 0 error.
  * evaluation_errors / outputs of the inputs whose flags ask for them come from the trace pass, as on the host road. */
 int cbh_wire_outputs(cbh_table* t, cbh_device_batch* b, uint8_t* bytes, size_t cap, uint64_t* offsets, uint8_t* flags, size_t* need);
+/* The whole device road in ONE call - what a Go caller's CheckBatch makes per batch (integration/go/gpu_cgo.go): serialized
+ * CheckInputs in, serialized CheckOutputs out (replaces the loop of engine.go:289-338 over checkInputToRequest / check /
+ * the CheckOutput marshalling of its callers).  The call is cut into up to four slices of contiguous messages that go down the
+ * road side by side (a thread and a stream each), so that one slice's copies run under another's kernels: from ONE caller
+ * thread this gives what several threads making the three calls in a row give.  out_offsets: n + 1 entries, output i =
+ * out_bytes[out_offsets[i] .. out_offsets[i + 1]); out_flags (n entries, may be NULL) = CBI_OUT_* of cerbos_ingest.h.
+ * Page-locked `bytes` / `out_bytes` (cbh_alloc_pinned) make every copy a DMA.  Returns 0; 1 = some message is the host
+ * flattener's (info->n_host; nothing was written: take the host road); 2 = out_cap is too small, *need holds the size; < 0 error
+ * (a malformed message: info->first_bad). */
+int cbh_wire_check_pb(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
+                      const char* default_version, const char* default_scope, const uint8_t* globals_pb, size_t globals_len,
+                      const cbh_params* p, uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags,
+                      size_t* need, cbh_wire_info* info);
 
 /* ---- Trace pass: evaluation_errors and outputs (evaluator/cel_errors.go:48-118, check.go:383-411, 776-807) ----
  * The decision kernels only mark the tuples whose evaluation absorbed a CEL error (CBH_ST_CEL_ERROR).  What the

@@ -190,35 +190,34 @@ func (g *gpuEngine) hostRoad(bytesPtr *C.uint8_t, offs []C.uint64_t, n int, dv, 
 	return obytes, ooffs, oflags, func() { C.cbi_outputs_free(assembled) }, nil
 }
 
-// deviceRoad: cbh_wire_flatten -> cbh_check_resident -> cbh_wire_outputs.  ok == false: these messages are the host
-// flattener's (cbh_wire_flatten returned 1).  The answers land in a page-locked block from g.outPool (DMA, no staging copy).
+// deviceRoad: cbh_wire_check_pb (= cbh_wire_flatten -> cbh_check_resident -> cbh_wire_outputs, sliced).  ok == false: these messages are the host
+// flattener's (the call returned 1).  The answers land in a page-locked block from g.outPool (DMA, no staging copy).
 func (g *gpuEngine) deviceRoad(bytesPtr *C.uint8_t, offs []C.uint64_t, n int, dv, ds *C.char, params *C.cbh_params) (obytes []byte, ooffs []uint64, oflags []byte, release func(), ok bool, err error) {
-	var db *C.cbh_device_batch
-	var info C.cbh_wire_info
-	switch rc := C.cbh_wire_flatten(g.table, 0, bytesPtr, &offs[0], C.uint32_t(n), dv, ds, nil, 0 /* per-call globals: a serialized Struct */, &db, &info); {
-	case rc == 1:
-		return nil, nil, nil, nil, false, nil
-	case rc != 0:
-		return nil, nil, nil, nil, false, errors.New(C.GoString(C.cbh_last_error()))
-	}
-	defer C.cbh_batch_release(db)
-	if C.cbh_check_resident(g.table, db, params) != 0 {
-		return nil, nil, nil, nil, false, errors.New(C.GoString(C.cbh_last_error()))
-	}
+	// cbh_wire_check_pb: the whole road in one cgo crossing - the library cuts the call into slices that go down side by side
+	// (one slice's copies under another's kernels), so ONE goroutine gets what several would making the three calls in a row
 	blk := g.outPool.get(192*n+4096, n) // bytes | offsets (n + 1) | flags (n), one page-locked block
 	if blk == nil {                     // no page-locked memory to be had: the host road answers this call
 		return nil, nil, nil, nil, false, nil
 	}
 	var need C.size_t
-	rc := C.cbh_wire_outputs(g.table, db, blk.bytes, C.size_t(blk.cap), blk.offs, blk.flags, &need)
+	var info C.cbh_wire_info
+	call := func() C.int {
+		return C.cbh_wire_check_pb(g.table, 0, bytesPtr, &offs[0], C.uint32_t(n), dv, ds, nil, 0 /* per-call globals: a serialized Struct */, params,
+			blk.bytes, C.size_t(blk.cap), blk.offs, blk.flags, &need, &info)
+	}
+	rc := call()
 	if rc == 2 { // the guess was short: `need` is exact
 		g.outPool.put(blk)
 		if blk = g.outPool.get(int(need), n); blk == nil {
 			return nil, nil, nil, nil, false, nil
 		}
-		rc = C.cbh_wire_outputs(g.table, db, blk.bytes, C.size_t(blk.cap), blk.offs, blk.flags, &need)
+		rc = call()
 	}
-	if rc != 0 {
+	switch {
+	case rc == 1: // some message is the host flattener's (more than 64 actions, ...): the host road takes the call
+		g.outPool.put(blk)
+		return nil, nil, nil, nil, false, nil
+	case rc != 0:
 		g.outPool.put(blk)
 		return nil, nil, nil, nil, false, errors.New(C.GoString(C.cbh_last_error()))
 	}

@@ -111,3 +111,43 @@ def test_evaluator_bytes_path_takes_the_device_road():
         assert have == want and np.array_equal(np.asarray(wflags), np.asarray(hflags))
     finally:
         ev.close()
+
+
+@pytest.mark.timeout(300)
+def test_the_road_in_one_call_gives_the_three_calls_bytes():
+    """cbh_wire_check_pb (the device road in one call, cut into slices that run side by side) against cbh_wire_flatten +
+    cbh_check_resident + cbh_wire_outputs: the same bytes, offsets and flags - at a size that takes four slices, at sizes that
+    take one, with an output buffer that is too small at first, and a message for the host flattener in the third slice."""
+    from cerbos_amd import wire, workloads
+    from cerbos_amd.lower.blob import lower_rule_table
+    from cerbos_amd.policy.loader import policies_from_docs
+    from cerbos_amd.ruletable.build import rule_table_from_policies
+    for pol_fn, req_fn in ((workloads.c5_policies, workloads.c5_requests), (workloads.c3_policies, workloads.c3_requests)):
+        lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol_fn())))
+        table = capi.Table(lt.blob)
+        inputs = req_fn(70_000).to_inputs()
+        msgs = [wire.encode_check_input(i) for i in inputs]
+        flags = capi.F_WANT_DERIVED_ROLES
+        for n in (70_000, 20_000, 130, 1, 0):
+            data, off = wire.pack_messages(msgs[:n])
+            db = table.wire_flatten(data, off)
+            table.launch(db, now_ns=NOW, flags=flags)
+            want, wflags = table.wire_outputs(db)
+            db.close()
+            got, gflags = table.wire_check_pb(data, off, now_ns=NOW, flags=flags)
+            assert got == want and list(gflags) == list(wflags), (n, len(got))
+        # a buffer that is too small at first: the binding grows it from `need`
+        data, off = wire.pack_messages(msgs[:40_000])
+        small = (np.empty(1000, dtype=np.uint8), np.empty(40_001, dtype=np.uint64), np.empty(40_000, dtype=np.uint8))
+        got, _ = table.wire_check_pb(data, off, now_ns=NOW, flags=flags, out=small)
+        db = table.wire_flatten(data, off)
+        table.launch(db, now_ns=NOW, flags=flags)
+        want, _ = table.wire_outputs(db)
+        db.close()
+        assert got == want
+        # a CheckInput with more than 64 actions is the host flattener's: the whole call says so
+        big = dict(inputs[50_000], actions=["a%d" % i for i in range(70)])
+        data, off = wire.pack_messages(msgs[:50_000] + [wire.encode_check_input(big)] + msgs[50_001:])
+        with pytest.raises(capi.HostFlattenerNeeded):
+            table.wire_check_pb(data, off, now_ns=NOW, flags=flags)
+        table.close()
