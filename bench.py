@@ -47,7 +47,7 @@ import numpy as np  # noqa: E402
 ALG_BYTES_PER_DECISION = {"C1": 33.0, "C2": 49.0, "C3": 42.0, "C4": 47.0, "C5": 83.0, "T": 47.0, "C5W": 83.0}
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 SERIAL_BATCHES = 16                     # resident batches of the one-stream leg (0.8 GB at C2: beyond the Infinity Cache)
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")   # written by tools/gpu_final_r03.sh
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")   # written by tools/gpu_final_r04.sh
 
 
 def pmc_traffic(kernel, workload):
@@ -62,7 +62,7 @@ def pmc_traffic(kernel, workload):
     e = (d.get("workloads") or {}).get(workload)
     if not e or not all(k in kernel for k in (e.get("kernels") or [e.get("kernel", "?")])):
         return None, None
-    return e["bytes_per_launch"], "profiles/r03_pmc_traffic.json: separate rocprofv3 --pmc passes of this command (%s)" % e.get("note", "")
+    return e["bytes_per_launch"], "profiles/r04_pmc_traffic.json: separate rocprofv3 --pmc passes of this command (%s)" % e.get("note", "")
 
 
 def main():

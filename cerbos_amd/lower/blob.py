@@ -22,7 +22,7 @@ from ..cel import parser as celparser
 from ..ruletable.build import KIND_RESOURCE
 from . import celc
 from .celc import COND_LEAF, COND_LEAFTREE, COND_PC_MASK, LoweringError, Params, ProgramBuilder
-from .globs import GlobNFA, has_meta
+from .globs import GlobError, GlobNFA, fix_glob, has_meta, parse_glob
 
 BLOB_MAGIC = 0x31484243
 BLOB_VERSION = 22
@@ -94,16 +94,29 @@ def hash4(a, b, c, d):
 
 
 class _Dim:
-    """Pattern set of one index dimension (action / role / resource kind)."""
+    """Pattern set of one index dimension (action / role / resource kind).  The device keeps ONE 64-bit word of match bits per
+    string and dimension and an automaton of at most eight state words: a pattern beyond either (`overflow`) gets no index."""
 
     def __init__(self):
         self.globs = {}  # pattern text -> glob index
+        self.positions = 0
+        self.overflow = set()
 
-    def glob_ref(self, pattern):
+    def glob_ref(self, pattern, may_overflow=False):
         gi = self.globs.get(pattern)
         if gi is None:
+            if pattern in self.overflow:
+                return None
+            try:
+                cost = sum(len(seq) + 1 for seq in parse_glob(fix_glob(pattern)))
+            except GlobError:
+                cost = 0     # an invalid glob never matches (globs_common.go:33-36): it takes an index, no states
+            if may_overflow and (len(self.globs) >= GlobNFA.MAX_GLOBS or self.positions + cost > 64 * GlobNFA.MAX_WORDS):
+                self.overflow.add(pattern)
+                return None
             gi = len(self.globs)
             self.globs[pattern] = gi
+            self.positions += cost
         return PAT_GLOB | gi
 
 
@@ -181,15 +194,36 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
             used_any.append(dim)
             return PAT_ANY          # fixGlob: "*" means "**" (util/globs_common.go:74-81)
         if "*" in key:
-            return dims[dim].glob_ref(key)
+            ref = dims[dim].glob_ref(key, may_overflow=dim != DIM_KIND)
+            if ref is None:           # beyond what the device holds for the dimension: see glob_overflows
+                used_any.append(dim)
+                return PAT_ANY
+            return ref
         return sid(key)
 
     def allow_action_ref(a):
         """Role-policy allow actions are matched with ``a == action || MatchesGlob(a, action)``
         (index.go:447-452): any glob metacharacter makes it a pattern."""
         if has_meta(a):
-            return dims[DIM_ACTION].glob_ref(a)
+            ref = dims[DIM_ACTION].glob_ref(a, may_overflow=True)
+            if ref is None:
+                used_any.append(DIM_ACTION)
+                return PAT_ANY
+            return ref
         return sid(a)
+
+    def glob_overflows(dim, keys, meta_is_glob=False):
+        """Does a role / action list hold a pattern the dimension has no room for (more than 64 patterns, or an automaton beyond
+        512 positions)?  Such a pattern is lowered as "*" - it matches MORE than it should - and the rule's condition as a
+        program that flags whoever evaluates it (CBH_ST_UNSUPPORTED): every request that could have matched the real pattern
+        is handed back to the caller's own engine, never answered wrongly, and the rest of the table still serves (the
+        reference has no such limit: index/glob_dimension.go:31-118)."""
+        hit = False
+        for k in keys or ():
+            if k and k != "*" and (("*" in k) or (meta_is_glob and has_meta(k))):
+                if dims[dim].glob_ref(k, may_overflow=True) is None:
+                    hit = True
+        return hit
 
     # ---- scopes: every scope of a row or role policy plus all ancestors; "" is index 0
     scope_set = {""}
@@ -291,7 +325,10 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
 
     def row_programs(r, principal_policy):
         params = Params(r["params"]["constants"], r["params"]["ordered_variables"], globals_) if r["params"] else Params(None, None, globals_)
-        if principal_policy and _cond_uses_runtime(r["condition"], params):
+        if glob_overflows(DIM_ROLE, [r["role"]]) | glob_overflows(DIM_ACTION, [r["action"]]):
+            cond = pb.unsupported_program(namer.policy_key_from_fqn(r["origin_fqn"]),
+                                          "more glob patterns in the role / action dimension than the device table holds (64 patterns, 512 automaton positions)")
+        elif principal_policy and _cond_uses_runtime(r["condition"], params):
             # in the reference the value then depends on the previously evaluated action (check.go:281), which a
             # per-tuple evaluation cannot reproduce: whoever reaches this rule is flagged, not answered
             cond = pb.unsupported_program(namer.policy_key_from_fqn(r["origin_fqn"]),
@@ -388,7 +425,13 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
         dr_begin = len(dr_cols[0])
         drs = rt["policy_derived_roles"].get(namer.resource_policy_fqn(kind, ver, scope)) or {}
         for name, dr in drs.items():
-            dr_cols[0].append(pb.dr_bit(name))
+            bit = pb.dr_bit(name)
+            if bit is None:
+                # A 65th derived role: the mask has no bit to report it with.  Its definition stays, under bit 63, with a condition
+                # that flags whoever evaluates it - the requests whose roles reach the definition go back to the caller's own
+                # engine (their effectiveDerivedRoles could not be told), every other request of the table is answered.
+                dr = dict(dr, condition=None)
+            dr_cols[0].append(63 if bit is None else bit)
             dr_parents.append(list(dr["parent_roles"]))
             if "*" in dr["parent_roles"]:
                 dr_cols[1].append(0)
@@ -406,8 +449,12 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
             # evaluated once per request, and every walk visits the chain in order) - the deepest scope sees none.  That is
             # what Lane.edr holds while the general walk evaluates a scope's definitions (cbh_check_wave.h), and tables whose
             # programs read runtime.* stay on that kernel.
-            dr_cols[3].append(pb.condition_program(dr["condition"], dparams, allow_runtime=True)
-                              if dr["condition"] is not None else NONE)
+            if bit is None:
+                dr_cols[3].append(pb.unsupported_program(namer.resource_policy_fqn(kind, ver, scope) + "#" + name,
+                                                         "more than 64 distinct derived role names: no bit of the effective-derived-roles mask is left for this one"))
+            else:
+                dr_cols[3].append(pb.condition_program(dr["condition"], dparams, allow_runtime=True)
+                                  if dr["condition"] is not None else NONE)
         entries.append((B_RESOURCE, sid(ver), sid(kind), lt.scope_index[scope],
                         begin, n_rows, dr_begin, len(dr_cols[0]) - dr_begin))
     for ver, kind, scope in sorted(res_exists):
@@ -449,7 +496,10 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
             rp_family.append(ver)
             rp_scope.append(scope)
             rp_allow.append(list(r["allow_actions"]))
-            if r["id"] in rp_history_dependent:
+            if glob_overflows(DIM_ACTION, r["allow_actions"], meta_is_glob=True):
+                rp_cols[3].append(pb.unsupported_program(namer.policy_key_from_fqn(r["origin_fqn"]),
+                                                         "more glob patterns among the allow actions than the device table holds (64 patterns, 512 automaton positions)"))
+            elif r["id"] in rp_history_dependent:
                 rp_cols[3].append(pb.unsupported_program(namer.policy_key_from_fqn(r["origin_fqn"]),
                                                          "role-policy rules for overlapping resource globs share an evaluation key but "
                                                          "not a condition (history dependent, ruletable.go:445-455)"))

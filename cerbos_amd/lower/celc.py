@@ -235,6 +235,7 @@ class ProgramBuilder:
         self.tree_strips = {}              # entry pc of a leaf tree -> (packed ops, n leaves, strip index / 8): _tree_strip
         self._pending_strip = None
         self.dr_names = {}                 # derived role name -> bit
+        self.dr_overflow = set()           # derived role names beyond the 64 bits of the mask
         self.unsupported = []              # [(expr text, reason)]
         self.uses_runtime = False
         self.reads_string_bytes = False   # some program may look INSIDE a string (ordering, prefix, size, parsing ...)
@@ -291,9 +292,13 @@ class ProgramBuilder:
         return i
 
     def dr_bit(self, name):
+        """Bit of a derived role in the effective-derived-roles mask (64 bits), or None: the table names more than 64 derived
+        roles and this one got no bit - what refers to it is lowered so that the requests it concerns are flagged
+        (CBH_ST_UNSUPPORTED), the rest of the table still serves."""
         if name not in self.dr_names:
             if len(self.dr_names) >= 64:
-                raise LoweringError("more than 64 distinct derived role names: not supported by the device table")
+                self.dr_overflow.add(name)
+                return None
             self.dr_names[name] = len(self.dr_names)
         return self.dr_names[name]
 
@@ -1043,7 +1048,10 @@ class _FuncCompiler:
                 if p is not None and p[0] == "edr":
                     if ast[2][0] == "lit" and ast[2][1] == "string" and self.allow_runtime:
                         pb.uses_runtime = True
-                        return self.emit(OP_EDRHAS, pb.dr_bit(ast[2][2]), +1)
+                        bit = pb.dr_bit(ast[2][2])
+                        if bit is None:
+                            return self.unsupported("runtime.effectiveDerivedRoles names a derived role beyond the 64 the device mask holds")
+                        return self.emit(OP_EDRHAS, bit, +1)
                     return self.unsupported("runtime.effectiveDerivedRoles membership with a non-constant name")
             if op in ("==", "!=") and self.allow_runtime:
                 # runtime.effectiveDerivedRoles == [constant names] (either order): the runtime list is the SORTED names of the
@@ -1054,8 +1062,11 @@ class _FuncCompiler:
                         names = [e[2] for e in rhs[1]]
                         never = any(a >= b for a, b in zip(names, names[1:]))   # not strictly ascending: never equal
                         mask = 0
-                        for nm in names:
-                            mask |= 1 << pb.dr_bit(nm)
+                        bits = [pb.dr_bit(nm) for nm in names]
+                        if any(b is None for b in bits):
+                            return self.unsupported("runtime.effectiveDerivedRoles compared with a derived role beyond the 64 the device mask holds")
+                        for b in bits:
+                            mask |= 1 << b
                         pb.uses_runtime = True
                         self.emit(OP_EDREQ, pb.const(T_UINT, mask) | (0x80000000 if never else 0), +1)
                         return self.emit(OP_NOT) if op == "!=" else None
