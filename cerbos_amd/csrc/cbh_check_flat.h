@@ -119,6 +119,8 @@ __device__ __forceinline__ FlatCol flat_col(const Ctx& c, u32 col, u32 req) {   
 // class it is is a wave-uniform switch.  Same answers as leaf_fast (cbh_check_wave.h), which stays the reference
 // for the shapes not listed here.  Returns bit 0 = satisfied, bit 1 = CEL error (counts as not satisfied),
 // bit 2 = undecided here (mixed numeric types, containers): the caller hands that lane to eval_cond_rec.
+// LISTS = false: the variant for tables closed over classes 1-4 and 6 (CBH_MF_FLAT_CLOSED), which never hold a membership leaf.
+template <bool LISTS = true>
 __device__ __forceinline__ u32 flat_leaf(const Ctx& c, const LeafRec& lr, u32 req, u32 pid) {
   const u32 a = lr.w >> 8;
   const u32 ka = (a >> 8) & 0xFu, op = a & 0xFFu;   // wave-uniform
@@ -167,6 +169,35 @@ __device__ __forceinline__ u32 flat_leaf(const Ctx& c, const LeafRec& lr, u32 re
       const bool found = x.t == CBH_T_STRING && (x.lo == lr.ctag || x.lo == lr.clo || x.lo == lr.chi);
       return err ? 2u : (u32)found;
     }
+    case 7:     // string constant in a list / among a map's keys the request brings
+    case 8: {   // column in such a column
+      if (!LISTS) return 4u;
+      const FlatCol h = flat_col(c, lr.a1, req);
+      u32 nt = CBH_T_STRING, nlo = lr.clo;
+      bool err = h.t >= CBH_T_ABSENT;
+      if (lr.pad == 8u) {
+        if (ka == 4u) nlo = pid;   // the principal's id
+        else { const FlatCol x = flat_col(c, lr.a0, req); nt = x.t; nlo = x.lo; err = err || x.t >= CBH_T_ABSENT; }
+      }
+      const bool is_map = h.t == CBH_T_MAP, cont = h.t == CBH_T_LIST || is_map;
+      const u32 sel = h.hi >> 30, off = h.hi & 0x3FFFFFFFu, len = cont ? h.lo : 0u, stride = is_map ? 2u : 1u;
+      // a needle that is not a string, a container outside the batch's heap, a long one: the shared evaluator's
+      const bool slow = !err && (nt != CBH_T_STRING || (cont && (sel != CBH_HEAP_BATCH || len > 64u)));
+      const u32 n = (err || slow) ? 0u : len;
+      bool found = false;
+      for (u32 i = 0; wave_ballot(i < n) != 0; i += 4u) {   // four elements a round (their loads fly together); as many rounds as the longest container in the wave needs
+        u32 tg[4]; u32 vl[4];
+#pragma unroll
+        for (u32 q = 0; q < 4; ++q) {
+          const u32 at = off + stride * (i + q < n ? i + q : (n ? n - 1u : 0u));   // (a lane beyond its end re-reads its last element)
+          tg[q] = n ? (u32)c.b.heap_tag[at] : 0u; vl[q] = n ? (u32)c.b.heap_val[at] : 0u;
+        }
+#pragma unroll
+        for (u32 q = 0; q < 4; ++q) found = found || (i + q < n && tg[q] == CBH_T_STRING && vl[q] == nlo);
+      }
+      // `in` has no overload for anything but a list or a map on the right (cel-go: no such overload -> an evaluation error)
+      return (err || (!slow && !cont)) ? 2u : slow ? 4u : (u32)found;
+    }
     default: return 4u;
   }
 }
@@ -175,6 +206,7 @@ __device__ __forceinline__ u32 flat_leaf(const Ctx& c, const LeafRec& lr, u32 re
 // slot): the 4-bit ops in order, leaves from the strip, no tape reads and no divergent branch.  Same bookkeeping as
 // eval_leaf_tree (cbh_check_wave.h): a leaf behind the deciding one of its level is not evaluated by the reference
 // (check.go:697-749), so its error / "needs the full evaluator" flags do not count.  Returns flat_leaf's bits for the tree.
+template <bool LISTS = true>
 __device__ __forceinline__ u32 flat_tree(const Ctx& c, const LeafRec& desc, u32 req, u32 pid) {
   const u32 opw[4] = {desc.w, desc.a0, desc.ret, desc.ctag};   // wave-uniform
   bool live = true, last = false;
@@ -184,7 +216,7 @@ __device__ __forceinline__ u32 flat_tree(const Ctx& c, const LeafRec& desc, u32 
     if (op == 0) break;
     if (op == 1) {
       const LeafRec lr = uload_rec<LeafRec>(c.t.code, leaf++);
-      const u32 lv = flat_leaf(c, lr, req, pid);
+      const u32 lv = flat_leaf<LISTS>(c, lr, req, pid);
       last = live && (lv & 1u) != 0;
       err |= live ? (lv & 2u) : 0u;
       slow |= live ? (lv & 4u) : 0u;
@@ -490,8 +522,8 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   auto leafish = [&](u32 ref, u32 how, const LeafRec& lr, bool active) -> u32 {
     u32 lv = 4u;
     FLAT_DBG(const u64 e0 = __builtin_readcyclecounter(); ++dbg_evals;)
-    if (how == 1u) lv = flat_leaf(c, lr, req, pid);
-    else if (how == 2u) lv = flat_tree(c, lr, req, pid);
+    if (how == 1u) lv = flat_leaf<WITH_CALL>(c, lr, req, pid);
+    else if (how == 2u) lv = flat_tree<WITH_CALL>(c, lr, req, pid);
     FLAT_DBG(cyc_eval += (__builtin_readcyclecounter() - e0) * (u64)(wave_ballot(lv != 77u) != 0);)
     const bool slow = active && lv == 4u;
     if (WITH_CALL) {

@@ -786,7 +786,7 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
     def site_kind(ref, leaf_class, how):
         if ref == NONE:
             return None
-        if how == 2 or (how == 1 and leaf_class in (1, 2, 3, 4, 6)):
+        if how == 2 or (how == 1 and leaf_class in (1, 2, 3, 4, 6, 7, 8)):
             return "open"
         return "generic"
 
@@ -984,7 +984,10 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
     # FLAT_CLOSED: besides, every condition is a classified leaf or a tree of them the flat kernel evaluates inline -
     # with a batch of plain scalars no evaluation can need the shared evaluator (the kernel variant without the call)
     def inline_ok(ref, leaf_slot_class, embedded, tree):
-        return ref == NONE or tree or (embedded and leaf_slot_class in (1, 2, 3, 4, 6))
+        if tree:   # every leaf of the strip must be one the kernels without the evaluator call decide (the mask walk's blocks: classes 1-4, 6)
+            _packed, n, first = pb.tree_strips[ref & COND_PC_MASK]
+            return all(pb.code[(first + j) * 8 + 7] in (1, 2, 3, 4, 6) for j in range(n))
+        return ref == NONE or (embedded and leaf_slot_class in (1, 2, 3, 4, 6))
     closed = flat and all(
         inline_ok(row_cols[ROW_COND][i], row_cols[ROW_LEAF + 7][i], f & ROW_F_LEAF_EMBEDDED, f & ROW_F_TREE_EMBEDDED)
         and inline_ok(row_cols[ROW_DRCOND][i], leaf2_cols[7][i], f & ROW_F_DRLEAF_EMBEDDED, f & ROW_F_DRTREE_EMBEDDED)

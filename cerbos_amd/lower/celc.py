@@ -360,6 +360,12 @@ class ProgramBuilder:
             return 3
         if eqne and ((ka == 3 and kb == 4) or (ka == 4 and kb == 3)):
             return 4
+        # membership in a list (or among a map's keys) the REQUEST brings - `"legal-hold" in R.attr.labels`,
+        # `R.attr.region in P.attr.regions`: 7 = a string constant, 8 = a column, in a column
+        if op == OP_IN and kb == 3 and ka == 0 and self.const_tag[ci] == T_STRING:
+            return 7
+        if op == OP_IN and kb == 3 and ka in (3, 4):     # (4: the principal's id as the needle)
+            return 8
         return 0
 
     def unsupported_program(self, text, reason):
@@ -398,6 +404,8 @@ class ProgramBuilder:
                 self.inline_cols.add(words[1])
                 if cls == 2:
                     self.sensitive_cols.add(words[1])
+            if cls == 7:
+                self.inline_cols.add(words[2])
             if cls == 6:   # column in [<= 3 strings]: the ids instead of the list's heap reference
                 off, n = (cv >> 32) & 0x3FFFFFFF, cv & 0xFFFFFFFF
                 ids = [int(self.theap_val[off + i]) & 0xFFFFFFFF for i in range(n)] + [0xFFFFFFFF] * (3 - n)
@@ -409,6 +417,11 @@ class ProgramBuilder:
             self.sensitive_cols.update((words[1], words[2]))
         elif cls == 4:
             self.inline_cols.add(words[1] if ka == 3 else words[2])
+        elif cls == 8 and ka == 4:
+            self.inline_cols.add(words[2])
+        elif cls == 8:
+            self.inline_cols.update((words[1], words[2]))
+            self.sensitive_cols.add(words[1])     # a needle that is not a string (numbers compare across types, containers by content) goes to the evaluator
         return words + [0xFFFFFFFF, 0, 0, cls]
 
     def _tree_strip(self, pc, words):
@@ -434,7 +447,7 @@ class ProgramBuilder:
             if depth > 8:
                 return
             i += 1
-        if not 1 <= len(leaves) <= TREE_STRIP_MAX or len(ops) > 32 or any(rec[7] not in (1, 2, 3, 4, 6) for rec in leaves):
+        if not 1 <= len(leaves) <= TREE_STRIP_MAX or len(ops) > 32 or any(rec[7] not in (1, 2, 3, 4, 6, 7, 8) for rec in leaves):
             return
         packed = [0, 0, 0, 0]
         for k, o in enumerate(ops):
