@@ -193,7 +193,9 @@ enum CbhBucketType {
                        // literal role class masks of its rules, v3 = union of their role glob masks (Index.Query's base test);
                        // v0 = 1 | CBH_BS_*: the evaluation sites the bucket holds (cbh_check_walk2.h: the pre-pass skips the rest)
   CBH_B_FAMILY = 9,    // (ver sid, kind sid, 0) -> v0 = OR of CBH_BS_* over the buckets of the family's scopes: a request whose
-                       // family holds no site the batch files needs no pre-pass walk
+                       // family holds no site the batch files needs no pre-pass walk; v1, v2 = union of the role classes of the
+                       // records / definitions that carry a GENERIC site, v3 bit 0 = that mask can be used (no role glob among them):
+                       // a request none of whose role sets meets it cannot reach one
   CBH_B_RPROLES = 8,   // (ver sid, scope idx, 0) -> v0 off, v1 cnt into U32POOL: the roles with a role policy at that scope, sorted by
                        // name (the order of a role's ancestor list, ruletable/build.py)
   CBH_B_RESSEG = 10,   // (ver sid, kind sid, scope idx), a table with CBH_SEC_SEGS: same key as RESOURCE -> v0 the bucket's first segment

@@ -131,14 +131,18 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
   const u32 first = chain_first(t, r_scope, FLAG_RES, lenient);
   bool pre_climbs = false;   // pre-pass: does anything on this request's path hold a site the batch files?
+  bool pre_family = false, pre_other = false, pre_pp = false;   // ... its family's records / definitions; role-policy rules; principal policies
+  u64 pre_fam_roles = ~0ull;   // the role classes that reach a generic site of the family (CBH_B_FAMILY v1, v2)
   if (PRE) {
     const u32 filed = (b.n_gslots ? (CBH_BS_ROW_GENERIC | CBH_BS_DR_GENERIC) : 0u) | (b.n_gslots > t.gslots_generic ? (CBH_BS_ROW_OPEN | CBH_BS_DR_OPEN) : 0u);
-    uint4 fv; fv.x = 0;
+    uint4 fv; fv.x = 0; fv.y = 0; fv.z = 0; fv.w = 0;
     const bool has_walks = valid && role_cnt != 0 && act_cnt != 0;
-    if (has_walks && first != CBH_NONE && dir_find(t, CBH_B_FAMILY, r_ver, kind, 0, fv)) pre_climbs = (fv.x & filed) != 0;
-    pre_climbs = pre_climbs || (has_walks && (t.q_sites & filed & (CBH_BS_ROW_GENERIC | CBH_BS_ROW_OPEN)) != 0);   // role-policy rules: any request of the version may reach them
-    const bool pre_principal = has_pp && (t.q_sites & filed & (CBH_BS_DR_GENERIC | CBH_BS_DR_OPEN)) != 0;   // principal policies with sites
-    if (wave_ballot(pre_climbs || (pre_principal && has_walks)) == 0) return;   // nothing to evaluate for this wave
+    if (has_walks && first != CBH_NONE && dir_find(t, CBH_B_FAMILY, r_ver, kind, 0, fv)) pre_family = (fv.x & filed) != 0;
+    if (pre_family && (fv.w & 1u) && b.n_gslots <= t.gslots_generic) pre_fam_roles = (u64)fv.y | ((u64)fv.z << 32);   // (only generic sites filed: the mask is theirs)
+    pre_other = has_walks && (t.q_sites & filed & (CBH_BS_ROW_GENERIC | CBH_BS_ROW_OPEN)) != 0;   // role-policy rules: any request of the version may reach them
+    pre_climbs = pre_family || pre_other;
+    pre_pp = has_walks && has_pp && (t.q_sites & filed & (CBH_BS_DR_GENERIC | CBH_BS_DR_OPEN)) != 0;   // principal policies with sites
+    if (wave_ballot(pre_climbs || pre_pp) == 0) return;   // nothing to evaluate for this wave
   }
   fill_column_cache(c, b, NRQ, req);
   const u32 all = (1u << act_cnt) - 1u;
@@ -254,6 +258,13 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
 #pragma unroll
   for (u32 k = 0; k < NR; ++k) {
     if (k < role_cnt) { lane_rs_lo |= rs_lo[k]; lane_rs_hi |= rs_hi[k]; walks |= (W)all << (NA * k); }
+  }
+  if (PRE) {
+    // the role sets are known now ([role] ++ ancestors, as classes): a request none of whose roles reaches a generic site of its
+    // family has nothing to evaluate there - and as requests are grouped by route and role list, whole waves leave here
+    if (pre_family && !rglobs && (((u64)lane_rs_lo | ((u64)lane_rs_hi << 32)) & pre_fam_roles) == 0) pre_family = false;
+    pre_climbs = pre_family || pre_other;
+    if (wave_ballot(pre_climbs || pre_pp) == 0) return;
   }
   // classes / glob bits present in the wave: a record none of them can match is skipped on the scalar unit
   const u64 wave_a = wave_or64((u64)lane_ac_lo | ((u64)lane_ac_hi << 32), wave, c.tid);

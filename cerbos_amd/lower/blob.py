@@ -926,8 +926,28 @@ def _lower_rule_table(rt: dict, globals_, trace, first_columns) -> LoweredTable:
     family_sites = {}
     for (_v, _k, _s), bits in bucket_sites.items():
         family_sites[(_v, _k)] = family_sites.get((_v, _k), 0) | bits
+    # ... and WHOSE requests can reach a generic site of the family: the union of the role classes of the records / definitions
+    # that carry one (v1, v2; v3 bit 0: usable - no role glob among them).  The pre-pass lets a request whose role sets miss it
+    # go (cbh_check_walk2.h): requests are grouped by route and role list, so whole waves leave before the walk.
+    family_roles = {}
+    ALL = 0xFFFFFFFFFFFFFFFF
+    for (_r, _fam, _prog, k, (what, i, _shift)) in sites:
+        if k != "generic":
+            continue
+        what = {"rowp": "row", "drp": "dr"}.get(what, what)
+        if what == "row" and i in row_key:
+            lit, glob = row_rmask[i]
+            m = ALL if glob or row_roles[i] is None else lit
+            key = row_key[i]
+        elif what == "dr" and i in dr_key:
+            m = drx_cols[0][i] | (drx_cols[1][i] << 32)
+            key = dr_key[i]
+        else:
+            continue
+        family_roles[key[:2]] = family_roles.get(key[:2], 0) | m
     for (fv, fk) in sorted({(e[1], e[2]) for e in entries if e[0] == B_RESOURCE}):
-        entries.append((B_FAMILY, fv, fk, 0, family_sites.get((fv, fk), 0), 0, 0, 0))
+        fm = family_roles.get((fv, fk), 0)
+        entries.append((B_FAMILY, fv, fk, 0, family_sites.get((fv, fk), 0), fm & 0xFFFFFFFF, fm >> 32, 0 if fm == ALL else 1))
     # per table string: is it a principal with a principal policy, a role with ancestors in some scope (what the walk would
     # otherwise probe the directory for, lane by lane)
     str_wflags = np.zeros(K, dtype=np.uint8)
