@@ -213,11 +213,10 @@ __device__ u32 eval_leaf_tree(const KernelArgs* ka, const VmLds lds, u32 req, u3
 // A real call on purpose: the table walk around it then carries none of the evaluator's code or
 // registers, and the three places that evaluate conditions (derived roles, role policies, rule rows)
 // share one copy.  Returns result | status bits << 8.
-template <bool GENERIC>
 #ifndef CBH_HOSTSIM
 __attribute__((noinline))
 #endif
-__device__ u32 eval_ref(const KernelArgs* ka, const VmLds lds, u32 req, u64 edr, bool edr_err, u32 ref, bool active) {
+__device__ u32 eval_classified(const KernelArgs* ka, const VmLds lds, u32 req, u32 ref, bool active) {
   ref = uniform(ref);
   if (ref & CBH_COND_LEAF) {
     const Ctx c = ctx_from_memory(uniform_ptr(ka), lds);
@@ -231,7 +230,15 @@ __device__ u32 eval_ref(const KernelArgs* ka, const VmLds lds, u32 req, u64 edr,
     }
     return r | (L.status << 8);
   }
-  if (ref & CBH_COND_LEAFTREE) return eval_leaf_tree(ka, lds, req, ref & CBH_COND_PC_MASK, active);
+  return eval_leaf_tree(ka, lds, req, ref & CBH_COND_PC_MASK, active);
+}
+// The two real calls are made from the caller's own frame (a function between the caller and run_uniform would add the
+// registers it keeps across that call to run_uniform's, and the sum - not the larger - is what the kernel is sized by:
+// 257 registers, one wave to a SIMD, where 253 fit two).
+template <bool GENERIC>
+__device__ __forceinline__ u32 eval_ref(const KernelArgs* ka, const VmLds lds, u32 req, u64 edr, bool edr_err, u32 ref, bool active) {
+  ref = uniform(ref);
+  if (ref & (CBH_COND_LEAF | CBH_COND_LEAFTREE)) return eval_classified(ka, lds, req, ref, active);
   if (GENERIC) return run_uniform(ka, lds, req, edr, edr_err, ref, active);
   return active ? ((u32)CBH_ST_UNSUPPORTED << 8) : 0u;   // unreachable: the host picks the GENERIC kernel for such tables
 }
