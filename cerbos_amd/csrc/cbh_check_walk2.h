@@ -46,7 +46,7 @@ __host__ __device__
 static inline W2Layout w2_layout(u32 ncc, bool arena, u32 table_max_depth, u32 table_scopes, bool pre, u32 n_gwords, u32 table_strings, u32 table_n_dr, u32 na = CBH_W2_NA) {
   W2Layout l;
   const u32 depth = table_max_depth < CBH_FLAT_MAX_DEPTH ? table_max_depth : CBH_FLAT_MAX_DEPTH;
-  l.cc_dw = 3u * ncc * CBH_BLOCK;
+  l.cc_dw = CBH_CC_DWORDS(ncc);
   l.arena_dw = (pre && arena) ? CBH_ARENA_ENTRIES * CBH_BLOCK * 9u / 4u : 0u;
   l.chain_dw = pre ? 0u : (table_scopes <= 256u ? depth * (CBH_BLOCK / 4u) : depth * CBH_BLOCK);
   l.aux_dw = pre ? 0u : na * CBH_BLOCK;
@@ -144,7 +144,9 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     pre_pp = has_walks && has_pp && (t.q_sites & filed & (CBH_BS_DR_GENERIC | CBH_BS_DR_OPEN)) != 0;   // principal policies with sites
     if (wave_ballot(pre_climbs || pre_pp) == 0) return;   // nothing to evaluate for this wave
   }
+  W2_DBG(const u64 cycA0 = __builtin_readcyclecounter();)
   fill_column_cache(c, b, NRQ, req);
+  W2_DBG(const u64 cycA = __builtin_readcyclecounter();)
   const u32 all = (1u << act_cnt) - 1u;
   const u32 max_depth = t.max_depth < CBH_FLAT_MAX_DEPTH ? t.max_depth : CBH_FLAT_MAX_DEPTH;
   const bool chain8 = t.n_scopes <= 256u;
@@ -230,6 +232,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
       rgp[k >> 1] |= g << (16u * (k & 1u));
     }
   }
+  W2_DBG(const u64 cycB = __builtin_readcyclecounter();)
   // role slots as class sets: [role] ++ ancestors for the request's own resource scope (check.go:172, 227)
   u32 rs_lo[NR], rs_hi[NR];
 #pragma unroll
@@ -249,6 +252,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
       }
     }
   }
+  W2_DBG(const u64 cycC = __builtin_readcyclecounter();)
   u32 lane_rs_lo = 0, lane_rs_hi = 0, lane_ac_lo = 0, lane_ac_hi = 0;
   W walks = 0;   // bit NA r + k: role r exists and action k exists
 #pragma unroll
@@ -343,6 +347,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   // their principal somewhere on the chain are walked group by group; what it decides is kept per action.
   u32 p_allow = 0, p_deny = 0, p_err = 0, p_unsup = 0, p_wtr = 0, p_pol = 0;
   u32 p_first = CBH_NONE;
+  W2_DBG(u64 cycP = cyc1;)
   if (has_pp && (!PRE || (t.q_sites & (CBH_BS_DR_GENERIC | CBH_BS_DR_OPEN)) != 0)) {   // (pre-pass: only when principal policies hold sites at all)
     p_first = chain_first(t, p_scope, FLAG_PRIN, lenient);
     const bool cand = valid && pid_has_pp && p_first != CBH_NONE && role_cnt > 0 && act_cnt > 0;
@@ -356,6 +361,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
       }
       p_pol = pe ? (((u32)CBH_P_PRINCIPAL << 28) | p_first) : ((u32)CBH_P_NO_MATCH << 28);
     }
+    W2_DBG(cycP = __builtin_readcyclecounter();)
     for (;;) {
       const u64 rem = wave_ballot(pend);
       if (rem == 0) break;
@@ -785,8 +791,13 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
 #ifdef CBH_PROFILE_CYCLES
   if (flags & CBH_F_DEBUG_CYCLES) {
     const u64 cyc4 = __builtin_readcyclecounter();
+#if CBH_PROFILE_CYCLES == 2   /* the prologue and the principal pass in parts */
+    pol[0] = (u32)(cycA0 - cyc0); pol[1] = (u32)(cycA - cycA0); pol[2] = (u32)(cycB - cycA); pol[3] = (u32)(cycC - cycB);
+    scp[0] = (u32)rt0; scp[1] = (u32)__builtin_amdgcn_s_memrealtime(); scp[2] = (u32)(cyc1 - cycC) | ((u32)((cycP - cyc1) >> 4) << 20); scp[3] = (u32)(cyc2 - cycP);
+#else
     pol[0] = (u32)(cyc1 - cyc0); pol[1] = (u32)(cyc2 - cyc1); pol[2] = (u32)(cyc3 - cyc2); pol[3] = (u32)(cyc4 - cyc3);
     scp[0] = (u32)rt0; scp[1] = (u32)__builtin_amdgcn_s_memrealtime(); scp[2] = dbg_rows; scp[3] = dbg_rounds;
+#endif
   }
 #endif
   const bool packed = valid && act_cnt == 4 && (act_off & 3u) == 0;
@@ -907,7 +918,7 @@ static inline CbhPlan cbh_plan(u32 table_flags, u32 n_derived_roles, bool has_gl
 // dynamic LDS of a one-wave workgroup of the general walk: the column cache and, for a table whose programs build lists, the arena
 static inline size_t cbh_general_lds(u32 table_flags, u32 n_columns) {
   const u32 ncc = n_columns < CBH_CACHE_COLS ? n_columns : CBH_CACHE_COLS;
-  return (size_t)ncc * CBH_BLOCK * 12 + ((table_flags & CBH_MF_NEEDS_ARENA) ? (size_t)CBH_ARENA_ENTRIES * CBH_BLOCK * 9 : 0);
+  return (size_t)CBH_CC_DWORDS(ncc) * 4 + ((table_flags & CBH_MF_NEEDS_ARENA) ? (size_t)CBH_ARENA_ENTRIES * CBH_BLOCK * 9 : 0);
 }
 // dynamic LDS of a launch of `kernel` (pre = the pre-pass of kind 2)
 static inline size_t cbh_plan_lds(const CbhPlan& p, u32 table_flags, u32 table_max_depth, u32 table_scopes, u32 table_strings, u32 n_columns, u32 inline_cols, u32 table_n_dr, bool pre, u32 na = CBH_W2_NA) {

@@ -387,21 +387,20 @@ __device__ __forceinline__ void load_args(KernelArgs& dst, const KernelArgs* src
 // column are in flight together; the destination of such a copy is wave-uniform base + lane * 4,
 // which is exactly a [column][lane] dword plane)
 __device__ __forceinline__ void fill_column_cache(const Ctx& c, const BatchDev& b, u32 NR, u32 req) {
+  // (the values straight into LDS; the tags through a register: a byte each - a dword each would be a quarter of the cache, and it is
+  // the cache that bounds how many workgroups of the flat and walk kernels a CU holds)
+  CBH_L u8* tags = (CBH_L u8*)(c.cc + 2u * c.n_cached * CBH_BLOCK);
   for (u32 k = 0; k < c.n_cached; ++k) {
     const size_t ix = (size_t)k * NR + req;
     const CBH_G u32* vsrc = (const CBH_G u32*)(b.col_val + ix);
-    const CBH_G u8* tsrc = b.col_tag + (ix & ~(size_t)3);   // the aligned dword holding this lane's tag byte
 #ifndef CBH_HOSTSIM
     __builtin_amdgcn_global_load_lds((const CBH_G void*)vsrc, (CBH_L void*)(c.cc + k * CBH_BLOCK), 4, 0, 0);
     __builtin_amdgcn_global_load_lds((const CBH_G void*)(vsrc + 1), (CBH_L void*)(c.cc + (c.n_cached + k) * CBH_BLOCK), 4, 0, 0);
-    __builtin_amdgcn_global_load_lds((const CBH_G void*)tsrc, (CBH_L void*)(c.cc + (2 * c.n_cached + k) * CBH_BLOCK), 4, 0, 0);
 #else
-    (void)tsrc;   // the host arrays carry no slack after their last byte: place the one byte instead
-    const u32 tw = (u32)b.col_tag[ix] << ((ix & 3u) * 8u);
     c.cc[k * CBH_BLOCK + c.tid] = vsrc[0];
     c.cc[(c.n_cached + k) * CBH_BLOCK + c.tid] = vsrc[1];
-    c.cc[(2 * c.n_cached + k) * CBH_BLOCK + c.tid] = tw;
 #endif
+    tags[((k >> 2) * CBH_BLOCK + c.tid) * 4u + (k & 3u)] = b.col_tag[ix];
   }
 }
 
@@ -1099,7 +1098,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
 #undef PS_SCP
 }
 
-// Dynamic LDS of the kernels = the column cache: n_cached * CBH_BLOCK * 12 bytes.
+// Dynamic LDS of the kernels = the column cache: CBH_CC_DWORDS(n_cached) dwords.
 #ifndef CBH_HOSTSIM
 extern __shared__ __attribute__((aligned(16))) unsigned char cbh_dyn_lds[];
 #else

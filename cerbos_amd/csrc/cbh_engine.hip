@@ -641,10 +641,10 @@ static void launch_plan(const CbhPlan& pl, const TableDev& dev, KernelArgs ka, c
 // CBH_LDS_PAD=<bytes> (measurement aid): extra dynamic LDS per workgroup of the resident launches, to hold the occupancy down
 static size_t lds_pad() { static const size_t pad = [] { const char* e = getenv("CBH_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }(); return pad; }
 static u32 nfa_maxw(const TableDev& d) { return std::max(std::max(d.nfa_words[0], d.nfa_words[1]), d.nfa_words[2]); }
-static size_t check_lds_bytes(const BatchDev& d, u32 table_flags) {   // column cache: value low / high / tag dword per lane
+static size_t check_lds_bytes(const BatchDev& d, u32 table_flags) {   // the column cache
   const u32 ncc = d.n_columns < CBH_CACHE_COLS ? d.n_columns : CBH_CACHE_COLS;
   // ... and, for a table whose programs build lists, the lanes' arenas behind it (cbh_vm.h arena_vals)
-  return (size_t)ncc * CBH_BLOCK * 12 + ((table_flags & CBH_MF_NEEDS_ARENA) ? (size_t)CBH_ARENA_ENTRIES * CBH_BLOCK * 9 : 0);
+  return (size_t)CBH_CC_DWORDS(ncc) * 4 + ((table_flags & CBH_MF_NEEDS_ARENA) ? (size_t)CBH_ARENA_ENTRIES * CBH_BLOCK * 9 : 0);
 }
 
 extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_params* p) {

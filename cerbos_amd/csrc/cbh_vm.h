@@ -167,6 +167,9 @@ __device__ __forceinline__ Ctx ctx_from_memory(const KernelArgs* ka, const VmLds
              m.it_state, m.cc, m.n_cached, ka};
 }
 #define CBH_CACHE_COLS 16
+// dwords of one wave's column cache (cbh_check_wave.h fill_column_cache): [value low word][value high word], each [column][lane],
+// then the tags - a byte each, the tags of four columns in a lane's dword: [column / 4][lane][column % 4]
+#define CBH_CC_DWORDS(n) ((2u * (n) + ((n) + 3u) / 4u) * CBH_BLOCK)
 
 __device__ __forceinline__ Val mk(u32 t, u64 v) { Val x; x.t = t; x.v = v; return x; }
 __device__ __forceinline__ Val mk_err() { return mk(CBH_T_ERR, 0); }
@@ -341,7 +344,7 @@ __device__ __forceinline__ u32 cont_len(u64 v) { return (u32)v; }
 
 // The arena of a lane: CBH_ARENA_ENTRIES values [slot][lane] in dynamic LDS behind the column cache (the launch sizes it when the
 // table has CBH_MF_NEEDS_ARENA).  Lists a program builds live there for the program's duration (cbh_interp.h bumps a pointer).
-__device__ __forceinline__ CBH_L u64* arena_vals(const Ctx& c) { return (CBH_L u64*)(c.cc + 3u * c.n_cached * CBH_BLOCK); }
+__device__ __forceinline__ CBH_L u64* arena_vals(const Ctx& c) { return (CBH_L u64*)(c.cc + CBH_CC_DWORDS(c.n_cached)); }
 __device__ __forceinline__ CBH_L u8* arena_tags(const Ctx& c) { return (CBH_L u8*)(arena_vals(c) + CBH_ARENA_ENTRIES * CBH_BLOCK); }
 __device__ __forceinline__ void arena_put(const Ctx& c, u32 idx, Val v) {
   arena_vals(c)[idx * CBH_BLOCK + c.tid] = v.v; arena_tags(c)[idx * CBH_BLOCK + c.tid] = (u8)v.t;
@@ -1000,8 +1003,7 @@ __device__ __forceinline__ int fast_compare(const Ctx& c, u32 op, Val x, Val y) 
 
 // a column of the kernel's LDS column cache (arg < n_cached)
 __device__ __forceinline__ Val cached_column(const Ctx& c, const Lane& L, u32 arg) {
-  const u32 tw = c.cc[(2 * c.n_cached + arg) * CBH_BLOCK + c.tid];
-  const u32 t = (tw >> ((((size_t)arg * c.b.n_requests + L.req) & 3u) * 8u)) & 0xFFu;
+  const u32 t = ((CBH_L u8*)(c.cc + 2u * c.n_cached * CBH_BLOCK))[((arg >> 2) * CBH_BLOCK + c.tid) * 4u + (arg & 3u)];
   if (t == CBH_T_ABSENT) return mk_err();
   return mk(t, (u64)c.cc[arg * CBH_BLOCK + c.tid] | ((u64)c.cc[(c.n_cached + arg) * CBH_BLOCK + c.tid] << 32));
 }

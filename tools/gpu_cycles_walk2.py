@@ -30,6 +30,11 @@ assert (batch.req_u32[9] == 4).all()
 pol = res.policy.reshape(-1, 4)[::64].astype(np.int64)
 scp = res.scope.reshape(-1, 4)[::64].astype(np.int64)
 print(W, "pre-pass" if pre else "walk", "waves", len(pol))
+if os.environ.get("CBH_PROFILE_PARTS") and not pre:   # library built with -DCBH_PROFILE_CYCLES=2: the prologue and the principal pass in parts
+    for name, a in (("request fields", pol[:, 0]), ("column cache", pol[:, 1]), ("ids classes globs", pol[:, 2]), ("parent roles", pol[:, 3]),
+                    ("sets, wave ORs", scp[:, 2] & 0xFFFFF), ("principal: who", (scp[:, 2] >> 20) << 4), ("principal: walk", scp[:, 3])):
+        print("%-18s min %8d  p10 %8d  p50 %8d  p90 %8d  max %8d  mean %10.1f" % (name, a.min(), np.percentile(a, 10), np.median(a), np.percentile(a, 90), a.max(), a.mean()))
+    sys.exit(0)
 names = ("prologue", "principal", "walk", "eval_sum" if pre else "fold+edr")
 for name, a in list(zip(names, (pol[:, 0], pol[:, 1], pol[:, 2], pol[:, 3]))) + [("records", scp[:, 2] & 0xFFFF), ("evals", scp[:, 2] >> 16), ("rounds", scp[:, 3])]:
     print("%-14s min %8d  p10 %8d  p50 %8d  p90 %8d  max %8d  mean %10.1f" % (name, a.min(), np.percentile(a, 10), np.median(a), np.percentile(a, 90), a.max(), a.mean()))
