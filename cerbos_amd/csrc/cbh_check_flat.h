@@ -108,8 +108,7 @@ struct __attribute__((aligned(64))) TblDrx { u32 rm_lo, rm_hi, flags, cond, name
 struct FlatCol { u32 t, lo, hi; };
 __device__ __forceinline__ FlatCol flat_col(const Ctx& c, u32 col, u32 req) {   // `col` wave-uniform
   FlatCol v;
-  (void)req;
-  v.t = ((CBH_L u8*)(c.cc + 2u * c.n_cached * CBH_BLOCK))[((col >> 2) * CBH_BLOCK + c.tid) * 4u + (col & 3u)];
+  v.t = cached_tag(c, col, req);
   v.lo = c.cc[col * CBH_BLOCK + c.tid];
   v.hi = c.cc[(c.n_cached + col) * CBH_BLOCK + c.tid];
   return v;
@@ -442,7 +441,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   // A table of at most 256 scopes keeps them as bytes: a quarter of the footprint.
   const bool chain8 = t.n_scopes <= 256u;
   const u32 chain_dwords = chain8 ? max_depth * (CBH_BLOCK / 4u) : max_depth * CBH_BLOCK;
-  CBH_L u32* chain_si = (CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * CBH_CC_DWORDS(c.n_cached) + wave * chain_dwords;
+  CBH_L u32* chain_si = (CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * CBH_CC_DWORDS(c.n_cached, (c.flags & CBH_FI_PACKED_TAGS) != 0) + wave * chain_dwords;
   CBH_L u8* chain_si8 = (CBH_L u8*)chain_si;
   // actions and roles -> classes (CBH_SEC_ACTION_CLASS / CBH_SEC_ROLE_CLASS; 63 = a string no rule names).
   // A flat table has fewer than 32 classes per dimension and its masks mirror "any other string" (bit 63)
@@ -454,7 +453,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   // flight - a table of up to CBH_FLAT_LDS_STRINGS strings - so that the lookups below are LDS reads, not a third
   // dependent trip to memory.
   const bool cls_in_lds = t.K <= CBH_FLAT_LDS_STRINGS;
-  CBH_L u8* cls_lds = (CBH_L u8*)((CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * (CBH_CC_DWORDS(c.n_cached) + chain_dwords));   // [action classes K][role classes K]
+  CBH_L u8* cls_lds = (CBH_L u8*)((CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * (CBH_CC_DWORDS(c.n_cached, (c.flags & CBH_FI_PACKED_TAGS) != 0) + chain_dwords));   // [action classes K][role classes K]
   if (cls_in_lds) {
     for (u32 i = threadIdx.x; i < t.K; i += CBH_FLAT_THREADS) { cls_lds[i] = t.action_class[i]; cls_lds[t.K + i] = t.role_class[i]; }
   }
@@ -956,7 +955,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 #define CBH_FLAT_CTX(a, ka)                                                                                                       \
   const u32 ncc = cached_columns(&a);                                                                                             \
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,  \
-        (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * CBH_CC_DWORDS(ncc), ncc, ka}
+        (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * CBH_CC_DWORDS(ncc, (a.flags & CBH_FI_PACKED_TAGS) != 0), ncc, ka}
 // batches of plain scalars (no int / uint / list / map attribute values): no call, ~64 VGPRs, 7-8 waves per SIMD
 __global__ CBH_FLAT_ATTRS(7) void cbh_check_flat_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
   CBH_FLAT_CTX(a, ka);

@@ -43,10 +43,10 @@ struct W2Layout { u32 cc_dw, arena_dw, chain_dw, aux_dw, gacc_dw, edr_dw, wave_d
 #ifndef CBH_HOSTSIM
 __host__ __device__
 #endif
-static inline W2Layout w2_layout(u32 ncc, bool arena, u32 table_max_depth, u32 table_scopes, bool pre, u32 n_gwords, u32 table_strings, u32 table_n_dr, u32 na = CBH_W2_NA) {
+static inline W2Layout w2_layout(u32 ncc, bool arena, u32 table_max_depth, u32 table_scopes, bool pre, u32 n_gwords, u32 table_strings, u32 table_n_dr, u32 na = CBH_W2_NA, bool packed_tags = false) {
   W2Layout l;
   const u32 depth = table_max_depth < CBH_FLAT_MAX_DEPTH ? table_max_depth : CBH_FLAT_MAX_DEPTH;
-  l.cc_dw = CBH_CC_DWORDS(ncc);
+  l.cc_dw = CBH_CC_DWORDS(ncc, packed_tags);
   l.arena_dw = (pre && arena) ? CBH_ARENA_ENTRIES * CBH_BLOCK * 9u / 4u : 0u;
   l.chain_dw = pre ? 0u : (table_scopes <= 256u ? depth * (CBH_BLOCK / 4u) : depth * CBH_BLOCK);
   l.aux_dw = pre ? 0u : na * CBH_BLOCK;
@@ -835,7 +835,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
 template <u32 NA, u32 NR>
 __device__ __forceinline__ void w2_walk_kernel_body(const KernelArgs& a, const KernelArgs* __restrict__ ka) {
   const u32 ncc = a.t.inline_cols;   // no generic program runs here: only the columns the inline leaf code reads are parked in LDS
-  const W2Layout ly = w2_layout(ncc, false, a.t.max_depth, a.t.n_scopes, false, 0, a.t.K, a.t.n_dr, NA);
+  const W2Layout ly = w2_layout(ncc, false, a.t.max_depth, a.t.n_scopes, false, 0, a.t.K, a.t.n_dr, NA, (a.flags & CBH_FI_PACKED_TAGS) != 0);
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
         (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * ly.wave_dw, ncc, ka};
   w2_body<false, NA, NR>(a, c, ly);
@@ -867,7 +867,7 @@ __device__ __forceinline__ void w2_pre_kernel_body(const KernelArgs& a, const Ke
     for (u32 k = 0; k < CBH_MAX_ITERS; ++k) { it_cont[k * CBH_BLOCK + tid] = 0; it_idx[k * CBH_BLOCK + tid] = 0; it_state[k * CBH_BLOCK + tid] = 0; }
   }
   const u32 ncc = cached_columns(&a);
-  const W2Layout ly = w2_layout(ncc, (a.t.flags & CBH_MF_NEEDS_ARENA) != 0, a.t.max_depth, a.t.n_scopes, true, a.b.n_gwords, a.t.K, a.t.n_dr);
+  const W2Layout ly = w2_layout(ncc, (a.t.flags & CBH_MF_NEEDS_ARENA) != 0, a.t.max_depth, a.t.n_scopes, true, a.b.n_gwords, a.t.K, a.t.n_dr, CBH_W2_NA, (a.flags & CBH_FI_PACKED_TAGS) != 0);
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x,
         (CBH_L u64*)s_val, (CBH_L u8*)s_tag, (CBH_L u64*)l_val, (CBH_L u8*)l_tag,
         (CBH_L u64*)it_cont, (CBH_L u32*)it_idx, (CBH_L u32*)it_state,
@@ -916,15 +916,15 @@ static inline CbhPlan cbh_plan(u32 table_flags, u32 n_derived_roles, bool has_gl
   return p;
 }
 // dynamic LDS of a one-wave workgroup of the general walk: the column cache and, for a table whose programs build lists, the arena
-static inline size_t cbh_general_lds(u32 table_flags, u32 n_columns) {
+static inline size_t cbh_general_lds(u32 table_flags, u32 n_columns, bool packed_tags = false) {
   const u32 ncc = n_columns < CBH_CACHE_COLS ? n_columns : CBH_CACHE_COLS;
-  return (size_t)CBH_CC_DWORDS(ncc) * 4 + ((table_flags & CBH_MF_NEEDS_ARENA) ? (size_t)CBH_ARENA_ENTRIES * CBH_BLOCK * 9 : 0);
+  return (size_t)CBH_CC_DWORDS(ncc, packed_tags) * 4 + ((table_flags & CBH_MF_NEEDS_ARENA) ? (size_t)CBH_ARENA_ENTRIES * CBH_BLOCK * 9 : 0);
 }
 // dynamic LDS of a launch of `kernel` (pre = the pre-pass of kind 2)
-static inline size_t cbh_plan_lds(const CbhPlan& p, u32 table_flags, u32 table_max_depth, u32 table_scopes, u32 table_strings, u32 n_columns, u32 inline_cols, u32 table_n_dr, bool pre, u32 na = CBH_W2_NA) {
+static inline size_t cbh_plan_lds(const CbhPlan& p, u32 table_flags, u32 table_max_depth, u32 table_scopes, u32 table_strings, u32 n_columns, u32 inline_cols, u32 table_n_dr, bool pre, u32 na = CBH_W2_NA, bool packed_tags = false) {
   const u32 ncc = n_columns < CBH_CACHE_COLS ? n_columns : CBH_CACHE_COLS;
-  if (p.kind == 2) return w2_lds_bytes(w2_layout(pre ? ncc : inline_cols, (table_flags & CBH_MF_NEEDS_ARENA) != 0, table_max_depth, table_scopes, pre, p.n_gwords, table_strings, table_n_dr, na), pre ? 1u : CBH_W2_WAVES);
-  const size_t wave = cbh_general_lds(table_flags, n_columns);
+  if (p.kind == 2) return w2_lds_bytes(w2_layout(pre ? ncc : inline_cols, (table_flags & CBH_MF_NEEDS_ARENA) != 0, table_max_depth, table_scopes, pre, p.n_gwords, table_strings, table_n_dr, na, packed_tags), pre ? 1u : CBH_W2_WAVES);
+  const size_t wave = cbh_general_lds(table_flags, n_columns, packed_tags);
   if (p.kind == 1) return (wave + cbh_flat_chain_bytes(table_max_depth, table_scopes)) * (p.threads / CBH_BLOCK) + cbh_flat_class_bytes(table_strings)
                           + (cbh_is_mask_kernel(p.kernel) ? cbh_flat_mask_bytes(p.threads) : 0);
   return wave;

@@ -387,8 +387,7 @@ __device__ __forceinline__ void load_args(KernelArgs& dst, const KernelArgs* src
 // column are in flight together; the destination of such a copy is wave-uniform base + lane * 4,
 // which is exactly a [column][lane] dword plane)
 __device__ __forceinline__ void fill_column_cache(const Ctx& c, const BatchDev& b, u32 NR, u32 req) {
-  // (the values straight into LDS; the tags through a register: a byte each - a dword each would be a quarter of the cache, and it is
-  // the cache that bounds how many workgroups of the flat and walk kernels a CU holds)
+  const bool packed = (c.flags & CBH_FI_PACKED_TAGS) != 0;   // the two forms of the tags: cbh_vm.h CBH_CC_DWORDS
   CBH_L u8* tags = (CBH_L u8*)(c.cc + 2u * c.n_cached * CBH_BLOCK);
   for (u32 k = 0; k < c.n_cached; ++k) {
     const size_t ix = (size_t)k * NR + req;
@@ -396,11 +395,14 @@ __device__ __forceinline__ void fill_column_cache(const Ctx& c, const BatchDev& 
 #ifndef CBH_HOSTSIM
     __builtin_amdgcn_global_load_lds((const CBH_G void*)vsrc, (CBH_L void*)(c.cc + k * CBH_BLOCK), 4, 0, 0);
     __builtin_amdgcn_global_load_lds((const CBH_G void*)(vsrc + 1), (CBH_L void*)(c.cc + (c.n_cached + k) * CBH_BLOCK), 4, 0, 0);
+    if (!packed) __builtin_amdgcn_global_load_lds((const CBH_G void*)(b.col_tag + (ix & ~(size_t)3)), (CBH_L void*)(c.cc + (2 * c.n_cached + k) * CBH_BLOCK), 4, 0, 0);
 #else
     c.cc[k * CBH_BLOCK + c.tid] = vsrc[0];
     c.cc[(c.n_cached + k) * CBH_BLOCK + c.tid] = vsrc[1];
+    // (the host arrays carry no slack after their last byte: place the one byte instead of copying its dword)
+    if (!packed) c.cc[(2 * c.n_cached + k) * CBH_BLOCK + c.tid] = (u32)b.col_tag[ix] << ((ix & 3u) * 8u);
 #endif
-    tags[((k >> 2) * CBH_BLOCK + c.tid) * 4u + (k & 3u)] = b.col_tag[ix];
+    if (packed) tags[((k >> 2) * CBH_BLOCK + c.tid) * 4u + (k & 3u)] = b.col_tag[ix];
   }
 }
 
@@ -1098,7 +1100,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
 #undef PS_SCP
 }
 
-// Dynamic LDS of the kernels = the column cache: CBH_CC_DWORDS(n_cached) dwords.
+// Dynamic LDS of the kernels = the column cache: CBH_CC_DWORDS(n_cached, packed) dwords.
 #ifndef CBH_HOSTSIM
 extern __shared__ __attribute__((aligned(16))) unsigned char cbh_dyn_lds[];
 #else

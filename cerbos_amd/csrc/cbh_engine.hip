@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <dlfcn.h>
+#include <map>
+#include <tuple>
 
 #include <algorithm>
 #include <atomic>
@@ -595,6 +597,27 @@ static CbhPlan plan_for(const TableDev& dev, u32 max_actions, u32 max_roles, boo
   return cbh_plan(dev.flags, dev.n_dr, has_globs, dev.gslots_generic, dev.gslots_all, max_actions, max_roles, plain_tags, eval_flags, no_flat, no_walk2,
                   force_staged ? 0xFFFFFFFFu : dev.max_bucket, no_walk2_wide, cbh_flat_use_masks(dev.segs, dev.max_bucket));
 }
+// Does the packed form of the column cache's tags (cbh_vm.h CBH_CC_DWORDS) let a CU hold more workgroups of `fn` than the wide one?
+// The runtime's occupancy figure for the kernel at either LDS size, kept per (kernel, size).  CBH_PACKED_TAGS=0/1 (tests,
+// measurement): never / always.
+static bool packed_tags_pay(cbh_check_kernel_fn fn, u32 threads, size_t lds_wide, size_t lds_packed) {
+  static const int forced = [] { const char* e = getenv("CBH_PACKED_TAGS"); return e ? atoi(e) : -1; }();
+  if (forced >= 0) return forced != 0;
+  if (lds_packed >= lds_wide) return false;
+  static std::mutex mu;
+  static std::map<std::tuple<const void*, u32, size_t>, int> memo;
+  auto blocks = [&](size_t lds) {
+    const auto key = std::make_tuple((const void*)fn, threads, lds);
+    std::lock_guard<std::mutex> g(mu);
+    auto it = memo.find(key);
+    if (it != memo.end()) return it->second;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)fn, (int)threads, lds) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    memo.emplace(key, n);
+    return n;
+  };
+  return blocks(lds_packed) > blocks(lds_wide);
+}
 // the launches that decide the requests [lo, hi) of `ka.b`; [wide_lo, wide_hi) = where the batch's requests wider than
 // cbh_walk2_kernel's shape lie (empty: none)
 static void launch_plan(const CbhPlan& pl, const TableDev& dev, KernelArgs ka, const KernelArgs* d_args, u32 lo, u32 hi, u32 wide_lo, u32 wide_hi,
@@ -605,9 +628,19 @@ static void launch_plan(const CbhPlan& pl, const TableDev& dev, KernelArgs ka, c
   const u32 n = hi - lo;
   // (timed launches: the start event rides on the first kernel of the plan, the stop event on the last - the figure is the
   // whole plan's, gaps between its kernels included)
-  auto go = [&](cbh_check_kernel_fn fn, u32 grid, u32 threads, size_t lds, const KernelArgs& a, bool last) {
+  // `lds_of(packed)`: the launch's dynamic LDS with the column cache's tags in either form (cbh_vm.h CBH_CC_DWORDS); the packed form
+  // where it lets a CU hold more workgroups of this kernel
+  auto go = [&](cbh_check_kernel_fn fn, u32 grid, u32 threads, auto lds_of, const KernelArgs& a0, bool last) {
+    const size_t wide = lds_of(false), packed = lds_of(true);
+    const bool use_packed = packed_tags_pay(fn, threads, wide, packed);
+    const size_t lds = use_packed ? packed : wide;
+    KernelArgs a = a0;
+    if (use_packed) a.flags |= CBH_FI_PACKED_TAGS;
     if (ev0 || (ev1 && last)) { hipExtLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, s, ev0, last ? ev1 : nullptr, 0, a, d_args); ev0 = nullptr; }
     else hipLaunchKernelGGL(fn, dim3(grid), dim3(threads), lds, s, a, d_args);
+  };
+  auto plan_lds = [&](bool pre, u32 na, size_t extra) {
+    return [=, &pl, &dev, &ka](bool packed) { return cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, dev.n_dr, pre, na, packed) + extra; };
   };
   if (pl.kind == 2) {
     const u32 wlo = std::max(lo, wide_lo), whi = std::min(hi, wide_hi);   // where the requests wider than the base shape lie
@@ -615,7 +648,7 @@ static void launch_plan(const CbhPlan& pl, const TableDev& dev, KernelArgs ka, c
       KernelArgs kw = ka;
       kw.b.req_lo = wlo; kw.b.req_hi = whi;
       kw.flags |= (pl.walk_wide || pl.walk_awide) ? CBH_FI_ONLY_WIDER : CBH_FI_ONLY_WIDE;
-      if (whi > wlo) go(pl.wide_kernel, (whi - wlo + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, cbh_general_lds(dev.flags, ka.b.n_columns), kw, false);
+      if (whi > wlo) go(pl.wide_kernel, (whi - wlo + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, [&](bool packed) { return cbh_general_lds(dev.flags, ka.b.n_columns, packed); }, kw, false);
     }
     if (pl.wide_kernel || pl.walk_wide || pl.walk_awide) ka.flags |= CBH_FI_SKIP_WIDE;
     ka.b.n_gwords = ka.b.gres ? pl.n_gwords : 0; ka.b.n_gslots = ka.b.gres ? pl.n_gslots : 0;
@@ -627,24 +660,24 @@ static void launch_plan(const CbhPlan& pl, const TableDev& dev, KernelArgs ka, c
       const u32 na = shape == 1 ? CBH_W2_NA : CBH_W2_AWIDE_NA;
       if (kv.b.n_gwords)
         go(shape == 1 ? cbh_walk2_pre_wide_kernel : cbh_walk2_pre_awide_kernel, (whi - wlo + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK,
-           cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, dev.n_dr, true, na), kv, false);
+           plan_lds(true, na, 0), kv, false);
       go(shape == 1 ? cbh_walk2_wide_kernel : cbh_walk2_awide_kernel, (whi - wlo + pl.threads - 1) / pl.threads, pl.threads,
-         cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, dev.n_dr, false, na), kv, false);
+         plan_lds(false, na, 0), kv, false);
     }
     if (ka.b.n_gwords)   // the evaluation sites first: their results are what the walk reads
-      go(cbh_walk2_pre_kernel, (n + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, dev.n_dr, true), ka, false);
+      go(cbh_walk2_pre_kernel, (n + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, plan_lds(true, CBH_W2_NA, 0), ka, false);
   }
   static const bool pre_only = getenv("CBH_PRE_ONLY") != nullptr;   // measurement aid (profiling build): the pre-pass alone
   if (pre_only && pl.kind == 2) return;
-  go(pl.kernel, (n + pl.threads - 1) / pl.threads, pl.threads, cbh_plan_lds(pl, dev.flags, dev.max_depth, dev.n_scopes, dev.K, ka.b.n_columns, dev.inline_cols, dev.n_dr, false) + pad, ka, true);
+  go(pl.kernel, (n + pl.threads - 1) / pl.threads, pl.threads, plan_lds(false, CBH_W2_NA, pad), ka, true);
 }
 // CBH_LDS_PAD=<bytes> (measurement aid): extra dynamic LDS per workgroup of the resident launches, to hold the occupancy down
 static size_t lds_pad() { static const size_t pad = [] { const char* e = getenv("CBH_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }(); return pad; }
 static u32 nfa_maxw(const TableDev& d) { return std::max(std::max(d.nfa_words[0], d.nfa_words[1]), d.nfa_words[2]); }
-static size_t check_lds_bytes(const BatchDev& d, u32 table_flags) {   // the column cache
+static size_t check_lds_bytes(const BatchDev& d, u32 table_flags) {   // the column cache (tags in the wide form)
   const u32 ncc = d.n_columns < CBH_CACHE_COLS ? d.n_columns : CBH_CACHE_COLS;
   // ... and, for a table whose programs build lists, the lanes' arenas behind it (cbh_vm.h arena_vals)
-  return (size_t)CBH_CC_DWORDS(ncc) * 4 + ((table_flags & CBH_MF_NEEDS_ARENA) ? (size_t)CBH_ARENA_ENTRIES * CBH_BLOCK * 9 : 0);
+  return (size_t)CBH_CC_DWORDS(ncc, false) * 4 + ((table_flags & CBH_MF_NEEDS_ARENA) ? (size_t)CBH_ARENA_ENTRIES * CBH_BLOCK * 9 : 0);
 }
 
 extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_params* p) {

@@ -111,7 +111,8 @@ struct __attribute__((aligned(16))) KernelArgs { TableDev t; BatchDev b; OutDev 
                                     /* the wider walks / their pre-passes: only the requests of their class are (cbh_w2_class)   */
 #define CBH_FI_ONLY_WIDE 0x20000u   /* cbh_check_kernel*: only the requests wider than the base shape are this launch's */
 #define CBH_FI_ONLY_WIDER 0x40000u  /* cbh_check_kernel*: only the requests no shape of the walk holds are this launch's */
-#define CBH_FI_MASK 0x70000u
+#define CBH_FI_PACKED_TAGS 0x80000u /* the column cache keeps a tag as a byte (CBH_CC_DWORDS): chosen per launch, where the smaller cache lets a CU hold more workgroups */
+#define CBH_FI_MASK 0xF0000u
 #define CBH_W2_NA 8u
 #define CBH_W2_NR 4u
 #define CBH_W2_WIDE_NR 8u           /* the wider shapes: 8 actions x 8 roles (cbh_walk2_wide_kernel) ... */
@@ -157,19 +158,23 @@ struct Ctx {
 struct VmLds {
   CBH_L u64* s_val; CBH_L u8* s_tag; CBH_L u64* l_val; CBH_L u8* l_tag;
   CBH_L u64* it_cont; CBH_L u32* it_idx; CBH_L u32* it_state;
-  CBH_L u32* cc; u32 n_cached; u32 tid;
+  CBH_L u32* cc; u32 n_cached; u32 tid;   // n_cached: bit 31 = the launch's CBH_FI_PACKED_TAGS (the arguments in memory are the batch's, not the launch's)
 };
 __device__ __forceinline__ VmLds lds_of(const Ctx& c) {
-  return VmLds{c.s_val, c.s_tag, c.l_val, c.l_tag, c.it_cont, c.it_idx, c.it_state, c.cc, c.n_cached, c.tid};
+  return VmLds{c.s_val, c.s_tag, c.l_val, c.l_tag, c.it_cont, c.it_idx, c.it_state, c.cc, c.n_cached | ((c.flags & CBH_FI_PACKED_TAGS) ? 0x80000000u : 0u), c.tid};
 }
 __device__ __forceinline__ Ctx ctx_from_memory(const KernelArgs* ka, const VmLds& m) {
-  return Ctx{ka->t, ka->b, ka->now_ns, ka->flags, m.tid, m.s_val, m.s_tag, m.l_val, m.l_tag, m.it_cont, m.it_idx,
-             m.it_state, m.cc, m.n_cached, ka};
+  return Ctx{ka->t, ka->b, ka->now_ns, (ka->flags & ~(u32)CBH_FI_PACKED_TAGS) | ((m.n_cached >> 31) ? CBH_FI_PACKED_TAGS : 0u), m.tid, m.s_val, m.s_tag, m.l_val, m.l_tag, m.it_cont, m.it_idx,
+             m.it_state, m.cc, m.n_cached & 0x7FFFFFFFu, ka};
 }
 #define CBH_CACHE_COLS 16
 // dwords of one wave's column cache (cbh_check_wave.h fill_column_cache): [value low word][value high word], each [column][lane],
-// then the tags - a byte each, the tags of four columns in a lane's dword: [column / 4][lane][column % 4]
-#define CBH_CC_DWORDS(n) ((2u * (n) + ((n) + 3u) / 4u) * CBH_BLOCK)
+// then the tags.  Two forms of those, chosen per launch (CBH_FI_PACKED_TAGS):
+//   wide    [column][lane] the aligned dword of the batch's tag bytes that holds the lane's - every load of the fill goes straight
+//           to LDS, nothing through a register: the form of a launch whose workgroups the cache does not limit (C2's 16 us kernel)
+//   packed  [column / 4][lane][column % 4] a byte each: a quarter less LDS - one more workgroup to a CU for the nine to twelve
+//           columns of C3, C4, T, C5 - for a load and a store through a register per column
+#define CBH_CC_DWORDS(n, packed) ((2u * (n) + ((packed) ? ((n) + 3u) / 4u : (n))) * CBH_BLOCK)
 
 __device__ __forceinline__ Val mk(u32 t, u64 v) { Val x; x.t = t; x.v = v; return x; }
 __device__ __forceinline__ Val mk_err() { return mk(CBH_T_ERR, 0); }
@@ -344,7 +349,7 @@ __device__ __forceinline__ u32 cont_len(u64 v) { return (u32)v; }
 
 // The arena of a lane: CBH_ARENA_ENTRIES values [slot][lane] in dynamic LDS behind the column cache (the launch sizes it when the
 // table has CBH_MF_NEEDS_ARENA).  Lists a program builds live there for the program's duration (cbh_interp.h bumps a pointer).
-__device__ __forceinline__ CBH_L u64* arena_vals(const Ctx& c) { return (CBH_L u64*)(c.cc + CBH_CC_DWORDS(c.n_cached)); }
+__device__ __forceinline__ CBH_L u64* arena_vals(const Ctx& c) { return (CBH_L u64*)(c.cc + CBH_CC_DWORDS(c.n_cached, (c.flags & CBH_FI_PACKED_TAGS) != 0)); }
 __device__ __forceinline__ CBH_L u8* arena_tags(const Ctx& c) { return (CBH_L u8*)(arena_vals(c) + CBH_ARENA_ENTRIES * CBH_BLOCK); }
 __device__ __forceinline__ void arena_put(const Ctx& c, u32 idx, Val v) {
   arena_vals(c)[idx * CBH_BLOCK + c.tid] = v.v; arena_tags(c)[idx * CBH_BLOCK + c.tid] = (u8)v.t;
@@ -1001,9 +1006,16 @@ __device__ __forceinline__ int fast_compare(const Ctx& c, u32 op, Val x, Val y) 
   return -2;
 }
 
+// the tag of a cached column (`col` wave-uniform): the lane's byte of its dword in either form of the cache (CBH_CC_DWORDS)
+__device__ __forceinline__ u32 cached_tag(const Ctx& c, u32 col, u32 req) {
+  const bool packed = (c.flags & CBH_FI_PACKED_TAGS) != 0;
+  const u32 tw = c.cc[(2u * c.n_cached + (packed ? col >> 2 : col)) * CBH_BLOCK + c.tid];
+  const u32 byte = packed ? (col & 3u) : (u32)(((size_t)col * c.b.n_requests + req) & 3u);
+  return (tw >> (byte * 8u)) & 0xFFu;
+}
 // a column of the kernel's LDS column cache (arg < n_cached)
 __device__ __forceinline__ Val cached_column(const Ctx& c, const Lane& L, u32 arg) {
-  const u32 t = ((CBH_L u8*)(c.cc + 2u * c.n_cached * CBH_BLOCK))[((arg >> 2) * CBH_BLOCK + c.tid) * 4u + (arg & 3u)];
+  const u32 t = cached_tag(c, arg, L.req);
   if (t == CBH_T_ABSENT) return mk_err();
   return mk(t, (u64)c.cc[arg * CBH_BLOCK + c.tid] | ((u64)c.cc[(c.n_cached + arg) * CBH_BLOCK + c.tid] << 32));
 }

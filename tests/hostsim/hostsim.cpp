@@ -229,8 +229,11 @@ static int run_sim(const void* blob, size_t len, const cbh_batch* in, const cbh_
   // one-shot path pipelines with (cbh_engine.hip) is exercised by every test of the CPU tier
   const uint32_t n = in->n_requests, mid = n > 3 ? (n / 2) - (n / 2) % 3 + 1 : n;
   const uint32_t cuts[3] = {0, mid, n};
-  const uint32_t user_flags = a.flags & ~(uint32_t)CBH_FI_MASK;
+  const uint32_t user_flags0 = a.flags & ~(uint32_t)CBH_FI_MASK;
+  const char* force_packed = getenv("CBH_PACKED_TAGS");   // (as cbh_engine.hip packed_tags_pay; unset: the first launch wide, the second packed)
   for (int c = 0; c < 2; ++c) {
+    // the two forms of the column cache's tags (cbh_vm.h CBH_CC_DWORDS): every test of the CPU tier runs both
+    const uint32_t user_flags = user_flags0 | ((force_packed ? atoi(force_packed) != 0 : c == 1) ? CBH_FI_PACKED_TAGS : 0u);
     b.req_lo = cuts[c]; b.req_hi = cuts[c + 1];
     const uint32_t nblocks = (b.req_hi - b.req_lo + CBH_BLOCK - 1) / CBH_BLOCK;   // one lane per request
     a.flags = user_flags;
@@ -252,7 +255,7 @@ static int run_sim(const void* blob, size_t len, const cbh_batch* in, const cbh_
     g_kernel = pl.kernel;
     for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
   }
-  a.flags = user_flags;
+  a.flags = user_flags0;
   return 0;
 }
 extern "C" int hostsim_check(const void* blob, size_t len, const cbh_batch* in, const cbh_params* p,

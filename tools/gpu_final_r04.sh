@@ -24,17 +24,19 @@ for w in $WL; do
   ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_$w -o r -- $BENCH > $OUT/prof_$w.log 2>&1 )
   DB=$(find $OUT/prof_$w -name '*.db' | head -1)
   [ -n "$DB" ] && python tools/rocpd_summary.py "$DB" $OUT/kernel_stats_$w.txt | sed -n 3,5p
-  for c in FETCH_SIZE WRITE_SIZE; do
+  [ -z "${SKIP_PMC:-}" ] && for c in FETCH_SIZE WRITE_SIZE; do
     ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$w/$c -o $c -- $BENCH > $OUT/pmc_${w}_$c.log 2>&1 )
   done
   rm -rf $OUT/prof_$w
 done
+if [ -z "${SKIP_PMC:-}" ]; then   # SKIP_PMC=1: the bench lines carry the traffic of the committed profiles/r04_pmc_traffic.json (an earlier call)
 hipcc --offload-arch=gfx950 -O3 tools/pmc_calib.hip -o /tmp/pmc_calib > $OUT/calib_build.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_calib/$c -o $c -- /tmp/pmc_calib > $OUT/pmc_calib_$c.log 2>&1 )
 done
 python tools/pmc_summary.py $OUT > /dev/null
 cp $OUT/pmc_traffic.json profiles/r04_pmc_traffic.json
+fi
 (timeout 900 python bench.py --steps 20 --warmup 3 2>$OUT/bench_C2.err | grep '^{' | tail -1) > $OUT/bench_C2.json
 cut -c1-330 $OUT/bench_C2.json; echo
 for w in $WL; do
