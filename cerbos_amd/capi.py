@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = [
     "cbh_synchronize", "cbh_result_download", "cbh_kernel_time_ms", "cbh_plan_describe",
     "cbh_check_resident_many", "cbh_table_set_resident_streams", "cbh_table_resident_streams",
     "cbh_wire_flatten", "cbh_wire_spans_download", "cbh_wire_outputs", "cbh_wire_check_pb",
+    "cbh_wire_flatten_requests", "cbh_wire_check_requests_pb",
 ]
 
 
@@ -165,6 +166,11 @@ def load():
     lib.cbh_wire_check_pb.argtypes = [vp, u32, vp, vp, u32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(CParams), vp, C.c_size_t, vp, vp,
                                       C.POINTER(C.c_size_t), C.POINTER(CWireInfo)]
     lib.cbh_wire_check_pb.restype = i32
+    lib.cbh_wire_flatten_requests.argtypes = [vp, u32, vp, vp, u32, vp, vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, vp, vp, C.POINTER(vp), C.POINTER(CWireInfo)]
+    lib.cbh_wire_flatten_requests.restype = i32
+    lib.cbh_wire_check_requests_pb.argtypes = [vp, u32, vp, vp, u32, vp, vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(CParams), vp, vp,
+                                               vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(CWireInfo)]
+    lib.cbh_wire_check_requests_pb.restype = i32
     _lib = lib
     return lib
 
@@ -398,6 +404,42 @@ class Table:
         _check(rc)
         raw = ob[:int(oo[n])].tobytes()
         return [raw[int(oo[i]):int(oo[i + 1])] for i in range(n)], of[:n].copy()
+
+    def wire_check_requests_pb(self, requests, aux=None, now_ns=0, flags=0, default_policy_version="default", default_scope="", device_index=0,
+                               globals_pb=b""):
+        """``cbh_wire_check_requests_pb``: serialized ``CheckResourcesRequest``s in (``requests``: [bytes]; ``aux``: per request the
+        serialized engine ``AuxData`` or None), per request the serialized ``CheckOutput``s of its resource entries out.
+        -> ([[bytes] per request], flags uint8[n_inputs], include_meta bool[n_requests])"""
+        from .wire import pack_messages
+        data, offsets = pack_messages(list(requests))
+        nr = len(offsets) - 1
+        a_data = a_off = None
+        if aux is not None and any(aux):
+            a_data, a_off = pack_messages([x or b"" for x in aux])
+        first = np.zeros(nr + 1, dtype=np.uint32)
+        rflags = np.zeros(max(nr, 1), dtype=np.uint8)
+        p = CParams(now_ns, flags, 0)
+        info, need = CWireInfo(), C.c_size_t()
+        cap, n_cap = 4096, 8 * max(nr, 1)
+        for _ in range(3):
+            ob = np.empty(cap, dtype=np.uint8)
+            oo, of = np.zeros(n_cap + 1, dtype=np.uint64), np.zeros(n_cap + 1, dtype=np.uint8)   # (the inputs are known after the call: grown on demand)
+            rc = load().cbh_wire_check_requests_pb(self.h, device_index, data.ctypes.data if data.size else None, offsets.ctypes.data, nr,
+                                                   a_data.ctypes.data if a_data is not None and a_data.size else (np.zeros(1, np.uint8).ctypes.data if a_off is not None else None),
+                                                   a_off.ctypes.data if a_off is not None else None,
+                                                   default_policy_version.encode(), default_scope.encode(), globals_pb or None, len(globals_pb or b""),
+                                                   C.byref(p), first.ctypes.data, rflags.ctypes.data, ob.ctypes.data, ob.size, oo.ctypes.data, of.ctypes.data,
+                                                   n_cap, C.byref(need), C.byref(info))
+            if rc != 2:
+                break
+            cap, n_cap = max(cap, int(need.value) + 64), max(n_cap, int(info.n_requests))
+        if rc == 1:
+            raise HostFlattenerNeeded(load().cbh_last_error().decode("utf-8", "replace"))
+        _check(rc)
+        n = int(first[nr])
+        raw = ob[:int(oo[n])].tobytes()
+        outs = [raw[int(oo[i]):int(oo[i + 1])] for i in range(n)]
+        return [outs[int(first[r]):int(first[r + 1])] for r in range(nr)], of[:n].copy(), (rflags[:nr] & 1).astype(bool)
 
     def wire_spans(self, dbatch):
         """``cbh_wire_spans_download`` -> (in_span uint32[n][12], act_span uint32[n_tuples][2], act_off uint32[n + 1])"""

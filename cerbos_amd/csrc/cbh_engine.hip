@@ -853,9 +853,25 @@ struct WireChain {
   std::atomic<int>* prev_recorded = nullptr; std::atomic<int>* recorded = nullptr;
   void done() { if (recorded) recorded->store(1, std::memory_order_release); }   // (also on every early return: the successor must not wait for ever)
 };
+// (cbh_wire_flatten_requests) `bytes` / `offsets` / `n` are CheckResourcesRequests: the messages the flattener works on are made on
+// the device (cbh_wire_req.h)
+struct WireRequests {
+  const uint8_t* aux = nullptr; const uint64_t* aux_offsets = nullptr;   // serialized engine AuxData per request, or null
+  uint32_t* first_input = nullptr;   // out [n + 1]: the inputs of request r are first_input[r] .. first_input[r + 1]
+  uint8_t* flags = nullptr;          // out [n] (may be null): bit 0 = include_meta
+};
 static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
                              const char* default_version, const char* default_scope, const uint8_t* globals_pb, size_t globals_len,
-                             cbh_device_batch** out, cbh_wire_info* info, WireChain* chain);
+                             cbh_device_batch** out, cbh_wire_info* info, WireChain* chain, const WireRequests* reqs = nullptr);
+extern "C" int cbh_wire_flatten_requests(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n_requests,
+                                         const uint8_t* aux_bytes, const uint64_t* aux_offsets, const char* default_version, const char* default_scope,
+                                         const uint8_t* globals_pb, size_t globals_len, uint32_t* first_input, uint8_t* request_flags,
+                                         cbh_device_batch** out, cbh_wire_info* info) {
+  if (!first_input) return fail("null argument");
+  if ((aux_bytes == nullptr) != (aux_offsets == nullptr)) return fail("cbh_wire_flatten_requests: aux_bytes and aux_offsets go together");
+  WireRequests rq; rq.aux = aux_bytes; rq.aux_offsets = aux_offsets; rq.first_input = first_input; rq.flags = request_flags;
+  return wire_flatten_impl(t, device_index, bytes, offsets, n_requests, default_version, default_scope, globals_pb, globals_len, out, info, nullptr, &rq);
+}
 extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
                                 const char* default_version, const char* default_scope, const uint8_t* globals_pb, size_t globals_len,
                                 cbh_device_batch** out, cbh_wire_info* info) {
@@ -863,14 +879,14 @@ extern "C" int cbh_wire_flatten(cbh_table* t, uint32_t device_index, const uint8
 }
 static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
                              const char* default_version, const char* default_scope, const uint8_t* globals_pb, size_t globals_len,
-                             cbh_device_batch** out, cbh_wire_info* info, WireChain* chain) {
+                             cbh_device_batch** out, cbh_wire_info* info, WireChain* chain, const WireRequests* reqs) {
   struct ChainGuard { WireChain* c; ~ChainGuard() { if (c) c->done(); } } chain_guard{chain};
   if (!t || !out || !info || (n && (!bytes || !offsets)) || (globals_len && !globals_pb)) return fail("null argument");
   std::memset(info, 0, sizeof(*info));
   info->first_bad = CBH_NONE; info->n_requests = n;
   if (device_index >= t->reps.size()) return fail("device index out of range");
   if (t->wire.why_not) { info->n_host = n; g_err = t->wire.why_not; return 1; }
-  const u64 total = n ? offsets[n] : 0;
+  u64 total = n ? offsets[n] : 0;   // (requests: of the CheckInputs made of them, below)
   std::string dv = default_version ? default_version : "default", ds = default_scope ? default_scope : "";
   if (!ds.empty() && ds[0] == '.') ds.erase(0, 1);   // scope_value (namer.go:276-278)
   if (total + dv.size() + ds.size() + globals_len + 64 > 0xFFFFFFFFull) return fail("cbh_wire_flatten: more than 4 GB of messages in one call");
@@ -900,6 +916,68 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
   if (!b->own_wire_stream) b->stream = rep->rstreams[rep->next_rstream.fetch_add(1, std::memory_order_relaxed) % (uint32_t)rep->n_rstreams.load(std::memory_order_relaxed)];
   hipStream_t s = b->stream;
   auto bail = [&](int rc) { cbh_batch_release(b); return rc; };
+  u8* d_msg = nullptr; u64* d_moff = nullptr;
+  const u32 n_in = n;
+  const size_t tail_room = dv.size() + ds.size() + globals_len + 64;
+  if (reqs) {
+    // ---- CheckResourcesRequests -> the CheckInputs of their resource entries, on the device (cbh_wire_req.h): counts, two prefix
+    // sums on the host, the split.  From here on `n` / `total` are the inputs' and their bytes'.
+    const u32 nr = n_in;
+    const u64 rtotal = total, atotal = (reqs->aux_offsets && nr) ? reqs->aux_offsets[nr] : 0;
+    if (atotal > 0xFFFFFFFFull) return bail(fail("cbh_wire_flatten_requests: more than 4 GB of auxiliary data in one call"));
+    WireReqArgs q; std::memset(&q, 0, sizeof(q));
+    u8* d_req = nullptr; u64* d_roff = nullptr; u8* d_aux = nullptr; u64* d_aoff = nullptr; u32* d_first = nullptr; u64* d_fbyte = nullptr;
+    int rq = 0;
+    rq |= dalloc(b, d_req, (size_t)rtotal + 8); rq |= dalloc(b, d_roff, (size_t)nr + 1);
+    rq |= dalloc(b, q.n_inputs, (size_t)nr + 1); rq |= dalloc(b, q.n_bytes, (size_t)nr + 1); rq |= dalloc(b, q.flags, (size_t)nr + 1);
+    rq |= dalloc(b, d_first, (size_t)nr + 1); rq |= dalloc(b, d_fbyte, (size_t)nr + 1);
+    if (reqs->aux_offsets) { rq |= dalloc(b, d_aux, (size_t)atotal + 8); rq |= dalloc(b, d_aoff, (size_t)nr + 1); }
+    if (rq != 0) return bail(-1);
+    if ((rtotal && hipMemcpyAsync(d_req, bytes, rtotal, hipMemcpyHostToDevice, s) != hipSuccess) ||
+        (nr && hipMemcpyAsync(d_roff, offsets, ((size_t)nr + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess) ||
+        (atotal && hipMemcpyAsync(d_aux, reqs->aux, atotal, hipMemcpyHostToDevice, s) != hipSuccess) ||
+        (reqs->aux_offsets && nr && hipMemcpyAsync(d_aoff, reqs->aux_offsets, ((size_t)nr + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess))
+      { fail("cbh_wire_flatten_requests: upload failed"); return bail(-1); }
+    q.req = d_req; q.roff = d_roff; q.n = nr; q.end = (u32)rtotal; q.aux = d_aux; q.aoff = reqs->aux_offsets ? d_aoff : nullptr;
+    if (nr) hipLaunchKernelGGL(cbh_wire_req_count_kernel, dim3((nr + CBH_BLOCK - 1) / CBH_BLOCK), dim3(CBH_BLOCK), 0, s, q);
+    std::vector<u32> h_inputs((size_t)nr + 1, 0), h_first((size_t)nr + 1, 0); std::vector<u64> h_bytes((size_t)nr + 1, 0), h_fbyte((size_t)nr + 1, 0);
+    if (nr && (hipMemcpyAsync(h_inputs.data(), q.n_inputs, (size_t)nr * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+               hipMemcpyAsync(h_bytes.data(), q.n_bytes, (size_t)nr * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+               (reqs->flags && hipMemcpyAsync(reqs->flags, q.flags, (size_t)nr, hipMemcpyDeviceToHost, s) != hipSuccess)))
+      { fail("cbh_wire_flatten_requests: download failed"); return bail(-1); }
+    if (hipStreamSynchronize(s) != hipSuccess) { fail("cbh_wire_flatten_requests failed"); return bail(-1); }
+    u64 n_inputs = 0, n_bytes = 0;
+    for (u32 r = 0; r < nr; ++r) {
+      if (h_inputs[r] == CBH_WREQ_BAD) { info->first_bad = r; fail("malformed CheckResourcesRequest at index " + std::to_string(r)); return bail(-1); }
+      h_first[r] = (u32)n_inputs; h_fbyte[r] = n_bytes;
+      n_inputs += h_inputs[r]; n_bytes += h_bytes[r];
+      if (n_inputs > 0x7FFFFFFFull) { fail("cbh_wire_flatten_requests: too many resource entries in one call"); return bail(-1); }
+    }
+    h_first[nr] = (u32)n_inputs; h_fbyte[nr] = n_bytes;
+    if (n_bytes + tail_room > 0xFFFFFFFFull) { fail("cbh_wire_flatten_requests: more than 4 GB of CheckInputs in one call"); return bail(-1); }
+    std::memcpy(reqs->first_input, h_first.data(), ((size_t)nr + 1) * 4);
+    n = (u32)n_inputs; total = n_bytes;
+    info->n_requests = n;
+    rq = 0;
+    rq |= dalloc(b, d_msg, (size_t)total + tail_room); rq |= dalloc(b, d_moff, (size_t)n + 1);
+    if (rq != 0) return bail(-1);
+    q.first_input = d_first; q.first_byte = d_fbyte; q.msg = d_msg; q.moff = d_moff;
+    // (pageable sources: the copies are staged before the call returns to this thread, the vectors outlive them)
+    if (hipMemcpyAsync(d_first, h_first.data(), ((size_t)nr + 1) * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_fbyte, h_fbyte.data(), ((size_t)nr + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemsetAsync(d_moff, 0, 8, s) != hipSuccess)
+      { fail("cbh_wire_flatten_requests: upload failed"); return bail(-1); }
+    if (nr) hipLaunchKernelGGL(cbh_wire_req_split_kernel, dim3((nr + (CBH_BLOCK / 64u) - 1) / (CBH_BLOCK / 64u)), dim3(CBH_BLOCK), 0, s, q);
+    if (hipStreamSynchronize(s) != hipSuccess) { fail("cbh_wire_flatten_requests failed"); return bail(-1); }   // (h_first / h_fbyte go out of scope)
+  }
+  // a malformed message: by index of the CheckInput, or - requests - of the request its resource entry belongs to
+  auto bad_input = [&](u32 i) {
+    if (!reqs) { info->first_bad = i; fail("malformed CheckInput at index " + std::to_string(i)); return; }
+    u32 r = 0;
+    while (r + 1u < n_in && reqs->first_input[r + 1u] <= i) ++r;
+    info->first_bad = r;
+    fail("malformed CheckResourcesRequest at index " + std::to_string(r) + " (resource entry " + std::to_string(i - reqs->first_input[r]) + ")");
+  };
   const u32 nw = (n + 63u) / 64u, ncol = t->meta[CBH_M_NCOLUMNS];
   WireArgs a; std::memset(&a, 0, sizeof(a));
   const TableDev& td = rep->dev;
@@ -910,10 +988,9 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
   a.dver_off = (u32)total; a.dver_len = (u32)dv.size(); a.dscope_off = (u32)(total + dv.size()); a.dscope_len = (u32)ds.size();
   a.claims_off = (u32)(total + dv.size() + ds.size());
   a.globals_off = a.claims_off + 6u; a.globals_len = (u32)globals_len;
-  u8* d_msg = nullptr; u64* d_moff = nullptr; WireStats* d_stats = nullptr;
+  WireStats* d_stats = nullptr;
   int rc = 0;
-  rc |= dalloc(b, d_msg, (size_t)total + dv.size() + ds.size() + globals_len + 64);
-  rc |= dalloc(b, d_moff, (size_t)n + 1);
+  if (!reqs) { rc |= dalloc(b, d_msg, (size_t)total + tail_room); rc |= dalloc(b, d_moff, (size_t)n + 1); }
   rc |= dalloc(b, a.cnt, (size_t)n + 1); rc |= dalloc(b, a.status, (size_t)n + 1);
   rc |= dalloc(b, a.wavesum, 2 * (size_t)nw + 2); rc |= dalloc(b, a.waveoff, 2 * (size_t)nw + 2);
   rc |= dalloc(b, d_stats, 1);
@@ -929,15 +1006,15 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
   u64* pin_off = reinterpret_cast<u64*>(pin + ((2 * sizeof(WireStats) + tail.size() + 63) & ~(size_t)63));
   *pin_st = st;
   std::memcpy(pin_tail, tail.data(), tail.size());
-  if (n) std::memcpy(pin_off, offsets, ((size_t)n + 1) * 8); else pin_off[0] = 0;
+  if (!reqs) { if (n) std::memcpy(pin_off, offsets, ((size_t)n + 1) * 8); else pin_off[0] = 0; }
   if (chain && chain->prev_recorded) {   // behind the predecessor's upload (its thread has enqueued the record by now, or is about to)
     while (!chain->prev_recorded->load(std::memory_order_acquire)) std::this_thread::yield();
     if (chain->wait && hipStreamWaitEvent(s, chain->wait, 0) != hipSuccess) { fail("cbh_wire_flatten: hipStreamWaitEvent failed"); return bail(-1); }
   }
-  if (total && hipMemcpyAsync(d_msg, bytes, total, hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
+  if (!reqs && total && hipMemcpyAsync(d_msg, bytes, total, hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
   if (chain && chain->record) { (void)hipEventRecord(chain->record, s); chain->done(); }
   if (hipMemcpyAsync(d_msg + total, pin_tail, tail.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
-      hipMemcpyAsync(d_moff, pin_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+      (!reqs && hipMemcpyAsync(d_moff, pin_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess) ||
       hipMemcpyAsync(d_stats, pin_st, sizeof(st), hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
   if (nw) hipLaunchKernelGGL(cbh_wire_count_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, a);
   u32 slots = cbh_wire_dict_slots(n), heap_cap = cbh_wire_heap_guess(total);
@@ -953,7 +1030,7 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
     if (wire_stats_read(b, d_stats, st) != 0) return bail(-1);
     if (!have_outputs) {
       n_host_count = st.n_host;
-      if (st.first_bad != CBH_NONE) { info->first_bad = st.first_bad; fail("malformed CheckInput at index " + std::to_string(st.first_bad)); return bail(-1); }
+      if (st.first_bad != CBH_NONE) { bad_input(st.first_bad); return bail(-1); }
       if (st.n_host) {   // the count already found messages for the host flattener (more than 64 actions / 255 roles): no point in filling
         info->n_tuples = st.n_tuples; info->n_host = st.n_host;
         g_err = "cbh_wire_flatten: " + std::to_string(st.n_host) + " message(s) are the host flattener's (more than 64 actions or 255 roles)";
@@ -992,7 +1069,7 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
   { const hipError_t le = hipGetLastError(); if (le != hipSuccess) { fail(std::string("cbh_wire_flatten: ") + hipGetErrorString(le)); return bail(-1); } }
   if (st.heap_used >= (1u << 30)) { fail("cbh_wire_flatten: batch too large: nested attribute values exceed the heap's 30-bit offsets"); return bail(-1); }   // (as cbi_flatten_pb)
   info->n_tuples = st.n_tuples; info->n_host = st.n_host; info->dict_slots = slots; info->heap_len = st.heap_used; info->fill_runs = runs;
-  if (st.first_bad != CBH_NONE) { info->first_bad = st.first_bad; fail("malformed CheckInput at index " + std::to_string(st.first_bad)); return bail(-1); }
+  if (st.first_bad != CBH_NONE) { bad_input(st.first_bad); return bail(-1); }
   if (st.n_host) { g_err = "cbh_wire_flatten: " + std::to_string(st.n_host) + " message(s) are the host flattener's (more than 64 actions, a resource kind to rewrite that no policy names, containers nested too deep)"; return bail(1); }
   // Group the requests by route (cbh_wire.h cbh_wire_route_kernel ...): what the host flattener's routing sort does for the
   // decision kernels' merged walk.  CBH_WIRE_GROUP=0: leave the batch in input order (measurement aid).
@@ -1123,6 +1200,31 @@ extern "C" int cbh_wire_outputs(cbh_table* t, cbh_device_batch* b, uint8_t* byte
     for (size_t i = b->allocs.size(); i-- > 0;) if (b->allocs[i].first == d_out) { rep->pool_free.push_back(b->allocs[i]); b->allocs.erase(b->allocs.begin() + (long)i); break; }
   }
   return 0;
+}
+
+// What the server receives in, what engine.Check returns out, in ONE call: serialized CheckResourcesRequests -> the serialized
+// CheckOutputs of their resource entries (cbh_wire_flatten_requests, cbh_check_resident, cbh_wire_outputs on one stream).  The
+// outputs of request r are out_offsets[first_input[r]] .. out_offsets[first_input[r + 1]].  Return values as cbh_wire_check_pb.
+extern "C" int cbh_wire_check_requests_pb(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n_requests,
+                                          const uint8_t* aux_bytes, const uint64_t* aux_offsets, const char* default_version, const char* default_scope,
+                                          const uint8_t* globals_pb, size_t globals_len, const cbh_params* p, uint32_t* first_input, uint8_t* request_flags,
+                                          uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags, size_t out_inputs_cap, size_t* need,
+                                          cbh_wire_info* info) {
+  if (!t || !p || !need || !info || !first_input || (out_cap && !out_bytes)) return fail("null argument");
+  cbh_device_batch* b = nullptr;
+  int rc = cbh_wire_flatten_requests(t, device_index, bytes, offsets, n_requests, aux_bytes, aux_offsets, default_version, default_scope, globals_pb, globals_len,
+                                     first_input, request_flags, &b, info);
+  if (rc != 0) return rc;
+  struct Release { cbh_device_batch* b; ~Release() { if (b) cbh_batch_release(b); } } release{b};
+  if ((rc = cbh_check_resident(t, b, p)) != 0) return rc;
+  const u32 n = info->n_requests;   // the inputs
+  std::vector<uint64_t> tmp_off; std::vector<uint8_t> tmp_flags;
+  const bool fits = (size_t)n <= out_inputs_cap && out_offsets;
+  uint64_t* off = out_offsets; uint8_t* fl = out_flags;
+  if (!fits) { tmp_off.resize((size_t)n + 1); off = tmp_off.data(); if (fl) { tmp_flags.resize((size_t)n + 1); fl = tmp_flags.data(); } }
+  rc = cbh_wire_outputs(t, b, fits ? out_bytes : nullptr, fits ? out_cap : 0, off, fl, need);   // (not fitting: sizes only)
+  if (rc == 0 && !fits) { g_err = "cbh_wire_check_requests_pb: out_offsets / out_flags hold fewer inputs than the requests have"; return 2; }
+  return rc;
 }
 
 // Bytes in, bytes out in ONE call: serialized CheckInputs -> serialized CheckOutputs by the device road (cbh_wire_flatten,

@@ -136,3 +136,4 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_resolve_globs_kernel(TableDev t
 #include "cbh_check_flat.h"
 #include "cbh_check_walk2.h"
 #include "cbh_wire.h"
+#include "cbh_wire_req.h"

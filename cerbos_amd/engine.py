@@ -279,6 +279,22 @@ class HipEvaluator:
             oflags = oflags & 0xEF   # traced: CBI_OUT_WANTS_TRACE is answered
         return raw, oflags
 
+    def check_requests_pb(self, requests, aux=None, now_ns=None, lenient_scope_search=None, strict_evaluation=None,
+                          default_policy_version=None, default_scope=None):
+        """Many serialized ``CheckResourcesRequest``s at once down the device road (``cbh_wire_check_requests_pb``: the requests are
+        split into the ``CheckInput``s of cerbos_svc.go:274-288 on the device) -> ([[serialized CheckOutput] per request], flags per
+        input, include_meta per request).  ``aux``: per request the serialized engine ``AuxData`` or None.  Requests the device road
+        leaves to the host flattener take ``check_request_pb`` one by one (``capi.HostFlattenerNeeded``)."""
+        conf = self.conf
+        lenient = conf.lenient_scope_search if lenient_scope_search is None else lenient_scope_search
+        strict = conf.strict_evaluation if strict_evaluation is None else strict_evaluation
+        dver = conf.default_policy_version if default_policy_version is None else default_policy_version
+        dscope = conf.default_scope if default_scope is None else default_scope
+        if now_ns is None:
+            now_ns = time.time_ns()
+        flags = capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0) | (capi.F_STRICT_EVALUATION if strict else 0)
+        return self.table.wire_check_requests_pb(requests, aux, now_ns=now_ns, flags=flags, default_policy_version=dver, default_scope=dscope)
+
     def _ingest_table(self):
         if self._ingest is None:
             with self._ingest_lock:

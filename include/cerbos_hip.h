@@ -309,6 +309,31 @@ int cbh_wire_check_pb(cbh_table* t, uint32_t device_index, const uint8_t* bytes,
                       const cbh_params* p, uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags,
                       size_t* need, cbh_wire_info* info);
 
+/* The device road for what the SERVER receives (internal/svc/cerbos_svc.go:255-344): `bytes` / `offsets` hold n_requests serialized
+ * cerbos.request.v1.CheckResourcesRequest messages (request.proto:222-273).  Every resource entry becomes the CheckInput that
+ * svc.CheckResources builds from it (cerbos_svc.go:274-288: the request's id and principal, the entry's resource and actions) - on
+ * the device, by two launches in front of the flattener (cbh_wire_req.h); the host never sees those messages.  aux_bytes /
+ * aux_offsets (n_requests + 1 entries; both NULL = none): per request the serialized cerbos.engine.v1.AuxData the server derived
+ * from the request's JWT (auxdata.Extract, cerbos_svc.go:262 - verification is the caller's business), empty where there is none.
+ * first_input [n_requests + 1]: the inputs (and, after the check, outputs) of request r are first_input[r] .. first_input[r + 1];
+ * request_flags [n_requests] (may be NULL): bit 0 = include_meta.  info->n_requests = the number of inputs; info->first_bad
+ * indexes requests.  The batch goes through cbh_check_resident / cbh_wire_outputs like one of cbh_wire_flatten (spans downloaded
+ * with cbh_wire_spans_download refer to the device-made messages, which the host does not have: use cbh_wire_outputs).
+ * Same last-field-wins grammar as cerbos_ingest.h cbi_flatten_request_pb, the host road for one request. */
+int cbh_wire_flatten_requests(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n_requests,
+                              const uint8_t* aux_bytes, const uint64_t* aux_offsets, const char* default_version, const char* default_scope,
+                              const uint8_t* globals_pb, size_t globals_len, uint32_t* first_input, uint8_t* request_flags,
+                              cbh_device_batch** out, cbh_wire_info* info);
+/* ... and bytes in, bytes out in one call: the serialized CheckOutputs (what engine.Check returns, engine.go:217-240) of every
+ * resource entry of every request, back to back; out_offsets (out_inputs_cap + 1 entries) / out_flags (out_inputs_cap entries, may
+ * be NULL) as cbh_wire_outputs.  Returns as cbh_wire_check_pb; 2 = out_cap or out_inputs_cap is too small: *need holds the bytes,
+ * info->n_requests the inputs (nothing was written; call again). */
+int cbh_wire_check_requests_pb(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n_requests,
+                               const uint8_t* aux_bytes, const uint64_t* aux_offsets, const char* default_version, const char* default_scope,
+                               const uint8_t* globals_pb, size_t globals_len, const cbh_params* p, uint32_t* first_input, uint8_t* request_flags,
+                               uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags, size_t out_inputs_cap, size_t* need,
+                               cbh_wire_info* info);
+
 /* ---- Trace pass: evaluation_errors and outputs (evaluator/cel_errors.go:48-118, check.go:383-411, 776-807) ----
  * The decision kernels only mark the tuples whose evaluation absorbed a CEL error (CBH_ST_CEL_ERROR).  What the
  * reference reports beyond the effect - the (expression, message) pairs and the values of the rules' output

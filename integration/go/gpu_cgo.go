@@ -377,6 +377,81 @@ func (g *gpuEngine) traceGPU(buf []byte, offs []C.uint64_t, oflags []byte, n int
 	return out, nil
 }
 
+// checkRequestsGPU is the device road for what the server receives: the bytes of MANY CheckResourcesRequests (a coalescer in front
+// of svc.CheckResources hands them over as they came off the wire) in, per request the serialized CheckOutputs of its resource
+// entries out - cbh_wire_check_requests_pb splits every request into the CheckInputs of cerbos_svc.go:274-288 on the device.
+// aux[r] = the serialized engine AuxData cs.auxData.Extract derived for request r, or nil.  outs[r][e] = CheckOutput bytes of resource
+// entry e of request r; flags as cbi_outputs_flags (CBI_OUT_*: which entries want the trace pass / the CPU path).
+func (g *gpuEngine) checkRequestsGPU(reqs [][]byte, aux [][]byte, p evaluator.EvalParams) (outs [][][]byte, oflags []byte, includeMeta []bool, err error) {
+	n := len(reqs)
+	offs := make([]C.uint64_t, n+1)
+	aoffs := make([]C.uint64_t, n+1)
+	total, atotal := 0, 0
+	for r := range reqs {
+		total += len(reqs[r])
+		offs[r+1] = C.uint64_t(total)
+		if aux != nil {
+			atotal += len(aux[r])
+		}
+		aoffs[r+1] = C.uint64_t(atotal)
+	}
+	buf, abuf := make([]byte, 0, total+8), make([]byte, 0, atotal+8)
+	for r := range reqs {
+		buf = append(buf, reqs[r]...)
+		if aux != nil {
+			abuf = append(abuf, aux[r]...)
+		}
+	}
+	buf, abuf = append(buf, 0), append(abuf, 0)
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	pin.Pin(&buf[0])
+	pin.Pin(&abuf[0])
+	var auxPtr *C.uint8_t
+	var aoffPtr *C.uint64_t
+	if atotal > 0 {
+		auxPtr, aoffPtr = (*C.uint8_t)(unsafe.Pointer(&abuf[0])), &aoffs[0]
+	}
+	dv, ds := C.CString(p.DefaultPolicyVersion), C.CString(p.DefaultScope)
+	defer C.free(unsafe.Pointer(dv))
+	defer C.free(unsafe.Pointer(ds))
+	flags := C.uint32_t(C.CBH_F_WANT_DERIVED_ROLES)
+	if p.LenientScopeSearch {
+		flags |= C.CBH_F_LENIENT_SCOPE_SEARCH
+	}
+	if p.StrictEvaluation {
+		flags |= C.CBH_F_STRICT_EVALUATION
+	}
+	params := C.cbh_params{now_ns: C.int64_t(p.NowFunc().UnixNano()), flags: flags}
+	first := make([]C.uint32_t, n+1)
+	rflags := make([]byte, n+1)
+	inputsCap, bytesCap := 8*n+8, 1<<16
+	for try := 0; try < 3; try++ {
+		out, ooffs, of := make([]byte, bytesCap), make([]C.uint64_t, inputsCap+1), make([]byte, inputsCap+1)
+		var need C.size_t
+		var info C.cbh_wire_info
+		rc := C.cbh_wire_check_requests_pb(g.table, 0, (*C.uint8_t)(unsafe.Pointer(&buf[0])), &offs[0], C.uint32_t(n), auxPtr, aoffPtr, dv, ds, nil, 0, &params,
+			&first[0], (*C.uint8_t)(unsafe.Pointer(&rflags[0])), (*C.uint8_t)(unsafe.Pointer(&out[0])), C.size_t(bytesCap), &ooffs[0],
+			(*C.uint8_t)(unsafe.Pointer(&of[0])), C.size_t(inputsCap), &need, &info)
+		if rc == 2 { // the outputs or the inputs outgrew the buffers: both sizes are exact now
+			bytesCap, inputsCap = max(bytesCap, int(need)+64), max(inputsCap, int(info.n_requests))
+			continue
+		}
+		if rc != 0 { // 1: some entry is the host flattener's (the caller takes checkResourcesGPU per request); < 0: info.first_bad names the request
+			return nil, nil, nil, errors.New(C.GoString(C.cbh_last_error()))
+		}
+		outs, includeMeta = make([][][]byte, n), make([]bool, n)
+		for r := 0; r < n; r++ {
+			includeMeta[r] = rflags[r]&1 != 0
+			for i := int(first[r]); i < int(first[r+1]); i++ {
+				outs[r] = append(outs[r], out[ooffs[i]:ooffs[i+1]])
+			}
+		}
+		return outs, of[:int(first[n])], includeMeta, nil
+	}
+	return nil, nil, nil, errors.New("cbh_wire_check_requests_pb: buffers kept growing")
+}
+
 // checkResourcesGPU serves one CheckResourcesRequest without building CheckInputs (svc/cerbos_svc.go:255-344 would
 // call this instead of cs.eng.Check when the engine is a GPU engine): the request's own bytes go in, the serialized
 // CheckResourcesResponse comes back.  auxData is what cs.auxData.Extract returned for the request's JWT (may be nil).

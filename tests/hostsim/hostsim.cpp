@@ -100,10 +100,12 @@ static bool g_trace;   // hostsim_trace: the trace pass's kernel (cbh_trace_batc
 static WireArgs* g_wargs;   // the device flattener's kernels (cbh_wire.h): 1 count, 2 scan, 3 fill
 static WireRouteArgs* g_wrargs;   // ... and the routing kernels': 7 routes, 8 scan, 9 gather
 static WireOutArgs* g_woargs;   // ... and the device assembler's: 4 sizes, 5 scan, 6 bytes
+static WireReqArgs* g_wqargs;   // ... and the request splitter's (cbh_wire_req.h): 10 count, 11 split
 static int g_wire_kind = 0;
 
 static void fiber_main() {
-  if (g_wire_kind >= 7) { if (g_wire_kind == 7) cbh_wire_route_kernel(*g_wrargs); else if (g_wire_kind == 8) cbh_wire_route_scan_kernel(*g_wrargs); else cbh_wire_gather_kernel(*g_wrargs); }
+  if (g_wire_kind >= 10) { if (g_wire_kind == 10) cbh_wire_req_count_kernel(*g_wqargs); else cbh_wire_req_split_kernel(*g_wqargs); }
+  else if (g_wire_kind >= 7) { if (g_wire_kind == 7) cbh_wire_route_kernel(*g_wrargs); else if (g_wire_kind == 8) cbh_wire_route_scan_kernel(*g_wrargs); else cbh_wire_gather_kernel(*g_wrargs); }
   else if (g_wire_kind >= 4) { if (g_wire_kind == 4) cbh_wire_out_size_kernel(*g_woargs); else if (g_wire_kind == 5) cbh_wire_out_scan_kernel(*g_woargs); else cbh_wire_out_write_kernel(*g_woargs); }
   else if (g_wire_kind == 1) cbh_wire_count_kernel(*g_wargs);
   else if (g_wire_kind == 2) cbh_wire_scan_kernel(*g_wargs);
@@ -374,6 +376,34 @@ extern "C" int hostsim_wire_flatten(const void* blob, size_t len, const uint8_t*
     }
   }
   return 0;
+}
+
+// The request splitter (cbh_wire_req.h) on the simulator: n serialized CheckResourcesRequests (+ per-request engine AuxData, or
+// null) -> the CheckInputs of their resource entries, as cbh_wire_flatten_requests makes them on the device.  Returns the number of
+// inputs (the buffers are valid until the next call), -1 with *first_bad = the first malformed request.
+static struct { std::vector<uint8_t> msg, flags; std::vector<uint64_t> moff, nbytes, first_byte; std::vector<uint32_t> ninputs, first_input; } g_q;
+extern "C" long long hostsim_wire_split_requests(const uint8_t* bytes, const uint64_t* offsets, uint32_t n, const uint8_t* aux, const uint64_t* aoff,
+                                                 const uint8_t** out_msg, const uint64_t** out_moff, const uint32_t** out_first_input,
+                                                 const uint8_t** out_flags, uint32_t* first_bad) {
+  WireReqArgs a{};
+  a.req = bytes; a.roff = offsets; a.n = n; a.end = n ? (uint32_t)offsets[n] : 0; a.aux = aux; a.aoff = aoff;
+  g_q.ninputs.assign(n + 1, 0); g_q.nbytes.assign(n + 1, 0); g_q.flags.assign(n + 1, 0);
+  a.n_inputs = g_q.ninputs.data(); a.n_bytes = g_q.nbytes.data(); a.flags = g_q.flags.data();
+  g_wqargs = &a;
+  wire_launch(10, (n + CBH_BLOCK - 1) / CBH_BLOCK);
+  g_q.first_input.assign(n + 1, 0); g_q.first_byte.assign(n + 1, 0);
+  *first_bad = CBH_NONE;
+  for (uint32_t r = 0; r < n; ++r) {
+    if (g_q.ninputs[r] == CBH_WREQ_BAD) { *first_bad = r; return -1; }
+    g_q.first_input[r + 1] = g_q.first_input[r] + g_q.ninputs[r];
+    g_q.first_byte[r + 1] = g_q.first_byte[r] + g_q.nbytes[r];
+  }
+  const uint32_t total_inputs = g_q.first_input[n];
+  g_q.msg.assign(g_q.first_byte[n] + 1, 0xEE); g_q.moff.assign((size_t)total_inputs + 1, 0xEEEEEEEEEEEEEEEEull);
+  a.first_input = g_q.first_input.data(); a.first_byte = g_q.first_byte.data(); a.msg = g_q.msg.data(); a.moff = g_q.moff.data();
+  if (n) wire_launch(11, (n + (CBH_BLOCK / 64) - 1) / (CBH_BLOCK / 64)); else g_q.moff[0] = 0;
+  *out_msg = g_q.msg.data(); *out_moff = g_q.moff.data(); *out_first_input = g_q.first_input.data(); *out_flags = g_q.flags.data();
+  return (long long)total_inputs;
 }
 
 // The device assembler on the batch the last hostsim_wire_flatten call built: results (input order) -> serialized CheckOutputs.
