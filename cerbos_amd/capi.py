@@ -19,6 +19,7 @@ MAX_DEVICES = 16
 F_LENIENT_SCOPE_SEARCH = 1
 F_STRICT_EVALUATION = 2
 F_WANT_DERIVED_ROLES = 4
+F_WANT_EFFECTIVE_POLICIES = 8
 
 EFFECT_ALLOW, EFFECT_DENY = 1, 2
 ST_OK, ST_CEL_ERROR, ST_UNSUPPORTED, ST_WANTS_TRACE = 0, 1, 2, 3
@@ -35,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "cbh_check_resident_many", "cbh_table_set_resident_streams", "cbh_table_resident_streams",
     "cbh_wire_flatten", "cbh_wire_spans_download", "cbh_wire_outputs", "cbh_wire_check_pb",
     "cbh_wire_flatten_requests", "cbh_wire_check_requests_pb",
+    "cbh_table_num_policies", "cbh_table_policy_key", "cbh_check_batch_trail",
 ]
 
 
@@ -171,6 +173,12 @@ def load():
     lib.cbh_wire_check_requests_pb.argtypes = [vp, u32, vp, vp, u32, vp, vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(CParams), vp, vp,
                                                vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(CWireInfo)]
     lib.cbh_wire_check_requests_pb.restype = i32
+    lib.cbh_table_num_policies.argtypes = [vp]
+    lib.cbh_table_num_policies.restype = u32
+    lib.cbh_table_policy_key.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(u32)]
+    lib.cbh_table_policy_key.restype = i32
+    lib.cbh_check_batch_trail.argtypes = [vp, C.POINTER(CBatch), C.POINTER(CParams), C.POINTER(CResult), vp, u32, vp]
+    lib.cbh_check_batch_trail.restype = i32
     _lib = lib
     return lib
 
@@ -333,6 +341,29 @@ class Table:
         p = CParams(now_ns, flags, 0)
         _check(load().cbh_check_batch(self.h, C.byref(cb), C.byref(p), C.byref(res.c)))
         return res if device_order else res.to_input_order(batch)
+
+    def check_trail(self, batch, groups=None, n_groups=1, now_ns=0, flags=0, want=("policy", "scope", "status", "edr")):
+        """``cbh_check_batch_trail``: the decisions (DEVICE order) and, per group of requests, the mask of the policies whose bindings
+        the walk iterated (AuditTrail.EffectivePolicies) -> (Result, uint32[n_groups][words]).  ``groups``: the group of every request
+        of ``batch`` in its (device) order, None = one group."""
+        res = Result(batch.n_tuples, batch.n_requests, want)
+        cb = make_cbatch(batch, self.num_columns)
+        p = CParams(now_ns, flags, 0)
+        words = (int(load().cbh_table_num_policies(self.h)) + 31) // 32
+        masks = np.zeros((max(n_groups, 1), max(words, 1)), dtype=np.uint32)
+        grp = None if groups is None else np.ascontiguousarray(groups, dtype=np.uint32)
+        _check(load().cbh_check_batch_trail(self.h, C.byref(cb), C.byref(p), C.byref(res.c), grp.ctypes.data if grp is not None else None,
+                                            n_groups, masks.ctypes.data))
+        return res, masks[:, :words]
+
+    def policy_keys(self):
+        """``cbh_table_policy_key`` for every policy of the table (the bit positions of ``check_trail``'s masks)."""
+        out = []
+        for i in range(int(load().cbh_table_num_policies(self.h))):
+            key, ln = C.c_char_p(), C.c_uint32()
+            _check(load().cbh_table_policy_key(self.h, i, C.byref(key), C.byref(ln)))
+            out.append(C.string_at(key, ln.value).decode("utf-8"))
+        return out
 
     def trace(self, batch, now_ns=0, flags=0, capacity=None):
         """``cbh_trace_batch``: decide ``batch`` with the tracing kernel -> (Result in DEVICE order, records uint32[n][8]).

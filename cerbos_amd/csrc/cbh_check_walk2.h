@@ -900,6 +900,9 @@ static inline CbhPlan cbh_plan(u32 table_flags, u32 n_derived_roles, bool has_gl
                                u32 max_roles, bool plain_tags, u32 eval_flags, bool no_flat, bool no_walk2, u32 max_bucket, bool no_walk2_wide = false, bool masks = false) {
   CbhPlan p; p.n_gwords = 0; p.n_gslots = 0; p.wide_kernel = nullptr; p.walk_wide = false; p.walk_awide = false;
   bool flat = false;
+  // the effective policies of a call are what the reference's loops TOUCH, role by role in order (check.go:208-442, 302-304): the
+  // general walk keeps that order; the flat kernels and cbh_walk2_kernel walk a request's roles side by side
+  if (eval_flags & CBH_F_WANT_EFFECTIVE_POLICIES) { p.kind = 0; p.kernel = cbh_check_trail_kernel; p.threads = CBH_BLOCK; return p; }
   p.kernel = cbh_pick_kernel(no_flat ? (table_flags & ~(u32)CBH_MF_FLAT) : table_flags, n_derived_roles, has_globs, max_actions, max_roles, plain_tags, eval_flags, max_bucket, &p.threads, &flat, masks);
   p.kind = flat ? 1 : 0;
   if (!flat && !no_walk2 && cbh_walk2_applies(table_flags, eval_flags)) {

@@ -216,29 +216,26 @@ __device__ u32 eval_leaf_tree(const KernelArgs* ka, const VmLds lds, u32 req, u3
 #ifndef CBH_HOSTSIM
 __attribute__((noinline))
 #endif
-__device__ u32 eval_classified(const KernelArgs* ka, const VmLds lds, u32 req, u32 ref, bool active) {
-  ref = uniform(ref);
-  if (ref & CBH_COND_LEAF) {
-    const Ctx c = ctx_from_memory(uniform_ptr(ka), lds);
-    const u32 pc = ref & CBH_COND_PC_MASK;
-    const u32 w = uload(&c.t.code[pc]), a0 = uload(&c.t.code[pc + 1]), a1 = uload(&c.t.code[pc + 2]);
-    Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false;   // leaves never read runtime.*
-    u32 r = 0;
-    if (active) {
-      r = (u32)leaf_value(c, L, w, a0, a1);
-      if (r == 3) { L.status |= CBH_ST_CEL_ERROR; r = (c.flags & CBH_F_STRICT_EVALUATION) ? 2u : 0u; }
-    }
-    return r | (L.status << 8);
+__device__ u32 eval_leaf_one(const KernelArgs* ka, const VmLds lds, u32 req, u32 ref, bool active) {   // CBH_COND_LEAF
+  const Ctx c = ctx_from_memory(uniform_ptr(ka), lds);
+  const u32 pc = ref & CBH_COND_PC_MASK;
+  const u32 w = uload(&c.t.code[pc]), a0 = uload(&c.t.code[pc + 1]), a1 = uload(&c.t.code[pc + 2]);
+  Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false;   // leaves never read runtime.*
+  u32 r = 0;
+  if (active) {
+    r = (u32)leaf_value(c, L, w, a0, a1);
+    if (r == 3) { L.status |= CBH_ST_CEL_ERROR; r = (c.flags & CBH_F_STRICT_EVALUATION) ? 2u : 0u; }
   }
-  return eval_leaf_tree(ka, lds, req, ref & CBH_COND_PC_MASK, active);
+  return r | (L.status << 8);
 }
-// The two real calls are made from the caller's own frame (a function between the caller and run_uniform would add the
-// registers it keeps across that call to run_uniform's, and the sum - not the larger - is what the kernel is sized by:
-// 257 registers, one wave to a SIMD, where 253 fit two).
+// Every real call is made from the caller's own frame and none of the callees calls on (a function between the caller and
+// run_uniform would add the registers it keeps across that call to run_uniform's, and the sum - not the larger - is what the kernel
+// is sized by: 257 registers, one wave to a SIMD, where 253 fit two).
 template <bool GENERIC>
 __device__ __forceinline__ u32 eval_ref(const KernelArgs* ka, const VmLds lds, u32 req, u64 edr, bool edr_err, u32 ref, bool active) {
   ref = uniform(ref);
-  if (ref & (CBH_COND_LEAF | CBH_COND_LEAFTREE)) return eval_classified(ka, lds, req, ref, active);
+  if (ref & CBH_COND_LEAF) return eval_leaf_one(ka, lds, req, ref, active);
+  if (ref & CBH_COND_LEAFTREE) return eval_leaf_tree(ka, lds, req, ref & CBH_COND_PC_MASK, active);
   if (GENERIC) return run_uniform(ka, lds, req, edr, edr_err, ref, active);
   return active ? ((u32)CBH_ST_UNSUPPORTED << 8) : 0u;   // unreachable: the host picks the GENERIC kernel for such tables
 }
@@ -417,6 +414,8 @@ struct CbhPassResource { static constexpr bool value = true; };     // policy pa
 #define CBH_FEAT_ALL 15
 #define CBH_FEAT_MAX4 16          /* a property of the batch, not the table: at most four actions per request */
 #define CBH_FEAT_TRACE 32         /* the trace pass (cbh_trace_batch): conditions run as trace programs, errors and outputs are logged */
+#define CBH_FEAT_TRAIL 64         /* cbh_check_batch_trail: the policy of every binding iterated is marked (its own kernel: the marks cost the */
+                                  /* general walk the registers that let it run two waves to a SIMD) */
 struct __attribute__((aligned(32))) TblTraceRow { u32 cond, drcond, vars_off, vars_cnt, drvars_off, drvars_cnt, out_activated, out_not_met; };
 struct __attribute__((aligned(16))) TblTraceCond { u32 cond, vars_off, vars_cnt, pad; };
 struct __attribute__((aligned(32))) TblTraceRp { u32 cond, vars_off, vars_cnt, out_activated, out_not_met, pad0, pad1, pad2; };
@@ -486,6 +485,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   const bool has_parents = F_RP && (t.flags & CBH_MF_HAS_PARENT_ROLES) != 0;
   const bool has_rolepol = F_RP && (t.flags & CBH_MF_HAS_ROLE_POLICIES) != 0;
   const bool want_ps = o.policy != nullptr || o.scope != nullptr;
+  const bool want_ep = (FEAT & CBH_FEAT_TRAIL) != 0 && (flags & CBH_F_WANT_EFFECTIVE_POLICIES) != 0 && o.eff_pol != nullptr;   // cbh_check_batch_trail
 
   Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false; L.pid = pid; L.edr_errmask = 0;
   u64 edr_acc = 0;
@@ -855,6 +855,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                 }
                 // no binding for the resource, or no allow-action matched (index.go:436-461)
                 AM deny = in2 ? (AM)(S & ~any_mask) : (AM)0;
+                if (want_ep && deny != 0) ep_mark(o, b, L.req, rp.z & 0x0FFFFFFFu);   // the synthetic DENY is a binding of the role policy (check.go:302-304)
                 const u32 site_base = site_ctr;   // trace pass: a visit's place in the walk = its row's place in the bucket
                 AM cond_seen = 0; int cond_r = 0;   // trace pass: actions a key-sharing conditional rule was evaluated for, and what it gave
                 // (trace pass: the output-only rules that share a key come last, when every conditional rule has been seen;
@@ -875,6 +876,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                     mm &= S & ~deny;
                   }
                   if (wave_ballot(mm != 0) == 0) continue;
+                  if (want_ep && mm != 0) ep_mark(o, b, L.req, rp.z & 0x0FFFFFFFu);
                   const bool shares = (rr.allow_cnt & CBH_RP_F_SHARES_KEY) != 0;
                   // an action at or behind the first one an output-only rule of the same key is visited for finds
                   // "satisfied" cached (check.go:324): the synthetic DENY would fire whatever the condition says
@@ -962,6 +964,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
               DBG2_ACC(dbg_c);
               if (wave_ballot(need != 0) == 0) continue;
               const bool m = need != 0;
+              if (want_ep && m) ep_mark(o, b, L.req, rw.policy);   // the binding is iterated: its policy set is in effect (check.go:302-304)
               // A request meets the same record once per role it holds; its conditions read only the
               // request (and this scope's derived roles), so the first outcome is kept per lane for the
               // first 64 records of the walk and replayed - including the error status - afterwards.
@@ -1181,6 +1184,10 @@ CBH_DEFINE_CHECK_KERNELS(u64, CBH_FEAT_ALL, )       // everything, > 32 actions
 // the trace pass (cbh_trace_batch): everything, every condition through its trace program
 __global__ __launch_bounds__(CBH_BLOCK) void cbh_trace_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
   generic_kernel_body<u64, CBH_FEAT_ALL | CBH_FEAT_TRACE>(a, ka);
+}
+// cbh_check_batch_trail: everything, and which policies' bindings the walk iterates (ep_mark)
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_check_trail_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+  generic_kernel_body<u64, CBH_FEAT_ALL | CBH_FEAT_TRAIL>(a, ka);
 }
 // the leaf kernels of the four common table classes once more for batches with <= 4 actions per request
 #define CBH_DEFINE_LEAF_A4(FEAT, SUF)                                                                                          \

@@ -816,6 +816,49 @@ extern "C" int cbh_result_download(cbh_table* t, cbh_device_batch* b, cbh_result
 }
 
 
+// ---- engine.Check's second return value: the policies a call touched (AuditTrail.EffectivePolicies) ---------------------------
+extern "C" uint32_t cbh_table_num_policies(const cbh_table* t) { return t ? t->wire.n_policies : 0; }
+extern "C" int cbh_table_policy_key(const cbh_table* t, uint32_t i, const char** key, uint32_t* len) {
+  if (!t || !key || !len) return fail("null argument");
+  if (i >= t->wire.n_policies) return fail("policy index out of range");
+  *key = reinterpret_cast<const char*>(t->wire.name_bytes.data()) + t->wire.name_off[i];
+  *len = t->wire.name_off[i + 1] - t->wire.name_off[i];
+  return 0;
+}
+// cbh_check_batch with the trail: the batch goes through the resident path of device 0 (upload, the general walk with
+// CBH_F_WANT_EFFECTIVE_POLICIES, download) - the walk that iterates a request's roles one after the other as check.go:208-442
+// does, so that "touched" means what it means there.
+extern "C" int cbh_check_batch_trail(cbh_table* t, const cbh_batch* in, const cbh_params* p, cbh_result* out, const uint32_t* group_of_request,
+                                     uint32_t n_groups, uint32_t* effective_policies) {
+  if (!t || !in || !p || !out || !effective_policies) return fail("null argument");
+  if (n_groups == 0) n_groups = 1;
+  if (group_of_request) for (uint32_t r = 0; r < in->n_requests; ++r) if (group_of_request[r] >= n_groups) return fail("cbh_check_batch_trail: group index out of range");
+  const u32 words = (t->wire.n_policies + 31u) / 32u;
+  cbh_device_batch* b = nullptr;
+  if (cbh_batch_upload_on(t, 0, in, &b) != 0) return -1;
+  struct Release { cbh_device_batch* b; ~Release() { cbh_batch_release(b); } } release{b};
+  Replica* rep = b->rep;
+  HIPCHK(hipSetDevice(rep->device));
+  hipStream_t s = b->stream;
+  u32* d_ep = nullptr; u32* d_grp = nullptr;
+  const size_t ep_n = (size_t)n_groups * (words ? words : 1u);
+  if (dalloc(b, d_ep, ep_n) != 0) return -1;
+  HIPCHK(hipMemsetAsync(d_ep, 0, ep_n * 4, s));
+  if (group_of_request && in->n_requests) {
+    if (dalloc(b, d_grp, (size_t)in->n_requests) != 0) return -1;
+    HIPCHK(hipMemcpyAsync(d_grp, group_of_request, (size_t)in->n_requests * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));   // (a pageable source)
+  }
+  b->out.eff_pol = d_ep; b->out.ep_words = words; b->dev.ep_group = d_grp;
+  cbh_params q = *p;
+  q.flags |= CBH_F_WANT_EFFECTIVE_POLICIES;
+  if (cbh_check_resident(t, b, &q) != 0) return -1;
+  if (cbh_result_download(t, b, out) != 0) return -1;
+  if (words) HIPCHK(hipMemcpyAsync(effective_policies, d_ep, (size_t)n_groups * words * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return 0;
+}
+
 #ifndef CBH_WIRE_LDS_DEFAULT
 #define CBH_WIRE_LDS_DEFAULT 1
 #endif

@@ -92,12 +92,26 @@ struct BatchDev {
   CBH_G u64* gbits; // [3][n_strings], written by the resolve kernel
   CBH_G u64* gres;  // [n_gwords][n_requests] results of the evaluation sites (cbh_walk2_pre_kernel writes, cbh_walk2_kernel reads)
   u32 n_gwords; u32 n_gslots;   // words per request; sites filed = slots 0 .. n_gslots - 1
+  const CBH_G u32* ep_group;    // cbh_check_batch_trail: the group (Check call) request i belongs to, or null (one group)
 };
 
 struct OutDev {
   CBH_G u8* effect; CBH_G u32* policy; CBH_G u32* scope; CBH_G u8* status; CBH_G u64* edr;
-  CBH_G u32* trace_rec; CBH_G u32* trace_cnt; u32 trace_cap; u32 pad;   // the trace pass's log (cerbos_hip.h cbh_trace), else null
+  CBH_G u32* trace_rec; CBH_G u32* trace_cnt; u32 trace_cap; u32 ep_words;   // the trace pass's log (cerbos_hip.h cbh_trace), else null
+  // cbh_check_batch_trail: [groups][ep_words] bit p = some binding of policy p (cbh_table_policy_key) was iterated for a request of
+  // the group (check.go:302-304, the AuditTrail's effective policies); null = not wanted
+  CBH_G u32* eff_pol;
 };
+// (the general walk, which iterates bindings in the reference's order; idempotent: a stale read costs an atomic, never a bit)
+__device__ __forceinline__ void ep_mark(const OutDev& o, const BatchDev& b, u32 req, u32 policy) {
+  CBH_G u32* w = o.eff_pol + (size_t)(b.ep_group ? b.ep_group[req] : 0u) * o.ep_words + (policy >> 5);
+  const u32 bit = 1u << (policy & 31u);
+#ifdef CBH_HOSTSIM
+  *w |= bit;
+#else
+  if (!(*w & bit)) atomicOr((unsigned int*)w, bit);
+#endif
+}
 
 // Launch arguments of the decision kernel.  They live in device memory (one uniform pointer
 // as the only kernel argument) so that every table / batch base address is a scalar load.

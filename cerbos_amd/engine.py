@@ -54,6 +54,26 @@ class Conf:
         self.strict_evaluation = strict_evaluation
 
 
+def effective_policy_keys(policy_keys, mask_words):
+    """A row of ``cbh_check_batch_trail``'s masks -> the keys of AuditTrail.EffectivePolicies: the policies whose bit is set and, for a
+    scoped resource / principal policy, its ancestors among the table's policies - the source attributes a policy SET carries
+    (compile.go:153-180, 474-494; a role policy carries its own only, compile.go:116-117)."""
+    have = set(policy_keys)
+    out = set()
+    for i, key in enumerate(policy_keys):
+        if not (int(mask_words[i >> 5]) >> (i & 31)) & 1:
+            continue
+        out.add(key)
+        if "/" in key and not key.startswith("role."):
+            head, scope = key.split("/", 1)
+            while scope:
+                scope = scope.rpartition(".")[0]
+                anc = head + "/" + scope if scope else head
+                if anc in have:
+                    out.add(anc)
+    return sorted(out)
+
+
 class HipEvaluator:
     _ingest = None
     _py_flattener = None
@@ -294,6 +314,33 @@ class HipEvaluator:
             now_ns = time.time_ns()
         flags = capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0) | (capi.F_STRICT_EVALUATION if strict else 0)
         return self.table.wire_check_requests_pb(requests, aux, now_ns=now_ns, flags=flags, default_policy_version=dver, default_scope=dscope)
+
+    def effective_policies(self, inputs, now_ns=None, lenient_scope_search=None, strict_evaluation=None, default_policy_version=None,
+                           default_scope=None, globals_=None, per_input=False):
+        """``engine.Check``'s second return value for ``inputs`` as ONE call: the keys of AuditTrail.EffectivePolicies
+        (engine.go:289-338, check.go:302-304) - sorted; ``per_input``: one list per input instead of the call's union.
+        (``cbh_check_batch_trail``: the general walk decides the batch once more, in the reference's order of roles.)"""
+        conf = self.conf
+        lenient = conf.lenient_scope_search if lenient_scope_search is None else lenient_scope_search
+        strict = conf.strict_evaluation if strict_evaluation is None else strict_evaluation
+        dver = conf.default_policy_version if default_policy_version is None else default_policy_version
+        dscope = conf.default_scope if default_scope is None else default_scope
+        if now_ns is None:
+            now_ns = time.time_ns()
+        g = self._call_globals(globals_)
+        batch = self.flattener.flatten(inputs, dver, dscope) if g is None else self.flattener.flatten(inputs, dver, dscope, globals_=g)
+        flags = (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0) | (capi.F_STRICT_EVALUATION if strict else 0)
+        n = len(inputs)
+        groups = None
+        if per_input:   # device request i <- pre-sort (virtual) request <- the CheckInput it came from
+            pre = np.arange(batch.n_requests) if batch.req_perm is None else np.asarray(batch.req_perm)
+            groups = np.asarray(batch.vreq_input)[pre].astype(np.uint32)
+        _, masks = self._check_trail(batch, groups, n if per_input else 1, now_ns, flags)
+        keys = [effective_policy_keys(self.lt.policy_keys, row) for row in masks]
+        return keys if per_input else keys[0]
+
+    def _check_trail(self, batch, groups, n_groups, now_ns, flags):
+        return self.table.check_trail(batch, groups, n_groups, now_ns=now_ns, flags=flags)
 
     def _ingest_table(self):
         if self._ingest is None:

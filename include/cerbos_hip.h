@@ -48,6 +48,8 @@ extern "C" {
 #define CBH_F_LENIENT_SCOPE_SEARCH 1u /* EvalParams.LenientScopeSearch */
 #define CBH_F_STRICT_EVALUATION 2u    /* EvalParams.StrictEvaluation   */
 #define CBH_F_WANT_DERIVED_ROLES 4u   /* fill cbh_result.edr_mask (CheckOutput.effective_derived_roles) */
+#define CBH_F_WANT_EFFECTIVE_POLICIES 8u /* cbh_check_batch_trail: which policies' bindings were iterated (AuditTrail.EffectivePolicies); */
+                                         /* decided by the general walk, which iterates bindings in the reference's order */
 #define CBH_F_DEBUG_CYCLES 0x100u     /* profiling aid: policy words carry per-wave cycle counts, not policies */
 
 /* Per-request u32 fields, field-major: req_u32[field * n_requests + r]. */
@@ -308,6 +310,23 @@ int cbh_wire_check_pb(cbh_table* t, uint32_t device_index, const uint8_t* bytes,
                       const char* default_version, const char* default_scope, const uint8_t* globals_pb, size_t globals_len,
                       const cbh_params* p, uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags,
                       size_t* need, cbh_wire_info* info);
+
+/* ---- engine.Check's second return value (internal/engine/engine.go:217-240, 289-338): AuditTrail.EffectivePolicies ----
+ * The reference records, for every binding its walk ITERATES, the source attributes of that binding's policy set
+ * (check.go:302-304: the policy itself and, for a scoped resource / principal policy, its ancestors - compile.go:153-180) and
+ * merges the inputs' trails per call.  cbh_check_batch_trail is cbh_check_batch plus that: effective_policies is
+ * [n_groups][(cbh_table_num_policies + 31) / 32] words, bit p of group g set iff a binding of policy p was iterated for a request of
+ * the group (group_of_request[i] < n_groups; NULL = every request in group 0: one engine.Check call).  cbh_table_policy_key names
+ * policy p as namer.PolicyKeyFromFQN does ("resource.leave_request.vdefault/acme"); the keys a set bit stands for are that one
+ * and, for a scoped resource / principal policy, those of its ancestor scopes that are policies of the table (drop the last scope
+ * segment until none is left - cerbos_amd/engine.py effective_policy_keys is ten lines).  Decided by the general walk (the one that
+ * iterates a request's roles one after the other as the reference does - the faster kernels walk them side by side and would also
+ * touch what a role BEHIND the allowing one reaches): an audit-enabled caller pays that kernel's rate.  Device 0. */
+#define CBH_HAS_CHECK_BATCH_TRAIL 1
+uint32_t cbh_table_num_policies(const cbh_table* t);
+int cbh_table_policy_key(const cbh_table* t, uint32_t i, const char** key, uint32_t* len);
+int cbh_check_batch_trail(cbh_table* t, const cbh_batch* in, const cbh_params* p, cbh_result* out, const uint32_t* group_of_request,
+                          uint32_t n_groups, uint32_t* effective_policies);
 
 /* The device road for what the SERVER receives (internal/svc/cerbos_svc.go:255-344): `bytes` / `offsets` hold n_requests serialized
  * cerbos.request.v1.CheckResourcesRequest messages (request.proto:222-273).  Every resource entry becomes the CheckInput that

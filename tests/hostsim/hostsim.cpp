@@ -172,6 +172,7 @@ static void run_block(uint32_t blk) {
   }
 }
 
+static uint32_t* g_ep = nullptr; static uint32_t g_ep_words = 0; static const uint32_t* g_ep_group = nullptr;   // hostsim_check_trail
 // gbits: [3][n_strings] glob match bits of the batch-local strings (computed by the caller with the
 // Python simulation of the same automaton).
 static int run_sim(const void* blob, size_t len, const cbh_batch* in, const cbh_params* p, cbh_result* out, uint64_t* gbits, cbh_trace* trace) {
@@ -191,6 +192,7 @@ static int run_sim(const void* blob, size_t len, const cbh_batch* in, const cbh_
   if (!b.roles) b.roles = none;
   if (!b.tuple_action) b.tuple_action = none;
   a.o = OutDev{out->effect, out->policy, out->scope, out->status, out->edr_mask, nullptr, nullptr, 0, 0};
+  a.o.eff_pol = g_ep; a.o.ep_words = g_ep_words; b.ep_group = g_ep_group;   // hostsim_check_trail (else null)
   g_trace = trace != nullptr;
   if (trace) {
     if (!a.t.trace_pool) { g_err = "the table was lowered without the trace sections"; return -1; }
@@ -263,6 +265,17 @@ static int run_sim(const void* blob, size_t len, const cbh_batch* in, const cbh_
 extern "C" int hostsim_check(const void* blob, size_t len, const cbh_batch* in, const cbh_params* p,
                              cbh_result* out, uint64_t* gbits) {
   return run_sim(blob, len, in, p, out, gbits, nullptr);
+}
+// cbh_check_batch_trail on the simulator: effective_policies [n_groups][(policies + 31) / 32], zeroed here (cerbos_hip.h)
+extern "C" int hostsim_check_trail(const void* blob, size_t len, const cbh_batch* in, const cbh_params* p, cbh_result* out, uint64_t* gbits,
+                                   const uint32_t* group_of_request, uint32_t n_groups, uint32_t n_policies, uint32_t* effective_policies) {
+  const uint32_t words = (n_policies + 31u) / 32u;
+  std::memset(effective_policies, 0, (size_t)(n_groups ? n_groups : 1u) * words * 4u);
+  g_ep = effective_policies; g_ep_words = words; g_ep_group = group_of_request;
+  cbh_params q = *p; q.flags |= CBH_F_WANT_EFFECTIVE_POLICIES;
+  const int rc = run_sim(blob, len, in, &q, out, gbits, nullptr);
+  g_ep = nullptr; g_ep_words = 0; g_ep_group = nullptr;
+  return rc;
 }
 extern "C" int hostsim_last_kind() { return g_last_kind; }
 extern "C" int hostsim_last_masks() { return g_last_masks ? 1 : 0; }   // did the last batch take the flat kernel's mask walk?

@@ -68,6 +68,26 @@ def check(lt, batch, now_ns=0, flags=0, device_order=False):
     return res if device_order else res.to_input_order(batch)
 
 
+def check_trail(lt, batch, groups=None, n_groups=1, now_ns=0, flags=0):
+    """cbh_check_batch_trail on the simulator -> (Result in device order, masks uint32[n_groups][words]); ``groups``: group of every
+    request of ``batch`` (device order), or None = one group."""
+    res = capi.Result(batch.n_tuples, batch.n_requests, ("policy", "scope", "status", "edr"))
+    cb = capi.make_cbatch(batch, len(lt.columns))
+    p = capi.CParams(now_ns, flags, 0)
+    g = batch_gbits(lt, batch)
+    buf = C.create_string_buffer(lt.blob, len(lt.blob))
+    n_pol = len(lt.policy_keys)
+    words = (n_pol + 31) // 32
+    masks = np.zeros((max(n_groups, 1), max(words, 1)), dtype=np.uint32)
+    grp = None if groups is None else np.ascontiguousarray(groups, dtype=np.uint32)
+    lib().hostsim_check_trail.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    rc = lib().hostsim_check_trail(C.cast(buf, C.c_void_p), len(lt.blob), C.byref(cb), C.byref(p), C.byref(res.c), g.ctypes.data_as(C.c_void_p),
+                                   grp.ctypes.data if grp is not None else None, n_groups, n_pol, masks.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(lib().hostsim_last_error().decode())
+    return res, masks[:, :words]
+
+
 def last_kind():
     """Which kernel family decided the last batch: 0 the general walk, 1 a flat kernel, 2 cbh_walk2_kernel."""
     return lib().hostsim_last_kind()

@@ -1,0 +1,82 @@
+"""AuditTrail.EffectivePolicies (engine.go:289-338, check.go:302-304) on the simulator: cbh_check_batch_trail's masks -> keys, against
+the reference's own decision logs (the engine goldens: the call's union), against the oracle input by input (goldens, fuzz stores,
+the synthetic configurations), and the decisions of that walk against the ordinary road's."""
+import numpy as np
+import pytest
+
+import hostsim_api
+from cerbos_amd import capi
+from cerbos_amd.engine import Conf, effective_policy_keys
+from cerbos_amd.flatten import Flattener
+from cerbos_amd.lower.blob import lower_rule_table
+from cerbos_amd.policy.loader import policies_from_docs
+from cerbos_amd.ruletable.build import rule_table_from_policies
+from helpers import load_json, store_rule_table
+from oracle.check import EvalParams, RuleTableOracle
+from test_fuzz_parity import _policies, _requests
+from test_hostsim_golden import GLOBALS, HostSimEvaluator
+
+NOW = 1_700_000_000_000_000_000
+CASES = [c for c in load_json("engine_cases.json") if c["hasDecisionLogs"] and not c["wantError"]]
+
+
+@pytest.fixture(scope="module")
+def store():
+    rt = store_rule_table()
+    lt = lower_rule_table(rt, GLOBALS)
+    return HostSimEvaluator(lt, Conf(globals_=GLOBALS)), RuleTableOracle(rt)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_the_reference_s_decision_logs(store, case):
+    ev, oracle = store
+    for lenient in ([False, True] if case["lenient"] is None else [case["lenient"]]):
+        have = ev.effective_policies(case["inputs"], now_ns=NOW, lenient_scope_search=lenient)
+        assert have == case["wantEffectivePolicies"], (case["name"], lenient)
+        per_input = ev.effective_policies(case["inputs"], now_ns=NOW, lenient_scope_search=lenient, per_input=True)
+        params = EvalParams(globals_=GLOBALS, now_ns=NOW, lenient_scope_search=lenient)
+        assert per_input == [oracle.check(i, params)["effectivePolicies"] for i in case["inputs"]]
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_all_golden_inputs_in_one_batch_by_input(store, strict):
+    """Every input of every case as ONE device batch, grouped per input (what a coalescer in front of many calls does)."""
+    ev, oracle = store
+    inputs = [i for c in CASES for i in c["inputs"]]
+    for lenient in (False, True):
+        have = ev.effective_policies(inputs, now_ns=NOW, lenient_scope_search=lenient, strict_evaluation=strict, per_input=True)
+        params = EvalParams(globals_=GLOBALS, now_ns=NOW, lenient_scope_search=lenient, strict_evaluation=strict)
+        want = [oracle.check(i, params)["effectivePolicies"] for i in inputs]
+        assert have == want, [k for k in range(len(inputs)) if have[k] != want[k]][:5]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_stores_by_input(seed):
+    """Generated stores (scopes, scope permissions, derived roles, role policies with parent roles, principal policies, globs)."""
+    rng = np.random.default_rng(100 + seed)
+    rt = rule_table_from_policies(policies_from_docs(_policies(rng)))
+    lt = lower_rule_table(rt)
+    ev, oracle = HostSimEvaluator(lt, Conf()), RuleTableOracle(rt)
+    inputs = _requests(rng, 300)
+    for lenient in (False, True):
+        have = ev.effective_policies(inputs, now_ns=NOW, lenient_scope_search=lenient, per_input=True)
+        params = EvalParams(now_ns=NOW, lenient_scope_search=lenient)
+        want = [oracle.check(i, params)["effectivePolicies"] for i in inputs]
+        bad = [k for k in range(len(inputs)) if have[k] != want[k]]
+        assert not bad, (seed, lenient, bad[:3], have[bad[0]], want[bad[0]], inputs[bad[0]])
+    assert any(len(k) > 1 for k in have)
+
+
+def test_the_trail_s_walk_decides_like_the_ordinary_road(store):
+    ev, _ = store
+    lt = ev.lt
+    inputs = [i for c in CASES for i in c["inputs"]]
+    batch = Flattener(lt).flatten(inputs, "default", "")
+    want = hostsim_api.check(lt, batch, NOW, capi.F_WANT_DERIVED_ROLES, device_order=True)
+    have, masks = hostsim_api.check_trail(lt, batch, None, 1, NOW, capi.F_WANT_DERIVED_ROLES)
+    assert hostsim_api.last_kind() == 0          # the general walk
+    for f in ("effect", "policy", "scope", "edr"):
+        assert np.array_equal(getattr(have, f), getattr(want, f)), f
+    # one group: the union of what the cases that run without lenient scope search log
+    want_keys = {k for c in CASES if not c["lenient"] for k in c["wantEffectivePolicies"]}
+    assert want_keys <= set(effective_policy_keys(lt.policy_keys, masks[0]))

@@ -33,6 +33,9 @@ class HostSimEvaluator(HipEvaluator):
             def trace(_self, batch, now_ns=0, flags=0, capacity=None):
                 return hostsim_api.trace(lt, batch, now_ns, flags, capacity)
 
+            def check_trail(_self, batch, groups=None, n_groups=1, now_ns=0, flags=0, want=()):
+                return hostsim_api.check_trail(lt, batch, groups, n_groups, now_ns, flags)
+
             # the device road of check_pb (cbh_wire.h) on the simulator: the GPU's flattener, decision and assembler kernels
             def wire_flatten(_self, data, offsets, default_policy_version="default", default_scope="", device_index=0, globals_pb=b""):
                 import wire_device_util as wu

@@ -34,6 +34,13 @@ def test_engine_case(oracle, case):
             have_outs = sorted(have["outputs"], key=lambda o: o["src"])
             if "output_now" not in case["name"]:
                 assert have_outs == want_outs
+        # the call's AuditTrail.EffectivePolicies (engine.go:289-338 merges the inputs' trails; check.go:302-304): the keys of the
+        # case's decision log
+        if case["hasDecisionLogs"] and not case["wantError"]:
+            touched = set()
+            for inp in case["inputs"]:
+                touched.update(oracle.check(inp, params)["effectivePolicies"])
+            assert sorted(touched) == case["wantEffectivePolicies"], (case["name"], lenient)
 
 
 SERVER_CASES = load_json("server_check_cases.json")

@@ -1,0 +1,77 @@
+"""GPU tier (sorts last - written after the round's GPU minutes were spent): cbh_check_batch_trail through the C ABI -
+AuditTrail.EffectivePolicies against the reference's decision logs (engine goldens), against the oracle input by input (goldens,
+fuzz stores, C5 at size) and the trail walk's decisions against cbh_check_batch's."""
+import numpy as np
+import pytest
+
+from cerbos_amd import capi, workloads
+from cerbos_amd.engine import Conf, HipEvaluator, effective_policy_keys
+from cerbos_amd.flatten import Flattener
+from cerbos_amd.lower.blob import lower_rule_table
+from cerbos_amd.policy.loader import policies_from_docs
+from cerbos_amd.ruletable.build import rule_table_from_policies
+from helpers import load_json, store_rule_table
+from oracle.check import EvalParams, RuleTableOracle
+from test_fuzz_parity import _policies, _requests
+from test_hostsim_golden import GLOBALS
+
+pytestmark = pytest.mark.gpu
+NOW = 1_700_000_000_000_000_000
+CASES = [c for c in load_json("engine_cases.json") if c["hasDecisionLogs"] and not c["wantError"]]
+
+
+def test_the_reference_s_decision_logs_and_the_oracle_by_input():
+    rt = store_rule_table()
+    ev, oracle = HipEvaluator(lower_rule_table(rt, GLOBALS), Conf(globals_=GLOBALS)), RuleTableOracle(rt)
+    try:
+        assert ev.table.policy_keys() == ev.lt.policy_keys
+        for case in CASES:
+            for lenient in ([False, True] if case["lenient"] is None else [case["lenient"]]):
+                assert ev.effective_policies(case["inputs"], now_ns=NOW, lenient_scope_search=lenient) == case["wantEffectivePolicies"], case["name"]
+        inputs = [i for c in CASES for i in c["inputs"]]
+        for lenient, strict in ((False, False), (True, False), (False, True)):
+            have = ev.effective_policies(inputs, now_ns=NOW, lenient_scope_search=lenient, strict_evaluation=strict, per_input=True)
+            params = EvalParams(globals_=GLOBALS, now_ns=NOW, lenient_scope_search=lenient, strict_evaluation=strict)
+            assert have == [oracle.check(i, params)["effectivePolicies"] for i in inputs]
+    finally:
+        ev.close()
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_fuzz_stores_by_input(seed):
+    rng = np.random.default_rng(100 + seed)
+    rt = rule_table_from_policies(policies_from_docs(_policies(rng)))
+    ev, oracle = HipEvaluator(lower_rule_table(rt), Conf()), RuleTableOracle(rt)
+    try:
+        inputs = _requests(rng, 600)
+        have = ev.effective_policies(inputs, now_ns=NOW, per_input=True)
+        params = EvalParams(now_ns=NOW)
+        assert have == [oracle.check(i, params)["effectivePolicies"] for i in inputs]
+    finally:
+        ev.close()
+
+
+def test_c5_at_size_groups_and_decisions():
+    rt = rule_table_from_policies(policies_from_docs(workloads.c5_policies()))
+    lt = lower_rule_table(rt)
+    n = 20_000
+    inputs = workloads.c5_requests(n_requests=n).to_inputs()
+    batch = Flattener(lt).flatten(inputs, "default", "")
+    pre = np.arange(batch.n_requests) if batch.req_perm is None else np.asarray(batch.req_perm)
+    groups = (np.asarray(batch.vreq_input)[pre] % 97).astype(np.uint32)          # 97 "calls" mixed through the batch
+    table = capi.Table(lt.blob)
+    try:
+        want = table.check(batch, now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES, device_order=True)
+        have, masks = table.check_trail(batch, groups, 97, now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES)
+        for f in ("effect", "policy", "scope", "edr"):
+            assert np.array_equal(getattr(have, f), getattr(want, f)), f
+        oracle, params = RuleTableOracle(rt), EvalParams(now_ns=NOW)
+        want_keys = [set() for _ in range(97)]
+        for k in range(0, n, 7):                                                  # a seventh of the inputs through the oracle: a lower bound per group
+            want_keys[k % 97].update(oracle.check(inputs[k], params)["effectivePolicies"])
+        for g in range(97):
+            assert want_keys[g] <= set(effective_policy_keys(lt.policy_keys, masks[g]))
+        every = set().union(*(set(effective_policy_keys(lt.policy_keys, m)) for m in masks))
+        assert every <= set(lt.policy_keys) and len(every) > 1
+    finally:
+        table.close()

@@ -16,8 +16,9 @@ Sources (data fixtures, not code):
                                                         that need neither JWT verification nor schema rejection
   internal/engine/testdata/policy_template.yaml.gotmpl  BenchmarkEvaluator policy family (rendered for N=0..1)
 
-The YAML is parsed and re-emitted as compact JSON (decision logs dropped: audit is out of
-scope), so the fixtures travel to the GPU box without the reference tree.
+The YAML is parsed and re-emitted as compact JSON (of the decision logs only the keys of
+auditTrail.effectivePolicies are kept: audit is out of scope, which policies a call touched is
+not), so the fixtures travel to the GPU box without the reference tree.
 """
 from __future__ import annotations
 
@@ -83,6 +84,11 @@ def engine_cases(subdir, lenient):
             "wantError": bool(doc.get("wantError", False)),
             "inputs": [_norm_input(i) for i in doc.get("inputs") or []],
             "wantOutputs": [_norm_output(o) for o in doc.get("wantOutputs") or []],
+            # the call's AuditTrail.EffectivePolicies (engine.go:242-287; check.go:302-304): the policy keys only - the attributes
+            # (driver, source file) are the store's
+            "wantEffectivePolicies": sorted({k for log in doc.get("wantDecisionLogs") or []
+                                            for k in ((log.get("auditTrail") or {}).get("effectivePolicies") or {})}),
+            "hasDecisionLogs": bool(doc.get("wantDecisionLogs")),
         })
     return out
 
