@@ -44,6 +44,14 @@ class FoldError(Exception):
     """Evaluating the constant expression is a CEL error: it is left to the device."""
 
 
+class Unknown(NotConst):
+    """The expression reads a part of the request the caller has not given (the query planner's unknown resource attributes)."""
+
+
+class PartialMap(dict):
+    """A map of which only some keys are known (cerbos_amd/plan): a key it does not hold is unknown, not absent."""
+
+
 class UInt(int):
     pass
 
@@ -169,11 +177,15 @@ def _map_get(m, k):
         for mk, mv in m.items():
             if type(mk) is type(k) and mk == k:
                 return True, mv
+        if isinstance(m, PartialMap):
+            raise Unknown(str(k))
         return False, None
     if _is_num(k):
         for mk, mv in m.items():
             if _is_num(mk) and _num_cmp(mk, k) == 0:
                 return True, mv
+    if isinstance(m, PartialMap):
+        raise Unknown(str(k))
     return False, None
 
 

@@ -1,0 +1,2 @@
+"""PlanResources (internal/ruletable/plan.go, internal/ruletable/planner): the query planner over the rule table."""
+from .planner import Planner, StrictEvaluationError  # noqa: F401

@@ -1,0 +1,181 @@
+"""Partial evaluation of a CEL condition for the query planner: everything the request gives - principal, globals, constants, the
+resource's kind / scope / the attributes the caller did supply - is evaluated, what reads the resource's unknown attributes is kept as
+a RESIDUAL expression.  What the reference does with cel-go's partial evaluation and AST pruning
+(internal/ruletable/planner/planner.go:370-470 evaluateConditionExpression / evalPartially / residualExpr): a known sub-expression
+becomes its value; `&&` / `||` / the ternary collapse where a known operand decides them; everything else keeps its shape with its
+known parts replaced by literals.  The evaluator of known parts is the lowering's constant folder (cerbos_amd/cel/fold.py)."""
+from __future__ import annotations
+
+from ..cel import fold
+from ..cel.fold import FoldError, NotConst, PartialMap, Unknown, to_ast
+
+
+class CelEvalError(Exception):
+    """A known (sub-)expression fails to evaluate: the condition is false, its error reported (planner.go:404-413)."""
+
+
+_ABBREV = {"R": ("request", "resource"), "P": ("request", "principal"), "G": ("globals",), "C": ("constants",), "V": ("variables",)}
+
+
+def to_cel(v, partial_paths=()):
+    """JSON-shaped value -> the folder's values (numbers are doubles: structpb)."""
+    if isinstance(v, bool) or v is None or isinstance(v, str):
+        return v
+    if isinstance(v, (int, float)):
+        return float(v)
+    if isinstance(v, list):
+        return [to_cel(x) for x in v]
+    if isinstance(v, dict):
+        return {str(k): to_cel(x) for k, x in v.items()}
+    raise TypeError(type(v).__name__)
+
+
+def request_env(principal, resource, aux_data, globals_, constants):
+    """The identifiers a condition can read (conditions/cel.go:30-63): request / R / P / G / C and their long names."""
+    p = {"id": principal.get("id", ""), "roles": list(principal.get("roles") or []), "attr": to_cel(principal.get("attr") or {}),
+         "policyVersion": principal.get("policyVersion", ""), "scope": principal.get("scope", "")}
+    r = PartialMap({"kind": resource.get("kind", ""), "policyVersion": resource.get("policyVersion", ""), "scope": resource.get("scope", ""),
+                    "attr": PartialMap(to_cel(resource.get("attr") or {}))})
+    req = {"principal": p, "resource": r, "auxData": {"jwt": to_cel(((aux_data or {}).get("jwt")) or {})}}
+    req["aux_data"] = req["auxData"]
+    g, c = to_cel(globals_ or {}), to_cel_consts(constants or {})
+    return {"request": req, "R": r, "P": p, "G": g, "globals": g, "C": c, "constants": c}
+
+
+def to_cel_consts(consts):
+    return to_cel(consts)
+
+
+def substitute(n, repl):
+    """Replace sub-trees: `repl(node)` -> a tree, or None to descend."""
+    r = repl(n)
+    if r is not None:
+        return r
+    kids = fold._children(n)
+    if not kids:
+        return n
+    return fold._rebuild(n, [substitute(c, repl) for c in kids])
+
+
+def inline_variables(n, variables):
+    """V.x / variables.x -> the variable's expression (planner ast.go:235-254 replaceVars); a name a comprehension binds shadows nothing
+    here: variables are selected from V / variables."""
+    def repl(x):
+        if x[0] == "select" and x[1][0] == "ident" and x[1][1] in ("V", "variables") and x[2] in variables:
+            return variables[x[2]]
+        return None
+    return substitute(n, repl)
+
+
+class Partial:
+    def __init__(self, env, now_ns=None):
+        self.env = env
+        self.now_ns = now_ns
+
+    # -> ("k", value) | ("r", ast)
+    def pe(self, n, env=None):   # noqa: C901
+        env = self.env if env is None else env
+        k = n[0]
+        if k == "lit":
+            return ("k", fold._Eval().ev(n, env))
+        try:
+            v = fold._Eval().ev(n, env)
+            if isinstance(v, PartialMap):
+                return ("r", n)      # the request's partly known parts stay paths
+            return ("k", v)
+        except Unknown:
+            pass
+        except NotConst:
+            pass
+        except FoldError as e:
+            if not self._reads_unknown(n, env):
+                raise CelEvalError(str(e))
+        except (RecursionError, OverflowError, ValueError) as e:
+            raise CelEvalError(str(e))
+        # structural
+        if k in ("and", "or"):
+            a, b = self.pe_guard(n[1], env), self.pe_guard(n[2], env)
+            absorbing = (k == "or")
+            for x, other in ((a, b), (b, a)):
+                if x[0] == "k" and isinstance(x[1], bool):
+                    if x[1] == absorbing:
+                        return ("k", absorbing)
+                    return other if other[0] != "e" else self._raise(other)
+            if a[0] == "e" and b[0] == "e":
+                self._raise(a)
+            # an error beside an unknown: cel-go keeps the unknown (the error may be absorbed); the planner keeps the residual of the other
+            if a[0] == "e":
+                return b
+            if b[0] == "e":
+                return a
+            return ("r", (k, self.ast(a), self.ast(b)))
+        if k == "not":
+            a = self.pe(n[1], env)
+            if a[0] == "k":
+                if not isinstance(a[1], bool):
+                    raise CelEvalError("no such overload")
+                return ("k", not a[1])
+            return ("r", ("not", a[1]))
+        if k == "tern":
+            c = self.pe(n[1], env)
+            if c[0] == "k":
+                if not isinstance(c[1], bool):
+                    raise CelEvalError("no such overload")
+                return self.pe(n[2] if c[1] else n[3], env)
+            return ("r", ("tern", c[1], self.ast(self.pe(n[2], env)), self.ast(self.pe(n[3], env))))
+        if k == "bind":
+            init = self.pe(n[2], env)
+            if init[0] == "k":
+                return self.pe(n[3], dict(env, **{n[1]: init[1]}))
+            body = substitute(n[3], lambda x: init[1] if x == ("ident", n[1]) else None)
+            return self.pe(body, env)
+        if k == "comp":
+            return self.comp(n, env)
+        if k == "ident":
+            return ("r", n)
+        kids = fold._children(n)
+        if k == "call" and n[2] is not None and n[2][0] == "ident" and n[2][1] not in env and n[2][1] in (
+                "sets", "math", "lists", "base64", "strings", "regex", "optional", "ip", "cidr"):
+            new = [n[2]] + [self.ast(self.pe(c, env)) for c in kids[1:]]     # a namespace, not a value
+        else:
+            new = [self.ast(self.pe(c, env)) for c in kids]
+        return ("r", fold._rebuild(n, new))
+
+    def pe_guard(self, n, env):
+        try:
+            return self.pe(n, env)
+        except CelEvalError as e:
+            return ("e", e)
+
+    @staticmethod
+    def _raise(x):
+        raise x[1]
+
+    def ast(self, x):
+        if x[0] == "r":
+            return x[1]
+        lit = to_ast(x[1])
+        if lit is None:
+            raise CelEvalError("a value without a literal form in a residual expression")
+        return lit
+
+    def _reads_unknown(self, n, env):
+        """Does the expression touch an unknown part of the request?  (An evaluation error in a sub-expression that does not is the
+        condition's; one that does may only be the evaluator giving up on a partial value.)"""
+        if n[0] in ("select", "index", "has"):
+            try:
+                fold._Eval().ev(n, env)
+            except Unknown:
+                return True
+            except Exception:
+                pass
+        return any(self._reads_unknown(c, env) for c in fold._children(n))
+
+    def comp(self, n, env):
+        """A comprehension over an unknown range stays a comprehension: its range and its body partially evaluated with the iteration
+        variables unknown (planner.go:598-650 evalComprehensionBody)."""
+        _, kind, target, vars_, args = n
+        rng = self.pe(target, env)
+        inner = {k: v for k, v in env.items() if k not in vars_}
+        new_args = tuple(self.ast(self.pe(a, inner)) for a in args)
+        return ("r", ("comp", kind, self.ast(rng), vars_, new_args))

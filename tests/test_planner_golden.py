@@ -1,0 +1,63 @@
+"""PlanResources against the reference's query-planner suites (internal/test/testdata/query_planner: 27 suites, 116 plans;
+engine_test.go:420-495 TestQueryPlan): the filter of every (principal, action(s), resource kind) compared as the reference compares
+it - operands of every expression in any order (protocmp.SortRepeatedFields on "operands", engine_test.go:486-488)."""
+import json
+
+import pytest
+
+from cerbos_amd.plan import Planner
+from cerbos_amd.policy.loader import policies_from_docs
+from cerbos_amd.ruletable.build import rule_table_from_policies
+from helpers import load_json
+
+DATA = load_json("planner_cases.json")
+NOW = 1705353507395000000            # 2024-01-16T10:18:27.395+13:00 (engine_test.go:448)
+AUX = {"jwt": {"customInt": 42}}     # engine_test.go:424-425
+CASES = [(s, k) for s in DATA["suites"] for k in range(len(s["tests"]))]
+
+
+@pytest.fixture(scope="module")
+def planner():
+    return Planner(rule_table_from_policies(policies_from_docs(DATA["policies"])))
+
+
+def canon(op):
+    """Operands in any order, numbers as doubles."""
+    if op is None:
+        return None
+    if "expression" in op:
+        e = op["expression"]
+        kids = sorted((canon(o) for o in e.get("operands") or []), key=lambda x: json.dumps(x, sort_keys=True))
+        return {"expression": {"operator": e["operator"], "operands": kids}}
+    if "value" in op:
+        return {"value": _num(op["value"])}
+    return {"variable": op["variable"]}
+
+
+def _num(v):
+    if isinstance(v, bool) or v is None or isinstance(v, str):
+        return v
+    if isinstance(v, (int, float)):
+        return float(v)
+    if isinstance(v, list):
+        return [_num(x) for x in v]
+    return {k: _num(x) for k, x in v.items()}
+
+
+def run(planner, suite, test, lenient):
+    inp = {"requestId": "requestId", "principal": suite["principal"], "resource": test["resource"], "actions": test["actions"], "auxData": AUX}
+    return planner.plan(inp, lenient_scope_search=lenient, now_ns=NOW)
+
+
+@pytest.mark.parametrize("suite,k", CASES, ids=["%s-%d" % (s["name"], k) for s, k in CASES])
+def test_plan(planner, suite, k):
+    test = suite["tests"][k]
+    for lenient in ([False, True] if suite["lenient"] is None else [suite["lenient"]]):
+        if test["wantErr"]:
+            with pytest.raises(Exception):
+                run(planner, suite, test, lenient)
+            continue
+        have = run(planner, suite, test, lenient)["filter"]
+        want = test["want"]
+        assert have["kind"] == want.get("kind"), (test["actions"], have)
+        assert canon(have.get("condition")) == canon(want.get("condition")), (test["actions"], json.dumps(have.get("condition")))

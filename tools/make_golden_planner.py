@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/planner_cases.json from the reference's query-planner fixtures (data, not code):
+
+  internal/test/testdata/query_planner/policies/**     the policies TestQueryPlan loads (engine_test.go:420-422)
+  internal/test/testdata/query_planner/suite/{common,strict_scope_search,lenient_scope_search}/*.yaml
+                                                        QueryPlannerTestSuite files: a principal and tests of (action(s), resource,
+                                                        wanted filter) - engine_test.go:427-495
+
+Run in the build container (needs /root/reference):   python tools/make_golden_planner.py
+YAML anchors / merge keys are resolved by the loader; the wanted filters are kept as written (operand order is free: the
+reference's own comparison sorts the operands of every expression, engine_test.go:486-488)."""
+from __future__ import annotations
+
+import glob
+import json
+import os
+import sys
+
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from cerbos_amd.policy.loader import load_policy_dir  # noqa: E402
+
+TD = "/root/reference/internal/test/testdata/query_planner"
+OUT = os.path.join(ROOT, "tests/golden/planner_cases.json")
+
+
+def main():
+    pols = load_policy_dir(os.path.join(TD, "policies"))
+    suites = []
+    for mode, sub in ((None, "common"), (False, "strict_scope_search"), (True, "lenient_scope_search")):
+        for p in sorted(glob.glob(os.path.join(TD, "suite", sub, "*.yaml"))):
+            with open(p, encoding="utf-8") as f:
+                doc = yaml.safe_load(f.read())
+            tests = []
+            for t in doc.get("tests") or []:
+                tests.append({"actions": t["actions"] if t.get("actions") is not None else [t.get("action", "")],
+                              "resource": t.get("resource") or {}, "want": t.get("want") or {}, "wantErr": bool(t.get("wantErr", False))})
+            suites.append({"name": "%s/%s" % (sub, os.path.basename(p)[:-5]), "lenient": mode, "description": doc.get("description", ""),
+                           "principal": doc.get("principal") or {}, "tests": tests})
+    with open(OUT, "w", encoding="utf-8") as f:
+        json.dump({"policies": [pols[k] for k in sorted(pols)], "suites": suites}, f, sort_keys=True, separators=(",", ":"), ensure_ascii=False)
+        f.write("\n")
+    print("wrote", OUT, os.path.getsize(OUT), "bytes;", len(suites), "suites,", sum(len(s["tests"]) for s in suites), "tests")
+
+
+if __name__ == "__main__":
+    main()
