@@ -10,6 +10,135 @@ from ..cel import fold
 from ..cel.fold import FoldError, NotConst, PartialMap, Unknown, to_ast
 
 
+class Ts(int):
+    """google.protobuf.Timestamp: nanoseconds since the epoch"""
+
+
+class Dur(int):
+    """google.protobuf.Duration: nanoseconds"""
+
+
+_UNITS = {"ns": 1, "us": 1000, "\u00b5s": 1000, "ms": 10**6, "s": 10**9, "m": 60 * 10**9, "h": 3600 * 10**9}
+
+
+def parse_duration(text):
+    """Go's time.ParseDuration: [-+]?([0-9]*(\.[0-9]*)?[a-z]+)+"""
+    import re
+    m = re.fullmatch(r"([+-])?((?:\d*\.?\d*(?:ns|us|\u00b5s|ms|s|m|h))+)", text)
+    if not m or not text.strip("+-"):
+        raise FoldError("invalid duration")
+    total = 0
+    for num, unit in re.findall(r"(\d*\.?\d*)(ns|us|\u00b5s|ms|s|m|h)", m.group(2)):
+        if num in ("", "."):
+            raise FoldError("invalid duration")
+        total += int(round(float(num) * _UNITS[unit]))
+    return Dur(-total if m.group(1) == "-" else total)
+
+
+def parse_timestamp(text):
+    import re
+    from datetime import datetime, timedelta, timezone
+    m = re.fullmatch(r"(\d{4})-(\d\d)-(\d\d)[Tt](\d\d):(\d\d):(\d\d)(\.\d+)?([Zz]|[+-]\d\d:\d\d)", text)
+    if not m:
+        raise FoldError("invalid timestamp")
+    y, mo, d, h, mi, sec = (int(m.group(i)) for i in range(1, 7))
+    frac = int(((m.group(7) or ".0")[1:] + "000000000")[:9])
+    tz = m.group(8)
+    off = 0
+    if tz not in ("Z", "z"):
+        off = (int(tz[1:3]) * 60 + int(tz[4:6])) * (1 if tz[0] == "+" else -1)
+    try:
+        base = datetime(y, mo, d, h, mi, sec, tzinfo=timezone.utc) - timedelta(minutes=off)
+    except ValueError:
+        raise FoldError("invalid timestamp")
+    return Ts(int((base - datetime(1970, 1, 1, tzinfo=timezone.utc)).total_seconds()) * 10**9 + frac)
+
+
+def format_duration(d):
+    sec, ns = divmod(abs(int(d)), 10**9)
+    body = "%d" % sec if ns == 0 else ("%d.%09d" % (sec, ns)).rstrip("0")
+    return ("-" if d < 0 else "") + body + "s"
+
+
+def format_timestamp(t):
+    from datetime import datetime, timezone
+    sec, ns = divmod(int(t), 10**9)
+    base = datetime.fromtimestamp(sec, tz=timezone.utc).strftime("%Y-%m-%dT%H:%M:%S")
+    frac = ("." + ("%09d" % ns).rstrip("0")) if ns else ""
+    return base + frac + "Z"
+
+
+class _Eval(fold._Eval):
+    """The constant folder plus what only a request has: the call's clock, timestamps and durations (conditions/cerbos_lib.go now /
+    timeSince; cel-go's timestamp / duration conversions and arithmetic)."""
+
+    def __init__(self, now_ns):
+        super().__init__()
+        self.now_ns = now_ns
+
+    def call(self, n, env):
+        _, name, target, args = n
+        if target is None:
+            if name == "now" and not args and self.now_ns is not None:
+                return Ts(self.now_ns)
+            if name in ("timestamp", "duration", "timeSince") and len(args) == 1:
+                v = self.ev(args[0], env)
+                if name == "timestamp":
+                    return v if isinstance(v, Ts) else parse_timestamp(fold._need(v, str))
+                if name == "duration":
+                    return v if isinstance(v, Dur) else parse_duration(fold._need(v, str))
+                if self.now_ns is None:
+                    raise NotConst("now")
+                return Dur(self.now_ns - fold._need(v, Ts))
+        elif name == "timeSince" and not args and self.now_ns is not None:
+            return Dur(self.now_ns - fold._need(self.ev(target, env), Ts))
+        return super().call(n, env)
+
+    def binop(self, op, a, b):
+        ta, tb = isinstance(a, (Ts, Dur)), isinstance(b, (Ts, Dur))
+        if ta or tb:
+            if op in ("==", "!="):
+                eq = type(a) is type(b) and int(a) == int(b)
+                return eq if op == "==" else not eq
+            if type(a) is type(b) and op in ("<", "<=", ">", ">="):
+                x, y = int(a), int(b)
+                return {"<": x < y, "<=": x <= y, ">": x > y, ">=": x >= y}[op]
+            if op == "+" and isinstance(a, Ts) and isinstance(b, Dur) or op == "+" and isinstance(a, Dur) and isinstance(b, Ts):
+                return Ts(int(a) + int(b))
+            if op == "+" and isinstance(a, Dur) and isinstance(b, Dur):
+                return Dur(int(a) + int(b))
+            if op == "-" and isinstance(a, Ts) and isinstance(b, Ts):
+                return Dur(int(a) - int(b))
+            if op == "-" and isinstance(a, Ts) and isinstance(b, Dur):
+                return Ts(int(a) - int(b))
+            if op == "-" and isinstance(a, Dur) and isinstance(b, Dur):
+                return Dur(int(a) - int(b))
+            if op == "in" and isinstance(b, list):
+                return any(type(a) is type(x) and int(a) == int(x) for x in b)
+            raise FoldError("no such overload")
+        return super().binop(op, a, b)
+
+
+def value_ast(v):
+    """A value as the residual expression shows it (fold.to_ast; a timestamp / duration as the conversion call that makes it)."""
+    if isinstance(v, Dur):
+        return ("call", "duration", None, (("lit", "string", format_duration(v)),))
+    if isinstance(v, Ts):
+        return ("call", "timestamp", None, (("lit", "string", format_timestamp(v)),))
+    if isinstance(v, list):
+        elems = [value_ast(x) for x in v]
+        return None if any(e is None for e in elems) else ("list", tuple(elems))
+    if isinstance(v, dict) and any(isinstance(x, (Ts, Dur, list, dict)) for x in v.values()):
+        ents = []
+        for k, x in v.items():
+            e = value_ast(x)
+            if e is None or not isinstance(k, str):
+                return None
+            ents.append((("lit", "string", k), e))
+        return ("map", tuple(ents))
+    return to_ast(v)
+
+
 class CelEvalError(Exception):
     """A known (sub-)expression fails to evaluate: the condition is false, its error reported (planner.go:404-413)."""
 
@@ -77,9 +206,9 @@ class Partial:
         env = self.env if env is None else env
         k = n[0]
         if k == "lit":
-            return ("k", fold._Eval().ev(n, env))
+            return ("k", _Eval(self.now_ns).ev(n, env))
         try:
-            v = fold._Eval().ev(n, env)
+            v = _Eval(self.now_ns).ev(n, env)
             if isinstance(v, PartialMap):
                 return ("r", n)      # the request's partly known parts stay paths
             return ("k", v)
@@ -154,7 +283,7 @@ class Partial:
     def ast(self, x):
         if x[0] == "r":
             return x[1]
-        lit = to_ast(x[1])
+        lit = value_ast(x[1])
         if lit is None:
             raise CelEvalError("a value without a literal form in a residual expression")
         return lit
@@ -164,7 +293,7 @@ class Partial:
         condition's; one that does may only be the evaluator giving up on a partial value.)"""
         if n[0] in ("select", "index", "has"):
             try:
-                fold._Eval().ev(n, env)
+                _Eval(self.now_ns).ev(n, env)
             except Unknown:
                 return True
             except Exception:

@@ -88,20 +88,21 @@ class Planner:
         self.resource_scopes = set(rt["resource_scopes"])
         self._parsed = {}
 
-    # ruletable.go:848-882 GetAllScopes
+    # ruletable.go:848-882 GetAllScopes: the scopes of the chain that hold SOME policy of the kind (not this name's: the index answers that)
     def all_scopes(self, kind, scope, name, version, lenient):
         have = self.principal_scopes if kind == KIND_PRINCIPAL else self.resource_scopes
         make = namer.principal_policy_fqn if kind == KIND_PRINCIPAL else namer.resource_policy_fqn
         scopes, first = [], ""
-        chain = [scope] + list(namer.scope_parents(scope))
-        for i, s in enumerate(chain):
-            fqn = make(name, version, s)
-            if fqn in self.rt["meta"]:
+        if scope in have:
+            scopes.append(scope)
+            first = make(name, version, scope)
+        elif not lenient:
+            return [], ""
+        for s in namer.scope_parents(scope):
+            if s in have:
                 scopes.append(s)
                 if not first:
-                    first = fqn
-            elif i == 0 and not lenient:
-                return [], ""
+                    first = make(name, version, s)
         return scopes, first
 
     def parse(self, text):

@@ -46,7 +46,7 @@ def _num(v):
 
 def run(planner, suite, test, lenient):
     inp = {"requestId": "requestId", "principal": suite["principal"], "resource": test["resource"], "actions": test["actions"], "auxData": AUX}
-    return planner.plan(inp, lenient_scope_search=lenient, now_ns=NOW)
+    return planner.plan(inp, globals_={"environment": "test"}, lenient_scope_search=lenient, now_ns=NOW)   # engine_test.go mkEngine: globals
 
 
 @pytest.mark.parametrize("suite,k", CASES, ids=["%s-%d" % (s["name"], k) for s, k in CASES])
