@@ -22,7 +22,7 @@ _UNITS = {"ns": 1, "us": 1000, "\u00b5s": 1000, "ms": 10**6, "s": 10**9, "m": 60
 
 
 def parse_duration(text):
-    """Go's time.ParseDuration: [-+]?([0-9]*(\.[0-9]*)?[a-z]+)+"""
+    """Go time.ParseDuration: a sign, then one or more <decimal number><unit> groups"""
     import re
     m = re.fullmatch(r"([+-])?((?:\d*\.?\d*(?:ns|us|\u00b5s|ms|s|m|h))+)", text)
     if not m or not text.strip("+-"):
@@ -137,6 +137,14 @@ def value_ast(v):
             ents.append((("lit", "string", k), e))
         return ("map", tuple(ents))
     return to_ast(v)
+
+
+def _right_nested(op, opts):
+    """mkLogicalOr / mkLogicalAnd (struct_matcher.go:214-236): a op (b op (c ...))"""
+    out = opts[-1]
+    for o in reversed(opts[:-1]):
+        out = (op, o, out)
+    return out
 
 
 class CelEvalError(Exception):
@@ -299,6 +307,90 @@ class Partial:
             except Exception:
                 pass
         return any(self._reads_unknown(c, env) for c in fold._children(n))
+
+    # ---- what the reference does to the ROOT of a residual expression (planner.go:415-438 evaluateUnknown; struct_matcher.go)
+    def process_root(self, n, env=None):
+        env = self.env if env is None else env
+        out = self._struct_index(n) or self._in_struct_index(n) or self._unroll(n, env)
+        if out is None:
+            return ("r", n)
+        return self.pe(out, env)
+
+    @staticmethod
+    def _known_only(n):
+        if n[0] == "lit":
+            return True
+        if n[0] == "list":
+            return all(Partial._known_only(e) for e in n[1])
+        if n[0] == "map":
+            return all(Partial._known_only(a) and Partial._known_only(b) for a, b in n[1])
+        return False
+
+    @staticmethod
+    def _indexed_struct(n):
+        """struct[indexer] or struct[indexer].field with `struct` a map literal and `indexer` a selection -> (map, indexer, field)"""
+        field = None
+        if n[0] == "select":
+            field, n = n[2], n[1]
+        if n[0] == "index" and n[1][0] == "map" and n[2][0] == "select":
+            return n[1], n[2], field
+        return None
+
+    @staticmethod
+    def _options(m, mk):
+        ents = list(m[1])
+        if all(k[0] == "lit" and k[1] == "string" for k, _ in ents):
+            ents.sort(key=lambda kv: kv[0][2])
+        opts = [mk(k, v) for k, v in ents]
+        if not opts:
+            return None
+        return _right_nested("or", opts)
+
+    def _struct_index(self, n):
+        """{..}[R.attr.x](.f) <op> const -> OR over the entries of (R.attr.x == key && const <op> value(.f))  (struct_matcher.go:128-170)"""
+        if n[0] != "bin" or n[1] not in ("==", "!=", "<", "<=", ">", ">=") or n[3][0] != "lit":
+            return None
+        hit = self._indexed_struct(n[2])
+        if hit is None:
+            return None
+        m, indexer, field = hit
+        return self._options(m, lambda k, v: ("and", ("bin", "==", indexer, k), ("bin", n[1], n[3], ("select", v, field) if field else v)))
+
+    def _in_struct_index(self, n):
+        """const in {..}[R.attr.x](.f)"""
+        if n[0] != "bin" or n[1] != "in" or n[2][0] != "lit":
+            return None
+        hit = self._indexed_struct(n[3])
+        if hit is None:
+            return None
+        m, indexer, field = hit
+        return self._options(m, lambda k, v: ("and", ("bin", "==", indexer, k), ("bin", "in", n[2], ("select", v, field) if field else v)))
+
+    def _unroll(self, n, env):
+        """exists / all over a known list or map of at most ten entries: one residual per entry, OR-ed / AND-ed (struct_matcher.go:300-390)"""
+        if n[0] != "comp" or n[1] not in ("exists", "all") or n[2][0] not in ("list", "map") or not self._known_only(n[2]):
+            return None
+        _, kind, target, vars_, args = n
+        items = list(target[1])
+        if len(items) > 10:
+            return None
+        opts = []
+        for i, it in enumerate(items):
+            e = dict(env)
+            if target[0] == "list":
+                v = _Eval(self.now_ns).ev(it, env)
+                if len(vars_) == 2:
+                    e[vars_[0]], e[vars_[1]] = i, v
+                else:
+                    e[vars_[0]] = v
+            else:
+                e[vars_[0]] = _Eval(self.now_ns).ev(it[0], env)
+                if len(vars_) == 2:
+                    e[vars_[1]] = _Eval(self.now_ns).ev(it[1], env)
+            opts.append(self.ast(self.pe(args[0], e)))
+        if not opts:
+            return None
+        return _right_nested("or" if kind == "exists" else "and", opts)
 
     def comp(self, n, env):
         """A comprehension over an unknown range stays a comprehension: its range and its body partially evaluated with the iteration

@@ -311,7 +311,10 @@ class _Cond:
             tree = _replace_runtime_edr(tree, dr_list)
         env = request_env(self.principal, self.resource, self.aux, self.globals, consts)
         try:
-            r = Partial(env, self.now_ns).pe(tree)
+            pe = Partial(env, self.now_ns)
+            r = pe.pe(tree)
+            if r[0] == "r":
+                r = pe.process_root(r[1])
         except CelEvalError as e:
             self.errors.append({"expr": text, "message": str(e)})
             if self.strict:
