@@ -245,7 +245,7 @@ class Partial:
                 return b
             if b[0] == "e":
                 return a
-            return ("r", (k, self.ast(a), self.ast(b)))
+            return ("r", (k, self.ast(a, n[1], env), self.ast(b, n[2], env)))
         if k == "not":
             a = self.pe(n[1], env)
             if a[0] == "k":
@@ -259,7 +259,7 @@ class Partial:
                 if not isinstance(c[1], bool):
                     raise CelEvalError("no such overload")
                 return self.pe(n[2] if c[1] else n[3], env)
-            return ("r", ("tern", c[1], self.ast(self.pe(n[2], env)), self.ast(self.pe(n[3], env))))
+            return ("r", ("tern", c[1], self.ast(self.pe(n[2], env), n[2], env), self.ast(self.pe(n[3], env), n[3], env)))
         if k == "bind":
             init = self.pe(n[2], env)
             if init[0] == "k":
@@ -273,9 +273,9 @@ class Partial:
         kids = fold._children(n)
         if k == "call" and n[2] is not None and n[2][0] == "ident" and n[2][1] not in env and n[2][1] in (
                 "sets", "math", "lists", "base64", "strings", "regex", "optional", "ip", "cidr"):
-            new = [n[2]] + [self.ast(self.pe(c, env)) for c in kids[1:]]     # a namespace, not a value
+            new = [n[2]] + [self.ast(self.pe(c, env), c, env) for c in kids[1:]]     # a namespace, not a value
         else:
-            new = [self.ast(self.pe(c, env)) for c in kids]
+            new = [self.ast(self.pe(c, env), c, env) for c in kids]
         return ("r", fold._rebuild(n, new))
 
     def pe_guard(self, n, env):
@@ -288,13 +288,23 @@ class Partial:
     def _raise(x):
         raise x[1]
 
-    def ast(self, x):
+    def ast(self, x, orig=None, env=None):
+        """A result as an expression: a residual as it is, a value as its literal - or, for a value without one (a hierarchy, an
+        address), the expression that makes it, its own operands evaluated."""
         if x[0] == "r":
             return x[1]
         lit = value_ast(x[1])
-        if lit is None:
+        if lit is not None:
+            return lit
+        if orig is None or not fold._children(orig):
             raise CelEvalError("a value without a literal form in a residual expression")
-        return lit
+        env = self.env if env is None else env
+        kids = fold._children(orig)
+        if orig[0] == "call" and orig[2] is not None and orig[2][0] == "ident" and orig[2][1] not in env:
+            new = [orig[2]] + [self.ast(self.pe(c, env), c, env) for c in kids[1:]]
+        else:
+            new = [self.ast(self.pe(c, env), c, env) for c in kids]
+        return fold._rebuild(orig, new)
 
     def _reads_unknown(self, n, env):
         """Does the expression touch an unknown part of the request?  (An evaluation error in a sub-expression that does not is the
@@ -398,5 +408,5 @@ class Partial:
         _, kind, target, vars_, args = n
         rng = self.pe(target, env)
         inner = {k: v for k, v in env.items() if k not in vars_}
-        new_args = tuple(self.ast(self.pe(a, inner)) for a in args)
-        return ("r", ("comp", kind, self.ast(rng), vars_, new_args))
+        new_args = tuple(self.ast(self.pe(a, inner), a, inner) for a in args)
+        return ("r", ("comp", kind, self.ast(rng, target, env), vars_, new_args))

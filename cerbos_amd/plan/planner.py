@@ -333,7 +333,8 @@ class _Cond:
             dr = drs[name]
             if not (set(dr["parent_roles"]) & all_roles) and "*" not in dr["parent_roles"]:
                 continue
-            node = self.condition(dr["condition"], dr["constants"], self.p.variable_exprs(dr["ordered_variables"]), None)
+            # (inside a definition the list is still empty: plan.go:142, 161)
+            node = self.condition(dr["condition"], dr["constants"], self.p.variable_exprs(dr["ordered_variables"]), [])
             items.append((name, node))
         return items
 
@@ -349,21 +350,13 @@ def _replace_runtime_edr(tree, dr_list):
 
 
 def _dr_list_expr(items):
-    """MkDerivedRolesList: [name] for a role that always applies, (cond ? [name] : []) for a conditional one, added up"""
-    parts = []
-    for name, node in items:
-        isc, bv = const_bool(node)
-        one = ("list", (("lit", "string", name),))
-        if isc:
-            if bv:
-                parts.append(one)
-            continue
-        parts.append(("tern", _node_to_cel(node), one, ("list", ())))
+    """MkDerivedRolesList (planner.go:844-893): (cond ? [name] : []) per role, added up right to left"""
+    parts = [("tern", _node_to_cel(node), ("list", (("lit", "string", name),)), ("list", ())) for name, node in items]
     if not parts:
         return ("list", ())
-    out = parts[0]
-    for p in parts[1:]:
-        out = ("bin", "+", out, p)
+    out = parts[-1]
+    for p in reversed(parts[:-1]):
+        out = ("bin", "+", p, out)
     return out
 
 
