@@ -137,4 +137,82 @@ int cbl_lower_ruletable_pb(const uint8_t* ruletable_pb, size_t len, const char* 
   return status;
 }
 
+// ---- PlanResources (cerbos_amd/plan) behind the same interpreter
+static int call_embedded(const char* fn, PyObject* args, char** error, PyObject** out_payload) {
+  // -> status; *out_payload = new reference to the second element of the result tuple on CBL_OK
+  int status = CBL_RUNTIME;
+  PyObject *mod = nullptr, *f = nullptr, *res = nullptr;
+  do {
+    mod = PyImport_ImportModule("cerbos_amd.lower.embedded");
+    if (!mod) { set_error(error, py_error_text()); break; }
+    f = PyObject_GetAttrString(mod, fn);
+    if (!f) { set_error(error, py_error_text()); break; }
+    res = PyObject_CallObject(f, args);
+    if (!res) { set_error(error, py_error_text()); break; }
+    if (!PyTuple_Check(res) || PyTuple_Size(res) != 2) { set_error(error, "unexpected result from the planner"); break; }
+    const long code = PyLong_AsLong(PyTuple_GetItem(res, 0));
+    PyObject* payload = PyTuple_GetItem(res, 1);
+    if (code == CBL_OK) { Py_INCREF(payload); *out_payload = payload; status = CBL_OK; }
+    else {
+      const char* msg = PyUnicode_Check(payload) ? PyUnicode_AsUTF8(payload) : nullptr;
+      set_error(error, msg ? msg : "planner failed");
+      status = code == CBL_BAD_INPUT ? CBL_BAD_INPUT : CBL_RUNTIME;
+    }
+  } while (false);
+  Py_XDECREF(res); Py_XDECREF(f); Py_XDECREF(mod);
+  return status;
+}
+
+int cbl_planner_open(const uint8_t* ruletable_pb, size_t len, uint64_t* planner, char** error) {
+  if (error) *error = nullptr;
+  if (!planner || (!ruletable_pb && len)) { set_error(error, "null argument"); return CBL_BAD_INPUT; }
+  *planner = 0;
+  std::call_once(g_once, start_interpreter);
+  if (!g_init_error.empty()) { set_error(error, g_init_error); return CBL_RUNTIME; }
+  PyGILState_STATE st = PyGILState_Ensure();
+  PyObject* args = Py_BuildValue("(y#)", reinterpret_cast<const char*>(ruletable_pb), static_cast<Py_ssize_t>(len));
+  PyObject* payload = nullptr;
+  int status = args ? call_embedded("planner_open", args, error, &payload) : CBL_RUNTIME;
+  if (status == CBL_OK) { *planner = (uint64_t)PyLong_AsUnsignedLongLong(payload); Py_DECREF(payload); }
+  Py_XDECREF(args);
+  PyGILState_Release(st);
+  return status;
+}
+
+void cbl_planner_close(uint64_t planner) {
+  if (!planner || !g_init_error.empty() || !Py_IsInitialized()) return;
+  PyGILState_STATE st = PyGILState_Ensure();
+  PyObject* args = Py_BuildValue("(K)", (unsigned long long)planner);
+  PyObject* payload = nullptr;
+  if (args && call_embedded("planner_close", args, nullptr, &payload) == CBL_OK) Py_XDECREF(payload);
+  PyErr_Clear();
+  Py_XDECREF(args);
+  PyGILState_Release(st);
+}
+
+int cbl_planner_plan_pb(uint64_t planner, const uint8_t* input_pb, size_t len, const char* params_json, uint8_t** output_pb, size_t* output_len,
+                        char** error) {
+  if (error) *error = nullptr;
+  if (!output_pb || !output_len || (!input_pb && len)) { set_error(error, "null argument"); return CBL_BAD_INPUT; }
+  *output_pb = nullptr; *output_len = 0;
+  if (!g_init_error.empty() || !Py_IsInitialized()) { set_error(error, g_init_error.empty() ? "no planner was opened" : g_init_error); return CBL_RUNTIME; }
+  PyGILState_STATE st = PyGILState_Ensure();
+  PyObject* args = Py_BuildValue("(Ky#z)", (unsigned long long)planner, reinterpret_cast<const char*>(input_pb), static_cast<Py_ssize_t>(len), params_json);
+  PyObject* payload = nullptr;
+  int status = args ? call_embedded("planner_plan_pb", args, error, &payload) : CBL_RUNTIME;
+  if (status == CBL_OK) {
+    char* data = nullptr; Py_ssize_t n = 0;
+    if (PyBytes_AsStringAndSize(payload, &data, &n) != 0) { set_error(error, py_error_text()); status = CBL_RUNTIME; }
+    else {
+      uint8_t* out = static_cast<uint8_t*>(malloc(n ? static_cast<size_t>(n) : 1));
+      if (!out) { set_error(error, "out of memory"); status = CBL_RUNTIME; }
+      else { memcpy(out, data, static_cast<size_t>(n)); *output_pb = out; *output_len = static_cast<size_t>(n); }
+    }
+    Py_DECREF(payload);
+  }
+  Py_XDECREF(args);
+  PyGILState_Release(st);
+  return status;
+}
+
 }  // extern "C"

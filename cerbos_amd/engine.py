@@ -99,7 +99,9 @@ class HipEvaluator:
         """``per_call_globals``: the image does not fold ``conf.globals`` in; every ``check`` brings its globals
         (``EvalParams.Globals``, evaluator.go:52-57; default: ``conf.globals``) and one image answers any of them."""
         conf = conf or Conf()
-        return cls(lower_rule_table(rt, conf.globals, per_call_globals=per_call_globals), conf, device)
+        ev = cls(lower_rule_table(rt, conf.globals, per_call_globals=per_call_globals), conf, device)
+        ev.rt = rt          # the query planner works on the rule table itself (plan_resources)
+        return ev
 
     @classmethod
     def from_rule_table_pb(cls, wire: bytes, conf: Conf = None, device: int = 0):
@@ -338,6 +340,26 @@ class HipEvaluator:
         _, masks = self._check_trail(batch, groups, n if per_input else 1, now_ns, flags)
         keys = [effective_policy_keys(self.lt.policy_keys, row) for row in masks]
         return keys if per_input else keys[0]
+
+    def plan_resources(self, inp, now_ns=None, lenient_scope_search=None, strict_evaluation=None, default_policy_version=None,
+                       default_scope=None, globals_=None):
+        """``Engine.PlanResources`` (engine.go:141-170, ruletable/plan.go): a ``PlanResourcesInput`` (JSON shape) -> the
+        ``PlanResourcesOutput`` - filter {kind, condition}, filterDebug, matchedScopes, evaluationErrors - and, beside it, the call's
+        ``effectivePolicies``.  Host-side and symbolic (cerbos_amd/plan), as in the reference: the GPU is not involved."""
+        rt = getattr(self, "rt", None)
+        if rt is None:
+            raise ValueError("plan_resources needs the rule table: build the evaluator with from_rule_table / from_policies / from_policy_dir")
+        if getattr(self, "_planner", None) is None:
+            from .plan import Planner
+            self._planner = Planner(rt)
+        conf = self.conf
+        return self._planner.plan(
+            inp, globals_=dict(conf.globals if globals_ is None else globals_),
+            default_policy_version=conf.default_policy_version if default_policy_version is None else default_policy_version,
+            default_scope=conf.default_scope if default_scope is None else default_scope,
+            lenient_scope_search=conf.lenient_scope_search if lenient_scope_search is None else lenient_scope_search,
+            strict_evaluation=conf.strict_evaluation if strict_evaluation is None else strict_evaluation,
+            now_ns=time.time_ns() if now_ns is None else now_ns)
 
     def _check_trail(self, batch, groups, n_groups, now_ns, flags):
         return self.table.check_trail(batch, groups, n_groups, now_ns=now_ns, flags=flags)

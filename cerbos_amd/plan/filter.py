@@ -11,7 +11,7 @@ _ABBREV = {"R": "request.resource", "P": "request.principal", "G": "globals", "C
 # macro -> operator (lambda.go:60-120)
 _MACRO = {"all": "all", "exists": "exists", "exists_one": "exists_one", "existsOne": "exists_one", "map": "map", "filter": "filter",
           "transformList": "transformList", "transformMap": "transformMap", "transformMapEntry": "transformMapEntry", "sortBy": "sortBy"}
-_ON_STRUCT = ("transformMap", "transformMapEntry", "transformList", "all", "exists", "exists_one", "map", "filter")
+_ON_STRUCT = ("transformMap", "transformMapEntry", "transformList")   # canOperateOnStruct (ast.go:875-877): the others range over a struct's keys
 
 
 def expr(op, *operands):
@@ -221,3 +221,48 @@ def merge_with_and(filters):
     if len(conds) == 1:
         return {"kind": "KIND_CONDITIONAL", "condition": next(iter(conds.values()))}
     return {"kind": "KIND_CONDITIONAL", "condition": expr("and", *[conds[k] for k in sorted(conds)])}
+
+
+def normalise_filter(f):
+    """normaliseFilter (ast.go:596-620) on a filter given as data"""
+    if f.get("kind") != "KIND_CONDITIONAL":
+        return {"kind": f.get("kind")}
+    cond = normalise_operand(f.get("condition")) if f.get("condition") else None
+    if cond is None:
+        return {"kind": "KIND_ALWAYS_ALLOWED"}
+    isb, bv = _as_bool(cond)
+    if isb:
+        return {"kind": "KIND_ALWAYS_ALLOWED" if bv else "KIND_ALWAYS_DENIED"}
+    return {"kind": "KIND_CONDITIONAL", "condition": cond}
+
+
+def _json(v):
+    """protojson of a google.protobuf.Value, compact"""
+    import json
+    if isinstance(v, float) and v == int(v) and abs(v) < 1e15:
+        return json.dumps(int(v))
+    if isinstance(v, list):
+        return "[" + ",".join(_json(x) for x in v) + "]"
+    if isinstance(v, dict):
+        return "{" + ",".join(json.dumps(k) + ":" + _json(x) for k, x in v.items()) + "}"
+    return json.dumps(v, ensure_ascii=False)
+
+
+def operand_to_string(op):
+    if op is None:
+        return ""
+    if "expression" in op:
+        e = op["expression"]
+        return "(" + e["operator"] + " " + " ".join(operand_to_string(o) for o in e.get("operands") or []) + ")"
+    if "value" in op:
+        return _json(op["value"])
+    return op["variable"]
+
+
+def filter_to_string(f):
+    """FilterToString (ast.go:821-834): the filterDebug of an output"""
+    if f["kind"] == "KIND_ALWAYS_ALLOWED":
+        return "(true)"
+    if f["kind"] == "KIND_ALWAYS_DENIED":
+        return "(false)"
+    return operand_to_string(f.get("condition"))

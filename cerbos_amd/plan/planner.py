@@ -87,6 +87,7 @@ class Planner:
         self.principal_scopes = set(rt["principal_scopes"])
         self.resource_scopes = set(rt["resource_scopes"])
         self._parsed = {}
+        self._sources = {}
 
     # ruletable.go:848-882 GetAllScopes: the scopes of the chain that hold SOME policy of the kind (not this name's: the index answers that)
     def all_scopes(self, kind, scope, name, version, lenient):
@@ -104,6 +105,23 @@ class Planner:
                 if not first:
                     first = make(name, version, s)
         return scopes, first
+
+    def source_keys(self, fqn):
+        """The keys of the policy set's SourceAttributes (compile.go:153-180, 474-494): the policy and, scoped, its ancestors"""
+        keys = self._sources.get(fqn)
+        if keys is None:
+            meta = self.rt["meta"].get(fqn)
+            keys = []
+            if meta is not None:
+                keys.append(namer.policy_key_from_fqn(fqn))
+                if meta["kind"] in ("resource", "principal") and "/" in fqn:
+                    make = namer.resource_policy_fqn if meta["kind"] == "resource" else namer.principal_policy_fqn
+                    for anc in namer.scope_parents(fqn.split("/", 1)[1]):
+                        a = make(meta["name"], meta["version"], anc)
+                        if a in self.rt["meta"]:
+                            keys.append(namer.policy_key_from_fqn(a))
+            self._sources[fqn] = keys
+        return keys
 
     def parse(self, text):
         t = self._parsed.get(text)
@@ -133,7 +151,9 @@ class Planner:
         if not p_scopes and not r_scopes:
             out["filter"] = {"kind": "KIND_ALWAYS_DENIED"}
             out["filterDebug"] = "NO_MATCH"
+            out["effectivePolicies"] = []
             return out
+        touched = set()
         errors = []
         ev = _Cond(self, principal, resource, inp.get("auxData"), globals_, strict_evaluation, errors, now_ns)
         sres = namer.sanitize(resource.get("kind", ""))
@@ -167,6 +187,7 @@ class Planner:
                                 dr_list = dr_lists[scope]
                             pid = principal.get("id", "") if pt == KIND_PRINCIPAL else ""
                             for b in self.idx.query(r_ver, sres, scope, action, roles_inc, pt, pid):
+                                touched.update(self.source_keys(b["origin_fqn"]))
                                 consts, variables = {}, {}
                                 if b.get("params") is not None:
                                     consts = b["params"]["constants"]
@@ -245,8 +266,9 @@ class Planner:
                 deny_nodes = [FALSE]
             filters.append(flt.to_filter(_node_filter_ast(allow_nodes, deny_nodes)))
         out["filter"] = flt.merge_with_and(filters)
-        out["filterDebug"] = "NO_MATCH" if not policy_match else ""
+        out["filterDebug"] = flt.filter_to_string(out["filter"]) if policy_match else "NO_MATCH"
         out["evaluationErrors"] = errors
+        out["effectivePolicies"] = sorted(touched)     # the call's AuditTrail.EffectivePolicies (plan.go:50-51, 201-203)
         return out
 
 

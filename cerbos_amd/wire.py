@@ -285,3 +285,166 @@ def decode_check_resources_response(buf: bytes) -> dict:
                     entry["meta"] = meta
             out["results"].append(entry)
     return out
+
+
+# ---- PlanResources (engine.proto:20-128): input 1 request_id, 2 action (deprecated), 3 principal, 4 resource {1 kind, 2 attr,
+# 3 policy_version, 4 scope}, 5 aux_data, 6 include_meta, 7 actions; output 1 request_id, 2 action, 3 kind, 4 policy_version, 5 scope,
+# 6 filter {1 kind, 2 condition}, 7 filter_debug, 9 actions, 10 matched_scopes, 11 evaluation_errors {1 expr, 2 message};
+# Operand: 1 value, 2 expression {1 operator, 2 operands}, 3 variable
+_FILTER_KINDS = {"KIND_UNSPECIFIED": 0, "KIND_ALWAYS_ALLOWED": 1, "KIND_ALWAYS_DENIED": 2, "KIND_CONDITIONAL": 3}
+
+
+def _decode_map(entries):
+    out = {}
+    for ent in entries:
+        k, val = "", None
+        for n3, v3 in _fields(ent):
+            if n3 == 1:
+                k = v3.decode("utf-8")
+            elif n3 == 2:
+                val = decode_value(v3)
+        out[k] = val
+    return out
+
+
+def _decode_principal(buf):
+    p = {"id": "", "policyVersion": "", "roles": [], "attr": {}, "scope": ""}
+    attrs = []
+    for n, v in _fields(buf):
+        if n == 1:
+            p["id"] = v.decode("utf-8")
+        elif n == 2:
+            p["policyVersion"] = v.decode("utf-8")
+        elif n == 3:
+            p["roles"].append(v.decode("utf-8"))
+        elif n == 4:
+            attrs.append(v)
+        elif n == 5:
+            p["scope"] = v.decode("utf-8")
+    p["attr"] = _decode_map(attrs)
+    return p
+
+
+def encode_plan_resources_input(inp: dict) -> bytes:
+    r = inp.get("resource") or {}
+    res = (_string(1, r.get("kind", "") or "") + encode_map(2, r.get("attr") or {}) + _string(3, r.get("policyVersion", "") or "")
+           + _string(4, r.get("scope", "") or ""))
+    out = _string(1, inp.get("requestId", "") or "") + _string(2, inp.get("action", "") or "")
+    out += _ld(3, encode_principal(inp.get("principal") or {})) + _ld(4, res)
+    aux = inp.get("auxData") or {}
+    if aux.get("jwt") or aux.get("jwts"):
+        out += _ld(5, encode_aux_data(aux))
+    if inp.get("includeMeta"):
+        out += _varint(6 << 3 | 0) + b"\1"
+    out += b"".join(_ld(7, str(a).encode("utf-8")) for a in (inp.get("actions") or []))
+    return out
+
+
+def decode_plan_resources_input(buf: bytes) -> dict:
+    inp = {"requestId": "", "actions": [], "principal": {}, "resource": {}, "auxData": None, "includeMeta": False}
+    action = ""
+    for n, v in _fields(buf):
+        if n == 1:
+            inp["requestId"] = v.decode("utf-8")
+        elif n == 2:
+            action = v.decode("utf-8")
+        elif n == 3:
+            inp["principal"] = _decode_principal(v)
+        elif n == 4:
+            r, attrs = {"kind": "", "policyVersion": "", "scope": ""}, []
+            for n2, v2 in _fields(v):
+                if n2 == 1:
+                    r["kind"] = v2.decode("utf-8")
+                elif n2 == 2:
+                    attrs.append(v2)
+                elif n2 == 3:
+                    r["policyVersion"] = v2.decode("utf-8")
+                elif n2 == 4:
+                    r["scope"] = v2.decode("utf-8")
+            r["attr"] = _decode_map(attrs)
+            inp["resource"] = r
+        elif n == 5:
+            inp["auxData"] = {"jwt": _decode_map([v2 for n2, v2 in _fields(v) if n2 == 1])}
+        elif n == 6:
+            inp["includeMeta"] = bool(v)
+        elif n == 7:
+            inp["actions"].append(v.decode("utf-8"))
+    if not inp["actions"] and action:
+        inp["actions"] = [action]
+    return inp
+
+
+def _encode_operand(op: dict) -> bytes:
+    if "expression" in op:
+        e = op["expression"]
+        body = _string(1, e["operator"]) + b"".join(_ld(2, _encode_operand(o)) for o in e.get("operands") or [])
+        return _ld(2, body)
+    if "variable" in op:
+        return _ld(3, op["variable"].encode("utf-8"))
+    return _ld(1, encode_value(op["value"]))
+
+
+def encode_plan_resources_output(out: dict) -> bytes:
+    f = out["filter"]
+    fb = _varint(1 << 3 | 0) + _varint(_FILTER_KINDS[f["kind"]])
+    if f.get("condition") is not None:
+        fb += _ld(2, _encode_operand(f["condition"]))
+    acts = out.get("actions") or []
+    b = _string(1, out.get("requestId", "")) + _string(3, out.get("kind", "")) + _string(4, out.get("policyVersion", "")) + _string(5, out.get("scope", ""))
+    b += _ld(6, fb) + _string(7, out.get("filterDebug", ""))
+    b += b"".join(_ld(9, a.encode("utf-8")) for a in acts)
+    for k, v in (out.get("matchedScopes") or {}).items():
+        b += _ld(10, _ld(1, k.encode("utf-8")) + _string(2, v))
+    for e in out.get("evaluationErrors") or []:
+        b += _ld(11, _string(1, e.get("expr", "")) + _string(2, e.get("message", "")))
+    return b
+
+
+def _decode_operand(buf: bytes) -> dict:
+    for n, v in _fields(buf):
+        if n == 1:
+            return {"value": decode_value(v)}
+        if n == 3:
+            return {"variable": v.decode("utf-8")}
+        if n == 2:
+            e = {"operator": "", "operands": []}
+            for n2, v2 in _fields(v):
+                if n2 == 1:
+                    e["operator"] = v2.decode("utf-8")
+                elif n2 == 2:
+                    e["operands"].append(_decode_operand(v2))
+            return {"expression": e}
+    return {"value": None}
+
+
+def decode_plan_resources_output(buf: bytes) -> dict:
+    kinds = {v: k for k, v in _FILTER_KINDS.items()}
+    out = {"requestId": "", "kind": "", "policyVersion": "", "scope": "", "filter": {"kind": "KIND_UNSPECIFIED"}, "filterDebug": "",
+           "actions": [], "matchedScopes": {}, "evaluationErrors": []}
+    for n, v in _fields(buf):
+        if n in (1, 3, 4, 5, 7):
+            out[{1: "requestId", 3: "kind", 4: "policyVersion", 5: "scope", 7: "filterDebug"}[n]] = v.decode("utf-8")
+        elif n == 6:
+            f = {"kind": "KIND_UNSPECIFIED"}
+            for n2, v2 in _fields(v):
+                if n2 == 1:
+                    f["kind"] = kinds[v2]
+                elif n2 == 2:
+                    f["condition"] = _decode_operand(v2)
+            out["filter"] = f
+        elif n == 9:
+            out["actions"].append(v.decode("utf-8"))
+        elif n == 10:
+            k = val = ""
+            for n2, v2 in _fields(v):
+                if n2 == 1:
+                    k = v2.decode("utf-8")
+                elif n2 == 2:
+                    val = v2.decode("utf-8")
+            out["matchedScopes"][k] = val
+        elif n == 11:
+            e = {"expr": "", "message": ""}
+            for n2, v2 in _fields(v):
+                e["expr" if n2 == 1 else "message"] = v2.decode("utf-8")
+            out["evaluationErrors"].append(e)
+    return out

@@ -49,6 +49,21 @@ char* cbl_last_stats_json(void);
 
 void cbl_free(void* p);
 
+/* ---- PlanResources (internal/ruletable/plan.go:31-415, internal/ruletable/planner): the query planner behind the same library.
+ * Host-side and symbolic in the reference too - one principal, actions and a resource KIND in, the condition under which a resource
+ * of that kind is allowed out - so it runs where the lowering runs (cerbos_amd/plan in the embedded interpreter), not on the GPU.
+ * A planner belongs to a published rule table: open it when the table is published (beside cbl_lower_ruletable_pb), plan with it
+ * from any thread (calls are serialised on the interpreter's lock), close it when the table is replaced.
+ *   input_pb    : proto.Marshal of the enginev1.PlanResourcesInput (api/public/cerbos/engine/v1/engine.proto:20-60)
+ *   params_json : NULL, or the call's evaluator parameters as a JSON object - "globals" {..}, "defaultPolicyVersion",
+ *                 "defaultScope", "lenientScopeSearch", "strictEvaluation", "nowNs" (evaluator.EvalParams)
+ *   output_pb   : on CBL_OK the serialized enginev1.PlanResourcesOutput (engine.proto:116-128: filter, filter_debug, matched_scopes,
+ *                 evaluation_errors), allocated by the library: release it with cbl_free */
+int cbl_planner_open(const uint8_t* ruletable_pb, size_t len, uint64_t* planner, char** error);
+int cbl_planner_plan_pb(uint64_t planner, const uint8_t* input_pb, size_t len, const char* params_json, uint8_t** output_pb, size_t* output_len,
+                        char** error);
+void cbl_planner_close(uint64_t planner);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,3 +61,24 @@ def test_plan(planner, suite, k):
         want = test["want"]
         assert have["kind"] == want.get("kind"), (test["actions"], have)
         assert canon(have.get("condition")) == canon(want.get("condition")), (test["actions"], json.dumps(have.get("condition")))
+
+
+@pytest.mark.parametrize("case", DATA["filters"], ids=[c["name"] for c in DATA["filters"]])
+def test_normalise_filter(case):
+    """TestNormaliseFilter (planner_test.go:443-456): exact, operands in order, and the debug string"""
+    from cerbos_amd.plan import filter as flt
+    have = flt.normalise_filter(case["input"])
+    want = case["wantFilter"]
+    assert have.get("kind") == want.get("kind")
+    assert _exact(have.get("condition")) == _exact(want.get("condition")), json.dumps(have)
+    assert flt.filter_to_string(have) == case["wantString"]
+
+
+def _exact(op):
+    if op is None:
+        return None
+    if "expression" in op:
+        return {"expression": {"operator": op["expression"]["operator"], "operands": [_exact(o) for o in op["expression"].get("operands") or []]}}
+    if "value" in op:
+        return {"value": _num(op["value"])}
+    return {"variable": op["variable"]}

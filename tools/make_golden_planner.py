@@ -2,6 +2,7 @@
 """Regenerate tests/golden/planner_cases.json from the reference's query-planner fixtures (data, not code):
 
   internal/test/testdata/query_planner/policies/**     the policies TestQueryPlan loads (engine_test.go:420-422)
+  internal/test/testdata/query_planner_filter/*.yaml    TestNormaliseFilter cases (planner_test.go:443-456)
   internal/test/testdata/query_planner/suite/{common,strict_scope_search,lenient_scope_search}/*.yaml
                                                         QueryPlannerTestSuite files: a principal and tests of (action(s), resource,
                                                         wanted filter) - engine_test.go:427-495
@@ -40,8 +41,15 @@ def main():
                               "resource": t.get("resource") or {}, "want": t.get("want") or {}, "wantErr": bool(t.get("wantErr", False))})
             suites.append({"name": "%s/%s" % (sub, os.path.basename(p)[:-5]), "lenient": mode, "description": doc.get("description", ""),
                            "principal": doc.get("principal") or {}, "tests": tests})
+    # TestNormaliseFilter (planner_test.go:443-456): filters in, normalised filters and their debug strings out
+    filters = []
+    for p in sorted(glob.glob("/root/reference/internal/test/testdata/query_planner_filter/*.yaml")):
+        with open(p, encoding="utf-8") as f:
+            doc = yaml.safe_load(f.read())
+        filters.append({"name": os.path.basename(p)[:-5], "description": doc.get("description", ""), "input": doc.get("input") or {},
+                        "wantFilter": doc.get("wantFilter") or {}, "wantString": doc.get("wantString", "")})
     with open(OUT, "w", encoding="utf-8") as f:
-        json.dump({"policies": [pols[k] for k in sorted(pols)], "suites": suites}, f, sort_keys=True, separators=(",", ":"), ensure_ascii=False)
+        json.dump({"policies": [pols[k] for k in sorted(pols)], "suites": suites, "filters": filters}, f, sort_keys=True, separators=(",", ":"), ensure_ascii=False)
         f.write("\n")
     print("wrote", OUT, os.path.getsize(OUT), "bytes;", len(suites), "suites,", sum(len(s["tests"]) for s in suites), "tests")
 
