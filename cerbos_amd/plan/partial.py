@@ -169,10 +169,13 @@ def to_cel(v, partial_paths=()):
 
 def request_env(principal, resource, aux_data, globals_, constants):
     """The identifiers a condition can read (conditions/cel.go:30-63): request / R / P / G / C and their long names."""
+    from .. import namer
     p = {"id": principal.get("id", ""), "roles": list(principal.get("roles") or []), "attr": to_cel(principal.get("attr") or {}),
-         "policyVersion": principal.get("policyVersion", ""), "scope": principal.get("scope", "")}
-    r = PartialMap({"kind": resource.get("kind", ""), "policyVersion": resource.get("policyVersion", ""), "scope": resource.get("scope", ""),
-                    "attr": PartialMap(to_cel(resource.get("attr") or {}))})
+         "policyVersion": principal.get("policyVersion", ""), "scope": namer.scope_value(principal.get("scope", "") or "")}
+    p["policy_version"] = p["policyVersion"]
+    r = PartialMap({"kind": resource.get("kind", ""), "policyVersion": resource.get("policyVersion", ""),
+                    "scope": namer.scope_value(resource.get("scope", "") or ""), "attr": PartialMap(to_cel(resource.get("attr") or {}))})
+    r["policy_version"] = r["policyVersion"]
     req = {"principal": p, "resource": r, "auxData": {"jwt": to_cel(((aux_data or {}).get("jwt")) or {})}}
     req["aux_data"] = req["auxData"]
     g, c = to_cel(globals_ or {}), to_cel_consts(constants or {})
