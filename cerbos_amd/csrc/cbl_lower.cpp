@@ -97,7 +97,13 @@ char* cbl_last_stats_json(void) { return t_stats.empty() ? nullptr : dup_cstr(t_
 
 int cbl_lower_ruletable_pb(const uint8_t* ruletable_pb, size_t len, const char* globals_json, uint32_t flags,
                            uint8_t** image, size_t* image_len, char** error) {
+  return cbl_lower_ruletable_pb_stats(ruletable_pb, len, globals_json, flags, image, image_len, nullptr, error);
+}
+
+int cbl_lower_ruletable_pb_stats(const uint8_t* ruletable_pb, size_t len, const char* globals_json, uint32_t flags,
+                                 uint8_t** image, size_t* image_len, char** stats_json, char** error) {
   if (error) *error = nullptr;
+  if (stats_json) *stats_json = nullptr;
   if (!image || !image_len || (!ruletable_pb && len)) { set_error(error, "null argument"); return CBL_BAD_INPUT; }
   *image = nullptr; *image_len = 0;
   std::call_once(g_once, start_interpreter);
@@ -124,7 +130,7 @@ int cbl_lower_ruletable_pb(const uint8_t* ruletable_pb, size_t len, const char* 
       if (!out) { set_error(error, "out of memory"); break; }
       memcpy(out, data, static_cast<size_t>(n));
       *image = out; *image_len = static_cast<size_t>(n);
-      if (const char* s = PyUnicode_AsUTF8(stats)) t_stats = s; else PyErr_Clear();
+      if (const char* s = PyUnicode_AsUTF8(stats)) { t_stats = s; if (stats_json) *stats_json = dup_cstr(t_stats); } else PyErr_Clear();
       status = CBL_OK;
     } else {
       const char* msg = PyUnicode_Check(payload) ? PyUnicode_AsUTF8(payload) : nullptr;

@@ -43,6 +43,12 @@ int cbl_abi_version(void);
 int cbl_lower_ruletable_pb(const uint8_t* ruletable_pb, size_t len, const char* globals_json, uint32_t flags,
                            uint8_t** image, size_t* image_len, char** error);
 
+/* The same, and the lowering's statistics with it: *stats_json (may be NULL) = one JSON object (sizes, the kernels the table is eligible
+ * for, what is outside the device subset), NUL-terminated, release with cbl_free.  What a caller whose threads are not its own (a Go
+ * program: a goroutine may resume on another OS thread) uses instead of cbl_last_stats_json. */
+int cbl_lower_ruletable_pb_stats(const uint8_t* ruletable_pb, size_t len, const char* globals_json, uint32_t flags,
+                                 uint8_t** image, size_t* image_len, char** stats_json, char** error);
+
 /* the lowering's statistics of the LAST successful call on this thread's behalf, one JSON object (sizes, kernels the table is
  * eligible for, what is outside the device subset); NUL-terminated, release with cbl_free; NULL before the first call */
 char* cbl_last_stats_json(void);

@@ -51,7 +51,7 @@ def test_lower_library_exports_every_declared_symbol():
     __graft_entry__.build_lower()
     text = open(os.path.join(ROOT, "include", "cerbos_lower.h")).read()
     declared = sorted(set(re.findall(r"\b(cbl_[a-z_]+)\s*\(", text)))
-    assert declared == ["cbl_abi_version", "cbl_free", "cbl_last_stats_json", "cbl_lower_ruletable_pb", "cbl_planner_close", "cbl_planner_open",
+    assert declared == ["cbl_abi_version", "cbl_free", "cbl_last_stats_json", "cbl_lower_ruletable_pb", "cbl_lower_ruletable_pb_stats", "cbl_planner_close", "cbl_planner_open",
                         "cbl_planner_plan_pb"]
     lib = ctypes.CDLL(os.path.join(ROOT, "cerbos_amd", "libcerbos_lower.so"))
     for sym in declared:

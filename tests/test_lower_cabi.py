@@ -88,3 +88,19 @@ def test_inside_a_running_interpreter(lib):
     st, msg = _call(lib, b"\x08")
     assert st == 3 and "bad input" in msg
     assert lib.cbl_abi_version() == 1
+
+
+def test_statistics_come_back_with_the_image(lib):
+    """cbl_lower_ruletable_pb_stats: no thread-local in between (a goroutine may resume on another OS thread)"""
+    lib.cbl_lower_ruletable_pb_stats.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                                 C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.cbl_lower_ruletable_pb_stats.restype = C.c_int
+    pb = encode_rule_table(store_rule_table())
+    image, n, stats, err = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_void_p()
+    assert lib.cbl_lower_ruletable_pb_stats(pb, len(pb), None, 0, C.byref(image), C.byref(n), C.byref(stats), C.byref(err)) == 0
+    want = lower_rule_table(decode_rule_table(pb))
+    assert C.string_at(image, n.value) == bytes(want.blob)
+    got = json.loads(C.string_at(stats).decode())
+    assert got["unsupported"] == [list(x) for x in want.unsupported] and got.keys() >= want.stats.keys()
+    for p in (image, stats, err):
+        lib.cbl_free(p)
