@@ -82,3 +82,11 @@ def _exact(op):
     if "value" in op:
         return {"value": _num(op["value"])}
     return {"variable": op["variable"]}
+
+
+@pytest.mark.parametrize("text", sorted(DATA["buildExpr"]), ids=sorted(DATA["buildExpr"]))
+def test_build_expr(text):
+    """Test_buildExpr (ast_test.go:49-70): CEL text -> filter operand, exactly"""
+    from cerbos_amd.cel.parser import parse
+    from cerbos_amd.plan import filter as flt
+    assert _exact(flt.build(parse(text))) == _exact(DATA["buildExpr"][text]), json.dumps(flt.build(parse(text)))

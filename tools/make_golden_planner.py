@@ -3,6 +3,7 @@
 
   internal/test/testdata/query_planner/policies/**     the policies TestQueryPlan loads (engine_test.go:420-422)
   internal/test/testdata/query_planner_filter/*.yaml    TestNormaliseFilter cases (planner_test.go:443-456)
+  internal/ruletable/planner/testdata/ast_build_expr.yaml   Test_buildExpr cases (ast_test.go:49-70)
   internal/test/testdata/query_planner/suite/{common,strict_scope_search,lenient_scope_search}/*.yaml
                                                         QueryPlannerTestSuite files: a principal and tests of (action(s), resource,
                                                         wanted filter) - engine_test.go:427-495
@@ -48,8 +49,11 @@ def main():
             doc = yaml.safe_load(f.read())
         filters.append({"name": os.path.basename(p)[:-5], "description": doc.get("description", ""), "input": doc.get("input") or {},
                         "wantFilter": doc.get("wantFilter") or {}, "wantString": doc.get("wantString", "")})
+    # Test_buildExpr (ast_test.go:49-70): CEL text -> the filter operand buildExpr makes of it
+    with open("/root/reference/internal/ruletable/planner/testdata/ast_build_expr.yaml", encoding="utf-8") as f:
+        build_expr = yaml.safe_load(f.read())
     with open(OUT, "w", encoding="utf-8") as f:
-        json.dump({"policies": [pols[k] for k in sorted(pols)], "suites": suites, "filters": filters}, f, sort_keys=True, separators=(",", ":"), ensure_ascii=False)
+        json.dump({"policies": [pols[k] for k in sorted(pols)], "suites": suites, "filters": filters, "buildExpr": build_expr}, f, sort_keys=True, separators=(",", ":"), ensure_ascii=False)
         f.write("\n")
     print("wrote", OUT, os.path.getsize(OUT), "bytes;", len(suites), "suites,", sum(len(s["tests"]) for s in suites), "tests")
 
