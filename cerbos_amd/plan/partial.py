@@ -176,7 +176,9 @@ def request_env(principal, resource, aux_data, globals_, constants):
     r = PartialMap({"kind": resource.get("kind", ""), "policyVersion": resource.get("policyVersion", ""),
                     "scope": namer.scope_value(resource.get("scope", "") or ""), "attr": PartialMap(to_cel(resource.get("attr") or {}))})
     r["policy_version"] = r["policyVersion"]
-    req = {"principal": p, "resource": r, "auxData": {"jwt": to_cel(((aux_data or {}).get("jwt")) or {})}}
+    aux = aux_data or {}
+    req = {"principal": p, "resource": r,
+           "auxData": {"jwt": to_cel(aux.get("jwt") or {}), "jwts": {k: {"claims": to_cel((v or {}).get("claims") or {})} for k, v in (aux.get("jwts") or {}).items()}}}
     req["aux_data"] = req["auxData"]
     g, c = to_cel(globals_ or {}), to_cel_consts(constants or {})
     return {"request": req, "R": r, "P": p, "G": g, "globals": g, "C": c, "constants": c}

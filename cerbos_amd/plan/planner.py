@@ -392,3 +392,26 @@ def _node_to_cel(node):
     for k in kids[1:]:
         out = (node[0], out, k)
     return out
+
+
+def plan_resources_response(planner, request: dict, **params):
+    """svc.PlanResources (internal/svc/cerbos_svc.go:53-118) around Planner.plan: a PlanResourcesRequest (its auxData already the engine's
+    AuxData: the claims of the verified JWT) -> the PlanResourcesResponse - requestId, action | actions, resourceKind, policyVersion, filter
+    and, with includeMeta, meta {filterDebug, matchedScope | matchedScopes}."""
+    one = request.get("action") or ""
+    actions = [one] if one else list(request.get("actions") or [])
+    out = planner.plan(dict(request, actions=actions), **params)
+    res = request.get("resource") or {}
+    resp = {"requestId": request.get("requestId", ""), "resourceKind": res.get("kind", ""), "policyVersion": res.get("policyVersion", ""),
+            "filter": out["filter"]}
+    if request.get("includeMeta"):
+        resp["meta"] = {"filterDebug": out["filterDebug"]}
+        if one:
+            resp["meta"]["matchedScope"] = out["matchedScopes"].get(one, "")
+        else:
+            resp["meta"]["matchedScopes"] = out["matchedScopes"]
+    if one:
+        resp["action"] = one
+    else:
+        resp["actions"] = actions
+    return resp

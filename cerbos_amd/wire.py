@@ -364,7 +364,17 @@ def decode_plan_resources_input(buf: bytes) -> dict:
             r["attr"] = _decode_map(attrs)
             inp["resource"] = r
         elif n == 5:
-            inp["auxData"] = {"jwt": _decode_map([v2 for n2, v2 in _fields(v) if n2 == 1])}
+            aux = {"jwt": _decode_map([v2 for n2, v2 in _fields(v) if n2 == 1]), "jwts": {}}
+            for n2, v2 in _fields(v):
+                if n2 == 2:          # map<string, JWT {1 claims}>
+                    name, claims = "", {}
+                    for n3, v3 in _fields(v2):
+                        if n3 == 1:
+                            name = v3.decode("utf-8")
+                        elif n3 == 2:
+                            claims = _decode_map([v4 for n4, v4 in _fields(v3) if n4 == 1])
+                    aux["jwts"][name] = {"claims": claims}
+            inp["auxData"] = aux
         elif n == 6:
             inp["includeMeta"] = bool(v)
         elif n == 7:

@@ -90,3 +90,30 @@ def test_build_expr(text):
     from cerbos_amd.cel.parser import parse
     from cerbos_amd.plan import filter as flt
     assert _exact(flt.build(parse(text))) == _exact(DATA["buildExpr"][text]), json.dumps(flt.build(parse(text)))
+
+
+# ---- the service-level cases (internal/test/testdata/server/plan_resources; svc/cerbos_svc.go:53-118) over the engine store
+SERVER = [c for c in DATA["serverPlans"] if "validationErrors" not in c["wantResponse"]]     # (schema validation is outside the path)
+
+
+@pytest.fixture(scope="module")
+def store_planner():
+    from helpers import store_rule_table
+    return Planner(store_rule_table())
+
+
+@pytest.mark.parametrize("case", SERVER, ids=[c["name"] for c in SERVER])
+def test_service_level_plan(store_planner, case):
+    from cerbos_amd.plan import plan_resources_response
+    have = plan_resources_response(store_planner, case["input"], globals_={"environment": "test"}, now_ns=NOW)
+    want = case["wantResponse"]
+    assert have["filter"]["kind"] == want["filter"]["kind"]
+    assert canon(have["filter"].get("condition")) == canon(want["filter"].get("condition")), json.dumps(have["filter"])
+    for k in ("requestId", "action", "actions", "resourceKind", "policyVersion"):
+        assert (have.get(k) or None) == (want.get(k) or None), k
+    hm, wm = have.get("meta") or {}, want.get("meta") or {}
+    assert (hm.get("matchedScope") or "") == (wm.get("matchedScope") or "") and (hm.get("matchedScopes") or {}) == (wm.get("matchedScopes") or {})
+    if want["filter"]["kind"] != "KIND_CONDITIONAL":
+        assert hm.get("filterDebug") == wm.get("filterDebug")
+    else:   # the debug string prints operands in the order the walk met them: compare what it says, not how
+        assert sorted(hm["filterDebug"].replace("(", " ( ").replace(")", " ) ").split()) == sorted(wm["filterDebug"].replace("(", " ( ").replace(")", " ) ").split())

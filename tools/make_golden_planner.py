@@ -52,8 +52,30 @@ def main():
     # Test_buildExpr (ast_test.go:49-70): CEL text -> the filter operand buildExpr makes of it
     with open("/root/reference/internal/ruletable/planner/testdata/ast_build_expr.yaml", encoding="utf-8") as f:
         build_expr = yaml.safe_load(f.read())
+    # the service-level cases (internal/test/testdata/server/plan_resources; svc/cerbos_svc.go:53-118) over the engine store of
+    # tests/golden/store_policies.json: PlanResourcesRequest in, PlanResourcesResponse out.  The request's JWT is replaced by its
+    # claims (the token's payload, decoded here: verification is the server's business, as on the check path)
+    import base64
+    server = []
+    for p in sorted(glob.glob("/root/reference/internal/test/testdata/server/plan_resources/*.yaml")):
+        with open(p, encoding="utf-8") as f:
+            doc = yaml.safe_load(f.read())
+        pr = doc.get("planResources") or {}
+        inp = dict(pr.get("input") or {})
+        def claims(tok):
+            payload = tok.split(".")[1]
+            return json.loads(base64.urlsafe_b64decode(payload + "=" * (-len(payload) % 4)))
+        aux = inp.get("auxData") or {}
+        if (aux.get("jwt") or {}).get("token") or aux.get("jwts"):
+            inp["auxData"] = {}
+            if (aux.get("jwt") or {}).get("token"):
+                inp["auxData"]["jwt"] = claims(aux["jwt"]["token"])
+            if aux.get("jwts"):
+                inp["auxData"]["jwts"] = {k: {"claims": claims(v["token"])} for k, v in aux["jwts"].items()}
+        server.append({"name": os.path.basename(p)[:-5], "description": doc.get("description", ""), "input": inp,
+                       "wantResponse": pr.get("wantResponse") or {}, "wantStatus": doc.get("wantStatus") or {}})
     with open(OUT, "w", encoding="utf-8") as f:
-        json.dump({"policies": [pols[k] for k in sorted(pols)], "suites": suites, "filters": filters, "buildExpr": build_expr}, f, sort_keys=True, separators=(",", ":"), ensure_ascii=False)
+        json.dump({"policies": [pols[k] for k in sorted(pols)], "suites": suites, "filters": filters, "buildExpr": build_expr, "serverPlans": server}, f, sort_keys=True, separators=(",", ":"), ensure_ascii=False)
         f.write("\n")
     print("wrote", OUT, os.path.getsize(OUT), "bytes;", len(suites), "suites,", sum(len(s["tests"]) for s in suites), "tests")
 
