@@ -70,3 +70,68 @@ func lowerRuleTable(rt *runtimev1.RuleTable, globals map[string]any, perCallGlob
 		return nil, fmt.Errorf("gpu engine: lowering failed (%d): %s", int(st), C.GoString(cErr))
 	}
 }
+
+// ---- PlanResources (Engine.PlanResources, internal/engine/engine.go:141-170; ruletable/plan.go): the query planner is host code in the
+// reference and stays host code here - it runs in the interpreter the lowering runs in (cerbos_amd/plan), one planner per published table.
+
+type gpuPlanner struct{ h C.uint64_t }
+
+// newPlanner: beside lowerRuleTable, when the manager publishes a table.
+func newPlanner(rt *runtimev1.RuleTable) (*gpuPlanner, error) {
+	pb, err := proto.MarshalOptions{Deterministic: true}.Marshal(rt)
+	if err != nil {
+		return nil, err
+	}
+	var h C.uint64_t
+	var cErr *C.char
+	var in *C.uint8_t
+	if len(pb) > 0 {
+		in = (*C.uint8_t)(unsafe.Pointer(&pb[0]))
+	}
+	if st := C.cbl_planner_open(in, C.size_t(len(pb)), &h, &cErr); st != C.CBL_OK {
+		defer C.cbl_free(unsafe.Pointer(cErr))
+		return nil, fmt.Errorf("gpu engine: planner (%d): %s", int(st), C.GoString(cErr))
+	}
+	return &gpuPlanner{h: h}, nil
+}
+
+func (p *gpuPlanner) close() { C.cbl_planner_close(p.h) }
+
+// planParams is what Plan reads of evaluator.EvalParams.
+type planParams struct {
+	Globals              map[string]any `json:"globals,omitempty"`
+	DefaultPolicyVersion string         `json:"defaultPolicyVersion,omitempty"`
+	DefaultScope         string         `json:"defaultScope,omitempty"`
+	LenientScopeSearch   bool           `json:"lenientScopeSearch,omitempty"`
+	StrictEvaluation     bool           `json:"strictEvaluation,omitempty"`
+	NowNs                int64          `json:"nowNs"`
+}
+
+// plan: proto.Marshal(input) in, the serialized enginev1.PlanResourcesOutput out (the caller unmarshals it; the AuditTrail's
+// effective policies are not part of that message).
+func (p *gpuPlanner) plan(inputPB []byte, params planParams) ([]byte, error) {
+	js, err := json.Marshal(params)
+	if err != nil {
+		return nil, err
+	}
+	cParams := C.CString(string(js))
+	defer C.free(unsafe.Pointer(cParams))
+	var (
+		out    *C.uint8_t
+		outLen C.size_t
+		cErr   *C.char
+		in     *C.uint8_t
+	)
+	if len(inputPB) > 0 {
+		in = (*C.uint8_t)(unsafe.Pointer(&inputPB[0]))
+	}
+	st := C.cbl_planner_plan_pb(p.h, in, C.size_t(len(inputPB)), cParams, &out, &outLen, &cErr)
+	if cErr != nil {
+		defer C.cbl_free(unsafe.Pointer(cErr))
+	}
+	if st != C.CBL_OK {
+		return nil, fmt.Errorf("gpu engine: plan (%d): %s", int(st), C.GoString(cErr))
+	}
+	defer C.cbl_free(unsafe.Pointer(out))
+	return C.GoBytes(unsafe.Pointer(out), C.int(outLen)), nil
+}
