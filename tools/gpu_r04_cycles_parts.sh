@@ -1,5 +1,7 @@
 #!/bin/bash
-# GPU box: the walk's prologue and principal pass in parts (library built with -DCBH_PROFILE_CYCLES=2)
+# GPU box: the walk's prologue and principal pass in parts.  The profiling library is built beforehand, in the build container:
+#   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DCBH_PROFILE_CYCLES=2 -Iinclude cerbos_amd/csrc/cbh_engine.hip -o build_variants/lib_profile2.so
+# (build_variants/ is git-ignored and travels with gpurun; -DCBH_PROFILE_CYCLES without a value gives lib_profile.so for the r03 scripts)
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/${1:-r04_parts}; mkdir -p $OUT; cd $R
