@@ -90,8 +90,20 @@ __device__ __forceinline__ typename W2Shape<NA, NR>::W w2_rep_role(u32 rbits) { 
   return m * (W)((1u << NA) - 1u);
 }
 
-template <bool PRE, u32 NA_, u32 NR_>
+// (one reservation of n consecutive entries of a site's list, by one lane)
+__device__ __forceinline__ u32 w2_list_reserve(CBH_G u32* cnt, u32 n) {
+#ifdef CBH_HOSTSIM
+  const u32 old = *cnt; *cnt += n; return old;
+#else
+  return atomicAdd((unsigned int*)cnt, n);
+#endif
+}
+// PMODE: 0 = the walk; 1 = the pre-pass (the sites a request reaches are evaluated where the walk meets them); 2 = the pre-pass's
+// COLLECTOR (cbh_walk2_collect_kernel: the same walk, no evaluator - every (request, site) met is appended to the site's list for
+// cbh_walk2_interp_kernel to evaluate on full waves)
+template <int PMODE, u32 NA_, u32 NR_>
 __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const W2Layout& ly) {
+  constexpr bool PRE = PMODE != 0;
   const TableDev& t = ka_regs.t;
   const BatchDev& b = ka_regs.b;
   const OutDev& o = ka_regs.o;
@@ -288,7 +300,24 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     const bool slow = active && lv == 4u;
     if (wave_ballot(slow) != 0) {
       const bool filed = gslot < b.n_gslots;   // uniform (CBH_GSLOT_NONE is beyond any count)
-      if (PRE) {
+      if (PMODE == 2) {
+        // the collector: the site goes on its slot's list once per request (bit 2 of the slot's result nibble says it did; the
+        // walk reads the nibble through 0xB), its outcome is taken as "satisfied" so that what lies behind it is collected too
+        const u32 nib = 4u * (gslot % CBH_W2_SLOTS_PER_WORD);
+        const bool add = slow && filed && !((gacc[(gslot / CBH_W2_SLOTS_PER_WORD) * CBH_BLOCK + c.tid] >> (nib + 2u)) & 1ull);
+        const u64 who = wave_ballot(add);
+        if (who != 0) {
+          u32 base = 0;
+          if (c.tid == first_lane(who)) base = w2_list_reserve(b.site_cnt + gslot, (u32)__builtin_popcountll(who));
+          base = wave_readlane(base, first_lane(who));
+          if (add) {
+            const u32 rank = (u32)__builtin_popcountll(who & ((1ull << c.tid) - 1ull));
+            b.site_list[(size_t)gslot * b.site_cap + base + rank] = (u64)req | ((u64)ref << 32);
+            gacc[(gslot / CBH_W2_SLOTS_PER_WORD) * CBH_BLOCK + c.tid] |= 4ull << nib;
+          }
+        }
+        if (slow) lv = filed ? 1u : 8u;
+      } else if (PRE) {
         W2_DBG(const u64 e0 = __builtin_readcyclecounter(); ++dbg_evals;)
         const u32 r = eval_ref<true>(c.ka_mem, lds_of(c), req, edr_scope, false, ref, slow);
         W2_DBG(cyc_eval += __builtin_readcyclecounter() - e0;)
@@ -877,6 +906,66 @@ __device__ __forceinline__ void w2_pre_kernel_body(const KernelArgs& a, const Ke
 __global__ __launch_bounds__(CBH_BLOCK) CBH_PRE_WAVES void cbh_walk2_pre_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_pre_kernel_body<CBH_W2_NA, CBH_W2_NR>(a, ka); }
 __global__ __launch_bounds__(CBH_BLOCK) CBH_PRE_WAVES void cbh_walk2_pre_wide_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_pre_kernel_body<CBH_W2_NA, CBH_W2_WIDE_NR>(a, ka); }
 __global__ __launch_bounds__(CBH_BLOCK) CBH_PRE_WAVES void cbh_walk2_pre_awide_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_pre_kernel_body<CBH_W2_AWIDE_NA, CBH_W2_NR>(a, ka); }
+
+// ---- the pre-pass in two kernels (CBH_PRE_SPLIT=1; measured in the round after this one: DESIGN §7): the collector walks as the
+// pre-pass does but evaluates nothing - it needs the walk's registers, not the interpreter's - and the interpreter runs over the
+// sites' lists, 64 (request, program) items to a wave, the items of a wave mostly one program (requests are grouped by route).
+template <u32 NA, u32 NR>
+__device__ __forceinline__ void w2_collect_kernel_body(const KernelArgs& a, const KernelArgs* __restrict__ ka) {
+  const u32 ncc = a.t.inline_cols;
+  const W2Layout ly = w2_layout(ncc, false, a.t.max_depth, a.t.n_scopes, true, a.b.n_gwords, a.t.K, a.t.n_dr, CBH_W2_NA, (a.flags & CBH_FI_PACKED_TAGS) != 0);
+  Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (CBH_L u32*)cbh_dyn_lds, ncc, ka};
+  w2_body<2, NA, NR>(a, c, ly);
+}
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_walk2_collect_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_collect_kernel_body<CBH_W2_NA, CBH_W2_NR>(a, ka); }
+// grid = slots x ceil(requests / 64); a block whose part of its slot's list is empty leaves at once
+__global__ __launch_bounds__(CBH_BLOCK) void cbh_walk2_interp_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+  __shared__ u64 s_val[CBH_STACK_DEPTH * CBH_BLOCK];
+  __shared__ u64 l_val[CBH_MAX_LOCALS * CBH_BLOCK];
+  __shared__ u64 it_cont[CBH_MAX_ITERS * CBH_BLOCK];
+  __shared__ u32 it_idx[CBH_MAX_ITERS * CBH_BLOCK];
+  __shared__ u32 it_state[CBH_MAX_ITERS * CBH_BLOCK];
+  __shared__ u8 s_tag[CBH_STACK_DEPTH * CBH_BLOCK];
+  __shared__ u8 l_tag[CBH_MAX_LOCALS * CBH_BLOCK];
+  const BatchDev& b = a.b;
+  const u32 tid = threadIdx.x;
+  const u32 n = b.req_hi - b.req_lo, chunks = (n + CBH_BLOCK - 1u) / CBH_BLOCK;
+  const u32 slot = blockIdx.x / chunks, first = (blockIdx.x % chunks) * CBH_BLOCK;
+  u32 cnt = uload(&b.site_cnt[slot]);
+  if (cnt > b.site_cap) cnt = b.site_cap;
+  if (first >= cnt) return;
+  {
+    for (u32 k = 0; k < CBH_STACK_DEPTH; ++k) { s_tag[k * CBH_BLOCK + tid] = CBH_T_ERR; s_val[k * CBH_BLOCK + tid] = 0; }
+    for (u32 k = 0; k < CBH_MAX_LOCALS; ++k) { l_tag[k * CBH_BLOCK + tid] = CBH_T_ERR; l_val[k * CBH_BLOCK + tid] = 0; }
+    for (u32 k = 0; k < CBH_MAX_ITERS; ++k) { it_cont[k * CBH_BLOCK + tid] = 0; it_idx[k * CBH_BLOCK + tid] = 0; it_state[k * CBH_BLOCK + tid] = 0; }
+  }
+  const bool valid = first + tid < cnt;
+  const u64 item = b.site_list[(size_t)slot * b.site_cap + (valid ? first + tid : first)];
+  const u32 req = (u32)item, ref = (u32)(item >> 32);
+  const u32 ncc = cached_columns(&a);
+  Ctx c{a.t, a.b, a.now_ns, a.flags, tid, (CBH_L u64*)s_val, (CBH_L u8*)s_tag, (CBH_L u64*)l_val, (CBH_L u8*)l_tag,
+        (CBH_L u64*)it_cont, (CBH_L u32*)it_idx, (CBH_L u32*)it_state, (CBH_L u32*)cbh_dyn_lds, ncc, ka};
+  fill_column_cache(c, b, b.n_requests, req);
+  bool pend = valid;
+  for (;;) {   // the programs of the wave's items, one after the other (mostly one)
+    const u64 rem = wave_ballot(pend);
+    if (rem == 0) break;
+    const u32 g_ref = wave_readlane(ref, first_lane(rem));
+    const bool mine = pend && ref == g_ref;
+    pend = pend && !mine;
+    const u32 r = eval_ref<true>(c.ka_mem, lds_of(c), req, 0, false, g_ref, mine);
+    if (mine) {
+      const u32 st = r >> 8;
+      const u64 code = (u64)(((r & 0xFFu) == 1u ? 1u : 0u) | ((st & CBH_ST_CEL_ERROR) ? 2u : 0u) | ((st & CBH_ST_UNSUPPORTED) ? 8u : 0u));
+      CBH_G u64* w = b.gres + (size_t)(slot / CBH_W2_SLOTS_PER_WORD) * b.n_requests + req;
+#ifdef CBH_HOSTSIM
+      *w |= code << (4u * (slot % CBH_W2_SLOTS_PER_WORD));
+#else
+      atomicOr((unsigned long long*)w, (unsigned long long)(code << (4u * (slot % CBH_W2_SLOTS_PER_WORD))));
+#endif
+    }
+  }
+}
 
 // Does cbh_walk2_kernel decide this table's batches?  (CBH_MF_WALK2; not strict mode, whose immediate DENYs are order
 // dependent.)  Requests with five to eight roles or nine to sixteen actions take the walk's wider forms, what is wider

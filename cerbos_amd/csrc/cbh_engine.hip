@@ -597,6 +597,7 @@ static CbhPlan plan_for(const TableDev& dev, u32 max_actions, u32 max_roles, boo
   return cbh_plan(dev.flags, dev.n_dr, has_globs, dev.gslots_generic, dev.gslots_all, max_actions, max_roles, plain_tags, eval_flags, no_flat, no_walk2,
                   force_staged ? 0xFFFFFFFFu : dev.max_bucket, no_walk2_wide, cbh_flat_use_masks(dev.segs, dev.max_bucket));
 }
+static bool pre_split_on() { static const bool on = [] { const char* e = getenv("CBH_PRE_SPLIT"); return e && atoi(e) != 0; }(); return on; }
 // Does the packed form of the column cache's tags (cbh_vm.h CBH_CC_DWORDS) let a CU hold more workgroups of `fn` than the wide one?
 // The runtime's occupancy figure for the kernel at either LDS size, kept per (kernel, size).  CBH_PACKED_TAGS=0/1 (tests,
 // measurement): never / always.
@@ -664,7 +665,13 @@ static void launch_plan(const CbhPlan& pl, const TableDev& dev, KernelArgs ka, c
       go(shape == 1 ? cbh_walk2_wide_kernel : cbh_walk2_awide_kernel, (whi - wlo + pl.threads - 1) / pl.threads, pl.threads,
          plan_lds(false, na, 0), kv, false);
     }
-    if (ka.b.n_gwords)   // the evaluation sites first: their results are what the walk reads
+    if (ka.b.n_gwords && ka.b.site_cnt && ka.b.site_cap >= n && pre_split_on()) {
+      // the evaluation sites in two kernels: who reaches which site (the walk's registers), then the sites' lists (the interpreter's)
+      (void)hipMemsetAsync(ka.b.site_cnt, 0, (size_t)ka.b.n_gslots * 4, s);
+      go(cbh_walk2_collect_kernel, (n + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK,
+         [&](bool packed) { return w2_lds_bytes(w2_layout(dev.inline_cols, false, dev.max_depth, dev.n_scopes, true, pl.n_gwords, dev.K, dev.n_dr, CBH_W2_NA, packed), 1u); }, ka, false);
+      go(cbh_walk2_interp_kernel, ka.b.n_gslots * ((n + CBH_BLOCK - 1) / CBH_BLOCK), CBH_BLOCK, plan_lds(true, CBH_W2_NA, 0), ka, false);
+    } else if (ka.b.n_gwords)   // the evaluation sites first: their results are what the walk reads
       go(cbh_walk2_pre_kernel, (n + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK, plan_lds(true, CBH_W2_NA, 0), ka, false);
   }
   static const bool pre_only = getenv("CBH_PRE_ONLY") != nullptr;   // measurement aid (profiling build): the pre-pass alone
@@ -688,6 +695,14 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   HIPCHK(hipSetDevice(rep->device));
   hipStream_t s = b->stream;
   b->w_total_known = false;   // (the sizes cbh_wire_outputs computed belong to the results this launch replaces)
+  // CBH_PRE_SPLIT=1 (to be measured: DESIGN §7): the walk's pre-pass as a collector and an interpreter over per-site lists - the lists
+  // live with the batch (slots x requests items).  Tables whose programs read runtime.effectiveDerivedRoles keep the fused pre-pass.
+  if (pre_split_on() && !b->dev.site_cnt && b->dev.n_requests && (rep->dev.flags & CBH_MF_WALK2) && rep->dev.gslots_all &&
+      !(rep->dev.flags & CBH_MF_USES_RUNTIME_EDR) && b->dev.gres) {
+    u32* cnt = nullptr; u64* list = nullptr;
+    if (dalloc(b, cnt, (size_t)rep->dev.gslots_all) != 0 || dalloc(b, list, (size_t)rep->dev.gslots_all * b->dev.n_requests) != 0) return -1;
+    b->dev.site_cnt = cnt; b->dev.site_list = list; b->dev.site_cap = b->dev.n_requests;
+  }
   // Kernel durations come from the dispatches' own begin / end timestamps (hipExtLaunchKernelGGL
   // with start / stop events: what rocprofv3's kernel trace reads too), not from event-record
   // packets placed around them, which would sit between back-to-back launches and add their own

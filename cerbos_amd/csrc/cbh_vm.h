@@ -93,6 +93,8 @@ struct BatchDev {
   CBH_G u64* gres;  // [n_gwords][n_requests] results of the evaluation sites (cbh_walk2_pre_kernel writes, cbh_walk2_kernel reads)
   u32 n_gwords; u32 n_gslots;   // words per request; sites filed = slots 0 .. n_gslots - 1
   const CBH_G u32* ep_group;    // cbh_check_batch_trail: the group (Check call) request i belongs to, or null (one group)
+  // the split pre-pass (cbh_walk2_collect_kernel / cbh_walk2_interp_kernel): per evaluation-site slot a list of (request | program << 32)
+  CBH_G u32* site_cnt; CBH_G u64* site_list; u32 site_cap; u32 pad_sites;   // [slots], [slots][site_cap]; null = the fused pre-pass
 };
 
 struct OutDev {

@@ -94,6 +94,7 @@ static cbh_check_kernel_fn g_kernel;   // the kernel the fibers run
 static bool g_used_walk_awide = false;
 static bool g_used_walk_wide = false;   // did the last batch launch cbh_walk2_wide_kernel? (hostsim_last_walk_wide)
 static bool g_last_masks = false;
+static bool g_used_pre_split = false;   // did the last batch run the pre-pass as collector + interpreter? (hostsim_last_pre_split)
 static int g_last_kind = -1;   // which kernel family decided the last batch (hostsim_last_kind: tests assert the one they mean to exercise)
 static bool g_trace;   // hostsim_trace: the trace pass's kernel (cbh_trace_batch)
 
@@ -225,6 +226,12 @@ static int run_sim(const void* blob, size_t len, const cbh_batch* in, const cbh_
                               cbh_flat_use_masks_now(a.t.segs, a.t.max_bucket));
   std::vector<uint64_t> gres((size_t)pl.n_gwords * in->n_requests + 1, 0xDDDDDDDDDDDDDDDDull);
   b.gres = pl.n_gwords ? gres.data() : nullptr; b.n_gwords = pl.n_gwords; b.n_gslots = pl.n_gslots;
+  // CBH_PRE_SPLIT=1: the pre-pass as cbh_walk2_collect_kernel + cbh_walk2_interp_kernel (as cbh_engine.hip launch_plan)
+  const bool pre_split = getenv("CBH_PRE_SPLIT") && atoi(getenv("CBH_PRE_SPLIT")) != 0 && pl.n_gwords && !(a.t.flags & CBH_MF_USES_RUNTIME_EDR);
+  std::vector<uint32_t> site_cnt(pl.n_gslots + 1, 0);
+  std::vector<uint64_t> site_list(pre_split ? (size_t)pl.n_gslots * in->n_requests + 1 : 1, 0xEEEEEEEEEEEEEEEEull);
+  if (pre_split) { b.site_cnt = site_cnt.data(); b.site_list = site_list.data(); b.site_cap = in->n_requests; }
+  g_used_pre_split = false;
   if (const char* e = getenv("CBH_HOSTSIM_REPORT")) { if (*e == '1') std::fprintf(stderr, "hostsim: kernel kind %d, %u result words\n", pl.kind, pl.n_gwords); }
   g_last_kind = trace ? -1 : pl.kind;
   g_last_masks = !trace && pl.kind == 1 && cbh_is_mask_kernel(pl.kernel);
@@ -254,7 +261,12 @@ static int run_sim(const void* blob, size_t len, const cbh_batch* in, const cbh_
         g_kernel = cbh_walk2_awide_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
         g_used_walk_awide = true;
       }
-      if (pl.n_gwords) { g_kernel = cbh_walk2_pre_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk); }
+      if (pl.n_gwords && pre_split) {
+        std::fill(site_cnt.begin(), site_cnt.end(), 0u);
+        g_kernel = cbh_walk2_collect_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
+        g_kernel = cbh_walk2_interp_kernel; for (uint32_t blk = 0; blk < pl.n_gslots * nblocks; ++blk) run_block(blk);
+        g_used_pre_split = true;
+      } else if (pl.n_gwords) { g_kernel = cbh_walk2_pre_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk); }
     }
     g_kernel = pl.kernel;
     for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
@@ -278,6 +290,7 @@ extern "C" int hostsim_check_trail(const void* blob, size_t len, const cbh_batch
   return rc;
 }
 extern "C" int hostsim_last_kind() { return g_last_kind; }
+extern "C" int hostsim_last_pre_split() { return g_used_pre_split ? 1 : 0; }
 extern "C" int hostsim_last_masks() { return g_last_masks ? 1 : 0; }   // did the last batch take the flat kernel's mask walk?
 extern "C" int hostsim_last_walk_wide() { return (g_used_walk_wide ? 1 : 0) | (g_used_walk_awide ? 2 : 0); }
 extern "C" int hostsim_trace(const void* blob, size_t len, const cbh_batch* in, const cbh_params* p,

@@ -88,6 +88,11 @@ def check_trail(lt, batch, groups=None, n_groups=1, now_ns=0, flags=0):
     return res, masks[:, :words]
 
 
+def last_pre_split():
+    """Did the last batch run the walk's pre-pass as collector + interpreter (CBH_PRE_SPLIT=1)?"""
+    return bool(lib().hostsim_last_pre_split())
+
+
 def last_kind():
     """Which kernel family decided the last batch: 0 the general walk, 1 a flat kernel, 2 cbh_walk2_kernel."""
     return lib().hostsim_last_kind()
