@@ -116,3 +116,100 @@ class BatchingEvaluator:
             self.calls += len(batch)
             for c in batch:
                 c.done.set()
+
+
+class _RequestCall:
+    __slots__ = ("request", "aux", "key", "done", "outputs", "flags", "include_meta", "error")
+
+    def __init__(self, request, aux, key):
+        self.request, self.aux, self.key = request, aux, key
+        self.done = threading.Event()
+        self.outputs = self.flags = self.include_meta = self.error = None
+
+
+class RequestBatcher:
+    """The same gathering for what a server's handler holds: the BYTES of a ``CheckResourcesRequest`` (and the serialized engine
+    ``AuxData`` it derived from the request's JWT).  ``check_request`` blocks like ``svc.CheckResources``' call of ``eng.Check`` and is safe
+    from any number of threads; the dispatcher sends what arrived within ``max_wait_s`` (or ``max_requests``) down the device road as ONE
+    call of ``cbh_wire_check_requests_pb`` (``HipEvaluator.check_requests_pb``: the requests are split into their ``CheckInput``s on the
+    device) and hands every caller the serialized ``CheckOutput``s of its own resource entries, their flags (``CBI_OUT_*``) and whether the
+    request asked for ``include_meta``.  A batch the device road leaves to the host flattener is answered request by request through
+    ``on_host`` (``HipEvaluator.check_request_pb`` bound by the caller), when given; else its callers get the error."""
+
+    def __init__(self, evaluator, max_requests: int = 2048, max_wait_s: float = 200e-6, on_host=None):
+        self.ev, self.max_requests, self.max_wait_s, self.on_host = evaluator, max_requests, max_wait_s, on_host
+        self._cv = threading.Condition()
+        self._queue = []
+        self._closed = False
+        self.batches = self.calls = 0
+        self._thread = threading.Thread(target=self._run, name="cbh-request-batcher", daemon=True)
+        self._thread.start()
+
+    def check_request(self, request: bytes, aux_data: bytes = None, now_ns=None, lenient_scope_search=None, strict_evaluation=None,
+                      default_policy_version=None, default_scope=None):
+        call = _RequestCall(bytes(request), aux_data, (now_ns, lenient_scope_search, strict_evaluation, default_policy_version, default_scope))
+        with self._cv:
+            if self._closed:
+                raise RuntimeError("RequestBatcher is closed")
+            self._queue.append(call)
+            self._cv.notify_all()
+        call.done.wait()
+        if call.error is not None:
+            raise call.error
+        return call.outputs, call.flags, call.include_meta
+
+    def close(self):
+        with self._cv:
+            self._closed = True
+            self._cv.notify_all()
+        self._thread.join()
+
+    def _take(self):
+        with self._cv:
+            while not self._queue and not self._closed:
+                self._cv.wait()
+            if not self._queue:
+                return None
+            deadline = time.monotonic() + self.max_wait_s
+            while not self._closed and len(self._queue) < self.max_requests:
+                left = deadline - time.monotonic()
+                if left <= 0:
+                    break
+                self._cv.wait(left)
+            key = self._queue[0].key
+            batch = [c for c in self._queue if c.key == key][:self.max_requests]
+            taken = set(map(id, batch))
+            self._queue = [c for c in self._queue if id(c) not in taken]
+            return batch
+
+    def _run(self):
+        from . import capi
+        while True:
+            batch = self._take()
+            if batch is None:
+                return
+            now_ns, lenient, strict, dver, dscope = batch[0].key
+            kw = dict(now_ns=now_ns, lenient_scope_search=lenient, strict_evaluation=strict, default_policy_version=dver, default_scope=dscope)
+            try:
+                aux = [c.aux for c in batch]
+                outs, flags, meta = self.ev.check_requests_pb([c.request for c in batch], aux if any(aux) else None, **kw)
+                at = 0
+                for c, o, m in zip(batch, outs, meta):
+                    c.outputs, c.flags, c.include_meta = o, flags[at:at + len(o)], bool(m)
+                    at += len(o)
+            except capi.HostFlattenerNeeded as e:
+                for c in batch:          # (rare: an entry with more than 64 actions, a kind to rewrite that no policy names, ...)
+                    if self.on_host is None:
+                        c.error = e
+                        continue
+                    try:
+                        c.outputs, c.flags, c.include_meta = self.on_host(c.request, c.aux, **kw)
+                    except Exception as e2:  # noqa: BLE001
+                        c.error = e2
+            except Exception as e:  # noqa: BLE001 - every waiting caller gets the failure, none is left hanging
+                for c in batch:
+                    c.error = e
+            self.batches += 1
+            self.calls += len(batch)
+            for c in batch:
+                c.done.set()

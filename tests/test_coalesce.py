@@ -56,3 +56,41 @@ def test_errors_and_empty_calls(evaluator):
     be.close()
     with pytest.raises(RuntimeError):
         be.check([load_json("engine_cases.json")[0]["inputs"][0]])
+
+
+# ---- the same gathering on the bytes a server's handler holds: CheckResourcesRequests (RequestBatcher over check_requests_pb)
+def _request_of(inputs, include_meta):
+    return {"requestId": inputs[0].get("requestId", ""), "includeMeta": include_meta, "principal": inputs[0]["principal"],
+            "resources": [{"actions": i["actions"], "resource": i["resource"]} for i in inputs]}
+
+
+def test_request_bytes_are_gathered_and_answered_per_request(evaluator):
+    from cerbos_amd import wire
+    from cerbos_amd.coalesce import RequestBatcher
+    cases = load_json("server_check_cases.json")
+    rng = np.random.default_rng(9)
+    picks = [cases[int(x)] for x in rng.integers(0, len(cases), size=90)]
+    reqs = [wire.encode_check_resources_request(_request_of(c["inputs"], bool(k & 1))) for k, c in enumerate(picks)]
+    want = [evaluator.check_requests_pb([r], now_ns=NOW) for r in reqs]
+    rb = RequestBatcher(evaluator, max_requests=32, max_wait_s=0.01)
+    got = [None] * len(reqs)
+
+    def worker(lo, hi):
+        for j in range(lo, hi):
+            got[j] = rb.check_request(reqs[j], now_ns=NOW)
+    threads = [threading.Thread(target=worker, args=(a, min(a + 9, len(reqs)))) for a in range(0, len(reqs), 9)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k, ((outs, flags, meta), (w_outs, w_flags, w_meta)) in enumerate(zip(got, want)):
+        assert outs == w_outs[0] and list(flags) == list(w_flags) and meta == bool(w_meta[0]) == bool(k & 1)
+        for raw, wnt in zip(outs, picks[k]["want"]):
+            assert {a: e["effect"] for a, e in wire.decode_check_output(raw)["actions"].items()} == wnt["actions"]
+    assert rb.calls == len(reqs) and rb.batches < len(reqs)
+    with pytest.raises(Exception, match="malformed CheckResourcesRequest"):
+        rb.check_request(reqs[0][:-2], now_ns=NOW)
+    assert rb.check_request(reqs[1], now_ns=NOW)[0] == want[1][0][0]       # the batcher survives a failed batch
+    rb.close()
+    with pytest.raises(RuntimeError):
+        rb.check_request(reqs[0])

@@ -59,6 +59,20 @@ class HostSimEvaluator(HipEvaluator):
                 import wire_device_util as wu
                 _self.device_road_calls = getattr(_self, "device_road_calls", 0) + 1
                 return wu.sim_outputs(lt, db.res, db.wb.n, edr_is_grouped=db.wb.grouped is not None)
+
+            # ... and of check_requests_pb (cbh_wire_req.h in front of it): split, flatten, decide, assemble - all on the simulator
+            def wire_check_requests_pb(_self, requests, aux=None, now_ns=0, flags=0, default_policy_version="default", default_scope="",
+                                       device_index=0, globals_pb=b""):
+                from cerbos_amd import wire
+                from test_request_road import sim_split
+                got = sim_split(list(requests), aux)
+                if isinstance(got, int):
+                    raise capi.HipEngineError("malformed CheckResourcesRequest at index %d" % got)
+                msgs, first, rflags = got
+                db = _self.wire_flatten(*wire.pack_messages(msgs), default_policy_version, default_scope, globals_pb=globals_pb)
+                _self.launch(db, now_ns, flags)
+                outs, oflags = _self.wire_outputs(db)
+                return [outs[int(first[r]):int(first[r + 1])] for r in range(len(requests))], oflags, (rflags & 1).astype(bool)
         self.table = _T()
 
 
