@@ -996,7 +996,7 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
         (atotal && hipMemcpyAsync(d_aux, reqs->aux, atotal, hipMemcpyHostToDevice, s) != hipSuccess) ||
         (reqs->aux_offsets && nr && hipMemcpyAsync(d_aoff, reqs->aux_offsets, ((size_t)nr + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess))
       { fail("cbh_wire_flatten_requests: upload failed"); return bail(-1); }
-    q.req = d_req; q.roff = d_roff; q.n = nr; q.end = (u32)rtotal; q.aux = d_aux; q.aoff = reqs->aux_offsets ? d_aoff : nullptr;
+    q.req = d_req; q.roff = d_roff; q.n = nr; q.end = (u32)rtotal; q.aux = d_aux; q.aoff = reqs->aux_offsets ? d_aoff : nullptr; q.aux_end = atotal;
     if (nr) hipLaunchKernelGGL(cbh_wire_req_count_kernel, dim3((nr + CBH_BLOCK - 1) / CBH_BLOCK), dim3(CBH_BLOCK), 0, s, q);
     std::vector<u32> h_inputs((size_t)nr + 1, 0), h_first((size_t)nr + 1, 0); std::vector<u64> h_bytes((size_t)nr + 1, 0), h_fbyte((size_t)nr + 1, 0);
     if (nr && (hipMemcpyAsync(h_inputs.data(), q.n_inputs, (size_t)nr * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||

@@ -22,7 +22,7 @@
 
 struct WireReqArgs {
   const CBH_G u8* req; const CBH_G u64* roff; u32 n; u32 end;   // request r = req[roff[r] .. roff[r + 1]); end = bytes of all requests
-  const CBH_G u8* aux; const CBH_G u64* aoff;                   // serialized engine AuxData of request r = aux[aoff[r] .. aoff[r + 1]), or null
+  const CBH_G u8* aux; const CBH_G u64* aoff; u64 aux_end;      // serialized engine AuxData of request r = aux[aoff[r] .. aoff[r + 1]), or null; aux_end = its bytes
   CBH_G u32* n_inputs;            // [n] resource entries of request r (CBH_WREQ_BAD: malformed)
   CBH_G u64* n_bytes;             // [n] bytes of their CheckInputs
   CBH_G u8* flags;                // [n] bit 0 = include_meta
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_req_count_kernel(WireReqAr
     WSpan s; s.p = (u32)o0; s.e = (u32)o1;
     w_req_top(m, s, top, n_entries, bad);
     u32 aux_len = 0;
-    if (a.aoff) { const u64 a0 = a.aoff[r], a1 = a.aoff[r + 1u]; if (a1 < a0 || a1 - a0 > 0xFFFFFFFFull) bad = true; else aux_len = (u32)(a1 - a0); }
+    if (a.aoff) { const u64 a0 = a.aoff[r], a1 = a.aoff[r + 1u]; if (a1 < a0 || a1 > a.aux_end || a1 - a0 > 0xFFFFFFFFull) bad = true; else aux_len = (u32)(a1 - a0); }
     // what every CheckInput of the request repeats
     const u64 shared = (top.has_rid ? w_ld_size(top.rid.e - top.rid.p) : 0u) + (top.has_principal ? w_ld_size(top.principal.e - top.principal.p) : 0u)
                      + (aux_len ? w_ld_size(aux_len) : 0u);

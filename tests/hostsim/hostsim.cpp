@@ -412,7 +412,7 @@ extern "C" long long hostsim_wire_split_requests(const uint8_t* bytes, const uin
                                                  const uint8_t** out_msg, const uint64_t** out_moff, const uint32_t** out_first_input,
                                                  const uint8_t** out_flags, uint32_t* first_bad) {
   WireReqArgs a{};
-  a.req = bytes; a.roff = offsets; a.n = n; a.end = n ? (uint32_t)offsets[n] : 0; a.aux = aux; a.aoff = aoff;
+  a.req = bytes; a.roff = offsets; a.n = n; a.end = n ? (uint32_t)offsets[n] : 0; a.aux = aux; a.aoff = aoff; a.aux_end = (aoff && n) ? aoff[n] : 0;
   g_q.ninputs.assign(n + 1, 0); g_q.nbytes.assign(n + 1, 0); g_q.flags.assign(n + 1, 0);
   a.n_inputs = g_q.ninputs.data(); a.n_bytes = g_q.nbytes.data(); a.flags = g_q.flags.data();
   g_wqargs = &a;

@@ -195,3 +195,20 @@ def test_requests_down_the_device_road_on_the_simulator(case):
         assert {a: e["effect"] for a, e in have["actions"].items()} == want["actions"], case["name"]
         for a, m in want["meta"].items():
             assert have["actions"][a]["policy"] == m["matchedPolicy"] and have["actions"][a]["scope"] == m["matchedScope"]
+
+
+def test_auxiliary_offsets_that_point_outside_are_refused():
+    """[0, far beyond the bytes, ..]: the request is named, nothing outside the auxiliary bytes is read."""
+    import ctypes as C
+    lib = hostsim_api.lib()
+    lib.hostsim_wire_split_requests.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p] + [C.POINTER(C.c_void_p)] * 4 + [C.POINTER(C.c_uint32)]
+    lib.hostsim_wire_split_requests.restype = C.c_longlong
+    req = wire.encode_check_resources_request(_request_of(_cases()[0]))
+    data, off = wire.pack_messages([req, req, req])
+    data = np.concatenate([data, np.zeros(8, np.uint8)])
+    aux = np.zeros(64, np.uint8)
+    aoff = np.array([0, 10, 1_000_000, 20], dtype=np.uint64)          # request 1's auxiliary data "ends" a megabyte away
+    outs = [C.c_void_p() for _ in range(4)]
+    bad = C.c_uint32()
+    n = lib.hostsim_wire_split_requests(data.ctypes.data, off.ctypes.data, 3, aux.ctypes.data, aoff.ctypes.data, *[C.byref(o) for o in outs], C.byref(bad))
+    assert n < 0 and bad.value == 1
