@@ -406,7 +406,10 @@ __device__ __forceinline__ u64 load_u64g(const CBH_G u32* p) {   // 8-byte align
 
 // MODE 0: records one scalar load at a time; 1: staged 64 at a time in the lanes' registers; 2: no record is visited - the
 // bucket's SEGMENTS decide by masks (cbh_blob.h CBH_SEC_SEGS).
-template <bool WITH_CALL, int MODE>
+// EP: the instantiations of cbh_check_batch_trail (AuditTrail.EffectivePolicies, check.go:302-304) - per chain position a lane keeps
+// which of its walks met a binding there and the bucket's policy; the fold marks the policies the walks the reference REALLY makes
+// (not those of a role behind the one that allowed) have touched.  A bucket of a flat table is one resource policy's.
+template <bool WITH_CALL, int MODE, bool EP = false>
 __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   constexpr bool STAGED = MODE == 1;
   constexpr u32 BTYPE = MODE == 2 ? (u32)CBH_B_RESSEG : (u32)CBH_B_RESOURCE;
@@ -462,6 +465,10 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   CBH_L u8* seg_rec = (CBH_L u8*)(segm + 64);      // [2][64]: record -> item of its condition / of its derived-role condition
   CBH_L u64* seg_desc = segm + 64 + 16;            // [64] CbhSegDesc
   CBH_L u8* lvtab = (CBH_L u8*)(segm + 64 + 16 + 64);   // [CBH_LV_ROWS][64]
+  // EP: [depth][touched walks | policy][lane], behind everything else (cbh_flat_trail_bytes)
+  CBH_L u32* ep_lds = (CBH_L u32*)(cls_lds + (cls_in_lds ? ((2u * t.K + 15u) & ~15u) : 0u) + (MODE == 2 ? CBH_FLAT_WAVES * CBH_SEG_LDS_BYTES : 0u)) + wave * max_depth * 2u * CBH_BLOCK;
+  const bool want_ep = EP && (flags & CBH_F_WANT_EFFECTIVE_POLICIES) != 0 && o.eff_pol != nullptr;
+  if (EP) { for (u32 d = 0; d < 2u * max_depth; ++d) ep_lds[d * CBH_BLOCK + c.tid] = 0; }
   // Actions: a batch of four-action requests laid out back to back has ACT_OFF = 4 * request - read the four ids from
   // there with ONE 16-byte load that does not wait for ACT_OFF to arrive, and fall back to the dependent loads for the
   // lanes where the guess was wrong.
@@ -573,6 +580,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
     if (go) {
       if (ing && mydepth < max_depth) { if (chain8) chain_si8[mydepth * CBH_BLOCK + c.tid] = (u8)g_si; else chain_si[mydepth * CBH_BLOCK + c.tid] = g_si; }
       const u32 S_before = S;
+      u32 touch = 0, g_pol = 0;   // EP: the walks that met a binding of this bucket, the bucket's policy
       if constexpr (MODE == 2) {
         // ---- the mask walk.  Index.Query answers a request with an AND of per-dimension bitmaps (index/index.go:270-305);
         // so does this: per segment of <= 64 records, a lane's candidates = (OR of the masks of its action classes) &
@@ -608,6 +616,16 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 #pragma unroll
           for (u32 k = 0; k < 4; ++k) { if (k < act_cnt) A |= segm[ac[k]]; if (k < role_cnt) R |= segm[32u + rc[k]]; }
           const u64 cand_any = (ing && S != 0) ? (A & R) : 0ull;
+          if (EP) {
+            if (sgi == 0) g_pol = uload(&t.rows[(size_t)hd.row_begin * 16u + 3u]);   // TblRow.policy of the bucket's first record
+            if (cand_any != 0) {
+#pragma unroll
+              for (u32 k = 0; k < 4; ++k)
+#pragma unroll
+                for (u32 r = 0; r < 4; ++r)
+                  if (((S >> (4u * r + k)) & 1u) && (segm[ac[k]] & segm[32u + rc[r]]) != 0) touch |= 1u << (4u * r + k);
+            }
+          }
           FLAT_DBG(dbg_rows += hd.n_records;)
           if (wave_ballot(cand_any != 0) != 0) {
             u64 csat = ~0ull, dsat = ~0ull, cerr = 0, derr = 0, cuns = 0, duns = 0;
@@ -763,6 +781,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
                                 ((0u - ((rw.rm_lo >> rc[2]) & 1u)) & 0xF00u) | ((0u - ((rw.rm_lo >> rc[3]) & 1u)) & 0xF000u);
               const u32 m = ing ? (mrole & (mact * 0x1111u) & S) : 0u;
               if (wave_ballot(m != 0) == 0) continue;
+              if (EP) touch |= m;
               FLAT_DBG(++dbg_visits;)
               // the walks this record's effect applies to: all matched ones unless a condition says no.  The derived-role
               // condition comes first and the rule's own condition is evaluated only where that held (check.go:328-380);
@@ -803,6 +822,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
                               ((0u - ((rw.rm_lo >> rc[2]) & 1u)) & 0xF00u) | ((0u - ((rw.rm_lo >> rc[3]) & 1u)) & 0xF000u);
             const u32 m = ing ? (mrole & (mact * 0x1111u) & S) : 0u;
             if (wave_ballot(m != 0) == 0) continue;
+            if (EP) touch |= m;
             // the walks this record's effect applies to: all matched ones unless a condition says no.  The derived-role
             // condition comes first and the rule's own condition is evaluated only where that held (check.go:328-380);
             // each once per record and request, whatever the roles (check.go:316-340)
@@ -824,6 +844,10 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
             else if ((rw.flags & 3u) == CBH_EFFECT_DENY) { deny |= hit; S &= ~hit; }   // ends these walks (check.go:392-403)
           }
         }
+      }
+      if (EP) {
+        if (MODE != 2 && have_bucket && bucket.y) g_pol = uload(&t.rows[(size_t)bucket.x * 16u + 3u]);   // TblRow.policy: a bucket = one policy
+        if (ing && mydepth < max_depth) { ep_lds[(2u * mydepth) * CBH_BLOCK + c.tid] = touch; ep_lds[(2u * mydepth + 1u) * CBH_BLOCK + c.tid] = g_pol; }
       }
       const u32 ha = ing ? (has_allow & S) : 0u;   // check.go:416-425
       const u32 sp = (uload(&t.scope_flags[g_si]) >> 2) & 3u;
@@ -859,6 +883,17 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
     st4 |= (u32)(uk ? CBH_ST_UNSUPPORTED : (ek ? CBH_ST_CEL_ERROR : st_ok)) << (8 * k);
   }
 
+  if (EP && want_ep && valid) {   // ---- effective policies: what the walks the reference really makes have touched
+    u32 legit = 0;
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+      const u32 ak = (allow >> k) & 0x1111u;
+      const u32 seen = ak ? (((ak & (0u - ak)) << 1) - 1u) : 0xFFFFu;
+      legit |= ((walks >> k) & 0x1111u & seen) << k;
+    }
+    for (u32 d = 0; d < max_depth; ++d)
+      if (ep_lds[(2u * d) * CBH_BLOCK + c.tid] & legit) ep_mark(o, b, req, ep_lds[(2u * d + 1u) * CBH_BLOCK + c.tid]);
+  }
   // ---- effective derived roles (check.go:237-282): the definitions of a scope's policy are evaluated when a role
   // walk REACHES that scope - a walk the reference really makes, i.e. not one of a role after the role that
   // allowed its action.  Known now: a decided walk reached the scopes up to the one that decided it, an undecided
@@ -985,6 +1020,15 @@ __global__ CBH_FLAT_ATTRS(3) void cbh_check_flat_kernel_any_masks(const KernelAr
   CBH_FLAT_CTX(a, ka);
   flat_body<true, 2>(a, c);
 }
+// cbh_check_batch_trail on a flat table: the same six walks with the effective policies kept (flat_body EP)
+#define CBH_FLAT_TRAIL_KERNEL(NAME, MINW, CALL, MODE)                                                                          \
+  __global__ CBH_FLAT_ATTRS(MINW) void NAME(const KernelArgs a, const KernelArgs* __restrict__ ka) { CBH_FLAT_CTX(a, ka); flat_body<CALL, MODE, true>(a, c); }
+CBH_FLAT_TRAIL_KERNEL(cbh_check_flat_trail_kernel, 6, false, 0)
+CBH_FLAT_TRAIL_KERNEL(cbh_check_flat_trail_kernel_any, 4, true, 0)
+CBH_FLAT_TRAIL_KERNEL(cbh_check_flat_trail_kernel_staged, 5, false, 1)
+CBH_FLAT_TRAIL_KERNEL(cbh_check_flat_trail_kernel_any_staged, 3, true, 1)
+CBH_FLAT_TRAIL_KERNEL(cbh_check_flat_trail_kernel_masks, 3, false, 2)
+CBH_FLAT_TRAIL_KERNEL(cbh_check_flat_trail_kernel_any_masks, 3, true, 2)
 #define CBH_FLAT_STAGE_MIN 32u
 // the mask walk decides a table that has segments and long buckets (CBH_FLAT_MASKS=0: never, =1: whatever the buckets' length - tests, A/B)
 static inline bool cbh_flat_use_masks(const void* segs, u32 max_bucket) {
@@ -1009,7 +1053,23 @@ static inline size_t cbh_flat_class_bytes(u32 table_strings) {
 }
 // ... and, for the mask walk, a segment's class masks per wave
 static inline size_t cbh_flat_mask_bytes(u32 threads) { return (size_t)(threads / CBH_BLOCK) * CBH_SEG_LDS_BYTES; }
-static inline bool cbh_is_mask_kernel(cbh_check_kernel_fn fn) { return fn == cbh_check_flat_kernel_masks || fn == cbh_check_flat_kernel_any_masks; }
+static inline bool cbh_is_mask_kernel(cbh_check_kernel_fn fn) {
+  return fn == cbh_check_flat_kernel_masks || fn == cbh_check_flat_kernel_any_masks || fn == cbh_check_flat_trail_kernel_masks || fn == cbh_check_flat_trail_kernel_any_masks;
+}
+// the instantiation of a flat kernel that also keeps the effective policies (cbh_check_batch_trail), and its extra LDS
+static inline cbh_check_kernel_fn cbh_flat_trail_variant(cbh_check_kernel_fn fn) {
+  return fn == cbh_check_flat_kernel ? cbh_check_flat_trail_kernel : fn == cbh_check_flat_kernel_any ? cbh_check_flat_trail_kernel_any
+       : fn == cbh_check_flat_kernel_staged ? cbh_check_flat_trail_kernel_staged : fn == cbh_check_flat_kernel_any_staged ? cbh_check_flat_trail_kernel_any_staged
+       : fn == cbh_check_flat_kernel_masks ? cbh_check_flat_trail_kernel_masks : fn == cbh_check_flat_kernel_any_masks ? cbh_check_flat_trail_kernel_any_masks : fn;
+}
+static inline bool cbh_is_flat_trail_kernel(cbh_check_kernel_fn fn) {
+  return fn == cbh_check_flat_trail_kernel || fn == cbh_check_flat_trail_kernel_any || fn == cbh_check_flat_trail_kernel_staged ||
+         fn == cbh_check_flat_trail_kernel_any_staged || fn == cbh_check_flat_trail_kernel_masks || fn == cbh_check_flat_trail_kernel_any_masks;
+}
+static inline size_t cbh_flat_trail_bytes(u32 threads, u32 table_max_depth) {
+  const u32 depth = table_max_depth < CBH_FLAT_MAX_DEPTH ? table_max_depth : CBH_FLAT_MAX_DEPTH;
+  return (size_t)(threads / CBH_BLOCK) * depth * 2u * CBH_BLOCK * 4u;
+}
 static inline cbh_check_kernel_fn cbh_pick_kernel(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 max_actions, u32 max_roles, bool plain_tags,
                                                   u32 eval_flags, u32 max_bucket, u32* threads, bool* flat, bool masks = false) {
   *flat = (table_flags & CBH_MF_FLAT) && max_actions <= 4 && max_roles <= 4 && !(eval_flags & CBH_F_STRICT_EVALUATION);

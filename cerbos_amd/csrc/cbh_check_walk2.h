@@ -991,7 +991,13 @@ static inline CbhPlan cbh_plan(u32 table_flags, u32 n_derived_roles, bool has_gl
   bool flat = false;
   // the effective policies of a call are what the reference's loops TOUCH, role by role in order (check.go:208-442, 302-304): the
   // general walk keeps that order; the flat kernels and cbh_walk2_kernel walk a request's roles side by side
-  if (eval_flags & CBH_F_WANT_EFFECTIVE_POLICIES) { p.kind = 0; p.kernel = cbh_check_trail_kernel; p.threads = CBH_BLOCK; return p; }
+  if (eval_flags & CBH_F_WANT_EFFECTIVE_POLICIES) {
+    // a flat table's walks keep what they touched per chain position and sort it out at the fold (flat_body EP); every other table
+    // takes the general walk, which iterates roles and bindings in the reference's own order
+    p.kernel = cbh_pick_kernel(no_flat ? (table_flags & ~(u32)CBH_MF_FLAT) : table_flags, n_derived_roles, has_globs, max_actions, max_roles, plain_tags, eval_flags, max_bucket, &p.threads, &flat, masks);
+    if (flat) { p.kind = 1; p.kernel = cbh_flat_trail_variant(p.kernel); return p; }
+    p.kind = 0; p.kernel = cbh_check_trail_kernel; p.threads = CBH_BLOCK; return p;
+  }
   p.kernel = cbh_pick_kernel(no_flat ? (table_flags & ~(u32)CBH_MF_FLAT) : table_flags, n_derived_roles, has_globs, max_actions, max_roles, plain_tags, eval_flags, max_bucket, &p.threads, &flat, masks);
   p.kind = flat ? 1 : 0;
   if (!flat && !no_walk2 && cbh_walk2_applies(table_flags, eval_flags)) {
@@ -1018,6 +1024,7 @@ static inline size_t cbh_plan_lds(const CbhPlan& p, u32 table_flags, u32 table_m
   if (p.kind == 2) return w2_lds_bytes(w2_layout(pre ? ncc : inline_cols, (table_flags & CBH_MF_NEEDS_ARENA) != 0, table_max_depth, table_scopes, pre, p.n_gwords, table_strings, table_n_dr, na, packed_tags), pre ? 1u : CBH_W2_WAVES);
   const size_t wave = cbh_general_lds(table_flags, n_columns, packed_tags);
   if (p.kind == 1) return (wave + cbh_flat_chain_bytes(table_max_depth, table_scopes)) * (p.threads / CBH_BLOCK) + cbh_flat_class_bytes(table_strings)
-                          + (cbh_is_mask_kernel(p.kernel) ? cbh_flat_mask_bytes(p.threads) : 0);
+                          + (cbh_is_mask_kernel(p.kernel) ? cbh_flat_mask_bytes(p.threads) : 0)
+                          + (cbh_is_flat_trail_kernel(p.kernel) ? cbh_flat_trail_bytes(p.threads, table_max_depth) : 0);
   return wave;
 }

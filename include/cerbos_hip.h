@@ -319,9 +319,10 @@ int cbh_wire_check_pb(cbh_table* t, uint32_t device_index, const uint8_t* bytes,
  * the group (group_of_request[i] < n_groups; NULL = every request in group 0: one engine.Check call).  cbh_table_policy_key names
  * policy p as namer.PolicyKeyFromFQN does ("resource.leave_request.vdefault/acme"); the keys a set bit stands for are that one
  * and, for a scoped resource / principal policy, those of its ancestor scopes that are policies of the table (drop the last scope
- * segment until none is left - cerbos_amd/engine.py effective_policy_keys is ten lines).  Decided by the general walk (the one that
- * iterates a request's roles one after the other as the reference does - the faster kernels walk them side by side and would also
- * touch what a role BEHIND the allowing one reaches): an audit-enabled caller pays that kernel's rate.  Device 0. */
+ * segment until none is left - cerbos_amd/engine.py effective_policy_keys is ten lines).  A flat table (resource policies only)
+ * keeps its trail in the flat kernels (their trail instantiations sort out at the fold what a role BEHIND the allowing one touched);
+ * any other table is decided by the general walk, which iterates a request's roles one after the other as the reference does: an
+ * audit-enabled caller pays that kernel's rate there.  Device 0. */
 #define CBH_HAS_CHECK_BATCH_TRAIL 1
 uint32_t cbh_table_num_policies(const cbh_table* t);
 int cbh_table_policy_key(const cbh_table* t, uint32_t i, const char** key, uint32_t* len);

@@ -80,3 +80,32 @@ def test_the_trail_s_walk_decides_like_the_ordinary_road(store):
     # one group: the union of what the cases that run without lenient scope search log
     want_keys = {k for c in CASES if not c["lenient"] for k in c["wantEffectivePolicies"]}
     assert want_keys <= set(effective_policy_keys(lt.policy_keys, masks[0]))
+
+
+# ---- flat tables: the trail from the fast kernels (flat_body EP: scalar, staged and mask walks), not the general walk
+from cerbos_amd import workloads   # noqa: E402
+
+
+@pytest.mark.parametrize("env", [{}, {"CBH_FLAT_MASKS": "0"}, {"CBH_FLAT_ANY": "1"}, {"CBH_FLAT_ANY": "1", "CBH_FLAT_MASKS": "0"}, {"CBH_FLAT_MASKS": "1"}],
+                         ids=["as planned", "staged", "with the evaluator call", "staged with the call", "masks forced"])
+@pytest.mark.parametrize("name,n", [("c2", 300), ("c3", 400), ("c4", 250), ("t", 250)])
+def test_flat_tables_keep_their_trail_in_the_flat_kernels(name, n, env, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rt = rule_table_from_policies(policies_from_docs(getattr(workloads, name + "_policies")()))
+    lt = lower_rule_table(rt)
+    ev, oracle = HostSimEvaluator(lt, Conf()), RuleTableOracle(rt)
+    inputs = getattr(workloads, name + "_requests")(n_requests=n).to_inputs()
+    for lenient in (False, True):
+        have = ev.effective_policies(inputs, now_ns=NOW, lenient_scope_search=lenient, per_input=True)
+        assert hostsim_api.last_kind() == 1, "a flat kernel decides this"
+        params = EvalParams(now_ns=NOW, lenient_scope_search=lenient)
+        want = [oracle.check(i, params)["effectivePolicies"] for i in inputs]
+        bad = [k for k in range(len(inputs)) if have[k] != want[k]]
+        assert not bad, (name, lenient, bad[:3], have[bad[0]], want[bad[0]], inputs[bad[0]])
+    # ... and decides as the ordinary flat kernel does
+    batch = Flattener(lt).flatten(inputs, "default", "")
+    want_res = hostsim_api.check(lt, batch, NOW, capi.F_WANT_DERIVED_ROLES, device_order=True)
+    have_res, _ = hostsim_api.check_trail(lt, batch, None, 1, NOW, capi.F_WANT_DERIVED_ROLES)
+    for f in ("effect", "policy", "scope", "status", "edr"):
+        assert np.array_equal(getattr(have_res, f), getattr(want_res, f)), f

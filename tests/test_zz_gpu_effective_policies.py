@@ -75,3 +75,26 @@ def test_c5_at_size_groups_and_decisions():
         assert every <= set(lt.policy_keys) and len(every) > 1
     finally:
         table.close()
+
+
+@pytest.mark.parametrize("name,n", [("c2", 20_000), ("c3", 20_000), ("t", 6_000)])
+def test_flat_tables_keep_their_trail_in_the_flat_kernels(name, n):
+    """flat_body EP (cbh_check_flat_trail_kernel*): the trail from the fast kernels - per input against the oracle, decisions as cbh_check_batch's"""
+    rt = rule_table_from_policies(policies_from_docs(getattr(workloads, name + "_policies")()))
+    lt = lower_rule_table(rt)
+    inputs = getattr(workloads, name + "_requests")(n_requests=n).to_inputs()
+    ev, oracle = HipEvaluator(lt, Conf()), RuleTableOracle(rt)
+    try:
+        have = ev.effective_policies(inputs, now_ns=NOW, per_input=True)
+        params = EvalParams(now_ns=NOW)
+        step = max(1, n // 3000)
+        for k in range(0, n, step):
+            assert have[k] == oracle.check(inputs[k], params)["effectivePolicies"], (name, k)
+        batch = Flattener(lt).flatten(inputs, "default", "")
+        want = ev.table.check(batch, now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES, device_order=True)
+        got, masks = ev.table.check_trail(batch, None, 1, now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES)
+        for f in ("effect", "policy", "scope", "edr"):
+            assert np.array_equal(getattr(got, f), getattr(want, f)), f
+        assert set(effective_policy_keys(lt.policy_keys, masks[0])) == set().union(*map(set, have))
+    finally:
+        ev.close()
