@@ -88,8 +88,10 @@ from cerbos_amd import workloads   # noqa: E402
 
 @pytest.mark.parametrize("env", [{}, {"CBH_FLAT_MASKS": "0"}, {"CBH_FLAT_ANY": "1"}, {"CBH_FLAT_ANY": "1", "CBH_FLAT_MASKS": "0"}, {"CBH_FLAT_MASKS": "1"}],
                          ids=["as planned", "staged", "with the evaluator call", "staged with the call", "masks forced"])
-@pytest.mark.parametrize("name,n", [("c2", 300), ("c3", 400), ("c4", 250), ("t", 250)])
+@pytest.mark.parametrize("name,n", [("c2", 300), ("c3", 400), ("c4", 100), ("t", 200)])
 def test_flat_tables_keep_their_trail_in_the_flat_kernels(name, n, env, monkeypatch):
+    if name == "c4" and env not in ({}, {"CBH_FLAT_MASKS": "0"}):
+        pytest.skip("C4's fifty thousand rules once per walk kind: T covers the other variants")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     rt = rule_table_from_policies(policies_from_docs(getattr(workloads, name + "_policies")()))
