@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "cbh_synchronize", "cbh_result_download", "cbh_kernel_time_ms", "cbh_plan_describe",
     "cbh_check_resident_many", "cbh_table_set_resident_streams", "cbh_table_resident_streams",
     "cbh_wire_flatten", "cbh_wire_spans_download", "cbh_wire_outputs", "cbh_wire_check_pb",
-    "cbh_wire_flatten_requests", "cbh_wire_check_requests_pb",
+    "cbh_wire_flatten_requests", "cbh_wire_check_requests_pb", "cbh_wire_check_requests_trail_pb",
     "cbh_table_num_policies", "cbh_table_policy_key", "cbh_check_batch_trail",
 ]
 
@@ -173,6 +173,8 @@ def load():
     lib.cbh_wire_check_requests_pb.argtypes = [vp, u32, vp, vp, u32, vp, vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(CParams), vp, vp,
                                                vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(CWireInfo)]
     lib.cbh_wire_check_requests_pb.restype = i32
+    lib.cbh_wire_check_requests_trail_pb.argtypes = lib.cbh_wire_check_requests_pb.argtypes + [vp]
+    lib.cbh_wire_check_requests_trail_pb.restype = i32
     lib.cbh_table_num_policies.argtypes = [vp]
     lib.cbh_table_num_policies.restype = u32
     lib.cbh_table_policy_key.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(u32)]
@@ -437,10 +439,12 @@ class Table:
         return [raw[int(oo[i]):int(oo[i + 1])] for i in range(n)], of[:n].copy()
 
     def wire_check_requests_pb(self, requests, aux=None, now_ns=0, flags=0, default_policy_version="default", default_scope="", device_index=0,
-                               globals_pb=b""):
+                               globals_pb=b"", trail=False):
         """``cbh_wire_check_requests_pb``: serialized ``CheckResourcesRequest``s in (``requests``: [bytes]; ``aux``: per request the
         serialized engine ``AuxData`` or None), per request the serialized ``CheckOutput``s of its resource entries out.
-        -> ([[bytes] per request], flags uint8[n_inputs], include_meta bool[n_requests])"""
+        -> ([[bytes] per request], flags uint8[n_inputs], include_meta bool[n_requests]); with ``trail``
+        (``cbh_wire_check_requests_trail_pb``) a fourth value: uint32[n_requests][words], the policies every request went through
+        (``policy_keys`` names the bits)."""
         from .wire import pack_messages
         data, offsets = pack_messages(list(requests))
         nr = len(offsets) - 1
@@ -452,15 +456,18 @@ class Table:
         p = CParams(now_ns, flags, 0)
         info, need = CWireInfo(), C.c_size_t()
         cap, n_cap = 4096, 8 * max(nr, 1)
+        words = (int(load().cbh_table_num_policies(self.h)) + 31) // 32 if trail else 0
+        ep = np.zeros((max(nr, 1), max(words, 1)), dtype=np.uint32)
+        fn = load().cbh_wire_check_requests_trail_pb if trail else load().cbh_wire_check_requests_pb
         for _ in range(3):
             ob = np.empty(cap, dtype=np.uint8)
             oo, of = np.zeros(n_cap + 1, dtype=np.uint64), np.zeros(n_cap + 1, dtype=np.uint8)   # (the inputs are known after the call: grown on demand)
-            rc = load().cbh_wire_check_requests_pb(self.h, device_index, data.ctypes.data if data.size else None, offsets.ctypes.data, nr,
-                                                   a_data.ctypes.data if a_data is not None and a_data.size else (np.zeros(1, np.uint8).ctypes.data if a_off is not None else None),
-                                                   a_off.ctypes.data if a_off is not None else None,
-                                                   default_policy_version.encode(), default_scope.encode(), globals_pb or None, len(globals_pb or b""),
-                                                   C.byref(p), first.ctypes.data, rflags.ctypes.data, ob.ctypes.data, ob.size, oo.ctypes.data, of.ctypes.data,
-                                                   n_cap, C.byref(need), C.byref(info))
+            rc = fn(self.h, device_index, data.ctypes.data if data.size else None, offsets.ctypes.data, nr,
+                    a_data.ctypes.data if a_data is not None and a_data.size else (np.zeros(1, np.uint8).ctypes.data if a_off is not None else None),
+                    a_off.ctypes.data if a_off is not None else None,
+                    default_policy_version.encode(), default_scope.encode(), globals_pb or None, len(globals_pb or b""),
+                    C.byref(p), first.ctypes.data, rflags.ctypes.data, ob.ctypes.data, ob.size, oo.ctypes.data, of.ctypes.data,
+                    n_cap, C.byref(need), C.byref(info), *([ep.ctypes.data] if trail else []))
             if rc != 2:
                 break
             cap, n_cap = max(cap, int(need.value) + 64), max(n_cap, int(info.n_requests))
@@ -470,7 +477,8 @@ class Table:
         n = int(first[nr])
         raw = ob[:int(oo[n])].tobytes()
         outs = [raw[int(oo[i]):int(oo[i + 1])] for i in range(n)]
-        return [outs[int(first[r]):int(first[r + 1])] for r in range(nr)], of[:n].copy(), (rflags[:nr] & 1).astype(bool)
+        res = [outs[int(first[r]):int(first[r + 1])] for r in range(nr)], of[:n].copy(), (rflags[:nr] & 1).astype(bool)
+        return res + (ep[:nr, :words],) if trail else res
 
     def wire_spans(self, dbatch):
         """``cbh_wire_spans_download`` -> (in_span uint32[n][12], act_span uint32[n_tuples][2], act_off uint32[n + 1])"""

@@ -1263,18 +1263,55 @@ extern "C" int cbh_wire_outputs(cbh_table* t, cbh_device_batch* b, uint8_t* byte
 // What the server receives in, what engine.Check returns out, in ONE call: serialized CheckResourcesRequests -> the serialized
 // CheckOutputs of their resource entries (cbh_wire_flatten_requests, cbh_check_resident, cbh_wire_outputs on one stream).  The
 // outputs of request r are out_offsets[first_input[r]] .. out_offsets[first_input[r + 1]].  Return values as cbh_wire_check_pb.
-extern "C" int cbh_wire_check_requests_pb(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n_requests,
-                                          const uint8_t* aux_bytes, const uint64_t* aux_offsets, const char* default_version, const char* default_scope,
-                                          const uint8_t* globals_pb, size_t globals_len, const cbh_params* p, uint32_t* first_input, uint8_t* request_flags,
-                                          uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags, size_t out_inputs_cap, size_t* need,
-                                          cbh_wire_info* info) {
+static int wire_check_requests_impl(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n_requests,
+                                    const uint8_t* aux_bytes, const uint64_t* aux_offsets, const char* default_version, const char* default_scope,
+                                    const uint8_t* globals_pb, size_t globals_len, const cbh_params* p, uint32_t* first_input, uint8_t* request_flags,
+                                    uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags, size_t out_inputs_cap, size_t* need,
+                                    cbh_wire_info* info, uint32_t* effective_policies) {
   if (!t || !p || !need || !info || !first_input || (out_cap && !out_bytes)) return fail("null argument");
   cbh_device_batch* b = nullptr;
   int rc = cbh_wire_flatten_requests(t, device_index, bytes, offsets, n_requests, aux_bytes, aux_offsets, default_version, default_scope, globals_pb, globals_len,
                                      first_input, request_flags, &b, info);
   if (rc != 0) return rc;
   struct Release { cbh_device_batch* b; ~Release() { if (b) cbh_batch_release(b); } } release{b};
-  if ((rc = cbh_check_resident(t, b, p)) != 0) return rc;
+  cbh_params q = *p;
+  u32* d_ep = nullptr;
+  const u32 words = (t->wire.n_policies + 31u) / 32u;
+  if (effective_policies) {
+    // the trail of cbh_check_batch_trail, one group per REQUEST (what one decision-log entry of the server covers): the inputs'
+    // groups follow from first_input; a batch the flattener grouped by route keeps its results by position, so they move with it
+    hipStream_t s = b->stream;
+    HIPCHK(hipSetDevice(b->rep->device));
+    const u32 n_in = info->n_requests;
+    const size_t ep_n = (size_t)(n_requests ? n_requests : 1u) * (words ? words : 1u);
+    if (dalloc(b, d_ep, ep_n) != 0) return -1;
+    HIPCHK(hipMemsetAsync(d_ep, 0, ep_n * 4, s));
+    u32* d_grp = nullptr;
+    if (n_in) {
+      std::vector<u32> grp(n_in);
+      for (u32 r = 0; r < n_requests; ++r) for (u32 i = first_input[r]; i < first_input[r + 1]; ++i) grp[i] = r;
+      u32* d_by_input = nullptr;
+      if (dalloc(b, d_by_input, (size_t)n_in) != 0) return -1;
+      HIPCHK(hipMemcpyAsync(d_by_input, grp.data(), (size_t)n_in * 4, hipMemcpyHostToDevice, s));
+      d_grp = d_by_input;
+      if (b->w_inv) {
+        if (dalloc(b, d_grp, (size_t)n_in) != 0) return -1;
+        WireScatterArgs sa; sa.by_input = d_by_input; sa.inv = b->w_inv; sa.by_position = d_grp; sa.n = n_in; sa.pad = 0;
+        hipLaunchKernelGGL(cbh_wire_scatter_u32_kernel, dim3((n_in + 255u) / 256u), dim3(256), 0, s, sa);
+        HIPCHK(hipGetLastError());
+      }
+      HIPCHK(hipStreamSynchronize(s));   // (grp is a pageable source going out of scope)
+    }
+    b->out.eff_pol = d_ep; b->out.ep_words = words; b->dev.ep_group = d_grp;
+    q.flags |= CBH_F_WANT_EFFECTIVE_POLICIES;
+  } else {
+    q.flags &= ~CBH_F_WANT_EFFECTIVE_POLICIES;
+  }
+  if ((rc = cbh_check_resident(t, b, &q)) != 0) return rc;
+  if (effective_policies && words && n_requests) {
+    HIPCHK(hipMemcpyAsync(effective_policies, d_ep, (size_t)n_requests * words * 4, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+  }
   const u32 n = info->n_requests;   // the inputs
   std::vector<uint64_t> tmp_off; std::vector<uint8_t> tmp_flags;
   const bool fits = (size_t)n <= out_inputs_cap && out_offsets;
@@ -1283,6 +1320,26 @@ extern "C" int cbh_wire_check_requests_pb(cbh_table* t, uint32_t device_index, c
   rc = cbh_wire_outputs(t, b, fits ? out_bytes : nullptr, fits ? out_cap : 0, off, fl, need);   // (not fitting: sizes only)
   if (rc == 0 && !fits) { g_err = "cbh_wire_check_requests_pb: out_offsets / out_flags hold fewer inputs than the requests have"; return 2; }
   return rc;
+}
+extern "C" int cbh_wire_check_requests_pb(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n_requests,
+                                          const uint8_t* aux_bytes, const uint64_t* aux_offsets, const char* default_version, const char* default_scope,
+                                          const uint8_t* globals_pb, size_t globals_len, const cbh_params* p, uint32_t* first_input, uint8_t* request_flags,
+                                          uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags, size_t out_inputs_cap, size_t* need,
+                                          cbh_wire_info* info) {
+  return wire_check_requests_impl(t, device_index, bytes, offsets, n_requests, aux_bytes, aux_offsets, default_version, default_scope, globals_pb, globals_len, p,
+                                  first_input, request_flags, out_bytes, out_cap, out_offsets, out_flags, out_inputs_cap, need, info, nullptr);
+}
+// ... and with the audit trail of every request: effective_policies[r * words + w] (words = (cbh_table_num_policies + 31) / 32) has bit
+// k set when policy k was among those the engine went through for ANY resource entry of request r - AuditTrail.EffectivePolicies of
+// the one decision-log entry the server writes for the call (check.go:302-304, svc CheckResources: one entry per request).
+extern "C" int cbh_wire_check_requests_trail_pb(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n_requests,
+                                                const uint8_t* aux_bytes, const uint64_t* aux_offsets, const char* default_version, const char* default_scope,
+                                                const uint8_t* globals_pb, size_t globals_len, const cbh_params* p, uint32_t* first_input, uint8_t* request_flags,
+                                                uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags, size_t out_inputs_cap, size_t* need,
+                                                cbh_wire_info* info, uint32_t* effective_policies) {
+  if (!effective_policies) return fail("null argument");
+  return wire_check_requests_impl(t, device_index, bytes, offsets, n_requests, aux_bytes, aux_offsets, default_version, default_scope, globals_pb, globals_len, p,
+                                  first_input, request_flags, out_bytes, out_cap, out_offsets, out_flags, out_inputs_cap, need, info, effective_policies);
 }
 
 // Bytes in, bytes out in ONE call: serialized CheckInputs -> serialized CheckOutputs by the device road (cbh_wire_flatten,

@@ -1091,4 +1091,10 @@ __global__ __launch_bounds__(256) void cbh_wire_unsort_edr_kernel(WireUnsortArgs
   const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < a.n) a.edr_input[i] = a.edr_grouped[a.inv[i]];
 }
+// the other way round: something known per input (the trail group of a request's inputs) to where the grouped batch keeps that input
+struct WireScatterArgs { const CBH_G u32* by_input; const CBH_G u32* inv; CBH_G u32* by_position; u32 n; u32 pad; };
+__global__ __launch_bounds__(256) void cbh_wire_scatter_u32_kernel(WireScatterArgs a) {
+  const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < a.n) a.by_position[a.inv[i]] = a.by_input[i];
+}
 #endif

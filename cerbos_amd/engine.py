@@ -302,11 +302,13 @@ class HipEvaluator:
         return raw, oflags
 
     def check_requests_pb(self, requests, aux=None, now_ns=None, lenient_scope_search=None, strict_evaluation=None,
-                          default_policy_version=None, default_scope=None):
+                          default_policy_version=None, default_scope=None, audit_trail=False):
         """Many serialized ``CheckResourcesRequest``s at once down the device road (``cbh_wire_check_requests_pb``: the requests are
         split into the ``CheckInput``s of cerbos_svc.go:274-288 on the device) -> ([[serialized CheckOutput] per request], flags per
         input, include_meta per request).  ``aux``: per request the serialized engine ``AuxData`` or None.  Requests the device road
-        leaves to the host flattener take ``check_request_pb`` one by one (``capi.HostFlattenerNeeded``)."""
+        leaves to the host flattener take ``check_request_pb`` one by one (``capi.HostFlattenerNeeded``).  ``audit_trail``: a fourth
+        value, per request the sorted keys of AuditTrail.EffectivePolicies (``cbh_wire_check_requests_trail_pb``: what the one
+        decision-log entry of the call carries, check.go:302-304)."""
         conf = self.conf
         lenient = conf.lenient_scope_search if lenient_scope_search is None else lenient_scope_search
         strict = conf.strict_evaluation if strict_evaluation is None else strict_evaluation
@@ -315,7 +317,12 @@ class HipEvaluator:
         if now_ns is None:
             now_ns = time.time_ns()
         flags = capi.F_WANT_DERIVED_ROLES | (capi.F_LENIENT_SCOPE_SEARCH if lenient else 0) | (capi.F_STRICT_EVALUATION if strict else 0)
-        return self.table.wire_check_requests_pb(requests, aux, now_ns=now_ns, flags=flags, default_policy_version=dver, default_scope=dscope)
+        if not audit_trail:
+            return self.table.wire_check_requests_pb(requests, aux, now_ns=now_ns, flags=flags, default_policy_version=dver, default_scope=dscope)
+        outs, oflags, meta, masks = self.table.wire_check_requests_pb(requests, aux, now_ns=now_ns, flags=flags, default_policy_version=dver,
+                                                                      default_scope=dscope, trail=True)
+        keys = self.lt.policy_keys
+        return outs, oflags, meta, [effective_policy_keys(keys, row) for row in masks]
 
     def effective_policies(self, inputs, now_ns=None, lenient_scope_search=None, strict_evaluation=None, default_policy_version=None,
                            default_scope=None, globals_=None, per_input=False):

@@ -353,6 +353,15 @@ int cbh_wire_check_requests_pb(cbh_table* t, uint32_t device_index, const uint8_
                                const uint8_t* globals_pb, size_t globals_len, const cbh_params* p, uint32_t* first_input, uint8_t* request_flags,
                                uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags, size_t out_inputs_cap, size_t* need,
                                cbh_wire_info* info);
+/* ... with the audit trail of every request beside its outputs: effective_policies [n_requests][words], words =
+ * (cbh_table_num_policies + 31) / 32 - bit k of row r set when policy k (cbh_table_policy_key) is among those the engine went
+ * through for any resource entry of request r: AuditTrail.EffectivePolicies (check.go:302-304) of the one decision-log entry
+ * the server writes for a CheckResources call.  The trail kernels of cbh_check_batch_trail with one group per request. */
+int cbh_wire_check_requests_trail_pb(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n_requests,
+                                     const uint8_t* aux_bytes, const uint64_t* aux_offsets, const char* default_version, const char* default_scope,
+                                     const uint8_t* globals_pb, size_t globals_len, const cbh_params* p, uint32_t* first_input, uint8_t* request_flags,
+                                     uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags, size_t out_inputs_cap, size_t* need,
+                                     cbh_wire_info* info, uint32_t* effective_policies);
 
 /* ---- Trace pass: evaluation_errors and outputs (evaluator/cel_errors.go:48-118, check.go:383-411, 776-807) ----
  * The decision kernels only mark the tuples whose evaluation absorbed a CEL error (CBH_ST_CEL_ERROR).  What the

@@ -19,6 +19,8 @@ import (
 	"errors"
 	"fmt"
 	"runtime"
+	"sort"
+	"strings"
 	"sync"
 	"unsafe"
 
@@ -381,7 +383,9 @@ func (g *gpuEngine) traceGPU(buf []byte, offs []C.uint64_t, oflags []byte, n int
 // of svc.CheckResources hands them over as they came off the wire) in, per request the serialized CheckOutputs of its resource
 // entries out - cbh_wire_check_requests_pb splits every request into the CheckInputs of cerbos_svc.go:274-288 on the device.
 // aux[r] = the serialized engine AuxData cs.auxData.Extract derived for request r, or nil.  outs[r][e] = CheckOutput bytes of resource
-// entry e of request r; flags as cbi_outputs_flags (CBI_OUT_*: which entries want the trace pass / the CPU path).
+// entry e of request r; flags as cbi_outputs_flags (CBI_OUT_*: which entries want the trace pass / the CPU path).  With decision logs
+// enabled the call is cbh_wire_check_requests_trail_pb (one more argument: masks [n][(cbh_table_num_policies+31)/32]uint32) and
+// masks[r] names the EffectivePolicies of request r's audit entry - see effectivePolicyKeys.
 func (g *gpuEngine) checkRequestsGPU(reqs [][]byte, aux [][]byte, p evaluator.EvalParams) (outs [][][]byte, oflags []byte, includeMeta []bool, err error) {
 	n := len(reqs)
 	offs := make([]C.uint64_t, n+1)
@@ -450,6 +454,46 @@ func (g *gpuEngine) checkRequestsGPU(reqs [][]byte, aux [][]byte, p evaluator.Ev
 		return outs, of[:int(first[n])], includeMeta, nil
 	}
 	return nil, nil, nil, errors.New("cbh_wire_check_requests_pb: buffers kept growing")
+}
+
+// effectivePolicyKeys turns one row of cbh_check_batch_trail's / cbh_wire_check_requests_trail_pb's masks into the keys of
+// AuditTrail.EffectivePolicies: the policies whose bit is set and, for a scoped resource or principal policy, those of its ancestors
+// the table holds (the source attributes a policy set carries, compile.go:153-180).  keys[i] = cbh_table_policy_key(t, i).
+func effectivePolicyKeys(keys []string, mask []uint32) []string {
+	have := make(map[string]struct{}, len(keys))
+	for _, k := range keys {
+		have[k] = struct{}{}
+	}
+	out := map[string]struct{}{}
+	for i, k := range keys {
+		if mask[i>>5]>>(uint(i)&31)&1 == 0 {
+			continue
+		}
+		out[k] = struct{}{}
+		if slash := strings.IndexByte(k, '/'); slash >= 0 && !strings.HasPrefix(k, "role.") {
+			head, scope := k[:slash], k[slash+1:]
+			for scope != "" {
+				if dot := strings.LastIndexByte(scope, '.'); dot >= 0 {
+					scope = scope[:dot]
+				} else {
+					scope = ""
+				}
+				anc := head
+				if scope != "" {
+					anc = head + "/" + scope
+				}
+				if _, ok := have[anc]; ok {
+					out[anc] = struct{}{}
+				}
+			}
+		}
+	}
+	res := make([]string, 0, len(out))
+	for k := range out {
+		res = append(res, k)
+	}
+	sort.Strings(res)
+	return res
 }
 
 // checkResourcesGPU serves one CheckResourcesRequest without building CheckInputs (svc/cerbos_svc.go:255-344 would

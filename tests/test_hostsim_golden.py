@@ -62,7 +62,9 @@ class HostSimEvaluator(HipEvaluator):
 
             # ... and of check_requests_pb (cbh_wire_req.h in front of it): split, flatten, decide, assemble - all on the simulator
             def wire_check_requests_pb(_self, requests, aux=None, now_ns=0, flags=0, default_policy_version="default", default_scope="",
-                                       device_index=0, globals_pb=b""):
+                                       device_index=0, globals_pb=b"", trail=False):
+                import numpy as np
+
                 from cerbos_amd import wire
                 from test_request_road import sim_split
                 got = sim_split(list(requests), aux)
@@ -70,9 +72,20 @@ class HostSimEvaluator(HipEvaluator):
                     raise capi.HipEngineError("malformed CheckResourcesRequest at index %d" % got)
                 msgs, first, rflags = got
                 db = _self.wire_flatten(*wire.pack_messages(msgs), default_policy_version, default_scope, globals_pb=globals_pb)
-                _self.launch(db, now_ns, flags)
+                masks = None
+                if trail:   # (cbh_wire_check_requests_trail_pb: one group per request, moved to where a grouped batch keeps the input)
+                    by_input = np.repeat(np.arange(len(requests), dtype=np.uint32), np.diff(first).astype(np.int64))
+                    groups = by_input
+                    if db.wb.grouped is not None:
+                        groups = np.zeros_like(by_input)
+                        groups[db.wb.grouped[3]] = by_input
+                    db.res, masks = hostsim_api.check_trail(lt, db.batch, groups, max(len(requests), 1), now_ns, flags)
+                    masks = masks[:len(requests)]
+                else:
+                    _self.launch(db, now_ns, flags)
                 outs, oflags = _self.wire_outputs(db)
-                return [outs[int(first[r]):int(first[r + 1])] for r in range(len(requests))], oflags, (rflags & 1).astype(bool)
+                res = [outs[int(first[r]):int(first[r + 1])] for r in range(len(requests))], oflags, (rflags & 1).astype(bool)
+                return res + (masks,) if trail else res
         self.table = _T()
 
 

@@ -212,3 +212,41 @@ def test_auxiliary_offsets_that_point_outside_are_refused():
     bad = C.c_uint32()
     n = lib.hostsim_wire_split_requests(data.ctypes.data, off.ctypes.data, 3, aux.ctypes.data, aoff.ctypes.data, *[C.byref(o) for o in outs], C.byref(bad))
     assert n < 0 and bad.value == 1
+
+
+def _trail_want(oracle, inputs, params):
+    keys = set()
+    for i in inputs:
+        keys.update(oracle.check(i, params)["effectivePolicies"])
+    return sorted(keys)
+
+
+def test_every_request_s_audit_trail_beside_its_outputs(monkeypatch):
+    """cbh_wire_check_requests_trail_pb's grouping on the simulator: one trail group per request (the one decision-log entry the server
+    writes for a call), also when the flattener reorders the batch by route - against the oracle's union over the request's entries."""
+    from cerbos_amd.engine import Conf
+    from oracle.check import EvalParams, RuleTableOracle
+    from test_hostsim_golden import HostSimEvaluator
+    rt = store_rule_table()
+    ev, oracle = HostSimEvaluator(lower_rule_table(rt, GLOBALS), Conf(globals_=GLOBALS)), RuleTableOracle(rt)
+    params = EvalParams(globals_=GLOBALS, now_ns=NOW)
+    cases = load_json("server_check_cases.json") + [c for c in load_json("engine_cases.json") if not c["wantError"]]
+    groups = [c["inputs"] for c in cases if not any("auxData" in i for i in c["inputs"])] + [[]]
+    reqs = [wire.encode_check_resources_request(_request_of(g)) if g else b"" for g in groups]
+    for group_by_route in ("0", "1"):
+        monkeypatch.setenv("CBH_WIRE_GROUP", group_by_route)
+        outs, oflags, _, trails = ev.check_requests_pb(reqs, now_ns=NOW, audit_trail=True)
+        plain, plain_flags, _ = ev.check_requests_pb(reqs, now_ns=NOW)
+        # the trail's kernels decide like the ordinary ones; the general walk, which keeps the trail of this table, cannot tell which
+        # inputs a trace pass has something to add to and says "all" (cerbos_hip.h CBH_ST_WANTS_TRACE) where cbh_walk2_kernel names them
+        # (CBI_OUT_CEL_ERROR 2 / CBI_OUT_WANTS_TRACE 16: either sends the input to the trace pass)
+        assert outs == plain and np.array_equal(oflags & 1, plain_flags & 1) and not ((plain_flags & 0x12) != 0)[(oflags & 0x12) == 0].any()
+        k = compared = 0
+        for g, trail in zip(groups, trails):
+            flagged = any(oflags[k + j] & 1 for j in range(len(g)))
+            k += len(g)
+            if flagged:
+                continue
+            assert trail == _trail_want(oracle, _as_built_by_the_service(g), params), g
+            compared += 1
+        assert compared > 40 and trails[-1] == []

@@ -87,3 +87,65 @@ def test_a_malformed_request_is_named():
         assert outs == []
     finally:
         table.close()
+
+
+def test_the_audit_trail_of_every_request_golden_store():
+    """cbh_wire_check_requests_trail_pb: per request the policies its entries went through (one decision-log entry per call), against
+    the oracle's union - the golden store (the general walk keeps its trail)."""
+    from cerbos_amd.engine import Conf, HipEvaluator
+    from oracle.check import EvalParams, RuleTableOracle
+    rt = store_rule_table()
+    ev, oracle = HipEvaluator(lower_rule_table(rt, GLOBALS), Conf(globals_=GLOBALS)), RuleTableOracle(rt)
+    params = EvalParams(globals_=GLOBALS, now_ns=NOW)
+    cases = load_json("server_check_cases.json") + [c for c in load_json("engine_cases.json") if not c["wantError"]]
+    groups = [c["inputs"] for c in cases if not any("auxData" in i for i in c["inputs"])] + [[]]
+    reqs = [wire.encode_check_resources_request(_request_of(g)) if g else b"" for g in groups]
+    try:
+        outs, oflags, _, trails = ev.check_requests_pb(reqs, now_ns=NOW, audit_trail=True)
+        plain, plain_flags, _ = ev.check_requests_pb(reqs, now_ns=NOW)
+        assert outs == plain and np.array_equal(oflags & 1, plain_flags & 1)
+        k = compared = 0
+        for g, trail in zip(groups, trails):
+            flagged = any(oflags[k + j] & 1 for j in range(len(g)))
+            k += len(g)
+            if flagged:
+                continue
+            want = set()
+            for i in _as_built_by_the_service(g):
+                want.update(oracle.check(i, params)["effectivePolicies"])
+            assert trail == sorted(want), g
+            compared += 1
+        assert compared > 40 and trails[-1] == []
+    finally:
+        ev.close()
+
+
+@pytest.mark.parametrize("name,n", [("C2", 30_000), ("C5", 30_000)])
+def test_the_audit_trail_of_every_request_at_size(name, n):
+    """... and at size (C2: the flat trail kernels; C5: the general walk, the batch reordered by route on the device): the masks the
+    request road returns against cbh_check_batch_trail over the host-flattened inputs with one group per request."""
+    from cerbos_amd.flatten import Flattener
+    pol = getattr(workloads, name.lower() + "_policies")
+    req_fn = getattr(workloads, name.lower() + "_requests")
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol())))
+    inputs = req_fn(n_requests=n).to_inputs()
+    rng = np.random.default_rng(11)
+    groups, k = [], 0
+    while k < n:
+        m = int(rng.integers(1, 41))
+        groups.append(inputs[k:k + m])
+        k += m
+    table = capi.Table(lt.blob)
+    try:
+        reqs = [wire.encode_check_resources_request(_request_of(g)) for g in groups]
+        outs, flags, _, masks = table.wire_check_requests_pb(reqs, now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES, trail=True)
+        plain, _, _ = table.wire_check_requests_pb(reqs, now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES)
+        assert outs == plain
+        flat = [i for g in groups for i in _as_built_by_the_service(g)]
+        batch = Flattener(lt).flatten(flat, "default", "")
+        pre = np.arange(batch.n_requests) if batch.req_perm is None else np.asarray(batch.req_perm)
+        by_input = np.repeat(np.arange(len(groups), dtype=np.uint32), [len(g) for g in groups])
+        _, want = table.check_trail(batch, by_input[np.asarray(batch.vreq_input)[pre]], len(groups), now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES)
+        assert np.array_equal(masks, want) and masks.any()
+    finally:
+        table.close()

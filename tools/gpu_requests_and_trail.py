@@ -48,7 +48,9 @@ pout, poff, pfl = capi.pinned_empty(cap, np.uint8), capi.pinned_empty(n + 1, np.
 first = np.zeros(len(reqs) + 1, np.uint32)
 rflags = np.zeros(len(reqs) + 1, np.uint8)
 answers = {}
-for name in ("inputs", "requests"):
+ep = np.zeros((len(reqs) + 1, (len(lt.policy_keys) + 31) // 32 or 1), np.uint32)
+lib.cbh_wire_check_requests_trail_pb.argtypes = lib.cbh_wire_check_requests_pb.argtypes + [C.c_void_p]
+for name in ("inputs", "requests", "requests + trail"):
     best, tuples = 1e9, 0
     for _ in range(8):
         info, need = capi.CWireInfo(), C.c_size_t()
@@ -56,16 +58,20 @@ for name in ("inputs", "requests"):
         if name == "inputs":
             rc = lib.cbh_wire_check_pb(table.h, 0, pid.ctypes.data, ioff.ctypes.data, n, b"default", b"", None, 0, C.byref(prm), pout.ctypes.data, cap,
                                        poff.ctypes.data, pfl.ctypes.data, C.byref(need), C.byref(info))
-        else:
+        elif name == "requests":
             rc = lib.cbh_wire_check_requests_pb(table.h, 0, prd.ctypes.data, roff.ctypes.data, len(reqs), None, None, b"default", b"", None, 0, C.byref(prm),
                                                 first.ctypes.data, rflags.ctypes.data, pout.ctypes.data, cap, poff.ctypes.data, pfl.ctypes.data, n,
                                                 C.byref(need), C.byref(info))
+        else:   # the audit trail of every request beside its outputs (flat tables: the flat trail kernels; others: the general walk)
+            rc = lib.cbh_wire_check_requests_trail_pb(table.h, 0, prd.ctypes.data, roff.ctypes.data, len(reqs), None, None, b"default", b"", None, 0, C.byref(prm),
+                                                      first.ctypes.data, rflags.ctypes.data, pout.ctypes.data, cap, poff.ctypes.data, pfl.ctypes.data, n,
+                                                      C.byref(need), C.byref(info), ep.ctypes.data)
         dt = time.perf_counter() - t0
         assert rc == 0, lib.cbh_last_error().decode()
         best, tuples = min(best, dt), info.n_tuples
     answers[name] = bytes(pout[:int(poff[n])])
     print("%s %s n=%d (%d per request): %.3f ms  %.1f M decisions/s  (in %.1f MB)" % (W, name, n, per, best * 1e3, tuples / best / 1e6, (idata if name == "inputs" else rdata).size / 1e6))
-assert answers["inputs"] == answers["requests"], "the two roads disagree"
+assert answers["inputs"] == answers["requests"] == answers["requests + trail"], "the roads disagree"
 print("same %d bytes of CheckOutputs by both roads" % len(answers["inputs"]))
 
 # ---- the trail
