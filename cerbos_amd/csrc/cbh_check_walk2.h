@@ -101,9 +101,15 @@ __device__ __forceinline__ u32 w2_list_reserve(CBH_G u32* cnt, u32 n) {
 // PMODE: 0 = the walk; 1 = the pre-pass (the sites a request reaches are evaluated where the walk meets them); 2 = the pre-pass's
 // COLLECTOR (cbh_walk2_collect_kernel: the same walk, no evaluator - every (request, site) met is appended to the site's list for
 // cbh_walk2_interp_kernel to evaluate on full waves)
-template <int PMODE, u32 NA_, u32 NR_>
+// EP (the walk only, cbh_walk2_trail_kernel*): AuditTrail.EffectivePolicies of the batch (cbh_check_batch_trail).  The reference meets a
+// request's roles one after the other and stops behind the first that allows (check.go:208-442); this walk takes them side by side.
+// So the walk runs TWICE: once as always - that tells, per action, the first allowing role -, then again for the walks the reference
+// really makes (the roles up to that one), and every binding that second walk iterates marks its policy (check.go:302-304).  The fold
+// reads the second walk's results: for the walks it is restricted to they are the first's.
+template <int PMODE, u32 NA_, u32 NR_, bool EP = false>
 __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const W2Layout& ly) {
   constexpr bool PRE = PMODE != 0;
+  static_assert(!(EP && PRE), "the trail is the walk's");
   const TableDev& t = ka_regs.t;
   const BatchDev& b = ka_regs.b;
   const OutDev& o = ka_regs.o;
@@ -372,11 +378,55 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   };
   W2_DBG(const u64 cyc1 = __builtin_readcyclecounter();)   // request fields, ids, classes, role sets are there
 
-  // ---- principal policies (check.go:195: the first pass; one role iteration, check.go:208-213).  Lanes with a policy of
-  // their principal somewhere on the chain are walked group by group; what it decides is kept per action.
+  const bool want_ep = EP && (flags & CBH_F_WANT_EFFECTIVE_POLICIES) != 0 && o.eff_pol != nullptr;
+  const u32 n_pass = want_ep ? 2u : 1u;
+  const W walks_all = walks;
+  bool marks = false;   // this lane's visits mark their policies (the second walk of a request that has anything to evaluate)
   u32 p_allow = 0, p_deny = 0, p_err = 0, p_unsup = 0, p_wtr = 0, p_pol = 0;
   u32 p_first = CBH_NONE;
-  W2_DBG(u64 cycP = cyc1;)
+  u32 p_done = 0;
+  W S = 0, has_allow = 0, allow = 0, deny = 0;
+  W dp0 = 0, dp1 = 0, dp2 = 0, dp3 = 0;
+  const u32 scope_bits = t.n_scopes > 1 ? 32u - (u32)__builtin_clz(t.n_scopes - 1u) : 0u;
+  u32 cur = first, mydepth = 0;
+  bool exists = false;
+  const bool pre_edr = PRE && (t.flags & CBH_MF_USES_RUNTIME_EDR) != 0;
+  const bool want_edr = !PRE && (flags & CBH_F_WANT_DERIVED_ROLES) != 0 && t.n_dr != 0;
+  u64 edr_all = 0; bool derr_all = false, dunsup_all = false, dwtr_all = false;   // derived roles over the chain positions visited with a walk still going
+  u32 edr_vis = 0;                                              // ... how many those were
+  // nothing to evaluate at all?  (check.go:116-121, 165-170; after a walk: `exists` is its finding)
+  bool p_exists = false;
+  auto nothing_to_evaluate = [&]() -> bool {
+    p_exists = false;
+    if (has_pp && valid && !exists && p_first != CBH_NONE) {
+      for (u32 si = p_first; si != CBH_NONE && !p_exists; si = chain_next(t, t.scope_parent[si], FLAG_PRIN)) {
+        uint4 v;
+        p_exists = dir_find(t, CBH_B_PPEXISTS, p_ver, si, 0, v);
+      }
+    }
+    return (p_first == CBH_NONE && first == CBH_NONE) || (!p_exists && !exists);
+  };
+  W2_DBG(u64 cycP = cyc1; u64 cyc2 = cyc1;)
+  for (u32 pass = 0; pass < n_pass; ++pass) {
+  if (EP && pass == 1u) {
+    // the walks the reference really makes: per action the roles up to the first that allowed (all of them when none did)
+    W legit = 0;
+#pragma unroll
+    for (u32 k = 0; k < NA; ++k) {
+      const W ak = (allow >> k) & REP;
+      const W seen = ak ? (((ak & ((W)0 - ak)) << 1) - 1u) : ~(W)0;
+      legit |= ((walks_all >> k) & REP & seen) << k;
+    }
+    marks = valid && !nothing_to_evaluate();
+    walks = walks_all & legit;
+    p_allow = p_deny = p_err = p_unsup = p_wtr = p_pol = 0; p_first = CBH_NONE;
+    has_allow = allow = deny = 0; dp0 = dp1 = dp2 = dp3 = 0;
+    cur = first; mydepth = 0; exists = false;
+    edr_all = 0; derr_all = dunsup_all = dwtr_all = false; edr_vis = 0;
+    err = unsup = wtr = 0;
+#pragma unroll
+    for (u32 k = 0; k < NA; ++k) aux[k * CBH_BLOCK + c.tid] = CBH_NONE;
+  }
   if (has_pp && (!PRE || (t.q_sites & (CBH_BS_DR_GENERIC | CBH_BS_DR_OPEN)) != 0)) {   // (pre-pass: only when principal policies hold sites at all)
     p_first = chain_first(t, p_scope, FLAG_PRIN, lenient);
     const bool cand = valid && pid_has_pp && p_first != CBH_NONE && role_cnt > 0 && act_cnt > 0;
@@ -429,6 +479,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
               mrow &= PRE ? all : S;
             }
             if (wave_ballot(mrow != 0) == 0) continue;
+            if (EP && marks && mrow != 0) ep_mark(o, b, req, rw.policy);   // the binding is iterated (check.go:302-304)
             u32 hit = mrow;
             u32 gslot = CBH_GSLOT_NONE;
             if (rw.flags & CBH_ROW_F_OUTPUT) p_wtr |= mrow;
@@ -465,21 +516,12 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
       }
     }
   }
-  const u32 p_done = p_allow | p_deny;   // a definitive principal-policy result ends the action (check.go:445-448)
-  W2_DBG(const u64 cyc2 = __builtin_readcyclecounter();)   // the principal pass is over
+  p_done = p_allow | p_deny;   // a definitive principal-policy result ends the action (check.go:445-448)
+  W2_DBG(cyc2 = __builtin_readcyclecounter();)   // the principal pass is over
   walks &= ~((W)p_done * REP);
 
   // ---- the resource walk (cbh_check_flat.h: merged climb, deepest scope first)
-  W S = walks;
-  W has_allow = 0, allow = 0, deny = 0;
-  W dp0 = 0, dp1 = 0, dp2 = 0, dp3 = 0;
-  const u32 scope_bits = t.n_scopes > 1 ? 32u - (u32)__builtin_clz(t.n_scopes - 1u) : 0u;
-  u32 cur = first, mydepth = 0;
-  bool exists = false;
-  const bool pre_edr = PRE && (t.flags & CBH_MF_USES_RUNTIME_EDR) != 0;
-  const bool want_edr = !PRE && (flags & CBH_F_WANT_DERIVED_ROLES) != 0 && t.n_dr != 0;
-  u64 edr_all = 0; bool derr_all = false, dunsup_all = false, dwtr_all = false;   // derived roles over the chain positions visited with a walk still going
-  u32 edr_vis = 0;                                              // ... how many those were
+  S = walks;
   for (;;) {
     const bool active = cur != CBH_NONE && (PRE ? pre_climbs : (S != 0 || !exists));
     if (wave_ballot(active) == 0) break;
@@ -592,6 +634,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
             if ((rr.cnt & (CBH_RP_F_OUTPUT_ONLY | CBH_RP_F_SHARES_KEY)) == (CBH_RP_F_OUTPUT_ONLY | CBH_RP_F_SHARES_KEY)) out_only |= ma;
           }
           W dn = Wg & ~((W)any_mask * REP);   // no rule for the resource, or no allow action matched (index.go:436-461)
+          if (EP && marks && dn != 0) ep_mark(o, b, req, rp.z & 0x0FFFFFFFu);   // the synthetic DENY is a binding of the role policy
           for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
             const TblRpx rr = uload_rec<TblRpx>(t.rpx, row);
             // (the reference visits a matched rule only if it has a condition - as the synthetic DENY row - or outputs)
@@ -599,6 +642,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
             const u32 ma = match_actions(rr.am_lo, rr.am_hi, rr.ag);
             const W mm = ((W)ma * REP) & Wg & ~dn;
             if (wave_ballot(mm != 0) == 0) continue;
+            if (EP && marks && mm != 0) ep_mark(o, b, req, rp.z & 0x0FFFFFFFu);
             if (rr.how & 4u) wtr |= mm;
             if (rp.w != CBH_NONE) {   // the policy's variables
               const u32 pv = leafish(PRE ? uload(&t.pool[rp.w]) : 0u, 0u, no_leaf, uload(&t.pool[rp.w + 1u]) & 0xFFFFu, mm != 0);
@@ -653,6 +697,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
           // (the walks a visit is for: those still going - the pre-pass evaluates for every walk the request has)
           const W m = ing ? (w2_rep_role<NA, NR>(mrole) & ((W)mact * REP) & (PRE ? walks : S)) : (W)0;
           if (wave_ballot(m != 0) == 0) continue;
+          if (EP && marks && m != 0) ep_mark(o, b, req, rw.policy);   // the binding is iterated: its policy set is in effect (check.go:302-304)
           W hit = m;
           if (rw.flags & CBH_ROW_F_OUTPUT) wtr |= m;
           if (probes != 0xFFFFFFFFu) {   // the variables of the rule's policy are evaluated on every visit (check.go:306-321)
@@ -693,6 +738,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     const u32 up = uchain_next(t, uload(&t.scope_parent[g_si]), FLAG_RES);
     if (ing) { cur = (mydepth + 1u < max_depth) ? up : CBH_NONE; ++mydepth; }
   }
+  }   // (pass)
 
   W2_DBG(const u64 cyc3 = __builtin_readcyclecounter();)   // the walk is over
   if (PRE) {   // file the results of this lane's sites
@@ -707,14 +753,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   }
 
   // ---- nothing to evaluate at all?  (check.go:116-121, 165-170)
-  bool p_exists = false;
-  if (has_pp && valid && !exists && p_first != CBH_NONE) {
-    for (u32 si = p_first; si != CBH_NONE && !p_exists; si = chain_next(t, t.scope_parent[si], FLAG_PRIN)) {
-      uint4 v;
-      p_exists = dir_find(t, CBH_B_PPEXISTS, p_ver, si, 0, v);
-    }
-  }
-  const bool decided = (p_first == CBH_NONE && first == CBH_NONE) || (!p_exists && !exists);
+  const bool decided = nothing_to_evaluate();
   // what an action no rule decided reports (check.go:191, 216-225, 429-431)
   const u32 pol_none = decided ? ((u32)CBH_P_NO_MATCH << 28)
                      : role_cnt == 0 ? ((u32)CBH_P_EMPTY << 28)
@@ -861,19 +900,23 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
 #define CBH_W2_ATTRS
 #endif
 // the walk: four independent waves to a workgroup, no evaluator call
-template <u32 NA, u32 NR>
+template <u32 NA, u32 NR, bool EP = false>
 __device__ __forceinline__ void w2_walk_kernel_body(const KernelArgs& a, const KernelArgs* __restrict__ ka) {
   const u32 ncc = a.t.inline_cols;   // no generic program runs here: only the columns the inline leaf code reads are parked in LDS
   const W2Layout ly = w2_layout(ncc, false, a.t.max_depth, a.t.n_scopes, false, 0, a.t.K, a.t.n_dr, NA, (a.flags & CBH_FI_PACKED_TAGS) != 0);
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
         (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * ly.wave_dw, ncc, ka};
-  w2_body<false, NA, NR>(a, c, ly);
+  w2_body<0, NA, NR, EP>(a, c, ly);
 }
 __global__ CBH_W2_ATTRS void cbh_walk2_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_walk_kernel_body<CBH_W2_NA, CBH_W2_NR>(a, ka); }
 // the same walk for the requests with five to eight roles, and for those with nine to sixteen actions: 64-bit walk vectors
 // (launched over the part of a batch that has any, CBH_FI_SKIP_WIDE)
 __global__ CBH_W2_ATTRS void cbh_walk2_wide_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_walk_kernel_body<CBH_W2_NA, CBH_W2_WIDE_NR>(a, ka); }
 __global__ CBH_W2_ATTRS void cbh_walk2_awide_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_walk_kernel_body<CBH_W2_AWIDE_NA, CBH_W2_NR>(a, ka); }
+// ... keeping the audit trail (w2_body EP: the walk twice, the second one marks; cbh_check_batch_trail on a table this walk decides)
+__global__ CBH_W2_ATTRS void cbh_walk2_trail_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_walk_kernel_body<CBH_W2_NA, CBH_W2_NR, true>(a, ka); }
+__global__ CBH_W2_ATTRS void cbh_walk2_wide_trail_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_walk_kernel_body<CBH_W2_NA, CBH_W2_WIDE_NR, true>(a, ka); }
+__global__ CBH_W2_ATTRS void cbh_walk2_awide_trail_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_walk_kernel_body<CBH_W2_AWIDE_NA, CBH_W2_NR, true>(a, ka); }
 // the pre-pass: one wave to a workgroup, the shared evaluator with its operand stack (cbh_check_wave.h generic_kernel_body)
 #if defined(CBH_PRE_WPE) && !defined(CBH_HOSTSIM)   /* lab: occupancy target of the pre-pass */
 #define CBH_PRE_WAVES __attribute__((amdgpu_waves_per_eu(CBH_PRE_WPE, CBH_PRE_WPE)))
@@ -901,7 +944,7 @@ __device__ __forceinline__ void w2_pre_kernel_body(const KernelArgs& a, const Ke
         (CBH_L u64*)s_val, (CBH_L u8*)s_tag, (CBH_L u64*)l_val, (CBH_L u8*)l_tag,
         (CBH_L u64*)it_cont, (CBH_L u32*)it_idx, (CBH_L u32*)it_state,
         (CBH_L u32*)cbh_dyn_lds, ncc, ka};
-  w2_body<true, NA, NR>(a, c, ly);
+  w2_body<1, NA, NR>(a, c, ly);
 }
 __global__ __launch_bounds__(CBH_BLOCK) CBH_PRE_WAVES void cbh_walk2_pre_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_pre_kernel_body<CBH_W2_NA, CBH_W2_NR>(a, ka); }
 __global__ __launch_bounds__(CBH_BLOCK) CBH_PRE_WAVES void cbh_walk2_pre_wide_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_pre_kernel_body<CBH_W2_NA, CBH_W2_WIDE_NR>(a, ka); }
@@ -984,20 +1027,24 @@ struct CbhPlan {
   cbh_check_kernel_fn wide_kernel;   // kind 2, batch with requests wider than the walk's shapes: the general walk's kernel for those (else null)
   bool walk_wide;                    // kind 2, batch with requests of five to eight roles: cbh_walk2_wide_kernel (+ its pre-pass) for those
   bool walk_awide;                   // kind 2, batch with requests of nine to sixteen actions: cbh_walk2_awide_kernel (+ its pre-pass) for those
+  bool trail;                        // kind 2: the walks are the cbh_walk2_*trail_kernel forms (CBH_F_WANT_EFFECTIVE_POLICIES)
 };
 static inline CbhPlan cbh_plan(u32 table_flags, u32 n_derived_roles, bool has_globs, u32 gslots_generic, u32 gslots_all, u32 max_actions,
                                u32 max_roles, bool plain_tags, u32 eval_flags, bool no_flat, bool no_walk2, u32 max_bucket, bool no_walk2_wide = false, bool masks = false) {
-  CbhPlan p; p.n_gwords = 0; p.n_gslots = 0; p.wide_kernel = nullptr; p.walk_wide = false; p.walk_awide = false;
+  CbhPlan p; p.n_gwords = 0; p.n_gslots = 0; p.wide_kernel = nullptr; p.walk_wide = false; p.walk_awide = false; p.trail = false;
   bool flat = false;
   // the effective policies of a call are what the reference's loops TOUCH, role by role in order (check.go:208-442, 302-304): the
   // general walk keeps that order; the flat kernels and cbh_walk2_kernel walk a request's roles side by side
-  if (eval_flags & CBH_F_WANT_EFFECTIVE_POLICIES) {
-    // a flat table's walks keep what they touched per chain position and sort it out at the fold (flat_body EP); every other table
-    // takes the general walk, which iterates roles and bindings in the reference's own order
+  const bool want_ep = (eval_flags & CBH_F_WANT_EFFECTIVE_POLICIES) != 0;
+  if (want_ep) {
+    // a flat table's walks keep what they touched per chain position and sort it out at the fold (flat_body EP); a table of
+    // cbh_walk2_kernel's walks twice (w2_body EP, below); every other table takes the general walk, which iterates roles and
+    // bindings in the reference's own order
     p.kernel = cbh_pick_kernel(no_flat ? (table_flags & ~(u32)CBH_MF_FLAT) : table_flags, n_derived_roles, has_globs, max_actions, max_roles, plain_tags, eval_flags, max_bucket, &p.threads, &flat, masks);
     if (flat) { p.kind = 1; p.kernel = cbh_flat_trail_variant(p.kernel); return p; }
-    p.kind = 0; p.kernel = cbh_check_trail_kernel; p.threads = CBH_BLOCK; return p;
-  }
+    p.kind = 0; p.kernel = cbh_check_trail_kernel; p.threads = CBH_BLOCK;
+    if (no_walk2 || !cbh_walk2_applies(table_flags, eval_flags)) return p;
+  } else
   p.kernel = cbh_pick_kernel(no_flat ? (table_flags & ~(u32)CBH_MF_FLAT) : table_flags, n_derived_roles, has_globs, max_actions, max_roles, plain_tags, eval_flags, max_bucket, &p.threads, &flat, masks);
   p.kind = flat ? 1 : 0;
   if (!flat && !no_walk2 && cbh_walk2_applies(table_flags, eval_flags)) {
@@ -1007,7 +1054,7 @@ static inline CbhPlan cbh_plan(u32 table_flags, u32 n_derived_roles, bool has_gl
     const bool beyond_base = max_actions > CBH_W2_NA || max_roles > CBH_W2_NR;
     const bool beyond_all = max_actions > CBH_W2_AWIDE_NA || max_roles > CBH_W2_WIDE_NR || (max_actions > CBH_W2_NA && max_roles > CBH_W2_NR);
     if (no_walk2_wide ? beyond_base : beyond_all) p.wide_kernel = p.kernel;
-    p.kind = 2; p.kernel = cbh_walk2_kernel; p.threads = CBH_W2_THREADS;
+    p.kind = 2; p.kernel = want_ep ? cbh_walk2_trail_kernel : cbh_walk2_kernel; p.threads = CBH_W2_THREADS; p.trail = want_ep;
     p.n_gwords = w2_gwords(gslots_generic, gslots_all, plain_tags);
     p.n_gslots = plain_tags ? gslots_generic : gslots_all;
   }

@@ -662,8 +662,8 @@ static void launch_plan(const CbhPlan& pl, const TableDev& dev, KernelArgs ka, c
       if (kv.b.n_gwords)
         go(shape == 1 ? cbh_walk2_pre_wide_kernel : cbh_walk2_pre_awide_kernel, (whi - wlo + CBH_BLOCK - 1) / CBH_BLOCK, CBH_BLOCK,
            plan_lds(true, na, 0), kv, false);
-      go(shape == 1 ? cbh_walk2_wide_kernel : cbh_walk2_awide_kernel, (whi - wlo + pl.threads - 1) / pl.threads, pl.threads,
-         plan_lds(false, na, 0), kv, false);
+      go(shape == 1 ? (pl.trail ? cbh_walk2_wide_trail_kernel : cbh_walk2_wide_kernel) : (pl.trail ? cbh_walk2_awide_trail_kernel : cbh_walk2_awide_kernel),
+         (whi - wlo + pl.threads - 1) / pl.threads, pl.threads, plan_lds(false, na, 0), kv, false);
     }
     if (ka.b.n_gwords && ka.b.site_cnt && ka.b.site_cap >= n && pre_split_on()) {
       // the evaluation sites in two kernels: who reaches which site (the walk's registers), then the sites' lists (the interpreter's)

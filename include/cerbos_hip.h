@@ -49,7 +49,7 @@ extern "C" {
 #define CBH_F_STRICT_EVALUATION 2u    /* EvalParams.StrictEvaluation   */
 #define CBH_F_WANT_DERIVED_ROLES 4u   /* fill cbh_result.edr_mask (CheckOutput.effective_derived_roles) */
 #define CBH_F_WANT_EFFECTIVE_POLICIES 8u /* cbh_check_batch_trail: which policies' bindings were iterated (AuditTrail.EffectivePolicies); */
-                                         /* decided by the general walk, which iterates bindings in the reference's order */
+                                         /* the trail forms of the decision kernels */
 #define CBH_F_DEBUG_CYCLES 0x100u     /* profiling aid: policy words carry per-wave cycle counts, not policies */
 
 /* Per-request u32 fields, field-major: req_u32[field * n_requests + r]. */
@@ -321,8 +321,9 @@ int cbh_wire_check_pb(cbh_table* t, uint32_t device_index, const uint8_t* bytes,
  * and, for a scoped resource / principal policy, those of its ancestor scopes that are policies of the table (drop the last scope
  * segment until none is left - cerbos_amd/engine.py effective_policy_keys is ten lines).  A flat table (resource policies only)
  * keeps its trail in the flat kernels (their trail instantiations sort out at the fold what a role BEHIND the allowing one touched);
- * any other table is decided by the general walk, which iterates a request's roles one after the other as the reference does: an
- * audit-enabled caller pays that kernel's rate there.  Device 0. */
+ * a table of cbh_walk2_kernel's walks twice - once to learn the allowing roles, once over the walks the reference really makes,
+ * marking; any other table is decided by the general walk, which iterates a request's roles one after the other as the reference
+ * does.  Device 0. */
 #define CBH_HAS_CHECK_BATCH_TRAIL 1
 uint32_t cbh_table_num_policies(const cbh_table* t);
 int cbh_table_policy_key(const cbh_table* t, uint32_t i, const char** key, uint32_t* len);

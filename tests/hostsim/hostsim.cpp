@@ -253,12 +253,12 @@ static int run_sim(const void* blob, size_t len, const cbh_batch* in, const cbh_
       if (pl.wide_kernel || pl.walk_wide || pl.walk_awide) a.flags = user_flags | CBH_FI_SKIP_WIDE;
       if (pl.walk_wide) {
         if (pl.n_gwords) { g_kernel = cbh_walk2_pre_wide_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk); }
-        g_kernel = cbh_walk2_wide_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
+        g_kernel = pl.trail ? cbh_walk2_wide_trail_kernel : cbh_walk2_wide_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
         g_used_walk_wide = true;
       }
       if (pl.walk_awide) {
         if (pl.n_gwords) { g_kernel = cbh_walk2_pre_awide_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk); }
-        g_kernel = cbh_walk2_awide_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
+        g_kernel = pl.trail ? cbh_walk2_awide_trail_kernel : cbh_walk2_awide_kernel; for (uint32_t blk = 0; blk < nblocks; ++blk) run_block(blk);
         g_used_walk_awide = true;
       }
       if (pl.n_gwords && pre_split) {

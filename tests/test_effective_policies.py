@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import hostsim_api
-from cerbos_amd import capi
+from cerbos_amd import capi, workloads
 from cerbos_amd.engine import Conf, effective_policy_keys
 from cerbos_amd.flatten import Flattener
 from cerbos_amd.lower.blob import lower_rule_table
@@ -67,23 +67,54 @@ def test_fuzz_stores_by_input(seed):
     assert any(len(k) > 1 for k in have)
 
 
-def test_the_trail_s_walk_decides_like_the_ordinary_road(store):
+@pytest.mark.parametrize("general", [False, True], ids=["cbh_walk2_trail_kernel", "the general walk"])
+def test_the_trail_s_walk_decides_like_the_ordinary_road(store, general, monkeypatch):
+    """The golden store is cbh_walk2_kernel's: its trail form walks twice (w2_body EP) and answers - status included - what the
+    ordinary walk answers; CBH_NO_WALK2=1: the general walk's trail form (what tables outside the walk's shapes take)."""
     ev, _ = store
     lt = ev.lt
     inputs = [i for c in CASES for i in c["inputs"]]
     batch = Flattener(lt).flatten(inputs, "default", "")
+    if general:
+        monkeypatch.setenv("CBH_NO_WALK2", "1")
     want = hostsim_api.check(lt, batch, NOW, capi.F_WANT_DERIVED_ROLES, device_order=True)
     have, masks = hostsim_api.check_trail(lt, batch, None, 1, NOW, capi.F_WANT_DERIVED_ROLES)
-    assert hostsim_api.last_kind() == 0          # the general walk
-    for f in ("effect", "policy", "scope", "edr"):
+    assert hostsim_api.last_kind() == (0 if general else 2)
+    for f in ("effect", "policy", "scope", "edr", "status"):
         assert np.array_equal(getattr(have, f), getattr(want, f)), f
     # one group: the union of what the cases that run without lenient scope search log
     want_keys = {k for c in CASES if not c["lenient"] for k in c["wantEffectivePolicies"]}
     assert want_keys <= set(effective_policy_keys(lt.policy_keys, masks[0]))
 
 
+@pytest.mark.parametrize("env", [{}, {"CBH_NO_WALK2": "1"}, {"CBH_NO_WALK2_WIDE": "1"}], ids=["walk2 trail", "general trail", "walk2 trail, wide requests to the general walk"])
+@pytest.mark.parametrize("name,n", [("c5", 600), ("c5w", 300), ("c5aw", 300)])
+def test_walk_tables_by_input(name, n, env, monkeypatch):
+    """C5 / C5W (scopes, derived roles, role policies, conditions with evaluation sites; C5W: five to eight roles, nine to sixteen
+    actions - the walk's wider forms) input by input against the oracle, through the walk's trail kernels and the general walk's."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rt = rule_table_from_policies(policies_from_docs(workloads.c5_policies()))   # (C5W: C5's policies, wider requests)
+    ev, oracle = HostSimEvaluator(lower_rule_table(rt), Conf()), RuleTableOracle(rt)
+    if name == "c5aw":   # nine to sixteen actions: every third input asks for twelve of the actions the workload uses
+        inputs = workloads.c5_requests(n_requests=n).to_inputs()
+        pool = sorted({a for i in inputs for a in i["actions"]}) + ["archive", "export", "print:public", "comment"]   # (+ some no rule names)
+        for k in range(0, n, 3):
+            inputs[k] = dict(inputs[k], actions=[pool[(k + j) % len(pool)] for j in range(9 + k % 4)])
+    else:
+        inputs = getattr(workloads, name + "_requests")(n_requests=n).to_inputs()
+    have = ev.effective_policies(inputs, now_ns=NOW, per_input=True)
+    if name != "c5" and "CBH_NO_WALK2" not in env:
+        assert hostsim_api.last_walk_wide() == (0 if "CBH_NO_WALK2_WIDE" in env else 1 if name == "c5w" else 2)
+    assert hostsim_api.last_kind() == (0 if "CBH_NO_WALK2" in env else 2)
+    params = EvalParams(now_ns=NOW)
+    want = [oracle.check(i, params)["effectivePolicies"] for i in inputs]
+    bad = [k for k in range(n) if have[k] != want[k]]
+    assert not bad, (bad[:3], have[bad[0]], want[bad[0]], inputs[bad[0]])
+    assert len({tuple(k) for k in have}) > 3
+
+
 # ---- flat tables: the trail from the fast kernels (flat_body EP: scalar, staged and mask walks), not the general walk
-from cerbos_amd import workloads   # noqa: E402
 
 
 @pytest.mark.parametrize("env", [{}, {"CBH_FLAT_MASKS": "0"}, {"CBH_FLAT_ANY": "1"}, {"CBH_FLAT_ANY": "1", "CBH_FLAT_MASKS": "0"}, {"CBH_FLAT_MASKS": "1"}],

@@ -237,10 +237,7 @@ def test_every_request_s_audit_trail_beside_its_outputs(monkeypatch):
         monkeypatch.setenv("CBH_WIRE_GROUP", group_by_route)
         outs, oflags, _, trails = ev.check_requests_pb(reqs, now_ns=NOW, audit_trail=True)
         plain, plain_flags, _ = ev.check_requests_pb(reqs, now_ns=NOW)
-        # the trail's kernels decide like the ordinary ones; the general walk, which keeps the trail of this table, cannot tell which
-        # inputs a trace pass has something to add to and says "all" (cerbos_hip.h CBH_ST_WANTS_TRACE) where cbh_walk2_kernel names them
-        # (CBI_OUT_CEL_ERROR 2 / CBI_OUT_WANTS_TRACE 16: either sends the input to the trace pass)
-        assert outs == plain and np.array_equal(oflags & 1, plain_flags & 1) and not ((plain_flags & 0x12) != 0)[(oflags & 0x12) == 0].any()
+        assert outs == plain and np.array_equal(oflags, plain_flags)     # the trail's kernels decide - and flag - like the ordinary ones
         k = compared = 0
         for g, trail in zip(groups, trails):
             flagged = any(oflags[k + j] & 1 for j in range(len(g)))

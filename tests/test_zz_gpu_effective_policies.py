@@ -63,7 +63,7 @@ def test_c5_at_size_groups_and_decisions():
     try:
         want = table.check(batch, now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES, device_order=True)
         have, masks = table.check_trail(batch, groups, 97, now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES)
-        for f in ("effect", "policy", "scope", "edr"):
+        for f in ("effect", "policy", "scope", "edr", "status"):   # (cbh_walk2_trail_kernel: the second walk's results are the first's)
             assert np.array_equal(getattr(have, f), getattr(want, f)), f
         oracle, params = RuleTableOracle(rt), EvalParams(now_ns=NOW)
         want_keys = [set() for _ in range(97)]
@@ -96,5 +96,26 @@ def test_flat_tables_keep_their_trail_in_the_flat_kernels(name, n):
         for f in ("effect", "policy", "scope", "edr"):
             assert np.array_equal(getattr(got, f), getattr(want, f)), f
         assert set(effective_policy_keys(lt.policy_keys, masks[0])) == set().union(*map(set, have))
+    finally:
+        ev.close()
+
+
+@pytest.mark.parametrize("name,n", [("c5", 3_000), ("c5w", 1_500)])
+def test_walk_tables_by_input(name, n):
+    """cbh_walk2_trail_kernel and its wider forms (w2_body EP: the walk twice, the second one marks) input by input against the oracle."""
+    rt = rule_table_from_policies(policies_from_docs(workloads.c5_policies()))
+    ev, oracle = HipEvaluator(lower_rule_table(rt), Conf()), RuleTableOracle(rt)
+    try:
+        inputs = getattr(workloads, name + "_requests")(n_requests=n).to_inputs()
+        if name == "c5w":   # ... and some with nine to twelve actions
+            pool = sorted({a for i in inputs for a in i["actions"]}) + ["archive", "export", "print:public", "comment"]
+            for k in range(0, n, 5):
+                inputs[k] = dict(inputs[k], actions=[pool[(k + j) % len(pool)] for j in range(9 + k % 4)],
+                                 principal=dict(inputs[k]["principal"], roles=inputs[k]["principal"]["roles"][:3]))   # (at most three roles: the nine-to-sixteen-action form)
+        have = ev.effective_policies(inputs, now_ns=NOW, per_input=True)
+        params = EvalParams(now_ns=NOW)
+        want = [oracle.check(i, params)["effectivePolicies"] for i in inputs]
+        bad = [k for k in range(n) if have[k] != want[k]]
+        assert not bad, (bad[:3], have[bad[0]], want[bad[0]])
     finally:
         ev.close()
