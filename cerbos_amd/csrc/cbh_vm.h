@@ -927,12 +927,11 @@ __device__ inline Val compare_op(const Ctx& c, Lane& L, u32 op, Val x, Val y) {
   return mk_bool(res);
 }
 
-#ifndef CBH_HOSTSIM
-__attribute__((noinline))
-#endif
 // Lane state crosses real calls BY VALUE (a reference would pin the caller's copy in scratch memory
 // and turn every L.req / L.status access of the hot path into a memory round trip).
 struct SlowVal { u32 t; u32 status; u64 v; };
+// (inlining left to the compiler: forced out of line this costs the leaf kernels an AGPR and their fourth wave - hipcc's
+// kernel-resource-usage remarks, tools/kernel_resources.py)
 __device__ SlowVal compare_op_slow(const KernelArgs* ka, u32 req, u32 op, Val x, Val y) {
   VmLds none{};   // comparisons touch only the table / batch arrays
   const Ctx c = ctx_from_memory(ka, none);
