@@ -119,12 +119,12 @@ class BatchingEvaluator:
 
 
 class _RequestCall:
-    __slots__ = ("request", "aux", "key", "done", "outputs", "flags", "include_meta", "error")
+    __slots__ = ("request", "aux", "key", "done", "outputs", "flags", "include_meta", "error", "effective_policies")
 
     def __init__(self, request, aux, key):
         self.request, self.aux, self.key = request, aux, key
         self.done = threading.Event()
-        self.outputs = self.flags = self.include_meta = self.error = None
+        self.outputs = self.flags = self.include_meta = self.error = self.effective_policies = None
 
 
 class RequestBatcher:
@@ -134,10 +134,13 @@ class RequestBatcher:
     call of ``cbh_wire_check_requests_pb`` (``HipEvaluator.check_requests_pb``: the requests are split into their ``CheckInput``s on the
     device) and hands every caller the serialized ``CheckOutput``s of its own resource entries, their flags (``CBI_OUT_*``) and whether the
     request asked for ``include_meta``.  A batch the device road leaves to the host flattener is answered request by request through
-    ``on_host`` (``HipEvaluator.check_request_pb`` bound by the caller), when given; else its callers get the error."""
+    ``on_host`` (``HipEvaluator.check_request_pb`` bound by the caller), when given; else its callers get the error.
+    ``audit_trail`` (a server with decision logs on): the call is ``cbh_wire_check_requests_trail_pb`` and ``check_request`` returns a
+    fourth value, the keys of the request's own ``AuditTrail.EffectivePolicies`` - the coalesced batch keeps a trail per request."""
 
-    def __init__(self, evaluator, max_requests: int = 2048, max_wait_s: float = 200e-6, on_host=None):
+    def __init__(self, evaluator, max_requests: int = 2048, max_wait_s: float = 200e-6, on_host=None, audit_trail: bool = False):
         self.ev, self.max_requests, self.max_wait_s, self.on_host = evaluator, max_requests, max_wait_s, on_host
+        self.audit_trail = audit_trail
         self._cv = threading.Condition()
         self._queue = []
         self._closed = False
@@ -156,6 +159,8 @@ class RequestBatcher:
         call.done.wait()
         if call.error is not None:
             raise call.error
+        if self.audit_trail:
+            return call.outputs, call.flags, call.include_meta, call.effective_policies
         return call.outputs, call.flags, call.include_meta
 
     def close(self):
@@ -192,10 +197,12 @@ class RequestBatcher:
             kw = dict(now_ns=now_ns, lenient_scope_search=lenient, strict_evaluation=strict, default_policy_version=dver, default_scope=dscope)
             try:
                 aux = [c.aux for c in batch]
-                outs, flags, meta = self.ev.check_requests_pb([c.request for c in batch], aux if any(aux) else None, **kw)
+                got = self.ev.check_requests_pb([c.request for c in batch], aux if any(aux) else None, audit_trail=self.audit_trail, **kw)
+                outs, flags, meta = got[:3]
                 at = 0
-                for c, o, m in zip(batch, outs, meta):
+                for k, (c, o, m) in enumerate(zip(batch, outs, meta)):
                     c.outputs, c.flags, c.include_meta = o, flags[at:at + len(o)], bool(m)
+                    c.effective_policies = got[3][k] if self.audit_trail else None
                     at += len(o)
             except capi.HostFlattenerNeeded as e:
                 for c in batch:          # (rare: an entry with more than 64 actions, a kind to rewrite that no policy names, ...)
@@ -203,7 +210,9 @@ class RequestBatcher:
                         c.error = e
                         continue
                     try:
-                        c.outputs, c.flags, c.include_meta = self.on_host(c.request, c.aux, **kw)
+                        got = self.on_host(c.request, c.aux, **kw)
+                        c.outputs, c.flags, c.include_meta = got[:3]
+                        c.effective_policies = got[3] if len(got) > 3 else None
                     except Exception as e2:  # noqa: BLE001
                         c.error = e2
             except Exception as e:  # noqa: BLE001 - every waiting caller gets the failure, none is left hanging

@@ -94,3 +94,27 @@ def test_request_bytes_are_gathered_and_answered_per_request(evaluator):
     rb.close()
     with pytest.raises(RuntimeError):
         rb.check_request(reqs[0])
+
+
+def test_a_coalesced_batch_keeps_a_trail_per_request(evaluator):
+    """Decision logs on: every handler gets the EffectivePolicies of ITS request out of the batch its request rode in."""
+    from cerbos_amd import wire
+    from cerbos_amd.coalesce import RequestBatcher
+    cases = [c for c in load_json("server_check_cases.json")]
+    reqs = [wire.encode_check_resources_request(_request_of(c["inputs"], False)) for c in cases]
+    alone = [evaluator.check_requests_pb([r], now_ns=NOW, audit_trail=True) for r in reqs]
+    rb = RequestBatcher(evaluator, max_requests=64, max_wait_s=0.02, audit_trail=True)
+    got = [None] * len(reqs)
+
+    def worker(j):
+        got[j] = rb.check_request(reqs[j], now_ns=NOW)
+    threads = [threading.Thread(target=worker, args=(j,)) for j in range(len(reqs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    rb.close()
+    assert rb.batches < len(reqs)
+    for (outs, flags, meta, trail), (w_outs, w_flags, _, w_trail) in zip(got, alone):
+        assert outs == w_outs[0] and list(flags) == list(w_flags) and trail == w_trail[0]
+    assert len({tuple(g[3]) for g in got}) > 1 and all(g[3] for g in got)
