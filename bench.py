@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="requests timed through the CPU oracle (~15 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the PCIe-inclusive / latency legs (profiling runs)")
+    ap.add_argument("--audit-trail", action="store_true",
+                    help="measurement aid: every launch also keeps AuditTrail.EffectivePolicies (cbh_batch_set_trail, the trail forms of the "
+                         "decision kernels: what a server with decision logs on pays); implies --no-side-legs except the one-stream leg")
     ap.add_argument("--inproc-gpus", type=int, default=0, help="also time one engine over this many devices in THIS process")
     args = ap.parse_args()
 
@@ -190,6 +193,10 @@ def main():
     now = 1_700_000_000_000_000_000
     # the reference always computes effective derived roles (part of CheckOutput): so does every step here
     FLAGS = int(os.environ.get("CBH_BENCH_FLAGS", capi.F_WANT_DERIVED_ROLES))   # (override: experiments only)
+    if args.audit_trail:
+        FLAGS |= capi.F_WANT_EFFECTIVE_POLICIES
+        for db in dbatches:
+            table.set_trail(db, None, 1)   # one group per batch: one engine.Check call
 
     def sync_all():
         table.synchronize()
@@ -230,6 +237,9 @@ def main():
     if rank == 0 and streams > 1 and not args.no_side_legs:
         table.set_resident_streams(1)
         sdb = [table.upload(hb) for hb in serial_host]
+        if args.audit_trail:
+            for db in sdb:
+                table.set_trail(db, None, 1)
         for _ in range(2):
             table.launch_many(sdb, now_ns=now, flags=FLAGS)
         table.synchronize()
@@ -249,6 +259,11 @@ def main():
     serial_host.clear()
 
     side = {}
+    if args.audit_trail:
+        args.no_side_legs = True   # (the one-shot legs have no trail to keep)
+        if rank == 0:
+            from cerbos_amd.engine import effective_policy_keys
+            side["effective_policies_of_batch_0"] = len(effective_policy_keys(lt.policy_keys, table.trail(dbatches[0])[0]))
     if rank == 0 and not args.no_side_legs:
         # per-launch latency distribution (each launch synchronised; outside the timed region)
         lat = []
@@ -550,6 +565,7 @@ def main():
                                    "Infinity Cache)"
                                    % (args.workload, wl[4], n_batches, tuples, n_requests, n_seeded, replicas, resident_bytes / 1e9),
                        "batch_tuples": tuples, "batches_per_step": n_batches, "seeded_batches": n_seeded, "replicas": replicas,
+                       "audit_trail": bool(args.audit_trail),
                        "parallelism": "independent request shards per GPU, policy image broadcast once"},
             "resident_decisions_per_s": total / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

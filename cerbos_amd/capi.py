@@ -35,7 +35,7 @@ EXPORTED_SYMBOLS = [
     "cbh_synchronize", "cbh_result_download", "cbh_kernel_time_ms", "cbh_plan_describe",
     "cbh_check_resident_many", "cbh_table_set_resident_streams", "cbh_table_resident_streams",
     "cbh_wire_flatten", "cbh_wire_spans_download", "cbh_wire_outputs", "cbh_wire_check_pb",
-    "cbh_wire_flatten_requests", "cbh_wire_check_requests_pb", "cbh_wire_check_requests_trail_pb",
+    "cbh_wire_flatten_requests", "cbh_wire_check_requests_pb", "cbh_wire_check_requests_trail_pb", "cbh_batch_set_trail", "cbh_trail_download",
     "cbh_table_num_policies", "cbh_table_policy_key", "cbh_check_batch_trail",
 ]
 
@@ -179,6 +179,10 @@ def load():
     lib.cbh_table_num_policies.restype = u32
     lib.cbh_table_policy_key.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(u32)]
     lib.cbh_table_policy_key.restype = i32
+    lib.cbh_batch_set_trail.argtypes = [vp, vp, vp, u32]
+    lib.cbh_batch_set_trail.restype = i32
+    lib.cbh_trail_download.argtypes = [vp, vp, vp]
+    lib.cbh_trail_download.restype = i32
     lib.cbh_check_batch_trail.argtypes = [vp, C.POINTER(CBatch), C.POINTER(CParams), C.POINTER(CResult), vp, u32, vp]
     lib.cbh_check_batch_trail.restype = i32
     _lib = lib
@@ -510,6 +514,20 @@ class Table:
     def launch(self, dbatch, now_ns=0, flags=0):
         p = CParams(now_ns, flags, 0)
         _check(load().cbh_check_resident(self.h, dbatch.h, C.byref(p)))
+
+    def set_trail(self, dbatch, groups=None, n_groups=1):
+        """``cbh_batch_set_trail``: the resident batch keeps an audit trail from now on (launch with ``F_WANT_EFFECTIVE_POLICIES``);
+        ``groups``: the group of every request in the batch's device order, None = one group.  Clears the masks."""
+        grp = None if groups is None else np.ascontiguousarray(groups, dtype=np.uint32)
+        _check(load().cbh_batch_set_trail(self.h, dbatch.h, grp.ctypes.data if grp is not None else None, n_groups))
+        dbatch.trail_groups = max(int(n_groups), 1)
+
+    def trail(self, dbatch):
+        """``cbh_trail_download`` -> uint32[n_groups][words]"""
+        words = (int(load().cbh_table_num_policies(self.h)) + 31) // 32
+        masks = np.zeros((dbatch.trail_groups, max(words, 1)), dtype=np.uint32)
+        _check(load().cbh_trail_download(self.h, dbatch.h, masks.ctypes.data))
+        return masks[:, :words]
 
     def launch_many(self, dbatches, now_ns=0, flags=0):
         """``cbh_check_resident_many``: one sweep over resident batches (a prepared handle array is cached per list)."""

@@ -208,6 +208,7 @@ struct cbh_device_batch {
   bool wire = false; bool own_wire_stream = false; u32* w_in_span = nullptr; u32* w_act_span = nullptr;
   void* w_pinned = nullptr; size_t w_pinned_cap = 0;
   const u32* w_req_input = nullptr;   // the request words in INPUT order (dev.req_u32 may be the grouped copy)
+  u32 trail_groups = 0; u32* trail_grp = nullptr;   // cbh_batch_set_trail: groups of out.eff_pol, the requests' groups
   const u32* w_inv = nullptr;         // grouped by route: input -> position of its per-request results; else null
   u64* w_edr_input = nullptr;         // scratch of cbh_result_download: the derived-role masks back in input order
   const u64* w_moff = nullptr; u32 w_dver_off = 0, w_dver_len = 0;   // (the device assembler reads the messages again)
@@ -769,7 +770,9 @@ extern "C" const char* cbh_plan_describe(cbh_table* t, cbh_device_batch* b, cons
   static thread_local std::string s;
   if (!t || !b || !p) return "";
   const CbhPlan pl = plan_for(b->rep->dev, b->max_actions, b->max_roles, b->plain_tags, p->flags & ~(u32)CBH_FI_MASK);
-  if (pl.kind == 2) s = std::string(pl.wide_kernel ? "cbh_check_kernel*(wide requests)+" : "") + (pl.walk_wide ? "cbh_walk2_wide_kernel(5-8 roles)+" : "") + (pl.walk_awide ? "cbh_walk2_awide_kernel(9-16 actions)+" : "") + (pl.n_gwords && b->dev.gres ? "cbh_walk2_pre_kernel+" : "") + "cbh_walk2_kernel";
+  if (pl.kind == 2) s = std::string(pl.wide_kernel ? "cbh_check_kernel*(wide requests)+" : "") + (pl.walk_wide ? (pl.trail ? "cbh_walk2_wide_trail_kernel(5-8 roles)+" : "cbh_walk2_wide_kernel(5-8 roles)+") : "") + (pl.walk_awide ? (pl.trail ? "cbh_walk2_awide_trail_kernel(9-16 actions)+" : "cbh_walk2_awide_kernel(9-16 actions)+") : "") + (pl.n_gwords && b->dev.gres ? "cbh_walk2_pre_kernel+" : "") + (pl.trail ? "cbh_walk2_trail_kernel" : "cbh_walk2_kernel");
+  else if (pl.kind == 1 && cbh_is_flat_trail_kernel(pl.kernel)) s = cbh_is_mask_kernel(pl.kernel) ? "cbh_check_flat_trail_kernel*_masks" : "cbh_check_flat_trail_kernel*";
+  else if (pl.kind == 0 && pl.kernel == cbh_check_trail_kernel) s = "cbh_check_trail_kernel";
   else if (pl.kind == 1) s = pl.kernel == cbh_check_flat_kernel ? "cbh_check_flat_kernel" : pl.kernel == cbh_check_flat_kernel_any ? "cbh_check_flat_kernel_any"
                            : pl.kernel == cbh_check_flat_kernel_staged ? "cbh_check_flat_kernel_staged" : pl.kernel == cbh_check_flat_kernel_masks ? "cbh_check_flat_kernel_masks"
                            : pl.kernel == cbh_check_flat_kernel_any_masks ? "cbh_check_flat_kernel_any_masks" : "cbh_check_flat_kernel_any_staged";
@@ -843,35 +846,55 @@ extern "C" int cbh_table_policy_key(const cbh_table* t, uint32_t i, const char**
 // cbh_check_batch with the trail: the batch goes through the resident path of device 0 (upload, the general walk with
 // CBH_F_WANT_EFFECTIVE_POLICIES, download) - the walk that iterates a request's roles one after the other as check.go:208-442
 // does, so that "touched" means what it means there.
-extern "C" int cbh_check_batch_trail(cbh_table* t, const cbh_batch* in, const cbh_params* p, cbh_result* out, const uint32_t* group_of_request,
-                                     uint32_t n_groups, uint32_t* effective_policies) {
-  if (!t || !in || !p || !out || !effective_policies) return fail("null argument");
+// The trail of a RESIDENT batch: cbh_batch_set_trail says which group (engine.Check call) every request of the batch belongs to and
+// gives the batch its masks; from then on a cbh_check_resident with CBH_F_WANT_EFFECTIVE_POLICIES ORs into them, cbh_trail_download
+// reads them (and cbh_batch_set_trail again clears them).  group_of_request: host memory, DEVICE order of the batch, NULL = one group.
+extern "C" int cbh_batch_set_trail(cbh_table* t, cbh_device_batch* b, const uint32_t* group_of_request, uint32_t n_groups) {
+  if (!t || !b) return fail("null argument");
+  if (b->table != t) return fail("batch was uploaded for a different table");
   if (n_groups == 0) n_groups = 1;
-  if (group_of_request) for (uint32_t r = 0; r < in->n_requests; ++r) if (group_of_request[r] >= n_groups) return fail("cbh_check_batch_trail: group index out of range");
-  const u32 words = (t->wire.n_policies + 31u) / 32u;
-  cbh_device_batch* b = nullptr;
-  if (cbh_batch_upload_on(t, 0, in, &b) != 0) return -1;
-  struct Release { cbh_device_batch* b; ~Release() { cbh_batch_release(b); } } release{b};
+  const u32 n = b->dev.n_requests;
+  if (group_of_request) for (u32 r = 0; r < n; ++r) if (group_of_request[r] >= n_groups) return fail("cbh_batch_set_trail: group index out of range");
   Replica* rep = b->rep;
   HIPCHK(hipSetDevice(rep->device));
   hipStream_t s = b->stream;
-  u32* d_ep = nullptr; u32* d_grp = nullptr;
+  const u32 words = (t->wire.n_policies + 31u) / 32u;
   const size_t ep_n = (size_t)n_groups * (words ? words : 1u);
-  if (dalloc(b, d_ep, ep_n) != 0) return -1;
-  HIPCHK(hipMemsetAsync(d_ep, 0, ep_n * 4, s));
-  if (group_of_request && in->n_requests) {
-    if (dalloc(b, d_grp, (size_t)in->n_requests) != 0) return -1;
-    HIPCHK(hipMemcpyAsync(d_grp, group_of_request, (size_t)in->n_requests * 4, hipMemcpyHostToDevice, s));
+  if (!b->out.eff_pol || b->trail_groups != n_groups) {
+    u32* d_ep = nullptr;
+    if (dalloc(b, d_ep, ep_n) != 0) return -1;
+    b->out.eff_pol = d_ep; b->out.ep_words = words; b->trail_groups = n_groups;
+  }
+  HIPCHK(hipMemsetAsync(b->out.eff_pol, 0, ep_n * 4, s));
+  if (group_of_request && n) {
+    if (!b->trail_grp && dalloc(b, b->trail_grp, (size_t)n) != 0) return -1;   // (kept: a batch is asked again and again)
+    HIPCHK(hipMemcpyAsync(b->trail_grp, group_of_request, (size_t)n * 4, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));   // (a pageable source)
   }
-  b->out.eff_pol = d_ep; b->out.ep_words = words; b->dev.ep_group = d_grp;
+  b->dev.ep_group = (group_of_request && n) ? b->trail_grp : nullptr;
+  return 0;
+}
+extern "C" int cbh_trail_download(cbh_table* t, cbh_device_batch* b, uint32_t* effective_policies) {
+  if (!t || !b || !effective_policies) return fail("null argument");
+  if (!b->out.eff_pol) return fail("cbh_trail_download: the batch has no trail (cbh_batch_set_trail)");
+  HIPCHK(hipSetDevice(b->rep->device));
+  if (b->out.ep_words) HIPCHK(hipMemcpyAsync(effective_policies, b->out.eff_pol, (size_t)b->trail_groups * b->out.ep_words * 4, hipMemcpyDeviceToHost, b->stream));
+  HIPCHK(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+extern "C" int cbh_check_batch_trail(cbh_table* t, const cbh_batch* in, const cbh_params* p, cbh_result* out, const uint32_t* group_of_request,
+                                     uint32_t n_groups, uint32_t* effective_policies) {
+  if (!t || !in || !p || !out || !effective_policies) return fail("null argument");
+  cbh_device_batch* b = nullptr;
+  if (cbh_batch_upload_on(t, 0, in, &b) != 0) return -1;
+  struct Release { cbh_device_batch* b; ~Release() { cbh_batch_release(b); } } release{b};
+  if (cbh_batch_set_trail(t, b, group_of_request, n_groups) != 0) return -1;
   cbh_params q = *p;
   q.flags |= CBH_F_WANT_EFFECTIVE_POLICIES;
   if (cbh_check_resident(t, b, &q) != 0) return -1;
   if (cbh_result_download(t, b, out) != 0) return -1;
-  if (words) HIPCHK(hipMemcpyAsync(effective_policies, d_ep, (size_t)n_groups * words * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-  return 0;
+  return cbh_trail_download(t, b, effective_policies);
 }
 
 #ifndef CBH_WIRE_LDS_DEFAULT

@@ -329,6 +329,11 @@ uint32_t cbh_table_num_policies(const cbh_table* t);
 int cbh_table_policy_key(const cbh_table* t, uint32_t i, const char** key, uint32_t* len);
 int cbh_check_batch_trail(cbh_table* t, const cbh_batch* in, const cbh_params* p, cbh_result* out, const uint32_t* group_of_request,
                           uint32_t n_groups, uint32_t* effective_policies);
+/* ... for a RESIDENT batch (cbh_batch_upload*): cbh_batch_set_trail names the group of every request (host memory, the batch's device
+ * order; NULL = one group) and clears the batch's masks; every cbh_check_resident with CBH_F_WANT_EFFECTIVE_POLICIES from then on ORs
+ * into them; cbh_trail_download copies them out ([n_groups][words]).  cbh_check_batch_trail is upload + these + download. */
+int cbh_batch_set_trail(cbh_table* t, cbh_device_batch* b, const uint32_t* group_of_request, uint32_t n_groups);
+int cbh_trail_download(cbh_table* t, cbh_device_batch* b, uint32_t* effective_policies);
 
 /* The device road for what the SERVER receives (internal/svc/cerbos_svc.go:255-344): `bytes` / `offsets` hold n_requests serialized
  * cerbos.request.v1.CheckResourcesRequest messages (request.proto:222-273).  Every resource entry becomes the CheckInput that

@@ -119,3 +119,33 @@ def test_walk_tables_by_input(name, n):
         assert not bad, (bad[:3], have[bad[0]], want[bad[0]])
     finally:
         ev.close()
+
+
+def test_a_resident_batch_keeps_its_trail_across_launches():
+    """cbh_batch_set_trail / cbh_trail_download: the masks of a resident batch are what cbh_check_batch_trail returns for it, launch
+    after launch (OR-ed: the same), cleared by the next cbh_batch_set_trail; the trail kernels are the ones the plan names."""
+    rt = rule_table_from_policies(policies_from_docs(workloads.c5_policies()))
+    lt = lower_rule_table(rt)
+    inputs = workloads.c5_requests(n_requests=5_000).to_inputs()
+    batch = Flattener(lt).flatten(inputs, "default", "")
+    groups = (np.arange(batch.n_requests) % 11).astype(np.uint32)
+    table = capi.Table(lt.blob)
+    try:
+        _, want = table.check_trail(batch, groups, 11, now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES)
+        db = table.upload(batch)
+        flags = capi.F_WANT_DERIVED_ROLES | capi.F_WANT_EFFECTIVE_POLICIES
+        assert "trail" in table.plan(db, flags)
+        table.set_trail(db, groups, 11)
+        for _ in range(3):
+            table.launch(db, now_ns=NOW, flags=flags)
+        assert np.array_equal(table.trail(db), want)
+        table.set_trail(db, None, 1)
+        assert not table.trail(db).any()
+        table.launch(db, now_ns=NOW, flags=flags)
+        assert np.array_equal(table.trail(db)[0], np.bitwise_or.reduce(want, axis=0))
+        plain = table.download(db)
+        ordinary = table.check(batch, now_ns=NOW, flags=capi.F_WANT_DERIVED_ROLES)   # (both in input order)
+        assert np.array_equal(plain.effect, ordinary.effect) and np.array_equal(plain.status, ordinary.status)
+        db.close()
+    finally:
+        table.close()

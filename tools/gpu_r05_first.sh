@@ -22,3 +22,10 @@ CBH_PRE_SPLIT=1 timeout 300 python -m pytest tests/test_gpu_synthetic.py -m gpu 
 for w in C2 C5; do
   timeout 300 python tools/gpu_requests_and_trail.py $w 250000 10 > $OUT/requests_and_trail_$w.txt 2>&1; tail -8 $OUT/requests_and_trail_$w.txt
 done
+# 5. what decision logs cost: the trail forms of the kernels, resident (bench.py --audit-trail), against the lines of step 2
+for w in C2 C3 T C5 C5W; do
+  CBH_BENCH_NO_DIST=1 timeout 600 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline --audit-trail > $OUT/bench_${w}_trail.json 2> $OUT/bench_${w}_trail.err
+  python -c "
+import json; d=json.load(open('$OUT/bench_${w}_trail.json')); r=d['roofline']; s=r.get('serial') or {}
+print('$w with the audit trail', '%.3g dec/s' % d['value'], r['kernel'], 'frac %.3f' % r['frac'], 'by itself %.1f us' % (s.get('kernel_ms', 0) * 1e3))"
+done
