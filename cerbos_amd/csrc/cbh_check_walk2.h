@@ -382,6 +382,8 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   const u32 n_pass = want_ep ? 2u : 1u;
   const W walks_all = walks;
   bool marks = false;   // this lane's visits mark their policies (the second walk of a request that has anything to evaluate)
+  u32 marked = CBH_NONE;   // ... the policy it marked last: a bucket's rules are one policy's, the mark is made once per bucket
+  auto mark = [&](u32 policy) { if (policy != marked) { ep_mark(o, b, req, policy); marked = policy; } };
   u32 p_allow = 0, p_deny = 0, p_err = 0, p_unsup = 0, p_wtr = 0, p_pol = 0;
   u32 p_first = CBH_NONE;
   u32 p_done = 0;
@@ -479,7 +481,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
               mrow &= PRE ? all : S;
             }
             if (wave_ballot(mrow != 0) == 0) continue;
-            if (EP && marks && mrow != 0) ep_mark(o, b, req, rw.policy);   // the binding is iterated (check.go:302-304)
+            if (EP && marks && mrow != 0) mark(rw.policy);   // the binding is iterated (check.go:302-304)
             u32 hit = mrow;
             u32 gslot = CBH_GSLOT_NONE;
             if (rw.flags & CBH_ROW_F_OUTPUT) p_wtr |= mrow;
@@ -634,7 +636,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
             if ((rr.cnt & (CBH_RP_F_OUTPUT_ONLY | CBH_RP_F_SHARES_KEY)) == (CBH_RP_F_OUTPUT_ONLY | CBH_RP_F_SHARES_KEY)) out_only |= ma;
           }
           W dn = Wg & ~((W)any_mask * REP);   // no rule for the resource, or no allow action matched (index.go:436-461)
-          if (EP && marks && dn != 0) ep_mark(o, b, req, rp.z & 0x0FFFFFFFu);   // the synthetic DENY is a binding of the role policy
+          if (EP && marks && dn != 0) mark(rp.z & 0x0FFFFFFFu);   // the synthetic DENY is a binding of the role policy
           for (u32 row = rp.x; row < rp.x + rp.y; ++row) {
             const TblRpx rr = uload_rec<TblRpx>(t.rpx, row);
             // (the reference visits a matched rule only if it has a condition - as the synthetic DENY row - or outputs)
@@ -642,7 +644,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
             const u32 ma = match_actions(rr.am_lo, rr.am_hi, rr.ag);
             const W mm = ((W)ma * REP) & Wg & ~dn;
             if (wave_ballot(mm != 0) == 0) continue;
-            if (EP && marks && mm != 0) ep_mark(o, b, req, rp.z & 0x0FFFFFFFu);
+            if (EP && marks && mm != 0) mark(rp.z & 0x0FFFFFFFu);
             if (rr.how & 4u) wtr |= mm;
             if (rp.w != CBH_NONE) {   // the policy's variables
               const u32 pv = leafish(PRE ? uload(&t.pool[rp.w]) : 0u, 0u, no_leaf, uload(&t.pool[rp.w + 1u]) & 0xFFFFu, mm != 0);
@@ -697,7 +699,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
           // (the walks a visit is for: those still going - the pre-pass evaluates for every walk the request has)
           const W m = ing ? (w2_rep_role<NA, NR>(mrole) & ((W)mact * REP) & (PRE ? walks : S)) : (W)0;
           if (wave_ballot(m != 0) == 0) continue;
-          if (EP && marks && m != 0) ep_mark(o, b, req, rw.policy);   // the binding is iterated: its policy set is in effect (check.go:302-304)
+          if (EP && marks && m != 0) mark(rw.policy);   // the binding is iterated: its policy set is in effect (check.go:302-304)
           W hit = m;
           if (rw.flags & CBH_ROW_F_OUTPUT) wtr |= m;
           if (probes != 0xFFFFFFFFu) {   // the variables of the rule's policy are evaluated on every visit (check.go:306-321)

@@ -104,14 +104,15 @@ struct OutDev {
   // the group (check.go:302-304, the AuditTrail's effective policies); null = not wanted
   CBH_G u32* eff_pol;
 };
-// (the general walk, which iterates bindings in the reference's order; idempotent: a stale read costs an atomic, never a bit)
+// (idempotent: a stale read costs an atomic, never a bit.  The read goes to L2 - agent scope - on purpose: a CU's L1 would keep
+// answering "not set" for the rest of the launch, and every later visit of every wave of that CU would queue an atomic on the one word)
 __device__ __forceinline__ void ep_mark(const OutDev& o, const BatchDev& b, u32 req, u32 policy) {
   CBH_G u32* w = o.eff_pol + (size_t)(b.ep_group ? b.ep_group[req] : 0u) * o.ep_words + (policy >> 5);
   const u32 bit = 1u << (policy & 31u);
 #ifdef CBH_HOSTSIM
   *w |= bit;
 #else
-  if (!(*w & bit)) atomicOr((unsigned int*)w, bit);
+  if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr((unsigned int*)w, bit);
 #endif
 }
 
