@@ -997,6 +997,15 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
   if (!b->own_wire_stream) b->stream = rep->rstreams[rep->next_rstream.fetch_add(1, std::memory_order_relaxed) % (uint32_t)rep->n_rstreams.load(std::memory_order_relaxed)];
   hipStream_t s = b->stream;
   auto bail = [&](int rc) { cbh_batch_release(b); return rc; };
+  // (a sliced call, WireChain) the big upload of this slice goes behind its predecessor's
+  auto chain_wait = [&]() -> bool {
+    if (chain && chain->prev_recorded) {   // (the predecessor's thread has enqueued the record by now, or is about to)
+      while (!chain->prev_recorded->load(std::memory_order_acquire)) std::this_thread::yield();
+      if (chain->wait && hipStreamWaitEvent(s, chain->wait, 0) != hipSuccess) { fail("cbh_wire_flatten: hipStreamWaitEvent failed"); return false; }
+    }
+    return true;
+  };
+  auto chain_record = [&]() { if (chain && chain->record) { (void)hipEventRecord(chain->record, s); chain->done(); } };
   u8* d_msg = nullptr; u64* d_moff = nullptr;
   const u32 n_in = n;
   const size_t tail_room = dv.size() + ds.size() + globals_len + 64;
@@ -1014,11 +1023,13 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
     rq |= dalloc(b, d_first, (size_t)nr + 1); rq |= dalloc(b, d_fbyte, (size_t)nr + 1);
     if (reqs->aux_offsets) { rq |= dalloc(b, d_aux, (size_t)atotal + 8); rq |= dalloc(b, d_aoff, (size_t)nr + 1); }
     if (rq != 0) return bail(-1);
+    if (!chain_wait()) return bail(-1);
     if ((rtotal && hipMemcpyAsync(d_req, bytes, rtotal, hipMemcpyHostToDevice, s) != hipSuccess) ||
         (nr && hipMemcpyAsync(d_roff, offsets, ((size_t)nr + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess) ||
         (atotal && hipMemcpyAsync(d_aux, reqs->aux, atotal, hipMemcpyHostToDevice, s) != hipSuccess) ||
         (reqs->aux_offsets && nr && hipMemcpyAsync(d_aoff, reqs->aux_offsets, ((size_t)nr + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess))
       { fail("cbh_wire_flatten_requests: upload failed"); return bail(-1); }
+    chain_record();
     q.req = d_req; q.roff = d_roff; q.n = nr; q.end = (u32)rtotal; q.aux = d_aux; q.aoff = reqs->aux_offsets ? d_aoff : nullptr; q.aux_end = atotal;
     if (nr) hipLaunchKernelGGL(cbh_wire_req_count_kernel, dim3((nr + CBH_BLOCK - 1) / CBH_BLOCK), dim3(CBH_BLOCK), 0, s, q);
     std::vector<u32> h_inputs((size_t)nr + 1, 0), h_first((size_t)nr + 1, 0); std::vector<u64> h_bytes((size_t)nr + 1, 0), h_fbyte((size_t)nr + 1, 0);
@@ -1088,12 +1099,11 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
   *pin_st = st;
   std::memcpy(pin_tail, tail.data(), tail.size());
   if (!reqs) { if (n) std::memcpy(pin_off, offsets, ((size_t)n + 1) * 8); else pin_off[0] = 0; }
-  if (chain && chain->prev_recorded) {   // behind the predecessor's upload (its thread has enqueued the record by now, or is about to)
-    while (!chain->prev_recorded->load(std::memory_order_acquire)) std::this_thread::yield();
-    if (chain->wait && hipStreamWaitEvent(s, chain->wait, 0) != hipSuccess) { fail("cbh_wire_flatten: hipStreamWaitEvent failed"); return bail(-1); }
+  if (!reqs) {
+    if (!chain_wait()) return bail(-1);
+    if (total && hipMemcpyAsync(d_msg, bytes, total, hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
+    chain_record();
   }
-  if (!reqs && total && hipMemcpyAsync(d_msg, bytes, total, hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
-  if (chain && chain->record) { (void)hipEventRecord(chain->record, s); chain->done(); }
   if (hipMemcpyAsync(d_msg + total, pin_tail, tail.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
       (!reqs && hipMemcpyAsync(d_moff, pin_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess) ||
       hipMemcpyAsync(d_stats, pin_st, sizeof(st), hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
@@ -1283,66 +1293,204 @@ extern "C" int cbh_wire_outputs(cbh_table* t, cbh_device_batch* b, uint8_t* byte
   return 0;
 }
 
-// What the server receives in, what engine.Check returns out, in ONE call: serialized CheckResourcesRequests -> the serialized
-// CheckOutputs of their resource entries (cbh_wire_flatten_requests, cbh_check_resident, cbh_wire_outputs on one stream).  The
-// outputs of request r are out_offsets[first_input[r]] .. out_offsets[first_input[r + 1]].  Return values as cbh_wire_check_pb.
-static int wire_check_requests_impl(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n_requests,
-                                    const uint8_t* aux_bytes, const uint64_t* aux_offsets, const char* default_version, const char* default_scope,
-                                    const uint8_t* globals_pb, size_t globals_len, const cbh_params* p, uint32_t* first_input, uint8_t* request_flags,
-                                    uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags, size_t out_inputs_cap, size_t* need,
-                                    cbh_wire_info* info, uint32_t* effective_policies) {
-  if (!t || !p || !need || !info || !first_input || (out_cap && !out_bytes)) return fail("null argument");
-  cbh_device_batch* b = nullptr;
-  int rc = cbh_wire_flatten_requests(t, device_index, bytes, offsets, n_requests, aux_bytes, aux_offsets, default_version, default_scope, globals_pb, globals_len,
-                                     first_input, request_flags, &b, info);
-  if (rc != 0) return rc;
-  struct Release { cbh_device_batch* b; ~Release() { if (b) cbh_batch_release(b); } } release{b};
-  cbh_params q = *p;
-  u32* d_ep = nullptr;
+// Bytes in, bytes out in ONE call: serialized CheckInputs -> serialized CheckOutputs by the device road (cbh_wire_flatten,
+// cbh_check_resident, cbh_wire_outputs), the call cut into up to four slices of contiguous messages that go down the road side
+// by side, each on a thread and a stream of its own - one slice's copies run under another's kernels, which a single caller
+// thread making the three calls in a row never gets (its H2D, kernels and D2H queue behind each other).  The slices' outputs
+// land back to back in `out_bytes`: every slice first learns its size (the size / scan launches), the bases follow, then each
+// writes and copies into its own range.  Returns 0; 1 = some message is the host flattener's (info->n_host; nothing was
+// written); 2 = `out_cap` is too small, *need holds the size; < 0 error.
+//
+// The same for what the SERVER receives (`rm`): the units are serialized CheckResourcesRequests, a slice is a range of requests, its
+// CheckInputs are made on the device (cbh_wire_req.h); the outputs of request r are out_offsets[first_input[r]] ..
+// out_offsets[first_input[r + 1]]; with `rm->effective_policies` every request also gets its audit trail (one group per request:
+// the one decision-log entry svc.CheckResources writes for the call).  2 also when out_offsets / out_flags hold fewer inputs than the
+// requests have (info->n_requests = the inputs).
+struct WireReqMode {
+  const uint8_t* aux = nullptr; const uint64_t* aux_offsets = nullptr;
+  uint32_t* first_input = nullptr; uint8_t* request_flags = nullptr; size_t out_inputs_cap = 0;
+  uint32_t* effective_policies = nullptr;
+};
+static int wire_check_sliced(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
+                             const char* default_version, const char* default_scope, const uint8_t* globals_pb, size_t globals_len,
+                             const cbh_params* p, uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags,
+                             size_t* need, cbh_wire_info* info, const WireReqMode* rm) {
+  TableRef ref(t);
+  std::memset(info, 0, sizeof(*info));
+  info->first_bad = CBH_NONE; info->n_requests = rm ? 0u : n;
+  *need = 0;
+  static const u32 max_slices = [] { const char* e = getenv("CBH_WIRE_SLICES"); const long v = e ? atol(e) : 4; return (u32)std::min<long>(std::max<long>(v, 1), 8); }();
+  // (requests: by their bytes - a request holds any number of resource entries -, about 4 MB to a slice)
+  const u32 S = std::max<u32>(1u, std::min<u32>(max_slices, rm ? (u32)std::min<u64>(n, (n ? offsets[n] : 0) >> 22) : n / 16384u));
   const u32 words = (t->wire.n_policies + 31u) / 32u;
-  if (effective_policies) {
-    // the trail of cbh_check_batch_trail, one group per REQUEST (what one decision-log entry of the server covers): the inputs'
-    // groups follow from first_input; a batch the flattener grouped by route keeps its results by position, so they move with it
+  struct Slice {
+    u32 lo = 0, hi = 0; cbh_device_batch* b = nullptr; cbh_wire_info wi{}; size_t total = 0, base = 0; int rc = 0; std::string err;
+    std::vector<uint64_t> off, ooff, aoff; std::vector<uint32_t> first; u32 n_in = 0, in_base = 0;
+  };
+  std::vector<Slice> sl(S);
+  for (u32 k = 0; k < S; ++k) { sl[k].lo = (u32)((u64)n * k / S); sl[k].hi = (u32)((u64)n * (k + 1) / S); }
+  // the slices' uploads in slice order (WireChain)
+  if (device_index >= t->reps.size()) return fail("device index out of range");
+  HIPCHK(hipSetDevice(t->reps[device_index]->device));
+  std::vector<hipEvent_t> evs(S, nullptr);
+  std::vector<std::atomic<int>> recorded(S);
+  std::vector<WireChain> chains(S);
+  struct EvGuard { std::vector<hipEvent_t>& e; ~EvGuard() { for (auto x : e) if (x) (void)hipEventDestroy(x); } } ev_guard{evs};
+  for (u32 k = 0; k < S; ++k) {
+    recorded[k].store(0);
+    if (S > 1 && hipEventCreateWithFlags(&evs[k], hipEventDisableTiming) != hipSuccess) return fail("cbh_wire_check_pb: hipEventCreate failed");
+    chains[k].record = evs[k]; chains[k].recorded = &recorded[k];
+    if (k) { chains[k].wait = evs[k - 1]; chains[k].prev_recorded = &recorded[k - 1]; }
+  }
+  // the trail of a slice of requests (cbh_check_batch_trail with one group per REQUEST): the inputs' groups follow from the split's
+  // first_input; a batch the flattener grouped by route keeps its results by position, so the groups move with the inputs
+  auto trail_on = [&](Slice& x, u32*& d_ep) -> int {
+    cbh_device_batch* b = x.b;
     hipStream_t s = b->stream;
-    HIPCHK(hipSetDevice(b->rep->device));
-    const u32 n_in = info->n_requests;
-    const size_t ep_n = (size_t)(n_requests ? n_requests : 1u) * (words ? words : 1u);
+    const u32 cnt = x.hi - x.lo;
+    const size_t ep_n = (size_t)(cnt ? cnt : 1u) * (words ? words : 1u);
     if (dalloc(b, d_ep, ep_n) != 0) return -1;
     HIPCHK(hipMemsetAsync(d_ep, 0, ep_n * 4, s));
     u32* d_grp = nullptr;
-    if (n_in) {
-      std::vector<u32> grp(n_in);
-      for (u32 r = 0; r < n_requests; ++r) for (u32 i = first_input[r]; i < first_input[r + 1]; ++i) grp[i] = r;
+    if (x.n_in) {
+      std::vector<u32> grp(x.n_in);
+      for (u32 r = 0; r < cnt; ++r) for (u32 i = x.first[r]; i < x.first[r + 1]; ++i) grp[i] = r;
       u32* d_by_input = nullptr;
-      if (dalloc(b, d_by_input, (size_t)n_in) != 0) return -1;
-      HIPCHK(hipMemcpyAsync(d_by_input, grp.data(), (size_t)n_in * 4, hipMemcpyHostToDevice, s));
+      if (dalloc(b, d_by_input, (size_t)x.n_in) != 0) return -1;
+      HIPCHK(hipMemcpyAsync(d_by_input, grp.data(), (size_t)x.n_in * 4, hipMemcpyHostToDevice, s));
       d_grp = d_by_input;
       if (b->w_inv) {
-        if (dalloc(b, d_grp, (size_t)n_in) != 0) return -1;
-        WireScatterArgs sa; sa.by_input = d_by_input; sa.inv = b->w_inv; sa.by_position = d_grp; sa.n = n_in; sa.pad = 0;
-        hipLaunchKernelGGL(cbh_wire_scatter_u32_kernel, dim3((n_in + 255u) / 256u), dim3(256), 0, s, sa);
+        if (dalloc(b, d_grp, (size_t)x.n_in) != 0) return -1;
+        WireScatterArgs sa; sa.by_input = d_by_input; sa.inv = b->w_inv; sa.by_position = d_grp; sa.n = x.n_in; sa.pad = 0;
+        hipLaunchKernelGGL(cbh_wire_scatter_u32_kernel, dim3((x.n_in + 255u) / 256u), dim3(256), 0, s, sa);
         HIPCHK(hipGetLastError());
       }
       HIPCHK(hipStreamSynchronize(s));   // (grp is a pageable source going out of scope)
     }
     b->out.eff_pol = d_ep; b->out.ep_words = words; b->dev.ep_group = d_grp;
-    q.flags |= CBH_F_WANT_EFFECTIVE_POLICIES;
-  } else {
-    q.flags &= ~CBH_F_WANT_EFFECTIVE_POLICIES;
+    return 0;
+  };
+  // stage 1 (per slice): flatten, decide, sizes of the outputs
+  auto stage1 = [&](u32 k) {
+    Slice& x = sl[k];
+    const u32 cnt = x.hi - x.lo;
+    x.off.resize((size_t)cnt + 1);
+    const uint64_t o0 = n ? offsets[x.lo] : 0;
+    for (u32 i = 0; i <= cnt; ++i) x.off[i] = (n ? offsets[x.lo + i] : 0) - o0;
+    WireRequests rq;
+    if (rm) {
+      x.first.assign((size_t)cnt + 1, 0u);
+      rq.first_input = x.first.data(); rq.flags = rm->request_flags ? rm->request_flags + x.lo : nullptr;
+      if (rm->aux_offsets) {
+        const uint64_t a0 = n ? rm->aux_offsets[x.lo] : 0;
+        x.aoff.resize((size_t)cnt + 1);
+        for (u32 i = 0; i <= cnt; ++i) x.aoff[i] = (n ? rm->aux_offsets[x.lo + i] : 0) - a0;   // (out of order: the device refuses the request)
+        rq.aux = rm->aux ? rm->aux + a0 : nullptr; rq.aux_offsets = x.aoff.data();
+      }
+    }
+    x.rc = wire_flatten_impl(t, device_index, bytes ? bytes + o0 : nullptr, x.off.data(), cnt, default_version, default_scope, globals_pb, globals_len, &x.b, &x.wi,
+                             S > 1 ? &chains[k] : nullptr, rm ? &rq : nullptr);
+    if (x.rc != 0) { x.err = g_err; x.b = nullptr; return; }
+    x.n_in = x.wi.n_requests;   // the slice's messages (requests: the inputs made of them)
+    cbh_params q = *p;
+    q.flags &= ~(u32)CBH_F_WANT_EFFECTIVE_POLICIES;
+    u32* d_ep = nullptr;
+    if (rm && rm->effective_policies) {
+      if (trail_on(x, d_ep) != 0) { x.rc = -1; x.err = g_err; return; }
+      q.flags |= CBH_F_WANT_EFFECTIVE_POLICIES;
+    }
+    x.rc = cbh_check_resident(t, x.b, &q);
+    if (x.rc != 0) { x.err = g_err; return; }
+    if (d_ep && words && cnt) {
+      if (hipMemcpyAsync(rm->effective_policies + (size_t)x.lo * words, d_ep, (size_t)cnt * words * 4, hipMemcpyDeviceToHost, x.b->stream) != hipSuccess ||
+          hipStreamSynchronize(x.b->stream) != hipSuccess) { x.rc = fail("cbh_wire_check_requests_trail_pb: download failed"); x.err = g_err; return; }
+    }
+    x.ooff.resize((size_t)x.n_in + 1);
+    size_t nd = 0;
+    const int r = cbh_wire_outputs(t, x.b, nullptr, 0, x.ooff.data(), nullptr, &nd);   // cap 0: sizes only (2 = "too small" unless the slice has no output bytes)
+    if (r != 0 && r != 2) { x.rc = r; x.err = g_err; return; }
+    x.total = nd;
+  };
+  auto stage2 = [&](u32 k) {
+    Slice& x = sl[k];
+    size_t nd = 0;
+    x.rc = cbh_wire_outputs(t, x.b, out_bytes + x.base, x.total, x.ooff.data(), out_flags ? out_flags + x.in_base : nullptr, &nd);
+    if (x.rc != 0) { x.err = g_err; return; }
+    for (u32 i = 0; i <= x.n_in; ++i) out_offsets[x.in_base + i] = x.ooff[i] + x.base;
+  };
+  // A slice writes as soon as the slices before it know their sizes (its base is their sum): no barrier between the stages, so
+  // the first slice's answers are on their way back while the last slice's messages are still going up.  A slice that failed,
+  // or met a message for the host flattener, publishes "no size": nobody writes after that.
+  std::vector<std::atomic<int>> sized(S);   // 0 not yet, 1 size known, 2 failed
+  for (auto& q : sized) q.store(0);
+  std::atomic<int> overflow{0};
+  const size_t inputs_cap = rm ? (out_offsets ? rm->out_inputs_cap : 0) : (size_t)n;
+  auto work = [&](u32 k) {
+    stage1(k);
+    Slice& x = sl[k];
+    sized[k].store(x.rc == 0 ? 1 : 2, std::memory_order_release);
+    if (x.rc != 0) return;
+    size_t base = 0; u32 in_base = 0;
+    for (u32 j = 0; j < k; ++j) {
+      int st;
+      while ((st = sized[j].load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+      if (st == 2) return;
+      base += sl[j].total; in_base += sl[j].n_in;
+    }
+    x.base = base; x.in_base = in_base;
+    if (base + x.total > out_cap || (size_t)in_base + x.n_in > inputs_cap) { overflow.store(1); return; }
+    stage2(k);
+  };
+  {
+    std::vector<std::thread> th;
+    for (u32 k = 1; k < S; ++k) th.emplace_back(work, k);
+    work(0);
+    for (auto& q : th) q.join();
   }
-  if ((rc = cbh_check_resident(t, b, &q)) != 0) return rc;
-  if (effective_policies && words && n_requests) {
-    HIPCHK(hipMemcpyAsync(effective_policies, d_ep, (size_t)n_requests * words * 4, hipMemcpyDeviceToHost, b->stream));
-    HIPCHK(hipStreamSynchronize(b->stream));
+  auto release = [&] { for (auto& x : sl) if (x.b) { cbh_batch_release(x.b); x.b = nullptr; } };
+  int rc = 0; std::string err;
+  size_t total = 0; u64 inputs = 0;
+  for (auto& x : sl) {
+    info->n_tuples += x.wi.n_tuples; info->n_host += x.wi.n_host; info->heap_len += x.wi.heap_len; info->dict_slots += x.wi.dict_slots;
+    info->fill_runs = std::max(info->fill_runs, x.wi.fill_runs); info->n_routes = std::max(info->n_routes, x.wi.n_routes);
+    if (x.wi.first_bad != CBH_NONE && info->first_bad == CBH_NONE) info->first_bad = x.lo + x.wi.first_bad;
+    if (x.rc < 0 && rc >= 0) { rc = x.rc; err = x.err; }
+    else if (x.rc == 1 && rc == 0) { rc = 1; err = x.err; }
+    total += x.total;
+    if (rm && x.rc == 0) { for (u32 r = 0; r <= x.hi - x.lo; ++r) rm->first_input[x.lo + r] = (u32)inputs + x.first[r]; }
+    inputs += x.n_in;
   }
-  const u32 n = info->n_requests;   // the inputs
-  std::vector<uint64_t> tmp_off; std::vector<uint8_t> tmp_flags;
-  const bool fits = (size_t)n <= out_inputs_cap && out_offsets;
-  uint64_t* off = out_offsets; uint8_t* fl = out_flags;
-  if (!fits) { tmp_off.resize((size_t)n + 1); off = tmp_off.data(); if (fl) { tmp_flags.resize((size_t)n + 1); fl = tmp_flags.data(); } }
-  rc = cbh_wire_outputs(t, b, fits ? out_bytes : nullptr, fits ? out_cap : 0, off, fl, need);   // (not fitting: sizes only)
-  if (rc == 0 && !fits) { g_err = "cbh_wire_check_requests_pb: out_offsets / out_flags hold fewer inputs than the requests have"; return 2; }
-  return rc;
+  release();
+  if (rm) info->n_requests = (u32)inputs;
+  if (rc != 0) { g_err = err; return rc; }
+  *need = total;
+  if (overflow.load() || total > out_cap || inputs > inputs_cap) {
+    g_err = rm ? "cbh_wire_check_requests_pb: the output buffer (or out_offsets / out_flags) is too small" : "cbh_wire_check_pb: the output buffer is too small";
+    return 2;
+  }
+  if (inputs == 0 && out_offsets) out_offsets[0] = 0;
+  return 0;
+}
+extern "C" int cbh_wire_check_pb(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
+                                 const char* default_version, const char* default_scope, const uint8_t* globals_pb, size_t globals_len,
+                                 const cbh_params* p, uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags,
+                                 size_t* need, cbh_wire_info* info) {
+  if (!t || !p || !out_offsets || !need || !info || (n && (!bytes || !offsets)) || (out_cap && !out_bytes)) return fail("null argument");
+  return wire_check_sliced(t, device_index, bytes, offsets, n, default_version, default_scope, globals_pb, globals_len, p, out_bytes, out_cap, out_offsets, out_flags,
+                           need, info, nullptr);
+}
+static int wire_check_requests_impl(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n_requests,
+                                    const uint8_t* aux_bytes, const uint64_t* aux_offsets, const char* default_version, const char* default_scope,
+                                    const uint8_t* globals_pb, size_t globals_len, const cbh_params* p, uint32_t* first_input, uint8_t* request_flags,
+                                    uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags, size_t out_inputs_cap, size_t* need,
+                                    cbh_wire_info* info, uint32_t* effective_policies) {
+  if (!t || !p || !need || !info || !first_input || (n_requests && (!bytes || !offsets)) || (out_cap && !out_bytes)) return fail("null argument");
+  if ((aux_bytes == nullptr) != (aux_offsets == nullptr)) return fail("cbh_wire_check_requests_pb: aux_bytes and aux_offsets go together");
+  WireReqMode rm;
+  rm.aux = aux_bytes; rm.aux_offsets = aux_offsets; rm.first_input = first_input; rm.request_flags = request_flags; rm.out_inputs_cap = out_inputs_cap;
+  rm.effective_policies = effective_policies;
+  return wire_check_sliced(t, device_index, bytes, offsets, n_requests, default_version, default_scope, globals_pb, globals_len, p, out_bytes, out_cap,
+                           out_offsets, out_flags, need, info, &rm);
 }
 extern "C" int cbh_wire_check_requests_pb(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n_requests,
                                           const uint8_t* aux_bytes, const uint64_t* aux_offsets, const char* default_version, const char* default_scope,
@@ -1363,116 +1511,6 @@ extern "C" int cbh_wire_check_requests_trail_pb(cbh_table* t, uint32_t device_in
   if (!effective_policies) return fail("null argument");
   return wire_check_requests_impl(t, device_index, bytes, offsets, n_requests, aux_bytes, aux_offsets, default_version, default_scope, globals_pb, globals_len, p,
                                   first_input, request_flags, out_bytes, out_cap, out_offsets, out_flags, out_inputs_cap, need, info, effective_policies);
-}
-
-// Bytes in, bytes out in ONE call: serialized CheckInputs -> serialized CheckOutputs by the device road (cbh_wire_flatten,
-// cbh_check_resident, cbh_wire_outputs), the call cut into up to four slices of contiguous messages that go down the road side
-// by side, each on a thread and a stream of its own - one slice's copies run under another's kernels, which a single caller
-// thread making the three calls in a row never gets (its H2D, kernels and D2H queue behind each other).  The slices' outputs
-// land back to back in `out_bytes`: every slice first learns its size (the size / scan launches), the bases follow, then each
-// writes and copies into its own range.  Returns 0; 1 = some message is the host flattener's (info->n_host; nothing was
-// written); 2 = `out_cap` is too small, *need holds the size; < 0 error.
-extern "C" int cbh_wire_check_pb(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
-                                 const char* default_version, const char* default_scope, const uint8_t* globals_pb, size_t globals_len,
-                                 const cbh_params* p, uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags,
-                                 size_t* need, cbh_wire_info* info) {
-  if (!t || !p || !out_offsets || !need || !info || (n && (!bytes || !offsets)) || (out_cap && !out_bytes)) return fail("null argument");
-  TableRef ref(t);
-  std::memset(info, 0, sizeof(*info));
-  info->first_bad = CBH_NONE; info->n_requests = n;
-  *need = 0;
-  static const u32 max_slices = [] { const char* e = getenv("CBH_WIRE_SLICES"); const long v = e ? atol(e) : 4; return (u32)std::min<long>(std::max<long>(v, 1), 8); }();
-  const u32 S = std::max<u32>(1u, std::min<u32>(max_slices, n / 16384u));
-  struct Slice {
-    u32 lo = 0, hi = 0; cbh_device_batch* b = nullptr; cbh_wire_info wi{}; size_t total = 0, base = 0; int rc = 0; std::string err;
-    std::vector<uint64_t> off, ooff;
-  };
-  std::vector<Slice> sl(S);
-  for (u32 k = 0; k < S; ++k) { sl[k].lo = (u32)((u64)n * k / S); sl[k].hi = (u32)((u64)n * (k + 1) / S); }
-  // the slices' uploads in slice order (WireChain)
-  if (device_index >= t->reps.size()) return fail("device index out of range");
-  HIPCHK(hipSetDevice(t->reps[device_index]->device));
-  std::vector<hipEvent_t> evs(S, nullptr);
-  std::vector<std::atomic<int>> recorded(S);
-  std::vector<WireChain> chains(S);
-  struct EvGuard { std::vector<hipEvent_t>& e; ~EvGuard() { for (auto x : e) if (x) (void)hipEventDestroy(x); } } ev_guard{evs};
-  for (u32 k = 0; k < S; ++k) {
-    recorded[k].store(0);
-    if (S > 1 && hipEventCreateWithFlags(&evs[k], hipEventDisableTiming) != hipSuccess) return fail("cbh_wire_check_pb: hipEventCreate failed");
-    chains[k].record = evs[k]; chains[k].recorded = &recorded[k];
-    if (k) { chains[k].wait = evs[k - 1]; chains[k].prev_recorded = &recorded[k - 1]; }
-  }
-  // stage 1 (per slice): flatten, decide, sizes of the outputs
-  auto stage1 = [&](u32 k) {
-    Slice& x = sl[k];
-    const u32 cnt = x.hi - x.lo;
-    x.off.resize((size_t)cnt + 1);
-    const uint64_t o0 = n ? offsets[x.lo] : 0;
-    for (u32 i = 0; i <= cnt; ++i) x.off[i] = (n ? offsets[x.lo + i] : 0) - o0;
-    x.rc = wire_flatten_impl(t, device_index, bytes ? bytes + o0 : nullptr, x.off.data(), cnt, default_version, default_scope, globals_pb, globals_len, &x.b, &x.wi,
-                             S > 1 ? &chains[k] : nullptr);
-    if (x.rc != 0) { x.err = g_err; x.b = nullptr; return; }
-    x.rc = cbh_check_resident(t, x.b, p);
-    if (x.rc != 0) { x.err = g_err; return; }
-    x.ooff.resize((size_t)cnt + 1);
-    size_t nd = 0;
-    const int r = cbh_wire_outputs(t, x.b, nullptr, 0, x.ooff.data(), nullptr, &nd);   // cap 0: sizes only (2 = "too small" unless the slice has no output bytes)
-    if (r != 0 && r != 2) { x.rc = r; x.err = g_err; return; }
-    x.total = nd;
-  };
-  auto stage2 = [&](u32 k) {
-    Slice& x = sl[k];
-    const u32 cnt = x.hi - x.lo;
-    size_t nd = 0;
-    x.rc = cbh_wire_outputs(t, x.b, out_bytes + x.base, x.total, x.ooff.data(), out_flags ? out_flags + x.lo : nullptr, &nd);
-    if (x.rc != 0) { x.err = g_err; return; }
-    for (u32 i = 0; i <= cnt; ++i) out_offsets[x.lo + i] = x.ooff[i] + x.base;
-  };
-  // A slice writes as soon as the slices before it know their sizes (its base is their sum): no barrier between the stages, so
-  // the first slice's answers are on their way back while the last slice's messages are still going up.  A slice that failed,
-  // or met a message for the host flattener, publishes "no size": nobody writes after that.
-  std::vector<std::atomic<int>> sized(S);   // 0 not yet, 1 size known, 2 failed
-  for (auto& q : sized) q.store(0);
-  std::atomic<int> overflow{0};
-  auto work = [&](u32 k) {
-    stage1(k);
-    Slice& x = sl[k];
-    sized[k].store(x.rc == 0 ? 1 : 2, std::memory_order_release);
-    if (x.rc != 0) return;
-    size_t base = 0;
-    for (u32 j = 0; j < k; ++j) {
-      int st;
-      while ((st = sized[j].load(std::memory_order_acquire)) == 0) std::this_thread::yield();
-      if (st == 2) return;
-      base += sl[j].total;
-    }
-    x.base = base;
-    if (base + x.total > out_cap) { overflow.store(1); return; }
-    stage2(k);
-  };
-  {
-    std::vector<std::thread> th;
-    for (u32 k = 1; k < S; ++k) th.emplace_back(work, k);
-    work(0);
-    for (auto& q : th) q.join();
-  }
-  auto release = [&] { for (auto& x : sl) if (x.b) { cbh_batch_release(x.b); x.b = nullptr; } };
-  int rc = 0; std::string err;
-  size_t total = 0;
-  for (auto& x : sl) {
-    info->n_tuples += x.wi.n_tuples; info->n_host += x.wi.n_host; info->heap_len += x.wi.heap_len; info->dict_slots += x.wi.dict_slots;
-    info->fill_runs = std::max(info->fill_runs, x.wi.fill_runs); info->n_routes = std::max(info->n_routes, x.wi.n_routes);
-    if (x.wi.first_bad != CBH_NONE && info->first_bad == CBH_NONE) info->first_bad = x.lo + x.wi.first_bad;
-    if (x.rc < 0 && rc >= 0) { rc = x.rc; err = x.err; }
-    else if (x.rc == 1 && rc == 0) { rc = 1; err = x.err; }
-    total += x.total;
-  }
-  release();
-  if (rc != 0) { g_err = err; return rc; }
-  *need = total;
-  if (overflow.load() || total > out_cap) { g_err = "cbh_wire_check_pb: the output buffer is too small"; return 2; }
-  if (n == 0) out_offsets[0] = 0;
-  return 0;
 }
 
 // ---- one-shot path: CheckResources round trip for a host batch ------------------------------------------

@@ -119,7 +119,7 @@ def test_walk_tables_by_input(name, n, env, monkeypatch):
 
 @pytest.mark.parametrize("env", [{}, {"CBH_FLAT_MASKS": "0"}, {"CBH_FLAT_ANY": "1"}, {"CBH_FLAT_ANY": "1", "CBH_FLAT_MASKS": "0"}, {"CBH_FLAT_MASKS": "1"}],
                          ids=["as planned", "staged", "with the evaluator call", "staged with the call", "masks forced"])
-@pytest.mark.parametrize("name,n", [("c2", 300), ("c3", 400), ("c4", 100), ("t", 200)])
+@pytest.mark.parametrize("name,n", [("c2", 300), ("c3", 400), ("c4", 40), ("t", 90)])
 def test_flat_tables_keep_their_trail_in_the_flat_kernels(name, n, env, monkeypatch):
     if name == "c4" and env not in ({}, {"CBH_FLAT_MASKS": "0"}):
         pytest.skip("C4's fifty thousand rules once per walk kind: T covers the other variants")
