@@ -486,6 +486,8 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
   const bool has_rolepol = F_RP && (t.flags & CBH_MF_HAS_ROLE_POLICIES) != 0;
   const bool want_ps = o.policy != nullptr || o.scope != nullptr;
   const bool want_ep = (FEAT & CBH_FEAT_TRAIL) != 0 && (flags & CBH_F_WANT_EFFECTIVE_POLICIES) != 0 && o.eff_pol != nullptr;   // cbh_check_batch_trail
+  u32 ep_last = CBH_NONE;   // the policy this lane marked last (a bucket's records are one policy's: one mark per bucket and role, not per record)
+  auto ep_note = [&](u32 policy) { if (policy != ep_last) { ep_mark(o, b, req, policy); ep_last = policy; } };
 
   Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false; L.pid = pid; L.edr_errmask = 0;
   u64 edr_acc = 0;
@@ -855,7 +857,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                 }
                 // no binding for the resource, or no allow-action matched (index.go:436-461)
                 AM deny = in2 ? (AM)(S & ~any_mask) : (AM)0;
-                if (want_ep && deny != 0) ep_mark(o, b, L.req, rp.z & 0x0FFFFFFFu);   // the synthetic DENY is a binding of the role policy (check.go:302-304)
+                if (want_ep && deny != 0) ep_note(rp.z & 0x0FFFFFFFu);   // the synthetic DENY is a binding of the role policy (check.go:302-304)
                 const u32 site_base = site_ctr;   // trace pass: a visit's place in the walk = its row's place in the bucket
                 AM cond_seen = 0; int cond_r = 0;   // trace pass: actions a key-sharing conditional rule was evaluated for, and what it gave
                 // (trace pass: the output-only rules that share a key come last, when every conditional rule has been seen;
@@ -876,7 +878,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
                     mm &= S & ~deny;
                   }
                   if (wave_ballot(mm != 0) == 0) continue;
-                  if (want_ep && mm != 0) ep_mark(o, b, L.req, rp.z & 0x0FFFFFFFu);
+                  if (want_ep && mm != 0) ep_note(rp.z & 0x0FFFFFFFu);
                   const bool shares = (rr.allow_cnt & CBH_RP_F_SHARES_KEY) != 0;
                   // an action at or behind the first one an output-only rule of the same key is visited for finds
                   // "satisfied" cached (check.go:324): the synthetic DENY would fire whatever the condition says
@@ -964,7 +966,7 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
               DBG2_ACC(dbg_c);
               if (wave_ballot(need != 0) == 0) continue;
               const bool m = need != 0;
-              if (want_ep && m) ep_mark(o, b, L.req, rw.policy);   // the binding is iterated: its policy set is in effect (check.go:302-304)
+              if (want_ep && m) ep_note(rw.policy);   // the binding is iterated: its policy set is in effect (check.go:302-304)
               // A request meets the same record once per role it holds; its conditions read only the
               // request (and this scope's derived roles), so the first outcome is kept per lane for the
               // first 64 records of the walk and replayed - including the error status - afterwards.
