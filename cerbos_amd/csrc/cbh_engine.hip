@@ -1320,8 +1320,11 @@ static int wire_check_sliced(cbh_table* t, uint32_t device_index, const uint8_t*
   info->first_bad = CBH_NONE; info->n_requests = rm ? 0u : n;
   *need = 0;
   static const u32 max_slices = [] { const char* e = getenv("CBH_WIRE_SLICES"); const long v = e ? atol(e) : 4; return (u32)std::min<long>(std::max<long>(v, 1), 8); }();
-  // (requests: by their bytes - a request holds any number of resource entries -, about 4 MB to a slice)
-  const u32 S = std::max<u32>(1u, std::min<u32>(max_slices, rm ? (u32)std::min<u64>(n, (n ? offsets[n] : 0) >> 22) : n / 16384u));
+  // (requests: by their bytes - a request holds any number of resource entries -, about 4 MB to a slice.  CBH_WIRE_SLICE_MIN /
+  // CBH_WIRE_SLICE_MIN_BYTES: the smallest slice, for tests and measurements)
+  static const u32 slice_min = [] { const char* e = getenv("CBH_WIRE_SLICE_MIN"); const long v = e ? atol(e) : 16384; return (u32)std::max<long>(v, 1); }();
+  static const u64 slice_min_bytes = [] { const char* e = getenv("CBH_WIRE_SLICE_MIN_BYTES"); const long long v = e ? atoll(e) : (1ll << 22); return (u64)std::max<long long>(v, 1); }();
+  const u32 S = std::max<u32>(1u, std::min<u32>(max_slices, rm ? (u32)std::min<u64>(n, (n ? offsets[n] : 0) / slice_min_bytes) : n / slice_min));
   const u32 words = (t->wire.n_policies + 31u) / 32u;
   struct Slice {
     u32 lo = 0, hi = 0; cbh_device_batch* b = nullptr; cbh_wire_info wi{}; size_t total = 0, base = 0; int rc = 0; std::string err;

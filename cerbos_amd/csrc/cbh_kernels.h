@@ -61,13 +61,17 @@ __device__ __forceinline__ u32 chain_first(const TableDev& t, u32 raw, u32 flagb
   return chain_next(t, si, flagbit);
 }
 
-#ifndef CBH_HOSTSIM
+#if !defined(CBH_HOSTSIM) || defined(CBH_HOSTSIM_ENGINE)   /* (the kernel simulation gets the glob bits from its caller; the engine's does not) */
 // --- glob NFA ----------------------------------------------------------------------------
 #ifndef NFA_MAXW
 #define NFA_MAXW 8
 #endif
 __global__ __launch_bounds__(CBH_BLOCK) void cbh_resolve_globs_kernel(TableDev t, BatchDev b) {
+#ifdef CBH_HOSTSIM
+  static unsigned char smem[(2 + 512) * NFA_MAXW * 8];
+#else
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#endif
   u64* lds = reinterpret_cast<u64*>(smem);
   const u32 i = blockIdx.x * CBH_BLOCK + threadIdx.x;
   for (u32 dim = 0; dim < 3; ++dim) {
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_resolve_globs_kernel(TableDev t
   }
 }
 
-#endif  // CBH_HOSTSIM
+#endif  // CBH_HOSTSIM (kernel simulation)
 
 #include "cbh_check_wave.h"
 #include "cbh_check_flat.h"

@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_gather_kernel(WireRouteArg
   for (u32 c = 0; c < a.n_cols; ++c) { a.col_tag_out[(size_t)c * N + pos] = a.col_tag[(size_t)c * N + i]; a.col_val_out[(size_t)c * N + pos] = a.col_val[(size_t)c * N + i]; }
 }
 
-#ifndef CBH_HOSTSIM
+#if !defined(CBH_HOSTSIM) || defined(CBH_HOSTSIM_ENGINE)
 // derived-role masks back in input order (cbh_result_download of a grouped batch).  (Arguments in a struct, as everywhere here: a
 // kernel whose SIGNATURE carries address-space qualified pointers has one mangled name in the device pass and another on the host.)
 struct WireUnsortArgs { const CBH_G u64* edr_grouped; const CBH_G u32* inv; CBH_G u64* edr_input; u32 n; u32 pad; };

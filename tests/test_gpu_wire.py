@@ -114,7 +114,7 @@ def test_evaluator_bytes_path_takes_the_device_road():
 
 
 @pytest.mark.timeout(300)
-def test_the_road_in_one_call_gives_the_three_calls_bytes():
+def test_the_road_in_one_call_gives_the_three_calls_bytes(total=70_000):
     """cbh_wire_check_pb (the device road in one call, cut into slices that run side by side) against cbh_wire_flatten +
     cbh_check_resident + cbh_wire_outputs: the same bytes, offsets and flags - at a size that takes four slices, at sizes that
     take one, with an output buffer that is too small at first, and a message for the host flattener in the third slice."""
@@ -125,10 +125,10 @@ def test_the_road_in_one_call_gives_the_three_calls_bytes():
     for pol_fn, req_fn in ((workloads.c5_policies, workloads.c5_requests), (workloads.c3_policies, workloads.c3_requests)):
         lt = lower_rule_table(rule_table_from_policies(policies_from_docs(pol_fn())))
         table = capi.Table(lt.blob)
-        inputs = req_fn(70_000).to_inputs()
+        inputs = req_fn(total).to_inputs()
         msgs = [wire.encode_check_input(i) for i in inputs]
         flags = capi.F_WANT_DERIVED_ROLES
-        for n in (70_000, 20_000, 130, 1, 0):
+        for n in (total, total * 2 // 7, 130, 1, 0):
             data, off = wire.pack_messages(msgs[:n])
             db = table.wire_flatten(data, off)
             table.launch(db, now_ns=NOW, flags=flags)
@@ -137,8 +137,9 @@ def test_the_road_in_one_call_gives_the_three_calls_bytes():
             got, gflags = table.wire_check_pb(data, off, now_ns=NOW, flags=flags)
             assert got == want and list(gflags) == list(wflags), (n, len(got))
         # a buffer that is too small at first: the binding grows it from `need`
-        data, off = wire.pack_messages(msgs[:40_000])
-        small = (np.empty(1000, dtype=np.uint8), np.empty(40_001, dtype=np.uint64), np.empty(40_000, dtype=np.uint8))
+        part = total * 4 // 7
+        data, off = wire.pack_messages(msgs[:part])
+        small = (np.empty(1000, dtype=np.uint8), np.empty(part + 1, dtype=np.uint64), np.empty(part, dtype=np.uint8))
         got, _ = table.wire_check_pb(data, off, now_ns=NOW, flags=flags, out=small)
         db = table.wire_flatten(data, off)
         table.launch(db, now_ns=NOW, flags=flags)
@@ -146,8 +147,9 @@ def test_the_road_in_one_call_gives_the_three_calls_bytes():
         db.close()
         assert got == want
         # a CheckInput with more than 64 actions is the host flattener's: the whole call says so
-        big = dict(inputs[50_000], actions=["a%d" % i for i in range(70)])
-        data, off = wire.pack_messages(msgs[:50_000] + [wire.encode_check_input(big)] + msgs[50_001:])
+        at = total * 5 // 7   # (in the third of four slices)
+        big = dict(inputs[at], actions=["a%d" % i for i in range(70)])
+        data, off = wire.pack_messages(msgs[:at] + [wire.encode_check_input(big)] + msgs[at + 1:])
         with pytest.raises(capi.HostFlattenerNeeded):
             table.wire_check_pb(data, off, now_ns=NOW, flags=flags)
         table.close()

@@ -1,0 +1,115 @@
+"""CPU tier: the library's HOST side on the simulator (tests/sim_engine.py) - the bodies of the GPU tier's last-sorting tests, at
+sizes a fiber scheduler finishes, through the same C ABI: what round 4 wrote after its GPU minutes were spent (request road in
+slices, the audit trail's entry points, the resident trail) has at least run end to end before it meets the hardware."""
+import pytest
+
+from sim_engine import sim_engine
+
+
+@pytest.fixture()
+def engine():
+    with sim_engine() as capi:
+        yield capi
+
+
+def test_request_road_service_cases(engine):
+    import test_zz_gpu_request_road as t
+    t.test_service_level_cases_requests_in_outputs_out()
+    t.test_a_malformed_request_is_named()
+
+
+@pytest.mark.parametrize("name,n", [("C2", 700), ("C5", 500)])
+def test_request_road_bytes(engine, name, n):
+    import test_zz_gpu_request_road as t
+    t.test_requests_give_the_bytes_their_check_inputs_give(name, n)
+
+
+def test_request_road_audit_trail_golden_store(engine):
+    import test_zz_gpu_request_road as t
+    t.test_the_audit_trail_of_every_request_golden_store()
+
+
+@pytest.mark.parametrize("name,n", [("C2", 600), ("C5", 400)])
+def test_request_road_audit_trail_at_size(engine, name, n):
+    import test_zz_gpu_request_road as t
+    t.test_the_audit_trail_of_every_request_at_size(name, n)
+
+
+def test_trail_decision_logs_and_oracle(engine):
+    import test_zz_gpu_effective_policies as t
+    t.test_the_reference_s_decision_logs_and_the_oracle_by_input()
+    t.test_fuzz_stores_by_input(1)
+
+
+def test_trail_c5_groups_and_resident_batch(engine):
+    import test_zz_gpu_effective_policies as t
+    t.test_c5_at_size_groups_and_decisions(n=1_400)
+    t.test_a_resident_batch_keeps_its_trail_across_launches(n=900)
+
+
+@pytest.mark.parametrize("name,n", [("c2", 500), ("c3", 500), ("t", 150)])
+def test_trail_flat_tables(engine, name, n):
+    import test_zz_gpu_effective_policies as t
+    t.test_flat_tables_keep_their_trail_in_the_flat_kernels(name, n)
+
+
+@pytest.mark.parametrize("name,n", [("c5", 400), ("c5w", 300)])
+def test_trail_walk_tables(engine, name, n):
+    import test_zz_gpu_effective_policies as t
+    t.test_walk_tables_by_input(name, n)
+
+
+def _in_own_process(body, env):
+    """Switches the library reads once (static) need a process of their own."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path[:0] = [%r, %r]\nfrom sim_engine import sim_engine\nwith sim_engine() as capi:\n" % (here, os.path.dirname(here))
+            + "".join("    " + line + "\n" for line in body.strip().splitlines()) + "print('sim ok')\n")
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "sim ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_the_roads_in_slices():
+    """Four slices side by side (threads, chained uploads, bases from the slices' sizes): the input road's own GPU test at a
+    fiftieth of its size, and the request road - with and without the trail - against the input road."""
+    _in_own_process('''
+import test_gpu_wire as w
+w.test_the_road_in_one_call_gives_the_three_calls_bytes(total=1_400)
+import test_zz_gpu_request_road as t
+t.test_requests_give_the_bytes_their_check_inputs_give("C2", 1_500)
+t.test_requests_give_the_bytes_their_check_inputs_give("C5", 1_200)
+t.test_the_audit_trail_of_every_request_at_size("C5", 1_200)
+t.test_the_audit_trail_of_every_request_golden_store()
+''', {"CBH_WIRE_SLICE_MIN": "200", "CBH_WIRE_SLICE_MIN_BYTES": "20000"})
+
+
+def test_the_pre_pass_in_two_kernels_through_the_library():
+    """CBH_PRE_SPLIT=1 on the library's side (the site lists live with the batch): C5 decisions equal to the fused pre-pass's."""
+    body = '''
+import numpy as np
+from cerbos_amd import workloads
+from cerbos_amd.flatten import Flattener
+from cerbos_amd.lower.blob import lower_rule_table
+from cerbos_amd.policy.loader import policies_from_docs
+from cerbos_amd.ruletable.build import rule_table_from_policies
+lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c5_policies())))
+batch = Flattener(lt).flatten(workloads.c5_requests(n_requests=900).to_inputs(), "default", "")
+table = capi.Table(lt.blob)
+res = table.check(batch, now_ns=1_700_000_000_000_000_000, flags=capi.F_WANT_DERIVED_ROLES)
+db = table.upload(batch)
+for _ in range(2):
+    table.launch(db, now_ns=1_700_000_000_000_000_000, flags=capi.F_WANT_DERIVED_ROLES)
+r2 = table.download(db)
+assert np.array_equal(res.effect, r2.effect) and np.array_equal(res.policy, r2.policy) and np.array_equal(res.status, r2.status)
+np.save(OUT, np.concatenate([res.effect.astype(np.uint32), res.policy, res.status.astype(np.uint32)]))
+'''
+    import os
+    import tempfile
+
+    import numpy as np
+    with tempfile.TemporaryDirectory() as d:
+        for mode in ("0", "1"):
+            _in_own_process("OUT = %r\n" % os.path.join(d, "m%s.npy" % mode) + body, {"CBH_PRE_SPLIT": mode})
+        assert np.array_equal(np.load(os.path.join(d, "m0.npy")), np.load(os.path.join(d, "m1.npy")))

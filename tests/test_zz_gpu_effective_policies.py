@@ -51,10 +51,9 @@ def test_fuzz_stores_by_input(seed):
         ev.close()
 
 
-def test_c5_at_size_groups_and_decisions():
+def test_c5_at_size_groups_and_decisions(n=20_000):
     rt = rule_table_from_policies(policies_from_docs(workloads.c5_policies()))
     lt = lower_rule_table(rt)
-    n = 20_000
     inputs = workloads.c5_requests(n_requests=n).to_inputs()
     batch = Flattener(lt).flatten(inputs, "default", "")
     pre = np.arange(batch.n_requests) if batch.req_perm is None else np.asarray(batch.req_perm)
@@ -121,12 +120,12 @@ def test_walk_tables_by_input(name, n):
         ev.close()
 
 
-def test_a_resident_batch_keeps_its_trail_across_launches():
+def test_a_resident_batch_keeps_its_trail_across_launches(n=5_000):
     """cbh_batch_set_trail / cbh_trail_download: the masks of a resident batch are what cbh_check_batch_trail returns for it, launch
     after launch (OR-ed: the same), cleared by the next cbh_batch_set_trail; the trail kernels are the ones the plan names."""
     rt = rule_table_from_policies(policies_from_docs(workloads.c5_policies()))
     lt = lower_rule_table(rt)
-    inputs = workloads.c5_requests(n_requests=5_000).to_inputs()
+    inputs = workloads.c5_requests(n_requests=n).to_inputs()
     batch = Flattener(lt).flatten(inputs, "default", "")
     groups = (np.arange(batch.n_requests) % 11).astype(np.uint32)
     table = capi.Table(lt.blob)
