@@ -162,9 +162,12 @@ struct hipPointerAttribute_t { int type; int device; void* devicePointer; void* 
 
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "engine sim"; }
-static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-static inline hipError_t hipSetDevice(int) { return hipSuccess; }
-static inline hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 0; return hipSuccess; }
+// CBH_SIM_DEVICES=<n>: the simulated node has n "devices" (they share the one memory; what is exercised is the library's
+// bookkeeping per replica - broadcast of the image by peer copies, request ranges per device, streams and pools per replica)
+static inline int hs_devices() { static const int n = [] { const char* e = getenv("CBH_SIM_DEVICES"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }(); return n; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = hs_devices(); return hipSuccess; }
+static inline hipError_t hipSetDevice(int d) { return d >= 0 && d < hs_devices() ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = hs_devices() > 1; return hipSuccess; }
 static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 static inline hipError_t hs_alloc(void** p, size_t n) {
   const size_t cap = (n + 255) & ~(size_t)255;
@@ -176,10 +179,25 @@ static inline hipError_t hs_alloc(void** p, size_t n) {
 }
 template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { return hs_alloc(reinterpret_cast<void**>(p), n); }
 static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
-template <class T> static inline hipError_t hipHostMalloc(T** p, size_t n, unsigned = 0) { return hs_alloc(reinterpret_cast<void**>(p), n); }
-static inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+// page-locked blocks are remembered: hipPointerGetAttributes tells them from pageable memory, as the library's one-shot path asks
+inline std::vector<std::pair<const char*, size_t>>& hs_pinned() { static std::vector<std::pair<const char*, size_t>> v; return v; }
+template <class T> static inline hipError_t hipHostMalloc(T** p, size_t n, unsigned = 0) {
+  const hipError_t e = hs_alloc(reinterpret_cast<void**>(p), n);
+  if (e == hipSuccess) { std::lock_guard<std::recursive_mutex> lk(hs::mu()); hs_pinned().emplace_back(reinterpret_cast<const char*>(*p), n ? n : 1); }
+  return e;
+}
+static inline hipError_t hipHostFree(void* p) {
+  { std::lock_guard<std::recursive_mutex> lk(hs::mu()); auto& v = hs_pinned(); for (size_t i = 0; i < v.size(); ++i) if (v[i].first == p) { v[i] = v.back(); v.pop_back(); break; } }
+  std::free(p);
+  return hipSuccess;
+}
 template <class T> static inline hipError_t hipHostGetDevicePointer(T** d, void* h, unsigned) { *d = static_cast<T*>(h); return hipSuccess; }
-static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void*) { a->type = 0; return hipErrorInvalidValue; }   // "pageable"
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
+  std::lock_guard<std::recursive_mutex> lk(hs::mu());
+  for (auto& b : hs_pinned()) if (static_cast<const char*>(p) >= b.first && static_cast<const char*>(p) < b.first + b.second) { a->type = hipMemoryTypeHost; return hipSuccess; }
+  a->type = 0;
+  return hipErrorInvalidValue;   // pageable memory: the runtime does not know the pointer
+}
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) std::memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) {
   std::lock_guard<std::recursive_mutex> lk(hs::mu());   // (kernels run under the same lock: a copy never lands in the middle of one)

@@ -113,3 +113,52 @@ np.save(OUT, np.concatenate([res.effect.astype(np.uint32), res.policy, res.statu
         for mode in ("0", "1"):
             _in_own_process("OUT = %r\n" % os.path.join(d, "m%s.npy" % mode) + body, {"CBH_PRE_SPLIT": mode})
         assert np.array_equal(np.load(os.path.join(d, "m0.npy")), np.load(os.path.join(d, "m1.npy")))
+
+
+def test_four_simulated_devices():
+    """The library's bookkeeping per replica on a simulated node of four devices (CBH_SIM_DEVICES: they share the one memory):
+    the image broadcast by peer copies, a large batch cut into one request range per device with every result at the caller's
+    offsets (engine.go:332) - pageable and page-locked -, resident batches and the wire road on any replica.  (The RCCL branch
+    needs real devices: tests/test_gpu_engine.py on a multi-GPU node.)"""
+    _in_own_process('''
+import numpy as np
+from cerbos_amd import wire, workloads
+from cerbos_amd.flatten import Flattener
+from cerbos_amd.lower.blob import lower_rule_table
+from cerbos_amd.policy.loader import policies_from_docs
+from cerbos_amd.ruletable.build import rule_table_from_policies
+NOW = 1_700_000_000_000_000_000
+capi.init(0)
+lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c3_policies())))
+cr = workloads.c3_requests(60_000)
+batch = cr.to_batch(Flattener(lt))
+flags = capi.F_WANT_DERIVED_ROLES
+one = capi.Table(lt.blob)
+want = one.check(batch, now_ns=NOW, flags=flags)
+one.close()
+capi.init([0, 1, 2, 3])
+assert capi.num_devices() == 4
+table = capi.Table(lt.blob)
+assert table.broadcast_kind() == "peer-copy"
+def same(a, b, what):
+    for f in ("effect", "policy", "scope", "status", "edr"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), (what, f)
+same(want, table.check(batch, now_ns=NOW, flags=flags), "sharded, pageable")
+capi.pin_batch(batch)
+same(want, table.check(batch, now_ns=NOW, flags=flags, pinned=True), "sharded, page-locked")
+for dev in (1, 3):
+    db = table.upload(batch, device_index=dev)
+    table.launch(db, now_ns=NOW, flags=flags)
+    same(want, table.download(db), "resident on replica %d" % dev)
+    db.close()
+inputs = cr.head(3_000).to_inputs()
+data, off = wire.pack_messages([wire.encode_check_input(i) for i in inputs])
+outs = []
+for dev in (0, 2):
+    db = table.wire_flatten(data, off, device_index=dev)
+    table.launch(db, now_ns=NOW, flags=flags)
+    outs.append(table.wire_outputs(db)[0])
+    db.close()
+assert outs[0] == outs[1] and len(outs[0]) == 3_000
+table.close()
+''', {"CBH_SIM_DEVICES": "4", "CBH_BCAST": "peer"})
