@@ -16,6 +16,8 @@ LIB = os.path.join(OUT_DIR, "libcerbos_hip_sim.so")
 
 
 def build():
+    if os.environ.get("CBH_TEST_SIM_LIB"):      # a variant built by hand (e.g. -fsanitize=address: tools/sim_engine_asan.sh)
+        return os.environ["CBH_TEST_SIM_LIB"]
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
     deps += [os.path.join(FAKE, "hip", f) for f in os.listdir(os.path.join(FAKE, "hip"))] + [os.path.join(ROOT, "include", "cerbos_hip.h")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):

@@ -166,10 +166,13 @@ def test_versioned_swap_under_load():
     mgr = TableManager(lts[0])
     stop, errors, seen = threading.Event(), [], set()
 
+    done = [0]
+
     def worker():
         while not stop.is_set():
             ver, _, _, res = mgr.check_batch(inputs, now_ns=NOW)
             seen.add(ver)
+            done[0] += 1
             if not np.array_equal(res.effect, want[(ver - 1) % 2]):
                 errors.append(ver)
 
@@ -178,11 +181,15 @@ def test_versioned_swap_under_load():
         x.start()
     from cerbos_amd.ruletable.proto import encode_rule_table
     wires = [encode_rule_table(rt) for rt in rts]   # the reference's artefact: serialized runtimev1.RuleTable
+    import time
     for k in range(1, 9):
         if k % 3 == 0:
             mgr.swap(lts[k % 2])
         else:
             mgr.swap_pb(wires[k % 2])
+        mark, t0 = done[0], time.time()          # (some answers under every version, however slow the machine)
+        while done[0] < mark + 2 and time.time() - t0 < 120:
+            time.sleep(0.001)
     stop.set()
     for x in th:
         x.join()
