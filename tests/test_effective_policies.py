@@ -121,8 +121,10 @@ def test_walk_tables_by_input(name, n, env, monkeypatch):
                          ids=["as planned", "staged", "with the evaluator call", "staged with the call", "masks forced"])
 @pytest.mark.parametrize("name,n", [("c2", 300), ("c3", 400), ("c4", 40), ("t", 90)])
 def test_flat_tables_keep_their_trail_in_the_flat_kernels(name, n, env, monkeypatch):
-    if name == "c4" and env not in ({}, {"CBH_FLAT_MASKS": "0"}):
-        pytest.skip("C4's fifty thousand rules once per walk kind: T covers the other variants")
+    if name == "c4" and env != {}:
+        pytest.skip("C4's fifty thousand rules once, as planned (the mask walk): T covers the other variants")
+    if name == "t" and env == {"CBH_FLAT_ANY": "1", "CBH_FLAT_MASKS": "0"}:
+        pytest.skip("the staged walk with the evaluator call: C2 and C3 cover it")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     rt = rule_table_from_policies(policies_from_docs(getattr(workloads, name + "_policies")()))
