@@ -89,4 +89,5 @@ for name in ("check_batch", "check_batch_trail"):
     print("%s %s: %.3f ms for %d tuples  %.1f M decisions/s (PCIe-inclusive, pageable arrays)" % (W, name, best * 1e3, batch.n_tuples, batch.n_tuples / best / 1e6))
 assert np.array_equal(res.effect, res2.effect) and np.array_equal(res.policy, res2.policy)
 from cerbos_amd.engine import effective_policy_keys
-print("effective policies of the batch:", effective_policy_keys(lt.policy_keys, masks[0]))
+keys = effective_policy_keys(lt.policy_keys, masks[0])
+print("effective policies of the batch: %d, e.g. %s" % (len(keys), keys[:4]))
