@@ -162,3 +162,9 @@ for dev in (0, 2):
 assert outs[0] == outs[1] and len(outs[0]) == 3_000
 table.close()
 ''', {"CBH_SIM_DEVICES": "4", "CBH_BCAST": "peer"})
+
+
+def test_smoke_body(engine):
+    """__graft_entry__.smoke() - what the driver runs first on the GPU box - against the simulator build."""
+    import __graft_entry__ as g
+    g.smoke()
