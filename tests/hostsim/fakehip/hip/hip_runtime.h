@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE ONLY - never part of the product, never on the product's include path.
 //
 // A stand-in for <hip/hip_runtime.h> that lets cerbos_amd/csrc/cbh_engine.hip - the library's HOST side: pools, streams, slices,
-// the launches of every entry point - be compiled as plain C++ and run without a GPU (tests/hostsim/build_engine_sim.sh ->
+// the launches of every entry point - be compiled as plain C++ and run without a GPU (tests/sim_engine.py build() ->
 // tests/hostsim/_build/libcerbos_hip_sim.so).  Device memory is host memory (filled with a pattern: nothing may rely on zeroes), copies
 // are memcpy, streams and events are tokens, and a kernel launch runs the kernel's source on the fiber scheduler of
 // tests/hostsim/hostsim.cpp (one workgroup = its lanes as ucontext fibers, wave primitives and __syncthreads() as rendezvous),
