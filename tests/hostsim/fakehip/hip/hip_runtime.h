@@ -169,7 +169,18 @@ static inline hipError_t hipGetDeviceCount(int* n) { *n = hs_devices(); return h
 static inline hipError_t hipSetDevice(int d) { return d >= 0 && d < hs_devices() ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = hs_devices() > 1; return hipSuccess; }
 static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+// fault injection (tests/test_sim_engine.py): after `n` more successful allocations every further one fails, until the budget is reset
+// (-1 = never).  What is under test is the library's way out: an error code and its message, nothing leaked into the next call, no
+// thread left waiting for a slice that gave up.
+inline long& hs_alloc_budget() { static long b = -1; return b; }
+extern "C" __attribute__((visibility("default"))) void cbh_sim_set_alloc_budget(long n) { std::lock_guard<std::recursive_mutex> lk(hs::mu()); hs_alloc_budget() = n; }
 static inline hipError_t hs_alloc(void** p, size_t n) {
+  {
+    std::lock_guard<std::recursive_mutex> lk(hs::mu());
+    long& b = hs_alloc_budget();
+    if (b == 0) { *p = nullptr; return hipErrorInvalidValue; }
+    if (b > 0) --b;
+  }
   const size_t cap = (n + 255) & ~(size_t)255;
   void* q = nullptr;
   if (posix_memalign(&q, 256, cap ? cap : 256) != 0) return hipErrorInvalidValue;

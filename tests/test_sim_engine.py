@@ -168,3 +168,63 @@ def test_smoke_body(engine):
     """__graft_entry__.smoke() - what the driver runs first on the GPU box - against the simulator build."""
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_allocation_failures_are_survived():
+    """Fault injection on the simulator build: the k-th device / page-locked allocation from now on fails, for k = 0 .. - in the middle of
+    a table load, a one-shot check, the sliced request road with its threads and chained uploads.  Every call then either succeeds or
+    returns an error with a message; none hangs (a slice that gives up must release the ones waiting on it), and the next call with
+    allocations allowed again answers as if nothing had happened."""
+    _in_own_process('''
+import ctypes as C
+import numpy as np
+from cerbos_amd import wire, workloads
+from cerbos_amd.flatten import Flattener
+from cerbos_amd.lower.blob import lower_rule_table
+from cerbos_amd.policy.loader import policies_from_docs
+from cerbos_amd.ruletable.build import rule_table_from_policies
+NOW = 1_700_000_000_000_000_000
+lib = capi.load()
+lib.cbh_sim_set_alloc_budget.argtypes = [C.c_long]
+lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c5_policies())))
+inputs = workloads.c5_requests(n_requests=360).to_inputs()
+batch = Flattener(lt).flatten(inputs, "default", "")
+groups = [inputs[k:k + 6] for k in range(0, len(inputs), 6)]
+reqs = [wire.encode_check_resources_request({"requestId": "r", "principal": g[0]["principal"],
+                                             "resources": [{"actions": i["actions"], "resource": i["resource"]} for i in g]}) for g in groups]
+table = capi.Table(lt.blob)
+flags = capi.F_WANT_DERIVED_ROLES
+want = table.check(batch, now_ns=NOW, flags=flags)
+want_road = table.wire_check_requests_pb(reqs, now_ns=NOW, flags=flags, trail=True)
+failed = survived = 0
+for what, ks in (("load", range(0, 12)), ("check", range(0, 14, 2)), ("road", range(0, 56, 5))):
+    for k in ks:
+        fresh = None if what == "load" else capi.Table(lt.blob)     # (a fresh table: empty pools, every buffer a real allocation)
+        lib.cbh_sim_set_alloc_budget(k)
+        try:
+            if what == "load":
+                capi.Table(lt.blob).close()
+            elif what == "check":
+                got = fresh.check(batch, now_ns=NOW, flags=flags)
+                assert np.array_equal(got.effect, want.effect)
+            else:
+                got = fresh.wire_check_requests_pb(reqs, now_ns=NOW, flags=flags, trail=True)
+                assert got[0] == want_road[0] and np.array_equal(got[3], want_road[3])
+            survived += 1
+        except capi.HipEngineError as e:
+            assert str(e), "an error without a message"
+            failed += 1
+        finally:
+            lib.cbh_sim_set_alloc_budget(-1)
+        for t in (fresh, table):                                      # allocations allowed again: as if nothing had happened
+            if t is not None:
+                again = t.check(batch, now_ns=NOW, flags=flags)
+                assert np.array_equal(again.effect, want.effect) and np.array_equal(again.policy, want.policy)
+        if fresh is not None:
+            road = fresh.wire_check_requests_pb(reqs, now_ns=NOW, flags=flags, trail=True)
+            assert road[0] == want_road[0] and np.array_equal(road[3], want_road[3])
+            fresh.close()
+assert failed > 15 and survived >= 2, (failed, survived)
+print("allocation failures survived: %d calls failed cleanly, %d had enough" % (failed, survived))
+table.close()
+''', {"CBH_WIRE_SLICE_MIN_BYTES": "20000"})
