@@ -210,8 +210,14 @@ static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const
   return hipErrorInvalidValue;   // pageable memory: the runtime does not know the pointer
 }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) std::memmove(d, s, n); return hipSuccess; }
+// ... and the same for asynchronous copies (a failed copy moves nothing)
+inline long& hs_copy_budget() { static long b = -1; return b; }
+extern "C" __attribute__((visibility("default"))) void cbh_sim_set_copy_budget(long n) { std::lock_guard<std::recursive_mutex> lk(hs::mu()); hs_copy_budget() = n; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) {
   std::lock_guard<std::recursive_mutex> lk(hs::mu());   // (kernels run under the same lock: a copy never lands in the middle of one)
+  long& b = hs_copy_budget();
+  if (b == 0) return hipErrorInvalidValue;
+  if (b > 0) --b;
   if (n) std::memmove(d, s, n);
   return hipSuccess;
 }

@@ -170,9 +170,9 @@ def test_smoke_body(engine):
     g.smoke()
 
 
-def test_allocation_failures_are_survived():
-    """Fault injection on the simulator build: the k-th device / page-locked allocation from now on fails, for k = 0 .. - in the middle of
-    a table load, a one-shot check, the sliced request road with its threads and chained uploads.  Every call then either succeeds or
+def test_failing_allocations_and_copies_are_survived():
+    """Fault injection on the simulator build: the k-th device / page-locked allocation (or asynchronous copy) from now on fails, for
+    k = 0 .. - in the middle of a table load, a one-shot check, the sliced request road with its threads and chained uploads.  Every call then either succeeds or
     returns an error with a message; none hangs (a slice that gives up must release the ones waiting on it), and the next call with
     allocations allowed again answers as if nothing had happened."""
     _in_own_process('''
@@ -196,11 +196,15 @@ table = capi.Table(lt.blob)
 flags = capi.F_WANT_DERIVED_ROLES
 want = table.check(batch, now_ns=NOW, flags=flags)
 want_road = table.wire_check_requests_pb(reqs, now_ns=NOW, flags=flags, trail=True)
+lib.cbh_sim_set_copy_budget.argtypes = [C.c_long]
 failed = survived = 0
-for what, ks in (("load", range(0, 12)), ("check", range(0, 14, 2)), ("road", range(0, 56, 5))):
+for what, ks in (("load", range(0, 12)), ("check", range(0, 14, 2)), ("road", range(0, 56, 5)), ("road, copies", range(0, 40, 3))):
     for k in ks:
         fresh = None if what == "load" else capi.Table(lt.blob)     # (a fresh table: empty pools, every buffer a real allocation)
-        lib.cbh_sim_set_alloc_budget(k)
+        if what == "road, copies":
+            lib.cbh_sim_set_copy_budget(k)                           # the k-th asynchronous copy from now on fails
+        else:
+            lib.cbh_sim_set_alloc_budget(k)
         try:
             if what == "load":
                 capi.Table(lt.blob).close()
@@ -216,6 +220,7 @@ for what, ks in (("load", range(0, 12)), ("check", range(0, 14, 2)), ("road", ra
             failed += 1
         finally:
             lib.cbh_sim_set_alloc_budget(-1)
+            lib.cbh_sim_set_copy_budget(-1)
         for t in (fresh, table):                                      # allocations allowed again: as if nothing had happened
             if t is not None:
                 again = t.check(batch, now_ns=NOW, flags=flags)
