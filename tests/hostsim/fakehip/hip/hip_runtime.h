@@ -184,7 +184,8 @@ static inline hipError_t hs_alloc(void** p, size_t n) {
   const size_t cap = (n + 255) & ~(size_t)255;
   void* q = nullptr;
   if (posix_memalign(&q, 256, cap ? cap : 256) != 0) return hipErrorInvalidValue;
-  std::memset(q, 0xA5, cap ? cap : 256);   // device memory is not zeroed
+  static const int fill = [] { const char* e = getenv("CBH_SIM_FILL"); return e ? (int)strtol(e, nullptr, 0) & 0xFF : 0xA5; }();
+  std::memset(q, fill, cap ? cap : 256);   // device memory is not zeroed (CBH_SIM_FILL=0x00 / 0xFF: other garbage, same answers expected)
   *p = q;
   return hipSuccess;
 }
