@@ -1109,7 +1109,10 @@ __device__ __forceinline__ void check_body(const KernelArgs& ka_regs, Ctx& c) {
 #ifndef CBH_HOSTSIM
 extern __shared__ __attribute__((aligned(16))) unsigned char cbh_dyn_lds[];
 #else
-static unsigned char cbh_dyn_lds[CBH_CACHE_COLS * CBH_BLOCK * 12 + CBH_ARENA_ENTRIES * CBH_BLOCK * 9 + 16 * CBH_BLOCK * 4 + 8 * CBH_BLOCK * 4 + 16 * CBH_BLOCK * 8 + 16 * CBH_BLOCK * 8 + 3 * 4096 + 4 * 1024 + 32 + 2560 + 16 * CBH_BLOCK * 8];   // + the flat / walk2 kernels' chain scratch, per-action notes, site results, class tables, the trail's touches
+#ifndef CBH_HOSTSIM_LDS_WAVES
+#define CBH_HOSTSIM_LDS_WAVES 1   /* (the engine simulation's four-wave build: 4) */
+#endif
+static unsigned char cbh_dyn_lds[(CBH_HOSTSIM_LDS_WAVES) * (CBH_CACHE_COLS * CBH_BLOCK * 12 + CBH_ARENA_ENTRIES * CBH_BLOCK * 9 + 16 * CBH_BLOCK * 4 + 8 * CBH_BLOCK * 4 + 16 * CBH_BLOCK * 8 + 16 * CBH_BLOCK * 8 + 3 * 4096 + 4 * 1024 + 32 + 2560 + 16 * CBH_BLOCK * 8)];   // + the flat / walk2 kernels' chain scratch, per-action notes, site results, class tables, the trail's touches
 #endif
 __device__ __forceinline__ u32 cached_columns(const KernelArgs* ka) {
   const u32 n = ka->b.n_columns;

@@ -254,5 +254,19 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, co
   return hipSuccess;
 }
 
-#define hipLaunchKernelGGL(fn, grid, block, lds, stream, ...) hs::launch((grid), (block), [=]() { fn(__VA_ARGS__); })
-#define hipExtLaunchKernelGGL(fn, grid, block, lds, stream, ev0, ev1, flags, ...) hs::launch((grid), (block), [=]() { fn(__VA_ARGS__); })
+// The kernels' dynamic LDS is one static array here (cbh_check_wave.h cbh_dyn_lds), larger than any launch asks for; the bytes BEHIND
+// what a launch asked for are painted before it and looked at after it: a kernel that writes beyond the size the host computed - on
+// the GPU such a write is dropped, or lands in a neighbour's LDS - aborts the test.
+namespace hs {
+template <class F>
+inline void launch_checked(dim3 grid, dim3 block, size_t lds, unsigned char* dyn, size_t dyn_bytes, const char* name, F&& f) {
+  std::lock_guard<std::recursive_mutex> lk(mu());
+  if (lds > dyn_bytes) { std::fprintf(stderr, "engine sim: %s asks for %zu bytes of dynamic LDS, the simulation holds %zu\n", name, lds, dyn_bytes); std::abort(); }
+  std::memset(dyn + lds, 0xC3, dyn_bytes - lds);
+  launch(grid, block, f);
+  for (size_t i = lds; i < dyn_bytes; ++i)
+    if (dyn[i] != 0xC3) { std::fprintf(stderr, "engine sim: %s wrote dynamic LDS at byte %zu, beyond the %zu its launch asked for\n", name, i, lds); std::abort(); }
+}
+}  // namespace hs
+#define hipLaunchKernelGGL(fn, grid, block, lds, stream, ...) hs::launch_checked((grid), (block), (size_t)(lds), cbh_dyn_lds, sizeof(cbh_dyn_lds), #fn, [=]() { fn(__VA_ARGS__); })
+#define hipExtLaunchKernelGGL(fn, grid, block, lds, stream, ev0, ev1, flags, ...) hs::launch_checked((grid), (block), (size_t)(lds), cbh_dyn_lds, sizeof(cbh_dyn_lds), #fn, [=]() { fn(__VA_ARGS__); })
