@@ -233,3 +233,18 @@ assert failed > 15 and survived >= 2, (failed, survived)
 print("allocation failures survived: %d calls failed cleanly, %d had enough" % (failed, survived))
 table.close()
 ''', {"CBH_WIRE_SLICE_MIN_BYTES": "20000"})
+
+
+def test_four_waves_to_a_workgroup():
+    """The workgroup shape of the GPU (tests/sim_engine.py build_four_waves): flat tables with and without the trail, C5 through the walk,
+    its pre-pass and its trail form, the request road."""
+    from sim_engine import build_four_waves
+    _in_own_process('''
+import test_zz_gpu_request_road as t
+t.test_requests_give_the_bytes_their_check_inputs_give("C5", 900)
+t.test_the_audit_trail_of_every_request_at_size("C2", 700)
+import test_zz_gpu_effective_policies as e
+e.test_walk_tables_by_input("c5w", 300)
+e.test_flat_tables_keep_their_trail_in_the_flat_kernels("t", 300)
+e.test_the_reference_s_decision_logs_and_the_oracle_by_input()
+''', {"CBH_TEST_SIM_LIB": build_four_waves()})
