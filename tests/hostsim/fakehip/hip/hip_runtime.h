@@ -261,6 +261,15 @@ namespace hs {
 template <class F>
 inline void launch_checked(dim3 grid, dim3 block, size_t lds, unsigned char* dyn, size_t dyn_bytes, const char* name, F&& f) {
   std::lock_guard<std::recursive_mutex> lk(mu());
+  if (lds > 160u * 1024u) { std::fprintf(stderr, "engine sim: %s asks for %zu bytes of dynamic LDS: more than a CU has\n", name, lds); std::abort(); }
+  if (getenv("CBH_SIM_LDS_REPORT")) {   // the largest request per kernel symbol, printed when the process ends
+    static std::vector<std::pair<std::string, size_t>> seen;
+    static const int once = std::atexit([] { for (auto& e : seen) std::fprintf(stderr, "engine sim: dynamic LDS of %s: up to %zu bytes\n", e.first.c_str(), e.second); });
+    (void)once;
+    bool found = false;
+    for (auto& e : seen) if (e.first == name) { e.second = std::max(e.second, lds); found = true; }
+    if (!found) seen.emplace_back(name, lds);
+  }
   if (lds > dyn_bytes) { std::fprintf(stderr, "engine sim: %s asks for %zu bytes of dynamic LDS, the simulation holds %zu\n", name, lds, dyn_bytes); std::abort(); }
   std::memset(dyn + lds, 0xC3, dyn_bytes - lds);
   launch(grid, block, f);
