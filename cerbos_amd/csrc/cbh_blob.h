@@ -374,7 +374,7 @@ enum CbhOp {
   OP_ITER_NEXT = 42,  // arg = slot; next word = end_pc : exhausted -> pc = end_pc, else bind locals
   OP_ITER_ACC = 43,   // arg = slot; next word = loop_pc : pop predicate, fold, maybe finish
   OP_ITER_END = 44,   // arg = slot: push folded result
-  OP_TOINT = 45, OP_TODOUBLE = 46, OP_TOSTRING_UNSUPPORTED = 47,
+  OP_TOINT = 45 /* arg 1: uint(x) */, OP_TODOUBLE = 46, OP_TOSTRING_UNSUPPORTED = 47,
   OP_INIPRANGE = 48, // pop cidr, ip (strings)
   OP_UNSUPPORTED = 49, // marks the tuple CBH_ST_UNSUPPORTED and yields an error
   OP_TS_GETTER = 50,  // arg = getter kind; pops tz string if arg bit 7 set

@@ -635,6 +635,19 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
       case OP_TOINT: {
         Val x = TOPV(0);
         ROPE_UNSUPPORTED2(x, x);
+        if (a == 1u) {   // uint(x) (cel-go common/types: int.go / double.go ConvertToType(UintType), overflow.go *ToUint64Checked)
+          if (x.t == CBH_T_UINT) break;
+          if (x.t == CBH_T_INT) { if ((i64)x.v < 0) SETTOP(mk_errc(CBH_ERR_UINT_OVERFLOW)); else ST(sp - 1) = CBH_T_UINT; break; }
+          if (x.t == CBH_T_DOUBLE) {
+            const double d = as_f64(x.v);
+            if (d != d || d < 0 || d >= 18446744073709551616.0) SETTOP(mk_errc(CBH_ERR_UINT_OVERFLOW));
+            else SETTOP(mk(CBH_T_UINT, (u64)d));
+            break;
+          }
+          if (x.t == CBH_T_STRING && live) L.status |= CBH_ST_UNSUPPORTED;
+          FAILTOP1(x, CBH_ERR_NO_SUCH_OVERLOAD);
+          break;
+        }
         if (x.t == CBH_T_INT) break;
         if (x.t == CBH_T_UINT) { if (x.v > (u64)INT64_MAX) SETTOP(mk_errc(CBH_ERR_INT_OVERFLOW)); else ST(sp - 1) = CBH_T_INT; break; }
         if (x.t == CBH_T_DOUBLE) {

@@ -1270,6 +1270,9 @@ class _FuncCompiler:
                 return None
             if name == "int" and n == 1 and target is None:
                 return unary(OP_TOINT)
+            if name == "uint" and n == 1 and target is None:   # (the same opcode, argument 1)
+                self._expr(allargs[0])
+                return self.emit(OP_TOINT, 1)
             if name == "double" and n == 1 and target is None:
                 return unary(OP_TODOUBLE)
             if name == "dyn" and n == 1 and target is None:
