@@ -75,9 +75,15 @@ def _run(make_evaluator, close):
     assert decided >= 4, (decided, lt.unsupported)
 
 
-def test_on_the_kernel_simulation():
+@pytest.mark.parametrize("env", [{}, {"CBH_NO_WALK2": "1"}], ids=["cbh_walk2_kernel and its pre-pass", "the general walk"])
+def test_on_the_kernel_simulation(env, monkeypatch):
+    """... through the interpreter as the walk's pre-pass calls it and as the general walk does (these conditions are nobody's leaves)."""
+    import hostsim_api
     from test_hostsim_golden import HostSimEvaluator
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     _run(lambda lt: HostSimEvaluator(lt, Conf()), False)
+    assert hostsim_api.last_kind() == (0 if env else 2)
 
 
 @pytest.mark.gpu
