@@ -304,3 +304,38 @@ def test_flat_kernel_large_buckets_with_evaluator_call_vs_oracle(seed):
 @pytest.mark.parametrize("seed", range(400, 406))
 def test_flat_kernel_large_buckets_with_evaluator_call_on_gpu(seed):
     _run_seed(seed, lambda lt: HipEvaluator(lt, Conf()), True, with_lists=True, many_rules=True)
+
+
+@pytest.mark.parametrize("env", [{"CBH_NO_FLAT": "1"}, {"CBH_NO_FLAT": "1", "CBH_NO_WALK2": "1"}], ids=["cbh_walk2_kernel", "the general walk's leaf kernels"])
+@pytest.mark.parametrize("name", ["c2", "c3"])
+def test_flat_workloads_through_the_other_kernel_families(name, env, monkeypatch):
+    """C2 / C3 are the flat kernels' - their classified leaves (a column against a constant, a column in a list of string constants,
+    two columns) are also leaves of the walk and of the general walk's leaf kernels, which no other test sends these shapes through
+    (the round's coverage table): the same answers, tuple by tuple, as the flat kernel and the oracle."""
+    import hostsim_api
+    from cerbos_amd import capi, workloads
+    from cerbos_amd.flatten import Flattener
+    from cerbos_amd.lower.blob import lower_rule_table
+    from cerbos_amd.policy.loader import policies_from_docs
+    from cerbos_amd.ruletable.build import rule_table_from_policies
+    from oracle.check import EvalParams, RuleTableOracle
+    rt = rule_table_from_policies(policies_from_docs(getattr(workloads, name + "_policies")()))
+    lt = lower_rule_table(rt)
+    cr = getattr(workloads, name + "_requests")(n_requests=400)
+    batch = cr.to_batch(Flattener(lt))
+    now = 1_700_000_000_000_000_000
+    want = hostsim_api.check(lt, batch, now, capi.F_WANT_DERIVED_ROLES)
+    assert hostsim_api.last_kind() == 1
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    have = hostsim_api.check(lt, batch, now, capi.F_WANT_DERIVED_ROLES)
+    assert hostsim_api.last_kind() == (2 if len(env) == 1 else 0)
+    for f in ("effect", "policy", "scope", "edr"):
+        assert np.array_equal(getattr(have, f), getattr(want, f)), f
+    assert ((have.status == capi.ST_UNSUPPORTED) == (want.status == capi.ST_UNSUPPORTED)).all()
+    orc = RuleTableOracle(rt)
+    effects = []
+    for inp in cr.to_inputs()[:150]:
+        out = orc.check(inp, EvalParams(now_ns=now))
+        effects.extend(1 if out["actions"][a]["effect"] == "EFFECT_ALLOW" else 2 for a in inp["actions"])
+    assert np.array_equal(have.effect[:len(effects)], np.array(effects, dtype=np.uint8))
