@@ -370,3 +370,50 @@ def test_bytes_road_on_the_simulator_with_grouping(monkeypatch):
     assert ev.last_road == "device"
     b = ev.check_pb(data, off, now_ns=1_700_000_000_000_000_000, device_ingest=False)
     assert ev.last_road == "host" and a[0] == b[0] and list(a[1]) == list(b[1])
+
+
+def test_the_whole_token_as_a_value():
+    """Conditions that take the claims of the verified token - or the map of named tokens - as ONE value (membership, size, indexing
+    by a computed key) make the column the whole map: the device flattener builds it on the heap (the claims under "claims", as the
+    reference's `request.aux_data.jwt` view has them; named tokens as name -> {"claims": ..}) - shapes the round's coverage table showed
+    no test reached.  Host flattener against device flattener value by value, then the decisions on both batches against the oracle."""
+    from cerbos_amd.policy.loader import policies_from_docs
+    from cerbos_amd.ruletable.build import rule_table_from_policies
+    from cerbos_amd import capi
+    from oracle.check import EvalParams, RuleTableOracle
+    conds = {"has_claim": '"aud" in request.aux_data.jwt', "n_claims": "size(request.auxData.jwt) == 3",
+             "by_key": 'request.aux_data.jwt[R.attr.claim] == "cerbos"', "named": '"partner" in request.auxData.jwts',
+             "named_claim": 'request.auxData.jwts[R.attr.token].claims.iss == "acme"'}
+    docs = [{"apiVersion": "api.cerbos.dev/v1", "resourcePolicy": {"resource": "tok", "version": "default", "rules": [
+        {"actions": [n], "roles": ["*"], "effect": "EFFECT_ALLOW", "condition": {"match": {"expr": e}}} for n, e in conds.items()]}}]
+    rt = rule_table_from_policies(policies_from_docs(docs))
+    lt = lower_rule_table(rt)
+    auxes = [{"jwt": {"aud": "cerbos", "iss": "acme", "n": 3}, "jwts": {"partner": {"iss": "acme", "k": [1, 2]}, "other": {"iss": "x"}}},
+             {"jwt": {"iss": "acme"}, "jwts": {"other": {"iss": "acme"}}},
+             {"jwt": {"aud": ["a", "b"], "sub": "s", "nested": {"a": {"b": 1}}}},
+             {"jwts": {"partner": {}}},
+             None]
+    inputs = []
+    for k, aux in enumerate(auxes):
+        for claim, token in (("aud", "partner"), ("iss", "other"), ("none", "none")):
+            inp = {"requestId": "t%d" % k, "actions": list(conds), "resource": {"kind": "tok", "id": "r", "attr": {"claim": claim, "token": token}},
+                   "principal": {"id": "p", "roles": ["user"], "attr": {}}}
+            if aux is not None:
+                inp["auxData"] = aux
+            inputs.append(inp)
+    hb, wb = _compare(lt, inputs)
+    now = 1_700_000_000_000_000_000
+    want = hostsim_api.check(lt, hb, now_ns=now, flags=4, device_order=True)
+    have = hostsim_api.check(lt, wu.to_batch(lt, wb), now_ns=now, flags=4, device_order=True)
+    for f in ("effect", "policy", "scope", "status", "edr"):
+        assert np.array_equal(getattr(want, f), getattr(have, f)), f
+    res = hostsim_api.check(lt, hb, now_ns=now, flags=4)
+    orc, at, decided = RuleTableOracle(rt), 0, 0
+    for inp in inputs:
+        out = orc.check(inp, EvalParams(now_ns=now))
+        for a in inp["actions"]:
+            if res.status[at] != capi.ST_UNSUPPORTED:
+                assert (res.effect[at] == 1) == (out["actions"][a]["effect"] == "EFFECT_ALLOW"), (a, inp.get("auxData"), inp["resource"]["attr"])
+                decided += 1
+            at += 1
+    assert decided > 40, (decided, lt.unsupported)
