@@ -339,3 +339,39 @@ def test_flat_workloads_through_the_other_kernel_families(name, env, monkeypatch
         out = orc.check(inp, EvalParams(now_ns=now))
         effects.extend(1 if out["actions"][a]["effect"] == "EFFECT_ALLOW" else 2 for a in inp["actions"])
     assert np.array_equal(have.effect[:len(effects)], np.array(effects, dtype=np.uint8))
+
+
+def test_condition_trees_over_pooled_leaves_in_the_mask_walk():
+    """A long bucket whose conditions are all / any / none trees over a handful of fused leaves (the table's leaves are POOLED: at most
+    64 distinct ones, evaluated once per wave) - the mask walk folds a tree's level from its leaves' pooled codes; no other test builds
+    that shape (the round's coverage table)."""
+    import hostsim_api
+    rng = np.random.default_rng(78)
+    leaves = ["R.attr.amount > 500", "R.attr.owner == P.id", "R.attr.public == true", 'R.attr.status == "OPEN"', "R.attr.amount > 1500",
+              'P.attr.department == R.attr.department']
+    rules = []
+    for i in range(90):
+        a, b, c = (leaves[int(x)] for x in rng.choice(len(leaves), size=3, replace=False))
+        kind = ("all", "any", "none")[i % 3]
+        cond = {kind: {"of": [{"expr": a}, {"expr": b}]}} if i % 2 else {kind: {"of": [{"expr": a}, {"any": {"of": [{"expr": b}, {"expr": c}]}}]}}
+        rules.append({"actions": [str(x) for x in rng.choice(ACTIONS, size=2, replace=False)], "roles": [str(r) for r in rng.choice(ROLES, size=2, replace=False)],
+                      "effect": "EFFECT_ALLOW" if rng.random() < 0.8 else "EFFECT_DENY", "condition": {"match": cond}})
+    docs = [{"apiVersion": API, "resourcePolicy": {"resource": "doc", "version": "default", "rules": rules}}]
+    rt = rule_table_from_policies(policies_from_docs(docs))
+    lt = lower_rule_table(rt)
+    assert lt.stats["flat"] and lt.seg_stats["pooled"], lt.seg_stats
+    inputs = [i for i in _requests(rng, 300, False, False) if i["resource"]["kind"] in ("doc", "other")]
+    for i in inputs:
+        i["resource"]["scope"] = ""
+    batch = Flattener(lt).flatten(inputs)
+    res = hostsim_api.check(lt, batch, NOW, capi.F_WANT_DERIVED_ROLES)
+    assert hostsim_api.lib().hostsim_last_masks() == 1
+    orc = RuleTableOracle(rt)
+    t = 0
+    for inp in inputs:
+        want = orc.check(inp, EvalParams(now_ns=NOW))
+        for a in inp["actions"]:
+            assert (res.effect[t] == capi.EFFECT_ALLOW) == (want["actions"][a]["effect"] == "EFFECT_ALLOW"), (inp, a)
+            t += 1
+        na = len(inp["actions"])
+        assert bool((res.status[t - na:t] == capi.ST_CEL_ERROR).any()) == bool(want.get("evaluationErrors"))
