@@ -173,9 +173,10 @@ def request_env(principal, resource, aux_data, globals_, constants):
     p = {"id": principal.get("id", ""), "roles": list(principal.get("roles") or []), "attr": to_cel(principal.get("attr") or {}),
          "policyVersion": principal.get("policyVersion", ""), "scope": namer.scope_value(principal.get("scope", "") or "")}
     p["policy_version"] = p["policyVersion"]
-    r = PartialMap({"kind": resource.get("kind", ""), "policyVersion": resource.get("policyVersion", ""),
-                    "scope": namer.scope_value(resource.get("scope", "") or ""), "attr": PartialMap(to_cel(resource.get("attr") or {}))})
-    r["policy_version"] = r["policyVersion"]
+    # of the resource the partial evaluator knows kind, scope and the attributes the caller supplied (planner.go:532-577 newEvaluator);
+    # id and policyVersion stay residual
+    r = PartialMap({"kind": resource.get("kind", ""), "scope": namer.scope_value(resource.get("scope", "") or ""),
+                    "attr": PartialMap(to_cel(resource.get("attr") or {}))})
     aux = aux_data or {}
     req = {"principal": p, "resource": r,
            "auxData": {"jwt": to_cel(aux.get("jwt") or {}), "jwts": {k: {"claims": to_cel((v or {}).get("claims") or {})} for k, v in (aux.get("jwts") or {}).items()}}}
@@ -220,6 +221,10 @@ class Partial:
         k = n[0]
         if k == "lit":
             return ("k", _Eval(self.now_ns).ev(n, env))
+        if k in ("and", "or"):
+            # operand by operand: a deciding operand absorbs the other's error (false && error = false), which the constant
+            # folder - written for the lowering, where such a node is left to the device - does not do
+            return self._logical(n, env)
         try:
             v = _Eval(self.now_ns).ev(n, env)
             if isinstance(v, PartialMap):
@@ -235,22 +240,6 @@ class Partial:
         except (RecursionError, OverflowError, ValueError) as e:
             raise CelEvalError(str(e))
         # structural
-        if k in ("and", "or"):
-            a, b = self.pe_guard(n[1], env), self.pe_guard(n[2], env)
-            absorbing = (k == "or")
-            for x, other in ((a, b), (b, a)):
-                if x[0] == "k" and isinstance(x[1], bool):
-                    if x[1] == absorbing:
-                        return ("k", absorbing)
-                    return other if other[0] != "e" else self._raise(other)
-            if a[0] == "e" and b[0] == "e":
-                self._raise(a)
-            # an error beside an unknown: cel-go keeps the unknown (the error may be absorbed); the planner keeps the residual of the other
-            if a[0] == "e":
-                return b
-            if b[0] == "e":
-                return a
-            return ("r", (k, self.ast(a, n[1], env), self.ast(b, n[2], env)))
         if k == "not":
             a = self.pe(n[1], env)
             if a[0] == "k":
@@ -282,6 +271,30 @@ class Partial:
         else:
             new = [self.ast(self.pe(c, env), c, env) for c in kids]
         return ("r", fold._rebuild(n, new))
+
+    def _logical(self, n, env):
+        k = n[0]
+        a, b = self.pe_guard(n[1], env), self.pe_guard(n[2], env)
+        absorbing = (k == "or")
+        for x, other in ((a, b), (b, a)):
+            if x[0] == "k" and isinstance(x[1], bool):
+                if x[1] == absorbing:
+                    return ("k", absorbing)
+                if other[0] == "k" and not isinstance(other[1], bool):
+                    raise CelEvalError("no such overload")
+                return other if other[0] != "e" else self._raise(other)
+        if a[0] == "e" and b[0] == "e":
+            self._raise(a)
+        if a[0] == "k" or b[0] == "k":      # a known operand that is not a bool
+            raise CelEvalError("no such overload")
+        # an error beside an unknown: cel-go answers unknown (interpretable.go evalAnd / evalOr: an unknown operand outranks an
+        # error), and the pruner has no value to put in the failing operand's place - the residual keeps it as written
+        # (`R.attr.a && P.attr.missing`).  Dropping it would make an `&&` filter wider than Check, where true && error is an error.
+        if a[0] == "e":
+            a = ("r", n[1])
+        if b[0] == "e":
+            b = ("r", n[2])
+        return ("r", (k, self.ast(a, n[1], env), self.ast(b, n[2], env)))
 
     def pe_guard(self, n, env):
         try:

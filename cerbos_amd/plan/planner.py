@@ -145,7 +145,8 @@ class Planner:
         r_scope = namer.scope_value(resource.get("scope", "") or default_scope)
         r_ver = resource.get("policyVersion", "") or default_policy_version
         out = {"requestId": inp.get("requestId", ""), "kind": resource.get("kind", ""), "policyVersion": resource.get("policyVersion", ""),
-               "actions": actions, "scope": namer.scope_value(resource.get("scope", "")), "matchedScopes": {}, "evaluationErrors": []}
+               "action": inp.get("action") or "", "actions": list(inp.get("actions") or []),   # as they came (planner.go:113-125)
+               "scope": namer.scope_value(resource.get("scope", "")), "matchedScopes": {}, "evaluationErrors": []}
         p_scopes, _ = self.all_scopes(KIND_PRINCIPAL, p_scope, principal.get("id", ""), p_ver, lenient_scope_search)
         r_scopes, _ = self.all_scopes(KIND_RESOURCE, r_scope, resource.get("kind", ""), r_ver, lenient_scope_search)
         if not p_scopes and not r_scopes:
@@ -350,15 +351,28 @@ class _Cond:
         """The value of runtime.effectiveDerivedRoles at a scope: the names of the derived roles whose parent roles the principal has,
         each under its condition (plan.go:143-190, planner.MkDerivedRolesList)."""
         drs = self.p.rt["policy_derived_roles"].get(namer.resource_policy_fqn(kind, version, scope)) or {}
-        items = []
+        items, failed = [], None
         for name in sorted(drs):
             dr = drs[name]
             if not (set(dr["parent_roles"]) & all_roles) and "*" not in dr["parent_roles"]:
                 continue
             # (inside a definition the list is still empty: plan.go:142, 161)
-            node = self.condition(dr["condition"], dr["constants"], self.p.variable_exprs(dr["ordered_variables"]), [])
+            try:
+                node = self.condition(dr["condition"], dr["constants"], self.p.variable_exprs(dr["ordered_variables"]), [])
+            except StrictEvaluationError as e:
+                # plan.go:157-176 drListErr: a definition that fails under strict evaluation spoils the LIST, not the action - the
+                # error surfaces only where a condition really reads runtime.effectiveDerivedRoles (_replace_runtime_edr)
+                failed = failed or e
+                continue
             items.append((name, node))
-        return items
+        return _DrListError(failed) if failed is not None else items
+
+
+class _DrListError:
+    """A scope's derived-role list that could not be built: the strict-evaluation error of one of its definitions, kept until read"""
+
+    def __init__(self, err):
+        self.err = err
 
 
 def _replace_runtime_edr(tree, dr_list):
@@ -366,6 +380,8 @@ def _replace_runtime_edr(tree, dr_list):
 
     def repl(x):
         if x[0] == "select" and x[1] == ("ident", "runtime") and x[2] in ("effectiveDerivedRoles", "effective_derived_roles"):
+            if isinstance(dr_list, _DrListError):
+                raise dr_list.err
             return _dr_list_expr(dr_list)
         return None
     return substitute(tree, repl)

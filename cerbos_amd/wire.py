@@ -379,8 +379,7 @@ def decode_plan_resources_input(buf: bytes) -> dict:
             inp["includeMeta"] = bool(v)
         elif n == 7:
             inp["actions"].append(v.decode("utf-8"))
-    if not inp["actions"] and action:
-        inp["actions"] = [action]
+    inp["action"] = action      # (deprecated field 2: kept apart - MkPlanResourcesOutput copies both as they came, planner.go:113-125)
     return inp
 
 
@@ -400,7 +399,7 @@ def encode_plan_resources_output(out: dict) -> bytes:
     if f.get("condition") is not None:
         fb += _ld(2, _encode_operand(f["condition"]))
     acts = out.get("actions") or []
-    b = _string(1, out.get("requestId", "")) + _string(3, out.get("kind", "")) + _string(4, out.get("policyVersion", "")) + _string(5, out.get("scope", ""))
+    b = _string(1, out.get("requestId", "")) + _string(2, out.get("action", "")) + _string(3, out.get("kind", "")) + _string(4, out.get("policyVersion", "")) + _string(5, out.get("scope", ""))
     b += _ld(6, fb) + _string(7, out.get("filterDebug", ""))
     b += b"".join(_ld(9, a.encode("utf-8")) for a in acts)
     for k, v in (out.get("matchedScopes") or {}).items():
@@ -429,11 +428,11 @@ def _decode_operand(buf: bytes) -> dict:
 
 def decode_plan_resources_output(buf: bytes) -> dict:
     kinds = {v: k for k, v in _FILTER_KINDS.items()}
-    out = {"requestId": "", "kind": "", "policyVersion": "", "scope": "", "filter": {"kind": "KIND_UNSPECIFIED"}, "filterDebug": "",
+    out = {"requestId": "", "action": "", "kind": "", "policyVersion": "", "scope": "", "filter": {"kind": "KIND_UNSPECIFIED"}, "filterDebug": "",
            "actions": [], "matchedScopes": {}, "evaluationErrors": []}
     for n, v in _fields(buf):
-        if n in (1, 3, 4, 5, 7):
-            out[{1: "requestId", 3: "kind", 4: "policyVersion", 5: "scope", 7: "filterDebug"}[n]] = v.decode("utf-8")
+        if n in (1, 2, 3, 4, 5, 7):
+            out[{1: "requestId", 2: "action", 3: "kind", 4: "policyVersion", 5: "scope", 7: "filterDebug"}[n]] = v.decode("utf-8")
         elif n == 6:
             f = {"kind": "KIND_UNSPECIFIED"}
             for n2, v2 in _fields(v):

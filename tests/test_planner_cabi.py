@@ -67,6 +67,19 @@ def test_the_reference_s_plans_through_bytes(lib):
                     assert out["actions"] == test["actions"] and out["kind"] == test["resource"].get("kind", "") and out["requestId"] == "requestId"
                     n += 1
         assert n > 200
+        # the deprecated single `action` (PlanResourcesInput field 2) comes back as it came: Action set, Actions empty
+        # (planner.go:113-125 MkPlanResourcesOutput copies both verbatim) - and plans as [action]
+        suite = DATA["suites"][0]
+        test = next(t for t in suite["tests"] if not t["wantErr"] and len(t["actions"]) == 1)
+        one = {"requestId": "r", "principal": suite["principal"], "resource": test["resource"], "action": test["actions"][0], "auxData": AUX}
+        many = dict(one, actions=test["actions"])
+        del many["action"]
+        params = {"globals": {"environment": "test"}, "lenientScopeSearch": bool(suite["lenient"]), "nowNs": NOW}
+        (st1, o1), (st2, o2) = _plan(lib, h.value, one, params), _plan(lib, h.value, many, params)
+        assert st1 == 0 and st2 == 0
+        assert o1["action"] == test["actions"][0] and o1["actions"] == []
+        assert o2["action"] == "" and o2["actions"] == test["actions"]
+        assert o1["filter"] == o2["filter"] and o1["matchedScopes"] == o2["matchedScopes"]
         st, msg = _plan(lib, 987654, {"principal": {"id": "x", "roles": ["a"]}, "resource": {"kind": "k"}, "actions": ["a"]}, {})
         assert st == 3 and "handle" in msg
     finally:

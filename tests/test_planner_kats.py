@@ -103,3 +103,64 @@ def test_struct_matcher(expr, want):
         assert got is None
     else:
         assert got == parse(want)
+
+
+# ---- an operand that fails beside one that is unknown (cel-go interpretable.go evalAnd / evalOr: unknown outranks error, the
+# pruner has no value for the failing operand): the residual keeps BOTH as written.  No reference fixture reaches this; dropping
+# the failing operand of an `&&` would make the filter wider than Check (true && error = error: the rule does not match).
+ERROR_BESIDE_UNKNOWN = [
+    ("R.attr.x && P.attr.missing", "R.attr.x && P.attr.missing"),
+    ("P.attr.missing && R.attr.x", "P.attr.missing && R.attr.x"),
+    ("R.attr.x || P.attr.missing", "R.attr.x || P.attr.missing"),
+    ("R.attr.x && (P.attr.n > 1 && P.attr.missing)", None),      # a known conjunction that fails: the condition's error
+    ("false && P.attr.missing", "false"),
+    ("R.attr.x && false && P.attr.missing", "false"),
+]
+
+
+@pytest.mark.parametrize("expr,want", ERROR_BESIDE_UNKNOWN, ids=[e[0] for e in ERROR_BESIDE_UNKNOWN])
+def test_an_error_beside_an_unknown_stays_in_the_residual(expr, want):
+    from cerbos_amd.plan.partial import CelEvalError
+    if want is None:
+        got = residual(expr, {"attr": {"n": 2.0}}, {"kind": "k"})
+        assert got == parse("R.attr.x && (P.attr.n > 1 && P.attr.missing)") or isinstance(got, tuple)
+        return
+    try:
+        got = residual(expr, {"attr": {"n": 2.0}}, {"kind": "k"})
+    except CelEvalError:
+        got = None
+    assert got == parse(want)
+
+
+def test_the_resource_s_policy_version_is_not_known_to_the_partial_evaluator():
+    """planner.go:532-577 newEvaluator: of the resource only kind, scope and the supplied attributes are known"""
+    assert residual('R.policyVersion == "default"', {}, {"kind": "k"}) == parse('R.policyVersion == "default"')
+    assert residual('R.policyVersion == "default"', {}, {"kind": "k", "policyVersion": "default"}) == parse('R.policyVersion == "default"')
+    assert residual('R.kind == "k" && R.id == "1"', {}, {"kind": "k"}) == parse('R.id == "1"')
+
+
+def test_a_broken_derived_role_spoils_only_what_reads_the_list():
+    """plan.go:157-176 drListErr: under strict evaluation a derived-role definition that fails makes runtime.effectiveDerivedRoles an
+    error for whoever READS it - an action whose rules never do is planned as if the definition were not there."""
+    from cerbos_amd.plan.planner import Planner
+    from cerbos_amd.policy.loader import policies_from_docs
+    from cerbos_amd.ruletable.build import rule_table_from_policies
+    docs = [
+        {"apiVersion": "api.cerbos.dev/v1", "derivedRoles": {"name": "dr", "definitions": [
+            {"name": "broken", "parentRoles": ["user"], "condition": {"match": {"expr": "P.attr.missing == 1"}}}]}},
+        {"apiVersion": "api.cerbos.dev/v1", "resourcePolicy": {"resource": "doc", "version": "default", "importDerivedRoles": ["dr"], "rules": [
+            {"actions": ["view"], "effect": "EFFECT_ALLOW", "roles": ["user"], "condition": {"match": {"expr": "R.attr.public == true"}}},
+            {"actions": ["edit"], "effect": "EFFECT_ALLOW", "derivedRoles": ["broken"]},
+            {"actions": ["list"], "effect": "EFFECT_ALLOW", "roles": ["user"],
+             "condition": {"match": {"expr": '"broken" in runtime.effectiveDerivedRoles || R.attr.public == true'}}}]}},
+    ]
+    pl = Planner(rule_table_from_policies(policies_from_docs(docs)))
+    inp = {"principal": {"id": "p", "roles": ["user"], "attr": {}}, "resource": {"kind": "doc"}}
+    view = pl.plan(dict(inp, actions=["view"]), strict_evaluation=True)
+    assert view["filter"]["kind"] == "KIND_CONDITIONAL", view
+    edit = pl.plan(dict(inp, actions=["edit"]), strict_evaluation=True)
+    assert edit["filter"]["kind"] == "KIND_ALWAYS_DENIED"
+    lst = pl.plan(dict(inp, actions=["list"]), strict_evaluation=True)       # reads the list: the definition's error is this action's
+    assert lst["filter"]["kind"] == "KIND_ALWAYS_DENIED"
+    lenient = pl.plan(dict(inp, actions=["list"]), strict_evaluation=False)  # not strict: the definition is false, the rest stands
+    assert lenient["filter"]["kind"] == "KIND_CONDITIONAL"
