@@ -1026,13 +1026,46 @@ static int flatten_source(const cbi_table* t, const Source& src, uint32_t n, con
 }
 
 // The resource entries (field 4) of a CheckResourcesRequest, its principal (3), request id (1), include_meta (2).
-struct RequestParts { std::vector<Span> entries; Span principal{nullptr, nullptr}; std::string_view request_id; bool include_meta = false; };
+// Scalars: the last occurrence wins.  The principal and an entry's resource are MESSAGE fields: protobuf merges their occurrences
+// (what proto.Unmarshal did to the request the server validated and logged), and parsing the concatenation of their bytes is that
+// merge - so a request that is not canonical in this way is read through a canonical copy (`owned`: the occurrences back to back),
+// as the device road's split does (cbh_wire_req.h).
+struct RequestParts {
+  std::vector<Span> entries; Span principal{nullptr, nullptr}; std::string_view request_id; bool include_meta = false;
+  std::vector<std::vector<u8>> owned;   // (an inner vector's bytes stay where they are when the outer one grows)
+};
+static void append_varint(std::vector<u8>& o, u64 v) { while (v >= 0x80) { o.push_back((u8)(v | 0x80)); v >>= 7; } o.push_back((u8)v); }
 static bool split_request(const uint8_t* request, uint64_t len, RequestParts& rp) {
   Span s{request, request + len}; Field f; bool bad = false;
+  u32 n_principal = 0;
   while (next(s, f, bad)) {
     if (f.num == 2 && f.wt == 0) rp.include_meta = f.v != 0;
     if (f.wt != 2) continue;
-    if (f.num == 1) rp.request_id = sv(f.s); else if (f.num == 3) rp.principal = f.s; else if (f.num == 4) rp.entries.push_back(f.s);
+    if (f.num == 1) rp.request_id = sv(f.s); else if (f.num == 3) { rp.principal = f.s; ++n_principal; } else if (f.num == 4) rp.entries.push_back(f.s);
+  }
+  if (bad) return false;
+  if (n_principal > 1) {
+    std::vector<u8> all;
+    s = Span{request, request + len};
+    while (next(s, f, bad)) if (f.wt == 2 && f.num == 3) all.insert(all.end(), f.s.p, f.s.e);
+    rp.owned.push_back(std::move(all));
+    rp.principal = Span{rp.owned.back().data(), rp.owned.back().data() + rp.owned.back().size()};
+  }
+  for (Span& e : rp.entries) {
+    u32 n_res = 0;
+    { Span t = e; while (next(t, f, bad)) n_res += (f.wt == 2 && f.num == 2); }
+    if (bad) return false;
+    if (n_res <= 1) continue;
+    std::vector<u8> canon, res;   // the entry's other fields as they are, then ONE resource made of all its occurrences
+    Span t = e;
+    for (;;) {
+      const u8* start = t.p;
+      if (!next(t, f, bad)) break;
+      if (f.wt == 2 && f.num == 2) res.insert(res.end(), f.s.p, f.s.e); else canon.insert(canon.end(), start, t.p);
+    }
+    canon.push_back((u8)(2u << 3 | 2u)); append_varint(canon, res.size()); canon.insert(canon.end(), res.begin(), res.end());
+    rp.owned.push_back(std::move(canon));
+    e = Span{rp.owned.back().data(), rp.owned.back().data() + rp.owned.back().size()};
   }
   return !bad;
 }

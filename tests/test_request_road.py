@@ -105,21 +105,50 @@ def test_engine_aux_data_rides_on_every_entry():
         sorted(wire._fields(msgs[len(plain)])) == sorted(wire._fields(wire.encode_check_input(_as_built_by_the_service(jwt_inputs[:1], aux)[0])))
 
 
+def _decode_check_input(buf):
+    """engine.proto CheckInput as a dict, read the protobuf way: a message field named more than once is the merge of its occurrences
+    (= its occurrences' bytes back to back), a scalar named more than once its last occurrence"""
+    parts = {2: b"", 3: b""}
+    out = {"requestId": "", "actions": []}
+    for n, v in wire._fields(buf):
+        if n in parts:
+            parts[n] += v
+        elif n == 1:
+            out["requestId"] = v.decode()
+        elif n == 4:
+            out["actions"].append(v.decode())
+    out["principal"] = wire._decode_principal(parts[3])
+    r = {"kind": "", "policyVersion": "", "id": "", "scope": ""}
+    attrs = []
+    for n, v in wire._fields(parts[2]):
+        if n == 4:
+            attrs.append(v)
+        elif n in (1, 2, 3, 5):
+            r[{1: "kind", 2: "policyVersion", 3: "id", 5: "scope"}[n]] = v.decode()
+    r["attr"] = wire._decode_map(attrs)
+    out["resource"] = r
+    return out
+
+
 def test_unusual_but_valid_encodings():
-    """Fields in any order, repeated (last wins), unknown fields, empty requests, entries without a resource."""
+    """Fields in any order, repeated, unknown fields, empty requests, entries without a resource.  A scalar named twice: the last
+    wins.  A MESSAGE field named twice (the principal, an entry's resource): its occurrences merge, as proto.Unmarshal merged them for
+    the server that validated and logged the request - the CheckInput carries them back to back, which parses as the merge."""
     p1, p2 = wire.encode_principal({"id": "a", "roles": ["x"]}), wire.encode_principal({"id": "b", "roles": ["y"]})
     r1 = wire.encode_resource({"kind": "k", "id": "1"})
     r2 = wire.encode_resource({"kind": "k", "id": "2"})
     ld = wire._ld
-    entry = ld(1, b"view") + ld(2, r1) + ld(1, b"edit") + ld(2, r2)          # the second resource wins, the actions accumulate
+    entry = ld(1, b"view") + ld(2, r1) + ld(1, b"edit") + ld(2, r2)          # the resources merge (id: the later one), the actions accumulate
     unknown = wire._varint(9 << 3 | 0) + b"\x05" + ld(12, b"zzz") + wire._varint(10 << 3 | 1) + bytes(8) + wire._varint(11 << 3 | 5) + bytes(4)
     req = ld(4, entry) + unknown + ld(3, p1) + ld(1, b"first") + ld(4, ld(1, b"only-actions")) + ld(3, p2) + ld(1, b"second") + ld(4, b"") + ld(6, b"ctx")
     msgs, first, flags = sim_split([b"", req, ld(3, p1)])
     assert list(first) == [0, 0, 3, 3] and not flags.any()
     f0 = list(wire._fields(msgs[0]))
-    assert f0 == [(1, b"second"), (2, r2), (3, p2), (4, b"view"), (4, b"edit")]
-    assert list(wire._fields(msgs[1])) == [(1, b"second"), (3, p2), (4, b"only-actions")]
-    assert list(wire._fields(msgs[2])) == [(1, b"second"), (3, p2)]
+    assert f0 == [(1, b"second"), (2, r1 + r2), (3, p1 + p2), (4, b"view"), (4, b"edit")]
+    assert list(wire._fields(msgs[1])) == [(1, b"second"), (3, p1 + p2), (4, b"only-actions")]
+    assert list(wire._fields(msgs[2])) == [(1, b"second"), (3, p1 + p2)]
+    merged = _decode_check_input(msgs[0])
+    assert merged["principal"]["id"] == "b" and merged["principal"]["roles"] == ["x", "y"] and merged["resource"]["id"] == "2"
     # the host road reads the same request the same way
     lt = lower_rule_table(store_rule_table(), GLOBALS)
     it = IngestTable(lt.blob)
@@ -127,6 +156,46 @@ def test_unusual_but_valid_encodings():
     dev = it.flatten_pb(*wire.pack_messages(msgs), sort=0)
     for name in ("req_u32", "roles", "tuple_action", "col_tag", "col_val"):
         assert np.array_equal(getattr(host, name), getattr(dev, name)), name
+
+
+def test_a_message_field_named_twice_is_merged_not_replaced():
+    """Requests of the service cases re-encoded so that the principal and every entry's resource arrive in TWO pieces (identity and roles
+    first, attributes - one of them overridden - later): both roads must read them as the canonical request they merge to."""
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    it = IngestTable(lt.blob)
+    ld = wire._ld
+    n = 0
+    for group in _cases()[:10]:
+        p = group[0]["principal"]
+        attr = dict(p.get("attr") or {})
+        first_half = wire.encode_principal({"id": p["id"], "roles": p["roles"][:1], "policyVersion": p.get("policyVersion", ""),
+                                            "attr": dict({k: "overridden" for k in list(attr)[:1]})})
+        second_half = wire.encode_principal({"roles": p["roles"][1:], "attr": attr, "scope": p.get("scope", "")})
+        entries_split, entries_canon = b"", b""
+        for i in group:
+            r = i["resource"]
+            ra = dict(r.get("attr") or {})
+            ka, kb = dict(list(ra.items())[: len(ra) // 2]), dict(list(ra.items())[len(ra) // 2:])
+            a = wire.encode_resource({"kind": r["kind"], "id": "to-be-replaced", "attr": ka})
+            b = wire.encode_resource({"id": r["id"], "policyVersion": r.get("policyVersion", ""), "scope": r.get("scope", ""), "attr": kb})
+            acts = b"".join(ld(1, x.encode()) for x in i["actions"])
+            entries_split += ld(4, ld(2, a) + acts + ld(2, b))
+            entries_canon += ld(4, acts + ld(2, wire.encode_resource(r)))
+        rid = ld(1, group[0].get("requestId", "").encode()) if group[0].get("requestId") else b""
+        split = rid + ld(3, first_half) + entries_split + ld(3, second_half)
+        canon = rid + ld(3, wire.encode_principal(p)) + entries_canon
+        (m_split, _, _), (m_canon, _, _) = sim_split([split]), sim_split([canon])
+        assert len(m_split) == len(m_canon) == len(group)
+        for x, y in zip(m_split, m_canon):
+            dx, dy = _decode_check_input(x), _decode_check_input(y)
+            assert dx == dy, (dx, dy)
+        h_split, h_canon = it.flatten_request_pb(split, sort=0), it.flatten_request_pb(canon, sort=0)
+        d_split = it.flatten_pb(*wire.pack_messages(m_split), sort=0)
+        for name in ("req_u32", "roles", "tuple_action", "col_tag"):
+            assert np.array_equal(getattr(h_split, name), getattr(h_canon, name)), name
+            assert np.array_equal(getattr(h_split, name), getattr(d_split, name)), name
+        n += len(group)
+    assert n > 10
 
 
 def test_corrupted_requests_are_refused_like_on_the_host_road():
