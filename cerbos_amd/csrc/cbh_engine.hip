@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -71,6 +72,12 @@ static struct Engine {
 
 // CBH_TRACE=1: one line per one-shot call on stderr (path taken, phase times) - measurement aid
 static bool trace_on() { static const bool on = getenv("CBH_TRACE") != nullptr; return on; }
+// ... and, for the sliced road (cbh_wire_check_pb), the phases of every slice's thread: marks of (label, microseconds since the call began)
+struct WireMarks { std::chrono::steady_clock::time_point t0; std::vector<std::pair<const char*, double>> v; };
+static thread_local WireMarks* tl_marks = nullptr;
+static inline void wmark(const char* label) {
+  if (tl_marks) tl_marks->v.push_back({label, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tl_marks->t0).count()});
+}
 static double now_us() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
 // CBH_SPIN=1: wait for a stream by polling hipStreamQuery instead of hipStreamSynchronize
 static hipError_t stream_wait(hipStream_t s) {
@@ -180,6 +187,12 @@ struct Replica {   // the table on one device
   // ... and a page-locked staging block (the call's offsets, defaults and statistics cross PCIe from / to it: a pageable source makes
   // hipMemcpyAsync a blocking, staged copy)
   std::vector<std::pair<void*, size_t>> wpinned_idle;
+  // The link's two directions, a stream each.  A stream's copies go to ONE copy engine, whatever their direction: with every slice
+  // of a call uploading and downloading on its own stream the link carried one copy at a time (tools/pcie_duplex2.hip: 4 x (12 MB up,
+  // 10 MB down) 1.55 ms a stream per slice, 0.94 ms with one upload stream and one download stream - the link is full duplex, the
+  // engines are per stream).  The bulk copies of the wire road go here; a batch's own stream waits for / is waited for by events.
+  hipStream_t up_stream = nullptr, down_stream = nullptr; bool link_streams_tried = false;
+  std::vector<hipEvent_t> wevents_idle;
 };
 
 struct cbh_table {
@@ -206,7 +219,8 @@ struct cbh_device_batch {
   std::vector<std::pair<void*, size_t>> allocs;   // (block, capacity) taken from the replica's pool
   // a batch the device flattened (cbh_wire_flatten): where the response's strings sit in the messages
   bool wire = false; bool own_wire_stream = false; u32* w_in_span = nullptr; u32* w_act_span = nullptr;
-  void* w_pinned = nullptr; size_t w_pinned_cap = 0;
+  void* w_pinned = nullptr; size_t w_pinned_cap = 0, w_pin_out_at = 0;
+  hipEvent_t w_ev[2] = {nullptr, nullptr};   // (the link streams) upload landed / the outputs are written; download landed
   const u32* w_req_input = nullptr;   // the request words in INPUT order (dev.req_u32 may be the grouped copy)
   u32 trail_groups = 0; u32* trail_grp = nullptr;   // cbh_batch_set_trail: groups of out.eff_pol, the requests' groups
   const u32* w_inv = nullptr;         // grouped by route: input -> position of its per-request results; else null
@@ -224,6 +238,8 @@ static void replica_destroy(Replica* r) {
   for (auto& sl : r->ring) for (auto& e : sl.ev) if (e) (void)hipEventDestroy(e);
   for (hipStream_t ws : r->wstreams_all) { (void)hipStreamSynchronize(ws); (void)hipStreamDestroy(ws); }
   for (auto& pb : r->wpinned_idle) (void)hipHostFree(pb.first);
+  for (hipStream_t ls : {r->up_stream, r->down_stream}) if (ls) { (void)hipStreamSynchronize(ls); (void)hipStreamDestroy(ls); }
+  for (hipEvent_t e : r->wevents_idle) (void)hipEventDestroy(e);
   if (r->image && r->owns_image) (void)hipFree(r->image);
   for (void* p : {(void*)r->w_tix, (void*)r->w_scope_of_sid, (void*)r->w_cols, (void*)r->w_col_keys, (void*)r->w_name_off, (void*)r->w_name_bytes}) if (p) (void)hipFree(p);
   for (auto& a : r->pool_free) (void)hipFree(a.first);
@@ -496,10 +512,11 @@ extern "C" void cbh_batch_release(cbh_device_batch* b) {
     std::lock_guard<std::mutex> lk(b->rep->pool_mu);
     for (auto& a : b->allocs) b->rep->pool_free.push_back(a);
   }
-  if (b->own_wire_stream || b->w_pinned) {
+  if (b->own_wire_stream || b->w_pinned || b->w_ev[0] || b->w_ev[1]) {
     std::lock_guard<std::mutex> lk(b->rep->wstream_mu);
     if (b->own_wire_stream) b->rep->wstreams_idle.push_back(b->stream);
     if (b->w_pinned) b->rep->wpinned_idle.push_back({b->w_pinned, b->w_pinned_cap});
+    for (hipEvent_t e : b->w_ev) if (e) b->rep->wevents_idle.push_back(e);
   }
   delete b;
   cbh_table_release(t);   // the reference the batch held
@@ -912,9 +929,50 @@ static u32 wire_lds_cap(size_t want, int needs_mode) {
   u32 c = 4096; while (c < want && c < 49152u) c <<= 1;
   return c > 49152u ? 49152u : c;
 }
+// The fill kernel's block of messages: staged in LDS - where the dependent loads of the parse are several times shorter than in L2 -
+// when the call's LARGEST block (WireStats.max_block) leaves a CU several waves (up to CBH_WIRE_FILL_LDS_MAX bytes, in 1 KB steps);
+// a call of larger messages parses them in place (the same code on a global pointer: cbh_wire_fill_kernel).
+// CBH_WIRE_LDS=0/1: never; CBH_WIRE_FILL_LDS_MAX=bytes: the bound.
+static u32 wire_fill_lds_cap(u32 max_block) {
+  static const int mode = [] { const char* e = getenv("CBH_WIRE_LDS"); return e ? atoi(e) : 2; }();
+  static const u32 most = [] { const char* e = getenv("CBH_WIRE_FILL_LDS_MAX"); return e ? (u32)atoi(e) : 32768u; }();
+  if (mode < 2 || max_block == 0 || max_block > most) return 0;
+  const u32 c = (max_block + 16u + CBH_WIRE_SLACK + 1023u) & ~1023u;
+  return c > most ? 0u : c;
+}
+static bool is_pinned(const void* p);
+// the replica's link streams (made on first use; CBH_WIRE_LINK_STREAMS=0: every batch copies on its own stream, as before)
+static bool wire_link_streams(Replica* rep) {
+  static const bool on = [] { const char* e = getenv("CBH_WIRE_LINK_STREAMS"); return !(e && *e == '0'); }();
+  if (!on) return false;
+  std::lock_guard<std::mutex> lk(rep->wstream_mu);
+  if (!rep->link_streams_tried) {
+    rep->link_streams_tried = true;
+    if (hipStreamCreateWithFlags(&rep->up_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); rep->up_stream = nullptr; }
+    if (rep->up_stream && hipStreamCreateWithFlags(&rep->down_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); rep->down_stream = nullptr; }
+    if (!rep->down_stream && rep->up_stream) { (void)hipStreamDestroy(rep->up_stream); rep->up_stream = nullptr; }
+  }
+  return rep->up_stream != nullptr;
+}
+static hipEvent_t wire_event(cbh_device_batch* b, int which) {
+  if (!b->w_ev[which]) {
+    std::lock_guard<std::mutex> lk(b->rep->wstream_mu);
+    if (!b->rep->wevents_idle.empty()) { b->w_ev[which] = b->rep->wevents_idle.back(); b->rep->wevents_idle.pop_back(); }
+    else if (hipEventCreateWithFlags(&b->w_ev[which], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); b->w_ev[which] = nullptr; }
+  }
+  return b->w_ev[which];
+}
+// n_words of device memory -> the batch's page-locked block (cbh_wire_publish_kernel: no copy engine); read after a synchronise
+static int wire_publish(cbh_device_batch* b, const void* d_src, void* pinned_dst, u32 n_words) {
+  WirePublishArgs pa; pa.src = static_cast<const u32*>(d_src); pa.dst = static_cast<u32*>(pinned_dst); pa.n_words = n_words; pa.pad = 0;
+  hipLaunchKernelGGL(cbh_wire_publish_kernel, dim3(1), dim3(64), 0, b->stream, pa);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static WireStats* wire_stats_land(cbh_device_batch* b) { return static_cast<WireStats*>(b->w_pinned) + 1; }   // (slot 1 of the batch's page-locked block)
 static int wire_stats_read(cbh_device_batch* b, const WireStats* d_stats, WireStats& st) {
-  WireStats* land = static_cast<WireStats*>(b->w_pinned) + 1;   // (slot 1 of the batch's page-locked block)
-  HIPCHK(hipMemcpyAsync(land, d_stats, sizeof(st), hipMemcpyDeviceToHost, b->stream));
+  WireStats* land = wire_stats_land(b);
+  if (wire_publish(b, d_stats, land, (u32)(sizeof(st) / 4)) != 0) return -1;
   HIPCHK(hipStreamSynchronize(b->stream));
   st = *land;
   return 0;
@@ -983,13 +1041,14 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
     else if (rep->wstreams_made < Replica::MAX_WIRE_STREAMS && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess) { ++rep->wstreams_made; rep->wstreams_all.push_back(b->stream); b->own_wire_stream = true; }
   }
   {
-    const size_t want = 2 * sizeof(WireStats) + dv.size() + ds.size() + 6 + globals_len + 64 + ((size_t)n + 1) * 8;
+    // (two WireStats, the call's tail strings, the messages' offsets - later the outputs' -, the outputs' flags, two route words)
+    const size_t want = 2 * sizeof(WireStats) + dv.size() + ds.size() + 6 + globals_len + 64 + ((size_t)n + 1) * 8 + (size_t)n + 64 + 64;
     std::lock_guard<std::mutex> lk(rep->wstream_mu);
     for (size_t k = 0; k < rep->wpinned_idle.size(); ++k)
       if (rep->wpinned_idle[k].second >= want) { b->w_pinned = rep->wpinned_idle[k].first; b->w_pinned_cap = rep->wpinned_idle[k].second; rep->wpinned_idle[k] = rep->wpinned_idle.back(); rep->wpinned_idle.pop_back(); break; }
     if (!b->w_pinned) {
       size_t cap = 1 << 16; while (cap < want) cap <<= 1;
-      if (hipHostMalloc(&b->w_pinned, cap, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); b->w_pinned = nullptr; }
+      if (hipHostMalloc(&b->w_pinned, cap, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); b->w_pinned = nullptr; }   // (kernels write it: wire_publish)
       b->w_pinned_cap = cap;
     }
   }
@@ -998,10 +1057,16 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
   hipStream_t s = b->stream;
   auto bail = [&](int rc) { cbh_batch_release(b); return rc; };
   // (a sliced call, WireChain) the big upload of this slice goes behind its predecessor's
-  auto chain_wait = [&]() -> bool {
+  auto chain_wait = [&](bool enqueue_order_only) -> bool {
     if (chain && chain->prev_recorded) {   // (the predecessor's thread has enqueued the record by now, or is about to)
       while (!chain->prev_recorded->load(std::memory_order_acquire)) std::this_thread::yield();
-      if (chain->wait && hipStreamWaitEvent(s, chain->wait, 0) != hipSuccess) { fail("cbh_wire_flatten: hipStreamWaitEvent failed"); return false; }
+      if (enqueue_order_only) return true;   // (one upload stream: its order is the order of the calls)
+      // The successor's upload is handed to the copy engines only when the predecessor's has LANDED (a wait on the host, not a
+      // dependency on the device): uploads queued ahead of time are spread over the engines, and a slice's answers - a copy the
+      // other way, asked for later - then wait behind them all (measured: downloads began when the last upload had ended, although
+      // the link carries both directions at once: tools/pcie_duplex.hip).  CBH_WIRE_CHAIN_DEVICE=1: the dependency on the device.
+      static const bool on_device = getenv("CBH_WIRE_CHAIN_DEVICE") != nullptr;
+      if (chain->wait && (on_device ? hipStreamWaitEvent(s, chain->wait, 0) : hipEventSynchronize(chain->wait)) != hipSuccess) { fail("cbh_wire_flatten: waiting for the previous slice's upload failed"); return false; }
     }
     return true;
   };
@@ -1023,13 +1088,19 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
     rq |= dalloc(b, d_first, (size_t)nr + 1); rq |= dalloc(b, d_fbyte, (size_t)nr + 1);
     if (reqs->aux_offsets) { rq |= dalloc(b, d_aux, (size_t)atotal + 8); rq |= dalloc(b, d_aoff, (size_t)nr + 1); }
     if (rq != 0) return bail(-1);
-    if (!chain_wait()) return bail(-1);
-    if ((rtotal && hipMemcpyAsync(d_req, bytes, rtotal, hipMemcpyHostToDevice, s) != hipSuccess) ||
-        (nr && hipMemcpyAsync(d_roff, offsets, ((size_t)nr + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess) ||
-        (atotal && hipMemcpyAsync(d_aux, reqs->aux, atotal, hipMemcpyHostToDevice, s) != hipSuccess) ||
-        (reqs->aux_offsets && nr && hipMemcpyAsync(d_aoff, reqs->aux_offsets, ((size_t)nr + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess))
+    hipEvent_t ev_rq = wire_link_streams(rep) ? wire_event(b, 0) : nullptr;   // (the replica's upload stream, as for CheckInputs below)
+    hipStream_t rs = ev_rq ? rep->up_stream : s;
+    if (!chain_wait(ev_rq != nullptr)) return bail(-1);
+    if ((rtotal && hipMemcpyAsync(d_req, bytes, rtotal, hipMemcpyHostToDevice, rs) != hipSuccess) ||
+        (nr && hipMemcpyAsync(d_roff, offsets, ((size_t)nr + 1) * 8, hipMemcpyHostToDevice, rs) != hipSuccess) ||
+        (atotal && hipMemcpyAsync(d_aux, reqs->aux, atotal, hipMemcpyHostToDevice, rs) != hipSuccess) ||
+        (reqs->aux_offsets && nr && hipMemcpyAsync(d_aoff, reqs->aux_offsets, ((size_t)nr + 1) * 8, hipMemcpyHostToDevice, rs) != hipSuccess))
       { fail("cbh_wire_flatten_requests: upload failed"); return bail(-1); }
-    chain_record();
+    if (ev_rq) {
+      const bool ok = hipEventRecord(ev_rq, rs) == hipSuccess;
+      if (chain) chain->done();
+      if (!ok || hipStreamWaitEvent(s, ev_rq, 0) != hipSuccess) { fail("cbh_wire_flatten_requests: upload failed"); return bail(-1); }
+    } else chain_record();
     q.req = d_req; q.roff = d_roff; q.n = nr; q.end = (u32)rtotal; q.aux = d_aux; q.aoff = reqs->aux_offsets ? d_aoff : nullptr; q.aux_end = atotal;
     if (nr) hipLaunchKernelGGL(cbh_wire_req_count_kernel, dim3((nr + CBH_BLOCK - 1) / CBH_BLOCK), dim3(CBH_BLOCK), 0, s, q);
     std::vector<u32> h_inputs((size_t)nr + 1, 0), h_first((size_t)nr + 1, 0); std::vector<u64> h_bytes((size_t)nr + 1, 0), h_fbyte((size_t)nr + 1, 0);
@@ -1099,26 +1170,76 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
   *pin_st = st;
   std::memcpy(pin_tail, tail.data(), tail.size());
   if (!reqs) { if (n) std::memcpy(pin_off, offsets, ((size_t)n + 1) * 8); else pin_off[0] = 0; }
+  b->w_pin_out_at = (size_t)(reinterpret_cast<u8*>(pin_off) - pin);   // (cbh_wire_outputs: the outputs' offsets and flags land here, written by the kernels)
+  // the uploads: on the replica's upload stream (one copy engine for this direction, the slices of a call in their order - the
+  // chain only orders the ENQUEUEING then), the batch's own stream takes over behind an event; else on the batch's stream
+  hipEvent_t ev_up = (!reqs && wire_link_streams(rep)) ? wire_event(b, 0) : nullptr;
+  hipStream_t us = ev_up ? rep->up_stream : s;
   if (!reqs) {
-    if (!chain_wait()) return bail(-1);
-    if (total && hipMemcpyAsync(d_msg, bytes, total, hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
-    chain_record();
+    if (!chain_wait(ev_up != nullptr)) return bail(-1);
+    if (total && hipMemcpyAsync(d_msg, bytes, total, hipMemcpyHostToDevice, us) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
+    if (!ev_up) chain_record();
   }
+  // (the small ones on the batch's own stream: on the upload stream every one of them would be a gap between two slices' messages)
   if (hipMemcpyAsync(d_msg + total, pin_tail, tail.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
       (!reqs && hipMemcpyAsync(d_moff, pin_off, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess) ||
       hipMemcpyAsync(d_stats, pin_st, sizeof(st), hipMemcpyHostToDevice, s) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
-  if (nw) hipLaunchKernelGGL(cbh_wire_count_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, a);
+  if (ev_up) {
+    const bool ok = hipEventRecord(ev_up, us) == hipSuccess;
+    if (chain) chain->done();   // (the successor may enqueue its uploads now)
+    if (!ok || hipStreamWaitEvent(s, ev_up, 0) != hipSuccess) { fail("cbh_wire_flatten: upload failed"); return bail(-1); }
+  }
+  {   // the count kernel's staging block: the call's average block and a half (the fill is sized by the largest, which the count finds)
+    const u64 avg_block = n ? total / n * 64u : 0u;
+    a.lds_cap = wire_fill_lds_cap((u32)std::min<u64>(avg_block + avg_block / 2u + 256u, 0xFFFFFFFFull));
+  }
+  if (nw) hipLaunchKernelGGL(cbh_wire_count_kernel, dim3(nw), dim3(CBH_BLOCK), a.lds_cap, s, a);
+  wmark("uploads+count enqueued");
+  // Group the requests by route (cbh_wire.h cbh_wire_route_kernel ...): what the host flattener's routing sort does for the
+  // decision kernels' merged walk - launched behind every fill (launch_routes).  CBH_WIRE_GROUP=0: leave the batch in input order
+  // (measurement aid).
+  static const bool group_on = [] { const char* e = getenv("CBH_WIRE_GROUP"); return !(e && *e == '0'); }();
+  WireRouteArgs ra; std::memset(&ra, 0, sizeof(ra));
+  u32* pin_routes = reinterpret_cast<u32*>(static_cast<u8*>(b->w_pinned) + b->w_pinned_cap - 64);   // (the block's last words: routes in use, overflow flag)
+  const bool try_group = group_on && n >= 2u * CBH_BLOCK;
+  auto launch_routes = [&]() -> int {
+    if (!try_group) return 0;
+    if (!ra.rt_key) {
+      ra.n = n; ra.n_cols = ncol; ra.req_u32 = a.req_u32; ra.roles = a.roles; ra.col_tag = a.col_tag; ra.col_val = a.col_val;
+      ra.multi = &d_stats->multi_route;
+      int rr = 0;
+      rr |= dalloc(b, ra.rt_key, (size_t)CBH_WIRE_ROUTE_SLOTS + ((size_t)CBH_WIRE_ROUTE_SLOTS + 2 + 1) / 2);   // (the keys and, behind them, the counters: one memset)
+      ra.rt_cnt = reinterpret_cast<u32*>(ra.rt_key + CBH_WIRE_ROUTE_SLOTS);
+      ra.host_routes = pin_routes; ra.stats = d_stats; ra.host_stats = wire_stats_land(b);
+      rr |= dalloc(b, ra.slot, (size_t)n); rr |= dalloc(b, ra.rank, (size_t)n); rr |= dalloc(b, ra.inv, (size_t)n);
+      rr |= dalloc(b, ra.req_out, (size_t)CBH_RQ_NFIELDS * n); rr |= dalloc(b, ra.col_tag_out, (size_t)ncol * n); rr |= dalloc(b, ra.col_val_out, (size_t)ncol * n);
+      if (rr != 0) return -1;
+    }
+    if (hipMemsetAsync(ra.rt_key, 0, ((size_t)CBH_WIRE_ROUTE_SLOTS + ((size_t)CBH_WIRE_ROUTE_SLOTS + 2 + 1) / 2) * 8, s) != hipSuccess) return fail("cbh_wire_flatten: memset failed");
+    hipLaunchKernelGGL(cbh_wire_route_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, ra);
+    hipLaunchKernelGGL(cbh_wire_route_scan_kernel, dim3(1), dim3(CBH_BLOCK), 0, s, ra);   // (leaves the route words AND the fill's statistics with the host)
+    hipLaunchKernelGGL(cbh_wire_gather_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, ra);
+    HIPCHK(hipGetLastError());
+    return 0;
+  };
   u32 slots = cbh_wire_dict_slots(n), heap_cap = cbh_wire_heap_guess(total);
   u32 n_host_count = 0; bool have_outputs = false; u32 runs = 0;
   for (;;) {
     // (re)start from the scan: the dictionary is empty, the scan interns the call's default strings first
     rc = 0;
-    rc |= dalloc(b, a.lix, (size_t)slots); rc |= dalloc(b, a.lflags, (size_t)slots / 4 + 1);
-    if (rc != 0) return bail(-1);
-    a.lix_mask = slots - 1;
-    if (hipMemsetAsync(a.lix, 0, (size_t)slots * 8, s) != hipSuccess || hipMemsetAsync(a.lflags, 0, ((size_t)slots / 4 + 1) * 4, s) != hipSuccess) { fail("cbh_wire_flatten: memset failed"); return bail(-1); }
+    {   // the dictionary's words and, behind them, its flag bytes: one block, one memset
+      u64* dict = nullptr;
+      rc |= dalloc(b, dict, (size_t)slots + ((size_t)slots / 4 + 1 + 1) / 2);
+      if (rc != 0) return bail(-1);
+      a.lix = dict; a.lflags = reinterpret_cast<u32*>(dict + slots);
+      a.lix_mask = slots - 1;
+      if (hipMemsetAsync(dict, 0, ((size_t)slots + ((size_t)slots / 4 + 1 + 1) / 2) * 8, s) != hipSuccess) { fail("cbh_wire_flatten: memset failed"); return bail(-1); }
+    }
+    a.host_stats = wire_stats_land(b);   // (the scan kernel leaves the statistics there itself)
     hipLaunchKernelGGL(cbh_wire_scan_kernel, dim3(1), dim3(CBH_BLOCK), 0, s, a);
-    if (wire_stats_read(b, d_stats, st) != 0) return bail(-1);
+    if (hipStreamSynchronize(s) != hipSuccess) { fail("cbh_wire_flatten failed"); return bail(-1); }
+    st = *wire_stats_land(b);
+    wmark("counts known");
     if (!have_outputs) {
       n_host_count = st.n_host;
       if (st.first_bad != CBH_NONE) { bad_input(st.first_bad); return bail(-1); }
@@ -1141,20 +1262,27 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
       if (rc != 0) return bail(-1);
       a.heap_cap = heap_cap;
       // dynamic LDS: room for a wave's 64 messages (a quarter above the call's average; a wave whose block is larger parses in place)
-      a.lds_cap = wire_lds_cap(n ? (size_t)(total / n) * 80u + 256u : 0u, 2);
-      if (nw) hipLaunchKernelGGL(cbh_wire_fill_kernel, dim3(nw), dim3(CBH_BLOCK), a.lds_cap, s, a);
+      a.lds_cap = wire_fill_lds_cap(st.max_block);
+      if (nw && a.lds_cap) hipLaunchKernelGGL(cbh_wire_fill_lds_kernel, dim3(nw), dim3(CBH_BLOCK), cbh_wire_fill_cur_bytes(ncol) + a.lds_cap, s, a);
+      else if (nw) hipLaunchKernelGGL(cbh_wire_fill_kernel, dim3(nw), dim3(CBH_BLOCK), cbh_wire_fill_cur_bytes(ncol), s, a);
       ++runs;
-      if (wire_stats_read(b, d_stats, st) != 0) return bail(-1);
+      // what the fill wanted and the routing of what it wrote (for nothing, the rare time the fill is run again) - ONE wait for both
+      if (!try_group && wire_publish(b, d_stats, wire_stats_land(b), (u32)(sizeof(st) / 4)) != 0) return bail(-1);
+      if (launch_routes() != 0) return bail(-1);
+      wmark("fill+routes enqueued");
+      if (hipStreamSynchronize(s) != hipSuccess) { fail("cbh_wire_flatten failed"); return bail(-1); }
+      wmark("filled");
+      st = *wire_stats_land(b);
       if (st.flags & CBH_WF_DICT_FULL) { again = true; break; }
       if (st.heap_used <= heap_cap) break;
       heap_cap = st.heap_used;
-      WireStats reset = st; reset.heap_used = 0; reset.n_host = n_host_count; reset.flags = 0;
+      WireStats reset = st; reset.heap_used = 0; reset.n_host = n_host_count; reset.flags = 0; reset.route_lo = reset.route_hi = reset.multi_route = 0;
       if (wire_stats_write(b, d_stats, reset) != 0) return bail(-1);
     }
     if (!again) break;
     if (slots >= (1u << 30)) { fail("cbh_wire_flatten: the batch-local dictionary cannot grow further"); return bail(-1); }
     slots *= 4;
-    WireStats reset = st; reset.heap_used = 0; reset.n_host = n_host_count; reset.flags = 0;
+    WireStats reset = st; reset.heap_used = 0; reset.n_host = n_host_count; reset.flags = 0; reset.route_lo = reset.route_hi = reset.multi_route = 0;
     if (wire_stats_write(b, d_stats, reset) != 0) return bail(-1);
   }
   { const hipError_t le = hipGetLastError(); if (le != hipSuccess) { fail(std::string("cbh_wire_flatten: ") + hipGetErrorString(le)); return bail(-1); } }
@@ -1162,25 +1290,6 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
   info->n_tuples = st.n_tuples; info->n_host = st.n_host; info->dict_slots = slots; info->heap_len = st.heap_used; info->fill_runs = runs;
   if (st.first_bad != CBH_NONE) { bad_input(st.first_bad); return bail(-1); }
   if (st.n_host) { g_err = "cbh_wire_flatten: " + std::to_string(st.n_host) + " message(s) are the host flattener's (more than 64 actions, a resource kind to rewrite that no policy names, containers nested too deep)"; return bail(1); }
-  // Group the requests by route (cbh_wire.h cbh_wire_route_kernel ...): what the host flattener's routing sort does for the
-  // decision kernels' merged walk.  CBH_WIRE_GROUP=0: leave the batch in input order (measurement aid).
-  static const bool group_on = [] { const char* e = getenv("CBH_WIRE_GROUP"); return !(e && *e == '0'); }();
-  WireRouteArgs ra; std::memset(&ra, 0, sizeof(ra));
-  u32* pin_routes = reinterpret_cast<u32*>(static_cast<WireStats*>(b->w_pinned) + 1);   // (slot 1 of the page-locked block: two words)
-  const bool try_group = group_on && n >= 2u * CBH_BLOCK;
-  if (try_group) {
-    ra.n = n; ra.n_cols = ncol; ra.req_u32 = a.req_u32; ra.roles = a.roles; ra.col_tag = a.col_tag; ra.col_val = a.col_val;
-    rc = 0;
-    rc |= dalloc(b, ra.rt_key, (size_t)CBH_WIRE_ROUTE_SLOTS); rc |= dalloc(b, ra.rt_cnt, (size_t)CBH_WIRE_ROUTE_SLOTS + 2);
-    rc |= dalloc(b, ra.slot, (size_t)n); rc |= dalloc(b, ra.rank, (size_t)n); rc |= dalloc(b, ra.inv, (size_t)n);
-    rc |= dalloc(b, ra.req_out, (size_t)CBH_RQ_NFIELDS * n); rc |= dalloc(b, ra.col_tag_out, (size_t)ncol * n); rc |= dalloc(b, ra.col_val_out, (size_t)ncol * n);
-    if (rc != 0) return bail(-1);
-    if (hipMemsetAsync(ra.rt_key, 0, (size_t)CBH_WIRE_ROUTE_SLOTS * 8, s) != hipSuccess || hipMemsetAsync(ra.rt_cnt, 0, ((size_t)CBH_WIRE_ROUTE_SLOTS + 2) * 4, s) != hipSuccess) { fail("cbh_wire_flatten: memset failed"); return bail(-1); }
-    hipLaunchKernelGGL(cbh_wire_route_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, ra);
-    hipLaunchKernelGGL(cbh_wire_route_scan_kernel, dim3(1), dim3(CBH_BLOCK), 0, s, ra);
-    hipLaunchKernelGGL(cbh_wire_gather_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, ra);
-    if (hipMemcpyAsync(pin_routes, ra.rt_cnt + CBH_WIRE_ROUTE_SLOTS, 8, hipMemcpyDeviceToHost, s) != hipSuccess) { fail("cbh_wire_flatten: download failed"); return bail(-1); }
-  }
   BatchDev& d = b->dev;
   d.n_requests = n; d.n_tuples = st.n_tuples; d.n_roles = st.n_roles; d.n_columns = ncol; d.n_strings = slots; d.heap_len = st.heap_used;
   d.req_lo = 0; d.req_hi = n;
@@ -1202,7 +1311,7 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
   rc |= dalloc(b, b->out.edr, (size_t)n); rc |= dalloc(b, b->d_args, 1);
   if (rc != 0) return bail(-1);
   if (globs && hipMemsetAsync(d.gbits, 0, (size_t)3 * slots * sizeof(u64), s) != hipSuccess) { fail("cbh_wire_flatten: memset failed"); return bail(-1); }
-  if (hipStreamSynchronize(s) != hipSuccess) { fail("cbh_wire_flatten failed"); return bail(-1); }
+  { const hipError_t le = hipGetLastError(); if (le != hipSuccess) { fail(std::string("cbh_wire_flatten: ") + hipGetErrorString(le)); return bail(-1); } }
   if (try_group && pin_routes[1] == 0u && pin_routes[0] > 1u) {   // grouped (not: a full route table, or one route - nothing to group)
     d.req_u32 = ra.req_out; d.col_tag = ra.col_tag_out; d.col_val = ra.col_val_out;
     b->w_inv = ra.inv;
@@ -1243,6 +1352,7 @@ extern "C" int cbh_wire_outputs(cbh_table* t, cbh_device_batch* b, uint8_t* byte
   const BatchDev& d = b->dev;
   const u32 n = d.n_requests, nw = (n + 63u) / 64u;
   *need = 0;
+  const bool fresh_ostats = !b->w_sizes;
   if (!b->w_sizes) {
     int rc = 0;
     rc |= dalloc(b, b->w_sizes, (size_t)n + 1); rc |= dalloc(b, b->w_wavesum, (size_t)nw + 1); rc |= dalloc(b, b->w_waveoff, (size_t)nw + 1);
@@ -1260,14 +1370,22 @@ extern "C" int cbh_wire_outputs(cbh_table* t, cbh_device_batch* b, uint8_t* byte
   a.sizes = b->w_sizes; a.wavesum = b->w_wavesum; a.waveoff = b->w_waveoff; a.stats = b->w_ostats; a.out_off = b->w_out_off; a.out_flags = b->w_out_flags;
   WireOutStats st; std::memset(&st, 0, sizeof(st));
   static_assert(sizeof(WireOutStats) <= sizeof(WireStats), "the batch's page-locked block has two WireStats slots");
+  // The outputs' offsets and flags are written by the kernels straight into the batch's page-locked block (where the messages'
+  // offsets went up from: long since on the device) when it has the room - two copies less on the link per call, and none that
+  // waits behind another slice's bulk copy; the caller's arrays are filled from there.
+  u8* pin = static_cast<u8*>(b->w_pinned);
+  const size_t off_bytes = ((size_t)n + 1) * 8, flags_at = b->w_pin_out_at + ((off_bytes + 63) & ~(size_t)63);
+  const bool direct = pin && b->w_pin_out_at && flags_at + (size_t)n + 64 + 64 <= b->w_pinned_cap;
+  u64* pin_off = direct ? reinterpret_cast<u64*>(pin + b->w_pin_out_at) : nullptr;
+  u8* pin_flags = direct ? pin + flags_at : nullptr;
+  if (direct) { a.out_off = pin_off; a.out_flags = pin_flags; }
   if (b->w_total_known) { st.total = b->w_total; st.errors = b->w_out_errors; }   // sizes and offsets of these results are on the device already
   else {
-    WireOutStats* pin_st = static_cast<WireOutStats*>(b->w_pinned);   // (page-locked: the copies below never block on staging)
-    *pin_st = st;
-    HIPCHK(hipMemcpyAsync(b->w_ostats, pin_st, sizeof(st), hipMemcpyHostToDevice, s));
+    WireOutStats* pin_st = static_cast<WireOutStats*>(b->w_pinned);   // (page-locked slot 0; the scan kernel writes it and clears the error bits behind itself)
+    if (fresh_ostats) HIPCHK(hipMemsetAsync(b->w_ostats, 0, sizeof(st), s));
+    a.host_stats = pin_st;
     if (nw) hipLaunchKernelGGL(cbh_wire_out_size_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, a);
     hipLaunchKernelGGL(cbh_wire_out_scan_kernel, dim3(1), dim3(CBH_BLOCK), 0, s, a);
-    HIPCHK(hipMemcpyAsync(pin_st, b->w_ostats, sizeof(st), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     st = *pin_st;
     b->w_total_known = true; b->w_total = st.total; b->w_out_errors = st.errors;
@@ -1276,17 +1394,44 @@ extern "C" int cbh_wire_outputs(cbh_table* t, cbh_device_batch* b, uint8_t* byte
   if (st.errors & 2u) return fail("cbh_wire_outputs: a CheckOutput exceeds 16 MB");
   *need = (size_t)st.total;
   if (st.total > cap) { g_err = "cbh_wire_outputs: the output buffer is too small"; return 2; }
-  u8* d_out = nullptr;
-  if (dalloc(b, d_out, (size_t)st.total + 1) != 0) return -1;
-  a.out = d_out;
+  // Where the bytes are written: into device memory and one copy back - or, with CBH_WIRE_OUT_DIRECT=1, into the CALLER's buffer when
+  // that is page-locked memory the device can reach (the kernel's 16-byte stores cross the link themselves).  Measured on the sliced
+  // road (C2, 250 000 messages per call): the direct stores run at 43 GB/s and slow the copy engine's uploads and the other slices'
+  // kernels beside them - 2.17 ms a call against 1.94 ms with the copy (tools/pcie_duplex.hip: engine upload + kernel download
+  // 1.16 ms, both by the engines 0.92 ms) - so the copy is the default.
+  static const bool direct_on = [] { const char* e = getenv("CBH_WIRE_OUT_DIRECT"); return e && *e == '1'; }();
+  u8* d_out = nullptr; u8* host_out = nullptr;
+  if (direct_on && st.total && is_pinned(bytes) && hipHostGetDevicePointer((void**)&host_out, bytes, 0) != hipSuccess) { (void)hipGetLastError(); host_out = nullptr; }
+  if (host_out) {
+    a.out_bias = (u32)(reinterpret_cast<uintptr_t>(host_out) & 15u);
+    a.out = host_out - a.out_bias;
+  } else {
+    if (dalloc(b, d_out, (size_t)st.total + 1) != 0) return -1;
+    a.out = d_out; a.out_bias = 0;
+  }
   a.lds_cap = wire_lds_cap(n ? (size_t)(st.total / n) * 80u + 256u : 0u, 1);
   if (nw) hipLaunchKernelGGL(cbh_wire_out_write_kernel, dim3(nw), dim3(CBH_BLOCK), a.lds_cap, s, a);
-  if (st.total) HIPCHK(hipMemcpyAsync(bytes, d_out, (size_t)st.total, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipMemcpyAsync(offsets, b->w_out_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, s));
-  if (flags && n) HIPCHK(hipMemcpyAsync(flags, b->w_out_flags, (size_t)n, hipMemcpyDeviceToHost, s));
+  // the bytes' way back: on the replica's download stream (the copy engine of that direction), behind an event of the kernel
+  hipEvent_t ev_w = (st.total && d_out && wire_link_streams(rep)) ? wire_event(b, 0) : nullptr, ev_d = ev_w ? wire_event(b, 1) : nullptr;
+  if (ev_w && ev_d && hipEventRecord(ev_w, s) == hipSuccess && hipStreamWaitEvent(rep->down_stream, ev_w, 0) == hipSuccess) {
+    HIPCHK(hipMemcpyAsync(bytes, d_out, (size_t)st.total, hipMemcpyDeviceToHost, rep->down_stream));
+    HIPCHK(hipEventRecord(ev_d, rep->down_stream));
+  } else {
+    ev_d = nullptr;
+    if (st.total && d_out) HIPCHK(hipMemcpyAsync(bytes, d_out, (size_t)st.total, hipMemcpyDeviceToHost, s));
+  }
+  if (!direct) {
+    HIPCHK(hipMemcpyAsync(offsets, b->w_out_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (flags && n) HIPCHK(hipMemcpyAsync(flags, b->w_out_flags, (size_t)n, hipMemcpyDeviceToHost, s));
+  }
   HIPCHK(hipStreamSynchronize(s));
+  if (ev_d) HIPCHK(hipEventSynchronize(ev_d));
   HIPCHK(hipGetLastError());
-  {   // the output block goes back to the pool now: a batch that is asked again allocates again
+  if (direct) {
+    std::memcpy(offsets, pin_off, off_bytes);
+    if (flags && n) std::memcpy(flags, pin_flags, (size_t)n);
+  }
+  if (d_out) {   // the output block goes back to the pool now: a batch that is asked again allocates again
     std::lock_guard<std::mutex> lk(rep->pool_mu);
     for (size_t i = b->allocs.size(); i-- > 0;) if (b->allocs[i].first == d_out) { rep->pool_free.push_back(b->allocs[i]); b->allocs.erase(b->allocs.begin() + (long)i); break; }
   }
@@ -1331,7 +1476,20 @@ static int wire_check_sliced(cbh_table* t, uint32_t device_index, const uint8_t*
     std::vector<uint64_t> off, ooff, aoff; std::vector<uint32_t> first; u32 n_in = 0, in_base = 0;
   };
   std::vector<Slice> sl(S);
-  for (u32 k = 0; k < S; ++k) { sl[k].lo = (u32)((u64)n * k / S); sl[k].hi = (u32)((u64)n * (k + 1) / S); }
+  // Even slices.  (A smaller LAST slice - what the call waits for at the end is that slice's road after the last message has gone up -
+  // was measured and lost: 1.98 ms a call against 1.79 ms, the larger slices in front delay everything behind them.
+  // CBH_WIRE_LAST_SLICE=percent of an even share for the last one.)
+  static const double last_share = [] { const char* e = getenv("CBH_WIRE_LAST_SLICE"); const double v = e ? atof(e) / 100.0 : 1.0; return v < 0.1 ? 0.1 : v > 1.0 ? 1.0 : v; }();
+  {
+    const double unit = (double)n / ((double)(S - 1) + (S > 1 ? last_share : 1.0));
+    u32 at = 0;
+    for (u32 k = 0; k < S; ++k) {
+      sl[k].lo = at;
+      at = (k + 1 == S) ? n : std::min<u32>(n, (u32)(unit * (double)(k + 1) + 0.5));
+      if (at < sl[k].lo) at = sl[k].lo;
+      sl[k].hi = at;
+    }
+  }
   // the slices' uploads in slice order (WireChain)
   if (device_index >= t->reps.size()) return fail("device index out of range");
   HIPCHK(hipSetDevice(t->reps[device_index]->device));
@@ -1402,8 +1560,10 @@ static int wire_check_sliced(cbh_table* t, uint32_t device_index, const uint8_t*
       if (trail_on(x, d_ep) != 0) { x.rc = -1; x.err = g_err; return; }
       q.flags |= CBH_F_WANT_EFFECTIVE_POLICIES;
     }
+    wmark("flattened");
     x.rc = cbh_check_resident(t, x.b, &q);
     if (x.rc != 0) { x.err = g_err; return; }
+    wmark("decision enqueued");
     if (d_ep && words && cnt) {
       if (hipMemcpyAsync(rm->effective_policies + (size_t)x.lo * words, d_ep, (size_t)cnt * words * 4, hipMemcpyDeviceToHost, x.b->stream) != hipSuccess ||
           hipStreamSynchronize(x.b->stream) != hipSuccess) { x.rc = fail("cbh_wire_check_requests_trail_pb: download failed"); x.err = g_err; return; }
@@ -1413,6 +1573,7 @@ static int wire_check_sliced(cbh_table* t, uint32_t device_index, const uint8_t*
     const int r = cbh_wire_outputs(t, x.b, nullptr, 0, x.ooff.data(), nullptr, &nd);   // cap 0: sizes only (2 = "too small" unless the slice has no output bytes)
     if (r != 0 && r != 2) { x.rc = r; x.err = g_err; return; }
     x.total = nd;
+    wmark("sizes known");
   };
   auto stage2 = [&](u32 k) {
     Slice& x = sl[k];
@@ -1420,6 +1581,7 @@ static int wire_check_sliced(cbh_table* t, uint32_t device_index, const uint8_t*
     x.rc = cbh_wire_outputs(t, x.b, out_bytes + x.base, x.total, x.ooff.data(), out_flags ? out_flags + x.in_base : nullptr, &nd);
     if (x.rc != 0) { x.err = g_err; return; }
     for (u32 i = 0; i <= x.n_in; ++i) out_offsets[x.in_base + i] = x.ooff[i] + x.base;
+    wmark("written + copied back");
   };
   // A slice writes as soon as the slices before it know their sizes (its base is their sum): no barrier between the stages, so
   // the first slice's answers are on their way back while the last slice's messages are still going up.  A slice that failed,
@@ -1428,7 +1590,12 @@ static int wire_check_sliced(cbh_table* t, uint32_t device_index, const uint8_t*
   for (auto& q : sized) q.store(0);
   std::atomic<int> overflow{0};
   const size_t inputs_cap = rm ? (out_offsets ? rm->out_inputs_cap : 0) : (size_t)n;
+  const auto call_t0 = std::chrono::steady_clock::now();
+  std::vector<WireMarks> marks(trace_on() ? S : 0);
   auto work = [&](u32 k) {
+    if (!marks.empty()) { marks[k].t0 = call_t0; tl_marks = &marks[k]; }
+    struct Untrace { ~Untrace() { tl_marks = nullptr; } } untrace;
+    wmark("thread runs");
     stage1(k);
     Slice& x = sl[k];
     sized[k].store(x.rc == 0 ? 1 : 2, std::memory_order_release);
@@ -1441,6 +1608,7 @@ static int wire_check_sliced(cbh_table* t, uint32_t device_index, const uint8_t*
       base += sl[j].total; in_base += sl[j].n_in;
     }
     x.base = base; x.in_base = in_base;
+    wmark("predecessors sized");
     if (base + x.total > out_cap || (size_t)in_base + x.n_in > inputs_cap) { overflow.store(1); return; }
     stage2(k);
   };
@@ -1449,6 +1617,14 @@ static int wire_check_sliced(cbh_table* t, uint32_t device_index, const uint8_t*
     for (u32 k = 1; k < S; ++k) th.emplace_back(work, k);
     work(0);
     for (auto& q : th) q.join();
+  }
+  if (!marks.empty()) {
+    const double end = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - call_t0).count();
+    for (u32 k = 0; k < S; ++k) {
+      std::string line = "[cbh] wire slice " + std::to_string(k) + ":";
+      for (auto& m : marks[k].v) { char buf[96]; std::snprintf(buf, sizeof(buf), "  %s %.0f", m.first, m.second); line += buf; }
+      std::fprintf(stderr, "%s  | joined %.0f us\n", line.c_str(), end);
+    }
   }
   auto release = [&] { for (auto& x : sl) if (x.b) { cbh_batch_release(x.b); x.b = nullptr; } };
   int rc = 0; std::string err;

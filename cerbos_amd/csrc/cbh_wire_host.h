@@ -34,14 +34,17 @@ static inline const char* cbh_wire_index_build(WireIndexHost& w, const uint8_t* 
   if (off[K] > sb->nbytes) return "image string bytes too short";
   size_t cap = 64;
   while (cap < 2 * (size_t)K) cap <<= 1;
-  w.tix.assign(cap, 0); w.tix_mask = (u32)cap - 1;
+  w.tix.assign(2 * cap, 0); w.tix_mask = (u32)cap - 1;    // slot i = tix[2 i], tix[2 i + 1] (cbh_wire.h w_table_sid)
   for (u32 i = 0; i < K; ++i) {
     if (off[i + 1] < off[i] || off[i + 1] > off[K]) return "image string offsets are not monotonic";
     const u32 hsh = cbh_wire_hash(bytes + off[i], off[i + 1] - off[i]);
     u32 at = hsh & w.tix_mask;
-    while (w.tix[at]) at = (at + 1) & w.tix_mask;
-    w.tix[at] = ((u64)hsh << 32) | (u64)(i + 1);
+    while (w.tix[2 * (size_t)at]) at = (at + 1) & w.tix_mask;
+    w.tix[2 * (size_t)at] = ((u64)hsh << 32) | (u64)(i + 1);
+    w.tix[2 * (size_t)at + 1] = ((u64)off[i] << 32) | (u64)(off[i + 1] - off[i]);
   }
+  // the device compares strings eight bytes at a time: the pool must be readable CBH_WIRE_SLACK bytes beyond its last string
+  if ((u64)sb->offset + off[K] + CBH_WIRE_SLACK > len) return "image ends within the device flattener's read-ahead of the string pool";
   w.scope_of_sid.assign(K ? K : 1, CBH_NONE);
   const u32* ssid = reinterpret_cast<const u32*>(image + ss->offset);
   for (u32 i = 0; i < ns; ++i) { if (ssid[i] >= K) return "image scope string id out of range"; w.scope_of_sid[ssid[i]] = i; }
@@ -61,6 +64,7 @@ static inline const char* cbh_wire_index_build(WireIndexHost& w, const uint8_t* 
       if (k < CBH_WIRE_MAX_KEYS) { col.key_off[k] = (u32)w.col_keys.size(); col.key_len[k] = l; w.col_keys.insert(w.col_keys.end(), p, p + l); }
       p += l;
     }
+    col.key_hash0 = nk ? cbh_wire_hash(w.col_keys.data() + col.key_off[0], col.key_len[0]) : 0u;
     w.cols.push_back(col);
   }
   w.scope_sid_offset = ss->offset; w.n_scopes = ns;
@@ -80,8 +84,8 @@ static inline const char* cbh_wire_index_build(WireIndexHost& w, const uint8_t* 
       *cnt_out = cnt;
     }
   } else return "image is missing the host name section";
-  if (w.name_bytes.empty()) w.name_bytes.push_back(0);
-  if (w.col_keys.empty()) w.col_keys.push_back(0);
+  w.name_bytes.insert(w.name_bytes.end(), CBH_WIRE_SLACK, 0);   // (read eight bytes at a time)
+  w.col_keys.insert(w.col_keys.end(), CBH_WIRE_SLACK, 0);
   if (w.cols.empty()) { WireCol z; memset(&z, 0, sizeof(z)); w.cols.push_back(z); }
   return nullptr;
 }

@@ -156,7 +156,7 @@ struct hs_event { int id; };
 typedef hs_stream* hipStream_t;
 typedef hs_event* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
-enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocPortable = 1 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocPortable = 1, hipHostMallocMapped = 2 };
 enum { hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
 struct hipPointerAttribute_t { int type; int device; void* devicePointer; void* hostPointer; };
 

@@ -110,7 +110,7 @@ static void fiber_main() {
   else if (g_wire_kind >= 4) { if (g_wire_kind == 4) cbh_wire_out_size_kernel(*g_woargs); else if (g_wire_kind == 5) cbh_wire_out_scan_kernel(*g_woargs); else cbh_wire_out_write_kernel(*g_woargs); }
   else if (g_wire_kind == 1) cbh_wire_count_kernel(*g_wargs);
   else if (g_wire_kind == 2) cbh_wire_scan_kernel(*g_wargs);
-  else if (g_wire_kind == 3) cbh_wire_fill_kernel(*g_wargs);
+  else if (g_wire_kind == 3) { if (g_wargs->lds_cap) cbh_wire_fill_lds_kernel(*g_wargs); else cbh_wire_fill_kernel(*g_wargs); }
   else if (g_trace) cbh_trace_kernel(*g_args, g_args);
   else g_kernel(*g_args, g_args);
   g_fibers[g_cur].done = true;
@@ -343,7 +343,13 @@ extern "C" int hostsim_wire_flatten(const void* blob, size_t len, const uint8_t*
   a.tix = wi.tix.data(); a.tix_mask = wi.tix_mask; a.scope_of_sid = wi.scope_of_sid.data();
   a.cols = wi.cols.data(); a.col_keys = wi.col_keys.data(); a.n_cols = meta[CBH_M_NCOLUMNS]; a.sens_cols = meta[CBH_M_SENS_COLS];
   a.msg = g_w.msg.data(); a.moff = g_w.moff.data(); a.n = n;
-  { const char* e = getenv("CBH_WIRE_LDS_CAP"); a.lds_cap = e ? (uint32_t)atoi(e) : 16384u; if (a.lds_cap > sizeof(cbh_dyn_lds)) a.lds_cap = sizeof(cbh_dyn_lds); }
+  // the fill kernel's staging block (behind its per-column cursors): CBH_WIRE_LDS_CAP bytes at most; by default calls alternate
+  // between "up to 16 KB" and "never" so that the suite parses every kind of message through both kernels
+  static uint32_t flip = 0;
+  uint32_t lds_most;
+  { const char* e = getenv("CBH_WIRE_LDS_CAP"); lds_most = e ? (uint32_t)atoi(e) : ((flip++ & 1u) ? 0u : 16384u);
+    const uint32_t room = (uint32_t)sizeof(cbh_dyn_lds) - cbh_wire_fill_cur_bytes(a.n_cols); if (lds_most > room) lds_most = room; }
+  a.lds_cap = 0;
   a.dver_off = (uint32_t)total; a.dver_len = (uint32_t)dv.size(); a.dscope_off = (uint32_t)(total + dv.size()); a.dscope_len = (uint32_t)ds.size();
   a.claims_off = (uint32_t)(total + dv.size() + ds.size());
   a.globals_off = a.claims_off + 6; a.globals_len = (uint32_t)globals_len;
@@ -352,6 +358,7 @@ extern "C" int hostsim_wire_flatten(const void* blob, size_t len, const uint8_t*
   WireStats st; cbh_wire_stats_init(st);
   a.stats = &st;
   g_wargs = &a;
+  a.lds_cap = lds_most;   // (the count kernel stages a wave's block when it fits, as the fill does)
   wire_launch(1, nw);
   uint32_t slots = dict_slots_hint ? dict_slots_hint : cbh_wire_dict_slots(n);
   uint32_t heap_cap = heap_hint ? heap_hint : cbh_wire_heap_guess(total);
@@ -359,7 +366,7 @@ extern "C" int hostsim_wire_flatten(const void* blob, size_t len, const uint8_t*
   for (;;) {
     g_w.dict.assign(slots, 0); g_w.dict_flags.assign(slots / 4 + 1, 0);
     a.lix = g_w.dict.data(); a.lix_mask = slots - 1; a.lflags = g_w.dict_flags.data();
-    st.flags = 0; st.heap_used = 0;
+    st.flags = 0; st.heap_used = 0; st.route_lo = st.route_hi = st.multi_route = 0;
     const uint32_t n_host0 = st.n_host;
     wire_launch(2, 1);
     g_w.req.assign((size_t)CBH_RQ_NFIELDS * n + 1, 0xDDDDDDDDu); g_w.roles.assign((size_t)st.n_roles + 1, 0xDDDDDDDDu);
@@ -369,6 +376,7 @@ extern "C" int hostsim_wire_flatten(const void* blob, size_t len, const uint8_t*
     g_w.in_span.assign((size_t)n * 2 * CBH_WSPAN_N + 1, 0); g_w.act_span.assign((size_t)st.n_tuples * 2 + 1, 0);
     a.req_u32 = g_w.req.data(); a.roles = g_w.roles.data(); a.tuple_action = g_w.tuple_action.data(); a.col_tag = g_w.col_tag.data(); a.col_val = g_w.col_val.data();
     a.heap_tag = g_w.heap_tag.data(); a.heap_val = g_w.heap_val.data(); a.heap_cap = heap_cap; a.in_span = g_w.in_span.data(); a.act_span = g_w.act_span.data();
+    a.lds_cap = (st.max_block && (uint64_t)st.max_block + 16u + CBH_WIRE_SLACK <= lds_most) ? lds_most : 0u;   // (cbh_engine.hip wire_fill_lds_cap)
     wire_launch(3, nw);
     ++runs;
     if (st.flags & CBH_WF_DICT_FULL) { if (slots >= (1u << 30)) { g_err = "dictionary cannot grow"; return -1; } slots *= 4; st.n_host = n_host0; continue; }
@@ -390,6 +398,7 @@ extern "C" int hostsim_wire_flatten(const void* blob, size_t len, const uint8_t*
     r.n = n; r.n_cols = a.n_cols; r.req_u32 = g_w.req.data(); r.roles = g_w.roles.data(); r.col_tag = g_w.col_tag.data(); r.col_val = g_w.col_val.data();
     g_w.rt_key.assign(CBH_WIRE_ROUTE_SLOTS, 0); g_w.rt_cnt.assign(CBH_WIRE_ROUTE_SLOTS + 2, 0); g_w.slot.assign(n, 0); g_w.rank.assign(n, 0); g_w.inv.assign(n, 0xDDDDDDDDu);
     g_w.req_g.assign((size_t)CBH_RQ_NFIELDS * n, 0xDDDDDDDDu); g_w.col_tag_g.assign((size_t)a.n_cols * n + 1, 0xDD); g_w.col_val_g.assign((size_t)a.n_cols * n + 1, 0);
+    r.multi = &st.multi_route;
     r.rt_key = g_w.rt_key.data(); r.rt_cnt = g_w.rt_cnt.data(); r.slot = g_w.slot.data(); r.rank = g_w.rank.data(); r.inv = g_w.inv.data();
     r.req_out = g_w.req_g.data(); r.col_tag_out = g_w.col_tag_g.data(); r.col_val_out = g_w.col_val_g.data();
     g_wrargs = &r;
@@ -452,7 +461,8 @@ extern "C" long long hostsim_wire_outputs(const void* blob, size_t len, const ui
   { const char* e = getenv("CBH_WIRE_LDS_CAP"); a.lds_cap = e ? (uint32_t)atoi(e) : 16384u; if (a.lds_cap > sizeof(cbh_dyn_lds)) a.lds_cap = sizeof(cbh_dyn_lds); }
   std::vector<uint32_t> sizes(n + 1, 0); std::vector<uint64_t> wavesum(nw + 1, 0), waveoff(nw + 1, 0);
   WireOutStats st{}; 
-  a.sizes = sizes.data(); a.wavesum = wavesum.data(); a.waveoff = waveoff.data(); a.stats = &st; a.out = out_bytes; a.out_off = out_off; a.out_flags = out_flags;
+  a.sizes = sizes.data(); a.wavesum = wavesum.data(); a.waveoff = waveoff.data(); a.stats = &st; a.out_off = out_off; a.out_flags = out_flags;
+  a.out_bias = (uint32_t)(reinterpret_cast<uintptr_t>(out_bytes) & 15u); a.out = out_bytes - a.out_bias;   // (as cbh_wire_outputs hands over a caller's page-locked buffer)
   g_woargs = &a;
   wire_launch(4, nw);
   wire_launch(5, 1);

@@ -21,7 +21,7 @@ class HsWire(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("n", "n_tuples", "n_roles", "n_columns", "dict_slots", "heap_len", "K", "fill_runs")] + \
                [(n, C.c_void_p) for n in ("req_u32", "roles", "tuple_action", "col_tag", "col_val", "heap_tag", "heap_val", "dict",
                                           "dict_flags", "in_span", "act_span", "msg", "status")] + \
-               [("stats", C.c_uint32 * 16)] + \
+               [("stats", C.c_uint32 * 20)] + \
                [(n, C.c_void_p) for n in ("req_grouped", "col_tag_grouped", "col_val_grouped", "inv")] + [("n_routes", C.c_uint32), ("pad", C.c_uint32)]
 
 

@@ -6,7 +6,7 @@ import sys
 
 cur, rows = None, []
 for line in open(sys.argv[1], errors="replace"):
-    m = re.search(r"remark: Function Name: (\S+)", line)
+    m = re.search(r"remark: (?:\S+: )?Function Name: (\S+)", line)
     if m:
         name = m.group(1)
         d = re.match(r"_Z(\d+)", name)
@@ -15,7 +15,7 @@ for line in open(sys.argv[1], errors="replace"):
         cur = {"name": name}
         rows.append(cur)
         continue
-    m = re.search(r"remark:\s+(\w[\w /\[\]]*?): (\d+)", line)
+    m = re.search(r"remark:\s+(?:\S+:\d+:\d+:\s+)?(\w[\w /\[\]]*?): (\d+)", line)
     if m and cur is not None:
         cur[m.group(1).strip()] = int(m.group(2))
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
