@@ -615,7 +615,8 @@ static CbhPlan plan_for(const TableDev& dev, u32 max_actions, u32 max_roles, boo
   return cbh_plan(dev.flags, dev.n_dr, has_globs, dev.gslots_generic, dev.gslots_all, max_actions, max_roles, plain_tags, eval_flags, no_flat, no_walk2,
                   force_staged ? 0xFFFFFFFFu : dev.max_bucket, no_walk2_wide, cbh_flat_use_masks(dev.segs, dev.max_bucket));
 }
-static bool pre_split_on() { static const bool on = [] { const char* e = getenv("CBH_PRE_SPLIT"); return e && atoi(e) != 0; }(); return on; }
+// (on by default since round 5: C5 11.8 -> 12.4 G decisions/s, C5W 7.61 -> 7.67, profiles/r05_presplit_ab.txt; CBH_PRE_SPLIT=0: the fused pre-pass)
+static bool pre_split_on() { static const bool on = [] { const char* e = getenv("CBH_PRE_SPLIT"); return e ? atoi(e) != 0 : true; }(); return on; }
 // Does the packed form of the column cache's tags (cbh_vm.h CBH_CC_DWORDS) let a CU hold more workgroups of `fn` than the wide one?
 // The runtime's occupancy figure for the kernel at either LDS size, kept per (kernel, size).  CBH_PACKED_TAGS=0/1 (tests,
 // measurement): never / always.
@@ -713,7 +714,7 @@ extern "C" int cbh_check_resident(cbh_table* t, cbh_device_batch* b, const cbh_p
   HIPCHK(hipSetDevice(rep->device));
   hipStream_t s = b->stream;
   b->w_total_known = false;   // (the sizes cbh_wire_outputs computed belong to the results this launch replaces)
-  // CBH_PRE_SPLIT=1 (to be measured: DESIGN §7): the walk's pre-pass as a collector and an interpreter over per-site lists - the lists
+  // The walk's pre-pass as a collector and an interpreter over per-site lists - the lists
   // live with the batch (slots x requests items).  Tables whose programs read runtime.effectiveDerivedRoles keep the fused pre-pass.
   if (pre_split_on() && !b->dev.site_cnt && b->dev.n_requests && (rep->dev.flags & CBH_MF_WALK2) && rep->dev.gslots_all &&
       !(rep->dev.flags & CBH_MF_USES_RUNTIME_EDR) && b->dev.gres) {
@@ -1155,7 +1156,7 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
   int rc = 0;
   if (!reqs) { rc |= dalloc(b, d_msg, (size_t)total + tail_room); rc |= dalloc(b, d_moff, (size_t)n + 1); }
   rc |= dalloc(b, a.cnt, (size_t)n + 1); rc |= dalloc(b, a.status, (size_t)n + 1);
-  rc |= dalloc(b, a.wavesum, 2 * (size_t)nw + 2); rc |= dalloc(b, a.waveoff, 2 * (size_t)nw + 2);
+  rc |= dalloc(b, a.wavesum, 4 * (size_t)nw + 4); rc |= dalloc(b, a.waveoff, 2 * (size_t)nw + 4);
   rc |= dalloc(b, d_stats, 1);
   if (rc != 0) return bail(-1);
   a.msg = d_msg; a.moff = d_moff; a.stats = d_stats;

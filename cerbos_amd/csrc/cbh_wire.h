@@ -79,7 +79,9 @@ struct WireArgs {
   // scratch
   CBH_G u32* cnt;         // [n] actions | roles << 8
   CBH_G u8* status;       // [n] CBH_WS_*
-  CBH_G u32* wavesum;     // [waves][2] actions, roles
+  CBH_G u32* wavesum;     // [waves][4] actions, roles, largest action count | largest role count << 16, bytes of the wave's block of messages
+                          // (reduced by the one wave of the scan kernel: an atomic per wave on one statistics word costs a launch of
+                          // 2 000 waves more than everything else it does)
   CBH_G u32* waveoff;     // [waves][2] exclusive
   CBH_G WireStats* stats;
   CBH_G WireStats* host_stats;   // page-locked host memory the device can write (or null): the scan kernel leaves a copy of `stats` there
@@ -472,6 +474,14 @@ __device__ __forceinline__ u32 w_wave_max(u32 x, u32 bits) {   // largest x of t
   return best;
 }
 
+#ifndef CBH_HOSTSIM
+typedef u32 w_v4 __attribute__((ext_vector_type(4)));
+#define W_LOAD4(dst, p) { const w_v4 t_ = *(const CBH_G w_v4*)(p); (dst)[0] = t_.x; (dst)[1] = t_.y; (dst)[2] = t_.z; (dst)[3] = t_.w; }
+#define W_STORE4(p, src) { w_v4 t_; t_.x = (src)[0]; t_.y = (src)[1]; t_.z = (src)[2]; t_.w = (src)[3]; *(CBH_G w_v4*)(p) = t_; }
+#else
+#define W_LOAD4(dst, p) { for (u32 q_ = 0; q_ < 4u; ++q_) (dst)[q_] = (p)[q_]; }
+#define W_STORE4(p, src) { for (u32 q_ = 0; q_ < 4u; ++q_) (p)[q_] = (src)[q_]; }
+#endif
 // The wave's block of messages src[0 .. need) -> LDS at `stage`: asynchronous 16-byte copies straight into LDS (global_load_lds_dwordx4:
 // destination = uniform base + lane * 16, no staging registers), every one of them in flight before the first has landed - a loop of
 // load / store pairs waits for HBM once per kilobyte, and these bytes have just come up over the link: none of them is in L2.
@@ -550,15 +560,16 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_count_kernel(WireArgs a)
   const u64 badm = wave_ballot(st == CBH_WS_BAD), hostm = wave_ballot(st == CBH_WS_HOST);
   if (lane == 0u) {
     const u32 w = blockIdx.x * (CBH_BLOCK / 64u) + threadIdx.x / 64u;
-    a.wavesum[2u * w] = ta; a.wavesum[2u * w + 1u] = tr;
+    // what the fill kernel would stage for this wave (offsets out of order: the call fails on them anyway)
+    const u64 blk = hi64 >= lo64 ? hi64 - (lo64 & ~15ull) : 0xFFFFFFFFull;
+    const u32 blk32 = blk > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)blk;
+#ifndef CBH_HOSTSIM
+    w_v4 rec; rec.x = ta; rec.y = tr; rec.z = wmax_a | (wmax_r << 16); rec.w = blk32;
+    *(CBH_G w_v4*)(a.wavesum + 4u * w) = rec;
+#else
+    a.wavesum[4u * w] = ta; a.wavesum[4u * w + 1u] = tr; a.wavesum[4u * w + 2u] = wmax_a | (wmax_r << 16); a.wavesum[4u * w + 3u] = blk32;
+#endif
     const u32 base = blockIdx.x * CBH_BLOCK + (threadIdx.x & ~63u);
-    {   // what the fill kernel would stage for this wave (offsets out of order: the call fails on them anyway)
-      const u64 blk = hi64 >= lo64 ? hi64 - (lo64 & ~15ull) : 0xFFFFFFFFull;
-      const u32 blk32 = blk > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)blk;
-      if (blk32 > a.stats->max_block) w_max32(&a.stats->max_block, blk32);
-    }
-    if (wmax_a > a.stats->max_actions) w_max32(&a.stats->max_actions, wmax_a);
-    if (wmax_r > a.stats->max_roles) w_max32(&a.stats->max_roles, wmax_r);
     if (wide) {
       w_min32(&a.stats->wide_lo, base + (u32)__builtin_ctzll(wide));
       w_max32(&a.stats->wide_hi, base + 64u - (u32)__builtin_clzll(wide));
@@ -572,14 +583,6 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_count_kernel(WireArgs a)
 // Every thread takes a run of consecutive waves; the runs' sums meet in LDS, thread 0 .. 63 of the first wave add them up by bit planes.
 // (a lane's run is read and written sixteen pairs per round trip: one wave, so what it costs is how often it waits)
 #define CBH_WIRE_SCAN_THREADS 64u
-#ifndef CBH_HOSTSIM
-typedef u32 w_v4 __attribute__((ext_vector_type(4)));
-#define W_LOAD4(dst, p) { const w_v4 t_ = *(const CBH_G w_v4*)(p); (dst)[0] = t_.x; (dst)[1] = t_.y; (dst)[2] = t_.z; (dst)[3] = t_.w; }
-#define W_STORE4(p, src) { w_v4 t_; t_.x = (src)[0]; t_.y = (src)[1]; t_.z = (src)[2]; t_.w = (src)[3]; *(CBH_G w_v4*)(p) = t_; }
-#else
-#define W_LOAD4(dst, p) { for (u32 q_ = 0; q_ < 4u; ++q_) (dst)[q_] = (p)[q_]; }
-#define W_STORE4(p, src) { for (u32 q_ = 0; q_ < 4u; ++q_) (p)[q_] = (src)[q_]; }
-#endif
 #ifdef CBH_HOSTSIM
 static void cbh_wire_scan_kernel(WireArgs a)
 #else
@@ -590,38 +593,49 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_scan_kernel(WireArgs a)
   const u32 nw = (a.n + 63u) / 64u;
   const u32 per = (nw + 63u) / 64u;
   const u32 lo = lane * per < nw ? lane * per : nw, hi = (lo + per < nw) ? lo + per : nw;
-  u32 sa = 0, sr = 0;
+  u32 sa = 0, sr = 0, mx_a = 0, mx_r = 0, mx_blk = 0;
   {
     u32 w = lo;
-    for (; w + 16u <= hi; w += 16u) {
+    for (; w + 8u <= hi; w += 8u) {
       u32 x[32];
 #pragma unroll
-      for (u32 j = 0; j < 8u; ++j) W_LOAD4(x + 4u * j, a.wavesum + 2u * w + 4u * j);
+      for (u32 j = 0; j < 8u; ++j) W_LOAD4(x + 4u * j, a.wavesum + 4u * (w + j));
 #pragma unroll
-      for (u32 j = 0; j < 16u; ++j) { sa += x[2u * j]; sr += x[2u * j + 1u]; }
+      for (u32 j = 0; j < 8u; ++j) {
+        sa += x[4u * j]; sr += x[4u * j + 1u];
+        const u32 ma = x[4u * j + 2u] & 0xFFFFu, mr = x[4u * j + 2u] >> 16, bk = x[4u * j + 3u];
+        mx_a = ma > mx_a ? ma : mx_a; mx_r = mr > mx_r ? mr : mx_r; mx_blk = bk > mx_blk ? bk : mx_blk;
+      }
     }
-    for (; w < hi; ++w) { sa += a.wavesum[2u * w]; sr += a.wavesum[2u * w + 1u]; }
+    for (; w < hi; ++w) {
+      u32 x[4]; W_LOAD4(x, a.wavesum + 4u * w);
+      sa += x[0]; sr += x[1];
+      const u32 ma = x[2] & 0xFFFFu, mr = x[2] >> 16;
+      mx_a = ma > mx_a ? ma : mx_a; mx_r = mr > mx_r ? mr : mx_r; mx_blk = x[3] > mx_blk ? x[3] : mx_blk;
+    }
   }
+  mx_a = w_wave_max(mx_a, 8u); mx_r = w_wave_max(mx_r, 9u); mx_blk = w_wave_max(mx_blk, 32u);
   u32 ta, tr;
   u32 pa = w_wave_prefix(sa, 32u, lane, ta), pr = w_wave_prefix(sr, 32u, lane, tr);
   {
     u32 w = lo;
-    for (; w + 16u <= hi; w += 16u) {
-      u32 x[32];
+    for (; w + 8u <= hi; w += 8u) {
+      u32 x[32], y[16];
 #pragma unroll
-      for (u32 j = 0; j < 8u; ++j) W_LOAD4(x + 4u * j, a.wavesum + 2u * w + 4u * j);
+      for (u32 j = 0; j < 8u; ++j) W_LOAD4(x + 4u * j, a.wavesum + 4u * (w + j));
 #pragma unroll
-      for (u32 j = 0; j < 16u; ++j) { const u32 ca = x[2u * j], cr = x[2u * j + 1u]; x[2u * j] = pa; x[2u * j + 1u] = pr; pa += ca; pr += cr; }
+      for (u32 j = 0; j < 8u; ++j) { y[2u * j] = pa; y[2u * j + 1u] = pr; pa += x[4u * j]; pr += x[4u * j + 1u]; }
 #pragma unroll
-      for (u32 j = 0; j < 8u; ++j) W_STORE4(a.waveoff + 2u * w + 4u * j, x + 4u * j);
+      for (u32 j = 0; j < 4u; ++j) W_STORE4(a.waveoff + 2u * w + 4u * j, y + 4u * j);
     }
     for (; w < hi; ++w) {
       a.waveoff[2u * w] = pa; a.waveoff[2u * w + 1u] = pr;
-      pa += a.wavesum[2u * w]; pr += a.wavesum[2u * w + 1u];
+      pa += a.wavesum[4u * w]; pr += a.wavesum[4u * w + 1u];
     }
   }
   if (lane == 0u) {
     a.stats->n_tuples = ta; a.stats->n_roles = tr;
+    a.stats->max_actions = mx_a; a.stats->max_roles = mx_r; a.stats->max_block = mx_blk;
     WLane L; L.bad = false; L.host = false; L.dict_full = false;
     WGlob m = (WGlob)a.msg; const u32 bias = 0u;
     const u32 v_empty = w_intern(a, m, bias, a.dver_off, 0u, 0u, L);
@@ -638,6 +652,7 @@ __global__ __launch_bounds__(CBH_BLOCK) void cbh_wire_scan_kernel(WireArgs a)
       for (u32 k = 0; k < (u32)(sizeof(WireStats) / 4u); ++k) { const u32 v = w_load32(src + k); if (k == 9u) fl = v; dst[k] = v; }
       static_assert(offsetof(WireStats, flags) == 36, "word 9 of WireStats is `flags`");
       a.host_stats->n_tuples = ta; a.host_stats->n_roles = tr;
+      a.host_stats->max_actions = mx_a; a.host_stats->max_roles = mx_r; a.host_stats->max_block = mx_blk;
       a.host_stats->sid_empty = v_empty; a.host_stats->sid_dver = v_dver; a.host_stats->dscope_word = v_dscope; a.host_stats->sid_claims = v_claims;
       a.host_stats->flags = fl | (L.dict_full ? CBH_WF_DICT_FULL : 0u);
     }

@@ -353,7 +353,7 @@ extern "C" int hostsim_wire_flatten(const void* blob, size_t len, const uint8_t*
   a.dver_off = (uint32_t)total; a.dver_len = (uint32_t)dv.size(); a.dscope_off = (uint32_t)(total + dv.size()); a.dscope_len = (uint32_t)ds.size();
   a.claims_off = (uint32_t)(total + dv.size() + ds.size());
   a.globals_off = a.claims_off + 6; a.globals_len = (uint32_t)globals_len;
-  g_w.cnt.assign(n + 1, 0); g_w.status.assign(n + 1, 0); g_w.wavesum.assign(2 * (size_t)nw + 2, 0); g_w.waveoff.assign(2 * (size_t)nw + 2, 0);
+  g_w.cnt.assign(n + 1, 0); g_w.status.assign(n + 1, 0); g_w.wavesum.assign(4 * (size_t)nw + 4, 0); g_w.waveoff.assign(2 * (size_t)nw + 4, 0);
   a.cnt = g_w.cnt.data(); a.status = g_w.status.data(); a.wavesum = g_w.wavesum.data(); a.waveoff = g_w.waveoff.data();
   WireStats st; cbh_wire_stats_init(st);
   a.stats = &st;

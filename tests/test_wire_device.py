@@ -417,3 +417,111 @@ def test_the_whole_token_as_a_value():
                 decided += 1
             at += 1
     assert decided > 40, (decided, lt.unsupported)
+
+
+def _raw_fields(buf):
+    """(field number, wire type, value or payload bytes) of a message; raises ValueError on malformed input"""
+    i, n = 0, len(buf)
+
+    def varint():
+        nonlocal i
+        r = sh = 0
+        while True:
+            if i >= n or sh >= 70:
+                raise ValueError("varint")
+            b = buf[i]
+            i += 1
+            r |= (b & 0x7F) << sh
+            sh += 7
+            if not b & 0x80:
+                return r & ((1 << 64) - 1)
+    while i < n:
+        key = varint()
+        num, wt = key >> 3, key & 7
+        if wt == 0:
+            yield num, wt, varint()
+        elif wt == 2:
+            ln = varint()
+            if ln > n - i:
+                raise ValueError("length")
+            yield num, wt, bytes(buf[i:i + ln])
+            i += ln
+        elif wt == 1:
+            yield num, wt, bytes(buf[i:i + 8]); i += 8
+        elif wt == 5:
+            yield num, wt, bytes(buf[i:i + 4]); i += 4
+        else:
+            raise ValueError("wire type")
+
+
+# which length-delimited fields of which message are messages themselves (engine.proto CheckInput and google.protobuf.Value)
+_SUB = {"CheckInput": {2: "Party", 3: "Party", 5: "AuxData"}, "Party": {4: "Entry"}, "Entry": {2: "Value"}, "Value": {5: "Struct", 6: "List"},
+        "Struct": {1: "Entry"}, "List": {1: "Value"}, "AuxData": {1: "Entry", 2: "JwtsEntry"}, "JwtsEntry": {2: "JWT"}, "JWT": {1: "Entry"}}
+
+
+def _overlong(buf, rng, ctx="CheckInput"):
+    """The same message with every tag, length and varint value - its sub-messages' too - written as a LONGER varint than needed
+    (padding continuation bytes: legal protobuf, nothing a marshaller emits), up to ten bytes."""
+    def varint(v, total):
+        return bytes(((v >> (7 * k)) & 0x7F) | (0x80 if k + 1 < total else 0) for k in range(total))
+
+    def padded(v):
+        need = max(1, (v.bit_length() + 6) // 7)
+        return varint(v, int(rng.integers(need, 11)))      # its own length .. ten bytes
+
+    out = bytearray()
+    for num, wt, v in _raw_fields(buf):
+        out += padded(num << 3 | wt)
+        if wt == 0:
+            out += padded(v)
+        elif wt == 2:
+            sub = _SUB.get(ctx, {}).get(num)
+            body = _overlong(v, rng, sub) if sub else v
+            out += padded(len(body)) + body
+        else:
+            out += v
+    return bytes(out)
+
+
+def test_varints_longer_than_they_need_to_be():
+    """Tags, lengths and values padded to up to ten bytes: the device flattener (an eight-byte window per round trip, the ninth and tenth
+    byte fetched apart) reads them as the host flattener (byte by byte) does; an eleventh byte, or a varint cut off by its message's end,
+    is malformed for both."""
+    from cerbos_amd.ingest import IngestError
+    lt = lower_rule_table(store_rule_table(), GLOBALS)
+    it = IngestTable(lt.blob)
+    inputs = [inp for case in load_json("engine_cases.json") for inp in case["inputs"] if len(inp.get("actions") or []) <= 64][:30]
+    msgs = [wire.encode_check_input(i) for i in inputs]
+    rng = np.random.default_rng(5)
+    same = refused = 0
+    for trial in range(160):
+        plain = msgs[trial % len(msgs)]
+        m = _overlong(plain, rng)
+        assert [(a, b) for a, b, _ in _raw_fields(m)] == [(a, b) for a, b, _ in _raw_fields(plain)] and len(m) > len(plain)
+        kind = trial % 4
+        if kind == 1:      # an eleven-byte tag in front: malformed
+            m = b"\x80" * 10 + b"\x01" + m
+        elif kind == 2:    # the last varint cut off by the message's end
+            m = m + b"\x88\x80"
+        data, off = wire.pack_messages([msgs[0], m, msgs[1]])
+        try:
+            hb = it.flatten_pb(data, off, sort=False)
+            host_bad = False
+        except IngestError:
+            host_bad = True
+        rc, wb = wu.sim_flatten(lt, data, off)
+        assert rc == 0
+        dev_bad = wb.stats["first_bad"] != 0xFFFFFFFF
+        assert dev_bad == host_bad == (kind in (1, 2)), (trial, kind, m)
+        if host_bad:
+            assert wb.stats["first_bad"] == 1
+            refused += 1
+        else:
+            data0, off0 = wire.pack_messages([msgs[0], plain, msgs[1]])
+            rc0, wb0 = wu.sim_flatten(lt, data0, off0)
+            assert rc0 == 0 and wb0.stats["n_host"] == wb.stats["n_host"]
+            if wb.stats["n_host"] == 0 and hb.n_requests == 3:
+                wu.assert_same_requests(lt, hb, wb, bool(_meta_flags(lt) & wu.MF_READS_REQUEST_STRINGS))
+                same += 1
+    it.close()
+    assert same > 40 and refused > 60, (same, refused)
