@@ -85,6 +85,20 @@ static uint32_t device_out_road(cbh_table* gt, const Slice& s, Scratch& x, doubl
   return info.n_tuples;
 }
 
+// one slice through cbh_wire_check_pb: the whole device road in ONE call (the library cuts the slice up and overlaps the pieces)
+static uint32_t onecall_road(cbh_table* gt, const Slice& s, Scratch& x, double* phase) {
+  const auto t0 = Clock::now();
+  cbh_wire_info info; size_t need = 0;
+  int rc = cbh_wire_check_pb(gt, 0, s.bytes, s.rel.data(), s.n, "default", "", nullptr, 0, &PARAMS, x.out, x.out_cap, x.out_off, x.out_flags, &need, &info);
+  if (rc == 2) {
+    cbh_free_pinned(x.out); x.out_cap = need + need / 4; x.out = (uint8_t*)cbh_alloc_pinned(x.out_cap);
+    rc = cbh_wire_check_pb(gt, 0, s.bytes, s.rel.data(), s.n, "default", "", nullptr, 0, &PARAMS, x.out, x.out_cap, x.out_off, x.out_flags, &need, &info);
+  }
+  if (rc != 0) { std::fprintf(stderr, "cbh_wire_check_pb: %s\n", cbh_last_error()); return 0; }
+  if (phase) phase[0] += secs(t0, Clock::now());
+  return info.n_tuples;
+}
+
 static uint32_t host_road(cbh_table* gt, const cbi_table* it, const Slice& s, Scratch& x, cbi_outputs** out, double* phase) {
   const auto t0 = Clock::now();
   cbi_batch* b = nullptr;
@@ -103,7 +117,7 @@ static uint32_t host_road(cbh_table* gt, const cbi_table* it, const Slice& s, Sc
 }
 
 int main(int argc, char** argv) {
-  if (argc < 5) { std::fprintf(stderr, "usage: %s <dir> <slice_requests> <seconds> <threads,...> [device|device_out|host|both] [verify]\n", argv[0]); return 2; }
+  if (argc < 5) { std::fprintf(stderr, "usage: %s <dir> <slice_requests> <seconds> <threads,...> [device|device_out|onecall|host|both] [verify]\n", argv[0]); return 2; }
   const std::string dir = argv[1];
   const uint32_t slice = (uint32_t)std::atoi(argv[2]);
   const double seconds = std::atof(argv[3]);
@@ -148,9 +162,9 @@ int main(int argc, char** argv) {
     }
     std::printf("{\"verified_identical_outputs\": %zu}\n", same);
   }
-  for (const char* road : {"device_out", "device", "host"}) {
-    if (roads != "both" && roads != road) continue;
-    const bool dev = !std::strcmp(road, "device"), dev_out = !std::strcmp(road, "device_out");
+  for (const char* road : {"onecall", "device_out", "device", "host"}) {
+    if (roads != road && (roads != "both" || !std::strcmp(road, "onecall"))) continue;
+    const bool dev = !std::strcmp(road, "device"), dev_out = !std::strcmp(road, "device_out"), one = !std::strcmp(road, "onecall");
     std::string tl = argv[4];
     for (char* tok = std::strtok(tl.data(), ","); tok; tok = std::strtok(nullptr, ",")) {
       const int T = std::atoi(tok);
@@ -166,7 +180,7 @@ int main(int argc, char** argv) {
         for (size_t i = (size_t)k; !stop.load(std::memory_order_relaxed); ++i) {
           const Slice& s = slices[i % slices.size()];
           cbi_outputs* o = nullptr;
-          const uint32_t d = dev_out ? device_out_road(gt, s, x, phases[k].data()) : dev ? device_road(gt, it, s, x, &o, phases[k].data()) : host_road(gt, it, s, x, &o, phases[k].data());
+          const uint32_t d = one ? onecall_road(gt, s, x, phases[k].data()) : dev_out ? device_out_road(gt, s, x, phases[k].data()) : dev ? device_road(gt, it, s, x, &o, phases[k].data()) : host_road(gt, it, s, x, &o, phases[k].data());
           if (!d) { failed = 1; break; }
           if (o) cbi_outputs_free(o);
           mine += d;
