@@ -268,7 +268,9 @@ class Planner:
             filters.append(flt.to_filter(_node_filter_ast(allow_nodes, deny_nodes)))
         out["filter"] = flt.merge_with_and(filters)
         out["filterDebug"] = flt.filter_to_string(out["filter"]) if policy_match else "NO_MATCH"
-        out["evaluationErrors"] = errors
+        # CELErrors.All() (evaluator/cel_errors.go:84-118): an (expression, message) pair once, ordered by expression then message;
+        # enginev1.EvaluationError in its protojson form, as a CheckOutput's
+        out["evaluationErrors"] = [{"celError": {"expression": e, "message": m}} for e, m in sorted({(x["expr"], x["message"]) for x in errors})]
         out["effectivePolicies"] = sorted(touched)     # the call's AuditTrail.EffectivePolicies (plan.go:50-51, 201-203)
         return out
 

@@ -289,7 +289,8 @@ def decode_check_resources_response(buf: bytes) -> dict:
 
 # ---- PlanResources (engine.proto:20-128): input 1 request_id, 2 action (deprecated), 3 principal, 4 resource {1 kind, 2 attr,
 # 3 policy_version, 4 scope}, 5 aux_data, 6 include_meta, 7 actions; output 1 request_id, 2 action, 3 kind, 4 policy_version, 5 scope,
-# 6 filter {1 kind, 2 condition}, 7 filter_debug, 9 actions, 10 matched_scopes, 11 evaluation_errors {1 expr, 2 message};
+# 6 filter {1 kind, 2 condition}, 7 filter_debug, 9 actions, 10 matched_scopes, 11 evaluation_errors: EvaluationError {1 cel_error
+# {1 expression, 2 message}} (engine.proto:127, 168-176 - the message a CheckOutput's field 7 repeats);
 # Operand: 1 value, 2 expression {1 operator, 2 operands}, 3 variable
 _FILTER_KINDS = {"KIND_UNSPECIFIED": 0, "KIND_ALWAYS_ALLOWED": 1, "KIND_ALWAYS_DENIED": 2, "KIND_CONDITIONAL": 3}
 
@@ -405,7 +406,8 @@ def encode_plan_resources_output(out: dict) -> bytes:
     for k, v in (out.get("matchedScopes") or {}).items():
         b += _ld(10, _ld(1, k.encode("utf-8")) + _string(2, v))
     for e in out.get("evaluationErrors") or []:
-        b += _ld(11, _string(1, e.get("expr", "")) + _string(2, e.get("message", "")))
+        ce = e.get("celError") or {}
+        b += _ld(11, _ld(1, _string(1, ce.get("expression", "")) + _string(2, ce.get("message", ""))))
     return b
 
 
@@ -452,8 +454,10 @@ def decode_plan_resources_output(buf: bytes) -> dict:
                     val = v2.decode("utf-8")
             out["matchedScopes"][k] = val
         elif n == 11:
-            e = {"expr": "", "message": ""}
+            ce = {"expression": "", "message": ""}
             for n2, v2 in _fields(v):
-                e["expr" if n2 == 1 else "message"] = v2.decode("utf-8")
-            out["evaluationErrors"].append(e)
+                if n2 == 1:
+                    for n3, v3 in _fields(v2):
+                        ce["expression" if n3 == 1 else "message"] = v3.decode("utf-8")
+            out["evaluationErrors"].append({"celError": ce})
     return out

@@ -164,3 +164,33 @@ def test_a_broken_derived_role_spoils_only_what_reads_the_list():
     assert lst["filter"]["kind"] == "KIND_ALWAYS_DENIED"
     lenient = pl.plan(dict(inp, actions=["list"]), strict_evaluation=False)  # not strict: the definition is false, the rest stands
     assert lenient["filter"]["kind"] == "KIND_CONDITIONAL"
+
+
+# ---- TestCELErrorsPlan / TestStrictEvaluationPlan (internal/ruletable/cel_errors_test.go:358-410, strict_evaluation_test.go:94-160):
+# the harness of the Check KATs (tests/golden/ruletable_cel_errors.json, tools/make_golden_ruletable_tests.py) through RuleTable.Plan -
+# the filter's kind and the expressions of PlanResourcesOutput.EvaluationErrors, in order.
+def _plan_kats():
+    from helpers import load_json
+    return load_json("ruletable_cel_errors.json")
+
+
+@pytest.mark.parametrize("case", _plan_kats()["planCases"], ids=lambda c: ("strict_" if c["strict"] else "") + c["name"])
+def test_cel_errors_in_plans(case):
+    from cerbos_amd.plan.planner import Planner
+    from cerbos_amd.policy.loader import policies_from_docs
+    from cerbos_amd.ruletable.build import rule_table_from_policies
+    doc = _plan_kats()
+    pl = Planner(rule_table_from_policies(policies_from_docs(doc["policies"])))
+    attr = {}
+    if "number" in case["amount"]:
+        attr["amount"] = case["amount"]["number"]
+    elif "string" in case["amount"]:
+        attr["amount"] = case["amount"]["string"]
+    out = pl.plan({"requestId": doc["requestId"], "actions": [case["action"]], "principal": doc["principal"],
+                   "resource": {"kind": case["kind"], "attr": attr}}, strict_evaluation=case["strict"])
+    assert out["filter"]["kind"] == case["wantKind"], out
+    assert [e["celError"]["expression"] for e in out.get("evaluationErrors") or []] == case["wantErrorExpressions"], out
+    assert all(e["celError"]["message"] for e in out.get("evaluationErrors") or [])
+    # ... and through the wire form of PlanResourcesOutput (field 11: EvaluationError {cel_error {expression, message}})
+    from cerbos_amd import wire
+    assert wire.decode_plan_resources_output(wire.encode_plan_resources_output(out))["evaluationErrors"] == (out.get("evaluationErrors") or [])

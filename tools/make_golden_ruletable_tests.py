@@ -3,6 +3,7 @@
 
   internal/ruletable/cel_errors_test.go          TestCELErrorsCheck        (fail-open semantics of CEL runtime errors)
   internal/ruletable/strict_evaluation_test.go   TestStrictEvaluationCheck (EvalParams.StrictEvaluation: an error denies)
+  ... and their planner halves, TestCELErrorsPlan / TestStrictEvaluationPlan (the filter's kind and the reported expressions)
 
 Both run RuleTable.Check over six small policies built in newCELErrorsHarness and assert, per case, the effect of every
 action (sometimes the policy) and the ORDERED list of expressions in CheckOutput.EvaluationErrors.  The policies are Go
@@ -121,6 +122,24 @@ def cases(src, func, strict, k):
     return out
 
 
+def plan_cases(src, func, strict, k):
+    """TestCELErrorsPlan / TestStrictEvaluationPlan: h.plan(t, params, kind, action, amount) -> the filter's kind and the expressions of
+    PlanResourcesOutput.EvaluationErrors."""
+    body = src[src.index("func %s(" % func):]
+    body = body[:body.index("\n}\n") + 3]
+    local = dict(re.findall(r"(\w+) := (structpb\.New\w+Value\([^)]*\))", body))
+    out = []
+    for m in re.finditer(r't\.Run\("(\w+)", func\(t \*testing\.T\) \{(.*?)\n\t\}\)', body, re.S):
+        name, blk = m.group(1), m.group(2)
+        c = re.search(r'h\.plan\(t, ([^,]+(?:\([^)]*\))?), ("[^"]+"), ("[^"]+"), (.+?)\)\n', blk)
+        kind = re.search(r"require\.Equal\(t, enginev1\.PlanResourcesFilter_(KIND_\w+), kind\)", blk)
+        errs = re.search(r"assertCELErrors\(t, entries((?:, [^,)]+)*)\)", blk)
+        out.append({"name": name, "strict": strict, "kind": go_string(c.group(2)), "action": go_string(c.group(3)),
+                    "amount": amount_of(c.group(4), local), "wantKind": kind.group(1),
+                    "wantErrorExpressions": [expr_of(x, k) for x in errs.group(1).split(",")[1:]]})
+    return out
+
+
 def main():
     a = open(os.path.join(REF, "cel_errors_test.go"), encoding="utf-8").read()
     b = open(os.path.join(REF, "strict_evaluation_test.go"), encoding="utf-8").read()
@@ -129,12 +148,14 @@ def main():
                       "internal/ruletable/strict_evaluation_test.go: TestStrictEvaluationCheck"],
            "principal": {"id": "sam", "roles": ["user"]}, "resourceId": "1", "requestId": "1",
            "policies": policies(a, k),
-           "cases": cases(a, "TestCELErrorsCheck", False, k) + cases(b, "TestStrictEvaluationCheck", True, k)}
-    assert len(doc["policies"]) == 6 and len(doc["cases"]) >= 22, (len(doc["policies"]), len(doc["cases"]))
+           "cases": cases(a, "TestCELErrorsCheck", False, k) + cases(b, "TestStrictEvaluationCheck", True, k),
+           # ... and the same harness through RuleTable.Plan (TestCELErrorsPlan, TestStrictEvaluationPlan)
+           "planCases": plan_cases(a, "TestCELErrorsPlan", False, k) + plan_cases(b, "TestStrictEvaluationPlan", True, k)}
+    assert len(doc["policies"]) == 6 and len(doc["cases"]) >= 22 and len(doc["planCases"]) >= 17, (len(doc["policies"]), len(doc["cases"]), len(doc["planCases"]))
     with open(OUT, "w", encoding="utf-8") as f:
         json.dump(doc, f, sort_keys=True, indent=1, ensure_ascii=False)
         f.write("\n")
-    print("wrote", OUT, len(doc["policies"]), "policies,", len(doc["cases"]), "cases")
+    print("wrote", OUT, len(doc["policies"]), "policies,", len(doc["cases"]), "cases,", len(doc["planCases"]), "plan cases")
 
 
 if __name__ == "__main__":
