@@ -220,6 +220,7 @@ struct cbh_device_batch {
   // a batch the device flattened (cbh_wire_flatten): where the response's strings sit in the messages
   bool wire = false; bool own_wire_stream = false; u32* w_in_span = nullptr; u32* w_act_span = nullptr;
   void* w_pinned = nullptr; size_t w_pinned_cap = 0, w_pin_out_at = 0;
+  ptrdiff_t w_pinned_delta = 0;   // device address of the page-locked block minus its host address (hipHostGetDevicePointer; 0 where both agree)
   hipEvent_t w_ev[2] = {nullptr, nullptr};   // (the link streams) upload landed / the outputs are written; download landed
   const u32* w_req_input = nullptr;   // the request words in INPUT order (dev.req_u32 may be the grouped copy)
   u32 trail_groups = 0; u32* trail_grp = nullptr;   // cbh_batch_set_trail: groups of out.eff_pol, the requests' groups
@@ -963,9 +964,14 @@ static hipEvent_t wire_event(cbh_device_batch* b, int which) {
   }
   return b->w_ev[which];
 }
+// a place of the batch's page-locked block as a KERNEL addresses it: what hipHostGetDevicePointer says of the block, not the host pointer
+// taken on trust
+template <class T> static T* pin_dev(const cbh_device_batch* b, T* host_ptr) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(host_ptr) + b->w_pinned_delta);
+}
 // n_words of device memory -> the batch's page-locked block (cbh_wire_publish_kernel: no copy engine); read after a synchronise
 static int wire_publish(cbh_device_batch* b, const void* d_src, void* pinned_dst, u32 n_words) {
-  WirePublishArgs pa; pa.src = static_cast<const u32*>(d_src); pa.dst = static_cast<u32*>(pinned_dst); pa.n_words = n_words; pa.pad = 0;
+  WirePublishArgs pa; pa.src = static_cast<const u32*>(d_src); pa.dst = pin_dev(b, static_cast<u32*>(pinned_dst)); pa.n_words = n_words; pa.pad = 0;
   hipLaunchKernelGGL(cbh_wire_publish_kernel, dim3(1), dim3(64), 0, b->stream, pa);
   HIPCHK(hipGetLastError());
   return 0;
@@ -1054,6 +1060,11 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
     }
   }
   if (!b->w_pinned) { cbh_batch_release(b); return fail("cbh_wire_flatten: hipHostMalloc failed"); }
+  {
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, b->w_pinned, 0) != hipSuccess || !dev) { (void)hipGetLastError(); dev = b->w_pinned; }
+    b->w_pinned_delta = static_cast<char*>(dev) - static_cast<char*>(b->w_pinned);
+  }
   if (!b->own_wire_stream) b->stream = rep->rstreams[rep->next_rstream.fetch_add(1, std::memory_order_relaxed) % (uint32_t)rep->n_rstreams.load(std::memory_order_relaxed)];
   hipStream_t s = b->stream;
   auto bail = [&](int rc) { cbh_batch_release(b); return rc; };
@@ -1211,7 +1222,7 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
       int rr = 0;
       rr |= dalloc(b, ra.rt_key, (size_t)CBH_WIRE_ROUTE_SLOTS + ((size_t)CBH_WIRE_ROUTE_SLOTS + 2 + 1) / 2);   // (the keys and, behind them, the counters: one memset)
       ra.rt_cnt = reinterpret_cast<u32*>(ra.rt_key + CBH_WIRE_ROUTE_SLOTS);
-      ra.host_routes = pin_routes; ra.stats = d_stats; ra.host_stats = wire_stats_land(b);
+      ra.host_routes = pin_dev(b, pin_routes); ra.stats = d_stats; ra.host_stats = pin_dev(b, wire_stats_land(b));
       rr |= dalloc(b, ra.slot, (size_t)n); rr |= dalloc(b, ra.rank, (size_t)n); rr |= dalloc(b, ra.inv, (size_t)n);
       rr |= dalloc(b, ra.req_out, (size_t)CBH_RQ_NFIELDS * n); rr |= dalloc(b, ra.col_tag_out, (size_t)ncol * n); rr |= dalloc(b, ra.col_val_out, (size_t)ncol * n);
       if (rr != 0) return -1;
@@ -1236,7 +1247,7 @@ static int wire_flatten_impl(cbh_table* t, uint32_t device_index, const uint8_t*
       a.lix_mask = slots - 1;
       if (hipMemsetAsync(dict, 0, ((size_t)slots + ((size_t)slots / 4 + 1 + 1) / 2) * 8, s) != hipSuccess) { fail("cbh_wire_flatten: memset failed"); return bail(-1); }
     }
-    a.host_stats = wire_stats_land(b);   // (the scan kernel leaves the statistics there itself)
+    a.host_stats = pin_dev(b, wire_stats_land(b));   // (the scan kernel leaves the statistics there itself)
     hipLaunchKernelGGL(cbh_wire_scan_kernel, dim3(1), dim3(CBH_BLOCK), 0, s, a);
     if (hipStreamSynchronize(s) != hipSuccess) { fail("cbh_wire_flatten failed"); return bail(-1); }
     st = *wire_stats_land(b);
@@ -1379,12 +1390,12 @@ extern "C" int cbh_wire_outputs(cbh_table* t, cbh_device_batch* b, uint8_t* byte
   const bool direct = pin && b->w_pin_out_at && flags_at + (size_t)n + 64 + 64 <= b->w_pinned_cap;
   u64* pin_off = direct ? reinterpret_cast<u64*>(pin + b->w_pin_out_at) : nullptr;
   u8* pin_flags = direct ? pin + flags_at : nullptr;
-  if (direct) { a.out_off = pin_off; a.out_flags = pin_flags; }
+  if (direct) { a.out_off = pin_dev(b, pin_off); a.out_flags = pin_dev(b, pin_flags); }
   if (b->w_total_known) { st.total = b->w_total; st.errors = b->w_out_errors; }   // sizes and offsets of these results are on the device already
   else {
     WireOutStats* pin_st = static_cast<WireOutStats*>(b->w_pinned);   // (page-locked slot 0; the scan kernel writes it and clears the error bits behind itself)
     if (fresh_ostats) HIPCHK(hipMemsetAsync(b->w_ostats, 0, sizeof(st), s));
-    a.host_stats = pin_st;
+    a.host_stats = pin_dev(b, pin_st);
     if (nw) hipLaunchKernelGGL(cbh_wire_out_size_kernel, dim3(nw), dim3(CBH_BLOCK), 0, s, a);
     hipLaunchKernelGGL(cbh_wire_out_scan_kernel, dim3(1), dim3(CBH_BLOCK), 0, s, a);
     HIPCHK(hipStreamSynchronize(s));
