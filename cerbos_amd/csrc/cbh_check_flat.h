@@ -37,13 +37,25 @@
 // OR of a 64-bit value over the wave, through LDS: a wave's LDS operations execute in program order, so the zeroing
 // store, the 64 atomic ORs and the read-back need no barrier on the device; the ballots are the rendezvous the host
 // simulation's lane fibers need (and cost the device one scalar move each).
+// Every access is an ATOMIC one: with a plain read-back the compiler may take a lane that ORs nothing in (v == 0: a request
+// without roles, a lane beyond the batch's end) to know the word already - it moved the read INTO `if (v)` and left such lanes
+// with what they last saw there (the previous call's result, or the zero lane 0 stored).  Harmless while a lane only asked
+// what IT can match; wrong as soon as a lane asks on behalf of the wave (one record to a lane: the staged walk, cbh_check_walk2.h).
 __device__ __forceinline__ u64 wave_or64(u64 v, u32 wave, u32 lane) {
   __shared__ unsigned long long acc[CBH_FLAT_WAVES];
+#ifndef CBH_HOSTSIM
+  if (lane == 0) __hip_atomic_store(&acc[wave], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  (void)wave_ballot(true);
+  if (v) (void)__hip_atomic_fetch_or(&acc[wave], (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  (void)wave_ballot(true);
+  const u64 r = __hip_atomic_load(&acc[wave], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
   if (lane == 0) acc[wave] = 0;
   (void)wave_ballot(true);
   if (v) atomicOr(&acc[wave], (unsigned long long)v);
   (void)wave_ballot(true);
   const u64 r = acc[wave];
+#endif
   (void)wave_ballot(true);
   return r;
 }
