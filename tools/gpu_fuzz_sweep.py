@@ -15,10 +15,15 @@ from cerbos_amd.engine import Conf, HipEvaluator   # noqa: E402
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+budget_s = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0   # stop cleanly (and say what was done) after this many seconds; 0 = never
 mk = lambda lt: HipEvaluator(lt, Conf())   # noqa: E731
 t0 = time.time()
 done = {"flat": 0, "lists": 0, "large": 0, "deep": 0, "general": 0, "skipped": 0}
+last = first - 1
 for s in range(first, first + n):
+    if budget_s and time.time() - t0 > budget_s:
+        break
+    last = s
     F._run_seed(s, mk, True); done["flat"] += 1
     if s % 3 == 0:
         F._run_seed(s, mk, True, with_lists=True); done["lists"] += 1
@@ -34,4 +39,4 @@ for s in range(first, first + n):
                 done["skipped"] += 1
             else:
                 raise
-print("sweep clean:", done, "seeds %d..%d" % (first, first + n - 1), "%.0f s" % (time.time() - t0))
+print("sweep clean:", done, "seeds %d..%d" % (first, last), "%.0f s" % (time.time() - t0))
