@@ -408,6 +408,8 @@ enum CbhOp {
   OP_EDREQ = 72,      // arg = constant index of a 64-bit mask | never << 31: push runtime.effectiveDerivedRoles == <the constant list whose names
                       // the mask holds> (the runtime list is sorted and duplicate free: a constant list that is not can never equal it)
   OP_HIERCOMMON = 71, // pop c, b; TOS a (dot-delimited strings) -> hierarchy(a).commonAncestors(hierarchy(b)) == hierarchy(c)
+  OP_EDRVAL = 73,     // trace programs only: push runtime.effectiveDerivedRoles AS A VALUE (CBH_T_EDRSET, the mask of the scope being walked) -
+                      // emitted only where it is the WHOLE expression of an output's part or of a variable: nothing else ever sees the tag
   OP_NOPS
 };
 enum CbhIterKind { IT_ALL = 0, IT_EXISTS = 1, IT_EXISTS_ONE = 2, IT_FILTER = 3, IT_MAP = 4,   // filter / map build a list in the lane's arena

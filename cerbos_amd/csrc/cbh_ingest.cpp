@@ -1593,6 +1593,14 @@ static int trace_decode(const cbi_table* t, const cbi_batch* b, const cbh_result
         for (u64 i = 0; i < cnt; ++i) r.items.push_back(to_tval(tags[off + i], vals[off + i], depth + 1));
         return r;
       }
+      case 11: {   // CBH_T_EDRSET: runtime.effectiveDerivedRoles as a value - the names of the mask's bits, sorted (check.go:593-610)
+        r.k = TVal::List;
+        std::vector<std::string> names;
+        for (u32 d = 0; d < 64 && d < t->dr_names.size(); ++d) if ((v >> d) & 1) names.push_back(t->dr_names[d]);
+        std::sort(names.begin(), names.end());
+        for (auto& nm : names) { TVal e; e.k = TVal::String; e.s = std::move(nm); r.items.push_back(std::move(e)); }
+        return r;
+      }
       default: throw TraceIncomplete{};   // timestamps / durations as output values
     }
   };

@@ -801,6 +801,15 @@ __device__ __forceinline__ u32 run_uniform_impl(const KernelArgs* ka, const VmLd
       }
       case OP_UNSUPPORTED:
       default:
+        if constexpr (TRACE) {   // OP_EDRVAL - runtime.effectiveDerivedRoles as a value (an output's part, a variable's definition) - lives
+                                 // here, in the trace instantiation only: the decision kernels' interpreter sits a register or two under
+                                 // its second wave (profiles/r04_kernel_resources_last_build.txt) and one more case label cost it that wave
+          if (op == OP_EDRVAL) {
+            if (L.edr_err) PUSHV((tfailed >> 56) == 0 ? mk(CBH_T_ERR, (u64)CBH_ERR_EDR_FAILED | (tfailed << 8)) : mk_err());
+            else PUSHV(mk(CBH_T_EDRSET, L.edr));
+            break;
+          }
+        }
         if (live) L.status |= CBH_ST_UNSUPPORTED;
         PUSHV(mk_err());
         break;

@@ -30,7 +30,7 @@ from . import regex
  OP_TODOUBLE, OP_TOSTRING_UNSUPPORTED, OP_INIPRANGE, OP_UNSUPPORTED, OP_TS_GETTER,
  OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN, OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC,
  OP_TREE_END, OP_HIER, OP_MATCHES, OP_INDEXOF, OP_STREQ_CASE, OP_VARSCOPE, OP_OUT, OP_LISTOP, OP_LISTFN, OP_STRCAT,
- OP_STRCASE, OP_IPFN, OP_STRVIEW, OP_STRREPLACE, OP_HIERCOMMON, OP_EDREQ) = range(73)
+ OP_STRCASE, OP_IPFN, OP_STRVIEW, OP_STRREPLACE, OP_HIERCOMMON, OP_EDREQ, OP_EDRVAL) = range(74)
 
 TREE_KINDS = {"all": 0, "any": 1, "none": 2}
 COND_LEAF = 0x80000000
@@ -85,7 +85,7 @@ _R_FIELDS = {"id": RQ_S_RESOURCE_ID, "kind": RQ_S_KIND, "scope": RQ_S_R_SCOPE,
 _ID_ONLY_OPS = frozenset([OP_RET, OP_CONST, OP_COL, OP_HASCOL, OP_REQSTR, OP_ROLES, OP_SELECT, OP_HASSEL, OP_INDEX, OP_EQ, OP_NE,
                           OP_IN, OP_NOT, OP_JF, OP_JT, OP_AND, OP_OR, OP_JTERN, OP_JMP, OP_POP, OP_LEAF, OP_EDRHAS, OP_LOCAL,
                           OP_ITER_BEGIN, OP_ITER_NEXT, OP_ITER_ACC, OP_ITER_END, OP_HASINTERSECTION, OP_ISSUBSET, OP_LEAF_BIN,
-                          OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC, OP_TREE_END, OP_UNSUPPORTED, OP_TS_GETTER, OP_VARSCOPE, OP_OUT, OP_LISTOP, OP_LISTFN, OP_EDREQ])
+                          OP_TERN, OP_TREE_BEGIN, OP_TREE_ACC, OP_TREE_END, OP_UNSUPPORTED, OP_TS_GETTER, OP_VARSCOPE, OP_OUT, OP_LISTOP, OP_LISTFN, OP_EDREQ, OP_EDRVAL])
 
 
 class LoweringError(ValueError):
@@ -587,7 +587,7 @@ class ProgramBuilder:
             def build(text=text):
                 fc = _FuncCompiler(self, params, True, trace=True)
                 fc.cur_text = text
-                fc.expr(params.inline(celparser.parse(text)))
+                fc.value_expr(params.inline(celparser.parse(text)))
                 fc.emit(OP_LEAF, self.tid(text) + 1)
                 return fc
             out.append(self._trace_compile(("trace-var", text, params.key()), build))
@@ -614,7 +614,7 @@ class ProgramBuilder:
             fc = _FuncCompiler(self, params, True, trace=True)
             fc.cur_text = text
             for j, h in enumerate(holes):
-                fc.expr(h)
+                fc.value_expr(h)
                 fc.emit(OP_OUT, self.tid(src))
                 fc.word(word)
                 fc.word(j)
@@ -924,6 +924,20 @@ class _FuncCompiler:
         self.word(a[1])
         self.word(b[1])
         return True
+
+    def value_expr(self, ast):
+        """An expression whose VALUE is wanted (a part of an output expression, a variable's definition - trace programs).  As
+        expr(), except that `runtime.effectiveDerivedRoles` may be the whole of it: the device pushes the derived-role mask of the
+        scope being walked under a tag of its own (OP_EDRVAL, CBH_T_EDRSET) and the host spells the sorted names (check.go:593-610
+        builds the list from the set the same way); inside a larger expression the list stays outside the subset, as before."""
+        if self.trace and self.allow_runtime:
+            if ast[0] in ("select", "index") and self._path(ast) == ("edr",):
+                self.pb.uses_runtime = True
+                return self.emit(OP_EDRVAL, 0, +1)
+            if ast[0] == "varscope":   # a variable that IS the list (V.derivedRoles: runtime.effectiveDerivedRoles), read as a whole
+                self.value_expr(ast[2])
+                return self.emit(OP_VARSCOPE, self.pb.tid(ast[1]) | (ast[3] << 23))
+        return self.expr(ast)
 
     # -- paths
     def _path(self, ast):

@@ -26,6 +26,7 @@ TR_DRFAIL = 32   # cbh_check_wave.h CBH_TR_DRFAIL
 (ERR_OTHER, ERR_NO_SUCH_KEY, ERR_ATTR_MISSING, ERR_NO_SUCH_OVERLOAD, ERR_UNDEFINED_FIELD, ERR_DIV_BY_ZERO, ERR_MOD_BY_ZERO,
  ERR_INT_OVERFLOW, ERR_UINT_OVERFLOW, ERR_EDR_FAILED) = range(10)
 T_NULL, T_BOOL, T_INT, T_UINT, T_DOUBLE, T_STRING, T_LIST, T_MAP, T_TIMESTAMP, T_DURATION = range(10)
+T_EDRSET = 11   # include/cerbos_hip.h CBH_T_EDRSET
 HEAP_TABLE, HEAP_ROLES = 0, 2
 RECORD_WORDS = 8
 
@@ -100,6 +101,8 @@ class TraceDecoder:
             return struct.unpack("<d", struct.pack("<Q", v))[0]
         if tag == T_STRING:
             return self.string(v & 0xFFFFFFFF)
+        if tag == T_EDRSET:   # runtime.effectiveDerivedRoles as a value: the mask of the scope's derived roles -> their names, sorted (check.go:593-610)
+            return sorted(n for i, n in enumerate(self.lt.dr_names) if (v >> i) & 1)
         if tag in (T_LIST, T_MAP):
             sel, off, n = v >> 62, (v >> 32) & 0x3FFFFFFF, v & 0xFFFFFFFF
             if sel == HEAP_ROLES:

@@ -92,6 +92,7 @@ enum cbh_tag {
   CBH_T_DURATION = 9,  /* int64 ns */
   CBH_T_ROPE = 10,     /* device only: a string a program put together (concatenation, lowerAscii / upperAscii as a value) - never  */
                        /* built, kept as the list of its parts: sel:2 (LOCAL) | off:30 | parts:32                                  */
+  CBH_T_EDRSET = 11,   /* device only, trace programs: runtime.effectiveDerivedRoles AS A VALUE - payload = the derived-role mask; the host spells the sorted names */
   CBH_T_ABSENT = 0xF0, /* last key of a column path missing (has() -> false, read -> error) */
   CBH_T_ERR = 0xFF     /* reading the path is a CEL error (missing / non-map intermediate)  */
 };

@@ -31,10 +31,10 @@ CASES = load_json("engine_cases.json")
 GLOBALS = {"environment": "test"}
 
 
-# Inputs whose errors / outputs the trace pass reports INCOMPLETE (loud, never guessed): case_21's policy variables and output
-# expressions are `runtime.effectiveDerivedRoles` AS A VALUE (a list of names); the device decides the case (round 3) but only
-# membership / equality tests of that list are in its subset.
-EXPECT_INCOMPLETE = {"engine/case_21"}
+# Inputs whose errors / outputs the trace pass reports INCOMPLETE (loud, never guessed): none since round 5 - case_21's policy
+# variables and output expressions are `runtime.effectiveDerivedRoles` AS A VALUE (a list of names), which the device hands over as the
+# scope's derived-role mask (OP_EDRVAL) and the host spells.
+EXPECT_INCOMPLETE = set()
 
 
 def _engine_cases(ev):
