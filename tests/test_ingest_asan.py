@@ -19,8 +19,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
-def fuzz_binary(tmp_path_factory):
-    out = str(tmp_path_factory.mktemp("asan") / "ingest_fuzz")
+def fuzz_binary():
+    # built in-tree and kept while its sources stand (half a minute of the tier's seven otherwise)
+    srcs = [os.path.join(ROOT, "tests", "asan", "ingest_fuzz.cpp"), os.path.join(ROOT, "cerbos_amd", "csrc", "cbh_ingest.cpp"),
+            os.path.join(ROOT, "cerbos_amd", "csrc", "cbh_blob.h"), os.path.join(ROOT, "include", "cerbos_ingest.h"), os.path.join(ROOT, "include", "cerbos_hip.h")]
+    os.makedirs(os.path.join(ROOT, "tests", "asan", "_build"), exist_ok=True)
+    out = os.path.join(ROOT, "tests", "asan", "_build", "ingest_fuzz")
+    if os.path.exists(out) and all(os.path.getmtime(x) <= os.path.getmtime(out) for x in srcs):
+        return out
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer",
            "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "asan", "ingest_fuzz.cpp"),
            os.path.join(ROOT, "cerbos_amd", "csrc", "cbh_ingest.cpp"), "-o", out]
