@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--audit-trail", action="store_true",
                     help="measurement aid: every launch also keeps AuditTrail.EffectivePolicies (cbh_batch_set_trail, the trail forms of the "
                          "decision kernels: what a server with decision logs on pays); implies --no-side-legs except the one-stream leg")
+    ap.add_argument("--serial-leg", action="store_true", help="measurement aid: keep the one-stream leg (the kernel by itself) under --no-side-legs")
+    ap.add_argument("--check-first", action="store_true",
+                    help="measurement aid (A/B runs): with --no-cpu-baseline, still compare every tuple of the first batch with oracle/ccheck.cpp after the timed region")
     ap.add_argument("--inproc-gpus", type=int, default=0, help="also time one engine over this many devices in THIS process")
     args = ap.parse_args()
 
@@ -234,7 +237,7 @@ def main():
     # copies of the first batches of the set - in the timed region above launches of different batches overlap on the
     # device, which lengthens each one's begin-to-end time while shortening the sweep
     serial = None
-    if rank == 0 and streams > 1 and not args.no_side_legs:
+    if rank == 0 and streams > 1 and (not args.no_side_legs or args.serial_leg):
         table.set_resident_streams(1)
         sdb = [table.upload(hb) for hb in serial_host]
         if args.audit_trail:
@@ -466,6 +469,17 @@ def main():
         t2.close()
         capi.init(local_rank)
 
+    first_checked = None
+    if rank == 0 and args.no_cpu_baseline and args.check_first:
+        from oracle import ccheck
+        try:
+            want_c = ccheck.check(lt, batch0, now, FLAGS, threads=min(32, os.cpu_count() or 1))
+            covered = want_c.status != capi.ST_UNSUPPORTED
+            for name in ("effect", "policy", "scope"):
+                assert np.array_equal(getattr(res, name)[covered], getattr(want_c, name)[covered]), "GPU %s differs from the C++ oracle" % name
+            first_checked = "%d of %d tuples of the first batch identical to oracle/ccheck.cpp" % (int(covered.sum()), covered.size)
+        except ccheck.Unsupported:
+            first_checked = "table outside oracle/ccheck.cpp"
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the oracle = checker + reported CPU baseline ("port": restatements, not the Go binary)
@@ -576,6 +590,7 @@ def main():
                                         if streams > 1 else "algorithmic bytes of one launch / kernel_ms",
                          "serial": serial},
             "cpu_baseline": cpu,
+            "first_batch_checked": first_checked,
             "target_T": target_t,
             "resolve_kernel_ms": resolve_ms,
             "allow_fraction": float((eff == 1).mean()),

@@ -101,6 +101,17 @@ __device__ __forceinline__ R staged_take(const StagedRec<NDW>& s, u32 lane) {   
   return r;
 }
 __device__ __forceinline__ u32 ctz64(u64 v) { return (u32)__builtin_ctzll(v); }
+// 1 for a word that is not zero, else 0 - as ONE instruction (min(v, 1)): written as a comparison the compiler makes it a compare
+// and a select through the condition register, and where sixteen of them follow each other that is a third of the loop.
+__device__ __forceinline__ u32 nz01(u32 v) {
+#ifndef CBH_HOSTSIM
+  u32 r;
+  asm("v_min_u32 %0, 1, %1" : "=v"(r) : "v"(v));
+  return r;
+#else
+  return v ? 1u : 0u;
+#endif
+}
 
 // stores of results nobody in this kernel reads again: written through, so that the end of the kernel does not have to
 // flush them out of the L2 (the dirty lines of a 1M-tuple batch are 12 MB)
@@ -223,7 +234,8 @@ __device__ __forceinline__ u32 flat_tree(const Ctx& c, const LeafRec& desc, u32 
   bool live = true, last = false;
   u32 saved = 0, acc = 0, depth = 0, leaf = desc.a1, err = 0, slow = 0;
   for (u32 k = 0; k < 32; ++k) {
-    const u32 op = (opw[k >> 3] >> (4u * (k & 7u))) & 15u;
+    const u32 ws = k >> 3, word = ws == 0u ? opw[0] : ws == 1u ? opw[1] : ws == 2u ? opw[2] : opw[3];
+    const u32 op = (word >> (4u * (k & 7u))) & 15u;
     if (op == 0) break;
     if (op == 1) {
       const LeafRec lr = uload_rec<LeafRec>(c.t.code, leaf++);
@@ -364,7 +376,8 @@ __device__ __forceinline__ u32 tree_from_codes(const u32 (&opw)[4], u64 idx, con
   bool live = true, last = false;
   u32 saved = 0, acc = 0, depth = 0, err = 0, slow = 0;
   for (u32 k = 0; k < 32; ++k) {
-    const u32 op = (opw[k >> 3] >> (4u * (k & 7u))) & 15u;
+    const u32 ws = k >> 3, word = ws == 0u ? opw[0] : ws == 1u ? opw[1] : ws == 2u ? opw[2] : opw[3];   // (scalar selects: an index the loop computes would put the four words in scratch)
+    const u32 op = (word >> (4u * (k & 7u))) & 15u;
     if (op == 0) break;
     if (op == 1) {
       const u32 code = lv_code(lvtab, tid, (u32)idx & 0xFFu); idx >>= 8;
@@ -429,7 +442,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   const BatchDev& b = ka_regs.b;
   const OutDev& o = ka_regs.o;
   const u32 flags = ka_regs.flags;
-  const u32 wave = threadIdx.x / CBH_BLOCK;   // which of the group's waves (c.tid is the lane within it)
+  const u32 wave = uniform(threadIdx.x / CBH_BLOCK);   // which of the group's waves (c.tid is the lane within it)
 #ifdef CBH_PROFILE_CYCLES   // profiling build only (tools/gpu_cycles_flat.py)
   const u64 cyc0 = __builtin_readcyclecounter();
   const u64 rt0 = __builtin_amdgcn_s_memrealtime();
@@ -448,7 +461,11 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   const u32 role_off = RQ(CBH_RQ_ROLE_OFF), act_off = RQ(CBH_RQ_ACT_OFF);
   const u32 role_cnt = valid ? RQ(CBH_RQ_ROLE_CNT) : 0, act_cnt = valid ? RQ(CBH_RQ_ACT_CNT) : 0;   // both <= 4 (host-checked)
 #undef RQ
-  fill_column_cache(c, b, NR, req);
+  {   // the wave's requests are consecutive: uniform base + lane offset (cbh_check_wave.h fill_column_cache_seq)
+    const u32 w0 = b.req_lo + blockIdx.x * CBH_FLAT_THREADS + wave * CBH_BLOCK;   // the wave's first request (uniform)
+    const bool some = w0 < b.req_hi;
+    fill_column_cache_seq(c, b, NR, some ? w0 : b.req_lo, valid ? c.tid : 0u);
+  }
   const u32 all = (1u << act_cnt) - 1u;
   // [depth][lane]: scope index at that depth of the lane's chain - in the dynamic LDS behind the column caches,
   // sized by the table's longest chain (a one-scope table pays 256 B per wave, not 4 KB: LDS sets the occupancy here)
@@ -743,29 +760,63 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
             const u64 satrec = dsat & csat, errrec = derr | (dsat & cerr), unsrec = duns | (dsat & cuns);
             const u64 allow_m = (u64)hd.allow_lo | ((u64)hd.allow_hi << 32), deny_m = (u64)hd.deny_lo | ((u64)hd.deny_hi << 32);
             const bool anybad = wave_ballot(((errrec | unsrec) & cand_any) != 0) != 0;
-            u64 amk[4];
+            // ---- the walks' outcomes in this segment.  Within a segment the sixteen walks (role r, action k) of a lane are
+            // independent of each other: a walk reads only its own bit of S.  What a walk needs is two facts - did it meet a
+            // satisfied ALLOW, did it meet a satisfied DENY (which ends it, check.go:392-403; an ALLOW of a walk a DENY ends is
+            // never read again) - i.e. whether two 64-bit ANDs are zero.  The action side of both ANDs is formed once per action
+            // (records of the lane's k-th action whose conditions hold, split by effect), a walk then costs two AND / AND-OR pairs
+            // and two min / shift-or pairs that push its two facts into two 16-bit words - bit 4r + k, roles and actions taken
+            // from the top so that the first fact pushed ends at bit 15 - and the bookkeeping is done once for all sixteen.
+            const u32 live16 = ing ? S : 0u;   // this lane's walks still going at the segment's start
+            if (anybad) {
+              // An evaluation error (or a condition outside the device subset) among the wave's candidates - a few lanes of a few
+              // waves: the walk's error bits are kept exactly, per walk, and only for the walks in which some lane has such a
+              // candidate (two cheap tests first: no lane's r-th role reaches one of its bad candidates; nor through its k-th action).
+              // An error counts for a walk when the reference evaluated that record: up to and including the walk's first
+              // satisfied DENY (a tree can be satisfied AND have absorbed an error).
+              const u64 badc = cand_any & (errrec | unsrec);   // this lane's candidates that raised one: none, for nearly every lane
 #pragma unroll
-            for (u32 k = 0; k < 4; ++k) amk[k] = segm[ac[k]] & satrec;
+              for (u32 r = 0; r < 4; ++r) {
+                const u64 rmk = segm[32u + rc[r]];
+                const bool rlive = ((live16 >> (4u * r)) & 0xFu) != 0;
+                if (wave_ballot(rlive && (rmk & badc) != 0) == 0) continue;
 #pragma unroll
-            for (u32 r = 0; r < 4; ++r) {
-              if (wave_ballot(ing && ((S >> (4u * r)) & 0xFu) != 0) == 0) continue;   // no lane has a live walk of its r-th role
-              const u64 rmk = segm[32u + rc[r]];
-#pragma unroll
-              for (u32 k = 0; k < 4; ++k) {
-                const u32 bit = 1u << (4u * r + k);
-                const bool live = ing && (S & bit) != 0;
-                const u64 hits = live ? (rmk & amk[k]) : 0ull;   // the walk's candidates whose conditions hold
-                const u64 dh = hits & deny_m;
-                has_allow |= (hits & allow_m) ? bit : 0u;   // (a walk a DENY ends leaves S: its has_allow bit is never read again)
-                if (anybad) {
-                  const u64 cand = live ? (rmk & segm[ac[k]]) : 0ull;
-                  const u64 below = dh ? (((dh & (0ull - dh)) << 1) - 1ull) : ~0ull;   // the records met up to and including the first satisfied DENY (a tree can be satisfied AND have absorbed an error)
+                for (u32 k = 0; k < 4; ++k) {
+                  const u32 bit = 1u << (4u * r + k);
+                  const u64 cand = (live16 & bit) ? (rmk & segm[ac[k]]) : 0ull;
+                  if (wave_ballot((cand & badc) != 0) == 0) continue;
+                  const u64 dh = cand & satrec & deny_m;
+                  const u64 below = dh ? (((dh & (0ull - dh)) << 1) - 1ull) : ~0ull;
                   err |= (cand & errrec & below) ? bit : 0u;
                   unsup |= (cand & unsrec & below) ? bit : 0u;
                 }
-                if (dh) { deny |= bit; S &= ~bit; }   // ends this walk (check.go:392-403)
               }
             }
+            u32 a_lo[4], a_hi[4], d_lo[4], d_hi[4];
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) {
+              const u64 am = segm[ac[k]] & satrec;
+              a_lo[k] = (u32)(am & allow_m); a_hi[k] = (u32)((am & allow_m) >> 32);
+              d_lo[k] = (u32)(am & deny_m); d_hi[k] = (u32)((am & deny_m) >> 32);
+            }
+            u32 A16 = 0, D16 = 0;
+#pragma unroll
+            for (u32 rr = 0; rr < 4; ++rr) {
+              const u32 r = 3u - rr;
+              if (wave_ballot(((live16 >> (4u * r)) & 0xFu) != 0) == 0) { A16 <<= 4; D16 <<= 4; continue; }   // no lane has a live walk of its r-th role
+              const u64 rmk = segm[32u + rc[r]];
+              const u32 r_lo = (u32)rmk, r_hi = (u32)(rmk >> 32);
+#pragma unroll
+              for (u32 kk = 0; kk < 4; ++kk) {
+                const u32 k = 3u - kk;
+                const u32 ta = (r_hi & a_hi[k]) | (r_lo & a_lo[k]), td = (r_hi & d_hi[k]) | (r_lo & d_lo[k]);
+                A16 = (A16 << 1) | nz01(ta);
+                D16 = (D16 << 1) | nz01(td);
+              }
+            }
+            A16 &= live16; D16 &= live16;
+            has_allow |= A16;
+            deny |= D16; S &= ~D16;
           }
           (void)wave_ballot(true);   // (the next segment's tables overwrite these)
         }
@@ -865,8 +916,10 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
       const u32 sp = (uload(&t.scope_flags[g_si]) >> 2) & 3u;
       if (sp == SP_REQUIRE_CONSENT) has_allow &= ~ha;
       else if (sp == SP_OVERRIDE_PARENT) { allow |= ha; S &= ~ha; }
-      const u32 newly = S_before & ~S;
-      dp0 |= (mydepth & 1u) ? newly : 0u; dp1 |= (mydepth & 2u) ? newly : 0u; dp2 |= (mydepth & 4u) ? newly : 0u; dp3 |= (mydepth & 8u) ? newly : 0u;
+      if (max_depth > 1u) {   // (a table of one scope: every walk is decided at depth 0 - the planes stay empty, the fold skips them)
+        const u32 newly = S_before & ~S;
+        dp0 |= (mydepth & 1u) ? newly : 0u; dp1 |= (mydepth & 2u) ? newly : 0u; dp2 |= (mydepth & 4u) ? newly : 0u; dp3 |= (mydepth & 8u) ? newly : 0u;
+      }
     }
     const u32 up = uchain_next(t, uload(&t.scope_parent[g_si]), FLAG_RES);   // check.go:231
     if (ing) { cur = (mydepth + 1u < max_depth) ? up : CBH_NONE; ++mydepth; }
@@ -884,7 +937,8 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
     const u32 ak = (allow >> k) & 0x1111u, dk = (deny >> k) & 0x1111u;
     const u32 win = ak ? (ak & (0u - ak)) : (dk & (0u - dk));   // lowest role bit of the deciding kind
     const u32 wb = win << k;                                     // back at its position 4r + k
-    const u32 d = ((dp0 & wb) ? 1u : 0u) | ((dp1 & wb) ? 2u : 0u) | ((dp2 & wb) ? 4u : 0u) | ((dp3 & wb) ? 8u : 0u);
+    u32 d = 0;
+    if (max_depth > 1u) d = ((dp0 & wb) ? 1u : 0u) | ((dp1 & wb) ? 2u : 0u) | ((dp2 & wb) ? 4u : 0u) | ((dp3 & wb) ? 8u : 0u);
     pol[k] = win ? pol_hit : pol_none;
     scp[k] = CBH_NONE;
     if (win && k < act_cnt) scp[k] = chain8 ? (u32)chain_si8[d * CBH_BLOCK + c.tid] : chain_si[d * CBH_BLOCK + c.tid];
@@ -1002,7 +1056,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 #define CBH_FLAT_CTX(a, ka)                                                                                                       \
   const u32 ncc = cached_columns(&a);                                                                                             \
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,  \
-        (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * CBH_CC_DWORDS(ncc, (a.flags & CBH_FI_PACKED_TAGS) != 0), ncc, ka}
+        (CBH_L u32*)cbh_dyn_lds + uniform(threadIdx.x / CBH_BLOCK) * CBH_CC_DWORDS(ncc, (a.flags & CBH_FI_PACKED_TAGS) != 0), ncc, ka}
 // batches of plain scalars (no int / uint / list / map attribute values): no call, ~64 VGPRs, 7-8 waves per SIMD
 __global__ CBH_FLAT_ATTRS(7) void cbh_check_flat_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
   CBH_FLAT_CTX(a, ka);

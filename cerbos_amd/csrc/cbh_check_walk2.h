@@ -114,7 +114,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   const BatchDev& b = ka_regs.b;
   const OutDev& o = ka_regs.o;
   const u32 flags = ka_regs.flags;
-  const u32 wave = threadIdx.x / CBH_BLOCK;
+  const u32 wave = uniform(threadIdx.x / CBH_BLOCK);
   constexpr u32 NA = NA_, NR = NR_;
   typedef typename W2Shape<NA, NR>::W W;
   constexpr W REP = W2Shape<NA, NR>::rep();       // x * REP: an action mask in every role's field
@@ -163,7 +163,10 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     if (wave_ballot(pre_climbs || pre_pp) == 0) return;   // nothing to evaluate for this wave
   }
   W2_DBG(const u64 cycA0 = __builtin_readcyclecounter();)
-  fill_column_cache(c, b, NRQ, req);
+  {   // the wave's requests are consecutive: uniform base + lane offset (cbh_check_wave.h fill_column_cache_seq)
+    const u32 w0 = b.req_lo + blockIdx.x * (PRE ? CBH_BLOCK : CBH_W2_THREADS) + wave * CBH_BLOCK;   // the wave's first request (uniform)
+    fill_column_cache_seq(c, b, NRQ, w0 < b.req_hi ? w0 : b.req_lo, valid ? c.tid : 0u);
+  }
   W2_DBG(const u64 cycA = __builtin_readcyclecounter();)
   const u32 all = (1u << act_cnt) - 1u;
   const u32 max_depth = t.max_depth < CBH_FLAT_MAX_DEPTH ? t.max_depth : CBH_FLAT_MAX_DEPTH;
@@ -907,7 +910,7 @@ __device__ __forceinline__ void w2_walk_kernel_body(const KernelArgs& a, const K
   const u32 ncc = a.t.inline_cols;   // no generic program runs here: only the columns the inline leaf code reads are parked in LDS
   const W2Layout ly = w2_layout(ncc, false, a.t.max_depth, a.t.n_scopes, false, 0, a.t.K, a.t.n_dr, NA, (a.flags & CBH_FI_PACKED_TAGS) != 0);
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-        (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * ly.wave_dw, ncc, ka};
+        (CBH_L u32*)cbh_dyn_lds + uniform(threadIdx.x / CBH_BLOCK) * ly.wave_dw, ncc, ka};
   w2_body<0, NA, NR, EP>(a, c, ly);
 }
 __global__ CBH_W2_ATTRS void cbh_walk2_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_walk_kernel_body<CBH_W2_NA, CBH_W2_NR>(a, ka); }

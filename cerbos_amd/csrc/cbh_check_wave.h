@@ -403,6 +403,47 @@ __device__ __forceinline__ void fill_column_cache(const Ctx& c, const BatchDev& 
   }
 }
 
+// one dword per lane, global memory -> LDS at `lds` + lane * 4 (`lds` wave-uniform).  On the device an asynchronous copy that needs no
+// staging register; the simulator performs the same copy at the same addresses, so that the address arithmetic of the callers runs
+// in the CPU tier too.  (The instruction's own offset field is deliberately not offered: it moves BOTH sides of the copy.)
+__device__ __forceinline__ void lds_dma_dword(const CBH_G void* g, CBH_L u32* lds, u32 lane) {
+#ifndef CBH_HOSTSIM
+  (void)lane;
+  __builtin_amdgcn_global_load_lds(g, (CBH_L void*)lds, 4, 0, 0);
+#else
+  __builtin_memcpy(&lds[lane], g, 4);
+#endif
+}
+// The same fill for the kernels whose lanes hold CONSECUTIVE requests (the flat kernels, the walk): every address is a wave-uniform
+// base - the column's plane at the wave's first request, formed on the scalar unit - plus a 32-bit lane offset, the form the
+// load instructions take as is (saddr + voffset): no 64-bit address arithmetic per lane and column, and the LDS side (the wave's
+// slice of the cache: uniform) goes to M0 without a read-back from a vector register.  `req0` = the wave's first request
+// (uniform), `d` = this lane's distance from it (< the workgroup's size; a lane beyond the batch's end passes 0: it shadows the
+// wave's first request here, and never stores).
+__device__ __forceinline__ void fill_column_cache_seq(const Ctx& c, const BatchDev& b, u32 NR, u32 req0, u32 d) {
+  const bool packed = (c.flags & CBH_FI_PACKED_TAGS) != 0;
+  CBH_L u8* tags = (CBH_L u8*)(c.cc + 2u * c.n_cached * CBH_BLOCK);
+  const u32 d8 = d * 8u;
+  for (u32 k = 0; k < c.n_cached; ++k) {
+    const size_t u = (size_t)k * NR + req0;   // uniform
+    const CBH_G char* vb = (const CBH_G char*)(b.col_val + u);
+    const CBH_G char* vb4 = vb + 4;   // (the value's high word from a second uniform base)
+    lds_dma_dword(vb + d8, c.cc + k * CBH_BLOCK, c.tid);
+    lds_dma_dword(vb4 + d8, c.cc + (c.n_cached + k) * CBH_BLOCK, c.tid);
+    if (!packed) {   // the aligned dword that holds the lane's tag byte (cached_tag picks the byte)
+      const u32 sh = (u32)u & 3u;
+#ifndef CBH_HOSTSIM
+      const CBH_G char* tb = (const CBH_G char*)(b.col_tag + (u - sh));
+      lds_dma_dword(tb + ((d + sh) & ~3u), c.cc + (2 * c.n_cached + k) * CBH_BLOCK, c.tid);
+#else
+      // (the host arrays carry no slack after their last byte and need not be dword-aligned: place the one byte where the device's
+      // aligned dword would have it)
+      c.cc[(2 * c.n_cached + k) * CBH_BLOCK + c.tid] = (u32)b.col_tag[u + d] << (((d + sh) & 3u) * 8u);
+#endif
+    } else tags[((k >> 2) * CBH_BLOCK + c.tid) * 4u + (k & 3u)] = ((const CBH_G u8*)(b.col_tag + u))[d];
+  }
+}
+
 struct CbhPassPrincipal { static constexpr bool value = false; };   // tags of the two instantiations of the
 struct CbhPassResource { static constexpr bool value = true; };     // policy pass (check_body below)
 

@@ -509,6 +509,10 @@ extern "C" void cbh_batch_release(cbh_device_batch* b) {
   if (!b) return;
   cbh_table* t = b->table;
   (void)hipSetDevice(b->rep->device); (void)hipStreamSynchronize(b->stream ? b->stream : b->rep->stream);
+  // a copy of this batch's outputs may still run on the replica's SHARED download stream (cbh_wire_outputs left early on an
+  // error between the copy's enqueue and its wait): its block must not go back to the pool - and its event not to another
+  // batch - before the copy has landed.  The event was recorded behind the copy; an event never recorded is complete.
+  if (b->w_ev[1]) { if (hipEventSynchronize(b->w_ev[1]) != hipSuccess) (void)hipGetLastError(); }
   {
     std::lock_guard<std::mutex> lk(b->rep->pool_mu);
     for (auto& a : b->allocs) b->rep->pool_free.push_back(a);
@@ -789,7 +793,10 @@ extern "C" const char* cbh_plan_describe(cbh_table* t, cbh_device_batch* b, cons
   static thread_local std::string s;
   if (!t || !b || !p) return "";
   const CbhPlan pl = plan_for(b->rep->dev, b->max_actions, b->max_roles, b->plain_tags, p->flags & ~(u32)CBH_FI_MASK);
-  if (pl.kind == 2) s = std::string(pl.wide_kernel ? "cbh_check_kernel*(wide requests)+" : "") + (pl.walk_wide ? (pl.trail ? "cbh_walk2_wide_trail_kernel(5-8 roles)+" : "cbh_walk2_wide_kernel(5-8 roles)+") : "") + (pl.walk_awide ? (pl.trail ? "cbh_walk2_awide_trail_kernel(9-16 actions)+" : "cbh_walk2_awide_kernel(9-16 actions)+") : "") + (pl.n_gwords && b->dev.gres ? "cbh_walk2_pre_kernel+" : "") + (pl.trail ? "cbh_walk2_trail_kernel" : "cbh_walk2_kernel");
+  // (the pre-pass's form: cbh_check_resident's own condition for giving the batch its site lists)
+  const Replica* rep = b->rep;
+  const bool pre_split = pre_split_on() && b->dev.n_requests && (rep->dev.flags & CBH_MF_WALK2) && rep->dev.gslots_all && !(rep->dev.flags & CBH_MF_USES_RUNTIME_EDR) && b->dev.gres;
+  if (pl.kind == 2) s = std::string(pl.wide_kernel ? "cbh_check_kernel*(wide requests)+" : "") + (pl.walk_wide ? (pl.trail ? "cbh_walk2_wide_trail_kernel(5-8 roles)+" : "cbh_walk2_wide_kernel(5-8 roles)+") : "") + (pl.walk_awide ? (pl.trail ? "cbh_walk2_awide_trail_kernel(9-16 actions)+" : "cbh_walk2_awide_kernel(9-16 actions)+") : "") + (pl.n_gwords && b->dev.gres ? (pre_split ? "cbh_walk2_collect_kernel+cbh_walk2_interp_kernel+" : "cbh_walk2_pre_kernel+") : "") + (pl.trail ? "cbh_walk2_trail_kernel" : "cbh_walk2_kernel");
   else if (pl.kind == 1 && cbh_is_flat_trail_kernel(pl.kernel)) s = cbh_is_mask_kernel(pl.kernel) ? "cbh_check_flat_trail_kernel*_masks" : "cbh_check_flat_trail_kernel*";
   else if (pl.kind == 0 && pl.kernel == cbh_check_trail_kernel) s = "cbh_check_trail_kernel";
   else if (pl.kind == 1) s = pl.kernel == cbh_check_flat_kernel ? "cbh_check_flat_kernel" : pl.kernel == cbh_check_flat_kernel_any ? "cbh_check_flat_kernel_any"
@@ -1427,7 +1434,10 @@ extern "C" int cbh_wire_outputs(cbh_table* t, cbh_device_batch* b, uint8_t* byte
   hipEvent_t ev_w = (st.total && d_out && wire_link_streams(rep)) ? wire_event(b, 0) : nullptr, ev_d = ev_w ? wire_event(b, 1) : nullptr;
   if (ev_w && ev_d && hipEventRecord(ev_w, s) == hipSuccess && hipStreamWaitEvent(rep->down_stream, ev_w, 0) == hipSuccess) {
     HIPCHK(hipMemcpyAsync(bytes, d_out, (size_t)st.total, hipMemcpyDeviceToHost, rep->down_stream));
-    HIPCHK(hipEventRecord(ev_d, rep->down_stream));
+    if (hipEventRecord(ev_d, rep->down_stream) != hipSuccess) {   // the copy flies with nothing to wait on but its stream
+      (void)hipGetLastError(); (void)hipStreamSynchronize(rep->down_stream);
+      return fail("cbh_wire_outputs: hipEventRecord failed behind the download");
+    }
   } else {
     ev_d = nullptr;
     if (st.total && d_out) HIPCHK(hipMemcpyAsync(bytes, d_out, (size_t)st.total, hipMemcpyDeviceToHost, s));

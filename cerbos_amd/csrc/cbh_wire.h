@@ -157,16 +157,25 @@ struct WSpan { u32 p, e; };   // byte offsets into WireArgs.msg
 struct WField { u32 num, wt; u64 v; WSpan s; };
 struct WVal { u32 kind; u64 v; WSpan s; };
 
+// the seven payload bits of each of eight bytes (continuation bits already masked off) closed up into 56 bits
+#if defined(CBH_WIRE_OOL) && !defined(CBH_HOSTSIM)
+// CBH_WIRE_OOL (an experiment's build): the fold as a real function, called only where a lane meets a multi-byte varint - the fill
+// kernel's code is two to three times the instruction cache and this fold sits inlined behind every one-byte fast path of it
+__device__ __attribute__((noinline)) u64 w_fold7(u64 x) {
+#else
+__device__ __forceinline__ u64 w_fold7(u64 x) {
+#endif
+  x = ((x & 0x7F007F007F007F00ull) >> 1) | (x & 0x007F007F007F007Full);
+  x = ((x & 0x3FFF00003FFF0000ull) >> 2) | (x & 0x00003FFF00003FFFull);
+  x = ((x & 0x0FFFFFFF00000000ull) >> 4) | (x & 0x000000000FFFFFFFull);
+  return x;
+}
 // a varint of at most eight bytes in the low bytes of `w`: its value; returns its length (0: it does not end within the window)
 __device__ __forceinline__ u32 w_varint_win(u64 w, u64& out) {
   const u64 stop = ~w & 0x8080808080808080ull;
   if (!stop) return 0u;
   const u32 n = ((u32)__builtin_ctzll(stop) >> 3) + 1u;
-  u64 x = w & (~0ull >> (64u - 8u * n)) & 0x7F7F7F7F7F7F7F7Full;
-  x = ((x & 0x7F007F007F007F00ull) >> 1) | (x & 0x007F007F007F007Full);
-  x = ((x & 0x3FFF00003FFF0000ull) >> 2) | (x & 0x00003FFF00003FFFull);
-  x = ((x & 0x0FFFFFFF00000000ull) >> 4) | (x & 0x000000000FFFFFFFull);
-  out = x;
+  out = w_fold7(w & (~0ull >> (64u - 8u * n)) & 0x7F7F7F7F7F7F7F7Full);
   return n;
 }
 // ... and of nine or ten: `w` = its first eight bytes (every one with the continuation bit), the rest follows at m[p + 8].  A tenth
@@ -174,10 +183,7 @@ __device__ __forceinline__ u32 w_varint_win(u64 w, u64& out) {
 template <class MP>
 __device__ __forceinline__ u32 w_varint_long(MP m, u32 p, u32 avail, u64 w, u64& out) {
   if (avail < 9u) return 0u;
-  u64 x = w & 0x7F7F7F7F7F7F7F7Full;
-  x = ((x & 0x7F007F007F007F00ull) >> 1) | (x & 0x007F007F007F007Full);
-  x = ((x & 0x3FFF00003FFF0000ull) >> 2) | (x & 0x00003FFF00003FFFull);
-  x = ((x & 0x0FFFFFFF00000000ull) >> 4) | (x & 0x000000000FFFFFFFull);
+  const u64 x = w_fold7(w & 0x7F7F7F7F7F7F7F7Full);
   const u32 w2 = (u32)w_peek8(m, p + 8u);
   if (!(w2 & 0x80u)) { out = x | ((u64)(w2 & 0x7Fu) << 56); return 9u; }
   if (avail >= 10u && !(w2 & 0x8000u)) { out = x | ((u64)(w2 & 0x7Fu) << 56) | ((u64)((w2 >> 8) & 1u) << 63); return 10u; }
@@ -475,7 +481,9 @@ __device__ __forceinline__ u32 w_wave_max(u32 x, u32 bits) {   // largest x of t
 }
 
 #ifndef CBH_HOSTSIM
-typedef u32 w_v4 __attribute__((ext_vector_type(4)));
+// (aligned(4): some of these accesses are only 8-byte aligned - a lane's run of per-wave records starts at an odd record when `per`
+// is odd.  The 16-byte instruction is the same; the type must not promise the compiler an alignment the address does not have.)
+typedef u32 w_v4 __attribute__((ext_vector_type(4), aligned(4)));
 #define W_LOAD4(dst, p) { const w_v4 t_ = *(const CBH_G w_v4*)(p); (dst)[0] = t_.x; (dst)[1] = t_.y; (dst)[2] = t_.z; (dst)[3] = t_.w; }
 #define W_STORE4(p, src) { w_v4 t_; t_.x = (src)[0]; t_.y = (src)[1]; t_.z = (src)[2]; t_.w = (src)[3]; *(CBH_G w_v4*)(p) = t_; }
 #else

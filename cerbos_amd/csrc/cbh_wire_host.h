@@ -44,12 +44,15 @@ static inline const char* cbh_wire_index_build(WireIndexHost& w, const uint8_t* 
     w.tix[2 * (size_t)at + 1] = ((u64)off[i] << 32) | (u64)(off[i + 1] - off[i]);
   }
   // the device compares strings eight bytes at a time: the pool must be readable CBH_WIRE_SLACK bytes beyond its last string
-  if ((u64)sb->offset + off[K] + CBH_WIRE_SLACK > len) return "image ends within the device flattener's read-ahead of the string pool";
+  // (blob.py always writes sections behind the pool; an image that ends with it is still a valid table: only the device road of the
+  // wire format is closed for it - every batch goes through libcerbos_ingest.so - the table itself loads and decides.)
+  const bool pool_at_end = (u64)sb->offset + off[K] + CBH_WIRE_SLACK > len;
   w.scope_of_sid.assign(K ? K : 1, CBH_NONE);
   const u32* ssid = reinterpret_cast<const u32*>(image + ss->offset);
   for (u32 i = 0; i < ns; ++i) { if (ssid[i] >= K) return "image scope string id out of range"; w.scope_of_sid[ssid[i]] = i; }
   const u8* p = image + sc->offset; const u8* e = p + sc->nbytes;
   w.cols.clear(); w.col_keys.clear(); w.why_not = nullptr;
+  if (pool_at_end) w.why_not = "the image ends within the device flattener's read-ahead of the string pool";
   for (u32 c = 0; c < ncol; ++c) {
     if (e - p < 2) return "image column path section truncated";
     WireCol col; memset(&col, 0, sizeof(col));

@@ -285,7 +285,10 @@ class Partial:
                 return other if other[0] != "e" else self._raise(other)
         if a[0] == "e" and b[0] == "e":
             self._raise(a)
-        if a[0] == "k" or b[0] == "k":      # a known operand that is not a bool
+        if (a[0] == "k" or b[0] == "k") and a[0] != "r" and b[0] != "r":
+            # a known operand that is not a bool beside another known operand or an error: no such overload.  Beside an
+            # UNKNOWN one the unknown outranks it as it outranks any error (evalAnd / evalOr): the residual below carries the
+            # non-bool operand as its literal, as the pruner does (`P.attr.num && R.attr.flag` with P.attr.num = 1 plans `1 && R.attr.flag`)
             raise CelEvalError("no such overload")
         # an error beside an unknown: cel-go answers unknown (interpretable.go evalAnd / evalOr: an unknown operand outranks an
         # error), and the pruner has no value to put in the failing operand's place - the residual keeps it as written

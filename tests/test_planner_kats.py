@@ -115,12 +115,20 @@ ERROR_BESIDE_UNKNOWN = [
     ("R.attr.x && (P.attr.n > 1 && P.attr.missing)", None),      # a known conjunction that fails: the condition's error
     ("false && P.attr.missing", "false"),
     ("R.attr.x && false && P.attr.missing", "false"),
+    # a known operand that is not a bool beside an unknown one: the unknown outranks "no such overload" as it outranks any error
+    ("P.attr.n && R.attr.x", "2.0 && R.attr.x"),
+    ("R.attr.x || P.attr.n", "R.attr.x || 2.0"),
+    ("P.attr.n && true", None),                                   # ... beside a known one: no such overload
 ]
 
 
 @pytest.mark.parametrize("expr,want", ERROR_BESIDE_UNKNOWN, ids=[e[0] for e in ERROR_BESIDE_UNKNOWN])
 def test_an_error_beside_an_unknown_stays_in_the_residual(expr, want):
     from cerbos_amd.plan.partial import CelEvalError
+    if want is None and expr.startswith("P.attr.n"):
+        with pytest.raises(CelEvalError):
+            residual(expr, {"attr": {"n": 2.0}}, {"kind": "k"})
+        return
     if want is None:
         got = residual(expr, {"attr": {"n": 2.0}}, {"kind": "k"})
         assert got == parse("R.attr.x && (P.attr.n > 1 && P.attr.missing)") or isinstance(got, tuple)

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 g++ -O1 -g -std=c++17 -shared -fPIC -Iinclude tests/hostsim/hostsim.cpp -o tests/hostsim/libcbh_hostsim.so
 g++ -O2 -std=c++17 -Wall -Wextra -shared -fPIC -pthread -Iinclude cerbos_amd/csrc/cbh_ingest.cpp -o cerbos_amd/libcerbos_ingest.so
 cd cerbos_amd/csrc
-LOG=$(mktemp)
+LOG=${CBH_BUILD_LOG:-$(mktemp)}
 # CBH_PROFILE=1 builds the per-wave cycle counters in (tools/gpu_cycles.py); never ship that build.
 if ! hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC ${CBH_PROFILE:+-DCBH_PROFILE_CYCLES} ${CBH_ABLATION:+-DCBH_ABLATION} ${CBH_EXTRA_FLAGS:-} -I../../include cbh_engine.hip -o ../libcerbos_hip.so -Rpass-analysis=kernel-resource-usage > "$LOG" 2>&1; then
   grep -E "error" -A3 "$LOG" | head -40
