@@ -442,7 +442,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   const BatchDev& b = ka_regs.b;
   const OutDev& o = ka_regs.o;
   const u32 flags = ka_regs.flags;
-  const u32 wave = uniform(threadIdx.x / CBH_BLOCK);   // which of the group's waves (c.tid is the lane within it)
+  const u32 wave = threadIdx.x / CBH_BLOCK;   // (NOT through readfirstlane: measured 7-19 % slower on every workload, profiles/r06_ab_prologue.txt)   // which of the group's waves (c.tid is the lane within it)
 #ifdef CBH_PROFILE_CYCLES   // profiling build only (tools/gpu_cycles_flat.py)
   const u64 cyc0 = __builtin_readcyclecounter();
   const u64 rt0 = __builtin_amdgcn_s_memrealtime();
@@ -461,11 +461,26 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   const u32 role_off = RQ(CBH_RQ_ROLE_OFF), act_off = RQ(CBH_RQ_ACT_OFF);
   const u32 role_cnt = valid ? RQ(CBH_RQ_ROLE_CNT) : 0, act_cnt = valid ? RQ(CBH_RQ_ACT_CNT) : 0;   // both <= 4 (host-checked)
 #undef RQ
-  {   // the wave's requests are consecutive: uniform base + lane offset (cbh_check_wave.h fill_column_cache_seq)
-    const u32 w0 = b.req_lo + blockIdx.x * CBH_FLAT_THREADS + wave * CBH_BLOCK;   // the wave's first request (uniform)
-    const bool some = w0 < b.req_hi;
-    fill_column_cache_seq(c, b, NR, some ? w0 : b.req_lo, valid ? c.tid : 0u);
-  }
+  // ---- the request's loads, in TWO round trips to memory.  First trip, all issued back to back and depending on nothing: the
+  // request words above, the four action ids (speculated, below), this thread's bytes of the two class tables, the tag bytes of
+  // the cached columns (cc_load_tags).  Second trip, issued when the request words are in: the role ids and every column's
+  // asynchronous copies into LDS (cc_fill).  The copies go out LAST - any LDS access the compiler cannot tell apart from
+  // their destinations waits for all of them - behind this prologue's own LDS stores.  (They used to go out first: the class
+  // tables' LDS stores then waited for the columns, the action ids were loaded behind that wait and the role ids behind another
+  // - three trips, and one more per column where the tags are packed.)
+  const u32 w0r = b.req_lo + blockIdx.x * CBH_FLAT_THREADS + wave * CBH_BLOCK;
+  const u32 w0 = w0r < b.req_hi ? w0r : b.req_lo;   // the wave's first request (uniform): the columns' planes are addressed from it
+  const u32 wd = valid ? c.tid : 0u;                // ... and this lane's distance from it
+  // Actions: a batch of four-action requests laid out back to back has ACT_OFF = 4 * request - read the four ids from
+  // there with ONE 16-byte load that does not wait for ACT_OFF to arrive, and fall back to the dependent loads for the
+  // lanes where the guess was wrong.  (Unconditional: without four tuples the load reads request words and is not used.)
+  const bool spec = b.n_tuples >= 4u;   // wave-uniform
+  const u32 spec_ix = (4u * req + 4u <= b.n_tuples) ? 4u * req : 0u;
+  const u32x4u sp = load_u32x4(spec ? b.tuple_action + spec_ix : b.req_u32);
+  const u32 kmax = t.K ? t.K - 1u : 0u;
+  const u32 cls_i = threadIdx.x < t.K ? threadIdx.x : kmax;
+  const u32 cls_a0 = (t.K ? t.action_class : (const CBH_G u8*)b.req_u32)[cls_i], cls_r0 = (t.K ? t.role_class : (const CBH_G u8*)b.req_u32)[cls_i];
+  const CcTags cct = cc_load_tags(c, b, NR, w0, wd);
   const u32 all = (1u << act_cnt) - 1u;
   // [depth][lane]: scope index at that depth of the lane's chain - in the dynamic LDS behind the column caches,
   // sized by the table's longest chain (a one-scope table pays 256 B per wave, not 4 KB: LDS sets the occupancy here)
@@ -480,14 +495,24 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   // in bit 31 of the low dword: the match is a 1-bit field extract from ONE dword at a per-lane position.
   // Every load below is unconditional (an index that does not exist reads element 0 instead and is masked
   // afterwards): the eight id loads go out together, then the eight class loads - two round trips, not sixteen.
-  u32 ac[4], rc[4], aid[4], rid[4];
   // The class tables (one byte per table string) are copied into LDS by the workgroup while the request loads are in
   // flight - a table of up to CBH_FLAT_LDS_STRINGS strings - so that the lookups below are LDS reads, not a third
   // dependent trip to memory.
   const bool cls_in_lds = t.K <= CBH_FLAT_LDS_STRINGS;
   CBH_L u8* cls_lds = (CBH_L u8*)((CBH_L u32*)cbh_dyn_lds + CBH_FLAT_WAVES * (CBH_CC_DWORDS(c.n_cached, (c.flags & CBH_FI_PACKED_TAGS) != 0) + chain_dwords));   // [action classes K][role classes K]
+  // second trip: the role ids (and, where the speculation missed, the action ids)
+  u32 ac[4], rc[4], aid[4], rid[4];
+#pragma unroll
+  for (u32 k = 0; k < 4; ++k) rid[k] = b.roles[k < role_cnt ? role_off + k : 0u];
+  const bool spec_hit = spec && act_cnt == 4u && act_off == spec_ix;
+  aid[0] = sp.x; aid[1] = sp.y; aid[2] = sp.z; aid[3] = sp.w;
+  if (!spec_hit) {
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) aid[k] = b.tuple_action[k < act_cnt ? act_off + k : 0u];
+  }
   if (cls_in_lds) {
-    for (u32 i = threadIdx.x; i < t.K; i += CBH_FLAT_THREADS) { cls_lds[i] = t.action_class[i]; cls_lds[t.K + i] = t.role_class[i]; }
+    if (threadIdx.x < t.K) { cls_lds[threadIdx.x] = (u8)cls_a0; cls_lds[t.K + threadIdx.x] = (u8)cls_r0; }
+    for (u32 i = threadIdx.x + CBH_FLAT_THREADS; i < t.K; i += CBH_FLAT_THREADS) { cls_lds[i] = t.action_class[i]; cls_lds[t.K + i] = t.role_class[i]; }
   }
   // MODE 2: the class masks of the segment being decided, per wave (behind the class tables: cbh_flat_class_bytes is a multiple of 16)
   CBH_L u64* segm = (CBH_L u64*)(cls_lds + (cls_in_lds ? ((2u * t.K + 15u) & ~15u) : 0u)) + wave * (CBH_SEG_LDS_BYTES / 8u);
@@ -498,22 +523,10 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   CBH_L u32* ep_lds = (CBH_L u32*)(cls_lds + (cls_in_lds ? ((2u * t.K + 15u) & ~15u) : 0u) + (MODE == 2 ? CBH_FLAT_WAVES * CBH_SEG_LDS_BYTES : 0u)) + wave * max_depth * 2u * CBH_BLOCK;
   const bool want_ep = EP && (flags & CBH_F_WANT_EFFECTIVE_POLICIES) != 0 && o.eff_pol != nullptr;
   if (EP) { for (u32 d = 0; d < 2u * max_depth; ++d) ep_lds[d * CBH_BLOCK + c.tid] = 0; }
-  // Actions: a batch of four-action requests laid out back to back has ACT_OFF = 4 * request - read the four ids from
-  // there with ONE 16-byte load that does not wait for ACT_OFF to arrive, and fall back to the dependent loads for the
-  // lanes where the guess was wrong.
-  const bool spec = b.n_tuples >= 4u;   // wave-uniform
-  const u32 spec_ix = (4u * req + 4u <= b.n_tuples) ? 4u * req : 0u;
-  u32x4u sp; sp.x = sp.y = sp.z = sp.w = 0;
-  if (spec) sp = load_u32x4(b.tuple_action + spec_ix);
-#pragma unroll
-  for (u32 k = 0; k < 4; ++k) rid[k] = b.roles[k < role_cnt ? role_off + k : 0u];
-  const bool spec_hit = spec && act_cnt == 4u && act_off == spec_ix;
-  aid[0] = sp.x; aid[1] = sp.y; aid[2] = sp.z; aid[3] = sp.w;
-  if (!spec_hit) {
-#pragma unroll
-    for (u32 k = 0; k < 4; ++k) aid[k] = b.tuple_action[k < act_cnt ? act_off + k : 0u];
-  }
-  const u32 kmax = t.K ? t.K - 1u : 0u;
+  cc_fill(c, b, NR, w0, wd, cct);   // (behind every LDS store of this prologue)
+  // ... and the chain's first scope (ruletable.go:848-882; per lane, reads the scope tables): its load goes out with the second trip
+  const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
+  const u32 first = chain_first(t, r_scope, FLAG_RES, lenient);
   if (cls_in_lds) {
     __syncthreads();
 #pragma unroll
@@ -542,7 +555,6 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   const u32 wave_ac = (u32)wave_cls, wave_rc = (u32)(wave_cls >> 32);
   FLAT_DBG(const u64 cyc1 = __builtin_readcyclecounter();)   // request fields, ids and classes have arrived
 
-  const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
   Lane L; L.req = req; L.edr = 0; L.status = 0; L.edr_err = false; L.pid = pid;
 
   u32 S = walks;                 // walks still going
@@ -583,7 +595,6 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   // fall in with each other as soon as the deeper ones have climbed to the shallower ones' start: a wave holding the
   // five request scopes of one kind walks its three buckets once, not once per request scope.  Each lane still meets
   // its own scopes in chain order and a bucket's records in binding order.
-  const u32 first = chain_first(t, r_scope, FLAG_RES, lenient);   // per lane (ruletable.go:848-882)
   u32 cur = first, mydepth = 0;
   bool exists = false;
   // MODE 2.  Pooled table: the leaves are numbered table-wide and evaluated ONCE per wave, when the first lane meets a
@@ -634,9 +645,11 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
           segm[c.tid] = m_nx;
           if (c.tid < 32u) ((CBH_L u32*)seg_rec)[c.tid] = r_nx;
           seg_desc[c.tid] = d_nx;
-          if (sgi + 1u < bucket.y) {   // the next segment's
-            hd_nx = uload_rec<SegHdr>(t.segs, blk16);
-            bn = t.segs + (size_t)blk16 * 16u;
+          {   // the next segment's (unconditional - behind the last segment the bucket's first block is read again and not used: a
+              // load inside a conditional block is waited for at the block's end, which made this fetch-ahead a wait per segment)
+            const u32 nb16 = (sgi + 1u < bucket.y) ? blk16 : bucket.x;
+            hd_nx = uload_rec<SegHdr>(t.segs, nb16);
+            bn = t.segs + (size_t)nb16 * 16u;
             m_nx = load_u64g(bn + 16u + 2u * c.tid); d_nx = load_u64g(bn + CBH_SEG_FIXED_DWORDS + 2u * c.tid);
             r_nx = bn[144u + (c.tid & 31u)];
           }
@@ -1056,7 +1069,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 #define CBH_FLAT_CTX(a, ka)                                                                                                       \
   const u32 ncc = cached_columns(&a);                                                                                             \
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,  \
-        (CBH_L u32*)cbh_dyn_lds + uniform(threadIdx.x / CBH_BLOCK) * CBH_CC_DWORDS(ncc, (a.flags & CBH_FI_PACKED_TAGS) != 0), ncc, ka}
+        (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * CBH_CC_DWORDS(ncc, (a.flags & CBH_FI_PACKED_TAGS) != 0), ncc, ka}
 // batches of plain scalars (no int / uint / list / map attribute values): no call, ~64 VGPRs, 7-8 waves per SIMD
 __global__ CBH_FLAT_ATTRS(7) void cbh_check_flat_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
   CBH_FLAT_CTX(a, ka);

@@ -114,7 +114,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   const BatchDev& b = ka_regs.b;
   const OutDev& o = ka_regs.o;
   const u32 flags = ka_regs.flags;
-  const u32 wave = uniform(threadIdx.x / CBH_BLOCK);
+  const u32 wave = threadIdx.x / CBH_BLOCK;   // (NOT through readfirstlane: measured 7-19 % slower on every workload, profiles/r06_ab_prologue.txt)
   constexpr u32 NA = NA_, NR = NR_;
   typedef typename W2Shape<NA, NR>::W W;
   constexpr W REP = W2Shape<NA, NR>::rep();       // x * REP: an action mask in every role's field
@@ -143,9 +143,19 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   const u32 pid = RQ(CBH_RQ_PRINCIPAL_ID), kind = RQ(CBH_RQ_KIND), r_scope = RQ(CBH_RQ_R_SCOPE), r_ver = RQ(CBH_RQ_R_VERSION);
   const u32 role_off = RQ(CBH_RQ_ROLE_OFF), act_off = RQ(CBH_RQ_ACT_OFF);
   const u32 role_cnt = valid ? RQ(CBH_RQ_ROLE_CNT) : 0, act_cnt = valid ? RQ(CBH_RQ_ACT_CNT) : 0;   // <= NR / <= NA (host-checked, or filtered above)
-  u32 p_scope = 0, p_ver = 0;
-  if (has_pp) { p_scope = RQ(CBH_RQ_P_SCOPE); p_ver = RQ(CBH_RQ_P_VERSION); }
+  // (unconditional: a load inside a conditional block is waited for at the block's end - with everything issued before it)
+  const u32 p_scope = RQ(CBH_RQ_P_SCOPE), p_ver = RQ(CBH_RQ_P_VERSION);
 #undef RQ
+  // The request's loads in two round trips (cbh_check_flat.h flat_body, cbh_check_wave.h cc_load_tags / cc_fill): first what
+  // depends on nothing - the request words above, the speculated action ids, the class tables' bytes, the columns' tag bytes -,
+  // then the role ids and, LAST, behind this prologue's own LDS stores, the columns' asynchronous copies.
+  const u32 w0r = b.req_lo + blockIdx.x * (PRE ? CBH_BLOCK : CBH_W2_THREADS) + wave * CBH_BLOCK;
+  const u32 w0 = w0r < b.req_hi ? w0r : b.req_lo;   // the wave's first request (uniform)
+  const u32 wd = valid ? c.tid : 0u;
+  const bool spec = b.n_tuples >= 4u;
+  const u32 spec_ix = (4u * req + 4u <= b.n_tuples) ? 4u * req : 0u;
+  const u32x4u sp = load_u32x4(spec ? b.tuple_action + spec_ix : b.req_u32);
+  const CcTags cct = cc_load_tags(c, b, NRQ, w0, wd);
   const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
   const u32 first = chain_first(t, r_scope, FLAG_RES, lenient);
   bool pre_climbs = false;   // pre-pass: does anything on this request's path hold a site the batch files?
@@ -163,10 +173,6 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     if (wave_ballot(pre_climbs || pre_pp) == 0) return;   // nothing to evaluate for this wave
   }
   W2_DBG(const u64 cycA0 = __builtin_readcyclecounter();)
-  {   // the wave's requests are consecutive: uniform base + lane offset (cbh_check_wave.h fill_column_cache_seq)
-    const u32 w0 = b.req_lo + blockIdx.x * (PRE ? CBH_BLOCK : CBH_W2_THREADS) + wave * CBH_BLOCK;   // the wave's first request (uniform)
-    fill_column_cache_seq(c, b, NRQ, w0 < b.req_hi ? w0 : b.req_lo, valid ? c.tid : 0u);
-  }
   W2_DBG(const u64 cycA = __builtin_readcyclecounter();)
   const u32 all = (1u << act_cnt) - 1u;
   const u32 max_depth = t.max_depth < CBH_FLAT_MAX_DEPTH ? t.max_depth : CBH_FLAT_MAX_DEPTH;
@@ -197,10 +203,6 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
 
   // ---- actions and roles: ids -> classes (63 = a string no rule names) and glob match bits
   u32 aid[NA], rid[NR], ac[NA];
-  const bool spec = b.n_tuples >= 4u;
-  const u32 spec_ix = (4u * req + 4u <= b.n_tuples) ? 4u * req : 0u;
-  u32x4u sp; sp.x = sp.y = sp.z = sp.w = 0;
-  if (spec) sp = load_u32x4(b.tuple_action + spec_ix);
 #pragma unroll
   for (u32 k = 0; k < NR; ++k) rid[k] = b.roles[k < role_cnt ? role_off + k : 0u];
   const bool spec_hit = spec && act_cnt == 4u && act_off == spec_ix;
@@ -215,6 +217,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
 #pragma unroll
     for (u32 k = 4; k < NA; ++k) aid[k] = b.tuple_action[k < act_cnt ? act_off + k : 0u];
   }
+  cc_fill(c, b, NRQ, w0, wd, cct);   // (behind every LDS store of this prologue)
   const u32 kmax = t.K ? t.K - 1u : 0u;
   u32 rcls[NR];
   u32 rpar = 0;   // bit r: the role has ancestors in some scope (CBH_SWF_PARENTS): the only ones the directory is asked about
@@ -910,7 +913,7 @@ __device__ __forceinline__ void w2_walk_kernel_body(const KernelArgs& a, const K
   const u32 ncc = a.t.inline_cols;   // no generic program runs here: only the columns the inline leaf code reads are parked in LDS
   const W2Layout ly = w2_layout(ncc, false, a.t.max_depth, a.t.n_scopes, false, 0, a.t.K, a.t.n_dr, NA, (a.flags & CBH_FI_PACKED_TAGS) != 0);
   Ctx c{a.t, a.b, a.now_ns, a.flags, threadIdx.x % CBH_BLOCK, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-        (CBH_L u32*)cbh_dyn_lds + uniform(threadIdx.x / CBH_BLOCK) * ly.wave_dw, ncc, ka};
+        (CBH_L u32*)cbh_dyn_lds + (threadIdx.x / CBH_BLOCK) * ly.wave_dw, ncc, ka};
   w2_body<0, NA, NR, EP>(a, c, ly);
 }
 __global__ CBH_W2_ATTRS void cbh_walk2_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) { w2_walk_kernel_body<CBH_W2_NA, CBH_W2_NR>(a, ka); }

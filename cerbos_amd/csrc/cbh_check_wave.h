@@ -385,7 +385,19 @@ __device__ __forceinline__ void load_args(KernelArgs& dst, const KernelArgs* src
 // which is exactly a [column][lane] dword plane)
 __device__ __forceinline__ void fill_column_cache(const Ctx& c, const BatchDev& b, u32 NR, u32 req) {
   const bool packed = (c.flags & CBH_FI_PACKED_TAGS) != 0;   // the two forms of the tags: cbh_vm.h CBH_CC_DWORDS
-  CBH_L u8* tags = (CBH_L u8*)(c.cc + 2u * c.n_cached * CBH_BLOCK);
+  if (packed) {
+    // the tag bytes of ALL columns first, back to back, then their LDS stores: a load followed by its store inside the loop
+    // over the columns made that loop one round trip to memory per column (cc_load_tags below tells the story)
+    CBH_L u32* tags = c.cc + 2u * c.n_cached * CBH_BLOCK;
+    const u32 n = c.n_cached, last = n ? n - 1u : 0u;
+    const CBH_G u8* base = n ? b.col_tag : (const CBH_G u8*)b.req_u32;
+    u32 by[CBH_CACHE_COLS];
+#pragma unroll
+    for (u32 k = 0; k < CBH_CACHE_COLS; ++k) by[k] = (u32)base[(size_t)(k < n ? k : last) * NR + (n ? req : 0u)];
+#pragma unroll
+    for (u32 g = 0; g < CBH_CACHE_COLS / 4; ++g)
+      if (4u * g < n) tags[g * CBH_BLOCK + c.tid] = by[4 * g] | (by[4 * g + 1] << 8) | (by[4 * g + 2] << 16) | (by[4 * g + 3] << 24);
+  }
   for (u32 k = 0; k < c.n_cached; ++k) {
     const size_t ix = (size_t)k * NR + req;
     const CBH_G u32* vsrc = (const CBH_G u32*)(b.col_val + ix);
@@ -399,7 +411,6 @@ __device__ __forceinline__ void fill_column_cache(const Ctx& c, const BatchDev& 
     // (the host arrays carry no slack after their last byte: place the one byte instead of copying its dword)
     if (!packed) c.cc[(2 * c.n_cached + k) * CBH_BLOCK + c.tid] = (u32)b.col_tag[ix] << ((ix & 3u) * 8u);
 #endif
-    if (packed) tags[((k >> 2) * CBH_BLOCK + c.tid) * 4u + (k & 3u)] = b.col_tag[ix];
   }
 }
 
@@ -414,15 +425,48 @@ __device__ __forceinline__ void lds_dma_dword(const CBH_G void* g, CBH_L u32* ld
   __builtin_memcpy(&lds[lane], g, 4);
 #endif
 }
-// The same fill for the kernels whose lanes hold CONSECUTIVE requests (the flat kernels, the walk): every address is a wave-uniform
-// base - the column's plane at the wave's first request, formed on the scalar unit - plus a 32-bit lane offset, the form the
-// load instructions take as is (saddr + voffset): no 64-bit address arithmetic per lane and column, and the LDS side (the wave's
-// slice of the cache: uniform) goes to M0 without a read-back from a vector register.  `req0` = the wave's first request
-// (uniform), `d` = this lane's distance from it (< the workgroup's size; a lane beyond the batch's end passes 0: it shadows the
-// wave's first request here, and never stores).
-__device__ __forceinline__ void fill_column_cache_seq(const Ctx& c, const BatchDev& b, u32 NR, u32 req0, u32 d) {
+// The same fill for the kernels whose lanes hold CONSECUTIVE requests (the flat kernels, the walk), in TWO steps the caller places:
+// every address is a wave-uniform base - the column's plane at the wave's first request, formed on the scalar unit - plus a 32-bit
+// lane offset: no 64-bit address arithmetic per lane and column, and the LDS side (the wave's slice of the cache: uniform) goes to
+// M0 without a read-back from a vector register.  `req0` = the wave's first request (uniform), `d` = this lane's distance from it
+// (< 64; a lane beyond the batch's end passes 0: it shadows the wave's first request here, and never stores).
+//
+// Why two steps.  In the packed form of the tags a lane's tag byte goes through a register (there is no one-byte copy into LDS),
+// and a load followed by its LDS store INSIDE the loop over the columns made that loop a chain of round trips to memory - one per
+// column, nine for the tables of C3 / C4 / T (the store waits for its byte, and with it for every copy issued before).  So:
+//   cc_load_tags   the tag bytes of ALL columns into registers, back to back, depending on nothing - issued with the request's
+//                  other first loads;
+//   cc_fill        the bytes into LDS (packed form), then every column's asynchronous copies.  Any LDS access the compiler
+//                  cannot tell apart from the copies' destinations waits for all of them, so the caller issues the copies as
+//                  late as it can: behind its own LDS stores, beside its last dependent loads.
+struct CcTags { u32 w[CBH_CACHE_COLS / 4]; };
+__device__ __forceinline__ CcTags cc_load_tags(const Ctx& c, const BatchDev& b, u32 NR, u32 req0, u32 d) {
+  CcTags t;
+#pragma unroll
+  for (u32 g = 0; g < CBH_CACHE_COLS / 4; ++g) t.w[g] = 0;
+  if ((c.flags & CBH_FI_PACKED_TAGS) == 0) return t;   // (uniform; the wide form's tags arrive as copies of their dwords)
+  const u32 n = c.n_cached, last = n ? n - 1u : 0u;
+  // (no branch around a load: a load inside a conditional block is waited for at the block's end.  A column beyond the last
+  // re-reads the last one's byte - the same line - and a table without columns reads a request word instead)
+  const CBH_G u8* base = n ? b.col_tag : (const CBH_G u8*)b.req_u32;
+  u32 by[CBH_CACHE_COLS];
+#pragma unroll
+  for (u32 k = 0; k < CBH_CACHE_COLS; ++k) {
+    const u32 kk = k < n ? k : last;
+    const size_t u = (size_t)kk * NR + req0;   // uniform
+    by[k] = (u32)(base + u)[d];
+  }
+#pragma unroll
+  for (u32 g = 0; g < CBH_CACHE_COLS / 4; ++g) t.w[g] = by[4 * g] | (by[4 * g + 1] << 8) | (by[4 * g + 2] << 16) | (by[4 * g + 3] << 24);
+  return t;
+}
+__device__ __forceinline__ void cc_fill(const Ctx& c, const BatchDev& b, u32 NR, u32 req0, u32 d, const CcTags& t) {
   const bool packed = (c.flags & CBH_FI_PACKED_TAGS) != 0;
-  CBH_L u8* tags = (CBH_L u8*)(c.cc + 2u * c.n_cached * CBH_BLOCK);
+  CBH_L u32* tags = c.cc + 2u * c.n_cached * CBH_BLOCK;
+  if (packed) {
+#pragma unroll
+    for (u32 g = 0; g < CBH_CACHE_COLS / 4; ++g) if (4u * g < c.n_cached) tags[g * CBH_BLOCK + c.tid] = t.w[g];
+  }
   const u32 d8 = d * 8u;
   for (u32 k = 0; k < c.n_cached; ++k) {
     const size_t u = (size_t)k * NR + req0;   // uniform
@@ -440,7 +484,7 @@ __device__ __forceinline__ void fill_column_cache_seq(const Ctx& c, const BatchD
       // aligned dword would have it)
       c.cc[(2 * c.n_cached + k) * CBH_BLOCK + c.tid] = (u32)b.col_tag[u + d] << (((d + sh) & 3u) * 8u);
 #endif
-    } else tags[((k >> 2) * CBH_BLOCK + c.tid) * 4u + (k & 3u)] = ((const CBH_G u8*)(b.col_tag + u))[d];
+    }
   }
 }
 
