@@ -55,10 +55,17 @@ __device__ __forceinline__ u32 chain_next(const TableDev& t, u32 si, u32 flagbit
 }
 // first scope of the chain for a request scope word (ruletable.go:848-882)
 __device__ __forceinline__ u32 chain_first(const TableDev& t, u32 raw, u32 flagbit, bool lenient) {
-  const u32 si = raw & ~CBH_SCOPE_EXACT;
+  u32 si = raw & ~CBH_SCOPE_EXACT;
   const bool exact = (raw & CBH_SCOPE_EXACT) != 0;
-  if (!lenient && !(exact && (t.scope_flags[si] & flagbit))) return CBH_NONE;
-  return chain_next(t, si, flagbit);
+  // (the scope's flags are read ONCE: read again by chain_next they were a second dependent round trip for every request)
+  u32 f = t.scope_flags[si < t.n_scopes ? si : 0u];   // (unconditional, from a valid place: the word is the flatteners', but nothing checked it)
+  if (si >= t.n_scopes || (!lenient && !(exact && (f & flagbit)))) return CBH_NONE;
+  while (!(f & flagbit)) {
+    si = t.scope_parent[si];
+    if (si == CBH_NONE) break;
+    f = t.scope_flags[si];
+  }
+  return si;
 }
 
 #if !defined(CBH_HOSTSIM) || defined(CBH_HOSTSIM_ENGINE)   /* (the kernel simulation gets the glob bits from its caller; the engine's does not) */
