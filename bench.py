@@ -47,22 +47,25 @@ import numpy as np  # noqa: E402
 ALG_BYTES_PER_DECISION = {"C1": 33.0, "C2": 49.0, "C3": 42.0, "C4": 47.0, "C5": 83.0, "T": 47.0, "C5W": 83.0}
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 SERIAL_BATCHES = 16                     # resident batches of the one-stream leg (0.8 GB at C2: beyond the Infinity Cache)
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")   # written by tools/gpu_final_r04.sh
+# written by tools/gpu_final_r06.sh (this round's kernels); the older summaries stand in for workloads it does not cover
+PMC_TRAFFIC_FILES = [os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_traffic.json", "r05_pmc_traffic_C3.json", "r04_pmc_traffic.json")]
 
 
 def pmc_traffic(kernel, workload):
     """HBM bytes per launch of `kernel` from separate rocprofv3 --pmc passes of THIS command (FETCH_SIZE and
     WRITE_SIZE do not fit one pass and a process cannot profile itself): read back from the committed summary,
     and the bench line says so in `traffic_source`.  None when no summary matches kernel and workload."""
-    try:
-        with open(PMC_TRAFFIC) as fh:
-            d = json.load(fh)
-    except (OSError, ValueError):
-        return None, None
-    e = (d.get("workloads") or {}).get(workload)
-    if not e or not all(k in kernel for k in (e.get("kernels") or [e.get("kernel", "?")])):
-        return None, None
-    return e["bytes_per_launch"], "profiles/r04_pmc_traffic.json: separate rocprofv3 --pmc passes of this command (%s)" % e.get("note", "")
+    for path in PMC_TRAFFIC_FILES:
+        try:
+            with open(path) as fh:
+                d = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        e = (d.get("workloads") or {}).get(workload)
+        if not e or not all(k in kernel for k in (e.get("kernels") or [e.get("kernel", "?")])):
+            continue
+        return e["bytes_per_launch"], "profiles/%s: separate rocprofv3 --pmc passes of this command (%s)" % (os.path.basename(path), e.get("note", ""))
+    return None, None
 
 
 def main():
@@ -376,6 +379,38 @@ def main():
                     raise RuntimeError("device road: rc %d: %s" % (rc, lib.cbh_last_error().decode()))
                 t3best, t3 = min(t3best, time.perf_counter() - w0), info.n_tuples
             side["wire_inclusive_three_calls_decisions_per_s"] = t3 / t3best
+            # ... and the same ONE caller thread keeping TWO calls in flight (cbh_wire_check_pb_submit / _collect): the second call's
+            # uploads run under the first's downloads.  Two sets of page-locked output buffers, the same input messages; ten calls,
+            # the clock around all of them.
+            try:
+                sets = [(pout, poff, pfl), (capi.pinned_empty(out_cap, np.uint8), capi.pinned_empty(nw + 1, np.uint64), capi.pinned_empty(nw + 1, np.uint8))]
+                def submit(k):
+                    h = C.c_void_p()
+                    rc_ = lib.cbh_wire_check_pb_submit(table.h, 0, pdata.ctypes.data, woff.ctypes.data, nw, b"default", b"", None, 0, C.byref(prm),
+                                                       sets[k][0].ctypes.data, out_cap, sets[k][1].ctypes.data, sets[k][2].ctypes.data, C.byref(h))
+                    if rc_ != 0:
+                        raise RuntimeError("cbh_wire_check_pb_submit: rc %d: %s" % (rc_, lib.cbh_last_error().decode()))
+                    return h
+                def collect(h):
+                    info_, need_ = capi.CWireInfo(), C.c_size_t()
+                    rc_ = lib.cbh_wire_check_pb_collect(table.h, h, C.byref(need_), C.byref(info_))
+                    if rc_ != 0:
+                        raise RuntimeError("cbh_wire_check_pb_collect: rc %d: %s" % (rc_, lib.cbh_last_error().decode()))
+                    return info_.n_tuples
+                n_calls, best2 = 10, 1e9
+                for _ in range(2):
+                    w0 = time.perf_counter()
+                    pend, done_t = [submit(0), submit(1)], 0
+                    for c in range(2, n_calls):
+                        done_t += collect(pend.pop(0))
+                        pend.append(submit(c & 1))
+                    while pend:
+                        done_t += collect(pend.pop(0))
+                    best2 = min(best2, (time.perf_counter() - w0) / n_calls)
+                assert bytes(sets[1][0][:int(sets[1][1][nw])]) == bytes(sets[0][0][:int(sets[0][1][nw])]), "the two sets of output buffers differ"
+                side["wire_inclusive_two_in_flight_decisions_per_s"] = (done_t / n_calls) / best2
+            except Exception as e:
+                side["wire_inclusive_two_in_flight_error"] = str(e)[:300]
             info, need = capi.CWireInfo(), C.c_size_t()
             rc = lib.cbh_wire_check_pb(table.h, 0, pdata.ctypes.data, woff.ctypes.data, nw, b"default", b"", None, 0, C.byref(prm),
                                        pout.ctypes.data, out_cap, poff.ctypes.data, pfl.ctypes.data, C.byref(need), C.byref(info))

@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "cbh_check_batch", "cbh_trace_batch", "cbh_batch_upload", "cbh_batch_upload_on", "cbh_batch_release", "cbh_check_resident",
     "cbh_synchronize", "cbh_result_download", "cbh_kernel_time_ms", "cbh_plan_describe",
     "cbh_check_resident_many", "cbh_table_set_resident_streams", "cbh_table_resident_streams",
-    "cbh_wire_flatten", "cbh_wire_spans_download", "cbh_wire_outputs", "cbh_wire_check_pb",
+    "cbh_wire_flatten", "cbh_wire_spans_download", "cbh_wire_outputs", "cbh_wire_check_pb", "cbh_wire_check_pb_submit", "cbh_wire_check_pb_collect",
     "cbh_wire_flatten_requests", "cbh_wire_check_requests_pb", "cbh_wire_check_requests_trail_pb", "cbh_batch_set_trail", "cbh_trail_download",
     "cbh_table_num_policies", "cbh_table_policy_key", "cbh_check_batch_trail",
 ]
@@ -168,6 +168,10 @@ def load():
     lib.cbh_wire_check_pb.argtypes = [vp, u32, vp, vp, u32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(CParams), vp, C.c_size_t, vp, vp,
                                       C.POINTER(C.c_size_t), C.POINTER(CWireInfo)]
     lib.cbh_wire_check_pb.restype = i32
+    lib.cbh_wire_check_pb_submit.argtypes = [vp, u32, vp, vp, u32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(CParams), vp, C.c_size_t, vp, vp, C.POINTER(vp)]
+    lib.cbh_wire_check_pb_submit.restype = i32
+    lib.cbh_wire_check_pb_collect.argtypes = [vp, vp, C.POINTER(C.c_size_t), C.POINTER(CWireInfo)]
+    lib.cbh_wire_check_pb_collect.restype = i32
     lib.cbh_wire_flatten_requests.argtypes = [vp, u32, vp, vp, u32, vp, vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, vp, vp, C.POINTER(vp), C.POINTER(CWireInfo)]
     lib.cbh_wire_flatten_requests.restype = i32
     lib.cbh_wire_check_requests_pb.argtypes = [vp, u32, vp, vp, u32, vp, vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(CParams), vp, vp,
@@ -438,6 +442,33 @@ class Table:
             ob = np.empty(int(need.value) + 64, dtype=np.uint8)
         if rc == 1:
             raise HostFlattenerNeeded(load().cbh_last_error().decode("utf-8", "replace"))
+        _check(rc)
+        raw = ob[:int(oo[n])].tobytes()
+        return [raw[int(oo[i]):int(oo[i + 1])] for i in range(n)], of[:n].copy()
+
+    def wire_check_pb_submit(self, data, offsets, out, now_ns=0, flags=0, default_policy_version="default", default_scope="", device_index=0):
+        """``cbh_wire_check_pb_submit``: the same call on a worker of the library.  ``out`` = (bytes uint8[cap], offsets uint64[n + 1],
+        flags uint8[n]) - the caller's buffers, untouched until ``wire_check_pb_collect``.  -> a ticket (keeps the arrays alive)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        ob, oo, of = out
+        p = CParams(now_ns, flags, 0)
+        h = C.c_void_p()
+        _check(load().cbh_wire_check_pb_submit(self.h, device_index, data.ctypes.data if data.size else None, offsets.ctypes.data, n,
+                                               default_policy_version.encode(), default_scope.encode(), None, 0, C.byref(p),
+                                               ob.ctypes.data, ob.size, oo.ctypes.data, of.ctypes.data, C.byref(h)))
+        return (h, data, offsets, out, n)
+
+    def wire_check_pb_collect(self, ticket):
+        """``cbh_wire_check_pb_collect``: -> ([serialized CheckOutput], flags uint8[n]) of the submitted call."""
+        h, _data, _offsets, (ob, oo, of), n = ticket
+        info, need = CWireInfo(), C.c_size_t()
+        rc = load().cbh_wire_check_pb_collect(self.h, h, C.byref(need), C.byref(info))
+        if rc == 1:
+            raise HostFlattenerNeeded(load().cbh_last_error().decode("utf-8", "replace"))
+        if rc == 2:
+            raise HipEngineError("cbh_wire_check_pb_collect: the output buffer is too small (%d bytes needed)" % need.value)
         _check(rc)
         raw = ob[:int(oo[n])].tobytes()
         return [raw[int(oo[i]):int(oo[i + 1])] for i in range(n)], of[:n].copy()

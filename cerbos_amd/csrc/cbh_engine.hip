@@ -1680,6 +1680,51 @@ extern "C" int cbh_wire_check_pb(cbh_table* t, uint32_t device_index, const uint
   return wire_check_sliced(t, device_index, bytes, offsets, n, default_version, default_scope, globals_pb, globals_len, p, out_bytes, out_cap, out_offsets, out_flags,
                            need, info, nullptr);
 }
+// ---- the same call without blocking the caller (include/cerbos_hip.h cbh_wire_check_pb_submit / _collect).  The ticket owns a
+// worker thread that makes the synchronous call; the strings are copied, the buffers are the caller's and stay untouched until
+// collect.  A caller that keeps two tickets in flight has the second call's uploads under the first's downloads - the fill and
+// drain of one call's slices are what a lone synchronous caller pays on top of the link's own time.
+struct cbh_wire_ticket {
+  std::thread worker;
+  std::string ver, scope, err;
+  int rc = -1;
+  size_t need = 0;
+  cbh_wire_info info{};
+};
+extern "C" int cbh_wire_check_pb_submit(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
+                                        const char* default_version, const char* default_scope, const uint8_t* globals_pb, size_t globals_len,
+                                        const cbh_params* p, uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags,
+                                        cbh_wire_ticket** ticket) {
+  if (!ticket) return fail("null argument");
+  *ticket = nullptr;
+  if (!t || !p || !out_offsets || (n && (!bytes || !offsets)) || (out_cap && !out_bytes)) return fail("null argument");
+  cbh_wire_ticket* k = new (std::nothrow) cbh_wire_ticket();
+  if (!k) return fail("out of memory");
+  k->ver = default_version ? default_version : ""; k->scope = default_scope ? default_scope : "";
+  const bool has_ver = default_version != nullptr, has_scope = default_scope != nullptr;
+  const cbh_params params = *p;
+  cbh_table_retain(t);   // the table outlives the call whatever the caller does with its own reference meanwhile
+  try {
+    k->worker = std::thread([=]() {
+      k->rc = wire_check_sliced(t, device_index, bytes, offsets, n, has_ver ? k->ver.c_str() : nullptr, has_scope ? k->scope.c_str() : nullptr, globals_pb, globals_len,
+                                &params, out_bytes, out_cap, out_offsets, out_flags, &k->need, &k->info, nullptr);
+      if (k->rc != 0) k->err = g_err;   // (the worker's own thread-local message: handed to the collecting thread)
+    });
+  } catch (...) { cbh_table_release(t); delete k; return fail("cbh_wire_check_pb_submit: cannot start a worker thread"); }
+  *ticket = k;
+  return 0;
+}
+extern "C" int cbh_wire_check_pb_collect(cbh_table* t, cbh_wire_ticket* ticket, size_t* need, cbh_wire_info* info) {
+  if (!ticket) return fail("null argument");
+  if (ticket->worker.joinable()) ticket->worker.join();
+  const int rc = ticket->rc;
+  if (need) *need = ticket->need;
+  if (info) *info = ticket->info;
+  if (rc != 0) g_err = ticket->err;
+  delete ticket;
+  cbh_table_release(t);   // submit's reference
+  return rc;
+}
 static int wire_check_requests_impl(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n_requests,
                                     const uint8_t* aux_bytes, const uint64_t* aux_offsets, const char* default_version, const char* default_scope,
                                     const uint8_t* globals_pb, size_t globals_len, const cbh_params* p, uint32_t* first_input, uint8_t* request_flags,

@@ -312,6 +312,22 @@ int cbh_wire_check_pb(cbh_table* t, uint32_t device_index, const uint8_t* bytes,
                       const cbh_params* p, uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags,
                       size_t* need, cbh_wire_info* info);
 
+/* ... and without blocking the caller.  cbh_wire_check_pb_submit starts the same call on a worker of the library and returns a
+ * ticket; cbh_wire_check_pb_collect (same table) waits for it, fills need / info and returns what cbh_wire_check_pb would have
+ * returned (the error text of a failed call is the collecting thread's cbh_last_error).  The strings are copied at submit; every
+ * buffer is the caller's and must stay valid and untouched until collect, which must be called exactly once per ticket.  ONE
+ * caller thread that keeps two tickets in flight has the second call's uploads under the first's downloads: the fill and drain of a
+ * call's slices are what a lone synchronous caller pays on top of the link's own time (bench.py `wire_inclusive_two_in_flight`).
+ * For a cgo caller: a blocking C call pins an OS thread for its duration, this pair does not (engine.go:289-338's loop over
+ * batches becomes submit, submit, collect, submit, collect ...). */
+#define CBH_HAS_WIRE_CHECK_ASYNC 1
+typedef struct cbh_wire_ticket cbh_wire_ticket;
+int cbh_wire_check_pb_submit(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n,
+                             const char* default_version, const char* default_scope, const uint8_t* globals_pb, size_t globals_len,
+                             const cbh_params* p, uint8_t* out_bytes, size_t out_cap, uint64_t* out_offsets, uint8_t* out_flags,
+                             cbh_wire_ticket** ticket);
+int cbh_wire_check_pb_collect(cbh_table* t, cbh_wire_ticket* ticket, size_t* need, cbh_wire_info* info);
+
 /* ---- engine.Check's second return value (internal/engine/engine.go:217-240, 289-338): AuditTrail.EffectivePolicies ----
  * The reference records, for every binding its walk ITERATES, the source attributes of that binding's policy set
  * (check.go:302-304: the policy itself and, for a scoped resource / principal policy, its ancestors - compile.go:153-180) and

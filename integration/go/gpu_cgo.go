@@ -229,6 +229,31 @@ func (g *gpuEngine) deviceRoad(bytesPtr *C.uint8_t, offs []C.uint64_t, n int, dv
 	return obytes, ooffs, oflags, func() { g.outPool.put(blk) }, true, nil
 }
 
+// deviceRoadAsync: the same road without holding an OS thread for the call's duration (a blocking cgo call pins one):
+// cbh_wire_check_pb_submit starts the call on a worker of the library, the returned function collects it.  A server loop that keeps
+// two of these in flight per GPU (submit, submit, collect, submit, collect ...) has one call's uploads under the other's downloads.
+// The input block and `blk` must stay untouched until collect; C memory only (cgo's pointer rules: no Go pointer outlives the call
+// that passed it - bytesPtr / offs must therefore be C allocations here, as blk is).
+func (g *gpuEngine) deviceRoadAsync(bytesPtr *C.uint8_t, offs *C.uint64_t, n int, dv, ds *C.char, params *C.cbh_params, blk *pinnedBlock) (collect func() (obytes []byte, ooffs []uint64, oflags []byte, rc int, err error), err error) {
+	var ticket *C.cbh_wire_ticket
+	if C.cbh_wire_check_pb_submit(g.table, 0, bytesPtr, offs, C.uint32_t(n), dv, ds, nil, 0, params, blk.bytes, C.size_t(blk.cap), blk.offs, blk.flags, &ticket) != 0 {
+		return nil, errors.New(C.GoString(C.cbh_last_error()))
+	}
+	return func() ([]byte, []uint64, []byte, int, error) {
+		var need C.size_t
+		var info C.cbh_wire_info
+		rc := int(C.cbh_wire_check_pb_collect(g.table, ticket, &need, &info))
+		if rc < 0 {
+			return nil, nil, nil, rc, errors.New(C.GoString(C.cbh_last_error()))
+		}
+		if rc != 0 { // 1: the host flattener's; 2: the block was short (need bytes)
+			return nil, nil, nil, rc, nil
+		}
+		ooffs := unsafe.Slice((*uint64)(unsafe.Pointer(blk.offs)), n+1)
+		return unsafe.Slice((*byte)(unsafe.Pointer(blk.bytes)), int(ooffs[n])), ooffs, unsafe.Slice((*byte)(unsafe.Pointer(blk.flags)), n), 0, nil
+	}, nil
+}
+
 // pinnedBlock / pinnedPool: page-locked output blocks (cbh_alloc_pinned) kept between calls.
 type pinnedBlock struct {
 	base  unsafe.Pointer

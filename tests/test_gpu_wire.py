@@ -153,3 +153,49 @@ def test_the_road_in_one_call_gives_the_three_calls_bytes(total=70_000):
         with pytest.raises(capi.HostFlattenerNeeded):
             table.wire_check_pb(data, off, now_ns=NOW, flags=flags)
         table.close()
+
+
+@pytest.mark.timeout(300)
+def test_two_calls_in_flight_from_one_thread(total=40_000):
+    """cbh_wire_check_pb_submit / _collect: two calls of the device road in flight at once from ONE caller thread (the second's
+    uploads under the first's downloads), collected in either order, give each the bytes the synchronous call gives; a ticket whose
+    output buffer is too small reports 2 at collect; a message for the host flattener reports 1 at collect - nothing is lost
+    between the worker's thread and the collecting one."""
+    from cerbos_amd import wire, workloads
+    from cerbos_amd.lower.blob import lower_rule_table
+    from cerbos_amd.policy.loader import policies_from_docs
+    from cerbos_amd.ruletable.build import rule_table_from_policies
+    lt = lower_rule_table(rule_table_from_policies(policies_from_docs(workloads.c5_policies())))
+    table = capi.Table(lt.blob)
+    inputs = workloads.c5_requests(total).to_inputs()
+    msgs = [wire.encode_check_input(i) for i in inputs]
+    flags = capi.F_WANT_DERIVED_ROLES
+    half = total // 2
+    parts = [wire.pack_messages(msgs[:half]), wire.pack_messages(msgs[half:])]
+    want = [table.wire_check_pb(d, o, now_ns=NOW, flags=flags) for d, o in parts]
+
+    def bufs(n, cap):
+        return (np.empty(cap, dtype=np.uint8), np.empty(n + 1, dtype=np.uint64), np.empty(max(n, 1), dtype=np.uint8))
+    for order in ((0, 1), (1, 0)):
+        tickets = [table.wire_check_pb_submit(d, o, bufs(len(o) - 1, 320 * (len(o) - 1) + 4096), now_ns=NOW, flags=flags) for d, o in parts]
+        for i in order:
+            got, gflags = table.wire_check_pb_collect(tickets[i])
+            assert got == want[i][0] and list(gflags) == list(want[i][1]), (order, i)
+    # three rounds back to back, the way a server's loop would: submit, submit, collect, submit, collect, collect
+    t0 = table.wire_check_pb_submit(*parts[0], bufs(half, 320 * half + 4096), now_ns=NOW, flags=flags)
+    t1 = table.wire_check_pb_submit(*parts[1], bufs(total - half, 320 * (total - half) + 4096), now_ns=NOW, flags=flags)
+    assert table.wire_check_pb_collect(t0)[0] == want[0][0]
+    t2 = table.wire_check_pb_submit(*parts[0], bufs(half, 320 * half + 4096), now_ns=NOW, flags=flags)
+    assert table.wire_check_pb_collect(t1)[0] == want[1][0]
+    assert table.wire_check_pb_collect(t2)[0] == want[0][0]
+    # too small an output buffer: 2 at collect (the size needed in the message)
+    t = table.wire_check_pb_submit(*parts[0], bufs(half, 1000), now_ns=NOW, flags=flags)
+    with pytest.raises(capi.HipEngineError, match="too small"):
+        table.wire_check_pb_collect(t)
+    # a CheckInput with more than 64 actions is the host flattener's: 1 at collect, with the worker's message
+    bad = dict(inputs[3], actions=["a%d" % k for k in range(70)])
+    d, o = wire.pack_messages(msgs[:100] + [wire.encode_check_input(bad)] + msgs[100:200])
+    t = table.wire_check_pb_submit(d, o, bufs(201, 320 * 201 + 4096), now_ns=NOW, flags=flags)
+    with pytest.raises(capi.HostFlattenerNeeded, match="host flattener"):
+        table.wire_check_pb_collect(t)
+    table.close()
