@@ -29,7 +29,13 @@
 #pragma once
 #include "cbh_check_flat.h"
 
+// Two waves to a workgroup (the flat kernels take four): measured on C5, 14.05 -> 14.5 G decisions/s (profiles/r06_ab_workgroup_waves.txt;
+// eight waves lose 8 %).  The simulator's one-wave and the override builds follow the flat kernels' setting.
+#if defined(CBH_HOSTSIM) || defined(CBH_FLAT_WAVES_OVERRIDE)
 #define CBH_W2_WAVES CBH_FLAT_WAVES
+#else
+#define CBH_W2_WAVES 2u
+#endif
 #define CBH_W2_THREADS (CBH_W2_WAVES * CBH_BLOCK)
 #define CBH_W2_LDS_GLOB_STRINGS 1024u   /* tables of at most this many strings keep their strings' glob match bits in LDS too */
 #define CBH_W2_MAX_RP_ROLES 32u   /* roles with a role policy at one (version, scope) */
