@@ -398,7 +398,7 @@ def main():
                         raise RuntimeError("cbh_wire_check_pb_collect: rc %d: %s" % (rc_, lib.cbh_last_error().decode()))
                     return info_.n_tuples
                 n_calls, best2 = 10, 1e9
-                for _ in range(2):
+                for _ in range(3):
                     w0 = time.perf_counter()
                     pend, done_t = [submit(0), submit(1)], 0
                     for c in range(2, n_calls):

@@ -1491,7 +1491,13 @@ static int wire_check_sliced(cbh_table* t, uint32_t device_index, const uint8_t*
   // CBH_WIRE_SLICE_MIN_BYTES: the smallest slice, for tests and measurements)
   static const u32 slice_min = [] { const char* e = getenv("CBH_WIRE_SLICE_MIN"); const long v = e ? atol(e) : 16384; return (u32)std::max<long>(v, 1); }();
   static const u64 slice_min_bytes = [] { const char* e = getenv("CBH_WIRE_SLICE_MIN_BYTES"); const long long v = e ? atoll(e) : (1ll << 22); return (u64)std::max<long long>(v, 1); }();
-  const u32 S = std::max<u32>(1u, std::min<u32>(max_slices, rm ? (u32)std::min<u64>(n, (n ? offsets[n] : 0) / slice_min_bytes) : n / slice_min));
+  // Calls of the road that are in flight at once (several caller threads, or one with cbh_wire_check_pb_submit) share the link and
+  // the copy engines: more than about four slices side by side lose (a lone call cut into eight: 392 M against 489 M decisions/s,
+  // profiles/r04_wire_onecall.txt; two calls of four: 420 M against 545 M one at a time, round 6) - so a call takes its share of four.
+  static std::atomic<int> in_flight{0};
+  struct InFlight { std::atomic<int>& c; int k; explicit InFlight(std::atomic<int>& c_) : c(c_), k(c_.fetch_add(1) + 1) {} ~InFlight() { c.fetch_sub(1); } } mine(in_flight);
+  const u32 share = std::max<u32>(1u, max_slices / (u32)std::max(1, mine.k));
+  const u32 S = std::max<u32>(1u, std::min<u32>(share, rm ? (u32)std::min<u64>(n, (n ? offsets[n] : 0) / slice_min_bytes) : n / slice_min));
   const u32 words = (t->wire.n_policies + 31u) / 32u;
   struct Slice {
     u32 lo = 0, hi = 0; cbh_device_batch* b = nullptr; cbh_wire_info wi{}; size_t total = 0, base = 0; int rc = 0; std::string err;
