@@ -161,9 +161,21 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   const bool spec = b.n_tuples >= 4u;
   const u32 spec_ix = (4u * req + 4u <= b.n_tuples) ? 4u * req : 0u;
   const u32x4u sp = load_u32x4(spec ? b.tuple_action + spec_ix : b.req_u32);
+  // this thread's entries of the tables the workgroup keeps in LDS (classes, string flags, glob bits): first-trip loads too - IN FRONT of
+  // the tag bytes, whose block (packed form only) ends in a full wait
+  const u32 kmax = t.K ? t.K - 1u : 0u;
+  const u32 tbl_i = threadIdx.x < t.K ? threadIdx.x : kmax;
+  const CBH_G u8* safe8 = (const CBH_G u8*)b.req_u32;   // (a table without strings / without glob bits: the unconditional loads read a request word)
+  const u32 tbl_a0 = (t.K ? t.action_class : safe8)[tbl_i], tbl_r0 = (t.K ? t.role_class : safe8)[tbl_i], tbl_w0 = (t.K ? t.str_wflags : safe8)[tbl_i];
+  const CBH_G u64* gb_base = (t.K && t.gbits && (aglobs || rglobs)) ? t.gbits : (const CBH_G u64*)b.req_u32;
+  const bool gb_real = gb_base == t.gbits && t.gbits != nullptr;
+  const u64 tbl_ga0 = gb_base[gb_real ? (size_t)DIM_ACTION * t.K + tbl_i : 0u], tbl_gr0 = gb_base[gb_real ? (size_t)DIM_ROLE * t.K + tbl_i : 0u];
   const CcTags cct = cc_load_tags(c, b, NRQ, w0, wd);
   const bool lenient = (flags & CBH_F_LENIENT_SCOPE_SEARCH) != 0;
-  const u32 first = chain_first(t, r_scope, FLAG_RES, lenient);
+  // the chain's first scope (per lane, reads the scope tables; needs the request words): the pre-pass forms ask about it at once,
+  // the walk issues its load with the second trip, behind the columns' copies
+  u32 first = CBH_NONE;
+  if (PRE) first = chain_first(t, r_scope, FLAG_RES, lenient);
   bool pre_climbs = false;   // pre-pass: does anything on this request's path hold a site the batch files?
   bool pre_family = false, pre_other = false, pre_pp = false;   // ... its family's records / definitions; role-policy rules; principal policies
   u64 pre_fam_roles = ~0ull;   // the role classes that reach a generic site of the family (CBH_B_FAMILY v1, v2)
@@ -193,7 +205,14 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
   const bool gb_in_lds = cls_in_lds && t.K <= CBH_W2_LDS_GLOB_STRINGS && (aglobs || rglobs);
   CBH_L unsigned short* gb_lds = (CBH_L unsigned short*)(cls_lds + ((3u * t.K + 15u) & ~15u));   // [action bits K][role bits K]
   if (cls_in_lds) {
-    for (u32 i = threadIdx.x; i < t.K; i += (PRE ? CBH_BLOCK : CBH_W2_THREADS)) {
+    if (threadIdx.x < t.K) {
+      cls_lds[threadIdx.x] = (u8)tbl_a0; cls_lds[t.K + threadIdx.x] = (u8)tbl_r0; cls_lds[2u * t.K + threadIdx.x] = (u8)tbl_w0;
+      if (gb_in_lds) {
+        gb_lds[threadIdx.x] = aglobs ? (unsigned short)tbl_ga0 : (unsigned short)0;
+        gb_lds[t.K + threadIdx.x] = rglobs ? (unsigned short)tbl_gr0 : (unsigned short)0;
+      }
+    }
+    for (u32 i = threadIdx.x + (PRE ? CBH_BLOCK : CBH_W2_THREADS); i < t.K; i += (PRE ? CBH_BLOCK : CBH_W2_THREADS)) {
       cls_lds[i] = t.action_class[i]; cls_lds[t.K + i] = t.role_class[i]; cls_lds[2u * t.K + i] = t.str_wflags[i];
       if (gb_in_lds) {
         gb_lds[i] = aglobs ? (unsigned short)t.gbits[(size_t)DIM_ACTION * t.K + i] : (unsigned short)0;
@@ -224,7 +243,7 @@ __device__ __forceinline__ void w2_body(const KernelArgs& ka_regs, Ctx& c, const
     for (u32 k = 4; k < NA; ++k) aid[k] = b.tuple_action[k < act_cnt ? act_off + k : 0u];
   }
   cc_fill(c, b, NRQ, w0, wd, cct);   // (behind every LDS store of this prologue)
-  const u32 kmax = t.K ? t.K - 1u : 0u;
+  if (!PRE) first = chain_first(t, r_scope, FLAG_RES, lenient);
   u32 rcls[NR];
   u32 rpar = 0;   // bit r: the role has ancestors in some scope (CBH_SWF_PARENTS): the only ones the directory is asked about
   if (cls_in_lds) __syncthreads();
