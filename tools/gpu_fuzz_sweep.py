@@ -24,13 +24,24 @@ for s in range(first, first + n):
     if budget_s and time.time() - t0 > budget_s:
         break
     last = s
-    F._run_seed(s, mk, True); done["flat"] += 1
+    def flat(kind, **kw):
+        # (the generator's own precondition - a store "with lists" must draw a list, one without must not - fails for a rare
+        # seed BEFORE anything reaches the device: such a seed is skipped and counted, any other failure stops the sweep)
+        import traceback
+        try:
+            F._run_seed(s, mk, True, **kw); done[kind] += 1
+        except AssertionError:
+            if "plain != with_lists" in traceback.format_exc().splitlines()[-2]:
+                done["skipped"] += 1
+            else:
+                raise
+    flat("flat")
     if s % 3 == 0:
-        F._run_seed(s, mk, True, with_lists=True); done["lists"] += 1
+        flat("lists", with_lists=True)
     if s % 5 == 0:
-        F._run_seed(s, mk, True, many_rules=True); done["large"] += 1
+        flat("large", many_rules=True)
     if s % 4 == 0:
-        F._run_seed(s, mk, True, deep=True); done["deep"] += 1
+        flat("deep", deep=True)
     for pool in ("base", "wide"):
         try:
             G.test_fuzz_store_on_gpu(s, pool); done["general"] += 1
