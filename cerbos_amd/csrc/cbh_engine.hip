@@ -1691,6 +1691,7 @@ extern "C" int cbh_wire_check_pb(cbh_table* t, uint32_t device_index, const uint
 // collect.  A caller that keeps two tickets in flight has the second call's uploads under the first's downloads - the fill and
 // drain of one call's slices are what a lone synchronous caller pays on top of the link's own time.
 struct cbh_wire_ticket {
+  cbh_table* table = nullptr;   // (the reference submit took: released by collect, whatever table the caller names there)
   std::thread worker;
   std::string ver, scope, err;
   int rc = -1;
@@ -1710,6 +1711,7 @@ extern "C" int cbh_wire_check_pb_submit(cbh_table* t, uint32_t device_index, con
   const bool has_ver = default_version != nullptr, has_scope = default_scope != nullptr;
   const cbh_params params = *p;
   cbh_table_retain(t);   // the table outlives the call whatever the caller does with its own reference meanwhile
+  k->table = t;
   try {
     k->worker = std::thread([=]() {
       k->rc = wire_check_sliced(t, device_index, bytes, offsets, n, has_ver ? k->ver.c_str() : nullptr, has_scope ? k->scope.c_str() : nullptr, globals_pb, globals_len,
@@ -1722,13 +1724,15 @@ extern "C" int cbh_wire_check_pb_submit(cbh_table* t, uint32_t device_index, con
 }
 extern "C" int cbh_wire_check_pb_collect(cbh_table* t, cbh_wire_ticket* ticket, size_t* need, cbh_wire_info* info) {
   if (!ticket) return fail("null argument");
+  if (t && t != ticket->table) return fail("cbh_wire_check_pb_collect: the ticket was issued for another table");   // (the ticket stays valid)
   if (ticket->worker.joinable()) ticket->worker.join();
   const int rc = ticket->rc;
   if (need) *need = ticket->need;
   if (info) *info = ticket->info;
   if (rc != 0) g_err = ticket->err;
+  cbh_table* held = ticket->table;
   delete ticket;
-  cbh_table_release(t);   // submit's reference
+  cbh_table_release(held);   // submit's reference
   return rc;
 }
 static int wire_check_requests_impl(cbh_table* t, uint32_t device_index, const uint8_t* bytes, const uint64_t* offsets, uint32_t n_requests,

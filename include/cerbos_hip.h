@@ -313,7 +313,7 @@ int cbh_wire_check_pb(cbh_table* t, uint32_t device_index, const uint8_t* bytes,
                       size_t* need, cbh_wire_info* info);
 
 /* ... and without blocking the caller.  cbh_wire_check_pb_submit starts the same call on a worker of the library and returns a
- * ticket; cbh_wire_check_pb_collect (same table) waits for it, fills need / info and returns what cbh_wire_check_pb would have
+ * ticket; cbh_wire_check_pb_collect (the same table, or NULL; another table is refused and the ticket stays) waits for it, fills need / info and returns what cbh_wire_check_pb would have
  * returned (the error text of a failed call is the collecting thread's cbh_last_error).  The strings are copied at submit; every
  * buffer is the caller's and must stay valid and untouched until collect, which must be called exactly once per ticket.  ONE
  * caller thread that keeps two tickets in flight has the second call's uploads under the first's downloads: the fill and drain of a

@@ -188,6 +188,13 @@ def test_two_calls_in_flight_from_one_thread(total=40_000):
     t2 = table.wire_check_pb_submit(*parts[0], bufs(half, 320 * half + 4096), now_ns=NOW, flags=flags)
     assert table.wire_check_pb_collect(t1)[0] == want[1][0]
     assert table.wire_check_pb_collect(t2)[0] == want[0][0]
+    # a ticket is collected through the table it was issued for: another table's name is refused and leaves the ticket as it was
+    other = capi.Table(lt.blob)
+    t = table.wire_check_pb_submit(*parts[1], bufs(total - half, 320 * (total - half) + 4096), now_ns=NOW, flags=flags)
+    with pytest.raises(capi.HipEngineError, match="another table"):
+        other.wire_check_pb_collect(t)
+    assert table.wire_check_pb_collect(t)[0] == want[1][0]
+    other.close()
     # too small an output buffer: 2 at collect (the size needed in the message)
     t = table.wire_check_pb_submit(*parts[0], bufs(half, 1000), now_ns=NOW, flags=flags)
     with pytest.raises(capi.HipEngineError, match="too small"):
