@@ -434,7 +434,9 @@ __device__ __forceinline__ u64 load_u64g(const CBH_G u32* p) {   // 8-byte align
 // EP: the instantiations of cbh_check_batch_trail (AuditTrail.EffectivePolicies, check.go:302-304) - per chain position a lane keeps
 // which of its walks met a binding there and the bucket's policy; the fold marks the policies the walks the reference REALLY makes
 // (not those of a role behind the one that allowed) have touched.  A bucket of a flat table is one resource policy's.
-template <bool WITH_CALL, int MODE, bool EP = false>
+// MEMO: the walk keeps the wave's last four condition outcomes (leafish_memo below) - the instantiation for tables WITH derived roles
+// (cbh_check_flat_kernel_dr): the memo's registers cost the plain kernel a wave of occupancy and C2 2 % for nothing.
+template <bool WITH_CALL, int MODE, bool EP = false, bool MEMO = false>
 __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
   constexpr bool STAGED = MODE == 1;
   constexpr u32 BTYPE = MODE == 2 ? (u32)CBH_B_RESSEG : (u32)CBH_B_RESOURCE;
@@ -585,6 +587,29 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
       }
     } else if (slow) lv = 8u;   // unreachable by the host's check; loud (UNSUPPORTED), never a guessed effect
     return active ? lv : 0u;
+  };
+
+  // The same with a MEMO of the wave's last outcomes (MEMO instantiations, without the evaluator call: there a classified condition's
+  // outcome is computed branch-free for EVERY lane, whoever asked).  A table's derived-role conditions are a handful of programs
+  // that every rule naming the role and every scope's definitions share (the lowering interns programs): C3 evaluates its four
+  // about a dozen times per wave - the walk per record, the second climb per scope.  Four entries: the reference (uniform) and
+  // the lanes' 4-bit outcomes, packed in one register.  `leaf` is called only on a miss (for a record's derived-role condition
+  // it is a scalar load of its own).
+  u32 memo_r0 = CBH_NONE, memo_r1 = CBH_NONE, memo_r2 = CBH_NONE, memo_r3 = CBH_NONE, memo_n = 0;   // wave-uniform
+  u32 memo_lv = 0;
+  auto leafish_memo = [&](u32 ref, u32 how, auto&& leaf, bool active) -> u32 {
+    if constexpr (WITH_CALL || !MEMO) return leafish(ref, how, leaf(), active);
+    else {
+      const u32 j = ref == memo_r0 ? 0u : ref == memo_r1 ? 1u : ref == memo_r2 ? 2u : ref == memo_r3 ? 3u : 4u;
+      if (j < 4u) return active ? ((memo_lv >> (4u * j)) & 15u) : 0u;
+      const u32 lv = leafish(ref, how, leaf(), true);   // every lane's outcome (a lane beyond the batch's end shadows a request)
+      if (memo_n < 4u) {
+        memo_r0 = memo_n == 0u ? ref : memo_r0; memo_r1 = memo_n == 1u ? ref : memo_r1; memo_r2 = memo_n == 2u ? ref : memo_r2; memo_r3 = memo_n == 3u ? ref : memo_r3;
+        memo_lv |= lv << (4u * memo_n);
+        ++memo_n;
+      }
+      return active ? lv : 0u;
+    }
   };
 
   // ---- the walk.  check.go:208-442 walks, per request, its scope chain from the request's scope up to the root and,
@@ -865,8 +890,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
               u32 hit = m;
               if (rw.drcond != CBH_NONE) {
                 const u32 how = (rw.flags & CBH_ROW_F_DRLEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_DRTREE_EMBEDDED) ? 2u : 0u;
-                const LeafRec l2 = staged_take<LeafRec>(s2, i);
-                const u32 lv = leafish(rw.drcond, how, l2, hit != 0);
+                const u32 lv = leafish_memo(rw.drcond, how, [&] { return staged_take<LeafRec>(s2, i); }, hit != 0);
                 err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
                 hit = (lv & 1u) ? hit : 0u;
               }
@@ -905,8 +929,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
             u32 hit = m;
             if (rw.drcond != CBH_NONE) {
               const u32 how = (rw.flags & CBH_ROW_F_DRLEAF_EMBEDDED) ? 1u : (rw.flags & CBH_ROW_F_DRTREE_EMBEDDED) ? 2u : 0u;
-              const LeafRec l2 = uload_rec<LeafRec>(t.rowleaf2, row);
-              const u32 lv = leafish(rw.drcond, how, l2, hit != 0);
+              const u32 lv = leafish_memo(rw.drcond, how, [&] { return uload_rec<LeafRec>(t.rowleaf2, row); }, hit != 0);
               err |= (lv & 2u) ? hit : 0u; unsup |= (lv & 8u) ? hit : 0u;
               hit = (lv & 1u) ? hit : 0u;
             }
@@ -1013,7 +1036,7 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
           const bool applies = ing && (dx.rm_lo & lane_rc) != 0;   // parent roles x the request's roles (check.go:244)
           if (wave_ballot(applies) == 0) continue;
           u32 lv = 1u;
-          if (dx.cond != CBH_NONE) lv = leafish(dx.cond, dx.flags & 3u, dx.leaf, applies);
+          if (dx.cond != CBH_NONE) lv = leafish_memo(dx.cond, dx.flags & 3u, [&] { return dx.leaf; }, applies);
           if (applies) { if (lv & 1u) edr |= 1ull << dx.name; derr = derr || (lv & 2u) != 0; dr_unsup = dr_unsup || (lv & 8u) != 0; }
         }
       }
@@ -1074,6 +1097,11 @@ __device__ __forceinline__ void flat_body(const KernelArgs& ka_regs, Ctx& c) {
 __global__ CBH_FLAT_ATTRS(7) void cbh_check_flat_kernel(const KernelArgs a, const KernelArgs* __restrict__ ka) {
   CBH_FLAT_CTX(a, ka);
   flat_body<false, 0>(a, c);
+}
+// ... and for a table with derived roles: the same with the memo of condition outcomes (C3 +4.5 %, profiles/r06_ab_condition_memo.txt)
+__global__ CBH_FLAT_ATTRS(7) void cbh_check_flat_kernel_dr(const KernelArgs a, const KernelArgs* __restrict__ ka) {
+  CBH_FLAT_CTX(a, ka);
+  flat_body<false, 0, false, true>(a, c);
 }
 // any batch: the same walk with the call into the shared evaluator compiled in (4 waves per SIMD)
 __global__ CBH_FLAT_ATTRS(4) void cbh_check_flat_kernel_any(const KernelArgs a, const KernelArgs* __restrict__ ka) {
@@ -1137,7 +1165,7 @@ static inline bool cbh_is_mask_kernel(cbh_check_kernel_fn fn) {
 }
 // the instantiation of a flat kernel that also keeps the effective policies (cbh_check_batch_trail), and its extra LDS
 static inline cbh_check_kernel_fn cbh_flat_trail_variant(cbh_check_kernel_fn fn) {
-  return fn == cbh_check_flat_kernel ? cbh_check_flat_trail_kernel : fn == cbh_check_flat_kernel_any ? cbh_check_flat_trail_kernel_any
+  return (fn == cbh_check_flat_kernel || fn == cbh_check_flat_kernel_dr) ? cbh_check_flat_trail_kernel : fn == cbh_check_flat_kernel_any ? cbh_check_flat_trail_kernel_any
        : fn == cbh_check_flat_kernel_staged ? cbh_check_flat_trail_kernel_staged : fn == cbh_check_flat_kernel_any_staged ? cbh_check_flat_trail_kernel_any_staged
        : fn == cbh_check_flat_kernel_masks ? cbh_check_flat_trail_kernel_masks : fn == cbh_check_flat_kernel_any_masks ? cbh_check_flat_trail_kernel_any_masks : fn;
 }
@@ -1156,7 +1184,7 @@ static inline cbh_check_kernel_fn cbh_pick_kernel(u32 table_flags, u32 n_derived
     *threads = CBH_FLAT_THREADS;
     const bool staged = max_bucket > CBH_FLAT_STAGE_MIN;
     if (masks) return (plain_tags && (table_flags & CBH_MF_FLAT_CLOSED)) ? cbh_check_flat_kernel_masks : cbh_check_flat_kernel_any_masks;
-    if (plain_tags && (table_flags & CBH_MF_FLAT_CLOSED)) return staged ? cbh_check_flat_kernel_staged : cbh_check_flat_kernel;
+    if (plain_tags && (table_flags & CBH_MF_FLAT_CLOSED)) return staged ? cbh_check_flat_kernel_staged : n_derived_roles ? cbh_check_flat_kernel_dr : cbh_check_flat_kernel;
     return staged ? cbh_check_flat_kernel_any_staged : cbh_check_flat_kernel_any;
   }
   *threads = CBH_BLOCK;

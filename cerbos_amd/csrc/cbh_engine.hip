@@ -799,7 +799,7 @@ extern "C" const char* cbh_plan_describe(cbh_table* t, cbh_device_batch* b, cons
   if (pl.kind == 2) s = std::string(pl.wide_kernel ? "cbh_check_kernel*(wide requests)+" : "") + (pl.walk_wide ? (pl.trail ? "cbh_walk2_wide_trail_kernel(5-8 roles)+" : "cbh_walk2_wide_kernel(5-8 roles)+") : "") + (pl.walk_awide ? (pl.trail ? "cbh_walk2_awide_trail_kernel(9-16 actions)+" : "cbh_walk2_awide_kernel(9-16 actions)+") : "") + (pl.n_gwords && b->dev.gres ? (pre_split ? "cbh_walk2_collect_kernel+cbh_walk2_interp_kernel+" : "cbh_walk2_pre_kernel+") : "") + (pl.trail ? "cbh_walk2_trail_kernel" : "cbh_walk2_kernel");
   else if (pl.kind == 1 && cbh_is_flat_trail_kernel(pl.kernel)) s = cbh_is_mask_kernel(pl.kernel) ? "cbh_check_flat_trail_kernel*_masks" : "cbh_check_flat_trail_kernel*";
   else if (pl.kind == 0 && pl.kernel == cbh_check_trail_kernel) s = "cbh_check_trail_kernel";
-  else if (pl.kind == 1) s = pl.kernel == cbh_check_flat_kernel ? "cbh_check_flat_kernel" : pl.kernel == cbh_check_flat_kernel_any ? "cbh_check_flat_kernel_any"
+  else if (pl.kind == 1) s = pl.kernel == cbh_check_flat_kernel ? "cbh_check_flat_kernel" : pl.kernel == cbh_check_flat_kernel_dr ? "cbh_check_flat_kernel_dr" : pl.kernel == cbh_check_flat_kernel_any ? "cbh_check_flat_kernel_any"
                            : pl.kernel == cbh_check_flat_kernel_staged ? "cbh_check_flat_kernel_staged" : pl.kernel == cbh_check_flat_kernel_masks ? "cbh_check_flat_kernel_masks"
                            : pl.kernel == cbh_check_flat_kernel_any_masks ? "cbh_check_flat_kernel_any_masks" : "cbh_check_flat_kernel_any_staged";
   else s = "cbh_check_kernel*";
